@@ -1,0 +1,1018 @@
+/*
+ * cozo_oracle.c -- CPU ORACLE (test infrastructure, see cozo_oracle.h).
+ *
+ * Restates, function by function, the reference hot path of cozodb/cozo v0.7.6
+ * (file:line citations are relative to cozo-core/src/).  Must be compiled with
+ * -ffp-contract=off: Rust never contracts a*b+c into an fma, and the "GPU order"
+ * mode uses explicit fmaf() where the HIP kernels use v_fma_f32.
+ *
+ * Third-party arithmetic that lives outside /root/reference (restated from the
+ * published crates, pinned versions from Cargo.lock):
+ *   ndarray 0.15.6  numeric_util::unrolled_dot   (8 accumulators, see orc_dot_ndarray)
+ *   graph   0.3.1   page_rank                    (GAP-style pull PageRank, Jacobi contrib refresh)
+ *   priority-queue 1.4.0 / ordered-float 4.2.0   (pop order among EQUAL priorities is
+ *        implementation-defined there; this oracle breaks ties by node id -- documented deviation)
+ */
+#include "cozo_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * Distances
+ * ---------------------------------------------------------------------------------------- */
+
+/* ndarray 0.15.6 src/numeric_util.rs `unrolled_dot` (call sites runtime/hnsw.rs:70-71,81-83,99):
+ * eight running products p0..p7 over blocks of 8, combined (p0+p4),(p1+p5),(p2+p6),(p3+p7)
+ * left to right into `sum`, then the <8 tail added sequentially.  No fma. */
+float orc_dot_ndarray(const float *a, const float *b, size_t n) {
+    float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        for (int j = 0; j < 8; j++) p[j] = p[j] + a[i + j] * b[i + j];
+    }
+    float sum = 0.0f;
+    sum = sum + (p[0] + p[4]);
+    sum = sum + (p[1] + p[5]);
+    sum = sum + (p[2] + p[6]);
+    sum = sum + (p[3] + p[7]);
+    for (; i < n; i++) sum = sum + a[i] * b[i];
+    return sum;
+}
+
+/* Summation tree of the HIP kernels (cozo_amd/csrc/distance.cuh): a vector of `dim` f32 is cut into
+ * 16-byte chunks; LPV lanes (16/32/64, smallest power of two >= #chunks) own chunks lane, lane+LPV, ...;
+ * each lane runs one fma chain over its elements in address order; lanes are combined by an xor
+ * butterfly with offsets LPV/2 ... 1.  Zero padding participates (fma(0,0,acc)). */
+static int gpu_lpv(int dim) {
+    int chunks = (dim + 3) / 4;
+    int lpv = 16;
+    while (lpv < chunks && lpv < 64) lpv <<= 1;
+    return lpv;
+}
+static float gpu_butterfly(float *p, int lpv) {
+    float t[64];
+    for (int off = lpv / 2; off >= 1; off >>= 1) {
+        for (int i = 0; i < lpv; i++) t[i] = p[i] + p[i ^ off];
+        memcpy(p, t, sizeof(float) * (size_t)lpv);
+    }
+    return p[0];
+}
+float orc_dot_gpu(const float *a, const float *b, int dim) {
+    int chunks = (dim + 3) / 4, lpv = gpu_lpv(dim);
+    float p[64];
+    memset(p, 0, sizeof p);
+    for (int c = 0; c < chunks; c++) {
+        int lane = c % lpv;
+        for (int e = 0; e < 4; e++) {
+            int idx = 4 * c + e;
+            float x = idx < dim ? a[idx] : 0.0f, y = idx < dim ? b[idx] : 0.0f;
+            p[lane] = fmaf(x, y, p[lane]);
+        }
+    }
+    return gpu_butterfly(p, lpv);
+}
+float orc_l2_gpu(const float *a, const float *b, int dim) {
+    int chunks = (dim + 3) / 4, lpv = gpu_lpv(dim);
+    float p[64];
+    memset(p, 0, sizeof p);
+    for (int c = 0; c < chunks; c++) {
+        int lane = c % lpv;
+        for (int e = 0; e < 4; e++) {
+            int idx = 4 * c + e;
+            float x = idx < dim ? a[idx] : 0.0f, y = idx < dim ? b[idx] : 0.0f;
+            float d = x - y;
+            p[lane] = fmaf(d, d, p[lane]);
+        }
+    }
+    return gpu_butterfly(p, lpv);
+}
+
+/* VectorCache::dist, runtime/hnsw.rs:66-109 (F32 arms).  a = query side (v1), b = stored (v2).
+ *   L2     : diff = a - b (f32 array); diff.dot(diff) as f64          (:68-72, squared, no sqrt)
+ *   Cosine : 1 - dot/sqrt(a_norm*b_norm), every dot f32 widened first (:79-85)
+ *   IP     : 1 - dot as f64                                            (:97-101) */
+double orc_distance(int metric, int dot_mode, const float *a, const float *b, int dim) {
+    if (metric == ORC_L2) {
+        if (dot_mode == ORC_DOT_GPU) return (double)orc_l2_gpu(a, b, dim);
+        float stackbuf[2048];
+        float *diff = dim <= 2048 ? stackbuf : (float *)malloc(sizeof(float) * (size_t)dim);
+        for (int i = 0; i < dim; i++) diff[i] = a[i] - b[i];
+        double r = (double)orc_dot_ndarray(diff, diff, (size_t)dim);
+        if (diff != stackbuf) free(diff);
+        return r;
+    }
+    if (metric == ORC_COSINE) {
+        double an, bn, d;
+        if (dot_mode == ORC_DOT_GPU) {
+            an = (double)orc_dot_gpu(a, a, dim);
+            bn = (double)orc_dot_gpu(b, b, dim);
+            d = (double)orc_dot_gpu(a, b, dim);
+        } else {
+            an = (double)orc_dot_ndarray(a, a, (size_t)dim);
+            bn = (double)orc_dot_ndarray(b, b, (size_t)dim);
+            d = (double)orc_dot_ndarray(a, b, (size_t)dim);
+        }
+        return 1.0 - d / sqrt(an * bn);
+    }
+    float d = dot_mode == ORC_DOT_GPU ? orc_dot_gpu(a, b, dim) : orc_dot_ndarray(a, b, (size_t)dim);
+    return 1.0 - (double)d;
+}
+
+void orc_distance_pairs(int metric, int dot_mode, const float *base, const float *queries, int dim,
+                        const uint32_t *pairs, uint64_t P, double *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)P; i++) {
+        out[i] = orc_distance(metric, dot_mode, queries + (size_t)pairs[2 * i] * dim,
+                              base + (size_t)pairs[2 * i + 1] * dim, dim);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * (dist, id) priority queues.  OrderedFloat: NaN sorts greatest and equals itself.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    double d;
+    uint32_t id;
+} pq_item;
+
+static int key_less(pq_item a, pq_item b) { /* total order (dist with NaN greatest, then id) */
+    int an = isnan(a.d), bn = isnan(b.d);
+    if (an != bn) return bn; /* a<b iff b is NaN and a is not */
+    if (!an && a.d != b.d) return a.d < b.d;
+    return a.id < b.id;
+}
+typedef struct {
+    pq_item *v;
+    int n, cap;
+    int is_max;
+} heap_t;
+static void heap_init(heap_t *h, int is_max) {
+    h->v = NULL;
+    h->n = h->cap = 0;
+    h->is_max = is_max;
+}
+static void heap_free(heap_t *h) {
+    free(h->v);
+    h->v = NULL;
+    h->n = h->cap = 0;
+}
+static int heap_before(const heap_t *h, pq_item a, pq_item b) { return h->is_max ? key_less(b, a) : key_less(a, b); }
+static void heap_push(heap_t *h, pq_item it) {
+    if (h->n == h->cap) {
+        h->cap = h->cap ? h->cap * 2 : 64;
+        h->v = (pq_item *)realloc(h->v, sizeof(pq_item) * (size_t)h->cap);
+    }
+    int i = h->n++;
+    while (i > 0) {
+        int p = (i - 1) / 2;
+        if (!heap_before(h, it, h->v[p])) break;
+        h->v[i] = h->v[p];
+        i = p;
+    }
+    h->v[i] = it;
+}
+static pq_item heap_pop(heap_t *h) {
+    pq_item top = h->v[0];
+    pq_item last = h->v[--h->n];
+    int i = 0;
+    for (;;) {
+        int l = 2 * i + 1, r = l + 1, c;
+        if (l >= h->n) break;
+        c = (r < h->n && heap_before(h, h->v[r], h->v[l])) ? r : l;
+        if (!heap_before(h, h->v[c], last)) break;
+        h->v[i] = h->v[c];
+        i = c;
+    }
+    if (h->n > 0) h->v[i] = last;
+    return top;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * HNSW: shared search-level over an abstract neighbour accessor
+ * ---------------------------------------------------------------------------------------- */
+typedef int (*nbr_fn)(const void *ctx, uint32_t node, int level, uint32_t *out);
+typedef struct {
+    const void *ctx;
+    nbr_fn nbrs;
+    const float *vecs;
+    int dim, metric, dot_mode;
+    uint32_t *stamp; /* visited stamps [n] */
+    uint32_t epoch;
+    uint64_t n_dist;
+    int max_width;
+} search_env;
+
+/* hnsw_search_level, runtime/hnsw.rs:539-587.  found_nn is a max-queue carried in and out. */
+static void search_level(search_env *E, const float *q, int ef, int level, heap_t *found_nn) {
+    heap_t cand;
+    heap_init(&cand, 0);
+    E->epoch++;
+    for (int i = 0; i < found_nn->n; i++) { /* :554-557 */
+        E->stamp[found_nn->v[i].id] = E->epoch;
+        heap_push(&cand, found_nn->v[i]);
+    }
+    uint32_t *nb = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(E->max_width > 0 ? E->max_width : 1));
+    while (cand.n > 0) { /* :559 */
+        pq_item c = heap_pop(&cand);
+        double furthest = found_nn->v[0].d; /* :560 peek */
+        if (c.d > furthest) break;          /* :562 raw f64 compare */
+        int cnt = E->nbrs(E->ctx, c.id, level, nb);
+        for (int j = 0; j < cnt; j++) { /* :566 ascending key order */
+            uint32_t v = nb[j];
+            if (E->stamp[v] == E->epoch) continue; /* :569 */
+            double nd = orc_distance(E->metric, E->dot_mode, q, E->vecs + (size_t)v * E->dim, E->dim);
+            E->n_dist++;
+            double cf = found_nn->v[0].d;             /* :574 */
+            if (found_nn->n < ef || nd < cf) {         /* :575 */
+                pq_item it = {nd, v};
+                heap_push(&cand, it);                  /* :576 */
+                heap_push(found_nn, it);               /* :577 */
+                if (found_nn->n > ef) heap_pop(found_nn); /* :578-580 */
+            }
+            E->stamp[v] = E->epoch; /* :582 */
+        }
+    }
+    free(nb);
+    heap_free(&cand);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * HNSW index construction
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t to;
+    uint8_t ignore;
+    double dist;
+} link_t;
+typedef struct {
+    link_t *v;
+    int n, cap;
+    double degree; /* the f64 kept in the self-loop row's `dist` column, hnsw.rs:270,338-357 */
+} adj_t;
+
+struct orc_hnsw {
+    int dim, metric, dot_mode;
+    int m, m_max, m_max0, ef_c, extend, keep_pruned;
+    uint32_t n, cap;
+    float *vecs;
+    int32_t *top; /* node exists on levels 0..top */
+    adj_t **adj;  /* adj[node][level] */
+    int max_level;
+    uint32_t entry;
+    uint32_t *stamp;
+    uint32_t epoch;
+    uint64_t n_dist;
+};
+
+orc_hnsw *orc_hnsw_new(int dim, int metric, int m, int ef_construction, int extend_candidates,
+                       int keep_pruned_connections, int dot_mode) {
+    orc_hnsw *h = (orc_hnsw *)calloc(1, sizeof(orc_hnsw));
+    h->dim = dim;
+    h->metric = metric;
+    h->dot_mode = dot_mode;
+    h->m = m;
+    h->m_max = m;      /* runtime/relation.rs:1136-1151: m_max = m */
+    h->m_max0 = 2 * m; /* m_max0 = 2m */
+    h->ef_c = ef_construction;
+    h->extend = extend_candidates;
+    h->keep_pruned = keep_pruned_connections;
+    h->max_level = -1;
+    h->entry = ORC_NONE;
+    return h;
+}
+void orc_hnsw_free(orc_hnsw *h) {
+    if (!h) return;
+    for (uint32_t i = 0; i < h->n; i++) {
+        for (int l = 0; l <= h->top[i]; l++) free(h->adj[i][l].v);
+        free(h->adj[i]);
+    }
+    free(h->adj);
+    free(h->top);
+    free(h->vecs);
+    free(h->stamp);
+    free(h);
+}
+static void adj_upsert(adj_t *a, uint32_t to, double dist, uint8_t ignore) { /* store_tx.put of a link row */
+    int lo = 0, hi = a->n;
+    while (lo < hi) {
+        int mid = (lo + hi) / 2;
+        if (a->v[mid].to < to) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo < a->n && a->v[lo].to == to) {
+        a->v[lo].dist = dist;
+        a->v[lo].ignore = ignore;
+        return;
+    }
+    if (a->n == a->cap) {
+        a->cap = a->cap ? a->cap * 2 : 8;
+        a->v = (link_t *)realloc(a->v, sizeof(link_t) * (size_t)a->cap);
+    }
+    memmove(a->v + lo + 1, a->v + lo, sizeof(link_t) * (size_t)(a->n - lo));
+    a->v[lo].to = to;
+    a->v[lo].dist = dist;
+    a->v[lo].ignore = ignore;
+    a->n++;
+}
+/* hnsw_get_neighbours(include_deleted=false), runtime/hnsw.rs:588-629: ascending `to` key, skipping
+ * soft-deleted rows (the self-loop row is held separately in adj_t.degree). */
+static int dyn_nbrs(const void *ctx, uint32_t node, int level, uint32_t *out) {
+    const orc_hnsw *h = (const orc_hnsw *)ctx;
+    if (level > h->top[node]) return 0;
+    const adj_t *a = &h->adj[node][level];
+    int c = 0;
+    for (int i = 0; i < a->n; i++)
+        if (!a->v[i].ignore) out[c++] = a->v[i].to;
+    return c;
+}
+static double hdist(orc_hnsw *h, const float *a, const float *b) {
+    h->n_dist++;
+    return orc_distance(h->metric, h->dot_mode, a, b, h->dim);
+}
+static const float *hvec(const orc_hnsw *h, uint32_t id) { return h->vecs + (size_t)id * h->dim; }
+
+/* hnsw_select_neighbours_heuristic, runtime/hnsw.rs:470-538.
+ * `found` = (id, dist-to-q) items; result written to sel (<= m items, nearest-first order of acceptance). */
+static int select_heuristic(orc_hnsw *h, const float *q, const pq_item *found, int nfound, int m, int level,
+                            pq_item *sel) {
+    heap_t cand, disc;
+    heap_init(&cand, 0);
+    heap_init(&disc, 0);
+    for (int i = 0; i < nfound; i++) heap_push(&cand, found[i]); /* :495-498 */
+    if (h->extend) { /* :499-511 ; PriorityQueue::push on an existing key keeps one entry per key */
+        uint32_t *nb = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(2 * h->m_max0 + 8));
+        h->epoch++;
+        for (int i = 0; i < nfound; i++) h->stamp[found[i].id] = h->epoch;
+        for (int i = 0; i < nfound; i++) {
+            int cnt = dyn_nbrs(h, found[i].id, level, nb);
+            for (int j = 0; j < cnt; j++) {
+                if (h->stamp[nb[j]] == h->epoch) continue; /* same key, same distance: push is a no-op */
+                h->stamp[nb[j]] = h->epoch;
+                pq_item it = {hdist(h, q, hvec(h, nb[j])), nb[j]};
+                heap_push(&cand, it);
+            }
+        }
+        free(nb);
+    }
+    int nsel = 0;
+    while (cand.n > 0 && nsel < m) { /* :512 */
+        pq_item c = heap_pop(&cand);
+        int add = 1;
+        for (int i = 0; i < nsel; i++) { /* :515-523 */
+            double de = hdist(h, hvec(h, sel[i].id), hvec(h, c.id));
+            if (de < c.d) {
+                add = 0;
+                break;
+            }
+        }
+        if (add) sel[nsel++] = c;
+        else if (h->keep_pruned) heap_push(&disc, c);
+    }
+    if (h->keep_pruned) { /* :530-536 */
+        while (disc.n > 0 && nsel < m) sel[nsel++] = heap_pop(&disc);
+    }
+    heap_free(&cand);
+    heap_free(&disc);
+    return nsel;
+}
+
+/* hnsw_shrink_neighbour, runtime/hnsw.rs:376-469 */
+static int shrink_neighbour(orc_hnsw *h, uint32_t target, int m, int level) {
+    adj_t *a = &h->adj[target][level];
+    int nold = 0;
+    pq_item *old = (pq_item *)malloc(sizeof(pq_item) * (size_t)(a->n + 1));
+    for (int i = 0; i < a->n; i++)
+        if (!a->v[i].ignore) { /* :389-393 stored distances, not recomputed */
+            old[nold].id = a->v[i].to;
+            old[nold].d = a->v[i].dist;
+            nold++;
+        }
+    pq_item *sel = (pq_item *)malloc(sizeof(pq_item) * (size_t)(m + 1));
+    int nsel = select_heuristic(h, hvec(h, target), old, nold, m, level, sel);
+    for (int i = 0; i < nsel; i++) { /* :413-433 new rows (only possible with extend_candidates) */
+        int was_old = 0;
+        for (int j = 0; j < nold; j++)
+            if (old[j].id == sel[i].id) {
+                was_old = 1;
+                break;
+            }
+        if (!was_old) adj_upsert(&h->adj[target][level], sel[i].id, sel[i].d, 0);
+    }
+    a = &h->adj[target][level];
+    for (int j = 0; j < nold; j++) { /* :434-466 dropped links: soft delete (ignore_link = true) */
+        int kept = 0;
+        for (int i = 0; i < nsel; i++)
+            if (sel[i].id == old[j].id) {
+                kept = 1;
+                break;
+            }
+        if (!kept) adj_upsert(a, old[j].id, old[j].d, 1);
+    }
+    free(old);
+    free(sel);
+    return nsel; /* :412,468 */
+}
+
+/* hnsw_put_vector, runtime/hnsw.rs:155-375 (fresh key; level drawn by the caller, :46-52) */
+static void put_vector(orc_hnsw *h, uint32_t id, int target_lv /* = -target_level >= 0 */) {
+    const float *q = hvec(h, id);
+    h->top[id] = target_lv;
+    h->adj[id] = (adj_t *)calloc((size_t)target_lv + 1, sizeof(adj_t));
+    if (h->max_level < 0) { /* :360-373 first vector */
+        h->max_level = target_lv;
+        h->entry = id;
+        return;
+    }
+    int bottom_lv = h->max_level; /* `bottom_level` of :195 is the TOP (most negative layer) */
+    uint32_t ep = h->entry;       /* :184-199 first row of the index = smallest key on the top layer */
+    heap_t found;
+    heap_init(&found, 1);
+    pq_item epi = {hdist(h, q, hvec(h, ep)), ep}; /* :200-204 */
+    heap_push(&found, epi);
+    search_env E = {h, dyn_nbrs, h->vecs, h->dim, h->metric, h->dot_mode, h->stamp, h->epoch, 0, 2 * h->m_max0 + 8};
+    /* :219-229 greedy descent on layers above the target */
+    for (int lv = bottom_lv; lv > target_lv; lv--) search_level(&E, q, 1, lv, &found);
+    pq_item *sel = (pq_item *)malloc(sizeof(pq_item) * (size_t)(h->m_max0 + 1));
+    int start_lv = target_lv < bottom_lv ? target_lv : bottom_lv; /* :242 max(target_level, bottom_level) */
+    for (int lv = start_lv; lv >= 0; lv--) {
+        int m_max = lv == 0 ? h->m_max0 : h->m_max; /* :243-247 */
+        search_level(&E, q, h->ef_c, lv, &found);   /* :248-256 found_nn carried un-truncated */
+        h->epoch = E.epoch;
+        int nsel = select_heuristic(h, q, found.v, found.n, m_max, lv, sel); /* :258-267 */
+        E.epoch = h->epoch;
+        h->adj[id][lv].degree = (double)nsel; /* :269-277 */
+        for (int i = 0; i < nsel; i++) {      /* :280-358 */
+            uint32_t nb = sel[i].id;
+            adj_upsert(&h->adj[id][lv], nb, sel[i].d, 0); /* out link */
+            adj_upsert(&h->adj[nb][lv], id, sel[i].d, 0); /* in link  */
+            int target_degree = (int)h->adj[nb][lv].degree + 1; /* :338 */
+            if (target_degree > m_max) {
+                target_degree = shrink_neighbour(h, nb, m_max, lv); /* :339-350 */
+                E.epoch = h->epoch;
+            }
+            h->adj[nb][lv].degree = (double)target_degree; /* :352 */
+        }
+    }
+    h->n_dist += E.n_dist;
+    h->epoch = E.epoch;
+    free(sel);
+    heap_free(&found);
+    if (target_lv > h->max_level) { /* :206-218 the new vector becomes the entry point */
+        h->max_level = target_lv;
+        h->entry = id;
+    }
+}
+
+int orc_hnsw_insert(orc_hnsw *h, const float *vectors, uint32_t n, const int32_t *levels) {
+    uint32_t need = h->n + n;
+    if (need > h->cap) {
+        uint32_t nc = h->cap ? h->cap : 1024;
+        while (nc < need) nc *= 2;
+        h->vecs = (float *)realloc(h->vecs, sizeof(float) * (size_t)nc * h->dim);
+        h->top = (int32_t *)realloc(h->top, sizeof(int32_t) * nc);
+        h->adj = (adj_t **)realloc(h->adj, sizeof(adj_t *) * nc);
+        h->stamp = (uint32_t *)realloc(h->stamp, sizeof(uint32_t) * nc);
+        memset(h->stamp + h->cap, 0, sizeof(uint32_t) * (nc - h->cap));
+        h->cap = nc;
+    }
+    memcpy(h->vecs + (size_t)h->n * h->dim, vectors, sizeof(float) * (size_t)n * h->dim);
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t id = h->n;
+        h->n++;
+        if (levels[i] < 0) return -1;
+        put_vector(h, id, levels[i]);
+    }
+    return 0;
+}
+uint32_t orc_hnsw_size(const orc_hnsw *h) { return h->n; }
+int orc_hnsw_n_levels(const orc_hnsw *h) { return h->max_level + 1; }
+uint32_t orc_hnsw_entry(const orc_hnsw *h) { return h->entry; }
+uint32_t orc_hnsw_level_size(const orc_hnsw *h, int level) {
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < h->n; i++) c += h->top[i] >= level;
+    return c;
+}
+int orc_hnsw_level_width(const orc_hnsw *h, int level) { return level == 0 ? h->m_max0 : h->m_max; }
+void orc_hnsw_export_level(const orc_hnsw *h, int level, uint32_t *node_ids, uint32_t *nbrs) {
+    int w = orc_hnsw_level_width(h, level);
+    uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(4 * w + 64));
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < h->n; i++) {
+        if (h->top[i] < level) continue;
+        node_ids[r] = i;
+        const adj_t *a = &h->adj[i][level];
+        int c = 0;
+        for (int k = 0; k < a->n; k++)
+            if (!a->v[k].ignore && c < w) tmp[c++] = a->v[k].to;
+        for (int k = 0; k < w; k++) nbrs[(size_t)r * w + k] = k < c ? tmp[k] : ORC_NONE;
+        r++;
+    }
+    free(tmp);
+}
+uint64_t orc_hnsw_dist_count(const orc_hnsw *h) { return h->n_dist; }
+uint64_t orc_hnsw_link_rows(const orc_hnsw *h, int include_ignored) {
+    uint64_t c = 0;
+    for (uint32_t i = 0; i < h->n; i++)
+        for (int l = 0; l <= h->top[i]; l++) {
+            const adj_t *a = &h->adj[i][l];
+            for (int k = 0; k < a->n; k++) c += include_ignored || !a->v[k].ignore;
+        }
+    return c;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * HNSW search over the flat layout
+ * ---------------------------------------------------------------------------------------- */
+static int flat_nbrs(const void *ctx, uint32_t node, int level, uint32_t *out) {
+    const orc_flat_index *ix = (const orc_flat_index *)ctx;
+    int w = ix->level_width[level];
+    size_t row;
+    if (level == 0 && ix->level_nodes[0] == NULL) row = node;
+    else { /* binary search of the ascending node list */
+        const uint32_t *ids = ix->level_nodes[level];
+        uint32_t lo = 0, hi = ix->level_size[level];
+        while (lo < hi) {
+            uint32_t mid = lo + (hi - lo) / 2;
+            if (ids[mid] < node) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo >= ix->level_size[level] || ids[lo] != node) return 0;
+        row = lo;
+    }
+    const uint32_t *r = ix->level_nbrs[level] + row * (size_t)w;
+    int c = 0;
+    for (int k = 0; k < w; k++)
+        if (r[k] != ORC_NONE) out[c++] = r[k];
+    return c;
+}
+
+/* hnsw_knn, runtime/hnsw.rs:869-1012 (no filter bytecode: the caller asks for k = ef when it filters) */
+static int knn_one(const orc_flat_index *ix, const float *q, int k, int ef, int has_radius, double radius,
+                   uint32_t *out_ids, double *out_dist, uint64_t *n_dist, uint32_t *stamp, uint32_t *epoch) {
+    if (ix->n_levels <= 0 || ix->n == 0) return 0; /* :900-909,1009-1011 */
+    int maxw = 1;
+    for (int l = 0; l < ix->n_levels; l++)
+        if (ix->level_width[l] > maxw) maxw = ix->level_width[l];
+    search_env E = {ix, flat_nbrs, ix->vectors, ix->dim, ix->metric, ix->dot_mode, stamp, *epoch, 0, maxw};
+    heap_t found;
+    heap_init(&found, 1);
+    pq_item epi = {orc_distance(ix->metric, ix->dot_mode, q, ix->vectors + (size_t)ix->entry * ix->dim, ix->dim),
+                   ix->entry}; /* :915-918 */
+    E.n_dist++;
+    heap_push(&found, epi);
+    for (int lv = ix->n_levels - 1; lv > 0; lv--) search_level(&E, q, 1, lv, &found); /* :919-929 */
+    search_level(&E, q, ef, 0, &found);                                               /* :930-938 */
+    while (found.n > k) heap_pop(&found);                                             /* :943-947 */
+    int cnt = 0;
+    while (found.n > 0) { /* :951-1004 farthest first */
+        pq_item it = heap_pop(&found);
+        if (has_radius && it.d > radius) continue; /* :952-956 */
+        out_ids[cnt] = it.id;
+        out_dist[cnt] = it.d;
+        cnt++;
+    }
+    for (int i = 0; i < cnt / 2; i++) { /* :1005 reverse */
+        uint32_t ti = out_ids[i];
+        out_ids[i] = out_ids[cnt - 1 - i];
+        out_ids[cnt - 1 - i] = ti;
+        double td = out_dist[i];
+        out_dist[i] = out_dist[cnt - 1 - i];
+        out_dist[cnt - 1 - i] = td;
+    }
+    if (cnt > k) cnt = k; /* :1006 */
+    heap_free(&found);
+    *epoch = E.epoch;
+    if (n_dist) *n_dist += E.n_dist;
+    return cnt;
+}
+int orc_hnsw_knn(const orc_flat_index *ix, const float *q, int k, int ef, int has_radius, double radius,
+                 uint32_t *out_ids, double *out_dist, uint64_t *n_dist) {
+    uint32_t *stamp = (uint32_t *)calloc(ix->n ? ix->n : 1, sizeof(uint32_t));
+    uint32_t epoch = 0;
+    int c = knn_one(ix, q, k, ef, has_radius, radius, out_ids, out_dist, n_dist, stamp, &epoch);
+    free(stamp);
+    return c;
+}
+void orc_hnsw_knn_batch(const orc_flat_index *ix, const float *queries, uint32_t B, int k, int ef, int has_radius,
+                        double radius, uint32_t *out_ids, double *out_dist, uint32_t *out_count,
+                        uint64_t *n_dist_total, int threads) {
+    uint64_t total = 0;
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads) reduction(+ : total)
+    {
+        uint32_t *stamp = (uint32_t *)calloc(ix->n ? ix->n : 1, sizeof(uint32_t));
+        uint32_t epoch = 0;
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t b = 0; b < (int64_t)B; b++) {
+            uint64_t nd = 0;
+            for (int j = 0; j < k; j++) {
+                out_ids[(size_t)b * k + j] = ORC_NONE;
+                out_dist[(size_t)b * k + j] = INFINITY;
+            }
+            if (epoch > 0xFFFF0000u) {
+                memset(stamp, 0, sizeof(uint32_t) * ix->n);
+                epoch = 0;
+            }
+            out_count[b] = (uint32_t)knn_one(ix, queries + (size_t)b * ix->dim, k, ef, has_radius, radius,
+                                             out_ids + (size_t)b * k, out_dist + (size_t)b * k, &nd, stamp, &epoch);
+            total += nd;
+        }
+        free(stamp);
+    }
+    if (n_dist_total) *n_dist_total = total;
+}
+
+void orc_bruteforce_knn(int metric, int dot_mode, const float *base, uint32_t n, int dim, const float *queries,
+                        uint32_t B, int k, uint32_t *out_ids, double *out_dist, int threads) {
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+    for (int64_t b = 0; b < (int64_t)B; b++) {
+        heap_t h;
+        heap_init(&h, 1);
+        const float *q = queries + (size_t)b * dim;
+        for (uint32_t i = 0; i < n; i++) {
+            pq_item it = {orc_distance(metric, dot_mode, q, base + (size_t)i * dim, dim), i};
+            if (h.n < k) heap_push(&h, it);
+            else if (key_less(it, h.v[0])) {
+                heap_pop(&h);
+                heap_push(&h, it);
+            }
+        }
+        int cnt = h.n;
+        for (int j = cnt - 1; j >= 0; j--) {
+            pq_item it = heap_pop(&h);
+            out_ids[(size_t)b * k + j] = it.id;
+            out_dist[(size_t)b * k + j] = it.d;
+        }
+        for (int j = cnt; j < k; j++) {
+            out_ids[(size_t)b * k + j] = ORC_NONE;
+            out_dist[(size_t)b * k + j] = INFINITY;
+        }
+        heap_free(&h);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * relation -> graph
+ * ---------------------------------------------------------------------------------------- */
+/* as_directed_graph id assignment, fixed_rule/mod.rs:144-186: rows in scan order, `from` before `to`,
+ * a new key gets id = indices.len().  (Open-addressing hash instead of the BTreeMap: same mapping.) */
+uint32_t orc_assign_ids(const int64_t *from, const int64_t *to, uint64_t E, uint32_t *from_idx, uint32_t *to_idx,
+                        int64_t *indices) {
+    uint64_t cap = 16;
+    while (cap < 4 * E + 16) cap <<= 1;
+    int64_t *keys = (int64_t *)malloc(sizeof(int64_t) * cap);
+    uint32_t *vals = (uint32_t *)malloc(sizeof(uint32_t) * cap);
+    memset(vals, 0xFF, sizeof(uint32_t) * cap);
+    uint32_t n = 0;
+    for (uint64_t e = 0; e < E; e++) {
+        for (int side = 0; side < 2; side++) {
+            int64_t key = side == 0 ? from[e] : to[e];
+            uint64_t hsh = (uint64_t)key * 0x9E3779B97F4A7C15ull;
+            hsh ^= hsh >> 29;
+            uint64_t pos = hsh & (cap - 1);
+            while (vals[pos] != ORC_NONE && keys[pos] != key) pos = (pos + 1) & (cap - 1);
+            if (vals[pos] == ORC_NONE) {
+                keys[pos] = key;
+                vals[pos] = n;
+                indices[n] = key;
+                n++;
+            }
+            if (side == 0) from_idx[e] = vals[pos];
+            else to_idx[e] = vals[pos];
+        }
+    }
+    free(keys);
+    free(vals);
+    return n;
+}
+
+/* GraphBuilder::csr_layout(CsrLayout::Sorted), fixed_rule/mod.rs:187-195 (graph_builder 0.4.0):
+ * per-node target lists sorted ascending, parallel edges kept. */
+typedef struct {
+    uint32_t t;
+    float w;
+    uint64_t seq;
+} tw_t;
+static int tw_cmp(const void *a, const void *b) {
+    const tw_t *x = (const tw_t *)a, *y = (const tw_t *)b;
+    if (x->t != y->t) return x->t < y->t ? -1 : 1;
+    return x->seq < y->seq ? -1 : (x->seq > y->seq);
+}
+void orc_build_csr(uint32_t n, uint64_t E, const uint32_t *src, const uint32_t *dst, const float *w_in, int undirected,
+                   uint64_t *off, uint32_t *tgt, float *w_out) {
+    uint64_t Et = undirected ? 2 * E : E;
+    memset(off, 0, sizeof(uint64_t) * ((size_t)n + 1));
+    for (uint64_t e = 0; e < E; e++) {
+        off[src[e] + 1]++;
+        if (undirected) off[dst[e] + 1]++;
+    }
+    for (uint32_t i = 0; i < n; i++) off[i + 1] += off[i];
+    uint64_t *cur = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)n + 1));
+    memcpy(cur, off, sizeof(uint64_t) * ((size_t)n + 1));
+    tw_t *tmp = (tw_t *)malloc(sizeof(tw_t) * (Et ? Et : 1));
+    uint64_t seq = 0;
+    for (uint64_t e = 0; e < E; e++) {
+        float w = w_in ? w_in[e] : 1.0f;
+        tw_t a = {dst[e], w, seq++};
+        tmp[cur[src[e]]++] = a;
+        if (undirected) {
+            tw_t b = {src[e], w, seq++};
+            tmp[cur[dst[e]]++] = b;
+        }
+    }
+    for (uint32_t i = 0; i < n; i++) qsort(tmp + off[i], off[i + 1] - off[i], sizeof(tw_t), tw_cmp);
+    for (uint64_t e = 0; e < Et; e++) {
+        tgt[e] = tmp[e].t;
+        if (w_out) w_out[e] = tmp[e].w;
+    }
+    free(tmp);
+    free(cur);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * PageRank: fixed_rule/algos/pagerank.rs:29-56 -> graph 0.3.1 `page_rank` (GAP pr.cc pull form)
+ *   init = 1/N ; base = (1-d)/N ; contrib[v] = score[v] / out_degree(v)       (all f32)
+ *   per iteration, every u: new = base + d * sum_{v in in(u)} contrib[v]       (sequential f32 sum,
+ *       in-neighbours in sorted order) ; err += |new - old| accumulated in f64
+ *   contrib refreshed in a separate pass (Jacobi) ; stop when err < tolerance or iter == max_iter.
+ *   No dangling-mass redistribution, no renormalisation (a sink's contrib is inf but never read).
+ * threads > 1: 16384-node dynamic chunks (the crate's scheduler); only the f64 error sum order varies.
+ * ---------------------------------------------------------------------------------------- */
+int orc_pagerank(uint32_t n, const uint64_t *in_off, const uint32_t *in_src, const uint32_t *out_deg, float damping,
+                 double tolerance, uint32_t max_iter, float *scores, uint32_t *iters_run, double *final_err,
+                 int threads) {
+    if (n == 0) {
+        if (iters_run) *iters_run = 0;
+        if (final_err) *final_err = 0;
+        return 0;
+    }
+    if (threads < 1) threads = 1;
+    float init = 1.0f / (float)n;
+    float base = (1.0f - damping) / (float)n;
+    float *contrib = (float *)malloc(sizeof(float) * n);
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t v = 0; v < (int64_t)n; v++) {
+        scores[v] = init;
+        contrib[v] = init / (float)out_deg[v];
+    }
+    uint32_t it = 0;
+    double err = 0;
+    for (;;) {
+        err = 0;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 16384) reduction(+ : err)
+        for (int64_t u = 0; u < (int64_t)n; u++) {
+            float s = 0.0f;
+            for (uint64_t e = in_off[u]; e < in_off[u + 1]; e++) s = s + contrib[in_src[e]];
+            float old = scores[u];
+            float nw = base + damping * s;
+            scores[u] = nw;
+            err += fabs((double)(nw - old));
+        }
+#pragma omp parallel for num_threads(threads) schedule(static)
+        for (int64_t v = 0; v < (int64_t)n; v++) contrib[v] = scores[v] / (float)out_deg[v];
+        it++;
+        if (err < tolerance || it == max_iter) break;
+    }
+    free(contrib);
+    if (iters_run) *iters_run = it;
+    if (final_err) *final_err = err;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * ShortestPathBFS, fixed_rule/algos/shortest_path_bfs.rs:65-94.  FIFO queue, neighbours in sorted
+ * key order, parent = first discoverer, `pending.is_empty()` only breaks the inner loop.
+ * ---------------------------------------------------------------------------------------- */
+void orc_shortest_path_bfs(uint32_t n, const uint64_t *off, const uint32_t *tgt, uint32_t start,
+                           const uint32_t *goals, uint32_t n_goals, uint32_t *parent) {
+    uint8_t *visited = (uint8_t *)calloc(n ? n : 1, 1);
+    uint8_t *is_goal = (uint8_t *)calloc(n ? n : 1, 1);
+    uint32_t *queue = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    for (uint32_t i = 0; i < n; i++) parent[i] = ORC_NONE;
+    uint32_t pending = 0;
+    for (uint32_t i = 0; i < n_goals; i++)
+        if (goals[i] < n && !is_goal[goals[i]]) {
+            is_goal[goals[i]] = 1;
+            pending++;
+        }
+    uint32_t head = 0, tail = 0;
+    if (start < n) {
+        visited[start] = 1;
+        queue[tail++] = start;
+    }
+    while (head < tail) {
+        uint32_t c = queue[head++];
+        for (uint64_t e = off[c]; e < off[c + 1]; e++) {
+            uint32_t t = tgt[e];
+            if (visited[t]) continue;
+            visited[t] = 1;
+            parent[t] = c;
+            if (is_goal[t]) {
+                is_goal[t] = 0;
+                pending--;
+            }
+            if (pending == 0) break;
+            queue[tail++] = t;
+        }
+    }
+    free(visited);
+    free(is_goal);
+    free(queue);
+}
+
+/* Bfs traversal order, fixed_rule/algos/bfs.rs:49-98 (visited/backtrace shared across starts, :43-45) */
+uint32_t orc_bfs_order(uint32_t n, const uint64_t *off, const uint32_t *tgt, uint32_t start, uint8_t *visited,
+                       uint32_t *parent, uint32_t *order) {
+    if (start >= n || visited[start]) return 0;
+    uint32_t *queue = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint32_t head = 0, tail = 0, cnt = 0;
+    visited[start] = 1;
+    queue[tail++] = start;
+    while (head < tail) {
+        uint32_t c = queue[head++];
+        for (uint64_t e = off[c]; e < off[c + 1]; e++) {
+            uint32_t t = tgt[e];
+            if (visited[t]) continue;
+            visited[t] = 1;
+            parent[t] = c;
+            order[cnt++] = t;
+            queue[tail++] = t;
+        }
+    }
+    free(queue);
+    return cnt;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * TarjanSccG, fixed_rule/algos/strongly_connected_components.rs:89-149, with an explicit stack.
+ * Note the reference updates low[at] from low[to] (not ids[to]) whenever `to` is on the stack, AFTER
+ * the recursive call returns (:134-141), and rewrites low[] of a finished component to the root id.
+ * Groups = BTreeMap<low, nodes> values in ascending key order (:103-108).
+ * ---------------------------------------------------------------------------------------- */
+uint32_t orc_tarjan_groups(uint32_t n, const uint64_t *off, const uint32_t *tgt, uint32_t *grp) {
+    uint32_t *ids = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t)); /* 0 = None */
+    uint32_t *low = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
+    uint8_t *on_stack = (uint8_t *)calloc(n ? n : 1, 1);
+    uint32_t *stack = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint32_t *cs_node = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint64_t *cs_edge = (uint64_t *)malloc(sizeof(uint64_t) * (n ? n : 1));
+    uint32_t sp = 0, id = 0;
+    for (uint32_t root = 0; root < n; root++) {
+        if (ids[root]) continue;
+        uint32_t cp = 0;
+        cs_node[cp] = root;
+        cs_edge[cp] = off[root];
+        cp++;
+        stack[sp++] = root;
+        on_stack[root] = 1;
+        ids[root] = low[root] = ++id;
+        while (cp > 0) {
+            uint32_t at = cs_node[cp - 1];
+            if (cs_edge[cp - 1] < off[at + 1]) {
+                uint32_t to = tgt[cs_edge[cp - 1]];
+                if (!ids[to]) { /* recurse; the edge is re-examined (on_stack check) when we come back */
+                    cs_node[cp] = to;
+                    cs_edge[cp] = off[to];
+                    cp++;
+                    stack[sp++] = to;
+                    on_stack[to] = 1;
+                    ids[to] = low[to] = ++id;
+                    continue;
+                }
+                if (on_stack[to] && low[to] < low[at]) low[at] = low[to];
+                cs_edge[cp - 1]++;
+            } else {
+                if (ids[at] == low[at]) {
+                    for (;;) {
+                        uint32_t node = stack[--sp];
+                        on_stack[node] = 0;
+                        low[node] = ids[at];
+                        if (node == at) break;
+                    }
+                }
+                cp--;
+            }
+        }
+    }
+    /* rank of each distinct low value, ascending */
+    uint8_t *is_root = (uint8_t *)calloc((size_t)id + 2, 1);
+    for (uint32_t i = 0; i < n; i++) is_root[low[i]] = 1;
+    uint32_t *rank = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)id + 2));
+    uint32_t r = 0;
+    for (uint32_t v = 0; v <= id; v++) {
+        rank[v] = r;
+        r += is_root[v];
+    }
+    for (uint32_t i = 0; i < n; i++) grp[i] = rank[low[i]];
+    free(ids);
+    free(low);
+    free(on_stack);
+    free(stack);
+    free(cs_node);
+    free(cs_edge);
+    free(is_root);
+    free(rank);
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * dijkstra, fixed_rule/algos/shortest_path_dijkstra.rs:274-339.  f32 costs, strict `<` relaxation,
+ * one queue entry per node (push_increase).  Equal-cost pop order is by node id here.
+ * ---------------------------------------------------------------------------------------- */
+void orc_dijkstra(uint32_t n, const uint64_t *off, const uint32_t *tgt, const float *w, uint32_t start,
+                  const uint32_t *goals, uint32_t n_goals, float *dist, uint32_t *parent) {
+    uint32_t *heap = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint32_t *pos = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    float *pri = (float *)malloc(sizeof(float) * (n ? n : 1));
+    uint8_t *is_goal = (uint8_t *)calloc(n ? n : 1, 1);
+    uint32_t remaining = 0, hn = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        dist[i] = INFINITY;
+        parent[i] = ORC_NONE;
+        pos[i] = ORC_NONE;
+    }
+    if (goals)
+        for (uint32_t i = 0; i < n_goals; i++)
+            if (goals[i] < n && !is_goal[goals[i]]) {
+                is_goal[goals[i]] = 1;
+                remaining++;
+            }
+#define HLESS(a, b) (pri[a] < pri[b] || (pri[a] == pri[b] && (a) < (b)))
+#define HSWAP(i, j)                 \
+    do {                            \
+        uint32_t _t = heap[i];      \
+        heap[i] = heap[j];          \
+        heap[j] = _t;               \
+        pos[heap[i]] = (uint32_t)(i); \
+        pos[heap[j]] = (uint32_t)(j); \
+    } while (0)
+    if (start < n) {
+        dist[start] = 0.0f;
+        pri[start] = 0.0f;
+        heap[0] = start;
+        pos[start] = 0;
+        hn = 1;
+    }
+    while (hn > 0) {
+        uint32_t node = heap[0];
+        float cost = pri[node];
+        hn--;
+        if (hn > 0) {
+            heap[0] = heap[hn];
+            pos[heap[0]] = 0;
+            uint32_t i = 0;
+            for (;;) {
+                uint32_t l = 2 * i + 1, r = l + 1, c;
+                if (l >= hn) break;
+                c = (r < hn && HLESS(heap[r], heap[l])) ? r : l;
+                if (!HLESS(heap[c], heap[i])) break;
+                HSWAP(i, c);
+                i = c;
+            }
+        }
+        pos[node] = ORC_NONE;
+        if (!(cost > dist[node])) {
+            for (uint64_t e = off[node]; e < off[node + 1]; e++) {
+                uint32_t nx = tgt[e];
+                float nc = cost + w[e];
+                if (nc < dist[nx]) {
+                    dist[nx] = nc;
+                    parent[nx] = node;
+                    pri[nx] = nc;
+                    uint32_t i;
+                    if (pos[nx] == ORC_NONE) {
+                        i = hn++;
+                        heap[i] = nx;
+                        pos[nx] = i;
+                    } else i = pos[nx];
+                    while (i > 0) {
+                        uint32_t p = (i - 1) / 2;
+                        if (!HLESS(heap[i], heap[p])) break;
+                        HSWAP(i, p);
+                        i = p;
+                    }
+                }
+            }
+            if (goals) {
+                if (is_goal[node]) {
+                    is_goal[node] = 0;
+                    remaining--;
+                }
+                if (remaining == 0) break;
+            }
+        }
+    }
+#undef HLESS
+#undef HSWAP
+    free(heap);
+    free(pos);
+    free(pri);
+    free(is_goal);
+}
