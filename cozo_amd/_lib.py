@@ -1,0 +1,120 @@
+"""ctypes binding of libcozo_gpu.so (include/cozo_gpu.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no gfx950 device is visible the
+calls fail loudly (CozoGpuError / OSError)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libcozo_gpu.so")
+
+CZ_NONE = 0xFFFFFFFF
+CZ_DEVICE_PTRS = 1
+CZ_L2, CZ_COSINE, CZ_IP = 0, 1, 2
+CZ_OK, CZ_E_INVALID, CZ_E_NO_DEVICE, CZ_E_HIP, CZ_E_CANCELLED, CZ_E_OOM, CZ_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+u64p = C.POINTER(C.c_uint64)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+u8p = C.POINTER(C.c_uint8)
+
+
+class CozoGpuError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libcozo_gpu error {code}: {msg}")
+        self.code = code
+
+
+class ProcessKilled(CozoGpuError):
+    """CZ_E_CANCELLED: the poison flag was set (runtime/db.rs:1932-1940 `ProcessKilled`)."""
+
+
+class HnswDesc(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32),
+        ("dim", C.c_uint32),
+        ("metric", C.c_int32),
+        ("n_levels", C.c_int32),
+        ("entry", C.c_uint32),
+        ("level_size", u32p),
+        ("level_width", i32p),
+        ("level_nodes", C.POINTER(u32p)),
+        ("level_nbrs", C.POINTER(u32p)),
+    ]
+
+
+# every symbol include/cozo_gpu.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "cz_init": (C.c_int, [C.c_int]),
+    "cz_shutdown": (None, []),
+    "cz_device_count": (C.c_int, []),
+    "cz_last_error": (C.c_char_p, []),
+    "cz_version": (C.c_char_p, []),
+    "cz_hnsw_index_create": (C.c_int, [C.POINTER(HnswDesc), C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cz_hnsw_index_destroy": (None, [C.c_void_p]),
+    "cz_hnsw_index_bytes": (C.c_uint64, [C.c_void_p]),
+    "cz_hnsw_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                       C.c_void_p]),
+    "cz_distance_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                    C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "cz_knn_bruteforce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                    C.c_void_p]),
+    "cz_pagerank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_double,
+                              C.c_uint32, C.c_void_p, u32p, f64p, C.c_void_p]),
+    "cz_pagerank_plan_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_float, C.POINTER(C.c_void_p)]),
+    "cz_pagerank_plan_destroy": (None, [C.c_void_p]),
+    "cz_pagerank_plan_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cz_pagerank_plan_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cz_pagerank_plan_scores": (C.c_void_p, [C.c_void_p]),
+    "cz_pagerank_plan_edges": (C.c_uint64, [C.c_void_p]),
+    "cz_pagerank_plan_read_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "cz_bfs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cz_connected_components": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, u32p, C.c_void_p]),
+    "cz_sssp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
+                          C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the library (no device needed to load; compute calls need a gfx950 GPU)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise OSError(f"{SO_PATH} is missing: build it with `python -m cozo_amd.build` "
+                          "(there is no CPU fallback for the cozo_amd product path)")
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc == CZ_OK:
+        return
+    msg = lib().cz_last_error().decode("utf-8", "replace")
+    if rc == CZ_E_CANCELLED:
+        raise ProcessKilled(rc, msg)
+    raise CozoGpuError(rc, msg)
+
+
+def ptr(a):
+    """void* of a numpy array / torch tensor / int / None."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(a.ctypes.data)

@@ -1,0 +1,59 @@
+// common.h -- host-side helpers shared by the libcozo_gpu translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/cozo_gpu.h"
+
+namespace cz {
+
+std::string &last_error_ref();
+int set_error(int code, const char *fmt, ...);
+int ensure_device();  // CZ_OK or CZ_E_NO_DEVICE; lazily runs cz_init(0)
+
+#define CZ_HIP(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            return cz::set_error(_e == hipErrorOutOfMemory ? CZ_E_OOM : CZ_E_HIP, "%s failed: %s (%s:%d)", #expr, \
+                                 hipGetErrorString(_e), __FILE__, __LINE__);                       \
+        }                                                                                          \
+    } while (0)
+
+static inline bool poisoned(const volatile uint8_t *p) { return p && *p; }
+
+// RAII device buffer (freed on scope exit unless released)
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { reset(); }
+    void reset() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count) {
+        reset();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        else p = nullptr;
+        return e;
+    }
+    T *release() {
+        T *r = p;
+        p = nullptr;
+        n = 0;
+        return r;
+    }
+};
+
+}  // namespace cz

@@ -1,0 +1,666 @@
+// hnsw_api.hip -- C ABI for vectors / HNSW: index upload, batched k-NN search, batched distance,
+// exhaustive k-NN.  Kernels: hnsw_kernels.cuh (search), this file (pairs, brute force).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "hnsw_index.h"
+#include "hnsw_kernels.cuh"
+
+using namespace czd;
+using czh::IndexDev;
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void pad_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, uint64_t n, uint32_t dim,
+                                uint32_t ld) {
+    uint64_t total = n * ld;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t r = i / ld;
+        uint32_t c = (uint32_t)(i % ld);
+        dst[i] = c < dim ? src[r * dim + c] : 0.f;
+    }
+}
+
+// VectorCache::dist over (query,node) pairs; one lane group per pair, U pairs in flight
+template <int LPV, int ITERS, int U>
+__global__ void __launch_bounds__(256)
+distance_pairs_kernel(int metric, const float *__restrict__ base, const float *__restrict__ queries, uint32_t ld,
+                      const uint32_t *__restrict__ pairs, uint64_t P, double *__restrict__ out) {
+    const int chunks = (int)(ld / 4);
+    const int lane = threadIdx.x & 63;
+    const int glane = lane % LPV;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPV;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / LPV;
+    for (uint64_t p0 = group * U; p0 < P; p0 += ngroups * U) {
+        const float4 *brow[U], *qrow[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            uint64_t p = p0 + u;
+            if (p < P) {
+                qrow[u] = (const float4 *)(queries + (size_t)pairs[2 * p] * ld);
+                brow[u] = (const float4 *)(base + (size_t)pairs[2 * p + 1] * ld);
+            } else {
+                qrow[u] = brow[u] = nullptr;
+            }
+        }
+        float a0[U], a1[U], a2[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) a0[u] = a1[u] = a2[u] = 0.f;
+        if constexpr (ITERS > 0) {
+            float4 bv[U][ITERS], qv[U][ITERS];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int j = 0; j < ITERS; j++) {
+                    int c = glane + LPV * j;
+                    bool ok = brow[u] != nullptr && c < chunks;
+                    bv[u][j] = ok ? brow[u][c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    qv[u][j] = ok ? qrow[u][c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int j = 0; j < ITERS; j++) {
+                    acc_chunk(metric, qv[u][j], bv[u][j], a0[u], a1[u]);
+                    if (metric == CZ_COSINE) {
+                        float d = 0.f;
+                        acc_chunk(CZ_IP, qv[u][j], qv[u][j], a2[u], d);
+                    }
+                }
+        } else {
+            for (int c = glane; c < chunks; c += LPV) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (brow[u] == nullptr) continue;
+                    float4 b = brow[u][c], q = qrow[u][c];
+                    acc_chunk(metric, q, b, a0[u], a1[u]);
+                    if (metric == CZ_COSINE) {
+                        float d = 0.f;
+                        acc_chunk(CZ_IP, q, q, a2[u], d);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float m = group_reduce<LPV>(a0[u]);
+            float bn = 0.f, qn = 0.f;
+            if (metric == CZ_COSINE) {
+                bn = group_reduce<LPV>(a1[u]);
+                qn = group_reduce<LPV>(a2[u]);
+            }
+            if (glane == 0 && p0 + u < P) out[p0 + u] = finish_distance(metric, m, bn, qn);
+        }
+    }
+}
+
+// exhaustive scan: grid (chunk of base rows, query); each workgroup keeps the k best of its chunk in LDS
+// (sorted insertion by one wave per candidate batch), a second kernel merges the chunk lists.
+template <int LPV, int ITERS, int U>
+__global__ void __launch_bounds__(256)
+bf_chunk_kernel(int metric, const float *__restrict__ base, uint32_t n, uint32_t ld, uint32_t dim,
+                const float *__restrict__ queries, uint32_t k, uint32_t rows_per_chunk, uint64_t *__restrict__ part_key,
+                uint32_t *__restrict__ part_id) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // layout: q[ld] floats | keys[256] u64 | ids[256] u32 | topk keys[k] u64 | topk ids[k] u32 | cnt
+    float4 *q_lds = (float4 *)smem_raw;
+    uint64_t *bkey = (uint64_t *)(smem_raw + (size_t)ld * 4);
+    uint32_t *bid = (uint32_t *)(bkey + 256);
+    uint64_t *tkey = (uint64_t *)(bid + 256);
+    uint32_t *tid_ = (uint32_t *)(tkey + k);
+    const int chunks = (int)(ld / 4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int glane = lane % LPV;
+    constexpr int VPW = 64 / LPV, TG = 4 * VPW;
+    const int group = wave * VPW + lane / LPV;
+    const uint32_t qi = blockIdx.y;
+    const uint32_t r0 = blockIdx.x * rows_per_chunk;
+    const uint32_t r1 = min(n, r0 + rows_per_chunk);
+    float *ql = (float *)q_lds;
+    for (uint32_t i = tid; i < ld; i += 256) ql[i] = i < dim ? queries[(size_t)qi * dim + i] : 0.f;
+    for (uint32_t i = tid; i < k; i += 256) {
+        tkey[i] = ~0ull;
+        tid_[i] = CZ_NONE;
+    }
+    __syncthreads();
+    float4 q[ITERS > 0 ? ITERS : 1];
+    if constexpr (ITERS > 0) {
+#pragma unroll
+        for (int j = 0; j < ITERS; j++) {
+            int c = glane + LPV * j;
+            q[j] = c < chunks ? q_lds[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float qnorm = metric == CZ_COSINE ? query_norm<LPV, ITERS>(q, q_lds, glane, chunks) : 0.f;
+    int tcnt = 0;  // valid entries in the top list (uniform)
+    // batches of 256 rows: distances into bkey/bid, then merge into the top-k by rank
+    for (uint32_t b0 = r0; b0 < r1; b0 += 256) {
+        const int nb = (int)min(256u, r1 - b0);
+        for (int base_i = group * U; base_i < nb; base_i += TG * U) {
+            const float4 *rows[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                int j = base_i + u;
+                rows[u] = j < nb ? (const float4 *)(base + (size_t)(b0 + j) * ld) : nullptr;
+            }
+            double d[U];
+            group_distances<LPV, ITERS, U>(metric, q, q_lds, glane, chunks, qnorm, rows, d);
+            if (glane == 0) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int j = base_i + u;
+                    if (j < nb) {
+                        bkey[j] = dist_key(d[u]);
+                        bid[j] = b0 + j;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // rank-merge the batch into the sorted top list (capacity k); ids are distinct => strict order
+        const uint64_t bound_k = tcnt >= (int)k ? tkey[k - 1] : ~0ull;
+        const uint32_t bound_i = tcnt >= (int)k ? tid_[k - 1] : CZ_NONE;
+        uint64_t mk = 0;
+        uint32_t mi = CZ_NONE;
+        bool elig = false;
+        if (tid < nb) {
+            mk = bkey[tid];
+            mi = bid[tid];
+            elig = tcnt < (int)k || czh::key_lt(mk, mi, bound_k, bound_i);
+        }
+        int nelig = __syncthreads_count(elig);
+        if (nelig > 0) {
+            if (tid < nb && !elig) bid[tid] = CZ_NONE;
+            __syncthreads();
+            // positions of old entries (each thread owns entries tid, tid+256, ...)
+            int npos = -1;
+            if (elig) {
+                int r1c = 0;
+                for (int t = 0; t < nb; t++) {
+                    uint32_t ni = bid[t];
+                    if (ni != CZ_NONE && czh::key_lt(bkey[t], ni, mk, mi)) r1c++;
+                }
+                int lo = 0, hi = tcnt;
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if (czh::key_lt(tkey[mid], tid_[mid], mk, mi)) lo = mid + 1;
+                    else hi = mid;
+                }
+                npos = r1c + lo;
+            }
+            constexpr int R = 4;  // k <= 1024
+            uint64_t wk[R];
+            uint32_t wi[R];
+            int wpos[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                int j = tid + r * 256;
+                wpos[r] = -1;
+                if (j < tcnt) {
+                    wk[r] = tkey[j];
+                    wi[r] = tid_[j];
+                    int sft = 0;
+                    for (int t = 0; t < nb; t++) {
+                        uint32_t ni = bid[t];
+                        if (ni != CZ_NONE && czh::key_lt(bkey[t], ni, wk[r], wi[r])) sft++;
+                    }
+                    if (sft > 0) wpos[r] = j + sft;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (wpos[r] >= 0 && wpos[r] < (int)k) {
+                    tkey[wpos[r]] = wk[r];
+                    tid_[wpos[r]] = wi[r];
+                }
+            if (elig && npos < (int)k) {
+                tkey[npos] = mk;
+                tid_[npos] = mi;
+            }
+            tcnt = min((int)k, tcnt + nelig);
+        }
+        __syncthreads();
+    }
+    const size_t o = ((size_t)qi * gridDim.x + blockIdx.x) * k;
+    for (uint32_t i = tid; i < k; i += 256) {
+        part_key[o + i] = tkey[i];
+        part_id[o + i] = tid_[i];
+    }
+}
+
+// merge the per-chunk lists of one query: thread-per-entry rank among all nchunks*k entries
+__global__ void __launch_bounds__(256)
+bf_merge_kernel(const uint64_t *__restrict__ part_key, const uint32_t *__restrict__ part_id, uint32_t nchunks, uint32_t k,
+                uint32_t *__restrict__ out_ids, double *__restrict__ out_dist) {
+    const uint32_t qi = blockIdx.x;
+    const uint32_t total = nchunks * k;
+    const uint64_t *pk = part_key + (size_t)qi * total;
+    const uint32_t *pi = part_id + (size_t)qi * total;
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        out_ids[(size_t)qi * k + i] = CZ_NONE;
+        out_dist[(size_t)qi * k + i] = __longlong_as_double(0x7FF0000000000000ll);
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+        uint32_t id = pi[e];
+        if (id == CZ_NONE) continue;
+        uint64_t key = pk[e];
+        // rank = sum over chunks of lower_bound in that chunk's sorted list
+        uint32_t rank = 0;
+        for (uint32_t c = 0; c < nchunks && rank < k; c++) {
+            const uint64_t *ck = pk + (size_t)c * k;
+            const uint32_t *ci = pi + (size_t)c * k;
+            uint32_t lo = 0, hi = k;
+            while (lo < hi) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (ci[mid] != CZ_NONE && czh::key_lt(ck[mid], ci[mid], key, id)) lo = mid + 1;
+                else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) {
+            out_ids[(size_t)qi * k + rank] = id;
+            out_dist[(size_t)qi * k + rank] = key_dist(key);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// shape dispatch
+// ------------------------------------------------------------------------------------------------
+#define CZ_DISPATCH_SHAPE(SH, CALL)                                            \
+    do {                                                                       \
+        if ((SH).lpv == 16) { CALL(16, 1, 4); }                                \
+        else if ((SH).lpv == 32) { CALL(32, 1, 4); }                           \
+        else switch ((SH).iters) {                                             \
+            case 1: CALL(64, 1, 4); break;                                     \
+            case 2: CALL(64, 2, 4); break;                                     \
+            case 3: CALL(64, 3, 2); break;                                     \
+            case 4: CALL(64, 4, 2); break;                                     \
+            case 5: CALL(64, 5, 1); break;                                     \
+            case 6: CALL(64, 6, 1); break;                                     \
+            case 7: CALL(64, 7, 1); break;                                     \
+            case 8: CALL(64, 8, 1); break;                                     \
+            default: CALL(64, 0, 2); break;                                    \
+        }                                                                      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// index handle
+// ------------------------------------------------------------------------------------------------
+namespace cz {
+
+HnswIndex::~HnswIndex() {
+    if (vec) (void)hipFree(vec);
+    if (nbr0) (void)hipFree(nbr0);
+    if (up_base) (void)hipFree(up_base);
+    if (up_nbrs) (void)hipFree(up_nbrs);
+    for (auto &w : pool) {
+        if (w.ptr) (void)hipFree(w.ptr);
+        if (w.ready) (void)hipEventDestroy(w.ready);
+    }
+}
+
+int HnswIndex::acquire(size_t bytes, hipStream_t stream, Workspace *out) {
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < pool.size(); i++) {
+            if (pool[i].bytes >= bytes) {
+                *out = pool[i];
+                pool.erase(pool.begin() + (long)i);
+                if (out->ready) CZ_HIP(hipStreamWaitEvent(stream, out->ready, 0));
+                return CZ_OK;
+            }
+        }
+    }
+    Workspace w;
+    CZ_HIP(hipMalloc(&w.ptr, bytes ? bytes : 16));
+    w.bytes = bytes;
+    CZ_HIP(hipEventCreateWithFlags(&w.ready, hipEventDisableTiming));
+    *out = w;
+    return CZ_OK;
+}
+
+int HnswIndex::release(Workspace w, hipStream_t stream) {
+    hipError_t e = hipEventRecord(w.ready, stream);
+    std::lock_guard<std::mutex> lk(mu);
+    pool.push_back(w);
+    if (e != hipSuccess) return set_error(CZ_E_HIP, "hipEventRecord: %s", hipGetErrorString(e));
+    return CZ_OK;
+}
+
+IndexDev HnswIndex::dev() const {
+    IndexDev d;
+    d.vec = vec;
+    d.n = n;
+    d.dim = dim;
+    d.ld = ld;
+    d.metric = metric;
+    d.nbr0 = nbr0;
+    d.w0 = w0;
+    d.up_base = up_base;
+    d.up_nbrs = up_nbrs;
+    d.wu = wu;
+    d.n_levels = n_levels;
+    d.entry = entry;
+    return d;
+}
+
+}  // namespace cz
+
+static int upload_padded(const float *src_host, uint64_t n, uint32_t dim, uint32_t ld, float *dst) {
+    if (n == 0) return CZ_OK;
+    if (ld != dim) CZ_HIP(hipMemset(dst, 0, n * (size_t)ld * 4));
+    CZ_HIP(hipMemcpy2D(dst, (size_t)ld * 4, src_host, (size_t)dim * 4, (size_t)dim * 4, n, hipMemcpyHostToDevice));
+    return CZ_OK;
+}
+
+extern "C" int cz_hnsw_index_create(const cz_hnsw_desc *desc, const float *vectors, cz_hnsw_index **out) {
+    if (!desc || !out) return cz::set_error(CZ_E_INVALID, "null argument");
+    *out = nullptr;
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if (desc->dim == 0) return cz::set_error(CZ_E_INVALID, "dim must be > 0");
+    if (desc->metric < CZ_L2 || desc->metric > CZ_IP) return cz::set_error(CZ_E_INVALID, "bad metric %d", desc->metric);
+    if (desc->n >= 0x7FFFFFFFu) return cz::set_error(CZ_E_UNSUPPORTED, "node ids must be < 2^31");
+    if (desc->n > 0 && !vectors) return cz::set_error(CZ_E_INVALID, "vectors is null");
+    auto *ix = new cz::HnswIndex();
+    std::unique_ptr<cz::HnswIndex> guard(ix);
+    ix->n = desc->n;
+    ix->dim = desc->dim;
+    ix->ld = (desc->dim + 3) & ~3u;
+    ix->metric = desc->metric;
+    ix->n_levels = desc->n == 0 ? 0 : desc->n_levels;
+    ix->entry = desc->entry;
+    if (ix->n_levels > 0) {
+        if (!desc->level_size || !desc->level_width || !desc->level_nbrs || !desc->level_nodes)
+            return cz::set_error(CZ_E_INVALID, "level tables missing");
+        if (desc->level_size[0] != desc->n)
+            return cz::set_error(CZ_E_INVALID, "level 0 must hold every node (level_size[0]=%u, n=%u)", desc->level_size[0],
+                                 desc->n);
+        if (desc->entry >= desc->n) return cz::set_error(CZ_E_INVALID, "entry %u out of range", desc->entry);
+        ix->w0 = desc->level_width[0];
+        ix->wu = ix->n_levels > 1 ? desc->level_width[1] : 1;
+        for (int l = 0; l < ix->n_levels; l++) {
+            if (desc->level_width[l] <= 0 || desc->level_width[l] > 256)
+                return cz::set_error(CZ_E_UNSUPPORTED, "level %d row width %d outside 1..256 (m_max0 = 2m <= 256)", l,
+                                     desc->level_width[l]);
+            if (l >= 1 && desc->level_width[l] != ix->wu)
+                return cz::set_error(CZ_E_INVALID, "upper levels must share one row width");
+            if (l >= 1 && !desc->level_nodes[l]) return cz::set_error(CZ_E_INVALID, "level_nodes[%d] is null", l);
+        }
+        if (desc->level_nodes[0]) {
+            for (uint32_t i = 0; i < desc->n; i++)
+                if (desc->level_nodes[0][i] != i) return cz::set_error(CZ_E_INVALID, "level_nodes[0] must be the identity");
+        }
+    }
+    // vectors
+    CZ_HIP(hipMalloc((void **)&ix->vec, std::max<size_t>(16, (size_t)ix->n * ix->ld * 4)));
+    rc = upload_padded(vectors, ix->n, ix->dim, ix->ld, ix->vec);
+    if (rc) return rc;
+    if (ix->n_levels > 0) {
+        CZ_HIP(hipMalloc((void **)&ix->nbr0, (size_t)ix->n * ix->w0 * 4));
+        CZ_HIP(hipMemcpy(ix->nbr0, desc->level_nbrs[0], (size_t)ix->n * ix->w0 * 4, hipMemcpyHostToDevice));
+        // upper levels: node -> first row; rows of one node are consecutive (level 1, 2, ... top)
+        std::vector<uint32_t> top(ix->n, 0);
+        for (int l = 1; l < ix->n_levels; l++) {
+            for (uint32_t i = 0; i < desc->level_size[l]; i++) {
+                uint32_t node = desc->level_nodes[l][i];
+                if (node >= ix->n) return cz::set_error(CZ_E_INVALID, "level %d node id %u out of range", l, node);
+                if (i > 0 && desc->level_nodes[l][i - 1] >= node)
+                    return cz::set_error(CZ_E_INVALID, "level_nodes[%d] must be strictly ascending", l);
+                if (top[node] != (uint32_t)(l - 1))
+                    return cz::set_error(CZ_E_INVALID, "node %u on level %d but not on level %d", node, l, l - 1);
+                top[node] = (uint32_t)l;
+            }
+        }
+        if ((int)top[ix->entry] != ix->n_levels - 1)
+            return cz::set_error(CZ_E_INVALID, "entry node %u is not on the top level", ix->entry);
+        std::vector<uint32_t> base(ix->n, CZ_NONE);
+        uint64_t rows = 0;
+        for (uint32_t i = 0; i < ix->n; i++)
+            if (top[i] > 0) {
+                base[i] = (uint32_t)rows;
+                rows += top[i];
+            }
+        if (rows >= 0xFFFFFFFFull) return cz::set_error(CZ_E_UNSUPPORTED, "too many upper-level rows");
+        std::vector<uint32_t> up((size_t)std::max<uint64_t>(rows, 1) * ix->wu, CZ_NONE);
+        for (int l = 1; l < ix->n_levels; l++)
+            for (uint32_t i = 0; i < desc->level_size[l]; i++) {
+                uint32_t node = desc->level_nodes[l][i];
+                memcpy(&up[((size_t)base[node] + (l - 1)) * ix->wu], desc->level_nbrs[l] + (size_t)i * ix->wu,
+                       (size_t)ix->wu * 4);
+            }
+        ix->up_rows = rows;
+        CZ_HIP(hipMalloc((void **)&ix->up_base, (size_t)ix->n * 4));
+        CZ_HIP(hipMemcpy(ix->up_base, base.data(), (size_t)ix->n * 4, hipMemcpyHostToDevice));
+        CZ_HIP(hipMalloc((void **)&ix->up_nbrs, up.size() * 4));
+        CZ_HIP(hipMemcpy(ix->up_nbrs, up.data(), up.size() * 4, hipMemcpyHostToDevice));
+    }
+    *out = reinterpret_cast<cz_hnsw_index *>(guard.release());
+    return CZ_OK;
+}
+
+extern "C" void cz_hnsw_index_destroy(cz_hnsw_index *h) {
+    if (!h) return;
+    (void)cz::ensure_device();
+    delete reinterpret_cast<cz::HnswIndex *>(h);
+}
+
+extern "C" uint64_t cz_hnsw_index_bytes(const cz_hnsw_index *h) {
+    if (!h) return 0;
+    auto *ix = reinterpret_cast<const cz::HnswIndex *>(h);
+    return (uint64_t)ix->n * ix->ld * 4 + (uint64_t)ix->n * ix->w0 * 4 + (uint64_t)ix->n * 4 + ix->up_rows * ix->wu * 4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// search
+// ------------------------------------------------------------------------------------------------
+namespace cz {
+
+int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32_t k, uint32_t ef, int has_radius,
+                       double radius, uint32_t *d_ids, double *d_dist, uint32_t *d_count, uint64_t *d_ndist,
+                       hipStream_t stream) {
+    if (B == 0) return CZ_OK;
+    if (k == 0) return set_error(CZ_E_INVALID, "k must be > 0");
+    if (ef == 0) return set_error(CZ_E_INVALID, "ef must be > 0");
+    if (ef > 1024) return set_error(CZ_E_UNSUPPORTED, "ef = %u exceeds the LDS-resident list limit (1024)", ef);
+    if (ix->n_levels <= 0) {  // empty index: no rows (hnsw.rs:903-909, 1009-1011)
+        CZ_HIP(hipMemsetAsync(d_count, 0, (size_t)B * 4, stream));
+        CZ_HIP(hipMemsetAsync(d_ids, 0xFF, (size_t)B * k * 4, stream));
+        CZ_HIP(hipMemsetAsync(d_dist, 0, (size_t)B * k * 8, stream));
+        if (d_ndist) CZ_HIP(hipMemsetAsync(d_ndist, 0, (size_t)B * 8, stream));
+        return CZ_OK;
+    }
+    const uint32_t words = (ix->n + 31) / 32;
+    HnswIndex::Workspace ws;
+    int rc = ix->acquire((size_t)B * words * 4, stream, &ws);
+    if (rc) return rc;
+    CZ_HIP(hipMemsetAsync(ws.ptr, 0, (size_t)B * words * 4, stream));
+    const uint32_t efcap = (std::max(ef, 1u) + 63) & ~63u;
+    const uint32_t wpad = (uint32_t)((std::max(ix->w0, ix->wu) + 63) & ~63);
+    const size_t smem = czh::smem_bytes(efcap, wpad, ix->ld);
+    if (smem > 160 * 1024) {
+        ix->release(ws, stream);
+        return set_error(CZ_E_UNSUPPORTED, "dim %u / ef %u need %zu bytes of LDS (> 160 KiB)", ix->dim, ef, smem);
+    }
+    IndexDev d = ix->dev();
+    Shape sh = shape_of(ix->dim);
+#define CZ_LAUNCH_KNN(LPV, ITERS, U)                                                                                    \
+    do {                                                                                                                \
+        auto kern = czh::hnsw_knn_kernel<LPV, ITERS, U>;                                                                \
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                        (int)smem);                                                    \
+        hipLaunchKernelGGL(kern, dim3(B), dim3(czh::kThreads), smem, stream, d, d_queries, k, ef, efcap, wpad,          \
+                           has_radius, radius, (uint32_t *)ws.ptr, words, d_ids, d_dist, d_count,                       \
+                           (unsigned long long *)d_ndist);                                                              \
+    } while (0)
+    CZ_DISPATCH_SHAPE(sh, CZ_LAUNCH_KNN);
+#undef CZ_LAUNCH_KNN
+    hipError_t e = hipGetLastError();
+    int rc2 = ix->release(ws, stream);
+    if (e != hipSuccess) return set_error(CZ_E_HIP, "hnsw_knn_kernel launch: %s", hipGetErrorString(e));
+    return rc2;
+}
+
+}  // namespace cz
+
+extern "C" int cz_hnsw_search_batch(cz_hnsw_index *h, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
+                                    int has_radius, double radius, uint32_t *out_ids, double *out_dist,
+                                    uint32_t *out_count, uint64_t *out_n_dist, const volatile uint8_t *poison,
+                                    uint32_t flags, void *stream_) {
+    if (!h) return cz::set_error(CZ_E_INVALID, "null index");
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    auto *ix = reinterpret_cast<cz::HnswIndex *>(h);
+    if (B == 0) return CZ_OK;
+    if (!queries || !out_ids || !out_dist || !out_count) return cz::set_error(CZ_E_INVALID, "null buffer");
+    if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (flags & CZ_DEVICE_PTRS)
+        return cz::hnsw_search_device(ix, queries, B, k, ef, has_radius, radius, out_ids, out_dist, out_count, out_n_dist,
+                                      stream);
+    cz::DevBuf<float> dq;
+    cz::DevBuf<uint32_t> dids, dcnt;
+    cz::DevBuf<double> ddist;
+    cz::DevBuf<uint64_t> dnd;
+    CZ_HIP(dq.alloc((size_t)B * ix->dim));
+    CZ_HIP(dids.alloc((size_t)B * k));
+    CZ_HIP(ddist.alloc((size_t)B * k));
+    CZ_HIP(dcnt.alloc(B));
+    if (out_n_dist) CZ_HIP(dnd.alloc(B));
+    CZ_HIP(hipMemcpyAsync(dq.p, queries, (size_t)B * ix->dim * 4, hipMemcpyHostToDevice, stream));
+    rc = cz::hnsw_search_device(ix, dq.p, B, k, ef, has_radius, radius, dids.p, ddist.p, dcnt.p, out_n_dist ? dnd.p : nullptr,
+                                stream);
+    if (rc) return rc;
+    CZ_HIP(hipMemcpyAsync(out_ids, dids.p, (size_t)B * k * 4, hipMemcpyDeviceToHost, stream));
+    CZ_HIP(hipMemcpyAsync(out_dist, ddist.p, (size_t)B * k * 8, hipMemcpyDeviceToHost, stream));
+    CZ_HIP(hipMemcpyAsync(out_count, dcnt.p, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+    if (out_n_dist) CZ_HIP(hipMemcpyAsync(out_n_dist, dnd.p, (size_t)B * 8, hipMemcpyDeviceToHost, stream));
+    CZ_HIP(hipStreamSynchronize(stream));
+    if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+    return CZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched distance
+// ------------------------------------------------------------------------------------------------
+static int distance_pairs_device(int metric, const float *d_base, const float *d_queries, uint32_t ld,
+                                 uint32_t dim, const uint32_t *d_pairs, uint64_t P, double *d_out, hipStream_t stream) {
+    Shape sh = shape_of(dim);
+    const int blocks = (int)std::min<uint64_t>(256 * 8, (P * (uint64_t)sh.lpv + 255) / 256);
+#define CZ_LAUNCH_PAIRS(LPV, ITERS, U)                                                                              \
+    hipLaunchKernelGGL((distance_pairs_kernel<LPV, ITERS, U>), dim3(std::max(blocks, 1)), dim3(256), 0, stream, metric, \
+                       d_base, d_queries, ld, d_pairs, P, d_out)
+    CZ_DISPATCH_SHAPE(sh, CZ_LAUNCH_PAIRS);
+#undef CZ_LAUNCH_PAIRS
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "distance_pairs_kernel launch: %s", hipGetErrorString(e));
+    return CZ_OK;
+}
+
+extern "C" int cz_distance_batch(int metric, const float *base, uint32_t n, uint32_t dim, const float *queries,
+                                 uint32_t nq, const uint32_t *pairs, uint64_t P, double *out, uint32_t flags,
+                                 void *stream_) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if (metric < CZ_L2 || metric > CZ_IP) return cz::set_error(CZ_E_INVALID, "bad metric %d", metric);
+    if (dim == 0) return cz::set_error(CZ_E_INVALID, "dim must be > 0");
+    if (P == 0) return CZ_OK;
+    if (!base || !queries || !pairs || !out) return cz::set_error(CZ_E_INVALID, "null buffer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const uint32_t ld = (dim + 3) & ~3u;
+    cz::DevBuf<float> pb, pq;
+    const float *d_base = base, *d_q = queries;
+    if (flags & CZ_DEVICE_PTRS) {
+        if (ld != dim) {  // repack to 16-byte aligned rows
+            CZ_HIP(pb.alloc((size_t)n * ld));
+            CZ_HIP(pq.alloc((size_t)nq * ld));
+            hipLaunchKernelGGL(pad_rows_kernel, dim3(1024), dim3(256), 0, stream, base, pb.p, (uint64_t)n, dim, ld);
+            hipLaunchKernelGGL(pad_rows_kernel, dim3(256), dim3(256), 0, stream, queries, pq.p, (uint64_t)nq, dim, ld);
+            d_base = pb.p;
+            d_q = pq.p;
+        }
+        rc = distance_pairs_device(metric, d_base, d_q, ld, dim, pairs, P, out, stream);
+        if (rc) return rc;
+        if (ld != dim) CZ_HIP(hipStreamSynchronize(stream));  // temporaries die with this scope
+        return CZ_OK;
+    }
+    cz::DevBuf<uint32_t> dp;
+    cz::DevBuf<double> dout;
+    CZ_HIP(pb.alloc((size_t)n * ld));
+    CZ_HIP(pq.alloc((size_t)nq * ld));
+    CZ_HIP(dp.alloc((size_t)P * 2));
+    CZ_HIP(dout.alloc(P));
+    rc = upload_padded(base, n, dim, ld, pb.p);
+    if (rc) return rc;
+    rc = upload_padded(queries, nq, dim, ld, pq.p);
+    if (rc) return rc;
+    CZ_HIP(hipMemcpy(dp.p, pairs, (size_t)P * 8, hipMemcpyHostToDevice));
+    rc = distance_pairs_device(metric, pb.p, pq.p, ld, dim, dp.p, P, dout.p, stream);
+    if (rc) return rc;
+    CZ_HIP(hipStreamSynchronize(stream));
+    CZ_HIP(hipMemcpy(out, dout.p, (size_t)P * 8, hipMemcpyDeviceToHost));
+    return CZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exhaustive k-NN
+// ------------------------------------------------------------------------------------------------
+extern "C" int cz_knn_bruteforce(cz_hnsw_index *h, const float *queries, uint32_t B, uint32_t k, uint32_t *out_ids,
+                                 double *out_dist, uint32_t flags, void *stream_) {
+    if (!h) return cz::set_error(CZ_E_INVALID, "null index");
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    auto *ix = reinterpret_cast<cz::HnswIndex *>(h);
+    if (B == 0) return CZ_OK;
+    if (k == 0 || k > 1024) return cz::set_error(CZ_E_UNSUPPORTED, "k must be in 1..1024");
+    if (!queries || !out_ids || !out_dist) return cz::set_error(CZ_E_INVALID, "null buffer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool dev = flags & CZ_DEVICE_PTRS;
+    cz::DevBuf<float> dq;
+    cz::DevBuf<uint32_t> dids, pid;
+    cz::DevBuf<double> ddist;
+    cz::DevBuf<uint64_t> pkey;
+    const float *d_q = queries;
+    uint32_t *d_ids = out_ids;
+    double *d_dist = out_dist;
+    if (!dev) {
+        CZ_HIP(dq.alloc((size_t)B * ix->dim));
+        CZ_HIP(dids.alloc((size_t)B * k));
+        CZ_HIP(ddist.alloc((size_t)B * k));
+        CZ_HIP(hipMemcpyAsync(dq.p, queries, (size_t)B * ix->dim * 4, hipMemcpyHostToDevice, stream));
+        d_q = dq.p;
+        d_ids = dids.p;
+        d_dist = ddist.p;
+    }
+    // chunking: enough workgroups to fill the chip, chunk lists small enough to merge cheaply
+    uint32_t nchunks = std::max<uint32_t>(1, std::min<uint32_t>((ix->n + 4095) / 4096, std::max<uint32_t>(1, 8192 / B)));
+    uint32_t rows_per_chunk = (ix->n + nchunks - 1) / nchunks;
+    rows_per_chunk = std::max<uint32_t>(256, (rows_per_chunk + 255) & ~255u);
+    nchunks = std::max<uint32_t>(1, (ix->n + rows_per_chunk - 1) / rows_per_chunk);
+    CZ_HIP(pkey.alloc((size_t)B * nchunks * k));
+    CZ_HIP(pid.alloc((size_t)B * nchunks * k));
+    const size_t smem = (size_t)ix->ld * 4 + 256 * 8 + 256 * 4 + (size_t)k * 8 + (size_t)k * 4 + 16;
+    Shape sh = shape_of(ix->dim);
+#define CZ_LAUNCH_BF(LPV, ITERS, U)                                                                                  \
+    hipLaunchKernelGGL((bf_chunk_kernel<LPV, ITERS, U>), dim3(nchunks, B), dim3(256), smem, stream, ix->metric, ix->vec, \
+                       ix->n, ix->ld, ix->dim, d_q, k, rows_per_chunk, pkey.p, pid.p)
+    CZ_DISPATCH_SHAPE(sh, CZ_LAUNCH_BF);
+#undef CZ_LAUNCH_BF
+    hipLaunchKernelGGL(bf_merge_kernel, dim3(B), dim3(256), 0, stream, pkey.p, pid.p, nchunks, k, d_ids, d_dist);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "bruteforce launch: %s", hipGetErrorString(e));
+    if (!dev) {
+        CZ_HIP(hipMemcpyAsync(out_ids, d_ids, (size_t)B * k * 4, hipMemcpyDeviceToHost, stream));
+        CZ_HIP(hipMemcpyAsync(out_dist, d_dist, (size_t)B * k * 8, hipMemcpyDeviceToHost, stream));
+    }
+    CZ_HIP(hipStreamSynchronize(stream));  // temporaries die with this scope
+    return CZ_OK;
+}

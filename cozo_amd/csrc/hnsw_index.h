@@ -1,0 +1,54 @@
+// hnsw_index.h -- device-resident HNSW index handle (the object behind cz_hnsw_index*).
+//
+// HBM layout (sized for 288 GB; everything a search touches is contiguous per node):
+//   vec     f32 [n][ld]        ld = dim rounded up to 4 floats, zero padded, rows 16-byte aligned
+//   nbr0    u32 [n][w0]        level-0 link rows (w0 = m_max0), ascending ids, CZ_NONE padded
+//   up_base u32 [n]            first upper-level row of a node, CZ_NONE if the node lives on level 0 only
+//   up_nbrs u32 [rows][wu]     rows of one node are consecutive: level 1, 2, ... top  (wu = m_max)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace czh {
+struct IndexDev;
+}
+
+namespace cz {
+
+struct HnswIndex {
+    uint32_t n = 0, dim = 0, ld = 0;
+    int metric = 0;
+    int n_levels = 0;
+    uint32_t entry = CZ_NONE;
+    int w0 = 1, wu = 1;
+    uint64_t up_rows = 0;
+    float *vec = nullptr;
+    uint32_t *nbr0 = nullptr;
+    uint32_t *up_base = nullptr;
+    uint32_t *up_nbrs = nullptr;
+
+    // per-call scratch (visited bitmaps): cached, handed out under a mutex, stream-ordered by an event
+    struct Workspace {
+        void *ptr = nullptr;
+        size_t bytes = 0;
+        hipEvent_t ready = nullptr;
+    };
+    std::mutex mu;
+    std::vector<Workspace> pool;
+
+    ~HnswIndex();
+    int acquire(size_t bytes, hipStream_t stream, Workspace *out);
+    int release(Workspace w, hipStream_t stream);
+    czh::IndexDev dev() const;
+};
+
+int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32_t k, uint32_t ef, int has_radius,
+                       double radius, uint32_t *d_ids, double *d_dist, uint32_t *d_count, uint64_t *d_ndist,
+                       hipStream_t stream);
+
+}  // namespace cz

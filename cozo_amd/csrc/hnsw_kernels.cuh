@@ -1,0 +1,401 @@
+// hnsw_kernels.cuh -- HNSW layer search for gfx950: one workgroup per query.
+//
+// Restates hnsw_search_level / hnsw_knn (cozo-core/src/runtime/hnsw.rs:539-587, 869-1012) in a form
+// that maps to a CDNA4 workgroup:
+//   * the reference keeps two priority queues (candidates: min, found_nn: max, capped at ef).  Every
+//     candidate is pushed to both at once and an element evicted from found_nn can never be expanded
+//     (it is farther than the current ef-th best, which only shrinks), so the pair is equivalent to
+//     ONE list W, sorted ascending by (distance, id), holding at most ef entries with an "expanded"
+//     flag: the next candidate is the nearest un-expanded entry, the loop ends when there is none.
+//     (Differs from the reference only when two distinct nodes have bit-identical distances at the
+//     eviction boundary, where the reference's priority-queue crate is itself unspecified.)
+//   * processing the neighbours of a candidate one by one against a running `furthest` equals merging
+//     the whole neighbour batch into W and truncating at ef (streaming top-k).
+//   * W lives in LDS; neighbour ids are fetched with one coalesced row load; `visited` is a per-query
+//     bitmap in HBM (test-and-set atomics at L2); distances use the wave-wide routines of
+//     distance.cuh, U rows in flight per lane group; the merge computes final positions by rank
+//     (binary search over W for new entries, linear count over the <= 64 new entries for W entries).
+#pragma once
+#include "distance.cuh"
+
+namespace czh {
+
+using namespace czd;
+
+constexpr uint32_t kExpanded = 0x80000000u;
+constexpr uint32_t kIdMask = 0x7FFFFFFFu;
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kVlogCap = 2048;
+
+struct IndexDev {
+    const float *vec;        // [n][ld]
+    uint32_t n, dim, ld;     // ld = dim rounded up to 4
+    int metric;
+    const uint32_t *nbr0;    // [n][w0]
+    int w0;
+    const uint32_t *up_base; // [n]  first upper row of the node (CZ_NONE: top level 0)
+    const uint32_t *up_nbrs; // [rows][wu]; row = up_base[node] + (level-1)
+    int wu;
+    int n_levels;
+    uint32_t entry;
+};
+
+// LDS carve-up (all offsets multiples of 16 bytes)
+struct Smem {
+    uint64_t *wkey;   // [efcap]
+    uint32_t *wid;    // [efcap]   id | kExpanded
+    uint64_t *nkey;   // [wpad]
+    uint32_t *nid;    // [wpad]    CZ_NONE = not eligible
+    uint32_t *todo;   // [wpad]
+    uint32_t *vlog;   // [kVlogCap]
+    float4 *q;        // [ld/4]
+    int *ctl;         // [16] control words
+};
+enum { C_CNT = 0, C_TODO = 1, C_LO = 2, C_VLOG = 3, C_NELIG = 4, C_NDIST_LO = 5, C_NDIST_HI = 6, C_KEEP = 7, C_NUM = 8 };
+
+__host__ __device__ inline size_t smem_bytes(uint32_t efcap, uint32_t wpad, uint32_t ld) {
+    size_t b = 0;
+    b += (size_t)efcap * 8;
+    b += (((size_t)efcap * 4 + 15) / 16) * 16;
+    b += (size_t)wpad * 8;
+    b += (size_t)wpad * 4;
+    b += (size_t)wpad * 4;
+    b += (size_t)kVlogCap * 4;
+    b += (size_t)ld * 4;
+    b += 64;
+    return b;
+}
+__device__ inline Smem carve(char *base, uint32_t efcap, uint32_t wpad, uint32_t ld) {
+    Smem s;
+    s.wkey = (uint64_t *)base;
+    base += (size_t)efcap * 8;
+    s.wid = (uint32_t *)base;
+    base += (((size_t)efcap * 4 + 15) / 16) * 16;
+    s.nkey = (uint64_t *)base;
+    base += (size_t)wpad * 8;
+    s.nid = (uint32_t *)base;
+    base += (size_t)wpad * 4;
+    s.todo = (uint32_t *)base;
+    base += (size_t)wpad * 4;
+    s.vlog = (uint32_t *)base;
+    base += (size_t)kVlogCap * 4;
+    s.q = (float4 *)base;
+    base += (size_t)ld * 4;
+    s.ctl = (int *)base;
+    return s;
+}
+
+__device__ __forceinline__ bool key_lt(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) {
+    return ka < kb || (ka == kb && ia < ib);
+}
+
+// visited bitmap helpers: reads/writes go to L2 (atomics), one bitmap per query, only this workgroup touches it
+__device__ __forceinline__ bool test_and_set(uint32_t *bitmap, uint32_t id) {
+    uint32_t bit = 1u << (id & 31);
+    uint32_t old = atomicOr(&bitmap[id >> 5], bit);
+    return (old & bit) != 0;
+}
+
+template <int LPV, int ITERS, int U>
+struct Searcher {
+    const IndexDev &ix;
+    Smem s;
+    uint32_t *bitmap;
+    uint32_t words;
+    int tid, lane, wave, glane, group;
+    int chunks;
+    float4 q[ITERS > 0 ? ITERS : 1];
+    float qnorm;
+
+    static constexpr int VPW = 64 / LPV;          // lane groups per wave
+    static constexpr int TG = kWaves * VPW;       // lane groups per workgroup
+
+    __device__ Searcher(const IndexDev &ix_, Smem s_, uint32_t *bitmap_, uint32_t words_)
+        : ix(ix_), s(s_), bitmap(bitmap_), words(words_) {
+        tid = threadIdx.x;
+        lane = tid & 63;
+        wave = tid >> 6;
+        glane = lane % LPV;
+        group = wave * VPW + lane / LPV;
+        chunks = (int)(ix.ld / 4);
+    }
+
+    // stage the query row (zero padded) into LDS and registers
+    __device__ void load_query(const float *qrow) {
+        float *ql = (float *)s.q;
+        for (uint32_t i = tid; i < ix.ld; i += kThreads) ql[i] = i < ix.dim ? qrow[i] : 0.f;
+        if (tid < 16) s.ctl[tid] = 0;
+        __syncthreads();
+        if constexpr (ITERS > 0) {
+#pragma unroll
+            for (int j = 0; j < ITERS; j++) {
+                int c = glane + LPV * j;
+                q[j] = c < chunks ? s.q[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        qnorm = ix.metric == CZ_COSINE ? query_norm<LPV, ITERS>(q, s.q, glane, chunks) : 0.f;
+    }
+
+    // distances for todo[0..n) -> nkey/nid   (all waves)
+    __device__ void eval_todo(int n) {
+        for (int base = group * U; base < n; base += TG * U) {
+            const float4 *rows[U];
+            uint32_t ids[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                int j = base + u;
+                ids[u] = j < n ? s.todo[j] : CZ_NONE;
+                rows[u] = j < n ? (const float4 *)(ix.vec + (size_t)ids[u] * ix.ld) : nullptr;
+            }
+            double d[U];
+            group_distances<LPV, ITERS, U>(ix.metric, q, s.q, glane, chunks, qnorm, rows, d);
+            if (glane == 0) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    int j = base + u;
+                    if (j < n) {
+                        s.nkey[j] = dist_key(d[u]);
+                        s.nid[j] = ids[u];
+                    }
+                }
+            }
+        }
+    }
+
+    // merge nkey/nid[0..n) into W (capacity ef).  Caller guarantees a barrier before; ends with a barrier.
+    __device__ void merge(int n, int ef) {
+        const int cnt = s.ctl[C_CNT];
+        const bool full = cnt >= ef;
+        const uint64_t bkey = cnt > 0 ? s.wkey[cnt - 1] : 0;
+        // eligibility (hnsw.rs:575 `found_nn.len() < ef || neighbour_dist < furthest`, raw f64 compare)
+        uint64_t mykey = 0;
+        uint32_t myid = CZ_NONE;
+        bool elig = false;
+        if (tid < n) {
+            mykey = s.nkey[tid];
+            myid = s.nid[tid];
+            elig = !full || (mykey < bkey && bkey != ~0ull);
+        }
+        int nelig = __syncthreads_count(elig);  // also orders the nkey/nid reads above before the rewrite below
+        if (nelig == 0) return;
+        if (tid < n && !elig) s.nid[tid] = CZ_NONE;
+        __syncthreads();
+        // phase A: final positions
+        constexpr int R = 4;  // ef <= R * kThreads
+        uint64_t wk[R];
+        uint32_t wi[R];
+        int wpos[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            int j = tid + r * kThreads;
+            wpos[r] = -1;
+            if (j < cnt) {
+                wk[r] = s.wkey[j];
+                wi[r] = s.wid[j];
+                int sft = 0;
+                for (int t = 0; t < n; t++) {
+                    uint32_t ni = s.nid[t];
+                    if (ni != CZ_NONE && key_lt(s.nkey[t], ni, wk[r], wi[r] & kIdMask)) sft++;
+                }
+                if (sft > 0) wpos[r] = j + sft;
+            }
+        }
+        int npos = -1;
+        if (elig) {
+            int r1 = 0;
+            for (int t = 0; t < n; t++) {
+                uint32_t ni = s.nid[t];
+                if (ni != CZ_NONE && key_lt(s.nkey[t], ni, mykey, myid)) r1++;
+            }
+            int lo = 0, hi = cnt;  // lower bound of (mykey,myid) in W
+            while (lo < hi) {
+                int mid = (lo + hi) >> 1;
+                if (key_lt(s.wkey[mid], s.wid[mid] & kIdMask, mykey, myid)) lo = mid + 1;
+                else hi = mid;
+            }
+            npos = r1 + lo;
+        }
+        __syncthreads();
+        // phase B: scatter in place
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (wpos[r] >= 0 && wpos[r] < ef) {
+                s.wkey[wpos[r]] = wk[r];
+                s.wid[wpos[r]] = wi[r];
+            }
+        }
+        if (elig && npos < ef) {
+            s.wkey[npos] = mykey;
+            s.wid[npos] = myid;  // un-expanded
+            atomicMin(&s.ctl[C_LO], npos);
+        }
+        if (tid == 0) s.ctl[C_CNT] = min(ef, cnt + nelig);
+        __syncthreads();
+    }
+
+    // forget the visited set of a finished upper level
+    __device__ void clear_visited() {
+        int nlog = s.ctl[C_VLOG];
+        if (nlog <= kVlogCap) {
+            for (int i = tid; i < nlog; i += kThreads) bitmap[s.vlog[i] >> 5] = 0;
+        } else {
+            for (uint32_t i = tid; i < words; i += kThreads) bitmap[i] = 0;
+        }
+        __syncthreads();
+        if (tid == 0) s.ctl[C_VLOG] = 0;
+        __syncthreads();
+    }
+
+    __device__ __forceinline__ void log_visit(uint32_t id, bool enable) {
+        if (!enable) return;
+        int p = atomicAdd(&s.ctl[C_VLOG], 1);
+        if (p < kVlogCap) s.vlog[p] = id;
+    }
+
+    // hnsw_search_level (hnsw.rs:539-587) with W carried in and out.  log = keep a visit log so the
+    // bitmap can be cleared afterwards (every level but the last one searched)
+    __device__ void search_level(int level, int ef, bool log) {
+        // :554-557 every carried entry is visited and a candidate again
+        int cnt = s.ctl[C_CNT];
+        for (int i = tid; i < cnt; i += kThreads) {
+            uint32_t id = s.wid[i] & kIdMask;
+            s.wid[i] = id;
+            test_and_set(bitmap, id);
+            log_visit(id, log);
+        }
+        if (tid == 0) s.ctl[C_LO] = 0;
+        __syncthreads();
+        const int width = level == 0 ? ix.w0 : ix.wu;
+        for (;;) {
+            // nearest un-expanded entry (uniform across the workgroup)
+            cnt = s.ctl[C_CNT];
+            int idx = -1;
+            for (int b = s.ctl[C_LO]; b < cnt; b += 64) {
+                int j = b + lane;
+                bool un = j < cnt && !(s.wid[j] & kExpanded);
+                unsigned long long m = __ballot(un);
+                if (m) {
+                    idx = b + __ffsll((long long)m) - 1;
+                    break;
+                }
+            }
+            if (idx < 0) break;
+            const uint32_t cand = s.wid[idx] & kIdMask;
+            __syncthreads();  // everyone has read wid[idx] / C_LO before they change
+            if (tid == 0) {
+                s.wid[idx] = cand | kExpanded;
+                s.ctl[C_LO] = idx + 1;
+                s.ctl[C_TODO] = 0;
+            }
+            __syncthreads();
+            // neighbour row + visited filter (wave 0), hnsw.rs:566-571
+            if (wave == 0) {
+                const uint32_t *row = level == 0 ? ix.nbr0 + (size_t)cand * ix.w0
+                                                 : ix.up_nbrs + ((size_t)ix.up_base[cand] + (level - 1)) * ix.wu;
+                int total = 0;
+                for (int c0 = 0; c0 < width; c0 += 64) {
+                    int c = c0 + lane;
+                    uint32_t nb = c < width ? row[c] : CZ_NONE;
+                    bool fresh = false;
+                    if (nb != CZ_NONE) fresh = !test_and_set(bitmap, nb);
+                    unsigned long long m = __ballot(fresh);
+                    if (fresh) {
+                        int p = total + __popcll(m & ((1ull << lane) - 1ull));
+                        s.todo[p] = nb;
+                        log_visit(nb, log);
+                    }
+                    total += __popcll(m);
+                }
+                if (lane == 0) {
+                    s.ctl[C_TODO] = total;
+                    // 64-bit distance-evaluation counter
+                    unsigned int lo = (unsigned int)s.ctl[C_NDIST_LO];
+                    unsigned int nl = lo + (unsigned int)total;
+                    s.ctl[C_NDIST_LO] = (int)nl;
+                    if (nl < lo) s.ctl[C_NDIST_HI] += 1;
+                }
+            }
+            __syncthreads();
+            const int n = s.ctl[C_TODO];
+            if (n == 0) continue;
+            eval_todo(n);
+            __syncthreads();
+            merge(n, ef);
+        }
+    }
+
+    // distance to the entry point seeds W (hnsw.rs:915-918)
+    __device__ void seed(uint32_t entry) {
+        if (tid == 0) {
+            s.todo[0] = entry;
+            s.ctl[C_CNT] = 0;
+            s.ctl[C_NDIST_LO] += 1;
+        }
+        __syncthreads();
+        eval_todo(1);
+        __syncthreads();
+        if (tid == 0) {
+            s.wkey[0] = s.nkey[0];
+            s.wid[0] = s.nid[0];
+            s.ctl[C_CNT] = 1;
+        }
+        __syncthreads();
+    }
+};
+
+// hnsw_knn (hnsw.rs:869-1012): one workgroup per query
+template <int LPV, int ITERS, int U>
+__global__ void __launch_bounds__(kThreads)
+hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t efcap,
+                uint32_t wpad, int has_radius, double radius, uint32_t *__restrict__ visited, uint32_t words,
+                uint32_t *__restrict__ out_ids, double *__restrict__ out_dist, uint32_t *__restrict__ out_count,
+                unsigned long long *__restrict__ out_n_dist) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const uint32_t b = blockIdx.x;
+    Smem s = carve(smem_raw, efcap, wpad, ix.ld);
+    Searcher<LPV, ITERS, U> S(ix, s, visited + (size_t)b * words, words);
+    S.load_query(queries + (size_t)b * ix.dim);
+    S.seed(ix.entry);
+    for (int lv = ix.n_levels - 1; lv > 0; lv--) {  // :919-929 greedy descent, ef = 1
+        S.search_level(lv, 1, true);
+        S.clear_visited();
+    }
+    S.search_level(0, (int)ef, false);  // :930-938
+    // :943-1006 truncate to k, radius cut (`distance > r` => skip; a NaN distance is never > r), ascending
+    const int cnt = s.ctl[C_CNT];
+    const int kk = min((int)k, cnt);
+    int c_keep = 0, c_num = 0;
+    for (int i = threadIdx.x; i < kk; i += kThreads) {
+        uint64_t key = s.wkey[i];
+        if (key != ~0ull) {
+            c_num++;
+            if (!(has_radius && key_dist(key) > radius)) c_keep++;
+        }
+    }
+    if (c_keep) atomicAdd(&s.ctl[C_KEEP], c_keep);
+    if (c_num) atomicAdd(&s.ctl[C_NUM], c_num);
+    __syncthreads();
+    // W is sorted: the kept finite entries are a prefix [0,p); NaN entries sit at [first_nan, kk)
+    const int p = s.ctl[C_KEEP], first_nan = s.ctl[C_NUM];
+    const int total = p + (kk - first_nan);
+    for (int j = threadIdx.x; j < (int)k; j += kThreads) {
+        uint32_t id = CZ_NONE;
+        double d = __longlong_as_double(0x7FF0000000000000ll);
+        int src = j < p ? j : (j < total ? first_nan + (j - p) : -1);
+        if (src >= 0) {
+            id = s.wid[src] & kIdMask;
+            d = key_dist(s.wkey[src]);
+        }
+        out_ids[(size_t)b * k + j] = id;
+        out_dist[(size_t)b * k + j] = d;
+    }
+    if (threadIdx.x == 0) {
+        out_count[b] = (uint32_t)total;
+        if (out_n_dist)
+            out_n_dist[b] = ((unsigned long long)(unsigned int)s.ctl[C_NDIST_HI] << 32) |
+                            (unsigned long long)(unsigned int)s.ctl[C_NDIST_LO];
+    }
+}
+
+}  // namespace czh

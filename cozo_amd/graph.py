@@ -1,0 +1,121 @@
+"""Thin array-level wrappers over the graph entry points of libcozo_gpu (include/cozo_gpu.h).
+
+Graphs are the CSR that `FixedRuleInputRelation::as_directed_graph` builds (fixed_rule/mod.rs:136-200).
+The rule-level mirror (options, payload, temp store) lives in cozo_amd/fixed_rule.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import CZ_NONE, check, ptr
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _csr32(off, tgt):
+    off = np.asarray(off)
+    if off.size and int(off[-1]) >= 0xFFFFFFFF:
+        raise _lib.CozoGpuError(_lib.CZ_E_UNSUPPORTED, "E must be < 2^32-1")
+    return _u32(off), _u32(tgt)
+
+
+def pagerank(in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10, poison=None):
+    """graph::page_rank as called by PageRank::run (pagerank.rs:47-50): (scores f32[N], iterations, error)."""
+    in_off, in_src = _csr32(in_off, in_src)
+    out_deg = _u32(out_deg)
+    N = out_deg.size
+    scores = np.empty(N, dtype=np.float32)
+    it = C.c_uint32(0)
+    err = C.c_double(0.0)
+    check(_lib.lib().cz_pagerank(ptr(in_off), ptr(in_src), ptr(out_deg), N, in_src.size, np.float32(damping),
+                                 float(tolerance), int(max_iter), ptr(scores), C.byref(it), C.byref(err), ptr(poison)))
+    return scores, it.value, err.value
+
+
+class PageRankPlan:
+    """Resident / row-sharded PageRank (cz_pagerank_plan_*): rows [row_begin,row_end) of the in-CSR."""
+
+    def __init__(self, in_off_local, in_src, out_deg, N, row_begin, row_end, damping=0.85):
+        in_off_local, in_src = _csr32(in_off_local, in_src)
+        out_deg = _u32(out_deg)
+        h = C.c_void_p()
+        check(_lib.lib().cz_pagerank_plan_create(ptr(in_off_local), ptr(in_src), ptr(out_deg), N, row_begin, row_end,
+                                                 np.float32(damping), C.byref(h)))
+        self._h = h
+        self.N, self.row_begin, self.row_end = N, row_begin, row_end
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().cz_pagerank_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def edges(self) -> int:
+        return int(_lib.lib().cz_pagerank_plan_edges(self._h))
+
+    def init(self, contrib, stream: int = 0):
+        check(_lib.lib().cz_pagerank_plan_init(self._h, ptr(contrib), C.c_void_p(stream)))
+
+    def step(self, contrib_in, contrib_out, err_out, stream: int = 0):
+        check(_lib.lib().cz_pagerank_plan_step(self._h, ptr(contrib_in), ptr(contrib_out), ptr(err_out),
+                                               C.c_void_p(stream)))
+
+    def scores_ptr(self) -> int:
+        return int(_lib.lib().cz_pagerank_plan_scores(self._h) or 0)
+
+    def read_scores(self, out=None, stream: int = 0):
+        """this shard's scores [row_end-row_begin]: into a device tensor, or returned as a numpy array."""
+        if out is not None:
+            check(_lib.lib().cz_pagerank_plan_read_scores(self._h, ptr(out), _lib.CZ_DEVICE_PTRS, C.c_void_p(stream)))
+            return out
+        host = np.empty(self.row_end - self.row_begin, dtype=np.float32)
+        check(_lib.lib().cz_pagerank_plan_read_scores(self._h, ptr(host), 0, C.c_void_p(stream)))
+        return host
+
+
+def bfs(out_off, out_tgt, starts, goals=None, share_visited=False, want_depth=False, want_order=False, poison=None):
+    out_off, out_tgt = _csr32(out_off, out_tgt)
+    N = out_off.size - 1
+    starts = _u32(starts)
+    g = _u32(goals) if goals is not None else None
+    parent = np.full((starts.size, N), CZ_NONE, dtype=np.uint32)
+    depth = np.full((starts.size, N), CZ_NONE, dtype=np.uint32) if want_depth else None
+    order = np.full((starts.size, N), CZ_NONE, dtype=np.uint32) if want_order else None
+    reached = np.zeros(starts.size, dtype=np.uint32)
+    check(_lib.lib().cz_bfs(ptr(out_off), ptr(out_tgt), N, out_tgt.size, ptr(starts), starts.size, ptr(g),
+                            0 if g is None else g.size, int(share_visited), ptr(parent), ptr(depth), ptr(order),
+                            ptr(reached), ptr(poison)))
+    return parent, depth, order, reached
+
+
+def connected_components(off, tgt, poison=None):
+    off, tgt = _csr32(off, tgt)
+    N = off.size - 1
+    grp = np.empty(N, dtype=np.uint32)
+    k = C.c_uint32(0)
+    check(_lib.lib().cz_connected_components(ptr(off), ptr(tgt), N, tgt.size, ptr(grp), C.byref(k), ptr(poison)))
+    return grp, k.value
+
+
+def sssp(out_off, out_tgt, weights, starts, poison=None):
+    out_off, out_tgt = _csr32(out_off, out_tgt)
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    N = out_off.size - 1
+    starts = _u32(starts)
+    dist = np.empty((starts.size, N), dtype=np.float32)
+    parent = np.empty((starts.size, N), dtype=np.uint32)
+    check(_lib.lib().cz_sssp(ptr(out_off), ptr(out_tgt), ptr(w), N, out_tgt.size, ptr(starts), starts.size, ptr(dist),
+                             ptr(parent), ptr(poison)))
+    return dist, parent

@@ -1,0 +1,161 @@
+"""Host-side mirror of the reference's HNSW operator surface over libcozo_gpu.
+
+Names follow cozo-core: `HnswIndexManifest` (runtime/hnsw.rs:27-43), `HnswSearch`
+(data/program.rs:975-991), `hnsw_knn` (runtime/hnsw.rs:869-1012).  The reference runs `hnsw_knn` once per
+parent tuple inside `HnswSearchRA::iter` (query/ra.rs:1085-1121); `hnsw_knn_batch` is the same operator
+applied to the whole batch of parent tuples in one GPU launch, results re-emitted in parent order.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import CZ_COSINE, CZ_DEVICE_PTRS, CZ_IP, CZ_L2, CZ_NONE, check, ptr
+
+DISTANCES = {"L2": CZ_L2, "Cosine": CZ_COSINE, "IP": CZ_IP}  # HnswDistance, parse/sys.rs:76-98
+
+
+@dataclass
+class HnswIndexManifest:
+    """runtime/hnsw.rs:27-43 (the fields the search path reads)."""
+    vec_dim: int
+    distance: str = "L2"
+    m_neighbours: int = 16
+    ef_construction: int = 100
+    dtype: str = "F32"
+    extend_candidates: bool = False
+    keep_pruned_connections: bool = False
+
+    @property
+    def m_max(self) -> int:  # runtime/relation.rs:1136-1151
+        return self.m_neighbours
+
+    @property
+    def m_max0(self) -> int:
+        return self.m_neighbours * 2
+
+    @property
+    def level_multiplier(self) -> float:
+        return 1.0 / float(np.log(self.m_neighbours))
+
+
+@dataclass
+class HnswSearch:
+    """data/program.rs:975-991: per-query search parameters."""
+    k: int
+    ef: int
+    radius: Optional[float] = None
+    has_filter: bool = False  # a filter keeps all ef candidates until after filtering (hnsw.rs:943-947)
+
+
+class GpuHnswIndex:
+    """A device-resident flat export of one `tbl:idx` relation (see include/cozo_gpu.h cz_hnsw_desc)."""
+
+    def __init__(self, manifest: HnswIndexManifest, vectors: np.ndarray, level_nodes: Sequence[np.ndarray],
+                 level_nbrs: Sequence[np.ndarray], entry: int):
+        if manifest.dtype != "F32":
+            raise _lib.CozoGpuError(_lib.CZ_E_UNSUPPORTED, "only F32 vector indices are GPU-resident")
+        self.manifest = manifest
+        vectors = np.ascontiguousarray(vectors, dtype=np.float32)
+        if vectors.ndim != 2 or vectors.shape[1] != manifest.vec_dim:
+            raise ValueError("vectors must be [n][vec_dim]")
+        self.n = vectors.shape[0]
+        nl = len(level_nbrs)
+        nodes = [None if x is None else np.ascontiguousarray(x, dtype=np.uint32) for x in level_nodes]
+        nbrs = [np.ascontiguousarray(x, dtype=np.uint32) for x in level_nbrs]
+        size = np.array([x.shape[0] for x in nbrs], dtype=np.uint32)
+        width = np.array([x.shape[1] for x in nbrs], dtype=np.int32)
+        node_ptrs = (_lib.u32p * max(nl, 1))(*[None if x is None else x.ctypes.data_as(_lib.u32p) for x in nodes])
+        nbr_ptrs = (_lib.u32p * max(nl, 1))(*[x.ctypes.data_as(_lib.u32p) for x in nbrs])
+        desc = _lib.HnswDesc(self.n, manifest.vec_dim, DISTANCES[manifest.distance], nl, int(entry) & 0xFFFFFFFF,
+                             size.ctypes.data_as(_lib.u32p), width.ctypes.data_as(_lib.i32p), node_ptrs, nbr_ptrs)
+        h = C.c_void_p()
+        check(_lib.lib().cz_hnsw_index_create(C.byref(desc), ptr(vectors), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().cz_hnsw_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self) -> int:
+        return int(_lib.lib().cz_hnsw_index_bytes(self._h))
+
+    # ---- hnsw_knn over a batch of parent tuples (host buffers) ----
+    def hnsw_knn_batch(self, queries: np.ndarray, config: HnswSearch, poison: Optional[np.ndarray] = None,
+                       with_n_dist: bool = False):
+        """Returns (ids [B][kk], dist [B][kk] f64, count [B]) with kk = ef if a filter follows else k
+        (hnsw.rs:943-947), rows ascending by distance; optionally the per-query distance-evaluation count."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[1] != self.manifest.vec_dim:
+            raise ValueError("query vector dimension mismatch")  # hnsw.rs:876-878
+        B = q.shape[0]
+        kk = config.ef if config.has_filter else config.k
+        ids = np.empty((B, kk), dtype=np.uint32)
+        dist = np.empty((B, kk), dtype=np.float64)
+        cnt = np.empty(B, dtype=np.uint32)
+        nd = np.zeros(B, dtype=np.uint64) if with_n_dist else None
+        check(_lib.lib().cz_hnsw_search_batch(self._h, ptr(q), B, kk, config.ef, int(config.radius is not None),
+                                              float(config.radius or 0.0), ptr(ids), ptr(dist), ptr(cnt), ptr(nd),
+                                              ptr(poison), 0, None))
+        return (ids, dist, cnt, nd) if with_n_dist else (ids, dist, cnt)
+
+    def hnsw_knn(self, q: np.ndarray, config: HnswSearch):
+        """One parent tuple: list of (node id, distance) rows, ascending (hnsw.rs:1005-1006)."""
+        ids, dist, cnt = self.hnsw_knn_batch(np.asarray(q)[None, :], config)
+        c = int(cnt[0])
+        return list(zip(ids[0, :c].tolist(), dist[0, :c].tolist()))
+
+    # ---- device-resident form (torch tensors on the GPU; used by bench.py and the sharded path) ----
+    def hnsw_knn_batch_device(self, queries, config: HnswSearch, out_ids, out_dist, out_count, out_n_dist=None,
+                              stream: int = 0):
+        B = queries.shape[0]
+        kk = config.ef if config.has_filter else config.k
+        check(_lib.lib().cz_hnsw_search_batch(self._h, ptr(queries), B, kk, config.ef, int(config.radius is not None),
+                                              float(config.radius or 0.0), ptr(out_ids), ptr(out_dist), ptr(out_count),
+                                              ptr(out_n_dist), None, CZ_DEVICE_PTRS, C.c_void_p(stream)))
+
+    def bruteforce_knn(self, queries: np.ndarray, k: int):
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        B = q.shape[0]
+        ids = np.empty((B, k), dtype=np.uint32)
+        dist = np.empty((B, k), dtype=np.float64)
+        check(_lib.lib().cz_knn_bruteforce(self._h, ptr(q), B, k, ptr(ids), ptr(dist), 0, None))
+        return ids, dist
+
+    def bruteforce_knn_device(self, queries, k: int, out_ids, out_dist, stream: int = 0):
+        check(_lib.lib().cz_knn_bruteforce(self._h, ptr(queries), queries.shape[0], k, ptr(out_ids), ptr(out_dist),
+                                           CZ_DEVICE_PTRS, C.c_void_p(stream)))
+
+
+def distance_batch(distance: str, base: np.ndarray, queries: np.ndarray, pairs: np.ndarray) -> np.ndarray:
+    """VectorCache::dist (hnsw.rs:66-109) == l2_dist / cos_dist / ip_dist (data/functions.rs:2185-2255) over
+    (query row, base row) pairs; returns f64 like the reference."""
+    base = np.ascontiguousarray(base, dtype=np.float32)
+    queries = np.ascontiguousarray(queries, dtype=np.float32)
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32)
+    if base.shape[1] != queries.shape[1]:
+        raise ValueError("requires two vectors of the same length")  # functions.rs:2190-2192
+    out = np.empty(pairs.shape[0], dtype=np.float64)
+    check(_lib.lib().cz_distance_batch(DISTANCES[distance], ptr(base), base.shape[0], base.shape[1], ptr(queries),
+                                       queries.shape[0], ptr(pairs), pairs.shape[0], ptr(out), 0, None))
+    return out
+
+
+def distance_batch_device(distance: str, base, queries, pairs, out, stream: int = 0):
+    check(_lib.lib().cz_distance_batch(DISTANCES[distance], ptr(base), base.shape[0], base.shape[1], ptr(queries),
+                                       queries.shape[0], ptr(pairs), pairs.shape[0], ptr(out), CZ_DEVICE_PTRS,
+                                       C.c_void_p(stream)))

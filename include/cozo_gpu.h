@@ -1,0 +1,182 @@
+/*
+ * cozo_gpu.h -- C ABI of libcozo_gpu.so: the MI355X (gfx950) implementation of CozoDB's
+ * HNSW k-NN search and whole-graph fixed-rule hot path.
+ *
+ * This header is the drop-in boundary.  cozo-core (Rust) has no C-level hook for this path
+ * (cozo-lib-c/cozo_c.h is string/JSON only), so each entry point states the reference
+ * interface it replaces (paths relative to /root/reference/cozo-core/src/); the Rust-side
+ * `extern "C"` declarations and the `impl FixedRule` / `HnswSearchRA::iter` patches that bind
+ * them are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 (CZ_OK) or a negative cz_status; a human-readable message for the
+ *     last failure on the calling thread is available from cz_last_error().
+ *   - the caller owns every pointer it passes in and every output buffer; the library owns device
+ *     memory behind the opaque handles.  No callbacks into the caller.
+ *   - `flags & CZ_DEVICE_PTRS`: the array arguments marked [dev-able] are device pointers (already
+ *     resident in HBM) and `stream` (a hipStream_t, may be NULL) orders the work; otherwise they are
+ *     host pointers and the call is synchronous (H2D, kernels, D2H).
+ *   - `poison` (may be NULL) mirrors runtime/db.rs:1926-1942 `Poison(Arc<AtomicBool>)`: a host byte
+ *     polled between kernel launches; non-zero => CZ_E_CANCELLED.
+ *   - all entry points are thread-safe; index / plan handles are immutable after creation.
+ *   - one process drives one GPU (cz_init(device)); multi-GPU = one process per GPU, with the
+ *     exchange steps done by the host over RCCL (see cozo_amd/distributed.py).
+ *   - node ids are dense u32 (< 2^31); CZ_NONE pads id arrays.
+ */
+#ifndef COZO_GPU_H
+#define COZO_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CZ_NONE 0xFFFFFFFFu
+#define CZ_DEVICE_PTRS 1u
+
+typedef enum {
+    CZ_OK = 0,
+    CZ_E_INVALID = -1,     /* bad argument */
+    CZ_E_NO_DEVICE = -2,   /* no gfx950 device / HIP runtime unusable: the product path never falls back to CPU */
+    CZ_E_HIP = -3,         /* a HIP call failed */
+    CZ_E_CANCELLED = -4,   /* *poison != 0 -> the shim raises ProcessKilled (runtime/db.rs:1932-1940) */
+    CZ_E_OOM = -5,
+    CZ_E_UNSUPPORTED = -6
+} cz_status;
+
+/* HnswDistance, parse/sys.rs:76-98 */
+typedef enum { CZ_L2 = 0, CZ_COSINE = 1, CZ_IP = 2 } cz_metric;
+
+/* ---- runtime ---- */
+int cz_init(int device);              /* hipSetDevice + capability check (gfx950) */
+void cz_shutdown(void);
+int cz_device_count(void);
+const char *cz_last_error(void);      /* thread-local */
+const char *cz_version(void);
+
+/* =====================================================================================
+ * Vectors / HNSW           replaces: runtime/hnsw.rs
+ * ===================================================================================== */
+
+/* Flat export of one `tbl:idx` index relation (schema runtime/relation.rs:1064-1126) plus the
+ * indexed vectors of the base relation.  A "node" is one CompoundKey (row key, field, sub-index)
+ * (runtime/hnsw.rs:55); the shim keeps the node -> CompoundKey table.  Level l here is layer -l of
+ * the reference (level 0 = dense bottom layer).  Neighbour rows hold the live links of
+ * hnsw_get_neighbours(include_deleted = false) (runtime/hnsw.rs:588-629): ascending node id,
+ * self-loop row, same-row-key links and ignore_link rows already dropped, CZ_NONE padded.  */
+typedef struct {
+    uint32_t n;                 /* number of nodes = rows of `vectors`; level 0 holds all of them */
+    uint32_t dim;               /* HnswIndexManifest::vec_dim (runtime/hnsw.rs:31) */
+    int32_t metric;             /* cz_metric */
+    int32_t n_levels;           /* 0 => empty index (hnsw_knn returns no rows, runtime/hnsw.rs:903-909) */
+    uint32_t entry;             /* first row of the index relation = smallest key on the top layer (:891-899) */
+    const uint32_t *level_size; /* [n_levels] nodes present on each level; level_size[0] == n */
+    const int32_t *level_width; /* [n_levels] row width: m_max0 on level 0, m_max above (:243-247) */
+    const uint32_t *const *level_nodes; /* [n_levels] ascending node ids per level; [0] may be NULL (identity) */
+    const uint32_t *const *level_nbrs;  /* [n_levels] -> [level_size][level_width] */
+} cz_hnsw_desc;
+
+typedef struct cz_hnsw_index cz_hnsw_index;
+
+/* Upload an index (host pointers).  vectors: f32 [n][dim] row-major (Vector::F32, data/value.rs:207-213). */
+int cz_hnsw_index_create(const cz_hnsw_desc *desc, const float *vectors, cz_hnsw_index **out);
+void cz_hnsw_index_destroy(cz_hnsw_index *ix);
+/* device bytes held by the index (vectors + link tables) */
+uint64_t cz_hnsw_index_bytes(const cz_hnsw_index *ix);
+
+/* SessionTx::hnsw_knn (runtime/hnsw.rs:869-1012) for a whole batch of parent tuples
+ * (HnswSearchRA::iter, query/ra.rs:1085-1121, calls it once per tuple).
+ *   queries [B][dim] f32 [dev-able]; k, ef as HnswSearch (data/program.rs:975-991);
+ *   has_radius/radius: `distance > r => skip` (:952-956), applied to the same (squared-L2 / 1-cos /
+ *   1-dot) value the reference compares.
+ *   out_ids [B][k] (CZ_NONE padded), out_dist [B][k] f64 (the reference returns f64 distances),
+ *   out_count [B]: results per query, ascending distance (:1005-1006)           [all dev-able]
+ *   out_n_dist [B] or NULL: distance evaluations per query (for roofline accounting) [dev-able]
+ * A filtered search (filter bytecode stays in Rust) asks for k = ef and filters the rows it gets
+ * back, which is what :943-947/:997-1006 do. */
+int cz_hnsw_search_batch(cz_hnsw_index *ix, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
+                         int has_radius, double radius, uint32_t *out_ids, double *out_dist, uint32_t *out_count,
+                         uint64_t *out_n_dist, const volatile uint8_t *poison, uint32_t flags, void *stream);
+
+/* VectorCache::dist (runtime/hnsw.rs:66-109) == op_l2_dist / op_cos_dist / op_ip_dist
+ * (data/functions.rs:2185-2255) over P (query, node) pairs:
+ *   base [n][dim], queries [nq][dim], pairs [P][2] = (query row, base row), out [P] f64  [all dev-able] */
+int cz_distance_batch(int metric, const float *base, uint32_t n, uint32_t dim, const float *queries, uint32_t nq,
+                      const uint32_t *pairs, uint64_t P, double *out, uint32_t flags, void *stream);
+
+/* exact k-NN by exhaustive scan over an uploaded index' vectors (recall ground truth; the "query batch
+ * turns distance into a dense GEMM" case).  Same outputs as cz_hnsw_search_batch. */
+int cz_knn_bruteforce(cz_hnsw_index *ix, const float *queries, uint32_t B, uint32_t k, uint32_t *out_ids,
+                      double *out_dist, uint32_t flags, void *stream);
+
+/* =====================================================================================
+ * Whole-graph fixed rules   replaces: fixed_rule/algos/ (one .rs per rule) behind `trait FixedRule`
+ * (fixed_rule/mod.rs:538-567).  Graphs arrive as the CSR that
+ * FixedRuleInputRelation::as_directed_graph builds (fixed_rule/mod.rs:136-200): dense u32 ids in
+ * first-appearance order, CsrLayout::Sorted adjacency, parallel edges kept.
+ * ===================================================================================== */
+
+/* PageRank::run (fixed_rule/algos/pagerank.rs:29-56) -> graph::page_rank.
+ *   in_offsets [N+1], in_sources [E] : in-adjacency (pull form)     out_degree [N]
+ *   damping = `theta` as f32, tolerance = `epsilon` (f32 widened to f64), max_iter = `iterations`
+ *   scores [N] f32 out (the shim emits `score as f64`), iters_run / final_err optional.
+ * Host pointers only (one-shot); the resident / sharded form is the plan API below. */
+int cz_pagerank(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N,
+                uint64_t E, float damping, double tolerance, uint32_t max_iter, float *scores, uint32_t *iters_run,
+                double *final_err, const volatile uint8_t *poison);
+
+/* Resident / row-sharded PageRank.  A plan owns rows [row_begin, row_end) of the in-CSR:
+ *   in_offsets [rows+1] relative to the shard (in_offsets[0] == 0), in_sources [E_local] GLOBAL ids,
+ *   out_degree [N] for all nodes.                                   (host pointers)
+ * One iteration = cz_pagerank_plan_step: reads the full contribution vector contrib_in [N] (device),
+ * writes this shard's scores and its slice of contrib_out [N] (device, may alias a gathered buffer
+ * the host then all-gathers over RCCL), and adds the shard's sum |new-old| into *err_out (device f64). */
+typedef struct cz_pagerank_plan cz_pagerank_plan;
+int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree,
+                            uint32_t N, uint32_t row_begin, uint32_t row_end, float damping,
+                            cz_pagerank_plan **out);
+void cz_pagerank_plan_destroy(cz_pagerank_plan *p);
+/* contrib [N] device: init/out_degree for every node (graph::page_rank initial state); zeroes scores */
+int cz_pagerank_plan_init(cz_pagerank_plan *p, float *contrib_dev, void *stream);
+int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_in_dev, float *contrib_out_dev,
+                          double *err_out_dev, void *stream);
+/* device pointer to this shard's scores [row_end-row_begin] */
+float *cz_pagerank_plan_scores(cz_pagerank_plan *p);
+uint64_t cz_pagerank_plan_edges(const cz_pagerank_plan *p);
+/* copy this shard's scores [row_end-row_begin] to `out` (host, or device with CZ_DEVICE_PTRS) */
+int cz_pagerank_plan_read_scores(cz_pagerank_plan *p, float *out, uint32_t flags, void *stream);
+
+/* ShortestPathBFS::run (fixed_rule/algos/shortest_path_bfs.rs:35-113) and the traversal of Bfs::run
+ * (algos/bfs.rs:25-113) on the out-CSR (neighbours in sorted order = the KV prefix-scan order).
+ *   starts [n_starts]: one BFS per start.  goals [n_goals] or NULL (NULL: full traversal; with goals the
+ *   traversal stops after the level in which the last goal was discovered, as the reference does).
+ *   parent [n_starts][N] out: first discoverer of every reached node in FIFO order (CZ_NONE: not reached
+ *   / the start itself) -- exactly the reference's `backtrace` for every node on a goal path.
+ *   depth  [n_starts][N] (optional): BFS level, CZ_NONE if unreached.
+ *   order  [n_starts][N] (optional): nodes in the reference's discovery (FIFO push) order, start excluded;
+ *   n_reached [n_starts] (optional): how many entries of `order` are valid.
+ *   share_visited != 0: Bfs semantics, `visited` shared across starts (algos/bfs.rs:43): a start that was
+ *   already reached is skipped and later traversals do not re-enter earlier territory. */
+int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E, const uint32_t *starts,
+           uint32_t n_starts, const uint32_t *goals, uint32_t n_goals, int share_visited, uint32_t *parent,
+           uint32_t *depth, uint32_t *order, uint32_t *n_reached, const volatile uint8_t *poison);
+
+/* StronglyConnectedComponent{strong:false}::run = ConnectedComponents
+ * (algos/strongly_connected_components.rs:42-77): adjacency of the symmetrised graph
+ * (as_directed_graph(undirected = true)); group [N] out = dense rank of each component by its
+ * smallest node index, which is what Tarjan over ascending roots yields; n_groups out. */
+int cz_connected_components(const uint32_t *offsets, const uint32_t *targets, uint32_t N, uint64_t E, uint32_t *group,
+                            uint32_t *n_groups, const volatile uint8_t *poison);
+
+/* dijkstra (algos/shortest_path_dijkstra.rs:274-339) for n_starts sources on the weighted out-CSR
+ * (as_directed_weighted_graph, fixed_rule/mod.rs:208-328; f32 weights >= 0):
+ *   dist [n_starts][N] f32 (inf = unreachable), parent [n_starts][N] (a predecessor p with
+ *   dist[p] + w(p,v) == dist[v] in f32; CZ_NONE for the start / unreachable). */
+int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
+            const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,168 @@
+"""GPU parity: PageRank / BFS / ConnectedComponents / SSSP through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _graphs(oracle):
+    out = []
+    for n, e, seed in [(50, 120, 1), (2000, 12000, 2), (30000, 200000, 3)]:
+        frm, to = util.random_relation(n, e, seed)
+        out.append(util.graph_from_relation(oracle, frm, to))
+    # skewed: a few hubs with very long in-rows (exercises the long-row path of the SpMV kernel)
+    rng = np.random.default_rng(9)
+    n = 20000
+    src = rng.integers(0, n, 150000)
+    dst = np.where(rng.random(150000) < 0.3, rng.integers(0, 3, 150000), rng.integers(0, n, 150000))
+    keep = src != dst
+    rows = np.unique(np.stack([src[keep], dst[keep]], 1), axis=0)
+    out.append(util.graph_from_relation(oracle, rows[:, 0].astype(np.int64), rows[:, 1].astype(np.int64)))
+    return out
+
+
+@pytest.fixture(scope="module")
+def graphs(oracle, gpu_lib):
+    return _graphs(oracle)
+
+
+@pytest.mark.parametrize("damping,tol,iters", [(0.85, 1e-4, 10), (0.85, 0.0, 20), (0.5, 1e-6, 7)])
+def test_pagerank_bitexact(graphs, oracle, damping, tol, iters):
+    from cozo_amd import graph as G
+    for g in graphs:
+        s, it, err = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], damping, tol, iters)
+        os_, oit, oerr = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], damping, tol, iters)
+        assert it == oit
+        assert np.array_equal(s, os_), "scores must be bit-identical (same sequential f32 sums)"
+        assert err == pytest.approx(oerr, rel=1e-9)
+
+
+def test_pagerank_undirected_and_empty(oracle, gpu_lib):
+    from cozo_amd import graph as G
+    frm, to = util.random_relation(500, 2000, 5)
+    g = util.graph_from_relation(oracle, frm, to, undirected=True)
+    s, it, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"])
+    os_, oit, _ = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"])
+    assert it == oit and np.array_equal(s, os_)
+    s, it, err = G.pagerank(np.zeros(1, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32))
+    assert s.size == 0 and it == 0  # empty input -> empty output (pagerank.rs:43-45)
+
+
+def test_pagerank_sharded_plan_matches_single(graphs, oracle):
+    """two row shards stepped in lock-step through the plan API == the one-shot result (what the
+    multi-GPU path does with an all-gather in between)."""
+    import torch
+    from cozo_amd import graph as G
+    g = graphs[2]
+    n = g["n"]
+    ioff = g["ioff"].astype(np.int64)
+    cut = int(np.searchsorted(ioff, ioff[-1] // 2))
+    plans = []
+    for rb, re in [(0, cut), (cut, n)]:
+        lo = (ioff[rb:re + 1] - ioff[rb]).astype(np.uint32)
+        plans.append(G.PageRankPlan(lo, g["isrc"][ioff[rb]:ioff[re]], g["outdeg"], n, rb, re, 0.85))
+    dev = torch.device("cuda:0")
+    c0 = torch.empty(n, dtype=torch.float32, device=dev)
+    c1 = torch.empty_like(c0)
+    err = torch.zeros(1, dtype=torch.float64, device=dev)
+    for p in plans:
+        p.init(c0)
+    it = 0
+    while True:
+        err.zero_()
+        for p in plans:
+            p.step(c0, c1, err)
+        torch.cuda.synchronize()
+        c0, c1 = c1, c0
+        it += 1
+        if err.item() < 1e-4 or it == 10:
+            break
+    os_, oit, _ = oracle.pagerank(n, g["ioff"], g["isrc"], g["outdeg"])
+    assert it == oit
+    got = np.empty(n, dtype=np.float32)
+    for p, (rb, re) in zip(plans, [(0, cut), (cut, n)]):
+        got[rb:re] = p.read_scores()
+    assert np.array_equal(got, os_)
+
+
+def test_shortest_path_bfs_paths(graphs, oracle):
+    from cozo_amd import graph as G
+    for g in graphs[:3]:
+        n = g["n"]
+        rng = np.random.default_rng(n)
+        starts = rng.integers(0, n, 3).astype(np.uint32)
+        goals = rng.integers(0, n, 12).astype(np.uint32)
+        parent, _, _, _ = G.bfs(g["ooff"], g["otgt"], starts, goals=goals)
+        for si, s in enumerate(starts):
+            op = oracle.shortest_path_bfs(n, g["ooff"], g["otgt"], int(s), goals)
+            for t in goals:
+                assert oracle.path_from_parent(parent[si], int(s), int(t)) == oracle.path_from_parent(op, int(s), int(t))
+
+
+def test_bfs_order_and_shared_visited(graphs, oracle):
+    from cozo_amd import graph as G
+    g = graphs[1]
+    n = g["n"]
+    starts = np.array([5, 9, 5, 700], dtype=np.uint32)
+    parent, depth, order, reached = G.bfs(g["ooff"], g["otgt"], starts, share_visited=True, want_depth=True,
+                                          want_order=True)
+    visited = np.zeros(n, np.uint8)
+    opar = np.full(n, 0xFFFFFFFF, np.uint32)
+    for si, s in enumerate(starts):
+        before = opar.copy()
+        oorder, opar, visited = oracle.bfs_order(n, g["ooff"], g["otgt"], int(s), visited, opar)
+        assert reached[si] == len(oorder)
+        assert np.array_equal(order[si, :reached[si]], oorder)
+        new = opar != before
+        assert np.array_equal(parent[si][new], opar[new]) and (parent[si][~new] == 0xFFFFFFFF).all()
+    # independent traversals: full order from one start
+    parent, depth, order, reached = G.bfs(g["ooff"], g["otgt"], starts[:1], want_order=True, want_depth=True)
+    oorder, opar, _ = oracle.bfs_order(n, g["ooff"], g["otgt"], 5)
+    assert np.array_equal(order[0, :reached[0]], oorder) and np.array_equal(parent[0], opar)
+
+
+def test_connected_components_bitexact(oracle, gpu_lib):
+    from cozo_amd import graph as G
+    for n, e, seed in [(40, 25, 1), (3000, 2500, 2), (50000, 60000, 3)]:
+        frm, to = util.random_relation(n, e, seed)
+        g = util.graph_from_relation(oracle, frm, to, undirected=True)
+        grp, k = G.connected_components(g["ooff"], g["otgt"])
+        ogrp, ok = oracle.tarjan_groups(g["n"], g["ooff"], g["otgt"])
+        assert k == ok and np.array_equal(grp, ogrp)
+    # a long chain (deep recursion in the reference) + isolated pairs
+    n = 200000
+    frm = np.arange(0, n - 1, dtype=np.int64)
+    g = util.graph_from_relation(oracle, frm, frm + 1, undirected=True)
+    grp, k = G.connected_components(g["ooff"], g["otgt"])
+    assert k == 1 and (grp == 0).all()
+
+
+def test_sssp_costs_bitexact(oracle, gpu_lib):
+    from cozo_amd import graph as G
+    for n, e, seed in [(60, 200, 1), (5000, 30000, 2)]:
+        frm, to = util.random_relation(n, e, seed)
+        w = np.random.default_rng(seed).random(len(frm)).astype(np.float32)
+        w[::17] = 0.0  # zero-weight edges
+        g = util.graph_from_relation(oracle, frm, to, weights=w)
+        starts = np.array([0, 3, g["n"] - 1], dtype=np.uint32)
+        dist, parent = G.sssp(g["ooff"], g["otgt"], g["ow"], starts)
+        for si, s in enumerate(starts):
+            od, _ = oracle.dijkstra(g["n"], g["ooff"], g["otgt"], g["ow"], int(s))
+            assert np.array_equal(dist[si], od)  # f32 costs bit-identical (inf == inf)
+            # every parent pointer is tight and leads back to the start
+            off, tgt, ow = g["ooff"].astype(np.int64), g["otgt"], g["ow"]
+            for v in np.random.default_rng(si).integers(0, g["n"], 50):
+                if not np.isfinite(dist[si, v]) or v == s:
+                    assert parent[si, v] == 0xFFFFFFFF
+                    continue
+                cur, hops = int(v), 0
+                while cur != s:
+                    p = int(parent[si, cur])
+                    ws = ow[off[p]:off[p + 1]][tgt[off[p]:off[p + 1]] == cur]
+                    assert (np.float32(dist[si, p]) + ws == dist[si, cur]).any()
+                    cur, hops = p, hops + 1
+                    assert hops <= g["n"]
+    with pytest.raises(Exception):
+        G.sssp(np.array([0, 1, 1], np.uint32), np.array([1], np.uint32), np.array([-1.0], np.float32), [0])

@@ -1,0 +1,151 @@
+"""GPU parity: distances and HNSW k-NN search through the C ABI vs the CPU oracle (same seeded inputs).
+
+Bars: the traversal (ids, visit counts) must be bit-identical to the oracle when the oracle uses the
+kernels' summation tree (ORC_DOT_GPU); distances must be within 1e-5 relative of the reference's ndarray
+summation order (ORC_DOT_NDARRAY) -- the tolerance BASELINE.json's north_star states for f32 distances."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+METRICS = [("L2", 0), ("Cosine", 1), ("IP", 2)]
+
+
+@pytest.mark.parametrize("dim", [1, 2, 7, 8, 9, 33, 100, 128, 129, 768, 1000, 1536, 2052, 2500])
+@pytest.mark.parametrize("name,metric", METRICS)
+def test_distance_batch_matches_oracle(gpu_lib, oracle, dim, name, metric):
+    from cozo_amd.hnsw import distance_batch
+    rng = np.random.default_rng(dim * 7 + metric)
+    base = util.vectors(300, dim, 1 + dim, "normal")
+    q = util.vectors(17, dim, 2 + dim, "normal")
+    pairs = np.stack([rng.integers(0, 17, 2000), rng.integers(0, 300, 2000)], 1).astype(np.uint32)
+    got = distance_batch(name, base, q, pairs)
+    exact = oracle.distance_pairs(metric, base, q, pairs, oracle.DOT_GPU)
+    ref = oracle.distance_pairs(metric, base, q, pairs, oracle.DOT_NDARRAY)
+    assert np.array_equal(got, exact), "kernel summation tree differs from its CPU restatement"
+    scale = np.maximum(np.abs(ref), 1e-3 if metric else 1e-30)
+    assert np.max(np.abs(got - ref) / scale) <= RTOL
+
+
+def test_distance_known_answers(gpu_lib, oracle):
+    """hand-computable values mirroring runtime/tests.rs:691-697 (l2_dist / cos_dist / ip_dist)."""
+    from cozo_amd.hnsw import distance_batch
+    base = np.array([[2, 3], [1, 2], [0.6, 0.8]], dtype=np.float32)
+    q = np.array([[1, 2], [0.6, 0.8]], dtype=np.float32)
+    assert distance_batch("L2", base, q, np.array([[0, 0]], np.uint32))[0] == 2.0
+    assert distance_batch("Cosine", base, q, np.array([[0, 1]], np.uint32))[0] == pytest.approx(0.0, abs=1e-7)
+    assert distance_batch("IP", base, q, np.array([[1, 2]], np.uint32))[0] == pytest.approx(0.0, abs=1e-7)
+    zero = distance_batch("Cosine", np.zeros((1, 2), np.float32), q, np.array([[0, 0]], np.uint32))[0]
+    assert np.isnan(zero)  # zero vector under cosine -> NaN, as in the reference
+
+
+CASES = [
+    # n, dim, distance, metric, m, ef_c, kind
+    (3000, 128, "L2", 0, 16, 100, "uniform"),
+    (2000, 768, "Cosine", 1, 16, 64, "lowrank"),
+    (2500, 100, "IP", 2, 8, 50, "normal"),
+    (1500, 36, "L2", 0, 12, 40, "uniform"),
+    (1200, 1536, "Cosine", 1, 8, 40, "lowrank"),
+]
+
+
+@pytest.fixture(scope="module", params=CASES, ids=lambda c: f"n{c[0]}_d{c[1]}_{c[2]}")
+def case(request, oracle, gpu_lib):
+    n, dim, dist, metric, m, efc, kind = request.param
+    x = util.vectors(n, dim, 42, kind)
+    builder, flat = util.build_index(oracle, x, metric, m, efc)
+    gix = util.gpu_index(flat, dist, m)
+    q = util.vectors(64, dim, 43, kind)
+    yield dict(x=x, flat=flat, gix=gix, q=q, metric=metric, m=m, dist=dist)
+    gix.close()
+
+
+@pytest.mark.parametrize("ef,k", [(1, 1), (10, 10), (64, 10), (200, 50), (700, 10)])
+def test_knn_bitexact_with_gpu_order_oracle(case, oracle, ef, k):
+    from cozo_amd.hnsw import HnswSearch
+    ids, dist, cnt, nd = case["gix"].hnsw_knn_batch(case["q"], HnswSearch(k=k, ef=ef), with_n_dist=True)
+    oids, odist, ocnt, ond = case["flat"].knn_batch(case["q"], k, ef, dot_mode=oracle.DOT_GPU)
+    assert np.array_equal(cnt, ocnt)
+    assert np.array_equal(ids, oids)
+    for b in range(len(cnt)):
+        assert np.array_equal(dist[b, :cnt[b]], odist[b, :cnt[b]])
+    assert int(nd.sum()) == ond, "different number of distance evaluations: traversal differs"
+
+
+@pytest.mark.parametrize("ef,k", [(64, 10)])
+def test_knn_within_tolerance_of_reference_order(case, oracle, ef, k):
+    from cozo_amd.hnsw import HnswSearch
+    ids, dist, cnt = case["gix"].hnsw_knn_batch(case["q"], HnswSearch(k=k, ef=ef))
+    oids, odist, ocnt, _ = case["flat"].knn_batch(case["q"], k, ef, dot_mode=oracle.DOT_NDARRAY)
+    assert np.array_equal(cnt, ocnt)
+    same = (ids == oids).all(axis=1)
+    assert same.mean() >= 0.95  # near-ties may swap under a different f32 summation order
+    scale = np.maximum(np.abs(odist[same]), 1e-3)
+    assert np.max(np.abs(dist[same] - odist[same]) / scale) <= RTOL
+
+
+def test_knn_radius_and_filter_width(case, oracle):
+    from cozo_amd.hnsw import HnswSearch
+    ef, k = 50, 10
+    _, d0, _ = case["gix"].hnsw_knn_batch(case["q"], HnswSearch(k=k, ef=ef))
+    r = float(np.median(d0[:, 4]))
+    ids, dist, cnt = case["gix"].hnsw_knn_batch(case["q"], HnswSearch(k=k, ef=ef, radius=r))
+    oids, odist, ocnt, _ = case["flat"].knn_batch(case["q"], k, ef, radius=r, dot_mode=oracle.DOT_GPU)
+    assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids)
+    assert (cnt < k).any() and (cnt > 0).any()
+    for b in range(len(cnt)):
+        assert (dist[b, :cnt[b]] <= r).all() and (ids[b, cnt[b]:] == 0xFFFFFFFF).all()
+    # a filtered query keeps all ef candidates (hnsw.rs:943-947): k = ef rows come back
+    ids2, _, cnt2 = case["gix"].hnsw_knn_batch(case["q"], HnswSearch(k=k, ef=ef, has_filter=True))
+    oids2, _, ocnt2, _ = case["flat"].knn_batch(case["q"], ef, ef, dot_mode=oracle.DOT_GPU)
+    assert ids2.shape[1] == ef and np.array_equal(ids2, oids2) and np.array_equal(cnt2, ocnt2)
+
+
+def test_bruteforce_knn_matches_oracle(case, oracle):
+    ids, dist = case["gix"].bruteforce_knn(case["q"], 10)
+    oids, odist = oracle.bruteforce_knn(case["metric"], case["x"], case["q"], 10, dot_mode=oracle.DOT_GPU)
+    assert np.array_equal(ids, oids) and np.array_equal(dist, odist)
+
+
+def test_recall_sanity(case, oracle):
+    from cozo_amd.hnsw import HnswSearch
+    gt, _ = case["gix"].bruteforce_knn(case["q"], 10)
+    ids, _, _ = case["gix"].hnsw_knn_batch(case["q"], HnswSearch(k=10, ef=200))
+    rec = np.mean([len(set(ids[i]) & set(gt[i])) / 10 for i in range(len(gt))])
+    assert rec >= 0.8
+
+
+def test_edge_cases(gpu_lib, oracle):
+    from cozo_amd import _lib
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest, HnswSearch
+    man = HnswIndexManifest(vec_dim=8, distance="L2", m_neighbours=4)
+    # empty index -> no rows (hnsw.rs:903-909)
+    e = GpuHnswIndex(man, np.zeros((0, 8), np.float32), [], [], 0xFFFFFFFF)
+    ids, dist, cnt = e.hnsw_knn_batch(np.ones((3, 8), np.float32), HnswSearch(k=5, ef=10))
+    assert (cnt == 0).all() and (ids == 0xFFFFFFFF).all()
+    # single vector, k larger than the index
+    x = util.vectors(1, 8, 1)
+    _, flat = util.build_index(oracle, x, 0, 4, 10)
+    g = util.gpu_index(flat, "L2", 4)
+    ids, dist, cnt = g.hnsw_knn_batch(x, HnswSearch(k=5, ef=10))
+    assert cnt[0] == 1 and ids[0, 0] == 0 and dist[0, 0] == 0.0 and (ids[0, 1:] == 0xFFFFFFFF).all()
+    # dimension mismatch is an error (hnsw.rs:876-878)
+    with pytest.raises(ValueError):
+        g.hnsw_knn_batch(np.ones((1, 9), np.float32), HnswSearch(k=1, ef=1))
+    # ef beyond the LDS-resident list is refused loudly, not silently clamped
+    with pytest.raises(_lib.CozoGpuError):
+        g.hnsw_knn_batch(x, HnswSearch(k=1, ef=5000))
+    # duplicates + a zero vector under cosine (NaN distances sort last, never beat a finite distance)
+    y = util.vectors(200, 16, 5, "normal")
+    y[10] = y[3]
+    y[77] = 0.0
+    _, flat = util.build_index(oracle, y, 1, 6, 30)
+    gc = util.gpu_index(flat, "Cosine", 6)
+    ids, dist, cnt = gc.hnsw_knn_batch(y[:32], HnswSearch(k=8, ef=40))
+    oids, odist, ocnt, _ = flat.knn_batch(y[:32], 8, 40, dot_mode=oracle.DOT_GPU)
+    assert np.array_equal(cnt, ocnt)
+    assert np.array_equal(np.nan_to_num(dist, nan=-1.0), np.nan_to_num(odist, nan=-1.0))
+    assert np.array_equal(ids, oids)
