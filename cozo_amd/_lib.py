@@ -82,6 +82,45 @@ SYMBOLS = {
 }
 
 _lib = None
+_hip_runtime_path = None
+
+
+def _preload_hip_runtime() -> str:
+    """libcozo_gpu.so carries no NEEDED entry for the HIP runtime: a process must hold exactly ONE
+    libamdhip64 / libhsa-runtime64 pair, and PyTorch wheels bundle their own.  Bring one in (RTLD_GLOBAL)
+    before the library's static constructors register its code objects.
+    COZO_HIP_RUNTIME = auto (default: torch's bundled runtime if torch is installed, else /opt/rocm) |
+    torch | system | /path/to/libamdhip64.so"""
+    global _hip_runtime_path
+    if _hip_runtime_path:
+        return _hip_runtime_path
+    choice = os.environ.get("COZO_HIP_RUNTIME", "auto")
+    cands = []
+    if choice in ("auto", "torch"):
+        try:
+            import importlib.util
+            spec = importlib.util.find_spec("torch")
+            if spec and spec.origin:
+                cands.append(os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so"))
+        except Exception:
+            pass
+    if choice in ("auto", "system"):
+        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+        cands += [os.path.join(rocm, "lib", "libamdhip64.so.7"), os.path.join(rocm, "lib", "libamdhip64.so"),
+                  "libamdhip64.so.7", "libamdhip64.so"]
+    if choice not in ("auto", "torch", "system"):
+        cands = [choice]
+    errs = []
+    for c in cands:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            C.CDLL(c, mode=C.RTLD_GLOBAL)
+            _hip_runtime_path = c
+            return c
+        except OSError as e:  # pragma: no cover
+            errs.append(f"{c}: {e}")
+    raise OSError("no HIP runtime (libamdhip64) could be loaded: " + "; ".join(errs))
 
 
 def lib() -> C.CDLL:
@@ -91,6 +130,7 @@ def lib() -> C.CDLL:
         if not os.path.exists(SO_PATH):
             raise OSError(f"{SO_PATH} is missing: build it with `python -m cozo_amd.build` "
                           "(there is no CPU fallback for the cozo_amd product path)")
+        _preload_hip_runtime()
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol

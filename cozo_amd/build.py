@@ -53,7 +53,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     srcs = _sources()
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(_compile, srcs))
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", SO])
+    # Linked WITHOUT a NEEDED entry for libamdhip64: a process must hold exactly one HIP/HSA runtime, and
+    # PyTorch wheels bundle their own (torch/lib/libamdhip64.so).  The loader (cozo_amd/_lib.py, or the host
+    # binary that links -lamdhip64 itself) brings the runtime in first; see INTEGRATION.md.
+    subprocess.check_call([os.environ.get("CXX", "g++"), "-shared", "-fPIC", *objs, "-o", SO])
     if verbose:
         print("built", SO)
     return SO
