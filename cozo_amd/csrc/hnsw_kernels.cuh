@@ -169,13 +169,24 @@ struct Searcher {
         const bool full = cnt >= ef;
         const uint64_t bkey = cnt > 0 ? s.wkey[cnt - 1] : 0;
         // eligibility (hnsw.rs:575 `found_nn.len() < ef || neighbour_dist < furthest`, raw f64 compare)
+        // NaN corner (zero vector under Cosine): the reference inserts one neighbour at a time; once the list is
+        // full with a NaN as its maximum, `x < NaN` is false for ever and nothing else gets in.  Reproduce it: if
+        // this batch overflows a not-yet-full list and a NaN is among what fills it, only the first free slots
+        // (in neighbour order) are taken.
+        const int free_slots = ef - cnt;
+        bool nan_gate = false;
+        if (!full && cnt + n > ef) {  // uniform
+            const bool nan_here = (tid < free_slots && tid < n && s.nkey[tid] == ~0ull) || (tid == 0 && cnt > 0 && bkey == ~0ull);
+            nan_gate = __syncthreads_or(nan_here);
+        }
         uint64_t mykey = 0;
         uint32_t myid = CZ_NONE;
         bool elig = false;
         if (tid < n) {
             mykey = s.nkey[tid];
             myid = s.nid[tid];
-            elig = !full || (mykey < bkey && bkey != ~0ull);
+            if (full) elig = mykey < bkey && bkey != ~0ull;
+            else elig = nan_gate ? tid < free_slots : true;
         }
         int nelig = __syncthreads_count(elig);  // also orders the nkey/nid reads above before the rewrite below
         if (nelig == 0) return;

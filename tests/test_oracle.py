@@ -1,0 +1,196 @@
+"""CPU tests of the oracle itself: reference-pinned golden cases, hand-computable known answers and
+independent cross-checks (numpy f64 / scipy).  No GPU needed."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import util
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_distance_known_answers(oracle):
+    O = oracle
+    # mirrors runtime/tests.rs:691-697: l2_dist([1,2],[2,3]) = 2 ; cos_dist(v,v) = 0 ; ip_dist of unit vector = 0
+    assert O.distance(O.L2, [1, 2], [2, 3]) == 2.0
+    assert O.distance(O.COSINE, [1, 2], [1, 2]) == pytest.approx(0.0, abs=1e-7)
+    assert O.distance(O.IP, [0.6, 0.8], [0.6, 0.8]) == pytest.approx(0.0, abs=1e-7)
+    assert np.isnan(O.distance(O.COSINE, [0, 0], [1, 2]))
+
+
+@pytest.mark.parametrize("dim", [1, 2, 7, 8, 9, 15, 16, 17, 128, 768, 1536])
+def test_distance_vs_float64(oracle, dim):
+    O = oracle
+    rng = np.random.default_rng(dim)
+    a = rng.standard_normal(dim).astype(np.float32)
+    b = rng.standard_normal(dim).astype(np.float32)
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    exact = {O.L2: np.sum((a64 - b64) ** 2), O.IP: 1 - a64 @ b64,
+             O.COSINE: 1 - a64 @ b64 / np.sqrt((a64 @ a64) * (b64 @ b64))}
+    for metric, ref in exact.items():
+        for mode in (O.DOT_NDARRAY, O.DOT_GPU):
+            got = O.distance(metric, a, b, mode)
+            assert abs(got - ref) <= 2e-6 * max(1.0, abs(ref), float(np.sum(np.abs(a64 * b64))))
+
+
+def test_unrolled_dot_order(oracle):
+    """ndarray's unrolled_dot: 8 lanes, (p0+p4)+(p1+p5)+(p2+p6)+(p3+p7), then the tail -- checked against a
+    literal numpy float32 transcription."""
+    rng = np.random.default_rng(3)
+    for n in [0, 1, 7, 8, 9, 23, 64, 100, 771]:
+        a = rng.standard_normal(n).astype(np.float32)
+        b = rng.standard_normal(n).astype(np.float32)
+        p = np.zeros(8, np.float32)
+        i = 0
+        while n - i >= 8:
+            p = (p + a[i:i + 8] * b[i:i + 8]).astype(np.float32)
+            i += 8
+        s = np.float32(0)
+        for j in range(4):
+            s = np.float32(s + np.float32(p[j] + p[j + 4]))
+        for j in range(i, n):
+            s = np.float32(s + np.float32(a[j] * b[j]))
+        assert oracle.dot_ndarray(a, b) == float(s)
+
+
+def test_love_graph_golden(oracle):
+    """the `love` graph of algos/shortest_path_bfs.rs:124-174: alice->bob has length 3, alice->george is Null."""
+    O = oracle
+    g = json.load(open(os.path.join(GOLD, "love_graph.json")))
+    names = sorted({x for e in g["edges"] for x in e})
+    key = {nm: i for i, nm in enumerate(names)}  # memcmp order of strings = lexicographic
+    rows = sorted((key[a], key[b]) for a, b in g["edges"])
+    fi, ti, ind = O.assign_ids([r[0] for r in rows], [r[1] for r in rows])
+    inv = {int(k): i for i, k in enumerate(ind)}
+    off, tgt = O.build_csr(len(ind), fi, ti)
+    for case in g["expect"]:
+        s, t = inv[key[case["from"]]], inv.get(key[case["to"]], None)
+        parent = O.shortest_path_bfs(len(ind), off, tgt, s, [t] if t is not None else [])
+        path = O.path_from_parent(parent, s, t) if t is not None else None
+        if case["len"] is None:
+            assert path is None
+        else:
+            assert len(path) == case["len"]
+            assert [names[int(ind[p])] for p in path][0] == case["from"]
+
+
+def test_csr_layout_sorted_with_duplicates(oracle):
+    O = oracle
+    src = np.array([2, 0, 0, 1, 0], np.uint32)
+    dst = np.array([1, 2, 1, 0, 1], np.uint32)  # duplicate 0->1 kept (CsrLayout::Sorted, not Deduplicated)
+    off, tgt = O.build_csr(3, src, dst)
+    assert off.tolist() == [0, 3, 4, 5] and tgt.tolist() == [1, 1, 2, 0, 1]
+    off, tgt = O.build_csr(3, src, dst, undirected=True)
+    assert off.tolist() == [0, 4, 8, 10] and tgt.tolist() == [1, 1, 1, 2, 0, 0, 0, 2, 0, 1]
+
+
+def test_first_appearance_ids(oracle):
+    fi, ti, ind = oracle.assign_ids([10, 10, 20, 5], [20, 5, 5, 10])
+    assert ind.tolist() == [10, 20, 5] and fi.tolist() == [0, 0, 1, 2] and ti.tolist() == [1, 2, 2, 0]
+
+
+def test_pagerank_vs_float64_power_iteration(oracle):
+    import scipy.sparse as sp
+    O = oracle
+    frm, to = util.random_relation(3000, 20000, 11)
+    g = util.graph_from_relation(O, frm, to)
+    n = g["n"]
+    s, it, err = O.pagerank(n, g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 15)
+    s8, it8, _ = O.pagerank(n, g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 15, threads=4)
+    assert it == it8 == 15 and np.array_equal(s, s8)
+    a = sp.csr_matrix((np.ones(len(g["fi"])), (g["ti"], g["fi"])), shape=(n, n))
+    x = np.full(n, 1.0 / n)
+    od = g["outdeg"].astype(np.float64)
+    for _ in range(15):
+        c = np.where(od > 0, x / np.where(od > 0, od, 1), 0)
+        x = (1 - 0.85) / n + 0.85 * (a @ c)
+    assert np.max(np.abs(s - x) / x) < 5e-6
+    # no dangling-mass redistribution: with sinks the scores do not sum to one
+    assert (g["outdeg"] == 0).any() and s.sum() < 1.0
+
+
+def test_tarjan_groups_vs_scipy(oracle):
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as cg
+    O = oracle
+    frm, to = util.random_relation(4000, 3500, 4)
+    g = util.graph_from_relation(O, frm, to, undirected=True)
+    n = g["n"]
+    grp, k = O.tarjan_groups(n, g["ooff"], g["otgt"])
+    ncomp, lab = cg.connected_components(sp.csr_matrix((np.ones(len(g["fi"])), (g["fi"], g["ti"])), shape=(n, n)),
+                                         directed=False)
+    first = np.full(ncomp, n)
+    np.minimum.at(first, lab, np.arange(n))
+    assert k == ncomp and np.array_equal(grp, np.argsort(np.argsort(first))[lab])
+    gd = util.graph_from_relation(O, frm, to)
+    _, kd = O.tarjan_groups(gd["n"], gd["ooff"], gd["otgt"])
+    nscc, _ = cg.connected_components(sp.csr_matrix((np.ones(len(gd["fi"])), (gd["fi"], gd["ti"])),
+                                                    shape=(gd["n"], gd["n"])), directed=True, connection="strong")
+    assert kd == nscc
+    # a 300k-node chain must not overflow (the reference recurses; the oracle uses an explicit stack)
+    c = np.arange(0, 299999, dtype=np.int64)
+    gc = util.graph_from_relation(O, c, c + 1, undirected=True)
+    assert O.tarjan_groups(gc["n"], gc["ooff"], gc["otgt"])[1] == 1
+
+
+def test_bfs_and_dijkstra_vs_scipy(oracle):
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as cg
+    O = oracle
+    frm, to = util.random_relation(1500, 6000, 8)
+    w = np.random.default_rng(8).random(len(frm)).astype(np.float32)
+    g = util.graph_from_relation(O, frm, to, weights=w)
+    n = g["n"]
+    rows = np.repeat(np.arange(n), np.diff(g["ooff"]).astype(int))
+    m = sp.csr_matrix((g["ow"].astype(np.float64), (rows, g["otgt"])), shape=(n, n))
+    hops = cg.shortest_path(m, unweighted=True, indices=0)
+    parent = O.shortest_path_bfs(n, g["ooff"], g["otgt"], 0, np.arange(n))
+    for t in range(1, n):
+        p = O.path_from_parent(parent, 0, t)
+        assert (p is None) == np.isinf(hops[t]) and (p is None or len(p) - 1 == hops[t])
+    assert O.path_from_parent(parent, 0, 0) is None  # start == end yields Null in the reference
+    dist, par = O.dijkstra(n, g["ooff"], g["otgt"], g["ow"], 0)
+    dd = cg.dijkstra(m, indices=0)
+    fin = np.isfinite(dd)
+    assert np.array_equal(np.isfinite(dist), fin)
+    assert np.max(np.abs(dist[fin] - dd[fin]) / np.maximum(dd[fin], 1e-9)) < 1e-5
+
+
+def test_hnsw_build_invariants_and_recall(oracle):
+    O = oracle
+    x = util.vectors(3000, 32, 1, "lowrank")
+    b, flat = util.build_index(O, x, O.L2, 8, 60)
+    assert flat.n_levels >= 2 and flat.level_size[0] == 3000
+    # level populations shrink geometrically; every upper-level node exists below
+    for lv in range(1, flat.n_levels):
+        assert flat.level_size[lv] < flat.level_size[lv - 1]
+        assert np.isin(flat.level_nodes[lv], flat.level_nodes[lv - 1]).all()
+    assert flat.entry in flat.level_nodes[-1]
+    # live degrees respect m_max0 / m_max, rows ascending, no self links
+    for lv in range(flat.n_levels):
+        tab = flat.level_nbrs[lv].astype(np.int64)
+        assert tab.shape[1] == (16 if lv == 0 else 8)
+        tab[tab == O.NONE] = 2 ** 40
+        assert (np.diff(tab, axis=1) >= 0).all()
+        assert not (tab == flat.level_nodes[lv][:, None]).any()
+    q = util.vectors(100, 32, 2, "lowrank")
+    gt, _ = O.bruteforce_knn(O.L2, x, q, 10)
+    ids, dist, cnt, nd = flat.knn_batch(q, 10, 100)
+    rec = np.mean([len(set(ids[i]) & set(gt[i])) / 10 for i in range(100)])
+    assert rec > 0.9 and (cnt == 10).all() and (np.diff(dist, axis=1) >= 0).all()
+    # both summation orders walk the same graph: near-identical results
+    ids2, dist2, _, _ = flat.knn_batch(q, 10, 100, dot_mode=O.DOT_GPU)
+    assert (ids == ids2).mean() > 0.98
+
+
+def test_hnsw_radius_empty_and_filter_width(oracle):
+    O = oracle
+    x = util.vectors(500, 16, 3)
+    _, flat = util.build_index(O, x, O.L2, 6, 30)
+    ids, dist, cnt, _ = flat.knn_batch(x[:5], 5, 20, radius=0.0)
+    assert (cnt == 1).all() and (ids[:, 0] == np.arange(5)).all() and (dist[:, 0] == 0).all()
+    empty = O.FlatIndex(np.zeros((0, 16), np.float32), O.L2, [], [], O.NONE)
+    ids, dist, cnt, _ = empty.knn_batch(x[:3], 5, 20)
+    assert (cnt == 0).all()
