@@ -1,0 +1,529 @@
+// hnsw_build.hip -- HNSW index construction on gfx950 (C ABI: cz_hnsw_build, cz_hnsw_index_export_*).
+//
+// Restates hnsw_put_vector / hnsw_select_neighbours_heuristic / hnsw_shrink_neighbour
+// (cozo-core/src/runtime/hnsw.rs:155-538) as a batch-parallel insert:
+//   K1 insert  : one workgroup per new vector: greedy descent (ef = 1) to its level, then per level
+//                hnsw_search_level(ef_construction) + the select-neighbours heuristic (m_max0 on level 0, m_max above,
+//                hnsw.rs:243-267); writes the vector's own link row and queues one reverse-link request per neighbour.
+//   K2 link    : appends the reverse links (:300-318) with an atomic slot counter per row; a row that grows past its
+//                width is queued for shrinking (:338-350).
+//   K3 shrink  : one workgroup per over-full row: re-select among its live links with the same heuristic, using the
+//                stored link distances (:389-393); dropped links disappear from this row only (one-directional,
+//                :434-466 -- the reference soft-deletes them, which is invisible to every reader on this path).
+// Vectors of one batch do not see each other (they are linked after the batch's searches), which is the only
+// difference from the reference's one-at-a-time insertion: with max_batch = 1 the link tables are identical to the
+// sequential algorithm's.  Levels are drawn by the caller (hnsw.rs:46-52 uses an unseedable thread_rng).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <random>
+#include <vector>
+
+#include "common.h"
+#include "hnsw_index.h"
+#include "hnsw_kernels.cuh"
+
+using namespace czd;
+using czh::IndexDev;
+using czh::kIdMask;
+using czh::kThreads;
+
+namespace {
+
+struct BuildTables {
+    uint32_t *nbr0;
+    double *dst0;
+    uint32_t *deg0;
+    int w0, cap0;
+    const uint32_t *up_base;
+    uint32_t *nbrU;
+    double *dstU;
+    uint32_t *degU;
+    int wu, capU;
+    const int32_t *level;
+};
+struct Req {
+    uint32_t *t, *q;
+    int32_t *lv;
+    double *d;
+};
+struct RowRef {
+    uint32_t *ids;
+    double *dst;
+    uint32_t *deg;
+    int width, cap;
+};
+__device__ __forceinline__ RowRef row_of(const BuildTables &T, uint32_t node, int lv) {
+    RowRef r;
+    if (lv == 0) {
+        r.ids = T.nbr0 + (size_t)node * T.cap0;
+        r.dst = T.dst0 + (size_t)node * T.cap0;
+        r.deg = T.deg0 + node;
+        r.width = T.w0;
+        r.cap = T.cap0;
+    } else {
+        const size_t row = (size_t)T.up_base[node] + (lv - 1);
+        r.ids = T.nbrU + row * T.capU;
+        r.dst = T.dstU + row * T.capU;
+        r.deg = T.degU + row;
+        r.width = T.wu;
+        r.cap = T.capU;
+    }
+    return r;
+}
+
+// K1
+template <int LPV, int ITERS, int U>
+__global__ void __launch_bounds__(kThreads)
+build_insert_kernel(IndexDev ix, BuildTables T, uint32_t b0, uint32_t bn, int top, uint32_t entry, int ef_c,
+                    uint32_t efcap, uint32_t wcap, int keep_pruned, uint32_t *__restrict__ visited, uint32_t words, Req req,
+                    uint32_t *__restrict__ req_count, uint32_t req_cap, unsigned long long *__restrict__ ndist_total) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    czh::Smem s = czh::carve(smem_raw, efcap, wcap, ix.ld);
+    czh::Searcher<LPV, ITERS, U> S(ix, s, visited + (size_t)blockIdx.x * words, words);
+    const int tid = threadIdx.x;
+    for (uint32_t qi = blockIdx.x; qi < bn; qi += gridDim.x) {
+        const uint32_t q = b0 + qi;
+        S.load_query(ix.vec + (size_t)q * ix.ld);
+        S.seed(entry);  // hnsw.rs:200-204
+        const int lq = T.level[q];
+        for (int lv = top; lv > lq; lv--) {  // :219-229
+            S.search_level(lv, 1, true);
+            S.clear_visited();
+        }
+        for (int lv = min(lq, top); lv >= 0; lv--) {  // :242-359
+            S.search_level(lv, ef_c, true);
+            const RowRef r = row_of(T, q, lv);
+            const int nsel = S.select_heuristic(r.width, keep_pruned != 0);
+            if (tid == 0) s.ctl[czh::C_KEEP] = (int)atomicAdd(req_count, (uint32_t)nsel);
+            __syncthreads();
+            const uint32_t base = (uint32_t)s.ctl[czh::C_KEEP];
+            for (int k = tid; k < r.cap; k += kThreads) {
+                if (k < nsel) {
+                    const uint32_t p = s.sel[k];
+                    const uint32_t id = s.wid[p] & kIdMask;
+                    const double d = key_dist(s.wkey[p]);
+                    r.ids[k] = id;
+                    r.dst[k] = d;
+                    if (base + k < req_cap) {  // the host checks the final count against req_cap
+                        req.t[base + k] = id;
+                        req.q[base + k] = q;
+                        req.lv[base + k] = lv;
+                        req.d[base + k] = d;
+                    }
+                } else {
+                    r.ids[k] = CZ_NONE;
+                }
+            }
+            if (tid == 0) *r.deg = (uint32_t)nsel;  // the self-loop row's degree, :269-277
+            S.clear_visited();
+        }
+        if (tid == 0) {
+            const unsigned long long nd = ((unsigned long long)(unsigned int)s.ctl[czh::C_NDIST_HI] << 32) |
+                                          (unsigned long long)(unsigned int)s.ctl[czh::C_NDIST_LO];
+            atomicAdd(ndist_total, nd);
+        }
+        __syncthreads();
+    }
+}
+
+// K2
+__global__ void __launch_bounds__(256)
+build_link_kernel(BuildTables T, Req in, uint32_t n, Req retry, uint32_t *__restrict__ retry_count,
+                  uint32_t *__restrict__ shrink_t, int32_t *__restrict__ shrink_lv, uint32_t *__restrict__ shrink_count) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t t = in.t[i], q = in.q[i];
+        const int lv = in.lv[i];
+        const double d = in.d[i];
+        const RowRef r = row_of(T, t, lv);
+        const uint32_t slot = atomicAdd(r.deg, 1u);
+        if (slot < (uint32_t)r.cap) {
+            r.ids[slot] = q;
+            r.dst[slot] = d;
+            if (slot == (uint32_t)r.width) {  // degree just exceeded the row width: shrink (:339)
+                const uint32_t p = atomicAdd(shrink_count, 1u);
+                shrink_t[p] = t;
+                shrink_lv[p] = lv;
+            }
+        } else {  // no room until the row has been shrunk: try again afterwards
+            atomicSub(r.deg, 1u);
+            const uint32_t p = atomicAdd(retry_count, 1u);
+            retry.t[p] = t;
+            retry.q[p] = q;
+            retry.lv[p] = lv;
+            retry.d[p] = d;
+        }
+    }
+}
+
+// K3
+template <int LPV, int ITERS, int U>
+__global__ void __launch_bounds__(kThreads)
+build_shrink_kernel(IndexDev ix, BuildTables T, const uint32_t *__restrict__ shrink_t, const int32_t *__restrict__ shrink_lv,
+                    uint32_t n, uint32_t efcap, uint32_t wcap, int keep_pruned, unsigned long long *__restrict__ ndist_total) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    czh::Smem s = czh::carve(smem_raw, efcap, wcap, ix.ld);
+    czh::Searcher<LPV, ITERS, U> S(ix, s, nullptr, 0);
+    const int tid = threadIdx.x;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t t = shrink_t[i];
+        const int lv = shrink_lv[i];
+        const RowRef r = row_of(T, t, lv);
+        S.load_query(ix.vec + (size_t)t * ix.ld);  // hnsw.rs:386-387
+        const int c = (int)min(*r.deg, (uint32_t)r.cap);
+        // candidates = live links with their stored distances (:389-393), sorted by (distance, id)
+        uint64_t mk = 0;
+        uint32_t mi = CZ_NONE;
+        if (tid < c) {
+            mk = dist_key(r.dst[tid]);
+            mi = r.ids[tid];
+            s.nkey[tid] = mk;
+            s.nid[tid] = mi;
+        }
+        __syncthreads();
+        if (tid < c) {
+            int rank = 0;
+            for (int j = 0; j < c; j++) rank += czh::key_lt(s.nkey[j], s.nid[j], mk, mi);
+            s.wkey[rank] = mk;
+            s.wid[rank] = mi;
+        }
+        if (tid == 0) s.ctl[czh::C_CNT] = c;
+        __syncthreads();
+        const int nsel = S.select_heuristic(r.width, keep_pruned != 0);
+        for (int k = tid; k < r.cap; k += kThreads) {
+            if (k < nsel) {
+                const uint32_t p = s.sel[k];
+                r.ids[k] = s.wid[p] & kIdMask;
+                r.dst[k] = key_dist(s.wkey[p]);
+            } else {
+                r.ids[k] = CZ_NONE;
+            }
+        }
+        if (tid == 0) {
+            *r.deg = (uint32_t)nsel;  // :352,412
+            const unsigned long long nd = ((unsigned long long)(unsigned int)s.ctl[czh::C_NDIST_HI] << 32) |
+                                          (unsigned long long)(unsigned int)s.ctl[czh::C_NDIST_LO];
+            atomicAdd(ndist_total, nd);
+        }
+        __syncthreads();
+    }
+}
+
+// final layout: rows sorted ascending by id, packed to the row width (one wave per row)
+__global__ void __launch_bounds__(256)
+build_pack_kernel(const uint32_t *__restrict__ src, int cap, uint32_t *__restrict__ dst, int width, uint64_t rows) {
+    __shared__ uint32_t buf[4][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + wave; r < rows; r += (uint64_t)gridDim.x * 4) {
+        const uint32_t *in = src + r * cap;
+        for (int j = lane; j < cap; j += 64) buf[wave][j] = in[j];
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < cap; j += 64) {
+            const uint32_t v = buf[wave][j];
+            int rank = 0;
+            for (int i = 0; i < cap; i++) {
+                const uint32_t o = buf[wave][i];
+                rank += (o < v) || (o == v && i < j);
+            }
+            if (rank < width) dst[r * width + rank] = v;  // CZ_NONE sorts last
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+#define CZ_DISPATCH_BUILD_SHAPE(SH, CALL)                                      \
+    do {                                                                       \
+        if ((SH).lpv == 16) { CALL(16, 1, 4); }                                \
+        else if ((SH).lpv == 32) { CALL(32, 1, 4); }                           \
+        else switch ((SH).iters) {                                             \
+            case 1: CALL(64, 1, 4); break;                                     \
+            case 2: CALL(64, 2, 4); break;                                     \
+            case 3: CALL(64, 3, 2); break;                                     \
+            case 4: CALL(64, 4, 2); break;                                     \
+            case 5: CALL(64, 5, 1); break;                                     \
+            case 6: CALL(64, 6, 1); break;                                     \
+            case 7: CALL(64, 7, 1); break;                                     \
+            default: CALL(64, 8, 1); break;                                    \
+        }                                                                      \
+    } while (0)
+
+struct ReqBuf {
+    cz::DevBuf<uint32_t> t, q;
+    cz::DevBuf<int32_t> lv;
+    cz::DevBuf<double> d;
+    hipError_t alloc(size_t n) {
+        hipError_t e;
+        if ((e = t.alloc(n)) != hipSuccess) return e;
+        if ((e = q.alloc(n)) != hipSuccess) return e;
+        if ((e = lv.alloc(n)) != hipSuccess) return e;
+        return d.alloc(n);
+    }
+    Req ref() { return Req{t.p, q.p, lv.p, d.p}; }
+};
+
+}  // namespace
+
+extern "C" int cz_hnsw_build(const float *vectors, uint32_t n, uint32_t dim, int metric, uint32_t m,
+                             uint32_t ef_construction, int keep_pruned_connections, const int32_t *levels, uint64_t seed,
+                             uint32_t max_batch, uint64_t *n_dist_out, cz_hnsw_index **out, uint32_t flags,
+                             void *stream_) {
+    if (!out) return cz::set_error(CZ_E_INVALID, "null out");
+    *out = nullptr;
+    if (n_dist_out) *n_dist_out = 0;
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (dim == 0) return cz::set_error(CZ_E_INVALID, "dim must be > 0");
+    if (metric < CZ_L2 || metric > CZ_IP) return cz::set_error(CZ_E_INVALID, "bad metric %d", metric);
+    if (m < 2) return cz::set_error(CZ_E_INVALID, "m must be >= 2");  // level_multiplier = 1/ln(m)
+    if (2 * m > 192) return cz::set_error(CZ_E_UNSUPPORTED, "m = %u: m_max0 = 2m must be <= 192 for the GPU build", m);
+    if (ef_construction == 0 || ef_construction > 1024)
+        return cz::set_error(CZ_E_UNSUPPORTED, "ef_construction must be in 1..1024");
+    if (n >= 0x7FFFFFFFu) return cz::set_error(CZ_E_UNSUPPORTED, "node ids must be < 2^31");
+    if (n > 0 && !vectors) return cz::set_error(CZ_E_INVALID, "vectors is null");
+    Shape sh = shape_of(dim);
+    if (sh.lpv == 64 && sh.iters > 8) return cz::set_error(CZ_E_UNSUPPORTED, "GPU index construction supports dim <= 2048");
+    if (max_batch == 0) max_batch = 4096;
+
+    std::unique_ptr<cz::HnswIndex> ix(new cz::HnswIndex());
+    ix->n = n;
+    ix->dim = dim;
+    ix->ld = (dim + 3) & ~3u;
+    ix->metric = metric;
+    ix->w0 = (int)(2 * m);
+    ix->wu = (int)m;
+    CZ_HIP(hipMalloc((void **)&ix->vec, std::max<size_t>(16, (size_t)n * ix->ld * 4)));
+    if (n == 0) {
+        ix->n_levels = 0;
+        *out = reinterpret_cast<cz_hnsw_index *>(ix.release());
+        return CZ_OK;
+    }
+    if (flags & CZ_DEVICE_PTRS) {
+        if (ix->ld == dim) CZ_HIP(hipMemcpyAsync(ix->vec, vectors, (size_t)n * dim * 4, hipMemcpyDeviceToDevice, stream));
+        else {
+            CZ_HIP(hipMemsetAsync(ix->vec, 0, (size_t)n * ix->ld * 4, stream));
+            CZ_HIP(hipMemcpy2DAsync(ix->vec, (size_t)ix->ld * 4, vectors, (size_t)dim * 4, (size_t)dim * 4, n,
+                                    hipMemcpyDeviceToDevice, stream));
+        }
+    } else {
+        if (ix->ld != dim) CZ_HIP(hipMemset(ix->vec, 0, (size_t)n * ix->ld * 4));
+        CZ_HIP(hipMemcpy2D(ix->vec, (size_t)ix->ld * 4, vectors, (size_t)dim * 4, (size_t)dim * 4, n, hipMemcpyHostToDevice));
+    }
+    // levels: caller-supplied (non-negative = -layer) or drawn here: floor(-ln(U) / ln(m)), hnsw.rs:46-52
+    ix->top.resize(n);
+    if (levels) {
+        for (uint32_t i = 0; i < n; i++) {
+            if (levels[i] < 0 || levels[i] > 60) return cz::set_error(CZ_E_INVALID, "levels[%u] = %d out of range", i, levels[i]);
+            ix->top[i] = levels[i];
+        }
+    } else {
+        std::mt19937_64 rng(seed);
+        std::uniform_real_distribution<double> uni(0.0, 1.0);
+        const double mult = 1.0 / std::log((double)m);
+        for (uint32_t i = 0; i < n; i++) {
+            double u = uni(rng);
+            if (u <= 0.0) u = 1e-300;
+            ix->top[i] = (int32_t)std::min(60.0, std::floor(-std::log(u) * mult));
+        }
+    }
+    std::vector<uint32_t> base(n, CZ_NONE);
+    uint64_t rows = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (ix->top[i] > 0) {
+            base[i] = (uint32_t)rows;
+            rows += (uint32_t)ix->top[i];
+        }
+    if (rows >= 0xFFFFFFFFull) return cz::set_error(CZ_E_UNSUPPORTED, "too many upper-level rows");
+    ix->up_rows = rows;
+    const int slack = 32;
+    const int cap0 = ix->w0 + slack, capU = ix->wu + slack;
+    cz::DevBuf<uint32_t> b_nbr0, b_deg0, b_nbrU, b_degU, b_shrink_t, b_misc, b_visited;
+    cz::DevBuf<double> b_dst0, b_dstU;
+    cz::DevBuf<int32_t> b_level, b_shrink_lv;
+    cz::DevBuf<unsigned long long> b_ndist;
+    CZ_HIP(b_nbr0.alloc((size_t)n * cap0));
+    CZ_HIP(b_dst0.alloc((size_t)n * cap0));
+    CZ_HIP(b_deg0.alloc(n));
+    CZ_HIP(b_nbrU.alloc(std::max<size_t>(1, rows) * capU));
+    CZ_HIP(b_dstU.alloc(std::max<size_t>(1, rows) * capU));
+    CZ_HIP(b_degU.alloc(std::max<size_t>(1, rows)));
+    CZ_HIP(b_level.alloc(n));
+    CZ_HIP(b_misc.alloc(8));
+    CZ_HIP(b_ndist.alloc(1));
+    CZ_HIP(hipMalloc((void **)&ix->up_base, (size_t)n * 4));
+    CZ_HIP(hipMemcpyAsync(ix->up_base, base.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    CZ_HIP(hipMemcpyAsync(b_level.p, ix->top.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    CZ_HIP(hipMemsetAsync(b_nbr0.p, 0xFF, (size_t)n * cap0 * 4, stream));
+    CZ_HIP(hipMemsetAsync(b_nbrU.p, 0xFF, std::max<size_t>(1, rows) * capU * 4, stream));
+    CZ_HIP(hipMemsetAsync(b_deg0.p, 0, (size_t)n * 4, stream));
+    CZ_HIP(hipMemsetAsync(b_degU.p, 0, std::max<size_t>(1, rows) * 4, stream));
+    CZ_HIP(hipMemsetAsync(b_ndist.p, 0, 8, stream));
+    const uint32_t words = (n + 31) / 32;
+    const int slots = 1024;
+    CZ_HIP(b_visited.alloc((size_t)slots * words));
+    CZ_HIP(hipMemsetAsync(b_visited.p, 0, (size_t)slots * words * 4, stream));
+    const size_t max_req = (size_t)max_batch * (size_t)(ix->w0 + 8 * ix->wu) + 1024;
+    ReqBuf reqA, reqB;
+    CZ_HIP(reqA.alloc(max_req));
+    CZ_HIP(reqB.alloc(max_req));
+    CZ_HIP(b_shrink_t.alloc(max_req));
+    CZ_HIP(b_shrink_lv.alloc(max_req));
+
+    BuildTables T{b_nbr0.p, b_dst0.p, b_deg0.p, ix->w0, cap0, ix->up_base, b_nbrU.p, b_dstU.p, b_degU.p, ix->wu, capU,
+                  b_level.p};
+    IndexDev dev = ix->dev();
+    dev.nbr0 = b_nbr0.p;
+    dev.w0 = cap0;  // rows are scanned at their build stride; unused slots hold CZ_NONE
+    dev.up_nbrs = b_nbrU.p;
+    dev.wu = capU;
+    const uint32_t efcap = (std::max<uint32_t>(ef_construction, (uint32_t)std::max(cap0, capU)) + 63) & ~63u;
+    const uint32_t wcap = std::max<uint32_t>(efcap, (uint32_t)((std::max(cap0, capU) + 63) & ~63));
+    const size_t smem = czh::smem_bytes(efcap, wcap, ix->ld);
+    if (smem > 160 * 1024) return cz::set_error(CZ_E_UNSUPPORTED, "dim/ef_construction need %zu bytes of LDS", smem);
+
+    int top = ix->top[0];
+    uint32_t entry = 0;
+    uint32_t i = 1;
+    while (i < n) {
+        // a vector that raises the top level is inserted alone and becomes the entry point (hnsw.rs:206-218)
+        uint32_t bn = 1;
+        if (ix->top[i] <= top) {
+            const uint32_t want = std::min<uint32_t>(max_batch, std::max<uint32_t>(1, i / 4));
+            while (bn < want && i + bn < n && ix->top[i + bn] <= top) bn++;
+        }
+        CZ_HIP(hipMemsetAsync(b_misc.p, 0, 32, stream));
+        const uint32_t grid = std::min<uint32_t>(bn, (uint32_t)slots);
+#define CZ_LAUNCH_INSERT(LPV, ITERS, U)                                                                                  \
+    do {                                                                                                                 \
+        auto kern = build_insert_kernel<LPV, ITERS, U>;                                                                  \
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                                        (int)smem);                                                     \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), smem, stream, dev, T, i, bn, top, entry,                     \
+                           (int)ef_construction, efcap, wcap, keep_pruned_connections, b_visited.p, words, reqA.ref(),    \
+                           b_misc.p + 0, (uint32_t)max_req, b_ndist.p);                                                                     \
+    } while (0)
+        CZ_DISPATCH_BUILD_SHAPE(sh, CZ_LAUNCH_INSERT);
+#undef CZ_LAUNCH_INSERT
+        uint32_t h[8];
+        CZ_HIP(hipMemcpyAsync(h, b_misc.p, 32, hipMemcpyDeviceToHost, stream));
+        CZ_HIP(hipStreamSynchronize(stream));
+        uint32_t nreq = h[0];
+        if (nreq > max_req) return cz::set_error(CZ_E_HIP, "internal: request buffer overflow (%u > %zu)", nreq, max_req);
+        ReqBuf *cur = &reqA, *nxt = &reqB;
+        int rounds = 0;
+        while (nreq > 0) {
+            CZ_HIP(hipMemsetAsync(b_misc.p + 1, 0, 8, stream));  // [1] retry count, [2] shrink count
+            hipLaunchKernelGGL(build_link_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>((nreq + 255) / 256, 4096))),
+                               dim3(256), 0, stream, T, cur->ref(), nreq, nxt->ref(), b_misc.p + 1, b_shrink_t.p,
+                               b_shrink_lv.p, b_misc.p + 2);
+            CZ_HIP(hipMemcpyAsync(h, b_misc.p, 32, hipMemcpyDeviceToHost, stream));
+            CZ_HIP(hipStreamSynchronize(stream));
+            const uint32_t nretry = h[1], nshrink = h[2];
+            if (nshrink > 0) {
+                const uint32_t g3 = std::min<uint32_t>(nshrink, (uint32_t)slots);
+#define CZ_LAUNCH_SHRINK(LPV, ITERS, U)                                                                                  \
+    do {                                                                                                                 \
+        auto kern = build_shrink_kernel<LPV, ITERS, U>;                                                                  \
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                                        (int)smem);                                                     \
+        hipLaunchKernelGGL(kern, dim3(g3), dim3(kThreads), smem, stream, dev, T, b_shrink_t.p, b_shrink_lv.p, nshrink,    \
+                           efcap, wcap, keep_pruned_connections, b_ndist.p);                                             \
+    } while (0)
+                CZ_DISPATCH_BUILD_SHAPE(sh, CZ_LAUNCH_SHRINK);
+#undef CZ_LAUNCH_SHRINK
+            }
+            std::swap(cur, nxt);
+            if (nretry >= nreq && nshrink == 0)
+                return cz::set_error(CZ_E_HIP, "internal: reverse-link requests made no progress");
+            nreq = nretry;
+            if (++rounds > 64) return cz::set_error(CZ_E_HIP, "internal: reverse-link retry did not converge");
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "hnsw build launch: %s", hipGetErrorString(e));
+        if (ix->top[i] > top) {
+            top = ix->top[i];
+            entry = i;
+        }
+        i += bn;
+    }
+    // final layout
+    ix->n_levels = top + 1;
+    ix->entry = entry;
+    CZ_HIP(hipMalloc((void **)&ix->nbr0, (size_t)n * ix->w0 * 4));
+    CZ_HIP(hipMalloc((void **)&ix->up_nbrs, std::max<size_t>(1, rows) * ix->wu * 4));
+    CZ_HIP(hipMemsetAsync(ix->up_nbrs, 0xFF, std::max<size_t>(1, rows) * ix->wu * 4, stream));
+    hipLaunchKernelGGL(build_pack_kernel, dim3(4096), dim3(256), 0, stream, b_nbr0.p, cap0, ix->nbr0, ix->w0, (uint64_t)n);
+    if (rows)
+        hipLaunchKernelGGL(build_pack_kernel, dim3(1024), dim3(256), 0, stream, b_nbrU.p, capU, ix->up_nbrs, ix->wu, rows);
+    unsigned long long nd = 0;
+    CZ_HIP(hipMemcpyAsync(&nd, b_ndist.p, 8, hipMemcpyDeviceToHost, stream));
+    CZ_HIP(hipStreamSynchronize(stream));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "hnsw pack launch: %s", hipGetErrorString(e));
+    if (n_dist_out) *n_dist_out = nd;
+    *out = reinterpret_cast<cz_hnsw_index *>(ix.release());
+    return CZ_OK;
+}
+
+// ---- export of a device-resident index back to the flat host layout (cz_hnsw_desc) ----
+extern "C" int cz_hnsw_index_info(const cz_hnsw_index *h, uint32_t *n, uint32_t *dim, int32_t *metric, int32_t *n_levels,
+                                  uint32_t *entry) {
+    if (!h) return cz::set_error(CZ_E_INVALID, "null index");
+    auto *ix = reinterpret_cast<const cz::HnswIndex *>(h);
+    if (n) *n = ix->n;
+    if (dim) *dim = ix->dim;
+    if (metric) *metric = ix->metric;
+    if (n_levels) *n_levels = ix->n_levels;
+    if (entry) *entry = ix->entry;
+    return CZ_OK;
+}
+
+extern "C" int cz_hnsw_index_level_info(const cz_hnsw_index *h, int32_t level, uint32_t *size, int32_t *width) {
+    if (!h) return cz::set_error(CZ_E_INVALID, "null index");
+    auto *ix = reinterpret_cast<const cz::HnswIndex *>(h);
+    if (level < 0 || level >= ix->n_levels) return cz::set_error(CZ_E_INVALID, "level %d out of range", level);
+    uint32_t c = 0;
+    if (level == 0) c = ix->n;
+    else
+        for (uint32_t i = 0; i < ix->n; i++) c += ix->top[i] >= level;
+    if (size) *size = c;
+    if (width) *width = level == 0 ? ix->w0 : ix->wu;
+    return CZ_OK;
+}
+
+extern "C" int cz_hnsw_index_export_level(const cz_hnsw_index *h, int32_t level, uint32_t *node_ids, uint32_t *nbrs) {
+    if (!h || !nbrs) return cz::set_error(CZ_E_INVALID, "null argument");
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    auto *ix = reinterpret_cast<const cz::HnswIndex *>(h);
+    if (level < 0 || level >= ix->n_levels) return cz::set_error(CZ_E_INVALID, "level %d out of range", level);
+    if (level == 0) {
+        if (node_ids)
+            for (uint32_t i = 0; i < ix->n; i++) node_ids[i] = i;
+        CZ_HIP(hipMemcpy(nbrs, ix->nbr0, (size_t)ix->n * ix->w0 * 4, hipMemcpyDeviceToHost));
+        return CZ_OK;
+    }
+    std::vector<uint32_t> base(ix->n);
+    CZ_HIP(hipMemcpy(base.data(), ix->up_base, (size_t)ix->n * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> up((size_t)std::max<uint64_t>(1, ix->up_rows) * ix->wu);
+    CZ_HIP(hipMemcpy(up.data(), ix->up_nbrs, up.size() * 4, hipMemcpyDeviceToHost));
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < ix->n; i++) {
+        if (ix->top[i] < level) continue;
+        if (node_ids) node_ids[r] = i;
+        memcpy(nbrs + (size_t)r * ix->wu, &up[((size_t)base[i] + (level - 1)) * ix->wu], (size_t)ix->wu * 4);
+        r++;
+    }
+    return CZ_OK;
+}
+
+extern "C" int cz_hnsw_index_export_vectors(const cz_hnsw_index *h, float *out) {
+    if (!h || !out) return cz::set_error(CZ_E_INVALID, "null argument");
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    auto *ix = reinterpret_cast<const cz::HnswIndex *>(h);
+    if (ix->n == 0) return CZ_OK;
+    CZ_HIP(hipMemcpy2D(out, (size_t)ix->dim * 4, ix->vec, (size_t)ix->ld * 4, (size_t)ix->dim * 4, ix->n, hipMemcpyDeviceToHost));
+    return CZ_OK;
+}

@@ -31,6 +31,7 @@ struct HnswIndex {
     uint32_t *nbr0 = nullptr;
     uint32_t *up_base = nullptr;
     uint32_t *up_nbrs = nullptr;
+    std::vector<int32_t> top;  // host copy: top level of every node (for export)
 
     // per-call scratch (visited bitmaps): cached, handed out under a mutex, stream-ordered by an event
     struct Workspace {

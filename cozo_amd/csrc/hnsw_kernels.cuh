@@ -51,6 +51,10 @@ struct Smem {
     uint32_t *vlog;   // [kVlogCap]
     float4 *q;        // [ld/4]
     int *ctl;         // [16] control words
+    // select-neighbours heuristic scratch (index construction only)
+    uint32_t *tpos;   // [efcap] list position of each pending candidate
+    uint32_t *sel;    // [256]   list positions of the selected neighbours
+    uint8_t *st;      // [efcap] 0 pending, 1 selected, 2 rejected
 };
 enum { C_CNT = 0, C_TODO = 1, C_LO = 2, C_VLOG = 3, C_NELIG = 4, C_NDIST_LO = 5, C_NDIST_HI = 6, C_KEEP = 7, C_NUM = 8 };
 
@@ -64,6 +68,7 @@ __host__ __device__ inline size_t smem_bytes(uint32_t efcap, uint32_t wpad, uint
     b += (size_t)kVlogCap * 4;
     b += (size_t)ld * 4;
     b += 64;
+    b += (size_t)efcap * 4 + 256 * 4 + (((size_t)efcap + 15) / 16) * 16;
     return b;
 }
 __device__ inline Smem carve(char *base, uint32_t efcap, uint32_t wpad, uint32_t ld) {
@@ -83,6 +88,12 @@ __device__ inline Smem carve(char *base, uint32_t efcap, uint32_t wpad, uint32_t
     s.q = (float4 *)base;
     base += (size_t)ld * 4;
     s.ctl = (int *)base;
+    base += 64;
+    s.tpos = (uint32_t *)base;
+    base += (size_t)efcap * 4;
+    s.sel = (uint32_t *)base;
+    base += 256 * 4;
+    s.st = (uint8_t *)base;
     return s;
 }
 
@@ -137,8 +148,8 @@ struct Searcher {
         qnorm = ix.metric == CZ_COSINE ? query_norm<LPV, ITERS>(q, s.q, glane, chunks) : 0.f;
     }
 
-    // distances for todo[0..n) -> nkey/nid   (all waves)
-    __device__ void eval_todo(int n) {
+    // distances from the register-resident vector (qq, qqn) to todo[0..n) -> nkey/nid   (all waves)
+    __device__ void eval_list(const float4 (&qq)[ITERS > 0 ? ITERS : 1], float qqn, int n) {
         for (int base = group * U; base < n; base += TG * U) {
             const float4 *rows[U];
             uint32_t ids[U];
@@ -149,7 +160,7 @@ struct Searcher {
                 rows[u] = j < n ? (const float4 *)(ix.vec + (size_t)ids[u] * ix.ld) : nullptr;
             }
             double d[U];
-            group_distances<LPV, ITERS, U>(ix.metric, q, s.q, glane, chunks, qnorm, rows, d);
+            group_distances<LPV, ITERS, U>(ix.metric, qq, s.q, glane, chunks, qqn, rows, d);
             if (glane == 0) {
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -161,6 +172,86 @@ struct Searcher {
                 }
             }
         }
+    }
+    __device__ void eval_todo(int n) { eval_list(q, qnorm, n); }
+
+    // hnsw_select_neighbours_heuristic (hnsw.rs:470-538) over the sorted list W (the `found` set, nearest
+    // first).  The reference pops candidates nearest-first and rejects one if an already selected neighbour is
+    // strictly closer to it than the centre is (:515-523).  Same result, batched: each time a candidate is
+    // accepted, its distances to all still-pending farther candidates are evaluated in one pass and the ones it
+    // dominates are rejected.  keep_pruned_connections back-fills from the rejected, nearest first (:530-536).
+    // Returns the number selected; their list positions are in s.sel.  (extend_candidates is not supported.)
+    __device__ int select_heuristic(int m, bool keep_pruned) {
+        static_assert(ITERS > 0, "index construction needs a register-resident vector (dim <= 2048)");
+        const int cnt = s.ctl[C_CNT];
+        for (int i = tid; i < cnt; i += kThreads) s.st[i] = 0;
+        __syncthreads();
+        int nsel = 0;
+        for (int i = 0; i < cnt && nsel < m; i++) {
+            if (s.st[i] != 0) continue;  // uniform
+            __syncthreads();
+            if (tid == 0) {
+                s.sel[nsel] = (uint32_t)i;
+                s.st[i] = 1;
+                s.ctl[C_TODO] = 0;
+            }
+            nsel++;
+            if (nsel == m) break;
+            __syncthreads();
+            if (wave == 0) {  // pending candidates farther than i, in order
+                int total = 0;
+                for (int b = i + 1; b < cnt; b += 64) {
+                    int j = b + lane;
+                    bool pend = j < cnt && s.st[j] == 0;
+                    unsigned long long mk = __ballot(pend);
+                    if (pend) {
+                        int p = total + __popcll(mk & ((1ull << lane) - 1ull));
+                        s.todo[p] = s.wid[j] & kIdMask;
+                        s.tpos[p] = (uint32_t)j;
+                    }
+                    total += __popcll(mk);
+                }
+                if (lane == 0) {
+                    s.ctl[C_TODO] = total;
+                    unsigned int lo = (unsigned int)s.ctl[C_NDIST_LO], nl = lo + (unsigned int)total;
+                    s.ctl[C_NDIST_LO] = (int)nl;
+                    if (nl < lo) s.ctl[C_NDIST_HI] += 1;
+                }
+            }
+            __syncthreads();
+            const int n = s.ctl[C_TODO];
+            if (n == 0) continue;
+            // the accepted neighbour becomes the "query" of this pass
+            const float4 *srow = (const float4 *)(ix.vec + (size_t)(s.wid[i] & kIdMask) * ix.ld);
+            float4 q2[ITERS > 0 ? ITERS : 1];
+#pragma unroll
+            for (int j = 0; j < ITERS; j++) {
+                int c = glane + LPV * j;
+                q2[j] = c < chunks ? srow[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const float q2n = ix.metric == CZ_COSINE ? query_norm<LPV, ITERS>(q2, s.q, glane, chunks) : 0.f;
+            eval_list(q2, q2n, n);
+            __syncthreads();
+            for (int j = tid; j < n; j += kThreads) {
+                const uint32_t p = s.tpos[j];
+                const uint64_t to_center = s.wkey[p], to_sel = s.nkey[j];
+                if (to_sel < to_center && to_center != ~0ull) s.st[p] = 2;  // raw `<`: false when either is NaN
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        if (keep_pruned && nsel < m) {
+            if (tid == 0) {
+                int k2 = nsel;
+                for (int i = 0; i < cnt && k2 < m; i++)
+                    if (s.st[i] == 2) s.sel[k2++] = (uint32_t)i;
+                s.ctl[C_TODO] = k2;
+            }
+            __syncthreads();
+            nsel = s.ctl[C_TODO];
+            __syncthreads();
+        }
+        return nsel;
     }
 
     // merge nkey/nid[0..n) into W (capacity ef).  Caller guarantees a barrier before; ends with a barrier.

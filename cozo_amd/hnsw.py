@@ -77,6 +77,59 @@ class GpuHnswIndex:
         check(_lib.lib().cz_hnsw_index_create(C.byref(desc), ptr(vectors), C.byref(h)))
         self._h = h
 
+    @classmethod
+    def build(cls, manifest: HnswIndexManifest, vectors, levels: Optional[np.ndarray] = None, seed: int = 0,
+              max_batch: int = 0, device_ptr: bool = False, n: Optional[int] = None, stream: int = 0):
+        """`::hnsw create` on the GPU (create_hnsw_index, runtime/relation.rs:1010-1201 -> hnsw_put per row):
+        batch-parallel insertion of all vectors in key order.  `vectors` is a host array, or (device_ptr=True) a
+        device tensor / pointer with `n` rows.  Returns the index; `.last_build_n_dist` holds the distance count."""
+        if manifest.dtype != "F32":
+            raise _lib.CozoGpuError(_lib.CZ_E_UNSUPPORTED, "only F32 vector indices are GPU-resident")
+        if manifest.extend_candidates:
+            raise _lib.CozoGpuError(_lib.CZ_E_UNSUPPORTED, "extend_candidates is not supported by the GPU build")
+        self = cls.__new__(cls)
+        self.manifest = manifest
+        if device_ptr:
+            nn = int(n if n is not None else vectors.shape[0])
+            vp = ptr(vectors)
+        else:
+            vectors = np.ascontiguousarray(vectors, dtype=np.float32)
+            nn = vectors.shape[0]
+            vp = ptr(vectors)
+        lv = None if levels is None else np.ascontiguousarray(levels, dtype=np.int32)
+        nd = C.c_uint64(0)
+        h = C.c_void_p()
+        check(_lib.lib().cz_hnsw_build(vp, nn, manifest.vec_dim, DISTANCES[manifest.distance], manifest.m_neighbours,
+                                       manifest.ef_construction, int(manifest.keep_pruned_connections), ptr(lv),
+                                       int(seed), int(max_batch), C.byref(nd), C.byref(h),
+                                       CZ_DEVICE_PTRS if device_ptr else 0, C.c_void_p(stream)))
+        self._h = h
+        self.n = nn
+        self.last_build_n_dist = nd.value
+        return self
+
+    def export(self):
+        """(level_nodes, level_nbrs, entry): the flat layout of cz_hnsw_desc, e.g. to write the links back as
+        `tbl:idx` rows or to hand the same index to another searcher."""
+        L = _lib.lib()
+        n, dim, metric, nl, entry = C.c_uint32(), C.c_uint32(), C.c_int32(), C.c_int32(), C.c_uint32()
+        check(L.cz_hnsw_index_info(self._h, C.byref(n), C.byref(dim), C.byref(metric), C.byref(nl), C.byref(entry)))
+        nodes, nbrs = [], []
+        for lv in range(nl.value):
+            size, width = C.c_uint32(), C.c_int32()
+            check(L.cz_hnsw_index_level_info(self._h, lv, C.byref(size), C.byref(width)))
+            ids = np.empty(size.value, dtype=np.uint32)
+            tab = np.empty((size.value, width.value), dtype=np.uint32)
+            check(L.cz_hnsw_index_export_level(self._h, lv, ptr(ids), ptr(tab)))
+            nodes.append(ids)
+            nbrs.append(tab)
+        return nodes, nbrs, entry.value
+
+    def export_vectors(self) -> np.ndarray:
+        out = np.empty((self.n, self.manifest.vec_dim), dtype=np.float32)
+        check(_lib.lib().cz_hnsw_index_export_vectors(self._h, ptr(out)))
+        return out
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.lib().cz_hnsw_index_destroy(self._h)

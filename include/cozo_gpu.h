@@ -85,6 +85,28 @@ void cz_hnsw_index_destroy(cz_hnsw_index *ix);
 /* device bytes held by the index (vectors + link tables) */
 uint64_t cz_hnsw_index_bytes(const cz_hnsw_index *ix);
 
+/* Index construction on the GPU: hnsw_put over all rows in key order (runtime/hnsw.rs:155-538, 679-727;
+ * create_hnsw_index, runtime/relation.rs:1010-1201), as a batch-parallel insert.
+ *   vectors [n][dim] f32 [dev-able]; m, ef_construction, keep_pruned_connections as HnswIndexManifest
+ *   (m_max = m, m_max0 = 2m; extend_candidates is not supported on the GPU).
+ *   levels [n] (host, may be NULL): level of every vector as the non-negative -layer of get_random_level
+ *   (:46-52); NULL draws floor(-ln(U)/ln(m)) from `seed` (the reference uses an unseedable thread_rng).
+ *   max_batch: vectors inserted concurrently (0 = default 4096; 1 reproduces the sequential algorithm and its
+ *   link tables exactly).  n_dist (optional): distance evaluations spent.
+ * The result is an ordinary index handle; cz_hnsw_index_export_* copies the link rows back so that the host
+ * can store them as `tbl:idx` rows (store_tx.put, :277-357). */
+int cz_hnsw_build(const float *vectors, uint32_t n, uint32_t dim, int metric, uint32_t m, uint32_t ef_construction,
+                  int keep_pruned_connections, const int32_t *levels, uint64_t seed, uint32_t max_batch,
+                  uint64_t *n_dist, cz_hnsw_index **out, uint32_t flags, void *stream);
+
+/* flat export of a device-resident index (the inverse of cz_hnsw_index_create; host buffers) */
+int cz_hnsw_index_info(const cz_hnsw_index *ix, uint32_t *n, uint32_t *dim, int32_t *metric, int32_t *n_levels,
+                       uint32_t *entry);
+int cz_hnsw_index_level_info(const cz_hnsw_index *ix, int32_t level, uint32_t *size, int32_t *width);
+int cz_hnsw_index_export_level(const cz_hnsw_index *ix, int32_t level, uint32_t *node_ids /* [size] or NULL */,
+                               uint32_t *nbrs /* [size][width] */);
+int cz_hnsw_index_export_vectors(const cz_hnsw_index *ix, float *out /* [n][dim] */);
+
 /* SessionTx::hnsw_knn (runtime/hnsw.rs:869-1012) for a whole batch of parent tuples
  * (HnswSearchRA::iter, query/ra.rs:1085-1121, calls it once per tuple).
  *   queries [B][dim] f32 [dev-able]; k, ef as HnswSearch (data/program.rs:975-991);
