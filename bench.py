@@ -1,0 +1,369 @@
+#!/usr/bin/env python
+"""bench.py -- the hot path of cozodb/cozo on MI355X: HNSW k-NN search (queries/s at recall@10 >= 0.95) and the
+PageRank fixed rule (edges/s), measured as BASELINE.json asks.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of `hnsw_knn` over one batch of 1024 parent tuples (query vectors) resident in HBM
+(BASELINE.json configs[1]: k = 10, cosine, 1M x 768 f32, batch 1024).  Queries are independent units, so at
+N > 1 every rank serves its own 1024-query batch from its own index replica (weak scaling, no data-path
+collective).  The same JSON line carries a `pagerank` object: PageRank on a synthetic 10M-node / 100M-edge
+graph per GPU (configs[2]); at N > 1 the graph is N times larger, row-sharded, with one RCCL all-gather of the
+contribution slice and one f64 all-reduce per iteration.
+
+All inputs are synthetic and generated on the GPU (no datasets here); the index is built on the GPU by
+cz_hnsw_build.  Rank 0 at N = 1 also times the CPU oracle (a C restatement of the reference, the reference
+itself being Rust and unbuildable here) on a bounded sample of the same workload: `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling there: 6290 GB/s
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--n", type=int, default=1_000_000, help="vectors per index (per GPU)")
+    p.add_argument("--dim", type=int, default=768)
+    p.add_argument("--batch", type=int, default=1024)
+    p.add_argument("--k", type=int, default=10)
+    p.add_argument("--m", type=int, default=32)
+    p.add_argument("--ef-construction", type=int, default=200)
+    p.add_argument("--max-batch", type=int, default=4096, help="vectors inserted concurrently during the build")
+    p.add_argument("--dist", default="lowrank", choices=["lowrank", "normal", "clustered"])
+    p.add_argument("--ef", type=int, default=0, help="0: smallest ef of the ladder reaching recall >= 0.95")
+    p.add_argument("--recall-target", type=float, default=0.95)
+    p.add_argument("--pr-nodes", type=int, default=10_000_000, help="PageRank nodes per GPU")
+    p.add_argument("--pr-edges", type=int, default=100_000_000, help="PageRank edges per GPU (before de-duplication)")
+    p.add_argument("--pr-iters", type=int, default=20)
+    p.add_argument("--skip-pagerank", action="store_true")
+    p.add_argument("--skip-hnsw", action="store_true")
+    p.add_argument("--skip-cpu", action="store_true")
+    p.add_argument("--cpu-queries", type=int, default=256)
+    return p.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------------
+def gen_vectors(torch, n, dim, kind, seed, device):
+    """Synthetic corpus.  `lowrank`: embedding-like vectors x = z W + 0.1 eps with a 32-d latent z ~ N(0,1) and a
+    fixed W (seed 12345) -- intrinsic dimension 32, ambient 768, so that recall@10 >= 0.95 is attainable by a
+    graph index (iid N(0,1)^768 has no neighbourhood structure: every point is almost equidistant).
+    `clustered`: BASELINE.md's 16 Gaussian centres (sigma_centre 1, sigma_within 0.5).  `normal`: iid N(0,1)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    if kind == "normal":
+        return torch.randn((n, dim), generator=g, device=device, dtype=torch.float32)
+    if kind == "clustered":
+        gc = torch.Generator(device=device)
+        gc.manual_seed(777)
+        centres = torch.randn((16, dim), generator=gc, device=device, dtype=torch.float32)
+        which = torch.randint(0, 16, (n,), generator=g, device=device)
+        x = torch.randn((n, dim), generator=g, device=device, dtype=torch.float32)
+        x.mul_(0.5).add_(centres[which])
+        return x
+    gw = torch.Generator(device=device)
+    gw.manual_seed(12345)
+    r = 32
+    w = torch.randn((r, dim), generator=gw, device=device, dtype=torch.float32)
+    out = torch.empty((n, dim), device=device, dtype=torch.float32)
+    step = 131072
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        z = torch.randn((e - s, r), generator=g, device=device, dtype=torch.float32)
+        out[s:e] = z @ w
+        out[s:e].add_(torch.randn((e - s, dim), generator=g, device=device, dtype=torch.float32), alpha=0.1)
+    return out
+
+
+def recall_at_k(torch, ids, gt):
+    # ids, gt: [B][k] int64 on device
+    hit = (ids.unsqueeze(2) == gt.unsqueeze(1)).any(dim=2).sum(dim=1).to(torch.float64)
+    return float((hit / gt.shape[1]).mean().item())
+
+
+def bench_hnsw(args, torch, dist, rank, world, device):
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest, HnswSearch
+    stream = torch.cuda.current_stream().cuda_stream
+    B, k, dim = args.batch, args.k, args.dim
+    t0 = time.time()
+    x = gen_vectors(torch, args.n, dim, args.dist, 42, device)  # every rank: the same corpus (replica)
+    q = gen_vectors(torch, B, dim, args.dist, 43 + rank, device)  # every rank: its own parent tuples
+    torch.cuda.synchronize()
+    log(f"generated {args.n} x {dim} vectors ({args.dist}) in {time.time() - t0:.1f}s")
+    man = HnswIndexManifest(vec_dim=dim, distance="Cosine", m_neighbours=args.m, ef_construction=args.ef_construction)
+    t0 = time.time()
+    ix = GpuHnswIndex.build(man, x, seed=7, max_batch=args.max_batch, device_ptr=True, n=args.n, stream=stream)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    build_nd = ix.last_build_n_dist
+    del x
+    torch.cuda.empty_cache()
+    log(f"built index in {build_s:.1f}s ({build_nd:.3e} distance evaluations, {build_nd * 4 * dim / build_s / 1e9:.0f} GB/s)")
+    # ground truth by exhaustive scan, then the smallest ef of the ladder that reaches the recall target
+    gt = torch.empty((B, k), dtype=torch.int32, device=device)
+    gtd = torch.empty((B, k), dtype=torch.float64, device=device)
+    ix.bruteforce_knn_device(q, k, gt, gtd, stream)
+    torch.cuda.synchronize()
+    gt64 = gt.to(torch.int64) & 0xFFFFFFFF
+    ids = torch.empty((B, k), dtype=torch.int32, device=device)
+    dd = torch.empty((B, k), dtype=torch.float64, device=device)
+    cnt = torch.empty(B, dtype=torch.int32, device=device)
+    nd = torch.zeros(B, dtype=torch.int64, device=device)
+
+    def run(ef):
+        ix.hnsw_knn_batch_device(q, HnswSearch(k=k, ef=ef), ids, dd, cnt, nd, stream)
+
+    ladder = [args.ef] if args.ef else [16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024]
+    ef, rec, sweep = ladder[-1], 0.0, []
+    for cand in ladder:
+        if cand < k:
+            continue
+        run(cand)
+        torch.cuda.synchronize()
+        rec = recall_at_k(torch, ids.to(torch.int64) & 0xFFFFFFFF, gt64)
+        sweep.append((cand, round(rec, 4)))
+        ef = cand
+        if rec >= args.recall_target:
+            break
+    if world > 1:  # every rank does the same work: take the largest ef any rank needs
+        t = torch.tensor([ef], device=device, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ef = int(t.item())
+        run(ef)
+        torch.cuda.synchronize()
+        rec = recall_at_k(torch, ids.to(torch.int64) & 0xFFFFFFFF, gt64)
+    log(f"ef sweep {sweep} -> ef = {ef}, recall@{k} = {rec:.4f}")
+    for _ in range(args.warmup):
+        run(ef)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        run(ef)
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([wall], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    n_dist = int(nd.sum().item())
+    algo_bytes = n_dist * 4 * dim  # 4*d bytes per distance evaluation (the query is on-chip)
+    kern_s = dev_ms / 1e3 / args.steps
+    res = dict(qps=world * B * args.steps / wall, ms_per_step=wall / args.steps * 1e3, ef=ef, recall=rec,
+               n_dist_per_query=n_dist / B, build_s=build_s, build_n_dist=build_nd,
+               roofline=dict(bound="hbm", kernel="hnsw_knn_kernel", achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
+                             unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS, traffic=None,
+                             algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=kern_s * 1e3),
+               index_bytes=ix.device_bytes, sweep=sweep)
+    # CPU baseline: the oracle (a port of the reference algorithm) on the same index and the same queries
+    if rank == 0 and world == 1 and not args.skip_cpu:
+        try:
+            res["cpu_baseline"] = cpu_baseline_hnsw(args, ix, q, ef, k)
+        except Exception as e:  # the baseline never blocks the GPU number
+            res["cpu_baseline"] = dict(value=None, unit="queries/s", cores=1, kind="port", sample=f"failed: {e}")
+    ix.close()
+    return res
+
+
+def cpu_baseline_hnsw(args, ix, q, ef, k):
+    from oracle import oracle as O
+    t0 = time.time()
+    nodes, nbrs, entry = ix.export()
+    vec = ix.export_vectors()
+    flat = O.FlatIndex(vec, O.COSINE, nodes, nbrs, entry)
+    log(f"exported the index to the host in {time.time() - t0:.1f}s")
+    qh = q[:args.cpu_queries].cpu().numpy()
+    flat.knn_batch(qh[:8], k, ef)  # touch
+    t0 = time.perf_counter()
+    _, _, _, nd = flat.knn_batch(qh, k, ef, dot_mode=O.DOT_NDARRAY, threads=1)
+    dt = time.perf_counter() - t0
+    return dict(value=len(qh) / dt, unit="queries/s", cores=1, kind="port",
+                sample=f"{len(qh)} of the {args.batch} queries, same index (exported), same ef={ef}, 1 thread "
+                       f"(HnswSearchRA::iter is sequential: one cozo script gets one core); C port of hnsw_knn "
+                       f"(oracle/, -O3 AVX2) without the reference's KV-store / msgpack overhead, so optimistic; "
+                       f"{nd / len(qh):.0f} dist evals/query; {os.cpu_count()} host cores present")
+
+
+# ------------------------------------------------------------------------------------------------------------
+def bench_pagerank(args, torch, dist, rank, world, device):
+    from cozo_amd.distributed import ShardedPageRank, equal_row_partition
+    from cozo_amd.graph import PageRankPlan
+    stream = torch.cuda.current_stream().cuda_stream
+    n_total = args.pr_nodes * world
+    per, ranges = equal_row_partition(n_total, world)
+    rb, re = ranges[rank]
+    rows = re - rb
+    t0 = time.time()
+    g = torch.Generator(device=device)
+    g.manual_seed(4242 + rank)
+    e_local = args.pr_edges
+    # uniform random directed graph, partitioned by destination: this rank draws the edges that end in its rows
+    dst = torch.randint(0, rows, (e_local,), generator=g, device=device, dtype=torch.int64)
+    src = torch.randint(0, n_total, (e_local,), generator=g, device=device, dtype=torch.int64)
+    keep = src != (dst + rb)  # no self loops
+    key = (dst[keep] * n_total + src[keep])
+    del dst, src, keep
+    key = torch.unique(key)  # a relation is a set; also sorts by (dst, src) = CsrLayout::Sorted in-adjacency
+    d = torch.div(key, n_total, rounding_mode="floor")
+    s = (key - d * n_total).to(torch.int32)
+    del key
+    counts = torch.bincount(d, minlength=rows)
+    off = torch.zeros(rows + 1, dtype=torch.int64, device=device)
+    off[1:] = torch.cumsum(counts, 0)
+    e_kept = int(off[-1].item())
+    outdeg = torch.bincount(s.to(torch.int64), minlength=n_total)
+    if world > 1:
+        dist.all_reduce(outdeg, op=dist.ReduceOp.SUM)
+    outdeg32 = outdeg.to(torch.int32)
+    off32 = off.to(torch.int32)
+    del d, counts, outdeg
+    torch.cuda.synchronize()
+    e_total = e_kept
+    if world > 1:
+        t = torch.tensor([e_kept], device=device, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        e_total = int(t.item())
+    log(f"pagerank graph: {n_total} nodes, {e_total} edges (rank 0 holds {e_kept}) generated in {time.time() - t0:.1f}s")
+    plan = PageRankPlan(off32, s, outdeg32, n_total, rb, re, 0.85, device_ptrs=True)
+    sp = ShardedPageRank(n_total, rank, world, device, lambda c: plan.init(c, stream),
+                         lambda cin, cout, err: plan.step(cin, cout, err, stream))
+    # reference defaults (epsilon 1e-4, 10 iterations) -> how many iterations the stopping rule takes
+    it_default, err_default = sp.run(1e-4, 10)
+    # steady state: fixed iteration count, tolerance 0
+    sp.run(0.0, 2)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    iters, _ = sp.run(0.0, args.pr_iters)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    # kernel-only time of the SpMV sweep (HIP events on the launch stream, no host round trip in between)
+    cin, cout = sp.contrib
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        plan.step(cin, cout, sp.err, stream)
+        cin, cout = cout, cin
+    e1.record()
+    torch.cuda.synchronize()
+    kern_s = e0.elapsed_time(e1) / 1e3 / reps
+    algo_bytes = 4 * e_kept + 4 * (rows + 1) + 20 * rows  # SURVEY 8d compulsory-traffic model, this rank's shard
+    res = dict(value=e_total * iters / wall, unit="edges/s", iterations=iters, ms_per_iteration=wall / iters * 1e3,
+               nodes=n_total, edges=e_total, default_run=dict(iterations=it_default, final_err=err_default),
+               roofline=dict(bound="hbm", kernel="pr_step_kernel", achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
+                             unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS, traffic=None,
+                             algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=kern_s * 1e3),
+               exchange="none" if world == 1 else f"all_gather {per * 4} B/rank/iter + all_reduce f64")
+    if rank == 0 and world == 1 and not args.skip_cpu:
+        try:
+            from oracle import oracle as O
+            ioff = off.cpu().numpy().astype(np.uint64)
+            isrc = s.cpu().numpy().astype(np.uint32)
+            od = outdeg32.cpu().numpy().astype(np.uint32)
+            cores = os.cpu_count() or 1
+            t0 = time.perf_counter()
+            _, it_cpu, _ = O.pagerank(n_total, ioff, isrc, od, 0.85, 0.0, 3, threads=cores)
+            dt = time.perf_counter() - t0
+            res["cpu_baseline"] = dict(value=e_total * it_cpu / dt, unit="edges/s", cores=cores, kind="port",
+                                       sample=f"{it_cpu} iterations on the same graph, {cores} threads, 16384-node dynamic "
+                                              f"chunks (graph crate's scheduler); C port of graph::page_rank, iterations "
+                                              f"only (the reference also pays the relation scan + id mapping)")
+        except Exception as e:
+            res["cpu_baseline"] = dict(value=None, unit="edges/s", cores=0, kind="port", sample=f"failed: {e}")
+    plan.close()
+    return res
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from cozo_amd import _lib  # loads exactly one HIP runtime before torch touches the GPU
+    L = _lib.lib()
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    rc = L.cz_init(local)
+    if rc != 0:
+        raise RuntimeError(L.cz_last_error().decode())
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    out = {}
+    hn = None if args.skip_hnsw else bench_hnsw(args, torch, dist, rank, world, device)
+    torch.cuda.empty_cache()
+    pr = None if args.skip_pagerank else bench_pagerank(args, torch, dist, rank, world, device)
+    if rank == 0:
+        if hn is not None:
+            out = {
+                "metric": "hnsw_knn_queries_per_sec_at_recall>=0.95", "value": hn["qps"], "unit": "queries/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": hn["ms_per_step"],
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"HNSW k={args.k} cosine, {args.n} x {args.dim} f32 ({args.dist}), query batch={args.batch}"
+                                       f" per GPU, m={args.m}, ef_construction={args.ef_construction}, ef={hn['ef']}, "
+                                       f"index built on the GPU (max_batch={args.max_batch})",
+                           "parallelism": "1 GPU" if world == 1 else f"{world} index replicas, query batches sharded across ranks",
+                           "recall_at_k": hn["recall"], "ef": hn["ef"], "n_dist_per_query": hn["n_dist_per_query"],
+                           "index_build_s": hn["build_s"], "index_bytes": hn["index_bytes"]},
+                "roofline": hn["roofline"],
+            }
+            if "cpu_baseline" in hn:
+                out["cpu_baseline"] = hn["cpu_baseline"]
+        else:
+            out = {"metric": "pagerank_edges_per_sec", "value": pr["value"], "unit": "edges/s", "n_gpus": world,
+                   "steps": pr["iterations"], "warmup": 2, "ms_per_step": pr["ms_per_iteration"], "higher_is_better": True,
+                   "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "config": {"workload": f"PageRank {pr['nodes']} nodes / {pr['edges']} edges"}, "roofline": pr["roofline"]}
+            if "cpu_baseline" in pr:
+                out["cpu_baseline"] = pr["cpu_baseline"]
+        if pr is not None and hn is not None:
+            out["pagerank"] = pr
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

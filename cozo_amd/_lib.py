@@ -73,7 +73,7 @@ SYMBOLS = {
     "cz_pagerank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_double,
                               C.c_uint32, C.c_void_p, u32p, f64p, C.c_void_p]),
     "cz_pagerank_plan_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
-                                          C.c_float, C.POINTER(C.c_void_p)]),
+                                          C.c_float, C.POINTER(C.c_void_p), C.c_uint32]),
     "cz_pagerank_plan_destroy": (None, [C.c_void_p]),
     "cz_pagerank_plan_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cz_pagerank_plan_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

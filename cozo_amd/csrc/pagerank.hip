@@ -153,11 +153,20 @@ struct cz_pagerank_plan {
 
 extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree,
                                        uint32_t N, uint32_t row_begin, uint32_t row_end, float damping,
-                                       cz_pagerank_plan **out) {
+                                       cz_pagerank_plan **out, uint32_t flags) {
     if (!out) return cz::set_error(CZ_E_INVALID, "null out");
     *out = nullptr;
     int rc = cz::ensure_device();
     if (rc) return rc;
+    const bool dev = flags & CZ_DEVICE_PTRS;
+    std::vector<uint32_t> host_off;
+    const uint32_t *dev_off = in_offsets;
+    if (dev && in_offsets && row_end >= row_begin && row_end <= N) {  // the row blocks are cut on the host
+        host_off.resize((size_t)(row_end - row_begin) + 1);
+        CZ_HIP(hipMemcpy(host_off.data(), in_offsets, host_off.size() * 4, hipMemcpyDeviceToHost));
+        in_offsets = host_off.data();
+    }
+    const hipMemcpyKind up = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (row_begin > row_end || row_end > N) return cz::set_error(CZ_E_INVALID, "bad row range [%u,%u) of %u", row_begin, row_end, N);
     if (N > 0 && (!in_offsets || !out_degree)) return cz::set_error(CZ_E_INVALID, "null CSR array");
     const uint32_t rows = row_end - row_begin;
@@ -196,13 +205,13 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     CZ_HIP(hipMalloc((void **)&p->d_scores, std::max<size_t>(1, rows) * 4));
     CZ_HIP(hipMalloc((void **)&p->d_partial, std::max<size_t>(1, blocks.size()) * 8));
     if (!blocks.empty()) CZ_HIP(hipMemcpy(p->d_blocks, blocks.data(), blocks.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
-    if (rows) CZ_HIP(hipMemcpy(p->d_off, in_offsets, ((size_t)rows + 1) * 4, hipMemcpyHostToDevice));
+    if (rows) CZ_HIP(hipMemcpy(p->d_off, dev ? dev_off : in_offsets, ((size_t)rows + 1) * 4, up));
     else {
         uint32_t z = 0;
         CZ_HIP(hipMemcpy(p->d_off, &z, 4, hipMemcpyHostToDevice));
     }
-    if (E) CZ_HIP(hipMemcpy(p->d_src, in_sources, E * 4, hipMemcpyHostToDevice));
-    if (N) CZ_HIP(hipMemcpy(p->d_outdeg, out_degree, (size_t)N * 4, hipMemcpyHostToDevice));
+    if (E) CZ_HIP(hipMemcpy(p->d_src, in_sources, E * 4, up));
+    if (N) CZ_HIP(hipMemcpy(p->d_outdeg, out_degree, (size_t)N * 4, up));
     *out = p.release();
     return CZ_OK;
 }
@@ -272,7 +281,7 @@ extern "C" int cz_pagerank(const uint32_t *in_offsets, const uint32_t *in_source
     if (max_iter == 0) return cz::set_error(CZ_E_INVALID, "iterations must be positive");
     if (in_offsets && in_offsets[N] != E) return cz::set_error(CZ_E_INVALID, "in_offsets[N] (%u) != E (%llu)", in_offsets[N], (unsigned long long)E);
     cz_pagerank_plan *plan = nullptr;
-    int rc = cz_pagerank_plan_create(in_offsets, in_sources, out_degree, N, 0, N, damping, &plan);
+    int rc = cz_pagerank_plan_create(in_offsets, in_sources, out_degree, N, 0, N, damping, &plan, 0);
     if (rc) return rc;
     std::unique_ptr<cz_pagerank_plan> guard(plan);
     cz::DevBuf<float> c0, c1;

@@ -1,0 +1,100 @@
+"""Multi-GPU form of the hot path: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI;
+"gloo" on CPU for the tests).  Only the two real exchange steps are collectives:
+
+* PageRank: 1-D row (destination-node) partition of the in-CSR.  Every rank keeps the full contribution
+  vector, computes its own rows with the plan kernels, then ALL-GATHERS its slice of the next contribution
+  vector (N/world * 4 bytes per rank per iteration, one direct hop per peer on the xGMI mesh) and ALL-REDUCES
+  one f64 (the |delta| sum that drives the reference's stopping rule).  A ring all-reduce of a zero-padded
+  full vector would move ~2x(world-1)/world * 4N bytes per link instead -- not used.
+* HNSW over an index partitioned into independent sub-indices (one per rank): every rank searches its own
+  shard for the same query batch, the per-shard (distance, id) lists are all-gathered (B*k*12 bytes per rank)
+  and merged to the global top-k on every rank.
+
+Query batches that are independent units are simply split across ranks (no collective): that is what
+bench.py does for the HNSW scaling line.
+
+The local compute is passed in as a callable so that the exchange logic can be exercised with world_size 2
+on CPU (gloo) in tests/; the product path binds it to the GPU kernels (cozo_amd.graph.PageRankPlan /
+cozo_amd.hnsw.GpuHnswIndex).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def equal_row_partition(n_rows: int, world: int) -> Tuple[int, list]:
+    """rows per rank (padded so every rank owns the same number: all_gather needs equal slices) and the
+    [begin, end) ranges clipped to n_rows."""
+    per = (n_rows + world - 1) // world
+    return per, [(min(n_rows, r * per), min(n_rows, (r + 1) * per)) for r in range(world)]
+
+
+class ShardedPageRank:
+    """graph::page_rank (pagerank.rs:47-50) over row shards.
+
+    local_init(contrib_full)                      -> writes init/out_degree for ALL nodes, resets local scores
+    local_step(contrib_in, contrib_out, err)      -> computes this rank's rows from the full contrib_in, writes
+                                                     ITS slice [rank*per, (rank+1)*per) of the full-length
+                                                     contrib_out and adds its sum |new - old| into err (f64[1])
+    """
+
+    def __init__(self, n_nodes: int, rank: int, world: int, device: torch.device,
+                 local_init: Callable, local_step: Callable, group=None):
+        self.n, self.rank, self.world, self.device, self.group = n_nodes, rank, world, device, group
+        self.per, self.ranges = equal_row_partition(n_nodes, world)
+        self.local_init, self.local_step = local_init, local_step
+        padded = self.per * world
+        self.contrib = [torch.zeros(padded, dtype=torch.float32, device=device) for _ in range(2)]
+        self.err = torch.zeros(1, dtype=torch.float64, device=device)
+
+    def run(self, tolerance: float, max_iter: int, poison: Optional[Callable[[], bool]] = None):
+        """Returns (iterations, final error).  Stopping rule of graph::page_rank: err < tolerance or
+        iterations == max_iter, decided on the all-reduced error so that every rank stops together."""
+        cin, cout = self.contrib
+        self.local_init(cin)
+        rb = self.rank * self.per
+        it = 0
+        while True:
+            if poison is not None and poison():
+                raise RuntimeError("ProcessKilled")
+            self.err.zero_()
+            self.local_step(cin, cout, self.err)
+            if self.world > 1:
+                # in-place all-gather: this rank's slice already sits at its final position in `cout`
+                dist.all_gather_into_tensor(cout, cout[rb:rb + self.per], group=self.group)
+                dist.all_reduce(self.err, op=dist.ReduceOp.SUM, group=self.group)
+            cin, cout = cout, cin
+            it += 1
+            e = float(self.err.item())
+            if e < tolerance or it == max_iter:
+                return it, e
+
+
+def merge_shard_topk(local_ids: torch.Tensor, local_dist: torch.Tensor, id_offset: int, k: int, world: int,
+                     group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Global top-k of per-shard k-NN lists.  local_ids [B][k] (0xFFFFFFFF = empty, as int64 here),
+    local_dist [B][k] f64; ids are made global by adding id_offset.  Every rank gets the same merged
+    (ids [B][k] int64 with -1 for empty, dist [B][k]) ordered by (distance, id) -- the order hnsw_knn returns."""
+    ids = local_ids.to(torch.int64)
+    empty = ids == 0xFFFFFFFF
+    ids = torch.where(empty, torch.full_like(ids, -1), ids + id_offset)
+    d = torch.where(empty, torch.full_like(local_dist, float("inf")), local_dist)
+    if world > 1:
+        B = ids.shape[0]
+        all_ids = torch.empty((world * B, k), dtype=ids.dtype, device=ids.device)
+        all_d = torch.empty((world * B, k), dtype=d.dtype, device=d.device)
+        dist.all_gather_into_tensor(all_ids, ids.contiguous(), group=group)
+        dist.all_gather_into_tensor(all_d, d.contiguous(), group=group)
+        ids = all_ids.view(world, B, k).permute(1, 0, 2).reshape(B, world * k)
+        d = all_d.view(world, B, k).permute(1, 0, 2).reshape(B, world * k)
+    # order by (distance, id): stable sort on id first, then on distance (NaN sorts last like ordered-float)
+    big = torch.iinfo(torch.int64).max
+    key_ids = torch.where(ids < 0, torch.full_like(ids, big), ids)
+    o1 = torch.argsort(key_ids, dim=1, stable=True)
+    ids, d = torch.gather(ids, 1, o1), torch.gather(d, 1, o1)
+    o2 = torch.argsort(d, dim=1, stable=True)
+    ids, d = torch.gather(ids, 1, o2)[:, :k], torch.gather(d, 1, o2)[:, :k]
+    return ids, d

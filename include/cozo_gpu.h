@@ -150,14 +150,14 @@ int cz_pagerank(const uint32_t *in_offsets, const uint32_t *in_sources, const ui
 
 /* Resident / row-sharded PageRank.  A plan owns rows [row_begin, row_end) of the in-CSR:
  *   in_offsets [rows+1] relative to the shard (in_offsets[0] == 0), in_sources [E_local] GLOBAL ids,
- *   out_degree [N] for all nodes.                                   (host pointers)
+ *   out_degree [N] for all nodes.                                   [dev-able]
  * One iteration = cz_pagerank_plan_step: reads the full contribution vector contrib_in [N] (device),
  * writes this shard's scores and its slice of contrib_out [N] (device, may alias a gathered buffer
  * the host then all-gathers over RCCL), and adds the shard's sum |new-old| into *err_out (device f64). */
 typedef struct cz_pagerank_plan cz_pagerank_plan;
 int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree,
                             uint32_t N, uint32_t row_begin, uint32_t row_end, float damping,
-                            cz_pagerank_plan **out);
+                            cz_pagerank_plan **out, uint32_t flags /* CZ_DEVICE_PTRS: the three arrays are in HBM */);
 void cz_pagerank_plan_destroy(cz_pagerank_plan *p);
 /* contrib [N] device: init/out_degree for every node (graph::page_rank initial state); zeroes scores */
 int cz_pagerank_plan_init(cz_pagerank_plan *p, float *contrib_dev, void *stream);
