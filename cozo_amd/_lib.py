@@ -12,6 +12,8 @@ SO_PATH = os.path.join(_HERE, "lib", "libcozo_gpu.so")
 
 CZ_NONE = 0xFFFFFFFF
 CZ_DEVICE_PTRS = 1
+CZ_PR_GATHER = 2
+CZ_PR_BLOCKED = 4
 CZ_L2, CZ_COSINE, CZ_IP = 0, 1, 2
 CZ_OK, CZ_E_INVALID, CZ_E_NO_DEVICE, CZ_E_HIP, CZ_E_CANCELLED, CZ_E_OOM, CZ_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 
@@ -79,6 +81,7 @@ SYMBOLS = {
     "cz_pagerank_plan_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cz_pagerank_plan_scores": (C.c_void_p, [C.c_void_p]),
     "cz_pagerank_plan_edges": (C.c_uint64, [C.c_void_p]),
+    "cz_pagerank_plan_is_blocked": (C.c_int, [C.c_void_p]),
     "cz_pagerank_plan_read_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "cz_bfs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -5,41 +5,70 @@
 //   new = base + d * sum_{v in in(u)} contrib[v]   (f32, in-neighbours summed SEQUENTIALLY in sorted order)
 //   err += |new - old| (f64); contrib refreshed after the sweep (Jacobi); stop at err < tol or max_iter.
 //
-// Kernel: CSR-stream pull SpMV.  A workgroup owns a run of consecutive rows whose in-edges fit one LDS
-// tile (kTileNnz entries).  Phase 1 streams the tile's source ids with coalesced loads and gathers
-// contrib[src] into LDS (every lane busy, many gathers in flight); phase 2 gives each row to one lane,
-// which adds its LDS segment in order -- the same sequential f32 order as the reference, so the scores
-// are bit-identical to it -- and runs the fused epilogue (new score, |delta| in f64, next contribution).
-// Rows longer than a tile are streamed tile by tile and summed by one lane, still in order.
-// Algorithmic HBM bytes per iteration: 4E (ids) + 4(N+1) (offsets) + 20N (contrib in/out, score
-// in/out, out-degree)  = 6.4 B/edge at N = 10M, E = 100M  (SURVEY.md section 8d).
+// Two device formulations of the same sweep, both bit-identical to the reference (each row's in-neighbour
+// contributions are added one by one in ascending source order by ONE lane):
+//
+//  * "blocked" (source-blocked two-phase sweep; the fast path).  A 4-byte gather from a 40 MB contribution
+//    vector moves a whole 128-byte line through the L2->L1 path: measured <= 215 G gathers/s even when the
+//    vector is L2-resident, 58 G/s from the Infinity Cache (scratch/gather_bench.hip).  So the gather is
+//    done in LDS instead:
+//      phase A `pb_expand_kernel`: the source range is cut into slices of W = 32768 nodes; a workgroup stages
+//        one slice of contrib[] in LDS (128 KiB), streams the slice's edges (u16 local source ids, stored in
+//        (slice, row-block, row, source) order), and writes val[i] = contrib[src_i] as one coalesced stream;
+//      phase B `pb_reduce_kernel`: a workgroup owns a row block (consecutive rows with <= 16384 in-edges),
+//        reads the block's pieces of every slice's value stream (contiguous runs), drops each value at its
+//        CSR position inside an LDS tile (u16 permutation), then each row is summed in order by one lane with
+//        the fused epilogue (new score, |delta| in f64, next contribution).
+//    HBM bytes per edge: 2 (local ids) + 4 (val out) + 4 (val in) + 2 (permutation) = 12 instead of the
+//    compulsory 4, all of it streaming.  The static layout (sort by slice, segment table, permutation) is
+//    built once on the device at plan creation.
+//  * "gather" (CSR-stream pull SpMV): phase 1 streams the row block's source ids and gathers contrib[src]
+//    from global memory into the LDS tile; phase 2 as above.  Used for small graphs, for shards whose slices
+//    would be too sparse, and for the rows of a blocked plan that are longer than a tile (streamed tile by
+//    tile and summed by one lane, still in order).
+//
+// Algorithmic HBM bytes per iteration (the roofline model of SURVEY.md section 8d, cache-perfect gathers):
+// 4E (ids) + 4(N+1) (offsets) + 20N (contrib in/out, score in/out, out-degree) = 6.4 B/edge at N = 10M, E = 100M.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <vector>
+
+#include <rocprim/rocprim.hpp>
 
 #include "common.h"
 
 namespace {
 
-constexpr int kThreads = 256;
-constexpr int kTileNnz = 4096;   // f32 values per LDS tile (16 KiB)
-constexpr int kMaxRowsPerBlock = 1024;
+constexpr int kGThreads = 256;      // gather kernel
+constexpr int kGTileNnz = 4096;     // f32 values per LDS tile of the gather kernel (16 KiB)
+constexpr int kBThreads = 512;      // blocked path, phase B
+constexpr int kBTileNnz = 16384;    // 64 KiB tile: two workgroups per CU
+constexpr int kAThreads = 1024;     // blocked path, phase A
+constexpr int kMaxSliceLog2 = 15;   // 32768 sources = 128 KiB of LDS
+constexpr uint32_t kPartEdges = 98304;  // phase-A work item: at most this many edges of one slice
+constexpr int kMaxRowsPerBlock = 4096;
 
 struct RowBlock {
     uint32_t row0, row1;  // local rows [row0, row1)
 };
+struct AItem {
+    uint32_t begin, end, slice, pad;  // positions [begin, end) of the slice-ordered edge stream
+};
 
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(256)
 pr_init_kernel(float *__restrict__ contrib, const uint32_t *__restrict__ out_deg, uint32_t N, float init) {
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < N; v += gridDim.x * blockDim.x)
         contrib[v] = init / (float)out_deg[v];
 }
 
-__global__ void __launch_bounds__(kThreads) pr_fill_kernel(float *__restrict__ p, uint32_t n, float v) {
+__global__ void __launch_bounds__(256) pr_fill_kernel(float *__restrict__ p, uint32_t n, float v) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
 
+template <int THREADS>
 __device__ __forceinline__ double block_sum_f64(double v, double *red) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -48,54 +77,65 @@ __device__ __forceinline__ double block_sum_f64(double v, double *red) {
     __syncthreads();
     double s = 0;
     if (threadIdx.x == 0)
-        for (int w = 0; w < kThreads / 64; w++) s += red[w];
+        for (int w = 0; w < THREADS / 64; w++) s += red[w];
     return s;  // valid on thread 0
 }
 
-__global__ void __launch_bounds__(kThreads)
+// phase 2 of both formulations: one lane per row adds its LDS segment in order; fused epilogue
+template <int THREADS>
+__device__ __forceinline__ double rows_epilogue(const RowBlock rb, const uint32_t *__restrict__ off, uint32_t e0,
+                                                const float *tile, const uint32_t *__restrict__ out_deg,
+                                                uint32_t row_begin, float *__restrict__ contrib_out,
+                                                float *__restrict__ scores, float base, float damping) {
+    double err = 0.0;
+    for (uint32_t r = rb.row0 + threadIdx.x; r < rb.row1; r += THREADS) {
+        const uint32_t a = off[r] - e0, b = off[r + 1] - e0;
+        float s = 0.0f;
+        for (uint32_t e = a; e < b; e++) s = s + tile[e];
+        const float old = scores[r];
+        const float nw = base + damping * s;  // two roundings, like the reference (no fma: -ffp-contract=off)
+        scores[r] = nw;
+        contrib_out[row_begin + r] = nw / (float)out_deg[row_begin + r];
+        err += fabs((double)(nw - old));
+    }
+    return err;
+}
+
+// ---- "gather" formulation -----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kGThreads)
 pr_step_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__ off /* local, [rows+1] */,
                const uint32_t *__restrict__ src, const uint32_t *__restrict__ out_deg /* global ids */,
                uint32_t row_begin, const float *__restrict__ contrib_in, float *__restrict__ contrib_out,
                float *__restrict__ scores /* local */, float base, float damping, double *__restrict__ partial) {
-    __shared__ float tile[kTileNnz];
-    __shared__ double red[kThreads / 64];
+    __shared__ float tile[kGTileNnz];
+    __shared__ double red[kGThreads / 64];
     const RowBlock rb = blocks[blockIdx.x];
     const int tid = threadIdx.x;
     const uint32_t e0 = off[rb.row0], e1 = off[rb.row1];
     double err = 0.0;
-    if (e1 - e0 <= (uint32_t)kTileNnz) {
+    if (e1 - e0 <= (uint32_t)kGTileNnz) {
         // phase 1: coalesced id stream + gather
         const uint32_t nnz = e1 - e0;
         uint32_t i = tid;
-        for (; i + 3 * kThreads < nnz; i += 4 * kThreads) {
-            uint32_t s0 = src[e0 + i], s1 = src[e0 + i + kThreads], s2 = src[e0 + i + 2 * kThreads],
-                     s3 = src[e0 + i + 3 * kThreads];
+        for (; i + 3 * kGThreads < nnz; i += 4 * kGThreads) {
+            uint32_t s0 = src[e0 + i], s1 = src[e0 + i + kGThreads], s2 = src[e0 + i + 2 * kGThreads],
+                     s3 = src[e0 + i + 3 * kGThreads];
             float c0 = contrib_in[s0], c1 = contrib_in[s1], c2 = contrib_in[s2], c3 = contrib_in[s3];
             tile[i] = c0;
-            tile[i + kThreads] = c1;
-            tile[i + 2 * kThreads] = c2;
-            tile[i + 3 * kThreads] = c3;
+            tile[i + kGThreads] = c1;
+            tile[i + 2 * kGThreads] = c2;
+            tile[i + 3 * kGThreads] = c3;
         }
-        for (; i < nnz; i += kThreads) tile[i] = contrib_in[src[e0 + i]];
+        for (; i < nnz; i += kGThreads) tile[i] = contrib_in[src[e0 + i]];
         __syncthreads();
-        // phase 2: one lane per row, sequential sum, fused epilogue
-        for (uint32_t r = rb.row0 + tid; r < rb.row1; r += kThreads) {
-            const uint32_t a = off[r] - e0, b = off[r + 1] - e0;
-            float s = 0.0f;
-            for (uint32_t e = a; e < b; e++) s = s + tile[e];
-            const float old = scores[r];
-            const float nw = base + damping * s;  // two roundings, like the reference (no fma: -ffp-contract=off)
-            scores[r] = nw;
-            contrib_out[row_begin + r] = nw / (float)out_deg[row_begin + r];
-            err += fabs((double)(nw - old));
-        }
+        err = rows_epilogue<kGThreads>(rb, off, e0, tile, out_deg, row_begin, contrib_out, scores, base, damping);
     } else {
         // a single long row: stream it tile by tile, lane 0 adds in order
         const uint32_t r = rb.row0;
         float s = 0.0f;
-        for (uint32_t t0 = e0; t0 < e1; t0 += kTileNnz) {
-            const uint32_t nnz = min((uint32_t)kTileNnz, e1 - t0);
-            for (uint32_t i = tid; i < nnz; i += kThreads) tile[i] = contrib_in[src[t0 + i]];
+        for (uint32_t t0 = e0; t0 < e1; t0 += kGTileNnz) {
+            const uint32_t nnz = min((uint32_t)kGTileNnz, e1 - t0);
+            for (uint32_t i = tid; i < nnz; i += kGThreads) tile[i] = contrib_in[src[t0 + i]];
             __syncthreads();
             if (tid == 0)
                 for (uint32_t e = 0; e < nnz; e++) s = s + tile[e];
@@ -109,8 +149,206 @@ pr_step_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__
             err = fabs((double)(nw - old));
         }
     }
-    const double total = block_sum_f64(err, red);
+    const double total = block_sum_f64<kGThreads>(err, red);
     if (tid == 0) partial[blockIdx.x] = total;
+}
+
+// ---- "blocked" formulation ----------------------------------------------------------------------------------
+// phase A: val[i] = contrib[slice_base + asrc[i]] for the positions of one work item, slice staged in LDS
+__global__ void __launch_bounds__(kAThreads)
+pb_expand_kernel(const AItem *__restrict__ items, const uint16_t *__restrict__ asrc,
+                 const float *__restrict__ contrib, uint32_t N, uint32_t wlog, float *__restrict__ val) {
+    __shared__ float sl[1 << kMaxSliceLog2];
+    const AItem it = items[blockIdx.x];
+    const uint32_t base = it.slice << wlog;
+    const uint32_t n = min(1u << wlog, N - base);
+    const float *c = contrib + base;
+    if ((reinterpret_cast<uintptr_t>(c) & 15) == 0) {
+        const uint32_t n4 = n & ~3u;
+        for (uint32_t i = threadIdx.x * 4; i < n4; i += kAThreads * 4) *(float4 *)(sl + i) = *(const float4 *)(c + i);
+        for (uint32_t i = n4 + threadIdx.x; i < n; i += kAThreads) sl[i] = c[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < n; i += kAThreads) sl[i] = c[i];
+    }
+    __syncthreads();
+    // 8 positions per lane per step, aligned to 8 (asrc / val are padded to a multiple of 8 past the stream's end)
+    for (uint32_t i = (it.begin & ~7u) + threadIdx.x * 8; i < it.end; i += kAThreads * 8) {
+        const uint4 k = *(const uint4 *)(asrc + i);
+        float4 v0, v1;
+        v0.x = sl[k.x & 0xffff];
+        v0.y = sl[k.x >> 16];
+        v0.z = sl[k.y & 0xffff];
+        v0.w = sl[k.y >> 16];
+        v1.x = sl[k.z & 0xffff];
+        v1.y = sl[k.z >> 16];
+        v1.z = sl[k.w & 0xffff];
+        v1.w = sl[k.w >> 16];
+        if (i >= it.begin && i + 8 <= it.end) {
+            *(float4 *)(val + i) = v0;
+            *(float4 *)(val + i + 4) = v1;
+        } else {
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (i + j >= it.begin && i + j < it.end) val[i + j] = v[j];
+        }
+    }
+}
+
+// phase B: row block b gathers its run of every slice's value stream into CSR order inside LDS, then sums rows
+__global__ void __launch_bounds__(kBThreads)
+pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint32_t *__restrict__ off,
+                 const uint2 *__restrict__ seg /* [blocks][S+1]: (stream position, block-local prefix) */, uint32_t S,
+                 const uint16_t *__restrict__ perm, const float *__restrict__ val,
+                 const uint32_t *__restrict__ out_deg, uint32_t row_begin, float *__restrict__ contrib_out,
+                 float *__restrict__ scores, float base, float damping, double *__restrict__ partial) {
+    __shared__ float tile[kBTileNnz];
+    __shared__ double red[kBThreads / 64];
+    constexpr int NW = kBThreads / 64;
+    const uint32_t b = blk0 + blockIdx.x;
+    const RowBlock rb = blocks[b];
+    const uint32_t e0 = off[rb.row0];
+    const uint2 *sg = seg + (size_t)b * (S + 1);
+    const uint16_t *pm = perm + e0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // wave w takes the segments s = w (mod NW): lane l of round g holds the descriptor of s = (g*64 + l)*NW + w
+    for (uint32_t g = 0; (g * 64) * NW + wave < S; g++) {
+        const uint32_t s = (g * 64 + lane) * NW + wave;
+        uint2 d = make_uint2(0, 0);
+        uint32_t cnt = 0;
+        if (s < S) {
+            d = sg[s];
+            cnt = sg[s + 1].y - d.y;
+        }
+        const int live = min(64u, (S - (g * 64 * NW + wave) + NW - 1) / NW);  // descriptors held by this round
+        for (int t0 = 0; t0 < live; t0 += 4) {
+            uint32_t st[4], p0[4], c[4];
+            float v[4];
+            uint32_t q[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                st[u] = __shfl(d.x, t0 + u, 64);
+                p0[u] = __shfl(d.y, t0 + u, 64);
+                c[u] = (t0 + u < live) ? __shfl(cnt, t0 + u, 64) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if ((uint32_t)lane < c[u]) {
+                    v[u] = val[st[u] + lane];
+                    q[u] = pm[p0[u] + lane];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if ((uint32_t)lane < c[u]) tile[q[u]] = v[u];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                for (uint32_t k = lane + 64; k < c[u]; k += 64) tile[pm[p0[u] + k]] = val[st[u] + k];
+        }
+    }
+    __syncthreads();
+    const double err =
+        rows_epilogue<kBThreads>(rb, off, e0, tile, out_deg, row_begin, contrib_out, scores, base, damping);
+    const double total = block_sum_f64<kBThreads>(err, red);
+    if (threadIdx.x == 0) partial[b] = total;
+}
+
+// ---- plan construction kernels (run once) -------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+pb_keys_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__ blk_chunk,
+               const uint32_t *__restrict__ off, const uint32_t *__restrict__ src, uint32_t wlog, uint32_t S,
+               uint32_t skip_key, uint32_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+    const RowBlock rb = blocks[blockIdx.x];
+    const uint32_t ch = blk_chunk[blockIdx.x];
+    const uint32_t e0 = off[rb.row0], e1 = off[rb.row1];
+    for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        keys[e] = ch == CZ_NONE ? skip_key : ch * S + (src[e] >> wlog);
+        idx[e] = e;
+    }
+}
+
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *__restrict__ a, uint32_t lo, uint32_t hi, uint32_t x) {
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < x) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256)
+pb_keyptr_kernel(const uint32_t *__restrict__ skeys, uint32_t E, uint32_t n_keys, uint32_t *__restrict__ key_ptr) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k <= n_keys) key_ptr[k] = lower_bound_u32(skeys, 0, E, k);
+}
+
+__global__ void __launch_bounds__(256)
+pb_asrc_kernel(const uint32_t *__restrict__ sidx, const uint32_t *__restrict__ src, uint32_t n, uint32_t wmask,
+               uint16_t *__restrict__ asrc) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        asrc[i] = (uint16_t)(src[sidx[i]] & wmask);
+}
+
+// stability of the sort (edge indices ascending inside every key bucket) is what the layout relies on: verify it
+__global__ void __launch_bounds__(256)
+pb_check_sorted_kernel(const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ sidx, uint32_t n,
+                       uint32_t *__restrict__ bad) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x + 1; i < n; i += gridDim.x * 256)
+        if (skeys[i] == skeys[i - 1] && sidx[i] <= sidx[i - 1]) atomicAdd(bad, 1u);
+}
+
+__global__ void __launch_bounds__(256)
+pb_seg_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__ blk_chunk, uint32_t n_blocks,
+              const uint32_t *__restrict__ off, const uint32_t *__restrict__ key_ptr,
+              const uint32_t *__restrict__ sidx, uint32_t S, uint2 *__restrict__ seg) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (uint64_t)n_blocks * S) return;
+    const uint32_t b = (uint32_t)(t / S), s = (uint32_t)(t % S);
+    const RowBlock rb = blocks[b];
+    const uint32_t key = blk_chunk[b] * S + s;
+    const uint32_t lo0 = key_ptr[key], hi0 = key_ptr[key + 1];
+    const uint32_t start = lower_bound_u32(sidx, lo0, hi0, off[rb.row0]);
+    const uint32_t end = lower_bound_u32(sidx, start, hi0, off[rb.row1]);
+    seg[(size_t)b * (S + 1) + s] = make_uint2(start, end - start);
+}
+
+// one wave per block: counts -> exclusive prefix; entry S holds the block's total
+__global__ void __launch_bounds__(64)
+pb_segscan_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__ off, uint32_t S,
+                  uint2 *__restrict__ seg, uint32_t *__restrict__ bad) {
+    uint2 *sg = seg + (size_t)blockIdx.x * (S + 1);
+    const int lane = threadIdx.x;
+    uint32_t run = 0;
+    for (uint32_t s0 = 0; s0 < S; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        const uint32_t c = s < S ? sg[s].y : 0;
+        uint32_t x = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (s < S) sg[s].y = run + x - c;
+        run += __shfl(x, 63, 64);
+    }
+    if (lane == 0) {
+        sg[S] = make_uint2(0, run);
+        const RowBlock rb = blocks[blockIdx.x];
+        if (run != off[rb.row1] - off[rb.row0]) atomicAdd(bad, 1u);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+pb_perm_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__ off, const uint2 *__restrict__ seg,
+               uint32_t S, const uint32_t *__restrict__ sidx, uint16_t *__restrict__ perm) {
+    const RowBlock rb = blocks[blockIdx.x];
+    const uint32_t e0 = off[rb.row0];
+    const uint2 *sg = seg + (size_t)blockIdx.x * (S + 1);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t s = wave; s < S; s += 4) {
+        const uint2 d = sg[s];
+        const uint32_t cnt = sg[s + 1].y - d.y;
+        for (uint32_t k = lane; k < cnt; k += 64) perm[e0 + d.y + k] = (uint16_t)(sidx[d.x + k] - e0);
+    }
 }
 
 // fixed-order reduction of the per-block partial errors; accumulates into *err_out
@@ -130,26 +368,200 @@ __global__ void __launch_bounds__(1024) pr_err_reduce_kernel(const double *__res
     }
 }
 
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
 }  // namespace
 
 struct cz_pagerank_plan {
     uint32_t N = 0, row_begin = 0, rows = 0;
     uint64_t E = 0;
     float damping = 0, base = 0, init = 0;
-    uint32_t n_blocks = 0;
-    RowBlock *d_blocks = nullptr;
+    bool blocked = false;
+    // gather formulation: every row block; blocked formulation: the long-row blocks only
+    uint32_t n_gblocks = 0;
+    RowBlock *d_gblocks = nullptr;
+    // blocked formulation
+    uint32_t wlog = 0, S = 0, n_chunks = 0, n_bblocks = 0;
+    RowBlock *d_bblocks = nullptr;
+    AItem *d_items = nullptr;
+    std::vector<uint32_t> item_ptr, blk_ptr;  // per chunk
+    uint16_t *d_asrc = nullptr, *d_perm = nullptr;
+    uint2 *d_seg = nullptr;
+    float *d_val = nullptr;
+    uint64_t E_blocked = 0;
+    // shared
     uint32_t *d_off = nullptr, *d_src = nullptr, *d_outdeg = nullptr;
     float *d_scores = nullptr;
     double *d_partial = nullptr;
     ~cz_pagerank_plan() {
-        if (d_blocks) (void)hipFree(d_blocks);
-        if (d_off) (void)hipFree(d_off);
-        if (d_src) (void)hipFree(d_src);
-        if (d_outdeg) (void)hipFree(d_outdeg);
-        if (d_scores) (void)hipFree(d_scores);
-        if (d_partial) (void)hipFree(d_partial);
+        void *ps[] = {d_gblocks, d_bblocks, d_items, d_asrc, d_perm, d_seg, d_val, d_off, d_src, d_outdeg, d_scores, d_partial};
+        for (void *p : ps)
+            if (p) (void)hipFree(p);
     }
 };
+
+namespace {
+
+// cut [0, rows) into row blocks: consecutive rows whose in-edges fit one tile; a row longer than a tile is alone
+int cut_row_blocks(const uint32_t *in_offsets, uint32_t rows, uint32_t tile, std::vector<RowBlock> &blocks) {
+    blocks.clear();
+    blocks.reserve((size_t)(in_offsets[rows] / tile) + rows / kMaxRowsPerBlock + 16);
+    uint32_t r = 0;
+    while (r < rows) {
+        uint32_t r1 = r + 1;
+        if (in_offsets[r1] - in_offsets[r] <= tile) {
+            const uint32_t lim = std::min<uint32_t>(rows, r + kMaxRowsPerBlock);
+            while (r1 < lim && in_offsets[r1 + 1] - in_offsets[r] <= tile) r1++;
+        }
+        blocks.push_back({r, r1});
+        r = r1;
+    }
+    return CZ_OK;
+}
+
+// builds the static layout of the blocked formulation on the device; p->d_off / d_src / d_outdeg are resident
+int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uint32_t n_chunks) {
+    const uint32_t rows = p->rows;
+    const uint64_t E = p->E;
+    std::vector<RowBlock> all;
+    cut_row_blocks(h_off, rows, kBTileNnz, all);
+    std::vector<RowBlock> bb, gb;  // blocked / long-row
+    uint64_t e_blocked = 0;
+    for (const RowBlock &rb : all) {
+        const uint32_t nnz = h_off[rb.row1] - h_off[rb.row0];
+        if (nnz > (uint32_t)kBTileNnz) gb.push_back(rb);
+        else {
+            bb.push_back(rb);
+            e_blocked += nnz;
+        }
+    }
+    const uint32_t S = (uint32_t)(((uint64_t)p->N + (1u << wlog) - 1) >> wlog);
+    n_chunks = std::max(1u, std::min<uint32_t>(n_chunks, (uint32_t)std::max<size_t>(1, bb.size())));
+    if ((uint64_t)n_chunks * S + 1 >= (1ull << 31)) return cz::set_error(CZ_E_UNSUPPORTED, "too many slices");
+    // chunks: consecutive blocked row blocks holding about e_blocked / n_chunks edges each
+    std::vector<uint32_t> blk_ptr(1, 0), chunk_of(bb.size());
+    {
+        uint64_t acc = 0;
+        uint32_t c = 0;
+        for (size_t i = 0; i < bb.size(); i++) {
+            if (c + 1 < n_chunks && i > blk_ptr.back() && acc >= (e_blocked * (c + 1)) / n_chunks) {
+                blk_ptr.push_back((uint32_t)i);
+                c++;
+            }
+            chunk_of[i] = c;
+            acc += h_off[bb[i].row1] - h_off[bb[i].row0];
+        }
+        blk_ptr.push_back((uint32_t)bb.size());
+        n_chunks = (uint32_t)blk_ptr.size() - 1;
+    }
+    p->wlog = wlog;
+    p->S = S;
+    p->n_chunks = n_chunks;
+    p->n_bblocks = (uint32_t)bb.size();
+    p->n_gblocks = (uint32_t)gb.size();
+    p->blk_ptr = blk_ptr;
+    p->E_blocked = e_blocked;
+    const uint32_t n_keys = n_chunks * S;  // key n_keys = "not in the blocked layout" (long rows)
+    // key pass works on the block list [blocked..., long...]
+    std::vector<RowBlock> key_blocks(bb);
+    key_blocks.insert(key_blocks.end(), gb.begin(), gb.end());
+    std::vector<uint32_t> key_chunk(chunk_of);
+    key_chunk.resize(key_blocks.size(), CZ_NONE);
+
+    CZ_HIP(hipMalloc((void **)&p->d_bblocks, std::max<size_t>(1, bb.size()) * sizeof(RowBlock)));
+    if (!bb.empty()) CZ_HIP(hipMemcpy(p->d_bblocks, bb.data(), bb.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
+    CZ_HIP(hipMalloc((void **)&p->d_gblocks, std::max<size_t>(1, gb.size()) * sizeof(RowBlock)));
+    if (!gb.empty()) CZ_HIP(hipMemcpy(p->d_gblocks, gb.data(), gb.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
+
+    cz::DevBuf<RowBlock> d_kblocks;
+    cz::DevBuf<uint32_t> d_kchunk, keys_in, keys_out, idx_in, idx_out, d_keyptr, d_bad;
+    cz::DevBuf<char> d_tmp;
+    CZ_HIP(d_kblocks.alloc(key_blocks.size()));
+    CZ_HIP(d_kchunk.alloc(key_blocks.size()));
+    CZ_HIP(hipMemcpy(d_kblocks.p, key_blocks.data(), key_blocks.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
+    CZ_HIP(hipMemcpy(d_kchunk.p, key_chunk.data(), key_chunk.size() * 4, hipMemcpyHostToDevice));
+    CZ_HIP(keys_in.alloc(E));
+    CZ_HIP(keys_out.alloc(E));
+    CZ_HIP(idx_in.alloc(E));
+    CZ_HIP(idx_out.alloc(E));
+    CZ_HIP(d_keyptr.alloc((size_t)n_keys + 2));
+    CZ_HIP(d_bad.alloc(1));
+    CZ_HIP(hipMemset(d_bad.p, 0, 4));
+    hipLaunchKernelGGL(pb_keys_kernel, dim3((uint32_t)key_blocks.size()), dim3(256), 0, nullptr, d_kblocks.p, d_kchunk.p,
+                       p->d_off, p->d_src, wlog, S, n_keys, keys_in.p, idx_in.p);
+    unsigned bits = 1;
+    while ((1ull << bits) <= n_keys) bits++;
+    size_t tmp_bytes = 0;
+    CZ_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in.p, keys_out.p, idx_in.p, idx_out.p, (size_t)E, 0u, bits,
+                                     (hipStream_t) nullptr));
+    CZ_HIP(d_tmp.alloc(tmp_bytes));
+    CZ_HIP(rocprim::radix_sort_pairs((void *)d_tmp.p, tmp_bytes, keys_in.p, keys_out.p, idx_in.p, idx_out.p, (size_t)E, 0u,
+                                     bits, (hipStream_t) nullptr));
+    keys_in.reset();
+    idx_in.reset();
+    d_tmp.reset();
+    hipLaunchKernelGGL(pb_keyptr_kernel, dim3((n_keys + 256) / 256), dim3(256), 0, nullptr, keys_out.p, (uint32_t)E, n_keys,
+                       d_keyptr.p);
+    std::vector<uint32_t> key_ptr((size_t)n_keys + 1);
+    CZ_HIP(hipMemcpy(key_ptr.data(), d_keyptr.p, key_ptr.size() * 4, hipMemcpyDeviceToHost));
+    if (key_ptr[n_keys] != e_blocked)
+        return cz::set_error(CZ_E_HIP, "blocked PageRank layout: %u edges sorted into slices, expected %llu", key_ptr[n_keys],
+                             (unsigned long long)e_blocked);
+    const uint32_t EB = (uint32_t)e_blocked;
+    hipLaunchKernelGGL(pb_check_sorted_kernel, dim3(2048), dim3(256), 0, nullptr, keys_out.p, idx_out.p, EB, d_bad.p);
+    // phase-A streams (padded to a multiple of 8 entries plus one vector so that aligned 16-byte loads stay inside)
+    const size_t padded = (((size_t)EB + 7) & ~(size_t)7) + 8;
+    CZ_HIP(hipMalloc((void **)&p->d_asrc, padded * 2));
+    CZ_HIP(hipMemset(p->d_asrc, 0, padded * 2));
+    CZ_HIP(hipMalloc((void **)&p->d_val, padded * 4));
+    CZ_HIP(hipMalloc((void **)&p->d_perm, std::max<uint64_t>(1, E) * 2));
+    CZ_HIP(hipMalloc((void **)&p->d_seg, std::max<size_t>(1, bb.size()) * ((size_t)S + 1) * sizeof(uint2)));
+    if (EB) hipLaunchKernelGGL(pb_asrc_kernel, dim3(4096), dim3(256), 0, nullptr, idx_out.p, p->d_src, EB, (1u << wlog) - 1, p->d_asrc);
+    if (!bb.empty()) {
+        const uint64_t pairs = (uint64_t)bb.size() * S;
+        hipLaunchKernelGGL(pb_seg_kernel, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, nullptr, d_kblocks.p, d_kchunk.p,
+                           (uint32_t)bb.size(), p->d_off, d_keyptr.p, idx_out.p, S, p->d_seg);
+        hipLaunchKernelGGL(pb_segscan_kernel, dim3((uint32_t)bb.size()), dim3(64), 0, nullptr, p->d_bblocks, p->d_off, S, p->d_seg,
+                           d_bad.p);
+        hipLaunchKernelGGL(pb_perm_kernel, dim3((uint32_t)bb.size()), dim3(256), 0, nullptr, p->d_bblocks, p->d_off, p->d_seg, S,
+                           idx_out.p, p->d_perm);
+    }
+    uint32_t bad = 0;
+    CZ_HIP(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
+    if (bad) return cz::set_error(CZ_E_HIP, "blocked PageRank layout failed its self-check (%u violations)", bad);
+    // phase-A work items: each key bucket cut into parts of <= kPartEdges positions (cuts on multiples of 8)
+    std::vector<AItem> items;
+    p->item_ptr.assign(1, 0);
+    for (uint32_t c = 0; c < n_chunks; c++) {
+        for (uint32_t s = 0; s < S; s++) {
+            const uint32_t lo = key_ptr[c * S + s], hi = key_ptr[c * S + s + 1];
+            if (hi == lo) continue;
+            const uint32_t parts = (hi - lo + kPartEdges - 1) / kPartEdges;
+            const uint32_t step = (((hi - lo + parts - 1) / parts) + 7) & ~7u;
+            for (uint32_t a = lo; a < hi;) {
+                uint32_t b = std::min<uint64_t>(hi, ((uint64_t)a + step) & ~7ull);
+                if (b <= a) b = std::min<uint64_t>(hi, (uint64_t)a + step);
+                items.push_back({a, b, s, 0});
+                a = b;
+            }
+        }
+        p->item_ptr.push_back((uint32_t)items.size());
+    }
+    CZ_HIP(hipMalloc((void **)&p->d_items, std::max<size_t>(1, items.size()) * sizeof(AItem)));
+    if (!items.empty()) CZ_HIP(hipMemcpy(p->d_items, items.data(), items.size() * sizeof(AItem), hipMemcpyHostToDevice));
+    CZ_HIP(hipDeviceSynchronize());
+    if (gb.empty()) {  // the global ids are only needed by the long-row gather
+        (void)hipFree(p->d_src);
+        p->d_src = nullptr;
+    }
+    p->blocked = true;
+    return CZ_OK;
+}
+
+}  // namespace
 
 extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree,
                                        uint32_t N, uint32_t row_begin, uint32_t row_end, float damping,
@@ -173,7 +585,9 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     const uint64_t E = rows ? in_offsets[rows] : 0;
     if (rows && in_offsets[0] != 0) return cz::set_error(CZ_E_INVALID, "in_offsets must be relative to the shard (in_offsets[0] == 0)");
     if (E > 0 && !in_sources) return cz::set_error(CZ_E_INVALID, "null in_sources");
-    if (E >= 0xFFFFFFFFull) return cz::set_error(CZ_E_UNSUPPORTED, "a shard holds at most 2^32-2 edges");
+    if (E >= 0xFFFFFFF0ull) return cz::set_error(CZ_E_UNSUPPORTED, "a shard holds at most 2^32-17 edges");
+    for (uint32_t q = 0; q < rows; q++)
+        if (in_offsets[q + 1] < in_offsets[q]) return cz::set_error(CZ_E_INVALID, "in_offsets not monotone at row %u", q);
     std::unique_ptr<cz_pagerank_plan> p(new cz_pagerank_plan());
     p->N = N;
     p->row_begin = row_begin;
@@ -182,29 +596,10 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     p->damping = damping;
     p->init = N ? 1.0f / (float)N : 0.f;
     p->base = N ? (1.0f - damping) / (float)N : 0.f;
-    // row blocks: consecutive rows whose edges fit one LDS tile
-    std::vector<RowBlock> blocks;
-    blocks.reserve((size_t)(E / kTileNnz) + rows / kMaxRowsPerBlock + 16);
-    uint32_t r = 0;
-    while (r < rows) {
-        uint32_t r1 = r + 1;
-        if (in_offsets[r1] - in_offsets[r] <= (uint32_t)kTileNnz) {
-            const uint32_t lim = std::min<uint32_t>(rows, r + kMaxRowsPerBlock);
-            while (r1 < lim && in_offsets[r1 + 1] - in_offsets[r] <= (uint32_t)kTileNnz) r1++;
-        }
-        for (uint32_t q = r; q < r1; q++)
-            if (in_offsets[q + 1] < in_offsets[q]) return cz::set_error(CZ_E_INVALID, "in_offsets not monotone at row %u", q);
-        blocks.push_back({r, r1});
-        r = r1;
-    }
-    p->n_blocks = (uint32_t)blocks.size();
-    CZ_HIP(hipMalloc((void **)&p->d_blocks, std::max<size_t>(1, blocks.size()) * sizeof(RowBlock)));
     CZ_HIP(hipMalloc((void **)&p->d_off, ((size_t)rows + 1) * 4));
     CZ_HIP(hipMalloc((void **)&p->d_src, std::max<uint64_t>(1, E) * 4));
     CZ_HIP(hipMalloc((void **)&p->d_outdeg, std::max<size_t>(1, N) * 4));
     CZ_HIP(hipMalloc((void **)&p->d_scores, std::max<size_t>(1, rows) * 4));
-    CZ_HIP(hipMalloc((void **)&p->d_partial, std::max<size_t>(1, blocks.size()) * 8));
-    if (!blocks.empty()) CZ_HIP(hipMemcpy(p->d_blocks, blocks.data(), blocks.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
     if (rows) CZ_HIP(hipMemcpy(p->d_off, dev ? dev_off : in_offsets, ((size_t)rows + 1) * 4, up));
     else {
         uint32_t z = 0;
@@ -212,6 +607,31 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     }
     if (E) CZ_HIP(hipMemcpy(p->d_src, in_sources, E * 4, up));
     if (N) CZ_HIP(hipMemcpy(p->d_outdeg, out_degree, (size_t)N * 4, up));
+
+    // formulation: explicit flag > CZ_PR_MODE (gather | blocked) > heuristic
+    int mode = 0;  // 0 auto, 1 gather, 2 blocked
+    if (flags & CZ_PR_GATHER) mode = 1;
+    else if (flags & CZ_PR_BLOCKED) mode = 2;
+    else if (const char *m = getenv("CZ_PR_MODE")) mode = !strcmp(m, "gather") ? 1 : !strcmp(m, "blocked") ? 2 : 0;
+    uint32_t wlog = (uint32_t)std::min(kMaxSliceLog2, std::max(4, env_int("CZ_PR_SLICE_LOG2", kMaxSliceLog2)));
+    const uint32_t n_chunks = (uint32_t)std::max(1, env_int("CZ_PR_CHUNKS", 1));
+    if (mode == 0) {
+        // the blocked layout pays off when a (row block, slice) run of the value stream is long enough to be a
+        // streaming read: average run = tile / #slices
+        const uint64_t S = ((uint64_t)N + (1u << wlog) - 1) >> wlog;
+        mode = (E >= (4u << 20) && (uint64_t)kBTileNnz >= 16 * S) ? 2 : 1;
+    }
+    if (mode == 2 && rows > 0 && E > 0) {
+        rc = build_blocked(p.get(), in_offsets, wlog, n_chunks);
+        if (rc) return rc;
+    } else {
+        std::vector<RowBlock> blocks;
+        if (rows) cut_row_blocks(in_offsets, rows, kGTileNnz, blocks);
+        p->n_gblocks = (uint32_t)blocks.size();
+        CZ_HIP(hipMalloc((void **)&p->d_gblocks, std::max<size_t>(1, blocks.size()) * sizeof(RowBlock)));
+        if (!blocks.empty()) CZ_HIP(hipMemcpy(p->d_gblocks, blocks.data(), blocks.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
+    }
+    CZ_HIP(hipMalloc((void **)&p->d_partial, std::max<size_t>(1, (size_t)p->n_gblocks + p->n_bblocks) * 8));
     *out = p.release();
     return CZ_OK;
 }
@@ -228,8 +648,8 @@ extern "C" int cz_pagerank_plan_init(cz_pagerank_plan *p, float *contrib_dev, vo
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     if (p->N == 0) return CZ_OK;
-    hipLaunchKernelGGL(pr_init_kernel, dim3(2048), dim3(kThreads), 0, stream, contrib_dev, p->d_outdeg, p->N, p->init);
-    if (p->rows) hipLaunchKernelGGL(pr_fill_kernel, dim3(2048), dim3(kThreads), 0, stream, p->d_scores, p->rows, p->init);
+    hipLaunchKernelGGL(pr_init_kernel, dim3(2048), dim3(256), 0, stream, contrib_dev, p->d_outdeg, p->N, p->init);
+    if (p->rows) hipLaunchKernelGGL(pr_fill_kernel, dim3(2048), dim3(256), 0, stream, p->d_scores, p->rows, p->init);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "pagerank init launch: %s", hipGetErrorString(e));
     return CZ_OK;
@@ -242,11 +662,30 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
     int rc = cz::ensure_device();
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    if (p->n_blocks == 0) return CZ_OK;
-    hipLaunchKernelGGL(pr_step_kernel, dim3(p->n_blocks), dim3(kThreads), 0, stream, p->d_blocks, p->d_off, p->d_src,
-                       p->d_outdeg, p->row_begin, contrib_in_dev, contrib_out_dev, p->d_scores, p->base, p->damping,
-                       p->d_partial);
-    hipLaunchKernelGGL(pr_err_reduce_kernel, dim3(1), dim3(1024), 0, stream, p->d_partial, p->n_blocks, err_out_dev);
+    const uint32_t n_partial = p->n_gblocks + p->n_bblocks;
+    if (n_partial == 0) return CZ_OK;
+    if (p->blocked) {
+        for (uint32_t c = 0; c < p->n_chunks; c++) {
+            const uint32_t i0 = p->item_ptr[c], i1 = p->item_ptr[c + 1];
+            const uint32_t b0 = p->blk_ptr[c], b1 = p->blk_ptr[c + 1];
+            if (i1 > i0)
+                hipLaunchKernelGGL(pb_expand_kernel, dim3(i1 - i0), dim3(kAThreads), 0, stream, p->d_items + i0, p->d_asrc,
+                                   contrib_in_dev, p->N, p->wlog, p->d_val);
+            if (b1 > b0)
+                hipLaunchKernelGGL(pb_reduce_kernel, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0, p->d_off,
+                                   p->d_seg, p->S, p->d_perm, p->d_val, p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores,
+                                   p->base, p->damping, p->d_partial);
+        }
+        if (p->n_gblocks)  // rows longer than a tile
+            hipLaunchKernelGGL(pr_step_kernel, dim3(p->n_gblocks), dim3(kGThreads), 0, stream, p->d_gblocks, p->d_off, p->d_src,
+                               p->d_outdeg, p->row_begin, contrib_in_dev, contrib_out_dev, p->d_scores, p->base, p->damping,
+                               p->d_partial + p->n_bblocks);
+    } else {
+        hipLaunchKernelGGL(pr_step_kernel, dim3(p->n_gblocks), dim3(kGThreads), 0, stream, p->d_gblocks, p->d_off, p->d_src,
+                           p->d_outdeg, p->row_begin, contrib_in_dev, contrib_out_dev, p->d_scores, p->base, p->damping,
+                           p->d_partial);
+    }
+    hipLaunchKernelGGL(pr_err_reduce_kernel, dim3(1), dim3(1024), 0, stream, p->d_partial, n_partial, err_out_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "pagerank step launch: %s", hipGetErrorString(e));
     return CZ_OK;
@@ -254,6 +693,7 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
 
 extern "C" float *cz_pagerank_plan_scores(cz_pagerank_plan *p) { return p ? p->d_scores : nullptr; }
 extern "C" uint64_t cz_pagerank_plan_edges(const cz_pagerank_plan *p) { return p ? p->E : 0; }
+extern "C" int cz_pagerank_plan_is_blocked(const cz_pagerank_plan *p) { return p && p->blocked ? 1 : 0; }
 
 extern "C" int cz_pagerank_plan_read_scores(cz_pagerank_plan *p, float *out, uint32_t flags, void *stream_) {
     if (!p || !out) return cz::set_error(CZ_E_INVALID, "null argument");

@@ -41,15 +41,20 @@ def pagerank(in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10,
 class PageRankPlan:
     """Resident / row-sharded PageRank (cz_pagerank_plan_*): rows [row_begin,row_end) of the in-CSR."""
 
-    def __init__(self, in_off_local, in_src, out_deg, N, row_begin, row_end, damping=0.85, device_ptrs=False):
-        """host arrays, or (device_ptrs=True) uint32 device tensors already resident in HBM."""
+    def __init__(self, in_off_local, in_src, out_deg, N, row_begin, row_end, damping=0.85, device_ptrs=False,
+                 mode: Optional[str] = None):
+        """host arrays, or (device_ptrs=True) uint32 device tensors already resident in HBM.
+        mode: None (chosen from the shard's shape) | "gather" | "blocked" -- the two device formulations of the
+        sweep (csrc/pagerank.hip); both give the reference's scores bit for bit."""
         if not device_ptrs:
             in_off_local, in_src = _csr32(in_off_local, in_src)
             out_deg = _u32(out_deg)
         h = C.c_void_p()
         check(_lib.lib().cz_pagerank_plan_create(ptr(in_off_local), ptr(in_src), ptr(out_deg), N, row_begin, row_end,
                                                  np.float32(damping), C.byref(h),
-                                                 _lib.CZ_DEVICE_PTRS if device_ptrs else 0))
+                                                 (_lib.CZ_DEVICE_PTRS if device_ptrs else 0)
+                                                 | {None: 0, "gather": _lib.CZ_PR_GATHER,
+                                                    "blocked": _lib.CZ_PR_BLOCKED}[mode]))
         self._h = h
         self.N, self.row_begin, self.row_end = N, row_begin, row_end
 
@@ -63,6 +68,10 @@ class PageRankPlan:
             self.close()
         except Exception:
             pass
+
+    @property
+    def blocked(self) -> bool:
+        return bool(_lib.lib().cz_pagerank_plan_is_blocked(self._h))
 
     @property
     def edges(self) -> int:

@@ -34,6 +34,10 @@ extern "C" {
 
 #define CZ_NONE 0xFFFFFFFFu
 #define CZ_DEVICE_PTRS 1u
+/* cz_pagerank_plan_create: force one of the two device formulations of the sweep (default: chosen from the
+ * shard's shape; the environment variable CZ_PR_MODE = gather | blocked overrides the default too) */
+#define CZ_PR_GATHER 2u
+#define CZ_PR_BLOCKED 4u
 
 typedef enum {
     CZ_OK = 0,
@@ -166,6 +170,8 @@ int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_in_dev, floa
 /* device pointer to this shard's scores [row_end-row_begin] */
 float *cz_pagerank_plan_scores(cz_pagerank_plan *p);
 uint64_t cz_pagerank_plan_edges(const cz_pagerank_plan *p);
+/* 1 when the plan runs the source-blocked two-phase sweep, 0 for the CSR-stream gather sweep */
+int cz_pagerank_plan_is_blocked(const cz_pagerank_plan *p);
 /* copy this shard's scores [row_end-row_begin] to `out` (host, or device with CZ_DEVICE_PTRS) */
 int cz_pagerank_plan_read_scores(cz_pagerank_plan *p, float *out, uint32_t flags, void *stream);
 

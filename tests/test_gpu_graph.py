@@ -87,6 +87,75 @@ def test_pagerank_sharded_plan_matches_single(graphs, oracle):
     assert np.array_equal(got, os_)
 
 
+def _run_plan(G, g, mode, damping=0.85, tol=1e-4, iters=10, shards=1):
+    """graph::page_rank's loop driven through the plan API (what cz_pagerank does internally)."""
+    import torch
+    n = g["n"]
+    ioff = g["ioff"].astype(np.int64)
+    cuts = [0] + [int(np.searchsorted(ioff, ioff[-1] * k // shards)) for k in range(1, shards)] + [n]
+    plans = []
+    for rb, re in zip(cuts[:-1], cuts[1:]):
+        lo = (ioff[rb:re + 1] - ioff[rb]).astype(np.uint32)
+        plans.append(G.PageRankPlan(lo, g["isrc"][ioff[rb]:ioff[re]], g["outdeg"], n, rb, re, damping, mode=mode))
+    dev = torch.device("cuda:0")
+    c0 = torch.empty(n, dtype=torch.float32, device=dev)
+    c1 = torch.empty_like(c0)
+    err = torch.zeros(1, dtype=torch.float64, device=dev)
+    for p in plans:
+        p.init(c0)
+    it = 0
+    while True:
+        err.zero_()
+        for p in plans:
+            p.step(c0, c1, err)
+        torch.cuda.synchronize()
+        c0, c1 = c1, c0
+        it += 1
+        if err.item() < tol or it == iters:
+            break
+    got = np.empty(n, dtype=np.float32)
+    for p, rb, re in zip(plans, cuts[:-1], cuts[1:]):
+        got[rb:re] = p.read_scores()
+    return got, it, err.item(), [p.blocked for p in plans]
+
+
+@pytest.fixture(scope="module")
+def hub_graph(oracle, gpu_lib):
+    """one hub whose in-row (~60k) is longer than a 16384-entry tile of the blocked sweep + ordinary rows"""
+    rng = np.random.default_rng(21)
+    n = 80000
+    src = rng.integers(0, n, 500000)
+    dst = np.where(rng.random(500000) < 0.15, 7, rng.integers(0, n, 500000))
+    keep = src != dst
+    rows = np.unique(np.stack([src[keep], dst[keep]], 1), axis=0)
+    return util.graph_from_relation(oracle, rows[:, 0].astype(np.int64), rows[:, 1].astype(np.int64))
+
+
+@pytest.mark.parametrize("slice_log2,chunks", [(15, 1), (8, 1), (4, 3), (11, 2)])
+def test_pagerank_blocked_sweep_bitexact(graphs, hub_graph, oracle, monkeypatch, slice_log2, chunks):
+    """the source-blocked two-phase sweep (csrc/pagerank.hip) on small graphs, forced, with narrow slices so that
+    every (row block, slice) run, empty runs, several chunks and the long-row side path are exercised"""
+    from cozo_amd import graph as G
+    monkeypatch.setenv("CZ_PR_SLICE_LOG2", str(slice_log2))
+    monkeypatch.setenv("CZ_PR_CHUNKS", str(chunks))
+    for g in graphs + [hub_graph]:
+        if slice_log2 == 4 and g["n"] > 30000:
+            continue
+        for tol, iters in [(1e-4, 10), (0.0, 6)]:
+            os_, oit, oerr = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, tol, iters)
+            got, it, err, blocked = _run_plan(G, g, "blocked", 0.85, tol, iters)
+            assert blocked == [True]
+            assert it == oit
+            assert np.array_equal(got, os_), "blocked sweep: scores must be bit-identical"
+            assert err == pytest.approx(oerr, rel=1e-9)
+    # the two formulations agree shard by shard as well
+    g = hub_graph
+    a, ita, _, ba = _run_plan(G, g, "gather", shards=3)
+    b, itb, _, bb = _run_plan(G, g, "blocked", shards=3)
+    assert ba == [False] * 3 and bb == [True] * 3
+    assert ita == itb and np.array_equal(a, b)
+
+
 def test_shortest_path_bfs_paths(graphs, oracle):
     from cozo_amd import graph as G
     for g in graphs[:3]:
