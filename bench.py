@@ -33,6 +33,20 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling there: 6290 GB/s
 
 
+def pmc_traffic(key, world):
+    """HBM bytes per launch of the dominant kernel(s) from the committed rocprofv3 --pmc summary of this same
+    workload (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied there).
+    PMC counters cannot be collected from inside the timed run; None when no summary is committed or the
+    workload differs from the profiled one (N > 1)."""
+    if world != 1:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)[key]["bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
@@ -181,7 +195,7 @@ def bench_hnsw(args, torch, dist, rank, world, device):
     res = dict(qps=world * B * args.steps / wall, ms_per_step=wall / args.steps * 1e3, ef=ef, recall=rec,
                n_dist_per_query=n_dist / B, build_s=build_s, build_n_dist=build_nd,
                roofline=dict(bound="hbm", kernel="hnsw_knn_kernel", achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
-                             unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS, traffic=None,
+                             unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS, traffic=pmc_traffic("hnsw_knn", world),
                              algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=kern_s * 1e3),
                index_bytes=ix.device_bytes, sweep=sweep)
     # CPU baseline: the oracle (a port of the reference algorithm) on the same index and the same queries
@@ -286,10 +300,14 @@ def bench_pagerank(args, torch, dist, rank, world, device):
     torch.cuda.synchronize()
     kern_s = e0.elapsed_time(e1) / 1e3 / reps
     algo_bytes = 4 * e_kept + 4 * (rows + 1) + 20 * rows  # SURVEY 8d compulsory-traffic model, this rank's shard
+    blocked = plan.blocked
+    kernel = "pb_expand_kernel + pb_reduce_kernel (one sweep)" if blocked else "pr_step_kernel"
     res = dict(value=e_total * iters / wall, unit="edges/s", iterations=iters, ms_per_iteration=wall / iters * 1e3,
                nodes=n_total, edges=e_total, default_run=dict(iterations=it_default, final_err=err_default),
-               roofline=dict(bound="hbm", kernel="pr_step_kernel", achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
-                             unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS, traffic=None,
+               formulation="blocked" if blocked else "gather",
+               roofline=dict(bound="hbm", kernel=kernel, achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
+                             unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
+                             traffic=pmc_traffic("pagerank_blocked" if blocked else "pagerank_gather", world),
                              algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=kern_s * 1e3),
                exchange="none" if world == 1 else f"all_gather {per * 4} B/rank/iter + all_reduce f64")
     if rank == 0 and world == 1 and not args.skip_cpu:

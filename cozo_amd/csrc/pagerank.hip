@@ -44,15 +44,16 @@ namespace {
 
 constexpr int kGThreads = 256;      // gather kernel
 constexpr int kGTileNnz = 4096;     // f32 values per LDS tile of the gather kernel (16 KiB)
-constexpr int kBThreads = 512;      // blocked path, phase B
-constexpr int kBTileNnz = 16384;    // 64 KiB tile: two workgroups per CU
+constexpr int kBThreads = 1024;     // blocked path, phase B
+constexpr int kBTileNnz = 16384;    // 64 KiB tile: two workgroups (32 waves) per CU
 constexpr int kAThreads = 1024;     // blocked path, phase A
 constexpr int kMaxSliceLog2 = 15;   // 32768 sources = 128 KiB of LDS
 constexpr uint32_t kPartEdges = 98304;  // phase-A work item: at most this many edges of one slice
-constexpr int kMaxRowsPerBlock = 4096;
+constexpr int kMaxRowsPerBlock = 2048;  // = 2 rows per lane of phase B
 
 struct RowBlock {
     uint32_t row0, row1;  // local rows [row0, row1)
+    uint32_t e0, e1;      // their in-edges [e0, e1) = off[row0], off[row1]
 };
 struct AItem {
     uint32_t begin, end, slice, pad;  // positions [begin, end) of the slice-ordered edge stream
@@ -111,7 +112,7 @@ pr_step_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__
     __shared__ double red[kGThreads / 64];
     const RowBlock rb = blocks[blockIdx.x];
     const int tid = threadIdx.x;
-    const uint32_t e0 = off[rb.row0], e1 = off[rb.row1];
+    const uint32_t e0 = rb.e0, e1 = rb.e1;
     double err = 0.0;
     if (e1 - e0 <= (uint32_t)kGTileNnz) {
         // phase 1: coalesced id stream + gather
@@ -154,12 +155,23 @@ pr_step_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__
 }
 
 // ---- "blocked" formulation ----------------------------------------------------------------------------------
-// phase A: val[i] = contrib[slice_base + asrc[i]] for the positions of one work item, slice staged in LDS
+// phase A: val[i] = contrib[slice_base + asrc[i]] for the positions of one work item, slice staged in LDS.
+// A workgroup step covers 4096 positions: lane t loads 4 local ids (8 bytes) and stores 4 values (16 bytes), so
+// that every wave store is one contiguous KiB; the first id vectors are requested before the slice is staged.
 __global__ void __launch_bounds__(kAThreads)
 pb_expand_kernel(const AItem *__restrict__ items, const uint16_t *__restrict__ asrc,
                  const float *__restrict__ contrib, uint32_t N, uint32_t wlog, float *__restrict__ val) {
     __shared__ float sl[1 << kMaxSliceLog2];
+    constexpr int PF = 4;
+    constexpr uint32_t STEP = kAThreads * 4;
     const AItem it = items[blockIdx.x];
+    const uint32_t a0 = (it.begin & ~3u) + threadIdx.x * 4;
+    uint2 k[PF];
+#pragma unroll
+    for (int j = 0; j < PF; j++) {
+        const uint32_t i = a0 + j * STEP;
+        k[j] = i < it.end ? *(const uint2 *)(asrc + i) : make_uint2(0, 0);
+    }
     const uint32_t base = it.slice << wlog;
     const uint32_t n = min(1u << wlog, N - base);
     const float *c = contrib + base;
@@ -171,32 +183,36 @@ pb_expand_kernel(const AItem *__restrict__ items, const uint16_t *__restrict__ a
         for (uint32_t i = threadIdx.x; i < n; i += kAThreads) sl[i] = c[i];
     }
     __syncthreads();
-    // 8 positions per lane per step, aligned to 8 (asrc / val are padded to a multiple of 8 past the stream's end)
-    for (uint32_t i = (it.begin & ~7u) + threadIdx.x * 8; i < it.end; i += kAThreads * 8) {
-        const uint4 k = *(const uint4 *)(asrc + i);
-        float4 v0, v1;
-        v0.x = sl[k.x & 0xffff];
-        v0.y = sl[k.x >> 16];
-        v0.z = sl[k.y & 0xffff];
-        v0.w = sl[k.y >> 16];
-        v1.x = sl[k.z & 0xffff];
-        v1.y = sl[k.z >> 16];
-        v1.z = sl[k.w & 0xffff];
-        v1.w = sl[k.w >> 16];
-        if (i >= it.begin && i + 8 <= it.end) {
-            *(float4 *)(val + i) = v0;
-            *(float4 *)(val + i + 4) = v1;
-        } else {
-            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    for (uint32_t i0 = a0; i0 < it.end; i0 += PF * STEP) {
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                if (i + j >= it.begin && i + j < it.end) val[i + j] = v[j];
+        for (int j = 0; j < PF; j++) {
+            const uint32_t i = i0 + j * STEP;
+            if (i < it.end) {
+                float4 v;
+                v.x = sl[k[j].x & 0xffff];
+                v.y = sl[k[j].x >> 16];
+                v.z = sl[k[j].y & 0xffff];
+                v.w = sl[k[j].y >> 16];
+                if (i >= it.begin && i + 4 <= it.end) {
+                    *(float4 *)(val + i) = v;
+                } else {
+                    if (i >= it.begin) val[i] = v.x;
+                    if (i + 1 >= it.begin && i + 1 < it.end) val[i + 1] = v.y;
+                    if (i + 2 >= it.begin && i + 2 < it.end) val[i + 2] = v.z;
+                    if (i + 3 >= it.begin && i + 3 < it.end) val[i + 3] = v.w;
+                }
+            }
+            const uint32_t i2 = i + PF * STEP;
+            k[j] = i2 < it.end ? *(const uint2 *)(asrc + i2) : make_uint2(0, 0);
         }
     }
 }
 
-// phase B: row block b gathers its run of every slice's value stream into CSR order inside LDS, then sums rows
-__global__ void __launch_bounds__(kBThreads)
+// phase B: row block b gathers its run of every slice's value stream into CSR order inside LDS, then sums rows.
+// A run is short (tile / #slices entries), so the kernel lives on loads in flight: 32 waves per CU, 8 runs
+// requested per wave before the first value is placed, and the rows' own data (offsets, old score, out-degree)
+// requested before the runs so that nothing is fetched after the barrier.
+__global__ void __launch_bounds__(kBThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
 pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint32_t *__restrict__ off,
                  const uint2 *__restrict__ seg /* [blocks][S+1]: (stream position, block-local prefix) */, uint32_t S,
                  const uint16_t *__restrict__ perm, const float *__restrict__ val,
@@ -205,49 +221,86 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
     __shared__ float tile[kBTileNnz];
     __shared__ double red[kBThreads / 64];
     constexpr int NW = kBThreads / 64;
+    constexpr int RPL = kMaxRowsPerBlock / kBThreads;  // rows per lane
+    constexpr int U = 10;
     const uint32_t b = blk0 + blockIdx.x;
     const RowBlock rb = blocks[b];
-    const uint32_t e0 = off[rb.row0];
+    const uint32_t e0 = rb.e0;
     const uint2 *sg = seg + (size_t)b * (S + 1);
     const uint16_t *pm = perm + e0;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // wave w takes the segments s = w (mod NW): lane l of round g holds the descriptor of s = (g*64 + l)*NW + w
-    for (uint32_t g = 0; (g * 64) * NW + wave < S; g++) {
-        const uint32_t s = (g * 64 + lane) * NW + wave;
-        uint2 d = make_uint2(0, 0);
-        uint32_t cnt = 0;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    // first descriptors of this wave: lane l of round g holds the run of slice s = (g*64 + l)*NW + wave
+    uint2 d = make_uint2(0, 0);
+    uint32_t cnt = 0;
+    {
+        const uint32_t s = lane * NW + wave;
         if (s < S) {
             d = sg[s];
             cnt = sg[s + 1].y - d.y;
         }
-        const int live = min(64u, (S - (g * 64 * NW + wave) + NW - 1) / NW);  // descriptors held by this round
-        for (int t0 = 0; t0 < live; t0 += 4) {
-            uint32_t st[4], p0[4], c[4];
-            float v[4];
-            uint32_t q[4];
+    }
+    uint32_t ra[RPL], rz[RPL], od[RPL];
+    float old[RPL];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                st[u] = __shfl(d.x, t0 + u, 64);
-                p0[u] = __shfl(d.y, t0 + u, 64);
-                c[u] = (t0 + u < live) ? __shfl(cnt, t0 + u, 64) : 0;
+    for (int j = 0; j < RPL; j++) {
+        const uint32_t r = rb.row0 + threadIdx.x + j * kBThreads;
+        if (r < rb.row1) {
+            ra[j] = off[r] - e0;
+            rz[j] = off[r + 1] - e0;
+            old[j] = scores[r];
+            od[j] = out_deg[row_begin + r];
+        }
+    }
+    for (uint32_t g = 0; (g * 64) * NW + wave < S; g++) {
+        if (g > 0) {
+            const uint32_t s = (g * 64 + lane) * NW + wave;
+            d = make_uint2(0, 0);
+            cnt = 0;
+            if (s < S) {
+                d = sg[s];
+                cnt = sg[s + 1].y - d.y;
+            }
+        }
+        const uint32_t live = min(64u, (S - (g * 64 * NW + wave) + NW - 1) / NW);  // descriptors held this round
+        for (uint32_t t0 = 0; t0 < live; t0 += U) {
+            uint32_t st[U], p0[U], c[U], q[U];
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t t = min(t0 + u, 63u);
+                st[u] = __builtin_amdgcn_readlane(d.x, t);
+                p0[u] = __builtin_amdgcn_readlane(d.y, t);
+                c[u] = t0 + u < live ? __builtin_amdgcn_readlane(cnt, t) : 0;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                if ((uint32_t)lane < c[u]) {
+            for (int u = 0; u < U; u++)
+                if (lane < c[u]) {
                     v[u] = val[st[u] + lane];
                     q[u] = pm[p0[u] + lane];
                 }
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                if ((uint32_t)lane < c[u]) tile[q[u]] = v[u];
+            for (int u = 0; u < U; u++)
+                if (lane < c[u]) tile[q[u]] = v[u];
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < U; u++)
                 for (uint32_t k = lane + 64; k < c[u]; k += 64) tile[pm[p0[u] + k]] = val[st[u] + k];
         }
     }
     __syncthreads();
-    const double err =
-        rows_epilogue<kBThreads>(rb, off, e0, tile, out_deg, row_begin, contrib_out, scores, base, damping);
+    double err = 0.0;
+#pragma unroll
+    for (int j = 0; j < RPL; j++) {
+        const uint32_t r = rb.row0 + threadIdx.x + j * kBThreads;
+        if (r < rb.row1) {
+            float s = 0.0f;
+            for (uint32_t e = ra[j]; e < rz[j]; e++) s = s + tile[e];
+            const float nw = base + damping * s;  // two roundings, like the reference (no fma: -ffp-contract=off)
+            scores[r] = nw;
+            contrib_out[row_begin + r] = nw / (float)od[j];
+            err += fabs((double)(nw - old[j]));
+        }
+    }
     const double total = block_sum_f64<kBThreads>(err, red);
     if (threadIdx.x == 0) partial[b] = total;
 }
@@ -259,7 +312,7 @@ pb_keys_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__
                uint32_t skip_key, uint32_t *__restrict__ keys, uint32_t *__restrict__ idx) {
     const RowBlock rb = blocks[blockIdx.x];
     const uint32_t ch = blk_chunk[blockIdx.x];
-    const uint32_t e0 = off[rb.row0], e1 = off[rb.row1];
+    const uint32_t e0 = rb.e0, e1 = rb.e1;
     for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) {
         keys[e] = ch == CZ_NONE ? skip_key : ch * S + (src[e] >> wlog);
         idx[e] = e;
@@ -306,8 +359,8 @@ pb_seg_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__ 
     const RowBlock rb = blocks[b];
     const uint32_t key = blk_chunk[b] * S + s;
     const uint32_t lo0 = key_ptr[key], hi0 = key_ptr[key + 1];
-    const uint32_t start = lower_bound_u32(sidx, lo0, hi0, off[rb.row0]);
-    const uint32_t end = lower_bound_u32(sidx, start, hi0, off[rb.row1]);
+    const uint32_t start = lower_bound_u32(sidx, lo0, hi0, rb.e0);
+    const uint32_t end = lower_bound_u32(sidx, start, hi0, rb.e1);
     seg[(size_t)b * (S + 1) + s] = make_uint2(start, end - start);
 }
 
@@ -333,7 +386,7 @@ pb_segscan_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restric
     if (lane == 0) {
         sg[S] = make_uint2(0, run);
         const RowBlock rb = blocks[blockIdx.x];
-        if (run != off[rb.row1] - off[rb.row0]) atomicAdd(bad, 1u);
+        if (run != rb.e1 - rb.e0) atomicAdd(bad, 1u);
     }
 }
 
@@ -341,7 +394,7 @@ __global__ void __launch_bounds__(256)
 pb_perm_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__ off, const uint2 *__restrict__ seg,
                uint32_t S, const uint32_t *__restrict__ sidx, uint16_t *__restrict__ perm) {
     const RowBlock rb = blocks[blockIdx.x];
-    const uint32_t e0 = off[rb.row0];
+    const uint32_t e0 = rb.e0;
     const uint2 *sg = seg + (size_t)blockIdx.x * (S + 1);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (uint32_t s = wave; s < S; s += 4) {
@@ -416,7 +469,7 @@ int cut_row_blocks(const uint32_t *in_offsets, uint32_t rows, uint32_t tile, std
             const uint32_t lim = std::min<uint32_t>(rows, r + kMaxRowsPerBlock);
             while (r1 < lim && in_offsets[r1 + 1] - in_offsets[r] <= tile) r1++;
         }
-        blocks.push_back({r, r1});
+        blocks.push_back({r, r1, in_offsets[r], in_offsets[r1]});
         r = r1;
     }
     return CZ_OK;
@@ -431,7 +484,7 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
     std::vector<RowBlock> bb, gb;  // blocked / long-row
     uint64_t e_blocked = 0;
     for (const RowBlock &rb : all) {
-        const uint32_t nnz = h_off[rb.row1] - h_off[rb.row0];
+        const uint32_t nnz = rb.e1 - rb.e0;
         if (nnz > (uint32_t)kBTileNnz) gb.push_back(rb);
         else {
             bb.push_back(rb);
@@ -452,7 +505,7 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
                 c++;
             }
             chunk_of[i] = c;
-            acc += h_off[bb[i].row1] - h_off[bb[i].row0];
+            acc += bb[i].e1 - bb[i].e0;
         }
         blk_ptr.push_back((uint32_t)bb.size());
         n_chunks = (uint32_t)blk_ptr.size() - 1;

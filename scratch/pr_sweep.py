@@ -34,8 +34,12 @@ def main():
     print(f"graph n={n} E={E} skew={skew} maxdeg={int((off[1:].to(torch.int64)-off[:-1].to(torch.int64)).max())}", flush=True)
     stream = torch.cuda.current_stream().cuda_stream
     ref = None
-    for mode, env in [("gather", {}), ("blocked", {}), ("blocked", {"CZ_PR_CHUNKS": "4"}), ("blocked", {"CZ_PR_CHUNKS": "8"}),
-                      ("blocked", {"CZ_PR_SLICE_LOG2": "14"}), ("blocked", {"CZ_PR_SLICE_LOG2": "14", "CZ_PR_CHUNKS": "4"})]:
+    cfgs = [("gather", {}), ("blocked", {}), ("blocked", {"CZ_PR_SLICE_LOG2": "14"})]
+    if os.environ.get("PR_SWEEP") == "chunks":
+        cfgs = [("gather", {}), ("blocked", {}), ("blocked", {"CZ_PR_CHUNKS": "2"}), ("blocked", {"CZ_PR_CHUNKS": "4"})]
+    if os.environ.get("PR_SWEEP") == "blocked_only":
+        cfgs = [("blocked", {})]
+    for mode, env in cfgs:
         for k in ("CZ_PR_CHUNKS", "CZ_PR_SLICE_LOG2"):
             os.environ.pop(k, None)
         os.environ.update(env)
