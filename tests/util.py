@@ -50,3 +50,53 @@ def graph_from_relation(O, frm, to, undirected=False, weights=None):
                     outdeg=np.diff(ooff).astype(np.uint32))
     ooff, otgt, ow = O.build_csr(n, fi, ti, weights=weights, undirected=undirected)
     return dict(n=n, fi=fi, ti=ti, ind=ind, ooff=ooff, otgt=otgt, ow=ow)
+
+
+class OracleGraphBackend:
+    """Stands in for cozo_amd.graph's four entry points on a box without a GPU, so that the host logic of
+    cozo_amd/fixed_rule.py (option parsing, id mapping, CSR build, row emission) is testable on CPU.
+    TEST-ONLY: the product never routes through it."""
+
+    def __init__(self, O):
+        self.O = O
+
+    def install(self, monkeypatch):
+        import cozo_amd.graph as G
+        for name in ("pagerank", "bfs", "connected_components", "sssp"):
+            monkeypatch.setattr(G, name, getattr(self, name))
+
+    def pagerank(self, in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10, poison=None):
+        return self.O.pagerank(len(out_deg), in_off, in_src, out_deg, damping, tolerance, max_iter)
+
+    def bfs(self, out_off, out_tgt, starts, goals=None, share_visited=False, want_depth=False, want_order=False,
+            poison=None):
+        O = self.O
+        n = len(out_off) - 1
+        S = len(starts)
+        parent = np.full((S, n), O.NONE, dtype=np.uint32)
+        order = np.full((S, n), O.NONE, dtype=np.uint32) if want_order else None
+        reached = np.zeros(S, dtype=np.uint32)
+        visited = np.zeros(n, dtype=np.uint8)
+        for si, s in enumerate(starts):
+            if goals is not None:
+                parent[si] = O.shortest_path_bfs(n, out_off, out_tgt, int(s), goals)
+                continue
+            if not share_visited:
+                visited = np.zeros(n, dtype=np.uint8)
+            o, p, visited = O.bfs_order(n, out_off, out_tgt, int(s), visited, parent[si].copy())
+            parent[si] = p
+            reached[si] = len(o)
+            if want_order:
+                order[si, :len(o)] = o
+        return parent, None, order, reached
+
+    def connected_components(self, off, tgt, poison=None):
+        return self.O.tarjan_groups(len(off) - 1, off, tgt)
+
+    def sssp(self, out_off, out_tgt, weights, starts, poison=None):
+        n = len(out_off) - 1
+        dist = np.empty((len(starts), n), dtype=np.float32)
+        parent = np.empty((len(starts), n), dtype=np.uint32)
+        for si, s in enumerate(starts):
+            dist[si], parent[si] = self.O.dijkstra(n, out_off, out_tgt, weights, int(s))
+        return dist, parent
