@@ -1,0 +1,149 @@
+"""The N > 1 form of the hot path (cozo_amd/distributed.py), world_size 2 over gloo on CPU.
+
+The exchange logic (row partition, in-place all-gather of the contribution slice, all-reduced stopping rule;
+all-gather + merge of per-shard k-NN lists) is what is under test; the local compute is a numpy restatement of
+one row-shard sweep here (on the GPU box the same callables are bound to cz_pagerank_plan_step /
+cz_hnsw_search_batch, bench.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import util
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _shard_step_factory(n, ioff, isrc, outdeg, rb, re, damping):
+    """one Jacobi sweep over rows [rb, re): sequential f32 sums in sorted in-neighbour order (graph::page_rank)"""
+    d = np.float32(damping)
+    base = (np.float32(1.0) - d) / np.float32(n)
+    init = np.float32(1.0) / np.float32(n)
+    state = {"scores": np.full(re - rb, init, dtype=np.float32)}
+
+    def local_init(contrib):
+        with np.errstate(divide="ignore"):
+            contrib[:n] = torch.from_numpy((np.full(n, init, dtype=np.float32) / outdeg.astype(np.float32)))
+        state["scores"][:] = init
+
+    def local_step(cin, cout, err):
+        c = cin.numpy()
+        o = cout.numpy()
+        e = 0.0
+        for r in range(rb, re):
+            s = np.float32(0)
+            for k in range(int(ioff[r]), int(ioff[r + 1])):
+                s = np.float32(s + c[isrc[k]])
+            nw = np.float32(base + np.float32(d * s))
+            e += abs(float(np.float32(nw - state["scores"][r - rb])))
+            state["scores"][r - rb] = nw
+            with np.errstate(divide="ignore"):
+                o[r] = nw / np.float32(outdeg[r])
+        err += e
+
+    return local_init, local_step, state
+
+
+def _pagerank_worker(rank, world, port, n, ioff, isrc, outdeg, tol, max_iter, q):
+    from cozo_amd.distributed import ShardedPageRank, equal_row_partition
+    _init(rank, world, port)
+    per, ranges = equal_row_partition(n, world)
+    rb, re = ranges[rank]
+    li, ls, state = _shard_step_factory(n, ioff, isrc, outdeg, rb, re, 0.85)
+    sp = ShardedPageRank(n, rank, world, torch.device("cpu"), li, ls)
+    it, err = sp.run(tol, max_iter)
+    q.put((rank, rb, re, state["scores"].copy(), it, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,e,tol,max_iter", [(301, 2500, 1e-4, 10), (64, 400, 0.0, 5), (7, 12, 1e-4, 10)])
+def test_sharded_pagerank_world2_matches_single_process(oracle, n, e, tol, max_iter):
+    frm, to = util.random_relation(n, e, 17)
+    g = util.graph_from_relation(oracle, frm, to)
+    want, want_it, want_err = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, tol, max_iter)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pagerank_worker, args=(r, 2, port, g["n"], g["ioff"], g["isrc"], g["outdeg"], tol,
+                                                         max_iter, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got = np.concatenate([r[3] for r in res])
+    assert [r[4] for r in res] == [want_it, want_it]  # both ranks stop at the same iteration, same as one process
+    assert np.array_equal(got, want)  # row sharding does not change a single bit of the scores
+    # the error is a sum of per-rank partial sums: equal up to the f64 reassociation of two partials
+    assert abs(res[0][5] - want_err) <= 1e-12 * max(1.0, abs(want_err)) and res[0][5] == res[1][5]
+
+
+def _topk_worker(rank, world, port, base, queries, k, q):
+    from cozo_amd.distributed import merge_shard_topk
+    _init(rank, world, port)
+    per = (base.shape[0] + world - 1) // world
+    lo, hi = rank * per, min(base.shape[0], (rank + 1) * per)
+    shard = base[lo:hi].astype(np.float64)
+    d = ((queries[:, None, :].astype(np.float64) - shard[None, :, :]) ** 2).sum(-1)  # [B][n_shard]
+    kk = min(k, hi - lo)
+    idx = np.argsort(d, axis=1, kind="stable")[:, :kk]
+    ids = np.full((queries.shape[0], k), 0xFFFFFFFF, dtype=np.int64)
+    dd = np.full((queries.shape[0], k), np.inf)
+    ids[:, :kk] = idx
+    dd[:, :kk] = np.take_along_axis(d, idx, 1)
+    mi, md = merge_shard_topk(torch.from_numpy(ids), torch.from_numpy(dd), lo, k, world)
+    q.put((rank, mi.numpy(), md.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,k", [(200, 10), (13, 10)])
+def test_shard_topk_merge_world2(n, k):
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((n, 16)).astype(np.float32)
+    base[3] = base[n - 2]  # an exact distance tie across shards: ordered by id
+    queries = rng.standard_normal((9, 16)).astype(np.float32)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_topk_worker, args=(r, 2, port, base, queries, k, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d = ((queries[:, None, :].astype(np.float64) - base[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    order = np.lexsort((np.broadcast_to(np.arange(n), d.shape), d), axis=1)[:, :k]
+    for _, mi, md in res:  # every rank holds the same merged result = the global top-k by (distance, id)
+        assert np.array_equal(mi[:, :min(k, n)], order[:, :min(k, n)])
+        assert np.array_equal(md[:, :min(k, n)], np.take_along_axis(d, order, 1)[:, :min(k, n)])
+    assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_equal_row_partition_covers_rows():
+    from cozo_amd.distributed import equal_row_partition
+    for n in (0, 1, 7, 8, 1000003):
+        for w in (1, 2, 3, 8):
+            per, ranges = equal_row_partition(n, w)
+            assert per * w >= n and ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            assert all(0 <= hi - lo <= per for lo, hi in ranges)
