@@ -2,6 +2,7 @@
 // exhaustive k-NN.  Kernels: hnsw_kernels.cuh (search), this file (pairs, brute force).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -276,17 +277,17 @@ bf_merge_kernel(const uint64_t *__restrict__ part_key, const uint32_t *__restric
 // ------------------------------------------------------------------------------------------------
 #define CZ_DISPATCH_SHAPE(SH, CALL)                                            \
     do {                                                                       \
-        if ((SH).lpv == 16) { CALL(16, 1, 4); }                                \
-        else if ((SH).lpv == 32) { CALL(32, 1, 4); }                           \
+        if ((SH).lpv == 16) { CALL(16, 1, 8); }                                \
+        else if ((SH).lpv == 32) { CALL(32, 1, 8); }                           \
         else switch ((SH).iters) {                                             \
-            case 1: CALL(64, 1, 4); break;                                     \
-            case 2: CALL(64, 2, 4); break;                                     \
-            case 3: CALL(64, 3, 2); break;                                     \
-            case 4: CALL(64, 4, 2); break;                                     \
-            case 5: CALL(64, 5, 1); break;                                     \
-            case 6: CALL(64, 6, 1); break;                                     \
-            case 7: CALL(64, 7, 1); break;                                     \
-            case 8: CALL(64, 8, 1); break;                                     \
+            case 1: CALL(64, 1, 8); break;                                     \
+            case 2: CALL(64, 2, 8); break;                                     \
+            case 3: CALL(64, 3, 4); break;                                     \
+            case 4: CALL(64, 4, 4); break;                                     \
+            case 5: CALL(64, 5, 2); break;                                     \
+            case 6: CALL(64, 6, 2); break;                                     \
+            case 7: CALL(64, 7, 2); break;                                     \
+            case 8: CALL(64, 8, 2); break;                                     \
             default: CALL(64, 0, 2); break;                                    \
         }                                                                      \
     } while (0)
@@ -502,7 +503,14 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
                            has_radius, radius, (uint32_t *)ws.ptr, words, d_ids, d_dist, d_count,                       \
                            (unsigned long long *)d_ndist);                                                              \
     } while (0)
-    CZ_DISPATCH_SHAPE(sh, CZ_LAUNCH_KNN);
+    // experiment knob: rows in flight per lane group for the 513..768-d shape (CZ_HNSW_U = 2 | 4 | 6 | 8)
+    const char *knn_u_env = getenv("CZ_HNSW_U");
+    const int knn_u = knn_u_env ? atoi(knn_u_env) : 0;
+    if (sh.lpv == 64 && sh.iters == 3 && knn_u == 2) CZ_LAUNCH_KNN(64, 3, 2);
+    else if (sh.lpv == 64 && sh.iters == 3 && knn_u == 4) CZ_LAUNCH_KNN(64, 3, 4);
+    else if (sh.lpv == 64 && sh.iters == 3 && knn_u == 6) CZ_LAUNCH_KNN(64, 3, 6);
+    else if (sh.lpv == 64 && sh.iters == 3 && knn_u == 8) CZ_LAUNCH_KNN(64, 3, 8);
+    else CZ_DISPATCH_SHAPE(sh, CZ_LAUNCH_KNN);
 #undef CZ_LAUNCH_KNN
     hipError_t e = hipGetLastError();
     int rc2 = ix->release(ws, stream);

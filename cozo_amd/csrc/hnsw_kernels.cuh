@@ -149,13 +149,15 @@ struct Searcher {
     }
 
     // distances from the register-resident vector (qq, qqn) to todo[0..n) -> nkey/nid   (all waves)
+    // Lane group g owns entries g, g + TG, g + 2 TG, ...; one round keeps U rows per group in flight, so a
+    // typical neighbour batch (n <= TG * U) costs ONE memory round trip instead of n / (TG * 2).
     __device__ void eval_list(const float4 (&qq)[ITERS > 0 ? ITERS : 1], float qqn, int n) {
-        for (int base = group * U; base < n; base += TG * U) {
+        for (int base = group; base < n; base += TG * U) {
             const float4 *rows[U];
             uint32_t ids[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                int j = base + u;
+                int j = base + u * TG;
                 ids[u] = j < n ? s.todo[j] : CZ_NONE;
                 rows[u] = j < n ? (const float4 *)(ix.vec + (size_t)ids[u] * ix.ld) : nullptr;
             }
@@ -164,7 +166,7 @@ struct Searcher {
             if (glane == 0) {
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    int j = base + u;
+                    int j = base + u * TG;
                     if (j < n) {
                         s.nkey[j] = dist_key(d[u]);
                         s.nid[j] = ids[u];

@@ -441,6 +441,7 @@ struct cz_pagerank_plan {
     RowBlock *d_bblocks = nullptr;
     AItem *d_items = nullptr;
     std::vector<uint32_t> item_ptr, blk_ptr;  // per chunk
+    std::vector<uint32_t> val_shift;          // per chunk: stream position that maps to d_val[0] (multiple of 4)
     uint16_t *d_asrc = nullptr, *d_perm = nullptr;
     uint2 *d_seg = nullptr;
     float *d_val = nullptr;
@@ -569,7 +570,23 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
     const size_t padded = (((size_t)EB + 7) & ~(size_t)7) + 8;
     CZ_HIP(hipMalloc((void **)&p->d_asrc, padded * 2));
     CZ_HIP(hipMemset(p->d_asrc, 0, padded * 2));
-    CZ_HIP(hipMalloc((void **)&p->d_val, padded * 4));
+    // value stream: with more than one chunk the chunks can share ONE buffer (each chunk's expand output is
+    // consumed by its reduce before the next chunk starts), which keeps it resident in the Infinity Cache
+    {
+        const bool reuse = n_chunks > 1 && env_int("CZ_PR_VAL_REUSE", 1) != 0;
+        p->val_shift.assign(n_chunks, 0);
+        size_t need = padded;
+        if (reuse) {
+            need = 0;
+            for (uint32_t c = 0; c < n_chunks; c++) {
+                const uint32_t lo = key_ptr[(size_t)c * S] & ~3u, hi = key_ptr[(size_t)(c + 1) * S];
+                p->val_shift[c] = lo;
+                need = std::max<size_t>(need, (size_t)(hi - lo));
+            }
+            need = ((need + 7) & ~(size_t)7) + 8;
+        }
+        CZ_HIP(hipMalloc((void **)&p->d_val, need * 4));
+    }
     CZ_HIP(hipMalloc((void **)&p->d_perm, std::max<uint64_t>(1, E) * 2));
     CZ_HIP(hipMalloc((void **)&p->d_seg, std::max<size_t>(1, bb.size()) * ((size_t)S + 1) * sizeof(uint2)));
     if (EB) hipLaunchKernelGGL(pb_asrc_kernel, dim3(4096), dim3(256), 0, nullptr, idx_out.p, p->d_src, EB, (1u << wlog) - 1, p->d_asrc);
@@ -721,12 +738,13 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
         for (uint32_t c = 0; c < p->n_chunks; c++) {
             const uint32_t i0 = p->item_ptr[c], i1 = p->item_ptr[c + 1];
             const uint32_t b0 = p->blk_ptr[c], b1 = p->blk_ptr[c + 1];
+            float *val = p->d_val - p->val_shift[c];  // stream position i of this chunk lives at val[i]
             if (i1 > i0)
                 hipLaunchKernelGGL(pb_expand_kernel, dim3(i1 - i0), dim3(kAThreads), 0, stream, p->d_items + i0, p->d_asrc,
-                                   contrib_in_dev, p->N, p->wlog, p->d_val);
+                                   contrib_in_dev, p->N, p->wlog, val);
             if (b1 > b0)
                 hipLaunchKernelGGL(pb_reduce_kernel, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0, p->d_off,
-                                   p->d_seg, p->S, p->d_perm, p->d_val, p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores,
+                                   p->d_seg, p->S, p->d_perm, val, p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores,
                                    p->base, p->damping, p->d_partial);
         }
         if (p->n_gblocks)  // rows longer than a tile
