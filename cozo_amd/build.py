@@ -62,5 +62,38 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return SO
 
 
+
+
+# ---- C++ host mirror (cozo_amd/host): libcozo_host.so, the compiled host side above the C ABI ------------------
+HOST = os.path.join(HERE, "host")
+HOST_SO = os.path.join(LIBDIR, "libcozo_host.so")
+CXX = os.environ.get("CXX", "g++")
+HOST_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter",
+              "-I" + os.path.join(HOST, "include"), "-I" + os.path.join(HERE, "..", "include")]
+
+
+def _host_mtime():
+    m = os.path.getmtime(os.path.join(HERE, "..", "include", "cozo_gpu.h"))
+    for root, _, files in os.walk(HOST):
+        for f in files:
+            m = max(m, os.path.getmtime(os.path.join(root, f)))
+    return m
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """g++ only (no device code).  Links against libcozo_gpu.so ($ORIGIN rpath); the HIP runtime is left to the
+    final executable / the process, exactly like libcozo_gpu.so itself."""
+    so = build(force=False)
+    if not force and os.path.exists(HOST_SO) and os.path.getmtime(HOST_SO) >= max(_host_mtime(), os.path.getmtime(so)):
+        return HOST_SO
+    srcs = sorted(os.path.join(HOST, "src", f) for f in os.listdir(os.path.join(HOST, "src")) if f.endswith(".cpp"))
+    subprocess.check_call([CXX, *HOST_FLAGS, "-shared", *srcs, "-o", HOST_SO, "-L" + LIBDIR, "-lcozo_gpu",
+                           "-Wl,-rpath,$ORIGIN", "-Wl,--allow-shlib-undefined"])
+    if verbose:
+        print("built", HOST_SO)
+    return HOST_SO
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    build_host(force="--force" in sys.argv, verbose=True)

@@ -23,11 +23,67 @@ constexpr int kWave = 64;
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// v[lane] + v[lane ^ OFF] without touching the LDS crossbar (ds_bpermute costs an LDS round trip per step and
+// serialises the butterfly: measured, the 12 dependent round trips per cosine row were most of a wave's time
+// between two row fetches).  Additions are commutative, so every lane gets exactly the value of the textbook
+// `v + __shfl_xor(v, OFF)` butterfly; scratch/dpp_butterfly_test.hip checks each step bit for bit on the device.
+//   32, 16: gfx950 v_permlane32_swap / v_permlane16_swap (halves / odd-even 16-lane rows exchanged between two copies)
+//   8:      DPP row_ror:8 (a rotation by half a 16-lane row is the xor)
+//   4:      two bank-masked DPP moves (row_shl:4 into banks 0,2; row_shr:4 into banks 1,3)
+//   2, 1:   DPP quad_perm
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(old), __float_as_uint(v), CTRL, 0xF, BANK, false));
+}
+template <int OFF>
+__device__ __forceinline__ float xor_add(float v) {
+    static_assert(OFF == 32 || OFF == 16 || OFF == 8 || OFF == 4 || OFF == 2 || OFF == 1, "butterfly offset");
+    if constexpr (OFF == 32) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else if constexpr (OFF == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else if constexpr (OFF == 8) {
+        return v + dpp_mov<0x128, 0xF>(v, v);
+    } else if constexpr (OFF == 4) {
+        float t = dpp_mov<0x104, 0x5>(v, v);
+        t = dpp_mov<0x114, 0xA>(t, v);
+        return v + t;
+    } else if constexpr (OFF == 2) {
+        return v + dpp_mov<0x4E, 0xF>(v, v);
+    } else {
+        return v + dpp_mov<0xB1, 0xF>(v, v);
+    }
+}
+
+// xor butterfly over a group of LPV lanes (offsets LPV/2 ... 1) for K independent values, step by step so that
+// the K chains interleave
+template <int LPV, int K>
+__device__ __forceinline__ void group_reduce_many(float (&v)[K]) {
+    if constexpr (LPV >= 64) {
+#pragma unroll
+        for (int k = 0; k < K; k++) v[k] = xor_add<32>(v[k]);
+    }
+    if constexpr (LPV >= 32) {
+#pragma unroll
+        for (int k = 0; k < K; k++) v[k] = xor_add<16>(v[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = xor_add<8>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = xor_add<4>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = xor_add<2>(v[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = xor_add<1>(v[k]);
+}
+
 template <int LPV>
 __device__ __forceinline__ float group_reduce(float v) {
-#pragma unroll
-    for (int off = LPV / 2; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, kWave);
-    return v;
+    float a[1] = {v};
+    group_reduce_many<LPV, 1>(a);
+    return a[0];
 }
 
 // order-preserving u64 key of an f64 distance; NaN sorts greatest (ordered-float semantics)
@@ -52,15 +108,16 @@ __device__ __forceinline__ float4 ld_chunk(const float4 *row, int c, int chunks)
     return c < chunks ? row[c] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// accumulate one chunk of one vector
-__device__ __forceinline__ void acc_chunk(int metric, const float4 &q, const float4 &v, float &a0, float &a1) {
-    if (metric == CZ_L2) {
+// accumulate one chunk of one vector (METRIC is a compile-time cz_metric)
+template <int METRIC>
+__device__ __forceinline__ void acc_chunk_m(const float4 &q, const float4 &v, float &a0, float &a1) {
+    if constexpr (METRIC == CZ_L2) {
         float d;
         d = q.x - v.x; a0 = fma_(d, d, a0);
         d = q.y - v.y; a0 = fma_(d, d, a0);
         d = q.z - v.z; a0 = fma_(d, d, a0);
         d = q.w - v.w; a0 = fma_(d, d, a0);
-    } else if (metric == CZ_COSINE) {
+    } else if constexpr (METRIC == CZ_COSINE) {
         a0 = fma_(q.x, v.x, a0); a1 = fma_(v.x, v.x, a1);
         a0 = fma_(q.y, v.y, a0); a1 = fma_(v.y, v.y, a1);
         a0 = fma_(q.z, v.z, a0); a1 = fma_(v.z, v.z, a1);
@@ -70,6 +127,69 @@ __device__ __forceinline__ void acc_chunk(int metric, const float4 &q, const flo
         a0 = fma_(q.y, v.y, a0);
         a0 = fma_(q.z, v.z, a0);
         a0 = fma_(q.w, v.w, a0);
+    }
+}
+__device__ __forceinline__ void acc_chunk(int metric, const float4 &q, const float4 &v, float &a0, float &a1) {
+    if (metric == CZ_L2) acc_chunk_m<CZ_L2>(q, v, a0, a1);
+    else if (metric == CZ_COSINE) acc_chunk_m<CZ_COSINE>(q, v, a0, a1);
+    else acc_chunk_m<CZ_IP>(q, v, a0, a1);
+}
+
+// Register-resident batch of U base rows of one lane group (ITERS chunks per lane each): the unit the traversal
+// kernels keep in flight.  `full` (uniform) = the row has exactly LPV * ITERS chunks, so no lane is ever out of range
+// and the loads carry no predicate.
+template <int ITERS, int U>
+struct RowRegs {
+    float4 v[U][ITERS];
+};
+template <int LPV, int ITERS, int U>
+__device__ __forceinline__ void load_rows(RowRegs<ITERS, U> &r, const float4 *const (&rows)[U], int glane, int chunks,
+                                          bool full) {
+    if (full) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int j = 0; j < ITERS; j++) r.v[u][j] = rows[u][glane + LPV * j];
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int j = 0; j < ITERS; j++) {
+                const int c = glane + LPV * j;
+                r.v[u][j] = c < chunks ? rows[u][c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    }
+}
+// raw accumulators of the U rows against the register-resident query, reduced over the lane group:
+// main[u] = dot / squared distance, bn[u] = self dot of the row (cosine only)
+template <int METRIC, int LPV, int ITERS, int U>
+__device__ __forceinline__ void dot_rows(const float4 (&q)[ITERS], const RowRegs<ITERS, U> &r, float (&main)[U],
+                                         float (&bn)[U]) {
+    if constexpr (METRIC == CZ_COSINE) {
+        float acc[2 * U];
+#pragma unroll
+        for (int u = 0; u < 2 * U; u++) acc[u] = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int j = 0; j < ITERS; j++) acc_chunk_m<METRIC>(q[j], r.v[u][j], acc[u], acc[U + u]);
+        group_reduce_many<LPV, 2 * U>(acc);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            main[u] = acc[u];
+            bn[u] = acc[U + u];
+        }
+    } else {
+        float dummy = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; u++) main[u] = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int j = 0; j < ITERS; j++) acc_chunk_m<METRIC>(q[j], r.v[u][j], main[u], dummy);
+        group_reduce_many<LPV, U>(main);
+#pragma unroll
+        for (int u = 0; u < U; u++) bn[u] = 0.f;
     }
 }
 
@@ -133,12 +253,10 @@ __device__ __forceinline__ void group_distances(int metric, const float4 (&q)[IT
             for (int u = 0; u < U; u++) acc_chunk(metric, qq, v[u], a0[u], a1[u]);
         }
     }
+    group_reduce_many<LPV, U>(a0);
+    if (metric == CZ_COSINE) group_reduce_many<LPV, U>(a1);
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        float m = group_reduce<LPV>(a0[u]);
-        float bn = metric == CZ_COSINE ? group_reduce<LPV>(a1[u]) : 0.f;
-        out[u] = finish_distance(metric, m, bn, qnorm);
-    }
+    for (int u = 0; u < U; u++) out[u] = finish_distance(metric, a0[u], a1[u], qnorm);
 }
 
 // compile-time shape of a dimension: lanes per vector and chunk iterations per lane

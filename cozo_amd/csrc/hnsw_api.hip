@@ -27,76 +27,80 @@ __global__ void pad_rows_kernel(const float *__restrict__ src, float *__restrict
     }
 }
 
-// VectorCache::dist over (query,node) pairs; one lane group per pair, U pairs in flight
+// VectorCache::dist over (query,node) pairs; one lane group per pair, U pairs in flight per group.  Pure streaming:
+// unpredicated 16-byte loads when the row has exactly LPV * ITERS chunks, DPP butterflies, and ONE f64 tail per
+// round (lane u of the group finishes pair u) instead of one per pair.
 template <int LPV, int ITERS, int U>
 __global__ void __launch_bounds__(256)
 distance_pairs_kernel(int metric, const float *__restrict__ base, const float *__restrict__ queries, uint32_t ld,
                       const uint32_t *__restrict__ pairs, uint64_t P, double *__restrict__ out) {
+    static_assert(U <= 16, "one lane of the group per pair of a round");
     const int chunks = (int)(ld / 4);
     const int lane = threadIdx.x & 63;
     const int glane = lane % LPV;
     const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPV;
     const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / LPV;
+    const bool cosine = metric == CZ_COSINE;
     for (uint64_t p0 = group * U; p0 < P; p0 += ngroups * U) {
         const float4 *brow[U], *qrow[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            uint64_t p = p0 + u;
-            if (p < P) {
-                qrow[u] = (const float4 *)(queries + (size_t)pairs[2 * p] * ld);
-                brow[u] = (const float4 *)(base + (size_t)pairs[2 * p + 1] * ld);
-            } else {
-                qrow[u] = brow[u] = nullptr;
-            }
+            const uint64_t p = p0 + u < P ? p0 + u : P - 1;  // past the end: repeat the last pair, result discarded
+            qrow[u] = (const float4 *)(queries + (size_t)pairs[2 * p] * ld);
+            brow[u] = (const float4 *)(base + (size_t)pairs[2 * p + 1] * ld);
         }
-        float a0[U], a1[U], a2[U];
+        float acc[3 * U];  // [0,U): main   [U,2U): row self dot   [2U,3U): query self dot
 #pragma unroll
-        for (int u = 0; u < U; u++) a0[u] = a1[u] = a2[u] = 0.f;
+        for (int u = 0; u < 3 * U; u++) acc[u] = 0.f;
         if constexpr (ITERS > 0) {
-            float4 bv[U][ITERS], qv[U][ITERS];
+            const bool full = chunks == LPV * ITERS;
+            RowRegs<ITERS, U> bv, qv;
+            load_rows<LPV, ITERS, U>(bv, brow, glane, chunks, full);
+            load_rows<LPV, ITERS, U>(qv, qrow, glane, chunks, full);
 #pragma unroll
             for (int u = 0; u < U; u++)
 #pragma unroll
                 for (int j = 0; j < ITERS; j++) {
-                    int c = glane + LPV * j;
-                    bool ok = brow[u] != nullptr && c < chunks;
-                    bv[u][j] = ok ? brow[u][c] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    qv[u][j] = ok ? qrow[u][c] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-            for (int u = 0; u < U; u++)
-#pragma unroll
-                for (int j = 0; j < ITERS; j++) {
-                    acc_chunk(metric, qv[u][j], bv[u][j], a0[u], a1[u]);
-                    if (metric == CZ_COSINE) {
+                    acc_chunk(metric, qv.v[u][j], bv.v[u][j], acc[u], acc[U + u]);
+                    if (cosine) {
                         float d = 0.f;
-                        acc_chunk(CZ_IP, qv[u][j], qv[u][j], a2[u], d);
+                        acc_chunk_m<CZ_IP>(qv.v[u][j], qv.v[u][j], acc[2 * U + u], d);
                     }
                 }
         } else {
             for (int c = glane; c < chunks; c += LPV) {
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    if (brow[u] == nullptr) continue;
                     float4 b = brow[u][c], q = qrow[u][c];
-                    acc_chunk(metric, q, b, a0[u], a1[u]);
-                    if (metric == CZ_COSINE) {
+                    acc_chunk(metric, q, b, acc[u], acc[U + u]);
+                    if (cosine) {
                         float d = 0.f;
-                        acc_chunk(CZ_IP, q, q, a2[u], d);
+                        acc_chunk_m<CZ_IP>(q, q, acc[2 * U + u], d);
                     }
                 }
             }
         }
+        if (cosine) {
+            group_reduce_many<LPV, 3 * U>(acc);
+        } else {
+            float m[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            float m = group_reduce<LPV>(a0[u]);
-            float bn = 0.f, qn = 0.f;
-            if (metric == CZ_COSINE) {
-                bn = group_reduce<LPV>(a1[u]);
-                qn = group_reduce<LPV>(a2[u]);
-            }
-            if (glane == 0 && p0 + u < P) out[p0 + u] = finish_distance(metric, m, bn, qn);
+            for (int u = 0; u < U; u++) m[u] = acc[u];
+            group_reduce_many<LPV, U>(m);
+#pragma unroll
+            for (int u = 0; u < U; u++) acc[u] = m[u];
         }
+        // every lane of the group holds every total: lane u keeps pair u's
+        float mm = acc[0], bn = acc[U], qn = acc[2 * U];
+#pragma unroll
+        for (int u = 1; u < U; u++)
+            if (glane == u) {
+                mm = acc[u];
+                bn = acc[U + u];
+                qn = acc[2 * U + u];
+            }
+        const double d = finish_distance(metric, mm, bn, qn);
+        if (glane < U && p0 + glane < P) out[p0 + glane] = d;
     }
 }
 
@@ -288,6 +292,25 @@ bf_merge_kernel(const uint64_t *__restrict__ part_key, const uint32_t *__restric
             case 6: CALL(64, 6, 2); break;                                     \
             case 7: CALL(64, 7, 2); break;                                     \
             case 8: CALL(64, 8, 2); break;                                     \
+            default: CALL(64, 0, 2); break;                                    \
+        }                                                                      \
+    } while (0)
+// The traversal kernels (search, build) double-buffer their rounds (the next U rows of a lane group are requested
+// before the current U are reduced), so U is half of what the streaming kernels (pairs, exhaustive scan) use and is
+// chosen to stay clear of register spills: 2 x U x ITERS float4 of rows + the query per lane.
+#define CZ_DISPATCH_SHAPE_SEARCH(SH, CALL)                                     \
+    do {                                                                       \
+        if ((SH).lpv == 16) { CALL(16, 1, 4); }                                \
+        else if ((SH).lpv == 32) { CALL(32, 1, 4); }                           \
+        else switch ((SH).iters) {                                             \
+            case 1: CALL(64, 1, 4); break;                                     \
+            case 2: CALL(64, 2, 2); break;                                     \
+            case 3: CALL(64, 3, 2); break;                                     \
+            case 4: CALL(64, 4, 2); break;                                     \
+            case 5: CALL(64, 5, 1); break;                                     \
+            case 6: CALL(64, 6, 1); break;                                     \
+            case 7: CALL(64, 7, 1); break;                                     \
+            case 8: CALL(64, 8, 1); break;                                     \
             default: CALL(64, 0, 2); break;                                    \
         }                                                                      \
     } while (0)
@@ -503,14 +526,12 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
                            has_radius, radius, (uint32_t *)ws.ptr, words, d_ids, d_dist, d_count,                       \
                            (unsigned long long *)d_ndist);                                                              \
     } while (0)
-    // experiment knob: rows in flight per lane group for the 513..768-d shape (CZ_HNSW_U = 2 | 4 | 6 | 8)
+    // experiment knob: rows per round of a lane group for the 513..768-d shape (CZ_HNSW_U = 1 | 2 | 3)
     const char *knn_u_env = getenv("CZ_HNSW_U");
     const int knn_u = knn_u_env ? atoi(knn_u_env) : 0;
-    if (sh.lpv == 64 && sh.iters == 3 && knn_u == 2) CZ_LAUNCH_KNN(64, 3, 2);
-    else if (sh.lpv == 64 && sh.iters == 3 && knn_u == 4) CZ_LAUNCH_KNN(64, 3, 4);
-    else if (sh.lpv == 64 && sh.iters == 3 && knn_u == 6) CZ_LAUNCH_KNN(64, 3, 6);
-    else if (sh.lpv == 64 && sh.iters == 3 && knn_u == 8) CZ_LAUNCH_KNN(64, 3, 8);
-    else CZ_DISPATCH_SHAPE(sh, CZ_LAUNCH_KNN);
+    if (sh.lpv == 64 && sh.iters == 3 && knn_u == 1) CZ_LAUNCH_KNN(64, 3, 1);
+    else if (sh.lpv == 64 && sh.iters == 3 && knn_u == 3) CZ_LAUNCH_KNN(64, 3, 3);
+    else CZ_DISPATCH_SHAPE_SEARCH(sh, CZ_LAUNCH_KNN);
 #undef CZ_LAUNCH_KNN
     hipError_t e = hipGetLastError();
     int rc2 = ix->release(ws, stream);

@@ -234,17 +234,17 @@ build_pack_kernel(const uint32_t *__restrict__ src, int cap, uint32_t *__restric
 
 #define CZ_DISPATCH_BUILD_SHAPE(SH, CALL)                                      \
     do {                                                                       \
-        if ((SH).lpv == 16) { CALL(16, 1, 8); }                                \
-        else if ((SH).lpv == 32) { CALL(32, 1, 8); }                           \
+        if ((SH).lpv == 16) { CALL(16, 1, 4); }                                \
+        else if ((SH).lpv == 32) { CALL(32, 1, 4); }                           \
         else switch ((SH).iters) {                                             \
-            case 1: CALL(64, 1, 8); break;                                     \
-            case 2: CALL(64, 2, 8); break;                                     \
-            case 3: CALL(64, 3, 4); break;                                     \
-            case 4: CALL(64, 4, 4); break;                                     \
-            case 5: CALL(64, 5, 2); break;                                     \
-            case 6: CALL(64, 6, 2); break;                                     \
-            case 7: CALL(64, 7, 2); break;                                     \
-            default: CALL(64, 8, 2); break;                                    \
+            case 1: CALL(64, 1, 4); break;                                     \
+            case 2: CALL(64, 2, 2); break;                                     \
+            case 3: CALL(64, 3, 2); break;                                     \
+            case 4: CALL(64, 4, 1); break;                                     \
+            case 5: CALL(64, 5, 1); break;                                     \
+            case 6: CALL(64, 6, 1); break;                                     \
+            case 7: CALL(64, 7, 1); break;                                     \
+            default: CALL(64, 8, 1); break;                                    \
         }                                                                      \
     } while (0)
 

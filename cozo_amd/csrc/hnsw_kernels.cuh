@@ -121,6 +121,7 @@ struct Searcher {
 
     static constexpr int VPW = 64 / LPV;          // lane groups per wave
     static constexpr int TG = kWaves * VPW;       // lane groups per workgroup
+    using Regs = RowRegs<(ITERS > 0 ? ITERS : 1), U>;
 
     __device__ Searcher(const IndexDev &ix_, Smem s_, uint32_t *bitmap_, uint32_t words_)
         : ix(ix_), s(s_), bitmap(bitmap_), words(words_) {
@@ -148,28 +149,95 @@ struct Searcher {
         qnorm = ix.metric == CZ_COSINE ? query_norm<LPV, ITERS>(q, s.q, glane, chunks) : 0.f;
     }
 
-    // distances from the register-resident vector (qq, qqn) to todo[0..n) -> nkey/nid   (all waves)
-    // Lane group g owns entries g, g + TG, g + 2 TG, ...; one round keeps U rows per group in flight, so a
-    // typical neighbour batch (n <= TG * U) costs ONE memory round trip instead of n / (TG * 2).
-    __device__ void eval_list(const float4 (&qq)[ITERS > 0 ? ITERS : 1], float qqn, int n) {
-        for (int base = group; base < n; base += TG * U) {
-            const float4 *rows[U];
-            uint32_t ids[U];
+    // distances from the register-resident vector (qq, qqn) to todo[0..n) -> nkey/nid   (all waves; ends with the
+    // entries written but NOT yet visible: the caller's barrier publishes them).
+    // Lane group g owns entries g + TG * t, t = 0, 1, ...; a "round" is U consecutive t.  The rounds of a group are
+    // software pipelined (the next round's rows are requested before the current round is reduced), the reductions
+    // are DPP butterflies (no LDS round trips), and the f64 tail of the distance (1 - x / sqrt(..)) is NOT done per
+    // row by the whole wave: the group leader parks the raw f32 accumulators in the entry's key slot and, after a
+    // barrier, thread j finishes entry j -- one f64 sqrt/div per thread per expansion step instead of one per row.
+    template <int METRIC>
+    __device__ __forceinline__ void issue_round(Regs &r, int base, int n, bool full) {
+        const float4 *rows[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int j = min(base + u * TG, n - 1);  // past the end: re-read the last row, result discarded
+            rows[u] = (const float4 *)(ix.vec + (size_t)s.todo[j] * ix.ld);
+        }
+        load_rows<LPV, ITERS, U>(r, rows, glane, chunks, full);
+    }
+    template <int METRIC>
+    __device__ __forceinline__ void retire_round(const float4 (&qq)[ITERS > 0 ? ITERS : 1], const Regs &r,
+                                                 int base, int n) {
+        float m[U], bn[U];
+        dot_rows<METRIC, LPV, ITERS, U>(qq, r, m, bn);
+        if (glane == 0) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                int j = base + u * TG;
-                ids[u] = j < n ? s.todo[j] : CZ_NONE;
-                rows[u] = j < n ? (const float4 *)(ix.vec + (size_t)ids[u] * ix.ld) : nullptr;
+                const int j = base + u * TG;
+                if (j < n) ((float2 *)s.nkey)[j] = make_float2(m[u], bn[u]);
             }
-            double d[U];
-            group_distances<LPV, ITERS, U>(ix.metric, qq, s.q, glane, chunks, qqn, rows, d);
-            if (glane == 0) {
+        }
+    }
+    template <int METRIC>
+    __device__ __forceinline__ void eval_rounds(const float4 (&qq)[ITERS > 0 ? ITERS : 1], int n) {
+        static_assert(ITERS > 0, "register-resident rows only");
+        const bool full = chunks == LPV * ITERS;
+        constexpr int STEP = TG * U;
+        // every group of a wave runs the same number of rounds (the wave's first group decides), so the
+        // cross-lane reductions always see whole groups
+        int wbase = wave * VPW;
+        if (wbase >= n) return;
+        int base = group;
+        Regs a, b;
+        issue_round<METRIC>(a, base, n, full);
+        for (;;) {
+            bool more = wbase + STEP < n;
+            if (more) issue_round<METRIC>(b, base + STEP, n, full);
+            retire_round<METRIC>(qq, a, base, n);
+            if (!more) break;
+            base += STEP;
+            wbase += STEP;
+            more = wbase + STEP < n;
+            if (more) issue_round<METRIC>(a, base + STEP, n, full);
+            retire_round<METRIC>(qq, b, base, n);
+            if (!more) break;
+            base += STEP;
+            wbase += STEP;
+        }
+    }
+    __device__ void eval_list(const float4 (&qq)[ITERS > 0 ? ITERS : 1], float qqn, int n) {
+        if constexpr (ITERS > 0) {
+            if (ix.metric == CZ_COSINE) eval_rounds<CZ_COSINE>(qq, n);
+            else if (ix.metric == CZ_L2) eval_rounds<CZ_L2>(qq, n);
+            else eval_rounds<CZ_IP>(qq, n);
+            __syncthreads();
+            for (int j = tid; j < n; j += kThreads) {
+                const float2 raw = ((const float2 *)s.nkey)[j];
+                s.nkey[j] = dist_key(finish_distance(ix.metric, raw.x, raw.y, qqn));
+                s.nid[j] = s.todo[j];
+            }
+        } else {
+            // generic dimension (> 2048): the query is read from LDS chunk by chunk
+            for (int base = group; base < n; base += TG * U) {
+                const float4 *rows[U];
+                uint32_t ids[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     int j = base + u * TG;
-                    if (j < n) {
-                        s.nkey[j] = dist_key(d[u]);
-                        s.nid[j] = ids[u];
+                    ids[u] = j < n ? s.todo[j] : CZ_NONE;
+                    rows[u] = j < n ? (const float4 *)(ix.vec + (size_t)ids[u] * ix.ld) : nullptr;
+                }
+                double d[U];
+                group_distances<LPV, ITERS, U>(ix.metric, qq, s.q, glane, chunks, qqn, rows, d);
+                if (glane == 0) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        int j = base + u * TG;
+                        if (j < n) {
+                            s.nkey[j] = dist_key(d[u]);
+                            s.nid[j] = ids[u];
+                        }
                     }
                 }
             }

@@ -217,13 +217,22 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
                  const uint2 *__restrict__ seg /* [blocks][S+1]: (stream position, block-local prefix) */, uint32_t S,
                  const uint16_t *__restrict__ perm, const float *__restrict__ val,
                  const uint32_t *__restrict__ out_deg, uint32_t row_begin, float *__restrict__ contrib_out,
-                 float *__restrict__ scores, float base, float damping, double *__restrict__ partial) {
+                 float *__restrict__ scores, float base, float damping, double *__restrict__ partial, int xcd_remap) {
     __shared__ float tile[kBTileNnz];
     __shared__ double red[kBThreads / 64];
     constexpr int NW = kBThreads / 64;
     constexpr int RPL = kMaxRowsPerBlock / kBThreads;  // rows per lane
     constexpr int U = 10;
-    const uint32_t b = blk0 + blockIdx.x;
+    // Workgroup i is dispatched to XCD i % 8, and every XCD has its own L2.  The runs of ADJACENT row blocks are
+    // adjacent in each slice's value stream and share their boundary cache lines, so adjacent row blocks are given
+    // to the same XCD (workgroups 8j + x, j = 0, 1, ... take a contiguous range of blocks): the shared line is then
+    // fetched from memory once instead of once per L2.
+    uint32_t local = blockIdx.x;
+    if (xcd_remap) {
+        const uint32_t nb = gridDim.x, x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        local = x * (nb >> 3) + min(x, nb & 7u) + j;
+    }
+    const uint32_t b = blk0 + local;
     const RowBlock rb = blocks[b];
     const uint32_t e0 = rb.e0;
     const uint2 *sg = seg + (size_t)b * (S + 1);
@@ -433,6 +442,7 @@ struct cz_pagerank_plan {
     uint64_t E = 0;
     float damping = 0, base = 0, init = 0;
     bool blocked = false;
+    int xcd_remap = 1;
     // gather formulation: every row block; blocked formulation: the long-row blocks only
     uint32_t n_gblocks = 0;
     RowBlock *d_gblocks = nullptr;
@@ -628,6 +638,7 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
         p->d_src = nullptr;
     }
     p->blocked = true;
+    p->xcd_remap = env_int("CZ_PR_XCD", 1);
     return CZ_OK;
 }
 
@@ -745,7 +756,7 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
             if (b1 > b0)
                 hipLaunchKernelGGL(pb_reduce_kernel, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0, p->d_off,
                                    p->d_seg, p->S, p->d_perm, val, p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores,
-                                   p->base, p->damping, p->d_partial);
+                                   p->base, p->damping, p->d_partial, p->xcd_remap);
         }
         if (p->n_gblocks)  // rows longer than a tile
             hipLaunchKernelGGL(pr_step_kernel, dim3(p->n_gblocks), dim3(kGThreads), 0, stream, p->d_gblocks, p->d_off, p->d_src,

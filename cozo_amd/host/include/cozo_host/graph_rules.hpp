@@ -1,0 +1,50 @@
+// graph_rules.hpp -- the whole-graph fixed rules of the GPU path as `impl FixedRule` (C++ host mirror).
+//
+// Each rule reads its options and inputs exactly like the reference's rule of the same name, maps node values to
+// dense ids on the host (as the reference does), hands a CSR to libcozo_gpu (include/cozo_gpu.h) and writes the
+// reference's rows to `out`.  There is no CPU fallback: without the device library / a gfx950 device `run` throws.
+//   PageRank                     fixed_rule/algos/pagerank.rs:29-56                    -> cz_pagerank
+//   ShortestPathBFS              fixed_rule/algos/shortest_path_bfs.rs:35-113          -> cz_bfs
+//   Bfs                          fixed_rule/algos/bfs.rs:25-113                        -> cz_bfs (share_visited)
+//   StronglyConnectedComponent   fixed_rule/algos/strongly_connected_components.rs:42-77 (strong = false only)
+//                                                                                      -> cz_connected_components
+//   ShortestPathDijkstra         fixed_rule/algos/shortest_path_dijkstra.rs:33-153     -> cz_sssp
+#pragma once
+#include "fixed_rule.hpp"
+
+namespace cozo {
+
+class PageRank : public FixedRule {
+public:
+    size_t arity(const std::map<std::string, DataValue> &, const std::vector<std::string> &) const override { return 2; }
+    void run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const override;
+};
+
+class ShortestPathBFS : public FixedRule {
+public:
+    size_t arity(const std::map<std::string, DataValue> &, const std::vector<std::string> &) const override { return 3; }
+    void run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const override;
+};
+
+class Bfs : public FixedRule {
+public:
+    size_t arity(const std::map<std::string, DataValue> &, const std::vector<std::string> &) const override { return 3; }
+    void run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const override;
+};
+
+class StronglyConnectedComponent : public FixedRule {
+    bool strong_;
+
+public:
+    explicit StronglyConnectedComponent(bool strong) : strong_(strong) {}
+    size_t arity(const std::map<std::string, DataValue> &, const std::vector<std::string> &) const override { return 2; }
+    void run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const override;
+};
+
+class ShortestPathDijkstra : public FixedRule {
+public:
+    size_t arity(const std::map<std::string, DataValue> &, const std::vector<std::string> &) const override { return 4; }
+    void run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const override;
+};
+
+}  // namespace cozo

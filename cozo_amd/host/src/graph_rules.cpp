@@ -1,0 +1,240 @@
+// graph_rules.cpp -- the GPU forms of the whole-graph fixed rules (see graph_rules.hpp for the reference map).
+#include "cozo_host/graph_rules.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <unordered_set>
+
+#include "cozo_gpu.h"
+
+namespace cozo {
+
+namespace {
+
+// walk the backtrace from `goal` to `start` (shortest_path_bfs.rs:85-92, bfs.rs:97-106)
+std::vector<uint32_t> walk_back(const uint32_t *parent, uint32_t start, uint32_t goal) {
+    std::vector<uint32_t> route;
+    uint32_t cur = goal;
+    while (cur != start) {
+        route.push_back(cur);
+        cur = parent[cur];
+        if (cur == CZ_NONE) throw CozoError("gpu::broken_backtrace", "broken backtrace returned by cz_bfs / cz_sssp");
+    }
+    route.push_back(start);
+    std::reverse(route.begin(), route.end());
+    return route;
+}
+
+DataValue path_value(const std::vector<uint32_t> &route, const std::vector<DataValue> &indices) {
+    std::vector<DataValue> items;
+    items.reserve(route.size());
+    for (uint32_t u : route) items.push_back(indices[u]);
+    return DataValue::list(std::move(items));
+}
+
+}  // namespace
+
+// ---- PageRank -------------------------------------------------------------------------------------------------
+void PageRank::run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const {
+    const FixedRuleInputRelation &edges = payload.get_input(0);
+    const bool undirected = payload.bool_option("undirected", false);
+    const float theta = (float)payload.unit_interval_option("theta", 0.85);
+    const float epsilon = (float)payload.unit_interval_option("epsilon", 0.0001);  // narrowed to f32 (:38), widened at :49
+    const size_t iterations = payload.pos_integer_option("iterations", 10);
+    GraphWithIndices g = edges.as_directed_graph(undirected);
+    if (g.indices.empty()) return;  // :43-45
+    const DirectedCsrGraph &gr = g.graph;
+    const std::vector<uint32_t> out_degree = gr.out_degrees();
+    std::vector<float> scores(gr.n);
+    uint32_t iters_run = 0;
+    double final_err = 0.0;
+    check_gpu(cz_pagerank(gr.in_offsets.data(), gr.in_sources.data(), out_degree.data(), gr.n, gr.edge_count(), theta,
+                          (double)epsilon, (uint32_t)iterations, scores.data(), &iters_run, &final_err, poison.flag_ptr()));
+    for (uint32_t i = 0; i < gr.n; i++) out.put(Tuple{g.indices[i], DataValue((double)scores[i])});
+}
+
+// ---- ShortestPathBFS ------------------------------------------------------------------------------------------
+void ShortestPathBFS::run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const {
+    const FixedRuleInputRelation &edges = payload.get_input(0).ensure_min_len(2);
+    const FixedRuleInputRelation &starting = payload.get_input(1).ensure_min_len(1);
+    const FixedRuleInputRelation &ending = payload.get_input(2).ensure_min_len(1);
+    std::vector<DataValue> starting_nodes;
+    for (const Tuple &t : starting.iter()) starting_nodes.push_back(t[0]);
+    std::vector<DataValue> ending_nodes;  // BTreeSet<DataValue> (:53-57): sorted, unique
+    for (const Tuple &t : ending.iter()) ending_nodes.push_back(t[0]);
+    std::sort(ending_nodes.begin(), ending_nodes.end());
+    ending_nodes.erase(std::unique(ending_nodes.begin(), ending_nodes.end()), ending_nodes.end());
+    if (starting_nodes.empty() || ending_nodes.empty()) return;
+    std::vector<DataValue> extra(starting_nodes);
+    extra.insert(extra.end(), ending_nodes.begin(), ending_nodes.end());
+    GraphWithIndices g = edges.as_ordered_graph(extra);
+    const DirectedCsrGraph &gr = g.graph;
+    std::vector<uint32_t> starts, goals;
+    for (const DataValue &s : starting_nodes) starts.push_back(g.inv_indices.at(s));
+    for (const DataValue &e : ending_nodes) goals.push_back(g.inv_indices.at(e));
+    std::vector<uint32_t> parent((size_t)starts.size() * gr.n);
+    check_gpu(cz_bfs(gr.out_offsets.data(), gr.out_targets.data(), gr.n, gr.edge_count(), starts.data(), (uint32_t)starts.size(),
+                     goals.data(), (uint32_t)goals.size(), 0, parent.data(), nullptr, nullptr, nullptr, poison.flag_ptr()));
+    for (size_t si = 0; si < starts.size(); si++) {
+        const uint32_t *par = parent.data() + si * gr.n;
+        for (size_t gi = 0; gi < goals.size(); gi++) {
+            // a goal equal to the start is never "discovered" (:66-84 only looks at neighbours): Null, like the reference
+            if (par[goals[gi]] != CZ_NONE)
+                out.put(Tuple{starting_nodes[si], ending_nodes[gi], path_value(walk_back(par, starts[si], goals[gi]), g.indices)});
+            else
+                out.put(Tuple{starting_nodes[si], ending_nodes[gi], DataValue()});
+        }
+        poison.check();
+    }
+}
+
+// ---- Bfs ------------------------------------------------------------------------------------------------------
+void Bfs::run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const {
+    const FixedRuleInputRelation &edges = payload.get_input(0).ensure_min_len(2);
+    const FixedRuleInputRelation &nodes = payload.get_input(1);
+    const FixedRuleInputRelation *starting_rel = &nodes;  // `payload.get_input(2).unwrap_or(nodes)` (:33)
+    if (payload.inputs_count() > 2) {
+        try {
+            starting_rel = &payload.get_input(2);
+        } catch (const FixedRuleInputNotFoundError &) {
+        }
+    }
+    const size_t limit = payload.pos_integer_option("limit", 1);
+    const ExprOption condition = payload.expr_option("condition");
+    const bool skip_query_nodes = condition.only_first_binding;
+    std::vector<DataValue> start_vals;
+    for (const Tuple &t : starting_rel->iter()) start_vals.push_back(t[0]);
+    if (start_vals.empty()) return;
+    GraphWithIndices g = edges.as_ordered_graph(start_vals);
+    const DirectedCsrGraph &gr = g.graph;
+    std::vector<uint32_t> starts;
+    for (const DataValue &s : start_vals) starts.push_back(g.inv_indices.at(s));
+    const size_t ns = starts.size();
+    std::vector<uint32_t> parent(ns * gr.n), order(ns * gr.n), reached(ns);
+    check_gpu(cz_bfs(gr.out_offsets.data(), gr.out_targets.data(), gr.n, gr.edge_count(), starts.data(), (uint32_t)ns, nullptr, 0,
+                     /*share_visited=*/1, parent.data(), nullptr, order.data(), reached.data(), poison.flag_ptr()));
+    struct Found {
+        uint32_t start, end;
+    };
+    std::vector<Found> found;
+    bool done = false;
+    for (size_t si = 0; si < ns && !done; si++) {
+        for (uint32_t j = 0; j < reached[si]; j++) {
+            const uint32_t to = order[si * gr.n + j];
+            const DataValue &to_val = g.indices[to];
+            Tuple cand_tuple;
+            if (skip_query_nodes) {
+                cand_tuple = Tuple{to_val};
+            } else {
+                auto range = nodes.prefix_iter(to_val);
+                if (range.first == range.second)  // sic: the reference reports the *discoverer* as missing (:74-77)
+                    throw NodeNotFoundError(g.indices[parent[si * gr.n + to]]);
+                cand_tuple = *range.first;
+            }
+            if (condition.eval(cand_tuple)) {
+                found.push_back({starts[si], to});
+                if (found.size() >= limit) {
+                    done = true;
+                    break;
+                }
+            }
+            poison.check();
+        }
+    }
+    // the backtrace is shared across starts (:44); every node has exactly one discoverer
+    std::vector<uint32_t> merged(gr.n, CZ_NONE);
+    for (size_t si = 0; si < ns; si++)
+        for (uint32_t v = 0; v < gr.n; v++)
+            if (parent[si * gr.n + v] != CZ_NONE) merged[v] = parent[si * gr.n + v];
+    for (const Found &f : found)
+        out.put(Tuple{g.indices[f.start], g.indices[f.end], path_value(walk_back(merged.data(), f.start, f.end), g.indices)});
+}
+
+// ---- ConnectedComponents / SCC --------------------------------------------------------------------------------
+void StronglyConnectedComponent::run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const {
+    if (strong_)  // Tarjan's DFS numbering is sequential and its group ids are DFS-order dependent: not on the GPU path
+        throw GpuError(CZ_E_UNSUPPORTED, "StronglyConnectedComponents (strong = true) is not available on the GPU path");
+    const FixedRuleInputRelation &edges = payload.get_input(0);
+    GraphWithIndices g = edges.as_directed_graph(/*undirected=*/true);  // `!self.strong` (:49)
+    uint32_t n_groups = 0;
+    if (!g.indices.empty()) {
+        const DirectedCsrGraph &gr = g.graph;
+        std::vector<uint32_t> group(gr.n);
+        check_gpu(cz_connected_components(gr.out_offsets.data(), gr.out_targets.data(), gr.n, gr.edge_count(), group.data(),
+                                          &n_groups, poison.flag_ptr()));
+        for (uint32_t i = 0; i < gr.n; i++) out.put(Tuple{g.indices[i], DataValue((int64_t)group[i])});
+    }
+    int64_t counter = n_groups;  // :61-74 nodes that appear only in the optional node relation
+    if (payload.inputs_count() > 1) {
+        const FixedRuleInputRelation *nodes = nullptr;
+        try {
+            nodes = &payload.get_input(1);
+        } catch (const FixedRuleInputNotFoundError &) {
+        }
+        if (nodes) {
+            for (const Tuple &t : nodes->iter()) {
+                if (t.empty()) continue;
+                if (!g.inv_indices.count(t[0])) {
+                    g.inv_indices.emplace(t[0], (uint32_t)g.inv_indices.size());
+                    out.put(Tuple{t[0], DataValue(counter)});
+                    counter++;
+                }
+            }
+        }
+    }
+}
+
+// ---- ShortestPathDijkstra -------------------------------------------------------------------------------------
+void ShortestPathDijkstra::run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const {
+    const FixedRuleInputRelation &edges = payload.get_input(0);
+    const FixedRuleInputRelation &starting = payload.get_input(1);
+    const FixedRuleInputRelation *termination = nullptr;
+    if (payload.inputs_count() > 2) {
+        try {
+            termination = &payload.get_input(2);
+        } catch (const FixedRuleInputNotFoundError &) {
+        }
+    }
+    const bool undirected = payload.bool_option("undirected", false);
+    const bool keep_ties = payload.bool_option("keep_ties", false);
+    GraphWithIndices g = edges.as_directed_weighted_graph(undirected, false);
+    const DirectedCsrGraph &gr = g.graph;
+    auto id_set = [&](const FixedRuleInputRelation &rel) {
+        std::vector<uint32_t> ids;  // BTreeSet<u32>
+        for (const Tuple &t : rel.iter()) {
+            if (t.empty()) continue;
+            auto it = g.inv_indices.find(t[0]);
+            if (it != g.inv_indices.end()) ids.push_back(it->second);
+        }
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        return ids;
+    };
+    const std::vector<uint32_t> starting_nodes = id_set(starting);
+    std::vector<uint32_t> termination_nodes;
+    if (termination) termination_nodes = id_set(*termination);
+    if (keep_ties) throw GpuError(CZ_E_UNSUPPORTED, "keep_ties is not available on the GPU path");
+    if (starting_nodes.empty()) return;
+    if (termination && termination_nodes.empty()) return;
+    const size_t ns = starting_nodes.size();
+    std::vector<float> dist(ns * gr.n);
+    std::vector<uint32_t> parent(ns * gr.n);
+    check_gpu(cz_sssp(gr.out_offsets.data(), gr.out_targets.data(), gr.out_weights.data(), gr.n, gr.edge_count(),
+                      starting_nodes.data(), (uint32_t)ns, dist.data(), parent.data(), poison.flag_ptr()));
+    for (size_t si = 0; si < ns; si++) {
+        const uint32_t s = starting_nodes[si];
+        auto emit = [&](uint32_t t) {
+            const float cost = dist[si * gr.n + t];
+            DataValue path = std::isfinite(cost) ? path_value(walk_back(parent.data() + si * gr.n, s, t), g.indices)
+                                                 : DataValue::list({});  // unreachable: (inf, []) (:319-324)
+            out.put(Tuple{g.indices[s], g.indices[t], DataValue((double)cost), std::move(path)});
+        };
+        if (termination)
+            for (uint32_t t : termination_nodes) emit(t);
+        else
+            for (uint32_t t = 0; t < gr.n; t++) emit(t);
+        poison.check();
+    }
+}
+
+}  // namespace cozo

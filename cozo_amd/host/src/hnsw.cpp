@@ -1,0 +1,156 @@
+// hnsw.cpp -- HNSW half of the C++ host mirror (see hnsw.hpp for the reference map).
+#include "cozo_host/hnsw.hpp"
+
+#include <algorithm>
+
+#include "cozo_gpu.h"
+
+namespace cozo {
+
+HnswIndexManifest HnswIndexManifest::create(std::string base, std::string index, size_t dim, std::vector<size_t> fields,
+                                            HnswDistance distance, size_t m, size_t ef_construction) {
+    HnswIndexManifest mf;
+    mf.base_relation = std::move(base);
+    mf.index_name = std::move(index);
+    mf.vec_dim = dim;
+    mf.vec_fields = std::move(fields);
+    mf.distance = distance;
+    mf.m_neighbours = m;
+    mf.ef_construction = ef_construction;
+    mf.m_max = m;       // runtime/relation.rs:1145
+    mf.m_max0 = m * 2;  // :1146
+    mf.level_multiplier = 1.0 / std::log((double)m);  // :1147
+    return mf;
+}
+
+GpuHnswIndex &GpuHnswIndex::operator=(GpuHnswIndex &&o) noexcept {
+    if (this != &o) {
+        if (h_) cz_hnsw_index_destroy(h_);
+        h_ = o.h_;
+        o.h_ = nullptr;
+        manifest_ = std::move(o.manifest_);
+        base_ = o.base_;
+        nodes_ = std::move(o.nodes_);
+        build_n_dist_ = o.build_n_dist_;
+    }
+    return *this;
+}
+
+GpuHnswIndex::~GpuHnswIndex() {
+    if (h_) cz_hnsw_index_destroy(h_);
+}
+
+uint64_t GpuHnswIndex::device_bytes() const { return h_ ? cz_hnsw_index_bytes(h_) : 0; }
+
+GpuHnswIndex GpuHnswIndex::create(const HnswIndexManifest &manifest, const BaseRelation &base, uint64_t seed,
+                                  uint32_t max_batch, const std::vector<int32_t> *levels) {
+    if (manifest.dtype != VecElementType::F32)
+        throw GpuError(CZ_E_UNSUPPORTED, "only F32 vector indices are GPU-resident");
+    if (manifest.extend_candidates) throw GpuError(CZ_E_UNSUPPORTED, "extend_candidates is not supported by the GPU build");
+    GpuHnswIndex ix;
+    ix.manifest_ = manifest;
+    ix.base_ = &base;
+    // hnsw_put (runtime/hnsw.rs:679-727): per row, per indexed field, a Vec or every Vec inside a List
+    std::vector<float> flat;
+    auto push = [&](const std::vector<float> &v, uint32_t row, uint32_t field, int32_t sub) {
+        if (v.size() != manifest.vec_dim)
+            throw CozoError("hnsw::dim_mismatch", "vector of length " + std::to_string(v.size()) + " in an index of dimension " +
+                                                      std::to_string(manifest.vec_dim));
+        flat.insert(flat.end(), v.begin(), v.end());
+        ix.nodes_.push_back({row, field, sub});
+    };
+    for (uint32_t r = 0; r < base.rows.size(); r++) {
+        const Tuple &t = base.rows[r];
+        for (size_t f : manifest.vec_fields) {
+            if (f >= t.size()) continue;
+            if (const std::vector<float> *v = t[f].get_vec()) {
+                push(*v, r, (uint32_t)f, -1);
+            } else if (const std::vector<DataValue> *l = t[f].get_slice()) {
+                for (size_t s = 0; s < l->size(); s++)
+                    if (const std::vector<float> *v2 = (*l)[s].get_vec()) push(*v2, r, (uint32_t)f, (int32_t)s);
+            }
+        }
+    }
+    if (levels && levels->size() != ix.nodes_.size())
+        throw CozoError("hnsw::bad_levels", "levels must hold one entry per indexed vector");
+    if (ix.nodes_.empty()) return ix;  // empty index: hnsw_knn returns no rows (:903-909)
+    check_gpu(cz_hnsw_build(flat.data(), (uint32_t)ix.nodes_.size(), (uint32_t)manifest.vec_dim, (int)manifest.distance,
+                            (uint32_t)manifest.m_neighbours, (uint32_t)manifest.ef_construction,
+                            manifest.keep_pruned_connections ? 1 : 0, levels ? levels->data() : nullptr, seed, max_batch,
+                            &ix.build_n_dist_, &ix.h_, 0, nullptr));
+    return ix;
+}
+
+void GpuHnswIndex::search_raw(const float *queries, uint32_t B, uint32_t k, uint32_t ef, std::vector<uint32_t> &ids,
+                              std::vector<double> &dist, std::vector<uint32_t> &count, const Poison &poison) const {
+    ids.assign((size_t)B * k, CZ_NONE);
+    dist.assign((size_t)B * k, 0.0);
+    count.assign(B, 0);
+    if (!h_ || B == 0) return;
+    check_gpu(cz_hnsw_search_batch(h_, queries, B, k, ef, 0, 0.0, ids.data(), dist.data(), count.data(), nullptr,
+                                   poison.flag_ptr(), 0, nullptr));
+}
+
+std::vector<std::vector<Tuple>> GpuHnswIndex::hnsw_knn_batch(const std::vector<const std::vector<float> *> &queries,
+                                                             const HnswSearch &config, const Poison &poison) const {
+    const uint32_t B = (uint32_t)queries.size();
+    std::vector<std::vector<Tuple>> result(B);
+    std::vector<float> q((size_t)B * manifest_.vec_dim);
+    for (uint32_t i = 0; i < B; i++) {
+        if (queries[i]->size() != manifest_.vec_dim)  // runtime/hnsw.rs:876-878
+            throw CozoError("", "query vector dimension mismatch");
+        std::copy(queries[i]->begin(), queries[i]->end(), q.begin() + (size_t)i * manifest_.vec_dim);
+    }
+    if (nodes_.empty() || B == 0) return result;
+    // without a filter the candidate set is cut to k before rows are fetched; with one, all ef survive until the
+    // filter has run (:943-947) -- ask the device for the same number of rows
+    const uint32_t kk = (uint32_t)(config.filter ? config.ef : std::min(config.k, config.ef));
+    std::vector<uint32_t> ids, count;
+    std::vector<double> dist;
+    search_raw(q.data(), B, kk, (uint32_t)config.ef, ids, dist, count, poison);
+    for (uint32_t i = 0; i < B; i++) {
+        std::vector<Tuple> &ret = result[i];
+        for (uint32_t j = 0; j < count[i]; j++) {
+            const double distance = dist[(size_t)i * kk + j];
+            if (config.radius && distance > *config.radius) continue;  // :952-956
+            const CompoundKey &ck = nodes_[ids[(size_t)i * kk + j]];
+            Tuple cand = base_->rows[ck.row];  // base_handle.get(cand_key.0)
+            const DataValue field_val = cand[ck.field];
+            // "make sure the order is the same as in all_bindings()" (:962): field, field_idx, distance, vector
+            if (config.bind_field) cand.push_back(DataValue(base_->column_name(ck.field)));
+            if (config.bind_field_idx) cand.push_back(ck.sub < 0 ? DataValue() : DataValue((int64_t)ck.sub));
+            if (config.bind_distance) cand.push_back(DataValue(distance));
+            if (config.bind_vector) {
+                if (ck.sub < 0) cand.push_back(field_val);
+                else cand.push_back((*field_val.get_slice())[(size_t)ck.sub]);
+            }
+            if (config.filter && !(*config.filter)(cand)) continue;  // :994-998
+            ret.push_back(std::move(cand));
+        }
+        if (ret.size() > config.k) ret.resize(config.k);  // :1005-1006 (rows already ascending by distance)
+    }
+    return result;
+}
+
+std::vector<Tuple> HnswSearchRA::iter(const std::vector<Tuple> &parent, const Poison &poison) const {
+    std::vector<const std::vector<float> *> queries;
+    queries.reserve(parent.size());
+    for (const Tuple &t : parent) {
+        const std::vector<float> *v = bind_idx < t.size() ? t[bind_idx].get_vec() : nullptr;
+        if (!v)  // query/ra.rs:1106-1109
+            throw CozoError("", "Expected vector, got " + (bind_idx < t.size() ? t[bind_idx].to_string() : std::string("nothing")));
+        queries.push_back(v);
+    }
+    std::vector<std::vector<Tuple>> res = index->hnsw_knn_batch(queries, hnsw_search, poison);
+    std::vector<Tuple> out;
+    for (size_t i = 0; i < parent.size(); i++) {
+        for (Tuple &r : res[i]) {
+            Tuple joined = parent[i];
+            joined.insert(joined.end(), std::make_move_iterator(r.begin()), std::make_move_iterator(r.end()));
+            out.push_back(std::move(joined));
+        }
+    }
+    return out;
+}
+
+}  // namespace cozo

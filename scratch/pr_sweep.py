@@ -37,10 +37,12 @@ def main():
     cfgs = [("gather", {}), ("blocked", {}), ("blocked", {"CZ_PR_SLICE_LOG2": "14"})]
     if os.environ.get("PR_SWEEP") == "chunks":
         cfgs = [("blocked", {})] + [("blocked", {"CZ_PR_CHUNKS": str(c), "CZ_PR_VAL_REUSE": r}) for c in (4, 8, 16, 32) for r in ("0", "1")]
+    if os.environ.get("PR_SWEEP") == "xcd":
+        cfgs = [("blocked", {"CZ_PR_XCD": "0"}), ("blocked", {"CZ_PR_XCD": "1"}), ("blocked", {"CZ_PR_XCD": "0"}), ("blocked", {"CZ_PR_XCD": "1"})]
     if os.environ.get("PR_SWEEP") == "blocked_only":
         cfgs = [("blocked", {})]
     for mode, env in cfgs:
-        for k in ("CZ_PR_CHUNKS", "CZ_PR_SLICE_LOG2", "CZ_PR_VAL_REUSE"):
+        for k in ("CZ_PR_CHUNKS", "CZ_PR_SLICE_LOG2", "CZ_PR_VAL_REUSE", "CZ_PR_XCD"):
             os.environ.pop(k, None)
         os.environ.update(env)
         torch.cuda.synchronize(); t0 = time.perf_counter()

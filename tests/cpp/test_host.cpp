@@ -1,0 +1,528 @@
+// test_host.cpp -- tests of the C++ host mirror (cozo_amd/host) through the C ABI, against the CPU oracle.
+//
+//   test_host cpu   host logic only: DataValue order, option readers, id assignment / CSR vs the oracle, registry
+//   test_host gpu   the fixed rules and HnswSearchRA on a real MI355X, rows compared with the oracle's
+// The oracle (oracle/cozo_oracle.h) is test infrastructure; it is linked into this test binary only.
+// Reads like the reference's own tests: runtime/tests.rs:529-577 (custom rule), algos/shortest_path_bfs.rs:124-174
+// (love graph), runtime/tests.rs:178-207 (PageRank options), runtime/tests.rs:700-809 (vector search).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "cozo_gpu.h"
+#include "cozo_host/fixed_rule.hpp"
+#include "cozo_host/graph_rules.hpp"
+#include "cozo_host/hnsw.hpp"
+#include "cozo_oracle.h"
+
+using namespace cozo;
+
+static int g_fail = 0, g_pass = 0;
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        if (cond) g_pass++;                                                      \
+        else {                                                                   \
+            g_fail++;                                                            \
+            std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);          \
+        }                                                                        \
+    } while (0)
+template <class E, class F>
+static bool throws(F f, const char *code = nullptr) {
+    try {
+        f();
+    } catch (const E &e) {
+        return !code || e.code == code;
+    } catch (...) {
+        return false;
+    }
+    return false;
+}
+
+static Tuple T(std::initializer_list<DataValue> l) { return Tuple(l); }
+
+// ---------------------------------------------------------------------------------------------------------------
+static void test_value_order() {
+    // Null < Bool < Num < Str < Bytes < List; Int before the equal Float; floats by total order
+    std::vector<DataValue> v = {DataValue::list({DataValue(1)}), DataValue("b"), DataValue(2.0), DataValue(2), DataValue(true),
+                                DataValue(), DataValue("a"), DataValue(1.5), DataValue(false), DataValue(-3),
+                                DataValue(Bytes{{1, 2}}), DataValue(std::nan(""))};
+    std::sort(v.begin(), v.end());
+    const char *want[] = {"null", "false", "true", "-3", "1.5", "2", "2.0", "nan", "\"a\"", "\"b\"", "bytes(2)", "[1]"};
+    for (size_t i = 0; i < v.size(); i++) CHECK(v[i].to_string() == want[i]);
+    CHECK(DataValue(1) != DataValue(1.0));
+    CHECK(DataValue(1).hash() != DataValue(1.0).hash());
+    int64_t i;
+    CHECK(DataValue(3.0).get_int(&i) && i == 3);
+    CHECK(!DataValue(3.5).get_int(&i));
+}
+
+static void test_options() {
+    std::map<std::string, DataValue> o = {{"theta", DataValue(0.5)}, {"iterations", DataValue(7)}, {"bad_iter", DataValue(2.5)},
+                                          {"neg", DataValue(-1)}, {"flag", DataValue(true)}, {"name", DataValue("x")},
+                                          {"big", DataValue(1.5)}};
+    FixedRulePayload p("PageRank", {}, o);
+    CHECK(p.unit_interval_option("theta") == 0.5);
+    CHECK(p.unit_interval_option("absent", 0.85) == 0.85);
+    CHECK(p.pos_integer_option("iterations") == 7);
+    CHECK(p.pos_integer_option("absent", 10) == 10);
+    CHECK(p.bool_option("flag") == true);
+    CHECK(p.string_option("name") == "x");
+    CHECK(p.float_option("iterations") == 7.0);
+    CHECK((throws<FixedRuleOptionNotFoundError>([&] { p.bool_option("absent"); }, "fixed_rule::arg_not_found")));
+    CHECK((throws<FixedRuleOptionNotFoundError>([&] { p.integer_option("bad_iter"); })));  // sic, see fixed_rule.cpp
+    CHECK((throws<WrongFixedRuleOptionError>([&] { p.pos_integer_option("neg"); }, "fixed_rule::arg_wrong")));
+    CHECK((throws<WrongFixedRuleOptionError>([&] { p.unit_interval_option("big"); })));
+    CHECK((throws<WrongFixedRuleOptionError>([&] { p.integer_option("name"); })));
+    CHECK((throws<WrongFixedRuleOptionError>([&] { p.bool_option("theta"); })));
+    CHECK((throws<WrongFixedRuleOptionError>([&] { p.string_option("flag"); })));
+    CHECK((throws<FixedRuleInputNotFoundError>([&] { p.get_input(0); }, "fixed_rule::not_enough_args")));
+}
+
+static std::vector<Tuple> random_edges(uint32_t n, size_t e, uint64_t seed, bool weighted, std::vector<int64_t> *from = nullptr,
+                                       std::vector<int64_t> *to = nullptr) {
+    std::mt19937_64 rng(seed);
+    std::vector<Tuple> rows;
+    for (size_t i = 0; i < e; i++) {
+        int64_t a = (int64_t)(rng() % n) * 7 - 100, b = (int64_t)(rng() % n) * 7 - 100;
+        if (weighted) rows.push_back(T({DataValue(a), DataValue(b), DataValue((double)(rng() % 1000) / 8.0)}));
+        else rows.push_back(T({DataValue(a), DataValue(b)}));
+    }
+    FixedRuleInputRelation rel(rows);
+    if (from) {
+        from->clear();
+        to->clear();
+        for (const Tuple &t : rel.iter()) {
+            int64_t a, b;
+            t[0].get_int(&a);
+            t[1].get_int(&b);
+            from->push_back(a);
+            to->push_back(b);
+        }
+    }
+    return rel.iter();
+}
+
+static void test_as_directed_graph_vs_oracle() {
+    for (int undirected = 0; undirected < 2; undirected++) {
+        std::vector<int64_t> from, to;
+        std::vector<Tuple> rows = random_edges(500, 4000, 11 + undirected, false, &from, &to);
+        FixedRuleInputRelation rel(rows);
+        GraphWithIndices g = rel.as_directed_graph(undirected != 0);
+        const uint64_t E = from.size();
+        std::vector<uint32_t> fi(E), ti(E);
+        std::vector<int64_t> ind(2 * E);
+        const uint32_t n = orc_assign_ids(from.data(), to.data(), E, fi.data(), ti.data(), ind.data());
+        CHECK(n == g.graph.n);
+        bool same = n == g.indices.size();
+        for (uint32_t i = 0; same && i < n; i++) {
+            int64_t v;
+            same = g.indices[i].get_int(&v) && v == ind[i] && g.inv_indices.at(g.indices[i]) == i;
+        }
+        CHECK(same);
+        const uint64_t E2 = undirected ? 2 * E : E;
+        std::vector<uint64_t> off(n + 1);
+        std::vector<uint32_t> tgt(E2);
+        orc_build_csr(n, E, fi.data(), ti.data(), nullptr, undirected, off.data(), tgt.data(), nullptr);
+        bool ok = g.graph.out_targets.size() == E2;
+        for (uint32_t v = 0; ok && v <= n; v++) ok = g.graph.out_offsets[v] == off[v];
+        for (uint64_t e = 0; ok && e < E2; e++) ok = g.graph.out_targets[e] == tgt[e];
+        CHECK(ok);
+        // in-adjacency = CSR of the reversed rows
+        orc_build_csr(n, E, ti.data(), fi.data(), nullptr, undirected, off.data(), tgt.data(), nullptr);
+        ok = true;
+        for (uint32_t v = 0; ok && v <= n; v++) ok = g.graph.in_offsets[v] == off[v];
+        for (uint64_t e = 0; ok && e < E2; e++) ok = g.graph.in_sources[e] == tgt[e];
+        CHECK(ok);
+    }
+    // weighted: default weight 1.0, bad weights rejected
+    {
+        FixedRuleInputRelation rel({T({DataValue("a"), DataValue("b"), DataValue(2.5)}), T({DataValue("b"), DataValue("c")})});
+        GraphWithIndices g = rel.as_directed_weighted_graph(false, false);
+        CHECK(g.graph.n == 3 && g.graph.out_weights.size() == 2 && g.graph.out_weights[0] == 2.5f && g.graph.out_weights[1] == 1.0f);
+        FixedRuleInputRelation bad1({T({DataValue("a"), DataValue("b"), DataValue(-1.0)})});
+        CHECK((throws<BadEdgeWeightError>([&] { bad1.as_directed_weighted_graph(false, false); }, "algo::invalid_edge_weight")));
+        CHECK(bad1.as_directed_weighted_graph(false, true).graph.out_weights[0] == -1.0f);
+        FixedRuleInputRelation bad2({T({DataValue("a"), DataValue("b"), DataValue("w")})});
+        CHECK((throws<BadEdgeWeightError>([&] { bad2.as_directed_weighted_graph(false, false); })));
+        FixedRuleInputRelation bad3({T({DataValue("a"), DataValue("b"), DataValue(INFINITY)})});
+        CHECK((throws<BadEdgeWeightError>([&] { bad3.as_directed_weighted_graph(false, false); })));
+        FixedRuleInputRelation bad4({T({DataValue("a")})});
+        CHECK((throws<NotAnEdgeError>([&] { bad4.as_directed_graph(false); }, "algo::not_an_edge")));
+    }
+}
+
+static void test_registry_and_simple_rule() {
+    // runtime/tests.rs:529-577: a custom rule summing a column, scaled by an option
+    FixedRuleRegistry reg = FixedRuleRegistry::with_gpu_defaults();
+    auto rule = std::make_shared<SimpleFixedRule>(1, [](const std::vector<NamedRows> &inputs, const std::map<std::string, DataValue> &opts) {
+        int64_t mul = 1;
+        opts.at("mul").get_int(&mul);
+        NamedRows out;
+        for (const Tuple &t : inputs[0].rows) {
+            int64_t v;
+            t[0].get_int(&v);
+            out.rows.push_back(T({DataValue(v * mul)}));
+        }
+        return out;
+    });
+    reg.register_fixed_rule("SumCols", rule);
+    CHECK((throws<CozoError>([&] { reg.register_fixed_rule("SumCols", rule); })));
+    CHECK((throws<CozoError>([&] { reg.register_fixed_rule("PageRank", rule); })));
+    CHECK((throws<CozoError>([&] { reg.unregister_fixed_rule("PageRank"); })));
+    FixedRulePayload p("SumCols", {FixedRuleInputRelation({T({DataValue(10)}), T({DataValue(26)})}, {"a"})}, {{"mul", DataValue(100)}});
+    RegularTempStore out = reg.run("SumCols", p, Poison(), {"x"});
+    std::vector<Tuple> rows = out.rows();
+    int64_t a = 0, b = 0;
+    CHECK(rows.size() == 2 && rows[0][0].get_int(&a) && rows[1][0].get_int(&b) && a == 1000 && b == 2600);
+    CHECK((throws<CozoError>([&] { reg.run("SumCols", p, Poison(), {"x", "y"}); }, "parser::fixed_rule_head_arity_mismatch")));
+    CHECK(reg.unregister_fixed_rule("SumCols"));
+    CHECK(!reg.unregister_fixed_rule("SumCols"));
+    CHECK((throws<CozoError>([&] { reg.get("SumCols"); }, "parser::fixed_rule_not_found")));
+    // no device -> the GPU rules fail loudly (no CPU fallback); a killed query reports ProcessKilled
+    Poison dead;
+    dead.kill();
+    CHECK((throws<ProcessKilled>([&] { dead.check(); }, "eval::killed")));
+}
+
+static void test_no_device_fails_loudly() {
+    FixedRuleRegistry reg = FixedRuleRegistry::with_gpu_defaults();
+    FixedRulePayload p("PageRank", {FixedRuleInputRelation({T({DataValue(1), DataValue(2)})})});
+    if (cz_device_count() <= 0) {
+        CHECK((throws<GpuError>([&] { reg.run("PageRank", p, Poison()); })));
+    } else {
+        CHECK(reg.run("PageRank", p, Poison()).size() == 2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GPU section
+static std::vector<uint64_t> to_u64(const std::vector<uint32_t> &v) { return std::vector<uint64_t>(v.begin(), v.end()); }
+
+static void gpu_pagerank() {
+    FixedRuleRegistry reg = FixedRuleRegistry::with_gpu_defaults();
+    for (int undirected = 0; undirected < 2; undirected++) {
+        std::vector<Tuple> rows = random_edges(3000, 30000, 5 + undirected, false);
+        FixedRuleInputRelation rel(rows);
+        std::map<std::string, DataValue> opts = {{"undirected", DataValue(undirected != 0)}, {"theta", DataValue(0.8)},
+                                                 {"epsilon", DataValue(1e-6)}, {"iterations", DataValue(15)}};
+        RegularTempStore out = reg.run("PageRank", FixedRulePayload("PageRank", {rel}, opts), Poison(), {"node", "rank"});
+        GraphWithIndices g = rel.as_directed_graph(undirected != 0);
+        std::vector<uint32_t> od = g.graph.out_degrees();
+        std::vector<float> sc(g.graph.n);
+        uint32_t it;
+        double err;
+        std::vector<uint64_t> off = to_u64(g.graph.in_offsets);
+        orc_pagerank(g.graph.n, off.data(), g.graph.in_sources.data(), od.data(), 0.8f, (double)(float)1e-6, 15, sc.data(), &it, &err, 1);
+        CHECK(out.size() == g.graph.n);
+        bool same = true;
+        for (const Tuple &t : out) {
+            double s;
+            same = same && t.size() == 2 && t[1].get_float(&s) && s == (double)sc[g.inv_indices.at(t[0])];
+        }
+        CHECK(same);  // bit-identical f32 scores, emitted as f64
+    }
+    // option validation happens before any device work, as in the reference (runtime/tests.rs:178-207)
+    FixedRuleInputRelation rel({T({DataValue(1), DataValue(2)})});
+    CHECK((throws<WrongFixedRuleOptionError>([&] { reg.run("PageRank", FixedRulePayload("PageRank", {rel}, {{"theta", DataValue(1.5)}}), Poison()); })));
+    CHECK((throws<WrongFixedRuleOptionError>([&] { reg.run("PageRank", FixedRulePayload("PageRank", {rel}, {{"iterations", DataValue(0)}}), Poison()); })));
+    CHECK(reg.run("PageRank", FixedRulePayload("PageRank", {FixedRuleInputRelation()}), Poison()).empty());  // :43-45
+    Poison dead;
+    dead.kill();
+    CHECK((throws<ProcessKilled>([&] { reg.run("PageRank", FixedRulePayload("PageRank", {rel}), dead); })));
+}
+
+static void gpu_love_graph() {
+    // algos/shortest_path_bfs.rs:124-174
+    const char *e[][2] = {{"alice", "eve"}, {"bob", "alice"}, {"eve", "alice"}, {"eve", "bob"}, {"eve", "charlie"},
+                          {"charlie", "eve"}, {"david", "george"}, {"george", "george"}};
+    std::vector<Tuple> rows;
+    for (auto &p : e) rows.push_back(T({DataValue(p[0]), DataValue(p[1])}));
+    FixedRuleRegistry reg = FixedRuleRegistry::with_gpu_defaults();
+    FixedRuleInputRelation love(rows, {"loving", "loved"});
+    FixedRuleInputRelation start({T({DataValue("alice")})}), end1({T({DataValue("bob")})}), end2({T({DataValue("george")})});
+    RegularTempStore r1 = reg.run("ShortestPathBFS", FixedRulePayload("ShortestPathBFS", {love, start, end1}), Poison());
+    CHECK(r1.size() == 1 && r1.rows()[0][2].get_slice() && r1.rows()[0][2].get_slice()->size() == 3);
+    RegularTempStore r2 = reg.run("ShortestPathBFS", FixedRulePayload("ShortestPathBFS", {love, start, end2}), Poison());
+    CHECK(r2.size() == 1 && r2.rows()[0][2].is_null());
+    // ConnectedComponents: {alice, bob, eve, charlie} and {david, george}; an extra node from input 1 gets a fresh id
+    FixedRuleInputRelation nodes({T({DataValue("zed")}), T({DataValue("alice")})});
+    RegularTempStore cc = reg.run("ConnectedComponents", FixedRulePayload("ConnectedComponents", {love, nodes}), Poison());
+    std::map<std::string, int64_t> grp;
+    for (const Tuple &t : cc) {
+        int64_t gid;
+        t[1].get_int(&gid);
+        grp[*t[0].get_str()] = gid;
+    }
+    CHECK(grp.size() == 7 && grp["alice"] == grp["bob"] && grp["alice"] == grp["charlie"] && grp["david"] == grp["george"] &&
+          grp["alice"] != grp["david"] && grp["zed"] == 2);
+    CHECK((throws<GpuError>([&] { reg.run("SCC", FixedRulePayload("SCC", {love}), Poison()); })));
+}
+
+static void gpu_bfs_cc_dijkstra_random() {
+    FixedRuleRegistry reg = FixedRuleRegistry::with_gpu_defaults();
+    std::vector<Tuple> rows = random_edges(2000, 7000, 99, false);
+    FixedRuleInputRelation rel(rows);
+    // --- ShortestPathBFS vs the oracle on the key-ordered graph
+    std::vector<Tuple> st = {T({rows[0][0]}), T({rows[17][0]}), T({rows[400][1]})};
+    std::vector<Tuple> en;
+    for (int i = 0; i < 40; i++) en.push_back(T({rows[(size_t)i * 53 % rows.size()][1]}));
+    FixedRuleInputRelation starts(st), ends(en);
+    RegularTempStore sp = reg.run("ShortestPathBFS", FixedRulePayload("ShortestPathBFS", {rel, starts, ends}), Poison());
+    std::vector<DataValue> extra;
+    for (const Tuple &t : starts.iter()) extra.push_back(t[0]);
+    for (const Tuple &t : ends.iter()) extra.push_back(t[0]);
+    GraphWithIndices og = rel.as_ordered_graph(extra);
+    std::vector<uint64_t> off = to_u64(og.graph.out_offsets);
+    size_t checked = 0;
+    bool same = true;
+    for (const Tuple &s : starts.iter()) {
+        std::vector<uint32_t> goals;
+        for (const Tuple &t : ends.iter()) goals.push_back(og.inv_indices.at(t[0]));
+        std::vector<uint32_t> par(og.graph.n);
+        const uint32_t s_id = og.inv_indices.at(s[0]);
+        orc_shortest_path_bfs(og.graph.n, off.data(), og.graph.out_targets.data(), s_id, goals.data(), (uint32_t)goals.size(), par.data());
+        for (const Tuple &t : ends.iter()) {
+            const uint32_t g_id = og.inv_indices.at(t[0]);
+            Tuple want = T({s[0], t[0], DataValue()});
+            if (par[g_id] != ORC_NONE) {
+                std::vector<DataValue> path;
+                for (uint32_t c = g_id; c != s_id; c = par[c]) path.push_back(og.indices[c]);
+                path.push_back(og.indices[s_id]);
+                std::reverse(path.begin(), path.end());
+                want[2] = DataValue::list(path);
+            }
+            same = same && sp.exists(want);
+            checked++;
+        }
+    }
+    CHECK(same && sp.size() == checked);
+    // --- BFS with a condition on the node id, limit 3 (bfs.rs): compare with the oracle's FIFO discovery order
+    {
+        int64_t threshold = 5000;
+        ExprOption cond{[threshold](const Tuple &t) {
+                            int64_t v;
+                            return t[0].get_int(&v) && v > threshold;
+                        },
+                        true};
+        FixedRuleInputRelation nodes;  // unused: the condition binds only the id column
+        RegularTempStore got = reg.run("BFS", FixedRulePayload("BFS", {rel, nodes, starts}, {{"limit", DataValue(3)}}, {{"condition", cond}}),
+                                       Poison());
+        std::vector<DataValue> sv;
+        for (const Tuple &t : starts.iter()) sv.push_back(t[0]);
+        GraphWithIndices bg = rel.as_ordered_graph(sv);
+        std::vector<uint64_t> boff = to_u64(bg.graph.out_offsets);
+        std::vector<uint8_t> visited(bg.graph.n, 0);
+        std::vector<uint32_t> par(bg.graph.n, ORC_NONE), order(bg.graph.n);
+        RegularTempStore want;
+        size_t found = 0;
+        for (const Tuple &s : starts.iter()) {
+            if (found >= 3) break;
+            const uint32_t s_id = bg.inv_indices.at(s[0]);
+            if (visited[s_id]) continue;
+            const uint32_t cnt = orc_bfs_order(bg.graph.n, boff.data(), bg.graph.out_targets.data(), s_id, visited.data(), par.data(), order.data());
+            for (uint32_t j = 0; j < cnt && found < 3; j++) {
+                int64_t v;
+                bg.indices[order[j]].get_int(&v);
+                if (v > threshold) {
+                    std::vector<DataValue> path;
+                    for (uint32_t c = order[j]; c != s_id; c = par[c]) path.push_back(bg.indices[c]);
+                    path.push_back(bg.indices[s_id]);
+                    std::reverse(path.begin(), path.end());
+                    want.put(T({s[0], bg.indices[order[j]], DataValue::list(path)}));
+                    found++;
+                }
+            }
+        }
+        CHECK(got.rows() == want.rows() && got.size() == 3);
+    }
+    // --- ConnectedComponents vs Tarjan on the symmetrised first-appearance graph
+    {
+        RegularTempStore cc = reg.run("ConnectedComponents", FixedRulePayload("ConnectedComponents", {rel}), Poison());
+        GraphWithIndices g = rel.as_directed_graph(true);
+        std::vector<uint64_t> o2 = to_u64(g.graph.out_offsets);
+        std::vector<uint32_t> grp(g.graph.n);
+        orc_tarjan_groups(g.graph.n, o2.data(), g.graph.out_targets.data(), grp.data());
+        bool ok = cc.size() == g.graph.n;
+        for (const Tuple &t : cc) {
+            int64_t gid;
+            ok = ok && t[1].get_int(&gid) && gid == (int64_t)grp[g.inv_indices.at(t[0])];
+        }
+        CHECK(ok);
+    }
+    // --- ShortestPathDijkstra: costs bit-exact vs the oracle, paths valid and tight
+    {
+        std::vector<Tuple> wrows = random_edges(1500, 6000, 7, true);
+        FixedRuleInputRelation wrel(wrows);
+        FixedRuleInputRelation wst({T({wrows[3][0]}), T({wrows[900][0]})});
+        RegularTempStore dj = reg.run("ShortestPathDijkstra", FixedRulePayload("ShortestPathDijkstra", {wrel, wst}, {{"undirected", DataValue(true)}}),
+                                      Poison());
+        GraphWithIndices g = wrel.as_directed_weighted_graph(true, false);
+        std::vector<uint64_t> o2 = to_u64(g.graph.out_offsets);
+        bool ok = true;
+        size_t nrows = 0;
+        for (const Tuple &s : wst.iter()) {
+            const uint32_t s_id = g.inv_indices.at(s[0]);
+            std::vector<float> dist(g.graph.n);
+            std::vector<uint32_t> par(g.graph.n);
+            orc_dijkstra(g.graph.n, o2.data(), g.graph.out_targets.data(), g.graph.out_weights.data(), s_id, nullptr, 0, dist.data(), par.data());
+            nrows += g.graph.n;
+            for (const Tuple &t : dj) {
+                if (!(t[0] == s[0])) continue;
+                double cost;
+                t[2].get_float(&cost);
+                const uint32_t t_id = g.inv_indices.at(t[1]);
+                ok = ok && ((double)dist[t_id] == cost || (std::isinf(cost) && std::isinf(dist[t_id])));
+                const std::vector<DataValue> &path = *t[3].get_slice();
+                if (std::isinf(cost)) {
+                    ok = ok && path.empty();
+                    continue;
+                }
+                // the path starts at s, ends at t, follows edges and its f32 running cost equals the reported cost
+                ok = ok && !path.empty() && path.front() == s[0] && path.back() == t[1];
+                float run = 0.f;
+                for (size_t i = 0; ok && i + 1 < path.size(); i++) {
+                    const uint32_t a = g.inv_indices.at(path[i]), b = g.inv_indices.at(path[i + 1]);
+                    float best = INFINITY;
+                    for (uint32_t e2 = g.graph.out_offsets[a]; e2 < g.graph.out_offsets[a + 1]; e2++)
+                        if (g.graph.out_targets[e2] == b && run + g.graph.out_weights[e2] == dist[b]) best = g.graph.out_weights[e2];
+                    ok = ok && std::isfinite(best);
+                    run = dist[b];
+                }
+            }
+        }
+        CHECK(ok && dj.size() == nrows);
+    }
+}
+
+static void gpu_hnsw_search_ra() {
+    // a base relation {k => v: <F32; 24>} with an L2 index, searched through HnswSearchRA (runtime/tests.rs:700-809 shape)
+    const size_t n = 3000, dim = 24;
+    std::mt19937 rng(3);
+    std::uniform_real_distribution<float> U(0.f, 1.f);
+    BaseRelation base;
+    base.keys = {"k"};
+    base.non_keys = {"v"};
+    std::vector<float> flat;
+    for (size_t i = 0; i < n; i++) {
+        std::vector<float> v(dim);
+        for (float &x : v) x = U(rng);
+        flat.insert(flat.end(), v.begin(), v.end());
+        base.rows.push_back(T({DataValue((int64_t)i), DataValue(F32Vec{v})}));
+    }
+    HnswIndexManifest mf = HnswIndexManifest::create("a", "vec", dim, {1}, HnswDistance::L2, 8, 40);
+    std::vector<int32_t> levels(n);
+    {
+        std::mt19937_64 r2(9);
+        for (auto &l : levels) {
+            double u = (double)(r2() >> 11) / 9007199254740992.0;
+            l = (int32_t)std::floor(-std::log(u > 0 ? u : 1e-300) * mf.level_multiplier);
+        }
+    }
+    // max_batch = 1 == the sequential hnsw_put order: the link tables equal the oracle's, so the search rows do too
+    GpuHnswIndex ix = GpuHnswIndex::create(mf, base, 0, 1, &levels);
+    CHECK(ix.node_count() == n && ix.device_bytes() > n * dim * 4);
+    orc_hnsw *ob = orc_hnsw_new((int)dim, ORC_L2, 8, 40, 0, 0, ORC_DOT_GPU);
+    orc_hnsw_insert(ob, flat.data(), (uint32_t)n, levels.data());
+    const int nl = orc_hnsw_n_levels(ob);
+    std::vector<uint32_t> lsize(nl);
+    std::vector<int32_t> lwidth(nl);
+    std::vector<std::vector<uint32_t>> lnodes(nl), lnbrs(nl);
+    std::vector<const uint32_t *> pn(nl), pb(nl);
+    for (int l = 0; l < nl; l++) {
+        lsize[l] = orc_hnsw_level_size(ob, l);
+        lwidth[l] = orc_hnsw_level_width(ob, l);
+        lnodes[l].resize(lsize[l]);
+        lnbrs[l].resize((size_t)lsize[l] * lwidth[l]);
+        orc_hnsw_export_level(ob, l, lnodes[l].data(), lnbrs[l].data());
+        pn[l] = lnodes[l].data();
+        pb[l] = lnbrs[l].data();
+    }
+    orc_flat_index fx = {(uint32_t)n, (int)dim, ORC_L2, ORC_DOT_GPU, flat.data(), nl, lsize.data(), lwidth.data(), pn.data(), pb.data(),
+                         orc_hnsw_entry(ob)};
+    // parent tuples (qid, query vector); k = 5, ef = 30, bind distance + field, radius, and a filter on the key
+    std::vector<Tuple> parent;
+    std::vector<std::vector<float>> qs;
+    for (int i = 0; i < 20; i++) {
+        std::vector<float> q(dim);
+        for (float &x : q) x = U(rng);
+        qs.push_back(q);
+        parent.push_back(T({DataValue((int64_t)i), DataValue(F32Vec{q})}));
+    }
+    HnswSearchRA ra{&ix, HnswSearch{}, 1};
+    ra.hnsw_search.k = 5;
+    ra.hnsw_search.ef = 30;
+    ra.hnsw_search.bind_distance = true;
+    std::vector<Tuple> got = ra.iter(parent, Poison());
+    bool ok = true;
+    size_t pos = 0;
+    for (int i = 0; i < 20; i++) {
+        uint32_t ids[5];
+        double dd[5];
+        uint64_t nd = 0;
+        const int cnt = orc_hnsw_knn(&fx, qs[i].data(), 5, 30, 0, 0.0, ids, dd, &nd);
+        for (int j = 0; j < cnt; j++, pos++) {
+            ok = ok && pos < got.size();
+            if (!ok) break;
+            const Tuple &t = got[pos];  // (qid, q, k, v, dist)
+            int64_t qid, key;
+            double d;
+            ok = ok && t.size() == 5 && t[0].get_int(&qid) && qid == i && t[2].get_int(&key) && key == (int64_t)ids[j] &&
+                 t[4].get_float(&d) && d == dd[j];
+        }
+    }
+    CHECK(ok && pos == got.size());
+    // filter + radius: the filter sees all ef candidates (hnsw.rs:943-947), then truncate(k)
+    ra.hnsw_search.filter = [](const Tuple &t) {
+        int64_t key;
+        return t[0].get_int(&key) && key % 2 == 0;
+    };
+    ra.hnsw_search.radius = 1.2;
+    got = ra.iter(parent, Poison());
+    ok = true;
+    pos = 0;
+    for (int i = 0; i < 20; i++) {
+        uint32_t ids[30];
+        double dd[30];
+        uint64_t nd = 0;
+        const int cnt = orc_hnsw_knn(&fx, qs[i].data(), 30, 30, 0, 0.0, ids, dd, &nd);
+        int taken = 0;
+        for (int j = 0; j < cnt && taken < 5; j++) {
+            if (dd[j] > 1.2 || ids[j] % 2 != 0) continue;
+            ok = ok && pos < got.size();
+            if (!ok) break;
+            int64_t key;
+            ok = ok && got[pos][2].get_int(&key) && key == (int64_t)ids[j];
+            pos++;
+            taken++;
+        }
+    }
+    CHECK(ok && pos == got.size());
+    CHECK((throws<CozoError>([&] { ra.iter({T({DataValue(1), DataValue("not a vector")})}, Poison()); })));
+    CHECK((throws<CozoError>([&] { ix.hnsw_knn(std::vector<float>(dim + 1, 0.f), HnswSearch{}, Poison()); })));
+    orc_hnsw_free(ob);
+}
+
+int main(int argc, char **argv) {
+    const std::string mode = argc > 1 ? argv[1] : "cpu";
+    test_value_order();
+    test_options();
+    test_as_directed_graph_vs_oracle();
+    test_registry_and_simple_rule();
+    test_no_device_fails_loudly();
+    if (mode == "gpu") {
+        if (cz_init(0) != CZ_OK) {
+            std::printf("FAIL: cz_init: %s\n", cz_last_error());
+            return 2;
+        }
+        gpu_pagerank();
+        gpu_love_graph();
+        gpu_bfs_cc_dijkstra_random();
+        gpu_hnsw_search_ra();
+    }
+    std::printf("%s: %d checks passed, %d failed\n", mode.c_str(), g_pass, g_fail);
+    return g_fail ? 1 : 0;
+}
