@@ -124,6 +124,7 @@ def bench_hnsw(args, torch, dist, rank, world, device):
     q = gen_vectors(torch, B, dim, args.dist, 43 + rank, device)  # every rank: its own parent tuples
     torch.cuda.synchronize()
     log(f"generated {args.n} x {dim} vectors ({args.dist}) in {time.time() - t0:.1f}s")
+    db = bench_distance_batch(args, torch, x, q, stream, device) if rank == 0 else None
     man = HnswIndexManifest(vec_dim=dim, distance="Cosine", m_neighbours=args.m, ef_construction=args.ef_construction)
     t0 = time.time()
     ix = GpuHnswIndex.build(man, x, seed=7, max_batch=args.max_batch, device_ptr=True, n=args.n, stream=stream)
@@ -197,7 +198,7 @@ def bench_hnsw(args, torch, dist, rank, world, device):
                roofline=dict(bound="hbm", kernel="hnsw_knn_kernel", achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
                              unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS, traffic=pmc_traffic("hnsw_knn", world),
                              algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=kern_s * 1e3),
-               index_bytes=ix.device_bytes, sweep=sweep)
+               index_bytes=ix.device_bytes, sweep=sweep, distance_batch=db)
     # CPU baseline: the oracle (a port of the reference algorithm) on the same index and the same queries
     if rank == 0 and world == 1 and not args.skip_cpu:
         try:
@@ -206,6 +207,32 @@ def bench_hnsw(args, torch, dist, rank, world, device):
             res["cpu_baseline"] = dict(value=None, unit="queries/s", cores=1, kind="port", sample=f"failed: {e}")
     ix.close()
     return res
+
+
+def bench_distance_batch(args, torch, x, q, stream, device):
+    """cz_distance_batch (VectorCache::dist over explicit (query, node) pairs) on the bench corpus: P random pairs,
+    4*d algorithmic bytes each; HIP events on the launch stream."""
+    from cozo_amd.hnsw import distance_batch_device
+    P = 1 << 22
+    g = torch.Generator(device=device)
+    g.manual_seed(1)
+    pairs = torch.stack([torch.randint(0, q.shape[0], (P,), generator=g, device=device, dtype=torch.int32),
+                         torch.randint(0, x.shape[0], (P,), generator=g, device=device, dtype=torch.int32)], 1).contiguous()
+    out = torch.empty(P, dtype=torch.float64, device=device)
+    for _ in range(2):
+        distance_batch_device("Cosine", x, q, pairs, out, stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        distance_batch_device("Cosine", x, q, pairs, out, stream)
+    e1.record()
+    torch.cuda.synchronize()
+    s = e0.elapsed_time(e1) / 1e3 / reps
+    algo = P * 4 * x.shape[1]
+    return dict(kernel="distance_pairs_kernel", pairs=P, metric="Cosine", ms=s * 1e3, distances_per_s=P / s,
+                roofline=dict(bound="hbm", achieved=algo / s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                              frac=algo / s / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_launch=algo, avg_launch_ms=s * 1e3))
 
 
 def cpu_baseline_hnsw(args, ix, q, ef, k):
@@ -368,6 +395,8 @@ def main():
             }
             if "cpu_baseline" in hn:
                 out["cpu_baseline"] = hn["cpu_baseline"]
+            if hn.get("distance_batch"):
+                out["distance_batch"] = hn["distance_batch"]
         else:
             out = {"metric": "pagerank_edges_per_sec", "value": pr["value"], "unit": "edges/s", "n_gpus": world,
                    "steps": pr["iterations"], "warmup": 2, "ms_per_step": pr["ms_per_iteration"], "higher_is_better": True,

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "libcozo_gpu.so")
+# COZO_GPU_LIB: an alternative build of the same library (e.g. the phase-timing profiling build of scratch/)
+SO_PATH = os.environ.get("COZO_GPU_LIB") or os.path.join(_HERE, "lib", "libcozo_gpu.so")
 
 CZ_NONE = 0xFFFFFFFF
 CZ_DEVICE_PTRS = 1

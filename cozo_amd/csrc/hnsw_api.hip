@@ -55,8 +55,15 @@ distance_pairs_kernel(int metric, const float *__restrict__ base, const float *_
         if constexpr (ITERS > 0) {
             const bool full = chunks == LPV * ITERS;
             RowRegs<ITERS, U> bv, qv;
-            load_rows<LPV, ITERS, U>(bv, brow, glane, chunks, full);
-            load_rows<LPV, ITERS, U>(qv, qrow, glane, chunks, full);
+            load_rows<LPV, ITERS, U, true>(bv, brow, glane, chunks, full);
+            // query rows ARE reused (by other pairs): plain loads, served by L2
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int j = 0; j < ITERS; j++) {
+                    const int c = glane + LPV * j;
+                    qv.v[u][j] = (full || c < chunks) ? qrow[u][c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
 #pragma unroll
             for (int u = 0; u < U; u++)
 #pragma unroll
@@ -373,6 +380,7 @@ IndexDev HnswIndex::dev() const {
     d.wu = wu;
     d.n_levels = n_levels;
     d.entry = entry;
+    d.flags = 0;
     return d;
 }
 
@@ -516,6 +524,7 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
         return set_error(CZ_E_UNSUPPORTED, "dim %u / ef %u need %zu bytes of LDS (> 160 KiB)", ix->dim, ef, smem);
     }
     IndexDev d = ix->dev();
+    if (const char *fl = getenv("CZ_HNSW_FLAGS")) d.flags = (uint32_t)atoi(fl);
     Shape sh = shape_of(ix->dim);
 #define CZ_LAUNCH_KNN(LPV, ITERS, U)                                                                                    \
     do {                                                                                                                \
@@ -526,11 +535,10 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
                            has_radius, radius, (uint32_t *)ws.ptr, words, d_ids, d_dist, d_count,                       \
                            (unsigned long long *)d_ndist);                                                              \
     } while (0)
-    // experiment knob: rows per round of a lane group for the 513..768-d shape (CZ_HNSW_U = 1 | 2 | 3)
+    // experiment knob: rows per round of a lane group for the 513..768-d shape (CZ_HNSW_U = 1 | 2)
     const char *knn_u_env = getenv("CZ_HNSW_U");
     const int knn_u = knn_u_env ? atoi(knn_u_env) : 0;
     if (sh.lpv == 64 && sh.iters == 3 && knn_u == 1) CZ_LAUNCH_KNN(64, 3, 1);
-    else if (sh.lpv == 64 && sh.iters == 3 && knn_u == 3) CZ_LAUNCH_KNN(64, 3, 3);
     else CZ_DISPATCH_SHAPE_SEARCH(sh, CZ_LAUNCH_KNN);
 #undef CZ_LAUNCH_KNN
     hipError_t e = hipGetLastError();
@@ -540,6 +548,19 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
 }
 
 }  // namespace cz
+
+#ifdef CZ_PHASE_TIMING
+// profiling builds only: total shader-clock cycles thread 0 of every workgroup spent per phase since the last reset
+extern "C" int cz_debug_phase_cycles(unsigned long long *out, int reset) {
+    CZ_HIP(hipDeviceSynchronize());
+    CZ_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(czh::cz_phase_cycles), 64));
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        CZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(czh::cz_phase_cycles), z, 64));
+    }
+    return CZ_OK;
+}
+#endif
 
 extern "C" int cz_hnsw_search_batch(cz_hnsw_index *h, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
                                     int has_radius, double radius, uint32_t *out_ids, double *out_dist,

@@ -88,12 +88,14 @@ build_insert_kernel(IndexDev ix, BuildTables T, uint32_t b0, uint32_t bn, int to
         S.load_query(ix.vec + (size_t)q * ix.ld);
         S.seed(entry);  // hnsw.rs:200-204
         const int lq = T.level[q];
-        for (int lv = top; lv > lq; lv--) {  // :219-229
-            S.search_level(lv, 1, true);
-            S.clear_visited();
-        }
-        for (int lv = min(lq, top); lv >= 0; lv--) {  // :242-359
-            S.search_level(lv, ef_c, true);
+        for (int lv = top; lv >= 0; lv--) {
+            const bool above = lv > lq;  // :219-229 greedy descent (ef = 1) above the vector's own top level
+            S.search_level(lv, above ? 1 : ef_c, true);  // one call site: the traversal is inlined once
+            if (above) {
+                S.clear_visited();
+                continue;
+            }
+            // :242-359
             const RowRef r = row_of(T, q, lv);
             const int nsel = S.select_heuristic(r.width, keep_pruned != 0);
             if (tid == 0) s.ctl[czh::C_KEEP] = (int)atomicAdd(req_count, (uint32_t)nsel);

@@ -22,11 +22,31 @@ namespace czh {
 
 using namespace czd;
 
+// Phase timing (profiling builds only: -DCZ_PHASE_TIMING, see scratch/phase_prof.sh): thread 0 of every workgroup
+// stamps the shader clock at the phase boundaries of the level-0 loop and the totals are added up per launch.
+#ifdef CZ_PHASE_TIMING
+__device__ unsigned long long cz_phase_cycles[8];
+#define CZ_PH_DECL unsigned long long ph_t0 = 0, ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define CZ_PH_START() do { if (tid == 0) ph_t0 = clock64(); } while (0)
+#define CZ_PH_MARK(i) do { if (tid == 0) { unsigned long long t_ = clock64(); if (ph_t0) ph_acc[i] += t_ - ph_t0; ph_t0 = t_; } } while (0)
+#define CZ_PH_COUNT(i, v) do { if (tid == 0) ph_acc[i] += (v); } while (0)
+#define CZ_PH_FLUSH() do { if (tid == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&cz_phase_cycles[i_], ph_acc[i_]); } while (0)
+#else
+#define CZ_PH_DECL
+#define CZ_PH_START() do {} while (0)
+#define CZ_PH_MARK(i) do {} while (0)
+#define CZ_PH_COUNT(i, v) do {} while (0)
+#define CZ_PH_FLUSH() do {} while (0)
+#endif
+
 constexpr uint32_t kExpanded = 0x80000000u;
 constexpr uint32_t kIdMask = 0x7FFFFFFFu;
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr int kVlogCap = 2048;
+// list capacity (x 256) and batch size (x 64) the register form of the merge covers; larger searches (ef > 512 or
+// link rows wider than 128) take the LDS-walking form
+constexpr int kMergeR = 2, kMergeEC = 2;
 
 struct IndexDev {
     const float *vec;        // [n][ld]
@@ -39,6 +59,7 @@ struct IndexDev {
     int wu;
     int n_levels;
     uint32_t entry;
+    uint32_t flags;          // experiment switches (CZ_HNSW_FLAGS); none defined at present
 };
 
 // LDS carve-up (all offsets multiples of 16 bytes)
@@ -56,7 +77,8 @@ struct Smem {
     uint32_t *sel;    // [256]   list positions of the selected neighbours
     uint8_t *st;      // [efcap] 0 pending, 1 selected, 2 rejected
 };
-enum { C_CNT = 0, C_TODO = 1, C_LO = 2, C_VLOG = 3, C_NELIG = 4, C_NDIST_LO = 5, C_NDIST_HI = 6, C_KEEP = 7, C_NUM = 8 };
+enum { C_CNT = 0, C_TODO = 1, C_LO = 2, C_VLOG = 3, C_NELIG = 4, C_NDIST_LO = 5, C_NDIST_HI = 6, C_KEEP = 7, C_NUM = 8,
+       C_WAVE0 = 9 /* .. C_WAVE0 + kWaves - 1: per-wave counts of the merge's compaction */ };
 
 __host__ __device__ inline size_t smem_bytes(uint32_t efcap, uint32_t wpad, uint32_t ld) {
     size_t b = 0;
@@ -108,7 +130,7 @@ __device__ __forceinline__ bool test_and_set(uint32_t *bitmap, uint32_t id) {
     return (old & bit) != 0;
 }
 
-template <int LPV, int ITERS, int U>
+template <int LPV, int ITERS, int U, bool NT = false>
 struct Searcher {
     const IndexDev &ix;
     Smem s;
@@ -118,6 +140,7 @@ struct Searcher {
     int chunks;
     float4 q[ITERS > 0 ? ITERS : 1];
     float qnorm;
+    CZ_PH_DECL
 
     static constexpr int VPW = 64 / LPV;          // lane groups per wave
     static constexpr int TG = kWaves * VPW;       // lane groups per workgroup
@@ -164,7 +187,7 @@ struct Searcher {
             const int j = min(base + u * TG, n - 1);  // past the end: re-read the last row, result discarded
             rows[u] = (const float4 *)(ix.vec + (size_t)s.todo[j] * ix.ld);
         }
-        load_rows<LPV, ITERS, U>(r, rows, glane, chunks, full);
+        load_rows<LPV, ITERS, U, NT>(r, rows, glane, chunks, full);
     }
     template <int METRIC>
     __device__ __forceinline__ void retire_round(const float4 (&qq)[ITERS > 0 ? ITERS : 1], const Regs &r,
@@ -212,6 +235,7 @@ struct Searcher {
             else if (ix.metric == CZ_L2) eval_rounds<CZ_L2>(qq, n);
             else eval_rounds<CZ_IP>(qq, n);
             __syncthreads();
+            CZ_PH_MARK(2);
             for (int j = tid; j < n; j += kThreads) {
                 const float2 raw = ((const float2 *)s.nkey)[j];
                 s.nkey[j] = dist_key(finish_distance(ix.metric, raw.x, raw.y, qqn));
@@ -325,7 +349,155 @@ struct Searcher {
     }
 
     // merge nkey/nid[0..n) into W (capacity ef).  Caller guarantees a barrier before; ends with a barrier.
+    // The eligible new entries (typically a handful of the ~50 evaluated per step once W is full) are compacted
+    // first; then every (W entry, new entry) pair is compared exactly ONCE, in registers: the new entries are
+    // broadcast one by one with v_readlane, a wave's 64 W entries answer with one ballot (= how many W entries
+    // precede the new one) while each lane counts the new entries that precede its own W entry (= how far it
+    // shifts).  No LDS traffic inside the loop (the previous form walked the whole batch through LDS per thread and
+    // spent 6 us of a 31 us step there).
     __device__ void merge(int n, int ef) {
+        if (ef > kMergeR * kThreads || n > kMergeEC * 64) {  // uniform: beyond what the register form holds
+            merge_wide(n, ef);
+            return;
+        }
+        const int cnt = s.ctl[C_CNT];
+        const bool full = cnt >= ef;
+        const uint64_t bkey = cnt > 0 ? s.wkey[cnt - 1] : 0;
+        // eligibility (hnsw.rs:575 `found_nn.len() < ef || neighbour_dist < furthest`, raw f64 compare)
+        // NaN corner (zero vector under Cosine): the reference inserts one neighbour at a time; once the list is
+        // full with a NaN as its maximum, `x < NaN` is false for ever and nothing else gets in.  Reproduce it: if
+        // this batch overflows a not-yet-full list and a NaN is among what fills it, only the first free slots
+        // (in neighbour order) are taken.
+        const int free_slots = ef - cnt;
+        bool nan_gate = false;
+        if (!full && cnt + n > ef) {  // uniform
+            const bool nan_here = (tid < free_slots && tid < n && s.nkey[tid] == ~0ull) || (tid == 0 && cnt > 0 && bkey == ~0ull);
+            nan_gate = __syncthreads_or(nan_here);
+        }
+        uint64_t mykey = 0;
+        uint32_t myid = CZ_NONE;
+        bool elig = false;
+        if (tid < n) {
+            mykey = s.nkey[tid];
+            myid = s.nid[tid];
+            if (full) elig = mykey < bkey && bkey != ~0ull;
+            else elig = nan_gate ? tid < free_slots : true;
+        }
+        // compaction (batch order kept): per-wave ballot + the wave totals through LDS
+        const unsigned long long em = __ballot(elig);
+        if (lane == 0) s.ctl[C_WAVE0 + wave] = __popcll(em);
+        __syncthreads();  // also orders the nkey/nid reads above before the in-place rewrite below
+        int before = 0, nelig = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) {
+            const int c = s.ctl[C_WAVE0 + w];
+            if (w < wave) before += c;
+            nelig += c;
+        }
+        if (nelig == 0) return;
+        if (elig) {
+            const int e = before + __popcll(em & ((1ull << lane) - 1ull));
+            s.nkey[e] = mykey;
+            s.nid[e] = myid;
+            s.todo[e] = 0;  // rank accumulator of compacted entry e
+        }
+        __syncthreads();
+        // registers: this thread's W entries (W index tid + r * kThreads: a wave holds 64 consecutive ones) and the
+        // compacted entries (lane l of EVERY wave holds entries l, 64 + l, ...)
+        constexpr int R = kMergeR;    // ef <= R * kThreads
+        constexpr int EC = kMergeEC;  // n <= EC * 64
+        uint64_t wk[R];
+        uint32_t wi[R];
+        int sft[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int j = tid + r * kThreads;
+            wk[r] = ~0ull;
+            wi[r] = CZ_NONE;
+            sft[r] = 0;
+            if (j < cnt) {
+                wk[r] = s.wkey[j];
+                wi[r] = s.wid[j];
+            }
+        }
+        uint64_t ek[EC];
+        uint32_t ei[EC];
+        int acc[EC];
+#pragma unroll
+        for (int c = 0; c < EC; c++) {
+            const int e = c * 64 + lane;
+            ek[c] = ~0ull;
+            ei[c] = CZ_NONE;
+            acc[c] = 0;
+            if (e < nelig) {
+                ek[c] = s.nkey[e];
+                ei[c] = s.nid[e];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < EC; c++) {
+            if (c * 64 >= nelig) break;  // uniform
+            const int tn = min(64, nelig - c * 64);
+            for (int t = 0; t < tn; t++) {
+                const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)ek[c], t);
+                const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(ek[c] >> 32), t);
+                const uint32_t it = __builtin_amdgcn_readlane(ei[c], t);
+                const uint64_t kt = ((uint64_t)khi << 32) | klo;
+                int before_t = 0;  // uniform: entries of W (this wave's chunks) / of the batch that precede entry t
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if (r * kThreads + wave * 64 >= cnt) break;  // uniform
+                    const bool valid = tid + r * kThreads < cnt;
+                    const bool lt = valid && key_lt(wk[r], wi[r] & kIdMask, kt, it);
+                    before_t += __popcll(__ballot(lt));
+                    sft[r] += (valid && !lt) ? 1 : 0;
+                }
+                if ((t & (kWaves - 1)) == wave) {  // one wave ranks entry t inside the batch
+#pragma unroll
+                    for (int c2 = 0; c2 < EC; c2++) {
+                        if (c2 * 64 >= nelig) break;  // uniform
+                        const bool lt2 = c2 * 64 + lane < nelig && key_lt(ek[c2], ei[c2], kt, it);
+                        before_t += __popcll(__ballot(lt2));
+                    }
+                }
+                if (lane == t) acc[c] += before_t;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < EC; c++)
+            if (c * 64 + lane < nelig && acc[c] != 0) atomicAdd(&s.todo[c * 64 + lane], (uint32_t)acc[c]);
+        __syncthreads();
+        // scatter in place: every W entry and every compacted entry is in a register by now
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int j = tid + r * kThreads;
+            if (j < cnt && sft[r] > 0 && j + sft[r] < ef) {
+                s.wkey[j + sft[r]] = wk[r];
+                s.wid[j + sft[r]] = wi[r];
+            }
+        }
+        if (tid < nelig) {  // thread e owns compacted entry e: chunk `wave`, lane `lane`
+            uint64_t k0 = ek[0];
+            uint32_t i0 = ei[0];
+#pragma unroll
+            for (int c = 1; c < EC; c++)
+                if (wave == c) {
+                    k0 = ek[c];
+                    i0 = ei[c];
+                }
+            const int npos = (int)s.todo[tid];
+            if (npos < ef) {
+                s.wkey[npos] = k0;
+                s.wid[npos] = i0;  // un-expanded
+                atomicMin(&s.ctl[C_LO], npos);
+            }
+        }
+        if (tid == 0) s.ctl[C_CNT] = min(ef, cnt + nelig);
+        __syncthreads();
+    }
+
+    // the general form of the merge (any ef <= 1024, any n <= 256): every thread walks the batch through LDS.
+    __device__ void merge_wide(int n, int ef) {
         const int cnt = s.ctl[C_CNT];
         const bool full = cnt >= ef;
         const uint64_t bkey = cnt > 0 ? s.wkey[cnt - 1] : 0;
@@ -438,6 +610,7 @@ struct Searcher {
         }
         if (tid == 0) s.ctl[C_LO] = 0;
         __syncthreads();
+        CZ_PH_START();
         const int width = level == 0 ? ix.w0 : ix.wu;
         for (;;) {
             // nearest un-expanded entry (uniform across the workgroup)
@@ -454,6 +627,7 @@ struct Searcher {
             }
             if (idx < 0) break;
             const uint32_t cand = s.wid[idx] & kIdMask;
+            CZ_PH_COUNT(5, 1);
             __syncthreads();  // everyone has read wid[idx] / C_LO before they change
             if (tid == 0) {
                 s.wid[idx] = cand | kExpanded;
@@ -461,6 +635,7 @@ struct Searcher {
                 s.ctl[C_TODO] = 0;
             }
             __syncthreads();
+            CZ_PH_MARK(0);
             // neighbour row + visited filter (wave 0), hnsw.rs:566-571
             if (wave == 0) {
                 const uint32_t *row = level == 0 ? ix.nbr0 + (size_t)cand * ix.w0
@@ -489,34 +664,56 @@ struct Searcher {
                 }
             }
             __syncthreads();
+            CZ_PH_MARK(1);
             const int n = s.ctl[C_TODO];
             if (n == 0) continue;
+            CZ_PH_COUNT(6, n);
             eval_todo(n);
             __syncthreads();
+            CZ_PH_MARK(3);
             merge(n, ef);
+            CZ_PH_MARK(4);
         }
     }
 
-    // distance to the entry point seeds W (hnsw.rs:915-918)
+    // distance to the entry point seeds W (hnsw.rs:915-918): one row, evaluated by the first lane group
     __device__ void seed(uint32_t entry) {
         if (tid == 0) {
-            s.todo[0] = entry;
             s.ctl[C_CNT] = 0;
             s.ctl[C_NDIST_LO] += 1;
         }
-        __syncthreads();
-        eval_todo(1);
-        __syncthreads();
-        if (tid == 0) {
-            s.wkey[0] = s.nkey[0];
-            s.wid[0] = s.nid[0];
-            s.ctl[C_CNT] = 1;
+        if (group == 0) {
+            const float4 *row = (const float4 *)(ix.vec + (size_t)entry * ix.ld);
+            float a0 = 0.f, a1 = 0.f;
+            if constexpr (ITERS > 0) {
+#pragma unroll
+                for (int j = 0; j < ITERS; j++) {
+                    const int c = glane + LPV * j;
+                    const float4 v = c < chunks ? row[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    acc_chunk(ix.metric, q[j], v, a0, a1);
+                }
+            } else {
+                for (int c = glane; c < chunks; c += LPV) acc_chunk(ix.metric, s.q[c], row[c], a0, a1);
+            }
+            float r2[2] = {a0, a1};
+            group_reduce_many<LPV, 2>(r2);
+            if (glane == 0) {
+                s.wkey[0] = dist_key(finish_distance(ix.metric, r2[0], r2[1], qnorm));
+                s.wid[0] = entry;
+                s.ctl[C_CNT] = 1;
+            }
         }
         __syncthreads();
     }
 };
 
 // hnsw_knn (hnsw.rs:869-1012): one workgroup per query
+// The search streams base rows with the non-temporal hint: same-box A/B at 1M x 768, batch 1024: 3.447 -> 3.267 ms
+// (the rows are read once; without the hint they push link rows and visited words out of L2).  Index construction
+// does NOT (its selection heuristic re-reads rows through L2 / Infinity Cache; NT cost it 40 %).
+#ifndef CZ_SEARCH_NT
+#define CZ_SEARCH_NT 1
+#endif
 template <int LPV, int ITERS, int U>
 __global__ void __launch_bounds__(kThreads)
 hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t efcap,
@@ -526,14 +723,20 @@ hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t k, uint
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t b = blockIdx.x;
     Smem s = carve(smem_raw, efcap, wpad, ix.ld);
-    Searcher<LPV, ITERS, U> S(ix, s, visited + (size_t)b * words, words);
+    Searcher<LPV, ITERS, U, CZ_SEARCH_NT != 0> S(ix, s, visited + (size_t)b * words, words);
     S.load_query(queries + (size_t)b * ix.dim);
     S.seed(ix.entry);
-    for (int lv = ix.n_levels - 1; lv > 0; lv--) {  // :919-929 greedy descent, ef = 1
-        S.search_level(lv, 1, true);
-        S.clear_visited();
+    // :919-938 greedy descent with ef = 1 through the upper levels, then the level-0 search with ef (one call site,
+    // so that the traversal is inlined once)
+    for (int lv = ix.n_levels - 1; lv >= 0; lv--) {
+        S.search_level(lv, lv > 0 ? 1 : (int)ef, lv > 0);
+        if (lv > 0) S.clear_visited();
     }
-    S.search_level(0, (int)ef, false);  // :930-938
+#ifdef CZ_PHASE_TIMING
+    if (threadIdx.x == 0) {
+        for (int i_ = 0; i_ < 8; i_++) atomicAdd(&cz_phase_cycles[i_], S.ph_acc[i_]);
+    }
+#endif
     // :943-1006 truncate to k, radius cut (`distance > r` => skip; a NaN distance is never > r), ascending
     const int cnt = s.ctl[C_CNT];
     const int kk = min((int)k, cnt);

@@ -46,9 +46,12 @@ def main():
     cnt = torch.empty(BMAX, dtype=torch.int32, device=dev)
     nd = torch.zeros(BMAX, dtype=torch.int64, device=dev)
     ref = None
-    for U in os.environ.get("HS_US", "2,4,6,8").split(","):
+    variants = [(U, fl) for fl in os.environ.get("HS_FLAGS", "0").split(",") for U in os.environ.get("HS_US", "0").split(",")]
+    variants = variants * int(os.environ.get("HS_REPEAT", "1"))
+    for U, fl in variants:
         os.environ["CZ_HNSW_U"] = U
-        for B in (1024, 4096, 8192):
+        os.environ["CZ_HNSW_FLAGS"] = fl
+        for B in [int(b) for b in os.environ.get("HS_BS", "1024,4096,8192").split(",")]:
             def run():
                 ix.hnsw_knn_batch_device(q[:B], HnswSearch(k=k, ef=ef), ids[:B], dd[:B], cnt[:B], nd[:B], stream)
             for _ in range(2): run()
@@ -65,6 +68,6 @@ def main():
                 else: same = bool(torch.equal(ref[0], ids[:B]) and torch.equal(ref[1], dd[:B]) and torch.equal(ref[2], nd[:B]))
             ndf = nd[:B].to(torch.float64)
             qs = torch.quantile(ndf, torch.tensor([0.5, 0.9, 0.99], dtype=torch.float64, device=dev)).tolist()
-            print(f"U={U} B={B}: {ms:.3f} ms, {B / ms * 1e3:.0f} q/s, {tot * 4 * dim / ms / 1e6:.0f} GB/s ({tot * 4 * dim / ms / 1e6 / 8000:.3f}), "
+            print(f"U={U} flags={fl} B={B}: {ms:.3f} ms, {B / ms * 1e3:.0f} q/s, {tot * 4 * dim / ms / 1e6:.0f} GB/s ({tot * 4 * dim / ms / 1e6 / 8000:.3f}), "
                   f"n_dist mean {ndf.mean().item():.0f} p50 {qs[0]:.0f} p90 {qs[1]:.0f} p99 {qs[2]:.0f} max {ndf.max().item():.0f}, same_as_first={same}", flush=True)
 main()
