@@ -174,11 +174,16 @@ struct Searcher {
 
     // distances from the register-resident vector (qq, qqn) to todo[0..n) -> nkey/nid   (all waves; ends with the
     // entries written but NOT yet visible: the caller's barrier publishes them).
-    // Lane group g owns entries g + TG * t, t = 0, 1, ...; a "round" is U consecutive t.  The rounds of a group are
-    // software pipelined (the next round's rows are requested before the current round is reduced), the reductions
-    // are DPP butterflies (no LDS round trips), and the f64 tail of the distance (1 - x / sqrt(..)) is NOT done per
-    // row by the whole wave: the group leader parks the raw f32 accumulators in the entry's key slot and, after a
-    // barrier, thread j finishes entry j -- one f64 sqrt/div per thread per expansion step instead of one per row.
+    // Lane group g owns entries g + TG * t, t = 0, 1, ...; a "round" is U consecutive t.  The next round's rows are
+    // requested before the current round is reduced, the reductions are DPP butterflies (no LDS round trips), and the
+    // f64 tail of the distance (1 - x / sqrt(..)) is NOT done per row by the whole wave: the group leader parks the raw
+    // f32 accumulators in the entry's key slot and, after a barrier, thread j finishes entry j -- one f64 sqrt/div per
+    // thread per expansion step instead of one per row.
+    // Depth of the row queue, measured (profiles/r01n): the compiler waits for BOTH rounds before it reduces the older
+    // one (vmcnt(0) at the join of the `more` branch), i.e. one round per wave is outstanding at a time.  Rewriting the
+    // loop as straight-line issue/consume pairs gives true double buffering (vmcnt(6..11)) and is 30 % SLOWER: a
+    // step's serial chain (link row -> visited atomics -> first row) of the other workgroups on the CU queues behind
+    // the deeper row stream.  Keep it shallow.
     template <int METRIC>
     __device__ __forceinline__ void issue_round(Regs &r, int base, int n, bool full) {
         const float4 *rows[U];

@@ -4,10 +4,11 @@
 set -e
 R=$(cd $(dirname $0)/.. && pwd)
 NAME=$1; shift
+SRC=${SRC:-$R/cozo_amd/csrc}
 mkdir -p $R/scratch/lib/obj_$NAME
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-value $*"
 for f in runtime hnsw_api hnsw_build graph pagerank; do
-  /opt/rocm/bin/hipcc $FLAGS -c $R/cozo_amd/csrc/$f.hip -o $R/scratch/lib/obj_$NAME/$f.o &
+  /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.hip -o $R/scratch/lib/obj_$NAME/$f.o &
 done
 wait
 g++ -shared -fPIC $R/scratch/lib/obj_$NAME/*.o -o $R/scratch/lib/libcozo_gpu_$NAME.so
