@@ -407,6 +407,79 @@ extern "C" int cz_connected_components(const uint32_t *offsets, const uint32_t *
     return CZ_OK;
 }
 
+// ---- ClusteringCoefficients (fixed_rule/algos/triangles.rs:25-110) ---------------------------------------------
+// For node v with adjacency list A (the symmetrised graph's out-neighbours: ascending, parallel edges kept),
+// n_triangles(v) = #{ (i, j) : A[i] > A[j] and A[j] is an out-neighbour of A[i] } -- list POSITIONS, so duplicates
+// count with their multiplicity exactly as the reference's nested `edges.iter()` loops do (:84-101); membership is
+// existence (`for nb in out_neighbors(e_src) { if nb == e_dst { return true } }`).  One wave per node: lane pairs
+// (i, j) are enumerated i-major, the membership test is a binary search in A[i]'s sorted list.  Integer output; the
+// host computes cc = 2 t / (d (d - 1)) in f64 like :102.
+__device__ __forceinline__ bool csr_contains(const uint32_t *__restrict__ tgt, uint32_t lo, uint32_t hi, uint32_t x) {
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const uint32_t v = tgt[mid];
+        if (v < x) lo = mid + 1;
+        else if (v > x) hi = mid;
+        else return true;
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(256)
+triangles_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t N,
+                 unsigned long long *__restrict__ n_tri, uint32_t *__restrict__ degree) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (gridDim.x * 256) >> 6;
+    for (uint32_t v = wave; v < N; v += n_waves) {
+        const uint32_t a = off[v], b = off[v + 1], d = b - a;
+        unsigned long long cnt = 0;
+        if (d >= 2) {
+            // pairs (i, j), j < i suffices: the list is ascending, so A[i] > A[j] implies j < i
+            for (uint32_t i = 1; i < d; i++) {
+                const uint32_t src = tgt[a + i];
+                const uint32_t lo = off[src], hi = off[src + 1];
+                for (uint32_t j = lane; j < i; j += 64) {
+                    const uint32_t dst = tgt[a + j];
+                    if (dst < src && csr_contains(tgt, lo, hi, dst)) cnt++;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if (lane == 0) {
+            n_tri[v] = cnt;
+            degree[v] = d;
+        }
+    }
+}
+
+extern "C" int cz_clustering_coefficients(const uint32_t *offsets, const uint32_t *targets, uint32_t N, uint64_t E,
+                                          uint64_t *n_triangles, uint32_t *degree, const volatile uint8_t *poison) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if (N == 0) return CZ_OK;
+    if (!n_triangles || !degree) return cz::set_error(CZ_E_INVALID, "null output");
+    rc = check_csr(offsets, targets, N, E);
+    if (rc) return rc;
+    if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+    cz::DevBuf<uint32_t> d_off, d_tgt, d_deg;
+    cz::DevBuf<unsigned long long> d_tri;
+    CZ_HIP(d_off.alloc((size_t)N + 1));
+    CZ_HIP(d_tgt.alloc(E));
+    CZ_HIP(d_deg.alloc(N));
+    CZ_HIP(d_tri.alloc(N));
+    CZ_HIP(hipMemcpy(d_off.p, offsets, ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
+    if (E) CZ_HIP(hipMemcpy(d_tgt.p, targets, E * 4, hipMemcpyHostToDevice));
+    const int blocks = (int)std::min<uint64_t>(256 * 16, ((uint64_t)N + 3) / 4);
+    hipLaunchKernelGGL(triangles_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, nullptr, d_off.p, d_tgt.p, N, d_tri.p, d_deg.p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "triangles launch: %s", hipGetErrorString(e));
+    CZ_HIP(hipMemcpy(n_triangles, d_tri.p, (size_t)N * 8, hipMemcpyDeviceToHost));
+    CZ_HIP(hipMemcpy(degree, d_deg.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+    return CZ_OK;
+}
+
 extern "C" int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N,
                        uint64_t E, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent,
                        const volatile uint8_t *poison) {

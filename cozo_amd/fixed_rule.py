@@ -658,6 +658,56 @@ class ShortestPathDijkstra(FixedRule):
                 out.put((indices[s], indices[t], cost, path))
 
 
+class ClusteringCoefficients(FixedRule):
+    """algos/triangles.rs:25-110 -> cz_clustering_coefficients.  Rows: (node, coefficient f64, triangles, degree)."""
+
+    def arity(self, options, rule_head) -> int:
+        return 4
+
+    def run(self, payload, out, poison):
+        edges = payload.get_input(0)
+        graph, indices, _ = edges.as_directed_graph(True)
+        if not indices:
+            return
+        tri, deg = _graph.clustering_coefficients(graph.out_offsets, graph.out_targets, poison=poison.flag)
+        for idx in range(graph.n):
+            d, t = int(deg[idx]), int(tri[idx])
+            cc = 0.0 if d < 2 else 2.0 * float(t) / (float(d) * (float(d) - 1.0))  # :80-82, :102
+            out.put((indices[idx], cc, t, d))
+
+
+class DegreeCentrality(FixedRule):
+    """algos/degree_centrality.rs:24-76: a scan with three counters per node -- no graph, nothing for the GPU to do;
+    mirrored on the host so that the rule family is complete.  Rows: (node, total, out, in)."""
+
+    def arity(self, options, rule_head) -> int:
+        return 4
+
+    def run(self, payload, out, poison):
+        counter: Dict[Any, list] = {}
+        vals: Dict[Any, Any] = {}
+        for t in payload.get_input(0).ensure_min_len(2).iter():
+            for pos, col in ((1, t[0]), (2, t[1])):
+                c = _canon(col)
+                vals.setdefault(c, col)
+                ent = counter.setdefault(c, [0, 0, 0])
+                ent[0] += 1
+                ent[pos] += 1
+            poison.check()
+        try:
+            nodes = payload.get_input(1)
+        except FixedRuleInputNotFoundError:
+            nodes = None
+        if nodes is not None:
+            for t in nodes.iter():
+                c = _canon(t[0])
+                vals.setdefault(c, t[0])
+                counter.setdefault(c, [0, 0, 0])
+                poison.check()
+        for c, (tot, o, i) in counter.items():
+            out.put((vals[c], tot, o, i))
+
+
 # ---- registry (Db::register_fixed_rule, runtime/db.rs:760-784) --------------------------------------------------
 class FixedRuleRegistry:
     """The GPU rules are registered under NEW names next to the built-ins (built-ins cannot be replaced or
@@ -665,13 +715,15 @@ class FixedRuleRegistry:
     (fixed_rule/mod.rs:799-802) -- see INTEGRATION.md."""
 
     BUILTIN = ("PageRank", "ShortestPathBFS", "BFS", "BreadthFirstSearch", "ConnectedComponents",
-               "StronglyConnectedComponents", "SCC", "ShortestPathDijkstra")
+               "StronglyConnectedComponents", "SCC", "ShortestPathDijkstra", "ClusteringCoefficients", "DegreeCentrality")
 
     def __init__(self):
         self._rules: Dict[str, FixedRule] = {}
         for name, impl in (("PageRankGpu", PageRank()), ("ShortestPathBFSGpu", ShortestPathBFS()), ("BFSGpu", Bfs()),
                            ("ConnectedComponentsGpu", ConnectedComponents()),
-                           ("ShortestPathDijkstraGpu", ShortestPathDijkstra())):
+                           ("ShortestPathDijkstraGpu", ShortestPathDijkstra()),
+                           ("ClusteringCoefficientsGpu", ClusteringCoefficients()),
+                           ("DegreeCentralityGpu", DegreeCentrality())):
             self._rules[name] = impl
 
     def register_fixed_rule(self, name: str, impl: FixedRule) -> None:

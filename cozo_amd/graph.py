@@ -121,6 +121,16 @@ def connected_components(off, tgt, poison=None):
     return grp, k.value
 
 
+def clustering_coefficients(off, tgt, poison=None):
+    """cz_clustering_coefficients on the symmetrised out-CSR -> (n_triangles u64 [N], degree u32 [N])"""
+    off, tgt = _csr32(off, tgt)
+    N = off.size - 1
+    tri = np.zeros(N, dtype=np.uint64)
+    deg = np.zeros(N, dtype=np.uint32)
+    check(_lib.lib().cz_clustering_coefficients(ptr(off), ptr(tgt), N, tgt.size, ptr(tri), ptr(deg), ptr(poison)))
+    return tri, deg
+
+
 def sssp(out_off, out_tgt, weights, starts, poison=None):
     out_off, out_tgt = _csr32(out_off, out_tgt)
     w = np.ascontiguousarray(weights, dtype=np.float32)

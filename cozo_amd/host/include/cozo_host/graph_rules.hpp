@@ -9,6 +9,8 @@
 //   StronglyConnectedComponent   fixed_rule/algos/strongly_connected_components.rs:42-77 (strong = false only)
 //                                                                                      -> cz_connected_components
 //   ShortestPathDijkstra         fixed_rule/algos/shortest_path_dijkstra.rs:33-153     -> cz_sssp
+//   ClusteringCoefficients       fixed_rule/algos/triangles.rs:25-110                  -> cz_clustering_coefficients
+//   DegreeCentrality             fixed_rule/algos/degree_centrality.rs:24-76           (a scan with counters: host only)
 #pragma once
 #include "fixed_rule.hpp"
 
@@ -42,6 +44,18 @@ public:
 };
 
 class ShortestPathDijkstra : public FixedRule {
+public:
+    size_t arity(const std::map<std::string, DataValue> &, const std::vector<std::string> &) const override { return 4; }
+    void run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const override;
+};
+
+class ClusteringCoefficients : public FixedRule {
+public:
+    size_t arity(const std::map<std::string, DataValue> &, const std::vector<std::string> &) const override { return 4; }
+    void run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const override;
+};
+
+class DegreeCentrality : public FixedRule {
 public:
     size_t arity(const std::map<std::string, DataValue> &, const std::vector<std::string> &) const override { return 4; }
     void run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const override;

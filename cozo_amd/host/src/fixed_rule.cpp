@@ -293,6 +293,8 @@ FixedRuleRegistry FixedRuleRegistry::with_gpu_defaults() {
     add("StronglyConnectedComponents", std::make_shared<StronglyConnectedComponent>(true));
     add("SCC", std::make_shared<StronglyConnectedComponent>(true));
     add("ShortestPathDijkstra", std::make_shared<ShortestPathDijkstra>());
+    add("ClusteringCoefficients", std::make_shared<ClusteringCoefficients>());
+    add("DegreeCentrality", std::make_shared<DegreeCentrality>());
     return r;
 }
 

@@ -237,4 +237,52 @@ void ShortestPathDijkstra::run(const FixedRulePayload &payload, RegularTempStore
     }
 }
 
+// ---- ClusteringCoefficients -----------------------------------------------------------------------------------
+void ClusteringCoefficients::run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const {
+    const FixedRuleInputRelation &edges = payload.get_input(0);
+    GraphWithIndices g = edges.as_directed_graph(/*undirected=*/true);  // triangles.rs:36
+    if (g.indices.empty()) return;
+    const DirectedCsrGraph &gr = g.graph;
+    std::vector<uint64_t> tri(gr.n);
+    std::vector<uint32_t> deg(gr.n);
+    check_gpu(cz_clustering_coefficients(gr.out_offsets.data(), gr.out_targets.data(), gr.n, gr.edge_count(), tri.data(),
+                                         deg.data(), poison.flag_ptr()));
+    for (uint32_t i = 0; i < gr.n; i++) {
+        const double d = (double)deg[i];
+        const double cc = deg[i] < 2 ? 0.0 : 2.0 * (double)tri[i] / (d * (d - 1.0));  // :80-82, :102
+        out.put(Tuple{g.indices[i], DataValue(cc), DataValue((int64_t)tri[i]), DataValue((int64_t)deg[i])});
+    }
+}
+
+// ---- DegreeCentrality (host only: the reference's rule is a scan with three counters per node) -----------------
+void DegreeCentrality::run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const {
+    struct Deg {
+        int64_t total = 0, out = 0, in = 0;
+    };
+    std::unordered_map<DataValue, Deg, DataValueHash> counter;
+    for (const Tuple &t : payload.get_input(0).ensure_min_len(2).iter()) {
+        Deg &f = counter[t[0]];
+        f.total++;
+        f.out++;
+        Deg &d = counter[t[1]];
+        d.total++;
+        d.in++;
+        poison.check();
+    }
+    if (payload.inputs_count() > 1) {
+        const FixedRuleInputRelation *nodes = nullptr;
+        try {
+            nodes = &payload.get_input(1);
+        } catch (const FixedRuleInputNotFoundError &) {
+        }
+        if (nodes)
+            for (const Tuple &t : nodes->iter()) {
+                if (!t.empty()) counter.emplace(t[0], Deg{});
+                poison.check();
+            }
+    }
+    for (const auto &kv : counter)
+        out.put(Tuple{kv.first, DataValue(kv.second.total), DataValue(kv.second.out), DataValue(kv.second.in)});
+}
+
 }  // namespace cozo

@@ -197,6 +197,14 @@ int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N,
 int cz_connected_components(const uint32_t *offsets, const uint32_t *targets, uint32_t N, uint64_t E, uint32_t *group,
                             uint32_t *n_groups, const volatile uint8_t *poison);
 
+/* ClusteringCoefficients::run (fixed_rule/algos/triangles.rs:25-110) on the adjacency of the symmetrised graph
+ * (as_directed_graph(undirected = true): ascending lists, parallel edges kept):
+ *   n_triangles [N] out: #{(i, j) list positions of node v : A[i] > A[j] and A[j] is an out-neighbour of A[i]}
+ *   degree [N] out: list length (multiplicity counted).  The shim emits
+ *   (node, 2 t / (d (d - 1)) as f64 -- 0.0 when d < 2 --, t, d) like :58-66, :102. */
+int cz_clustering_coefficients(const uint32_t *offsets, const uint32_t *targets, uint32_t N, uint64_t E,
+                               uint64_t *n_triangles, uint32_t *degree, const volatile uint8_t *poison);
+
 /* dijkstra (algos/shortest_path_dijkstra.rs:274-339) for n_starts sources on the weighted out-CSR
  * (as_directed_weighted_graph, fixed_rule/mod.rs:208-328; f32 weights >= 0):
  *   dist [n_starts][N] f32 (inf = unreachable), parent [n_starts][N] (a predecessor p with

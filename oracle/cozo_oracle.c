@@ -1016,3 +1016,35 @@ void orc_dijkstra(uint32_t n, const uint64_t *off, const uint32_t *tgt, const fl
     free(pri);
     free(is_goal);
 }
+
+/* ---- ClusteringCoefficients (fixed_rule/algos/triangles.rs:70-110) ----
+ * Restated loop for loop: for every node, `edges` = its out-neighbour list on the symmetrised graph (duplicates
+ * kept); n_triangles = sum over e_src in edges of #{ e_dst in edges : e_src > e_dst and e_dst is among
+ * out_neighbors(e_src) } (:84-101); cc = 2 t / (d (d - 1)) in f64, (0, 0, d) when d < 2 (:80-82, :102). */
+void orc_clustering_coefficients(uint32_t n, const uint64_t *off, const uint32_t *tgt, double *cc, uint64_t *n_tri,
+                                 uint32_t *degree) {
+    for (uint32_t v = 0; v < n; v++) {
+        const uint64_t a = off[v], b = off[v + 1];
+        const uint64_t d = b - a;
+        uint64_t t = 0;
+        if (d >= 2) {
+            for (uint64_t i = a; i < b; i++) {
+                const uint32_t e_src = tgt[i];
+                for (uint64_t j = a; j < b; j++) {
+                    const uint32_t e_dst = tgt[j];
+                    if (e_src <= e_dst) continue;
+                    for (uint64_t k = off[e_src]; k < off[e_src + 1]; k++) {
+                        if (tgt[k] == e_dst) {
+                            t++;
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+        degree[v] = (uint32_t)d;
+        n_tri[v] = t;
+        cc[v] = d < 2 ? 0.0 : 2.0 * (double)t / ((double)d * ((double)d - 1.0));
+    }
+}
+

@@ -113,6 +113,10 @@ uint32_t orc_bfs_order(uint32_t n, const uint64_t *off, const uint32_t *tgt, uin
 /* Tarjan exactly as TarjanSccG (explicit stack), grp[n] = rank of the component's root discovery id */
 uint32_t orc_tarjan_groups(uint32_t n, const uint64_t *off, const uint32_t *tgt, uint32_t *grp);
 
+/* ---- ClusteringCoefficients (algos/triangles.rs:25-110) on the symmetrised out-CSR (duplicates kept) ---- */
+void orc_clustering_coefficients(uint32_t n, const uint64_t *off, const uint32_t *tgt, double *cc, uint64_t *n_tri,
+                                 uint32_t *degree);
+
 /* ---- ShortestPathDijkstra (algos/shortest_path_dijkstra.rs:274-339) ---- */
 /* goals NULL => all nodes.  dist[n] f32 (inf unreachable), parent[n] (ORC_NONE) */
 void orc_dijkstra(uint32_t n, const uint64_t *off, const uint32_t *tgt, const float *w, uint32_t start,

@@ -112,6 +112,8 @@ def lib():
         L.orc_bfs_order.argtypes = [C.c_uint32, _u64p, _u32p, C.c_uint32, _u8p, _u32p, _u32p]
         L.orc_tarjan_groups.restype = C.c_uint32
         L.orc_tarjan_groups.argtypes = [C.c_uint32, _u64p, _u32p, _u32p]
+        L.orc_clustering_coefficients.restype = None
+        L.orc_clustering_coefficients.argtypes = [C.c_uint32, _u64p, _u32p, C.POINTER(C.c_double), _u64p, _u32p]
         L.orc_dijkstra.restype = None
         L.orc_dijkstra.argtypes = [C.c_uint32, _u64p, _u32p, _f32p, C.c_uint32, _u32p, C.c_uint32, _f32p, _u32p]
         _lib = L
@@ -331,6 +333,18 @@ def tarjan_groups(n, off, tgt):
     grp = np.empty(n, dtype=np.uint32)
     k = lib().orc_tarjan_groups(n, _p(off, _u64p), _p(tgt, _u32p), _p(grp, _u32p))
     return grp, k
+
+
+def clustering_coefficients(n, off, tgt):
+    """algos/triangles.rs:70-110 on the symmetrised out-CSR -> (cc f64 [n], n_triangles u64 [n], degree u32 [n])"""
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    tgt = _u32(tgt)
+    cc = np.empty(n, dtype=np.float64)
+    tri = np.empty(n, dtype=np.uint64)
+    deg = np.empty(n, dtype=np.uint32)
+    lib().orc_clustering_coefficients(n, _p(off, _u64p), _p(tgt, _u32p), cc.ctypes.data_as(C.POINTER(C.c_double)),
+                                      _p(tri, _u64p), _p(deg, _u32p))
+    return cc, tri, deg
 
 
 def dijkstra(n, off, tgt, w, start, goals=None):

@@ -188,6 +188,21 @@ static void test_registry_and_simple_rule() {
     CHECK((throws<ProcessKilled>([&] { dead.check(); }, "eval::killed")));
 }
 
+static void test_degree_centrality() {
+    // degree_centrality.rs:24-76: (node, total, out, in); nodes of the optional second relation get zeros
+    FixedRuleRegistry reg = FixedRuleRegistry::with_gpu_defaults();
+    FixedRuleInputRelation edges({T({DataValue("a"), DataValue("b")}), T({DataValue("a"), DataValue("c")}), T({DataValue("c"), DataValue("a")})});
+    FixedRuleInputRelation nodes({T({DataValue("z")}), T({DataValue("a")})});
+    RegularTempStore out = reg.run("DegreeCentrality", FixedRulePayload("DegreeCentrality", {edges, nodes}), Poison(), {"n", "t", "o", "i"});
+    CHECK(out.size() == 4);
+    CHECK(out.exists(T({DataValue("a"), DataValue(3), DataValue(2), DataValue(1)})));
+    CHECK(out.exists(T({DataValue("b"), DataValue(1), DataValue(0), DataValue(1)})));
+    CHECK(out.exists(T({DataValue("c"), DataValue(2), DataValue(1), DataValue(1)})));
+    CHECK(out.exists(T({DataValue("z"), DataValue(0), DataValue(0), DataValue(0)})));
+    FixedRuleInputRelation narrow({T({DataValue("a")})});
+    CHECK((throws<InputRelationArityError>([&] { reg.run("DegreeCentrality", FixedRulePayload("DegreeCentrality", {narrow}), Poison()); })));
+}
+
 static void test_no_device_fails_loudly() {
     FixedRuleRegistry reg = FixedRuleRegistry::with_gpu_defaults();
     FixedRulePayload p("PageRank", {FixedRuleInputRelation({T({DataValue(1), DataValue(2)})})});
@@ -398,6 +413,29 @@ static void gpu_bfs_cc_dijkstra_random() {
     }
 }
 
+static void gpu_clustering_coefficients() {
+    FixedRuleRegistry reg = FixedRuleRegistry::with_gpu_defaults();
+    std::vector<Tuple> rows = random_edges(300, 2500, 21, false);
+    for (size_t i = 0; i < 100; i++) rows.push_back(T({rows[i][1], rows[i][0]}));  // bidirectional pairs: doubled multiplicity
+    rows.push_back(T({rows[0][0], rows[0][0]}));                                    // a self loop
+    FixedRuleInputRelation rel(rows);
+    RegularTempStore out = reg.run("ClusteringCoefficients", FixedRulePayload("ClusteringCoefficients", {rel}), Poison());
+    GraphWithIndices g = rel.as_directed_graph(true);
+    std::vector<uint64_t> off = to_u64(g.graph.out_offsets);
+    std::vector<double> cc(g.graph.n);
+    std::vector<uint64_t> tri(g.graph.n);
+    std::vector<uint32_t> deg(g.graph.n);
+    orc_clustering_coefficients(g.graph.n, off.data(), g.graph.out_targets.data(), cc.data(), tri.data(), deg.data());
+    bool ok = out.size() == g.graph.n;
+    for (const Tuple &t : out) {
+        const uint32_t v = g.inv_indices.at(t[0]);
+        double c;
+        int64_t tt, dd;
+        ok = ok && t[1].get_float(&c) && c == cc[v] && t[2].get_int(&tt) && (uint64_t)tt == tri[v] && t[3].get_int(&dd) && (uint32_t)dd == deg[v];
+    }
+    CHECK(ok);
+}
+
 static void gpu_hnsw_search_ra() {
     // a base relation {k => v: <F32; 24>} with an L2 index, searched through HnswSearchRA (runtime/tests.rs:700-809 shape)
     const size_t n = 3000, dim = 24;
@@ -512,6 +550,7 @@ int main(int argc, char **argv) {
     test_options();
     test_as_directed_graph_vs_oracle();
     test_registry_and_simple_rule();
+    test_degree_centrality();
     test_no_device_fails_loudly();
     if (mode == "gpu") {
         if (cz_init(0) != CZ_OK) {
@@ -521,6 +560,7 @@ int main(int argc, char **argv) {
         gpu_pagerank();
         gpu_love_graph();
         gpu_bfs_cc_dijkstra_random();
+        gpu_clustering_coefficients();
         gpu_hnsw_search_ra();
     }
     std::printf("%s: %d checks passed, %d failed\n", mode.c_str(), g_pass, g_fail);

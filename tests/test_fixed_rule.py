@@ -345,6 +345,64 @@ def test_connected_components_int_keys_fast_path(registry):
     assert_same_rows(rows, ref_connected_components(edges))
 
 
+def ref_clustering_coefficients(edge_rows):
+    """triangles.rs:25-110 at the DataValue level: first-appearance ids, symmetrised multi-adjacency"""
+    rows = sorted({FR._canon(tuple(r)): tuple(r) for r in edge_rows}.values(), key=FR._tuple_key)
+    ids, vals = {}, []
+    adj = {}
+    for f, t in ((r[0], r[1]) for r in rows):
+        for v in (f, t):
+            if FR._canon(v) not in ids:
+                ids[FR._canon(v)] = len(vals)
+                vals.append(v)
+        a, b = ids[FR._canon(f)], ids[FR._canon(t)]
+        adj.setdefault(a, []).append(b)
+        adj.setdefault(b, []).append(a)
+    out = []
+    for v in range(len(vals)):
+        edges = sorted(adj.get(v, []))
+        d = len(edges)
+        if d < 2:
+            out.append((vals[v], 0.0, 0, d))
+            continue
+        t = sum(1 for s in edges for e in edges if s > e and e in adj.get(s, []))
+        out.append((vals[v], 2.0 * t / (d * (d - 1.0)), t, d))
+    return out
+
+
+def ref_degree_centrality(edge_rows, node_rows=()):
+    """degree_centrality.rs:24-76"""
+    counter, vals = {}, {}
+    for r in sorted({FR._canon(tuple(r)): tuple(r) for r in edge_rows}.values(), key=FR._tuple_key):
+        for pos, v in ((1, r[0]), (2, r[1])):
+            vals.setdefault(FR._canon(v), v)
+            c = counter.setdefault(FR._canon(v), [0, 0, 0])
+            c[0] += 1
+            c[pos] += 1
+    for r in node_rows:
+        vals.setdefault(FR._canon(r[0]), r[0])
+        counter.setdefault(FR._canon(r[0]), [0, 0, 0])
+    return [(vals[k], c[0], c[1], c[2]) for k, c in counter.items()]
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_clustering_coefficients_rule(registry, seed):
+    edges = str_graph(60, 200, seed)
+    edges += [(b, a) for a, b in edges[:20]] + [(edges[0][0], edges[0][0])]  # bidirectional pairs, a self loop
+    rows = registry.run("ClusteringCoefficientsGpu", [rel(edges)])
+    assert_same_rows(rows, ref_clustering_coefficients(edges))
+    assert registry.run("ClusteringCoefficientsGpu", [rel([])]) == []
+
+
+def test_degree_centrality_rule(registry):
+    edges = str_graph(40, 90, 3)
+    extra = [("nobody",), (edges[0][0],)]
+    assert_same_rows(registry.run("DegreeCentralityGpu", [rel(edges), rel(extra)]), ref_degree_centrality(edges, extra))
+    assert_same_rows(registry.run("DegreeCentralityGpu", [rel(edges)]), ref_degree_centrality(edges))
+    with pytest.raises(FR.InputRelationArityError):
+        registry.run("DegreeCentralityGpu", [rel([("a",)])])
+
+
 @pytest.mark.parametrize("undirected", [False, True])
 def test_dijkstra_rule(registry, undirected):
     rng = np.random.default_rng(21)

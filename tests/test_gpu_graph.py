@@ -208,6 +208,28 @@ def test_connected_components_bitexact(oracle, gpu_lib):
     assert k == 1 and (grp == 0).all()
 
 
+def test_clustering_coefficients_bitexact(oracle, gpu_lib):
+    """triangles.rs:70-110: integer triangle / degree counts per node, duplicates and self loops included"""
+    from cozo_amd import graph as G
+    for n, e, seed in [(30, 60, 1), (400, 3000, 2), (5000, 40000, 3)]:
+        frm, to = util.random_relation(n, e, seed)
+        # add reversed duplicates (an already-bidirectional pair doubles its multiplicity under `undirected`) and self loops
+        frm = np.concatenate([frm, to[: e // 10], frm[:5]])
+        to = np.concatenate([to, frm[: e // 10], frm[-5:]])
+        g = util.graph_from_relation(oracle, frm, to, undirected=True)
+        tri, deg = G.clustering_coefficients(g["ooff"], g["otgt"])
+        occ, otri, odeg = oracle.clustering_coefficients(g["n"], g["ooff"], g["otgt"])
+        assert np.array_equal(tri, otri) and np.array_equal(deg, odeg)
+    # a hub: one node adjacent to everything (long list, many pairs per wave)
+    n = 600
+    frm = np.concatenate([np.zeros(n - 1, dtype=np.int64), np.arange(1, n - 1, dtype=np.int64)])
+    to = np.concatenate([np.arange(1, n, dtype=np.int64), np.arange(2, n, dtype=np.int64)])
+    g = util.graph_from_relation(oracle, frm, to, undirected=True)
+    tri, deg = G.clustering_coefficients(g["ooff"], g["otgt"])
+    _, otri, odeg = oracle.clustering_coefficients(g["n"], g["ooff"], g["otgt"])
+    assert np.array_equal(tri, otri) and np.array_equal(deg, odeg) and tri.max() == n - 2
+
+
 def test_sssp_costs_bitexact(oracle, gpu_lib):
     from cozo_amd import graph as G
     for n, e, seed in [(60, 200, 1), (5000, 30000, 2)]:

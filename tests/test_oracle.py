@@ -194,3 +194,26 @@ def test_hnsw_radius_empty_and_filter_width(oracle):
     empty = O.FlatIndex(np.zeros((0, 16), np.float32), O.L2, [], [], O.NONE)
     ids, dist, cnt, _ = empty.knn_batch(x[:3], 5, 20)
     assert (cnt == 0).all()
+
+
+def test_clustering_coefficients_against_matrix_powers(oracle):
+    """triangles.rs:70-110 on SIMPLE undirected graphs: triangles(v) = (A^3)_vv / 2, degree = row sum; plus a
+    hand-checked multigraph (a doubled edge doubles the pairs it takes part in)."""
+    rng = np.random.default_rng(7)
+    for n, p in [(12, 0.5), (60, 0.15), (150, 0.05)]:
+        A = np.triu((rng.random((n, n)) < p).astype(np.int64), 1)
+        A = A + A.T
+        f, t = np.nonzero(A)
+        off, tgt = oracle.build_csr(n, f, t)
+        cc, tri, deg = oracle.clustering_coefficients(n, off, tgt)
+        want_tri = np.diag(np.linalg.matrix_power(A, 3)) // 2
+        want_deg = A.sum(1)
+        assert np.array_equal(tri.astype(np.int64), want_tri) and np.array_equal(deg.astype(np.int64), want_deg)
+        want_cc = np.where(want_deg >= 2, 2.0 * want_tri / np.maximum(want_deg * (want_deg - 1.0), 1.0), 0.0)
+        assert np.array_equal(cc, want_cc)
+    # triangle 0-1-2 with the edge 0-1 present twice: node 2 sees one pair (1 > 0), nodes 0 and 1 see their
+    # doubled neighbour twice
+    f = np.array([0, 1, 0, 1, 1, 2, 0, 2]); t = np.array([1, 0, 1, 0, 2, 1, 2, 0])
+    off, tgt = oracle.build_csr(3, f, t)
+    cc, tri, deg = oracle.clustering_coefficients(3, off, tgt)
+    assert deg.tolist() == [3, 3, 2] and tri.tolist() == [2, 2, 1]

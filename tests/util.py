@@ -62,7 +62,7 @@ class OracleGraphBackend:
 
     def install(self, monkeypatch):
         import cozo_amd.graph as G
-        for name in ("pagerank", "bfs", "connected_components", "sssp"):
+        for name in ("pagerank", "bfs", "connected_components", "sssp", "clustering_coefficients"):
             monkeypatch.setattr(G, name, getattr(self, name))
 
     def pagerank(self, in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10, poison=None):
@@ -92,6 +92,10 @@ class OracleGraphBackend:
 
     def connected_components(self, off, tgt, poison=None):
         return self.O.tarjan_groups(len(off) - 1, off, tgt)
+
+    def clustering_coefficients(self, off, tgt, poison=None):
+        _, tri, deg = self.O.clustering_coefficients(len(off) - 1, off, tgt)
+        return tri, deg
 
     def sssp(self, out_off, out_tgt, weights, starts, poison=None):
         n = len(out_off) - 1
