@@ -57,19 +57,27 @@ class ShardedPageRank:
         self.local_init(cin)
         rb = self.rank * self.per
         it = 0
+        # `err < tolerance` can never hold for tolerance <= 0 (err is a sum of absolute values): the loop then runs
+        # max_iter sweeps back to back without a host round trip per iteration; the error is read once at the end
+        never_stops_early = not (tolerance > 0.0)
         while True:
             if poison is not None and poison():
                 raise RuntimeError("ProcessKilled")
+            last = it + 1 == max_iter
             self.err.zero_()
             self.local_step(cin, cout, self.err)
             if self.world > 1:
                 # in-place all-gather: this rank's slice already sits at its final position in `cout`
                 dist.all_gather_into_tensor(cout, cout[rb:rb + self.per], group=self.group)
-                dist.all_reduce(self.err, op=dist.ReduceOp.SUM, group=self.group)
+                if last or not never_stops_early:
+                    dist.all_reduce(self.err, op=dist.ReduceOp.SUM, group=self.group)
             cin, cout = cout, cin
             it += 1
+            if never_stops_early and not last:
+                continue
             e = float(self.err.item())
             if e < tolerance or it == max_iter:
+                self.contrib = [cin, cout]  # contrib[0] is the vector the next sweep would read
                 return it, e
 
 
