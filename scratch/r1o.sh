@@ -1,7 +1,7 @@
 #!/bin/bash
 # final round-1 measurement set: plain bench, bench under rocprofv3 kernel trace, PMC traffic passes
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r1o
+O=$R/gpurun_out/r1t
 rm -rf $O; mkdir -p $O
 cd $R
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cat $O/bench.json
@@ -12,18 +12,18 @@ db=$(find $O/trace -name "*.db" | head -1)
 python $R/profiles/summarize.py "$db" > $O/bench_kernel_stats.txt; head -14 $O/bench_kernel_stats.txt | cut -c1-150; grep "^# " $O/bench_kernel_stats.txt | tail -8
 rm -rf $O/trace
 for set in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $set --kernel-include-regex "hnsw_knn_kernel|distance_pairs_kernel|pb_expand_kernel|pb_reduce_kernel" --output-format csv -d $O/pmc_$set -o pmc -- python $R/bench.py --skip-cpu --steps 3 --warmup 1 --ef 96 --pr-iters 3 > $O/pmc_$set.out 2>&1
+  timeout 600 rocprofv3 --pmc $set --kernel-include-regex "hnsw_knn_kernel|distance_pairs_kernel|distance_runs_kernel|pb_expand_kernel|pb_reduce_kernel" --output-format csv -d $O/pmc_$set -o pmc -- python $R/bench.py --skip-cpu --steps 3 --warmup 1 --ef 96 --pr-iters 3 > $O/pmc_$set.out 2>&1
   echo "pmc $set rc=$?"
 done
 python - <<'PY'
 import csv, glob, os, collections
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(R + "/gpurun_out/r1o/pmc_*/**/*counter_collection.csv", recursive=True):
+for f in glob.glob(R + "/gpurun_out/r1t/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-with open(R + "/gpurun_out/r1o/pmc_summary.txt", "w") as out:
+with open(R + "/gpurun_out/r1t/pmc_summary.txt", "w") as out:
     out.write("# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs, no tracing) over `python bench.py --skip-cpu --steps 3 --warmup 1 --ef 96 --pr-iters 3`\n# per-dispatch values in KiB as rocprofv3 reports them (uncorrected); last3avg = the timed-loop launches\n")
     for k in sorted(acc):
         for cn, vals in sorted(acc[k].items()):
