@@ -137,8 +137,11 @@ def bench_hnsw(args, torch, dist, rank, world, device):
     # ground truth by exhaustive scan, then the smallest ef of the ladder that reaches the recall target
     gt = torch.empty((B, k), dtype=torch.int32, device=device)
     gtd = torch.empty((B, k), dtype=torch.float64, device=device)
-    ix.bruteforce_knn_device(q, k, gt, gtd, stream)
+    t0 = time.time()
+    ix.bruteforce_knn_device(q, k, gt, gtd, stream, gemm=True)  # B x N x d dot products as one f32 MFMA GEMM
     torch.cuda.synchronize()
+    gt_s = time.time() - t0
+    log(f"exact ground truth (GEMM form on the matrix cores): {gt_s * 1e3:.0f} ms, {2.0 * B * args.n * dim / gt_s / 1e12:.1f} TFLOP/s incl. selection")
     gt64 = gt.to(torch.int64) & 0xFFFFFFFF
     ids = torch.empty((B, k), dtype=torch.int32, device=device)
     dd = torch.empty((B, k), dtype=torch.float64, device=device)

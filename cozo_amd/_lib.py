@@ -13,6 +13,7 @@ SO_PATH = os.environ.get("COZO_GPU_LIB") or os.path.join(_HERE, "lib", "libcozo_
 
 CZ_NONE = 0xFFFFFFFF
 CZ_DEVICE_PTRS = 1
+CZ_BF_GEMM = 8
 CZ_PR_GATHER = 2
 CZ_PR_BLOCKED = 4
 CZ_L2, CZ_COSINE, CZ_IP = 0, 1, 2

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "hnsw_index.h"
 #include "hnsw_kernels.cuh"
+#include "topk.cuh"
 
 using namespace czd;
 using czh::IndexDev;
@@ -251,70 +252,7 @@ bf_chunk_kernel(int metric, const float *__restrict__ base, uint32_t n, uint32_t
             }
         }
         __syncthreads();
-        // rank-merge the batch into the sorted top list (capacity k); ids are distinct => strict order
-        const uint64_t bound_k = tcnt >= (int)k ? tkey[k - 1] : ~0ull;
-        const uint32_t bound_i = tcnt >= (int)k ? tid_[k - 1] : CZ_NONE;
-        uint64_t mk = 0;
-        uint32_t mi = CZ_NONE;
-        bool elig = false;
-        if (tid < nb) {
-            mk = bkey[tid];
-            mi = bid[tid];
-            elig = tcnt < (int)k || czh::key_lt(mk, mi, bound_k, bound_i);
-        }
-        int nelig = __syncthreads_count(elig);
-        if (nelig > 0) {
-            if (tid < nb && !elig) bid[tid] = CZ_NONE;
-            __syncthreads();
-            // positions of old entries (each thread owns entries tid, tid+256, ...)
-            int npos = -1;
-            if (elig) {
-                int r1c = 0;
-                for (int t = 0; t < nb; t++) {
-                    uint32_t ni = bid[t];
-                    if (ni != CZ_NONE && czh::key_lt(bkey[t], ni, mk, mi)) r1c++;
-                }
-                int lo = 0, hi = tcnt;
-                while (lo < hi) {
-                    int mid = (lo + hi) >> 1;
-                    if (czh::key_lt(tkey[mid], tid_[mid], mk, mi)) lo = mid + 1;
-                    else hi = mid;
-                }
-                npos = r1c + lo;
-            }
-            constexpr int R = 4;  // k <= 1024
-            uint64_t wk[R];
-            uint32_t wi[R];
-            int wpos[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                int j = tid + r * 256;
-                wpos[r] = -1;
-                if (j < tcnt) {
-                    wk[r] = tkey[j];
-                    wi[r] = tid_[j];
-                    int sft = 0;
-                    for (int t = 0; t < nb; t++) {
-                        uint32_t ni = bid[t];
-                        if (ni != CZ_NONE && czh::key_lt(bkey[t], ni, wk[r], wi[r])) sft++;
-                    }
-                    if (sft > 0) wpos[r] = j + sft;
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < R; r++)
-                if (wpos[r] >= 0 && wpos[r] < (int)k) {
-                    tkey[wpos[r]] = wk[r];
-                    tid_[wpos[r]] = wi[r];
-                }
-            if (elig && npos < (int)k) {
-                tkey[npos] = mk;
-                tid_[npos] = mi;
-            }
-            tcnt = min((int)k, tcnt + nelig);
-        }
-        __syncthreads();
+        tcnt = topk_merge_batch(nb, bkey, bid, tkey, tid_, tcnt, (int)k);
     }
     const size_t o = ((size_t)qi * gridDim.x + blockIdx.x) * k;
     for (uint32_t i = tid; i < k; i += 256) {
@@ -796,6 +734,16 @@ extern "C" int cz_distance_batch(int metric, const float *base, uint32_t n, uint
 // ------------------------------------------------------------------------------------------------
 // exhaustive k-NN
 // ------------------------------------------------------------------------------------------------
+namespace cz {
+int knn_gemm_device(HnswIndex *ix, const float *d_q, uint32_t B, uint32_t k, uint32_t *d_ids, double *d_dist,
+                    hipStream_t stream, void (*merge)(const uint64_t *, const uint32_t *, uint32_t, uint32_t, uint32_t,
+                                                      uint32_t *, double *, hipStream_t));
+}
+static void launch_bf_merge(const uint64_t *pkey, const uint32_t *pid, uint32_t B, uint32_t nchunks, uint32_t k,
+                            uint32_t *d_ids, double *d_dist, hipStream_t stream) {
+    hipLaunchKernelGGL(bf_merge_kernel, dim3(B), dim3(256), 0, stream, pkey, pid, nchunks, k, d_ids, d_dist);
+}
+
 extern "C" int cz_knn_bruteforce(cz_hnsw_index *h, const float *queries, uint32_t B, uint32_t k, uint32_t *out_ids,
                                  double *out_dist, uint32_t flags, void *stream_) {
     if (!h) return cz::set_error(CZ_E_INVALID, "null index");
@@ -822,6 +770,16 @@ extern "C" int cz_knn_bruteforce(cz_hnsw_index *h, const float *queries, uint32_
         d_q = dq.p;
         d_ids = dids.p;
         d_dist = ddist.p;
+    }
+    if (flags & CZ_BF_GEMM) {  // dense-GEMM form on the matrix cores (knn_gemm.hip): Cosine / IP
+        rc = cz::knn_gemm_device(ix, d_q, B, k, d_ids, d_dist, stream, launch_bf_merge);
+        if (rc) return rc;
+        if (!dev) {
+            CZ_HIP(hipMemcpyAsync(out_ids, d_ids, (size_t)B * k * 4, hipMemcpyDeviceToHost, stream));
+            CZ_HIP(hipMemcpyAsync(out_dist, d_dist, (size_t)B * k * 8, hipMemcpyDeviceToHost, stream));
+            CZ_HIP(hipStreamSynchronize(stream));
+        }
+        return CZ_OK;
     }
     // chunking: enough workgroups to fill the chip, chunk lists small enough to merge cheaply
     uint32_t nchunks = std::max<uint32_t>(1, std::min<uint32_t>((ix->n + 4095) / 4096, std::max<uint32_t>(1, 8192 / B)));

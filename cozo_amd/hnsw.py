@@ -181,17 +181,19 @@ class GpuHnswIndex:
                                               float(config.radius or 0.0), ptr(out_ids), ptr(out_dist), ptr(out_count),
                                               ptr(out_n_dist), None, CZ_DEVICE_PTRS, C.c_void_p(stream)))
 
-    def bruteforce_knn(self, queries: np.ndarray, k: int):
+    def bruteforce_knn(self, queries: np.ndarray, k: int, gemm: bool = False):
+        """exact k-NN by exhaustive scan; gemm=True computes the B x N dot products as one dense f32 GEMM on the
+        matrix cores (Cosine / IP; every dot product is then a k-ordered fmaf chain)"""
         q = np.ascontiguousarray(queries, dtype=np.float32)
         B = q.shape[0]
         ids = np.empty((B, k), dtype=np.uint32)
         dist = np.empty((B, k), dtype=np.float64)
-        check(_lib.lib().cz_knn_bruteforce(self._h, ptr(q), B, k, ptr(ids), ptr(dist), 0, None))
+        check(_lib.lib().cz_knn_bruteforce(self._h, ptr(q), B, k, ptr(ids), ptr(dist), _lib.CZ_BF_GEMM if gemm else 0, None))
         return ids, dist
 
-    def bruteforce_knn_device(self, queries, k: int, out_ids, out_dist, stream: int = 0):
+    def bruteforce_knn_device(self, queries, k: int, out_ids, out_dist, stream: int = 0, gemm: bool = False):
         check(_lib.lib().cz_knn_bruteforce(self._h, ptr(queries), queries.shape[0], k, ptr(out_ids), ptr(out_dist),
-                                           CZ_DEVICE_PTRS, C.c_void_p(stream)))
+                                           CZ_DEVICE_PTRS | (_lib.CZ_BF_GEMM if gemm else 0), C.c_void_p(stream)))
 
 
 def distance_batch(distance: str, base: np.ndarray, queries: np.ndarray, pairs: np.ndarray) -> np.ndarray:

@@ -38,6 +38,9 @@ extern "C" {
  * shard's shape; the environment variable CZ_PR_MODE = gather | blocked overrides the default too) */
 #define CZ_PR_GATHER 2u
 #define CZ_PR_BLOCKED 4u
+/* cz_knn_bruteforce: compute the B x N dot products as one dense f32 GEMM on the matrix cores (Cosine / IP only;
+ * every dot product is then a k-ordered fmaf chain instead of the search kernel's lane-parallel tree) */
+#define CZ_BF_GEMM 8u
 
 typedef enum {
     CZ_OK = 0,
@@ -132,7 +135,8 @@ int cz_distance_batch(int metric, const float *base, uint32_t n, uint32_t dim, c
                       const uint32_t *pairs, uint64_t P, double *out, uint32_t flags, void *stream);
 
 /* exact k-NN by exhaustive scan over an uploaded index' vectors (recall ground truth; the "query batch
- * turns distance into a dense GEMM" case).  Same outputs as cz_hnsw_search_batch. */
+ * turns distance into a dense GEMM" case).  Same outputs as cz_hnsw_search_batch.  flags: CZ_DEVICE_PTRS,
+ * CZ_BF_GEMM (MFMA form, Cosine / IP). */
 int cz_knn_bruteforce(cz_hnsw_index *ix, const float *queries, uint32_t B, uint32_t k, uint32_t *out_ids,
                       double *out_dist, uint32_t flags, void *stream);
 

@@ -97,7 +97,20 @@ float orc_l2_gpu(const float *a, const float *b, int dim) {
  *   L2     : diff = a - b (f32 array); diff.dot(diff) as f64          (:68-72, squared, no sqrt)
  *   Cosine : 1 - dot/sqrt(a_norm*b_norm), every dot f32 widened first (:79-85)
  *   IP     : 1 - dot as f64                                            (:97-101) */
+/* ORC_DOT_SEQ: one k-ordered fmaf chain per dot product, starting from +0 -- what v_mfma_f32_32x32x2_f32 computes
+ * per output element (the GEMM form of the exhaustive scan, cozo_amd/csrc/knn_gemm.hip).  Cosine / IP only. */
+float orc_dot_seq(const float *a, const float *b, int dim) {
+    float acc = 0.0f;
+    for (int i = 0; i < dim; i++) acc = fmaf(a[i], b[i], acc);
+    return acc;
+}
+
 double orc_distance(int metric, int dot_mode, const float *a, const float *b, int dim) {
+    if (dot_mode == ORC_DOT_SEQ && metric != ORC_L2) {
+        const double d = (double)orc_dot_seq(a, b, dim);
+        if (metric == ORC_COSINE) return 1.0 - d / sqrt((double)orc_dot_seq(a, a, dim) * (double)orc_dot_seq(b, b, dim));
+        return 1.0 - d;
+    }
     if (metric == ORC_L2) {
         if (dot_mode == ORC_DOT_GPU) return (double)orc_l2_gpu(a, b, dim);
         float stackbuf[2048];

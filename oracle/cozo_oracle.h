@@ -29,13 +29,14 @@ enum { ORC_L2 = 0, ORC_COSINE = 1, ORC_IP = 2 };
 /* ORC_DOT_NDARRAY: ndarray 0.15.6 `unrolled_dot` order (what the reference runs).
  * ORC_DOT_GPU:     the summation tree of the HIP kernels (per-lane fma chains + xor butterfly);
  *                  used to show the GPU traversal is bit-identical given identical arithmetic. */
-enum { ORC_DOT_NDARRAY = 0, ORC_DOT_GPU = 1 };
+enum { ORC_DOT_NDARRAY = 0, ORC_DOT_GPU = 1, ORC_DOT_SEQ = 2 /* k-ordered fmaf chain = the MFMA GEMM form (Cosine / IP) */ };
 
 #define ORC_NONE 0xFFFFFFFFu
 
 /* ---- distances (runtime/hnsw.rs:66-109, data/functions.rs:2185-2255) ---- */
 float orc_dot_ndarray(const float *a, const float *b, size_t n);
 float orc_dot_gpu(const float *a, const float *b, int dim);
+float orc_dot_seq(const float *a, const float *b, int dim);
 float orc_l2_gpu(const float *a, const float *b, int dim);
 double orc_distance(int metric, int dot_mode, const float *a, const float *b, int dim);
 void orc_distance_pairs(int metric, int dot_mode, const float *base, const float *queries, int dim,

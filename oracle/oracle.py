@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libcozo_oracle.so")
 
 L2, COSINE, IP = 0, 1, 2
-DOT_NDARRAY, DOT_GPU = 0, 1
+DOT_NDARRAY, DOT_GPU, DOT_SEQ = 0, 1, 2
 NONE = 0xFFFFFFFF
 
 _u32p = C.POINTER(C.c_uint32)

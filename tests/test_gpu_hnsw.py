@@ -111,6 +111,32 @@ def test_knn_within_tolerance_of_reference_order(case, oracle, ef, k):
     assert np.max(np.abs(dist[same] - odist[same]) / scale) <= RTOL
 
 
+@pytest.mark.parametrize("name,metric", [("Cosine", 1), ("IP", 2)])
+@pytest.mark.parametrize("n,dim,B", [(1000, 96, 37), (5000, 768, 130), (700, 130, 5)])
+def test_bruteforce_gemm_form_matches_sequential_chain_oracle(gpu_lib, oracle, name, metric, n, dim, B):
+    """cz_knn_bruteforce(CZ_BF_GEMM): dot products on the matrix cores (v_mfma_f32_32x32x2_f32 = a k-ordered fmaf
+    chain per element).  Bit-exact against the oracle in ORC_DOT_SEQ order; ragged tile edges (n, B, dim not
+    multiples of the 128 x 128 x 16 tile) included."""
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest
+    k = 10
+    base = util.vectors(n, dim, 11 + dim, "normal")
+    q = util.vectors(B, dim, 12 + dim, "normal")
+    man = HnswIndexManifest(vec_dim=dim, distance=name, m_neighbours=8)
+    ix = GpuHnswIndex(man, base, [None], [np.full((n, 16), 0xFFFFFFFF, dtype=np.uint32)], 0)
+    ids, dist = ix.bruteforce_knn(q, k, gemm=True)
+    oids, odist = oracle.bruteforce_knn(metric, base, q, k, dot_mode=oracle.DOT_SEQ)
+    assert np.array_equal(ids, oids) and np.array_equal(dist, odist)
+    # and it is the same neighbourhood the streaming form finds, up to near-ties of the two summation orders
+    sids, sdist = ix.bruteforce_knn(q, k)
+    assert (ids == sids).all(axis=1).mean() >= 0.95
+    assert np.max(np.abs(dist - sdist) / np.maximum(np.abs(sdist), 1e-3)) <= 1e-4 or (ids != sids).any()
+    ix.close()
+    with pytest.raises(Exception):
+        l2 = GpuHnswIndex(HnswIndexManifest(vec_dim=dim, distance="L2", m_neighbours=8), base, [None],
+                          [np.full((n, 16), 0xFFFFFFFF, dtype=np.uint32)], 0)
+        l2.bruteforce_knn(q, k, gemm=True)
+
+
 def test_knn_radius_and_filter_width(case, oracle):
     from cozo_amd.hnsw import HnswSearch
     ef, k = 50, 10
