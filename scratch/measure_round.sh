@@ -1,7 +1,7 @@
 #!/bin/bash
-# final round-1 measurement set: plain bench, bench under rocprofv3 kernel trace, PMC traffic passes
+# one round's measurement set: plain bench, bench under rocprofv3 kernel trace, PMC traffic passes (copy the summaries to profiles/)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r1t
+O=$R/gpurun_out/round
 rm -rf $O; mkdir -p $O
 cd $R
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cat $O/bench.json
@@ -19,11 +19,11 @@ python - <<'PY'
 import csv, glob, os, collections
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(R + "/gpurun_out/r1t/pmc_*/**/*counter_collection.csv", recursive=True):
+for f in glob.glob(R + "/gpurun_out/round/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-with open(R + "/gpurun_out/r1t/pmc_summary.txt", "w") as out:
+with open(R + "/gpurun_out/round/pmc_summary.txt", "w") as out:
     out.write("# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs, no tracing) over `python bench.py --skip-cpu --steps 3 --warmup 1 --ef 96 --pr-iters 3`\n# per-dispatch values in KiB as rocprofv3 reports them (uncorrected); last3avg = the timed-loop launches\n")
     for k in sorted(acc):
         for cn, vals in sorted(acc[k].items()):
