@@ -395,7 +395,6 @@ IndexDev HnswIndex::dev() const {
     d.wu = wu;
     d.n_levels = n_levels;
     d.entry = entry;
-    d.flags = 0;
     return d;
 }
 
@@ -539,7 +538,6 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
         return set_error(CZ_E_UNSUPPORTED, "dim %u / ef %u need %zu bytes of LDS (> 160 KiB)", ix->dim, ef, smem);
     }
     IndexDev d = ix->dev();
-    if (const char *fl = getenv("CZ_HNSW_FLAGS")) d.flags = (uint32_t)atoi(fl);
     Shape sh = shape_of(ix->dim);
 #define CZ_LAUNCH_KNN(LPV, ITERS, U)                                                                                    \
     do {                                                                                                                \

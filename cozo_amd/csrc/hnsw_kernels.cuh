@@ -59,7 +59,6 @@ struct IndexDev {
     int wu;
     int n_levels;
     uint32_t entry;
-    uint32_t flags;          // experiment switches (CZ_HNSW_FLAGS); none defined at present
 };
 
 // LDS carve-up (all offsets multiples of 16 bytes)

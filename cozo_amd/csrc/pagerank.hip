@@ -212,10 +212,15 @@ pb_expand_kernel(const AItem *__restrict__ items, const uint16_t *__restrict__ a
 // A run is short (tile / #slices entries), so the kernel lives on loads in flight: 32 waves per CU, 8 runs
 // requested per wave before the first value is placed, and the rows' own data (offsets, old score, out-degree)
 // requested before the runs so that nothing is fetched after the barrier.
+// FLAT: the (row block, slice) runs are too short to be walked one wave-instruction each (a shard of a wide graph:
+// 7 values per run at 8 ranks, 57 of 64 lanes idle and the kernel instruction bound).  The plan then also holds, for
+// every element of the block in slice-major order, its position in the value stream (`vpos`, 4 more bytes per edge),
+// and the tile is filled element by element with every lane busy: tile[perm[e]] = val[vpos[e]].
+template <bool FLAT>
 __global__ void __launch_bounds__(kBThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
 pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint32_t *__restrict__ off,
                  const uint2 *__restrict__ seg /* [blocks][S+1]: (stream position, block-local prefix) */, uint32_t S,
-                 const uint16_t *__restrict__ perm, const float *__restrict__ val,
+                 const uint16_t *__restrict__ perm, const uint32_t *__restrict__ vpos, const float *__restrict__ val,
                  const uint32_t *__restrict__ out_deg, uint32_t row_begin, float *__restrict__ contrib_out,
                  float *__restrict__ scores, float base, float damping, double *__restrict__ partial, int xcd_remap) {
     __shared__ float tile[kBTileNnz];
@@ -239,16 +244,6 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
     const uint16_t *pm = perm + e0;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    // first descriptors of this wave: lane l of round g holds the run of slice s = (g*64 + l)*NW + wave
-    uint2 d = make_uint2(0, 0);
-    uint32_t cnt = 0;
-    {
-        const uint32_t s = lane * NW + wave;
-        if (s < S) {
-            d = sg[s];
-            cnt = sg[s + 1].y - d.y;
-        }
-    }
     uint32_t ra[RPL], rz[RPL], od[RPL];
     float old[RPL];
 #pragma unroll
@@ -259,6 +254,37 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
             rz[j] = off[r + 1] - e0;
             old[j] = scores[r];
             od[j] = out_deg[row_begin + r];
+        }
+    }
+    if constexpr (FLAT) {
+        const uint32_t nnz = rb.e1 - e0;
+        const uint32_t *vp = vpos + e0;
+        constexpr int F = 8;
+        for (uint32_t eb = threadIdx.x; eb < nnz; eb += kBThreads * F) {
+            uint32_t src[F], q[F];
+            float v[F];
+#pragma unroll
+            for (int i = 0; i < F; i++) {
+                const uint32_t e = eb + i * kBThreads;
+                src[i] = e < nnz ? vp[e] : 0;
+                q[i] = e < nnz ? pm[e] : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < F; i++)
+                if (eb + i * kBThreads < nnz) v[i] = val[src[i]];
+#pragma unroll
+            for (int i = 0; i < F; i++)
+                if (eb + i * kBThreads < nnz) tile[q[i]] = v[i];
+        }
+    } else {
+    // first descriptors of this wave: lane l of round g holds the run of slice s = (g*64 + l)*NW + wave
+    uint2 d = make_uint2(0, 0);
+    uint32_t cnt = 0;
+    {
+        const uint32_t s = lane * NW + wave;
+        if (s < S) {
+            d = sg[s];
+            cnt = sg[s + 1].y - d.y;
         }
     }
     for (uint32_t g = 0; (g * 64) * NW + wave < S; g++) {
@@ -295,6 +321,7 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
             for (int u = 0; u < U; u++)
                 for (uint32_t k = lane + 64; k < c[u]; k += 64) tile[pm[p0[u] + k]] = val[st[u] + k];
         }
+    }
     }
     __syncthreads();
     double err = 0.0;
@@ -413,6 +440,18 @@ pb_perm_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__
     }
 }
 
+__global__ void __launch_bounds__(256)
+pb_vpos_kernel(const RowBlock *__restrict__ blocks, const uint2 *__restrict__ seg, uint32_t S, uint32_t *__restrict__ vpos) {
+    const RowBlock rb = blocks[blockIdx.x];
+    const uint2 *sg = seg + (size_t)blockIdx.x * (S + 1);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t s = wave; s < S; s += 4) {
+        const uint2 d = sg[s];
+        const uint32_t cnt = sg[s + 1].y - d.y;
+        for (uint32_t k = lane; k < cnt; k += 64) vpos[rb.e0 + d.y + k] = d.x + k;
+    }
+}
+
 // fixed-order reduction of the per-block partial errors; accumulates into *err_out
 __global__ void __launch_bounds__(1024) pr_err_reduce_kernel(const double *__restrict__ partial, uint32_t n,
                                                               double *__restrict__ err_out) {
@@ -453,6 +492,7 @@ struct cz_pagerank_plan {
     std::vector<uint32_t> item_ptr, blk_ptr;  // per chunk
     std::vector<uint32_t> val_shift;          // per chunk: stream position that maps to d_val[0] (multiple of 4)
     uint16_t *d_asrc = nullptr, *d_perm = nullptr;
+    uint32_t *d_vpos = nullptr;  // flat phase B only (short runs)
     uint2 *d_seg = nullptr;
     float *d_val = nullptr;
     uint64_t E_blocked = 0;
@@ -461,7 +501,7 @@ struct cz_pagerank_plan {
     float *d_scores = nullptr;
     double *d_partial = nullptr;
     ~cz_pagerank_plan() {
-        void *ps[] = {d_gblocks, d_bblocks, d_items, d_asrc, d_perm, d_seg, d_val, d_off, d_src, d_outdeg, d_scores, d_partial};
+        void *ps[] = {d_gblocks, d_bblocks, d_items, d_asrc, d_perm, d_vpos, d_seg, d_val, d_off, d_src, d_outdeg, d_scores, d_partial};
         for (void *p : ps)
             if (p) (void)hipFree(p);
     }
@@ -608,6 +648,13 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
                            d_bad.p);
         hipLaunchKernelGGL(pb_perm_kernel, dim3((uint32_t)bb.size()), dim3(256), 0, nullptr, p->d_bblocks, p->d_off, p->d_seg, S,
                            idx_out.p, p->d_perm);
+        // short runs (average tile / #slices below 20 values): phase B fills its tile element by element
+        const int flat_env = env_int("CZ_PR_FLAT", -1);
+        const bool flat = flat_env >= 0 ? flat_env != 0 : (uint64_t)kBTileNnz < 20ull * S;
+        if (flat && n_chunks == 1) {
+            CZ_HIP(hipMalloc((void **)&p->d_vpos, std::max<uint64_t>(1, E) * 4));
+            hipLaunchKernelGGL(pb_vpos_kernel, dim3((uint32_t)bb.size()), dim3(256), 0, nullptr, p->d_bblocks, p->d_seg, S, p->d_vpos);
+        }
     }
     uint32_t bad = 0;
     CZ_HIP(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
@@ -699,7 +746,7 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     if (mode == 0) {
         // The blocked layout wins whenever there is enough work to stream, short runs included: measured on one
         // rank's shard of a row-sharded graph (10M rows, 100M in-edges, sources over N = 10M * world nodes), runs of
-        // 53 / 27 / 13 / 7 values at world = 1 / 2 / 4 / 8: blocked 0.34 / 0.37 / 0.50 / 0.72 ms per sweep, gather
+        // 53 / 27 / 13 / 7 values at world = 1 / 2 / 4 / 8: blocked 0.34 / 0.37 / 0.44 / 0.50 ms per sweep, gather
         // 1.7 / 1.9 / 2.0 / 2.0 ms (adjacent row blocks run on the same XCD, so a short run's cache line is fetched
         // once and shared through that L2).  The segment table (row blocks x slices x 8 bytes) bounds it.
         const uint64_t S = ((uint64_t)N + (1u << wlog) - 1) >> wlog;
@@ -758,9 +805,14 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
                 hipLaunchKernelGGL(pb_expand_kernel, dim3(i1 - i0), dim3(kAThreads), 0, stream, p->d_items + i0, p->d_asrc,
                                    contrib_in_dev, p->N, p->wlog, val);
             if (b1 > b0)
-                hipLaunchKernelGGL(pb_reduce_kernel, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0, p->d_off,
-                                   p->d_seg, p->S, p->d_perm, val, p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores,
-                                   p->base, p->damping, p->d_partial, p->xcd_remap);
+                if (p->d_vpos)
+                    hipLaunchKernelGGL(pb_reduce_kernel<true>, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
+                                       p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
+                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap);
+                else
+                    hipLaunchKernelGGL(pb_reduce_kernel<false>, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
+                                       p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
+                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap);
         }
         if (p->n_gblocks)  // rows longer than a tile
             hipLaunchKernelGGL(pr_step_kernel, dim3(p->n_gblocks), dim3(kGThreads), 0, stream, p->d_gblocks, p->d_off, p->d_src,

@@ -46,11 +46,10 @@ def main():
     cnt = torch.empty(BMAX, dtype=torch.int32, device=dev)
     nd = torch.zeros(BMAX, dtype=torch.int64, device=dev)
     ref = None
-    variants = [(U, fl) for fl in os.environ.get("HS_FLAGS", "0").split(",") for U in os.environ.get("HS_US", "0").split(",")]
+    variants = [(U, "0") for U in os.environ.get("HS_US", "0").split(",")]
     variants = variants * int(os.environ.get("HS_REPEAT", "1"))
     for U, fl in variants:
         os.environ["CZ_HNSW_U"] = U
-        os.environ["CZ_HNSW_FLAGS"] = fl
         for B in [int(b) for b in os.environ.get("HS_BS", "1024,4096,8192").split(",")]:
             def run():
                 ix.hnsw_knn_batch_device(q[:B], HnswSearch(k=k, ef=ef), ids[:B], dd[:B], cnt[:B], nd[:B], stream)

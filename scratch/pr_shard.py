@@ -29,9 +29,9 @@ def main():
         n = rows * world
         off, s, od, E = gen(n, rows, e, dev)
         ref = None
-        for mode, env in [("auto", {}), ("blocked", {"CZ_PR_XCD": "1"}), ("blocked", {"CZ_PR_XCD": "0"}), ("gather", {})]:
+        for mode, env in [("auto", {}), ("blocked", {"CZ_PR_FLAT": "0"}), ("blocked", {"CZ_PR_FLAT": "1"}), ("gather", {})]:
             if world == 1 and mode == "gather": continue
-            for k in ("CZ_PR_XCD",): os.environ.pop(k, None)
+            for k in ("CZ_PR_XCD", "CZ_PR_FLAT"): os.environ.pop(k, None)
             os.environ.update(env)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             plan = PageRankPlan(off, s, od, n, 0, rows, 0.85, device_ptrs=True, mode=None if mode == "auto" else mode)
