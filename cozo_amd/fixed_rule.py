@@ -676,6 +676,39 @@ class ClusteringCoefficients(FixedRule):
             out.put((indices[idx], cc, t, d))
 
 
+class ClosenessCentrality(FixedRule):
+    """algos/all_pairs_shortest_path.rs:97-144: one cost-only Dijkstra per node (`dijkstra_cost_only`, :146-176, the same
+    strict-`<` f32 relaxation as `dijkstra`) -> cz_sssp over batches of starts; the per-start epilogue is the reference's
+    f32 arithmetic in the reference's order: total = sequential sum of the finite distances in node order, nc = their
+    count, centrality = nc * nc / total / (n - 1).  Rows: (node, centrality as f64)."""
+
+    BATCH = 256
+
+    def arity(self, options, rule_head) -> int:
+        return 2
+
+    def run(self, payload, out, poison):
+        edges = payload.get_input(0)
+        undirected = payload.bool_option("undirected", False)
+        graph, indices, _ = edges.as_directed_weighted_graph(undirected, False)
+        n = graph.n
+        if n == 0:
+            return
+        denom = np.float32(n - 1)
+        for b0 in range(0, n, self.BATCH):
+            starts = np.arange(b0, min(n, b0 + self.BATCH), dtype=np.uint32)
+            dist, _ = _graph.sssp(graph.out_offsets, graph.out_targets, graph.out_weights, starts, poison=poison.flag)
+            for si, s in enumerate(starts):
+                d = dist[si]
+                fin = d[np.isfinite(d)]
+                total = np.cumsum(fin, dtype=np.float32)[-1]  # a sequential f32 sum, like `.sum()` over the iterator
+                nc = np.float32(fin.size)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    c = np.float32(np.float32(nc * nc) / total) / denom
+                out.put((indices[int(s)], float(c)))
+            poison.check()
+
+
 class DegreeCentrality(FixedRule):
     """algos/degree_centrality.rs:24-76: a scan with three counters per node -- no graph, nothing for the GPU to do;
     mirrored on the host so that the rule family is complete.  Rows: (node, total, out, in)."""
@@ -715,7 +748,7 @@ class FixedRuleRegistry:
     (fixed_rule/mod.rs:799-802) -- see INTEGRATION.md."""
 
     BUILTIN = ("PageRank", "ShortestPathBFS", "BFS", "BreadthFirstSearch", "ConnectedComponents",
-               "StronglyConnectedComponents", "SCC", "ShortestPathDijkstra", "ClusteringCoefficients", "DegreeCentrality")
+               "StronglyConnectedComponents", "SCC", "ShortestPathDijkstra", "ClusteringCoefficients", "DegreeCentrality", "ClosenessCentrality")
 
     def __init__(self):
         self._rules: Dict[str, FixedRule] = {}
@@ -723,7 +756,8 @@ class FixedRuleRegistry:
                            ("ConnectedComponentsGpu", ConnectedComponents()),
                            ("ShortestPathDijkstraGpu", ShortestPathDijkstra()),
                            ("ClusteringCoefficientsGpu", ClusteringCoefficients()),
-                           ("DegreeCentralityGpu", DegreeCentrality())):
+                           ("DegreeCentralityGpu", DegreeCentrality()),
+                           ("ClosenessCentralityGpu", ClosenessCentrality())):
             self._rules[name] = impl
 
     def register_fixed_rule(self, name: str, impl: FixedRule) -> None:

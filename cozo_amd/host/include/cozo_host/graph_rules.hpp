@@ -11,6 +11,7 @@
 //   ShortestPathDijkstra         fixed_rule/algos/shortest_path_dijkstra.rs:33-153     -> cz_sssp
 //   ClusteringCoefficients       fixed_rule/algos/triangles.rs:25-110                  -> cz_clustering_coefficients
 //   DegreeCentrality             fixed_rule/algos/degree_centrality.rs:24-76           (a scan with counters: host only)
+//   ClosenessCentrality          fixed_rule/algos/all_pairs_shortest_path.rs:97-176    -> cz_sssp from every node
 #pragma once
 #include "fixed_rule.hpp"
 
@@ -52,6 +53,12 @@ public:
 class ClusteringCoefficients : public FixedRule {
 public:
     size_t arity(const std::map<std::string, DataValue> &, const std::vector<std::string> &) const override { return 4; }
+    void run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const override;
+};
+
+class ClosenessCentrality : public FixedRule {
+public:
+    size_t arity(const std::map<std::string, DataValue> &, const std::vector<std::string> &) const override { return 2; }
     void run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const override;
 };
 

@@ -254,6 +254,40 @@ void ClusteringCoefficients::run(const FixedRulePayload &payload, RegularTempSto
     }
 }
 
+// ---- ClosenessCentrality --------------------------------------------------------------------------------------
+void ClosenessCentrality::run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const {
+    const FixedRuleInputRelation &edges = payload.get_input(0);
+    const bool undirected = payload.bool_option("undirected", false);
+    GraphWithIndices g = edges.as_directed_weighted_graph(undirected, false);
+    const DirectedCsrGraph &gr = g.graph;
+    const uint32_t n = gr.n;
+    if (n == 0) return;
+    constexpr uint32_t kBatch = 256;  // starts per cz_sssp call (dist / parent are [starts][n])
+    std::vector<float> dist((size_t)std::min(n, kBatch) * n);
+    std::vector<uint32_t> parent(dist.size());
+    std::vector<uint32_t> starts;
+    for (uint32_t b0 = 0; b0 < n; b0 += kBatch) {
+        const uint32_t nb = std::min(kBatch, n - b0);
+        starts.resize(nb);
+        for (uint32_t i = 0; i < nb; i++) starts[i] = b0 + i;
+        check_gpu(cz_sssp(gr.out_offsets.data(), gr.out_targets.data(), gr.out_weights.data(), n, gr.edge_count(), starts.data(),
+                          nb, dist.data(), parent.data(), poison.flag_ptr()));
+        for (uint32_t i = 0; i < nb; i++) {
+            // all_pairs_shortest_path.rs:118-122, f32 throughout: total = sum of the finite distances in node order
+            const float *d = dist.data() + (size_t)i * n;
+            float total = 0.0f, nc = 0.0f;
+            for (uint32_t v = 0; v < n; v++)
+                if (std::isfinite(d[v])) {
+                    total = total + d[v];
+                    nc = nc + 1.0f;
+                }
+            const float c = nc * nc / total / (float)(n - 1);
+            out.put(Tuple{g.indices[b0 + i], DataValue((double)c)});
+        }
+        poison.check();
+    }
+}
+
 // ---- DegreeCentrality (host only: the reference's rule is a scan with three counters per node) -----------------
 void DegreeCentrality::run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const {
     struct Deg {

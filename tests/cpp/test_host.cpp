@@ -436,6 +436,34 @@ static void gpu_clustering_coefficients() {
     CHECK(ok);
 }
 
+static void gpu_closeness_centrality() {
+    // all_pairs_shortest_path.rs:97-176: Dijkstra costs from every node (oracle), f32 sum in node order, nc * nc / total / (n - 1)
+    FixedRuleRegistry reg = FixedRuleRegistry::with_gpu_defaults();
+    std::vector<Tuple> rows = random_edges(300, 1500, 33, true);
+    FixedRuleInputRelation rel(rows);
+    RegularTempStore out = reg.run("ClosenessCentrality", FixedRulePayload("ClosenessCentrality", {rel}, {{"undirected", DataValue(true)}}), Poison());
+    GraphWithIndices g = rel.as_directed_weighted_graph(true, false);
+    const uint32_t n = g.graph.n;
+    std::vector<uint64_t> off = to_u64(g.graph.out_offsets);
+    bool ok = out.size() == n;
+    std::vector<float> dist(n);
+    std::vector<uint32_t> par(n);
+    for (const Tuple &t : out) {
+        const uint32_t s = g.inv_indices.at(t[0]);
+        orc_dijkstra(n, off.data(), g.graph.out_targets.data(), g.graph.out_weights.data(), s, nullptr, 0, dist.data(), par.data());
+        float total = 0.f, nc = 0.f;
+        for (uint32_t v = 0; v < n; v++)
+            if (std::isfinite(dist[v])) {
+                total = total + dist[v];
+                nc = nc + 1.f;
+            }
+        const float c = nc * nc / total / (float)(n - 1);
+        double got;
+        ok = ok && t[1].get_float(&got) && (got == (double)c || (std::isnan(got) && std::isnan(c)));
+    }
+    CHECK(ok);
+}
+
 static void gpu_hnsw_search_ra() {
     // a base relation {k => v: <F32; 24>} with an L2 index, searched through HnswSearchRA (runtime/tests.rs:700-809 shape)
     const size_t n = 3000, dim = 24;
@@ -561,6 +589,7 @@ int main(int argc, char **argv) {
         gpu_love_graph();
         gpu_bfs_cc_dijkstra_random();
         gpu_clustering_coefficients();
+        gpu_closeness_centrality();
         gpu_hnsw_search_ra();
     }
     std::printf("%s: %d checks passed, %d failed\n", mode.c_str(), g_pass, g_fail);

@@ -394,6 +394,60 @@ def test_clustering_coefficients_rule(registry, seed):
     assert registry.run("ClusteringCoefficientsGpu", [rel([])]) == []
 
 
+def ref_closeness_centrality(edge_rows, undirected):
+    """all_pairs_shortest_path.rs:97-176 at the DataValue level, f32 arithmetic in the reference's order"""
+    rows = sorted({FR._canon(tuple(r)): tuple(r) for r in edge_rows}.values(), key=FR._tuple_key)
+    ids, vals, adj = {}, [], {}
+    for r in rows:
+        for v in (r[0], r[1]):
+            if FR._canon(v) not in ids:
+                ids[FR._canon(v)] = len(vals)
+                vals.append(v)
+        a, b, w = ids[FR._canon(r[0])], ids[FR._canon(r[1])], np.float32(r[2] if len(r) > 2 else 1.0)
+        adj.setdefault(a, []).append((b, w))
+        if undirected:
+            adj.setdefault(b, []).append((a, w))
+    n = len(vals)
+    out = []
+    for start in range(n):
+        dist = [np.float32(np.inf)] * n
+        dist[start] = np.float32(0.0)
+        pq = [(np.float32(0.0), start)]
+        while pq:
+            cost, node = heapq.heappop(pq)
+            if cost > dist[node]:
+                continue
+            for tgt, w in adj.get(node, ()):
+                nxt = np.float32(cost + w)
+                if nxt < dist[tgt]:
+                    dist[tgt] = nxt
+                    heapq.heappush(pq, (nxt, tgt))
+        total, nc = np.float32(0.0), np.float32(0.0)
+        for d in dist:
+            if np.isfinite(d):
+                total = np.float32(total + d)
+                nc = np.float32(nc + np.float32(1.0))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            c = np.float32(np.float32(np.float32(nc * nc) / total) / np.float32(n - 1))
+        out.append((vals[start], float(c)))
+    return out
+
+
+@pytest.mark.parametrize("undirected", [False, True])
+def test_closeness_centrality_rule(registry, undirected):
+    rng = np.random.default_rng(17)
+    names = [f"n{i:02d}" for i in range(40)]
+    edges = sorted({(names[a], names[b]) for a, b in rng.integers(0, 40, (150, 2)) if a != b})
+    edges = [(a, b, float(np.float32(rng.integers(1, 64) / 8.0))) for a, b in edges]
+    rows = registry.run("ClosenessCentralityGpu", [rel(edges)], {"undirected": undirected})
+    want = ref_closeness_centrality(edges, undirected)
+    got = {FR._canon(r[0]): r[1] for r in rows}
+    assert len(rows) == len(want)
+    for node, c in want:
+        g = got[FR._canon(node)]
+        assert g == c or (math.isnan(g) and math.isnan(c))
+
+
 def test_degree_centrality_rule(registry):
     edges = str_graph(40, 90, 3)
     extra = [("nobody",), (edges[0][0],)]
