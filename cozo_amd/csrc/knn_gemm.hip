@@ -60,22 +60,33 @@ dot_gemm_mfma_kernel(const float *__restrict__ A, uint32_t M, const float *__res
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    for (uint32_t k0 = 0; k0 < ld; k0 += KT) {
-        // stage 128 x 16 of A and of B: 512 float4 each, two per thread; rows past the matrix / k past ld read as zero
+    // the K loop is software pipelined through registers: the next 128 x 16 slices of A and B are requested before the
+    // MFMAs of the current slice are issued, so the global latency hides behind 32 MFMAs (2 048 cycles) per wave
+    float4 ra[2], rbv[2];
+    auto fetch = [&](uint32_t k0) {
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int idx = tid + 256 * i, r = idx >> 2, k4 = idx & 3;
             const uint32_t gk = k0 + 4 * k4;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            if (gk < ld) {
-                if (m0 + r < M) a = *(const float4 *)(A + (size_t)(m0 + r) * ld + gk);
-                if (n0 + r < N) b = *(const float4 *)(Bm + (size_t)(n0 + r) * ld + gk);
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rbv[i] = ra[i];
+            if (gk < ld) {  // rows past the matrix / k past ld read as zero
+                if (m0 + r < M) ra[i] = *(const float4 *)(A + (size_t)(m0 + r) * ld + gk);
+                if (n0 + r < N) rbv[i] = *(const float4 *)(Bm + (size_t)(n0 + r) * ld + gk);
             }
+        }
+    };
+    fetch(0);
+    for (uint32_t k0 = 0; k0 < ld; k0 += KT) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int idx = tid + 256 * i, r = idx >> 2, k4 = idx & 3;
             float *as = As + r * LDP + 4 * k4, *bs = Bs + r * LDP + 4 * k4;
-            as[0] = a.x; as[1] = a.y; as[2] = a.z; as[3] = a.w;
-            bs[0] = b.x; bs[1] = b.y; bs[2] = b.z; bs[3] = b.w;
+            as[0] = ra[i].x; as[1] = ra[i].y; as[2] = ra[i].z; as[3] = ra[i].w;
+            bs[0] = rbv[i].x; bs[1] = rbv[i].y; bs[2] = rbv[i].z; bs[3] = rbv[i].w;
         }
         __syncthreads();
+        if (k0 + KT < ld) fetch(k0 + KT);
 #pragma unroll
         for (int kp = 0; kp < KT / 2; kp++) {
             // operand layout of v_mfma_f32_32x32x2_f32: lane l holds A[row = l % 32][k = l / 32] and B[k = l / 32][col = l % 32]
