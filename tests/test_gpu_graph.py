@@ -257,3 +257,45 @@ def test_sssp_costs_bitexact(oracle, gpu_lib):
                     assert hops <= g["n"]
     with pytest.raises(Exception):
         G.sssp(np.array([0, 1, 1], np.uint32), np.array([1], np.uint32), np.array([-1.0], np.float32), [0])
+
+
+def test_entry_points_are_reentrant_across_host_threads(oracle, gpu_lib):
+    """`FixedRule: Send + Sync`: sibling rules run on rayon workers (query/eval.rs:199-207) and scripts run concurrently,
+    so the C ABI is called from several host threads at once.  Four threads x (PageRank, CC, BFS, triangles) on different
+    graphs, each result compared with its single-threaded value."""
+    import threading
+    from cozo_amd import graph as G
+    jobs = []
+    for seed in range(4):
+        frm, to = util.random_relation(3000 + 500 * seed, 20000, 40 + seed)
+        d = util.graph_from_relation(oracle, frm, to)
+        u = util.graph_from_relation(oracle, frm, to, undirected=True)
+        jobs.append((d, u))
+
+    def work(d, u):
+        s, it, _ = G.pagerank(d["ioff"], d["isrc"], d["outdeg"], max_iter=6)
+        grp, k = G.connected_components(u["ooff"], u["otgt"])
+        par, _, _, _ = G.bfs(d["ooff"], d["otgt"], np.array([0, 1], dtype=np.uint32))
+        tri, deg = G.clustering_coefficients(u["ooff"], u["otgt"])
+        return s, it, grp, k, par, tri, deg
+
+    serial = [work(d, u) for d, u in jobs]
+    results = [None] * len(jobs)
+    errors = []
+
+    def runner(i):
+        try:
+            for _ in range(3):
+                results[i] = work(*jobs[i])
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=runner, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for got, want in zip(results, serial):
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)

@@ -137,6 +137,34 @@ def test_bruteforce_gemm_form_matches_sequential_chain_oracle(gpu_lib, oracle, n
         l2.bruteforce_knn(q, k, gemm=True)
 
 
+def test_search_is_reentrant_on_a_shared_index(case):
+    """index handles are immutable after creation and shared by concurrent readers (one SessionTx per thread in the
+    reference): four host threads search the same handle at once, every result equals the single-threaded one."""
+    import threading
+    from cozo_amd.hnsw import HnswSearch
+    gix, q = case["gix"], case["q"]
+    cfgs = [HnswSearch(k=10, ef=40), HnswSearch(k=5, ef=16), HnswSearch(k=10, ef=120), HnswSearch(k=1, ef=1)]
+    serial = [gix.hnsw_knn_batch(q, c, with_n_dist=True) for c in cfgs]
+    results, errors = [None] * len(cfgs), []
+
+    def runner(i):
+        try:
+            for _ in range(4):
+                results[i] = gix.hnsw_knn_batch(q, cfgs[i], with_n_dist=True)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=runner, args=(i,)) for i in range(len(cfgs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for got, want in zip(results, serial):
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_knn_radius_and_filter_width(case, oracle):
     from cozo_amd.hnsw import HnswSearch
     ef, k = 50, 10
