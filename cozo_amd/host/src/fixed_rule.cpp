@@ -91,7 +91,97 @@ struct IdAssigner {
 };
 }  // namespace
 
+namespace {
+// Fast path of the id assignment for the common relation whose two node columns are integers: a flat open-addressing
+// table (i64 key -> dense id) instead of a node-based map of DataValues.  Same first-appearance order.
+struct IntIdAssigner {
+    std::vector<int64_t> keys;   // slot -> key
+    std::vector<uint32_t> vals;  // slot -> id, UINT32_MAX = empty
+    std::vector<int64_t> order;  // id -> key
+    uint64_t mask = 0;
+    explicit IntIdAssigner(size_t expected) {
+        size_t cap = 64;
+        while (cap < expected * 2 + 16) cap <<= 1;
+        keys.resize(cap);
+        vals.assign(cap, UINT32_MAX);
+        mask = cap - 1;
+    }
+    static uint64_t mix(uint64_t x) {
+        x ^= x >> 33;
+        x *= 0xff51afd7ed558ccdull;
+        x ^= x >> 33;
+        x *= 0xc4ceb9fe1a85ec53ull;
+        return x ^ (x >> 33);
+    }
+    void grow() {
+        std::vector<int64_t> ok;
+        std::vector<uint32_t> ov;
+        ok.swap(keys);
+        ov.swap(vals);
+        keys.resize(ok.size() * 2);
+        vals.assign(ok.size() * 2, UINT32_MAX);
+        mask = keys.size() - 1;
+        for (size_t i = 0; i < ok.size(); i++)
+            if (ov[i] != UINT32_MAX) {
+                uint64_t h = mix((uint64_t)ok[i]) & mask;
+                while (vals[h] != UINT32_MAX) h = (h + 1) & mask;
+                keys[h] = ok[i];
+                vals[h] = ov[i];
+            }
+    }
+    uint32_t id(int64_t k) {
+        uint64_t h = mix((uint64_t)k) & mask;
+        while (vals[h] != UINT32_MAX) {
+            if (keys[h] == k) return vals[h];
+            h = (h + 1) & mask;
+        }
+        const uint32_t i = (uint32_t)order.size();
+        keys[h] = k;
+        vals[h] = i;
+        order.push_back(k);
+        if (order.size() * 2 > keys.size()) grow();
+        return i;
+    }
+};
+
+// true when the first two columns of every row are Int (not Float: 1 and 1.0 are different DataValues)
+bool int_keyed(const std::vector<Tuple> &rows) {
+    for (const Tuple &t : rows)
+        if (t.size() < 2 || !t[0].is_int() || !t[1].is_int()) return false;
+    return true;
+}
+
+void finish_int_ids(IntIdAssigner &ids, GraphWithIndices &r) {
+    r.indices.reserve(ids.order.size());
+    r.inv_indices.reserve(ids.order.size());
+    for (uint32_t i = 0; i < ids.order.size(); i++) {
+        r.indices.emplace_back(ids.order[i]);
+        r.inv_indices.emplace(r.indices.back(), i);
+    }
+}
+}  // namespace
+
 GraphWithIndices FixedRuleInputRelation::as_directed_graph(bool undirected) const {
+    if (!rows_->empty() && int_keyed(*rows_)) {
+        IntIdAssigner ids(rows_->size());
+        std::vector<uint32_t> from, to;
+        from.reserve(rows_->size() * (undirected ? 2 : 1));
+        to.reserve(rows_->size() * (undirected ? 2 : 1));
+        for (const Tuple &t : *rows_) {
+            const uint32_t f = ids.id(std::get<int64_t>(t[0].r));
+            const uint32_t d = ids.id(std::get<int64_t>(t[1].r));
+            from.push_back(f);
+            to.push_back(d);
+            if (undirected) {
+                from.push_back(d);
+                to.push_back(f);
+            }
+        }
+        GraphWithIndices r;
+        r.graph = DirectedCsrGraph::build((uint32_t)ids.order.size(), from, to, nullptr);
+        finish_int_ids(ids, r);
+        return r;
+    }
     IdAssigner ids;
     ids.inv.reserve(rows_->size());
     std::vector<uint32_t> from, to;
