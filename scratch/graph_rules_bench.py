@@ -1,0 +1,49 @@
+"""scratch: the other whole-graph rules on a BASELINE-sized graph (10M nodes / 100M edges, uniform): wall time of the C ABI call
+(host pointers: H2D + kernels + D2H) -- run it under `rocprofv3 --kernel-trace --stats` for the kernel-only split."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cozo_amd import _lib
+L = _lib.lib()
+import numpy as np
+import torch
+from cozo_amd import graph as G
+
+def main():
+    dev = torch.device("cuda:0")
+    assert L.cz_init(0) == 0
+    n, e = int(os.environ.get("GN", 10_000_000)), int(os.environ.get("GE", 100_000_000))
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    src = torch.randint(0, n, (e,), generator=g, device=dev, dtype=torch.int64)
+    dst = torch.randint(0, n, (e,), generator=g, device=dev, dtype=torch.int64)
+    keep = src != dst
+    key = torch.unique(src[keep] * n + dst[keep])          # directed out-CSR, CsrLayout::Sorted
+    s = torch.div(key, n, rounding_mode="floor"); t = key - s * n
+    off = torch.zeros(n + 1, dtype=torch.int64, device=dev); off[1:] = torch.cumsum(torch.bincount(s, minlength=n), 0)
+    ooff, otgt = off.to(torch.int32).cpu().numpy().view(np.uint32), t.to(torch.int32).cpu().numpy().view(np.uint32)
+    E = otgt.size
+    w = (torch.randint(1, 64, (E,), generator=g, device=dev, dtype=torch.int32).to(torch.float32) / 8).cpu().numpy()
+    # symmetrised graph for CC / triangles (parallel edges kept, like as_directed_graph(undirected = true))
+    key2 = torch.sort(torch.cat([key, t * n + s])).values
+    s2 = torch.div(key2, n, rounding_mode="floor"); t2 = key2 - s2 * n
+    off2 = torch.zeros(n + 1, dtype=torch.int64, device=dev); off2[1:] = torch.cumsum(torch.bincount(s2, minlength=n), 0)
+    uoff, utgt = off2.to(torch.int32).cpu().numpy().view(np.uint32), t2.to(torch.int32).cpu().numpy().view(np.uint32)
+    del src, dst, keep, key, key2, s, t, s2, t2, off, off2
+    torch.cuda.empty_cache()
+    print(f"graph: {n} nodes, {E} directed edges ({utgt.size} symmetrised)", flush=True)
+
+    def timed(name, fn, edges, note=""):
+        fn()  # warm (allocations, code objects)
+        t0 = time.perf_counter(); r = fn(); dt = time.perf_counter() - t0
+        print(f"{name:34s} {dt * 1e3:9.1f} ms wall  {edges / dt / 1e9:7.2f} G edges/s  {note}", flush=True)
+        return r
+    starts = np.array([0], dtype=np.uint32)
+    par, dep, _, _ = timed("cz_bfs (1 start, full traversal)", lambda: G.bfs(ooff, otgt, starts, want_depth=True), E)
+    reached = int((dep[0] != 0xFFFFFFFF).sum()); print(f"    reached {reached} nodes, depth {int(dep[0][dep[0] != 0xFFFFFFFF].max())}")
+    grp, k = timed("cz_connected_components", lambda: G.connected_components(uoff, utgt), utgt.size)
+    print(f"    {k} components")
+    dist, _ = timed("cz_sssp (1 start)", lambda: G.sssp(ooff, otgt, w, starts), E)
+    print(f"    reached {int(np.isfinite(dist[0]).sum())} nodes, max cost {float(dist[0][np.isfinite(dist[0])].max()):.3f}")
+    tri, deg = timed("cz_clustering_coefficients", lambda: G.clustering_coefficients(uoff, utgt), utgt.size)
+    print(f"    {int(tri.sum())} (node, triangle) incidences, max degree {int(deg.max())}")
+main()
