@@ -106,12 +106,26 @@ int exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, uint32_t *
 // ---------------------------------------------------------------------------------------------
 // BFS
 // ---------------------------------------------------------------------------------------------
+// Frontier expansion: a group of kBfsLanes lanes owns one frontier node and reads its adjacency list coalesced (one
+// thread per node walked its list serially and uncoalesced: 3.3 ms per pass at the widest level of the 10M / 100M
+// graph).  The three passes keep the reference's FIFO order: claim (atomicMin of the frontier position per target),
+// count, emit in (frontier position, adjacency position) order; duplicates of a target are adjacent in the sorted list
+// and only the first one counts.  Group-wide counts / offsets come from wave ballots.
+constexpr int kBfsLanes = 16;
+
+__device__ __forceinline__ unsigned int bfs_group_mask(unsigned long long ballot, int lane) {
+    return (unsigned int)(ballot >> (lane & ~(kBfsLanes - 1))) & ((1u << kBfsLanes) - 1u);
+}
+
 __global__ void __launch_bounds__(kT)
 bfs_claim_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
                  uint32_t fsize, const uint32_t *__restrict__ depth, uint32_t *__restrict__ claim) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < fsize; i += gridDim.x * blockDim.x) {
+    const uint32_t glane = threadIdx.x & (kBfsLanes - 1);
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kBfsLanes, ngroups = gridDim.x * blockDim.x / kBfsLanes;
+    for (uint32_t i = group; i < fsize; i += ngroups) {
         const uint32_t u = frontier[i];
-        for (uint32_t e = off[u]; e < off[u + 1]; e++) {
+        const uint32_t e1 = off[u + 1];
+        for (uint32_t e = off[u] + glane; e < e1; e += kBfsLanes) {
             const uint32_t v = tgt[e];
             if (depth[v] == CZ_NONE) atomicMin(&claim[v], i);
         }
@@ -122,15 +136,30 @@ __global__ void __launch_bounds__(kT)
 bfs_count_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
                  uint32_t fsize, const uint32_t *__restrict__ depth, const uint32_t *__restrict__ claim,
                  uint32_t *__restrict__ cnt) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < fsize; i += gridDim.x * blockDim.x) {
-        const uint32_t u = frontier[i];
-        uint32_t c = 0, prev = CZ_NONE;
-        for (uint32_t e = off[u]; e < off[u + 1]; e++) {
-            const uint32_t v = tgt[e];
-            if (v != prev && depth[v] == CZ_NONE && claim[v] == i) c++;
-            prev = v;
+    const int lane = threadIdx.x & 63;
+    const uint32_t glane = threadIdx.x & (kBfsLanes - 1);
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kBfsLanes, ngroups = gridDim.x * blockDim.x / kBfsLanes;
+    const uint32_t rounds = (fsize + ngroups - 1) / ngroups;  // every group of a wave runs the same trip count (ballots)
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i = group + r * ngroups;
+        const bool live = i < fsize;
+        const uint32_t u = live ? frontier[i] : 0;
+        const uint32_t e0 = live ? off[u] : 0, e1 = live ? off[u + 1] : 0;
+        uint32_t c = 0;
+        // the widest list among the wave's groups decides the trip count
+        uint32_t len = e1 - e0, maxlen = len;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, o, 64));
+        for (uint32_t b = 0; b < maxlen; b += kBfsLanes) {
+            const uint32_t e = e0 + b + glane;
+            bool hit = false;
+            if (e < e1) {
+                const uint32_t v = tgt[e];
+                hit = (e == e0 || tgt[e - 1] != v) && depth[v] == CZ_NONE && claim[v] == i;
+            }
+            c += __popc(bfs_group_mask(__ballot(hit), lane));
         }
-        cnt[i] = c;
+        if (live && glane == 0) cnt[i] = c;
     }
 }
 
@@ -139,17 +168,36 @@ bfs_emit_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ t
                 uint32_t fsize, uint32_t *__restrict__ depth, const uint32_t *__restrict__ claim,
                 const uint32_t *__restrict__ pos, uint32_t *__restrict__ next, uint32_t *__restrict__ parent,
                 uint32_t next_depth) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < fsize; i += gridDim.x * blockDim.x) {
-        const uint32_t u = frontier[i];
-        uint32_t o = pos[i], prev = CZ_NONE;
-        for (uint32_t e = off[u]; e < off[u + 1]; e++) {
-            const uint32_t v = tgt[e];
-            if (v != prev && claim[v] == i && depth[v] == CZ_NONE) {
-                next[o++] = v;
-                parent[v] = u;
-                depth[v] = next_depth;  // only the winner touches v
+    const int lane = threadIdx.x & 63;
+    const uint32_t glane = threadIdx.x & (kBfsLanes - 1);
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kBfsLanes, ngroups = gridDim.x * blockDim.x / kBfsLanes;
+    const uint32_t rounds = (fsize + ngroups - 1) / ngroups;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i = group + r * ngroups;
+        const bool live = i < fsize;
+        const uint32_t u = live ? frontier[i] : 0;
+        const uint32_t e0 = live ? off[u] : 0, e1 = live ? off[u + 1] : 0;
+        uint32_t o = live ? pos[i] : 0;
+        uint32_t maxlen = e1 - e0;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, s, 64));
+        for (uint32_t b = 0; b < maxlen; b += kBfsLanes) {
+            const uint32_t e = e0 + b + glane;
+            bool hit = false;
+            uint32_t v = 0;
+            if (e < e1) {
+                v = tgt[e];
+                // `depth[v] == NONE` is read before any lane of this launch can have set it for v: only the claim
+                // winner writes depth[v], and the winner is this very lane group (claim[v] == i)
+                hit = (e == e0 || tgt[e - 1] != v) && claim[v] == i && depth[v] == CZ_NONE;
             }
-            prev = v;
+            const unsigned int m = bfs_group_mask(__ballot(hit), lane);
+            if (hit) {
+                next[o + __popc(m & ((1u << glane) - 1u))] = v;
+                parent[v] = u;
+                depth[v] = next_depth;
+            }
+            o += __popc(m);
         }
     }
 }
@@ -328,7 +376,7 @@ extern "C" int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, 
             while (fsize > 0) {
                 if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
                 const uint32_t *fr = d_order.p + lo;
-                const int g = grid_for(fsize);
+                const int g = grid_for((uint64_t)fsize * kBfsLanes);  // a 16-lane group per frontier node
                 hipLaunchKernelGGL(bfs_claim_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, fr, fsize, d_depth.p, d_claim.p);
                 hipLaunchKernelGGL(bfs_count_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, fr, fsize, d_depth.p, d_claim.p,
                                    d_cnt.p);
