@@ -140,3 +140,29 @@ def test_pagerank_vs_float64(air, registry):
     assert worst <= 1e-5, worst  # north_star tolerance, against an independent float64 implementation
     top = sorted(rows, key=lambda r: -r[1])[:10]
     assert [c for c, _ in top] == [c for c, _ in air["exp"]["pagerank"]["top10"]]
+
+
+def test_degree_centrality_against_the_references_own_asserts(air):
+    """PINNED BY THE REFERENCE: cozo-core/tests/air_routes.rs asserts these route counts on this very fixture
+    (most_out_routes :475-505, most_routes :539-566, airport_with_one_route :570-586, airports_by_route_number
+    :783-799).  DegreeCentrality (algos/degree_centrality.rs:24-76) computes the same counts per node."""
+    ref = json.load(open(os.path.join(G, "air_routes_reference_asserts.json")))
+    edges = FR.FixedRuleInputRelation([(t[0], t[1]) for t in air["route"].iter()])
+    rows = FR.FixedRuleRegistry().run("DegreeCentralityGpu", [edges, air["airport"]])
+    assert len(rows) == air["exp"]["airports"]  # airports without routes appear with zeros (:47-56)
+    out_deg = {r[0]: r[2] for r in rows}
+    total = {r[0]: r[1] for r in rows}
+    assert all(r[1] == r[2] + r[3] for r in rows)
+    top_out = sorted(((c, n) for c, n in out_deg.items() if n > 180), key=lambda x: (-x[1], x[0]))
+    assert [list(x) for x in top_out] == ref["most_out_routes_gt_180"]
+    top_tot = sorted(((c, n) for c, n in total.items() if n > 400), key=lambda x: (-x[1], x[0]))
+    assert [list(x) for x in top_tot] == ref["most_routes_gt_400"]
+    assert sum(1 for n in out_deg.values() if n == 1) == ref["airports_with_exactly_one_out_route"]
+    assert sorted(c for c, n in out_deg.items() if n == 106) == ref["airports_with_106_out_routes"]
+    for code, n in ref["routes_per_airport"]:
+        assert out_deg[code] == n
+    hist = {}
+    for n in out_deg.values():
+        hist[n] = hist.get(n, 0) + 1
+    assert [[n, hist[n]] for n in sorted(hist)[:10]] == ref["group_count_by_out_first_10"]
+    assert abs(sum(out_deg.values()) / len(out_deg) - ref["mean_out_routes_over_all_airports"]) <= 1e-8
