@@ -214,3 +214,97 @@ def distance_batch_device(distance: str, base, queries, pairs, out, stream: int 
     check(_lib.lib().cz_distance_batch(DISTANCES[distance], ptr(base), base.shape[0], base.shape[1], ptr(queries),
                                        queries.shape[0], ptr(pairs), pairs.shape[0], ptr(out), CZ_DEVICE_PTRS,
                                        C.c_void_p(stream)))
+
+
+# ---- HnswSearchRA::iter (query/ra.rs:1085-1121) + the row assembly of hnsw_knn (runtime/hnsw.rs:939-1006) ---------
+@dataclass
+class BaseRelation:
+    """The stored relation an index hangs off: key columns then non-key columns; rows in key order."""
+    keys: Sequence[str]
+    non_keys: Sequence[str]
+    rows: Sequence[tuple]
+
+    def column_name(self, idx: int) -> str:
+        return self.keys[idx] if idx < len(self.keys) else self.non_keys[idx - len(self.keys)]
+
+
+@dataclass
+class HnswSearchBinding:
+    """data/program.rs:975-991: which extra columns the search binds, plus radius / filter."""
+    k: int
+    ef: int
+    bind_field: bool = False
+    bind_field_idx: bool = False
+    bind_distance: bool = False
+    bind_vector: bool = False
+    radius: Optional[float] = None
+    filter: Optional[callable] = None  # the compiled filter expression over the bound result tuple
+
+
+def index_nodes(base: BaseRelation, vec_fields: Sequence[int]):
+    """hnsw_put's extraction order (runtime/hnsw.rs:679-727): per row, per indexed field, a vector or every vector of
+    a list -> [(row position, field, sub-index)] = the node -> CompoundKey table, and the vectors in that order."""
+    nodes, vecs = [], []
+    for r, t in enumerate(base.rows):
+        for f in vec_fields:
+            v = t[f]
+            if isinstance(v, np.ndarray):
+                nodes.append((r, f, -1))
+                vecs.append(v)
+            elif isinstance(v, (list, tuple)):
+                for s, x in enumerate(v):
+                    if isinstance(x, np.ndarray):
+                        nodes.append((r, f, s))
+                        vecs.append(x)
+    return nodes, (np.stack(vecs).astype(np.float32) if vecs else np.zeros((0, 0), np.float32))
+
+
+class HnswSearchRA:
+    """`parent` yields tuples carrying a vector at `bind_idx`; the reference calls hnsw_knn once per parent tuple, this
+    drains the parent into ONE batch, searches it with one launch and re-emits `parent ++ result` in parent order.
+    `index` is anything with hnsw_knn_batch(queries, HnswSearch) -> (ids, dist, count): a GpuHnswIndex."""
+
+    def __init__(self, index, base: BaseRelation, nodes: Sequence[tuple], search: HnswSearchBinding, bind_idx: int):
+        self.index, self.base, self.nodes, self.search, self.bind_idx = index, base, list(nodes), search, bind_idx
+
+    def iter(self, parent: Sequence[tuple]):
+        sb = self.search
+        qs = []
+        for t in parent:
+            v = t[self.bind_idx] if self.bind_idx < len(t) else None
+            if not isinstance(v, np.ndarray):
+                raise ValueError(f"Expected vector, got {v!r}")  # ra.rs:1106-1109
+            qs.append(np.asarray(v, dtype=np.float32))
+        if not qs:
+            return []
+        # without a filter the candidates are cut to k before rows are fetched; with one all ef survive until the
+        # filter has run (hnsw.rs:943-947)
+        cfg = HnswSearch(k=sb.k, ef=sb.ef, has_filter=sb.filter is not None)
+        if sb.filter is None:
+            cfg = HnswSearch(k=min(sb.k, sb.ef), ef=sb.ef)
+        ids, dist, cnt = self.index.hnsw_knn_batch(np.stack(qs), cfg)
+        out = []
+        for i, t in enumerate(parent):
+            rows = []
+            for j in range(int(cnt[i])):
+                d = float(dist[i, j])
+                if sb.radius is not None and d > sb.radius:  # :952-956
+                    continue
+                r, f, s = self.nodes[int(ids[i, j])]
+                cand = list(self.base.rows[r])
+                field_val = cand[f]
+                # "make sure the order is the same as in all_bindings()" (:962): field, field_idx, distance, vector
+                if sb.bind_field:
+                    cand.append(self.base.column_name(f))
+                if sb.bind_field_idx:
+                    cand.append(None if s < 0 else s)
+                if sb.bind_distance:
+                    cand.append(d)
+                if sb.bind_vector:
+                    cand.append(field_val if s < 0 else field_val[s])
+                if sb.filter is not None and not sb.filter(tuple(cand)):  # :994-998
+                    continue
+                rows.append(tuple(cand))
+            for c in rows[:sb.k]:  # :1005-1006 (rows already ascending by distance)
+                out.append(tuple(t) + c)
+        return out
