@@ -1,0 +1,101 @@
+/* oracle_shim.c -- TEST ONLY.  The graph entry points of include/cozo_gpu.h implemented with the CPU oracle, so that the
+ * C++ host mirror's rule logic (options, id mapping, CSR build, row emission) can be exercised on a box without a GPU:
+ * tests/cpp/test_host is linked against THIS library ahead of libcozo_gpu.so for its `rules-cpu` mode, exactly like
+ * tests/util.py's OracleGraphBackend stands in for cozo_amd.graph in the Python rule tests.  Never shipped, never loaded
+ * by the product. */
+#include <stdlib.h>
+#include <string.h>
+
+#include "cozo_gpu.h"
+#include "cozo_oracle.h"
+
+static const char *g_err = "";
+const char *cz_last_error(void) { return g_err; }
+int cz_device_count(void) { return 1; }
+int cz_init(int device) { (void)device; return CZ_OK; }
+
+static uint64_t *widen(const uint32_t *off, uint32_t n) {
+    uint64_t *o = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)n + 1));
+    for (uint32_t i = 0; i <= n; i++) o[i] = off[i];
+    return o;
+}
+static int poisoned(const volatile uint8_t *p) { return p && *p; }
+
+int cz_pagerank(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N, uint64_t E,
+                float damping, double tolerance, uint32_t max_iter, float *scores, uint32_t *iters_run, double *final_err,
+                const volatile uint8_t *poison) {
+    (void)E;
+    if (poisoned(poison)) { g_err = "cancelled"; return CZ_E_CANCELLED; }
+    if (N == 0) return CZ_OK;
+    uint64_t *off = widen(in_offsets, N);
+    uint32_t it = 0;
+    double err = 0;
+    orc_pagerank(N, off, in_sources, out_degree, damping, tolerance, max_iter, scores, &it, &err, 1);
+    free(off);
+    if (iters_run) *iters_run = it;
+    if (final_err) *final_err = err;
+    return CZ_OK;
+}
+
+int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E, const uint32_t *starts,
+           uint32_t n_starts, const uint32_t *goals, uint32_t n_goals, int share_visited, uint32_t *parent, uint32_t *depth,
+           uint32_t *order, uint32_t *n_reached, const volatile uint8_t *poison) {
+    (void)E; (void)depth;
+    if (poisoned(poison)) { g_err = "cancelled"; return CZ_E_CANCELLED; }
+    uint64_t *off = widen(out_offsets, N);
+    uint8_t *visited = (uint8_t *)calloc(N ? N : 1, 1);
+    uint32_t *ord = (uint32_t *)malloc(sizeof(uint32_t) * (N ? N : 1));
+    for (uint32_t s = 0; s < n_starts; s++) {
+        uint32_t *par = parent + (size_t)s * N;
+        for (uint32_t v = 0; v < N; v++) par[v] = CZ_NONE;
+        if (order) for (uint32_t v = 0; v < N; v++) order[(size_t)s * N + v] = CZ_NONE;
+        if (n_reached) n_reached[s] = 0;
+        if (goals) {
+            orc_shortest_path_bfs(N, off, out_targets, starts[s], goals, n_goals, par);
+            continue;
+        }
+        if (!share_visited) memset(visited, 0, N);
+        if (visited[starts[s]]) continue; /* algos/bfs.rs:52-54 */
+        const uint32_t c = orc_bfs_order(N, off, out_targets, starts[s], visited, par, ord);
+        if (n_reached) n_reached[s] = c;
+        if (order) memcpy(order + (size_t)s * N, ord, sizeof(uint32_t) * c);
+    }
+    free(ord);
+    free(visited);
+    free(off);
+    return CZ_OK;
+}
+
+int cz_connected_components(const uint32_t *offsets, const uint32_t *targets, uint32_t N, uint64_t E, uint32_t *group,
+                            uint32_t *n_groups, const volatile uint8_t *poison) {
+    (void)E;
+    if (poisoned(poison)) { g_err = "cancelled"; return CZ_E_CANCELLED; }
+    uint64_t *off = widen(offsets, N);
+    const uint32_t k = orc_tarjan_groups(N, off, targets, group);
+    free(off);
+    if (n_groups) *n_groups = k;
+    return CZ_OK;
+}
+
+int cz_clustering_coefficients(const uint32_t *offsets, const uint32_t *targets, uint32_t N, uint64_t E, uint64_t *n_triangles,
+                               uint32_t *degree, const volatile uint8_t *poison) {
+    (void)E;
+    if (poisoned(poison)) { g_err = "cancelled"; return CZ_E_CANCELLED; }
+    uint64_t *off = widen(offsets, N);
+    double *cc = (double *)malloc(sizeof(double) * (N ? N : 1));
+    orc_clustering_coefficients(N, off, targets, cc, n_triangles, degree);
+    free(cc);
+    free(off);
+    return CZ_OK;
+}
+
+int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
+            const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison) {
+    (void)E;
+    if (poisoned(poison)) { g_err = "cancelled"; return CZ_E_CANCELLED; }
+    uint64_t *off = widen(out_offsets, N);
+    for (uint32_t s = 0; s < n_starts; s++)
+        orc_dijkstra(N, off, out_targets, weights, starts[s], NULL, 0, dist + (size_t)s * N, parent + (size_t)s * N);
+    free(off);
+    return CZ_OK;
+}

@@ -2,6 +2,7 @@
 //
 //   test_host cpu   host logic only: DataValue order, option readers, id assignment / CSR vs the oracle, registry
 //   test_host gpu   the fixed rules and HnswSearchRA on a real MI355X, rows compared with the oracle's
+//   test_host_shim rules-cpu   (linked against tests/cpp/oracle_shim.c) the same rule checks without a device
 // The oracle (oracle/cozo_oracle.h) is test infrastructure; it is linked into this test binary only.
 // Reads like the reference's own tests: runtime/tests.rs:529-577 (custom rule), algos/shortest_path_bfs.rs:124-174
 // (love graph), runtime/tests.rs:178-207 (PageRank options), runtime/tests.rs:700-809 (vector search).
@@ -580,6 +581,15 @@ int main(int argc, char **argv) {
     test_registry_and_simple_rule();
     test_degree_centrality();
     test_no_device_fails_loudly();
+    if (mode == "rules-cpu") {
+        // the binary was linked against tests/cpp/oracle_shim.c ahead of libcozo_gpu.so: the rules' host logic runs on
+        // CPU with the oracle standing in for the device entry points (TEST ONLY; HNSW needs the real library)
+        gpu_pagerank();
+        gpu_love_graph();
+        gpu_bfs_cc_dijkstra_random();
+        gpu_clustering_coefficients();
+        gpu_closeness_centrality();
+    }
     if (mode == "gpu") {
         if (cz_init(0) != CZ_OK) {
             std::printf("FAIL: cz_init: %s\n", cz_last_error());
