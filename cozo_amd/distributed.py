@@ -106,3 +106,75 @@ def merge_shard_topk(local_ids: torch.Tensor, local_dist: torch.Tensor, id_offse
     o2 = torch.argsort(d, dim=1, stable=True)
     ids, d = torch.gather(ids, 1, o2)[:, :k], torch.gather(d, 1, o2)[:, :k]
     return ids, d
+
+
+def symmetrised_csr(n: int, a, b):
+    """out-CSR (offsets u64 [n+1], targets u32) of the rows (a,b) and their mirrors, neighbour lists ascending,
+    duplicates kept -- the layout as_directed_graph(undirected = true) hands to the rules (fixed_rule/mod.rs:187-195)."""
+    import numpy as np
+    a = np.asarray(a, dtype=np.uint32)
+    b = np.asarray(b, dtype=np.uint32)
+    src = np.concatenate([a, b])
+    dst = np.concatenate([b, a])
+    order = np.lexsort((dst, src)) if src.size else np.zeros(0, dtype=np.int64)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    if src.size:
+        off[1:] = np.cumsum(np.bincount(src, minlength=n))
+    return off, dst[order].astype(np.uint32)
+
+
+def sharded_connected_components(n_nodes: int, edge_from, edge_to, world: int, device: torch.device,
+                                 local_cc: Callable, group=None):
+    """ConnectedComponents (strongly_connected_components.rs:42-77, strong = false) over an EDGE partition: every rank
+    holds any subset of the edge rows (dense ids over the same n_nodes), and the union over ranks is the relation.
+
+    1. local_cc(offsets, targets) -> (group u32 [N], n_groups) on the rank's own symmetrised rows (the single-GPU rule:
+       group = rank of the component by its smallest member).  label[v] = smallest member of v's local component.
+    2. ONE exchange: all-gather of the label vectors (4N bytes per rank).
+    3. the components of the union are the components of the star graph {(v, label_r[v]) : r < world, label_r[v] != v}
+       (<= world * N rows): every rank runs local_cc on it.  Replicated on purpose: the result is needed everywhere and
+       a broadcast of 4N bytes costs what the gather did.
+    Group ids come out exactly as the single-process rule numbers them (ranked by smallest member), so the rows are
+    identical to the unsharded run's.  Returns (group u32 [N], n_groups)."""
+    import numpy as np
+    off, tgt = symmetrised_csr(n_nodes, edge_from, edge_to)
+    grp, _ = local_cc(off, tgt)
+    grp = np.asarray(grp, dtype=np.int64)
+    # groups are numbered in order of their smallest member, so the first node carrying a group id IS that member
+    _, first = np.unique(grp, return_index=True)
+    label = first[grp].astype(np.int64) if n_nodes else np.zeros(0, dtype=np.int64)
+    if world > 1:
+        mine = torch.from_numpy(label).to(device)
+        every = torch.empty(world * n_nodes, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(every, mine, group=group)
+        labels = every.cpu().numpy().reshape(world, n_nodes)
+    else:
+        labels = label.reshape(1, n_nodes)
+    v = np.broadcast_to(np.arange(n_nodes, dtype=np.int64), labels.shape)
+    keep = labels != v
+    off2, tgt2 = symmetrised_csr(n_nodes, v[keep], labels[keep])
+    grp2, k = local_cc(off2, tgt2)
+    return np.asarray(grp2, dtype=np.uint32), int(k)
+
+
+def shard_sources(n_sources: int, rank: int, world: int) -> Tuple[int, int]:
+    """[begin, end) of the start nodes this rank traverses from.  Traversals from different start nodes are
+    independent units (ShortestPathBFS / ShortestPathDijkstra run them one after another or under rayon,
+    shortest_path_dijkstra.rs:70-153; ClosenessCentrality is one SSSP per node, all_pairs_shortest_path.rs:113-144):
+    they are split across ranks with NO collective on the data path."""
+    per = (n_sources + world - 1) // world
+    return min(n_sources, rank * per), min(n_sources, (rank + 1) * per)
+
+
+def gather_source_rows(local_rows: torch.Tensor, n_sources: int, world: int, group=None) -> torch.Tensor:
+    """Puts the per-source result rows ([local sources][width], any dtype) of every rank back into start-node order on
+    every rank: one all-gather of the padded slices at the END of the job (not part of the traversal)."""
+    if world == 1:
+        return local_rows
+    per = (n_sources + world - 1) // world
+    width = local_rows.shape[1:]
+    mine = torch.zeros((per,) + tuple(width), dtype=local_rows.dtype, device=local_rows.device)
+    mine[:local_rows.shape[0]] = local_rows
+    every = torch.empty((world * per,) + tuple(width), dtype=local_rows.dtype, device=local_rows.device)
+    dist.all_gather_into_tensor(every, mine.contiguous(), group=group)
+    return every[:n_sources]

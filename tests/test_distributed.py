@@ -147,3 +147,90 @@ def test_equal_row_partition_covers_rows():
             assert per * w >= n and ranges[0][0] == 0 and ranges[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
             assert all(0 <= hi - lo <= per for lo, hi in ranges)
+
+
+def _cc_worker(rank, world, port, n, fi, ti, q):
+    from oracle import oracle as O
+    from cozo_amd.distributed import sharded_connected_components
+    _init(rank, world, port)
+    # an edge partition with nothing nice about it: rows dealt round-robin
+    mine = slice(rank, None, world)
+    grp, k = sharded_connected_components(n, fi[mine], ti[mine], world, torch.device("cpu"),
+                                          lambda off, tgt: O.tarjan_groups(off.size - 1, off, tgt))
+    q.put((rank, grp, k))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,e", [(400, 300), (50, 400), (9, 0), (1000, 700)])
+def test_sharded_connected_components_world2_matches_single_process(oracle, n, e):
+    """edge-partitioned ConnectedComponents: group ids (ranked by smallest member) identical to the unsharded rule's"""
+    rng = np.random.default_rng(n + e)
+    fi = rng.integers(0, n, e).astype(np.uint32)
+    ti = rng.integers(0, n, e).astype(np.uint32)
+    off, tgt = oracle.build_csr(n, fi, ti, undirected=True)
+    want, want_k = oracle.tarjan_groups(n, off, tgt)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cc_worker, args=(r, 2, port, n, fi, ti, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, grp, k in res:
+        assert k == want_k and np.array_equal(grp, want)
+
+
+def test_sharded_connected_components_world1_and_symmetrised_csr(oracle):
+    from cozo_amd.distributed import sharded_connected_components, symmetrised_csr
+    rng = np.random.default_rng(2)
+    n, e = 120, 90
+    fi = rng.integers(0, n, e).astype(np.uint32)
+    ti = rng.integers(0, n, e).astype(np.uint32)
+    off, tgt = oracle.build_csr(n, fi, ti, undirected=True)
+    off2, tgt2 = symmetrised_csr(n, fi, ti)
+    assert np.array_equal(off, off2) and np.array_equal(tgt, tgt2)  # same layout as as_directed_graph(undirected)
+    want, want_k = oracle.tarjan_groups(n, off, tgt)
+    grp, k = sharded_connected_components(n, fi, ti, 1, torch.device("cpu"),
+                                          lambda o, t: oracle.tarjan_groups(o.size - 1, o, t))
+    assert k == want_k and np.array_equal(grp, want)
+
+
+def _sources_worker(rank, world, port, n, off, tgt, w, starts, q):
+    from oracle import oracle as O
+    from cozo_amd.distributed import gather_source_rows, shard_sources
+    _init(rank, world, port)
+    lo, hi = shard_sources(len(starts), rank, world)
+    rows = np.zeros((hi - lo, n), dtype=np.float32)
+    for i, s in enumerate(starts[lo:hi]):
+        rows[i], _ = O.dijkstra(n, off, tgt, w, int(s))
+    every = gather_source_rows(torch.from_numpy(rows), len(starts), world)
+    q.put((rank, every.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_starts", [7, 2, 1])
+def test_sharded_sources_world2(oracle, n_starts):
+    """start nodes are independent units: split across ranks, rows put back in start order by one final gather"""
+    frm, to = util.random_relation(60, 300, 3)
+    wts = np.random.default_rng(4).random(frm.size).astype(np.float32)
+    g = util.graph_from_relation(oracle, frm, to, weights=wts)
+    starts = np.arange(n_starts, dtype=np.uint32) * 3
+    want = np.stack([oracle.dijkstra(g["n"], g["ooff"], g["otgt"], g["ow"], int(s))[0] for s in starts])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sources_worker, args=(r, 2, port, g["n"], g["ooff"], g["otgt"], g["ow"], starts, q))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, got in res:
+        assert np.array_equal(got, want)
