@@ -30,7 +30,7 @@ def _deps_mtime():
     m = 0.0
     for root in (CSRC, os.path.join(HERE, "..", "include")):
         for f in os.listdir(root):
-            if f.endswith((".h", ".cuh", ".hip")):
+            if f.endswith((".h", ".cuh", ".hip")) and f != "cozo_ingest.h":
                 m = max(m, os.path.getmtime(os.path.join(root, f)))
     return m
 
@@ -94,6 +94,26 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     return HOST_SO
 
 
+# ---- host ingest (cozo_amd/ingest): libcozo_ingest.so, stored rows -> flat arrays; no device code, no HIP ----------
+INGEST_SRC = os.path.join(HERE, "ingest", "ingest.cpp")
+INGEST_SO = os.path.join(LIBDIR, "libcozo_ingest.so")
+
+
+def build_ingest(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    inc = os.path.join(HERE, "..", "include")
+    newest = max(os.path.getmtime(INGEST_SRC), os.path.getmtime(os.path.join(inc, "cozo_ingest.h")),
+                 os.path.getmtime(os.path.join(inc, "cozo_gpu.h")))
+    if not force and os.path.exists(INGEST_SO) and os.path.getmtime(INGEST_SO) >= newest:
+        return INGEST_SO
+    subprocess.check_call([CXX, "-std=c++17", "-O2", "-fPIC", "-Wall", "-Wextra", "-shared", "-I" + inc, INGEST_SRC,
+                           "-o", INGEST_SO])
+    if verbose:
+        print("built", INGEST_SO)
+    return INGEST_SO
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
     build_host(force="--force" in sys.argv, verbose=True)
+    build_ingest(force="--force" in sys.argv, verbose=True)

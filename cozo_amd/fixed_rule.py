@@ -17,6 +17,7 @@ data/value.rs (Null < Bool < Num < Str < Bytes < List); relations are sets of tu
 from __future__ import annotations
 
 import math
+import struct
 from typing import Any, Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -108,11 +109,12 @@ def sort_key(v):
     (data/value.rs Num::cmp); NaN greatest among numbers."""
     r = _rank(v)
     if r == 2:
-        f = float(v)
+        # floats by f64::total_cmp (-0.0 < +0.0, NaN by its sign), an Int through its f64 image and before the Float it
+        # equals (data/value.rs:575-598); Ints sharing an image by their exact value
         is_float = isinstance(v, (float, np.floating))
-        if f != f:
-            return (2, 1, 0.0, 1)
-        return (2, 0, f, 1 if is_float else 0)
+        u = struct.unpack(">Q", struct.pack(">d", float(v)))[0]
+        u = (~u & 0xFFFFFFFFFFFFFFFF) if u >> 63 else (u | 0x8000000000000000)
+        return (2, u, 1, 0) if is_float else (2, u, 0, int(v))
     if r == 9:
         return (9, tuple(sort_key(x) for x in v))
     if r == 1:

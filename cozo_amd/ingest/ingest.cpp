@@ -1,0 +1,1100 @@
+// ingest.cpp -- libcozo_ingest.so: stored rows (key bytes + value bytes) -> the flat arrays libcozo_gpu.so takes.
+// Host code only.  See include/cozo_ingest.h for the contract; the byte formats restated here are
+//   memcmp keys      data/memcmp.rs:22-163 (encode), :165-365 (decode)
+//   stored key/value data/tuple.rs:27-52, runtime/relation.rs:169-296, 520-531
+//   msgpack values   rmp-serde 1.2.0 over the derives of data/value.rs:143-175 (+ Vector's own impl, :226-252)
+#include "cozo_ingest.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+struct Error {
+    int code;
+};
+[[noreturn]] void raise(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    throw Error{code};
+}
+
+inline uint64_t be64(const uint8_t *p) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    return __builtin_bswap64(v);
+}
+inline uint32_t be32(const uint8_t *p) {
+    uint32_t v;
+    memcpy(&v, p, 4);
+    return __builtin_bswap32(v);
+}
+inline uint16_t be16(const uint8_t *p) { return (uint16_t)((p[0] << 8) | p[1]); }
+
+// ------------------------------------------------------------------------------------------------ memcmp keys
+enum : uint8_t {
+    INIT_TAG = 0x00, NULL_TAG = 0x01, FALSE_TAG = 0x02, TRUE_TAG = 0x03, VEC_TAG = 0x04, NUM_TAG = 0x05, STR_TAG = 0x06,
+    BYTES_TAG = 0x07, UUID_TAG = 0x08, REGEX_TAG = 0x09, LIST_TAG = 0x0A, SET_TAG = 0x0B, VLD_TAG = 0x0C, JSON_TAG = 0x0D,
+    BOT_TAG = 0xFF
+};
+enum : uint8_t { VEC_F32 = 0x01, VEC_F64 = 0x02 };
+enum : uint8_t { IS_FLOAT = 0x10, IS_APPROX_INT = 0x04, IS_EXACT_INT = 0x00 };
+constexpr uint64_t SIGN_MARK = 0x8000000000000000ull;
+constexpr int64_t EXACT_INT_BOUND = 0x20000000000000ll;
+constexpr int kMaxDepth = 64;
+
+// encode_bytes groups (memcmp.rs:147-163): 8 payload bytes + a marker 0xFF - pad; the group with pad > 0 ends the string
+const uint8_t *mc_skip_groups(const uint8_t *p, const uint8_t *end) {
+    for (;;) {
+        if (end - p < 9) raise(CZI_E_CORRUPT, "truncated byte-string group in a key");
+        const uint8_t marker = p[8];
+        p += 9;
+        if (marker == 0xFF) continue;
+        if (marker < 0xF7) raise(CZI_E_CORRUPT, "bad byte-string group marker 0x%02x", marker);
+        return p;
+    }
+}
+
+// one encoded DataValue -> pointer past it
+const uint8_t *mc_skip(const uint8_t *p, const uint8_t *end, int depth = 0) {
+    if (p >= end) raise(CZI_E_CORRUPT, "key ends where a column should start");
+    if (depth > kMaxDepth) raise(CZI_E_CORRUPT, "key nests deeper than %d lists", kMaxDepth);
+    const uint8_t tag = *p++;
+    switch (tag) {
+    case NULL_TAG: case FALSE_TAG: case TRUE_TAG: case BOT_TAG:
+        return p;
+    case NUM_TAG: {
+        if (end - p < 9) raise(CZI_E_CORRUPT, "truncated number in a key");
+        const uint8_t kind = p[8];
+        p += 9;
+        if (kind == IS_APPROX_INT) {
+            if (end - p < 8) raise(CZI_E_CORRUPT, "truncated number in a key");
+            p += 8;
+        } else if (kind != IS_FLOAT && kind != IS_EXACT_INT) {
+            raise(CZI_E_CORRUPT, "bad number kind 0x%02x in a key", kind);
+        }
+        return p;
+    }
+    case STR_TAG: case BYTES_TAG: case REGEX_TAG: case JSON_TAG:
+        return mc_skip_groups(p, end);
+    case UUID_TAG:
+        if (end - p < 16) raise(CZI_E_CORRUPT, "truncated uuid in a key");
+        return p + 16;
+    case VLD_TAG:
+        if (end - p < 9) raise(CZI_E_CORRUPT, "truncated validity in a key");
+        return p + 9;
+    case VEC_TAG: {
+        if (end - p < 9) raise(CZI_E_CORRUPT, "truncated vector in a key");
+        const uint8_t t = p[0];
+        const uint64_t len = be64(p + 1);
+        p += 9;
+        const uint64_t w = t == VEC_F32 ? 4 : t == VEC_F64 ? 8 : 0;
+        if (!w) raise(CZI_E_CORRUPT, "bad vector element tag 0x%02x in a key", t);
+        if (len > (uint64_t)(end - p) / w) raise(CZI_E_CORRUPT, "truncated vector in a key");
+        return p + len * w;
+    }
+    case LIST_TAG: case SET_TAG:
+        for (;;) {
+            if (p >= end) raise(CZI_E_CORRUPT, "unterminated list in a key");
+            if (*p == INIT_TAG) return p + 1;
+            p = mc_skip(p, end, depth + 1);
+        }
+    default:
+        raise(CZI_E_CORRUPT, "unknown key tag 0x%02x", tag);
+    }
+}
+
+inline double order_decode_f64(uint64_t u) {
+    u = (u & SIGN_MARK) ? (u & ~SIGN_MARK) : ~u;
+    double f;
+    memcpy(&f, &u, 8);
+    return f;
+}
+inline uint64_t order_encode_f64(double v) {
+    uint64_t u;
+    memcpy(&u, &v, 8);
+    return (u >> 63) ? ~u : (u | SIGN_MARK);  // is_sign_positive <=> sign bit clear (also for NaN)
+}
+
+struct NumVal {
+    bool is_int;
+    int64_t i;
+    double f;  // get_float(): the int widened
+};
+// Num::decode_from_key (memcmp.rs:227-245); p points past NUM_TAG
+NumVal mc_num(const uint8_t *p, const uint8_t *end) {
+    if (end - p < 9) raise(CZI_E_CORRUPT, "truncated number in a key");
+    const double f = order_decode_f64(be64(p));
+    const uint8_t kind = p[8];
+    if (kind == IS_FLOAT) return {false, 0, f};
+    if (kind == IS_EXACT_INT) return {true, (int64_t)f, f};
+    if (kind != IS_APPROX_INT || end - p < 17) raise(CZI_E_CORRUPT, "bad number in a key");
+    const int64_t i = (int64_t)(be64(p + 9) ^ SIGN_MARK);
+    return {true, i, (double)i};
+}
+
+struct Buf {
+    std::vector<uint8_t> b;
+    void u8(uint8_t v) { b.push_back(v); }
+    void u64be(uint64_t v) {
+        v = __builtin_bswap64(v);
+        const uint8_t *p = (const uint8_t *)&v;
+        b.insert(b.end(), p, p + 8);
+    }
+    void raw(const uint8_t *p, size_t n) { b.insert(b.end(), p, p + n); }
+    // encode_bytes (memcmp.rs:147-163)
+    void groups(const uint8_t *key, size_t len) {
+        size_t index = 0;
+        while (index <= len) {
+            const size_t remain = len - index;
+            if (remain > 8) {
+                raw(key + index, 8);
+                u8(0xFF);
+            } else {
+                const size_t pad = 8 - remain;
+                raw(key + index, remain);
+                for (size_t i = 0; i < pad; i++) u8(0);
+                u8((uint8_t)(0xFF - pad));
+            }
+            index += 8;
+        }
+    }
+    void num_int(int64_t i) {  // encode_num (memcmp.rs:127-145)
+        u8(NUM_TAG);
+        u64be(order_encode_f64((double)i));
+        if (i > -EXACT_INT_BOUND && i < EXACT_INT_BOUND) {
+            u8(IS_EXACT_INT);
+        } else {
+            u8(IS_APPROX_INT);
+            u64be((uint64_t)i ^ SIGN_MARK);
+        }
+    }
+    void num_float(double f) {
+        u8(NUM_TAG);
+        u64be(order_encode_f64(f));
+        u8(IS_FLOAT);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ msgpack values
+struct Mp {
+    const uint8_t *p, *end;
+    void need(size_t n) const {
+        if ((size_t)(end - p) < n) raise(CZI_E_CORRUPT, "truncated msgpack value");
+    }
+    uint8_t peek() const {
+        need(1);
+        return *p;
+    }
+    bool is_str() const {
+        const uint8_t t = peek();
+        return (t >= 0xa0 && t <= 0xbf) || t == 0xd9 || t == 0xda || t == 0xdb;
+    }
+    bool is_map() const {
+        const uint8_t t = peek();
+        return (t >= 0x80 && t <= 0x8f) || t == 0xde || t == 0xdf;
+    }
+    bool is_int() const {
+        const uint8_t t = peek();
+        return t <= 0x7f || t >= 0xe0 || (t >= 0xcc && t <= 0xd3);
+    }
+    uint32_t array() {
+        const uint8_t t = peek();
+        if (t >= 0x90 && t <= 0x9f) { p++; return t & 0x0f; }
+        if (t == 0xdc) { need(3); const uint32_t n = be16(p + 1); p += 3; return n; }
+        if (t == 0xdd) { need(5); const uint32_t n = be32(p + 1); p += 5; return n; }
+        raise(CZI_E_CORRUPT, "msgpack: expected an array, found 0x%02x", t);
+    }
+    uint32_t map() {
+        const uint8_t t = peek();
+        if (t >= 0x80 && t <= 0x8f) { p++; return t & 0x0f; }
+        if (t == 0xde) { need(3); const uint32_t n = be16(p + 1); p += 3; return n; }
+        if (t == 0xdf) { need(5); const uint32_t n = be32(p + 1); p += 5; return n; }
+        raise(CZI_E_CORRUPT, "msgpack: expected a map, found 0x%02x", t);
+    }
+    void str(const uint8_t *&s, uint32_t &n) {
+        const uint8_t t = peek();
+        if (t >= 0xa0 && t <= 0xbf) { n = t & 0x1f; p++; }
+        else if (t == 0xd9) { need(2); n = p[1]; p += 2; }
+        else if (t == 0xda) { need(3); n = be16(p + 1); p += 3; }
+        else if (t == 0xdb) { need(5); n = be32(p + 1); p += 5; }
+        else raise(CZI_E_CORRUPT, "msgpack: expected a string, found 0x%02x", t);
+        need(n);
+        s = p;
+        p += n;
+    }
+    // serde_bytes writes bin; a Vec<u8> without it would be an array of ints -- accepted too
+    void bin(const uint8_t *&s, uint32_t &n, std::vector<uint8_t> &scratch) {
+        const uint8_t t = peek();
+        if (t == 0xc4) { need(2); n = p[1]; p += 2; }
+        else if (t == 0xc5) { need(3); n = be16(p + 1); p += 3; }
+        else if (t == 0xc6) { need(5); n = be32(p + 1); p += 5; }
+        else if (is_str()) { str(s, n); return; }
+        else {
+            const uint32_t k = array();
+            scratch.resize(k);
+            for (uint32_t i = 0; i < k; i++) scratch[i] = (uint8_t)integer();
+            s = scratch.data();
+            n = k;
+            return;
+        }
+        need(n);
+        s = p;
+        p += n;
+    }
+    int64_t integer() {
+        const uint8_t t = peek();
+        if (t <= 0x7f) { p++; return t; }
+        if (t >= 0xe0) { p++; return (int8_t)t; }
+        switch (t) {
+        case 0xcc: need(2); p += 2; return p[-1];
+        case 0xcd: need(3); p += 3; return be16(p - 2);
+        case 0xce: need(5); p += 5; return be32(p - 4);
+        case 0xcf: need(9); p += 9; return (int64_t)be64(p - 8);
+        case 0xd0: need(2); p += 2; return (int8_t)p[-1];
+        case 0xd1: need(3); p += 3; return (int16_t)be16(p - 2);
+        case 0xd2: need(5); p += 5; return (int32_t)be32(p - 4);
+        case 0xd3: need(9); p += 9; return (int64_t)be64(p - 8);
+        }
+        raise(CZI_E_CORRUPT, "msgpack: expected an integer, found 0x%02x", t);
+    }
+    double real() {
+        const uint8_t t = peek();
+        if (t == 0xcb) {
+            need(9);
+            const uint64_t u = be64(p + 1);
+            p += 9;
+            double f;
+            memcpy(&f, &u, 8);
+            return f;
+        }
+        if (t == 0xca) {
+            need(5);
+            const uint32_t u = be32(p + 1);
+            p += 5;
+            float f;
+            memcpy(&f, &u, 4);
+            return f;
+        }
+        return (double)integer();
+    }
+    bool boolean() {
+        const uint8_t t = peek();
+        if (t != 0xc2 && t != 0xc3) raise(CZI_E_CORRUPT, "msgpack: expected a bool, found 0x%02x", t);
+        p++;
+        return t == 0xc3;
+    }
+    void skip(int depth = 0) {
+        if (depth > kMaxDepth) raise(CZI_E_CORRUPT, "msgpack value nests too deep");
+        const uint8_t t = peek();
+        size_t n = 0;
+        if (t <= 0x7f || t >= 0xe0 || t == 0xc0 || t == 0xc2 || t == 0xc3) { p++; return; }
+        if (t >= 0xa0 && t <= 0xbf) n = 1 + (t & 0x1f);
+        else if (t >= 0x90 && t <= 0x9f) { uint32_t k = array(); while (k--) skip(depth + 1); return; }
+        else if (t >= 0x80 && t <= 0x8f) { uint32_t k = map(); while (k--) { skip(depth + 1); skip(depth + 1); } return; }
+        else switch (t) {
+        case 0xc4: case 0xd9: need(2); n = 2 + p[1]; break;
+        case 0xc5: case 0xda: need(3); n = 3 + be16(p + 1); break;
+        case 0xc6: case 0xdb: need(5); n = 5 + (size_t)be32(p + 1); break;
+        case 0xca: case 0xce: case 0xd2: n = 5; break;
+        case 0xcb: case 0xcf: case 0xd3: n = 9; break;
+        case 0xcc: case 0xd0: n = 2; break;
+        case 0xcd: case 0xd1: n = 3; break;
+        case 0xd4: n = 3; break;
+        case 0xd5: n = 4; break;
+        case 0xd6: n = 6; break;
+        case 0xd7: n = 10; break;
+        case 0xd8: n = 18; break;
+        case 0xc7: need(2); n = 3 + p[1]; break;
+        case 0xc8: need(3); n = 4 + be16(p + 1); break;
+        case 0xc9: need(5); n = 6 + (size_t)be32(p + 1); break;
+        case 0xdc: case 0xdd: { uint32_t k = array(); while (k--) skip(depth + 1); return; }
+        case 0xde: case 0xdf: { uint32_t k = map(); while (k--) { skip(depth + 1); skip(depth + 1); } return; }
+        default: raise(CZI_E_CORRUPT, "msgpack: reserved byte 0x%02x", t);
+        }
+        need(n);
+        p += n;
+    }
+};
+
+// DataValue's variants in declaration order (data/value.rs:146-175) -- the index form some serde encoders use
+enum Variant { V_NULL, V_BOOL, V_NUM, V_STR, V_BYTES, V_UUID, V_REGEX, V_LIST, V_SET, V_VEC, V_JSON, V_VALIDITY, V_BOT, V_COUNT };
+const char *const kVariantName[V_COUNT] = {"Null", "Bool", "Num", "Str", "Bytes", "Uuid", "Regex", "List", "Set", "Vec", "Json",
+                                           "Validity", "Bot"};
+
+int variant_of(Mp &m, const char *const *names, int count, const char *what) {
+    if (m.is_str()) {
+        const uint8_t *s;
+        uint32_t n;
+        m.str(s, n);
+        for (int v = 0; v < count; v++)
+            if (strlen(names[v]) == n && memcmp(names[v], s, n) == 0) return v;
+        raise(CZI_E_CORRUPT, "msgpack: unknown %s variant '%.*s'", what, (int)std::min<uint32_t>(n, 32), (const char *)s);
+    }
+    if (m.is_int()) {
+        const int64_t v = m.integer();
+        if (v < 0 || v >= count) raise(CZI_E_CORRUPT, "msgpack: %s variant index %lld out of range", what, (long long)v);
+        return (int)v;
+    }
+    raise(CZI_E_CORRUPT, "msgpack: expected a %s variant, found 0x%02x", what, m.peek());
+}
+
+// reads the head of one DataValue: unit variants are bare, the others a one-entry map whose value follows
+Variant mp_value_head(Mp &m) {
+    if (m.is_map()) {
+        if (m.map() != 1) raise(CZI_E_CORRUPT, "msgpack: a value must be a one-entry map");
+        return (Variant)variant_of(m, kVariantName, V_COUNT, "DataValue");
+    }
+    const Variant v = (Variant)variant_of(m, kVariantName, V_COUNT, "DataValue");
+    if (v != V_NULL && v != V_BOT) raise(CZI_E_CORRUPT, "msgpack: variant %s needs a payload", kVariantName[v]);
+    return v;
+}
+
+NumVal mp_num(Mp &m) {  // enum Num { Int(i64), Float(f64) }, data/value.rs:493-499
+    static const char *const names[2] = {"Int", "Float"};
+    if (m.map() != 1) raise(CZI_E_CORRUPT, "msgpack: a number must be a one-entry map");
+    if (variant_of(m, names, 2, "Num") == 0) {
+        const int64_t i = m.integer();
+        return {true, i, (double)i};
+    }
+    return {false, 0, m.real()};
+}
+
+// Vector (data/value.rs:226-252): tuple (0u8 | 1u8, bytes of the elements in NATIVE = little-endian order)
+void mp_vec(Mp &m, int &el, const uint8_t *&bytes, uint32_t &n, std::vector<uint8_t> &scratch) {
+    if (m.array() != 2) raise(CZI_E_CORRUPT, "msgpack: a vector must be a 2-tuple");
+    el = (int)m.integer();
+    if (el != 0 && el != 1) raise(CZI_E_CORRUPT, "msgpack: bad vector element type %d", el);
+    m.bin(bytes, n, scratch);
+    if (n % (el == 0 ? 4 : 8)) raise(CZI_E_CORRUPT, "msgpack: vector payload of %u bytes", n);
+}
+
+// one msgpack DataValue -> its memcmp encoding appended to `out` (so that a node value stored in the value part of a
+// row gets the same identity as the same value stored in a key column)
+void mp_to_memcmp(Mp &m, Buf &out, std::vector<uint8_t> &scratch, int depth = 0) {
+    if (depth > kMaxDepth) raise(CZI_E_CORRUPT, "msgpack value nests too deep");
+    const Variant v = mp_value_head(m);
+    const uint8_t *s;
+    uint32_t n;
+    switch (v) {
+    case V_NULL: out.u8(NULL_TAG); return;
+    case V_BOT: out.u8(BOT_TAG); return;
+    case V_BOOL: out.u8(m.boolean() ? TRUE_TAG : FALSE_TAG); return;
+    case V_NUM: {
+        const NumVal x = mp_num(m);
+        if (x.is_int) out.num_int(x.i); else out.num_float(x.f);
+        return;
+    }
+    case V_STR: m.str(s, n); out.u8(STR_TAG); out.groups(s, n); return;
+    case V_BYTES: m.bin(s, n, scratch); out.u8(BYTES_TAG); out.groups(s, n); return;
+    case V_UUID: {  // uuid's binary form is its 16 bytes; memcmp.rs:86-93 writes d3, d2, d1, rest
+        m.bin(s, n, scratch);
+        if (n != 16) raise(CZI_E_CORRUPT, "msgpack: uuid of %u bytes", n);
+        out.u8(UUID_TAG);
+        out.raw(s + 6, 2); out.raw(s + 4, 2); out.raw(s, 4); out.raw(s + 8, 8);
+        return;
+    }
+    case V_LIST: case V_SET: {
+        uint32_t k = m.array();
+        out.u8(v == V_LIST ? LIST_TAG : SET_TAG);
+        while (k--) mp_to_memcmp(m, out, scratch, depth + 1);
+        out.u8(INIT_TAG);
+        return;
+    }
+    case V_VEC: {
+        int el;
+        mp_vec(m, el, s, n, scratch);
+        out.u8(VEC_TAG);
+        out.u8(el == 0 ? VEC_F32 : VEC_F64);
+        const uint32_t w = el == 0 ? 4 : 8;
+        out.u64be(n / w);
+        for (uint32_t i = 0; i < n; i += w)  // little-endian payload -> big-endian key bytes
+            for (uint32_t b = 0; b < w; b++) out.u8(s[i + w - 1 - b]);
+        return;
+    }
+    case V_VALIDITY: {  // struct Validity { timestamp: ValidityTs(Reverse<i64>), is_assert: Reverse<bool> } as an array
+        if (m.array() != 2) raise(CZI_E_CORRUPT, "msgpack: a validity must be a 2-tuple");
+        const int64_t ts = m.integer();
+        const bool is_assert = m.boolean();
+        out.u8(VLD_TAG);
+        out.u64be(~((uint64_t)ts ^ SIGN_MARK));
+        out.u8(is_assert ? 0 : 1);
+        return;
+    }
+    default:
+        raise(CZI_E_UNSUPPORTED, "a %s node value in the value part of a row", kVariantName[v]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ byte-string table
+inline uint64_t mix(uint64_t a, uint64_t b) {
+    const __uint128_t r = (__uint128_t)a * b;
+    return (uint64_t)r ^ (uint64_t)(r >> 64);
+}
+uint64_t hash_bytes(const uint8_t *p, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+    while (n >= 8) {
+        uint64_t w;
+        memcpy(&w, p, 8);
+        h = mix(h ^ w, 0xA0761D6478BD642Full);
+        p += 8;
+        n -= 8;
+    }
+    if (n) {
+        uint64_t w = 0;
+        memcpy(&w, p, n);
+        h = mix(h ^ w, 0xE7037ED1A0B428DBull);
+    }
+    return mix(h, 0x8EBC6AF09C88C6E3ull);
+}
+
+// byte strings -> dense ids in insertion order; the strings are kept (concatenated) for the way back.
+// Lookups are latency bound (a random slot, then the candidate's bytes): a slot therefore carries where the candidate's
+// bytes are (no second indirection), and callers that know their next keys call hint() on them a few dozen lookups
+// ahead so that both cache lines are in flight before the authoritative probe.
+struct ByteTable {
+    struct Slot {
+        uint64_t at;   // offset of the entry in `arena`: u32 length, then the bytes
+        uint32_t id;   // CZ_NONE = empty
+        uint32_t tag;  // high half of the hash
+    };
+    std::vector<Slot> slots;
+    std::vector<uint8_t> arena;
+    std::vector<uint8_t> bytes;  // the same strings back to back, in id order (the way back)
+    std::vector<uint64_t> off{0};
+    uint64_t mask = 0;
+
+    ByteTable() { rehash(1024); }
+    uint32_t size() const { return (uint32_t)(off.size() - 1); }
+    void rehash(size_t cap) {
+        std::vector<Slot> old;
+        old.swap(slots);
+        slots.assign(cap, Slot{0, CZ_NONE, 0});
+        mask = cap - 1;
+        for (const Slot &s : old)
+            if (s.id != CZ_NONE) {
+                uint32_t len;
+                memcpy(&len, arena.data() + s.at, 4);
+                uint64_t i = hash_bytes(arena.data() + s.at + 4, len) & mask;
+                while (slots[i].id != CZ_NONE) i = (i + 1) & mask;
+                slots[i] = s;
+            }
+    }
+    bool same(const Slot &s, const uint8_t *k, size_t len) const {
+        uint32_t l;
+        memcpy(&l, arena.data() + s.at, 4);
+        return l == len && memcmp(arena.data() + s.at + 4, k, len) == 0;
+    }
+    void hint_slot(uint64_t h) const { __builtin_prefetch(&slots[h & mask]); }
+    void hint_bytes(uint64_t h) const {
+        const Slot &s = slots[h & mask];
+        if (s.id != CZ_NONE && s.tag == (uint32_t)(h >> 32)) __builtin_prefetch(arena.data() + s.at);
+    }
+    uint32_t find_h(const uint8_t *k, size_t len, uint64_t h) const {
+        const uint32_t tag = (uint32_t)(h >> 32);
+        for (uint64_t i = h & mask;; i = (i + 1) & mask) {
+            const Slot &s = slots[i];
+            if (s.id == CZ_NONE) return CZ_NONE;
+            if (s.tag == tag && same(s, k, len)) return s.id;
+        }
+    }
+    uint32_t find(const uint8_t *k, size_t len) const { return find_h(k, len, hash_bytes(k, len)); }
+    uint32_t find_or_insert_h(const uint8_t *k, size_t len, uint64_t h) {
+        const uint32_t tag = (uint32_t)(h >> 32);
+        uint64_t i = h & mask;
+        for (;; i = (i + 1) & mask) {
+            const Slot &s = slots[i];
+            if (s.id == CZ_NONE) break;
+            if (s.tag == tag && same(s, k, len)) return s.id;
+        }
+        const uint32_t id = size();
+        if (id >= 0xFFFFFFFEu) raise(CZI_E_TOO_LARGE, "more than 2^32 - 2 distinct nodes");
+        if (len > 0xFFFFFFFFull) raise(CZI_E_TOO_LARGE, "a node value of %zu bytes", len);
+        const uint64_t at = arena.size();
+        const uint32_t l = (uint32_t)len;
+        arena.insert(arena.end(), (const uint8_t *)&l, (const uint8_t *)&l + 4);
+        arena.insert(arena.end(), k, k + len);
+        bytes.insert(bytes.end(), k, k + len);
+        off.push_back(bytes.size());
+        slots[i] = Slot{at, id, tag};
+        if ((uint64_t)(id + 1) * 2 > mask + 1) rehash((mask + 1) * 2);
+        return id;
+    }
+    uint32_t find_or_insert(const uint8_t *k, size_t len) { return find_or_insert_h(k, len, hash_bytes(k, len)); }
+};
+
+// ------------------------------------------------------------------------------------------------ rows
+struct Row {
+    const uint8_t *k, *kend, *v, *vend;
+};
+Row row_at(const czi_rows *r, uint64_t i) {
+    Row x;
+    x.k = r->keys + r->key_off[i];
+    x.kend = r->keys + r->key_off[i + 1];
+    if (x.kend - x.k < 8) raise(CZI_E_CORRUPT, "row %llu: a stored key is at least the 8-byte relation id", (unsigned long long)i);
+    x.k += 8;  // ENCODED_KEY_MIN_LEN, data/tuple.rs:86
+    x.v = x.vend = nullptr;
+    if (r->vals && r->val_off) {
+        x.v = r->vals + r->val_off[i];
+        x.vend = r->vals + r->val_off[i + 1];
+        if (x.vend - x.v >= 8) x.v += 8; else x.v = x.vend;  // extend_tuple_from_v: empty value = no columns
+    }
+    return x;
+}
+void check_rows(const czi_rows *r, const char *what) {
+    if (!r) raise(CZI_E_INVALID, "%s: null rows", what);
+    if (r->n_rows && (!r->keys || !r->key_off)) raise(CZI_E_INVALID, "%s: null key buffers", what);
+    if (r->n_rows && (r->vals == nullptr) != (r->val_off == nullptr)) raise(CZI_E_INVALID, "%s: vals and val_off go together", what);
+}
+
+// walks the columns of one stored row in tuple order: key columns first, then the msgpack array of the value
+struct ColumnCursor {
+    const uint8_t *kp, *kend;
+    uint32_t key_left;
+    Mp m;
+    uint32_t val_left;
+    bool val_open;
+    ColumnCursor(const Row &r, uint32_t n_key_cols) : kp(r.k), kend(r.kend), key_left(n_key_cols), m{r.v, r.vend}, val_left(0), val_open(false) {}
+    // 0 = no more columns, 1 = a key column [a, b), 2 = a value column (m.p stands on it; the caller consumes it)
+    int next(const uint8_t *&a, const uint8_t *&b) {
+        if (key_left) {
+            key_left--;
+            a = kp;
+            b = kp = mc_skip(kp, kend);
+            return 1;
+        }
+        if (!val_open) {
+            val_open = true;
+            val_left = (m.p && m.p < m.end) ? m.array() : 0;
+        }
+        if (!val_left) return 0;
+        val_left--;
+        return 2;
+    }
+};
+
+template <class F>
+int guarded(F &&f) {
+    try {
+        f();
+        return CZI_OK;
+    } catch (const Error &e) {
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        return fail(CZI_E_INVALID, "out of host memory");
+    }
+}
+
+}  // namespace
+
+// ==================================================================================================== graph
+struct czi_graph {
+    ByteTable nodes;
+    std::vector<uint32_t> src, dst;
+    std::vector<float> w;
+    bool weighted = false, undirected = false;
+};
+
+namespace {
+
+// CsrLayout::Sorted: lists ascending by target, parallel edges kept, ties in input order.  The entries are sorted as
+// 64-bit (source << 32 | target) keys by a stable LSD radix sort over just the bits two node ids need: every pass
+// streams the arrays through 2^11 write cursors, where a counting sort over N buckets would pay a cache miss per entry.
+// `undirected` feeds every row a second time with the ends swapped, right after it (fixed_rule/mod.rs:187-191).
+void build_csr(const czi_graph &g, bool inverse, uint32_t *offsets, uint32_t *targets, float *weights) {
+    const uint32_t n = g.nodes.size();
+    const uint64_t rows = g.src.size();
+    const uint64_t e = g.undirected ? rows * 2 : rows;
+    const std::vector<uint32_t> &A = inverse ? g.dst : g.src, &B = inverse ? g.src : g.dst;
+    const bool carry = weights != nullptr && g.weighted;
+    std::vector<uint64_t> key(e), key2(e);
+    std::vector<uint32_t> pay, pay2;  // the entry a key came from (weights follow their edges through the sort)
+    if (carry) {
+        pay.resize(e);
+        pay2.resize(e);
+    }
+    for (uint64_t r = 0; r < rows; r++) {
+        const uint64_t a = A[r], b = B[r];
+        if (g.undirected) {
+            key[2 * r] = a << 32 | b;
+            key[2 * r + 1] = b << 32 | a;
+            if (carry) pay[2 * r] = pay[2 * r + 1] = (uint32_t)r;
+        } else {
+            key[r] = a << 32 | b;
+            if (carry) pay[r] = (uint32_t)r;
+        }
+    }
+    int id_bits = 1;
+    while (id_bits < 32 && (1ull << id_bits) < (uint64_t)n) id_bits++;
+    constexpr int kRadix = 11;
+    struct Digit {
+        int shift, bits;
+    };
+    std::vector<Digit> digits;  // target bits first (least significant), then source bits
+    for (int half = 0; half < 2; half++)
+        for (int done = 0; done < id_bits; done += kRadix) digits.push_back({32 * half + done, std::min(kRadix, id_bits - done)});
+    // all histograms in one sweep over the keys
+    std::vector<std::vector<uint64_t>> cnt(digits.size(), std::vector<uint64_t>(1u << kRadix, 0));
+    for (uint64_t j = 0; j < e; j++) {
+        const uint64_t k = key[j];
+        for (size_t d = 0; d < digits.size(); d++) cnt[d][(k >> digits[d].shift) & ((1ull << digits[d].bits) - 1)]++;
+    }
+    for (size_t d = 0; d < digits.size(); d++) {
+        const int shift = digits[d].shift;
+        const uint64_t m = (1ull << digits[d].bits) - 1;
+        uint64_t *c = cnt[d].data();
+        uint64_t sum = 0;
+        for (uint64_t x = 0; x <= m; x++) {
+            const uint64_t t = c[x];
+            c[x] = sum;
+            sum += t;
+        }
+        if (carry) {
+            for (uint64_t j = 0; j < e; j++) {
+                const uint64_t at = c[(key[j] >> shift) & m]++;
+                key2[at] = key[j];
+                pay2[at] = pay[j];
+            }
+            pay.swap(pay2);
+        } else {
+            for (uint64_t j = 0; j < e; j++) key2[c[(key[j] >> shift) & m]++] = key[j];
+        }
+        key.swap(key2);
+    }
+    std::fill(offsets, offsets + n + 1, 0u);
+    for (uint64_t j = 0; j < e; j++) {
+        offsets[(key[j] >> 32) + 1]++;
+        targets[j] = (uint32_t)key[j];
+    }
+    for (uint32_t v = 0; v < n; v++) offsets[v + 1] += offsets[v];
+    if (weights)
+        for (uint64_t j = 0; j < e; j++) weights[j] = carry ? g.w[pay[j]] : 1.0f;
+}
+
+}  // namespace
+
+extern "C" const char *czi_last_error(void) { return g_err.c_str(); }
+extern "C" const char *czi_version(void) { return "cozo_ingest 0.1 (memcmp keys + rmp-serde 1.2 values of cozo 0.7.6)"; }
+
+extern "C" int czi_graph_ingest(const czi_rows *rel, int undirected, int weighted, int allow_negative_weights, czi_graph **out) {
+    if (!out) return fail(CZI_E_INVALID, "null out");
+    *out = nullptr;
+    std::unique_ptr<czi_graph> g(new (std::nothrow) czi_graph);
+    if (!g) return fail(CZI_E_INVALID, "out of host memory");
+    const int rc = guarded([&] {
+        check_rows(rel, "czi_graph_ingest");
+        g->weighted = weighted != 0;
+        g->undirected = undirected != 0;
+        const uint64_t E = rel->n_rows;
+        if ((g->undirected ? E * 2 : E) >= 0xFFFFFFFFull) raise(CZI_E_TOO_LARGE, "%llu rows do not fit u32 CSR offsets", (unsigned long long)E);
+        g->src.resize(E);
+        g->dst.resize(E);
+        if (g->weighted) g->w.resize(E);
+        // Rows are handled in blocks: parse a block (endpoint slices + weights), hash every endpoint and start its two
+        // cache lines moving (slot, then candidate bytes), and only then resolve the endpoints IN ROW ORDER -- the
+        // first-appearance numbering is untouched, the lookups of a block overlap instead of queueing behind each other.
+        constexpr uint32_t kBlock = 32;
+        struct End {
+            const uint8_t *a;
+            size_t len;
+            uint64_t h;
+        };
+        End ends[2 * kBlock];
+        Buf tmp[2 * kBlock];  // memcmp form of endpoints that live in the value part
+        std::vector<uint8_t> scratch;
+        for (uint64_t i0 = 0; i0 < E; i0 += kBlock) {
+            const uint32_t nb = (uint32_t)std::min<uint64_t>(kBlock, E - i0);
+            for (uint32_t r = 0; r < nb; r++) {
+                const uint64_t i = i0 + r;
+                ColumnCursor cur(row_at(rel, i), rel->n_key_cols);
+                for (int c = 0; c < 2; c++) {
+                    const uint8_t *a, *b;
+                    const int where = cur.next(a, b);
+                    if (where == 0) raise(CZI_E_NOT_AN_EDGE, "The relation cannot be interpreted as an edge");  // mod.rs:846-850
+                    End &e = ends[2 * r + c];
+                    if (where == 2) {
+                        Buf &t = tmp[2 * r + c];
+                        t.b.clear();
+                        mp_to_memcmp(cur.m, t, scratch);
+                        a = t.b.data();
+                        b = a + t.b.size();
+                    }
+                    e.a = a;
+                    e.len = (size_t)(b - a);
+                    e.h = hash_bytes(a, e.len);
+                    g->nodes.hint_slot(e.h);
+                }
+                if (!g->weighted) continue;
+                const uint8_t *a, *b;
+                const int where = cur.next(a, b);
+                double f = 1.0;
+                if (where == 1) {
+                    if (*a != NUM_TAG) raise(CZI_E_BAD_WEIGHT, "row %llu: the value cannot be interpreted as an edge weight", (unsigned long long)i);
+                    f = mc_num(a + 1, b).f;
+                } else if (where == 2) {
+                    if (mp_value_head(cur.m) != V_NUM) raise(CZI_E_BAD_WEIGHT, "row %llu: the value cannot be interpreted as an edge weight", (unsigned long long)i);
+                    f = mp_num(cur.m).f;
+                }
+                if (where != 0 && (!std::isfinite(f) || (f < 0.0 && !allow_negative_weights)))
+                    raise(CZI_E_BAD_WEIGHT, "row %llu: the value %g cannot be interpreted as an edge weight", (unsigned long long)i, f);
+                g->w[i] = (float)f;
+            }
+            for (uint32_t x = 0; x < 2 * nb; x++) g->nodes.hint_bytes(ends[x].h);
+            for (uint32_t r = 0; r < nb; r++) {
+                g->src[i0 + r] = g->nodes.find_or_insert_h(ends[2 * r].a, ends[2 * r].len, ends[2 * r].h);
+                g->dst[i0 + r] = g->nodes.find_or_insert_h(ends[2 * r + 1].a, ends[2 * r + 1].len, ends[2 * r + 1].h);
+            }
+        }
+    });
+    if (rc) return rc;
+    *out = g.release();
+    return CZI_OK;
+}
+
+extern "C" void czi_graph_free(czi_graph *g) { delete g; }
+extern "C" uint32_t czi_graph_node_count(const czi_graph *g) { return g ? g->nodes.size() : 0; }
+extern "C" uint64_t czi_graph_edge_count(const czi_graph *g) { return g ? (uint64_t)g->src.size() * (g->undirected ? 2 : 1) : 0; }
+
+extern "C" int czi_graph_csr(const czi_graph *g, int inverse, uint32_t *offsets, uint32_t *targets, float *weights) {
+    if (!g || !offsets || (!targets && !g->src.empty())) return fail(CZI_E_INVALID, "null argument");
+    return guarded([&] { build_csr(*g, inverse != 0, offsets, targets, weights); });
+}
+
+extern "C" int czi_graph_node_keys(const czi_graph *g, const uint8_t **bytes, const uint64_t **off) {
+    if (!g || !bytes || !off) return fail(CZI_E_INVALID, "null argument");
+    *bytes = g->nodes.bytes.data();
+    *off = g->nodes.off.data();
+    return CZI_OK;
+}
+
+extern "C" uint32_t czi_graph_lookup(const czi_graph *g, const uint8_t *key, uint64_t len) {
+    if (!g || (!key && len)) return CZ_NONE;
+    return g->nodes.find(key, (size_t)len);
+}
+
+// ==================================================================================================== hnsw
+struct czi_hnsw {
+    uint32_t n = 0, dim = 0;
+    int32_t metric = 0, n_levels = 0;
+    uint32_t entry = 0;
+    std::vector<float> vectors;
+    std::vector<uint32_t> level_size;
+    std::vector<int32_t> level_width;
+    std::vector<std::vector<uint32_t>> level_nodes, level_nbrs;
+    std::vector<const uint32_t *> level_nodes_p, level_nbrs_p;
+    std::vector<uint64_t> base_row;
+    std::vector<uint32_t> field;
+    std::vector<int32_t> sub;
+    uint64_t n_rows = 0, n_self = 0, n_live = 0, n_ignored = 0;
+};
+
+namespace {
+
+struct IdxRow {
+    int64_t layer;
+    const uint8_t *fr, *fr_end, *to, *to_end;  // [key x K, field, sub] of either end, as raw key bytes
+    const uint8_t *fr_key_end, *to_key_end;    // end of the K row-key columns inside each
+    bool ignore;
+};
+
+int64_t key_int(const uint8_t *a, const uint8_t *b, const char *what) {
+    if (a >= b || *a != NUM_TAG) raise(CZI_E_CORRUPT, "index row: %s is not a number", what);
+    const NumVal x = mc_num(a + 1, b);
+    if (!x.is_int) raise(CZI_E_CORRUPT, "index row: %s is not an integer", what);
+    return x.i;
+}
+
+// one row of `tbl:idx`; returns false for the canary row (layer 1, all-Null ends; hnsw.rs:641-669)
+bool parse_idx_row(const czi_rows *idx, uint64_t i, uint32_t K, IdxRow &r) {
+    const Row row = row_at(idx, i);
+    const uint8_t *p = row.k, *q = mc_skip(p, row.kend);
+    r.layer = key_int(p, q, "layer");
+    if (r.layer > 0) return false;
+    p = q;
+    for (int side = 0; side < 2; side++) {
+        const uint8_t *start = p;
+        for (uint32_t c = 0; c < K; c++) p = mc_skip(p, row.kend);
+        const uint8_t *key_end = p;
+        p = mc_skip(p, row.kend);
+        p = mc_skip(p, row.kend);
+        if (side == 0) { r.fr = start; r.fr_key_end = key_end; r.fr_end = p; }
+        else { r.to = start; r.to_key_end = key_end; r.to_end = p; }
+    }
+    if (p != row.kend) raise(CZI_E_CORRUPT, "index row %llu: %zu bytes after the last key column", (unsigned long long)i, (size_t)(row.kend - p));
+    // value [dist, hash, ignore_link]: only ignore_link matters for the link tables
+    r.ignore = false;
+    if (row.v && row.v < row.vend) {
+        Mp m{row.v, row.vend};
+        if (m.array() != 3) raise(CZI_E_CORRUPT, "index row %llu: the value is not [dist, hash, ignore_link]", (unsigned long long)i);
+        m.skip();
+        m.skip();
+        if (mp_value_head(m) != V_BOOL) raise(CZI_E_CORRUPT, "index row %llu: ignore_link is not a bool", (unsigned long long)i);
+        r.ignore = m.boolean();
+    } else {
+        raise(CZI_E_CORRUPT, "index row %llu has no value", (unsigned long long)i);
+    }
+    return true;
+}
+
+// the vector a node names, copied as f32[dim] into dst; col = the field's column of the base row
+void copy_vector(const czi_rows *base, uint64_t brow, uint32_t fld, int32_t sub_idx, uint32_t dim, float *dst,
+                 std::vector<uint8_t> &scratch) {
+    ColumnCursor cur(row_at(base, brow), base->n_key_cols);
+    const uint8_t *a = nullptr, *b = nullptr;
+    int where = 0;
+    for (uint32_t c = 0; c <= fld; c++) {
+        where = cur.next(a, b);
+        if (where == 0) raise(CZI_E_MISSING_ROW, "base row %llu has no column %u", (unsigned long long)brow, fld);
+        if (where == 2 && c < fld) cur.m.skip();
+    }
+    if (where == 1) {  // a key column: [LIST_TAG elements.. INIT] or VEC_TAG
+        if (sub_idx >= 0) {
+            if (*a != LIST_TAG) raise(CZI_E_MISSING_ROW, "base row %llu column %u is not a list", (unsigned long long)brow, fld);
+            a++;
+            for (int32_t s = 0; s < sub_idx; s++) {
+                if (a >= b || *a == INIT_TAG) raise(CZI_E_MISSING_ROW, "base row %llu column %u has no element %d", (unsigned long long)brow, fld, sub_idx);
+                a = mc_skip(a, b);
+            }
+        }
+        if (a >= b || *a != VEC_TAG) raise(CZI_E_MISSING_ROW, "base row %llu column %u: not a vector", (unsigned long long)brow, fld);
+        if (a[1] != VEC_F32) raise(CZI_E_UNSUPPORTED, "F64 vectors are not supported on the GPU path");
+        if (be64(a + 2) != dim) raise(CZI_E_CORRUPT, "base row %llu: vector of length %llu, index dimension %u", (unsigned long long)brow, (unsigned long long)be64(a + 2), dim);
+        a += 10;
+        for (uint32_t d = 0; d < dim; d++) {
+            const uint32_t u = be32(a + 4 * d);
+            memcpy(dst + d, &u, 4);
+        }
+        return;
+    }
+    Mp &m = cur.m;
+    Variant v = mp_value_head(m);
+    if (sub_idx >= 0) {
+        if (v != V_LIST) raise(CZI_E_MISSING_ROW, "base row %llu column %u is not a list", (unsigned long long)brow, fld);
+        const uint32_t k = m.array();
+        if ((uint32_t)sub_idx >= k) raise(CZI_E_MISSING_ROW, "base row %llu column %u has no element %d", (unsigned long long)brow, fld, sub_idx);
+        for (int32_t s = 0; s < sub_idx; s++) m.skip();
+        v = mp_value_head(m);
+    }
+    if (v != V_VEC) raise(CZI_E_MISSING_ROW, "base row %llu column %u: not a vector", (unsigned long long)brow, fld);
+    int el;
+    const uint8_t *s;
+    uint32_t nb;
+    mp_vec(m, el, s, nb, scratch);
+    if (el != 0) raise(CZI_E_UNSUPPORTED, "F64 vectors are not supported on the GPU path");
+    if (nb != dim * 4) raise(CZI_E_CORRUPT, "base row %llu: vector of length %u, index dimension %u", (unsigned long long)brow, nb / 4, dim);
+    memcpy(dst, s, nb);
+}
+
+void ingest_hnsw(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_fields, uint32_t n_fields, uint32_t dim,
+                 int32_t metric, uint32_t m_max, uint32_t m_max0, czi_hnsw &h) {
+    check_rows(idx, "czi_hnsw_ingest(idx)");
+    check_rows(base, "czi_hnsw_ingest(base)");
+    if (!dim || !m_max || !m_max0) raise(CZI_E_INVALID, "dim, m_max and m_max0 must be > 0");
+    if (n_fields && !vec_fields) raise(CZI_E_INVALID, "null vec_fields");
+    const uint32_t K = base->n_key_cols;
+    if (idx->n_rows && idx->n_key_cols != 2 * K + 5)
+        raise(CZI_E_INVALID, "the index relation of a %u-key base relation has %u key columns, not %u", K, 2 * K + 5, idx->n_key_cols);
+    h.dim = dim;
+    h.metric = metric;
+    h.n_rows = idx->n_rows;
+
+    // pass 1: parse every row once
+    std::vector<IdxRow> rows;
+    rows.reserve(idx->n_rows);
+    int64_t min_layer = 1;
+    for (uint64_t i = 0; i < idx->n_rows; i++) {
+        IdxRow r;
+        if (!parse_idx_row(idx, i, K, r)) continue;
+        if (!rows.empty() && r.layer < rows.back().layer) raise(CZI_E_CORRUPT, "index rows are not in key order (row %llu)", (unsigned long long)i);
+        min_layer = std::min(min_layer, r.layer);
+        rows.push_back(r);
+    }
+    if (rows.empty()) return;  // only the canary, or nothing: an empty index (hnsw.rs:903-909)
+    if (min_layer < -62) raise(CZI_E_CORRUPT, "index has layer %lld", (long long)min_layer);
+    h.n_levels = (int32_t)(-min_layer) + 1;
+
+    // pass 2: node ids = order of the `fr` groups of layer 0 (every node has its self-loop row there, hnsw.rs:630-678)
+    ByteTable nodes;
+    {
+        const uint8_t *prev = nullptr;
+        size_t prev_len = 0;
+        for (const IdxRow &r : rows) {
+            if (r.layer != 0) continue;
+            const size_t len = (size_t)(r.fr_end - r.fr);
+            if (prev && len == prev_len && memcmp(prev, r.fr, len) == 0) continue;
+            const uint32_t before = nodes.size();
+            if (nodes.find_or_insert(r.fr, len) != before) raise(CZI_E_CORRUPT, "index rows are not in key order (layer 0)");
+            prev = r.fr;
+            prev_len = len;
+        }
+    }
+    h.n = nodes.size();
+    if (!h.n) raise(CZI_E_CORRUPT, "the index has upper layers but no layer 0");
+
+    // node -> CompoundKey -> base row -> vector
+    ByteTable base_keys;
+    for (uint64_t i = 0; i < base->n_rows; i++) {
+        const Row r = row_at(base, i);
+        const uint8_t *p = r.k;
+        for (uint32_t c = 0; c < K; c++) p = mc_skip(p, r.kend);
+        if (base_keys.find_or_insert(r.k, (size_t)(p - r.k)) != (uint32_t)i) raise(CZI_E_CORRUPT, "base row %llu repeats a key", (unsigned long long)i);
+    }
+    h.base_row.resize(h.n);
+    h.field.resize(h.n);
+    h.sub.resize(h.n);
+    h.vectors.resize((size_t)h.n * dim);
+    std::vector<uint8_t> scratch;
+    for (uint32_t v = 0; v < h.n; v++) {
+        const uint8_t *a = nodes.bytes.data() + nodes.off[v], *b = nodes.bytes.data() + nodes.off[v + 1];
+        const uint8_t *p = a;
+        for (uint32_t c = 0; c < K; c++) p = mc_skip(p, b);
+        const uint8_t *q = mc_skip(p, b);
+        const int64_t fld = key_int(p, q, "fr__field");
+        const int64_t sb = key_int(q, b, "fr__sub_idx");
+        const uint32_t br = base_keys.find(a, (size_t)(p - a));
+        if (br == CZ_NONE) raise(CZI_E_MISSING_ROW, "node %u of the index has no base row (corrupted index, hnsw.rs:131-140)", v);
+        bool known = n_fields == 0;
+        for (uint32_t f = 0; f < n_fields; f++) known |= vec_fields[f] == (uint32_t)fld;
+        if (fld < 0 || !known) raise(CZI_E_CORRUPT, "node %u: field %lld is not one of the index' vec_fields", v, (long long)fld);
+        h.base_row[v] = br;
+        h.field[v] = (uint32_t)fld;
+        h.sub[v] = (int32_t)sb;
+        copy_vector(base, br, (uint32_t)fld, (int32_t)sb, dim, h.vectors.data() + (size_t)v * dim, scratch);
+    }
+
+    // pass 3: per level, the nodes present (ascending id = key order) and their live rows
+    const int L = h.n_levels;
+    h.level_size.assign(L, 0);
+    h.level_width.assign(L, 0);
+    h.level_nodes.assign(L, {});
+    h.level_nbrs.assign(L, {});
+    std::vector<std::vector<uint32_t>> row_len(L);   // live links per present node
+    std::vector<std::vector<uint32_t>> flat(L);      // concatenated live links per level
+    {
+        size_t i = 0;
+        while (i < rows.size()) {
+            const int lv = (int)(-rows[i].layer);
+            const size_t len = (size_t)(rows[i].fr_end - rows[i].fr);
+            const uint32_t fr = nodes.find(rows[i].fr, len);
+            if (fr == CZ_NONE) raise(CZI_E_CORRUPT, "a layer %lld row starts at a node with no layer-0 row", (long long)rows[i].layer);
+            if (!h.level_nodes[lv].empty() && h.level_nodes[lv].back() >= fr) raise(CZI_E_CORRUPT, "index rows are not in key order");
+            uint32_t live = 0;
+            bool self = false;
+            size_t j = i;
+            for (; j < rows.size() && rows[j].layer == rows[i].layer && (size_t)(rows[j].fr_end - rows[j].fr) == len &&
+                   memcmp(rows[j].fr, rows[i].fr, len) == 0; j++) {
+                const IdxRow &r = rows[j];
+                const size_t klen = (size_t)(r.fr_key_end - r.fr);
+                const bool same_row = (size_t)(r.to_key_end - r.to) == klen && memcmp(r.to, r.fr, klen) == 0;
+                if (same_row) {  // hnsw.rs:609-610: the self-loop row and links between vectors of one base row
+                    if ((size_t)(r.to_end - r.to) == len && memcmp(r.to, r.fr, len) == 0) { self = true; h.n_self++; }
+                    continue;
+                }
+                if (r.ignore) { h.n_ignored++; continue; }  // :616-619
+                const uint32_t to = nodes.find(r.to, (size_t)(r.to_end - r.to));
+                if (to == CZ_NONE) raise(CZI_E_CORRUPT, "a link points at a node with no layer-0 row");
+                flat[lv].push_back(to);
+                live++;
+            }
+            if (!self) raise(CZI_E_CORRUPT, "node %u has rows on layer %lld but no self-loop row there", fr, (long long)rows[i].layer);
+            h.level_nodes[lv].push_back(fr);
+            row_len[lv].push_back(live);
+            h.n_live += live;
+            i = j;
+        }
+    }
+    if (h.level_nodes[0].size() != h.n) raise(CZI_E_CORRUPT, "layer 0 holds %zu of %u nodes", h.level_nodes[0].size(), h.n);
+    for (int lv = 0; lv < L; lv++) {
+        if (h.level_nodes[lv].empty()) raise(CZI_E_CORRUPT, "layer %d is empty", -lv);
+        uint32_t width = lv == 0 ? m_max0 : m_max;
+        for (uint32_t x : row_len[lv]) width = std::max(width, x);
+        const size_t sz = h.level_nodes[lv].size();
+        h.level_size[lv] = (uint32_t)sz;
+        h.level_width[lv] = (int32_t)width;
+        std::vector<uint32_t> &tab = h.level_nbrs[lv];
+        tab.assign(sz * width, CZ_NONE);
+        size_t at = 0;
+        for (size_t r = 0; r < sz; r++) {
+            // the scan yields `to` ends in key order = ascending id already; sort defensively (ids are what the kernels need)
+            std::copy(flat[lv].begin() + at, flat[lv].begin() + at + row_len[lv][r], tab.begin() + r * width);
+            std::sort(tab.begin() + r * width, tab.begin() + r * width + row_len[lv][r]);
+            at += row_len[lv][r];
+        }
+    }
+    h.entry = nodes.find(rows[0].fr, (size_t)(rows[0].fr_end - rows[0].fr));  // hnsw.rs:891-915
+    for (int lv = 0; lv < L; lv++) {
+        h.level_nodes_p.push_back(h.level_nodes[lv].data());
+        h.level_nbrs_p.push_back(h.level_nbrs[lv].data());
+    }
+}
+
+}  // namespace
+
+extern "C" int czi_hnsw_ingest(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_fields, uint32_t n_fields,
+                               uint32_t dim, int32_t metric, uint32_t m_max, uint32_t m_max0, czi_hnsw **out) {
+    if (!out) return fail(CZI_E_INVALID, "null out");
+    *out = nullptr;
+    std::unique_ptr<czi_hnsw> h(new (std::nothrow) czi_hnsw);
+    if (!h) return fail(CZI_E_INVALID, "out of host memory");
+    const int rc = guarded([&] { ingest_hnsw(idx, base, vec_fields, n_fields, dim, metric, m_max, m_max0, *h); });
+    if (rc) return rc;
+    *out = h.release();
+    return CZI_OK;
+}
+
+extern "C" void czi_hnsw_free(czi_hnsw *h) { delete h; }
+
+extern "C" int czi_hnsw_desc(const czi_hnsw *h, cz_hnsw_desc *desc, const float **vectors) {
+    if (!h || !desc || !vectors) return fail(CZI_E_INVALID, "null argument");
+    desc->n = h->n;
+    desc->dim = h->dim;
+    desc->metric = h->metric;
+    desc->n_levels = h->n_levels;
+    desc->entry = h->entry;
+    desc->level_size = h->level_size.data();
+    desc->level_width = h->level_width.data();
+    desc->level_nodes = h->level_nodes_p.data();
+    desc->level_nbrs = h->level_nbrs_p.data();
+    *vectors = h->vectors.data();
+    return CZI_OK;
+}
+
+extern "C" int czi_hnsw_nodes(const czi_hnsw *h, const uint64_t **base_row, const uint32_t **field, const int32_t **sub) {
+    if (!h) return fail(CZI_E_INVALID, "null handle");
+    if (base_row) *base_row = h->base_row.data();
+    if (field) *field = h->field.data();
+    if (sub) *sub = h->sub.data();
+    return CZI_OK;
+}
+
+extern "C" int czi_hnsw_row_counts(const czi_hnsw *h, uint64_t *n_rows, uint64_t *n_self, uint64_t *n_live_links, uint64_t *n_ignored) {
+    if (!h) return fail(CZI_E_INVALID, "null handle");
+    if (n_rows) *n_rows = h->n_rows;
+    if (n_self) *n_self = h->n_self;
+    if (n_live_links) *n_live_links = h->n_live;
+    if (n_ignored) *n_ignored = h->n_ignored;
+    return CZI_OK;
+}

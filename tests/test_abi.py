@@ -26,6 +26,24 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == declared
 
 
+def test_ingest_library_exports_every_declared_symbol():
+    """include/cozo_ingest.h <-> libcozo_ingest.so <-> cozo_amd/ingest.py (host-only library: no HIP needed to load it)"""
+    from cozo_amd import build as B, ingest
+    B.build_ingest()
+    text = open(os.path.join(ROOT, "include", "cozo_ingest.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(czi_[a-z0-9_]+)\s*\(", text)))
+    L = ingest.lib()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/cozo_ingest.h but not exported"
+    assert sorted(ingest.SYMBOLS) == declared
+    assert b"cozo_ingest" in L.czi_version()
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", ingest.SO_PATH], capture_output=True, text=True).stdout
+    assert "amdhip" not in needed and "cozo_gpu" not in needed  # stands alone
+
+
 def test_no_cpu_fallback_without_device():
     import torch
     if torch.cuda.is_available():
@@ -60,3 +78,4 @@ def test_graft_entry_build_is_idempotent():
     ge.build()
     assert os.path.exists(os.path.join(ROOT, "cozo_amd", "lib", "libcozo_gpu.so"))
     assert os.path.exists(os.path.join(ROOT, "oracle", "libcozo_oracle.so"))
+    assert os.path.exists(os.path.join(ROOT, "cozo_amd", "lib", "libcozo_ingest.so"))

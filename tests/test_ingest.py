@@ -1,0 +1,240 @@
+"""libcozo_ingest.so (include/cozo_ingest.h): stored rows -> CSR / flat HNSW arrays, checked against the oracle's
+restatement of as_directed_graph / CsrLayout::Sorted and the oracle-built index, and against the Python host mirror
+(cozo_amd/fixed_rule.py, cozo_amd/codec.py) -- two independent restatements of the same reference formats."""
+import numpy as np
+import pytest
+
+from cozo_amd import codec, ingest
+from cozo_amd.fixed_rule import FixedRuleInputRelation
+from cozo_amd.ingest import CozoIngestError, StoredGraph, StoredHnswIndex, index_relation_tuples
+from tests import util
+
+NONE = 0xFFFFFFFF
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    from cozo_amd import build as B
+    B.build_ingest()
+
+
+@pytest.mark.parametrize("undirected", [False, True])
+@pytest.mark.parametrize("n,e", [(50, 400), (2000, 9000), (3, 2)])
+def test_int_relation_matches_oracle(oracle, n, e, undirected):
+    frm, to = util.random_relation(n, e, n + e, self_loops=True)
+    rows = codec.StoredRows.from_tuples(5, list(zip(frm.tolist(), to.tolist())), 2)
+    g = StoredGraph(rows, undirected=undirected)
+    fi, ti, ind = oracle.assign_ids(frm, to)
+    assert g.n == len(ind) and g.indices() == ind.tolist()
+    for inverse in (False, True):
+        a, b = (ti, fi) if inverse else (fi, ti)
+        want_off, want_tgt = oracle.build_csr(g.n, a, b, undirected=undirected)
+        off, tgt, w = g.csr(inverse)
+        assert w is None and np.array_equal(off, want_off) and np.array_equal(tgt, want_tgt)
+    assert g.e == (2 if undirected else 1) * frm.size
+    assert g.get_node_idx(int(ind[0])) == 0 and g.get_node_idx(float(ind[0])) is None and g.get_node_idx(10 ** 9) is None
+
+
+def _value_rows(seed, n_rows):
+    rng = np.random.default_rng(seed)
+    pool = [None, True, False, 0, 1, 1.0, -3, 2.5, -0.0, 2 ** 60, "a", "b", "node-17", "", b"\x00\x01", b"", [1, "x"], [], [[2]],
+            "a much longer string key than one group", 7, 7.0, float("inf")]
+    rows = []
+    for _ in range(n_rows):
+        a, b = pool[rng.integers(len(pool))], pool[rng.integers(len(pool))]
+        rows.append((a, b, float(rng.integers(0, 50)) / 4 if rng.random() < 0.5 else int(rng.integers(0, 50))))
+    return rows
+
+
+@pytest.mark.parametrize("n_key_cols", [3, 2, 1, 0])
+@pytest.mark.parametrize("undirected", [False, True])
+def test_mixed_values_match_python_host_mirror(n_key_cols, undirected):
+    """endpoints of every DataValue kind, living in the key part or in the msgpack value part of the row: ids, CSR and
+    weights equal those of FixedRuleInputRelation over the decoded tuples"""
+    tuples = _value_rows(3, 300)
+    rows = codec.StoredRows.from_tuples(9, tuples, n_key_cols)
+    decoded = rows.tuples()  # scan order; later puts of a key replaced earlier ones
+    want_g, want_ind, _ = FixedRuleInputRelation(decoded, arity=3).as_directed_weighted_graph(undirected, False)
+    g = StoredGraph(rows, undirected=undirected, weighted=True)
+    got_ind = g.indices()
+    assert len(got_ind) == len(want_ind) == g.n
+    for x, y in zip(got_ind, want_ind):
+        assert type(x) is type(y) and (x == y) and str(x) == str(y)
+    off, tgt, w = g.csr(False)
+    assert np.array_equal(off, want_g.out_offsets) and np.array_equal(tgt, want_g.out_targets)
+    assert np.array_equal(w, want_g.out_weights)
+    off, tgt, _ = g.csr(True)
+    assert np.array_equal(off, want_g.in_offsets) and np.array_equal(tgt, want_g.in_sources)
+    for i, v in enumerate(want_ind):
+        assert g.get_node_idx(v) == i
+
+
+def test_rows_in_the_scan_are_ordered_by_key_bytes_like_the_relation():
+    """FixedRuleInputRelation sorts its rows by DataValue order; a stored relation by key bytes: same scan"""
+    tuples = [(a, b) for a, b, _ in _value_rows(5, 200)]
+    rows = codec.StoredRows.from_tuples(1, tuples, 2)
+    rel = FixedRuleInputRelation(tuples, arity=2)
+    want_g, want_ind, _ = rel.as_directed_graph(False)
+    g = StoredGraph(rows)
+    assert [str(x) for x in g.indices()] == [str(x) for x in want_ind]
+    off, tgt, _ = g.csr(False)
+    assert np.array_equal(off, want_g.out_offsets) and np.array_equal(tgt, want_g.out_targets)
+
+
+def test_graph_errors():
+    with pytest.raises(CozoIngestError) as e:
+        StoredGraph(codec.StoredRows.from_tuples(1, [(1,), (2,)], 1))
+    assert e.value.code == ingest.CZI_E_NOT_AN_EDGE  # NotAnEdgeError
+    for bad in ("heavy", None, float("inf"), float("nan"), -1.0, -1):
+        with pytest.raises(CozoIngestError) as e:
+            StoredGraph(codec.StoredRows.from_tuples(1, [(1, 2, 1.0), (2, 3, bad)], 2), weighted=True)
+        assert e.value.code == ingest.CZI_E_BAD_WEIGHT
+        with pytest.raises(CozoIngestError) as e:
+            StoredGraph(codec.StoredRows.from_tuples(1, [(1, 2, 1.0), (2, 3, bad)], 3), weighted=True)
+        assert e.value.code == ingest.CZI_E_BAD_WEIGHT
+    g = StoredGraph(codec.StoredRows.from_tuples(1, [(1, 2, -1.5)], 2), weighted=True, allow_negative_weights=True)
+    assert g.csr()[2].tolist() == [-1.5]
+    g = StoredGraph(codec.StoredRows.from_tuples(1, [(1, 2), (2, 3)], 2), weighted=True)  # no third column: 1.0
+    assert g.csr()[2].tolist() == [1.0, 1.0]
+    assert StoredGraph(codec.StoredRows.from_tuples(1, [], 2)).n == 0
+    rows = codec.StoredRows.from_tuples(1, [(1, 2)], 2)
+    rows.keys = rows.keys[:-3]
+    rows.key_off = rows.key_off.copy()
+    rows.key_off[-1] -= 3
+    with pytest.raises(CozoIngestError) as e:
+        StoredGraph(rows)
+    assert e.value.code == ingest.CZI_E_CORRUPT
+
+
+def test_variant_index_form_of_values_is_accepted():
+    """a serde encoder that writes variant indices instead of names ({2: {0: 5}}) decodes to the same graph"""
+    import msgpack
+    import struct
+    names = codec.StoredRows.from_tuples(4, [(1, 2, 3.5), (2, "x", 1)], 1)
+    alt_vals = [struct.pack(">Q", 4) + msgpack.packb([{2: {0: 2}}, {2: {1: 3.5}}]),
+                struct.pack(">Q", 4) + msgpack.packb([{3: "x"}, {2: {0: 1}}])]
+    alt = codec.StoredRows(names.keys, names.key_off, b"".join(alt_vals),
+                           np.array([0, len(alt_vals[0]), len(alt_vals[0]) + len(alt_vals[1])], dtype=np.uint64), 1)
+    a, b = StoredGraph(names, weighted=True), StoredGraph(alt, weighted=True)
+    assert a.indices() == b.indices() == [1, 2, "x"]
+    for x, y in zip(a.csr(), b.csr()):
+        assert np.array_equal(x, y)
+
+
+# ---------------------------------------------------------------------------------------------------- HNSW
+def _index_case(oracle, multi):
+    rng = np.random.default_rng(11)
+    dim, n_rows = 8, 260
+    rows = []
+    for i in range(n_rows):
+        v = rng.random(dim, dtype=np.float32)
+        extra = [rng.random(dim, dtype=np.float32) for _ in range(i % 3)] if multi else []
+        rows.append((i * 3 - 100, f"row-{i}", v, extra))  # negative and positive int keys: byte order == numeric order
+    from cozo_amd.hnsw import BaseRelation, index_nodes
+    base = BaseRelation(keys=["k"], non_keys=["name", "v", "vs"], rows=rows)
+    nodes, vecs = index_nodes(base, [2, 3])
+    builder, flat = util.build_index(oracle, vecs, oracle.L2, 6, 30)
+    key_of_node = [(rows[r][0], f, s) for r, f, s in nodes]
+
+    def link_distance(pairs):
+        return oracle.distance_pairs(oracle.L2, vecs, vecs, pairs)
+    tuples = index_relation_tuples(key_of_node, vecs, flat.level_nodes, flat.level_nbrs, flat.entry, link_distance, relation_id=21)
+    return dict(rows=rows, nodes=nodes, vecs=vecs, flat=flat, tuples=tuples, dim=dim,
+                idx=codec.StoredRows.from_tuples(21, tuples, 7), base=codec.StoredRows.from_tuples(20, rows, 1))
+
+
+def test_index_relation_round_trip(oracle):
+    """flat index -> `tbl:idx` tuples -> stored bytes -> flat index: identical tables, entry point and vectors"""
+    c = _index_case(oracle, multi=False)
+    flat = c["flat"]
+    got = StoredHnswIndex(c["idx"], c["base"], [2, 3], c["dim"], oracle.L2, 6)
+    assert (got.n, got.dim, got.n_levels, got.entry) == (flat.n, flat.dim, flat.n_levels, flat.entry)
+    assert np.array_equal(got.vectors, flat.vectors)
+    assert got.nodes == [(r, f, s) for r, f, s in c["nodes"]]
+    for lv in range(flat.n_levels):
+        assert got.level_width[lv] == flat.level_width[lv]
+        assert np.array_equal(got.level_nodes[lv], flat.level_nodes[lv])
+        assert np.array_equal(got.level_nbrs[lv], flat.level_nbrs[lv])
+    # structural counters, as runtime/tests.rs:730,737 count rows of the index relation
+    live = sum(int((t != NONE).sum()) for t in flat.level_nbrs)
+    assert (got.n_self, got.n_live_links, got.n_ignored) == (sum(int(s) for s in flat.level_size), live, 0)
+    assert got.n_rows == got.n_self + live + 1  # + the canary row
+    # the reference's own reading of the tuples: the first row in key order names the entry point on the top layer
+    first = c["idx"].tuples()[0]
+    assert first[0] == -(flat.n_levels - 1) and tuple(first[1:4]) == (c["rows"][c["nodes"][flat.entry][0]][0],) + tuple(c["nodes"][flat.entry][1:])
+
+
+def test_index_rows_dropped_like_hnsw_get_neighbours(oracle):
+    """links between two vectors of one base row and ignore_link rows are not neighbours (hnsw.rs:609-624)"""
+    c = _index_case(oracle, multi=True)
+    flat, nodes = c["flat"], c["nodes"]
+    tuples = [list(t) for t in c["tuples"]]
+    flagged = set()
+    k = 0
+    for t in tuples:  # soft-delete every 7th link row
+        if t[0] <= 0 and tuple(t[1:4]) != tuple(t[4:7]):
+            k += 1
+            if k % 7 == 0:
+                t[9] = True
+                flagged.add((t[0], tuple(t[1:4]), tuple(t[4:7])))
+    idx = codec.StoredRows.from_tuples(21, tuples, 7)
+    got = StoredHnswIndex(idx, c["base"], [2, 3], c["dim"], oracle.L2, 6)
+    key_of = [(c["rows"][r][0], f, s) for r, f, s in nodes]
+    n_same_row = 0
+    for lv in range(flat.n_levels):
+        for r, fr in enumerate(flat.level_nodes[lv]):
+            want = []
+            for t in flat.level_nbrs[lv][r]:
+                if t == NONE:
+                    continue
+                if nodes[t][0] == nodes[fr][0]:
+                    n_same_row += 1
+                    continue
+                if (-lv, key_of[fr], key_of[t]) in flagged:
+                    continue
+                want.append(int(t))
+            row = got.level_nbrs[lv][r]
+            assert row[row != NONE].tolist() == want
+    assert got.n_ignored > 0 and n_same_row > 0  # the case exercises both rules
+    assert np.array_equal(got.vectors, c["vecs"])  # list elements and plain vectors, all from the msgpack value part
+
+
+def test_vectors_in_key_columns_and_empty_index(oracle):
+    rng = np.random.default_rng(2)
+    dim = 4
+    vecs = rng.random((40, dim), dtype=np.float32)
+    rows = [(i, vecs[i]) for i in range(40)]  # both columns are keys: the vector sits in the key (big-endian there)
+    builder, flat = util.build_index(oracle, vecs, oracle.L2, 4, 20)
+    tuples = index_relation_tuples([(i, vecs[i], 1, -1) for i in range(40)], vecs, flat.level_nodes, flat.level_nbrs, flat.entry,
+                                   lambda p: oracle.distance_pairs(oracle.L2, vecs, vecs, p))
+    idx = codec.StoredRows.from_tuples(2, tuples, 2 * 2 + 5)
+    base = codec.StoredRows.from_tuples(1, rows, 2)
+    # ids follow the KEY order of the rows = the order of the ints here
+    got = StoredHnswIndex(idx, base, [1], dim, oracle.L2, 4)
+    assert np.array_equal(got.vectors, vecs) and got.entry == flat.entry
+    for lv in range(flat.n_levels):
+        assert np.array_equal(got.level_nbrs[lv], flat.level_nbrs[lv])
+    # an index holding only the canary row, or nothing at all: empty (hnsw.rs:903-909)
+    canary_only = codec.StoredRows.from_tuples(2, [tuples[-1]], 9)
+    assert tuples[-1][0] == 1
+    for stored in (canary_only, codec.StoredRows.from_tuples(2, [], 9)):
+        e = StoredHnswIndex(stored, base, [1], dim, oracle.L2, 4)
+        assert (e.n, e.n_levels) == (0, 0)
+
+
+def test_hnsw_errors(oracle):
+    c = _index_case(oracle, multi=False)
+    with pytest.raises(CozoIngestError) as e:  # a base row is gone: "corrupted index"
+        StoredHnswIndex(c["idx"], codec.StoredRows.from_tuples(20, c["rows"][1:], 1), [2, 3], c["dim"], oracle.L2, 6)
+    assert e.value.code == ingest.CZI_E_MISSING_ROW
+    with pytest.raises(CozoIngestError) as e:  # wrong dimension
+        StoredHnswIndex(c["idx"], c["base"], [2, 3], c["dim"] + 1, oracle.L2, 6)
+    assert e.value.code == ingest.CZI_E_CORRUPT
+    with pytest.raises(CozoIngestError) as e:  # key column count of the index relation does not fit the base relation
+        StoredHnswIndex(codec.StoredRows(c["idx"].keys, c["idx"].key_off, c["idx"].vals, c["idx"].val_off, 9), c["base"], [2, 3],
+                        c["dim"], oracle.L2, 6)
+    assert e.value.code == ingest.CZI_E_INVALID
+    f64rows = [(r[0], r[1], r[2].astype(np.float64), r[3]) for r in c["rows"]]
+    with pytest.raises(CozoIngestError) as e:
+        StoredHnswIndex(c["idx"], codec.StoredRows.from_tuples(20, f64rows, 1), [2, 3], c["dim"], oracle.L2, 6)
+    assert e.value.code == ingest.CZI_E_UNSUPPORTED
