@@ -19,6 +19,7 @@ SO_PATH = os.environ.get("COZO_INGEST_LIB") or os.path.join(_HERE, "lib", "libco
 
 CZI_OK, CZI_E_INVALID, CZI_E_CORRUPT, CZI_E_NOT_AN_EDGE, CZI_E_BAD_WEIGHT = 0, -1, -2, -3, -4
 CZI_E_UNSUPPORTED, CZI_E_TOO_LARGE, CZI_E_MISSING_ROW = -5, -6, -7
+CZI_UNDIRECTED, CZI_WEIGHTED, CZI_ALLOW_NEGATIVE_WEIGHTS, CZI_ORDERED_IDS = 1, 2, 4, 8
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
@@ -42,7 +43,7 @@ class CozoIngestError(RuntimeError):
 SYMBOLS = {
     "czi_last_error": (C.c_char_p, []),
     "czi_version": (C.c_char_p, []),
-    "czi_graph_ingest": (C.c_int, [C.POINTER(Rows), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "czi_graph_ingest": (C.c_int, [C.POINTER(Rows), C.c_uint32, C.POINTER(C.c_void_p)]),
     "czi_graph_free": (None, [C.c_void_p]),
     "czi_graph_node_count": (C.c_uint32, [C.c_void_p]),
     "czi_graph_edge_count": (C.c_uint64, [C.c_void_p]),
@@ -95,10 +96,14 @@ class StoredGraph:
     stored bytes of a relation."""
 
     def __init__(self, rows: codec.StoredRows, undirected: bool = False, weighted: bool = False,
-                 allow_negative_weights: bool = False):
+                 allow_negative_weights: bool = False, ordered_ids: bool = False):
+        """ordered_ids: ids = rank of the node value (what ShortestPathBFS / Bfs need, as_ordered_graph in
+        cozo_amd/fixed_rule.py) instead of first appearance"""
         arg = _RowsArg(rows)
         h = C.c_void_p()
-        check(lib().czi_graph_ingest(C.byref(arg.c), int(undirected), int(weighted), int(allow_negative_weights), C.byref(h)))
+        flags = (CZI_UNDIRECTED if undirected else 0) | (CZI_WEIGHTED if weighted else 0) | \
+            (CZI_ALLOW_NEGATIVE_WEIGHTS if allow_negative_weights else 0) | (CZI_ORDERED_IDS if ordered_ids else 0)
+        check(lib().czi_graph_ingest(C.byref(arg.c), flags, C.byref(h)))
         self._h = h
         self.weighted = weighted
         self.n = int(lib().czi_graph_node_count(h))

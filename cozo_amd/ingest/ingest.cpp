@@ -544,6 +544,33 @@ struct ByteTable {
         return id;
     }
     uint32_t find_or_insert(const uint8_t *k, size_t len) { return find_or_insert_h(k, len, hash_bytes(k, len)); }
+
+    // renumber: id = rank of the string in byte order (memcmp keys: the DataValue order); a, b are relabelled with it
+    void relabel_by_rank(std::vector<uint32_t> &a, std::vector<uint32_t> &b) {
+        const uint32_t n = size();
+        std::vector<uint32_t> order(n), rank(n);
+        for (uint32_t i = 0; i < n; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            const size_t lx = off[x + 1] - off[x], ly = off[y + 1] - off[y];
+            const int c = memcmp(bytes.data() + off[x], bytes.data() + off[y], std::min(lx, ly));
+            return c ? c < 0 : lx < ly;
+        });
+        for (uint32_t r = 0; r < n; r++) rank[order[r]] = r;
+        std::vector<uint8_t> nb;
+        nb.reserve(bytes.size());
+        std::vector<uint64_t> noff{0};
+        noff.reserve(n + 1);
+        for (uint32_t r = 0; r < n; r++) {
+            nb.insert(nb.end(), bytes.begin() + off[order[r]], bytes.begin() + off[order[r] + 1]);
+            noff.push_back(nb.size());
+        }
+        bytes.swap(nb);
+        off.swap(noff);
+        for (Slot &s : slots)
+            if (s.id != CZ_NONE) s.id = rank[s.id];
+        for (uint32_t &x : a) x = rank[x];
+        for (uint32_t &x : b) x = rank[x];
+    }
 };
 
 // ------------------------------------------------------------------------------------------------ rows
@@ -699,15 +726,16 @@ void build_csr(const czi_graph &g, bool inverse, uint32_t *offsets, uint32_t *ta
 extern "C" const char *czi_last_error(void) { return g_err.c_str(); }
 extern "C" const char *czi_version(void) { return "cozo_ingest 0.1 (memcmp keys + rmp-serde 1.2 values of cozo 0.7.6)"; }
 
-extern "C" int czi_graph_ingest(const czi_rows *rel, int undirected, int weighted, int allow_negative_weights, czi_graph **out) {
+extern "C" int czi_graph_ingest(const czi_rows *rel, uint32_t flags, czi_graph **out) {
     if (!out) return fail(CZI_E_INVALID, "null out");
     *out = nullptr;
     std::unique_ptr<czi_graph> g(new (std::nothrow) czi_graph);
     if (!g) return fail(CZI_E_INVALID, "out of host memory");
     const int rc = guarded([&] {
         check_rows(rel, "czi_graph_ingest");
-        g->weighted = weighted != 0;
-        g->undirected = undirected != 0;
+        g->weighted = (flags & CZI_WEIGHTED) != 0;
+        g->undirected = (flags & CZI_UNDIRECTED) != 0;
+        const bool allow_negative_weights = (flags & CZI_ALLOW_NEGATIVE_WEIGHTS) != 0;
         const uint64_t E = rel->n_rows;
         if ((g->undirected ? E * 2 : E) >= 0xFFFFFFFFull) raise(CZI_E_TOO_LARGE, "%llu rows do not fit u32 CSR offsets", (unsigned long long)E);
         g->src.resize(E);
@@ -768,6 +796,7 @@ extern "C" int czi_graph_ingest(const czi_rows *rel, int undirected, int weighte
                 g->dst[i0 + r] = g->nodes.find_or_insert_h(ends[2 * r + 1].a, ends[2 * r + 1].len, ends[2 * r + 1].h);
             }
         }
+        if (flags & CZI_ORDERED_IDS) g->nodes.relabel_by_rank(g->src, g->dst);
     });
     if (rc) return rc;
     *out = g.release();
@@ -817,6 +846,7 @@ struct IdxRow {
     int64_t layer;
     const uint8_t *fr, *fr_end, *to, *to_end;  // [key x K, field, sub] of either end, as raw key bytes
     const uint8_t *fr_key_end, *to_key_end;    // end of the K row-key columns inside each
+    uint64_t to_hash;
     bool ignore;
 };
 
@@ -930,6 +960,7 @@ void ingest_hnsw(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_
         if (!parse_idx_row(idx, i, K, r)) continue;
         if (!rows.empty() && r.layer < rows.back().layer) raise(CZI_E_CORRUPT, "index rows are not in key order (row %llu)", (unsigned long long)i);
         min_layer = std::min(min_layer, r.layer);
+        r.to_hash = hash_bytes(r.to, (size_t)(r.to_end - r.to));
         rows.push_back(r);
     }
     if (rows.empty()) return;  // only the canary, or nothing: an empty index (hnsw.rs:903-909)
@@ -1007,6 +1038,9 @@ void ingest_hnsw(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_
             for (; j < rows.size() && rows[j].layer == rows[i].layer && (size_t)(rows[j].fr_end - rows[j].fr) == len &&
                    memcmp(rows[j].fr, rows[i].fr, len) == 0; j++) {
                 const IdxRow &r = rows[j];
+                // the `to` lookups are random probes of the node table: keep two stages of them in flight
+                if (j + 32 < rows.size()) nodes.hint_slot(rows[j + 32].to_hash);
+                if (j + 16 < rows.size()) nodes.hint_bytes(rows[j + 16].to_hash);
                 const size_t klen = (size_t)(r.fr_key_end - r.fr);
                 const bool same_row = (size_t)(r.to_key_end - r.to) == klen && memcmp(r.to, r.fr, klen) == 0;
                 if (same_row) {  // hnsw.rs:609-610: the self-loop row and links between vectors of one base row
@@ -1014,7 +1048,7 @@ void ingest_hnsw(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_
                     continue;
                 }
                 if (r.ignore) { h.n_ignored++; continue; }  // :616-619
-                const uint32_t to = nodes.find(r.to, (size_t)(r.to_end - r.to));
+                const uint32_t to = nodes.find_h(r.to, (size_t)(r.to_end - r.to), r.to_hash);
                 if (to == CZ_NONE) raise(CZI_E_CORRUPT, "a link points at a node with no layer-0 row");
                 flat[lv].push_back(to);
                 live++;

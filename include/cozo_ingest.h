@@ -61,11 +61,19 @@ typedef struct {
  *                                         (fixed_rule/mod.rs:136-328)
  * =====================================================================================
  * Columns 0 and 1 of every row are the endpoints; dense ids in FIRST-APPEARANCE order over the scan, `from` before `to`
- * within a row (:164-179); undirected: every row is mirrored after id assignment (:187-191); adjacency lists ascending
- * by id, parallel edges kept, ties in scan order (CsrLayout::Sorted).  weighted: column 2 is the weight (absent => 1.0;
- * not a number / not finite / negative without allow_negative_weights => CZI_E_BAD_WEIGHT, :226-262), stored as f32. */
+ * within a row (:164-179); CZI_UNDIRECTED: every row is mirrored after id assignment (:187-191); adjacency lists
+ * ascending by id, parallel edges kept, ties in scan order (CsrLayout::Sorted).  CZI_WEIGHTED: column 2 is the weight
+ * (absent => 1.0; not a number / not finite / negative without CZI_ALLOW_NEGATIVE_WEIGHTS => CZI_E_BAD_WEIGHT,
+ * :226-262), stored as f32.
+ * CZI_ORDERED_IDS: ids are instead the RANK of the node value in DataValue order (= the order of the memcmp bytes).
+ * ShortestPathBFS / Bfs walk `prefix_iter(node)` (algos/shortest_path_bfs.rs:64-72, algos/bfs.rs:58-66), i.e. they meet
+ * neighbours in key order of the `to` value; with rank ids "ascending id" in the CSR is that order. */
+#define CZI_UNDIRECTED 1u
+#define CZI_WEIGHTED 2u
+#define CZI_ALLOW_NEGATIVE_WEIGHTS 4u
+#define CZI_ORDERED_IDS 8u
 typedef struct czi_graph czi_graph;
-int czi_graph_ingest(const czi_rows *rel, int undirected, int weighted, int allow_negative_weights, czi_graph **out);
+int czi_graph_ingest(const czi_rows *rel, uint32_t flags, czi_graph **out);
 void czi_graph_free(czi_graph *g);
 uint32_t czi_graph_node_count(const czi_graph *g);
 uint64_t czi_graph_edge_count(const czi_graph *g); /* CSR entries per direction (2x the rows when undirected) */
@@ -75,7 +83,8 @@ int czi_graph_csr(const czi_graph *g, int inverse, uint32_t *offsets, uint32_t *
 /* `indices` of the reference (id -> node value), as the memcmp bytes of each value, concatenated:
  * value of id i = bytes[off[i] .. off[i+1]) -- DataValue::decode_from_key reads it back (N decodes instead of 2E). */
 int czi_graph_node_keys(const czi_graph *g, const uint8_t **bytes, const uint64_t **off);
-/* get_node_idx (fixed_rule/mod.rs:78-97 callers): id of the node whose memcmp bytes are `key`, CZ_NONE if absent */
+/* `inv_indices.get(node)` (the BTreeMap<DataValue, u32> as_directed_graph returns, fixed_rule/mod.rs:143-145; used e.g. by
+ * algos/shortest_path_dijkstra.rs:47-66 to map start / goal nodes): id of the node whose memcmp bytes are `key`, CZ_NONE if absent */
 uint32_t czi_graph_lookup(const czi_graph *g, const uint8_t *key, uint64_t len);
 
 /* =====================================================================================

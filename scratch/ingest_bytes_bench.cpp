@@ -73,7 +73,7 @@ int main(int argc, char **argv) {
         czi_rows rel{bytes.data(), off.data(), nullptr, nullptr, keys.size(), 2};
         auto t0 = clk::now();
         czi_graph *g = nullptr;
-        if (czi_graph_ingest(&rel, 0, 0, 0, &g)) {
+        if (czi_graph_ingest(&rel, 0, &g)) {
             fprintf(stderr, "%s\n", czi_last_error());
             return 1;
         }

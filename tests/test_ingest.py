@@ -238,3 +238,20 @@ def test_hnsw_errors(oracle):
     with pytest.raises(CozoIngestError) as e:
         StoredHnswIndex(c["idx"], codec.StoredRows.from_tuples(20, f64rows, 1), [2, 3], c["dim"], oracle.L2, 6)
     assert e.value.code == ingest.CZI_E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("n_key_cols", [2, 1])
+def test_ordered_ids_are_value_ranks(n_key_cols):
+    """CZI_ORDERED_IDS == FixedRuleInputRelation.as_ordered_graph: ids by DataValue order, so that ascending id in a CSR
+    row is the key order ShortestPathBFS / Bfs meet neighbours in"""
+    tuples = [(a, b) for a, b, _ in _value_rows(8, 250)]
+    rows = codec.StoredRows.from_tuples(1, tuples, n_key_cols)
+    want_g, want_ind, _ = FixedRuleInputRelation(rows.tuples(), arity=2).as_ordered_graph()
+    g = StoredGraph(rows, ordered_ids=True)
+    assert [str(x) for x in g.indices()] == [str(x) for x in want_ind]
+    off, tgt, _ = g.csr(False)
+    assert np.array_equal(off, want_g.out_offsets) and np.array_equal(tgt, want_g.out_targets)
+    off, tgt, _ = g.csr(True)
+    assert np.array_equal(off, want_g.in_offsets) and np.array_equal(tgt, want_g.in_sources)
+    for i, v in enumerate(want_ind):
+        assert g.get_node_idx(v) == i
