@@ -117,3 +117,25 @@ class StoredInputRelation(FixedRuleInputRelation):
         if any(_canon(v) not in inv for v in extra):  # a start / goal with no edge gets an id of its own: the generic path
             return super().as_ordered_graph(extra)
         return _graph_of(g), indices, inv
+
+
+class _LazyRows:
+    """rows[i] of a stored relation, decoded when asked for (a k-NN query touches k rows per parent tuple, not N)"""
+
+    def __init__(self, rows: codec.StoredRows):
+        self._rows = rows
+
+    def __len__(self):
+        return len(self._rows)
+
+    def __getitem__(self, i: int) -> tuple:
+        return tuple(codec.decode_tuple_from_kv(*self._rows.row(int(i))))
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+def stored_base_relation(rows: codec.StoredRows, keys: Sequence[str], non_keys: Sequence[str]):
+    """the base relation of an index for HnswSearchRA (cozo_amd/hnsw.py), rows decoded on demand"""
+    from .hnsw import BaseRelation
+    return BaseRelation(keys=list(keys), non_keys=list(non_keys), rows=_LazyRows(rows))

@@ -92,3 +92,50 @@ def test_errors_and_fallbacks_match(registry):
     b = registry.run("ShortestPathBFSGpu", [stored, rel([[10 ** 6], [tuples[0][0]]]), rel([[tuples[5][1]]])], {})
     assert a == b and len(a) == 2
     assert stored.arity() == 2 and list(stored.iter()) == list(plain.iter())
+
+
+# ---- HnswSearchRA over an index and a base relation that are read off their stored bytes -------------------------
+class _OracleIndex:
+    def __init__(self, O, flat):
+        self.O, self.flat = O, flat
+
+    def hnsw_knn_batch(self, queries, cfg):
+        kk = cfg.ef if cfg.has_filter else cfg.k
+        ids, dist, cnt, _ = self.flat.knn_batch(queries, kk, cfg.ef, radius=cfg.radius, dot_mode=self.O.DOT_GPU)
+        return ids, dist, cnt
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_hnsw_search_ra_over_stored_bytes(request, oracle, backend):
+    from cozo_amd import build as B
+    from cozo_amd.hnsw import BaseRelation, HnswIndexManifest, HnswSearchBinding, HnswSearchRA, index_nodes
+    from cozo_amd.ingest import StoredHnswIndex, index_relation_tuples
+    from cozo_amd.stored_relation import stored_base_relation
+    B.build_ingest()
+    rng = np.random.default_rng(3)
+    dim = 16
+    rows = [(f"doc-{i:04d}", i % 5, rng.random(dim, dtype=np.float32)) for i in range(300)]
+    base = BaseRelation(keys=["id"], non_keys=["tag", "v"], rows=rows)
+    nodes, vecs = index_nodes(base, [2])
+    builder, flat = util.build_index(oracle, vecs, oracle.L2, 8, 40)
+    tuples = index_relation_tuples([(rows[r][0], f, s) for r, f, s in nodes], vecs, flat.level_nodes, flat.level_nbrs, flat.entry,
+                                   lambda p: oracle.distance_pairs(oracle.L2, vecs, vecs, p))
+    s_idx, s_base = codec.StoredRows.from_tuples(8, tuples, 7), codec.StoredRows.from_tuples(7, rows, 1)
+    got = StoredHnswIndex(s_idx, s_base, [2], dim, oracle.L2, 8)
+    if backend == "oracle":
+        ix_mem = _OracleIndex(oracle, flat)
+        ix_sto = _OracleIndex(oracle, oracle.FlatIndex(got.vectors, oracle.L2, got.level_nodes, got.level_nbrs, got.entry))
+    else:
+        request.getfixturevalue("gpu_lib")
+        ix_mem = util.gpu_index(flat, "L2", 8)
+        ix_sto = got.to_gpu(HnswIndexManifest(vec_dim=dim, distance="L2", m_neighbours=8))
+    sb = HnswSearchBinding(k=4, ef=24, bind_field=True, bind_field_idx=True, bind_distance=True, bind_vector=True,
+                           filter=lambda t: t[1] != 3)
+    parent = [(i, rng.random(dim, dtype=np.float32)) for i in range(9)]
+    a = HnswSearchRA(ix_mem, base, nodes, sb, bind_idx=1).iter(parent)
+    b = HnswSearchRA(ix_sto, stored_base_relation(s_base, ["id"], ["tag", "v"]), got.nodes, sb, bind_idx=1).iter(parent)
+    assert len(a) == len(b) > 0
+    for x, y in zip(a, b):
+        assert len(x) == len(y)
+        for u, v in zip(x, y):
+            assert np.array_equal(u, v) if isinstance(u, np.ndarray) else u == v
