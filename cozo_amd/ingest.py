@@ -56,6 +56,10 @@ SYMBOLS = {
     "czi_hnsw_desc": (C.c_int, [C.c_void_p, C.POINTER(HnswDesc), C.POINTER(f32p)]),
     "czi_hnsw_nodes": (C.c_int, [C.c_void_p, C.POINTER(u64p), C.POINTER(u32p), C.POINTER(i32p)]),
     "czi_hnsw_row_counts": (C.c_int, [C.c_void_p, u64p, u64p, u64p, u64p]),
+    "czi_hnsw_encode_rows": (C.c_int, [C.POINTER(HnswDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                       C.POINTER(C.c_void_p)]),
+    "czi_row_buf_rows": (C.c_int, [C.c_void_p, C.POINTER(Rows)]),
+    "czi_row_buf_free": (None, [C.c_void_p]),
 }
 
 _L = None
@@ -223,3 +227,39 @@ def index_relation_tuples(key_of_node: Sequence[Sequence[Any]], vectors: np.ndar
     target_key = codec.encode_key_for_store(relation_id, (None, *key_of_node[entry], *key_of_node[entry]))
     rows.append((1, *([None] * (2 * width)), -(n_levels - 1), target_key, False))
     return rows
+
+
+def encode_index_rows(key_of_node: Sequence[Sequence[Any]], vectors: np.ndarray, level_nodes: Sequence, level_nbrs: Sequence,
+                      entry: int, metric: int, level_dist: Sequence[np.ndarray], relation_id: int) -> codec.StoredRows:
+    """index_relation_tuples + the store's encoding in one native pass (czi_hnsw_encode_rows): the key / value bytes of
+    every `tbl:idx` row of a flat index, in key order.  level_dist[l] [size][width] f64 = the distance of every link slot."""
+    from ._lib import i32p as _i32p, u32p as _u32p
+    vectors = np.ascontiguousarray(vectors, dtype=np.float32)
+    n, dim = vectors.shape
+    L = len(level_nbrs)
+    sizes = np.array([len(t) for t in level_nbrs], dtype=np.uint32)
+    widths = np.array([np.asarray(t).shape[1] for t in level_nbrs], dtype=np.int32)
+    nodes = [None if level_nodes[l] is None else np.ascontiguousarray(level_nodes[l], dtype=np.uint32) for l in range(L)]
+    nbrs = [np.ascontiguousarray(level_nbrs[l], dtype=np.uint32) for l in range(L)]
+    dists = [np.ascontiguousarray(level_dist[l], dtype=np.float64) for l in range(L)]
+    nodes_p = (_u32p * max(L, 1))(*[C.cast(None if a is None else a.ctypes.data, _u32p) for a in nodes])
+    nbrs_p = (_u32p * max(L, 1))(*[C.cast(a.ctypes.data, _u32p) for a in nbrs])
+    dist_p = (C.c_void_p * max(L, 1))(*[a.ctypes.data for a in dists])
+    d = HnswDesc(n, dim, metric, L, entry, C.cast(sizes.ctypes.data, _u32p), C.cast(widths.ctypes.data, _i32p), nodes_p, nbrs_p)
+    keys = [b"".join(codec.memcmp_bytes(v) for v in k) for k in key_of_node]
+    off = np.zeros(len(keys) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(k) for k in keys], dtype=np.uint64) if keys else []
+    blob = np.frombuffer(b"".join(keys) or b"\0", dtype=np.uint8)
+    h = C.c_void_p()
+    check(lib().czi_hnsw_encode_rows(C.byref(d), vectors.ctypes.data, blob.ctypes.data, off.ctypes.data, dist_p, relation_id,
+                                     C.byref(h)))
+    r = Rows()
+    check(lib().czi_row_buf_rows(h, C.byref(r)))
+    nr = int(r.n_rows)
+    key_off = np.ctypeslib.as_array(C.cast(r.key_off, u64p), shape=(nr + 1,)).copy()
+    val_off = np.ctypeslib.as_array(C.cast(r.val_off, u64p), shape=(nr + 1,)).copy()
+    kb = C.string_at(r.keys, int(key_off[-1])) if nr else b""
+    vb = C.string_at(r.vals, int(val_off[-1])) if nr else b""
+    lib().czi_row_buf_free(h)
+    width = len(key_of_node[0]) if len(key_of_node) else 0
+    return codec.StoredRows(kb, key_off, vb, val_off, 2 * width + 1)

@@ -111,6 +111,30 @@ int czi_hnsw_nodes(const czi_hnsw *h, const uint64_t **base_row, const uint32_t 
 /* rows of the index relation seen / kept as live links (structural counters, runtime/tests.rs:730,737) */
 int czi_hnsw_row_counts(const czi_hnsw *h, uint64_t *n_rows, uint64_t *n_self, uint64_t *n_live_links, uint64_t *n_ignored);
 
+/* =====================================================================================
+ * flat index -> the stored rows of its `tbl:idx` relation        replaces: the puts of hnsw_put_vector /
+ *                                                                hnsw_put_fresh_at_levels (runtime/hnsw.rs:270-330, 630-678)
+ * =====================================================================================
+ * The way back: what `::hnsw create` leaves in the store for an index built by cz_hnsw_build, as
+ * key / value bytes ready for `store_tx.put`, in key order:
+ *   per level l (layer -l) and node present there
+ *     the self-loop row  [layer, fr.., fr..]  ->  [degree as f64, Bytes(SHA-256 of the vector's little-endian bytes,
+ *                                                  data/value.rs:333-348), false]
+ *     per live link      [layer, fr.., to..]  ->  [distance f64, Null, false]
+ *   the canary row       [1, Null x (2K+4)]    ->  [bottom layer as an Int, Bytes(key of the entry's self row with a Null
+ *                                                  layer), false]                                        (:641-669)
+ * node_keys: per node the memcmp bytes of its CompoundKey columns [row key x K, field, sub index], concatenated
+ * (node i = node_keys[node_key_off[i] .. node_key_off[i+1])); level_dist[l] = [size][width] f64, the distance of every
+ * link slot of desc->level_nbrs[l] (cz_distance_batch over the (node, neighbour) pairs; slots holding CZ_NONE are not
+ * read).  relation_id = the index relation's id (the 8-byte prefix of every key and value). */
+typedef struct czi_row_buf czi_row_buf;
+int czi_hnsw_encode_rows(const cz_hnsw_desc *desc, const float *vectors, const uint8_t *node_keys,
+                         const uint64_t *node_key_off, const double *const *level_dist, uint64_t relation_id,
+                         czi_row_buf **out);
+/* the rows (pointers into the buffer; n_key_cols is left 0 -- the caller knows K) */
+int czi_row_buf_rows(const czi_row_buf *b, czi_rows *rows);
+void czi_row_buf_free(czi_row_buf *b);
+
 #ifdef __cplusplus
 }
 #endif

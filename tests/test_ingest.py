@@ -255,3 +255,45 @@ def test_ordered_ids_are_value_ranks(n_key_cols):
     assert np.array_equal(off, want_g.in_offsets) and np.array_equal(tgt, want_g.in_sources)
     for i, v in enumerate(want_ind):
         assert g.get_node_idx(v) == i
+
+
+@pytest.mark.parametrize("multi", [False, True])
+def test_native_row_encoder_equals_python_codec(oracle, multi):
+    """czi_hnsw_encode_rows (hand-written msgpack / memcmp / SHA-256) == index_relation_tuples + cozo_amd/codec.py
+    (the msgpack package, hashlib), byte for byte, keys and values, in key order"""
+    from cozo_amd.ingest import encode_index_rows
+    c = _index_case(oracle, multi)
+    flat, vecs, nodes = c["flat"], c["vecs"], c["nodes"]
+    key_of_node = [(c["rows"][r][0], f, s) for r, f, s in nodes]
+    level_dist = []
+    for lv in range(flat.n_levels):
+        tab = flat.level_nbrs[lv]
+        ids = flat.level_nodes[lv]
+        dist = np.zeros(tab.shape, dtype=np.float64)
+        for r in range(tab.shape[0]):
+            live = np.nonzero(tab[r] != NONE)[0]
+            pairs = np.stack([np.full(live.size, ids[r], dtype=np.uint32), tab[r][live]], 1)
+            dist[r, live] = oracle.distance_pairs(oracle.L2, vecs, vecs, pairs)
+        level_dist.append(dist)
+    got = encode_index_rows(key_of_node, vecs, flat.level_nodes, flat.level_nbrs, flat.entry, oracle.L2, level_dist, 21)
+    want = c["idx"]
+    assert len(got) == len(want) and got.n_key_cols == want.n_key_cols == 7
+    assert np.array_equal(got.key_off, want.key_off) and got.keys == want.keys
+    assert np.array_equal(got.val_off, want.val_off) and got.vals == want.vals
+    # and it reads back as the index it came from
+    back = StoredHnswIndex(got, c["base"], [2, 3], c["dim"], oracle.L2, 6)
+    assert back.entry == flat.entry and back.n == flat.n
+
+
+def test_sha256_of_the_row_encoder_known_answers():
+    """FIPS 180-4 vectors through the self-loop row's hash column: a vector whose little-endian bytes are the message"""
+    import hashlib
+    from cozo_amd.ingest import encode_index_rows
+    for dim in (1, 13, 14, 16, 31, 200):  # 4*dim bytes: below / at / above the 55-byte and 64-byte padding boundaries
+        vecs = np.arange(2 * dim, dtype=np.float32).reshape(2, dim) / 7
+        nb = [np.array([[1, NONE], [0, NONE]], dtype=np.uint32)]
+        rows = encode_index_rows([(0, 1, -1), (1, 1, -1)], vecs, [None], nb, 0, 0, [np.zeros((2, 2))], 5)
+        tup = rows.tuples()
+        selfs = [t for t in tup if t[0] == 0 and t[1:4] == t[4:7]]
+        assert [t[8] for t in selfs] == [hashlib.sha256(vecs[i].tobytes()).digest() for i in range(2)]
+        assert [t[7] for t in selfs] == [1.0, 1.0]
