@@ -73,7 +73,8 @@ HOST_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-par
 
 
 def _host_mtime():
-    m = os.path.getmtime(os.path.join(HERE, "..", "include", "cozo_gpu.h"))
+    m = max(os.path.getmtime(os.path.join(HERE, "..", "include", "cozo_gpu.h")),
+            os.path.getmtime(os.path.join(HERE, "..", "include", "cozo_ingest.h")))
     for root, _, files in os.walk(HOST):
         for f in files:
             m = max(m, os.path.getmtime(os.path.join(root, f)))
@@ -84,10 +85,12 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     """g++ only (no device code).  Links against libcozo_gpu.so ($ORIGIN rpath); the HIP runtime is left to the
     final executable / the process, exactly like libcozo_gpu.so itself."""
     so = build(force=False)
-    if not force and os.path.exists(HOST_SO) and os.path.getmtime(HOST_SO) >= max(_host_mtime(), os.path.getmtime(so)):
+    ingest_so = build_ingest(force=False)
+    if not force and os.path.exists(HOST_SO) and os.path.getmtime(HOST_SO) >= max(_host_mtime(), os.path.getmtime(so),
+                                                                                os.path.getmtime(ingest_so)):
         return HOST_SO
     srcs = sorted(os.path.join(HOST, "src", f) for f in os.listdir(os.path.join(HOST, "src")) if f.endswith(".cpp"))
-    subprocess.check_call([CXX, *HOST_FLAGS, "-shared", *srcs, "-o", HOST_SO, "-L" + LIBDIR, "-lcozo_gpu",
+    subprocess.check_call([CXX, *HOST_FLAGS, "-shared", *srcs, "-o", HOST_SO, "-L" + LIBDIR, "-lcozo_gpu", "-lcozo_ingest",
                            "-Wl,-rpath,$ORIGIN", "-Wl,--allow-shlib-undefined"])
     if verbose:
         print("built", HOST_SO)

@@ -25,6 +25,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "codec.hpp"
 #include "value.hpp"
 
 namespace cozo {
@@ -131,13 +132,21 @@ struct GraphWithIndices {
 // ---- FixedRuleInputRelation -----------------------------------------------------------------------------------
 // A stored or in-memory relation is a set of tuples scanned in key order; this mirror materialises it sorted.
 class FixedRuleInputRelation {
-    std::shared_ptr<const std::vector<Tuple>> rows_;  // sorted, de-duplicated
+    mutable std::shared_ptr<const std::vector<Tuple>> rows_;  // sorted, de-duplicated (decoded on demand when stored_)
+    std::shared_ptr<const StoredRows> stored_;                // from_stored: the graph conversions read the bytes
     std::vector<std::string> bindings_;
     size_t arity_ = 0;
+    void ensure_rows() const;
 
 public:
     FixedRuleInputRelation() : rows_(std::make_shared<std::vector<Tuple>>()) {}
     FixedRuleInputRelation(std::vector<Tuple> rows, std::vector<std::string> bindings = {}, std::optional<size_t> arity = {});
+    // A relation that lives in the store (MagicFixedRuleRuleArg::Stored, fixed_rule/mod.rs:94-101): the key / value bytes
+    // of its scan.  as_directed_graph / as_directed_weighted_graph / as_ordered_graph hand them to libcozo_ingest
+    // (include/cozo_ingest.h) -- same ids, same CSR, no tuple per row; iter() / prefix_iter() decode on first use.
+    static FixedRuleInputRelation from_stored(StoredRows rows, std::vector<std::string> bindings = {},
+                                              std::optional<size_t> arity = {});
+    bool is_stored() const { return stored_ != nullptr; }
 
     size_t arity() const { return arity_; }
     const FixedRuleInputRelation &ensure_min_len(size_t len) const {
@@ -149,7 +158,10 @@ public:
         for (size_t i = 0; i < bindings_.size(); i++) m[bindings_[i]] = i + offset;
         return m;
     }
-    const std::vector<Tuple> &iter() const { return *rows_; }
+    const std::vector<Tuple> &iter() const {
+        ensure_rows();
+        return *rows_;
+    }
     // all tuples whose first column equals `prefix`, in key order
     std::pair<std::vector<Tuple>::const_iterator, std::vector<Tuple>::const_iterator> prefix_iter(const DataValue &prefix) const;
 

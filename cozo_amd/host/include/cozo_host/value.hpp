@@ -163,13 +163,20 @@ struct DataValue {
                 return x.size() < y.size() ? -1 : (x.size() > y.size() ? 1 : 0);
             }
             default: {
+                // impl Ord for Vector (data/value.rs:389-404): length first, then elements as OrderedFloat (numeric
+                // order, -0.0 == 0.0, NaN greatest and equal to itself)
                 const auto &x = std::get<F32Vec>(a.r).v, &y = std::get<F32Vec>(b.r).v;
-                const size_t n = std::min(x.size(), y.size());
-                for (size_t i = 0; i < n; i++) {
-                    const int c = total_cmp((double)x[i], (double)y[i]);
-                    if (c) return c;
+                if (x.size() != y.size()) return x.size() < y.size() ? -1 : 1;
+                for (size_t i = 0; i < x.size(); i++) {
+                    const bool nx = std::isnan(x[i]), ny = std::isnan(y[i]);
+                    if (nx || ny) {
+                        if (nx != ny) return nx ? 1 : -1;
+                        continue;
+                    }
+                    if (x[i] < y[i]) return -1;
+                    if (x[i] > y[i]) return 1;
                 }
-                return x.size() < y.size() ? -1 : (x.size() > y.size() ? 1 : 0);
+                return 0;
             }
         }
     }

@@ -66,8 +66,64 @@ FixedRuleInputRelation::FixedRuleInputRelation(std::vector<Tuple> rows, std::vec
     rows_ = std::make_shared<const std::vector<Tuple>>(std::move(rows));
 }
 
+FixedRuleInputRelation FixedRuleInputRelation::from_stored(StoredRows rows, std::vector<std::string> bindings,
+                                                           std::optional<size_t> arity) {
+    FixedRuleInputRelation r;
+    r.rows_.reset();
+    r.bindings_ = std::move(bindings);
+    r.arity_ = arity ? *arity : (rows.size() ? rows.tuple(0).size() : r.bindings_.size());
+    r.stored_ = std::make_shared<const StoredRows>(std::move(rows));
+    return r;
+}
+
+void FixedRuleInputRelation::ensure_rows() const {
+    if (rows_) return;
+    std::vector<Tuple> rows;
+    rows.reserve(stored_->size());
+    for (size_t i = 0; i < stored_->size(); i++) rows.push_back(stored_->tuple(i));  // key-byte order == tuple order
+    rows_ = std::make_shared<const std::vector<Tuple>>(std::move(rows));
+}
+
+namespace {
+// the ingest route: bytes -> ids + CSR (include/cozo_ingest.h); returns false when the relation holds a bad weight, so
+// that the caller can take the tuple route and report the offending value like the reference does
+bool graph_from_stored(const StoredRows &stored, uint32_t flags, GraphWithIndices &r) {
+    const czi_rows view = stored.view();
+    czi_graph *g = nullptr;
+    const int rc = czi_graph_ingest(&view, flags, &g);
+    if (rc == CZI_E_NOT_AN_EDGE) throw NotAnEdgeError();
+    if (rc == CZI_E_BAD_WEIGHT) return false;
+    if (rc != CZI_OK) throw CozoError("ingest::error", std::string("libcozo_ingest: ") + czi_last_error());
+    std::unique_ptr<czi_graph, void (*)(czi_graph *)> hold(g, czi_graph_free);
+    const uint32_t n = czi_graph_node_count(g);
+    const uint64_t e = czi_graph_edge_count(g);
+    DirectedCsrGraph &d = r.graph;
+    d.n = n;
+    d.out_offsets.resize((size_t)n + 1);
+    d.out_targets.resize(e);
+    d.in_offsets.resize((size_t)n + 1);
+    d.in_sources.resize(e);
+    if (flags & CZI_WEIGHTED) d.out_weights.resize(e);
+    if (czi_graph_csr(g, 0, d.out_offsets.data(), d.out_targets.data(), (flags & CZI_WEIGHTED) ? d.out_weights.data() : nullptr) ||
+        czi_graph_csr(g, 1, d.in_offsets.data(), d.in_sources.data(), nullptr))
+        throw CozoError("ingest::error", std::string("libcozo_ingest: ") + czi_last_error());
+    const uint8_t *bytes = nullptr;
+    const uint64_t *off = nullptr;
+    czi_graph_node_keys(g, &bytes, &off);
+    r.indices.reserve(n);
+    r.inv_indices.reserve(n);
+    for (uint32_t i = 0; i < n; i++) {  // N decodes, not 2E
+        const uint8_t *p = bytes + off[i];
+        r.indices.push_back(decode_datavalue(p, bytes + off[i + 1]));
+        r.inv_indices.emplace(r.indices.back(), i);
+    }
+    return true;
+}
+}  // namespace
+
 std::pair<std::vector<Tuple>::const_iterator, std::vector<Tuple>::const_iterator>
 FixedRuleInputRelation::prefix_iter(const DataValue &prefix) const {
+    ensure_rows();
     auto lo = std::lower_bound(rows_->begin(), rows_->end(), prefix, [](const Tuple &t, const DataValue &p) {
         return !t.empty() && DataValue::compare(t[0], p) < 0;
     });
@@ -162,6 +218,11 @@ void finish_int_ids(IntIdAssigner &ids, GraphWithIndices &r) {
 }  // namespace
 
 GraphWithIndices FixedRuleInputRelation::as_directed_graph(bool undirected) const {
+    if (stored_) {
+        GraphWithIndices r;
+        graph_from_stored(*stored_, undirected ? CZI_UNDIRECTED : 0u, r);
+        return r;
+    }
     if (!rows_->empty() && int_keyed(*rows_)) {
         IntIdAssigner ids(rows_->size());
         std::vector<uint32_t> from, to;
@@ -206,6 +267,13 @@ GraphWithIndices FixedRuleInputRelation::as_directed_graph(bool undirected) cons
 }
 
 GraphWithIndices FixedRuleInputRelation::as_directed_weighted_graph(bool undirected, bool allow_negative_weights) const {
+    if (stored_) {
+        GraphWithIndices r;
+        if (graph_from_stored(*stored_, CZI_WEIGHTED | (undirected ? CZI_UNDIRECTED : 0u) |
+                                            (allow_negative_weights ? CZI_ALLOW_NEGATIVE_WEIGHTS : 0u), r))
+            return r;
+        ensure_rows();  // a bad weight: the tuple route below throws BadEdgeWeightError with the value
+    }
     IdAssigner ids;
     ids.inv.reserve(rows_->size());
     std::vector<uint32_t> from, to;
@@ -239,6 +307,14 @@ GraphWithIndices FixedRuleInputRelation::as_directed_weighted_graph(bool undirec
 }
 
 GraphWithIndices FixedRuleInputRelation::as_ordered_graph(const std::vector<DataValue> &extra_nodes) const {
+    if (stored_) {
+        GraphWithIndices r;
+        graph_from_stored(*stored_, CZI_ORDERED_IDS, r);
+        bool all_present = true;
+        for (const DataValue &v : extra_nodes) all_present &= r.inv_indices.count(v) != 0;
+        if (all_present) return r;
+        ensure_rows();  // a start / goal without an edge needs an id of its own: the tuple route
+    }
     std::vector<DataValue> vals;
     vals.reserve(rows_->size() * 2 + extra_nodes.size());
     for (const Tuple &t : *rows_) {

@@ -65,9 +65,10 @@ typedef struct {
  * ascending by id, parallel edges kept, ties in scan order (CsrLayout::Sorted).  CZI_WEIGHTED: column 2 is the weight
  * (absent => 1.0; not a number / not finite / negative without CZI_ALLOW_NEGATIVE_WEIGHTS => CZI_E_BAD_WEIGHT,
  * :226-262), stored as f32.
- * CZI_ORDERED_IDS: ids are instead the RANK of the node value in DataValue order (= the order of the memcmp bytes).
- * ShortestPathBFS / Bfs walk `prefix_iter(node)` (algos/shortest_path_bfs.rs:64-72, algos/bfs.rs:58-66), i.e. they meet
- * neighbours in key order of the `to` value; with rank ids "ascending id" in the CSR is that order. */
+ * CZI_ORDERED_IDS: ids are instead the RANK of the node value's key bytes, i.e. the order a stored relation is scanned
+ * in.  ShortestPathBFS / Bfs walk `prefix_iter(node)` (algos/shortest_path_bfs.rs:64-72, algos/bfs.rs:58-66), i.e. they
+ * meet neighbours in key order of the `to` value; with rank ids "ascending id" in the CSR is that order.  (Byte order is
+ * DataValue::cmp for every variant except Vec and Json / Validity, whose tags are out of enum order, memcmp.rs:22-36.) */
 #define CZI_UNDIRECTED 1u
 #define CZI_WEIGHTED 2u
 #define CZI_ALLOW_NEGATIVE_WEIGHTS 4u

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "cozo_gpu.h"
+#include "cozo_host/codec.hpp"
 #include "cozo_host/fixed_rule.hpp"
 #include "cozo_host/graph_rules.hpp"
 #include "cozo_host/hnsw.hpp"
@@ -202,6 +203,174 @@ static void test_degree_centrality() {
     CHECK(out.exists(T({DataValue("z"), DataValue(0), DataValue(0), DataValue(0)})));
     FixedRuleInputRelation narrow({T({DataValue("a")})});
     CHECK((throws<InputRelationArityError>([&] { reg.run("DegreeCentrality", FixedRulePayload("DegreeCentrality", {narrow}), Poison()); })));
+}
+
+// ---- stored-row formats (cozo_host/codec.hpp); the property tests restate data/tests/memcmp.rs ---------------------
+static std::vector<uint8_t> enc(const DataValue &v) { return memcmp_bytes(v); }
+static DataValue dec(const std::vector<uint8_t> &b) {
+    const uint8_t *p = b.data();
+    DataValue v = decode_datavalue(p, b.data() + b.size());
+    CHECK(p == b.data() + b.size());
+    return v;
+}
+
+static void test_codec_numbers_and_order() {
+    // data/tests/memcmp.rs:15-51: ints around every power of two, infinities, random floats and their reciprocals
+    std::vector<DataValue> nums;
+    const int64_t n = INT64_MAX;
+    for (int i = 0; i < 54; i++)
+        for (int j = 0; j < 1000; j += 41) {
+            const int64_t vb = (n >> i) - j;
+            nums.push_back(DataValue(vb));
+            nums.push_back(DataValue(-vb - 1));
+        }
+    nums.push_back(DataValue(INFINITY));
+    nums.push_back(DataValue(-INFINITY));
+    std::mt19937_64 rng(3);
+    for (int i = 0; i < 4000; i++) {
+        const double f = ((double)(rng() >> 11) / 9007199254740992.0 - 0.5) * 2.0;
+        nums.push_back(DataValue(f));
+        nums.push_back(DataValue(1.0 / f));
+    }
+    for (int64_t i : {(int64_t)0, (int64_t)1, (int64_t)-1, (int64_t)1 << 53, ((int64_t)1 << 53) + 1, -((int64_t)1 << 53)}) nums.push_back(DataValue(i));
+    for (double f : {0.0, -0.0, 1.0, -1.0, 9007199254740992.0}) nums.push_back(DataValue(f));
+    bool round_trip = true;
+    std::vector<std::pair<std::vector<uint8_t>, DataValue>> encoded;
+    for (const DataValue &x : nums) {
+        const std::vector<uint8_t> b = enc(x);
+        const uint8_t *p = b.data();
+        const DataValue y = decode_datavalue(p, b.data() + b.size());
+        round_trip &= p == b.data() + b.size() && y.is_int() == x.is_int() && DataValue::compare(x, y) == 0;
+        encoded.push_back({b, x});
+    }
+    CHECK(round_trip);
+    // sorting the encodings sorts the numbers (Num::cmp: an Int before the Float it equals, floats by total_cmp)
+    std::sort(encoded.begin(), encoded.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    bool ordered = true;
+    for (size_t i = 1; i < encoded.size(); i++) ordered &= DataValue::compare(encoded[i - 1].second, encoded[i].second) <= 0;
+    CHECK(ordered);
+    CHECK(enc(DataValue((int64_t)1)) < enc(DataValue(1.0)) && enc(DataValue(1.0)) < enc(DataValue((int64_t)2)));
+    CHECK(enc(DataValue(((int64_t)1 << 53) - 1)).size() == 10 && enc(DataValue((int64_t)1 << 53)).size() == 18);  // memcmp.rs:130-140
+    double nan_back;
+    CHECK(dec(enc(DataValue((double)NAN))).get_float(&nan_back) && std::isnan(nan_back));
+}
+
+static void test_codec_bytes_and_values() {
+    // data/tests/memcmp.rs:65-98
+    const std::string target = "Lorem ipsum dolor sit amet, consectetur adipiscing elit...";
+    bool ok = true;
+    for (size_t i = 0; i < target.size(); i++) {
+        const std::string bs = target.substr(i);
+        std::vector<uint8_t> e;
+        for (const std::string *part : {&target, &bs, &bs, &target}) encode_bytes(e, (const uint8_t *)part->data(), part->size());
+        const uint8_t *p = e.data();
+        for (const std::string *part : {&target, &bs, &bs, &target}) {
+            const std::vector<uint8_t> d = decode_bytes(p, e.data() + e.size());
+            ok &= std::string(d.begin(), d.end()) == *part;
+        }
+        ok &= p == e.data() + e.size();
+    }
+    CHECK(ok);
+    // :100-113 and :115-137
+    std::vector<uint8_t> two = enc(DataValue((int64_t)2095));
+    encode_datavalue(two, DataValue("MSS"));
+    const uint8_t *p = two.data();
+    CHECK(decode_datavalue(p, two.data() + two.size()) == DataValue((int64_t)2095));
+    CHECK(decode_datavalue(p, two.data() + two.size()) == DataValue("MSS") && p == two.data() + two.size());
+    std::vector<DataValue> dv = {DataValue(), DataValue(false), DataValue(true), DataValue((int64_t)1), DataValue(1.0), DataValue(INT64_MAX),
+                                 DataValue(INT64_MAX - 1), DataValue(INT64_MAX - 2), DataValue(INT64_MIN), DataValue(INT64_MIN + 1),
+                                 DataValue(INT64_MIN + 2), DataValue(INFINITY), DataValue(-INFINITY), DataValue::list({})};
+    dv.push_back(DataValue::list(dv));
+    dv.push_back(DataValue::list(dv));
+    const DataValue nested = DataValue::list(dv);
+    CHECK(dec(enc(nested)) == nested);
+    // the store's row order (key bytes) is the evaluator's tuple order
+    std::vector<DataValue> vals = {DataValue(), DataValue(false), DataValue(true), DataValue((int64_t)-5), DataValue(-5.0), DataValue((int64_t)0),
+                                   DataValue(-0.0), DataValue(0.5), DataValue((int64_t)3), DataValue(3.0), DataValue(""), DataValue("a"),
+                                   DataValue("ab"), DataValue("abcdefgh"), DataValue("abcdefghi"), DataValue("b"), DataValue(Bytes{{}}),
+                                   DataValue(Bytes{{0}}), DataValue(Bytes{{0, 0}}), DataValue::list({}), DataValue::list({DataValue((int64_t)1)}),
+                                   DataValue::list({DataValue((int64_t)1), DataValue("a")}), DataValue::list({DataValue::list({})})};
+    bool same_order = true;
+    for (const DataValue &a : vals)
+        for (const DataValue &b : vals) {
+            const int c = DataValue::compare(a, b);
+            const std::vector<uint8_t> ea = enc(a), eb = enc(b);
+            same_order &= (c < 0) == (ea < eb) && (c == 0) == (ea == eb);
+        }
+    CHECK(same_order);
+    // ... except for Vec: VEC_TAG = 0x04 sorts a vector before every number in the store (memcmp.rs:25-26) while the enum
+    // declares Vec after Set (value.rs:146-170) -- a stored relation and an in-memory one order vector columns differently
+    CHECK(enc(DataValue(F32Vec{{1.5f}})) < enc(DataValue((int64_t)-5)) && DataValue::compare(DataValue(F32Vec{{1.5f}}), DataValue((int64_t)-5)) > 0);
+    CHECK(enc(DataValue(F32Vec{{9.0f}})) < enc(DataValue(F32Vec{{1.0f, 1.0f}})) &&
+          DataValue::compare(DataValue(F32Vec{{9.0f}}), DataValue(F32Vec{{1.0f, 1.0f}})) < 0);  // both: length first
+    // a row through the store and back: key columns memcmp, value columns msgpack
+    const Tuple row = T({DataValue((int64_t)9), DataValue("k"), DataValue(F32Vec{{1.5f, -2.0f, 0.25f}}),
+                         DataValue::list({DataValue(F32Vec{{1.0f}}), DataValue("x")}), DataValue(2.5), DataValue(), DataValue(true),
+                         DataValue(Bytes{{1, 2, 3}}), DataValue((int64_t)-70000), DataValue((int64_t)1 << 40)});
+    for (uint32_t kcols : {0u, 2u, 10u}) {
+        const std::vector<uint8_t> k = encode_key_for_store(3, row, kcols), v = encode_val_for_store(3, row, kcols);
+        CHECK(k[7] == 3 && v[7] == 3);
+        CHECK(decode_tuple_from_kv(k.data(), k.size(), v.data(), v.size()) == row);
+    }
+    const std::vector<uint8_t> v = encode_val_for_store(3, T({DataValue((int64_t)5), DataValue()}), 0);
+    const uint8_t want[] = {0, 0, 0, 0, 0, 0, 0, 3, 0x92, 0x81, 0xa3, 'N', 'u', 'm', 0x81, 0xa3, 'I', 'n', 't', 5, 0xa4, 'N', 'u', 'l', 'l'};
+    CHECK(v == std::vector<uint8_t>(want, want + sizeof want));  // [{"Num": {"Int": 5}}, "Null"]
+}
+
+static bool same_graph(const GraphWithIndices &a, const GraphWithIndices &b) {
+    return a.graph.n == b.graph.n && a.graph.out_offsets == b.graph.out_offsets && a.graph.out_targets == b.graph.out_targets &&
+           a.graph.in_offsets == b.graph.in_offsets && a.graph.in_sources == b.graph.in_sources &&
+           a.graph.out_weights == b.graph.out_weights && a.indices == b.indices && a.inv_indices.size() == b.inv_indices.size();
+}
+
+static std::vector<Tuple> mixed_rows(uint64_t seed, size_t n_rows) {
+    const std::vector<DataValue> pool = {DataValue(), DataValue(true), DataValue((int64_t)0), DataValue((int64_t)1), DataValue(1.0),
+                                         DataValue(-0.0), DataValue((int64_t)1 << 60), DataValue("a"), DataValue("node-17"),
+                                         DataValue("a much longer string key than one group"), DataValue(Bytes{{0, 1}}),
+                                         DataValue::list({DataValue((int64_t)1), DataValue("x")}), DataValue::list({}), DataValue((int64_t)7),
+                                         DataValue(7.0), DataValue(2.5)};
+    std::mt19937_64 rng(seed);
+    std::vector<Tuple> rows;
+    for (size_t i = 0; i < n_rows; i++) {
+        const DataValue w = (rng() & 1) ? DataValue((double)(rng() % 200) / 4) : DataValue((int64_t)(rng() % 50));
+        rows.push_back(T({pool[rng() % pool.size()], pool[rng() % pool.size()], w}));
+    }
+    return rows;
+}
+
+static void test_stored_relation_graphs() {
+    // FixedRuleInputRelation::from_stored (bytes -> libcozo_ingest) against the tuple route, endpoints of every modelled
+    // kind, in the key part or the value part of the row
+    for (uint32_t kcols : {3u, 2u, 1u, 0u}) {
+        const StoredRows stored = StoredRows::from_tuples(9, mixed_rows(5, 300), kcols);
+        std::vector<Tuple> decoded;
+        for (size_t i = 0; i < stored.size(); i++) decoded.push_back(stored.tuple(i));
+        const FixedRuleInputRelation plain(decoded), fast = FixedRuleInputRelation::from_stored(stored);
+        CHECK(fast.is_stored() && fast.arity() == 3 && fast.iter() == plain.iter());
+        for (bool undirected : {false, true}) {
+            CHECK(same_graph(fast.as_directed_graph(undirected), plain.as_directed_graph(undirected)));
+            CHECK(same_graph(fast.as_directed_weighted_graph(undirected, false), plain.as_directed_weighted_graph(undirected, false)));
+        }
+        CHECK(same_graph(fast.as_ordered_graph({}), plain.as_ordered_graph({})));
+        const std::vector<DataValue> extra = {DataValue("nobody"), decoded[0][0]};
+        CHECK(same_graph(fast.as_ordered_graph(extra), plain.as_ordered_graph(extra)));
+    }
+    // an integer-keyed relation: the tuple route takes its flat i64 table here, the byte route does not care
+    const std::vector<Tuple> ints = random_edges(500, 4000, 21, true);
+    const FixedRuleInputRelation plain(ints), fast = FixedRuleInputRelation::from_stored(StoredRows::from_tuples(1, ints, 3));
+    CHECK(fast.iter() == plain.iter());
+    CHECK(same_graph(fast.as_directed_graph(false), plain.as_directed_graph(false)));
+    CHECK(same_graph(fast.as_directed_weighted_graph(true, false), plain.as_directed_weighted_graph(true, false)));
+    // errors of the reference, by the same types
+    const FixedRuleInputRelation one_col = FixedRuleInputRelation::from_stored(StoredRows::from_tuples(1, {T({DataValue((int64_t)1)})}, 1));
+    CHECK((throws<NotAnEdgeError>([&] { one_col.as_directed_graph(false); })));
+    const FixedRuleInputRelation bad = FixedRuleInputRelation::from_stored(
+        StoredRows::from_tuples(1, {T({DataValue((int64_t)1), DataValue((int64_t)2), DataValue("heavy")})}, 2));
+    CHECK((throws<BadEdgeWeightError>([&] { bad.as_directed_weighted_graph(false, false); })));
+    const FixedRuleInputRelation neg = FixedRuleInputRelation::from_stored(
+        StoredRows::from_tuples(1, {T({DataValue((int64_t)1), DataValue((int64_t)2), DataValue(-1.5)})}, 2));
+    CHECK((throws<BadEdgeWeightError>([&] { neg.as_directed_weighted_graph(false, false); })));
+    CHECK(neg.as_directed_weighted_graph(false, true).graph.out_weights == std::vector<float>{-1.5f});
 }
 
 static void test_no_device_fails_loudly() {
@@ -465,6 +634,41 @@ static void gpu_closeness_centrality() {
     CHECK(ok);
 }
 
+static void gpu_rules_on_stored_relation() {
+    // every rule off the stored bytes of its edge relation (FixedRuleInputRelation::from_stored -> libcozo_ingest) and off
+    // the decoded tuples: the same rows
+    FixedRuleRegistry reg = FixedRuleRegistry::with_gpu_defaults();
+    std::vector<Tuple> rows;
+    std::mt19937_64 rng(77);
+    for (int i = 0; i < 900; i++) {
+        const std::string a = "n" + std::to_string(rng() % 150), b = "n" + std::to_string(rng() % 150);
+        if (a != b) rows.push_back(T({DataValue(a), DataValue(b), DataValue((double)(1 + rng() % 40) / 4)}));
+    }
+    for (uint32_t kcols : {3u, 2u}) {
+        const StoredRows stored = StoredRows::from_tuples(4, rows, kcols);
+        std::vector<Tuple> decoded;
+        for (size_t i = 0; i < stored.size(); i++) decoded.push_back(stored.tuple(i));
+        const FixedRuleInputRelation plain(decoded), fast = FixedRuleInputRelation::from_stored(stored);
+        const FixedRuleInputRelation starts({T({decoded[0][0]}), T({decoded[40][0]})}), ends({T({decoded[7][1]}), T({decoded[99][1]})});
+        auto both = [&](const char *name, std::vector<std::optional<FixedRuleInputRelation>> extra, std::map<std::string, DataValue> opts) {
+            std::vector<std::optional<FixedRuleInputRelation>> a{plain}, b{fast};
+            a.insert(a.end(), extra.begin(), extra.end());
+            b.insert(b.end(), extra.begin(), extra.end());
+            const RegularTempStore ra = reg.run(name, FixedRulePayload(name, a, opts), Poison());
+            const RegularTempStore rb = reg.run(name, FixedRulePayload(name, b, opts), Poison());
+            CHECK(ra.size() > 0 && ra.rows() == rb.rows());
+        };
+        both("PageRank", {}, {});
+        both("PageRank", {}, {{"undirected", DataValue(true)}, {"iterations", DataValue((int64_t)3)}});
+        both("ConnectedComponents", {}, {});
+        both("ShortestPathBFS", {starts, ends}, {});
+        both("ShortestPathDijkstra", {starts}, {});
+        both("ShortestPathDijkstra", {starts, ends}, {{"undirected", DataValue(true)}});
+        both("ClusteringCoefficients", {}, {});
+        both("DegreeCentrality", {}, {});
+    }
+}
+
 static void gpu_hnsw_search_ra() {
     // a base relation {k => v: <F32; 24>} with an L2 index, searched through HnswSearchRA (runtime/tests.rs:700-809 shape)
     const size_t n = 3000, dim = 24;
@@ -580,6 +784,9 @@ int main(int argc, char **argv) {
     test_as_directed_graph_vs_oracle();
     test_registry_and_simple_rule();
     test_degree_centrality();
+    test_codec_numbers_and_order();
+    test_codec_bytes_and_values();
+    test_stored_relation_graphs();
     test_no_device_fails_loudly();
     if (mode == "rules-cpu") {
         // the binary was linked against tests/cpp/oracle_shim.c ahead of libcozo_gpu.so: the rules' host logic runs on
@@ -589,6 +796,7 @@ int main(int argc, char **argv) {
         gpu_bfs_cc_dijkstra_random();
         gpu_clustering_coefficients();
         gpu_closeness_centrality();
+        gpu_rules_on_stored_relation();
     }
     if (mode == "gpu") {
         if (cz_init(0) != CZ_OK) {
@@ -600,6 +808,7 @@ int main(int argc, char **argv) {
         gpu_bfs_cc_dijkstra_random();
         gpu_clustering_coefficients();
         gpu_closeness_centrality();
+        gpu_rules_on_stored_relation();
         gpu_hnsw_search_ra();
     }
     std::printf("%s: %d checks passed, %d failed\n", mode.c_str(), g_pass, g_fail);

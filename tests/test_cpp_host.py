@@ -28,7 +28,7 @@ def build_test_host():
     # the executable is what brings the HIP runtime into the process (libcozo_gpu.so has no NEEDED entry for it)
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "cozo_amd", "host", "include"),
                            "-I" + os.path.join(ROOT, "include"), "-I" + ordir, SRC, "-o", BIN,
-                           "-L" + libdir, "-lcozo_host", "-lcozo_gpu", "-L" + ordir, "-lcozo_oracle",
+                           "-L" + libdir, "-lcozo_host", "-lcozo_gpu", "-lcozo_ingest", "-L" + ordir, "-lcozo_oracle",
                            "-L" + ROCM_LIB, "-lamdhip64", "-Wl,--no-as-needed",
                            "-Wl,-rpath," + libdir, "-Wl,-rpath," + ordir, "-Wl,-rpath," + ROCM_LIB])
     return BIN
@@ -53,7 +53,7 @@ def build_test_host_shim():
                            "-o", shim_so, "-L" + ordir, "-lcozo_oracle", "-Wl,-rpath," + ordir])
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "cozo_amd", "host", "include"),
                            "-I" + os.path.join(ROOT, "include"), "-I" + ordir, SRC, "-o", SHIM_BIN,
-                           "-Wl,--no-as-needed", "-L" + os.path.dirname(shim_so), "-lcozo_gpu_shim", "-L" + libdir, "-lcozo_host", "-lcozo_gpu",
+                           "-Wl,--no-as-needed", "-L" + os.path.dirname(shim_so), "-lcozo_gpu_shim", "-L" + libdir, "-lcozo_host", "-lcozo_gpu", "-lcozo_ingest",
                            "-L" + ordir, "-lcozo_oracle", "-L" + ROCM_LIB, "-lamdhip64",
                            "-Wl,-rpath," + os.path.dirname(shim_so), "-Wl,-rpath," + libdir, "-Wl,-rpath," + ordir,
                            "-Wl,-rpath," + ROCM_LIB])
