@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <new>
 #include <string>
@@ -632,6 +633,8 @@ int guarded(F &&f) {
         return e.code;
     } catch (const std::bad_alloc &) {
         return fail(CZI_E_INVALID, "out of host memory");
+    } catch (const std::exception &e) {  // nothing may unwind through the C ABI
+        return fail(CZI_E_INVALID, "%s", e.what());
     }
 }
 

@@ -297,3 +297,36 @@ def test_sha256_of_the_row_encoder_known_answers():
         selfs = [t for t in tup if t[0] == 0 and t[1:4] == t[4:7]]
         assert [t[8] for t in selfs] == [hashlib.sha256(vecs[i].tobytes()).digest() for i in range(2)]
         assert [t[7] for t in selfs] == [1.0, 1.0]
+
+
+def _dump(rows: codec.StoredRows, path):
+    import struct
+    with open(path, "wb") as f:
+        f.write(struct.pack("<IQ", rows.n_key_cols, len(rows)))
+        f.write(np.ascontiguousarray(rows.key_off, dtype="<u8").tobytes())
+        f.write(np.ascontiguousarray(rows.val_off, dtype="<u8").tobytes())
+        f.write(struct.pack("<Q", len(rows.keys)) + rows.keys)
+        f.write(struct.pack("<Q", len(rows.vals)) + rows.vals)
+
+
+def test_parsers_survive_damaged_rows_under_asan(oracle, tmp_path):
+    """tests/cpp/fuzz_ingest.cpp: ingest.cpp built with -fsanitize=address,undefined, 3000 mutated inputs (byte flips,
+    shifted row boundaries, wrong column counts): a status code every time, never a fault"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = _index_case(oracle, multi=True)
+    graph = codec.StoredRows.from_tuples(9, _value_rows(3, 200), 2)
+    for name, rows in (("graph", graph), ("idx", c["idx"]), ("base", c["base"])):
+        _dump(rows, tmp_path / f"{name}.bin")
+    exe = os.path.join(root, "tests", "cpp", "bin", "fuzz_ingest")
+    src = [os.path.join(root, "tests", "cpp", "fuzz_ingest.cpp"), os.path.join(root, "cozo_amd", "ingest", "ingest.cpp")]
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(s) for s in src):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                               "-I" + os.path.join(root, "include"), *src, "-o", exe])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", LD_PRELOAD="")
+    res = subprocess.run([exe, str(tmp_path / "graph.bin"), str(tmp_path / "idx.bin"), str(tmp_path / "base.bin"), "1500"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "no fault" in res.stdout
