@@ -109,8 +109,8 @@ def build_ingest(force: bool = False, verbose: bool = False) -> str:
                  os.path.getmtime(os.path.join(inc, "cozo_gpu.h")))
     if not force and os.path.exists(INGEST_SO) and os.path.getmtime(INGEST_SO) >= newest:
         return INGEST_SO
-    subprocess.check_call([CXX, "-std=c++17", "-O2", "-fPIC", "-Wall", "-Wextra", "-shared", "-I" + inc, INGEST_SRC,
-                           "-o", INGEST_SO])
+    subprocess.check_call([CXX, "-std=c++17", "-O2", "-fPIC", "-Wall", "-Wextra", "-pthread", "-shared", "-I" + inc,
+                           INGEST_SRC, "-o", INGEST_SO])
     if verbose:
         print("built", INGEST_SO)
     return INGEST_SO

@@ -18,6 +18,17 @@ def built():
     B.build_ingest()
 
 
+@pytest.fixture(params=["one-thread", "threaded"], autouse=True)
+def id_assignment_path(request, monkeypatch):
+    """every case runs through both forms of the first-appearance id assignment: the one-thread loop and the
+    hash-partitioned one (forced on for small inputs here); they must produce the same ids bit for bit"""
+    if request.param == "threaded":
+        monkeypatch.setenv("CZI_THREADS", "5")
+        monkeypatch.setenv("CZI_THREADED_MIN_ROWS", "0")
+    else:
+        monkeypatch.setenv("CZI_THREADS", "1")
+
+
 @pytest.mark.parametrize("undirected", [False, True])
 @pytest.mark.parametrize("n,e", [(50, 400), (2000, 9000), (3, 2)])
 def test_int_relation_matches_oracle(oracle, n, e, undirected):
@@ -309,9 +320,9 @@ def _dump(rows: codec.StoredRows, path):
         f.write(struct.pack("<Q", len(rows.vals)) + rows.vals)
 
 
-def test_parsers_survive_damaged_rows_under_asan(oracle, tmp_path):
-    """tests/cpp/fuzz_ingest.cpp: ingest.cpp built with -fsanitize=address,undefined, 3000 mutated inputs (byte flips,
-    shifted row boundaries, wrong column counts): a status code every time, never a fault"""
+def test_parsers_survive_damaged_rows_under_sanitizers(oracle, tmp_path):
+    """tests/cpp/fuzz_ingest.cpp: ingest.cpp built with -fsanitize=address,undefined and with -fsanitize=thread, thousands of
+    mutated inputs (byte flips, shifted row boundaries, wrong column counts): a status code every time, never a fault or race"""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -319,14 +330,18 @@ def test_parsers_survive_damaged_rows_under_asan(oracle, tmp_path):
     graph = codec.StoredRows.from_tuples(9, _value_rows(3, 200), 2)
     for name, rows in (("graph", graph), ("idx", c["idx"]), ("base", c["base"])):
         _dump(rows, tmp_path / f"{name}.bin")
-    exe = os.path.join(root, "tests", "cpp", "bin", "fuzz_ingest")
     src = [os.path.join(root, "tests", "cpp", "fuzz_ingest.cpp"), os.path.join(root, "cozo_amd", "ingest", "ingest.cpp")]
-    os.makedirs(os.path.dirname(exe), exist_ok=True)
-    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(s) for s in src):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                               "-I" + os.path.join(root, "include"), *src, "-o", exe])
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", LD_PRELOAD="")
-    res = subprocess.run([exe, str(tmp_path / "graph.bin"), str(tmp_path / "idx.bin"), str(tmp_path / "base.bin"), "1500"],
-                         capture_output=True, text=True, env=env, timeout=600)
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    assert "no fault" in res.stdout
+    os.makedirs(os.path.join(root, "tests", "cpp", "bin"), exist_ok=True)
+    args = [str(tmp_path / "graph.bin"), str(tmp_path / "idx.bin"), str(tmp_path / "base.bin")]
+    # address + undefined-behaviour sanitizers: the one-thread path and the hash-partitioned one; thread sanitizer: the latter
+    for san, name, runs in (("address,undefined", "fuzz_ingest", (("1", "1500"), ("3", "700"))), ("thread", "fuzz_ingest_tsan", (("4", "300"),))):
+        exe = os.path.join(root, "tests", "cpp", "bin", name)
+        if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(s) for s in src):
+            subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=" + san, "-fno-sanitize-recover=all",
+                                   "-I" + os.path.join(root, "include"), *src, "-o", exe])
+        for threads, iters in runs:
+            env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", TSAN_OPTIONS="halt_on_error=1", LD_PRELOAD="",
+                       CZI_THREADS=threads, CZI_THREADED_MIN_ROWS="0")
+            res = subprocess.run([exe, *args, iters], capture_output=True, text=True, env=env, timeout=900)
+            assert res.returncode == 0, (san, threads, res.stdout[-2000:] + res.stderr[-4000:])
+            assert "no fault" in res.stdout
