@@ -361,6 +361,42 @@ def bench_pagerank(args, torch, dist, rank, world, device):
     return res
 
 
+def bench_host_ingest(n_rows=4_000_000, n_nodes=400_000, seed=9):
+    """Host side of a whole-graph rule on a STORED relation (not part of `value`): the stored bytes of a
+    synthetic (int, int)-keyed edge relation -> first-appearance ids + both CSR directions through libcozo_ingest
+    (include/cozo_ingest.h), on this box's host cores.  The key bytes are built vectorised here (memcmp encoding of two
+    non-negative ints: tag 0x05, the f64 image with the sign bit set, big-endian, 0x00; data/memcmp.rs:127-145)."""
+    import time
+    import numpy as np
+    from cozo_amd import build as B, codec
+    from cozo_amd.ingest import StoredGraph
+    B.build_ingest()
+    rng = np.random.default_rng(seed)
+    pairs = np.unique(rng.integers(0, n_nodes, (n_rows, 2), dtype=np.int64), axis=0)  # a relation is a sorted set
+    e = pairs.shape[0]
+    rec = np.zeros((e, 28), dtype=np.uint8)
+    rec[:, 7] = 1  # relation id 1
+    for c in range(2):
+        img = pairs[:, c].astype(np.float64).view(np.uint64) | np.uint64(0x8000000000000000)
+        rec[:, 8 + 10 * c] = 0x05
+        rec[:, 9 + 10 * c:17 + 10 * c] = img.byteswap().view(np.uint8).reshape(e, 8)
+    rows = codec.StoredRows(rec.tobytes(), np.arange(e + 1, dtype=np.uint64) * 28, b"", np.zeros(e + 1, dtype=np.uint64), 2)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        g = StoredGraph(rows)
+        t1 = time.perf_counter()
+        g.csr(False)
+        g.csr(True)
+        t2 = time.perf_counter()
+        cur = (t2 - t0, t1 - t0, t2 - t1, g.n)
+        g.close()
+        best = cur if best is None or cur[0] < best[0] else best
+    return {"rows": int(e), "nodes": int(best[3]), "rows_per_s": e / best[0], "id_assignment_s": best[1], "csr_both_s": best[2],
+            "threads": int(os.environ.get("CZI_THREADS", min(16, os.cpu_count() or 1))), "host_cores": os.cpu_count(),
+            "what": "stored key bytes -> first-appearance ids + out/in CSR (libcozo_ingest), host only"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -410,6 +446,11 @@ def main():
                 out["cpu_baseline"] = pr["cpu_baseline"]
         if pr is not None and hn is not None:
             out["pagerank"] = pr
+        if not args.skip_cpu:
+            try:  # informational; never allowed to cost the bench line
+                out["host_ingest"] = bench_host_ingest()
+            except Exception as e:  # noqa: BLE001
+                out["host_ingest"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
