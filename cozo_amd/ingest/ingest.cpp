@@ -1189,41 +1189,68 @@ void ingest_hnsw(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_
     h.metric = metric;
     h.n_rows = idx->n_rows;
 
-    // pass 1: parse every row once
-    std::vector<IdxRow> rows;
-    rows.reserve(idx->n_rows);
-    int64_t min_layer = 1;
-    for (uint64_t i = 0; i < idx->n_rows; i++) {
-        IdxRow r;
-        if (!parse_idx_row(idx, i, K, r)) continue;
-        if (!rows.empty() && r.layer < rows.back().layer) raise(CZI_E_CORRUPT, "index rows are not in key order (row %llu)", (unsigned long long)i);
-        min_layer = std::min(min_layer, r.layer);
-        r.to_hash = hash_bytes(r.to, (size_t)(r.to_end - r.to));
-        rows.push_back(r);
+    const uint32_t T = ingest_threads(idx->n_rows);
+    WorkerError err;
+    auto rethrow = [&] {
+        if (err.set) {
+            g_err = err.msg;
+            throw Error{err.code};
+        }
+    };
+    auto guarded_worker = [&](uint64_t order, auto &&body) {
+        try {
+            body();
+        } catch (const Error &e) {
+            err.report(order, e.code, g_err);
+        } catch (const std::exception &e) {
+            err.report(order, CZI_E_INVALID, e.what());
+        }
+    };
+
+    // pass 1 (threads over rows): parse every row once.  Rows are in key order, so the layers never decrease and the
+    // canary rows (layer 1) are a suffix.
+    const uint64_t R = idx->n_rows;
+    std::unique_ptr<IdxRow[]> rows(new IdxRow[R + 1]);
+    parallel_for(T, [&](uint32_t t) {
+        uint64_t i = R * t / T;
+        guarded_worker(i, [&] {
+            for (; i < R * (t + 1) / T; i++)
+                if (parse_idx_row(idx, i, K, rows[i])) rows[i].to_hash = hash_bytes(rows[i].to, (size_t)(rows[i].to_end - rows[i].to));
+        });
+    });
+    rethrow();
+    uint64_t nv = 0;  // rows that are not the canary
+    for (uint64_t i = 0; i < R; i++) {
+        if (i && rows[i].layer < rows[i - 1].layer) raise(CZI_E_CORRUPT, "index rows are not in key order (row %llu)", (unsigned long long)i);
+        if (rows[i].layer <= 0) nv = i + 1;
     }
-    if (rows.empty()) return;  // only the canary, or nothing: an empty index (hnsw.rs:903-909)
+    if (nv == 0) return;  // only the canary, or nothing: an empty index (hnsw.rs:903-909)
+    const int64_t min_layer = rows[0].layer;
     if (min_layer < -62) raise(CZI_E_CORRUPT, "index has layer %lld", (long long)min_layer);
     h.n_levels = (int32_t)(-min_layer) + 1;
 
+    // group starts: a (layer, fr) group is one node's rows on one layer
+    std::unique_ptr<uint8_t[]> group_start(new uint8_t[nv + 1]);
+    parallel_for(T, [&](uint32_t t) {
+        for (uint64_t j = nv * t / T; j < nv * (t + 1) / T; j++) {
+            const size_t len = (size_t)(rows[j].fr_end - rows[j].fr);
+            group_start[j] = j == 0 || rows[j].layer != rows[j - 1].layer || (size_t)(rows[j - 1].fr_end - rows[j - 1].fr) != len ||
+                             memcmp(rows[j - 1].fr, rows[j].fr, len) != 0;
+        }
+    });
+
     // pass 2: node ids = order of the `fr` groups of layer 0 (every node has its self-loop row there, hnsw.rs:630-678)
     ByteTable nodes;
-    {
-        const uint8_t *prev = nullptr;
-        size_t prev_len = 0;
-        for (const IdxRow &r : rows) {
-            if (r.layer != 0) continue;
-            const size_t len = (size_t)(r.fr_end - r.fr);
-            if (prev && len == prev_len && memcmp(prev, r.fr, len) == 0) continue;
-            const uint32_t before = nodes.size();
-            if (nodes.find_or_insert(r.fr, len) != before) raise(CZI_E_CORRUPT, "index rows are not in key order (layer 0)");
-            prev = r.fr;
-            prev_len = len;
-        }
+    for (uint64_t j = 0; j < nv; j++) {
+        if (!group_start[j] || rows[j].layer != 0) continue;
+        const uint32_t before = nodes.size();
+        if (nodes.find_or_insert(rows[j].fr, (size_t)(rows[j].fr_end - rows[j].fr)) != before)
+            raise(CZI_E_CORRUPT, "index rows are not in key order (layer 0)");
     }
     h.n = nodes.size();
     if (!h.n) raise(CZI_E_CORRUPT, "the index has upper layers but no layer 0");
 
-    // node -> CompoundKey -> base row -> vector
+    // node -> CompoundKey -> base row -> vector (threads over nodes)
     ByteTable base_keys;
     for (uint64_t i = 0; i < base->n_rows; i++) {
         const Row r = row_at(base, i);
@@ -1235,86 +1262,108 @@ void ingest_hnsw(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_
     h.field.resize(h.n);
     h.sub.resize(h.n);
     h.vectors.resize((size_t)h.n * dim);
-    std::vector<uint8_t> scratch;
-    for (uint32_t v = 0; v < h.n; v++) {
-        const uint8_t *a = nodes.bytes.data() + nodes.off[v], *b = nodes.bytes.data() + nodes.off[v + 1];
-        const uint8_t *p = a;
-        for (uint32_t c = 0; c < K; c++) p = mc_skip(p, b);
-        const uint8_t *q = mc_skip(p, b);
-        const int64_t fld = key_int(p, q, "fr__field");
-        const int64_t sb = key_int(q, b, "fr__sub_idx");
-        const uint32_t br = base_keys.find(a, (size_t)(p - a));
-        if (br == CZ_NONE) raise(CZI_E_MISSING_ROW, "node %u of the index has no base row (corrupted index, hnsw.rs:131-140)", v);
-        bool known = n_fields == 0;
-        for (uint32_t f = 0; f < n_fields; f++) known |= vec_fields[f] == (uint32_t)fld;
-        if (fld < 0 || !known) raise(CZI_E_CORRUPT, "node %u: field %lld is not one of the index' vec_fields", v, (long long)fld);
-        h.base_row[v] = br;
-        h.field[v] = (uint32_t)fld;
-        h.sub[v] = (int32_t)sb;
-        copy_vector(base, br, (uint32_t)fld, (int32_t)sb, dim, h.vectors.data() + (size_t)v * dim, scratch);
-    }
+    parallel_for(T, [&](uint32_t t) {
+        std::vector<uint8_t> scratch;
+        uint32_t v = (uint32_t)((uint64_t)h.n * t / T);
+        guarded_worker(v, [&] {
+            for (; v < (uint32_t)((uint64_t)h.n * (t + 1) / T); v++) {
+                const uint8_t *a = nodes.bytes.data() + nodes.off[v], *b = nodes.bytes.data() + nodes.off[v + 1];
+                const uint8_t *p = a;
+                for (uint32_t c = 0; c < K; c++) p = mc_skip(p, b);
+                const uint8_t *q = mc_skip(p, b);
+                const int64_t fld = key_int(p, q, "fr__field");
+                const int64_t sb = key_int(q, b, "fr__sub_idx");
+                const uint32_t br = base_keys.find(a, (size_t)(p - a));
+                if (br == CZ_NONE) raise(CZI_E_MISSING_ROW, "node %u of the index has no base row (corrupted index, hnsw.rs:131-140)", v);
+                bool known = n_fields == 0;
+                for (uint32_t f = 0; f < n_fields; f++) known |= vec_fields[f] == (uint32_t)fld;
+                if (fld < 0 || !known) raise(CZI_E_CORRUPT, "node %u: field %lld is not one of the index' vec_fields", v, (long long)fld);
+                h.base_row[v] = br;
+                h.field[v] = (uint32_t)fld;
+                h.sub[v] = (int32_t)sb;
+                copy_vector(base, br, (uint32_t)fld, (int32_t)sb, dim, h.vectors.data() + (size_t)v * dim, scratch);
+            }
+        });
+    });
+    rethrow();
 
-    // pass 3: per level, the nodes present (ascending id = key order) and their live rows
+    // pass 3a (threads over rows): what every row is -- dropped exactly as hnsw_get_neighbours drops it -- and the id of `to`
+    enum : uint8_t { LIVE = 0, SELF = 1, SAME_ROW = 2, IGNORED = 3 };
+    std::unique_ptr<uint8_t[]> kind(new uint8_t[nv + 1]);
+    std::unique_ptr<uint32_t[]> to_id(new uint32_t[nv + 1]);
+    parallel_for(T, [&](uint32_t t) {
+        uint64_t j = nv * t / T;
+        const uint64_t hi = nv * (t + 1) / T;
+        guarded_worker(j, [&] {
+            for (; j < hi; j++) {
+                const IdxRow &r = rows[j];
+                // the `to` lookups are random probes of the node table: keep two stages of them in flight
+                if (j + 32 < hi) nodes.hint_slot(rows[j + 32].to_hash);
+                if (j + 16 < hi) nodes.hint_bytes(rows[j + 16].to_hash);
+                const size_t len = (size_t)(r.fr_end - r.fr), klen = (size_t)(r.fr_key_end - r.fr);
+                const bool same_row = (size_t)(r.to_key_end - r.to) == klen && memcmp(r.to, r.fr, klen) == 0;
+                if (same_row) {  // hnsw.rs:609-610: the self-loop row and links between vectors of one base row
+                    kind[j] = ((size_t)(r.to_end - r.to) == len && memcmp(r.to, r.fr, len) == 0) ? SELF : SAME_ROW;
+                } else if (r.ignore) {  // :616-619
+                    kind[j] = IGNORED;
+                } else {
+                    kind[j] = LIVE;
+                    to_id[j] = nodes.find_h(r.to, (size_t)(r.to_end - r.to), r.to_hash);
+                    if (to_id[j] == CZ_NONE) raise(CZI_E_CORRUPT, "a link points at a node with no layer-0 row");
+                }
+            }
+        });
+    });
+    rethrow();
+
+    // pass 3b: per level, the nodes present (ascending id = key order) and their live rows
     const int L = h.n_levels;
     h.level_size.assign(L, 0);
     h.level_width.assign(L, 0);
     h.level_nodes.assign(L, {});
     h.level_nbrs.assign(L, {});
-    std::vector<std::vector<uint32_t>> row_len(L);   // live links per present node
-    std::vector<std::vector<uint32_t>> flat(L);      // concatenated live links per level
-    {
-        size_t i = 0;
-        while (i < rows.size()) {
-            const int lv = (int)(-rows[i].layer);
-            const size_t len = (size_t)(rows[i].fr_end - rows[i].fr);
-            const uint32_t fr = nodes.find(rows[i].fr, len);
-            if (fr == CZ_NONE) raise(CZI_E_CORRUPT, "a layer %lld row starts at a node with no layer-0 row", (long long)rows[i].layer);
-            if (!h.level_nodes[lv].empty() && h.level_nodes[lv].back() >= fr) raise(CZI_E_CORRUPT, "index rows are not in key order");
-            uint32_t live = 0;
-            bool self = false;
-            size_t j = i;
-            for (; j < rows.size() && rows[j].layer == rows[i].layer && (size_t)(rows[j].fr_end - rows[j].fr) == len &&
-                   memcmp(rows[j].fr, rows[i].fr, len) == 0; j++) {
-                const IdxRow &r = rows[j];
-                // the `to` lookups are random probes of the node table: keep two stages of them in flight
-                if (j + 32 < rows.size()) nodes.hint_slot(rows[j + 32].to_hash);
-                if (j + 16 < rows.size()) nodes.hint_bytes(rows[j + 16].to_hash);
-                const size_t klen = (size_t)(r.fr_key_end - r.fr);
-                const bool same_row = (size_t)(r.to_key_end - r.to) == klen && memcmp(r.to, r.fr, klen) == 0;
-                if (same_row) {  // hnsw.rs:609-610: the self-loop row and links between vectors of one base row
-                    if ((size_t)(r.to_end - r.to) == len && memcmp(r.to, r.fr, len) == 0) { self = true; h.n_self++; }
-                    continue;
-                }
-                if (r.ignore) { h.n_ignored++; continue; }  // :616-619
-                const uint32_t to = nodes.find_h(r.to, (size_t)(r.to_end - r.to), r.to_hash);
-                if (to == CZ_NONE) raise(CZI_E_CORRUPT, "a link points at a node with no layer-0 row");
-                flat[lv].push_back(to);
-                live++;
+    std::vector<std::vector<uint64_t>> row_at_flat(L);  // per present node: where its live links start in flat[lv]
+    std::vector<std::vector<uint32_t>> flat(L);         // concatenated live links per level
+    for (uint64_t i = 0; i < nv;) {
+        const int lv = (int)(-rows[i].layer);
+        const uint32_t fr = nodes.find(rows[i].fr, (size_t)(rows[i].fr_end - rows[i].fr));
+        if (fr == CZ_NONE) raise(CZI_E_CORRUPT, "a layer %lld row starts at a node with no layer-0 row", (long long)rows[i].layer);
+        if (!h.level_nodes[lv].empty() && h.level_nodes[lv].back() >= fr) raise(CZI_E_CORRUPT, "index rows are not in key order");
+        row_at_flat[lv].push_back(flat[lv].size());
+        bool self = false;
+        uint64_t j = i;
+        do {
+            switch (kind[j]) {
+            case LIVE: flat[lv].push_back(to_id[j]); h.n_live++; break;
+            case SELF: self = true; h.n_self++; break;
+            case IGNORED: h.n_ignored++; break;
+            default: break;
             }
-            if (!self) raise(CZI_E_CORRUPT, "node %u has rows on layer %lld but no self-loop row there", fr, (long long)rows[i].layer);
-            h.level_nodes[lv].push_back(fr);
-            row_len[lv].push_back(live);
-            h.n_live += live;
-            i = j;
-        }
+            j++;
+        } while (j < nv && !group_start[j]);
+        if (!self) raise(CZI_E_CORRUPT, "node %u has rows on layer %lld but no self-loop row there", fr, (long long)rows[i].layer);
+        h.level_nodes[lv].push_back(fr);
+        i = j;
     }
     if (h.level_nodes[0].size() != h.n) raise(CZI_E_CORRUPT, "layer 0 holds %zu of %u nodes", h.level_nodes[0].size(), h.n);
     for (int lv = 0; lv < L; lv++) {
         if (h.level_nodes[lv].empty()) raise(CZI_E_CORRUPT, "layer %d is empty", -lv);
-        uint32_t width = lv == 0 ? m_max0 : m_max;
-        for (uint32_t x : row_len[lv]) width = std::max(width, x);
         const size_t sz = h.level_nodes[lv].size();
+        row_at_flat[lv].push_back(flat[lv].size());
+        uint32_t width = lv == 0 ? m_max0 : m_max;
+        for (size_t r = 0; r < sz; r++) width = std::max<uint32_t>(width, (uint32_t)(row_at_flat[lv][r + 1] - row_at_flat[lv][r]));
         h.level_size[lv] = (uint32_t)sz;
         h.level_width[lv] = (int32_t)width;
         std::vector<uint32_t> &tab = h.level_nbrs[lv];
         tab.assign(sz * width, CZ_NONE);
-        size_t at = 0;
-        for (size_t r = 0; r < sz; r++) {
-            // the scan yields `to` ends in key order = ascending id already; sort defensively (ids are what the kernels need)
-            std::copy(flat[lv].begin() + at, flat[lv].begin() + at + row_len[lv][r], tab.begin() + r * width);
-            std::sort(tab.begin() + r * width, tab.begin() + r * width + row_len[lv][r]);
-            at += row_len[lv][r];
-        }
+        parallel_for(T, [&](uint32_t t) {
+            for (size_t r = sz * t / T; r < sz * (t + 1) / T; r++) {
+                // the scan yields `to` ends in key order = ascending id already; sort defensively (ids are what the kernels need)
+                const uint64_t a0 = row_at_flat[lv][r], a1 = row_at_flat[lv][r + 1];
+                std::copy(flat[lv].begin() + a0, flat[lv].begin() + a1, tab.begin() + r * width);
+                std::sort(tab.begin() + r * width, tab.begin() + r * width + (a1 - a0));
+            }
+        });
     }
     h.entry = nodes.find(rows[0].fr, (size_t)(rows[0].fr_end - rows[0].fr));  // hnsw.rs:891-915
     for (int lv = 0; lv < L; lv++) {
