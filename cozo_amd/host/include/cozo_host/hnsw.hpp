@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include "codec.hpp"
 #include "fixed_rule.hpp"
 
 struct cz_hnsw_index;
@@ -83,6 +84,17 @@ public:
     // max_batch = 1 reproduces the sequential insertion order exactly.
     static GpuHnswIndex create(const HnswIndexManifest &manifest, const BaseRelation &base, uint64_t seed = 0,
                                uint32_t max_batch = 0, const std::vector<int32_t> *levels = nullptr);
+
+    // The index as it lives in the store: the key / value bytes of `tbl:idx` and of the base relation.
+    // libcozo_ingest turns them into the flat layout (include/cozo_ingest.h: node ids in key order, rows dropped as
+    // hnsw_get_neighbours drops them), cz_hnsw_index_create uploads it.  `base` holds the decoded rows for the row
+    // assembly of hnsw_knn and must be the same relation, in key order.
+    static GpuHnswIndex from_stored(const HnswIndexManifest &manifest, const StoredRows &idx, const StoredRows &base_rows,
+                                    const BaseRelation &base);
+    // The way back (section 8 f2): every `tbl:idx` row of this index as key / value bytes in key order, ready for
+    // store_tx.put -- link tables exported from the device, link distances recomputed by cz_distance_batch (the values
+    // the kernels work with), self-loop rows with degree and vector hash, the canary row (hnsw.rs:270-330, 630-678).
+    StoredRows index_rows(uint64_t relation_id) const;
 
     size_t node_count() const { return nodes_.size(); }
     const CompoundKey &node(uint32_t id) const { return nodes_[id]; }

@@ -2,8 +2,10 @@
 #include "cozo_host/hnsw.hpp"
 
 #include <algorithm>
+#include <memory>
 
 #include "cozo_gpu.h"
+#include "cozo_ingest.h"
 
 namespace cozo {
 
@@ -79,6 +81,101 @@ GpuHnswIndex GpuHnswIndex::create(const HnswIndexManifest &manifest, const BaseR
                             manifest.keep_pruned_connections ? 1 : 0, levels ? levels->data() : nullptr, seed, max_batch,
                             &ix.build_n_dist_, &ix.h_, 0, nullptr));
     return ix;
+}
+
+GpuHnswIndex GpuHnswIndex::from_stored(const HnswIndexManifest &manifest, const StoredRows &idx, const StoredRows &base_rows,
+                                       const BaseRelation &base) {
+    if (manifest.dtype != VecElementType::F32) throw GpuError(CZ_E_UNSUPPORTED, "only F32 vector indices are GPU-resident");
+    if (base.rows.size() != base_rows.size()) throw CozoError("hnsw::base_mismatch", "`base` and its stored rows differ in length");
+    GpuHnswIndex ix;
+    ix.manifest_ = manifest;
+    ix.base_ = &base;
+    std::vector<uint32_t> fields(manifest.vec_fields.begin(), manifest.vec_fields.end());
+    const czi_rows vi = idx.view(), vb = base_rows.view();
+    czi_hnsw *h = nullptr;
+    if (czi_hnsw_ingest(&vi, &vb, fields.data(), (uint32_t)fields.size(), (uint32_t)manifest.vec_dim, (int32_t)manifest.distance,
+                        (uint32_t)manifest.m_max, (uint32_t)manifest.m_max0, &h) != CZI_OK)
+        throw CozoError("ingest::error", std::string("libcozo_ingest: ") + czi_last_error());
+    std::unique_ptr<czi_hnsw, void (*)(czi_hnsw *)> hold(h, czi_hnsw_free);
+    cz_hnsw_desc desc;
+    const float *vectors = nullptr;
+    czi_hnsw_desc(h, &desc, &vectors);
+    const uint64_t *row = nullptr;
+    const uint32_t *field = nullptr;
+    const int32_t *sub = nullptr;
+    czi_hnsw_nodes(h, &row, &field, &sub);
+    for (uint32_t v = 0; v < desc.n; v++) ix.nodes_.push_back({(uint32_t)row[v], field[v], sub[v]});
+    if (desc.n_levels == 0) return ix;  // an empty index: hnsw_knn returns no rows (hnsw.rs:903-909)
+    check_gpu(cz_hnsw_index_create(&desc, vectors, &ix.h_));
+    return ix;
+}
+
+StoredRows GpuHnswIndex::index_rows(uint64_t relation_id) const {
+    StoredRows out;
+    const uint32_t K = (uint32_t)base_->keys.size();
+    out.n_key_cols = 2 * K + 5;
+    if (!h_) return out;
+    uint32_t n = 0, dim = 0, entry = 0;
+    int32_t metric = 0, n_levels = 0;
+    check_gpu(cz_hnsw_index_info(h_, &n, &dim, &metric, &n_levels, &entry));
+    std::vector<float> vectors((size_t)n * dim);
+    check_gpu(cz_hnsw_index_export_vectors(h_, vectors.data()));
+    std::vector<uint32_t> sizes(n_levels);
+    std::vector<int32_t> widths(n_levels);
+    std::vector<std::vector<uint32_t>> ids(n_levels), nbrs(n_levels);
+    std::vector<std::vector<double>> dist(n_levels);
+    for (int32_t lv = 0; lv < n_levels; lv++) {
+        check_gpu(cz_hnsw_index_level_info(h_, lv, &sizes[lv], &widths[lv]));
+        ids[lv].resize(sizes[lv]);
+        nbrs[lv].resize((size_t)sizes[lv] * widths[lv]);
+        check_gpu(cz_hnsw_index_export_level(h_, lv, ids[lv].data(), nbrs[lv].data()));
+        // the distance column of every link row: the same arithmetic the search uses
+        std::vector<uint32_t> pairs;
+        std::vector<size_t> slot;
+        for (uint32_t r = 0; r < sizes[lv]; r++)
+            for (int32_t s = 0; s < widths[lv]; s++) {
+                const uint32_t t = nbrs[lv][(size_t)r * widths[lv] + s];
+                if (t == CZ_NONE) continue;
+                pairs.push_back(ids[lv][r]);
+                pairs.push_back(t);
+                slot.push_back((size_t)r * widths[lv] + s);
+            }
+        dist[lv].assign(nbrs[lv].size(), 0.0);
+        if (!slot.empty()) {
+            std::vector<double> d(slot.size());
+            check_gpu(cz_distance_batch(metric, vectors.data(), n, dim, vectors.data(), n, pairs.data(), slot.size(), d.data(), 0, nullptr));
+            for (size_t i = 0; i < slot.size(); i++) dist[lv][slot[i]] = d[i];
+        }
+    }
+    // CompoundKey columns of every node in their key encoding: [row key x K, field, sub index]
+    std::vector<uint8_t> node_keys;
+    std::vector<uint64_t> node_key_off{0};
+    for (const CompoundKey &ck : nodes_) {
+        const Tuple &t = base_->rows[ck.row];
+        for (uint32_t c = 0; c < K; c++) encode_datavalue(node_keys, t[c]);
+        encode_datavalue(node_keys, DataValue((int64_t)ck.field));
+        encode_datavalue(node_keys, DataValue((int64_t)ck.sub));
+        node_key_off.push_back(node_keys.size());
+    }
+    std::vector<const uint32_t *> ids_p, nbrs_p;
+    std::vector<const double *> dist_p;
+    for (int32_t lv = 0; lv < n_levels; lv++) {
+        ids_p.push_back(ids[lv].data());
+        nbrs_p.push_back(nbrs[lv].data());
+        dist_p.push_back(dist[lv].data());
+    }
+    cz_hnsw_desc desc{n, dim, metric, n_levels, entry, sizes.data(), widths.data(), ids_p.data(), nbrs_p.data()};
+    czi_row_buf *buf = nullptr;
+    if (czi_hnsw_encode_rows(&desc, vectors.data(), node_keys.data(), node_key_off.data(), dist_p.data(), relation_id, &buf) != CZI_OK)
+        throw CozoError("ingest::error", std::string("libcozo_ingest: ") + czi_last_error());
+    std::unique_ptr<czi_row_buf, void (*)(czi_row_buf *)> hold(buf, czi_row_buf_free);
+    czi_rows rows;
+    czi_row_buf_rows(buf, &rows);
+    out.keys.assign(rows.keys, rows.keys + rows.key_off[rows.n_rows]);
+    out.vals.assign(rows.vals, rows.vals + rows.val_off[rows.n_rows]);
+    out.key_off.assign(rows.key_off, rows.key_off + rows.n_rows + 1);
+    out.val_off.assign(rows.val_off, rows.val_off + rows.n_rows + 1);
+    return out;
 }
 
 void GpuHnswIndex::search_raw(const float *queries, uint32_t B, uint32_t k, uint32_t ef, std::vector<uint32_t> &ids,

@@ -1346,12 +1346,20 @@ void ingest_hnsw(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_
         i = j;
     }
     if (h.level_nodes[0].size() != h.n) raise(CZI_E_CORRUPT, "layer 0 holds %zu of %u nodes", h.level_nodes[0].size(), h.n);
+    // row widths: m_max0 on level 0, m_max above -- one width for ALL upper levels (cz_hnsw_index_create keeps them in one
+    // table); a live row longer than that (never written by hnsw_put_vector, which shrinks to m_max) widens its group
+    uint32_t width0 = m_max0, width_up = m_max;
     for (int lv = 0; lv < L; lv++) {
         if (h.level_nodes[lv].empty()) raise(CZI_E_CORRUPT, "layer %d is empty", -lv);
-        const size_t sz = h.level_nodes[lv].size();
         row_at_flat[lv].push_back(flat[lv].size());
-        uint32_t width = lv == 0 ? m_max0 : m_max;
-        for (size_t r = 0; r < sz; r++) width = std::max<uint32_t>(width, (uint32_t)(row_at_flat[lv][r + 1] - row_at_flat[lv][r]));
+        for (size_t r = 0; r < h.level_nodes[lv].size(); r++) {
+            const uint32_t len = (uint32_t)(row_at_flat[lv][r + 1] - row_at_flat[lv][r]);
+            if (lv == 0) width0 = std::max(width0, len); else width_up = std::max(width_up, len);
+        }
+    }
+    for (int lv = 0; lv < L; lv++) {
+        const size_t sz = h.level_nodes[lv].size();
+        const uint32_t width = lv == 0 ? width0 : width_up;
         h.level_size[lv] = (uint32_t)sz;
         h.level_width[lv] = (int32_t)width;
         std::vector<uint32_t> &tab = h.level_nbrs[lv];

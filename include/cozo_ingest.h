@@ -95,7 +95,8 @@ uint32_t czi_graph_lookup(const czi_graph *g, const uint8_t *key, uint64_t len);
  * idx : every row of the index relation (schema runtime/relation.rs:1064-1126; K = base->n_key_cols):
  *       key [layer, fr_key x K, fr__field, fr__sub_idx, to_key x K, to__field, to__sub_idx], value [dist, hash, ignore_link].
  * base: every row of the base relation.  vec_fields = HnswIndexManifest::vec_fields (positions in the base tuple),
- *       dim = vec_dim, m_max / m_max0 = m_neighbours / 2 m_neighbours (row widths; a longer live row widens its level).
+ *       dim = vec_dim, m_max / m_max0 = m_neighbours / 2 m_neighbours (row widths of the upper levels / of level 0; a longer
+ *       live row widens level 0 or all upper levels together).
  * A node is one (row key, field, sub index) (:55).  Node ids follow the key order of the self-loop rows of layer 0, so
  * "ascending id" is the order hnsw_get_neighbours yields neighbours in.  Rows dropped exactly as :609-624 drops them:
  * the self-loop row, links to a vector of the same base row, ignore_link rows.  The canary row (layer 1, :641-669) is

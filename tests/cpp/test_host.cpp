@@ -3,6 +3,7 @@
 //   test_host cpu   host logic only: DataValue order, option readers, id assignment / CSR vs the oracle, registry
 //   test_host gpu   the fixed rules and HnswSearchRA on a real MI355X, rows compared with the oracle's
 //   test_host_shim rules-cpu   (linked against tests/cpp/oracle_shim.c) the same rule checks without a device
+//   test_host gpu-stored   a GPU-built index written out as `tbl:idx` stored bytes and read back off them (device)
 // The oracle (oracle/cozo_oracle.h) is test infrastructure; it is linked into this test binary only.
 // Reads like the reference's own tests: runtime/tests.rs:529-577 (custom rule), algos/shortest_path_bfs.rs:124-174
 // (love graph), runtime/tests.rs:178-207 (PageRank options), runtime/tests.rs:700-809 (vector search).
@@ -777,6 +778,77 @@ static void gpu_hnsw_search_ra() {
     orc_hnsw_free(ob);
 }
 
+static void gpu_index_through_the_store() {
+    // build on the GPU -> the `tbl:idx` rows as stored bytes (GpuHnswIndex::index_rows) -> read back off those bytes
+    // (GpuHnswIndex::from_stored): the same index, the same rows from HnswSearchRA
+    const size_t n = 1500, dim = 24;
+    std::mt19937 rng(5);
+    std::uniform_real_distribution<float> U(0.f, 1.f);
+    BaseRelation base;
+    base.keys = {"id"};
+    base.non_keys = {"tag", "v"};
+    for (size_t i = 0; i < n; i++) {
+        std::vector<float> v(dim);
+        for (float &x : v) x = U(rng);
+        char key[16];
+        std::snprintf(key, sizeof key, "doc-%05zu", i);  // string keys in key order
+        base.rows.push_back(T({DataValue(std::string(key)), DataValue((int64_t)(i % 7)), DataValue(F32Vec{v})}));
+    }
+    HnswIndexManifest mf = HnswIndexManifest::create("docs", "vec", dim, {2}, HnswDistance::Cosine, 8, 40);
+    GpuHnswIndex built = GpuHnswIndex::create(mf, base, 11, 64, nullptr);
+    const StoredRows idx = built.index_rows(31), stored_base = StoredRows::from_tuples(30, base.rows, 1);
+    CHECK(idx.n_key_cols == 7 && idx.size() > n);
+    // the rows read like the reference's: first row = the entry point on the top layer, last row = the canary
+    const Tuple first = idx.tuple(0), last = idx.tuple(idx.size() - 1);
+    int64_t top = 0, canary_layer = 0;
+    CHECK(first[0].get_int(&top) && top <= 0 && first.size() == 10 && first[1] == first[4] && first[2] == first[5]);
+    CHECK(last[0].get_int(&canary_layer) && canary_layer == 1 && last[1].is_null() && last[6].is_null());
+    size_t self_rows = 0, link_rows = 0;
+    bool shapes = true;
+    for (size_t i = 0; i + 1 < idx.size(); i++) {
+        const Tuple t = idx.tuple(i);
+        const bool self = t[1] == t[4] && t[2] == t[5] && t[3] == t[6];
+        bool ignore = true;
+        shapes &= t.size() == 10 && t[7].is_float() && t[9].get_bool(&ignore) && !ignore && (self ? !t[8].is_null() : t[8].is_null());
+        (self ? self_rows : link_rows)++;
+    }
+    CHECK(shapes && self_rows >= n && link_rows > n);
+    GpuHnswIndex read = GpuHnswIndex::from_stored(mf, idx, stored_base, base);
+    CHECK(read.node_count() == built.node_count());
+    bool same_nodes = true;
+    for (uint32_t v = 0; v < read.node_count(); v++)
+        same_nodes &= read.node(v).row == built.node(v).row && read.node(v).field == built.node(v).field && read.node(v).sub == built.node(v).sub;
+    CHECK(same_nodes);
+    CHECK(read.index_rows(31).keys == idx.keys && read.index_rows(31).vals == idx.vals);  // and back again: a fixed point
+    std::vector<Tuple> parent;
+    for (int i = 0; i < 24; i++) {
+        std::vector<float> q(dim);
+        for (float &x : q) x = U(rng);
+        parent.push_back(T({DataValue((int64_t)i), DataValue(F32Vec{q})}));
+    }
+    HnswSearch hs;
+    hs.k = 6;
+    hs.ef = 40;
+    hs.bind_distance = true;
+    hs.bind_field = true;
+    hs.filter = [](const Tuple &t) {
+        int64_t tag = 0;
+        return t[1].get_int(&tag) && tag != 3;
+    };
+    const std::vector<Tuple> a = HnswSearchRA{&built, hs, 1}.iter(parent, Poison());
+    const std::vector<Tuple> b = HnswSearchRA{&read, hs, 1}.iter(parent, Poison());
+    CHECK(!a.empty() && a == b);
+    // an empty index goes through the store as nothing at all
+    BaseRelation none;
+    none.keys = {"id"};
+    none.non_keys = {"tag", "v"};
+    GpuHnswIndex empty = GpuHnswIndex::create(mf, none, 0, 0, nullptr);
+    CHECK(empty.index_rows(31).size() == 0);
+    GpuHnswIndex empty_read = GpuHnswIndex::from_stored(mf, empty.index_rows(31), StoredRows::from_tuples(30, {}, 1), none);
+    const HnswSearchRA empty_ra{&empty_read, hs, 1};
+    CHECK(empty_read.node_count() == 0 && empty_ra.iter(parent, Poison()).empty());
+}
+
 int main(int argc, char **argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     test_value_order();
@@ -810,6 +882,13 @@ int main(int argc, char **argv) {
         gpu_closeness_centrality();
         gpu_rules_on_stored_relation();
         gpu_hnsw_search_ra();
+    }
+    if (mode == "gpu-stored") {
+        if (cz_init(0) != CZ_OK) {
+            std::printf("FAIL: cz_init: %s\n", cz_last_error());
+            return 2;
+        }
+        gpu_index_through_the_store();
     }
     std::printf("%s: %d checks passed, %d failed\n", mode.c_str(), g_pass, g_fail);
     return g_fail ? 1 : 0;
