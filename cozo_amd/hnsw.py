@@ -125,6 +125,26 @@ class GpuHnswIndex:
             nbrs.append(tab)
         return nodes, nbrs, entry.value
 
+    def index_rows(self, key_of_node: Sequence[Sequence], relation_id: int):
+        """The way back: every `tbl:idx` row of this index as stored key / value bytes in key order
+        (cozo_amd.codec.StoredRows), ready for store_tx.put -- link tables exported from the device, link distances from
+        cz_distance_batch (the values the kernels work with), self-loop rows with degree and vector hash, the canary row
+        (runtime/hnsw.rs:270-330, 630-678).  key_of_node[i] = (row key columns.., field, sub index) of node i."""
+        from .ingest import encode_index_rows
+        nodes, nbrs, entry = self.export()
+        vecs = self.export_vectors()
+        level_dist = []
+        for ids, tab in zip(nodes, nbrs):
+            d = np.zeros(tab.shape, dtype=np.float64)
+            live = tab != CZ_NONE
+            if live.any():
+                fr = np.broadcast_to(ids[:, None], tab.shape)[live]
+                pairs = np.stack([fr, tab[live]], 1).astype(np.uint32)
+                d[live] = distance_batch(self.manifest.distance, vecs, vecs, pairs)
+            level_dist.append(d)
+        return encode_index_rows(key_of_node, vecs, nodes, nbrs, entry, DISTANCES[self.manifest.distance], level_dist,
+                                 relation_id)
+
     def export_vectors(self) -> np.ndarray:
         out = np.empty((self.n, self.manifest.vec_dim), dtype=np.float32)
         check(_lib.lib().cz_hnsw_index_export_vectors(self._h, ptr(out)))
