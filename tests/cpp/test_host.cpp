@@ -3,7 +3,8 @@
 //   test_host cpu   host logic only: DataValue order, option readers, id assignment / CSR vs the oracle, registry
 //   test_host gpu   the fixed rules and HnswSearchRA on a real MI355X, rows compared with the oracle's
 //   test_host_shim rules-cpu   (linked against tests/cpp/oracle_shim.c) the same rule checks without a device
-//   test_host gpu-stored   a GPU-built index written out as `tbl:idx` stored bytes and read back off them (device)
+//   test_host gpu-stored   the rules off a stored relation's bytes; a GPU-built index written out as `tbl:idx` stored bytes
+//                          and read back off them (device)
 // The oracle (oracle/cozo_oracle.h) is test infrastructure; it is linked into this test binary only.
 // Reads like the reference's own tests: runtime/tests.rs:529-577 (custom rule), algos/shortest_path_bfs.rs:124-174
 // (love graph), runtime/tests.rs:178-207 (PageRank options), runtime/tests.rs:700-809 (vector search).
@@ -880,7 +881,6 @@ int main(int argc, char **argv) {
         gpu_bfs_cc_dijkstra_random();
         gpu_clustering_coefficients();
         gpu_closeness_centrality();
-        gpu_rules_on_stored_relation();
         gpu_hnsw_search_ra();
     }
     if (mode == "gpu-stored") {
@@ -888,6 +888,7 @@ int main(int argc, char **argv) {
             std::printf("FAIL: cz_init: %s\n", cz_last_error());
             return 2;
         }
+        gpu_rules_on_stored_relation();
         gpu_index_through_the_store();
     }
     std::printf("%s: %d checks passed, %d failed\n", mode.c_str(), g_pass, g_fail);
