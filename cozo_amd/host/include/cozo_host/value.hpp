@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstring>
 #include <functional>
+#include <limits>
 #include <memory>
 #include <ostream>
 #include <sstream>
@@ -208,8 +209,15 @@ struct DataValue {
                 return h;
             }
             default: {
-                const auto &v = std::get<F32Vec>(r).v;
-                return mix(h, std::hash<std::string_view>()(std::string_view((const char *)v.data(), v.size() * 4)));
+                // OrderedFloat's Hash (value.rs:424-437): -0.0 hashes like 0.0 and every NaN alike, as they compare equal
+                for (float x : std::get<F32Vec>(r).v) {
+                    if (x == 0.0f) x = 0.0f;
+                    if (std::isnan(x)) x = std::numeric_limits<float>::quiet_NaN();
+                    uint32_t b;
+                    std::memcpy(&b, &x, 4);
+                    h = mix(h, b);
+                }
+                return h;
             }
         }
     }
