@@ -123,7 +123,7 @@ static void test_as_directed_graph_vs_oracle() {
         CHECK(n == g.graph.n);
         bool same = n == g.indices.size();
         for (uint32_t i = 0; same && i < n; i++) {
-            int64_t v;
+            int64_t v = 0;
             same = g.indices[i].get_int(&v) && v == ind[i] && g.inv_indices.at(g.indices[i]) == i;
         }
         CHECK(same);
@@ -167,7 +167,7 @@ static void test_registry_and_simple_rule() {
         opts.at("mul").get_int(&mul);
         NamedRows out;
         for (const Tuple &t : inputs[0].rows) {
-            int64_t v;
+            int64_t v = 0;
             t[0].get_int(&v);
             out.rows.push_back(T({DataValue(v * mul)}));
         }
@@ -440,7 +440,7 @@ static void gpu_love_graph() {
     RegularTempStore cc = reg.run("ConnectedComponents", FixedRulePayload("ConnectedComponents", {love, nodes}), Poison());
     std::map<std::string, int64_t> grp;
     for (const Tuple &t : cc) {
-        int64_t gid;
+        int64_t gid = 0;
         t[1].get_int(&gid);
         grp[*t[0].get_str()] = gid;
     }
@@ -491,7 +491,7 @@ static void gpu_bfs_cc_dijkstra_random() {
     {
         int64_t threshold = 5000;
         ExprOption cond{[threshold](const Tuple &t) {
-                            int64_t v;
+                            int64_t v = 0;
                             return t[0].get_int(&v) && v > threshold;
                         },
                         true};
@@ -512,7 +512,7 @@ static void gpu_bfs_cc_dijkstra_random() {
             if (visited[s_id]) continue;
             const uint32_t cnt = orc_bfs_order(bg.graph.n, boff.data(), bg.graph.out_targets.data(), s_id, visited.data(), par.data(), order.data());
             for (uint32_t j = 0; j < cnt && found < 3; j++) {
-                int64_t v;
+                int64_t v = 0;
                 bg.indices[order[j]].get_int(&v);
                 if (v > threshold) {
                     std::vector<DataValue> path;
@@ -535,7 +535,7 @@ static void gpu_bfs_cc_dijkstra_random() {
         orc_tarjan_groups(g.graph.n, o2.data(), g.graph.out_targets.data(), grp.data());
         bool ok = cc.size() == g.graph.n;
         for (const Tuple &t : cc) {
-            int64_t gid;
+            int64_t gid = 0;
             ok = ok && t[1].get_int(&gid) && gid == (int64_t)grp[g.inv_indices.at(t[0])];
         }
         CHECK(ok);
