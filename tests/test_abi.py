@@ -44,6 +44,25 @@ def test_ingest_library_exports_every_declared_symbol():
     assert "amdhip" not in needed and "cozo_gpu" not in needed  # stands alone
 
 
+def test_public_headers_are_plain_c(tmp_path):
+    """the boundary is a C ABI: both headers compile as strict C99 (no C++-isms, no torch / HIP types in a signature) and a
+    C program links against libcozo_ingest.so"""
+    import subprocess
+    from cozo_amd import build as B, ingest
+    B.build_ingest()
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "cozo_gpu.h"\n#include "cozo_ingest.h"\n#include <stdio.h>\n'
+                   'int main(void) { czi_rows r; cz_hnsw_desc d; (void)r; (void)d; puts(czi_version()); return 0; }\n')
+    exe = tmp_path / "hdr"
+    libdir = os.path.dirname(ingest.SO_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L" + libdir, "-lcozo_ingest", "-Wl,-rpath," + libdir])
+    assert "cozo_ingest" in subprocess.run([str(exe)], capture_output=True, text=True).stdout
+    for h in ("cozo_gpu.h", "cozo_ingest.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        assert "torch" not in text and "hipStream_t " not in re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+
 def test_no_cpu_fallback_without_device():
     import torch
     if torch.cuda.is_available():
