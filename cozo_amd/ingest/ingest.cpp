@@ -1589,16 +1589,31 @@ void encode_index_rows(const cz_hnsw_desc *d, const float *vectors, const uint8_
         memcpy(at, &u, 8);
     };
 
-    // pass 1: validate and size the output exactly
-    uint64_t n_rows = 1, key_bytes = 0, val_bytes = 0;
-    for (int lv = 0; lv < d->n_levels; lv++) {
+    // pass 1: validate, and lay the output out exactly.  An item = one node on one level (its self-loop row + its link
+    // rows); items in output order: top layer first (most negative layer = smallest key), nodes by key order.
+    struct Item {
+        int lv;
+        uint32_t r, fr;            // row in the level's tables, node id
+        uint64_t row0, key0, val0;  // where its rows start in the output
+    };
+    std::vector<Item> items;
+    uint64_t n_rows = 0, key_bytes = 0, val_bytes = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> present;  // (rank of node, row in the level's tables)
+    for (int lv = d->n_levels - 1; lv >= 0; lv--) {
         const uint32_t sz = d->level_size[lv], width = (uint32_t)d->level_width[lv];
         const uint32_t *ids = d->level_nodes[lv], *tab = d->level_nbrs[lv];
         if (!tab || (lv > 0 && !ids)) raise(CZI_E_INVALID, "level %d: null table", lv);
+        present.clear();
         for (uint32_t r = 0; r < sz; r++) {
             const uint32_t fr = ids ? ids[r] : r;
             if (fr >= n) raise(CZI_E_INVALID, "level %d names node %u of %u", lv, fr, n);
+            present.push_back({rank[fr], r});
+        }
+        std::sort(present.begin(), present.end());
+        for (const auto &pr : present) {
+            const uint32_t r = pr.second, fr = ids ? ids[r] : r;
             const uint64_t flen = nko[fr + 1] - nko[fr];
+            items.push_back({lv, r, fr, n_rows, key_bytes, val_bytes});
             n_rows++;
             key_bytes += 18 + 2 * flen;
             val_bytes += self_val.size();
@@ -1626,6 +1641,8 @@ void encode_index_rows(const cz_hnsw_desc *d, const float *vectors, const uint8_
     mp_put_int(canary_val, -(int64_t)(d->n_levels - 1));
     mp_put_bytes(canary_val, target.b.data(), target.b.size());
     mp_put_bool(canary_val, false);
+    const uint64_t canary_row = n_rows, canary_key = key_bytes, canary_valat = val_bytes;
+    n_rows++;
     key_bytes += 18 + 2 * cols;
     val_bytes += canary_val.size();
 
@@ -1633,91 +1650,93 @@ void encode_index_rows(const cz_hnsw_desc *d, const float *vectors, const uint8_
     out.vals.resize(val_bytes);
     out.key_off.resize(n_rows + 1);
     out.val_off.resize(n_rows + 1);
-    uint8_t *kw = out.keys.data(), *vw = out.vals.data();
-    uint64_t row = 0;
-    uint8_t head[18];  // relation id + the layer column
-    for (int i = 0; i < 8; i++) head[i] = (uint8_t)(rid >> (56 - 8 * i));
-    auto end_row = [&] {
-        row++;
-        out.key_off[row] = (uint64_t)(kw - out.keys.data());
-        out.val_off[row] = (uint64_t)(vw - out.vals.data());
-    };
-    auto put_key = [&](uint32_t fr, uint32_t to) {
-        memcpy(kw, head, 18);
-        kw += 18;
-        memcpy(kw, nk + nko[fr], nko[fr + 1] - nko[fr]);
-        kw += nko[fr + 1] - nko[fr];
-        memcpy(kw, nk + nko[to], nko[to + 1] - nko[to]);
-        kw += nko[to + 1] - nko[to];
-    };
+    out.key_off[n_rows] = key_bytes;
+    out.val_off[n_rows] = val_bytes;
 
-    // pass 2: write, top layer first (most negative layer = smallest key)
+    const uint32_t T = ingest_threads(n_rows);
+    // SHA-256 of every vector (Vector::get_hash): threads over nodes
     std::vector<uint8_t> hashes((size_t)n * 32);
-    std::vector<uint8_t> hashed(n, 0);
-    struct Link {
-        uint32_t rank, to;
-        double dist;
-    };
-    std::vector<Link> links;
-    std::vector<std::pair<uint32_t, uint32_t>> present;  // (rank of node, row in the level's tables)
-    Buf layer_key;
-    for (int lv = d->n_levels - 1; lv >= 0; lv--) {
-        const uint32_t sz = d->level_size[lv], width = (uint32_t)d->level_width[lv];
-        const uint32_t *ids = d->level_nodes[lv], *tab = d->level_nbrs[lv];
-        const double *dist = level_dist ? level_dist[lv] : nullptr;
-        layer_key.b.clear();
-        layer_key.num_int(-(int64_t)lv);  // |layer| < 2^53: 10 bytes
-        memcpy(head + 8, layer_key.b.data(), 10);
-        present.clear();
-        for (uint32_t r = 0; r < sz; r++) present.push_back({rank[ids ? ids[r] : r], r});
-        std::sort(present.begin(), present.end());
-        for (const auto &pr : present) {
-            const uint32_t r = pr.second, fr = ids ? ids[r] : r;
+    parallel_for(T, [&](uint32_t t) {
+        for (uint32_t v = (uint32_t)((uint64_t)n * t / T); v < (uint32_t)((uint64_t)n * (t + 1) / T); v++) {
+            Sha256 sha;
+            sha.update((const uint8_t *)(vectors + (size_t)v * d->dim), (size_t)d->dim * 4);  // host is little-endian
+            sha.finish(hashes.data() + (size_t)v * 32);
+        }
+    });
+    std::vector<std::array<uint8_t, 10>> layer_keys(d->n_levels);
+    for (int lv = 0; lv < d->n_levels; lv++) {
+        Buf k;
+        k.num_int(-(int64_t)lv);  // |layer| < 2^53: 10 bytes
+        memcpy(layer_keys[lv].data(), k.b.data(), 10);
+    }
+    // pass 2: write (threads over items; every item knows where its rows go)
+    parallel_for(T, [&](uint32_t t) {
+        struct Link {
+            uint32_t rank, to;
+            double dist;
+        };
+        std::vector<Link> links;
+        uint8_t head[18];  // relation id + the layer column
+        for (int i = 0; i < 8; i++) head[i] = (uint8_t)(rid >> (56 - 8 * i));
+        for (size_t it = items.size() * t / T; it < items.size() * (t + 1) / T; it++) {
+            const Item &item = items[it];
+            const uint32_t width = (uint32_t)d->level_width[item.lv], fr = item.fr;
+            const uint32_t *tab = d->level_nbrs[item.lv];
+            const double *dist = level_dist ? level_dist[item.lv] : nullptr;
+            memcpy(head + 8, layer_keys[item.lv].data(), 10);
+            uint8_t *kw = out.keys.data() + item.key0, *vw = out.vals.data() + item.val0;
+            uint64_t row = item.row0;
+            auto begin_row = [&] {
+                out.key_off[row] = (uint64_t)(kw - out.keys.data());
+                out.val_off[row] = (uint64_t)(vw - out.vals.data());
+                row++;
+            };
+            auto put_key = [&](uint32_t to) {
+                memcpy(kw, head, 18);
+                kw += 18;
+                memcpy(kw, nk + nko[fr], nko[fr + 1] - nko[fr]);
+                kw += nko[fr + 1] - nko[fr];
+                memcpy(kw, nk + nko[to], nko[to + 1] - nko[to]);
+                kw += nko[to + 1] - nko[to];
+            };
             links.clear();
             for (uint32_t s = 0; s < width; s++) {
-                const uint32_t t = tab[(size_t)r * width + s];
-                if (t != CZ_NONE) links.push_back({rank[t], t, dist ? dist[(size_t)r * width + s] : 0.0});
+                const uint32_t to = tab[(size_t)item.r * width + s];
+                if (to != CZ_NONE) links.push_back({rank[to], to, dist ? dist[(size_t)item.r * width + s] : 0.0});
             }
             std::sort(links.begin(), links.end(), [](const Link &a, const Link &b) { return a.rank < b.rank; });
-            if (!hashed[fr]) {
-                Sha256 sha;
-                sha.update((const uint8_t *)(vectors + (size_t)fr * d->dim), (size_t)d->dim * 4);  // host is little-endian
-                sha.finish(hashes.data() + (size_t)fr * 32);
-                hashed[fr] = 1;
-            }
             bool self_done = false;
             auto put_self = [&] {
-                put_key(fr, fr);
+                begin_row();
+                put_key(fr);
                 memcpy(vw, self_val.data(), self_val.size());
                 patch_f64(vw + self_num_at, (double)links.size());
                 memcpy(vw + self_hash_at, hashes.data() + (size_t)fr * 32, 32);
                 vw += self_val.size();
-                end_row();
                 self_done = true;
             };
             for (const Link &l : links) {
                 if (!self_done && rank[fr] < l.rank) put_self();
-                put_key(fr, l.to);
+                begin_row();
+                put_key(l.to);
                 memcpy(vw, link_val.data(), link_val.size());
                 patch_f64(vw + link_num_at, l.dist);
                 vw += link_val.size();
-                end_row();
             }
             if (!self_done) put_self();
         }
+    });
+    {
+        uint8_t *kw = out.keys.data() + canary_key;
+        for (int i = 0; i < 8; i++) kw[i] = (uint8_t)(rid >> (56 - 8 * i));
+        Buf k;
+        k.num_int(1);
+        memcpy(kw + 8, k.b.data(), 10);
+        memset(kw + 18, NULL_TAG, 2 * cols);
+        memcpy(out.vals.data() + canary_valat, canary_val.data(), canary_val.size());
+        out.key_off[canary_row] = canary_key;
+        out.val_off[canary_row] = canary_valat;
     }
-    layer_key.b.clear();
-    layer_key.num_int(1);
-    memcpy(head + 8, layer_key.b.data(), 10);
-    memcpy(kw, head, 18);
-    kw += 18;
-    memset(kw, NULL_TAG, 2 * cols);
-    kw += 2 * cols;
-    memcpy(vw, canary_val.data(), canary_val.size());
-    vw += canary_val.size();
-    end_row();
-    if (row != n_rows || kw != out.keys.data() + key_bytes || vw != out.vals.data() + val_bytes)
-        raise(CZI_E_INVALID, "internal: row sizing mismatch");
 }
 
 }  // namespace
