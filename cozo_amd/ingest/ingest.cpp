@@ -939,8 +939,11 @@ void build_csr(const czi_graph &g, bool inverse, uint32_t *offsets, uint32_t *ta
     std::vector<std::vector<uint64_t>> cnt(T, std::vector<uint64_t>(D << kRadix, 0));
     parallel_for(T, [&](uint32_t t) {
         uint64_t *c = cnt[t].data();
-        const uint64_t m0 = (1ull << digits[0].bits) - 1;
-        auto tally = [&](uint64_t k) { c[k & m0]++; };  // digit 0 (shift 0); later digits are counted once their slices are known
+        // digit 0 always; with one thread the slice is the whole array in every pass, so all digits can be counted now
+        const size_t Dnow = T == 1 ? D : 1;
+        auto tally = [&](uint64_t k) {
+            for (size_t d = 0; d < Dnow; d++) c[(d << kRadix) + ((k >> digits[d].shift) & ((1ull << digits[d].bits) - 1))]++;
+        };
         for (uint64_t r = rows * t / T; r < rows * (t + 1) / T; r++) {
             const uint64_t a = A[r], b = B[r];
             if (g.undirected) {
@@ -961,7 +964,7 @@ void build_csr(const czi_graph &g, bool inverse, uint32_t *offsets, uint32_t *ta
     for (size_t d = 0; d < D; d++) {
         const int shift = digits[d].shift;
         const uint64_t m = (1ull << digits[d].bits) - 1;
-        if (d > 0) {  // digit 0 was counted while the keys were built
+        if (d > 0 && T > 1) {  // digit 0 was counted while the keys were built; the slices of later passes are known only now
             parallel_for(T, [&](uint32_t t) {
                 uint64_t *c = cnt[t].data() + (d << kRadix);
                 std::fill(c, c + m + 1, 0);
