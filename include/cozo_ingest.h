@@ -18,6 +18,8 @@
  *
  * Conventions as cozo_gpu.h: 0 / negative status, czi_last_error() per thread, the caller owns what it passes in,
  * the library owns what is behind a handle (pointers returned by accessors live until the handle is freed).
+ * Re-entrant, no global state.  Inputs of 2^18 rows and more are spread over min(16, cores) threads of the library's own
+ * (environment: CZI_THREADS = n; 1 keeps a call on the calling thread); results do not depend on the thread count.
  */
 #ifndef COZO_INGEST_H
 #define COZO_INGEST_H
