@@ -1,0 +1,218 @@
+//! cozo-core/src/fixed_rule/algos/gpu.rs -- whole-graph fixed rules on libcozo_gpu.so.
+//! Not compiled in this repository's image (no rustc); the executable specification of the same logic is
+//! cozo_amd/host/src/graph_rules.cpp (C++) and cozo_amd/fixed_rule.py + cozo_amd/stored_relation.py (Python).
+//!
+//! Registration (runtime/db.rs:760-776; a built-in name cannot be re-registered, :779-784):
+//!     db.register_fixed_rule("PageRankGpu".to_string(), PageRankGpu)?;
+//!     db.register_fixed_rule("ConnectedComponentsGpu".to_string(), ConnectedComponentsGpu)?;
+//! or, in a patched build, swap the entries of DEFAULT_FIXED_RULES (fixed_rule/mod.rs:799-802).
+
+use std::collections::BTreeMap;
+use std::ffi::CStr;
+use std::os::raw::c_int;
+
+use miette::{bail, miette, Result};
+use smartstring::{LazyCompact, SmartString};
+
+use crate::data::expr::Expr;
+use crate::data::symb::Symbol;
+use crate::data::tuple::{Tuple, TupleT};
+use crate::data::value::DataValue;
+use crate::fixed_rule::{BadEdgeWeightError, FixedRule, FixedRuleInputRelation, FixedRulePayload, NotAnEdgeError};
+use crate::parse::SourceSpan;
+use crate::runtime::db::Poison;
+use crate::runtime::temp_store::RegularTempStore;
+
+use super::cozo_gpu_sys::*;
+
+fn check(rc: c_int) -> Result<()> {
+    match rc {
+        CZ_OK => Ok(()),
+        CZ_E_CANCELLED => bail!(crate::runtime::db::ProcessKilled), // runtime/db.rs:1932-1940
+        _ => Err(miette!("libcozo_gpu: {}", unsafe { CStr::from_ptr(cz_last_error()) }.to_string_lossy())),
+    }
+}
+
+/// `Poison(Arc<AtomicBool>)` (runtime/db.rs:1926): AtomicBool has the layout of u8; the library polls it between launches.
+fn poison_ptr(p: &Poison) -> *const u8 {
+    p.0.as_ptr() as *const u8
+}
+
+/// Ids + CSR of an input relation.  A relation that lives in the store goes through libcozo_ingest on the bytes of its scan
+/// (no Vec<DataValue> per row, no BTreeMap lookup per endpoint); anything else through as_directed_graph.
+pub(crate) struct GpuGraph {
+    pub n: u32,
+    pub offsets: Vec<u32>,
+    pub targets: Vec<u32>,
+    pub out_degree: Vec<u32>, // only filled for `inverse` graphs (PageRank needs the out-degrees next to the in-CSR)
+    pub indices: Vec<DataValue>,
+}
+
+impl<'a, 'b> FixedRuleInputRelation<'a, 'b> {
+    /// (key bytes, value bytes) of every row, in scan order -- None unless the relation is stored and read at the present
+    /// (MagicFixedRuleRuleArg::Stored without valid_at, fixed_rule/mod.rs:94-101).
+    pub(crate) fn stored_scan(&self) -> Result<Option<(StoredBytes, u32)>> {
+        let (name, valid_at) = match self.arg_manifest {
+            crate::data::program::MagicFixedRuleRuleArg::Stored { name, valid_at, .. } => (name, valid_at),
+            _ => return Ok(None),
+        };
+        if valid_at.is_some() {
+            return Ok(None);
+        }
+        let rel = self.tx.get_relation(name, false)?;
+        let lower = Tuple::default().encode_as_key(rel.id); // the bounds of RelationHandle::scan_all, runtime/relation.rs:357-368
+        let upper = Tuple::default().encode_as_key(rel.id.next());
+        let mut b = StoredBytes::new();
+        let it = if rel.is_temp { self.tx.temp_store_tx.range_scan(&lower, &upper) } else { self.tx.store_tx.range_scan(&lower, &upper) };
+        for kv in it {
+            let (k, v) = kv?; // StoreTx::range_scan, storage/mod.rs:146-154
+            b.keys.extend_from_slice(&k);
+            b.key_off.push(b.keys.len() as u64);
+            b.vals.extend_from_slice(&v);
+            b.val_off.push(b.vals.len() as u64);
+        }
+        Ok(Some((b, rel.metadata.keys.len() as u32)))
+    }
+
+    pub(crate) fn as_gpu_graph(&self, undirected: bool, inverse: bool) -> Result<GpuGraph> {
+        if let Some((bytes, n_key_cols)) = self.stored_scan()? {
+            let rows = bytes.view(n_key_cols);
+            let mut g = std::ptr::null_mut();
+            match unsafe { czi_graph_ingest(&rows, if undirected { CZI_UNDIRECTED } else { 0 }, &mut g) } {
+                CZI_OK => {}
+                CZI_E_NOT_AN_EDGE => bail!(NotAnEdgeError(self.span())),
+                _ => bail!("libcozo_ingest: {}", unsafe { CStr::from_ptr(czi_last_error()) }.to_string_lossy()),
+            }
+            let g = IngestGraph(g); // frees on drop
+            let n = unsafe { czi_graph_node_count(g.0) };
+            let e = unsafe { czi_graph_edge_count(g.0) } as usize;
+            let (mut offsets, mut targets) = (vec![0u32; n as usize + 1], vec![0u32; e]);
+            unsafe { czi_graph_csr(g.0, inverse as c_int, offsets.as_mut_ptr(), targets.as_mut_ptr(), std::ptr::null_mut()) };
+            let mut out_degree = vec![];
+            if inverse {
+                let (mut o, mut t) = (vec![0u32; n as usize + 1], vec![0u32; e]);
+                unsafe { czi_graph_csr(g.0, 0, o.as_mut_ptr(), t.as_mut_ptr(), std::ptr::null_mut()) };
+                out_degree = o.windows(2).map(|w| w[1] - w[0]).collect();
+            }
+            // N decodes instead of 2E: the node values, from their key bytes (DataValue::decode_from_key, data/memcmp.rs:258)
+            let (mut nb, mut no) = (std::ptr::null(), std::ptr::null());
+            unsafe { czi_graph_node_keys(g.0, &mut nb, &mut no) };
+            let mut indices = Vec::with_capacity(n as usize);
+            for i in 0..n as usize {
+                let (lo, hi) = unsafe { (*no.add(i) as usize, *no.add(i + 1) as usize) };
+                let key = unsafe { std::slice::from_raw_parts(nb.add(lo), hi - lo) };
+                indices.push(DataValue::decode_from_key(key).0);
+            }
+            return Ok(GpuGraph { n, offsets, targets, out_degree, indices });
+        }
+        // not stored (a rule result, or a time-travel scan): the reference's route, then flatten graph_builder's CSR
+        let (graph, indices, _) = self.as_directed_graph(undirected)?;
+        use graph::prelude::{DirectedDegrees, DirectedNeighbors, Graph};
+        let n = graph.node_count();
+        let (mut offsets, mut targets, mut out_degree) = (vec![0u32], vec![], vec![]);
+        for u in 0..n {
+            if inverse {
+                targets.extend(graph.in_neighbors(u)); // CsrLayout::Sorted: ascending
+                out_degree.push(graph.out_degree(u));
+            } else {
+                targets.extend(graph.out_neighbors(u));
+            }
+            offsets.push(targets.len() as u32);
+        }
+        Ok(GpuGraph { n, offsets, targets, out_degree, indices })
+    }
+}
+
+pub(crate) struct StoredBytes {
+    pub keys: Vec<u8>,
+    pub key_off: Vec<u64>, // [n_rows + 1], starts with 0
+    pub vals: Vec<u8>,
+    pub val_off: Vec<u64>,
+}
+impl StoredBytes {
+    pub(crate) fn new() -> Self {
+        StoredBytes { keys: vec![], key_off: vec![0], vals: vec![], val_off: vec![0] }
+    }
+    pub(crate) fn view(&self, n_key_cols: u32) -> czi_rows {
+        czi_rows {
+            keys: self.keys.as_ptr(),
+            key_off: self.key_off.as_ptr(),
+            vals: self.vals.as_ptr(),
+            val_off: self.val_off.as_ptr(),
+            n_rows: (self.key_off.len() - 1) as u64,
+            n_key_cols,
+        }
+    }
+}
+struct IngestGraph(*mut czi_graph);
+impl Drop for IngestGraph {
+    fn drop(&mut self) {
+        unsafe { czi_graph_free(self.0) }
+    }
+}
+
+/// fixed_rule/algos/pagerank.rs:29-56 on the device.
+pub(crate) struct PageRankGpu;
+impl FixedRule for PageRankGpu {
+    fn run(&self, payload: FixedRulePayload<'_, '_>, out: &mut RegularTempStore, poison: Poison) -> Result<()> {
+        let edges = payload.get_input(0)?;
+        let undirected = payload.bool_option("undirected", Some(false))?;
+        let theta = payload.unit_interval_option("theta", Some(0.85))? as f32;
+        let epsilon = payload.unit_interval_option("epsilon", Some(0.0001))? as f32;
+        let iterations = payload.pos_integer_option("iterations", Some(10))?;
+        let g = edges.as_gpu_graph(undirected, true)?;
+        if g.indices.is_empty() {
+            return Ok(()); // pagerank.rs:43-45
+        }
+        let mut scores = vec![0f32; g.n as usize];
+        let (mut it, mut err) = (0u32, 0f64);
+        check(unsafe {
+            cz_pagerank(g.offsets.as_ptr(), g.targets.as_ptr(), g.out_degree.as_ptr(), g.n, g.targets.len() as u64, theta,
+                        epsilon as f64, iterations as u32, scores.as_mut_ptr(), &mut it, &mut err, poison_ptr(&poison))
+        })?;
+        for (idx, score) in scores.iter().enumerate() {
+            out.put(vec![g.indices[idx].clone(), DataValue::from(*score as f64)]);
+        }
+        Ok(())
+    }
+    fn arity(&self, _: &BTreeMap<SmartString<LazyCompact>, Expr>, _: &[Symbol], _: SourceSpan) -> Result<usize> {
+        Ok(2)
+    }
+}
+
+/// StronglyConnectedComponent { strong: false } (fixed_rule/algos/strongly_connected_components.rs:42-77) on the device.
+pub(crate) struct ConnectedComponentsGpu;
+impl FixedRule for ConnectedComponentsGpu {
+    fn run(&self, payload: FixedRulePayload<'_, '_>, out: &mut RegularTempStore, poison: Poison) -> Result<()> {
+        let edges = payload.get_input(0)?;
+        let g = edges.as_gpu_graph(true, false)?; // !strong: the symmetrised graph (:47-48)
+        let mut group = vec![0u32; g.n as usize];
+        let mut n_groups = 0u32;
+        if g.n > 0 {
+            check(unsafe {
+                cz_connected_components(g.offsets.as_ptr(), g.targets.as_ptr(), g.n, g.targets.len() as u64, group.as_mut_ptr(),
+                                        &mut n_groups, poison_ptr(&poison))
+            })?;
+        }
+        for (idx, grp) in group.iter().enumerate() {
+            out.put(vec![g.indices[idx].clone(), DataValue::from(*grp as i64)]);
+        }
+        // nodes that only appear in the optional node relation get fresh ids in scan order (:61-74)
+        let mut counter = n_groups as i64;
+        if let Ok(nodes) = payload.get_input(1) {
+            let mut known: std::collections::BTreeSet<DataValue> = g.indices.iter().cloned().collect();
+            for tuple in nodes.iter()? {
+                let tuple = tuple?;
+                let node = tuple.into_iter().next().unwrap();
+                if known.insert(node.clone()) {
+                    out.put(vec![node, DataValue::from(counter)]);
+                    counter += 1;
+                }
+            }
+        }
+        Ok(())
+    }
+    fn arity(&self, _: &BTreeMap<SmartString<LazyCompact>, Expr>, _: &[Symbol], _: SourceSpan) -> Result<usize> {
+        Ok(2)
+    }
+}

@@ -1,0 +1,273 @@
+//! cozo-core/src/runtime/hnsw_gpu.rs -- HNSW search and index construction on libcozo_gpu.so.
+//! Not compiled in this repository's image (no rustc); the executable specification of the same logic is
+//! cozo_amd/host/src/hnsw.cpp (GpuHnswIndex::{from_stored, index_rows, hnsw_knn_batch}, HnswSearchRA::iter) and
+//! cozo_amd/hnsw.py + cozo_amd/ingest.py.
+//!
+//! Three pieces:
+//!   1. `SessionTx::gpu_hnsw_index`  -- one scan of `tbl:idx` + one of the base relation, as bytes, through libcozo_ingest
+//!      into a device-resident index; cached per (index relation id, tx snapshot).
+//!   2. `HnswSearchRA::iter`          -- the patch of query/ra.rs:1085-1121: the parent tuples become ONE batch.
+//!   3. `SessionTx::hnsw_build_gpu`  -- `::hnsw create` (runtime/relation.rs:1010-1201): build on the device, write the
+//!      `tbl:idx` rows back with store_tx.put so that the index stays an ordinary relation.
+
+use std::ffi::CStr;
+use std::os::raw::c_int;
+
+use itertools::Itertools;
+use miette::{bail, ensure, miette, Result};
+
+use crate::data::program::HnswSearch;
+use crate::data::tuple::{Tuple, TupleT};
+use crate::data::value::{DataValue, Vector};
+use crate::runtime::relation::RelationHandle;
+use crate::runtime::transact::SessionTx;
+
+use super::cozo_gpu_sys::*;
+use crate::fixed_rule::algos::gpu::StoredBytes; // the (key bytes, value bytes) buffers of a scan
+
+pub(crate) struct GpuHnswIndex {
+    pub handle: *mut cz_hnsw_index,
+    /// node id -> (position of the base row in the scan, field, sub index) = CompoundKey (runtime/hnsw.rs:55)
+    pub node_row: Vec<u64>,
+    pub node_field: Vec<u32>,
+    pub node_sub: Vec<i32>,
+    /// key bytes of every base row (scan order): `base_handle.get` of a result goes through them
+    pub base_keys: StoredBytes,
+}
+unsafe impl Send for GpuHnswIndex {}
+unsafe impl Sync for GpuHnswIndex {} // immutable after creation; the library's entry points are re-entrant
+impl Drop for GpuHnswIndex {
+    fn drop(&mut self) {
+        unsafe { cz_hnsw_index_destroy(self.handle) }
+    }
+}
+
+fn scan_bytes(tx: &SessionTx<'_>, rel: &RelationHandle) -> Result<StoredBytes> {
+    let lower = Tuple::default().encode_as_key(rel.id);
+    let upper = Tuple::default().encode_as_key(rel.id.next());
+    let mut b = StoredBytes::new();
+    for kv in tx.store_tx.range_scan(&lower, &upper) {
+        let (k, v) = kv?;
+        b.keys.extend_from_slice(&k);
+        b.key_off.push(b.keys.len() as u64);
+        b.vals.extend_from_slice(&v);
+        b.val_off.push(b.vals.len() as u64);
+    }
+    Ok(b)
+}
+
+fn check_ingest(rc: c_int) -> Result<()> {
+    ensure!(rc == CZI_OK, "libcozo_ingest: {}", unsafe { CStr::from_ptr(czi_last_error()) }.to_string_lossy());
+    Ok(())
+}
+fn check(rc: c_int) -> Result<()> {
+    match rc {
+        CZ_OK => Ok(()),
+        CZ_E_CANCELLED => bail!(crate::runtime::db::ProcessKilled),
+        _ => Err(miette!("libcozo_gpu: {}", unsafe { CStr::from_ptr(cz_last_error()) }.to_string_lossy())),
+    }
+}
+
+impl<'a> SessionTx<'a> {
+    /// 1. the export
+    pub(crate) fn gpu_hnsw_index(&self, config: &HnswSearch) -> Result<GpuHnswIndex> {
+        let mf = &config.manifest;
+        let idx = scan_bytes(self, &config.idx_handle)?;
+        let base = scan_bytes(self, &config.base_handle)?;
+        let k = config.base_handle.metadata.keys.len() as u32;
+        let (idx_rows, base_rows) = (idx.view(2 * k + 5), base.view(k));
+        let fields = mf.vec_fields.iter().map(|f| *f as u32).collect_vec();
+        let mut h = std::ptr::null_mut();
+        check_ingest(unsafe {
+            czi_hnsw_ingest(&idx_rows, &base_rows, fields.as_ptr(), fields.len() as u32, mf.vec_dim as u32, mf.distance as i32,
+                            mf.m_max as u32, mf.m_max0 as u32, &mut h)
+        })?;
+        let mut desc = std::mem::MaybeUninit::<cz_hnsw_desc>::uninit();
+        let mut vectors = std::ptr::null();
+        unsafe { czi_hnsw_desc(h, desc.as_mut_ptr(), &mut vectors) };
+        let desc = unsafe { desc.assume_init() };
+        let (mut row, mut field, mut sub) = (std::ptr::null(), std::ptr::null(), std::ptr::null());
+        unsafe { czi_hnsw_nodes(h, &mut row, &mut field, &mut sub) };
+        let n = desc.n as usize;
+        let mut handle = std::ptr::null_mut();
+        let rc = if desc.n_levels > 0 { unsafe { cz_hnsw_index_create(&desc, vectors, &mut handle) } } else { CZ_OK };
+        let out = GpuHnswIndex {
+            handle,
+            node_row: unsafe { std::slice::from_raw_parts(row, n) }.to_vec(),
+            node_field: unsafe { std::slice::from_raw_parts(field, n) }.to_vec(),
+            node_sub: unsafe { std::slice::from_raw_parts(sub, n) }.to_vec(),
+            base_keys: base,
+        };
+        unsafe { czi_hnsw_free(h) };
+        check(rc)?;
+        Ok(out)
+    }
+
+    /// SessionTx::hnsw_knn (runtime/hnsw.rs:869-1012) for a whole batch of queries: the traversal on the device, the row
+    /// assembly of :939-1006 unchanged (base row, bind columns in all_bindings() order, radius, filter bytecode, truncate).
+    pub(crate) fn hnsw_knn_batch(
+        &self, gpu: &GpuHnswIndex, queries: &[f32], b: usize, config: &HnswSearch,
+        filter_bytecode: &Option<(Vec<crate::data::expr::Bytecode>, crate::parse::SourceSpan)>, stack: &mut Vec<DataValue>,
+    ) -> Result<Vec<Vec<Tuple>>> {
+        if gpu.handle.is_null() {
+            return Ok(vec![vec![]; b]); // empty index (:903-909)
+        }
+        // no filter: cut to k before rows are fetched; with a filter all ef candidates survive until it has run (:943-947)
+        let kk = if config.filter.is_some() { config.ef } else { config.k.min(config.ef) };
+        let (mut ids, mut dist, mut cnt) = (vec![0u32; b * kk], vec![0f64; b * kk], vec![0u32; b]);
+        check(unsafe {
+            cz_hnsw_search_batch(gpu.handle, queries.as_ptr(), b as u32, kk as u32, config.ef as u32, config.radius.is_some() as c_int,
+                                 config.radius.unwrap_or(0.0), ids.as_mut_ptr(), dist.as_mut_ptr(), cnt.as_mut_ptr(),
+                                 std::ptr::null_mut(), self.poison_ptr(), 0, std::ptr::null_mut())
+        })?;
+        let keys = &config.base_handle.metadata.keys;
+        let mut out = Vec::with_capacity(b);
+        for q in 0..b {
+            let mut ret = vec![];
+            for j in 0..cnt[q] as usize {
+                let (node, distance) = (ids[q * kk + j] as usize, dist[q * kk + j]);
+                let r = gpu.node_row[node] as usize;
+                let key_bytes = &gpu.base_keys.keys[gpu.base_keys.key_off[r] as usize..gpu.base_keys.key_off[r + 1] as usize];
+                let mut cand_tuple = match self.store_tx.get(key_bytes, false)? {
+                    Some(v) => crate::runtime::relation::decode_tuple_from_kv(key_bytes, &v, None),
+                    None => bail!("corrupted index"),
+                };
+                let (fld, sub) = (gpu.node_field[node] as usize, gpu.node_sub[node]);
+                if config.bind_field.is_some() {
+                    let name = if fld < keys.len() { keys[fld].name.clone() } else { config.base_handle.metadata.non_keys[fld - keys.len()].name.clone() };
+                    cand_tuple.push(DataValue::Str(name));
+                }
+                if config.bind_field_idx.is_some() {
+                    cand_tuple.push(if sub < 0 { DataValue::Null } else { DataValue::from(sub as i64) });
+                }
+                if config.bind_distance.is_some() {
+                    cand_tuple.push(DataValue::from(distance));
+                }
+                if config.bind_vector.is_some() {
+                    let vec = if sub < 0 { cand_tuple[fld].clone() } else {
+                        match &cand_tuple[fld] {
+                            DataValue::List(v) => v[sub as usize].clone(),
+                            v => bail!("corrupted index value {:?}", v),
+                        }
+                    };
+                    cand_tuple.push(vec);
+                }
+                if let Some((code, span)) = filter_bytecode {
+                    if !crate::data::expr::eval_bytecode_pred(code, &cand_tuple, stack, *span)? {
+                        continue;
+                    }
+                }
+                ret.push(cand_tuple);
+            }
+            ret.truncate(config.k); // rows arrive ascending by (distance, node id): the order ret.reverse() produces (:1005)
+            out.push(ret);
+        }
+        Ok(out)
+    }
+}
+
+// 2. query/ra.rs -- HnswSearchRA::iter with the parent drained into one batch
+//
+// fn iter<'a>(&'a self, tx: &'a SessionTx<'_>, delta_rule: Option<&MagicSymbol>,
+//             stores: &'a BTreeMap<MagicSymbol, EpochStore>) -> Result<TupleIter<'a>> {
+//     let bind_idx = /* unchanged, ra.rs:1091-1098 */;
+//     let config = self.hnsw_search.clone();
+//     let parents: Vec<Tuple> = self.parent.iter(tx, delta_rule, stores)?.try_collect()?;
+//     let mut q = Vec::<f32>::with_capacity(parents.len() * config.manifest.vec_dim);
+//     for t in &parents {
+//         match &t[bind_idx] {
+//             DataValue::Vec(Vector::F32(v)) => { ensure!(v.len() == config.manifest.vec_dim, "query vector dimension mismatch"); q.extend(v.iter()) }
+//             DataValue::Vec(Vector::F64(v)) => q.extend(v.iter().map(|x| *x as f32)),          // hnsw.rs:879-884
+//             d => bail!("Expected vector, got {:?}", d),                                         // ra.rs:1106-1109
+//         }
+//     }
+//     let gpu = tx.gpu_hnsw_index_cached(&config)?;
+//     let mut stack = vec![];
+//     let rows = tx.hnsw_knn_batch(&gpu, &q, parents.len(), &config, &self.filter_bytecode, &mut stack)?;
+//     Ok(Box::new(parents.into_iter().zip(rows).flat_map(|(p, rs)| rs.into_iter().map(move |t| {
+//         let mut r = p.clone();
+//         r.extend(t);
+//         Ok(r)
+//     }))))
+// }
+
+impl<'a> SessionTx<'a> {
+    /// 3. `::hnsw create` on the device.  One vector per base row only: cz_hnsw_build knows vectors, not row keys, so it cannot
+    /// apply "two vectors of one row are never neighbours" (hnsw.rs:609-610); multi-vector rows keep the hnsw_put route.
+    pub(crate) fn hnsw_build_gpu(&mut self, config: &HnswSearch) -> Result<()> {
+        let mf = &config.manifest;
+        let k = config.base_handle.metadata.keys.len();
+        let (mut vectors, mut node_keys, mut node_key_off) = (Vec::<f32>::new(), Vec::<u8>::new(), vec![0u64]);
+        for tuple in config.base_handle.scan_all(self) {
+            let tuple = tuple?;
+            let fld = mf.vec_fields[0];
+            if let DataValue::Vec(Vector::F32(v)) = &tuple[fld] {
+                vectors.extend(v.iter());
+                // the CompoundKey columns [row key.., field, sub index] in their key encoding (data/memcmp.rs:47)
+                use crate::data::memcmp::MemCmpEncoder;
+                for c in &tuple[..k] {
+                    node_keys.encode_datavalue(c);
+                }
+                node_keys.encode_datavalue(&DataValue::from(fld as i64));
+                node_keys.encode_datavalue(&DataValue::from(-1i64));
+                node_key_off.push(node_keys.len() as u64);
+            }
+        }
+        let n = (node_key_off.len() - 1) as u32;
+        if n == 0 {
+            return Ok(());
+        }
+        let mut h = std::ptr::null_mut();
+        check(unsafe {
+            cz_hnsw_build(vectors.as_ptr(), n, mf.vec_dim as u32, mf.distance as c_int, mf.m_neighbours as u32, mf.ef_construction as u32,
+                          mf.keep_pruned_connections as c_int, std::ptr::null(), rand::random(), 0, std::ptr::null_mut(), &mut h, 0,
+                          std::ptr::null_mut())
+        })?;
+        // export the link tables, recompute the link distances with the kernels' arithmetic, encode the rows
+        let (mut nn, mut dim, mut metric, mut n_levels, mut entry) = (0u32, 0u32, 0i32, 0i32, 0u32);
+        check(unsafe { cz_hnsw_index_info(h, &mut nn, &mut dim, &mut metric, &mut n_levels, &mut entry) })?;
+        let (mut sizes, mut widths) = (vec![0u32; n_levels as usize], vec![0i32; n_levels as usize]);
+        let (mut ids, mut nbrs, mut dists) = (vec![], vec![], vec![]);
+        for lv in 0..n_levels as usize {
+            check(unsafe { cz_hnsw_index_level_info(h, lv as i32, &mut sizes[lv], &mut widths[lv]) })?;
+            let (mut i, mut t) = (vec![0u32; sizes[lv] as usize], vec![0u32; sizes[lv] as usize * widths[lv] as usize]);
+            check(unsafe { cz_hnsw_index_export_level(h, lv as i32, i.as_mut_ptr(), t.as_mut_ptr()) })?;
+            let (mut pairs, mut slot) = (vec![], vec![]);
+            for (s, to) in t.iter().enumerate().filter(|(_, to)| **to != CZ_NONE) {
+                pairs.extend([i[s / widths[lv] as usize], *to]);
+                slot.push(s);
+            }
+            let mut d = vec![0f64; slot.len()];
+            check(unsafe {
+                cz_distance_batch(metric, vectors.as_ptr(), n, dim, vectors.as_ptr(), n, pairs.as_ptr(), slot.len() as u64, d.as_mut_ptr(), 0,
+                                  std::ptr::null_mut())
+            })?;
+            let mut full = vec![0f64; t.len()];
+            for (s, x) in slot.iter().zip(d) {
+                full[*s] = x;
+            }
+            ids.push(i);
+            nbrs.push(t);
+            dists.push(full);
+        }
+        unsafe { cz_hnsw_index_destroy(h) };
+        let (ids_p, nbrs_p, dist_p) = (ids.iter().map(|v| v.as_ptr()).collect_vec(), nbrs.iter().map(|v| v.as_ptr()).collect_vec(),
+                                       dists.iter().map(|v| v.as_ptr()).collect_vec());
+        let desc = cz_hnsw_desc { n, dim, metric, n_levels, entry, level_size: sizes.as_ptr(), level_width: widths.as_ptr(),
+                                  level_nodes: ids_p.as_ptr(), level_nbrs: nbrs_p.as_ptr() };
+        let mut buf = std::ptr::null_mut();
+        check_ingest(unsafe {
+            czi_hnsw_encode_rows(&desc, vectors.as_ptr(), node_keys.as_ptr(), node_key_off.as_ptr(), dist_p.as_ptr(), config.idx_handle.id.0, &mut buf)
+        })?;
+        let mut rows = std::mem::MaybeUninit::<czi_rows>::uninit();
+        unsafe { czi_row_buf_rows(buf, rows.as_mut_ptr()) };
+        let rows = unsafe { rows.assume_init() };
+        for r in 0..rows.n_rows as usize {
+            let (k0, k1, v0, v1) = unsafe { (*rows.key_off.add(r) as usize, *rows.key_off.add(r + 1) as usize, *rows.val_off.add(r) as usize, *rows.val_off.add(r + 1) as usize) };
+            let (key, val) = unsafe { (std::slice::from_raw_parts(rows.keys.add(k0), k1 - k0), std::slice::from_raw_parts(rows.vals.add(v0), v1 - v0)) };
+            self.store_tx.put(key, val)?; // what hnsw_put_vector / hnsw_put_fresh_at_levels do row by row (hnsw.rs:277-357, 630-678)
+        }
+        unsafe { czi_row_buf_free(buf) };
+        Ok(())
+    }
+}
