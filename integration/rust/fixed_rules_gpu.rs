@@ -25,10 +25,12 @@ use crate::runtime::temp_store::RegularTempStore;
 
 use super::cozo_gpu_sys::*;
 
-fn check(rc: c_int) -> Result<()> {
+fn check(rc: c_int, poison: &Poison) -> Result<()> {
+    if rc == CZ_E_CANCELLED {
+        poison.check()?; // the flag is set: this bails with ProcessKilled (a type local to Poison::check, runtime/db.rs:1930-1940)
+    }
     match rc {
         CZ_OK => Ok(()),
-        CZ_E_CANCELLED => bail!(crate::runtime::db::ProcessKilled), // runtime/db.rs:1932-1940
         _ => Err(miette!("libcozo_gpu: {}", unsafe { CStr::from_ptr(cz_last_error()) }.to_string_lossy())),
     }
 }
@@ -169,7 +171,7 @@ impl FixedRule for PageRankGpu {
         check(unsafe {
             cz_pagerank(g.offsets.as_ptr(), g.targets.as_ptr(), g.out_degree.as_ptr(), g.n, g.targets.len() as u64, theta,
                         epsilon as f64, iterations as u32, scores.as_mut_ptr(), &mut it, &mut err, poison_ptr(&poison))
-        })?;
+        }, &poison)?;
         for (idx, score) in scores.iter().enumerate() {
             out.put(vec![g.indices[idx].clone(), DataValue::from(*score as f64)]);
         }
@@ -192,7 +194,7 @@ impl FixedRule for ConnectedComponentsGpu {
             check(unsafe {
                 cz_connected_components(g.offsets.as_ptr(), g.targets.as_ptr(), g.n, g.targets.len() as u64, group.as_mut_ptr(),
                                         &mut n_groups, poison_ptr(&poison))
-            })?;
+            }, &poison)?;
         }
         for (idx, grp) in group.iter().enumerate() {
             out.put(vec![g.indices[idx].clone(), DataValue::from(*grp as i64)]);

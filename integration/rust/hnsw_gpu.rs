@@ -61,11 +61,8 @@ fn check_ingest(rc: c_int) -> Result<()> {
     Ok(())
 }
 fn check(rc: c_int) -> Result<()> {
-    match rc {
-        CZ_OK => Ok(()),
-        CZ_E_CANCELLED => bail!(crate::runtime::db::ProcessKilled),
-        _ => Err(miette!("libcozo_gpu: {}", unsafe { CStr::from_ptr(cz_last_error()) }.to_string_lossy())),
-    }
+    ensure!(rc == CZ_OK, "libcozo_gpu: {}", unsafe { CStr::from_ptr(cz_last_error()) }.to_string_lossy());
+    Ok(())
 }
 
 impl<'a> SessionTx<'a> {
@@ -118,7 +115,7 @@ impl<'a> SessionTx<'a> {
         check(unsafe {
             cz_hnsw_search_batch(gpu.handle, queries.as_ptr(), b as u32, kk as u32, config.ef as u32, config.radius.is_some() as c_int,
                                  config.radius.unwrap_or(0.0), ids.as_mut_ptr(), dist.as_mut_ptr(), cnt.as_mut_ptr(),
-                                 std::ptr::null_mut(), self.poison_ptr(), 0, std::ptr::null_mut())
+                                 std::ptr::null_mut(), std::ptr::null() /* hnsw_knn takes no Poison in the reference either */, 0, std::ptr::null_mut())
         })?;
         let keys = &config.base_handle.metadata.keys;
         let mut out = Vec::with_capacity(b);
