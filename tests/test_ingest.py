@@ -345,3 +345,39 @@ def test_parsers_survive_damaged_rows_under_sanitizers(oracle, tmp_path):
             res = subprocess.run([exe, *args, iters], capture_output=True, text=True, env=env, timeout=900)
             assert res.returncode == 0, (san, threads, res.stdout[-2000:] + res.stderr[-4000:])
             assert "no fault" in res.stdout
+
+
+def test_threaded_and_one_thread_agree_at_scale(monkeypatch):
+    """0.6 M rows (past the default threshold): the hash-partitioned numbering and the position-split radix CSR against the
+    one-thread forms -- node keys, ids, offsets, targets and weights identical"""
+    rng = np.random.default_rng(17)
+    e = 600_000
+    pairs = np.unique(rng.integers(0, 70_000, (e, 2), dtype=np.int64), axis=0)
+    n = pairs.shape[0]
+    w = (rng.integers(0, 64, n) / 8).astype(np.float64)
+    # (int, int) keys, f64 weight in the value part; built vectorised: 28-byte keys, 25-byte values
+    rec = np.zeros((n, 28), dtype=np.uint8)
+    rec[:, 7] = 3
+    for c in range(2):
+        img = pairs[:, c].astype(np.float64).view(np.uint64) | np.uint64(0x8000000000000000)
+        rec[:, 8 + 10 * c] = 0x05
+        rec[:, 9 + 10 * c:17 + 10 * c] = img.byteswap().view(np.uint8).reshape(n, 8)
+    head = bytes([0, 0, 0, 0, 0, 0, 0, 3, 0x91, 0x81, 0xa3]) + b"Num" + bytes([0x81, 0xa5]) + b"Float" + bytes([0xcb])
+    val = np.zeros((n, len(head) + 8), dtype=np.uint8)
+    val[:, :len(head)] = np.frombuffer(head, dtype=np.uint8)
+    val[:, len(head):] = w.view(np.uint64).byteswap().view(np.uint8).reshape(n, 8)
+    rows = codec.StoredRows(rec.tobytes(), np.arange(n + 1, dtype=np.uint64) * 28, val.tobytes(),
+                            np.arange(n + 1, dtype=np.uint64) * val.shape[1], 2)
+    assert rows.tuples()[:1] == [[int(pairs[0, 0]), int(pairs[0, 1]), float(w[0])]]  # the fabricated bytes are real rows
+    out = {}
+    for threads in ("1", "6"):
+        monkeypatch.setenv("CZI_THREADS", threads)
+        monkeypatch.delenv("CZI_THREADED_MIN_ROWS", raising=False)
+        g = StoredGraph(rows, undirected=True, weighted=True)
+        out[threads] = (g.n, g.node_keys(), g.csr(False), g.csr(True), g.get_node_idx(int(pairs[n // 2, 1])))
+        g.close()
+    a, b = out["1"], out["6"]
+    assert a[0] == b[0] and a[1][0] == b[1][0] and np.array_equal(a[1][1], b[1][1]) and a[4] == b[4]
+    for x, y in zip(a[2] + a[3], b[2] + b[3]):
+        assert (x is None and y is None) or np.array_equal(x, y)
+    assert a[0] <= 70_000 and a[2][1].size == 2 * n
