@@ -178,3 +178,22 @@ def gather_source_rows(local_rows: torch.Tensor, n_sources: int, world: int, gro
     every = torch.empty((world * per,) + tuple(width), dtype=local_rows.dtype, device=local_rows.device)
     dist.all_gather_into_tensor(every, mine.contiguous(), group=group)
     return every[:n_sources]
+
+
+def sharded_hnsw_knn(local_search: Callable, queries: Optional[torch.Tensor], n_queries: int, dim: int, id_offset: int, k: int,
+                     rank: int, world: int, device: torch.device, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """hnsw_knn over an index partitioned into one independent sub-index per rank (config 4 of BASELINE.json: 10 M x 768
+    as 8 shards of 1.25 M): rank 0 holds the query batch and broadcasts it (B x dim x 4 bytes), every rank searches ITS
+    shard with the same k / ef through `local_search(queries f32 [B][dim]) -> (ids [B][k] with 0xFFFFFFFF padding, dist f64
+    [B][k])` (bound to GpuHnswIndex.hnsw_knn_batch on the device), and merge_shard_topk all-gathers and merges the lists.
+    Every rank returns the same (ids int64 [B][k], -1 padded, global = local + id_offset; dist [B][k]).  Recall of the
+    merged result is at least the per-shard recall: a true neighbour is in exactly one shard and competes there with fewer
+    candidates."""
+    if world > 1:
+        q = queries.to(device=device, dtype=torch.float32).contiguous() if rank == 0 else \
+            torch.empty((n_queries, dim), dtype=torch.float32, device=device)
+        dist.broadcast(q, src=0, group=group)
+    else:
+        q = queries.to(device=device, dtype=torch.float32)
+    ids, d = local_search(q)
+    return merge_shard_topk(torch.as_tensor(ids).to(device), torch.as_tensor(d).to(device), id_offset, k, world, group=group)

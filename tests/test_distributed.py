@@ -234,3 +234,46 @@ def test_sharded_sources_world2(oracle, n_starts):
         assert p.exitcode == 0
     for _, got in res:
         assert np.array_equal(got, want)
+
+
+def _sharded_knn_worker(rank, world, port, base, queries, k, ef, q):
+    from oracle import oracle as O
+    from cozo_amd.distributed import sharded_hnsw_knn
+    _init(rank, world, port)
+    per = (base.shape[0] + world - 1) // world
+    lo, hi = rank * per, min(base.shape[0], (rank + 1) * per)
+    _, flat = util.build_index(O, base[lo:hi], O.L2, 8, 40, seed=rank + 1)  # an independent sub-index per rank
+
+    def local_search(qt):
+        ids, dist, _, _ = flat.knn_batch(qt.numpy(), k, ef)
+        return ids.astype(np.int64), dist
+    mi, md = sharded_hnsw_knn(local_search, torch.from_numpy(queries) if rank == 0 else None, queries.shape[0], queries.shape[1],
+                              lo, k, rank, world, torch.device("cpu"))
+    q.put((rank, mi.numpy(), md.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_hnsw_knn_world2(oracle):
+    """two independent sub-indices, queries broadcast from rank 0, lists merged: every rank ends with the same global top-k,
+    and its recall against the exact scan is at least what one index over everything reaches"""
+    rng = np.random.default_rng(8)
+    base = rng.random((1200, 16), dtype=np.float32)
+    queries = rng.random((20, 16), dtype=np.float32)
+    k, ef = 10, 60
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_knn_worker, args=(r, 2, port, base, queries, k, ef, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    d = ((queries[:, None, :].astype(np.float64) - base[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    truth = np.argsort(d, axis=1, kind="stable")[:, :k]
+    hits = sum(len(set(res[0][1][i].tolist()) & set(truth[i].tolist())) for i in range(queries.shape[0]))
+    assert hits / (k * queries.shape[0]) >= 0.95
+    assert np.all(np.diff(res[0][2], axis=1) >= 0)  # ascending by distance
