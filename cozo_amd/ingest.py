@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("COZO_INGEST_LIB") or os.path.join(_HERE, "lib", "libcozo_ingest.so")
 
 CZI_OK, CZI_E_INVALID, CZI_E_CORRUPT, CZI_E_NOT_AN_EDGE, CZI_E_BAD_WEIGHT = 0, -1, -2, -3, -4
-CZI_E_UNSUPPORTED, CZI_E_TOO_LARGE, CZI_E_MISSING_ROW = -5, -6, -7
+CZI_E_UNSUPPORTED, CZI_E_TOO_LARGE, CZI_E_MISSING_ROW, CZI_E_OOM = -5, -6, -7, -8
 CZI_UNDIRECTED, CZI_WEIGHTED, CZI_ALLOW_NEGATIVE_WEIGHTS, CZI_ORDERED_IDS = 1, 2, 4, 8
 
 u8p = C.POINTER(C.c_uint8)

@@ -636,7 +636,7 @@ int guarded(F &&f) {
     } catch (const Error &e) {
         return e.code;
     } catch (const std::bad_alloc &) {
-        return fail(CZI_E_INVALID, "out of host memory");
+        return fail(CZI_E_OOM, "out of host memory");
     } catch (const std::exception &e) {  // nothing may unwind through the C ABI
         return fail(CZI_E_INVALID, "%s", e.what());
     }
@@ -1015,7 +1015,7 @@ extern "C" int czi_graph_ingest(const czi_rows *rel, uint32_t flags, czi_graph *
     if (!out) return fail(CZI_E_INVALID, "null out");
     *out = nullptr;
     std::unique_ptr<czi_graph> g(new (std::nothrow) czi_graph);
-    if (!g) return fail(CZI_E_INVALID, "out of host memory");
+    if (!g) return fail(CZI_E_OOM, "out of host memory");
     const int rc = guarded([&] {
         check_rows(rel, "czi_graph_ingest");
         g->weighted = (flags & CZI_WEIGHTED) != 0;
@@ -1390,7 +1390,7 @@ extern "C" int czi_hnsw_ingest(const czi_rows *idx, const czi_rows *base, const 
     if (!out) return fail(CZI_E_INVALID, "null out");
     *out = nullptr;
     std::unique_ptr<czi_hnsw> h(new (std::nothrow) czi_hnsw);
-    if (!h) return fail(CZI_E_INVALID, "out of host memory");
+    if (!h) return fail(CZI_E_OOM, "out of host memory");
     const int rc = guarded([&] { ingest_hnsw(idx, base, vec_fields, n_fields, dim, metric, m_max, m_max0, *h); });
     if (rc) return rc;
     *out = h.release();
@@ -1751,7 +1751,7 @@ extern "C" int czi_hnsw_encode_rows(const cz_hnsw_desc *desc, const float *vecto
     *out = nullptr;
     if (!desc || (desc->n && (!vectors || !node_keys || !node_key_off))) return fail(CZI_E_INVALID, "null argument");
     std::unique_ptr<czi_row_buf> b(new (std::nothrow) czi_row_buf);
-    if (!b) return fail(CZI_E_INVALID, "out of host memory");
+    if (!b) return fail(CZI_E_OOM, "out of host memory");
     const int rc = guarded([&] { encode_index_rows(desc, vectors, node_keys, node_key_off, level_dist, relation_id, *b); });
     if (rc) return rc;
     *out = b.release();

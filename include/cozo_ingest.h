@@ -40,7 +40,8 @@ typedef enum {
     CZI_E_BAD_WEIGHT = -4,    /* BadEdgeWeightError, fixed_rule/mod.rs:852-860 */
     CZI_E_UNSUPPORTED = -5,   /* F64 vectors; Json / Regex / Validity node values that live in the VALUE part of a row */
     CZI_E_TOO_LARGE = -6,     /* more than 2^32 - 2 nodes or 2^32 - 1 CSR entries (the reference's ids are u32 too) */
-    CZI_E_MISSING_ROW = -7    /* an index row names a base row / vector that is not there ("corrupted index") */
+    CZI_E_MISSING_ROW = -7,   /* an index row names a base row / vector that is not there ("corrupted index") */
+    CZI_E_OOM = -8            /* host memory */
 } czi_status;
 
 const char *czi_last_error(void);

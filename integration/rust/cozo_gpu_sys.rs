@@ -107,6 +107,7 @@ pub const CZI_E_BAD_WEIGHT: c_int = -4; // -> BadEdgeWeightError (fixed_rule/mod
 pub const CZI_E_UNSUPPORTED: c_int = -5;
 pub const CZI_E_TOO_LARGE: c_int = -6;
 pub const CZI_E_MISSING_ROW: c_int = -7;
+pub const CZI_E_OOM: c_int = -8;
 
 pub const CZI_UNDIRECTED: u32 = 1;
 pub const CZI_WEIGHTED: u32 = 2;
