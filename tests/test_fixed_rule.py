@@ -570,3 +570,29 @@ def test_poison_is_honoured(registry):
     with pytest.raises(Exception) as ei:
         registry.run("ShortestPathBFSGpu", [rel([(1, 2)]), rel([[1]]), rel([[2]])], poison=p)
     assert "kill" in str(ei.value).lower() or "cancel" in str(ei.value).lower()
+
+
+def test_custom_rule_plumbing_like_the_reference():
+    """runtime/tests.rs:529-577 `test_custom_rules`: a user rule registered next to the GPU rules, fed by rel[] <- [[1,2,3,4],
+    [5,6,7,8]] with mult: 100, answers [[1000], [2600]] -- the boundary conformance case the reference itself pins."""
+    class Custom(FR.FixedRule):
+        def arity(self, options, rule_head):
+            return 1
+
+        def run(self, payload, out, poison):
+            rel_ = payload.get_input(0)
+            mult = payload.integer_option("mult", 2)
+            for row in rel_.iter():
+                out.put((sum(c if type(c) is int else 0 for c in row) * mult,))
+
+    reg = FR.FixedRuleRegistry()
+    reg.register_fixed_rule("SumCols", Custom())
+    assert reg.run("SumCols", [rel([[1, 2, 3, 4], [5, 6, 7, 8]])], {"mult": 100}) == [(1000,), (2600,)]
+    assert reg.run("SumCols", [rel([[1, 2, 3, 4], [5, 6, 7, 8]])]) == [(20,), (52,)]  # the default, mult = 2
+    with pytest.raises(FR.FixedRuleNameConflict):
+        reg.register_fixed_rule("SumCols", Custom())  # runtime/db.rs:769-774
+    with pytest.raises(FR.FixedRuleNameConflict):
+        reg.register_fixed_rule("PageRank", Custom())  # a built-in name
+    with pytest.raises(FR.FixedRuleNameConflict):
+        reg.unregister_fixed_rule("PageRank")  # :780-782
+    assert reg.unregister_fixed_rule("SumCols") and not reg.unregister_fixed_rule("SumCols")
