@@ -381,3 +381,24 @@ def test_threaded_and_one_thread_agree_at_scale(monkeypatch):
     for x, y in zip(a[2] + a[3], b[2] + b[3]):
         assert (x is None and y is None) or np.array_equal(x, y)
     assert a[0] <= 70_000 and a[2][1].size == 2 * n
+
+
+def test_reference_pinned_index_row_counts():
+    """runtime/tests.rs:700-741 `test_vec_index_insertion`: of two rows only 'a' passes the index filter; the reference asserts
+    that `?[k] := *a:vec{layer: 0, fr_k, to_k}, k = fr_k or k = to_k` then has exactly ONE row, and none once 'a' leaves the
+    index.  The rows the write-back emits for that one-vector index answer the same query the same way."""
+    vecs = np.array([[1, 2]], dtype=np.float32)
+    nbrs = [np.full((1, 100), NONE, dtype=np.uint32)]  # m = 50: level 0 rows are 2m wide, no links yet
+    tuples = index_relation_tuples([("a", 1, -1)], vecs, [None], nbrs, 0, lambda p: np.zeros(len(p)))
+    layer0 = [t for t in tuples if t[0] == 0]
+    assert {t[1] for t in layer0} | {t[4] for t in layer0} == {"a"}  # the query's distinct k: one row
+    assert len(tuples) == 2 and tuples[-1][0] == 1  # the self-loop row + the canary
+    assert layer0[0][7] == 0.0 and len(layer0[0][8]) == 32 and layer0[0][9] is False  # degree 0, SHA-256, not ignored
+    idx = codec.StoredRows.from_tuples(2, tuples, 7)
+    base = codec.StoredRows.from_tuples(1, [("a", vecs[0], True), ("b", np.array([2, 3], np.float32), False)], 1)
+    got = StoredHnswIndex(idx, base, [1], 2, 0, 50)
+    assert (got.n, got.n_levels, got.entry, got.nodes) == (1, 1, 0, [(0, 1, -1)]) and np.array_equal(got.vectors, vecs)
+    assert got.level_nbrs[0].shape == (1, 100) and (got.level_nbrs[0] == NONE).all()
+    # 'a' leaves the index: no rows at layer 0 (what is left of an emptied index is at most the canary)
+    emptied = StoredHnswIndex(codec.StoredRows.from_tuples(2, [tuples[-1]], 7), base, [1], 2, 0, 50)
+    assert emptied.n == 0 and emptied.n_levels == 0
