@@ -98,19 +98,24 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
 
 
 # ---- host ingest (cozo_amd/ingest): libcozo_ingest.so, stored rows -> flat arrays; no device code, no HIP ----------
-INGEST_SRC = os.path.join(HERE, "ingest", "ingest.cpp")
+INGEST_DIR = os.path.join(HERE, "ingest")
 INGEST_SO = os.path.join(LIBDIR, "libcozo_ingest.so")
+
+
+def ingest_sources():
+    return sorted(os.path.join(INGEST_DIR, f) for f in os.listdir(INGEST_DIR) if f.endswith(".cpp"))
 
 
 def build_ingest(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     inc = os.path.join(HERE, "..", "include")
-    newest = max(os.path.getmtime(INGEST_SRC), os.path.getmtime(os.path.join(inc, "cozo_ingest.h")),
-                 os.path.getmtime(os.path.join(inc, "cozo_gpu.h")))
+    deps = [os.path.join(INGEST_DIR, f) for f in os.listdir(INGEST_DIR) if f.endswith((".cpp", ".hpp"))]
+    deps += [os.path.join(inc, "cozo_ingest.h"), os.path.join(inc, "cozo_gpu.h")]
+    newest = max(os.path.getmtime(d) for d in deps)
     if not force and os.path.exists(INGEST_SO) and os.path.getmtime(INGEST_SO) >= newest:
         return INGEST_SO
-    subprocess.check_call([CXX, "-std=c++17", "-O2", "-fPIC", "-Wall", "-Wextra", "-pthread", "-shared", "-I" + inc,
-                           INGEST_SRC, "-o", INGEST_SO])
+    subprocess.check_call([CXX, "-std=c++17", "-O2", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wextra", "-pthread", "-shared",
+                           "-I" + inc, *ingest_sources(), "-o", INGEST_SO])
     if verbose:
         print("built", INGEST_SO)
     return INGEST_SO

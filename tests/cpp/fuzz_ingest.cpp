@@ -1,6 +1,6 @@
 // fuzz_ingest.cpp -- TEST ONLY.  Robustness of libcozo_ingest's parsers: a valid set of stored rows (written by the test
 // harness to a file) is mutated at random -- byte flips, truncations, offset-table damage -- and fed to the entry
-// points.  Built together with ingest.cpp under -fsanitize=address,undefined: every input must come back with CZI_OK or
+// points.  Built together with cozo_amd/ingest/*.cpp under -fsanitize=address,undefined: every input must come back with CZI_OK or
 // a negative status; a crash, an out-of-bounds read or an exception through the C ABI fails the test.
 //   fuzz_ingest <graph.bin> <idx.bin> <base.bin> <iterations>
 // file format: u32 n_key_cols, u64 n_rows, key_off[n_rows+1], val_off[n_rows+1], u64 key_bytes, keys, u64 val_bytes, vals

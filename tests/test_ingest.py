@@ -321,7 +321,7 @@ def _dump(rows: codec.StoredRows, path):
 
 
 def test_parsers_survive_damaged_rows_under_sanitizers(oracle, tmp_path):
-    """tests/cpp/fuzz_ingest.cpp: ingest.cpp built with -fsanitize=address,undefined and with -fsanitize=thread, thousands of
+    """tests/cpp/fuzz_ingest.cpp: the library's sources built with -fsanitize=address,undefined and with -fsanitize=thread, thousands of
     mutated inputs (byte flips, shifted row boundaries, wrong column counts): a status code every time, never a fault or race"""
     import os
     import subprocess
@@ -330,13 +330,15 @@ def test_parsers_survive_damaged_rows_under_sanitizers(oracle, tmp_path):
     graph = codec.StoredRows.from_tuples(9, _value_rows(3, 200), 2)
     for name, rows in (("graph", graph), ("idx", c["idx"]), ("base", c["base"])):
         _dump(rows, tmp_path / f"{name}.bin")
-    src = [os.path.join(root, "tests", "cpp", "fuzz_ingest.cpp"), os.path.join(root, "cozo_amd", "ingest", "ingest.cpp")]
+    from cozo_amd.build import INGEST_DIR, ingest_sources
+    src = [os.path.join(root, "tests", "cpp", "fuzz_ingest.cpp"), *ingest_sources()]
+    deps = src + [os.path.join(INGEST_DIR, "common.hpp")]
     os.makedirs(os.path.join(root, "tests", "cpp", "bin"), exist_ok=True)
     args = [str(tmp_path / "graph.bin"), str(tmp_path / "idx.bin"), str(tmp_path / "base.bin")]
     # address + undefined-behaviour sanitizers: the one-thread path and the hash-partitioned one; thread sanitizer: the latter
     for san, name, runs in (("address,undefined", "fuzz_ingest", (("1", "1500"), ("3", "700"))), ("thread", "fuzz_ingest_tsan", (("4", "300"),))):
         exe = os.path.join(root, "tests", "cpp", "bin", name)
-        if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(s) for s in src):
+        if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(s) for s in deps):
             subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=" + san, "-fno-sanitize-recover=all",
                                    "-I" + os.path.join(root, "include"), *src, "-o", exe])
         for threads, iters in runs:
