@@ -12,6 +12,8 @@
 //   ClusteringCoefficients       fixed_rule/algos/triangles.rs:25-110                  -> cz_clustering_coefficients
 //   DegreeCentrality             fixed_rule/algos/degree_centrality.rs:24-76           (a scan with counters: host only)
 //   ClosenessCentrality          fixed_rule/algos/all_pairs_shortest_path.rs:97-176    -> cz_sssp from every node
+//   BetweennessCentrality        fixed_rule/algos/all_pairs_shortest_path.rs:31-95     -> cz_sssp from every node + Brandes
+//                                                                                      accumulation on the tight-edge DAG (host)
 #pragma once
 #include "fixed_rule.hpp"
 
@@ -57,6 +59,12 @@ public:
 };
 
 class ClosenessCentrality : public FixedRule {
+public:
+    size_t arity(const std::map<std::string, DataValue> &, const std::vector<std::string> &) const override { return 2; }
+    void run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const override;
+};
+
+class BetweennessCentrality : public FixedRule {
 public:
     size_t arity(const std::map<std::string, DataValue> &, const std::vector<std::string> &) const override { return 2; }
     void run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const override;

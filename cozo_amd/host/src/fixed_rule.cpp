@@ -461,6 +461,7 @@ FixedRuleRegistry FixedRuleRegistry::with_gpu_defaults() {
     add("ShortestPathDijkstra", std::make_shared<ShortestPathDijkstra>());
     add("ClusteringCoefficients", std::make_shared<ClusteringCoefficients>());
     add("DegreeCentrality", std::make_shared<DegreeCentrality>());
+    add("BetweennessCentrality", std::make_shared<BetweennessCentrality>());
     add("ClosenessCentrality", std::make_shared<ClosenessCentrality>());
     return r;
 }

@@ -1061,3 +1061,91 @@ void orc_clustering_coefficients(uint32_t n, const uint64_t *off, const uint32_t
     }
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * BetweennessCentrality::run, fixed_rule/algos/all_pairs_shortest_path.rs:31-95, over dijkstra_keep_ties
+ * (shortest_path_dijkstra.rs:341-450).  Per start: the f32 distances of Dijkstra; back_pointers[v] = every in-edge (u, v)
+ * with dist[u] + w == dist[v] in f32 (one entry per edge occurrence: parallel edges multiply paths, :371-380); ALL
+ * shortest paths to every target are enumerated through them (:397-430), and every path of >= 3 nodes adds 1 / l (f32;
+ * l = the number of paths to that target) to each of its middle nodes (all_pairs:57-69).  The per-start maps are then
+ * added up in start order in f32 (:74-79).  The order of additions within one target is immaterial (equal addends), so
+ * the result is fully determined.  Literal enumeration: exponential in ties, for small graphs only (returns -1 past
+ * `max_paths` per start).  Weights must be > 0 (a zero-weight cycle makes the reference's recursion endless).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const uint32_t *bp_off, *bp;
+    uint32_t start;
+    float add;
+    float *seg;
+    uint32_t *chain;
+    uint64_t paths, max_paths;
+} orc_bc_ctx;
+
+static void orc_bc_walk(orc_bc_ctx *c, uint32_t depth, int count_only) {
+    const uint32_t last = c->chain[depth - 1];
+    for (uint32_t e = c->bp_off[last]; e < c->bp_off[last + 1]; e++) {
+        const uint32_t nxt = c->bp[e];
+        if (c->paths > c->max_paths) return;
+        c->chain[depth] = nxt;
+        if (nxt == c->start) {
+            c->paths++;
+            if (!count_only && depth + 1 >= 3)
+                for (uint32_t i = 1; i < depth; i++) c->seg[c->chain[i]] += c->add; /* the middle nodes */
+        } else {
+            orc_bc_walk(c, depth + 1, count_only);
+        }
+    }
+}
+
+int orc_betweenness(uint32_t n, const uint64_t *off, const uint32_t *tgt, const float *w, float *out, uint64_t max_paths) {
+    const uint64_t E = n ? off[n] : 0;
+    /* in-adjacency with weights, in out-CSR scan order */
+    uint32_t *in_off = (uint32_t *)calloc((size_t)n + 2, sizeof(uint32_t));
+    uint32_t *in_src = (uint32_t *)malloc(sizeof(uint32_t) * (E ? E : 1));
+    float *in_w = (float *)malloc(sizeof(float) * (E ? E : 1));
+    for (uint64_t e = 0; e < E; e++) in_off[tgt[e] + 1]++;
+    for (uint32_t v = 0; v < n; v++) in_off[v + 1] += in_off[v];
+    uint32_t *cur = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)n + 1));
+    memcpy(cur, in_off, sizeof(uint32_t) * ((size_t)n + 1));
+    for (uint32_t u = 0; u < n; u++)
+        for (uint64_t e = off[u]; e < off[u + 1]; e++) {
+            in_src[cur[tgt[e]]] = u;
+            in_w[cur[tgt[e]]++] = w[e];
+        }
+    float *dist = (float *)malloc(sizeof(float) * (n ? n : 1));
+    uint32_t *parent = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint32_t *bp_off = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)n + 1));
+    uint32_t *bp = (uint32_t *)malloc(sizeof(uint32_t) * (E ? E : 1));
+    float *seg = (float *)malloc(sizeof(float) * (n ? n : 1));
+    uint32_t *chain = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)n + 2));
+    int rc = 0;
+    for (uint32_t i = 0; i < n; i++) out[i] = 0.0f;
+    for (uint32_t s = 0; s < n && rc == 0; s++) {
+        orc_dijkstra(n, off, tgt, w, s, NULL, 0, dist, parent);
+        uint32_t k = 0;
+        for (uint32_t v = 0; v < n; v++) {
+            bp_off[v] = k;
+            if (v == s || !isfinite(dist[v])) continue;
+            for (uint32_t e = in_off[v]; e < in_off[v + 1]; e++) {
+                const uint32_t u = in_src[e];
+                if (isfinite(dist[u]) && (float)(dist[u] + in_w[e]) == dist[v]) bp[k++] = u;
+            }
+        }
+        bp_off[n] = k;
+        for (uint32_t i = 0; i < n; i++) seg[i] = 0.0f;
+        orc_bc_ctx c = {bp_off, bp, s, 0.0f, seg, chain, 0, max_paths};
+        for (uint32_t t = 0; t < n; t++) {
+            if (t == s || !isfinite(dist[t])) continue;
+            c.chain[0] = t;
+            c.paths = 0;
+            orc_bc_walk(&c, 1, 1);
+            if (c.paths > max_paths) { rc = -1; break; }
+            c.add = 1.0f / (float)c.paths; /* `1. / l`, l = grp.len() as f32 */
+            c.paths = 0;
+            orc_bc_walk(&c, 1, 0);
+        }
+        for (uint32_t i = 0; i < n; i++) out[i] += seg[i];
+    }
+    free(in_off); free(in_src); free(in_w); free(cur); free(dist); free(parent); free(bp_off); free(bp); free(seg); free(chain);
+    return rc;
+}

@@ -123,6 +123,10 @@ void orc_clustering_coefficients(uint32_t n, const uint64_t *off, const uint32_t
 void orc_dijkstra(uint32_t n, const uint64_t *off, const uint32_t *tgt, const float *w, uint32_t start,
                   const uint32_t *goals, uint32_t n_goals, float *dist, uint32_t *parent);
 
+/* ---- BetweennessCentrality (algos/all_pairs_shortest_path.rs:31-95 over dijkstra_keep_ties, shortest_path_dijkstra.rs:341-450) ---- */
+/* literal path enumeration (small graphs); out[n] f32 as the reference accumulates it; -1 when a start has > max_paths paths */
+int orc_betweenness(uint32_t n, const uint64_t *off, const uint32_t *tgt, const float *w, float *out, uint64_t max_paths);
+
 #ifdef __cplusplus
 }
 #endif

@@ -356,3 +356,16 @@ def dijkstra(n, off, tgt, w, start, goals=None):
     lib().orc_dijkstra(n, _p(off, _u64p), _p(tgt, _u32p), _p(w, _f32p), start, _p(g, _u32p),
                        0 if g is None else g.size, _p(dist, _f32p), _p(parent, _u32p))
     return dist, parent
+
+
+def betweenness(n, off, tgt, w, max_paths=10_000_000):
+    """BetweennessCentrality by literal enumeration of all shortest paths (small graphs) -> f32 [n]"""
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    tgt, w = _u32(tgt), _f32(w)
+    out = np.empty(n, dtype=np.float32)
+    fn = lib().orc_betweenness
+    fn.restype = C.c_int
+    rc = fn(n, _p(off, _u64p), _p(tgt, _u32p), _p(w, _f32p), _p(out, _f32p), C.c_uint64(max_paths))
+    if rc != 0:
+        raise RuntimeError("too many shortest paths to enumerate")
+    return out

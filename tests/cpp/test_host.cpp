@@ -636,6 +636,39 @@ static void gpu_closeness_centrality() {
     CHECK(ok);
 }
 
+static void gpu_betweenness_centrality() {
+    // all_pairs_shortest_path.rs:31-95: against the oracle's literal enumeration of all shortest paths (f32, the reference's
+    // order); small integer weights make ties, i.e. several shortest paths per pair and fractional shares
+    FixedRuleRegistry reg = FixedRuleRegistry::with_gpu_defaults();
+    std::mt19937_64 rng(41);
+    std::vector<Tuple> rows;
+    for (int i = 0; i < 110; i++) {
+        const int64_t a = (int64_t)(rng() % 30), b = (int64_t)(rng() % 30);
+        if (a != b) rows.push_back(T({DataValue(a), DataValue(b), DataValue((int64_t)(1 + rng() % 3))}));
+    }
+    for (bool undirected : {false, true}) {
+        FixedRuleInputRelation rel(rows);
+        RegularTempStore out = reg.run("BetweennessCentrality",
+                                       FixedRulePayload("BetweennessCentrality", {rel}, {{"undirected", DataValue(undirected)}}), Poison());
+        GraphWithIndices g = rel.as_directed_weighted_graph(undirected, false);
+        const uint32_t n = g.graph.n;
+        std::vector<uint64_t> off = to_u64(g.graph.out_offsets);
+        std::vector<float> want(n);
+        CHECK(orc_betweenness(n, off.data(), g.graph.out_targets.data(), g.graph.out_weights.data(), want.data(), 10000000) == 0);
+        bool ok = out.size() == n, fractional = false;
+        for (const Tuple &t : out) {
+            const uint32_t v = g.inv_indices.at(t[0]);
+            double got = 0;
+            ok = ok && t[1].get_float(&got) && std::fabs(got - (double)want[v]) <= 1e-5 * std::fabs((double)want[v]) + 1e-6;
+            fractional |= std::fabs(want[v] - std::round(want[v])) > 1e-3f;
+        }
+        CHECK(ok && fractional);
+    }
+    CHECK((throws<CozoError>([&] {
+        reg.run("BetweennessCentrality", FixedRulePayload("BetweennessCentrality", {FixedRuleInputRelation({T({DataValue("a"), DataValue("b"), DataValue(0.0)})})}), Poison());
+    }, "algo::betweenness_needs_positive_weights")));
+}
+
 static void gpu_rules_on_stored_relation() {
     // every rule off the stored bytes of its edge relation (FixedRuleInputRelation::from_stored -> libcozo_ingest) and off
     // the decoded tuples: the same rows
@@ -869,6 +902,7 @@ int main(int argc, char **argv) {
         gpu_bfs_cc_dijkstra_random();
         gpu_clustering_coefficients();
         gpu_closeness_centrality();
+        gpu_betweenness_centrality();
         gpu_rules_on_stored_relation();
     }
     if (mode == "gpu") {
@@ -888,6 +922,7 @@ int main(int argc, char **argv) {
             std::printf("FAIL: cz_init: %s\n", cz_last_error());
             return 2;
         }
+        gpu_betweenness_centrality();
         gpu_rules_on_stored_relation();
         gpu_index_through_the_store();
     }
