@@ -71,7 +71,7 @@ def test_weighted_rules_read_stored_bytes(registry, n_key_cols):
     starts, ends = [[nodes[0]], [nodes[5]]], [[nodes[2]], [nodes[9]]]
     for name, extra, opts in [("ShortestPathDijkstraGpu", [rel(starts)], {}),
                               ("ShortestPathDijkstraGpu", [rel(starts), rel(ends)], {"undirected": True}),
-                              ("ClosenessCentralityGpu", [], {})]:
+                              ("ClosenessCentralityGpu", [], {}), ("BetweennessCentralityGpu", [], {"undirected": True})]:
         a = registry.run(name, [plain] + extra, opts)
         b = registry.run(name, [stored] + extra, opts)
         assert a == b and len(a) > 0, name
