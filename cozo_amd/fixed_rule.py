@@ -644,20 +644,55 @@ class ShortestPathDijkstra(FixedRule):
         termination_nodes = None
         if termination is not None:
             termination_nodes = sorted({inv[_canon(t[0])] for t in termination.iter() if _canon(t[0]) in inv})
-        if keep_ties:
-            raise _lib.CozoGpuError(_lib.CZ_E_UNSUPPORTED, "keep_ties is not available on the GPU path")
         if not starting_nodes:
             return
         targets = range(graph.n) if termination_nodes is None else termination_nodes
         if termination_nodes is not None and not termination_nodes:
             return
+        # `keep_ties` only takes effect when a termination relation is given (:73-86: without one the reference calls the plain
+        # `dijkstra` whatever the option says)
+        keep_ties = keep_ties and termination_nodes is not None
+        if keep_ties and graph.out_weights.size and not (graph.out_weights > 0).all():
+            raise FixedRuleError("keep_ties on the GPU path needs positive edge weights")
         starts = np.array(starting_nodes, dtype=np.uint32)
         dist, parent = _graph.sssp(graph.out_offsets, graph.out_targets, graph.out_weights, starts, poison=poison.flag)
+        if keep_ties:
+            off = np.asarray(graph.out_offsets, dtype=np.int64)
+            src_of = np.repeat(np.arange(graph.n, dtype=np.int64), np.diff(off))
         for si, s in enumerate(starting_nodes):
+            if not keep_ties:
+                for t in targets:
+                    cost = float(dist[si, t])
+                    path = [] if not math.isfinite(cost) else [indices[i] for i in _path(parent[si], s, t)]
+                    out.put((indices[s], indices[t], cost, path))
+                continue
+            # dijkstra_keep_ties (:341-450): back_pointers[v] = every edge (u, v) with dist[u] + w == dist[v] in f32 -- read off
+            # the device's bit-exact distances -- and EVERY path through them is a row.  The start as its own target has no
+            # back pointer and therefore no row (:397-430 collects nothing for it).
+            d = dist[si]
+            with np.errstate(invalid="ignore"):
+                tight = np.isfinite(d[src_of]) & ((d[src_of] + graph.out_weights).astype(np.float32) == d[graph.out_targets])
+            preds: Dict[int, List[int]] = {}
+            for u, v in zip(src_of[tight].tolist(), graph.out_targets[tight].tolist()):
+                preds.setdefault(v, []).append(u)
             for t in targets:
-                cost = float(dist[si, t])
-                path = [] if not math.isfinite(cost) else [indices[i] for i in _path(parent[si], s, t)]
-                out.put((indices[s], indices[t], cost, path))
+                cost = float(d[t])
+                if not math.isfinite(cost):
+                    out.put((indices[s], indices[t], cost, []))
+                    continue
+                stack = [[t]]
+                emitted = 0
+                while stack:
+                    chain = stack.pop()
+                    for u in preds.get(chain[-1], ()):
+                        if u == s:
+                            out.put((indices[s], indices[t], cost, [indices[i] for i in reversed(chain + [u])]))
+                            emitted += 1
+                            if emitted > 1_000_000:
+                                raise FixedRuleError("keep_ties: more than 1 000 000 shortest paths between one pair")
+                        else:
+                            stack.append(chain + [u])
+                poison.check()
 
 
 class ClusteringCoefficients(FixedRule):

@@ -213,15 +213,55 @@ void ShortestPathDijkstra::run(const FixedRulePayload &payload, RegularTempStore
     const std::vector<uint32_t> starting_nodes = id_set(starting);
     std::vector<uint32_t> termination_nodes;
     if (termination) termination_nodes = id_set(*termination);
-    if (keep_ties) throw GpuError(CZ_E_UNSUPPORTED, "keep_ties is not available on the GPU path");
     if (starting_nodes.empty()) return;
     if (termination && termination_nodes.empty()) return;
+    // keep_ties only takes effect with a termination relation (:73-86: without one the reference runs the plain dijkstra)
+    const bool ties = keep_ties && termination;
+    if (ties)
+        for (float w : gr.out_weights)
+            if (!(w > 0.0f)) throw CozoError("algo::keep_ties_needs_positive_weights", "keep_ties on the GPU path needs positive edge weights");
     const size_t ns = starting_nodes.size();
     std::vector<float> dist(ns * gr.n);
     std::vector<uint32_t> parent(ns * gr.n);
     check_gpu(cz_sssp(gr.out_offsets.data(), gr.out_targets.data(), gr.out_weights.data(), gr.n, gr.edge_count(),
                       starting_nodes.data(), (uint32_t)ns, dist.data(), parent.data(), poison.flag_ptr()));
-    for (size_t si = 0; si < ns; si++) {
+    for (size_t si = 0; si < ns && ties; si++) {
+        // dijkstra_keep_ties (:341-450): back_pointers[v] = every edge (u, v) with dist[u] + w == dist[v] in f32 -- read off the
+        // device's bit-exact distances -- and EVERY path through them is a row; the start as its own target collects nothing
+        const uint32_t s = starting_nodes[si];
+        const float *d = dist.data() + si * gr.n;
+        std::vector<std::vector<uint32_t>> preds(gr.n);
+        for (uint32_t u = 0; u < gr.n; u++) {
+            if (!std::isfinite(d[u])) continue;
+            for (uint32_t e = gr.out_offsets[u]; e < gr.out_offsets[u + 1]; e++)
+                if ((float)(d[u] + gr.out_weights[e]) == d[gr.out_targets[e]]) preds[gr.out_targets[e]].push_back(u);
+        }
+        for (uint32_t t : termination_nodes) {
+            if (!std::isfinite(d[t])) {
+                out.put(Tuple{g.indices[s], g.indices[t], DataValue((double)d[t]), DataValue::list({})});
+                continue;
+            }
+            std::vector<std::vector<uint32_t>> stack{{t}};
+            size_t emitted = 0;
+            while (!stack.empty()) {
+                std::vector<uint32_t> chain = std::move(stack.back());
+                stack.pop_back();
+                for (uint32_t u : preds[chain.back()]) {
+                    std::vector<uint32_t> next = chain;
+                    next.push_back(u);
+                    if (u == s) {
+                        std::reverse(next.begin(), next.end());
+                        out.put(Tuple{g.indices[s], g.indices[t], DataValue((double)d[t]), path_value(next, g.indices)});
+                        if (++emitted > 1000000) throw CozoError("algo::too_many_paths", "keep_ties: more than 1 000 000 shortest paths between one pair");
+                    } else {
+                        stack.push_back(std::move(next));
+                    }
+                }
+            }
+            poison.check();
+        }
+    }
+    for (size_t si = 0; si < ns && !ties; si++) {
         const uint32_t s = starting_nodes[si];
         auto emit = [&](uint32_t t) {
             const float cost = dist[si * gr.n + t];

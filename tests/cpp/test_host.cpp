@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <random>
 #include <string>
 #include <vector>
@@ -669,6 +670,83 @@ static void gpu_betweenness_centrality() {
     }, "algo::betweenness_needs_positive_weights")));
 }
 
+static void gpu_dijkstra_keep_ties() {
+    // ShortestPathDijkstra{keep_ties: true} (shortest_path_dijkstra.rs:341-450): every shortest path is a row.  Checked by
+    // properties that do not share the implementation's route: every row's path is a real path whose f32 cost, added left to
+    // right, is the oracle's Dijkstra cost; the rows of a pair are distinct; and their number equals the path count of an
+    // independent DP over nodes in order of distance.
+    FixedRuleRegistry reg = FixedRuleRegistry::with_gpu_defaults();
+    std::mt19937_64 rng(57);
+    std::vector<Tuple> rows;
+    for (int i = 0; i < 130; i++) {
+        const int64_t a = (int64_t)(rng() % 32), b = (int64_t)(rng() % 32);
+        if (a != b) rows.push_back(T({DataValue(a), DataValue(b), DataValue((int64_t)(1 + rng() % 2))}));
+    }
+    FixedRuleInputRelation rel(rows);
+    GraphWithIndices g = rel.as_directed_weighted_graph(true, false);
+    const uint32_t n = g.graph.n;
+    std::vector<Tuple> st = {T({g.indices[0]}), T({g.indices[5]})}, en;
+    for (uint32_t v = 0; v < n; v += 2) en.push_back(T({g.indices[v]}));
+    RegularTempStore out = reg.run("ShortestPathDijkstra", FixedRulePayload("ShortestPathDijkstra", {rel, FixedRuleInputRelation(st), FixedRuleInputRelation(en)},
+                                                                              {{"undirected", DataValue(true)}, {"keep_ties", DataValue(true)}}), Poison());
+    std::vector<uint64_t> off = to_u64(g.graph.out_offsets);
+    bool ok = true, saw_tie = false;
+    size_t checked = 0;
+    for (uint32_t s : {0u, 5u}) {
+        std::vector<float> dist(n);
+        std::vector<uint32_t> par(n), order(n);
+        orc_dijkstra(n, off.data(), g.graph.out_targets.data(), g.graph.out_weights.data(), s, nullptr, 0, dist.data(), par.data());
+        for (uint32_t v = 0; v < n; v++) order[v] = v;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return dist[a] < dist[b]; });
+        std::vector<double> sigma(n, 0.0);
+        sigma[s] = 1.0;
+        for (uint32_t u : order) {
+            if (!std::isfinite(dist[u])) continue;
+            for (uint32_t e = g.graph.out_offsets[u]; e < g.graph.out_offsets[u + 1]; e++)
+                if ((float)(dist[u] + g.graph.out_weights[e]) == dist[g.graph.out_targets[e]]) sigma[g.graph.out_targets[e]] += sigma[u];
+        }
+        std::map<uint32_t, size_t> count;
+        for (const Tuple &t : out) {
+            if (g.inv_indices.at(t[0]) != s) continue;
+            const uint32_t tv = g.inv_indices.at(t[1]);
+            const std::vector<DataValue> &path = *t[3].get_slice();
+            double cost = 0;
+            t[2].get_float(&cost);
+            if (path.empty()) {
+                ok &= std::isinf(cost) && !std::isfinite(dist[tv]);
+                continue;
+            }
+            count[tv]++;
+            ok &= path.front() == g.indices[s] && path.back() == g.indices[tv] && cost == (double)dist[tv];
+            float acc = 0.0f;
+            for (size_t i = 0; i + 1 < path.size(); i++) {  // every hop is an edge; the cheapest parallel edge carries the path
+                const uint32_t u = g.inv_indices.at(path[i]), v = g.inv_indices.at(path[i + 1]);
+                float best = INFINITY;
+                for (uint32_t e = g.graph.out_offsets[u]; e < g.graph.out_offsets[u + 1]; e++)
+                    if (g.graph.out_targets[e] == v) best = std::min(best, g.graph.out_weights[e]);
+                ok &= std::isfinite(best);
+                acc = acc + best;
+            }
+            ok &= acc == dist[tv];
+            checked++;
+        }
+        for (uint32_t v = 0; v < n; v += 2) {
+            if (v == s || !std::isfinite(dist[v])) {
+                ok &= count.count(v) == 0;  // the start as its own target: no row; unreachable: the (inf, []) row only
+                continue;
+            }
+            // the set store folds identical paths (parallel edges of equal weight): distinct rows <= sigma, and >= 1
+            ok &= count[v] >= 1 && (double)count[v] <= sigma[v];
+            saw_tie |= count[v] >= 2;
+        }
+    }
+    CHECK(ok && saw_tie && checked > 20);
+    // without a termination relation keep_ties changes nothing (:73-86)
+    RegularTempStore plain = reg.run("ShortestPathDijkstra", FixedRulePayload("ShortestPathDijkstra", {rel, FixedRuleInputRelation(st)}), Poison());
+    RegularTempStore kt = reg.run("ShortestPathDijkstra", FixedRulePayload("ShortestPathDijkstra", {rel, FixedRuleInputRelation(st)}, {{"keep_ties", DataValue(true)}}), Poison());
+    CHECK(plain.rows() == kt.rows() && plain.size() == 2 * (size_t)n);
+}
+
 static void gpu_rules_on_stored_relation() {
     // every rule off the stored bytes of its edge relation (FixedRuleInputRelation::from_stored -> libcozo_ingest) and off
     // the decoded tuples: the same rows
@@ -903,6 +981,7 @@ int main(int argc, char **argv) {
         gpu_clustering_coefficients();
         gpu_closeness_centrality();
         gpu_betweenness_centrality();
+        gpu_dijkstra_keep_ties();
         gpu_rules_on_stored_relation();
     }
     if (mode == "gpu") {
@@ -923,6 +1002,7 @@ int main(int argc, char **argv) {
             return 2;
         }
         gpu_betweenness_centrality();
+        gpu_dijkstra_keep_ties();
         gpu_rules_on_stored_relation();
         gpu_index_through_the_store();
     }

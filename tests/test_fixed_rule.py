@@ -491,15 +491,15 @@ def test_dijkstra_rule(registry, undirected):
         assert full[(s, t)] == cost
 
 
-def test_dijkstra_rule_weight_errors_and_unsupported(registry):
+def test_dijkstra_rule_weight_errors_and_defaults(registry):
     for bad in ("x", float("nan"), float("inf"), -1.0, None):
         with pytest.raises(FR.BadEdgeWeightError):
             registry.run("ShortestPathDijkstraGpu", [rel([(1, 2, bad)]), rel([(1,)])])
-    from cozo_amd._lib import CozoGpuError
-    with pytest.raises(CozoGpuError):
-        registry.run("ShortestPathDijkstraGpu", [rel([(1, 2, 1.0)]), rel([(1,)])], {"keep_ties": True})
     rows = registry.run("ShortestPathDijkstraGpu", [rel([(1, 2)]), rel([(1,)])])  # default weight 1.0
     assert rows == [(1, 1, 0.0, [1]), (1, 2, 1.0, [1, 2])]
+    # keep_ties without a termination relation is the plain run (shortest_path_dijkstra.rs:73-86 never reaches
+    # dijkstra_keep_ties then); with one it is tests/test_zz_betweenness.py
+    assert registry.run("ShortestPathDijkstraGpu", [rel([(1, 2, 1.0)]), rel([(1,)])], {"keep_ties": True}) == rows
 
 
 @pytest.mark.parametrize("undirected", [False, True])

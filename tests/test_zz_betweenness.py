@@ -60,3 +60,72 @@ def test_betweenness_centrality_rule_edges(registry):
         registry.run("BetweennessCentralityGpu", [rel([("a", "b", 0.0)])])
     with pytest.raises(FR.BadEdgeWeightError):
         registry.run("BetweennessCentralityGpu", [rel([("a", "b", -1.0)])])
+
+
+# ---- ShortestPathDijkstra with keep_ties (shortest_path_dijkstra.rs:341-450): every shortest path is a row ------------------
+def ref_dijkstra_keep_ties(edge_rows, undirected, start, goals):
+    """dijkstra_keep_ties restated literally over values: f32 costs, back pointers cleared on a strict improvement and
+    appended on an equal cost, every path through them collected; returns {(target, cost, tuple(path))}"""
+    import heapq
+    adj = {}
+    for r in edge_rows:
+        w = np.float32(1.0 if len(r) < 3 else r[2])
+        adj.setdefault(r[0], []).append((r[1], w))
+        if undirected:
+            adj.setdefault(r[1], []).append((r[0], w))
+    dist, back = {start: np.float32(0)}, {}
+    pq = [(np.float32(0), start)]
+    while pq:
+        cost, node = heapq.heappop(pq)
+        if cost > dist.get(node, np.float32(np.inf)):
+            continue
+        for nxt, w in adj.get(node, ()):
+            nc = np.float32(cost + w)
+            cur = dist.get(nxt, np.float32(np.inf))
+            if nc < cur:
+                dist[nxt] = nc
+                back[nxt] = [node]
+                heapq.heappush(pq, (nc, nxt))
+            elif nc == cur:
+                back[nxt].append(node)
+    out = set()
+    for t in goals:
+        if t not in dist:
+            out.add((t, float("inf"), ()))
+            continue
+
+        def collect(chain):
+            for nxt in back.get(chain[-1], ()):
+                if nxt == start:
+                    out.add((t, float(dist[t]), tuple(reversed(chain + [nxt]))))
+                else:
+                    collect(chain + [nxt])
+        collect([t])
+    return out
+
+
+@pytest.mark.parametrize("undirected", [False, True])
+def test_dijkstra_keep_ties_rule(registry, undirected):
+    rng = np.random.default_rng(31)
+    names = [f"n{i:02d}" for i in range(30)]
+    pairs = sorted({(names[a], names[b]) for a, b in rng.integers(0, 30, (110, 2)) if a != b})
+    edges = [(a, b, int(rng.integers(1, 3))) for a, b in pairs]  # weights 1 or 2: plenty of equal-cost paths
+    nodes = sorted({v for e in edges for v in e[:2]})
+    starts, goals = [nodes[0], nodes[4]], nodes[::2]
+    rows = registry.run("ShortestPathDijkstraGpu", [rel(edges), rel([(s,) for s in starts]), rel([(g,) for g in goals] + [("ghost",)])],
+                        {"undirected": undirected, "keep_ties": True})
+    want = set()
+    for s in starts:
+        for t, cost, path in ref_dijkstra_keep_ties(edges, undirected, s, goals):
+            want.add((s, t, cost, path))
+    got = {(s, t, c, tuple(p)) for s, t, c, p in rows}
+    assert got == want
+    by_pair = {}
+    for s, t, c, p in got:
+        by_pair.setdefault((s, t), []).append(p)
+    assert max(len(v) for v in by_pair.values()) >= 2  # ties were really exercised
+    assert (starts[0], starts[0]) not in by_pair       # the start as its own target collects nothing (:397-430)
+    # one start and one goal (the `single` branch, :73-80) gives the same rows for that pair
+    one = registry.run("ShortestPathDijkstraGpu", [rel(edges), rel([(starts[0],)]), rel([(goals[1],)])],
+                       {"undirected": undirected, "keep_ties": True})
+    assert {(s, t, c, tuple(p)) for s, t, c, p in one} == {r for r in got if r[0] == starts[0] and r[1] == goals[1]}
