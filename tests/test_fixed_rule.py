@@ -498,7 +498,7 @@ def test_dijkstra_rule_weight_errors_and_defaults(registry):
     rows = registry.run("ShortestPathDijkstraGpu", [rel([(1, 2)]), rel([(1,)])])  # default weight 1.0
     assert rows == [(1, 1, 0.0, [1]), (1, 2, 1.0, [1, 2])]
     # keep_ties without a termination relation is the plain run (shortest_path_dijkstra.rs:73-86 never reaches
-    # dijkstra_keep_ties then); with one it is tests/test_zz_betweenness.py
+    # dijkstra_keep_ties then); with one it is tests/test_zz_tie_rules.py
     assert registry.run("ShortestPathDijkstraGpu", [rel([(1, 2, 1.0)]), rel([(1,)])], {"keep_ties": True}) == rows
 
 

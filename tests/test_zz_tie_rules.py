@@ -1,5 +1,6 @@
-"""BetweennessCentralityGpu: device SSSP from every node + Brandes accumulation on the tight-edge DAG,
-against the oracle's literal restatement of the reference (dijkstra_keep_ties + enumeration of all shortest paths).  Host logic
+"""The two rules built on `dijkstra_keep_ties` (shortest_path_dijkstra.rs:341-450).  BetweennessCentralityGpu (SURVEY section 8
+f3): device SSSP from every node + Brandes accumulation on the tight-edge DAG, against the oracle's literal restatement of the
+reference (enumeration of all shortest paths).  ShortestPathDijkstraGpu with keep_ties: every shortest path is a row.  Host logic
 on CPU with the oracle standing in for cz_sssp, and, marked gpu, through the C ABI on the device.  (In a file of its own so that
 it runs after the established device tests.)"""
 import numpy as np
