@@ -197,3 +197,70 @@ def sharded_hnsw_knn(local_search: Callable, queries: Optional[torch.Tensor], n_
         q = queries.to(device=device, dtype=torch.float32)
     ids, d = local_search(q)
     return merge_shard_topk(torch.as_tensor(ids).to(device), torch.as_tensor(d).to(device), id_offset, k, world, group=group)
+
+
+class OverlappedShardedPageRank:
+    """ShardedPageRank with the exchange of the first half of a rank's rows in flight while the second half computes.
+
+    The exchange of iteration k feeds iteration k+1, so the only overlap there is lies inside an iteration: the rank's row
+    range [rb, re) is cut at `mid` into TWO plans (two cz_pagerank_plan handles over the two sub-CSRs -- no new device code);
+    step(first) -> start gathering every rank's first-half slice (async, on the collective's own stream) -> step(second) runs
+    meanwhile -> gather the second-half slices -> wait.  Slices land at their natural places in the full contribution vector
+    (a list all-gather into views), so sources keep their ids and every row sum keeps its order: scores are bit-identical to
+    the unsplit run.  Hides min(second-half sweep, first-half gather) per iteration.
+
+    local_init(contrib_full); local_steps = (step_first, step_second), each (contrib_in, contrib_out, err) like
+    ShardedPageRank.local_step but for rows [rb, mid) / [mid, re).  `halves` = how many rows of the padded per-rank range
+    belong to the first plan (the same on every rank)."""
+
+    def __init__(self, n_nodes: int, rank: int, world: int, device: torch.device, local_init: Callable,
+                 local_steps: Tuple[Callable, Callable], halves: Optional[int] = None, group=None):
+        self.n, self.rank, self.world, self.device, self.group = n_nodes, rank, world, device, group
+        self.per, self.ranges = equal_row_partition(n_nodes, world)
+        self.half = self.per // 2 if halves is None else halves
+        self.local_init, self.local_steps = local_init, local_steps
+        padded = self.per * world
+        self.contrib = [torch.zeros(padded, dtype=torch.float32, device=device) for _ in range(2)]
+        self.err = torch.zeros(1, dtype=torch.float64, device=device)
+
+    def split_rows(self) -> Tuple[int, int, int]:
+        """(row_begin, mid, row_end) of this rank: what the two plans are created over"""
+        rb, re = self.ranges[self.rank]
+        return rb, min(re, self.rank * self.per + self.half), re
+
+    def _views(self, buf: torch.Tensor, first: bool):
+        lo, hi = (0, self.half) if first else (self.half, self.per)
+        return [buf[r * self.per + lo:r * self.per + hi] for r in range(self.world)]
+
+    def run(self, tolerance: float, max_iter: int, poison: Optional[Callable[[], bool]] = None):
+        cin, cout = self.contrib
+        self.local_init(cin)
+        it = 0
+        never_stops_early = not (tolerance > 0.0)
+        while True:
+            if poison is not None and poison():
+                raise RuntimeError("ProcessKilled")
+            last = it + 1 == max_iter
+            self.err.zero_()
+            self.local_steps[0](cin, cout, self.err)
+            pending = None
+            if self.world > 1 and self.half > 0:
+                v = self._views(cout, True)
+                pending = dist.all_gather(v, v[self.rank], group=self.group, async_op=True)
+            self.local_steps[1](cin, cout, self.err)
+            if self.world > 1:
+                if self.per - self.half > 0:
+                    v = self._views(cout, False)
+                    dist.all_gather(v, v[self.rank], group=self.group)
+                if pending is not None:
+                    pending.wait()
+                if last or not never_stops_early:
+                    dist.all_reduce(self.err, op=dist.ReduceOp.SUM, group=self.group)
+            cin, cout = cout, cin
+            it += 1
+            if never_stops_early and not last:
+                continue
+            e = float(self.err.item())
+            if e < tolerance or it == max_iter:
+                self.contrib = [cin, cout]
+                return it, e

@@ -277,3 +277,45 @@ def test_sharded_hnsw_knn_world2(oracle):
     hits = sum(len(set(res[0][1][i].tolist()) & set(truth[i].tolist())) for i in range(queries.shape[0]))
     assert hits / (k * queries.shape[0]) >= 0.95
     assert np.all(np.diff(res[0][2], axis=1) >= 0)  # ascending by distance
+
+
+def _overlap_worker(rank, world, port, n, ioff, isrc, outdeg, tol, max_iter, q):
+    from cozo_amd.distributed import OverlappedShardedPageRank
+    _init(rank, world, port)
+    probe = OverlappedShardedPageRank(n, rank, world, torch.device("cpu"), None, (None, None))
+    rb, mid, re = probe.split_rows()
+    li1, ls1, st1 = _shard_step_factory(n, ioff, isrc, outdeg, rb, mid, 0.85)
+    li2, ls2, st2 = _shard_step_factory(n, ioff, isrc, outdeg, mid, re, 0.85)
+
+    def init(c):
+        li1(c)
+        li2(c)
+    sp = OverlappedShardedPageRank(n, rank, world, torch.device("cpu"), init, (ls1, ls2))
+    it, err = sp.run(tol, max_iter)
+    q.put((rank, rb, re, np.concatenate([st1["scores"], st2["scores"]]), it, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,e,tol,max_iter", [(301, 2500, 1e-4, 10), (64, 400, 0.0, 5), (7, 12, 1e-4, 10), (2, 1, 0.0, 3)])
+def test_overlapped_sharded_pagerank_world2_is_bit_identical(oracle, n, e, tol, max_iter):
+    """two plans per rank, first-half slices gathered (async) while the second half computes: the scores, the iteration count
+    and the stopping decision of the single-process run"""
+    frm, to = util.random_relation(n, e, 19)
+    g = util.graph_from_relation(oracle, frm, to)
+    want, want_it, want_err = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, tol, max_iter)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, g["n"], g["ioff"], g["isrc"], g["outdeg"], tol, max_iter, q))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got = np.concatenate([r[3] for r in res])
+    assert [r[4] for r in res] == [want_it, want_it]
+    assert np.array_equal(got, want)
+    assert abs(res[0][5] - want_err) <= 1e-12 * max(1.0, abs(want_err)) and res[0][5] == res[1][5]
