@@ -149,3 +149,25 @@ def test_stored_rows_sorted_and_replacing():
     assert rows.tuples() == [[1, "a", 9.0], [2, "b", 3.0], [3, "c", 1.0]]
     k, v = rows.row(0)
     assert k[:8] == (11).to_bytes(8, "big") and v[:8] == (11).to_bytes(8, "big")
+
+
+def test_golden_stored_rows():
+    """tests/golden/stored_rows.json (made by tests/golden/make_stored_rows.py): our encoders write today what they wrote when
+    the fixture was committed, and the fixture decodes back to the rows"""
+    import importlib.util
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_stored_rows", os.path.join(here, "golden", "make_stored_rows.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    golden = json.load(open(os.path.join(here, "golden", "stored_rows.json")))
+    assert mod.build() == golden
+    g = golden["ints"]
+    assert codec.decode_tuple_from_kv(bytes.fromhex(g["key"]), bytes.fromhex(g["val"])) == [2095, -1, 0, 2 ** 53, -(2 ** 63)]
+    g = golden["mixed-key-and-value"]
+    back = codec.decode_tuple_from_kv(bytes.fromhex(g["key"]), bytes.fromhex(g["val"]))
+    assert back == [7, "k", None, True, False, b"\x00\x01", [1, "x", [2.5]], 3.25, "value", -70000, 2 ** 40]
+    # the two spelled-out examples of the formats (include/cozo_ingest.h): 2095 as a key column, [5, Null] as a value
+    assert codec.memcmp_bytes(2095).hex() == "05" + "c0a05e0000000000" + "00"
+    assert codec.encode_val_for_store(3, [5, None]).hex() == "0000000000000003" + "92" + "81a34e756d" + "81a3496e74" + "05" + "a44e756c6c"
