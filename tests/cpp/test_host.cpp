@@ -320,6 +320,35 @@ static void test_codec_bytes_and_values() {
     CHECK(v == std::vector<uint8_t>(want, want + sizeof want));  // [{"Num": {"Int": 5}}, "Null"]
 }
 
+static std::string hex(const std::vector<uint8_t> &b) {
+    static const char *d = "0123456789abcdef";
+    std::string s;
+    for (uint8_t x : b) {
+        s.push_back(d[x >> 4]);
+        s.push_back(d[x & 15]);
+    }
+    return s;
+}
+
+static void test_codec_agrees_with_the_python_codec() {
+    // tests/golden/stored_rows.json (written by cozo_amd/codec.py): the C++ encoders produce the same bytes
+    const Tuple ints = T({DataValue((int64_t)2095), DataValue((int64_t)-1), DataValue((int64_t)0), DataValue((int64_t)1 << 53), DataValue(INT64_MIN)});
+    CHECK(hex(encode_key_for_store(9, ints, 5)) ==
+          "000000000000000905c0a05e00000000000005400fffffffffffff000580000000000000000005c340000000000000048020000000000000053c1fffffffffffff040000000000000000");
+    CHECK(hex(encode_val_for_store(9, ints, 5)) == "000000000000000990");
+    const Tuple strs = T({DataValue("MSS"), DataValue(""), DataValue("abcdefgh"), DataValue("abcdefghi"), DataValue("\xc3\xbc")});
+    CHECK(hex(encode_key_for_store(9, strs, 5)) ==
+          "0000000000000009064d53530000000000fa060000000000000000f7066162636465666768ff0000000000000000f7066162636465666768ff6900000000000000f806c3bc000000000000f9");
+    const Tuple mixed = T({DataValue((int64_t)7), DataValue("k"), DataValue(), DataValue(true), DataValue(false), DataValue(Bytes{{0, 1}}),
+                           DataValue::list({DataValue((int64_t)1), DataValue("x"), DataValue::list({DataValue(2.5)})}), DataValue(3.25),
+                           DataValue("value"), DataValue((int64_t)-70000), DataValue((int64_t)1 << 40)});
+    CHECK(hex(encode_key_for_store(9, mixed, 2)) == "000000000000000905c01c00000000000000066b00000000000000f8");
+    CHECK(hex(encode_val_for_store(9, mixed, 2)) ==
+          "000000000000000999a44e756c6c81a4426f6f6cc381a4426f6f6cc281a54279746573c402000181a44c6973749381a34e756d81a3496e740181a3537472a17881a44c"
+          "6973749181a34e756d81a5466c6f6174cb400400000000000081a34e756d81a5466c6f6174cb400a00000000000081a3537472a576616c756581a34e756d81a3496e74d2"
+          "fffeee9081a34e756d81a3496e74cf0000010000000000");
+}
+
 static bool same_graph(const GraphWithIndices &a, const GraphWithIndices &b) {
     return a.graph.n == b.graph.n && a.graph.out_offsets == b.graph.out_offsets && a.graph.out_targets == b.graph.out_targets &&
            a.graph.in_offsets == b.graph.in_offsets && a.graph.in_sources == b.graph.in_sources &&
@@ -970,6 +999,7 @@ int main(int argc, char **argv) {
     test_degree_centrality();
     test_codec_numbers_and_order();
     test_codec_bytes_and_values();
+    test_codec_agrees_with_the_python_codec();
     test_stored_relation_graphs();
     test_no_device_fails_loudly();
     if (mode == "rules-cpu") {
