@@ -130,3 +130,26 @@ def test_dijkstra_keep_ties_rule(registry, undirected):
     one = registry.run("ShortestPathDijkstraGpu", [rel(edges), rel([(starts[0],)]), rel([(goals[1],)])],
                        {"undirected": undirected, "keep_ties": True})
     assert {(s, t, c, tuple(p)) for s, t, c, p in one} == {r for r in got if r[0] == starts[0] and r[1] == goals[1]}
+
+
+def test_betweenness_on_air_routes_against_networkx(registry):
+    """An independent cross-check on the reference's own fixture (cozo-core/tests/air_routes.rs data): the routes among the
+    220 busiest airports, weight = distance in miles (integers: f32 and f64 agree on every tie), BetweennessCentralityGpu against
+    networkx's weighted betweenness (Brandes, float64, unnormalised, endpoints excluded) -- the same quantity the reference's
+    path enumeration sums up."""
+    import os
+    nx = pytest.importorskip("networkx")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "air_routes.npz"))
+    codes = [str(c) for c in z["codes"]]
+    busiest = np.argsort(-np.bincount(z["fr"], minlength=len(codes)), kind="stable")[:220]  # the 220 airports with most routes out
+    keep = {codes[i] for i in busiest}
+    routes = [(codes[a], codes[b], float(d)) for a, b, d in zip(z["fr"], z["to"], z["dist"]) if codes[a] in keep and codes[b] in keep]
+    assert len(routes) > 5000 and all(r[2] > 0 and r[2] == int(r[2]) for r in routes)
+    rows = registry.run("BetweennessCentralityGpu", [rel(routes)])
+    g = nx.DiGraph()
+    g.add_weighted_edges_from(routes)
+    want = nx.betweenness_centrality(g, normalized=False, weight="weight", endpoints=False)
+    got = dict(rows)
+    assert set(got) == set(want) and max(want.values()) > 100
+    for node, c in want.items():
+        assert got[node] == pytest.approx(c, rel=1e-9, abs=1e-9), node
