@@ -153,3 +153,21 @@ def test_betweenness_on_air_routes_against_networkx(registry):
     assert set(got) == set(want) and max(want.values()) > 100
     for node, c in want.items():
         assert got[node] == pytest.approx(c, rel=1e-9, abs=1e-9), node
+
+
+def test_clustering_coefficients_on_air_routes_against_networkx(registry):
+    """ClusteringCoefficientsGpu on the reference's fixture with every unordered airport pair kept once (the rule symmetrises its
+    input; a pair stored in both directions would count double, triangles.rs:36) == networkx's clustering / triangles / degree on
+    the simple undirected graph"""
+    import os
+    nx = pytest.importorskip("networkx")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "air_routes.npz"))
+    codes = [str(c) for c in z["codes"]]
+    pairs = sorted({tuple(sorted((codes[a], codes[b]))) for a, b in zip(z["fr"], z["to"]) if a != b})
+    rows = registry.run("ClusteringCoefficientsGpu", [rel(pairs)])
+    g = nx.Graph()
+    g.add_edges_from(pairs)
+    cc, tri, deg = nx.clustering(g), nx.triangles(g), dict(g.degree())
+    assert len(rows) == g.number_of_nodes() > 3000 and sum(tri.values()) > 100_000
+    for node, c, t, d in rows:
+        assert (t, d) == (tri[node], deg[node]) and c == pytest.approx(cc[node], rel=1e-12, abs=1e-15), node
