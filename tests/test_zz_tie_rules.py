@@ -171,3 +171,30 @@ def test_clustering_coefficients_on_air_routes_against_networkx(registry):
     assert len(rows) == g.number_of_nodes() > 3000 and sum(tri.values()) > 100_000
     for node, c, t, d in rows:
         assert (t, d) == (tri[node], deg[node]) and c == pytest.approx(cc[node], rel=1e-12, abs=1e-15), node
+
+
+def test_closeness_centrality_on_air_routes_against_scipy(registry):
+    """ClosenessCentralityGpu on the 220 busiest airports of the reference's fixture against scipy's Dijkstra (float64;
+    distances are integer miles, every partial sum stays below 2^24, so the reference's f32 epilogue is exact and the
+    comparison is bit for bit): nc * nc / total / (n - 1), all_pairs_shortest_path.rs:118-122"""
+    import os
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import dijkstra
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "air_routes.npz"))
+    codes = [str(c) for c in z["codes"]]
+    busiest = np.argsort(-np.bincount(z["fr"], minlength=len(codes)), kind="stable")[:220]
+    keep = {codes[i] for i in busiest}
+    routes = [(codes[a], codes[b], float(d)) for a, b, d in zip(z["fr"], z["to"], z["dist"]) if codes[a] in keep and codes[b] in keep]
+    rows = registry.run("ClosenessCentralityGpu", [rel(routes)])
+    nodes = sorted({r[0] for r in routes} | {r[1] for r in routes})
+    pos = {c: i for i, c in enumerate(nodes)}
+    n = len(nodes)
+    m = csr_matrix(([r[2] for r in routes], ([pos[r[0]] for r in routes], [pos[r[1]] for r in routes])), shape=(n, n))
+    d = dijkstra(m, directed=True)
+    got = dict(rows)
+    assert len(rows) == n
+    for c, i in pos.items():
+        fin = d[i][np.isfinite(d[i])]
+        assert fin.sum() < 2 ** 24
+        want = np.float32(np.float32(np.float32(fin.size) * np.float32(fin.size)) / np.float32(fin.sum())) / np.float32(n - 1)
+        assert got[c] == float(want), c
