@@ -27,6 +27,10 @@ def recall(ids, truth):
 
 def test_config1_on_the_oracle(c1, oracle):
     flat = c1["flat"]
+    # the recall ground truth itself, against float64 numpy: the same neighbour sets up to f32-level near-ties
+    d64 = ((c1["q"][:50, None, :].astype(np.float64) - c1["x"][None, :, :].astype(np.float64)) ** 2).sum(-1)
+    exact = np.argsort(d64, axis=1, kind="stable")[:, :K]
+    assert np.mean([len(set(exact[i].tolist()) & set(c1["truth"][i].tolist())) / K for i in range(50)]) >= 0.998
     assert flat.n == N and flat.level_width[0] == 2 * M and all(w == M for w in flat.level_width[1:])
     assert flat.level_size[0] == N and all(a > b for a, b in zip(flat.level_size, flat.level_size[1:]))
     rec, evals = [], []
