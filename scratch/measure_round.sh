@@ -31,3 +31,5 @@ with open(R + "/gpurun_out/round/pmc_summary.txt", "w") as out:
             print(line); out.write(line + "\n")
 PY
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+# end to end on a stored relation: bytes -> libcozo_ingest (host) -> cz_pagerank on host arrays (upload + plan + run + scores back)
+cd $R && timeout 900 python scratch/e2e_pagerank_stored.py --rows 100000000 --nodes 10000000 > $O/e2e_pagerank_stored.txt 2>&1; echo "e2e rc=$?"; cat $O/e2e_pagerank_stored.txt
