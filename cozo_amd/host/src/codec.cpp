@@ -373,7 +373,7 @@ struct MpReader {
             const std::vector<uint8_t> b = bin();
             F32Vec v;
             v.v.resize(b.size() / 4);
-            std::memcpy(v.v.data(), b.data(), v.v.size() * 4);
+            if (!v.v.empty()) std::memcpy(v.v.data(), b.data(), v.v.size() * 4);
             return DataValue(std::move(v));
         }
         throw CodecError("msgpack: variant " + name + " is not modelled");

@@ -349,6 +349,34 @@ static void test_codec_agrees_with_the_python_codec() {
           "fffeee9081a34e756d81a3496e74cf0000010000000000");
 }
 
+static void test_codec_rejects_damaged_bytes() {
+    // decode_tuple_from_kv on mutated stored bytes: a tuple or a CodecError, never a fault (bounds are checked everywhere)
+    const Tuple row = T({DataValue((int64_t)9), DataValue("key"), DataValue(F32Vec{{1.5f, -2.0f, 0.25f}}),
+                         DataValue::list({DataValue("x"), DataValue((int64_t)1 << 40), DataValue(Bytes{{1, 2, 3}})}), DataValue(2.5), DataValue()});
+    const std::vector<uint8_t> k = encode_key_for_store(3, row, 2), v = encode_val_for_store(3, row, 2);
+    std::mt19937_64 rng(99);
+    size_t decoded = 0, rejected = 0;
+    for (int it = 0; it < 4000; it++) {
+        std::vector<uint8_t> kk = k, vv = v;
+        std::vector<uint8_t> &victim = (it & 1) ? kk : vv;
+        const int kind = (int)(rng() % 3);
+        if (kind == 0) victim[rng() % victim.size()] = (uint8_t)rng();
+        else if (kind == 1) victim.resize(rng() % victim.size());
+        else for (int j = 0; j < 8; j++) victim[rng() % victim.size()] = (uint8_t)rng();
+        try {
+            (void)decode_tuple_from_kv(kk.data(), kk.size(), vv.data(), vv.size());
+            decoded++;
+        } catch (const CodecError &) {
+            rejected++;
+        } catch (const std::length_error &) {  // an absurd length from a damaged header, refused by the allocator
+            rejected++;
+        } catch (const std::bad_alloc &) {
+            rejected++;
+        }
+    }
+    CHECK(decoded > 100 && rejected > 1000);
+}
+
 static bool same_graph(const GraphWithIndices &a, const GraphWithIndices &b) {
     return a.graph.n == b.graph.n && a.graph.out_offsets == b.graph.out_offsets && a.graph.out_targets == b.graph.out_targets &&
            a.graph.in_offsets == b.graph.in_offsets && a.graph.in_sources == b.graph.in_sources &&
@@ -1000,6 +1028,7 @@ int main(int argc, char **argv) {
     test_codec_numbers_and_order();
     test_codec_bytes_and_values();
     test_codec_agrees_with_the_python_codec();
+    test_codec_rejects_damaged_bytes();
     test_stored_relation_graphs();
     test_no_device_fails_loudly();
     if (mode == "rules-cpu") {
