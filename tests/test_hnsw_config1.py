@@ -61,3 +61,37 @@ def test_config1_on_the_device(c1, oracle, gpu_lib):
             assert abs(recall(ids, c1["truth"]) - recall(rids, c1["truth"])) <= 0.01
     finally:
         gix.close()
+
+
+# ---- the reference's own tiny index (runtime/tests.rs:743-809 `test_vec_index`) ------------------------------------------------
+TINY = [("a", [112, 0]), ("a2", [2, 31]), ("b", [1, 1]), ("b2", [1, 10]), ("bb", [2, 3]), ("bb2", [2, 33]), ("c", [3, 4]), ("c2", [2, 32]),
+        ("x", [0, 0.1])]  # the relation after both puts: later rows replaced 'a' and 'b', 'a2'.. were added; key order
+
+
+def _tiny(oracle):
+    x = np.array([v for _, v in TINY], dtype=np.float32)
+    builder, flat = util.build_index(oracle, x, oracle.L2, 50, 20)
+    return x, flat
+
+
+def test_reference_tiny_index_known_answer(oracle):
+    """`~a:vec{k, v | query: q, k: 2, ef: 20, bind_distance: dist}, q = vec([200, 34])` on the nine 2-d rows of the reference's
+    test_vec_index (m: 50, ef_construction: 20, L2).  The reference only prints the rows; with ef = 20 > 9 nodes the level-0
+    search reaches the whole index, so the answer is arithmetic: 'a' = [112, 0] at 88^2 + 34^2 = 8900, then 'bb2' = [2, 33] at
+    198^2 + 1 = 39205."""
+    x, flat = _tiny(oracle)
+    ids, dist, cnt, _ = flat.knn_batch(np.array([[200, 34]], dtype=np.float32), 2, 20)
+    assert cnt[0] == 2 and [TINY[i][0] for i in ids[0]] == ["a", "bb2"] and dist[0].tolist() == [8900.0, 39205.0]
+    assert flat.n_levels >= 1 and flat.level_width[0] == 100
+
+
+@pytest.mark.gpu
+def test_reference_tiny_index_on_the_device(oracle, gpu_lib):
+    from cozo_amd.hnsw import HnswSearch
+    x, flat = _tiny(oracle)
+    gix = util.gpu_index(flat, "L2", 50)
+    try:
+        ids, dist, cnt = gix.hnsw_knn_batch(np.array([[200, 34]], dtype=np.float32), HnswSearch(k=2, ef=20))
+        assert cnt[0] == 2 and [TINY[i][0] for i in ids[0]] == ["a", "bb2"] and dist[0].tolist() == [8900.0, 39205.0]
+    finally:
+        gix.close()
