@@ -83,27 +83,34 @@ def test_cpp_host_rules_gpu():
     run("gpu")
 
 
-def test_cpp_host_under_sanitizers(tmp_path):
+def test_cpp_host_under_sanitizers():
     """the whole compiled host side -- rules, codec, libcozo_ingest's sources, with the oracle shim standing in for the device
     entry points -- built with -fsanitize=address,undefined and run through the rules-cpu checks: no finding"""
     from cozo_amd import build as B
     B.build()
     libdir = os.path.join(ROOT, "cozo_amd", "lib")
     ordir = os.path.join(ROOT, "oracle")
+    bindir = os.path.join(ROOT, "tests", "cpp", "bin")
+    os.makedirs(bindir, exist_ok=True)
     san = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"]
-    objs = []
-    for src, extra in ((os.path.join(ROOT, "tests", "cpp", "oracle_shim.c"), ["-I" + os.path.join(ROOT, "include"), "-I" + ordir]),
-                       (os.path.join(ordir, "cozo_oracle.c"), ["-I" + ordir, "-fopenmp"])):
-        obj = str(tmp_path / (os.path.basename(src) + ".o"))
-        subprocess.check_call(["gcc", "-c", *san, *extra, src, "-o", obj])
-        objs.append(obj)
-    host_src = sorted(os.path.join(ROOT, "cozo_amd", "host", "src", f) for f in os.listdir(os.path.join(ROOT, "cozo_amd", "host", "src"))
-                      if f.endswith(".cpp"))
-    exe = str(tmp_path / "test_host_san")
-    subprocess.check_call(["g++", "-std=c++17", *san, "-pthread", "-fopenmp", "-I" + os.path.join(ROOT, "cozo_amd", "host", "include"),
-                           "-I" + os.path.join(ROOT, "include"), "-I" + ordir, SRC, *host_src, *B.ingest_sources(), *objs, "-o", exe,
-                           "-L" + libdir, "-lcozo_gpu", "-L" + ROCM_LIB, "-lamdhip64", "-lm", "-Wl,-rpath," + libdir,
-                           "-Wl,-rpath," + ROCM_LIB])
+    hostdir = os.path.join(ROOT, "cozo_amd", "host")
+    host_src = sorted(os.path.join(hostdir, "src", f) for f in os.listdir(os.path.join(hostdir, "src")) if f.endswith(".cpp"))
+    c_src = [(os.path.join(ROOT, "tests", "cpp", "oracle_shim.c"), ["-I" + os.path.join(ROOT, "include"), "-I" + ordir]),
+             (os.path.join(ordir, "cozo_oracle.c"), ["-I" + ordir, "-fopenmp"])]
+    deps = [SRC, *host_src, *B.ingest_sources(), *(c for c, _ in c_src), os.path.join(B.INGEST_DIR, "common.hpp"),
+            os.path.join(ordir, "cozo_oracle.h"), os.path.join(ROOT, "include", "cozo_gpu.h"), os.path.join(ROOT, "include", "cozo_ingest.h")]
+    deps += [os.path.join(hostdir, "include", "cozo_host", f) for f in os.listdir(os.path.join(hostdir, "include", "cozo_host"))]
+    exe = os.path.join(bindir, "test_host_san")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        objs = []
+        for src, extra in c_src:
+            obj = os.path.join(bindir, os.path.basename(src) + ".san.o")
+            subprocess.check_call(["gcc", "-c", *san, *extra, src, "-o", obj])
+            objs.append(obj)
+        subprocess.check_call(["g++", "-std=c++17", *san, "-pthread", "-fopenmp", "-I" + os.path.join(hostdir, "include"),
+                               "-I" + os.path.join(ROOT, "include"), "-I" + ordir, SRC, *host_src, *B.ingest_sources(), *objs, "-o", exe,
+                               "-L" + libdir, "-lcozo_gpu", "-L" + ROCM_LIB, "-lamdhip64", "-lm", "-Wl,-rpath," + libdir,
+                               "-Wl,-rpath," + ROCM_LIB])
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", LD_PRELOAD="")
     p = subprocess.run([exe, "rules-cpu"], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0 and "0 failed" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
