@@ -299,9 +299,10 @@ class HnswSearchRA:
             return []
         # without a filter the candidates are cut to k before rows are fetched; with one all ef survive until the
         # filter has run (hnsw.rs:943-947)
-        cfg = HnswSearch(k=sb.k, ef=sb.ef, has_filter=sb.filter is not None)
+        # the radius cut (`distance > r => skip`, :952-956) is applied on the device to the rows that come back
+        cfg = HnswSearch(k=sb.k, ef=sb.ef, radius=sb.radius, has_filter=sb.filter is not None)
         if sb.filter is None:
-            cfg = HnswSearch(k=min(sb.k, sb.ef), ef=sb.ef)
+            cfg = HnswSearch(k=min(sb.k, sb.ef), ef=sb.ef, radius=sb.radius)
         ids, dist, cnt = self.index.hnsw_knn_batch(np.stack(qs), cfg)
         out = []
         for i, t in enumerate(parent):

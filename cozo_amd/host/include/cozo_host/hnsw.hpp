@@ -110,7 +110,8 @@ public:
     }
     // raw (node id, distance) rows, ascending, <= k per query
     void search_raw(const float *queries, uint32_t B, uint32_t k, uint32_t ef, std::vector<uint32_t> &ids,
-                    std::vector<double> &dist, std::vector<uint32_t> &count, const Poison &poison) const;
+                    std::vector<double> &dist, std::vector<uint32_t> &count, const Poison &poison,
+                    const std::optional<double> &radius = {}) const;
 };
 
 // HnswSearchRA (query/ra.rs:1085-1121): `parent` yields tuples carrying a DataValue::Vec at `bind_idx`

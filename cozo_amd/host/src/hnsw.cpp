@@ -179,13 +179,15 @@ StoredRows GpuHnswIndex::index_rows(uint64_t relation_id) const {
 }
 
 void GpuHnswIndex::search_raw(const float *queries, uint32_t B, uint32_t k, uint32_t ef, std::vector<uint32_t> &ids,
-                              std::vector<double> &dist, std::vector<uint32_t> &count, const Poison &poison) const {
+                              std::vector<double> &dist, std::vector<uint32_t> &count, const Poison &poison,
+                              const std::optional<double> &radius) const {
     ids.assign((size_t)B * k, CZ_NONE);
     dist.assign((size_t)B * k, 0.0);
     count.assign(B, 0);
     if (!h_ || B == 0) return;
-    check_gpu(cz_hnsw_search_batch(h_, queries, B, k, ef, 0, 0.0, ids.data(), dist.data(), count.data(), nullptr,
-                                   poison.flag_ptr(), 0, nullptr));
+    // the radius cut (`distance > r => skip`, hnsw.rs:952-956) is applied on the device to the rows that come back
+    check_gpu(cz_hnsw_search_batch(h_, queries, B, k, ef, radius ? 1 : 0, radius ? *radius : 0.0, ids.data(), dist.data(),
+                                   count.data(), nullptr, poison.flag_ptr(), 0, nullptr));
 }
 
 std::vector<std::vector<Tuple>> GpuHnswIndex::hnsw_knn_batch(const std::vector<const std::vector<float> *> &queries,
@@ -204,7 +206,7 @@ std::vector<std::vector<Tuple>> GpuHnswIndex::hnsw_knn_batch(const std::vector<c
     const uint32_t kk = (uint32_t)(config.filter ? config.ef : std::min(config.k, config.ef));
     std::vector<uint32_t> ids, count;
     std::vector<double> dist;
-    search_raw(q.data(), B, kk, (uint32_t)config.ef, ids, dist, count, poison);
+    search_raw(q.data(), B, kk, (uint32_t)config.ef, ids, dist, count, poison, config.radius);
     for (uint32_t i = 0; i < B; i++) {
         std::vector<Tuple> &ret = result[i];
         for (uint32_t j = 0; j < count[i]; j++) {
