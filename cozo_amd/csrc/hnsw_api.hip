@@ -342,43 +342,77 @@ bf_merge_kernel(const uint64_t *__restrict__ part_key, const uint32_t *__restric
 // ------------------------------------------------------------------------------------------------
 namespace cz {
 
+void HnswIndex::destroy(Workspace &w) {
+    if (w.tab) (void)hipFree(w.tab);
+    if (w.bitmap) (void)hipFree(w.bitmap);
+    if (w.ready) (void)hipEventDestroy(w.ready);
+    w = Workspace();
+}
+
 HnswIndex::~HnswIndex() {
     if (vec) (void)hipFree(vec);
     if (nbr0) (void)hipFree(nbr0);
     if (up_base) (void)hipFree(up_base);
     if (up_nbrs) (void)hipFree(up_nbrs);
-    for (auto &w : pool) {
-        if (w.ptr) (void)hipFree(w.ptr);
-        if (w.ready) (void)hipEventDestroy(w.ready);
-    }
+    for (auto &w : pool) destroy(w);
 }
 
-int HnswIndex::acquire(size_t bytes, hipStream_t stream, Workspace *out) {
+int HnswIndex::acquire(size_t tab_bytes, size_t bitmap_bytes, hipStream_t stream, Workspace *out) {
     {
         std::lock_guard<std::mutex> lk(mu);
         for (size_t i = 0; i < pool.size(); i++) {
-            if (pool[i].bytes >= bytes) {
-                *out = pool[i];
+            if (pool[i].tab_bytes >= tab_bytes && pool[i].bitmap_bytes >= bitmap_bytes) {
+                Workspace w = pool[i];
                 pool.erase(pool.begin() + (long)i);
-                if (out->ready) CZ_HIP(hipStreamWaitEvent(stream, out->ready, 0));
+                if (w.ready) {
+                    hipError_t e = hipStreamWaitEvent(stream, w.ready, 0);
+                    if (e != hipSuccess) {
+                        pool.push_back(w);  // still clean: nothing was launched on it
+                        return set_error(CZ_E_HIP, "hipStreamWaitEvent: %s", hipGetErrorString(e));
+                    }
+                }
+                *out = w;
                 return CZ_OK;
             }
         }
     }
     Workspace w;
-    CZ_HIP(hipMalloc(&w.ptr, bytes ? bytes : 16));
-    w.bytes = bytes;
-    CZ_HIP(hipEventCreateWithFlags(&w.ready, hipEventDisableTiming));
+    w.tab_bytes = std::max<size_t>(tab_bytes, 16);
+    w.bitmap_bytes = std::max<size_t>(bitmap_bytes, 16);
+    hipError_t e = hipMalloc(&w.tab, w.tab_bytes);
+    if (e == hipSuccess) e = hipMalloc(&w.bitmap, w.bitmap_bytes);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&w.ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMemsetAsync(w.tab, 0xFF, w.tab_bytes, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(w.bitmap, 0, w.bitmap_bytes, stream);
+    if (e != hipSuccess) {
+        destroy(w);
+        return set_error(e == hipErrorOutOfMemory ? CZ_E_OOM : CZ_E_HIP, "visited workspace (%zu + %zu bytes): %s", tab_bytes,
+                         bitmap_bytes, hipGetErrorString(e));
+    }
     *out = w;
     return CZ_OK;
 }
 
 int HnswIndex::release(Workspace w, hipStream_t stream) {
     hipError_t e = hipEventRecord(w.ready, stream);
+    if (e != hipSuccess) {
+        destroy(w);
+        return set_error(CZ_E_HIP, "hipEventRecord: %s", hipGetErrorString(e));
+    }
     std::lock_guard<std::mutex> lk(mu);
     pool.push_back(w);
-    if (e != hipSuccess) return set_error(CZ_E_HIP, "hipEventRecord: %s", hipGetErrorString(e));
     return CZ_OK;
+}
+
+void visited_shape(uint32_t n, uint32_t ef, uint32_t width, uint32_t *hbits, uint32_t *words) {
+    *words = (n + 31) / 32;
+    uint64_t want = std::max<uint64_t>(4096, 2ull * ef * width);
+    if (const char *e = getenv("CZ_HNSW_VSLOTS")) want = std::max<uint64_t>(64, strtoull(e, nullptr, 10));
+    uint32_t bits = 6;
+    while ((1ull << bits) < want && bits < 30) bits++;
+    bool hash = (1ull << bits) < (uint64_t)*words;  // a table smaller than the bitmap it replaces
+    if (const char *e = getenv("CZ_HNSW_VISITED")) hash = strcmp(e, "bitmap") != 0;
+    *hbits = hash ? bits : 0;
 }
 
 IndexDev HnswIndex::dev() const {
@@ -525,18 +559,16 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
         if (d_ndist) CZ_HIP(hipMemsetAsync(d_ndist, 0, (size_t)B * 8, stream));
         return CZ_OK;
     }
-    const uint32_t words = (ix->n + 31) / 32;
-    HnswIndex::Workspace ws;
-    int rc = ix->acquire((size_t)B * words * 4, stream, &ws);
-    if (rc) return rc;
-    CZ_HIP(hipMemsetAsync(ws.ptr, 0, (size_t)B * words * 4, stream));
+    uint32_t hbits = 0, words = 0;
+    visited_shape(ix->n, ef, (uint32_t)std::max(ix->w0, ix->wu), &hbits, &words);
     const uint32_t efcap = (std::max(ef, 1u) + 63) & ~63u;
     const uint32_t wpad = (uint32_t)((std::max(ix->w0, ix->wu) + 63) & ~63);
     const size_t smem = czh::smem_bytes(efcap, wpad, ix->ld);
-    if (smem > 160 * 1024) {
-        ix->release(ws, stream);
+    if (smem > 160 * 1024)
         return set_error(CZ_E_UNSUPPORTED, "dim %u / ef %u need %zu bytes of LDS (> 160 KiB)", ix->dim, ef, smem);
-    }
+    HnswIndex::Workspace ws;
+    int rc = ix->acquire(hbits ? ((size_t)B << hbits) * 4 : 0, (size_t)B * words * 4, stream, &ws);
+    if (rc) return rc;
     IndexDev d = ix->dev();
     Shape sh = shape_of(ix->dim);
 #define CZ_LAUNCH_KNN(LPV, ITERS, U)                                                                                    \
@@ -545,8 +577,8 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                         (int)smem);                                                    \
         hipLaunchKernelGGL(kern, dim3(B), dim3(czh::kThreads), smem, stream, d, d_queries, k, ef, efcap, wpad,          \
-                           has_radius, radius, (uint32_t *)ws.ptr, words, d_ids, d_dist, d_count,                       \
-                           (unsigned long long *)d_ndist);                                                              \
+                           has_radius, radius, (uint32_t *)ws.tab, hbits, (uint32_t *)ws.bitmap, words, d_ids,          \
+                           d_dist, d_count, (unsigned long long *)d_ndist);                                             \
     } while (0)
     // experiment knob: rows per round of a lane group for the 513..768-d shape (CZ_HNSW_U = 1 | 2)
     const char *knn_u_env = getenv("CZ_HNSW_U");
@@ -555,9 +587,11 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
     else CZ_DISPATCH_SHAPE_SEARCH(sh, CZ_LAUNCH_KNN);
 #undef CZ_LAUNCH_KNN
     hipError_t e = hipGetLastError();
-    int rc2 = ix->release(ws, stream);
-    if (e != hipSuccess) return set_error(CZ_E_HIP, "hnsw_knn_kernel launch: %s", hipGetErrorString(e));
-    return rc2;
+    if (e != hipSuccess) {
+        HnswIndex::destroy(ws);  // its contents are unknown
+        return set_error(CZ_E_HIP, "hnsw_knn_kernel launch: %s", hipGetErrorString(e));
+    }
+    return ix->release(ws, stream);
 }
 
 }  // namespace cz

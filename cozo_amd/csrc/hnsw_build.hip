@@ -15,6 +15,7 @@
 // sequential algorithm's.  Levels are drawn by the caller (hnsw.rs:46-52 uses an unseedable thread_rng).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <random>
@@ -77,11 +78,17 @@ __device__ __forceinline__ RowRef row_of(const BuildTables &T, uint32_t node, in
 template <int LPV, int ITERS, int U>
 __global__ void __launch_bounds__(kThreads)
 build_insert_kernel(IndexDev ix, BuildTables T, uint32_t b0, uint32_t bn, int top, uint32_t entry, int ef_c,
-                    uint32_t efcap, uint32_t wcap, int keep_pruned, uint32_t *__restrict__ visited, uint32_t words, Req req,
+                    uint32_t efcap, uint32_t wcap, int keep_pruned, uint32_t *__restrict__ vtab, uint32_t hbits,
+                    uint32_t *__restrict__ vbitmap, uint32_t words, Req req,
                     uint32_t *__restrict__ req_count, uint32_t req_cap, unsigned long long *__restrict__ ndist_total) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     czh::Smem s = czh::carve(smem_raw, efcap, wcap, ix.ld);
-    czh::Searcher<LPV, ITERS, U> S(ix, s, visited + (size_t)blockIdx.x * words, words);
+    czh::VisitedDev vis;
+    vis.tab = hbits ? vtab + ((size_t)blockIdx.x << hbits) : nullptr;
+    vis.hbits = hbits;
+    vis.bitmap = vbitmap + (size_t)blockIdx.x * words;
+    vis.words = words;
+    czh::Searcher<LPV, ITERS, U> S(ix, s, vis);
     const int tid = threadIdx.x;
     for (uint32_t qi = blockIdx.x; qi < bn; qi += gridDim.x) {
         const uint32_t q = b0 + qi;
@@ -132,7 +139,7 @@ build_insert_kernel(IndexDev ix, BuildTables T, uint32_t b0, uint32_t bn, int to
 
 // K2
 __global__ void __launch_bounds__(256)
-build_link_kernel(BuildTables T, Req in, uint32_t n, Req retry, uint32_t *__restrict__ retry_count,
+build_link_kernel(BuildTables T, Req in, uint32_t n, int lazy, Req retry, uint32_t *__restrict__ retry_count,
                   uint32_t *__restrict__ shrink_t, int32_t *__restrict__ shrink_lv, uint32_t *__restrict__ shrink_count) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t t = in.t[i], q = in.q[i];
@@ -143,7 +150,9 @@ build_link_kernel(BuildTables T, Req in, uint32_t n, Req retry, uint32_t *__rest
         if (slot < (uint32_t)r.cap) {
             r.ids[slot] = q;
             r.dst[slot] = d;
-            if (slot == (uint32_t)r.width) {  // degree just exceeded the row width: shrink (:339)
+            // degree just exceeded the row width: shrink (:339).  Lazy form (batched builds): only when the row's
+            // slack slots are used up too -- one re-selection per `slack` appended links instead of one per link
+            if (slot == (uint32_t)(lazy ? r.cap - 1 : r.width)) {
                 const uint32_t p = atomicAdd(shrink_count, 1u);
                 shrink_t[p] = t;
                 shrink_lv[p] = lv;
@@ -159,6 +168,25 @@ build_link_kernel(BuildTables T, Req in, uint32_t n, Req retry, uint32_t *__rest
     }
 }
 
+// lazy builds: rows still wider than their final width when the last batch is in
+__global__ void __launch_bounds__(256)
+build_overfull_kernel(BuildTables T, uint32_t n, uint32_t *__restrict__ shrink_t, int32_t *__restrict__ shrink_lv,
+                      uint32_t *__restrict__ shrink_count, uint32_t cap) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int top = T.level[i];
+        for (int lv = 0; lv <= top; lv++) {
+            const RowRef r = row_of(T, i, lv);
+            if (*r.deg > (uint32_t)r.width) {
+                const uint32_t p = atomicAdd(shrink_count, 1u);
+                if (p < cap) {
+                    shrink_t[p] = i;
+                    shrink_lv[p] = lv;
+                }
+            }
+        }
+    }
+}
+
 // K3
 template <int LPV, int ITERS, int U>
 __global__ void __launch_bounds__(kThreads)
@@ -166,7 +194,7 @@ build_shrink_kernel(IndexDev ix, BuildTables T, const uint32_t *__restrict__ shr
                     uint32_t n, uint32_t efcap, uint32_t wcap, int keep_pruned, unsigned long long *__restrict__ ndist_total) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     czh::Smem s = czh::carve(smem_raw, efcap, wcap, ix.ld);
-    czh::Searcher<LPV, ITERS, U> S(ix, s, nullptr, 0);
+    czh::Searcher<LPV, ITERS, U> S(ix, s, czh::VisitedDev{nullptr, 0, nullptr, 0});
     const int tid = threadIdx.x;
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         const uint32_t t = shrink_t[i];
@@ -361,10 +389,22 @@ extern "C" int cz_hnsw_build(const float *vectors, uint32_t n, uint32_t dim, int
     CZ_HIP(hipMemsetAsync(b_deg0.p, 0, (size_t)n * 4, stream));
     CZ_HIP(hipMemsetAsync(b_degU.p, 0, std::max<size_t>(1, rows) * 4, stream));
     CZ_HIP(hipMemsetAsync(b_ndist.p, 0, 8, stream));
-    const uint32_t words = (n + 31) / 32;
+    // one visited set (hash table + overflow bitmap, hnsw_kernels.cuh VisitedDev) per resident workgroup
     const int slots = 1024;
+    uint32_t hbits = 0, words = 0;
+    cz::visited_shape(n, ef_construction, (uint32_t)std::max(cap0, capU), &hbits, &words);
+    cz::DevBuf<uint32_t> b_vtab;
+    CZ_HIP(b_vtab.alloc(hbits ? ((size_t)slots << hbits) : 4));
+    if (hbits) CZ_HIP(hipMemsetAsync(b_vtab.p, 0xFF, ((size_t)slots << hbits) * 4, stream));
     CZ_HIP(b_visited.alloc((size_t)slots * words));
     CZ_HIP(hipMemsetAsync(b_visited.p, 0, (size_t)slots * words * 4, stream));
+    // Lazy shrinking (batched builds only; CZ_BUILD_LAZY=0 turns it off): a row is re-selected when its slack slots are
+    // used up, not every time a reverse link takes it past its final width, and once more at the end.  On dense data
+    // the heuristic keeps almost every link, so the eager form re-selects a row on nearly every reverse link: at
+    // 10M x 768 that was 68 k of the 83 k distance evaluations per inserted vector.  max_batch = 1 keeps the
+    // reference's eager order (hnsw.rs:338-350) and with it the identical link tables.
+    const char *lazy_env = getenv("CZ_BUILD_LAZY");
+    const int lazy = max_batch > 1 && !(lazy_env && atoi(lazy_env) == 0);
     const size_t max_req = (size_t)max_batch * (size_t)(ix->w0 + 8 * ix->wu) + 1024;
     ReqBuf reqA, reqB;
     CZ_HIP(reqA.alloc(max_req));
@@ -402,7 +442,8 @@ extern "C" int cz_hnsw_build(const float *vectors, uint32_t n, uint32_t dim, int
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                                         (int)smem);                                                     \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), smem, stream, dev, T, i, bn, top, entry,                     \
-                           (int)ef_construction, efcap, wcap, keep_pruned_connections, b_visited.p, words, reqA.ref(),    \
+                           (int)ef_construction, efcap, wcap, keep_pruned_connections, b_vtab.p, hbits, b_visited.p, words, \
+                           reqA.ref(),                                                                                   \
                            b_misc.p + 0, (uint32_t)max_req, b_ndist.p);                                                                     \
     } while (0)
         CZ_DISPATCH_BUILD_SHAPE(sh, CZ_LAUNCH_INSERT);
@@ -417,7 +458,7 @@ extern "C" int cz_hnsw_build(const float *vectors, uint32_t n, uint32_t dim, int
         while (nreq > 0) {
             CZ_HIP(hipMemsetAsync(b_misc.p + 1, 0, 8, stream));  // [1] retry count, [2] shrink count
             hipLaunchKernelGGL(build_link_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>((nreq + 255) / 256, 4096))),
-                               dim3(256), 0, stream, T, cur->ref(), nreq, nxt->ref(), b_misc.p + 1, b_shrink_t.p,
+                               dim3(256), 0, stream, T, cur->ref(), nreq, lazy, nxt->ref(), b_misc.p + 1, b_shrink_t.p,
                                b_shrink_lv.p, b_misc.p + 2);
             CZ_HIP(hipMemcpyAsync(h, b_misc.p, 32, hipMemcpyDeviceToHost, stream));
             CZ_HIP(hipStreamSynchronize(stream));
@@ -448,6 +489,35 @@ extern "C" int cz_hnsw_build(const float *vectors, uint32_t n, uint32_t dim, int
             entry = i;
         }
         i += bn;
+    }
+    if (lazy) {  // rows that still hold more links than their final width
+        cz::DevBuf<uint32_t> f_t;
+        cz::DevBuf<int32_t> f_lv;
+        const size_t fcap = (size_t)n + rows;
+        CZ_HIP(f_t.alloc(fcap));
+        CZ_HIP(f_lv.alloc(fcap));
+        CZ_HIP(hipMemsetAsync(b_misc.p + 2, 0, 4, stream));
+        hipLaunchKernelGGL(build_overfull_kernel, dim3(4096), dim3(256), 0, stream, T, n, f_t.p, f_lv.p, b_misc.p + 2,
+                           (uint32_t)std::min<size_t>(fcap, 0xFFFFFFFFu));
+        uint32_t nfinal = 0;
+        CZ_HIP(hipMemcpyAsync(&nfinal, b_misc.p + 2, 4, hipMemcpyDeviceToHost, stream));
+        CZ_HIP(hipStreamSynchronize(stream));
+        if (nfinal > 0) {
+            const uint32_t g3 = std::min<uint32_t>(nfinal, (uint32_t)slots);
+#define CZ_LAUNCH_SHRINK(LPV, ITERS, U)                                                                                  \
+    do {                                                                                                                 \
+        auto kern = build_shrink_kernel<LPV, ITERS, U>;                                                                  \
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                                        (int)smem);                                                     \
+        hipLaunchKernelGGL(kern, dim3(g3), dim3(kThreads), smem, stream, dev, T, f_t.p, f_lv.p, nfinal, efcap, wcap,      \
+                           keep_pruned_connections, b_ndist.p);                                                          \
+    } while (0)
+            CZ_DISPATCH_BUILD_SHAPE(sh, CZ_LAUNCH_SHRINK);
+#undef CZ_LAUNCH_SHRINK
+            CZ_HIP(hipStreamSynchronize(stream));  // f_t / f_lv die with this scope
+        }
+        hipError_t fe = hipGetLastError();
+        if (fe != hipSuccess) return cz::set_error(CZ_E_HIP, "hnsw build final shrink: %s", hipGetErrorString(fe));
     }
     // final layout
     ix->n_levels = top + 1;

@@ -33,23 +33,34 @@ struct HnswIndex {
     uint32_t *up_nbrs = nullptr;
     std::vector<int32_t> top;  // host copy: top level of every node (for export)
 
-    // per-call scratch (visited bitmaps): cached, handed out under a mutex, stream-ordered by an event
+    // per-call scratch (the visited sets of a batch: hash tables + overflow bitmaps, hnsw_kernels.cuh VisitedDev):
+    // cached, handed out under a mutex, stream-ordered by an event.  Invariant while pooled: every word of `tab` is
+    // CZ_NONE and every word of `bitmap` 0 -- set once when the buffers are allocated, restored by the kernels that use
+    // them (so a search never pays a per-launch memset).  A workspace whose kernel failed to launch is destroyed, not pooled.
     struct Workspace {
-        void *ptr = nullptr;
-        size_t bytes = 0;
+        void *tab = nullptr;
+        size_t tab_bytes = 0;
+        void *bitmap = nullptr;
+        size_t bitmap_bytes = 0;
         hipEvent_t ready = nullptr;
     };
     std::mutex mu;
     std::vector<Workspace> pool;
 
     ~HnswIndex();
-    int acquire(size_t bytes, hipStream_t stream, Workspace *out);
+    int acquire(size_t tab_bytes, size_t bitmap_bytes, hipStream_t stream, Workspace *out);
     int release(Workspace w, hipStream_t stream);
+    static void destroy(Workspace &w);
     czh::IndexDev dev() const;
 };
 
 int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32_t k, uint32_t ef, int has_radius,
                        double radius, uint32_t *d_ids, double *d_dist, uint32_t *d_count, uint64_t *d_ndist,
                        hipStream_t stream);
+
+// shape of the per-query visited set for a traversal with list size `ef` over link rows of `width` slots on an index
+// of n nodes: hash-table bits (0 = bitmap only) and bitmap words.  CZ_HNSW_VISITED = bitmap | hash and
+// CZ_HNSW_VSLOTS = <slots> override the choice (experiments, and the test of the overflow path).
+void visited_shape(uint32_t n, uint32_t ef, uint32_t width, uint32_t *hbits, uint32_t *words);
 
 }  // namespace cz

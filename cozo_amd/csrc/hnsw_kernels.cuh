@@ -12,7 +12,10 @@
 //   * processing the neighbours of a candidate one by one against a running `furthest` equals merging
 //     the whole neighbour batch into W and truncating at ef (streaming top-k).
 //   * W lives in LDS; neighbour ids are fetched with one coalesced row load; `visited` is a per-query
-//     bitmap in HBM (test-and-set atomics at L2); distances use the wave-wide routines of
+//     open-addressing hash set of node ids in global memory (CAS at L2; 128 KiB per query at ef = 192, so the
+//     1024 tables of a batch stay in L2 / Infinity Cache -- the per-query BITMAP it replaces is 1.25 MB per query
+//     at n = 10M: every test-and-set was an HBM miss and the rows had to be re-zeroed per launch), with the
+//     bitmap kept as the overflow form; distances use the wave-wide routines of
 //     distance.cuh, U rows in flight per lane group; the merge computes final positions by rank
 //     (binary search over W for new entries, linear count over the <= 64 new entries for W entries).
 #pragma once
@@ -67,7 +70,7 @@ struct Smem {
     uint32_t *wid;    // [efcap]   id | kExpanded
     uint64_t *nkey;   // [wpad]
     uint32_t *nid;    // [wpad]    CZ_NONE = not eligible
-    uint32_t *todo;   // [wpad]
+    uint32_t *todo;   // [wpad]   ids to evaluate in this step
     uint32_t *vlog;   // [kVlogCap]
     float4 *q;        // [ld/4]
     int *ctl;         // [16] control words
@@ -77,18 +80,18 @@ struct Smem {
     uint8_t *st;      // [efcap] 0 pending, 1 selected, 2 rejected
 };
 enum { C_CNT = 0, C_TODO = 1, C_LO = 2, C_VLOG = 3, C_NELIG = 4, C_NDIST_LO = 5, C_NDIST_HI = 6, C_KEEP = 7, C_NUM = 8,
-       C_WAVE0 = 9 /* .. C_WAVE0 + kWaves - 1: per-wave counts of the merge's compaction */ };
+       C_WAVE0 = 9 /* .. C_WAVE0 + kWaves - 1: per-wave counts of the merge's compaction */,
+       C_VCNT = 13 /* members of the visited set */, C_VMODE = 14 /* 0 hash set, 1 bitmap */, C_WORDS = 16 };
 
 __host__ __device__ inline size_t smem_bytes(uint32_t efcap, uint32_t wpad, uint32_t ld) {
     size_t b = 0;
     b += (size_t)efcap * 8;
     b += (((size_t)efcap * 4 + 15) / 16) * 16;
     b += (size_t)wpad * 8;
-    b += (size_t)wpad * 4;
-    b += (size_t)wpad * 4;
+    b += (size_t)wpad * 4 * 2;
     b += (size_t)kVlogCap * 4;
     b += (size_t)ld * 4;
-    b += 64;
+    b += C_WORDS * 4;
     b += (size_t)efcap * 4 + 256 * 4 + (((size_t)efcap + 15) / 16) * 16;
     return b;
 }
@@ -109,7 +112,7 @@ __device__ inline Smem carve(char *base, uint32_t efcap, uint32_t wpad, uint32_t
     s.q = (float4 *)base;
     base += (size_t)ld * 4;
     s.ctl = (int *)base;
-    base += 64;
+    base += C_WORDS * 4;
     s.tpos = (uint32_t *)base;
     base += (size_t)efcap * 4;
     s.sel = (uint32_t *)base;
@@ -122,19 +125,26 @@ __device__ __forceinline__ bool key_lt(uint64_t ka, uint32_t ia, uint64_t kb, ui
     return ka < kb || (ka == kb && ia < ib);
 }
 
-// visited bitmap helpers: reads/writes go to L2 (atomics), one bitmap per query, only this workgroup touches it
-__device__ __forceinline__ bool test_and_set(uint32_t *bitmap, uint32_t id) {
-    uint32_t bit = 1u << (id & 31);
-    uint32_t old = atomicOr(&bitmap[id >> 5], bit);
-    return (old & bit) != 0;
-}
+// The visited set of one query (hnsw.rs:552 `visited`).  Exact (a set of node ids, never a filter):
+//   tab     open-addressing hash set, 1 << hbits slots, CZ_NONE = empty; nullptr / hbits 0 when the bitmap is no
+//           bigger than a table would be (small indices)
+//   bitmap  n bits; the overflow form: when the table reaches 70 % of its slots its members move here
+// Between launches every table word is CZ_NONE and every bitmap word 0: the workgroup that used them restores that
+// (no per-launch memset: at n = 10M the bitmaps of a 1024-query batch are 1.28 GB).  Only wave 0 of the owning
+// workgroup touches either, with L2 atomics.
+struct VisitedDev {
+    uint32_t *tab;
+    uint32_t hbits;
+    uint32_t *bitmap;
+    uint32_t words;
+};
 
 template <int LPV, int ITERS, int U, bool NT = false>
 struct Searcher {
     const IndexDev &ix;
     Smem s;
-    uint32_t *bitmap;
-    uint32_t words;
+    VisitedDev vis;
+    uint32_t *tcur;  // ids evaluated in this step (s.todo)
     int tid, lane, wave, glane, group;
     int chunks;
     float4 q[ITERS > 0 ? ITERS : 1];
@@ -145,8 +155,8 @@ struct Searcher {
     static constexpr int TG = kWaves * VPW;       // lane groups per workgroup
     using Regs = RowRegs<(ITERS > 0 ? ITERS : 1), U>;
 
-    __device__ Searcher(const IndexDev &ix_, Smem s_, uint32_t *bitmap_, uint32_t words_)
-        : ix(ix_), s(s_), bitmap(bitmap_), words(words_) {
+    __device__ Searcher(const IndexDev &ix_, Smem s_, VisitedDev vis_) : ix(ix_), s(s_), vis(vis_) {
+        tcur = s.todo;
         tid = threadIdx.x;
         lane = tid & 63;
         wave = tid >> 6;
@@ -159,7 +169,7 @@ struct Searcher {
     __device__ void load_query(const float *qrow) {
         float *ql = (float *)s.q;
         for (uint32_t i = tid; i < ix.ld; i += kThreads) ql[i] = i < ix.dim ? qrow[i] : 0.f;
-        if (tid < 16) s.ctl[tid] = 0;
+        if (tid < C_WORDS) s.ctl[tid] = tid == C_VMODE ? (vis.tab ? 0 : 1) : 0;
         __syncthreads();
         if constexpr (ITERS > 0) {
 #pragma unroll
@@ -189,7 +199,7 @@ struct Searcher {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int j = min(base + u * TG, n - 1);  // past the end: re-read the last row, result discarded
-            rows[u] = (const float4 *)(ix.vec + (size_t)s.todo[j] * ix.ld);
+            rows[u] = (const float4 *)(ix.vec + (size_t)tcur[j] * ix.ld);
         }
         load_rows<LPV, ITERS, U, NT>(r, rows, glane, chunks, full);
     }
@@ -243,7 +253,7 @@ struct Searcher {
             for (int j = tid; j < n; j += kThreads) {
                 const float2 raw = ((const float2 *)s.nkey)[j];
                 s.nkey[j] = dist_key(finish_distance(ix.metric, raw.x, raw.y, qqn));
-                s.nid[j] = s.todo[j];
+                s.nid[j] = tcur[j];
             }
         } else {
             // generic dimension (> 2048): the query is read from LDS chunk by chunk
@@ -253,7 +263,7 @@ struct Searcher {
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     int j = base + u * TG;
-                    ids[u] = j < n ? s.todo[j] : CZ_NONE;
+                    ids[u] = j < n ? tcur[j] : CZ_NONE;
                     rows[u] = j < n ? (const float4 *)(ix.vec + (size_t)ids[u] * ix.ld) : nullptr;
                 }
                 double d[U];
@@ -304,7 +314,7 @@ struct Searcher {
                     unsigned long long mk = __ballot(pend);
                     if (pend) {
                         int p = total + __popcll(mk & ((1ull << lane) - 1ull));
-                        s.todo[p] = s.wid[j] & kIdMask;
+                        tcur[p] = s.wid[j] & kIdMask;
                         s.tpos[p] = (uint32_t)j;
                     }
                     total += __popcll(mk);
@@ -403,7 +413,7 @@ struct Searcher {
             const int e = before + __popcll(em & ((1ull << lane) - 1ull));
             s.nkey[e] = mykey;
             s.nid[e] = myid;
-            s.todo[e] = 0;  // rank accumulator of compacted entry e
+            tcur[e] = 0;  // rank accumulator of compacted entry e (the step's ids were copied to nid)
         }
         __syncthreads();
         // registers: this thread's W entries (W index tid + r * kThreads: a wave holds 64 consecutive ones) and the
@@ -469,7 +479,7 @@ struct Searcher {
         }
 #pragma unroll
         for (int c = 0; c < EC; c++)
-            if (c * 64 + lane < nelig && acc[c] != 0) atomicAdd(&s.todo[c * 64 + lane], (uint32_t)acc[c]);
+            if (c * 64 + lane < nelig && acc[c] != 0) atomicAdd(&tcur[c * 64 + lane], (uint32_t)acc[c]);
         __syncthreads();
         // scatter in place: every W entry and every compacted entry is in a register by now
 #pragma unroll
@@ -489,7 +499,7 @@ struct Searcher {
                     k0 = ek[c];
                     i0 = ei[c];
                 }
-            const int npos = (int)s.todo[tid];
+            const int npos = (int)tcur[tid];
             if (npos < ef) {
                 s.wkey[npos] = k0;
                 s.wid[npos] = i0;  // un-expanded
@@ -582,35 +592,138 @@ struct Searcher {
         __syncthreads();
     }
 
-    // forget the visited set of a finished upper level
-    __device__ void clear_visited() {
-        int nlog = s.ctl[C_VLOG];
-        if (nlog <= kVlogCap) {
-            for (int i = tid; i < nlog; i += kThreads) bitmap[s.vlog[i] >> 5] = 0;
-        } else {
-            for (uint32_t i = tid; i < words; i += kThreads) bitmap[i] = 0;
+    // ---------------------------------------------------------------------------------------------------------
+    // visited set
+    // ---------------------------------------------------------------------------------------------------------
+    // restore "every table word CZ_NONE, every bitmap word 0" wholesale (all threads)
+    __device__ void clear_all() {
+        if (vis.tab) {
+            const uint32_t quads = (1u << vis.hbits) / 4;
+            uint4 *t4 = (uint4 *)vis.tab;
+            for (uint32_t i = tid; i < quads; i += kThreads) t4[i] = make_uint4(CZ_NONE, CZ_NONE, CZ_NONE, CZ_NONE);
+        }
+        if (s.ctl[C_VMODE] == 1)
+            for (uint32_t i = tid; i < vis.words; i += kThreads) vis.bitmap[i] = 0;
+        __syncthreads();
+        if (tid == 0) {
+            s.ctl[C_VLOG] = 0;
+            s.ctl[C_VCNT] = 0;
+            s.ctl[C_VMODE] = vis.tab ? 0 : 1;
         }
         __syncthreads();
-        if (tid == 0) s.ctl[C_VLOG] = 0;
+    }
+    // forget the visited set of a finished level: by the log of touched slots / ids when it is short and whole
+    __device__ void clear_visited() {
+        const int nlog = s.ctl[C_VLOG];
+        if (nlog > kVlogCap) {  // uniform
+            clear_all();
+            return;
+        }
+        if (s.ctl[C_VMODE] == 0) {
+            for (int i = tid; i < nlog; i += kThreads) vis.tab[s.vlog[i]] = CZ_NONE;
+        } else {
+            for (int i = tid; i < nlog; i += kThreads) vis.bitmap[s.vlog[i] >> 5] = 0;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            s.ctl[C_VLOG] = 0;
+            s.ctl[C_VCNT] = 0;
+        }
         __syncthreads();
     }
-
-    __device__ __forceinline__ void log_visit(uint32_t id, bool enable) {
+    // slot (hash form) or id (bitmap form) of a new member
+    __device__ __forceinline__ void log_visit(uint32_t what, bool enable) {
         if (!enable) return;
         int p = atomicAdd(&s.ctl[C_VLOG], 1);
-        if (p < kVlogCap) s.vlog[p] = id;
+        if (p < kVlogCap) s.vlog[p] = what;
+    }
+    // wave 0: the table is about to pass its load limit: its members move into the query's bitmap row
+    __device__ void to_bitmap() {
+        const uint32_t slots = 1u << vis.hbits;
+        for (uint32_t i = lane; i < slots; i += 64) {
+            const uint32_t v = __hip_atomic_load(&vis.tab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != CZ_NONE) atomicOr(&vis.bitmap[v >> 5], 1u << (v & 31));
+        }
+        if (lane == 0) {
+            s.ctl[C_VMODE] = 1;
+            s.ctl[C_VLOG] = kVlogCap + 1;  // the log mixes slots and ids from here on: clear wholesale
+        }
+    }
+    // wave 0: test-and-set of up to 64 DISTINCT ids, one per active lane; true where the id was new.
+    // `where` = the slot (hash form) or the id (bitmap form), for the log.
+    __device__ __forceinline__ bool visit(uint32_t id, bool active, uint32_t &where) {
+        int mode = s.ctl[C_VMODE];  // uniform
+        if (mode == 0 && (uint32_t)s.ctl[C_VCNT] + 64u > (7u << vis.hbits) / 10u) {
+            to_bitmap();
+            mode = 1;
+        }
+        bool fresh = false;
+        where = id;
+        if (active) {
+            if (mode == 0) {
+                const uint32_t hmask = (1u << vis.hbits) - 1u;
+                uint32_t h = (id * 0x9E3779B1u) >> (32 - vis.hbits);
+                for (;;) {
+                    const uint32_t old = atomicCAS(&vis.tab[h], CZ_NONE, id);
+                    if (old == CZ_NONE) {
+                        fresh = true;
+                        break;
+                    }
+                    if (old == id) break;
+                    h = (h + 1) & hmask;
+                }
+                where = h;
+            } else {
+                const uint32_t bit = 1u << (id & 31);
+                fresh = !(atomicOr(&vis.bitmap[id >> 5], bit) & bit);
+            }
+        }
+        const int c = __popcll(__ballot(fresh));
+        if (lane == 0 && c) s.ctl[C_VCNT] += c;
+        return fresh;
     }
 
-    // hnsw_search_level (hnsw.rs:539-587) with W carried in and out.  log = keep a visit log so the
-    // bitmap can be cleared afterwards (every level but the last one searched)
+    // ---------------------------------------------------------------------------------------------------------
+    // one expansion: link row of `cand` -> its not-yet-visited neighbours, in row order (hnsw.rs:566-571).  Wave 0.
+    // ---------------------------------------------------------------------------------------------------------
+    __device__ int expand_row(uint32_t cand, int level, int width, uint32_t *dst, bool log) {
+        const uint32_t *row = level == 0 ? ix.nbr0 + (size_t)cand * ix.w0
+                                         : ix.up_nbrs + ((size_t)ix.up_base[cand] + (level - 1)) * ix.wu;
+        int total = 0;
+        for (int c0 = 0; c0 < width; c0 += 64) {
+            const int c = c0 + lane;
+            const uint32_t nb = c < width ? row[c] : CZ_NONE;
+            uint32_t where;
+            const bool fresh = visit(nb, nb != CZ_NONE, where);
+            const unsigned long long m = __ballot(fresh);
+            if (fresh) {
+                const int p = total + __popcll(m & ((1ull << lane) - 1ull));
+                dst[p] = nb;
+                log_visit(where, log);
+            }
+            total += __popcll(m);
+        }
+        return total;
+    }
+    __device__ __forceinline__ void count_dist(int n) {  // lane 0 of wave 0: 64-bit distance-evaluation counter
+        unsigned int lo = (unsigned int)s.ctl[C_NDIST_LO];
+        unsigned int nl = lo + (unsigned int)n;
+        s.ctl[C_NDIST_LO] = (int)nl;
+        if (nl < lo) s.ctl[C_NDIST_HI] += 1;
+    }
+    // hnsw_search_level (hnsw.rs:539-587) with W carried in and out.  log = keep a log of the visited set's new
+    // members so that it can be emptied cheaply afterwards (every level but the last one of a search)
     __device__ void search_level(int level, int ef, bool log) {
         // :554-557 every carried entry is visited and a candidate again
         int cnt = s.ctl[C_CNT];
-        for (int i = tid; i < cnt; i += kThreads) {
-            uint32_t id = s.wid[i] & kIdMask;
-            s.wid[i] = id;
-            test_and_set(bitmap, id);
-            log_visit(id, log);
+        for (int i = tid; i < cnt; i += kThreads) s.wid[i] &= kIdMask;
+        if (wave == 0) {
+            for (int b = 0; b < cnt; b += 64) {
+                const int j = b + lane;
+                uint32_t where;
+                const bool fresh = visit(j < cnt ? (s.wid[j] & kIdMask) : CZ_NONE, j < cnt, where);
+                if (fresh) log_visit(where, log);
+            }
         }
         if (tid == 0) s.ctl[C_LO] = 0;
         __syncthreads();
@@ -636,35 +749,14 @@ struct Searcher {
             if (tid == 0) {
                 s.wid[idx] = cand | kExpanded;
                 s.ctl[C_LO] = idx + 1;
-                s.ctl[C_TODO] = 0;
             }
-            __syncthreads();
             CZ_PH_MARK(0);
             // neighbour row + visited filter (wave 0), hnsw.rs:566-571
             if (wave == 0) {
-                const uint32_t *row = level == 0 ? ix.nbr0 + (size_t)cand * ix.w0
-                                                 : ix.up_nbrs + ((size_t)ix.up_base[cand] + (level - 1)) * ix.wu;
-                int total = 0;
-                for (int c0 = 0; c0 < width; c0 += 64) {
-                    int c = c0 + lane;
-                    uint32_t nb = c < width ? row[c] : CZ_NONE;
-                    bool fresh = false;
-                    if (nb != CZ_NONE) fresh = !test_and_set(bitmap, nb);
-                    unsigned long long m = __ballot(fresh);
-                    if (fresh) {
-                        int p = total + __popcll(m & ((1ull << lane) - 1ull));
-                        s.todo[p] = nb;
-                        log_visit(nb, log);
-                    }
-                    total += __popcll(m);
-                }
+                const int total = expand_row(cand, level, width, tcur, log);
                 if (lane == 0) {
                     s.ctl[C_TODO] = total;
-                    // 64-bit distance-evaluation counter
-                    unsigned int lo = (unsigned int)s.ctl[C_NDIST_LO];
-                    unsigned int nl = lo + (unsigned int)total;
-                    s.ctl[C_NDIST_LO] = (int)nl;
-                    if (nl < lo) s.ctl[C_NDIST_HI] += 1;
+                    count_dist(total);
                 }
             }
             __syncthreads();
@@ -721,13 +813,18 @@ struct Searcher {
 template <int LPV, int ITERS, int U>
 __global__ void __launch_bounds__(kThreads)
 hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t efcap,
-                uint32_t wpad, int has_radius, double radius, uint32_t *__restrict__ visited, uint32_t words,
-                uint32_t *__restrict__ out_ids, double *__restrict__ out_dist, uint32_t *__restrict__ out_count,
+                uint32_t wpad, int has_radius, double radius, uint32_t *__restrict__ vtab, uint32_t hbits,
+                uint32_t *__restrict__ vbitmap, uint32_t words, uint32_t *__restrict__ out_ids, double *__restrict__ out_dist, uint32_t *__restrict__ out_count,
                 unsigned long long *__restrict__ out_n_dist) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t b = blockIdx.x;
     Smem s = carve(smem_raw, efcap, wpad, ix.ld);
-    Searcher<LPV, ITERS, U, CZ_SEARCH_NT != 0> S(ix, s, visited + (size_t)b * words, words);
+    VisitedDev vis;
+    vis.tab = hbits ? vtab + ((size_t)b << hbits) : nullptr;
+    vis.hbits = hbits;
+    vis.bitmap = vbitmap + (size_t)b * words;
+    vis.words = words;
+    Searcher<LPV, ITERS, U, CZ_SEARCH_NT != 0> S(ix, s, vis);
     S.load_query(queries + (size_t)b * ix.dim);
     S.seed(ix.entry);
     // :919-938 greedy descent with ef = 1 through the upper levels, then the level-0 search with ef (one call site,
@@ -736,6 +833,7 @@ hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t k, uint
         S.search_level(lv, lv > 0 ? 1 : (int)ef, lv > 0);
         if (lv > 0) S.clear_visited();
     }
+    S.clear_all();  // the table / bitmap go back to the pool empty
 #ifdef CZ_PHASE_TIMING
     if (threadIdx.x == 0) {
         for (int i_ = 0; i_ < 8; i_++) atomicAdd(&cz_phase_cycles[i_], S.ph_acc[i_]);
