@@ -5,20 +5,28 @@ PageRank fixed rule (edges/s), measured as BASELINE.json asks.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of `hnsw_knn` over one batch of 1024 parent tuples (query vectors) resident in HBM
-(BASELINE.json configs[1]: k = 10, cosine, 1M x 768 f32, batch 1024).  Queries are independent units, so at
-N > 1 every rank serves its own 1024-query batch from its own index replica (weak scaling, no data-path
-collective).  The same JSON line carries a `pagerank` object: PageRank on a synthetic 10M-node / 100M-edge
-graph per GPU (configs[2]); at N > 1 the graph is N times larger, row-sharded, with one RCCL all-gather of the
-contribution slice and one f64 all-reduce per iteration.
+A "step" is one pass of `hnsw_knn` over one batch of 1024 parent tuples (query vectors) resident in HBM, on the
+configuration BASELINE.json's metric is quoted on: k = 10, cosine, N = 10M x 768 f32, batch 1024, one GPU (the index is
+33 GB of the 288 GB).  The JSON line also carries, as secondary objects that are not part of `value`:
+  hnsw_1m / hnsw_1m_clustered   BASELINE.json configs[1] (1M x 768) on the same corpus family and on BASELINE.md's
+                                16-cluster data
+  distance_batch                cz_distance_batch (VectorCache::dist over explicit pairs) on the 10M corpus
+  pagerank / pagerank_rmat      configs[2]: PageRank on a 10M-node / 100M-edge graph (uniform; R-MAT 0.57/0.19/0.19/0.05)
+  host_ingest                   stored bytes -> ids + CSR on the box's host cores (libcozo_ingest)
+At N > 1 (one process per GPU, RCCL): every rank serves its own 1024-query batch from its own replica of the 10M index
+(weak scaling, no data-path collective: `value`); `hnsw_sharded` is configs[3] (the 10M vectors split into N sub-indices,
+per-shard search + all-gather/merge of the top-k lists) and `pagerank` is configs[4] (100M nodes / 1B edges in total,
+row-sharded, one all-gather of the contribution slices + one f64 all-reduce per iteration).
 
-All inputs are synthetic and generated on the GPU (no datasets here); the index is built on the GPU by
-cz_hnsw_build.  Rank 0 at N = 1 also times the CPU oracle (a C restatement of the reference, the reference
-itself being Rust and unbuildable here) on a bounded sample of the same workload: `cpu_baseline`.
+All inputs are synthetic and generated on the GPU (no datasets here); the index is built on the GPU by cz_hnsw_build.
+Rank 0 at N = 1 also times the CPU oracle (a C restatement of the reference, the reference itself being Rust and
+unbuildable here) on a bounded sample of the same workload -- `cpu_baseline` -- and uses the same oracle run as a parity
+check of what was just timed (`parity_checked`).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,18 +39,33 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling there: 6290 GB/s
+EF_LADDER = [16, 24, 32, 48, 64, 80, 96, 112, 128, 144, 160, 176, 192, 224, 256, 320, 384, 512, 768, 1024]
+
+
+def kernel_source_hash():
+    """sha256 over the device sources: ties profiles/pmc_traffic.json to the kernels it was measured on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cozo_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".cuh", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(key, world):
-    """HBM bytes per launch of the dominant kernel(s) from the committed rocprofv3 --pmc summary of this same
-    workload (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied there).
-    PMC counters cannot be collected from inside the timed run; None when no summary is committed or the
-    workload differs from the profiled one (N > 1)."""
+    """HBM bytes per launch of the dominant kernel(s) from the committed rocprofv3 --pmc summary of this same workload
+    (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied there).  PMC counters cannot be
+    collected from inside the timed run.  None when no summary is committed, when the workload differs from the profiled
+    one (N > 1), or when the summary was taken on OTHER kernels than the ones in this tree (source hash mismatch)."""
     if world != 1:
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)[key]["bytes_per_launch"]
+            d = json.load(f)
+        if d.get("kernel_source_hash") != kernel_source_hash():
+            return None
+        return d[key]["bytes_per_launch"]
     except Exception:
         return None
 
@@ -57,7 +80,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--n", type=int, default=1_000_000, help="vectors per index (per GPU)")
+    p.add_argument("--n", type=int, default=10_000_000, help="vectors per index (BASELINE.json's metric: N = 10M)")
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--batch", type=int, default=1024)
     p.add_argument("--k", type=int, default=10)
@@ -67,12 +90,15 @@ def parse():
     p.add_argument("--dist", default="lowrank", choices=["lowrank", "normal", "clustered"])
     p.add_argument("--ef", type=int, default=0, help="0: smallest ef of the ladder reaching recall >= 0.95")
     p.add_argument("--recall-target", type=float, default=0.95)
-    p.add_argument("--pr-nodes", type=int, default=10_000_000, help="PageRank nodes per GPU")
-    p.add_argument("--pr-edges", type=int, default=100_000_000, help="PageRank edges per GPU (before de-duplication)")
+    p.add_argument("--pr-nodes", type=int, default=10_000_000, help="PageRank nodes (N = 1; configs[2])")
+    p.add_argument("--pr-edges", type=int, default=100_000_000, help="PageRank edges before de-duplication (N = 1)")
+    p.add_argument("--pr-nodes-total", type=int, default=100_000_000, help="PageRank nodes over all ranks at N > 1 (configs[4])")
+    p.add_argument("--pr-edges-total", type=int, default=1_000_000_000)
     p.add_argument("--pr-iters", type=int, default=20)
     p.add_argument("--skip-pagerank", action="store_true")
     p.add_argument("--skip-hnsw", action="store_true")
     p.add_argument("--skip-cpu", action="store_true")
+    p.add_argument("--skip-secondary", action="store_true", help="only the primary HNSW workload and the uniform PageRank graph")
     p.add_argument("--cpu-queries", type=int, default=256)
     return p.parse_args()
 
@@ -91,10 +117,14 @@ def gen_vectors(torch, n, dim, kind, seed, device):
         gc = torch.Generator(device=device)
         gc.manual_seed(777)
         centres = torch.randn((16, dim), generator=gc, device=device, dtype=torch.float32)
-        which = torch.randint(0, 16, (n,), generator=g, device=device)
-        x = torch.randn((n, dim), generator=g, device=device, dtype=torch.float32)
-        x.mul_(0.5).add_(centres[which])
-        return x
+        out = torch.empty((n, dim), device=device, dtype=torch.float32)
+        step = 1 << 20
+        for s in range(0, n, step):
+            e = min(n, s + step)
+            which = torch.randint(0, 16, (e - s,), generator=g, device=device)
+            x = torch.randn((e - s, dim), generator=g, device=device, dtype=torch.float32)
+            out[s:e] = x.mul_(0.5).add_(centres[which])
+        return out
     gw = torch.Generator(device=device)
     gw.manual_seed(12345)
     r = 32
@@ -115,101 +145,223 @@ def recall_at_k(torch, ids, gt):
     return float((hit / gt.shape[1]).mean().item())
 
 
-def bench_hnsw(args, torch, dist, rank, world, device):
-    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest, HnswSearch
-    stream = torch.cuda.current_stream().cuda_stream
-    B, k, dim = args.batch, args.k, args.dim
-    t0 = time.time()
-    x = gen_vectors(torch, args.n, dim, args.dist, 42, device)  # every rank: the same corpus (replica)
-    q = gen_vectors(torch, B, dim, args.dist, 43 + rank, device)  # every rank: its own parent tuples
-    torch.cuda.synchronize()
-    log(f"generated {args.n} x {dim} vectors ({args.dist}) in {time.time() - t0:.1f}s")
-    db = bench_distance_batch(args, torch, x, q, stream, device) if rank == 0 else None
-    man = HnswIndexManifest(vec_dim=dim, distance="Cosine", m_neighbours=args.m, ef_construction=args.ef_construction)
-    t0 = time.time()
-    ix = GpuHnswIndex.build(man, x, seed=7, max_batch=args.max_batch, device_ptr=True, n=args.n, stream=stream)
-    torch.cuda.synchronize()
-    build_s = time.time() - t0
-    build_nd = ix.last_build_n_dist
-    del x
-    torch.cuda.empty_cache()
-    log(f"built index in {build_s:.1f}s ({build_nd:.3e} distance evaluations, {build_nd * 4 * dim / build_s / 1e9:.0f} GB/s)")
-    # ground truth by exhaustive scan, then the smallest ef of the ladder that reaches the recall target
-    gt = torch.empty((B, k), dtype=torch.int32, device=device)
-    gtd = torch.empty((B, k), dtype=torch.float64, device=device)
-    t0 = time.time()
-    ix.bruteforce_knn_device(q, k, gt, gtd, stream, gemm=True)  # B x N x d dot products as one f32 MFMA GEMM
-    torch.cuda.synchronize()
-    gt_s = time.time() - t0
-    log(f"exact ground truth (GEMM form on the matrix cores): {gt_s * 1e3:.0f} ms, {2.0 * B * args.n * dim / gt_s / 1e12:.1f} TFLOP/s incl. selection")
-    gt64 = gt.to(torch.int64) & 0xFFFFFFFF
-    ids = torch.empty((B, k), dtype=torch.int32, device=device)
-    dd = torch.empty((B, k), dtype=torch.float64, device=device)
-    cnt = torch.empty(B, dtype=torch.int32, device=device)
-    nd = torch.zeros(B, dtype=torch.int64, device=device)
+class HnswRun:
+    """one HNSW workload on this rank: corpus -> index (built on the GPU) -> exact ground truth -> ef -> timed steps"""
 
-    def run(ef):
-        ix.hnsw_knn_batch_device(q, HnswSearch(k=k, ef=ef), ids, dd, cnt, nd, stream)
-
-    ladder = [args.ef] if args.ef else [16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024]
-    ef, rec, sweep = ladder[-1], 0.0, []
-    for cand in ladder:
-        if cand < k:
-            continue
-        run(cand)
+    def __init__(self, args, torch, device, n, kind, q, max_batch=None, x=None):
+        from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest
+        self.args, self.torch, self.device, self.n, self.kind, self.q = args, torch, device, n, kind, q
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.B, self.k, self.dim = q.shape[0], args.k, args.dim
+        t0 = time.time()
+        own = x is None
+        if own:
+            x = gen_vectors(torch, n, self.dim, kind, 42, device)
+            torch.cuda.synchronize()
+            log(f"generated {n} x {self.dim} vectors ({kind}) in {time.time() - t0:.1f}s")
+        self.x = x
+        man = HnswIndexManifest(vec_dim=self.dim, distance="Cosine", m_neighbours=args.m, ef_construction=args.ef_construction)
+        t0 = time.time()
+        self.ix = GpuHnswIndex.build(man, x, seed=7, max_batch=max_batch or args.max_batch, device_ptr=True, n=n, stream=self.stream)
         torch.cuda.synchronize()
-        rec = recall_at_k(torch, ids.to(torch.int64) & 0xFFFFFFFF, gt64)
-        sweep.append((cand, round(rec, 4)))
-        ef = cand
-        if rec >= args.recall_target:
-            break
+        self.build_s = time.time() - t0
+        self.build_nd = self.ix.last_build_n_dist
+        log(f"built the {n}-vector index in {self.build_s:.1f}s ({self.build_nd:.3e} distance evaluations, "
+            f"{self.build_nd / max(n, 1):.0f} per vector)")
+        B, k = self.B, self.k
+        self.ids = torch.empty((B, k), dtype=torch.int32, device=device)
+        self.dd = torch.empty((B, k), dtype=torch.float64, device=device)
+        self.cnt = torch.empty(B, dtype=torch.int32, device=device)
+        self.nd = torch.zeros(B, dtype=torch.int64, device=device)
+
+    def drop_corpus(self):
+        self.x = None
+        self.torch.cuda.empty_cache()
+
+    def ground_truth(self, q=None):
+        torch = self.torch
+        q = self.q if q is None else q
+        gt = torch.empty((q.shape[0], self.k), dtype=torch.int32, device=self.device)
+        gtd = torch.empty((q.shape[0], self.k), dtype=torch.float64, device=self.device)
+        t0 = time.time()
+        self.ix.bruteforce_knn_device(q, self.k, gt, gtd, self.stream, gemm=True)  # B x N x d dot products as one f32 MFMA GEMM
+        torch.cuda.synchronize()
+        gt_s = time.time() - t0
+        log(f"exact ground truth over {self.n} vectors (GEMM form on the matrix cores): {gt_s * 1e3:.0f} ms, "
+            f"{2.0 * q.shape[0] * self.n * self.dim / gt_s / 1e12:.1f} TFLOP/s incl. selection")
+        return gt.to(torch.int64) & 0xFFFFFFFF
+
+    def search(self, ef, q=None):
+        from cozo_amd.hnsw import HnswSearch
+        self.ix.hnsw_knn_batch_device(self.q if q is None else q, HnswSearch(k=self.k, ef=ef), self.ids, self.dd, self.cnt,
+                                      self.nd, self.stream)
+
+    def pick_ef(self, gt64, forced=0):
+        torch = self.torch
+        ladder = [forced] if forced else EF_LADDER
+        ef, rec, sweep = ladder[-1], 0.0, []
+        for cand in ladder:
+            if cand < self.k:
+                continue
+            self.search(cand)
+            torch.cuda.synchronize()
+            rec = recall_at_k(torch, self.ids.to(torch.int64) & 0xFFFFFFFF, gt64)
+            sweep.append((cand, round(rec, 4)))
+            ef = cand
+            if rec >= self.args.recall_target:
+                break
+        return ef, rec, sweep
+
+    def timed(self, ef, steps, warmup, dist=None, world=1):
+        torch = self.torch
+        for _ in range(warmup):
+            self.search(ef)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            self.search(ef)
+        e1.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        dev_ms = e0.elapsed_time(e1)
+        if world > 1:
+            t = torch.tensor([wall], device=self.device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        n_dist = int(self.nd.sum().item())
+        algo_bytes = n_dist * 4 * self.dim  # SURVEY 8d: 4*d bytes per distance evaluation (the query is on-chip)
+        kern_s = dev_ms / 1e3 / steps
+        return dict(wall=wall, ms_per_step=wall / steps * 1e3, n_dist=n_dist,
+                    roofline=dict(bound="hbm", kernel="hnsw_knn_kernel", achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
+                                  unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS, traffic=None,
+                                  algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=kern_s * 1e3))
+
+    def close(self):
+        self.ix.close()
+        self.x = None
+        self.torch.cuda.empty_cache()
+
+
+def hnsw_secondary(args, torch, device, n, kind, steps, warmup):
+    """configs[1]-sized workloads beside the headline one: same pipeline, reported as an object"""
+    q = gen_vectors(torch, args.batch, args.dim, kind, 43, device)
+    run = HnswRun(args, torch, device, n, kind, q)
+    try:
+        run.drop_corpus()
+        gt64 = run.ground_truth()
+        ef, rec, sweep = run.pick_ef(gt64)
+        t = run.timed(ef, steps, warmup)
+        log(f"hnsw {n} x {args.dim} ({kind}): ef sweep {sweep} -> ef = {ef}, recall = {rec:.4f}, {t['ms_per_step']:.3f} ms/batch")
+        return dict(workload=f"HNSW k={args.k} cosine, {n} x {args.dim} f32 ({kind}), query batch={args.batch}, m={args.m}, "
+                             f"ef_construction={args.ef_construction}", value=args.batch * steps / t["wall"], unit="queries/s",
+                    ms_per_step=t["ms_per_step"], ef=ef, recall_at_k=rec, reached_recall_target=rec >= args.recall_target,
+                    n_dist_per_query=t["n_dist"] / args.batch, index_build_s=run.build_s, sweep=sweep, roofline=t["roofline"])
+    finally:
+        run.close()
+
+
+def bench_hnsw(args, torch, dist, rank, world, device):
+    B, k, dim = args.batch, args.k, args.dim
+    q = gen_vectors(torch, B, dim, args.dist, 43 + rank, device)  # every rank: its own parent tuples
+    run = HnswRun(args, torch, device, args.n, args.dist, q)  # every rank: the same corpus (its own replica of the index)
+    stream = run.stream
+    db = bench_distance_batch(args, torch, run.x, q, stream, device) if rank == 0 else None
+    shard_x = None
+    if world > 1:  # this rank's part of the partitioned index of configs[3], cut out before the corpus is dropped
+        per = (args.n + world - 1) // world
+        shard_x = run.x[rank * per:min(args.n, (rank + 1) * per)].clone()
+    run.drop_corpus()
+    gt64 = run.ground_truth()
+    q0 = gt0 = None
+    if world > 1:
+        q0 = q.clone()
+        dist.broadcast(q0, src=0)
+        gt0 = run.ground_truth(q0)  # exact neighbours of rank 0's batch over all N vectors: the sharded search is scored on it
+    ef, rec, sweep = run.pick_ef(gt64, args.ef)
     if world > 1:  # every rank does the same work: take the largest ef any rank needs
         t = torch.tensor([ef], device=device, dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ef = int(t.item())
-        run(ef)
+        run.search(ef)
         torch.cuda.synchronize()
-        rec = recall_at_k(torch, ids.to(torch.int64) & 0xFFFFFFFF, gt64)
+        rec = recall_at_k(torch, run.ids.to(torch.int64) & 0xFFFFFFFF, gt64)
     log(f"ef sweep {sweep} -> ef = {ef}, recall@{k} = {rec:.4f}")
-    for _ in range(args.warmup):
-        run(ef)
-    torch.cuda.synchronize()
+    t = run.timed(ef, args.steps, args.warmup, dist, world)
+    t["roofline"]["traffic"] = pmc_traffic("hnsw_knn", world)
+    res = dict(qps=world * B * args.steps / t["wall"], ms_per_step=t["ms_per_step"], ef=ef, recall=rec,
+               n_dist_per_query=t["n_dist"] / B, build_s=run.build_s, build_n_dist=run.build_nd, roofline=t["roofline"],
+               index_bytes=run.ix.device_bytes, sweep=sweep, distance_batch=db)
+    # CPU baseline + parity: the oracle (a port of the reference algorithm) on the same index and the same queries
+    if rank == 0 and world == 1 and not args.skip_cpu:
+        try:
+            res["cpu_baseline"], res["parity"] = cpu_baseline_hnsw(args, run, ef)
+        except Exception as e:  # the baseline never blocks the GPU number
+            res["cpu_baseline"] = dict(value=None, unit="queries/s", cores=1, kind="port", sample=f"failed: {type(e).__name__}: {e}")
+    run.close()
     if world > 1:
+        try:
+            res["sharded"] = bench_hnsw_sharded(args, torch, dist, rank, world, device, shard_x, q0, gt0)
+        except Exception as e:  # noqa: BLE001
+            res["sharded"] = dict(error=f"{type(e).__name__}: {e}")
+    return res
+
+
+def bench_hnsw_sharded(args, torch, dist, rank, world, device, shard_x, q0, gt0):
+    """configs[3]: the N vectors partitioned into `world` independent sub-indices (contiguous ranges of the same corpus),
+    rank 0's query batch broadcast, per-shard hnsw_knn with the same k / ef, all-gather + merge of the top-k lists
+    (cozo_amd.distributed.sharded_hnsw_knn).  Scored against the exact neighbours over ALL N vectors."""
+    from cozo_amd.distributed import merge_shard_topk
+    B, k = args.batch, args.k
+    per = (args.n + world - 1) // world
+    run = HnswRun(args, torch, device, shard_x.shape[0], args.dist, q0, x=shard_x)
+    try:
+        run.drop_corpus()
+
+        def step(ef):
+            run.search(ef)
+            return merge_shard_topk(run.ids.to(torch.int64) & 0xFFFFFFFF, run.dd, rank * per, k, world)
+
+        ef, rec, sweep = EF_LADDER[-1], 0.0, []
+        for cand in EF_LADDER:
+            if cand < k:
+                continue
+            ids, _ = step(cand)
+            torch.cuda.synchronize()
+            rec = recall_at_k(torch, ids, gt0)
+            sweep.append((cand, round(rec, 4)))
+            ef = cand
+            if rec >= args.recall_target:
+                break
+        for _ in range(args.warmup):
+            step(ef)
+        torch.cuda.synchronize()
         dist.barrier()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        run(ef)
-    e1.record()
-    torch.cuda.synchronize()
-    if world > 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(ef)
+        torch.cuda.synchronize()
         dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)
-    if world > 1:
+        wall = time.perf_counter() - t0
         t = torch.tensor([wall], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-    n_dist = int(nd.sum().item())
-    algo_bytes = n_dist * 4 * dim  # 4*d bytes per distance evaluation (the query is on-chip)
-    kern_s = dev_ms / 1e3 / args.steps
-    res = dict(qps=world * B * args.steps / wall, ms_per_step=wall / args.steps * 1e3, ef=ef, recall=rec,
-               n_dist_per_query=n_dist / B, build_s=build_s, build_n_dist=build_nd,
-               roofline=dict(bound="hbm", kernel="hnsw_knn_kernel", achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
-                             unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS, traffic=pmc_traffic("hnsw_knn", world),
-                             algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=kern_s * 1e3),
-               index_bytes=ix.device_bytes, sweep=sweep, distance_batch=db)
-    # CPU baseline: the oracle (a port of the reference algorithm) on the same index and the same queries
-    if rank == 0 and world == 1 and not args.skip_cpu:
-        try:
-            res["cpu_baseline"] = cpu_baseline_hnsw(args, ix, q, ef, k)
-        except Exception as e:  # the baseline never blocks the GPU number
-            res["cpu_baseline"] = dict(value=None, unit="queries/s", cores=1, kind="port", sample=f"failed: {e}")
-    ix.close()
-    return res
+        return dict(workload=f"{args.n} x {args.dim} split into {world} sub-indices of {per}, one per GPU; the same "
+                             f"{B}-query batch searched on every shard, top-k lists all-gathered ({B * k * 16} B per rank) and merged",
+                    value=B * args.steps / wall, unit="queries/s", ms_per_step=wall / args.steps * 1e3, ef=ef,
+                    merged_recall_at_k=rec, sweep=sweep, shard_build_s=run.build_s,
+                    note="a partition buys capacity, not throughput: every shard's traversal costs almost what the whole "
+                         "index's does, so the replica form above is the throughput configuration while N x 768 x 4 B fits one GPU")
+    finally:
+        run.close()
 
 
 def bench_distance_batch(args, torch, x, q, stream, device):
@@ -233,147 +385,270 @@ def bench_distance_batch(args, torch, x, q, stream, device):
     torch.cuda.synchronize()
     s = e0.elapsed_time(e1) / 1e3 / reps
     algo = P * 4 * x.shape[1]
-    return dict(kernel="cz_distance_batch = pair_keys + rocprim radix sort by query + distance_runs_kernel (the whole call is timed)",
-                pairs=P, metric="Cosine", ms=s * 1e3, distances_per_s=P / s,
+    return dict(kernel="cz_distance_batch: pairs grouped by query (hand-written counting sort) + distance_runs_kernel; the whole call is timed",
+                pairs=P, base_rows=int(x.shape[0]), metric="Cosine", ms=s * 1e3, distances_per_s=P / s,
                 roofline=dict(bound="hbm", achieved=algo / s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                              frac=algo / s / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_launch=algo, avg_launch_ms=s * 1e3))
+                              frac=algo / s / 1e9 / HBM_PEAK_GBS, traffic=pmc_traffic("distance_batch", 1),
+                              algorithmic_bytes_per_launch=algo, avg_launch_ms=s * 1e3))
 
 
-def cpu_baseline_hnsw(args, ix, q, ef, k):
+def cpu_baseline_hnsw(args, run, ef):
+    """The oracle on the SAME index (exported from the device) and the same queries.  Three runs:
+    (a) 1 thread, the reference's summation order: what one cozo script gets (HnswSearchRA::iter is sequential);
+    (b) every host core over the query batch (the reference has no such path; an upper bound for a CPU deployment);
+    (c) the kernel's summation order: ids, distances and per-query evaluation counts must equal the GPU's bit for bit --
+        the parity check of what was just timed -- plus the measured relative error against (a)'s arithmetic."""
     from oracle import oracle as O
+    torch, k = run.torch, run.k
     t0 = time.time()
-    nodes, nbrs, entry = ix.export()
-    vec = ix.export_vectors()
+    nodes, nbrs, entry = run.ix.export()
+    vec = run.ix.export_vectors()
     flat = O.FlatIndex(vec, O.COSINE, nodes, nbrs, entry)
     log(f"exported the index to the host in {time.time() - t0:.1f}s")
-    qh = q[:args.cpu_queries].cpu().numpy()
+    qall = run.q.cpu().numpy()
+    nq = min(args.cpu_queries, qall.shape[0])
+    qh = qall[:nq]
+    cores = os.cpu_count() or 1
     flat.knn_batch(qh[:8], k, ef)  # touch
     t0 = time.perf_counter()
-    _, _, _, nd = flat.knn_batch(qh, k, ef, dot_mode=O.DOT_NDARRAY, threads=1)
-    dt = time.perf_counter() - t0
-    return dict(value=len(qh) / dt, unit="queries/s", cores=1, kind="port",
-                sample=f"{len(qh)} of the {args.batch} queries, same index (exported), same ef={ef}, 1 thread "
+    rids, rdist, _, nd1 = flat.knn_batch(qh, k, ef, dot_mode=O.DOT_NDARRAY, threads=1)
+    dt1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    flat.knn_batch(qall, k, ef, dot_mode=O.DOT_NDARRAY, threads=cores)
+    dtn = time.perf_counter() - t0
+    # parity: the launch that was timed last left its results in run.ids / run.dd / run.nd
+    gids = (run.ids[:nq].cpu().numpy().astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)
+    gdist = run.dd[:nq].cpu().numpy()
+    gcnt = run.cnt[:nq].cpu().numpy().astype(np.uint32)
+    gnd = int(run.nd[:nq].sum().item())
+    oids, odist, ocnt, ond = flat.knn_batch(qh, k, ef, dot_mode=O.DOT_GPU, threads=cores)
+    bit_equal = bool(np.array_equal(gids, oids) and np.array_equal(gdist, odist) and np.array_equal(gcnt, ocnt) and gnd == ond)
+    # measured error of the kernel's arithmetic against the reference's (ndarray order) on the rows the search returned
+    pairs = np.stack([np.repeat(np.arange(nq, dtype=np.uint32), k), gids.reshape(-1)], 1)
+    ok = pairs[:, 1] != 0xFFFFFFFF
+    ref = O.distance_pairs(O.COSINE, vec, qh, pairs[ok], O.DOT_NDARRAY)
+    got = gdist.reshape(-1)[ok]
+    rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)
+    same_rows = float(np.mean(gids == rids))
+    parity = dict(parity_checked=bit_equal, queries=nq,
+                  what="ids, f64 distances, row counts and the distance-evaluation count of the timed launch == the CPU oracle "
+                       "with the kernel's summation tree (ORC_DOT_GPU), bit for bit, on the exported 10M-scale index",
+                  max_rel_err_vs_reference_arithmetic=float(rel.max()) if rel.size else 0.0,
+                  tolerance=1e-5, within_tolerance=bool(rel.size == 0 or rel.max() <= 1e-5),
+                  same_rows_as_reference_order=same_rows)
+    log(f"parity vs the oracle on {nq} queries: bit-equal = {bit_equal}; max relative distance error vs the reference's "
+        f"summation order = {parity['max_rel_err_vs_reference_arithmetic']:.2e}")
+    base = dict(value=nq / dt1, unit="queries/s", cores=1, kind="port",
+                sample=f"{nq} of the {qall.shape[0]} queries, same index (exported), same ef={ef}, 1 thread "
                        f"(HnswSearchRA::iter is sequential: one cozo script gets one core); C port of hnsw_knn "
                        f"(oracle/, -O3 AVX2) without the reference's KV-store / msgpack overhead, so optimistic; "
-                       f"{nd / len(qh):.0f} dist evals/query; {os.cpu_count()} host cores present")
+                       f"{nd1 / nq:.0f} dist evals/query",
+                all_cores=dict(value=qall.shape[0] / dtn, unit="queries/s", cores=cores,
+                               sample=f"all {qall.shape[0]} queries over {cores} OpenMP threads of this box's host (the "
+                                      f"reference has no parallel-over-queries path; upper bound for a CPU deployment)"))
+    return base, parity
 
 
 # ------------------------------------------------------------------------------------------------------------
-def bench_pagerank(args, torch, dist, rank, world, device):
-    from cozo_amd.distributed import ShardedPageRank, equal_row_partition
-    from cozo_amd.graph import PageRankPlan
-    stream = torch.cuda.current_stream().cuda_stream
-    n_total = args.pr_nodes * world
-    per, ranges = equal_row_partition(n_total, world)
-    rb, re = ranges[rank]
-    rows = re - rb
-    t0 = time.time()
+def rmat_edges(torch, scale, n_edges, device, seed, abcd=(0.57, 0.19, 0.19, 0.05)):
+    """R-MAT (Chakrabarti et al.) edge list of 2^scale nodes: per bit one of four quadrants, probabilities (a, b, c, d).
+    Returns (src, dst) int64; no permutation of the ids (hubs are the low ids), duplicates / self loops still inside."""
+    a, b, c, _ = abcd
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    src = torch.zeros(n_edges, dtype=torch.int64, device=device)
+    dst = torch.zeros(n_edges, dtype=torch.int64, device=device)
+    for _ in range(scale):
+        r = torch.rand(n_edges, generator=g, device=device, dtype=torch.float32)
+        sbit = (r >= a + b).to(torch.int64)
+        dbit = (((r >= a) & (r < a + b)) | (r >= a + b + c)).to(torch.int64)
+        src = (src << 1) | sbit
+        dst = (dst << 1) | dbit
+        del r, sbit, dbit
+    return src, dst
+
+
+def make_graph(args, torch, dist, rank, world, device, kind, n_total, e_local, rb, rows):
+    """this rank's rows [rb, rb + rows) of the in-CSR of a synthetic directed graph: (off int64 [rows+1], src int32 [E],
+    out_degree int32 [n_total])"""
     g = torch.Generator(device=device)
     g.manual_seed(4242 + rank)
-    e_local = args.pr_edges
-    # uniform random directed graph, partitioned by destination: this rank draws the edges that end in its rows
-    dst = torch.randint(0, rows, (e_local,), generator=g, device=device, dtype=torch.int64)
-    src = torch.randint(0, n_total, (e_local,), generator=g, device=device, dtype=torch.int64)
+    if kind == "uniform":
+        # uniform random directed graph, partitioned by destination: this rank draws the edges that end in its rows
+        dst = torch.randint(0, rows, (e_local,), generator=g, device=device, dtype=torch.int64)
+        src = torch.randint(0, n_total, (e_local,), generator=g, device=device, dtype=torch.int64)
+    else:
+        # R-MAT scale ceil(log2 N), truncated to N (SURVEY 8d C3-ii); 1.6x the edges are drawn because truncation,
+        # self loops and duplicates take their share.  Single rank only.
+        scale = max(1, (n_total - 1).bit_length())
+        src, dst = rmat_edges(torch, scale, int(e_local * 1.6), device, 4242)
+        keep = (src < n_total) & (dst < n_total)
+        src, dst = src[keep], dst[keep]
+        del keep
     keep = src != (dst + rb)  # no self loops
     key = (dst[keep] * n_total + src[keep])
     del dst, src, keep
     key = torch.unique(key)  # a relation is a set; also sorts by (dst, src) = CsrLayout::Sorted in-adjacency
+    if kind != "uniform" and key.numel() > e_local:
+        sel = torch.randperm(key.numel(), generator=g, device=device)[:e_local]
+        key = torch.sort(key[sel]).values
+        del sel
     d = torch.div(key, n_total, rounding_mode="floor")
     s = (key - d * n_total).to(torch.int32)
     del key
     counts = torch.bincount(d, minlength=rows)
     off = torch.zeros(rows + 1, dtype=torch.int64, device=device)
     off[1:] = torch.cumsum(counts, 0)
-    e_kept = int(off[-1].item())
     outdeg = torch.bincount(s.to(torch.int64), minlength=n_total)
     if world > 1:
         dist.all_reduce(outdeg, op=dist.ReduceOp.SUM)
-    outdeg32 = outdeg.to(torch.int32)
+    max_in = int(counts.max().item()) if rows else 0
+    del d, counts
+    return off, s, outdeg.to(torch.int32), max_in
+
+
+def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
+    from cozo_amd.distributed import ShardedPageRank, equal_row_partition
+    from cozo_amd.graph import PageRankPlan
+    stream = torch.cuda.current_stream().cuda_stream
+    if world == 1:
+        n_total, e_local = args.pr_nodes, args.pr_edges
+    else:  # configs[4]: a fixed total, row-sharded (strong scaling)
+        n_total, e_local = args.pr_nodes_total, args.pr_edges_total // world
+    per, ranges = equal_row_partition(n_total, world)
+    rb, re = ranges[rank]
+    rows = re - rb
+    t0 = time.time()
+    off, s, outdeg32, max_in = make_graph(args, torch, dist, rank, world, device, kind, n_total, e_local, rb, rows)
+    e_kept = int(off[-1].item())
     off32 = off.to(torch.int32)
-    del d, counts, outdeg
     torch.cuda.synchronize()
     e_total = e_kept
     if world > 1:
         t = torch.tensor([e_kept], device=device, dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         e_total = int(t.item())
-    log(f"pagerank graph: {n_total} nodes, {e_total} edges (rank 0 holds {e_kept}) generated in {time.time() - t0:.1f}s")
-    plan = PageRankPlan(off32, s, outdeg32, n_total, rb, re, 0.85, device_ptrs=True)
-    sp = ShardedPageRank(n_total, rank, world, device, lambda c: plan.init(c, stream),
-                         lambda cin, cout, err: plan.step(cin, cout, err, stream))
-    # reference defaults (epsilon 1e-4, 10 iterations) -> how many iterations the stopping rule takes
-    it_default, err_default = sp.run(1e-4, 10)
-    # steady state: fixed iteration count, tolerance 0
-    sp.run(0.0, 2)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    iters, _ = sp.run(0.0, args.pr_iters)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    wall = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([wall], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    # kernel-only time of the SpMV sweep (HIP events on the launch stream, no host round trip in between)
-    cin, cout = sp.contrib
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 10
-    e0.record()
-    for _ in range(reps):
-        plan.step(cin, cout, sp.err, stream)
-        cin, cout = cout, cin
-    e1.record()
-    torch.cuda.synchronize()
-    kern_s = e0.elapsed_time(e1) / 1e3 / reps
-    algo_bytes = 4 * e_kept + 4 * (rows + 1) + 20 * rows  # SURVEY 8d compulsory-traffic model, this rank's shard
-    blocked = plan.blocked
-    kernel = "pb_expand_kernel + pb_reduce_kernel (one sweep)" if blocked else "pr_step_kernel"
-    res = dict(value=e_total * iters / wall, unit="edges/s", iterations=iters, ms_per_iteration=wall / iters * 1e3,
-               nodes=n_total, edges=e_total, default_run=dict(iterations=it_default, final_err=err_default),
-               formulation="blocked" if blocked else "gather",
-               roofline=dict(bound="hbm", kernel=kernel, achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
-                             unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
-                             traffic=pmc_traffic("pagerank_blocked" if blocked else "pagerank_gather", world),
-                             algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=kern_s * 1e3),
-               exchange="none" if world == 1 else f"all_gather {per * 4} B/rank/iter + all_reduce f64")
+    log(f"pagerank graph ({kind}): {n_total} nodes, {e_total} edges (rank 0 holds {e_kept}; longest in-row {max_in}) generated in {time.time() - t0:.1f}s")
+
+    def measure(relaxed):
+        plan = PageRankPlan(off32, s, outdeg32, n_total, rb, re, 0.85, device_ptrs=True, relaxed=relaxed)
+        sp = ShardedPageRank(n_total, rank, world, device, lambda c: plan.init(c, stream),
+                             lambda cin, cout, err: plan.step(cin, cout, err, stream))
+        # reference defaults (epsilon 1e-4, 10 iterations) -> how many iterations the stopping rule takes
+        it_default, err_default = sp.run(1e-4, 10)
+        # steady state: fixed iteration count, tolerance 0 (SURVEY 8d)
+        sp.run(0.0, 2)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        iters, _ = sp.run(0.0, args.pr_iters)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([wall], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        # kernel-only time of the SpMV sweep (HIP events on the launch stream, no host round trip in between)
+        cin, cout = sp.contrib
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            plan.step(cin, cout, sp.err, stream)
+            cin, cout = cout, cin
+        e1.record()
+        torch.cuda.synchronize()
+        kern_s = e0.elapsed_time(e1) / 1e3 / reps
+        algo_bytes = 4 * e_kept + 4 * (rows + 1) + 20 * rows  # SURVEY 8d compulsory-traffic model, this rank's shard
+        blocked = plan.blocked
+        kernel = "pb_expand_kernel + pb_reduce_kernel (one sweep)" if blocked else "pr_step_kernel"
+        h2d_ms, build_ms = plan.timing
+        res = dict(value=e_total * iters / wall, unit="edges/s", iterations=iters, ms_per_iteration=wall / iters * 1e3,
+                   nodes=n_total, edges=e_total, graph=kind, longest_in_row=max_in,
+                   default_run=dict(iterations=it_default, final_err=err_default),
+                   formulation=("blocked" if blocked else "gather") + (", hub rows as parallel segments (CZ_PR_RELAXED)" if relaxed else
+                                                                          ", every row bit-identical to the reference"),
+                   plan_build_ms=build_ms,
+                   roofline=dict(bound="hbm", kernel=kernel, achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
+                                 unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
+                                 traffic=pmc_traffic("pagerank_blocked" if blocked else "pagerank_gather", world)
+                                 if kind == "uniform" and not relaxed else None,
+                                 algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=kern_s * 1e3),
+                   exchange="none" if world == 1 else f"all_gather {per * 4} B/rank/iter + all_reduce f64")
+        return res, plan, sp
+
+    res, plan, sp = measure(False)
     if rank == 0 and world == 1 and not args.skip_cpu:
+        h_off = off.cpu().numpy()
+        h_src = s.cpu().numpy().astype(np.uint32)
+        h_od = outdeg32.cpu().numpy().astype(np.uint32)
         try:  # SURVEY 8d: also the end-to-end figure through the host-pointer ABI (what an `impl FixedRule` pays per call)
-            from cozo_amd import graph as G
-            h_off = off.cpu().numpy().astype(np.uint32)
-            h_src = s.cpu().numpy().astype(np.uint32)
-            h_od = outdeg32.cpu().numpy().astype(np.uint32)
+            from cozo_amd import _lib, graph as G
+            _lib.lib().cz_pagerank_cache_clear()
+            h_off32 = h_off.astype(np.uint32)
+            tm0, tm1 = {}, {}
+            t0 = time.perf_counter()
+            _, it_e2e, _ = G.pagerank(h_off32, h_src, h_od, 0.85, 1e-4, 10, cache_key=(0xC0207, 1), timing=tm0)
+            first = time.perf_counter() - t0
             best = None
             for _ in range(2):
                 t0 = time.perf_counter()
-                _, it_e2e, _ = G.pagerank(h_off, h_src, h_od, 0.85, 1e-4, 10)
+                G.pagerank(h_off32, h_src, h_od, 0.85, 1e-4, 10, cache_key=(0xC0207, 1), timing=tm1)
                 dt = time.perf_counter() - t0
                 best = dt if best is None else min(best, dt)
-            res["end_to_end"] = dict(seconds=best, iterations=int(it_e2e), edges_per_s=e_total * int(it_e2e) / best,
-                                     what="cz_pagerank on host arrays: CSR upload over PCIe + plan build + the reference's "
-                                          "default run (epsilon 1e-4, <= 10 iterations) + scores back; not part of `value`")
+            _lib.lib().cz_pagerank_cache_clear()
+            res["end_to_end"] = dict(
+                iterations=int(it_e2e), first_call=dict(seconds=first, edges_per_s=e_total * int(it_e2e) / first, **tm0),
+                repeated_call=dict(seconds=best, edges_per_s=e_total * int(it_e2e) / best, **tm1),
+                what="cz_pagerank_cached on host arrays, the reference's default run (epsilon 1e-4, <= 10 iterations): the first "
+                     "call pays CSR upload over PCIe + plan build + iterations + scores back; a repeated call on the same "
+                     "(relation, snapshot) key reuses the device layout.  Not part of `value`")
         except Exception as e:  # noqa: BLE001
             res["end_to_end"] = dict(error=f"{type(e).__name__}: {e}")
         try:
             from oracle import oracle as O
-            ioff = off.cpu().numpy().astype(np.uint64)
-            isrc = s.cpu().numpy().astype(np.uint32)
-            od = outdeg32.cpu().numpy().astype(np.uint32)
+            ioff = h_off.astype(np.uint64)
             cores = os.cpu_count() or 1
             t0 = time.perf_counter()
-            _, it_cpu, _ = O.pagerank(n_total, ioff, isrc, od, 0.85, 0.0, 3, threads=cores)
+            o_scores, it_cpu, _ = O.pagerank(n_total, ioff, h_src, h_od, 0.85, 0.0, 3, threads=cores)
             dt = time.perf_counter() - t0
+            # parity: 3 sweeps from the initial state on the device == the oracle's, bit for bit
+            sp.run(0.0, 3)
+            torch.cuda.synchronize()
+            g_scores = plan.read_scores()
+            res["parity"] = dict(parity_checked=bool(np.array_equal(g_scores, o_scores)), iterations=3,
+                                 what="f32 scores of every node after 3 sweeps == the CPU oracle (graph::page_rank restated), bit for bit")
             res["cpu_baseline"] = dict(value=e_total * it_cpu / dt, unit="edges/s", cores=cores, kind="port",
                                        sample=f"{it_cpu} iterations on the same graph, {cores} threads, 16384-node dynamic "
                                               f"chunks (graph crate's scheduler); C port of graph::page_rank, iterations "
                                               f"only (the reference also pays the relation scan + id mapping)")
+            log(f"pagerank ({kind}) parity vs the oracle after 3 sweeps: {res['parity']['parity_checked']}")
         except Exception as e:
-            res["cpu_baseline"] = dict(value=None, unit="edges/s", cores=0, kind="port", sample=f"failed: {e}")
+            res["cpu_baseline"] = dict(value=None, unit="edges/s", cores=0, kind="port", sample=f"failed: {type(e).__name__}: {e}")
     plan.close()
+    del plan, sp
+    if kind != "uniform" and max_in > 16384:
+        try:  # the same graph with the hub rows summed as parallel segments
+            rel, plan2, sp2 = measure(True)
+            res["relaxed"] = {k2: rel[k2] for k2 in ("value", "unit", "ms_per_iteration", "formulation", "roofline", "default_run")}
+            if rank == 0 and world == 1 and not args.skip_cpu and "parity" in res:
+                from oracle import oracle as O
+                o_scores, _, _ = O.pagerank(n_total, off.cpu().numpy().astype(np.uint64), s.cpu().numpy().astype(np.uint32),
+                                            outdeg32.cpu().numpy().astype(np.uint32), 0.85, 0.0, 3, threads=os.cpu_count() or 1)
+                sp2.run(0.0, 3)
+                torch.cuda.synchronize()
+                g_scores = plan2.read_scores().astype(np.float64)
+                err = np.abs(g_scores - o_scores) / np.abs(o_scores)
+                res["relaxed"]["parity"] = dict(max_rel_err_vs_oracle=float(err.max()), tolerance=1e-5,
+                                                within_tolerance=bool(err.max() <= 1e-5),
+                                                rows_differing=int(np.count_nonzero(g_scores != o_scores.astype(np.float64))))
+            plan2.close()
+        except Exception as e:  # noqa: BLE001
+            res["relaxed"] = dict(error=f"{type(e).__name__}: {e}")
     return res
 
 
@@ -382,8 +657,6 @@ def bench_host_ingest(n_rows=4_000_000, n_nodes=400_000, seed=9):
     synthetic (int, int)-keyed edge relation -> first-appearance ids + both CSR directions through libcozo_ingest
     (include/cozo_ingest.h), on this box's host cores.  The key bytes are built vectorised here (memcmp encoding of two
     non-negative ints: tag 0x05, the f64 image with the sign bit set, big-endian, 0x00; data/memcmp.rs:127-145)."""
-    import time
-    import numpy as np
     from cozo_amd import build as B, codec
     from cozo_amd.ingest import StoredGraph
     B.build_ingest()
@@ -431,10 +704,27 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    t_start = time.time()
     out = {}
     hn = None if args.skip_hnsw else bench_hnsw(args, torch, dist, rank, world, device)
     torch.cuda.empty_cache()
     pr = None if args.skip_pagerank else bench_pagerank(args, torch, dist, rank, world, device)
+    torch.cuda.empty_cache()
+    extra = {}
+    if rank == 0 and world == 1 and not args.skip_secondary:
+        if not args.skip_pagerank:
+            try:
+                extra["pagerank_rmat"] = bench_pagerank(args, torch, dist, rank, world, device, kind="rmat")
+            except Exception as e:  # noqa: BLE001
+                extra["pagerank_rmat"] = dict(error=f"{type(e).__name__}: {e}")
+            torch.cuda.empty_cache()
+        if not args.skip_hnsw and args.n > 1_000_000:
+            for name, kind in (("hnsw_1m", args.dist), ("hnsw_1m_clustered", "clustered")):
+                try:
+                    extra[name] = hnsw_secondary(args, torch, device, 1_000_000, kind, args.steps, args.warmup)
+                except Exception as e:  # noqa: BLE001
+                    extra[name] = dict(error=f"{type(e).__name__}: {e}")
+                torch.cuda.empty_cache()
     if rank == 0:
         if hn is not None:
             out = {
@@ -446,27 +736,32 @@ def main():
                                        f"index built on the GPU (max_batch={args.max_batch})",
                            "parallelism": "1 GPU" if world == 1 else f"{world} index replicas, query batches sharded across ranks",
                            "recall_at_k": hn["recall"], "ef": hn["ef"], "n_dist_per_query": hn["n_dist_per_query"],
-                           "index_build_s": hn["build_s"], "index_bytes": hn["index_bytes"]},
+                           "index_build_s": hn["build_s"], "index_build_n_dist": hn["build_n_dist"],
+                           "index_bytes": hn["index_bytes"], "ef_sweep": hn["sweep"]},
                 "roofline": hn["roofline"],
             }
-            if "cpu_baseline" in hn:
-                out["cpu_baseline"] = hn["cpu_baseline"]
-            if hn.get("distance_batch"):
-                out["distance_batch"] = hn["distance_batch"]
+            for key in ("cpu_baseline", "parity", "distance_batch"):
+                if hn.get(key):
+                    out[key] = hn[key]
+            if hn.get("sharded"):
+                out["hnsw_sharded"] = hn["sharded"]
         else:
             out = {"metric": "pagerank_edges_per_sec", "value": pr["value"], "unit": "edges/s", "n_gpus": world,
                    "steps": pr["iterations"], "warmup": 2, "ms_per_step": pr["ms_per_iteration"], "higher_is_better": True,
-                   "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                   "config": {"workload": f"PageRank {pr['nodes']} nodes / {pr['edges']} edges"}, "roofline": pr["roofline"]}
+                   "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "config": {"workload": f"PageRank {pr['nodes']} nodes / {pr['edges']} edges ({pr['graph']})"},
+                   "roofline": pr["roofline"]}
             if "cpu_baseline" in pr:
                 out["cpu_baseline"] = pr["cpu_baseline"]
         if pr is not None and hn is not None:
             out["pagerank"] = pr
-        if not args.skip_cpu:
+        out.update(extra)
+        if not args.skip_cpu and not args.skip_secondary:
             try:  # informational; never allowed to cost the bench line
                 out["host_ingest"] = bench_host_ingest()
             except Exception as e:  # noqa: BLE001
                 out["host_ingest"] = {"error": f"{type(e).__name__}: {e}"}
+        out["bench_wall_s"] = time.time() - t_start
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -16,6 +16,7 @@ CZ_DEVICE_PTRS = 1
 CZ_BF_GEMM = 8
 CZ_PR_GATHER = 2
 CZ_PR_BLOCKED = 4
+CZ_PR_RELAXED = 16
 CZ_L2, CZ_COSINE, CZ_IP = 0, 1, 2
 CZ_OK, CZ_E_INVALID, CZ_E_NO_DEVICE, CZ_E_HIP, CZ_E_CANCELLED, CZ_E_OOM, CZ_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 
@@ -51,6 +52,11 @@ class HnswDesc(C.Structure):
     ]
 
 
+class PagerankTiming(C.Structure):
+    _fields_ = [("h2d_ms", C.c_double), ("plan_build_ms", C.c_double), ("iterate_ms", C.c_double), ("d2h_ms", C.c_double),
+                ("cache_hit", C.c_int32), ("reserved", C.c_int32)]
+
+
 # every symbol include/cozo_gpu.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "cz_init": (C.c_int, [C.c_int]),
@@ -76,6 +82,11 @@ SYMBOLS = {
                                     C.c_void_p]),
     "cz_pagerank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_double,
                               C.c_uint32, C.c_void_p, u32p, f64p, C.c_void_p]),
+    "cz_pagerank_cached": (C.c_int, [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
+                                     C.c_float, C.c_double, C.c_uint32, C.c_uint32, C.c_void_p, u32p, f64p, C.c_void_p,
+                                     C.POINTER(PagerankTiming)]),
+    "cz_pagerank_cache_clear": (None, []),
+    "cz_pagerank_plan_timing": (C.c_int, [C.c_void_p, f64p, f64p]),
     "cz_pagerank_plan_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_float, C.POINTER(C.c_void_p), C.c_uint32]),
     "cz_pagerank_plan_destroy": (None, [C.c_void_p]),

@@ -7,8 +7,6 @@
 #include <mutex>
 #include <vector>
 
-#include <rocprim/rocprim.hpp>
-
 #include "common.h"
 #include "hnsw_index.h"
 #include "hnsw_kernels.cuh"
@@ -122,8 +120,10 @@ distance_pairs_kernel(int metric, const float *__restrict__ base, const float *_
 template <int LPV, int ITERS, int U>
 __global__ void __launch_bounds__(256)
 distance_runs_kernel(int metric, const float *__restrict__ base, const float *__restrict__ queries, uint32_t ld,
-                     const uint32_t *__restrict__ pairs, const uint32_t *__restrict__ qkey,
-                     const uint32_t *__restrict__ perm, uint64_t P, uint32_t stretch, double *__restrict__ out) {
+                     const uint32_t *__restrict__ brow, const uint32_t *__restrict__ qkey,
+                     const uint32_t *__restrict__ perm, uint64_t P_all, const uint32_t *__restrict__ n_dropped,
+                     uint32_t stretch, double *__restrict__ out) {
+    const uint64_t P = P_all - *n_dropped;  // pairs naming a query row >= nq were left out of the sorted arrays
     static_assert(ITERS > 0 && U <= 16, "register-resident query; one lane of the group per pair of a round");
     const int chunks = (int)(ld / 4);
     const bool full = chunks == LPV * ITERS;
@@ -156,8 +156,9 @@ distance_runs_kernel(int metric, const float *__restrict__ base, const float *__
             const float4 *rows[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                slot[u] = perm[pos + min(u, cnt - 1)];  // past the round's end: repeat the last pair, result discarded
-                rows[u] = (const float4 *)(base + (size_t)pairs[2 * (size_t)slot[u] + 1] * ld);
+                const uint64_t at = pos + min(u, cnt - 1);  // past the round's end: repeat the last pair, result discarded
+                slot[u] = perm[at];
+                rows[u] = (const float4 *)(base + (size_t)brow[at] * ld);
             }
             RowRegs<ITERS, U> r;
             load_rows<LPV, ITERS, U, true>(r, rows, glane, chunks, full);
@@ -181,11 +182,92 @@ distance_runs_kernel(int metric, const float *__restrict__ base, const float *__
     }
 }
 
-__global__ void __launch_bounds__(256)
-pair_keys_kernel(const uint32_t *__restrict__ pairs, uint64_t P, uint32_t *__restrict__ keys, uint32_t *__restrict__ idx) {
-    for (uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (uint64_t)gridDim.x * 256) {
-        keys[p] = pairs[2 * p];
-        idx[p] = (uint32_t)p;
+// ---- grouping the pairs of a batch by query: a hand-written counting sort -------------------------------------
+// P pairs over nq <= kGroupMaxQueries query rows.  The pair list is cut into G contiguous parts, one per workgroup:
+//   A  group_hist_kernel     per-part histogram of the query ids in LDS -> hist[part][q]
+//   B  group_scan_kernel     one workgroup: hist[part][q] becomes the first sorted position of (q, part) --
+//                            query-major, part-minor, i.e. an exclusive scan in that order
+//   C  group_scatter_kernel  every part walks its pairs again: position = first[part][q] + its rank among the part's
+//                            pairs of q (LDS counter) -> qkey[pos] = q, brow[pos] = base row, perm[pos] = pair index
+// 8 bytes per pair are read twice and 12 written: 0.1 GB at P = 4M against the 12.9 GB of rows the distances read.
+constexpr int kGroupMaxQueries = 8192;  // 32 KiB of LDS counters
+constexpr int kGroupThreads = 1024;
+
+__global__ void __launch_bounds__(kGroupThreads)
+group_hist_kernel(const uint32_t *__restrict__ pairs, uint64_t P, uint32_t nq, uint64_t part_len, uint32_t *__restrict__ hist,
+                  uint32_t *__restrict__ bad) {
+    __shared__ uint32_t cnt[kGroupMaxQueries];
+    for (uint32_t i = threadIdx.x; i < nq; i += kGroupThreads) cnt[i] = 0;
+    __syncthreads();
+    const uint64_t p0 = (uint64_t)blockIdx.x * part_len, p1 = min(P, p0 + part_len);
+    for (uint64_t p = p0 + threadIdx.x; p < p1; p += kGroupThreads) {
+        const uint32_t q = pairs[2 * p];
+        if (q < nq) atomicAdd(&cnt[q], 1u);
+        else atomicAdd(bad, 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nq; i += kGroupThreads) hist[(size_t)blockIdx.x * nq + i] = cnt[i];
+}
+
+__global__ void __launch_bounds__(kGroupThreads)
+group_scan_kernel(uint32_t *__restrict__ hist, uint32_t G, uint32_t nq) {
+    __shared__ uint32_t tot[kGroupMaxQueries];
+    __shared__ uint32_t wsum[kGroupThreads / 64];
+    // per query: exclusive scan over the parts (in place), total into LDS
+    for (uint32_t q = threadIdx.x; q < nq; q += kGroupThreads) {
+        uint32_t run = 0;
+        for (uint32_t g = 0; g < G; g++) {
+            const uint32_t c = hist[(size_t)g * nq + q];
+            hist[(size_t)g * nq + q] = run;
+            run += c;
+        }
+        tot[q] = run;
+    }
+    __syncthreads();
+    // exclusive scan of the totals: thread t owns a contiguous run of queries
+    const uint32_t per = (nq + kGroupThreads - 1) / kGroupThreads;
+    const uint32_t q0 = threadIdx.x * per, q1 = min(nq, q0 + per);
+    uint32_t mine = 0;
+    for (uint32_t q = q0; q < q1; q++) mine += tot[q];
+    uint32_t x = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t before = x - mine;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    __syncthreads();
+    for (uint32_t q = q0; q < q1; q++) {
+        const uint32_t t = tot[q];
+        tot[q] = before;
+        before += t;
+    }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < nq; q += kGroupThreads) {
+        const uint32_t b = tot[q];
+        for (uint32_t g = 0; g < G; g++) hist[(size_t)g * nq + q] += b;
+    }
+}
+
+__global__ void __launch_bounds__(kGroupThreads)
+group_scatter_kernel(const uint32_t *__restrict__ pairs, uint64_t P, uint32_t nq, uint64_t part_len,
+                     const uint32_t *__restrict__ first, uint32_t *__restrict__ qkey, uint32_t *__restrict__ brow,
+                     uint32_t *__restrict__ perm) {
+    __shared__ uint32_t cur[kGroupMaxQueries];
+    for (uint32_t i = threadIdx.x; i < nq; i += kGroupThreads) cur[i] = first[(size_t)blockIdx.x * nq + i];
+    __syncthreads();
+    const uint64_t p0 = (uint64_t)blockIdx.x * part_len, p1 = min(P, p0 + part_len);
+    for (uint64_t p = p0 + threadIdx.x; p < p1; p += kGroupThreads) {
+        const uint2 pr = *(const uint2 *)(pairs + 2 * p);
+        if (pr.x >= nq) continue;  // reported by group_hist_kernel
+        const uint32_t pos = atomicAdd(&cur[pr.x], 1u);
+        qkey[pos] = pr.x;
+        brow[pos] = pr.y;
+        perm[pos] = (uint32_t)p;
     }
 }
 
@@ -502,6 +584,20 @@ extern "C" int cz_hnsw_index_create(const cz_hnsw_desc *desc, const float *vecto
         }
         if ((int)top[ix->entry] != ix->n_levels - 1)
             return cz::set_error(CZ_E_INVALID, "entry node %u is not on the top level", ix->entry);
+        // every link must name a node that exists on that level: the kernels fetch its vector and insert it into the
+        // visited set without another check
+        for (int l = 0; l < ix->n_levels; l++) {
+            const uint32_t *tab = desc->level_nbrs[l];
+            if (!tab) return cz::set_error(CZ_E_INVALID, "level_nbrs[%d] is null", l);
+            const size_t cells = (size_t)desc->level_size[l] * (size_t)desc->level_width[l];
+            for (size_t c = 0; c < cells; c++) {
+                const uint32_t nb = tab[c];
+                if (nb == CZ_NONE) continue;
+                if (nb >= ix->n || (l >= 1 && top[nb] < (uint32_t)l))
+                    return cz::set_error(CZ_E_INVALID, "level %d row %zu links to node %u, which is not on that level", l,
+                                         c / (size_t)desc->level_width[l], nb);
+            }
+        }
         std::vector<uint32_t> base(ix->n, CZ_NONE);
         uint64_t rows = 0;
         for (uint32_t i = 0; i < ix->n; i++)
@@ -670,42 +766,49 @@ static int distance_pairs_device(int metric, const float *d_base, const float *d
                                  uint32_t dim, const uint32_t *d_pairs, uint64_t P, uint32_t nq, double *d_out,
                                  hipStream_t stream) {
     Shape sh = shape_of(dim);
-    // Large batches over few queries (the shape a batched re-rank has): group the pairs by query first -- one
-    // device radix sort of (query id, position), 16 bytes of scratch per pair from the stream-ordered pool.
+    // Large batches over few queries (the shape a batched re-rank has): group the pairs by query first (counting
+    // sort above; 12 bytes of scratch per pair + the part histograms, from the stream-ordered pool, freed in stream order
+    // on every path out of this block).
     const char *env = getenv("CZ_PAIRS_GROUPED");
     const bool allow = !env || atoi(env) != 0;
-    if (allow && sh.iters > 0 && sh.iters <= 8 && P >= (1u << 16) && P < (1ull << 32) && (uint64_t)nq * 16 <= P) {
-        uint32_t *keys_in = nullptr, *keys_out = nullptr, *idx_in = nullptr, *idx_out = nullptr;
-        void *tmp = nullptr;
-        size_t tmp_bytes = 0;
-        unsigned bits = 1;
-        while ((1ull << bits) < nq) bits++;
-        CZ_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, idx_in, idx_out, (size_t)P, 0u, bits, stream));
-        CZ_HIP(hipMallocAsync((void **)&keys_in, P * 4, stream));
-        CZ_HIP(hipMallocAsync((void **)&keys_out, P * 4, stream));
-        CZ_HIP(hipMallocAsync((void **)&idx_in, P * 4, stream));
-        CZ_HIP(hipMallocAsync((void **)&idx_out, P * 4, stream));
-        CZ_HIP(hipMallocAsync(&tmp, std::max<size_t>(tmp_bytes, 16), stream));
-        hipLaunchKernelGGL(pair_keys_kernel, dim3(2048), dim3(256), 0, stream, d_pairs, P, keys_in, idx_in);
-        hipError_t se = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, idx_in, idx_out, (size_t)P, 0u, bits, stream);
-        if (se == hipSuccess) {
-            const uint32_t stretch = 256;  // sorted positions per lane group and grid step
-            const uint64_t n_stretch = (P + stretch - 1) / stretch;
-            const int blocks = (int)std::min<uint64_t>(256 * 8, (n_stretch * (uint64_t)sh.lpv + 255) / 256);
+    if (allow && sh.iters > 0 && sh.iters <= 8 && P >= (1u << 16) && P < (1ull << 32) && nq <= (uint32_t)kGroupMaxQueries &&
+        (uint64_t)nq * 16 <= P) {
+        struct AsyncBuf {  // hipMallocAsync / hipFreeAsync pair
+            void *p = nullptr;
+            hipStream_t st;
+            explicit AsyncBuf(hipStream_t s) : st(s) {}
+            ~AsyncBuf() {
+                if (p) (void)hipFreeAsync(p, st);
+            }
+            hipError_t alloc(size_t bytes) { return hipMallocAsync(&p, bytes ? bytes : 16, st); }
+        };
+        const uint32_t G = (uint32_t)std::min<uint64_t>(512, (P + 8191) / 8192);
+        const uint64_t part_len = (P + G - 1) / G;
+        AsyncBuf qkey(stream), brow(stream), perm(stream), hist(stream), bad(stream);
+        CZ_HIP(qkey.alloc(P * 4));
+        CZ_HIP(brow.alloc(P * 4));
+        CZ_HIP(perm.alloc(P * 4));
+        CZ_HIP(hist.alloc((size_t)G * nq * 4));
+        CZ_HIP(bad.alloc(4));
+        CZ_HIP(hipMemsetAsync(bad.p, 0, 4, stream));
+        hipLaunchKernelGGL(group_hist_kernel, dim3(G), dim3(kGroupThreads), 0, stream, d_pairs, P, nq, part_len, (uint32_t *)hist.p,
+                           (uint32_t *)bad.p);
+        hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(kGroupThreads), 0, stream, (uint32_t *)hist.p, G, nq);
+        hipLaunchKernelGGL(group_scatter_kernel, dim3(G), dim3(kGroupThreads), 0, stream, d_pairs, P, nq, part_len,
+                           (const uint32_t *)hist.p, (uint32_t *)qkey.p, (uint32_t *)brow.p, (uint32_t *)perm.p);
+        const char *st_env = getenv("CZ_RUNS_STRETCH");
+        const uint32_t stretch = st_env ? (uint32_t)std::max(4, atoi(st_env)) : 256;  // sorted positions per lane group and grid step
+        const uint64_t n_stretch = (P + stretch - 1) / stretch;
+        const int blocks = (int)std::min<uint64_t>(256 * 8, (n_stretch * (uint64_t)sh.lpv + 255) / 256);
 #define CZ_LAUNCH_RUNS(LPV, ITERS, U)                                                                                  \
     hipLaunchKernelGGL((distance_runs_kernel<LPV, ITERS, U>), dim3(std::max(blocks, 1)), dim3(256), 0, stream, metric, \
-                       d_base, d_queries, ld, d_pairs, keys_out, idx_out, P, stretch, d_out)
-            CZ_DISPATCH_SHAPE_RUNS(sh, CZ_LAUNCH_RUNS);
+                       d_base, d_queries, ld, (const uint32_t *)brow.p, (const uint32_t *)qkey.p, (const uint32_t *)perm.p, P, \
+                       (const uint32_t *)bad.p, stretch, d_out)
+        CZ_DISPATCH_SHAPE_RUNS(sh, CZ_LAUNCH_RUNS);
 #undef CZ_LAUNCH_RUNS
-            se = hipGetLastError();
-        }
-        (void)hipFreeAsync(keys_in, stream);
-        (void)hipFreeAsync(keys_out, stream);
-        (void)hipFreeAsync(idx_in, stream);
-        (void)hipFreeAsync(idx_out, stream);
-        (void)hipFreeAsync(tmp, stream);
+        hipError_t se = hipGetLastError();
         if (se != hipSuccess) return cz::set_error(CZ_E_HIP, "grouped distance batch: %s", hipGetErrorString(se));
-        return CZ_OK;
+        return CZ_OK;  // (a pair naming a query row >= nq is skipped, its output left untouched; the call stays asynchronous)
     }
     const int blocks = (int)std::min<uint64_t>(256 * 8, (P * (uint64_t)sh.lpv + 255) / 256);
 #define CZ_LAUNCH_PAIRS(LPV, ITERS, U)                                                                              \

@@ -30,10 +30,13 @@
 // Algorithmic HBM bytes per iteration (the roofline model of SURVEY.md section 8d, cache-perfect gathers):
 // 4E (ids) + 4(N+1) (offsets) + 20N (contrib in/out, score in/out, out-degree) = 6.4 B/edge at N = 10M, E = 100M.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <list>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -257,7 +260,8 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
                  const uint2 *__restrict__ seg /* [blocks][S+1]: (stream position, block-local prefix) */, uint32_t S,
                  const uint16_t *__restrict__ perm, const uint32_t *__restrict__ vpos, const float *__restrict__ val,
                  const uint32_t *__restrict__ out_deg, uint32_t row_begin, float *__restrict__ contrib_out,
-                 float *__restrict__ scores, float base, float damping, double *__restrict__ partial, int xcd_remap) {
+                 float *__restrict__ scores, float base, float damping, double *__restrict__ partial, int xcd_remap,
+                 double *__restrict__ seg_sum /* relaxed plans: sum of a hub-row segment, per block */) {
     __shared__ float tile[kBTileNnz];
     __shared__ double red[kBThreads / 64];
     constexpr int NW = kBThreads / 64;
@@ -359,6 +363,25 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
     }
     }
     __syncthreads();
+    if (rb.row1 == rb.row0) {
+        // relaxed plans only: this block is one SEGMENT of a row longer than a tile (a hub).  Its values are added by
+        // the whole workgroup -- 16 consecutive values per lane in f32, the lanes' sums in f64 in a fixed order -- and
+        // pr_hub_finish_kernel adds the row's segments and runs the epilogue.  (The exact form keeps such a row on one
+        // lane: the reference's sequential f32 sum, ~14 cycles per term, 3 ms for a 438 k-term row.)
+        const uint32_t nnz = rb.e1 - e0;
+        float s = 0.0f;
+        const uint32_t a = threadIdx.x * 16;
+        if (a < nnz) {
+            const uint32_t z = min(nnz, a + 16);
+            for (uint32_t e = a; e < z; e++) s = s + tile[e];
+        }
+        const double total = block_sum_f64<kBThreads>((double)s, red);
+        if (threadIdx.x == 0) {
+            seg_sum[b] = total;
+            partial[b] = 0.0;
+        }
+        return;
+    }
     double err = 0.0;
 #pragma unroll
     for (int j = 0; j < RPL; j++) {
@@ -374,6 +397,27 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
     }
     const double total = block_sum_f64<kBThreads>(err, red);
     if (threadIdx.x == 0) partial[b] = total;
+}
+
+// relaxed plans: one thread per hub row adds the row's segment sums (ascending, f64) and runs the epilogue
+struct HubRow {
+    uint32_t row, blk0, nblk, pad;
+};
+__global__ void __launch_bounds__(256)
+pr_hub_finish_kernel(const HubRow *__restrict__ hubs, uint32_t n_hubs, const double *__restrict__ seg_sum,
+                     const uint32_t *__restrict__ out_deg, uint32_t row_begin, float *__restrict__ contrib_out,
+                     float *__restrict__ scores, float base, float damping, double *__restrict__ partial) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_hubs) return;
+    const HubRow h = hubs[i];
+    double acc = 0.0;
+    for (uint32_t k = 0; k < h.nblk; k++) acc += seg_sum[h.blk0 + k];
+    const float s = (float)acc;
+    const float old = scores[h.row];
+    const float nw = base + damping * s;
+    scores[h.row] = nw;
+    contrib_out[row_begin + h.row] = nw / (float)out_deg[row_begin + h.row];
+    partial[i] = fabs((double)(nw - old));
 }
 
 // ---- plan construction kernels (run once) -------------------------------------------------------------------
@@ -531,12 +575,19 @@ struct cz_pagerank_plan {
     uint2 *d_seg = nullptr;
     float *d_val = nullptr;
     uint64_t E_blocked = 0;
+    // relaxed plans: rows longer than a tile, cut into segment blocks of the blocked layout
+    bool relaxed = false;
+    uint32_t n_hubs = 0;
+    HubRow *d_hubs = nullptr;
+    double *d_segsum = nullptr;
+    double h2d_ms = 0, build_ms = 0;  // what creating the plan cost: CSR upload / static layout
     // shared
     uint32_t *d_off = nullptr, *d_src = nullptr, *d_outdeg = nullptr;
     float *d_scores = nullptr;
     double *d_partial = nullptr;
     ~cz_pagerank_plan() {
-        void *ps[] = {d_gblocks, d_bblocks, d_items, d_asrc, d_perm, d_vpos, d_seg, d_val, d_off, d_src, d_outdeg, d_scores, d_partial};
+        void *ps[] = {d_gblocks, d_bblocks, d_items, d_asrc, d_perm, d_vpos, d_seg, d_val, d_off, d_src, d_outdeg, d_scores, d_partial,
+                      d_hubs, d_segsum};
         for (void *p : ps)
             if (p) (void)hipFree(p);
     }
@@ -545,12 +596,23 @@ struct cz_pagerank_plan {
 namespace {
 
 // cut [0, rows) into row blocks: consecutive rows whose in-edges fit one tile; a row longer than a tile is alone
-int cut_row_blocks(const uint32_t *in_offsets, uint32_t rows, uint32_t tile, std::vector<RowBlock> &blocks) {
+int cut_row_blocks(const uint32_t *in_offsets, uint32_t rows, uint32_t tile, std::vector<RowBlock> &blocks,
+                   std::vector<HubRow> *hubs = nullptr) {
     blocks.clear();
     blocks.reserve((size_t)(in_offsets[rows] / tile) + rows / kMaxRowsPerBlock + 16);
     uint32_t r = 0;
     while (r < rows) {
         uint32_t r1 = r + 1;
+        if (hubs && in_offsets[r1] - in_offsets[r] > tile) {  // relaxed: a hub row becomes segment blocks (row1 == row0)
+            HubRow h{r, (uint32_t)blocks.size(), 0, 0};
+            for (uint32_t e = in_offsets[r]; e < in_offsets[r1]; e += tile) {
+                blocks.push_back({r, r, e, std::min(in_offsets[r1], e + tile)});
+                h.nblk++;
+            }
+            hubs->push_back(h);
+            r = r1;
+            continue;
+        }
         if (in_offsets[r1] - in_offsets[r] <= tile) {
             const uint32_t lim = std::min<uint32_t>(rows, r + kMaxRowsPerBlock);
             while (r1 < lim && in_offsets[r1 + 1] - in_offsets[r] <= tile) r1++;
@@ -566,7 +628,8 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
     const uint32_t rows = p->rows;
     const uint64_t E = p->E;
     std::vector<RowBlock> all;
-    cut_row_blocks(h_off, rows, kBTileNnz, all);
+    std::vector<HubRow> hubs;
+    cut_row_blocks(h_off, rows, kBTileNnz, all, p->relaxed ? &hubs : nullptr);
     std::vector<RowBlock> bb, gb;  // blocked / long-row
     uint64_t e_blocked = 0;
     for (const RowBlock &rb : all) {
@@ -576,6 +639,14 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
             bb.push_back(rb);
             e_blocked += nnz;
         }
+    }
+    if (!hubs.empty()) {  // relaxed: every block is in the blocked layout, so `all` and `bb` number blocks alike
+        if (!gb.empty() || bb.size() != all.size()) return cz::set_error(CZ_E_HIP, "internal: relaxed plan with long-row blocks");
+        p->n_hubs = (uint32_t)hubs.size();
+        CZ_HIP(hipMalloc((void **)&p->d_hubs, hubs.size() * sizeof(HubRow)));
+        CZ_HIP(hipMemcpy(p->d_hubs, hubs.data(), hubs.size() * sizeof(HubRow), hipMemcpyHostToDevice));
+        CZ_HIP(hipMalloc((void **)&p->d_segsum, bb.size() * sizeof(double)));
+        n_chunks = 1;  // hub segments index seg_sum by global block number
     }
     const uint32_t S = (uint32_t)(((uint64_t)p->N + (1u << wlog) - 1) >> wlog);
     n_chunks = std::max(1u, std::min<uint32_t>(n_chunks, (uint32_t)std::max<size_t>(1, bb.size())));
@@ -759,6 +830,8 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     p->damping = damping;
     p->init = N ? 1.0f / (float)N : 0.f;
     p->base = N ? (1.0f - damping) / (float)N : 0.f;
+    p->relaxed = (flags & CZ_PR_RELAXED) != 0;
+    const auto t_h2d = std::chrono::steady_clock::now();
     CZ_HIP(hipMalloc((void **)&p->d_off, ((size_t)rows + 1) * 4));
     CZ_HIP(hipMalloc((void **)&p->d_src, std::max<uint64_t>(1, E) * 4));
     CZ_HIP(hipMalloc((void **)&p->d_outdeg, std::max<size_t>(1, N) * 4));
@@ -770,6 +843,9 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     }
     if (E) CZ_HIP(hipMemcpy(p->d_src, in_sources, E * 4, up));
     if (N) CZ_HIP(hipMemcpy(p->d_outdeg, out_degree, (size_t)N * 4, up));
+    CZ_HIP(hipDeviceSynchronize());
+    const auto t_build = std::chrono::steady_clock::now();
+    p->h2d_ms = std::chrono::duration<double, std::milli>(t_build - t_h2d).count();
 
     // formulation: explicit flag > CZ_PR_MODE (gather | blocked) > heuristic
     int mode = 0;  // 0 auto, 1 gather, 2 blocked
@@ -798,7 +874,9 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
         CZ_HIP(hipMalloc((void **)&p->d_gblocks, std::max<size_t>(1, blocks.size()) * sizeof(RowBlock)));
         if (!blocks.empty()) CZ_HIP(hipMemcpy(p->d_gblocks, blocks.data(), blocks.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
     }
-    CZ_HIP(hipMalloc((void **)&p->d_partial, std::max<size_t>(1, (size_t)p->n_gblocks + p->n_bblocks) * 8));
+    CZ_HIP(hipMalloc((void **)&p->d_partial, std::max<size_t>(1, (size_t)p->n_gblocks + p->n_bblocks + p->n_hubs) * 8));
+    CZ_HIP(hipDeviceSynchronize());
+    p->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
     *out = p.release();
     return CZ_OK;
 }
@@ -829,7 +907,7 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
     int rc = cz::ensure_device();
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    const uint32_t n_partial = p->n_gblocks + p->n_bblocks;
+    const uint32_t n_partial = p->n_gblocks + p->n_bblocks + p->n_hubs;
     if (n_partial == 0) return CZ_OK;
     if (p->blocked) {
         for (uint32_t c = 0; c < p->n_chunks; c++) {
@@ -843,12 +921,18 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
                 if (p->d_vpos)
                     hipLaunchKernelGGL(pb_reduce_kernel<true>, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
                                        p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
-                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap);
+                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap,
+                                       p->d_segsum);
                 else
                     hipLaunchKernelGGL(pb_reduce_kernel<false>, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
                                        p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
-                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap);
+                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap,
+                                       p->d_segsum);
         }
+        if (p->n_hubs)  // relaxed: the hub rows' segment sums -> scores
+            hipLaunchKernelGGL(pr_hub_finish_kernel, dim3((p->n_hubs + 255) / 256), dim3(256), 0, stream, p->d_hubs, p->n_hubs,
+                               p->d_segsum, p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores, p->base, p->damping,
+                               p->d_partial + p->n_bblocks + p->n_gblocks);
         if (p->n_gblocks)  // rows longer than a tile
             hipLaunchKernelGGL(pr_step_kernel, dim3(p->n_gblocks), dim3(kGThreads), 0, stream, p->d_gblocks, p->d_off, p->d_src,
                                p->d_outdeg, p->row_begin, contrib_in_dev, contrib_out_dev, p->d_scores, p->base, p->damping,
@@ -883,26 +967,26 @@ extern "C" int cz_pagerank_plan_read_scores(cz_pagerank_plan *p, float *out, uin
     return CZ_OK;
 }
 
-// one-shot form: upload, iterate with the reference's stopping rule, download
-extern "C" int cz_pagerank(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N,
-                           uint64_t E, float damping, double tolerance, uint32_t max_iter, float *scores,
-                           uint32_t *iters_run, double *final_err, const volatile uint8_t *poison) {
-    if (iters_run) *iters_run = 0;
-    if (final_err) *final_err = 0.0;
-    if (N == 0) return CZ_OK;  // pagerank.rs:43-45 empty input -> empty output
-    if (!scores) return cz::set_error(CZ_E_INVALID, "null scores");
-    if (max_iter == 0) return cz::set_error(CZ_E_INVALID, "iterations must be positive");
-    if (in_offsets && in_offsets[N] != E) return cz::set_error(CZ_E_INVALID, "in_offsets[N] (%u) != E (%llu)", in_offsets[N], (unsigned long long)E);
-    cz_pagerank_plan *plan = nullptr;
-    int rc = cz_pagerank_plan_create(in_offsets, in_sources, out_degree, N, 0, N, damping, &plan, 0);
-    if (rc) return rc;
-    std::unique_ptr<cz_pagerank_plan> guard(plan);
+extern "C" int cz_pagerank_plan_timing(const cz_pagerank_plan *p, double *h2d_ms, double *build_ms) {
+    if (!p) return cz::set_error(CZ_E_INVALID, "null plan");
+    if (h2d_ms) *h2d_ms = p->h2d_ms;
+    if (build_ms) *build_ms = p->build_ms;
+    return CZ_OK;
+}
+
+namespace {
+
+// graph::page_rank's loop on a resident plan: iterate with the reference's stopping rule, scores back to the host
+int run_plan(cz_pagerank_plan *plan, double tolerance, uint32_t max_iter, float *scores, uint32_t *iters_run,
+             double *final_err, const volatile uint8_t *poison, cz_pagerank_timing *tm) {
+    const uint32_t N = plan->N;
     cz::DevBuf<float> c0, c1;
     cz::DevBuf<double> derr;
     CZ_HIP(c0.alloc(N));
     CZ_HIP(c1.alloc(N));
     CZ_HIP(derr.alloc(1));
-    rc = cz_pagerank_plan_init(plan, c0.p, nullptr);
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = cz_pagerank_plan_init(plan, c0.p, nullptr);
     if (rc) return rc;
     float *cin = c0.p, *cout = c1.p;
     uint32_t it = 0;
@@ -917,8 +1001,92 @@ extern "C" int cz_pagerank(const uint32_t *in_offsets, const uint32_t *in_source
         it++;
         if (err < tolerance || it == max_iter) break;
     }
+    const auto t1 = std::chrono::steady_clock::now();
     CZ_HIP(hipMemcpy(scores, plan->d_scores, (size_t)N * 4, hipMemcpyDeviceToHost));
+    const auto t2 = std::chrono::steady_clock::now();
+    if (tm) {
+        tm->iterate_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        tm->d2h_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    }
     if (iters_run) *iters_run = it;
     if (final_err) *final_err = err;
     return CZ_OK;
+}
+
+// Plans of relations that are queried again (the same stored relation at the same snapshot): keyed by the caller's
+// 128-bit identity of (relation, snapshot) -- the library never looks at the arrays again on a hit, so the key is a
+// promise that they are the same.  A plan is handed to ONE caller at a time (it owns scores / value-stream scratch).
+struct CacheEntry {
+    uint64_t hi, lo;
+    uint32_t N;
+    uint64_t E;
+    float damping;
+    uint32_t flags;
+    std::unique_ptr<cz_pagerank_plan> plan;
+};
+std::mutex g_cache_mu;
+std::list<CacheEntry> g_cache;  // most recently used first; entries in use are taken out
+size_t cache_capacity() { return (size_t)std::max(0, env_int("CZ_PR_CACHE_PLANS", 4)); }
+
+}  // namespace
+
+extern "C" void cz_pagerank_cache_clear(void) {
+    (void)cz::ensure_device();
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_cache.clear();
+}
+
+extern "C" int cz_pagerank_cached(uint64_t key_hi, uint64_t key_lo, const uint32_t *in_offsets, const uint32_t *in_sources,
+                                  const uint32_t *out_degree, uint32_t N, uint64_t E, float damping, double tolerance,
+                                  uint32_t max_iter, uint32_t flags, float *scores, uint32_t *iters_run, double *final_err,
+                                  const volatile uint8_t *poison, cz_pagerank_timing *timing) {
+    if (iters_run) *iters_run = 0;
+    if (final_err) *final_err = 0.0;
+    if (timing) memset(timing, 0, sizeof(*timing));
+    if (N == 0) return CZ_OK;  // pagerank.rs:43-45 empty input -> empty output
+    if (!scores) return cz::set_error(CZ_E_INVALID, "null scores");
+    if (max_iter == 0) return cz::set_error(CZ_E_INVALID, "iterations must be positive");
+    if (flags & CZ_DEVICE_PTRS) return cz::set_error(CZ_E_INVALID, "cz_pagerank takes host arrays (device-resident CSR: the plan API)");
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    const bool keyed = (key_hi | key_lo) != 0 && cache_capacity() > 0;
+    std::unique_ptr<cz_pagerank_plan> plan;
+    if (keyed) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
+            if (it->hi == key_hi && it->lo == key_lo && it->N == N && it->E == E && it->damping == damping && it->flags == flags) {
+                plan = std::move(it->plan);
+                g_cache.erase(it);
+                break;
+            }
+    }
+    if (plan) {
+        if (timing) timing->cache_hit = 1;
+    } else {
+        if (!in_offsets || !out_degree || (E && !in_sources)) return cz::set_error(CZ_E_INVALID, "null CSR array");
+        if (in_offsets[N] != E) return cz::set_error(CZ_E_INVALID, "in_offsets[N] (%u) != E (%llu)", in_offsets[N], (unsigned long long)E);
+        cz_pagerank_plan *raw = nullptr;
+        rc = cz_pagerank_plan_create(in_offsets, in_sources, out_degree, N, 0, N, damping, &raw, flags);
+        if (rc) return rc;
+        plan.reset(raw);
+        if (timing) {
+            timing->h2d_ms = plan->h2d_ms;
+            timing->plan_build_ms = plan->build_ms;
+        }
+    }
+    rc = run_plan(plan.get(), tolerance, max_iter, scores, iters_run, final_err, poison, timing);
+    if (keyed && (rc == CZ_OK || rc == CZ_E_CANCELLED)) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        g_cache.push_front(CacheEntry{key_hi, key_lo, N, E, damping, flags, std::move(plan)});
+        while (g_cache.size() > cache_capacity()) g_cache.pop_back();
+    }
+    return rc;
+}
+
+// one-shot form: upload, iterate with the reference's stopping rule, download
+extern "C" int cz_pagerank(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N,
+                           uint64_t E, float damping, double tolerance, uint32_t max_iter, float *scores,
+                           uint32_t *iters_run, double *final_err, const volatile uint8_t *poison) {
+    return cz_pagerank_cached(0, 0, in_offsets, in_sources, out_degree, N, E, damping, tolerance, max_iter, 0, scores, iters_run,
+                              final_err, poison, nullptr);
 }

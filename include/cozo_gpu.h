@@ -41,6 +41,12 @@ extern "C" {
 /* cz_knn_bruteforce: compute the B x N dot products as one dense f32 GEMM on the matrix cores (Cosine / IP only;
  * every dot product is then a k-ordered fmaf chain instead of the search kernel's lane-parallel tree) */
 #define CZ_BF_GEMM 8u
+/* cz_pagerank_plan_create / cz_pagerank_cached: rows longer than one tile of the blocked sweep (hubs, > 16384 in-edges)
+ * are cut into segments that are summed in parallel instead of by one lane in the reference's sequential f32 order.
+ * Scores then differ from the reference's in the last bits on those rows (well inside north_star's 1e-5 relative on
+ * ordinary rows; on a hub the difference is bounded by the rounding error of the reference's own 10^5-term f32 sum);
+ * every other row stays bit-identical.  Default (flag absent): every row bit-identical. */
+#define CZ_PR_RELAXED 16u
 
 typedef enum {
     CZ_OK = 0,
@@ -156,6 +162,26 @@ int cz_pagerank(const uint32_t *in_offsets, const uint32_t *in_sources, const ui
                 uint64_t E, float damping, double tolerance, uint32_t max_iter, float *scores, uint32_t *iters_run,
                 double *final_err, const volatile uint8_t *poison);
 
+/* The same with the static device layout (CSR upload + blocked plan) kept between calls: `key_hi:key_lo` is the
+ * caller's identity of (relation, snapshot) -- e.g. the stored relation's id and the transaction's snapshot; 0:0 = do
+ * not cache.  On a hit with the same N, E, damping and flags the arrays are not read again (the key is the caller's
+ * promise that they are unchanged), which takes a repeated `?[] <~ PageRank(*rel[])` from upload + plan + iterations
+ * to iterations alone.  Up to CZ_PR_CACHE_PLANS (default 4) plans are kept, least recently used dropped first.
+ * flags: CZ_PR_GATHER | CZ_PR_BLOCKED | CZ_PR_RELAXED.  timing (optional): where the call's time went. */
+typedef struct {
+    double h2d_ms;        /* CSR upload (0 on a cache hit) */
+    double plan_build_ms; /* static layout of the sweep (0 on a cache hit) */
+    double iterate_ms;    /* init + iterations incl. the per-iteration error read-back */
+    double d2h_ms;        /* scores back to the host */
+    int32_t cache_hit;
+    int32_t reserved;
+} cz_pagerank_timing;
+int cz_pagerank_cached(uint64_t key_hi, uint64_t key_lo, const uint32_t *in_offsets, const uint32_t *in_sources,
+                       const uint32_t *out_degree, uint32_t N, uint64_t E, float damping, double tolerance,
+                       uint32_t max_iter, uint32_t flags, float *scores, uint32_t *iters_run, double *final_err,
+                       const volatile uint8_t *poison, cz_pagerank_timing *timing);
+void cz_pagerank_cache_clear(void);
+
 /* Resident / row-sharded PageRank.  A plan owns rows [row_begin, row_end) of the in-CSR:
  *   in_offsets [rows+1] relative to the shard (in_offsets[0] == 0), in_sources [E_local] GLOBAL ids,
  *   out_degree [N] for all nodes.                                   [dev-able]
@@ -176,6 +202,8 @@ float *cz_pagerank_plan_scores(cz_pagerank_plan *p);
 uint64_t cz_pagerank_plan_edges(const cz_pagerank_plan *p);
 /* 1 when the plan runs the source-blocked two-phase sweep, 0 for the CSR-stream gather sweep */
 int cz_pagerank_plan_is_blocked(const cz_pagerank_plan *p);
+/* what creating the plan cost: CSR upload and static layout, milliseconds */
+int cz_pagerank_plan_timing(const cz_pagerank_plan *p, double *h2d_ms, double *build_ms);
 /* copy this shard's scores [row_end-row_begin] to `out` (host, or device with CZ_DEVICE_PTRS) */
 int cz_pagerank_plan_read_scores(cz_pagerank_plan *p, float *out, uint32_t flags, void *stream);
 

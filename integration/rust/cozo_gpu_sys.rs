@@ -9,6 +9,7 @@ pub const CZ_DEVICE_PTRS: u32 = 1;
 pub const CZ_PR_GATHER: u32 = 2;
 pub const CZ_PR_BLOCKED: u32 = 4;
 pub const CZ_BF_GEMM: u32 = 8;
+pub const CZ_PR_RELAXED: u32 = 16;
 
 pub const CZ_OK: c_int = 0;
 pub const CZ_E_INVALID: c_int = -1;
@@ -29,6 +30,17 @@ pub struct cz_hnsw_index {
 #[repr(C)]
 pub struct cz_pagerank_plan {
     _private: [u8; 0],
+}
+
+#[repr(C)]
+#[derive(Default, Clone, Copy)]
+pub struct cz_pagerank_timing {
+    pub h2d_ms: c_double,
+    pub plan_build_ms: c_double,
+    pub iterate_ms: c_double,
+    pub d2h_ms: c_double,
+    pub cache_hit: i32,
+    pub reserved: i32,
 }
 
 #[repr(C)]
@@ -75,6 +87,12 @@ extern "C" {
     pub fn cz_pagerank(in_offsets: *const u32, in_sources: *const u32, out_degree: *const u32, n: u32, e: u64,
                        damping: c_float, tolerance: c_double, max_iter: u32, scores: *mut c_float, iters_run: *mut u32,
                        final_err: *mut c_double, poison: *const u8) -> c_int;
+    pub fn cz_pagerank_cached(key_hi: u64, key_lo: u64, in_offsets: *const u32, in_sources: *const u32,
+                              out_degree: *const u32, n: u32, e: u64, damping: c_float, tolerance: c_double, max_iter: u32,
+                              flags: u32, scores: *mut c_float, iters_run: *mut u32, final_err: *mut c_double,
+                              poison: *const u8, timing: *mut cz_pagerank_timing) -> c_int;
+    pub fn cz_pagerank_cache_clear();
+    pub fn cz_pagerank_plan_timing(p: *const cz_pagerank_plan, h2d_ms: *mut c_double, build_ms: *mut c_double) -> c_int;
     pub fn cz_pagerank_plan_create(in_offsets: *const u32, in_sources: *const u32, out_degree: *const u32, n: u32,
                                    row_begin: u32, row_end: u32, damping: c_float, out: *mut *mut cz_pagerank_plan,
                                    flags: u32) -> c_int;

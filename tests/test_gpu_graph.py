@@ -299,3 +299,59 @@ def test_entry_points_are_reentrant_across_host_threads(oracle, gpu_lib):
     for got, want in zip(results, serial):
         for a, b in zip(got, want):
             assert np.array_equal(a, b)
+
+
+def _hub_graph(oracle, n=60000, e=900000, hubs=3, seed=21):
+    """a graph big enough for the blocked sweep (E >= 4M is the automatic bar, so the mode is forced) with a few rows far
+    longer than one 16384-value tile"""
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, n, e)
+    dst = np.where(rng.random(e) < 0.25, rng.integers(0, hubs, e), rng.integers(0, n, e))
+    keep = src != dst
+    rows = np.unique(np.stack([src[keep], dst[keep]], 1), axis=0)
+    return util.graph_from_relation(oracle, rows[:, 0].astype(np.int64), rows[:, 1].astype(np.int64))
+
+
+def test_pagerank_relaxed_hub_rows(oracle, gpu_lib):
+    """CZ_PR_RELAXED: rows longer than a tile are summed as parallel segments.  Every other row keeps the reference's
+    bits; the hub rows stay within 1e-5 relative of the sequential f32 sum (north_star's bar for PageRank scores)."""
+    from cozo_amd import graph as G
+    g = _hub_graph(oracle)
+    indeg = np.diff(g["ioff"].astype(np.int64))
+    assert (indeg > 16384).sum() >= 2
+    exact, it0, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 6, mode="blocked")
+    os_, oit, _ = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 6)
+    assert np.array_equal(exact, os_)
+    rel, it1, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 6, mode="blocked", relaxed=True)
+    assert it1 == it0 == oit
+    err = np.abs(rel.astype(np.float64) - os_) / np.abs(os_)
+    assert err.max() <= 1e-5, err.max()
+    # one sweep from identical inputs: only the hub rows may differ at all
+    one_e, _, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 1, mode="blocked")
+    one_r, _, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 1, mode="blocked", relaxed=True)
+    diff = np.flatnonzero(one_e != one_r)
+    assert set(diff.tolist()) <= set(np.flatnonzero(indeg > 16384).tolist())
+
+
+def test_pagerank_plan_cache(graphs, oracle):
+    """cz_pagerank_cached: the second call with the same (relation, snapshot) key reuses the device layout -- no upload,
+    no plan build -- and returns the same bits; a different key or another damping builds anew."""
+    from cozo_amd import _lib, graph as G
+    _lib.lib().cz_pagerank_cache_clear()
+    g = graphs[2]
+    os_, oit, _ = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"])
+    t1, t2, t3, t4 = {}, {}, {}, {}
+    s1, it1, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], cache_key=(7, 42), timing=t1)
+    s2, it2, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], cache_key=(7, 42), timing=t2)
+    assert not t1["cache_hit"] and t2["cache_hit"] and t2["h2d_ms"] == 0 and t2["plan_build_ms"] == 0
+    assert it1 == it2 == oit and np.array_equal(s1, os_) and np.array_equal(s2, os_)
+    G.pagerank(g["ioff"], g["isrc"], g["outdeg"], cache_key=(7, 43), timing=t3)
+    G.pagerank(g["ioff"], g["isrc"], g["outdeg"], damping=0.5, cache_key=(7, 42), timing=t4)
+    assert not t3["cache_hit"] and not t4["cache_hit"]
+    # a cancelled run leaves the plan usable
+    poison = np.ones(1, dtype=np.uint8)
+    with pytest.raises(_lib.ProcessKilled):
+        G.pagerank(g["ioff"], g["isrc"], g["outdeg"], cache_key=(7, 42), poison=poison)
+    s5, _, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], cache_key=(7, 42), timing=t1)
+    assert t1["cache_hit"] and np.array_equal(s5, os_)
+    _lib.lib().cz_pagerank_cache_clear()

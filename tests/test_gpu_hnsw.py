@@ -227,3 +227,47 @@ def test_edge_cases(gpu_lib, oracle):
     assert np.array_equal(cnt, ocnt)
     assert np.array_equal(np.nan_to_num(dist, nan=-1.0), np.nan_to_num(odist, nan=-1.0))
     assert np.array_equal(ids, oids)
+
+
+@pytest.mark.parametrize("env", [{"CZ_HNSW_VISITED": "hash"}, {"CZ_HNSW_VISITED": "bitmap"},
+                                 {"CZ_HNSW_VISITED": "hash", "CZ_HNSW_VSLOTS": "64"},
+                                 {"CZ_HNSW_VISITED": "hash", "CZ_HNSW_VSLOTS": "512"}],
+                         ids=["hash", "bitmap", "overflow-at-once", "overflow-midway"])
+def test_visited_set_forms_are_the_same_set(case, oracle, monkeypatch, env):
+    """The per-query visited set is a hash table of node ids that spills into the query's bitmap row when it fills up
+    (hnsw_kernels.cuh VisitedDev).  Every form is an exact set: ids, distances and the evaluation count stay those of the
+    oracle -- forced hash tables on these small indices, bitmap only, and tables so small that the move to the bitmap
+    happens on the first expansion / in the middle of the level-0 search.  Run twice: the workspace must come back clean."""
+    from cozo_amd.hnsw import HnswSearch
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    ef, k = 120, 10
+    oids, odist, ocnt, ond = case["flat"].knn_batch(case["q"], k, ef, dot_mode=oracle.DOT_GPU)
+    for _ in range(2):
+        ids, dist, cnt, nd = case["gix"].hnsw_knn_batch(case["q"], HnswSearch(k=k, ef=ef), with_n_dist=True)
+        assert np.array_equal(ids, oids) and np.array_equal(cnt, ocnt) and np.array_equal(dist, odist)
+        assert int(nd.sum()) == ond
+
+
+def test_index_upload_rejects_links_to_missing_nodes(gpu_lib):
+    """cz_hnsw_index_create walks every link: an id >= n, or (above level 0) a node that is not on that level, would be
+    fetched and inserted into the visited set unchecked by the kernels."""
+    from cozo_amd import _lib
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest
+    man = HnswIndexManifest(vec_dim=4, distance="L2", m_neighbours=2)
+    x = np.zeros((5, 4), np.float32)
+    nb0 = np.full((5, 4), 0xFFFFFFFF, dtype=np.uint32)
+    nb0[0, 0] = 1
+    GpuHnswIndex(man, x, [None], [nb0], 0).close()
+    bad = nb0.copy()
+    bad[2, 1] = 5
+    with pytest.raises(_lib.CozoGpuError):
+        GpuHnswIndex(man, x, [None], [bad], 0)
+    # level 1 holds nodes 1 and 3; a level-1 link to node 2 (level 0 only) is refused
+    nodes1 = np.array([1, 3], dtype=np.uint32)
+    nb1 = np.full((2, 2), 0xFFFFFFFF, dtype=np.uint32)
+    nb1[0, 0] = 3
+    GpuHnswIndex(man, x, [None, nodes1], [nb0, nb1], 1).close()
+    nb1[1, 0] = 2
+    with pytest.raises(_lib.CozoGpuError):
+        GpuHnswIndex(man, x, [None, nodes1], [nb0, nb1], 1)
