@@ -1,0 +1,88 @@
+"""RCCL communicators behind the C ABI (include/cozo_gpu.h, multi-GPU section): what a Rust `impl FixedRule` binds for the
+multi-GPU form of the rules.  One process per GPU here (the launch contract of bench.py / torch.distributed); the 128-byte
+unique id travels over whatever the launcher offers -- `Comm.from_torch_distributed` uses the existing process group.
+The single-process form (one cozo process driving n GPUs) is `pagerank_multi`."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, ptr
+
+
+class Comm:
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == _lib.CZ_UNIQUE_ID_BYTES
+        h = C.c_void_p()
+        buf = (C.c_uint8 * _lib.CZ_UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        check(_lib.lib().cz_comm_create_rank(buf, rank, world, C.byref(h)))
+        self._h, self.rank, self.world = h, rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * _lib.CZ_UNIQUE_ID_BYTES)()
+        check(_lib.lib().cz_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_torch_distributed(cls, device=None, group=None):
+        """rank 0 draws the id, the process group (any backend) carries it"""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ident = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0, group=group)
+        return cls(ident[0], rank, world)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().cz_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def all_gather(self, buf, bytes_per_rank: int, stream: int = 0):
+        check(_lib.lib().cz_comm_all_gather(self._h, ptr(buf), bytes_per_rank, C.c_void_p(stream)))
+
+    def all_reduce_sum_f64(self, buf, n: int, stream: int = 0):
+        check(_lib.lib().cz_comm_all_reduce_sum_f64(self._h, ptr(buf), n, C.c_void_p(stream)))
+
+    def pagerank_sharded(self, plan, rows_per_rank: int, tolerance: float, max_iter: int, allreduce_exchange: bool = False,
+                         poison: Optional[np.ndarray] = None, stream: int = 0):
+        """graph::page_rank over row shards, collectively (cz_pagerank_sharded): `plan` is this rank's PageRankPlan over rows
+        [rank * rows_per_rank, ...).  Returns (iterations, final error); the rank's scores stay in the plan."""
+        it, err = C.c_uint32(0), C.c_double(0.0)
+        check(_lib.lib().cz_pagerank_sharded(self._h, plan._h, rows_per_rank, float(tolerance), int(max_iter),
+                                             _lib.CZ_PR_EXCHANGE_ALLREDUCE if allreduce_exchange else 0, C.byref(it),
+                                             C.byref(err), ptr(poison), C.c_void_p(stream)))
+        return it.value, err.value
+
+    def hnsw_search_sharded(self, shard_index, queries_dev, B: int, k: int, ef: int, id_offset: int, out_ids, out_dist,
+                            out_count, stream: int = 0):
+        """hnsw_knn over one sub-index per rank (cz_hnsw_search_sharded): rank 0's queries are broadcast, per-shard lists
+        all-gathered and merged.  out_ids int64/uint64 [B][k] (global ids, -1 = empty), out_dist f64, out_count i32 -- device."""
+        check(_lib.lib().cz_hnsw_search_sharded(self._h, shard_index._h, ptr(queries_dev), B, k, ef, int(id_offset),
+                                                ptr(out_ids), ptr(out_dist), ptr(out_count), C.c_void_p(stream)))
+
+
+def pagerank_multi(in_off, in_src, out_deg, n_gpus: int, damping=0.85, tolerance=1e-4, max_iter=10, relaxed=False,
+                   allreduce_exchange=False, poison=None):
+    """cz_pagerank on n_gpus devices of THIS process (one host thread + one RCCL communicator per GPU)."""
+    in_off = np.ascontiguousarray(in_off, dtype=np.uint32)
+    in_src = np.ascontiguousarray(in_src, dtype=np.uint32)
+    out_deg = np.ascontiguousarray(out_deg, dtype=np.uint32)
+    N = out_deg.size
+    scores = np.empty(N, dtype=np.float32)
+    it, err = C.c_uint32(0), C.c_double(0.0)
+    flags = (_lib.CZ_PR_RELAXED if relaxed else 0) | (_lib.CZ_PR_EXCHANGE_ALLREDUCE if allreduce_exchange else 0)
+    check(_lib.lib().cz_pagerank_multi(ptr(in_off), ptr(in_src), ptr(out_deg), N, in_src.size, np.float32(damping),
+                                       float(tolerance), int(max_iter), int(n_gpus), flags, ptr(scores), C.byref(it),
+                                       C.byref(err), ptr(poison)))
+    return scores, it.value, err.value

@@ -1,0 +1,450 @@
+// comm.hip -- the multi-GPU side of the C ABI: RCCL communicators (cz_comm_*), row-sharded PageRank behind the
+// boundary (cz_pagerank_sharded for one process per GPU, cz_pagerank_multi for one process driving several GPUs -- what
+// a cozo process is), and hnsw_knn over an index partitioned into one sub-index per rank (cz_hnsw_search_sharded).
+//
+// RCCL is bound at run time (dlopen of librccl.so.1): libcozo_gpu.so must not drag a second copy of the collectives
+// library -- or of the HIP runtime it depends on -- into a process that already holds one (a PyTorch process carries its
+// own librccl.so with the same SONAME; the loader then hands back that copy).  COZO_RCCL_LIB names another file.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+#include "distance.cuh"
+#include "hnsw_index.h"
+#include "sharded_pagerank.hpp"
+
+// ---- the few RCCL declarations this file needs (rccl.h: NCCL 2.x ABI) -------------------------------------------------
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+    char internal[128];
+} ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6,
+               ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+}
+
+namespace {
+
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+
+Rccl *rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::vector<std::string> names;
+        if (const char *e = getenv("COZO_RCCL_LIB")) names.push_back(e);
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
+        const char *rocm = getenv("ROCM_PATH");
+        names.push_back(std::string(rocm ? rocm : "/opt/rocm") + "/lib/librccl.so.1");
+        for (const auto &n : names) {
+            r.h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
+            if (r.h) break;
+            r.why += n + ": " + dlerror() + "; ";
+        }
+        if (!r.h) return;
+#define CZ_SYM(field, name)                                  \
+    r.field = (decltype(r.field))dlsym(r.h, name);          \
+    if (!r.field) {                                          \
+        r.why = std::string("librccl lacks ") + name;        \
+        r.h = nullptr;                                       \
+        return;                                              \
+    }
+        CZ_SYM(GetUniqueId, "ncclGetUniqueId")
+        CZ_SYM(CommInitRank, "ncclCommInitRank")
+        CZ_SYM(CommInitAll, "ncclCommInitAll")
+        CZ_SYM(CommDestroy, "ncclCommDestroy")
+        CZ_SYM(AllGather, "ncclAllGather")
+        CZ_SYM(AllReduce, "ncclAllReduce")
+        CZ_SYM(Broadcast, "ncclBroadcast")
+        CZ_SYM(GetErrorString, "ncclGetErrorString")
+#undef CZ_SYM
+    });
+    return r.h ? &r : nullptr;
+}
+
+std::string g_rccl_why;
+int need_rccl(Rccl **out) {
+    Rccl *r = rccl();
+    if (!r) return cz::set_error(CZ_E_UNSUPPORTED, "RCCL (librccl.so.1) could not be loaded into this process; set COZO_RCCL_LIB");
+    *out = r;
+    return CZ_OK;
+}
+
+#define CZ_NCCL(R, expr)                                                                                   \
+    do {                                                                                                   \
+        ncclResult_t _r = (expr);                                                                          \
+        if (_r != ncclSuccess)                                                                             \
+            return cz::set_error(CZ_E_HIP, "%s failed: %s (%s:%d)", #expr, (R)->GetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
+}  // namespace
+
+struct cz_comm {
+    int rank = 0, world = 1, device = 0;
+    ncclComm_t nccl = nullptr;
+};
+
+extern "C" int cz_comm_unique_id(uint8_t *id) {
+    if (!id) return cz::set_error(CZ_E_INVALID, "null id");
+    Rccl *R = nullptr;
+    int rc = need_rccl(&R);
+    if (rc) return rc;
+    ncclUniqueId u;
+    CZ_NCCL(R, R->GetUniqueId(&u));
+    static_assert(sizeof(u) == CZ_UNIQUE_ID_BYTES, "unique id size");
+    memcpy(id, &u, sizeof u);
+    return CZ_OK;
+}
+
+extern "C" int cz_comm_create_rank(const uint8_t *id, int rank, int world, cz_comm **out) {
+    if (!out) return cz::set_error(CZ_E_INVALID, "null out");
+    *out = nullptr;
+    if (!id || world < 1 || rank < 0 || rank >= world) return cz::set_error(CZ_E_INVALID, "bad rank %d of %d", rank, world);
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    Rccl *R = nullptr;
+    if ((rc = need_rccl(&R))) return rc;
+    std::unique_ptr<cz_comm> c(new cz_comm());
+    c->rank = rank;
+    c->world = world;
+    CZ_HIP(hipGetDevice(&c->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    CZ_NCCL(R, R->CommInitRank(&c->nccl, world, u, rank));
+    *out = c.release();
+    return CZ_OK;
+}
+
+extern "C" void cz_comm_destroy(cz_comm *c) {
+    if (!c) return;
+    if (c->nccl) {
+        if (Rccl *R = rccl()) {
+            (void)hipSetDevice(c->device);
+            (void)R->CommDestroy(c->nccl);
+        }
+    }
+    delete c;
+}
+
+extern "C" int cz_comm_rank(const cz_comm *c) { return c ? c->rank : -1; }
+extern "C" int cz_comm_size(const cz_comm *c) { return c ? c->world : 0; }
+
+extern "C" int cz_comm_all_gather(cz_comm *c, void *buf_dev, uint64_t bytes_per_rank, void *stream) {
+    if (!c || !buf_dev) return cz::set_error(CZ_E_INVALID, "null argument");
+    Rccl *R = nullptr;
+    int rc = need_rccl(&R);
+    if (rc) return rc;
+    CZ_NCCL(R, R->AllGather((const char *)buf_dev + (size_t)c->rank * bytes_per_rank, buf_dev, (size_t)bytes_per_rank, ncclUint8,
+                            c->nccl, (hipStream_t)stream));
+    return CZ_OK;
+}
+
+extern "C" int cz_comm_all_reduce_sum_f64(cz_comm *c, double *buf_dev, uint64_t n, void *stream) {
+    if (!c || !buf_dev) return cz::set_error(CZ_E_INVALID, "null argument");
+    Rccl *R = nullptr;
+    int rc = need_rccl(&R);
+    if (rc) return rc;
+    CZ_NCCL(R, R->AllReduce(buf_dev, buf_dev, (size_t)n, ncclFloat64, ncclSum, c->nccl, (hipStream_t)stream));
+    return CZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// row-sharded PageRank
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void __launch_bounds__(256) err2_set_kernel(double *e2, double flag) {
+    if (threadIdx.x == 0) {
+        e2[0] = 0.0;
+        e2[1] = flag;
+    }
+}
+
+struct HipPagerankBackend {
+    Rccl *R;
+    cz_comm *comm;
+    cz_pagerank_plan *plan;
+    hipStream_t stream;
+    uint32_t per;
+    cz::DevBuf<float> c0, c1;
+    cz::DevBuf<double> e2;
+
+    int alloc() {
+        const size_t padded = (size_t)per * (size_t)comm->world;
+        CZ_HIP(c0.alloc(padded));
+        CZ_HIP(c1.alloc(padded));
+        CZ_HIP(e2.alloc(2));
+        // the padding beyond N is gathered but never read; keep it defined
+        CZ_HIP(hipMemsetAsync(c0.p, 0, padded * 4, stream));
+        CZ_HIP(hipMemsetAsync(c1.p, 0, padded * 4, stream));
+        return CZ_OK;
+    }
+    float *contrib(int i) { return i ? c1.p : c0.p; }
+    int init(float *c) { return cz_pagerank_plan_init(plan, c, stream); }
+    int begin_iteration(double flag) {
+        hipLaunchKernelGGL(err2_set_kernel, dim3(1), dim3(64), 0, stream, e2.p, flag);
+        return CZ_OK;
+    }
+    int step(const float *cin, float *cout) { return cz_pagerank_plan_step(plan, cin, cout, e2.p, stream); }
+    int all_gather_slices(float *buf) {
+        CZ_NCCL(R, R->AllGather(buf + (size_t)comm->rank * per, buf, (size_t)per, ncclFloat32, comm->nccl, stream));
+        return CZ_OK;
+    }
+    int zero_other_slices(float *buf) {
+        const size_t lo = (size_t)comm->rank * per, total = (size_t)per * comm->world;
+        if (lo) CZ_HIP(hipMemsetAsync(buf, 0, lo * 4, stream));
+        if (lo + per < total) CZ_HIP(hipMemsetAsync(buf + lo + per, 0, (total - lo - per) * 4, stream));
+        return CZ_OK;
+    }
+    int all_reduce_sum_f32(float *buf, size_t n) {
+        CZ_NCCL(R, R->AllReduce(buf, buf, n, ncclFloat32, ncclSum, comm->nccl, stream));
+        return CZ_OK;
+    }
+    int all_reduce_err2() {
+        CZ_NCCL(R, R->AllReduce(e2.p, e2.p, 2, ncclFloat64, ncclSum, comm->nccl, stream));
+        return CZ_OK;
+    }
+    int read_err2(double out[2]) {
+        CZ_HIP(hipMemcpyAsync(out, e2.p, 16, hipMemcpyDeviceToHost, stream));
+        CZ_HIP(hipStreamSynchronize(stream));
+        return CZ_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" int cz_pagerank_sharded(cz_comm *comm, cz_pagerank_plan *plan, uint32_t rows_per_rank, double tolerance,
+                                   uint32_t max_iter, uint32_t flags, uint32_t *iters_run, double *final_err,
+                                   const volatile uint8_t *poison, void *stream) {
+    if (iters_run) *iters_run = 0;
+    if (final_err) *final_err = 0.0;
+    if (!comm || !plan) return cz::set_error(CZ_E_INVALID, "null argument");
+    if (max_iter == 0) return cz::set_error(CZ_E_INVALID, "iterations must be positive");
+    const uint32_t N = cz_pagerank_plan_nodes(plan);
+    if ((uint64_t)rows_per_rank * (uint64_t)comm->world < N)
+        return cz::set_error(CZ_E_INVALID, "rows_per_rank %u x %d ranks does not cover %u nodes", rows_per_rank, comm->world, N);
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    Rccl *R = nullptr;
+    if ((rc = need_rccl(&R))) return rc;
+    HipPagerankBackend b{R, comm, plan, (hipStream_t)stream, rows_per_rank, {}, {}, {}};
+    if ((rc = b.alloc())) return rc;
+    rc = czs::run_sharded_pagerank(b, comm->world, rows_per_rank, tolerance, max_iter,
+                                   (flags & CZ_PR_EXCHANGE_ALLREDUCE) ? czs::EXCHANGE_ALLREDUCE : czs::EXCHANGE_ALLGATHER, poison,
+                                   iters_run, final_err);
+    (void)hipStreamSynchronize((hipStream_t)stream);  // the buffers die with this scope
+    if (rc == czs::RUN_CANCELLED) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+    return rc;
+}
+
+// One process, n_gpus devices: rows split evenly, one host thread per GPU, one RCCL communicator per GPU (ncclCommInitAll).
+extern "C" int cz_pagerank_multi(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N,
+                                 uint64_t E, float damping, double tolerance, uint32_t max_iter, int n_gpus, uint32_t flags,
+                                 float *scores, uint32_t *iters_run, double *final_err, const volatile uint8_t *poison) {
+    if (iters_run) *iters_run = 0;
+    if (final_err) *final_err = 0.0;
+    if (N == 0) return CZ_OK;  // pagerank.rs:43-45
+    if (!scores || !in_offsets || !out_degree || (E && !in_sources)) return cz::set_error(CZ_E_INVALID, "null argument");
+    if (max_iter == 0) return cz::set_error(CZ_E_INVALID, "iterations must be positive");
+    if (in_offsets[N] != E) return cz::set_error(CZ_E_INVALID, "in_offsets[N] (%u) != E (%llu)", in_offsets[N], (unsigned long long)E);
+    int have = cz_device_count();
+    if (n_gpus < 1 || n_gpus > have) return cz::set_error(CZ_E_INVALID, "n_gpus = %d, %d device(s) visible", n_gpus, have);
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    Rccl *R = nullptr;
+    if ((rc = need_rccl(&R))) return rc;
+    const int world = n_gpus;
+    const uint32_t per = (uint32_t)(((uint64_t)N + world - 1) / world);
+    std::vector<int> devs(world);
+    for (int i = 0; i < world; i++) devs[i] = i;
+    std::vector<ncclComm_t> comms(world, nullptr);
+    CZ_NCCL(R, R->CommInitAll(comms.data(), world, devs.data()));
+    std::vector<int> rcs(world, CZ_OK);
+    std::vector<std::string> msgs(world);
+    std::vector<uint32_t> its(world, 0);
+    std::vector<double> errs(world, 0.0);
+    auto worker = [&](int r) {
+        cz::t_device_override = devs[r];
+        auto fail = [&](int code) {
+            rcs[r] = code;
+            msgs[r] = cz_last_error();
+        };
+        int wrc = cz::ensure_device();
+        if (wrc) return fail(wrc);
+        const uint32_t rb = std::min<uint64_t>(N, (uint64_t)r * per), re = std::min<uint64_t>(N, (uint64_t)(r + 1) * per);
+        std::vector<uint32_t> off((size_t)(re - rb) + 1);
+        for (uint32_t i = 0; i <= re - rb; i++) off[i] = in_offsets[rb + i] - in_offsets[rb];
+        cz_pagerank_plan *plan = nullptr;
+        wrc = cz_pagerank_plan_create(off.data(), in_sources + in_offsets[rb], out_degree, N, rb, re, damping, &plan,
+                                      flags & (CZ_PR_GATHER | CZ_PR_BLOCKED | CZ_PR_RELAXED));
+        // a rank that failed before the loop would leave the others blocked in the first collective: every rank enters
+        // the loop, a failed one with its poison flag raised
+        cz_comm c;
+        c.rank = r;
+        c.world = world;
+        c.device = devs[r];
+        c.nccl = comms[r];
+        hipStream_t st = nullptr;
+        if (!wrc && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) wrc = cz::set_error(CZ_E_HIP, "hipStreamCreate failed");
+        if (wrc) fail(wrc);
+        static const uint8_t kSet = 1;
+        std::unique_ptr<cz_pagerank_plan, void (*)(cz_pagerank_plan *)> guard(plan, cz_pagerank_plan_destroy);
+        cz_pagerank_plan *use = plan;
+        cz_pagerank_plan *empty = nullptr;
+        if (!use) {  // an empty stand-in so that this rank can still take part in the exchanges
+            uint32_t z = 0;
+            if (cz_pagerank_plan_create(&z, nullptr, out_degree, N, rb, rb, damping, &empty, 0) == CZ_OK) use = empty;
+        }
+        if (use) {
+            int lrc = cz_pagerank_sharded(&c, use, per, tolerance, max_iter, flags, &its[r], &errs[r], wrc ? &kSet : poison, st);
+            if (!wrc && lrc) fail(lrc);
+            if (!wrc && !lrc && re > rb) {
+                lrc = cz_pagerank_plan_read_scores(use, scores + rb, 0, st);
+                if (lrc) fail(lrc);
+            }
+        }
+        if (empty) cz_pagerank_plan_destroy(empty);
+        if (st) (void)hipStreamDestroy(st);
+        c.nccl = nullptr;
+        cz::t_device_override = -1;
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < world; r++) th.emplace_back(worker, r);
+    worker(0);
+    for (auto &t : th) t.join();
+    for (int r = 0; r < world; r++) {
+        (void)hipSetDevice(devs[r]);
+        (void)R->CommDestroy(comms[r]);
+    }
+    (void)cz::ensure_device();
+    for (int r = 0; r < world; r++)
+        if (rcs[r]) return cz::set_error(rcs[r], "GPU %d: %s", r, msgs[r].c_str());
+    if (iters_run) *iters_run = its[0];
+    if (final_err) *final_err = errs[0];
+    return CZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// hnsw_knn over an index partitioned into one independent sub-index per rank (BASELINE.json configs[3])
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// per query: `world` sorted lists of k (key = order-preserving image of the f64 distance, id = global node id or
+// 0xFFFF... for an empty slot) -> the k smallest by (key, id).  One workgroup per query, one thread per list entry:
+// rank = sum over lists of the lower bound of (key, id) in that list.
+__global__ void __launch_bounds__(256)
+shard_merge_kernel(const double *__restrict__ all_dist /* [world][B][k] */, const uint64_t *__restrict__ all_ids, uint32_t world,
+                   uint32_t B, uint32_t k, uint64_t *__restrict__ out_ids, double *__restrict__ out_dist,
+                   uint32_t *__restrict__ out_count) {
+    const uint32_t q = blockIdx.x;
+    __shared__ uint32_t found;
+    if (threadIdx.x == 0) found = 0;
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        out_ids[(size_t)q * k + i] = ~0ull;
+        out_dist[(size_t)q * k + i] = __longlong_as_double(0x7FF0000000000000ll);
+    }
+    __syncthreads();
+    const uint32_t total = world * k;
+    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+        const uint32_t w = e / k, j = e % k;
+        const size_t at = ((size_t)w * B + q) * k + j;
+        const uint64_t id = all_ids[at];
+        if (id == ~0ull) continue;
+        const uint64_t key = czd::dist_key(all_dist[at]);
+        uint32_t rank = 0;
+        for (uint32_t c = 0; c < world && rank < k; c++) {
+            const size_t base = ((size_t)c * B + q) * k;
+            uint32_t lo = 0, hi = k;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint64_t mid_id = all_ids[base + mid];
+                const uint64_t mid_key = czd::dist_key(all_dist[base + mid]);
+                const bool lt = mid_id != ~0ull && (mid_key < key || (mid_key == key && mid_id < id));
+                if (lt) lo = mid + 1;
+                else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) {
+            out_ids[(size_t)q * k + rank] = id;
+            out_dist[(size_t)q * k + rank] = all_dist[at];
+            atomicAdd(&found, 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out_count[q] = found;
+}
+
+__global__ void __launch_bounds__(256)
+shard_pack_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ cnt, uint32_t B, uint32_t k, uint64_t id_offset,
+                  uint64_t *__restrict__ out) {
+    const size_t n = (size_t)B * k;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t q = (uint32_t)(i / k), j = (uint32_t)(i % k);
+        out[i] = (j < cnt[q] && ids[i] != CZ_NONE) ? (uint64_t)ids[i] + id_offset : ~0ull;
+    }
+}
+
+}  // namespace
+
+extern "C" int cz_hnsw_search_sharded(cz_comm *comm, cz_hnsw_index *shard, const float *queries_dev, uint32_t B, uint32_t k,
+                                      uint32_t ef, uint64_t id_offset, uint64_t *out_ids_dev, double *out_dist_dev,
+                                      uint32_t *out_count_dev, void *stream_) {
+    if (!comm || !shard || !queries_dev || !out_ids_dev || !out_dist_dev || !out_count_dev)
+        return cz::set_error(CZ_E_INVALID, "null argument");
+    if (B == 0) return CZ_OK;
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    Rccl *R = nullptr;
+    if ((rc = need_rccl(&R))) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    auto *ix = reinterpret_cast<cz::HnswIndex *>(shard);
+    const uint32_t world = (uint32_t)comm->world;
+    const size_t nk = (size_t)B * k;
+    cz::DevBuf<float> q;
+    cz::DevBuf<uint32_t> ids, cnt;
+    cz::DevBuf<double> all_d;
+    cz::DevBuf<uint64_t> all_i;
+    CZ_HIP(q.alloc((size_t)B * ix->dim));
+    CZ_HIP(ids.alloc(nk));
+    CZ_HIP(cnt.alloc(B));
+    CZ_HIP(all_d.alloc(nk * world));
+    CZ_HIP(all_i.alloc(nk * world));
+    // rank 0's parent tuples go to every shard (B x dim x 4 bytes)
+    if (comm->rank == 0) CZ_HIP(hipMemcpyAsync(q.p, queries_dev, (size_t)B * ix->dim * 4, hipMemcpyDeviceToDevice, stream));
+    CZ_NCCL(R, R->Broadcast(q.p, q.p, (size_t)B * ix->dim, ncclFloat32, 0, comm->nccl, stream));
+    double *my_d = all_d.p + nk * comm->rank;
+    uint64_t *my_i = all_i.p + nk * comm->rank;
+    rc = cz::hnsw_search_device(ix, q.p, B, k, ef, 0, 0.0, ids.p, my_d, cnt.p, nullptr, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(shard_pack_kernel, dim3((unsigned)std::min<size_t>(1024, (nk + 255) / 256)), dim3(256), 0, stream, ids.p, cnt.p,
+                       B, k, id_offset, my_i);
+    CZ_NCCL(R, R->AllGather(my_d, all_d.p, nk, ncclFloat64, comm->nccl, stream));
+    CZ_NCCL(R, R->AllGather(my_i, all_i.p, nk, ncclUint64, comm->nccl, stream));
+    hipLaunchKernelGGL(shard_merge_kernel, dim3(B), dim3(256), 0, stream, all_d.p, all_i.p, world, B, k, out_ids_dev, out_dist_dev,
+                       out_count_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sharded search launch: %s", hipGetErrorString(e));
+    CZ_HIP(hipStreamSynchronize(stream));  // temporaries die with this scope
+    return CZ_OK;
+}

@@ -14,6 +14,9 @@ namespace cz {
 std::string &last_error_ref();
 int set_error(int code, const char *fmt, ...);
 int ensure_device();  // CZ_OK or CZ_E_NO_DEVICE; lazily runs cz_init(0)
+// the device a worker thread of cz_pagerank_multi drives instead of the process-wide one (-1: none).  HIP's current
+// device is per thread and every entry point re-selects it through ensure_device().
+extern thread_local int t_device_override;
 
 #define CZ_HIP(expr)                                                                               \
     do {                                                                                           \

@@ -185,9 +185,9 @@ distance_runs_kernel(int metric, const float *__restrict__ base, const float *__
 // ---- grouping the pairs of a batch by query: a hand-written counting sort -------------------------------------
 // P pairs over nq <= kGroupMaxQueries query rows.  The pair list is cut into G contiguous parts, one per workgroup:
 //   A  group_hist_kernel     per-part histogram of the query ids in LDS -> hist[part][q]
-//   B  group_scan_kernel     one workgroup: hist[part][q] becomes the first sorted position of (q, part) --
-//                            query-major, part-minor, i.e. an exclusive scan in that order
-//   C  group_scatter_kernel  every part walks its pairs again: position = first[part][q] + its rank among the part's
+//   B  group_within_kernel   per query: exclusive scan of its counts over the parts;  group_base_kernel: exclusive scan
+//                            of the per-query totals -- base[q] + within[part][q] = first sorted position of (q, part)
+//   C  group_scatter_kernel  every part walks its pairs again: position = that first position + its rank among the part's
 //                            pairs of q (LDS counter) -> qkey[pos] = q, brow[pos] = base row, perm[pos] = pair index
 // 8 bytes per pair are read twice and 12 written: 0.1 GB at P = 4M against the 12.9 GB of rows the distances read.
 constexpr int kGroupMaxQueries = 8192;  // 32 KiB of LDS counters
@@ -209,22 +209,38 @@ group_hist_kernel(const uint32_t *__restrict__ pairs, uint64_t P, uint32_t nq, u
     for (uint32_t i = threadIdx.x; i < nq; i += kGroupThreads) hist[(size_t)blockIdx.x * nq + i] = cnt[i];
 }
 
-__global__ void __launch_bounds__(kGroupThreads)
-group_scan_kernel(uint32_t *__restrict__ hist, uint32_t G, uint32_t nq) {
-    __shared__ uint32_t tot[kGroupMaxQueries];
-    __shared__ uint32_t wsum[kGroupThreads / 64];
-    // per query: exclusive scan over the parts (in place), total into LDS
-    for (uint32_t q = threadIdx.x; q < nq; q += kGroupThreads) {
-        uint32_t run = 0;
-        for (uint32_t g = 0; g < G; g++) {
-            const uint32_t c = hist[(size_t)g * nq + q];
-            hist[(size_t)g * nq + q] = run;
-            run += c;
+// B1: one thread per query id: exclusive scan of its counts over the parts (reads and writes different arrays so that
+// the loads of consecutive parts are in flight together; the in-place form waited for memory once per part -- 0.5 ms of
+// a 2.3 ms call at 512 parts)
+__global__ void __launch_bounds__(256)
+group_within_kernel(const uint32_t *__restrict__ hist, uint32_t G, uint32_t nq, uint32_t *__restrict__ within,
+                    uint32_t *__restrict__ tot) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    uint32_t run = 0;
+    uint32_t g = 0;
+    for (; g + 16 <= G; g += 16) {
+        uint32_t c[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) c[j] = hist[(size_t)(g + j) * nq + q];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            within[(size_t)(g + j) * nq + q] = run;
+            run += c[j];
         }
-        tot[q] = run;
     }
-    __syncthreads();
-    // exclusive scan of the totals: thread t owns a contiguous run of queries
+    for (; g < G; g++) {
+        const uint32_t c = hist[(size_t)g * nq + q];
+        within[(size_t)g * nq + q] = run;
+        run += c;
+    }
+    tot[q] = run;
+}
+
+// B2: one workgroup: tot[q] -> first sorted position of query q (exclusive scan, in place)
+__global__ void __launch_bounds__(kGroupThreads)
+group_base_kernel(uint32_t *__restrict__ tot, uint32_t nq) {
+    __shared__ uint32_t wsum[kGroupThreads / 64];
     const uint32_t per = (nq + kGroupThreads - 1) / kGroupThreads;
     const uint32_t q0 = threadIdx.x * per, q1 = min(nq, q0 + per);
     uint32_t mine = 0;
@@ -240,25 +256,19 @@ group_scan_kernel(uint32_t *__restrict__ hist, uint32_t G, uint32_t nq) {
     __syncthreads();
     uint32_t before = x - mine;
     for (int w = 0; w < wave; w++) before += wsum[w];
-    __syncthreads();
     for (uint32_t q = q0; q < q1; q++) {
         const uint32_t t = tot[q];
         tot[q] = before;
         before += t;
     }
-    __syncthreads();
-    for (uint32_t q = threadIdx.x; q < nq; q += kGroupThreads) {
-        const uint32_t b = tot[q];
-        for (uint32_t g = 0; g < G; g++) hist[(size_t)g * nq + q] += b;
-    }
 }
 
 __global__ void __launch_bounds__(kGroupThreads)
 group_scatter_kernel(const uint32_t *__restrict__ pairs, uint64_t P, uint32_t nq, uint64_t part_len,
-                     const uint32_t *__restrict__ first, uint32_t *__restrict__ qkey, uint32_t *__restrict__ brow,
-                     uint32_t *__restrict__ perm) {
+                     const uint32_t *__restrict__ within, const uint32_t *__restrict__ base, uint32_t *__restrict__ qkey,
+                     uint32_t *__restrict__ brow, uint32_t *__restrict__ perm) {
     __shared__ uint32_t cur[kGroupMaxQueries];
-    for (uint32_t i = threadIdx.x; i < nq; i += kGroupThreads) cur[i] = first[(size_t)blockIdx.x * nq + i];
+    for (uint32_t i = threadIdx.x; i < nq; i += kGroupThreads) cur[i] = base[i] + within[(size_t)blockIdx.x * nq + i];
     __syncthreads();
     const uint64_t p0 = (uint64_t)blockIdx.x * part_len, p1 = min(P, p0 + part_len);
     for (uint64_t p = p0 + threadIdx.x; p < p1; p += kGroupThreads) {
@@ -782,20 +792,25 @@ static int distance_pairs_device(int metric, const float *d_base, const float *d
             }
             hipError_t alloc(size_t bytes) { return hipMallocAsync(&p, bytes ? bytes : 16, st); }
         };
-        const uint32_t G = (uint32_t)std::min<uint64_t>(512, (P + 8191) / 8192);
+        const uint32_t G = (uint32_t)std::min<uint64_t>(128, (P + 32767) / 32768);
         const uint64_t part_len = (P + G - 1) / G;
-        AsyncBuf qkey(stream), brow(stream), perm(stream), hist(stream), bad(stream);
+        AsyncBuf qkey(stream), brow(stream), perm(stream), hist(stream), within(stream), tot(stream), bad(stream);
         CZ_HIP(qkey.alloc(P * 4));
         CZ_HIP(brow.alloc(P * 4));
         CZ_HIP(perm.alloc(P * 4));
         CZ_HIP(hist.alloc((size_t)G * nq * 4));
+        CZ_HIP(within.alloc((size_t)G * nq * 4));
+        CZ_HIP(tot.alloc((size_t)nq * 4));
         CZ_HIP(bad.alloc(4));
         CZ_HIP(hipMemsetAsync(bad.p, 0, 4, stream));
         hipLaunchKernelGGL(group_hist_kernel, dim3(G), dim3(kGroupThreads), 0, stream, d_pairs, P, nq, part_len, (uint32_t *)hist.p,
                            (uint32_t *)bad.p);
-        hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(kGroupThreads), 0, stream, (uint32_t *)hist.p, G, nq);
+        hipLaunchKernelGGL(group_within_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, (const uint32_t *)hist.p, G, nq,
+                           (uint32_t *)within.p, (uint32_t *)tot.p);
+        hipLaunchKernelGGL(group_base_kernel, dim3(1), dim3(kGroupThreads), 0, stream, (uint32_t *)tot.p, nq);
         hipLaunchKernelGGL(group_scatter_kernel, dim3(G), dim3(kGroupThreads), 0, stream, d_pairs, P, nq, part_len,
-                           (const uint32_t *)hist.p, (uint32_t *)qkey.p, (uint32_t *)brow.p, (uint32_t *)perm.p);
+                           (const uint32_t *)within.p, (const uint32_t *)tot.p, (uint32_t *)qkey.p, (uint32_t *)brow.p,
+                           (uint32_t *)perm.p);
         const char *st_env = getenv("CZ_RUNS_STRETCH");
         const uint32_t stretch = st_env ? (uint32_t)std::max(4, atoi(st_env)) : 256;  // sorted positions per lane group and grid step
         const uint64_t n_stretch = (P + stretch - 1) / stretch;

@@ -264,6 +264,14 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
                  double *__restrict__ seg_sum /* relaxed plans: sum of a hub-row segment, per block */) {
     __shared__ float tile[kBTileNnz];
     __shared__ double red[kBThreads / 64];
+    // runs longer than one wave instruction (a skewed graph: most of a row block's edges come from the few slices that
+    // hold the hubs): the first 64 values are placed by the wave that owns the run, the rest is queued here and placed by
+    // the whole workgroup afterwards -- walking such a run 64 values at a time on ONE wave cost 4 ms per sweep on R-MAT.
+    // A tile holds 16384 values, so at most 255 runs can be longer than 64.
+    __shared__ uint32_t tail_st[256], tail_p0[256], tail_cnt[256];
+    __shared__ uint32_t n_tail;
+    if (threadIdx.x == 0) n_tail = 0;
+    __syncthreads();
     constexpr int NW = kBThreads / 64;
     constexpr int RPL = kMaxRowsPerBlock / kBThreads;  // rows per lane
     constexpr int U = 10;
@@ -358,8 +366,19 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
                 if (lane < c[u]) tile[q[u]] = v[u];
 #pragma unroll
             for (int u = 0; u < U; u++)
-                for (uint32_t k = lane + 64; k < c[u]; k += 64) tile[pm[p0[u] + k]] = val[st[u] + k];
+                if (c[u] > 64 && lane == 0) {
+                    const uint32_t i = atomicAdd(&n_tail, 1u);
+                    tail_st[i] = st[u] + 64;
+                    tail_p0[i] = p0[u] + 64;
+                    tail_cnt[i] = c[u] - 64;
+                }
         }
+    }
+    __syncthreads();
+    const uint32_t nt = n_tail;
+    for (uint32_t i = 0; i < nt; i++) {
+        const uint32_t ts = tail_st[i], tp = tail_p0[i], tc = tail_cnt[i];
+        for (uint32_t k = threadIdx.x; k < tc; k += kBThreads) tile[pm[tp + k]] = val[ts + k];
     }
     }
     __syncthreads();
@@ -950,6 +969,7 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
 
 extern "C" float *cz_pagerank_plan_scores(cz_pagerank_plan *p) { return p ? p->d_scores : nullptr; }
 extern "C" uint64_t cz_pagerank_plan_edges(const cz_pagerank_plan *p) { return p ? p->E : 0; }
+extern "C" uint32_t cz_pagerank_plan_nodes(const cz_pagerank_plan *p) { return p ? p->N : 0; }
 extern "C" int cz_pagerank_plan_is_blocked(const cz_pagerank_plan *p) { return p && p->blocked ? 1 : 0; }
 
 extern "C" int cz_pagerank_plan_read_scores(cz_pagerank_plan *p, float *out, uint32_t flags, void *stream_) {

@@ -22,6 +22,7 @@ int set_error(int code, const char *fmt, ...) {
     return code;
 }
 
+thread_local int t_device_override = -1;
 static std::atomic<int> g_device{-1};
 static std::mutex g_init_mu;
 
@@ -44,6 +45,7 @@ static int init_device(int device) {
 
 int ensure_device() {
     int d = g_device.load();
+    if (d >= 0 && t_device_override >= 0) d = t_device_override;
     if (d >= 0) {
         // HIP's current device is per thread: make this thread target the selected GPU
         hipError_t e = hipSetDevice(d);

@@ -19,8 +19,8 @@
  *   - `poison` (may be NULL) mirrors runtime/db.rs:1926-1942 `Poison(Arc<AtomicBool>)`: a host byte
  *     polled between kernel launches; non-zero => CZ_E_CANCELLED.
  *   - all entry points are thread-safe; index / plan handles are immutable after creation.
- *   - one process drives one GPU (cz_init(device)); multi-GPU = one process per GPU, with the
- *     exchange steps done by the host over RCCL (see cozo_amd/distributed.py).
+ *   - cz_init(device) selects the GPU of the process; multi-GPU is either one process per GPU (cz_comm_create_rank)
+ *     or one process driving several (cz_pagerank_multi) -- see the multi-GPU section below and INTEGRATION.md.
  *   - node ids are dense u32 (< 2^31); CZ_NONE pads id arrays.
  */
 #ifndef COZO_GPU_H
@@ -206,6 +206,56 @@ int cz_pagerank_plan_is_blocked(const cz_pagerank_plan *p);
 int cz_pagerank_plan_timing(const cz_pagerank_plan *p, double *h2d_ms, double *build_ms);
 /* copy this shard's scores [row_end-row_begin] to `out` (host, or device with CZ_DEVICE_PTRS) */
 int cz_pagerank_plan_read_scores(cz_pagerank_plan *p, float *out, uint32_t flags, void *stream);
+
+uint32_t cz_pagerank_plan_nodes(const cz_pagerank_plan *p);
+
+/* =====================================================================================
+ * Multi-GPU, one node (RCCL over xGMI).  SURVEY section 8b proposed `cz_pagerank(..., int n_gpus, ...)`; a cozo
+ * process is ONE process, so that form is cz_pagerank_multi below (one host thread and one RCCL communicator per GPU).
+ * Launchers that run one process per GPU (MPI-style) use cz_comm_create_rank + cz_pagerank_sharded /
+ * cz_hnsw_search_sharded.  RCCL is bound at run time (dlopen "librccl.so.1", or $COZO_RCCL_LIB): CZ_E_UNSUPPORTED when
+ * the process cannot load it.
+ * ===================================================================================== */
+typedef struct cz_comm cz_comm;
+#define CZ_UNIQUE_ID_BYTES 128
+/* rank 0: a fresh RCCL unique id (ncclGetUniqueId); the caller ships the 128 bytes to the other ranks by its own means */
+int cz_comm_unique_id(uint8_t *id /* [CZ_UNIQUE_ID_BYTES] */);
+/* every rank, collectively: this process = rank `rank` of `world` on the device chosen by cz_init */
+int cz_comm_create_rank(const uint8_t *id, int rank, int world, cz_comm **out);
+void cz_comm_destroy(cz_comm *c);
+int cz_comm_rank(const cz_comm *c);
+int cz_comm_size(const cz_comm *c);
+/* the two exchange steps of the path on device buffers, stream-ordered.  all_gather is in place: rank r's part sits at
+ * buf + r * bytes_per_rank before the call, every part everywhere after it. */
+int cz_comm_all_gather(cz_comm *c, void *buf_dev, uint64_t bytes_per_rank, void *stream);
+int cz_comm_all_reduce_sum_f64(cz_comm *c, double *buf_dev, uint64_t n, void *stream);
+
+/* cz_pagerank_sharded / cz_pagerank_multi: exchange the next contribution vector by an all-reduce(sum) of the full
+ * vector with the other ranks' slices zeroed (north_star's literal wording) instead of the in-place all-gather of the
+ * slices.  Same values bit for bit, ~2(world-1)/world * 4N bytes per link instead of 4N/world: a labelled comparison. */
+#define CZ_PR_EXCHANGE_ALLREDUCE 32u
+
+/* graph::page_rank over row shards, collectively on every rank: `plan` owns this rank's rows
+ * [rank * rows_per_rank, min(N, (rank + 1) * rows_per_rank)) (cz_pagerank_plan_create with those bounds).  Per iteration:
+ * the plan's sweep, the exchange of the contribution slices, an all-reduce of {sum |new - old|, cancellation flag}.
+ * Every rank stops at the same iteration: by the reference's rule on the reduced error, or with CZ_E_CANCELLED as soon
+ * as ANY rank's poison flag is set.  The rank's scores stay in the plan (cz_pagerank_plan_read_scores). */
+int cz_pagerank_sharded(cz_comm *comm, cz_pagerank_plan *plan, uint32_t rows_per_rank, double tolerance, uint32_t max_iter,
+                        uint32_t flags /* CZ_PR_EXCHANGE_ALLREDUCE */, uint32_t *iters_run, double *final_err,
+                        const volatile uint8_t *poison, void *stream);
+/* cz_pagerank on n_gpus devices of this process (devices 0 .. n_gpus-1): host CSR in, scores [N] out.
+ * flags: CZ_PR_GATHER | CZ_PR_BLOCKED | CZ_PR_RELAXED | CZ_PR_EXCHANGE_ALLREDUCE. */
+int cz_pagerank_multi(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N,
+                      uint64_t E, float damping, double tolerance, uint32_t max_iter, int n_gpus, uint32_t flags,
+                      float *scores, uint32_t *iters_run, double *final_err, const volatile uint8_t *poison);
+/* hnsw_knn over an index partitioned into one independent sub-index per rank (BASELINE.json configs[3]), collectively:
+ * rank 0's `queries_dev` [B][dim] are broadcast, every rank searches ITS shard with the same k / ef, the per-shard lists
+ * are all-gathered (B * k * 16 bytes per rank) and merged by (distance, id) on every rank.
+ * out_ids_dev [B][k] u64: global ids = shard-local id + id_offset of the owning rank, ~0 padded; out_dist_dev [B][k] f64;
+ * out_count_dev [B].  Device pointers; returns after the stream has drained. */
+int cz_hnsw_search_sharded(cz_comm *comm, cz_hnsw_index *shard, const float *queries_dev, uint32_t B, uint32_t k,
+                           uint32_t ef, uint64_t id_offset, uint64_t *out_ids_dev, double *out_dist_dev,
+                           uint32_t *out_count_dev, void *stream);
 
 /* ShortestPathBFS::run (fixed_rule/algos/shortest_path_bfs.rs:35-113) and the traversal of Bfs::run
  * (algos/bfs.rs:25-113) on the out-CSR (neighbours in sorted order = the KV prefix-scan order).

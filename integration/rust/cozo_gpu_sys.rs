@@ -10,6 +10,8 @@ pub const CZ_PR_GATHER: u32 = 2;
 pub const CZ_PR_BLOCKED: u32 = 4;
 pub const CZ_BF_GEMM: u32 = 8;
 pub const CZ_PR_RELAXED: u32 = 16;
+pub const CZ_PR_EXCHANGE_ALLREDUCE: u32 = 32;
+pub const CZ_UNIQUE_ID_BYTES: u32 = 128;
 
 pub const CZ_OK: c_int = 0;
 pub const CZ_E_INVALID: c_int = -1;
@@ -29,6 +31,11 @@ pub struct cz_hnsw_index {
 }
 #[repr(C)]
 pub struct cz_pagerank_plan {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct cz_comm {
     _private: [u8; 0],
 }
 
@@ -104,6 +111,26 @@ extern "C" {
     pub fn cz_pagerank_plan_edges(p: *const cz_pagerank_plan) -> u64;
     pub fn cz_pagerank_plan_is_blocked(p: *const cz_pagerank_plan) -> c_int;
     pub fn cz_pagerank_plan_read_scores(p: *mut cz_pagerank_plan, out: *mut c_float, flags: u32, stream: *mut c_void) -> c_int;
+
+    pub fn cz_pagerank_plan_nodes(p: *const cz_pagerank_plan) -> u32;
+
+    // multi-GPU, one node (RCCL over xGMI)
+    pub fn cz_comm_unique_id(id: *mut u8) -> c_int;
+    pub fn cz_comm_create_rank(id: *const u8, rank: c_int, world: c_int, out: *mut *mut cz_comm) -> c_int;
+    pub fn cz_comm_destroy(c: *mut cz_comm);
+    pub fn cz_comm_rank(c: *const cz_comm) -> c_int;
+    pub fn cz_comm_size(c: *const cz_comm) -> c_int;
+    pub fn cz_comm_all_gather(c: *mut cz_comm, buf_dev: *mut c_void, bytes_per_rank: u64, stream: *mut c_void) -> c_int;
+    pub fn cz_comm_all_reduce_sum_f64(c: *mut cz_comm, buf_dev: *mut c_double, n: u64, stream: *mut c_void) -> c_int;
+    pub fn cz_pagerank_sharded(comm: *mut cz_comm, plan: *mut cz_pagerank_plan, rows_per_rank: u32, tolerance: c_double,
+                               max_iter: u32, flags: u32, iters_run: *mut u32, final_err: *mut c_double, poison: *const u8,
+                               stream: *mut c_void) -> c_int;
+    pub fn cz_pagerank_multi(in_offsets: *const u32, in_sources: *const u32, out_degree: *const u32, n: u32, e: u64,
+                             damping: c_float, tolerance: c_double, max_iter: u32, n_gpus: c_int, flags: u32,
+                             scores: *mut c_float, iters_run: *mut u32, final_err: *mut c_double, poison: *const u8) -> c_int;
+    pub fn cz_hnsw_search_sharded(comm: *mut cz_comm, shard: *mut cz_hnsw_index, queries_dev: *const c_float, b: u32, k: u32,
+                                  ef: u32, id_offset: u64, out_ids_dev: *mut u64, out_dist_dev: *mut c_double,
+                                  out_count_dev: *mut u32, stream: *mut c_void) -> c_int;
 
     pub fn cz_bfs(out_offsets: *const u32, out_targets: *const u32, n: u32, e: u64, starts: *const u32, n_starts: u32,
                   goals: *const u32, n_goals: u32, share_visited: c_int, parent: *mut u32, depth: *mut u32, order: *mut u32,

@@ -1,0 +1,137 @@
+"""The multi-GPU PageRank loop that sits BEHIND the C ABI (cozo_amd/csrc/sharded_pagerank.hpp: what cz_pagerank_sharded and
+cz_pagerank_multi run over HIP + RCCL), exercised with world_size 2 on CPU: tests/cpp/sharded_driver_test.cpp instantiates
+the same template with a host backend, and the exchange steps run over torch.distributed/gloo through ctypes callbacks.
+Scores must be bit-identical to the single-process oracle for both exchange forms; cancellation must be collective."""
+import ctypes as C
+import os
+import socket
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "sharded_driver_test.cpp")
+HDR = os.path.join(ROOT, "cozo_amd", "csrc", "sharded_pagerank.hpp")
+SO = os.path.join(ROOT, "tests", "cpp", "bin", "libsharded_driver_test.so")
+
+AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_uint64)
+AR32 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_uint64)
+AR64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_uint64)
+
+
+def build():
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", SRC, "-o", SO])
+    return SO
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, g, tol, max_iter, exchange, poison_at, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = C.CDLL(SO)
+    n = g["n"]
+    per = (n + world - 1) // world
+    rb, re = min(n, rank * per), min(n, (rank + 1) * per)
+    ioff = g["ioff"].astype(np.uint64)
+    off_local = np.ascontiguousarray(ioff[rb:re + 1] - ioff[rb])
+    src = np.ascontiguousarray(g["isrc"][int(ioff[rb]):int(ioff[re])], dtype=np.uint32)
+    outdeg = np.ascontiguousarray(g["outdeg"], dtype=np.uint32)
+    poison = np.zeros(1, dtype=np.uint8)
+    calls = {"ag": 0}
+
+    def ag(_ctx, buf, per_):
+        t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(int(per_) * world,)))
+        dist.all_gather_into_tensor(t, t[rank * per_:(rank + 1) * per_].clone())
+        calls["ag"] += 1
+        if poison_at is not None and rank == poison_at[0] and calls["ag"] == poison_at[1]:
+            poison[0] = 1  # this rank's Poison is set between two iterations; the other rank never sees its own flag
+        return 0
+
+    def ar32(_ctx, buf, n_):
+        t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(int(n_),)))
+        dist.all_reduce(t)
+        calls["ag"] += 1
+        if poison_at is not None and rank == poison_at[0] and calls["ag"] == poison_at[1]:
+            poison[0] = 1
+        return 0
+
+    def ar64(_ctx, buf, n_):
+        t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(int(n_),)))
+        dist.all_reduce(t)
+        return 0
+
+    cbs = (AG(ag), AR32(ar32), AR64(ar64))
+    scores = np.zeros(re - rb, dtype=np.float32)
+    it = C.c_uint32(0)
+    err = C.c_double(0)
+    counters = (C.c_int * 3)()
+    L.cz_test_sharded_pagerank_host.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_float, C.c_double, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, AG, AR32, AR64,
+                                                C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    rc = L.cz_test_sharded_pagerank_host(n, per, rank, world, off_local.ctypes.data, src.ctypes.data, outdeg.ctypes.data,
+                                         np.float32(0.85), float(tol), int(max_iter), int(exchange), poison.ctypes.data, None,
+                                         *cbs, scores.ctypes.data, C.byref(it), C.byref(err), counters)
+    q.put((rank, rb, re, rc, scores, it.value, err.value, list(counters)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(g, tol, max_iter, exchange, poison_at=None, world=2):
+    build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, g, tol, max_iter, exchange, poison_at, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(out)
+
+
+@pytest.mark.parametrize("exchange", [0, 1], ids=["all_gather", "all_reduce"])
+@pytest.mark.parametrize("n,e,tol,max_iter", [(301, 2500, 1e-4, 10), (64, 400, 0.0, 5), (7, 12, 1e-4, 10), (1000, 9000, 0.0, 20)])
+def test_cpp_sharded_loop_world2_bit_identical(oracle, n, e, tol, max_iter, exchange):
+    frm, to = util.random_relation(n, e, 23)
+    g = util.graph_from_relation(oracle, frm, to)
+    want, want_it, want_err = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, tol, max_iter)
+    out = _run(g, tol, max_iter, exchange)
+    got = np.concatenate([o[4] for o in out])
+    assert all(o[3] == 0 for o in out)
+    assert all(o[5] == want_it for o in out), "every rank stops at the same iteration"
+    assert np.array_equal(got, want), "scores bit-identical to the single-process oracle"
+    assert all(o[6] == pytest.approx(want_err, rel=1e-12) for o in out)
+    # one sweep, one exchange and one error reduction per iteration on every rank
+    assert all(o[7] == [want_it, want_it if exchange == 0 else 0, want_it] for o in out)
+
+
+def test_cpp_sharded_loop_cancellation_is_collective(oracle):
+    """Poison set on ONE rank after its 3rd exchange: both ranks leave with the cancelled code at the same point (tolerance > 0:
+    the reduced flag is read every iteration) instead of one of them blocking in the next collective."""
+    frm, to = util.random_relation(400, 3000, 5)
+    g = util.graph_from_relation(oracle, frm, to)
+    out = _run(g, 1e-12, 50, 0, poison_at=(1, 3))
+    assert [o[3] for o in out] == [1, 1]  # czs::RUN_CANCELLED on both
+    assert out[0][7][1] == out[1][7][1] == 4  # ... after the same number of exchanges
+    assert out[0][7][0] == 4 and out[1][7][0] == 3  # the poisoned rank skipped its last sweep
+    # tolerance <= 0 (sweeps back to back): the flag is looked at every 8th iteration
+    out = _run(g, 0.0, 50, 0, poison_at=(0, 2))
+    assert [o[3] for o in out] == [1, 1] and out[0][7][1] == out[1][7][1] == 8
