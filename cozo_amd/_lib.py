@@ -54,6 +54,15 @@ class HnswDesc(C.Structure):
     ]
 
 
+class Predicate(C.Structure):
+    _fields_ = [("column", C.c_void_p), ("op", C.c_int32), ("const_type", C.c_int32), ("f64_value", C.c_double),
+                ("i64_value", C.c_int64)]
+
+
+CZ_COL_F64, CZ_COL_I64 = 0, 1
+CZ_OPS = {"<": 0, "<=": 1, "==": 2, ">=": 3, ">": 4, "!=": 5}
+
+
 class PagerankTiming(C.Structure):
     _fields_ = [("h2d_ms", C.c_double), ("plan_build_ms", C.c_double), ("iterate_ms", C.c_double), ("d2h_ms", C.c_double),
                 ("cache_hit", C.c_int32), ("reserved", C.c_int32)]
@@ -78,6 +87,11 @@ SYMBOLS = {
     "cz_hnsw_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                        C.c_void_p]),
+    "cz_column_upload": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "cz_column_destroy": (None, [C.c_void_p]),
+    "cz_hnsw_search_filtered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double,
+                                          C.POINTER(Predicate), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_uint32, C.c_void_p]),
     "cz_distance_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                     C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "cz_knn_bruteforce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
@@ -157,6 +171,12 @@ def _preload_hip_runtime() -> str:
         try:
             C.CDLL(c, mode=C.RTLD_GLOBAL)
             _hip_runtime_path = c
+            # the collectives library must come from the same distribution as the runtime (a PyTorch wheel bundles its own
+            # librccl.so next to its libamdhip64.so; mixing it with /opt/rocm's drags a second set of ROCm support
+            # libraries into the process -- observed: "double free or corruption" at interpreter exit)
+            rccl = os.path.join(os.path.dirname(c), "librccl.so")
+            if os.path.isabs(c) and os.path.exists(rccl):
+                os.environ.setdefault("COZO_RCCL_LIB", rccl)
             return c
         except OSError as e:  # pragma: no cover
             errs.append(f"{c}: {e}")

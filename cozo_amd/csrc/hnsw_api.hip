@@ -112,32 +112,63 @@ distance_pairs_kernel(int metric, const float *__restrict__ base, const float *_
     }
 }
 
-// The same over pairs GROUPED BY QUERY (sorted positions `perm`, their query ids `qkey`): a lane group walks a
-// contiguous stretch of the sorted list, keeps the current query in registers like the search kernel does, and only
-// streams base rows -- the second (query-row) stream, which costs the ungrouped kernel 20 % of its bandwidth
+// The same over pairs GROUPED BY QUERY (sorted positions `perm`, their query ids `qkey`, their base rows `brow`): a lane
+// group walks a contiguous stretch of the sorted list, keeps the current query in registers like the search kernel does,
+// and only streams base rows -- the second (query-row) stream, which costs the ungrouped kernel 20 % of its bandwidth
 // (scratch/rowfetch_bench: 6.5 -> 5.1 TB/s), disappears.  Arithmetic per pair is unchanged (same lane mapping, same
 // butterfly; the query's self dot is the same chain the ungrouped kernel runs per pair), so results are bit-identical.
+// The stretch's three index arrays are staged in LDS with coalesced loads first (a round's addresses then cost an LDS
+// read instead of a dependent L2 round trip ahead of every row fetch), and the rows of round r + 1 are requested before
+// round r is reduced.
+constexpr int kRunStretch = 256;  // sorted positions per lane group and grid step
+
 template <int LPV, int ITERS, int U>
 __global__ void __launch_bounds__(256)
 distance_runs_kernel(int metric, const float *__restrict__ base, const float *__restrict__ queries, uint32_t ld,
                      const uint32_t *__restrict__ brow, const uint32_t *__restrict__ qkey,
                      const uint32_t *__restrict__ perm, uint64_t P_all, const uint32_t *__restrict__ n_dropped,
-                     uint32_t stretch, double *__restrict__ out) {
-    const uint64_t P = P_all - *n_dropped;  // pairs naming a query row >= nq were left out of the sorted arrays
+                     double *__restrict__ out) {
     static_assert(ITERS > 0 && U <= 16, "register-resident query; one lane of the group per pair of a round");
+    constexpr int GPB = 256 / LPV;  // lane groups per workgroup
+    __shared__ uint32_t s_q[GPB][kRunStretch], s_b[GPB][kRunStretch], s_p[GPB][kRunStretch];
+    const uint64_t P = P_all - *n_dropped;  // pairs naming a query row >= nq were left out of the sorted arrays
     const int chunks = (int)(ld / 4);
     const bool full = chunks == LPV * ITERS;
     const int lane = threadIdx.x & 63;
     const int glane = lane % LPV;
-    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPV;
-    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / LPV;
-    for (uint64_t c0 = group * stretch; c0 < P; c0 += ngroups * stretch) {
-        const uint64_t end = min(P, c0 + (uint64_t)stretch);
+    const int g = threadIdx.x / LPV;
+    const uint64_t group = (uint64_t)blockIdx.x * GPB + g;
+    const uint64_t ngroups = (uint64_t)gridDim.x * GPB;
+    using Regs = RowRegs<ITERS, U>;
+    for (uint64_t c0 = group * kRunStretch; c0 < P; c0 += ngroups * kRunStretch) {
+        const int n = (int)min((uint64_t)kRunStretch, P - c0);
+        for (int i = glane; i < n; i += LPV) {
+            s_q[g][i] = qkey[c0 + i];
+            s_b[g][i] = brow[c0 + i];
+            s_p[g][i] = perm[c0 + i];
+        }
+        __builtin_amdgcn_wave_barrier();  // a group's lanes belong to one wave; LDS operations of a wave complete in order
         uint32_t cur_q = CZ_NONE;
         float4 q[ITERS];
         float qn = 0.f;
-        for (uint64_t pos = c0; pos < end;) {
-            const uint32_t qid = qkey[pos];
+        // a round = up to U consecutive positions that share their query
+        auto round_len = [&](int pos) {
+            const uint32_t qid = s_q[g][pos];
+            int cnt = 1;
+#pragma unroll
+            for (int u = 1; u < U; u++)
+                if (cnt == u && pos + u < n && s_q[g][pos + u] == qid) cnt = u + 1;
+            return cnt;
+        };
+        auto issue = [&](Regs &r, int pos, int cnt) {
+            const float4 *rows[U];
+#pragma unroll
+            for (int u = 0; u < U; u++)  // past the round's end: repeat the last pair, result discarded
+                rows[u] = (const float4 *)(base + (size_t)s_b[g][pos + min(u, cnt - 1)] * ld);
+            load_rows<LPV, ITERS, U, true>(r, rows, glane, chunks, full);
+        };
+        auto retire = [&](const Regs &r, int pos, int cnt) {
+            const uint32_t qid = s_q[g][pos];
             if (qid != cur_q) {  // uniform over the group
                 const float4 *qrow = (const float4 *)(queries + (size_t)qid * ld);
 #pragma unroll
@@ -148,37 +179,42 @@ distance_runs_kernel(int metric, const float *__restrict__ base, const float *__
                 qn = metric == CZ_COSINE ? query_norm<LPV, ITERS>(q, nullptr, glane, chunks) : 0.f;
                 cur_q = qid;
             }
-            int cnt = 1;  // positions of this round: as many of the next U as share the query
-#pragma unroll
-            for (int u = 1; u < U; u++)
-                if (cnt == u && pos + u < end && qkey[pos + u] == qid) cnt = u + 1;
-            uint32_t slot[U];
-            const float4 *rows[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint64_t at = pos + min(u, cnt - 1);  // past the round's end: repeat the last pair, result discarded
-                slot[u] = perm[at];
-                rows[u] = (const float4 *)(base + (size_t)brow[at] * ld);
-            }
-            RowRegs<ITERS, U> r;
-            load_rows<LPV, ITERS, U, true>(r, rows, glane, chunks, full);
             float m[U], bn[U];
             if (metric == CZ_COSINE) dot_rows<CZ_COSINE, LPV, ITERS, U>(q, r, m, bn);
             else if (metric == CZ_L2) dot_rows<CZ_L2, LPV, ITERS, U>(q, r, m, bn);
             else dot_rows<CZ_IP, LPV, ITERS, U>(q, r, m, bn);
             float mm = m[0], bb = bn[0];
-            uint32_t dst = slot[0];
 #pragma unroll
             for (int u = 1; u < U; u++)
                 if (glane == u) {
                     mm = m[u];
                     bb = bn[u];
-                    dst = slot[u];
                 }
             const double d = finish_distance(metric, mm, bb, qn);
-            if (glane < cnt) out[dst] = d;
-            pos += cnt;
+            if (glane < cnt) out[s_p[g][pos + glane]] = d;
+        };
+        Regs ra, rb;
+        int pos_a = 0, cnt_a = round_len(0);
+        issue(ra, pos_a, cnt_a);
+        for (;;) {
+            const int pos_b = pos_a + cnt_a;
+            int cnt_b = 0;
+            if (pos_b < n) {
+                cnt_b = round_len(pos_b);
+                issue(rb, pos_b, cnt_b);
+            }
+            retire(ra, pos_a, cnt_a);
+            if (pos_b >= n) break;
+            pos_a = pos_b + cnt_b;
+            cnt_a = 0;
+            if (pos_a < n) {
+                cnt_a = round_len(pos_a);
+                issue(ra, pos_a, cnt_a);
+            }
+            retire(rb, pos_b, cnt_b);
+            if (pos_a >= n) break;
         }
+        __builtin_amdgcn_wave_barrier();  // the next stretch overwrites the staged indices
     }
 }
 
@@ -653,7 +689,7 @@ namespace cz {
 
 int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32_t k, uint32_t ef, int has_radius,
                        double radius, uint32_t *d_ids, double *d_dist, uint32_t *d_count, uint64_t *d_ndist,
-                       hipStream_t stream) {
+                       hipStream_t stream, const czh::PredSet *preds_in) {
     if (B == 0) return CZ_OK;
     if (k == 0) return set_error(CZ_E_INVALID, "k must be > 0");
     if (ef == 0) return set_error(CZ_E_INVALID, "ef must be > 0");
@@ -677,13 +713,16 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
     if (rc) return rc;
     IndexDev d = ix->dev();
     Shape sh = shape_of(ix->dim);
+    czh::PredSet preds;
+    memset(&preds, 0, sizeof preds);
+    if (preds_in) preds = *preds_in;
 #define CZ_LAUNCH_KNN(LPV, ITERS, U)                                                                                    \
     do {                                                                                                                \
         auto kern = czh::hnsw_knn_kernel<LPV, ITERS, U>;                                                                \
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                         (int)smem);                                                    \
         hipLaunchKernelGGL(kern, dim3(B), dim3(czh::kThreads), smem, stream, d, d_queries, k, ef, efcap, wpad,          \
-                           has_radius, radius, (uint32_t *)ws.tab, hbits, (uint32_t *)ws.bitmap, words, d_ids,          \
+                           has_radius, radius, (uint32_t *)ws.tab, hbits, (uint32_t *)ws.bitmap, words, preds, d_ids,   \
                            d_dist, d_count, (unsigned long long *)d_ndist);                                             \
     } while (0)
     // experiment knob: rows per round of a lane group for the 513..768-d shape (CZ_HNSW_U = 1 | 2)
@@ -753,6 +792,98 @@ extern "C" int cz_hnsw_search_batch(cz_hnsw_index *h, const float *queries, uint
 }
 
 // ------------------------------------------------------------------------------------------------
+// filtered search: per-node columns in HBM + predicates evaluated by the kernel's output stage
+// ------------------------------------------------------------------------------------------------
+struct cz_column {
+    void *d = nullptr;
+    uint32_t n = 0;
+    int32_t type = 0;
+    ~cz_column() {
+        if (d) (void)hipFree(d);
+    }
+};
+
+extern "C" int cz_column_upload(const void *values, uint32_t n, int32_t type, cz_column **out) {
+    if (!out) return cz::set_error(CZ_E_INVALID, "null out");
+    *out = nullptr;
+    if (type != CZ_COL_F64 && type != CZ_COL_I64) return cz::set_error(CZ_E_INVALID, "bad column type %d", type);
+    if (n > 0 && !values) return cz::set_error(CZ_E_INVALID, "null values");
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    std::unique_ptr<cz_column> c(new cz_column());
+    c->n = n;
+    c->type = type;
+    CZ_HIP(hipMalloc(&c->d, std::max<size_t>(8, (size_t)n * 8)));
+    if (n) CZ_HIP(hipMemcpy(c->d, values, (size_t)n * 8, hipMemcpyHostToDevice));
+    *out = c.release();
+    return CZ_OK;
+}
+
+extern "C" void cz_column_destroy(cz_column *c) {
+    if (!c) return;
+    (void)cz::ensure_device();
+    delete c;
+}
+
+extern "C" int cz_hnsw_search_filtered(cz_hnsw_index *h, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
+                                       int has_radius, double radius, const cz_predicate *preds, uint32_t n_preds,
+                                       uint32_t *out_ids, double *out_dist, uint32_t *out_count, uint64_t *out_n_dist,
+                                       const volatile uint8_t *poison, uint32_t flags, void *stream_) {
+    if (!h) return cz::set_error(CZ_E_INVALID, "null index");
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    auto *ix = reinterpret_cast<cz::HnswIndex *>(h);
+    if (n_preds == 0 || n_preds > (uint32_t)czh::kMaxPreds)
+        return cz::set_error(CZ_E_UNSUPPORTED, "1..%d predicates are evaluated on the device (got %u)", czh::kMaxPreds, n_preds);
+    if (!preds) return cz::set_error(CZ_E_INVALID, "null predicates");
+    czh::PredSet ps;
+    memset(&ps, 0, sizeof ps);
+    ps.n = (int)n_preds;
+    for (uint32_t i = 0; i < n_preds; i++) {
+        const cz_predicate &p = preds[i];
+        if (!p.column) return cz::set_error(CZ_E_INVALID, "predicate %u: null column", i);
+        if (p.column->n != ix->n)
+            return cz::set_error(CZ_E_INVALID, "predicate %u: column has %u values, the index %u nodes", i, p.column->n, ix->n);
+        if (p.op < CZ_OP_LT || p.op > CZ_OP_NE) return cz::set_error(CZ_E_INVALID, "predicate %u: bad operator %d", i, p.op);
+        if (p.const_type != CZ_COL_F64 && p.const_type != CZ_COL_I64)
+            return cz::set_error(CZ_E_INVALID, "predicate %u: bad constant type %d", i, p.const_type);
+        ps.t[i].col = p.column->d;
+        ps.t[i].col_is_int = p.column->type == CZ_COL_I64;
+        ps.t[i].const_is_int = p.const_type == CZ_COL_I64;
+        ps.t[i].op = p.op;
+        ps.t[i].fv = p.f64_value;
+        ps.t[i].iv = p.i64_value;
+    }
+    if (B == 0) return CZ_OK;
+    if (!queries || !out_ids || !out_dist || !out_count) return cz::set_error(CZ_E_INVALID, "null buffer");
+    if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (flags & CZ_DEVICE_PTRS)
+        return cz::hnsw_search_device(ix, queries, B, k, ef, has_radius, radius, out_ids, out_dist, out_count, out_n_dist, stream,
+                                      &ps);
+    cz::DevBuf<float> dq;
+    cz::DevBuf<uint32_t> dids, dcnt;
+    cz::DevBuf<double> ddist;
+    cz::DevBuf<uint64_t> dnd;
+    CZ_HIP(dq.alloc((size_t)B * ix->dim));
+    CZ_HIP(dids.alloc((size_t)B * k));
+    CZ_HIP(ddist.alloc((size_t)B * k));
+    CZ_HIP(dcnt.alloc(B));
+    if (out_n_dist) CZ_HIP(dnd.alloc(B));
+    CZ_HIP(hipMemcpyAsync(dq.p, queries, (size_t)B * ix->dim * 4, hipMemcpyHostToDevice, stream));
+    rc = cz::hnsw_search_device(ix, dq.p, B, k, ef, has_radius, radius, dids.p, ddist.p, dcnt.p, out_n_dist ? dnd.p : nullptr, stream,
+                                &ps);
+    if (rc) return rc;
+    CZ_HIP(hipMemcpyAsync(out_ids, dids.p, (size_t)B * k * 4, hipMemcpyDeviceToHost, stream));
+    CZ_HIP(hipMemcpyAsync(out_dist, ddist.p, (size_t)B * k * 8, hipMemcpyDeviceToHost, stream));
+    CZ_HIP(hipMemcpyAsync(out_count, dcnt.p, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+    if (out_n_dist) CZ_HIP(hipMemcpyAsync(out_n_dist, dnd.p, (size_t)B * 8, hipMemcpyDeviceToHost, stream));
+    CZ_HIP(hipStreamSynchronize(stream));
+    if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+    return CZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // batched distance
 // ------------------------------------------------------------------------------------------------
 // CZ_DISPATCH_SHAPE restricted to register-resident queries, U = 4 rows per round
@@ -811,15 +942,16 @@ static int distance_pairs_device(int metric, const float *d_base, const float *d
         hipLaunchKernelGGL(group_scatter_kernel, dim3(G), dim3(kGroupThreads), 0, stream, d_pairs, P, nq, part_len,
                            (const uint32_t *)within.p, (const uint32_t *)tot.p, (uint32_t *)qkey.p, (uint32_t *)brow.p,
                            (uint32_t *)perm.p);
-        const char *st_env = getenv("CZ_RUNS_STRETCH");
-        const uint32_t stretch = st_env ? (uint32_t)std::max(4, atoi(st_env)) : 256;  // sorted positions per lane group and grid step
-        const uint64_t n_stretch = (P + stretch - 1) / stretch;
+        const uint64_t n_stretch = (P + kRunStretch - 1) / kRunStretch;
         const int blocks = (int)std::min<uint64_t>(256 * 8, (n_stretch * (uint64_t)sh.lpv + 255) / 256);
 #define CZ_LAUNCH_RUNS(LPV, ITERS, U)                                                                                  \
     hipLaunchKernelGGL((distance_runs_kernel<LPV, ITERS, U>), dim3(std::max(blocks, 1)), dim3(256), 0, stream, metric, \
                        d_base, d_queries, ld, (const uint32_t *)brow.p, (const uint32_t *)qkey.p, (const uint32_t *)perm.p, P, \
-                       (const uint32_t *)bad.p, stretch, d_out)
-        CZ_DISPATCH_SHAPE_RUNS(sh, CZ_LAUNCH_RUNS);
+                       (const uint32_t *)bad.p, d_out)
+        // experiment knob: rows per round for the 513..768-d shape (CZ_RUNS_U = 2 | 4)
+        const char *ru_env = getenv("CZ_RUNS_U");
+        if (sh.lpv == 64 && sh.iters == 3 && ru_env && atoi(ru_env) == 2) CZ_LAUNCH_RUNS(64, 3, 2);
+        else CZ_DISPATCH_SHAPE_RUNS(sh, CZ_LAUNCH_RUNS);
 #undef CZ_LAUNCH_RUNS
         hipError_t se = hipGetLastError();
         if (se != hipSuccess) return cz::set_error(CZ_E_HIP, "grouped distance batch: %s", hipGetErrorString(se));

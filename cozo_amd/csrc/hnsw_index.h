@@ -16,6 +16,7 @@
 
 namespace czh {
 struct IndexDev;
+struct PredSet;
 }
 
 namespace cz {
@@ -56,7 +57,7 @@ struct HnswIndex {
 
 int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32_t k, uint32_t ef, int has_radius,
                        double radius, uint32_t *d_ids, double *d_dist, uint32_t *d_count, uint64_t *d_ndist,
-                       hipStream_t stream);
+                       hipStream_t stream, const czh::PredSet *preds = nullptr);
 
 // shape of the per-query visited set for a traversal with list size `ef` over link rows of `width` slots on an index
 // of n nodes: hash-table bits (0 = bitmap only) and bitmap words.  CZ_HNSW_VISITED = bitmap | hash and

@@ -803,6 +803,68 @@ struct Searcher {
     }
 };
 
+// Column predicates of a filtered search, evaluated on the device over the ef candidates (hnsw.rs:943-947 keeps all ef
+// when a filter is present, :997-1006 filters then truncates to k): a conjunction of `column[node] OP constant` over
+// per-node numeric columns resident in HBM.  Comparison semantics are the reference's (data/functions.rs:298-380 over
+// data/value.rs:575-598): Int with Int as integers, Float with Float by f64::total_cmp (so -0.0 < 0.0 and NaN == NaN),
+// mixed pairs as IEEE f64 after `as f64`.
+struct PredTerm {
+    const void *col;  // f64 or i64, [n]
+    int col_is_int, const_is_int, op, pad;
+    double fv;
+    long long iv;
+};
+constexpr int kMaxPreds = 4;
+struct PredSet {
+    int n;
+    int pad;
+    PredTerm t[kMaxPreds];
+};
+__device__ __forceinline__ long long f64_total_key(double d) {  // order-preserving integer image of f64::total_cmp
+    const long long b = __double_as_longlong(d);
+    return b ^ (long long)((unsigned long long)(b >> 63) >> 1);
+}
+__device__ __forceinline__ bool pred_cmp(int op, int c /* -1, 0, 1 */) {
+    switch (op) {
+        case 0: return c < 0;    // CZ_OP_LT
+        case 1: return c <= 0;   // CZ_OP_LE
+        case 2: return c == 0;   // CZ_OP_EQ
+        case 3: return c >= 0;   // CZ_OP_GE
+        case 4: return c > 0;    // CZ_OP_GT
+        default: return c != 0;  // CZ_OP_NE
+    }
+}
+__device__ __forceinline__ bool pred_ieee(int op, double l, double r) {
+    switch (op) {
+        case 0: return l < r;
+        case 1: return l <= r;
+        case 2: return l == r;
+        case 3: return l >= r;
+        case 4: return l > r;
+        default: return l != r;
+    }
+}
+__device__ __forceinline__ bool pred_pass(const PredSet &ps, uint32_t node) {
+    for (int i = 0; i < ps.n; i++) {
+        const PredTerm &t = ps.t[i];
+        bool ok;
+        if (t.col_is_int) {
+            const long long v = ((const long long *)t.col)[node];
+            if (t.const_is_int) ok = pred_cmp(t.op, v < t.iv ? -1 : (v > t.iv ? 1 : 0));
+            else ok = pred_ieee(t.op, (double)v, t.fv);
+        } else {
+            const double v = ((const double *)t.col)[node];
+            if (t.const_is_int) ok = pred_ieee(t.op, v, (double)t.iv);
+            else {
+                const long long a = f64_total_key(v), b = f64_total_key(t.fv);
+                ok = pred_cmp(t.op, a < b ? -1 : (a > b ? 1 : 0));
+            }
+        }
+        if (!ok) return false;
+    }
+    return true;
+}
+
 // hnsw_knn (hnsw.rs:869-1012): one workgroup per query
 // The search streams base rows with the non-temporal hint: same-box A/B at 1M x 768, batch 1024: 3.447 -> 3.267 ms
 // (the rows are read once; without the hint they push link rows and visited words out of L2).  Index construction
@@ -814,8 +876,8 @@ template <int LPV, int ITERS, int U>
 __global__ void __launch_bounds__(kThreads)
 hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t efcap,
                 uint32_t wpad, int has_radius, double radius, uint32_t *__restrict__ vtab, uint32_t hbits,
-                uint32_t *__restrict__ vbitmap, uint32_t words, uint32_t *__restrict__ out_ids, double *__restrict__ out_dist, uint32_t *__restrict__ out_count,
-                unsigned long long *__restrict__ out_n_dist) {
+                uint32_t *__restrict__ vbitmap, uint32_t words, PredSet preds, uint32_t *__restrict__ out_ids,
+                double *__restrict__ out_dist, uint32_t *__restrict__ out_count, unsigned long long *__restrict__ out_n_dist) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t b = blockIdx.x;
     Smem s = carve(smem_raw, efcap, wpad, ix.ld);
@@ -839,8 +901,44 @@ hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t k, uint
         for (int i_ = 0; i_ < 8; i_++) atomicAdd(&cz_phase_cycles[i_], S.ph_acc[i_]);
     }
 #endif
-    // :943-1006 truncate to k, radius cut (`distance > r` => skip; a NaN distance is never > r), ascending
     const int cnt = s.ctl[C_CNT];
+    int total;
+    if (preds.n > 0) {
+        // filtered search (:943-947, :997-1006): ALL ef candidates are looked at in ascending order -- radius cut, then the
+        // predicates -- and the first k survivors are the result
+        for (int i = threadIdx.x; i < cnt; i += kThreads) {
+            const uint64_t key = s.wkey[i];
+            bool ok = !(has_radius && key != ~0ull && key_dist(key) > radius);
+            if (ok) ok = pred_pass(preds, s.wid[i] & kIdMask);
+            s.st[i] = ok ? 1 : 0;
+        }
+        for (int j = threadIdx.x; j < (int)k; j += kThreads) {
+            out_ids[(size_t)b * k + j] = CZ_NONE;
+            out_dist[(size_t)b * k + j] = __longlong_as_double(0x7FF0000000000000ll);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {  // one wave walks the flags in order
+            const int lane = threadIdx.x;
+            int kept = 0;
+            for (int b0 = 0; b0 < cnt && kept < (int)k; b0 += 64) {
+                const int i = b0 + lane;
+                const bool ok = i < cnt && s.st[i] != 0;
+                const unsigned long long m = __ballot(ok);
+                if (ok) {
+                    const int pos = kept + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < (int)k) {
+                        out_ids[(size_t)b * k + pos] = s.wid[i] & kIdMask;
+                        out_dist[(size_t)b * k + pos] = key_dist(s.wkey[i]);
+                    }
+                }
+                kept += __popcll(m);
+            }
+            if (lane == 0) s.ctl[C_KEEP] = min(kept, (int)k);
+        }
+        __syncthreads();
+        total = s.ctl[C_KEEP];
+    } else {
+    // :943-1006 truncate to k, radius cut (`distance > r` => skip; a NaN distance is never > r), ascending
     const int kk = min((int)k, cnt);
     int c_keep = 0, c_num = 0;
     for (int i = threadIdx.x; i < kk; i += kThreads) {
@@ -855,7 +953,7 @@ hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t k, uint
     __syncthreads();
     // W is sorted: the kept finite entries are a prefix [0,p); NaN entries sit at [first_nan, kk)
     const int p = s.ctl[C_KEEP], first_nan = s.ctl[C_NUM];
-    const int total = p + (kk - first_nan);
+    total = p + (kk - first_nan);
     for (int j = threadIdx.x; j < (int)k; j += kThreads) {
         uint32_t id = CZ_NONE;
         double d = __longlong_as_double(0x7FF0000000000000ll);
@@ -866,6 +964,7 @@ hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t k, uint
         }
         out_ids[(size_t)b * k + j] = id;
         out_dist[(size_t)b * k + j] = d;
+    }
     }
     if (threadIdx.x == 0) {
         out_count[b] = (uint32_t)total;

@@ -261,14 +261,15 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
                  const uint16_t *__restrict__ perm, const uint32_t *__restrict__ vpos, const float *__restrict__ val,
                  const uint32_t *__restrict__ out_deg, uint32_t row_begin, float *__restrict__ contrib_out,
                  float *__restrict__ scores, float base, float damping, double *__restrict__ partial, int xcd_remap,
-                 double *__restrict__ seg_sum /* relaxed plans: sum of a hub-row segment, per block */) {
+                 double *__restrict__ seg_sum /* relaxed plans: sum of a hub-row segment, per block */, int relaxed_rows) {
     __shared__ float tile[kBTileNnz];
     __shared__ double red[kBThreads / 64];
     // runs longer than one wave instruction (a skewed graph: most of a row block's edges come from the few slices that
-    // hold the hubs): the first 64 values are placed by the wave that owns the run, the rest is queued here and placed by
-    // the whole workgroup afterwards -- walking such a run 64 values at a time on ONE wave cost 4 ms per sweep on R-MAT.
-    // A tile holds 16384 values, so at most 255 runs can be longer than 64.
-    __shared__ uint32_t tail_st[256], tail_p0[256], tail_cnt[256];
+    // hold the hubs): the first 64 values are placed by the wave that owns the run, the rest is queued here in pieces of
+    // <= 64 values and placed afterwards by ALL waves, one piece per wave instruction -- not 64 values at a time by the
+    // one wave that owns the slice.  A tile holds 16384 values: at most 256 full pieces plus one partial piece per run
+    // longer than 64 (< 256 of those).
+    __shared__ uint32_t tail_st[512], tail_p0[512], tail_cnt[512];
     __shared__ uint32_t n_tail;
     if (threadIdx.x == 0) n_tail = 0;
     __syncthreads();
@@ -366,20 +367,23 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
                 if (lane < c[u]) tile[q[u]] = v[u];
 #pragma unroll
             for (int u = 0; u < U; u++)
-                if (c[u] > 64 && lane == 0) {
-                    const uint32_t i = atomicAdd(&n_tail, 1u);
-                    tail_st[i] = st[u] + 64;
-                    tail_p0[i] = p0[u] + 64;
-                    tail_cnt[i] = c[u] - 64;
+                if (c[u] > 64) {  // uniform over the wave
+                    const uint32_t rest = c[u] - 64, pieces = (rest + 63) / 64;
+                    uint32_t first = 0;
+                    if (lane == 0) first = atomicAdd(&n_tail, pieces);
+                    first = __builtin_amdgcn_readfirstlane(first);
+                    for (uint32_t pc = lane; pc < pieces; pc += 64) {
+                        tail_st[first + pc] = st[u] + 64 + pc * 64;
+                        tail_p0[first + pc] = p0[u] + 64 + pc * 64;
+                        tail_cnt[first + pc] = min(64u, rest - pc * 64);
+                    }
                 }
         }
     }
     __syncthreads();
     const uint32_t nt = n_tail;
-    for (uint32_t i = 0; i < nt; i++) {
-        const uint32_t ts = tail_st[i], tp = tail_p0[i], tc = tail_cnt[i];
-        for (uint32_t k = threadIdx.x; k < tc; k += kBThreads) tile[pm[tp + k]] = val[ts + k];
-    }
+    for (uint32_t i = wave; i < nt; i += NW)
+        if (lane < tail_cnt[i]) tile[pm[tail_p0[i] + lane]] = val[tail_st[i] + lane];
     }
     __syncthreads();
     if (rb.row1 == rb.row0) {
@@ -402,16 +406,73 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
         return;
     }
     double err = 0.0;
+    // Rows are summed by ONE lane each, in order (the reference's sequential f32 sum).  A long row is a serial chain; its
+    // LDS reads are kept 16 values ahead of the adds (a read waited for in place costs ~100 cycles per add: a 10^4-term
+    // row then holds its whole workgroup for 0.5 ms, which is what made a sweep over an R-MAT graph 4 ms).
+    // Relaxed plans (`relaxed_rows`): rows of >= kWaveRow terms are left out here and summed afterwards by a whole wave
+    // each -- every lane a strided share in f32, the lanes' sums in f64 -- like the hub segments above.
+    constexpr uint32_t kWaveRow = 256;
+    __shared__ uint32_t long_row[64];  // relaxed: local rows handed to the waves (a tile holds <= 64 rows of >= 256 terms)
+    __shared__ uint32_t n_long;
+    if (relaxed_rows) {
+        if (threadIdx.x == 0) n_long = 0;
+        __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < RPL; j++) {
         const uint32_t r = rb.row0 + threadIdx.x + j * kBThreads;
         if (r < rb.row1) {
+            const uint32_t len = rz[j] - ra[j];
+            if (relaxed_rows && len >= kWaveRow) {
+                long_row[atomicAdd(&n_long, 1u)] = threadIdx.x + j * kBThreads;
+                continue;
+            }
             float s = 0.0f;
-            for (uint32_t e = ra[j]; e < rz[j]; e++) s = s + tile[e];
+            uint32_t e = ra[j];
+            if (len >= 32) {
+                float a[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) a[i] = tile[e + i];
+                for (; e + 32 <= rz[j]; e += 16) {
+                    float nx[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) nx[i] = tile[e + 16 + i];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) s = s + a[i];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) a[i] = nx[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) s = s + a[i];
+                e += 16;
+            }
+            for (; e < rz[j]; e++) s = s + tile[e];
             const float nw = base + damping * s;  // two roundings, like the reference (no fma: -ffp-contract=off)
             scores[r] = nw;
             contrib_out[row_begin + r] = nw / (float)od[j];
             err += fabs((double)(nw - old[j]));
+        }
+    }
+    if (relaxed_rows) {
+        __syncthreads();
+        const uint32_t nl = n_long;
+        for (uint32_t i = wave; i < nl; i += NW) {
+            const uint32_t lr = long_row[i];
+            const uint32_t r = rb.row0 + lr;
+            const uint32_t a0 = off[r] - e0, z0 = off[r + 1] - e0;
+            float s = 0.0f;
+            for (uint32_t e = a0 + lane; e < z0; e += 64) s = s + tile[e];
+            double d = (double)s;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o, 64);
+            if (lane == 0) {
+                const float sum = (float)d;
+                const float old_r = scores[r];
+                const float nw = base + damping * sum;
+                scores[r] = nw;
+                contrib_out[row_begin + r] = nw / (float)out_deg[row_begin + r];
+                err += fabs((double)(nw - old_r));
+            }
         }
     }
     const double total = block_sum_f64<kBThreads>(err, red);
@@ -941,12 +1002,12 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
                     hipLaunchKernelGGL(pb_reduce_kernel<true>, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
                                        p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
                                        contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap,
-                                       p->d_segsum);
+                                       p->d_segsum, p->relaxed ? 1 : 0);
                 else
                     hipLaunchKernelGGL(pb_reduce_kernel<false>, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
                                        p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
                                        contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap,
-                                       p->d_segsum);
+                                       p->d_segsum, p->relaxed ? 1 : 0);
         }
         if (p->n_hubs)  // relaxed: the hub rows' segment sums -> scores
             hipLaunchKernelGGL(pr_hub_finish_kernel, dim3((p->n_hubs + 255) / 256), dim3(256), 0, stream, p->d_hubs, p->n_hubs,

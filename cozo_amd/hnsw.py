@@ -186,6 +186,46 @@ class GpuHnswIndex:
                                               ptr(poison), 0, None))
         return (ids, dist, cnt, nd) if with_n_dist else (ids, dist, cnt)
 
+    # ---- filtered search with the comparisons on the device (cz_hnsw_search_filtered) ----
+    def upload_column(self, values: np.ndarray):
+        """one numeric value per node (f64 or i64) -> a device-resident column handle for `predicates`"""
+        v = np.ascontiguousarray(values)
+        if v.shape != (self.n,):
+            raise ValueError("a column holds one value per node of the index")
+        if v.dtype == np.int64:
+            ty = _lib.CZ_COL_I64
+        elif v.dtype == np.float64:
+            ty = _lib.CZ_COL_F64
+        else:
+            raise ValueError("columns are int64 or float64")
+        h = C.c_void_p()
+        check(_lib.lib().cz_column_upload(ptr(v), self.n, ty, C.byref(h)))
+        return DeviceColumn(h, ty)
+
+    def hnsw_knn_batch_filtered(self, queries: np.ndarray, config: HnswSearch, predicates, with_n_dist: bool = False):
+        """hnsw_knn with a filter that is a conjunction of `column OP constant` (predicates = [(DeviceColumn, op, constant)],
+        op in < <= == >= > !=, constant int or float): all ef candidates are filtered on the device, k rows come back
+        (hnsw.rs:943-947, 997-1006)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[1] != self.manifest.vec_dim:
+            raise ValueError("query vector dimension mismatch")
+        B = q.shape[0]
+        arr = (_lib.Predicate * len(predicates))()
+        for i, (col, op, const) in enumerate(predicates):
+            is_int = isinstance(const, (int, np.integer)) and not isinstance(const, bool)
+            arr[i] = _lib.Predicate(col._h, _lib.CZ_OPS[op], _lib.CZ_COL_I64 if is_int else _lib.CZ_COL_F64,
+                                    0.0 if is_int else float(const), int(const) if is_int else 0)
+        ids = np.empty((B, config.k), dtype=np.uint32)
+        dist = np.empty((B, config.k), dtype=np.float64)
+        cnt = np.empty(B, dtype=np.uint32)
+        nd = np.zeros(B, dtype=np.uint64) if with_n_dist else None
+        check(_lib.lib().cz_hnsw_search_filtered(self._h, ptr(q), B, config.k, config.ef, int(config.radius is not None),
+                                                 float(config.radius or 0.0), arr, len(predicates), ptr(ids), ptr(dist),
+                                                 ptr(cnt), ptr(nd), None, 0, None))
+        return (ids, dist, cnt, nd) if with_n_dist else (ids, dist, cnt)
+
     def hnsw_knn(self, q: np.ndarray, config: HnswSearch):
         """One parent tuple: list of (node id, distance) rows, ascending (hnsw.rs:1005-1006)."""
         ids, dist, cnt = self.hnsw_knn_batch(np.asarray(q)[None, :], config)
@@ -214,6 +254,24 @@ class GpuHnswIndex:
     def bruteforce_knn_device(self, queries, k: int, out_ids, out_dist, stream: int = 0, gemm: bool = False):
         check(_lib.lib().cz_knn_bruteforce(self._h, ptr(queries), queries.shape[0], k, ptr(out_ids), ptr(out_dist),
                                            CZ_DEVICE_PTRS | (_lib.CZ_BF_GEMM if gemm else 0), C.c_void_p(stream)))
+
+
+class DeviceColumn:
+    """a per-node numeric column resident in HBM (cz_column)"""
+
+    def __init__(self, handle, ty):
+        self._h, self.type = handle, ty
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().cz_column_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def distance_batch(distance: str, base: np.ndarray, queries: np.ndarray, pairs: np.ndarray) -> np.ndarray:
@@ -259,6 +317,31 @@ class HnswSearchBinding:
     bind_vector: bool = False
     radius: Optional[float] = None
     filter: Optional[callable] = None  # the compiled filter expression over the bound result tuple
+    # the part of the filter that is a conjunction of `base column OP constant` over numeric columns: [(column index of
+    # the base relation, op, constant)].  HnswSearchRA hands it to the device (cz_hnsw_search_filtered) when every value
+    # of those columns is an int / a float and `filter` is None; the reference evaluates the same comparisons as filter
+    # bytecode on the ef candidate rows (hnsw.rs:994-998)
+    predicates: Optional[Sequence[tuple]] = None
+
+
+def _compare(a, op, b) -> bool:
+    """op_lt / op_le / op_eq / op_ge / op_gt / op_neq on two numbers (data/functions.rs:298-380): Int with Int as integers,
+    Float with Float by total order (data/value.rs:595), mixed pairs as f64; anything else is the reference's error"""
+    num = lambda x: isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, bool)
+    if not (num(a) and num(b)):
+        raise TypeError("comparison can only be done between the same datatypes")
+    ai, bi = isinstance(a, (int, np.integer)), isinstance(b, (int, np.integer))
+    if ai and bi:
+        c = (int(a) > int(b)) - (int(a) < int(b))
+    elif not ai and not bi:
+        import struct
+        key = lambda x: (lambda u: u ^ (0x7FFFFFFFFFFFFFFF if u < 0 else 0))(struct.unpack("<q", struct.pack("<d", float(x)))[0])
+        ka, kb = key(a), key(b)
+        c = (ka > kb) - (ka < kb)
+    else:
+        fa, fb = float(a), float(b)
+        return {"<": fa < fb, "<=": fa <= fb, "==": fa == fb, ">=": fa >= fb, ">": fa > fb, "!=": fa != fb}[op]
+    return {"<": c < 0, "<=": c <= 0, "==": c == 0, ">=": c >= 0, ">": c > 0, "!=": c != 0}[op]
 
 
 def index_nodes(base: BaseRelation, vec_fields: Sequence[int]):
@@ -287,6 +370,27 @@ class HnswSearchRA:
     def __init__(self, index, base: BaseRelation, nodes: Sequence[tuple], search: HnswSearchBinding, bind_idx: int):
         self.index, self.base, self.nodes, self.search, self.bind_idx = index, base, list(nodes), search, bind_idx
 
+    def _device_predicates(self, preds):
+        """[(DeviceColumn, op, constant)] for cz_hnsw_search_filtered, or None when a column is not purely Int or purely
+        Float over the indexed rows (Null, strings, a mix: the reference's comparison then depends on the row, or raises)"""
+        cache = self.__dict__.setdefault("_columns", {})
+        out = []
+        for c, op, v in preds:
+            if isinstance(v, bool) or not isinstance(v, (int, float, np.integer, np.floating)) or op not in _lib.CZ_OPS:
+                return None
+            if c not in cache:
+                vals = [self.base.rows[r][c] for r, _, _ in self.nodes]
+                if vals and all(isinstance(x, (int, np.integer)) and not isinstance(x, bool) for x in vals):
+                    cache[c] = self.index.upload_column(np.asarray(vals, dtype=np.int64))
+                elif vals and all(isinstance(x, (float, np.floating)) for x in vals):
+                    cache[c] = self.index.upload_column(np.asarray(vals, dtype=np.float64))
+                else:
+                    cache[c] = None
+            if cache[c] is None:
+                return None
+            out.append((cache[c], op, v))
+        return out if 0 < len(out) <= 4 else None
+
     def iter(self, parent: Sequence[tuple]):
         sb = self.search
         qs = []
@@ -300,10 +404,22 @@ class HnswSearchRA:
         # without a filter the candidates are cut to k before rows are fetched; with one all ef survive until the
         # filter has run (hnsw.rs:943-947)
         # the radius cut (`distance > r => skip`, :952-956) is applied on the device to the rows that come back
-        cfg = HnswSearch(k=sb.k, ef=sb.ef, radius=sb.radius, has_filter=sb.filter is not None)
-        if sb.filter is None:
-            cfg = HnswSearch(k=min(sb.k, sb.ef), ef=sb.ef, radius=sb.radius)
-        ids, dist, cnt = self.index.hnsw_knn_batch(np.stack(qs), cfg)
+        preds = list(sb.predicates or [])
+        host_filter = sb.filter
+        on_device = None
+        if preds and sb.filter is None and hasattr(self.index, "hnsw_knn_batch_filtered"):
+            on_device = self._device_predicates(preds)
+        if preds and on_device is None:  # evaluated on the host rows below, with the reference's comparison semantics
+            inner = sb.filter
+            host_filter = lambda row: all(_compare(row[c], op, v) for c, op, v in preds) and (inner is None or inner(row))
+        if on_device is not None:
+            ids, dist, cnt = self.index.hnsw_knn_batch_filtered(np.stack(qs), HnswSearch(k=sb.k, ef=sb.ef, radius=sb.radius),
+                                                                on_device)
+        else:
+            cfg = HnswSearch(k=sb.k, ef=sb.ef, radius=sb.radius, has_filter=host_filter is not None)
+            if host_filter is None:
+                cfg = HnswSearch(k=min(sb.k, sb.ef), ef=sb.ef, radius=sb.radius)
+            ids, dist, cnt = self.index.hnsw_knn_batch(np.stack(qs), cfg)
         out = []
         for i, t in enumerate(parent):
             rows = []
@@ -323,7 +439,7 @@ class HnswSearchRA:
                     cand.append(d)
                 if sb.bind_vector:
                     cand.append(field_val if s < 0 else field_val[s])
-                if sb.filter is not None and not sb.filter(tuple(cand)):  # :994-998
+                if host_filter is not None and not host_filter(tuple(cand)):  # :994-998
                     continue
                 rows.append(tuple(cand))
             for c in rows[:sb.k]:  # :1005-1006 (rows already ascending by distance)

@@ -41,11 +41,12 @@ extern "C" {
 /* cz_knn_bruteforce: compute the B x N dot products as one dense f32 GEMM on the matrix cores (Cosine / IP only;
  * every dot product is then a k-ordered fmaf chain instead of the search kernel's lane-parallel tree) */
 #define CZ_BF_GEMM 8u
-/* cz_pagerank_plan_create / cz_pagerank_cached: rows longer than one tile of the blocked sweep (hubs, > 16384 in-edges)
- * are cut into segments that are summed in parallel instead of by one lane in the reference's sequential f32 order.
- * Scores then differ from the reference's in the last bits on those rows (well inside north_star's 1e-5 relative on
- * ordinary rows; on a hub the difference is bounded by the rounding error of the reference's own 10^5-term f32 sum);
- * every other row stays bit-identical.  Default (flag absent): every row bit-identical. */
+/* cz_pagerank_plan_create / cz_pagerank_cached: long rows of the blocked sweep are summed in parallel instead of by one
+ * lane in the reference's sequential f32 order -- rows of >= 256 in-edges by a wave, rows longer than one tile (hubs,
+ * > 16384 in-edges) as segments by whole workgroups.  After ONE sweep only those rows differ from the reference, in the
+ * last bits; over the iterations the difference spreads and stays at the level of the rounding error of the reference's
+ * own long f32 sums (~1e-5 relative on R-MAT at 10M / 100M; north_star's bar is 1e-5).  On a skewed graph a sweep is
+ * then bounded by bandwidth instead of by the longest serial chain.  Default (flag absent): every row bit-identical. */
 #define CZ_PR_RELAXED 16u
 
 typedef enum {
@@ -133,6 +134,34 @@ int cz_hnsw_index_export_vectors(const cz_hnsw_index *ix, float *out /* [n][dim]
 int cz_hnsw_search_batch(cz_hnsw_index *ix, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
                          int has_radius, double radius, uint32_t *out_ids, double *out_dist, uint32_t *out_count,
                          uint64_t *out_n_dist, const volatile uint8_t *poison, uint32_t flags, void *stream);
+
+/* Filtered search with the filter on the device.  The reference keeps all ef candidates when a
+ * filter is present, walks them in ascending distance -- radius cut, fetch the row, bind columns, filter bytecode -- and
+ * truncates to k afterwards (runtime/hnsw.rs:943-947, 951-1006).  When the filter is a conjunction of comparisons of a
+ * numeric column of the candidate's row with a constant, the shim uploads those columns once per index (one value per
+ * node: cz_column_upload) and hands the comparisons over: the kernel's output stage evaluates them on the ef candidates
+ * and only k rows per query leave the device instead of ef.  Comparison semantics are op_lt / op_le / op_eq / op_ge /
+ * op_gt / op_neq of data/functions.rs:298-380: Int with Int as integers, Float with Float by total order, mixed as f64.
+ * Anything else (Null / non-numeric values, other expressions) stays with the host path (k = ef, filter in Rust). */
+typedef struct cz_column cz_column;
+typedef enum { CZ_COL_F64 = 0, CZ_COL_I64 = 1 } cz_col_type;
+typedef enum { CZ_OP_LT = 0, CZ_OP_LE = 1, CZ_OP_EQ = 2, CZ_OP_GE = 3, CZ_OP_GT = 4, CZ_OP_NE = 5 } cz_cmp_op;
+typedef struct {
+    const cz_column *column; /* [n nodes of the index] */
+    int32_t op;              /* cz_cmp_op: column[node] OP constant */
+    int32_t const_type;      /* cz_col_type of the constant */
+    double f64_value;
+    int64_t i64_value;
+} cz_predicate;
+/* values: f64 [n] or i64 [n] (host), one per node of the index the column will be used with */
+int cz_column_upload(const void *values, uint32_t n, int32_t type, cz_column **out);
+void cz_column_destroy(cz_column *c);
+/* cz_hnsw_search_batch with 1..4 predicates (AND): out_ids / out_dist [B][k], the first k of the ef candidates that pass
+ * the radius cut and every predicate, ascending distance; out_count [B]. */
+int cz_hnsw_search_filtered(cz_hnsw_index *ix, const float *queries, uint32_t B, uint32_t k, uint32_t ef, int has_radius,
+                            double radius, const cz_predicate *preds, uint32_t n_preds, uint32_t *out_ids, double *out_dist,
+                            uint32_t *out_count, uint64_t *out_n_dist, const volatile uint8_t *poison, uint32_t flags,
+                            void *stream);
 
 /* VectorCache::dist (runtime/hnsw.rs:66-109) == op_l2_dist / op_cos_dist / op_ip_dist
  * (data/functions.rs:2185-2255) over P (query, node) pairs:

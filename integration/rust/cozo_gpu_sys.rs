@@ -35,6 +35,30 @@ pub struct cz_pagerank_plan {
 }
 
 #[repr(C)]
+pub struct cz_column {
+    _private: [u8; 0],
+}
+
+pub const CZ_COL_F64: c_int = 0;
+pub const CZ_COL_I64: c_int = 1;
+pub const CZ_OP_LT: c_int = 0;
+pub const CZ_OP_LE: c_int = 1;
+pub const CZ_OP_EQ: c_int = 2;
+pub const CZ_OP_GE: c_int = 3;
+pub const CZ_OP_GT: c_int = 4;
+pub const CZ_OP_NE: c_int = 5;
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct cz_predicate {
+    pub column: *const cz_column,
+    pub op: i32,
+    pub const_type: i32,
+    pub f64_value: c_double,
+    pub i64_value: i64,
+}
+
+#[repr(C)]
 pub struct cz_comm {
     _private: [u8; 0],
 }
@@ -112,6 +136,12 @@ extern "C" {
     pub fn cz_pagerank_plan_is_blocked(p: *const cz_pagerank_plan) -> c_int;
     pub fn cz_pagerank_plan_read_scores(p: *mut cz_pagerank_plan, out: *mut c_float, flags: u32, stream: *mut c_void) -> c_int;
 
+    pub fn cz_column_upload(values: *const c_void, n: u32, ty: i32, out: *mut *mut cz_column) -> c_int;
+    pub fn cz_column_destroy(c: *mut cz_column);
+    pub fn cz_hnsw_search_filtered(ix: *mut cz_hnsw_index, queries: *const c_float, b: u32, k: u32, ef: u32, has_radius: c_int,
+                                   radius: c_double, preds: *const cz_predicate, n_preds: u32, out_ids: *mut u32,
+                                   out_dist: *mut c_double, out_count: *mut u32, out_n_dist: *mut u64, poison: *const u8,
+                                   flags: u32, stream: *mut c_void) -> c_int;
     pub fn cz_pagerank_plan_nodes(p: *const cz_pagerank_plan) -> u32;
 
     // multi-GPU, one node (RCCL over xGMI)

@@ -326,11 +326,11 @@ def test_pagerank_relaxed_hub_rows(oracle, gpu_lib):
     assert it1 == it0 == oit
     err = np.abs(rel.astype(np.float64) - os_) / np.abs(os_)
     assert err.max() <= 1e-5, err.max()
-    # one sweep from identical inputs: only the hub rows may differ at all
+    # one sweep from identical inputs: only rows long enough to be summed in parallel (>= 256 terms) may differ at all
     one_e, _, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 1, mode="blocked")
     one_r, _, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 1, mode="blocked", relaxed=True)
     diff = np.flatnonzero(one_e != one_r)
-    assert set(diff.tolist()) <= set(np.flatnonzero(indeg > 16384).tolist())
+    assert set(diff.tolist()) <= set(np.flatnonzero(indeg >= 256).tolist())
 
 
 def test_pagerank_plan_cache(graphs, oracle):

@@ -26,12 +26,20 @@ def test_distance_batch_matches_oracle(gpu_lib, oracle, dim, name, metric):
     exact = oracle.distance_pairs(metric, base, q, pairs, oracle.DOT_GPU)
     ref = oracle.distance_pairs(metric, base, q, pairs, oracle.DOT_NDARRAY)
     assert np.array_equal(got, exact), "kernel summation tree differs from its CPU restatement"
-    # 1e-5 relative to the magnitude the f32 accumulation works at: `1 - x` cancels, and two summation orders of
-    # an f32 dot cannot agree tighter than eps * sum|a_i b_i| (Cosine: the normalised dot, i.e. 1)
+    # north_star's bar: 1e-5 RELATIVE to the reference's value (ndarray summation order), asserted as such wherever the
+    # value is not the difference of much larger terms.  `1 - x` (Cosine, IP) and L2 of nearly equal vectors cancel: two
+    # f32 summation orders of the same dot cannot agree tighter than eps * sum|a_i b_i| in ABSOLUTE terms, whatever is
+    # subtracted afterwards -- there (|ref| below 5 % of the magnitude the f32 sums work at) the bound is 1e-5 of that
+    # magnitude instead.  Both bounds are stated here, neither folds into the other; bench.py reports the measured
+    # true-relative error of the search's distances (`parity.max_rel_err_vs_reference_arithmetic`, ~1e-6).
     a64, b64 = q[pairs[:, 0]].astype(np.float64), base[pairs[:, 1]].astype(np.float64)
-    mag = {0: np.abs(ref), 1: np.ones(len(ref)), 2: 1.0 + np.sum(np.abs(a64 * b64), axis=1)}[metric]
-    scale = np.maximum(np.abs(ref), mag)
-    assert np.max(np.abs(got - ref) / np.maximum(scale, 1e-30)) <= RTOL
+    mag = {0: np.sum((a64 - b64) ** 2, axis=1), 1: np.ones(len(ref)), 2: 1.0 + np.sum(np.abs(a64 * b64), axis=1)}[metric]
+    finite = np.isfinite(ref)
+    true_rel = np.abs(got - ref)[finite] / np.maximum(np.abs(ref[finite]), 1e-300)
+    well = np.abs(ref[finite]) >= 0.05 * mag[finite]
+    if well.any():
+        assert true_rel[well].max() <= RTOL, true_rel[well].max()
+    assert np.max(np.abs(got - ref)[finite] / np.maximum(mag[finite], 1e-300)) <= RTOL
 
 
 @pytest.mark.parametrize("dim,nq", [(33, 17), (128, 4000), (768, 60), (1000, 300), (2052, 9)])
@@ -106,9 +114,15 @@ def test_knn_within_tolerance_of_reference_order(case, oracle, ef, k):
     oids, odist, ocnt, _ = case["flat"].knn_batch(case["q"], k, ef, dot_mode=oracle.DOT_NDARRAY)
     assert np.array_equal(cnt, ocnt)
     same = (ids == oids).all(axis=1)
-    assert same.mean() >= 0.95  # near-ties may swap under a different f32 summation order
-    scale = np.maximum(np.abs(odist[same]), 1e-3)
-    assert np.max(np.abs(dist[same] - odist[same]) / scale) <= RTOL
+    assert same.mean() >= 0.95  # near-ties may swap under a different f32 summation order (then the ROWS differ, not the bar)
+    # true relative error on every row both orders return (distances below 1e-3 -- a query next to a stored copy of
+    # itself -- are pure cancellation: absolute 1e-8 there)
+    g, o = dist[same], odist[same]
+    big = np.abs(o) >= 1e-3
+    if big.any():
+        assert np.max(np.abs(g[big] - o[big]) / np.abs(o[big])) <= RTOL
+    if (~big).any():
+        assert np.max(np.abs(g[~big] - o[~big])) <= 1e-8
 
 
 @pytest.mark.parametrize("name,metric", [("Cosine", 1), ("IP", 2)])
@@ -271,3 +285,51 @@ def test_index_upload_rejects_links_to_missing_nodes(gpu_lib):
     nb1[1, 0] = 2
     with pytest.raises(_lib.CozoGpuError):
         GpuHnswIndex(man, x, [None, nodes1], [nb0, nb1], 1)
+
+
+def test_filtered_search_predicates_on_the_device(case, oracle):
+    """cz_hnsw_search_filtered: the kernel's output stage evaluates `column OP constant` terms on ALL ef candidates and
+    returns the first k survivors -- the reference's order of operations (hnsw.rs:943-947 keep ef, :951-1006 radius cut,
+    filter, truncate to k).  Checked against the oracle's ef candidates filtered on the host with the reference's
+    comparison semantics (Int/Int, Float/Float by total order incl. -0.0 and NaN, mixed as f64)."""
+    from cozo_amd.hnsw import HnswSearch, _compare
+    gix, flat, q = case["gix"], case["flat"], case["q"]
+    n = flat.n
+    rng = np.random.default_rng(99)
+    col_i = rng.integers(-50, 50, n).astype(np.int64)
+    col_f = rng.standard_normal(n)
+    col_f[::97] = -0.0
+    col_f[5::131] = np.nan
+    ci, cf = gix.upload_column(col_i), gix.upload_column(col_f)
+    ef, k = 80, 7
+    oids, odist, ocnt, ond = flat.knn_batch(q, ef, ef, dot_mode=oracle.DOT_GPU)
+    d_med = float(np.median(odist[:, ef // 2]))
+    cases = [
+        ([(ci, ">=", 10)], None),
+        ([(ci, "<", 0), (cf, ">", -0.25)], None),
+        ([(cf, "<", 0.0)], None),          # Float vs Float: total order, -0.0 < 0.0 holds
+        ([(cf, "==", float("nan"))], None),  # ... and NaN == NaN
+        ([(ci, "!=", 3.0), (cf, "<=", 1)], d_med),  # mixed pairs compare as f64; with a radius
+        ([(ci, ">", 1000)], None),          # nothing passes
+    ]
+    cols = {id(ci): col_i, id(cf): col_f}
+    for preds, radius in cases:
+        ids, dist, cnt, nd = gix.hnsw_knn_batch_filtered(q, HnswSearch(k=k, ef=ef, radius=radius), preds, with_n_dist=True)
+        assert int(nd.sum()) == ond
+        for b in range(q.shape[0]):
+            keep = []
+            for j in range(int(ocnt[b])):
+                node, d = int(oids[b, j]), float(odist[b, j])
+                if radius is not None and d > radius:
+                    continue
+                vals = [(cols[id(c)][node], op, v) for c, op, v in preds]
+                if all(_compare(int(x) if isinstance(x, np.integer) else float(x), op, v) for x, op, v in vals):
+                    keep.append((node, d))
+                if len(keep) == k:
+                    break
+            assert cnt[b] == len(keep)
+            assert ids[b, :len(keep)].tolist() == [a for a, _ in keep]
+            assert dist[b, :len(keep)].tolist() == [d for _, d in keep]
+            assert (ids[b, len(keep):] == 0xFFFFFFFF).all()
+    ci.close()
+    cf.close()
