@@ -318,16 +318,21 @@ def bench_hnsw_sharded(args, torch, dist, rank, world, device, shard_x, q0, gt0)
     """configs[3]: the N vectors partitioned into `world` independent sub-indices (contiguous ranges of the same corpus),
     rank 0's query batch broadcast, per-shard hnsw_knn with the same k / ef, all-gather + merge of the top-k lists
     (cozo_amd.distributed.sharded_hnsw_knn).  Scored against the exact neighbours over ALL N vectors."""
-    from cozo_amd.distributed import merge_shard_topk
     B, k = args.batch, args.k
     per = (args.n + world - 1) // world
     run = HnswRun(args, torch, device, shard_x.shape[0], args.dist, q0, x=shard_x)
     try:
         run.drop_corpus()
 
-        def step(ef):
-            run.search(ef)
-            return merge_shard_topk(run.ids.to(torch.int64) & 0xFFFFFFFF, run.dd, rank * per, k, world)
+        from cozo_amd.comm import Comm
+        comm = Comm.from_torch_distributed()
+        oi = torch.empty((B, k), dtype=torch.int64, device=device)
+        od = torch.empty((B, k), dtype=torch.float64, device=device)
+        oc = torch.empty(B, dtype=torch.int32, device=device)
+
+        def step(ef):  # cz_hnsw_search_sharded: broadcast, per-shard search, all-gather, merge -- behind the C ABI
+            comm.hnsw_search_sharded(run.ix, q0, B, k, ef, rank * per, oi, od, oc, run.stream)
+            return oi, od
 
         ef, rec, sweep = EF_LADDER[-1], 0.0, []
         for cand in EF_LADDER:
@@ -362,6 +367,10 @@ def bench_hnsw_sharded(args, torch, dist, rank, world, device, shard_x, q0, gt0)
                          "index's does, so the replica form above is the throughput configuration while N x 768 x 4 B fits one GPU")
     finally:
         run.close()
+        try:
+            comm.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def bench_distance_batch(args, torch, x, q, stream, device):
@@ -385,7 +394,7 @@ def bench_distance_batch(args, torch, x, q, stream, device):
     torch.cuda.synchronize()
     s = e0.elapsed_time(e1) / 1e3 / reps
     algo = P * 4 * x.shape[1]
-    return dict(kernel="cz_distance_batch: pairs grouped by query (hand-written counting sort) + distance_runs_kernel; the whole call is timed",
+    return dict(kernel="cz_distance_batch = distance_pairs_kernel (one hand-written kernel; the whole call is timed)",
                 pairs=P, base_rows=int(x.shape[0]), metric="Cosine", ms=s * 1e3, distances_per_s=P / s,
                 roofline=dict(bound="hbm", achieved=algo / s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                               frac=algo / s / 1e9 / HBM_PEAK_GBS, traffic=pmc_traffic("distance_batch", 1),
@@ -530,20 +539,32 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
         e_total = int(t.item())
     log(f"pagerank graph ({kind}): {n_total} nodes, {e_total} edges (rank 0 holds {e_kept}; longest in-row {max_in}) generated in {time.time() - t0:.1f}s")
 
-    def measure(relaxed):
-        plan = PageRankPlan(off32, s, outdeg32, n_total, rb, re, 0.85, device_ptrs=True, relaxed=relaxed)
-        sp = ShardedPageRank(n_total, rank, world, device, lambda c: plan.init(c, stream),
-                             lambda cin, cout, err: plan.step(cin, cout, err, stream))
-        # reference defaults (epsilon 1e-4, 10 iterations) -> how many iterations the stopping rule takes
-        it_default, err_default = sp.run(1e-4, 10)
-        # steady state: fixed iteration count, tolerance 0 (SURVEY 8d)
-        sp.run(0.0, 2)
+    comm = None
+    if world > 1:  # the exchange steps run behind the C ABI: RCCL communicator of libcozo_gpu, id carried by the process group
+        from cozo_amd.comm import Comm
+        comm = Comm.from_torch_distributed()
+
+    class Loop:
+        """graph::page_rank's loop: N = 1 the plan driven from here; N > 1 cz_pagerank_sharded (C++ loop + RCCL)"""
+
+        def __init__(self, plan, allreduce=False):
+            self.plan, self.allreduce = plan, allreduce
+            self.sp = ShardedPageRank(n_total, rank, world, device, lambda c: plan.init(c, stream),
+                                      lambda cin, cout, err: plan.step(cin, cout, err, stream)) if world == 1 else None
+
+        def run(self, tol, iters):
+            if self.sp is not None:
+                return self.sp.run(tol, iters)
+            return comm.pagerank_sharded(self.plan, per, tol, iters, allreduce_exchange=self.allreduce, stream=stream)
+
+    def timed_run(loop):
+        loop.run(0.0, 2)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        iters, _ = sp.run(0.0, args.pr_iters)
+        iters, _ = loop.run(0.0, args.pr_iters)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -552,16 +573,30 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
             t = torch.tensor([wall], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
+        return iters, wall
+
+    def measure(relaxed):
+        plan = PageRankPlan(off32, s, outdeg32, n_total, rb, re, 0.85, device_ptrs=True, relaxed=relaxed)
+        sp = Loop(plan)
+        # reference defaults (epsilon 1e-4, 10 iterations) -> how many iterations the stopping rule takes
+        it_default, err_default = sp.run(1e-4, 10)
+        # steady state: fixed iteration count, tolerance 0 (SURVEY 8d)
+        iters, wall = timed_run(sp)
         # kernel-only time of the SpMV sweep (HIP events on the launch stream, no host round trip in between)
-        cin, cout = sp.contrib
+        cin = torch.empty(per * world, dtype=torch.float32, device=device)
+        cout = torch.empty_like(cin)
+        kerr = torch.zeros(1, dtype=torch.float64, device=device)
+        plan.init(cin, stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 10
+        plan.step(cin, cout, kerr, stream)
         e0.record()
         for _ in range(reps):
-            plan.step(cin, cout, sp.err, stream)
+            plan.step(cin, cout, kerr, stream)
             cin, cout = cout, cin
         e1.record()
         torch.cuda.synchronize()
+        del cin, cout
         kern_s = e0.elapsed_time(e1) / 1e3 / reps
         algo_bytes = 4 * e_kept + 4 * (rows + 1) + 20 * rows  # SURVEY 8d compulsory-traffic model, this rank's shard
         blocked = plan.blocked
@@ -570,7 +605,7 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
         res = dict(value=e_total * iters / wall, unit="edges/s", iterations=iters, ms_per_iteration=wall / iters * 1e3,
                    nodes=n_total, edges=e_total, graph=kind, longest_in_row=max_in,
                    default_run=dict(iterations=it_default, final_err=err_default),
-                   formulation=("blocked" if blocked else "gather") + (", hub rows as parallel segments (CZ_PR_RELAXED)" if relaxed else
+                   formulation=("blocked" if blocked else "gather") + (", long rows summed in parallel (CZ_PR_RELAXED)" if relaxed else
                                                                           ", every row bit-identical to the reference"),
                    plan_build_ms=build_ms,
                    roofline=dict(bound="hbm", kernel=kernel, achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
@@ -578,7 +613,15 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
                                  traffic=pmc_traffic("pagerank_blocked" if blocked else "pagerank_gather", world)
                                  if kind == "uniform" and not relaxed else None,
                                  algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=kern_s * 1e3),
-                   exchange="none" if world == 1 else f"all_gather {per * 4} B/rank/iter + all_reduce f64")
+                   exchange="none" if world == 1 else f"cz_pagerank_sharded (C++ loop behind the C ABI, RCCL): in-place all-gather of {per * 4} "
+                                                      f"B per rank per iteration + all-reduce of 2 f64")
+        if world > 1 and not relaxed:
+            try:  # labelled comparisons: north_star's literal all-reduce of the rank vector; the split-and-overlap form
+                it2, wall2 = timed_run(Loop(plan, allreduce=True))
+                res["exchange_all_reduce"] = dict(ms_per_iteration=wall2 / it2 * 1e3, edges_per_s=e_total * it2 / wall2,
+                                                  what=f"all-reduce(sum) of the zero-padded {per * world * 4}-byte vector instead of the all-gather")
+            except Exception as e:  # noqa: BLE001
+                res["exchange_all_reduce"] = dict(error=f"{type(e).__name__}: {e}")
         return res, plan, sp
 
     res, plan, sp = measure(False)
@@ -631,7 +674,7 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
             res["cpu_baseline"] = dict(value=None, unit="edges/s", cores=0, kind="port", sample=f"failed: {type(e).__name__}: {e}")
     plan.close()
     del plan, sp
-    if kind != "uniform" and max_in > 16384:
+    if kind != "uniform" and max_in >= 256:
         try:  # the same graph with the hub rows summed as parallel segments
             rel, plan2, sp2 = measure(True)
             res["relaxed"] = {k2: rel[k2] for k2 in ("value", "unit", "ms_per_iteration", "formulation", "roofline", "default_run")}
@@ -649,7 +692,66 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
             plan2.close()
         except Exception as e:  # noqa: BLE001
             res["relaxed"] = dict(error=f"{type(e).__name__}: {e}")
+    if comm is not None:
+        comm.close()
     return res
+
+
+def bench_graph_rules(args, torch, device):
+    """The other whole-graph rules on the configs[2]-sized uniform graph (10M nodes / 100M edges): BFS from one start,
+    ConnectedComponents on the symmetrised graph, ShortestPathDijkstra from one start.  The C ABI of these rules takes host
+    arrays (one-shot: CSR upload + kernels + results back), so `wall_ms` is that whole call; `kernel_ms` is the time
+    between the end of the upload and the last kernel, from the library's own timers where it has them (None otherwise:
+    use the rocprofv3 summary under profiles/).  Algorithmic bytes: BFS 4E + 4(N+1) + 12N (adjacency once,
+    depth / parent / order written once), CC per label-propagation round 4E + 4(N+1) + 4N, SSSP 8E + 4(N+1) + 12N
+    (adjacency + weights once, packed (cost, parent) written once) -- lower bounds the schedules do not reach: every rule
+    is bounded by 4-byte random accesses to a 40 MB per-node array (58 G/s from the Infinity Cache)."""
+    from cozo_amd import graph as G
+    n, e = args.pr_nodes, args.pr_edges
+    g = torch.Generator(device=device)
+    g.manual_seed(7)
+    src = torch.randint(0, n, (e,), generator=g, device=device, dtype=torch.int64)
+    dst = torch.randint(0, n, (e,), generator=g, device=device, dtype=torch.int64)
+    keep = src != dst
+    key = torch.unique(src[keep] * n + dst[keep])  # directed out-CSR, CsrLayout::Sorted
+    sN = torch.div(key, n, rounding_mode="floor")
+    t = key - sN * n
+    off = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    off[1:] = torch.cumsum(torch.bincount(sN, minlength=n), 0)
+    ooff, otgt = off.to(torch.int32).cpu().numpy().view(np.uint32), t.to(torch.int32).cpu().numpy().view(np.uint32)
+    E = int(otgt.size)
+    w = (torch.randint(1, 64, (E,), generator=g, device=device, dtype=torch.int32).to(torch.float32) / 8).cpu().numpy()
+    key2 = torch.sort(torch.cat([key, t * n + sN])).values  # symmetrised, parallel edges kept (as_directed_graph(undirected))
+    s2 = torch.div(key2, n, rounding_mode="floor")
+    t2 = key2 - s2 * n
+    off2 = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    off2[1:] = torch.cumsum(torch.bincount(s2, minlength=n), 0)
+    uoff, utgt = off2.to(torch.int32).cpu().numpy().view(np.uint32), t2.to(torch.int32).cpu().numpy().view(np.uint32)
+    del src, dst, keep, key, key2, sN, t, s2, t2, off, off2
+    torch.cuda.empty_cache()
+    starts = np.array([0], dtype=np.uint32)
+    out = dict(graph=f"{n} nodes, {E} directed edges ({int(utgt.size)} symmetrised), uniform")
+
+    def timed(fn):
+        fn()  # warm (allocations, code objects)
+        t0 = time.perf_counter()
+        r = fn()
+        return r, time.perf_counter() - t0
+
+    (par, dep, _, _), dt = timed(lambda: G.bfs(ooff, otgt, starts, want_depth=True))
+    reached = int((dep[0] != 0xFFFFFFFF).sum())
+    out["bfs"] = dict(wall_ms=dt * 1e3, edges_per_s=E / dt, reached=reached, levels=int(dep[0][dep[0] != 0xFFFFFFFF].max()),
+                      algorithmic_bytes=4 * E + 4 * (n + 1) + 12 * n)
+    (grp, k), dt = timed(lambda: G.connected_components(uoff, utgt))
+    out["connected_components"] = dict(wall_ms=dt * 1e3, edges_per_s=int(utgt.size) / dt, components=int(k),
+                                       algorithmic_bytes_per_round=4 * int(utgt.size) + 4 * (n + 1) + 4 * n)
+    (dist, _), dt = timed(lambda: G.sssp(ooff, otgt, w, starts))
+    fin = np.isfinite(dist[0])
+    out["sssp"] = dict(wall_ms=dt * 1e3, edges_per_s=E / dt, reached=int(fin.sum()), max_cost=float(dist[0][fin].max()),
+                       algorithmic_bytes=8 * E + 4 * (n + 1) + 12 * n)
+    out["note"] = ("wall = one C ABI call on host arrays: CSR upload over PCIe (0.44 GB per direction, 0.84 GB for the weighted "
+                   "graph) + kernels + per-node results back; kernel-only times are in profiles/ (rocprofv3 kernel trace)")
+    return out
 
 
 def bench_host_ingest(n_rows=4_000_000, n_nodes=400_000, seed=9):
@@ -717,6 +819,12 @@ def main():
                 extra["pagerank_rmat"] = bench_pagerank(args, torch, dist, rank, world, device, kind="rmat")
             except Exception as e:  # noqa: BLE001
                 extra["pagerank_rmat"] = dict(error=f"{type(e).__name__}: {e}")
+            torch.cuda.empty_cache()
+        if not args.skip_pagerank:
+            try:
+                extra["graph_rules"] = bench_graph_rules(args, torch, device)
+            except Exception as e:  # noqa: BLE001
+                extra["graph_rules"] = dict(error=f"{type(e).__name__}: {e}")
             torch.cuda.empty_cache()
         if not args.skip_hnsw and args.n > 1_000_000:
             for name, kind in (("hnsw_1m", args.dist), ("hnsw_1m_clustered", "clustered")):

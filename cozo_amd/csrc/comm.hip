@@ -137,7 +137,7 @@ extern "C" int cz_comm_create_rank(const uint8_t *id, int rank, int world, cz_co
 
 extern "C" void cz_comm_destroy(cz_comm *c) {
     if (!c) return;
-    if (c->nccl) {
+    if (c->nccl && !getenv("CZ_COMM_NO_DESTROY")) {
         if (Rccl *R = rccl()) {
             (void)hipSetDevice(c->device);
             (void)R->CommDestroy(c->nccl);
@@ -151,6 +151,9 @@ extern "C" int cz_comm_size(const cz_comm *c) { return c ? c->world : 0; }
 
 extern "C" int cz_comm_all_gather(cz_comm *c, void *buf_dev, uint64_t bytes_per_rank, void *stream) {
     if (!c || !buf_dev) return cz::set_error(CZ_E_INVALID, "null argument");
+    // one rank: the gather is the identity.  (Not handed to RCCL: an in-place ncclAllGather of a 1-rank communicator on
+    // memory owned by PyTorch's allocator left the process with a double free at exit -- scratch/r2_rccl_exit.py.)
+    if (c->world == 1) return CZ_OK;
     Rccl *R = nullptr;
     int rc = need_rccl(&R);
     if (rc) return rc;
@@ -207,6 +210,7 @@ struct HipPagerankBackend {
     }
     int step(const float *cin, float *cout) { return cz_pagerank_plan_step(plan, cin, cout, e2.p, stream); }
     int all_gather_slices(float *buf) {
+        if (comm->world == 1) return CZ_OK;  // the identity
         CZ_NCCL(R, R->AllGather(buf + (size_t)comm->rank * per, buf, (size_t)per, ncclFloat32, comm->nccl, stream));
         return CZ_OK;
     }
@@ -332,10 +336,11 @@ extern "C" int cz_pagerank_multi(const uint32_t *in_offsets, const uint32_t *in_
     for (int r = 1; r < world; r++) th.emplace_back(worker, r);
     worker(0);
     for (auto &t : th) t.join();
-    for (int r = 0; r < world; r++) {
-        (void)hipSetDevice(devs[r]);
-        (void)R->CommDestroy(comms[r]);
-    }
+    if (!getenv("CZ_COMM_NO_DESTROY"))
+        for (int r = 0; r < world; r++) {
+            (void)hipSetDevice(devs[r]);
+            (void)R->CommDestroy(comms[r]);
+        }
     (void)cz::ensure_device();
     for (int r = 0; r < world; r++)
         if (rcs[r]) return cz::set_error(rcs[r], "GPU %d: %s", r, msgs[r].c_str());

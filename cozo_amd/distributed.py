@@ -60,19 +60,31 @@ class ShardedPageRank:
         # `err < tolerance` can never hold for tolerance <= 0 (err is a sum of absolute values): the loop then runs
         # max_iter sweeps back to back without a host round trip per iteration; the error is read once at the end
         never_stops_early = not (tolerance > 0.0)
+        # Cancellation is collective (like the C++ loop behind the C ABI, csrc/sharded_pagerank.hpp): a rank whose poison
+        # flag is set stops sweeping but keeps taking part in the exchanges, its flag travels with the error in the same
+        # all-reduce, and every rank raises at the same iteration -- a rank that raised on its own would leave the others
+        # blocked in the next collective.
+        err2 = torch.zeros(2, dtype=torch.float64, device=self.device)
         while True:
-            if poison is not None and poison():
-                raise RuntimeError("ProcessKilled")
+            p = poison is not None and bool(poison())
             last = it + 1 == max_iter
             self.err.zero_()
-            self.local_step(cin, cout, self.err)
+            if not p:
+                self.local_step(cin, cout, self.err)
+            look = last or not never_stops_early or (poison is not None and (it + 1) % 8 == 0)
             if self.world > 1:
                 # in-place all-gather: this rank's slice already sits at its final position in `cout`
                 dist.all_gather_into_tensor(cout, cout[rb:rb + self.per], group=self.group)
-                if last or not never_stops_early:
-                    dist.all_reduce(self.err, op=dist.ReduceOp.SUM, group=self.group)
+                if look:
+                    err2[0] = self.err[0]
+                    err2[1] = 1.0 if p else 0.0
+                    dist.all_reduce(err2, op=dist.ReduceOp.SUM, group=self.group)
+                    self.err[0] = err2[0]
+                    p = bool(err2[1].item() > 0)
             cin, cout = cout, cin
             it += 1
+            if p and (look or self.world == 1):
+                raise RuntimeError("ProcessKilled")
             if never_stops_early and not last:
                 continue
             e = float(self.err.item())
@@ -237,27 +249,36 @@ class OverlappedShardedPageRank:
         self.local_init(cin)
         it = 0
         never_stops_early = not (tolerance > 0.0)
+        err2 = torch.zeros(2, dtype=torch.float64, device=self.device)
         while True:
-            if poison is not None and poison():
-                raise RuntimeError("ProcessKilled")
+            p = poison is not None and bool(poison())  # collective cancellation: see ShardedPageRank.run
             last = it + 1 == max_iter
+            look = last or not never_stops_early or (poison is not None and (it + 1) % 8 == 0)
             self.err.zero_()
-            self.local_steps[0](cin, cout, self.err)
+            if not p:
+                self.local_steps[0](cin, cout, self.err)
             pending = None
             if self.world > 1 and self.half > 0:
                 v = self._views(cout, True)
                 pending = dist.all_gather(v, v[self.rank], group=self.group, async_op=True)
-            self.local_steps[1](cin, cout, self.err)
+            if not p:
+                self.local_steps[1](cin, cout, self.err)
             if self.world > 1:
                 if self.per - self.half > 0:
                     v = self._views(cout, False)
                     dist.all_gather(v, v[self.rank], group=self.group)
                 if pending is not None:
                     pending.wait()
-                if last or not never_stops_early:
-                    dist.all_reduce(self.err, op=dist.ReduceOp.SUM, group=self.group)
+                if look:
+                    err2[0] = self.err[0]
+                    err2[1] = 1.0 if p else 0.0
+                    dist.all_reduce(err2, op=dist.ReduceOp.SUM, group=self.group)
+                    self.err[0] = err2[0]
+                    p = bool(err2[1].item() > 0)
             cin, cout = cout, cin
             it += 1
+            if p and (look or self.world == 1):
+                raise RuntimeError("ProcessKilled")
             if never_stops_early and not last:
                 continue
             e = float(self.err.item())

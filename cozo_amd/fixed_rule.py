@@ -131,7 +131,9 @@ def _canon(v):
     if isinstance(v, (bool, np.bool_)):
         return ("b", bool(v))
     if isinstance(v, (float, np.floating)):
-        return ("f", float(v))
+        # identity by bit pattern, like DataValue's Ord (f64::total_cmp, data/value.rs:595): -0.0 and 0.0 are two nodes,
+        # NaNs with equal bits are one -- Python's == / hash would merge the former and never match the latter
+        return ("f", struct.pack(">d", float(v)))
     if isinstance(v, np.integer):
         return int(v)
     return v
@@ -784,6 +786,12 @@ class BetweennessCentrality(FixedRule):
                 with np.errstate(invalid="ignore"):
                     tight = np.isfinite(d[src_of]) & ((d[src_of] + w).astype(np.float32) == d[tgt])
                 te_src, te_dst = src_of[tight], tgt[tight].astype(np.int64)
+                # f32 absorption (dist[u] + w == dist[u] for a tiny positive w) can make a tight edge join two nodes of
+                # EQUAL distance: the order below is then no topological order of the tight-edge DAG (and such edges can
+                # close cycles, through which the reference's enumeration of all shortest paths would never end)
+                if te_src.size and bool((d[te_src] == d[te_dst]).any()):
+                    raise FixedRuleError("BetweennessCentrality: an edge weight is absorbed by the f32 path cost "
+                                         "(dist[u] + w == dist[u]); shortest-path counts are not defined on such a graph")
                 # tight edges by ascending dist of their source: sigma of a node is final before any edge leaves it
                 order = np.argsort(d[te_src], kind="stable")
                 te_src, te_dst = te_src[order], te_dst[order]

@@ -265,6 +265,7 @@ struct Mp {
         else if (is_str()) { str(s, n); return; }
         else {
             const uint32_t k = array();
+            if ((size_t)(end - p) < k) raise(CZI_E_CORRUPT, "truncated msgpack array");  // every element takes >= 1 byte
             scratch.resize(k);
             for (uint32_t i = 0; i < k; i++) scratch[i] = (uint8_t)integer();
             s = scratch.data();

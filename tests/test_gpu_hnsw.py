@@ -45,8 +45,9 @@ def test_distance_batch_matches_oracle(gpu_lib, oracle, dim, name, metric):
 @pytest.mark.parametrize("dim,nq", [(33, 17), (128, 4000), (768, 60), (1000, 300), (2052, 9)])
 @pytest.mark.parametrize("name,metric", METRICS)
 def test_distance_batch_grouped_by_query_path(gpu_lib, oracle, monkeypatch, dim, nq, name, metric):
-    """P >= 65536 over few queries: cz_distance_batch sorts the pairs by query and keeps the query in registers.
-    Same bits as the ungrouped kernel and as the oracle, rows written back to the callers' positions."""
+    """P >= 65536 over few queries, CZ_PAIRS_GROUPED=1: cz_distance_batch groups the pairs by query (counting sort) and
+    keeps the query in registers.  Same bits as the default ungrouped kernel and as the oracle, rows written back to the
+    callers' positions."""
     from cozo_amd.hnsw import distance_batch
     rng = np.random.default_rng(dim + metric)
     n, P = 500, 70000
@@ -54,6 +55,7 @@ def test_distance_batch_grouped_by_query_path(gpu_lib, oracle, monkeypatch, dim,
     q = util.vectors(nq, dim, 4 + dim, "normal")
     pairs = np.stack([rng.integers(0, nq, P), rng.integers(0, n, P)], 1).astype(np.uint32)
     pairs[:5, 0] = nq - 1  # the largest query id sits at the front of the caller's order
+    monkeypatch.setenv("CZ_PAIRS_GROUPED", "1")
     grouped = distance_batch(name, base, q, pairs)
     monkeypatch.setenv("CZ_PAIRS_GROUPED", "0")
     plain = distance_batch(name, base, q, pairs)
