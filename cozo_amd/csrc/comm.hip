@@ -444,8 +444,10 @@ extern "C" int cz_hnsw_search_sharded(cz_comm *comm, cz_hnsw_index *shard, const
     if (rc) return rc;
     hipLaunchKernelGGL(shard_pack_kernel, dim3((unsigned)std::min<size_t>(1024, (nk + 255) / 256)), dim3(256), 0, stream, ids.p, cnt.p,
                        B, k, id_offset, my_i);
-    CZ_NCCL(R, R->AllGather(my_d, all_d.p, nk, ncclFloat64, comm->nccl, stream));
-    CZ_NCCL(R, R->AllGather(my_i, all_i.p, nk, ncclUint64, comm->nccl, stream));
+    if (world > 1) {
+        CZ_NCCL(R, R->AllGather(my_d, all_d.p, nk, ncclFloat64, comm->nccl, stream));
+        CZ_NCCL(R, R->AllGather(my_i, all_i.p, nk, ncclUint64, comm->nccl, stream));
+    }
     hipLaunchKernelGGL(shard_merge_kernel, dim3(B), dim3(256), 0, stream, all_d.p, all_i.p, world, B, k, out_ids_dev, out_dist_dev,
                        out_count_dev);
     hipError_t e = hipGetLastError();

@@ -661,6 +661,7 @@ extern "C" int cz_hnsw_index_create(const cz_hnsw_desc *desc, const float *vecto
             }
         ix->up_rows = rows;
         ix->top.assign(top.begin(), top.end());
+        ix->layout_top = ix->top;
         CZ_HIP(hipMalloc((void **)&ix->up_base, (size_t)ix->n * 4));
         CZ_HIP(hipMemcpy(ix->up_base, base.data(), (size_t)ix->n * 4, hipMemcpyHostToDevice));
         CZ_HIP(hipMalloc((void **)&ix->up_nbrs, up.size() * 4));

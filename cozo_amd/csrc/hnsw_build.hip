@@ -240,6 +240,56 @@ build_shrink_kernel(IndexDev ix, BuildTables T, const uint32_t *__restrict__ shr
     }
 }
 
+// An existing index goes back into build form (cz_hnsw_insert): every live row of the packed tables is copied into the
+// build tables and its link distances -- the `dist` column of the tbl:idx rows, which hnsw_shrink_neighbour reads
+// (:389-393) -- are evaluated again.  They are the same bits the original insertion stored: the kernels' distance is
+// symmetric in its two arguments (products, per-lane order and butterfly do not depend on which side is the query).
+template <int LPV, int ITERS, int U>
+__global__ void __launch_bounds__(kThreads)
+build_unpack_kernel(IndexDev ix, BuildTables T, const uint32_t *__restrict__ old_nbr0, int old_w0,
+                    const uint32_t *__restrict__ old_up_base, const uint32_t *__restrict__ old_up, int old_wu, uint32_t n_old,
+                    uint32_t efcap, uint32_t wcap,
+                    unsigned long long *__restrict__ ndist_total) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    czh::Smem s = czh::carve(smem_raw, efcap, wcap, ix.ld);
+    czh::Searcher<LPV, ITERS, U> S(ix, s, czh::VisitedDev{nullptr, 0, nullptr, 0});
+    const int tid = threadIdx.x;
+    for (uint32_t node = blockIdx.x; node < n_old; node += gridDim.x) {
+        const int top = T.level[node];
+        if (top < 0) continue;  // a removed node: no rows
+        S.load_query(ix.vec + (size_t)node * ix.ld);
+        for (int lv = 0; lv <= top; lv++) {
+            const RowRef r = row_of(T, node, lv);
+            // (the packed upper rows are laid out by the OLD row numbering: removals since then renumber the build tables)
+            const uint32_t *row = lv == 0 ? old_nbr0 + (size_t)node * old_w0
+                                          : old_up + ((size_t)old_up_base[node] + (lv - 1)) * old_wu;
+            const int width = lv == 0 ? old_w0 : old_wu;
+            // packed rows hold their live links first (ascending), CZ_NONE after them
+            const uint32_t id = tid < width ? row[tid] : CZ_NONE;
+            const int c = __syncthreads_count(id != CZ_NONE);
+            if (id != CZ_NONE) S.tcur[tid] = id;
+            __syncthreads();
+            if (c > 0) {
+                S.eval_todo(c);
+                __syncthreads();
+            }
+            for (int k = tid; k < r.cap; k += kThreads) {
+                if (k < c) {
+                    r.ids[k] = s.nid[k];
+                    r.dst[k] = key_dist(s.nkey[k]);
+                } else {
+                    r.ids[k] = CZ_NONE;
+                }
+            }
+            if (tid == 0) {
+                *r.deg = (uint32_t)c;
+                atomicAdd(ndist_total, (unsigned long long)c);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // final layout: rows sorted ascending by id, packed to the row width (one wave per row)
 __global__ void __launch_bounds__(256)
 build_pack_kernel(const uint32_t *__restrict__ src, int cap, uint32_t *__restrict__ dst, int width, uint64_t rows) {
@@ -294,81 +344,79 @@ struct ReqBuf {
 
 }  // namespace
 
-extern "C" int cz_hnsw_build(const float *vectors, uint32_t n, uint32_t dim, int metric, uint32_t m,
-                             uint32_t ef_construction, int keep_pruned_connections, const int32_t *levels, uint64_t seed,
-                             uint32_t max_batch, uint64_t *n_dist_out, cz_hnsw_index **out, uint32_t flags,
-                             void *stream_) {
-    if (!out) return cz::set_error(CZ_E_INVALID, "null out");
-    *out = nullptr;
-    if (n_dist_out) *n_dist_out = 0;
-    int rc = cz::ensure_device();
-    if (rc) return rc;
-    hipStream_t stream = (hipStream_t)stream_;
-    if (dim == 0) return cz::set_error(CZ_E_INVALID, "dim must be > 0");
-    if (metric < CZ_L2 || metric > CZ_IP) return cz::set_error(CZ_E_INVALID, "bad metric %d", metric);
-    if (m < 2) return cz::set_error(CZ_E_INVALID, "m must be >= 2");  // level_multiplier = 1/ln(m)
-    if (2 * m > 192) return cz::set_error(CZ_E_UNSUPPORTED, "m = %u: m_max0 = 2m must be <= 192 for the GPU build", m);
-    if (ef_construction == 0 || ef_construction > 1024)
-        return cz::set_error(CZ_E_UNSUPPORTED, "ef_construction must be in 1..1024");
-    if (n >= 0x7FFFFFFFu) return cz::set_error(CZ_E_UNSUPPORTED, "node ids must be < 2^31");
-    if (n > 0 && !vectors) return cz::set_error(CZ_E_INVALID, "vectors is null");
-    Shape sh = shape_of(dim);
-    if (sh.lpv == 64 && sh.iters > 8) return cz::set_error(CZ_E_UNSUPPORTED, "GPU index construction supports dim <= 2048");
-    if (max_batch == 0) max_batch = 4096;
+namespace {
 
-    std::unique_ptr<cz::HnswIndex> ix(new cz::HnswIndex());
-    ix->n = n;
-    ix->dim = dim;
-    ix->ld = (dim + 3) & ~3u;
-    ix->metric = metric;
-    ix->w0 = (int)(2 * m);
-    ix->wu = (int)m;
-    CZ_HIP(hipMalloc((void **)&ix->vec, std::max<size_t>(16, (size_t)n * ix->ld * 4)));
-    if (n == 0) {
-        ix->n_levels = 0;
-        *out = reinterpret_cast<cz_hnsw_index *>(ix.release());
-        return CZ_OK;
-    }
-    if (flags & CZ_DEVICE_PTRS) {
-        if (ix->ld == dim) CZ_HIP(hipMemcpyAsync(ix->vec, vectors, (size_t)n * dim * 4, hipMemcpyDeviceToDevice, stream));
-        else {
-            CZ_HIP(hipMemsetAsync(ix->vec, 0, (size_t)n * ix->ld * 4, stream));
-            CZ_HIP(hipMemcpy2DAsync(ix->vec, (size_t)ix->ld * 4, vectors, (size_t)dim * 4, (size_t)dim * 4, n,
-                                    hipMemcpyDeviceToDevice, stream));
+// hnsw_put over `n_new` more vectors (runtime/hnsw.rs:679-727 -> :155-375) into `ix`, which holds n_old >= 0 nodes in the
+// packed search layout.  The whole index goes into build form (rows with slack slots, link distances, degree counters),
+// the new vectors are inserted batch by batch, and the tables are packed again.
+int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t m, uint32_t ef_construction,
+               int keep_pruned_connections, const int32_t *levels, uint64_t seed, uint32_t max_batch, uint64_t *n_dist_out,
+               uint32_t flags, hipStream_t stream) {
+    const uint32_t dim = ix->dim, ld = ix->ld, n_old = ix->n;
+    const uint64_t n64 = (uint64_t)n_old + n_new;
+    if (n64 >= 0x7FFFFFFFull) return cz::set_error(CZ_E_UNSUPPORTED, "node ids must be < 2^31");
+    const uint32_t n = (uint32_t)n64;
+    Shape sh = shape_of(dim);
+    if (max_batch == 0) max_batch = 4096;
+    // vectors: old rows kept, new rows appended
+    {
+        float *nv = nullptr;
+        CZ_HIP(hipMalloc((void **)&nv, std::max<size_t>(16, (size_t)n * ld * 4)));
+        std::unique_ptr<float, void (*)(float *)> guard(nv, [](float *p) { (void)hipFree(p); });
+        if (n_old) CZ_HIP(hipMemcpyAsync(nv, ix->vec, (size_t)n_old * ld * 4, hipMemcpyDeviceToDevice, stream));
+        float *dst = nv + (size_t)n_old * ld;
+        if (flags & CZ_DEVICE_PTRS) {
+            if (ld == dim) CZ_HIP(hipMemcpyAsync(dst, vectors, (size_t)n_new * dim * 4, hipMemcpyDeviceToDevice, stream));
+            else {
+                CZ_HIP(hipMemsetAsync(dst, 0, (size_t)n_new * ld * 4, stream));
+                CZ_HIP(hipMemcpy2DAsync(dst, (size_t)ld * 4, vectors, (size_t)dim * 4, (size_t)dim * 4, n_new, hipMemcpyDeviceToDevice,
+                                        stream));
+            }
+        } else {
+            CZ_HIP(hipStreamSynchronize(stream));
+            if (ld != dim) CZ_HIP(hipMemset(dst, 0, (size_t)n_new * ld * 4));
+            CZ_HIP(hipMemcpy2D(dst, (size_t)ld * 4, vectors, (size_t)dim * 4, (size_t)dim * 4, n_new, hipMemcpyHostToDevice));
         }
-    } else {
-        if (ix->ld != dim) CZ_HIP(hipMemset(ix->vec, 0, (size_t)n * ix->ld * 4));
-        CZ_HIP(hipMemcpy2D(ix->vec, (size_t)ix->ld * 4, vectors, (size_t)dim * 4, (size_t)dim * 4, n, hipMemcpyHostToDevice));
+        CZ_HIP(hipStreamSynchronize(stream));
+        if (ix->vec) (void)hipFree(ix->vec);
+        ix->vec = guard.release();
     }
     // levels: caller-supplied (non-negative = -layer) or drawn here: floor(-ln(U) / ln(m)), hnsw.rs:46-52
     ix->top.resize(n);
     if (levels) {
-        for (uint32_t i = 0; i < n; i++) {
+        for (uint32_t i = 0; i < n_new; i++) {
             if (levels[i] < 0 || levels[i] > 60) return cz::set_error(CZ_E_INVALID, "levels[%u] = %d out of range", i, levels[i]);
-            ix->top[i] = levels[i];
+            ix->top[n_old + i] = levels[i];
         }
     } else {
         std::mt19937_64 rng(seed);
         std::uniform_real_distribution<double> uni(0.0, 1.0);
         const double mult = 1.0 / std::log((double)m);
-        for (uint32_t i = 0; i < n; i++) {
+        for (uint32_t i = 0; i < n_new; i++) {
             double u = uni(rng);
             if (u <= 0.0) u = 1e-300;
-            ix->top[i] = (int32_t)std::min(60.0, std::floor(-std::log(u) * mult));
+            ix->top[n_old + i] = (int32_t)std::min(60.0, std::floor(-std::log(u) * mult));
         }
     }
+    // upper-level rows: one per (node, level >= 1), a node's rows consecutive; old nodes keep theirs (appended nodes come after)
     std::vector<uint32_t> base(n, CZ_NONE);
-    uint64_t rows = 0;
-    for (uint32_t i = 0; i < n; i++)
+    uint64_t rows = 0, rows_old = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (i == n_old) rows_old = rows;
         if (ix->top[i] > 0) {
             base[i] = (uint32_t)rows;
             rows += (uint32_t)ix->top[i];
         }
+    }
+    if (n_old == n) rows_old = rows;
     if (rows >= 0xFFFFFFFFull) return cz::set_error(CZ_E_UNSUPPORTED, "too many upper-level rows");
-    ix->up_rows = rows;
+    const int old_w0 = ix->w0, old_wu = ix->wu;
+    const int w0 = (int)(2 * m), wu = (int)m;
     const int slack = 32;
-    const int cap0 = ix->w0 + slack, capU = ix->wu + slack;
-    cz::DevBuf<uint32_t> b_nbr0, b_deg0, b_nbrU, b_degU, b_shrink_t, b_misc, b_visited;
+    const int cap0 = w0 + slack, capU = wu + slack;
+    if (n_old && (old_w0 > cap0 || old_wu > capU))
+        return cz::set_error(CZ_E_UNSUPPORTED, "the index has rows of %d / %d links, wider than m = %u allows", old_w0, old_wu, m);
+    cz::DevBuf<uint32_t> b_nbr0, b_deg0, b_nbrU, b_degU, b_shrink_t, b_misc, b_visited, b_upbase;
     cz::DevBuf<double> b_dst0, b_dstU;
     cz::DevBuf<int32_t> b_level, b_shrink_lv;
     cz::DevBuf<unsigned long long> b_ndist;
@@ -381,8 +429,8 @@ extern "C" int cz_hnsw_build(const float *vectors, uint32_t n, uint32_t dim, int
     CZ_HIP(b_level.alloc(n));
     CZ_HIP(b_misc.alloc(8));
     CZ_HIP(b_ndist.alloc(1));
-    CZ_HIP(hipMalloc((void **)&ix->up_base, (size_t)n * 4));
-    CZ_HIP(hipMemcpyAsync(ix->up_base, base.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    CZ_HIP(b_upbase.alloc(n));
+    CZ_HIP(hipMemcpyAsync(b_upbase.p, base.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
     CZ_HIP(hipMemcpyAsync(b_level.p, ix->top.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
     CZ_HIP(hipMemsetAsync(b_nbr0.p, 0xFF, (size_t)n * cap0 * 4, stream));
     CZ_HIP(hipMemsetAsync(b_nbrU.p, 0xFF, std::max<size_t>(1, rows) * capU * 4, stream));
@@ -405,28 +453,53 @@ extern "C" int cz_hnsw_build(const float *vectors, uint32_t n, uint32_t dim, int
     // reference's eager order (hnsw.rs:338-350) and with it the identical link tables.
     const char *lazy_env = getenv("CZ_BUILD_LAZY");
     const int lazy = max_batch > 1 && !(lazy_env && atoi(lazy_env) == 0);
-    const size_t max_req = (size_t)max_batch * (size_t)(ix->w0 + 8 * ix->wu) + 1024;
+    const size_t max_req = (size_t)max_batch * (size_t)(w0 + 8 * wu) + 1024;
     ReqBuf reqA, reqB;
     CZ_HIP(reqA.alloc(max_req));
     CZ_HIP(reqB.alloc(max_req));
     CZ_HIP(b_shrink_t.alloc(max_req));
     CZ_HIP(b_shrink_lv.alloc(max_req));
 
-    BuildTables T{b_nbr0.p, b_dst0.p, b_deg0.p, ix->w0, cap0, ix->up_base, b_nbrU.p, b_dstU.p, b_degU.p, ix->wu, capU,
-                  b_level.p};
+    BuildTables T{b_nbr0.p, b_dst0.p, b_deg0.p, w0, cap0, b_upbase.p, b_nbrU.p, b_dstU.p, b_degU.p, wu, capU, b_level.p};
     IndexDev dev = ix->dev();
+    dev.n = n;
     dev.nbr0 = b_nbr0.p;
     dev.w0 = cap0;  // rows are scanned at their build stride; unused slots hold CZ_NONE
+    dev.up_base = b_upbase.p;
     dev.up_nbrs = b_nbrU.p;
     dev.wu = capU;
     const uint32_t efcap = (std::max<uint32_t>(ef_construction, (uint32_t)std::max(cap0, capU)) + 63) & ~63u;
     const uint32_t wcap = std::max<uint32_t>(efcap, (uint32_t)((std::max(cap0, capU) + 63) & ~63));
-    const size_t smem = czh::smem_bytes(efcap, wcap, ix->ld);
+    const size_t smem = czh::smem_bytes(efcap, wcap, ld);
     if (smem > 160 * 1024) return cz::set_error(CZ_E_UNSUPPORTED, "dim/ef_construction need %zu bytes of LDS", smem);
 
-    int top = ix->top[0];
+    int top = -1;
     uint32_t entry = 0;
-    uint32_t i = 1;
+    uint32_t i = n_old;
+    if (n_old > 0 && ix->n_levels > 0) {
+        // the existing rows, with their link distances, into the build tables
+        top = ix->n_levels - 1;
+        entry = ix->entry;
+        const uint32_t g0 = std::min<uint32_t>(n_old, 4096);
+#define CZ_LAUNCH_UNPACK(LPV, ITERS, U)                                                                                  \
+    do {                                                                                                                 \
+        auto kern = build_unpack_kernel<LPV, ITERS, U>;                                                                  \
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                                        (int)smem);                                                     \
+        hipLaunchKernelGGL(kern, dim3(g0), dim3(kThreads), smem, stream, dev, T, ix->nbr0, old_w0, ix->up_base, ix->up_nbrs,     \
+                           old_wu, n_old, efcap, wcap, b_ndist.p);                                                       \
+    } while (0)
+        CZ_DISPATCH_BUILD_SHAPE(sh, CZ_LAUNCH_UNPACK);
+#undef CZ_LAUNCH_UNPACK
+        CZ_HIP(hipStreamSynchronize(stream));
+    } else if (n > 0) {
+        // an empty index: the first vector is its own entry point (hnsw.rs:206-218 with no rows yet)
+        uint32_t first = n_old;
+        top = ix->top[first];
+        entry = first;
+        i = first + 1;
+    }
+    (void)rows_old;
     while (i < n) {
         // a vector that raises the top level is inserted alone and becomes the entry point (hnsw.rs:206-218)
         uint32_t bn = 1;
@@ -490,7 +563,7 @@ extern "C" int cz_hnsw_build(const float *vectors, uint32_t n, uint32_t dim, int
         }
         i += bn;
     }
-    if (lazy) {  // rows that still hold more links than their final width
+    if (lazy || n_old > 0) {  // rows that still hold more links than their final width
         cz::DevBuf<uint32_t> f_t;
         cz::DevBuf<int32_t> f_lv;
         const size_t fcap = (size_t)n + rows;
@@ -520,21 +593,175 @@ extern "C" int cz_hnsw_build(const float *vectors, uint32_t n, uint32_t dim, int
         if (fe != hipSuccess) return cz::set_error(CZ_E_HIP, "hnsw build final shrink: %s", hipGetErrorString(fe));
     }
     // final layout
-    ix->n_levels = top + 1;
-    ix->entry = entry;
-    CZ_HIP(hipMalloc((void **)&ix->nbr0, (size_t)n * ix->w0 * 4));
-    CZ_HIP(hipMalloc((void **)&ix->up_nbrs, std::max<size_t>(1, rows) * ix->wu * 4));
-    CZ_HIP(hipMemsetAsync(ix->up_nbrs, 0xFF, std::max<size_t>(1, rows) * ix->wu * 4, stream));
-    hipLaunchKernelGGL(build_pack_kernel, dim3(4096), dim3(256), 0, stream, b_nbr0.p, cap0, ix->nbr0, ix->w0, (uint64_t)n);
-    if (rows)
-        hipLaunchKernelGGL(build_pack_kernel, dim3(1024), dim3(256), 0, stream, b_nbrU.p, capU, ix->up_nbrs, ix->wu, rows);
+    uint32_t *new_nbr0 = nullptr, *new_up = nullptr;
+    CZ_HIP(hipMalloc((void **)&new_nbr0, (size_t)n * w0 * 4));
+    if (hipMalloc((void **)&new_up, std::max<size_t>(1, rows) * wu * 4) != hipSuccess) {
+        (void)hipFree(new_nbr0);
+        return cz::set_error(CZ_E_OOM, "out of device memory for the packed link tables");
+    }
+    CZ_HIP(hipMemsetAsync(new_up, 0xFF, std::max<size_t>(1, rows) * wu * 4, stream));
+    hipLaunchKernelGGL(build_pack_kernel, dim3(4096), dim3(256), 0, stream, b_nbr0.p, cap0, new_nbr0, w0, (uint64_t)n);
+    if (rows) hipLaunchKernelGGL(build_pack_kernel, dim3(1024), dim3(256), 0, stream, b_nbrU.p, capU, new_up, wu, rows);
     unsigned long long nd = 0;
     CZ_HIP(hipMemcpyAsync(&nd, b_ndist.p, 8, hipMemcpyDeviceToHost, stream));
     CZ_HIP(hipStreamSynchronize(stream));
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "hnsw pack launch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipFree(new_nbr0);
+        (void)hipFree(new_up);
+        return cz::set_error(CZ_E_HIP, "hnsw pack launch: %s", hipGetErrorString(e));
+    }
+    if (ix->nbr0) (void)hipFree(ix->nbr0);
+    if (ix->up_nbrs) (void)hipFree(ix->up_nbrs);
+    if (ix->up_base) (void)hipFree(ix->up_base);
+    ix->nbr0 = new_nbr0;
+    ix->up_nbrs = new_up;
+    ix->up_base = b_upbase.release();
+    ix->n = n;
+    ix->w0 = w0;
+    ix->wu = wu;
+    ix->up_rows = rows;
+    ix->n_levels = top + 1;
+    ix->entry = entry;
+    ix->layout_top.assign(ix->top.begin(), ix->top.end());
+    {   // the visited workspaces were sized for the old n
+        std::lock_guard<std::mutex> lk(ix->mu);
+        for (auto &w : ix->pool) cz::HnswIndex::destroy(w);
+        ix->pool.clear();
+    }
     if (n_dist_out) *n_dist_out = nd;
+    return CZ_OK;
+}
+
+int check_build_args(uint32_t dim, int metric, uint32_t m, uint32_t ef_construction) {
+    if (dim == 0) return cz::set_error(CZ_E_INVALID, "dim must be > 0");
+    if (metric < CZ_L2 || metric > CZ_IP) return cz::set_error(CZ_E_INVALID, "bad metric %d", metric);
+    if (m < 2) return cz::set_error(CZ_E_INVALID, "m must be >= 2");  // level_multiplier = 1/ln(m)
+    if (2 * m > 192) return cz::set_error(CZ_E_UNSUPPORTED, "m = %u: m_max0 = 2m must be <= 192 for the GPU build", m);
+    if (ef_construction == 0 || ef_construction > 1024)
+        return cz::set_error(CZ_E_UNSUPPORTED, "ef_construction must be in 1..1024");
+    Shape sh = shape_of(dim);
+    if (sh.lpv == 64 && sh.iters > 8) return cz::set_error(CZ_E_UNSUPPORTED, "GPU index construction supports dim <= 2048");
+    return CZ_OK;
+}
+
+// drop every link to a removed node, keep the rows' order (one wave per row)
+__global__ void __launch_bounds__(256)
+remove_links_kernel(uint32_t *__restrict__ tab, int width, uint64_t rows, const uint32_t *__restrict__ removed_bits,
+                    const uint32_t *__restrict__ row_owner /* level 0: nullptr (row = node) */) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + wave; r < rows; r += (uint64_t)gridDim.x * 4) {
+        uint32_t *row = tab + r * width;
+        const uint32_t owner = row_owner ? row_owner[r] : (uint32_t)r;
+        const bool dead_row = owner != CZ_NONE && ((removed_bits[owner >> 5] >> (owner & 31)) & 1u);
+        int kept = 0;
+        for (int c0 = 0; c0 < width; c0 += 64) {
+            const int c = c0 + lane;
+            const uint32_t id = c < width ? row[c] : CZ_NONE;
+            const bool keep = !dead_row && id != CZ_NONE && !((removed_bits[id >> 5] >> (id & 31)) & 1u);
+            const unsigned long long mk = __ballot(keep);
+            __builtin_amdgcn_wave_barrier();
+            if (keep) row[kept + __popcll(mk & ((1ull << lane) - 1ull))] = id;  // never ahead of the slots read so far
+            kept += __popcll(mk);
+        }
+        for (int c = kept + lane; c < width; c += 64) row[c] = CZ_NONE;
+    }
+}
+
+}  // namespace
+
+extern "C" int cz_hnsw_build(const float *vectors, uint32_t n, uint32_t dim, int metric, uint32_t m,
+                             uint32_t ef_construction, int keep_pruned_connections, const int32_t *levels, uint64_t seed,
+                             uint32_t max_batch, uint64_t *n_dist_out, cz_hnsw_index **out, uint32_t flags,
+                             void *stream_) {
+    if (!out) return cz::set_error(CZ_E_INVALID, "null out");
+    *out = nullptr;
+    if (n_dist_out) *n_dist_out = 0;
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if ((rc = check_build_args(dim, metric, m, ef_construction))) return rc;
+    if (n >= 0x7FFFFFFFu) return cz::set_error(CZ_E_UNSUPPORTED, "node ids must be < 2^31");
+    if (n > 0 && !vectors) return cz::set_error(CZ_E_INVALID, "vectors is null");
+    std::unique_ptr<cz::HnswIndex> ix(new cz::HnswIndex());
+    ix->n = 0;
+    ix->dim = dim;
+    ix->ld = (dim + 3) & ~3u;
+    ix->metric = metric;
+    ix->w0 = (int)(2 * m);
+    ix->wu = (int)m;
+    ix->n_levels = 0;
+    if (n == 0) {
+        CZ_HIP(hipMalloc((void **)&ix->vec, 16));
+        *out = reinterpret_cast<cz_hnsw_index *>(ix.release());
+        return CZ_OK;
+    }
+    rc = build_into(ix.get(), vectors, n, m, ef_construction, keep_pruned_connections, levels, seed, max_batch, n_dist_out, flags,
+                    (hipStream_t)stream_);
+    if (rc) return rc;
     *out = reinterpret_cast<cz_hnsw_index *>(ix.release());
+    return CZ_OK;
+}
+
+extern "C" int cz_hnsw_insert(cz_hnsw_index *h, const float *vectors, uint32_t n_new, uint32_t m, uint32_t ef_construction,
+                              int keep_pruned_connections, const int32_t *levels, uint64_t seed, uint32_t max_batch,
+                              uint64_t *n_dist_out, uint32_t flags, void *stream_) {
+    if (n_dist_out) *n_dist_out = 0;
+    if (!h) return cz::set_error(CZ_E_INVALID, "null index");
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    auto *ix = reinterpret_cast<cz::HnswIndex *>(h);
+    if ((rc = check_build_args(ix->dim, ix->metric, m, ef_construction))) return rc;
+    if (n_new == 0) return CZ_OK;
+    if (!vectors) return cz::set_error(CZ_E_INVALID, "vectors is null");
+    return build_into(ix, vectors, n_new, m, ef_construction, keep_pruned_connections, levels, seed, max_batch, n_dist_out, flags,
+                      (hipStream_t)stream_);
+}
+
+extern "C" int cz_hnsw_remove(cz_hnsw_index *h, const uint32_t *nodes, uint32_t n_nodes) {
+    if (!h) return cz::set_error(CZ_E_INVALID, "null index");
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    auto *ix = reinterpret_cast<cz::HnswIndex *>(h);
+    if (n_nodes == 0 || ix->n == 0) return CZ_OK;
+    if (!nodes) return cz::set_error(CZ_E_INVALID, "null nodes");
+    if (ix->top.size() != ix->n || ix->layout_top.size() != ix->n) return cz::set_error(CZ_E_HIP, "internal: level table out of step");
+    std::vector<uint32_t> bits((ix->n + 31) / 32, 0);
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        if (nodes[i] >= ix->n) return cz::set_error(CZ_E_INVALID, "node %u out of range", nodes[i]);
+        bits[nodes[i] >> 5] |= 1u << (nodes[i] & 31);
+    }
+    // owner of every upper-level row (for the rows of the removed nodes themselves)
+    std::vector<uint32_t> owner((size_t)std::max<uint64_t>(1, ix->up_rows), CZ_NONE);
+    {
+        uint64_t r = 0;
+        for (uint32_t i = 0; i < ix->n; i++)
+            for (int l = 0; l < ix->layout_top[i]; l++) owner[(size_t)r++] = i;
+    }
+    cz::DevBuf<uint32_t> d_bits, d_owner;
+    CZ_HIP(d_bits.alloc(bits.size()));
+    CZ_HIP(d_owner.alloc(owner.size()));
+    CZ_HIP(hipMemcpy(d_bits.p, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
+    CZ_HIP(hipMemcpy(d_owner.p, owner.data(), owner.size() * 4, hipMemcpyHostToDevice));
+    if (ix->n_levels > 0) {
+        hipLaunchKernelGGL(remove_links_kernel, dim3(4096), dim3(256), 0, nullptr, ix->nbr0, ix->w0, (uint64_t)ix->n, d_bits.p,
+                           (const uint32_t *)nullptr);
+        if (ix->up_rows)
+            hipLaunchKernelGGL(remove_links_kernel, dim3(1024), dim3(256), 0, nullptr, ix->up_nbrs, ix->wu, ix->up_rows, d_bits.p,
+                               d_owner.p);
+        CZ_HIP(hipDeviceSynchronize());
+    }
+    // the removed nodes leave every level (their upper rows stay allocated, empty); the entry point is positional: the
+    // smallest node on the highest level that still has one (hnsw.rs:184-191, 891-899)
+    for (uint32_t i = 0; i < n_nodes; i++) ix->top[nodes[i]] = -1;
+    int top = -1;
+    uint32_t entry = CZ_NONE;
+    for (uint32_t i = 0; i < ix->n; i++)
+        if (ix->top[i] > top) {
+            top = ix->top[i];
+            entry = i;
+        }
+    ix->n_levels = top + 1;
+    ix->entry = top >= 0 ? entry : CZ_NONE;
     return CZ_OK;
 }
 

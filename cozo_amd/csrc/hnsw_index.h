@@ -32,7 +32,8 @@ struct HnswIndex {
     uint32_t *nbr0 = nullptr;
     uint32_t *up_base = nullptr;
     uint32_t *up_nbrs = nullptr;
-    std::vector<int32_t> top;  // host copy: top level of every node (for export)
+    std::vector<int32_t> top;         // host copy: top level of every node (-1: removed, cz_hnsw_remove)
+    std::vector<int32_t> layout_top;  // the same when the upper-level rows were last laid out (row numbering)
 
     // per-call scratch (the visited sets of a batch: hash tables + overflow bitmaps, hnsw_kernels.cuh VisitedDev):
     // cached, handed out under a mutex, stream-ordered by an event.  Invariant while pooled: every word of `tab` is

@@ -108,6 +108,26 @@ class GpuHnswIndex:
         self.last_build_n_dist = nd.value
         return self
 
+    def insert(self, vectors, levels: Optional[np.ndarray] = None, seed: int = 0, max_batch: int = 0):
+        """hnsw_put for more rows on a later write (stored.rs:431-450 -> hnsw.rs:679-727): the vectors become nodes
+        n .. n + len - 1 of this index (cz_hnsw_insert)."""
+        v = np.ascontiguousarray(vectors, dtype=np.float32)
+        if v.ndim != 2 or v.shape[1] != self.manifest.vec_dim:
+            raise ValueError("vectors must be [n][vec_dim]")
+        lv = None if levels is None else np.ascontiguousarray(levels, dtype=np.int32)
+        nd = C.c_uint64(0)
+        man = self.manifest
+        check(_lib.lib().cz_hnsw_insert(self._h, ptr(v), v.shape[0], man.m_neighbours, man.ef_construction,
+                                        int(man.keep_pruned_connections), ptr(lv), int(seed), int(max_batch), C.byref(nd), 0,
+                                        None))
+        self.n += v.shape[0]
+        self.last_build_n_dist = nd.value
+
+    def remove(self, nodes):
+        """hnsw_remove (hnsw.rs:728-868) for a set of nodes: they leave every level, links from and to them disappear"""
+        a = np.ascontiguousarray(nodes, dtype=np.uint32)
+        check(_lib.lib().cz_hnsw_remove(self._h, ptr(a), a.size))
+
     def export(self):
         """(level_nodes, level_nbrs, entry): the flat layout of cz_hnsw_desc, e.g. to write the links back as
         `tbl:idx` rows or to hand the same index to another searcher."""

@@ -113,6 +113,25 @@ int cz_hnsw_build(const float *vectors, uint32_t n, uint32_t dim, int metric, ui
                   int keep_pruned_connections, const int32_t *levels, uint64_t seed, uint32_t max_batch,
                   uint64_t *n_dist, cz_hnsw_index **out, uint32_t flags, void *stream);
 
+/* Index maintenance on the device.
+ * cz_hnsw_insert: hnsw_put for `n_new` more rows on a later write (query/stored.rs:431-450 -> runtime/hnsw.rs:679-727),
+ *   batched like cz_hnsw_build: the new vectors become nodes n .. n + n_new - 1 of the same handle.  The existing link
+ *   rows go back into build form first (their link distances -- the `dist` column hnsw_shrink_neighbour reads,
+ *   :389-393 -- are evaluated again by the same arithmetic, bit for bit), the new vectors are inserted, the tables are
+ *   packed again.  m / ef_construction / keep_pruned_connections as at build time; max_batch = 1 reproduces the
+ *   sequential algorithm's tables.  The write-back of the changed rows is the shim's (cz_hnsw_index_export_level +
+ *   czi_hnsw_encode_rows).  Not concurrent with searches on the same handle.
+ * cz_hnsw_remove: hnsw_remove / hnsw_remove_vec (:728-868) for a set of nodes: the nodes leave every level, the links
+ *   from and to them disappear, the entry point moves to the smallest node of the highest level that is left (the
+ *   reference's entry point is positional, :184-191).  Node ids are not renumbered: a removed node keeps its id, holds no
+ *   rows and can never be reached.  Unlike the reference, links INTO a removed node from nodes it did not link back to
+ *   are dropped as well (the reference leaves those rows behind and a later search that follows one fails with
+ *   "corrupted index"). */
+int cz_hnsw_insert(cz_hnsw_index *ix, const float *vectors /* [n_new][dim], dev-able */, uint32_t n_new, uint32_t m,
+                   uint32_t ef_construction, int keep_pruned_connections, const int32_t *levels, uint64_t seed,
+                   uint32_t max_batch, uint64_t *n_dist, uint32_t flags, void *stream);
+int cz_hnsw_remove(cz_hnsw_index *ix, const uint32_t *nodes, uint32_t n_nodes);
+
 /* flat export of a device-resident index (the inverse of cz_hnsw_index_create; host buffers) */
 int cz_hnsw_index_info(const cz_hnsw_index *ix, uint32_t *n, uint32_t *dim, int32_t *metric, int32_t *n_levels,
                        uint32_t *entry);

@@ -95,3 +95,95 @@ def test_build_edge_cases(gpu_lib, oracle):
         GpuHnswIndex.build(HnswIndexManifest(vec_dim=8, m_neighbours=4, extend_candidates=True), x)
     with pytest.raises(_lib.CozoGpuError):
         GpuHnswIndex.build(HnswIndexManifest(vec_dim=8, m_neighbours=200), x)
+
+
+@pytest.mark.parametrize("n,dim,dist,metric,m,efc,keep,kind", SEQ_CASES[:3])
+def test_insert_into_existing_index_identical_to_one_sequential_build(gpu_lib, oracle, n, dim, dist, metric, m, efc, keep, kind):
+    """cz_hnsw_insert = hnsw_put on a later write (stored.rs:431-450 -> hnsw.rs:679-727).  With max_batch = 1 the tables
+    after build(first part) + insert(second part) are the tables of ONE sequential build over all rows -- both when the first
+    part was built on the device and when it was uploaded from the store (its link distances are then evaluated again on
+    the way back into build form, and must be the bits the original insertion stored)."""
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest
+    x = util.vectors(n, dim, 11, kind)
+    levels = oracle.random_levels(n, m, 3)
+    h = n * 2 // 3
+    b = oracle.HnswBuilder(dim, metric, m, efc, keep_pruned_connections=keep, dot_mode=oracle.DOT_GPU)
+    b.insert(x[:h], levels[:h])
+    part = b.export()
+    b.insert(x[h:], levels[h:])
+    flat = b.export()
+    man = HnswIndexManifest(vec_dim=dim, distance=dist, m_neighbours=m, ef_construction=efc, keep_pruned_connections=keep)
+    built = GpuHnswIndex.build(man, x[:h], levels=levels[:h], max_batch=1)
+    uploaded = GpuHnswIndex(man, part.vectors, [None] + part.level_nodes[1:], part.level_nbrs, part.entry)
+    for g in (built, uploaded):
+        g.insert(x[h:], levels=levels[h:], max_batch=1)
+        nodes, nbrs, entry = g.export()
+        assert entry == flat.entry and len(nbrs) == flat.n_levels
+        for lv in range(flat.n_levels):
+            assert np.array_equal(nodes[lv], flat.level_nodes[lv])
+            assert np.array_equal(nbrs[lv], flat.level_nbrs[lv]), f"level {lv} link rows differ"
+        assert np.array_equal(g.export_vectors(), x)
+        g.close()
+
+
+def test_remove_then_insert(gpu_lib, oracle):
+    """cz_hnsw_remove (hnsw_remove, hnsw.rs:728-868): the nodes leave every level, no link names them any more, the entry
+    point moves to the smallest node of the highest level left; the search over what remains equals the oracle's search
+    over the same tables.  A later insert (rows renumbered underneath) keeps all of that."""
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest, HnswSearch
+    n, dim, m, efc = 4000, 48, 8, 40
+    x = util.vectors(n + 500, dim, 31, "lowrank")
+    q = util.vectors(64, dim, 32, "lowrank")
+    levels = oracle.random_levels(n + 500, m, 7)
+    man = HnswIndexManifest(vec_dim=dim, distance="Cosine", m_neighbours=m, ef_construction=efc)
+    g = GpuHnswIndex.build(man, x[:n], levels=levels[:n], max_batch=256)
+    nodes0, nbrs0, entry0 = g.export()
+    rng = np.random.default_rng(5)
+    dead = np.unique(np.concatenate([rng.choice(n, 300, replace=False), [entry0], np.nonzero(levels[:n] >= 2)[0]])).astype(np.uint32)
+    g.remove(dead)
+
+    def check(g, n_now, lv_now, dead):
+        nodes, nbrs, entry = g.export()
+        alive_lv = np.where(np.isin(np.arange(n_now), dead), -1, lv_now[:n_now])
+        assert len(nbrs) == alive_lv.max() + 1
+        assert entry == int(np.nonzero(alive_lv == alive_lv.max())[0][0])
+        for lv in range(len(nbrs)):
+            tab = nbrs[lv]
+            live = tab != 0xFFFFFFFF
+            assert not np.isin(tab[live], dead).any(), "a link still names a removed node"
+            if lv == 0:
+                assert not live[dead].any(), "a removed node still holds links"
+            else:
+                assert np.array_equal(nodes[lv], np.nonzero(alive_lv >= lv)[0].astype(np.uint32))
+            # live links first, ascending
+            t = tab.astype(np.int64)
+            t[~live] = 2 ** 40
+            assert (np.diff(t, axis=1) >= 0).all()
+        return nodes, nbrs, entry
+
+    nodes, nbrs, entry = check(g, n, levels, dead)
+    # what survived of every row is exactly the old row minus the removed ids
+    for lv in range(len(nbrs)):
+        keep_rows = np.isin(nodes0[lv], nodes[lv]) if lv else np.ones(n, bool)
+        old = nbrs0[lv][keep_rows]
+        for r in range(0, old.shape[0], 97):
+            want = [v for v in old[r].tolist() if v != 0xFFFFFFFF and v not in set(dead.tolist())]
+            if lv == 0 and r in set(dead.tolist()):
+                want = []
+            assert nbrs[lv][r][:len(want)].tolist() == want
+    flat = oracle.FlatIndex(x[:n], oracle.COSINE, nodes, nbrs, entry)
+    ids, dist, cnt = g.hnsw_knn_batch(q, HnswSearch(k=10, ef=50))
+    oids, odist, ocnt, _ = flat.knn_batch(q, 10, 50, dot_mode=oracle.DOT_GPU)
+    assert np.array_equal(ids, oids) and np.array_equal(dist, odist) and np.array_equal(cnt, ocnt)
+    assert not np.isin(ids[ids != 0xFFFFFFFF], dead).any()
+    # insert after remove: the upper-level rows are renumbered, the removed nodes stay gone
+    g.insert(x[n:], levels=levels[n:], max_batch=64)
+    nodes, nbrs, entry = check(g, n + 500, levels, dead)
+    flat = oracle.FlatIndex(x, oracle.COSINE, nodes, nbrs, entry)
+    ids, dist, cnt = g.hnsw_knn_batch(q, HnswSearch(k=10, ef=50))
+    oids, odist, ocnt, _ = flat.knn_batch(q, 10, 50, dot_mode=oracle.DOT_GPU)
+    assert np.array_equal(ids, oids) and np.array_equal(dist, odist)
+    gt, _ = g.bruteforce_knn(q, 10)  # (the exhaustive scan still sees the removed rows' vectors: compare on the living)
+    rec = np.mean([len(set(ids[i]) & (set(gt[i]) - set(dead.tolist()))) / max(1, len(set(gt[i]) - set(dead.tolist()))) for i in range(len(q))])
+    assert rec >= 0.8
+    g.close()
