@@ -874,6 +874,12 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        # Two users of the RCCL shared library in one process (torch.distributed and libcozo_gpu's communicators): the
+        # library's static destructors were observed to abort at interpreter exit after all work was done
+        # (scratch/r2_rccl_exit.py, tests/gpu_comm_child.py).  The line is out and flushed; leave without them.
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

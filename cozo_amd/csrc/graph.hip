@@ -228,11 +228,38 @@ __global__ void __launch_bounds__(kT) iota_kernel(uint32_t *__restrict__ p, uint
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
 }
 
-// A group of kCcLanes lanes owns one node and reads its adjacency list coalesced (one thread per node walked its list
-// serially: every lane of a wave then touches a different cache line per step -- 9.3 ms per round on the symmetrised
-// 10M / 200M graph, 21 G edges/s).  The group's minimum neighbour label comes from a butterfly over the group.  The fixed
-// point (label[v] = smallest index of v's component) does not depend on the schedule, so the group ids are unchanged.
+// Two forms of one label-propagation round; the fixed point (label[v] = smallest index of v's component) does not
+// depend on the schedule, so the group ids are the same whichever runs.
+//   cc_relax_node_kernel   one thread per node walks its list serially.  Used for the FIRST round, when almost every edge
+//                          issues an atomicMin (labels are still the node ids): 9.3 ms on the symmetrised 10M / 200M graph.
+//   cc_relax_kernel        a group of kCcLanes lanes owns one node and reads its adjacency list coalesced; the group's
+//                          minimum neighbour label comes from a butterfly.  Used from the second round on, when the round
+//                          is mostly reads: 3.4 ms against 9.3 ms (profiles/r02_graph_rules_kernel_stats.txt).  As the first
+//                          round it measured 30.9 ms -- 16 times more lanes issuing the same 10^8 atomics at once.
 constexpr int kCcLanes = 16;
+
+__global__ void __launch_bounds__(kT)
+cc_relax_node_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t N, uint32_t *__restrict__ label,
+                     uint32_t *__restrict__ changed) {
+    bool ch = false;
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < N; u += gridDim.x * blockDim.x) {
+        uint32_t lu = label[u], m = lu;
+        for (uint32_t e = off[u]; e < off[u + 1]; e++) {
+            const uint32_t v = tgt[e];
+            const uint32_t lv = label[v];
+            if (lv < m) m = lv;
+            if (lu < lv) {
+                if (atomicMin(&label[v], lu) > lu) ch = true;
+            }
+        }
+        if (m < lu) {
+            if (atomicMin(&label[u], m) > m) ch = true;
+            // hook the old representative too, so whole trees move at once
+            if (atomicMin(&label[lu], m) > m) ch = true;
+        }
+    }
+    if (ch) *changed = 1;
+}
 
 __global__ void __launch_bounds__(kT)
 cc_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t N, uint32_t *__restrict__ label,
@@ -549,11 +576,14 @@ extern "C" int cz_connected_components(const uint32_t *offsets, const uint32_t *
     hipStream_t s = nullptr;
     const int g = grid_for(N);
     hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(kT), 0, s, d_label.p, N);
-    for (;;) {
+    for (uint32_t round = 0;; round++) {
         if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
         CZ_HIP(hipMemsetAsync(d_misc.p, 0, 4, s));
-        hipLaunchKernelGGL(cc_relax_kernel, dim3(grid_for((uint64_t)N * kCcLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, N, d_label.p,
-                           d_misc.p);
+        if (round == 0)
+            hipLaunchKernelGGL(cc_relax_node_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, N, d_label.p, d_misc.p);
+        else
+            hipLaunchKernelGGL(cc_relax_kernel, dim3(grid_for((uint64_t)N * kCcLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, N,
+                               d_label.p, d_misc.p);
         hipLaunchKernelGGL(cc_jump_kernel, dim3(g), dim3(kT), 0, s, N, d_label.p);
         uint32_t changed = 0;
         CZ_HIP(hipMemcpy(&changed, d_misc.p, 4, hipMemcpyDeviceToHost));

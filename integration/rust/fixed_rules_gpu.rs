@@ -35,7 +35,8 @@ fn check(rc: c_int, poison: &Poison) -> Result<()> {
     }
 }
 
-/// `Poison(Arc<AtomicBool>)` (runtime/db.rs:1926): AtomicBool has the layout of u8; the library polls it between launches.
+/// `pub struct Poison(pub(crate) Arc<AtomicBool>)` (runtime/db.rs:1926): this file lives inside cozo-core
+/// (fixed_rule/algos/gpu.rs), so the field is visible; AtomicBool has the layout of u8 and the library polls it between launches.
 fn poison_ptr(p: &Poison) -> *const u8 {
     p.0.as_ptr() as *const u8
 }
@@ -74,6 +75,19 @@ impl<'a, 'b> FixedRuleInputRelation<'a, 'b> {
             b.val_off.push(b.vals.len() as u64);
         }
         Ok(Some((b, rel.metadata.keys.len() as u32)))
+    }
+
+    /// (relation id, write version) of a stored input read at the present; None for rule results / time travel.  The
+    /// version is the storage engine's monotonically increasing commit counter as seen by this transaction's snapshot
+    /// (for the `mem` / RocksDB engines: the sequence number the read snapshot was taken at).
+    pub(crate) fn stored_identity(&self) -> Result<Option<(u64, u64)>> {
+        match self.arg_manifest {
+            crate::data::program::MagicFixedRuleRuleArg::Stored { name, valid_at: None, .. } => {
+                let rel = self.tx.get_relation(name, false)?;
+                Ok(Some((rel.id.0, self.tx.store_tx.snapshot_version())))
+            }
+            _ => Ok(None),
+        }
     }
 
     pub(crate) fn as_gpu_graph(&self, undirected: bool, inverse: bool) -> Result<GpuGraph> {
@@ -162,16 +176,36 @@ impl FixedRule for PageRankGpu {
         let theta = payload.unit_interval_option("theta", Some(0.85))? as f32;
         let epsilon = payload.unit_interval_option("epsilon", Some(0.0001))? as f32;
         let iterations = payload.pos_integer_option("iterations", Some(10))?;
+        // extra options of the GPU rule (absent = the reference's behaviour on one GPU):
+        //   gpus: n      row-shard the sweep over n GPUs of this process (cz_pagerank_multi: one host thread + one RCCL
+        //                communicator per GPU, in-place all-gather of the contribution slices each iteration)
+        //   relaxed: b   long rows summed in parallel (CZ_PR_RELAXED): scores differ from the sequential f32 sums in the last bits
+        let gpus = payload.pos_integer_option("gpus", Some(1))? as c_int;
+        let relaxed = payload.bool_option("relaxed", Some(false))?;
+        let flags = if relaxed { CZ_PR_RELAXED } else { 0 };
         let g = edges.as_gpu_graph(undirected, true)?;
         if g.indices.is_empty() {
             return Ok(()); // pagerank.rs:43-45
         }
         let mut scores = vec![0f32; g.n as usize];
         let (mut it, mut err) = (0u32, 0f64);
-        check(unsafe {
-            cz_pagerank(g.offsets.as_ptr(), g.targets.as_ptr(), g.out_degree.as_ptr(), g.n, g.targets.len() as u64, theta,
-                        epsilon as f64, iterations as u32, scores.as_mut_ptr(), &mut it, &mut err, poison_ptr(&poison))
-        }, &poison)?;
+        if gpus > 1 {
+            check(unsafe {
+                cz_pagerank_multi(g.offsets.as_ptr(), g.targets.as_ptr(), g.out_degree.as_ptr(), g.n, g.targets.len() as u64,
+                                  theta, epsilon as f64, iterations as u32, gpus, flags, scores.as_mut_ptr(), &mut it, &mut err,
+                                  poison_ptr(&poison))
+            }, &poison)?;
+        } else {
+            // the device layout of a STORED relation is kept between calls: the key is (relation id, the store's write
+            // version at this snapshot, the `undirected` bit) -- the same relation at the same version is the same CSR.
+            // A rule result (no stored relation behind the input) is never cached: key 0:0.
+            let (key_hi, key_lo) = edges.stored_identity()?.map_or((0, 0), |(rel_id, version)| (rel_id, (version << 1) | undirected as u64));
+            check(unsafe {
+                cz_pagerank_cached(key_hi, key_lo, g.offsets.as_ptr(), g.targets.as_ptr(), g.out_degree.as_ptr(), g.n,
+                                   g.targets.len() as u64, theta, epsilon as f64, iterations as u32, flags, scores.as_mut_ptr(),
+                                   &mut it, &mut err, poison_ptr(&poison), std::ptr::null_mut())
+            }, &poison)?;
+        }
         for (idx, score) in scores.iter().enumerate() {
             out.put(vec![g.indices[idx].clone(), DataValue::from(*score as f64)]);
         }

@@ -1,0 +1,83 @@
+"""Child process of tests/test_gpu_comm.py: the multi-GPU entry points of the C ABI on ONE GPU (RCCL communicators of one
+rank).  Runs in its own process and leaves with os._exit: a process in which BOTH PyTorch and libcozo_gpu have used the
+RCCL shared library was observed to die in the library's static destructors at interpreter exit ("double free or
+corruption", after every check had passed) -- scratch/r2_rccl_exit.py narrows it down.  PyTorch is imported FIRST (the
+order bench.py uses), every buffer handed to a collective is owned by libcozo_gpu."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    from cozo_amd import _lib
+    L = _lib.lib()
+    import torch
+    assert L.cz_init(0) == 0, L.cz_last_error()
+    from cozo_amd import graph as G
+    from cozo_amd.comm import Comm, pagerank_multi
+    from cozo_amd.hnsw import HnswSearch
+    from oracle import oracle as O
+    from tests import util
+    O.build()
+    comm = Comm(Comm.unique_id(), 0, 1)
+    assert comm.rank == 0 and comm.world == 1
+
+    frm, to = util.random_relation(30000, 200000, 3)
+    g = util.graph_from_relation(O, frm, to)
+    for allreduce in (False, True):
+        for tol, iters in ((1e-4, 10), (0.0, 20)):
+            want, want_it, want_err = O.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, tol, iters)
+            plan = G.PageRankPlan(g["ioff"], g["isrc"], g["outdeg"], g["n"], 0, g["n"], 0.85)
+            it, err = comm.pagerank_sharded(plan, g["n"], tol, iters, allreduce_exchange=allreduce)
+            assert it == want_it and np.array_equal(plan.read_scores(), want) and abs(err - want_err) <= 1e-9 * abs(want_err)
+            try:  # cancellation through the collective path
+                comm.pagerank_sharded(plan, g["n"], tol, iters, poison=np.ones(1, dtype=np.uint8))
+                raise AssertionError("a set poison flag must cancel the run")
+            except _lib.ProcessKilled:
+                pass
+            # the bare exchange steps on a library-owned device buffer (the plan's scores): one rank = the identity
+            ptr = plan.scores_ptr()
+            comm.all_gather(ptr, g["n"] * 4)
+            comm.all_reduce_sum_f64(ptr, g["n"] // 2)
+            torch.cuda.synchronize()
+            assert np.array_equal(plan.read_scores(), want)
+            plan.close()
+            s, it2, _ = pagerank_multi(g["ioff"], g["isrc"], g["outdeg"], 1, 0.85, tol, iters, allreduce_exchange=allreduce)
+            assert it2 == want_it and np.array_equal(s, want)
+    print("OK pagerank_sharded / pagerank_multi / collectives", flush=True)
+
+    x = util.vectors(3000, 96, 42, "lowrank")
+    _, flat = util.build_index(O, x, 1, 12, 60)
+    gix = util.gpu_index(flat, "Cosine", 12)
+    q = util.vectors(50, 96, 43, "lowrank")
+    ids, dist, cnt = gix.hnsw_knn_batch(q, HnswSearch(k=10, ef=64))
+    dev = torch.device("cuda:0")
+    qd = torch.from_numpy(q).to(dev)
+    oi = torch.empty((50, 10), dtype=torch.int64, device=dev)
+    od = torch.empty((50, 10), dtype=torch.float64, device=dev)
+    oc = torch.empty(50, dtype=torch.int32, device=dev)
+    comm.hnsw_search_sharded(gix, qd, 50, 10, 64, 1000, oi, od, oc)
+    torch.cuda.synchronize()
+    assert np.array_equal(oi.cpu().numpy(), ids.astype(np.int64) + 1000)
+    assert np.array_equal(od.cpu().numpy(), dist) and np.array_equal(oc.cpu().numpy().astype(np.uint32), cnt)
+    gix.close()
+    print("OK hnsw_search_sharded", flush=True)
+    comm.close()
+    print("ALL OK", flush=True)
+
+
+if __name__ == "__main__":
+    code = 1
+    try:
+        main()
+        code = 0
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(code)

@@ -41,9 +41,10 @@ def test_every_c_symbol_is_declared_with_the_same_arity():
 
 def test_repr_c_structs_match_field_by_field():
     _, rust = _rust_functions()
-    for header, struct in (("cozo_gpu.h", "cz_hnsw_desc"), ("cozo_ingest.h", "czi_rows")):
+    for header, struct in (("cozo_gpu.h", "cz_hnsw_desc"), ("cozo_gpu.h", "cz_pagerank_timing"), ("cozo_gpu.h", "cz_predicate"),
+                           ("cozo_ingest.h", "czi_rows")):
         text = _strip_c(open(os.path.join(ROOT, "include", header)).read())
-        body = re.search(r"typedef struct \{(.*?)\}\s*" + struct + r"\s*;", text, flags=re.S).group(1)
+        body = re.search(r"typedef struct \{([^}]*)\}\s*" + struct + r"\s*;", text, flags=re.S).group(1)
         c_fields = [re.sub(r".*[\s\*]", "", f.strip()) for f in body.split(";") if f.strip()]
         rbody = re.search(r"pub struct " + struct + r"\s*\{(.*?)\}", rust, flags=re.S).group(1)
         r_fields = [f.split(":")[0].replace("pub", "").strip() for f in rbody.split(",") if ":" in f]
@@ -61,3 +62,93 @@ def test_constants_match():
         for name, val in re.findall(r"\b(CZI?_(?:OK|E_[A-Z_]+|L2|COSINE|IP))\s*=\s*(-?\d+)", text):
             m = re.search(r"pub const " + name + r": c_int = (-?\d+);", rust)
             assert m and int(m.group(1)) == int(val), name
+
+
+# ---- type by type: every parameter and the return type of every function ------------------------------------------------
+_C2R = {"void": "c_void", "int": "c_int", "float": "c_float", "double": "c_double", "char": "c_char", "uint8_t": "u8",
+        "uint16_t": "u16", "uint32_t": "u32", "uint64_t": "u64", "int32_t": "i32", "int64_t": "i64", "size_t": "usize"}
+
+
+def _c_type_to_rust(t):
+    """`const uint32_t *const *` -> `*const *const u32`; `cz_comm **` -> `*mut *mut cz_comm`; `const volatile uint8_t *` ->
+    `*const u8` (volatile is not part of a Rust pointer type)."""
+    t = re.sub(r"/\*.*?\*/", "", t).strip()
+    t = re.sub(r"\bvolatile\b", "", t)
+    t = re.sub(r"\[[^\]]*\]", "*", t)  # array parameter = pointer
+    toks = re.findall(r"\*|\w+", t)
+    # split at the stars: base part, then one qualifier set per star (the `const` AFTER a star qualifies that pointer)
+    parts, cur = [], []
+    for tok in toks:
+        if tok == "*":
+            parts.append(cur)
+            cur = []
+        else:
+            cur.append(tok)
+    trailing = cur  # qualifiers after the last star (or the whole type when there is no star)
+    if not parts:
+        base = [x for x in trailing if x not in ("const", "struct", "enum")]
+        assert len(base) == 1, t
+        return _C2R.get(base[0], base[0])
+    base_toks = parts[0]
+    base_const = "const" in base_toks
+    base = [x for x in base_toks if x not in ("const", "struct", "enum")]
+    assert len(base) == 1, t
+    out = _C2R.get(base[0], base[0])
+    # pointer levels, innermost first: level i points at something that is const iff the qualifiers BEFORE its star say so
+    consts = [base_const] + [("const" in p) for p in parts[1:]]
+    for c in consts:
+        out = ("*const " if c else "*mut ") + out
+    return out
+
+
+def _c_signatures(header, prefix):
+    text = _strip_c(open(os.path.join(ROOT, "include", header)).read())
+    out = {}
+    for m in re.finditer(r"([\w \*]+?)\b(" + prefix + r"[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        ret = m.group(1).strip()
+        if "typedef" in ret:
+            continue
+        args = m.group(3).strip()
+        params = []
+        if args not in ("", "void"):
+            for a in args.split(","):
+                a = " ".join(a.split())
+                # drop the parameter name (the last identifier, unless the declaration is a bare type)
+                mm = re.match(r"^(.*?[\*\s])(\w+)(\[[^\]]*\])?$", a)
+                ty = (mm.group(1) + (mm.group(3) or "")) if mm else a
+                params.append(_c_type_to_rust(ty))
+        out[m.group(2)] = (None if ret == "void" else _c_type_to_rust(ret), params)
+    return out
+
+
+def _rust_signatures():
+    text = re.sub(r"//.*", "", open(os.path.join(ROOT, "integration", "rust", "cozo_gpu_sys.rs")).read())
+    out = {}
+    for m in re.finditer(r"pub fn ([a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", text, flags=re.S):
+        params = []
+        for a in m.group(2).split(","):
+            if a.strip():
+                params.append(" ".join(a.split(":", 1)[1].split()))
+        ret = " ".join(m.group(3).split()) if m.group(3) else None
+        out[m.group(1)] = (ret, params)
+    return out
+
+
+def test_every_parameter_and_return_type_matches():
+    """the uncompiled Rust declarations cannot drift from the headers unnoticed: each function's return type and each
+    parameter's type, translated from C (uint32_t -> u32, `const T *` -> *const T, `T **` -> *mut *mut T, ...), must be
+    literally what cozo_gpu_sys.rs declares"""
+    c = {}
+    c.update(_c_signatures("cozo_gpu.h", "cz_"))
+    c.update(_c_signatures("cozo_ingest.h", "czi_"))
+    rust = _rust_signatures()
+    assert sorted(c) == sorted(rust)
+    bad = []
+    for name, (ret, params) in sorted(c.items()):
+        rret, rparams = rust[name]
+        if ret != rret:
+            bad.append((name, "return", ret, rret))
+        for i, (a, b) in enumerate(zip(params, rparams)):
+            if a != b:
+                bad.append((name, i, a, b))
+    assert not bad, bad
