@@ -446,12 +446,40 @@ sssp_seed_kernel(const uint32_t *__restrict__ starts, uint32_t n, uint32_t N, un
     q[atomicAdd(count, 1u)] = ((unsigned long long)i << 32) | st;
 }
 
+// Which tight predecessor ends up as a node's parent depends on which CAS came first.  The costs do not, so the parents
+// are made canonical afterwards: among the predecessors u with dist[u] + w == dist[v] and dist[u] < dist[v] the smallest
+// id wins (one pass over the edges per source).  A node whose tight predecessors all sit at its own cost (zero-weight or
+// absorbed edges) keeps the parent the relaxation found: that one is acyclic by construction, a smallest-id rule there
+// could close a cycle.  (The reference's own choice among equal-cost predecessors is its heap's pop order.)
 __global__ void __launch_bounds__(kT)
-sssp_unpack_kernel(const unsigned long long *__restrict__ dp, uint64_t n, float *__restrict__ dist, uint32_t *__restrict__ parent) {
+sssp_canon_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t N,
+                  uint32_t n_src, const unsigned long long *__restrict__ dp, uint32_t *__restrict__ canon) {
+    const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes;
+    const uint64_t ngroups = (uint64_t)gridDim.x * blockDim.x / kSsspLanes, total = (uint64_t)n_src * N;
+    for (uint64_t i = group; i < total; i += ngroups) {
+        const uint32_t si = (uint32_t)(i / N), u = (uint32_t)(i % N);
+        const unsigned long long *dps = dp + (size_t)si * N;
+        const uint32_t cu = (uint32_t)(dps[u] >> 32);
+        if (cu == 0x7F800000u) continue;  // unreached
+        const float du = __uint_as_float(cu);
+        const uint32_t e1 = off[u + 1];
+        for (uint32_t e = off[u] + glane; e < e1; e += kSsspLanes) {
+            const uint32_t v = tgt[e];
+            const uint32_t cv = (uint32_t)(dps[v] >> 32);
+            if (cu < cv && __float_as_uint(du + w[e]) == cv) atomicMin(&canon[(size_t)si * N + v], u);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kT)
+sssp_unpack_kernel(const unsigned long long *__restrict__ dp, const uint32_t *__restrict__ canon, uint64_t n,
+                   float *__restrict__ dist, uint32_t *__restrict__ parent) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const unsigned long long c = dp[i];
         dist[i] = __uint_as_float((uint32_t)(c >> 32));
-        parent[i] = (uint32_t)c;
+        const uint32_t cp = canon[i];
+        parent[i] = cp != CZ_NONE ? cp : (uint32_t)c;
     }
 }
 
@@ -779,7 +807,10 @@ extern "C" int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets,
             round++;
             if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
         }
-        hipLaunchKernelGGL(sssp_unpack_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, d_dp.p, nsN, d_dist.p, d_parent.p);
+        CZ_HIP(hipMemsetAsync(d_qtag.p, 0xFF, nsN * 4, s));  // the round tags are done with: the array holds the canonical parents
+        hipLaunchKernelGGL(sssp_canon_kernel, dim3(grid_for(nsN * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, d_w.p, N, ns,
+                           d_dp.p, d_qtag.p);
+        hipLaunchKernelGGL(sssp_unpack_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, d_dp.p, d_qtag.p, nsN, d_dist.p, d_parent.p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sssp launch: %s", hipGetErrorString(e));
         CZ_HIP(hipMemcpy(dist + (size_t)s0 * N, d_dist.p, nsN * 4, hipMemcpyDeviceToHost));
