@@ -42,14 +42,21 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured 
 EF_LADDER = [16, 24, 32, 48, 64, 80, 96, 112, 128, 144, 160, 176, 192, 224, 256, 320, 384, 512, 768, 1024]
 
 
-def kernel_source_hash():
-    """sha256 over the device sources: ties profiles/pmc_traffic.json to the kernels it was measured on"""
+PMC_SOURCES = {  # the device sources each PMC entry of profiles/pmc_traffic.json was measured on
+    "hnsw_knn": ["hnsw_kernels.cuh", "distance.cuh", "hnsw_api.hip", "hnsw_index.h", "common.h"],
+    "distance_batch": ["distance.cuh", "hnsw_api.hip", "common.h"],
+    "pagerank_blocked": ["pagerank.hip", "common.h"],
+    "pagerank_gather": ["pagerank.hip", "common.h"],
+}
+
+
+def kernel_source_hash(key):
+    """sha256 over the device sources behind one PMC entry: ties profiles/pmc_traffic.json to the kernels it was measured on"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "cozo_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".cuh", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in PMC_SOURCES[key]:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -63,7 +70,7 @@ def pmc_traffic(key, world):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             d = json.load(f)
-        if d.get("kernel_source_hash") != kernel_source_hash():
+        if d[key].get("source_hash") != kernel_source_hash(key):
             return None
         return d[key]["bytes_per_launch"]
     except Exception:

@@ -13,6 +13,7 @@
 // a gfx950 device every search throws GpuError.
 #pragma once
 #include <cmath>
+#include <map>
 #include <optional>
 #include <string>
 #include <vector>
@@ -57,11 +58,23 @@ struct CompoundKey {
     int32_t sub;     // -1, or the position inside a List of vectors
 };
 
+// one term of a filter that is a conjunction of `base column OP constant` over numeric columns (what the shim extracts from
+// the filter bytecode; the reference evaluates the same comparisons on the ef candidate rows, hnsw.rs:994-998)
+struct ColumnPredicate {
+    size_t column;     // position in the base relation's row
+    int op;            // cz_cmp_op
+    DataValue constant;  // Int or Float
+};
+
 struct HnswSearch {
     size_t k = 10, ef = 10;
     bool bind_field = false, bind_field_idx = false, bind_distance = false, bind_vector = false;
     std::optional<double> radius;
     std::optional<TuplePredicate> filter;  // the compiled filter expression over the bound result tuple
+    // evaluated on the DEVICE over all ef candidates (cz_hnsw_search_filtered) when `filter` is absent, there are 1..4 of
+    // them and every value of the named columns is an Int (or every value a Float); otherwise on the host rows with the
+    // reference's comparison semantics (data/functions.rs:298-380)
+    std::vector<ColumnPredicate> predicates;
 };
 
 class GpuHnswIndex {
@@ -70,6 +83,9 @@ class GpuHnswIndex {
     const BaseRelation *base_ = nullptr;
     std::vector<CompoundKey> nodes_;  // node id -> CompoundKey
     uint64_t build_n_dist_ = 0;
+    // per base column: the device copy of its per-node values (nullptr: the column is not purely Int / purely Float)
+    mutable std::map<size_t, cz_column *> columns_;
+    cz_column *device_column(size_t column) const;
 
 public:
     GpuHnswIndex() = default;

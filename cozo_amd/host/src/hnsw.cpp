@@ -1,6 +1,8 @@
 // hnsw.cpp -- HNSW half of the C++ host mirror (see hnsw.hpp for the reference map).
 #include "cozo_host/hnsw.hpp"
 
+#include <cstring>
+
 #include <algorithm>
 #include <memory>
 
@@ -34,11 +36,17 @@ GpuHnswIndex &GpuHnswIndex::operator=(GpuHnswIndex &&o) noexcept {
         base_ = o.base_;
         nodes_ = std::move(o.nodes_);
         build_n_dist_ = o.build_n_dist_;
+        for (auto &kv : columns_)
+            if (kv.second) cz_column_destroy(kv.second);
+        columns_ = std::move(o.columns_);
+        o.columns_.clear();
     }
     return *this;
 }
 
 GpuHnswIndex::~GpuHnswIndex() {
+    for (auto &kv : columns_)
+        if (kv.second) cz_column_destroy(kv.second);
     if (h_) cz_hnsw_index_destroy(h_);
 }
 
@@ -178,6 +186,77 @@ StoredRows GpuHnswIndex::index_rows(uint64_t relation_id) const {
     return out;
 }
 
+// op_lt / op_le / op_eq / op_ge / op_gt / op_neq on two numbers (data/functions.rs:298-380): Int with Int as integers,
+// Float with Float by total order (data/value.rs:595), mixed pairs as f64; anything else is the reference's error
+static bool compare_values(const DataValue &a, int op, const DataValue &b) {
+    int64_t ai = 0, bi = 0;
+    double af = 0, bf = 0;
+    const bool a_int = a.is_int(), b_int = b.is_int();
+    if (!a.is_num() || !b.is_num()) throw CozoError("", "comparison can only be done between the same datatypes");
+    if (a_int) a.get_int(&ai);
+    else a.get_float(&af);
+    if (b_int) b.get_int(&bi);
+    else b.get_float(&bf);
+    int c;
+    if (a_int && b_int) c = ai < bi ? -1 : (ai > bi ? 1 : 0);
+    else if (!a_int && !b_int) {
+        auto key = [](double d) {
+            int64_t u;
+            memcpy(&u, &d, 8);
+            return u ^ (int64_t)((uint64_t)(u >> 63) >> 1);
+        };
+        const int64_t ka = key(af), kb = key(bf);
+        c = ka < kb ? -1 : (ka > kb ? 1 : 0);
+    } else {
+        const double l = a_int ? (double)ai : af, r = b_int ? (double)bi : bf;
+        switch (op) {
+            case CZ_OP_LT: return l < r;
+            case CZ_OP_LE: return l <= r;
+            case CZ_OP_EQ: return l == r;
+            case CZ_OP_GE: return l >= r;
+            case CZ_OP_GT: return l > r;
+            default: return l != r;
+        }
+    }
+    switch (op) {
+        case CZ_OP_LT: return c < 0;
+        case CZ_OP_LE: return c <= 0;
+        case CZ_OP_EQ: return c == 0;
+        case CZ_OP_GE: return c >= 0;
+        case CZ_OP_GT: return c > 0;
+        default: return c != 0;
+    }
+}
+
+cz_column *GpuHnswIndex::device_column(size_t column) const {
+    auto it = columns_.find(column);
+    if (it != columns_.end()) return it->second;
+    cz_column *col = nullptr;
+    std::vector<int64_t> iv;
+    std::vector<double> fv;
+    bool all_int = true, all_float = true;
+    for (const CompoundKey &ck : nodes_) {
+        const Tuple &t = base_->rows[ck.row];
+        int64_t i = 0;
+        double f = 0;
+        if (column >= t.size()) {
+            all_int = all_float = false;
+            break;
+        }
+        const bool is_float = t[column].is_float() && t[column].get_float(&f);
+        const bool is_int = t[column].is_int() && t[column].get_int(&i);
+        all_int = all_int && is_int;
+        all_float = all_float && is_float;
+        if (!all_int && !all_float) break;
+        if (is_int) iv.push_back(i);
+        else fv.push_back(f);
+    }
+    if (!nodes_.empty() && all_int) check_gpu(cz_column_upload(iv.data(), (uint32_t)iv.size(), CZ_COL_I64, &col));
+    else if (!nodes_.empty() && all_float) check_gpu(cz_column_upload(fv.data(), (uint32_t)fv.size(), CZ_COL_F64, &col));
+    columns_[column] = col;
+    return col;
+}
+
 void GpuHnswIndex::search_raw(const float *queries, uint32_t B, uint32_t k, uint32_t ef, std::vector<uint32_t> &ids,
                               std::vector<double> &dist, std::vector<uint32_t> &count, const Poison &poison,
                               const std::optional<double> &radius) const {
@@ -201,12 +280,38 @@ std::vector<std::vector<Tuple>> GpuHnswIndex::hnsw_knn_batch(const std::vector<c
         std::copy(queries[i]->begin(), queries[i]->end(), q.begin() + (size_t)i * manifest_.vec_dim);
     }
     if (nodes_.empty() || B == 0) return result;
+    // column predicates: on the device when every named column is purely Int or purely Float over the indexed rows
+    std::vector<cz_predicate> dev_preds;
+    bool on_device = !config.predicates.empty() && !config.filter && config.predicates.size() <= 4;
+    for (const ColumnPredicate &p : config.predicates) {
+        if (!on_device) break;
+        cz_column *c = device_column(p.column);
+        int64_t iv = 0;
+        double fv = 0;
+        const bool is_int = p.constant.is_int();
+        if (is_int) p.constant.get_int(&iv);
+        if (!c || (!is_int && !(p.constant.is_float() && p.constant.get_float(&fv))) || p.op < CZ_OP_LT || p.op > CZ_OP_NE) {
+            on_device = false;
+            break;
+        }
+        dev_preds.push_back(cz_predicate{c, p.op, is_int ? CZ_COL_I64 : CZ_COL_F64, fv, iv});
+    }
+    const bool host_filter = config.filter.has_value() || (!config.predicates.empty() && !on_device);
     // without a filter the candidate set is cut to k before rows are fetched; with one, all ef survive until the
     // filter has run (:943-947) -- ask the device for the same number of rows
-    const uint32_t kk = (uint32_t)(config.filter ? config.ef : std::min(config.k, config.ef));
+    const uint32_t kk = (uint32_t)(host_filter ? config.ef : std::min(config.k, config.ef));
     std::vector<uint32_t> ids, count;
     std::vector<double> dist;
-    search_raw(q.data(), B, kk, (uint32_t)config.ef, ids, dist, count, poison, config.radius);
+    if (on_device) {
+        ids.assign((size_t)B * kk, CZ_NONE);
+        dist.assign((size_t)B * kk, 0.0);
+        count.assign(B, 0);
+        check_gpu(cz_hnsw_search_filtered(h_, q.data(), B, kk, (uint32_t)config.ef, config.radius ? 1 : 0,
+                                          config.radius ? *config.radius : 0.0, dev_preds.data(), (uint32_t)dev_preds.size(),
+                                          ids.data(), dist.data(), count.data(), nullptr, poison.flag_ptr(), 0, nullptr));
+    } else {
+        search_raw(q.data(), B, kk, (uint32_t)config.ef, ids, dist, count, poison, config.radius);
+    }
     for (uint32_t i = 0; i < B; i++) {
         std::vector<Tuple> &ret = result[i];
         for (uint32_t j = 0; j < count[i]; j++) {
@@ -224,6 +329,11 @@ std::vector<std::vector<Tuple>> GpuHnswIndex::hnsw_knn_batch(const std::vector<c
                 else cand.push_back((*field_val.get_slice())[(size_t)ck.sub]);
             }
             if (config.filter && !(*config.filter)(cand)) continue;  // :994-998
+            if (!on_device && !config.predicates.empty()) {  // the same comparisons on the host row (op_lt .. op_neq)
+                bool ok = true;
+                for (const ColumnPredicate &p : config.predicates) ok = ok && compare_values(cand[p.column], p.op, p.constant);
+                if (!ok) continue;
+            }
             ret.push_back(std::move(cand));
         }
         if (ret.size() > config.k) ret.resize(config.k);  // :1005-1006 (rows already ascending by distance)

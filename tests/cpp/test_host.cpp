@@ -942,6 +942,29 @@ static void gpu_hnsw_search_ra() {
         }
     }
     CHECK(ok && pos == got.size());
+    // the same search with the comparison handed over as column predicates: the key column is purely Int, so they are
+    // evaluated on the device over all ef candidates (cz_hnsw_search_filtered) -- `k >= 1000 and k != 1500`, radius as before;
+    // rows must equal the host-filter route's
+    {
+        HnswSearchRA dev_ra{&ix, HnswSearch{}, 1}, host_ra{&ix, HnswSearch{}, 1};
+        for (HnswSearchRA *r : {&dev_ra, &host_ra}) {
+            r->hnsw_search.k = 5;
+            r->hnsw_search.ef = 30;
+            r->hnsw_search.bind_distance = true;
+            r->hnsw_search.radius = 1.2;
+        }
+        dev_ra.hnsw_search.predicates = {ColumnPredicate{0, CZ_OP_GE, DataValue((int64_t)1000)}, ColumnPredicate{0, CZ_OP_NE, DataValue(1500.0)}};
+        host_ra.hnsw_search.filter = [](const Tuple &t) {
+            int64_t key;
+            return t[0].get_int(&key) && key >= 1000 && key != 1500;
+        };
+        const std::vector<Tuple> a = dev_ra.iter(parent, Poison()), b = host_ra.iter(parent, Poison());
+        CHECK(!a.empty() && a == b);
+        // a predicate on the vector column cannot go to the device: same rows through the host comparison ... which raises the
+        // reference's error for a non-numeric value
+        dev_ra.hnsw_search.predicates = {ColumnPredicate{1, CZ_OP_GE, DataValue((int64_t)0)}};
+        CHECK((throws<CozoError>([&] { dev_ra.iter(parent, Poison()); })));
+    }
     CHECK((throws<CozoError>([&] { ra.iter({T({DataValue(1), DataValue("not a vector")})}, Poison()); })));
     CHECK((throws<CozoError>([&] { ix.hnsw_knn(std::vector<float>(dim + 1, 0.f), HnswSearch{}, Poison()); })));
     orc_hnsw_free(ob);
