@@ -72,6 +72,41 @@ class Comm:
                                                 ptr(out_ids), ptr(out_dist), ptr(out_count), C.c_void_p(stream)))
 
 
+def _shard_csr(off_local, tgt):
+    off_local = np.ascontiguousarray(off_local, dtype=np.uint32)
+    tgt = np.ascontiguousarray(tgt, dtype=np.uint32)
+    return off_local, tgt
+
+
+def bfs_sharded(comm: Comm, off_local, tgt, n: int, row_begin: int, row_end: int, starts, goals=None, share_visited=False,
+                want_depth=False, want_order=False, poison=None):
+    """ONE BFS over a vertex-partitioned graph, collectively (cz_bfs_sharded): this rank passes the out-adjacency of
+    [row_begin, row_end); outputs as cozo_amd.graph.bfs, identical on every rank and to the whole graph's on one GPU."""
+    off_local, tgt = _shard_csr(off_local, tgt)
+    starts = np.ascontiguousarray(starts, dtype=np.uint32)
+    g = None if goals is None else np.ascontiguousarray(goals, dtype=np.uint32)
+    parent = np.full((starts.size, n), _lib.CZ_NONE, dtype=np.uint32)
+    depth = np.full((starts.size, n), _lib.CZ_NONE, dtype=np.uint32) if want_depth else None
+    order = np.full((starts.size, n), _lib.CZ_NONE, dtype=np.uint32) if want_order else None
+    reached = np.zeros(starts.size, dtype=np.uint32)
+    check(_lib.lib().cz_bfs_sharded(comm._h, ptr(off_local), ptr(tgt), n, row_begin, row_end, tgt.size, ptr(starts), starts.size,
+                                    ptr(g), 0 if g is None else g.size, int(share_visited), ptr(parent), ptr(depth), ptr(order),
+                                    ptr(reached), ptr(poison)))
+    return parent, depth, order, reached
+
+
+def sssp_sharded(comm: Comm, off_local, tgt, weights, n: int, row_begin: int, row_end: int, starts, poison=None):
+    """ONE SSSP per start over a vertex-partitioned graph, collectively (cz_sssp_sharded) -> (dist f32, parent) [starts][n]"""
+    off_local, tgt = _shard_csr(off_local, tgt)
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    starts = np.ascontiguousarray(starts, dtype=np.uint32)
+    dist = np.empty((starts.size, n), dtype=np.float32)
+    parent = np.empty((starts.size, n), dtype=np.uint32)
+    check(_lib.lib().cz_sssp_sharded(comm._h, ptr(off_local), ptr(tgt), ptr(w), n, row_begin, row_end, tgt.size, ptr(starts),
+                                     starts.size, ptr(dist), ptr(parent), ptr(poison)))
+    return dist, parent
+
+
 def pagerank_multi(in_off, in_src, out_deg, n_gpus: int, damping=0.85, tolerance=1e-4, max_iter=10, relaxed=False,
                    allreduce_exchange=False, poison=None):
     """cz_pagerank on n_gpus devices of THIS process (one host thread + one RCCL communicator per GPU)."""

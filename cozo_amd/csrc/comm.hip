@@ -28,7 +28,7 @@ typedef struct {
 typedef enum { ncclSuccess = 0 } ncclResult_t;
 typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6,
                ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
-typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
 }
 
 namespace {
@@ -103,6 +103,21 @@ struct cz_comm {
     int rank = 0, world = 1, device = 0;
     ncclComm_t nccl = nullptr;
 };
+
+namespace cz {
+int comm_world(const cz_comm *c) { return c ? c->world : 0; }
+int comm_rank(const cz_comm *c) { return c ? c->rank : -1; }
+int comm_all_reduce(cz_comm *c, void *buf, size_t count, int dtype, int op, hipStream_t stream) {
+    if (!c || !buf) return set_error(CZ_E_INVALID, "null argument");
+    if (c->world == 1 || count == 0) return CZ_OK;
+    Rccl *R = nullptr;
+    int rc = need_rccl(&R);
+    if (rc) return rc;
+    static const ncclDataType_t types[] = {ncclUint32, ncclUint64, ncclFloat32, ncclFloat64};
+    CZ_NCCL(R, R->AllReduce(buf, buf, count, types[dtype], op == COMM_MIN ? ncclMin : ncclSum, c->nccl, stream));
+    return CZ_OK;
+}
+}  // namespace cz
 
 extern "C" int cz_comm_unique_id(uint8_t *id) {
     if (!id) return cz::set_error(CZ_E_INVALID, "null id");

@@ -29,6 +29,13 @@ extern thread_local int t_device_override;
 
 static inline bool poisoned(const volatile uint8_t *p) { return p && *p; }
 
+// collectives of a cz_comm for the other translation units (comm.hip): in place, stream-ordered; one rank = the identity
+enum { COMM_U32 = 0, COMM_U64 = 1, COMM_F32 = 2, COMM_F64 = 3 };
+enum { COMM_SUM = 0, COMM_MIN = 1 };
+int comm_all_reduce(cz_comm *c, void *buf_dev, size_t count, int dtype, int op, hipStream_t stream);
+int comm_world(const cz_comm *c);
+int comm_rank(const cz_comm *c);
+
 // RAII device buffer (freed on scope exit unless released)
 template <typename T>
 struct DevBuf {

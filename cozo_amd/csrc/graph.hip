@@ -125,13 +125,15 @@ __device__ __forceinline__ unsigned int bfs_group_mask(unsigned long long ballot
 
 __global__ void __launch_bounds__(kT)
 bfs_claim_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
-                 uint32_t fsize, const uint32_t *__restrict__ depth, uint32_t *__restrict__ claim) {
+                 uint32_t fsize, const uint32_t *__restrict__ depth, uint32_t *__restrict__ claim, uint32_t rb, uint32_t re) {
+    // [rb, re): the nodes whose adjacency this device holds (`off` is relative to rb); the whole graph on one GPU
     const uint32_t glane = threadIdx.x & (kBfsLanes - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kBfsLanes, ngroups = gridDim.x * blockDim.x / kBfsLanes;
     for (uint32_t i = group; i < fsize; i += ngroups) {
         const uint32_t u = frontier[i];
-        const uint32_t e1 = off[u + 1];
-        for (uint32_t e = off[u] + glane; e < e1; e += kBfsLanes) {
+        if (u < rb || u >= re) continue;
+        const uint32_t e1 = off[u - rb + 1];
+        for (uint32_t e = off[u - rb] + glane; e < e1; e += kBfsLanes) {
             const uint32_t v = tgt[e];
             if (depth[v] == CZ_NONE) atomicMin(&claim[v], i);
         }
@@ -141,16 +143,17 @@ bfs_claim_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
 __global__ void __launch_bounds__(kT)
 bfs_count_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
                  uint32_t fsize, const uint32_t *__restrict__ depth, const uint32_t *__restrict__ claim,
-                 uint32_t *__restrict__ cnt) {
+                 uint32_t *__restrict__ cnt, uint32_t rb, uint32_t re) {
     const int lane = threadIdx.x & 63;
     const uint32_t glane = threadIdx.x & (kBfsLanes - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kBfsLanes, ngroups = gridDim.x * blockDim.x / kBfsLanes;
     const uint32_t rounds = (fsize + ngroups - 1) / ngroups;  // every group of a wave runs the same trip count (ballots)
     for (uint32_t r = 0; r < rounds; r++) {
         const uint32_t i = group + r * ngroups;
-        const bool live = i < fsize;
+        bool live = i < fsize;
         const uint32_t u = live ? frontier[i] : 0;
-        const uint32_t e0 = live ? off[u] : 0, e1 = live ? off[u + 1] : 0;
+        live = live && u >= rb && u < re;
+        const uint32_t e0 = live ? off[u - rb] : 0, e1 = live ? off[u - rb + 1] : 0;
         uint32_t c = 0;
         // the widest list among the wave's groups decides the trip count
         uint32_t len = e1 - e0, maxlen = len;
@@ -173,16 +176,17 @@ __global__ void __launch_bounds__(kT)
 bfs_emit_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
                 uint32_t fsize, uint32_t *__restrict__ depth, const uint32_t *__restrict__ claim,
                 const uint32_t *__restrict__ pos, uint32_t *__restrict__ next, uint32_t *__restrict__ parent,
-                uint32_t next_depth) {
+                uint32_t next_depth, uint32_t rb, uint32_t re, uint32_t plus_one) {
     const int lane = threadIdx.x & 63;
     const uint32_t glane = threadIdx.x & (kBfsLanes - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kBfsLanes, ngroups = gridDim.x * blockDim.x / kBfsLanes;
     const uint32_t rounds = (fsize + ngroups - 1) / ngroups;
     for (uint32_t r = 0; r < rounds; r++) {
         const uint32_t i = group + r * ngroups;
-        const bool live = i < fsize;
+        bool live = i < fsize;
         const uint32_t u = live ? frontier[i] : 0;
-        const uint32_t e0 = live ? off[u] : 0, e1 = live ? off[u + 1] : 0;
+        live = live && u >= rb && u < re;
+        const uint32_t e0 = live ? off[u - rb] : 0, e1 = live ? off[u - rb + 1] : 0;
         uint32_t o = live ? pos[i] : 0;
         uint32_t maxlen = e1 - e0;
 #pragma unroll
@@ -199,7 +203,7 @@ bfs_emit_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ t
             }
             const unsigned int m = bfs_group_mask(__ballot(hit), lane);
             if (hit) {
-                next[o + __popc(m & ((1u << glane) - 1u))] = v;
+                next[o + __popc(m & ((1u << glane) - 1u))] = v + plus_one;
                 parent[v] = u;
                 depth[v] = next_depth;
             }
@@ -453,18 +457,20 @@ sssp_seed_kernel(const uint32_t *__restrict__ starts, uint32_t n, uint32_t N, un
 // could close a cycle.  (The reference's own choice among equal-cost predecessors is its heap's pop order.)
 __global__ void __launch_bounds__(kT)
 sssp_canon_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t N,
-                  uint32_t n_src, const unsigned long long *__restrict__ dp, uint32_t *__restrict__ canon) {
+                  uint32_t n_src, const unsigned long long *__restrict__ dp, uint32_t *__restrict__ canon, uint32_t rb,
+                  uint32_t re) {
     const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
     const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes;
     const uint64_t ngroups = (uint64_t)gridDim.x * blockDim.x / kSsspLanes, total = (uint64_t)n_src * N;
     for (uint64_t i = group; i < total; i += ngroups) {
         const uint32_t si = (uint32_t)(i / N), u = (uint32_t)(i % N);
+        if (u < rb || u >= re) continue;  // (a vertex-partitioned graph: this device holds the adjacency of [rb, re) only)
         const unsigned long long *dps = dp + (size_t)si * N;
         const uint32_t cu = (uint32_t)(dps[u] >> 32);
         if (cu == 0x7F800000u) continue;  // unreached
         const float du = __uint_as_float(cu);
-        const uint32_t e1 = off[u + 1];
-        for (uint32_t e = off[u] + glane; e < e1; e += kSsspLanes) {
+        const uint32_t e1 = off[u - rb + 1];
+        for (uint32_t e = off[u - rb] + glane; e < e1; e += kSsspLanes) {
             const uint32_t v = tgt[e];
             const uint32_t cv = (uint32_t)(dps[v] >> 32);
             if (cu < cv && __float_as_uint(du + w[e]) == cv) atomicMin(&canon[(size_t)si * N + v], u);
@@ -548,13 +554,13 @@ extern "C" int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, 
                 if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
                 const uint32_t *fr = d_order.p + lo;
                 const int g = grid_for((uint64_t)fsize * kBfsLanes);  // a 16-lane group per frontier node
-                hipLaunchKernelGGL(bfs_claim_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, fr, fsize, d_depth.p, d_claim.p);
+                hipLaunchKernelGGL(bfs_claim_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, fr, fsize, d_depth.p, d_claim.p, 0u, N);
                 hipLaunchKernelGGL(bfs_count_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, fr, fsize, d_depth.p, d_claim.p,
-                                   d_cnt.p);
+                                   d_cnt.p, 0u, N);
                 rc = exclusive_scan(d_cnt.p, d_pos.p, fsize, d_misc.p, d_scratch.p, s);
                 if (rc) return rc;
                 hipLaunchKernelGGL(bfs_emit_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, fr, fsize, d_depth.p, d_claim.p,
-                                   d_pos.p, d_order.p + lo + fsize, d_parent.p, level + 1);
+                                   d_pos.p, d_order.p + lo + fsize, d_parent.p, level + 1, 0u, N, 0u);
                 CZ_HIP(hipMemsetAsync(d_misc.p + 1, 0, 4, s));
                 if (goals)
                     hipLaunchKernelGGL(bfs_goals_left_kernel, dim3(grid_for(n_goals)), dim3(kT), 0, s, d_goals.p, n_goals, N,
@@ -809,12 +815,334 @@ extern "C" int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets,
         }
         CZ_HIP(hipMemsetAsync(d_qtag.p, 0xFF, nsN * 4, s));  // the round tags are done with: the array holds the canonical parents
         hipLaunchKernelGGL(sssp_canon_kernel, dim3(grid_for(nsN * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, d_w.p, N, ns,
-                           d_dp.p, d_qtag.p);
+                           d_dp.p, d_qtag.p, 0u, N);
         hipLaunchKernelGGL(sssp_unpack_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, d_dp.p, d_qtag.p, nsN, d_dist.p, d_parent.p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sssp launch: %s", hipGetErrorString(e));
         CZ_HIP(hipMemcpy(dist + (size_t)s0 * N, d_dist.p, nsN * 4, hipMemcpyDeviceToHost));
         CZ_HIP(hipMemcpy(parent + (size_t)s0 * N, d_parent.p, nsN * 4, hipMemcpyDeviceToHost));
+    }
+    return CZ_OK;
+}
+
+// =====================================================================================================================
+// ONE traversal over a vertex-partitioned graph (third row): the loops of sharded_traversal.hpp
+// over these kernels + the communicator's all-reduces.  Rank r holds the out-adjacency of [row_begin, row_end) (offsets
+// relative to row_begin); every per-node array is full length on every rank.
+// =====================================================================================================================
+#include "sharded_traversal.hpp"
+
+namespace {
+
+__global__ void __launch_bounds__(kT)
+bfs_commit_kernel(const uint32_t *__restrict__ buf, uint32_t total, uint32_t *__restrict__ order_at, uint32_t *__restrict__ depth,
+                  uint32_t next_depth) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        const uint32_t v = buf[j] - 1u;  // written as id + 1 by exactly one rank, 0 by the others: the sum is id + 1
+        order_at[j] = v;
+        depth[v] = next_depth;
+    }
+}
+
+struct HipShardedBfs {
+    cz_comm *comm;
+    hipStream_t s;
+    uint32_t N, rb, re;
+    const uint32_t *goals_host;
+    uint32_t n_goals;
+    cz::DevBuf<uint32_t> off, tgt, depth, parent, claim, order, cnt, pos, scratch, buf, misc, goals;
+
+    int alloc(const uint32_t *h_off, const uint32_t *h_tgt, uint64_t e_local) {
+        const uint32_t rows = re - rb;
+        CZ_HIP(off.alloc((size_t)rows + 1));
+        CZ_HIP(tgt.alloc(e_local));
+        CZ_HIP(depth.alloc(N));
+        CZ_HIP(parent.alloc(N));
+        CZ_HIP(claim.alloc(N));
+        CZ_HIP(order.alloc((size_t)N + 1));
+        CZ_HIP(cnt.alloc(N));
+        CZ_HIP(pos.alloc(N));
+        CZ_HIP(buf.alloc(N));
+        CZ_HIP(scratch.alloc(scan_scratch_words(N)));
+        CZ_HIP(misc.alloc(4));
+        CZ_HIP(hipMemcpy(off.p, h_off, ((size_t)rows + 1) * 4, hipMemcpyHostToDevice));
+        if (e_local) CZ_HIP(hipMemcpy(tgt.p, h_tgt, e_local * 4, hipMemcpyHostToDevice));
+        if (goals_host && n_goals) {
+            CZ_HIP(goals.alloc(n_goals));
+            CZ_HIP(hipMemcpy(goals.p, goals_host, (size_t)n_goals * 4, hipMemcpyHostToDevice));
+        }
+        CZ_HIP(hipMemsetAsync(depth.p, 0xFF, (size_t)N * 4, s));
+        CZ_HIP(hipMemsetAsync(claim.p, 0xFF, (size_t)N * 4, s));
+        return CZ_OK;
+    }
+    int any_poisoned(bool mine, bool *any) {
+        const uint32_t v = mine ? 1u : 0u;
+        CZ_HIP(hipMemcpyAsync(misc.p + 2, &v, 4, hipMemcpyHostToDevice, s));
+        int rc = cz::comm_all_reduce(comm, misc.p + 2, 1, cz::COMM_U32, cz::COMM_SUM, s);
+        if (rc) return rc;
+        uint32_t h = 0;
+        CZ_HIP(hipMemcpyAsync(&h, misc.p + 2, 4, hipMemcpyDeviceToHost, s));
+        CZ_HIP(hipStreamSynchronize(s));
+        *any = h != 0;
+        return CZ_OK;
+    }
+    int bfs_reset(bool keep_visited) {
+        CZ_HIP(hipMemsetAsync(parent.p, 0xFF, (size_t)N * 4, s));
+        if (!keep_visited) {
+            CZ_HIP(hipMemsetAsync(depth.p, 0xFF, (size_t)N * 4, s));
+            CZ_HIP(hipMemsetAsync(claim.p, 0xFF, (size_t)N * 4, s));
+        }
+        return CZ_OK;
+    }
+    int bfs_seed(uint32_t start, bool *already) {
+        uint32_t d = 0;
+        CZ_HIP(hipMemcpyAsync(&d, depth.p + start, 4, hipMemcpyDeviceToHost, s));
+        CZ_HIP(hipStreamSynchronize(s));
+        *already = d != CZ_NONE;
+        if (*already) return CZ_OK;
+        hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, s, depth.p, start, 0u);
+        hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, s, order.p, 0u, start);
+        return CZ_OK;
+    }
+    int bfs_claim(uint32_t lo, uint32_t fsize) {
+        hipLaunchKernelGGL(bfs_claim_kernel, dim3(grid_for((uint64_t)fsize * kBfsLanes)), dim3(kT), 0, s, off.p, tgt.p, order.p + lo,
+                           fsize, depth.p, claim.p, rb, re);
+        return CZ_OK;
+    }
+    int reduce_claim() { return cz::comm_all_reduce(comm, claim.p, N, cz::COMM_U32, cz::COMM_MIN, s); }
+    int bfs_count(uint32_t lo, uint32_t fsize) {
+        CZ_HIP(hipMemsetAsync(cnt.p, 0, (size_t)fsize * 4, s));
+        hipLaunchKernelGGL(bfs_count_kernel, dim3(grid_for((uint64_t)fsize * kBfsLanes)), dim3(kT), 0, s, off.p, tgt.p, order.p + lo,
+                           fsize, depth.p, claim.p, cnt.p, rb, re);
+        return CZ_OK;
+    }
+    int reduce_counts(uint32_t fsize) { return cz::comm_all_reduce(comm, cnt.p, fsize, cz::COMM_U32, cz::COMM_SUM, s); }
+    int bfs_scan(uint32_t fsize, uint32_t *total) {
+        int rc = exclusive_scan(cnt.p, pos.p, fsize, misc.p, scratch.p, s);
+        if (rc) return rc;
+        CZ_HIP(hipMemcpyAsync(total, misc.p, 4, hipMemcpyDeviceToHost, s));
+        CZ_HIP(hipStreamSynchronize(s));
+        return CZ_OK;
+    }
+    int bfs_emit(uint32_t lo, uint32_t fsize, uint32_t total, uint32_t next_depth) {
+        if (total) CZ_HIP(hipMemsetAsync(buf.p, 0, (size_t)total * 4, s));
+        hipLaunchKernelGGL(bfs_emit_kernel, dim3(grid_for((uint64_t)fsize * kBfsLanes)), dim3(kT), 0, s, off.p, tgt.p, order.p + lo,
+                           fsize, depth.p, claim.p, pos.p, buf.p, parent.p, next_depth, rb, re, 1u);
+        return CZ_OK;
+    }
+    int reduce_next(uint32_t total) { return cz::comm_all_reduce(comm, buf.p, total, cz::COMM_U32, cz::COMM_SUM, s); }
+    int bfs_commit(uint32_t at, uint32_t total, uint32_t next_depth) {
+        if (total)
+            hipLaunchKernelGGL(bfs_commit_kernel, dim3(grid_for(total)), dim3(kT), 0, s, buf.p, total, order.p + at, depth.p, next_depth);
+        return CZ_OK;
+    }
+    int goals_left(uint32_t start, uint32_t *left) {
+        CZ_HIP(hipMemsetAsync(misc.p + 1, 0, 4, s));
+        hipLaunchKernelGGL(bfs_goals_left_kernel, dim3(grid_for(n_goals)), dim3(kT), 0, s, goals.p, n_goals, N, depth.p, start, misc.p + 1);
+        CZ_HIP(hipMemcpyAsync(left, misc.p + 1, 4, hipMemcpyDeviceToHost, s));
+        CZ_HIP(hipStreamSynchronize(s));
+        return CZ_OK;
+    }
+    int reduce_parents() { return cz::comm_all_reduce(comm, parent.p, N, cz::COMM_U32, cz::COMM_MIN, s); }
+};
+
+// ---- SSSP ----
+__global__ void __launch_bounds__(kT)
+sssp_sh_propose_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t rb,
+                       uint32_t re, const uint32_t *__restrict__ frontier, uint32_t fsize, const unsigned long long *__restrict__ dp,
+                       unsigned long long *__restrict__ prop) {
+    const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes, ngroups = gridDim.x * blockDim.x / kSsspLanes;
+    for (uint32_t i = group; i < fsize; i += ngroups) {
+        const uint32_t u = frontier[i];
+        if (u < rb || u >= re) continue;
+        const float du = __uint_as_float((uint32_t)(dp[u] >> 32));
+        const uint32_t e1 = off[u - rb + 1];
+        for (uint32_t e = off[u - rb] + glane; e < e1; e += kSsspLanes) {
+            const uint32_t v = tgt[e];
+            const uint32_t nb = __float_as_uint(du + w[e]);  // `cost + path_weight` in f32 (shortest_path_dijkstra.rs:303)
+            if (nb < (uint32_t)(dp[v] >> 32))                // strict `<` against the round's starting cost (:304)
+                atomicMin(&prop[v], ((unsigned long long)nb << 32) | u);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kT)
+sssp_sh_advance_kernel(const unsigned long long *__restrict__ dp, const unsigned long long *__restrict__ prop, uint32_t N,
+                       uint32_t *__restrict__ frontier, uint32_t *__restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t total = gridDim.x * blockDim.x;
+    const uint32_t rounds = (N + total - 1) / total;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x + r * total;
+        const bool changed = v < N && prop[v] != dp[v];
+        const unsigned long long m = __ballot(changed);
+        if (!m) continue;
+        uint32_t base = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (changed) frontier[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
+    }
+}
+
+struct HipShardedSssp {
+    cz_comm *comm;
+    hipStream_t s;
+    uint32_t N, rb, re;
+    cz::DevBuf<uint32_t> off, tgt, frontier, canon, misc, parent;
+    cz::DevBuf<float> w, dist;
+    cz::DevBuf<unsigned long long> a, b;
+    unsigned long long *dp = nullptr, *prop = nullptr;
+
+    int alloc(const uint32_t *h_off, const uint32_t *h_tgt, const float *h_w, uint64_t e_local) {
+        const uint32_t rows = re - rb;
+        CZ_HIP(off.alloc((size_t)rows + 1));
+        CZ_HIP(tgt.alloc(e_local));
+        CZ_HIP(w.alloc(e_local));
+        CZ_HIP(frontier.alloc(N));
+        CZ_HIP(canon.alloc(N));
+        CZ_HIP(misc.alloc(4));
+        CZ_HIP(parent.alloc(N));
+        CZ_HIP(dist.alloc(N));
+        CZ_HIP(a.alloc(N));
+        CZ_HIP(b.alloc(N));
+        CZ_HIP(hipMemcpy(off.p, h_off, ((size_t)rows + 1) * 4, hipMemcpyHostToDevice));
+        if (e_local) {
+            CZ_HIP(hipMemcpy(tgt.p, h_tgt, e_local * 4, hipMemcpyHostToDevice));
+            CZ_HIP(hipMemcpy(w.p, h_w, e_local * 4, hipMemcpyHostToDevice));
+        }
+        dp = a.p;
+        prop = b.p;
+        return CZ_OK;
+    }
+    int any_poisoned(bool mine, bool *any) {
+        const uint32_t v = mine ? 1u : 0u;
+        CZ_HIP(hipMemcpyAsync(misc.p + 2, &v, 4, hipMemcpyHostToDevice, s));
+        int rc = cz::comm_all_reduce(comm, misc.p + 2, 1, cz::COMM_U32, cz::COMM_SUM, s);
+        if (rc) return rc;
+        uint32_t h = 0;
+        CZ_HIP(hipMemcpyAsync(&h, misc.p + 2, 4, hipMemcpyDeviceToHost, s));
+        CZ_HIP(hipStreamSynchronize(s));
+        *any = h != 0;
+        return CZ_OK;
+    }
+    int sssp_seed(uint32_t start, uint32_t *fsize) {
+        hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(N)), dim3(kT), 0, s, dp, (uint64_t)N, kInfPacked);
+        *fsize = 0;
+        if (start < N) {
+            const unsigned long long zero = 0x00000000FFFFFFFFull;  // cost 0.0, no parent
+            CZ_HIP(hipMemcpyAsync(dp + start, &zero, 8, hipMemcpyHostToDevice, s));
+            CZ_HIP(hipMemcpyAsync(frontier.p, &start, 4, hipMemcpyHostToDevice, s));
+            CZ_HIP(hipStreamSynchronize(s));
+            *fsize = 1;
+        }
+        return CZ_OK;
+    }
+    int sssp_propose(uint32_t fsize) {
+        CZ_HIP(hipMemcpyAsync(prop, dp, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(sssp_sh_propose_kernel, dim3(grid_for((uint64_t)fsize * kSsspLanes)), dim3(kT), 0, s, off.p, tgt.p, w.p, rb, re,
+                           frontier.p, fsize, dp, prop);
+        return CZ_OK;
+    }
+    int reduce_proposals() { return cz::comm_all_reduce(comm, prop, N, cz::COMM_U64, cz::COMM_MIN, s); }
+    int sssp_advance(uint32_t *fsize) {
+        CZ_HIP(hipMemsetAsync(misc.p, 0, 4, s));
+        hipLaunchKernelGGL(sssp_sh_advance_kernel, dim3(grid_for(N)), dim3(kT), 0, s, dp, prop, N, frontier.p, misc.p);
+        CZ_HIP(hipMemcpyAsync(fsize, misc.p, 4, hipMemcpyDeviceToHost, s));
+        CZ_HIP(hipStreamSynchronize(s));
+        std::swap(dp, prop);
+        return CZ_OK;
+    }
+    int sssp_canonical_parents() {
+        CZ_HIP(hipMemsetAsync(canon.p, 0xFF, (size_t)N * 4, s));
+        hipLaunchKernelGGL(sssp_canon_kernel, dim3(grid_for((uint64_t)N * kSsspLanes)), dim3(kT), 0, s, off.p, tgt.p, w.p, N, 1u, dp,
+                           canon.p, rb, re);
+        return CZ_OK;
+    }
+    int reduce_canonical() { return cz::comm_all_reduce(comm, canon.p, N, cz::COMM_U32, cz::COMM_MIN, s); }
+};
+
+int check_shard(const uint32_t *off, const uint32_t *tgt, uint32_t N, uint32_t rb, uint32_t re, uint64_t e_local) {
+    if (rb > re || re > N) return cz::set_error(CZ_E_INVALID, "bad row range [%u,%u) of %u", rb, re, N);
+    if (!off) return cz::set_error(CZ_E_INVALID, "null offsets");
+    if (off[0] != 0 || off[re - rb] != e_local) return cz::set_error(CZ_E_INVALID, "offsets must be relative to the shard and end at E_local");
+    if (e_local > 0 && !tgt) return cz::set_error(CZ_E_INVALID, "null targets");
+    if (e_local >= 0xFFFFFFFFull) return cz::set_error(CZ_E_UNSUPPORTED, "a shard holds fewer than 2^32-1 edges");
+    return CZ_OK;
+}
+
+}  // namespace
+
+extern "C" int cz_bfs_sharded(cz_comm *comm, const uint32_t *out_offsets_local, const uint32_t *out_targets, uint32_t N,
+                              uint32_t row_begin, uint32_t row_end, uint64_t E_local, const uint32_t *starts, uint32_t n_starts,
+                              const uint32_t *goals, uint32_t n_goals, int share_visited, uint32_t *parent, uint32_t *depth,
+                              uint32_t *order, uint32_t *n_reached, const volatile uint8_t *poison) {
+    if (!comm) return cz::set_error(CZ_E_INVALID, "null communicator");
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if (n_starts == 0 || N == 0) return CZ_OK;
+    if (!starts || !parent) return cz::set_error(CZ_E_INVALID, "null starts/parent");
+    if ((rc = check_shard(out_offsets_local, out_targets, N, row_begin, row_end, E_local))) return rc;
+    HipShardedBfs b;
+    b.comm = comm;
+    b.s = nullptr;
+    b.N = N;
+    b.rb = row_begin;
+    b.re = row_end;
+    b.goals_host = goals;
+    b.n_goals = goals ? n_goals : 0;
+    if ((rc = b.alloc(out_offsets_local, out_targets, E_local))) return rc;
+    for (uint32_t si = 0; si < n_starts; si++) {
+        uint32_t reached = 0;
+        const bool skip = goals && n_goals == 0;  // nothing pending: the reference discovers nothing useful
+        rc = skip ? b.bfs_reset(share_visited != 0 && si > 0)
+                  : czs::run_sharded_bfs(b, starts[si], N, goals != nullptr, share_visited != 0 && si > 0, poison, &reached);
+        if (rc == czs::TRAVERSAL_CANCELLED) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+        if (rc) return rc;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sharded bfs launch: %s", hipGetErrorString(e));
+        CZ_HIP(hipMemcpy(parent + (size_t)si * N, b.parent.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+        if (depth) CZ_HIP(hipMemcpy(depth + (size_t)si * N, b.depth.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+        if (order) {
+            for (uint32_t i = 0; i < N; i++) order[(size_t)si * N + i] = CZ_NONE;
+            if (reached) CZ_HIP(hipMemcpy(order + (size_t)si * N, b.order.p + 1, (size_t)reached * 4, hipMemcpyDeviceToHost));
+        }
+        if (n_reached) n_reached[si] = reached;
+    }
+    return CZ_OK;
+}
+
+extern "C" int cz_sssp_sharded(cz_comm *comm, const uint32_t *out_offsets_local, const uint32_t *out_targets, const float *weights,
+                               uint32_t N, uint32_t row_begin, uint32_t row_end, uint64_t E_local, const uint32_t *starts,
+                               uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison) {
+    if (!comm) return cz::set_error(CZ_E_INVALID, "null communicator");
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if (n_starts == 0 || N == 0) return CZ_OK;
+    if (!starts || !dist || !parent) return cz::set_error(CZ_E_INVALID, "null starts/dist/parent");
+    if ((rc = check_shard(out_offsets_local, out_targets, N, row_begin, row_end, E_local))) return rc;
+    if (E_local > 0 && !weights) return cz::set_error(CZ_E_INVALID, "null weights");
+    for (uint64_t e = 0; e < E_local; e++)
+        if (!(weights[e] >= 0.0f))
+            return cz::set_error(CZ_E_INVALID, "edge %llu has weight %g: weights must be non-negative numbers", (unsigned long long)e,
+                                 (double)weights[e]);
+    HipShardedSssp b;
+    b.comm = comm;
+    b.s = nullptr;
+    b.N = N;
+    b.rb = row_begin;
+    b.re = row_end;
+    if ((rc = b.alloc(out_offsets_local, out_targets, weights, E_local))) return rc;
+    for (uint32_t si = 0; si < n_starts; si++) {
+        rc = czs::run_sharded_sssp(b, starts[si], N, poison);
+        if (rc == czs::TRAVERSAL_CANCELLED) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+        if (rc) return rc;
+        hipLaunchKernelGGL(sssp_unpack_kernel, dim3(grid_for(N)), dim3(kT), 0, b.s, b.dp, b.canon.p, (uint64_t)N, b.dist.p, b.parent.p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sharded sssp launch: %s", hipGetErrorString(e));
+        CZ_HIP(hipMemcpy(dist + (size_t)si * N, b.dist.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+        CZ_HIP(hipMemcpy(parent + (size_t)si * N, b.parent.p, (size_t)N * 4, hipMemcpyDeviceToHost));
     }
     return CZ_OK;
 }

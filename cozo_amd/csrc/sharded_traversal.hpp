@@ -1,0 +1,120 @@
+// sharded_traversal.hpp -- ONE BFS / ONE SSSP over a graph whose vertices are partitioned across ranks (SURVEY.md section 8e,
+// third row), written once against a backend interface like sharded_pagerank.hpp:
+//   * libcozo_gpu instantiates the loops with the HIP + RCCL backend (graph.hip: cz_bfs_sharded / cz_sssp_sharded);
+//   * tests/cpp/sharded_driver_test.cpp instantiates the SAME loops with a host backend whose exchange steps run over
+//     torch.distributed/gloo with world_size 2, and compares with the single-process oracle.
+// Plain C++17, no HIP in here.
+//
+// Partition: rank r owns the OUT-adjacency of the nodes [row_begin, row_end); every per-node array (depth, parent, claim,
+// the packed (cost, parent) words) has full length N on every rank, and every rank runs the same control flow on the same
+// reduced values, so all of them take the same branches.
+//
+// BFS keeps the reference's FIFO semantics (shortest_path_bfs.rs:65-94, bfs.rs:49-98: a node's parent is its FIRST
+// discoverer, nodes are discovered in the order the queue pushes them).  The frontier is one globally ordered list; its
+// entries are expanded by whichever rank owns them, under their GLOBAL positions:
+//   claim   every rank: for its frontier entries, claim[v] = min(claim[v], position) over undiscovered targets v
+//           all-reduce(min) of claim (N words)                    <- the exchange that decides every parent
+//   count   every rank: how many targets each of ITS entries won (others 0); all-reduce(sum) over the frontier's length
+//   scan    exclusive prefix over the counts (identical on every rank) -> where each entry's targets go in the next frontier
+//   emit    every rank writes the targets its entries won, in adjacency order, as id + 1 into a zeroed buffer, and their
+//           parents; all-reduce(sum) of the buffer (every slot is written by exactly one rank) = the next frontier
+//   commit  every rank marks the new nodes' depth
+// and once at the end an all-reduce(min) of the parent words (each written by exactly one rank, CZ_NONE elsewhere).
+//
+// SSSP: dist[v] = min over predecessors of fl32(dist[u] + w) is the unique fixpoint of monotone relaxation, so costs are
+// bit-identical to Dijkstra's under any schedule.  Per round every rank relaxes the out-edges of ITS frontier nodes into
+// a proposal array (a copy of the packed (cost << 32 | parent) words; atomicMin with proposals that STRICTLY improve on the
+// round's starting cost), the proposals are all-reduced(min, u64), and the nodes whose word changed are the next frontier.
+// A proposal never has the cost a node already has, so no parent pointer is ever replaced at equal cost: the predecessor
+// graph stays a tree.  Afterwards the parents are made canonical exactly like the single-GPU rule does it (the smallest
+// tight predecessor of strictly smaller cost): per-rank candidates + an all-reduce(min).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace czs {
+
+enum { TRAVERSAL_OK = 0, TRAVERSAL_CANCELLED = 1 };
+
+// Backend interface, both:
+//   int any_poisoned(bool mine, bool *any)           all-reduce(sum) of one word: is ANY rank's cancellation flag set?
+// Backend interface, BFS:
+//   int bfs_reset(bool keep_visited)                 parent = NONE everywhere; unless keep_visited: depth = claim = NONE
+//   int bfs_seed(uint32_t start, bool *already)      *already = depth[start] != NONE; else depth[start] = 0, order[0] = start
+//   int bfs_claim(uint32_t lo, uint32_t fsize)       as above, for the owned entries of order[lo .. lo + fsize)
+//   int reduce_claim()                               all-reduce(min) over the N claim words
+//   int bfs_count(uint32_t lo, uint32_t fsize)       cnt[0 .. fsize): owned entries' counts, 0 elsewhere
+//   int reduce_counts(uint32_t fsize)                all-reduce(sum)
+//   int bfs_scan(uint32_t fsize, uint32_t *total)    pos = exclusive scan of cnt; *total on the host
+//   int bfs_emit(uint32_t lo, uint32_t fsize, uint32_t total, uint32_t next_depth)
+//   int reduce_next(uint32_t total)                  all-reduce(sum) of the emit buffer
+//   int bfs_commit(uint32_t at, uint32_t total, uint32_t next_depth)   order[at + j] = buffer[j] - 1, depth of those = next_depth
+//   int goals_left(uint32_t start, uint32_t *left)   goals still without a backtrace entry (the start never gets one)
+//   int reduce_parents()                             all-reduce(min) over the N parent words
+template <class B>
+int run_sharded_bfs(B &b, uint32_t start, uint32_t N, bool has_goals, bool keep_visited, const volatile uint8_t *poison,
+                    uint32_t *reached_out) {
+    int rc;
+    uint32_t reached = 0;
+    if ((rc = b.bfs_reset(keep_visited))) return rc;
+    bool already = false;
+    bool run = start < N;
+    if (run && (rc = b.bfs_seed(start, &already))) return rc;
+    if (already) run = false;  // algos/bfs.rs:52-54: a start that an earlier traversal reached is skipped
+    if (run) {
+        uint32_t lo = 0, fsize = 1, level = 0;
+        while (fsize > 0) {
+            bool cancel = false;  // collective: every rank leaves at the same level when ANY rank's Poison is set
+            if ((rc = b.any_poisoned(poison && *poison, &cancel))) return rc;
+            if (cancel) return TRAVERSAL_CANCELLED;
+            if ((rc = b.bfs_claim(lo, fsize))) return rc;
+            if ((rc = b.reduce_claim())) return rc;
+            if ((rc = b.bfs_count(lo, fsize))) return rc;
+            if ((rc = b.reduce_counts(fsize))) return rc;
+            uint32_t total = 0;
+            if ((rc = b.bfs_scan(fsize, &total))) return rc;
+            if ((rc = b.bfs_emit(lo, fsize, total, level + 1))) return rc;
+            if ((rc = b.reduce_next(total))) return rc;
+            if ((rc = b.bfs_commit(lo + fsize, total, level + 1))) return rc;
+            lo += fsize;
+            fsize = total;
+            reached += total;
+            level++;
+            if (has_goals) {
+                uint32_t left = 0;
+                if ((rc = b.goals_left(start, &left))) return rc;
+                if (left == 0) break;  // the traversal stops after the level in which the last goal was discovered
+            }
+        }
+    }
+    if ((rc = b.reduce_parents())) return rc;
+    if (reached_out) *reached_out = reached;
+    return TRAVERSAL_OK;
+}
+
+// Backend interface, SSSP:
+//   int sssp_seed(uint32_t start, uint32_t *fsize)   every word = (inf, NONE); the start's = (0.0, NONE); frontier = [start]
+//   int sssp_propose(uint32_t fsize)                 proposals = copy of the words; relax the owned frontier nodes into it
+//   int reduce_proposals()                           all-reduce(min, u64) over N words
+//   int sssp_advance(uint32_t *fsize)                frontier = nodes whose proposal differs from their word; words = proposals
+//   int sssp_canonical_parents()                     per-rank smallest tight predecessor of strictly smaller cost ...
+//   int reduce_canonical()                           ... all-reduce(min) over N words; a backend's unpack prefers it
+template <class B>
+int run_sharded_sssp(B &b, uint32_t start, uint32_t N, const volatile uint8_t *poison) {
+    int rc;
+    uint32_t fsize = 0;
+    if ((rc = b.sssp_seed(start, &fsize))) return rc;
+    if (start >= N) fsize = 0;
+    while (fsize > 0) {
+        bool cancel = false;
+        if ((rc = b.any_poisoned(poison && *poison, &cancel))) return rc;
+        if (cancel) return TRAVERSAL_CANCELLED;
+        if ((rc = b.sssp_propose(fsize))) return rc;
+        if ((rc = b.reduce_proposals())) return rc;
+        if ((rc = b.sssp_advance(&fsize))) return rc;
+    }
+    if ((rc = b.sssp_canonical_parents())) return rc;
+    return b.reduce_canonical();
+}
+
+}  // namespace czs

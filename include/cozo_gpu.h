@@ -305,6 +305,23 @@ int cz_hnsw_search_sharded(cz_comm *comm, cz_hnsw_index *shard, const float *que
                            uint32_t ef, uint64_t id_offset, uint64_t *out_ids_dev, double *out_dist_dev,
                            uint32_t *out_count_dev, void *stream);
 
+/* ONE traversal over a graph whose vertices are partitioned across ranks (third row), collectively:
+ * rank r passes the out-adjacency of the nodes [row_begin, row_end) -- out_offsets_local [row_end-row_begin+1] relative to
+ * the shard, out_targets / weights [E_local] with GLOBAL target ids; starts / goals and every output (full length N per
+ * start, as for cz_bfs / cz_sssp) are the same on every rank.
+ * cz_bfs_sharded keeps the reference's FIFO semantics across the ranks (parents = first discoverers, discovery order):
+ * per level an all-reduce(min) of the N claim words, an all-reduce(sum) of the frontier's counts and one of the next
+ * frontier; results are bit-identical to cz_bfs on the whole graph.  cz_sssp_sharded: per round an all-reduce(min) of
+ * the N packed (cost, parent) proposals; costs and parents identical to cz_sssp's (positive weights).
+ * A set poison flag on ANY rank cancels every rank at the same level / round. */
+int cz_bfs_sharded(cz_comm *comm, const uint32_t *out_offsets_local, const uint32_t *out_targets, uint32_t N,
+                   uint32_t row_begin, uint32_t row_end, uint64_t E_local, const uint32_t *starts, uint32_t n_starts,
+                   const uint32_t *goals, uint32_t n_goals, int share_visited, uint32_t *parent, uint32_t *depth,
+                   uint32_t *order, uint32_t *n_reached, const volatile uint8_t *poison);
+int cz_sssp_sharded(cz_comm *comm, const uint32_t *out_offsets_local, const uint32_t *out_targets, const float *weights,
+                    uint32_t N, uint32_t row_begin, uint32_t row_end, uint64_t E_local, const uint32_t *starts,
+                    uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison);
+
 /* ShortestPathBFS::run (fixed_rule/algos/shortest_path_bfs.rs:35-113) and the traversal of Bfs::run
  * (algos/bfs.rs:25-113) on the out-CSR (neighbours in sorted order = the KV prefix-scan order).
  *   starts [n_starts]: one BFS per start.  goals [n_goals] or NULL (NULL: full traversal; with goals the

@@ -120,3 +120,242 @@ extern "C" int cz_test_sharded_pagerank_host(uint32_t N, uint32_t per, int rank,
     }
     return rc;
 }
+
+// =====================================================================================================================
+// the vertex-partitioned traversals (cozo_amd/csrc/sharded_traversal.hpp) with a host backend
+// =====================================================================================================================
+#include "../../cozo_amd/csrc/sharded_traversal.hpp"
+
+extern "C" {
+typedef int (*cz_test_all_reduce_u32)(void *ctx, uint32_t *buf, uint64_t n, int op /* 0 sum, 1 min */);
+typedef int (*cz_test_all_reduce_u64)(void *ctx, uint64_t *buf, uint64_t n, int op);
+}
+
+namespace {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+struct HostTraversal {
+    uint32_t N, rb, re;
+    const uint64_t *off;  // local
+    const uint32_t *tgt;
+    const float *w;
+    const uint32_t *goals;
+    uint32_t n_goals;
+    void *ctx;
+    cz_test_all_reduce_u32 ar32;
+    cz_test_all_reduce_u64 ar64;
+    const volatile uint8_t *poison_after;  // set by the test between levels
+    std::vector<uint32_t> depth, parent, claim, order, cnt, pos, buf, frontier, canon;
+    std::vector<uint64_t> dp, prop;
+    int exchanges = 0;
+
+    bool owned(uint32_t u) const { return u >= rb && u < re; }
+    int any_poisoned(bool mine, bool *any) {
+        uint32_t v = mine ? 1u : 0u;
+        int rc = ar32(ctx, &v, 1, 0);
+        exchanges++;
+        *any = v != 0;
+        return rc;
+    }
+    // ---- BFS ----
+    int bfs_reset(bool keep) {
+        parent.assign(N, kNone);
+        if (!keep) {
+            depth.assign(N, kNone);
+            claim.assign(N, kNone);
+        }
+        order.assign((size_t)N + 1, kNone);
+        cnt.assign(N, 0);
+        pos.assign(N, 0);
+        buf.assign(N, 0);
+        return 0;
+    }
+    int bfs_seed(uint32_t start, bool *already) {
+        *already = depth[start] != kNone;
+        if (*already) return 0;
+        depth[start] = 0;
+        order[0] = start;
+        return 0;
+    }
+    int bfs_claim(uint32_t lo, uint32_t fsize) {
+        for (uint32_t i = 0; i < fsize; i++) {
+            const uint32_t u = order[lo + i];
+            if (!owned(u)) continue;
+            for (uint64_t e = off[u - rb]; e < off[u - rb + 1]; e++) {
+                const uint32_t v = tgt[e];
+                if (depth[v] == kNone && i < claim[v]) claim[v] = i;
+            }
+        }
+        return 0;
+    }
+    int reduce_claim() { return ar32(ctx, claim.data(), N, 1); }
+    int bfs_count(uint32_t lo, uint32_t fsize) {
+        for (uint32_t i = 0; i < fsize; i++) {
+            cnt[i] = 0;
+            const uint32_t u = order[lo + i];
+            if (!owned(u)) continue;
+            const uint64_t e0 = off[u - rb], e1 = off[u - rb + 1];
+            for (uint64_t e = e0; e < e1; e++) {
+                const uint32_t v = tgt[e];
+                if ((e == e0 || tgt[e - 1] != v) && depth[v] == kNone && claim[v] == i) cnt[i]++;
+            }
+        }
+        return 0;
+    }
+    int reduce_counts(uint32_t fsize) { return ar32(ctx, cnt.data(), fsize, 0); }
+    int bfs_scan(uint32_t fsize, uint32_t *total) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < fsize; i++) {
+            pos[i] = run;
+            run += cnt[i];
+        }
+        *total = run;
+        return 0;
+    }
+    int bfs_emit(uint32_t lo, uint32_t fsize, uint32_t total, uint32_t next_depth) {
+        std::fill(buf.begin(), buf.begin() + total, 0u);
+        for (uint32_t i = 0; i < fsize; i++) {
+            const uint32_t u = order[lo + i];
+            if (!owned(u)) continue;
+            uint32_t o = pos[i];
+            const uint64_t e0 = off[u - rb], e1 = off[u - rb + 1];
+            for (uint64_t e = e0; e < e1; e++) {
+                const uint32_t v = tgt[e];
+                if ((e == e0 || tgt[e - 1] != v) && depth[v] == kNone && claim[v] == i) {
+                    buf[o++] = v + 1;
+                    parent[v] = u;
+                }
+            }
+        }
+        (void)next_depth;
+        return 0;
+    }
+    int reduce_next(uint32_t total) { return ar32(ctx, buf.data(), total, 0); }
+    int bfs_commit(uint32_t at, uint32_t total, uint32_t next_depth) {
+        for (uint32_t j = 0; j < total; j++) {
+            const uint32_t v = buf[j] - 1;
+            order[at + j] = v;
+            depth[v] = next_depth;
+        }
+        return 0;
+    }
+    int goals_left(uint32_t start, uint32_t *left) {
+        uint32_t c = 0;
+        for (uint32_t i = 0; i < n_goals; i++)
+            if (goals[i] < N && (depth[goals[i]] == kNone || goals[i] == start)) c++;
+        *left = c;
+        return 0;
+    }
+    int reduce_parents() { return ar32(ctx, parent.data(), N, 1); }
+    // ---- SSSP ----
+    static uint32_t bits(float f) {
+        uint32_t b;
+        std::memcpy(&b, &f, 4);
+        return b;
+    }
+    static float val(uint32_t b) {
+        float f;
+        std::memcpy(&f, &b, 4);
+        return f;
+    }
+    int sssp_seed(uint32_t start, uint32_t *fsize) {
+        dp.assign(N, ((uint64_t)0x7F800000u << 32) | kNone);
+        prop = dp;
+        frontier.assign(N, 0);
+        canon.assign(N, kNone);
+        *fsize = 0;
+        if (start < N) {
+            dp[start] = 0x00000000FFFFFFFFull;
+            frontier[0] = start;
+            *fsize = 1;
+        }
+        return 0;
+    }
+    int sssp_propose(uint32_t fsize) {
+        prop = dp;
+        for (uint32_t i = 0; i < fsize; i++) {
+            const uint32_t u = frontier[i];
+            if (!owned(u)) continue;
+            const float du = val((uint32_t)(dp[u] >> 32));
+            for (uint64_t e = off[u - rb]; e < off[u - rb + 1]; e++) {
+                const uint32_t v = tgt[e];
+                const uint32_t nb = bits(du + w[e]);
+                if (nb < (uint32_t)(dp[v] >> 32)) prop[v] = std::min(prop[v], ((uint64_t)nb << 32) | u);
+            }
+        }
+        return 0;
+    }
+    int reduce_proposals() { return ar64(ctx, prop.data(), N, 1); }
+    int sssp_advance(uint32_t *fsize) {
+        uint32_t c = 0;
+        for (uint32_t v = 0; v < N; v++)
+            if (prop[v] != dp[v]) frontier[c++] = v;
+        dp.swap(prop);
+        *fsize = c;
+        return 0;
+    }
+    int sssp_canonical_parents() {
+        canon.assign(N, kNone);
+        for (uint32_t u = rb; u < re; u++) {
+            const uint32_t cu = (uint32_t)(dp[u] >> 32);
+            if (cu == 0x7F800000u) continue;
+            for (uint64_t e = off[u - rb]; e < off[u - rb + 1]; e++) {
+                const uint32_t v = tgt[e], cv = (uint32_t)(dp[v] >> 32);
+                if (cu < cv && bits(val(cu) + w[e]) == cv) canon[v] = std::min(canon[v], u);
+            }
+        }
+        return 0;
+    }
+    int reduce_canonical() { return ar32(ctx, canon.data(), N, 1); }
+};
+
+}  // namespace
+
+// BFS from `start` over this rank's rows; outputs full length N (+ order without the start) on every rank
+extern "C" int cz_test_sharded_bfs_host(uint32_t N, uint32_t rb, uint32_t re, const uint64_t *off_local, const uint32_t *tgt,
+                                        uint32_t start, const uint32_t *goals, uint32_t n_goals, int has_goals,
+                                        const volatile uint8_t *poison, void *ctx, cz_test_all_reduce_u32 ar32,
+                                        cz_test_all_reduce_u64 ar64, uint32_t *parent, uint32_t *depth, uint32_t *order,
+                                        uint32_t *reached) {
+    HostTraversal b;
+    b.N = N;
+    b.rb = rb;
+    b.re = re;
+    b.off = off_local;
+    b.tgt = tgt;
+    b.w = nullptr;
+    b.goals = goals;
+    b.n_goals = n_goals;
+    b.ctx = ctx;
+    b.ar32 = ar32;
+    b.ar64 = ar64;
+    const int rc = czs::run_sharded_bfs(b, start, N, has_goals != 0, false, poison, reached);
+    std::memcpy(parent, b.parent.data(), (size_t)N * 4);
+    std::memcpy(depth, b.depth.data(), (size_t)N * 4);
+    std::memcpy(order, b.order.data() + 1, (size_t)N * 4);
+    return rc;
+}
+
+extern "C" int cz_test_sharded_sssp_host(uint32_t N, uint32_t rb, uint32_t re, const uint64_t *off_local, const uint32_t *tgt,
+                                         const float *w, uint32_t start, const volatile uint8_t *poison, void *ctx,
+                                         cz_test_all_reduce_u32 ar32, cz_test_all_reduce_u64 ar64, float *dist, uint32_t *parent) {
+    HostTraversal b;
+    b.N = N;
+    b.rb = rb;
+    b.re = re;
+    b.off = off_local;
+    b.tgt = tgt;
+    b.w = w;
+    b.goals = nullptr;
+    b.n_goals = 0;
+    b.ctx = ctx;
+    b.ar32 = ar32;
+    b.ar64 = ar64;
+    const int rc = czs::run_sharded_sssp(b, start, N, poison);
+    for (uint32_t v = 0; v < N; v++) {
+        dist[v] = HostTraversal::val((uint32_t)(b.dp[v] >> 32));
+        parent[v] = b.canon[v] != kNone ? b.canon[v] : (uint32_t)b.dp[v];
+    }
+    return rc;
+}

@@ -67,6 +67,26 @@ def main():
     assert np.array_equal(od.cpu().numpy(), dist) and np.array_equal(oc.cpu().numpy().astype(np.uint32), cnt)
     gix.close()
     print("OK hnsw_search_sharded", flush=True)
+    # ONE traversal over a "vertex-partitioned" graph of one rank == the single-GPU rule on the same graph
+    from cozo_amd.comm import bfs_sharded, sssp_sharded
+    frm, to = util.random_relation(20000, 90000, 8)
+    rng = np.random.default_rng(8)
+    gw = util.graph_from_relation(O, frm, to, weights=(rng.integers(1, 40, len(frm)) / 4).astype(np.float64))
+    starts = np.array([0, 7, 123], dtype=np.uint32)
+    goals = np.array([19999, 5000, 42], dtype=np.uint32)
+    for gl in (None, goals):
+        a = G.bfs(gw["ooff"], gw["otgt"], starts, goals=gl, want_depth=True, want_order=True)
+        b = bfs_sharded(comm, gw["ooff"], gw["otgt"], gw["n"], 0, gw["n"], starts, goals=gl, want_depth=True, want_order=True)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), "cz_bfs_sharded differs from cz_bfs"
+    a = G.bfs(gw["ooff"], gw["otgt"], starts, share_visited=True, want_order=True)
+    b = bfs_sharded(comm, gw["ooff"], gw["otgt"], gw["n"], 0, gw["n"], starts, share_visited=True, want_order=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    d0, p0 = G.sssp(gw["ooff"], gw["otgt"], gw["ow"], starts)
+    d1, p1 = sssp_sharded(comm, gw["ooff"], gw["otgt"], gw["ow"], gw["n"], 0, gw["n"], starts)
+    assert np.array_equal(d0, d1) and np.array_equal(p0, p1), "cz_sssp_sharded differs from cz_sssp"
+    want, _ = O.dijkstra(gw["n"], gw["ooff"], gw["otgt"], gw["ow"], 7)
+    assert np.array_equal(d1[1], want)
+    print("OK bfs_sharded / sssp_sharded", flush=True)
     comm.close()
     print("ALL OK", flush=True)
 

@@ -18,4 +18,5 @@ def test_comm_entry_points_on_one_gpu(gpu_lib):
                        timeout=900, cwd=ROOT)
     print(p.stdout[-3000:], p.stderr[-3000:])
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
-    assert "OK pagerank_sharded" in p.stdout and "OK hnsw_search_sharded" in p.stdout and "ALL OK" in p.stdout
+    assert "OK pagerank_sharded" in p.stdout and "OK hnsw_search_sharded" in p.stdout and "OK bfs_sharded" in p.stdout
+    assert "ALL OK" in p.stdout

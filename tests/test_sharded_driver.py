@@ -135,3 +135,137 @@ def test_cpp_sharded_loop_cancellation_is_collective(oracle):
     # tolerance <= 0 (sweeps back to back): the flag is looked at every 8th iteration
     out = _run(g, 0.0, 50, 0, poison_at=(0, 2))
     assert [o[3] for o in out] == [1, 1] and out[0][7][1] == out[1][7][1] == 8
+
+
+# ---- ONE BFS / ONE SSSP over a vertex-partitioned graph (cozo_amd/csrc/sharded_traversal.hpp) -------------------------
+ARU32 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint64, C.c_int)
+ARU64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64, C.c_int)
+
+
+def _traversal_worker(rank, world, port, what, g, start, goals, poison_at, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = C.CDLL(SO)
+    n = g["n"]
+    per = (n + world - 1) // world
+    rb, re = min(n, rank * per), min(n, (rank + 1) * per)
+    ooff = g["ooff"].astype(np.uint64)
+    off_local = np.ascontiguousarray(ooff[rb:re + 1] - ooff[rb])
+    tgt = np.ascontiguousarray(g["otgt"][int(ooff[rb]):int(ooff[re])], dtype=np.uint32)
+    poison = np.zeros(1, dtype=np.uint8)
+    calls = {"n": 0}
+
+    def _reduce(buf, n_, op, dtype):
+        a = np.ctypeslib.as_array(buf, shape=(int(n_),))
+        # gloo has no unsigned types: the values fit the signed ones except the all-ones "none" words, which MIN must keep
+        # as the largest value -- reduce on the bit-flipped sign image
+        t = torch.from_numpy((a ^ dtype(1 << (a.itemsize * 8 - 1))).view(np.int64 if a.itemsize == 8 else np.int32).copy())
+        if op == 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        else:
+            base = dtype(1 << (a.itemsize * 8 - 1))
+            t = torch.from_numpy(a.astype(np.int64).copy())  # sums stay far below 2^63
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            a[:] = t.numpy().astype(a.dtype)
+            calls["n"] += 1
+            if poison_at is not None and rank == poison_at[0] and calls["n"] == poison_at[1]:
+                poison[0] = 1
+            return 0
+        a[:] = t.numpy().view(a.dtype) ^ dtype(1 << (a.itemsize * 8 - 1))
+        return 0
+
+    ar32 = ARU32(lambda _c, buf, n_, op: _reduce(buf, n_, op, np.uint32))
+    ar64 = ARU64(lambda _c, buf, n_, op: _reduce(buf, n_, op, np.uint64))
+    if what == "bfs":
+        parent = np.empty(n, np.uint32)
+        depth = np.empty(n, np.uint32)
+        order = np.empty(n, np.uint32)
+        reached = C.c_uint32(0)
+        gl = None if goals is None else np.ascontiguousarray(goals, dtype=np.uint32)
+        L.cz_test_sharded_bfs_host.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                               C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, ARU32, ARU64, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.POINTER(C.c_uint32)]
+        rc = L.cz_test_sharded_bfs_host(n, rb, re, off_local.ctypes.data, tgt.ctypes.data, start,
+                                        None if gl is None else gl.ctypes.data, 0 if gl is None else gl.size, int(gl is not None),
+                                        poison.ctypes.data, None, ar32, ar64, parent.ctypes.data, depth.ctypes.data,
+                                        order.ctypes.data, C.byref(reached))
+        q.put((rank, rc, parent, depth, order[:reached.value].copy(), reached.value))
+    else:
+        w = np.ascontiguousarray(g["ow"][int(ooff[rb]):int(ooff[re])], dtype=np.float32)
+        dist_out = np.empty(n, np.float32)
+        parent = np.empty(n, np.uint32)
+        L.cz_test_sharded_sssp_host.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                C.c_void_p, C.c_void_p, ARU32, ARU64, C.c_void_p, C.c_void_p]
+        rc = L.cz_test_sharded_sssp_host(n, rb, re, off_local.ctypes.data, tgt.ctypes.data, w.ctypes.data, start, poison.ctypes.data,
+                                         None, ar32, ar64, dist_out.ctypes.data, parent.ctypes.data)
+        q.put((rank, rc, dist_out, parent))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_traversal(what, g, start, goals=None, poison_at=None, world=2):
+    build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_traversal_worker, args=(r, world, port, what, g, start, goals, poison_at, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(out, key=lambda o: o[0])
+
+
+@pytest.mark.parametrize("n,e,seed", [(400, 1500, 1), (2000, 9000, 2), (50, 60, 3)])
+def test_vertex_partitioned_bfs_world2_is_the_fifo_bfs(oracle, n, e, seed):
+    """parents (first discoverers), depths and the discovery order of ONE BFS whose frontier entries are expanded by the
+    rank that owns them == the single-process FIFO BFS of the oracle, on both ranks"""
+    frm, to = util.random_relation(n, e, seed)
+    g = util.graph_from_relation(oracle, frm, to)
+    want_order, want_parent, _ = oracle.bfs_order(g["n"], g["ooff"], g["otgt"], 0)
+    out = _run_traversal("bfs", g, 0)
+    for _, rc, parent, depth, order, reached in out:
+        assert rc == 0 and reached == len(want_order)
+        assert np.array_equal(order, want_order), "discovery order differs from the reference's FIFO order"
+        assert np.array_equal(parent, want_parent)
+        assert depth[0] == 0 and (depth[want_order] != 0xFFFFFFFF).all()
+    # with goals: the traversal stops after the level in which the last goal was discovered; goal paths equal the oracle's
+    goals = np.array([g["n"] - 1, g["n"] // 2, 3], dtype=np.uint32)
+    wp = oracle.shortest_path_bfs(g["n"], g["ooff"], g["otgt"], 0, goals)
+    out = _run_traversal("bfs", g, 0, goals=goals)
+    for _, rc, parent, depth, order, reached in out:
+        assert rc == 0
+        for t in goals.tolist():
+            assert oracle.path_from_parent(parent, 0, t) == oracle.path_from_parent(wp, 0, t)
+
+
+@pytest.mark.parametrize("n,e,seed", [(400, 1500, 4), (1500, 7000, 5)])
+def test_vertex_partitioned_sssp_world2_costs_are_dijkstras(oracle, n, e, seed):
+    frm, to = util.random_relation(n, e, seed)
+    rng = np.random.default_rng(seed)
+    g = util.graph_from_relation(oracle, frm, to, weights=(rng.integers(1, 40, len(frm)) / 4).astype(np.float64))
+    want_dist, _ = oracle.dijkstra(g["n"], g["ooff"], g["otgt"], g["ow"], 0)
+    out = _run_traversal("sssp", g, 0)
+    ooff = g["ooff"].astype(np.int64)
+    for _, rc, d, parent in out:
+        assert rc == 0 and np.array_equal(d, want_dist), "f32 costs must be bit-identical to Dijkstra's"
+        # every parent is a tight predecessor of strictly smaller cost -- the smallest such node -- on both ranks alike
+        for v in range(g["n"]):
+            if v == 0 or not np.isfinite(d[v]):
+                assert parent[v] == 0xFFFFFFFF
+                continue
+            tight = [u for u in range(g["n"]) if np.isfinite(d[u]) and d[u] < d[v] and any(
+                g["otgt"][k] == v and np.float32(d[u] + g["ow"][k]) == d[v] for k in range(ooff[u], ooff[u + 1]))] if g["n"] <= 400 else None
+            if tight is not None:
+                assert parent[v] == min(tight)
+    assert np.array_equal(out[0][3], out[1][3])
+
+
+def test_vertex_partitioned_bfs_cancellation_is_collective(oracle):
+    frm, to = util.random_relation(600, 1500, 9)
+    g = util.graph_from_relation(oracle, frm, to)
+    out = _run_traversal("bfs", g, 0, poison_at=(1, 4))
+    assert [o[1] for o in out] == [1, 1]  # czs::TRAVERSAL_CANCELLED on both ranks, at the same level
