@@ -726,28 +726,12 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
                            has_radius, radius, (uint32_t *)ws.tab, hbits, (uint32_t *)ws.bitmap, words, preds, d_ids,   \
                            d_dist, d_count, (unsigned long long *)d_ndist);                                             \
     } while (0)
-#define CZ_LAUNCH_KNN_MR4(LPV, ITERS, U)                                                                                \
-    do {                                                                                                                \
-        auto kern = czh::hnsw_knn_kernel<LPV, ITERS, U, 4>;                                                             \
-        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                                        (int)smem);                                                    \
-        hipLaunchKernelGGL(kern, dim3(B), dim3(czh::kThreads), smem, stream, d, d_queries, k, ef, efcap, wpad,          \
-                           has_radius, radius, (uint32_t *)ws.tab, hbits, (uint32_t *)ws.bitmap, words, preds, d_ids,   \
-                           d_dist, d_count, (unsigned long long *)d_ndist);                                             \
-    } while (0)
     // experiment knob: rows per round of a lane group for the 513..768-d shape (CZ_HNSW_U = 1 | 2)
     const char *knn_u_env = getenv("CZ_HNSW_U");
     const int knn_u = knn_u_env ? atoi(knn_u_env) : 0;
-    const char *mr_env = getenv("CZ_HNSW_WIDE_MERGE");  // A/B knob: 0 = the LDS-walking merge beyond ef = 512
-    const bool wide_regs = ef > 512 && !(mr_env && atoi(mr_env) == 0);
     if (sh.lpv == 64 && sh.iters == 3 && knn_u == 1) CZ_LAUNCH_KNN(64, 3, 1);
-    else if (wide_regs && sh.lpv == 64 && sh.iters == 3) CZ_LAUNCH_KNN_MR4(64, 3, 2);
-    else if (wide_regs && sh.lpv == 32) CZ_LAUNCH_KNN_MR4(32, 1, 4);
-    else if (wide_regs && sh.lpv == 64 && sh.iters == 2) CZ_LAUNCH_KNN_MR4(64, 2, 2);
-    else if (wide_regs && sh.lpv == 64 && sh.iters == 4) CZ_LAUNCH_KNN_MR4(64, 4, 2);
     else CZ_DISPATCH_SHAPE_SEARCH(sh, CZ_LAUNCH_KNN);
 #undef CZ_LAUNCH_KNN
-#undef CZ_LAUNCH_KNN_MR4
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         HnswIndex::destroy(ws);  // its contents are unknown

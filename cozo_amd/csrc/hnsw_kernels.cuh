@@ -49,7 +49,7 @@ constexpr int kWaves = kThreads / 64;
 constexpr int kVlogCap = 2048;
 // list capacity (x 256) and batch size (x 64) the register form of the merge covers; larger searches (ef > 512 or
 // link rows wider than 128) take the LDS-walking form
-constexpr int kMergeEC = 2;  // (the list capacity the register form covers is the Searcher's MR x 256)
+constexpr int kMergeR = 2, kMergeEC = 2;
 
 struct IndexDev {
     const float *vec;        // [n][ld]
@@ -139,7 +139,7 @@ struct VisitedDev {
     uint32_t words;
 };
 
-template <int LPV, int ITERS, int U, bool NT = false, int MR = 2>
+template <int LPV, int ITERS, int U, bool NT = false>
 struct Searcher {
     const IndexDev &ix;
     Smem s;
@@ -370,7 +370,7 @@ struct Searcher {
     // shifts).  No LDS traffic inside the loop (the previous form walked the whole batch through LDS per thread and
     // spent 6 us of a 31 us step there).
     __device__ void merge(int n, int ef) {
-        if (ef > MR * kThreads || n > kMergeEC * 64) {  // uniform: beyond what the register form holds
+        if (ef > kMergeR * kThreads || n > kMergeEC * 64) {  // uniform: beyond what the register form holds
             merge_wide(n, ef);
             return;
         }
@@ -418,7 +418,7 @@ struct Searcher {
         __syncthreads();
         // registers: this thread's W entries (W index tid + r * kThreads: a wave holds 64 consecutive ones) and the
         // compacted entries (lane l of EVERY wave holds entries l, 64 + l, ...)
-        constexpr int R = MR;         // ef <= R * kThreads
+        constexpr int R = kMergeR;    // ef <= R * kThreads
         constexpr int EC = kMergeEC;  // n <= EC * 64
         uint64_t wk[R];
         uint32_t wi[R];
@@ -872,10 +872,7 @@ __device__ __forceinline__ bool pred_pass(const PredSet &ps, uint32_t node) {
 #ifndef CZ_SEARCH_NT
 #define CZ_SEARCH_NT 1
 #endif
-// MR = 256-entry register chunks of the merge: 2 covers ef <= 512 (the common case: 123 of the 128 VGPRs that keep four
-// workgroups on a CU), 4 is the instantiation for 512 < ef <= 1024 (hard corpora; the LDS-walking merge it replaces there
-// cost a third of a step)
-template <int LPV, int ITERS, int U, int MR = 2>
+template <int LPV, int ITERS, int U>
 __global__ void __launch_bounds__(kThreads)
 hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t efcap,
                 uint32_t wpad, int has_radius, double radius, uint32_t *__restrict__ vtab, uint32_t hbits,
@@ -889,7 +886,7 @@ hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t k, uint
     vis.hbits = hbits;
     vis.bitmap = vbitmap + (size_t)b * words;
     vis.words = words;
-    Searcher<LPV, ITERS, U, CZ_SEARCH_NT != 0, MR> S(ix, s, vis);
+    Searcher<LPV, ITERS, U, CZ_SEARCH_NT != 0> S(ix, s, vis);
     S.load_query(queries + (size_t)b * ix.dim);
     S.seed(ix.entry);
     // :919-938 greedy descent with ef = 1 through the upper levels, then the level-0 search with ef (one call site,
