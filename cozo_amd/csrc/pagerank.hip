@@ -48,14 +48,11 @@ namespace {
 constexpr int kGThreads = 256;      // gather kernel
 constexpr int kGTileNnz = 4096;     // f32 values per LDS tile of the gather kernel (16 KiB)
 constexpr int kBThreads = 1024;     // blocked path, phase B
-#ifndef CZ_PR_TILE_LOG2
-#define CZ_PR_TILE_LOG2 14
-#endif
-constexpr int kBTileNnz = 1 << CZ_PR_TILE_LOG2;  // 14: 64 KiB tile, two workgroups (32 waves) per CU; 15: 128 KiB, one
+constexpr int kBTileNnz = 16384;    // 64 KiB tile: two workgroups (32 waves) per CU
 constexpr int kAThreads = 1024;     // blocked path, phase A
 constexpr int kMaxSliceLog2 = 15;   // 32768 sources = 128 KiB of LDS
 constexpr uint32_t kPartEdges = 98304;  // phase-A work item: at most this many edges of one slice
-constexpr int kMaxRowsPerBlock = kBTileNnz / 8;  // = 2 (4) rows per lane of phase B
+constexpr int kMaxRowsPerBlock = 2048;  // = 2 rows per lane of phase B
 
 struct RowBlock {
     uint32_t row0, row1;  // local rows [row0, row1)
@@ -258,7 +255,7 @@ pb_expand_kernel(const AItem *__restrict__ items, const uint16_t *__restrict__ a
 // every element of the block in slice-major order, its position in the value stream (`vpos`, 4 more bytes per edge),
 // and the tile is filled element by element with every lane busy: tile[perm[e]] = val[vpos[e]].
 template <bool FLAT>
-__global__ void __launch_bounds__(kBThreads) __attribute__((amdgpu_waves_per_eu(CZ_PR_TILE_LOG2 == 14 ? 8 : 4, CZ_PR_TILE_LOG2 == 14 ? 8 : 4)))
+__global__ void __launch_bounds__(kBThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
 pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint32_t *__restrict__ off,
                  const uint2 *__restrict__ seg /* [blocks][S+1]: (stream position, block-local prefix) */, uint32_t S,
                  const uint16_t *__restrict__ perm, const uint32_t *__restrict__ vpos, const float *__restrict__ val,
@@ -272,7 +269,7 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
     // <= 64 values and placed afterwards by ALL waves, one piece per wave instruction -- not 64 values at a time by the
     // one wave that owns the slice.  A tile holds 16384 values: at most 256 full pieces plus one partial piece per run
     // longer than 64 (< 256 of those).
-    __shared__ uint32_t tail_st[kBTileNnz / 32], tail_p0[kBTileNnz / 32], tail_cnt[kBTileNnz / 32];
+    __shared__ uint32_t tail_st[512], tail_p0[512], tail_cnt[512];
     __shared__ uint32_t n_tail;
     if (threadIdx.x == 0) n_tail = 0;
     __syncthreads();
@@ -415,7 +412,7 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
     // Relaxed plans (`relaxed_rows`): rows of >= kWaveRow terms are left out here and summed afterwards by a whole wave
     // each -- every lane a strided share in f32, the lanes' sums in f64 -- like the hub segments above.
     constexpr uint32_t kWaveRow = 256;
-    __shared__ uint32_t long_row[kBTileNnz / 256];  // relaxed: local rows handed to the waves (rows of >= 256 terms in a tile)
+    __shared__ uint32_t long_row[64];  // relaxed: local rows handed to the waves (a tile holds <= 64 rows of >= 256 terms)
     __shared__ uint32_t n_long;
     if (relaxed_rows) {
         if (threadIdx.x == 0) n_long = 0;
