@@ -42,11 +42,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured 
 EF_LADDER = [16, 24, 32, 48, 64, 80, 96, 112, 128, 144, 160, 176, 192, 224, 256, 320, 384, 512, 768, 1024]
 
 
-PMC_SOURCES = {  # the device sources each PMC entry of profiles/pmc_traffic.json was measured on
-    "hnsw_knn": ["hnsw_kernels.cuh", "distance.cuh", "hnsw_api.hip", "hnsw_index.h", "common.h"],
-    "distance_batch": ["distance.cuh", "hnsw_api.hip", "common.h"],
-    "pagerank_blocked": ["pagerank.hip", "common.h"],
-    "pagerank_gather": ["pagerank.hip", "common.h"],
+PMC_SOURCES = {  # the kernel-bearing sources each PMC entry of profiles/pmc_traffic.json was measured on
+    "hnsw_knn": ["hnsw_kernels.cuh", "distance.cuh", "hnsw_api.hip"],
+    "distance_batch": ["distance.cuh", "hnsw_api.hip"],
+    "pagerank_blocked": ["pagerank.hip"],
+    "pagerank_gather": ["pagerank.hip"],
 }
 
 
