@@ -756,6 +756,19 @@ def bench_graph_rules(args, torch, device):
     fin = np.isfinite(dist[0])
     out["sssp"] = dict(wall_ms=dt * 1e3, edges_per_s=E / dt, reached=int(fin.sum()), max_cost=float(dist[0][fin].max()),
                        algorithmic_bytes=8 * E + 4 * (n + 1) + 12 * n)
+    # BetweennessCentrality: SSSP from EVERY node + path counts over the tight edges, all on the device (a 20k-node graph:
+    # 4e8 (source, node) pairs; the reference enumerates paths, so there is no CPU figure at this size)
+    nb, eb = 20_000, 200_000
+    rb = np.random.default_rng(11)
+    kb = np.unique(rb.integers(0, nb, eb, dtype=np.int64) * nb + rb.integers(0, nb, eb, dtype=np.int64))
+    kb = kb[kb // nb != kb % nb]
+    boff = np.zeros(nb + 1, dtype=np.uint32)
+    boff[1:] = np.cumsum(np.bincount(kb // nb, minlength=nb))
+    btgt = (kb % nb).astype(np.uint32)
+    bw = (rb.integers(1, 64, btgt.size) / 8).astype(np.float32)
+    cent, dt = timed(lambda: G.betweenness(boff, btgt, bw))
+    out["betweenness"] = dict(nodes=nb, edges=int(btgt.size), wall_ms=dt * 1e3, sources_per_s=nb / dt,
+                              source_node_pairs_per_s=nb * nb / dt, max_centrality=float(cent.max()))
     out["note"] = ("wall = one C ABI call on host arrays: CSR upload over PCIe (0.44 GB per direction, 0.84 GB for the weighted "
                    "graph) + kernels + per-node results back; kernel-only times are in profiles/ (rocprofv3 kernel trace)")
     return out

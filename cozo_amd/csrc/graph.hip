@@ -709,63 +709,67 @@ extern "C" int cz_clustering_coefficients(const uint32_t *offsets, const uint32_
     return CZ_OK;
 }
 
-extern "C" int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N,
-                       uint64_t E, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent,
-                       const volatile uint8_t *poison) {
-    int rc = cz::ensure_device();
-    if (rc) return rc;
-    if (n_starts == 0 || N == 0) return CZ_OK;
-    if (!starts || !dist || !parent) return cz::set_error(CZ_E_INVALID, "null starts/dist/parent");
-    rc = check_csr(out_offsets, out_targets, N, E);
-    if (rc) return rc;
-    if (E > 0 && !weights) return cz::set_error(CZ_E_INVALID, "null weights");
-    double wsum = 0.0;
-    for (uint64_t e = 0; e < E; e++) {  // BadEdgeWeightError, fixed_rule/mod.rs:258-286: negative / NaN weights
-        // (+inf is legal here: the reference checks the f64 value, and a finite f64 beyond f32's range becomes +inf in
-        // its `as f32` cast; such an edge never improves anything -- inf < inf is false -- exactly as in dijkstra :304)
-        if (!(weights[e] >= 0.0f))
-            return cz::set_error(CZ_E_INVALID, "edge %llu has weight %g: weights must be non-negative numbers",
-                                 (unsigned long long)e, (double)weights[e]);
-        wsum += weights[e];
-    }
-    // bucket width of the near-far schedule: the mean edge weight (CZ_SSSP_DELTA overrides; <= 0 or "inf" = one pile,
-    // i.e. plain frontier Bellman-Ford).  Only the schedule depends on it, never the result.
-    float delta = E ? (float)(wsum / (double)E) : 0.f;
-    if (const char *de = getenv("CZ_SSSP_DELTA")) delta = (float)atof(de);
-    const bool one_pile = !(delta > 0.f) || !std::isfinite(delta);
-    // sources per launch: 16 bytes of state + 32 bytes of queue space per (source, node); about 4 GB in all
-    const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_starts, (80ull << 20) / std::max<uint32_t>(N, 1)));
-    const uint64_t SN = (uint64_t)S * N;
-    if (SN >= 0xFFFFFFFFull) return cz::set_error(CZ_E_UNSUPPORTED, "too many (source, node) pairs per launch");
-    cz::DevBuf<uint32_t> d_off, d_tgt, d_qtag, d_ftag, d_misc, d_parent, d_starts;
-    cz::DevBuf<float> d_w, d_dist;
-    cz::DevBuf<unsigned long long> d_dp, d_q[4];
-    CZ_HIP(d_off.alloc((size_t)N + 1));
-    CZ_HIP(d_tgt.alloc(E));
-    CZ_HIP(d_w.alloc(E));
-    CZ_HIP(d_qtag.alloc(SN));
-    CZ_HIP(d_ftag.alloc(SN));
-    CZ_HIP(d_misc.alloc(8));
-    CZ_HIP(d_parent.alloc(SN));
-    CZ_HIP(d_dist.alloc(SN));
-    CZ_HIP(d_dp.alloc(SN));
-    CZ_HIP(d_starts.alloc(S));
-    for (auto &q : d_q) CZ_HIP(q.alloc(SN));
-    CZ_HIP(hipMemcpy(d_off.p, out_offsets, ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
-    if (E) {
-        CZ_HIP(hipMemcpy(d_tgt.p, out_targets, E * 4, hipMemcpyHostToDevice));
-        CZ_HIP(hipMemcpy(d_w.p, weights, E * 4, hipMemcpyHostToDevice));
-    }
+namespace {
+
+// the multi-source near-far SSSP on device-resident state: `run` leaves the packed (cost, parent) words of `ns` sources in
+// dp [ns][N]; shared by cz_sssp (which unpacks them) and cz_betweenness (which goes on to count paths over them)
+struct SsspBatch {
+    uint32_t N = 0, S = 0;
+    uint64_t E = 0;
+    float delta = 0.f;
+    bool one_pile = false;
     hipStream_t s = nullptr;
+    cz::DevBuf<uint32_t> d_off, d_tgt, d_qtag, d_ftag, d_misc, d_starts;
+    cz::DevBuf<float> d_w;
+    cz::DevBuf<unsigned long long> d_dp, d_q[4];
+
+    int alloc(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t n, uint64_t e,
+              uint32_t n_starts, uint64_t pairs_budget) {
+        N = n;
+        E = e;
+        double wsum = 0.0;
+        for (uint64_t i = 0; i < E; i++) {  // BadEdgeWeightError, fixed_rule/mod.rs:258-286: negative / NaN weights
+            // (+inf is legal here: the reference checks the f64 value, and a finite f64 beyond f32's range becomes +inf in
+            // its `as f32` cast; such an edge never improves anything -- inf < inf is false -- exactly as in dijkstra :304)
+            if (!(weights[i] >= 0.0f))
+                return cz::set_error(CZ_E_INVALID, "edge %llu has weight %g: weights must be non-negative numbers",
+                                     (unsigned long long)i, (double)weights[i]);
+            wsum += weights[i];
+        }
+        // bucket width of the near-far schedule: the mean edge weight (CZ_SSSP_DELTA overrides; <= 0 or "inf" = one pile,
+        // i.e. plain frontier Bellman-Ford).  Only the schedule depends on it, never the result.
+        delta = E ? (float)(wsum / (double)E) : 0.f;
+        if (const char *de = getenv("CZ_SSSP_DELTA")) delta = (float)atof(de);
+        one_pile = !(delta > 0.f) || !std::isfinite(delta);
+        // sources per launch: 16 bytes of state + 32 bytes of queue space per (source, node)
+        S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_starts, pairs_budget / std::max<uint32_t>(N, 1)));
+        const uint64_t SN = (uint64_t)S * N;
+        if (SN >= 0xFFFFFFFFull) return cz::set_error(CZ_E_UNSUPPORTED, "too many (source, node) pairs per launch");
+        CZ_HIP(d_off.alloc((size_t)N + 1));
+        CZ_HIP(d_tgt.alloc(E));
+        CZ_HIP(d_w.alloc(E));
+        CZ_HIP(d_qtag.alloc(SN));
+        CZ_HIP(d_ftag.alloc(SN));
+        CZ_HIP(d_misc.alloc(8));
+        CZ_HIP(d_dp.alloc(SN));
+        CZ_HIP(d_starts.alloc(S));
+        for (auto &q : d_q) CZ_HIP(q.alloc(SN));
+        CZ_HIP(hipMemcpy(d_off.p, out_offsets, ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
+        if (E) {
+            CZ_HIP(hipMemcpy(d_tgt.p, out_targets, E * 4, hipMemcpyHostToDevice));
+            CZ_HIP(hipMemcpy(d_w.p, weights, E * 4, hipMemcpyHostToDevice));
+        }
+        return CZ_OK;
+    }
+
     // d_misc: [0] near-next count, [1] far count, [2] far-next count, [3] min far cost bits
-    for (uint32_t s0 = 0; s0 < n_starts; s0 += S) {
-        const uint32_t ns = std::min<uint32_t>(S, n_starts - s0);
+    int run(const uint32_t *starts, uint32_t ns, const volatile uint8_t *poison) {
         const uint64_t nsN = (uint64_t)ns * N;
         hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, d_dp.p, nsN, kInfPacked);
         CZ_HIP(hipMemsetAsync(d_qtag.p, 0, nsN * 4, s));
         CZ_HIP(hipMemsetAsync(d_ftag.p, 0, nsN * 4, s));
         CZ_HIP(hipMemsetAsync(d_misc.p, 0, 32, s));
-        CZ_HIP(hipMemcpyAsync(d_starts.p, starts + s0, (size_t)ns * 4, hipMemcpyHostToDevice, s));
+        CZ_HIP(hipMemcpyAsync(d_starts.p, starts, (size_t)ns * 4, hipMemcpyHostToDevice, s));
         unsigned long long *near_cur = d_q[0].p, *near_next = d_q[1].p, *far_cur = d_q[2].p, *far_next = d_q[3].p;
         hipLaunchKernelGGL(sssp_seed_kernel, dim3((ns + kT - 1) / kT), dim3(kT), 0, s, d_starts.p, ns, N, d_dp.p, near_cur, d_misc.p);
         uint32_t h[4];
@@ -813,15 +817,248 @@ extern "C" int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets,
             round++;
             if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
         }
-        CZ_HIP(hipMemsetAsync(d_qtag.p, 0xFF, nsN * 4, s));  // the round tags are done with: the array holds the canonical parents
-        hipLaunchKernelGGL(sssp_canon_kernel, dim3(grid_for(nsN * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, d_w.p, N, ns,
-                           d_dp.p, d_qtag.p, 0u, N);
-        hipLaunchKernelGGL(sssp_unpack_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, d_dp.p, d_qtag.p, nsN, d_dist.p, d_parent.p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sssp launch: %s", hipGetErrorString(e));
+        return CZ_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N,
+                       uint64_t E, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent,
+                       const volatile uint8_t *poison) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if (n_starts == 0 || N == 0) return CZ_OK;
+    if (!starts || !dist || !parent) return cz::set_error(CZ_E_INVALID, "null starts/dist/parent");
+    rc = check_csr(out_offsets, out_targets, N, E);
+    if (rc) return rc;
+    if (E > 0 && !weights) return cz::set_error(CZ_E_INVALID, "null weights");
+    SsspBatch sb;
+    if ((rc = sb.alloc(out_offsets, out_targets, weights, N, E, n_starts, 80ull << 20))) return rc;  // about 4 GB in all
+    const uint64_t SN = (uint64_t)sb.S * N;
+    cz::DevBuf<uint32_t> d_parent;
+    cz::DevBuf<float> d_dist;
+    CZ_HIP(d_parent.alloc(SN));
+    CZ_HIP(d_dist.alloc(SN));
+    hipStream_t s = sb.s;
+    for (uint32_t s0 = 0; s0 < n_starts; s0 += sb.S) {
+        const uint32_t ns = std::min<uint32_t>(sb.S, n_starts - s0);
+        const uint64_t nsN = (uint64_t)ns * N;
+        if ((rc = sb.run(starts + s0, ns, poison))) return rc;
+        CZ_HIP(hipMemsetAsync(sb.d_qtag.p, 0xFF, nsN * 4, s));  // the round tags are done with: the array holds the canonical parents
+        hipLaunchKernelGGL(sssp_canon_kernel, dim3(grid_for(nsN * kSsspLanes)), dim3(kT), 0, s, sb.d_off.p, sb.d_tgt.p, sb.d_w.p, N, ns,
+                           sb.d_dp.p, sb.d_qtag.p, 0u, N);
+        hipLaunchKernelGGL(sssp_unpack_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, sb.d_dp.p, sb.d_qtag.p, nsN, d_dist.p, d_parent.p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sssp launch: %s", hipGetErrorString(e));
         CZ_HIP(hipMemcpy(dist + (size_t)s0 * N, d_dist.p, nsN * 4, hipMemcpyDeviceToHost));
         CZ_HIP(hipMemcpy(parent + (size_t)s0 * N, d_parent.p, nsN * 4, hipMemcpyDeviceToHost));
     }
+    return CZ_OK;
+}
+
+// ---- BetweennessCentrality (fixed_rule/algos/all_pairs_shortest_path.rs:31-95) --------------------------------------------
+// The reference runs dijkstra_keep_ties from every node, enumerates ALL shortest paths to every target and adds 1 / (number
+// of shortest paths to that target) to every inner node of every path.  Its back pointers are exactly the "tight" edges
+// dist[u] + w == dist[v] (f32), so the same sums come out of path COUNTS over the tight-edge DAG (Brandes):
+//   sigma[v] = number of shortest paths s -> v = sum over tight (u, v) of sigma[u]                      (sigma[s] = 1)
+//   delta[u] = sum over tight (u, v) of sigma[u] / sigma[v] * (1 + delta[v]);   centrality[u] += delta[u]   (u != s)
+// Both recurrences are evaluated by Jacobi sweeps until nothing changes (one sweep per hop of the DAG's depth), a 16-lane
+// group per (source, node) pulling over the node's in- (sigma) or out-adjacency (delta) in a fixed order, f64 throughout
+// (the reference adds f32 terms; the parity bar of this rule is 1e-5 against its literal enumeration).  Sources run in
+// batches on the distances the multi-source SSSP above leaves on the device.
+namespace {
+
+__global__ void __launch_bounds__(kT)
+bc_sigma_kernel(const uint32_t *__restrict__ in_off, const uint32_t *__restrict__ in_src, const float *__restrict__ in_w, uint32_t N,
+                uint32_t ns, const unsigned long long *__restrict__ dp, const uint32_t *__restrict__ starts,
+                const double *__restrict__ sig_old, double *__restrict__ sig_new, uint32_t *__restrict__ changed,
+                uint32_t *__restrict__ absorbed) {
+    const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes;
+    const uint64_t ngroups = (uint64_t)gridDim.x * blockDim.x / kSsspLanes, total = (uint64_t)ns * N;
+    const uint64_t rounds = (total + ngroups - 1) / ngroups;  // every group of a wave runs the same trip count (shuffles)
+    for (uint64_t r = 0; r < rounds; r++) {
+        const uint64_t i = group + r * ngroups;
+        const bool live = i < total;
+        const uint32_t si = live ? (uint32_t)(i / N) : 0, v = live ? (uint32_t)(i % N) : 0;
+        const unsigned long long *dps = dp + (size_t)si * N;
+        const double *so = sig_old + (size_t)si * N;
+        double sum = 0.0;
+        bool is_start = false;
+        if (live) {
+            is_start = v == starts[si];
+            const uint32_t cv = (uint32_t)(dps[v] >> 32);
+            if (!is_start && cv != 0x7F800000u) {
+                const uint32_t e1 = in_off[v + 1];
+                for (uint32_t e = in_off[v] + glane; e < e1; e += kSsspLanes) {
+                    const uint32_t u = in_src[e];
+                    const uint32_t cu = (uint32_t)(dps[u] >> 32);
+                    if (cu != 0x7F800000u && __float_as_uint(__uint_as_float(cu) + in_w[e]) == cv) {
+                        if (cu == cv) atomicAdd(absorbed, 1u);  // dist[u] + w == dist[u]: no topological order, see the host
+                        sum += so[u];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = kSsspLanes / 2; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (live && glane == 0) {
+            const double nw = is_start ? 1.0 : sum;
+            if (nw != so[v]) *changed = 1;
+            sig_new[(size_t)si * N + v] = nw;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kT)
+bc_delta_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t N, uint32_t ns,
+                const unsigned long long *__restrict__ dp, const double *__restrict__ sigma, const double *__restrict__ del_old,
+                double *__restrict__ del_new, uint32_t *__restrict__ changed) {
+    const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes;
+    const uint64_t ngroups = (uint64_t)gridDim.x * blockDim.x / kSsspLanes, total = (uint64_t)ns * N;
+    const uint64_t rounds = (total + ngroups - 1) / ngroups;
+    for (uint64_t r = 0; r < rounds; r++) {
+        const uint64_t i = group + r * ngroups;
+        const bool live = i < total;
+        const uint32_t si = live ? (uint32_t)(i / N) : 0, u = live ? (uint32_t)(i % N) : 0;
+        const unsigned long long *dps = dp + (size_t)si * N;
+        const double *sg = sigma + (size_t)si * N, *dl = del_old + (size_t)si * N;
+        double sum = 0.0;
+        if (live) {
+            const uint32_t cu = (uint32_t)(dps[u] >> 32);
+            if (cu != 0x7F800000u) {
+                const double su = sg[u];
+                const float du = __uint_as_float(cu);
+                const uint32_t e1 = off[u + 1];
+                for (uint32_t e = off[u] + glane; e < e1; e += kSsspLanes) {
+                    const uint32_t v = tgt[e];
+                    if (__float_as_uint(du + w[e]) == (uint32_t)(dps[v] >> 32)) sum += su / sg[v] * (1.0 + dl[v]);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = kSsspLanes / 2; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (live && glane == 0) {
+            if (sum != dl[u]) *changed = 1;
+            del_new[(size_t)si * N + u] = sum;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kT)
+bc_accumulate_kernel(uint32_t N, uint32_t ns, const double *__restrict__ delta, const uint32_t *__restrict__ starts,
+                     double *__restrict__ cent) {
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < N; v += gridDim.x * blockDim.x) {
+        double c = cent[v];
+        for (uint32_t si = 0; si < ns; si++)
+            if (starts[si] != v) c += delta[(size_t)si * N + v];
+        cent[v] = c;
+    }
+}
+
+}  // namespace
+
+extern "C" int cz_betweenness(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N,
+                              uint64_t E, double *centrality, const volatile uint8_t *poison) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if (N == 0) return CZ_OK;
+    if (!centrality) return cz::set_error(CZ_E_INVALID, "null centrality");
+    rc = check_csr(out_offsets, out_targets, N, E);
+    if (rc) return rc;
+    if (E > 0 && !weights) return cz::set_error(CZ_E_INVALID, "null weights");
+    for (uint64_t e = 0; e < E; e++)
+        if (!(weights[e] > 0.0f))
+            return cz::set_error(CZ_E_UNSUPPORTED, "edge %llu has weight %g: the device path of BetweennessCentrality needs positive weights",
+                                 (unsigned long long)e, (double)weights[e]);
+    // the transposed graph (sigma pulls over in-edges), in-lists in ascending source order (a counting sort)
+    std::vector<uint32_t> in_off((size_t)N + 1, 0), in_src(E);
+    std::vector<float> in_w(E);
+    for (uint64_t e = 0; e < E; e++) {
+        if (out_targets[e] >= N) return cz::set_error(CZ_E_INVALID, "target %u out of range", out_targets[e]);
+        in_off[out_targets[e] + 1]++;
+    }
+    for (uint32_t v = 0; v < N; v++) in_off[v + 1] += in_off[v];
+    {
+        std::vector<uint32_t> cur(in_off.begin(), in_off.end() - 1);
+        for (uint32_t u = 0; u < N; u++)
+            for (uint32_t e = out_offsets[u]; e < out_offsets[u + 1]; e++) {
+                const uint32_t at = cur[out_targets[e]]++;
+                in_src[at] = u;
+                in_w[at] = weights[e];
+            }
+    }
+    SsspBatch sb;
+    // 56 bytes per (source, node) here: 16 + 32 of the SSSP, + 4 x 8 of sigma / delta double buffers -> a smaller batch
+    std::vector<uint32_t> all(N);
+    for (uint32_t i = 0; i < N; i++) all[i] = i;
+    uint64_t pairs = 48ull << 20;
+    if (const char *b = getenv("CZ_BC_BATCH")) pairs = std::max<uint64_t>(1, strtoull(b, nullptr, 10)) * N;  // sources per batch (tests)
+    if ((rc = sb.alloc(out_offsets, out_targets, weights, N, E, N, pairs))) return rc;
+    const uint64_t SN = (uint64_t)sb.S * N;
+    cz::DevBuf<uint32_t> d_ioff, d_isrc, d_flags;
+    cz::DevBuf<float> d_iw;
+    cz::DevBuf<double> d_sig[2], d_del[2], d_cent;
+    CZ_HIP(d_ioff.alloc((size_t)N + 1));
+    CZ_HIP(d_isrc.alloc(E));
+    CZ_HIP(d_iw.alloc(E));
+    CZ_HIP(d_flags.alloc(2));
+    CZ_HIP(d_cent.alloc(N));
+    for (int i = 0; i < 2; i++) {
+        CZ_HIP(d_sig[i].alloc(SN));
+        CZ_HIP(d_del[i].alloc(SN));
+    }
+    CZ_HIP(hipMemcpy(d_ioff.p, in_off.data(), ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
+    if (E) {
+        CZ_HIP(hipMemcpy(d_isrc.p, in_src.data(), E * 4, hipMemcpyHostToDevice));
+        CZ_HIP(hipMemcpy(d_iw.p, in_w.data(), E * 4, hipMemcpyHostToDevice));
+    }
+    hipStream_t s = sb.s;
+    CZ_HIP(hipMemsetAsync(d_cent.p, 0, (size_t)N * 8, s));
+    for (uint32_t s0 = 0; s0 < N; s0 += sb.S) {
+        const uint32_t ns = std::min<uint32_t>(sb.S, N - s0);
+        const uint64_t nsN = (uint64_t)ns * N;
+        if ((rc = sb.run(all.data() + s0, ns, poison))) return rc;
+        const int g = grid_for(nsN * kSsspLanes);
+        uint32_t h[2] = {0, 0};
+        // sigma: Jacobi sweeps from the indicator of the source until nothing changes
+        CZ_HIP(hipMemsetAsync(d_sig[0].p, 0, nsN * 8, s));
+        int cur = 0;
+        for (uint32_t sweep = 0;; sweep++) {
+            if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+            CZ_HIP(hipMemsetAsync(d_flags.p, 0, 8, s));
+            hipLaunchKernelGGL(bc_sigma_kernel, dim3(g), dim3(kT), 0, s, d_ioff.p, d_isrc.p, d_iw.p, N, ns, sb.d_dp.p, sb.d_starts.p,
+                               d_sig[cur].p, d_sig[cur ^ 1].p, d_flags.p, d_flags.p + 1);
+            CZ_HIP(hipMemcpy(h, d_flags.p, 8, hipMemcpyDeviceToHost));
+            cur ^= 1;
+            if (h[1])
+                return cz::set_error(CZ_E_UNSUPPORTED, "BetweennessCentrality: an edge weight is absorbed by the f32 path cost "
+                                                       "(dist[u] + w == dist[u]); shortest-path counts are not defined on such a graph");
+            if (!h[0]) break;
+            if (sweep > N) return cz::set_error(CZ_E_HIP, "internal: path counts did not settle");
+        }
+        const double *sigma = d_sig[cur].p;
+        CZ_HIP(hipMemsetAsync(d_del[0].p, 0, nsN * 8, s));
+        int dc = 0;
+        for (uint32_t sweep = 0;; sweep++) {
+            if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+            CZ_HIP(hipMemsetAsync(d_flags.p, 0, 4, s));
+            hipLaunchKernelGGL(bc_delta_kernel, dim3(g), dim3(kT), 0, s, sb.d_off.p, sb.d_tgt.p, sb.d_w.p, N, ns, sb.d_dp.p, sigma,
+                               d_del[dc].p, d_del[dc ^ 1].p, d_flags.p);
+            CZ_HIP(hipMemcpy(h, d_flags.p, 4, hipMemcpyDeviceToHost));
+            dc ^= 1;
+            if (!h[0]) break;
+            if (sweep > N) return cz::set_error(CZ_E_HIP, "internal: dependencies did not settle");
+        }
+        hipLaunchKernelGGL(bc_accumulate_kernel, dim3(grid_for(N)), dim3(kT), 0, s, N, ns, d_del[dc].p, sb.d_starts.p, d_cent.p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "betweenness launch: %s", hipGetErrorString(e));
+    }
+    CZ_HIP(hipMemcpy(centrality, d_cent.p, (size_t)N * 8, hipMemcpyDeviceToHost));
     return CZ_OK;
 }
 

@@ -751,16 +751,16 @@ class ClosenessCentrality(FixedRule):
 class BetweennessCentrality(FixedRule):
     """algos/all_pairs_shortest_path.rs:31-95 over `dijkstra_keep_ties` (shortest_path_dijkstra.rs:341-450): from every start,
     ALL shortest paths to every target; each path of >= 3 nodes gives 1 / (number of paths to that target) to each of its
-    middle nodes.  The reference enumerates the paths (exponential in ties); here the device does the part that scales --
-    cz_sssp from every node in batches of starts, bit-exact f32 costs -- and the host turns each distance row into the same
-    sums without enumerating: the tight edges (dist[u] + w == dist[v] in f32, one per edge occurrence, exactly the
-    reference's back_pointers) form a DAG, sigma = path counts along it, and Brandes' dependency
+    middle nodes.  The reference enumerates the paths (exponential in ties); cz_betweenness computes the same sums on the
+    device without enumerating: SSSP from every node in batches (bit-exact f32 costs), the tight edges
+    (dist[u] + w == dist[v] in f32, one per edge occurrence, exactly the reference's back_pointers) form a DAG,
+    sigma = path counts along it, and Brandes' dependency
     delta(v) = sum over tight (v, x) of sigma(v) / sigma(x) * (1 + delta(x)) IS sum over targets of (paths through v) / l.
     Accumulated in f64 (the reference adds 1/l path by path in f32): equal within 1e-5 relative, not bit for bit.
-    Weights must be positive (a zero-weight cycle sends the reference's path recursion into the ground).
+    Weights must be positive (a zero-weight cycle sends the reference's path recursion into the ground), and none may be
+    absorbed by an f32 path cost (dist[u] + w == dist[u]): such tight edges join nodes of equal distance and can close
+    cycles, through which the reference's enumeration would never end.
     Rows: (node, centrality as f64)."""
-
-    BATCH = 256
 
     def arity(self, options, rule_head) -> int:
         return 2
@@ -772,39 +772,16 @@ class BetweennessCentrality(FixedRule):
         n = graph.n
         if n == 0:
             return
-        off = np.asarray(graph.out_offsets, dtype=np.int64)
-        tgt, w = graph.out_targets, graph.out_weights
+        w = graph.out_weights
         if w.size and not (w > 0).all():
             raise FixedRuleError("BetweennessCentrality on the GPU path needs positive edge weights")
-        src_of = np.repeat(np.arange(n, dtype=np.int64), np.diff(off))
-        cent = np.zeros(n, dtype=np.float64)
-        for b0 in range(0, n, self.BATCH):
-            starts = np.arange(b0, min(n, b0 + self.BATCH), dtype=np.uint32)
-            dist, _ = _graph.sssp(graph.out_offsets, graph.out_targets, graph.out_weights, starts, poison=poison.flag)
-            for si, s in enumerate(starts):
-                d = dist[si]
-                with np.errstate(invalid="ignore"):
-                    tight = np.isfinite(d[src_of]) & ((d[src_of] + w).astype(np.float32) == d[tgt])
-                te_src, te_dst = src_of[tight], tgt[tight].astype(np.int64)
-                # f32 absorption (dist[u] + w == dist[u] for a tiny positive w) can make a tight edge join two nodes of
-                # EQUAL distance: the order below is then no topological order of the tight-edge DAG (and such edges can
-                # close cycles, through which the reference's enumeration of all shortest paths would never end)
-                if te_src.size and bool((d[te_src] == d[te_dst]).any()):
-                    raise FixedRuleError("BetweennessCentrality: an edge weight is absorbed by the f32 path cost "
-                                         "(dist[u] + w == dist[u]); shortest-path counts are not defined on such a graph")
-                # tight edges by ascending dist of their source: sigma of a node is final before any edge leaves it
-                order = np.argsort(d[te_src], kind="stable")
-                te_src, te_dst = te_src[order], te_dst[order]
-                sigma = np.zeros(n, dtype=np.float64)
-                sigma[int(s)] = 1.0
-                for u, v in zip(te_src.tolist(), te_dst.tolist()):
-                    sigma[v] += sigma[u]
-                delta = np.zeros(n, dtype=np.float64)
-                for u, v in zip(reversed(te_src.tolist()), reversed(te_dst.tolist())):  # descending dist of the source...
-                    delta[u] += sigma[u] / sigma[v] * (1.0 + delta[v])                    # ...so delta[v] is final (dist[v] > dist[u])
-                delta[int(s)] = 0.0
-                cent += delta
-            poison.check()
+        try:
+            cent = _graph.betweenness(graph.out_offsets, graph.out_targets, w, poison=poison.flag)
+        except _lib.CozoGpuError as e:
+            if e.code == _lib.CZ_E_UNSUPPORTED:
+                raise FixedRuleError(str(e)) from e
+            raise
+        poison.check()
         for i in range(n):
             out.put((indices[i], float(cent[i])))
 

@@ -159,3 +159,13 @@ def sssp(out_off, out_tgt, weights, starts, poison=None):
     check(_lib.lib().cz_sssp(ptr(out_off), ptr(out_tgt), ptr(w), N, out_tgt.size, ptr(starts), starts.size, ptr(dist),
                              ptr(parent), ptr(poison)))
     return dist, parent
+
+
+def betweenness(out_off, out_tgt, weights, poison=None):
+    """cz_betweenness on the weighted out-CSR (weights > 0) -> centrality f64 [N]"""
+    out_off, out_tgt = _csr32(out_off, out_tgt)
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    N = out_off.size - 1
+    cent = np.zeros(N, dtype=np.float64)
+    check(_lib.lib().cz_betweenness(ptr(out_off), ptr(out_tgt), ptr(w), N, out_tgt.size, ptr(cent), ptr(poison)))
+    return cent

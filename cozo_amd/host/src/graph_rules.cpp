@@ -330,11 +330,10 @@ void ClosenessCentrality::run(const FixedRulePayload &payload, RegularTempStore 
 
 // ---- BetweennessCentrality (algos/all_pairs_shortest_path.rs:31-95 over dijkstra_keep_ties) -----------------------
 // The reference enumerates ALL shortest paths from every start and gives each path's middle nodes 1 / (paths to that target).
-// Here cz_sssp does what scales (bit-exact f32 costs from every start, in batches) and the host turns every distance row into
-// the same sums without enumerating: the tight edges (dist[u] + w == dist[v] in f32, one per edge occurrence = the reference's
-// back_pointers) form a DAG; sigma = path counts along it; Brandes' dependency
-// delta(v) = sum over tight (v, x) of sigma(v) / sigma(x) * (1 + delta(x)) is sum over targets of (paths through v) / l.
-// f64 accumulation (the reference adds 1/l path by path in f32): equal within 1e-5 relative.
+// cz_betweenness computes the same sums on the device without enumerating: SSSP from every start in batches (bit-exact f32
+// costs); the tight edges (dist[u] + w == dist[v] in f32, one per edge occurrence = the reference's back_pointers) form a DAG;
+// sigma = path counts along it; Brandes' dependency delta(v) = sum over tight (v, x) of sigma(v) / sigma(x) * (1 + delta(x))
+// is sum over targets of (paths through v) / l.  f64 sums (the reference adds 1/l path by path in f32): equal within 1e-5.
 void BetweennessCentrality::run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const {
     const FixedRuleInputRelation &edges = payload.get_input(0);
     const bool undirected = payload.bool_option("undirected", false);
@@ -344,44 +343,12 @@ void BetweennessCentrality::run(const FixedRulePayload &payload, RegularTempStor
     if (n == 0) return;
     for (float w : gr.out_weights)
         if (!(w > 0.0f)) throw CozoError("algo::betweenness_needs_positive_weights", "BetweennessCentrality on the GPU path needs positive edge weights");
-    constexpr uint32_t kBatch = 256;
-    std::vector<float> dist((size_t)std::min(n, kBatch) * n);
-    std::vector<uint32_t> parent(dist.size()), starts, order(n);
-    std::vector<double> cent(n, 0.0), sigma(n), delta(n);
-    for (uint32_t b0 = 0; b0 < n; b0 += kBatch) {
-        const uint32_t nb = std::min(kBatch, n - b0);
-        starts.resize(nb);
-        for (uint32_t i = 0; i < nb; i++) starts[i] = b0 + i;
-        check_gpu(cz_sssp(gr.out_offsets.data(), gr.out_targets.data(), gr.out_weights.data(), n, gr.edge_count(), starts.data(),
-                          nb, dist.data(), parent.data(), poison.flag_ptr()));
-        for (uint32_t i = 0; i < nb; i++) {
-            const float *d = dist.data() + (size_t)i * n;
-            const uint32_t s = b0 + i;
-            uint32_t reached = 0;
-            for (uint32_t v = 0; v < n; v++)
-                if (std::isfinite(d[v])) order[reached++] = v;
-            std::stable_sort(order.begin(), order.begin() + reached, [&](uint32_t a, uint32_t b) { return d[a] < d[b]; });
-            std::fill(sigma.begin(), sigma.end(), 0.0);
-            std::fill(delta.begin(), delta.end(), 0.0);
-            sigma[s] = 1.0;
-            auto tight = [&](uint32_t u, uint32_t e) { return (float)(d[u] + gr.out_weights[e]) == d[gr.out_targets[e]]; };
-            for (uint32_t k = 0; k < reached; k++) {  // ascending distance: sigma[u] is final before an edge leaves u
-                const uint32_t u = order[k];
-                for (uint32_t e = gr.out_offsets[u]; e < gr.out_offsets[u + 1]; e++)
-                    if (tight(u, e)) sigma[gr.out_targets[e]] += sigma[u];
-            }
-            for (uint32_t k = reached; k-- > 0;) {  // descending distance: delta of every successor is final
-                const uint32_t u = order[k];
-                for (uint32_t e = gr.out_offsets[u]; e < gr.out_offsets[u + 1]; e++)
-                    if (tight(u, e)) {
-                        const uint32_t x = gr.out_targets[e];
-                        delta[u] += sigma[u] / sigma[x] * (1.0 + delta[x]);
-                    }
-                if (u != s) cent[u] += delta[u];
-            }
-        }
-        poison.check();
-    }
+    std::vector<double> cent(n, 0.0);
+    const int rc = cz_betweenness(gr.out_offsets.data(), gr.out_targets.data(), gr.out_weights.data(), n, gr.edge_count(), cent.data(),
+                                  poison.flag_ptr());
+    if (rc == CZ_E_UNSUPPORTED) throw CozoError("algo::betweenness_absorbed_weight", cz_last_error());
+    check_gpu(rc);
+    poison.check();
     for (uint32_t v = 0; v < n; v++) out.put(Tuple{g.indices[v], DataValue(cent[v])});
 }
 

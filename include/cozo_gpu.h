@@ -359,6 +359,16 @@ int cz_clustering_coefficients(const uint32_t *offsets, const uint32_t *targets,
 int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
             const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison);
 
+/* BetweennessCentrality::run (fixed_rule/algos/all_pairs_shortest_path.rs:31-95 over dijkstra_keep_ties,
+ * shortest_path_dijkstra.rs:341-450) on the weighted out-CSR, weights > 0:
+ *   centrality [N] f64 out: the sum, over every (start, target) pair and every one of the l shortest paths between them,
+ *   of 1 / l for each inner node of the path -- computed from path counts over the tight edges (dist[u] + w == dist[v]
+ *   in f32, the reference's back pointers) instead of enumerating paths; f64 sums (the reference adds f32 terms path by
+ *   path): equal within 1e-5 relative.  CZ_E_UNSUPPORTED for a weight <= 0 or one absorbed by an f32 path cost
+ *   (dist[u] + w == dist[u]: shortest-path counts are not defined; the reference's enumeration would not end). */
+int cz_betweenness(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
+                   double *centrality, const volatile uint8_t *poison);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,3 +99,17 @@ int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets, const floa
     free(off);
     return CZ_OK;
 }
+
+int cz_betweenness(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
+                   double *centrality, const volatile uint8_t *poison) {
+    (void)E;
+    if (poisoned(poison)) { g_err = "cancelled"; return CZ_E_CANCELLED; }
+    uint64_t *off = widen(out_offsets, N);
+    float *c = (float *)malloc(((size_t)N + 1) * sizeof(float));
+    const int rc = orc_betweenness(N, off, out_targets, weights, c, 100000000ull);
+    for (uint32_t v = 0; v < N; v++) centrality[v] = c[v];
+    free(c);
+    free(off);
+    if (rc) { g_err = "oracle: too many shortest paths"; return CZ_E_UNSUPPORTED; }
+    return CZ_OK;
+}

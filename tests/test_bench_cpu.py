@@ -19,7 +19,7 @@ def test_argument_contract(monkeypatch):
     b = _bench()
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = b.parse()
-    assert a.gpus == 1 and a.steps > 0 and a.warmup >= 0 and a.n == 1_000_000 and a.dim == 768 and a.batch == 1024 and a.k == 10
+    assert a.gpus == 1 and a.steps > 0 and a.warmup >= 0 and a.n == 10_000_000 and a.dim == 768 and a.batch == 1024 and a.k == 10
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
     a = b.parse()
     assert (a.gpus, a.steps, a.warmup) == (8, 5, 2)

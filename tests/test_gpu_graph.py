@@ -355,3 +355,71 @@ def test_pagerank_plan_cache(graphs, oracle):
     s5, _, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], cache_key=(7, 42), timing=t1)
     assert t1["cache_hit"] and np.array_equal(s5, os_)
     _lib.lib().cz_pagerank_cache_clear()
+
+
+def _brandes_f64(n, off, tgt, w, dist_of):
+    """path-count (Brandes) betweenness over the f32 tight edges, f64 sums, in node order per level: the test's own statement of
+    what cz_betweenness computes (the literal enumeration of the oracle is exponential in ties)"""
+    off = off.astype(np.int64)
+    src_of = np.repeat(np.arange(n, dtype=np.int64), np.diff(off))
+    cent = np.zeros(n)
+    for s in range(n):
+        d = dist_of(s)
+        with np.errstate(invalid="ignore"):
+            tight = np.isfinite(d[src_of]) & ((d[src_of] + w).astype(np.float32) == d[tgt])
+        ts, td = src_of[tight], tgt[tight].astype(np.int64)
+        order = np.argsort(d[ts], kind="stable")
+        ts, td = ts[order], td[order]
+        sigma = np.zeros(n)
+        sigma[s] = 1.0
+        for u, v in zip(ts.tolist(), td.tolist()):
+            sigma[v] += sigma[u]
+        delta = np.zeros(n)
+        for u, v in zip(reversed(ts.tolist()), reversed(td.tolist())):
+            delta[u] += sigma[u] / sigma[v] * (1.0 + delta[v])
+        delta[s] = 0.0
+        cent += delta
+    return cent
+
+
+@pytest.mark.parametrize("batch", [None, "7"])
+def test_betweenness_against_enumeration_and_path_counts(oracle, gpu_lib, monkeypatch, batch):
+    """cz_betweenness (all_pairs_shortest_path.rs:31-95): against the oracle's literal enumeration of all shortest paths on
+    a graph with many ties (integer weights 1..3), and against path counts over the oracle's Dijkstra costs on a larger
+    one; with the sources in one batch and in batches of 7."""
+    from cozo_amd import graph as G
+    if batch:
+        monkeypatch.setenv("CZ_BC_BATCH", batch)
+    rng = np.random.default_rng(5)
+    frm, to = util.random_relation(40, 150, 3)
+    g = util.graph_from_relation(oracle, frm, to, weights=rng.integers(1, 4, len(frm)).astype(np.float32))
+    got = G.betweenness(g["ooff"], g["otgt"], g["ow"])
+    want = oracle.betweenness(g["n"], g["ooff"], g["otgt"], g["ow"]).astype(np.float64)
+    assert np.abs(want - np.round(want)).max() > 1e-3  # fractional shares: ties exist
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
+    frm, to = util.random_relation(300, 2400, 9)
+    w = rng.integers(1, 6, len(frm)).astype(np.float32)
+    w[::5] = rng.random(len(w[::5])).astype(np.float32) + 0.5
+    g = util.graph_from_relation(oracle, frm, to, weights=w, undirected=True)
+    got = G.betweenness(g["ooff"], g["otgt"], g["ow"])
+    want = _brandes_f64(g["n"], g["ooff"], g["otgt"], g["ow"],
+                        lambda s: oracle.dijkstra(g["n"], g["ooff"], g["otgt"], g["ow"], s)[0])
+    assert want.max() > 100 and np.allclose(got, want, rtol=1e-10, atol=1e-9)
+
+
+def test_betweenness_refusals(gpu_lib):
+    from cozo_amd import _lib, graph as G
+    off, tgt = np.array([0, 1, 2, 2], np.uint32), np.array([1, 2], np.uint32)
+    assert np.array_equal(G.betweenness(off, tgt, np.array([1.0, 2.0], np.float32)), [0.0, 1.0, 0.0])
+    assert G.betweenness(np.array([0], np.uint32), np.array([], np.uint32), np.array([], np.float32)).size == 0
+    for bad in (0.0, -1.0, float("nan")):
+        with pytest.raises(_lib.CozoGpuError) as e:
+            G.betweenness(off, tgt, np.array([1.0, bad], np.float32))
+        assert e.value.code == _lib.CZ_E_UNSUPPORTED
+    # 2^25 + 1 == 2^25 in f32: the second edge is absorbed by the path cost
+    with pytest.raises(_lib.CozoGpuError) as e:
+        G.betweenness(off, tgt, np.array([2.0 ** 25, 1.0], np.float32))
+    assert e.value.code == _lib.CZ_E_UNSUPPORTED and "absorbed" in str(e.value)
+    flag = np.ones(1, dtype=np.uint8)
+    with pytest.raises(_lib.ProcessKilled):
+        G.betweenness(off, tgt, np.array([1.0, 2.0], np.float32), poison=flag)

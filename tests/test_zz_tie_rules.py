@@ -132,7 +132,7 @@ def test_dijkstra_keep_ties_rule(registry, undirected):
     assert {(s, t, c, tuple(p)) for s, t, c, p in one} == {r for r in got if r[0] == starts[0] and r[1] == goals[1]}
 
 
-def test_betweenness_on_air_routes_against_networkx(registry):
+def test_betweenness_on_air_routes_against_networkx(registry, request):
     """An independent cross-check on the reference's own fixture (cozo-core/tests/air_routes.rs data): the routes among the
     220 busiest airports, weight = distance in miles (integers: f32 and f64 agree on every tie), BetweennessCentralityGpu against
     networkx's weighted betweenness (Brandes, float64, unnormalised, endpoints excluded) -- the same quantity the reference's
@@ -151,8 +151,10 @@ def test_betweenness_on_air_routes_against_networkx(registry):
     want = nx.betweenness_centrality(g, normalized=False, weight="weight", endpoints=False)
     got = dict(rows)
     assert set(got) == set(want) and max(want.values()) > 100
+    # the device sums in f64; the host-logic stand-in is the oracle's literal f32 enumeration (the reference's arithmetic)
+    tol = 1e-9 if "gpu" in request.node.callspec.id else 1e-5
     for node, c in want.items():
-        assert got[node] == pytest.approx(c, rel=1e-9, abs=1e-9), node
+        assert got[node] == pytest.approx(c, rel=tol, abs=tol), node
 
 
 def test_clustering_coefficients_on_air_routes_against_networkx(registry):

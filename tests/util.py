@@ -53,7 +53,7 @@ def graph_from_relation(O, frm, to, undirected=False, weights=None):
 
 
 class OracleGraphBackend:
-    """Stands in for cozo_amd.graph's four entry points on a box without a GPU, so that the host logic of
+    """Stands in for cozo_amd.graph's entry points on a box without a GPU, so that the host logic of
     cozo_amd/fixed_rule.py (option parsing, id mapping, CSR build, row emission) is testable on CPU.
     TEST-ONLY: the product never routes through it."""
 
@@ -62,7 +62,7 @@ class OracleGraphBackend:
 
     def install(self, monkeypatch):
         import cozo_amd.graph as G
-        for name in ("pagerank", "bfs", "connected_components", "sssp", "clustering_coefficients"):
+        for name in ("pagerank", "bfs", "connected_components", "sssp", "clustering_coefficients", "betweenness"):
             monkeypatch.setattr(G, name, getattr(self, name))
 
     def pagerank(self, in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10, poison=None):
@@ -104,3 +104,6 @@ class OracleGraphBackend:
         for si, s in enumerate(starts):
             dist[si], parent[si] = self.O.dijkstra(n, out_off, out_tgt, weights, int(s))
         return dist, parent
+
+    def betweenness(self, out_off, out_tgt, weights, poison=None):
+        return self.O.betweenness(len(out_off) - 1, out_off, out_tgt, weights, max_paths=200_000_000).astype(np.float64)
