@@ -232,82 +232,74 @@ __global__ void __launch_bounds__(kT) iota_kernel(uint32_t *__restrict__ p, uint
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
 }
 
-// Two forms of one label-propagation round; the fixed point (label[v] = smallest index of v's component) does not
-// depend on the schedule, so the group ids are the same whichever runs.
-//   cc_relax_node_kernel   one thread per node walks its list serially.  Used for the FIRST round, when almost every edge
-//                          issues an atomicMin (labels are still the node ids): 9.3 ms on the symmetrised 10M / 200M graph.
-//   cc_relax_kernel        a group of kCcLanes lanes owns one node and reads its adjacency list coalesced; the group's
-//                          minimum neighbour label comes from a butterfly.  Used from the second round on, when the round
-//                          is mostly reads: 3.4 ms against 9.3 ms (profiles/r02_graph_rules_kernel_stats.txt).  As the first
-//                          round it measured 30.9 ms -- 16 times more lanes issuing the same 10^8 atomics at once.
+// Union-find with sampling (the "Afforest" scheme): comp[] is a forest whose links always point from a higher to a lower
+// index, so the root of every tree is the SMALLEST index of its component -- the label the group numbering needs, whatever
+// the order in which links happen.
+//   1. every node links with its first two neighbours (2 x N links instead of E), trees are compressed;
+//   2. a sample of the nodes names the component most of them are in (on a graph with a giant component: that one);
+//   3. nodes OUTSIDE that component link with the rest of their neighbours -- the nodes inside skip their lists: an edge
+//      leaving the big component is seen from its other end, the adjacency being symmetric (as_directed_graph(undirected =
+//      true), which is what the rule passes; header);
+//   4. compress.
+// On the symmetrised 10M / 200M uniform graph step 3 skips all but a handful of lists: the rule reads ~2 N adjacency
+// entries, not E.  Round 1/2's min-label propagation (one atomicMin per edge per round) took 9.3 + 3.4 ms there.
 constexpr int kCcLanes = 16;
+constexpr uint32_t kCcNeighbourRounds = 2, kCcSamples = 1024;
 
-__global__ void __launch_bounds__(kT)
-cc_relax_node_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t N, uint32_t *__restrict__ label,
-                     uint32_t *__restrict__ changed) {
-    bool ch = false;
-    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < N; u += gridDim.x * blockDim.x) {
-        uint32_t lu = label[u], m = lu;
-        for (uint32_t e = off[u]; e < off[u + 1]; e++) {
-            const uint32_t v = tgt[e];
-            const uint32_t lv = label[v];
-            if (lv < m) m = lv;
-            if (lu < lv) {
-                if (atomicMin(&label[v], lu) > lu) ch = true;
-            }
-        }
-        if (m < lu) {
-            if (atomicMin(&label[u], m) > m) ch = true;
-            // hook the old representative too, so whole trees move at once
-            if (atomicMin(&label[lu], m) > m) ch = true;
-        }
+__device__ __forceinline__ uint32_t cc_load(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // other lanes' links must become visible
+}
+
+__device__ __forceinline__ void cc_link(uint32_t u, uint32_t v, uint32_t *__restrict__ comp) {
+    uint32_t p1 = cc_load(&comp[u]), p2 = cc_load(&comp[v]);
+    while (p1 != p2) {
+        const uint32_t high = p1 > p2 ? p1 : p2, low = p1 > p2 ? p2 : p1;
+        const uint32_t ph = cc_load(&comp[high]);
+        if (ph == low) break;                                                 // already hooked there
+        if (ph == high && atomicCAS(&comp[high], high, low) == high) break;   // high was a root: hook it under low
+        p1 = cc_load(&comp[cc_load(&comp[high])]);                            // somebody moved it: climb and retry
+        p2 = cc_load(&comp[low]);
     }
-    if (ch) *changed = 1;
 }
 
 __global__ void __launch_bounds__(kT)
-cc_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t N, uint32_t *__restrict__ label,
-                uint32_t *__restrict__ changed) {
-    bool ch = false;
+cc_link_nth_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t N, uint32_t nth, uint32_t *__restrict__ comp) {
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < N; u += gridDim.x * blockDim.x) {
+        const uint32_t e = off[u] + nth;
+        if (e < off[u + 1]) cc_link(u, tgt[e], comp);
+    }
+}
+
+// pointer jumping in place: every node keeps replacing its pointer by its grandparent's until it points at a root; the
+// lanes shorten each other's paths as they go, so a chain of length L costs O(log L) steps per node, not L
+__global__ void __launch_bounds__(kT) cc_compress_kernel(uint32_t N, uint32_t *__restrict__ comp) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        uint32_t p = cc_load(&comp[i]);
+        for (;;) {
+            const uint32_t pp = cc_load(&comp[p]);
+            if (pp == p) break;
+            __hip_atomic_store(&comp[i], pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p = pp;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kT)
+cc_sample_kernel(uint32_t N, const uint32_t *__restrict__ comp, uint32_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < kCcSamples) out[i] = comp[(uint32_t)(((uint64_t)i * 2654435761ull + 12345ull) % N)];
+}
+
+// step 3: a group of kCcLanes lanes per node outside `skip`, the rest of its list read coalesced
+__global__ void __launch_bounds__(kT)
+cc_link_rest_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t N, uint32_t first, uint32_t skip,
+                    uint32_t *__restrict__ comp) {
     const uint32_t glane = threadIdx.x & (kCcLanes - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kCcLanes, ngroups = gridDim.x * blockDim.x / kCcLanes;
-    const uint32_t rounds = (N + ngroups - 1) / ngroups;  // every group of a wave runs the same trip count (shuffles)
-    for (uint32_t r = 0; r < rounds; r++) {
-        const uint32_t u = group + r * ngroups;
-        const bool live = u < N;
-        const uint32_t lu = live ? label[u] : CZ_NONE;
-        uint32_t m = lu;
-        if (live) {
-            const uint32_t e1 = off[u + 1];
-            for (uint32_t e = off[u] + glane; e < e1; e += kCcLanes) {
-                const uint32_t v = tgt[e];
-                const uint32_t lv = label[v];
-                if (lv < m) m = lv;
-                if (lu < lv) {
-                    if (atomicMin(&label[v], lu) > lu) ch = true;
-                }
-            }
-        }
-#pragma unroll
-        for (int o = kCcLanes / 2; o >= 1; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o, 64));
-        if (live && glane == 0 && m < lu) {
-            if (atomicMin(&label[u], m) > m) ch = true;
-            // hook the old representative too, so whole trees move at once
-            if (atomicMin(&label[lu], m) > m) ch = true;
-        }
-    }
-    if (ch) *changed = 1;
-}
-
-__global__ void __launch_bounds__(kT) cc_jump_kernel(uint32_t N, uint32_t *__restrict__ label) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-        uint32_t l = label[i];
-        for (;;) {
-            const uint32_t ll = label[l];
-            if (ll == l) break;
-            l = ll;
-        }
-        label[i] = l;
+    for (uint32_t u = group; u < N; u += ngroups) {
+        if (cc_load(&comp[u]) == skip) continue;
+        const uint32_t e1 = off[u + 1];
+        for (uint32_t e = off[u] + first + glane; e < e1; e += kCcLanes) cc_link(u, tgt[e], comp);
     }
 }
 
@@ -352,6 +344,8 @@ __device__ __forceinline__ void sssp_push(const SsspQueue &q, bool want, unsigne
 // relax the out-edges of every (source, node) entry of `cur`: a 16-lane group per entry reads the adjacency coalesced.
 // An improved target goes to `near` when its new cost is below the threshold, else to `far`; `qtag` / `ftag` (one word
 // per (source, node)) keep a pair from entering the same pile twice in one round / one phase.
+// (V: scratch experiments only -- pieces of the kernel left out to see what each costs; V = 0 is the kernel)
+template <int V>
 __global__ void __launch_bounds__(kT)
 sssp_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t N,
                   const unsigned long long *__restrict__ cur, uint32_t n_cur, unsigned long long *__restrict__ dp,
@@ -381,17 +375,31 @@ sssp_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__
                 v = tgt[e];
                 const float nd = du + w[e];  // `cost + path_weight` in f32 (shortest_path_dijkstra.rs:303)
                 const uint32_t nb = __float_as_uint(nd);
-                unsigned long long seen = __hip_atomic_load(&dps[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while (nb < (uint32_t)(seen >> 32)) {  // strict `<` (:304); non-negative floats order as their bits
-                    const unsigned long long want = ((unsigned long long)nb << 32) | u;
-                    const unsigned long long got = atomicCAS(&dps[v], seen, want);
-                    if (got == seen) {
-                        const size_t at = (size_t)si * N + v;
-                        if (nb < thr_bits) to_near = atomicExch(&qtag[at], round_tag) != round_tag;
-                        else to_far = atomicExch(&ftag[at], phase_tag) != phase_tag;
-                        break;
-                    }
-                    seen = got;
+                if (V >= 4) {
+                    to_near = nb == 0x12345678u && v == 77u;
+                } else {
+                    unsigned long long seen = __hip_atomic_load(&dps[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (V == 3) {
+                        to_near = nb < (uint32_t)(seen >> 32) && v == 0xFFFFFFF0u;
+                    } else
+                        while (nb < (uint32_t)(seen >> 32)) {  // strict `<` (:304); non-negative floats order as their bits
+                            const unsigned long long want = ((unsigned long long)nb << 32) | u;
+                            const unsigned long long got = atomicCAS(&dps[v], seen, want);
+                            if (got == seen) {
+                                const size_t at = (size_t)si * N + v;
+                                if (V == 1) {
+                                    to_near = nb < thr_bits;
+                                    to_far = !to_near;
+                                } else if (V == 2) {
+                                    to_near = v == 0xFFFFFFF0u;
+                                } else {
+                                    if (nb < thr_bits) to_near = atomicExch(&qtag[at], round_tag) != round_tag;
+                                    else to_far = atomicExch(&ftag[at], phase_tag) != phase_tag;
+                                }
+                                break;
+                            }
+                            seen = got;
+                        }
                 }
             }
             const unsigned long long item = ((unsigned long long)si << 32) | v;
@@ -601,7 +609,7 @@ extern "C" int cz_connected_components(const uint32_t *offsets, const uint32_t *
     CZ_HIP(d_off.alloc((size_t)N + 1));
     CZ_HIP(d_tgt.alloc(E));
     CZ_HIP(d_label.alloc(N));
-    CZ_HIP(d_flag.alloc(N));
+    CZ_HIP(d_flag.alloc(std::max<size_t>(N, kCcSamples)));  // (first the sample of step 2, then the root flags)
     CZ_HIP(d_rank.alloc(N));
     CZ_HIP(d_scratch.alloc(scan_scratch_words(N)));
     CZ_HIP(d_misc.alloc(4));
@@ -610,19 +618,24 @@ extern "C" int cz_connected_components(const uint32_t *offsets, const uint32_t *
     hipStream_t s = nullptr;
     const int g = grid_for(N);
     hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(kT), 0, s, d_label.p, N);
-    for (uint32_t round = 0;; round++) {
-        if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
-        CZ_HIP(hipMemsetAsync(d_misc.p, 0, 4, s));
-        if (round == 0)
-            hipLaunchKernelGGL(cc_relax_node_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, N, d_label.p, d_misc.p);
-        else
-            hipLaunchKernelGGL(cc_relax_kernel, dim3(grid_for((uint64_t)N * kCcLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, N,
-                               d_label.p, d_misc.p);
-        hipLaunchKernelGGL(cc_jump_kernel, dim3(g), dim3(kT), 0, s, N, d_label.p);
-        uint32_t changed = 0;
-        CZ_HIP(hipMemcpy(&changed, d_misc.p, 4, hipMemcpyDeviceToHost));
-        if (!changed) break;
+    for (uint32_t r = 0; r < kCcNeighbourRounds; r++) {
+        hipLaunchKernelGGL(cc_link_nth_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, N, r, d_label.p);
+        hipLaunchKernelGGL(cc_compress_kernel, dim3(g), dim3(kT), 0, s, N, d_label.p);
     }
+    // the component most of a fixed sample of the nodes is in
+    uint32_t sample[kCcSamples];
+    hipLaunchKernelGGL(cc_sample_kernel, dim3(kCcSamples / kT), dim3(kT), 0, s, N, d_label.p, d_flag.p);
+    CZ_HIP(hipMemcpy(sample, d_flag.p, sizeof sample, hipMemcpyDeviceToHost));
+    if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+    std::sort(sample, sample + kCcSamples);
+    uint32_t skip = sample[0], best = 0;
+    for (uint32_t i = 0, j; i < kCcSamples; i = j) {
+        for (j = i; j < kCcSamples && sample[j] == sample[i]; j++) {}
+        if (j - i > best) best = j - i, skip = sample[i];
+    }
+    hipLaunchKernelGGL(cc_link_rest_kernel, dim3(grid_for((uint64_t)N * kCcLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, N,
+                       kCcNeighbourRounds, skip, d_label.p);
+    hipLaunchKernelGGL(cc_compress_kernel, dim3(g), dim3(kT), 0, s, N, d_label.p);
     hipLaunchKernelGGL(cc_rootflag_kernel, dim3(g), dim3(kT), 0, s, N, d_label.p, d_flag.p);
     rc = exclusive_scan(d_flag.p, d_rank.p, N, d_misc.p, d_scratch.p, s);
     if (rc) return rc;
@@ -762,6 +775,69 @@ struct SsspBatch {
         return CZ_OK;
     }
 
+    // scratch: one big round replayed with pieces of the relax kernel left out (CZ_SSSP_EXPERIMENT); state restored after
+    template <int V>
+    float replay(const unsigned long long *cur, uint32_t n_cur, unsigned long long *nq, unsigned long long *fq, uint32_t round,
+                 uint32_t phase, uint32_t thr_bits, const unsigned long long *dp0, const uint32_t *q0, const uint32_t *f0,
+                 const uint32_t *m0, int blocks_cap) {
+        const uint64_t nN = N;
+        hipMemcpy(d_dp.p, dp0, nN * 8, hipMemcpyDeviceToDevice);
+        hipMemcpy(d_qtag.p, q0, nN * 4, hipMemcpyDeviceToDevice);
+        hipMemcpy(d_ftag.p, f0, nN * 4, hipMemcpyDeviceToDevice);
+        hipMemcpy(d_misc.p, m0, 32, hipMemcpyDeviceToDevice);
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        int g = grid_for((uint64_t)n_cur * kSsspLanes);
+        if (blocks_cap) g = (int)std::min<uint64_t>(((uint64_t)n_cur * kSsspLanes + kT - 1) / kT, (uint64_t)blocks_cap);
+        hipEventRecord(a, s);
+        hipLaunchKernelGGL(sssp_relax_kernel<V>, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, d_w.p, N, cur, n_cur, d_dp.p, d_qtag.p, round,
+                           d_ftag.p, phase, thr_bits, SsspQueue{nq, d_misc.p}, SsspQueue{fq, d_misc.p + 1});
+        hipEventRecord(b, s);
+        hipEventSynchronize(b);
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        uint32_t h[2];
+        hipMemcpy(h, d_misc.p, 8, hipMemcpyDeviceToHost);
+        fprintf(stderr, "  V=%d blocks=%d: %.3f ms (near %u far %u)\n", V, g, ms, h[0], h[1]);
+        hipEventDestroy(a);
+        hipEventDestroy(b);
+        return ms;
+    }
+    void experiment(const unsigned long long *cur, uint32_t n_cur, unsigned long long *nq, unsigned long long *fq, uint32_t round,
+                    uint32_t phase, uint32_t thr_bits) {
+        cz::DevBuf<unsigned long long> dp0, fq0;
+        cz::DevBuf<uint32_t> q0, f0, m0;
+        dp0.alloc(N);
+        q0.alloc(N);
+        f0.alloc(N);
+        m0.alloc(8);
+        hipStreamSynchronize(s);
+        uint32_t hm[8];
+        hipMemcpy(hm, d_misc.p, 32, hipMemcpyDeviceToHost);
+        fq0.alloc(hm[1] + 1);
+        hipMemcpy(fq0.p, fq, (size_t)hm[1] * 8, hipMemcpyDeviceToDevice);
+        hipMemcpy(dp0.p, d_dp.p, (size_t)N * 8, hipMemcpyDeviceToDevice);
+        hipMemcpy(q0.p, d_qtag.p, (size_t)N * 4, hipMemcpyDeviceToDevice);
+        hipMemcpy(f0.p, d_ftag.p, (size_t)N * 4, hipMemcpyDeviceToDevice);
+        hipMemcpy(m0.p, d_misc.p, 32, hipMemcpyDeviceToDevice);
+        fprintf(stderr, "experiment: round %u, %u near entries, far %u\n", round, n_cur, hm[1]);
+        for (int rep = 0; rep < 2; rep++) {
+            replay<0>(cur, n_cur, nq, fq, round, phase, thr_bits, dp0.p, q0.p, f0.p, m0.p, 0);
+            replay<1>(cur, n_cur, nq, fq, round, phase, thr_bits, dp0.p, q0.p, f0.p, m0.p, 0);
+            replay<2>(cur, n_cur, nq, fq, round, phase, thr_bits, dp0.p, q0.p, f0.p, m0.p, 0);
+            replay<3>(cur, n_cur, nq, fq, round, phase, thr_bits, dp0.p, q0.p, f0.p, m0.p, 0);
+            replay<4>(cur, n_cur, nq, fq, round, phase, thr_bits, dp0.p, q0.p, f0.p, m0.p, 0);
+            replay<0>(cur, n_cur, nq, fq, round, phase, thr_bits, dp0.p, q0.p, f0.p, m0.p, 2048);
+            replay<0>(cur, n_cur, nq, fq, round, phase, thr_bits, dp0.p, q0.p, f0.p, m0.p, 65536);
+        }
+        hipMemcpy(d_dp.p, dp0.p, (size_t)N * 8, hipMemcpyDeviceToDevice);
+        hipMemcpy(d_qtag.p, q0.p, (size_t)N * 4, hipMemcpyDeviceToDevice);
+        hipMemcpy(d_ftag.p, f0.p, (size_t)N * 4, hipMemcpyDeviceToDevice);
+        hipMemcpy(d_misc.p, m0.p, 32, hipMemcpyDeviceToDevice);
+        hipMemcpy(fq, fq0.p, (size_t)hm[1] * 8, hipMemcpyDeviceToDevice);
+    }
+
     // d_misc: [0] near-next count, [1] far count, [2] far-next count, [3] min far cost bits
     int run(const uint32_t *starts, uint32_t ns, const volatile uint8_t *poison) {
         const uint64_t nsN = (uint64_t)ns * N;
@@ -776,13 +852,16 @@ struct SsspBatch {
         CZ_HIP(hipMemcpy(h, d_misc.p, 16, hipMemcpyDeviceToHost));
         uint32_t n_near = h[0], n_far = 0, round = 1, phase = 1;
         float thr = one_pile ? INFINITY : delta;
+        static const bool trace = getenv("CZ_SSSP_TRACE") != nullptr;  // per-round pile sizes on stderr (scratch/ experiments)
         for (;;) {
             while (n_near > 0) {
+                if (trace) fprintf(stderr, "sssp phase %u round %u thr %g near %u far %u\n", phase, round, (double)thr, n_near, n_far);
                 if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
                 CZ_HIP(hipMemsetAsync(d_misc.p, 0, 4, s));
                 uint32_t thr_bits;
                 memcpy(&thr_bits, &thr, 4);
-                hipLaunchKernelGGL(sssp_relax_kernel, dim3(grid_for((uint64_t)n_near * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p,
+                if (n_near > 3000000 && getenv("CZ_SSSP_EXPERIMENT")) experiment(near_cur, n_near, near_next, far_cur, round, phase, thr_bits);
+                hipLaunchKernelGGL(sssp_relax_kernel<0>, dim3(grid_for((uint64_t)n_near * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p,
                                    d_w.p, N, near_cur, n_near, d_dp.p, d_qtag.p, round, d_ftag.p, phase, thr_bits,
                                    SsspQueue{near_next, d_misc.p}, SsspQueue{far_cur, d_misc.p + 1});
                 CZ_HIP(hipMemcpy(h, d_misc.p, 8, hipMemcpyDeviceToHost));

@@ -208,6 +208,50 @@ def test_connected_components_bitexact(oracle, gpu_lib):
     assert k == 1 and (grp == 0).all()
 
 
+def _numpy_components(n, frm, to):
+    """group ids the way the rule numbers them (rank of the component by its smallest member), from scipy's labels"""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    k, lab = connected_components(coo_matrix((np.ones(len(frm), np.int8), (frm, to)), shape=(n, n)), directed=False)
+    first = np.full(k, n, dtype=np.int64)
+    np.minimum.at(first, lab, np.arange(n))
+    return np.argsort(np.argsort(first))[lab].astype(np.uint32), k
+
+
+def _sym_csr(n, frm, to):
+    s = np.concatenate([frm, to])
+    t = np.concatenate([to, frm])
+    order = np.lexsort((t, s))
+    off = np.zeros(n + 1, dtype=np.uint32)
+    off[1:] = np.cumsum(np.bincount(s, minlength=n))
+    return off, t[order].astype(np.uint32)
+
+
+def test_connected_components_shapes_of_the_union_find(gpu_lib):
+    """the shapes the sampling union-find could get wrong: a giant component + thousands of small ones (its lists are
+    skipped, theirs are not), no dominant component at all, components whose smallest member is reached last (descending
+    chains: every hook moves a root), a 2M-node path in a scrambled numbering (deep trees before compression), stars."""
+    from cozo_amd import graph as G
+    rng = np.random.default_rng(8)
+    cases = []
+    n = 300_000
+    big = rng.integers(0, 200_000, (2, 500_000))                               # giant component among the first 200k
+    small = 200_000 + rng.integers(0, 100_000, 60_000)
+    cases.append((n, np.concatenate([big[0], small]), np.concatenate([big[1], np.minimum(small + rng.integers(1, 3, small.size), n - 1)])))
+    cases.append((n, np.arange(0, n - 1, 2), np.arange(1, n, 2)))              # 150k pairs: no dominant component
+    perm = rng.permutation(2_000_000)
+    cases.append((2_000_000, perm[:-1], perm[1:]))                             # one path, scrambled numbering
+    cases.append((n, np.arange(n - 1, 0, -1), np.arange(n - 2, -1, -1)))       # descending chain
+    hubs = rng.integers(0, 50, n)
+    cases.append((n + 50, 50 + np.arange(n), hubs))                            # 50 stars of ~6000 leaves
+    for n, frm, to in cases:
+        frm, to = np.asarray(frm, dtype=np.int64), np.asarray(to, dtype=np.int64)
+        off, tgt = _sym_csr(n, frm, to)
+        grp, k = G.connected_components(off, tgt)
+        want, wk = _numpy_components(n, frm, to)
+        assert k == wk and np.array_equal(grp, want)
+
+
 def test_clustering_coefficients_bitexact(oracle, gpu_lib):
     """triangles.rs:70-110: integer triangle / degree counts per node, duplicates and self loops included"""
     from cozo_amd import graph as G
