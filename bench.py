@@ -707,10 +707,10 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
 def bench_graph_rules(args, torch, device):
     """The other whole-graph rules on the configs[2]-sized uniform graph (10M nodes / 100M edges): BFS from one start,
     ConnectedComponents on the symmetrised graph, ShortestPathDijkstra from one start.  The C ABI of these rules takes host
-    arrays (one-shot: CSR upload + kernels + results back), so `wall_ms` is that whole call; `kernel_ms` is the time
-    between the end of the upload and the last kernel, from the library's own timers where it has them (None otherwise:
-    use the rocprofv3 summary under profiles/).  Algorithmic bytes: BFS 4E + 4(N+1) + 12N (adjacency once,
-    depth / parent / order written once), CC per label-propagation round 4E + 4(N+1) + 4N, SSSP 8E + 4(N+1) + 12N
+    arrays (one-shot: CSR upload + kernels + results back), so `wall_ms` is that whole call; `device_ms` is the time
+    between the end of the upload and the start of the download by the library's own clock (cz_graph_last_timing), and
+    `roofline` prices the rule's algorithmic bytes against it.  Algorithmic bytes: BFS 4E + 4(N+1) + 12N
+    (adjacency once, depth / parent / order written once), CC 4E + 4(N+1) + 4N (the adjacency once), SSSP 8E + 4(N+1) + 12N
     (adjacency + weights once, packed (cost, parent) written once) -- lower bounds the schedules do not reach: every rule
     is bounded by 4-byte random accesses to a 40 MB per-node array (58 G/s from the Infinity Cache)."""
     from cozo_amd import graph as G
@@ -745,17 +745,25 @@ def bench_graph_rules(args, torch, device):
         r = fn()
         return r, time.perf_counter() - t0
 
+    def entry(dt, edges, algorithmic_bytes, **extra):
+        """one rule's object: wall of the host-pointer call, its split by the library's own clock (cz_graph_last_timing), and
+        the device part against the HBM roofline of the rule's algorithmic bytes (a lower bound no schedule reaches: every
+        rule here is bound by 4- / 8-byte random accesses to per-node arrays)"""
+        up, devms, down = G.last_timing()
+        gbs = algorithmic_bytes / (devms * 1e-3) / 1e9 if devms > 0 else None
+        return dict(wall_ms=dt * 1e3, upload_ms=up, device_ms=devms, download_ms=down, edges_per_s=edges / dt,
+                    edges_per_s_device=edges / (devms * 1e-3) if devms > 0 else None, algorithmic_bytes=algorithmic_bytes,
+                    roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS if gbs else None,
+                                  traffic=None), **extra)
+
     (par, dep, _, _), dt = timed(lambda: G.bfs(ooff, otgt, starts, want_depth=True))
     reached = int((dep[0] != 0xFFFFFFFF).sum())
-    out["bfs"] = dict(wall_ms=dt * 1e3, edges_per_s=E / dt, reached=reached, levels=int(dep[0][dep[0] != 0xFFFFFFFF].max()),
-                      algorithmic_bytes=4 * E + 4 * (n + 1) + 12 * n)
+    out["bfs"] = entry(dt, E, 4 * E + 4 * (n + 1) + 12 * n, reached=reached, levels=int(dep[0][dep[0] != 0xFFFFFFFF].max()))
     (grp, k), dt = timed(lambda: G.connected_components(uoff, utgt))
-    out["connected_components"] = dict(wall_ms=dt * 1e3, edges_per_s=int(utgt.size) / dt, components=int(k),
-                                       algorithmic_bytes_per_round=4 * int(utgt.size) + 4 * (n + 1) + 4 * n)
+    out["connected_components"] = entry(dt, int(utgt.size), 4 * int(utgt.size) + 4 * (n + 1) + 4 * n, components=int(k))
     (dist, _), dt = timed(lambda: G.sssp(ooff, otgt, w, starts))
     fin = np.isfinite(dist[0])
-    out["sssp"] = dict(wall_ms=dt * 1e3, edges_per_s=E / dt, reached=int(fin.sum()), max_cost=float(dist[0][fin].max()),
-                       algorithmic_bytes=8 * E + 4 * (n + 1) + 12 * n)
+    out["sssp"] = entry(dt, E, 8 * E + 4 * (n + 1) + 12 * n, reached=int(fin.sum()), max_cost=float(dist[0][fin].max()))
     # BetweennessCentrality: SSSP from EVERY node + path counts over the tight edges, all on the device (a 20k-node graph:
     # 4e8 (source, node) pairs; the reference enumerates paths, so there is no CPU figure at this size)
     nb, eb = 20_000, 200_000
@@ -767,10 +775,12 @@ def bench_graph_rules(args, torch, device):
     btgt = (kb % nb).astype(np.uint32)
     bw = (rb.integers(1, 64, btgt.size) / 8).astype(np.float32)
     cent, dt = timed(lambda: G.betweenness(boff, btgt, bw))
-    out["betweenness"] = dict(nodes=nb, edges=int(btgt.size), wall_ms=dt * 1e3, sources_per_s=nb / dt,
+    up, devms, down = G.last_timing()
+    out["betweenness"] = dict(nodes=nb, edges=int(btgt.size), wall_ms=dt * 1e3, device_ms=devms, sources_per_s=nb / dt,
                               source_node_pairs_per_s=nb * nb / dt, max_centrality=float(cent.max()))
     out["note"] = ("wall = one C ABI call on host arrays: CSR upload over PCIe (0.44 GB per direction, 0.84 GB for the weighted "
-                   "graph) + kernels + per-node results back; kernel-only times are in profiles/ (rocprofv3 kernel trace)")
+                   "graph) + kernels + per-node results back; device_ms = the part between upload and download by the "
+                   "library's own clock (cz_graph_last_timing); per-kernel times are in profiles/ (rocprofv3 kernel trace)")
     return out
 
 

@@ -21,6 +21,7 @@
 //   re-relaxed the 10M / 100M graph for 35 rounds at 1 G edges/s.  Several sources share every launch (one (source, node)
 //   pair per queue entry), which is what the all-sources rules (Closeness / Betweenness centrality) need on small graphs.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -30,6 +31,26 @@
 #include "common.h"
 
 namespace {
+
+// where the last whole-graph rule called on this host thread spent its time (cz_graph_last_timing): the entry points take
+// host arrays, so a call is upload + kernels + results back, and only the middle part says anything about the kernels
+struct CallTiming {
+    double ms[3] = {0, 0, 0};  // upload (H2D + allocation), device (kernels and their control round trips), download
+    std::chrono::steady_clock::time_point last;
+    void start() {
+        ms[0] = ms[1] = ms[2] = 0;
+        last = std::chrono::steady_clock::now();
+    }
+    // everything since the previous lap (the device drained first) is booked under `slot`
+    void lap(int slot) {
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        ms[slot] += std::chrono::duration<double, std::milli>(now - last).count();
+        last = now;
+    }
+};
+thread_local CallTiming t_timing;
+enum { T_UPLOAD = 0, T_DEVICE = 1, T_DOWNLOAD = 2 };
 
 constexpr int kT = 256;
 inline int grid_for(uint64_t n, int per_block = kT) {
@@ -117,7 +138,16 @@ int exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, uint32_t *
 // graph).  The three passes keep the reference's FIFO order: claim (atomicMin of the frontier position per target),
 // count, emit in (frontier position, adjacency position) order; duplicates of a target are adjacent in the sorted list
 // and only the first one counts.  Group-wide counts / offsets come from wave ballots.
+// Two optional helpers cut the random traffic (one GPU; the vertex-partitioned form passes null and keeps the plain reads):
+//   vis   one bit per node, set when the node is discovered: 1.25 MB for 10M nodes, i.e. L2-resident, where depth[] is a
+//         40 MB array served by the Infinity Cache -- on the dense levels most targets are already visited and never get past it;
+//   won   one byte per edge slot, written by the count pass (did this slot win its target?) and read back coalesced by the
+//         emit pass, which then does no random reads at all.
 constexpr int kBfsLanes = 16;
+
+__device__ __forceinline__ bool bfs_unvisited(const uint32_t *__restrict__ vis, const uint32_t *__restrict__ depth, uint32_t v) {
+    return vis ? !((vis[v >> 5] >> (v & 31)) & 1u) : depth[v] == CZ_NONE;
+}
 
 __device__ __forceinline__ unsigned int bfs_group_mask(unsigned long long ballot, int lane) {
     return (unsigned int)(ballot >> (lane & ~(kBfsLanes - 1))) & ((1u << kBfsLanes) - 1u);
@@ -125,7 +155,8 @@ __device__ __forceinline__ unsigned int bfs_group_mask(unsigned long long ballot
 
 __global__ void __launch_bounds__(kT)
 bfs_claim_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
-                 uint32_t fsize, const uint32_t *__restrict__ depth, uint32_t *__restrict__ claim, uint32_t rb, uint32_t re) {
+                 uint32_t fsize, const uint32_t *__restrict__ depth, const uint32_t *__restrict__ vis, uint32_t *__restrict__ claim,
+                 uint32_t rb, uint32_t re) {
     // [rb, re): the nodes whose adjacency this device holds (`off` is relative to rb); the whole graph on one GPU
     const uint32_t glane = threadIdx.x & (kBfsLanes - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kBfsLanes, ngroups = gridDim.x * blockDim.x / kBfsLanes;
@@ -135,15 +166,15 @@ bfs_claim_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
         const uint32_t e1 = off[u - rb + 1];
         for (uint32_t e = off[u - rb] + glane; e < e1; e += kBfsLanes) {
             const uint32_t v = tgt[e];
-            if (depth[v] == CZ_NONE) atomicMin(&claim[v], i);
+            if (bfs_unvisited(vis, depth, v)) atomicMin(&claim[v], i);
         }
     }
 }
 
 __global__ void __launch_bounds__(kT)
 bfs_count_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
-                 uint32_t fsize, const uint32_t *__restrict__ depth, const uint32_t *__restrict__ claim,
-                 uint32_t *__restrict__ cnt, uint32_t rb, uint32_t re) {
+                 uint32_t fsize, const uint32_t *__restrict__ depth, const uint32_t *__restrict__ vis,
+                 const uint32_t *__restrict__ claim, uint32_t *__restrict__ cnt, uint8_t *__restrict__ won, uint32_t rb, uint32_t re) {
     const int lane = threadIdx.x & 63;
     const uint32_t glane = threadIdx.x & (kBfsLanes - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kBfsLanes, ngroups = gridDim.x * blockDim.x / kBfsLanes;
@@ -164,7 +195,8 @@ bfs_count_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
             bool hit = false;
             if (e < e1) {
                 const uint32_t v = tgt[e];
-                hit = (e == e0 || tgt[e - 1] != v) && depth[v] == CZ_NONE && claim[v] == i;
+                hit = (e == e0 || tgt[e - 1] != v) && bfs_unvisited(vis, depth, v) && claim[v] == i;
+                if (won) won[e] = hit;
             }
             c += __popc(bfs_group_mask(__ballot(hit), lane));
         }
@@ -174,9 +206,9 @@ bfs_count_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
 
 __global__ void __launch_bounds__(kT)
 bfs_emit_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
-                uint32_t fsize, uint32_t *__restrict__ depth, const uint32_t *__restrict__ claim,
-                const uint32_t *__restrict__ pos, uint32_t *__restrict__ next, uint32_t *__restrict__ parent,
-                uint32_t next_depth, uint32_t rb, uint32_t re, uint32_t plus_one) {
+                uint32_t fsize, uint32_t *__restrict__ depth, uint32_t *__restrict__ vis, const uint32_t *__restrict__ claim,
+                const uint8_t *__restrict__ won, const uint32_t *__restrict__ pos, uint32_t *__restrict__ next,
+                uint32_t *__restrict__ parent, uint32_t next_depth, uint32_t rb, uint32_t re, uint32_t plus_one) {
     const int lane = threadIdx.x & 63;
     const uint32_t glane = threadIdx.x & (kBfsLanes - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kBfsLanes, ngroups = gridDim.x * blockDim.x / kBfsLanes;
@@ -199,13 +231,15 @@ bfs_emit_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ t
                 v = tgt[e];
                 // `depth[v] == NONE` is read before any lane of this launch can have set it for v: only the claim
                 // winner writes depth[v], and the winner is this very lane group (claim[v] == i)
-                hit = (e == e0 || tgt[e - 1] != v) && claim[v] == i && depth[v] == CZ_NONE;
+                // (no `won`: the visited bits are not used either, and this is the same test the count pass made)
+                hit = won ? won[e] != 0 : (e == e0 || tgt[e - 1] != v) && claim[v] == i && depth[v] == CZ_NONE;
             }
             const unsigned int m = bfs_group_mask(__ballot(hit), lane);
             if (hit) {
                 next[o + __popc(m & ((1u << glane) - 1u))] = v + plus_one;
                 parent[v] = u;
                 depth[v] = next_depth;
+                if (vis) atomicOr(&vis[v >> 5], 1u << (v & 31));
             }
             o += __popc(m);
         }
@@ -224,6 +258,7 @@ __global__ void bfs_goals_left_kernel(const uint32_t *__restrict__ goals, uint32
 }
 
 __global__ void set_u32_kernel(uint32_t *p, uint32_t idx, uint32_t v) { p[idx] = v; }
+__global__ void or_u32_kernel(uint32_t *p, uint32_t idx, uint32_t v) { p[idx] |= v; }
 
 // ---------------------------------------------------------------------------------------------
 // connected components
@@ -341,11 +376,54 @@ __device__ __forceinline__ void sssp_push(const SsspQueue &q, bool want, unsigne
     if (want) q.items[base + __popcll(m & ((1ull << lane) - 1ull))] = item;
 }
 
+// One counter per pile would see one returning atomicAdd per wave instruction from every wave of the grid -- and same-address
+// atomics are served one after another: a round that pushes 8M entries spent 15.7 of its 16.6 ms there
+// (profiles/r02_sssp_push_experiment.txt).  So pushes are staged per WORKGROUP: a wave reserves slots in an LDS buffer with an
+// LDS atomic, and every few iterations the workgroup moves what has gathered to the pile with ONE global atomicAdd and a
+// coalesced copy.  Entries that do not fit the buffer (a hub's list) take the wave-level path above.
+constexpr uint32_t kStageCap = 1024;
+
+struct StagedPile {
+    unsigned long long buf[kStageCap];
+    uint32_t count, base;
+};
+
+__device__ __forceinline__ void staged_push(const SsspQueue &q, StagedPile &st, bool want, unsigned long long item, int lane) {
+    const unsigned long long m = __ballot(want);
+    if (!m) return;
+    uint32_t base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(&st.count, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    const uint32_t slot = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (want && slot < kStageCap) st.buf[slot] = item;
+    sssp_push(q, want && slot >= kStageCap, item, lane);
+}
+
+// every thread of the workgroup, in uniform control flow
+__device__ __forceinline__ void staged_flush(const SsspQueue &q, StagedPile &st) {
+    __syncthreads();
+    const uint32_t n = min(st.count, kStageCap);
+    if (threadIdx.x == 0 && n) st.base = atomicAdd(q.count, n);
+    __syncthreads();
+    const uint32_t gb = st.base;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) q.items[gb + i] = st.buf[i];
+    __syncthreads();
+    if (threadIdx.x == 0) st.count = 0;
+    __syncthreads();
+}
+
 // relax the out-edges of every (source, node) entry of `cur`: a 16-lane group per entry reads the adjacency coalesced.
 // An improved target goes to `near` when its new cost is below the threshold, else to `far`; `qtag` / `ftag` (one word
 // per (source, node)) keep a pair from entering the same pile twice in one round / one phase.
-// (V: scratch experiments only -- pieces of the kernel left out to see what each costs; V = 0 is the kernel)
-template <int V>
+// The packed word of a (source, node) pair is (cost bits << 32 | improper << 31 | parent): `improper` marks a parent whose
+// own cost equals the node's (a zero-weight edge, or a weight the f32 sum absorbs).  A relaxation replaces the word when it
+// lowers the cost (`cost + path_weight < seen`, shortest_path_dijkstra.rs:303-304) -- or, at EQUAL cost, when it comes from a
+// proper predecessor and the packed word gets smaller: every tight predecessor offers the final cost once, so the parent ends
+// up as the SMALLEST tight predecessor of strictly smaller cost whatever the schedule was (two runs return the same rows;
+// the reference's own choice among equal-cost predecessors is its heap's pop order).  A node all of whose tight predecessors
+// sit at its own cost keeps the one that lowered its cost: that pointer is acyclic by construction, a smallest-id rule there
+// could close a cycle.  Node ids stay below 2^31 for the flag bit.
 __global__ void __launch_bounds__(kT)
 sssp_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t N,
                   const unsigned long long *__restrict__ cur, uint32_t n_cur, unsigned long long *__restrict__ dp,
@@ -354,7 +432,10 @@ sssp_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__
     const int lane = threadIdx.x & 63;
     const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes, ngroups = gridDim.x * blockDim.x / kSsspLanes;
-    const uint32_t rounds = (n_cur + ngroups - 1) / ngroups;  // every group of a wave runs the same trip count (ballots)
+    const uint32_t rounds = (n_cur + ngroups - 1) / ngroups;  // every group of the GRID runs the same trip count (ballots, barriers)
+    __shared__ StagedPile st_near, st_far;
+    if (threadIdx.x == 0) st_near.count = st_far.count = 0;
+    __syncthreads();
     for (uint32_t r = 0; r < rounds; r++) {
         const uint32_t i = group + r * ngroups;
         const bool live = i < n_cur;
@@ -375,36 +456,31 @@ sssp_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__
                 v = tgt[e];
                 const float nd = du + w[e];  // `cost + path_weight` in f32 (shortest_path_dijkstra.rs:303)
                 const uint32_t nb = __float_as_uint(nd);
-                if (V >= 4) {
-                    to_near = nb == 0x12345678u && v == 77u;
-                } else {
-                    unsigned long long seen = __hip_atomic_load(&dps[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (V == 3) {
-                        to_near = nb < (uint32_t)(seen >> 32) && v == 0xFFFFFFF0u;
-                    } else
-                        while (nb < (uint32_t)(seen >> 32)) {  // strict `<` (:304); non-negative floats order as their bits
-                            const unsigned long long want = ((unsigned long long)nb << 32) | u;
-                            const unsigned long long got = atomicCAS(&dps[v], seen, want);
-                            if (got == seen) {
-                                const size_t at = (size_t)si * N + v;
-                                if (V == 1) {
-                                    to_near = nb < thr_bits;
-                                    to_far = !to_near;
-                                } else if (V == 2) {
-                                    to_near = v == 0xFFFFFFF0u;
-                                } else {
-                                    if (nb < thr_bits) to_near = atomicExch(&qtag[at], round_tag) != round_tag;
-                                    else to_far = atomicExch(&ftag[at], phase_tag) != phase_tag;
-                                }
-                                break;
-                            }
-                            seen = got;
+                const bool proper = nb != __float_as_uint(du);
+                const unsigned long long want = ((unsigned long long)nb << 32) | (proper ? 0u : 0x80000000u) | u;
+                unsigned long long seen = __hip_atomic_load(&dps[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (;;) {
+                    const bool lower = nb < (uint32_t)(seen >> 32);  // strict `<` (:304); non-negative floats order as their bits
+                    if (!lower && !(proper && nb == (uint32_t)(seen >> 32) && want < seen)) break;
+                    const unsigned long long got = atomicCAS(&dps[v], seen, want);
+                    if (got == seen) {
+                        if (lower) {  // (an equal-cost change of parent is nothing the node's own edges need to hear about)
+                            const size_t at = (size_t)si * N + v;
+                            if (nb < thr_bits) to_near = atomicExch(&qtag[at], round_tag) != round_tag;
+                            else to_far = atomicExch(&ftag[at], phase_tag) != phase_tag;
                         }
+                        break;
+                    }
+                    seen = got;
                 }
             }
             const unsigned long long item = ((unsigned long long)si << 32) | v;
-            sssp_push(near, to_near, item, lane);
-            sssp_push(far, to_far, item, lane);
+            staged_push(near, st_near, to_near, item, lane);
+            staged_push(far, st_far, to_far, item, lane);
+        }
+        if ((r & 7) == 7 || r + 1 == rounds) {  // 16 entries per iteration and workgroup: a few hundred pushes gather in 8
+            staged_flush(near, st_near);
+            staged_flush(far, st_far);
         }
     }
 }
@@ -417,6 +493,9 @@ sssp_split_kernel(const unsigned long long *__restrict__ farq, uint32_t n_far, u
     const int lane = threadIdx.x & 63;
     const uint32_t total = gridDim.x * blockDim.x;
     const uint32_t rounds = (n_far + total - 1) / total;
+    __shared__ StagedPile st_near, st_far;
+    if (threadIdx.x == 0) st_near.count = st_far.count = 0;
+    __syncthreads();
     for (uint32_t r = 0; r < rounds; r++) {
         const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x + r * total;
         bool to_near = false, to_far = false;
@@ -428,8 +507,12 @@ sssp_split_kernel(const unsigned long long *__restrict__ farq, uint32_t n_far, u
             if (cb < thr_bits) to_near = atomicExch(&qtag[at], round_tag) != round_tag;
             else to_far = atomicExch(&ftag[at], phase_tag) != phase_tag;
         }
-        sssp_push(near, to_near, ent, lane);
-        sssp_push(far_next, to_far, ent, lane);
+        staged_push(near, st_near, to_near, ent, lane);
+        staged_push(far_next, st_far, to_far, ent, lane);
+        if ((r & 1) == 1 || r + 1 == rounds) {  // at most one entry per thread and iteration: two iterations fit the buffer
+            staged_flush(near, st_near);
+            staged_flush(far_next, st_far);
+        }
     }
 }
 
@@ -497,6 +580,34 @@ sssp_unpack_kernel(const unsigned long long *__restrict__ dp, const uint32_t *__
     }
 }
 
+// the single-GPU words: (cost << 32 | improper << 31 | parent), 0xFFFFFFFF = no parent
+__global__ void __launch_bounds__(kT)
+sssp_unpack_flagged_kernel(const unsigned long long *__restrict__ dp, uint64_t n, float *__restrict__ dist, uint32_t *__restrict__ parent) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long c = dp[i];
+        dist[i] = __uint_as_float((uint32_t)(c >> 32));
+        const uint32_t p = (uint32_t)c;
+        parent[i] = p == CZ_NONE ? CZ_NONE : (p & 0x7FFFFFFFu);
+    }
+}
+
+// BadEdgeWeightError (fixed_rule/mod.rs:258-286) on the device copy: the smallest index of a weight that is negative or NaN,
+// and the sum of the weights (its mean is the bucket width of the near-far schedule)
+__global__ void __launch_bounds__(kT)
+weights_check_kernel(const float *__restrict__ w, uint64_t E, double *__restrict__ sum, unsigned long long *__restrict__ bad) {
+    double acc = 0.0;
+    unsigned long long first = ~0ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = w[i];
+        if (!(x >= 0.0f)) first = min(first, (unsigned long long)i);
+        else acc += x;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum, acc);
+    if (first != ~0ull) atomicMin(bad, first);
+}
+
 int check_csr(const uint32_t *off, const uint32_t *tgt, uint32_t N, uint64_t E) {
     if (N == 0) return CZ_OK;
     if (!off) return cz::set_error(CZ_E_INVALID, "null offsets");
@@ -508,17 +619,29 @@ int check_csr(const uint32_t *off, const uint32_t *tgt, uint32_t N, uint64_t E) 
 
 }  // namespace
 
+extern "C" int cz_graph_last_timing(double *upload_ms, double *device_ms, double *download_ms) {
+    if (upload_ms) *upload_ms = t_timing.ms[T_UPLOAD];
+    if (device_ms) *device_ms = t_timing.ms[T_DEVICE];
+    if (download_ms) *download_ms = t_timing.ms[T_DOWNLOAD];
+    return CZ_OK;
+}
+
 extern "C" int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E,
                       const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals,
                       int share_visited, uint32_t *parent, uint32_t *depth, uint32_t *order, uint32_t *n_reached,
                       const volatile uint8_t *poison) {
     int rc = cz::ensure_device();
     if (rc) return rc;
+    t_timing.start();
     if (n_starts == 0 || N == 0) return CZ_OK;
     if (!starts || !parent) return cz::set_error(CZ_E_INVALID, "null starts/parent");
     rc = check_csr(out_offsets, out_targets, N, E);
     if (rc) return rc;
-    cz::DevBuf<uint32_t> d_off, d_tgt, d_depth, d_parent, d_claim, d_order, d_cnt, d_pos, d_scratch, d_goals, d_misc;
+    cz::DevBuf<uint32_t> d_off, d_tgt, d_depth, d_parent, d_claim, d_order, d_cnt, d_pos, d_scratch, d_goals, d_misc, d_vis;
+    cz::DevBuf<uint8_t> d_won;
+    const size_t vis_words = ((size_t)N + 31) / 32;
+    CZ_HIP(d_vis.alloc(vis_words));
+    CZ_HIP(d_won.alloc(E));
     CZ_HIP(d_off.alloc((size_t)N + 1));
     CZ_HIP(d_tgt.alloc(E));
     CZ_HIP(d_depth.alloc(N));
@@ -536,8 +659,10 @@ extern "C" int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, 
         CZ_HIP(hipMemcpy(d_goals.p, goals, (size_t)n_goals * 4, hipMemcpyHostToDevice));
     }
     hipStream_t s = nullptr;
+    t_timing.lap(T_UPLOAD);
     CZ_HIP(hipMemsetAsync(d_depth.p, 0xFF, (size_t)N * 4, s));
     CZ_HIP(hipMemsetAsync(d_claim.p, 0xFF, (size_t)N * 4, s));
+    CZ_HIP(hipMemsetAsync(d_vis.p, 0, vis_words * 4, s));
     for (uint32_t si = 0; si < n_starts; si++) {
         if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
         const uint32_t start = starts[si];
@@ -545,6 +670,7 @@ extern "C" int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, 
         if (!share_visited && si > 0) {
             CZ_HIP(hipMemsetAsync(d_depth.p, 0xFF, (size_t)N * 4, s));
             CZ_HIP(hipMemsetAsync(d_claim.p, 0xFF, (size_t)N * 4, s));
+            CZ_HIP(hipMemsetAsync(d_vis.p, 0, vis_words * 4, s));
         }
         CZ_HIP(hipMemsetAsync(d_parent.p, 0xFF, (size_t)N * 4, s));
         bool run = start < N;
@@ -556,19 +682,21 @@ extern "C" int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, 
         if (run && goals && n_goals == 0) run = false;  // nothing pending: the reference discovers nothing useful
         if (run) {
             hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, s, d_depth.p, start, 0u);
+            hipLaunchKernelGGL(or_u32_kernel, dim3(1), dim3(1), 0, s, d_vis.p, start >> 5, 1u << (start & 31));
             hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, s, d_order.p, 0u, start);
             uint32_t lo = 0, fsize = 1, level = 0;
             while (fsize > 0) {
                 if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
                 const uint32_t *fr = d_order.p + lo;
                 const int g = grid_for((uint64_t)fsize * kBfsLanes);  // a 16-lane group per frontier node
-                hipLaunchKernelGGL(bfs_claim_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, fr, fsize, d_depth.p, d_claim.p, 0u, N);
-                hipLaunchKernelGGL(bfs_count_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, fr, fsize, d_depth.p, d_claim.p,
-                                   d_cnt.p, 0u, N);
+                hipLaunchKernelGGL(bfs_claim_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, fr, fsize, d_depth.p, d_vis.p, d_claim.p,
+                                   0u, N);
+                hipLaunchKernelGGL(bfs_count_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, fr, fsize, d_depth.p, d_vis.p, d_claim.p,
+                                   d_cnt.p, d_won.p, 0u, N);
                 rc = exclusive_scan(d_cnt.p, d_pos.p, fsize, d_misc.p, d_scratch.p, s);
                 if (rc) return rc;
-                hipLaunchKernelGGL(bfs_emit_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, fr, fsize, d_depth.p, d_claim.p,
-                                   d_pos.p, d_order.p + lo + fsize, d_parent.p, level + 1, 0u, N, 0u);
+                hipLaunchKernelGGL(bfs_emit_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, fr, fsize, d_depth.p, d_vis.p, d_claim.p,
+                                   d_won.p, d_pos.p, d_order.p + lo + fsize, d_parent.p, level + 1, 0u, N, 0u);
                 CZ_HIP(hipMemsetAsync(d_misc.p + 1, 0, 4, s));
                 if (goals)
                     hipLaunchKernelGGL(bfs_goals_left_kernel, dim3(grid_for(n_goals)), dim3(kT), 0, s, d_goals.p, n_goals, N,
@@ -584,6 +712,7 @@ extern "C" int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, 
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "bfs launch: %s", hipGetErrorString(e));
         }
+        t_timing.lap(T_DEVICE);
         CZ_HIP(hipMemcpy(parent + (size_t)si * N, d_parent.p, (size_t)N * 4, hipMemcpyDeviceToHost));
         if (depth) {
             CZ_HIP(hipMemcpy(depth + (size_t)si * N, d_depth.p, (size_t)N * 4, hipMemcpyDeviceToHost));
@@ -592,6 +721,7 @@ extern "C" int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, 
         }
         if (order && reached) CZ_HIP(hipMemcpy(order + (size_t)si * N, d_order.p + 1, (size_t)reached * 4, hipMemcpyDeviceToHost));
         if (n_reached) n_reached[si] = reached;
+        t_timing.lap(T_DOWNLOAD);
     }
     return CZ_OK;
 }
@@ -601,6 +731,7 @@ extern "C" int cz_connected_components(const uint32_t *offsets, const uint32_t *
     if (n_groups) *n_groups = 0;
     int rc = cz::ensure_device();
     if (rc) return rc;
+    t_timing.start();
     if (N == 0) return CZ_OK;
     if (!group) return cz::set_error(CZ_E_INVALID, "null group");
     rc = check_csr(offsets, targets, N, E);
@@ -617,6 +748,7 @@ extern "C" int cz_connected_components(const uint32_t *offsets, const uint32_t *
     if (E) CZ_HIP(hipMemcpy(d_tgt.p, targets, E * 4, hipMemcpyHostToDevice));
     hipStream_t s = nullptr;
     const int g = grid_for(N);
+    t_timing.lap(T_UPLOAD);
     hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(kT), 0, s, d_label.p, N);
     for (uint32_t r = 0; r < kCcNeighbourRounds; r++) {
         hipLaunchKernelGGL(cc_link_nth_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, N, r, d_label.p);
@@ -642,10 +774,12 @@ extern "C" int cz_connected_components(const uint32_t *offsets, const uint32_t *
     hipLaunchKernelGGL(cc_group_kernel, dim3(g), dim3(kT), 0, s, N, d_label.p, d_rank.p, d_flag.p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "cc launch: %s", hipGetErrorString(e));
+    t_timing.lap(T_DEVICE);
     CZ_HIP(hipMemcpy(group, d_flag.p, (size_t)N * 4, hipMemcpyDeviceToHost));
     uint32_t total = 0;
     CZ_HIP(hipMemcpy(&total, d_misc.p, 4, hipMemcpyDeviceToHost));
     if (n_groups) *n_groups = total;
+    t_timing.lap(T_DOWNLOAD);
     return CZ_OK;
 }
 
@@ -699,6 +833,7 @@ extern "C" int cz_clustering_coefficients(const uint32_t *offsets, const uint32_
                                           uint64_t *n_triangles, uint32_t *degree, const volatile uint8_t *poison) {
     int rc = cz::ensure_device();
     if (rc) return rc;
+    t_timing.start();
     if (N == 0) return CZ_OK;
     if (!n_triangles || !degree) return cz::set_error(CZ_E_INVALID, "null output");
     rc = check_csr(offsets, targets, N, E);
@@ -713,11 +848,14 @@ extern "C" int cz_clustering_coefficients(const uint32_t *offsets, const uint32_
     CZ_HIP(hipMemcpy(d_off.p, offsets, ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
     if (E) CZ_HIP(hipMemcpy(d_tgt.p, targets, E * 4, hipMemcpyHostToDevice));
     const int blocks = (int)std::min<uint64_t>(256 * 16, ((uint64_t)N + 3) / 4);
+    t_timing.lap(T_UPLOAD);
     hipLaunchKernelGGL(triangles_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, nullptr, d_off.p, d_tgt.p, N, d_tri.p, d_deg.p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "triangles launch: %s", hipGetErrorString(e));
+    t_timing.lap(T_DEVICE);
     CZ_HIP(hipMemcpy(n_triangles, d_tri.p, (size_t)N * 8, hipMemcpyDeviceToHost));
     CZ_HIP(hipMemcpy(degree, d_deg.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    t_timing.lap(T_DOWNLOAD);
     if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
     return CZ_OK;
 }
@@ -740,14 +878,31 @@ struct SsspBatch {
               uint32_t n_starts, uint64_t pairs_budget) {
         N = n;
         E = e;
+        if (N >= 0x80000000u) return cz::set_error(CZ_E_UNSUPPORTED, "node ids must stay below 2^31");
+        CZ_HIP(d_off.alloc((size_t)N + 1));
+        CZ_HIP(d_tgt.alloc(E));
+        CZ_HIP(d_w.alloc(E));
+        CZ_HIP(d_misc.alloc(8));
+        CZ_HIP(hipMemcpy(d_off.p, out_offsets, ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
         double wsum = 0.0;
-        for (uint64_t i = 0; i < E; i++) {  // BadEdgeWeightError, fixed_rule/mod.rs:258-286: negative / NaN weights
-            // (+inf is legal here: the reference checks the f64 value, and a finite f64 beyond f32's range becomes +inf in
-            // its `as f32` cast; such an edge never improves anything -- inf < inf is false -- exactly as in dijkstra :304)
-            if (!(weights[i] >= 0.0f))
-                return cz::set_error(CZ_E_INVALID, "edge %llu has weight %g: weights must be non-negative numbers",
-                                     (unsigned long long)i, (double)weights[i]);
-            wsum += weights[i];
+        if (E) {
+            CZ_HIP(hipMemcpy(d_tgt.p, out_targets, E * 4, hipMemcpyHostToDevice));
+            CZ_HIP(hipMemcpy(d_w.p, weights, E * 4, hipMemcpyHostToDevice));
+            // negative / NaN weights (+inf is legal here: the reference checks the f64 value, and a finite f64 beyond f32's
+            // range becomes +inf in its `as f32` cast; such an edge never improves anything -- inf < inf is false -- exactly
+            // as in dijkstra :304); checked on the device copy, a host loop over 1e8 weights costs 30 ms
+            cz::DevBuf<double> d_sum;
+            cz::DevBuf<unsigned long long> d_bad;
+            CZ_HIP(d_sum.alloc(1));
+            CZ_HIP(d_bad.alloc(1));
+            CZ_HIP(hipMemsetAsync(d_sum.p, 0, 8, s));
+            CZ_HIP(hipMemsetAsync(d_bad.p, 0xFF, 8, s));
+            hipLaunchKernelGGL(weights_check_kernel, dim3(grid_for(E)), dim3(kT), 0, s, d_w.p, E, d_sum.p, d_bad.p);
+            unsigned long long bad = 0;
+            CZ_HIP(hipMemcpy(&bad, d_bad.p, 8, hipMemcpyDeviceToHost));
+            CZ_HIP(hipMemcpy(&wsum, d_sum.p, 8, hipMemcpyDeviceToHost));
+            if (bad != ~0ull)
+                return cz::set_error(CZ_E_INVALID, "edge %llu has weight %g: weights must be non-negative numbers", bad, (double)weights[bad]);
         }
         // bucket width of the near-far schedule: the mean edge weight (CZ_SSSP_DELTA overrides; <= 0 or "inf" = one pile,
         // i.e. plain frontier Bellman-Ford).  Only the schedule depends on it, never the result.
@@ -758,84 +913,12 @@ struct SsspBatch {
         S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_starts, pairs_budget / std::max<uint32_t>(N, 1)));
         const uint64_t SN = (uint64_t)S * N;
         if (SN >= 0xFFFFFFFFull) return cz::set_error(CZ_E_UNSUPPORTED, "too many (source, node) pairs per launch");
-        CZ_HIP(d_off.alloc((size_t)N + 1));
-        CZ_HIP(d_tgt.alloc(E));
-        CZ_HIP(d_w.alloc(E));
         CZ_HIP(d_qtag.alloc(SN));
         CZ_HIP(d_ftag.alloc(SN));
-        CZ_HIP(d_misc.alloc(8));
         CZ_HIP(d_dp.alloc(SN));
         CZ_HIP(d_starts.alloc(S));
         for (auto &q : d_q) CZ_HIP(q.alloc(SN));
-        CZ_HIP(hipMemcpy(d_off.p, out_offsets, ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
-        if (E) {
-            CZ_HIP(hipMemcpy(d_tgt.p, out_targets, E * 4, hipMemcpyHostToDevice));
-            CZ_HIP(hipMemcpy(d_w.p, weights, E * 4, hipMemcpyHostToDevice));
-        }
         return CZ_OK;
-    }
-
-    // scratch: one big round replayed with pieces of the relax kernel left out (CZ_SSSP_EXPERIMENT); state restored after
-    template <int V>
-    float replay(const unsigned long long *cur, uint32_t n_cur, unsigned long long *nq, unsigned long long *fq, uint32_t round,
-                 uint32_t phase, uint32_t thr_bits, const unsigned long long *dp0, const uint32_t *q0, const uint32_t *f0,
-                 const uint32_t *m0, int blocks_cap) {
-        const uint64_t nN = N;
-        hipMemcpy(d_dp.p, dp0, nN * 8, hipMemcpyDeviceToDevice);
-        hipMemcpy(d_qtag.p, q0, nN * 4, hipMemcpyDeviceToDevice);
-        hipMemcpy(d_ftag.p, f0, nN * 4, hipMemcpyDeviceToDevice);
-        hipMemcpy(d_misc.p, m0, 32, hipMemcpyDeviceToDevice);
-        hipEvent_t a, b;
-        hipEventCreate(&a);
-        hipEventCreate(&b);
-        int g = grid_for((uint64_t)n_cur * kSsspLanes);
-        if (blocks_cap) g = (int)std::min<uint64_t>(((uint64_t)n_cur * kSsspLanes + kT - 1) / kT, (uint64_t)blocks_cap);
-        hipEventRecord(a, s);
-        hipLaunchKernelGGL(sssp_relax_kernel<V>, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, d_w.p, N, cur, n_cur, d_dp.p, d_qtag.p, round,
-                           d_ftag.p, phase, thr_bits, SsspQueue{nq, d_misc.p}, SsspQueue{fq, d_misc.p + 1});
-        hipEventRecord(b, s);
-        hipEventSynchronize(b);
-        float ms = 0;
-        hipEventElapsedTime(&ms, a, b);
-        uint32_t h[2];
-        hipMemcpy(h, d_misc.p, 8, hipMemcpyDeviceToHost);
-        fprintf(stderr, "  V=%d blocks=%d: %.3f ms (near %u far %u)\n", V, g, ms, h[0], h[1]);
-        hipEventDestroy(a);
-        hipEventDestroy(b);
-        return ms;
-    }
-    void experiment(const unsigned long long *cur, uint32_t n_cur, unsigned long long *nq, unsigned long long *fq, uint32_t round,
-                    uint32_t phase, uint32_t thr_bits) {
-        cz::DevBuf<unsigned long long> dp0, fq0;
-        cz::DevBuf<uint32_t> q0, f0, m0;
-        dp0.alloc(N);
-        q0.alloc(N);
-        f0.alloc(N);
-        m0.alloc(8);
-        hipStreamSynchronize(s);
-        uint32_t hm[8];
-        hipMemcpy(hm, d_misc.p, 32, hipMemcpyDeviceToHost);
-        fq0.alloc(hm[1] + 1);
-        hipMemcpy(fq0.p, fq, (size_t)hm[1] * 8, hipMemcpyDeviceToDevice);
-        hipMemcpy(dp0.p, d_dp.p, (size_t)N * 8, hipMemcpyDeviceToDevice);
-        hipMemcpy(q0.p, d_qtag.p, (size_t)N * 4, hipMemcpyDeviceToDevice);
-        hipMemcpy(f0.p, d_ftag.p, (size_t)N * 4, hipMemcpyDeviceToDevice);
-        hipMemcpy(m0.p, d_misc.p, 32, hipMemcpyDeviceToDevice);
-        fprintf(stderr, "experiment: round %u, %u near entries, far %u\n", round, n_cur, hm[1]);
-        for (int rep = 0; rep < 2; rep++) {
-            replay<0>(cur, n_cur, nq, fq, round, phase, thr_bits, dp0.p, q0.p, f0.p, m0.p, 0);
-            replay<1>(cur, n_cur, nq, fq, round, phase, thr_bits, dp0.p, q0.p, f0.p, m0.p, 0);
-            replay<2>(cur, n_cur, nq, fq, round, phase, thr_bits, dp0.p, q0.p, f0.p, m0.p, 0);
-            replay<3>(cur, n_cur, nq, fq, round, phase, thr_bits, dp0.p, q0.p, f0.p, m0.p, 0);
-            replay<4>(cur, n_cur, nq, fq, round, phase, thr_bits, dp0.p, q0.p, f0.p, m0.p, 0);
-            replay<0>(cur, n_cur, nq, fq, round, phase, thr_bits, dp0.p, q0.p, f0.p, m0.p, 2048);
-            replay<0>(cur, n_cur, nq, fq, round, phase, thr_bits, dp0.p, q0.p, f0.p, m0.p, 65536);
-        }
-        hipMemcpy(d_dp.p, dp0.p, (size_t)N * 8, hipMemcpyDeviceToDevice);
-        hipMemcpy(d_qtag.p, q0.p, (size_t)N * 4, hipMemcpyDeviceToDevice);
-        hipMemcpy(d_ftag.p, f0.p, (size_t)N * 4, hipMemcpyDeviceToDevice);
-        hipMemcpy(d_misc.p, m0.p, 32, hipMemcpyDeviceToDevice);
-        hipMemcpy(fq, fq0.p, (size_t)hm[1] * 8, hipMemcpyDeviceToDevice);
     }
 
     // d_misc: [0] near-next count, [1] far count, [2] far-next count, [3] min far cost bits
@@ -860,8 +943,7 @@ struct SsspBatch {
                 CZ_HIP(hipMemsetAsync(d_misc.p, 0, 4, s));
                 uint32_t thr_bits;
                 memcpy(&thr_bits, &thr, 4);
-                if (n_near > 3000000 && getenv("CZ_SSSP_EXPERIMENT")) experiment(near_cur, n_near, near_next, far_cur, round, phase, thr_bits);
-                hipLaunchKernelGGL(sssp_relax_kernel<0>, dim3(grid_for((uint64_t)n_near * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p,
+                hipLaunchKernelGGL(sssp_relax_kernel, dim3(grid_for((uint64_t)n_near * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p,
                                    d_w.p, N, near_cur, n_near, d_dp.p, d_qtag.p, round, d_ftag.p, phase, thr_bits,
                                    SsspQueue{near_next, d_misc.p}, SsspQueue{far_cur, d_misc.p + 1});
                 CZ_HIP(hipMemcpy(h, d_misc.p, 8, hipMemcpyDeviceToHost));
@@ -909,6 +991,7 @@ extern "C" int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets,
                        const volatile uint8_t *poison) {
     int rc = cz::ensure_device();
     if (rc) return rc;
+    t_timing.start();
     if (n_starts == 0 || N == 0) return CZ_OK;
     if (!starts || !dist || !parent) return cz::set_error(CZ_E_INVALID, "null starts/dist/parent");
     rc = check_csr(out_offsets, out_targets, N, E);
@@ -922,18 +1005,18 @@ extern "C" int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets,
     CZ_HIP(d_parent.alloc(SN));
     CZ_HIP(d_dist.alloc(SN));
     hipStream_t s = sb.s;
+    t_timing.lap(T_UPLOAD);
     for (uint32_t s0 = 0; s0 < n_starts; s0 += sb.S) {
         const uint32_t ns = std::min<uint32_t>(sb.S, n_starts - s0);
         const uint64_t nsN = (uint64_t)ns * N;
         if ((rc = sb.run(starts + s0, ns, poison))) return rc;
-        CZ_HIP(hipMemsetAsync(sb.d_qtag.p, 0xFF, nsN * 4, s));  // the round tags are done with: the array holds the canonical parents
-        hipLaunchKernelGGL(sssp_canon_kernel, dim3(grid_for(nsN * kSsspLanes)), dim3(kT), 0, s, sb.d_off.p, sb.d_tgt.p, sb.d_w.p, N, ns,
-                           sb.d_dp.p, sb.d_qtag.p, 0u, N);
-        hipLaunchKernelGGL(sssp_unpack_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, sb.d_dp.p, sb.d_qtag.p, nsN, d_dist.p, d_parent.p);
+        hipLaunchKernelGGL(sssp_unpack_flagged_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, sb.d_dp.p, nsN, d_dist.p, d_parent.p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sssp launch: %s", hipGetErrorString(e));
+        t_timing.lap(T_DEVICE);
         CZ_HIP(hipMemcpy(dist + (size_t)s0 * N, d_dist.p, nsN * 4, hipMemcpyDeviceToHost));
         CZ_HIP(hipMemcpy(parent + (size_t)s0 * N, d_parent.p, nsN * 4, hipMemcpyDeviceToHost));
+        t_timing.lap(T_DOWNLOAD);
     }
     return CZ_OK;
 }
@@ -944,17 +1027,19 @@ extern "C" int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets,
 // dist[u] + w == dist[v] (f32), so the same sums come out of path COUNTS over the tight-edge DAG (Brandes):
 //   sigma[v] = number of shortest paths s -> v = sum over tight (u, v) of sigma[u]                      (sigma[s] = 1)
 //   delta[u] = sum over tight (u, v) of sigma[u] / sigma[v] * (1 + delta[v]);   centrality[u] += delta[u]   (u != s)
-// Both recurrences are evaluated by Jacobi sweeps until nothing changes (one sweep per hop of the DAG's depth), a 16-lane
-// group per (source, node) pulling over the node's in- (sigma) or out-adjacency (delta) in a fixed order, f64 throughout
-// (the reference adds f32 terms; the parity bar of this rule is 1e-5 against its literal enumeration).  Sources run in
-// batches on the distances the multi-source SSSP above leaves on the device.
+// Both recurrences are evaluated level by level of the tight-edge DAG (level = longest tight path from the source): a pair
+// enters the next level when the last of its tight predecessors has been counted (a pending count per pair), every pair is
+// visited once per recurrence by a 16-lane group pulling over its in- (sigma) or out-adjacency (delta) in a fixed order,
+// f64 throughout (the reference adds f32 terms; the parity bar of this rule is 1e-5 against its literal enumeration).
+// Round 2's first form swept ALL pairs once per level (3.2 of 3.5 s on a 20 000-node graph).  Sources run in batches on
+// the distances the multi-source SSSP above leaves on the device.
 namespace {
 
+// number of tight in-edges of every (source, node) pair (what has to be final before the pair's path count is)
 __global__ void __launch_bounds__(kT)
-bc_sigma_kernel(const uint32_t *__restrict__ in_off, const uint32_t *__restrict__ in_src, const float *__restrict__ in_w, uint32_t N,
-                uint32_t ns, const unsigned long long *__restrict__ dp, const uint32_t *__restrict__ starts,
-                const double *__restrict__ sig_old, double *__restrict__ sig_new, uint32_t *__restrict__ changed,
-                uint32_t *__restrict__ absorbed) {
+bc_tight_in_kernel(const uint32_t *__restrict__ in_off, const uint32_t *__restrict__ in_src, const float *__restrict__ in_w, uint32_t N,
+                   uint32_t ns, const unsigned long long *__restrict__ dp, const uint32_t *__restrict__ starts,
+                   uint32_t *__restrict__ tin, uint32_t *__restrict__ absorbed) {
     const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
     const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes;
     const uint64_t ngroups = (uint64_t)gridDim.x * blockDim.x / kSsspLanes, total = (uint64_t)ns * N;
@@ -964,67 +1049,119 @@ bc_sigma_kernel(const uint32_t *__restrict__ in_off, const uint32_t *__restrict_
         const bool live = i < total;
         const uint32_t si = live ? (uint32_t)(i / N) : 0, v = live ? (uint32_t)(i % N) : 0;
         const unsigned long long *dps = dp + (size_t)si * N;
-        const double *so = sig_old + (size_t)si * N;
-        double sum = 0.0;
-        bool is_start = false;
-        if (live) {
-            is_start = v == starts[si];
+        uint32_t c = 0;
+        if (live && v != starts[si]) {
             const uint32_t cv = (uint32_t)(dps[v] >> 32);
-            if (!is_start && cv != 0x7F800000u) {
+            if (cv != 0x7F800000u) {
                 const uint32_t e1 = in_off[v + 1];
                 for (uint32_t e = in_off[v] + glane; e < e1; e += kSsspLanes) {
-                    const uint32_t u = in_src[e];
-                    const uint32_t cu = (uint32_t)(dps[u] >> 32);
+                    const uint32_t cu = (uint32_t)(dps[in_src[e]] >> 32);
                     if (cu != 0x7F800000u && __float_as_uint(__uint_as_float(cu) + in_w[e]) == cv) {
-                        if (cu == cv) atomicAdd(absorbed, 1u);  // dist[u] + w == dist[u]: no topological order, see the host
-                        sum += so[u];
+                        if (cu == cv) atomicAdd(absorbed, 1u);  // dist[u] + w == dist[u]: the tight edges are no DAG, see the host
+                        c++;
                     }
                 }
             }
         }
 #pragma unroll
-        for (int o = kSsspLanes / 2; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        if (live && glane == 0) {
-            const double nw = is_start ? 1.0 : sum;
-            if (nw != so[v]) *changed = 1;
-            sig_new[(size_t)si * N + v] = nw;
-        }
+        for (int o = kSsspLanes / 2; o >= 1; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o, 64);
+        if (live && glane == 0) tin[i] = c;
     }
 }
 
 __global__ void __launch_bounds__(kT)
-bc_delta_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t N, uint32_t ns,
-                const unsigned long long *__restrict__ dp, const double *__restrict__ sigma, const double *__restrict__ del_old,
-                double *__restrict__ del_new, uint32_t *__restrict__ changed) {
+bc_seed_kernel(const uint32_t *__restrict__ starts, uint32_t ns, uint32_t N, unsigned long long *__restrict__ order, double *__restrict__ sigma) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    order[i] = ((unsigned long long)i << 32) | starts[i];
+    sigma[(size_t)i * N + starts[i]] = 1.0;
+}
+
+// one level of the tight-edge DAG (level = longest tight path from the source): the pairs order[lo, lo + fsize) have all their
+// tight predecessors in earlier levels.  A 16-lane group per pair: path count by a pull over the tight in-edges (fixed order;
+// the counts are integers, exact in f64 up to 2^53), then every tight out-edge takes one off its target's pending count, and the
+// pair that takes the last one appends the target to the next level.
+__global__ void __launch_bounds__(kT)
+bc_sigma_level_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w,
+                      const uint32_t *__restrict__ in_off, const uint32_t *__restrict__ in_src, const float *__restrict__ in_w, uint32_t N,
+                      const unsigned long long *__restrict__ dp, const uint32_t *__restrict__ starts, uint32_t lo, uint32_t fsize,
+                      double *__restrict__ sigma, uint32_t *__restrict__ tin, SsspQueue order) {
+    const int lane = threadIdx.x & 63;
     const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
-    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes;
-    const uint64_t ngroups = (uint64_t)gridDim.x * blockDim.x / kSsspLanes, total = (uint64_t)ns * N;
-    const uint64_t rounds = (total + ngroups - 1) / ngroups;
-    for (uint64_t r = 0; r < rounds; r++) {
-        const uint64_t i = group + r * ngroups;
-        const bool live = i < total;
-        const uint32_t si = live ? (uint32_t)(i / N) : 0, u = live ? (uint32_t)(i % N) : 0;
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes, ngroups = gridDim.x * blockDim.x / kSsspLanes;
+    const uint32_t rounds = (fsize + ngroups - 1) / ngroups;
+    __shared__ StagedPile st;
+    if (threadIdx.x == 0) st.count = 0;
+    __syncthreads();
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i = group + r * ngroups;
+        const bool live = i < fsize;
+        const unsigned long long ent = live ? order.items[lo + i] : 0ull;
+        const uint32_t si = (uint32_t)(ent >> 32), v = (uint32_t)ent;
         const unsigned long long *dps = dp + (size_t)si * N;
-        const double *sg = sigma + (size_t)si * N, *dl = del_old + (size_t)si * N;
+        double *sg = sigma + (size_t)si * N;
+        const uint32_t cv = live ? (uint32_t)(dps[v] >> 32) : 0;
         double sum = 0.0;
-        if (live) {
-            const uint32_t cu = (uint32_t)(dps[u] >> 32);
-            if (cu != 0x7F800000u) {
-                const double su = sg[u];
-                const float du = __uint_as_float(cu);
-                const uint32_t e1 = off[u + 1];
-                for (uint32_t e = off[u] + glane; e < e1; e += kSsspLanes) {
-                    const uint32_t v = tgt[e];
-                    if (__float_as_uint(du + w[e]) == (uint32_t)(dps[v] >> 32)) sum += su / sg[v] * (1.0 + dl[v]);
-                }
+        const bool is_start = live && v == starts[si];
+        if (live && !is_start) {
+            const uint32_t e1 = in_off[v + 1];
+            for (uint32_t e = in_off[v] + glane; e < e1; e += kSsspLanes) {
+                const uint32_t u = in_src[e];
+                const uint32_t cu = (uint32_t)(dps[u] >> 32);
+                if (cu != 0x7F800000u && __float_as_uint(__uint_as_float(cu) + in_w[e]) == cv) sum += sg[u];
             }
         }
 #pragma unroll
         for (int o = kSsspLanes / 2; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        if (live && glane == 0) {
-            if (sum != dl[u]) *changed = 1;
-            del_new[(size_t)si * N + u] = sum;
+        if (live && !is_start && glane == 0) sg[v] = sum;
+        const uint32_t e0 = live ? off[v] : 0, e1 = live ? off[v + 1] : 0;
+        const float dv = __uint_as_float(cv);
+        uint32_t maxlen = e1 - e0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, o, 64));
+        for (uint32_t b = 0; b < maxlen; b += kSsspLanes) {
+            const uint32_t e = e0 + b + glane;
+            bool ready = false;
+            uint32_t x = 0;
+            if (e < e1) {
+                x = tgt[e];
+                if (__float_as_uint(dv + w[e]) == (uint32_t)(dps[x] >> 32)) ready = atomicSub(&tin[(size_t)si * N + x], 1u) == 1u;
+            }
+            staged_push(order, st, ready, ((unsigned long long)si << 32) | x, lane);
         }
+        if ((r & 7) == 7 || r + 1 == rounds) staged_flush(order, st);
+    }
+}
+
+// the levels again, last one first: the dependency of a pair by a pull over its tight out-edges (all in later levels: final)
+__global__ void __launch_bounds__(kT)
+bc_delta_level_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t N,
+                      const unsigned long long *__restrict__ dp, const unsigned long long *__restrict__ order, uint32_t fsize,
+                      const double *__restrict__ sigma, double *__restrict__ delta) {
+    const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes, ngroups = gridDim.x * blockDim.x / kSsspLanes;
+    const uint32_t rounds = (fsize + ngroups - 1) / ngroups;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i = group + r * ngroups;
+        const bool live = i < fsize;
+        const unsigned long long ent = live ? order[i] : 0ull;
+        const uint32_t si = (uint32_t)(ent >> 32), u = (uint32_t)ent;
+        const unsigned long long *dps = dp + (size_t)si * N;
+        const double *sg = sigma + (size_t)si * N;
+        double *dl = delta + (size_t)si * N;
+        double sum = 0.0;
+        if (live) {
+            const double su = sg[u];
+            const float du = __uint_as_float((uint32_t)(dps[u] >> 32));
+            const uint32_t e1 = off[u + 1];
+            for (uint32_t e = off[u] + glane; e < e1; e += kSsspLanes) {
+                const uint32_t v = tgt[e];
+                if (__float_as_uint(du + w[e]) == (uint32_t)(dps[v] >> 32)) sum += su / sg[v] * (1.0 + dl[v]);
+            }
+        }
+#pragma unroll
+        for (int o = kSsspLanes / 2; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (live && glane == 0) dl[u] = sum;
     }
 }
 
@@ -1045,6 +1182,7 @@ extern "C" int cz_betweenness(const uint32_t *out_offsets, const uint32_t *out_t
                               uint64_t E, double *centrality, const volatile uint8_t *poison) {
     int rc = cz::ensure_device();
     if (rc) return rc;
+    t_timing.start();
     if (N == 0) return CZ_OK;
     if (!centrality) return cz::set_error(CZ_E_INVALID, "null centrality");
     rc = check_csr(out_offsets, out_targets, N, E);
@@ -1072,7 +1210,7 @@ extern "C" int cz_betweenness(const uint32_t *out_offsets, const uint32_t *out_t
             }
     }
     SsspBatch sb;
-    // 56 bytes per (source, node) here: 16 + 32 of the SSSP, + 4 x 8 of sigma / delta double buffers -> a smaller batch
+    // 64 bytes per (source, node) here: 48 of the SSSP + sigma and delta -> a smaller batch than cz_sssp's
     std::vector<uint32_t> all(N);
     for (uint32_t i = 0; i < N; i++) all[i] = i;
     uint64_t pairs = 48ull << 20;
@@ -1081,63 +1219,68 @@ extern "C" int cz_betweenness(const uint32_t *out_offsets, const uint32_t *out_t
     const uint64_t SN = (uint64_t)sb.S * N;
     cz::DevBuf<uint32_t> d_ioff, d_isrc, d_flags;
     cz::DevBuf<float> d_iw;
-    cz::DevBuf<double> d_sig[2], d_del[2], d_cent;
+    cz::DevBuf<double> d_sig, d_del, d_cent;
     CZ_HIP(d_ioff.alloc((size_t)N + 1));
     CZ_HIP(d_isrc.alloc(E));
     CZ_HIP(d_iw.alloc(E));
     CZ_HIP(d_flags.alloc(2));
     CZ_HIP(d_cent.alloc(N));
-    for (int i = 0; i < 2; i++) {
-        CZ_HIP(d_sig[i].alloc(SN));
-        CZ_HIP(d_del[i].alloc(SN));
-    }
+    CZ_HIP(d_sig.alloc(SN));
+    CZ_HIP(d_del.alloc(SN));
     CZ_HIP(hipMemcpy(d_ioff.p, in_off.data(), ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
     if (E) {
         CZ_HIP(hipMemcpy(d_isrc.p, in_src.data(), E * 4, hipMemcpyHostToDevice));
         CZ_HIP(hipMemcpy(d_iw.p, in_w.data(), E * 4, hipMemcpyHostToDevice));
     }
     hipStream_t s = sb.s;
+    t_timing.lap(T_UPLOAD);
     CZ_HIP(hipMemsetAsync(d_cent.p, 0, (size_t)N * 8, s));
+    std::vector<uint32_t> level_lo;
     for (uint32_t s0 = 0; s0 < N; s0 += sb.S) {
         const uint32_t ns = std::min<uint32_t>(sb.S, N - s0);
         const uint64_t nsN = (uint64_t)ns * N;
         if ((rc = sb.run(all.data() + s0, ns, poison))) return rc;
-        const int g = grid_for(nsN * kSsspLanes);
-        uint32_t h[2] = {0, 0};
-        // sigma: Jacobi sweeps from the indicator of the source until nothing changes
-        CZ_HIP(hipMemsetAsync(d_sig[0].p, 0, nsN * 8, s));
-        int cur = 0;
-        for (uint32_t sweep = 0;; sweep++) {
+        // the SSSP is done with its round tags and queues: the tags hold the pending tight in-edges of every pair, the first
+        // queue the pairs in level order
+        uint32_t *tin = sb.d_qtag.p;
+        SsspQueue order{sb.d_q[0].p, d_flags.p};
+        uint32_t h[2] = {ns, 0};
+        CZ_HIP(hipMemcpy(d_flags.p, h, 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(bc_tight_in_kernel, dim3(grid_for(nsN * kSsspLanes)), dim3(kT), 0, s, d_ioff.p, d_isrc.p, d_iw.p, N, ns, sb.d_dp.p,
+                           sb.d_starts.p, tin, d_flags.p + 1);
+        CZ_HIP(hipMemsetAsync(d_sig.p, 0, nsN * 8, s));
+        CZ_HIP(hipMemsetAsync(d_del.p, 0, nsN * 8, s));
+        hipLaunchKernelGGL(bc_seed_kernel, dim3((ns + kT - 1) / kT), dim3(kT), 0, s, sb.d_starts.p, ns, N, order.items, d_sig.p);
+        CZ_HIP(hipMemcpy(h, d_flags.p, 8, hipMemcpyDeviceToHost));
+        if (h[1])
+            return cz::set_error(CZ_E_UNSUPPORTED, "BetweennessCentrality: an edge weight is absorbed by the f32 path cost "
+                                                   "(dist[u] + w == dist[u]); shortest-path counts are not defined on such a graph");
+        level_lo.clear();
+        uint32_t lo = 0, fsize = ns;
+        while (fsize > 0) {
             if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
-            CZ_HIP(hipMemsetAsync(d_flags.p, 0, 8, s));
-            hipLaunchKernelGGL(bc_sigma_kernel, dim3(g), dim3(kT), 0, s, d_ioff.p, d_isrc.p, d_iw.p, N, ns, sb.d_dp.p, sb.d_starts.p,
-                               d_sig[cur].p, d_sig[cur ^ 1].p, d_flags.p, d_flags.p + 1);
-            CZ_HIP(hipMemcpy(h, d_flags.p, 8, hipMemcpyDeviceToHost));
-            cur ^= 1;
-            if (h[1])
-                return cz::set_error(CZ_E_UNSUPPORTED, "BetweennessCentrality: an edge weight is absorbed by the f32 path cost "
-                                                       "(dist[u] + w == dist[u]); shortest-path counts are not defined on such a graph");
-            if (!h[0]) break;
-            if (sweep > N) return cz::set_error(CZ_E_HIP, "internal: path counts did not settle");
+            level_lo.push_back(lo);
+            hipLaunchKernelGGL(bc_sigma_level_kernel, dim3(grid_for((uint64_t)fsize * kSsspLanes)), dim3(kT), 0, s, sb.d_off.p, sb.d_tgt.p,
+                               sb.d_w.p, d_ioff.p, d_isrc.p, d_iw.p, N, sb.d_dp.p, sb.d_starts.p, lo, fsize, d_sig.p, tin, order);
+            uint32_t end = 0;
+            CZ_HIP(hipMemcpy(&end, d_flags.p, 4, hipMemcpyDeviceToHost));
+            lo += fsize;
+            fsize = end - lo;
+            if (level_lo.size() > (size_t)N + 1) return cz::set_error(CZ_E_HIP, "internal: the tight edges have no level order");
         }
-        const double *sigma = d_sig[cur].p;
-        CZ_HIP(hipMemsetAsync(d_del[0].p, 0, nsN * 8, s));
-        int dc = 0;
-        for (uint32_t sweep = 0;; sweep++) {
-            if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
-            CZ_HIP(hipMemsetAsync(d_flags.p, 0, 4, s));
-            hipLaunchKernelGGL(bc_delta_kernel, dim3(g), dim3(kT), 0, s, sb.d_off.p, sb.d_tgt.p, sb.d_w.p, N, ns, sb.d_dp.p, sigma,
-                               d_del[dc].p, d_del[dc ^ 1].p, d_flags.p);
-            CZ_HIP(hipMemcpy(h, d_flags.p, 4, hipMemcpyDeviceToHost));
-            dc ^= 1;
-            if (!h[0]) break;
-            if (sweep > N) return cz::set_error(CZ_E_HIP, "internal: dependencies did not settle");
+        level_lo.push_back(lo);
+        for (size_t k = level_lo.size() - 1; k-- > 0;) {
+            const uint32_t l0 = level_lo[k], n = level_lo[k + 1] - l0;
+            hipLaunchKernelGGL(bc_delta_level_kernel, dim3(grid_for((uint64_t)n * kSsspLanes)), dim3(kT), 0, s, sb.d_off.p, sb.d_tgt.p, sb.d_w.p,
+                               N, sb.d_dp.p, order.items + l0, n, d_sig.p, d_del.p);
         }
-        hipLaunchKernelGGL(bc_accumulate_kernel, dim3(grid_for(N)), dim3(kT), 0, s, N, ns, d_del[dc].p, sb.d_starts.p, d_cent.p);
+        hipLaunchKernelGGL(bc_accumulate_kernel, dim3(grid_for(N)), dim3(kT), 0, s, N, ns, d_del.p, sb.d_starts.p, d_cent.p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "betweenness launch: %s", hipGetErrorString(e));
     }
+    t_timing.lap(T_DEVICE);
     CZ_HIP(hipMemcpy(centrality, d_cent.p, (size_t)N * 8, hipMemcpyDeviceToHost));
+    t_timing.lap(T_DOWNLOAD);
     return CZ_OK;
 }
 
@@ -1222,14 +1365,14 @@ struct HipShardedBfs {
     }
     int bfs_claim(uint32_t lo, uint32_t fsize) {
         hipLaunchKernelGGL(bfs_claim_kernel, dim3(grid_for((uint64_t)fsize * kBfsLanes)), dim3(kT), 0, s, off.p, tgt.p, order.p + lo,
-                           fsize, depth.p, claim.p, rb, re);
+                           fsize, depth.p, (const uint32_t *)nullptr, claim.p, rb, re);
         return CZ_OK;
     }
     int reduce_claim() { return cz::comm_all_reduce(comm, claim.p, N, cz::COMM_U32, cz::COMM_MIN, s); }
     int bfs_count(uint32_t lo, uint32_t fsize) {
         CZ_HIP(hipMemsetAsync(cnt.p, 0, (size_t)fsize * 4, s));
         hipLaunchKernelGGL(bfs_count_kernel, dim3(grid_for((uint64_t)fsize * kBfsLanes)), dim3(kT), 0, s, off.p, tgt.p, order.p + lo,
-                           fsize, depth.p, claim.p, cnt.p, rb, re);
+                           fsize, depth.p, (const uint32_t *)nullptr, claim.p, cnt.p, (uint8_t *)nullptr, rb, re);
         return CZ_OK;
     }
     int reduce_counts(uint32_t fsize) { return cz::comm_all_reduce(comm, cnt.p, fsize, cz::COMM_U32, cz::COMM_SUM, s); }
@@ -1243,7 +1386,7 @@ struct HipShardedBfs {
     int bfs_emit(uint32_t lo, uint32_t fsize, uint32_t total, uint32_t next_depth) {
         if (total) CZ_HIP(hipMemsetAsync(buf.p, 0, (size_t)total * 4, s));
         hipLaunchKernelGGL(bfs_emit_kernel, dim3(grid_for((uint64_t)fsize * kBfsLanes)), dim3(kT), 0, s, off.p, tgt.p, order.p + lo,
-                           fsize, depth.p, claim.p, pos.p, buf.p, parent.p, next_depth, rb, re, 1u);
+                           fsize, depth.p, (uint32_t *)nullptr, claim.p, (const uint8_t *)nullptr, pos.p, buf.p, parent.p, next_depth, rb, re, 1u);
         return CZ_OK;
     }
     int reduce_next(uint32_t total) { return cz::comm_all_reduce(comm, buf.p, total, cz::COMM_U32, cz::COMM_SUM, s); }

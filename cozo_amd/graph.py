@@ -161,6 +161,13 @@ def sssp(out_off, out_tgt, weights, starts, poison=None):
     return dist, parent
 
 
+def last_timing():
+    """cz_graph_last_timing: (upload_ms, device_ms, download_ms) of this thread's last whole-graph rule call"""
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    check(_lib.lib().cz_graph_last_timing(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
 def betweenness(out_off, out_tgt, weights, poison=None):
     """cz_betweenness on the weighted out-CSR (weights > 0) -> centrality f64 [N]"""
     out_off, out_tgt = _csr32(out_off, out_tgt)

@@ -35,7 +35,9 @@ def main():
     def timed(name, fn, edges, note=""):
         fn()  # warm (allocations, code objects)
         t0 = time.perf_counter(); r = fn(); dt = time.perf_counter() - t0
-        print(f"{name:34s} {dt * 1e3:9.1f} ms wall  {edges / dt / 1e9:7.2f} G edges/s  {note}", flush=True)
+        up, dev_ms, down = G.last_timing()
+        print(f"{name:34s} {dt * 1e3:9.1f} ms wall  {edges / dt / 1e9:7.2f} G edges/s   upload {up:6.1f}  device {dev_ms:7.2f} ms "
+              f"({edges / dev_ms / 1e6:7.2f} G edges/s)  download {down:5.1f}  {note}", flush=True)
         return r
     starts = np.array([0], dtype=np.uint32)
     par, dep, _, _ = timed("cz_bfs (1 start, full traversal)", lambda: G.bfs(ooff, otgt, starts, want_depth=True), E)
@@ -69,8 +71,8 @@ def all_sources():
     t0 = time.perf_counter()
     c = G.betweenness(off, tgt, w)
     dt = time.perf_counter() - t0
-    print(f"cz_betweenness: {n} nodes / {tgt.size} edges: {dt:.2f} s ({dt / n * 1e3:.3f} ms per source), max centrality {c.max():.1f}",
-          flush=True)
+    print(f"cz_betweenness: {n} nodes / {tgt.size} edges: {dt:.2f} s ({dt / n * 1e3:.3f} ms per source; device {G.last_timing()[1] / 1e3:.2f} s), "
+          f"max centrality {c.max():.1f}", flush=True)
 
 
 if not os.environ.get("ONLY_ALL_SOURCES"):
