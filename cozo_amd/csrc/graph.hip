@@ -809,16 +809,18 @@ triangles_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
     for (uint32_t v = wave; v < N; v += n_waves) {
         const uint32_t a = off[v], b = off[v + 1], d = b - a;
         unsigned long long cnt = 0;
-        if (d >= 2) {
-            // pairs (i, j), j < i suffices: the list is ascending, so A[i] > A[j] implies j < i
-            for (uint32_t i = 1; i < d; i++) {
-                const uint32_t src = tgt[a + i];
-                const uint32_t lo = off[src], hi = off[src + 1];
-                for (uint32_t j = lane; j < i; j += 64) {
-                    const uint32_t dst = tgt[a + j];
-                    if (dst < src && csr_contains(tgt, lo, hi, dst)) cnt++;
-                }
-            }
+        // pairs (i, j), j < i suffices: the list is ascending, so A[i] > A[j] implies j < i.  The d (d - 1) / 2 pairs are laid
+        // out flat, p = i (i - 1) / 2 + j, and dealt to the lanes 64 at a time: every lane is busy and a node of degree 20
+        // takes 3 steps (one step per i with the lanes j < i -- 19 steps, 15 % of the lanes -- measured 77 ms on the
+        // symmetrised 10M / 200M graph)
+        const unsigned long long P = (unsigned long long)d * (d - (d > 0)) / 2;
+        for (unsigned long long p = lane; p < P; p += 64) {
+            uint32_t i = (uint32_t)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
+            while ((unsigned long long)i * (i - 1) / 2 > p) i--;
+            while ((unsigned long long)(i + 1) * i / 2 <= p) i++;
+            const uint32_t j = (uint32_t)(p - (unsigned long long)i * (i - 1) / 2);
+            const uint32_t src = tgt[a + i], dst = tgt[a + j];
+            if (dst < src && csr_contains(tgt, off[src], off[src + 1], dst)) cnt++;
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
