@@ -1286,6 +1286,328 @@ extern "C" int cz_betweenness(const uint32_t *out_offsets, const uint32_t *out_t
     return CZ_OK;
 }
 
+// ---- LabelPropagation (fixed_rule/algos/label_propagation.rs:56-109), one FIXED execution of it --------------------------------
+// The reference visits the nodes in a freshly shuffled order every iteration (:63-66), updates labels in place, and picks a
+// random label among the best-scored ones (:85): no two runs agree, so there is no result to be identical to.  This rule
+// fixes both choices so that the run is (a) one the reference itself can produce and (b) parallel:
+//   * order: the colour classes of a deterministic colouring, ascending, ids ascending inside a class.  In round r every
+//     still uncoloured node whose key (hash(id) << 32 | id) is the largest among its uncoloured neighbours -- edges in EITHER
+//     direction -- takes colour r.  Nodes of one class share no edge, so updating a class at once is the sequential loop over
+//     its nodes in any order: one kernel launch per class.
+//   * tie: the smallest label among those whose score == the largest score (f32::total_cmp order, :81-84).
+// Scores are what :70-73 computes: per label, the f32 sum of the edge values in adjacency order, starting from 0.0 -- a wave
+// per node walks the list 64 entries at a time and adds each label's entries one after the other.
+namespace {
+
+constexpr uint32_t kLpTable = 512;        // per-wave LDS table; nodes of degree <= kLpSmall never fill it beyond 3/4
+constexpr uint32_t kLpSmall = 384;
+
+__device__ __forceinline__ unsigned long long lp_priority(uint32_t v) {
+    uint32_t x = v;
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return ((unsigned long long)x << 32) | v;
+}
+
+__global__ void __launch_bounds__(kT)
+lp_colour_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ in_off,
+                 const uint32_t *__restrict__ in_src, uint32_t N, uint32_t round, uint32_t *__restrict__ colour, uint32_t *__restrict__ taken) {
+    const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes, ngroups = gridDim.x * blockDim.x / kSsspLanes;
+    const uint32_t rounds = (N + ngroups - 1) / ngroups;  // every group of a wave runs the same trip count (shuffles)
+    uint32_t mine = 0;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t v = group + r * ngroups;
+        const bool live = v < N && __hip_atomic_load(&colour[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == CZ_NONE;
+        int beaten = 0;
+        if (live) {
+            const unsigned long long kv = lp_priority(v);
+            // a neighbour that took THIS round's colour a moment ago was uncoloured when the round began: it still counts
+            for (int side = 0; side < 2; side++) {
+                const uint32_t *o = side ? in_off : off, *t = side ? in_src : tgt;
+                const uint32_t e1 = o[v + 1];
+                for (uint32_t e = o[v] + glane; e < e1 && !beaten; e += kSsspLanes) {
+                    const uint32_t u = t[e];
+                    if (u == v) continue;
+                    const uint32_t cu = __hip_atomic_load(&colour[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((cu == CZ_NONE || cu == round) && lp_priority(u) > kv) beaten = 1;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = kSsspLanes / 2; o >= 1; o >>= 1) beaten |= __shfl_xor(beaten, o, 64);
+        if (live && !beaten && glane == 0) {
+            __hip_atomic_store(&colour[v], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mine++;
+        }
+    }
+    if (mine) atomicAdd(taken, mine);
+}
+
+__global__ void __launch_bounds__(kT)
+lp_indegree_kernel(const uint32_t *__restrict__ tgt, uint64_t E, uint32_t N, uint32_t *__restrict__ cnt, uint32_t *__restrict__ bad) {
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = tgt[e];
+        if (v < N) atomicAdd(&cnt[v], 1u);
+        else *bad = 1;
+    }
+}
+
+__global__ void __launch_bounds__(kT)
+lp_transpose_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t N, const uint32_t *__restrict__ in_off,
+                    uint32_t *__restrict__ cursor, uint32_t *__restrict__ in_src) {
+    const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes, ngroups = gridDim.x * blockDim.x / kSsspLanes;
+    for (uint32_t u = group; u < N; u += ngroups) {
+        const uint32_t e1 = off[u + 1];
+        for (uint32_t e = off[u] + glane; e < e1; e += kSsspLanes) {
+            const uint32_t v = tgt[e];
+            if (v < N) in_src[in_off[v] + atomicAdd(&cursor[v], 1u)] = u;
+        }
+    }
+}
+
+struct LpTab {
+    uint32_t *keys;   // CZ_NONE = empty
+    float *vals;
+    uint32_t *slots;  // the slots in use, in order of first use
+    uint32_t bits;
+};
+
+// one node, by one wave (all lanes in the same control flow; table accesses are wave-uniform: every lane reads and writes
+// the same words with the same values)
+__device__ __forceinline__ void lp_update_node(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w,
+                                               uint32_t v, uint32_t *__restrict__ labels, const LpTab &tab, int lane,
+                                               uint32_t *__restrict__ flags) {
+    const uint32_t a = off[v], b = off[v + 1];
+    if (a == b) return;  // :74-76
+    const uint32_t tmask = (1u << tab.bits) - 1u;
+    uint32_t used = 0;
+    for (uint32_t base = a; base < b; base += 64) {
+        const uint32_t e = base + lane;
+        const bool valid = e < b;
+        const uint32_t l = valid ? labels[tgt[e]] : CZ_NONE;
+        const float wv = valid ? w[e] : 0.f;
+        unsigned long long remaining = __ballot(valid);
+        while (remaining) {
+            const int leader = __ffsll((long long)remaining) - 1;
+            const uint32_t L = (uint32_t)__shfl((int)l, leader, 64);
+            unsigned long long m = __ballot(valid && l == L);
+            remaining &= ~m;
+            uint32_t h = (L * 0x9E3779B1u) >> (32 - tab.bits);
+            float sum = 0.0f;  // `entry(label).or_default()`
+            for (;;) {
+                const uint32_t k = tab.keys[h];
+                if (k == L) {
+                    sum = tab.vals[h];
+                    break;
+                }
+                if (k == CZ_NONE) {
+                    tab.keys[h] = L;
+                    tab.slots[used++] = h;
+                    break;
+                }
+                h = (h + 1) & tmask;
+            }
+            while (m) {  // `+= edge.value`, one entry after the other in adjacency order (:72)
+                const int j = __ffsll((long long)m) - 1;
+                sum += __shfl(wv, j, 64);
+                m &= m - 1;
+            }
+            tab.vals[h] = sum;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+    }
+    // :77-85: the largest score under total_cmp; among the labels whose score == it, the smallest
+    uint32_t best_key = 0;
+    for (uint32_t i = lane; i < used; i += 64) {
+        const uint32_t bts = __float_as_uint(tab.vals[tab.slots[i]]);
+        const uint32_t key = (bts & 0x80000000u) ? ~bts : (bts | 0x80000000u);
+        best_key = max(best_key, key);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) best_key = max(best_key, (uint32_t)__shfl_xor((int)best_key, o, 64));
+    const float max_score = __uint_as_float((best_key & 0x80000000u) ? (best_key & 0x7FFFFFFFu) : ~best_key);
+    uint32_t new_label = CZ_NONE;
+    for (uint32_t i = lane; i < used; i += 64) {
+        const uint32_t sl = tab.slots[i];
+        if (tab.vals[sl] == max_score) new_label = min(new_label, tab.keys[sl]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) new_label = min(new_label, (uint32_t)__shfl_xor((int)new_label, o, 64));
+    for (uint32_t i = lane; i < used; i += 64) tab.keys[tab.slots[i]] = CZ_NONE;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (lane == 0) {
+        if (new_label == CZ_NONE) flags[1] = 1;  // the best score is NaN: `choose` on an empty list, the reference panics
+        else if (new_label != labels[v]) {
+            labels[v] = new_label;
+            flags[0] = 1;
+        }
+    }
+}
+
+// the nodes order[0 .. count) of one colour class, degree <= kLpSmall: tables in LDS
+__global__ void __launch_bounds__(kT)
+lp_update_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w,
+                 const uint32_t *__restrict__ order, uint32_t count, uint32_t *__restrict__ labels, uint32_t *__restrict__ flags) {
+    __shared__ uint32_t keys[kT / 64][kLpTable];
+    __shared__ float vals[kT / 64][kLpTable];
+    __shared__ uint32_t slots[kT / 64][kLpTable];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t i = lane; i < kLpTable; i += 64) keys[wv][i] = CZ_NONE;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    LpTab tab{keys[wv], vals[wv], slots[wv], 9};
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = wave; i < count; i += n_waves) lp_update_node(off, tgt, w, order[i], labels, tab, lane, flags);
+}
+
+// the class's nodes of larger degree: a table per wave in global memory, sized for the largest degree of the graph
+__global__ void __launch_bounds__(kT)
+lp_update_hub_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w,
+                     const uint32_t *__restrict__ order, uint32_t count, uint32_t *__restrict__ labels, uint32_t *__restrict__ flags,
+                     uint32_t *__restrict__ tkeys, float *__restrict__ tvals, uint32_t *__restrict__ tslots, uint32_t bits) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const size_t at = (size_t)wave << bits;
+    LpTab tab{tkeys + at, tvals + at, tslots + at, bits};
+    for (uint32_t i = wave; i < count; i += n_waves) lp_update_node(off, tgt, w, order[i], labels, tab, lane, flags);
+}
+
+}  // namespace
+
+extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N,
+                                    uint64_t E, uint32_t max_iter, uint32_t *labels, uint32_t *iters_run, uint32_t *n_colours,
+                                    const volatile uint8_t *poison) {
+    if (iters_run) *iters_run = 0;
+    if (n_colours) *n_colours = 0;
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    t_timing.start();
+    if (N == 0) return CZ_OK;
+    if (!labels) return cz::set_error(CZ_E_INVALID, "null labels");
+    rc = check_csr(out_offsets, out_targets, N, E);
+    if (rc) return rc;
+    if (E > 0 && !weights) return cz::set_error(CZ_E_INVALID, "null weights");
+    uint32_t max_deg = 0;
+    for (uint32_t v = 0; v < N; v++) max_deg = std::max(max_deg, out_offsets[v + 1] - out_offsets[v]);
+    cz::DevBuf<uint32_t> d_off, d_tgt, d_ioff, d_isrc, d_colour, d_labels, d_order, d_flags, d_cnt, d_scratch;
+    cz::DevBuf<float> d_w;
+    CZ_HIP(d_off.alloc((size_t)N + 1));
+    CZ_HIP(d_tgt.alloc(E));
+    CZ_HIP(d_w.alloc(E));
+    CZ_HIP(d_ioff.alloc((size_t)N + 1));
+    CZ_HIP(d_isrc.alloc(E));
+    CZ_HIP(d_colour.alloc(N));
+    CZ_HIP(d_labels.alloc(N));
+    CZ_HIP(d_order.alloc(N));
+    CZ_HIP(d_flags.alloc(4));
+    CZ_HIP(d_cnt.alloc((size_t)N + 1));
+    CZ_HIP(d_scratch.alloc(scan_scratch_words((size_t)N + 1)));
+    CZ_HIP(hipMemcpy(d_off.p, out_offsets, ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
+    if (E) {
+        CZ_HIP(hipMemcpy(d_tgt.p, out_targets, E * 4, hipMemcpyHostToDevice));
+        CZ_HIP(hipMemcpy(d_w.p, weights, E * 4, hipMemcpyHostToDevice));
+    }
+    hipStream_t s = nullptr;
+    t_timing.lap(T_UPLOAD);
+    // ---- the transposed adjacency (sources only, in any order inside a list): the colouring looks at edges in either direction
+    CZ_HIP(hipMemsetAsync(d_cnt.p, 0, ((size_t)N + 1) * 4, s));
+    CZ_HIP(hipMemsetAsync(d_flags.p, 0, 16, s));
+    if (E) hipLaunchKernelGGL(lp_indegree_kernel, dim3(grid_for(E)), dim3(kT), 0, s, d_tgt.p, E, N, d_cnt.p, d_flags.p + 2);
+    rc = exclusive_scan(d_cnt.p, d_ioff.p, N + 1, d_flags.p + 3, d_scratch.p, s);
+    if (rc) return rc;
+    CZ_HIP(hipMemsetAsync(d_cnt.p, 0, ((size_t)N + 1) * 4, s));
+    if (E)
+        hipLaunchKernelGGL(lp_transpose_kernel, dim3(grid_for((uint64_t)N * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, N, d_ioff.p,
+                           d_cnt.p, d_isrc.p);
+    {
+        uint32_t bad = 0;
+        CZ_HIP(hipMemcpy(&bad, d_flags.p + 2, 4, hipMemcpyDeviceToHost));
+        if (bad) return cz::set_error(CZ_E_INVALID, "a target is out of range");
+    }
+    // ---- colouring
+    CZ_HIP(hipMemsetAsync(d_colour.p, 0xFF, (size_t)N * 4, s));
+    uint32_t left = N, n_col = 0;
+    while (left > 0) {
+        if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+        CZ_HIP(hipMemsetAsync(d_flags.p, 0, 4, s));
+        hipLaunchKernelGGL(lp_colour_kernel, dim3(grid_for((uint64_t)N * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, d_ioff.p, d_isrc.p, N,
+                           n_col, d_colour.p, d_flags.p);
+        uint32_t took = 0;
+        CZ_HIP(hipMemcpy(&took, d_flags.p, 4, hipMemcpyDeviceToHost));
+        if (took == 0 || took > left) return cz::set_error(CZ_E_HIP, "internal: colouring round %u took %u of %u nodes", n_col, took, left);
+        left -= took;
+        n_col++;
+    }
+    // ---- the classes as lists (ids ascending inside a class), the nodes of larger degree at the end of each
+    std::vector<uint32_t> colour(N), order(N), small_end((size_t)n_col + 1, 0), class_off((size_t)n_col + 1, 0);
+    CZ_HIP(hipMemcpy(colour.data(), d_colour.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    for (uint32_t v = 0; v < N; v++) class_off[colour[v] + 1]++;
+    for (uint32_t c = 0; c < n_col; c++) class_off[c + 1] += class_off[c];
+    {
+        std::vector<uint32_t> cur_small(class_off.begin(), class_off.end() - 1), n_small(n_col, 0);
+        for (uint32_t v = 0; v < N; v++)
+            if (out_offsets[v + 1] - out_offsets[v] <= kLpSmall) n_small[colour[v]]++;
+        std::vector<uint32_t> cur_hub(n_col);
+        for (uint32_t c = 0; c < n_col; c++) {
+            small_end[c] = class_off[c] + n_small[c];
+            cur_hub[c] = small_end[c];
+        }
+        for (uint32_t v = 0; v < N; v++) {
+            const uint32_t c = colour[v];
+            if (out_offsets[v + 1] - out_offsets[v] <= kLpSmall) order[cur_small[c]++] = v;
+            else order[cur_hub[c]++] = v;
+        }
+    }
+    CZ_HIP(hipMemcpy(d_order.p, order.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    // tables of the hub waves
+    uint32_t hub_bits = 10;
+    while ((1ull << hub_bits) * 3 / 4 < max_deg) hub_bits++;
+    const bool any_hub = max_deg > kLpSmall;
+    const uint32_t hub_blocks = any_hub ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (256ull << 20) / ((12ull << hub_bits) * (kT / 64)))) : 0;
+    cz::DevBuf<uint32_t> d_tkeys, d_tslots;
+    cz::DevBuf<float> d_tvals;
+    if (any_hub) {
+        const size_t words = ((size_t)hub_blocks * (kT / 64)) << hub_bits;
+        CZ_HIP(d_tkeys.alloc(words));
+        CZ_HIP(d_tvals.alloc(words));
+        CZ_HIP(d_tslots.alloc(words));
+        CZ_HIP(hipMemsetAsync(d_tkeys.p, 0xFF, words * 4, s));
+    }
+    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(N)), dim3(kT), 0, s, d_labels.p, N);  // :61
+    uint32_t iters = 0;
+    for (uint32_t it = 0; it < max_iter; it++) {
+        if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+        CZ_HIP(hipMemsetAsync(d_flags.p, 0, 8, s));
+        iters++;
+        for (uint32_t c = 0; c < n_col; c++) {
+            const uint32_t ns = small_end[c] - class_off[c], nh = class_off[c + 1] - small_end[c];
+            if (ns)
+                hipLaunchKernelGGL(lp_update_kernel, dim3(grid_for((uint64_t)ns * 64)), dim3(kT), 0, s, d_off.p, d_tgt.p, d_w.p,
+                                   d_order.p + class_off[c], ns, d_labels.p, d_flags.p);
+            if (nh)
+                hipLaunchKernelGGL(lp_update_hub_kernel, dim3(std::min<uint32_t>(hub_blocks, (nh + kT / 64 - 1) / (kT / 64))), dim3(kT), 0, s,
+                                   d_off.p, d_tgt.p, d_w.p, d_order.p + small_end[c], nh, d_labels.p, d_flags.p, d_tkeys.p, d_tvals.p,
+                                   d_tslots.p, hub_bits);
+        }
+        uint32_t h[2];
+        CZ_HIP(hipMemcpy(h, d_flags.p, 8, hipMemcpyDeviceToHost));
+        if (h[1]) return cz::set_error(CZ_E_INVALID, "LabelPropagation: a node's best label score is NaN (the reference panics there)");
+        if (!h[0]) break;  // :92-94
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "label propagation launch: %s", hipGetErrorString(e));
+    t_timing.lap(T_DEVICE);
+    CZ_HIP(hipMemcpy(labels, d_labels.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    t_timing.lap(T_DOWNLOAD);
+    if (iters_run) *iters_run = iters;
+    if (n_colours) *n_colours = n_col;
+    return CZ_OK;
+}
+
 // =====================================================================================================================
 // ONE traversal over a vertex-partitioned graph (third row): the loops of sharded_traversal.hpp
 // over these kernels + the communicator's all-reduces.  Rank r holds the out-adjacency of [row_begin, row_end) (offsets

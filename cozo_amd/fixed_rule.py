@@ -818,6 +818,30 @@ class DegreeCentrality(FixedRule):
             out.put((vals[c], tot, o, i))
 
 
+class LabelPropagation(FixedRule):
+    """algos/label_propagation.rs:27-109 -> cz_label_propagation.  The reference shuffles the node order in every iteration and
+    picks a random label among the best-scored ones (`thread_rng`, :63-66 and :85): two of ITS runs do not agree, so the GPU
+    rule fixes both choices -- colour classes of a deterministic colouring in ascending order (nodes of one class share no
+    edge: a class is updated at once, which is the sequential loop over its nodes) and the smallest label on ties -- and
+    returns the result of that one execution, which the reference could produce itself (include/cozo_gpu.h).
+    Options as the reference: `undirected` (false), `max_iter` (10).  Rows: (label as i64, node)."""
+
+    def arity(self, options, rule_head) -> int:
+        return 2
+
+    def run(self, payload, out, poison):
+        edges = payload.get_input(0)
+        undirected = payload.bool_option("undirected", False)
+        max_iter = payload.pos_integer_option("max_iter", 10)
+        graph, indices, _ = edges.as_directed_weighted_graph(undirected, True)
+        if graph.n == 0:
+            return
+        labels, _, _ = _graph.label_propagation(graph.out_offsets, graph.out_targets, graph.out_weights, max_iter, poison=poison.flag)
+        poison.check()
+        for i in range(graph.n):
+            out.put((int(labels[i]), indices[i]))
+
+
 # ---- registry (Db::register_fixed_rule, runtime/db.rs:760-784) --------------------------------------------------
 class FixedRuleRegistry:
     """The GPU rules are registered under NEW names next to the built-ins (built-ins cannot be replaced or
@@ -826,7 +850,7 @@ class FixedRuleRegistry:
 
     BUILTIN = ("PageRank", "ShortestPathBFS", "BFS", "BreadthFirstSearch", "ConnectedComponents",
                "StronglyConnectedComponents", "SCC", "ShortestPathDijkstra", "ClusteringCoefficients", "DegreeCentrality", "ClosenessCentrality",
-               "BetweennessCentrality")
+               "BetweennessCentrality", "LabelPropagation")
 
     def __init__(self):
         self._rules: Dict[str, FixedRule] = {}
@@ -836,7 +860,8 @@ class FixedRuleRegistry:
                            ("ClusteringCoefficientsGpu", ClusteringCoefficients()),
                            ("DegreeCentralityGpu", DegreeCentrality()),
                            ("ClosenessCentralityGpu", ClosenessCentrality()),
-                           ("BetweennessCentralityGpu", BetweennessCentrality())):
+                           ("BetweennessCentralityGpu", BetweennessCentrality()),
+                           ("LabelPropagationGpu", LabelPropagation())):
             self._rules[name] = impl
 
     def register_fixed_rule(self, name: str, impl: FixedRule) -> None:

@@ -176,3 +176,15 @@ def betweenness(out_off, out_tgt, weights, poison=None):
     cent = np.zeros(N, dtype=np.float64)
     check(_lib.lib().cz_betweenness(ptr(out_off), ptr(out_tgt), ptr(w), N, out_tgt.size, ptr(cent), ptr(poison)))
     return cent
+
+
+def label_propagation(out_off, out_tgt, weights, max_iter=10, poison=None):
+    """cz_label_propagation on the weighted out-CSR -> (labels u32 [N], iterations run, colour classes)"""
+    out_off, out_tgt = _csr32(out_off, out_tgt)
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    N = out_off.size - 1
+    labels = np.empty(N, dtype=np.uint32)
+    it, nc = C.c_uint32(0), C.c_uint32(0)
+    check(_lib.lib().cz_label_propagation(ptr(out_off), ptr(out_tgt), ptr(w), N, out_tgt.size, int(max_iter), ptr(labels),
+                                          C.byref(it), C.byref(nc), ptr(poison)))
+    return labels, it.value, nc.value

@@ -12,7 +12,8 @@
 //   ClusteringCoefficients       fixed_rule/algos/triangles.rs:25-110                  -> cz_clustering_coefficients
 //   DegreeCentrality             fixed_rule/algos/degree_centrality.rs:24-76           (a scan with counters: host only)
 //   ClosenessCentrality          fixed_rule/algos/all_pairs_shortest_path.rs:97-176    -> cz_sssp from every node
-//   BetweennessCentrality        fixed_rule/algos/all_pairs_shortest_path.rs:31-95     -> cz_sssp from every node + Brandes
+//   BetweennessCentrality        fixed_rule/algos/all_pairs_shortest_path.rs:31-95     -> cz_betweenness
+//   LabelPropagation             fixed_rule/algos/label_propagation.rs:27-109          -> cz_label_propagation (one fixed execution)
 //                                                                                      accumulation on the tight-edge DAG (host)
 #pragma once
 #include "fixed_rule.hpp"
@@ -65,6 +66,15 @@ public:
 };
 
 class BetweennessCentrality : public FixedRule {
+public:
+    size_t arity(const std::map<std::string, DataValue> &, const std::vector<std::string> &) const override { return 2; }
+    void run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const override;
+};
+
+// algos/label_propagation.rs:27-109 as ONE fixed execution of the reference's loop (it shuffles the node order in every iteration
+// and breaks ties with thread_rng): colour classes of a deterministic colouring in ascending order, the smallest label on ties
+// (include/cozo_gpu.h cz_label_propagation).  Options: undirected (false), max_iter (10).  Rows: (label as i64, node).
+class LabelPropagation : public FixedRule {
 public:
     size_t arity(const std::map<std::string, DataValue> &, const std::vector<std::string> &) const override { return 2; }
     void run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const override;

@@ -463,6 +463,7 @@ FixedRuleRegistry FixedRuleRegistry::with_gpu_defaults() {
     add("DegreeCentrality", std::make_shared<DegreeCentrality>());
     add("BetweennessCentrality", std::make_shared<BetweennessCentrality>());
     add("ClosenessCentrality", std::make_shared<ClosenessCentrality>());
+    add("LabelPropagation", std::make_shared<LabelPropagation>());
     return r;
 }
 

@@ -352,6 +352,21 @@ void BetweennessCentrality::run(const FixedRulePayload &payload, RegularTempStor
     for (uint32_t v = 0; v < n; v++) out.put(Tuple{g.indices[v], DataValue(cent[v])});
 }
 
+// ---- LabelPropagation (algos/label_propagation.rs:27-109, one fixed execution: see the header) ------------------------------
+void LabelPropagation::run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const {
+    const FixedRuleInputRelation &edges = payload.get_input(0);
+    const bool undirected = payload.bool_option("undirected", false);
+    const size_t max_iter = payload.pos_integer_option("max_iter", 10);
+    GraphWithIndices g = edges.as_directed_weighted_graph(undirected, true);
+    const DirectedCsrGraph &gr = g.graph;
+    if (gr.n == 0) return;
+    std::vector<uint32_t> labels(gr.n);
+    check_gpu(cz_label_propagation(gr.out_offsets.data(), gr.out_targets.data(), gr.out_weights.data(), gr.n, gr.edge_count(),
+                                   (uint32_t)std::min<size_t>(max_iter, 0xFFFFFFFFu), labels.data(), nullptr, nullptr, poison.flag_ptr()));
+    poison.check();
+    for (uint32_t v = 0; v < gr.n; v++) out.put(Tuple{DataValue((int64_t)labels[v]), g.indices[v]});
+}
+
 // ---- DegreeCentrality (host only: the reference's rule is a scan with three counters per node) -----------------
 void DegreeCentrality::run(const FixedRulePayload &payload, RegularTempStore &out, const Poison &poison) const {
     struct Deg {

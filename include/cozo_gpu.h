@@ -359,7 +359,8 @@ int cz_clustering_coefficients(const uint32_t *offsets, const uint32_t *targets,
 int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
             const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison);
 
-/* Where the last cz_bfs / cz_connected_components / cz_sssp / cz_clustering_coefficients / cz_betweenness call of THIS
+/* Where the last cz_bfs / cz_connected_components / cz_sssp / cz_clustering_coefficients / cz_betweenness /
+ * cz_label_propagation call of THIS
  * host thread spent its wall time, in milliseconds (any pointer may be null): these entry points take host arrays
  * (FixedRule::run hands over a relation, fixed_rule/mod.rs:538-567), so a call is upload (allocation + CSR over PCIe) +
  * device (kernels and their control round trips) + download (per-node results back). */
@@ -374,6 +375,20 @@ int cz_graph_last_timing(double *upload_ms, double *device_ms, double *download_
  *   (dist[u] + w == dist[u]: shortest-path counts are not defined; the reference's enumeration would not end). */
 int cz_betweenness(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
                    double *centrality, const volatile uint8_t *poison);
+
+/* LabelPropagation (fixed_rule/algos/label_propagation.rs:56-109) on the weighted out-CSR
+ * (as_directed_weighted_graph(undirected, allow_negative_weights = true); finite f32 weights, default 1.0), as ONE fixed
+ * execution of the reference's loop -- which shuffles the node order every iteration and breaks ties with thread_rng
+ * (:63-66, :85), so that no two of its own runs agree:
+ *   order  every iteration visits the colour classes of a deterministic colouring in ascending order, ids ascending
+ *          inside a class (round r of the colouring: every uncoloured node whose key hash(id) << 32 | id is the largest
+ *          among its uncoloured neighbours, edges in either direction, takes colour r; hash = the murmur3 finaliser);
+ *   tie    the smallest label among those whose score equals the largest one.
+ * Scores are the reference's: per label the f32 sum of the edge values in adjacency order.  labels [N] out (a label is
+ * a node index, :61), iters_run / n_colours optional.  CZ_E_INVALID when a best score is NaN (the reference panics). */
+int cz_label_propagation(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N,
+                         uint64_t E, uint32_t max_iter, uint32_t *labels, uint32_t *iters_run, uint32_t *n_colours,
+                         const volatile uint8_t *poison);
 
 #ifdef __cplusplus
 }

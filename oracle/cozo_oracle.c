@@ -1149,3 +1149,116 @@ int orc_betweenness(uint32_t n, const uint64_t *off, const uint32_t *tgt, const 
     free(in_off); free(in_src); free(in_w); free(cur); free(dist); free(parent); free(bp_off); free(bp); free(seg); free(chain);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * LabelPropagation (fixed_rule/algos/label_propagation.rs:56-109)
+ * ---------------------------------------------------------------------------------------- */
+static uint32_t lp_total_key(float f) { /* f32::total_cmp as an unsigned compare */
+    uint32_t b;
+    memcpy(&b, &f, 4);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+int orc_label_propagation_in_order(uint32_t n, const uint64_t *off, const uint32_t *tgt, const float *w, const uint32_t *order,
+                                   uint32_t max_iter, uint32_t *labels) {
+    /* :61 labels = 0..n; the BTreeMap<u32, f32> of :69 as a dense score array + the list of labels it holds */
+    float *score = (float *)calloc(n ? n : 1, sizeof(float));
+    uint8_t *present = (uint8_t *)calloc(n ? n : 1, 1);
+    uint32_t *seen = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    for (uint32_t i = 0; i < n; i++) labels[i] = i;
+    int iters = 0, rc = 0;
+    for (uint32_t it = 0; it < max_iter && rc == 0; it++) {
+        int changed = 0;
+        iters++;
+        for (uint32_t oi = 0; oi < n; oi++) {
+            const uint32_t node = order[oi];
+            uint32_t ns = 0;
+            for (uint64_t e = off[node]; e < off[node + 1]; e++) { /* :70-73, adjacency order, f32 adds starting from 0.0 */
+                const uint32_t l = labels[tgt[e]];
+                if (!present[l]) {
+                    present[l] = 1;
+                    score[l] = 0.0f;
+                    seen[ns++] = l;
+                }
+                score[l] += w[e];
+            }
+            if (ns == 0) continue; /* :74-76 */
+            /* :77-84: the largest score under total_cmp; candidates = the labels whose score == it */
+            uint32_t best = 0;
+            for (uint32_t k = 1; k < ns; k++)
+                if (lp_total_key(score[seen[k]]) > lp_total_key(score[seen[best]])) best = k;
+            const float max_score = score[seen[best]];
+            uint32_t new_label = ORC_NONE;
+            for (uint32_t k = 0; k < ns; k++)
+                if (score[seen[k]] == max_score && seen[k] < new_label) new_label = seen[k]; /* `choose`: here the smallest */
+            for (uint32_t k = 0; k < ns; k++) present[seen[k]] = 0;
+            if (new_label == ORC_NONE) { /* max_score is NaN: nothing equals it, `choose` on an empty list -> the reference panics */
+                rc = -1;
+                break;
+            }
+            if (new_label != labels[node]) { /* :86-89 */
+                changed = 1;
+                labels[node] = new_label;
+            }
+        }
+        if (!changed) break; /* :92-94 */
+    }
+    free(score);
+    free(present);
+    free(seen);
+    return rc ? rc : iters;
+}
+
+static uint64_t lp_priority(uint32_t v) {
+    uint32_t x = v;
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return ((uint64_t)x << 32) | v;
+}
+
+uint32_t orc_lp_colouring(uint32_t n, const uint64_t *off, const uint32_t *tgt, uint32_t *colour) {
+    const uint64_t E = n ? off[n] : 0;
+    /* the transposed adjacency: independence is about edges in either direction */
+    uint64_t *in_off = (uint64_t *)calloc((size_t)n + 2, sizeof(uint64_t));
+    uint32_t *in_src = (uint32_t *)malloc(sizeof(uint32_t) * (E ? E : 1));
+    for (uint64_t e = 0; e < E; e++) in_off[tgt[e] + 1]++;
+    for (uint32_t v = 0; v < n; v++) in_off[v + 1] += in_off[v];
+    uint64_t *cur = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)n + 1));
+    memcpy(cur, in_off, sizeof(uint64_t) * ((size_t)n + 1));
+    for (uint32_t u = 0; u < n; u++)
+        for (uint64_t e = off[u]; e < off[u + 1]; e++) in_src[cur[tgt[e]]++] = u;
+    for (uint32_t v = 0; v < n; v++) colour[v] = ORC_NONE;
+    uint32_t left = n, round = 0;
+    uint8_t *take = (uint8_t *)malloc(n ? n : 1);
+    while (left > 0) {
+        for (uint32_t v = 0; v < n; v++) {
+            take[v] = 0;
+            if (colour[v] != ORC_NONE) continue;
+            const uint64_t kv = lp_priority(v);
+            int is_max = 1;
+            for (uint64_t e = off[v]; e < off[v + 1] && is_max; e++) {
+                const uint32_t u = tgt[e];
+                if (u != v && colour[u] == ORC_NONE && lp_priority(u) > kv) is_max = 0;
+            }
+            for (uint64_t e = in_off[v]; e < in_off[v + 1] && is_max; e++) {
+                const uint32_t u = in_src[e];
+                if (u != v && colour[u] == ORC_NONE && lp_priority(u) > kv) is_max = 0;
+            }
+            take[v] = (uint8_t)is_max;
+        }
+        for (uint32_t v = 0; v < n; v++)
+            if (take[v]) {
+                colour[v] = round;
+                left--;
+            }
+        round++;
+    }
+    free(in_off);
+    free(in_src);
+    free(cur);
+    free(take);
+    return round;
+}

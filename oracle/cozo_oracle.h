@@ -127,6 +127,18 @@ void orc_dijkstra(uint32_t n, const uint64_t *off, const uint32_t *tgt, const fl
 /* literal path enumeration (small graphs); out[n] f32 as the reference accumulates it; -1 when a start has > max_paths paths */
 int orc_betweenness(uint32_t n, const uint64_t *off, const uint32_t *tgt, const float *w, float *out, uint64_t max_paths);
 
+/* ---- LabelPropagation (algos/label_propagation.rs:56-109) ---- */
+/* The reference shuffles the node order every iteration and breaks score ties with thread_rng (:63-66, :90): no two runs agree.
+ * orc_label_propagation_in_order is its loop with both choices handed in: the SAME node order in every iteration and the SMALLEST
+ * label among the best-scored ones -- one of the executions the reference can produce.  labels[n] out, returns iterations run
+ * (the one that changed nothing included), -1 when a best score is NaN (the reference panics there: `choose` on an empty list). */
+int orc_label_propagation_in_order(uint32_t n, const uint64_t *off, const uint32_t *tgt, const float *w, const uint32_t *order,
+                                   uint32_t max_iter, uint32_t *labels);
+/* the order the GPU rule fixes: colour classes of a deterministic colouring of the graph (both edge directions):
+ * in round r every still uncoloured node whose key (hash(id) << 32 | id) is the largest among its uncoloured neighbours takes colour r.
+ * colour[n] out, returns the number of colours */
+uint32_t orc_lp_colouring(uint32_t n, const uint64_t *off, const uint32_t *tgt, uint32_t *colour);
+
 #ifdef __cplusplus
 }
 #endif

@@ -369,3 +369,35 @@ def betweenness(n, off, tgt, w, max_paths=10_000_000):
     if rc != 0:
         raise RuntimeError("too many shortest paths to enumerate")
     return out
+
+
+def lp_colouring(n, off, tgt):
+    """the colour classes the GPU LabelPropagation rule processes in order (orc_lp_colouring) -> (colour u32 [n], n_colours)"""
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    tgt = _u32(tgt)
+    colour = np.empty(n, dtype=np.uint32)
+    fn = lib().orc_lp_colouring
+    fn.restype = C.c_uint32
+    k = fn(n, _p(off, _u64p), _p(tgt, _u32p), _p(colour, _u32p))
+    return colour, int(k)
+
+
+def label_propagation_in_order(n, off, tgt, w, order, max_iter=10):
+    """label_propagation.rs:56-109 with the node order of every iteration and the tie-break (smallest label) handed in
+    -> (labels u32 [n], iterations)"""
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    tgt, w, order = _u32(tgt), _f32(w), _u32(order)
+    labels = np.empty(n, dtype=np.uint32)
+    fn = lib().orc_label_propagation_in_order
+    fn.restype = C.c_int
+    it = fn(n, _p(off, _u64p), _p(tgt, _u32p), _p(w, _f32p), _p(order, _u32p), C.c_uint32(max_iter), _p(labels, _u32p))
+    if it < 0:
+        raise RuntimeError("a best score is NaN (the reference panics)")
+    return labels, int(it)
+
+
+def label_propagation(n, off, tgt, w, max_iter=10):
+    """the execution the GPU rule fixes: colour classes in ascending order, ids ascending inside a class"""
+    colour, _ = lp_colouring(n, off, tgt)
+    order = np.lexsort((np.arange(n), colour)).astype(np.uint32)
+    return label_propagation_in_order(n, off, tgt, w, order, max_iter)

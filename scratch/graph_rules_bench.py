@@ -48,6 +48,10 @@ def main():
     print(f"    reached {int(np.isfinite(dist[0]).sum())} nodes, max cost {float(dist[0][np.isfinite(dist[0])].max()):.3f}")
     tri, deg = timed("cz_clustering_coefficients", lambda: G.clustering_coefficients(uoff, utgt), utgt.size)
     print(f"    {int(tri.sum())} (node, triangle) incidences, max degree {int(deg.max())}")
+    if os.environ.get("WITH_LP"):
+        ones = np.ones(utgt.size, dtype=np.float32)
+        lab, it, k = timed("cz_label_propagation (<= 10 iter)", lambda: G.label_propagation(uoff, utgt, ones, 10), utgt.size * 10)
+        print(f"    {it} iterations over {k} colour classes, {len(np.unique(lab))} labels left")
 def all_sources():
     """the device part of ClosenessCentrality / BetweennessCentrality: cz_sssp from EVERY node, 256 starts per call"""
     n, e = int(os.environ.get("AN", 20_000)), int(os.environ.get("AE", 200_000))

@@ -113,3 +113,25 @@ int cz_betweenness(const uint32_t *out_offsets, const uint32_t *out_targets, con
     if (rc) { g_err = "oracle: too many shortest paths"; return CZ_E_UNSUPPORTED; }
     return CZ_OK;
 }
+
+int cz_label_propagation(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
+                         uint32_t max_iter, uint32_t *labels, uint32_t *iters_run, uint32_t *n_colours, const volatile uint8_t *poison) {
+    (void)E;
+    if (poisoned(poison)) { g_err = "cancelled"; return CZ_E_CANCELLED; }
+    uint64_t *off = widen(out_offsets, N);
+    uint32_t *colour = (uint32_t *)malloc(sizeof(uint32_t) * (N ? N : 1));
+    uint32_t *order = (uint32_t *)malloc(sizeof(uint32_t) * (N ? N : 1));
+    const uint32_t k = orc_lp_colouring(N, off, out_targets, colour);
+    uint32_t at = 0;
+    for (uint32_t c = 0; c < k; c++)
+        for (uint32_t v = 0; v < N; v++)
+            if (colour[v] == c) order[at++] = v;
+    const int it = orc_label_propagation_in_order(N, off, out_targets, weights, order, max_iter, labels);
+    free(colour);
+    free(order);
+    free(off);
+    if (it < 0) { g_err = "a best score is NaN"; return CZ_E_INVALID; }
+    if (iters_run) *iters_run = (uint32_t)it;
+    if (n_colours) *n_colours = k;
+    return CZ_OK;
+}

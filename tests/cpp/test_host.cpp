@@ -15,6 +15,7 @@
 #include <map>
 #include <random>
 #include <string>
+#include <set>
 #include <vector>
 
 #include "cozo_gpu.h"
@@ -727,6 +728,45 @@ static void gpu_betweenness_centrality() {
     }, "algo::betweenness_needs_positive_weights")));
 }
 
+static void gpu_label_propagation() {
+    // label_propagation.rs:56-109 in the fixed order (colour classes ascending) with the smallest label on ties: the oracle's loop
+    FixedRuleRegistry reg = FixedRuleRegistry::with_gpu_defaults();
+    std::mt19937_64 rng(77);
+    std::vector<Tuple> rows;
+    for (int c = 0; c < 4; c++)
+        for (int i = 0; i < 120; i++) {
+            const int64_t a = c * 25 + (int64_t)(rng() % 25), b = c * 25 + (int64_t)(rng() % 25);
+            rows.push_back(T({DataValue(a), DataValue(b), DataValue((double)(1 + rng() % 8) / 4.0)}));
+        }
+    for (int i = 0; i < 10; i++) rows.push_back(T({DataValue((int64_t)(rng() % 100)), DataValue((int64_t)(rng() % 100)), DataValue(0.25)}));
+    for (bool undirected : {false, true}) {
+        FixedRuleInputRelation rel(rows);
+        RegularTempStore out = reg.run("LabelPropagation",
+                                       FixedRulePayload("LabelPropagation", {rel}, {{"undirected", DataValue(undirected)}, {"max_iter", DataValue((int64_t)10)}}),
+                                       Poison());
+        GraphWithIndices g = rel.as_directed_weighted_graph(undirected, true);
+        const uint32_t n = g.graph.n;
+        std::vector<uint64_t> off = to_u64(g.graph.out_offsets);
+        std::vector<uint32_t> colour(n), order, want(n);
+        const uint32_t k = orc_lp_colouring(n, off.data(), g.graph.out_targets.data(), colour.data());
+        for (uint32_t c = 0; c < k; c++)
+            for (uint32_t v = 0; v < n; v++)
+                if (colour[v] == c) order.push_back(v);
+        CHECK(orc_label_propagation_in_order(n, off.data(), g.graph.out_targets.data(), g.graph.out_weights.data(), order.data(), 10, want.data()) > 0);
+        bool ok = out.size() == n;
+        std::set<int64_t> distinct;
+        for (const Tuple &t : out) {
+            int64_t lab = -1;
+            ok = ok && t[0].get_int(&lab) && lab == (int64_t)want[g.inv_indices.at(t[1])];
+            distinct.insert(lab);
+        }
+        CHECK(ok && distinct.size() < n / 4);
+    }
+    CHECK((throws<CozoError>([&] {
+        reg.run("LabelPropagation", FixedRulePayload("LabelPropagation", {FixedRuleInputRelation(rows)}, {{"max_iter", DataValue((int64_t)0)}}), Poison());
+    })));
+}
+
 static void gpu_dijkstra_keep_ties() {
     // ShortestPathDijkstra{keep_ties: true} (shortest_path_dijkstra.rs:341-450): every shortest path is a row.  Checked by
     // properties that do not share the implementation's route: every row's path is a real path whose f32 cost, added left to
@@ -1063,6 +1103,7 @@ int main(int argc, char **argv) {
         gpu_clustering_coefficients();
         gpu_closeness_centrality();
         gpu_betweenness_centrality();
+        gpu_label_propagation();
         gpu_dijkstra_keep_ties();
         gpu_rules_on_stored_relation();
     }
@@ -1084,6 +1125,7 @@ int main(int argc, char **argv) {
             return 2;
         }
         gpu_betweenness_centrality();
+        gpu_label_propagation();
         gpu_dijkstra_keep_ties();
         gpu_rules_on_stored_relation();
         gpu_index_through_the_store();

@@ -596,3 +596,98 @@ def test_custom_rule_plumbing_like_the_reference():
     with pytest.raises(FR.FixedRuleNameConflict):
         reg.unregister_fixed_rule("PageRank")  # :780-782
     assert reg.unregister_fixed_rule("SumCols") and not reg.unregister_fixed_rule("SumCols")
+
+
+def ref_label_propagation_in_python(edge_rows, undirected, max_iter, colour_of):
+    """label_propagation.rs:56-109 word for word in Python (BTreeMap -> dict kept in insertion order of ascending... no: a dict
+    keyed by label, summed in adjacency order), with the node order (colour classes ascending, ids ascending inside) and the
+    tie-break (smallest label) the GPU rule fixes"""
+    rows = sorted({FR._canon(tuple(r)): tuple(r) for r in edge_rows}.values(), key=FR._tuple_key)  # a relation is a sorted set
+    ids, vals = {}, []
+    for r in rows:
+        for v in (r[0], r[1]):
+            if v not in ids:
+                ids[v] = len(vals)
+                vals.append(v)
+    triples = []
+    for r in rows:
+        w = np.float32(r[2]) if len(r) > 2 else np.float32(1.0)
+        triples.append((ids[r[0]], ids[r[1]], w))
+        if undirected:
+            triples.append((ids[r[1]], ids[r[0]], w))
+    triples.sort(key=lambda t: (t[0], t[1]))  # CsrLayout::Sorted: by target inside a node, stable for parallel edges
+    n = len(vals)
+    adj = [[] for _ in range(n)]
+    for a, b, w in triples:
+        adj[a].append((b, w))
+    colour = colour_of(n, adj)
+    order = sorted(range(n), key=lambda v: (colour[v], v))
+    labels = list(range(n))
+    for _ in range(max_iter):
+        changed = False
+        for node in order:
+            scores = {}
+            for t, w in adj[node]:
+                lab = labels[t]
+                scores[lab] = np.float32(scores.get(lab, np.float32(0.0)) + w)
+            if not scores:
+                continue
+            best = max(scores.values())
+            new = min(lab for lab, sc in scores.items() if sc == best)
+            if new != labels[node]:
+                changed, labels[node] = True, new
+        if not changed:
+            break
+    return sorted(((labels[i], vals[i]) for i in range(n)), key=lambda r: (r[0], r[1]))
+
+
+def _python_colouring(n, adj):
+    def key(v):
+        x = v
+        x ^= x >> 16
+        x = (x * 0x85EBCA6B) & 0xFFFFFFFF
+        x ^= x >> 13
+        x = (x * 0xC2B2AE35) & 0xFFFFFFFF
+        x ^= x >> 16
+        return (x << 32) | v
+    nb = [set() for _ in range(n)]
+    for a in range(n):
+        for b, _ in adj[a]:
+            if a != b:
+                nb[a].add(b)
+                nb[b].add(a)
+    colour, r = [None] * n, 0
+    while any(c is None for c in colour):
+        take = [v for v in range(n) if colour[v] is None and all(colour[u] is not None or key(u) < key(v) for u in nb[v])]
+        for v in take:
+            colour[v] = r
+        r += 1
+    return colour
+
+
+@pytest.mark.parametrize("undirected", [False, True])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_label_propagation_rule(registry, undirected, weighted):
+    """LabelPropagationGpu == the reference's loop run with the fixed node order and tie-break (a Python restatement of
+    label_propagation.rs:56-109 and of the colouring; the oracle's C restatement is checked against the same in
+    tests/test_oracle.py).  Three planted communities with a few cross edges; weights in quarter steps make score ties."""
+    rng = np.random.default_rng(11 + undirected + 2 * weighted)
+    edges = []
+    for c in range(3):
+        members = list(range(c * 12, c * 12 + 12))
+        for _ in range(40):
+            a, b = rng.choice(members, 2, replace=False)
+            edges.append((int(a), int(b)))
+    for _ in range(6):
+        edges.append((int(rng.integers(0, 36)), int(rng.integers(0, 36))))
+    rows = [(f"n{a}", f"n{b}", float(rng.integers(1, 9)) / 4) if weighted else (f"n{a}", f"n{b}") for a, b in edges]
+    got = registry.run("LabelPropagationGpu", [rel(rows)], {"undirected": undirected, "max_iter": 10})
+    want = ref_label_propagation_in_python(rows, undirected, 10, _python_colouring)
+    assert got == want
+    assert len({r[0] for r in got}) < len(got) / 3  # labels did spread: far fewer labels than nodes
+    assert registry.run("LabelPropagationGpu", [rel([])]) == []
+    # max_iter is honoured: one iteration changes less than ten
+    one = registry.run("LabelPropagationGpu", [rel(rows)], {"undirected": undirected, "max_iter": 1})
+    assert one == ref_label_propagation_in_python(rows, undirected, 1, _python_colouring)
+    with pytest.raises(Exception):
+        registry.run("LabelPropagationGpu", [rel(rows)], {"max_iter": 0})

@@ -467,3 +467,71 @@ def test_betweenness_refusals(gpu_lib):
     flag = np.ones(1, dtype=np.uint8)
     with pytest.raises(_lib.ProcessKilled):
         G.betweenness(off, tgt, np.array([1.0, 2.0], np.float32), poison=flag)
+
+
+def _weighted_csr(n, frm, to, w):
+    order = np.lexsort((to, frm))
+    off = np.zeros(n + 1, dtype=np.uint32)
+    off[1:] = np.cumsum(np.bincount(frm, minlength=n))
+    return off, to[order].astype(np.uint32), w[order].astype(np.float32)
+
+
+@pytest.mark.parametrize("case", ["communities", "weighted_ties", "hubs", "negative_and_loops"])
+def test_label_propagation_matches_the_fixed_order_execution(oracle, gpu_lib, case):
+    """cz_label_propagation == label_propagation.rs:56-109 run with the node order and tie-break the rule fixes (the oracle's
+    literal loop, itself checked word for word against a Python restatement in tests/test_fixed_rule.py): labels, the number of
+    iterations and the colouring, bit for bit."""
+    from cozo_amd import graph as G
+    rng = np.random.default_rng({"communities": 1, "weighted_ties": 2, "hubs": 3, "negative_and_loops": 4}[case])
+    if case == "communities":  # 40 planted groups of 250, sparse cross edges, unit weights, symmetric
+        n = 10_000
+        a = rng.integers(0, n, 60_000)
+        b = (a // 250) * 250 + rng.integers(0, 250, a.size)
+        x = rng.integers(0, n, 3_000)
+        y = rng.integers(0, n, 3_000)
+        frm, to = np.concatenate([a, b, x, y]), np.concatenate([b, a, y, x])
+        w = np.ones(frm.size, dtype=np.float32)
+    elif case == "weighted_ties":  # directed, weights in eighths (ties between labels), parallel edges
+        n = 5_000
+        frm, to = rng.integers(0, n, 40_000), rng.integers(0, n, 40_000)
+        w = (rng.integers(1, 17, frm.size) / 8).astype(np.float32)
+    elif case == "hubs":  # a few nodes with thousands of out-edges (the global-table path), non-dyadic weights (f32 order matters)
+        n = 20_000
+        hubs = rng.integers(0, 8, 30_000)
+        frm = np.concatenate([hubs, rng.integers(0, n, 60_000)])
+        to = np.concatenate([rng.integers(0, n, 30_000), rng.integers(0, n, 60_000)])
+        w = rng.random(frm.size).astype(np.float32) + np.float32(0.1)
+    else:  # negative weights are legal for this rule (allow_negative_weights = true), self loops, isolated targets
+        n = 3_000
+        frm, to = rng.integers(0, n // 2, 20_000), rng.integers(0, n, 20_000)
+        frm[::50] = to[::50] % (n // 2)
+        to[::50] = frm[::50]
+        w = (rng.integers(-8, 9, frm.size) / 4).astype(np.float32)
+    off, tgt, ww = _weighted_csr(n, frm, to, w)
+    labels, iters, n_col = G.label_propagation(off, tgt, ww, max_iter=10)
+    want_col, want_k = oracle.lp_colouring(n, off, tgt)
+    want, want_it = oracle.label_propagation(n, off, tgt, ww, 10)
+    assert n_col == want_k and iters == want_it
+    assert np.array_equal(labels, want)
+    if case == "communities":
+        assert len(np.unique(labels)) < n / 20
+    # a second run returns the same labels (nothing about the schedule leaks into the result)
+    again, _, _ = G.label_propagation(off, tgt, ww, max_iter=10)
+    assert np.array_equal(again, labels)
+    one, it1, _ = G.label_propagation(off, tgt, ww, max_iter=1)
+    assert it1 == 1 and np.array_equal(one, oracle.label_propagation(n, off, tgt, ww, 1)[0])
+
+
+def test_label_propagation_edges(gpu_lib):
+    from cozo_amd import _lib, graph as G
+    labels, it, k = G.label_propagation(np.array([0], np.uint32), np.array([], np.uint32), np.array([], np.float32))
+    assert labels.size == 0 and it == 0 and k == 0
+    # no edges: every node keeps its own label, the first iteration changes nothing
+    labels, it, k = G.label_propagation(np.zeros(6, np.uint32), np.array([], np.uint32), np.array([], np.float32))
+    assert list(labels) == [0, 1, 2, 3, 4] and it == 1 and k == 1
+    # +inf and -inf into the same label: the best score is NaN, the reference panics
+    with pytest.raises(_lib.CozoGpuError):
+        G.label_propagation(np.array([0, 2, 2, 2], np.uint32), np.array([1, 1], np.uint32), np.array([np.inf, -np.inf], np.float32))
+    flag = np.ones(1, dtype=np.uint8)
+    with pytest.raises(_lib.ProcessKilled):
+        G.label_propagation(np.array([0, 1, 2], np.uint32), np.array([1, 0], np.uint32), np.ones(2, np.float32), poison=flag)
