@@ -788,6 +788,16 @@ def bench_graph_rules(args, torch, device):
     (dist, _), dt = timed(lambda: G.sssp(ooff, otgt, w, starts))
     fin = np.isfinite(dist[0])
     out["sssp"] = entry(dt, E, 8 * E + 4 * (n + 1) + 12 * n, reached=int(fin.sum()), max_cost=float(dist[0][fin].max()))
+    (tri, deg), dt = timed(lambda: G.clustering_coefficients(uoff, utgt))
+    out["clustering_coefficients"] = entry(dt, int(utgt.size), 4 * int(utgt.size) + 4 * (n + 1) + 12 * n,
+                                           triangle_incidences=int(tri.sum()), max_degree=int(deg.max()))
+    ones = np.ones(utgt.size, dtype=np.float32)
+    (lab, lp_it, lp_col), dt = timed(lambda: G.label_propagation(uoff, utgt, ones, 10))
+    out["label_propagation"] = entry(dt, int(utgt.size) * lp_it, lp_it * (8 * int(utgt.size) + 4 * (n + 1) + 8 * n), iterations=lp_it,
+                                     colour_classes=lp_col, labels_left=int(np.unique(lab).size),
+                                     what="one fixed execution of the reference's randomised loop (include/cozo_gpu.h); device_ms "
+                                          "includes the colouring and the class lists")
+    del ones, lab, tri, deg
     # BetweennessCentrality: SSSP from EVERY node + path counts over the tight edges, all on the device (a 20k-node graph:
     # 4e8 (source, node) pairs; the reference enumerates paths, so there is no CPU figure at this size)
     nb, eb = 20_000, 200_000

@@ -535,3 +535,25 @@ def test_label_propagation_edges(gpu_lib):
     flag = np.ones(1, dtype=np.uint8)
     with pytest.raises(_lib.ProcessKilled):
         G.label_propagation(np.array([0, 1, 2], np.uint32), np.array([1, 0], np.uint32), np.ones(2, np.float32), poison=flag)
+
+
+def test_rules_on_graphs_without_edges_and_single_nodes(gpu_lib):
+    """every whole-graph entry point on the degenerate shapes: nodes without any edge, one node, one self loop"""
+    from cozo_amd import graph as G
+    none = 0xFFFFFFFF
+    for n, off, tgt in [(5, np.zeros(6, np.uint32), np.zeros(0, np.uint32)), (1, np.zeros(2, np.uint32), np.zeros(0, np.uint32)),
+                        (1, np.array([0, 1], np.uint32), np.array([0], np.uint32))]:
+        w = np.ones(tgt.size, dtype=np.float32)
+        par, dep, order, reached = G.bfs(off, tgt, np.array([0], np.uint32), want_depth=True, want_order=True)
+        assert reached[0] == 0 and dep[0, 0] == 0 and (par[0] == none).all() and (dep[0, 1:] == none).all()
+        grp, k = G.connected_components(off, tgt)
+        assert k == n and list(grp) == list(range(n))
+        dist, parent = G.sssp(off, tgt, w, np.arange(n, dtype=np.uint32))
+        assert (np.diag(dist) == 0).all() and np.isinf(dist[~np.eye(n, dtype=bool)]).all() and (parent == none).all()
+        tri, deg = G.clustering_coefficients(off, tgt)
+        assert (tri == 0).all() and list(deg) == list(np.diff(off))
+        assert (G.betweenness(off, tgt, w) == 0).all()
+        labels, it, k = G.label_propagation(off, tgt, w)
+        assert list(labels) == list(range(n)) and it == 1
+        up, dev_ms, down = G.last_timing()
+        assert up >= 0 and dev_ms >= 0 and down >= 0
