@@ -62,17 +62,20 @@ def kernel_source_hash(key):
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(key, world):
+def pmc_traffic(key, world, algorithmic_bytes):
     """HBM bytes per launch of the dominant kernel(s) from the committed rocprofv3 --pmc summary of this same workload
     (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied there).  PMC counters cannot be
     collected from inside the timed run.  None when no summary is committed, when the workload differs from the profiled
-    one (N > 1), or when the summary was taken on OTHER kernels than the ones in this tree (source hash mismatch)."""
+    one (N > 1, or other sizes: the launch's algorithmic bytes must be the profiled launch's within 2 %), or when the summary
+    was taken on OTHER kernels than the ones in this tree (source hash mismatch)."""
     if world != 1:
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             d = json.load(f)
         if d[key].get("source_hash") != kernel_source_hash(key):
+            return None
+        if abs(algorithmic_bytes - d[key]["algorithmic_bytes"]) > 0.02 * d[key]["algorithmic_bytes"]:
             return None
         return d[key]["bytes_per_launch"]
     except Exception:
@@ -304,7 +307,7 @@ def bench_hnsw(args, torch, dist, rank, world, device):
         rec = recall_at_k(torch, run.ids.to(torch.int64) & 0xFFFFFFFF, gt64)
     log(f"ef sweep {sweep} -> ef = {ef}, recall@{k} = {rec:.4f}")
     t = run.timed(ef, args.steps, args.warmup, dist, args.multi)
-    t["roofline"]["traffic"] = pmc_traffic("hnsw_knn", world)
+    t["roofline"]["traffic"] = pmc_traffic("hnsw_knn", world, t["roofline"]["algorithmic_bytes_per_launch"]) if args.dist == "lowrank" else None
     res = dict(qps=world * B * args.steps / t["wall"], ms_per_step=t["ms_per_step"], ef=ef, recall=rec,
                n_dist_per_query=t["n_dist"] / B, build_s=run.build_s, build_n_dist=run.build_nd, roofline=t["roofline"],
                index_bytes=run.ix.device_bytes, sweep=sweep, distance_batch=db)
@@ -406,7 +409,7 @@ def bench_distance_batch(args, torch, x, q, stream, device):
     return dict(kernel="cz_distance_batch = distance_pairs_kernel (one hand-written kernel; the whole call is timed)",
                 pairs=P, base_rows=int(x.shape[0]), metric="Cosine", ms=s * 1e3, distances_per_s=P / s,
                 roofline=dict(bound="hbm", achieved=algo / s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                              frac=algo / s / 1e9 / HBM_PEAK_GBS, traffic=pmc_traffic("distance_batch", 1),
+                              frac=algo / s / 1e9 / HBM_PEAK_GBS, traffic=pmc_traffic("distance_batch", 1, algo) if x.shape[0] == 10_000_000 else None,
                               algorithmic_bytes_per_launch=algo, avg_launch_ms=s * 1e3))
 
 
@@ -635,7 +638,7 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
                    plan_build_ms=build_ms,
                    roofline=dict(bound="hbm", kernel=kernel, achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
                                  unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
-                                 traffic=pmc_traffic("pagerank_blocked" if blocked else "pagerank_gather", world)
+                                 traffic=pmc_traffic("pagerank_blocked" if blocked else "pagerank_gather", world, algo_bytes)
                                  if kind == "uniform" and not relaxed else None,
                                  algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=kern_s * 1e3),
                    exchange="none" if not args.multi else f"cz_pagerank_sharded (C++ loop behind the C ABI, RCCL): in-place all-gather of {per * 4} "
