@@ -1081,8 +1081,87 @@ static void gpu_index_through_the_store() {
     CHECK(empty_read.node_count() == 0 && empty_ra.iter(parent, Poison()).empty());
 }
 
+// ---- `test_host run-rule <in> <out>`: one rule invocation handed over by tests/test_mirrors_agree.py -----------------------------
+// in : u32 magic, str rule, u32 n_options x (str name, blob memcmp-encoded DataValue), u32 n_inputs x (u32 n_rows x blob stored key)
+// out: u32 1 + u32 n_rows x blob (the row as a stored key of relation 0)   |   u32 0 + str diagnostic code
+// (str / blob = u32 length + bytes, little endian).  The Python mirror runs the same invocation; the rows must be the same bytes.
+static int run_rule_from_file(const char *in_path, const char *out_path, bool need_device) {
+    std::vector<uint8_t> buf;
+    {
+        FILE *f = std::fopen(in_path, "rb");
+        if (!f) return 3;
+        uint8_t tmp[65536];
+        size_t got;
+        while ((got = std::fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + got);
+        std::fclose(f);
+    }
+    size_t at = 0;
+    auto u32 = [&]() {
+        if (at + 4 > buf.size()) throw std::runtime_error("truncated");
+        uint32_t v;
+        std::memcpy(&v, buf.data() + at, 4);
+        at += 4;
+        return v;
+    };
+    auto blob = [&]() {
+        const uint32_t n = u32();
+        if (at + n > buf.size()) throw std::runtime_error("truncated");
+        std::vector<uint8_t> b(buf.begin() + at, buf.begin() + at + n);
+        at += n;
+        return b;
+    };
+    std::vector<uint8_t> out;
+    auto put_u32 = [&](uint32_t v) {
+        uint8_t b[4];
+        std::memcpy(b, &v, 4);
+        out.insert(out.end(), b, b + 4);
+    };
+    auto put_blob = [&](const std::vector<uint8_t> &b) {
+        put_u32((uint32_t)b.size());
+        out.insert(out.end(), b.begin(), b.end());
+    };
+    try {
+        if (u32() != 0x52525A43u) throw std::runtime_error("bad magic");
+        const std::vector<uint8_t> name_b = blob();
+        const std::string name(name_b.begin(), name_b.end());
+        std::map<std::string, DataValue> options;
+        for (uint32_t n = u32(); n > 0; n--) {
+            const std::vector<uint8_t> kb = blob(), vb = blob();
+            const uint8_t *p = vb.data();
+            options[std::string(kb.begin(), kb.end())] = decode_datavalue(p, vb.data() + vb.size());
+        }
+        std::vector<std::optional<FixedRuleInputRelation>> inputs;
+        for (uint32_t n = u32(); n > 0; n--) {
+            std::vector<Tuple> rows;
+            for (uint32_t r = u32(); r > 0; r--) rows.push_back(decode_tuple_from_key(blob()));
+            inputs.emplace_back(FixedRuleInputRelation(rows));
+        }
+        if (need_device && cz_init(0) != CZ_OK) throw std::runtime_error(cz_last_error());
+        FixedRuleRegistry reg = FixedRuleRegistry::with_gpu_defaults();
+        try {
+            RegularTempStore res = reg.run(name, FixedRulePayload(name, inputs, options), Poison());
+            put_u32(1);
+            put_u32((uint32_t)res.size());
+            for (const Tuple &t : res) put_blob(encode_key_for_store(0, t, t.size()));
+        } catch (const CozoError &e) {
+            out.clear();
+            put_u32(0);
+            put_blob(std::vector<uint8_t>(e.code.begin(), e.code.end()));
+        }
+    } catch (const std::exception &e) {
+        std::printf("run-rule: %s\n", e.what());
+        return 2;
+    }
+    FILE *f = std::fopen(out_path, "wb");
+    if (!f) return 3;
+    std::fwrite(out.data(), 1, out.size(), f);
+    std::fclose(f);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
+    if ((mode == "run-rule" || mode == "run-rule-gpu") && argc == 4) return run_rule_from_file(argv[2], argv[3], mode == "run-rule-gpu");
     test_value_order();
     test_options();
     test_as_directed_graph_vs_oracle();

@@ -1,0 +1,121 @@
+"""The two executable host mirrors of cozo-core's FixedRule surface -- Python (cozo_amd/fixed_rule.py) and C++
+(cozo_amd/host -> libcozo_host.so) -- run the SAME rule invocation and must return the SAME rows, byte for byte in the store's
+own key encoding (types included: an Int is not a Float).  The invocation travels as stored-key bytes (the codec both sides
+already share, tests/cpp/test_host.cpp `run-rule`).  On CPU both mirrors sit on the oracle (tests/util.OracleGraphBackend /
+tests/cpp/oracle_shim.c), marked gpu both call libcozo_gpu.so.  A drift in either mirror -- an option default, an id order, a
+rounding step, an error code -- fails here."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from cozo_amd import codec, fixed_rule as FR
+from tests import util
+from tests.test_cpp_host import build_test_host, build_test_host_shim
+
+MAGIC = 0x52525A43
+
+
+def _blob(b: bytes) -> bytes:
+    return struct.pack("<I", len(b)) + b
+
+
+def run_cpp(tmp_path, gpu, name, inputs, options):
+    exe = build_test_host() if gpu else build_test_host_shim()
+    buf = bytearray(struct.pack("<I", MAGIC)) + _blob(name.encode())
+    buf += struct.pack("<I", len(options))
+    for k, v in options.items():
+        buf += _blob(k.encode()) + _blob(codec.memcmp_bytes(v))
+    buf += struct.pack("<I", len(inputs))
+    for rows in inputs:
+        buf += struct.pack("<I", len(rows))
+        for r in rows:
+            buf += _blob(codec.encode_key_for_store(1, list(r)))
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    fin.write_bytes(bytes(buf))
+    if fout.exists():
+        fout.unlink()
+    p = subprocess.run([exe, "run-rule-gpu" if gpu else "run-rule", str(fin), str(fout)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    out = fout.read_bytes()
+    ok, = struct.unpack_from("<I", out, 0)
+    at = 4
+    if not ok:
+        n, = struct.unpack_from("<I", out, at)
+        return ("error", out[at + 4:at + 4 + n].decode())
+    n, = struct.unpack_from("<I", out, at)
+    at += 4
+    rows = []
+    for _ in range(n):
+        ln, = struct.unpack_from("<I", out, at)
+        rows.append(out[at + 4:at + 4 + ln])
+        at += 4 + ln
+    return ("rows", rows)
+
+
+def run_python(registry, name, inputs, options):
+    try:
+        rows = registry.run(name + "Gpu", [FR.FixedRuleInputRelation(list(r)) for r in inputs], dict(options))
+    except FR.FixedRuleError as e:
+        return ("error", e.code)
+    return ("rows", [codec.encode_key_for_store(0, list(r)) for r in rows])
+
+
+def _cases():
+    rng = np.random.default_rng(2024)
+    ew = [(f"n{int(a)}", f"n{int(b)}", float(rng.integers(1, 9)) / 2) for a, b in rng.integers(0, 40, (160, 2))]
+    e = [(a, b) for a, b, _ in ew]
+    ints = [(int(a), int(b)) for a, b in rng.integers(0, 60, (220, 2))]
+    mixed = [(1, 2.5), (2.5, "x"), ("x", 1), (1, 1), (3, 1)]  # ids of different DataValue types
+    starts, goals = [("n1",), ("n7",), ("nowhere",)], [("n3",), ("n9",), ("n1",)]
+    cases = [
+        ("PageRank", [e], {}),
+        ("PageRank", [ints], {"undirected": True, "theta": 0.7, "epsilon": 1e-6, "iterations": 20}),
+        ("PageRank", [mixed], {}),
+        ("PageRank", [[]], {}),
+        ("ConnectedComponents", [ints], {}),
+        ("ConnectedComponents", [e, [("lonely",), ("n3",)]], {}),
+        ("ShortestPathBFS", [e, starts, goals], {}),
+        ("ShortestPathDijkstra", [ew, starts, goals], {}),
+        ("ShortestPathDijkstra", [ew, starts], {"undirected": True}),
+        ("ShortestPathDijkstra", [ew, starts, goals], {"keep_ties": True}),
+        ("ClusteringCoefficients", [ints], {}),
+        ("DegreeCentrality", [e], {}),
+        ("ClosenessCentrality", [ew], {"undirected": True}),
+        ("BetweennessCentrality", [ew], {}),
+        ("BetweennessCentrality", [ew], {"undirected": True}),
+        ("LabelPropagation", [ew], {"undirected": True, "max_iter": 5}),
+        ("LabelPropagation", [ints], {}),
+        # diagnostics: the same code out of both mirrors
+        ("PageRank", [[("a",)]], {}),                                      # not an edge
+        ("ShortestPathDijkstra", [[("a", "b", -1.0)], [("a",)]], {}),      # negative weight
+        ("ShortestPathDijkstra", [[("a", "b", "w")], [("a",)]], {}),       # not a number
+        ("PageRank", [e], {"iterations": 0}),                              # a positive integer is required
+        ("PageRank", [e], {"theta": 1.5}),
+        ("LabelPropagation", [ew], {"max_iter": "ten"}),
+    ]
+    return [pytest.param(*c, id=f"{i:02d}-{c[0]}") for i, c in enumerate(cases)]
+
+
+@pytest.fixture(params=[pytest.param(False, id="host-logic"), pytest.param(True, marks=pytest.mark.gpu, id="gpu")])
+def on_gpu(request, monkeypatch, oracle):
+    if request.param:
+        request.getfixturevalue("gpu_lib")
+    else:
+        util.OracleGraphBackend(oracle).install(monkeypatch)
+    return request.param
+
+
+@pytest.mark.parametrize("name,inputs,options", _cases())
+def test_python_and_cpp_mirrors_return_the_same_rows(tmp_path, on_gpu, name, inputs, options):
+    want = run_python(FR.FixedRuleRegistry(), name, inputs, options)
+    got = run_cpp(tmp_path, on_gpu, name, inputs, options)
+    assert got[0] == want[0], (got[:1], want[:1], got[1] if got[0] == "error" else "", want[1] if want[0] == "error" else "")
+    if want[0] == "error":
+        assert got[1] == want[1]
+    else:
+        assert len(got[1]) == len(want[1])
+        for a, b in zip(got[1], want[1]):
+            assert a == b, (codec.decode_tuple_from_key(a), codec.decode_tuple_from_key(b))
