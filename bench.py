@@ -570,7 +570,17 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
     comm = None
     if args.multi:  # the exchange steps run behind the C ABI: RCCL communicator of libcozo_gpu, id carried by the process group
         from cozo_amd.comm import Comm
-        comm = Comm.from_torch_distributed()
+        try:
+            comm = Comm.from_torch_distributed()
+        except Exception as e:  # noqa: BLE001
+            log(f"libcozo_gpu's communicator could not be created on rank {rank}: {type(e).__name__}: {e}")
+        ok = torch.tensor([0 if comm is None else 1], device=device, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:  # every rank takes the same path: the round-1 loop over torch.distributed (RCCL through PyTorch)
+            if comm is not None:
+                comm.close()
+                comm = None
+            log("falling back to the exchange over torch.distributed (cozo_amd.distributed.ShardedPageRank)")
 
     class Loop:
         """graph::page_rank's loop: N = 1 the plan driven from here; N > 1 cz_pagerank_sharded (C++ loop + RCCL)"""
@@ -578,7 +588,7 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
         def __init__(self, plan, allreduce=False):
             self.plan, self.allreduce = plan, allreduce
             self.sp = ShardedPageRank(n_total, rank, world, device, lambda c: plan.init(c, stream),
-                                      lambda cin, cout, err: plan.step(cin, cout, err, stream)) if not args.multi else None
+                                      lambda cin, cout, err: plan.step(cin, cout, err, stream)) if comm is None else None
 
         def run(self, tol, iters):
             if self.sp is not None:
@@ -641,9 +651,12 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
                                  traffic=pmc_traffic("pagerank_blocked" if blocked else "pagerank_gather", world, algo_bytes)
                                  if kind == "uniform" and not relaxed else None,
                                  algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=kern_s * 1e3),
-                   exchange="none" if not args.multi else f"cz_pagerank_sharded (C++ loop behind the C ABI, RCCL): in-place all-gather of {per * 4} "
-                                                      f"B per rank per iteration + all-reduce of 2 f64")
-        if args.multi and not relaxed:
+                   exchange="none" if not args.multi else
+                   (f"cz_pagerank_sharded (C++ loop behind the C ABI, RCCL): in-place all-gather of {per * 4} B per rank per iteration + "
+                    f"all-reduce of 2 f64" if comm is not None else
+                    f"cozo_amd.distributed.ShardedPageRank over torch.distributed (fallback: libcozo_gpu's communicator failed): "
+                    f"all-gather of {per * 4} B per rank per iteration + all-reduce of 2 f64"))
+        if args.multi and not relaxed and comm is not None:
             try:  # labelled comparisons: north_star's literal all-reduce of the rank vector; the split-and-overlap form
                 it2, wall2 = timed_run(Loop(plan, allreduce=True))
                 res["exchange_all_reduce"] = dict(ms_per_iteration=wall2 / it2 * 1e3, edges_per_s=e_total * it2 / wall2,
