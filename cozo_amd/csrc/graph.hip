@@ -138,7 +138,7 @@ int exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, uint32_t *
 // graph).  The three passes keep the reference's FIFO order: claim (atomicMin of the frontier position per target),
 // count, emit in (frontier position, adjacency position) order; duplicates of a target are adjacent in the sorted list
 // and only the first one counts.  Group-wide counts / offsets come from wave ballots.
-// Two optional helpers cut the random traffic (one GPU; the vertex-partitioned form passes null and keeps the plain reads):
+// Two helpers cut the random traffic (null = the plain reads):
 //   vis   one bit per node, set when the node is discovered: 1.25 MB for 10M nodes, i.e. L2-resident, where depth[] is a
 //         40 MB array served by the Infinity Cache -- on the dense levels most targets are already visited and never get past it;
 //   won   one byte per edge slot, written by the count pass (did this slot win its target?) and read back coalesced by the
@@ -359,14 +359,17 @@ __global__ void __launch_bounds__(kT) fill_u64_kernel(unsigned long long *__rest
 
 constexpr int kSsspLanes = 16;
 
-// one queue: entries (source index << 32 | node), a device counter
-struct SsspQueue {
-    unsigned long long *items;
+// one queue: entries (source index << 32 | node) -- or plain node ids --, a device counter
+template <class T>
+struct QueueT {
+    T *items;
     uint32_t *count;
 };
+using SsspQueue = QueueT<unsigned long long>;
 
 // wave-aggregated push: one atomicAdd per wave instruction and queue
-__device__ __forceinline__ void sssp_push(const SsspQueue &q, bool want, unsigned long long item, int lane) {
+template <class T>
+__device__ __forceinline__ void sssp_push(const QueueT<T> &q, bool want, T item, int lane) {
     const unsigned long long m = __ballot(want);
     if (!m) return;
     uint32_t base = 0;
@@ -383,12 +386,15 @@ __device__ __forceinline__ void sssp_push(const SsspQueue &q, bool want, unsigne
 // coalesced copy.  Entries that do not fit the buffer (a hub's list) take the wave-level path above.
 constexpr uint32_t kStageCap = 1024;
 
-struct StagedPile {
-    unsigned long long buf[kStageCap];
+template <class T>
+struct StagedPileT {
+    T buf[kStageCap];
     uint32_t count, base;
 };
+using StagedPile = StagedPileT<unsigned long long>;
 
-__device__ __forceinline__ void staged_push(const SsspQueue &q, StagedPile &st, bool want, unsigned long long item, int lane) {
+template <class T>
+__device__ __forceinline__ void staged_push(const QueueT<T> &q, StagedPileT<T> &st, bool want, T item, int lane) {
     const unsigned long long m = __ballot(want);
     if (!m) return;
     uint32_t base = 0;
@@ -401,7 +407,8 @@ __device__ __forceinline__ void staged_push(const SsspQueue &q, StagedPile &st, 
 }
 
 // every thread of the workgroup, in uniform control flow
-__device__ __forceinline__ void staged_flush(const SsspQueue &q, StagedPile &st) {
+template <class T>
+__device__ __forceinline__ void staged_flush(const QueueT<T> &q, StagedPileT<T> &st) {
     __syncthreads();
     const uint32_t n = min(st.count, kStageCap);
     if (threadIdx.x == 0 && n) st.base = atomicAdd(q.count, n);
@@ -1619,11 +1626,12 @@ namespace {
 
 __global__ void __launch_bounds__(kT)
 bfs_commit_kernel(const uint32_t *__restrict__ buf, uint32_t total, uint32_t *__restrict__ order_at, uint32_t *__restrict__ depth,
-                  uint32_t next_depth) {
+                  uint32_t *__restrict__ vis, uint32_t next_depth) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
         const uint32_t v = buf[j] - 1u;  // written as id + 1 by exactly one rank, 0 by the others: the sum is id + 1
         order_at[j] = v;
         depth[v] = next_depth;
+        atomicOr(&vis[v >> 5], 1u << (v & 31));  // (the rank that emitted v has set the bit already)
     }
 }
 
@@ -1633,10 +1641,16 @@ struct HipShardedBfs {
     uint32_t N, rb, re;
     const uint32_t *goals_host;
     uint32_t n_goals;
-    cz::DevBuf<uint32_t> off, tgt, depth, parent, claim, order, cnt, pos, scratch, buf, misc, goals;
+    cz::DevBuf<uint32_t> off, tgt, depth, parent, claim, order, cnt, pos, scratch, buf, misc, goals, vis;
+    cz::DevBuf<uint8_t> won;
+    size_t vis_words = 0;
 
     int alloc(const uint32_t *h_off, const uint32_t *h_tgt, uint64_t e_local) {
         const uint32_t rows = re - rb;
+        vis_words = ((size_t)N + 31) / 32;
+        CZ_HIP(vis.alloc(vis_words));  // the visited bits and the won bytes of the one-GPU rule (section BFS above)
+        CZ_HIP(won.alloc(e_local));
+        CZ_HIP(hipMemsetAsync(vis.p, 0, vis_words * 4, s));
         CZ_HIP(off.alloc((size_t)rows + 1));
         CZ_HIP(tgt.alloc(e_local));
         CZ_HIP(depth.alloc(N));
@@ -1674,6 +1688,7 @@ struct HipShardedBfs {
         if (!keep_visited) {
             CZ_HIP(hipMemsetAsync(depth.p, 0xFF, (size_t)N * 4, s));
             CZ_HIP(hipMemsetAsync(claim.p, 0xFF, (size_t)N * 4, s));
+            CZ_HIP(hipMemsetAsync(vis.p, 0, vis_words * 4, s));
         }
         return CZ_OK;
     }
@@ -1684,19 +1699,20 @@ struct HipShardedBfs {
         *already = d != CZ_NONE;
         if (*already) return CZ_OK;
         hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, s, depth.p, start, 0u);
+        hipLaunchKernelGGL(or_u32_kernel, dim3(1), dim3(1), 0, s, vis.p, start >> 5, 1u << (start & 31));
         hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, s, order.p, 0u, start);
         return CZ_OK;
     }
     int bfs_claim(uint32_t lo, uint32_t fsize) {
         hipLaunchKernelGGL(bfs_claim_kernel, dim3(grid_for((uint64_t)fsize * kBfsLanes)), dim3(kT), 0, s, off.p, tgt.p, order.p + lo,
-                           fsize, depth.p, (const uint32_t *)nullptr, claim.p, rb, re);
+                           fsize, depth.p, (const uint32_t *)vis.p, claim.p, rb, re);
         return CZ_OK;
     }
     int reduce_claim() { return cz::comm_all_reduce(comm, claim.p, N, cz::COMM_U32, cz::COMM_MIN, s); }
     int bfs_count(uint32_t lo, uint32_t fsize) {
         CZ_HIP(hipMemsetAsync(cnt.p, 0, (size_t)fsize * 4, s));
         hipLaunchKernelGGL(bfs_count_kernel, dim3(grid_for((uint64_t)fsize * kBfsLanes)), dim3(kT), 0, s, off.p, tgt.p, order.p + lo,
-                           fsize, depth.p, (const uint32_t *)nullptr, claim.p, cnt.p, (uint8_t *)nullptr, rb, re);
+                           fsize, depth.p, (const uint32_t *)vis.p, claim.p, cnt.p, won.p, rb, re);
         return CZ_OK;
     }
     int reduce_counts(uint32_t fsize) { return cz::comm_all_reduce(comm, cnt.p, fsize, cz::COMM_U32, cz::COMM_SUM, s); }
@@ -1710,13 +1726,13 @@ struct HipShardedBfs {
     int bfs_emit(uint32_t lo, uint32_t fsize, uint32_t total, uint32_t next_depth) {
         if (total) CZ_HIP(hipMemsetAsync(buf.p, 0, (size_t)total * 4, s));
         hipLaunchKernelGGL(bfs_emit_kernel, dim3(grid_for((uint64_t)fsize * kBfsLanes)), dim3(kT), 0, s, off.p, tgt.p, order.p + lo,
-                           fsize, depth.p, (uint32_t *)nullptr, claim.p, (const uint8_t *)nullptr, pos.p, buf.p, parent.p, next_depth, rb, re, 1u);
+                           fsize, depth.p, vis.p, claim.p, (const uint8_t *)won.p, pos.p, buf.p, parent.p, next_depth, rb, re, 1u);
         return CZ_OK;
     }
     int reduce_next(uint32_t total) { return cz::comm_all_reduce(comm, buf.p, total, cz::COMM_U32, cz::COMM_SUM, s); }
     int bfs_commit(uint32_t at, uint32_t total, uint32_t next_depth) {
         if (total)
-            hipLaunchKernelGGL(bfs_commit_kernel, dim3(grid_for(total)), dim3(kT), 0, s, buf.p, total, order.p + at, depth.p, next_depth);
+            hipLaunchKernelGGL(bfs_commit_kernel, dim3(grid_for(total)), dim3(kT), 0, s, buf.p, total, order.p + at, depth.p, vis.p, next_depth);
         return CZ_OK;
     }
     int goals_left(uint32_t start, uint32_t *left) {
@@ -1756,16 +1772,15 @@ sssp_sh_advance_kernel(const unsigned long long *__restrict__ dp, const unsigned
     const int lane = threadIdx.x & 63;
     const uint32_t total = gridDim.x * blockDim.x;
     const uint32_t rounds = (N + total - 1) / total;
+    const QueueT<uint32_t> q{frontier, count};
+    __shared__ StagedPileT<uint32_t> st;  // (one counter for every wave of the grid serialises: see staged_push)
+    if (threadIdx.x == 0) st.count = 0;
+    __syncthreads();
     for (uint32_t r = 0; r < rounds; r++) {
         const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x + r * total;
         const bool changed = v < N && prop[v] != dp[v];
-        const unsigned long long m = __ballot(changed);
-        if (!m) continue;
-        uint32_t base = 0;
-        const int leader = __ffsll((long long)m) - 1;
-        if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, leader, 64);
-        if (changed) frontier[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
+        staged_push(q, st, changed, v, lane);
+        if ((r & 3) == 3 || r + 1 == rounds) staged_flush(q, st);  // at most one entry per thread and iteration
     }
 }
 
