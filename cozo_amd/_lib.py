@@ -141,6 +141,16 @@ SYMBOLS = {
                                              C.c_void_p]),
     "cz_sssp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
                           C.c_void_p, C.c_void_p]),
+    "cz_graph_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "cz_graph_destroy": (None, [C.c_void_p]),
+    "cz_graph_acquire": (C.c_int, [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_int)]),
+    "cz_graph_release": (None, [C.c_uint64, C.c_uint64, C.c_void_p]),
+    "cz_graph_cache_clear": (None, []),
+    "cz_bfs_on": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                            C.c_void_p]),
+    "cz_connected_components_on": (C.c_int, [C.c_void_p, C.c_void_p, u32p, C.c_void_p]),
+    "cz_sssp_on": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cz_graph_last_timing": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cz_label_propagation": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, u32p, u32p,
                                        C.c_void_p]),

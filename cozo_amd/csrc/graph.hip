@@ -25,7 +25,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <list>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -626,6 +628,119 @@ int check_csr(const uint32_t *off, const uint32_t *tgt, uint32_t N, uint64_t E) 
 
 }  // namespace
 
+// ---- a relation's CSR resident on the device (cz_graph_upload / cz_graph_cached): the *_on forms of the rules skip the upload --
+struct cz_graph {
+    cz::DevBuf<uint32_t> off, tgt;
+    cz::DevBuf<float> w;
+    uint32_t N = 0;
+    uint64_t E = 0;
+    bool has_w = false;
+    double wsum = 0.0;                 // of the valid weights (the near-far bucket width is their mean)
+    unsigned long long bad = ~0ull;    // smallest index of a negative / NaN weight (BadEdgeWeightError when a rule needs them)
+    float bad_value = 0.f;
+};
+
+namespace {
+
+int graph_fill(cz_graph &G, const uint32_t *offsets, const uint32_t *targets, const float *weights, uint32_t N, uint64_t E) {
+    int rc = check_csr(offsets, targets, N, E);
+    if (rc) return rc;
+    G.N = N;
+    G.E = E;
+    CZ_HIP(G.off.alloc((size_t)N + 1));
+    CZ_HIP(G.tgt.alloc(E));
+    CZ_HIP(hipMemcpy(G.off.p, offsets, ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
+    if (E) CZ_HIP(hipMemcpy(G.tgt.p, targets, E * 4, hipMemcpyHostToDevice));
+    if (weights || E == 0) {
+        G.has_w = true;
+        CZ_HIP(G.w.alloc(E));
+        if (E) {
+            CZ_HIP(hipMemcpy(G.w.p, weights, E * 4, hipMemcpyHostToDevice));
+            // negative / NaN weights (+inf is legal here: the reference checks the f64 value, and a finite f64 beyond f32's
+            // range becomes +inf in its `as f32` cast; such an edge never improves anything -- inf < inf is false -- exactly
+            // as in dijkstra :304); checked on the device copy, a host loop over 1e8 weights costs 50 ms
+            cz::DevBuf<double> d_sum;
+            cz::DevBuf<unsigned long long> d_bad;
+            CZ_HIP(d_sum.alloc(1));
+            CZ_HIP(d_bad.alloc(1));
+            CZ_HIP(hipMemsetAsync(d_sum.p, 0, 8, nullptr));
+            CZ_HIP(hipMemsetAsync(d_bad.p, 0xFF, 8, nullptr));
+            hipLaunchKernelGGL(weights_check_kernel, dim3(grid_for(E)), dim3(kT), 0, nullptr, G.w.p, E, d_sum.p, d_bad.p);
+            CZ_HIP(hipMemcpy(&G.bad, d_bad.p, 8, hipMemcpyDeviceToHost));
+            CZ_HIP(hipMemcpy(&G.wsum, d_sum.p, 8, hipMemcpyDeviceToHost));
+            if (G.bad != ~0ull) G.bad_value = weights[G.bad];
+        }
+    }
+    return CZ_OK;
+}
+
+}  // namespace
+
+extern "C" int cz_graph_upload(const uint32_t *offsets, const uint32_t *targets, const float *weights, uint32_t N, uint64_t E,
+                               cz_graph **out) {
+    if (!out) return cz::set_error(CZ_E_INVALID, "null out");
+    *out = nullptr;
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    std::unique_ptr<cz_graph> g(new cz_graph);
+    if ((rc = graph_fill(*g, offsets, targets, weights, N, E))) return rc;
+    *out = g.release();
+    return CZ_OK;
+}
+
+extern "C" void cz_graph_destroy(cz_graph *g) { delete g; }
+
+// Resident graphs under the caller's (relation id, snapshot) key, like cz_pagerank_cached's plans: FixedRule::run is handed the
+// relation anew on every call, and on the 10M / 100M graph the CSR upload is 8-15 ms of a 20-32 ms call.  An entry is taken OUT of
+// the cache while a caller holds it (cz_graph_acquire) and comes back with cz_graph_release, so entries are never shared
+// between threads; most recently used first, CZ_GRAPH_CACHE entries (default 4, 0 = nothing is kept).
+namespace {
+struct GraphCacheEntry {
+    uint64_t hi, lo;
+    std::unique_ptr<cz_graph> g;
+};
+std::mutex g_graph_mu;
+std::list<GraphCacheEntry> g_graph_cache;
+size_t graph_cache_capacity() {
+    const char *e = getenv("CZ_GRAPH_CACHE");
+    return e ? (size_t)std::max(0, atoi(e)) : 4;
+}
+}  // namespace
+
+extern "C" int cz_graph_acquire(uint64_t key_hi, uint64_t key_lo, const uint32_t *offsets, const uint32_t *targets,
+                                const float *weights, uint32_t N, uint64_t E, cz_graph **out, int *cache_hit) {
+    if (cache_hit) *cache_hit = 0;
+    if (!out) return cz::set_error(CZ_E_INVALID, "null out");
+    *out = nullptr;
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if ((key_hi | key_lo) != 0) {
+        std::lock_guard<std::mutex> lk(g_graph_mu);
+        for (auto it = g_graph_cache.begin(); it != g_graph_cache.end(); ++it)
+            if (it->hi == key_hi && it->lo == key_lo && it->g->N == N && it->g->E == E && (it->g->has_w || !weights)) {
+                *out = it->g.release();
+                g_graph_cache.erase(it);
+                if (cache_hit) *cache_hit = 1;
+                return CZ_OK;
+            }
+    }
+    return cz_graph_upload(offsets, targets, weights, N, E, out);
+}
+
+extern "C" void cz_graph_release(uint64_t key_hi, uint64_t key_lo, cz_graph *g) {
+    if (!g) return;
+    std::unique_ptr<cz_graph> own(g);
+    if ((key_hi | key_lo) == 0 || graph_cache_capacity() == 0) return;
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    g_graph_cache.push_front(GraphCacheEntry{key_hi, key_lo, std::move(own)});
+    while (g_graph_cache.size() > graph_cache_capacity()) g_graph_cache.pop_back();
+}
+
+extern "C" void cz_graph_cache_clear(void) {
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    g_graph_cache.clear();
+}
+
 extern "C" int cz_graph_last_timing(double *upload_ms, double *device_ms, double *download_ms) {
     if (upload_ms) *upload_ms = t_timing.ms[T_UPLOAD];
     if (device_ms) *device_ms = t_timing.ms[T_DEVICE];
@@ -633,24 +748,19 @@ extern "C" int cz_graph_last_timing(double *upload_ms, double *device_ms, double
     return CZ_OK;
 }
 
-extern "C" int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E,
-                      const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals,
-                      int share_visited, uint32_t *parent, uint32_t *depth, uint32_t *order, uint32_t *n_reached,
-                      const volatile uint8_t *poison) {
-    int rc = cz::ensure_device();
-    if (rc) return rc;
-    t_timing.start();
-    if (n_starts == 0 || N == 0) return CZ_OK;
-    if (!starts || !parent) return cz::set_error(CZ_E_INVALID, "null starts/parent");
-    rc = check_csr(out_offsets, out_targets, N, E);
-    if (rc) return rc;
-    cz::DevBuf<uint32_t> d_off, d_tgt, d_depth, d_parent, d_claim, d_order, d_cnt, d_pos, d_scratch, d_goals, d_misc, d_vis;
+namespace {
+
+// the rule on a resident graph (cz_bfs uploads one for the call, cz_bfs_on is handed one)
+int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals, int share_visited,
+            uint32_t *parent, uint32_t *depth, uint32_t *order, uint32_t *n_reached, const volatile uint8_t *poison) {
+    const uint32_t N = G.N;
+    const uint64_t E = G.E;
+    int rc = CZ_OK;
+    cz::DevBuf<uint32_t> d_depth, d_parent, d_claim, d_order, d_cnt, d_pos, d_scratch, d_goals, d_misc, d_vis;
     cz::DevBuf<uint8_t> d_won;
     const size_t vis_words = ((size_t)N + 31) / 32;
     CZ_HIP(d_vis.alloc(vis_words));
     CZ_HIP(d_won.alloc(E));
-    CZ_HIP(d_off.alloc((size_t)N + 1));
-    CZ_HIP(d_tgt.alloc(E));
     CZ_HIP(d_depth.alloc(N));
     CZ_HIP(d_parent.alloc(N));
     CZ_HIP(d_claim.alloc(N));
@@ -659,8 +769,6 @@ extern "C" int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, 
     CZ_HIP(d_pos.alloc(N));
     CZ_HIP(d_scratch.alloc(scan_scratch_words(N)));
     CZ_HIP(d_misc.alloc(4));
-    CZ_HIP(hipMemcpy(d_off.p, out_offsets, ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
-    if (E) CZ_HIP(hipMemcpy(d_tgt.p, out_targets, E * 4, hipMemcpyHostToDevice));
     if (goals && n_goals) {
         CZ_HIP(d_goals.alloc(n_goals));
         CZ_HIP(hipMemcpy(d_goals.p, goals, (size_t)n_goals * 4, hipMemcpyHostToDevice));
@@ -696,13 +804,13 @@ extern "C" int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, 
                 if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
                 const uint32_t *fr = d_order.p + lo;
                 const int g = grid_for((uint64_t)fsize * kBfsLanes);  // a 16-lane group per frontier node
-                hipLaunchKernelGGL(bfs_claim_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, fr, fsize, d_depth.p, d_vis.p, d_claim.p,
+                hipLaunchKernelGGL(bfs_claim_kernel, dim3(g), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, fsize, d_depth.p, d_vis.p, d_claim.p,
                                    0u, N);
-                hipLaunchKernelGGL(bfs_count_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, fr, fsize, d_depth.p, d_vis.p, d_claim.p,
+                hipLaunchKernelGGL(bfs_count_kernel, dim3(g), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, fsize, d_depth.p, d_vis.p, d_claim.p,
                                    d_cnt.p, d_won.p, 0u, N);
                 rc = exclusive_scan(d_cnt.p, d_pos.p, fsize, d_misc.p, d_scratch.p, s);
                 if (rc) return rc;
-                hipLaunchKernelGGL(bfs_emit_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, fr, fsize, d_depth.p, d_vis.p, d_claim.p,
+                hipLaunchKernelGGL(bfs_emit_kernel, dim3(g), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, fsize, d_depth.p, d_vis.p, d_claim.p,
                                    d_won.p, d_pos.p, d_order.p + lo + fsize, d_parent.p, level + 1, 0u, N, 0u);
                 CZ_HIP(hipMemsetAsync(d_misc.p + 1, 0, 4, s));
                 if (goals)
@@ -733,32 +841,51 @@ extern "C" int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, 
     return CZ_OK;
 }
 
-extern "C" int cz_connected_components(const uint32_t *offsets, const uint32_t *targets, uint32_t N, uint64_t E,
-                                       uint32_t *group, uint32_t *n_groups, const volatile uint8_t *poison) {
-    if (n_groups) *n_groups = 0;
+}  // namespace
+
+extern "C" int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E,
+                      const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals,
+                      int share_visited, uint32_t *parent, uint32_t *depth, uint32_t *order, uint32_t *n_reached,
+                      const volatile uint8_t *poison) {
     int rc = cz::ensure_device();
     if (rc) return rc;
     t_timing.start();
-    if (N == 0) return CZ_OK;
-    if (!group) return cz::set_error(CZ_E_INVALID, "null group");
-    rc = check_csr(offsets, targets, N, E);
+    if (n_starts == 0 || N == 0) return CZ_OK;
+    if (!starts || !parent) return cz::set_error(CZ_E_INVALID, "null starts/parent");
+    cz_graph G;
+    if ((rc = graph_fill(G, out_offsets, out_targets, nullptr, N, E))) return rc;
+    return bfs_run(G, starts, n_starts, goals, n_goals, share_visited, parent, depth, order, n_reached, poison);
+}
+
+extern "C" int cz_bfs_on(const cz_graph *g, const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals,
+                         int share_visited, uint32_t *parent, uint32_t *depth, uint32_t *order, uint32_t *n_reached,
+                         const volatile uint8_t *poison) {
+    int rc = cz::ensure_device();
     if (rc) return rc;
-    cz::DevBuf<uint32_t> d_off, d_tgt, d_label, d_flag, d_rank, d_scratch, d_misc;
-    CZ_HIP(d_off.alloc((size_t)N + 1));
-    CZ_HIP(d_tgt.alloc(E));
+    t_timing.start();
+    if (!g) return cz::set_error(CZ_E_INVALID, "null graph");
+    if (n_starts == 0 || g->N == 0) return CZ_OK;
+    if (!starts || !parent) return cz::set_error(CZ_E_INVALID, "null starts/parent");
+    return bfs_run(*g, starts, n_starts, goals, n_goals, share_visited, parent, depth, order, n_reached, poison);
+}
+
+namespace {
+
+int cc_run(const cz_graph &G, uint32_t *group, uint32_t *n_groups, const volatile uint8_t *poison) {
+    const uint32_t N = G.N;
+    int rc = CZ_OK;
+    cz::DevBuf<uint32_t> d_label, d_flag, d_rank, d_scratch, d_misc;
     CZ_HIP(d_label.alloc(N));
     CZ_HIP(d_flag.alloc(std::max<size_t>(N, kCcSamples)));  // (first the sample of step 2, then the root flags)
     CZ_HIP(d_rank.alloc(N));
     CZ_HIP(d_scratch.alloc(scan_scratch_words(N)));
     CZ_HIP(d_misc.alloc(4));
-    CZ_HIP(hipMemcpy(d_off.p, offsets, ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
-    if (E) CZ_HIP(hipMemcpy(d_tgt.p, targets, E * 4, hipMemcpyHostToDevice));
     hipStream_t s = nullptr;
     const int g = grid_for(N);
     t_timing.lap(T_UPLOAD);
     hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(kT), 0, s, d_label.p, N);
     for (uint32_t r = 0; r < kCcNeighbourRounds; r++) {
-        hipLaunchKernelGGL(cc_link_nth_kernel, dim3(g), dim3(kT), 0, s, d_off.p, d_tgt.p, N, r, d_label.p);
+        hipLaunchKernelGGL(cc_link_nth_kernel, dim3(g), dim3(kT), 0, s, G.off.p, G.tgt.p, N, r, d_label.p);
         hipLaunchKernelGGL(cc_compress_kernel, dim3(g), dim3(kT), 0, s, N, d_label.p);
     }
     // the component most of a fixed sample of the nodes is in
@@ -772,7 +899,7 @@ extern "C" int cz_connected_components(const uint32_t *offsets, const uint32_t *
         for (j = i; j < kCcSamples && sample[j] == sample[i]; j++) {}
         if (j - i > best) best = j - i, skip = sample[i];
     }
-    hipLaunchKernelGGL(cc_link_rest_kernel, dim3(grid_for((uint64_t)N * kCcLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, N,
+    hipLaunchKernelGGL(cc_link_rest_kernel, dim3(grid_for((uint64_t)N * kCcLanes)), dim3(kT), 0, s, G.off.p, G.tgt.p, N,
                        kCcNeighbourRounds, skip, d_label.p);
     hipLaunchKernelGGL(cc_compress_kernel, dim3(g), dim3(kT), 0, s, N, d_label.p);
     hipLaunchKernelGGL(cc_rootflag_kernel, dim3(g), dim3(kT), 0, s, N, d_label.p, d_flag.p);
@@ -788,6 +915,32 @@ extern "C" int cz_connected_components(const uint32_t *offsets, const uint32_t *
     if (n_groups) *n_groups = total;
     t_timing.lap(T_DOWNLOAD);
     return CZ_OK;
+}
+
+}  // namespace
+
+extern "C" int cz_connected_components(const uint32_t *offsets, const uint32_t *targets, uint32_t N, uint64_t E,
+                                       uint32_t *group, uint32_t *n_groups, const volatile uint8_t *poison) {
+    if (n_groups) *n_groups = 0;
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    t_timing.start();
+    if (N == 0) return CZ_OK;
+    if (!group) return cz::set_error(CZ_E_INVALID, "null group");
+    cz_graph G;
+    if ((rc = graph_fill(G, offsets, targets, nullptr, N, E))) return rc;
+    return cc_run(G, group, n_groups, poison);
+}
+
+extern "C" int cz_connected_components_on(const cz_graph *g, uint32_t *group, uint32_t *n_groups, const volatile uint8_t *poison) {
+    if (n_groups) *n_groups = 0;
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    t_timing.start();
+    if (!g) return cz::set_error(CZ_E_INVALID, "null graph");
+    if (g->N == 0) return CZ_OK;
+    if (!group) return cz::set_error(CZ_E_INVALID, "null group");
+    return cc_run(*g, group, n_groups, poison);
 }
 
 // ---- ClusteringCoefficients (fixed_rule/algos/triangles.rs:25-110) ---------------------------------------------
@@ -879,40 +1032,27 @@ struct SsspBatch {
     float delta = 0.f;
     bool one_pile = false;
     hipStream_t s = nullptr;
-    cz::DevBuf<uint32_t> d_off, d_tgt, d_qtag, d_ftag, d_misc, d_starts;
-    cz::DevBuf<float> d_w;
+    template <class T>
+    struct View {  // the graph's arrays are somebody else's (a cz_graph: the call's own upload or a resident one)
+        const T *p = nullptr;
+    };
+    View<uint32_t> d_off, d_tgt;
+    View<float> d_w;
+    cz::DevBuf<uint32_t> d_qtag, d_ftag, d_misc, d_starts;
     cz::DevBuf<unsigned long long> d_dp, d_q[4];
 
-    int alloc(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t n, uint64_t e,
-              uint32_t n_starts, uint64_t pairs_budget) {
-        N = n;
-        E = e;
+    int attach(const cz_graph &G, uint32_t n_starts, uint64_t pairs_budget) {
+        N = G.N;
+        E = G.E;
         if (N >= 0x80000000u) return cz::set_error(CZ_E_UNSUPPORTED, "node ids must stay below 2^31");
-        CZ_HIP(d_off.alloc((size_t)N + 1));
-        CZ_HIP(d_tgt.alloc(E));
-        CZ_HIP(d_w.alloc(E));
+        if (!G.has_w) return cz::set_error(CZ_E_INVALID, "the graph was uploaded without weights");
+        if (G.bad != ~0ull)  // BadEdgeWeightError, fixed_rule/mod.rs:258-286
+            return cz::set_error(CZ_E_INVALID, "edge %llu has weight %g: weights must be non-negative numbers", G.bad, (double)G.bad_value);
+        d_off.p = G.off.p;
+        d_tgt.p = G.tgt.p;
+        d_w.p = G.w.p;
         CZ_HIP(d_misc.alloc(8));
-        CZ_HIP(hipMemcpy(d_off.p, out_offsets, ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
-        double wsum = 0.0;
-        if (E) {
-            CZ_HIP(hipMemcpy(d_tgt.p, out_targets, E * 4, hipMemcpyHostToDevice));
-            CZ_HIP(hipMemcpy(d_w.p, weights, E * 4, hipMemcpyHostToDevice));
-            // negative / NaN weights (+inf is legal here: the reference checks the f64 value, and a finite f64 beyond f32's
-            // range becomes +inf in its `as f32` cast; such an edge never improves anything -- inf < inf is false -- exactly
-            // as in dijkstra :304); checked on the device copy, a host loop over 1e8 weights costs 30 ms
-            cz::DevBuf<double> d_sum;
-            cz::DevBuf<unsigned long long> d_bad;
-            CZ_HIP(d_sum.alloc(1));
-            CZ_HIP(d_bad.alloc(1));
-            CZ_HIP(hipMemsetAsync(d_sum.p, 0, 8, s));
-            CZ_HIP(hipMemsetAsync(d_bad.p, 0xFF, 8, s));
-            hipLaunchKernelGGL(weights_check_kernel, dim3(grid_for(E)), dim3(kT), 0, s, d_w.p, E, d_sum.p, d_bad.p);
-            unsigned long long bad = 0;
-            CZ_HIP(hipMemcpy(&bad, d_bad.p, 8, hipMemcpyDeviceToHost));
-            CZ_HIP(hipMemcpy(&wsum, d_sum.p, 8, hipMemcpyDeviceToHost));
-            if (bad != ~0ull)
-                return cz::set_error(CZ_E_INVALID, "edge %llu has weight %g: weights must be non-negative numbers", bad, (double)weights[bad]);
-        }
+        const double wsum = G.wsum;
         // bucket width of the near-far schedule: the mean edge weight (CZ_SSSP_DELTA overrides; <= 0 or "inf" = one pile,
         // i.e. plain frontier Bellman-Ford).  Only the schedule depends on it, never the result.
         delta = E ? (float)(wsum / (double)E) : 0.f;
@@ -993,6 +1133,8 @@ struct SsspBatch {
     }
 };
 
+int sssp_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison);
+
 }  // namespace
 
 extern "C" int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N,
@@ -1003,11 +1145,30 @@ extern "C" int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets,
     t_timing.start();
     if (n_starts == 0 || N == 0) return CZ_OK;
     if (!starts || !dist || !parent) return cz::set_error(CZ_E_INVALID, "null starts/dist/parent");
-    rc = check_csr(out_offsets, out_targets, N, E);
-    if (rc) return rc;
     if (E > 0 && !weights) return cz::set_error(CZ_E_INVALID, "null weights");
+    cz_graph G;
+    if ((rc = graph_fill(G, out_offsets, out_targets, weights, N, E))) return rc;
+    return sssp_run(G, starts, n_starts, dist, parent, poison);
+}
+
+extern "C" int cz_sssp_on(const cz_graph *g, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent,
+                          const volatile uint8_t *poison) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    t_timing.start();
+    if (!g) return cz::set_error(CZ_E_INVALID, "null graph");
+    if (n_starts == 0 || g->N == 0) return CZ_OK;
+    if (!starts || !dist || !parent) return cz::set_error(CZ_E_INVALID, "null starts/dist/parent");
+    return sssp_run(*g, starts, n_starts, dist, parent, poison);
+}
+
+namespace {
+
+int sssp_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison) {
+    const uint32_t N = G.N;
+    int rc = CZ_OK;
     SsspBatch sb;
-    if ((rc = sb.alloc(out_offsets, out_targets, weights, N, E, n_starts, 80ull << 20))) return rc;  // about 4 GB in all
+    if ((rc = sb.attach(G, n_starts, 80ull << 20))) return rc;  // about 4 GB in all
     const uint64_t SN = (uint64_t)sb.S * N;
     cz::DevBuf<uint32_t> d_parent;
     cz::DevBuf<float> d_dist;
@@ -1029,6 +1190,8 @@ extern "C" int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets,
     }
     return CZ_OK;
 }
+
+}  // namespace
 
 // ---- BetweennessCentrality (fixed_rule/algos/all_pairs_shortest_path.rs:31-95) --------------------------------------------
 // The reference runs dijkstra_keep_ties from every node, enumerates ALL shortest paths to every target and adds 1 / (number
@@ -1224,7 +1387,9 @@ extern "C" int cz_betweenness(const uint32_t *out_offsets, const uint32_t *out_t
     for (uint32_t i = 0; i < N; i++) all[i] = i;
     uint64_t pairs = 48ull << 20;
     if (const char *b = getenv("CZ_BC_BATCH")) pairs = std::max<uint64_t>(1, strtoull(b, nullptr, 10)) * N;  // sources per batch (tests)
-    if ((rc = sb.alloc(out_offsets, out_targets, weights, N, E, N, pairs))) return rc;
+    cz_graph G;
+    if ((rc = graph_fill(G, out_offsets, out_targets, weights, N, E))) return rc;
+    if ((rc = sb.attach(G, N, pairs))) return rc;
     const uint64_t SN = (uint64_t)sb.S * N;
     cz::DevBuf<uint32_t> d_ioff, d_isrc, d_flags;
     cz::DevBuf<float> d_iw;

@@ -115,26 +115,86 @@ class PageRankPlan:
         return host
 
 
+class DeviceGraph:
+    """a relation's CSR resident on the device (cz_graph_upload, or cz_graph_acquire / cz_graph_release under the caller's
+    (relation id, snapshot) key): bfs / connected_components / sssp take one in place of the host arrays and skip the upload.
+    `with DeviceGraph.acquire(key, off, tgt, w) as g:` gives the graph back to the library's cache on exit."""
+
+    def __init__(self, off, tgt, weights=None, _handle=None, _key=None, hit=False):
+        self.key, self.cache_hit = _key, hit
+        if _handle is not None:
+            self._h = _handle
+            return
+        off, tgt = _csr32(off, tgt)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+        h = C.c_void_p()
+        check(_lib.lib().cz_graph_upload(ptr(off), ptr(tgt), ptr(w), off.size - 1, tgt.size, C.byref(h)))
+        self._h = h
+        self.n = off.size - 1
+
+    @classmethod
+    def acquire(cls, key, off, tgt, weights=None):
+        off, tgt = _csr32(off, tgt)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+        h, hit = C.c_void_p(), C.c_int(0)
+        check(_lib.lib().cz_graph_acquire(int(key[0]), int(key[1]), ptr(off), ptr(tgt), ptr(w), off.size - 1, tgt.size, C.byref(h),
+                                          C.byref(hit)))
+        g = cls(None, None, _handle=h, _key=(int(key[0]), int(key[1])), hit=bool(hit.value))
+        g.n = off.size - 1
+        return g
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if self.key is not None:
+                _lib.lib().cz_graph_release(self.key[0], self.key[1], self._h)
+            else:
+                _lib.lib().cz_graph_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 def bfs(out_off, out_tgt, starts, goals=None, share_visited=False, want_depth=False, want_order=False, poison=None):
-    out_off, out_tgt = _csr32(out_off, out_tgt)
-    N = out_off.size - 1
+    """cz_bfs; `out_off` may be a DeviceGraph (then `out_tgt` is ignored): cz_bfs_on"""
+    on = out_off if isinstance(out_off, DeviceGraph) else None
+    if on is None:
+        out_off, out_tgt = _csr32(out_off, out_tgt)
+    N = on.n if on is not None else out_off.size - 1
     starts = _u32(starts)
     g = _u32(goals) if goals is not None else None
     parent = np.full((starts.size, N), CZ_NONE, dtype=np.uint32)
     depth = np.full((starts.size, N), CZ_NONE, dtype=np.uint32) if want_depth else None
     order = np.full((starts.size, N), CZ_NONE, dtype=np.uint32) if want_order else None
     reached = np.zeros(starts.size, dtype=np.uint32)
-    check(_lib.lib().cz_bfs(ptr(out_off), ptr(out_tgt), N, out_tgt.size, ptr(starts), starts.size, ptr(g),
-                            0 if g is None else g.size, int(share_visited), ptr(parent), ptr(depth), ptr(order),
-                            ptr(reached), ptr(poison)))
+    tail = (ptr(starts), starts.size, ptr(g), 0 if g is None else g.size, int(share_visited), ptr(parent), ptr(depth), ptr(order),
+            ptr(reached), ptr(poison))
+    if on is not None:
+        check(_lib.lib().cz_bfs_on(on._h, *tail))
+    else:
+        check(_lib.lib().cz_bfs(ptr(out_off), ptr(out_tgt), N, out_tgt.size, *tail))
     return parent, depth, order, reached
 
 
-def connected_components(off, tgt, poison=None):
+def connected_components(off, tgt=None, poison=None):
+    """cz_connected_components on the symmetrised CSR; `off` may be a DeviceGraph: cz_connected_components_on"""
+    k = C.c_uint32(0)
+    if isinstance(off, DeviceGraph):
+        grp = np.empty(off.n, dtype=np.uint32)
+        check(_lib.lib().cz_connected_components_on(off._h, ptr(grp), C.byref(k), ptr(poison)))
+        return grp, k.value
     off, tgt = _csr32(off, tgt)
     N = off.size - 1
     grp = np.empty(N, dtype=np.uint32)
-    k = C.c_uint32(0)
     check(_lib.lib().cz_connected_components(ptr(off), ptr(tgt), N, tgt.size, ptr(grp), C.byref(k), ptr(poison)))
     return grp, k.value
 
@@ -150,6 +210,13 @@ def clustering_coefficients(off, tgt, poison=None):
 
 
 def sssp(out_off, out_tgt, weights, starts, poison=None):
+    """cz_sssp; `out_off` may be a DeviceGraph uploaded with weights (then out_tgt / weights are ignored): cz_sssp_on"""
+    if isinstance(out_off, DeviceGraph):
+        starts = _u32(starts)
+        dist = np.empty((starts.size, out_off.n), dtype=np.float32)
+        parent = np.empty((starts.size, out_off.n), dtype=np.uint32)
+        check(_lib.lib().cz_sssp_on(out_off._h, ptr(starts), starts.size, ptr(dist), ptr(parent), ptr(poison)))
+        return dist, parent
     out_off, out_tgt = _csr32(out_off, out_tgt)
     w = np.ascontiguousarray(weights, dtype=np.float32)
     N = out_off.size - 1

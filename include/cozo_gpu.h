@@ -359,6 +359,27 @@ int cz_clustering_coefficients(const uint32_t *offsets, const uint32_t *targets,
 int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
             const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison);
 
+/* A relation's CSR resident on the device.  FixedRule::run (fixed_rule/mod.rs:538-567) is handed the relation anew on every
+ * call; on a 10M-node / 100M-edge graph the upload is 8-15 ms of a 20-32 ms call.  cz_graph_upload keeps the arrays of one
+ * graph (weights may be null: BFS / ConnectedComponents only) until cz_graph_destroy; cz_graph_acquire / cz_graph_release do the
+ * same under the caller's (relation id, snapshot) key like cz_pagerank_cached: acquire hands out the cached graph (taken out
+ * of the cache: an entry is never shared between threads) or uploads, release gives it back (CZ_GRAPH_CACHE entries, default
+ * 4).  The *_on forms of the rules are the rules of the host-array forms, minus the upload. */
+typedef struct cz_graph cz_graph;
+int cz_graph_upload(const uint32_t *offsets, const uint32_t *targets, const float *weights, uint32_t N, uint64_t E,
+                    cz_graph **out);
+void cz_graph_destroy(cz_graph *g);
+int cz_graph_acquire(uint64_t key_hi, uint64_t key_lo, const uint32_t *offsets, const uint32_t *targets, const float *weights,
+                     uint32_t N, uint64_t E, cz_graph **out, int *cache_hit);
+void cz_graph_release(uint64_t key_hi, uint64_t key_lo, cz_graph *g);
+void cz_graph_cache_clear(void);
+int cz_bfs_on(const cz_graph *g, const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals,
+              int share_visited, uint32_t *parent, uint32_t *depth, uint32_t *order, uint32_t *n_reached,
+              const volatile uint8_t *poison);
+int cz_connected_components_on(const cz_graph *g, uint32_t *group, uint32_t *n_groups, const volatile uint8_t *poison);
+int cz_sssp_on(const cz_graph *g, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent,
+               const volatile uint8_t *poison);
+
 /* Where the last cz_bfs / cz_connected_components / cz_sssp / cz_clustering_coefficients / cz_betweenness /
  * cz_label_propagation call of THIS
  * host thread spent its wall time, in milliseconds (any pointer may be null): these entry points take host arrays

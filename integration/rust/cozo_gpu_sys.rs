@@ -62,6 +62,10 @@ pub struct cz_predicate {
 pub struct cz_comm {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct cz_graph {
+    _private: [u8; 0],
+}
 
 #[repr(C)]
 #[derive(Default, Clone, Copy)]
@@ -183,6 +187,16 @@ extern "C" {
                                       degree: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_sssp(out_offsets: *const u32, out_targets: *const u32, weights: *const c_float, n: u32, e: u64,
                    starts: *const u32, n_starts: u32, dist: *mut c_float, parent: *mut u32, poison: *const u8) -> c_int;
+    pub fn cz_graph_upload(offsets: *const u32, targets: *const u32, weights: *const c_float, n: u32, e: u64, out: *mut *mut cz_graph) -> c_int;
+    pub fn cz_graph_destroy(g: *mut cz_graph);
+    pub fn cz_graph_acquire(key_hi: u64, key_lo: u64, offsets: *const u32, targets: *const u32, weights: *const c_float, n: u32, e: u64,
+                            out: *mut *mut cz_graph, cache_hit: *mut c_int) -> c_int;
+    pub fn cz_graph_release(key_hi: u64, key_lo: u64, g: *mut cz_graph);
+    pub fn cz_graph_cache_clear();
+    pub fn cz_bfs_on(g: *const cz_graph, starts: *const u32, n_starts: u32, goals: *const u32, n_goals: u32, share_visited: c_int,
+                     parent: *mut u32, depth: *mut u32, order: *mut u32, n_reached: *mut u32, poison: *const u8) -> c_int;
+    pub fn cz_connected_components_on(g: *const cz_graph, group: *mut u32, n_groups: *mut u32, poison: *const u8) -> c_int;
+    pub fn cz_sssp_on(g: *const cz_graph, starts: *const u32, n_starts: u32, dist: *mut c_float, parent: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_label_propagation(out_offsets: *const u32, out_targets: *const u32, weights: *const c_float, n: u32, e: u64,
                                 max_iter: u32, labels: *mut u32, iters_run: *mut u32, n_colours: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_graph_last_timing(upload_ms: *mut c_double, device_ms: *mut c_double, download_ms: *mut c_double) -> c_int;

@@ -46,6 +46,14 @@ def main():
     print(f"    {k} components")
     dist, _ = timed("cz_sssp (1 start)", lambda: G.sssp(ooff, otgt, w, starts), E)
     print(f"    reached {int(np.isfinite(dist[0]).sum())} nodes, max cost {float(dist[0][np.isfinite(dist[0])].max()):.3f}")
+    for name, key, a, b, c, fn in (("cz_bfs_on (graph held by the cache)", (1, 1), ooff, otgt, None, lambda dg: G.bfs(dg, None, starts, want_depth=True)),
+                                  ("cz_connected_components_on (held)", (1, 2), uoff, utgt, None, lambda dg: G.connected_components(dg)),
+                                  ("cz_sssp_on (held)", (1, 3), ooff, otgt, w, lambda dg: G.sssp(dg, None, None, starts))):
+        def call():
+            with G.DeviceGraph.acquire(key, a, b, c) as dg:
+                return fn(dg)
+        timed(name, call, b.size)
+    L.cz_graph_cache_clear()
     tri, deg = timed("cz_clustering_coefficients", lambda: G.clustering_coefficients(uoff, utgt), utgt.size)
     print(f"    {int(tri.sum())} (node, triangle) incidences, max degree {int(deg.max())}")
     if os.environ.get("WITH_LP"):

@@ -557,3 +557,53 @@ def test_rules_on_graphs_without_edges_and_single_nodes(gpu_lib):
         assert list(labels) == list(range(n)) and it == 1
         up, dev_ms, down = G.last_timing()
         assert up >= 0 and dev_ms >= 0 and down >= 0
+
+
+def test_resident_graphs_and_their_cache(oracle, gpu_lib, monkeypatch):
+    """cz_graph_upload / cz_graph_acquire + the *_on rules: the same rows as the host-array forms, minus the upload; the
+    cache hands a graph out under its key, takes it back, forgets the least recently used one"""
+    from cozo_amd import _lib, graph as G
+    _lib.lib().cz_graph_cache_clear()
+    frm, to = util.random_relation(4000, 30000, 12)
+    w = (np.random.default_rng(3).integers(1, 40, len(frm)) / 8).astype(np.float32)
+    g = util.graph_from_relation(oracle, frm, to, weights=w)
+    u = util.graph_from_relation(oracle, frm, to, undirected=True)
+    starts = np.array([0, 7, g["n"] - 1], dtype=np.uint32)
+    with G.DeviceGraph(g["ooff"], g["otgt"], g["ow"]) as dg:
+        a, b = G.bfs(dg, None, starts, want_depth=True, want_order=True), G.bfs(g["ooff"], g["otgt"], starts, want_depth=True, want_order=True)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        a, b = G.sssp(dg, None, None, starts), G.sssp(g["ooff"], g["otgt"], g["ow"], starts)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        up, dev_ms, down = G.last_timing()
+        assert up < dev_ms + down + 5.0  # no CSR went over the bus for this call
+    with G.DeviceGraph(u["ooff"], u["otgt"]) as du:  # no weights: BFS / CC only
+        a, b = G.connected_components(du), G.connected_components(u["ooff"], u["otgt"])
+        assert a[1] == b[1] and np.array_equal(a[0], b[0])
+        with pytest.raises(_lib.CozoGpuError):
+            G.sssp(du, None, None, starts)
+    bad = g["ow"].copy()
+    bad[5] = -1.0
+    with G.DeviceGraph(g["ooff"], g["otgt"], bad) as dbad:  # the weights are judged when a rule needs them
+        G.bfs(dbad, None, starts)
+        with pytest.raises(_lib.CozoGpuError, match="edge 5 has weight -1"):
+            G.sssp(dbad, None, None, starts)
+    # the cache: miss, hit, a second holder of the same key misses while the first holds the entry, eviction
+    key = (77, 1)
+    g1 = G.DeviceGraph.acquire(key, g["ooff"], g["otgt"], g["ow"])
+    assert not g1.cache_hit
+    g2 = G.DeviceGraph.acquire(key, g["ooff"], g["otgt"], g["ow"])
+    assert not g2.cache_hit
+    g1.close()
+    g2.close()
+    g3 = G.DeviceGraph.acquire(key, g["ooff"], g["otgt"], g["ow"])
+    assert g3.cache_hit and np.array_equal(G.sssp(g3, None, None, starts)[0], G.sssp(g["ooff"], g["otgt"], g["ow"], starts)[0])
+    g3.close()
+    assert G.DeviceGraph.acquire(key, g["ooff"], g["otgt"]).cache_hit                   # weights not asked for: the weighted entry serves
+    assert not G.DeviceGraph.acquire((77, 2), g["ooff"], g["otgt"], g["ow"]).cache_hit   # another snapshot
+    for i in range(6):                                                                  # default capacity 4
+        G.DeviceGraph.acquire((900 + i, 0), u["ooff"], u["otgt"]).close()
+    assert not G.DeviceGraph.acquire((900, 0), u["ooff"], u["otgt"]).cache_hit
+    assert G.DeviceGraph.acquire((905, 0), u["ooff"], u["otgt"]).cache_hit
+    _lib.lib().cz_graph_cache_clear()
+    assert not G.DeviceGraph.acquire((905, 0), u["ooff"], u["otgt"]).cache_hit
+    _lib.lib().cz_graph_cache_clear()
