@@ -1193,6 +1193,64 @@ int sssp_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, float
 
 }  // namespace
 
+// ---- ClosenessCentrality (fixed_rule/algos/all_pairs_shortest_path.rs:97-176) ----------------------------------------------
+// One cost-only Dijkstra per node (`dijkstra_cost_only`, :146-176: the same strict-`<` f32 relaxation as `dijkstra`), then
+// per start, f32 throughout (:118-122): total = the finite distances summed one after the other in node order, nc = their
+// count, centrality = nc * nc / total / (n - 1).  The all-sources SSSP leaves a batch's costs on the device; one lane per
+// source walks its row in node order (the sum is one f32 chain: its order is the result), so neither the [starts][n]
+// distances nor a per-source host loop cross the bus.
+namespace {
+
+__global__ void __launch_bounds__(kT)
+closeness_kernel(const unsigned long long *__restrict__ dp, uint32_t N, uint32_t ns, double *__restrict__ out) {
+    for (uint32_t si = blockIdx.x * blockDim.x + threadIdx.x; si < ns; si += gridDim.x * blockDim.x) {
+        const unsigned long long *row = dp + (size_t)si * N;
+        float total = 0.0f, nc = 0.0f;
+        for (uint32_t v = 0; v < N; v++) {
+            const uint32_t c = (uint32_t)(row[v] >> 32);
+            if (c != 0x7F800000u) {  // `.filter(|d| d.is_finite())` (the costs are never NaN; +inf = unreached)
+                total = total + __uint_as_float(c);
+                nc = nc + 1.0f;
+            }
+        }
+        out[si] = (double)(nc * nc / total / (float)(N - 1));
+    }
+}
+
+}  // namespace
+
+extern "C" int cz_closeness(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
+                            double *centrality, const volatile uint8_t *poison) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    t_timing.start();
+    if (N == 0) return CZ_OK;
+    if (!centrality) return cz::set_error(CZ_E_INVALID, "null centrality");
+    if (E > 0 && !weights) return cz::set_error(CZ_E_INVALID, "null weights");
+    cz_graph G;
+    if ((rc = graph_fill(G, out_offsets, out_targets, weights, N, E))) return rc;
+    SsspBatch sb;
+    uint64_t pairs = 80ull << 20;
+    if (const char *b = getenv("CZ_BC_BATCH")) pairs = std::max<uint64_t>(1, strtoull(b, nullptr, 10)) * N;  // sources per batch (tests)
+    if ((rc = sb.attach(G, N, pairs))) return rc;
+    cz::DevBuf<double> d_out;
+    CZ_HIP(d_out.alloc(sb.S));
+    std::vector<uint32_t> all(N);
+    for (uint32_t i = 0; i < N; i++) all[i] = i;
+    t_timing.lap(T_UPLOAD);
+    for (uint32_t s0 = 0; s0 < N; s0 += sb.S) {
+        const uint32_t ns = std::min<uint32_t>(sb.S, N - s0);
+        if ((rc = sb.run(all.data() + s0, ns, poison))) return rc;
+        hipLaunchKernelGGL(closeness_kernel, dim3(grid_for(ns, 64)), dim3(64), 0, sb.s, sb.d_dp.p, N, ns, d_out.p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "closeness launch: %s", hipGetErrorString(e));
+        t_timing.lap(T_DEVICE);
+        CZ_HIP(hipMemcpy(centrality + s0, d_out.p, (size_t)ns * 8, hipMemcpyDeviceToHost));
+        t_timing.lap(T_DOWNLOAD);
+    }
+    return CZ_OK;
+}
+
 // ---- BetweennessCentrality (fixed_rule/algos/all_pairs_shortest_path.rs:31-95) --------------------------------------------
 // The reference runs dijkstra_keep_ties from every node, enumerates ALL shortest paths to every target and adds 1 / (number
 // of shortest paths to that target) to every inner node of every path.  Its back pointers are exactly the "tight" edges

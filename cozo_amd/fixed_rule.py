@@ -717,11 +717,10 @@ class ClusteringCoefficients(FixedRule):
 
 class ClosenessCentrality(FixedRule):
     """algos/all_pairs_shortest_path.rs:97-144: one cost-only Dijkstra per node (`dijkstra_cost_only`, :146-176, the same
-    strict-`<` f32 relaxation as `dijkstra`) -> cz_sssp over batches of starts; the per-start epilogue is the reference's
-    f32 arithmetic in the reference's order: total = sequential sum of the finite distances in node order, nc = their
-    count, centrality = nc * nc / total / (n - 1).  Rows: (node, centrality as f64)."""
-
-    BATCH = 256
+    strict-`<` f32 relaxation as `dijkstra`) and, per start, the reference's f32 arithmetic in the reference's order:
+    total = sequential sum of the finite distances in node order, nc = their count, centrality = nc * nc / total / (n - 1)
+    -> cz_closeness (the all-sources SSSP in batches and the per-start sums, both on the device).
+    Rows: (node, centrality as f64)."""
 
     def arity(self, options, rule_head) -> int:
         return 2
@@ -733,19 +732,10 @@ class ClosenessCentrality(FixedRule):
         n = graph.n
         if n == 0:
             return
-        denom = np.float32(n - 1)
-        for b0 in range(0, n, self.BATCH):
-            starts = np.arange(b0, min(n, b0 + self.BATCH), dtype=np.uint32)
-            dist, _ = _graph.sssp(graph.out_offsets, graph.out_targets, graph.out_weights, starts, poison=poison.flag)
-            for si, s in enumerate(starts):
-                d = dist[si]
-                fin = d[np.isfinite(d)]
-                total = np.cumsum(fin, dtype=np.float32)[-1]  # a sequential f32 sum, like `.sum()` over the iterator
-                nc = np.float32(fin.size)
-                with np.errstate(divide="ignore", invalid="ignore"):
-                    c = np.float32(np.float32(nc * nc) / total) / denom
-                out.put((indices[int(s)], float(c)))
-            poison.check()
+        cent = _graph.closeness(graph.out_offsets, graph.out_targets, graph.out_weights, poison=poison.flag)
+        poison.check()
+        for i in range(n):
+            out.put((indices[i], float(cent[i])))
 
 
 class BetweennessCentrality(FixedRule):

@@ -235,6 +235,16 @@ def last_timing():
     return a.value, b.value, c.value
 
 
+def closeness(out_off, out_tgt, weights, poison=None):
+    """cz_closeness on the weighted out-CSR (weights >= 0) -> centrality f64 [N] (the reference's f32 arithmetic)"""
+    out_off, out_tgt = _csr32(out_off, out_tgt)
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    N = out_off.size - 1
+    cent = np.zeros(N, dtype=np.float64)
+    check(_lib.lib().cz_closeness(ptr(out_off), ptr(out_tgt), ptr(w), N, out_tgt.size, ptr(cent), ptr(poison)))
+    return cent
+
+
 def betweenness(out_off, out_tgt, weights, poison=None):
     """cz_betweenness on the weighted out-CSR (weights > 0) -> centrality f64 [N]"""
     out_off, out_tgt = _csr32(out_off, out_tgt)

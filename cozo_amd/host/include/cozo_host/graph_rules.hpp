@@ -11,7 +11,7 @@
 //   ShortestPathDijkstra         fixed_rule/algos/shortest_path_dijkstra.rs:33-153     -> cz_sssp
 //   ClusteringCoefficients       fixed_rule/algos/triangles.rs:25-110                  -> cz_clustering_coefficients
 //   DegreeCentrality             fixed_rule/algos/degree_centrality.rs:24-76           (a scan with counters: host only)
-//   ClosenessCentrality          fixed_rule/algos/all_pairs_shortest_path.rs:97-176    -> cz_sssp from every node
+//   ClosenessCentrality          fixed_rule/algos/all_pairs_shortest_path.rs:97-176    -> cz_closeness
 //   BetweennessCentrality        fixed_rule/algos/all_pairs_shortest_path.rs:31-95     -> cz_betweenness
 //   LabelPropagation             fixed_rule/algos/label_propagation.rs:27-109          -> cz_label_propagation (one fixed execution)
 //                                                                                      accumulation on the tight-edge DAG (host)

@@ -302,30 +302,12 @@ void ClosenessCentrality::run(const FixedRulePayload &payload, RegularTempStore 
     const DirectedCsrGraph &gr = g.graph;
     const uint32_t n = gr.n;
     if (n == 0) return;
-    constexpr uint32_t kBatch = 256;  // starts per cz_sssp call (dist / parent are [starts][n])
-    std::vector<float> dist((size_t)std::min(n, kBatch) * n);
-    std::vector<uint32_t> parent(dist.size());
-    std::vector<uint32_t> starts;
-    for (uint32_t b0 = 0; b0 < n; b0 += kBatch) {
-        const uint32_t nb = std::min(kBatch, n - b0);
-        starts.resize(nb);
-        for (uint32_t i = 0; i < nb; i++) starts[i] = b0 + i;
-        check_gpu(cz_sssp(gr.out_offsets.data(), gr.out_targets.data(), gr.out_weights.data(), n, gr.edge_count(), starts.data(),
-                          nb, dist.data(), parent.data(), poison.flag_ptr()));
-        for (uint32_t i = 0; i < nb; i++) {
-            // all_pairs_shortest_path.rs:118-122, f32 throughout: total = sum of the finite distances in node order
-            const float *d = dist.data() + (size_t)i * n;
-            float total = 0.0f, nc = 0.0f;
-            for (uint32_t v = 0; v < n; v++)
-                if (std::isfinite(d[v])) {
-                    total = total + d[v];
-                    nc = nc + 1.0f;
-                }
-            const float c = nc * nc / total / (float)(n - 1);
-            out.put(Tuple{g.indices[b0 + i], DataValue((double)c)});
-        }
-        poison.check();
-    }
+    // all_pairs_shortest_path.rs:113-144: the all-sources SSSP and the per-start f32 sums (:118-122) both run on the device
+    std::vector<double> cent(n, 0.0);
+    check_gpu(cz_closeness(gr.out_offsets.data(), gr.out_targets.data(), gr.out_weights.data(), n, gr.edge_count(), cent.data(),
+                           poison.flag_ptr()));
+    poison.check();
+    for (uint32_t v = 0; v < n; v++) out.put(Tuple{g.indices[v], DataValue(cent[v])});
 }
 
 // ---- BetweennessCentrality (algos/all_pairs_shortest_path.rs:31-95 over dijkstra_keep_ties) -----------------------

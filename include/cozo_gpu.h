@@ -380,12 +380,18 @@ int cz_connected_components_on(const cz_graph *g, uint32_t *group, uint32_t *n_g
 int cz_sssp_on(const cz_graph *g, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent,
                const volatile uint8_t *poison);
 
-/* Where the last cz_bfs / cz_connected_components / cz_sssp / cz_clustering_coefficients / cz_betweenness /
- * cz_label_propagation call of THIS
+/* Where the last cz_bfs / cz_connected_components / cz_sssp / cz_clustering_coefficients / cz_closeness /
+ * cz_betweenness / cz_label_propagation call of THIS
  * host thread spent its wall time, in milliseconds (any pointer may be null): these entry points take host arrays
  * (FixedRule::run hands over a relation, fixed_rule/mod.rs:538-567), so a call is upload (allocation + CSR over PCIe) +
  * device (kernels and their control round trips) + download (per-node results back). */
 int cz_graph_last_timing(double *upload_ms, double *device_ms, double *download_ms);
+
+/* ClosenessCentrality::run (fixed_rule/algos/all_pairs_shortest_path.rs:97-176) on the weighted out-CSR (weights >= 0):
+ *   centrality [N] f64 out = nc * nc / total / (N - 1) computed in f32 like :118-122, total = the finite dijkstra_cost_only
+ *   distances from the node summed one after the other in node order, nc = their count (bit-identical to the reference). */
+int cz_closeness(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
+                 double *centrality, const volatile uint8_t *poison);
 
 /* BetweennessCentrality::run (fixed_rule/algos/all_pairs_shortest_path.rs:31-95 over dijkstra_keep_ties,
  * shortest_path_dijkstra.rs:341-450) on the weighted out-CSR, weights > 0:

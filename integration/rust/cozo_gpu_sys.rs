@@ -200,6 +200,8 @@ extern "C" {
     pub fn cz_label_propagation(out_offsets: *const u32, out_targets: *const u32, weights: *const c_float, n: u32, e: u64,
                                 max_iter: u32, labels: *mut u32, iters_run: *mut u32, n_colours: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_graph_last_timing(upload_ms: *mut c_double, device_ms: *mut c_double, download_ms: *mut c_double) -> c_int;
+    pub fn cz_closeness(out_offsets: *const u32, out_targets: *const u32, weights: *const c_float, n: u32, e: u64,
+                        centrality: *mut c_double, poison: *const u8) -> c_int;
     pub fn cz_betweenness(out_offsets: *const u32, out_targets: *const u32, weights: *const c_float, n: u32, e: u64,
                           centrality: *mut c_double, poison: *const u8) -> c_int;
 }

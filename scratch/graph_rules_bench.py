@@ -79,6 +79,10 @@ def all_sources():
     dt = time.perf_counter() - t0
     print(f"all-sources cz_sssp: {n} starts on {n} nodes / {tgt.size} edges in batches of 256: {dt:.2f} s "
           f"({n * tgt.size / dt / 1e9:.2f} G edge relaxations-equivalent/s, {dt / n * 1e3:.3f} ms per start)", flush=True)
+    t0 = time.perf_counter()
+    cc = G.closeness(off, tgt, w)
+    dt = time.perf_counter() - t0
+    print(f"cz_closeness: {n} nodes / {tgt.size} edges: {dt:.2f} s (device {G.last_timing()[1] / 1e3:.2f} s), max {np.nanmax(cc[np.isfinite(cc)]):.4f}", flush=True)
     G.betweenness(off[:2001].copy(), tgt[:off[2000]] % 2000, w[:off[2000]])  # warm
     t0 = time.perf_counter()
     c = G.betweenness(off, tgt, w)

@@ -3,6 +3,7 @@
  * tests/cpp/test_host is linked against THIS library ahead of libcozo_gpu.so for its `rules-cpu` mode, exactly like
  * tests/util.py's OracleGraphBackend stands in for cozo_amd.graph in the Python rule tests.  Never shipped, never loaded
  * by the product. */
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -133,5 +134,28 @@ int cz_label_propagation(const uint32_t *out_offsets, const uint32_t *out_target
     if (it < 0) { g_err = "a best score is NaN"; return CZ_E_INVALID; }
     if (iters_run) *iters_run = (uint32_t)it;
     if (n_colours) *n_colours = k;
+    return CZ_OK;
+}
+
+int cz_closeness(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
+                 double *centrality, const volatile uint8_t *poison) {
+    (void)E;
+    if (poisoned(poison)) { g_err = "cancelled"; return CZ_E_CANCELLED; }
+    uint64_t *off = widen(out_offsets, N);
+    float *dist = (float *)malloc(sizeof(float) * (N ? N : 1));
+    uint32_t *par = (uint32_t *)malloc(sizeof(uint32_t) * (N ? N : 1));
+    for (uint32_t s = 0; s < N; s++) { /* all_pairs_shortest_path.rs:118-122, f32 throughout */
+        orc_dijkstra(N, off, out_targets, weights, s, NULL, 0, dist, par);
+        float total = 0.0f, nc = 0.0f;
+        for (uint32_t v = 0; v < N; v++)
+            if (isfinite(dist[v])) {
+                total = total + dist[v];
+                nc = nc + 1.0f;
+            }
+        centrality[s] = (double)(nc * nc / total / (float)(N - 1));
+    }
+    free(dist);
+    free(par);
+    free(off);
     return CZ_OK;
 }

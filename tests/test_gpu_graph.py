@@ -607,3 +607,28 @@ def test_resident_graphs_and_their_cache(oracle, gpu_lib, monkeypatch):
     _lib.lib().cz_graph_cache_clear()
     assert not G.DeviceGraph.acquire((905, 0), u["ooff"], u["otgt"]).cache_hit
     _lib.lib().cz_graph_cache_clear()
+
+
+@pytest.mark.parametrize("batch", [None, "9"])
+def test_closeness_matches_the_reference_arithmetic(oracle, gpu_lib, monkeypatch, batch):
+    """cz_closeness (all_pairs_shortest_path.rs:97-176): per node, the oracle's Dijkstra costs summed in f32 in node order,
+    nc * nc / total / (n - 1) -- bit for bit, unreachable nodes, isolated nodes (0 / 0 -> NaN... 1 / 0 -> inf) included"""
+    from cozo_amd import graph as G
+    if batch:
+        monkeypatch.setenv("CZ_BC_BATCH", batch)
+    rng = np.random.default_rng(21)
+    frm, to = util.random_relation(400, 1500, 6)
+    w = (rng.integers(0, 30, len(frm)) / 8).astype(np.float32)  # zero weights too
+    g = util.graph_from_relation(oracle, frm, to, weights=w)
+    n = g["n"]
+    got = G.closeness(g["ooff"], g["otgt"], g["ow"])
+    want = np.empty(n, dtype=np.float64)
+    for s in range(n):
+        d, _ = oracle.dijkstra(n, g["ooff"], g["otgt"], g["ow"], s)
+        fin = d[np.isfinite(d)]
+        total = np.cumsum(fin, dtype=np.float32)[-1]
+        nc = np.float32(fin.size)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            want[s] = np.float32(np.float32(nc * nc) / total) / np.float32(n - 1)
+    assert np.array_equal(got, want, equal_nan=True)
+    assert np.isinf(want).any() or (want > 0).all()

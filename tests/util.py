@@ -62,7 +62,7 @@ class OracleGraphBackend:
 
     def install(self, monkeypatch):
         import cozo_amd.graph as G
-        for name in ("pagerank", "bfs", "connected_components", "sssp", "clustering_coefficients", "betweenness", "label_propagation"):
+        for name in ("pagerank", "bfs", "connected_components", "sssp", "clustering_coefficients", "betweenness", "label_propagation", "closeness"):
             monkeypatch.setattr(G, name, getattr(self, name))
 
     def pagerank(self, in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10, poison=None):
@@ -110,6 +110,18 @@ class OracleGraphBackend:
         colour, k = self.O.lp_colouring(n, out_off, out_tgt)
         labels, it = self.O.label_propagation(n, out_off, out_tgt, weights, max_iter)
         return labels, it, k
+
+    def closeness(self, out_off, out_tgt, weights, poison=None):
+        n = len(out_off) - 1
+        out = np.zeros(n, dtype=np.float64)
+        for s in range(n):  # all_pairs_shortest_path.rs:118-122, f32 throughout
+            d, _ = self.O.dijkstra(n, out_off, out_tgt, weights, s)
+            fin = d[np.isfinite(d)]
+            total = np.cumsum(fin, dtype=np.float32)[-1]
+            nc = np.float32(fin.size)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                out[s] = np.float32(np.float32(nc * nc) / total) / np.float32(n - 1)
+        return out
 
     def betweenness(self, out_off, out_tgt, weights, poison=None):
         return self.O.betweenness(len(out_off) - 1, out_off, out_tgt, weights, max_paths=200_000_000).astype(np.float64)
