@@ -95,6 +95,17 @@ def bfs_sharded(comm: Comm, off_local, tgt, n: int, row_begin: int, row_end: int
     return parent, depth, order, reached
 
 
+def connected_components_sharded(comm: Comm, off_local, tgt, n: int, row_begin: int, row_end: int, poison=None):
+    """ConnectedComponents over a vertex partition of the symmetrised graph, collectively (cz_connected_components_sharded)
+    -> (group u32 [n], n_groups, rounds): the same rows on every rank, the single-GPU rule's numbering"""
+    off_local, tgt = _shard_csr(off_local, tgt)
+    grp = np.empty(n, dtype=np.uint32)
+    k, rounds = C.c_uint32(0), C.c_uint32(0)
+    check(_lib.lib().cz_connected_components_sharded(comm._h, ptr(off_local), ptr(tgt), n, row_begin, row_end, tgt.size, ptr(grp),
+                                                     C.byref(k), C.byref(rounds), ptr(poison)))
+    return grp, k.value, rounds.value
+
+
 def sssp_sharded(comm: Comm, off_local, tgt, weights, n: int, row_begin: int, row_end: int, starts, poison=None):
     """ONE SSSP per start over a vertex-partitioned graph, collectively (cz_sssp_sharded) -> (dist f32, parent) [starts][n]"""
     off_local, tgt = _shard_csr(off_local, tgt)

@@ -2167,3 +2167,126 @@ extern "C" int cz_sssp_sharded(cz_comm *comm, const uint32_t *out_offsets_local,
     }
     return CZ_OK;
 }
+
+// ---- ConnectedComponents over a vertex partition (czs::run_sharded_cc): an all-reduce(min) of the N pointers per round ----------
+namespace {
+
+__global__ void __launch_bounds__(kT)
+cc_link_rows_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t rb, uint32_t re, uint32_t *__restrict__ comp) {
+    const uint32_t glane = threadIdx.x & (kCcLanes - 1);
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kCcLanes, ngroups = gridDim.x * blockDim.x / kCcLanes;
+    for (uint32_t u = rb + group; u < re; u += ngroups) {
+        const uint32_t e1 = off[u - rb + 1];
+        for (uint32_t e = off[u - rb] + glane; e < e1; e += kCcLanes) cc_link(u, tgt[e], comp);
+    }
+}
+
+__global__ void __launch_bounds__(kT)
+cc_differs_kernel(const uint32_t *__restrict__ a, uint32_t *__restrict__ prev, uint32_t N, uint32_t *__restrict__ flag) {
+    bool d = false;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const uint32_t x = a[i];
+        if (x != prev[i]) {
+            d = true;
+            prev[i] = x;
+        }
+    }
+    if (d) *flag = 1;
+}
+
+struct HipShardedCc {
+    cz_comm *comm;
+    hipStream_t s;
+    uint32_t N, rb, re;
+    cz::DevBuf<uint32_t> off, tgt, comp, prev, flag, rank, scratch, misc;
+
+    int alloc(const uint32_t *h_off, const uint32_t *h_tgt, uint64_t e_local) {
+        const uint32_t rows = re - rb;
+        CZ_HIP(off.alloc((size_t)rows + 1));
+        CZ_HIP(tgt.alloc(e_local));
+        CZ_HIP(comp.alloc(N));
+        CZ_HIP(prev.alloc(N));
+        CZ_HIP(flag.alloc(N));
+        CZ_HIP(rank.alloc(N));
+        CZ_HIP(scratch.alloc(scan_scratch_words(N)));
+        CZ_HIP(misc.alloc(4));
+        CZ_HIP(hipMemcpy(off.p, h_off, ((size_t)rows + 1) * 4, hipMemcpyHostToDevice));
+        if (e_local) CZ_HIP(hipMemcpy(tgt.p, h_tgt, e_local * 4, hipMemcpyHostToDevice));
+        return CZ_OK;
+    }
+    int any_poisoned(bool mine, bool *any) {
+        const uint32_t v = mine ? 1u : 0u;
+        CZ_HIP(hipMemcpyAsync(misc.p + 2, &v, 4, hipMemcpyHostToDevice, s));
+        int rc = cz::comm_all_reduce(comm, misc.p + 2, 1, cz::COMM_U32, cz::COMM_SUM, s);
+        if (rc) return rc;
+        uint32_t h = 0;
+        CZ_HIP(hipMemcpyAsync(&h, misc.p + 2, 4, hipMemcpyDeviceToHost, s));
+        CZ_HIP(hipStreamSynchronize(s));
+        *any = h != 0;
+        return CZ_OK;
+    }
+    int cc_init() {
+        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(N)), dim3(kT), 0, s, comp.p, N);
+        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(N)), dim3(kT), 0, s, prev.p, N);
+        return CZ_OK;
+    }
+    int cc_local_round() {
+        if (re > rb)
+            hipLaunchKernelGGL(cc_link_rows_kernel, dim3(grid_for((uint64_t)(re - rb) * kCcLanes)), dim3(kT), 0, s, off.p, tgt.p, rb, re, comp.p);
+        hipLaunchKernelGGL(cc_compress_kernel, dim3(grid_for(N)), dim3(kT), 0, s, N, comp.p);
+        return CZ_OK;
+    }
+    int reduce_labels() { return cz::comm_all_reduce(comm, comp.p, N, cz::COMM_U32, cz::COMM_MIN, s); }
+    int cc_settle(bool *changed) {
+        hipLaunchKernelGGL(cc_compress_kernel, dim3(grid_for(N)), dim3(kT), 0, s, N, comp.p);
+        CZ_HIP(hipMemsetAsync(misc.p, 0, 4, s));
+        hipLaunchKernelGGL(cc_differs_kernel, dim3(grid_for(N)), dim3(kT), 0, s, comp.p, prev.p, N, misc.p);
+        uint32_t h = 0;
+        CZ_HIP(hipMemcpyAsync(&h, misc.p, 4, hipMemcpyDeviceToHost, s));
+        CZ_HIP(hipStreamSynchronize(s));
+        *changed = h != 0;
+        return CZ_OK;
+    }
+    int cc_number_groups() {
+        hipLaunchKernelGGL(cc_rootflag_kernel, dim3(grid_for(N)), dim3(kT), 0, s, N, comp.p, flag.p);
+        int rc = exclusive_scan(flag.p, rank.p, N, misc.p, scratch.p, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(cc_group_kernel, dim3(grid_for(N)), dim3(kT), 0, s, N, comp.p, rank.p, flag.p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sharded cc launch: %s", hipGetErrorString(e));
+        return CZ_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" int cz_connected_components_sharded(cz_comm *comm, const uint32_t *offsets_local, const uint32_t *targets, uint32_t N,
+                                               uint32_t row_begin, uint32_t row_end, uint64_t E_local, uint32_t *group,
+                                               uint32_t *n_groups, uint32_t *rounds, const volatile uint8_t *poison) {
+    if (n_groups) *n_groups = 0;
+    if (rounds) *rounds = 0;
+    if (!comm) return cz::set_error(CZ_E_INVALID, "null communicator");
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if (N == 0) return CZ_OK;
+    if (!group) return cz::set_error(CZ_E_INVALID, "null group");
+    if ((rc = check_shard(offsets_local, targets, N, row_begin, row_end, E_local))) return rc;
+    for (uint64_t e = 0; e < E_local; e++)
+        if (targets[e] >= N) return cz::set_error(CZ_E_INVALID, "target %u out of range", targets[e]);
+    HipShardedCc b;
+    b.comm = comm;
+    b.s = nullptr;
+    b.N = N;
+    b.rb = row_begin;
+    b.re = row_end;
+    if ((rc = b.alloc(offsets_local, targets, E_local))) return rc;
+    rc = czs::run_sharded_cc(b, poison, rounds);
+    if (rc == czs::TRAVERSAL_CANCELLED) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+    if (rc) return rc;
+    CZ_HIP(hipMemcpy(group, b.flag.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    uint32_t total = 0;
+    CZ_HIP(hipMemcpy(&total, b.misc.p, 4, hipMemcpyDeviceToHost));
+    if (n_groups) *n_groups = total;
+    return CZ_OK;
+}
+

@@ -1,5 +1,5 @@
-// sharded_traversal.hpp -- ONE BFS / ONE SSSP over a graph whose vertices are partitioned across ranks (SURVEY.md section 8e,
-// third row), written once against a backend interface like sharded_pagerank.hpp:
+// sharded_traversal.hpp -- ONE BFS / ONE SSSP / ConnectedComponents over a graph whose vertices are partitioned across ranks
+// (third row), written once against a backend interface like sharded_pagerank.hpp:
 //   * libcozo_gpu instantiates the loops with the HIP + RCCL backend (graph.hip: cz_bfs_sharded / cz_sssp_sharded);
 //   * tests/cpp/sharded_driver_test.cpp instantiates the SAME loops with a host backend whose exchange steps run over
 //     torch.distributed/gloo with world_size 2, and compares with the single-process oracle.
@@ -115,6 +115,39 @@ int run_sharded_sssp(B &b, uint32_t start, uint32_t N, const volatile uint8_t *p
     }
     if ((rc = b.sssp_canonical_parents())) return rc;
     return b.reduce_canonical();
+}
+
+// ConnectedComponents over a vertex partition of the SYMMETRISED graph (strongly_connected_components.rs:42-77, strong = false;
+// an all-reduce(min) of the u32 label vector per round).  `comp` is a forest over all N nodes whose
+// pointers always lead to a lower-or-equal index of the same component, identical on every rank at round boundaries:
+//   round   every rank links the endpoints of ITS rows' edges in its copy (union-find, higher root under lower) and compresses;
+//           all-reduce(min) of the N pointers -- the elementwise minimum of such forests is such a forest --; compress again
+//   stop    when a round leaves the forest as it found it: then no edge of any rank joins two trees, and a root is the smallest
+//           member of its component -- the label the reference's group numbering is the rank of.
+// Backend interface:
+//   int cc_init()                               comp = prev = 0 .. N-1
+//   int cc_local_round()                        link the endpoints of every local edge in comp; compress
+//   int reduce_labels()                         all-reduce(min) over the N words of comp
+//   int cc_settle(bool *changed)                compress comp; *changed = comp != prev (the same on every rank); prev = comp
+//   int cc_number_groups()                      group[v] = rank of comp[v] among the roots, ascending
+template <class B>
+int run_sharded_cc(B &b, const volatile uint8_t *poison, uint32_t *rounds_out) {
+    int rc;
+    uint32_t rounds = 0;
+    if ((rc = b.cc_init())) return rc;
+    for (;;) {
+        bool cancel = false;
+        if ((rc = b.any_poisoned(poison && *poison, &cancel))) return rc;
+        if (cancel) return TRAVERSAL_CANCELLED;
+        if ((rc = b.cc_local_round())) return rc;
+        if ((rc = b.reduce_labels())) return rc;
+        bool changed = false;
+        if ((rc = b.cc_settle(&changed))) return rc;
+        rounds++;
+        if (!changed) break;
+    }
+    if (rounds_out) *rounds_out = rounds;
+    return b.cc_number_groups();
 }
 
 }  // namespace czs

@@ -322,6 +322,16 @@ int cz_sssp_sharded(cz_comm *comm, const uint32_t *out_offsets_local, const uint
                     uint32_t N, uint32_t row_begin, uint32_t row_end, uint64_t E_local, const uint32_t *starts,
                     uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison);
 
+/* ConnectedComponents (strongly_connected_components.rs:42-77, strong = false) over a vertex partition of the SYMMETRISED
+ * graph, collectively: this rank passes the adjacency of [row_begin, row_end) (offsets relative to the shard).  Per round every
+ * rank links the endpoints of its rows' edges in its copy of one forest over all N nodes (pointers lead to lower indices of
+ * the same component), the N pointers are all-reduced(min), and the rounds stop when one leaves the forest unchanged; group
+ * ids are numbered like cz_connected_components' (rank of the component by its smallest node), identical on every rank.
+ * rounds (optional) = rounds run. */
+int cz_connected_components_sharded(cz_comm *comm, const uint32_t *offsets_local, const uint32_t *targets, uint32_t N,
+                                    uint32_t row_begin, uint32_t row_end, uint64_t E_local, uint32_t *group, uint32_t *n_groups,
+                                    uint32_t *rounds, const volatile uint8_t *poison);
+
 /* ShortestPathBFS::run (fixed_rule/algos/shortest_path_bfs.rs:35-113) and the traversal of Bfs::run
  * (algos/bfs.rs:25-113) on the out-CSR (neighbours in sorted order = the KV prefix-scan order).
  *   starts [n_starts]: one BFS per start.  goals [n_goals] or NULL (NULL: full traversal; with goals the

@@ -170,6 +170,9 @@ extern "C" {
                                   ef: u32, id_offset: u64, out_ids_dev: *mut u64, out_dist_dev: *mut c_double,
                                   out_count_dev: *mut u32, stream: *mut c_void) -> c_int;
 
+    pub fn cz_connected_components_sharded(comm: *mut cz_comm, offsets_local: *const u32, targets: *const u32, n: u32, row_begin: u32,
+                                           row_end: u32, e_local: u64, group: *mut u32, n_groups: *mut u32, rounds: *mut u32,
+                                           poison: *const u8) -> c_int;
     pub fn cz_bfs_sharded(comm: *mut cz_comm, out_offsets_local: *const u32, out_targets: *const u32, n: u32, row_begin: u32,
                           row_end: u32, e_local: u64, starts: *const u32, n_starts: u32, goals: *const u32, n_goals: u32,
                           share_visited: c_int, parent: *mut u32, depth: *mut u32, order: *mut u32, n_reached: *mut u32,

@@ -359,3 +359,93 @@ extern "C" int cz_test_sharded_sssp_host(uint32_t N, uint32_t rb, uint32_t re, c
     }
     return rc;
 }
+
+// ---- ConnectedComponents over a vertex partition (czs::run_sharded_cc) with a host backend ---------------------------------------
+namespace {
+
+struct HostCc {
+    uint32_t N, rb, re;
+    const uint64_t *off;  // local rows of the symmetrised graph
+    const uint32_t *tgt;
+    void *ctx;
+    cz_test_all_reduce_u32 ar32;
+    std::vector<uint32_t> comp, prev, group;
+    uint32_t n_groups = 0;
+    int exchanges = 0;
+
+    uint32_t root(uint32_t v) const {
+        while (comp[v] != v) v = comp[v];
+        return v;
+    }
+    void compress() {
+        for (uint32_t v = 0; v < N; v++) comp[v] = root(v);  // ascending: comp[comp[v]] is final already
+    }
+    int any_poisoned(bool mine, bool *any) {
+        uint32_t v = mine ? 1u : 0u;
+        const int rc = ar32(ctx, &v, 1, 0);
+        exchanges++;
+        *any = v != 0;
+        return rc;
+    }
+    int cc_init() {
+        comp.resize(N);
+        for (uint32_t v = 0; v < N; v++) comp[v] = v;
+        prev = comp;
+        return 0;
+    }
+    int cc_local_round() {
+        for (uint32_t u = rb; u < re; u++)
+            for (uint64_t e = off[u - rb]; e < off[u - rb + 1]; e++) {
+                const uint32_t a = root(u), b = root(tgt[e]);
+                if (a != b) comp[std::max(a, b)] = std::min(a, b);  // the higher root goes under the lower
+            }
+        compress();
+        return 0;
+    }
+    int reduce_labels() {
+        exchanges++;
+        return ar32(ctx, comp.data(), N, 1);
+    }
+    int cc_settle(bool *changed) {
+        compress();
+        *changed = comp != prev;
+        prev = comp;
+        return 0;
+    }
+    int cc_number_groups() {
+        std::vector<uint32_t> rank(N, 0);
+        uint32_t k = 0;
+        for (uint32_t v = 0; v < N; v++)
+            if (comp[v] == v) rank[v] = k++;
+        group.resize(N);
+        for (uint32_t v = 0; v < N; v++) group[v] = rank[comp[v]];
+        n_groups = k;
+        return 0;
+    }
+};
+
+}  // namespace
+
+// counters [2] = rounds, exchanges
+extern "C" int cz_test_sharded_cc_host(uint32_t N, uint32_t rb, uint32_t re, const uint64_t *off_local, const uint32_t *tgt,
+                                       const volatile uint8_t *poison, void *ctx, cz_test_all_reduce_u32 ar32, uint32_t *group,
+                                       uint32_t *n_groups, uint32_t *counters) {
+    HostCc b;
+    b.N = N;
+    b.rb = rb;
+    b.re = re;
+    b.off = off_local;
+    b.tgt = tgt;
+    b.ctx = ctx;
+    b.ar32 = ar32;
+    uint32_t rounds = 0;
+    const int rc = czs::run_sharded_cc(b, poison, &rounds);
+    if (rc == 0) {
+        std::memcpy(group, b.group.data(), (size_t)N * 4);
+        *n_groups = b.n_groups;
+    }
+    counters[0] = rounds;
+    counters[1] = (uint32_t)b.exchanges;
+    return rc;
+}
+

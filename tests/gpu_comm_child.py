@@ -87,6 +87,13 @@ def main():
     want, _ = O.dijkstra(gw["n"], gw["ooff"], gw["otgt"], gw["ow"], 7)
     assert np.array_equal(d1[1], want)
     print("OK bfs_sharded / sssp_sharded", flush=True)
+    from cozo_amd.comm import connected_components_sharded
+    fr2, to2 = util.random_relation(30000, 28000, 9)  # sparse: hundreds of components
+    gu = util.graph_from_relation(O, fr2, to2, undirected=True)
+    g0, k0 = G.connected_components(gu["ooff"], gu["otgt"])
+    g1, k1, rounds = connected_components_sharded(comm, gu["ooff"], gu["otgt"], gu["n"], 0, gu["n"])
+    assert k0 == k1 and k0 > 100 and np.array_equal(g0, g1) and rounds >= 1, "cz_connected_components_sharded differs"
+    print(f"OK connected_components_sharded ({k1} components, {rounds} rounds)", flush=True)
     comm.close()
     print("ALL OK", flush=True)
 

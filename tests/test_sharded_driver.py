@@ -191,6 +191,15 @@ def _traversal_worker(rank, world, port, what, g, start, goals, poison_at, q):
                                         poison.ctypes.data, None, ar32, ar64, parent.ctypes.data, depth.ctypes.data,
                                         order.ctypes.data, C.byref(reached))
         q.put((rank, rc, parent, depth, order[:reached.value].copy(), reached.value))
+    elif what == "cc":
+        group = np.empty(n, np.uint32)
+        k = C.c_uint32(0)
+        counters = np.zeros(2, np.uint32)
+        L.cz_test_sharded_cc_host.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, ARU32,
+                                              C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]
+        rc = L.cz_test_sharded_cc_host(n, rb, re, off_local.ctypes.data, tgt.ctypes.data, poison.ctypes.data, None, ar32,
+                                       group.ctypes.data, C.byref(k), counters.ctypes.data)
+        q.put((rank, rc, group, k.value, counters.copy()))
     else:
         w = np.ascontiguousarray(g["ow"][int(ooff[rb]):int(ooff[re])], dtype=np.float32)
         dist_out = np.empty(n, np.float32)
@@ -269,3 +278,29 @@ def test_vertex_partitioned_bfs_cancellation_is_collective(oracle):
     g = util.graph_from_relation(oracle, frm, to)
     out = _run_traversal("bfs", g, 0, poison_at=(1, 4))
     assert [o[1] for o in out] == [1, 1]  # czs::TRAVERSAL_CANCELLED on both ranks, at the same level
+
+
+@pytest.mark.parametrize("n,e,seed", [(500, 420, 1), (3000, 2500, 2), (2000, 9000, 3), (40, 0, 4)])
+def test_vertex_partitioned_cc_world2_numbers_the_groups_like_the_rule(oracle, n, e, seed):
+    """ConnectedComponents over a 2-way vertex partition of the symmetrised graph (one all-reduce(min) of the pointer vector
+    per round, the loop of sharded_traversal.hpp with a host backend over gloo) == Tarjan's numbering over ascending roots (the
+    oracle), on both ranks; sparse graphs with hundreds of components, a dense one, one without edges"""
+    if e:
+        frm, to = util.random_relation(n, e, seed)
+        g = util.graph_from_relation(oracle, frm, to, undirected=True)
+    else:
+        g = dict(n=n, ooff=np.zeros(n + 1, dtype=np.uint64), otgt=np.zeros(0, dtype=np.uint32))
+    want, want_k = oracle.tarjan_groups(g["n"], g["ooff"], g["otgt"])
+    out = _run_traversal("cc", g, 0)
+    for _, rc, group, k, counters in out:
+        assert rc == 0 and k == want_k and np.array_equal(group, want)
+        assert 1 <= counters[0] <= 8 and counters[1] == 2 * counters[0]  # per round: the cancellation word + the labels
+    assert np.array_equal(out[0][4], out[1][4])
+
+
+def test_vertex_partitioned_cc_cancellation_is_collective(oracle):
+    frm, to = util.random_relation(3000, 2500, 7)
+    g = util.graph_from_relation(oracle, frm, to, undirected=True)
+    out = _run_traversal("cc", g, 0, poison_at=(1, 1))
+    assert [o[1] for o in out] == [1, 1]
+
