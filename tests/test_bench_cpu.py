@@ -30,3 +30,24 @@ def test_host_ingest_leg_runs_without_a_device():
     json.dumps(out)  # goes into the bench line
     assert out["rows"] > 20_000 and out["nodes"] == 3_000 and out["rows_per_s"] > 0
     assert out["id_assignment_s"] > 0 and out["csr_both_s"] > 0 and out["threads"] >= 1
+
+
+def test_pmc_traffic_is_tied_to_kernels_and_workload():
+    """roofline.traffic comes from the committed PMC summary only for the kernels AND the workload it was measured on"""
+    b = _bench()
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        d = json.load(f)
+    for key in ("hnsw_knn", "distance_batch", "pagerank_blocked"):
+        ent = d[key]
+        if ent["source_hash"] != b.kernel_source_hash(key):  # the kernels changed since the summary was taken: no traffic figure
+            assert b.pmc_traffic(key, 1, ent["algorithmic_bytes"]) is None
+            continue
+        assert b.pmc_traffic(key, 1, ent["algorithmic_bytes"]) == ent["bytes_per_launch"]
+        assert b.pmc_traffic(key, 1, ent["algorithmic_bytes"] * 10) is None   # another size: not this measurement
+        assert b.pmc_traffic(key, 8, ent["algorithmic_bytes"]) is None        # N > 1: not this measurement
+        assert ent["bytes_per_launch"] >= ent["algorithmic_bytes"] * 0.98     # traffic below the algorithmic bytes would be a model error
+
+
+def test_thread_ladder_is_sane():
+    ladder, usable = _bench().thread_ladder()
+    assert usable >= 1 and ladder == sorted(set(ladder)) and ladder[-1] == usable and all(1 <= t <= usable for t in ladder)

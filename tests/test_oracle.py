@@ -217,3 +217,39 @@ def test_clustering_coefficients_against_matrix_powers(oracle):
     off, tgt = oracle.build_csr(3, f, t)
     cc, tri, deg = oracle.clustering_coefficients(3, off, tgt)
     assert deg.tolist() == [3, 3, 2] and tri.tolist() == [2, 2, 1]
+
+
+def test_label_propagation_fixed_order_is_a_fixpoint_of_the_reference_rule(oracle):
+    """orc_label_propagation_in_order (label_propagation.rs:56-109 with the order and the tie-break handed in): when the loop
+    stops before max_iter, every node's label is one of the best-scored labels among its out-neighbours (what :77-91 leaves
+    behind), whatever order was handed in; and the colouring is proper (no edge inside a class, either direction)."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    n = 300
+    frm = rng.integers(0, n, 1500)
+    to = (frm // 30) * 30 + rng.integers(0, 30, frm.size)  # ten planted groups
+    frm, to = np.concatenate([frm, to]), np.concatenate([to, frm])
+    order = np.lexsort((to, frm))
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(np.bincount(frm, minlength=n))
+    tgt = to[order].astype(np.uint32)
+    w = (rng.integers(1, 5, tgt.size) / 2).astype(np.float32)
+    colour, k = oracle.lp_colouring(n, off, tgt)
+    src = np.repeat(np.arange(n), np.diff(off).astype(np.int64))
+    assert k >= 2 and (colour[src[src != tgt]] != colour[tgt[src != tgt]]).all()
+    for node_order in (np.arange(n, dtype=np.uint32), rng.permutation(n).astype(np.uint32),
+                       np.lexsort((np.arange(n), colour)).astype(np.uint32)):
+        labels, it = oracle.label_propagation_in_order(n, off, tgt, w, node_order, 50)
+        assert it < 50
+        for v in range(n):
+            lo, hi = int(off[v]), int(off[v + 1])
+            if lo == hi:
+                assert labels[v] == v
+                continue
+            score = {}
+            for e in range(lo, hi):
+                lab = int(labels[tgt[e]])
+                score[lab] = np.float32(score.get(lab, np.float32(0.0)) + w[e])
+            best = max(score.values())
+            assert labels[v] == min(lab for lab, sc in score.items() if sc == best)
+    assert len(np.unique(labels)) <= 40
