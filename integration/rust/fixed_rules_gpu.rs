@@ -252,3 +252,129 @@ impl FixedRule for ConnectedComponentsGpu {
         Ok(2)
     }
 }
+
+// ---- the weighted rules ---------------------------------------------------------------------------------------------------
+// `as_directed_weighted_graph` (fixed_rule/mod.rs:208-328) flattened for the C ABI: graph_builder's sorted out-CSR with the
+// f32 values beside the targets.  (A stored relation goes through czi_graph_ingest + czi_graph_csr with a weights pointer,
+// exactly like `as_gpu_graph` above; the reference's route is shown here.)
+pub(crate) struct GpuWeightedGraph {
+    pub n: u32,
+    pub offsets: Vec<u32>,
+    pub targets: Vec<u32>,
+    pub weights: Vec<f32>,
+    pub indices: Vec<DataValue>,
+}
+impl<'a, 'b> FixedRuleInputRelation<'a, 'b> {
+    pub(crate) fn as_gpu_weighted_graph(&self, undirected: bool, allow_negative_weights: bool) -> Result<GpuWeightedGraph> {
+        let (graph, indices, _) = self.as_directed_weighted_graph(undirected, allow_negative_weights)?;
+        use graph::prelude::{DirectedNeighborsWithValues, Graph};
+        let n = graph.node_count();
+        let (mut offsets, mut targets, mut weights) = (vec![0u32], vec![], vec![]);
+        for u in 0..n {
+            for t in graph.out_neighbors_with_values(u) {
+                targets.push(t.target);
+                weights.push(t.value);
+            }
+            offsets.push(targets.len() as u32);
+        }
+        Ok(GpuWeightedGraph { n, offsets, targets, weights, indices })
+    }
+}
+
+/// fixed_rule/algos/all_pairs_shortest_path.rs:97-176 on the device: all-sources SSSP + the f32 sums per source (bit-identical).
+pub(crate) struct ClosenessCentralityGpu;
+impl FixedRule for ClosenessCentralityGpu {
+    fn run(&self, payload: FixedRulePayload<'_, '_>, out: &mut RegularTempStore, poison: Poison) -> Result<()> {
+        let edges = payload.get_input(0)?;
+        let undirected = payload.bool_option("undirected", Some(false))?;
+        let g = edges.as_gpu_weighted_graph(undirected, false)?;
+        if g.n == 0 {
+            return Ok(());
+        }
+        let mut cent = vec![0f64; g.n as usize];
+        check(unsafe {
+            cz_closeness(g.offsets.as_ptr(), g.targets.as_ptr(), g.weights.as_ptr(), g.n, g.targets.len() as u64, cent.as_mut_ptr(),
+                         poison_ptr(&poison))
+        }, &poison)?;
+        for (idx, c) in cent.iter().enumerate() {
+            out.put(vec![g.indices[idx].clone(), DataValue::from(*c)]);
+        }
+        Ok(())
+    }
+    fn arity(&self, _: &BTreeMap<SmartString<LazyCompact>, Expr>, _: &[Symbol], _: SourceSpan) -> Result<usize> {
+        Ok(2)
+    }
+}
+
+/// fixed_rule/algos/all_pairs_shortest_path.rs:31-95 on the device: path counts over the tight edges instead of the
+/// enumeration of every shortest path (f64 sums: within 1e-5 of the reference's f32 ones; weights must be positive).
+pub(crate) struct BetweennessCentralityGpu;
+impl FixedRule for BetweennessCentralityGpu {
+    fn run(&self, payload: FixedRulePayload<'_, '_>, out: &mut RegularTempStore, poison: Poison) -> Result<()> {
+        let edges = payload.get_input(0)?;
+        let undirected = payload.bool_option("undirected", Some(false))?;
+        let g = edges.as_gpu_weighted_graph(undirected, false)?;
+        if g.n == 0 {
+            return Ok(());
+        }
+        let mut cent = vec![0f64; g.n as usize];
+        check(unsafe {
+            cz_betweenness(g.offsets.as_ptr(), g.targets.as_ptr(), g.weights.as_ptr(), g.n, g.targets.len() as u64, cent.as_mut_ptr(),
+                           poison_ptr(&poison))
+        }, &poison)?;
+        for (idx, c) in cent.iter().enumerate() {
+            out.put(vec![g.indices[idx].clone(), DataValue::from(*c)]);
+        }
+        Ok(())
+    }
+    fn arity(&self, _: &BTreeMap<SmartString<LazyCompact>, Expr>, _: &[Symbol], _: SourceSpan) -> Result<usize> {
+        Ok(2)
+    }
+}
+
+/// fixed_rule/algos/label_propagation.rs:27-109 as ONE fixed execution of its randomised loop (colour classes of a
+/// deterministic colouring in ascending order, the smallest label on ties): what the reference can return, the same on every run.
+pub(crate) struct LabelPropagationGpu;
+impl FixedRule for LabelPropagationGpu {
+    fn run(&self, payload: FixedRulePayload<'_, '_>, out: &mut RegularTempStore, poison: Poison) -> Result<()> {
+        let edges = payload.get_input(0)?;
+        let undirected = payload.bool_option("undirected", Some(false))?;
+        let max_iter = payload.pos_integer_option("max_iter", Some(10))?;
+        let g = edges.as_gpu_weighted_graph(undirected, true)?;
+        if g.n == 0 {
+            return Ok(());
+        }
+        let mut labels = vec![0u32; g.n as usize];
+        check(unsafe {
+            cz_label_propagation(g.offsets.as_ptr(), g.targets.as_ptr(), g.weights.as_ptr(), g.n, g.targets.len() as u64,
+                                 max_iter.min(u32::MAX as usize) as u32, labels.as_mut_ptr(), std::ptr::null_mut(),
+                                 std::ptr::null_mut(), poison_ptr(&poison))
+        }, &poison)?;
+        for (idx, label) in labels.into_iter().enumerate() {
+            out.put(vec![DataValue::from(label as i64), g.indices[idx].clone()]); // (label, node), :41-44
+        }
+        Ok(())
+    }
+    fn arity(&self, _: &BTreeMap<SmartString<LazyCompact>, Expr>, _: &[Symbol], _: SourceSpan) -> Result<usize> {
+        Ok(2)
+    }
+}
+
+/// The costs and parents of ShortestPathDijkstra (fixed_rule/algos/shortest_path_dijkstra.rs:274-339) for a batch of starts, on
+/// a graph the library keeps between calls under the stored relation's identity: the route
+/// reconstruction and row emission of :70-153 stay as they are in the rule.
+pub(crate) fn sssp_on_held_graph(edges: &FixedRuleInputRelation<'_, '_>, undirected: bool, g: &GpuWeightedGraph, starts: &[u32],
+                                 poison: &Poison) -> Result<(Vec<f32>, Vec<u32>)> {
+    let (hi, lo) = edges.stored_identity()?.map_or((0, 0), |(rel_id, version)| (rel_id, (version << 2) | 2 | undirected as u64));
+    let mut held: *mut cz_graph = std::ptr::null_mut();
+    let mut hit: c_int = 0;
+    check(unsafe {
+        cz_graph_acquire(hi, lo, g.offsets.as_ptr(), g.targets.as_ptr(), g.weights.as_ptr(), g.n, g.targets.len() as u64, &mut held, &mut hit)
+    }, poison)?;
+    let mut dist = vec![0f32; starts.len() * g.n as usize];
+    let mut parent = vec![0u32; starts.len() * g.n as usize];
+    let rc = unsafe { cz_sssp_on(held, starts.as_ptr(), starts.len() as u32, dist.as_mut_ptr(), parent.as_mut_ptr(), poison_ptr(poison)) };
+    unsafe { cz_graph_release(hi, lo, held) }; // back into the cache, whatever the rule's outcome
+    check(rc, poison)?;
+    Ok((dist, parent))
+}
