@@ -661,6 +661,10 @@ struct cz_pagerank_plan {
     HubRow *d_hubs = nullptr;
     double *d_segsum = nullptr;
     double h2d_ms = 0, build_ms = 0;  // what creating the plan cost: CSR upload / static layout
+    // rows longer than a tile are single f32 chains on a handful of workgroups (pr_step_kernel): they run on a stream of their
+    // own beside the blocked sweep of the other rows (both read contrib_in, write disjoint rows), joined before the error sum
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // shared
     uint32_t *d_off = nullptr, *d_src = nullptr, *d_outdeg = nullptr;
     float *d_scores = nullptr;
@@ -670,6 +674,9 @@ struct cz_pagerank_plan {
                       d_hubs, d_segsum};
         for (void *p : ps)
             if (p) (void)hipFree(p);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
     }
 };
 
@@ -990,6 +997,20 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
     const uint32_t n_partial = p->n_gblocks + p->n_bblocks + p->n_hubs;
     if (n_partial == 0) return CZ_OK;
     if (p->blocked) {
+        const bool fork = p->n_gblocks > 0 && p->n_bblocks > 0;
+        if (fork) {
+            if (!p->side) {
+                CZ_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+                CZ_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+                CZ_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+            }
+            CZ_HIP(hipEventRecord(p->ev_fork, stream));  // contrib_in is ready where the caller's stream stands
+            CZ_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+            hipLaunchKernelGGL(pr_step_kernel, dim3(p->n_gblocks), dim3(kGThreads), 0, p->side, p->d_gblocks, p->d_off, p->d_src,
+                               p->d_outdeg, p->row_begin, contrib_in_dev, contrib_out_dev, p->d_scores, p->base, p->damping,
+                               p->d_partial + p->n_bblocks);
+            CZ_HIP(hipEventRecord(p->ev_join, p->side));
+        }
         for (uint32_t c = 0; c < p->n_chunks; c++) {
             const uint32_t i0 = p->item_ptr[c], i1 = p->item_ptr[c + 1];
             const uint32_t b0 = p->blk_ptr[c], b1 = p->blk_ptr[c + 1];
@@ -997,7 +1018,7 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
             if (i1 > i0)
                 hipLaunchKernelGGL(pb_expand_kernel, dim3(i1 - i0), dim3(kAThreads), 0, stream, p->d_items + i0, p->d_asrc,
                                    contrib_in_dev, p->N, p->wlog, val);
-            if (b1 > b0)
+            if (b1 > b0) {
                 if (p->d_vpos)
                     hipLaunchKernelGGL(pb_reduce_kernel<true>, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
                                        p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
@@ -1008,12 +1029,15 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
                                        p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
                                        contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap,
                                        p->d_segsum, p->relaxed ? 1 : 0);
+            }
         }
         if (p->n_hubs)  // relaxed: the hub rows' segment sums -> scores
             hipLaunchKernelGGL(pr_hub_finish_kernel, dim3((p->n_hubs + 255) / 256), dim3(256), 0, stream, p->d_hubs, p->n_hubs,
                                p->d_segsum, p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores, p->base, p->damping,
                                p->d_partial + p->n_bblocks + p->n_gblocks);
-        if (p->n_gblocks)  // rows longer than a tile
+        if (fork)
+            CZ_HIP(hipStreamWaitEvent(stream, p->ev_join, 0));
+        else if (p->n_gblocks)  // rows longer than a tile (and nothing else)
             hipLaunchKernelGGL(pr_step_kernel, dim3(p->n_gblocks), dim3(kGThreads), 0, stream, p->d_gblocks, p->d_off, p->d_src,
                                p->d_outdeg, p->row_begin, contrib_in_dev, contrib_out_dev, p->d_scores, p->base, p->damping,
                                p->d_partial + p->n_bblocks);
