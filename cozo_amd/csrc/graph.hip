@@ -437,11 +437,12 @@ __global__ void __launch_bounds__(kT)
 sssp_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t N,
                   const unsigned long long *__restrict__ cur, uint32_t n_cur, unsigned long long *__restrict__ dp,
                   uint32_t *__restrict__ qtag, uint32_t round_tag, uint32_t *__restrict__ ftag, uint32_t phase_tag,
-                  uint32_t thr_bits, SsspQueue near, SsspQueue far) {
+                  uint32_t thr_bits, SsspQueue near, SsspQueue far, uint32_t *__restrict__ zero_me) {
     const int lane = threadIdx.x & 63;
     const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes, ngroups = gridDim.x * blockDim.x / kSsspLanes;
     const uint32_t rounds = (n_cur + ngroups - 1) / ngroups;  // every group of the GRID runs the same trip count (ballots, barriers)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;  // the NEXT round's near counter (this round appends to the other one)
     __shared__ StagedPile st_near, st_far;
     if (threadIdx.x == 0) st_near.count = st_far.count = 0;
     __syncthreads();
@@ -1040,6 +1041,16 @@ struct SsspBatch {
     View<float> d_w;
     cz::DevBuf<uint32_t> d_qtag, d_ftag, d_misc, d_starts;
     cz::DevBuf<unsigned long long> d_dp, d_q[4];
+    uint32_t *h_pin = nullptr;  // the counters come back through pinned memory: a round is a launch and one 32-byte copy
+    ~SsspBatch() {
+        if (h_pin) (void)hipHostFree(h_pin);
+    }
+    int read_counters(uint32_t *h) {
+        CZ_HIP(hipMemcpyAsync(h_pin, d_misc.p, 32, hipMemcpyDeviceToHost, s));
+        CZ_HIP(hipStreamSynchronize(s));
+        memcpy(h, h_pin, 32);
+        return CZ_OK;
+    }
 
     int attach(const cz_graph &G, uint32_t n_starts, uint64_t pairs_budget) {
         N = G.N;
@@ -1052,6 +1063,7 @@ struct SsspBatch {
         d_tgt.p = G.tgt.p;
         d_w.p = G.w.p;
         CZ_HIP(d_misc.alloc(8));
+        if (!h_pin) CZ_HIP(hipHostMalloc((void **)&h_pin, 32));
         const double wsum = G.wsum;
         // bucket width of the near-far schedule: the mean edge weight (CZ_SSSP_DELTA overrides; <= 0 or "inf" = one pile,
         // i.e. plain frontier Bellman-Ford).  Only the schedule depends on it, never the result.
@@ -1070,7 +1082,8 @@ struct SsspBatch {
         return CZ_OK;
     }
 
-    // d_misc: [0] near-next count, [1] far count, [2] far-next count, [3] min far cost bits
+    // d_misc: [0] seed / split near count, [1] far count, [2] far-next count, [3] min far cost bits, [4], [5] the near counters of
+    // even / odd rounds (a round appends under its own and zeroes the other for the round after it: no memset per round)
     int run(const uint32_t *starts, uint32_t ns, const volatile uint8_t *poison) {
         const uint64_t nsN = (uint64_t)ns * N;
         hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, d_dp.p, nsN, kInfPacked);
@@ -1080,8 +1093,9 @@ struct SsspBatch {
         CZ_HIP(hipMemcpyAsync(d_starts.p, starts, (size_t)ns * 4, hipMemcpyHostToDevice, s));
         unsigned long long *near_cur = d_q[0].p, *near_next = d_q[1].p, *far_cur = d_q[2].p, *far_next = d_q[3].p;
         hipLaunchKernelGGL(sssp_seed_kernel, dim3((ns + kT - 1) / kT), dim3(kT), 0, s, d_starts.p, ns, N, d_dp.p, near_cur, d_misc.p);
-        uint32_t h[4];
-        CZ_HIP(hipMemcpy(h, d_misc.p, 16, hipMemcpyDeviceToHost));
+        uint32_t h[8];
+        int rc = read_counters(h);
+        if (rc) return rc;
         uint32_t n_near = h[0], n_far = 0, round = 1, phase = 1;
         float thr = one_pile ? INFINITY : delta;
         static const bool trace = getenv("CZ_SSSP_TRACE") != nullptr;  // per-round pile sizes on stderr (scratch/ experiments)
@@ -1089,14 +1103,14 @@ struct SsspBatch {
             while (n_near > 0) {
                 if (trace) fprintf(stderr, "sssp phase %u round %u thr %g near %u far %u\n", phase, round, (double)thr, n_near, n_far);
                 if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
-                CZ_HIP(hipMemsetAsync(d_misc.p, 0, 4, s));
                 uint32_t thr_bits;
                 memcpy(&thr_bits, &thr, 4);
+                uint32_t *mine = d_misc.p + 4 + (round & 1), *next = d_misc.p + 4 + ((round + 1) & 1);
                 hipLaunchKernelGGL(sssp_relax_kernel, dim3(grid_for((uint64_t)n_near * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p,
                                    d_w.p, N, near_cur, n_near, d_dp.p, d_qtag.p, round, d_ftag.p, phase, thr_bits,
-                                   SsspQueue{near_next, d_misc.p}, SsspQueue{far_cur, d_misc.p + 1});
-                CZ_HIP(hipMemcpy(h, d_misc.p, 8, hipMemcpyDeviceToHost));
-                n_near = h[0];
+                                   SsspQueue{near_next, mine}, SsspQueue{far_cur, d_misc.p + 1}, next);
+                if ((rc = read_counters(h))) return rc;
+                n_near = h[4 + (round & 1)];
                 n_far = h[1];
                 std::swap(near_cur, near_next);
                 round++;
@@ -1105,7 +1119,7 @@ struct SsspBatch {
             // move the threshold to the bucket of the nearest waiting node, then split the far pile
             CZ_HIP(hipMemsetAsync(d_misc.p + 3, 0xFF, 4, s));
             hipLaunchKernelGGL(sssp_far_min_kernel, dim3(grid_for(n_far)), dim3(kT), 0, s, far_cur, n_far, N, d_dp.p, d_misc.p + 3);
-            CZ_HIP(hipMemcpy(h, d_misc.p, 16, hipMemcpyDeviceToHost));
+            if ((rc = read_counters(h))) return rc;
             float fmin;
             memcpy(&fmin, &h[3], 4);
             thr = std::max(thr + delta, (std::floor(fmin / delta) + 1.0f) * delta);
@@ -1117,7 +1131,7 @@ struct SsspBatch {
             CZ_HIP(hipMemsetAsync(d_misc.p + 2, 0, 4, s));
             hipLaunchKernelGGL(sssp_split_kernel, dim3(grid_for(n_far)), dim3(kT), 0, s, far_cur, n_far, N, d_dp.p, d_qtag.p, round,
                                d_ftag.p, phase, thr_bits, SsspQueue{near_cur, d_misc.p}, SsspQueue{far_next, d_misc.p + 2});
-            CZ_HIP(hipMemcpy(h, d_misc.p, 16, hipMemcpyDeviceToHost));
+            if ((rc = read_counters(h))) return rc;
             n_near = h[0];
             n_far = h[2];
             std::swap(far_cur, far_next);
