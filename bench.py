@@ -842,6 +842,12 @@ def bench_graph_rules(args, torch, device):
     boff[1:] = np.cumsum(np.bincount(kb // nb, minlength=nb))
     btgt = (kb % nb).astype(np.uint32)
     bw = (rb.integers(1, 64, btgt.size) / 8).astype(np.float32)
+    try:  # ClosenessCentrality on the same graph: the all-sources SSSP + the reference's f32 sums per source, on the device
+        clo, dtc = timed(lambda: G.closeness(boff, btgt, bw))
+        out["closeness"] = dict(nodes=nb, edges=int(btgt.size), wall_ms=dtc * 1e3, device_ms=G.last_timing()[1], sources_per_s=nb / dtc,
+                                max_centrality=float(np.nanmax(clo[np.isfinite(clo)])) if np.isfinite(clo).any() else None)
+    except Exception as e:  # noqa: BLE001
+        out["closeness"] = dict(error=f"{type(e).__name__}: {e}")
     cent, dt = timed(lambda: G.betweenness(boff, btgt, bw))
     up, devms, down = G.last_timing()
     out["betweenness"] = dict(nodes=nb, edges=int(btgt.size), wall_ms=dt * 1e3, device_ms=devms, sources_per_s=nb / dt,
