@@ -364,8 +364,10 @@ int cz_clustering_coefficients(const uint32_t *offsets, const uint32_t *targets,
 
 /* dijkstra (algos/shortest_path_dijkstra.rs:274-339) for n_starts sources on the weighted out-CSR
  * (as_directed_weighted_graph, fixed_rule/mod.rs:208-328; f32 weights >= 0):
- *   dist [n_starts][N] f32 (inf = unreachable), parent [n_starts][N] (a predecessor p with
- *   dist[p] + w(p,v) == dist[v] in f32; CZ_NONE for the start / unreachable). */
+ *   dist [n_starts][N] f32 (inf = unreachable), parent [n_starts][N]: the SMALLEST predecessor p with
+ *   dist[p] + w(p,v) == dist[v] in f32 and dist[p] < dist[v] -- the same on every run, whatever the schedule (a node all
+ *   of whose such predecessors sit at its own cost, zero-weight edges, keeps the one that set its cost); CZ_NONE for the
+ *   start / unreachable.  (The reference's choice among equal-cost predecessors is its heap's pop order.) */
 int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
             const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison);
 
