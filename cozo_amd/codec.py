@@ -318,3 +318,58 @@ class StoredRows:
 
     def tuples(self) -> List[List[Any]]:
         return [decode_tuple_from_kv(*self.row(i)) for i in range(len(self))]
+
+    @classmethod
+    def from_items(cls, items: Sequence[Tuple[bytes, bytes]], n_key_cols: int) -> "StoredRows":
+        """(key bytes, value bytes) pairs, ascending by key"""
+        key_off = np.zeros(len(items) + 1, dtype=np.uint64)
+        val_off = np.zeros(len(items) + 1, dtype=np.uint64)
+        if items:
+            key_off[1:] = np.cumsum([len(k) for k, _ in items], dtype=np.uint64)
+            val_off[1:] = np.cumsum([len(v) for _, v in items], dtype=np.uint64)
+        return cls(b"".join(k for k, _ in items), key_off, b"".join(v for _, v in items), val_off, n_key_cols)
+
+
+def stored_rows_delta(old: StoredRows, new: StoredRows) -> Tuple[StoredRows, List[bytes]]:
+    """What a statement has to write to turn the stored rows `old` into `new`: (puts, dels) -- the rows of `new` whose key is
+    not in `old` or whose value bytes differ, as StoredRows ready for store_tx.put, and the keys of `old` that `new` no longer
+    has, for store_tx.del.  This is the write-back of index maintenance on the device: after
+    cz_hnsw_insert / cz_hnsw_remove the index's `tbl:idx` rows are encoded again (GpuHnswIndex.index_rows) and only the delta
+    against the rows the store holds is written -- the rows hnsw_put_vector / hnsw_remove_vec would have touched
+    (runtime/hnsw.rs:270-357, 389-466, 728-868).  Both inputs ascending by key bytes (a scan's order): one merge walk."""
+    puts: List[Tuple[bytes, bytes]] = []
+    dels: List[bytes] = []
+    i, j, n_old, n_new = 0, 0, len(old), len(new)
+    while i < n_old or j < n_new:
+        if j == n_new:
+            dels.append(old.row(i)[0])
+            i += 1
+            continue
+        if i == n_old:
+            puts.append(new.row(j))
+            j += 1
+            continue
+        (ko, vo), (kn, vn) = old.row(i), new.row(j)
+        if ko == kn:
+            if vo != vn:
+                puts.append((kn, vn))
+            i += 1
+            j += 1
+        elif ko < kn:
+            dels.append(ko)
+            i += 1
+        else:
+            puts.append((kn, vn))
+            j += 1
+    return StoredRows.from_items(puts, new.n_key_cols), dels
+
+
+def apply_stored_delta(rows: StoredRows, puts: StoredRows, dels: Sequence[bytes]) -> StoredRows:
+    """the store after `dels` and `puts` (tests: delta(old, new) applied to old is new)"""
+    kv = {rows.row(i)[0]: rows.row(i)[1] for i in range(len(rows))}
+    for k in dels:
+        kv.pop(k, None)
+    for i in range(len(puts)):
+        k, v = puts.row(i)
+        kv[k] = v
+    return StoredRows.from_items(sorted(kv.items()), rows.n_key_cols)

@@ -127,6 +127,7 @@ class GpuHnswIndex:
         """hnsw_remove (hnsw.rs:728-868) for a set of nodes: they leave every level, links from and to them disappear"""
         a = np.ascontiguousarray(nodes, dtype=np.uint32)
         check(_lib.lib().cz_hnsw_remove(self._h, ptr(a), a.size))
+        self.__dict__.setdefault("_removed", set()).update(int(x) for x in a)  # (a removed node keeps its id; it has no rows)
 
     def export(self):
         """(level_nodes, level_nbrs, entry): the flat layout of cz_hnsw_desc, e.g. to write the links back as
@@ -149,12 +150,21 @@ class GpuHnswIndex:
         """The way back: every `tbl:idx` row of this index as stored key / value bytes in key order
         (cozo_amd.codec.StoredRows), ready for store_tx.put -- link tables exported from the device, link distances from
         cz_distance_batch (the values the kernels work with), self-loop rows with degree and vector hash, the canary row
-        (runtime/hnsw.rs:270-330, 630-678).  key_of_node[i] = (row key columns.., field, sub index) of node i."""
+        (runtime/hnsw.rs:270-330, 630-678).  key_of_node[i] = (row key columns.., field, sub index) of node i.  Nodes taken out
+        with `remove` have no rows (hnsw_remove deletes them, :728-868).  After an insert / remove, codec.stored_rows_delta against
+        the rows the store holds is what has to be written."""
         from .ingest import encode_index_rows
         nodes, nbrs, entry = self.export()
         vecs = self.export_vectors()
+        gone = self.__dict__.get("_removed")
+        if gone and len(nbrs):
+            live0 = np.setdiff1d(np.arange(self.n, dtype=np.uint32), np.fromiter(gone, dtype=np.uint32), assume_unique=False)
+            nodes = [live0.astype(np.uint32)] + list(nodes[1:])
+            nbrs = [nbrs[0][live0]] + list(nbrs[1:])
         level_dist = []
-        for ids, tab in zip(nodes, nbrs):
+        for lv, (ids, tab) in enumerate(zip(nodes, nbrs)):
+            if ids is None or (lv == 0 and not gone):
+                ids = np.arange(tab.shape[0], dtype=np.uint32)
             d = np.zeros(tab.shape, dtype=np.float64)
             live = tab != CZ_NONE
             if live.any():

@@ -171,3 +171,23 @@ def test_golden_stored_rows():
     # the two spelled-out examples of the formats (include/cozo_ingest.h): 2095 as a key column, [5, Null] as a value
     assert codec.memcmp_bytes(2095).hex() == "05" + "c0a05e0000000000" + "00"
     assert codec.encode_val_for_store(3, [5, None]).hex() == "0000000000000003" + "92" + "81a34e756d" + "81a3496e74" + "05" + "a44e756c6c"
+
+
+def test_stored_rows_delta_is_what_turns_old_into_new():
+    """codec.stored_rows_delta: puts = new or changed rows, dels = vanished keys; applying them to `old` gives `new`"""
+    rng = np.random.default_rng(4)
+    for trial in range(20):
+        keys = rng.choice(400, size=int(rng.integers(0, 200)), replace=False)
+        old_t = [(int(k), f"v{int(k) % 7}", float(k)) for k in keys]
+        keep = [t for t in old_t if rng.random() < 0.8]
+        changed = [(t[0], t[1] + "!", t[2]) if rng.random() < 0.2 else t for t in keep]
+        fresh = [(int(k), "new", 0.5) for k in rng.choice(np.arange(400, 500), size=int(rng.integers(0, 30)), replace=False)]
+        old = codec.StoredRows.from_tuples(9, old_t, 1)
+        new = codec.StoredRows.from_tuples(9, changed + fresh, 1)
+        puts, dels = codec.stored_rows_delta(old, new)
+        assert len(dels) == len(old_t) - len(keep)
+        assert len(puts) == len(fresh) + sum(1 for a, b in zip(keep, changed) if a != b)
+        got = codec.apply_stored_delta(old, puts, dels)
+        assert got.keys == new.keys and got.vals == new.vals and np.array_equal(got.key_off, new.key_off)
+    same, none = codec.stored_rows_delta(new, new)
+    assert len(same) == 0 and none == []

@@ -187,3 +187,45 @@ def test_remove_then_insert(gpu_lib, oracle):
     rec = np.mean([len(set(ids[i]) & (set(gt[i]) - set(dead.tolist()))) / max(1, len(set(gt[i]) - set(dead.tolist()))) for i in range(len(q))])
     assert rec >= 0.8
     g.close()
+
+
+def test_write_back_of_insert_and_remove_is_a_delta(oracle, gpu_lib):
+    """Index maintenance on the device, written back as the rows that changed: the `tbl:idx` rows of the index
+    after cz_hnsw_insert / cz_hnsw_remove against the rows the store holds -- codec.stored_rows_delta -- are a small part of the
+    relation, and applying them to the stored rows gives exactly the rows of the new index; read back (libcozo_ingest) it
+    searches like the device index it came from."""
+    from cozo_amd import build as B, codec
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest, HnswSearch
+    from cozo_amd.ingest import StoredHnswIndex
+    B.build_ingest()
+    rng = np.random.default_rng(12)
+    n0, n1, dim, m = 3000, 40, 24, 8
+    vecs = rng.standard_normal((n0 + n1, dim)).astype(np.float32)
+    man = HnswIndexManifest(vec_dim=dim, distance="L2", m_neighbours=m, ef_construction=40)
+    levels = oracle.random_levels(n0 + n1, m, 5)
+    ix = GpuHnswIndex.build(man, vecs[:n0], levels=levels[:n0], max_batch=1)
+    keys = [(f"k{i:05d}", 1, -1) for i in range(n0 + n1)]
+    stored = ix.index_rows(keys[:n0], relation_id=12)
+    # ---- insert: the new nodes' rows + the rows of the nodes whose lists they entered (and whatever those shrinks dropped)
+    ix.insert(vecs[n0:], levels=levels[n0:], max_batch=1)
+    after = ix.index_rows(keys, relation_id=12)
+    puts, dels = codec.stored_rows_delta(stored, after)
+    assert 0 < len(puts) < len(after) // 10 and len(dels) < len(after) // 50
+    stored = codec.apply_stored_delta(stored, puts, dels)
+    assert stored.keys == after.keys and stored.vals == after.vals
+    # ---- remove: the rows of the removed nodes go, the rows that pointed at them go
+    gone = np.array([7, 500, n0 + 3], dtype=np.uint32)
+    ix.remove(gone)
+    after = ix.index_rows(keys, relation_id=12)
+    puts, dels = codec.stored_rows_delta(stored, after)
+    assert len(dels) > 0 and len(puts) + len(dels) < len(after) // 10
+    stored = codec.apply_stored_delta(stored, puts, dels)
+    assert stored.keys == after.keys and stored.vals == after.vals
+    base = codec.StoredRows.from_tuples(11, [(k[0], vecs[i]) for i, k in enumerate(keys) if i not in set(gone.tolist())], 1)
+    back = StoredHnswIndex(stored, base, [1], dim, oracle.L2, m).to_gpu(man)
+    q = rng.standard_normal((32, dim)).astype(np.float32)
+    a = ix.hnsw_knn_batch(q, HnswSearch(k=10, ef=40))
+    b = back.hnsw_knn_batch(q, HnswSearch(k=10, ef=40))
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])  # the same distances and counts (ids are renumbered by the scan)
+    ix.close()
+    back.close()
