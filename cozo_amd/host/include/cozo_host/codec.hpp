@@ -57,4 +57,10 @@ struct StoredRows {
     czi_rows view() const { return czi_rows{keys.data(), key_off.data(), vals.data(), val_off.data(), size(), n_key_cols}; }
 };
 
+// What a statement has to write to turn the stored rows `old_rows` into `new_rows` (both ascending by key bytes, as a scan
+// yields them): `puts` = the rows of new_rows whose key is new or whose value bytes differ, `dels` = the keys only old_rows
+// has.  The write-back of index maintenance on the device: the encoded `tbl:idx` rows after cz_hnsw_insert / cz_hnsw_remove
+// against the rows the store holds.
+void stored_rows_delta(const StoredRows &old_rows, const StoredRows &new_rows, StoredRows *puts, std::vector<std::vector<uint8_t>> *dels);
+
 }  // namespace cozo

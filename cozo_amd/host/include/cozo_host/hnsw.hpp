@@ -82,6 +82,7 @@ class GpuHnswIndex {
     HnswIndexManifest manifest_;
     const BaseRelation *base_ = nullptr;
     std::vector<CompoundKey> nodes_;  // node id -> CompoundKey
+    std::vector<uint8_t> removed_;    // node id -> taken out by remove_rows (keeps its id, has no index rows)
     uint64_t build_n_dist_ = 0;
     // per base column: the device copy of its per-node values (nullptr: the column is not purely Int / purely Float)
     mutable std::map<size_t, cz_column *> columns_;
@@ -111,6 +112,14 @@ public:
     // store_tx.put -- link tables exported from the device, link distances recomputed by cz_distance_batch (the values
     // the kernels work with), self-loop rows with degree and vector hash, the canary row (hnsw.rs:270-330, 630-678).
     StoredRows index_rows(uint64_t relation_id) const;
+
+    // Index maintenance on a later write (query/stored.rs:431-450, 486-503 -> runtime/hnsw.rs:679-727, 728-868), on the device:
+    //   put_rows     hnsw_put for the rows base.rows[first_row ..) the caller appended to the base relation since the index was
+    //                built / last extended (cz_hnsw_insert; max_batch = 1 == the reference's one-at-a-time order)
+    //   remove_rows  hnsw_remove for base rows: every vector of each row leaves every level, no link names it any more
+    // then index_rows() again and stored_rows_delta (codec.hpp) against the rows the store holds = what to put / delete.
+    void put_rows(uint32_t first_row, uint64_t seed = 0, uint32_t max_batch = 0, const std::vector<int32_t> *levels = nullptr);
+    void remove_rows(const std::vector<uint32_t> &rows);
 
     size_t node_count() const { return nodes_.size(); }
     const CompoundKey &node(uint32_t id) const { return nodes_[id]; }

@@ -433,4 +433,45 @@ StoredRows StoredRows::from_tuples(uint64_t relation_id, const std::vector<Tuple
     return r;
 }
 
+void stored_rows_delta(const StoredRows &a, const StoredRows &b, StoredRows *puts, std::vector<std::vector<uint8_t>> *dels) {
+    *puts = StoredRows();
+    puts->n_key_cols = b.n_key_cols;
+    dels->clear();
+    auto key = [](const StoredRows &r, size_t i) { return std::make_pair(r.keys.data() + r.key_off[i], (size_t)(r.key_off[i + 1] - r.key_off[i])); };
+    auto val = [](const StoredRows &r, size_t i) { return std::make_pair(r.vals.data() + r.val_off[i], (size_t)(r.val_off[i + 1] - r.val_off[i])); };
+    auto cmp = [](std::pair<const uint8_t *, size_t> x, std::pair<const uint8_t *, size_t> y) {
+        const int c = std::memcmp(x.first, y.first, std::min(x.second, y.second));
+        return c ? c : (x.second < y.second ? -1 : x.second > y.second ? 1 : 0);
+    };
+    auto put = [&](size_t j) {
+        const auto k = key(b, j), v = val(b, j);
+        puts->keys.insert(puts->keys.end(), k.first, k.first + k.second);
+        puts->key_off.push_back(puts->keys.size());
+        puts->vals.insert(puts->vals.end(), v.first, v.first + v.second);
+        puts->val_off.push_back(puts->vals.size());
+    };
+    size_t i = 0, j = 0;
+    const size_t na = a.size(), nb = b.size();
+    while (i < na || j < nb) {
+        if (j == nb) {
+            const auto k = key(a, i++);
+            dels->emplace_back(k.first, k.first + k.second);
+        } else if (i == na) {
+            put(j++);
+        } else {
+            const int c = cmp(key(a, i), key(b, j));
+            if (c == 0) {
+                if (cmp(val(a, i), val(b, j)) != 0) put(j);
+                i++;
+                j++;
+            } else if (c < 0) {
+                const auto k = key(a, i++);
+                dels->emplace_back(k.first, k.first + k.second);
+            } else {
+                put(j++);
+            }
+        }
+    }
+}
+
 }  // namespace cozo

@@ -35,6 +35,7 @@ GpuHnswIndex &GpuHnswIndex::operator=(GpuHnswIndex &&o) noexcept {
         manifest_ = std::move(o.manifest_);
         base_ = o.base_;
         nodes_ = std::move(o.nodes_);
+        removed_ = std::move(o.removed_);
         build_n_dist_ = o.build_n_dist_;
         for (auto &kv : columns_)
             if (kv.second) cz_column_destroy(kv.second);
@@ -91,6 +92,64 @@ GpuHnswIndex GpuHnswIndex::create(const HnswIndexManifest &manifest, const BaseR
     return ix;
 }
 
+void GpuHnswIndex::put_rows(uint32_t first_row, uint64_t seed, uint32_t max_batch, const std::vector<int32_t> *levels) {
+    if (manifest_.extend_candidates) throw GpuError(CZ_E_UNSUPPORTED, "extend_candidates is not supported by the GPU build");
+    std::vector<float> flat;
+    const size_t n_before = nodes_.size();
+    for (uint32_t r = first_row; r < base_->rows.size(); r++) {  // hnsw_put (runtime/hnsw.rs:679-727): a Vec or every Vec inside a List
+        const Tuple &t = base_->rows[r];
+        for (size_t f : manifest_.vec_fields) {
+            if (f >= t.size()) continue;
+            auto push = [&](const std::vector<float> &v, int32_t sub) {
+                if (v.size() != manifest_.vec_dim)
+                    throw CozoError("hnsw::dim_mismatch", "vector of length " + std::to_string(v.size()) + " in an index of dimension " +
+                                                              std::to_string(manifest_.vec_dim));
+                flat.insert(flat.end(), v.begin(), v.end());
+                nodes_.push_back({r, (uint32_t)f, sub});
+            };
+            if (const std::vector<float> *v = t[f].get_vec()) push(*v, -1);
+            else if (const std::vector<DataValue> *l = t[f].get_slice())
+                for (size_t s = 0; s < l->size(); s++)
+                    if (const std::vector<float> *v2 = (*l)[s].get_vec()) push(*v2, (int32_t)s);
+        }
+    }
+    const size_t n_new = nodes_.size() - n_before;
+    if (levels && levels->size() != n_new) {
+        nodes_.resize(n_before);
+        throw CozoError("hnsw::bad_levels", "levels must hold one entry per new vector");
+    }
+    if (n_new == 0) return;
+    uint64_t nd = 0;
+    int rc;
+    if (!h_)  // the first rows of an index that was empty so far
+        rc = cz_hnsw_build(flat.data(), (uint32_t)n_new, (uint32_t)manifest_.vec_dim, (int)manifest_.distance, (uint32_t)manifest_.m_neighbours,
+                           (uint32_t)manifest_.ef_construction, manifest_.keep_pruned_connections ? 1 : 0, levels ? levels->data() : nullptr,
+                           seed, max_batch, &nd, &h_, 0, nullptr);
+    else
+        rc = cz_hnsw_insert(h_, flat.data(), (uint32_t)n_new, (uint32_t)manifest_.m_neighbours, (uint32_t)manifest_.ef_construction,
+                            manifest_.keep_pruned_connections ? 1 : 0, levels ? levels->data() : nullptr, seed, max_batch, &nd, 0, nullptr);
+    if (rc != CZ_OK) nodes_.resize(n_before);
+    check_gpu(rc);
+    build_n_dist_ += nd;
+    for (auto &kv : columns_)  // the per-node copies of base columns no longer cover every node
+        if (kv.second) cz_column_destroy(kv.second);
+    columns_.clear();
+}
+
+void GpuHnswIndex::remove_rows(const std::vector<uint32_t> &rows) {
+    if (!h_ || rows.empty()) return;
+    std::vector<uint8_t> hit(base_->rows.size(), 0);
+    for (uint32_t r : rows)
+        if (r < hit.size()) hit[r] = 1;
+    std::vector<uint32_t> ids;
+    removed_.resize(nodes_.size(), 0);
+    for (uint32_t v = 0; v < nodes_.size(); v++)
+        if (hit[nodes_[v].row] && !removed_[v]) ids.push_back(v);
+    if (ids.empty()) return;
+    check_gpu(cz_hnsw_remove(h_, ids.data(), (uint32_t)ids.size()));
+    for (uint32_t v : ids) removed_[v] = 1;
+}
+
 GpuHnswIndex GpuHnswIndex::from_stored(const HnswIndexManifest &manifest, const StoredRows &idx, const StoredRows &base_rows,
                                        const BaseRelation &base) {
     if (manifest.dtype != VecElementType::F32) throw GpuError(CZ_E_UNSUPPORTED, "only F32 vector indices are GPU-resident");
@@ -137,6 +196,20 @@ StoredRows GpuHnswIndex::index_rows(uint64_t relation_id) const {
         ids[lv].resize(sizes[lv]);
         nbrs[lv].resize((size_t)sizes[lv] * widths[lv]);
         check_gpu(cz_hnsw_index_export_level(h_, lv, ids[lv].data(), nbrs[lv].data()));
+        if (lv == 0 && !removed_.empty()) {  // a removed node keeps its id on the device and has no rows in the store (hnsw_remove, :728-868)
+            uint32_t keep = 0;
+            for (uint32_t r = 0; r < sizes[0]; r++) {
+                const uint32_t v = ids[0][r];
+                if (v < removed_.size() && removed_[v]) continue;
+                ids[0][keep] = v;
+                std::copy(nbrs[0].begin() + (size_t)r * widths[0], nbrs[0].begin() + (size_t)(r + 1) * widths[0],
+                          nbrs[0].begin() + (size_t)keep * widths[0]);
+                keep++;
+            }
+            sizes[0] = keep;
+            ids[0].resize(keep);
+            nbrs[0].resize((size_t)keep * widths[0]);
+        }
         // the distance column of every link row: the same arithmetic the search uses
         std::vector<uint32_t> pairs;
         std::vector<size_t> slot;

@@ -1081,6 +1081,135 @@ static void gpu_index_through_the_store() {
     CHECK(empty_read.node_count() == 0 && empty_ra.iter(parent, Poison()).empty());
 }
 
+static void test_stored_rows_delta_cpu() {
+    // stored_rows_delta: puts = new or changed rows, dels = vanished keys; old with the delta applied is new
+    std::mt19937 rng(17);
+    for (int trial = 0; trial < 20; trial++) {
+        std::vector<Tuple> old_t, new_t;
+        size_t want_puts = 0, want_dels = 0;
+        for (int64_t k = 0; k < 300; k++) {
+            if (rng() % 2) continue;
+            old_t.push_back(T({DataValue(k), DataValue(std::string("v")), DataValue((double)k)}));
+            const unsigned what = rng() % 10;
+            if (what == 0) { want_dels++; continue; }
+            if (what == 1) { new_t.push_back(T({DataValue(k), DataValue(std::string("changed")), DataValue((double)k)})); want_puts++; }
+            else new_t.push_back(old_t.back());
+        }
+        for (int64_t k = 300; k < 330; k++)
+            if (rng() % 3 == 0) { new_t.push_back(T({DataValue(k), DataValue(std::string("new")), DataValue(0.5)})); want_puts++; }
+        const StoredRows a = StoredRows::from_tuples(9, old_t, 1), b = StoredRows::from_tuples(9, new_t, 1);
+        StoredRows puts;
+        std::vector<std::vector<uint8_t>> dels;
+        stored_rows_delta(a, b, &puts, &dels);
+        CHECK(puts.size() == want_puts && dels.size() == want_dels);
+        std::map<std::vector<uint8_t>, std::vector<uint8_t>> kv;
+        for (size_t i = 0; i < a.size(); i++)
+            kv[std::vector<uint8_t>(a.keys.begin() + a.key_off[i], a.keys.begin() + a.key_off[i + 1])] =
+                std::vector<uint8_t>(a.vals.begin() + a.val_off[i], a.vals.begin() + a.val_off[i + 1]);
+        for (const auto &k : dels) kv.erase(k);
+        for (size_t i = 0; i < puts.size(); i++)
+            kv[std::vector<uint8_t>(puts.keys.begin() + puts.key_off[i], puts.keys.begin() + puts.key_off[i + 1])] =
+                std::vector<uint8_t>(puts.vals.begin() + puts.val_off[i], puts.vals.begin() + puts.val_off[i + 1]);
+        std::vector<uint8_t> keys, vals;
+        for (const auto &e : kv) {
+            keys.insert(keys.end(), e.first.begin(), e.first.end());
+            vals.insert(vals.end(), e.second.begin(), e.second.end());
+        }
+        CHECK(kv.size() == b.size() && keys == b.keys && vals == b.vals);
+    }
+}
+
+static void gpu_index_maintenance_writeback() {
+    // hnsw_put / hnsw_remove on a later write, on the device (GpuHnswIndex::put_rows / remove_rows), and what goes back to the
+    // store: build(first rows) + put_rows(the rest) with max_batch = 1 leaves byte for byte the `tbl:idx` rows of ONE sequential
+    // build over all rows; the delta against the rows of the first index is a small part of them and turns the one into the
+    // other; after remove_rows no row names a removed node and the delta applies again.
+    const size_t n0 = 1200, n1 = 30, dim = 16;
+    std::mt19937 rng(23);
+    std::uniform_real_distribution<float> U(0.f, 1.f);
+    BaseRelation base, all;
+    base.keys = all.keys = {"id"};
+    base.non_keys = all.non_keys = {"v"};
+    for (size_t i = 0; i < n0 + n1; i++) {
+        std::vector<float> v(dim);
+        for (float &x : v) x = U(rng);
+        char key[16];
+        std::snprintf(key, sizeof key, "r%05zu", i);
+        all.rows.push_back(T({DataValue(std::string(key)), DataValue(F32Vec{v})}));
+        if (i < n0) base.rows.push_back(all.rows.back());
+    }
+    HnswIndexManifest mf = HnswIndexManifest::create("t", "vec", dim, {1}, HnswDistance::L2, 8, 40);
+    std::vector<int32_t> levels(n0 + n1);
+    {
+        std::mt19937_64 r2(4);
+        for (auto &l : levels) {
+            const double u = (double)(r2() >> 11) / 9007199254740992.0;
+            l = (int32_t)std::floor(-std::log(u > 0 ? u : 1e-300) * mf.level_multiplier);
+        }
+    }
+    const std::vector<int32_t> lv0(levels.begin(), levels.begin() + n0), lv1(levels.begin() + n0, levels.end());
+    GpuHnswIndex ix = GpuHnswIndex::create(mf, base, 0, 1, &lv0);
+    StoredRows stored = ix.index_rows(31);
+    for (size_t i = n0; i < n0 + n1; i++) base.rows.push_back(all.rows[i]);
+    ix.put_rows((uint32_t)n0, 0, 1, &lv1);
+    CHECK(ix.node_count() == n0 + n1);
+    const StoredRows after = ix.index_rows(31);
+    GpuHnswIndex whole = GpuHnswIndex::create(mf, all, 0, 1, &levels);
+    const StoredRows want = whole.index_rows(31);
+    CHECK(after.keys == want.keys && after.vals == want.vals);
+    StoredRows puts;
+    std::vector<std::vector<uint8_t>> dels;
+    stored_rows_delta(stored, after, &puts, &dels);
+    CHECK(puts.size() > n1 && puts.size() < after.size() / 5 && dels.size() < after.size() / 20);
+    auto apply = [](const StoredRows &a, const StoredRows &p, const std::vector<std::vector<uint8_t>> &d) {
+        std::map<std::vector<uint8_t>, std::vector<uint8_t>> kv;
+        for (size_t i = 0; i < a.size(); i++)
+            kv[std::vector<uint8_t>(a.keys.begin() + a.key_off[i], a.keys.begin() + a.key_off[i + 1])] =
+                std::vector<uint8_t>(a.vals.begin() + a.val_off[i], a.vals.begin() + a.val_off[i + 1]);
+        for (const auto &k : d) kv.erase(k);
+        for (size_t i = 0; i < p.size(); i++)
+            kv[std::vector<uint8_t>(p.keys.begin() + p.key_off[i], p.keys.begin() + p.key_off[i + 1])] =
+                std::vector<uint8_t>(p.vals.begin() + p.val_off[i], p.vals.begin() + p.val_off[i + 1]);
+        std::pair<std::vector<uint8_t>, std::vector<uint8_t>> out;
+        for (const auto &e : kv) {
+            out.first.insert(out.first.end(), e.first.begin(), e.first.end());
+            out.second.insert(out.second.end(), e.second.begin(), e.second.end());
+        }
+        return out;
+    };
+    auto applied = apply(stored, puts, dels);
+    CHECK(applied.first == after.keys && applied.second == after.vals);
+    // remove three rows: their self rows and every link row from / to them leave
+    ix.remove_rows({5, 700, (uint32_t)n0 + 2});
+    const StoredRows after2 = ix.index_rows(31);
+    stored_rows_delta(after, after2, &puts, &dels);
+    CHECK(!dels.empty() && puts.size() + dels.size() < after2.size() / 5);
+    applied = apply(after, puts, dels);
+    CHECK(applied.first == after2.keys && applied.second == after2.vals);
+    bool named = false;
+    for (size_t i = 0; i + 1 < after2.size(); i++) {  // (the last row is the canary)
+        const Tuple t = after2.tuple(i);
+        for (const char *gone : {"r00005", "r00700", "r01202"})
+            named |= (t[1] == DataValue(std::string(gone))) || (t[4] == DataValue(std::string(gone)));
+    }
+    CHECK(!named);
+    // the index still answers, and never with a removed row
+    HnswSearchRA ra{&ix, HnswSearch{}, 1};
+    ra.hnsw_search.k = 10;
+    ra.hnsw_search.ef = 40;
+    std::vector<Tuple> parent;
+    for (int i = 0; i < 16; i++) {
+        std::vector<float> q(dim);
+        for (float &x : q) x = U(rng);
+        parent.push_back(T({DataValue((int64_t)i), DataValue(F32Vec{q})}));
+    }
+    const std::vector<Tuple> got = ra.iter(parent, Poison());
+    bool clean = got.size() == 160;
+    for (const Tuple &t : got)
+        for (const char *gone : {"r00005", "r00700", "r01202"}) clean &= !(t[2] == DataValue(std::string(gone)));
+    CHECK(clean);
+}
+
 // ---- `test_host run-rule <in> <out>`: one rule invocation handed over by tests/test_mirrors_agree.py -----------------------------
 // in : u32 magic, str rule, u32 n_options x (str name, blob memcmp-encoded DataValue), u32 n_inputs x (u32 n_rows x blob stored key)
 // out: u32 1 + u32 n_rows x blob (the row as a stored key of relation 0)   |   u32 0 + str diagnostic code
@@ -1172,6 +1301,7 @@ int main(int argc, char **argv) {
     test_codec_agrees_with_the_python_codec();
     test_codec_rejects_damaged_bytes();
     test_stored_relation_graphs();
+    test_stored_rows_delta_cpu();
     test_no_device_fails_loudly();
     if (mode == "rules-cpu") {
         // the binary was linked against tests/cpp/oracle_shim.c ahead of libcozo_gpu.so: the rules' host logic runs on
@@ -1208,6 +1338,7 @@ int main(int argc, char **argv) {
         gpu_dijkstra_keep_ties();
         gpu_rules_on_stored_relation();
         gpu_index_through_the_store();
+        gpu_index_maintenance_writeback();
     }
     std::printf("%s: %d checks passed, %d failed\n", mode.c_str(), g_pass, g_fail);
     return g_fail ? 1 : 0;
