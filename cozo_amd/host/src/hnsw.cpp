@@ -82,6 +82,12 @@ GpuHnswIndex GpuHnswIndex::create(const HnswIndexManifest &manifest, const BaseR
             }
         }
     }
+    // two vectors of one row are never neighbours for the reference (hnsw_get_neighbours drops such links, :609-610, also
+    // while the index is being built); the device build has no such rule: refuse instead of building a different graph
+    for (size_t i = 1; i < ix.nodes_.size(); i++)
+        if (ix.nodes_[i].row == ix.nodes_[i - 1].row)
+            throw GpuError(CZ_E_UNSUPPORTED, "rows carrying several indexed vectors are not built on the GPU (build the index with the "
+                                             "reference and read it with from_stored)");
     if (levels && levels->size() != ix.nodes_.size())
         throw CozoError("hnsw::bad_levels", "levels must hold one entry per indexed vector");
     if (ix.nodes_.empty()) return ix;  // empty index: hnsw_knn returns no rows (:903-909)
@@ -114,6 +120,11 @@ void GpuHnswIndex::put_rows(uint32_t first_row, uint64_t seed, uint32_t max_batc
         }
     }
     const size_t n_new = nodes_.size() - n_before;
+    for (size_t i = n_before + 1; i < nodes_.size(); i++)
+        if (nodes_[i].row == nodes_[i - 1].row) {
+            nodes_.resize(n_before);
+            throw GpuError(CZ_E_UNSUPPORTED, "rows carrying several indexed vectors are not built on the GPU");
+        }
     if (levels && levels->size() != n_new) {
         nodes_.resize(n_before);
         throw CozoError("hnsw::bad_levels", "levels must hold one entry per new vector");

@@ -1193,6 +1193,15 @@ static void gpu_index_maintenance_writeback() {
             named |= (t[1] == DataValue(std::string(gone))) || (t[4] == DataValue(std::string(gone)));
     }
     CHECK(!named);
+    // a row carrying two vectors: the device build has no same-row rule (hnsw.rs:609-610), so it refuses loudly
+    {
+        BaseRelation two;
+        two.keys = {"id"};
+        two.non_keys = {"v"};
+        std::vector<float> a(dim, 0.25f), b(dim, 0.5f);
+        two.rows.push_back(T({DataValue(std::string("x")), DataValue::list({DataValue(F32Vec{a}), DataValue(F32Vec{b})})}));
+        CHECK((throws<GpuError>([&] { GpuHnswIndex::create(mf, two, 0, 1, nullptr); })));
+    }
     // the index still answers, and never with a removed row
     HnswSearchRA ra{&ix, HnswSearch{}, 1};
     ra.hnsw_search.k = 10;
