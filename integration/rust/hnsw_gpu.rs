@@ -268,3 +268,61 @@ impl<'a> SessionTx<'a> {
         Ok(())
     }
 }
+
+// 4. query/stored.rs:431-450, 486-503 -- put / rm on a relation with an HNSW index, the index resident on the device
+//
+// The statement's rows are collected first (the reference calls hnsw_put / hnsw_remove per row); the device index takes them
+// in one call, the `tbl:idx` rows are encoded again, and only what differs from the stored rows is written.
+impl<'a> SessionTx<'a> {
+    /// `stored`: the `tbl:idx` rows as the store holds them (one scan, ascending by key -- scan_bytes above);
+    /// `encode_rows(gpu)`: the export + cz_distance_batch + czi_hnsw_encode_rows sequence of hnsw_build_gpu, for the index as it
+    /// is now, with the removed nodes' level-0 rows left out.  Both are ascending by key bytes: one merge walk.
+    pub(crate) fn hnsw_write_back_delta(&mut self, stored: &StoredBytes, now: &StoredBytes) -> Result<(usize, usize)> {
+        let key = |b: &'_ StoredBytes, i: usize| -> (usize, usize) { (b.key_off[i] as usize, b.key_off[i + 1] as usize) };
+        let val = |b: &'_ StoredBytes, i: usize| -> (usize, usize) { (b.val_off[i] as usize, b.val_off[i + 1] as usize) };
+        let (na, nb) = (stored.key_off.len() - 1, now.key_off.len() - 1);
+        let (mut i, mut j, mut puts, mut dels) = (0usize, 0usize, 0usize, 0usize);
+        while i < na || j < nb {
+            let ord = if j == nb { std::cmp::Ordering::Less } else if i == na { std::cmp::Ordering::Greater } else {
+                let ((a0, a1), (b0, b1)) = (key(stored, i), key(now, j));
+                stored.keys[a0..a1].cmp(&now.keys[b0..b1])
+            };
+            match ord {
+                std::cmp::Ordering::Less => { // only the store has it: a dropped link, or a row of a removed node (hnsw.rs:434-466, 728-868)
+                    let (a0, a1) = key(stored, i);
+                    self.store_tx.del(&stored.keys[a0..a1])?;
+                    dels += 1;
+                    i += 1;
+                }
+                std::cmp::Ordering::Greater => { // new: a row of an inserted node or a new reverse link (:277-357)
+                    let ((b0, b1), (v0, v1)) = (key(now, j), val(now, j));
+                    self.store_tx.put(&now.keys[b0..b1], &now.vals[v0..v1])?;
+                    puts += 1;
+                    j += 1;
+                }
+                std::cmp::Ordering::Equal => {
+                    let ((a0, a1), (v0, v1)) = (val(stored, i), val(now, j));
+                    if stored.vals[a0..a1] != now.vals[v0..v1] { // a self row whose degree changed (:338-357)
+                        let (b0, b1) = key(now, j);
+                        self.store_tx.put(&now.keys[b0..b1], &now.vals[v0..v1])?;
+                        puts += 1;
+                    }
+                    i += 1;
+                    j += 1;
+                }
+            }
+        }
+        Ok((puts, dels))
+    }
+
+    /// hnsw_put for the rows of one statement: cz_hnsw_insert (the new vectors become nodes n .. n + n_new - 1; the shim extends
+    /// its node -> CompoundKey table in the same order), then the delta above.  hnsw_remove: cz_hnsw_remove with the nodes of the
+    /// deleted rows, then the same delta (their rows and every link row that named them are deleted from the store).
+    pub(crate) fn hnsw_put_gpu(&mut self, gpu: &mut GpuHnswIndex, new_vectors: &[f32], n_new: u32, config: &HnswSearch) -> Result<()> {
+        let mf = &config.manifest;
+        check(unsafe {
+            cz_hnsw_insert(gpu.handle, new_vectors.as_ptr(), n_new, mf.m_neighbours as u32, mf.ef_construction as u32,
+                           mf.keep_pruned_connections as c_int, std::ptr::null(), rand::random(), 0, std::ptr::null_mut(), 0, std::ptr::null_mut())
+        })
+    }
+}
