@@ -16,7 +16,6 @@ CZ_DEVICE_PTRS = 1
 CZ_BF_GEMM = 8
 CZ_PR_GATHER = 2
 CZ_PR_BLOCKED = 4
-CZ_PR_RELAXED = 16
 CZ_PR_EXCHANGE_ALLREDUCE = 32
 CZ_UNIQUE_ID_BYTES = 128
 CZ_L2, CZ_COSINE, CZ_IP = 0, 1, 2

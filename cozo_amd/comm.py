@@ -118,7 +118,7 @@ def sssp_sharded(comm: Comm, off_local, tgt, weights, n: int, row_begin: int, ro
     return dist, parent
 
 
-def pagerank_multi(in_off, in_src, out_deg, n_gpus: int, damping=0.85, tolerance=1e-4, max_iter=10, relaxed=False,
+def pagerank_multi(in_off, in_src, out_deg, n_gpus: int, damping=0.85, tolerance=1e-4, max_iter=10,
                    allreduce_exchange=False, poison=None):
     """cz_pagerank on n_gpus devices of THIS process (one host thread + one RCCL communicator per GPU)."""
     in_off = np.ascontiguousarray(in_off, dtype=np.uint32)
@@ -127,7 +127,7 @@ def pagerank_multi(in_off, in_src, out_deg, n_gpus: int, damping=0.85, tolerance
     N = out_deg.size
     scores = np.empty(N, dtype=np.float32)
     it, err = C.c_uint32(0), C.c_double(0.0)
-    flags = (_lib.CZ_PR_RELAXED if relaxed else 0) | (_lib.CZ_PR_EXCHANGE_ALLREDUCE if allreduce_exchange else 0)
+    flags = _lib.CZ_PR_EXCHANGE_ALLREDUCE if allreduce_exchange else 0
     check(_lib.lib().cz_pagerank_multi(ptr(in_off), ptr(in_src), ptr(out_deg), N, in_src.size, np.float32(damping),
                                        float(tolerance), int(max_iter), int(n_gpus), flags, ptr(scores), C.byref(it),
                                        C.byref(err), ptr(poison)))

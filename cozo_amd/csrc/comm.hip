@@ -315,7 +315,7 @@ extern "C" int cz_pagerank_multi(const uint32_t *in_offsets, const uint32_t *in_
         for (uint32_t i = 0; i <= re - rb; i++) off[i] = in_offsets[rb + i] - in_offsets[rb];
         cz_pagerank_plan *plan = nullptr;
         wrc = cz_pagerank_plan_create(off.data(), in_sources + in_offsets[rb], out_degree, N, rb, re, damping, &plan,
-                                      flags & (CZ_PR_GATHER | CZ_PR_BLOCKED | CZ_PR_RELAXED));
+                                      flags & (CZ_PR_GATHER | CZ_PR_BLOCKED));
         // a rank that failed before the loop would leave the others blocked in the first collective: every rank enters
         // the loop, a failed one with its poison flag raised
         cz_comm c;

@@ -5,8 +5,9 @@
 //   new = base + d * sum_{v in in(u)} contrib[v]   (f32, in-neighbours summed SEQUENTIALLY in sorted order)
 //   err += |new - old| (f64); contrib refreshed after the sweep (Jacobi); stop at err < tol or max_iter.
 //
-// Two device formulations of the same sweep, both bit-identical to the reference (each row's in-neighbour
-// contributions are added one by one in ascending source order by ONE lane):
+// Two device formulations of the same sweep, both bit-identical to the oracle's restatement of it (each row's
+// in-neighbour contributions are added one by one in ascending source order: short rows by ONE lane each, rows of
+// >= kWaveRow terms by a whole wave through exact_sum.cuh -- the same value as the sequential f32 loop, bit for bit):
 //
 //  * "blocked" (source-blocked two-phase sweep; the fast path).  A 4-byte gather from a 40 MB contribution
 //    vector moves a whole 128-byte line through the L2->L1 path: measured <= 215 G gathers/s even when the
@@ -24,8 +25,8 @@
 //    built once on the device at plan creation.
 //  * "gather" (CSR-stream pull SpMV): phase 1 streams the row block's source ids and gathers contrib[src]
 //    from global memory into the LDS tile; phase 2 as above.  Used for small graphs, for shards whose slices
-//    would be too sparse, and for the rows of a blocked plan that are longer than a tile (streamed tile by
-//    tile and summed by one lane, still in order).
+//    would be too sparse.  Rows longer than a tile (hubs) of either formulation: `pr_hub_kernel`, one workgroup per
+//    row, gathered tile by tile while one wave sums the tile before it, still in order.
 //
 // Algorithmic HBM bytes per iteration (the roofline model of SURVEY.md section 8d, cache-perfect gathers):
 // 4E (ids) + 4(N+1) (offsets) + 20N (contrib in/out, score in/out, out-degree) = 6.4 B/edge at N = 10M, E = 100M.
@@ -42,6 +43,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "common.h"
+#include "exact_sum.cuh"
 
 namespace {
 
@@ -53,6 +55,9 @@ constexpr int kAThreads = 1024;     // blocked path, phase A
 constexpr int kMaxSliceLog2 = 15;   // 32768 sources = 128 KiB of LDS
 constexpr uint32_t kPartEdges = 98304;  // phase-A work item: at most this many edges of one slice
 constexpr int kMaxRowsPerBlock = 2048;  // = 2 rows per lane of phase B
+constexpr uint32_t kWaveRow = 128;      // rows of at least this many terms are summed by a wave (exact_sum.cuh)
+constexpr int kHThreads = 1024;         // hub rows: one workgroup per row
+constexpr int kHTileNnz = 8192;         // two of these in LDS (64 KiB)
 
 struct RowBlock {
     uint32_t row0, row1;  // local rows [row0, row1)
@@ -85,22 +90,78 @@ __device__ __forceinline__ double block_sum_f64(double v, double *red) {
     return s;  // valid on thread 0
 }
 
-// phase 2 of both formulations: one lane per row adds its LDS segment in order; fused epilogue
+// ---- rows of a tile -> scores -------------------------------------------------------------------------------------
+// the fused epilogue of a row whose f32 sum is s; returns |new - old| for the f64 error
+__device__ __forceinline__ double finish_row(float s, uint32_t r, float old, uint32_t od, uint32_t row_begin,
+                                             float *__restrict__ contrib_out, float *__restrict__ scores, float base,
+                                             float damping) {
+    const float nw = base + damping * s;  // two roundings, like the reference (no fma: -ffp-contract=off)
+    scores[r] = nw;
+    contrib_out[row_begin + r] = nw / (float)od;
+    return fabs((double)(nw - old));
+}
+
+// one lane adds tile[e .. z) in order.  A long row is a serial chain: its LDS reads are kept 16 values ahead of the
+// adds (a read waited for in place costs ~100 cycles per add).
+__device__ __forceinline__ float lane_row_sum(const float *tile, uint32_t e, uint32_t z) {
+    float s = 0.0f;
+    if (z - e >= 32) {
+        float a[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) a[i] = tile[e + i];
+        for (; e + 32 <= z; e += 16) {
+            float nx[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) nx[i] = tile[e + 16 + i];
+#pragma unroll
+            for (int i = 0; i < 16; i++) s = s + a[i];
+#pragma unroll
+            for (int i = 0; i < 16; i++) a[i] = nx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) s = s + a[i];
+        e += 16;
+    }
+    for (; e < z; e++) s = s + tile[e];
+    return s;
+}
+
+// Rows of >= kWaveRow terms are pushed to `raw` in whatever order the lanes get there; the list is then put in row order
+// so that which wave sums which row -- and with it the order of the f64 error terms -- does not depend on timing.
+// Ends with a barrier; every thread gets the list length.
+constexpr int kMaxWaveRows = kBTileNnz / (int)kWaveRow;
+struct WaveRowList {
+    uint32_t raw[kMaxWaveRows], sorted[kMaxWaveRows];
+    uint32_t n;
+};
+__device__ __forceinline__ uint32_t order_wave_rows(WaveRowList &l) {
+    __syncthreads();
+    const uint32_t nl = l.n;
+    if (nl == 0) return 0;
+    if (threadIdx.x < nl) {
+        const uint32_t mine = l.raw[threadIdx.x];
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < nl; i++) rank += l.raw[i] < mine ? 1u : 0u;
+        l.sorted[rank] = mine;
+    }
+    __syncthreads();
+    return nl;
+}
+
+// the listed rows, one wave each: exact_sum.cuh gives the value of the sequential f32 loop
 template <int THREADS>
-__device__ __forceinline__ double rows_epilogue(const RowBlock rb, const uint32_t *__restrict__ off, uint32_t e0,
-                                                const float *tile, const uint32_t *__restrict__ out_deg,
-                                                uint32_t row_begin, float *__restrict__ contrib_out,
-                                                float *__restrict__ scores, float base, float damping) {
+__device__ __forceinline__ double wave_rows(const WaveRowList &l, uint32_t nl, const RowBlock rb,
+                                            const uint32_t *__restrict__ off, uint32_t e0, const float *tile,
+                                            const uint32_t *__restrict__ out_deg, uint32_t row_begin,
+                                            float *__restrict__ contrib_out, float *__restrict__ scores, float base,
+                                            float damping) {
     double err = 0.0;
-    for (uint32_t r = rb.row0 + threadIdx.x; r < rb.row1; r += THREADS) {
-        const uint32_t a = off[r] - e0, b = off[r + 1] - e0;
-        float s = 0.0f;
-        for (uint32_t e = a; e < b; e++) s = s + tile[e];
-        const float old = scores[r];
-        const float nw = base + damping * s;  // two roundings, like the reference (no fma: -ffp-contract=off)
-        scores[r] = nw;
-        contrib_out[row_begin + r] = nw / (float)out_deg[row_begin + r];
-        err += fabs((double)(nw - old));
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t i = wave; i < nl; i += THREADS / 64) {
+        const uint32_t r = rb.row0 + l.sorted[i];
+        const uint32_t a0 = off[r] - e0, z0 = off[r + 1] - e0;
+        const float s = cz_exact::wave_seq_sum<8>(tile + a0, z0 - a0, 0.0f);
+        if (lane == 0) err += finish_row(s, r, scores[r], out_deg[row_begin + r], row_begin, contrib_out, scores, base, damping);
     }
     return err;
 }
@@ -112,84 +173,83 @@ pr_step_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__
                uint32_t row_begin, const float *__restrict__ contrib_in, float *__restrict__ contrib_out,
                float *__restrict__ scores /* local */, float base, float damping, double *__restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float tile[kGTileNnz];
-    __shared__ __attribute__((aligned(16))) float tile2[kGTileNnz];  // long rows only: the tile being gathered while `tile` is summed
     __shared__ double red[kGThreads / 64];
+    __shared__ WaveRowList wl;
     const RowBlock rb = blocks[blockIdx.x];
     const int tid = threadIdx.x;
     const uint32_t e0 = rb.e0, e1 = rb.e1;
-    double err = 0.0;
-    if (e1 - e0 <= (uint32_t)kGTileNnz) {
-        // phase 1: coalesced id stream + gather
-        const uint32_t nnz = e1 - e0;
-        uint32_t i = tid;
-        for (; i + 3 * kGThreads < nnz; i += 4 * kGThreads) {
-            uint32_t s0 = src[e0 + i], s1 = src[e0 + i + kGThreads], s2 = src[e0 + i + 2 * kGThreads],
-                     s3 = src[e0 + i + 3 * kGThreads];
-            float c0 = contrib_in[s0], c1 = contrib_in[s1], c2 = contrib_in[s2], c3 = contrib_in[s3];
-            tile[i] = c0;
-            tile[i + kGThreads] = c1;
-            tile[i + 2 * kGThreads] = c2;
-            tile[i + 3 * kGThreads] = c3;
-        }
-        for (; i < nnz; i += kGThreads) tile[i] = contrib_in[src[e0 + i]];
-        __syncthreads();
-        err = rows_epilogue<kGThreads>(rb, off, e0, tile, out_deg, row_begin, contrib_out, scores, base, damping);
-    } else {
-        // A single long row (a hub): its in-order f32 sum is a serial chain that ONE lane has to walk -- the critical
-        // path of a sweep on a skewed graph (a 438 k-term row: 5 ms when fill and sum alternated).  So the chain is
-        // kept as tight as it can be: two LDS tiles, waves 1..3 gather the next tile while lane 0 of wave 0 adds the
-        // current one, four values per ds_read_b128, nothing but dependent v_add_f32 in between.
-        const uint32_t r = rb.row0;
-        float s = 0.0f;
-        {
-            const uint32_t nnz = min((uint32_t)kGTileNnz, e1 - e0);
-            for (uint32_t i = tid; i < nnz; i += kGThreads) tile[i] = contrib_in[src[e0 + i]];
-        }
-        __syncthreads();
-        int cur = 0;
-        for (uint32_t t0 = e0; t0 < e1; t0 += kGTileNnz, cur ^= 1) {
-            const uint32_t nnz = min((uint32_t)kGTileNnz, e1 - t0);
-            if (tid == 0) {
-                const float *cb = cur ? tile2 : tile;
-                const float4 *t4 = (const float4 *)cb;
-                // the LDS reads of the next 16 values are in flight while the current 16 are added (a read waited for
-                // in place costs ~100 cycles per 4 adds: 24 cycles per term measured)
-                uint32_t e = 0;
-                if (nnz >= 16) {
-                    float4 a0 = t4[0], a1 = t4[1], a2 = t4[2], a3 = t4[3];
-                    for (; e + 32 <= nnz; e += 16) {
-                        const float4 b0 = t4[(e >> 2) + 4], b1 = t4[(e >> 2) + 5], b2 = t4[(e >> 2) + 6], b3 = t4[(e >> 2) + 7];
-                        s = s + a0.x; s = s + a0.y; s = s + a0.z; s = s + a0.w;
-                        s = s + a1.x; s = s + a1.y; s = s + a1.z; s = s + a1.w;
-                        s = s + a2.x; s = s + a2.y; s = s + a2.z; s = s + a2.w;
-                        s = s + a3.x; s = s + a3.y; s = s + a3.z; s = s + a3.w;
-                        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-                    }
-                    s = s + a0.x; s = s + a0.y; s = s + a0.z; s = s + a0.w;
-                    s = s + a1.x; s = s + a1.y; s = s + a1.z; s = s + a1.w;
-                    s = s + a2.x; s = s + a2.y; s = s + a2.z; s = s + a2.w;
-                    s = s + a3.x; s = s + a3.y; s = s + a3.z; s = s + a3.w;
-                    e += 16;
-                }
-                for (; e < nnz; e++) s = s + cb[e];
-            } else if (tid >= 64 && t0 + kGTileNnz < e1) {
-                const uint32_t n0 = t0 + kGTileNnz;
-                const uint32_t nn = min((uint32_t)kGTileNnz, e1 - n0);
-                float *nx = cur ? tile : tile2;
-                for (uint32_t i = tid - 64; i < nn; i += kGThreads - 64) nx[i] = contrib_in[src[n0 + i]];
-            }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            const float old = scores[r];
-            const float nw = base + damping * s;
-            scores[r] = nw;
-            contrib_out[row_begin + r] = nw / (float)out_deg[row_begin + r];
-            err = fabs((double)(nw - old));
-        }
+    if (tid == 0) wl.n = 0;
+    // phase 1: coalesced id stream + gather (a block holds at most one tile; longer rows: pr_hub_kernel)
+    const uint32_t nnz = e1 - e0;
+    uint32_t i = tid;
+    for (; i + 3 * kGThreads < nnz; i += 4 * kGThreads) {
+        uint32_t s0 = src[e0 + i], s1 = src[e0 + i + kGThreads], s2 = src[e0 + i + 2 * kGThreads],
+                 s3 = src[e0 + i + 3 * kGThreads];
+        float c0 = contrib_in[s0], c1 = contrib_in[s1], c2 = contrib_in[s2], c3 = contrib_in[s3];
+        tile[i] = c0;
+        tile[i + kGThreads] = c1;
+        tile[i + 2 * kGThreads] = c2;
+        tile[i + 3 * kGThreads] = c3;
     }
+    for (; i < nnz; i += kGThreads) tile[i] = contrib_in[src[e0 + i]];
+    __syncthreads();
+    // phase 2: one lane per row adds its LDS segment in order; rows of >= kWaveRow terms are left to the waves
+    double err = 0.0;
+    for (uint32_t r = rb.row0 + tid; r < rb.row1; r += kGThreads) {
+        const uint32_t a = off[r] - e0, b = off[r + 1] - e0;
+        if (b - a >= kWaveRow) {
+            wl.raw[atomicAdd(&wl.n, 1u)] = r - rb.row0;
+            continue;
+        }
+        const float s = lane_row_sum(tile, a, b);
+        err += finish_row(s, r, scores[r], out_deg[row_begin + r], row_begin, contrib_out, scores, base, damping);
+    }
+    const uint32_t nl = order_wave_rows(wl);
+    if (nl) err += wave_rows<kGThreads>(wl, nl, rb, off, e0, tile, out_deg, row_begin, contrib_out, scores, base, damping);
     const double total = block_sum_f64<kGThreads>(err, red);
     if (tid == 0) partial[blockIdx.x] = total;
+}
+
+// ---- hub rows: a row longer than a tile, one workgroup per row -------------------------------------------------------
+// The row is gathered tile by tile (two LDS tiles: waves 1..15 gather the next one while wave 0 adds the current one
+// to the running sum with exact_sum.cuh, ~1 cycle per term instead of the ~14 of a one-lane chain).
+__global__ void __launch_bounds__(kHThreads)
+pr_hub_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__ src, const uint32_t *__restrict__ out_deg,
+              uint32_t row_begin, const float *__restrict__ contrib_in, float *__restrict__ contrib_out,
+              float *__restrict__ scores, float base, float damping, double *__restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float tiles[2][kHTileNnz];
+    const RowBlock rb = blocks[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t e0 = rb.e0, e1 = rb.e1, r = rb.row0;
+    {
+        const uint32_t nnz = min((uint32_t)kHTileNnz, e1 - e0);
+        for (uint32_t i = tid; i < nnz; i += kHThreads) tiles[0][i] = contrib_in[src[e0 + i]];
+    }
+    __syncthreads();
+    float s = 0.0f;
+    int cur = 0;
+    for (uint32_t t0 = e0; t0 < e1; t0 += kHTileNnz, cur ^= 1) {
+        if (tid < 64) {
+            s = cz_exact::wave_seq_sum<16>(tiles[cur], min((uint32_t)kHTileNnz, e1 - t0), s);
+        } else if (t0 + kHTileNnz < e1) {
+            const uint32_t n0 = t0 + kHTileNnz;
+            const uint32_t nn = min((uint32_t)kHTileNnz, e1 - n0);
+            float *nx = tiles[cur ^ 1];
+            constexpr uint32_t G = kHThreads - 64;
+            uint32_t i = tid - 64;
+            for (; i + 3 * G < nn; i += 4 * G) {
+                const uint32_t s0 = src[n0 + i], s1 = src[n0 + i + G], s2 = src[n0 + i + 2 * G], s3 = src[n0 + i + 3 * G];
+                const float c0 = contrib_in[s0], c1 = contrib_in[s1], c2 = contrib_in[s2], c3 = contrib_in[s3];
+                nx[i] = c0;
+                nx[i + G] = c1;
+                nx[i + 2 * G] = c2;
+                nx[i + 3 * G] = c3;
+            }
+            for (; i < nn; i += G) nx[i] = contrib_in[src[n0 + i]];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) partial[blockIdx.x] = finish_row(s, r, scores[r], out_deg[row_begin + r], row_begin, contrib_out, scores, base, damping);
 }
 
 // ---- "blocked" formulation ----------------------------------------------------------------------------------
@@ -260,10 +320,10 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
                  const uint2 *__restrict__ seg /* [blocks][S+1]: (stream position, block-local prefix) */, uint32_t S,
                  const uint16_t *__restrict__ perm, const uint32_t *__restrict__ vpos, const float *__restrict__ val,
                  const uint32_t *__restrict__ out_deg, uint32_t row_begin, float *__restrict__ contrib_out,
-                 float *__restrict__ scores, float base, float damping, double *__restrict__ partial, int xcd_remap,
-                 double *__restrict__ seg_sum /* relaxed plans: sum of a hub-row segment, per block */, int relaxed_rows) {
+                 float *__restrict__ scores, float base, float damping, double *__restrict__ partial, int xcd_remap) {
     __shared__ float tile[kBTileNnz];
     __shared__ double red[kBThreads / 64];
+    __shared__ WaveRowList wl;
     // runs longer than one wave instruction (a skewed graph: most of a row block's edges come from the few slices that
     // hold the hubs): the first 64 values are placed by the wave that owns the run, the rest is queued here in pieces of
     // <= 64 values and placed afterwards by ALL waves, one piece per wave instruction -- not 64 values at a time by the
@@ -271,7 +331,10 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
     // longer than 64 (< 256 of those).
     __shared__ uint32_t tail_st[512], tail_p0[512], tail_cnt[512];
     __shared__ uint32_t n_tail;
-    if (threadIdx.x == 0) n_tail = 0;
+    if (threadIdx.x == 0) {
+        n_tail = 0;
+        wl.n = 0;
+    }
     __syncthreads();
     constexpr int NW = kBThreads / 64;
     constexpr int RPL = kMaxRowsPerBlock / kBThreads;  // rows per lane
@@ -386,118 +449,25 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
         if (lane < tail_cnt[i]) tile[pm[tail_p0[i] + lane]] = val[tail_st[i] + lane];
     }
     __syncthreads();
-    if (rb.row1 == rb.row0) {
-        // relaxed plans only: this block is one SEGMENT of a row longer than a tile (a hub).  Its values are added by
-        // the whole workgroup -- 16 consecutive values per lane in f32, the lanes' sums in f64 in a fixed order -- and
-        // pr_hub_finish_kernel adds the row's segments and runs the epilogue.  (The exact form keeps such a row on one
-        // lane: the reference's sequential f32 sum, ~14 cycles per term, 3 ms for a 438 k-term row.)
-        const uint32_t nnz = rb.e1 - e0;
-        float s = 0.0f;
-        const uint32_t a = threadIdx.x * 16;
-        if (a < nnz) {
-            const uint32_t z = min(nnz, a + 16);
-            for (uint32_t e = a; e < z; e++) s = s + tile[e];
-        }
-        const double total = block_sum_f64<kBThreads>((double)s, red);
-        if (threadIdx.x == 0) {
-            seg_sum[b] = total;
-            partial[b] = 0.0;
-        }
-        return;
-    }
     double err = 0.0;
-    // Rows are summed by ONE lane each, in order (the reference's sequential f32 sum).  A long row is a serial chain; its
-    // LDS reads are kept 16 values ahead of the adds (a read waited for in place costs ~100 cycles per add: a 10^4-term
-    // row then holds its whole workgroup for 0.5 ms, which is what made a sweep over an R-MAT graph 4 ms).
-    // Relaxed plans (`relaxed_rows`): rows of >= kWaveRow terms are left out here and summed afterwards by a whole wave
-    // each -- every lane a strided share in f32, the lanes' sums in f64 -- like the hub segments above.
-    constexpr uint32_t kWaveRow = 256;
-    __shared__ uint32_t long_row[64];  // relaxed: local rows handed to the waves (a tile holds <= 64 rows of >= 256 terms)
-    __shared__ uint32_t n_long;
-    if (relaxed_rows) {
-        if (threadIdx.x == 0) n_long = 0;
-        __syncthreads();
-    }
+    // Rows are summed in order (the reference's sequential f32 sum): one lane per row, and the rows of >= kWaveRow terms
+    // afterwards by a wave each (exact_sum.cuh: the same bits, without the serial chain a skewed graph's sweep waited for).
 #pragma unroll
     for (int j = 0; j < RPL; j++) {
         const uint32_t r = rb.row0 + threadIdx.x + j * kBThreads;
         if (r < rb.row1) {
-            const uint32_t len = rz[j] - ra[j];
-            if (relaxed_rows && len >= kWaveRow) {
-                long_row[atomicAdd(&n_long, 1u)] = threadIdx.x + j * kBThreads;
+            if (rz[j] - ra[j] >= kWaveRow) {
+                wl.raw[atomicAdd(&wl.n, 1u)] = threadIdx.x + j * kBThreads;
                 continue;
             }
-            float s = 0.0f;
-            uint32_t e = ra[j];
-            if (len >= 32) {
-                float a[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) a[i] = tile[e + i];
-                for (; e + 32 <= rz[j]; e += 16) {
-                    float nx[16];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) nx[i] = tile[e + 16 + i];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) s = s + a[i];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) a[i] = nx[i];
-                }
-#pragma unroll
-                for (int i = 0; i < 16; i++) s = s + a[i];
-                e += 16;
-            }
-            for (; e < rz[j]; e++) s = s + tile[e];
-            const float nw = base + damping * s;  // two roundings, like the reference (no fma: -ffp-contract=off)
-            scores[r] = nw;
-            contrib_out[row_begin + r] = nw / (float)od[j];
-            err += fabs((double)(nw - old[j]));
+            const float s = lane_row_sum(tile, ra[j], rz[j]);
+            err += finish_row(s, r, old[j], od[j], row_begin, contrib_out, scores, base, damping);
         }
     }
-    if (relaxed_rows) {
-        __syncthreads();
-        const uint32_t nl = n_long;
-        for (uint32_t i = wave; i < nl; i += NW) {
-            const uint32_t lr = long_row[i];
-            const uint32_t r = rb.row0 + lr;
-            const uint32_t a0 = off[r] - e0, z0 = off[r + 1] - e0;
-            float s = 0.0f;
-            for (uint32_t e = a0 + lane; e < z0; e += 64) s = s + tile[e];
-            double d = (double)s;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o, 64);
-            if (lane == 0) {
-                const float sum = (float)d;
-                const float old_r = scores[r];
-                const float nw = base + damping * sum;
-                scores[r] = nw;
-                contrib_out[row_begin + r] = nw / (float)out_deg[row_begin + r];
-                err += fabs((double)(nw - old_r));
-            }
-        }
-    }
+    const uint32_t nl = order_wave_rows(wl);
+    if (nl) err += wave_rows<kBThreads>(wl, nl, rb, off, e0, tile, out_deg, row_begin, contrib_out, scores, base, damping);
     const double total = block_sum_f64<kBThreads>(err, red);
     if (threadIdx.x == 0) partial[b] = total;
-}
-
-// relaxed plans: one thread per hub row adds the row's segment sums (ascending, f64) and runs the epilogue
-struct HubRow {
-    uint32_t row, blk0, nblk, pad;
-};
-__global__ void __launch_bounds__(256)
-pr_hub_finish_kernel(const HubRow *__restrict__ hubs, uint32_t n_hubs, const double *__restrict__ seg_sum,
-                     const uint32_t *__restrict__ out_deg, uint32_t row_begin, float *__restrict__ contrib_out,
-                     float *__restrict__ scores, float base, float damping, double *__restrict__ partial) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_hubs) return;
-    const HubRow h = hubs[i];
-    double acc = 0.0;
-    for (uint32_t k = 0; k < h.nblk; k++) acc += seg_sum[h.blk0 + k];
-    const float s = (float)acc;
-    const float old = scores[h.row];
-    const float nw = base + damping * s;
-    scores[h.row] = nw;
-    contrib_out[row_begin + h.row] = nw / (float)out_deg[row_begin + h.row];
-    partial[i] = fabs((double)(nw - old));
 }
 
 // ---- plan construction kernels (run once) -------------------------------------------------------------------
@@ -641,9 +611,9 @@ struct cz_pagerank_plan {
     float damping = 0, base = 0, init = 0;
     bool blocked = false;
     int xcd_remap = 1;
-    // gather formulation: every row block; blocked formulation: the long-row blocks only
-    uint32_t n_gblocks = 0;
-    RowBlock *d_gblocks = nullptr;
+    // gather formulation: the row blocks of at most one tile; either formulation: the rows longer than a tile (hubs)
+    uint32_t n_gblocks = 0, n_hblocks = 0;
+    RowBlock *d_gblocks = nullptr, *d_hblocks = nullptr;
     // blocked formulation
     uint32_t wlog = 0, S = 0, n_chunks = 0, n_bblocks = 0;
     RowBlock *d_bblocks = nullptr;
@@ -655,14 +625,9 @@ struct cz_pagerank_plan {
     uint2 *d_seg = nullptr;
     float *d_val = nullptr;
     uint64_t E_blocked = 0;
-    // relaxed plans: rows longer than a tile, cut into segment blocks of the blocked layout
-    bool relaxed = false;
-    uint32_t n_hubs = 0;
-    HubRow *d_hubs = nullptr;
-    double *d_segsum = nullptr;
     double h2d_ms = 0, build_ms = 0;  // what creating the plan cost: CSR upload / static layout
-    // rows longer than a tile are single f32 chains on a handful of workgroups (pr_step_kernel): they run on a stream of their
-    // own beside the blocked sweep of the other rows (both read contrib_in, write disjoint rows), joined before the error sum
+    // rows longer than a tile are a handful of workgroups (pr_hub_kernel): they run on a stream of their own beside the
+    // sweep of the other rows (both read contrib_in, write disjoint rows), joined before the error sum
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // shared
@@ -670,8 +635,8 @@ struct cz_pagerank_plan {
     float *d_scores = nullptr;
     double *d_partial = nullptr;
     ~cz_pagerank_plan() {
-        void *ps[] = {d_gblocks, d_bblocks, d_items, d_asrc, d_perm, d_vpos, d_seg, d_val, d_off, d_src, d_outdeg, d_scores, d_partial,
-                      d_hubs, d_segsum};
+        void *ps[] = {d_gblocks, d_hblocks, d_bblocks, d_items, d_asrc, d_perm, d_vpos, d_seg, d_val, d_off, d_src, d_outdeg, d_scores,
+                      d_partial};
         for (void *p : ps)
             if (p) (void)hipFree(p);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -683,23 +648,12 @@ struct cz_pagerank_plan {
 namespace {
 
 // cut [0, rows) into row blocks: consecutive rows whose in-edges fit one tile; a row longer than a tile is alone
-int cut_row_blocks(const uint32_t *in_offsets, uint32_t rows, uint32_t tile, std::vector<RowBlock> &blocks,
-                   std::vector<HubRow> *hubs = nullptr) {
+int cut_row_blocks(const uint32_t *in_offsets, uint32_t rows, uint32_t tile, std::vector<RowBlock> &blocks) {
     blocks.clear();
     blocks.reserve((size_t)(in_offsets[rows] / tile) + rows / kMaxRowsPerBlock + 16);
     uint32_t r = 0;
     while (r < rows) {
         uint32_t r1 = r + 1;
-        if (hubs && in_offsets[r1] - in_offsets[r] > tile) {  // relaxed: a hub row becomes segment blocks (row1 == row0)
-            HubRow h{r, (uint32_t)blocks.size(), 0, 0};
-            for (uint32_t e = in_offsets[r]; e < in_offsets[r1]; e += tile) {
-                blocks.push_back({r, r, e, std::min(in_offsets[r1], e + tile)});
-                h.nblk++;
-            }
-            hubs->push_back(h);
-            r = r1;
-            continue;
-        }
         if (in_offsets[r1] - in_offsets[r] <= tile) {
             const uint32_t lim = std::min<uint32_t>(rows, r + kMaxRowsPerBlock);
             while (r1 < lim && in_offsets[r1 + 1] - in_offsets[r] <= tile) r1++;
@@ -715,8 +669,7 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
     const uint32_t rows = p->rows;
     const uint64_t E = p->E;
     std::vector<RowBlock> all;
-    std::vector<HubRow> hubs;
-    cut_row_blocks(h_off, rows, kBTileNnz, all, p->relaxed ? &hubs : nullptr);
+    cut_row_blocks(h_off, rows, kBTileNnz, all);
     std::vector<RowBlock> bb, gb;  // blocked / long-row
     uint64_t e_blocked = 0;
     for (const RowBlock &rb : all) {
@@ -726,14 +679,6 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
             bb.push_back(rb);
             e_blocked += nnz;
         }
-    }
-    if (!hubs.empty()) {  // relaxed: every block is in the blocked layout, so `all` and `bb` number blocks alike
-        if (!gb.empty() || bb.size() != all.size()) return cz::set_error(CZ_E_HIP, "internal: relaxed plan with long-row blocks");
-        p->n_hubs = (uint32_t)hubs.size();
-        CZ_HIP(hipMalloc((void **)&p->d_hubs, hubs.size() * sizeof(HubRow)));
-        CZ_HIP(hipMemcpy(p->d_hubs, hubs.data(), hubs.size() * sizeof(HubRow), hipMemcpyHostToDevice));
-        CZ_HIP(hipMalloc((void **)&p->d_segsum, bb.size() * sizeof(double)));
-        n_chunks = 1;  // hub segments index seg_sum by global block number
     }
     const uint32_t S = (uint32_t)(((uint64_t)p->N + (1u << wlog) - 1) >> wlog);
     n_chunks = std::max(1u, std::min<uint32_t>(n_chunks, (uint32_t)std::max<size_t>(1, bb.size())));
@@ -758,7 +703,8 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
     p->S = S;
     p->n_chunks = n_chunks;
     p->n_bblocks = (uint32_t)bb.size();
-    p->n_gblocks = (uint32_t)gb.size();
+    p->n_gblocks = 0;
+    p->n_hblocks = (uint32_t)gb.size();
     p->blk_ptr = blk_ptr;
     p->E_blocked = e_blocked;
     const uint32_t n_keys = n_chunks * S;  // key n_keys = "not in the blocked layout" (long rows)
@@ -770,8 +716,8 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
 
     CZ_HIP(hipMalloc((void **)&p->d_bblocks, std::max<size_t>(1, bb.size()) * sizeof(RowBlock)));
     if (!bb.empty()) CZ_HIP(hipMemcpy(p->d_bblocks, bb.data(), bb.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
-    CZ_HIP(hipMalloc((void **)&p->d_gblocks, std::max<size_t>(1, gb.size()) * sizeof(RowBlock)));
-    if (!gb.empty()) CZ_HIP(hipMemcpy(p->d_gblocks, gb.data(), gb.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
+    CZ_HIP(hipMalloc((void **)&p->d_hblocks, std::max<size_t>(1, gb.size()) * sizeof(RowBlock)));
+    if (!gb.empty()) CZ_HIP(hipMemcpy(p->d_hblocks, gb.data(), gb.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
 
     cz::DevBuf<RowBlock> d_kblocks;
     cz::DevBuf<uint32_t> d_kchunk, keys_in, keys_out, idx_in, idx_out, d_keyptr, d_bad;
@@ -873,7 +819,7 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
     CZ_HIP(hipMalloc((void **)&p->d_items, std::max<size_t>(1, items.size()) * sizeof(AItem)));
     if (!items.empty()) CZ_HIP(hipMemcpy(p->d_items, items.data(), items.size() * sizeof(AItem), hipMemcpyHostToDevice));
     CZ_HIP(hipDeviceSynchronize());
-    if (gb.empty()) {  // the global ids are only needed by the long-row gather
+    if (gb.empty()) {  // the global ids are only needed by the hub rows' gather
         (void)hipFree(p->d_src);
         p->d_src = nullptr;
     }
@@ -917,7 +863,6 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     p->damping = damping;
     p->init = N ? 1.0f / (float)N : 0.f;
     p->base = N ? (1.0f - damping) / (float)N : 0.f;
-    p->relaxed = (flags & CZ_PR_RELAXED) != 0;
     const auto t_h2d = std::chrono::steady_clock::now();
     CZ_HIP(hipMalloc((void **)&p->d_off, ((size_t)rows + 1) * 4));
     CZ_HIP(hipMalloc((void **)&p->d_src, std::max<uint64_t>(1, E) * 4));
@@ -955,13 +900,17 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
         rc = build_blocked(p.get(), in_offsets, wlog, n_chunks);
         if (rc) return rc;
     } else {
-        std::vector<RowBlock> blocks;
-        if (rows) cut_row_blocks(in_offsets, rows, kGTileNnz, blocks);
+        std::vector<RowBlock> all, blocks, hubs;
+        if (rows) cut_row_blocks(in_offsets, rows, kGTileNnz, all);
+        for (const RowBlock &rb : all) (rb.e1 - rb.e0 > (uint32_t)kGTileNnz ? hubs : blocks).push_back(rb);
         p->n_gblocks = (uint32_t)blocks.size();
+        p->n_hblocks = (uint32_t)hubs.size();
         CZ_HIP(hipMalloc((void **)&p->d_gblocks, std::max<size_t>(1, blocks.size()) * sizeof(RowBlock)));
         if (!blocks.empty()) CZ_HIP(hipMemcpy(p->d_gblocks, blocks.data(), blocks.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
+        CZ_HIP(hipMalloc((void **)&p->d_hblocks, std::max<size_t>(1, hubs.size()) * sizeof(RowBlock)));
+        if (!hubs.empty()) CZ_HIP(hipMemcpy(p->d_hblocks, hubs.data(), hubs.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
     }
-    CZ_HIP(hipMalloc((void **)&p->d_partial, std::max<size_t>(1, (size_t)p->n_gblocks + p->n_bblocks + p->n_hubs) * 8));
+    CZ_HIP(hipMalloc((void **)&p->d_partial, std::max<size_t>(1, (size_t)p->n_bblocks + p->n_gblocks + p->n_hblocks) * 8));
     CZ_HIP(hipDeviceSynchronize());
     p->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
     *out = p.release();
@@ -994,10 +943,12 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
     int rc = cz::ensure_device();
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    const uint32_t n_partial = p->n_gblocks + p->n_bblocks + p->n_hubs;
+    const uint32_t n_partial = p->n_bblocks + p->n_gblocks + p->n_hblocks;  // partial errors: [blocked | gather | hub]
     if (n_partial == 0) return CZ_OK;
-    if (p->blocked) {
-        const bool fork = p->n_gblocks > 0 && p->n_bblocks > 0;
+    const uint32_t n_main = p->n_bblocks + p->n_gblocks;
+    const bool fork = p->n_hblocks > 0 && n_main > 0;
+    if (p->n_hblocks) {
+        hipStream_t hs = stream;
         if (fork) {
             if (!p->side) {
                 CZ_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
@@ -1006,11 +957,13 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
             }
             CZ_HIP(hipEventRecord(p->ev_fork, stream));  // contrib_in is ready where the caller's stream stands
             CZ_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
-            hipLaunchKernelGGL(pr_step_kernel, dim3(p->n_gblocks), dim3(kGThreads), 0, p->side, p->d_gblocks, p->d_off, p->d_src,
-                               p->d_outdeg, p->row_begin, contrib_in_dev, contrib_out_dev, p->d_scores, p->base, p->damping,
-                               p->d_partial + p->n_bblocks);
-            CZ_HIP(hipEventRecord(p->ev_join, p->side));
+            hs = p->side;
         }
+        hipLaunchKernelGGL(pr_hub_kernel, dim3(p->n_hblocks), dim3(kHThreads), 0, hs, p->d_hblocks, p->d_src, p->d_outdeg,
+                           p->row_begin, contrib_in_dev, contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial + n_main);
+        if (fork) CZ_HIP(hipEventRecord(p->ev_join, p->side));
+    }
+    if (p->blocked) {
         for (uint32_t c = 0; c < p->n_chunks; c++) {
             const uint32_t i0 = p->item_ptr[c], i1 = p->item_ptr[c + 1];
             const uint32_t b0 = p->blk_ptr[c], b1 = p->blk_ptr[c + 1];
@@ -1022,30 +975,19 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
                 if (p->d_vpos)
                     hipLaunchKernelGGL(pb_reduce_kernel<true>, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
                                        p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
-                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap,
-                                       p->d_segsum, p->relaxed ? 1 : 0);
+                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap);
                 else
                     hipLaunchKernelGGL(pb_reduce_kernel<false>, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
                                        p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
-                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap,
-                                       p->d_segsum, p->relaxed ? 1 : 0);
+                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap);
             }
         }
-        if (p->n_hubs)  // relaxed: the hub rows' segment sums -> scores
-            hipLaunchKernelGGL(pr_hub_finish_kernel, dim3((p->n_hubs + 255) / 256), dim3(256), 0, stream, p->d_hubs, p->n_hubs,
-                               p->d_segsum, p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores, p->base, p->damping,
-                               p->d_partial + p->n_bblocks + p->n_gblocks);
-        if (fork)
-            CZ_HIP(hipStreamWaitEvent(stream, p->ev_join, 0));
-        else if (p->n_gblocks)  // rows longer than a tile (and nothing else)
-            hipLaunchKernelGGL(pr_step_kernel, dim3(p->n_gblocks), dim3(kGThreads), 0, stream, p->d_gblocks, p->d_off, p->d_src,
-                               p->d_outdeg, p->row_begin, contrib_in_dev, contrib_out_dev, p->d_scores, p->base, p->damping,
-                               p->d_partial + p->n_bblocks);
-    } else {
+    } else if (p->n_gblocks) {
         hipLaunchKernelGGL(pr_step_kernel, dim3(p->n_gblocks), dim3(kGThreads), 0, stream, p->d_gblocks, p->d_off, p->d_src,
                            p->d_outdeg, p->row_begin, contrib_in_dev, contrib_out_dev, p->d_scores, p->base, p->damping,
                            p->d_partial);
     }
+    if (fork) CZ_HIP(hipStreamWaitEvent(stream, p->ev_join, 0));
     hipLaunchKernelGGL(pr_err_reduce_kernel, dim3(1), dim3(1024), 0, stream, p->d_partial, n_partial, err_out_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "pagerank step launch: %s", hipGetErrorString(e));

@@ -26,10 +26,10 @@ def _csr32(off, tgt):
 
 
 def pagerank(in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10, poison=None, cache_key=None,
-             relaxed=False, mode: Optional[str] = None, timing: Optional[dict] = None):
+             mode: Optional[str] = None, timing: Optional[dict] = None):
     """graph::page_rank as called by PageRank::run (pagerank.rs:47-50): (scores f32[N], iterations, error).
     cache_key = (hi, lo): the caller's identity of (relation, snapshot); the device layout is then kept between calls
-    (cz_pagerank_cached).  relaxed: hub rows summed in parallel (CZ_PR_RELAXED).  timing: filled with where the time went."""
+    (cz_pagerank_cached).  timing: filled with where the time went."""
     in_off, in_src = _csr32(in_off, in_src)
     out_deg = _u32(out_deg)
     N = out_deg.size
@@ -38,7 +38,7 @@ def pagerank(in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10,
     err = C.c_double(0.0)
     tm = _lib.PagerankTiming()
     hi, lo = cache_key if cache_key is not None else (0, 0)
-    flags = (_lib.CZ_PR_RELAXED if relaxed else 0) | {None: 0, "gather": _lib.CZ_PR_GATHER, "blocked": _lib.CZ_PR_BLOCKED}[mode]
+    flags = {None: 0, "gather": _lib.CZ_PR_GATHER, "blocked": _lib.CZ_PR_BLOCKED}[mode]
     check(_lib.lib().cz_pagerank_cached(int(hi), int(lo), ptr(in_off), ptr(in_src), ptr(out_deg), N, in_src.size,
                                         np.float32(damping), float(tolerance), int(max_iter), flags, ptr(scores),
                                         C.byref(it), C.byref(err), ptr(poison), C.byref(tm)))
@@ -52,7 +52,7 @@ class PageRankPlan:
     """Resident / row-sharded PageRank (cz_pagerank_plan_*): rows [row_begin,row_end) of the in-CSR."""
 
     def __init__(self, in_off_local, in_src, out_deg, N, row_begin, row_end, damping=0.85, device_ptrs=False,
-                 mode: Optional[str] = None, relaxed: bool = False):
+                 mode: Optional[str] = None):
         """host arrays, or (device_ptrs=True) uint32 device tensors already resident in HBM.
         mode: None (chosen from the shard's shape) | "gather" | "blocked" -- the two device formulations of the
         sweep (csrc/pagerank.hip); both give the reference's scores bit for bit."""
@@ -63,7 +63,6 @@ class PageRankPlan:
         check(_lib.lib().cz_pagerank_plan_create(ptr(in_off_local), ptr(in_src), ptr(out_deg), N, row_begin, row_end,
                                                  np.float32(damping), C.byref(h),
                                                  (_lib.CZ_DEVICE_PTRS if device_ptrs else 0)
-                                                 | (_lib.CZ_PR_RELAXED if relaxed else 0)
                                                  | {None: 0, "gather": _lib.CZ_PR_GATHER,
                                                     "blocked": _lib.CZ_PR_BLOCKED}[mode]))
         self._h = h

@@ -41,13 +41,8 @@ extern "C" {
 /* cz_knn_bruteforce: compute the B x N dot products as one dense f32 GEMM on the matrix cores (Cosine / IP only;
  * every dot product is then a k-ordered fmaf chain instead of the search kernel's lane-parallel tree) */
 #define CZ_BF_GEMM 8u
-/* cz_pagerank_plan_create / cz_pagerank_cached: long rows of the blocked sweep are summed in parallel instead of by one
- * lane in the reference's sequential f32 order -- rows of >= 256 in-edges by a wave, rows longer than one tile (hubs,
- * > 16384 in-edges) as segments by whole workgroups.  After ONE sweep only those rows differ from the reference, in the
- * last bits; over the iterations the difference spreads and stays at the level of the rounding error of the reference's
- * own long f32 sums (~1e-5 relative on R-MAT at 10M / 100M; north_star's bar is 1e-5).  On a skewed graph a sweep is
- * then bounded by bandwidth instead of by the longest serial chain.  Default (flag absent): every row bit-identical. */
-#define CZ_PR_RELAXED 16u
+/* (16u was CZ_PR_RELAXED until round 3 -- reordered sums for long rows, out of north_star's 1e-5 on R-MAT.  Removed:
+ * long rows are now summed in parallel AND in the reference's sequential f32 order, csrc/exact_sum.cuh.) */
 
 typedef enum {
     CZ_OK = 0,
@@ -215,7 +210,7 @@ int cz_pagerank(const uint32_t *in_offsets, const uint32_t *in_sources, const ui
  * not cache.  On a hit with the same N, E, damping and flags the arrays are not read again (the key is the caller's
  * promise that they are unchanged), which takes a repeated `?[] <~ PageRank(*rel[])` from upload + plan + iterations
  * to iterations alone.  Up to CZ_PR_CACHE_PLANS (default 4) plans are kept, least recently used dropped first.
- * flags: CZ_PR_GATHER | CZ_PR_BLOCKED | CZ_PR_RELAXED.  timing (optional): where the call's time went. */
+ * flags: CZ_PR_GATHER | CZ_PR_BLOCKED.  timing (optional): where the call's time went. */
 typedef struct {
     double h2d_ms;        /* CSR upload (0 on a cache hit) */
     double plan_build_ms; /* static layout of the sweep (0 on a cache hit) */
@@ -292,7 +287,7 @@ int cz_pagerank_sharded(cz_comm *comm, cz_pagerank_plan *plan, uint32_t rows_per
                         uint32_t flags /* CZ_PR_EXCHANGE_ALLREDUCE */, uint32_t *iters_run, double *final_err,
                         const volatile uint8_t *poison, void *stream);
 /* cz_pagerank on n_gpus devices of this process (devices 0 .. n_gpus-1): host CSR in, scores [N] out.
- * flags: CZ_PR_GATHER | CZ_PR_BLOCKED | CZ_PR_RELAXED | CZ_PR_EXCHANGE_ALLREDUCE. */
+ * flags: CZ_PR_GATHER | CZ_PR_BLOCKED | CZ_PR_EXCHANGE_ALLREDUCE. */
 int cz_pagerank_multi(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N,
                       uint64_t E, float damping, double tolerance, uint32_t max_iter, int n_gpus, uint32_t flags,
                       float *scores, uint32_t *iters_run, double *final_err, const volatile uint8_t *poison);

@@ -9,7 +9,6 @@ pub const CZ_DEVICE_PTRS: u32 = 1;
 pub const CZ_PR_GATHER: u32 = 2;
 pub const CZ_PR_BLOCKED: u32 = 4;
 pub const CZ_BF_GEMM: u32 = 8;
-pub const CZ_PR_RELAXED: u32 = 16;
 pub const CZ_PR_EXCHANGE_ALLREDUCE: u32 = 32;
 pub const CZ_UNIQUE_ID_BYTES: u32 = 128;
 

@@ -179,10 +179,8 @@ impl FixedRule for PageRankGpu {
         // extra options of the GPU rule (absent = the reference's behaviour on one GPU):
         //   gpus: n      row-shard the sweep over n GPUs of this process (cz_pagerank_multi: one host thread + one RCCL
         //                communicator per GPU, in-place all-gather of the contribution slices each iteration)
-        //   relaxed: b   long rows summed in parallel (CZ_PR_RELAXED): scores differ from the sequential f32 sums in the last bits
         let gpus = payload.pos_integer_option("gpus", Some(1))? as c_int;
-        let relaxed = payload.bool_option("relaxed", Some(false))?;
-        let flags = if relaxed { CZ_PR_RELAXED } else { 0 };
+        let flags = 0u32;
         let g = edges.as_gpu_graph(undirected, true)?;
         if g.indices.is_empty() {
             return Ok(()); // pagerank.rs:43-45

@@ -356,25 +356,62 @@ def _hub_graph(oracle, n=60000, e=900000, hubs=3, seed=21):
     return util.graph_from_relation(oracle, rows[:, 0].astype(np.int64), rows[:, 1].astype(np.int64))
 
 
-def test_pagerank_relaxed_hub_rows(oracle, gpu_lib):
-    """CZ_PR_RELAXED: rows longer than a tile are summed as parallel segments.  Every other row keeps the reference's
-    bits; the hub rows stay within 1e-5 relative of the sequential f32 sum (north_star's bar for PageRank scores)."""
+def _rows_of_lengths(oracle, lengths, n, seed):
+    """a graph whose first len(lengths) nodes have exactly the given in-degrees (sources drawn without repetition),
+    everything else sparse; contributions span a few binades (out-degrees 1 .. ~200)"""
+    rng = np.random.default_rng(seed)
+    frm, to = [], []
+    for v, k in enumerate(lengths):
+        frm.append(rng.choice(np.arange(len(lengths), n), size=k, replace=False))
+        to.append(np.full(k, v))
+    m = 4 * n
+    s, d = rng.integers(0, n, m), rng.integers(len(lengths), n, m)
+    heavy = rng.integers(len(lengths), n, 40)   # a few sources with large out-degree: small contributions
+    s = np.where(rng.random(m) < 0.2, heavy[rng.integers(0, 40, m)], s)
+    frm.append(s[s != d])
+    to.append(d[s != d])
+    rows = np.unique(np.stack([np.concatenate(frm), np.concatenate(to)], 1), axis=0)
+    return util.graph_from_relation(oracle, rows[:, 0].astype(np.int64), rows[:, 1].astype(np.int64))
+
+
+@pytest.mark.parametrize("mode", ["blocked", "gather"])
+def test_pagerank_long_rows_summed_by_waves_keep_the_sequential_bits(oracle, gpu_lib, mode):
+    """Rows of >= 128 terms are summed by a whole wave (csrc/exact_sum.cuh), rows longer than a tile by pr_hub_kernel,
+    and both must give the bits of the reference's one-after-the-other f32 sum: lengths on both sides of every
+    threshold (lane / wave row at 128, pass sizes 512 / 1024, the tiles 4096 / 8192 / 16384), hubs of several tiles."""
     from cozo_amd import graph as G
-    g = _hub_graph(oracle)
+    lengths = [127, 128, 129, 191, 256, 511, 512, 513, 1023, 1024, 1025, 2000, 4095, 4096, 4097, 8191, 8192, 8193,
+               12345, 16383, 16384, 16385, 24576, 24577, 40000, 70001]
+    g = _rows_of_lengths(oracle, lengths, 90000, 5)
     indeg = np.diff(g["ioff"].astype(np.int64))
-    assert (indeg > 16384).sum() >= 2
-    exact, it0, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 6, mode="blocked")
-    os_, oit, _ = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 6)
-    assert np.array_equal(exact, os_)
-    rel, it1, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 6, mode="blocked", relaxed=True)
-    assert it1 == it0 == oit
-    err = np.abs(rel.astype(np.float64) - os_) / np.abs(os_)
-    assert err.max() <= 1e-5, err.max()
-    # one sweep from identical inputs: only rows long enough to be summed in parallel (>= 256 terms) may differ at all
-    one_e, _, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 1, mode="blocked")
-    one_r, _, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 1, mode="blocked", relaxed=True)
-    diff = np.flatnonzero(one_e != one_r)
-    assert set(diff.tolist()) <= set(np.flatnonzero(indeg >= 256).tolist())
+    assert indeg.max() >= 70001
+    for damping, tol, iters in [(0.85, 0.0, 6), (0.85, 1e-4, 10), (0.5, 0.0, 3)]:
+        got, it, err = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], damping, tol, iters, mode=mode)
+        want, oit, oerr = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], damping, tol, iters)
+        assert it == oit
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, (mode, damping, bad[:10], indeg[bad[:10]])
+        assert abs(err - oerr) <= 1e-9 * max(1.0, abs(oerr))
+    # the same call twice: the error sum is formed in a fixed order
+    a = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 4, mode=mode)
+    b = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 4, mode=mode)
+    assert np.array_equal(a[0], b[0]) and a[2] == b[2]
+
+
+def test_pagerank_skewed_degrees_bitexact(oracle, gpu_lib):
+    """power-law in-degrees (many rows between 32 and a few thousand terms in every row block)"""
+    from cozo_amd import graph as G
+    rng = np.random.default_rng(77)
+    n, e = 50000, 1500000
+    dst = np.minimum((n * rng.random(e) ** 4).astype(np.int64), n - 1)
+    src = rng.integers(0, n, e)
+    keep = src != dst
+    rows = np.unique(np.stack([src[keep], dst[keep]], 1), axis=0)
+    g = util.graph_from_relation(oracle, rows[:, 0], rows[:, 1])
+    want, oit, _ = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 5)
+    for mode in ("blocked", "gather"):
+        got, it, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 5, mode=mode)
+        assert it == oit and np.array_equal(got, want), mode
 
 
 def test_pagerank_plan_cache(graphs, oracle):
