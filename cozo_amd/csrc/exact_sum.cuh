@@ -51,36 +51,47 @@ CZ_XS_FN void split(uint32_t sbits, uint32_t &M, uint32_t &eb) {
 // bits of M * 2^(eb - 150) for M < 2^24 (M >= 2^23 carries into the exponent field by itself)
 CZ_XS_FN uint32_t join(uint32_t M, uint32_t eb) { return ((eb - 1u) << 23) + M; }
 
-// one term against a sum whose folded exponent is eb_s (and which is positive or zero)
+// one term against a sum whose folded exponent is eb_s (and which is positive or zero); straight-line code.
+// a / u = q + f with 0 <= f < 1 (u = the sum's ulp): `rup` rounds halves up, and on an exact tie the composition steps
+// back by one when that makes M + increment even (`tie`).  Everything else is "past the binade" (rup = kSat), i.e. left
+// to the true additions: a term at or above the sum's own exponent (it takes a normal sum out of its binade anyway),
+// negative terms (-0.0 included: the sign bit makes ea0 > 255), inf and nan (ea0 = 255 >= any eb_s).
+struct Term {
+    uint32_t rup, tie;  // tie: 1 when a / u is exactly q + 1/2 (then rup = q + 1)
+};
+CZ_XS_FN uint32_t funnel_low(uint32_t ma, uint32_t sh) {  // the sh bits dropped by ma >> sh, left-aligned (1 <= sh <= 31)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(ma, 0u, sh);
+#else
+    return ma << (32u - sh);
+#endif
+}
+CZ_XS_FN Term classify(uint32_t abits, uint32_t eb_s) {
+    const uint32_t ea0 = abits >> 23;
+    const uint32_t ea = ea0 ? ea0 : 1u;
+    const int32_t d = (int32_t)eb_s - (int32_t)ea;
+    const uint32_t ma = abits - ((ea - 1u) << 23);  // the mantissa with its implicit bit (none for a denormal)
+    const uint32_t sh = (uint32_t)(d < 1 ? 1 : (d > 25 ? 25 : d));  // ma / 2^25 < 1/2: adds nothing
+    const uint32_t low = funnel_low(ma, sh);
+    Term t;
+    t.rup = (ma >> sh) + (low >> 31);
+    t.tie = low == 0x80000000u ? 1u : 0u;
+    if (d <= 0) t.rup = kSat;  // kSat is even: a tie flag next to it changes nothing that matters
+    return t;
+}
+// the term as an increment pair: M even -> M + increment must be even on a tie; M odd -> the increment must be odd
 CZ_XS_FN Inc term_inc(uint32_t abits, uint32_t eb_s) {
+    const Term t = classify(abits, eb_s);
     Inc r;
-    uint32_t ea = (abits >> 23) & 0xffu;
-    uint32_t ma = abits & 0x7fffffu;
-    const bool negative = (abits >> 31) != 0 && (abits << 1) != 0;  // -0.0 adds nothing to a positive sum
-    if (negative || ea == 255u || eb_s == 255u) {
-        r.even = r.odd = kSat;
-        return r;
-    }
-    if (ea) ma |= 0x800000u;
-    else ea = 1;
-    if (ea >= eb_s) {
-        const uint32_t sh = ea - eb_s;
-        const uint32_t q = sh >= 3u ? kSat : (ma << sh);  // ma < 2^24: sh <= 2 stays below 2^26
-        r.even = r.odd = q < kSat ? q : kSat;
-        return r;
-    }
-    uint32_t sh = eb_s - ea;
-    if (sh > 25u) sh = 25u;  // ma / 2^25 < 1/2: adds nothing
-    const uint32_t q = ma >> sh;
-    const uint32_t rem = ma & ((1u << sh) - 1u);
-    const uint32_t half = 1u << (sh - 1u);
-    if (rem > half) r.even = r.odd = q + 1u;
-    else if (rem < half) r.even = r.odd = q;
-    else {  // tie: to the even one of M + q, M + q + 1
-        r.even = q + (q & 1u);
-        r.odd = q + ((q & 1u) ^ 1u);
-    }
+    r.even = t.rup - (t.tie & t.rup);
+    r.odd = t.rup - (t.tie & (t.rup ^ 1u));
     return r;
+}
+// one more term on a run whose increment (for a start of known parity) is x: x + rup, stepped back to the even / odd
+// neighbour on a tie (start_odd = 0: M + x must end even; 1: x must end odd)
+CZ_XS_FN uint32_t add_term(uint32_t x, Term t, uint32_t start_odd) {
+    const uint32_t y = x + t.rup;
+    return y - (t.tie & (y ^ start_odd));
 }
 
 // the run f followed by the run g
@@ -103,67 +114,127 @@ CZ_XS_FN uint32_t apply(uint32_t M, Inc f) {
 #if defined(__HIPCC__)
 namespace cz_exact {
 
-// Adds t[0..n) to s one after the other in f32 -- the value of `for (i) s = s + t[i]` -- with a whole wave.
-// Every lane of the wave calls it with the same arguments (t in LDS or global memory); the result is uniform.
-// T = terms per lane and pass.  PRO: a row that starts from nothing doubles its sum -- leaves its binade -- with almost
-// every term at first, so the first PRO terms of a row of >= 2 PRO terms are simply added (by every lane, redundantly).
-template <int T, int PRO = 32>
-__device__ __forceinline__ float wave_seq_sum(const float *t, uint32_t n, float s) {
+// lane shifted reads for the scan: DPP row_shr:n inside a row of 16 lanes (lanes without a source read 0 = "adds
+// nothing"), row_bcast:15 / row_bcast:31 to carry a row's total into the rows above it, wave_shr:1 for the exclusive form
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Inc dpp_fetch(Inc old, Inc v) {
+    Inc r;
+    r.even = __builtin_amdgcn_update_dpp(old.even, v.even, CTRL, ROW_MASK, 0xF, false);
+    r.odd = __builtin_amdgcn_update_dpp(old.odd, v.odd, CTRL, ROW_MASK, 0xF, false);
+    return r;
+}
+
+// inclusive scan of `then` over the lanes of a group (LANES = 16: one DPP row; 64: the wave), lower lanes first
+template <int LANES>
+__device__ __forceinline__ Inc scan_then(Inc g) {
+    const Inc zero{0u, 0u};
+    g = then(dpp_fetch<0x111, 0xF>(zero, g), g);  // row_shr:1
+    g = then(dpp_fetch<0x112, 0xF>(zero, g), g);  // row_shr:2
+    g = then(dpp_fetch<0x114, 0xF>(zero, g), g);  // row_shr:4
+    g = then(dpp_fetch<0x118, 0xF>(zero, g), g);  // row_shr:8
+    if (LANES == 64) {
+        g = then(dpp_fetch<0x142, 0xA>(zero, g), g);  // row_bcast:15 into rows 1 and 3
+        g = then(dpp_fetch<0x143, 0xC>(zero, g), g);  // row_bcast:31 into rows 2 and 3
+    }
+    return g;
+}
+
+// Adds t[0..n) to s one after the other in f32 -- the value of `for (i) s = s + t[i]` -- with a group of LANES lanes
+// (16: four independent rows per wave, each group with its own t / n / s; 64: the whole wave on one row).  Every lane of
+// the wave calls it (a group without a row passes n = 0); the result is uniform over the group.
+// T = most terms per lane and pass (<= 16: a lane's increments stay below 2^30).  A pass takes about as many terms as
+// the sum already holds -- the next binade is about that far away, and what lies behind a crossing is done again --
+// so a row of n terms costs ~n / LANES term steps plus ~2 log2(n) passes.
+// PRO: a row that starts from nothing leaves its binade with almost every term at first, so the first PRO terms of a
+// row of >= 2 PRO terms are simply added (by every lane of the group, redundantly).
+template <int LANES, int T, int PRO = 32>
+__device__ __forceinline__ float group_seq_sum(const float *t, uint32_t n, float s) {
+    static_assert(LANES == 16 || LANES == 64, "a DPP row or the wave");
+    static_assert(T >= 4 && T <= 16 && T % 4 == 0, "increments of one lane must stay below 2^30; terms are taken four at a time");
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gl = lane & (LANES - 1);       // lane inside the group
+    const uint32_t gbase = lane & ~(LANES - 1u);  // first lane of the group
     uint32_t p = 0;
     if (PRO > 0 && n >= 2u * PRO) {
 #pragma unroll
         for (int j = 0; j < PRO; j++) s = s + t[j];
         p = PRO;
     }
-    while (p < n) {
-        const uint32_t rem = n - p;
-        // short remainders are spread over all lanes (per = terms per lane of this pass)
-        const uint32_t per = rem >= 64u * T ? (uint32_t)T : (rem + 63u) / 64u;
-        const uint32_t first = p + lane * per;
-        uint32_t a[T];
+    while (__ballot(p < n) != 0ull) {  // groups whose row is done idle until the wave's longest row is
+        const bool live = p < n;
+        const uint32_t rem = live ? n - p : 0u;
+        const uint32_t ext = min(min(rem, max(p, (uint32_t)LANES)), (uint32_t)(LANES * T));  // terms of this pass
+        const uint32_t per = (ext + LANES - 1u) / LANES;                                     // ... per lane
+        const uint32_t first = p + gl * per;
+        uint32_t per_max = per;
+        if (LANES != 64) {
 #pragma unroll
-        for (int j = 0; j < T; j++) {
-            const uint32_t i = first + j;
-            a[j] = ((uint32_t)j < per && i < n) ? __float_as_uint(t[i]) : 0u;  // +0.0 adds nothing
+            for (int o = 16; o < 64; o <<= 1) per_max = max(per_max, (uint32_t)__shfl_xor((int)per_max, o, 64));
         }
         uint32_t M, eb;
-        split(__float_as_uint(s), M, eb);
-        const bool s_ok = (__float_as_uint(s) >> 31) == 0 || (__float_as_uint(s) << 1) == 0;  // a negative sum: true additions only
-        Inc f = term_inc(a[0], eb);
+        const uint32_t sbits = __float_as_uint(s);
+        split(sbits, M, eb);
+        uint32_t e = 0, o = 0;  // this lane's terms as ONE increment pair (composed in order; clamped once at the end)
+        for (uint32_t j0 = 0; j0 < per_max; j0 += 4) {
+            uint32_t a[4];
 #pragma unroll
-        for (int j = 1; j < T; j++) f = then(f, term_inc(a[j], eb));
-        if (!s_ok) f.even = f.odd = kSat;
-        // inclusive scan over the lanes (lower lanes first), then the exclusive prefix
-        Inc g = f;
+            for (int u = 0; u < 4; u++) {
+                const uint32_t j = j0 + u, i = first + j;
+                a[u] = (j < per && i < n) ? __float_as_uint(t[i]) : 0u;  // +0.0 adds nothing
+            }
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            Inc lo;
-            lo.even = __shfl_up(g.even, o, 64);
-            lo.odd = __shfl_up(g.odd, o, 64);
-            if (lane >= (uint32_t)o) g = then(lo, g);
+            for (int u = 0; u < 4; u++) {
+                const Term x = classify(a[u], eb);
+                e = add_term(e, x, 0u);
+                o = add_term(o, x, 1u);
+            }
         }
-        Inc ex;
-        ex.even = __shfl_up(g.even, 1, 64);
-        ex.odd = __shfl_up(g.odd, 1, 64);
-        if (lane == 0) ex.even = ex.odd = 0;
-        const uint32_t m0 = apply(M, ex);   // this lane's starting M (exact while below kLimit)
-        const uint32_t m1 = apply(m0, f);   // ... and where it ends
-        const unsigned long long out = __ballot(m1 >= kLimit);
-        if (out == 0ull) {
-            s = __uint_as_float(join(__shfl(m1, 63, 64), eb));
-            p += 64u * per;
-        } else {
-            const uint32_t L = (uint32_t)__ffsll((long long)out) - 1u;
-            // lane 0 starts from s itself (also when s is negative, inf or nan: then every lane is "out" and L = 0)
-            float sl = lane == 0 ? s : __uint_as_float(join(m0 < kLimit ? m0 : 0u, eb));
+        Inc f;
+        f.even = e < kSat ? e : kSat;
+        f.odd = o < kSat ? o : kSat;
+        if (sbits > 0x7f7fffffu) f.even = f.odd = kSat;  // a negative / inf / nan sum: true additions only
+        const Inc g = scan_then<LANES>(f);
+        Inc ex = dpp_fetch<0x138, 0xF>(Inc{0u, 0u}, g);  // wave_shr:1: the lanes below
+        if (gl == 0) ex.even = ex.odd = 0;
+        const uint32_t m0 = apply(M, ex);  // this lane's starting M (exact while below kLimit)
+        const uint32_t m1 = apply(m0, f);  // ... and where it ends
+        const unsigned long long out_all = __ballot(live && m1 >= kLimit);
+        const uint32_t out = LANES == 64 ? 0u : (uint32_t)(out_all >> gbase) & ((1u << (LANES & 31)) - 1u);
+        const bool crossed = LANES == 64 ? out_all != 0ull : out != 0u;
+        // no lane of the group left the binade: the last lane's end is the new sum
+        const uint32_t m_last = LANES == 64 ? (uint32_t)__builtin_amdgcn_readlane((int)m1, 63) : (uint32_t)__shfl(m1, (int)(gbase + LANES - 1), 64);
+        if (out_all != 0ull) {  // some group of the wave crossed: its first such lane re-adds its terms for real
+            // lane 0 of a group starts from s itself (also when s is negative, inf or nan: then every lane is "out")
+            float sl = gl == 0 ? s : __uint_as_float(join(m0 < kLimit ? m0 : 0u, eb));
+            for (uint32_t j0 = 0; j0 < per_max; j0 += 4) {
+                float a[4];
 #pragma unroll
-            for (int j = 0; j < T; j++) sl = sl + __uint_as_float(a[j]);  // padding is +0.0
-            s = __shfl(sl, (int)L, 64);
-            p += (L + 1u) * per;
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t j = j0 + u, i = first + j;
+                    a[u] = (j < per && i < n) ? t[i] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) sl = sl + a[u];
+            }
+            const uint32_t L = LANES == 64 ? (uint32_t)__ffsll((long long)out_all) - 1u : (uint32_t)__ffs((int)out) - 1u;
+            const float sx = LANES == 64 ? __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sl), (int)L))
+                                         : __shfl(sl, (int)(gbase + (crossed ? L : 0u)), 64);
+            if (live && crossed) {
+                s = sx;
+                p += (L + 1u) * per;
+            }
+        }
+        if (live && !crossed) {
+            s = __uint_as_float(join(m_last, eb));
+            p += (uint32_t)LANES * per;
         }
     }
     return s;
+}
+
+template <int T, int PRO = 32>
+__device__ __forceinline__ float wave_seq_sum(const float *t, uint32_t n, float s) {
+    return group_seq_sum<64, T, PRO>(t, n, s);
 }
 
 }  // namespace cz_exact

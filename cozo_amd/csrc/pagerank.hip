@@ -55,7 +55,9 @@ constexpr int kAThreads = 1024;     // blocked path, phase A
 constexpr int kMaxSliceLog2 = 15;   // 32768 sources = 128 KiB of LDS
 constexpr uint32_t kPartEdges = 98304;  // phase-A work item: at most this many edges of one slice
 constexpr int kMaxRowsPerBlock = 2048;  // = 2 rows per lane of phase B
-constexpr uint32_t kWaveRow = 128;      // rows of at least this many terms are summed by a wave (exact_sum.cuh)
+constexpr uint32_t kMinWaveRow = 128;   // rows of at least `wave_row` (>= this) terms are summed by a wave (exact_sum.cuh)
+constexpr uint32_t kWaveRowDefault = 1024;
+constexpr uint32_t kHeavyRowDefault = 64;  // rows of at least this many terms are moved behind the others, longest first
 constexpr int kHThreads = 1024;         // hub rows: one workgroup per row
 constexpr int kHTileNnz = 8192;         // two of these in LDS (64 KiB)
 
@@ -92,6 +94,7 @@ __device__ __forceinline__ double block_sum_f64(double v, double *red) {
 
 // ---- rows of a tile -> scores -------------------------------------------------------------------------------------
 // the fused epilogue of a row whose f32 sum is s; returns |new - old| for the f64 error
+// (r = the row as the CALLER numbers it: plans that moved their long rows pass row_id[plan row])
 __device__ __forceinline__ double finish_row(float s, uint32_t r, float old, uint32_t od, uint32_t row_begin,
                                              float *__restrict__ contrib_out, float *__restrict__ scores, float base,
                                              float damping) {
@@ -100,36 +103,50 @@ __device__ __forceinline__ double finish_row(float s, uint32_t r, float old, uin
     contrib_out[row_begin + r] = nw / (float)od;
     return fabs((double)(nw - old));
 }
+__device__ __forceinline__ uint32_t caller_row(const uint32_t *__restrict__ row_id, uint32_t r) { return row_id ? row_id[r] : r; }
 
-// one lane adds tile[e .. z) in order.  A long row is a serial chain: its LDS reads are kept 16 values ahead of the
-// adds (a read waited for in place costs ~100 cycles per add).
+// one lane adds tile[e .. z) in order.  A long row is a serial chain of dependent v_add_f32: its LDS reads are kept 16
+// values ahead of the adds in two register sets that take turns (a read waited for in place costs ~100 cycles per add).
 __device__ __forceinline__ float lane_row_sum(const float *tile, uint32_t e, uint32_t z) {
     float s = 0.0f;
     if (z - e >= 32) {
-        float a[16];
+        float a[16], b[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) a[i] = tile[e + i];
-        for (; e + 32 <= z; e += 16) {
-            float nx[16];
+        while (e + 48 <= z) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) nx[i] = tile[e + 16 + i];
+            for (int i = 0; i < 16; i++) b[i] = tile[e + 16 + i];
 #pragma unroll
             for (int i = 0; i < 16; i++) s = s + a[i];
 #pragma unroll
-            for (int i = 0; i < 16; i++) a[i] = nx[i];
-        }
+            for (int i = 0; i < 16; i++) a[i] = tile[e + 32 + i];
 #pragma unroll
-        for (int i = 0; i < 16; i++) s = s + a[i];
-        e += 16;
+            for (int i = 0; i < 16; i++) s = s + b[i];
+            e += 32;
+        }
+        // a holds [e, e + 16); between 16 and 47 values are left
+        if (e + 32 <= z) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) b[i] = tile[e + 16 + i];
+#pragma unroll
+            for (int i = 0; i < 16; i++) s = s + a[i];
+#pragma unroll
+            for (int i = 0; i < 16; i++) s = s + b[i];
+            e += 32;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) s = s + a[i];
+            e += 16;
+        }
     }
     for (; e < z; e++) s = s + tile[e];
     return s;
 }
 
-// Rows of >= kWaveRow terms are pushed to `raw` in whatever order the lanes get there; the list is then put in row order
+// Rows of >= wave_row terms are pushed to `raw` in whatever order the lanes get there; the list is then put in row order
 // so that which wave sums which row -- and with it the order of the f64 error terms -- does not depend on timing.
 // Ends with a barrier; every thread gets the list length.
-constexpr int kMaxWaveRows = kBTileNnz / (int)kWaveRow;
+constexpr int kMaxWaveRows = kBTileNnz / (int)kMinWaveRow;
 struct WaveRowList {
     uint32_t raw[kMaxWaveRows], sorted[kMaxWaveRows];
     uint32_t n;
@@ -154,14 +171,17 @@ __device__ __forceinline__ double wave_rows(const WaveRowList &l, uint32_t nl, c
                                             const uint32_t *__restrict__ off, uint32_t e0, const float *tile,
                                             const uint32_t *__restrict__ out_deg, uint32_t row_begin,
                                             float *__restrict__ contrib_out, float *__restrict__ scores, float base,
-                                            float damping) {
+                                            float damping, const uint32_t *__restrict__ row_id) {
     double err = 0.0;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (uint32_t i = wave; i < nl; i += THREADS / 64) {
         const uint32_t r = rb.row0 + l.sorted[i];
         const uint32_t a0 = off[r] - e0, z0 = off[r + 1] - e0;
-        const float s = cz_exact::wave_seq_sum<8>(tile + a0, z0 - a0, 0.0f);
-        if (lane == 0) err += finish_row(s, r, scores[r], out_deg[row_begin + r], row_begin, contrib_out, scores, base, damping);
+        const float s = cz_exact::wave_seq_sum<16>(tile + a0, z0 - a0, 0.0f);
+        if (lane == 0) {
+            const uint32_t cr = caller_row(row_id, r);
+            err += finish_row(s, cr, scores[cr], out_deg[row_begin + cr], row_begin, contrib_out, scores, base, damping);
+        }
     }
     return err;
 }
@@ -171,7 +191,8 @@ __global__ void __launch_bounds__(kGThreads)
 pr_step_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__ off /* local, [rows+1] */,
                const uint32_t *__restrict__ src, const uint32_t *__restrict__ out_deg /* global ids */,
                uint32_t row_begin, const float *__restrict__ contrib_in, float *__restrict__ contrib_out,
-               float *__restrict__ scores /* local */, float base, float damping, double *__restrict__ partial) {
+               float *__restrict__ scores /* local */, float base, float damping, double *__restrict__ partial,
+               const uint32_t *__restrict__ row_id, uint32_t wave_row) {
     __shared__ __attribute__((aligned(16))) float tile[kGTileNnz];
     __shared__ double red[kGThreads / 64];
     __shared__ WaveRowList wl;
@@ -193,19 +214,20 @@ pr_step_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__
     }
     for (; i < nnz; i += kGThreads) tile[i] = contrib_in[src[e0 + i]];
     __syncthreads();
-    // phase 2: one lane per row adds its LDS segment in order; rows of >= kWaveRow terms are left to the waves
+    // phase 2: one lane per row adds its LDS segment in order; rows of >= wave_row terms are left to the waves
     double err = 0.0;
     for (uint32_t r = rb.row0 + tid; r < rb.row1; r += kGThreads) {
         const uint32_t a = off[r] - e0, b = off[r + 1] - e0;
-        if (b - a >= kWaveRow) {
+        if (b - a >= wave_row) {
             wl.raw[atomicAdd(&wl.n, 1u)] = r - rb.row0;
             continue;
         }
         const float s = lane_row_sum(tile, a, b);
-        err += finish_row(s, r, scores[r], out_deg[row_begin + r], row_begin, contrib_out, scores, base, damping);
+        const uint32_t cr = caller_row(row_id, r);
+        err += finish_row(s, cr, scores[cr], out_deg[row_begin + cr], row_begin, contrib_out, scores, base, damping);
     }
     const uint32_t nl = order_wave_rows(wl);
-    if (nl) err += wave_rows<kGThreads>(wl, nl, rb, off, e0, tile, out_deg, row_begin, contrib_out, scores, base, damping);
+    if (nl) err += wave_rows<kGThreads>(wl, nl, rb, off, e0, tile, out_deg, row_begin, contrib_out, scores, base, damping, row_id);
     const double total = block_sum_f64<kGThreads>(err, red);
     if (tid == 0) partial[blockIdx.x] = total;
 }
@@ -216,7 +238,8 @@ pr_step_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__
 __global__ void __launch_bounds__(kHThreads)
 pr_hub_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__ src, const uint32_t *__restrict__ out_deg,
               uint32_t row_begin, const float *__restrict__ contrib_in, float *__restrict__ contrib_out,
-              float *__restrict__ scores, float base, float damping, double *__restrict__ partial) {
+              float *__restrict__ scores, float base, float damping, double *__restrict__ partial,
+              const uint32_t *__restrict__ row_id) {
     __shared__ __attribute__((aligned(16))) float tiles[2][kHTileNnz];
     const RowBlock rb = blocks[blockIdx.x];
     const uint32_t tid = threadIdx.x;
@@ -249,7 +272,10 @@ pr_hub_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__ 
         }
         __syncthreads();
     }
-    if (tid == 0) partial[blockIdx.x] = finish_row(s, r, scores[r], out_deg[row_begin + r], row_begin, contrib_out, scores, base, damping);
+    if (tid == 0) {
+        const uint32_t cr = caller_row(row_id, r);
+        partial[blockIdx.x] = finish_row(s, cr, scores[cr], out_deg[row_begin + cr], row_begin, contrib_out, scores, base, damping);
+    }
 }
 
 // ---- "blocked" formulation ----------------------------------------------------------------------------------
@@ -320,7 +346,8 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
                  const uint2 *__restrict__ seg /* [blocks][S+1]: (stream position, block-local prefix) */, uint32_t S,
                  const uint16_t *__restrict__ perm, const uint32_t *__restrict__ vpos, const float *__restrict__ val,
                  const uint32_t *__restrict__ out_deg, uint32_t row_begin, float *__restrict__ contrib_out,
-                 float *__restrict__ scores, float base, float damping, double *__restrict__ partial, int xcd_remap) {
+                 float *__restrict__ scores, float base, float damping, double *__restrict__ partial, int xcd_remap,
+                 const uint32_t *__restrict__ row_id, uint32_t wave_row) {
     __shared__ float tile[kBTileNnz];
     __shared__ double red[kBThreads / 64];
     __shared__ WaveRowList wl;
@@ -363,8 +390,9 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
         if (r < rb.row1) {
             ra[j] = off[r] - e0;
             rz[j] = off[r + 1] - e0;
-            old[j] = scores[r];
-            od[j] = out_deg[row_begin + r];
+            const uint32_t cr = caller_row(row_id, r);
+            old[j] = scores[cr];
+            od[j] = out_deg[row_begin + cr];
         }
     }
     if constexpr (FLAT) {
@@ -450,22 +478,23 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
     }
     __syncthreads();
     double err = 0.0;
-    // Rows are summed in order (the reference's sequential f32 sum): one lane per row, and the rows of >= kWaveRow terms
+    // Rows are summed in order (the reference's sequential f32 sum): one lane per row, and the rows of >= wave_row terms
     // afterwards by a wave each (exact_sum.cuh: the same bits, without the serial chain a skewed graph's sweep waited for).
 #pragma unroll
     for (int j = 0; j < RPL; j++) {
         const uint32_t r = rb.row0 + threadIdx.x + j * kBThreads;
         if (r < rb.row1) {
-            if (rz[j] - ra[j] >= kWaveRow) {
+            if (rz[j] - ra[j] >= wave_row) {
                 wl.raw[atomicAdd(&wl.n, 1u)] = threadIdx.x + j * kBThreads;
                 continue;
             }
             const float s = lane_row_sum(tile, ra[j], rz[j]);
-            err += finish_row(s, r, old[j], od[j], row_begin, contrib_out, scores, base, damping);
+            // (the caller's row number is fetched again rather than kept in a register through the tile fill)
+            err += finish_row(s, caller_row(row_id, r), old[j], od[j], row_begin, contrib_out, scores, base, damping);
         }
     }
     const uint32_t nl = order_wave_rows(wl);
-    if (nl) err += wave_rows<kBThreads>(wl, nl, rb, off, e0, tile, out_deg, row_begin, contrib_out, scores, base, damping);
+    if (nl) err += wave_rows<kBThreads>(wl, nl, rb, off, e0, tile, out_deg, row_begin, contrib_out, scores, base, damping, row_id);
     const double total = block_sum_f64<kBThreads>(err, red);
     if (threadIdx.x == 0) partial[b] = total;
 }
@@ -581,6 +610,32 @@ pb_vpos_kernel(const RowBlock *__restrict__ blocks, const uint2 *__restrict__ se
     }
 }
 
+// plan construction, skewed graphs: in-edges of the rows in their new order.  A workgroup owns 256 consecutive new rows
+// (their edges are one contiguous stretch of the new array): new offsets of those rows in LDS, every edge finds its row by
+// bisection there and copies src[old offset of that row + position in the row].
+__global__ void __launch_bounds__(256)
+pr_permute_src_kernel(const uint32_t *__restrict__ old_off, const uint32_t *__restrict__ new_off,
+                      const uint32_t *__restrict__ row_id, uint32_t rows, const uint32_t *__restrict__ src_in,
+                      uint32_t *__restrict__ src_out) {
+    __shared__ uint32_t noff[257], ooff[256];
+    const uint32_t r0 = blockIdx.x * 256u;
+    const uint32_t nr = min(256u, rows - r0);
+    if (threadIdx.x < nr) ooff[threadIdx.x] = old_off[row_id[r0 + threadIdx.x]];
+    if (threadIdx.x <= nr) noff[threadIdx.x] = new_off[r0 + threadIdx.x];
+    if (threadIdx.x == 0 && nr == 256) noff[256] = new_off[r0 + 256];
+    __syncthreads();
+    const uint32_t e0 = noff[0], e1 = noff[nr];
+    for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        uint32_t lo = 0, hi = nr;  // the last row whose new offset is <= e
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (noff[mid] <= e) lo = mid;
+            else hi = mid;
+        }
+        src_out[e] = src_in[ooff[lo] + (e - noff[lo])];
+    }
+}
+
 // fixed-order reduction of the per-block partial errors; accumulates into *err_out
 __global__ void __launch_bounds__(1024) pr_err_reduce_kernel(const double *__restrict__ partial, uint32_t n,
                                                               double *__restrict__ err_out) {
@@ -630,13 +685,17 @@ struct cz_pagerank_plan {
     // sweep of the other rows (both read contrib_in, write disjoint rows), joined before the error sum
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // shared
+    // skewed graphs: rows of >= kHeavyRow in-edges are moved behind the others, longest first, so that the rows of one
+    // row block -- and with them the lanes of one wave -- carry similar lengths; row_id[plan row] = the caller's row
+    uint32_t *d_rowid = nullptr;
+    uint32_t wave_row = kWaveRowDefault;
+    // shared (d_off / d_src: in plan row order)
     uint32_t *d_off = nullptr, *d_src = nullptr, *d_outdeg = nullptr;
     float *d_scores = nullptr;
     double *d_partial = nullptr;
     ~cz_pagerank_plan() {
         void *ps[] = {d_gblocks, d_hblocks, d_bblocks, d_items, d_asrc, d_perm, d_vpos, d_seg, d_val, d_off, d_src, d_outdeg, d_scores,
-                      d_partial};
+                      d_partial, d_rowid};
         for (void *p : ps)
             if (p) (void)hipFree(p);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -879,6 +938,47 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     const auto t_build = std::chrono::steady_clock::now();
     p->h2d_ms = std::chrono::duration<double, std::milli>(t_build - t_h2d).count();
 
+    p->wave_row = (uint32_t)std::max<int>((int)kMinWaveRow, env_int("CZ_PR_WAVE_ROW", (int)kWaveRowDefault));
+    // Skewed graphs: one lane adds one row, so a wave takes as long as its longest row, and a row block as long as its
+    // longest wave.  Rows of >= `heavy` in-edges are taken out of the natural order and appended longest first: the blocks
+    // cut from that tail hold rows of similar length (and the few rows worth a whole wave sit together).  The kernels
+    // write every result through row_id, so the caller sees its own numbering.
+    std::vector<uint32_t> perm_off;  // offsets in plan row order (when rows were moved)
+    {
+        const uint32_t heavy = (uint32_t)std::max(0, env_int("CZ_PR_HEAVY", (int)kHeavyRowDefault));
+        std::vector<uint32_t> heavy_rows;
+        if (heavy > 0)
+            for (uint32_t r = 0; r < rows; r++)
+                if (in_offsets[r + 1] - in_offsets[r] >= heavy) heavy_rows.push_back(r);
+        if (!heavy_rows.empty() && heavy_rows.size() < rows) {
+            std::stable_sort(heavy_rows.begin(), heavy_rows.end(), [&](uint32_t a, uint32_t b) {
+                return in_offsets[a + 1] - in_offsets[a] > in_offsets[b + 1] - in_offsets[b];
+            });
+            std::vector<uint32_t> row_id;
+            row_id.reserve(rows);
+            for (uint32_t r = 0; r < rows; r++)
+                if (in_offsets[r + 1] - in_offsets[r] < heavy) row_id.push_back(r);
+            row_id.insert(row_id.end(), heavy_rows.begin(), heavy_rows.end());
+            perm_off.resize((size_t)rows + 1);
+            perm_off[0] = 0;
+            for (uint32_t r = 0; r < rows; r++) perm_off[r + 1] = perm_off[r] + (in_offsets[row_id[r] + 1] - in_offsets[row_id[r]]);
+            cz::DevBuf<uint32_t> new_off, new_src;
+            CZ_HIP(new_off.alloc((size_t)rows + 1));
+            CZ_HIP(new_src.alloc(std::max<uint64_t>(1, E)));
+            CZ_HIP(hipMalloc((void **)&p->d_rowid, (size_t)rows * 4));
+            CZ_HIP(hipMemcpy(p->d_rowid, row_id.data(), (size_t)rows * 4, hipMemcpyHostToDevice));
+            CZ_HIP(hipMemcpy(new_off.p, perm_off.data(), ((size_t)rows + 1) * 4, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(pr_permute_src_kernel, dim3((rows + 255) / 256), dim3(256), 0, nullptr, p->d_off, new_off.p, p->d_rowid,
+                               rows, p->d_src, new_src.p);
+            CZ_HIP(hipDeviceSynchronize());
+            (void)hipFree(p->d_off);
+            (void)hipFree(p->d_src);
+            p->d_off = new_off.release();
+            p->d_src = new_src.release();
+            in_offsets = perm_off.data();
+        }
+    }
+
     // formulation: explicit flag > CZ_PR_MODE (gather | blocked) > heuristic
     int mode = 0;  // 0 auto, 1 gather, 2 blocked
     if (flags & CZ_PR_GATHER) mode = 1;
@@ -960,7 +1060,8 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
             hs = p->side;
         }
         hipLaunchKernelGGL(pr_hub_kernel, dim3(p->n_hblocks), dim3(kHThreads), 0, hs, p->d_hblocks, p->d_src, p->d_outdeg,
-                           p->row_begin, contrib_in_dev, contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial + n_main);
+                           p->row_begin, contrib_in_dev, contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial + n_main,
+                           p->d_rowid);
         if (fork) CZ_HIP(hipEventRecord(p->ev_join, p->side));
     }
     if (p->blocked) {
@@ -975,17 +1076,19 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
                 if (p->d_vpos)
                     hipLaunchKernelGGL(pb_reduce_kernel<true>, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
                                        p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
-                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap);
+                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap, p->d_rowid,
+                                       p->wave_row);
                 else
                     hipLaunchKernelGGL(pb_reduce_kernel<false>, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
                                        p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
-                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap);
+                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap, p->d_rowid,
+                                       p->wave_row);
             }
         }
     } else if (p->n_gblocks) {
         hipLaunchKernelGGL(pr_step_kernel, dim3(p->n_gblocks), dim3(kGThreads), 0, stream, p->d_gblocks, p->d_off, p->d_src,
                            p->d_outdeg, p->row_begin, contrib_in_dev, contrib_out_dev, p->d_scores, p->base, p->damping,
-                           p->d_partial);
+                           p->d_partial, p->d_rowid, p->wave_row);
     }
     if (fork) CZ_HIP(hipStreamWaitEvent(stream, p->ev_join, 0));
     hipLaunchKernelGGL(pr_err_reduce_kernel, dim3(1), dim3(1024), 0, stream, p->d_partial, n_partial, err_out_dev);

@@ -354,11 +354,37 @@ class HnswSearchBinding:
     predicates: Optional[Sequence[tuple]] = None
 
 
+def _value_eq(a, b) -> bool:
+    """DataValue equality for a pair that is not two numbers: different kinds are different values"""
+    kind = lambda x: ("null" if x is None else "bool" if isinstance(x, (bool, np.bool_)) else
+                      "num" if isinstance(x, (int, float, np.integer, np.floating)) else "str" if isinstance(x, str) else
+                      "bytes" if isinstance(x, (bytes, bytearray)) else "vec" if isinstance(x, np.ndarray) else
+                      "list" if isinstance(x, (list, tuple)) else type(x).__name__)
+    if kind(a) != kind(b):
+        return False
+    if kind(a) == "num":  # Num::eq is cmp == Equal (data/value.rs:531-576): an Int never equals a Float, floats by total order
+        ai, bi = isinstance(a, (int, np.integer)), isinstance(b, (int, np.integer))
+        if ai != bi:
+            return False
+        return int(a) == int(b) if ai else np.float64(a).tobytes() == np.float64(b).tobytes()
+    if isinstance(a, np.ndarray):
+        return a.dtype == b.dtype and a.shape == b.shape and bool(np.array_equal(a, b))
+    if isinstance(a, (list, tuple)):
+        return len(a) == len(b) and all(_value_eq(x, y) for x, y in zip(a, b))
+    return bool(a == b)
+
+
 def _compare(a, op, b) -> bool:
-    """op_lt / op_le / op_eq / op_ge / op_gt / op_neq on two numbers (data/functions.rs:298-380): Int with Int as integers,
-    Float with Float by total order (data/value.rs:595), mixed pairs as f64; anything else is the reference's error"""
-    num = lambda x: isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, bool)
+    """op_lt / op_le / op_eq / op_ge / op_gt / op_neq (data/functions.rs:298-380).  Numbers: Int with Int as integers,
+    Float with Float by total order (data/value.rs:595), mixed pairs as f64.  op_eq / op_neq never check types
+    (:298-304, :337-343): a pair that is not two numbers is compared as DataValues (None == 5 is false, 'a' != 5 is
+    true); the ordering operators call ensure_same_value_type first and fail on such a pair -- that error is kept."""
+    num = lambda x: isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, (bool, np.bool_))
     if not (num(a) and num(b)):
+        if op == "==":
+            return _value_eq(a, b)
+        if op == "!=":
+            return not _value_eq(a, b)
         raise TypeError("comparison can only be done between the same datatypes")
     ai, bi = isinstance(a, (int, np.integer)), isinstance(b, (int, np.integer))
     if ai and bi:

@@ -270,13 +270,19 @@ StoredRows GpuHnswIndex::index_rows(uint64_t relation_id) const {
     return out;
 }
 
-// op_lt / op_le / op_eq / op_ge / op_gt / op_neq on two numbers (data/functions.rs:298-380): Int with Int as integers,
-// Float with Float by total order (data/value.rs:595), mixed pairs as f64; anything else is the reference's error
+// op_lt / op_le / op_eq / op_ge / op_gt / op_neq (data/functions.rs:298-380).  Numbers: Int with Int as integers, Float
+// with Float by total order (data/value.rs:595), mixed pairs as f64.  op_eq / op_neq never check types (:298-304, :337-343):
+// anything that is not a pair of numbers is compared as DataValues (Null == 5 is false, 'a' != 5 is true); the ordering
+// operators call ensure_same_value_type first and fail on such a pair -- that error is kept.
 static bool compare_values(const DataValue &a, int op, const DataValue &b) {
     int64_t ai = 0, bi = 0;
     double af = 0, bf = 0;
     const bool a_int = a.is_int(), b_int = b.is_int();
-    if (!a.is_num() || !b.is_num()) throw CozoError("", "comparison can only be done between the same datatypes");
+    if (!a.is_num() || !b.is_num()) {
+        if (op == CZ_OP_EQ) return a == b;
+        if (op != CZ_OP_LT && op != CZ_OP_LE && op != CZ_OP_GE && op != CZ_OP_GT) return !(a == b);
+        throw CozoError("", "comparison can only be done between the same datatypes");
+    }
     if (a_int) a.get_int(&ai);
     else a.get_float(&af);
     if (b_int) b.get_int(&bi);

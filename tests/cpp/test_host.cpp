@@ -1004,6 +1004,15 @@ static void gpu_hnsw_search_ra() {
         // reference's error for a non-numeric value
         dev_ra.hnsw_search.predicates = {ColumnPredicate{1, CZ_OP_GE, DataValue((int64_t)0)}};
         CHECK((throws<CozoError>([&] { dev_ra.iter(parent, Poison()); })));
+        // ... but op_eq / op_neq never check types (data/functions.rs:298-304, :337-343): `v != 0` holds for every row and
+        // `v == 0` for none, exactly as if the filter were absent / always false
+        HnswSearchRA plain{&ix, HnswSearch{}, 1};
+        plain.hnsw_search = host_ra.hnsw_search;
+        plain.hnsw_search.filter = nullptr;
+        dev_ra.hnsw_search.predicates = {ColumnPredicate{1, CZ_OP_NE, DataValue((int64_t)0)}};
+        CHECK(dev_ra.iter(parent, Poison()) == plain.iter(parent, Poison()));
+        dev_ra.hnsw_search.predicates = {ColumnPredicate{1, CZ_OP_EQ, DataValue((int64_t)0)}};
+        CHECK(dev_ra.iter(parent, Poison()).empty());
     }
     CHECK((throws<CozoError>([&] { ra.iter({T({DataValue(1), DataValue("not a vector")})}, Poison()); })));
     CHECK((throws<CozoError>([&] { ix.hnsw_knn(std::vector<float>(dim + 1, 0.f), HnswSearch{}, Poison()); })));
