@@ -141,54 +141,68 @@ __device__ __forceinline__ Inc scan_then(Inc g) {
 
 // Adds t[0..n) to s one after the other in f32 -- the value of `for (i) s = s + t[i]` -- with a group of LANES lanes
 // (16: four independent rows per wave, each group with its own t / n / s; 64: the whole wave on one row).  Every lane of
-// the wave calls it (a group without a row passes n = 0); the result is uniform over the group.
-// T = most terms per lane and pass (<= 16: a lane's increments stay below 2^30).  A pass takes about as many terms as
-// the sum already holds -- the next binade is about that far away, and what lies behind a crossing is done again --
-// so a row of n terms costs ~n / LANES term steps plus ~2 log2(n) passes.
-// PRO: a row that starts from nothing leaves its binade with almost every term at first, so the first PRO terms of a
-// row of >= 2 PRO terms are simply added (by every lane of the group, redundantly).
+// the wave calls it (a group without a row passes n = 0); the result is uniform over the group.  t: 4-byte aligned.
+// A pass takes about as many terms as the sum already holds -- the next binade is about that far away, and what lies
+// behind a crossing is done again -- as 4, 8 or 16 (<= T) consecutive terms per lane, read as 16-byte vectors: a row of
+// n terms costs ~n / LANES term steps plus ~2 log2(n) passes.
+// PRO: a row that starts from nothing leaves its binade with almost every term at first, so the first PRO (+ 0..3, up to
+// a 16-byte boundary of t) terms are simply added, by every lane of the group redundantly; rows too short for a pass
+// after that are added that way entirely.
 template <int LANES, int T, int PRO = 32>
 __device__ __forceinline__ float group_seq_sum(const float *t, uint32_t n, float s) {
     static_assert(LANES == 16 || LANES == 64, "a DPP row or the wave");
-    static_assert(T >= 4 && T <= 16 && T % 4 == 0, "increments of one lane must stay below 2^30; terms are taken four at a time");
+    static_assert(T == 4 || T == 8 || T == 16, "increments of one lane must stay below 2^30; terms are read four at a time");
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gl = lane & (LANES - 1);       // lane inside the group
     const uint32_t gbase = lane & ~(LANES - 1u);  // first lane of the group
-    uint32_t p = 0;
-    if (PRO > 0 && n >= 2u * PRO) {
+    uint32_t p = PRO + ((4u - ((((uint32_t)(uintptr_t)t >> 2) + PRO) & 3u)) & 3u);  // t + p is 16-byte aligned
+    if (n < 2u * PRO + 4u) p = n;
+    {
+        uint32_t pmax = p;
+        if (LANES != 64) {
 #pragma unroll
-        for (int j = 0; j < PRO; j++) s = s + t[j];
-        p = PRO;
+            for (int o = 16; o < 64; o <<= 1) pmax = max(pmax, (uint32_t)__shfl_xor((int)pmax, o, 64));
+        }
+        for (uint32_t j = 0; j < pmax; j++)
+            if (j < p) s = s + t[j];
     }
     while (__ballot(p < n) != 0ull) {  // groups whose row is done idle until the wave's longest row is
         const bool live = p < n;
         const uint32_t rem = live ? n - p : 0u;
-        const uint32_t ext = min(min(rem, max(p, (uint32_t)LANES)), (uint32_t)(LANES * T));  // terms of this pass
-        const uint32_t per = (ext + LANES - 1u) / LANES;                                     // ... per lane
+        const uint32_t ext = min(min(rem, max(p, (uint32_t)LANES)), (uint32_t)(LANES * T));  // terms wanted from this pass
+        const uint32_t per = (T >= 16 && ext > (uint32_t)LANES * 8u) ? 16u : (T >= 8 && ext > (uint32_t)LANES * 4u) ? 8u : 4u;
+        const uint32_t used = (ext + per - 1u) / per;  // lanes of the group that take terms (the pass covers used * per)
         const uint32_t first = p + gl * per;
         uint32_t per_max = per;
         if (LANES != 64) {
 #pragma unroll
             for (int o = 16; o < 64; o <<= 1) per_max = max(per_max, (uint32_t)__shfl_xor((int)per_max, o, 64));
         }
+        uint32_t a[T];
+#pragma unroll
+        for (int c = 0; c < T / 4; c++) {
+            const uint32_t i = first + 4u * c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);  // +0.0 adds nothing
+            if (gl < used && 4u * c < per && i < n) v = *(const float4 *)(t + i);
+            a[4 * c + 0] = __float_as_uint(v.x);
+            a[4 * c + 1] = i + 1u < n ? __float_as_uint(v.y) : 0u;  // the row's last vector may reach past its end
+            a[4 * c + 2] = i + 2u < n ? __float_as_uint(v.z) : 0u;
+            a[4 * c + 3] = i + 3u < n ? __float_as_uint(v.w) : 0u;
+        }
         uint32_t M, eb;
         const uint32_t sbits = __float_as_uint(s);
         split(sbits, M, eb);
         uint32_t e = 0, o = 0;  // this lane's terms as ONE increment pair (composed in order; clamped once at the end)
-        for (uint32_t j0 = 0; j0 < per_max; j0 += 4) {
-            uint32_t a[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t j = j0 + u, i = first + j;
-                a[u] = (j < per && i < n) ? __float_as_uint(t[i]) : 0u;  // +0.0 adds nothing
-            }
+        for (int c = 0; c < T / 4; c++)
+            if (4u * c < per_max) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const Term x = classify(a[u], eb);
-                e = add_term(e, x, 0u);
-                o = add_term(o, x, 1u);
+                for (int u = 0; u < 4; u++) {
+                    const Term x = classify(a[4 * c + u], eb);
+                    e = add_term(e, x, 0u);
+                    o = add_term(o, x, 1u);
+                }
             }
-        }
         Inc f;
         f.even = e < kSat ? e : kSat;
         f.odd = o < kSat ? o : kSat;
@@ -206,16 +220,12 @@ __device__ __forceinline__ float group_seq_sum(const float *t, uint32_t n, float
         if (out_all != 0ull) {  // some group of the wave crossed: its first such lane re-adds its terms for real
             // lane 0 of a group starts from s itself (also when s is negative, inf or nan: then every lane is "out")
             float sl = gl == 0 ? s : __uint_as_float(join(m0 < kLimit ? m0 : 0u, eb));
-            for (uint32_t j0 = 0; j0 < per_max; j0 += 4) {
-                float a[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t j = j0 + u, i = first + j;
-                    a[u] = (j < per && i < n) ? t[i] : 0.0f;
+            for (int c = 0; c < T / 4; c++)
+                if (4u * c < per_max) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) sl = sl + __uint_as_float(a[4 * c + u]);  // padding is +0.0
                 }
-#pragma unroll
-                for (int u = 0; u < 4; u++) sl = sl + a[u];
-            }
             const uint32_t L = LANES == 64 ? (uint32_t)__ffsll((long long)out_all) - 1u : (uint32_t)__ffs((int)out) - 1u;
             const float sx = LANES == 64 ? __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sl), (int)L))
                                          : __shfl(sl, (int)(gbase + (crossed ? L : 0u)), 64);
@@ -226,7 +236,7 @@ __device__ __forceinline__ float group_seq_sum(const float *t, uint32_t n, float
         }
         if (live && !crossed) {
             s = __uint_as_float(join(m_last, eb));
-            p += (uint32_t)LANES * per;
+            p += used * per;
         }
     }
     return s;

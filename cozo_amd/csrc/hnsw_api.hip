@@ -1009,10 +1009,12 @@ static int distance_pairs_device(int metric, const float *d_base, const float *d
     hipLaunchKernelGGL((distance_pairs_kernel<LPV, ITERS, U>), dim3(std::max(blocks, 1)), dim3(256), 0, stream, metric, \
                        d_base, d_queries, ld, src_pairs, P, d_out, src_perm, src_dropped)
     const uint32_t *src_pairs = d_pairs, *src_perm = nullptr, *src_dropped = nullptr;
-    // Region order: worth it when the table is far larger than what the resident workgroups can keep close (measured: +9 %
-    // at 30 GB, nothing at 3 GB) and the batch is large enough to pay for the sort.  CZ_PAIRS_REGION = 0 | 1 forces it.
+    // Region order (opt-in, CZ_PAIRS_REGION=1).  Round 2 measured 9 % off the kernel when the pairs ARRIVE bucketed by
+    // 25 MB regions of a 30 GB table; done inside the call (this counting sort + six stream-ordered allocations) the
+    // whole call got slower, 2.26 -> 2.69 ms at 4M pairs on 10M x 768 (profiles/r03_distance_region_order.txt), so the
+    // default stays ONE kernel in caller order.
     const char *renv = getenv("CZ_PAIRS_REGION");
-    const bool region = renv ? atoi(renv) != 0 : ((uint64_t)n * ld * 4 >= (8ull << 30) && P >= (1u << 18));
+    const bool region = renv && atoi(renv) != 0;
     if (region && P < (1ull << 32) && n > 0) {
         struct AsyncBuf {
             void *p = nullptr;

@@ -56,8 +56,8 @@ constexpr int kMaxSliceLog2 = 15;   // 32768 sources = 128 KiB of LDS
 constexpr uint32_t kPartEdges = 98304;  // phase-A work item: at most this many edges of one slice
 constexpr int kMaxRowsPerBlock = 2048;  // = 2 rows per lane of phase B
 constexpr uint32_t kMinWaveRow = 128;   // rows of at least `wave_row` (>= this) terms are summed by a wave (exact_sum.cuh)
-constexpr uint32_t kWaveRowDefault = 1024;
-constexpr uint32_t kHeavyRowDefault = 64;  // rows of at least this many terms are moved behind the others, longest first
+constexpr uint32_t kWaveRowDefault = 2048;
+constexpr uint32_t kHeavyRowDefault = 128;  // rows of at least this many terms are moved behind the others, longest first
 constexpr int kHThreads = 1024;         // hub rows: one workgroup per row
 constexpr int kHTileNnz = 8192;         // two of these in LDS (64 KiB)
 
@@ -332,6 +332,24 @@ pb_expand_kernel(const AItem *__restrict__ items, const uint16_t *__restrict__ a
     }
 }
 
+// Phase timing (profiling builds only: scratch/build_variant.sh prphase -DCZ_PR_PHASE_TIMING): thread 0 of every phase-B
+// workgroup adds the cycles between its stamps to g_pr_phase[]; cz_pagerank_phase_cycles reads / clears the counters.
+#ifdef CZ_PR_PHASE_TIMING
+__device__ unsigned long long g_pr_phase[8];
+#define PR_STAMP(k)                                             \
+    do {                                                        \
+        if (threadIdx.x == 0) {                                 \
+            const unsigned long long now_ = clock64();          \
+            atomicAdd(&g_pr_phase[k], now_ - t_prev_);          \
+            t_prev_ = now_;                                     \
+        }                                                       \
+    } while (0)
+#define PR_STAMP_INIT unsigned long long t_prev_ = clock64()
+#else
+#define PR_STAMP(k)
+#define PR_STAMP_INIT
+#endif
+
 // phase B: row block b gathers its run of every slice's value stream into CSR order inside LDS, then sums rows.
 // A run is short (tile / #slices entries), so the kernel lives on loads in flight: 32 waves per CU, 8 runs
 // requested per wave before the first value is placed, and the rows' own data (offsets, old score, out-degree)
@@ -348,7 +366,7 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
                  const uint32_t *__restrict__ out_deg, uint32_t row_begin, float *__restrict__ contrib_out,
                  float *__restrict__ scores, float base, float damping, double *__restrict__ partial, int xcd_remap,
                  const uint32_t *__restrict__ row_id, uint32_t wave_row) {
-    __shared__ float tile[kBTileNnz];
+    __shared__ __attribute__((aligned(16))) float tile[kBTileNnz];
     __shared__ double red[kBThreads / 64];
     __shared__ WaveRowList wl;
     // runs longer than one wave instruction (a skewed graph: most of a row block's edges come from the few slices that
@@ -358,6 +376,7 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
     // longer than 64 (< 256 of those).
     __shared__ uint32_t tail_st[512], tail_p0[512], tail_cnt[512];
     __shared__ uint32_t n_tail;
+    PR_STAMP_INIT;
     if (threadIdx.x == 0) {
         n_tail = 0;
         wl.n = 0;
@@ -472,11 +491,31 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
         }
     }
     __syncthreads();
+    PR_STAMP(0);  // descriptors + the first 64 values of every run
+    // the queued pieces: TU of them in flight per wave (one piece after the other waited a memory round trip each --
+    // most of a skewed graph's row block arrives this way)
     const uint32_t nt = n_tail;
-    for (uint32_t i = wave; i < nt; i += NW)
-        if (lane < tail_cnt[i]) tile[pm[tail_p0[i] + lane]] = val[tail_st[i] + lane];
+    constexpr int TU = 8;
+    for (uint32_t i0 = wave; i0 < nt; i0 += NW * TU) {
+        float v[TU];
+        uint32_t q[TU];
+        bool on[TU];
+#pragma unroll
+        for (int u = 0; u < TU; u++) {
+            const uint32_t i = i0 + u * NW;
+            on[u] = i < nt && lane < tail_cnt[min(i, 511u)];
+            if (on[u]) {
+                v[u] = val[tail_st[i] + lane];
+                q[u] = pm[tail_p0[i] + lane];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TU; u++)
+            if (on[u]) tile[q[u]] = v[u];
+    }
     }
     __syncthreads();
+    PR_STAMP(1);  // queued pieces (FLAT: the whole fill)
     double err = 0.0;
     // Rows are summed in order (the reference's sequential f32 sum): one lane per row, and the rows of >= wave_row terms
     // afterwards by a wave each (exact_sum.cuh: the same bits, without the serial chain a skewed graph's sweep waited for).
@@ -494,9 +533,18 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
         }
     }
     const uint32_t nl = order_wave_rows(wl);
+    PR_STAMP(2);  // one lane per row (until the slowest wave is through)
     if (nl) err += wave_rows<kBThreads>(wl, nl, rb, off, e0, tile, out_deg, row_begin, contrib_out, scores, base, damping, row_id);
     const double total = block_sum_f64<kBThreads>(err, red);
+    PR_STAMP(3);  // rows summed by whole waves
     if (threadIdx.x == 0) partial[b] = total;
+#ifdef CZ_PR_PHASE_TIMING
+    if (threadIdx.x == 0) {
+        atomicAdd(&g_pr_phase[4], 1ull);
+        atomicAdd(&g_pr_phase[5], (unsigned long long)nl);
+        atomicAdd(&g_pr_phase[6], (unsigned long long)n_tail);
+    }
+#endif
 }
 
 // ---- plan construction kernels (run once) -------------------------------------------------------------------
@@ -610,6 +658,24 @@ pb_vpos_kernel(const RowBlock *__restrict__ blocks, const uint2 *__restrict__ se
     }
 }
 
+// rows without in-edges (a skewed graph has many): new score = base, no tile, no runs -- they are kept out of the row
+// blocks (whose cost per block is fixed: one descriptor per slice) and handled here, 2048 rows per workgroup
+constexpr int kERowsPerBlock = 2048;
+__global__ void __launch_bounds__(256)
+pr_empty_rows_kernel(const uint32_t *__restrict__ row_id, uint32_t r0, uint32_t r1, const uint32_t *__restrict__ out_deg,
+                     uint32_t row_begin, float *__restrict__ contrib_out, float *__restrict__ scores, float base, float damping,
+                     double *__restrict__ partial) {
+    __shared__ double red[256 / 64];
+    double err = 0.0;
+    const uint32_t b0 = r0 + blockIdx.x * kERowsPerBlock, b1 = min(r1, b0 + kERowsPerBlock);
+    for (uint32_t r = b0 + threadIdx.x; r < b1; r += 256) {
+        const uint32_t cr = caller_row(row_id, r);
+        err += finish_row(0.0f, cr, scores[cr], out_deg[row_begin + cr], row_begin, contrib_out, scores, base, damping);
+    }
+    const double total = block_sum_f64<256>(err, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+
 // plan construction, skewed graphs: in-edges of the rows in their new order.  A workgroup owns 256 consecutive new rows
 // (their edges are one contiguous stretch of the new array): new offsets of those rows in LDS, every edge finds its row by
 // bisection there and copies src[old offset of that row + position in the row].
@@ -689,6 +755,7 @@ struct cz_pagerank_plan {
     // row block -- and with them the lanes of one wave -- carry similar lengths; row_id[plan row] = the caller's row
     uint32_t *d_rowid = nullptr;
     uint32_t wave_row = kWaveRowDefault;
+    uint32_t n_empty = 0, n_eblocks = 0;  // rows without in-edges, moved to the very end (pr_empty_rows_kernel)
     // shared (d_off / d_src: in plan row order)
     uint32_t *d_off = nullptr, *d_src = nullptr, *d_outdeg = nullptr;
     float *d_scores = nullptr;
@@ -725,7 +792,7 @@ int cut_row_blocks(const uint32_t *in_offsets, uint32_t rows, uint32_t tile, std
 
 // builds the static layout of the blocked formulation on the device; p->d_off / d_src / d_outdeg are resident
 int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uint32_t n_chunks) {
-    const uint32_t rows = p->rows;
+    const uint32_t rows = p->rows - p->n_empty;  // the rows without in-edges sit behind the others: pr_empty_rows_kernel
     const uint64_t E = p->E;
     std::vector<RowBlock> all;
     cut_row_blocks(h_off, rows, kBTileNnz, all);
@@ -946,19 +1013,28 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     std::vector<uint32_t> perm_off;  // offsets in plan row order (when rows were moved)
     {
         const uint32_t heavy = (uint32_t)std::max(0, env_int("CZ_PR_HEAVY", (int)kHeavyRowDefault));
-        std::vector<uint32_t> heavy_rows;
-        if (heavy > 0)
-            for (uint32_t r = 0; r < rows; r++)
-                if (in_offsets[r + 1] - in_offsets[r] >= heavy) heavy_rows.push_back(r);
-        if (!heavy_rows.empty() && heavy_rows.size() < rows) {
+        std::vector<uint32_t> heavy_rows, empty_rows;
+        for (uint32_t r = 0; r < rows; r++) {
+            const uint32_t len = in_offsets[r + 1] - in_offsets[r];
+            if (len == 0) empty_rows.push_back(r);
+            else if (heavy > 0 && len >= heavy) heavy_rows.push_back(r);
+        }
+        if (heavy == 0 || empty_rows.size() < rows / 8) empty_rows.clear();  // a few empty rows stay where they are
+        if ((!heavy_rows.empty() || !empty_rows.empty()) && heavy_rows.size() + empty_rows.size() < rows) {
             std::stable_sort(heavy_rows.begin(), heavy_rows.end(), [&](uint32_t a, uint32_t b) {
                 return in_offsets[a + 1] - in_offsets[a] > in_offsets[b + 1] - in_offsets[b];
             });
+            const bool drop_empty = !empty_rows.empty();
             std::vector<uint32_t> row_id;
             row_id.reserve(rows);
-            for (uint32_t r = 0; r < rows; r++)
-                if (in_offsets[r + 1] - in_offsets[r] < heavy) row_id.push_back(r);
+            for (uint32_t r = 0; r < rows; r++) {
+                const uint32_t len = in_offsets[r + 1] - in_offsets[r];
+                if ((len > 0 || !drop_empty) && !(heavy > 0 && len >= heavy)) row_id.push_back(r);
+            }
             row_id.insert(row_id.end(), heavy_rows.begin(), heavy_rows.end());
+            row_id.insert(row_id.end(), empty_rows.begin(), empty_rows.end());
+            p->n_empty = (uint32_t)empty_rows.size();
+            p->n_eblocks = (p->n_empty + kERowsPerBlock - 1) / kERowsPerBlock;
             perm_off.resize((size_t)rows + 1);
             perm_off[0] = 0;
             for (uint32_t r = 0; r < rows; r++) perm_off[r + 1] = perm_off[r] + (in_offsets[row_id[r] + 1] - in_offsets[row_id[r]]);
@@ -1001,7 +1077,7 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
         if (rc) return rc;
     } else {
         std::vector<RowBlock> all, blocks, hubs;
-        if (rows) cut_row_blocks(in_offsets, rows, kGTileNnz, all);
+        if (rows > p->n_empty) cut_row_blocks(in_offsets, rows - p->n_empty, kGTileNnz, all);
         for (const RowBlock &rb : all) (rb.e1 - rb.e0 > (uint32_t)kGTileNnz ? hubs : blocks).push_back(rb);
         p->n_gblocks = (uint32_t)blocks.size();
         p->n_hblocks = (uint32_t)hubs.size();
@@ -1010,7 +1086,7 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
         CZ_HIP(hipMalloc((void **)&p->d_hblocks, std::max<size_t>(1, hubs.size()) * sizeof(RowBlock)));
         if (!hubs.empty()) CZ_HIP(hipMemcpy(p->d_hblocks, hubs.data(), hubs.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
     }
-    CZ_HIP(hipMalloc((void **)&p->d_partial, std::max<size_t>(1, (size_t)p->n_bblocks + p->n_gblocks + p->n_hblocks) * 8));
+    CZ_HIP(hipMalloc((void **)&p->d_partial, std::max<size_t>(1, (size_t)p->n_bblocks + p->n_gblocks + p->n_hblocks + p->n_eblocks) * 8));
     CZ_HIP(hipDeviceSynchronize());
     p->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
     *out = p.release();
@@ -1043,10 +1119,14 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
     int rc = cz::ensure_device();
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    const uint32_t n_partial = p->n_bblocks + p->n_gblocks + p->n_hblocks;  // partial errors: [blocked | gather | hub]
+    const uint32_t n_partial = p->n_bblocks + p->n_gblocks + p->n_hblocks + p->n_eblocks;  // partial errors: [blocked | gather | hub | empty]
     if (n_partial == 0) return CZ_OK;
     const uint32_t n_main = p->n_bblocks + p->n_gblocks;
     const bool fork = p->n_hblocks > 0 && n_main > 0;
+    if (p->n_eblocks)  // rows without in-edges: nothing to read but their own score
+        hipLaunchKernelGGL(pr_empty_rows_kernel, dim3(p->n_eblocks), dim3(256), 0, stream, p->d_rowid, p->rows - p->n_empty, p->rows,
+                           p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores, p->base, p->damping,
+                           p->d_partial + n_main + p->n_hblocks);
     if (p->n_hblocks) {
         hipStream_t hs = stream;
         if (fork) {
@@ -1240,3 +1320,16 @@ extern "C" int cz_pagerank(const uint32_t *in_offsets, const uint32_t *in_source
     return cz_pagerank_cached(0, 0, in_offsets, in_sources, out_degree, N, E, damping, tolerance, max_iter, 0, scores, iters_run,
                               final_err, poison, nullptr);
 }
+
+#ifdef CZ_PR_PHASE_TIMING
+// profiling builds only: {fill, queued pieces, lane rows, wave rows} cycles of thread 0 summed over the workgroups,
+// then workgroups, wave rows, queued pieces counted
+extern "C" int cz_pagerank_phase_cycles(unsigned long long *out8, int reset) {
+    if (out8) CZ_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pr_phase), 64));
+    if (reset) {
+        unsigned long long z[8] = {0};
+        CZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pr_phase), z, 64));
+    }
+    return CZ_OK;
+}
+#endif

@@ -77,14 +77,16 @@ impl<'a, 'b> FixedRuleInputRelation<'a, 'b> {
         Ok(Some((b, rel.metadata.keys.len() as u32)))
     }
 
-    /// (relation id, write version) of a stored input read at the present; None for rule results / time travel.  The
-    /// version is the storage engine's monotonically increasing commit counter as seen by this transaction's snapshot
-    /// (for the `mem` / RocksDB engines: the sequence number the read snapshot was taken at).
+    /// (relation id, commit epoch) of a stored input read at the present; None for rule results, time travel, and
+    /// whenever the transaction cannot name the state it reads (a write transaction, or a snapshot taken while a commit
+    /// was in flight) -- the caller then passes the key 0:0 and nothing is cached.  The reference has no version or
+    /// snapshot id anywhere (`StoreTx`, storage/mod.rs:31-164, is get / put / del / scan / commit): the epoch is the
+    /// commit counter db_patch.rs adds to `Db` / `SessionTx` (`SessionTx::gpu_snapshot_key`).
     pub(crate) fn stored_identity(&self) -> Result<Option<(u64, u64)>> {
         match self.arg_manifest {
             crate::data::program::MagicFixedRuleRuleArg::Stored { name, valid_at: None, .. } => {
                 let rel = self.tx.get_relation(name, false)?;
-                Ok(Some((rel.id.0, self.tx.store_tx.snapshot_version())))
+                Ok(self.tx.gpu_snapshot_key().map(|epoch| (rel.id.0, epoch)))
             }
             _ => Ok(None),
         }

@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 3, call c: PageRank after queued pieces with 8 in flight, empty rows out of the row blocks, 16-byte reads in the exact sum;
+# settings sweep, per-phase cycles of phase B (profiling build), kernel trace
+R=$GRAFT_REPO_ROOT; O=gpurun_out/r3c; mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_gpu_graph.py -m gpu -x -q -k "long_rows or skewed or blocked_sweep or pagerank_bitexact or sharded_plan or undirected" > $O/pytest_pagerank.txt 2>&1; echo "pytest rc=$?"; tail -5 $O/pytest_pagerank.txt
+timeout 900 python scratch/r3_pr_rmat.py > $O/pr_rmat.txt 2>&1; echo "pr sweep rc=$?"; grep -v Warning $O/pr_rmat.txt | tail -30
+COZO_GPU_LIB=$R/scratch/lib/libcozo_gpu_prphase.so timeout 600 python scratch/r3_pr_rmat.py --only-default --parity 0 > $O/pr_phase.txt 2>&1; echo "phase rc=$?"; grep -v Warning $O/pr_phase.txt | tail -8
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/trace -o pr -- python $R/scratch/r3_pr_rmat.py --kinds rmat --parity 0 --only-default > $R/$O/pr_rmat_traced.txt 2>&1
+echo "trace rc=$?"
+cd $R
+db=$(find $O/trace -name "*.db" | head -1)
+python profiles/summarize.py "$db" > $O/kernel_stats.txt; grep -E "pb_|pr_" $O/kernel_stats.txt | cut -c1-170
+rm -rf $O/trace

@@ -43,8 +43,8 @@ for kind in a.kinds.split(","):
     print(f"{kind}: {int(off[-1])} edges, longest in-row {max_in}", flush=True)
     settings = [(None, None)]
     if kind == "rmat" and not a.only_default:
-        settings += [("0", None), ("32", None), ("128", None), ("256", None), (None, "256"), (None, "512"), (None, "2048"), (None, "4096"), (None, "16384"),
-                     ("32", "512"), ("128", "2048")]
+        settings += [("0", None), ("64", None), ("256", None), ("512", None), (None, "512"), (None, "1024"), (None, "4096"), (None, "8192"),
+                     ("64", "1024"), ("256", "4096")]
     for heavy, wrow in settings:
         for k, v in (("CZ_PR_HEAVY", heavy), ("CZ_PR_WAVE_ROW", wrow)):
             if v is None:
@@ -57,7 +57,16 @@ for kind in a.kinds.split(","):
         tb = time.time() - t0
         ms = sweep_ms(plan)
         algo = 4 * int(off[-1]) + 4 * (n + 1) + 20 * n
-        print(f"  heavy={heavy or 'default(64)':12s} wave_row={wrow or 'default(1024)':14s}: {ms:.4f} ms/sweep  frac {algo / ms / 1e6 / 8000:.4f}  (plan {tb * 1e3:.0f} ms)", flush=True)
+        if os.environ.get("COZO_GPU_LIB", "").endswith("prphase.so"):
+            import ctypes
+            ph = (ctypes.c_ulonglong * 8)()
+            L.cz_pagerank_phase_cycles(ph, 1)
+            ms = sweep_ms(plan)
+            L.cz_pagerank_phase_cycles(ph, 1)
+            nb = max(1, ph[4])
+            print(f"  phase cycles per workgroup (thread 0): fill {ph[0] / nb:.0f}  queued pieces {ph[1] / nb:.0f}  lane rows {ph[2] / nb:.0f}  "
+                  f"wave rows + reduce {ph[3] / nb:.0f}; workgroups {nb / 11:.0f} per sweep, wave rows {ph[5] / 11:.0f}, queued pieces {ph[6] / 11:.0f} per sweep", flush=True)
+        print(f"  heavy={heavy or 'default':12s} wave_row={wrow or 'default':14s}: {ms:.4f} ms/sweep  frac {algo / ms / 1e6 / 8000:.4f}  (plan {tb * 1e3:.0f} ms)", flush=True)
         if heavy is None and wrow is None and a.parity:
             from oracle import oracle as O
             from cozo_amd.distributed import ShardedPageRank
