@@ -332,6 +332,17 @@ pb_expand_kernel(const AItem *__restrict__ items, const uint16_t *__restrict__ a
     }
 }
 
+// Build-time knobs of phase B (defaults = the measured best; scratch/build_variant.sh builds the other settings for A/B runs)
+#ifndef CZ_PR_U
+#define CZ_PR_U 20  // runs requested per wave before the first value is placed (S = 306 slices: all of a wave's 20 runs at once)
+#endif
+#ifndef CZ_PR_LATE_ROWS
+#define CZ_PR_LATE_ROWS 1  // the rows' own data is requested after the runs (its registers are free while the runs are in flight)
+#endif
+#ifndef CZ_PR_ROWS_BATCHED
+#define CZ_PR_ROWS_BATCHED 1  // short rows: both rows of a lane advance together, eight LDS reads in flight
+#endif
+
 // Phase timing (profiling builds only: scratch/build_variant.sh prphase -DCZ_PR_PHASE_TIMING): thread 0 of every phase-B
 // workgroup adds the cycles between its stamps to g_pr_phase[]; cz_pagerank_phase_cycles reads / clears the counters.
 #ifdef CZ_PR_PHASE_TIMING
@@ -384,7 +395,7 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
     __syncthreads();
     constexpr int NW = kBThreads / 64;
     constexpr int RPL = kMaxRowsPerBlock / kBThreads;  // rows per lane
-    constexpr int U = 10;
+    constexpr int U = CZ_PR_U;
     // Workgroup i is dispatched to XCD i % 8, and every XCD has its own L2.  The runs of ADJACENT row blocks are
     // adjacent in each slice's value stream and share their boundary cache lines, so adjacent row blocks are given
     // to the same XCD (workgroups 8j + x, j = 0, 1, ... take a contiguous range of blocks): the shared line is then
@@ -403,17 +414,21 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
     const uint32_t lane = threadIdx.x & 63;
     uint32_t ra[RPL], rz[RPL], od[RPL];
     float old[RPL];
+    auto load_rows = [&]() {
 #pragma unroll
-    for (int j = 0; j < RPL; j++) {
-        const uint32_t r = rb.row0 + threadIdx.x + j * kBThreads;
-        if (r < rb.row1) {
-            ra[j] = off[r] - e0;
-            rz[j] = off[r + 1] - e0;
-            const uint32_t cr = caller_row(row_id, r);
-            old[j] = scores[cr];
-            od[j] = out_deg[row_begin + cr];
+        for (int j = 0; j < RPL; j++) {
+            const uint32_t r = rb.row0 + threadIdx.x + j * kBThreads;
+            ra[j] = rz[j] = 0;
+            if (r < rb.row1) {
+                ra[j] = off[r] - e0;
+                rz[j] = off[r + 1] - e0;
+                const uint32_t cr = caller_row(row_id, r);
+                old[j] = scores[cr];
+                od[j] = out_deg[row_begin + cr];
+            }
         }
-    }
+    };
+    if (FLAT || !CZ_PR_LATE_ROWS) load_rows();
     if constexpr (FLAT) {
         const uint32_t nnz = rb.e1 - e0;
         const uint32_t *vp = vpos + e0;
@@ -457,39 +472,49 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
         }
         const uint32_t live = min(64u, (S - (g * 64 * NW + wave) + NW - 1) / NW);  // descriptors held this round
         for (uint32_t t0 = 0; t0 < live; t0 += U) {
-            uint32_t st[U], p0[U], c[U], q[U];
+            // a run's descriptor is read out of the holding lane where it is needed (three times) rather than kept:
+            // U = 20 runs' worth of scalars do not fit the scalar registers
+            uint32_t q[U];
             float v[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t t = min(t0 + u, 63u);
-                st[u] = __builtin_amdgcn_readlane(d.x, t);
-                p0[u] = __builtin_amdgcn_readlane(d.y, t);
-                c[u] = t0 + u < live ? __builtin_amdgcn_readlane(cnt, t) : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (lane < c[u]) {
-                    v[u] = val[st[u] + lane];
-                    q[u] = pm[p0[u] + lane];
+                const uint32_t st = __builtin_amdgcn_readlane(d.x, t), p0 = __builtin_amdgcn_readlane(d.y, t);
+                const uint32_t c = t0 + u < live ? __builtin_amdgcn_readlane(cnt, t) : 0;
+                if (lane < c) {
+                    v[u] = val[st + lane];
+                    q[u] = pm[p0 + lane];
                 }
+            }
+            asm volatile("" : "+v"(cnt));  // (keeps the compiler from holding the scalars of the loop above)
 #pragma unroll
-            for (int u = 0; u < U; u++)
-                if (lane < c[u]) tile[q[u]] = v[u];
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (c[u] > 64) {  // uniform over the wave
-                    const uint32_t rest = c[u] - 64, pieces = (rest + 63) / 64;
-                    uint32_t first = 0;
-                    if (lane == 0) first = atomicAdd(&n_tail, pieces);
-                    first = __builtin_amdgcn_readfirstlane(first);
-                    for (uint32_t pc = lane; pc < pieces; pc += 64) {
-                        tail_st[first + pc] = st[u] + 64 + pc * 64;
-                        tail_p0[first + pc] = p0[u] + 64 + pc * 64;
-                        tail_cnt[first + pc] = min(64u, rest - pc * 64);
+            for (int u = 0; u < U; u++) {
+                const uint32_t c = t0 + u < live ? __builtin_amdgcn_readlane(cnt, min(t0 + u, 63u)) : 0;
+                if (lane < c) tile[q[u]] = v[u];
+            }
+            asm volatile("" : "+v"(cnt));
+            if (__ballot(cnt > 64) != 0ull) {  // some run of this wave is longer than one wave instruction (rare on a uniform graph)
+#pragma unroll 1
+                for (uint32_t u = 0; u < (uint32_t)U && t0 + u < live; u++) {
+                    const uint32_t t = t0 + u;
+                    const uint32_t c = __builtin_amdgcn_readlane(cnt, t);
+                    if (c > 64) {  // uniform over the wave
+                        const uint32_t st = __builtin_amdgcn_readlane(d.x, t), p0 = __builtin_amdgcn_readlane(d.y, t);
+                        const uint32_t rest = c - 64, pieces = (rest + 63) / 64;
+                        uint32_t first = 0;
+                        if (lane == 0) first = atomicAdd(&n_tail, pieces);
+                        first = __builtin_amdgcn_readfirstlane(first);
+                        for (uint32_t pc = lane; pc < pieces; pc += 64) {
+                            tail_st[first + pc] = st + 64 + pc * 64;
+                            tail_p0[first + pc] = p0 + 64 + pc * 64;
+                            tail_cnt[first + pc] = min(64u, rest - pc * 64);
+                        }
                     }
                 }
+            }
         }
     }
+    if (CZ_PR_LATE_ROWS) load_rows();  // in flight through the barrier and the queued pieces; first used by the row sums
     __syncthreads();
     PR_STAMP(0);  // descriptors + the first 64 values of every run
     // the queued pieces: TU of them in flight per wave (one piece after the other waited a memory round trip each --
@@ -519,6 +544,47 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
     double err = 0.0;
     // Rows are summed in order (the reference's sequential f32 sum): one lane per row, and the rows of >= wave_row terms
     // afterwards by a wave each (exact_sum.cuh: the same bits, without the serial chain a skewed graph's sweep waited for).
+#if CZ_PR_ROWS_BATCHED
+    {
+        // Rows of < 32 terms (all of a uniform graph's): the lane's two rows advance together, eight values each per step,
+        // requested before the first is added -- padding reads return +0.0, which adds nothing to a sum that is never -0.0.
+        // One LDS read at a time per term (waited for in place) made this phase a quarter of the workgroup's time.
+        static_assert(RPL == 2, "two rows per lane");
+        const uint32_t len0 = rz[0] - ra[0], len1 = rz[1] - ra[1];
+        const bool short0 = len0 < 32, short1 = len1 < 32;
+        float s0 = 0.0f, s1 = 0.0f;
+        uint32_t steps = max(short0 ? len0 : 0u, short1 ? len1 : 0u);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, o, 64));
+        for (uint32_t k = 0; k < steps; k += 8) {
+            float a[8], c[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                a[i] = (short0 && k + i < len0) ? tile[ra[0] + k + i] : 0.0f;
+                c[i] = (short1 && k + i < len1) ? tile[ra[1] + k + i] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                s0 = s0 + a[i];
+                s1 = s1 + c[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+            const uint32_t r = rb.row0 + threadIdx.x + j * kBThreads;
+            if (r < rb.row1) {
+                const uint32_t len = rz[j] - ra[j];
+                if (len >= wave_row) {
+                    wl.raw[atomicAdd(&wl.n, 1u)] = threadIdx.x + j * kBThreads;
+                    continue;
+                }
+                const float s = len < 32 ? (j == 0 ? s0 : s1) : lane_row_sum(tile, ra[j], rz[j]);
+                // (the caller's row number is fetched again rather than kept in a register through the tile fill)
+                err += finish_row(s, caller_row(row_id, r), old[j], od[j], row_begin, contrib_out, scores, base, damping);
+            }
+        }
+    }
+#else
 #pragma unroll
     for (int j = 0; j < RPL; j++) {
         const uint32_t r = rb.row0 + threadIdx.x + j * kBThreads;
@@ -532,6 +598,7 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
             err += finish_row(s, caller_row(row_id, r), old[j], od[j], row_begin, contrib_out, scores, base, damping);
         }
     }
+#endif
     const uint32_t nl = order_wave_rows(wl);
     PR_STAMP(2);  // one lane per row (until the slowest wave is through)
     if (nl) err += wave_rows<kBThreads>(wl, nl, rb, off, e0, tile, out_deg, row_begin, contrib_out, scores, base, damping, row_id);
@@ -1122,28 +1189,28 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
     const uint32_t n_partial = p->n_bblocks + p->n_gblocks + p->n_hblocks + p->n_eblocks;  // partial errors: [blocked | gather | hub | empty]
     if (n_partial == 0) return CZ_OK;
     const uint32_t n_main = p->n_bblocks + p->n_gblocks;
-    const bool fork = p->n_hblocks > 0 && n_main > 0;
-    if (p->n_eblocks)  // rows without in-edges: nothing to read but their own score
-        hipLaunchKernelGGL(pr_empty_rows_kernel, dim3(p->n_eblocks), dim3(256), 0, stream, p->d_rowid, p->rows - p->n_empty, p->rows,
-                           p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores, p->base, p->damping,
-                           p->d_partial + n_main + p->n_hblocks);
-    if (p->n_hblocks) {
-        hipStream_t hs = stream;
-        if (fork) {
-            if (!p->side) {
-                CZ_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-                CZ_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-                CZ_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-            }
-            CZ_HIP(hipEventRecord(p->ev_fork, stream));  // contrib_in is ready where the caller's stream stands
-            CZ_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
-            hs = p->side;
+    const bool side_work = p->n_hblocks > 0 || p->n_eblocks > 0;
+    const bool fork = side_work && n_main > 0;
+    hipStream_t hs = stream;
+    if (fork) {  // hub rows and rows without in-edges run beside the sweep of the others, joined before the error sum
+        if (!p->side) {
+            CZ_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+            CZ_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+            CZ_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
         }
+        CZ_HIP(hipEventRecord(p->ev_fork, stream));  // contrib_in is ready where the caller's stream stands
+        CZ_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+        hs = p->side;
+    }
+    if (p->n_hblocks)
         hipLaunchKernelGGL(pr_hub_kernel, dim3(p->n_hblocks), dim3(kHThreads), 0, hs, p->d_hblocks, p->d_src, p->d_outdeg,
                            p->row_begin, contrib_in_dev, contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial + n_main,
                            p->d_rowid);
-        if (fork) CZ_HIP(hipEventRecord(p->ev_join, p->side));
-    }
+    if (p->n_eblocks)  // rows without in-edges: nothing to read but their own score
+        hipLaunchKernelGGL(pr_empty_rows_kernel, dim3(p->n_eblocks), dim3(256), 0, hs, p->d_rowid, p->rows - p->n_empty, p->rows,
+                           p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores, p->base, p->damping,
+                           p->d_partial + n_main + p->n_hblocks);
+    if (fork) CZ_HIP(hipEventRecord(p->ev_join, p->side));
     if (p->blocked) {
         for (uint32_t c = 0; c < p->n_chunks; c++) {
             const uint32_t i0 = p->item_ptr[c], i1 = p->item_ptr[c + 1];

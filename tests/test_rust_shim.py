@@ -152,3 +152,80 @@ def test_every_parameter_and_return_type_matches():
             if a != b:
                 bad.append((name, i, a, b))
     assert not bad, bad
+
+
+# ---- the reference-side identifiers the shim files lean on -------------------------------------------------------------
+REF = "/root/reference/cozo-core/src"
+SHIM_DIR = os.path.join(ROOT, "integration", "rust")
+
+
+def _shim_sources():
+    return {f: re.sub(r"//.*", "", open(os.path.join(SHIM_DIR, f)).read()) for f in sorted(os.listdir(SHIM_DIR)) if f.endswith(".rs")}
+
+
+def _ref_text():
+    out = []
+    for d, _, files in os.walk(REF):
+        for f in files:
+            if f.endswith(".rs"):
+                out.append(open(os.path.join(d, f), errors="replace").read())
+    return "\n".join(out)
+
+
+def _module_text(path):
+    """source of crate::<path> (a file or a directory module) in the reference, None when there is no such module"""
+    base = os.path.join(REF, *path)
+    for cand in (base + ".rs", os.path.join(base, "mod.rs")):
+        if os.path.exists(cand):
+            if cand.endswith("mod.rs"):
+                return "\n".join(open(os.path.join(d, f), errors="replace").read() for d, _, fs in os.walk(base) for f in fs if f.endswith(".rs"))
+            return open(cand, errors="replace").read()
+    return None
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is only present in the build container")
+def test_shim_only_names_things_the_reference_or_the_patch_defines():
+    """Round 2's shim called `store_tx.snapshot_version()`, which `StoreTx` (storage/mod.rs:31-164) does not have, and nothing
+    noticed: there is no rustc here.  This is the check that can be made without one: every `crate::` item the shim files
+    import or name, and every method they call on the transaction / payload / store objects, must be defined in
+    /root/reference/cozo-core/src -- or in integration/rust/db_patch.rs, the file that lists what the patch ADDS."""
+    shims = _shim_sources()
+    ref_all = _ref_text()
+    own = "\n".join(shims.values())
+    missing = []
+    # 1. `use crate::a::b::{X, Y}` / `use crate::a::b::X` / inline `crate::a::b::X`
+    names = set()
+    for text in shims.values():
+        for m in re.finditer(r"crate::((?:[a-z_0-9]+::)+)\{([^}]*)\}", text):
+            for item in m.group(2).split(","):
+                item = item.strip().split(" as ")[0].strip()
+                if item and item != "self":
+                    names.add((tuple(m.group(1).strip(":").split("::")), item))
+        for m in re.finditer(r"crate::((?:[a-z_0-9]+::)+)([A-Za-z_][A-Za-z0-9_]*)", text):
+            names.add((tuple(m.group(1).strip(":").split("::")), m.group(2)))
+    assert len(names) >= 15
+    for path, item in sorted(names):
+        mod = _module_text(path)
+        if mod is None and len(path) > 1:  # crate::a::b::Type::Variant: the last path element is a type, not a module
+            mod = _module_text(path[:-1])
+        defined = mod is not None and re.search(r"\b(struct|enum|trait|fn|type|const|static|mod|macro_rules!)\s+" + re.escape(item) + r"\b", mod)
+        variant = mod is not None and re.search(r"\b" + re.escape(item) + r"\s*[\{\(,]", mod)  # an enum variant / re-export
+        in_patch = re.search(r"\b(struct|enum|trait|fn|type|const)\s+" + re.escape(item) + r"\b", own)
+        if not (defined or variant or in_patch):
+            missing.append("crate::" + "::".join(path) + "::" + item)
+    # 2. methods called on the reference's objects
+    receivers = r"(?:self\.tx|tx|payload|edges|nodes|self\.tx\.store_tx|self\.tx\.temp_store_tx|store_tx|temp_store_tx|rel|out|poison|self)"
+    calls = set()
+    for text in shims.values():
+        calls.update(re.findall(receivers + r"\.([a-z_][a-z0-9_]*)\s*\(", text))
+    assert "get_relation" in calls and "range_scan" in calls
+    for name in sorted(calls):
+        pat = r"\bfn\s+" + re.escape(name) + r"\b"
+        if not (re.search(pat, ref_all) or re.search(pat, own)):
+            missing.append("." + name + "()")
+    assert not missing, missing
+    # and the one that started it stays gone
+    assert "snapshot_version" not in own.replace("Round 2's shim called a `snapshot_version()`", "")
