@@ -41,11 +41,15 @@ for kind in a.kinds.split(","):
     off, s, outdeg32, max_in = Bn.make_graph(args, torch, None, 0, 1, dev, kind, n, e, 0, n)
     off32 = off.to(torch.int32)
     print(f"{kind}: {int(off[-1])} edges, longest in-row {max_in}", flush=True)
-    settings = [(None, None)]
+    settings = [(None, None, {})]
     if kind == "rmat" and not a.only_default:
-        settings += [("0", None), ("64", None), ("256", None), ("512", None), (None, "512"), (None, "1024"), (None, "4096"), (None, "8192"),
-                     ("64", "1024"), ("256", "4096")]
-    for heavy, wrow in settings:
+        settings += [(None, None, {"CZ_PR_XCD_BALANCE": "0"}), (None, None, {"CZ_PR_XCD": "0"}), (None, None, {"CZ_PR_BLOCK_FIXED_COST": "2000"}),
+                     (None, None, {"CZ_PR_BLOCK_FIXED_COST": "12000"}), (None, None, {"CZ_PR_BLOCK_FIXED_COST": "20000"}),
+                     ("64", None, {}), ("512", None, {}), (None, "1024", {}), (None, "4096", {})]
+    for heavy, wrow, extra in settings:
+        for k in ("CZ_PR_XCD_BALANCE", "CZ_PR_XCD", "CZ_PR_BLOCK_FIXED_COST"):
+            os.environ.pop(k, None)
+        os.environ.update(extra)
         for k, v in (("CZ_PR_HEAVY", heavy), ("CZ_PR_WAVE_ROW", wrow)):
             if v is None:
                 os.environ.pop(k, None)
@@ -66,7 +70,7 @@ for kind in a.kinds.split(","):
             nb = max(1, ph[4])
             print(f"  phase cycles per workgroup (thread 0): fill {ph[0] / nb:.0f}  queued pieces {ph[1] / nb:.0f}  lane rows {ph[2] / nb:.0f}  "
                   f"wave rows + reduce {ph[3] / nb:.0f}; workgroups {nb / 11:.0f} per sweep, wave rows {ph[5] / 11:.0f}, queued pieces {ph[6] / 11:.0f} per sweep", flush=True)
-        print(f"  heavy={heavy or 'default':12s} wave_row={wrow or 'default':14s}: {ms:.4f} ms/sweep  frac {algo / ms / 1e6 / 8000:.4f}  (plan {tb * 1e3:.0f} ms)", flush=True)
+        print(f"  heavy={heavy or 'default':12s} wave_row={wrow or 'default':8s} {str(extra):38s}: {ms:.4f} ms/sweep  frac {algo / ms / 1e6 / 8000:.4f}  (plan {tb * 1e3:.0f} ms)", flush=True)
         if heavy is None and wrow is None and a.parity:
             from oracle import oracle as O
             from cozo_amd.distributed import ShardedPageRank
