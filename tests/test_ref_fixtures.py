@@ -1,0 +1,238 @@
+"""The oracle against the REFERENCE ITSELF: tests/golden/ref_fixtures.json is what the real cozo-core returned on the seeded
+inputs of tests/golden/make_ref_inputs.py (produced by oracle/ref_fixtures/make_ref_fixtures.sh on a box with cargo).  The
+image this repository is developed in has no Rust toolchain, so the file is absent there and these tests skip, saying so;
+DESIGN.md section 3 therefore still reads "parity unpinned".  REF_FIXTURES=<path> points the tests at another file.
+
+What is compared, and how strictly:
+  distances      l2_dist / ip_dist / cos_dist f64 results == the oracle in ORC_DOT_NDARRAY order, bit for bit
+  hnsw_knn       the reference's own index rows (`*tbl:idx{..}`) loaded into the oracle's flat layout, the oracle's search on
+                 them == the reference's rows (keys and f64 distances), bit for bit -- the reference's random levels make the
+                 BUILD unrepeatable (thread_rng, hnsw.rs:47-48), so the build is pinned through structure only: row counts per
+                 level within m_max, symmetric stored distances
+  PageRank       every score within 1e-5 relative (north_star's bar); whether it is ALSO bit-identical is reported, which settles
+                 the Jacobi / in-place question of SURVEY section 8 a10 for graph 0.3.1
+  CC / Dijkstra / ShortestPathBFS   group ids, f32 costs (as f64) and path lengths equal
+"""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PATH = os.environ.get("REF_FIXTURES") or os.path.join(HERE, "golden", "ref_fixtures.json")
+needs_ref = pytest.mark.skipif(not os.path.exists(PATH), reason="no reference-generated fixtures (needs cargo: oracle/ref_fixtures/make_ref_fixtures.sh); parity stays unpinned")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    with open(PATH) as f:
+        d = json.load(f)["results"]
+    bad = [k for k, v in d.items() if v.get("ok") is not True]
+    assert not bad, f"reference steps that failed: {bad}"
+    return d
+
+
+@pytest.fixture(scope="module")
+def inputs():
+    spec = importlib.util.spec_from_file_location("make_ref_inputs", os.path.join(HERE, "golden", "make_ref_inputs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, mod.dataset()
+
+
+def _bits(x):
+    return np.asarray(x, dtype=np.float64).view(np.uint64)
+
+
+def check_distances(ref, inputs, oracle):
+    mod, d = inputs
+    for dim in mod.DIMS:
+        a, b = d["pairs"][dim]
+        rows = ref[f"distances d={dim}"]["rows"]
+        assert [r[0] for r in rows] == list(range(len(a)))
+        pairs = np.stack([np.arange(len(a), dtype=np.uint32)] * 2, 1).copy()
+        for col, metric in ((1, oracle.L2), (2, oracle.IP), (3, oracle.COSINE)):
+            want = np.array([np.nan if r[col] is None else r[col] for r in rows], dtype=np.float64)
+            got = oracle.distance_pairs(metric, b, a, pairs, oracle.DOT_NDARRAY)  # dist(query a[i], row b[i]); the metrics are symmetric
+            nan = np.isnan(want)
+            assert np.array_equal(np.isnan(got), nan), (dim, metric)
+            assert np.array_equal(_bits(got[~nan]), _bits(want[~nan])), (dim, metric, got[~nan][:3], want[~nan][:3])
+
+
+def _flat_from_rows(oracle, rows, vectors, metric, m):
+    """the reference's `tbl:idx` rows -> the flat layout (level l = layer -l; self rows and ignore_link rows are not links)"""
+    by_level = {}
+    for layer, fr_k, _ff, _fs, to_k, _tf, _ts, dist, ignore in rows:
+        lvl = by_level.setdefault(-int(layer), {})
+        lst = lvl.setdefault(int(fr_k), [])
+        if int(fr_k) != int(to_k) and not ignore:
+            lst.append((int(to_k), float(dist)))
+    n_levels = max(by_level) + 1
+    nodes, nbrs = [], []
+    for l in range(n_levels):
+        ids = sorted(by_level[l])
+        width = max(1, max(len(by_level[l][i]) for i in ids))
+        assert width <= (2 * m if l == 0 else m)
+        tab = np.full((len(ids), width), oracle.NONE, dtype=np.uint32)
+        for r, i in enumerate(ids):
+            tos = sorted(t for t, _ in by_level[l][i])
+            tab[r, :len(tos)] = tos
+        nodes.append(np.array(ids, dtype=np.uint32))
+        nbrs.append(tab)
+    entry = int(nodes[-1][0])  # the first row of the index relation: smallest key on the top level (hnsw.rs:891-899)
+    return oracle.FlatIndex(vectors, metric, nodes, nbrs, entry), by_level
+
+
+def check_hnsw(ref, inputs, oracle):
+    mod, d = inputs
+    H = mod.HNSW
+    for name, metric in (("L2", oracle.L2), ("Cosine", oracle.COSINE), ("IP", oracle.IP)):
+        flat, by_level = _flat_from_rows(oracle, ref[f"hnsw index rows {name}"]["rows"], d["vectors"], metric, H["m"])
+        assert sorted(by_level[0]) == list(range(H["n"]))
+        # stored link distances are the metric's value for that pair, in the reference's arithmetic
+        some = [(i, t, dist) for i in list(by_level[0])[:50] for t, dist in by_level[0][i]]
+        pairs = np.array([[i, t] for i, t, _ in some], dtype=np.uint32)
+        got = oracle.distance_pairs(metric, d["vectors"], d["vectors"], pairs, oracle.DOT_NDARRAY)
+        assert np.array_equal(_bits(got), _bits([x for _, _, x in some])), name
+        ids, dist, cnt, _ = flat.knn_batch(d["queries"], H["k"], H["ef"])
+        want = {}
+        for qi, k, dd in ref[f"hnsw knn {name}"]["rows"]:
+            want.setdefault(int(qi), []).append((float(dd), int(k)))
+        for qi in range(H["queries"]):
+            w = sorted(want.get(qi, []))
+            g = sorted((float(dist[qi, j]), int(ids[qi, j])) for j in range(cnt[qi]))
+            assert [k for _, k in g] == [k for _, k in w], (name, qi)
+            assert np.array_equal(_bits([x for x, _ in g]), _bits([x for x, _ in w])), (name, qi)
+
+
+def _graph(oracle, d):
+    from tests import util
+    return util.graph_from_relation(oracle, d["frm"], d["to"]), util.graph_from_relation(oracle, d["frm"], d["to"], undirected=True), \
+        util.graph_from_relation(oracle, d["frm"], d["to"], weights=d["w"])
+
+
+def check_pagerank(ref, inputs, oracle):
+    _, d = inputs
+    g, _, _ = _graph(oracle, d)
+    index_of = {int(v): i for i, v in enumerate(g["ind"])}
+    for step, args in (("pagerank defaults", (0.85, 1e-4, 10)), ("pagerank theta=0.5 4 iterations", (0.5, 0.0, 4))):
+        rows = ref[step]["rows"]
+        assert len(rows) == g["n"]
+        want = np.empty(g["n"], dtype=np.float64)
+        for n, r in rows:
+            want[index_of[int(n)]] = r
+        got, _, _ = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], *args)
+        rel = np.abs(got.astype(np.float64) - want) / np.abs(want)
+        assert rel.max() <= 1e-5, (step, rel.max())
+        print(f"{step}: max relative difference {rel.max():.3e}; bit-identical: {bool(np.array_equal(got.astype(np.float64), want))}")
+
+
+def _bfs_path(parent, start, goal):
+    if goal != start and parent[goal] == 0xFFFFFFFF:
+        return None
+    path = [goal]
+    while path[-1] != start:
+        path.append(int(parent[path[-1]]))
+        assert len(path) <= len(parent)
+    return path[::-1]
+
+
+def check_components_dijkstra_bfs(ref, inputs, oracle):
+    _, d = inputs
+    g, u, gw = _graph(oracle, d)
+    index_of = {int(v): i for i, v in enumerate(g["ind"])}
+    grp, _ = oracle.tarjan_groups(u["n"], u["ooff"], u["otgt"])
+    rows = ref["connected components"]["rows"]
+    assert len(rows) == g["n"]
+    for n, gid in rows:
+        assert int(grp[index_of[int(n)]]) == int(gid), n
+    dist, _ = oracle.dijkstra(gw["n"], gw["ooff"], gw["otgt"], gw["ow"], index_of[d["dijkstra_start"]])
+    seen = 0
+    for s, t, c, p in ref["dijkstra"]["rows"]:
+        assert int(s) == d["dijkstra_start"]
+        got = float(dist[index_of[int(t)]])
+        want = float("inf") if c is None else float(c)  # JSON has no inf: cozo prints it as null
+        assert got == want, (t, got, want)
+        assert (len(p) == 0) == np.isinf(want)
+        seen += 1
+    assert seen == g["n"]
+    goals = np.array([index_of[x] for x in d["bfs_goals"]], dtype=np.uint32)
+    start = index_of[d["bfs_start"]]
+    parent = oracle.shortest_path_bfs(g["n"], g["ooff"], g["otgt"], start, goals)
+    by_goal = {int(gv): p for _, gv, p in ref["shortest path bfs"]["rows"]}
+    for gv, gi in zip(d["bfs_goals"], goals):
+        want = by_goal[gv]
+        got = _bfs_path(parent, start, int(gi))
+        assert (want is None) == (got is None), gv
+        if want is not None:  # FIFO order + sorted adjacency: the same path, node for node
+            assert [index_of[int(x)] for x in want] == got, gv
+
+
+@needs_ref
+def test_distances_bit_for_bit(ref, inputs, oracle):
+    check_distances(ref, inputs, oracle)
+
+
+@needs_ref
+def test_hnsw_knn_on_the_reference_built_index(ref, inputs, oracle):
+    check_hnsw(ref, inputs, oracle)
+
+
+@needs_ref
+def test_pagerank_within_tolerance_and_whether_bit_identical(ref, inputs, oracle):
+    check_pagerank(ref, inputs, oracle)
+
+
+@needs_ref
+def test_components_dijkstra_and_bfs(ref, inputs, oracle):
+    check_components_dijkstra_bfs(ref, inputs, oracle)
+
+
+def test_the_checks_themselves_on_rows_the_oracle_produced(inputs, oracle):
+    """No reference output exists in this image, so the four checks above would never run here and could rot.  This feeds them
+    a stand-in `results` object built from the ORACLE's own outputs in the row shapes cozo returns (headers as in
+    make_ref_inputs.steps): it proves nothing about parity, only that the plumbing a maintainer will run is sound."""
+    mod, d = inputs
+    from tests import util
+    fake = {}
+    for dim in mod.DIMS:
+        a, b = d["pairs"][dim]
+        pairs = np.stack([np.arange(len(a), dtype=np.uint32)] * 2, 1).copy()
+        cols = [oracle.distance_pairs(m, b, a, pairs, oracle.DOT_NDARRAY) for m in (oracle.L2, oracle.IP, oracle.COSINE)]
+        fake[f"distances d={dim}"] = dict(ok=True, rows=[[i] + [None if np.isnan(c[i]) else float(c[i]) for c in cols] for i in range(len(a))])
+    H = mod.HNSW
+    for name, metric in (("L2", oracle.L2), ("Cosine", oracle.COSINE), ("IP", oracle.IP)):
+        _, flat = util.build_index(oracle, d["vectors"], metric, H["m"], H["ef_construction"])
+        rows = []
+        for l in range(flat.n_levels):
+            for r, i in enumerate(flat.level_nodes[l]):
+                tos = [int(t) for t in flat.level_nbrs[l][r] if t != oracle.NONE]
+                rows.append([-l, int(i), 1, -1, int(i), 1, -1, float(len(tos)), False])  # the self row carries the degree
+                if tos:
+                    pr = np.array([[int(i), t] for t in tos], dtype=np.uint32)
+                    dd = oracle.distance_pairs(metric, d["vectors"], d["vectors"], pr, oracle.DOT_NDARRAY)
+                    rows += [[-l, int(i), 1, -1, t, 1, -1, float(x), False] for t, x in zip(tos, dd)]
+        fake[f"hnsw index rows {name}"] = dict(ok=True, rows=rows)
+        ids, dist, cnt, _ = flat.knn_batch(d["queries"], H["k"], H["ef"])
+        fake[f"hnsw knn {name}"] = dict(ok=True, rows=[[qi, int(ids[qi, j]), float(dist[qi, j])] for qi in range(H["queries"]) for j in range(cnt[qi])])
+    g, u, gw = _graph(oracle, d)
+    for step, args in (("pagerank defaults", (0.85, 1e-4, 10)), ("pagerank theta=0.5 4 iterations", (0.5, 0.0, 4))):
+        s, _, _ = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], *args)
+        fake[step] = dict(ok=True, rows=[[int(g["ind"][i]), float(s[i])] for i in range(g["n"])])
+    grp, _ = oracle.tarjan_groups(u["n"], u["ooff"], u["otgt"])
+    fake["connected components"] = dict(ok=True, rows=[[int(g["ind"][i]), int(grp[i])] for i in range(g["n"])])
+    index_of = {int(v): i for i, v in enumerate(g["ind"])}
+    dist, par = oracle.dijkstra(gw["n"], gw["ooff"], gw["otgt"], gw["ow"], index_of[d["dijkstra_start"]])
+    fake["dijkstra"] = dict(ok=True, rows=[[d["dijkstra_start"], int(g["ind"][i]), None if np.isinf(dist[i]) else float(dist[i]),
+                                            [] if np.isinf(dist[i]) else [0]] for i in range(g["n"])])
+    goals = np.array([index_of[x] for x in d["bfs_goals"]], dtype=np.uint32)
+    start = index_of[d["bfs_start"]]
+    parent = oracle.shortest_path_bfs(g["n"], g["ooff"], g["otgt"], start, goals)
+    fake["shortest path bfs"] = dict(ok=True, rows=[[d["bfs_start"], gv, (lambda p: None if p is None else [int(g["ind"][x]) for x in p])(_bfs_path(parent, start, int(gi)))]
+                                                    for gv, gi in zip(d["bfs_goals"], goals)])
+    check_distances(fake, inputs, oracle)
+    check_hnsw(fake, inputs, oracle)
+    check_pagerank(fake, inputs, oracle)
+    check_components_dijkstra_bfs(fake, inputs, oracle)
