@@ -378,7 +378,7 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
                  const uint16_t *__restrict__ perm, const uint32_t *__restrict__ vpos, const float *__restrict__ val,
                  const uint32_t *__restrict__ out_deg, uint32_t row_begin, float *__restrict__ contrib_out,
                  float *__restrict__ scores, float base, float damping, double *__restrict__ partial, int xcd_remap,
-                 const uint32_t *__restrict__ row_id, uint32_t wave_row, const uint32_t *__restrict__ xcd_ranges) {
+                 const uint32_t *__restrict__ row_id, uint32_t wave_row) {
     __shared__ __attribute__((aligned(16))) float tile[kBTileNnz];
     __shared__ double red[kBThreads / 64];
     __shared__ WaveRowList wl;
@@ -403,14 +403,7 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
     // to the same XCD (workgroups 8j + x, j = 0, 1, ... take a contiguous range of blocks): the shared line is then
     // fetched from memory once instead of once per L2.
     uint32_t local = blockIdx.x;
-    if (xcd_ranges) {
-        // skewed plans: the row blocks differ in cost (a block of light rows holds a third of the edges of a block of heavy
-        // ones), so equal COUNTS per XCD leave some XCDs idle half of the kernel; the ranges are cut by cost at plan build
-        const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
-        const uint32_t lo = xcd_ranges[x], hi = xcd_ranges[x + 1];
-        if (j >= hi - lo) return;  // the grid holds 8 x the longest range
-        local = lo + j;
-    } else if (xcd_remap) {
+    if (xcd_remap) {
         const uint32_t nb = gridDim.x, x = blockIdx.x & 7u, j = blockIdx.x >> 3;
         local = x * (nb >> 3) + min(x, nb & 7u) + j;
     }
@@ -832,15 +825,13 @@ struct cz_pagerank_plan {
     uint32_t *d_rowid = nullptr;
     uint32_t wave_row = kWaveRowDefault;
     uint32_t n_empty = 0, n_eblocks = 0;  // rows without in-edges, moved to the very end (pr_empty_rows_kernel)
-    uint32_t *d_xcd = nullptr;            // skewed plans: block ranges per XCD cut by cost, [9]
-    uint32_t xcd_grid = 0;                // 8 x the longest range
     // shared (d_off / d_src: in plan row order)
     uint32_t *d_off = nullptr, *d_src = nullptr, *d_outdeg = nullptr;
     float *d_scores = nullptr;
     double *d_partial = nullptr;
     ~cz_pagerank_plan() {
         void *ps[] = {d_gblocks, d_hblocks, d_bblocks, d_items, d_asrc, d_perm, d_vpos, d_seg, d_val, d_off, d_src, d_outdeg, d_scores,
-                      d_partial, d_rowid, d_xcd};
+                      d_partial, d_rowid};
         for (void *p : ps)
             if (p) (void)hipFree(p);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -1028,28 +1019,12 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
         p->d_src = nullptr;
     }
     p->blocked = true;
-    p->xcd_remap = env_int("CZ_PR_XCD", 1);
-    if (p->d_rowid && n_chunks == 1 && !bb.empty() && env_int("CZ_PR_XCD_BALANCE", 1) != 0 && p->xcd_remap) {
-        // cost of a row block: its edges (the streams it reads) + a fixed part (one descriptor per slice, the rows' own data)
-        const uint64_t fixed = (uint64_t)std::max(0, env_int("CZ_PR_BLOCK_FIXED_COST", 6000));
-        uint64_t total = 0;
-        for (const RowBlock &rb : bb) total += (rb.e1 - rb.e0) + fixed;
-        uint32_t ranges[9];
-        ranges[0] = 0;
-        uint64_t acc = 0;
-        uint32_t x = 1;
-        for (size_t i = 0; i < bb.size() && x < 8; i++) {
-            acc += (bb[i].e1 - bb[i].e0) + fixed;
-            if (acc >= total * x / 8) ranges[x++] = (uint32_t)i + 1;
-        }
-        while (x < 8) ranges[x++] = (uint32_t)bb.size();
-        ranges[8] = (uint32_t)bb.size();
-        uint32_t longest = 0;
-        for (int k = 0; k < 8; k++) longest = std::max(longest, ranges[k + 1] - ranges[k]);
-        p->xcd_grid = 8 * longest;
-        CZ_HIP(hipMalloc((void **)&p->d_xcd, sizeof(ranges)));
-        CZ_HIP(hipMemcpy(p->d_xcd, ranges, sizeof(ranges), hipMemcpyHostToDevice));
-    }
+    // Adjacent row blocks on one XCD share the boundary lines of their runs (1.82 -> 1.58 GB per sweep on the uniform graph).
+    // A plan that moved its heavy rows has blocks of very different cost in different parts of the list -- light rows
+    // first, then the heavy ones longest first -- and a contiguous range per XCD then leaves some XCDs with nothing but
+    // blocks whose long row sums hold their LDS tile while memory idles: R-MAT 10M / 100M 0.614 ms per sweep with ranges
+    // of equal count, 0.587 with ranges of equal cost, 0.527 dealt round-robin (profiles/r03_pagerank_rmat.txt).
+    p->xcd_remap = env_int("CZ_PR_XCD", p->d_rowid ? 0 : 1);
     return CZ_OK;
 }
 
@@ -1253,15 +1228,15 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
                                    contrib_in_dev, p->N, p->wlog, val);
             if (b1 > b0) {
                 if (p->d_vpos)
-                    hipLaunchKernelGGL(pb_reduce_kernel<true>, dim3(p->d_xcd ? p->xcd_grid : b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
+                    hipLaunchKernelGGL(pb_reduce_kernel<true>, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
                                        p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
                                        contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap, p->d_rowid,
-                                       p->wave_row, p->d_xcd);
+                                       p->wave_row);
                 else
-                    hipLaunchKernelGGL(pb_reduce_kernel<false>, dim3(p->d_xcd ? p->xcd_grid : b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
+                    hipLaunchKernelGGL(pb_reduce_kernel<false>, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
                                        p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
                                        contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap, p->d_rowid,
-                                       p->wave_row, p->d_xcd);
+                                       p->wave_row);
             }
         }
     } else if (p->n_gblocks) {

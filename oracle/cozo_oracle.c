@@ -341,7 +341,7 @@ static int dyn_nbrs(const void *ctx, uint32_t node, int level, uint32_t *out) {
     const adj_t *a = &h->adj[node][level];
     int c = 0;
     for (int i = 0; i < a->n; i++)
-        if (!a->v[i].ignore) out[c++] = a->v[i].to;
+        if (!a->v[i].ignore && h->top[a->v[i].to] >= level) out[c++] = a->v[i].to; /* (rows left dangling by a removal: see orc_hnsw_remove) */
     return c;
 }
 static double hdist(orc_hnsw *h, const float *a, const float *b) {
@@ -503,6 +503,68 @@ int orc_hnsw_insert(orc_hnsw *h, const float *vectors, uint32_t n, const int32_t
     }
     return 0;
 }
+/* hnsw_remove_vec, runtime/hnsw.rs:754-868, on the same row model as put_vector (adj[node][level] = the link rows
+ * `[layer, fr.., to..]` with their ignore_link flag, adj_t.degree = the f64 in the self row):
+ *   per layer 0, -1, ... while the node's self row exists (:766-778): delete the self row; walk the node's out-rows
+ *   INCLUDING the soft-deleted ones (hnsw_get_neighbours(.., include_deleted = true), :780-782); for every neighbour delete
+ *   the out-row and the reverse row -- whether or not that one exists (:786-805) -- and take ONE off the neighbour's stored
+ *   degree (:806-823) even when it held no live link back.
+ * What the reference leaves behind: rows Z -> X of nodes Z that X did not link to (X was shrunk out of by nobody's choice
+ * but Z's own shrink never ran the other way).  A later search that follows such a row fails in ensure_key ("Cannot find
+ * compound key for HNSW", :133) because the base row is gone.  orc_hnsw_dangling_links counts them; the exports skip
+ * them, which is the state the device's cz_hnsw_remove produces.
+ * The entry point is positional (:184-191, :891-899): the smallest node of the highest layer that still has a row. */
+static void adj_remove(adj_t *a, uint32_t to) {
+    for (int i = 0; i < a->n; i++)
+        if (a->v[i].to == to) {
+            memmove(a->v + i, a->v + i + 1, sizeof(link_t) * (size_t)(a->n - i - 1));
+            a->n--;
+            return;
+        }
+}
+int orc_hnsw_remove(orc_hnsw *h, uint32_t node) {
+    if (node >= h->n || h->top[node] < 0) return 0; /* no self row at layer 0: nothing is indexed under this key */
+    for (int lv = 0; lv <= h->top[node]; lv++) {
+        adj_t *a = &h->adj[node][lv];
+        for (int i = 0; i < a->n; i++) {
+            const uint32_t nb = a->v[i].to;
+            if (nb < h->n && h->top[nb] >= lv) {
+                adj_remove(&h->adj[nb][lv], node); /* :796-805 the reverse row, present or not */
+                h->adj[nb][lv].degree -= 1.0;      /* :806-823 */
+            }
+        }
+        free(a->v);
+        a->v = NULL;
+        a->n = a->cap = 0;
+        a->degree = 0.0;
+    }
+    free(h->adj[node]);
+    h->adj[node] = NULL;
+    h->top[node] = -1;
+    /* the first row of what is left */
+    h->max_level = -1;
+    h->entry = ORC_NONE;
+    for (uint32_t i = 0; i < h->n; i++)
+        if (h->top[i] > h->max_level) {
+            h->max_level = h->top[i];
+            h->entry = i;
+        }
+    return 1;
+}
+uint64_t orc_hnsw_dangling_links(const orc_hnsw *h) {
+    uint64_t c = 0;
+    for (uint32_t i = 0; i < h->n; i++)
+        for (int l = 0; l <= h->top[i]; l++) {
+            const adj_t *a = &h->adj[i][l];
+            for (int k = 0; k < a->n; k++) c += h->top[a->v[k].to] < l;
+        }
+    return c;
+}
+/* stored degree of a node's self row at a level (NaN when the node has no row there) */
+double orc_hnsw_degree(const orc_hnsw *h, uint32_t node, int level) {
+    if (node >= h->n || h->top[node] < level) return NAN;
+    return h->adj[node][level].degree;
+}
 uint32_t orc_hnsw_size(const orc_hnsw *h) { return h->n; }
 int orc_hnsw_n_levels(const orc_hnsw *h) { return h->max_level + 1; }
 uint32_t orc_hnsw_entry(const orc_hnsw *h) { return h->entry; }
@@ -522,7 +584,7 @@ void orc_hnsw_export_level(const orc_hnsw *h, int level, uint32_t *node_ids, uin
         const adj_t *a = &h->adj[i][level];
         int c = 0;
         for (int k = 0; k < a->n; k++)
-            if (!a->v[k].ignore && c < w) tmp[c++] = a->v[k].to;
+            if (!a->v[k].ignore && c < w && h->top[a->v[k].to] >= level) tmp[c++] = a->v[k].to; /* (not a row left dangling by a removal) */
         for (int k = 0; k < w; k++) nbrs[(size_t)r * w + k] = k < c ? tmp[k] : ORC_NONE;
         r++;
     }

@@ -49,6 +49,11 @@ orc_hnsw *orc_hnsw_new(int dim, int metric, int m, int ef_construction, int exte
 void orc_hnsw_free(orc_hnsw *h);
 /* insert vectors id = n_existing .. n_existing+n-1 in order; levels[i] >= 0 is -layer of hnsw.rs:46-52 */
 int orc_hnsw_insert(orc_hnsw *h, const float *vectors, uint32_t n, const int32_t *levels);
+/* hnsw_remove_vec (hnsw.rs:754-868) for one node; 1 when it was indexed.  Rows the reference leaves pointing at the removed
+ * node are counted by orc_hnsw_dangling_links and skipped by the exports. */
+int orc_hnsw_remove(orc_hnsw *h, uint32_t node);
+uint64_t orc_hnsw_dangling_links(const orc_hnsw *h);
+double orc_hnsw_degree(const orc_hnsw *h, uint32_t node, int level);
 uint32_t orc_hnsw_size(const orc_hnsw *h);
 int orc_hnsw_n_levels(const orc_hnsw *h);
 uint32_t orc_hnsw_entry(const orc_hnsw *h);

@@ -90,6 +90,12 @@ def lib():
         L.orc_hnsw_dist_count.argtypes = [C.c_void_p]
         L.orc_hnsw_link_rows.restype = C.c_uint64
         L.orc_hnsw_link_rows.argtypes = [C.c_void_p, C.c_int]
+        L.orc_hnsw_remove.restype = C.c_int
+        L.orc_hnsw_remove.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_hnsw_dangling_links.restype = C.c_uint64
+        L.orc_hnsw_dangling_links.argtypes = [C.c_void_p]
+        L.orc_hnsw_degree.restype = C.c_double
+        L.orc_hnsw_degree.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
         L.orc_hnsw_knn.restype = C.c_int
         L.orc_hnsw_knn.argtypes = [C.POINTER(_FlatIndex), _f32p, C.c_int, C.c_int, C.c_int, C.c_double, _u32p, _f64p,
                                    _u64p]
@@ -230,6 +236,17 @@ class HnswBuilder:
 
     def link_rows(self, include_ignored=False):
         return lib().orc_hnsw_link_rows(self._h, int(include_ignored))
+
+    def remove(self, nodes):
+        """hnsw_remove_vec (hnsw.rs:754-868) for every listed node, in order; how many were indexed"""
+        return sum(lib().orc_hnsw_remove(self._h, int(v)) for v in nodes)
+
+    def dangling_links(self):
+        """rows the reference leaves pointing at removed nodes (a search following one fails in ensure_key, hnsw.rs:133)"""
+        return lib().orc_hnsw_dangling_links(self._h)
+
+    def degree(self, node, level):
+        return lib().orc_hnsw_degree(self._h, int(node), int(level))
 
     def export(self) -> FlatIndex:
         L = lib()

@@ -229,3 +229,46 @@ def test_write_back_of_insert_and_remove_is_a_delta(oracle, gpu_lib):
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])  # the same distances and counts (ids are renumbered by the scan)
     ix.close()
     back.close()
+
+
+@pytest.mark.gpu
+def test_remove_equals_the_restated_hnsw_remove(gpu_lib, oracle):
+    """cz_hnsw_remove against the oracle's restatement of hnsw_remove_vec (hnsw.rs:754-868) on the SAME index: after the same
+    removals the device holds exactly the reference's rows minus the ones the reference leaves dangling (rows of other nodes
+    that still name a removed node, which the reference can no longer follow: ensure_key fails on them, :133).  That is the
+    one deliberate difference, and the count of such rows is reported.  Node lists per level, link rows, entry point: equal."""
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest, HnswSearch
+    n, dim, m, efc = 3000, 32, 8, 40
+    x = util.vectors(n, dim, 41, "lowrank")
+    levels = oracle.random_levels(n, m, 11)
+    for dist, metric in (("L2", oracle.L2), ("Cosine", oracle.COSINE)):
+        b = oracle.HnswBuilder(dim, metric, m, efc, dot_mode=oracle.DOT_GPU)
+        b.insert(x, levels)
+        flat = b.export()
+        man = HnswIndexManifest(vec_dim=dim, distance=dist, m_neighbours=m, ef_construction=efc)
+        g = GpuHnswIndex(man, flat.vectors, [None] + flat.level_nodes[1:], flat.level_nbrs, flat.entry)
+        rng = np.random.default_rng(6)
+        dead = np.unique(np.concatenate([rng.choice(n, 400, replace=False), [flat.entry], flat.level_nodes[-1]])).astype(np.uint32)
+        g.remove(dead)
+        assert b.remove(dead.tolist()) == len(dead)
+        want = b.export()
+        nodes, nbrs, entry = g.export()
+        assert entry == want.entry and len(nbrs) == want.n_levels
+        alive0 = want.level_nodes[0]
+        for lv in range(want.n_levels):
+            if lv == 0:  # the device keeps a (now empty) level-0 row per removed id: ids are not renumbered
+                assert (nbrs[0][dead] == 0xFFFFFFFF).all()
+                got_rows = nbrs[0][alive0]
+            else:
+                assert np.array_equal(nodes[lv], want.level_nodes[lv])
+                got_rows = nbrs[lv]
+            w = want.level_nbrs[lv].shape[1]
+            assert (got_rows[:, w:] == 0xFFFFFFFF).all()
+            assert np.array_equal(got_rows[:, :w], want.level_nbrs[lv]), f"{dist}: level {lv} rows differ from hnsw_remove's"
+        print(f"{dist}: rows the reference leaves dangling after {len(dead)} removals: {b.dangling_links()}")
+        q = util.vectors(32, dim, 42, "lowrank")
+        ids, dd, cnt = g.hnsw_knn_batch(q, HnswSearch(k=10, ef=50))
+        oids, odd, ocnt, _ = want.knn_batch(q, 10, 50, dot_mode=oracle.DOT_GPU)
+        # (ids of the oracle's export are positions in ITS node list at level 0 == node ids, since ids are kept)
+        assert np.array_equal(ids, oids) and np.array_equal(dd, odd) and np.array_equal(cnt, ocnt)
+        g.close()

@@ -253,3 +253,43 @@ def test_label_propagation_fixed_order_is_a_fixpoint_of_the_reference_rule(oracl
             best = max(score.values())
             assert labels[v] == min(lab for lab, sc in score.items() if sc == best)
     assert len(np.unique(labels)) <= 40
+
+
+def test_hnsw_remove_restated(oracle):
+    """orc_hnsw_remove = hnsw_remove_vec (hnsw.rs:754-868): the node's rows go at every layer, so does the reverse row of every
+    node it linked to (live or soft-deleted), that neighbour's stored degree drops by one EVEN IF it held no live link back;
+    rows of other nodes that still name the removed one are left behind (counted; a reference search following one fails)."""
+    rng = np.random.default_rng(3)
+    x = rng.random((1500, 12), dtype=np.float32)
+    levels = oracle.random_levels(1500, 6, 4)
+    b = oracle.HnswBuilder(12, oracle.L2, 6, 30)
+    b.insert(x, levels)
+    before = b.export()
+    links_before = {(l, int(i), int(t)) for l in range(before.n_levels) for r, i in enumerate(before.level_nodes[l])
+                    for t in before.level_nbrs[l][r] if t != oracle.NONE}
+    deg_before = {(l, int(i)): b.degree(i, l) for l in range(before.n_levels) for i in before.level_nodes[l]}
+    dead = sorted({int(before.entry), 5, 17, 300, 301, 1499} | {int(i) for i in before.level_nodes[-1]})
+    assert b.remove(dead) == len(dead)
+    assert b.remove([5]) == 0  # no self row any more: nothing to do (:766-778 breaks at layer 0)
+    after = b.export()
+    alive_top = np.where(np.isin(np.arange(1500), dead), -1, levels)
+    assert after.n_levels == alive_top.max() + 1
+    assert after.entry == int(np.nonzero(alive_top == alive_top.max())[0][0])  # smallest key on the highest layer left
+    links_after = {(l, int(i), int(t)) for l in range(after.n_levels) for r, i in enumerate(after.level_nodes[l])
+                   for t in after.level_nbrs[l][r] if t != oracle.NONE}
+    ds = set(dead)
+    # the exports (dangling rows skipped) hold exactly the old live links between surviving nodes
+    assert links_after == {(l, i, t) for l, i, t in links_before if i not in ds and t not in ds and l < after.n_levels}
+    for l in range(after.n_levels):
+        assert set(after.level_nodes[l].tolist()) == set(np.nonzero(alive_top >= l)[0].tolist())
+    # degrees: one off per removed node the survivor was linked FROM (live or soft-deleted row of the removed node)
+    dropped = sum(deg_before[(l, i)] - b.degree(i, l) for (l, i) in deg_before if i not in ds and l < after.n_levels)
+    assert dropped >= len({(l, i, t) for l, i, t in links_before if t in ds and i not in ds and (l, t, i) in links_before})
+    assert b.dangling_links() >= 0
+    # the cleaned index still answers queries, and never with a removed node
+    q = rng.random((16, 12), dtype=np.float32)
+    ids, _, cnt, _ = after.knn_batch(q, 5, 30)
+    assert (cnt == 5).all() and not np.isin(ids, dead).any()
+    # inserting after a removal goes on from the cleaned graph
+    b.insert(rng.random((50, 12), dtype=np.float32), oracle.random_levels(50, 6, 9))
+    assert b.export().level_nodes[0].size == 1500 - len(dead) + 50
