@@ -248,6 +248,130 @@ bfs_emit_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ t
     }
 }
 
+// ---- one pass over the frontier's adjacency per level (round 3; the one-GPU rule) ---------------------------------------
+// The three passes above read every edge slot of the frontier three times.  With adjacency lists sorted ascending, the
+// reference's FIFO order of the next frontier is simply (position of the discoverer in the frontier, node id): so ONE pass
+// claims (atomicMin of the frontier position, as before) and lists every node the first time it is claimed; what follows
+// is frontier-sized, not edge-sized: count the listed nodes per claimer, prefix sums, place them, order each claimer's few
+// nodes by id.  A claimer with many new nodes (a hub early in the search) re-reads its own list instead, which is in order.
+__global__ void __launch_bounds__(kT)
+bfs_discover_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
+                    uint32_t fsize, const uint32_t *__restrict__ vis, uint32_t *__restrict__ claim,
+                    uint32_t *__restrict__ fresh, uint32_t *__restrict__ n_fresh) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t glane = threadIdx.x & (kBfsLanes - 1);
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kBfsLanes, ngroups = gridDim.x * blockDim.x / kBfsLanes;
+    const uint32_t rounds = (fsize + ngroups - 1) / ngroups;  // every group of a wave runs the same trip count (ballots)
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i = group + r * ngroups;
+        const bool live = i < fsize;
+        const uint32_t u = live ? frontier[i] : 0;
+        const uint32_t e0 = live ? off[u] : 0, e1 = live ? off[u + 1] : 0;
+        uint32_t maxlen = e1 - e0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, o, 64));
+        for (uint32_t b = 0; b < maxlen; b += kBfsLanes) {
+            const uint32_t e = e0 + b + glane;
+            bool first = false;
+            uint32_t v = 0;
+            if (e < e1) {
+                v = tgt[e];
+                if (!((vis[v >> 5] >> (v & 31)) & 1u)) first = atomicMin(&claim[v], i) == CZ_NONE;  // nobody had claimed v yet
+            }
+            const unsigned long long m = __ballot(first);
+            if (m) {  // one counter update per wave instruction
+                uint32_t base = 0;
+                if (lane == __ffsll((long long)m) - 1) base = atomicAdd(n_fresh, (uint32_t)__popcll(m));
+                base = __shfl((int)base, __ffsll((long long)m) - 1, 64);
+                if (first) fresh[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kT)
+bfs_tally_kernel(const uint32_t *__restrict__ fresh, const uint32_t *__restrict__ n_fresh, const uint32_t *__restrict__ claim,
+                 uint32_t *__restrict__ cnt) {
+    const uint32_t n = *n_fresh;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) atomicAdd(&cnt[claim[fresh[k]]], 1u);
+}
+
+// places every new node in its claimer's stretch of the next frontier (any order inside the stretch) and marks it found
+__global__ void __launch_bounds__(kT)
+bfs_place_kernel(const uint32_t *__restrict__ fresh, const uint32_t *__restrict__ n_fresh, const uint32_t *__restrict__ claim,
+                 const uint32_t *__restrict__ frontier, const uint32_t *__restrict__ pos, uint32_t *__restrict__ cnt,
+                 uint32_t *__restrict__ next, uint32_t *__restrict__ parent, uint32_t *__restrict__ depth,
+                 uint32_t *__restrict__ vis, uint32_t next_depth) {
+    const uint32_t n = *n_fresh;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t v = fresh[k], i = claim[v];
+        next[pos[i] + atomicSub(&cnt[i], 1u) - 1u] = v;
+        parent[v] = frontier[i];
+        depth[v] = next_depth;
+        atomicOr(&vis[v >> 5], 1u << (v & 31));
+    }
+}
+
+// every claimer's stretch ascending by node id = the order of its (sorted) adjacency list.  Short stretches: one thread,
+// insertion sort; long ones are listed for bfs_order_big_kernel.
+constexpr uint32_t kBfsSmallGroup = 24;
+__global__ void __launch_bounds__(kT)
+bfs_order_small_kernel(const uint32_t *__restrict__ pos, uint32_t fsize, const uint32_t *__restrict__ total,
+                       uint32_t *__restrict__ next, uint32_t *__restrict__ big, uint32_t *__restrict__ n_big) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < fsize; i += gridDim.x * blockDim.x) {
+        const uint32_t a = pos[i], z = i + 1 < fsize ? pos[i + 1] : *total;
+        const uint32_t len = z - a;
+        if (len < 2) continue;
+        if (len > kBfsSmallGroup) {
+            big[atomicAdd(n_big, 1u)] = i;
+            continue;
+        }
+        uint32_t x[kBfsSmallGroup];
+#pragma unroll
+        for (uint32_t k = 0; k < kBfsSmallGroup; k++) x[k] = k < len ? next[a + k] : CZ_NONE;
+#pragma unroll
+        for (uint32_t k = 1; k < kBfsSmallGroup; k++) {  // a fixed network over registers (padding sorts last)
+#pragma unroll
+            for (uint32_t j = k; j > 0; j--) {
+                const uint32_t lo = min(x[j - 1], x[j]), hi = max(x[j - 1], x[j]);
+                x[j - 1] = lo;
+                x[j] = hi;
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kBfsSmallGroup; k++)
+            if (k < len) next[a + k] = x[k];
+    }
+}
+
+// a wave per long stretch: the claimer's adjacency list is walked again and its new nodes written in list order
+__global__ void __launch_bounds__(kT)
+bfs_order_big_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
+                     const uint32_t *__restrict__ pos, const uint32_t *__restrict__ big, const uint32_t *__restrict__ n_big,
+                     const uint32_t *__restrict__ claim, const uint32_t *__restrict__ depth, uint32_t next_depth,
+                     uint32_t *__restrict__ next) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = *n_big;
+    for (uint32_t k = wave; k < n; k += nwaves) {
+        const uint32_t i = big[k], u = frontier[i];
+        const uint32_t e0 = off[u], e1 = off[u + 1];
+        uint32_t o = pos[i];
+        for (uint32_t b = e0; b < e1; b += 64) {
+            const uint32_t e = b + lane;
+            bool hit = false;
+            uint32_t v = 0;
+            if (e < e1) {
+                v = tgt[e];
+                hit = (e == e0 || tgt[e - 1] != v) && claim[v] == i && depth[v] == next_depth;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (hit) next[o + __popcll(m & ((1ull << lane) - 1ull))] = v;
+            o += (uint32_t)__popcll(m);
+        }
+    }
+}
+
 __global__ void bfs_goals_left_kernel(const uint32_t *__restrict__ goals, uint32_t n_goals, uint32_t N,
                                       const uint32_t *__restrict__ depth, uint32_t start, uint32_t *__restrict__ left) {
     uint32_t c = 0;
@@ -757,11 +881,20 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
     const uint32_t N = G.N;
     const uint64_t E = G.E;
     int rc = CZ_OK;
-    cz::DevBuf<uint32_t> d_depth, d_parent, d_claim, d_order, d_cnt, d_pos, d_scratch, d_goals, d_misc, d_vis;
+    cz::DevBuf<uint32_t> d_depth, d_parent, d_claim, d_order, d_cnt, d_pos, d_scratch, d_goals, d_misc, d_vis, d_fresh, d_big;
     cz::DevBuf<uint8_t> d_won;
     const size_t vis_words = ((size_t)N + 31) / 32;
+    // CZ_BFS_PASSES=3: the round-2 level (claim / count / emit over the edge slots), kept for A/B runs and as what the
+    // vertex-partitioned loop (sharded_traversal.hpp) still runs
+    const char *pv = getenv("CZ_BFS_PASSES");
+    const bool one_pass = !(pv && atoi(pv) == 3);
     CZ_HIP(d_vis.alloc(vis_words));
-    CZ_HIP(d_won.alloc(E));
+    if (one_pass) {
+        CZ_HIP(d_fresh.alloc(N));
+        CZ_HIP(d_big.alloc(N));
+    } else {
+        CZ_HIP(d_won.alloc(E));
+    }
     CZ_HIP(d_depth.alloc(N));
     CZ_HIP(d_parent.alloc(N));
     CZ_HIP(d_claim.alloc(N));
@@ -805,6 +938,23 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
                 if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
                 const uint32_t *fr = d_order.p + lo;
                 const int g = grid_for((uint64_t)fsize * kBfsLanes);  // a 16-lane group per frontier node
+                if (one_pass) {
+                    // d_misc: [0] next frontier size (scan total), [1] goals left, [2] nodes listed, [3] long stretches
+                    CZ_HIP(hipMemsetAsync(d_misc.p + 2, 0, 8, s));
+                    CZ_HIP(hipMemsetAsync(d_cnt.p, 0, (size_t)fsize * 4, s));
+                    hipLaunchKernelGGL(bfs_discover_kernel, dim3(g), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, fsize, d_vis.p, d_claim.p,
+                                       d_fresh.p, d_misc.p + 2);
+                    const int gf = grid_for(std::min<uint64_t>(N, (uint64_t)fsize * 64));  // (the listed count stays on the device)
+                    hipLaunchKernelGGL(bfs_tally_kernel, dim3(gf), dim3(kT), 0, s, d_fresh.p, d_misc.p + 2, d_claim.p, d_cnt.p);
+                    rc = exclusive_scan(d_cnt.p, d_pos.p, fsize, d_misc.p, d_scratch.p, s);
+                    if (rc) return rc;
+                    hipLaunchKernelGGL(bfs_place_kernel, dim3(gf), dim3(kT), 0, s, d_fresh.p, d_misc.p + 2, d_claim.p, fr, d_pos.p, d_cnt.p,
+                                       d_order.p + lo + fsize, d_parent.p, d_depth.p, d_vis.p, level + 1);
+                    hipLaunchKernelGGL(bfs_order_small_kernel, dim3(grid_for(fsize)), dim3(kT), 0, s, d_pos.p, fsize, d_misc.p,
+                                       d_order.p + lo + fsize, d_big.p, d_misc.p + 3);
+                    hipLaunchKernelGGL(bfs_order_big_kernel, dim3(std::min(g, 1024)), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, d_pos.p, d_big.p,
+                                       d_misc.p + 3, d_claim.p, d_depth.p, level + 1, d_order.p + lo + fsize);
+                } else {
                 hipLaunchKernelGGL(bfs_claim_kernel, dim3(g), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, fsize, d_depth.p, d_vis.p, d_claim.p,
                                    0u, N);
                 hipLaunchKernelGGL(bfs_count_kernel, dim3(g), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, fsize, d_depth.p, d_vis.p, d_claim.p,
@@ -813,6 +963,7 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
                 if (rc) return rc;
                 hipLaunchKernelGGL(bfs_emit_kernel, dim3(g), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, fsize, d_depth.p, d_vis.p, d_claim.p,
                                    d_won.p, d_pos.p, d_order.p + lo + fsize, d_parent.p, level + 1, 0u, N, 0u);
+                }
                 CZ_HIP(hipMemsetAsync(d_misc.p + 1, 0, 4, s));
                 if (goals)
                     hipLaunchKernelGGL(bfs_goals_left_kernel, dim3(grid_for(n_goals)), dim3(kT), 0, s, d_goals.p, n_goals, N,
