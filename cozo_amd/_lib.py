@@ -82,6 +82,7 @@ SYMBOLS = {
     "cz_hnsw_insert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64,
                                  C.c_uint32, u64p, C.c_uint32, C.c_void_p]),
     "cz_hnsw_remove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "cz_hnsw_set_key_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "cz_hnsw_index_info": (C.c_int, [C.c_void_p, u32p, u32p, i32p, i32p, u32p]),
     "cz_hnsw_index_level_info": (C.c_int, [C.c_void_p, C.c_int32, u32p, i32p]),
     "cz_hnsw_index_export_level": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),

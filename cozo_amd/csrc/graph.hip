@@ -254,14 +254,21 @@ bfs_emit_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ t
 // claims (atomicMin of the frontier position, as before) and lists every node the first time it is claimed; what follows
 // is frontier-sized, not edge-sized: count the listed nodes per claimer, prefix sums, place them, order each claimer's few
 // nodes by id.  A claimer with many new nodes (a hub early in the search) re-reads its own list instead, which is in order.
+// The list of new nodes is written in chunks of kBfsChunk slots that a WAVE reserves for itself: one atomic on the shared
+// counter per chunk, not per wave instruction -- a single word takes ~88 M atomics a second (MI355X_MICROARCH.md), and at
+// the widest level of the 10M / 100M graph a million appending instructions made this pass 10 ms.  Slots a wave leaves
+// unused (the end of a chunk it could not fit a batch into, the end of its last chunk) hold CZ_NONE and are skipped by
+// the passes that read the list; `*n_slots` is the number of slots handed out.
+constexpr uint32_t kBfsChunk = 256;
 __global__ void __launch_bounds__(kT)
 bfs_discover_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
                     uint32_t fsize, const uint32_t *__restrict__ vis, uint32_t *__restrict__ claim,
-                    uint32_t *__restrict__ fresh, uint32_t *__restrict__ n_fresh) {
+                    uint32_t *__restrict__ fresh, uint32_t *__restrict__ n_slots) {
     const int lane = threadIdx.x & 63;
     const uint32_t glane = threadIdx.x & (kBfsLanes - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kBfsLanes, ngroups = gridDim.x * blockDim.x / kBfsLanes;
     const uint32_t rounds = (fsize + ngroups - 1) / ngroups;  // every group of a wave runs the same trip count (ballots)
+    uint32_t w_base = 0, w_used = kBfsChunk;  // this wave's chunk (uniform): none yet
     for (uint32_t r = 0; r < rounds; r++) {
         const uint32_t i = group + r * ngroups;
         const bool live = i < fsize;
@@ -279,21 +286,33 @@ bfs_discover_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict
                 if (!((vis[v >> 5] >> (v & 31)) & 1u)) first = atomicMin(&claim[v], i) == CZ_NONE;  // nobody had claimed v yet
             }
             const unsigned long long m = __ballot(first);
-            if (m) {  // one counter update per wave instruction
-                uint32_t base = 0;
-                if (lane == __ffsll((long long)m) - 1) base = atomicAdd(n_fresh, (uint32_t)__popcll(m));
-                base = __shfl((int)base, __ffsll((long long)m) - 1, 64);
-                if (first) fresh[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
+            if (m) {
+                const uint32_t cnt = (uint32_t)__popcll(m);
+                if (w_used + cnt > kBfsChunk) {  // uniform over the wave: close the chunk, take the next
+                    if (w_used < kBfsChunk)
+                        for (uint32_t k = w_used + lane; k < kBfsChunk; k += 64) fresh[w_base + k] = CZ_NONE;
+                    uint32_t nb = 0;
+                    if (lane == 0) nb = atomicAdd(n_slots, kBfsChunk);
+                    w_base = __builtin_amdgcn_readfirstlane(nb);
+                    w_used = 0;
+                }
+                if (first) fresh[w_base + w_used + __popcll(m & ((1ull << lane) - 1ull))] = v;
+                w_used += cnt;
             }
         }
     }
+    if (w_used < kBfsChunk)  // (a wave that never listed a node holds no chunk: w_used == kBfsChunk)
+        for (uint32_t k = w_used + lane; k < kBfsChunk; k += 64) fresh[w_base + k] = CZ_NONE;
 }
 
 __global__ void __launch_bounds__(kT)
-bfs_tally_kernel(const uint32_t *__restrict__ fresh, const uint32_t *__restrict__ n_fresh, const uint32_t *__restrict__ claim,
+bfs_tally_kernel(const uint32_t *__restrict__ fresh, const uint32_t *__restrict__ n_slots, const uint32_t *__restrict__ claim,
                  uint32_t *__restrict__ cnt) {
-    const uint32_t n = *n_fresh;
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) atomicAdd(&cnt[claim[fresh[k]]], 1u);
+    const uint32_t n = *n_slots;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t v = fresh[k];
+        if (v != CZ_NONE) atomicAdd(&cnt[claim[v]], 1u);
+    }
 }
 
 // places every new node in its claimer's stretch of the next frontier (any order inside the stretch) and marks it found
@@ -304,7 +323,9 @@ bfs_place_kernel(const uint32_t *__restrict__ fresh, const uint32_t *__restrict_
                  uint32_t *__restrict__ vis, uint32_t next_depth) {
     const uint32_t n = *n_fresh;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        const uint32_t v = fresh[k], i = claim[v];
+        const uint32_t v = fresh[k];
+        if (v == CZ_NONE) continue;  // a slot its wave did not use
+        const uint32_t i = claim[v];
         next[pos[i] + atomicSub(&cnt[i], 1u) - 1u] = v;
         parent[v] = frontier[i];
         depth[v] = next_depth;
@@ -890,7 +911,9 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
     const bool one_pass = !(pv && atoi(pv) == 3);
     CZ_HIP(d_vis.alloc(vis_words));
     if (one_pass) {
-        CZ_HIP(d_fresh.alloc(N));
+        // every chunk but a wave's last is closed with fewer than 64 of its 256 slots unused; grid_for caps a launch at
+        // 4096 workgroups of 4 waves
+        CZ_HIP(d_fresh.alloc(((size_t)N / (kBfsChunk - 63) + 4096 * (kT / 64) + 2) * kBfsChunk));
         CZ_HIP(d_big.alloc(N));
     } else {
         CZ_HIP(d_won.alloc(E));
@@ -944,7 +967,7 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
                     CZ_HIP(hipMemsetAsync(d_cnt.p, 0, (size_t)fsize * 4, s));
                     hipLaunchKernelGGL(bfs_discover_kernel, dim3(g), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, fsize, d_vis.p, d_claim.p,
                                        d_fresh.p, d_misc.p + 2);
-                    const int gf = grid_for(std::min<uint64_t>(N, (uint64_t)fsize * 64));  // (the listed count stays on the device)
+                    const int gf = grid_for(std::min<uint64_t>((uint64_t)N + N / 2, (uint64_t)fsize * 64 + 4096));  // (the slot count stays on the device)
                     hipLaunchKernelGGL(bfs_tally_kernel, dim3(gf), dim3(kT), 0, s, d_fresh.p, d_misc.p + 2, d_claim.p, d_cnt.p);
                     rc = exclusive_scan(d_cnt.p, d_pos.p, fsize, d_misc.p, d_scratch.p, s);
                     if (rc) return rc;

@@ -560,6 +560,9 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
         if (ix->top[i] > top) {
             top = ix->top[i];
             entry = i;
+        } else {  // a row on the top layer whose KEY sorts before the entry point's becomes the first row of the index
+            for (uint32_t k = i; k < i + bn; k++)
+                if (ix->top[k] == top && ix->key_before(k, entry)) entry = k;
         }
         i += bn;
     }
@@ -717,6 +720,18 @@ extern "C" int cz_hnsw_insert(cz_hnsw_index *h, const float *vectors, uint32_t n
                       (hipStream_t)stream_);
 }
 
+extern "C" int cz_hnsw_set_key_order(cz_hnsw_index *h, const uint32_t *rank, uint32_t n) {
+    if (!h) return cz::set_error(CZ_E_INVALID, "null index");
+    cz::HnswIndex *ix = (cz::HnswIndex *)h;
+    if (!rank || n == 0) {
+        ix->key_rank.clear();
+        return CZ_OK;
+    }
+    if (n < ix->n) return cz::set_error(CZ_E_INVALID, "key order for %u nodes, the index holds %u", n, ix->n);
+    ix->key_rank.assign(rank, rank + n);
+    return CZ_OK;
+}
+
 extern "C" int cz_hnsw_remove(cz_hnsw_index *h, const uint32_t *nodes, uint32_t n_nodes) {
     if (!h) return cz::set_error(CZ_E_INVALID, "null index");
     int rc = cz::ensure_device();
@@ -756,7 +771,7 @@ extern "C" int cz_hnsw_remove(cz_hnsw_index *h, const uint32_t *nodes, uint32_t 
     int top = -1;
     uint32_t entry = CZ_NONE;
     for (uint32_t i = 0; i < ix->n; i++)
-        if (ix->top[i] > top) {
+        if (ix->top[i] > top || (ix->top[i] == top && top >= 0 && ix->key_before(i, entry))) {
             top = ix->top[i];
             entry = i;
         }

@@ -34,6 +34,14 @@ struct HnswIndex {
     uint32_t *up_nbrs = nullptr;
     std::vector<int32_t> top;         // host copy: top level of every node (-1: removed, cz_hnsw_remove)
     std::vector<int32_t> layout_top;  // the same when the upper-level rows were last laid out (row numbering)
+    // Position of every node's KEY among all keys (cz_hnsw_set_key_order); empty = node ids are in key order, which is what
+    // an index read from the store or built over rows in key order has.  The reference's entry point is positional -- the
+    // first row of the index relation = the smallest KEY on the top layer (hnsw.rs:184-191, 891-899) -- so rows inserted
+    // later with keys that sort before existing ones need their rank, not their id, to be compared.
+    std::vector<uint32_t> key_rank;
+    bool key_before(uint32_t a, uint32_t b) const {
+        return key_rank.empty() ? a < b : (key_rank[a] != key_rank[b] ? key_rank[a] < key_rank[b] : a < b);
+    }
 
     // per-call scratch (the visited sets of a batch: hash tables + overflow bitmaps, hnsw_kernels.cuh VisitedDev):
     // cached, handed out under a mutex, stream-ordered by an event.  Invariant while pooled: every word of `tab` is

@@ -108,12 +108,27 @@ class GpuHnswIndex:
         self.last_build_n_dist = nd.value
         return self
 
-    def insert(self, vectors, levels: Optional[np.ndarray] = None, seed: int = 0, max_batch: int = 0):
+    def set_key_order(self, key_rank):
+        """key_rank[node] = position of the node's (row key, field, sub-index) among all of them, for the nodes held and the
+        ones the next insert adds (cz_hnsw_set_key_order); None = ids are in key order.  The reference's entry point is
+        the smallest KEY on the top layer (hnsw.rs:184-191, 891-899), which insert / remove then reproduce."""
+        if key_rank is None:
+            check(_lib.lib().cz_hnsw_set_key_order(self._h, None, 0))
+            return
+        r = np.ascontiguousarray(key_rank, dtype=np.uint32)
+        check(_lib.lib().cz_hnsw_set_key_order(self._h, ptr(r), r.size))
+
+    def insert(self, vectors, levels: Optional[np.ndarray] = None, seed: int = 0, max_batch: int = 0, key_rank=None):
         """hnsw_put for more rows on a later write (stored.rs:431-450 -> hnsw.rs:679-727): the vectors become nodes
-        n .. n + len - 1 of this index (cz_hnsw_insert)."""
+        n .. n + len - 1 of this index (cz_hnsw_insert).  key_rank: see set_key_order -- needed when the new rows' keys do
+        not all sort behind the existing ones."""
         v = np.ascontiguousarray(vectors, dtype=np.float32)
         if v.ndim != 2 or v.shape[1] != self.manifest.vec_dim:
             raise ValueError("vectors must be [n][vec_dim]")
+        if key_rank is not None:
+            if len(key_rank) != self.n + v.shape[0]:
+                raise ValueError("key_rank must cover the nodes held and the ones inserted")
+            self.set_key_order(key_rank)
         lv = None if levels is None else np.ascontiguousarray(levels, dtype=np.int32)
         nd = C.c_uint64(0)
         man = self.manifest

@@ -136,9 +136,29 @@ void GpuHnswIndex::put_rows(uint32_t first_row, uint64_t seed, uint32_t max_batc
         rc = cz_hnsw_build(flat.data(), (uint32_t)n_new, (uint32_t)manifest_.vec_dim, (int)manifest_.distance, (uint32_t)manifest_.m_neighbours,
                            (uint32_t)manifest_.ef_construction, manifest_.keep_pruned_connections ? 1 : 0, levels ? levels->data() : nullptr,
                            seed, max_batch, &nd, &h_, 0, nullptr);
-    else
-        rc = cz_hnsw_insert(h_, flat.data(), (uint32_t)n_new, (uint32_t)manifest_.m_neighbours, (uint32_t)manifest_.ef_construction,
-                            manifest_.keep_pruned_connections ? 1 : 0, levels ? levels->data() : nullptr, seed, max_batch, &nd, 0, nullptr);
+    else {
+        // Node ids follow insertion order, the reference's entry point follows KEY order (the first row of the index relation,
+        // hnsw.rs:184-191, 891-899): hand the library every node's position among the (row key, field, sub-index) triples so
+        // that a later row whose key sorts before the entry point's takes its place exactly as in the reference.
+        const size_t K = base_->keys.size();
+        std::vector<uint32_t> by_key(nodes_.size());
+        for (uint32_t i = 0; i < by_key.size(); i++) by_key[i] = i;
+        std::stable_sort(by_key.begin(), by_key.end(), [&](uint32_t a, uint32_t b) {
+            const Tuple &ta = base_->rows[nodes_[a].row], &tb = base_->rows[nodes_[b].row];
+            for (size_t c = 0; c < K; c++) {
+                const int cmp = DataValue::compare(ta[c], tb[c]);
+                if (cmp) return cmp < 0;
+            }
+            if (nodes_[a].field != nodes_[b].field) return nodes_[a].field < nodes_[b].field;
+            return nodes_[a].sub < nodes_[b].sub;
+        });
+        std::vector<uint32_t> rank(nodes_.size());
+        for (uint32_t pos = 0; pos < by_key.size(); pos++) rank[by_key[pos]] = pos;
+        rc = cz_hnsw_set_key_order(h_, rank.data(), (uint32_t)rank.size());
+        if (rc == CZ_OK)
+            rc = cz_hnsw_insert(h_, flat.data(), (uint32_t)n_new, (uint32_t)manifest_.m_neighbours, (uint32_t)manifest_.ef_construction,
+                                manifest_.keep_pruned_connections ? 1 : 0, levels ? levels->data() : nullptr, seed, max_batch, &nd, 0, nullptr);
+    }
     if (rc != CZ_OK) nodes_.resize(n_before);
     check_gpu(rc);
     build_n_dist_ += nd;

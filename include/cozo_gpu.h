@@ -126,6 +126,12 @@ int cz_hnsw_insert(cz_hnsw_index *ix, const float *vectors /* [n_new][dim], dev-
                    uint32_t ef_construction, int keep_pruned_connections, const int32_t *levels, uint64_t seed,
                    uint32_t max_batch, uint64_t *n_dist, uint32_t flags, void *stream);
 int cz_hnsw_remove(cz_hnsw_index *ix, const uint32_t *nodes, uint32_t n_nodes);
+/* The reference's entry point is POSITIONAL: the first row of the index relation, i.e. the smallest KEY on the top layer
+ * (hnsw.rs:184-191, 891-899).  Node ids follow key order when the index was read from the store or built over rows in key
+ * order; rows inserted later get ids n, n+1, ... whatever their keys are.  rank[node] = the position of the node's
+ * (row key, field, sub-index) among all of them, for the nodes the index holds AND the ones the next cz_hnsw_insert adds
+ * (n >= both); cz_hnsw_insert and cz_hnsw_remove then choose the entry point by rank.  rank = NULL: ids are key order. */
+int cz_hnsw_set_key_order(cz_hnsw_index *ix, const uint32_t *rank, uint32_t n);
 
 /* flat export of a device-resident index (the inverse of cz_hnsw_index_create; host buffers) */
 int cz_hnsw_index_info(const cz_hnsw_index *ix, uint32_t *n, uint32_t *dim, int32_t *metric, int32_t *n_levels,

@@ -143,6 +143,7 @@ extern "C" {
                           keep_pruned_connections: c_int, levels: *const i32, seed: u64, max_batch: u32, n_dist: *mut u64,
                           flags: u32, stream: *mut c_void) -> c_int;
     pub fn cz_hnsw_remove(ix: *mut cz_hnsw_index, nodes: *const u32, n_nodes: u32) -> c_int;
+    pub fn cz_hnsw_set_key_order(ix: *mut cz_hnsw_index, rank: *const u32, n: u32) -> c_int;
     pub fn cz_column_upload(values: *const c_void, n: u32, ty: i32, out: *mut *mut cz_column) -> c_int;
     pub fn cz_column_destroy(c: *mut cz_column);
     pub fn cz_hnsw_search_filtered(ix: *mut cz_hnsw_index, queries: *const c_float, b: u32, k: u32, ef: u32, has_radius: c_int,

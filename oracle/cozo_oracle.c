@@ -281,7 +281,14 @@ struct orc_hnsw {
     uint32_t *stamp;
     uint32_t epoch;
     uint64_t n_dist;
+    uint32_t *key_rank; /* position of every node's key among all keys; NULL = ids are key order (orc_hnsw_set_key_order) */
+    uint32_t n_rank;
 };
+/* the index relation is scanned in KEY order: its first row -- the entry point -- is the smallest key on the top layer */
+static int key_before(const orc_hnsw *h, uint32_t a, uint32_t b) {
+    if (!h->key_rank || a >= h->n_rank || b >= h->n_rank || h->key_rank[a] == h->key_rank[b]) return a < b;
+    return h->key_rank[a] < h->key_rank[b];
+}
 
 orc_hnsw *orc_hnsw_new(int dim, int metric, int m, int ef_construction, int extend_candidates,
                        int keep_pruned_connections, int dot_mode) {
@@ -309,7 +316,18 @@ void orc_hnsw_free(orc_hnsw *h) {
     free(h->top);
     free(h->vecs);
     free(h->stamp);
+    free(h->key_rank);
     free(h);
+}
+void orc_hnsw_set_key_order(orc_hnsw *h, const uint32_t *rank, uint32_t n) {
+    free(h->key_rank);
+    h->key_rank = NULL;
+    h->n_rank = 0;
+    if (rank && n) {
+        h->key_rank = (uint32_t *)malloc(sizeof(uint32_t) * n);
+        memcpy(h->key_rank, rank, sizeof(uint32_t) * n);
+        h->n_rank = n;
+    }
 }
 static void adj_upsert(adj_t *a, uint32_t to, double dist, uint8_t ignore) { /* store_tx.put of a link row */
     int lo = 0, hi = a->n;
@@ -479,6 +497,8 @@ static void put_vector(orc_hnsw *h, uint32_t id, int target_lv /* = -target_leve
     if (target_lv > h->max_level) { /* :206-218 the new vector becomes the entry point */
         h->max_level = target_lv;
         h->entry = id;
+    } else if (target_lv == h->max_level && key_before(h, id, h->entry)) {
+        h->entry = id; /* :184-191: a row on the top layer with a smaller key is now the first row of the index */
     }
 }
 
@@ -545,7 +565,7 @@ int orc_hnsw_remove(orc_hnsw *h, uint32_t node) {
     h->max_level = -1;
     h->entry = ORC_NONE;
     for (uint32_t i = 0; i < h->n; i++)
-        if (h->top[i] > h->max_level) {
+        if (h->top[i] > h->max_level || (h->top[i] >= 0 && h->top[i] == h->max_level && key_before(h, i, h->entry))) {
             h->max_level = h->top[i];
             h->entry = i;
         }

@@ -52,6 +52,9 @@ int orc_hnsw_insert(orc_hnsw *h, const float *vectors, uint32_t n, const int32_t
 /* hnsw_remove_vec (hnsw.rs:754-868) for one node; 1 when it was indexed.  Rows the reference leaves pointing at the removed
  * node are counted by orc_hnsw_dangling_links and skipped by the exports. */
 int orc_hnsw_remove(orc_hnsw *h, uint32_t node);
+/* rank[node] = position of the node's key among all keys (nodes held and to come); NULL = ids are key order.  The entry point
+ * is the smallest KEY on the top layer (hnsw.rs:184-191, 891-899). */
+void orc_hnsw_set_key_order(orc_hnsw *h, const uint32_t *rank, uint32_t n);
 uint64_t orc_hnsw_dangling_links(const orc_hnsw *h);
 double orc_hnsw_degree(const orc_hnsw *h, uint32_t node, int level);
 uint32_t orc_hnsw_size(const orc_hnsw *h);

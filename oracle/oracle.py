@@ -90,6 +90,8 @@ def lib():
         L.orc_hnsw_dist_count.argtypes = [C.c_void_p]
         L.orc_hnsw_link_rows.restype = C.c_uint64
         L.orc_hnsw_link_rows.argtypes = [C.c_void_p, C.c_int]
+        L.orc_hnsw_set_key_order.restype = None
+        L.orc_hnsw_set_key_order.argtypes = [C.c_void_p, _u32p, C.c_uint32]
         L.orc_hnsw_remove.restype = C.c_int
         L.orc_hnsw_remove.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_hnsw_dangling_links.restype = C.c_uint64
@@ -236,6 +238,14 @@ class HnswBuilder:
 
     def link_rows(self, include_ignored=False):
         return lib().orc_hnsw_link_rows(self._h, int(include_ignored))
+
+    def set_key_order(self, key_rank):
+        """key_rank[node] = position of the node's key among all keys (held and to come); None: ids are key order"""
+        if key_rank is None:
+            lib().orc_hnsw_set_key_order(self._h, None, 0)
+        else:
+            r = _u32(key_rank)
+            lib().orc_hnsw_set_key_order(self._h, _p(r, _u32p), r.size)
 
     def remove(self, nodes):
         """hnsw_remove_vec (hnsw.rs:754-868) for every listed node, in order; how many were indexed"""

@@ -1008,7 +1008,7 @@ static void gpu_hnsw_search_ra() {
         // `v == 0` for none, exactly as if the filter were absent / always false
         HnswSearchRA plain{&ix, HnswSearch{}, 1};
         plain.hnsw_search = host_ra.hnsw_search;
-        plain.hnsw_search.filter = nullptr;
+        plain.hnsw_search.filter.reset();
         dev_ra.hnsw_search.predicates = {ColumnPredicate{1, CZ_OP_NE, DataValue((int64_t)0)}};
         CHECK(dev_ra.iter(parent, Poison()) == plain.iter(parent, Poison()));
         dev_ra.hnsw_search.predicates = {ColumnPredicate{1, CZ_OP_EQ, DataValue((int64_t)0)}};

@@ -272,3 +272,51 @@ def test_remove_equals_the_restated_hnsw_remove(gpu_lib, oracle):
         # (ids of the oracle's export are positions in ITS node list at level 0 == node ids, since ids are kept)
         assert np.array_equal(ids, oids) and np.array_equal(dd, odd) and np.array_equal(cnt, ocnt)
         g.close()
+
+
+@pytest.mark.gpu
+def test_entry_point_is_the_smallest_key_on_the_top_layer(gpu_lib, oracle):
+    """The reference's entry point is positional: the first row of the index relation = the smallest KEY on the top layer
+    (hnsw.rs:184-191, 891-899).  Rows inserted later get node ids n, n+1, ... whatever their keys are, so insert / remove
+    compare key ranks (cz_hnsw_set_key_order), not ids: a later row on the top layer whose key sorts first becomes the entry
+    point, for the inserts after it and for every search -- as in the oracle's restatement, table for table."""
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest, HnswSearch
+    n0, n1, dim, m, efc = 1500, 400, 24, 8, 40
+    x = util.vectors(n0 + n1, dim, 51, "lowrank")
+    levels = oracle.random_levels(n0 + n1, m, 13)
+    top0 = int(levels[:n0].max())
+    levels[n0:] = np.minimum(levels[n0:], top0)
+    levels[n0 + 5] = top0   # two later rows on the top layer: one with the smallest key of all, one with a large key
+    levels[n0 + 9] = top0
+    rng = np.random.default_rng(14)
+    keys = np.concatenate([1000 + 2 * np.arange(n0), rng.permutation(np.arange(1001, 1001 + 2 * n1, 2))])
+    keys[n0 + 5] = 3        # sorts before everything
+    keys[n0 + 9] = 10 ** 6  # sorts behind everything
+    assert len(set(keys.tolist())) == n0 + n1
+    rank = np.argsort(np.argsort(keys)).astype(np.uint32)
+    man = HnswIndexManifest(vec_dim=dim, distance="L2", m_neighbours=m, ef_construction=efc)
+    b = oracle.HnswBuilder(dim, oracle.L2, m, efc, dot_mode=oracle.DOT_GPU)
+    b.insert(x[:n0], levels[:n0])
+    entry_before = b.export().entry
+    b.set_key_order(rank)
+    b.insert(x[n0:], levels[n0:])
+    want = b.export()
+    assert want.entry == n0 + 5 != entry_before
+    g = GpuHnswIndex.build(man, x[:n0], levels=levels[:n0], max_batch=1)
+    g.insert(x[n0:], levels=levels[n0:], max_batch=1, key_rank=rank)
+    nodes, nbrs, entry = g.export()
+    assert entry == want.entry
+    for lv in range(want.n_levels):
+        assert np.array_equal(nodes[lv], want.level_nodes[lv])
+        assert np.array_equal(nbrs[lv][:, :want.level_nbrs[lv].shape[1]], want.level_nbrs[lv]), f"level {lv}"
+    q = util.vectors(16, dim, 52, "lowrank")
+    ids, dd, cnt = g.hnsw_knn_batch(q, HnswSearch(k=5, ef=30))
+    oids, odd, ocnt, _ = want.knn_batch(q, 5, 30, dot_mode=oracle.DOT_GPU)
+    assert np.array_equal(ids, oids) and np.array_equal(dd, odd)
+    # removing the entry point: the next smallest key on the top layer takes over, on both sides
+    g.remove([entry])
+    b.remove([entry])
+    top_nodes = [int(v) for v in np.nonzero(levels == top0)[0] if v != entry]
+    expect = min(top_nodes, key=lambda v: rank[v])
+    assert g.export()[2] == b.export().entry == expect
+    g.close()
