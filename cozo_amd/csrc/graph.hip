@@ -260,6 +260,7 @@ bfs_emit_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ t
 // unused (the end of a chunk it could not fit a batch into, the end of its last chunk) hold CZ_NONE and are skipped by
 // the passes that read the list; `*n_slots` is the number of slots handed out.
 constexpr uint32_t kBfsChunk = 256;
+constexpr int kBfsNodes = 4;  // frontier nodes a lane group works on at once
 __global__ void __launch_bounds__(kT)
 bfs_discover_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
                     uint32_t fsize, const uint32_t *__restrict__ vis, uint32_t *__restrict__ claim,
@@ -269,35 +270,63 @@ bfs_discover_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kBfsLanes, ngroups = gridDim.x * blockDim.x / kBfsLanes;
     const uint32_t rounds = (fsize + ngroups - 1) / ngroups;  // every group of a wave runs the same trip count (ballots)
     uint32_t w_base = 0, w_used = kBfsChunk;  // this wave's chunk (uniform): none yet
-    for (uint32_t r = 0; r < rounds; r++) {
-        const uint32_t i = group + r * ngroups;
-        const bool live = i < fsize;
-        const uint32_t u = live ? frontier[i] : 0;
-        const uint32_t e0 = live ? off[u] : 0, e1 = live ? off[u + 1] : 0;
-        uint32_t maxlen = e1 - e0;
+    // lists the nodes of `first` lanes (wave-wide) in the wave's chunk
+    auto append = [&](bool first, uint32_t v) {
+        const unsigned long long m = __ballot(first);
+        if (!m) return;
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        if (w_used + cnt > kBfsChunk) {  // uniform over the wave: close the chunk, take the next
+            if (w_used < kBfsChunk)
+                for (uint32_t k = w_used + lane; k < kBfsChunk; k += 64) fresh[w_base + k] = CZ_NONE;
+            uint32_t nb = 0;
+            if (lane == 0) nb = atomicAdd(n_slots, kBfsChunk);
+            w_base = __builtin_amdgcn_readfirstlane(nb);
+            w_used = 0;
+        }
+        if (first) fresh[w_base + w_used + __popcll(m & ((1ull << lane) - 1ull))] = v;
+        w_used += cnt;
+    };
+    auto claim_first = [&](uint32_t v, uint32_t i) {  // nobody had claimed v yet?
+        return !((vis[v >> 5] >> (v & 31)) & 1u) && atomicMin(&claim[v], i) == CZ_NONE;
+    };
+    // A level is a chain of dependent reads per frontier node (frontier -> offsets -> targets -> visited bit -> claim): one
+    // node at a time per lane group leaves the wave waiting on each link of the chain.  kBfsNodes nodes go down the chain
+    // together; the first 16 targets of each (all of them, for most nodes of a sparse graph) are handled in that form,
+    // longer lists finish in the loop below.
+    for (uint32_t r = 0; r < rounds; r += kBfsNodes) {
+        uint32_t i[kBfsNodes], e0[kBfsNodes], e1[kBfsNodes], v[kBfsNodes];
+        bool first[kBfsNodes];
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, o, 64));
-        for (uint32_t b = 0; b < maxlen; b += kBfsLanes) {
-            const uint32_t e = e0 + b + glane;
-            bool first = false;
-            uint32_t v = 0;
-            if (e < e1) {
-                v = tgt[e];
-                if (!((vis[v >> 5] >> (v & 31)) & 1u)) first = atomicMin(&claim[v], i) == CZ_NONE;  // nobody had claimed v yet
-            }
-            const unsigned long long m = __ballot(first);
-            if (m) {
-                const uint32_t cnt = (uint32_t)__popcll(m);
-                if (w_used + cnt > kBfsChunk) {  // uniform over the wave: close the chunk, take the next
-                    if (w_used < kBfsChunk)
-                        for (uint32_t k = w_used + lane; k < kBfsChunk; k += 64) fresh[w_base + k] = CZ_NONE;
-                    uint32_t nb = 0;
-                    if (lane == 0) nb = atomicAdd(n_slots, kBfsChunk);
-                    w_base = __builtin_amdgcn_readfirstlane(nb);
-                    w_used = 0;
+        for (int k = 0; k < kBfsNodes; k++) {
+            i[k] = group + (r + k) * ngroups;
+            e0[k] = (r + k < rounds && i[k] < fsize) ? frontier[i[k]] : CZ_NONE;  // (the node, for now)
+        }
+#pragma unroll
+        for (int k = 0; k < kBfsNodes; k++) {
+            const uint32_t u = e0[k];
+            e0[k] = u != CZ_NONE ? off[u] : 0;
+            e1[k] = u != CZ_NONE ? off[u + 1] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < kBfsNodes; k++) v[k] = e0[k] + glane < e1[k] ? tgt[e0[k] + glane] : CZ_NONE;
+#pragma unroll
+        for (int k = 0; k < kBfsNodes; k++) first[k] = v[k] != CZ_NONE && claim_first(v[k], i[k]);
+#pragma unroll
+        for (int k = 0; k < kBfsNodes; k++) append(first[k], v[k]);
+#pragma unroll
+        for (int k = 0; k < kBfsNodes; k++) {
+            uint32_t maxlen = e1[k] - e0[k];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, o, 64));
+            for (uint32_t b = kBfsLanes; b < maxlen; b += kBfsLanes) {
+                const uint32_t e = e0[k] + b + glane;
+                bool f = false;
+                uint32_t t = 0;
+                if (e < e1[k]) {
+                    t = tgt[e];
+                    f = claim_first(t, i[k]);
                 }
-                if (first) fresh[w_base + w_used + __popcll(m & ((1ull << lane) - 1ull))] = v;
-                w_used += cnt;
+                append(f, t);
             }
         }
     }
