@@ -17,6 +17,7 @@ CZ_BF_GEMM = 8
 CZ_PR_GATHER = 2
 CZ_PR_BLOCKED = 4
 CZ_PR_EXCHANGE_ALLREDUCE = 32
+CZ_PR_OVERLAP_EXCHANGE = 64
 CZ_UNIQUE_ID_BYTES = 128
 CZ_L2, CZ_COSINE, CZ_IP = 0, 1, 2
 CZ_OK, CZ_E_INVALID, CZ_E_NO_DEVICE, CZ_E_HIP, CZ_E_CANCELLED, CZ_E_OOM, CZ_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
@@ -125,6 +126,8 @@ SYMBOLS = {
     "cz_comm_all_reduce_sum_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "cz_pagerank_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_uint32, C.c_uint32, u32p, f64p,
                                       C.c_void_p, C.c_void_p]),
+    "cz_pagerank_sharded_overlapped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32,
+                                                 u32p, f64p, C.c_void_p, C.c_void_p]),
     "cz_pagerank_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_double,
                                     C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, u32p, f64p, C.c_void_p]),
     "cz_hnsw_search_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,

@@ -64,6 +64,16 @@ class Comm:
                                              C.byref(err), ptr(poison), C.c_void_p(stream)))
         return it.value, err.value
 
+    def pagerank_sharded_overlapped(self, plan_first, plan_second, rows_per_rank: int, half_rows: int, tolerance: float, max_iter: int,
+                                    poison: Optional[np.ndarray] = None, stream: int = 0):
+        """cz_pagerank_sharded_overlapped: the rank's rows as two PageRankPlans (rows [rb, rb + half_rows) and the rest); the
+        first part's contributions travel while the second part is swept.  Scores equal pagerank_sharded's."""
+        it, err = C.c_uint32(0), C.c_double(0.0)
+        check(_lib.lib().cz_pagerank_sharded_overlapped(self._h, plan_first._h, plan_second._h, rows_per_rank, half_rows,
+                                                        float(tolerance), int(max_iter), C.byref(it), C.byref(err), ptr(poison),
+                                                        C.c_void_p(stream)))
+        return it.value, err.value
+
     def hnsw_search_sharded(self, shard_index, queries_dev, B: int, k: int, ef: int, id_offset: int, out_ids, out_dist,
                             out_count, stream: int = 0):
         """hnsw_knn over one sub-index per rank (cz_hnsw_search_sharded): rank 0's queries are broadcast, per-shard lists
@@ -119,7 +129,7 @@ def sssp_sharded(comm: Comm, off_local, tgt, weights, n: int, row_begin: int, ro
 
 
 def pagerank_multi(in_off, in_src, out_deg, n_gpus: int, damping=0.85, tolerance=1e-4, max_iter=10,
-                   allreduce_exchange=False, poison=None):
+                   allreduce_exchange=False, overlap_exchange=False, poison=None):
     """cz_pagerank on n_gpus devices of THIS process (one host thread + one RCCL communicator per GPU)."""
     in_off = np.ascontiguousarray(in_off, dtype=np.uint32)
     in_src = np.ascontiguousarray(in_src, dtype=np.uint32)
@@ -127,7 +137,7 @@ def pagerank_multi(in_off, in_src, out_deg, n_gpus: int, damping=0.85, tolerance
     N = out_deg.size
     scores = np.empty(N, dtype=np.float32)
     it, err = C.c_uint32(0), C.c_double(0.0)
-    flags = _lib.CZ_PR_EXCHANGE_ALLREDUCE if allreduce_exchange else 0
+    flags = (_lib.CZ_PR_EXCHANGE_ALLREDUCE if allreduce_exchange else 0) | (_lib.CZ_PR_OVERLAP_EXCHANGE if overlap_exchange else 0)
     check(_lib.lib().cz_pagerank_multi(ptr(in_off), ptr(in_src), ptr(out_deg), N, in_src.size, np.float32(damping),
                                        float(tolerance), int(max_iter), int(n_gpus), flags, ptr(scores), C.byref(it),
                                        C.byref(err), ptr(poison)))

@@ -42,6 +42,8 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
@@ -76,6 +78,8 @@ Rccl *rccl() {
         CZ_SYM(AllGather, "ncclAllGather")
         CZ_SYM(AllReduce, "ncclAllReduce")
         CZ_SYM(Broadcast, "ncclBroadcast")
+        CZ_SYM(GroupStart, "ncclGroupStart")
+        CZ_SYM(GroupEnd, "ncclGroupEnd")
         CZ_SYM(GetErrorString, "ncclGetErrorString")
 #undef CZ_SYM
     });
@@ -248,9 +252,103 @@ struct HipPagerankBackend {
         CZ_HIP(hipStreamSynchronize(stream));
         return CZ_OK;
     }
+
+    // ---- the overlapped form (czs::run_sharded_pagerank_overlapped): two plans over the two parts of the rank's rows, the
+    // exchanges on a stream of their own.  A part's pieces sit `per` floats apart (piece r at buf + r * per + lo), which an
+    // all-gather cannot address: one broadcast per rank, grouped into one RCCL operation.
+    cz_pagerank_plan *plan2 = nullptr;
+    uint32_t half = 0;
+    hipStream_t xs = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    int overlapped_setup() {
+        CZ_HIP(hipStreamCreateWithFlags(&xs, hipStreamNonBlocking));
+        CZ_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+        CZ_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+        return CZ_OK;
+    }
+    void overlapped_teardown() {
+        if (xs) (void)hipStreamSynchronize(xs);
+        if (ev_ready) (void)hipEventDestroy(ev_ready);
+        if (ev_done) (void)hipEventDestroy(ev_done);
+        if (xs) (void)hipStreamDestroy(xs);
+        xs = nullptr;
+        ev_ready = ev_done = nullptr;
+    }
+    int init_both(float *c) {
+        int rc = cz_pagerank_plan_init(plan, c, stream);
+        return rc ? rc : cz_pagerank_plan_init(plan2, c, stream);  // (the contribution vector is written twice, alike)
+    }
+    int step_part(int part, const float *cin, float *cout) {
+        return cz_pagerank_plan_step(part ? plan2 : plan, cin, cout, e2.p, stream);
+    }
+    int exchange_part_begin(int part, float *buf) {
+        if (comm->world == 1) return CZ_OK;
+        const size_t lo = part ? half : 0, cnt = part ? (size_t)per - half : half;
+        if (cnt == 0) return CZ_OK;
+        CZ_HIP(hipEventRecord(ev_ready, stream));  // behind the sweep of this part
+        CZ_HIP(hipStreamWaitEvent(xs, ev_ready, 0));
+        CZ_NCCL(R, R->GroupStart());
+        for (int r = 0; r < comm->world; r++) {
+            float *piece = buf + (size_t)r * per + lo;
+            ncclResult_t nr = R->Broadcast(piece, piece, cnt, ncclFloat32, r, comm->nccl, xs);
+            if (nr != ncclSuccess) {
+                (void)R->GroupEnd();
+                return cz::set_error(CZ_E_HIP, "ncclBroadcast failed: %s", R->GetErrorString(nr));
+            }
+        }
+        CZ_NCCL(R, R->GroupEnd());
+        return CZ_OK;
+    }
+    int exchange_join() {
+        if (comm->world == 1) return CZ_OK;
+        CZ_HIP(hipEventRecord(ev_done, xs));
+        CZ_HIP(hipStreamWaitEvent(stream, ev_done, 0));
+        return CZ_OK;
+    }
+};
+
+// the loop hands `init` the first buffer; the overlapped form has two plans to initialise
+struct HipPagerankBackendOverlapped : HipPagerankBackend {
+    int init(float *c) { return init_both(c); }
 };
 
 }  // namespace
+
+extern "C" int cz_pagerank_sharded_overlapped(cz_comm *comm, cz_pagerank_plan *plan_first, cz_pagerank_plan *plan_second,
+                                              uint32_t rows_per_rank, uint32_t half_rows, double tolerance, uint32_t max_iter,
+                                              uint32_t *iters_run, double *final_err, const volatile uint8_t *poison, void *stream) {
+    if (iters_run) *iters_run = 0;
+    if (final_err) *final_err = 0.0;
+    if (!comm || !plan_first || !plan_second) return cz::set_error(CZ_E_INVALID, "null argument");
+    if (max_iter == 0) return cz::set_error(CZ_E_INVALID, "iterations must be positive");
+    if (half_rows > rows_per_rank) return cz::set_error(CZ_E_INVALID, "half_rows %u > rows_per_rank %u", half_rows, rows_per_rank);
+    const uint32_t N = cz_pagerank_plan_nodes(plan_first);
+    if (cz_pagerank_plan_nodes(plan_second) != N) return cz::set_error(CZ_E_INVALID, "the two plans belong to different graphs");
+    if ((uint64_t)rows_per_rank * (uint64_t)comm->world < N)
+        return cz::set_error(CZ_E_INVALID, "rows_per_rank %u x %d ranks does not cover %u nodes", rows_per_rank, comm->world, N);
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    Rccl *R = nullptr;
+    if ((rc = need_rccl(&R))) return rc;
+    HipPagerankBackendOverlapped b;
+    b.R = R;
+    b.comm = comm;
+    b.plan = plan_first;
+    b.plan2 = plan_second;
+    b.stream = (hipStream_t)stream;
+    b.per = rows_per_rank;
+    b.half = half_rows;
+    if ((rc = b.alloc())) return rc;
+    if ((rc = b.overlapped_setup())) {
+        b.overlapped_teardown();
+        return rc;
+    }
+    rc = czs::run_sharded_pagerank_overlapped(b, comm->world, rows_per_rank, tolerance, max_iter, poison, iters_run, final_err);
+    (void)hipStreamSynchronize((hipStream_t)stream);  // the buffers die with this scope
+    b.overlapped_teardown();
+    if (rc == czs::RUN_CANCELLED) return cz::set_error(CZ_E_CANCELLED, "cancelled");
+    return rc;
+}
 
 extern "C" int cz_pagerank_sharded(cz_comm *comm, cz_pagerank_plan *plan, uint32_t rows_per_rank, double tolerance,
                                    uint32_t max_iter, uint32_t flags, uint32_t *iters_run, double *final_err,
@@ -266,7 +364,12 @@ extern "C" int cz_pagerank_sharded(cz_comm *comm, cz_pagerank_plan *plan, uint32
     if (rc) return rc;
     Rccl *R = nullptr;
     if ((rc = need_rccl(&R))) return rc;
-    HipPagerankBackend b{R, comm, plan, (hipStream_t)stream, rows_per_rank, {}, {}, {}};
+    HipPagerankBackend b;
+    b.R = R;
+    b.comm = comm;
+    b.plan = plan;
+    b.stream = (hipStream_t)stream;
+    b.per = rows_per_rank;
     if ((rc = b.alloc())) return rc;
     rc = czs::run_sharded_pagerank(b, comm->world, rows_per_rank, tolerance, max_iter,
                                    (flags & CZ_PR_EXCHANGE_ALLREDUCE) ? czs::EXCHANGE_ALLREDUCE : czs::EXCHANGE_ALLGATHER, poison,
@@ -313,9 +416,20 @@ extern "C" int cz_pagerank_multi(const uint32_t *in_offsets, const uint32_t *in_
         const uint32_t rb = std::min<uint64_t>(N, (uint64_t)r * per), re = std::min<uint64_t>(N, (uint64_t)(r + 1) * per);
         std::vector<uint32_t> off((size_t)(re - rb) + 1);
         for (uint32_t i = 0; i <= re - rb; i++) off[i] = in_offsets[rb + i] - in_offsets[rb];
-        cz_pagerank_plan *plan = nullptr;
-        wrc = cz_pagerank_plan_create(off.data(), in_sources + in_offsets[rb], out_degree, N, rb, re, damping, &plan,
+        cz_pagerank_plan *plan = nullptr, *plan_b = nullptr;
+        // CZ_PR_OVERLAP_EXCHANGE: the rank's rows as two plans cut in the middle of the padded range; the first part's
+        // exchange runs while the second part is swept (cz_pagerank_sharded_overlapped)
+        const bool overlap = (flags & CZ_PR_OVERLAP_EXCHANGE) != 0 && !(flags & CZ_PR_EXCHANGE_ALLREDUCE);
+        const uint32_t half = per / 2;
+        const uint32_t mid = overlap ? std::min<uint32_t>(re, rb + half) : re;
+        wrc = cz_pagerank_plan_create(off.data(), in_sources + in_offsets[rb], out_degree, N, rb, mid, damping, &plan,
                                       flags & (CZ_PR_GATHER | CZ_PR_BLOCKED));
+        if (!wrc && overlap) {
+            std::vector<uint32_t> off2((size_t)(re - mid) + 1);
+            for (uint32_t i = 0; i <= re - mid; i++) off2[i] = in_offsets[mid + i] - in_offsets[mid];
+            wrc = cz_pagerank_plan_create(off2.data(), in_sources + in_offsets[mid], out_degree, N, mid, re, damping, &plan_b,
+                                          flags & (CZ_PR_GATHER | CZ_PR_BLOCKED));
+        }
         // a rank that failed before the loop would leave the others blocked in the first collective: every rank enters
         // the loop, a failed one with its poison flag raised
         cz_comm c;
@@ -327,21 +441,31 @@ extern "C" int cz_pagerank_multi(const uint32_t *in_offsets, const uint32_t *in_
         if (!wrc && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) wrc = cz::set_error(CZ_E_HIP, "hipStreamCreate failed");
         if (wrc) fail(wrc);
         static const uint8_t kSet = 1;
-        std::unique_ptr<cz_pagerank_plan, void (*)(cz_pagerank_plan *)> guard(plan, cz_pagerank_plan_destroy);
-        cz_pagerank_plan *use = plan;
-        cz_pagerank_plan *empty = nullptr;
+        std::unique_ptr<cz_pagerank_plan, void (*)(cz_pagerank_plan *)> guard(plan, cz_pagerank_plan_destroy), guard_b(plan_b, cz_pagerank_plan_destroy);
+        cz_pagerank_plan *use = plan, *use_b = plan_b;
+        cz_pagerank_plan *empty = nullptr, *empty_b = nullptr;
+        uint32_t z = 0;
         if (!use) {  // an empty stand-in so that this rank can still take part in the exchanges
-            uint32_t z = 0;
             if (cz_pagerank_plan_create(&z, nullptr, out_degree, N, rb, rb, damping, &empty, 0) == CZ_OK) use = empty;
         }
-        if (use) {
-            int lrc = cz_pagerank_sharded(&c, use, per, tolerance, max_iter, flags, &its[r], &errs[r], wrc ? &kSet : poison, st);
+        if (overlap && !use_b) {
+            if (cz_pagerank_plan_create(&z, nullptr, out_degree, N, mid, mid, damping, &empty_b, 0) == CZ_OK) use_b = empty_b;
+        }
+        if (use && (!overlap || use_b)) {
+            int lrc = overlap ? cz_pagerank_sharded_overlapped(&c, use, use_b, per, half, tolerance, max_iter, &its[r], &errs[r],
+                                                               wrc ? &kSet : poison, st)
+                              : cz_pagerank_sharded(&c, use, per, tolerance, max_iter, flags, &its[r], &errs[r], wrc ? &kSet : poison, st);
             if (!wrc && lrc) fail(lrc);
-            if (!wrc && !lrc && re > rb) {
+            if (!wrc && !lrc && mid > rb) {
                 lrc = cz_pagerank_plan_read_scores(use, scores + rb, 0, st);
                 if (lrc) fail(lrc);
             }
+            if (!wrc && !lrc && overlap && re > mid) {
+                lrc = cz_pagerank_plan_read_scores(use_b, scores + mid, 0, st);
+                if (lrc) fail(lrc);
+            }
         }
+        if (empty_b) cz_pagerank_plan_destroy(empty_b);
         if (empty) cz_pagerank_plan_destroy(empty);
         if (st) (void)hipStreamDestroy(st);
         c.nccl = nullptr;

@@ -75,4 +75,53 @@ int run_sharded_pagerank(Backend &b, int world, uint32_t per, double tolerance, 
     }
 }
 
+// The same loop with the exchange of the FIRST part of a rank's rows in flight while the SECOND part is swept (round 3;
+// until then only cozo_amd/distributed.py had this form, over torch.distributed).  The exchange of iteration k feeds
+// iteration k + 1, so the only overlap there is lies inside an iteration: the rank's rows are cut at `half` (the same
+// cut, in rows of the padded per-rank range, on every rank) into two plans;
+//   sweep part 0 -> begin the exchange of every rank's part-0 piece (on the backend's exchange stream, behind the sweep)
+//   sweep part 1 (runs meanwhile) -> begin the exchange of the part-1 pieces -> join -> all-reduce of the two f64.
+// Pieces land at their natural places in the full contribution vector, sources keep their ids, every row sum keeps its
+// order: the scores equal the unsplit run's bit for bit.  Hides min(part-1 sweep, part-0 exchange) per iteration.
+// Backend additions:
+//   int step_part(int part, const float *cin, float *cout)     rows [rb, rb + half) / [rb + half, re); adds into err2[0]
+//   int exchange_part_begin(int part, float *buf)              piece r at buf + r * per + (part ? half : 0), `half` or
+//                                                              `per - half` floats; ordered behind the work queued so far
+//   int exchange_join()                                        the work queued after it waits for the exchanges begun
+template <class Backend>
+int run_sharded_pagerank_overlapped(Backend &b, int world, uint32_t per, double tolerance, uint32_t max_iter,
+                                    const volatile uint8_t *poison, uint32_t *iters_run, double *final_err) {
+    (void)world;
+    (void)per;
+    float *cin = b.contrib(0), *cout = b.contrib(1);
+    int rc = b.init(cin);
+    if (rc) return rc;
+    uint32_t it = 0;
+    const bool never_stops_early = !(tolerance > 0.0);
+    for (;;) {
+        const bool last = it + 1 == max_iter;
+        const bool p = poison && *poison;
+        if ((rc = b.begin_iteration(p ? 1.0 : 0.0))) return rc;
+        if (!p && (rc = b.step_part(0, cin, cout))) return rc;
+        if ((rc = b.exchange_part_begin(0, cout))) return rc;
+        if (!p && (rc = b.step_part(1, cin, cout))) return rc;
+        if ((rc = b.exchange_part_begin(1, cout))) return rc;
+        if ((rc = b.exchange_join())) return rc;
+        if ((rc = b.all_reduce_err2())) return rc;
+        float *t = cin;
+        cin = cout;
+        cout = t;
+        it++;
+        if (never_stops_early && !last && !(poison && it % 8 == 0)) continue;
+        double h[2] = {0.0, 0.0};
+        if ((rc = b.read_err2(h))) return rc;
+        if (h[1] > 0.0) return RUN_CANCELLED;
+        if (h[0] < tolerance || it == max_iter) {
+            if (iters_run) *iters_run = it;
+            if (final_err) *final_err = h[0];
+            return RUN_OK;
+        }
+    }
+}
+
 }  // namespace czs

@@ -283,6 +283,10 @@ int cz_comm_all_reduce_sum_f64(cz_comm *c, double *buf_dev, uint64_t n, void *st
  * vector with the other ranks' slices zeroed (north_star's literal wording) instead of the in-place all-gather of the
  * slices.  Same values bit for bit, ~2(world-1)/world * 4N bytes per link instead of 4N/world: a labelled comparison. */
 #define CZ_PR_EXCHANGE_ALLREDUCE 32u
+/* cz_pagerank_multi: every rank's rows as TWO plans cut in the middle; the exchange of the first part's contributions runs (on
+ * a stream of its own) while the second part is swept -- cz_pagerank_sharded_overlapped per rank.  Scores unchanged bit for
+ * bit; hides min(second-part sweep, first-part exchange) per iteration.  Ignored together with CZ_PR_EXCHANGE_ALLREDUCE. */
+#define CZ_PR_OVERLAP_EXCHANGE 64u
 
 /* graph::page_rank over row shards, collectively on every rank: `plan` owns this rank's rows
  * [rank * rows_per_rank, min(N, (rank + 1) * rows_per_rank)) (cz_pagerank_plan_create with those bounds).  Per iteration:
@@ -292,8 +296,15 @@ int cz_comm_all_reduce_sum_f64(cz_comm *c, double *buf_dev, uint64_t n, void *st
 int cz_pagerank_sharded(cz_comm *comm, cz_pagerank_plan *plan, uint32_t rows_per_rank, double tolerance, uint32_t max_iter,
                         uint32_t flags /* CZ_PR_EXCHANGE_ALLREDUCE */, uint32_t *iters_run, double *final_err,
                         const volatile uint8_t *poison, void *stream);
+/* The same loop with the rank's rows in two plans (rows [rb, rb + half_rows) and the rest; half_rows counts rows of the padded
+ * per-rank range and is the same on every rank): sweep part 1 -> its pieces start travelling -> sweep part 2 meanwhile -> its
+ * pieces -> join -> the f64 all-reduce.  Pieces land at their natural places of the full contribution vector (one grouped
+ * ncclBroadcast per rank: a part's pieces sit rows_per_rank floats apart), so the scores equal cz_pagerank_sharded's. */
+int cz_pagerank_sharded_overlapped(cz_comm *comm, cz_pagerank_plan *plan_first, cz_pagerank_plan *plan_second,
+                                   uint32_t rows_per_rank, uint32_t half_rows, double tolerance, uint32_t max_iter,
+                                   uint32_t *iters_run, double *final_err, const volatile uint8_t *poison, void *stream);
 /* cz_pagerank on n_gpus devices of this process (devices 0 .. n_gpus-1): host CSR in, scores [N] out.
- * flags: CZ_PR_GATHER | CZ_PR_BLOCKED | CZ_PR_EXCHANGE_ALLREDUCE. */
+ * flags: CZ_PR_GATHER | CZ_PR_BLOCKED | CZ_PR_EXCHANGE_ALLREDUCE | CZ_PR_OVERLAP_EXCHANGE. */
 int cz_pagerank_multi(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N,
                       uint64_t E, float damping, double tolerance, uint32_t max_iter, int n_gpus, uint32_t flags,
                       float *scores, uint32_t *iters_run, double *final_err, const volatile uint8_t *poison);

@@ -10,6 +10,7 @@ pub const CZ_PR_GATHER: u32 = 2;
 pub const CZ_PR_BLOCKED: u32 = 4;
 pub const CZ_BF_GEMM: u32 = 8;
 pub const CZ_PR_EXCHANGE_ALLREDUCE: u32 = 32;
+pub const CZ_PR_OVERLAP_EXCHANGE: u32 = 64;
 pub const CZ_UNIQUE_ID_BYTES: u32 = 128;
 
 pub const CZ_OK: c_int = 0;
@@ -163,6 +164,9 @@ extern "C" {
     pub fn cz_pagerank_sharded(comm: *mut cz_comm, plan: *mut cz_pagerank_plan, rows_per_rank: u32, tolerance: c_double,
                                max_iter: u32, flags: u32, iters_run: *mut u32, final_err: *mut c_double, poison: *const u8,
                                stream: *mut c_void) -> c_int;
+    pub fn cz_pagerank_sharded_overlapped(comm: *mut cz_comm, plan_first: *mut cz_pagerank_plan, plan_second: *mut cz_pagerank_plan,
+                                          rows_per_rank: u32, half_rows: u32, tolerance: c_double, max_iter: u32, iters_run: *mut u32,
+                                          final_err: *mut c_double, poison: *const u8, stream: *mut c_void) -> c_int;
     pub fn cz_pagerank_multi(in_offsets: *const u32, in_sources: *const u32, out_degree: *const u32, n: u32, e: u64,
                              damping: c_float, tolerance: c_double, max_iter: u32, n_gpus: c_int, flags: u32,
                              scores: *mut c_float, iters_run: *mut u32, final_err: *mut c_double, poison: *const u8) -> c_int;

@@ -17,6 +17,8 @@ extern "C" {
 typedef int (*cz_test_all_gather_f32)(void *ctx, float *buf, uint64_t per);   // in place, slice r at buf + r * per
 typedef int (*cz_test_all_reduce_f32)(void *ctx, float *buf, uint64_t n);
 typedef int (*cz_test_all_reduce_f64)(void *ctx, double *buf, uint64_t n);
+// every rank's piece [lo, lo + cnt) of its slice: piece r at buf + r * per + lo
+typedef int (*cz_test_exchange_piece)(void *ctx, float *buf, uint64_t per, uint64_t lo, uint64_t cnt);
 }
 
 namespace {
@@ -65,6 +67,33 @@ struct HostBackend {
         gathers++;
         return ag(ctx, buf, per);
     }
+    // the overlapped form: two parts of the rank's rows, cut `half` rows into the padded per-rank range
+    uint32_t half = 0;
+    cz_test_exchange_piece xp = nullptr;
+    int pieces = 0;
+    int step_part(int part, const float *cin, float *cout) {
+        const uint32_t cut = std::min<uint32_t>(re, rb + half);
+        const uint32_t r0 = part ? cut : rb, r1 = part ? re : cut;
+        double err = 0.0;
+        for (uint32_t r = r0; r < r1; r++) {
+            float s = 0.0f;
+            for (uint64_t e = off[r - rb]; e < off[r - rb + 1]; e++) s = s + cin[src[e]];
+            const float old = scores[r - rb];
+            const float nw = base + damping * s;
+            scores[r - rb] = nw;
+            cout[r] = nw / (float)outdeg[r];
+            err += std::fabs((double)(nw - old));
+        }
+        e2[0] += err;
+        steps++;
+        return 0;
+    }
+    int exchange_part_begin(int part, float *buf) {
+        pieces++;
+        const uint64_t lo = part ? half : 0, cnt = part ? per - half : half;
+        return cnt ? xp(ctx, buf, per, lo, cnt) : 0;  // (the host callback completes the exchange before it returns)
+    }
+    int exchange_join() { return 0; }
     int zero_other_slices(float *buf) {
         const size_t lo = (size_t)rank * per, total = (size_t)per * world;
         std::memset(buf, 0, lo * 4);
@@ -116,6 +145,45 @@ extern "C" int cz_test_sharded_pagerank_host(uint32_t N, uint32_t per, int rank,
     if (counters) {
         counters[0] = b.steps;
         counters[1] = b.gathers;
+        counters[2] = b.reduces;
+    }
+    return rc;
+}
+
+// the overlapped form of the same loop (czs::run_sharded_pagerank_overlapped); counters [3] = part sweeps, pieces begun, reduces
+extern "C" int cz_test_sharded_pagerank_overlapped_host(uint32_t N, uint32_t per, uint32_t half, int rank, int world,
+                                                        const uint64_t *off_local, const uint32_t *src, const uint32_t *outdeg,
+                                                        float damping, double tolerance, uint32_t max_iter,
+                                                        const volatile uint8_t *poison, void *ctx, cz_test_exchange_piece xp,
+                                                        cz_test_all_reduce_f64 ar64, float *scores_out, uint32_t *iters_run,
+                                                        double *final_err, int *counters) {
+    HostBackend b;
+    b.N = N;
+    b.per = per;
+    b.half = half;
+    b.rank = rank;
+    b.world = world;
+    b.rb = (uint32_t)std::min<uint64_t>(N, (uint64_t)rank * per);
+    b.re = (uint32_t)std::min<uint64_t>(N, (uint64_t)(rank + 1) * per);
+    b.off = off_local;
+    b.src = src;
+    b.outdeg = outdeg;
+    b.damping = damping;
+    b.init0 = 1.0f / (float)N;
+    b.base = (1.0f - damping) / (float)N;
+    b.c[0].assign((size_t)per * world, 0.f);
+    b.c[1].assign((size_t)per * world, 0.f);
+    b.scores.assign(b.re - b.rb, 0.f);
+    b.ctx = ctx;
+    b.ag = nullptr;
+    b.ar32 = nullptr;
+    b.ar64 = ar64;
+    b.xp = xp;
+    const int rc = czs::run_sharded_pagerank_overlapped(b, world, per, tolerance, max_iter, poison, iters_run, final_err);
+    if (scores_out) std::memcpy(scores_out, b.scores.data(), b.scores.size() * 4);
+    if (counters) {
+        counters[0] = b.steps;
+        counters[1] = b.pieces;
         counters[2] = b.reduces;
     }
     return rc;

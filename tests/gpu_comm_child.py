@@ -49,7 +49,21 @@ def main():
             plan.close()
             s, it2, _ = pagerank_multi(g["ioff"], g["isrc"], g["outdeg"], 1, 0.85, tol, iters, allreduce_exchange=allreduce)
             assert it2 == want_it and np.array_equal(s, want)
-    print("OK pagerank_sharded / pagerank_multi / collectives", flush=True)
+    # the overlapped exchange: the rank's rows as two plans, one rank (the exchanges are the identity, the order of work is not)
+    for tol, iters in ((1e-4, 10), (0.0, 20)):
+        want, want_it, want_err = O.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, tol, iters)
+        n, mid = g["n"], g["n"] // 3
+        ioff = g["ioff"].astype(np.int64)
+        pa = G.PageRankPlan((ioff[:mid + 1] - ioff[0]).astype(np.uint32), g["isrc"][:ioff[mid]], g["outdeg"], n, 0, mid, 0.85)
+        pb = G.PageRankPlan((ioff[mid:] - ioff[mid]).astype(np.uint32), g["isrc"][ioff[mid]:], g["outdeg"], n, mid, n, 0.85)
+        it, err = comm.pagerank_sharded_overlapped(pa, pb, n, mid, tol, iters)
+        got = np.concatenate([pa.read_scores(), pb.read_scores()])
+        assert it == want_it and np.array_equal(got, want) and abs(err - want_err) <= 1e-9 * abs(want_err)
+        pa.close()
+        pb.close()
+        s, it2, _ = pagerank_multi(g["ioff"], g["isrc"], g["outdeg"], 1, 0.85, tol, iters, overlap_exchange=True)
+        assert it2 == want_it and np.array_equal(s, want)
+    print("OK pagerank_sharded / pagerank_sharded_overlapped / pagerank_multi / collectives", flush=True)
 
     x = util.vectors(3000, 96, 42, "lowrank")
     _, flat = util.build_index(O, x, 1, 12, 60)

@@ -304,3 +304,100 @@ def test_vertex_partitioned_cc_cancellation_is_collective(oracle):
     out = _run_traversal("cc", g, 0, poison_at=(1, 1))
     assert [o[1] for o in out] == [1, 1]
 
+
+
+# ---- the overlapped form of the same loop (czs::run_sharded_pagerank_overlapped) ---------------------------------------------
+XP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_uint64, C.c_uint64, C.c_uint64)
+
+
+def _worker_overlapped(rank, world, port, g, tol, max_iter, half, poison_at, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = C.CDLL(SO)
+    n = g["n"]
+    per = (n + world - 1) // world
+    rb, re = min(n, rank * per), min(n, (rank + 1) * per)
+    ioff = g["ioff"].astype(np.uint64)
+    off_local = np.ascontiguousarray(ioff[rb:re + 1] - ioff[rb])
+    src = np.ascontiguousarray(g["isrc"][int(ioff[rb]):int(ioff[re])], dtype=np.uint32)
+    outdeg = np.ascontiguousarray(g["outdeg"], dtype=np.uint32)
+    poison = np.zeros(1, dtype=np.uint8)
+    calls = {"xp": 0}
+
+    def xp(_ctx, buf, per_, lo, cnt):
+        # every rank's piece [lo, lo + cnt) of its slice lands at buf + r * per + lo: a list all-gather into views
+        full = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(int(per_) * world,)))
+        views = [full[r * per_ + lo:r * per_ + lo + cnt] for r in range(world)]
+        outs = [torch.empty(int(cnt), dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(outs, views[rank].clone())
+        for r in range(world):
+            views[r].copy_(outs[r])
+        calls["xp"] += 1
+        if poison_at is not None and rank == poison_at[0] and calls["xp"] == poison_at[1]:
+            poison[0] = 1
+        return 0
+
+    def ar64(_ctx, buf, n_):
+        t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(int(n_),)))
+        dist.all_reduce(t)
+        return 0
+
+    cbs = (XP(xp), AR64(ar64))
+    scores = np.zeros(re - rb, dtype=np.float32)
+    it = C.c_uint32(0)
+    err = C.c_double(0)
+    counters = (C.c_int * 3)()
+    L.cz_test_sharded_pagerank_overlapped_host.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                           C.c_void_p, C.c_float, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, XP, AR64,
+                                                           C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    rc = L.cz_test_sharded_pagerank_overlapped_host(n, per, half, rank, world, off_local.ctypes.data, src.ctypes.data, outdeg.ctypes.data,
+                                                    np.float32(0.85), float(tol), int(max_iter), poison.ctypes.data, None, *cbs,
+                                                    scores.ctypes.data, C.byref(it), C.byref(err), counters)
+    q.put((rank, rb, re, rc, scores, it.value, err.value, list(counters)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_overlapped(g, tol, max_iter, half, poison_at=None, world=2):
+    build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlapped, args=(r, world, port, g, tol, max_iter, half, poison_at, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(out)
+
+
+@pytest.mark.parametrize("n,e,tol,max_iter,half_of", [(301, 2500, 1e-4, 10, 0.5), (64, 400, 0.0, 5, 0.25), (7, 12, 1e-4, 10, 0.5),
+                                                      (1000, 9000, 0.0, 12, 0.0), (1000, 9000, 0.0, 12, 1.0)])
+def test_cpp_overlapped_loop_world2_bit_identical(oracle, n, e, tol, max_iter, half_of):
+    """run_sharded_pagerank_overlapped (what cz_pagerank_sharded_overlapped / cz_pagerank_multi with CZ_PR_OVERLAP_EXCHANGE run over
+    RCCL): the rank's rows in two parts, the exchange of part 0 begun before part 1 is swept.  Scores, iteration count and error
+    equal the single-process oracle's whatever the cut -- including the degenerate cuts (everything in one part)."""
+    frm, to = util.random_relation(n, e, 23)
+    g = util.graph_from_relation(oracle, frm, to)
+    per = (g["n"] + 1) // 2
+    half = int(per * half_of)
+    want, want_it, want_err = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, tol, max_iter)
+    out = _run_overlapped(g, tol, max_iter, half)
+    got = np.concatenate([o[4] for o in out])
+    assert all(o[3] == 0 for o in out)
+    assert all(o[5] == want_it for o in out)
+    assert np.array_equal(got, want), "scores bit-identical to the single-process oracle"
+    assert all(o[6] == pytest.approx(want_err, rel=1e-12) for o in out)
+    assert all(o[7] == [2 * want_it, 2 * want_it, want_it] for o in out)  # two part sweeps, two exchanges begun, one reduction per iteration
+
+
+def test_cpp_overlapped_loop_cancellation_is_collective(oracle):
+    frm, to = util.random_relation(400, 3000, 5)
+    g = util.graph_from_relation(oracle, frm, to)
+    out = _run_overlapped(g, 1e-12, 50, 100, poison_at=(1, 5))
+    assert all(o[3] == 1 for o in out), "both ranks return RUN_CANCELLED"
+    assert out[0][7][1:] == out[1][7][1:], "and leave at the same iteration (same exchanges, same reductions)"
+    assert out[1][7][0] == out[0][7][0] - 2, "the poisoned rank skipped the two part sweeps of its last iteration"
