@@ -745,6 +745,63 @@ pr_empty_rows_kernel(const uint32_t *__restrict__ row_id, uint32_t r0, uint32_t 
     if (threadIdx.x == 0) partial[blockIdx.x] = total;
 }
 
+// plan construction, skewed graphs: the row order is built on the device (on the host it was 0.1 s of loops over 10M rows
+// for a sweep that takes 0.5 ms).  Classes: 0 = stays in the natural order, 1 = heavy, 2 = without in-edges (when those
+// are moved); the class flags are scanned into positions, the heavy rows sorted by length (descending, stable).
+__global__ void __launch_bounds__(256)
+pr_row_class_kernel(const uint32_t *__restrict__ off, uint32_t rows, uint32_t heavy, int drop_empty, uint32_t *__restrict__ is_light,
+                    uint32_t *__restrict__ is_heavy, uint32_t *__restrict__ is_empty, uint32_t *__restrict__ counts /* [2] heavy, empty */) {
+    uint32_t nh = 0, ne = 0;
+    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
+        const uint32_t len = off[r + 1] - off[r];
+        const bool h = heavy > 0 && len >= heavy, e = len == 0;
+        if (is_light) {
+            const bool moved_empty = e && drop_empty;
+            is_heavy[r] = h ? 1u : 0u;
+            is_empty[r] = moved_empty ? 1u : 0u;
+            is_light[r] = (h || moved_empty) ? 0u : 1u;
+        }
+        nh += h ? 1u : 0u;
+        ne += e ? 1u : 0u;
+    }
+    if (counts) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            nh += __shfl_xor(nh, o, 64);
+            ne += __shfl_xor(ne, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (nh) atomicAdd(&counts[0], nh);
+            if (ne) atomicAdd(&counts[1], ne);
+        }
+    }
+}
+// positions of the three classes -> row_id for the light and the empty rows; (inverted length, row) pairs of the heavy ones
+__global__ void __launch_bounds__(256)
+pr_row_place_kernel(const uint32_t *__restrict__ off, uint32_t rows, const uint32_t *__restrict__ is_heavy,
+                    const uint32_t *__restrict__ is_empty, const uint32_t *__restrict__ pos_light, const uint32_t *__restrict__ pos_heavy,
+                    const uint32_t *__restrict__ pos_empty, uint32_t n_light, uint32_t n_heavy, uint32_t *__restrict__ row_id,
+                    uint32_t *__restrict__ hkey, uint32_t *__restrict__ hrow) {
+    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
+        if (is_heavy[r]) {
+            hkey[pos_heavy[r]] = ~(off[r + 1] - off[r]);  // ascending key = descending length; the sort is stable: rows ascending
+            hrow[pos_heavy[r]] = r;
+        } else if (is_empty[r]) {
+            row_id[n_light + n_heavy + pos_empty[r]] = r;
+        } else {
+            row_id[pos_light[r]] = r;
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+pr_row_len_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ row_id, uint32_t rows, uint32_t *__restrict__ len) {
+    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
+        const uint32_t o = row_id[r];
+        len[r] = off[o + 1] - off[o];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) len[rows] = 0;
+}
+
 // plan construction, skewed graphs: in-edges of the rows in their new order.  A workgroup owns 256 consecutive new rows
 // (their edges are one contiguous stretch of the new array): new offsets of those rows in LDS, every edge finds its row by
 // bisection there and copies src[old offset of that row + position in the row].
@@ -1087,40 +1144,68 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     std::vector<uint32_t> perm_off;  // offsets in plan row order (when rows were moved)
     {
         const uint32_t heavy = (uint32_t)std::max(0, env_int("CZ_PR_HEAVY", (int)kHeavyRowDefault));
-        std::vector<uint32_t> heavy_rows, empty_rows;
-        for (uint32_t r = 0; r < rows; r++) {
-            const uint32_t len = in_offsets[r + 1] - in_offsets[r];
-            if (len == 0) empty_rows.push_back(r);
-            else if (heavy > 0 && len >= heavy) heavy_rows.push_back(r);
+        cz::DevBuf<uint32_t> counts;
+        uint32_t h_counts[2] = {0, 0};
+        if (heavy > 0 && rows > 0) {
+            CZ_HIP(counts.alloc(2));
+            CZ_HIP(hipMemset(counts.p, 0, 8));
+            hipLaunchKernelGGL(pr_row_class_kernel, dim3(2048), dim3(256), 0, nullptr, p->d_off, rows, heavy, 0, (uint32_t *)nullptr,
+                               (uint32_t *)nullptr, (uint32_t *)nullptr, counts.p);
+            CZ_HIP(hipMemcpy(h_counts, counts.p, 8, hipMemcpyDeviceToHost));
         }
-        if (heavy == 0 || empty_rows.size() < rows / 8) empty_rows.clear();  // a few empty rows stay where they are
-        if ((!heavy_rows.empty() || !empty_rows.empty()) && heavy_rows.size() + empty_rows.size() < rows) {
-            std::stable_sort(heavy_rows.begin(), heavy_rows.end(), [&](uint32_t a, uint32_t b) {
-                return in_offsets[a + 1] - in_offsets[a] > in_offsets[b + 1] - in_offsets[b];
-            });
-            const bool drop_empty = !empty_rows.empty();
-            std::vector<uint32_t> row_id;
-            row_id.reserve(rows);
-            for (uint32_t r = 0; r < rows; r++) {
-                const uint32_t len = in_offsets[r + 1] - in_offsets[r];
-                if ((len > 0 || !drop_empty) && !(heavy > 0 && len >= heavy)) row_id.push_back(r);
-            }
-            row_id.insert(row_id.end(), heavy_rows.begin(), heavy_rows.end());
-            row_id.insert(row_id.end(), empty_rows.begin(), empty_rows.end());
-            p->n_empty = (uint32_t)empty_rows.size();
-            p->n_eblocks = (p->n_empty + kERowsPerBlock - 1) / kERowsPerBlock;
-            perm_off.resize((size_t)rows + 1);
-            perm_off[0] = 0;
-            for (uint32_t r = 0; r < rows; r++) perm_off[r + 1] = perm_off[r] + (in_offsets[row_id[r] + 1] - in_offsets[row_id[r]]);
-            cz::DevBuf<uint32_t> new_off, new_src;
+        const uint32_t n_heavy = h_counts[0];
+        const bool drop_empty = heavy > 0 && h_counts[1] >= rows / 8 && h_counts[1] > 0;  // a few empty rows stay where they are
+        const uint32_t n_empty = drop_empty ? h_counts[1] : 0;
+        if ((n_heavy > 0 || n_empty > 0) && n_heavy + n_empty < rows) {
+            const uint32_t n_light = rows - n_heavy - n_empty;
+            cz::DevBuf<uint32_t> f_light, f_heavy, f_empty, p_light, p_heavy, p_empty, hkey_in, hkey_out, hrow_in, new_len, new_off, new_src;
+            cz::DevBuf<char> tmp;
+            for (cz::DevBuf<uint32_t> *b3 : {&f_light, &f_heavy, &f_empty, &p_light, &p_heavy, &p_empty}) CZ_HIP(b3->alloc(rows));
+            CZ_HIP(hkey_in.alloc(n_heavy));
+            CZ_HIP(hkey_out.alloc(n_heavy));
+            CZ_HIP(hrow_in.alloc(n_heavy));
+            CZ_HIP(new_len.alloc((size_t)rows + 1));
             CZ_HIP(new_off.alloc((size_t)rows + 1));
             CZ_HIP(new_src.alloc(std::max<uint64_t>(1, E)));
             CZ_HIP(hipMalloc((void **)&p->d_rowid, (size_t)rows * 4));
-            CZ_HIP(hipMemcpy(p->d_rowid, row_id.data(), (size_t)rows * 4, hipMemcpyHostToDevice));
-            CZ_HIP(hipMemcpy(new_off.p, perm_off.data(), ((size_t)rows + 1) * 4, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(pr_row_class_kernel, dim3(2048), dim3(256), 0, nullptr, p->d_off, rows, heavy, drop_empty ? 1 : 0,
+                               f_light.p, f_heavy.p, f_empty.p, (uint32_t *)nullptr);
+            size_t tb = 0, need = 0;
+            CZ_HIP(rocprim::exclusive_scan(nullptr, need, f_light.p, p_light.p, 0u, (size_t)rows, rocprim::plus<uint32_t>(), (hipStream_t) nullptr));
+            tb = need;
+            CZ_HIP(rocprim::exclusive_scan(nullptr, need, new_len.p, new_off.p, 0u, (size_t)rows + 1, rocprim::plus<uint32_t>(), (hipStream_t) nullptr));
+            tb = std::max(tb, need);
+            if (n_heavy) {
+                CZ_HIP(rocprim::radix_sort_pairs(nullptr, need, hkey_in.p, hkey_out.p, hrow_in.p, p->d_rowid + n_light, (size_t)n_heavy, 0u, 32u,
+                                                 (hipStream_t) nullptr));
+                tb = std::max(tb, need);
+            }
+            CZ_HIP(tmp.alloc(tb));
+            for (auto pr : {std::make_pair(&f_light, &p_light), std::make_pair(&f_heavy, &p_heavy), std::make_pair(&f_empty, &p_empty)}) {
+                need = tb;
+                CZ_HIP(rocprim::exclusive_scan((void *)tmp.p, need, pr.first->p, pr.second->p, 0u, (size_t)rows, rocprim::plus<uint32_t>(),
+                                               (hipStream_t) nullptr));
+            }
+            hipLaunchKernelGGL(pr_row_place_kernel, dim3(2048), dim3(256), 0, nullptr, p->d_off, rows, f_heavy.p, f_empty.p, p_light.p,
+                               p_heavy.p, p_empty.p, n_light, n_heavy, p->d_rowid, hkey_in.p, hrow_in.p);
+            if (n_heavy) {
+                need = tb;
+                CZ_HIP(rocprim::radix_sort_pairs((void *)tmp.p, need, hkey_in.p, hkey_out.p, hrow_in.p, p->d_rowid + n_light, (size_t)n_heavy, 0u,
+                                                 32u, (hipStream_t) nullptr));
+            }
+            hipLaunchKernelGGL(pr_row_len_kernel, dim3(2048), dim3(256), 0, nullptr, p->d_off, p->d_rowid, rows, new_len.p);
+            need = tb;
+            CZ_HIP(rocprim::exclusive_scan((void *)tmp.p, need, new_len.p, new_off.p, 0u, (size_t)rows + 1, rocprim::plus<uint32_t>(),
+                                           (hipStream_t) nullptr));
             hipLaunchKernelGGL(pr_permute_src_kernel, dim3((rows + 255) / 256), dim3(256), 0, nullptr, p->d_off, new_off.p, p->d_rowid,
                                rows, p->d_src, new_src.p);
-            CZ_HIP(hipDeviceSynchronize());
+            perm_off.resize((size_t)rows + 1);
+            CZ_HIP(hipMemcpy(perm_off.data(), new_off.p, ((size_t)rows + 1) * 4, hipMemcpyDeviceToHost));  // the row blocks are cut on the host
+            hipError_t le = hipGetLastError();
+            if (le != hipSuccess) return cz::set_error(CZ_E_HIP, "pagerank row order: %s", hipGetErrorString(le));
+            if (perm_off[rows] != E) return cz::set_error(CZ_E_HIP, "internal: the reordered rows hold %u edges, expected %llu", perm_off[rows], (unsigned long long)E);
+            p->n_empty = n_empty;
+            p->n_eblocks = (n_empty + kERowsPerBlock - 1) / kERowsPerBlock;
             (void)hipFree(p->d_off);
             (void)hipFree(p->d_src);
             p->d_off = new_off.release();
