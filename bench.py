@@ -585,6 +585,12 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
                 comm.close()
                 comm = None
             log("falling back to the exchange over torch.distributed (cozo_amd.distributed.ShardedPageRank)")
+    rccl_ranks_seen = None
+    if comm is not None:  # how many ranks libcozo_gpu's OWN communicator reaches: an all-reduce of one f64 per rank through it
+        one = torch.ones(1, dtype=torch.float64, device=device)
+        comm.all_reduce_sum_f64(one, 1, stream)
+        torch.cuda.synchronize()
+        rccl_ranks_seen = int(round(float(one.item())))
 
     class Loop:
         """graph::page_rank's loop: N = 1 the plan driven from here; N > 1 cz_pagerank_sharded (C++ loop + RCCL)"""
@@ -661,7 +667,25 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
                     f"all-reduce of 2 f64" if comm is not None else
                     f"cozo_amd.distributed.ShardedPageRank over torch.distributed (fallback: libcozo_gpu's communicator failed): "
                     f"all-gather of {per * 4} B per rank per iteration + all-reduce of 2 f64"))
+        if args.multi:
+            res["rccl_ranks_seen"] = rccl_ranks_seen
         if args.multi and comm is not None:
+            try:  # the rank's rows as two plans, the first part's exchange in flight while the second is swept (cz_pagerank_sharded_overlapped)
+                half = per // 2
+                mid = min(re, rb + half)
+                cut = int(off[mid - rb].item())
+                pa = PageRankPlan(off32[:mid - rb + 1].contiguous(), s[:cut].contiguous(), outdeg32, n_total, rb, mid, 0.85, device_ptrs=True)
+                pb = PageRankPlan((off32[mid - rb:] - off32[mid - rb]).contiguous(), s[cut:].contiguous(), outdeg32, n_total, mid, re, 0.85, device_ptrs=True)
+
+                class OLoop:
+                    def run(self, tol, iters):
+                        return comm.pagerank_sharded_overlapped(pa, pb, per, half, tol, iters, stream=stream)
+                it3, wall3 = timed_run(OLoop())
+                res["exchange_overlapped"] = dict(ms_per_iteration=wall3 / it3 * 1e3, edges_per_s=e_total * it3 / wall3)
+                pa.close()
+                pb.close()
+            except Exception as e:  # noqa: BLE001
+                res["exchange_overlapped"] = dict(error=f"{type(e).__name__}: {e}")
             try:  # labelled comparisons: north_star's literal all-reduce of the rank vector; the split-and-overlap form
                 it2, wall2 = timed_run(Loop(plan, allreduce=True))
                 res["exchange_all_reduce"] = dict(ms_per_iteration=wall2 / it2 * 1e3, edges_per_s=e_total * it2 / wall2,

@@ -130,6 +130,11 @@ SYMBOLS = {
                                                  u32p, f64p, C.c_void_p, C.c_void_p]),
     "cz_pagerank_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_double,
                                     C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, u32p, f64p, C.c_void_p]),
+    "cz_bfs_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cz_sssp_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cz_connected_components_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, u32p, C.c_void_p]),
     "cz_hnsw_search_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cz_connected_components_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p,

@@ -142,3 +142,45 @@ def pagerank_multi(in_off, in_src, out_deg, n_gpus: int, damping=0.85, tolerance
                                        float(tolerance), int(max_iter), int(n_gpus), flags, ptr(scores), C.byref(it),
                                        C.byref(err), ptr(poison)))
     return scores, it.value, err.value
+
+
+def bfs_multi(out_off, out_tgt, n_gpus: int, starts, goals=None, share_visited=False, want_depth=False, want_order=False, poison=None):
+    """cz_bfs on n_gpus devices of THIS process (cz_bfs_multi): the whole host CSR in, cz_bfs's results out"""
+    out_off = np.ascontiguousarray(out_off, dtype=np.uint32)
+    out_tgt = np.ascontiguousarray(out_tgt, dtype=np.uint32)
+    n = out_off.size - 1
+    starts = np.ascontiguousarray(starts, dtype=np.uint32)
+    g = np.ascontiguousarray(goals, dtype=np.uint32) if goals is not None else None
+    parent = np.empty((starts.size, n), dtype=np.uint32)
+    depth = np.empty((starts.size, n), dtype=np.uint32) if want_depth else None
+    order = np.full((starts.size, n), _lib.CZ_NONE, dtype=np.uint32) if want_order else None
+    reached = np.zeros(starts.size, dtype=np.uint32)
+    check(_lib.lib().cz_bfs_multi(ptr(out_off), ptr(out_tgt), n, out_tgt.size, int(n_gpus), ptr(starts), starts.size, ptr(g),
+                                  0 if g is None else g.size, int(share_visited), ptr(parent), ptr(depth), ptr(order), ptr(reached),
+                                  ptr(poison)))
+    return parent, depth, order, reached
+
+
+def sssp_multi(out_off, out_tgt, weights, n_gpus: int, starts, poison=None):
+    """cz_sssp on n_gpus devices of this process (cz_sssp_multi)"""
+    out_off = np.ascontiguousarray(out_off, dtype=np.uint32)
+    out_tgt = np.ascontiguousarray(out_tgt, dtype=np.uint32)
+    w = np.ascontiguousarray(weights, dtype=np.float32)
+    n = out_off.size - 1
+    starts = np.ascontiguousarray(starts, dtype=np.uint32)
+    dist = np.empty((starts.size, n), dtype=np.float32)
+    parent = np.empty((starts.size, n), dtype=np.uint32)
+    check(_lib.lib().cz_sssp_multi(ptr(out_off), ptr(out_tgt), ptr(w), n, out_tgt.size, int(n_gpus), ptr(starts), starts.size, ptr(dist),
+                                   ptr(parent), ptr(poison)))
+    return dist, parent
+
+
+def connected_components_multi(off, tgt, n_gpus: int, poison=None):
+    """cz_connected_components on n_gpus devices of this process (cz_connected_components_multi)"""
+    off = np.ascontiguousarray(off, dtype=np.uint32)
+    tgt = np.ascontiguousarray(tgt, dtype=np.uint32)
+    n = off.size - 1
+    grp = np.empty(n, dtype=np.uint32)
+    k = C.c_uint32(0)
+    check(_lib.lib().cz_connected_components_multi(ptr(off), ptr(tgt), n, tgt.size, int(n_gpus), ptr(grp), C.byref(k), ptr(poison)))
+    return grp, k.value

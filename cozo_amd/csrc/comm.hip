@@ -489,6 +489,133 @@ extern "C" int cz_pagerank_multi(const uint32_t *in_offsets, const uint32_t *in_
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// One cozo process, n GPUs: the vertex-partitioned traversals without a process per GPU (round 3; until then only PageRank
+// had this form).  One host thread per device, one RCCL communicator per device (ncclCommInitAll), rows split evenly; every
+// thread runs the collective entry point on its range of the host CSR.  The results are the same on every rank: rank 0
+// writes the caller's buffers, the others scratch.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <class F>
+int run_on_devices(int n_gpus, F fn /* int(int rank, cz_comm *comm) */) {
+    int have = cz_device_count();
+    if (n_gpus < 1 || n_gpus > have) return cz::set_error(CZ_E_INVALID, "n_gpus = %d, %d device(s) visible", n_gpus, have);
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    Rccl *R = nullptr;
+    if ((rc = need_rccl(&R))) return rc;
+    std::vector<int> devs(n_gpus);
+    for (int i = 0; i < n_gpus; i++) devs[i] = i;
+    std::vector<ncclComm_t> comms(n_gpus, nullptr);
+    CZ_NCCL(R, R->CommInitAll(comms.data(), n_gpus, devs.data()));
+    std::vector<int> rcs(n_gpus, CZ_OK);
+    std::vector<std::string> msgs(n_gpus);
+    auto worker = [&](int r) {
+        cz::t_device_override = devs[r];
+        int wrc = cz::ensure_device();
+        cz_comm c;
+        c.rank = r;
+        c.world = n_gpus;
+        c.device = devs[r];
+        c.nccl = comms[r];
+        if (!wrc) wrc = fn(r, &c);
+        if (wrc) {
+            rcs[r] = wrc;
+            msgs[r] = cz_last_error();
+        }
+        c.nccl = nullptr;
+        cz::t_device_override = -1;
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < n_gpus; r++) th.emplace_back(worker, r);
+    worker(0);
+    for (auto &t : th) t.join();
+    if (!getenv("CZ_COMM_NO_DESTROY"))
+        for (int r = 0; r < n_gpus; r++) {
+            (void)hipSetDevice(devs[r]);
+            (void)R->CommDestroy(comms[r]);
+        }
+    (void)cz::ensure_device();
+    for (int r = 0; r < n_gpus; r++)
+        if (rcs[r]) return cz::set_error(rcs[r], "GPU %d: %s", r, msgs[r].c_str());
+    return CZ_OK;
+}
+
+// this rank's rows [rb, re) of a host CSR: offsets relative to the shard
+struct RowShard {
+    uint32_t rb, re;
+    std::vector<uint32_t> off;
+    RowShard(const uint32_t *offsets, uint32_t N, int rank, int world) {
+        const uint32_t per = (uint32_t)(((uint64_t)N + world - 1) / world);
+        rb = (uint32_t)std::min<uint64_t>(N, (uint64_t)rank * per);
+        re = (uint32_t)std::min<uint64_t>(N, (uint64_t)(rank + 1) * per);
+        off.resize((size_t)(re - rb) + 1);
+        for (uint32_t i = 0; i <= re - rb; i++) off[i] = offsets[rb + i] - offsets[rb];
+    }
+};
+
+}  // namespace
+
+extern "C" int cz_bfs_multi(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E, int n_gpus,
+                            const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals, int share_visited,
+                            uint32_t *parent, uint32_t *depth, uint32_t *order, uint32_t *n_reached, const volatile uint8_t *poison) {
+    if (N == 0 || n_starts == 0) return CZ_OK;
+    if (!out_offsets || !starts || !parent || (E && !out_targets)) return cz::set_error(CZ_E_INVALID, "null argument");
+    if (out_offsets[N] != E) return cz::set_error(CZ_E_INVALID, "out_offsets[N] (%u) != E (%llu)", out_offsets[N], (unsigned long long)E);
+    return run_on_devices(n_gpus, [&](int r, cz_comm *c) {
+        RowShard sh(out_offsets, N, r, c->world);
+        const size_t full = (size_t)n_starts * N;
+        std::vector<uint32_t> sp, sd, so, sr;  // the other ranks' copies of the (identical) results
+        if (r) {
+            sp.resize(full);
+            if (depth) sd.resize(full);
+            if (order) so.resize(full);
+            sr.resize(n_starts);
+        }
+        return cz_bfs_sharded(c, sh.off.data(), out_targets + out_offsets[sh.rb], N, sh.rb, sh.re, sh.off.back(), starts, n_starts, goals,
+                              n_goals, share_visited, r ? sp.data() : parent, r ? (depth ? sd.data() : nullptr) : depth,
+                              r ? (order ? so.data() : nullptr) : order, r ? sr.data() : n_reached, poison);
+    });
+}
+
+extern "C" int cz_sssp_multi(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
+                             int n_gpus, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent,
+                             const volatile uint8_t *poison) {
+    if (N == 0 || n_starts == 0) return CZ_OK;
+    if (!out_offsets || !starts || !dist || !parent || (E && (!out_targets || !weights))) return cz::set_error(CZ_E_INVALID, "null argument");
+    if (out_offsets[N] != E) return cz::set_error(CZ_E_INVALID, "out_offsets[N] (%u) != E (%llu)", out_offsets[N], (unsigned long long)E);
+    return run_on_devices(n_gpus, [&](int r, cz_comm *c) {
+        RowShard sh(out_offsets, N, r, c->world);
+        const size_t full = (size_t)n_starts * N;
+        std::vector<float> sdist;
+        std::vector<uint32_t> spar;
+        if (r) {
+            sdist.resize(full);
+            spar.resize(full);
+        }
+        return cz_sssp_sharded(c, sh.off.data(), out_targets + out_offsets[sh.rb], weights + out_offsets[sh.rb], N, sh.rb, sh.re,
+                               sh.off.back(), starts, n_starts, r ? sdist.data() : dist, r ? spar.data() : parent, poison);
+    });
+}
+
+extern "C" int cz_connected_components_multi(const uint32_t *offsets, const uint32_t *targets, uint32_t N, uint64_t E, int n_gpus,
+                                             uint32_t *group, uint32_t *n_groups, const volatile uint8_t *poison) {
+    if (n_groups) *n_groups = 0;
+    if (N == 0) return CZ_OK;
+    if (!offsets || !group || (E && !targets)) return cz::set_error(CZ_E_INVALID, "null argument");
+    if (offsets[N] != E) return cz::set_error(CZ_E_INVALID, "offsets[N] (%u) != E (%llu)", offsets[N], (unsigned long long)E);
+    return run_on_devices(n_gpus, [&](int r, cz_comm *c) {
+        RowShard sh(offsets, N, r, c->world);
+        std::vector<uint32_t> sg;
+        uint32_t k = 0;
+        if (r) sg.resize(N);
+        const int rc = cz_connected_components_sharded(c, sh.off.data(), targets + offsets[sh.rb], N, sh.rb, sh.re, sh.off.back(),
+                                                       r ? sg.data() : group, r ? &k : n_groups, nullptr, poison);
+        return rc;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // hnsw_knn over an index partitioned into one independent sub-index per rank (BASELINE.json configs[3])
 // ------------------------------------------------------------------------------------------------------------------
 namespace {

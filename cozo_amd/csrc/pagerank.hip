@@ -850,6 +850,19 @@ int env_int(const char *name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// CZ_PR_PLAN_TRACE=1: where the plan build's time goes, stage by stage, on stderr (scratch/ experiments)
+struct StageTimer {
+    bool on = getenv("CZ_PR_PLAN_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[plan] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 }  // namespace
 
 struct cz_pagerank_plan {
@@ -920,8 +933,10 @@ int cut_row_blocks(const uint32_t *in_offsets, uint32_t rows, uint32_t tile, std
 int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uint32_t n_chunks) {
     const uint32_t rows = p->rows - p->n_empty;  // the rows without in-edges sit behind the others: pr_empty_rows_kernel
     const uint64_t E = p->E;
+    StageTimer st;
     std::vector<RowBlock> all;
     cut_row_blocks(h_off, rows, kBTileNnz, all);
+    st.lap("cut row blocks (host)");
     std::vector<RowBlock> bb, gb;  // blocked / long-row
     uint64_t e_blocked = 0;
     for (const RowBlock &rb : all) {
@@ -995,6 +1010,7 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
     CZ_HIP(d_tmp.alloc(tmp_bytes));
     CZ_HIP(rocprim::radix_sort_pairs((void *)d_tmp.p, tmp_bytes, keys_in.p, keys_out.p, idx_in.p, idx_out.p, (size_t)E, 0u,
                                      bits, (hipStream_t) nullptr));
+    st.lap("keys + radix sort");
     keys_in.reset();
     idx_in.reset();
     d_tmp.reset();
@@ -1047,6 +1063,7 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
             hipLaunchKernelGGL(pb_vpos_kernel, dim3((uint32_t)bb.size()), dim3(256), 0, nullptr, p->d_bblocks, p->d_seg, S, p->d_vpos);
         }
     }
+    st.lap("asrc / seg / perm kernels");
     uint32_t bad = 0;
     CZ_HIP(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
     if (bad) return cz::set_error(CZ_E_HIP, "blocked PageRank layout failed its self-check (%u violations)", bad);
@@ -1071,6 +1088,7 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
     CZ_HIP(hipMalloc((void **)&p->d_items, std::max<size_t>(1, items.size()) * sizeof(AItem)));
     if (!items.empty()) CZ_HIP(hipMemcpy(p->d_items, items.data(), items.size() * sizeof(AItem), hipMemcpyHostToDevice));
     CZ_HIP(hipDeviceSynchronize());
+    st.lap("phase-A items (host)");
     if (gb.empty()) {  // the global ids are only needed by the hub rows' gather
         (void)hipFree(p->d_src);
         p->d_src = nullptr;
@@ -1142,6 +1160,7 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     // cut from that tail hold rows of similar length (and the few rows worth a whole wave sit together).  The kernels
     // write every result through row_id, so the caller sees its own numbering.
     std::vector<uint32_t> perm_off;  // offsets in plan row order (when rows were moved)
+    StageTimer st_plan;
     {
         const uint32_t heavy = (uint32_t)std::max(0, env_int("CZ_PR_HEAVY", (int)kHeavyRowDefault));
         cz::DevBuf<uint32_t> counts;
@@ -1214,6 +1233,7 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
         }
     }
 
+    st_plan.lap("row order");
     // formulation: explicit flag > CZ_PR_MODE (gather | blocked) > heuristic
     int mode = 0;  // 0 auto, 1 gather, 2 blocked
     if (flags & CZ_PR_GATHER) mode = 1;

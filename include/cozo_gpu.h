@@ -344,6 +344,19 @@ int cz_connected_components_sharded(cz_comm *comm, const uint32_t *offsets_local
                                     uint32_t row_begin, uint32_t row_end, uint64_t E_local, uint32_t *group, uint32_t *n_groups,
                                     uint32_t *rounds, const volatile uint8_t *poison);
 
+/* The same three traversals on n_gpus devices of THIS process (devices 0 .. n_gpus-1; one host thread and one RCCL
+ * communicator per device, rows split evenly): host CSR of the whole graph in, the results of cz_bfs / cz_sssp /
+ * cz_connected_components out.  What a cozo process with several GPUs calls; the per-rank forms above are what a launcher
+ * with one process per GPU calls. */
+int cz_bfs_multi(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E, int n_gpus,
+                 const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals, int share_visited,
+                 uint32_t *parent, uint32_t *depth, uint32_t *order, uint32_t *n_reached, const volatile uint8_t *poison);
+int cz_sssp_multi(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
+                  int n_gpus, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent,
+                  const volatile uint8_t *poison);
+int cz_connected_components_multi(const uint32_t *offsets, const uint32_t *targets, uint32_t N, uint64_t E, int n_gpus,
+                                  uint32_t *group, uint32_t *n_groups, const volatile uint8_t *poison);
+
 /* ShortestPathBFS::run (fixed_rule/algos/shortest_path_bfs.rs:35-113) and the traversal of Bfs::run
  * (algos/bfs.rs:25-113) on the out-CSR (neighbours in sorted order = the KV prefix-scan order).
  *   starts [n_starts]: one BFS per start.  goals [n_goals] or NULL (NULL: full traversal; with goals the

@@ -164,6 +164,13 @@ extern "C" {
     pub fn cz_pagerank_sharded(comm: *mut cz_comm, plan: *mut cz_pagerank_plan, rows_per_rank: u32, tolerance: c_double,
                                max_iter: u32, flags: u32, iters_run: *mut u32, final_err: *mut c_double, poison: *const u8,
                                stream: *mut c_void) -> c_int;
+    pub fn cz_bfs_multi(out_offsets: *const u32, out_targets: *const u32, n: u32, e: u64, n_gpus: c_int, starts: *const u32, n_starts: u32,
+                        goals: *const u32, n_goals: u32, share_visited: c_int, parent: *mut u32, depth: *mut u32, order: *mut u32,
+                        n_reached: *mut u32, poison: *const u8) -> c_int;
+    pub fn cz_sssp_multi(out_offsets: *const u32, out_targets: *const u32, weights: *const c_float, n: u32, e: u64, n_gpus: c_int,
+                         starts: *const u32, n_starts: u32, dist: *mut c_float, parent: *mut u32, poison: *const u8) -> c_int;
+    pub fn cz_connected_components_multi(offsets: *const u32, targets: *const u32, n: u32, e: u64, n_gpus: c_int, group: *mut u32,
+                                         n_groups: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_pagerank_sharded_overlapped(comm: *mut cz_comm, plan_first: *mut cz_pagerank_plan, plan_second: *mut cz_pagerank_plan,
                                           rows_per_rank: u32, half_rows: u32, tolerance: c_double, max_iter: u32, iters_run: *mut u32,
                                           final_err: *mut c_double, poison: *const u8, stream: *mut c_void) -> c_int;

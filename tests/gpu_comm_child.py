@@ -108,6 +108,16 @@ def main():
     g1, k1, rounds = connected_components_sharded(comm, gu["ooff"], gu["otgt"], gu["n"], 0, gu["n"])
     assert k0 == k1 and k0 > 100 and np.array_equal(g0, g1) and rounds >= 1, "cz_connected_components_sharded differs"
     print(f"OK connected_components_sharded ({k1} components, {rounds} rounds)", flush=True)
+    # the single-process forms (one host thread + one communicator per device; one device here): the one-GPU rules' results
+    from cozo_amd.comm import bfs_multi, sssp_multi, connected_components_multi
+    a = G.bfs(gw["ooff"], gw["otgt"], starts, goals=goals, want_depth=True, want_order=True)
+    b = bfs_multi(gw["ooff"], gw["otgt"], 1, starts, goals=goals, want_depth=True, want_order=True)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)), "cz_bfs_multi differs from cz_bfs"
+    d2, p2 = sssp_multi(gw["ooff"], gw["otgt"], gw["ow"], 1, starts)
+    assert np.array_equal(d0, d2) and np.array_equal(p0, p2), "cz_sssp_multi differs from cz_sssp"
+    g2, k2 = connected_components_multi(gu["ooff"], gu["otgt"], 1)
+    assert k2 == k0 and np.array_equal(g2, g0), "cz_connected_components_multi differs"
+    print("OK bfs_multi / sssp_multi / connected_components_multi", flush=True)
     comm.close()
     print("ALL OK", flush=True)
 
