@@ -850,6 +850,44 @@ int env_int(const char *name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// Temporaries of the plan build and of a run come from the device's stream-ordered pool, which keeps what is freed (release
+// threshold = never): the build allocates and frees ~2 GB of scratch, and handing that to the driver and back cost 20-50 ms
+// per stage whenever the driver actually mapped / unmapped it (CZ_PR_PLAN_TRACE: the same stage took 2.8 or 56 ms).
+// Everything here runs on the null stream and is waited for before the buffers go.
+void pool_keep_freed_memory() {
+    static std::mutex mu;
+    static std::vector<int> done;  // devices whose pool has been told (one pool per device; cz_pagerank_multi drives several)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(mu);
+    if (std::find(done.begin(), done.end(), dev) != done.end()) return;
+    done.push_back(dev);
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+        uint64_t keep = ~0ull;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+}
+template <typename T>
+struct PoolBuf {
+    T *p = nullptr;
+    PoolBuf() = default;
+    PoolBuf(const PoolBuf &) = delete;
+    PoolBuf &operator=(const PoolBuf &) = delete;
+    ~PoolBuf() { reset(); }
+    void reset() {
+        if (p) (void)hipFreeAsync(p, nullptr);
+        p = nullptr;
+    }
+    hipError_t alloc(size_t count) {
+        reset();
+        pool_keep_freed_memory();
+        hipError_t e = hipMallocAsync((void **)&p, std::max<size_t>(1, count) * sizeof(T), nullptr);
+        if (e != hipSuccess) p = nullptr;
+        return e;
+    }
+};
+
 // CZ_PR_PLAN_TRACE=1: where the plan build's time goes, stage by stage, on stderr (scratch/ experiments)
 struct StageTimer {
     bool on = getenv("CZ_PR_PLAN_TRACE") != nullptr;
@@ -986,9 +1024,9 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
     CZ_HIP(hipMalloc((void **)&p->d_hblocks, std::max<size_t>(1, gb.size()) * sizeof(RowBlock)));
     if (!gb.empty()) CZ_HIP(hipMemcpy(p->d_hblocks, gb.data(), gb.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
 
-    cz::DevBuf<RowBlock> d_kblocks;
-    cz::DevBuf<uint32_t> d_kchunk, keys_in, keys_out, idx_in, idx_out, d_keyptr, d_bad;
-    cz::DevBuf<char> d_tmp;
+    PoolBuf<RowBlock> d_kblocks;
+    PoolBuf<uint32_t> d_kchunk, keys_in, keys_out, idx_in, idx_out, d_keyptr, d_bad;
+    PoolBuf<char> d_tmp;
     CZ_HIP(d_kblocks.alloc(key_blocks.size()));
     CZ_HIP(d_kchunk.alloc(key_blocks.size()));
     CZ_HIP(hipMemcpy(d_kblocks.p, key_blocks.data(), key_blocks.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
@@ -1163,7 +1201,7 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     StageTimer st_plan;
     {
         const uint32_t heavy = (uint32_t)std::max(0, env_int("CZ_PR_HEAVY", (int)kHeavyRowDefault));
-        cz::DevBuf<uint32_t> counts;
+        PoolBuf<uint32_t> counts;
         uint32_t h_counts[2] = {0, 0};
         if (heavy > 0 && rows > 0) {
             CZ_HIP(counts.alloc(2));
@@ -1177,9 +1215,10 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
         const uint32_t n_empty = drop_empty ? h_counts[1] : 0;
         if ((n_heavy > 0 || n_empty > 0) && n_heavy + n_empty < rows) {
             const uint32_t n_light = rows - n_heavy - n_empty;
-            cz::DevBuf<uint32_t> f_light, f_heavy, f_empty, p_light, p_heavy, p_empty, hkey_in, hkey_out, hrow_in, new_len, new_off, new_src;
-            cz::DevBuf<char> tmp;
-            for (cz::DevBuf<uint32_t> *b3 : {&f_light, &f_heavy, &f_empty, &p_light, &p_heavy, &p_empty}) CZ_HIP(b3->alloc(rows));
+            PoolBuf<uint32_t> f_light, f_heavy, f_empty, p_light, p_heavy, p_empty, hkey_in, hkey_out, hrow_in, new_len;
+            cz::DevBuf<uint32_t> new_off, new_src;  // these two become the plan's CSR
+            PoolBuf<char> tmp;
+            for (PoolBuf<uint32_t> *b3 : {&f_light, &f_heavy, &f_empty, &p_light, &p_heavy, &p_empty}) CZ_HIP(b3->alloc(rows));
             CZ_HIP(hkey_in.alloc(n_heavy));
             CZ_HIP(hkey_out.alloc(n_heavy));
             CZ_HIP(hrow_in.alloc(n_heavy));
@@ -1389,8 +1428,8 @@ namespace {
 int run_plan(cz_pagerank_plan *plan, double tolerance, uint32_t max_iter, float *scores, uint32_t *iters_run,
              double *final_err, const volatile uint8_t *poison, cz_pagerank_timing *tm) {
     const uint32_t N = plan->N;
-    cz::DevBuf<float> c0, c1;
-    cz::DevBuf<double> derr;
+    PoolBuf<float> c0, c1;  // (freed in stream order behind the last kernel that uses them)
+    PoolBuf<double> derr;
     CZ_HIP(c0.alloc(N));
     CZ_HIP(c1.alloc(N));
     CZ_HIP(derr.alloc(1));
