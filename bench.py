@@ -276,6 +276,8 @@ def hnsw_secondary(args, torch, device, n, kind, steps, warmup):
         ef, rec, sweep = run.pick_ef(gt64)
         t = run.timed(ef, steps, warmup)
         log(f"hnsw {n} x {args.dim} ({kind}): ef sweep {sweep} -> ef = {ef}, recall = {rec:.4f}, {t['ms_per_step']:.3f} ms/batch")
+        if kind == "lowrank" and n == 1_000_000:
+            t["roofline"]["traffic"] = pmc_traffic("hnsw_knn_1m", 1, t["roofline"]["algorithmic_bytes_per_launch"])
         return dict(workload=f"HNSW k={args.k} cosine, {n} x {args.dim} f32 ({kind}), query batch={args.batch}, m={args.m}, "
                              f"ef_construction={args.ef_construction}", value=args.batch * steps / t["wall"], unit="queries/s",
                     ms_per_step=t["ms_per_step"], ef=ef, recall_at_k=rec, reached_recall_target=rec >= args.recall_target,
@@ -795,7 +797,7 @@ def bench_graph_rules(args, torch, device):
         r = fn()
         return r, time.perf_counter() - t0
 
-    def entry(dt, edges, algorithmic_bytes, **extra):
+    def entry(dt, edges, algorithmic_bytes, pmc_key=None, **extra):
         """one rule's object: wall of the host-pointer call, its split by the library's own clock (cz_graph_last_timing), and
         the device part against the HBM roofline of the rule's algorithmic bytes (a lower bound no schedule reaches: every
         rule here is bound by 4- / 8-byte random accesses to per-node arrays)"""
@@ -804,16 +806,16 @@ def bench_graph_rules(args, torch, device):
         return dict(wall_ms=dt * 1e3, upload_ms=up, device_ms=devms, download_ms=down, edges_per_s=edges / dt,
                     edges_per_s_device=edges / (devms * 1e-3) if devms > 0 else None, algorithmic_bytes=algorithmic_bytes,
                     roofline=dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS if gbs else None,
-                                  traffic=None), **extra)
+                                  traffic=pmc_traffic(pmc_key, 1, algorithmic_bytes) if pmc_key and n == 10_000_000 else None), **extra)
 
     (par, dep, _, _), dt = timed(lambda: G.bfs(ooff, otgt, starts, want_depth=True))
     reached = int((dep[0] != 0xFFFFFFFF).sum())
-    out["bfs"] = entry(dt, E, 4 * E + 4 * (n + 1) + 12 * n, reached=reached, levels=int(dep[0][dep[0] != 0xFFFFFFFF].max()))
+    out["bfs"] = entry(dt, E, 4 * E + 4 * (n + 1) + 12 * n, pmc_key="bfs", reached=reached, levels=int(dep[0][dep[0] != 0xFFFFFFFF].max()))
     (grp, k), dt = timed(lambda: G.connected_components(uoff, utgt))
     out["connected_components"] = entry(dt, int(utgt.size), 4 * int(utgt.size) + 4 * (n + 1) + 4 * n, components=int(k))
     (dist, _), dt = timed(lambda: G.sssp(ooff, otgt, w, starts))
     fin = np.isfinite(dist[0])
-    out["sssp"] = entry(dt, E, 8 * E + 4 * (n + 1) + 12 * n, reached=int(fin.sum()), max_cost=float(dist[0][fin].max()))
+    out["sssp"] = entry(dt, E, 8 * E + 4 * (n + 1) + 12 * n, pmc_key="sssp", reached=int(fin.sum()), max_cost=float(dist[0][fin].max()))
     # the same three rules on a graph the library already holds under the caller's (relation, snapshot) key (cz_graph_acquire:
     # what a second FixedRule::run on an unchanged stored relation costs)
     def held(key, off_, tgt_, w_, fn):

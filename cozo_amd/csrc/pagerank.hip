@@ -886,7 +886,22 @@ struct PoolBuf {
         if (e != hipSuccess) p = nullptr;
         return e;
     }
+    T *release() {
+        T *r = p;
+        p = nullptr;
+        return r;
+    }
 };
+
+// the plan's own arrays come from the same pool (a plan of the 10M / 100M graph holds 1.5 GB: creating and destroying one
+// through hipMalloc / hipFree cost tens of milliseconds of driver time)
+hipError_t plan_alloc(void **p, size_t bytes) {
+    pool_keep_freed_memory();
+    return hipMallocAsync(p, std::max<size_t>(1, bytes), nullptr);
+}
+void plan_free(void *p) {
+    if (p) (void)hipFreeAsync(p, nullptr);
+}
 
 // CZ_PR_PLAN_TRACE=1: where the plan build's time goes, stage by stage, on stderr (scratch/ experiments)
 struct StageTimer {
@@ -940,8 +955,8 @@ struct cz_pagerank_plan {
     ~cz_pagerank_plan() {
         void *ps[] = {d_gblocks, d_hblocks, d_bblocks, d_items, d_asrc, d_perm, d_vpos, d_seg, d_val, d_off, d_src, d_outdeg, d_scores,
                       d_partial, d_rowid};
-        for (void *p : ps)
-            if (p) (void)hipFree(p);
+        (void)hipDeviceSynchronize();  // (what hipFree did implicitly: nothing of this plan is in flight any more)
+        for (void *p : ps) plan_free(p);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (side) (void)hipStreamDestroy(side);
@@ -1019,9 +1034,9 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
     std::vector<uint32_t> key_chunk(chunk_of);
     key_chunk.resize(key_blocks.size(), CZ_NONE);
 
-    CZ_HIP(hipMalloc((void **)&p->d_bblocks, std::max<size_t>(1, bb.size()) * sizeof(RowBlock)));
+    CZ_HIP(plan_alloc((void **)&p->d_bblocks, std::max<size_t>(1, bb.size()) * sizeof(RowBlock)));
     if (!bb.empty()) CZ_HIP(hipMemcpy(p->d_bblocks, bb.data(), bb.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
-    CZ_HIP(hipMalloc((void **)&p->d_hblocks, std::max<size_t>(1, gb.size()) * sizeof(RowBlock)));
+    CZ_HIP(plan_alloc((void **)&p->d_hblocks, std::max<size_t>(1, gb.size()) * sizeof(RowBlock)));
     if (!gb.empty()) CZ_HIP(hipMemcpy(p->d_hblocks, gb.data(), gb.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
 
     PoolBuf<RowBlock> d_kblocks;
@@ -1063,7 +1078,7 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
     hipLaunchKernelGGL(pb_check_sorted_kernel, dim3(2048), dim3(256), 0, nullptr, keys_out.p, idx_out.p, EB, d_bad.p);
     // phase-A streams (padded to a multiple of 8 entries plus one vector so that aligned 16-byte loads stay inside)
     const size_t padded = (((size_t)EB + 7) & ~(size_t)7) + 8;
-    CZ_HIP(hipMalloc((void **)&p->d_asrc, padded * 2));
+    CZ_HIP(plan_alloc((void **)&p->d_asrc, padded * 2));
     CZ_HIP(hipMemset(p->d_asrc, 0, padded * 2));
     // value stream: with more than one chunk the chunks can share ONE buffer (each chunk's expand output is
     // consumed by its reduce before the next chunk starts), which keeps it resident in the Infinity Cache
@@ -1080,10 +1095,10 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
             }
             need = ((need + 7) & ~(size_t)7) + 8;
         }
-        CZ_HIP(hipMalloc((void **)&p->d_val, need * 4));
+        CZ_HIP(plan_alloc((void **)&p->d_val, need * 4));
     }
-    CZ_HIP(hipMalloc((void **)&p->d_perm, std::max<uint64_t>(1, E) * 2));
-    CZ_HIP(hipMalloc((void **)&p->d_seg, std::max<size_t>(1, bb.size()) * ((size_t)S + 1) * sizeof(uint2)));
+    CZ_HIP(plan_alloc((void **)&p->d_perm, std::max<uint64_t>(1, E) * 2));
+    CZ_HIP(plan_alloc((void **)&p->d_seg, std::max<size_t>(1, bb.size()) * ((size_t)S + 1) * sizeof(uint2)));
     if (EB) hipLaunchKernelGGL(pb_asrc_kernel, dim3(4096), dim3(256), 0, nullptr, idx_out.p, p->d_src, EB, (1u << wlog) - 1, p->d_asrc);
     if (!bb.empty()) {
         const uint64_t pairs = (uint64_t)bb.size() * S;
@@ -1097,7 +1112,7 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
         const int flat_env = env_int("CZ_PR_FLAT", -1);
         const bool flat = flat_env >= 0 ? flat_env != 0 : (uint64_t)kBTileNnz < 20ull * S;
         if (flat && n_chunks == 1) {
-            CZ_HIP(hipMalloc((void **)&p->d_vpos, std::max<uint64_t>(1, E) * 4));
+            CZ_HIP(plan_alloc((void **)&p->d_vpos, std::max<uint64_t>(1, E) * 4));
             hipLaunchKernelGGL(pb_vpos_kernel, dim3((uint32_t)bb.size()), dim3(256), 0, nullptr, p->d_bblocks, p->d_seg, S, p->d_vpos);
         }
     }
@@ -1123,12 +1138,12 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
         }
         p->item_ptr.push_back((uint32_t)items.size());
     }
-    CZ_HIP(hipMalloc((void **)&p->d_items, std::max<size_t>(1, items.size()) * sizeof(AItem)));
+    CZ_HIP(plan_alloc((void **)&p->d_items, std::max<size_t>(1, items.size()) * sizeof(AItem)));
     if (!items.empty()) CZ_HIP(hipMemcpy(p->d_items, items.data(), items.size() * sizeof(AItem), hipMemcpyHostToDevice));
     CZ_HIP(hipDeviceSynchronize());
     st.lap("phase-A items (host)");
     if (gb.empty()) {  // the global ids are only needed by the hub rows' gather
-        (void)hipFree(p->d_src);
+        plan_free(p->d_src);
         p->d_src = nullptr;
     }
     p->blocked = true;
@@ -1177,10 +1192,10 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     p->init = N ? 1.0f / (float)N : 0.f;
     p->base = N ? (1.0f - damping) / (float)N : 0.f;
     const auto t_h2d = std::chrono::steady_clock::now();
-    CZ_HIP(hipMalloc((void **)&p->d_off, ((size_t)rows + 1) * 4));
-    CZ_HIP(hipMalloc((void **)&p->d_src, std::max<uint64_t>(1, E) * 4));
-    CZ_HIP(hipMalloc((void **)&p->d_outdeg, std::max<size_t>(1, N) * 4));
-    CZ_HIP(hipMalloc((void **)&p->d_scores, std::max<size_t>(1, rows) * 4));
+    CZ_HIP(plan_alloc((void **)&p->d_off, ((size_t)rows + 1) * 4));
+    CZ_HIP(plan_alloc((void **)&p->d_src, std::max<uint64_t>(1, E) * 4));
+    CZ_HIP(plan_alloc((void **)&p->d_outdeg, std::max<size_t>(1, N) * 4));
+    CZ_HIP(plan_alloc((void **)&p->d_scores, std::max<size_t>(1, rows) * 4));
     if (rows) CZ_HIP(hipMemcpy(p->d_off, dev ? dev_off : in_offsets, ((size_t)rows + 1) * 4, up));
     else {
         uint32_t z = 0;
@@ -1216,7 +1231,7 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
         if ((n_heavy > 0 || n_empty > 0) && n_heavy + n_empty < rows) {
             const uint32_t n_light = rows - n_heavy - n_empty;
             PoolBuf<uint32_t> f_light, f_heavy, f_empty, p_light, p_heavy, p_empty, hkey_in, hkey_out, hrow_in, new_len;
-            cz::DevBuf<uint32_t> new_off, new_src;  // these two become the plan's CSR
+            PoolBuf<uint32_t> new_off, new_src;  // these two become the plan's CSR
             PoolBuf<char> tmp;
             for (PoolBuf<uint32_t> *b3 : {&f_light, &f_heavy, &f_empty, &p_light, &p_heavy, &p_empty}) CZ_HIP(b3->alloc(rows));
             CZ_HIP(hkey_in.alloc(n_heavy));
@@ -1225,7 +1240,7 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
             CZ_HIP(new_len.alloc((size_t)rows + 1));
             CZ_HIP(new_off.alloc((size_t)rows + 1));
             CZ_HIP(new_src.alloc(std::max<uint64_t>(1, E)));
-            CZ_HIP(hipMalloc((void **)&p->d_rowid, (size_t)rows * 4));
+            CZ_HIP(plan_alloc((void **)&p->d_rowid, (size_t)rows * 4));
             hipLaunchKernelGGL(pr_row_class_kernel, dim3(2048), dim3(256), 0, nullptr, p->d_off, rows, heavy, drop_empty ? 1 : 0,
                                f_light.p, f_heavy.p, f_empty.p, (uint32_t *)nullptr);
             size_t tb = 0, need = 0;
@@ -1264,8 +1279,8 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
             if (perm_off[rows] != E) return cz::set_error(CZ_E_HIP, "internal: the reordered rows hold %u edges, expected %llu", perm_off[rows], (unsigned long long)E);
             p->n_empty = n_empty;
             p->n_eblocks = (n_empty + kERowsPerBlock - 1) / kERowsPerBlock;
-            (void)hipFree(p->d_off);
-            (void)hipFree(p->d_src);
+            plan_free(p->d_off);
+            plan_free(p->d_src);
             p->d_off = new_off.release();
             p->d_src = new_src.release();
             in_offsets = perm_off.data();
@@ -1299,12 +1314,12 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
         for (const RowBlock &rb : all) (rb.e1 - rb.e0 > (uint32_t)kGTileNnz ? hubs : blocks).push_back(rb);
         p->n_gblocks = (uint32_t)blocks.size();
         p->n_hblocks = (uint32_t)hubs.size();
-        CZ_HIP(hipMalloc((void **)&p->d_gblocks, std::max<size_t>(1, blocks.size()) * sizeof(RowBlock)));
+        CZ_HIP(plan_alloc((void **)&p->d_gblocks, std::max<size_t>(1, blocks.size()) * sizeof(RowBlock)));
         if (!blocks.empty()) CZ_HIP(hipMemcpy(p->d_gblocks, blocks.data(), blocks.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
-        CZ_HIP(hipMalloc((void **)&p->d_hblocks, std::max<size_t>(1, hubs.size()) * sizeof(RowBlock)));
+        CZ_HIP(plan_alloc((void **)&p->d_hblocks, std::max<size_t>(1, hubs.size()) * sizeof(RowBlock)));
         if (!hubs.empty()) CZ_HIP(hipMemcpy(p->d_hblocks, hubs.data(), hubs.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
     }
-    CZ_HIP(hipMalloc((void **)&p->d_partial, std::max<size_t>(1, (size_t)p->n_bblocks + p->n_gblocks + p->n_hblocks + p->n_eblocks) * 8));
+    CZ_HIP(plan_alloc((void **)&p->d_partial, std::max<size_t>(1, (size_t)p->n_bblocks + p->n_gblocks + p->n_hblocks + p->n_eblocks) * 8));
     CZ_HIP(hipDeviceSynchronize());
     p->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
     *out = p.release();
