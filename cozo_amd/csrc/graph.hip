@@ -2419,6 +2419,29 @@ int check_shard(const uint32_t *off, const uint32_t *tgt, uint32_t N, uint32_t r
     if (off[0] != 0 || off[re - rb] != e_local) return cz::set_error(CZ_E_INVALID, "offsets must be relative to the shard and end at E_local");
     if (e_local > 0 && !tgt) return cz::set_error(CZ_E_INVALID, "null targets");
     if (e_local >= 0xFFFFFFFFull) return cz::set_error(CZ_E_UNSUPPORTED, "a shard holds fewer than 2^32-1 edges");
+    // the kernels index full-length per-node arrays by the targets (prop[v], claim[v], comp[v]) and walk [off[r], off[r+1]):
+    // both are checked here, on the host arrays the caller handed over
+    for (uint32_t r = 0; r < re - rb; r++)
+        if (off[r + 1] < off[r]) return cz::set_error(CZ_E_INVALID, "offsets not monotone at local row %u", r);
+    for (uint64_t e = 0; e < e_local; e++)
+        if (tgt[e] >= N) return cz::set_error(CZ_E_INVALID, "target %u of local edge %llu is out of range (N = %u)", tgt[e], (unsigned long long)e, N);
+    return CZ_OK;
+}
+
+// A rank that rejected its shard (or could not allocate) must not leave the others blocked in the loop's first collective:
+// every rank reports its status, the sum is all-reduced, and all of them leave together.
+int collective_status(cz_comm *comm, int mine) {
+    if (cz::comm_world(comm) <= 1) return mine;
+    const std::string my_msg = mine ? std::string(cz_last_error()) : std::string();
+    cz::DevBuf<uint32_t> d;
+    uint32_t h = mine ? 1u : 0u;
+    if (d.alloc(1) != hipSuccess) return mine ? mine : cz::set_error(CZ_E_OOM, "out of device memory");
+    if (hipMemcpy(d.p, &h, 4, hipMemcpyHostToDevice) != hipSuccess) return mine ? mine : cz::set_error(CZ_E_HIP, "status upload failed");
+    int rc = cz::comm_all_reduce(comm, d.p, 1, cz::COMM_U32, cz::COMM_SUM, nullptr);
+    if (rc) return mine ? mine : rc;
+    if (hipMemcpy(&h, d.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return mine ? mine : cz::set_error(CZ_E_HIP, "status download failed");
+    if (mine) return cz::set_error(mine, "%s", my_msg.c_str());
+    if (h) return cz::set_error(CZ_E_INVALID, "%u other rank(s) rejected their shard of this call", h);
     return CZ_OK;
 }
 
@@ -2433,7 +2456,7 @@ extern "C" int cz_bfs_sharded(cz_comm *comm, const uint32_t *out_offsets_local, 
     if (rc) return rc;
     if (n_starts == 0 || N == 0) return CZ_OK;
     if (!starts || !parent) return cz::set_error(CZ_E_INVALID, "null starts/parent");
-    if ((rc = check_shard(out_offsets_local, out_targets, N, row_begin, row_end, E_local))) return rc;
+    rc = check_shard(out_offsets_local, out_targets, N, row_begin, row_end, E_local);
     HipShardedBfs b;
     b.comm = comm;
     b.s = nullptr;
@@ -2442,7 +2465,8 @@ extern "C" int cz_bfs_sharded(cz_comm *comm, const uint32_t *out_offsets_local, 
     b.re = row_end;
     b.goals_host = goals;
     b.n_goals = goals ? n_goals : 0;
-    if ((rc = b.alloc(out_offsets_local, out_targets, E_local))) return rc;
+    if (!rc) rc = b.alloc(out_offsets_local, out_targets, E_local);
+    if ((rc = collective_status(comm, rc))) return rc;
     for (uint32_t si = 0; si < n_starts; si++) {
         uint32_t reached = 0;
         const bool skip = goals && n_goals == 0;  // nothing pending: the reference discovers nothing useful
@@ -2471,19 +2495,20 @@ extern "C" int cz_sssp_sharded(cz_comm *comm, const uint32_t *out_offsets_local,
     if (rc) return rc;
     if (n_starts == 0 || N == 0) return CZ_OK;
     if (!starts || !dist || !parent) return cz::set_error(CZ_E_INVALID, "null starts/dist/parent");
-    if ((rc = check_shard(out_offsets_local, out_targets, N, row_begin, row_end, E_local))) return rc;
-    if (E_local > 0 && !weights) return cz::set_error(CZ_E_INVALID, "null weights");
-    for (uint64_t e = 0; e < E_local; e++)
+    rc = check_shard(out_offsets_local, out_targets, N, row_begin, row_end, E_local);
+    if (!rc && E_local > 0 && !weights) rc = cz::set_error(CZ_E_INVALID, "null weights");
+    for (uint64_t e = 0; !rc && e < E_local; e++)
         if (!(weights[e] >= 0.0f))
-            return cz::set_error(CZ_E_INVALID, "edge %llu has weight %g: weights must be non-negative numbers", (unsigned long long)e,
-                                 (double)weights[e]);
+            rc = cz::set_error(CZ_E_INVALID, "edge %llu has weight %g: weights must be non-negative numbers", (unsigned long long)e,
+                               (double)weights[e]);
     HipShardedSssp b;
     b.comm = comm;
     b.s = nullptr;
     b.N = N;
     b.rb = row_begin;
     b.re = row_end;
-    if ((rc = b.alloc(out_offsets_local, out_targets, weights, E_local))) return rc;
+    if (!rc) rc = b.alloc(out_offsets_local, out_targets, weights, E_local);
+    if ((rc = collective_status(comm, rc))) return rc;
     for (uint32_t si = 0; si < n_starts; si++) {
         rc = czs::run_sharded_sssp(b, starts[si], N, poison);
         if (rc == czs::TRAVERSAL_CANCELLED) return cz::set_error(CZ_E_CANCELLED, "cancelled");
@@ -2599,16 +2624,15 @@ extern "C" int cz_connected_components_sharded(cz_comm *comm, const uint32_t *of
     if (rc) return rc;
     if (N == 0) return CZ_OK;
     if (!group) return cz::set_error(CZ_E_INVALID, "null group");
-    if ((rc = check_shard(offsets_local, targets, N, row_begin, row_end, E_local))) return rc;
-    for (uint64_t e = 0; e < E_local; e++)
-        if (targets[e] >= N) return cz::set_error(CZ_E_INVALID, "target %u out of range", targets[e]);
+    rc = check_shard(offsets_local, targets, N, row_begin, row_end, E_local);
     HipShardedCc b;
     b.comm = comm;
     b.s = nullptr;
     b.N = N;
     b.rb = row_begin;
     b.re = row_end;
-    if ((rc = b.alloc(offsets_local, targets, E_local))) return rc;
+    if (!rc) rc = b.alloc(offsets_local, targets, E_local);
+    if ((rc = collective_status(comm, rc))) return rc;
     rc = czs::run_sharded_cc(b, poison, rounds);
     if (rc == czs::TRAVERSAL_CANCELLED) return cz::set_error(CZ_E_CANCELLED, "cancelled");
     if (rc) return rc;

@@ -381,7 +381,18 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
         if (ix->vec) (void)hipFree(ix->vec);
         ix->vec = guard.release();
     }
-    // levels: caller-supplied (non-negative = -layer) or drawn here: floor(-ln(U) / ln(m)), hnsw.rs:46-52
+    // levels: caller-supplied (non-negative = -layer) or drawn here: floor(-ln(U) / ln(m)), hnsw.rs:46-52.
+    // Until the build has gone through, the handle must stay what it was: a failure further down (a bad level, an
+    // allocation, a launch) would otherwise leave ix->n == n_old beside a level table of n entries, and every later
+    // cz_hnsw_remove would refuse the handle ("level table out of step").  The vector buffer swapped above only grew.
+    struct TopGuard {
+        std::vector<int32_t> &top;
+        size_t n_old;
+        bool keep = false;
+        ~TopGuard() {
+            if (!keep) top.resize(n_old);
+        }
+    } top_guard{ix->top, n_old};
     ix->top.resize(n);
     if (levels) {
         for (uint32_t i = 0; i < n_new; i++) {
@@ -621,6 +632,7 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
     ix->up_nbrs = new_up;
     ix->up_base = b_upbase.release();
     ix->n = n;
+    top_guard.keep = true;
     ix->w0 = w0;
     ix->wu = wu;
     ix->up_rows = rows;

@@ -52,6 +52,14 @@ class HnswSearch:
     has_filter: bool = False  # a filter keeps all ef candidates until after filtering (hnsw.rs:943-947)
 
 
+def _refuse_shared_rows(row_of):
+    if row_of is None:
+        return
+    r = np.asarray(row_of)
+    if r.size and np.unique(r).size != r.size:
+        raise _lib.CozoGpuError(_lib.CZ_E_UNSUPPORTED, "rows carrying several indexed vectors are not built on the GPU")
+
+
 class GpuHnswIndex:
     """A device-resident flat export of one `tbl:idx` relation (see include/cozo_gpu.h cz_hnsw_desc)."""
 
@@ -79,14 +87,18 @@ class GpuHnswIndex:
 
     @classmethod
     def build(cls, manifest: HnswIndexManifest, vectors, levels: Optional[np.ndarray] = None, seed: int = 0,
-              max_batch: int = 0, device_ptr: bool = False, n: Optional[int] = None, stream: int = 0):
+              max_batch: int = 0, device_ptr: bool = False, n: Optional[int] = None, stream: int = 0, row_of=None):
         """`::hnsw create` on the GPU (create_hnsw_index, runtime/relation.rs:1010-1201 -> hnsw_put per row):
         batch-parallel insertion of all vectors in key order.  `vectors` is a host array, or (device_ptr=True) a
-        device tensor / pointer with `n` rows.  Returns the index; `.last_build_n_dist` holds the distance count."""
+        device tensor / pointer with `n` rows.  Returns the index; `.last_build_n_dist` holds the distance count.
+        row_of: the base row each vector comes from (index_nodes gives it).  The reference never links two vectors of one row
+        (hnsw_get_neighbours drops them, hnsw.rs:609-610); the device build has no such rule, so rows carrying several indexed
+        vectors are refused here exactly as the C++ mirror refuses them (the shim falls back to the CPU path)."""
         if manifest.dtype != "F32":
             raise _lib.CozoGpuError(_lib.CZ_E_UNSUPPORTED, "only F32 vector indices are GPU-resident")
         if manifest.extend_candidates:
             raise _lib.CozoGpuError(_lib.CZ_E_UNSUPPORTED, "extend_candidates is not supported by the GPU build")
+        _refuse_shared_rows(row_of)
         self = cls.__new__(cls)
         self.manifest = manifest
         if device_ptr:
@@ -118,13 +130,14 @@ class GpuHnswIndex:
         r = np.ascontiguousarray(key_rank, dtype=np.uint32)
         check(_lib.lib().cz_hnsw_set_key_order(self._h, ptr(r), r.size))
 
-    def insert(self, vectors, levels: Optional[np.ndarray] = None, seed: int = 0, max_batch: int = 0, key_rank=None):
+    def insert(self, vectors, levels: Optional[np.ndarray] = None, seed: int = 0, max_batch: int = 0, key_rank=None, row_of=None):
         """hnsw_put for more rows on a later write (stored.rs:431-450 -> hnsw.rs:679-727): the vectors become nodes
         n .. n + len - 1 of this index (cz_hnsw_insert).  key_rank: see set_key_order -- needed when the new rows' keys do
         not all sort behind the existing ones."""
         v = np.ascontiguousarray(vectors, dtype=np.float32)
         if v.ndim != 2 or v.shape[1] != self.manifest.vec_dim:
             raise ValueError("vectors must be [n][vec_dim]")
+        _refuse_shared_rows(row_of)  # (rows of the NEW vectors; see build)
         if key_rank is not None:
             if len(key_rank) != self.n + v.shape[0]:
                 raise ValueError("key_rank must cover the nodes held and the ones inserted")

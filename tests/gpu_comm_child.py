@@ -118,6 +118,27 @@ def main():
     g2, k2 = connected_components_multi(gu["ooff"], gu["otgt"], 1)
     assert k2 == k0 and np.array_equal(g2, g0), "cz_connected_components_multi differs"
     print("OK bfs_multi / sssp_multi / connected_components_multi", flush=True)
+    # a shard whose targets point outside the graph, or whose offsets go backwards, is refused on the host arrays (the kernels
+    # index full-length per-node arrays by the targets)
+    bad_t = gw["otgt"].copy()
+    bad_t[5] = gw["n"] + 7
+    bad_o = gw["ooff"].copy()
+    row = int(np.flatnonzero(np.diff(bad_o.astype(np.int64)) > 0)[3])  # a row with edges: its end pulled below its start
+    bad_o[row + 1] = bad_o[row] - 1 if bad_o[row] > 0 else 0
+    if bad_o[row + 1] >= bad_o[row]:
+        bad_o[row] += 2
+    for off_, tgt_ in ((gw["ooff"], bad_t), (bad_o, gw["otgt"])):
+        if np.array_equal(off_, gw["ooff"]) and np.array_equal(tgt_, gw["otgt"]):
+            continue
+        for call in (lambda: bfs_sharded(comm, off_, tgt_, gw["n"], 0, gw["n"], starts),
+                     lambda: sssp_sharded(comm, off_, tgt_, gw["ow"], gw["n"], 0, gw["n"], starts),
+                     lambda: connected_components_sharded(comm, off_, tgt_, gw["n"], 0, gw["n"])):
+            try:
+                call()
+                raise AssertionError("a malformed shard must be refused")
+            except _lib.CozoGpuError as e:
+                assert "out of range" in str(e) or "monotone" in str(e), str(e)
+    print("OK malformed shards refused", flush=True)
     comm.close()
     print("ALL OK", flush=True)
 
