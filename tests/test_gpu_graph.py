@@ -272,6 +272,29 @@ def test_clustering_coefficients_bitexact(oracle, gpu_lib):
     tri, deg = G.clustering_coefficients(g["ooff"], g["otgt"])
     _, otri, odeg = oracle.clustering_coefficients(g["n"], g["ooff"], g["otgt"])
     assert np.array_equal(tri, otri) and np.array_equal(deg, odeg) and tri.max() == n - 2
+    # no self loops: the oriented kernel (every triangle found once from its smallest corner, all three corners credited
+    # with the reference's multiplicities) -- against the oracle and against the general kernel
+    import os
+    for n, e, seed in [(50, 200, 4), (3000, 60000, 5), (20000, 150000, 6)]:
+        frm, to = util.random_relation(n, e, seed)
+        frm, to = np.concatenate([frm, to[: e // 7]]), np.concatenate([to, frm[: e // 7]])  # pairs linked in both directions: multiplicity 2
+        g = util.graph_from_relation(oracle, frm, to, undirected=True)
+        tri, deg = G.clustering_coefficients(g["ooff"], g["otgt"])
+        _, otri, odeg = oracle.clustering_coefficients(g["n"], g["ooff"], g["otgt"])
+        assert np.array_equal(tri, otri) and np.array_equal(deg, odeg) and tri.sum() > 0
+        os.environ["CZ_TRI_GENERAL"] = "1"
+        try:
+            tri2, _ = G.clustering_coefficients(g["ooff"], g["otgt"])
+        finally:
+            del os.environ["CZ_TRI_GENERAL"]
+        assert np.array_equal(tri2, otri)
+    # an adjacency that is NOT symmetric (not what the rule passes, but what the entry point accepts): the sample test notices
+    # and the general kernel answers -- the reference's count is defined on any graph
+    frm, to = util.random_relation(2000, 30000, 7)
+    g = util.graph_from_relation(oracle, frm, to)  # directed
+    tri, deg = G.clustering_coefficients(g["ooff"], g["otgt"])
+    _, otri, odeg = oracle.clustering_coefficients(g["n"], g["ooff"], g["otgt"])
+    assert np.array_equal(tri, otri) and np.array_equal(deg, odeg)
 
 
 def test_sssp_costs_bitexact(oracle, gpu_lib):
