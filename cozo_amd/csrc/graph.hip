@@ -261,10 +261,13 @@ bfs_emit_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ t
 // the passes that read the list; `*n_slots` is the number of slots handed out.
 constexpr uint32_t kBfsChunk = 256;
 constexpr int kBfsNodes = 4;  // frontier nodes a lane group works on at once
+constexpr uint32_t kBfsLongList = 4096;  // adjacency lists beyond this are cut over workgroups (a 454k-edge hub walked by one
+                                         // 16-lane group was 60 of the 64 ms of a BFS on the skewed test graph)
 __global__ void __launch_bounds__(kT)
 bfs_discover_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
                     uint32_t fsize, const uint32_t *__restrict__ vis, uint32_t *__restrict__ claim,
-                    uint32_t *__restrict__ fresh, uint32_t *__restrict__ n_slots) {
+                    uint32_t *__restrict__ fresh, uint32_t *__restrict__ n_slots, uint32_t *__restrict__ long_nodes,
+                    uint32_t *__restrict__ n_long) {
     const int lane = threadIdx.x & 63;
     const uint32_t glane = threadIdx.x & (kBfsLanes - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kBfsLanes, ngroups = gridDim.x * blockDim.x / kBfsLanes;
@@ -306,6 +309,10 @@ bfs_discover_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict
             const uint32_t u = e0[k];
             e0[k] = u != CZ_NONE ? off[u] : 0;
             e1[k] = u != CZ_NONE ? off[u + 1] : 0;
+            if (e1[k] - e0[k] > kBfsLongList) {  // a hub: its list goes to bfs_discover_long_kernel, cut over workgroups
+                if (glane == 0) long_nodes[atomicAdd(n_long, 1u)] = i[k];
+                e1[k] = e0[k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < kBfsNodes; k++) v[k] = e0[k] + glane < e1[k] ? tgt[e0[k] + glane] : CZ_NONE;
@@ -332,6 +339,48 @@ bfs_discover_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict
     }
     if (w_used < kBfsChunk)  // (a wave that never listed a node holds no chunk: w_used == kBfsChunk)
         for (uint32_t k = w_used + lane; k < kBfsChunk; k += 64) fresh[w_base + k] = CZ_NONE;
+}
+
+// the lists set aside by bfs_discover_kernel: every workgroup takes stretches of kBfsLongList edges of every listed node
+__global__ void __launch_bounds__(kT)
+bfs_discover_long_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
+                         const uint32_t *__restrict__ long_nodes, const uint32_t *__restrict__ n_long, const uint32_t *__restrict__ vis,
+                         uint32_t *__restrict__ claim, uint32_t *__restrict__ fresh, uint32_t *__restrict__ n_slots) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t nl = *n_long;
+    uint32_t w_base = 0, w_used = kBfsChunk;
+    for (uint32_t k = 0; k < nl; k++) {
+        const uint32_t i = long_nodes[k], u = frontier[i];
+        const uint32_t e0 = off[u], e1 = off[u + 1];
+        for (uint32_t s0 = e0 + blockIdx.x * kBfsLongList; s0 < e1; s0 += gridDim.x * kBfsLongList) {
+            const uint32_t s1 = min(e1, s0 + kBfsLongList);
+            for (uint32_t b = s0; b < s1; b += kT) {  // (uniform trip count over the workgroup's waves)
+                const uint32_t e = b + threadIdx.x;
+                bool first = false;
+                uint32_t v = 0;
+                if (e < s1) {
+                    v = tgt[e];
+                    first = !((vis[v >> 5] >> (v & 31)) & 1u) && atomicMin(&claim[v], i) == CZ_NONE;
+                }
+                const unsigned long long m = __ballot(first);
+                if (m) {
+                    const uint32_t cnt = (uint32_t)__popcll(m);
+                    if (w_used + cnt > kBfsChunk) {
+                        if (w_used < kBfsChunk)
+                            for (uint32_t q = w_used + lane; q < kBfsChunk; q += 64) fresh[w_base + q] = CZ_NONE;
+                        uint32_t nb = 0;
+                        if (lane == 0) nb = atomicAdd(n_slots, kBfsChunk);
+                        w_base = __builtin_amdgcn_readfirstlane(nb);
+                        w_used = 0;
+                    }
+                    if (first) fresh[w_base + w_used + __popcll(m & ((1ull << lane) - 1ull))] = v;
+                    w_used += cnt;
+                }
+            }
+        }
+    }
+    if (w_used < kBfsChunk)
+        for (uint32_t q = w_used + lane; q < kBfsChunk; q += 64) fresh[w_base + q] = CZ_NONE;
 }
 
 __global__ void __launch_bounds__(kT)
@@ -931,7 +980,7 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
     const uint32_t N = G.N;
     const uint64_t E = G.E;
     int rc = CZ_OK;
-    cz::DevBuf<uint32_t> d_depth, d_parent, d_claim, d_order, d_cnt, d_pos, d_scratch, d_goals, d_misc, d_vis, d_fresh, d_big;
+    cz::DevBuf<uint32_t> d_depth, d_parent, d_claim, d_order, d_cnt, d_pos, d_scratch, d_goals, d_misc, d_vis, d_fresh, d_big, d_long;
     cz::DevBuf<uint8_t> d_won;
     const size_t vis_words = ((size_t)N + 31) / 32;
     // CZ_BFS_PASSES=3: the round-2 level (claim / count / emit over the edge slots), kept for A/B runs and as what the
@@ -942,8 +991,10 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
     if (one_pass) {
         // every chunk but a wave's last is closed with fewer than 64 of its 256 slots unused; grid_for caps a launch at
         // 4096 workgroups of 4 waves
-        CZ_HIP(d_fresh.alloc(((size_t)N / (kBfsChunk - 63) + 4096 * (kT / 64) + 2) * kBfsChunk));
+        // every chunk but a wave's last is closed with fewer than 64 of its 256 slots unused; two kernels list per level
+        CZ_HIP(d_fresh.alloc(((size_t)N / (kBfsChunk - 63) + (4096 + 1024) * (kT / 64) + 2) * kBfsChunk));
         CZ_HIP(d_big.alloc(N));
+        CZ_HIP(d_long.alloc((size_t)E / kBfsLongList + 2));  // at most this many lists are longer than kBfsLongList
     } else {
         CZ_HIP(d_won.alloc(E));
     }
@@ -954,7 +1005,7 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
     CZ_HIP(d_cnt.alloc(N));
     CZ_HIP(d_pos.alloc(N));
     CZ_HIP(d_scratch.alloc(scan_scratch_words(N)));
-    CZ_HIP(d_misc.alloc(4));
+    CZ_HIP(d_misc.alloc(8));
     if (goals && n_goals) {
         CZ_HIP(d_goals.alloc(n_goals));
         CZ_HIP(hipMemcpy(d_goals.p, goals, (size_t)n_goals * 4, hipMemcpyHostToDevice));
@@ -991,11 +1042,13 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
                 const uint32_t *fr = d_order.p + lo;
                 const int g = grid_for((uint64_t)fsize * kBfsLanes);  // a 16-lane group per frontier node
                 if (one_pass) {
-                    // d_misc: [0] next frontier size (scan total), [1] goals left, [2] nodes listed, [3] long stretches
-                    CZ_HIP(hipMemsetAsync(d_misc.p + 2, 0, 8, s));
+                    // d_misc: [0] next frontier size (scan total), [1] goals left, [2] list slots, [3] long stretches, [4] long lists
+                    CZ_HIP(hipMemsetAsync(d_misc.p + 2, 0, 12, s));
                     CZ_HIP(hipMemsetAsync(d_cnt.p, 0, (size_t)fsize * 4, s));
                     hipLaunchKernelGGL(bfs_discover_kernel, dim3(g), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, fsize, d_vis.p, d_claim.p,
-                                       d_fresh.p, d_misc.p + 2);
+                                       d_fresh.p, d_misc.p + 2, d_long.p, d_misc.p + 4);
+                    hipLaunchKernelGGL(bfs_discover_long_kernel, dim3(1024), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, d_long.p, d_misc.p + 4,
+                                       d_vis.p, d_claim.p, d_fresh.p, d_misc.p + 2);
                     const int gf = grid_for(std::min<uint64_t>((uint64_t)N + N / 2, (uint64_t)fsize * 64 + 4096));  // (the slot count stays on the device)
                     hipLaunchKernelGGL(bfs_tally_kernel, dim3(gf), dim3(kT), 0, s, d_fresh.p, d_misc.p + 2, d_claim.p, d_cnt.p);
                     rc = exclusive_scan(d_cnt.p, d_pos.p, fsize, d_misc.p, d_scratch.p, s);

@@ -64,6 +64,13 @@ def main():
                    "slice staging = 360 MB are reported as 178 MiB), WRITE_SIZE as reported (392 MiB vs 400 MB known).  Every entry carries "
                    "the hash of the device sources it was measured on (bench.py PMC_SOURCES); bench.py reports traffic = null when they "
                    "have changed since, or when the launch's algorithmic bytes differ from the profiled launch's by more than 2 %."}
+    try:  # entries whose passes are not under round_dir this time stay as they are (bench.py checks their source hash)
+        with open(path) as f:
+            for k, v in json.load(f).items():
+                if k != "_how":
+                    out[k] = v
+    except Exception:  # noqa: BLE001
+        pass
     for key, sp in SPEC.items():
         parts, total, ok = {}, 0.0, True
         for counter, scale in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
@@ -78,7 +85,7 @@ def main():
                 parts[f"{k} {counter}"] = kib
                 total += kib * 1024.0 * scale
         if not ok:
-            print(f"{key}: no PMC rows under pmc_{sp['tag']}_*: entry left out")
+            print(f"{key}: no PMC rows under pmc_{sp['tag']}_*: entry left as it was")
             continue
         algo = sp["algo"] or algos.get(key)
         out[key] = dict(bytes_per_launch=int(total), parts_KiB={k: round(v, 1) for k, v in parts.items()}, algorithmic_bytes=algo,
