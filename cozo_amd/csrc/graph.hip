@@ -1294,10 +1294,28 @@ tri_self_loop_kernel(const uint32_t *__restrict__ off, const uint32_t *__restric
         if (csr_count(tgt, off[v], off[v + 1], v)) atomicAdd(found, 1u);
 }
 
-// A 16-lane group per node: a node of the 10M / 200M graph has ~10 neighbours above itself, i.e. ~45 pairs -- a wave per node
-// (first form: 14.4 ms) spent its time on the chain of dependent reads per node (offsets -> the split position -> the pair's
-// two neighbours -> the third list), not on the pairs; four nodes per wave keep four such chains in flight.
+// A 16-lane group per node.  Second form (a wave per node, every pair (c, b) a binary search in c's list): 14.4 ms -- a node of
+// the 10M / 200M graph has ~10 neighbours above itself, i.e. ~45 pairs x ~5 probes, and 2 x 10^9 probes through the L1 / L2
+// path are what that costs, wherever the lines come from.  Now c's list is loaded ONCE per (node, c), a lane per entry, and
+// rotated past the lanes (DPP row_ror:1 inside the 16-lane row): every lane holds one neighbour b of the node and counts how
+// often it meets it -- 2 loads and 48 register steps per list instead of 45 probe chains per node.  Nodes with more than
+// kTriMerge neighbours above themselves (hubs) keep the pair form, whose cost does not grow with the square of the list.
 constexpr int kTriLanes = 16;
+constexpr uint32_t kTriMerge = 256;
+
+__device__ __forceinline__ void tri_credit(const uint32_t *__restrict__ tgt, uint32_t a, uint32_t b, uint32_t v, uint32_t pi, uint32_t pj,
+                                           uint32_t m_bc, unsigned long long *__restrict__ n_tri) {
+    // pi / pj: FIRST positions of the neighbours c > bb > v in v's list; multiplicities = run lengths (pairs linked both ways)
+    const uint32_t c = tgt[pi], bb = tgt[pj];
+    uint32_t m_ac = 1, m_ab = 1;
+    while (pi + m_ac < b && tgt[pi + m_ac] == c) m_ac++;
+    while (pj + m_ab < b && tgt[pj + m_ab] == bb) m_ab++;
+    atomicAdd(&n_tri[v], (unsigned long long)m_ab * m_ac);
+    atomicAdd(&n_tri[bb], (unsigned long long)m_ab * m_bc);
+    atomicAdd(&n_tri[c], (unsigned long long)m_ac * m_bc);
+    (void)a;
+}
+
 __global__ void __launch_bounds__(256)
 triangles_oriented_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t N,
                           unsigned long long *__restrict__ n_tri /* zeroed */, uint32_t *__restrict__ degree) {
@@ -1314,7 +1332,36 @@ triangles_oriented_kernel(const uint32_t *__restrict__ off, const uint32_t *__re
             else h = mid;
         }
         const uint32_t m = b - s;
-        const unsigned long long P = (unsigned long long)m * (m - (m > 0)) / 2;
+        if (m < 2) continue;
+        if (m <= kTriMerge) {
+            for (uint32_t ca = 0; ca < m; ca += kTriLanes) {  // this lane's neighbour bb (first occurrences only)
+                const uint32_t pj = s + ca + glane;
+                const bool have = ca + glane < m;
+                const uint32_t bb = have ? tgt[pj] : CZ_NONE;
+                const bool first_b = have && !(pj > a && tgt[pj - 1] == bb);
+                // (group-uniform) the larger corner c, at a position behind the chunk's first: positions ascend with values, so a
+                // chunk that starts at or behind c's position holds nothing below c
+                for (uint32_t ci = ca + 1; ci < m; ci++) {
+                    const uint32_t pi = s + ci;
+                    const uint32_t c = tgt[pi];
+                    if (tgt[pi - 1] == c) continue;  // a repeated neighbour: its multiplicity is counted at its first position
+                    const bool want = first_b && bb < c;
+                    uint32_t cnt = 0;
+                    const uint32_t oc = off[c], oc1 = off[c + 1];
+                    for (uint32_t k = oc; k < oc1; k += kTriLanes) {
+                        uint32_t L = k + glane < oc1 ? tgt[k + glane] : CZ_NONE - 1u;
+#pragma unroll
+                        for (int r = 0; r < kTriLanes; r++) {
+                            cnt += L == bb ? 1u : 0u;
+                            L = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)L, 0x121 /* row_ror:1 */, 0xF, 0xF, false);
+                        }
+                    }
+                    if (want && cnt) tri_credit(tgt, a, b, v, pi, pj, cnt, n_tri);
+                }
+            }
+            continue;
+        }
+        const unsigned long long P = (unsigned long long)m * (m - 1) / 2;
         for (unsigned long long p = glane; p < P; p += kTriLanes) {
             uint32_t i = p < (1ull << 22) ? (uint32_t)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f)
                                           : (uint32_t)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
@@ -1325,15 +1372,8 @@ triangles_oriented_kernel(const uint32_t *__restrict__ off, const uint32_t *__re
             const uint32_t c = tgt[pi], bb = tgt[pj];  // c >= bb > v
             // one representative per pair of distinct values: the FIRST position of each value
             if (c == bb || tgt[pi - 1] == c || (pj > a && tgt[pj - 1] == bb)) continue;
-            uint32_t m_ac = 1, m_ab = 1;
-            while (pi + m_ac < b && tgt[pi + m_ac] == c) m_ac++;
-            while (pj + m_ab < b && tgt[pj + m_ab] == bb) m_ab++;
             const uint32_t m_bc = csr_count(tgt, off[c], off[c + 1], bb);
-            if (m_bc) {
-                atomicAdd(&n_tri[v], (unsigned long long)m_ab * m_ac);
-                atomicAdd(&n_tri[bb], (unsigned long long)m_ab * m_bc);
-                atomicAdd(&n_tri[c], (unsigned long long)m_ac * m_bc);
-            }
+            if (m_bc) tri_credit(tgt, a, b, v, pi, pj, m_bc, n_tri);
         }
     }
 }
