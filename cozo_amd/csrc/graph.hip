@@ -1339,24 +1339,35 @@ triangles_oriented_kernel(const uint32_t *__restrict__ off, const uint32_t *__re
                 const bool have = ca + glane < m;
                 const uint32_t bb = have ? tgt[pj] : CZ_NONE;
                 const bool first_b = have && !(pj > a && tgt[pj - 1] == bb);
-                // (group-uniform) the larger corner c, at a position behind the chunk's first: positions ascend with values, so a
-                // chunk that starts at or behind c's position holds nothing below c
-                for (uint32_t ci = ca + 1; ci < m; ci++) {
-                    const uint32_t pi = s + ci;
-                    const uint32_t c = tgt[pi];
-                    if (tgt[pi - 1] == c) continue;  // a repeated neighbour: its multiplicity is counted at its first position
-                    const bool want = first_b && bb < c;
-                    uint32_t cnt = 0;
-                    const uint32_t oc = off[c], oc1 = off[c + 1];
-                    for (uint32_t k = oc; k < oc1; k += kTriLanes) {
-                        uint32_t L = k + glane < oc1 ? tgt[k + glane] : CZ_NONE - 1u;
+                // the larger corners c, 16 at a time: every lane fetches ONE c with the bounds of its list, so that the chain
+                // neighbour -> offsets costs one round trip per 16 corners instead of one per corner; the loop over the corners
+                // then only reads lanes.  Positions ascend with values: corners at or before the chunk's first position have
+                // nothing of this chunk below them.
+                for (uint32_t cc = ca & ~(uint32_t)(kTriLanes - 1); cc < m; cc += kTriLanes) {
+                    const uint32_t pc = s + cc + glane;
+                    const bool have_c = cc + glane < m;
+                    const uint32_t my_c = have_c ? tgt[pc] : CZ_NONE;
+                    const bool rep = have_c && pc > a && tgt[pc - 1] == my_c;  // a repeated neighbour: counted at its first position
+                    const uint32_t my_oc = have_c && !rep ? off[my_c] : 0, my_oc1 = have_c && !rep ? off[my_c + 1] : 0;
+                    const uint32_t c_end = min((uint32_t)kTriLanes, m - cc);
+                    for (uint32_t t = 0; t < c_end; t++) {  // (group-uniform)
+                        const uint32_t ci = cc + t;
+                        if (ci <= ca) continue;
+                        const uint32_t c = (uint32_t)__shfl((int)my_c, (int)t, kTriLanes);
+                        const uint32_t oc = (uint32_t)__shfl((int)my_oc, (int)t, kTriLanes), oc1 = (uint32_t)__shfl((int)my_oc1, (int)t, kTriLanes);
+                        if (oc1 == oc) continue;  // repeated (or a neighbour without a list: cannot be, the graph is symmetric)
+                        const bool want = first_b && bb < c;
+                        uint32_t cnt = 0;
+                        for (uint32_t k = oc; k < oc1; k += kTriLanes) {
+                            uint32_t L = k + glane < oc1 ? tgt[k + glane] : CZ_NONE - 1u;
 #pragma unroll
-                        for (int r = 0; r < kTriLanes; r++) {
-                            cnt += L == bb ? 1u : 0u;
-                            L = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)L, 0x121 /* row_ror:1 */, 0xF, 0xF, false);
+                            for (int r = 0; r < kTriLanes; r++) {
+                                cnt += L == bb ? 1u : 0u;
+                                L = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)L, 0x121 /* row_ror:1 */, 0xF, 0xF, false);
+                            }
                         }
+                        if (want && cnt) tri_credit(tgt, a, b, v, s + ci, pj, cnt, n_tri);
                     }
-                    if (want && cnt) tri_credit(tgt, a, b, v, pi, pj, cnt, n_tri);
                 }
             }
             continue;
