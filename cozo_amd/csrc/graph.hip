@@ -1350,44 +1350,23 @@ triangles_oriented_kernel(const uint32_t *__restrict__ off, const uint32_t *__re
                     const bool rep = have_c && pc > a && tgt[pc - 1] == my_c;  // a repeated neighbour: counted at its first position
                     const uint32_t my_oc = have_c && !rep ? off[my_c] : 0, my_oc1 = have_c && !rep ? off[my_c + 1] : 0;
                     const uint32_t c_end = min((uint32_t)kTriLanes, m - cc);
-                    // ... and the first 32 entries of kTriAhead corners' lists are requested together before the first is
-                    // rotated (one corner's list after the other left the group waiting on every one of them)
-                    constexpr int kTriAhead = 8;
-                    for (uint32_t t0 = 0; t0 < c_end; t0 += kTriAhead) {  // (group-uniform)
-                        uint32_t L0[kTriAhead], L1[kTriAhead], oc[kTriAhead], oc1[kTriAhead];
-#pragma unroll
-                        for (int u = 0; u < kTriAhead; u++) {
-                            const uint32_t t = t0 + u;
-                            const bool live = t < c_end && cc + t > ca;
-                            oc[u] = live ? (uint32_t)__shfl((int)my_oc, (int)t, kTriLanes) : 0;
-                            oc1[u] = live ? (uint32_t)__shfl((int)my_oc1, (int)t, kTriLanes) : 0;
-                            L0[u] = oc[u] + glane < oc1[u] ? tgt[oc[u] + glane] : CZ_NONE - 1u;
-                            L1[u] = oc[u] + kTriLanes + glane < oc1[u] ? tgt[oc[u] + kTriLanes + glane] : CZ_NONE - 1u;
-                        }
-#pragma unroll
-                        for (int u = 0; u < kTriAhead; u++) {
-                            if (oc1[u] == oc[u]) continue;  // not live, repeated, or (cannot be: the graph is symmetric) no list
-                            const uint32_t t = t0 + u;
-                            const uint32_t c = (uint32_t)__shfl((int)my_c, (int)t, kTriLanes);
-                            const bool want = first_b && bb < c;
-                            uint32_t cnt = 0;
-                            uint32_t La = L0[u], Lb = L1[u];
+                    for (uint32_t t = 0; t < c_end; t++) {  // (group-uniform)
+                        const uint32_t ci = cc + t;
+                        if (ci <= ca) continue;
+                        const uint32_t c = (uint32_t)__shfl((int)my_c, (int)t, kTriLanes);
+                        const uint32_t oc = (uint32_t)__shfl((int)my_oc, (int)t, kTriLanes), oc1 = (uint32_t)__shfl((int)my_oc1, (int)t, kTriLanes);
+                        if (oc1 == oc) continue;  // repeated (or a neighbour without a list: cannot be, the graph is symmetric)
+                        const bool want = first_b && bb < c;
+                        uint32_t cnt = 0;
+                        for (uint32_t k = oc; k < oc1; k += kTriLanes) {
+                            uint32_t L = k + glane < oc1 ? tgt[k + glane] : CZ_NONE - 1u;
 #pragma unroll
                             for (int r = 0; r < kTriLanes; r++) {
-                                cnt += (La == bb ? 1u : 0u) + (Lb == bb ? 1u : 0u);
-                                La = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)La, 0x121 /* row_ror:1 */, 0xF, 0xF, false);
-                                Lb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Lb, 0x121, 0xF, 0xF, false);
+                                cnt += L == bb ? 1u : 0u;
+                                L = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)L, 0x121 /* row_ror:1 */, 0xF, 0xF, false);
                             }
-                            for (uint32_t k = oc[u] + 2 * kTriLanes; k < oc1[u]; k += kTriLanes) {  // lists of more than 32 entries
-                                uint32_t L = k + glane < oc1[u] ? tgt[k + glane] : CZ_NONE - 1u;
-#pragma unroll
-                                for (int r = 0; r < kTriLanes; r++) {
-                                    cnt += L == bb ? 1u : 0u;
-                                    L = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)L, 0x121, 0xF, 0xF, false);
-                                }
-                            }
-                            if (want && cnt) tri_credit(tgt, a, b, v, s + cc + t, pj, cnt, n_tri);
                         }
+                        if (want && cnt) tri_credit(tgt, a, b, v, s + ci, pj, cnt, n_tri);
                     }
                 }
             }
