@@ -433,7 +433,12 @@ static int shrink_neighbour(orc_hnsw *h, uint32_t target, int m, int level) {
                 was_old = 1;
                 break;
             }
-        if (!was_old) adj_upsert(&h->adj[target][level], sel[i].id, sel[i].d, 0);
+        /* With extend_candidates the target is reachable through its neighbours' back links, at the distance of a vector
+         * to itself, and is selected like anything else.  Its "new row" [layer, target, target] IS the self row: the put
+         * of :413-433 overwrites it and hnsw_put_vector puts the self row back right after this call returns (:352-357).
+         * Net effect: no link row, one of the m slots spent, and the stored degree counts it (tests/literal_hnsw_store.py
+         * plays the same steps on a literal row store). */
+        if (!was_old && sel[i].id != target) adj_upsert(&h->adj[target][level], sel[i].id, sel[i].d, 0);
     }
     a = &h->adj[target][level];
     for (int j = 0; j < nold; j++) { /* :434-466 dropped links: soft delete (ignore_link = true) */

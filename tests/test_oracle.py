@@ -293,3 +293,48 @@ def test_hnsw_remove_restated(oracle):
     # inserting after a removal goes on from the cleaned graph
     b.insert(rng.random((50, 12), dtype=np.float32), oracle.random_levels(50, 6, 9))
     assert b.export().level_nodes[0].size == 1500 - len(dead) + 50
+
+
+LITERAL_CASES = [
+    # n, dim, metric, m, ef_c, extend, keep
+    (140, 6, "L2", 3, 12, False, False),
+    (140, 6, "L2", 3, 12, True, False),
+    (120, 10, "Cosine", 4, 10, True, True),
+    (120, 5, "IP", 3, 8, True, False),
+    (100, 4, "L2", 2, 6, True, True),
+]
+
+
+@pytest.mark.parametrize("n,dim,metric,m,efc,extend,keep", LITERAL_CASES)
+def test_index_construction_equals_a_literal_row_store(oracle, n, dim, metric, m, efc, extend, keep):
+    """hnsw_put_vector / select_neighbours_heuristic / shrink_neighbour (hnsw.rs:155-538): the adjacency-list restatement in
+    cozo_oracle.c against tests/literal_hnsw_store.py, which plays the same insertions on the reference's row model (one
+    ordered map, get / put / del).  With extend_candidates this covers the self-link quirk: shrink selects the target itself,
+    writes a link row onto the target's self row, and put_vector restores it -- a slot spent and a degree one above the
+    number of link rows, no row of its own."""
+    from tests.literal_hnsw_store import LiteralStore
+    mid = {"L2": oracle.L2, "Cosine": oracle.COSINE, "IP": oracle.IP}[metric]
+    x = util.vectors(n, dim, 5, "normal" if metric == "IP" else "uniform")
+    levels = oracle.random_levels(n, m, 9)
+    b = oracle.HnswBuilder(dim, mid, m, efc, extend_candidates=extend, keep_pruned_connections=keep)
+    b.insert(x, levels)
+    flat = b.export()
+    st = LiteralStore(lambda a, c: oracle.distance(mid, a, c), m, efc, extend, keep)
+    for i in range(n):
+        st.put(x[i], int(levels[i]))
+    assert st.entry() == flat.entry
+    phantom = 0
+    for lv in range(flat.n_levels):
+        ids, tab = flat.level_nodes[lv], flat.level_nbrs[lv]
+        assert [int(v) for v in ids] == [i for i in range(n) if levels[i] >= lv]
+        for r, node in enumerate(ids):
+            live = [int(t) for t in tab[r] if t != oracle.NONE]
+            assert live == st.live_links(int(node), lv), (lv, int(node))
+            assert b.degree(int(node), lv) == st.degree(int(node), lv), (lv, int(node))
+            assert st.rows[(-lv, int(node), int(node))][1] is not None  # the self row is a self row again
+            phantom += int(st.degree(int(node), lv)) - len(live)
+    assert b.link_rows(include_ignored=True) - b.link_rows() == st.n_ignored()
+    if extend:
+        assert st.self_row_overwrites > 0 and phantom > 0
+    else:
+        assert st.self_row_overwrites == 0 and phantom == 0
