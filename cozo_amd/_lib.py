@@ -13,6 +13,7 @@ SO_PATH = os.environ.get("COZO_GPU_LIB") or os.path.join(_HERE, "lib", "libcozo_
 
 CZ_NONE = 0xFFFFFFFF
 CZ_DEVICE_PTRS = 1
+CZ_HNSW_EXTEND_CANDIDATES = 256
 CZ_BF_GEMM = 8
 CZ_PR_GATHER = 2
 CZ_PR_BLOCKED = 4
@@ -88,6 +89,7 @@ SYMBOLS = {
     "cz_hnsw_index_level_info": (C.c_int, [C.c_void_p, C.c_int32, u32p, i32p]),
     "cz_hnsw_index_export_level": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "cz_hnsw_index_export_vectors": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cz_hnsw_index_export_degrees": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "cz_hnsw_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                        C.c_void_p]),

@@ -10,6 +10,13 @@
 //   K3 shrink  : one workgroup per over-full row: re-select among its live links with the same heuristic, using the
 //                stored link distances (:389-393); dropped links disappear from this row only (one-directional,
 //                :434-466 -- the reference soft-deletes them, which is invisible to every reader on this path).
+// extend_candidates (:499-511): the heuristic's candidates are the found set plus the neighbours of its members -- gathered
+// into a per-workgroup scratch array in global memory, sorted there and fed through the LDS list chunk by chunk
+// (hnsw_kernels.cuh select_extended).  In a shrink the target reaches ITSELF through its neighbours' back links and is
+// selected like anything else; the reference writes that "link" onto the target's self row and puts the self row back
+// (:413-433, :352-357), so all that remains is a degree one above the number of link rows: `ph` below.  A shrink now reads
+// OTHER rows, so the selections of one round are staged and applied afterwards (every shrink of a round sees the rows as
+// the round found them), and max_batch = 1 links and shrinks one neighbour at a time, in the order of selection.
 // Vectors of one batch do not see each other (they are linked after the batch's searches), which is the only
 // difference from the reference's one-at-a-time insertion: with max_batch = 1 the link tables are identical to the
 // sequential algorithm's.  Levels are drawn by the caller (hnsw.rs:46-52 uses an unseedable thread_rng).
@@ -36,13 +43,31 @@ struct BuildTables {
     uint32_t *nbr0;
     double *dst0;
     uint32_t *deg0;
+    uint8_t *ph0;  // 1 = the degree counts a self link that holds no slot (extend_candidates)
     int w0, cap0;
     const uint32_t *up_base;
     uint32_t *nbrU;
     double *dstU;
     uint32_t *degU;
+    uint8_t *phU;
     int wu, capU;
     const int32_t *level;
+};
+// extend_candidates scratch: per workgroup `cap` candidate slots (a power of two) and a copy of the found list
+struct ExtBuf {
+    uint64_t *key;
+    uint32_t *id;
+    uint32_t cap, keep;  // slots per workgroup = cap + keep
+    __device__ uint64_t *cand_key(uint32_t wg) const { return key + (size_t)wg * (cap + keep); }
+    __device__ uint32_t *cand_id(uint32_t wg) const { return id + (size_t)wg * (cap + keep); }
+};
+// selections of one round of shrinks, applied after the round (extend_candidates)
+struct Stage {
+    uint32_t *ids;  // [rows][width]
+    double *dst;
+    uint32_t *n;    // [rows] links kept
+    uint8_t *self;  // [rows] the target itself was selected
+    int width;
 };
 struct Req {
     uint32_t *t, *q;
@@ -53,6 +78,7 @@ struct RowRef {
     uint32_t *ids;
     double *dst;
     uint32_t *deg;
+    uint8_t *ph;
     int width, cap;
 };
 __device__ __forceinline__ RowRef row_of(const BuildTables &T, uint32_t node, int lv) {
@@ -61,6 +87,7 @@ __device__ __forceinline__ RowRef row_of(const BuildTables &T, uint32_t node, in
         r.ids = T.nbr0 + (size_t)node * T.cap0;
         r.dst = T.dst0 + (size_t)node * T.cap0;
         r.deg = T.deg0 + node;
+        r.ph = T.ph0 + node;
         r.width = T.w0;
         r.cap = T.cap0;
     } else {
@@ -68,6 +95,7 @@ __device__ __forceinline__ RowRef row_of(const BuildTables &T, uint32_t node, in
         r.ids = T.nbrU + row * T.capU;
         r.dst = T.dstU + row * T.capU;
         r.deg = T.degU + row;
+        r.ph = T.phU + row;
         r.width = T.wu;
         r.cap = T.capU;
     }
@@ -75,12 +103,14 @@ __device__ __forceinline__ RowRef row_of(const BuildTables &T, uint32_t node, in
 }
 
 // K1
-template <int LPV, int ITERS, int U>
+template <int LPV, int ITERS, int U, bool EXT>
 __global__ void __launch_bounds__(kThreads)
 build_insert_kernel(IndexDev ix, BuildTables T, uint32_t b0, uint32_t bn, int top, uint32_t entry, int ef_c,
                     uint32_t efcap, uint32_t wcap, int keep_pruned, uint32_t *__restrict__ vtab, uint32_t hbits,
                     uint32_t *__restrict__ vbitmap, uint32_t words, Req req,
-                    uint32_t *__restrict__ req_count, uint32_t req_cap, unsigned long long *__restrict__ ndist_total) {
+                    uint32_t *__restrict__ req_count, uint32_t req_cap, unsigned long long *__restrict__ ndist_total,
+                    ExtBuf ext) {
+    constexpr bool extend = EXT;  // a template parameter: the plain build keeps its registers (the extended path spills)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     czh::Smem s = czh::carve(smem_raw, efcap, wcap, ix.ld);
     czh::VisitedDev vis;
@@ -104,15 +134,33 @@ build_insert_kernel(IndexDev ix, BuildTables T, uint32_t b0, uint32_t bn, int to
             }
             // :242-359
             const RowRef r = row_of(T, q, lv);
-            const int nsel = S.select_heuristic(r.width, keep_pruned != 0);
+            int nsel;
+            int found_cnt = 0;
+            uint64_t *gk = nullptr;
+            uint32_t *gi = nullptr;
+            if constexpr (EXT) {
+                gk = ext.cand_key(blockIdx.x);
+                gi = ext.cand_id(blockIdx.x);
+                found_cnt = s.ctl[czh::C_CNT];  // found_nn goes on to the next level as it is (:248-256): a copy
+                for (int k = tid; k < found_cnt; k += kThreads) {
+                    gk[ext.cap + k] = s.wkey[k];
+                    gi[ext.cap + k] = s.wid[k];
+                }
+                S.clear_visited();
+                const uint32_t nc = S.gather_extended(lv, gk, gi, wcap);
+                S.sort_scratch(gk, gi, nc);
+                nsel = S.select_extended(gk, gi, nc, r.width, keep_pruned != 0, efcap);
+            } else {
+                nsel = S.select_heuristic(r.width, keep_pruned != 0);
+            }
             if (tid == 0) s.ctl[czh::C_KEEP] = (int)atomicAdd(req_count, (uint32_t)nsel);
             __syncthreads();
             const uint32_t base = (uint32_t)s.ctl[czh::C_KEEP];
             for (int k = tid; k < r.cap; k += kThreads) {
                 if (k < nsel) {
                     const uint32_t p = s.sel[k];
-                    const uint32_t id = s.wid[p] & kIdMask;
-                    const double d = key_dist(s.wkey[p]);
+                    const uint32_t id = extend ? p : s.wid[p] & kIdMask;
+                    const double d = key_dist(extend ? S.ext_sel_key()[k] : s.wkey[p]);
                     r.ids[k] = id;
                     r.dst[k] = d;
                     if (base + k < req_cap) {  // the host checks the final count against req_cap
@@ -124,6 +172,14 @@ build_insert_kernel(IndexDev ix, BuildTables T, uint32_t b0, uint32_t bn, int to
                 } else {
                     r.ids[k] = CZ_NONE;
                 }
+            }
+            if (EXT && lv > 0) {  // W was the heuristic's chunk buffer
+                __syncthreads();
+                for (int k = tid; k < found_cnt; k += kThreads) {
+                    s.wkey[k] = gk[ext.cap + k];
+                    s.wid[k] = gi[ext.cap + k];
+                }
+                if (tid == 0) s.ctl[czh::C_CNT] = found_cnt;
             }
             if (tid == 0) *r.deg = (uint32_t)nsel;  // the self-loop row's degree, :269-277
             S.clear_visited();
@@ -146,13 +202,14 @@ build_link_kernel(BuildTables T, Req in, uint32_t n, int lazy, Req retry, uint32
         const int lv = in.lv[i];
         const double d = in.d[i];
         const RowRef r = row_of(T, t, lv);
-        const uint32_t slot = atomicAdd(r.deg, 1u);
+        const uint32_t old = atomicAdd(r.deg, 1u);  // the degree of the self row, :338
+        const uint32_t slot = old - *r.ph;
         if (slot < (uint32_t)r.cap) {
             r.ids[slot] = q;
             r.dst[slot] = d;
             // degree just exceeded the row width: shrink (:339).  Lazy form (batched builds): only when the row's
             // slack slots are used up too -- one re-selection per `slack` appended links instead of one per link
-            if (slot == (uint32_t)(lazy ? r.cap - 1 : r.width)) {
+            if (lazy ? slot == (uint32_t)(r.cap - 1) : old == (uint32_t)r.width) {
                 const uint32_t p = atomicAdd(shrink_count, 1u);
                 shrink_t[p] = t;
                 shrink_lv[p] = lv;
@@ -176,7 +233,7 @@ build_overfull_kernel(BuildTables T, uint32_t n, uint32_t *__restrict__ shrink_t
         const int top = T.level[i];
         for (int lv = 0; lv <= top; lv++) {
             const RowRef r = row_of(T, i, lv);
-            if (*r.deg > (uint32_t)r.width) {
+            if (*r.deg - *r.ph > (uint32_t)r.width) {
                 const uint32_t p = atomicAdd(shrink_count, 1u);
                 if (p < cap) {
                     shrink_t[p] = i;
@@ -188,20 +245,31 @@ build_overfull_kernel(BuildTables T, uint32_t n, uint32_t *__restrict__ shrink_t
 }
 
 // K3
-template <int LPV, int ITERS, int U>
+template <int LPV, int ITERS, int U, bool EXT>
 __global__ void __launch_bounds__(kThreads)
 build_shrink_kernel(IndexDev ix, BuildTables T, const uint32_t *__restrict__ shrink_t, const int32_t *__restrict__ shrink_lv,
-                    uint32_t n, uint32_t efcap, uint32_t wcap, int keep_pruned, unsigned long long *__restrict__ ndist_total) {
+                    uint32_t n, const uint32_t *__restrict__ n_dev /* or the count is read here (max_batch = 1 + extend) */,
+                    uint32_t efcap, uint32_t wcap, int keep_pruned, unsigned long long *__restrict__ ndist_total,
+                    uint32_t *__restrict__ vtab, uint32_t hbits, uint32_t *__restrict__ vbitmap, uint32_t words,
+                    ExtBuf ext, Stage stage) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     czh::Smem s = czh::carve(smem_raw, efcap, wcap, ix.ld);
-    czh::Searcher<LPV, ITERS, U> S(ix, s, czh::VisitedDev{nullptr, 0, nullptr, 0});
+    czh::VisitedDev vis{nullptr, 0, nullptr, 0};
+    if constexpr (EXT) {
+        vis.tab = hbits ? vtab + ((size_t)blockIdx.x << hbits) : nullptr;
+        vis.hbits = hbits;
+        vis.bitmap = vbitmap + (size_t)blockIdx.x * words;
+        vis.words = words;
+    }
+    czh::Searcher<LPV, ITERS, U> S(ix, s, vis);
     const int tid = threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         const uint32_t t = shrink_t[i];
         const int lv = shrink_lv[i];
         const RowRef r = row_of(T, t, lv);
         S.load_query(ix.vec + (size_t)t * ix.ld);  // hnsw.rs:386-387
-        const int c = (int)min(*r.deg, (uint32_t)r.cap);
+        const int c = (int)min(*r.deg - *r.ph, (uint32_t)r.cap);
         // candidates = live links with their stored distances (:389-393), sorted by (distance, id)
         uint64_t mk = 0;
         uint32_t mi = CZ_NONE;
@@ -220,23 +288,80 @@ build_shrink_kernel(IndexDev ix, BuildTables T, const uint32_t *__restrict__ shr
         }
         if (tid == 0) s.ctl[czh::C_CNT] = c;
         __syncthreads();
-        const int nsel = S.select_heuristic(r.width, keep_pruned != 0);
-        for (int k = tid; k < r.cap; k += kThreads) {
-            if (k < nsel) {
-                const uint32_t p = s.sel[k];
-                r.ids[k] = s.wid[p] & kIdMask;
-                r.dst[k] = key_dist(s.wkey[p]);
-            } else {
-                r.ids[k] = CZ_NONE;
+        if constexpr (!EXT) {
+            const int nsel = S.select_heuristic(r.width, keep_pruned != 0);
+            for (int k = tid; k < r.cap; k += kThreads) {
+                if (k < nsel) {
+                    const uint32_t p = s.sel[k];
+                    r.ids[k] = s.wid[p] & kIdMask;
+                    r.dst[k] = key_dist(s.wkey[p]);
+                } else {
+                    r.ids[k] = CZ_NONE;
+                }
+            }
+            if (tid == 0) {
+                *r.deg = (uint32_t)nsel;  // :352,412
+                *r.ph = 0;
+            }
+        } else {
+            // the neighbours' neighbours join in (:499-511) -- the target among them, through the back links; what is
+            // selected is staged: the other shrinks of this round still read this row as the round found it
+            uint64_t *gk = ext.cand_key(blockIdx.x);
+            uint32_t *gi = ext.cand_id(blockIdx.x);
+            const uint32_t nc = S.gather_extended(lv, gk, gi, wcap);
+            S.sort_scratch(gk, gi, nc);
+            const int nsel = S.select_extended(gk, gi, nc, r.width, keep_pruned != 0, efcap);
+            if (tid == 0) {
+                int at = -1;
+                for (int k = 0; k < nsel; k++)
+                    if (s.sel[k] == t) at = k;
+                s.ctl[czh::C_KEEP] = at;
+            }
+            __syncthreads();
+            const int at = s.ctl[czh::C_KEEP];
+            uint32_t *sid = stage.ids + (size_t)i * stage.width;
+            double *sd = stage.dst + (size_t)i * stage.width;
+            for (int k = tid; k < nsel; k += kThreads) {
+                if (k == at) continue;  // the self row, put back by hnsw_put_vector (:352-357): a slot, not a link
+                const int o = k - (at >= 0 && k > at ? 1 : 0);
+                sid[o] = s.sel[k];
+                sd[o] = key_dist(S.ext_sel_key()[k]);
+            }
+            if (tid == 0) {
+                stage.n[i] = (uint32_t)(nsel - (at >= 0 ? 1 : 0));
+                stage.self[i] = at >= 0 ? 1 : 0;
             }
         }
         if (tid == 0) {
-            *r.deg = (uint32_t)nsel;  // :352,412
             const unsigned long long nd = ((unsigned long long)(unsigned int)s.ctl[czh::C_NDIST_HI] << 32) |
                                           (unsigned long long)(unsigned int)s.ctl[czh::C_NDIST_LO];
             atomicAdd(ndist_total, nd);
         }
         __syncthreads();
+    }
+}
+
+// the staged selections of one round of shrinks go into the rows (one wave per row)
+__global__ void __launch_bounds__(256)
+build_apply_kernel(BuildTables T, const uint32_t *__restrict__ shrink_t, const int32_t *__restrict__ shrink_lv, uint32_t n,
+                   const uint32_t *__restrict__ n_dev, Stage stage) {
+    if (n_dev) n = min(n, *n_dev);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+        const RowRef r = row_of(T, shrink_t[i], shrink_lv[i]);
+        const uint32_t kept = stage.n[i];
+        for (int k = lane; k < r.cap; k += 64) {
+            if ((uint32_t)k < kept) {
+                r.ids[k] = stage.ids[(size_t)i * stage.width + k];
+                r.dst[k] = stage.dst[(size_t)i * stage.width + k];
+            } else {
+                r.ids[k] = CZ_NONE;
+            }
+        }
+        if (lane == 0) {
+            *r.deg = kept + stage.self[i];  // :412: the selected count, the self link included
+            *r.ph = stage.self[i];
+        }
     }
 }
 
@@ -282,7 +407,7 @@ build_unpack_kernel(IndexDev ix, BuildTables T, const uint32_t *__restrict__ old
                 }
             }
             if (tid == 0) {
-                *r.deg = (uint32_t)c;
+                *r.deg = (uint32_t)c + *r.ph;
                 atomicAdd(ndist_total, (unsigned long long)c);
             }
             __syncthreads();
@@ -431,6 +556,15 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
     cz::DevBuf<double> b_dst0, b_dstU;
     cz::DevBuf<int32_t> b_level, b_shrink_lv;
     cz::DevBuf<unsigned long long> b_ndist;
+    cz::DevBuf<uint8_t> b_ph0, b_phU;
+    CZ_HIP(b_ph0.alloc(std::max<size_t>(1, n)));
+    CZ_HIP(b_phU.alloc(std::max<size_t>(1, rows)));
+    CZ_HIP(hipMemsetAsync(b_ph0.p, 0, std::max<size_t>(1, n), stream));
+    CZ_HIP(hipMemsetAsync(b_phU.p, 0, std::max<size_t>(1, rows), stream));
+    if (!ix->ph0.empty())
+        CZ_HIP(hipMemcpyAsync(b_ph0.p, ix->ph0.data(), std::min<size_t>(ix->ph0.size(), n_old), hipMemcpyHostToDevice, stream));
+    if (!ix->phU.empty() && rows_old)
+        CZ_HIP(hipMemcpyAsync(b_phU.p, ix->phU.data(), std::min<size_t>(ix->phU.size(), rows_old), hipMemcpyHostToDevice, stream));
     CZ_HIP(b_nbr0.alloc((size_t)n * cap0));
     CZ_HIP(b_dst0.alloc((size_t)n * cap0));
     CZ_HIP(b_deg0.alloc(n));
@@ -471,7 +605,8 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
     CZ_HIP(b_shrink_t.alloc(max_req));
     CZ_HIP(b_shrink_lv.alloc(max_req));
 
-    BuildTables T{b_nbr0.p, b_dst0.p, b_deg0.p, w0, cap0, b_upbase.p, b_nbrU.p, b_dstU.p, b_degU.p, wu, capU, b_level.p};
+    BuildTables T{b_nbr0.p, b_dst0.p, b_deg0.p, b_ph0.p, w0, cap0, b_upbase.p, b_nbrU.p, b_dstU.p, b_degU.p, b_phU.p, wu, capU,
+                  b_level.p};
     IndexDev dev = ix->dev();
     dev.n = n;
     dev.nbr0 = b_nbr0.p;
@@ -483,6 +618,57 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
     const uint32_t wcap = std::max<uint32_t>(efcap, (uint32_t)((std::max(cap0, capU) + 63) & ~63));
     const size_t smem = czh::smem_bytes(efcap, wcap, ld);
     if (smem > 160 * 1024) return cz::set_error(CZ_E_UNSUPPORTED, "dim/ef_construction need %zu bytes of LDS", smem);
+    // extend_candidates: per resident workgroup the candidate scratch (every member of the found set -- or of a row --
+    // brings at most a row of neighbours) and the copy of the found list; per shrink of a round its staged selection
+    const int extend = (flags & CZ_HNSW_EXTEND_CANDIDATES) ? 1 : 0;
+    const uint32_t kStageRows = 65536;
+    cz::DevBuf<uint64_t> b_ext_key;
+    cz::DevBuf<uint32_t> b_ext_id, b_stage_ids, b_stage_n;
+    cz::DevBuf<double> b_stage_dst;
+    cz::DevBuf<uint8_t> b_stage_self;
+    ExtBuf ext{nullptr, nullptr, 0, 0};
+    Stage stage{nullptr, nullptr, nullptr, nullptr, std::max(w0, wu)};
+    if (extend) {
+        const uint64_t members = std::max<uint64_t>(ef_construction, (uint64_t)std::max(cap0, capU));
+        const uint64_t need = members * (uint64_t)(std::max(cap0, capU) + 1);
+        uint64_t cap = 2;
+        while (cap < need) cap <<= 1;
+        ext.cap = (uint32_t)cap;
+        ext.keep = efcap;
+        CZ_HIP(b_ext_key.alloc((size_t)slots * (cap + efcap)));
+        CZ_HIP(b_ext_id.alloc((size_t)slots * (cap + efcap)));
+        ext.key = b_ext_key.p;
+        ext.id = b_ext_id.p;
+        CZ_HIP(b_stage_ids.alloc((size_t)kStageRows * stage.width));
+        CZ_HIP(b_stage_dst.alloc((size_t)kStageRows * stage.width));
+        CZ_HIP(b_stage_n.alloc(kStageRows));
+        CZ_HIP(b_stage_self.alloc(kStageRows));
+        stage.ids = b_stage_ids.p;
+        stage.dst = b_stage_dst.p;
+        stage.n = b_stage_n.p;
+        stage.self = b_stage_self.p;
+    }
+    // one round of shrinks: rows [0, count) of the request arrays (count on the host, or read on the device when `count_dev`)
+    auto launch_shrinks = [&](const uint32_t *sh_t, const int32_t *sh_lv, uint32_t count, const uint32_t *count_dev) {
+        for (uint32_t off = 0; off < count; off += extend ? kStageRows : count) {
+            const uint32_t part = extend ? std::min(kStageRows, count - off) : count;
+            const uint32_t g3 = std::min<uint32_t>(part, (uint32_t)slots);
+#define CZ_LAUNCH_SHRINK(LPV, ITERS, U)                                                                                  \
+    do {                                                                                                                 \
+        auto kern = extend ? build_shrink_kernel<LPV, ITERS, U, true> : build_shrink_kernel<LPV, ITERS, U, false>;      \
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                                        (int)smem);                                                     \
+        hipLaunchKernelGGL(kern, dim3(g3), dim3(kThreads), smem, stream, dev, T, sh_t + off, sh_lv + off, part, count_dev, \
+                           efcap, wcap, keep_pruned_connections, b_ndist.p, b_vtab.p, hbits, b_visited.p, words, ext,     \
+                           stage);                                                                                       \
+    } while (0)
+            CZ_DISPATCH_BUILD_SHAPE(sh, CZ_LAUNCH_SHRINK);
+#undef CZ_LAUNCH_SHRINK
+            if (extend)
+                hipLaunchKernelGGL(build_apply_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>((part + 3) / 4, 4096))),
+                                   dim3(256), 0, stream, T, sh_t + off, sh_lv + off, part, count_dev, stage);
+        }
+    };
 
     int top = -1;
     uint32_t entry = 0;
@@ -522,13 +708,13 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
         const uint32_t grid = std::min<uint32_t>(bn, (uint32_t)slots);
 #define CZ_LAUNCH_INSERT(LPV, ITERS, U)                                                                                  \
     do {                                                                                                                 \
-        auto kern = build_insert_kernel<LPV, ITERS, U>;                                                                  \
+        auto kern = extend ? build_insert_kernel<LPV, ITERS, U, true> : build_insert_kernel<LPV, ITERS, U, false>;      \
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                                         (int)smem);                                                     \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), smem, stream, dev, T, i, bn, top, entry,                     \
                            (int)ef_construction, efcap, wcap, keep_pruned_connections, b_vtab.p, hbits, b_visited.p, words, \
                            reqA.ref(),                                                                                   \
-                           b_misc.p + 0, (uint32_t)max_req, b_ndist.p);                                                                     \
+                           b_misc.p + 0, (uint32_t)max_req, b_ndist.p, ext);                                              \
     } while (0)
         CZ_DISPATCH_BUILD_SHAPE(sh, CZ_LAUNCH_INSERT);
 #undef CZ_LAUNCH_INSERT
@@ -539,6 +725,19 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
         if (nreq > max_req) return cz::set_error(CZ_E_HIP, "internal: request buffer overflow (%u > %zu)", nreq, max_req);
         ReqBuf *cur = &reqA, *nxt = &reqB;
         int rounds = 0;
+        if (extend && max_batch == 1) {
+            // The reference's order (:280-358): one neighbour after the other gets its reverse link and, if that takes it
+            // past the row width, its shrink -- which with extend_candidates reads the rows of the neighbours still to
+            // come.  No host round trip in between: the shrink and the apply kernel read the count the link kernel left.
+            for (uint32_t k = 0; k < nreq; k++) {
+                CZ_HIP(hipMemsetAsync(b_misc.p + 1, 0, 8, stream));
+                const Req one{cur->t.p + k, cur->q.p + k, cur->lv.p + k, cur->d.p + k};
+                hipLaunchKernelGGL(build_link_kernel, dim3(1), dim3(64), 0, stream, T, one, 1u, 0, nxt->ref(), b_misc.p + 1,
+                                   b_shrink_t.p, b_shrink_lv.p, b_misc.p + 2);
+                launch_shrinks(b_shrink_t.p, b_shrink_lv.p, 1u, b_misc.p + 2);
+            }
+            nreq = 0;
+        }
         while (nreq > 0) {
             CZ_HIP(hipMemsetAsync(b_misc.p + 1, 0, 8, stream));  // [1] retry count, [2] shrink count
             hipLaunchKernelGGL(build_link_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>((nreq + 255) / 256, 4096))),
@@ -547,19 +746,7 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
             CZ_HIP(hipMemcpyAsync(h, b_misc.p, 32, hipMemcpyDeviceToHost, stream));
             CZ_HIP(hipStreamSynchronize(stream));
             const uint32_t nretry = h[1], nshrink = h[2];
-            if (nshrink > 0) {
-                const uint32_t g3 = std::min<uint32_t>(nshrink, (uint32_t)slots);
-#define CZ_LAUNCH_SHRINK(LPV, ITERS, U)                                                                                  \
-    do {                                                                                                                 \
-        auto kern = build_shrink_kernel<LPV, ITERS, U>;                                                                  \
-        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                                        (int)smem);                                                     \
-        hipLaunchKernelGGL(kern, dim3(g3), dim3(kThreads), smem, stream, dev, T, b_shrink_t.p, b_shrink_lv.p, nshrink,    \
-                           efcap, wcap, keep_pruned_connections, b_ndist.p);                                             \
-    } while (0)
-                CZ_DISPATCH_BUILD_SHAPE(sh, CZ_LAUNCH_SHRINK);
-#undef CZ_LAUNCH_SHRINK
-            }
+            if (nshrink > 0) launch_shrinks(b_shrink_t.p, b_shrink_lv.p, nshrink, nullptr);
             std::swap(cur, nxt);
             if (nretry >= nreq && nshrink == 0)
                 return cz::set_error(CZ_E_HIP, "internal: reverse-link requests made no progress");
@@ -590,17 +777,7 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
         CZ_HIP(hipMemcpyAsync(&nfinal, b_misc.p + 2, 4, hipMemcpyDeviceToHost, stream));
         CZ_HIP(hipStreamSynchronize(stream));
         if (nfinal > 0) {
-            const uint32_t g3 = std::min<uint32_t>(nfinal, (uint32_t)slots);
-#define CZ_LAUNCH_SHRINK(LPV, ITERS, U)                                                                                  \
-    do {                                                                                                                 \
-        auto kern = build_shrink_kernel<LPV, ITERS, U>;                                                                  \
-        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                                        (int)smem);                                                     \
-        hipLaunchKernelGGL(kern, dim3(g3), dim3(kThreads), smem, stream, dev, T, f_t.p, f_lv.p, nfinal, efcap, wcap,      \
-                           keep_pruned_connections, b_ndist.p);                                                          \
-    } while (0)
-            CZ_DISPATCH_BUILD_SHAPE(sh, CZ_LAUNCH_SHRINK);
-#undef CZ_LAUNCH_SHRINK
+            launch_shrinks(f_t.p, f_lv.p, nfinal, nullptr);
             CZ_HIP(hipStreamSynchronize(stream));  // f_t / f_lv die with this scope
         }
         hipError_t fe = hipGetLastError();
@@ -639,6 +816,12 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
     ix->n_levels = top + 1;
     ix->entry = entry;
     ix->layout_top.assign(ix->top.begin(), ix->top.end());
+    if (extend || !ix->ph0.empty()) {  // degrees that count a self link (extend_candidates), for the next insert and the write-back
+        ix->ph0.assign(n, 0);
+        ix->phU.assign((size_t)rows, 0);
+        CZ_HIP(hipMemcpy(ix->ph0.data(), b_ph0.p, n, hipMemcpyDeviceToHost));
+        if (rows) CZ_HIP(hipMemcpy(ix->phU.data(), b_phU.p, (size_t)rows, hipMemcpyDeviceToHost));
+    }
     {   // the visited workspaces were sized for the old n
         std::lock_guard<std::mutex> lk(ix->mu);
         for (auto &w : ix->pool) cz::HnswIndex::destroy(w);
@@ -840,6 +1023,35 @@ extern "C" int cz_hnsw_index_export_level(const cz_hnsw_index *h, int32_t level,
         if (node_ids) node_ids[r] = i;
         memcpy(nbrs + (size_t)r * ix->wu, &up[((size_t)base[i] + (level - 1)) * ix->wu], (size_t)ix->wu * 4);
         r++;
+    }
+    return CZ_OK;
+}
+
+extern "C" int cz_hnsw_index_export_degrees(const cz_hnsw_index *h, int32_t level, double *degree) {
+    if (!h || !degree) return cz::set_error(CZ_E_INVALID, "null argument");
+    auto *ix = reinterpret_cast<const cz::HnswIndex *>(h);
+    if (level < 0 || level >= ix->n_levels) return cz::set_error(CZ_E_INVALID, "level %d out of range", level);
+    uint32_t size = 0;
+    int32_t width = 0;
+    int rc = cz_hnsw_index_level_info(h, level, &size, &width);
+    if (rc) return rc;
+    std::vector<uint32_t> ids(std::max<uint32_t>(1, size)), tab((size_t)std::max<uint32_t>(1, size) * width);
+    if ((rc = cz_hnsw_index_export_level(h, level, ids.data(), tab.data()))) return rc;
+    std::vector<uint32_t> base;
+    if (level > 0 && !ix->phU.empty()) {
+        base.resize(ix->n);
+        CZ_HIP(hipMemcpy(base.data(), ix->up_base, (size_t)ix->n * 4, hipMemcpyDeviceToHost));
+    }
+    for (uint32_t r = 0; r < size; r++) {
+        uint32_t live = 0;
+        for (int k = 0; k < width; k++) live += tab[(size_t)r * width + k] != CZ_NONE;
+        uint32_t self = 0;
+        if (level == 0) self = ids[r] < ix->ph0.size() ? ix->ph0[ids[r]] : 0;
+        else if (!base.empty()) {
+            const size_t row = (size_t)base[ids[r]] + (level - 1);
+            self = row < ix->phU.size() ? ix->phU[row] : 0;
+        }
+        degree[r] = (double)(live + self);
     }
     return CZ_OK;
 }

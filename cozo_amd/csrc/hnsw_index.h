@@ -39,6 +39,11 @@ struct HnswIndex {
     // first row of the index relation = the smallest KEY on the top layer (hnsw.rs:184-191, 891-899) -- so rows inserted
     // later with keys that sort before existing ones need their rank, not their id, to be compared.
     std::vector<uint32_t> key_rank;
+    // extend_candidates: rows whose stored degree is one above their number of link rows -- the self link a shrink
+    // selected and hnsw_put_vector overwrote with the self row again (hnsw.rs:413-433, 352-357).  ph0[node], phU[upper row];
+    // empty = none.  Kept between builds and inserts: the next reverse link onto such a row triggers its shrink one link
+    // earlier (:338-339), and the self row written back carries the degree.
+    std::vector<uint8_t> ph0, phU;
     bool key_before(uint32_t a, uint32_t b) const {
         return key_rank.empty() ? a < b : (key_rank[a] != key_rank[b] ? key_rank[a] < key_rank[b] : a < b);
     }

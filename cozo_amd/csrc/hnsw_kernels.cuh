@@ -288,7 +288,7 @@ struct Searcher {
     // strictly closer to it than the centre is (:515-523).  Same result, batched: each time a candidate is
     // accepted, its distances to all still-pending farther candidates are evaluated in one pass and the ones it
     // dominates are rejected.  keep_pruned_connections back-fills from the rejected, nearest first (:530-536).
-    // Returns the number selected; their list positions are in s.sel.  (extend_candidates is not supported.)
+    // Returns the number selected; their list positions are in s.sel.  (extend_candidates: select_extended below.)
     __device__ int select_heuristic(int m, bool keep_pruned) {
         static_assert(ITERS > 0, "index construction needs a register-resident vector (dim <= 2048)");
         const int cnt = s.ctl[C_CNT];
@@ -305,47 +305,7 @@ struct Searcher {
             }
             nsel++;
             if (nsel == m) break;
-            __syncthreads();
-            if (wave == 0) {  // pending candidates farther than i, in order
-                int total = 0;
-                for (int b = i + 1; b < cnt; b += 64) {
-                    int j = b + lane;
-                    bool pend = j < cnt && s.st[j] == 0;
-                    unsigned long long mk = __ballot(pend);
-                    if (pend) {
-                        int p = total + __popcll(mk & ((1ull << lane) - 1ull));
-                        tcur[p] = s.wid[j] & kIdMask;
-                        s.tpos[p] = (uint32_t)j;
-                    }
-                    total += __popcll(mk);
-                }
-                if (lane == 0) {
-                    s.ctl[C_TODO] = total;
-                    unsigned int lo = (unsigned int)s.ctl[C_NDIST_LO], nl = lo + (unsigned int)total;
-                    s.ctl[C_NDIST_LO] = (int)nl;
-                    if (nl < lo) s.ctl[C_NDIST_HI] += 1;
-                }
-            }
-            __syncthreads();
-            const int n = s.ctl[C_TODO];
-            if (n == 0) continue;
-            // the accepted neighbour becomes the "query" of this pass
-            const float4 *srow = (const float4 *)(ix.vec + (size_t)(s.wid[i] & kIdMask) * ix.ld);
-            float4 q2[ITERS > 0 ? ITERS : 1];
-#pragma unroll
-            for (int j = 0; j < ITERS; j++) {
-                int c = glane + LPV * j;
-                q2[j] = c < chunks ? srow[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            const float q2n = ix.metric == CZ_COSINE ? query_norm<LPV, ITERS>(q2, s.q, glane, chunks) : 0.f;
-            eval_list(q2, q2n, n);
-            __syncthreads();
-            for (int j = tid; j < n; j += kThreads) {
-                const uint32_t p = s.tpos[j];
-                const uint64_t to_center = s.wkey[p], to_sel = s.nkey[j];
-                if (to_sel < to_center && to_center != ~0ull) s.st[p] = 2;  // raw `<`: false when either is NaN
-            }
-            __syncthreads();
+            reject_dominated(s.wid[i] & kIdMask, i, cnt);
         }
         __syncthreads();
         if (keep_pruned && nsel < m) {
@@ -357,6 +317,201 @@ struct Searcher {
             }
             __syncthreads();
             nsel = s.ctl[C_TODO];
+            __syncthreads();
+        }
+        return nsel;
+    }
+
+    // ---------------------------------------------------------------------------------------------------------
+    // extend_candidates (hnsw.rs:499-511): the candidate set of the heuristic is W plus every neighbour of W's entries.
+    // Up to cnt * (row width + 1) entries, which no LDS list holds: they live in a per-workgroup scratch array in global
+    // memory (`gkey` / `gid`, capacity a power of two), are sorted there, and pass through the LDS list one chunk at a time.
+    // ---------------------------------------------------------------------------------------------------------
+    // W and the not-yet-seen neighbours of its entries, with their distances to the register-resident vector -> the
+    // scratch array; returns how many.  The visited set must be empty on entry and is empty again on return (it is the
+    // `one entry per key` of PriorityQueue::push here).  W itself is left alone.
+    __device__ uint32_t gather_extended(int level, uint64_t *__restrict__ gkey, uint32_t *__restrict__ gid, uint32_t wcap) {
+        static_assert(ITERS > 0, "index construction needs a register-resident vector (dim <= 2048)");
+        const int cnt = s.ctl[C_CNT];
+        for (int i = tid; i < cnt; i += kThreads) {
+            gkey[i] = s.wkey[i];
+            gid[i] = s.wid[i] & kIdMask;
+        }
+        if (wave == 0) {
+            for (int b = 0; b < cnt; b += 64) {
+                const int j = b + lane;
+                uint32_t where;
+                const bool fresh = visit(j < cnt ? (s.wid[j] & kIdMask) : CZ_NONE, j < cnt, where);
+                if (fresh) log_visit(where, true);
+            }
+        }
+        __syncthreads();
+        const int width = level == 0 ? ix.w0 : ix.wu;
+        uint32_t total = (uint32_t)cnt;
+        int i = 0;
+        while (i < cnt) {  // uniform
+            if (wave == 0) {  // the link rows of as many entries as the evaluation list takes
+                int n = 0, j = i;
+                while (j < cnt && n + width <= (int)wcap) {
+                    n += expand_row(s.wid[j] & kIdMask, level, width, tcur + n, true);
+                    j++;
+                }
+                if (lane == 0) {
+                    s.ctl[C_TODO] = n;
+                    s.ctl[C_KEEP] = j;
+                    count_dist(n);
+                }
+            }
+            __syncthreads();
+            const int n = s.ctl[C_TODO];
+            i = s.ctl[C_KEEP];
+            if (n > 0) {
+                eval_todo(n);
+                __syncthreads();
+                for (int j = tid; j < n; j += kThreads) {
+                    gkey[total + j] = s.nkey[j];
+                    gid[total + j] = s.nid[j];
+                }
+                total += (uint32_t)n;
+            }
+            __syncthreads();
+        }
+        clear_visited();
+        return total;
+    }
+
+    // ascending by (key, id): a bitonic network over the scratch array (entries past n are padded with the greatest pair)
+    __device__ void sort_scratch(uint64_t *__restrict__ gkey, uint32_t *__restrict__ gid, uint32_t n) {
+        uint32_t P = 2;
+        while (P < n) P <<= 1;
+        for (uint32_t i = n + tid; i < P; i += kThreads) {
+            gkey[i] = ~0ull;
+            gid[i] = CZ_NONE;
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= P; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = tid; t < P / 2; t += kThreads) {
+                    const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo + j;
+                    const uint64_t ka = gkey[lo], kb = gkey[hi];
+                    const uint32_t ia = gid[lo], ib = gid[hi];
+                    const bool up = (lo & k) == 0;
+                    if (key_lt(kb, ib, ka, ia) == up) {
+                        gkey[lo] = kb;
+                        gid[lo] = ib;
+                        gkey[hi] = ka;
+                        gid[hi] = ia;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // one accepted neighbour `a` against the pending candidates at list positions > from: the ones it is strictly closer to
+    // than the centre is are rejected (:515-523).  All threads; begins and ends with a barrier.
+    __device__ void reject_dominated(uint32_t a, int from, int cnt) {
+        __syncthreads();
+        if (wave == 0) {
+            int total = 0;
+            for (int b = from + 1; b < cnt; b += 64) {
+                const int j = b + lane;
+                const bool pend = j < cnt && s.st[j] == 0;
+                const unsigned long long mk = __ballot(pend);
+                if (pend) {
+                    const int p = total + __popcll(mk & ((1ull << lane) - 1ull));
+                    tcur[p] = s.wid[j] & kIdMask;
+                    s.tpos[p] = (uint32_t)j;
+                }
+                total += __popcll(mk);
+            }
+            if (lane == 0) {
+                s.ctl[C_TODO] = total;
+                count_dist(total);
+            }
+        }
+        __syncthreads();
+        const int n = s.ctl[C_TODO];
+        if (n == 0) return;
+        const float4 *srow = (const float4 *)(ix.vec + (size_t)a * ix.ld);
+        float4 q2[ITERS > 0 ? ITERS : 1];
+#pragma unroll
+        for (int j = 0; j < ITERS; j++) {
+            const int c = glane + LPV * j;
+            q2[j] = c < chunks ? srow[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float q2n = ix.metric == CZ_COSINE ? query_norm<LPV, ITERS>(q2, s.q, glane, chunks) : 0.f;
+        eval_list(q2, q2n, n);
+        __syncthreads();
+        for (int j = tid; j < n; j += kThreads) {
+            const uint32_t p = s.tpos[j];
+            const uint64_t to_center = s.wkey[p], to_sel = s.nkey[j];
+            if (to_sel < to_center && to_center != ~0ull) s.st[p] = 2;  // raw `<`: false when either is NaN
+        }
+        __syncthreads();
+    }
+
+    // the selected neighbours of select_extended: ids in s.sel, distance keys here (the log of the visited set is idle
+    // while the heuristic runs: kVlogCap words hold 2 x 256 keys and 256 ids)
+    __device__ __forceinline__ uint64_t *ext_sel_key() const { return (uint64_t *)s.vlog; }
+
+    // hnsw_select_neighbours_heuristic over the sorted scratch array, `chunk` (<= the LDS list's capacity) entries at a
+    // time: a chunk's entries first meet the neighbours accepted from earlier chunks, then each other, exactly the
+    // comparisons the reference makes when it pops them one by one.  Overwrites W.  Returns the number selected
+    // (s.sel[k], ext_sel_key()[k], in the order of acceptance; back-filled ones after them).
+    __device__ int select_extended(const uint64_t *__restrict__ gkey, const uint32_t *__restrict__ gid, uint32_t n_cand, int m,
+                                   bool keep_pruned, uint32_t chunk) {
+        uint64_t *acc_key = ext_sel_key();
+        uint64_t *disc_key = acc_key + 256;
+        uint32_t *disc_id = (uint32_t *)(disc_key + 256);
+        int nsel = 0, ndisc = 0;
+        for (uint32_t base = 0; base < n_cand && nsel < m; base += chunk) {  // uniform
+            const int cnt = (int)min(chunk, n_cand - base);
+            __syncthreads();
+            for (int i = tid; i < cnt; i += kThreads) {
+                s.wkey[i] = gkey[base + i];
+                s.wid[i] = gid[base + i];
+                s.st[i] = 0;
+            }
+            for (int a = 0; a < nsel; a++) reject_dominated(s.sel[a], -1, cnt);
+            __syncthreads();
+            for (int i = 0; i < cnt && nsel < m; i++) {
+                if (s.st[i] != 0) continue;  // uniform
+                __syncthreads();
+                const uint32_t a = s.wid[i];
+                if (tid == 0) {
+                    s.sel[nsel] = a;
+                    acc_key[nsel] = s.wkey[i];
+                    s.st[i] = 1;
+                }
+                nsel++;
+                if (nsel == m) break;
+                reject_dominated(a, i, cnt);
+            }
+            __syncthreads();
+            if (keep_pruned && nsel < m) {  // the whole chunk has been popped: its rejected entries queue up, nearest first
+                if (tid == 0) {
+                    int k = ndisc;
+                    for (int i = 0; i < cnt && k < m; i++)
+                        if (s.st[i] == 2) {
+                            disc_id[k] = s.wid[i];
+                            disc_key[k] = s.wkey[i];
+                            k++;
+                        }
+                    s.ctl[C_TODO] = k;
+                }
+                __syncthreads();
+                ndisc = s.ctl[C_TODO];
+            }
+        }
+        __syncthreads();
+        if (keep_pruned && nsel < m && ndisc > 0) {  // :530-536
+            const int take = min(ndisc, m - nsel);
+            if (tid < take) {
+                s.sel[nsel + tid] = disc_id[tid];
+                acc_key[nsel + tid] = disc_key[tid];
+            }
+            nsel += take;
             __syncthreads();
         }
         return nsel;

@@ -52,6 +52,10 @@ class HnswSearch:
     has_filter: bool = False  # a filter keeps all ef candidates until after filtering (hnsw.rs:943-947)
 
 
+def _build_flags(manifest) -> int:
+    return _lib.CZ_HNSW_EXTEND_CANDIDATES if manifest.extend_candidates else 0
+
+
 def _refuse_shared_rows(row_of):
     if row_of is None:
         return
@@ -96,8 +100,6 @@ class GpuHnswIndex:
         vectors are refused here exactly as the C++ mirror refuses them (the shim falls back to the CPU path)."""
         if manifest.dtype != "F32":
             raise _lib.CozoGpuError(_lib.CZ_E_UNSUPPORTED, "only F32 vector indices are GPU-resident")
-        if manifest.extend_candidates:
-            raise _lib.CozoGpuError(_lib.CZ_E_UNSUPPORTED, "extend_candidates is not supported by the GPU build")
         _refuse_shared_rows(row_of)
         self = cls.__new__(cls)
         self.manifest = manifest
@@ -114,7 +116,7 @@ class GpuHnswIndex:
         check(_lib.lib().cz_hnsw_build(vp, nn, manifest.vec_dim, DISTANCES[manifest.distance], manifest.m_neighbours,
                                        manifest.ef_construction, int(manifest.keep_pruned_connections), ptr(lv),
                                        int(seed), int(max_batch), C.byref(nd), C.byref(h),
-                                       CZ_DEVICE_PTRS if device_ptr else 0, C.c_void_p(stream)))
+                                       (CZ_DEVICE_PTRS if device_ptr else 0) | _build_flags(manifest), C.c_void_p(stream)))
         self._h = h
         self.n = nn
         self.last_build_n_dist = nd.value
@@ -146,8 +148,8 @@ class GpuHnswIndex:
         nd = C.c_uint64(0)
         man = self.manifest
         check(_lib.lib().cz_hnsw_insert(self._h, ptr(v), v.shape[0], man.m_neighbours, man.ef_construction,
-                                        int(man.keep_pruned_connections), ptr(lv), int(seed), int(max_batch), C.byref(nd), 0,
-                                        None))
+                                        int(man.keep_pruned_connections), ptr(lv), int(seed), int(max_batch), C.byref(nd),
+                                        _build_flags(man), None))
         self.n += v.shape[0]
         self.last_build_n_dist = nd.value
 
@@ -156,6 +158,21 @@ class GpuHnswIndex:
         a = np.ascontiguousarray(nodes, dtype=np.uint32)
         check(_lib.lib().cz_hnsw_remove(self._h, ptr(a), a.size))
         self.__dict__.setdefault("_removed", set()).update(int(x) for x in a)  # (a removed node keeps its id; it has no rows)
+
+    def degrees(self):
+        """per level the f64 of every self row (hnsw.rs:270, 338-357) in export()'s node order: the number of link rows, plus
+        one where an extend_candidates shrink selected the node itself (cz_hnsw_index_export_degrees)"""
+        L = _lib.lib()
+        n, dim, metric, nl, entry = C.c_uint32(), C.c_uint32(), C.c_int32(), C.c_int32(), C.c_uint32()
+        check(L.cz_hnsw_index_info(self._h, C.byref(n), C.byref(dim), C.byref(metric), C.byref(nl), C.byref(entry)))
+        out = []
+        for lv in range(nl.value):
+            size, width = C.c_uint32(), C.c_int32()
+            check(L.cz_hnsw_index_level_info(self._h, lv, C.byref(size), C.byref(width)))
+            d = np.empty(size.value, dtype=np.float64)
+            check(L.cz_hnsw_index_export_degrees(self._h, lv, ptr(d)))
+            out.append(d)
+        return out
 
     def export(self):
         """(level_nodes, level_nbrs, entry): the flat layout of cz_hnsw_desc, e.g. to write the links back as
@@ -183,8 +200,11 @@ class GpuHnswIndex:
         the rows the store holds is what has to be written."""
         from .ingest import encode_index_rows
         nodes, nbrs, entry = self.export()
+        degs = self.degrees() if self.manifest.extend_candidates else None
         vecs = self.export_vectors()
         gone = self.__dict__.get("_removed")
+        if gone and len(nbrs) and degs is not None:
+            degs = [degs[0][np.setdiff1d(np.arange(self.n), np.fromiter(gone, dtype=np.int64))]] + list(degs[1:])
         if gone and len(nbrs):
             live0 = np.setdiff1d(np.arange(self.n, dtype=np.uint32), np.fromiter(gone, dtype=np.uint32), assume_unique=False)
             nodes = [live0.astype(np.uint32)] + list(nodes[1:])
@@ -201,7 +221,7 @@ class GpuHnswIndex:
                 d[live] = distance_batch(self.manifest.distance, vecs, vecs, pairs)
             level_dist.append(d)
         return encode_index_rows(key_of_node, vecs, nodes, nbrs, entry, DISTANCES[self.manifest.distance], level_dist,
-                                 relation_id)
+                                 relation_id, level_degree=degs)
 
     def export_vectors(self) -> np.ndarray:
         out = np.empty((self.n, self.manifest.vec_dim), dtype=np.float32)

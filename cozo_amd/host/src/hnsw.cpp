@@ -57,7 +57,6 @@ GpuHnswIndex GpuHnswIndex::create(const HnswIndexManifest &manifest, const BaseR
                                   uint32_t max_batch, const std::vector<int32_t> *levels) {
     if (manifest.dtype != VecElementType::F32)
         throw GpuError(CZ_E_UNSUPPORTED, "only F32 vector indices are GPU-resident");
-    if (manifest.extend_candidates) throw GpuError(CZ_E_UNSUPPORTED, "extend_candidates is not supported by the GPU build");
     GpuHnswIndex ix;
     ix.manifest_ = manifest;
     ix.base_ = &base;
@@ -94,12 +93,11 @@ GpuHnswIndex GpuHnswIndex::create(const HnswIndexManifest &manifest, const BaseR
     check_gpu(cz_hnsw_build(flat.data(), (uint32_t)ix.nodes_.size(), (uint32_t)manifest.vec_dim, (int)manifest.distance,
                             (uint32_t)manifest.m_neighbours, (uint32_t)manifest.ef_construction,
                             manifest.keep_pruned_connections ? 1 : 0, levels ? levels->data() : nullptr, seed, max_batch,
-                            &ix.build_n_dist_, &ix.h_, 0, nullptr));
+                            &ix.build_n_dist_, &ix.h_, manifest.extend_candidates ? CZ_HNSW_EXTEND_CANDIDATES : 0u, nullptr));
     return ix;
 }
 
 void GpuHnswIndex::put_rows(uint32_t first_row, uint64_t seed, uint32_t max_batch, const std::vector<int32_t> *levels) {
-    if (manifest_.extend_candidates) throw GpuError(CZ_E_UNSUPPORTED, "extend_candidates is not supported by the GPU build");
     std::vector<float> flat;
     const size_t n_before = nodes_.size();
     for (uint32_t r = first_row; r < base_->rows.size(); r++) {  // hnsw_put (runtime/hnsw.rs:679-727): a Vec or every Vec inside a List
@@ -135,7 +133,7 @@ void GpuHnswIndex::put_rows(uint32_t first_row, uint64_t seed, uint32_t max_batc
     if (!h_)  // the first rows of an index that was empty so far
         rc = cz_hnsw_build(flat.data(), (uint32_t)n_new, (uint32_t)manifest_.vec_dim, (int)manifest_.distance, (uint32_t)manifest_.m_neighbours,
                            (uint32_t)manifest_.ef_construction, manifest_.keep_pruned_connections ? 1 : 0, levels ? levels->data() : nullptr,
-                           seed, max_batch, &nd, &h_, 0, nullptr);
+                           seed, max_batch, &nd, &h_, manifest_.extend_candidates ? CZ_HNSW_EXTEND_CANDIDATES : 0u, nullptr);
     else {
         // Node ids follow insertion order, the reference's entry point follows KEY order (the first row of the index relation,
         // hnsw.rs:184-191, 891-899): hand the library every node's position among the (row key, field, sub-index) triples so
@@ -157,7 +155,8 @@ void GpuHnswIndex::put_rows(uint32_t first_row, uint64_t seed, uint32_t max_batc
         rc = cz_hnsw_set_key_order(h_, rank.data(), (uint32_t)rank.size());
         if (rc == CZ_OK)
             rc = cz_hnsw_insert(h_, flat.data(), (uint32_t)n_new, (uint32_t)manifest_.m_neighbours, (uint32_t)manifest_.ef_construction,
-                                manifest_.keep_pruned_connections ? 1 : 0, levels ? levels->data() : nullptr, seed, max_batch, &nd, 0, nullptr);
+                                manifest_.keep_pruned_connections ? 1 : 0, levels ? levels->data() : nullptr, seed, max_batch, &nd,
+                                manifest_.extend_candidates ? CZ_HNSW_EXTEND_CANDIDATES : 0u, nullptr);
     }
     if (rc != CZ_OK) nodes_.resize(n_before);
     check_gpu(rc);
@@ -221,24 +220,28 @@ StoredRows GpuHnswIndex::index_rows(uint64_t relation_id) const {
     std::vector<uint32_t> sizes(n_levels);
     std::vector<int32_t> widths(n_levels);
     std::vector<std::vector<uint32_t>> ids(n_levels), nbrs(n_levels);
-    std::vector<std::vector<double>> dist(n_levels);
+    std::vector<std::vector<double>> dist(n_levels), degree(n_levels);
     for (int32_t lv = 0; lv < n_levels; lv++) {
         check_gpu(cz_hnsw_index_level_info(h_, lv, &sizes[lv], &widths[lv]));
         ids[lv].resize(sizes[lv]);
         nbrs[lv].resize((size_t)sizes[lv] * widths[lv]);
         check_gpu(cz_hnsw_index_export_level(h_, lv, ids[lv].data(), nbrs[lv].data()));
+        degree[lv].resize(sizes[lv]);  // the f64 of the self rows: with extend_candidates not always the number of link rows
+        check_gpu(cz_hnsw_index_export_degrees(h_, lv, degree[lv].data()));
         if (lv == 0 && !removed_.empty()) {  // a removed node keeps its id on the device and has no rows in the store (hnsw_remove, :728-868)
             uint32_t keep = 0;
             for (uint32_t r = 0; r < sizes[0]; r++) {
                 const uint32_t v = ids[0][r];
                 if (v < removed_.size() && removed_[v]) continue;
                 ids[0][keep] = v;
+                degree[0][keep] = degree[0][r];
                 std::copy(nbrs[0].begin() + (size_t)r * widths[0], nbrs[0].begin() + (size_t)(r + 1) * widths[0],
                           nbrs[0].begin() + (size_t)keep * widths[0]);
                 keep++;
             }
             sizes[0] = keep;
             ids[0].resize(keep);
+            degree[0].resize(keep);
             nbrs[0].resize((size_t)keep * widths[0]);
         }
         // the distance column of every link row: the same arithmetic the search uses
@@ -270,15 +273,17 @@ StoredRows GpuHnswIndex::index_rows(uint64_t relation_id) const {
         node_key_off.push_back(node_keys.size());
     }
     std::vector<const uint32_t *> ids_p, nbrs_p;
-    std::vector<const double *> dist_p;
+    std::vector<const double *> dist_p, degree_p;
     for (int32_t lv = 0; lv < n_levels; lv++) {
         ids_p.push_back(ids[lv].data());
         nbrs_p.push_back(nbrs[lv].data());
         dist_p.push_back(dist[lv].data());
+        degree_p.push_back(degree[lv].data());
     }
     cz_hnsw_desc desc{n, dim, metric, n_levels, entry, sizes.data(), widths.data(), ids_p.data(), nbrs_p.data()};
     czi_row_buf *buf = nullptr;
-    if (czi_hnsw_encode_rows(&desc, vectors.data(), node_keys.data(), node_key_off.data(), dist_p.data(), relation_id, &buf) != CZI_OK)
+    if (czi_hnsw_encode_rows_degrees(&desc, vectors.data(), node_keys.data(), node_key_off.data(), dist_p.data(), degree_p.data(),
+                                     relation_id, &buf) != CZI_OK)
         throw CozoError("ingest::error", std::string("libcozo_ingest: ") + czi_last_error());
     std::unique_ptr<czi_row_buf, void (*)(czi_row_buf *)> hold(buf, czi_row_buf_free);
     czi_rows rows;

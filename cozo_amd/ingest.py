@@ -56,6 +56,8 @@ SYMBOLS = {
     "czi_hnsw_desc": (C.c_int, [C.c_void_p, C.POINTER(HnswDesc), C.POINTER(f32p)]),
     "czi_hnsw_nodes": (C.c_int, [C.c_void_p, C.POINTER(u64p), C.POINTER(u32p), C.POINTER(i32p)]),
     "czi_hnsw_row_counts": (C.c_int, [C.c_void_p, u64p, u64p, u64p, u64p]),
+    "czi_hnsw_encode_rows_degrees": (C.c_int, [C.POINTER(HnswDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_uint64, C.POINTER(C.c_void_p)]),
     "czi_hnsw_encode_rows": (C.c_int, [C.POINTER(HnswDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                        C.POINTER(C.c_void_p)]),
     "czi_row_buf_rows": (C.c_int, [C.c_void_p, C.POINTER(Rows)]),
@@ -230,9 +232,11 @@ def index_relation_tuples(key_of_node: Sequence[Sequence[Any]], vectors: np.ndar
 
 
 def encode_index_rows(key_of_node: Sequence[Sequence[Any]], vectors: np.ndarray, level_nodes: Sequence, level_nbrs: Sequence,
-                      entry: int, metric: int, level_dist: Sequence[np.ndarray], relation_id: int) -> codec.StoredRows:
-    """index_relation_tuples + the store's encoding in one native pass (czi_hnsw_encode_rows): the key / value bytes of
-    every `tbl:idx` row of a flat index, in key order.  level_dist[l] [size][width] f64 = the distance of every link slot."""
+                      entry: int, metric: int, level_dist: Sequence[np.ndarray], relation_id: int,
+                      level_degree: Optional[Sequence[np.ndarray]] = None) -> codec.StoredRows:
+    """index_relation_tuples + the store's encoding in one native pass (czi_hnsw_encode_rows_degrees): the key / value bytes of
+    every `tbl:idx` row of a flat index, in key order.  level_dist[l] [size][width] f64 = the distance of every link slot;
+    level_degree[l] [size] f64 = the degree of every self row (None: the number of link rows)."""
     from ._lib import i32p as _i32p, u32p as _u32p
     vectors = np.ascontiguousarray(vectors, dtype=np.float32)
     n, dim = vectors.shape
@@ -251,8 +255,10 @@ def encode_index_rows(key_of_node: Sequence[Sequence[Any]], vectors: np.ndarray,
     off[1:] = np.cumsum([len(k) for k in keys], dtype=np.uint64) if keys else []
     blob = np.frombuffer(b"".join(keys) or b"\0", dtype=np.uint8)
     h = C.c_void_p()
-    check(lib().czi_hnsw_encode_rows(C.byref(d), vectors.ctypes.data, blob.ctypes.data, off.ctypes.data, dist_p, relation_id,
-                                     C.byref(h)))
+    degs = None if level_degree is None else [np.ascontiguousarray(level_degree[l], dtype=np.float64) for l in range(L)]
+    deg_p = None if degs is None else (C.c_void_p * max(L, 1))(*[a.ctypes.data for a in degs])
+    check(lib().czi_hnsw_encode_rows_degrees(C.byref(d), vectors.ctypes.data, blob.ctypes.data, off.ctypes.data, dist_p, deg_p,
+                                             relation_id, C.byref(h)))
     r = Rows()
     check(lib().czi_row_buf_rows(h, C.byref(r)))
     nr = int(r.n_rows)

@@ -124,7 +124,7 @@ void put_prefix(std::vector<uint8_t> &o, uint64_t relation_id) {
 }
 
 void encode_index_rows(const cz_hnsw_desc *d, const float *vectors, const uint8_t *nk, const uint64_t *nko,
-                       const double *const *level_dist, uint64_t rid, czi_row_buf &out) {
+                       const double *const *level_dist, const double *const *level_degree, uint64_t rid, czi_row_buf &out) {
     if (d->n_levels <= 0 || d->n == 0) return;
     const uint32_t n = d->n;
     // key order of the nodes: rows of one layer are ordered by the `fr` bytes, then by the `to` bytes
@@ -285,7 +285,9 @@ void encode_index_rows(const cz_hnsw_desc *d, const float *vectors, const uint8_
                 begin_row();
                 put_key(fr);
                 memcpy(vw, self_val.data(), self_val.size());
-                patch_f64(vw + self_num_at, (double)links.size());
+                // the degree: the link rows, unless the caller knows better (cz_hnsw_index_export_degrees: an
+                // extend_candidates shrink leaves it one above them, hnsw.rs:413-433 + 352-357)
+                patch_f64(vw + self_num_at, level_degree && level_degree[item.lv] ? level_degree[item.lv][item.r] : (double)links.size());
                 memcpy(vw + self_hash_at, hashes.data() + (size_t)fr * 32, 32);
                 vw += self_val.size();
                 self_done = true;
@@ -319,12 +321,18 @@ void encode_index_rows(const cz_hnsw_desc *d, const float *vectors, const uint8_
 extern "C" int czi_hnsw_encode_rows(const cz_hnsw_desc *desc, const float *vectors, const uint8_t *node_keys,
                                     const uint64_t *node_key_off, const double *const *level_dist, uint64_t relation_id,
                                     czi_row_buf **out) {
+    return czi_hnsw_encode_rows_degrees(desc, vectors, node_keys, node_key_off, level_dist, nullptr, relation_id, out);
+}
+
+extern "C" int czi_hnsw_encode_rows_degrees(const cz_hnsw_desc *desc, const float *vectors, const uint8_t *node_keys,
+                                            const uint64_t *node_key_off, const double *const *level_dist,
+                                            const double *const *level_degree, uint64_t relation_id, czi_row_buf **out) {
     if (!out) return fail(CZI_E_INVALID, "null out");
     *out = nullptr;
     if (!desc || (desc->n && (!vectors || !node_keys || !node_key_off))) return fail(CZI_E_INVALID, "null argument");
     std::unique_ptr<czi_row_buf> b(new (std::nothrow) czi_row_buf);
     if (!b) return fail(CZI_E_OOM, "out of host memory");
-    const int rc = guarded([&] { encode_index_rows(desc, vectors, node_keys, node_key_off, level_dist, relation_id, *b); });
+    const int rc = guarded([&] { encode_index_rows(desc, vectors, node_keys, node_key_off, level_dist, level_degree, relation_id, *b); });
     if (rc) return rc;
     *out = b.release();
     return CZI_OK;

@@ -34,6 +34,8 @@ extern "C" {
 
 #define CZ_NONE 0xFFFFFFFFu
 #define CZ_DEVICE_PTRS 1u
+/* cz_hnsw_build / cz_hnsw_insert: HnswIndexManifest::extend_candidates (runtime/hnsw.rs:499-511) */
+#define CZ_HNSW_EXTEND_CANDIDATES 256u
 /* cz_pagerank_plan_create: force one of the two device formulations of the sweep (default: chosen from the
  * shard's shape; the environment variable CZ_PR_MODE = gather | blocked overrides the default too) */
 #define CZ_PR_GATHER 2u
@@ -97,7 +99,7 @@ uint64_t cz_hnsw_index_bytes(const cz_hnsw_index *ix);
 /* Index construction on the GPU: hnsw_put over all rows in key order (runtime/hnsw.rs:155-538, 679-727;
  * create_hnsw_index, runtime/relation.rs:1010-1201), as a batch-parallel insert.
  *   vectors [n][dim] f32 [dev-able]; m, ef_construction, keep_pruned_connections as HnswIndexManifest
- *   (m_max = m, m_max0 = 2m; extend_candidates is not supported on the GPU).
+ *   (m_max = m, m_max0 = 2m); flags & CZ_HNSW_EXTEND_CANDIDATES = HnswIndexManifest::extend_candidates (:499-511).
  *   levels [n] (host, may be NULL): level of every vector as the non-negative -layer of get_random_level
  *   (:46-52); NULL draws floor(-ln(U)/ln(m)) from `seed` (the reference uses an unseedable thread_rng).
  *   max_batch: vectors inserted concurrently (0 = default 4096; 1 reproduces the sequential algorithm and its
@@ -140,6 +142,9 @@ int cz_hnsw_index_level_info(const cz_hnsw_index *ix, int32_t level, uint32_t *s
 int cz_hnsw_index_export_level(const cz_hnsw_index *ix, int32_t level, uint32_t *node_ids /* [size] or NULL */,
                                uint32_t *nbrs /* [size][width] */);
 int cz_hnsw_index_export_vectors(const cz_hnsw_index *ix, float *out /* [n][dim] */);
+/* the f64 of every self row of a level (runtime/hnsw.rs:270, 338-357), in cz_hnsw_index_export_level's node order: the
+ * number of live link rows, plus one where an extend_candidates shrink selected the node itself (:413-433) */
+int cz_hnsw_index_export_degrees(const cz_hnsw_index *ix, int32_t level, double *degree /* [size] */);
 
 /* SessionTx::hnsw_knn (runtime/hnsw.rs:869-1012) for a whole batch of parent tuples
  * (HnswSearchRA::iter, query/ra.rs:1085-1121, calls it once per tuple).

@@ -136,6 +136,12 @@ typedef struct czi_row_buf czi_row_buf;
 int czi_hnsw_encode_rows(const cz_hnsw_desc *desc, const float *vectors, const uint8_t *node_keys,
                          const uint64_t *node_key_off, const double *const *level_dist, uint64_t relation_id,
                          czi_row_buf **out);
+/* the same with the f64 of the self rows handed in: level_degree[l] = [size] (cz_hnsw_index_export_degrees), or NULL /
+ * a NULL level = the number of link rows.  With extend_candidates a shrink can leave the stored degree one above the link
+ * rows (the target selects itself and the self row is put back, runtime/hnsw.rs:413-433, 352-357). */
+int czi_hnsw_encode_rows_degrees(const cz_hnsw_desc *desc, const float *vectors, const uint8_t *node_keys,
+                                 const uint64_t *node_key_off, const double *const *level_dist,
+                                 const double *const *level_degree, uint64_t relation_id, czi_row_buf **out);
 /* the rows (pointers into the buffer; n_key_cols is left 0 -- the caller knows K) */
 int czi_row_buf_rows(const czi_row_buf *b, czi_rows *rows);
 void czi_row_buf_free(czi_row_buf *b);

@@ -6,6 +6,7 @@ use std::os::raw::{c_char, c_double, c_float, c_int, c_void};
 
 pub const CZ_NONE: u32 = 0xFFFF_FFFF;
 pub const CZ_DEVICE_PTRS: u32 = 1;
+pub const CZ_HNSW_EXTEND_CANDIDATES: u32 = 256;
 pub const CZ_PR_GATHER: u32 = 2;
 pub const CZ_PR_BLOCKED: u32 = 4;
 pub const CZ_BF_GEMM: u32 = 8;
@@ -111,6 +112,7 @@ extern "C" {
     pub fn cz_hnsw_index_level_info(ix: *const cz_hnsw_index, level: i32, size: *mut u32, width: *mut i32) -> c_int;
     pub fn cz_hnsw_index_export_level(ix: *const cz_hnsw_index, level: i32, node_ids: *mut u32, nbrs: *mut u32) -> c_int;
     pub fn cz_hnsw_index_export_vectors(ix: *const cz_hnsw_index, out: *mut c_float) -> c_int;
+    pub fn cz_hnsw_index_export_degrees(ix: *const cz_hnsw_index, level: i32, degree: *mut c_double) -> c_int;
     pub fn cz_hnsw_search_batch(ix: *mut cz_hnsw_index, queries: *const c_float, b: u32, k: u32, ef: u32, has_radius: c_int,
                                 radius: c_double, out_ids: *mut u32, out_dist: *mut c_double, out_count: *mut u32,
                                 out_n_dist: *mut u64, poison: *const u8, flags: u32, stream: *mut c_void) -> c_int;
@@ -282,6 +284,9 @@ extern "C" {
     pub fn czi_hnsw_encode_rows(desc: *const cz_hnsw_desc, vectors: *const c_float, node_keys: *const u8,
                                 node_key_off: *const u64, level_dist: *const *const c_double, relation_id: u64,
                                 out: *mut *mut czi_row_buf) -> c_int;
+    pub fn czi_hnsw_encode_rows_degrees(desc: *const cz_hnsw_desc, vectors: *const c_float, node_keys: *const u8,
+                                        node_key_off: *const u64, level_dist: *const *const c_double,
+                                        level_degree: *const *const c_double, relation_id: u64, out: *mut *mut czi_row_buf) -> c_int;
     pub fn czi_row_buf_rows(b: *const czi_row_buf, rows: *mut czi_rows) -> c_int;
     pub fn czi_row_buf_free(b: *mut czi_row_buf);
 }

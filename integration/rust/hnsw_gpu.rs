@@ -217,16 +217,20 @@ impl<'a> SessionTx<'a> {
         let mut h = std::ptr::null_mut();
         check(unsafe {
             cz_hnsw_build(vectors.as_ptr(), n, mf.vec_dim as u32, mf.distance as c_int, mf.m_neighbours as u32, mf.ef_construction as u32,
-                          mf.keep_pruned_connections as c_int, std::ptr::null(), rand::random(), 0, std::ptr::null_mut(), &mut h, 0,
-                          std::ptr::null_mut())
+                          mf.keep_pruned_connections as c_int, std::ptr::null(), rand::random(), 0, std::ptr::null_mut(), &mut h,
+                          if mf.extend_candidates { CZ_HNSW_EXTEND_CANDIDATES } else { 0 }, std::ptr::null_mut())
         })?;
         // export the link tables, recompute the link distances with the kernels' arithmetic, encode the rows
         let (mut nn, mut dim, mut metric, mut n_levels, mut entry) = (0u32, 0u32, 0i32, 0i32, 0u32);
         check(unsafe { cz_hnsw_index_info(h, &mut nn, &mut dim, &mut metric, &mut n_levels, &mut entry) })?;
         let (mut sizes, mut widths) = (vec![0u32; n_levels as usize], vec![0i32; n_levels as usize]);
-        let (mut ids, mut nbrs, mut dists) = (vec![], vec![], vec![]);
+        let (mut ids, mut nbrs, mut dists, mut degrees) = (vec![], vec![], vec![], vec![]);
         for lv in 0..n_levels as usize {
             check(unsafe { cz_hnsw_index_level_info(h, lv as i32, &mut sizes[lv], &mut widths[lv]) })?;
+            // the f64 of the self rows (hnsw.rs:270, 338-357): with extend_candidates not always the number of link rows
+            let mut dg = vec![0f64; sizes[lv] as usize];
+            check(unsafe { cz_hnsw_index_export_degrees(h, lv as i32, dg.as_mut_ptr()) })?;
+            degrees.push(dg);
             let (mut i, mut t) = (vec![0u32; sizes[lv] as usize], vec![0u32; sizes[lv] as usize * widths[lv] as usize]);
             check(unsafe { cz_hnsw_index_export_level(h, lv as i32, i.as_mut_ptr(), t.as_mut_ptr()) })?;
             let (mut pairs, mut slot) = (vec![], vec![]);
@@ -250,11 +254,13 @@ impl<'a> SessionTx<'a> {
         unsafe { cz_hnsw_index_destroy(h) };
         let (ids_p, nbrs_p, dist_p) = (ids.iter().map(|v| v.as_ptr()).collect_vec(), nbrs.iter().map(|v| v.as_ptr()).collect_vec(),
                                        dists.iter().map(|v| v.as_ptr()).collect_vec());
+        let degree_p = degrees.iter().map(|v| v.as_ptr()).collect_vec();
         let desc = cz_hnsw_desc { n, dim, metric, n_levels, entry, level_size: sizes.as_ptr(), level_width: widths.as_ptr(),
                                   level_nodes: ids_p.as_ptr(), level_nbrs: nbrs_p.as_ptr() };
         let mut buf = std::ptr::null_mut();
         check_ingest(unsafe {
-            czi_hnsw_encode_rows(&desc, vectors.as_ptr(), node_keys.as_ptr(), node_key_off.as_ptr(), dist_p.as_ptr(), config.idx_handle.id.0, &mut buf)
+            czi_hnsw_encode_rows_degrees(&desc, vectors.as_ptr(), node_keys.as_ptr(), node_key_off.as_ptr(), dist_p.as_ptr(), degree_p.as_ptr(),
+                                         config.idx_handle.id.0, &mut buf)
         })?;
         let mut rows = std::mem::MaybeUninit::<czi_rows>::uninit();
         unsafe { czi_row_buf_rows(buf, rows.as_mut_ptr()) };
@@ -275,7 +281,7 @@ impl<'a> SessionTx<'a> {
 // in one call, the `tbl:idx` rows are encoded again, and only what differs from the stored rows is written.
 impl<'a> SessionTx<'a> {
     /// `stored`: the `tbl:idx` rows as the store holds them (one scan, ascending by key -- scan_bytes above);
-    /// `encode_rows(gpu)`: the export + cz_distance_batch + czi_hnsw_encode_rows sequence of hnsw_build_gpu, for the index as it
+    /// `encode_rows(gpu)`: the export + cz_distance_batch + czi_hnsw_encode_rows_degrees sequence of hnsw_build_gpu, for the index as it
     /// is now, with the removed nodes' level-0 rows left out.  Both are ascending by key bytes: one merge walk.
     pub(crate) fn hnsw_write_back_delta(&mut self, stored: &StoredBytes, now: &StoredBytes) -> Result<(usize, usize)> {
         let key = |b: &'_ StoredBytes, i: usize| -> (usize, usize) { (b.key_off[i] as usize, b.key_off[i + 1] as usize) };
@@ -322,7 +328,8 @@ impl<'a> SessionTx<'a> {
         let mf = &config.manifest;
         check(unsafe {
             cz_hnsw_insert(gpu.handle, new_vectors.as_ptr(), n_new, mf.m_neighbours as u32, mf.ef_construction as u32,
-                           mf.keep_pruned_connections as c_int, std::ptr::null(), rand::random(), 0, std::ptr::null_mut(), 0, std::ptr::null_mut())
+                           mf.keep_pruned_connections as c_int, std::ptr::null(), rand::random(), 0, std::ptr::null_mut(),
+                           if mf.extend_candidates { CZ_HNSW_EXTEND_CANDIDATES } else { 0 }, std::ptr::null_mut())
         })
     }
 }

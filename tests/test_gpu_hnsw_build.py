@@ -92,8 +92,6 @@ def test_build_edge_cases(gpu_lib, oracle):
     b = GpuHnswIndex.build(man, x, seed=9, max_batch=1).export()
     assert all(np.array_equal(u, v) for u, v in zip(a[1], b[1]))
     with pytest.raises(_lib.CozoGpuError):
-        GpuHnswIndex.build(HnswIndexManifest(vec_dim=8, m_neighbours=4, extend_candidates=True), x)
-    with pytest.raises(_lib.CozoGpuError):
         GpuHnswIndex.build(HnswIndexManifest(vec_dim=8, m_neighbours=200), x)
 
 
@@ -320,3 +318,89 @@ def test_entry_point_is_the_smallest_key_on_the_top_layer(gpu_lib, oracle):
     expect = min(top_nodes, key=lambda v: rank[v])
     assert g.export()[2] == b.export().entry == expect
     g.close()
+
+
+EXT_CASES = [
+    (500, 24, "L2", 0, 4, 20, False, "uniform"),
+    (360, 100, "Cosine", 1, 6, 16, True, "lowrank"),
+    (300, 768, "Cosine", 1, 4, 12, False, "lowrank"),
+    (400, 33, "IP", 2, 3, 10, True, "normal"),
+]
+
+
+def _oracle_degrees(b, flat):
+    return [np.array([b.degree(int(v), lv) for v in flat.level_nodes[lv]]) for lv in range(flat.n_levels)]
+
+
+@pytest.mark.parametrize("n,dim,dist,metric,m,efc,keep,kind", EXT_CASES)
+def test_sequential_build_with_extend_candidates_identical_to_oracle(gpu_lib, oracle, n, dim, dist, metric, m, efc, keep, kind):
+    """extend_candidates (hnsw.rs:499-511) with max_batch = 1: the neighbours' neighbours join the heuristic's candidates
+    (a scratch array in global memory, sorted, chunked through the LDS list), one neighbour after the other gets its reverse
+    link and its shrink, and a shrink that selects the target itself leaves a degree one above the row's links (:413-433,
+    :352-357; pinned for the oracle by tests/literal_hnsw_store.py).  Tables AND degrees equal the oracle's; so do the tables
+    of build(first part) + insert(second part), which carries the self-link flags across the two calls."""
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest
+    x = util.vectors(n, dim, 13, kind)
+    levels = oracle.random_levels(n, m, 4)
+    b = oracle.HnswBuilder(dim, metric, m, efc, extend_candidates=True, keep_pruned_connections=keep, dot_mode=oracle.DOT_GPU)
+    b.insert(x, levels)
+    flat = b.export()
+    want_deg = _oracle_degrees(b, flat)
+    man = HnswIndexManifest(vec_dim=dim, distance=dist, m_neighbours=m, ef_construction=efc, extend_candidates=True,
+                            keep_pruned_connections=keep)
+    whole = GpuHnswIndex.build(man, x, levels=levels, max_batch=1)
+    h = n * 2 // 3
+    parts = GpuHnswIndex.build(man, x[:h], levels=levels[:h], max_batch=1)
+    parts.insert(x[h:], levels=levels[h:], max_batch=1)
+    self_links = 0
+    for g in (whole, parts):
+        nodes, nbrs, entry = g.export()
+        assert entry == flat.entry and len(nbrs) == flat.n_levels
+        deg = g.degrees()
+        for lv in range(flat.n_levels):
+            assert np.array_equal(nodes[lv], flat.level_nodes[lv])
+            assert np.array_equal(nbrs[lv], flat.level_nbrs[lv]), f"level {lv} link rows differ"
+            assert np.array_equal(deg[lv], want_deg[lv]), f"level {lv} degrees differ"
+            self_links += int((deg[lv] - (nbrs[lv] != 0xFFFFFFFF).sum(axis=1)).sum())
+        g.close()
+    assert self_links > 0  # the quirk was exercised
+    # and it is a different index from the one built without the extension
+    plain = oracle.HnswBuilder(dim, metric, m, efc, keep_pruned_connections=keep, dot_mode=oracle.DOT_GPU)
+    plain.insert(x, levels)
+    assert not np.array_equal(plain.export().level_nbrs[0], flat.level_nbrs[0])
+
+
+def test_batched_build_with_extend_candidates(gpu_lib, oracle):
+    """Batched: shrinks of one round read the rows as the round found them (staged selections), so two builds give the same
+    tables; structure and search quality as for the plain batched build."""
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest, HnswSearch
+    n, dim, m, efc = 12000, 48, 8, 40
+    x = util.vectors(n, dim, 23, "lowrank")
+    q = util.vectors(200, dim, 24, "lowrank")
+    levels = oracle.random_levels(n, m, 6)
+    man = HnswIndexManifest(vec_dim=dim, distance="L2", m_neighbours=m, ef_construction=efc, extend_candidates=True)
+    g = GpuHnswIndex.build(man, x, levels=levels, max_batch=512)
+    nodes, nbrs, entry = g.export()
+    g2 = GpuHnswIndex.build(man, x, levels=levels, max_batch=512)
+    assert all(np.array_equal(a, c) for a, c in zip(nbrs, g2.export()[1]))
+    assert all(np.array_equal(a, c) for a, c in zip(g.degrees(), g2.degrees()))
+    for lv in range(len(nbrs)):
+        tab = nbrs[lv]
+        assert tab.shape[1] == (2 * m if lv == 0 else m)
+        live = tab != 0xFFFFFFFF
+        assert (tab[live] < n).all() and not (tab == nodes[lv][:, None]).any()
+        extra = g.degrees()[lv] - live.sum(axis=1)
+        assert ((extra == 0) | (extra == 1)).all()
+        if lv > 0:
+            assert np.isin(tab[live], nodes[lv]).all()
+    ids, dist, cnt = g.hnsw_knn_batch(q, HnswSearch(k=10, ef=64))
+    flat = oracle.FlatIndex(x, oracle.L2, nodes, nbrs, entry)
+    oids, odist, _, _ = flat.knn_batch(q, 10, 64, dot_mode=oracle.DOT_GPU)
+    assert np.array_equal(ids, oids) and np.array_equal(dist, odist)
+    gt, _ = g.bruteforce_knn(q, 10)
+    rec = np.mean([len(set(ids[i]) & set(gt[i])) / 10 for i in range(len(q))])
+    plain = GpuHnswIndex.build(HnswIndexManifest(vec_dim=dim, distance="L2", m_neighbours=m, ef_construction=efc), x, levels=levels,
+                               max_batch=512)
+    pids, _, _ = plain.hnsw_knn_batch(q, HnswSearch(k=10, ef=64))
+    rec_plain = np.mean([len(set(pids[i]) & set(gt[i])) / 10 for i in range(len(q))])
+    assert rec >= rec_plain - 0.05, (rec, rec_plain)
