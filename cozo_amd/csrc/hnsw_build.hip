@@ -109,7 +109,7 @@ build_insert_kernel(IndexDev ix, BuildTables T, uint32_t b0, uint32_t bn, int to
                     uint32_t efcap, uint32_t wcap, int keep_pruned, uint32_t *__restrict__ vtab, uint32_t hbits,
                     uint32_t *__restrict__ vbitmap, uint32_t words, Req req,
                     uint32_t *__restrict__ req_count, uint32_t req_cap, unsigned long long *__restrict__ ndist_total,
-                    ExtBuf ext) {
+                    ExtBuf ext, int defer_out /* the out links are written one by one, by the link kernel */) {
     constexpr bool extend = EXT;  // a template parameter: the plain build keeps its registers (the extended path spills)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     czh::Smem s = czh::carve(smem_raw, efcap, wcap, ix.ld);
@@ -161,7 +161,7 @@ build_insert_kernel(IndexDev ix, BuildTables T, uint32_t b0, uint32_t bn, int to
                     const uint32_t p = s.sel[k];
                     const uint32_t id = extend ? p : s.wid[p] & kIdMask;
                     const double d = key_dist(extend ? S.ext_sel_key()[k] : s.wkey[p]);
-                    r.ids[k] = id;
+                    r.ids[k] = defer_out ? CZ_NONE : id;
                     r.dst[k] = d;
                     if (base + k < req_cap) {  // the host checks the final count against req_cap
                         req.t[base + k] = id;
@@ -196,11 +196,19 @@ build_insert_kernel(IndexDev ix, BuildTables T, uint32_t b0, uint32_t bn, int to
 // K2
 __global__ void __launch_bounds__(256)
 build_link_kernel(BuildTables T, Req in, uint32_t n, int lazy, Req retry, uint32_t *__restrict__ retry_count,
-                  uint32_t *__restrict__ shrink_t, int32_t *__restrict__ shrink_lv, uint32_t *__restrict__ shrink_count) {
+                  uint32_t *__restrict__ shrink_t, int32_t *__restrict__ shrink_lv, uint32_t *__restrict__ shrink_count,
+                  int out_links) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t t = in.t[i], q = in.q[i];
         const int lv = in.lv[i];
         const double d = in.d[i];
+        if (out_links) {  // (one request per launch) the out link goes in with its reverse link, hnsw.rs:281-318: a shrink
+            const RowRef rq = row_of(T, q, lv);  // between two of them sees the new vector's row as far as it has got
+            int k = 0;
+            while (k < rq.cap - 1 && rq.ids[k] != CZ_NONE) k++;
+            rq.ids[k] = t;
+            rq.dst[k] = d;
+        }
         const RowRef r = row_of(T, t, lv);
         const uint32_t old = atomicAdd(r.deg, 1u);  // the degree of the self row, :338
         const uint32_t slot = old - *r.ph;
@@ -714,7 +722,7 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), smem, stream, dev, T, i, bn, top, entry,                     \
                            (int)ef_construction, efcap, wcap, keep_pruned_connections, b_vtab.p, hbits, b_visited.p, words, \
                            reqA.ref(),                                                                                   \
-                           b_misc.p + 0, (uint32_t)max_req, b_ndist.p, ext);                                              \
+                           b_misc.p + 0, (uint32_t)max_req, b_ndist.p, ext, (extend && max_batch == 1) ? 1 : 0);          \
     } while (0)
         CZ_DISPATCH_BUILD_SHAPE(sh, CZ_LAUNCH_INSERT);
 #undef CZ_LAUNCH_INSERT
@@ -733,7 +741,7 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
                 CZ_HIP(hipMemsetAsync(b_misc.p + 1, 0, 8, stream));
                 const Req one{cur->t.p + k, cur->q.p + k, cur->lv.p + k, cur->d.p + k};
                 hipLaunchKernelGGL(build_link_kernel, dim3(1), dim3(64), 0, stream, T, one, 1u, 0, nxt->ref(), b_misc.p + 1,
-                                   b_shrink_t.p, b_shrink_lv.p, b_misc.p + 2);
+                                   b_shrink_t.p, b_shrink_lv.p, b_misc.p + 2, 1);
                 launch_shrinks(b_shrink_t.p, b_shrink_lv.p, 1u, b_misc.p + 2);
             }
             nreq = 0;
@@ -742,7 +750,7 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
             CZ_HIP(hipMemsetAsync(b_misc.p + 1, 0, 8, stream));  // [1] retry count, [2] shrink count
             hipLaunchKernelGGL(build_link_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>((nreq + 255) / 256, 4096))),
                                dim3(256), 0, stream, T, cur->ref(), nreq, lazy, nxt->ref(), b_misc.p + 1, b_shrink_t.p,
-                               b_shrink_lv.p, b_misc.p + 2);
+                               b_shrink_lv.p, b_misc.p + 2, 0);
             CZ_HIP(hipMemcpyAsync(h, b_misc.p, 32, hipMemcpyDeviceToHost, stream));
             CZ_HIP(hipStreamSynchronize(stream));
             const uint32_t nretry = h[1], nshrink = h[2];
