@@ -22,6 +22,7 @@
 // sequential algorithm's.  Levels are drawn by the caller (hnsw.rs:46-52 uses an unseedable thread_rng).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -147,7 +148,7 @@ build_insert_kernel(IndexDev ix, BuildTables T, uint32_t b0, uint32_t bn, int to
                     gi[ext.cap + k] = s.wid[k];
                 }
                 S.clear_visited();
-                const uint32_t nc = S.gather_extended(lv, gk, gi, wcap);
+                const uint32_t nc = S.gather_extended(lv, gk, gi, wcap, ext.cap);
                 S.sort_scratch(gk, gi, nc);
                 nsel = S.select_extended(gk, gi, nc, r.width, keep_pruned != 0, efcap);
             } else {
@@ -197,7 +198,7 @@ build_insert_kernel(IndexDev ix, BuildTables T, uint32_t b0, uint32_t bn, int to
 __global__ void __launch_bounds__(256)
 build_link_kernel(BuildTables T, Req in, uint32_t n, int lazy, Req retry, uint32_t *__restrict__ retry_count,
                   uint32_t *__restrict__ shrink_t, int32_t *__restrict__ shrink_lv, uint32_t *__restrict__ shrink_count,
-                  int out_links) {
+                  int out_links, int upsert) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t t = in.t[i], q = in.q[i];
         const int lv = in.lv[i];
@@ -210,6 +211,14 @@ build_link_kernel(BuildTables T, Req in, uint32_t n, int lazy, Req retry, uint32
             rq.dst[k] = d;
         }
         const RowRef r = row_of(T, t, lv);
+        if (upsert) {
+            // extend_candidates, batched: while this request waited for room, a shrink of `t` may have picked q up through
+            // the extension and linked it already.  The reference's put of an existing row replaces it (:300-318): no second
+            // entry, no degree change beyond the one the shrink accounted for.
+            bool held = false;
+            for (int k = 0; k < r.cap; k++) held |= r.ids[k] == q;
+            if (held) continue;
+        }
         const uint32_t old = atomicAdd(r.deg, 1u);  // the degree of the self row, :338
         const uint32_t slot = old - *r.ph;
         if (slot < (uint32_t)r.cap) {
@@ -278,6 +287,9 @@ build_shrink_kernel(IndexDev ix, BuildTables T, const uint32_t *__restrict__ shr
         const RowRef r = row_of(T, t, lv);
         S.load_query(ix.vec + (size_t)t * ix.ld);  // hnsw.rs:386-387
         const int c = (int)min(*r.deg - *r.ph, (uint32_t)r.cap);
+        CZ_CHECK(t < ix.n && *r.deg >= *r.ph && *r.deg - *r.ph <= (uint32_t)r.cap, "shrink: node %u level %d degree %u self %u cap %d\n", t,
+                 lv, *r.deg, (unsigned)*r.ph, r.cap);
+        if (tid < c) CZ_CHECK(r.ids[tid] < ix.n, "shrink: node %u level %d slot %d of %d holds %u\n", t, lv, tid, c, r.ids[tid]);
         // candidates = live links with their stored distances (:389-393), sorted by (distance, id)
         uint64_t mk = 0;
         uint32_t mi = CZ_NONE;
@@ -316,9 +328,10 @@ build_shrink_kernel(IndexDev ix, BuildTables T, const uint32_t *__restrict__ shr
             // selected is staged: the other shrinks of this round still read this row as the round found it
             uint64_t *gk = ext.cand_key(blockIdx.x);
             uint32_t *gi = ext.cand_id(blockIdx.x);
-            const uint32_t nc = S.gather_extended(lv, gk, gi, wcap);
+            const uint32_t nc = S.gather_extended(lv, gk, gi, wcap, ext.cap);
             S.sort_scratch(gk, gi, nc);
             const int nsel = S.select_extended(gk, gi, nc, r.width, keep_pruned != 0, efcap);
+            CZ_CHECK(nsel <= r.width && nsel <= stage.width + 1, "shrink: %d selected, width %d\n", nsel, r.width);
             if (tid == 0) {
                 int at = -1;
                 for (int k = 0; k < nsel; k++)
@@ -656,6 +669,13 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
         stage.n = b_stage_n.p;
         stage.self = b_stage_self.p;
     }
+    // CZ_BUILD_TRACE=1: wait after every stage and name it (a faulting kernel is the one after the last name printed)
+    const bool trace = getenv("CZ_BUILD_TRACE") && atoi(getenv("CZ_BUILD_TRACE")) != 0;
+    auto stage_done = [&](const char *what, uint32_t count) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(stream);
+        fprintf(stderr, "[build] %s (%u) done\n", what, count);
+    };
     // one round of shrinks: rows [0, count) of the request arrays (count on the host, or read on the device when `count_dev`)
     auto launch_shrinks = [&](const uint32_t *sh_t, const int32_t *sh_lv, uint32_t count, const uint32_t *count_dev) {
         for (uint32_t off = 0; off < count; off += extend ? kStageRows : count) {
@@ -672,9 +692,11 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
     } while (0)
             CZ_DISPATCH_BUILD_SHAPE(sh, CZ_LAUNCH_SHRINK);
 #undef CZ_LAUNCH_SHRINK
+            stage_done("shrink", part);
             if (extend)
                 hipLaunchKernelGGL(build_apply_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>((part + 3) / 4, 4096))),
                                    dim3(256), 0, stream, T, sh_t + off, sh_lv + off, part, count_dev, stage);
+            stage_done("apply", part);
         }
     };
 
@@ -726,6 +748,7 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
     } while (0)
         CZ_DISPATCH_BUILD_SHAPE(sh, CZ_LAUNCH_INSERT);
 #undef CZ_LAUNCH_INSERT
+        stage_done("insert", bn);
         uint32_t h[8];
         CZ_HIP(hipMemcpyAsync(h, b_misc.p, 32, hipMemcpyDeviceToHost, stream));
         CZ_HIP(hipStreamSynchronize(stream));
@@ -741,7 +764,7 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
                 CZ_HIP(hipMemsetAsync(b_misc.p + 1, 0, 8, stream));
                 const Req one{cur->t.p + k, cur->q.p + k, cur->lv.p + k, cur->d.p + k};
                 hipLaunchKernelGGL(build_link_kernel, dim3(1), dim3(64), 0, stream, T, one, 1u, 0, nxt->ref(), b_misc.p + 1,
-                                   b_shrink_t.p, b_shrink_lv.p, b_misc.p + 2, 1);
+                                   b_shrink_t.p, b_shrink_lv.p, b_misc.p + 2, 1, 0);
                 launch_shrinks(b_shrink_t.p, b_shrink_lv.p, 1u, b_misc.p + 2);
             }
             nreq = 0;
@@ -750,7 +773,8 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
             CZ_HIP(hipMemsetAsync(b_misc.p + 1, 0, 8, stream));  // [1] retry count, [2] shrink count
             hipLaunchKernelGGL(build_link_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>((nreq + 255) / 256, 4096))),
                                dim3(256), 0, stream, T, cur->ref(), nreq, lazy, nxt->ref(), b_misc.p + 1, b_shrink_t.p,
-                               b_shrink_lv.p, b_misc.p + 2, 0);
+                               b_shrink_lv.p, b_misc.p + 2, 0, extend);
+            stage_done("link", nreq);
             CZ_HIP(hipMemcpyAsync(h, b_misc.p, 32, hipMemcpyDeviceToHost, stream));
             CZ_HIP(hipStreamSynchronize(stream));
             const uint32_t nretry = h[1], nshrink = h[2];

@@ -42,6 +42,13 @@ __device__ unsigned long long cz_phase_cycles[8];
 #define CZ_PH_FLUSH() do {} while (0)
 #endif
 
+// consistency checks of the index construction (debug builds: -DCZ_BUILD_CHECKS): a message and a trap
+#ifdef CZ_BUILD_CHECKS
+#define CZ_CHECK(cond, ...) do { if (!(cond)) { printf("CZ_CHECK " __VA_ARGS__); __builtin_trap(); } } while (0)
+#else
+#define CZ_CHECK(cond, ...) do {} while (0)
+#endif
+
 constexpr uint32_t kExpanded = 0x80000000u;
 constexpr uint32_t kIdMask = 0x7FFFFFFFu;
 constexpr int kThreads = 256;
@@ -330,7 +337,8 @@ struct Searcher {
     // W and the not-yet-seen neighbours of its entries, with their distances to the register-resident vector -> the
     // scratch array; returns how many.  The visited set must be empty on entry and is empty again on return (it is the
     // `one entry per key` of PriorityQueue::push here).  W itself is left alone.
-    __device__ uint32_t gather_extended(int level, uint64_t *__restrict__ gkey, uint32_t *__restrict__ gid, uint32_t wcap) {
+    __device__ uint32_t gather_extended(int level, uint64_t *__restrict__ gkey, uint32_t *__restrict__ gid, uint32_t wcap,
+                                        uint32_t gcap) {
         static_assert(ITERS > 0, "index construction needs a register-resident vector (dim <= 2048)");
         const int cnt = s.ctl[C_CNT];
         for (int i = tid; i < cnt; i += kThreads) {
@@ -366,6 +374,9 @@ struct Searcher {
             const int n = s.ctl[C_TODO];
             i = s.ctl[C_KEEP];
             if (n > 0) {
+                CZ_CHECK(total + (uint32_t)n <= gcap, "gather: %u + %d candidates, room for %u (level %d, cnt %d)\n", total, n, gcap, level, cnt);
+                for (int j = tid; j < n; j += kThreads)
+                    CZ_CHECK(tcur[j] < ix.n, "gather: candidate id %u of %u nodes (level %d, slot %d of %d)\n", tcur[j], ix.n, level, j, n);
                 eval_todo(n);
                 __syncthreads();
                 for (int j = tid; j < n; j += kThreads) {
@@ -848,6 +859,7 @@ struct Searcher {
         for (int c0 = 0; c0 < width; c0 += 64) {
             const int c = c0 + lane;
             const uint32_t nb = c < width ? row[c] : CZ_NONE;
+            CZ_CHECK(nb == CZ_NONE || nb < ix.n, "expand_row: node %u level %d slot %d holds %u (n = %u)\n", cand, level, c, nb, ix.n);
             uint32_t where;
             const bool fresh = visit(nb, nb != CZ_NONE, where);
             const unsigned long long m = __ballot(fresh);
