@@ -310,6 +310,24 @@ def test_sha256_of_the_row_encoder_known_answers():
         assert [t[7] for t in selfs] == [1.0, 1.0]
 
 
+def test_row_encoder_takes_the_degrees_of_the_self_rows():
+    """czi_hnsw_encode_rows_degrees: the f64 of a self row is what the caller hands in (cz_hnsw_index_export_degrees: with
+    extend_candidates a shrink leaves it one above the number of link rows, hnsw.rs:413-433 + 352-357); without, the link count"""
+    from cozo_amd.ingest import encode_index_rows
+    vecs = np.arange(12, dtype=np.float32).reshape(3, 4)
+    nb = [np.array([[1, 2], [0, NONE], [0, NONE]], dtype=np.uint32), np.array([[NONE]], dtype=np.uint32)]
+    nodes = [None, np.array([1], dtype=np.uint32)]
+    keys = [(10, 1, -1), (11, 1, -1), (12, 1, -1)]
+    dist = [np.ones((3, 2)), np.zeros((1, 1))]
+    plain = encode_index_rows(keys, vecs, nodes, nb, 1, 0, dist, 5).tuples()
+    given = encode_index_rows(keys, vecs, nodes, nb, 1, 0, dist, 5, level_degree=[np.array([3.0, 1.0, 2.0]), np.array([0.0])]).tuples()
+    selfs = lambda tup: {(t[0], t[1]): t[7] for t in tup if t[0] <= 0 and t[1:4] == t[4:7]}
+    assert selfs(plain) == {(0, 10): 2.0, (0, 11): 1.0, (0, 12): 1.0, (-1, 11): 0.0}
+    assert selfs(given) == {(0, 10): 3.0, (0, 11): 1.0, (0, 12): 2.0, (-1, 11): 0.0}
+    strip = lambda tup: [t for t in tup if not (t[0] <= 0 and t[1:4] == t[4:7])]
+    assert strip(plain) == strip(given)
+
+
 def _dump(rows: codec.StoredRows, path):
     import struct
     with open(path, "wb") as f:
