@@ -410,3 +410,32 @@ def test_batched_build_with_extend_candidates(gpu_lib, oracle, monkeypatch):
     pids, _, _ = plain.hnsw_knn_batch(q, HnswSearch(k=10, ef=64))
     rec_plain = np.mean([len(set(pids[i]) & set(gt[i])) / 10 for i in range(len(q))])
     assert rec >= rec_plain - 0.05, (rec, rec_plain)
+
+
+def test_write_back_with_extend_candidates_carries_the_degrees(oracle, gpu_lib):
+    """The self rows written back hold the reference's degree (cz_hnsw_index_export_degrees -> czi_hnsw_encode_rows_degrees): with
+    extend_candidates one above the node's link rows wherever a shrink selected the node itself."""
+    from cozo_amd import build as B
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest
+    B.build_ingest()
+    n, dim, m = 400, 16, 4
+    vecs = util.vectors(n, dim, 3)
+    levels = oracle.random_levels(n, m, 8)
+    man = HnswIndexManifest(vec_dim=dim, distance="L2", m_neighbours=m, ef_construction=16, extend_candidates=True)
+    ix = GpuHnswIndex.build(man, vecs, levels=levels, max_batch=1)
+    b = oracle.HnswBuilder(dim, oracle.L2, m, 16, extend_candidates=True, dot_mode=oracle.DOT_GPU)
+    b.insert(vecs, levels)
+    keys = [(i, 1, -1) for i in range(n)]
+    tup = ix.index_rows(keys, relation_id=3).tuples()
+    selfs = {(-t[0], t[1]): t[7] for t in tup if t[0] <= 0 and t[1:4] == t[4:7]}
+    links = {}
+    for t in tup:
+        if t[0] <= 0 and t[1:4] != t[4:7]:
+            links[(-t[0], t[1])] = links.get((-t[0], t[1]), 0) + 1
+    assert len(selfs) == int((levels + 1).sum())
+    above = 0
+    for (lv, node), deg in selfs.items():
+        assert deg == b.degree(node, lv)
+        above += int(deg) - links.get((lv, node), 0)
+    assert above > 0
+    ix.close()
