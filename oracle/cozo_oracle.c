@@ -283,7 +283,16 @@ struct orc_hnsw {
     uint64_t n_dist;
     uint32_t *key_rank; /* position of every node's key among all keys; NULL = ids are key order (orc_hnsw_set_key_order) */
     uint32_t n_rank;
+    uint32_t *row_of; /* the base row every node's vector comes from; NULL = one vector per row (orc_hnsw_set_row_of) */
+    uint32_t n_row_of;
 };
+/* hnsw_get_neighbours drops every link whose far end lies in the SAME base row as the node asked about (key_tup == cand_key.0,
+ * runtime/hnsw.rs:609-610): rows that carry several indexed vectors (a List of vectors, several vec_fields, :694-706).  Such a
+ * link row is written like any other (:281-318) and counted into both degrees, but no reader ever sees it -- not the search, not
+ * the extension, not the shrink (which therefore never drops it and does not count it into the new degree), not the removal. */
+static int same_row(const orc_hnsw *h, uint32_t a, uint32_t b) {
+    return h->row_of && a < h->n_row_of && b < h->n_row_of && h->row_of[a] == h->row_of[b];
+}
 /* the index relation is scanned in KEY order: its first row -- the entry point -- is the smallest key on the top layer */
 static int key_before(const orc_hnsw *h, uint32_t a, uint32_t b) {
     if (!h->key_rank || a >= h->n_rank || b >= h->n_rank || h->key_rank[a] == h->key_rank[b]) return a < b;
@@ -317,6 +326,7 @@ void orc_hnsw_free(orc_hnsw *h) {
     free(h->vecs);
     free(h->stamp);
     free(h->key_rank);
+    free(h->row_of);
     free(h);
 }
 void orc_hnsw_set_key_order(orc_hnsw *h, const uint32_t *rank, uint32_t n) {
@@ -327,6 +337,16 @@ void orc_hnsw_set_key_order(orc_hnsw *h, const uint32_t *rank, uint32_t n) {
         h->key_rank = (uint32_t *)malloc(sizeof(uint32_t) * n);
         memcpy(h->key_rank, rank, sizeof(uint32_t) * n);
         h->n_rank = n;
+    }
+}
+void orc_hnsw_set_row_of(orc_hnsw *h, const uint32_t *row_of, uint32_t n) {
+    free(h->row_of);
+    h->row_of = NULL;
+    h->n_row_of = 0;
+    if (row_of && n) {
+        h->row_of = (uint32_t *)malloc(sizeof(uint32_t) * n);
+        memcpy(h->row_of, row_of, sizeof(uint32_t) * n);
+        h->n_row_of = n;
     }
 }
 static void adj_upsert(adj_t *a, uint32_t to, double dist, uint8_t ignore) { /* store_tx.put of a link row */
@@ -359,7 +379,8 @@ static int dyn_nbrs(const void *ctx, uint32_t node, int level, uint32_t *out) {
     const adj_t *a = &h->adj[node][level];
     int c = 0;
     for (int i = 0; i < a->n; i++)
-        if (!a->v[i].ignore && h->top[a->v[i].to] >= level) out[c++] = a->v[i].to; /* (rows left dangling by a removal: see orc_hnsw_remove) */
+        if (!a->v[i].ignore && h->top[a->v[i].to] >= level && !same_row(h, node, a->v[i].to))
+            out[c++] = a->v[i].to; /* (rows left dangling by a removal: see orc_hnsw_remove) */
     return c;
 }
 static double hdist(orc_hnsw *h, const float *a, const float *b) {
@@ -419,7 +440,7 @@ static int shrink_neighbour(orc_hnsw *h, uint32_t target, int m, int level) {
     int nold = 0;
     pq_item *old = (pq_item *)malloc(sizeof(pq_item) * (size_t)(a->n + 1));
     for (int i = 0; i < a->n; i++)
-        if (!a->v[i].ignore) { /* :389-393 stored distances, not recomputed */
+        if (!a->v[i].ignore && !same_row(h, target, a->v[i].to)) { /* :389-393 stored distances, not recomputed */
             old[nold].id = a->v[i].to;
             old[nold].d = a->v[i].dist;
             nold++;
@@ -553,6 +574,7 @@ int orc_hnsw_remove(orc_hnsw *h, uint32_t node) {
         adj_t *a = &h->adj[node][lv];
         for (int i = 0; i < a->n; i++) {
             const uint32_t nb = a->v[i].to;
+            if (same_row(h, node, nb)) continue; /* the walk is hnsw_get_neighbours too: the row and its reverse stay behind, dead */
             if (nb < h->n && h->top[nb] >= lv) {
                 adj_remove(&h->adj[nb][lv], node); /* :796-805 the reverse row, present or not */
                 h->adj[nb][lv].degree -= 1.0;      /* :806-823 */
@@ -609,7 +631,8 @@ void orc_hnsw_export_level(const orc_hnsw *h, int level, uint32_t *node_ids, uin
         const adj_t *a = &h->adj[i][level];
         int c = 0;
         for (int k = 0; k < a->n; k++)
-            if (!a->v[k].ignore && c < w && h->top[a->v[k].to] >= level) tmp[c++] = a->v[k].to; /* (not a row left dangling by a removal) */
+            if (!a->v[k].ignore && c < w && h->top[a->v[k].to] >= level && !same_row(h, i, a->v[k].to))
+                tmp[c++] = a->v[k].to; /* (not a row left dangling by a removal, not a link inside one base row: what readers see) */
         for (int k = 0; k < w; k++) nbrs[(size_t)r * w + k] = k < c ? tmp[k] : ORC_NONE;
         r++;
     }

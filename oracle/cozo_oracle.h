@@ -55,6 +55,9 @@ int orc_hnsw_remove(orc_hnsw *h, uint32_t node);
 /* rank[node] = position of the node's key among all keys (nodes held and to come); NULL = ids are key order.  The entry point
  * is the smallest KEY on the top layer (hnsw.rs:184-191, 891-899). */
 void orc_hnsw_set_key_order(orc_hnsw *h, const uint32_t *rank, uint32_t n);
+/* row_of[node] = the base row the node's vector comes from, for the nodes held and the ones to come; links inside one row are
+ * stored and counted but never read (hnsw.rs:609-610).  NULL: one vector per row. */
+void orc_hnsw_set_row_of(orc_hnsw *h, const uint32_t *row_of, uint32_t n);
 uint64_t orc_hnsw_dangling_links(const orc_hnsw *h);
 double orc_hnsw_degree(const orc_hnsw *h, uint32_t node, int level);
 uint32_t orc_hnsw_size(const orc_hnsw *h);

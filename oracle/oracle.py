@@ -90,6 +90,8 @@ def lib():
         L.orc_hnsw_dist_count.argtypes = [C.c_void_p]
         L.orc_hnsw_link_rows.restype = C.c_uint64
         L.orc_hnsw_link_rows.argtypes = [C.c_void_p, C.c_int]
+        L.orc_hnsw_set_row_of.restype = None
+        L.orc_hnsw_set_row_of.argtypes = [C.c_void_p, _u32p, C.c_uint32]
         L.orc_hnsw_set_key_order.restype = None
         L.orc_hnsw_set_key_order.argtypes = [C.c_void_p, _u32p, C.c_uint32]
         L.orc_hnsw_remove.restype = C.c_int
@@ -246,6 +248,15 @@ class HnswBuilder:
         else:
             r = _u32(key_rank)
             lib().orc_hnsw_set_key_order(self._h, _p(r, _u32p), r.size)
+
+    def set_row_of(self, row_of):
+        """row_of[node] = the base row of the node's vector (nodes held and to come): links inside one row are invisible to
+        every reader (hnsw_get_neighbours, hnsw.rs:609-610)"""
+        if row_of is None:
+            lib().orc_hnsw_set_row_of(self._h, None, 0)
+        else:
+            r = _u32(row_of)
+            lib().orc_hnsw_set_row_of(self._h, _p(r, _u32p), r.size)
 
     def remove(self, nodes):
         """hnsw_remove_vec (hnsw.rs:754-868) for every listed node, in order; how many were indexed"""

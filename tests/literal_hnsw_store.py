@@ -39,22 +39,24 @@ class MaxQueue(dict):  # PriorityQueue<_, OrderedFloat>
 
 
 class LiteralStore:
-    def __init__(self, dist, m, ef_construction, extend_candidates=False, keep_pruned_connections=False):
+    def __init__(self, dist, m, ef_construction, extend_candidates=False, keep_pruned_connections=False, row_of=None):
         """dist(a, b) -> f64 on two f32 vectors (the oracle's orc_distance, so that both models see the same bits)"""
         self.dist = dist
         self.m_max, self.m_max0 = m, 2 * m  # runtime/relation.rs:1136-1151
         self.ef_c = ef_construction
         self.extend = extend_candidates
         self.keep_pruned = keep_pruned_connections
+        self.row_of = row_of  # base row of every node's vector (None: one vector per row)
         self.rows = {}  # (layer <= 0, from, to) -> [f64, hash | None, bool]
         self.vec = []
         self.self_row_overwrites = 0
 
-    # ---- hnsw_get_neighbours, hnsw.rs:588-629 (one vector per row: the same-row rule skips the self row only)
+    # ---- hnsw_get_neighbours, hnsw.rs:588-629: `key_tup == cand_key.0` skips the self row and every link to another vector
+    # of the same base row (:609-610)
     def neighbours(self, cand, layer, include_deleted):
         out = []
         for (la, fr, to) in sorted(k for k in self.rows if k[0] == layer and k[1] == cand):
-            if to == cand:
+            if to == cand or (self.row_of is not None and self.row_of[to] == self.row_of[cand]):
                 continue
             val = self.rows[(la, fr, to)]
             if include_deleted or not val[2]:

@@ -338,3 +338,40 @@ def test_index_construction_equals_a_literal_row_store(oracle, n, dim, metric, m
         assert st.self_row_overwrites > 0 and phantom > 0
     else:
         assert st.self_row_overwrites == 0 and phantom == 0
+
+
+@pytest.mark.parametrize("extend,keep", [(False, False), (True, False), (True, True)])
+def test_rows_with_several_vectors_equal_a_literal_row_store(oracle, extend, keep):
+    """Several indexed vectors per base row (hnsw.rs:694-706): hnsw_get_neighbours drops links inside a row (:609-610), so they
+    are written and counted into the degrees but never searched, extended over, shrunk away or removed.  The oracle with
+    orc_hnsw_set_row_of against the literal row store with the same rule."""
+    from tests.literal_hnsw_store import LiteralStore
+    n, dim, m, efc = 150, 5, 3, 10
+    rng = np.random.default_rng(4)
+    row_of = np.sort(rng.integers(0, n // 3, n)).astype(np.uint32)  # ~3 vectors per row, rows in key order
+    base = rng.random((n // 3, dim), dtype=np.float32)
+    x = (base[row_of] + 0.05 * rng.standard_normal((n, dim))).astype(np.float32)  # a row's vectors are near each other
+    levels = oracle.random_levels(n, m, 2)
+    b = oracle.HnswBuilder(dim, oracle.L2, m, efc, extend_candidates=extend, keep_pruned_connections=keep)
+    b.set_row_of(row_of)
+    b.insert(x, levels)
+    flat = b.export()
+    st = LiteralStore(lambda a, c: oracle.distance(oracle.L2, a, c), m, efc, extend, keep, row_of=row_of)
+    for i in range(n):
+        st.put(x[i], int(levels[i]))
+    assert st.entry() == flat.entry
+    hidden = 0
+    for lv in range(flat.n_levels):
+        ids, tab = flat.level_nodes[lv], flat.level_nbrs[lv]
+        for r, node in enumerate(ids):
+            live = [int(t) for t in tab[r] if t != oracle.NONE]
+            assert live == st.live_links(int(node), lv), (lv, int(node))
+            assert not any(row_of[t] == row_of[node] for t in live)
+            assert b.degree(int(node), lv) == st.degree(int(node), lv), (lv, int(node))
+            hidden += sum(1 for k, v in st.rows.items() if k[0] == -lv and k[1] == node and k[2] != node and not v[2]
+                          and row_of[k[2]] == row_of[node])
+    assert hidden > 0  # links inside a row were made, and stayed
+    # a different index from the one that treats every vector as its own row
+    plain = oracle.HnswBuilder(dim, oracle.L2, m, efc, extend_candidates=extend, keep_pruned_connections=keep)
+    plain.insert(x, levels)
+    assert not np.array_equal(plain.export().level_nbrs[0], flat.level_nbrs[0])
