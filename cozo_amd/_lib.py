@@ -90,6 +90,7 @@ SYMBOLS = {
     "cz_hnsw_index_export_level": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "cz_hnsw_index_export_vectors": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cz_hnsw_index_export_degrees": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "cz_hnsw_set_row_of": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "cz_hnsw_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                        C.c_void_p]),

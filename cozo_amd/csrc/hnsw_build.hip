@@ -17,6 +17,10 @@
 // (:413-433, :352-357), so all that remains is a degree one above the number of link rows: `ph` below.  A shrink now reads
 // OTHER rows, so the selections of one round are staged and applied afterwards (every shrink of a round sees the rows as
 // the round found them), and max_batch = 1 links and shrinks one neighbour at a time, in the order of selection.
+// Rows that carry several indexed vectors (:694-706): hnsw_get_neighbours drops every link inside one base row (:609-610), so
+// such a link is written and counted into both degrees but never read again.  With T.row_of set, the tables simply do not
+// hold them (no reader could tell) and the degree word counts them: word = degree | hidden << 16, hidden = the links the
+// degree counts that hold no slot -- links inside a row, and the self link of an extended shrink.
 // Vectors of one batch do not see each other (they are linked after the batch's searches), which is the only
 // difference from the reference's one-at-a-time insertion: with max_batch = 1 the link tables are identical to the
 // sequential algorithm's.  Levels are drawn by the caller (hnsw.rs:46-52 uses an unseedable thread_rng).
@@ -43,17 +47,25 @@ namespace {
 struct BuildTables {
     uint32_t *nbr0;
     double *dst0;
-    uint32_t *deg0;
-    uint8_t *ph0;  // 1 = the degree counts a self link that holds no slot (extend_candidates)
+    uint32_t *deg0;        // degree word per row: the self row's degree | hidden << 16 (deg_of / hid_of)
+    const uint8_t *hid_in0;  // what an earlier build left hidden (read by the unpack kernel only)
     int w0, cap0;
     const uint32_t *up_base;
     uint32_t *nbrU;
     double *dstU;
     uint32_t *degU;
-    uint8_t *phU;
+    const uint8_t *hid_inU;
     int wu, capU;
     const int32_t *level;
+    const uint32_t *row_of;  // base row of every node's vector, or nullptr: one vector per row
 };
+constexpr uint32_t kHiddenOne = 0x10001u;  // one more link in the degree that holds no slot
+constexpr int32_t kReqHidden = 0x40000000;  // request flag (in its level word): the two ends lie in one base row
+__host__ __device__ __forceinline__ uint32_t deg_of(uint32_t w) { return w & 0xFFFFu; }
+__host__ __device__ __forceinline__ uint32_t hid_of(uint32_t w) { return w >> 16; }
+__device__ __forceinline__ bool same_row(const BuildTables &T, uint32_t a, uint32_t b) {
+    return T.row_of && T.row_of[a] == T.row_of[b];
+}
 // extend_candidates scratch: per workgroup `cap` candidate slots (a power of two) and a copy of the found list
 struct ExtBuf {
     uint64_t *key;
@@ -67,7 +79,7 @@ struct Stage {
     uint32_t *ids;  // [rows][width]
     double *dst;
     uint32_t *n;    // [rows] links kept
-    uint8_t *self;  // [rows] the target itself was selected
+    uint8_t *self;  // [rows] selected but not kept: the target itself, vectors of the target's own base row
     int width;
 };
 struct Req {
@@ -79,7 +91,7 @@ struct RowRef {
     uint32_t *ids;
     double *dst;
     uint32_t *deg;
-    uint8_t *ph;
+    const uint8_t *hid_in;
     int width, cap;
 };
 __device__ __forceinline__ RowRef row_of(const BuildTables &T, uint32_t node, int lv) {
@@ -88,7 +100,7 @@ __device__ __forceinline__ RowRef row_of(const BuildTables &T, uint32_t node, in
         r.ids = T.nbr0 + (size_t)node * T.cap0;
         r.dst = T.dst0 + (size_t)node * T.cap0;
         r.deg = T.deg0 + node;
-        r.ph = T.ph0 + node;
+        r.hid_in = T.hid_in0 + node;
         r.width = T.w0;
         r.cap = T.cap0;
     } else {
@@ -96,7 +108,7 @@ __device__ __forceinline__ RowRef row_of(const BuildTables &T, uint32_t node, in
         r.ids = T.nbrU + row * T.capU;
         r.dst = T.dstU + row * T.capU;
         r.deg = T.degU + row;
-        r.ph = T.phU + row;
+        r.hid_in = T.hid_inU + row;
         r.width = T.wu;
         r.cap = T.capU;
     }
@@ -155,25 +167,37 @@ build_insert_kernel(IndexDev ix, BuildTables T, uint32_t b0, uint32_t bn, int to
                 nsel = S.select_heuristic(r.width, keep_pruned != 0);
             }
             if (tid == 0) s.ctl[czh::C_KEEP] = (int)atomicAdd(req_count, (uint32_t)nsel);
-            __syncthreads();
+            // a selected neighbour inside the vector's own base row: link rows and both degrees as for any other (:281-357),
+            // but no reader will ever see the link (:609-610) -- it gets no slot, here or in the neighbour's row
+            uint32_t id = CZ_NONE;
+            double d = 0.0;
+            bool hidden = false;
+            if (tid < nsel) {  // (nsel <= m_max0 <= 192 < kThreads)
+                const uint32_t p = s.sel[tid];
+                id = EXT ? p : s.wid[p] & kIdMask;
+                d = key_dist(EXT ? S.ext_sel_key()[tid] : s.wkey[p]);
+                hidden = same_row(T, id, q);
+                s.st[tid] = hidden ? 1 : 0;
+            }
+            const int nhid = __syncthreads_count(hidden);
             const uint32_t base = (uint32_t)s.ctl[czh::C_KEEP];
-            for (int k = tid; k < r.cap; k += kThreads) {
-                if (k < nsel) {
-                    const uint32_t p = s.sel[k];
-                    const uint32_t id = extend ? p : s.wid[p] & kIdMask;
-                    const double d = key_dist(extend ? S.ext_sel_key()[k] : s.wkey[p]);
-                    r.ids[k] = defer_out ? CZ_NONE : id;
-                    r.dst[k] = d;
-                    if (base + k < req_cap) {  // the host checks the final count against req_cap
-                        req.t[base + k] = id;
-                        req.q[base + k] = q;
-                        req.lv[base + k] = lv;
-                        req.d[base + k] = d;
-                    }
-                } else {
-                    r.ids[k] = CZ_NONE;
+            if (tid < nsel) {
+                int before = 0;
+                if (nhid)
+                    for (int j = 0; j < tid; j++) before += s.st[j];
+                if (!hidden) {
+                    r.ids[tid - before] = defer_out ? CZ_NONE : id;
+                    r.dst[tid - before] = d;
+                }
+                if (base + tid < req_cap) {  // the host checks the final count against req_cap
+                    req.t[base + tid] = id;
+                    req.q[base + tid] = q;
+                    req.lv[base + tid] = lv | (hidden ? kReqHidden : 0);
+                    req.d[base + tid] = d;
                 }
             }
+            for (int k = nsel - nhid + tid; k < r.cap; k += kThreads) r.ids[k] = CZ_NONE;
+            if (tid == 0) *r.deg = (uint32_t)nsel | ((uint32_t)nhid << 16);  // the self row's degree, :269-277
             if (EXT && lv > 0) {  // W was the heuristic's chunk buffer
                 __syncthreads();
                 for (int k = tid; k < found_cnt; k += kThreads) {
@@ -182,7 +206,6 @@ build_insert_kernel(IndexDev ix, BuildTables T, uint32_t b0, uint32_t bn, int to
                 }
                 if (tid == 0) s.ctl[czh::C_CNT] = found_cnt;
             }
-            if (tid == 0) *r.deg = (uint32_t)nsel;  // the self-loop row's degree, :269-277
             S.clear_visited();
         }
         if (tid == 0) {
@@ -201,16 +224,26 @@ build_link_kernel(BuildTables T, Req in, uint32_t n, int lazy, Req retry, uint32
                   int out_links, int upsert) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t t = in.t[i], q = in.q[i];
-        const int lv = in.lv[i];
+        const int lv = in.lv[i] & ~kReqHidden;
+        const bool hidden = (in.lv[i] & kReqHidden) != 0;
         const double d = in.d[i];
-        if (out_links) {  // (one request per launch) the out link goes in with its reverse link, hnsw.rs:281-318: a shrink
-            const RowRef rq = row_of(T, q, lv);  // between two of them sees the new vector's row as far as it has got
+        if (out_links && !hidden) {  // (one request per launch) the out link goes in with its reverse link, hnsw.rs:281-318: a
+            const RowRef rq = row_of(T, q, lv);  // shrink between two of them sees the new vector's row as far as it has got
             int k = 0;
             while (k < rq.cap - 1 && rq.ids[k] != CZ_NONE) k++;
             rq.ids[k] = t;
             rq.dst[k] = d;
         }
         const RowRef r = row_of(T, t, lv);
+        if (hidden) {  // counted (:338), never read (:609-610): no slot; the shrink test is the reference's
+            const uint32_t old = atomicAdd(r.deg, kHiddenOne);
+            if (!lazy && deg_of(old) == (uint32_t)r.width) {
+                const uint32_t p = atomicAdd(shrink_count, 1u);
+                shrink_t[p] = t;
+                shrink_lv[p] = lv;
+            }
+            continue;
+        }
         if (upsert) {
             // extend_candidates, batched: while this request waited for room, a shrink of `t` may have picked q up through
             // the extension and linked it already.  The reference's put of an existing row replaces it (:300-318): no second
@@ -219,14 +252,14 @@ build_link_kernel(BuildTables T, Req in, uint32_t n, int lazy, Req retry, uint32
             for (int k = 0; k < r.cap; k++) held |= r.ids[k] == q;
             if (held) continue;
         }
-        const uint32_t old = atomicAdd(r.deg, 1u);  // the degree of the self row, :338
-        const uint32_t slot = old - *r.ph;
+        const uint32_t old = atomicAdd(r.deg, 1u);  // the degree of the self row, :338 (one word with the hidden count: a
+        const uint32_t slot = deg_of(old) - hid_of(old);  // concurrent hidden link cannot slip between the two)
         if (slot < (uint32_t)r.cap) {
             r.ids[slot] = q;
             r.dst[slot] = d;
             // degree just exceeded the row width: shrink (:339).  Lazy form (batched builds): only when the row's
             // slack slots are used up too -- one re-selection per `slack` appended links instead of one per link
-            if (lazy ? slot == (uint32_t)(r.cap - 1) : old == (uint32_t)r.width) {
+            if (lazy ? slot == (uint32_t)(r.cap - 1) : deg_of(old) == (uint32_t)r.width) {
                 const uint32_t p = atomicAdd(shrink_count, 1u);
                 shrink_t[p] = t;
                 shrink_lv[p] = lv;
@@ -250,7 +283,7 @@ build_overfull_kernel(BuildTables T, uint32_t n, uint32_t *__restrict__ shrink_t
         const int top = T.level[i];
         for (int lv = 0; lv <= top; lv++) {
             const RowRef r = row_of(T, i, lv);
-            if (*r.deg - *r.ph > (uint32_t)r.width) {
+            if (deg_of(*r.deg) - hid_of(*r.deg) > (uint32_t)r.width) {
                 const uint32_t p = atomicAdd(shrink_count, 1u);
                 if (p < cap) {
                     shrink_t[p] = i;
@@ -286,9 +319,10 @@ build_shrink_kernel(IndexDev ix, BuildTables T, const uint32_t *__restrict__ shr
         const int lv = shrink_lv[i];
         const RowRef r = row_of(T, t, lv);
         S.load_query(ix.vec + (size_t)t * ix.ld);  // hnsw.rs:386-387
-        const int c = (int)min(*r.deg - *r.ph, (uint32_t)r.cap);
-        CZ_CHECK(t < ix.n && *r.deg >= *r.ph && *r.deg - *r.ph <= (uint32_t)r.cap, "shrink: node %u level %d degree %u self %u cap %d\n", t,
-                 lv, *r.deg, (unsigned)*r.ph, r.cap);
+        const uint32_t word = *r.deg;
+        const int c = (int)min(deg_of(word) - hid_of(word), (uint32_t)r.cap);
+        CZ_CHECK(t < ix.n && deg_of(word) >= hid_of(word) && deg_of(word) - hid_of(word) <= (uint32_t)r.cap,
+                 "shrink: node %u level %d degree word %x cap %d\n", t, lv, word, r.cap);
         if (tid < c) CZ_CHECK(r.ids[tid] < ix.n, "shrink: node %u level %d slot %d of %d holds %u\n", t, lv, tid, c, r.ids[tid]);
         // candidates = live links with their stored distances (:389-393), sorted by (distance, id)
         uint64_t mk = 0;
@@ -319,10 +353,8 @@ build_shrink_kernel(IndexDev ix, BuildTables T, const uint32_t *__restrict__ shr
                     r.ids[k] = CZ_NONE;
                 }
             }
-            if (tid == 0) {
-                *r.deg = (uint32_t)nsel;  // :352,412
-                *r.ph = 0;
-            }
+            if (tid == 0) *r.deg = (uint32_t)nsel;  // :352,412: links inside the base row are not among the candidates and
+                                                    // no longer counted
         } else {
             // the neighbours' neighbours join in (:499-511) -- the target among them, through the back links; what is
             // selected is staged: the other shrinks of this round still read this row as the round found it
@@ -332,25 +364,28 @@ build_shrink_kernel(IndexDev ix, BuildTables T, const uint32_t *__restrict__ shr
             S.sort_scratch(gk, gi, nc);
             const int nsel = S.select_extended(gk, gi, nc, r.width, keep_pruned != 0, efcap);
             CZ_CHECK(nsel <= r.width && nsel <= stage.width + 1, "shrink: %d selected, width %d\n", nsel, r.width);
-            if (tid == 0) {
-                int at = -1;
-                for (int k = 0; k < nsel; k++)
-                    if (s.sel[k] == t) at = k;
-                s.ctl[czh::C_KEEP] = at;
+            // selected without a slot: the target itself (its "link row" is the self row, put back by hnsw_put_vector,
+            // :352-357) and vectors of the target's own base row (:609-610) -- counted into the degree, kept nowhere
+            bool hidden = false;
+            uint32_t id = CZ_NONE;
+            if (tid < nsel) {
+                id = s.sel[tid];
+                hidden = id == t || same_row(T, id, t);
+                s.st[tid] = hidden ? 1 : 0;
             }
-            __syncthreads();
-            const int at = s.ctl[czh::C_KEEP];
+            const int nhid = __syncthreads_count(hidden);
             uint32_t *sid = stage.ids + (size_t)i * stage.width;
             double *sd = stage.dst + (size_t)i * stage.width;
-            for (int k = tid; k < nsel; k += kThreads) {
-                if (k == at) continue;  // the self row, put back by hnsw_put_vector (:352-357): a slot, not a link
-                const int o = k - (at >= 0 && k > at ? 1 : 0);
-                sid[o] = s.sel[k];
-                sd[o] = key_dist(S.ext_sel_key()[k]);
+            if (tid < nsel && !hidden) {
+                int before = 0;
+                if (nhid)
+                    for (int j = 0; j < tid; j++) before += s.st[j];
+                sid[tid - before] = id;
+                sd[tid - before] = key_dist(S.ext_sel_key()[tid]);
             }
             if (tid == 0) {
-                stage.n[i] = (uint32_t)(nsel - (at >= 0 ? 1 : 0));
-                stage.self[i] = at >= 0 ? 1 : 0;
+                stage.n[i] = (uint32_t)(nsel - nhid);
+                stage.self[i] = (uint8_t)nhid;
             }
         }
         if (tid == 0) {
@@ -379,10 +414,7 @@ build_apply_kernel(BuildTables T, const uint32_t *__restrict__ shrink_t, const i
                 r.ids[k] = CZ_NONE;
             }
         }
-        if (lane == 0) {
-            *r.deg = kept + stage.self[i];  // :412: the selected count, the self link included
-            *r.ph = stage.self[i];
-        }
+        if (lane == 0) *r.deg = (kept + stage.self[i]) | ((uint32_t)stage.self[i] << 16);  // :412: the selected count
     }
 }
 
@@ -428,7 +460,7 @@ build_unpack_kernel(IndexDev ix, BuildTables T, const uint32_t *__restrict__ old
                 }
             }
             if (tid == 0) {
-                *r.deg = (uint32_t)c + *r.ph;
+                *r.deg = ((uint32_t)c + *r.hid_in) | ((uint32_t)*r.hid_in << 16);
                 atomicAdd(ndist_total, (unsigned long long)c);
             }
             __syncthreads();
@@ -577,7 +609,7 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
     cz::DevBuf<double> b_dst0, b_dstU;
     cz::DevBuf<int32_t> b_level, b_shrink_lv;
     cz::DevBuf<unsigned long long> b_ndist;
-    cz::DevBuf<uint8_t> b_ph0, b_phU;
+    cz::DevBuf<uint8_t> b_ph0, b_phU;  // what earlier builds left hidden in the degrees (hnsw_index.h), for the unpack kernel
     CZ_HIP(b_ph0.alloc(std::max<size_t>(1, n)));
     CZ_HIP(b_phU.alloc(std::max<size_t>(1, rows)));
     CZ_HIP(hipMemsetAsync(b_ph0.p, 0, std::max<size_t>(1, n), stream));
@@ -586,6 +618,13 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
         CZ_HIP(hipMemcpyAsync(b_ph0.p, ix->ph0.data(), std::min<size_t>(ix->ph0.size(), n_old), hipMemcpyHostToDevice, stream));
     if (!ix->phU.empty() && rows_old)
         CZ_HIP(hipMemcpyAsync(b_phU.p, ix->phU.data(), std::min<size_t>(ix->phU.size(), rows_old), hipMemcpyHostToDevice, stream));
+    cz::DevBuf<uint32_t> b_rowof;  // the base row of every node's vector (cz_hnsw_set_row_of), or none: one vector per row
+    if (!ix->row_of.empty()) {
+        if (ix->row_of.size() < n)
+            return cz::set_error(CZ_E_INVALID, "cz_hnsw_set_row_of covers %zu nodes, the index will hold %u", ix->row_of.size(), n);
+        CZ_HIP(b_rowof.alloc(n));
+        CZ_HIP(hipMemcpyAsync(b_rowof.p, ix->row_of.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    }
     CZ_HIP(b_nbr0.alloc((size_t)n * cap0));
     CZ_HIP(b_dst0.alloc((size_t)n * cap0));
     CZ_HIP(b_deg0.alloc(n));
@@ -627,7 +666,7 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
     CZ_HIP(b_shrink_lv.alloc(max_req));
 
     BuildTables T{b_nbr0.p, b_dst0.p, b_deg0.p, b_ph0.p, w0, cap0, b_upbase.p, b_nbrU.p, b_dstU.p, b_degU.p, b_phU.p, wu, capU,
-                  b_level.p};
+                  b_level.p, ix->row_of.empty() ? nullptr : b_rowof.p};
     IndexDev dev = ix->dev();
     dev.n = n;
     dev.nbr0 = b_nbr0.p;
@@ -848,11 +887,16 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
     ix->n_levels = top + 1;
     ix->entry = entry;
     ix->layout_top.assign(ix->top.begin(), ix->top.end());
-    if (extend || !ix->ph0.empty()) {  // degrees that count a self link (extend_candidates), for the next insert and the write-back
+    if (extend || !ix->ph0.empty() || !ix->row_of.empty()) {
+        // degrees that count links without a slot (the self link of an extended shrink, links inside a base row), for the next
+        // insert and the write-back: the high half of every degree word
+        std::vector<uint32_t> w0v(n), wUv((size_t)rows);
+        CZ_HIP(hipMemcpy(w0v.data(), b_deg0.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (rows) CZ_HIP(hipMemcpy(wUv.data(), b_degU.p, (size_t)rows * 4, hipMemcpyDeviceToHost));
         ix->ph0.assign(n, 0);
         ix->phU.assign((size_t)rows, 0);
-        CZ_HIP(hipMemcpy(ix->ph0.data(), b_ph0.p, n, hipMemcpyDeviceToHost));
-        if (rows) CZ_HIP(hipMemcpy(ix->phU.data(), b_phU.p, (size_t)rows, hipMemcpyDeviceToHost));
+        for (uint32_t v = 0; v < n; v++) ix->ph0[v] = (uint8_t)std::min<uint32_t>(255, hid_of(w0v[v]));
+        for (uint64_t r = 0; r < rows; r++) ix->phU[r] = (uint8_t)std::min<uint32_t>(255, hid_of(wUv[r]));
     }
     {   // the visited workspaces were sized for the old n
         std::lock_guard<std::mutex> lk(ix->mu);
@@ -956,6 +1000,18 @@ extern "C" int cz_hnsw_set_key_order(cz_hnsw_index *h, const uint32_t *rank, uin
     }
     if (n < ix->n) return cz::set_error(CZ_E_INVALID, "key order for %u nodes, the index holds %u", n, ix->n);
     ix->key_rank.assign(rank, rank + n);
+    return CZ_OK;
+}
+
+extern "C" int cz_hnsw_set_row_of(cz_hnsw_index *h, const uint32_t *row_of, uint32_t n) {
+    if (!h) return cz::set_error(CZ_E_INVALID, "null index");
+    cz::HnswIndex *ix = (cz::HnswIndex *)h;
+    if (!row_of || n == 0) {
+        ix->row_of.clear();
+        return CZ_OK;
+    }
+    if (n < ix->n) return cz::set_error(CZ_E_INVALID, "base rows for %u nodes, the index holds %u", n, ix->n);
+    ix->row_of.assign(row_of, row_of + n);
     return CZ_OK;
 }
 

@@ -39,11 +39,14 @@ struct HnswIndex {
     // first row of the index relation = the smallest KEY on the top layer (hnsw.rs:184-191, 891-899) -- so rows inserted
     // later with keys that sort before existing ones need their rank, not their id, to be compared.
     std::vector<uint32_t> key_rank;
-    // extend_candidates: rows whose stored degree is one above their number of link rows -- the self link a shrink
-    // selected and hnsw_put_vector overwrote with the self row again (hnsw.rs:413-433, 352-357).  ph0[node], phU[upper row];
-    // empty = none.  Kept between builds and inserts: the next reverse link onto such a row triggers its shrink one link
-    // earlier (:338-339), and the self row written back carries the degree.
+    // How far a row's stored degree lies above its number of visible link rows: the self link an extend_candidates shrink
+    // selected and hnsw_put_vector overwrote with the self row again (hnsw.rs:413-433, 352-357), and links inside one base row,
+    // which are written and counted but never read (:609-610).  ph0[node], phU[upper row]; empty = none.  Kept between builds
+    // and inserts: the next reverse link onto such a row triggers its shrink earlier (:338-339), and the self row written
+    // back carries the degree.
     std::vector<uint8_t> ph0, phU;
+    // the base row every node's vector comes from (cz_hnsw_set_row_of); empty = one vector per row
+    std::vector<uint32_t> row_of;
     bool key_before(uint32_t a, uint32_t b) const {
         return key_rank.empty() ? a < b : (key_rank[a] != key_rank[b] ? key_rank[a] < key_rank[b] : a < b);
     }

@@ -56,12 +56,12 @@ def _build_flags(manifest) -> int:
     return _lib.CZ_HNSW_EXTEND_CANDIDATES if manifest.extend_candidates else 0
 
 
-def _refuse_shared_rows(row_of):
+def _shared_rows(row_of) -> bool:
+    """does any base row carry more than one indexed vector (a List of vectors, several vec_fields: hnsw.rs:694-706)?"""
     if row_of is None:
-        return
+        return False
     r = np.asarray(row_of)
-    if r.size and np.unique(r).size != r.size:
-        raise _lib.CozoGpuError(_lib.CZ_E_UNSUPPORTED, "rows carrying several indexed vectors are not built on the GPU")
+    return bool(r.size and np.unique(r).size != r.size)
 
 
 class GpuHnswIndex:
@@ -95,12 +95,26 @@ class GpuHnswIndex:
         """`::hnsw create` on the GPU (create_hnsw_index, runtime/relation.rs:1010-1201 -> hnsw_put per row):
         batch-parallel insertion of all vectors in key order.  `vectors` is a host array, or (device_ptr=True) a
         device tensor / pointer with `n` rows.  Returns the index; `.last_build_n_dist` holds the distance count.
-        row_of: the base row each vector comes from (index_nodes gives it).  The reference never links two vectors of one row
-        (hnsw_get_neighbours drops them, hnsw.rs:609-610); the device build has no such rule, so rows carrying several indexed
-        vectors are refused here exactly as the C++ mirror refuses them (the shim falls back to the CPU path)."""
+        row_of: the base row each vector comes from (index_nodes gives it).  hnsw_get_neighbours drops every link inside one
+        base row (hnsw.rs:609-610): such links are written and counted into the degrees but never read.  When some row carries
+        several vectors the index is built as empty handle + cz_hnsw_set_row_of + cz_hnsw_insert, and the tables hold no link
+        inside a row (`degrees()` counts them)."""
         if manifest.dtype != "F32":
             raise _lib.CozoGpuError(_lib.CZ_E_UNSUPPORTED, "only F32 vector indices are GPU-resident")
-        _refuse_shared_rows(row_of)
+        if _shared_rows(row_of):
+            if device_ptr:
+                raise ValueError("rows carrying several vectors: hand the vectors in as a host array")
+            self = cls.__new__(cls)
+            self.manifest = manifest
+            h = C.c_void_p()
+            check(_lib.lib().cz_hnsw_build(None, 0, manifest.vec_dim, DISTANCES[manifest.distance], manifest.m_neighbours,
+                                           manifest.ef_construction, int(manifest.keep_pruned_connections), None, 0, 0, None,
+                                           C.byref(h), 0, None))
+            self._h = h
+            self.n = 0
+            self.last_build_n_dist = 0
+            self.insert(vectors, levels=levels, seed=seed, max_batch=max_batch, row_of=row_of)
+            return self
         self = cls.__new__(cls)
         self.manifest = manifest
         if device_ptr:
@@ -135,11 +149,16 @@ class GpuHnswIndex:
     def insert(self, vectors, levels: Optional[np.ndarray] = None, seed: int = 0, max_batch: int = 0, key_rank=None, row_of=None):
         """hnsw_put for more rows on a later write (stored.rs:431-450 -> hnsw.rs:679-727): the vectors become nodes
         n .. n + len - 1 of this index (cz_hnsw_insert).  key_rank: see set_key_order -- needed when the new rows' keys do
-        not all sort behind the existing ones."""
+        not all sort behind the existing ones.  row_of: the base row of every node's vector, the nodes held and the ones
+        inserted (cz_hnsw_set_row_of; see build) -- needed as soon as some row carries several vectors."""
         v = np.ascontiguousarray(vectors, dtype=np.float32)
         if v.ndim != 2 or v.shape[1] != self.manifest.vec_dim:
             raise ValueError("vectors must be [n][vec_dim]")
-        _refuse_shared_rows(row_of)  # (rows of the NEW vectors; see build)
+        if row_of is not None:
+            r = np.ascontiguousarray(row_of, dtype=np.uint32)
+            if r.size != self.n + v.shape[0]:
+                raise ValueError("row_of must cover the nodes held and the ones inserted")
+            check(_lib.lib().cz_hnsw_set_row_of(self._h, ptr(r), r.size))
         if key_rank is not None:
             if len(key_rank) != self.n + v.shape[0]:
                 raise ValueError("key_rank must cover the nodes held and the ones inserted")

@@ -53,6 +53,18 @@ GpuHnswIndex::~GpuHnswIndex() {
 
 uint64_t GpuHnswIndex::device_bytes() const { return h_ ? cz_hnsw_index_bytes(h_) : 0; }
 
+// nodes are appended row by row: a row that carries several vectors has them side by side
+static bool shares_rows(const std::vector<CompoundKey> &nodes) {
+    for (size_t i = 1; i < nodes.size(); i++)
+        if (nodes[i].row == nodes[i - 1].row) return true;
+    return false;
+}
+static std::vector<uint32_t> rows_of(const std::vector<CompoundKey> &nodes) {
+    std::vector<uint32_t> r(nodes.size());
+    for (size_t i = 0; i < nodes.size(); i++) r[i] = nodes[i].row;
+    return r;
+}
+
 GpuHnswIndex GpuHnswIndex::create(const HnswIndexManifest &manifest, const BaseRelation &base, uint64_t seed,
                                   uint32_t max_batch, const std::vector<int32_t> *levels) {
     if (manifest.dtype != VecElementType::F32)
@@ -81,15 +93,23 @@ GpuHnswIndex GpuHnswIndex::create(const HnswIndexManifest &manifest, const BaseR
             }
         }
     }
-    // two vectors of one row are never neighbours for the reference (hnsw_get_neighbours drops such links, :609-610, also
-    // while the index is being built); the device build has no such rule: refuse instead of building a different graph
-    for (size_t i = 1; i < ix.nodes_.size(); i++)
-        if (ix.nodes_[i].row == ix.nodes_[i - 1].row)
-            throw GpuError(CZ_E_UNSUPPORTED, "rows carrying several indexed vectors are not built on the GPU (build the index with the "
-                                             "reference and read it with from_stored)");
     if (levels && levels->size() != ix.nodes_.size())
         throw CozoError("hnsw::bad_levels", "levels must hold one entry per indexed vector");
     if (ix.nodes_.empty()) return ix;  // empty index: hnsw_knn returns no rows (:903-909)
+    const uint32_t build_flags = manifest.extend_candidates ? CZ_HNSW_EXTEND_CANDIDATES : 0u;
+    if (shares_rows(ix.nodes_)) {
+        // Some row carries several vectors: hnsw_get_neighbours drops every link inside one base row (:609-610), also while
+        // the index is being built.  The library needs every node's base row for that: an empty handle, the rows, the insert.
+        const std::vector<uint32_t> rows = rows_of(ix.nodes_);
+        check_gpu(cz_hnsw_build(nullptr, 0, (uint32_t)manifest.vec_dim, (int)manifest.distance, (uint32_t)manifest.m_neighbours,
+                                (uint32_t)manifest.ef_construction, manifest.keep_pruned_connections ? 1 : 0, nullptr, 0, 0, nullptr,
+                                &ix.h_, 0, nullptr));
+        check_gpu(cz_hnsw_set_row_of(ix.h_, rows.data(), (uint32_t)rows.size()));
+        check_gpu(cz_hnsw_insert(ix.h_, flat.data(), (uint32_t)ix.nodes_.size(), (uint32_t)manifest.m_neighbours,
+                                 (uint32_t)manifest.ef_construction, manifest.keep_pruned_connections ? 1 : 0,
+                                 levels ? levels->data() : nullptr, seed, max_batch, &ix.build_n_dist_, build_flags, nullptr));
+        return ix;
+    }
     check_gpu(cz_hnsw_build(flat.data(), (uint32_t)ix.nodes_.size(), (uint32_t)manifest.vec_dim, (int)manifest.distance,
                             (uint32_t)manifest.m_neighbours, (uint32_t)manifest.ef_construction,
                             manifest.keep_pruned_connections ? 1 : 0, levels ? levels->data() : nullptr, seed, max_batch,
@@ -118,11 +138,6 @@ void GpuHnswIndex::put_rows(uint32_t first_row, uint64_t seed, uint32_t max_batc
         }
     }
     const size_t n_new = nodes_.size() - n_before;
-    for (size_t i = n_before + 1; i < nodes_.size(); i++)
-        if (nodes_[i].row == nodes_[i - 1].row) {
-            nodes_.resize(n_before);
-            throw GpuError(CZ_E_UNSUPPORTED, "rows carrying several indexed vectors are not built on the GPU");
-        }
     if (levels && levels->size() != n_new) {
         nodes_.resize(n_before);
         throw CozoError("hnsw::bad_levels", "levels must hold one entry per new vector");
@@ -130,6 +145,16 @@ void GpuHnswIndex::put_rows(uint32_t first_row, uint64_t seed, uint32_t max_batc
     if (n_new == 0) return;
     uint64_t nd = 0;
     int rc;
+    const bool shared = shares_rows(nodes_);
+    if (!h_ && shared) {  // (see create)
+        rc = cz_hnsw_build(nullptr, 0, (uint32_t)manifest_.vec_dim, (int)manifest_.distance, (uint32_t)manifest_.m_neighbours,
+                           (uint32_t)manifest_.ef_construction, manifest_.keep_pruned_connections ? 1 : 0, nullptr, 0, 0, nullptr, &h_, 0,
+                           nullptr);
+        if (rc != CZ_OK) {
+            nodes_.resize(n_before);
+            check_gpu(rc);
+        }
+    }
     if (!h_)  // the first rows of an index that was empty so far
         rc = cz_hnsw_build(flat.data(), (uint32_t)n_new, (uint32_t)manifest_.vec_dim, (int)manifest_.distance, (uint32_t)manifest_.m_neighbours,
                            (uint32_t)manifest_.ef_construction, manifest_.keep_pruned_connections ? 1 : 0, levels ? levels->data() : nullptr,
@@ -153,6 +178,10 @@ void GpuHnswIndex::put_rows(uint32_t first_row, uint64_t seed, uint32_t max_batc
         std::vector<uint32_t> rank(nodes_.size());
         for (uint32_t pos = 0; pos < by_key.size(); pos++) rank[by_key[pos]] = pos;
         rc = cz_hnsw_set_key_order(h_, rank.data(), (uint32_t)rank.size());
+        if (rc == CZ_OK && shared) {  // links inside one base row are never read (hnsw.rs:609-610): the library needs the rows
+            const std::vector<uint32_t> rows = rows_of(nodes_);
+            rc = cz_hnsw_set_row_of(h_, rows.data(), (uint32_t)rows.size());
+        }
         if (rc == CZ_OK)
             rc = cz_hnsw_insert(h_, flat.data(), (uint32_t)n_new, (uint32_t)manifest_.m_neighbours, (uint32_t)manifest_.ef_construction,
                                 manifest_.keep_pruned_connections ? 1 : 0, levels ? levels->data() : nullptr, seed, max_batch, &nd,

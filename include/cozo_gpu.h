@@ -135,6 +135,14 @@ int cz_hnsw_remove(cz_hnsw_index *ix, const uint32_t *nodes, uint32_t n_nodes);
  * (n >= both); cz_hnsw_insert and cz_hnsw_remove then choose the entry point by rank.  rank = NULL: ids are key order. */
 int cz_hnsw_set_key_order(cz_hnsw_index *ix, const uint32_t *rank, uint32_t n);
 
+/* Rows that carry several indexed vectors (a List of vectors, several vec_fields: runtime/hnsw.rs:694-706).
+ * row_of[node] = the base row the node's vector comes from, for the nodes held and the ones the next cz_hnsw_insert adds
+ * (NULL / 0: one vector per row).  hnsw_get_neighbours drops every link inside one base row (:609-610): it is written and
+ * counted into both degrees (:281-357) and never read again -- not by the search, the extension, the shrink or the removal.
+ * The device tables do not hold such links; the degrees count them (cz_hnsw_index_export_degrees).  To BUILD an index over
+ * such rows: cz_hnsw_build with n = 0, cz_hnsw_set_row_of, cz_hnsw_insert. */
+int cz_hnsw_set_row_of(cz_hnsw_index *ix, const uint32_t *row_of, uint32_t n);
+
 /* flat export of a device-resident index (the inverse of cz_hnsw_index_create; host buffers) */
 int cz_hnsw_index_info(const cz_hnsw_index *ix, uint32_t *n, uint32_t *dim, int32_t *metric, int32_t *n_levels,
                        uint32_t *entry);
@@ -143,7 +151,8 @@ int cz_hnsw_index_export_level(const cz_hnsw_index *ix, int32_t level, uint32_t 
                                uint32_t *nbrs /* [size][width] */);
 int cz_hnsw_index_export_vectors(const cz_hnsw_index *ix, float *out /* [n][dim] */);
 /* the f64 of every self row of a level (runtime/hnsw.rs:270, 338-357), in cz_hnsw_index_export_level's node order: the
- * number of live link rows, plus one where an extend_candidates shrink selected the node itself (:413-433) */
+ * number of visible link rows, plus one where an extend_candidates shrink selected the node itself (:413-433), plus the
+ * links into the node's own base row that are counted and never read (:609-610) */
 int cz_hnsw_index_export_degrees(const cz_hnsw_index *ix, int32_t level, double *degree /* [size] */);
 
 /* SessionTx::hnsw_knn (runtime/hnsw.rs:869-1012) for a whole batch of parent tuples

@@ -113,6 +113,7 @@ extern "C" {
     pub fn cz_hnsw_index_export_level(ix: *const cz_hnsw_index, level: i32, node_ids: *mut u32, nbrs: *mut u32) -> c_int;
     pub fn cz_hnsw_index_export_vectors(ix: *const cz_hnsw_index, out: *mut c_float) -> c_int;
     pub fn cz_hnsw_index_export_degrees(ix: *const cz_hnsw_index, level: i32, degree: *mut c_double) -> c_int;
+    pub fn cz_hnsw_set_row_of(ix: *mut cz_hnsw_index, row_of: *const u32, n: u32) -> c_int;
     pub fn cz_hnsw_search_batch(ix: *mut cz_hnsw_index, queries: *const c_float, b: u32, k: u32, ef: u32, has_radius: c_int,
                                 radius: c_double, out_ids: *mut u32, out_dist: *mut c_double, out_count: *mut u32,
                                 out_n_dist: *mut u64, poison: *const u8, flags: u32, stream: *mut c_void) -> c_int;

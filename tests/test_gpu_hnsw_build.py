@@ -439,3 +439,53 @@ def test_write_back_with_extend_candidates_carries_the_degrees(oracle, gpu_lib):
         above += int(deg) - links.get((lv, node), 0)
     assert above > 0
     ix.close()
+
+
+@pytest.mark.parametrize("extend,keep,dist,metric", [(False, False, "L2", 0), (False, True, "Cosine", 1), (True, False, "L2", 0),
+                                                     (True, True, "IP", 2)])
+def test_rows_with_several_vectors_identical_to_oracle(gpu_lib, oracle, extend, keep, dist, metric):
+    """Rows that carry several indexed vectors (hnsw.rs:694-706): links inside one base row are written and counted into the
+    degrees, and hnsw_get_neighbours never returns them (:609-610).  cz_hnsw_set_row_of + max_batch = 1: the visible tables and
+    the degrees equal the oracle's (pinned by tests/literal_hnsw_store.py), for one build and for build + insert, and no row
+    holds a link into its own base row."""
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest
+    n, dim, m, efc = 420, 20, 4, 16
+    rng = np.random.default_rng(7)
+    row_of = np.sort(rng.integers(0, n // 3, n)).astype(np.uint32)
+    base = rng.standard_normal((n // 3, dim)).astype(np.float32)
+    x = (base[row_of] + 0.05 * rng.standard_normal((n, dim))).astype(np.float32)  # a row's vectors are each other's nearest
+    levels = oracle.random_levels(n, m, 5)
+    b = oracle.HnswBuilder(dim, metric, m, efc, extend_candidates=extend, keep_pruned_connections=keep, dot_mode=oracle.DOT_GPU)
+    b.set_row_of(row_of)
+    b.insert(x, levels)
+    flat = b.export()
+    want_deg = _oracle_degrees(b, flat)
+    man = HnswIndexManifest(vec_dim=dim, distance=dist, m_neighbours=m, ef_construction=efc, extend_candidates=extend,
+                            keep_pruned_connections=keep)
+    whole = GpuHnswIndex.build(man, x, levels=levels, max_batch=1, row_of=row_of)
+    h = n * 2 // 3
+    parts = GpuHnswIndex.build(man, x[:h], levels=levels[:h], max_batch=1, row_of=row_of[:h])
+    parts.insert(x[h:], levels=levels[h:], max_batch=1, row_of=row_of)
+    hidden = 0
+    for g in (whole, parts):
+        nodes, nbrs, entry = g.export()
+        assert entry == flat.entry and len(nbrs) == flat.n_levels
+        deg = g.degrees()
+        for lv in range(flat.n_levels):
+            assert np.array_equal(nodes[lv], flat.level_nodes[lv])
+            assert np.array_equal(nbrs[lv], flat.level_nbrs[lv]), f"level {lv} link rows differ"
+            assert np.array_equal(deg[lv], want_deg[lv]), f"level {lv} degrees differ"
+            live = nbrs[lv] != 0xFFFFFFFF
+            fr = np.broadcast_to(nodes[lv][:, None], nbrs[lv].shape)
+            assert not (row_of[nbrs[lv][live]] == row_of[fr[live]]).any()
+            hidden += int((deg[lv] - live.sum(axis=1)).sum())
+        g.close()
+    assert hidden > 0
+    # batched: the same rule, structurally
+    g = GpuHnswIndex.build(man, x, levels=levels, max_batch=64, row_of=row_of)
+    nodes, nbrs, _ = g.export()
+    for lv in range(len(nbrs)):
+        live = nbrs[lv] != 0xFFFFFFFF
+        fr = np.broadcast_to(nodes[lv][:, None], nbrs[lv].shape)
+        assert not (row_of[nbrs[lv][live]] == row_of[fr[live]]).any()
+    g.close()
