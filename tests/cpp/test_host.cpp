@@ -1090,6 +1090,67 @@ static void gpu_index_through_the_store() {
     CHECK(empty_read.node_count() == 0 && empty_ra.iter(parent, Poison()).empty());
 }
 
+static void gpu_index_over_rows_with_several_vectors() {
+    // hnsw_put indexes every Vec inside a List (runtime/hnsw.rs:694-706); hnsw_get_neighbours never returns a link between two
+    // vectors of one base row (:609-610).  create() hands the library every node's base row (cz_hnsw_set_row_of): the stored
+    // rows hold no link inside a row, the self rows' degrees count them, and the index reads back as itself.
+    const size_t n_rows = 300, dim = 12;
+    std::mt19937 rng(17);
+    std::normal_distribution<float> N(0.f, 1.f);
+    BaseRelation base;
+    base.keys = {"id"};
+    base.non_keys = {"vs"};
+    size_t n_vec = 0;
+    for (size_t i = 0; i < n_rows; i++) {
+        std::vector<float> centre(dim);
+        for (float &x : centre) x = N(rng);
+        std::vector<DataValue> items;
+        for (size_t j = 0; j < 1 + i % 3; j++) {  // 1..3 vectors per row, close to each other
+            std::vector<float> v = centre;
+            for (float &x : v) x += 0.05f * N(rng);
+            items.push_back(DataValue(F32Vec{v}));
+            n_vec++;
+        }
+        base.rows.push_back(T({DataValue((int64_t)i), DataValue::list(items)}));
+    }
+    HnswIndexManifest mf = HnswIndexManifest::create("docs", "vec", dim, {1}, HnswDistance::L2, 4, 16);
+    GpuHnswIndex built = GpuHnswIndex::create(mf, base, 3, 1, nullptr);
+    CHECK(built.node_count() == n_vec);
+    const StoredRows idx = built.index_rows(41), stored_base = StoredRows::from_tuples(40, base.rows, 1);
+    size_t inside = 0, above = 0, links_of_row0 = 0;
+    double degree_of_row0 = -1;
+    for (size_t i = 0; i + 1 < idx.size(); i++) {
+        const Tuple t = idx.tuple(i);  // [layer, fr key, fr field, fr sub, to key, to field, to sub] -> [f64, hash | Null, ignore]
+        const bool self = t[1] == t[4] && t[2] == t[5] && t[3] == t[6];
+        if (!self && t[1] == t[4]) inside++;
+        int64_t layer = 1;
+        t[0].get_int(&layer);
+        if (layer == 0 && t[1] == DataValue((int64_t)2) && t[3] == DataValue((int64_t)0)) {  // first vector of row 2 (three vectors)
+            if (self) t[7].get_float(&degree_of_row0);
+            else links_of_row0++;
+        }
+    }
+    CHECK(inside == 0);
+    CHECK(degree_of_row0 >= (double)links_of_row0);
+    above += (size_t)(degree_of_row0 - (double)links_of_row0);
+    CHECK(above > 0);  // its two row mates were selected (they are its nearest), counted, and not kept
+    GpuHnswIndex read = GpuHnswIndex::from_stored(mf, idx, stored_base, base);
+    CHECK(read.node_count() == built.node_count());
+    std::vector<Tuple> parent;
+    for (int i = 0; i < 16; i++) {
+        std::vector<float> q(dim);
+        for (float &x : q) x = N(rng);
+        parent.push_back(T({DataValue((int64_t)i), DataValue(F32Vec{q})}));
+    }
+    HnswSearch hs;
+    hs.k = 5;
+    hs.ef = 30;
+    hs.bind_distance = true;
+    const std::vector<Tuple> a = HnswSearchRA{&built, hs, 1}.iter(parent, Poison());
+    const std::vector<Tuple> b = HnswSearchRA{&read, hs, 1}.iter(parent, Poison());
+    CHECK(!a.empty() && a == b);
+}
+
 static void test_stored_rows_delta_cpu() {
     // stored_rows_delta: puts = new or changed rows, dels = vanished keys; old with the delta applied is new
     std::mt19937 rng(17);
@@ -1356,6 +1417,7 @@ int main(int argc, char **argv) {
         gpu_dijkstra_keep_ties();
         gpu_rules_on_stored_relation();
         gpu_index_through_the_store();
+        gpu_index_over_rows_with_several_vectors();
         gpu_index_maintenance_writeback();
     }
     std::printf("%s: %d checks passed, %d failed\n", mode.c_str(), g_pass, g_fail);
