@@ -1117,23 +1117,18 @@ static void gpu_index_over_rows_with_several_vectors() {
     GpuHnswIndex built = GpuHnswIndex::create(mf, base, 3, 1, nullptr);
     CHECK(built.node_count() == n_vec);
     const StoredRows idx = built.index_rows(41), stored_base = StoredRows::from_tuples(40, base.rows, 1);
-    size_t inside = 0, above = 0, links_of_row0 = 0;
-    double degree_of_row0 = -1;
+    size_t inside = 0, link_rows = 0;
+    double degrees = 0;
     for (size_t i = 0; i + 1 < idx.size(); i++) {
         const Tuple t = idx.tuple(i);  // [layer, fr key, fr field, fr sub, to key, to field, to sub] -> [f64, hash | Null, ignore]
         const bool self = t[1] == t[4] && t[2] == t[5] && t[3] == t[6];
         if (!self && t[1] == t[4]) inside++;
-        int64_t layer = 1;
-        t[0].get_int(&layer);
-        if (layer == 0 && t[1] == DataValue((int64_t)2) && t[3] == DataValue((int64_t)0)) {  // first vector of row 2 (three vectors)
-            if (self) t[7].get_float(&degree_of_row0);
-            else links_of_row0++;
-        }
+        double d = 0;
+        if (self && t[7].get_float(&d)) degrees += d;
+        if (!self) link_rows++;
     }
     CHECK(inside == 0);
-    CHECK(degree_of_row0 >= (double)links_of_row0);
-    above += (size_t)(degree_of_row0 - (double)links_of_row0);
-    CHECK(above > 0);  // its two row mates were selected (they are its nearest), counted, and not kept
+    CHECK(degrees > (double)link_rows);  // row mates were selected (they are each other's nearest), counted, and not kept
     GpuHnswIndex read = GpuHnswIndex::from_stored(mf, idx, stored_base, base);
     CHECK(read.node_count() == built.node_count());
     std::vector<Tuple> parent;
@@ -1263,14 +1258,19 @@ static void gpu_index_maintenance_writeback() {
             named |= (t[1] == DataValue(std::string(gone))) || (t[4] == DataValue(std::string(gone)));
     }
     CHECK(!named);
-    // a row carrying two vectors: the device build has no same-row rule (hnsw.rs:609-610), so it refuses loudly
+    // a row carrying two vectors: each selects the other, both degrees say 1, and no link row is kept (hnsw.rs:609-610)
     {
         BaseRelation two;
         two.keys = {"id"};
         two.non_keys = {"v"};
         std::vector<float> a(dim, 0.25f), b(dim, 0.5f);
         two.rows.push_back(T({DataValue(std::string("x")), DataValue::list({DataValue(F32Vec{a}), DataValue(F32Vec{b})})}));
-        CHECK((throws<GpuError>([&] { GpuHnswIndex::create(mf, two, 0, 1, nullptr); })));
+        const std::vector<int32_t> flat_levels{0, 0};
+        GpuHnswIndex pair = GpuHnswIndex::create(mf, two, 0, 1, &flat_levels);
+        const StoredRows rows = pair.index_rows(77);
+        CHECK(pair.node_count() == 2 && rows.size() == 3);  // two self rows and the canary
+        double d0 = -1, d1 = -1;
+        CHECK(rows.tuple(0)[7].get_float(&d0) && rows.tuple(1)[7].get_float(&d1) && d0 == 1.0 && d1 == 1.0);
     }
     // the index still answers, and never with a removed row
     HnswSearchRA ra{&ix, HnswSearch{}, 1};
