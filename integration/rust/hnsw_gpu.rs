@@ -189,16 +189,16 @@ impl<'a> SessionTx<'a> {
 // }
 
 impl<'a> SessionTx<'a> {
-    /// 3. `::hnsw create` on the device.  One vector per base row only: cz_hnsw_build knows vectors, not row keys, so it cannot
-    /// apply "two vectors of one row are never neighbours" (hnsw.rs:609-610); multi-vector rows keep the hnsw_put route.
+    /// 3. `::hnsw create` on the device: every indexed vector of every row, as hnsw_put collects them (hnsw.rs:694-706: each
+    /// vec_field, a Vec or every Vec inside a List).  When some row carries several vectors the library is told every node's base
+    /// row (cz_hnsw_set_row_of): hnsw_get_neighbours never returns a link between two vectors of one row (:609-610).
     pub(crate) fn hnsw_build_gpu(&mut self, config: &HnswSearch) -> Result<()> {
         let mf = &config.manifest;
         let k = config.base_handle.metadata.keys.len();
-        let (mut vectors, mut node_keys, mut node_key_off) = (Vec::<f32>::new(), Vec::<u8>::new(), vec![0u64]);
-        for tuple in config.base_handle.scan_all(self) {
+        let (mut vectors, mut node_keys, mut node_key_off, mut row_of) = (Vec::<f32>::new(), Vec::<u8>::new(), vec![0u64], Vec::<u32>::new());
+        for (row, tuple) in config.base_handle.scan_all(self).enumerate() {
             let tuple = tuple?;
-            let fld = mf.vec_fields[0];
-            if let DataValue::Vec(Vector::F32(v)) = &tuple[fld] {
+            let mut push = |v: &ndarray::Array1<f32>, fld: usize, sub: i64| {
                 vectors.extend(v.iter());
                 // the CompoundKey columns [row key.., field, sub index] in their key encoding (data/memcmp.rs:47)
                 use crate::data::memcmp::MemCmpEncoder;
@@ -206,20 +206,49 @@ impl<'a> SessionTx<'a> {
                     node_keys.encode_datavalue(c);
                 }
                 node_keys.encode_datavalue(&DataValue::from(fld as i64));
-                node_keys.encode_datavalue(&DataValue::from(-1i64));
+                node_keys.encode_datavalue(&DataValue::from(sub));
                 node_key_off.push(node_keys.len() as u64);
+                row_of.push(row as u32);
+            };
+            for fld in &mf.vec_fields {
+                match &tuple[*fld] {
+                    DataValue::Vec(Vector::F32(v)) => push(v, *fld, -1),
+                    DataValue::List(l) => {
+                        for (sub, item) in l.iter().enumerate() {
+                            if let DataValue::Vec(Vector::F32(v)) = item {
+                                push(v, *fld, sub as i64)
+                            }
+                        }
+                    }
+                    _ => {}
+                }
             }
         }
         let n = (node_key_off.len() - 1) as u32;
         if n == 0 {
             return Ok(());
         }
+        let flags = if mf.extend_candidates { CZ_HNSW_EXTEND_CANDIDATES } else { 0 };
+        let shared = row_of.windows(2).any(|w| w[0] == w[1]);
         let mut h = std::ptr::null_mut();
-        check(unsafe {
-            cz_hnsw_build(vectors.as_ptr(), n, mf.vec_dim as u32, mf.distance as c_int, mf.m_neighbours as u32, mf.ef_construction as u32,
-                          mf.keep_pruned_connections as c_int, std::ptr::null(), rand::random(), 0, std::ptr::null_mut(), &mut h,
-                          if mf.extend_candidates { CZ_HNSW_EXTEND_CANDIDATES } else { 0 }, std::ptr::null_mut())
-        })?;
+        if shared {
+            // an empty handle, the base rows, the insert (include/cozo_gpu.h cz_hnsw_set_row_of)
+            check(unsafe {
+                cz_hnsw_build(std::ptr::null(), 0, mf.vec_dim as u32, mf.distance as c_int, mf.m_neighbours as u32, mf.ef_construction as u32,
+                              mf.keep_pruned_connections as c_int, std::ptr::null(), 0, 0, std::ptr::null_mut(), &mut h, 0, std::ptr::null_mut())
+            })?;
+            check(unsafe { cz_hnsw_set_row_of(h, row_of.as_ptr(), n) })?;
+            check(unsafe {
+                cz_hnsw_insert(h, vectors.as_ptr(), n, mf.m_neighbours as u32, mf.ef_construction as u32, mf.keep_pruned_connections as c_int,
+                               std::ptr::null(), rand::random(), 0, std::ptr::null_mut(), flags, std::ptr::null_mut())
+            })?;
+        } else {
+            check(unsafe {
+                cz_hnsw_build(vectors.as_ptr(), n, mf.vec_dim as u32, mf.distance as c_int, mf.m_neighbours as u32, mf.ef_construction as u32,
+                              mf.keep_pruned_connections as c_int, std::ptr::null(), rand::random(), 0, std::ptr::null_mut(), &mut h, flags,
+                              std::ptr::null_mut())
+            })?;
+        }
         // export the link tables, recompute the link distances with the kernels' arithmetic, encode the rows
         let (mut nn, mut dim, mut metric, mut n_levels, mut entry) = (0u32, 0u32, 0i32, 0i32, 0u32);
         check(unsafe { cz_hnsw_index_info(h, &mut nn, &mut dim, &mut metric, &mut n_levels, &mut entry) })?;
