@@ -1044,7 +1044,8 @@ def main():
                                        f" per GPU, m={args.m}, ef_construction={args.ef_construction}, ef={hn['ef']}, "
                                        f"index built on the GPU (max_batch={args.max_batch})",
                            "parallelism": "1 GPU" if world == 1 else f"{world} index replicas, query batches sharded across ranks",
-                           "recall_at_k": hn["recall"], "ef": hn["ef"], "n_dist_per_query": hn["n_dist_per_query"],
+                           "recall_at_k": hn["recall"], "reached_recall_target": bool(hn["recall"] >= args.recall_target),
+                           "ef": hn["ef"], "n_dist_per_query": hn["n_dist_per_query"],
                            "index_build_s": hn["build_s"], "index_build_n_dist": hn["build_n_dist"],
                            "index_bytes": hn["index_bytes"], "ef_sweep": hn["sweep"]},
                 "roofline": hn["roofline"],

@@ -34,3 +34,14 @@ with G.DeviceGraph.acquire((3, 3), ooff, otgt, w if rule == "sssp" else None) as
             G.sssp(dg, None, None, starts)
         print(rule, "device ms", G.last_timing()[1], flush=True)
 print("edges", otgt.size, "runs", runs)
+if rule == "sssp" and os.environ.get("SWEEP_DELTA"):
+    # near-far bucket width: multiples of the mean edge weight (the default)
+    mean = float(w.mean())
+    with G.DeviceGraph.acquire((3, 4), ooff, otgt, w) as dg:
+        for mult in (0.125, 0.25, 0.5, 1.0, 2.0, 4.0):
+            os.environ["CZ_SSSP_DELTA"] = repr(mean * mult)
+            best = 1e9
+            for _ in range(3):
+                G.sssp(dg, None, None, starts)
+                best = min(best, G.last_timing()[1])
+            print(f"delta = {mult:5.3f} x mean weight ({mean * mult:.3f}): device {best:.2f} ms", flush=True)
