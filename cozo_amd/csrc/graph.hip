@@ -1962,6 +1962,7 @@ namespace {
 
 constexpr uint32_t kLpTable = 512;        // per-wave LDS table; nodes of degree <= kLpSmall never fill it beyond 3/4
 constexpr uint32_t kLpSmall = 384;
+constexpr uint32_t kLpTiny = 32;          // up to here a 16-lane group keeps a node's whole list in registers (two entries a lane)
 
 __device__ __forceinline__ unsigned long long lp_priority(uint32_t v) {
     uint32_t x = v;
@@ -2083,7 +2084,7 @@ lp_transpose_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict
     }
 }
 
-// bucket = 2 * colour + (degree > kLpSmall).  SCATTER = false: counts per bucket; true: order[] filled, `cursor` holding the
+// bucket = 3 * colour + (0: degree <= kLpTiny, 1: <= kLpSmall, 2: above).  SCATTER = false: counts per bucket; true: order[] filled, `cursor` holding the
 // buckets' first positions.  Per chunk of blockDim nodes: LDS counts (which also give every node its rank inside the chunk),
 // then one global atomicAdd per bucket the chunk touched.
 constexpr uint32_t kLpBuckets = 2048;
@@ -2101,7 +2102,8 @@ lp_bucket_kernel(const uint32_t *__restrict__ colour, const uint32_t *__restrict
         const uint32_t v = r * total + blockIdx.x * blockDim.x + threadIdx.x;
         uint32_t b = 0, mine = 0;
         if (v < N) {
-            b = 2 * colour[v] + ((off[v + 1] - off[v]) > kLpSmall ? 1u : 0u);
+            const uint32_t deg = off[v + 1] - off[v];
+            b = 3 * colour[v] + (deg > kLpSmall ? 2u : deg > kLpTiny ? 1u : 0u);
             mine = atomicAdd(&lcnt[b], 1u);
         }
         __syncthreads();
@@ -2188,6 +2190,73 @@ __device__ __forceinline__ void lp_update_node(const uint32_t *__restrict__ off,
         else if (new_label != labels[v]) {
             labels[v] = new_label;
             flags[0] = 1;
+        }
+    }
+}
+
+// the nodes of one colour class with at most kLpTiny neighbours: a 16-lane group per node, the list in registers.  A label's
+// score is the sum of its edges' weights IN ADJACENCY ORDER starting from 0.0 (`*entry(label).or_default() += weight`, :72):
+// every lane walks the whole list in that order and adds up the entries that carry its own label -- the same additions in
+// the same order as the table form, without the table (which serialises a wave per distinct label: 10 M nodes of ~10
+// neighbours spent 50 of the rule's 80 ms there).
+__global__ void __launch_bounds__(kT)
+lp_update_tiny_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w,
+                      const uint32_t *__restrict__ order, uint32_t count, uint32_t *__restrict__ labels, uint32_t *__restrict__ flags) {
+    constexpr int GL = 16;
+    const int glane = threadIdx.x & (GL - 1);
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / GL, ngroups = gridDim.x * blockDim.x / GL;
+    const uint32_t rounds = (count + ngroups - 1) / ngroups;  // every group of the grid runs the same trip count (shuffles)
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i = group + r * ngroups;
+        const bool live = i < count;
+        const uint32_t v = live ? order[i] : 0;
+        const uint32_t a = live ? off[v] : 0, b = live ? off[v + 1] : 0;
+        const bool v0 = a + glane < b, v1 = a + GL + glane < b;
+        const uint32_t l0 = v0 ? labels[tgt[a + glane]] : CZ_NONE, l1 = v1 ? labels[tgt[a + GL + glane]] : CZ_NONE;
+        const float w0 = v0 ? w[a + glane] : 0.f, w1 = v1 ? w[a + GL + glane] : 0.f;
+        float s0 = 0.0f, s1 = 0.0f;
+        const uint32_t n0 = min(b - a, (uint32_t)GL);
+#pragma unroll
+        for (int j = 0; j < GL; j++) {
+            const uint32_t lj = (uint32_t)__shfl((int)l0, j, GL);
+            const float wj = __shfl(w0, j, GL);
+            if ((uint32_t)j < n0) {
+                if (lj == l0) s0 += wj;
+                if (lj == l1) s1 += wj;
+            }
+        }
+        if (__any(b - a > (uint32_t)GL)) {
+            const uint32_t n1 = b - a > (uint32_t)GL ? b - a - GL : 0;
+#pragma unroll
+            for (int j = 0; j < GL; j++) {
+                const uint32_t lj = (uint32_t)__shfl((int)l1, j, GL);
+                const float wj = __shfl(w1, j, GL);
+                if ((uint32_t)j < n1) {
+                    if (lj == l0) s0 += wj;
+                    if (lj == l1) s1 += wj;
+                }
+            }
+        }
+        // :77-85: the largest score under total_cmp; among the labels whose score == it, the smallest
+        auto key_of = [](float f) {
+            const uint32_t bts = __float_as_uint(f);
+            return (bts & 0x80000000u) ? ~bts : (bts | 0x80000000u);
+        };
+        uint32_t best_key = max(v0 ? key_of(s0) : 0u, v1 ? key_of(s1) : 0u);
+#pragma unroll
+        for (int o = GL / 2; o >= 1; o >>= 1) best_key = max(best_key, (uint32_t)__shfl_xor((int)best_key, o, GL));
+        const float max_score = __uint_as_float((best_key & 0x80000000u) ? (best_key & 0x7FFFFFFFu) : ~best_key);
+        uint32_t new_label = CZ_NONE;
+        if (v0 && s0 == max_score) new_label = l0;
+        if (v1 && s1 == max_score) new_label = min(new_label, l1);
+#pragma unroll
+        for (int o = GL / 2; o >= 1; o >>= 1) new_label = min(new_label, (uint32_t)__shfl_xor((int)new_label, o, GL));
+        if (live && glane == 0 && a != b) {  // (no neighbours: the node keeps its label, :74-76)
+            if (new_label == CZ_NONE) flags[1] = 1;  // the best score is NaN: `choose` on an empty list, the reference panics
+            else if (new_label != labels[v]) {
+                labels[v] = new_label;
+                flags[0] = 1;
+            }
         }
     }
 }
@@ -2294,9 +2363,9 @@ extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t 
     // ---- the classes as lists, the nodes of larger degree at the end of each.  (The order inside a class does not matter: its
     // nodes share no edge.)  Two buckets per class, filled on the device: per-workgroup counts in LDS, one reservation per
     // (workgroup, bucket); the host only sees the 2 x n_col totals.  More classes than the LDS counters hold: on the host.
-    std::vector<uint32_t> small_end((size_t)n_col + 1, 0), class_off((size_t)n_col + 1, 0);
-    if (2 * (size_t)n_col <= kLpBuckets) {
-        const uint32_t nb = 2 * n_col;
+    std::vector<uint32_t> small_end((size_t)n_col + 1, 0), class_off((size_t)n_col + 1, 0), tiny_end((size_t)n_col + 1, 0);
+    if (3 * (size_t)n_col <= kLpBuckets) {
+        const uint32_t nb = 3 * n_col;
         cz::DevBuf<uint32_t> d_bcnt;
         CZ_HIP(d_bcnt.alloc(nb));
         CZ_HIP(hipMemsetAsync(d_bcnt.p, 0, (size_t)nb * 4, s));
@@ -2306,13 +2375,16 @@ extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t 
         uint32_t at = 0;
         for (uint32_t c = 0; c < n_col; c++) {
             class_off[c] = at;
-            cur[2 * c] = at;
-            at += cnt[2 * c];
+            cur[3 * c] = at;
+            at += cnt[3 * c];
+            tiny_end[c] = at;
+            cur[3 * c + 1] = at;
+            at += cnt[3 * c + 1];
             small_end[c] = at;
-            cur[2 * c + 1] = at;
-            at += cnt[2 * c + 1];
+            cur[3 * c + 2] = at;
+            at += cnt[3 * c + 2];
         }
-        class_off[n_col] = small_end[n_col] = at;
+        class_off[n_col] = small_end[n_col] = tiny_end[n_col] = at;
         if (at != N) return cz::set_error(CZ_E_HIP, "internal: the classes hold %u of %u nodes", at, N);
         CZ_HIP(hipMemcpy(d_bcnt.p, cur.data(), (size_t)nb * 4, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(lp_bucket_kernel<true>, dim3(grid_for(N)), dim3(kT), 0, s, d_colour.p, d_off.p, N, nb, d_bcnt.p, d_order.p);
@@ -2327,8 +2399,10 @@ extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t 
         std::vector<uint32_t> cur_hub(n_col);
         for (uint32_t c = 0; c < n_col; c++) {
             small_end[c] = class_off[c] + n_small[c];
+            tiny_end[c] = class_off[c];  // (this many classes: no separate list of the short nodes)
             cur_hub[c] = small_end[c];
         }
+        tiny_end[n_col] = class_off[n_col];
         for (uint32_t v = 0; v < N; v++) {
             const uint32_t c = colour[v];
             if (out_offsets[v + 1] - out_offsets[v] <= kLpSmall) order[cur_small[c]++] = v;
@@ -2357,10 +2431,13 @@ extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t 
         CZ_HIP(hipMemsetAsync(d_flags.p, 0, 8, s));
         iters++;
         for (uint32_t c = 0; c < n_col; c++) {
-            const uint32_t ns = small_end[c] - class_off[c], nh = class_off[c + 1] - small_end[c];
+            const uint32_t nt = tiny_end[c] - class_off[c], ns = small_end[c] - tiny_end[c], nh = class_off[c + 1] - small_end[c];
+            if (nt)
+                hipLaunchKernelGGL(lp_update_tiny_kernel, dim3(grid_for((uint64_t)nt * 16)), dim3(kT), 0, s, d_off.p, d_tgt.p, d_w.p,
+                                   d_order.p + class_off[c], nt, d_labels.p, d_flags.p);
             if (ns)
                 hipLaunchKernelGGL(lp_update_kernel, dim3(grid_for((uint64_t)ns * 64)), dim3(kT), 0, s, d_off.p, d_tgt.p, d_w.p,
-                                   d_order.p + class_off[c], ns, d_labels.p, d_flags.p);
+                                   d_order.p + tiny_end[c], ns, d_labels.p, d_flags.p);
             if (nh)
                 hipLaunchKernelGGL(lp_update_hub_kernel, dim3(std::min<uint32_t>(hub_blocks, (nh + kT / 64 - 1) / (kT / 64))), dim3(kT), 0, s,
                                    d_off.p, d_tgt.p, d_w.p, d_order.p + small_end[c], nh, d_labels.p, d_flags.p, d_tkeys.p, d_tvals.p,
