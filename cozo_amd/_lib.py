@@ -138,6 +138,12 @@ SYMBOLS = {
     "cz_sssp_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "cz_connected_components_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, u32p, C.c_void_p]),
+    "cz_hnsw_multi_build": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, C.c_uint32,
+                                      C.c_int, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cz_hnsw_multi_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "cz_hnsw_multi_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cz_hnsw_multi_shards": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cz_hnsw_multi_destroy": (None, [C.c_void_p]),
     "cz_hnsw_search_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cz_connected_components_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p,

@@ -184,3 +184,50 @@ def connected_components_multi(off, tgt, n_gpus: int, poison=None):
     k = C.c_uint32(0)
     check(_lib.lib().cz_connected_components_multi(ptr(off), ptr(tgt), n, tgt.size, int(n_gpus), ptr(grp), C.byref(k), ptr(poison)))
     return grp, k.value
+
+
+class HnswMulti:
+    """An index partitioned over n GPUs of THIS process (cz_hnsw_multi_*): sub-index r on GPU r, built there from the rows
+    [r * ceil(n / n_gpus), ...) of `vectors`; a search runs on every device at once and merges the per-shard lists by
+    (distance, id).  Ids are GLOBAL row numbers."""
+
+    def __init__(self, handle, n_gpus: int):
+        self._h, self.n_gpus = handle, n_gpus
+
+    @classmethod
+    def build(cls, manifest, vectors, n_gpus: int, seed: int = 0, max_batch: int = 0):
+        from .hnsw import DISTANCES, _build_flags
+        v = np.ascontiguousarray(vectors, dtype=np.float32)
+        h = C.c_void_p()
+        nd = C.c_uint64(0)
+        check(_lib.lib().cz_hnsw_multi_build(ptr(v), v.shape[0], manifest.vec_dim, DISTANCES[manifest.distance], manifest.m_neighbours,
+                                             manifest.ef_construction, int(manifest.keep_pruned_connections), int(seed), int(max_batch),
+                                             int(n_gpus), _build_flags(manifest), C.byref(nd), C.byref(h)))
+        self = cls(h, n_gpus)
+        self.build_n_dist = nd.value
+        return self
+
+    def id_offsets(self) -> np.ndarray:
+        off = np.zeros(self.n_gpus, dtype=np.uint64)
+        _lib.lib().cz_hnsw_multi_shards(self._h, ptr(off))
+        return off
+
+    def search(self, queries, k: int, ef: int):
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        B = q.shape[0]
+        ids = np.empty((B, k), dtype=np.uint64)
+        dist = np.empty((B, k), dtype=np.float64)
+        cnt = np.empty(B, dtype=np.uint32)
+        check(_lib.lib().cz_hnsw_multi_search(self._h, ptr(q), B, k, ef, ptr(ids), ptr(dist), ptr(cnt)))
+        return ids, dist, cnt
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().cz_hnsw_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -721,3 +721,168 @@ extern "C" int cz_hnsw_search_sharded(cz_comm *comm, cz_hnsw_index *shard, const
     CZ_HIP(hipStreamSynchronize(stream));  // temporaries die with this scope
     return CZ_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same partitioned index held by ONE process: sub-index r on GPU r, one host thread and one RCCL communicator per GPU
+// for the lifetime of the handle (a cozo process is one process; building the handle is `::hnsw create` over shards, a search
+// is cz_hnsw_search_sharded on every device at once).
+// ------------------------------------------------------------------------------------------------------------------
+struct cz_hnsw_multi {
+    int n_gpus = 0;
+    uint32_t dim = 0;
+    std::vector<ncclComm_t> comms;
+    std::vector<cz_hnsw_index *> shards;
+    std::vector<uint64_t> id_offset;
+};
+
+namespace {
+
+// fn(rank, comm) on every device of the handle at once, each on its own host thread with that device current
+template <class F>
+int on_devices_of(cz_hnsw_multi *m, F fn) {
+    std::vector<int> rcs(m->n_gpus, CZ_OK);
+    std::vector<std::string> msgs(m->n_gpus);
+    auto worker = [&](int r) {
+        cz::t_device_override = r;
+        int wrc = cz::ensure_device();
+        cz_comm c;
+        c.rank = r;
+        c.world = m->n_gpus;
+        c.device = r;
+        c.nccl = m->comms.empty() ? nullptr : m->comms[r];
+        if (!wrc) wrc = fn(r, &c);
+        if (wrc) {
+            rcs[r] = wrc;
+            msgs[r] = cz_last_error();
+        }
+        c.nccl = nullptr;
+        cz::t_device_override = -1;
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < m->n_gpus; r++) th.emplace_back(worker, r);
+    worker(0);
+    for (auto &t : th) t.join();
+    (void)cz::ensure_device();
+    for (int r = 0; r < m->n_gpus; r++)
+        if (rcs[r]) return cz::set_error(rcs[r], "GPU %d: %s", r, msgs[r].c_str());
+    return CZ_OK;
+}
+
+int multi_open(int n_gpus, cz_hnsw_multi **out) {
+    if (!out) return cz::set_error(CZ_E_INVALID, "null out");
+    *out = nullptr;
+    const int have = cz_device_count();
+    if (n_gpus < 1 || n_gpus > have) return cz::set_error(CZ_E_INVALID, "n_gpus = %d, %d device(s) visible", n_gpus, have);
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    std::unique_ptr<cz_hnsw_multi> m(new cz_hnsw_multi());
+    m->n_gpus = n_gpus;
+    m->shards.assign(n_gpus, nullptr);
+    m->id_offset.assign(n_gpus, 0);
+    Rccl *R = nullptr;
+    if ((rc = need_rccl(&R))) return rc;
+    std::vector<int> devs(n_gpus);
+    for (int i = 0; i < n_gpus; i++) devs[i] = i;
+    m->comms.assign(n_gpus, nullptr);
+    CZ_NCCL(R, R->CommInitAll(m->comms.data(), n_gpus, devs.data()));
+    *out = m.release();
+    return CZ_OK;
+}
+
+}  // namespace
+
+extern "C" void cz_hnsw_multi_destroy(cz_hnsw_multi *m) {
+    if (!m) return;
+    Rccl *R = rccl();
+    for (int r = 0; r < m->n_gpus; r++) {
+        (void)hipSetDevice(r);
+        if (m->shards[r]) cz_hnsw_index_destroy(m->shards[r]);
+        if (R && !m->comms.empty() && m->comms[r] && !getenv("CZ_COMM_NO_DESTROY")) (void)R->CommDestroy(m->comms[r]);
+    }
+    (void)cz::ensure_device();
+    delete m;
+}
+
+extern "C" int cz_hnsw_multi_create(const cz_hnsw_desc *const *shards, const float *const *vectors, const uint64_t *id_offsets,
+                                    int n_gpus, cz_hnsw_multi **out) {
+    if (!shards || !vectors || !id_offsets) return cz::set_error(CZ_E_INVALID, "null argument");
+    cz_hnsw_multi *m = nullptr;
+    int rc = multi_open(n_gpus, &m);
+    if (rc) return rc;
+    for (int r = 0; r < n_gpus; r++) {
+        if (!shards[r] || shards[r]->dim != shards[0]->dim || shards[r]->metric != shards[0]->metric) {
+            cz_hnsw_multi_destroy(m);
+            return cz::set_error(CZ_E_INVALID, "shard %d: null, or dimension / metric differ from shard 0", r);
+        }
+        m->id_offset[r] = id_offsets[r];
+    }
+    m->dim = shards[0]->dim;
+    rc = on_devices_of(m, [&](int r, cz_comm *) { return cz_hnsw_index_create(shards[r], vectors[r], &m->shards[r]); });
+    if (rc) {
+        cz_hnsw_multi_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return CZ_OK;
+}
+
+extern "C" int cz_hnsw_multi_build(const float *vectors, uint32_t n, uint32_t dim, int metric, uint32_t m_neighbours,
+                                   uint32_t ef_construction, int keep_pruned_connections, uint64_t seed, uint32_t max_batch, int n_gpus,
+                                   uint32_t flags, uint64_t *n_dist, cz_hnsw_multi **out) {
+    if (n_dist) *n_dist = 0;
+    if (n > 0 && !vectors) return cz::set_error(CZ_E_INVALID, "vectors is null");
+    if (flags & CZ_DEVICE_PTRS) return cz::set_error(CZ_E_INVALID, "cz_hnsw_multi_build takes host vectors (they go to several devices)");
+    cz_hnsw_multi *m = nullptr;
+    int rc = multi_open(n_gpus, &m);
+    if (rc) return rc;
+    m->dim = dim;
+    const uint32_t per = (uint32_t)(((uint64_t)n + n_gpus - 1) / n_gpus);
+    std::vector<uint64_t> nd(n_gpus, 0);
+    rc = on_devices_of(m, [&](int r, cz_comm *) {
+        const uint32_t rb = (uint32_t)std::min<uint64_t>(n, (uint64_t)r * per), re = (uint32_t)std::min<uint64_t>(n, (uint64_t)(r + 1) * per);
+        m->id_offset[r] = rb;  // rows [rb, re) of the relation in key order: a global id is rb + the shard's node id
+        return cz_hnsw_build(vectors + (size_t)rb * dim, re - rb, dim, metric, m_neighbours, ef_construction, keep_pruned_connections,
+                             nullptr, seed + (uint64_t)r, max_batch, &nd[r], &m->shards[r], flags, nullptr);
+    });
+    if (rc) {
+        cz_hnsw_multi_destroy(m);
+        return rc;
+    }
+    if (n_dist)
+        for (uint64_t v : nd) *n_dist += v;
+    *out = m;
+    return CZ_OK;
+}
+
+extern "C" int cz_hnsw_multi_search(cz_hnsw_multi *m, const float *queries, uint32_t B, uint32_t k, uint32_t ef, uint64_t *ids,
+                                    double *dist, uint32_t *count) {
+    if (!m || !queries || !ids || !dist || !count) return cz::set_error(CZ_E_INVALID, "null argument");
+    if (B == 0) return CZ_OK;
+    const size_t nk = (size_t)B * k;
+    return on_devices_of(m, [&](int r, cz_comm *c) {
+        cz::DevBuf<float> q;
+        cz::DevBuf<uint64_t> oi;
+        cz::DevBuf<double> od;
+        cz::DevBuf<uint32_t> oc;
+        CZ_HIP(q.alloc((size_t)B * m->dim));
+        CZ_HIP(oi.alloc(nk));
+        CZ_HIP(od.alloc(nk));
+        CZ_HIP(oc.alloc(B));
+        if (r == 0) CZ_HIP(hipMemcpy(q.p, queries, (size_t)B * m->dim * 4, hipMemcpyHostToDevice));  // (the others receive the broadcast)
+        int rc = cz_hnsw_search_sharded(c, m->shards[r], q.p, B, k, ef, m->id_offset[r], oi.p, od.p, oc.p, nullptr);
+        if (rc) return rc;
+        if (r == 0) {  // every rank holds the same merged lists
+            CZ_HIP(hipMemcpy(ids, oi.p, nk * 8, hipMemcpyDeviceToHost));
+            CZ_HIP(hipMemcpy(dist, od.p, nk * 8, hipMemcpyDeviceToHost));
+            CZ_HIP(hipMemcpy(count, oc.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+        }
+        return (int)CZ_OK;
+    });
+}
+
+extern "C" int cz_hnsw_multi_shards(const cz_hnsw_multi *m, uint64_t *id_offsets /* [n_gpus] or NULL */) {
+    if (!m) return 0;
+    if (id_offsets)
+        for (int r = 0; r < m->n_gpus; r++) id_offsets[r] = m->id_offset[r];
+    return m->n_gpus;
+}

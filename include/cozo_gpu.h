@@ -331,6 +331,27 @@ int cz_hnsw_search_sharded(cz_comm *comm, cz_hnsw_index *shard, const float *que
                            uint32_t ef, uint64_t id_offset, uint64_t *out_ids_dev, double *out_dist_dev,
                            uint32_t *out_count_dev, void *stream);
 
+/* The same partitioned index held by ONE process (what a cozo process with several GPUs uses; HnswSearchRA::iter,
+ * query/ra.rs:1085-1121, calls hnsw_knn per parent tuple -- here once per batch): sub-index r lives on GPU r, with one host
+ * thread and one RCCL communicator per GPU for the lifetime of the handle.
+ *   cz_hnsw_multi_build: `::hnsw create` over shards -- rows [r * ceil(n / n_gpus), ...) of `vectors` (host, in key order) are
+ *     built into an index on GPU r with cz_hnsw_build's parameters, all devices at once; n_dist (optional) = evaluations spent.
+ *   cz_hnsw_multi_create: shards read from the store (cz_hnsw_desc + vectors per shard, id_offsets[r] = the global id of
+ *     shard r's node 0).
+ *   cz_hnsw_multi_search: queries [B][dim] (host) -> ids [B][k] u64 global ids (~0 = none), dist [B][k] f64, count [B]
+ *     (host): cz_hnsw_search_sharded on every device at once.
+ *   cz_hnsw_multi_shards: the number of shards (and their id offsets). */
+typedef struct cz_hnsw_multi cz_hnsw_multi;
+int cz_hnsw_multi_build(const float *vectors, uint32_t n, uint32_t dim, int metric, uint32_t m, uint32_t ef_construction,
+                        int keep_pruned_connections, uint64_t seed, uint32_t max_batch, int n_gpus, uint32_t flags,
+                        uint64_t *n_dist, cz_hnsw_multi **out);
+int cz_hnsw_multi_create(const cz_hnsw_desc *const *shards, const float *const *vectors, const uint64_t *id_offsets,
+                         int n_gpus, cz_hnsw_multi **out);
+int cz_hnsw_multi_search(cz_hnsw_multi *m, const float *queries, uint32_t B, uint32_t k, uint32_t ef, uint64_t *ids,
+                         double *dist, uint32_t *count);
+int cz_hnsw_multi_shards(const cz_hnsw_multi *m, uint64_t *id_offsets);
+void cz_hnsw_multi_destroy(cz_hnsw_multi *m);
+
 /* ONE traversal over a graph whose vertices are partitioned across ranks (third row), collectively:
  * rank r passes the out-adjacency of the nodes [row_begin, row_end) -- out_offsets_local [row_end-row_begin+1] relative to
  * the shard, out_targets / weights [E_local] with GLOBAL target ids; starts / goals and every output (full length N per

@@ -60,6 +60,10 @@ pub struct cz_predicate {
 }
 
 #[repr(C)]
+pub struct cz_hnsw_multi {
+    _private: [u8; 0],
+}
+#[repr(C)]
 pub struct cz_comm {
     _private: [u8; 0],
 }
@@ -180,6 +184,15 @@ extern "C" {
     pub fn cz_pagerank_multi(in_offsets: *const u32, in_sources: *const u32, out_degree: *const u32, n: u32, e: u64,
                              damping: c_float, tolerance: c_double, max_iter: u32, n_gpus: c_int, flags: u32,
                              scores: *mut c_float, iters_run: *mut u32, final_err: *mut c_double, poison: *const u8) -> c_int;
+    pub fn cz_hnsw_multi_build(vectors: *const c_float, n: u32, dim: u32, metric: c_int, m: u32, ef_construction: u32,
+                               keep_pruned_connections: c_int, seed: u64, max_batch: u32, n_gpus: c_int, flags: u32, n_dist: *mut u64,
+                               out: *mut *mut cz_hnsw_multi) -> c_int;
+    pub fn cz_hnsw_multi_create(shards: *const *const cz_hnsw_desc, vectors: *const *const c_float, id_offsets: *const u64, n_gpus: c_int,
+                                out: *mut *mut cz_hnsw_multi) -> c_int;
+    pub fn cz_hnsw_multi_search(m: *mut cz_hnsw_multi, queries: *const c_float, b: u32, k: u32, ef: u32, ids: *mut u64, dist: *mut c_double,
+                                count: *mut u32) -> c_int;
+    pub fn cz_hnsw_multi_shards(m: *const cz_hnsw_multi, id_offsets: *mut u64) -> c_int;
+    pub fn cz_hnsw_multi_destroy(m: *mut cz_hnsw_multi);
     pub fn cz_hnsw_search_sharded(comm: *mut cz_comm, shard: *mut cz_hnsw_index, queries_dev: *const c_float, b: u32, k: u32,
                                   ef: u32, id_offset: u64, out_ids_dev: *mut u64, out_dist_dev: *mut c_double,
                                   out_count_dev: *mut u32, stream: *mut c_void) -> c_int;

@@ -81,6 +81,24 @@ def main():
     assert np.array_equal(od.cpu().numpy(), dist) and np.array_equal(oc.cpu().numpy().astype(np.uint32), cnt)
     gix.close()
     print("OK hnsw_search_sharded", flush=True)
+    # the same partitioned index held by one process (cz_hnsw_multi_*): with one device, one shard == the plain index
+    from cozo_amd.comm import HnswMulti
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest
+    man = HnswIndexManifest(vec_dim=96, distance="Cosine", m_neighbours=12, ef_construction=60)
+    multi = HnswMulti.build(man, x, 1, seed=5, max_batch=64)
+    plain = GpuHnswIndex.build(man, x, seed=5, max_batch=64)
+    mi, md, mc = multi.search(q, 10, 64)
+    pi, pd, pc = plain.hnsw_knn_batch(q, HnswSearch(k=10, ef=64))
+    assert multi.n_gpus == 1 and multi.id_offsets().tolist() == [0] and multi.build_n_dist > 0
+    assert np.array_equal(mi, pi.astype(np.uint64)) and np.array_equal(md, pd) and np.array_equal(mc, pc)
+    try:
+        HnswMulti.build(man, x, 64)
+        raise AssertionError("more GPUs than the box has must be refused")
+    except _lib.CozoGpuError:
+        pass
+    multi.close()
+    plain.close()
+    print("OK hnsw_multi", flush=True)
     # ONE traversal over a "vertex-partitioned" graph of one rank == the single-GPU rule on the same graph
     from cozo_amd.comm import bfs_sharded, sssp_sharded
     frm, to = util.random_relation(20000, 90000, 8)

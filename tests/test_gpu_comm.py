@@ -20,4 +20,5 @@ def test_comm_entry_points_on_one_gpu(gpu_lib):
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "OK pagerank_sharded" in p.stdout and "OK hnsw_search_sharded" in p.stdout and "OK bfs_sharded" in p.stdout
     assert "OK bfs_multi / sssp_multi / connected_components_multi" in p.stdout and "pagerank_sharded_overlapped" in p.stdout
+    assert "OK hnsw_multi" in p.stdout
     assert "ALL OK" in p.stdout
