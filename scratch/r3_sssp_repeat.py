@@ -1,0 +1,45 @@
+"""why is the repeated SSSP call on a held graph 50 ms in the bench and 19 ms earlier in the round?  The same call before and
+after a PageRank plan has been through the stream-ordered memory pool."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cozo_amd import _lib
+L = _lib.lib()
+import numpy as np
+import torch
+from cozo_amd import graph as G
+
+dev = torch.device("cuda:0")
+assert L.cz_init(0) == 0
+n, e = 10_000_000, 100_000_000
+g = torch.Generator(device=dev); g.manual_seed(7)
+src = torch.randint(0, n, (e,), generator=g, device=dev, dtype=torch.int64)
+dst = torch.randint(0, n, (e,), generator=g, device=dev, dtype=torch.int64)
+keep = src != dst
+key = torch.unique(src[keep] * n + dst[keep])
+s = torch.div(key, n, rounding_mode="floor"); t = key - s * n
+off = torch.zeros(n + 1, dtype=torch.int64, device=dev); off[1:] = torch.cumsum(torch.bincount(s, minlength=n), 0)
+ooff, otgt = off.to(torch.int32).cpu().numpy().view(np.uint32), t.to(torch.int32).cpu().numpy().view(np.uint32)
+w = (torch.randint(1, 64, (otgt.size,), generator=g, device=dev, dtype=torch.int32).to(torch.float32) / 8).cpu().numpy()
+del src, dst, keep, key, s, t, off
+torch.cuda.empty_cache()
+starts = np.array([0], dtype=np.uint32)
+
+
+def held(tag):
+    for i in range(3):
+        t0 = time.perf_counter()
+        with G.DeviceGraph.acquire((0xC0, 3), ooff, otgt, w) as dg:
+            t1 = time.perf_counter()
+            G.sssp(dg, None, None, starts)
+            t2 = time.perf_counter()
+        t3 = time.perf_counter()
+        up, dv, dn = G.last_timing()
+        print(f"{tag} call {i}: wall {1e3 * (t3 - t0):6.1f} ms  (acquire {1e3 * (t1 - t0):5.1f}, rule {1e3 * (t2 - t1):5.1f}: upload lap {up:5.1f} device {dv:5.1f} "
+              f"download {dn:5.1f}, release {1e3 * (t3 - t2):5.1f})", flush=True)
+
+
+held("fresh process")
+deg = np.diff(ooff.astype(np.int64)).astype(np.uint32)
+G.pagerank(ooff, otgt, deg, max_iter=3)  # a plan built and destroyed through the memory pool
+held("after a PageRank call")
