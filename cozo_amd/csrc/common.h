@@ -66,4 +66,43 @@ struct DevBuf {
     }
 };
 
+// The same for scratch that a call allocates and frees again: from the device's stream-ordered pool, which is told to keep
+// what is freed (release threshold = max) -- hipMalloc / hipFree of a few hundred MB per call is driver work (map / unmap)
+// that grows with what the process has mapped already.
+inline void pool_keep_freed() {
+    static const bool once = [] {
+        int dev = 0;
+        hipMemPool_t pool = nullptr;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+            uint64_t keep = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        return true;
+    }();
+    (void)once;
+}
+template <typename T>
+struct PoolBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    PoolBuf() = default;
+    PoolBuf(const PoolBuf &) = delete;
+    PoolBuf &operator=(const PoolBuf &) = delete;
+    ~PoolBuf() { reset(); }
+    void reset() {
+        if (p) (void)hipFreeAsync(p, nullptr);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count) {
+        reset();
+        pool_keep_freed();
+        if (count == 0) count = 1;
+        hipError_t e = hipMallocAsync((void **)&p, count * sizeof(T), nullptr);
+        if (e == hipSuccess) n = count;
+        else p = nullptr;
+        return e;
+    }
+};
+
 }  // namespace cz

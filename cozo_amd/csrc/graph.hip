@@ -1456,8 +1456,9 @@ struct SsspBatch {
     };
     View<uint32_t> d_off, d_tgt;
     View<float> d_w;
-    cz::DevBuf<uint32_t> d_qtag, d_ftag, d_misc, d_starts;
-    cz::DevBuf<unsigned long long> d_dp, d_q[4];
+    // (from the stream-ordered pool: 0.56 GB per source batch, allocated and freed by every call -- common.h PoolBuf)
+    cz::PoolBuf<uint32_t> d_qtag, d_ftag, d_misc, d_starts;
+    cz::PoolBuf<unsigned long long> d_dp, d_q[4];
     uint32_t *h_pin = nullptr;  // the counters come back through pinned memory: a round is a launch and one 32-byte copy
     ~SsspBatch() {
         if (h_pin) (void)hipHostFree(h_pin);
@@ -1601,8 +1602,8 @@ int sssp_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, float
     SsspBatch sb;
     if ((rc = sb.attach(G, n_starts, 80ull << 20))) return rc;  // about 4 GB in all
     const uint64_t SN = (uint64_t)sb.S * N;
-    cz::DevBuf<uint32_t> d_parent;
-    cz::DevBuf<float> d_dist;
+    cz::PoolBuf<uint32_t> d_parent;
+    cz::PoolBuf<float> d_dist;
     CZ_HIP(d_parent.alloc(SN));
     CZ_HIP(d_dist.alloc(SN));
     hipStream_t s = sb.s;
