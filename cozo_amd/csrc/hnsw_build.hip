@@ -237,7 +237,9 @@ build_link_kernel(BuildTables T, Req in, uint32_t n, int lazy, Req retry, uint32
         const RowRef r = row_of(T, t, lv);
         if (hidden) {  // counted (:338), never read (:609-610): no slot; the shrink test is the reference's
             const uint32_t old = atomicAdd(r.deg, kHiddenOne);
-            if (!lazy && deg_of(old) == (uint32_t)r.width) {
+            // (lazy builds: such links fill no slot, so the slot test never sees them -- every 16th one onto a row whose degree
+            // is past its width asks for the shrink that forgets them, which also keeps the two 16-bit halves far from full)
+            if (lazy ? (deg_of(old) >= (uint32_t)r.width && (hid_of(old) & 15u) == 15u) : deg_of(old) == (uint32_t)r.width) {
                 const uint32_t p = atomicAdd(shrink_count, 1u);
                 shrink_t[p] = t;
                 shrink_lv[p] = lv;

@@ -1,0 +1,12 @@
+#!/bin/bash
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r3z2
+timeout 900 python bench.py --skip-hnsw --skip-cpu > gpurun_out/r3z2/bench_pr_rules.json 2> gpurun_out/r3z2/bench.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/bench_detail.json"))
+g = d["graph_rules"]
+for k in ("bfs", "connected_components", "sssp"):
+    print(k, g[k]["device_ms"], g[k].get("repeated_call_wall_ms"), g[k].get("repeated_call_laps_ms"), g[k]["roofline"].get("traffic"))
+print(g.get("repeated_call_error"))
+PY
