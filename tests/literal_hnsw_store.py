@@ -38,6 +38,10 @@ class MaxQueue(dict):  # PriorityQueue<_, OrderedFloat>
         return key, pri
 
 
+class ReferencePanic(Exception):
+    """a step at which the reference itself panics (an `unwrap()` on a row that is not there)"""
+
+
 class LiteralStore:
     def __init__(self, dist, m, ef_construction, extend_candidates=False, keep_pruned_connections=False, row_of=None):
         """dist(a, b) -> f64 on two f32 vectors (the oracle's orc_distance, so that both models see the same bits)"""
@@ -169,9 +173,32 @@ class LiteralStore:
                 self.rows[(la, nb, nb)] = self_val  # :352-357
         return node
 
+    # ---- hnsw_remove_vec, :754-868 (without the canary row, which this model does not keep: the entry point is read off the
+    # first row of the map, as every reader does)
+    def remove(self, node):
+        layer = 0
+        while True:
+            if (layer, node, node) not in self.rows:  # :766-778
+                break
+            del self.rows[(layer, node, node)]
+            for nb, _ in self.neighbours(node, layer, True):  # :780-782 soft-deleted rows too; links inside the base row never
+                self.rows.pop((layer, node, nb), None)  # :786-795
+                self.rows.pop((layer, nb, node), None)  # :796-805 present or not
+                self_val = self.rows.get((layer, nb, nb))
+                if self_val is None:  # :806-815 `.get(..)?.unwrap()`: a link left dangling by an earlier removal leads here
+                    raise ReferencePanic(f"layer {layer}: node {node} links to {nb}, which has no self row")
+                self_val = list(self_val)
+                self_val[0] -= 1.0  # :816-823
+                self.rows[(layer, nb, nb)] = self_val
+            layer -= 1
+
+    def dangling(self):
+        return sum(1 for (la, fr, to) in self.rows if fr != to and (la, to, to) not in self.rows)
+
     # ---- views for the comparison with the oracle
     def live_links(self, node, level):
-        return [to for to, _ in self.neighbours(node, -level, False)]
+        """what a reader that survives sees: the non-deleted links to nodes that still have their row on this layer"""
+        return [to for to, _ in self.neighbours(node, -level, False) if (-level, to, to) in self.rows]
 
     def degree(self, node, level):
         return self.rows[(-level, node, node)][0]

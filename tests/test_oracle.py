@@ -375,3 +375,46 @@ def test_rows_with_several_vectors_equal_a_literal_row_store(oracle, extend, kee
     plain = oracle.HnswBuilder(dim, oracle.L2, m, efc, extend_candidates=extend, keep_pruned_connections=keep)
     plain.insert(x, levels)
     assert not np.array_equal(plain.export().level_nbrs[0], flat.level_nbrs[0])
+
+
+@pytest.mark.parametrize("extend", [False, True])
+def test_removal_equals_a_literal_row_store(oracle, extend):
+    """hnsw_remove_vec (hnsw.rs:754-868) restated in the oracle against the same deletions played on the literal row store:
+    self rows and out rows at every layer, the reverse rows present or not, one off each neighbour's degree, the rows of
+    OTHER nodes that pointed at the removed one left dangling; the entry point is whatever row comes first afterwards.  The
+    reference panics when it removes a node that still holds such a dangling row (`.unwrap()` on the missing self row, :806-815):
+    those removals are skipped in both models and counted."""
+    import copy
+    from tests.literal_hnsw_store import LiteralStore, ReferencePanic
+    n, dim, m, efc = 160, 6, 3, 10
+    x = util.vectors(n, dim, 8)
+    levels = oracle.random_levels(n, m, 1)
+    b = oracle.HnswBuilder(dim, oracle.L2, m, efc, extend_candidates=extend)
+    b.insert(x, levels)
+    st = LiteralStore(lambda a, c: oracle.distance(oracle.L2, a, c), m, efc, extend)
+    for i in range(n):
+        st.put(x[i], int(levels[i]))
+    rng = np.random.default_rng(3)
+    gone, panics = [], 0
+    for v in rng.permutation(n)[:70]:
+        trial = copy.deepcopy(st.rows)
+        try:
+            st.remove(int(v))
+        except ReferencePanic:
+            st.rows = trial
+            panics += 1
+            continue
+        assert b.remove([int(v)]) == 1
+        gone.append(int(v))
+    assert len(gone) >= 40
+    left = [i for i in range(n) if i not in set(gone)]
+    flat = b.export()
+    assert st.entry() == flat.entry
+    assert b.dangling_links() == st.dangling()
+    for lv in range(flat.n_levels):
+        ids, tab = flat.level_nodes[lv], flat.level_nbrs[lv]
+        assert [int(v) for v in ids] == [i for i in left if levels[i] >= lv]
+        for r, node in enumerate(ids):
+            assert [int(t) for t in tab[r] if t != oracle.NONE] == st.live_links(int(node), lv), (lv, int(node))
+            assert b.degree(int(node), lv) == st.degree(int(node), lv), (lv, int(node))
+    print(f"removed {len(gone)}, reference panics skipped {panics}, dangling rows {st.dangling()}")
