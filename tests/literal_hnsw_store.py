@@ -173,6 +173,31 @@ class LiteralStore:
                 self.rows[(la, nb, nb)] = self_val  # :352-357
         return node
 
+    # ---- hnsw_knn, :869-1012 (the rows it returns as (node, distance); `accept(node)` stands for the filter bytecode)
+    def knn(self, q, k, ef, radius=None, accept=None):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        if not self.rows:
+            return []
+        ep_row = min(self.rows)  # :891-899
+        found = MaxQueue()
+        found.push(ep_row[1], self.v_dist(q, ep_row[1]))
+        for la in range(ep_row[0], 0):  # :919-929
+            self.search_level(q, 1, la, found)
+        self.search_level(q, ef, 0, found)  # :930-938
+        if accept is None:  # :943-947
+            while len(found) > k:
+                found.pop()
+        ret = []
+        while found:  # :951-1004 farthest first
+            node, d = found.pop()
+            if radius is not None and d > radius:
+                continue
+            if accept is not None and not accept(node):
+                continue
+            ret.append((node, d))
+        ret.reverse()
+        return ret[:k]  # :1005-1006
+
     # ---- hnsw_remove_vec, :754-868 (without the canary row, which this model does not keep: the entry point is read off the
     # first row of the map, as every reader does)
     def remove(self, node):

@@ -418,3 +418,38 @@ def test_removal_equals_a_literal_row_store(oracle, extend):
             assert [int(t) for t in tab[r] if t != oracle.NONE] == st.live_links(int(node), lv), (lv, int(node))
             assert b.degree(int(node), lv) == st.degree(int(node), lv), (lv, int(node))
     print(f"removed {len(gone)}, reference panics skipped {panics}, dangling rows {st.dangling()}")
+
+
+@pytest.mark.parametrize("rows", [False, True])
+def test_search_equals_the_literal_row_store(oracle, rows):
+    """hnsw_knn (hnsw.rs:869-1012): the oracle's search over the exported flat tables against the literal walk over the row store
+    -- descent with ef = 1, the bottom layer with ef, truncation to k only without a filter, radius, ascending rows -- also on
+    an index whose base rows carry several vectors (the flat tables then hold no link inside a row, which is all a reader sees)."""
+    from tests.literal_hnsw_store import LiteralStore
+    n, dim, m, efc = 200, 7, 4, 12
+    rng = np.random.default_rng(6)
+    row_of = np.sort(rng.integers(0, n // 2, n)).astype(np.uint32) if rows else None
+    x = util.vectors(n, dim, 15)
+    levels = oracle.random_levels(n, m, 12)
+    b = oracle.HnswBuilder(dim, oracle.L2, m, efc)
+    if rows:
+        b.set_row_of(row_of)
+    b.insert(x, levels)
+    flat = b.export()
+    st = LiteralStore(lambda a, c: oracle.distance(oracle.L2, a, c), m, efc, row_of=row_of)
+    for i in range(n):
+        st.put(x[i], int(levels[i]))
+    q = util.vectors(30, dim, 16)
+    for k, ef, radius in ((5, 20, None), (8, 8, None), (6, 30, 0.35)):
+        ids, dist, cnt, _ = flat.knn_batch(q, k, ef, radius=radius)
+        for i in range(q.shape[0]):
+            want = st.knn(q[i], k, ef, radius=radius)
+            assert cnt[i] == len(want)
+            assert [int(v) for v in ids[i][:cnt[i]]] == [v for v, _ in want]
+            assert [float(d) for d in dist[i][:cnt[i]]] == [d for _, d in want]
+    # with a filter the list is NOT cut to k before the filter runs (:943-947): k rows out of the ef found that pass
+    keep = lambda v: v % 3 != 0
+    ids, dist, cnt, _ = flat.knn_batch(q, 25, 25)
+    for i in range(q.shape[0]):
+        passed = [(int(v), float(d)) for v, d in zip(ids[i][:cnt[i]], dist[i][:cnt[i]]) if keep(int(v))][:4]
+        assert passed == st.knn(q[i], 4, 25, accept=keep)
