@@ -50,6 +50,23 @@ def compute():
             out[f"hnsw knn {name} ef={ef}"] = _h(ids, dist, cnt, np.array([nd]))
         ids, dist, cnt, nd = flat.knn_batch(q, 10, 40, radius=float(np.median(dist)))
         out[f"hnsw knn {name} radius"] = _h(ids, dist, cnt)
+    # ---- index construction with the two options and over rows that carry several vectors (hnsw.rs:499-511, 524-536, 609-610),
+    # removal (hnsw.rs:754-868): tables, degrees of the self rows, soft-deleted and dangling rows
+    xs, lv = x[:400], O.random_levels(400, 4, 3)
+    row_of = np.sort(np.random.default_rng(8).integers(0, 150, 400)).astype(np.uint32)
+    for tag, kw, rows in (("extend", dict(extend_candidates=True), None), ("extend+keep", dict(extend_candidates=True, keep_pruned_connections=True), None),
+                          ("rows", {}, row_of), ("rows+extend", dict(extend_candidates=True), row_of)):
+        b = O.HnswBuilder(32, O.L2, 4, 16, **kw)
+        if rows is not None:
+            b.set_row_of(rows)
+        b.insert(xs, lv)
+        flat = b.export()
+        deg = [np.array([b.degree(int(v), l) for v in flat.level_nodes[l]]) for l in range(flat.n_levels)]
+        out[f"hnsw build {tag}"] = _h(*flat.level_nbrs, *deg, np.array([flat.entry, b.link_rows(True), b.link_rows()]))
+        b.remove(range(0, 400, 7))
+        flat = b.export()
+        deg = [np.array([b.degree(int(v), l) for v in flat.level_nodes[l]]) for l in range(flat.n_levels)]
+        out[f"hnsw remove after {tag}"] = _h(*flat.level_nbrs, *flat.level_nodes, *deg, np.array([flat.entry, b.dangling_links()]))
     # ---- graph rules on one seeded relation
     frm, to = util.random_relation(3000, 14000, 77)
     w = (np.random.default_rng(5).integers(0, 40, len(frm)) / 8).astype(np.float32)
