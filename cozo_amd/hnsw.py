@@ -219,7 +219,7 @@ class GpuHnswIndex:
         the rows the store holds is what has to be written."""
         from .ingest import encode_index_rows
         nodes, nbrs, entry = self.export()
-        degs = self.degrees() if self.manifest.extend_candidates else None
+        degs = self.degrees()  # (not always the number of link rows: extend_candidates, rows with several vectors)
         vecs = self.export_vectors()
         gone = self.__dict__.get("_removed")
         if gone and len(nbrs) and degs is not None:
