@@ -16,6 +16,9 @@ sys.path.insert(0, ROOT)
 DIMS = (1, 2, 7, 8, 9, 128, 768)
 HNSW = dict(n=600, dim=16, m=8, ef_construction=40, queries=32, k=10, ef=40)
 METRICS = ("L2", "Cosine", "IP")
+# round 3: the two paths that were added to the device build -- small, so that the literal row store of the tests can stand in
+EXT = dict(n=150, dim=8, m=3, ef_construction=10, queries=16, k=6, ef=20)   # extend_candidates: true
+ROWS = dict(rows=60, dim=8, m=3, ef_construction=10, queries=16, k=6, ef=20)  # a List of 1..3 vectors per row
 
 
 def dataset():
@@ -33,6 +36,13 @@ def dataset():
         d["pairs"][dim] = (a, b)
     d["vectors"] = np.random.default_rng(42).random((HNSW["n"], HNSW["dim"]), dtype=np.float32)
     d["queries"] = np.random.default_rng(43).random((HNSW["queries"], HNSW["dim"]), dtype=np.float32)
+    d["ext_vectors"] = np.random.default_rng(44).random((EXT["n"], EXT["dim"]), dtype=np.float32)
+    d["ext_queries"] = np.random.default_rng(45).random((EXT["queries"], EXT["dim"]), dtype=np.float32)
+    rr = np.random.default_rng(46)
+    centres = rr.random((ROWS["rows"], ROWS["dim"]), dtype=np.float32)
+    d["rows_vectors"] = [[(centres[i] + 0.05 * rr.standard_normal(ROWS["dim"])).astype(np.float32) for _ in range(1 + i % 3)]
+                         for i in range(ROWS["rows"])]  # a row's vectors are each other's nearest
+    d["rows_queries"] = rr.random((ROWS["queries"], ROWS["dim"]), dtype=np.float32)
     from tests import util
     frm, to = util.random_relation(3000, 14000, 77)
     d["frm"], d["to"] = frm, to
@@ -74,6 +84,35 @@ def steps():
                                f"?[qi, k, dist] := qs[qi, qv], q = vec(qv), ~{t}:idx{{k | query: q, k: {HNSW['k']}, ef: {HNSW['ef']}, bind_distance: dist}}\n"
                                f":order qi, dist, k",
                         params=dict(queries=q_rows)))
+    # ---- extend_candidates (hnsw.rs:499-511): the index rows WITH the hash column -- a shrink that selects its own target writes a
+    # link row onto the self row and hnsw_put_vector puts the self row back (:413-433, :352-357)
+    all_cols = "layer, fr_k, fr__field, fr__sub_idx, to_k, to__field, to__sub_idx, dist, hash, ignore_link"
+    out.append(dict(name="ext create table", mutable=True, script=f":create vt_ext {{k: Int => v: <F32; {EXT['dim']}>}}"))
+    out.append(dict(name="ext put", mutable=True, script="?[k, v] <- $rows\n:put vt_ext {k => v}",
+                    params=dict(rows=[[i, f32_list(v)] for i, v in enumerate(d["ext_vectors"])])))
+    out.append(dict(name="ext create index", mutable=True,
+                    script=f"::hnsw create vt_ext:idx {{dim: {EXT['dim']}, m: {EXT['m']}, dtype: F32, fields: [v], distance: L2, "
+                           f"ef_construction: {EXT['ef_construction']}, extend_candidates: true}}"))
+    out.append(dict(name="ext index rows", script=f"?[{all_cols}] := *vt_ext:idx{{{all_cols}}}"))
+    out.append(dict(name="ext knn",
+                    script=f"qs[qi, qv] <- $queries\n"
+                           f"?[qi, k, dist] := qs[qi, qv], q = vec(qv), ~vt_ext:idx{{k | query: q, k: {EXT['k']}, ef: {EXT['ef']}, bind_distance: dist}}\n"
+                           f":order qi, dist, k",
+                    params=dict(queries=[[i, f32_list(v)] for i, v in enumerate(d["ext_queries"])])))
+    # ---- rows that carry several vectors (hnsw.rs:694-706): links inside a base row are stored and never read (:609-610)
+    out.append(dict(name="rows create table", mutable=True, script=f":create vt_rows {{k: Int => vs: [<F32; {ROWS['dim']}>]}}"))
+    out.append(dict(name="rows put", mutable=True, script="?[k, vs] <- $rows\n:put vt_rows {k => vs}",
+                    params=dict(rows=[[i, [f32_list(v) for v in vs]] for i, vs in enumerate(d["rows_vectors"])])))
+    out.append(dict(name="rows create index", mutable=True,
+                    script=f"::hnsw create vt_rows:idx {{dim: {ROWS['dim']}, m: {ROWS['m']}, dtype: F32, fields: [vs], distance: L2, "
+                           f"ef_construction: {ROWS['ef_construction']}}}"))
+    out.append(dict(name="rows index rows", script=f"?[{all_cols}] := *vt_rows:idx{{{all_cols}}}"))
+    out.append(dict(name="rows knn",
+                    script=f"qs[qi, qv] <- $queries\n"
+                           f"?[qi, k, sub, dist] := qs[qi, qv], q = vec(qv), ~vt_rows:idx{{k | query: q, k: {ROWS['k']}, ef: {ROWS['ef']}, "
+                           f"bind_distance: dist, bind_field_idx: sub}}\n"
+                           f":order qi, dist, k, sub",
+                    params=dict(queries=[[i, f32_list(v)] for i, v in enumerate(d["rows_queries"])])))
     out.append(dict(name="graph create", mutable=True, script=":create edges {fr: Int, to: Int => w: Float}"))
     out.append(dict(name="graph put", mutable=True, script="?[fr, to, w] <- $rows\n:put edges {fr, to => w}",
                     params=dict(rows=[[int(f), int(t), float(w)] for f, t, w in zip(d["frm"], d["to"], d["w"])])))

@@ -12,6 +12,11 @@ What is compared, and how strictly:
   PageRank       every score within 1e-5 relative (north_star's bar); whether it is ALSO bit-identical is reported, which settles
                  the Jacobi / in-place question of SURVEY section 8 a10 for graph 0.3.1
   CC / Dijkstra / ShortestPathBFS   group ids, f32 costs (as f64) and path lengths equal
+  extend_candidates / rows with several vectors (round 3)   what the device build and the oracle ASSUME about the reference's
+                 rows, as predictions on the reference-built index: every self row is a self row again after a shrink wrote a
+                 link onto it (hash column not null), the degree sits 0 or 1 above the live link rows and somewhere 1; links
+                 inside a base row exist in the store, are not among what the search walks, and the degree may count them;
+                 and the oracle's search over what a reader sees of those rows == the reference's rows, bit for bit
 """
 import importlib.util
 import json
@@ -170,6 +175,82 @@ def check_components_dijkstra_bfs(ref, inputs, oracle):
             assert [index_of[int(x)] for x in want] == got, gv
 
 
+def _flat_of_nodes(oracle, rows, node_of, vectors, metric, m):
+    """ten-column `tbl:idx` rows -> the flat layout over nodes node_of[(k, sub)] (ids in key order); what a READER sees: no self
+    rows, no soft-deleted rows, no link inside a base row (hnsw.rs:609-610).  Also: per (level, node) the self row's degree and
+    hash, the live links a reader sees, the live links inside the base row."""
+    info = {}
+    for layer, fr_k, _ff, fr_s, to_k, _tf, to_s, dist, hsh, ignore in rows:
+        fr, to = node_of[(int(fr_k), int(fr_s))], node_of[(int(to_k), int(to_s))]
+        e = info.setdefault((-int(layer), fr), dict(degree=None, hash=None, seen=[], hidden=[]))
+        if fr == to:
+            e["degree"], e["hash"] = float(dist), hsh
+        elif not ignore:
+            (e["hidden"] if int(fr_k) == int(to_k) else e["seen"]).append(to)
+    n_levels = max(l for l, _ in info) + 1
+    nodes, nbrs = [], []
+    for l in range(n_levels):
+        ids = sorted(v for lv, v in info if lv == l)
+        width = max(1, max(len(info[(l, v)]["seen"]) for v in ids))
+        assert width <= (2 * m if l == 0 else m)
+        tab = np.full((len(ids), width), oracle.NONE, dtype=np.uint32)
+        for r, v in enumerate(ids):
+            tos = sorted(info[(l, v)]["seen"])
+            tab[r, :len(tos)] = tos
+        nodes.append(np.array(ids, dtype=np.uint32))
+        nbrs.append(tab)
+    return oracle.FlatIndex(vectors, metric, nodes, nbrs, int(nodes[-1][0])), info
+
+
+def check_extend_candidates(ref, inputs, oracle):
+    mod, d = inputs
+    E = mod.EXT
+    node_of = {(i, -1): i for i in range(E["n"])}
+    flat, info = _flat_of_nodes(oracle, ref["ext index rows"]["rows"], node_of, d["ext_vectors"], oracle.L2, E["m"])
+    assert sorted(v for l, v in info if l == 0) == list(range(E["n"]))
+    above = 0
+    for (l, v), e in info.items():
+        assert e["hash"] is not None, (l, v)  # the self row was put back (hnsw.rs:352-357) after the shrink wrote onto it (:413-433)
+        extra = e["degree"] - len(e["seen"])
+        assert extra in (0.0, 1.0), (l, v, e["degree"], len(e["seen"]))  # the target selected itself: a slot, no row
+        above += int(extra)
+    assert above > 0
+    ids, dist, cnt, _ = flat.knn_batch(d["ext_queries"], E["k"], E["ef"])
+    want = {}
+    for qi, k, dd in ref["ext knn"]["rows"]:
+        want.setdefault(int(qi), []).append((float(dd), int(k)))
+    for qi in range(E["queries"]):
+        g = sorted((float(dist[qi, j]), int(ids[qi, j])) for j in range(cnt[qi]))
+        assert g == sorted(want.get(qi, [])), qi
+
+
+def _row_nodes(d):
+    keys = [(k, s) for k, vs in enumerate(d["rows_vectors"]) for s in range(len(vs))]
+    return {ks: i for i, ks in enumerate(keys)}, keys, np.stack([d["rows_vectors"][k][s] for k, s in keys]).astype(np.float32)
+
+
+def check_rows_with_several_vectors(ref, inputs, oracle):
+    mod, d = inputs
+    R = mod.ROWS
+    node_of, keys, vectors = _row_nodes(d)
+    flat, info = _flat_of_nodes(oracle, ref["rows index rows"]["rows"], node_of, vectors, oracle.L2, R["m"])
+    assert sorted(v for l, v in info if l == 0) == list(range(len(keys)))
+    hidden = 0
+    for (l, v), e in info.items():
+        assert e["hash"] is not None
+        hidden += len(e["hidden"])
+        # counted at insertion like any link (:281-357); a later shrink re-counts only what hnsw_get_neighbours returns (:609-610)
+        assert len(e["seen"]) <= e["degree"] <= len(e["seen"]) + len(e["hidden"]), (l, v, e)
+    assert hidden > 0  # links inside a base row ARE written
+    ids, dist, cnt, _ = flat.knn_batch(d["rows_queries"], R["k"], R["ef"])
+    want = {}
+    for qi, k, sub, dd in ref["rows knn"]["rows"]:
+        want.setdefault(int(qi), []).append((float(dd), node_of[(int(k), int(sub))]))
+    for qi in range(R["queries"]):
+        g = sorted((float(dist[qi, j]), int(ids[qi, j])) for j in range(cnt[qi]))
+        assert g == sorted(want.get(qi, [])), qi
+
+
 @needs_ref
 def test_distances_bit_for_bit(ref, inputs, oracle):
     check_distances(ref, inputs, oracle)
@@ -188,6 +269,16 @@ def test_pagerank_within_tolerance_and_whether_bit_identical(ref, inputs, oracle
 @needs_ref
 def test_components_dijkstra_and_bfs(ref, inputs, oracle):
     check_components_dijkstra_bfs(ref, inputs, oracle)
+
+
+@needs_ref
+def test_extend_candidates_on_the_reference_built_index(ref, inputs, oracle):
+    check_extend_candidates(ref, inputs, oracle)
+
+
+@needs_ref
+def test_rows_with_several_vectors_on_the_reference_built_index(ref, inputs, oracle):
+    check_rows_with_several_vectors(ref, inputs, oracle)
 
 
 def test_the_checks_themselves_on_rows_the_oracle_produced(inputs, oracle):
@@ -232,6 +323,27 @@ def test_the_checks_themselves_on_rows_the_oracle_produced(inputs, oracle):
     parent = oracle.shortest_path_bfs(g["n"], g["ooff"], g["otgt"], start, goals)
     fake["shortest path bfs"] = dict(ok=True, rows=[[d["bfs_start"], gv, (lambda p: None if p is None else [int(g["ind"][x]) for x in p])(_bfs_path(parent, start, int(gi)))]
                                                     for gv, gi in zip(d["bfs_goals"], goals)])
+    # the two round-3 paths: rows of the literal row store (tests/literal_hnsw_store.py), which keeps ALL rows like the reference
+    from tests.literal_hnsw_store import LiteralStore
+    dist_l2 = lambda a, c: oracle.distance(oracle.L2, a, c, oracle.DOT_NDARRAY)
+    E, R = mod.EXT, mod.ROWS
+    st = LiteralStore(dist_l2, E["m"], E["ef_construction"], extend_candidates=True)
+    for v, lv in zip(d["ext_vectors"], oracle.random_levels(E["n"], E["m"], 11)):
+        st.put(v, int(lv))
+    fake["ext index rows"] = dict(ok=True, rows=[[la, fr, 1, -1, to, 1, -1, val[0], None if val[1] is None else "h", val[2]]
+                                                 for (la, fr, to), val in sorted(st.rows.items())])
+    fake["ext knn"] = dict(ok=True, rows=[[qi, node, dd] for qi, q in enumerate(d["ext_queries"]) for node, dd in st.knn(q, E["k"], E["ef"])])
+    node_of, keys, vectors = _row_nodes(d)
+    row_of = np.array([k for k, _ in keys], dtype=np.uint32)
+    st = LiteralStore(dist_l2, R["m"], R["ef_construction"], row_of=row_of)
+    for v, lv in zip(vectors, oracle.random_levels(len(keys), R["m"], 12)):
+        st.put(v, int(lv))
+    fake["rows index rows"] = dict(ok=True, rows=[[la, keys[fr][0], 1, keys[fr][1], keys[to][0], 1, keys[to][1], val[0],
+                                                   None if val[1] is None else "h", val[2]] for (la, fr, to), val in sorted(st.rows.items())])
+    fake["rows knn"] = dict(ok=True, rows=[[qi, keys[node][0], keys[node][1], dd] for qi, q in enumerate(d["rows_queries"])
+                                           for node, dd in st.knn(q, R["k"], R["ef"])])
+    check_extend_candidates(fake, inputs, oracle)
+    check_rows_with_several_vectors(fake, inputs, oracle)
     check_distances(fake, inputs, oracle)
     check_hnsw(fake, inputs, oracle)
     check_pagerank(fake, inputs, oracle)
