@@ -53,6 +53,9 @@ PMC_SOURCES = {  # the kernel-bearing sources each PMC entry of profiles/pmc_tra
     "hnsw_knn_1m": ["hnsw_kernels.cuh", "distance.cuh", "hnsw_api.hip"],
     "bfs": ["graph.hip"],
     "sssp": ["graph.hip"],
+    "connected_components": ["graph.hip"],
+    "clustering_coefficients": ["graph.hip"],
+    "label_propagation": ["graph.hip"],
 }
 
 
@@ -812,7 +815,8 @@ def bench_graph_rules(args, torch, device):
     reached = int((dep[0] != 0xFFFFFFFF).sum())
     out["bfs"] = entry(dt, E, 4 * E + 4 * (n + 1) + 12 * n, pmc_key="bfs", reached=reached, levels=int(dep[0][dep[0] != 0xFFFFFFFF].max()))
     (grp, k), dt = timed(lambda: G.connected_components(uoff, utgt))
-    out["connected_components"] = entry(dt, int(utgt.size), 4 * int(utgt.size) + 4 * (n + 1) + 4 * n, components=int(k))
+    out["connected_components"] = entry(dt, int(utgt.size), 4 * int(utgt.size) + 4 * (n + 1) + 4 * n, pmc_key="connected_components",
+                                        components=int(k))
     (dist, _), dt = timed(lambda: G.sssp(ooff, otgt, w, starts))
     fin = np.isfinite(dist[0])
     out["sssp"] = entry(dt, E, 8 * E + 4 * (n + 1) + 12 * n, pmc_key="sssp", reached=int(fin.sum()), max_cost=float(dist[0][fin].max()))
@@ -841,11 +845,12 @@ def bench_graph_rules(args, torch, device):
     _lib_clear = getattr(__import__("cozo_amd._lib", fromlist=["lib"]).lib(), "cz_graph_cache_clear")
     _lib_clear()
     (tri, deg), dt = timed(lambda: G.clustering_coefficients(uoff, utgt))
-    out["clustering_coefficients"] = entry(dt, int(utgt.size), 4 * int(utgt.size) + 4 * (n + 1) + 12 * n,
+    out["clustering_coefficients"] = entry(dt, int(utgt.size), 4 * int(utgt.size) + 4 * (n + 1) + 12 * n, pmc_key="clustering_coefficients",
                                            triangle_incidences=int(tri.sum()), max_degree=int(deg.max()))
     ones = np.ones(utgt.size, dtype=np.float32)
     (lab, lp_it, lp_col), dt = timed(lambda: G.label_propagation(uoff, utgt, ones, 10))
-    out["label_propagation"] = entry(dt, int(utgt.size) * lp_it, lp_it * (8 * int(utgt.size) + 4 * (n + 1) + 8 * n), iterations=lp_it,
+    out["label_propagation"] = entry(dt, int(utgt.size) * lp_it, lp_it * (8 * int(utgt.size) + 4 * (n + 1) + 8 * n),
+                                     pmc_key="label_propagation", iterations=lp_it,
                                      colour_classes=lp_col, labels_left=int(np.unique(lab).size),
                                      what="one fixed execution of the reference's randomised loop (include/cozo_gpu.h); device_ms "
                                           "includes the colouring and the class lists")

@@ -30,6 +30,9 @@ SPEC = {
     "hnsw_knn_1m": dict(tag="hnsw1m", regex=r"hnsw_knn_kernel", mode="last", n=3, algo=None),
     "bfs": dict(tag="bfs", regex=r"bfs_|scan_tiles_kernel|scan_add_kernel", mode="per_run", runs=2, algo=None),
     "sssp": dict(tag="sssp", regex=r"sssp_|fill_u64_kernel", mode="per_run", runs=2, algo=None),
+    "connected_components": dict(tag="cc", regex=r"cc_|scan_tiles_kernel|scan_add_kernel", mode="per_run", runs=2, algo=None),
+    "clustering_coefficients": dict(tag="tri", regex=r"triangles_|tri_", mode="per_run", runs=2, algo=None),
+    "label_propagation": dict(tag="lp", regex=r"lp_|iota_kernel|scan_tiles_kernel|scan_add_kernel", mode="per_run", runs=2, algo=None),
 }
 
 
@@ -55,6 +58,8 @@ def main():
         algos["hnsw_knn_1m"] = d["hnsw_1m"]["roofline"]["algorithmic_bytes_per_launch"]
         algos["bfs"] = d["graph_rules"]["bfs"]["algorithmic_bytes"]
         algos["sssp"] = d["graph_rules"]["sssp"]["algorithmic_bytes"]
+        for k in ("connected_components", "clustering_coefficients", "label_propagation"):
+            algos[k] = d["graph_rules"][k]["algorithmic_bytes"]
     except Exception as e:  # noqa: BLE001
         print("no bench_detail.json beside the PMC passes:", e)
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -23,15 +23,33 @@ s = torch.div(key, n, rounding_mode="floor"); t = key - s * n
 off = torch.zeros(n + 1, dtype=torch.int64, device=dev); off[1:] = torch.cumsum(torch.bincount(s, minlength=n), 0)
 ooff, otgt = off.to(torch.int32).cpu().numpy().view(np.uint32), t.to(torch.int32).cpu().numpy().view(np.uint32)
 w = (torch.randint(1, 64, (otgt.size,), generator=g, device=dev, dtype=torch.int32).to(torch.float32) / 8).cpu().numpy()
+uoff = utgt = None
+if rule in ("cc", "tri", "lp"):  # the symmetrised graph, parallel edges kept (bench.py bench_graph_rules), on the device like there
+    key2 = torch.sort(torch.cat([key, t * n + s])).values
+    s2 = torch.div(key2, n, rounding_mode="floor")
+    off2 = torch.zeros(n + 1, dtype=torch.int64, device=dev); off2[1:] = torch.cumsum(torch.bincount(s2, minlength=n), 0)
+    uoff, utgt = off2.to(torch.int32).cpu().numpy().view(np.uint32), (key2 - s2 * n).to(torch.int32).cpu().numpy().view(np.uint32)
+    del key2, s2, off2
 del src, dst, keep, key, s, t, off
 torch.cuda.empty_cache()
 starts = np.array([0], dtype=np.uint32)
-with G.DeviceGraph.acquire((3, 3), ooff, otgt, w if rule == "sssp" else None) as dg:
+if rule in ("bfs", "sssp"):
+    with G.DeviceGraph.acquire((3, 3), ooff, otgt, w if rule == "sssp" else None) as dg:
+        for _ in range(runs):
+            if rule == "bfs":
+                G.bfs(dg, None, starts, want_depth=True)
+            else:
+                G.sssp(dg, None, None, starts)
+            print(rule, "device ms", G.last_timing()[1], flush=True)
+else:
+    ones = np.ones(utgt.size, dtype=np.float32)
     for _ in range(runs):
-        if rule == "bfs":
-            G.bfs(dg, None, starts, want_depth=True)
+        if rule == "cc":
+            G.connected_components(uoff, utgt)
+        elif rule == "tri":
+            G.clustering_coefficients(uoff, utgt)
         else:
-            G.sssp(dg, None, None, starts)
+            G.label_propagation(uoff, utgt, ones, 10)
         print(rule, "device ms", G.last_timing()[1], flush=True)
 print("edges", otgt.size, "runs", runs)
 if rule == "sssp" and os.environ.get("SWEEP_DELTA"):
