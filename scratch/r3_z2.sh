@@ -6,7 +6,7 @@ python - <<'PY'
 import json
 d = json.load(open("gpurun_out/bench_detail.json"))
 g = d["graph_rules"]
-for k in ("bfs", "connected_components", "sssp"):
-    print(k, g[k]["device_ms"], g[k].get("repeated_call_wall_ms"), g[k].get("repeated_call_laps_ms"), g[k]["roofline"].get("traffic"))
-print(g.get("repeated_call_error"))
+for k in ("bfs", "connected_components", "sssp", "clustering_coefficients", "label_propagation"):
+    print(k, g[k]["device_ms"], g[k]["roofline"].get("traffic"))
+print("line bytes", len(open("gpurun_out/r3z2/bench_pr_rules.json").read()))
 PY
