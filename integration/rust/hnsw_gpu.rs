@@ -353,8 +353,17 @@ impl<'a> SessionTx<'a> {
     /// hnsw_put for the rows of one statement: cz_hnsw_insert (the new vectors become nodes n .. n + n_new - 1; the shim extends
     /// its node -> CompoundKey table in the same order), then the delta above.  hnsw_remove: cz_hnsw_remove with the nodes of the
     /// deleted rows, then the same delta (their rows and every link row that named them are deleted from the store).
-    pub(crate) fn hnsw_put_gpu(&mut self, gpu: &mut GpuHnswIndex, new_vectors: &[f32], n_new: u32, config: &HnswSearch) -> Result<()> {
+    pub(crate) fn hnsw_put_gpu(&mut self, gpu: &mut GpuHnswIndex, new_vectors: &[f32], new_node_rows: &[u64], config: &HnswSearch) -> Result<()> {
         let mf = &config.manifest;
+        let n_new = new_node_rows.len() as u32;
+        // the base row of every node, the new ones appended (the caller extends node_field / node_sub the same way); when some row
+        // carries several vectors the library needs them: links inside a base row are never read (hnsw.rs:609-610)
+        gpu.node_row.extend_from_slice(new_node_rows);
+        let mut dense = std::collections::BTreeMap::new();
+        let row_of = gpu.node_row.iter().map(|r| { let next = dense.len() as u32; *dense.entry(*r).or_insert(next) }).collect_vec();
+        if dense.len() < row_of.len() {
+            check(unsafe { cz_hnsw_set_row_of(gpu.handle, row_of.as_ptr(), row_of.len() as u32) })?;
+        }
         check(unsafe {
             cz_hnsw_insert(gpu.handle, new_vectors.as_ptr(), n_new, mf.m_neighbours as u32, mf.ef_construction as u32,
                            mf.keep_pruned_connections as c_int, std::ptr::null(), rand::random(), 0, std::ptr::null_mut(),
