@@ -240,16 +240,19 @@ class HnswRun:
             dist.barrier()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()
-        for _ in range(steps):
-            self.search(ef)
-        e1.record()
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
+        import boxstate
+        with boxstate.Sampler(boxstate.device_sysfs(torch, self.device.index or 0)) as smp:  # clocks / power DURING the timed loop (sysfs, a thread)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(steps):
+                self.search(ef)
+            e1.record()
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+        self.clocks = smp.summary()
         dev_ms = e0.elapsed_time(e1)
         if multi:
             t = torch.tensor([wall], device=self.device, dtype=torch.float64)
@@ -317,7 +320,7 @@ def bench_hnsw(args, torch, dist, rank, world, device):
     log(f"ef sweep {sweep} -> ef = {ef}, recall@{k} = {rec:.4f}")
     t = run.timed(ef, args.steps, args.warmup, dist, args.multi)
     t["roofline"]["traffic"] = pmc_traffic("hnsw_knn", world, t["roofline"]["algorithmic_bytes_per_launch"]) if args.dist == "lowrank" else None
-    res = dict(qps=world * B * args.steps / t["wall"], ms_per_step=t["ms_per_step"], ef=ef, recall=rec,
+    res = dict(qps=world * B * args.steps / t["wall"], ms_per_step=t["ms_per_step"], ef=ef, recall=rec, clocks=getattr(run, "clocks", None),
                n_dist_per_query=t["n_dist"] / B, build_s=run.build_s, build_n_dist=run.build_nd, roofline=t["roofline"],
                index_bytes=run.ix.device_bytes, sweep=sweep, distance_batch=db)
     # CPU baseline + parity: the oracle (a port of the reference algorithm) on the same index and the same queries
@@ -404,10 +407,10 @@ def bench_distance_batch(args, torch, x, q, stream, device):
     pairs = torch.stack([torch.randint(0, q.shape[0], (P,), generator=g, device=device, dtype=torch.int32),
                          torch.randint(0, x.shape[0], (P,), generator=g, device=device, dtype=torch.int32)], 1).contiguous()
     out = torch.empty(P, dtype=torch.float64, device=device)
-    for _ in range(2):
+    for _ in range(10):  # the first launches after the corpus generation run 3-5 % slow (profiles/r04_placement_ab.txt)
         distance_batch_device("Cosine", x, q, pairs, out, stream)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
+    reps = 10
     e0.record()
     for _ in range(reps):
         distance_batch_device("Cosine", x, q, pairs, out, stream)
@@ -759,6 +762,72 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
     return res
 
 
+def bench_single_process_multi(args, torch, world, device):
+    """The `*_multi` forms (ONE process driving n GPUs: one host thread + one RCCL communicator per device, what a cozo process
+    is): cz_pagerank_multi (plain and overlapped exchange), cz_{bfs,sssp,connected_components}_multi, cz_hnsw_multi_*.  Rank 0
+    runs them over all `world` devices while the other ranks wait at a barrier (their own work is finished; their resident
+    arrays leave > 200 GB per device).  Host-pointer entry points: the walls include upload and results, sizes are modest."""
+    from cozo_amd import comm as CM
+    from cozo_amd.hnsw import HnswIndexManifest
+    n_gpus = max(1, world)
+    small = os.environ.get("CZ_BENCH_FORCE_MULTI") == "1"
+    N, E = (200_000, 2_000_000) if small else (10_000_000, 100_000_000)
+    res = dict(n_gpus=n_gpus, what="one process, one host thread + one RCCL communicator per device; walls of whole host-pointer calls")
+
+    off, s, outdeg, _ = make_graph(args, torch, None, 0, 1, device, "uniform", N, E, 0, N)
+    h_off = off.to(torch.int32).cpu().numpy().astype(np.uint32)
+    h_src = s.cpu().numpy().astype(np.uint32)
+    h_od = outdeg.cpu().numpy().astype(np.uint32)
+    e_kept = int(h_src.size)
+    del off, s, outdeg
+    torch.cuda.empty_cache()
+
+    def wall(fn, reps=2):
+        best, out = None, None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best, out
+
+    try:
+        iters = 10
+        dt, (sc, it, _) = wall(lambda: CM.pagerank_multi(h_off, h_src, h_od, n_gpus, 0.85, 0.0, iters))
+        res["pagerank_multi"] = dict(nodes=N, edges=e_kept, iterations=int(it), wall_ms=dt * 1e3, edges_per_s=e_kept * int(it) / dt)
+        dt2, (sc2, it2, _) = wall(lambda: CM.pagerank_multi(h_off, h_src, h_od, n_gpus, 0.85, 0.0, iters, overlap_exchange=True))
+        res["pagerank_multi_overlapped"] = dict(wall_ms=dt2 * 1e3, edges_per_s=e_kept * int(it2) / dt2,
+                                                scores_equal_plain=bool(np.array_equal(sc, sc2)))
+        del sc, sc2
+    except Exception as e:  # noqa: BLE001
+        res["pagerank_multi"] = dict(error=f"{type(e).__name__}: {e}")
+    try:  # the traversals read the same arrays as an OUT-adjacency (a graph is a graph)
+        w = ((np.arange(e_kept, dtype=np.uint64) * 2654435761 >> 7) % 1000 + 1).astype(np.float32)
+        starts = np.array([0], dtype=np.uint32)
+        dt, _ = wall(lambda: CM.bfs_multi(h_off, h_src, n_gpus, starts), 1)
+        res["bfs_multi"] = dict(wall_ms=dt * 1e3)
+        dt, _ = wall(lambda: CM.sssp_multi(h_off, h_src, w, n_gpus, starts), 1)
+        res["sssp_multi"] = dict(wall_ms=dt * 1e3)
+        dt, (_, k) = wall(lambda: CM.connected_components_multi(h_off, h_src, n_gpus), 1)
+        res["connected_components_multi"] = dict(wall_ms=dt * 1e3, groups=int(k), note="the directed CSR taken as is (the rule symmetrises first)")
+    except Exception as e:  # noqa: BLE001
+        res["traversal_multi"] = dict(error=f"{type(e).__name__}: {e}")
+    try:
+        n = 20_000 if small else 400_000 * n_gpus
+        x = gen_vectors(torch, n, args.dim, args.dist, 42, device).cpu().numpy()
+        q = gen_vectors(torch, args.batch, args.dim, args.dist, 43, device).cpu().numpy()
+        t0 = time.perf_counter()
+        mi = CM.HnswMulti.build(HnswIndexManifest(vec_dim=args.dim, distance="Cosine", m_neighbours=args.m,
+                                                  ef_construction=args.ef_construction), x, n_gpus, seed=1, max_batch=args.max_batch)
+        build_s = time.perf_counter() - t0
+        dt, _ = wall(lambda: mi.search(q, args.k, 64), 3)
+        res["hnsw_multi"] = dict(rows=n, shards=n_gpus, build_s=build_s, ef=64, search_wall_ms=dt * 1e3, queries_per_s=args.batch / dt)
+        mi.close()
+    except Exception as e:  # noqa: BLE001
+        res["hnsw_multi"] = dict(error=f"{type(e).__name__}: {e}")
+    return res
+
+
 def bench_graph_rules(args, torch, device):
     """The other whole-graph rules on the configs[2]-sized uniform graph (10M nodes / 100M edges): BFS from one start,
     ConnectedComponents on the symmetrised graph, ShortestPathDijkstra from one start.  The C ABI of these rules takes host
@@ -926,7 +995,9 @@ NESTED_DROP = {"what", "note", "sample", "tried", "sweep", "ef_sweep", "workload
                "h2d_ms", "d2h_ms", "cache_hit", "iterate_ms", "queries", "tolerance", "same_rows_as_reference_order",
                "base_rows", "pairs", "metric", "id_assignment_s", "csr_both_s", "host_cores", "rows", "graph", "reached",
                "levels", "components", "max_cost", "triangle_incidences", "max_degree", "colour_classes", "labels_left",
-               "max_centrality", "source_node_pairs_per_s", "algorithmic_bytes_per_launch", "iterations", "all_cores"}
+               "max_centrality", "source_node_pairs_per_s", "algorithmic_bytes_per_launch", "iterations", "all_cores",
+               "sysfs", "sclk_levels", "mclk_levels", "fclk_levels", "vbios", "vram_total", "kernel", "amdgpu_version", "samples",
+               "temp_mem_c", "mclk_mhz"}
 
 
 def _num(x):
@@ -995,8 +1066,65 @@ def write_detail(full):
     return None
 
 
+def visible_gpus():
+    """GPUs this process could use, counted WITHOUT creating a HIP context here (the launcher must stay clean: its children
+    bring their own runtime): the KFD topology nodes that carry SIMDs, cut down by HIP/ROCR_VISIBLE_DEVICES when set."""
+    n = 0
+    top = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for d in os.listdir(top):
+            try:
+                with open(os.path.join(top, d, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except OSError:
+                continue
+    except OSError:
+        n = 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def ensure_ranks(args):
+    """`python bench.py --gpus N` (N > 1, no launcher around it) starts its own N ranks: one process per GPU through
+    torch.distributed.run on 127.0.0.1, then this process becomes the launcher (exec: its exit code is the job's).  Under a
+    launcher (WORLD_SIZE set) WORLD_SIZE must equal --gpus; N GPUs must be visible -- never a 1-GPU line labelled otherwise."""
+    forced = os.environ.get("CZ_BENCH_FORCE_MULTI") == "1"
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus and not (forced and world == 1):
+            sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or run "
+                     f"`python bench.py --gpus {args.gpus}` alone, which starts the ranks itself)")
+        return
+    if args.gpus <= 1 or forced:
+        return
+    have = visible_gpus()
+    if have < args.gpus and os.environ.get("CZ_BENCH_LAUNCH_DRY") != "1":
+        sys.exit(f"bench.py: {args.gpus} GPUs requested, {have} visible")
+    import socket
+    with socket.socket() as sk:  # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log("starting", args.gpus, "ranks:", " ".join(cmd))
+    if os.environ.get("CZ_BENCH_LAUNCH_DRY") == "1":  # tests: show the command, start nothing
+        print(json.dumps({"launch": cmd}))
+        sys.exit(0)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def main():
     args = parse()
+    ensure_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1016,7 +1144,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    assert world == args.gpus or (world == 1 and os.environ.get("CZ_BENCH_FORCE_MULTI") == "1") or (world == 1 and args.gpus == 1), \
+        f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPUs visible")
     t_start = time.time()
     out = {}
     hn = None if args.skip_hnsw else bench_hnsw(args, torch, dist, rank, world, device)
@@ -1044,6 +1175,15 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     extra[name] = dict(error=f"{type(e).__name__}: {e}")
                 torch.cuda.empty_cache()
+    if args.multi and not args.skip_secondary:
+        if rank == 0:
+            try:
+                extra["single_process_multi"] = bench_single_process_multi(args, torch, world, device)
+            except Exception as e:  # noqa: BLE001
+                extra["single_process_multi"] = dict(error=f"{type(e).__name__}: {e}")
+            torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        dist.barrier()
     if rank == 0:
         if hn is not None:
             out = {
@@ -1063,6 +1203,11 @@ def main():
             for key in ("cpu_baseline", "parity", "distance_batch"):
                 if hn.get(key):
                     out[key] = hn[key]
+            try:  # what the box says about itself: partitions, which GPU of the node, clocks / power during the timed loop
+                import boxstate
+                out["box"] = dict(boxstate.static_state(torch, local), during_timed_loop=hn.get("clocks"))
+            except Exception as e:  # noqa: BLE001
+                out["box"] = dict(error=f"{type(e).__name__}: {e}")
             if hn.get("sharded"):
                 out["hnsw_sharded"] = hn["sharded"]
         else:

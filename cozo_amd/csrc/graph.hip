@@ -1021,9 +1021,13 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
         uint32_t reached = 0;
         if (!share_visited && si > 0) {
             CZ_HIP(hipMemsetAsync(d_depth.p, 0xFF, (size_t)N * 4, s));
-            CZ_HIP(hipMemsetAsync(d_claim.p, 0xFF, (size_t)N * 4, s));
             CZ_HIP(hipMemsetAsync(d_vis.p, 0, vis_words * 4, s));
         }
+        // the claim words are per START even when `visited` is shared (algos/bfs.rs:43-53): bfs_order_big_kernel recognises a
+        // level's new nodes by (claim == frontier position, depth == level + 1), and a node an EARLIER start reached at the same
+        // position and depth would pass that test again -- written into the next frontier twice, the last new node pushed past
+        // the stretch and never expanded.  Every claimed node is visited, so forgetting the claims loses nothing.
+        if (si > 0) CZ_HIP(hipMemsetAsync(d_claim.p, 0xFF, (size_t)N * 4, s));
         CZ_HIP(hipMemsetAsync(d_parent.p, 0xFF, (size_t)N * 4, s));
         bool run = start < N;
         if (run && share_visited) {

@@ -9,7 +9,8 @@
  * Third-party arithmetic that lives outside /root/reference (restated from the
  * published crates, pinned versions from Cargo.lock):
  *   ndarray 0.15.6  numeric_util::unrolled_dot   (8 accumulators, see orc_dot_ndarray)
- *   graph   0.3.1   page_rank                    (GAP-style pull PageRank, Jacobi contrib refresh)
+ *   graph   0.3.1   page_rank                    (GAP-style pull PageRank; Jacobi contrib refresh = orc_pagerank, the in-place
+ *                                                 reading = orc_pagerank_mode(ORC_PR_INPLACE): which one the crate is, only a run of it can say)
  *   priority-queue 1.4.0 / ordered-float 4.2.0   (pop order among EQUAL priorities is
  *        implementation-defined there; this oracle breaks ties by node id -- documented deviation)
  */
@@ -900,6 +901,55 @@ int orc_pagerank(uint32_t n, const uint64_t *in_off, const uint32_t *in_src, con
         }
 #pragma omp parallel for num_threads(threads) schedule(static)
         for (int64_t v = 0; v < (int64_t)n; v++) contrib[v] = scores[v] / (float)out_deg[v];
+        it++;
+        if (err < tolerance || it == max_iter) break;
+    }
+    free(contrib);
+    if (iters_run) *iters_run = it;
+    if (final_err) *final_err = err;
+    return 0;
+}
+
+/* The OTHER reading of graph 0.3.1 `page_rank` (SURVEY 8 a10's flagged uncertainty; crate source absent, Cargo.lock:1562-1565).
+ * ORC_PR_JACOBI (0) is orc_pagerank above: contributions refreshed in a pass of their own, after the sweep.
+ * ORC_PR_INPLACE (1): `out_scores[u] = new_score / out_degree(u)` is written INSIDE the per-node loop, right after
+ *   `scores[u] = new_score`, so every node later in the same sweep already pulls the updated contribution -- on one thread
+ *   (and below one 16 384-node chunk) that is a Gauss-Seidel sweep in ascending node order, deterministic; with several rayon
+ *   threads it depends on the schedule and no restatement can pin it.  This mode is the ONE-THREAD execution.
+ * err_f64_diff: how `error += |new - old|` is formed -- 0: the f32 difference widened to f64 (`(new - old).abs() as f64`),
+ *   1: the difference of the widened values (`f64::abs(new as f64 - old as f64)`).  Scores do not depend on it; the
+ *   iteration count does when the error sits near `tolerance`.
+ * tests/test_ref_fixtures.py runs the reference's rows against all four combinations and reports which one they equal. */
+int orc_pagerank_mode(uint32_t n, const uint64_t *in_off, const uint32_t *in_src, const uint32_t *out_deg, float damping,
+                      double tolerance, uint32_t max_iter, int mode, int err_f64_diff, float *scores, uint32_t *iters_run,
+                      double *final_err) {
+    if (n == 0) {
+        if (iters_run) *iters_run = 0;
+        if (final_err) *final_err = 0;
+        return 0;
+    }
+    const float init = 1.0f / (float)n;
+    const float base = (1.0f - damping) / (float)n;
+    float *contrib = (float *)malloc(sizeof(float) * n);
+    for (uint32_t v = 0; v < n; v++) {
+        scores[v] = init;
+        contrib[v] = init / (float)out_deg[v];
+    }
+    uint32_t it = 0;
+    double err = 0;
+    for (;;) {
+        err = 0;
+        for (uint32_t u = 0; u < n; u++) {
+            float s = 0.0f;
+            for (uint64_t e = in_off[u]; e < in_off[u + 1]; e++) s = s + contrib[in_src[e]];
+            const float old = scores[u];
+            const float nw = base + damping * s;
+            scores[u] = nw;
+            if (mode == 1) contrib[u] = nw / (float)out_deg[u];
+            err += err_f64_diff ? fabs((double)nw - (double)old) : fabs((double)(nw - old));
+        }
+        if (mode != 1)
+            for (uint32_t v = 0; v < n; v++) contrib[v] = scores[v] / (float)out_deg[v];
         it++;
         if (err < tolerance || it == max_iter) break;
     }

@@ -112,6 +112,14 @@ int orc_pagerank(uint32_t n, const uint64_t *in_off, const uint32_t *in_src, con
                  double tolerance, uint32_t max_iter, float *scores, uint32_t *iters_run, double *final_err,
                  int threads);
 
+/* both readings of the crate's loop (see the .c): mode ORC_PR_JACOBI / ORC_PR_INPLACE (one thread, ascending nodes),
+ * err_f64_diff 0 / 1 */
+#define ORC_PR_JACOBI 0
+#define ORC_PR_INPLACE 1
+int orc_pagerank_mode(uint32_t n, const uint64_t *in_off, const uint32_t *in_src, const uint32_t *out_deg, float damping,
+                      double tolerance, uint32_t max_iter, int mode, int err_f64_diff, float *scores, uint32_t *iters_run,
+                      double *final_err);
+
 /* ---- ShortestPathBFS (fixed_rule/algos/shortest_path_bfs.rs:35-113) ---- */
 /* parent[n]: ORC_NONE when no backtrace entry.  Goal semantics as the reference (start itself has no entry). */
 void orc_shortest_path_bfs(uint32_t n, const uint64_t *off, const uint32_t *tgt, uint32_t start,

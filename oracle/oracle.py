@@ -113,6 +113,9 @@ def lib():
         L.orc_assign_ids.argtypes = [_i64p, _i64p, C.c_uint64, _u32p, _u32p, _i64p]
         L.orc_build_csr.restype = None
         L.orc_build_csr.argtypes = [C.c_uint32, C.c_uint64, _u32p, _u32p, _f32p, C.c_int, _u64p, _u32p, _f32p]
+        L.orc_pagerank_mode.restype = C.c_int
+        L.orc_pagerank_mode.argtypes = [C.c_uint32, _u64p, _u32p, _u32p, C.c_float, C.c_double, C.c_uint32, C.c_int, C.c_int,
+                                        _f32p, _u32p, C.POINTER(C.c_double)]
         L.orc_pagerank.restype = C.c_int
         L.orc_pagerank.argtypes = [C.c_uint32, _u64p, _u32p, _u32p, C.c_float, C.c_double, C.c_uint32, _f32p, _u32p,
                                    _f64p, C.c_int]
@@ -328,6 +331,22 @@ def pagerank(n, in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=
     err = C.c_double(0)
     lib().orc_pagerank(n, _p(in_off, _u64p), _p(in_src, _u32p), _p(out_deg, _u32p), np.float32(damping),
                        float(tolerance), max_iter, _p(scores, _f32p), C.byref(it), C.byref(err), threads)
+    return scores, it.value, err.value
+
+
+PR_JACOBI, PR_INPLACE = 0, 1
+
+
+def pagerank_mode(n, in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10, mode=PR_JACOBI, err_f64_diff=False):
+    """both readings of graph 0.3.1's loop on ONE thread (cozo_oracle.c: orc_pagerank_mode)"""
+    in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+    in_src, out_deg = _u32(in_src), _u32(out_deg)
+    scores = np.empty(n, dtype=np.float32)
+    it = C.c_uint32(0)
+    err = C.c_double(0)
+    lib().orc_pagerank_mode(n, _p(in_off, _u64p), _p(in_src, _u32p), _p(out_deg, _u32p), np.float32(damping),
+                            float(tolerance), max_iter, int(mode), int(bool(err_f64_diff)), _p(scores, _f32p), C.byref(it),
+                            C.byref(err))
     return scores, it.value, err.value
 
 

@@ -17,4 +17,8 @@ cp "$HERE/src/main.rs" "$WORK/src/main.rs"
 python3 "$ROOT/tests/golden/make_ref_inputs.py" "$WORK/inputs.json"
 (cd "$WORK" && CARGO_TARGET_DIR="$ROOT/oracle/_ref/target" cargo build --release)
 "$ROOT/oracle/_ref/target/release/cozo_ref_fixtures" "$WORK/inputs.json" "$ROOT/tests/golden/ref_fixtures.json"
-echo "wrote $ROOT/tests/golden/ref_fixtures.json; now run: python -m pytest tests/test_ref_fixtures.py -q"
+# PageRank again on ONE rayon thread: graph 0.3.1's loop is deterministic there under either reading of its contribution refresh
+# (tests/test_ref_fixtures.py::check_pagerank tells the readings apart from these rows and the default-thread rows above)
+python3 "$ROOT/tests/golden/make_ref_inputs.py" --pagerank-only "$WORK/inputs_pagerank.json"
+RAYON_NUM_THREADS=1 "$ROOT/oracle/_ref/target/release/cozo_ref_fixtures" "$WORK/inputs_pagerank.json" "$ROOT/tests/golden/ref_fixtures_pagerank_1thread.json"
+echo "wrote $ROOT/tests/golden/ref_fixtures.json and ref_fixtures_pagerank_1thread.json; now run: python -m pytest tests/test_ref_fixtures.py -q -s"

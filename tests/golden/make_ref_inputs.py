@@ -47,6 +47,8 @@ def dataset():
     frm, to = util.random_relation(3000, 14000, 77)
     d["frm"], d["to"] = frm, to
     d["w"] = (np.random.default_rng(5).integers(0, 40, len(frm)) / 8).astype(np.float32)
+    # a graph of several 16 384-node chunks (graph crate's scheduler unit): where a thread-schedule dependence would show
+    d["big_frm"], d["big_to"] = util.random_relation(40000, 240000, 78)
     d["dijkstra_start"] = int(frm[7])
     d["bfs_start"] = int(frm[3])
     d["bfs_goals"] = [int(to[5]), int(to[17]), int(frm[-1])]
@@ -118,6 +120,7 @@ def steps():
                     params=dict(rows=[[int(f), int(t), float(w)] for f, t, w in zip(d["frm"], d["to"], d["w"])])))
     out.append(dict(name="pagerank defaults", script="?[n, r] <~ PageRank(*edges[fr, to])"))
     out.append(dict(name="pagerank theta=0.5 4 iterations", script="?[n, r] <~ PageRank(*edges[fr, to], theta: 0.5, epsilon: 0, iterations: 4)"))
+    out += pagerank_big_steps(d)
     out.append(dict(name="connected components", script="?[n, g] <~ ConnectedComponents(*edges[fr, to])"))
     out.append(dict(name="dijkstra", script=f"start[] <- [[{d['dijkstra_start']}]]\n?[s, t, c, p] <~ ShortestPathDijkstra(*edges[fr, to, w], start[])"))
     out.append(dict(name="shortest path bfs",
@@ -126,8 +129,31 @@ def steps():
     return out
 
 
+def pagerank_big_steps(d):
+    out = [dict(name="big graph create", mutable=True, script=":create edges_big {fr: Int, to: Int}"),
+           dict(name="big graph put", mutable=True, script="?[fr, to] <- $rows\n:put edges_big {fr, to}",
+                params=dict(rows=[[int(f), int(t)] for f, t in zip(d["big_frm"], d["big_to"])]))]
+    for i in (1, 2, 3):  # the same script three times: a schedule-dependent loop gives three different answers
+        out.append(dict(name=f"pagerank big run {i}", script="?[n, r] <~ PageRank(*edges_big[fr, to])"))
+    out.append(dict(name="pagerank big converged", script="?[n, r] <~ PageRank(*edges_big[fr, to], epsilon: 0.000000001, iterations: 200)"))
+    return out
+
+
+def steps_pagerank_only():
+    """the PageRank steps alone, for the second run of the recipe under RAYON_NUM_THREADS=1"""
+    d = dataset()
+    out = [dict(name="graph create", mutable=True, script=":create edges {fr: Int, to: Int => w: Float}"),
+           dict(name="graph put", mutable=True, script="?[fr, to, w] <- $rows\n:put edges {fr, to => w}",
+                params=dict(rows=[[int(f), int(t), float(w)] for f, t, w in zip(d["frm"], d["to"], d["w"])])),
+           dict(name="pagerank defaults", script="?[n, r] <~ PageRank(*edges[fr, to])"),
+           dict(name="pagerank theta=0.5 4 iterations", script="?[n, r] <~ PageRank(*edges[fr, to], theta: 0.5, epsilon: 0, iterations: 4)")]
+    return out + pagerank_big_steps(d)
+
+
 if __name__ == "__main__":
-    path = sys.argv[1] if len(sys.argv) > 1 else "inputs.json"
+    only = "--pagerank-only" in sys.argv
+    argv = [a for a in sys.argv[1:] if a != "--pagerank-only"]
+    path = argv[0] if argv else "inputs.json"
     with open(path, "w") as f:
-        json.dump({"steps": steps()}, f)
+        json.dump({"steps": steps_pagerank_only() if only else steps()}, f)
     print("wrote", path)

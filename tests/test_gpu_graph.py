@@ -192,6 +192,35 @@ def test_bfs_order_and_shared_visited(graphs, oracle):
     assert np.array_equal(order[0, :reached[0]], oorder) and np.array_equal(parent[0], opar)
 
 
+def test_bfs_shared_visited_stale_claims(oracle, gpu_lib):
+    """with share_visited the claim words of an earlier start must not pass for this level's discoveries.
+    s1 -> v gives v (claim 0, depth 1); s2 -> v as well, and s2 has > 24 fresh neighbours (the stretch is ordered by
+    bfs_order_big_kernel, which tells new nodes by claim / depth): v must not enter s2's frontier again, and s2's last new
+    neighbour must still be expanded (its child `tail` is reachable only through it)."""
+    from cozo_amd import graph as G
+    fan = 40
+    s1, s2, v = 0, 1, 2
+    kids = list(range(3, 3 + fan))          # s2's fresh neighbours; ids above v, so v sorts first in s2's list
+    tail = 3 + fan                          # reachable only through the LAST kid
+    n = tail + 1
+    edges = [(s1, v), (s2, v)] + [(s2, c) for c in kids] + [(kids[-1], tail)]
+    frm = np.array([e[0] for e in edges], dtype=np.uint32)
+    to = np.array([e[1] for e in edges], dtype=np.uint32)
+    ooff, otgt = oracle.build_csr(n, frm, to)
+    starts = np.array([s1, s2], dtype=np.uint32)
+    parent, depth, order, reached = G.bfs(ooff, otgt, starts, share_visited=True, want_depth=True, want_order=True)
+    visited = np.zeros(n, np.uint8)
+    opar = np.full(n, 0xFFFFFFFF, np.uint32)
+    for si, s in enumerate(starts):
+        before = opar.copy()
+        oorder, opar, visited = oracle.bfs_order(n, ooff, otgt, int(s), visited, opar)
+        assert reached[si] == len(oorder)
+        assert np.array_equal(order[si, :reached[si]], oorder)
+        new = opar != before
+        assert np.array_equal(parent[si][new], opar[new]) and (parent[si][~new] == 0xFFFFFFFF).all()
+    assert tail in order[1, :reached[1]] and v not in order[1, :reached[1]]
+
+
 def test_connected_components_bitexact(oracle, gpu_lib):
     from cozo_amd import graph as G
     for n, e, seed in [(40, 25, 1), (3000, 2500, 2), (50000, 60000, 3)]:
