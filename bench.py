@@ -261,10 +261,16 @@ class HnswRun:
         n_dist = int(self.nd.sum().item())
         algo_bytes = n_dist * 4 * self.dim  # 4*d bytes per distance evaluation (the query is on-chip)
         kern_s = dev_ms / 1e3 / steps
-        return dict(wall=wall, ms_per_step=wall / steps * 1e3, n_dist=n_dist,
-                    roofline=dict(bound="hbm", kernel="hnsw_knn_kernel", achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
-                                  unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS, traffic=None,
-                                  algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=kern_s * 1e3))
+        roof = dict(bound="hbm", kernel="hnsw_knn_kernel", achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS, traffic=None,
+                    algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=kern_s * 1e3)
+        try:  # what THIS box's HBM delivers over THIS table (cz_hbm_probe: two fetch-only kernels): the measured ceilings next to the nominal peak
+            stream_gbs, rows_gbs = self.ix.hbm_probe()
+            roof["measured_ceiling"] = dict(stream_read_gbs=stream_gbs, random_row_fetch_gbs=rows_gbs,
+                                            frac_of_random_row_fetch=roof["achieved"] / rows_gbs if rows_gbs else None)
+        except Exception as e:  # noqa: BLE001
+            roof["measured_ceiling"] = dict(error=f"{type(e).__name__}: {e}")
+        return dict(wall=wall, ms_per_step=wall / steps * 1e3, n_dist=n_dist, roofline=roof)
 
     def close(self):
         self.ix.close()

@@ -76,6 +76,8 @@ SYMBOLS = {
     "cz_device_count": (C.c_int, []),
     "cz_last_error": (C.c_char_p, []),
     "cz_version": (C.c_char_p, []),
+    "cz_hnsw_index_probe": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "cz_hbm_probe": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cz_hnsw_index_create": (C.c_int, [C.POINTER(HnswDesc), C.c_void_p, C.POINTER(C.c_void_p)]),
     "cz_hnsw_index_destroy": (None, [C.c_void_p]),
     "cz_hnsw_index_bytes": (C.c_uint64, [C.c_void_p]),

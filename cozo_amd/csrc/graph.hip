@@ -52,6 +52,17 @@ struct CallTiming {
     }
 };
 thread_local CallTiming t_timing;
+
+// CZ_SSSP_TRACE: where a call's wall time goes, mark by mark (host clock, the device drained at each mark; scratch/ experiments)
+inline void trace_mark(const char *what) {
+    static const bool on = getenv("CZ_SSSP_TRACE") != nullptr;
+    if (!on) return;
+    static thread_local std::chrono::steady_clock::time_point prev = std::chrono::steady_clock::now();
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "sssp mark %-28s +%.1f us\n", what, std::chrono::duration<double, std::micro>(now - prev).count());
+    prev = now;
+}
 enum { T_UPLOAD = 0, T_DEVICE = 1, T_DOWNLOAD = 2 };
 
 constexpr int kT = 256;
@@ -1508,10 +1519,13 @@ struct SsspBatch {
     // even / odd rounds (a round appends under its own and zeroes the other for the round after it: no memset per round)
     int run(const uint32_t *starts, uint32_t ns, const volatile uint8_t *poison) {
         const uint64_t nsN = (uint64_t)ns * N;
+        trace_mark("run: entry");
         hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, d_dp.p, nsN, kInfPacked);
+        trace_mark("run: fill dp");
         CZ_HIP(hipMemsetAsync(d_qtag.p, 0, nsN * 4, s));
         CZ_HIP(hipMemsetAsync(d_ftag.p, 0, nsN * 4, s));
         CZ_HIP(hipMemsetAsync(d_misc.p, 0, 32, s));
+        trace_mark("run: memsets");
         CZ_HIP(hipMemcpyAsync(d_starts.p, starts, (size_t)ns * 4, hipMemcpyHostToDevice, s));
         unsigned long long *near_cur = d_q[0].p, *near_next = d_q[1].p, *far_cur = d_q[2].p, *far_next = d_q[3].p;
         hipLaunchKernelGGL(sssp_seed_kernel, dim3((ns + kT - 1) / kT), dim3(kT), 0, s, d_starts.p, ns, N, d_dp.p, near_cur, d_misc.p);
@@ -1523,7 +1537,13 @@ struct SsspBatch {
         static const bool trace = getenv("CZ_SSSP_TRACE") != nullptr;  // per-round pile sizes on stderr (scratch/ experiments)
         for (;;) {
             while (n_near > 0) {
-                if (trace) fprintf(stderr, "sssp phase %u round %u thr %g near %u far %u\n", phase, round, (double)thr, n_near, n_far);
+                if (trace) {
+                    static thread_local std::chrono::steady_clock::time_point t_prev = std::chrono::steady_clock::now();
+                    const auto t_now = std::chrono::steady_clock::now();
+                    fprintf(stderr, "sssp phase %u round %u thr %g near %u far %u  (+%.1f us since the previous round's line)\n", phase, round,
+                            (double)thr, n_near, n_far, std::chrono::duration<double, std::micro>(t_now - t_prev).count());
+                    t_prev = t_now;
+                }
                 if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
                 uint32_t thr_bits;
                 memcpy(&thr_bits, &thr, 4);
@@ -1563,6 +1583,7 @@ struct SsspBatch {
             round++;
             if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
         }
+        trace_mark("run: rounds done");
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sssp launch: %s", hipGetErrorString(e));
         return CZ_OK;
@@ -1604,6 +1625,7 @@ int sssp_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, float
     const uint32_t N = G.N;
     int rc = CZ_OK;
     SsspBatch sb;
+    trace_mark("sssp_run: entry");
     if ((rc = sb.attach(G, n_starts, 80ull << 20))) return rc;  // about 4 GB in all
     const uint64_t SN = (uint64_t)sb.S * N;
     cz::PoolBuf<uint32_t> d_parent;
@@ -1611,6 +1633,7 @@ int sssp_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, float
     CZ_HIP(d_parent.alloc(SN));
     CZ_HIP(d_dist.alloc(SN));
     hipStream_t s = sb.s;
+    trace_mark("sssp_run: attach + allocs");
     t_timing.lap(T_UPLOAD);
     for (uint32_t s0 = 0; s0 < n_starts; s0 += sb.S) {
         const uint32_t ns = std::min<uint32_t>(sb.S, n_starts - s0);
@@ -1619,9 +1642,11 @@ int sssp_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, float
         hipLaunchKernelGGL(sssp_unpack_flagged_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, sb.d_dp.p, nsN, d_dist.p, d_parent.p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sssp launch: %s", hipGetErrorString(e));
+        trace_mark("sssp_run: unpack");
         t_timing.lap(T_DEVICE);
         CZ_HIP(hipMemcpy(dist + (size_t)s0 * N, d_dist.p, nsN * 4, hipMemcpyDeviceToHost));
         CZ_HIP(hipMemcpy(parent + (size_t)s0 * N, d_parent.p, nsN * 4, hipMemcpyDeviceToHost));
+        trace_mark("sssp_run: download");
         t_timing.lap(T_DOWNLOAD);
     }
     return CZ_OK;

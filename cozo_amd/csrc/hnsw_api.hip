@@ -726,6 +726,12 @@ extern "C" uint64_t cz_hnsw_index_bytes(const cz_hnsw_index *h) {
     return (uint64_t)ix->n * ix->ld * 4 + (uint64_t)ix->n * ix->w0 * 4 + (uint64_t)ix->n * 4 + ix->up_rows * ix->wu * 4;
 }
 
+extern "C" int cz_hnsw_index_probe(const cz_hnsw_index *h, uint64_t n_fetch, uint32_t reps, double *stream_gbs, double *row_fetch_gbs) {
+    auto *ix = reinterpret_cast<const cz::HnswIndex *>(h);
+    if (!ix || !ix->vec || ix->n == 0) return cz::set_error(CZ_E_INVALID, "null or empty index");
+    return cz_hbm_probe(ix->vec, ix->n, ix->ld * 4u, n_fetch, reps, stream_gbs, row_fetch_gbs);
+}
+
 // ------------------------------------------------------------------------------------------------
 // search
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,108 @@
+// probe.hip -- what THIS box's HBM delivers, measured with the access patterns of the path ("report both nominal
+// and measured ceilings").  Two hand-written gfx950 kernels, no arithmetic worth the name:
+//   stream   every lane reads 16 bytes of a contiguous buffer per instruction, grid-stride, non-temporal (what PageRank's
+//            phase A / a brute-force scan does);
+//   rows     a wave fetches whole `row_bytes`-byte rows at pseudo-random row numbers of a table, 4 rows in flight, non-temporal
+//            (what hnsw_knn_kernel / distance_pairs_kernel do with 3 KiB vectors) -- over the CALLER's table, i.e. with its
+//            size, its allocation and its translation footprint.
+// The roofline fractions in bench.py stay priced against the nominal 8 TB/s; these two numbers say how much of a box-to-box
+// difference is the box (the same binary measured 0.64-0.76 of the nominal peak on different GPUs).
+#include "common.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) probe_stream_kernel(const f4 *__restrict__ p, uint64_t n16, float *__restrict__ sink) {
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {  // four independent 16-byte loads per lane in flight
+        const f4 a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride);
+        const f4 c = __builtin_nontemporal_load(p + i + 2 * stride), d = __builtin_nontemporal_load(p + i + 3 * stride);
+        acc += (a + b) + (c + d);
+    }
+    for (; i < n16; i += stride) acc += __builtin_nontemporal_load(p + i);
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;  // keeps the loads alive, never true in practice
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+template <int U>
+__global__ void __launch_bounds__(256) probe_rows_kernel(const char *__restrict__ base, uint64_t rows, uint32_t row_bytes, uint64_t n_fetch,
+                                                         uint64_t seed, float *__restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * 256) >> 6;
+    const uint32_t pieces = (row_bytes + 1023) / 1024;  // a wave instruction moves 1 KiB
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (uint64_t r0 = wave * U; r0 < n_fetch; r0 += n_waves * U) {
+        const f4 *p[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) p[u] = (const f4 *)(base + (mix64(seed + r0 + u) % rows) * (uint64_t)row_bytes);
+        for (uint32_t j = 0; j < pieces; j++) {
+            const uint32_t c = j * 64 + lane;
+            if (c * 16 < row_bytes) {
+                f4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load(p[u] + c);
+#pragma unroll
+                for (int u = 0; u < U; u++) acc += v[u];
+            }
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;
+}
+
+}  // namespace
+
+extern "C" int cz_hbm_probe(const void *table, uint64_t rows, uint32_t row_bytes, uint64_t n_fetch, uint32_t reps, double *stream_gbs,
+                            double *row_fetch_gbs) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if (stream_gbs) *stream_gbs = 0.0;
+    if (row_fetch_gbs) *row_fetch_gbs = 0.0;
+    if (row_bytes == 0 || row_bytes % 16 != 0) return cz::set_error(CZ_E_INVALID, "row_bytes must be a positive multiple of 16");
+    if (reps == 0) reps = 5;
+    cz::DevBuf<char> own;
+    cz::DevBuf<float> sink;
+    CZ_HIP(sink.alloc(4));
+    const char *base = (const char *)table;
+    if (!base) {  // no table of the caller's: 4 GiB of our own (contents irrelevant, but written once so that pages exist)
+        rows = (4ull << 30) / row_bytes;
+        CZ_HIP(own.alloc(rows * row_bytes));
+        CZ_HIP(hipMemset(own.p, 1, rows * row_bytes));
+        base = own.p;
+    }
+    if (rows == 0) return cz::set_error(CZ_E_INVALID, "empty table");
+    if (n_fetch == 0) n_fetch = 4u << 20;
+    hipEvent_t e0, e1;
+    CZ_HIP(hipEventCreate(&e0));
+    CZ_HIP(hipEventCreate(&e1));
+    float ms = 0.f;
+    // (a) stream: at most 8 GiB of the table, contiguous
+    const uint64_t sbytes = std::min<uint64_t>(rows * (uint64_t)row_bytes, 8ull << 30) & ~15ull;
+    for (uint32_t i = 0; i < 2; i++) hipLaunchKernelGGL(probe_stream_kernel, dim3(256 * 16), dim3(256), 0, nullptr, (const f4 *)base, sbytes / 16, sink.p);
+    CZ_HIP(hipEventRecord(e0, nullptr));
+    for (uint32_t i = 0; i < reps; i++) hipLaunchKernelGGL(probe_stream_kernel, dim3(256 * 16), dim3(256), 0, nullptr, (const f4 *)base, sbytes / 16, sink.p);
+    CZ_HIP(hipEventRecord(e1, nullptr));
+    CZ_HIP(hipEventSynchronize(e1));
+    CZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (stream_gbs && ms > 0.f) *stream_gbs = (double)sbytes * reps / (ms * 1e-3) / 1e9;
+    // (b) random whole rows
+    for (uint32_t i = 0; i < 2; i++) hipLaunchKernelGGL(probe_rows_kernel<4>, dim3(2048), dim3(256), 0, nullptr, base, rows, row_bytes, n_fetch, 77ull + i, sink.p);
+    CZ_HIP(hipEventRecord(e0, nullptr));
+    for (uint32_t i = 0; i < reps; i++) hipLaunchKernelGGL(probe_rows_kernel<4>, dim3(2048), dim3(256), 0, nullptr, base, rows, row_bytes, n_fetch, 1000ull + i * n_fetch, sink.p);
+    CZ_HIP(hipEventRecord(e1, nullptr));
+    CZ_HIP(hipEventSynchronize(e1));
+    CZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (row_fetch_gbs && ms > 0.f) *row_fetch_gbs = (double)n_fetch * row_bytes * reps / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "probe launch: %s", hipGetErrorString(e));
+    return CZ_OK;
+}

@@ -262,6 +262,12 @@ class GpuHnswIndex:
     def device_bytes(self) -> int:
         return int(_lib.lib().cz_hnsw_index_bytes(self._h))
 
+    def hbm_probe(self, n_fetch: int = 0, reps: int = 0):
+        """cz_hnsw_index_probe: (contiguous read GB/s, random whole-row fetch GB/s) over this index' vector table"""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        check(_lib.lib().cz_hnsw_index_probe(self._h, int(n_fetch), int(reps), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     # ---- hnsw_knn over a batch of parent tuples (host buffers) ----
     def hnsw_knn_batch(self, queries: np.ndarray, config: HnswSearch, poison: Optional[np.ndarray] = None,
                        with_n_dist: bool = False):

@@ -65,6 +65,13 @@ void cz_shutdown(void);
 int cz_device_count(void);
 const char *cz_last_error(void);      /* thread-local */
 const char *cz_version(void);
+/* What this box's HBM delivers under the path's two access patterns (measurement aid; SURVEY 8d asks for measured ceilings
+ * beside the nominal 8 TB/s): a contiguous non-temporal read (`stream_gbs`) and whole `row_bytes`-byte rows at pseudo-random
+ * row numbers of `table` [rows][row_bytes] (a DEVICE pointer -- e.g. an index' vector table, so that the size, the allocation
+ * and the translation footprint are the real ones; NULL = 4 GiB of the library's own), `n_fetch` rows per launch (0 = 4M),
+ * `reps` timed launches each (0 = 5).  GB/s = 1e9 bytes per second of bytes requested. */
+int cz_hbm_probe(const void *table, uint64_t rows, uint32_t row_bytes, uint64_t n_fetch, uint32_t reps, double *stream_gbs,
+                 double *row_fetch_gbs);
 
 /* =====================================================================================
  * Vectors / HNSW           replaces: runtime/hnsw.rs
@@ -95,6 +102,8 @@ int cz_hnsw_index_create(const cz_hnsw_desc *desc, const float *vectors, cz_hnsw
 void cz_hnsw_index_destroy(cz_hnsw_index *ix);
 /* device bytes held by the index (vectors + link tables) */
 uint64_t cz_hnsw_index_bytes(const cz_hnsw_index *ix);
+/* cz_hbm_probe over THIS index' vector table (its rows, its allocation): the ceiling the search kernels run under on this box */
+int cz_hnsw_index_probe(const cz_hnsw_index *ix, uint64_t n_fetch, uint32_t reps, double *stream_gbs, double *row_fetch_gbs);
 
 /* Index construction on the GPU: hnsw_put over all rows in key order (runtime/hnsw.rs:155-538, 679-727;
  * create_hnsw_index, runtime/relation.rs:1010-1201), as a batch-parallel insert.

@@ -5,6 +5,8 @@
 //! Registration (runtime/db.rs:760-776; a built-in name cannot be re-registered, :779-784):
 //!     db.register_fixed_rule("PageRankGpu".to_string(), PageRankGpu)?;
 //!     db.register_fixed_rule("ConnectedComponentsGpu".to_string(), ConnectedComponentsGpu)?;
+//!     ... ShortestPathBFSGpu, BfsGpu ("BFSGpu"), ShortestPathDijkstraGpu, ClusteringCoefficientsGpu, ClosenessCentralityGpu,
+//!     BetweennessCentralityGpu, LabelPropagationGpu: every rule INTEGRATION.md lists has its `impl FixedRule` in this file
 //! or, in a patched build, swap the entries of DEFAULT_FIXED_RULES (fixed_rule/mod.rs:799-802).
 
 use std::collections::BTreeMap;
@@ -14,11 +16,11 @@ use std::os::raw::c_int;
 use miette::{bail, miette, Result};
 use smartstring::{LazyCompact, SmartString};
 
-use crate::data::expr::Expr;
+use crate::data::expr::{eval_bytecode_pred, Expr};
 use crate::data::symb::Symbol;
 use crate::data::tuple::{Tuple, TupleT};
 use crate::data::value::DataValue;
-use crate::fixed_rule::{BadEdgeWeightError, FixedRule, FixedRuleInputRelation, FixedRulePayload, NotAnEdgeError};
+use crate::fixed_rule::{BadEdgeWeightError, FixedRule, FixedRuleInputRelation, FixedRulePayload, NodeNotFoundError, NotAnEdgeError};
 use crate::parse::SourceSpan;
 use crate::runtime::db::Poison;
 use crate::runtime::temp_store::RegularTempStore;
@@ -377,4 +379,371 @@ pub(crate) fn sssp_on_held_graph(edges: &FixedRuleInputRelation<'_, '_>, undirec
     unsafe { cz_graph_release(hi, lo, held) }; // back into the cache, whatever the rule's outcome
     check(rc, poison)?;
     Ok((dist, parent))
+}
+
+// ---- the traversal rules: ids by RANK ---------------------------------------------------------------------------------------
+// ShortestPathBFS and Bfs walk `edges.prefix_iter(&candidate)` (shortest_path_bfs.rs:67, bfs.rs:61): a node's neighbours come
+// in KEY order of the stored tuples, i.e. ascending `DataValue` of the `to` column -- not in the first-appearance order
+// `as_directed_graph` numbers nodes in.  The device keeps the frontier as the reference's FIFO and its adjacency lists ascending
+// by id (CsrLayout::Sorted), so the ids handed to it must ascend with the values: node id = rank of the value among all
+// endpoint values (plus the start / goal values that have no edge: they are nodes of the traversal all the same, :59-62).
+pub(crate) struct GpuOrderedGraph {
+    pub n: u32,
+    pub offsets: Vec<u32>,
+    pub targets: Vec<u32>,
+    pub indices: Vec<DataValue>,               // rank -> value, ascending
+    pub inv_indices: BTreeMap<DataValue, u32>, // value -> rank
+}
+impl<'a, 'b> FixedRuleInputRelation<'a, 'b> {
+    /// The mirror of `as_ordered_graph` (cozo_amd/host/src/fixed_rule.cpp, cozo_amd/fixed_rule.py).  A stored relation whose
+    /// start / goal values all occur as endpoints goes through libcozo_ingest with CZI_ORDERED_IDS (ids by the rank of the key
+    /// bytes, which IS the value order: data/memcmp.rs); otherwise the tuples are read once.
+    pub(crate) fn as_gpu_ordered_graph(&self, extra_nodes: &[DataValue]) -> Result<GpuOrderedGraph> {
+        if let Some((bytes, n_key_cols)) = self.stored_scan()? {
+            let rows = bytes.view(n_key_cols);
+            let mut g = std::ptr::null_mut();
+            match unsafe { czi_graph_ingest(&rows, CZI_ORDERED_IDS, &mut g) } {
+                CZI_OK => {}
+                CZI_E_NOT_AN_EDGE => bail!(NotAnEdgeError(self.span())),
+                _ => bail!("libcozo_ingest: {}", unsafe { CStr::from_ptr(czi_last_error()) }.to_string_lossy()),
+            }
+            let g = IngestGraph(g);
+            let n = unsafe { czi_graph_node_count(g.0) };
+            let e = unsafe { czi_graph_edge_count(g.0) } as usize;
+            let (mut nb, mut no) = (std::ptr::null(), std::ptr::null());
+            unsafe { czi_graph_node_keys(g.0, &mut nb, &mut no) };
+            let mut indices = Vec::with_capacity(n as usize);
+            for i in 0..n as usize {
+                let (lo, hi) = unsafe { (*no.add(i) as usize, *no.add(i + 1) as usize) };
+                indices.push(DataValue::decode_from_key(unsafe { std::slice::from_raw_parts(nb.add(lo), hi - lo) }).0);
+            }
+            let inv_indices: BTreeMap<DataValue, u32> = indices.iter().cloned().zip(0u32..).collect();
+            if extra_nodes.iter().all(|v| inv_indices.contains_key(v)) {
+                let (mut offsets, mut targets) = (vec![0u32; n as usize + 1], vec![0u32; e]);
+                unsafe { czi_graph_csr(g.0, 0, offsets.as_mut_ptr(), targets.as_mut_ptr(), std::ptr::null_mut()) };
+                return Ok(GpuOrderedGraph { n, offsets, targets, indices, inv_indices });
+            }
+            // a start / goal without an edge needs an id of its own: fall through to the tuple route
+        }
+        let mut rows: Vec<(DataValue, DataValue)> = vec![];
+        let mut vals: std::collections::BTreeSet<DataValue> = extra_nodes.iter().cloned().collect();
+        for tuple in self.iter()? {
+            let tuple = tuple?;
+            if tuple.len() < 2 {
+                bail!(NotAnEdgeError(self.span()));
+            }
+            vals.insert(tuple[0].clone());
+            vals.insert(tuple[1].clone());
+            rows.push((tuple[0].clone(), tuple[1].clone()));
+        }
+        let indices: Vec<DataValue> = vals.into_iter().collect(); // BTreeSet: ascending
+        let inv_indices: BTreeMap<DataValue, u32> = indices.iter().cloned().zip(0u32..).collect();
+        let n = indices.len() as u32;
+        // CsrLayout::Sorted out-adjacency, duplicates kept: count, prefix sum, fill, sort each list
+        let mut offsets = vec![0u32; n as usize + 1];
+        let edges: Vec<(u32, u32)> = rows.iter().map(|(f, t)| (inv_indices[f], inv_indices[t])).collect();
+        for (f, _) in edges.iter() {
+            offsets[*f as usize + 1] += 1;
+        }
+        for i in 0..n as usize {
+            offsets[i + 1] += offsets[i];
+        }
+        let mut cursor = offsets.clone();
+        let mut targets = vec![0u32; edges.len()];
+        for (f, t) in edges.iter() {
+            targets[cursor[*f as usize] as usize] = *t;
+            cursor[*f as usize] += 1;
+        }
+        for u in 0..n as usize {
+            targets[offsets[u] as usize..offsets[u + 1] as usize].sort_unstable();
+        }
+        Ok(GpuOrderedGraph { n, offsets, targets, indices, inv_indices })
+    }
+}
+
+/// the backtrace walk of shortest_path_bfs.rs:87-94 / bfs.rs:97-106 over the device's parent array
+fn walk_back(parent: &[u32], start: u32, goal: u32, indices: &[DataValue]) -> Result<DataValue> {
+    let mut route = vec![];
+    let mut current = goal;
+    while current != start {
+        route.push(indices[current as usize].clone());
+        current = parent[current as usize];
+        if current == CZ_NONE {
+            bail!("libcozo_gpu: broken backtrace");
+        }
+    }
+    route.push(indices[start as usize].clone());
+    route.reverse();
+    Ok(DataValue::List(route))
+}
+
+/// fixed_rule/algos/shortest_path_bfs.rs:35-113 on the device: one cz_bfs call for all starting nodes, the goal set handed to
+/// the library (it stops a start's traversal when every goal has been discovered, and does not expand the goal that was
+/// discovered last -- `pending.is_empty()` breaks before the push, :77-81; the library restates exactly that).
+pub(crate) struct ShortestPathBFSGpu;
+impl FixedRule for ShortestPathBFSGpu {
+    fn run(&self, payload: FixedRulePayload<'_, '_>, out: &mut RegularTempStore, poison: Poison) -> Result<()> {
+        let edges = payload.get_input(0)?.ensure_min_len(2)?;
+        let mut starting_nodes: Vec<DataValue> = vec![];
+        for tuple in payload.get_input(1)?.ensure_min_len(1)?.iter()? {
+            starting_nodes.push(tuple?.into_iter().next().unwrap());
+        }
+        let mut ending_nodes: std::collections::BTreeSet<DataValue> = Default::default(); // :48-53
+        for tuple in payload.get_input(2)?.ensure_min_len(1)?.iter()? {
+            ending_nodes.insert(tuple?.into_iter().next().unwrap());
+        }
+        if starting_nodes.is_empty() || ending_nodes.is_empty() {
+            return Ok(());
+        }
+        let mut extra = starting_nodes.clone();
+        extra.extend(ending_nodes.iter().cloned());
+        let g = edges.as_gpu_ordered_graph(&extra)?;
+        let starts: Vec<u32> = starting_nodes.iter().map(|s| g.inv_indices[s]).collect();
+        let goals: Vec<u32> = ending_nodes.iter().map(|e| g.inv_indices[e]).collect();
+        let n = g.n as usize;
+        let mut parent = vec![CZ_NONE; starts.len() * n];
+        check(unsafe {
+            cz_bfs(g.offsets.as_ptr(), g.targets.as_ptr(), g.n, g.targets.len() as u64, starts.as_ptr(), starts.len() as u32,
+                   goals.as_ptr(), goals.len() as u32, 0, parent.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut(),
+                   std::ptr::null_mut(), poison_ptr(&poison))
+        }, &poison)?;
+        for (si, starting_node) in starting_nodes.iter().enumerate() {
+            let par = &parent[si * n..(si + 1) * n];
+            for (ending_node, goal) in ending_nodes.iter().zip(goals.iter()) {
+                // `backtrace.contains_key(ending_node)` (:86): a goal equal to the start was never discovered -> Null
+                if par[*goal as usize] != CZ_NONE {
+                    out.put(vec![starting_node.clone(), ending_node.clone(), walk_back(par, starts[si], *goal, &g.indices)?]);
+                } else {
+                    out.put(vec![starting_node.clone(), ending_node.clone(), DataValue::Null]);
+                }
+            }
+            poison.check()?;
+        }
+        Ok(())
+    }
+    fn arity(&self, _: &BTreeMap<SmartString<LazyCompact>, Expr>, _: &[Symbol], _: SourceSpan) -> Result<usize> {
+        Ok(3)
+    }
+}
+
+/// fixed_rule/algos/bfs.rs:25-113 on the device.  The traversal -- `visited` and `backtrace` shared by all starting nodes
+/// (:43-45), a starting node already visited skipped (:52-54) -- is one cz_bfs call with share_visited = 1 that returns the
+/// discovery sequence per start (`order`); `condition` and `limit` are then evaluated on the host over that sequence, in
+/// order, which is where the reference evaluates them (:66-90): the rows are the ones the reference finds, only the traversal
+/// past the limit-th hit is wasted work.
+pub(crate) struct BfsGpu;
+impl FixedRule for BfsGpu {
+    fn run(&self, payload: FixedRulePayload<'_, '_>, out: &mut RegularTempStore, poison: Poison) -> Result<()> {
+        let edges = payload.get_input(0)?.ensure_min_len(2)?;
+        let nodes = payload.get_input(1)?;
+        let starting_nodes = payload.get_input(2).unwrap_or(nodes);
+        let limit = payload.pos_integer_option("limit", Some(1))?;
+        let mut condition = payload.expr_option("condition", None)?;
+        let binding_map = nodes.get_binding_map(0);
+        condition.fill_binding_indices(&binding_map)?;
+        let condition_bytecode = condition.compile()?;
+        let condition_span = condition.span();
+        let binding_indices = condition.binding_indices()?;
+        let skip_query_nodes = binding_indices.is_subset(&std::collections::BTreeSet::from([0]));
+
+        let mut start_vals: Vec<DataValue> = vec![];
+        for node_tuple in starting_nodes.iter()? {
+            start_vals.push(node_tuple?[0].clone());
+        }
+        if start_vals.is_empty() {
+            return Ok(());
+        }
+        let g = edges.as_gpu_ordered_graph(&start_vals)?;
+        let starts: Vec<u32> = start_vals.iter().map(|s| g.inv_indices[s]).collect();
+        let (n, ns) = (g.n as usize, starts.len());
+        let mut parent = vec![CZ_NONE; ns * n];
+        let mut order = vec![CZ_NONE; ns * n];
+        let mut reached = vec![0u32; ns];
+        check(unsafe {
+            cz_bfs(g.offsets.as_ptr(), g.targets.as_ptr(), g.n, g.targets.len() as u64, starts.as_ptr(), ns as u32, std::ptr::null(), 0,
+                   1, parent.as_mut_ptr(), std::ptr::null_mut(), order.as_mut_ptr(), reached.as_mut_ptr(), poison_ptr(&poison))
+        }, &poison)?;
+        let mut found: Vec<(u32, u32)> = vec![];
+        let mut stack = vec![];
+        'outer: for si in 0..ns {
+            for j in 0..reached[si] as usize {
+                let to = order[si * n + j];
+                let to_node = &g.indices[to as usize];
+                let cand_tuple = if skip_query_nodes {
+                    vec![to_node.clone()]
+                } else {
+                    // sic: the reference names the DISCOVERER as the missing key (:74-77)
+                    let candidate = g.indices[parent[si * n + to as usize] as usize].clone();
+                    nodes.prefix_iter(to_node)?.next().ok_or_else(|| NodeNotFoundError { missing: candidate, span: nodes.span() })??
+                };
+                if eval_bytecode_pred(&condition_bytecode, &cand_tuple, &mut stack, condition_span)? {
+                    found.push((starts[si], to));
+                    if found.len() >= limit {
+                        break 'outer;
+                    }
+                }
+                poison.check()?;
+            }
+        }
+        // one backtrace for all starts (:44): every node has exactly one discoverer
+        let mut merged = vec![CZ_NONE; n];
+        for si in 0..ns {
+            for v in 0..n {
+                if parent[si * n + v] != CZ_NONE {
+                    merged[v] = parent[si * n + v];
+                }
+            }
+        }
+        for (starting, ending) in found {
+            out.put(vec![g.indices[starting as usize].clone(), g.indices[ending as usize].clone(), walk_back(&merged, starting, ending, &g.indices)?]);
+        }
+        Ok(())
+    }
+    fn arity(&self, _: &BTreeMap<SmartString<LazyCompact>, Expr>, _: &[Symbol], _: SourceSpan) -> Result<usize> {
+        Ok(3)
+    }
+}
+
+/// fixed_rule/algos/shortest_path_dijkstra.rs:33-163 on the device: every starting node is one row of ONE cz_sssp call on the
+/// graph the library keeps under the stored relation's identity (`sssp_on_held_graph`); the reference's rayon loop over the
+/// starts (:110-153) becomes the batch.  Costs are Dijkstra's f32 values bit for bit; the parent of a node is its smallest
+/// tight predecessor of smaller cost (the reference's own choice among equal-cost predecessors is its heap's pop order).
+/// `keep_ties` (dijkstra_keep_ties, :341-450): the back pointers are exactly the edges with dist[u] + w == dist[v] in f32, so
+/// every shortest path is enumerated on the host off the device's distances; as in the reference it only takes effect together
+/// with a termination relation (:73-86).
+pub(crate) struct ShortestPathDijkstraGpu;
+impl FixedRule for ShortestPathDijkstraGpu {
+    fn run(&self, payload: FixedRulePayload<'_, '_>, out: &mut RegularTempStore, poison: Poison) -> Result<()> {
+        let edges = payload.get_input(0)?;
+        let starting = payload.get_input(1)?;
+        let termination = payload.get_input(2);
+        let undirected = payload.bool_option("undirected", Some(false))?;
+        let keep_ties = payload.bool_option("keep_ties", Some(false))?;
+        let g = edges.as_gpu_weighted_graph(undirected, false)?;
+        let inv_indices: BTreeMap<&DataValue, u32> = g.indices.iter().zip(0u32..).collect();
+        let mut starting_nodes = std::collections::BTreeSet::new(); // :49-56
+        for tuple in starting.iter()? {
+            let tuple = tuple?;
+            if let Some(idx) = inv_indices.get(&tuple[0]) {
+                starting_nodes.insert(*idx);
+            }
+        }
+        let term_ids = match termination {
+            Err(_) => None,
+            Ok(t) => {
+                let mut tn = std::collections::BTreeSet::new();
+                for tuple in t.iter()? {
+                    let tuple = tuple?;
+                    if let Some(idx) = inv_indices.get(&tuple[0]) {
+                        tn.insert(*idx);
+                    }
+                }
+                Some(tn)
+            }
+        };
+        if starting_nodes.is_empty() || term_ids.as_ref().map_or(false, |tn| tn.is_empty()) {
+            return Ok(());
+        }
+        let ties = keep_ties && term_ids.is_some();
+        if ties && g.weights.iter().any(|w| !(*w > 0.0)) {
+            bail!("keep_ties on the GPU path needs positive edge weights"); // a zero-weight cycle has infinitely many shortest paths
+        }
+        let starts: Vec<u32> = starting_nodes.into_iter().collect();
+        let n = g.n as usize;
+        let (dist, parent) = sssp_on_held_graph(&edges, undirected, &g, &starts, &poison)?;
+        for (si, start) in starts.iter().enumerate() {
+            let d = &dist[si * n..(si + 1) * n];
+            let par = &parent[si * n..(si + 1) * n];
+            let mut emit = |target: u32, path: DataValue| {
+                out.put(vec![g.indices[*start as usize].clone(), g.indices[target as usize].clone(),
+                             DataValue::from(d[target as usize] as f64), path]);
+            };
+            if ties {
+                // back_pointers[v] = every edge (u, v) with dist[u] + w == dist[v] (f32), one entry per edge occurrence
+                let mut preds: Vec<Vec<u32>> = vec![vec![]; n];
+                for u in 0..n {
+                    if !d[u].is_finite() {
+                        continue;
+                    }
+                    for e in g.offsets[u] as usize..g.offsets[u + 1] as usize {
+                        if d[u] + g.weights[e] == d[g.targets[e] as usize] {
+                            preds[g.targets[e] as usize].push(u as u32);
+                        }
+                    }
+                }
+                for target in term_ids.as_ref().unwrap().iter() {
+                    if !d[*target as usize].is_finite() {
+                        emit(*target, DataValue::List(vec![])); // unreachable: (inf, []) (:321-324)
+                        continue;
+                    }
+                    let mut pending: Vec<Vec<u32>> = vec![vec![*target]];
+                    while let Some(chain) = pending.pop() {
+                        for u in preds[*chain.last().unwrap() as usize].iter() {
+                            let mut next = chain.clone();
+                            next.push(*u);
+                            if u == start {
+                                next.reverse();
+                                emit(*target, DataValue::List(next.into_iter().map(|x| g.indices[x as usize].clone()).collect()));
+                            } else {
+                                pending.push(next);
+                            }
+                        }
+                    }
+                    poison.check()?;
+                }
+            } else {
+                let mut row = |target: u32| -> Result<()> {
+                    let path = if d[target as usize].is_finite() { walk_back(par, *start, target, &g.indices)? } else { DataValue::List(vec![]) };
+                    emit(target, path);
+                    Ok(())
+                };
+                match &term_ids {
+                    Some(tn) => {
+                        for target in tn.iter() {
+                            row(*target)?;
+                        }
+                    }
+                    None => {
+                        for target in 0..g.n {
+                            row(target)?;
+                        }
+                    }
+                }
+            }
+            poison.check()?;
+        }
+        Ok(())
+    }
+    fn arity(&self, _: &BTreeMap<SmartString<LazyCompact>, Expr>, _: &[Symbol], _: SourceSpan) -> Result<usize> {
+        Ok(4)
+    }
+}
+
+/// fixed_rule/algos/triangles.rs:28-99 on the device: per node the count of (i, j) list positions with A[i] > A[j] and A[j]
+/// among A[i]'s out-neighbours (duplicates kept, :84-101) and the list length; the coefficient is formed here in f64 exactly as
+/// :102 does (0.0 below two neighbours, :80-82).
+pub(crate) struct ClusteringCoefficientsGpu;
+impl FixedRule for ClusteringCoefficientsGpu {
+    fn run(&self, payload: FixedRulePayload<'_, '_>, out: &mut RegularTempStore, poison: Poison) -> Result<()> {
+        let edges = payload.get_input(0)?;
+        let g = edges.as_gpu_graph(true, false)?; // `as_directed_graph(true)` (:37)
+        if g.n == 0 {
+            return Ok(());
+        }
+        let mut n_triangles = vec![0u64; g.n as usize];
+        let mut degree = vec![0u32; g.n as usize];
+        check(unsafe {
+            cz_clustering_coefficients(g.offsets.as_ptr(), g.targets.as_ptr(), g.n, g.targets.len() as u64, n_triangles.as_mut_ptr(),
+                                       degree.as_mut_ptr(), poison_ptr(&poison))
+        }, &poison)?;
+        for idx in 0..g.n as usize {
+            let (t, d) = (n_triangles[idx], degree[idx]);
+            let cc = if d < 2 { 0. } else { 2. * t as f64 / ((d as f64) * ((d as f64) - 1.)) };
+            out.put(vec![g.indices[idx].clone(), DataValue::from(cc), DataValue::from(t as i64), DataValue::from(d as i64)]);
+        }
+        Ok(())
+    }
+    fn arity(&self, _: &BTreeMap<SmartString<LazyCompact>, Expr>, _: &[Symbol], _: SourceSpan) -> Result<usize> {
+        Ok(4)
+    }
 }

@@ -1333,10 +1333,36 @@ static int run_rule_from_file(const char *in_path, const char *out_path, bool ne
         const std::vector<uint8_t> name_b = blob();
         const std::string name(name_b.begin(), name_b.end());
         std::map<std::string, DataValue> options;
+        std::map<std::string, ExprOption> exprs;
         for (uint32_t n = u32(); n > 0; n--) {
             const std::vector<uint8_t> kb = blob(), vb = blob();
             const uint8_t *p = vb.data();
-            options[std::string(kb.begin(), kb.end())] = decode_datavalue(p, vb.data() + vb.size());
+            const std::string key(kb.begin(), kb.end());
+            DataValue val = decode_datavalue(p, vb.data() + vb.size());
+            if (key.rfind("expr:", 0) == 0) {
+                // an expression option on the wire (tests/test_mirrors_agree.py): [op, column, constant] = `tuple[column] OP constant`
+                // in DataValue's total order; binding_indices = {column}
+                const std::vector<DataValue> *l = val.get_slice();
+                int64_t col = 0;
+                if (!l || l->size() != 3 || !(*l)[0].get_str() || !(*l)[1].get_int(&col)) throw std::runtime_error("bad expr option");
+                const std::string op = *(*l)[0].get_str();
+                const DataValue c = (*l)[2];
+                ExprOption e;
+                e.only_first_binding = col == 0;
+                e.eval = [op, col, c](const Tuple &t) {
+                    const DataValue &v = t.at((size_t)col);
+                    if (op == "eq") return v == c;
+                    if (op == "ne") return !(v == c);
+                    if (op == "lt") return v < c;
+                    if (op == "ge") return !(v < c);
+                    if (op == "gt") return c < v;
+                    if (op == "le") return !(c < v);
+                    throw std::runtime_error("bad expr op");
+                };
+                exprs[key.substr(5)] = std::move(e);
+            } else {
+                options[key] = std::move(val);
+            }
         }
         std::vector<std::optional<FixedRuleInputRelation>> inputs;
         for (uint32_t n = u32(); n > 0; n--) {
@@ -1347,7 +1373,7 @@ static int run_rule_from_file(const char *in_path, const char *out_path, bool ne
         if (need_device && cz_init(0) != CZ_OK) throw std::runtime_error(cz_last_error());
         FixedRuleRegistry reg = FixedRuleRegistry::with_gpu_defaults();
         try {
-            RegularTempStore res = reg.run(name, FixedRulePayload(name, inputs, options), Poison());
+            RegularTempStore res = reg.run(name, FixedRulePayload(name, inputs, options, exprs), Poison());
             put_u32(1);
             put_u32((uint32_t)res.size());
             for (const Tuple &t : res) put_blob(encode_key_for_store(0, t, t.size()));

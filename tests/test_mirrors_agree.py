@@ -55,7 +55,22 @@ def run_cpp(tmp_path, gpu, name, inputs, options):
     return ("rows", rows)
 
 
+def _py_expr(spec):
+    """[op, column, constant] -> a predicate over the bound tuple in DataValue's total order (the wire form of an expression
+    option, decoded the same way by tests/cpp/test_host.cpp `run-rule`)"""
+    op, col, const = spec
+    kc = FR.sort_key(const)
+    cmp = {"eq": lambda k: k == kc, "ne": lambda k: k != kc, "lt": lambda k: k < kc, "ge": lambda k: k >= kc,
+           "gt": lambda k: k > kc, "le": lambda k: k <= kc}[op]
+
+    def pred(t):
+        return cmp(FR.sort_key(t[col]))
+    pred.only_node_id = col == 0
+    return pred
+
+
 def run_python(registry, name, inputs, options):
+    options = {(k[5:] if k.startswith("expr:") else k): (_py_expr(v) if k.startswith("expr:") else v) for k, v in options.items()}
     try:
         rows = registry.run(name + "Gpu", [FR.FixedRuleInputRelation(list(r)) for r in inputs], dict(options))
     except FR.FixedRuleError as e:
@@ -82,6 +97,16 @@ def _cases():
         ("ShortestPathDijkstra", [ew, starts], {"undirected": True}),
         ("ShortestPathDijkstra", [ew, starts, goals], {"keep_ties": True}),
         ("ClusteringCoefficients", [ints], {}),
+        ("ClusteringCoefficients", [mixed], {}),
+        # Bfs (bfs.rs:25-113): `condition` over the node id alone (no node lookup), over a column of `nodes`, with a limit, with a
+        # starting relation of its own, and the NodeNotFoundError of a target that `nodes` does not hold
+        ("BFS", [ints, [(int(a),) for a in range(0, 60, 7)]], {"expr:condition": ["gt", 0, 50], "limit": 4}),
+        ("BFS", [ints, [(i, i % 5) for i in range(60)], [(3,), (17,), (3,)]], {"expr:condition": ["eq", 1, 2], "limit": 6}),
+        ("BFS", [e, [(f"n{i}", i) for i in range(40)], [("n1",), ("n7",)]], {"expr:condition": ["ge", 1, 30]}),
+        ("BFS", [ints, [(i, i) for i in range(30)], [(3,)]], {"expr:condition": ["eq", 1, 1000], "limit": 2}),
+        ("ShortestPathBFS", [ints, [(5,), (9,)], [(5,), (11,), (58,), (1000,)]], {}),
+        ("ShortestPathDijkstra", [ew, starts, goals], {"undirected": True, "keep_ties": True}),
+        ("ShortestPathDijkstra", [ew, starts], {"keep_ties": True}),  # without a termination relation keep_ties has no effect (:73-86)
         ("DegreeCentrality", [e], {}),
         ("ClosenessCentrality", [ew], {"undirected": True}),
         ("BetweennessCentrality", [ew], {}),

@@ -229,3 +229,44 @@ def test_shim_only_names_things_the_reference_or_the_patch_defines():
     assert not missing, missing
     # and the one that started it stays gone
     assert "snapshot_version" not in own.replace("Round 2's shim called a `snapshot_version()`", "")
+
+
+# ---- every rule the integration guide lists has its `impl FixedRule`, with the reference's arity and option names -------------
+RULES = {  # GPU struct -> (reference file under fixed_rule/algos, reference struct, options the GPU rule may ADD)
+    "PageRankGpu": ("pagerank.rs", "PageRank", {"gpus"}),
+    "ConnectedComponentsGpu": ("strongly_connected_components.rs", "StronglyConnectedComponent", set()),
+    "ShortestPathBFSGpu": ("shortest_path_bfs.rs", "ShortestPathBFS", set()),
+    "BfsGpu": ("bfs.rs", "Bfs", set()),
+    "ShortestPathDijkstraGpu": ("shortest_path_dijkstra.rs", "ShortestPathDijkstra", set()),
+    "ClusteringCoefficientsGpu": ("triangles.rs", "ClusteringCoefficients", set()),
+    "ClosenessCentralityGpu": ("all_pairs_shortest_path.rs", "ClosenessCentrality", set()),
+    "BetweennessCentralityGpu": ("all_pairs_shortest_path.rs", "BetweennessCentrality", set()),
+    "LabelPropagationGpu": ("label_propagation.rs", "LabelPropagation", set()),
+}
+
+
+def _impl_block(text, struct):
+    m = re.search(r"impl FixedRule for " + struct + r"\s*\{", text)
+    assert m, f"no `impl FixedRule for {struct}`"
+    depth, i = 1, m.end()
+    while depth and i < len(text):
+        depth += {"{": 1, "}": -1}.get(text[i], 0)
+        i += 1
+    return text[m.end():i]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is only present in the build container")
+def test_every_listed_rule_has_an_impl_with_the_reference_arity_and_options():
+    shim = re.sub(r"//.*", "", open(os.path.join(SHIM_DIR, "fixed_rules_gpu.rs")).read())
+    guide = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for gpu, (ref_file, ref_struct, extra) in RULES.items():
+        assert gpu in guide or gpu.replace("Bfs", "BFS") in guide, gpu
+        mine = _impl_block(shim, gpu)
+        ref = _impl_block(re.sub(r"//.*", "", open(os.path.join(REF, "fixed_rule", "algos", ref_file)).read()), ref_struct)
+        opt = lambda t: set(re.findall(r"_option\(\s*\"([a-z_]+)\"", t))
+        assert opt(mine) - extra == opt(ref), (gpu, opt(mine), opt(ref))
+        arity = lambda t: re.search(r"fn arity\b.*?Ok\((\d+)\)", t, flags=re.S).group(1)
+        assert arity(mine) == arity(ref), (gpu, arity(mine), arity(ref))
+        # inputs are read by the same positions
+        inputs = lambda t: sorted(set(re.findall(r"get_input\((\d)\)", t)))
+        assert inputs(mine) == inputs(ref), (gpu, inputs(mine), inputs(ref))
