@@ -41,7 +41,8 @@ os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling there: 6290 GB/s
-EF_LADDER = [16, 24, 32, 48, 64, 80, 96, 112, 128, 144, 160, 176, 192, 224, 256, 320, 384, 512, 768, 1024]
+EF_LADDER = [16, 24, 32, 48, 64, 80, 96, 112, 128, 144, 160, 176, 192, 224, 256, 320, 384, 512, 768, 1024, 1536, 2048, 3072, 4096,
+             6144, 8192]  # (the list lives in LDS: 8 192 entries = 119 KiB, one workgroup per CU)
 
 
 PMC_SOURCES = {  # the kernel-bearing sources each PMC entry of profiles/pmc_traffic.json was measured on
@@ -736,6 +737,29 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
                      "(relation, snapshot) key reuses the device layout.  Not part of `value`")
         except Exception as e:  # noqa: BLE001
             res["end_to_end"] = dict(error=f"{type(e).__name__}: {e}")
+        if kind == "uniform" and not args.skip_secondary:
+            try:  # the OTHER reading of graph::page_rank (contribution refreshed inside the sweep): level-scheduled on the device
+                from cozo_amd import graph as G
+                from oracle import oracle as O
+                h_off32 = h_off.astype(np.uint32)
+                G.pagerank_inplace(h_off32, h_src, h_od, 0.85, 0.0, 1)  # warm
+                t0 = time.perf_counter()
+                G.pagerank_inplace(h_off32, h_src, h_od, 0.85, 0.0, 1)
+                t1 = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                gs, git, _, levels = G.pagerank_inplace(h_off32, h_src, h_od, 0.85, 0.0, 11)
+                t11 = time.perf_counter() - t0
+                sweep = (t11 - t1) / 10
+                os_, oit, _ = O.pagerank_mode(n_total, h_off.astype(np.uint64), h_src, h_od, 0.85, 0.0, 3, mode=O.PR_INPLACE)
+                g3, _, _, _ = G.pagerank_inplace(h_off32, h_src, h_od, 0.85, 0.0, 3)
+                res["inplace_reading"] = dict(
+                    ms_per_iteration=sweep * 1e3, edges_per_s=e_total / sweep, launches_per_sweep=int(levels), setup_and_one_sweep_ms=t1 * 1e3,
+                    parity_checked=bool(np.array_equal(g3, os_)),
+                    what="cz_pagerank_inplace: the reference's ONE-THREAD execution if graph 0.3.1 refreshes contributions inside the "
+                         "sweep (an ascending Gauss-Seidel sweep), level-scheduled; every score after 3 sweeps == orc_pagerank_mode(INPLACE); "
+                         "whole host-pointer calls, per-sweep time = (11 sweeps - 1 sweep) / 10")
+            except Exception as e:  # noqa: BLE001
+                res["inplace_reading"] = dict(error=f"{type(e).__name__}: {e}")
         try:
             from oracle import oracle as O
             ioff = h_off.astype(np.uint64)

@@ -19,6 +19,7 @@ CZ_PR_GATHER = 2
 CZ_PR_BLOCKED = 4
 CZ_PR_EXCHANGE_ALLREDUCE = 32
 CZ_PR_OVERLAP_EXCHANGE = 64
+CZ_PR_ERR_F64_DIFF = 128
 CZ_UNIQUE_ID_BYTES = 128
 CZ_L2, CZ_COSINE, CZ_IP = 0, 1, 2
 CZ_OK, CZ_E_INVALID, CZ_E_NO_DEVICE, CZ_E_HIP, CZ_E_CANCELLED, CZ_E_OOM, CZ_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
@@ -77,6 +78,7 @@ SYMBOLS = {
     "cz_last_error": (C.c_char_p, []),
     "cz_version": (C.c_char_p, []),
     "cz_hnsw_index_probe": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "cz_debug_seq_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
     "cz_hbm_probe": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cz_hnsw_index_create": (C.c_int, [C.POINTER(HnswDesc), C.c_void_p, C.POINTER(C.c_void_p)]),
     "cz_hnsw_index_destroy": (None, [C.c_void_p]),
@@ -133,6 +135,9 @@ SYMBOLS = {
                                       C.c_void_p, C.c_void_p]),
     "cz_pagerank_sharded_overlapped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32,
                                                  u32p, f64p, C.c_void_p, C.c_void_p]),
+    "cz_pagerank_inplace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_double, C.c_uint32,
+                                      C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_uint32),
+                                      C.c_void_p]),
     "cz_pagerank_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_double,
                                     C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, u32p, f64p, C.c_void_p]),
     "cz_bfs_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,

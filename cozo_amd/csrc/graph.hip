@@ -873,6 +873,9 @@ struct cz_graph {
     double wsum = 0.0;                 // of the valid weights (the near-far bucket width is their mean)
     unsigned long long bad = ~0ull;    // smallest index of a negative / NaN weight (BadEdgeWeightError when a rule needs them)
     float bad_value = 0.f;
+    // the state arrays of the last cz_sssp_on call on this graph (0.64 GB per source batch at 10M nodes), kept for the next one: a
+    // resident graph is what repeated calls run on, and they should not allocate at all (an entry is never shared between threads)
+    mutable std::shared_ptr<void> sssp_state;
 };
 
 namespace {
@@ -1495,7 +1498,7 @@ struct SsspBatch {
         d_off.p = G.off.p;
         d_tgt.p = G.tgt.p;
         d_w.p = G.w.p;
-        CZ_HIP(d_misc.alloc(8));
+        if (d_misc.n != 8) CZ_HIP(d_misc.alloc(8));
         if (!h_pin) CZ_HIP(hipHostMalloc((void **)&h_pin, 32));
         const double wsum = G.wsum;
         // bucket width of the near-far schedule: the mean edge weight (CZ_SSSP_DELTA overrides; <= 0 or "inf" = one pile,
@@ -1507,6 +1510,7 @@ struct SsspBatch {
         S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_starts, pairs_budget / std::max<uint32_t>(N, 1)));
         const uint64_t SN = (uint64_t)S * N;
         if (SN >= 0xFFFFFFFFull) return cz::set_error(CZ_E_UNSUPPORTED, "too many (source, node) pairs per launch");
+        if (d_dp.n == SN && d_starts.n == S) return CZ_OK;  // a kept state of the same shape (a resident graph's repeated call)
         CZ_HIP(d_qtag.alloc(SN));
         CZ_HIP(d_ftag.alloc(SN));
         CZ_HIP(d_dp.alloc(SN));
@@ -1590,7 +1594,8 @@ struct SsspBatch {
     }
 };
 
-int sssp_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison);
+int sssp_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison,
+             bool keep_state);
 
 }  // namespace
 
@@ -1605,7 +1610,7 @@ extern "C" int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets,
     if (E > 0 && !weights) return cz::set_error(CZ_E_INVALID, "null weights");
     cz_graph G;
     if ((rc = graph_fill(G, out_offsets, out_targets, weights, N, E))) return rc;
-    return sssp_run(G, starts, n_starts, dist, parent, poison);
+    return sssp_run(G, starts, n_starts, dist, parent, poison, false);
 }
 
 extern "C" int cz_sssp_on(const cz_graph *g, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent,
@@ -1616,22 +1621,34 @@ extern "C" int cz_sssp_on(const cz_graph *g, const uint32_t *starts, uint32_t n_
     if (!g) return cz::set_error(CZ_E_INVALID, "null graph");
     if (n_starts == 0 || g->N == 0) return CZ_OK;
     if (!starts || !dist || !parent) return cz::set_error(CZ_E_INVALID, "null starts/dist/parent");
-    return sssp_run(*g, starts, n_starts, dist, parent, poison);
+    return sssp_run(*g, starts, n_starts, dist, parent, poison, true);
 }
 
 namespace {
 
-int sssp_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison) {
+struct SsspCallState {
+    SsspBatch sb;
+    cz::PoolBuf<uint32_t> d_parent;
+    cz::PoolBuf<float> d_dist;
+};
+
+int sssp_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison,
+             bool keep_state) {
     const uint32_t N = G.N;
     int rc = CZ_OK;
-    SsspBatch sb;
+    // a resident graph (cz_sssp_on) keeps its state arrays between calls; a one-shot call owns them for its own duration
+    std::shared_ptr<SsspCallState> own;
+    if (keep_state && G.sssp_state) own = std::static_pointer_cast<SsspCallState>(G.sssp_state);
+    else own = std::make_shared<SsspCallState>();
+    if (keep_state) G.sssp_state = own;
+    SsspBatch &sb = own->sb;
+    cz::PoolBuf<uint32_t> &d_parent = own->d_parent;
+    cz::PoolBuf<float> &d_dist = own->d_dist;
     trace_mark("sssp_run: entry");
     if ((rc = sb.attach(G, n_starts, 80ull << 20))) return rc;  // about 4 GB in all
     const uint64_t SN = (uint64_t)sb.S * N;
-    cz::PoolBuf<uint32_t> d_parent;
-    cz::PoolBuf<float> d_dist;
-    CZ_HIP(d_parent.alloc(SN));
-    CZ_HIP(d_dist.alloc(SN));
+    if (d_parent.n != SN) CZ_HIP(d_parent.alloc(SN));
+    if (d_dist.n != SN) CZ_HIP(d_dist.alloc(SN));
     hipStream_t s = sb.s;
     trace_mark("sssp_run: attach + allocs");
     t_timing.lap(T_UPLOAD);

@@ -743,7 +743,6 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
     if (B == 0) return CZ_OK;
     if (k == 0) return set_error(CZ_E_INVALID, "k must be > 0");
     if (ef == 0) return set_error(CZ_E_INVALID, "ef must be > 0");
-    if (ef > 1024) return set_error(CZ_E_UNSUPPORTED, "ef = %u exceeds the LDS-resident list limit (1024)", ef);
     if (ix->n_levels <= 0) {  // empty index: no rows (hnsw.rs:903-909, 1009-1011)
         CZ_HIP(hipMemsetAsync(d_count, 0, (size_t)B * 4, stream));
         CZ_HIP(hipMemsetAsync(d_ids, 0xFF, (size_t)B * k * 4, stream));
@@ -755,7 +754,9 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
     visited_shape(ix->n, ef, (uint32_t)std::max(ix->w0, ix->wu), &hbits, &words);
     const uint32_t efcap = (std::max(ef, 1u) + 63) & ~63u;
     const uint32_t wpad = (uint32_t)((std::max(ix->w0, ix->wu) + 63) & ~63);
-    const size_t smem = czh::smem_bytes(efcap, wpad, ix->ld);
+    // the list lives in LDS: 12 bytes + 1 flag byte per entry.  ef = 4 096 takes 62 KiB (two workgroups per CU), the largest list
+    // one workgroup can hold next to a 768-d query is ~11 000 entries; the reference has no limit (hnsw.rs:930-938)
+    const size_t smem = czh::smem_bytes(efcap, wpad, ix->ld, false);
     if (smem > 160 * 1024)
         return set_error(CZ_E_UNSUPPORTED, "dim %u / ef %u need %zu bytes of LDS (> 160 KiB)", ix->dim, ef, smem);
     HnswIndex::Workspace ws;

@@ -55,7 +55,7 @@ constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr int kVlogCap = 2048;
 // list capacity (x 256) and batch size (x 64) the register form of the merge covers; larger searches (ef > 512 or
-// link rows wider than 128) take the LDS-walking form
+// link rows wider than 128) take the ranked form (merge_wide)
 constexpr int kMergeR = 2, kMergeEC = 2;
 
 struct IndexDev {
@@ -90,7 +90,9 @@ enum { C_CNT = 0, C_TODO = 1, C_LO = 2, C_VLOG = 3, C_NELIG = 4, C_NDIST_LO = 5,
        C_WAVE0 = 9 /* .. C_WAVE0 + kWaves - 1: per-wave counts of the merge's compaction */,
        C_VCNT = 13 /* members of the visited set */, C_VMODE = 14 /* 0 hash set, 1 bitmap */, C_WORDS = 16 };
 
-__host__ __device__ inline size_t smem_bytes(uint32_t efcap, uint32_t wpad, uint32_t ld) {
+// `build`: the select-neighbours scratch (tpos / sel) exists only in the index-construction kernels; a search carries `st` alone
+// (the pass flags of a filtered search): 15.3 KiB per 1 024 list entries instead of 19.3, i.e. ef = 4 096 in 62 KiB
+__host__ __device__ inline size_t smem_bytes(uint32_t efcap, uint32_t wpad, uint32_t ld, bool build = true) {
     size_t b = 0;
     b += (size_t)efcap * 8;
     b += (((size_t)efcap * 4 + 15) / 16) * 16;
@@ -99,10 +101,11 @@ __host__ __device__ inline size_t smem_bytes(uint32_t efcap, uint32_t wpad, uint
     b += (size_t)kVlogCap * 4;
     b += (size_t)ld * 4;
     b += C_WORDS * 4;
-    b += (size_t)efcap * 4 + 256 * 4 + (((size_t)efcap + 15) / 16) * 16;
+    if (build) b += (size_t)efcap * 4 + 256 * 4;
+    b += (((size_t)efcap + 15) / 16) * 16;
     return b;
 }
-__device__ inline Smem carve(char *base, uint32_t efcap, uint32_t wpad, uint32_t ld) {
+__device__ inline Smem carve(char *base, uint32_t efcap, uint32_t wpad, uint32_t ld, bool build = true) {
     Smem s;
     s.wkey = (uint64_t *)base;
     base += (size_t)efcap * 8;
@@ -121,9 +124,9 @@ __device__ inline Smem carve(char *base, uint32_t efcap, uint32_t wpad, uint32_t
     s.ctl = (int *)base;
     base += C_WORDS * 4;
     s.tpos = (uint32_t *)base;
-    base += (size_t)efcap * 4;
+    if (build) base += (size_t)efcap * 4;
     s.sel = (uint32_t *)base;
-    base += 256 * 4;
+    if (build) base += 256 * 4;
     s.st = (uint8_t *)base;
     return s;
 }
@@ -536,7 +539,7 @@ struct Searcher {
     // shifts).  No LDS traffic inside the loop (the previous form walked the whole batch through LDS per thread and
     // spent 6 us of a 31 us step there).
     __device__ void merge(int n, int ef) {
-        if (ef > kMergeR * kThreads || n > kMergeEC * 64) {  // uniform: beyond what the register form holds
+        if (ef > kMergeR * kThreads || n > kMergeEC * 64) {  // uniform: beyond what the register form holds: the ranked form
             merge_wide(n, ef);
             return;
         }
@@ -676,7 +679,16 @@ struct Searcher {
         __syncthreads();
     }
 
-    // the general form of the merge (any ef <= 1024, any n <= 256): every thread walks the batch through LDS.
+    // the general form of the merge (any ef the LDS list holds, any n <= 256).  Round 4: the batch is RANKED instead of walked.
+    // Until then every thread compared each of its W entries with every batch entry through LDS (R x n reads per thread and
+    // step: the "slow ef > 512 step", 0.58-0.61 of the HBM peak at ef = 768) and W sat in registers (R = 4: ef <= 1024 was the
+    // limit).  Now: (a) the eligible entries are compacted; (b) thread e ranks entry e inside the batch (<= n reads) and finds
+    // its lower bound in W by bisection (log2 cnt reads): final position = lower bound + rank; the lower bounds, stored by rank,
+    // are ascending; (c) a W entry at j moves up by the number of lower bounds <= j -- a bisection over <= 256 sorted words --
+    // and since every move goes UP, W is shifted in place chunk by chunk from the top, one entry per thread and chunk, two
+    // barriers per chunk, and only the chunks at or above the first insertion point are touched; (d) the new entries drop into
+    // the holes.  No per-thread copy of W, so ef is bounded by LDS alone (4 096 at 64 KiB, the API's limit is the 160 KiB).
+    // Same result as the one-at-a-time push / pop of the reference (hnsw.rs:572-583) like the register form above.
     __device__ void merge_wide(int n, int ef) {
         const int cnt = s.ctl[C_CNT];
         const bool full = cnt >= ef;
@@ -701,55 +713,69 @@ struct Searcher {
             if (full) elig = mykey < bkey && bkey != ~0ull;
             else elig = nan_gate ? tid < free_slots : true;
         }
-        int nelig = __syncthreads_count(elig);  // also orders the nkey/nid reads above before the rewrite below
-        if (nelig == 0) return;
-        if (tid < n && !elig) s.nid[tid] = CZ_NONE;
-        __syncthreads();
-        // phase A: final positions
-        constexpr int R = 4;  // ef <= R * kThreads
-        uint64_t wk[R];
-        uint32_t wi[R];
-        int wpos[R];
+        // (a) compaction, batch order kept: per-wave ballot + the wave totals through LDS
+        const unsigned long long em = __ballot(elig);
+        if (lane == 0) s.ctl[C_WAVE0 + wave] = __popcll(em);
+        __syncthreads();  // also orders the nkey/nid reads above before the in-place rewrite below
+        int before = 0, nelig = 0;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            int j = tid + r * kThreads;
-            wpos[r] = -1;
-            if (j < cnt) {
-                wk[r] = s.wkey[j];
-                wi[r] = s.wid[j];
-                int sft = 0;
-                for (int t = 0; t < n; t++) {
-                    uint32_t ni = s.nid[t];
-                    if (ni != CZ_NONE && key_lt(s.nkey[t], ni, wk[r], wi[r] & kIdMask)) sft++;
-                }
-                if (sft > 0) wpos[r] = j + sft;
-            }
+        for (int w = 0; w < kWaves; w++) {
+            const int c = s.ctl[C_WAVE0 + w];
+            if (w < wave) before += c;
+            nelig += c;
         }
-        int npos = -1;
+        if (nelig == 0) return;
         if (elig) {
+            const int e = before + __popcll(em & ((1ull << lane) - 1ull));
+            s.nkey[e] = mykey;
+            s.nid[e] = myid;
+        }
+        __syncthreads();
+        // (b) thread e < nelig: rank inside the batch, lower bound in W
+        int npos = -1;
+        if (tid < nelig) {
+            mykey = s.nkey[tid];
+            myid = s.nid[tid];
             int r1 = 0;
-            for (int t = 0; t < n; t++) {
-                uint32_t ni = s.nid[t];
-                if (ni != CZ_NONE && key_lt(s.nkey[t], ni, mykey, myid)) r1++;
-            }
-            int lo = 0, hi = cnt;  // lower bound of (mykey,myid) in W
+            for (int t = 0; t < nelig; t++)
+                if (key_lt(s.nkey[t], s.nid[t], mykey, myid)) r1++;
+            int lo = 0, hi = cnt;
             while (lo < hi) {
-                int mid = (lo + hi) >> 1;
+                const int mid = (lo + hi) >> 1;
                 if (key_lt(s.wkey[mid], s.wid[mid] & kIdMask, mykey, myid)) lo = mid + 1;
                 else hi = mid;
             }
-            npos = r1 + lo;
+            tcur[r1] = (uint32_t)lo;  // lower bounds by rank: ascending (the step's ids were copied to nid)
+            npos = lo + r1;
         }
         __syncthreads();
-        // phase B: scatter in place
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            if (wpos[r] >= 0 && wpos[r] < ef) {
-                s.wkey[wpos[r]] = wk[r];
-                s.wid[wpos[r]] = wi[r];
+        // (c) shift W in place, top chunk first
+        const int first = (int)tcur[0];
+        for (int base = ((cnt - 1) / kThreads) * kThreads; base >= 0 && base + kThreads > first; base -= kThreads) {  // uniform
+            const int j = base + tid;
+            uint64_t wk = 0;
+            uint32_t wi = 0;
+            int sft = 0;
+            if (j < cnt && j >= first) {
+                wk = s.wkey[j];
+                wi = s.wid[j];
+                int lo = 0, hi = nelig;  // number of lower bounds <= j
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((int)tcur[mid] <= j) lo = mid + 1;
+                    else hi = mid;
+                }
+                sft = lo;
             }
+            __syncthreads();
+            if (sft > 0 && j + sft < ef) {
+                s.wkey[j + sft] = wk;
+                s.wid[j + sft] = wi;
+            }
+            __syncthreads();
         }
-        if (elig && npos < ef) {
+        // (d) the new entries into the holes
+        if (npos >= 0 && npos < ef) {
             s.wkey[npos] = mykey;
             s.wid[npos] = myid;  // un-expanded
             atomicMin(&s.ctl[C_LO], npos);
@@ -1047,7 +1073,7 @@ hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t k, uint
                 double *__restrict__ out_dist, uint32_t *__restrict__ out_count, unsigned long long *__restrict__ out_n_dist) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t b = blockIdx.x;
-    Smem s = carve(smem_raw, efcap, wpad, ix.ld);
+    Smem s = carve(smem_raw, efcap, wpad, ix.ld, false);
     VisitedDev vis;
     vis.tab = hbits ? vtab + ((size_t)b << hbits) : nullptr;
     vis.hbits = hbits;

@@ -8,6 +8,7 @@
 // The roofline fractions in bench.py stay priced against the nominal 8 TB/s; these two numbers say how much of a box-to-box
 // difference is the box (the same binary measured 0.64-0.76 of the nominal peak on different GPUs).
 #include "common.h"
+#include "exact_sum.cuh"
 
 namespace {
 
@@ -104,5 +105,57 @@ extern "C" int cz_hbm_probe(const void *table, uint64_t rows, uint32_t row_bytes
     (void)hipEventDestroy(e1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "probe launch: %s", hipGetErrorString(e));
+    return CZ_OK;
+}
+
+// ---- test hook: exact_sum.cuh's wave procedure on arbitrary rows (tests/test_gpu_graph.py) -------------------------------------
+// PageRank only ever feeds it non-negative finite terms; the paths it maps "past the binade" (negative terms, inf / nan, denormal
+// running sums, a term above the sum's exponent, a negative or non-finite start) are reached through this entry alone.
+namespace {
+
+template <int LANES, int T>
+__global__ void __launch_bounds__(64) debug_seq_sum_kernel(const float *__restrict__ terms, const unsigned long long *__restrict__ off,
+                                                           const float *__restrict__ init, uint32_t n_rows, float *__restrict__ out) {
+    constexpr uint32_t per_wave = 64 / LANES;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t row = blockIdx.x * per_wave + lane / LANES;
+    const bool have = row < n_rows;
+    const unsigned long long b = have ? off[row] : 0ull, e = have ? off[row + 1] : 0ull;
+    const float s = cz_exact::group_seq_sum<LANES, T>(terms + b, (uint32_t)(e - b), have ? init[row] : 0.f);
+    if (have && (lane & (LANES - 1)) == 0) out[row] = s;
+}
+
+}  // namespace
+
+extern "C" int cz_debug_seq_sum(const float *terms, const uint64_t *row_off, const float *init, uint32_t n_rows, int lanes, int per_lane,
+                                float *out) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if (n_rows == 0) return CZ_OK;
+    if (!row_off || !init || !out) return cz::set_error(CZ_E_INVALID, "null buffer");
+    const uint64_t total = row_off[n_rows];
+    cz::DevBuf<float> d_t, d_i, d_o;
+    cz::DevBuf<unsigned long long> d_off;
+    CZ_HIP(d_t.alloc(total + 4));  // (a row's last 16-byte vector may reach past its end: exact_sum.cuh masks the lanes, the bytes must exist)
+    CZ_HIP(d_i.alloc(n_rows));
+    CZ_HIP(d_o.alloc(n_rows));
+    CZ_HIP(d_off.alloc((size_t)n_rows + 1));
+    CZ_HIP(hipMemset(d_t.p, 0, (total + 4) * 4));
+    if (total) CZ_HIP(hipMemcpy(d_t.p, terms, total * 4, hipMemcpyHostToDevice));
+    CZ_HIP(hipMemcpy(d_i.p, init, (size_t)n_rows * 4, hipMemcpyHostToDevice));
+    CZ_HIP(hipMemcpy(d_off.p, row_off, ((size_t)n_rows + 1) * 8, hipMemcpyHostToDevice));
+#define CZ_DBG(L, T_)                                                                                                              \
+    hipLaunchKernelGGL((debug_seq_sum_kernel<L, T_>), dim3((n_rows + 64 / L - 1) / (64 / L)), dim3(64), 0, nullptr, d_t.p, d_off.p, d_i.p, \
+                       n_rows, d_o.p)
+    if (lanes == 64 && per_lane == 16) CZ_DBG(64, 16);
+    else if (lanes == 64 && per_lane == 8) CZ_DBG(64, 8);
+    else if (lanes == 64 && per_lane == 4) CZ_DBG(64, 4);
+    else if (lanes == 16 && per_lane == 16) CZ_DBG(16, 16);
+    else if (lanes == 16 && per_lane == 4) CZ_DBG(16, 4);
+    else return cz::set_error(CZ_E_INVALID, "lanes must be 16 or 64, per_lane 4 / 8 / 16");
+#undef CZ_DBG
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "debug_seq_sum launch: %s", hipGetErrorString(e));
+    CZ_HIP(hipMemcpy(out, d_o.p, (size_t)n_rows * 4, hipMemcpyDeviceToHost));
     return CZ_OK;
 }

@@ -48,6 +48,21 @@ def pagerank(in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10,
     return scores, it.value, err.value
 
 
+def pagerank_inplace(in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10, err_f64_diff=False, poison=None):
+    """cz_pagerank_inplace: graph::page_rank under the reading that refreshes a node's contribution INSIDE the sweep (the reference's
+    one-thread execution, an ascending Gauss-Seidel sweep) -> (scores f32[N], iterations, error, launches per sweep)"""
+    in_off, in_src = _csr32(in_off, in_src)
+    out_deg = _u32(out_deg)
+    N = out_deg.size
+    scores = np.empty(N, dtype=np.float32)
+    it, lv = C.c_uint32(0), C.c_uint32(0)
+    err = C.c_double(0.0)
+    check(_lib.lib().cz_pagerank_inplace(ptr(in_off), ptr(in_src), ptr(out_deg), N, in_src.size, np.float32(damping), float(tolerance),
+                                         int(max_iter), _lib.CZ_PR_ERR_F64_DIFF if err_f64_diff else 0, ptr(scores), C.byref(it),
+                                         C.byref(err), C.byref(lv), ptr(poison)))
+    return scores, it.value, err.value, lv.value
+
+
 class PageRankPlan:
     """Resident / row-sharded PageRank (cz_pagerank_plan_*): rows [row_begin,row_end) of the in-CSR."""
 
@@ -278,3 +293,16 @@ def label_propagation(out_off, out_tgt, weights, max_iter=10, poison=None):
     check(_lib.lib().cz_label_propagation(ptr(out_off), ptr(out_tgt), ptr(w), N, out_tgt.size, int(max_iter), ptr(labels),
                                           C.byref(it), C.byref(nc), ptr(poison)))
     return labels, it.value, nc.value
+
+
+def debug_seq_sum(rows, init, lanes=64, per_lane=16):
+    """TEST HOOK (cz_debug_seq_sum): init[r] + rows[r][0] + rows[r][1] + ... one after the other in f32, by csrc/exact_sum.cuh's
+    wave procedure; rows = a list of float32 arrays."""
+    rows = [np.ascontiguousarray(r, dtype=np.float32) for r in rows]
+    off = np.zeros(len(rows) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([r.size for r in rows])
+    terms = np.concatenate(rows) if rows and off[-1] else np.zeros(1, dtype=np.float32)
+    init = np.ascontiguousarray(init, dtype=np.float32)
+    out = np.empty(len(rows), dtype=np.float32)
+    check(_lib.lib().cz_debug_seq_sum(ptr(terms), ptr(off), ptr(init), len(rows), int(lanes), int(per_lane), ptr(out)))
+    return out

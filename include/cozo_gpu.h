@@ -72,6 +72,12 @@ const char *cz_version(void);
  * `reps` timed launches each (0 = 5).  GB/s = 1e9 bytes per second of bytes requested. */
 int cz_hbm_probe(const void *table, uint64_t rows, uint32_t row_bytes, uint64_t n_fetch, uint32_t reps, double *stream_gbs,
                  double *row_fetch_gbs);
+/* TEST HOOK: the wave-parallel form of a sequential f32 sum (csrc/exact_sum.cuh, what PageRank's long rows use) on arbitrary rows:
+ * out[r] = init[r] + terms[row_off[r]] + terms[row_off[r] + 1] + ... added one after the other in f32, by a group of `lanes`
+ * (16 | 64) lanes taking `per_lane` (4 | 8 | 16) terms each per pass.  Host pointers.  Exists so that the paths PageRank's
+ * non-negative finite terms never reach (negative terms, inf / nan, denormal sums ...) are tested on the device. */
+int cz_debug_seq_sum(const float *terms, const uint64_t *row_off, const float *init, uint32_t n_rows, int lanes, int per_lane,
+                     float *out);
 
 /* =====================================================================================
  * Vectors / HNSW           replaces: runtime/hnsw.rs
@@ -233,6 +239,18 @@ int cz_knn_bruteforce(cz_hnsw_index *ix, const float *queries, uint32_t B, uint3
 int cz_pagerank(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N,
                 uint64_t E, float damping, double tolerance, uint32_t max_iter, float *scores, uint32_t *iters_run,
                 double *final_err, const volatile uint8_t *poison);
+
+/* The same rule under the OTHER reading of graph 0.3.1's loop (crate source absent from the reference tree): the
+ * contribution of node u is refreshed INSIDE the sweep, right after its score, so nodes later in the sweep pull the new value --
+ * on one rayon thread an ascending Gauss-Seidel sweep, which is the execution reproduced here bit for bit (oracle:
+ * orc_pagerank_mode(ORC_PR_INPLACE)); with several threads the reference would depend on their schedule.  Level-scheduled on the
+ * device (csrc/pagerank_inplace.hip).  Same arguments as cz_pagerank; flags: CZ_PR_ERR_F64_DIFF = the error term is
+ * |f64(new) - f64(old)| instead of the f32 difference widened (scores do not depend on it); n_levels (optional): launches per sweep.
+ * Which reading is the reference's is decided by tests/test_ref_fixtures.py on a box with cargo; cz_pagerank stays the default. */
+#define CZ_PR_ERR_F64_DIFF 128u
+int cz_pagerank_inplace(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N, uint64_t E,
+                        float damping, double tolerance, uint32_t max_iter, uint32_t flags, float *scores, uint32_t *iters_run,
+                        double *final_err, uint32_t *n_levels, const volatile uint8_t *poison);
 
 /* The same with the static device layout (CSR upload + blocked plan) kept between calls: `key_hi:key_lo` is the
  * caller's identity of (relation, snapshot) -- e.g. the stored relation's id and the transaction's snapshot; 0:0 = do

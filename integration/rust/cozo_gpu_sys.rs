@@ -12,6 +12,7 @@ pub const CZ_PR_BLOCKED: u32 = 4;
 pub const CZ_BF_GEMM: u32 = 8;
 pub const CZ_PR_EXCHANGE_ALLREDUCE: u32 = 32;
 pub const CZ_PR_OVERLAP_EXCHANGE: u32 = 64;
+pub const CZ_PR_ERR_F64_DIFF: u32 = 128;
 pub const CZ_UNIQUE_ID_BYTES: u32 = 128;
 
 pub const CZ_OK: c_int = 0;
@@ -106,6 +107,8 @@ extern "C" {
     pub fn cz_version() -> *const c_char;
     pub fn cz_hbm_probe(table: *const c_void, rows: u64, row_bytes: u32, n_fetch: u64, reps: u32, stream_gbs: *mut c_double,
                         row_fetch_gbs: *mut c_double) -> c_int;
+    pub fn cz_debug_seq_sum(terms: *const c_float, row_off: *const u64, init: *const c_float, n_rows: u32, lanes: c_int, per_lane: c_int,
+                            out: *mut c_float) -> c_int;
 
     pub fn cz_hnsw_index_create(desc: *const cz_hnsw_desc, vectors: *const c_float, out: *mut *mut cz_hnsw_index) -> c_int;
     pub fn cz_hnsw_index_destroy(ix: *mut cz_hnsw_index);
@@ -132,6 +135,9 @@ extern "C" {
     pub fn cz_pagerank(in_offsets: *const u32, in_sources: *const u32, out_degree: *const u32, n: u32, e: u64,
                        damping: c_float, tolerance: c_double, max_iter: u32, scores: *mut c_float, iters_run: *mut u32,
                        final_err: *mut c_double, poison: *const u8) -> c_int;
+    pub fn cz_pagerank_inplace(in_offsets: *const u32, in_sources: *const u32, out_degree: *const u32, n: u32, e: u64, damping: c_float,
+                               tolerance: c_double, max_iter: u32, flags: u32, scores: *mut c_float, iters_run: *mut u32,
+                               final_err: *mut c_double, n_levels: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_pagerank_cached(key_hi: u64, key_lo: u64, in_offsets: *const u32, in_sources: *const u32,
                               out_degree: *const u32, n: u32, e: u64, damping: c_float, tolerance: c_double, max_iter: u32,
                               flags: u32, scores: *mut c_float, iters_run: *mut u32, final_err: *mut c_double,

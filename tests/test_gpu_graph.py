@@ -39,6 +39,43 @@ def test_pagerank_bitexact(graphs, oracle, damping, tol, iters):
         assert err == pytest.approx(oerr, rel=1e-9)
 
 
+@pytest.mark.parametrize("damping,tol,iters", [(0.85, 1e-4, 10), (0.85, 0.0, 6), (0.5, 1e-6, 30)])
+def test_pagerank_inplace_reading_bitexact(graphs, oracle, damping, tol, iters):
+    """cz_pagerank_inplace: graph::page_rank under the reading that refreshes a node's contribution inside the sweep -- the
+    reference's one-thread execution, an ascending Gauss-Seidel sweep, level-scheduled on the device -- equals the oracle's
+    orc_pagerank_mode(ORC_PR_INPLACE) bit for bit: scores, iteration count, both forms of the error term; and it is NOT the
+    Jacobi reading (the two are ~1e-2 apart after a few sweeps, which is why the device carries both until a run of the real
+    crate decides)."""
+    from cozo_amd import graph as G
+    for g in graphs:
+        for f64d in (False, True):
+            s, it, err, levels = G.pagerank_inplace(g["ioff"], g["isrc"], g["outdeg"], damping, tol, iters, err_f64_diff=f64d)
+            os_, oit, oerr = oracle.pagerank_mode(g["n"], g["ioff"], g["isrc"], g["outdeg"], damping, tol, iters,
+                                                  mode=oracle.PR_INPLACE, err_f64_diff=f64d)
+            assert it == oit and levels >= 1
+            assert np.array_equal(s, os_), "in-place sweep: scores must be bit-identical"
+            assert err == pytest.approx(oerr, rel=1e-9)
+        js, _, _ = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], damping, tol, iters)
+        assert not np.array_equal(s, js)
+
+
+def test_pagerank_inplace_self_loops_sinks_and_long_rows(oracle, gpu_lib):
+    from cozo_amd import graph as G
+    rng = np.random.default_rng(31)
+    n = 6000
+    src = rng.integers(0, n, 90000)
+    dst = np.where(rng.random(90000) < 0.5, rng.integers(0, 2, 90000), rng.integers(0, n // 2, 90000))  # two hub rows of > 8 192 terms; the upper half has no in-edges
+    src[:200] = dst[:200]  # self loops: a node reads its OWN old contribution
+    rows = np.unique(np.stack([src, dst], 1), axis=0)
+    g = util.graph_from_relation(oracle, rows[:, 0].astype(np.int64), rows[:, 1].astype(np.int64))
+    assert np.diff(g["ioff"].astype(np.int64)).max() > 8192
+    s, it, err, levels = G.pagerank_inplace(g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 5)
+    os_, oit, oerr = oracle.pagerank_mode(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 5, mode=oracle.PR_INPLACE)
+    assert it == oit == 5 and np.array_equal(s, os_) and err == pytest.approx(oerr, rel=1e-9)
+    s0, it0, _, _ = G.pagerank_inplace(np.zeros(1, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32))
+    assert s0.size == 0 and it0 == 0
+
+
 def test_pagerank_undirected_and_empty(oracle, gpu_lib):
     from cozo_amd import graph as G
     frm, to = util.random_relation(500, 2000, 5)
@@ -721,3 +758,58 @@ def test_closeness_matches_the_reference_arithmetic(oracle, gpu_lib, monkeypatch
             want[s] = np.float32(np.float32(nc * nc) / total) / np.float32(n - 1)
     assert np.array_equal(got, want, equal_nan=True)
     assert np.isinf(want).any() or (want > 0).all()
+
+
+def _seq_sum_f32(terms, s):
+    s = np.float32(s)
+    with np.errstate(all="ignore"):
+        for a in np.asarray(terms, dtype=np.float32):
+            s = np.float32(s + a)
+    return s
+
+
+def _same_f32(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    both_nan = np.isnan(a) & np.isnan(b)
+    return bool(np.all(both_nan | (a.view(np.uint32) == b.view(np.uint32))))
+
+
+@pytest.mark.parametrize("lanes,per_lane", [(64, 16), (64, 8), (64, 4), (16, 16), (16, 4)])
+def test_exact_sum_fallback_paths_on_the_device(gpu_lib, lanes, per_lane):
+    """exact_sum.cuh maps everything outside its integer view -- negative terms, inf / nan, denormal running
+    sums, a term above the sum's exponent, a negative / non-finite start -- onto true f32 additions, and PageRank's terms
+    (non-negative, finite) never go there; until now only the CPU emulation (tests/cpp/exact_sum_test.cpp) did.  Through the
+    test hook cz_debug_seq_sum every row here is summed by the device's wave procedure and must equal the plain f32 loop
+    bit for bit (NaN == NaN)."""
+    from cozo_amd import graph as G
+    rng = np.random.default_rng(lanes * 100 + per_lane)
+    rows, init = [], []
+
+    def add(terms, s0=0.0):
+        rows.append(np.asarray(terms, dtype=np.float32))
+        init.append(np.float32(s0))
+
+    tiny = np.float32(1e-45)  # the smallest denormal
+    for n in (0, 1, 3, 63, 64, 65, 127, 200, 1000, 5000, 20000):
+        pos = rng.random(n, dtype=np.float32)
+        add(pos)                                            # the PageRank case, for reference
+        add(pos - np.float32(0.5))                          # negative terms, cancellation
+        add(-pos)                                           # a negative running sum throughout
+        add(pos * np.float32(1e-41))                        # denormal terms, denormal running sum
+        add(pos * np.float32(1e-41), s0=1e-38)              # ... crossing into the normal range
+        add(np.where(rng.random(n) < 0.02, np.float32(1e6), pos).astype(np.float32))    # terms far above the sum's exponent
+        add(pos, s0=-3.0)                                   # a negative start that turns positive
+        add(pos, s0=np.inf)
+        add(pos, s0=np.nan)
+        if n >= 3:
+            x = pos.copy(); x[n // 2] = np.inf; add(x)      # +inf in the middle: the sum stays inf
+            x = pos.copy(); x[n // 3] = np.inf; x[2 * n // 3] = -np.inf; add(x)  # inf - inf = nan from there on
+            x = pos.copy(); x[n - 1] = np.nan; add(x)       # a nan as the last term
+            x = pos.copy(); x[::7] = -0.0; add(x)           # -0.0 terms (sign bit set: off the integer path)
+            add(np.full(n, tiny), s0=0.0)                   # a sum that stays denormal
+            add(np.full(n, np.float32(2.0 ** -24)), s0=1.0)   # exact ties at every step (round to even)
+            add(np.full(n, np.float32(3.0e38)), s0=0.0)     # overflow to +inf
+    got = G.debug_seq_sum(rows, init, lanes, per_lane)
+    want = np.array([_seq_sum_f32(r, s0) for r, s0 in zip(rows, init)], dtype=np.float32)
+    bad = [i for i in range(len(rows)) if not _same_f32(got[i], want[i])]
+    assert not bad, [(i, rows[i].size, float(init[i]), got[i], want[i]) for i in bad[:5]]
