@@ -678,36 +678,60 @@ shard_pack_kernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__
 
 }  // namespace
 
-extern "C" int cz_hnsw_search_sharded(cz_comm *comm, cz_hnsw_index *shard, const float *queries_dev, uint32_t B, uint32_t k,
-                                      uint32_t ef, uint64_t id_offset, uint64_t *out_ids_dev, double *out_dist_dev,
-                                      uint32_t *out_count_dev, void *stream_) {
-    if (!comm || !shard || !queries_dev || !out_ids_dev || !out_dist_dev || !out_count_dev)
-        return cz::set_error(CZ_E_INVALID, "null argument");
+// `entry_status`: what the caller already knows about this rank (a failed allocation of its own): it joins the first agreement
+static int cz_hnsw_search_sharded_status(cz_comm *comm, cz_hnsw_index *shard, const float *queries_dev, uint32_t B, uint32_t k,
+                                         uint32_t ef, uint64_t id_offset, uint64_t *out_ids_dev, double *out_dist_dev,
+                                         uint32_t *out_count_dev, void *stream_, int entry_status) {
+    if (!comm) return cz::set_error(CZ_E_INVALID, "null communicator");
     if (B == 0) return CZ_OK;
     int rc = cz::ensure_device();
     if (rc) return rc;
     Rccl *R = nullptr;
     if ((rc = need_rccl(&R))) return rc;
+    if (!entry_status && (!shard || !queries_dev || !out_ids_dev || !out_dist_dev || !out_count_dev))
+        entry_status = cz::set_error(CZ_E_INVALID, "null argument");
     hipStream_t stream = (hipStream_t)stream_;
     auto *ix = reinterpret_cast<cz::HnswIndex *>(shard);
     const uint32_t world = (uint32_t)comm->world;
     const size_t nk = (size_t)B * k;
     cz::DevBuf<float> q;
-    cz::DevBuf<uint32_t> ids, cnt;
+    cz::DevBuf<uint32_t> ids, cnt, flag;
     cz::DevBuf<double> all_d;
     cz::DevBuf<uint64_t> all_i;
-    CZ_HIP(q.alloc((size_t)B * ix->dim));
-    CZ_HIP(ids.alloc(nk));
-    CZ_HIP(cnt.alloc(B));
-    CZ_HIP(all_d.alloc(nk * world));
-    CZ_HIP(all_i.alloc(nk * world));
+    // A rank that fails on its own (an allocation, a shard the search refuses) must not leave the others blocked in the next
+    // collective: every rank's status is summed through the communicator before each collective step and all ranks
+    // leave together.  `agree` returns this rank's own error, or CZ_E_INVALID naming how many OTHER ranks failed.
+    auto agree = [&](int mine) -> int {
+        if (world <= 1) return mine;
+        const std::string my_msg = mine ? std::string(cz_last_error()) : std::string();
+        uint32_t h = mine ? 1u : 0u;
+        if (!flag.p && flag.alloc(1) != hipSuccess) return mine ? mine : cz::set_error(CZ_E_OOM, "out of device memory");
+        if (hipMemcpyAsync(flag.p, &h, 4, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+            return mine ? mine : cz::set_error(CZ_E_HIP, "status upload failed");
+        if (R->AllReduce(flag.p, flag.p, 1, ncclUint32, ncclSum, comm->nccl, stream) != 0) return mine ? mine : cz::set_error(CZ_E_HIP, "status all-reduce failed");
+        if (hipMemcpyAsync(&h, flag.p, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+            return mine ? mine : cz::set_error(CZ_E_HIP, "status download failed");
+        if (mine) return cz::set_error(mine, "%s", my_msg.c_str());
+        if (h) return cz::set_error(CZ_E_INVALID, "%u other rank(s) failed in this sharded search", h);
+        return CZ_OK;
+    };
+    auto allocs = [&]() -> int {
+        CZ_HIP(q.alloc((size_t)B * ix->dim));
+        CZ_HIP(ids.alloc(nk));
+        CZ_HIP(cnt.alloc(B));
+        CZ_HIP(all_d.alloc(nk * world));
+        CZ_HIP(all_i.alloc(nk * world));
+        if (k == 0 || ef == 0) return cz::set_error(CZ_E_INVALID, "k and ef must be > 0");
+        return CZ_OK;
+    };
+    if ((rc = agree(entry_status ? entry_status : allocs()))) return rc;
     // rank 0's parent tuples go to every shard (B x dim x 4 bytes)
     if (comm->rank == 0) CZ_HIP(hipMemcpyAsync(q.p, queries_dev, (size_t)B * ix->dim * 4, hipMemcpyDeviceToDevice, stream));
     CZ_NCCL(R, R->Broadcast(q.p, q.p, (size_t)B * ix->dim, ncclFloat32, 0, comm->nccl, stream));
     double *my_d = all_d.p + nk * comm->rank;
     uint64_t *my_i = all_i.p + nk * comm->rank;
     rc = cz::hnsw_search_device(ix, q.p, B, k, ef, 0, 0.0, ids.p, my_d, cnt.p, nullptr, stream);
-    if (rc) return rc;
+    if ((rc = agree(rc))) return rc;  // (an empty shard -- n < n_gpus -- searches fine: zero rows; a refused one stops every rank here)
     hipLaunchKernelGGL(shard_pack_kernel, dim3((unsigned)std::min<size_t>(1024, (nk + 255) / 256)), dim3(256), 0, stream, ids.p, cnt.p,
                        B, k, id_offset, my_i);
     if (world > 1) {
@@ -720,6 +744,13 @@ extern "C" int cz_hnsw_search_sharded(cz_comm *comm, cz_hnsw_index *shard, const
     if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sharded search launch: %s", hipGetErrorString(e));
     CZ_HIP(hipStreamSynchronize(stream));  // temporaries die with this scope
     return CZ_OK;
+}
+
+extern "C" int cz_hnsw_search_sharded(cz_comm *comm, cz_hnsw_index *shard, const float *queries_dev, uint32_t B, uint32_t k,
+                                      uint32_t ef, uint64_t id_offset, uint64_t *out_ids_dev, double *out_dist_dev,
+                                      uint32_t *out_count_dev, void *stream_) {
+    return cz_hnsw_search_sharded_status(comm, shard, queries_dev, B, k, ef, id_offset, out_ids_dev, out_dist_dev, out_count_dev, stream_,
+                                         CZ_OK);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -805,6 +836,8 @@ extern "C" void cz_hnsw_multi_destroy(cz_hnsw_multi *m) {
 
 extern "C" int cz_hnsw_multi_create(const cz_hnsw_desc *const *shards, const float *const *vectors, const uint64_t *id_offsets,
                                     int n_gpus, cz_hnsw_multi **out) {
+    if (!out) return cz::set_error(CZ_E_INVALID, "null out");
+    *out = nullptr;
     if (!shards || !vectors || !id_offsets) return cz::set_error(CZ_E_INVALID, "null argument");
     cz_hnsw_multi *m = nullptr;
     int rc = multi_open(n_gpus, &m);
@@ -830,6 +863,8 @@ extern "C" int cz_hnsw_multi_build(const float *vectors, uint32_t n, uint32_t di
                                    uint32_t ef_construction, int keep_pruned_connections, uint64_t seed, uint32_t max_batch, int n_gpus,
                                    uint32_t flags, uint64_t *n_dist, cz_hnsw_multi **out) {
     if (n_dist) *n_dist = 0;
+    if (!out) return cz::set_error(CZ_E_INVALID, "null out");
+    *out = nullptr;
     if (n > 0 && !vectors) return cz::set_error(CZ_E_INVALID, "vectors is null");
     if (flags & CZ_DEVICE_PTRS) return cz::set_error(CZ_E_INVALID, "cz_hnsw_multi_build takes host vectors (they go to several devices)");
     cz_hnsw_multi *m = nullptr;
@@ -864,12 +899,18 @@ extern "C" int cz_hnsw_multi_search(cz_hnsw_multi *m, const float *queries, uint
         cz::DevBuf<uint64_t> oi;
         cz::DevBuf<double> od;
         cz::DevBuf<uint32_t> oc;
-        CZ_HIP(q.alloc((size_t)B * m->dim));
-        CZ_HIP(oi.alloc(nk));
-        CZ_HIP(od.alloc(nk));
-        CZ_HIP(oc.alloc(B));
-        if (r == 0) CZ_HIP(hipMemcpy(q.p, queries, (size_t)B * m->dim * 4, hipMemcpyHostToDevice));  // (the others receive the broadcast)
-        int rc = cz_hnsw_search_sharded(c, m->shards[r], q.p, B, k, ef, m->id_offset[r], oi.p, od.p, oc.p, nullptr);
+        // (a rank that fails HERE still enters the collective call below, with null buffers: cz_hnsw_search_sharded rejects them
+        // AFTER the ranks have agreed on a status, so nobody is left waiting in a broadcast -- ADVICE r3)
+        auto prepare = [&]() -> int {
+            CZ_HIP(q.alloc((size_t)B * m->dim));
+            CZ_HIP(oi.alloc(nk));
+            CZ_HIP(od.alloc(nk));
+            CZ_HIP(oc.alloc(B));
+            if (r == 0) CZ_HIP(hipMemcpy(q.p, queries, (size_t)B * m->dim * 4, hipMemcpyHostToDevice));  // (the others receive the broadcast)
+            return CZ_OK;
+        };
+        const int prc = prepare();
+        int rc = cz_hnsw_search_sharded_status(c, m->shards[r], q.p, B, k, ef, m->id_offset[r], oi.p, od.p, oc.p, nullptr, prc);
         if (rc) return rc;
         if (r == 0) {  // every rank holds the same merged lists
             CZ_HIP(hipMemcpy(ids, oi.p, nk * 8, hipMemcpyDeviceToHost));

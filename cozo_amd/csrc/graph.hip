@@ -1273,8 +1273,8 @@ triangles_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
 // tri(c) += m_ac m_bc.  So node v only enumerates pairs of DISTINCT neighbours above itself -- a quarter of the pairs -- tests
 // membership once with the multiplicity (equal range instead of existence), and credits all three corners with atomics
 // (triangles are rare next to pairs: 4 125 incidences against 10^9 pairs on the 10M / 200M uniform graph).
-// Precondition: the adjacency is symmetric with symmetric multiplicities; tri_symmetry_sample_kernel tests a sample of the
-// edges for it and the call falls back to the general kernel when the sample finds a violation (CZ_TRI_GENERAL=1 forces it).
+// Precondition: the adjacency is symmetric with symmetric multiplicities; the caller vouches for it (CZ_TRI_SYMMETRIC) or
+// tri_symmetry_kernel verifies it exactly, and the call falls back to the general kernel otherwise (CZ_TRI_GENERAL=1 forces it).
 __device__ __forceinline__ uint32_t csr_count(const uint32_t *__restrict__ tgt, uint32_t lo, uint32_t hi, uint32_t x) {
     uint32_t l = lo, h = hi;
     while (l < h) {  // lower bound
@@ -1287,21 +1287,34 @@ __device__ __forceinline__ uint32_t csr_count(const uint32_t *__restrict__ tgt, 
     return c;
 }
 
+// EXACT (round 4; the sampled form of round 3 could miss a violation): a 16-lane group per node u walks its list; every entry
+// v > u that is the first of its run must occur in v's list as often as v does in u's; and the graph must hold as many entries
+// below their node as above -- a pair (u < v) that only v lists is never met from u, but it adds to `below` alone.
+// bad: violations; updown[0] / [1]: entries above / below their node.
 __global__ void __launch_bounds__(256)
-tri_symmetry_sample_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t N, uint64_t E, uint32_t samples,
-                           uint32_t *__restrict__ bad) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= samples || E == 0) return;
-    const uint64_t e = ((uint64_t)i * 0x9E3779B97F4A7C15ull >> 11) % E;
-    // the row of edge slot e: bisection over the offsets
-    uint32_t lo = 0, hi = N;
-    while (hi - lo > 1) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (off[mid] <= e) lo = mid;
-        else hi = mid;
+tri_symmetry_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t N, uint32_t *__restrict__ bad,
+                    unsigned long long *__restrict__ updown) {
+    const uint32_t gl = threadIdx.x & 15u;
+    const uint64_t group = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 4, ngroups = ((uint64_t)gridDim.x * 256) >> 4;
+    unsigned long long up = 0, down = 0;
+    uint32_t wrong = 0;
+    for (uint64_t u = group; u < N; u += ngroups) {
+        const uint32_t a = off[u], z = off[u + 1];
+        for (uint32_t e = a + gl; e < z; e += 16) {
+            const uint32_t v = tgt[e];
+            if (v >= N) { wrong++; continue; }
+            if (v < (uint32_t)u) { down++; continue; }
+            if (v == (uint32_t)u) continue;  // self loops are judged by tri_self_loop_kernel
+            up++;
+            if (e > a && tgt[e - 1] == v) continue;  // not the first of its run
+            uint32_t mine = 1;
+            while (e + mine < z && tgt[e + mine] == v) mine++;
+            if (csr_count(tgt, off[v], off[v + 1], (uint32_t)u) != mine) wrong++;
+        }
     }
-    const uint32_t u = lo, v = tgt[e];
-    if (v >= N || csr_count(tgt, off[u], off[u + 1], v) != csr_count(tgt, off[v], off[v + 1], u)) atomicAdd(bad, 1u);
+    if (wrong) atomicAdd(bad, wrong);
+    if (up) atomicAdd(&updown[0], up);
+    if (down) atomicAdd(&updown[1], down);
 }
 
 // self loops make degenerate "triangles" (the entry v of A(v) pairs with every other neighbour: triangles.rs:84-101 has no
@@ -1408,7 +1421,7 @@ triangles_oriented_kernel(const uint32_t *__restrict__ off, const uint32_t *__re
 }
 
 extern "C" int cz_clustering_coefficients(const uint32_t *offsets, const uint32_t *targets, uint32_t N, uint64_t E,
-                                          uint64_t *n_triangles, uint32_t *degree, const volatile uint8_t *poison) {
+                                          uint64_t *n_triangles, uint32_t *degree, const volatile uint8_t *poison, uint32_t flags) {
     int rc = cz::ensure_device();
     if (rc) return rc;
     t_timing.start();
@@ -1428,18 +1441,23 @@ extern "C" int cz_clustering_coefficients(const uint32_t *offsets, const uint32_
     const int blocks = (int)std::min<uint64_t>(256 * 16, ((uint64_t)N + 3) / 4);
     t_timing.lap(T_UPLOAD);
     bool general = getenv("CZ_TRI_GENERAL") && atoi(getenv("CZ_TRI_GENERAL")) != 0;
-    if (!general && E > 0) {  // the oriented count needs a symmetric adjacency without self loops: the latter is checked exactly, the
-                              // former on a sample of the edges
+    if (!general && E > 0) {  // the oriented count needs a symmetric adjacency without self loops: both are checked EXACTLY, the former
+                              // unless the caller vouches for it (CZ_TRI_SYMMETRIC: the rule, which builds the adjacency that way)
         cz::DevBuf<uint32_t> d_bad;
+        cz::DevBuf<unsigned long long> d_updown;
         CZ_HIP(d_bad.alloc(1));
+        CZ_HIP(d_updown.alloc(2));
         CZ_HIP(hipMemsetAsync(d_bad.p, 0, 4, nullptr));
-        const uint32_t samples = (uint32_t)std::min<uint64_t>(E, 1u << 16);
-        hipLaunchKernelGGL(tri_symmetry_sample_kernel, dim3((samples + 255) / 256), dim3(256), 0, nullptr, d_off.p, d_tgt.p, N, E, samples,
-                           d_bad.p);
+        CZ_HIP(hipMemsetAsync(d_updown.p, 0, 16, nullptr));
+        if (!(flags & CZ_TRI_SYMMETRIC))
+            hipLaunchKernelGGL(tri_symmetry_kernel, dim3(grid_for((uint64_t)N * 16)), dim3(256), 0, nullptr, d_off.p, d_tgt.p, N, d_bad.p,
+                               d_updown.p);
         hipLaunchKernelGGL(tri_self_loop_kernel, dim3(grid_for(N)), dim3(256), 0, nullptr, d_off.p, d_tgt.p, N, d_bad.p);
         uint32_t bad = 0;
+        unsigned long long updown[2] = {0, 0};
         CZ_HIP(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
-        general = bad != 0;
+        CZ_HIP(hipMemcpy(updown, d_updown.p, 16, hipMemcpyDeviceToHost));
+        general = bad != 0 || updown[0] != updown[1];
     }
     if (general) {
         hipLaunchKernelGGL(triangles_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, nullptr, d_off.p, d_tgt.p, N, d_tri.p, d_deg.p);

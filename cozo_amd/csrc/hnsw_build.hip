@@ -717,7 +717,12 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
         (void)hipStreamSynchronize(stream);
         fprintf(stderr, "[build] %s (%u) done\n", what, count);
     };
-    // one round of shrinks: rows [0, count) of the request arrays (count on the host, or read on the device when `count_dev`)
+    // one round of shrinks: rows [0, count) of the request arrays (count on the host, or read on the device when `count_dev`).
+    // With extend_candidates a shrink reads OTHER rows, so its selection is staged and applied afterwards -- per part of kStageRows
+    // (65 536) requests: inside a part every shrink sees the rows as the part found them; a round of MORE requests than that (only
+    // the final lazy round of a large batched build) is applied part by part, and a later part reads rows an earlier part of the
+    // same round has already rewritten.  That makes those tables depend on the request order of that round; the
+    // sequential build (max_batch = 1: one request per round) is untouched, and it is the only form whose tables are pinned to the oracle.
     auto launch_shrinks = [&](const uint32_t *sh_t, const int32_t *sh_lv, uint32_t count, const uint32_t *count_dev) {
         for (uint32_t off = 0; off < count; off += extend ? kStageRows : count) {
             const uint32_t part = extend ? std::min(kStageRows, count - off) : count;
@@ -897,8 +902,16 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
         if (rows) CZ_HIP(hipMemcpy(wUv.data(), b_degU.p, (size_t)rows * 4, hipMemcpyDeviceToHost));
         ix->ph0.assign(n, 0);
         ix->phU.assign((size_t)rows, 0);
-        for (uint32_t v = 0; v < n; v++) ix->ph0[v] = (uint8_t)std::min<uint32_t>(255, hid_of(w0v[v]));
-        for (uint64_t r = 0; r < rows; r++) ix->phU[r] = (uint8_t)std::min<uint32_t>(255, hid_of(wUv[r]));
+        // (kept as one byte per row; a row that hides more than 255 links -- a base row carrying more than 256 indexed vectors that all
+        // select each other -- is refused rather than written back with a degree that no longer matches what the build counted)
+        uint32_t hid_max = 0;
+        for (uint32_t v = 0; v < n; v++) hid_max = std::max(hid_max, hid_of(w0v[v]));
+        for (uint64_t r = 0; r < rows; r++) hid_max = std::max(hid_max, hid_of(wUv[r]));
+        if (hid_max > 255)
+            return cz::set_error(CZ_E_UNSUPPORTED, "a row's degree counts %u links that have no slot (links inside one base row): at most 255 are kept",
+                                 hid_max);
+        for (uint32_t v = 0; v < n; v++) ix->ph0[v] = (uint8_t)hid_of(w0v[v]);
+        for (uint64_t r = 0; r < rows; r++) ix->phU[r] = (uint8_t)hid_of(wUv[r]);
     }
     {   // the visited workspaces were sized for the old n
         std::lock_guard<std::mutex> lk(ix->mu);

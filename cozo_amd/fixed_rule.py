@@ -708,7 +708,7 @@ class ClusteringCoefficients(FixedRule):
         graph, indices, _ = edges.as_directed_graph(True)
         if not indices:
             return
-        tri, deg = _graph.clustering_coefficients(graph.out_offsets, graph.out_targets, poison=poison.flag)
+        tri, deg = _graph.clustering_coefficients(graph.out_offsets, graph.out_targets, poison=poison.flag, symmetric=True)  # as_directed_graph(True)
         for idx in range(graph.n):
             d, t = int(deg[idx]), int(tri[idx])
             cc = 0.0 if d < 2 else 2.0 * float(t) / (float(d) * (float(d) - 1.0))  # :80-82, :102

@@ -227,13 +227,16 @@ def connected_components(off, tgt=None, poison=None):
     return grp, k.value
 
 
-def clustering_coefficients(off, tgt, poison=None):
-    """cz_clustering_coefficients on the symmetrised out-CSR -> (n_triangles u64 [N], degree u32 [N])"""
+def clustering_coefficients(off, tgt, poison=None, symmetric=False):
+    """cz_clustering_coefficients on the symmetrised out-CSR -> (n_triangles u64 [N], degree u32 [N]).
+    symmetric=True: the caller built the adjacency with as_directed_graph(undirected=True) and vouches for it (CZ_TRI_SYMMETRIC);
+    otherwise the library verifies the symmetry exactly before it takes the kernel that relies on it."""
     off, tgt = _csr32(off, tgt)
     N = off.size - 1
     tri = np.zeros(N, dtype=np.uint64)
     deg = np.zeros(N, dtype=np.uint32)
-    check(_lib.lib().cz_clustering_coefficients(ptr(off), ptr(tgt), N, tgt.size, ptr(tri), ptr(deg), ptr(poison)))
+    check(_lib.lib().cz_clustering_coefficients(ptr(off), ptr(tgt), N, tgt.size, ptr(tri), ptr(deg), ptr(poison),
+                                                _lib.CZ_TRI_SYMMETRIC if symmetric else 0))
     return tri, deg
 
 

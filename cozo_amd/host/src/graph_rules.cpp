@@ -286,7 +286,7 @@ void ClusteringCoefficients::run(const FixedRulePayload &payload, RegularTempSto
     std::vector<uint64_t> tri(gr.n);
     std::vector<uint32_t> deg(gr.n);
     check_gpu(cz_clustering_coefficients(gr.out_offsets.data(), gr.out_targets.data(), gr.n, gr.edge_count(), tri.data(),
-                                         deg.data(), poison.flag_ptr()));
+                                         deg.data(), poison.flag_ptr(), CZ_TRI_SYMMETRIC));  // built two lines up with undirected = true
     for (uint32_t i = 0; i < gr.n; i++) {
         const double d = (double)deg[i];
         const double cc = deg[i] < 2 ? 0.0 : 2.0 * (double)tri[i] / (d * (d - 1.0));  // :80-82, :102

@@ -446,8 +446,13 @@ int cz_connected_components(const uint32_t *offsets, const uint32_t *targets, ui
  *   n_triangles [N] out: #{(i, j) list positions of node v : A[i] > A[j] and A[j] is an out-neighbour of A[i]}
  *   degree [N] out: list length (multiplicity counted).  The shim emits
  *   (node, 2 t / (d (d - 1)) as f64 -- 0.0 when d < 2 --, t, d) like :58-66, :102. */
+/* flags: CZ_TRI_SYMMETRIC = the caller built the adjacency with as_directed_graph(undirected = true) (symmetric, symmetric
+ * multiplicities -- what the rule always passes): the kernel that finds every triangle once is taken without further ado.
+ * Without the flag the library VERIFIES that precondition exactly (every entry above its node matched in the other list with
+ * the same multiplicity, as many entries below as above) and counts with the general kernel when it does not hold. */
+#define CZ_TRI_SYMMETRIC 512u
 int cz_clustering_coefficients(const uint32_t *offsets, const uint32_t *targets, uint32_t N, uint64_t E,
-                               uint64_t *n_triangles, uint32_t *degree, const volatile uint8_t *poison);
+                               uint64_t *n_triangles, uint32_t *degree, const volatile uint8_t *poison, uint32_t flags);
 
 /* dijkstra (algos/shortest_path_dijkstra.rs:274-339) for n_starts sources on the weighted out-CSR
  * (as_directed_weighted_graph, fixed_rule/mod.rs:208-328; f32 weights >= 0):

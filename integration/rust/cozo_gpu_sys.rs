@@ -13,6 +13,7 @@ pub const CZ_BF_GEMM: u32 = 8;
 pub const CZ_PR_EXCHANGE_ALLREDUCE: u32 = 32;
 pub const CZ_PR_OVERLAP_EXCHANGE: u32 = 64;
 pub const CZ_PR_ERR_F64_DIFF: u32 = 128;
+pub const CZ_TRI_SYMMETRIC: u32 = 512;
 pub const CZ_UNIQUE_ID_BYTES: u32 = 128;
 
 pub const CZ_OK: c_int = 0;
@@ -223,7 +224,7 @@ extern "C" {
     pub fn cz_connected_components(offsets: *const u32, targets: *const u32, n: u32, e: u64, group: *mut u32,
                                    n_groups: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_clustering_coefficients(offsets: *const u32, targets: *const u32, n: u32, e: u64, n_triangles: *mut u64,
-                                      degree: *mut u32, poison: *const u8) -> c_int;
+                                      degree: *mut u32, poison: *const u8, flags: u32) -> c_int;
     pub fn cz_sssp(out_offsets: *const u32, out_targets: *const u32, weights: *const c_float, n: u32, e: u64,
                    starts: *const u32, n_starts: u32, dist: *mut c_float, parent: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_graph_upload(offsets: *const u32, targets: *const u32, weights: *const c_float, n: u32, e: u64, out: *mut *mut cz_graph) -> c_int;

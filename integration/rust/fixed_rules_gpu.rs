@@ -734,7 +734,7 @@ impl FixedRule for ClusteringCoefficientsGpu {
         let mut degree = vec![0u32; g.n as usize];
         check(unsafe {
             cz_clustering_coefficients(g.offsets.as_ptr(), g.targets.as_ptr(), g.n, g.targets.len() as u64, n_triangles.as_mut_ptr(),
-                                       degree.as_mut_ptr(), poison_ptr(&poison))
+                                       degree.as_mut_ptr(), poison_ptr(&poison), CZ_TRI_SYMMETRIC)
         }, &poison)?;
         for idx in 0..g.n as usize {
             let (t, d) = (n_triangles[idx], degree[idx]);

@@ -79,8 +79,9 @@ int cz_connected_components(const uint32_t *offsets, const uint32_t *targets, ui
 }
 
 int cz_clustering_coefficients(const uint32_t *offsets, const uint32_t *targets, uint32_t N, uint64_t E, uint64_t *n_triangles,
-                               uint32_t *degree, const volatile uint8_t *poison) {
+                               uint32_t *degree, const volatile uint8_t *poison, uint32_t flags) {
     (void)E;
+    (void)flags;
     if (poisoned(poison)) { g_err = "cancelled"; return CZ_E_CANCELLED; }
     uint64_t *off = widen(offsets, N);
     double *cc = (double *)malloc(sizeof(double) * (N ? N : 1));

@@ -62,9 +62,9 @@ def test_pagerank_inplace_reading_bitexact(graphs, oracle, damping, tol, iters):
 def test_pagerank_inplace_self_loops_sinks_and_long_rows(oracle, gpu_lib):
     from cozo_amd import graph as G
     rng = np.random.default_rng(31)
-    n = 6000
-    src = rng.integers(0, n, 90000)
-    dst = np.where(rng.random(90000) < 0.5, rng.integers(0, 2, 90000), rng.integers(0, n // 2, 90000))  # two hub rows of > 8 192 terms; the upper half has no in-edges
+    n = 24000
+    src = rng.integers(0, n, 300000)
+    dst = np.where(rng.random(300000) < 0.5, rng.integers(0, 2, 300000), rng.integers(0, n // 2, 300000))  # two hub rows of > 8 192 terms; the upper half has no in-edges
     src[:200] = dst[:200]  # self loops: a node reads its OWN old contribution
     rows = np.unique(np.stack([src, dst], 1), axis=0)
     g = util.graph_from_relation(oracle, rows[:, 0].astype(np.int64), rows[:, 1].astype(np.int64))
@@ -361,6 +361,30 @@ def test_clustering_coefficients_bitexact(oracle, gpu_lib):
     tri, deg = G.clustering_coefficients(g["ooff"], g["otgt"])
     _, otri, odeg = oracle.clustering_coefficients(g["n"], g["ooff"], g["otgt"])
     assert np.array_equal(tri, otri) and np.array_equal(deg, odeg)
+    # ONE asymmetric entry in 1.3 M slots -- round 3's 65 536-slot sample would miss it 19 times out of 20 and
+    # the oriented kernel would then count wrongly; the exact verification sends the call to the general kernel.  Three shapes of
+    # violation: an edge only its upper end lists, an edge only its lower end lists, a multiplicity that differs.
+    frm, to = util.random_relation(60000, 660000, 8)
+    sym_f, sym_t = np.concatenate([frm, to]), np.concatenate([to, frm])
+    for extra in ([(59999, 5)], [(7, 59998)], [(100, 200), (100, 200), (200, 100)]):
+        ef = np.concatenate([sym_f, np.array([a for a, _ in extra], dtype=np.int64)])
+        et = np.concatenate([sym_t, np.array([b for _, b in extra], dtype=np.int64)])
+        o = np.lexsort((et, ef))
+        ooff = np.zeros(60001, dtype=np.uint64)
+        ooff[1:] = np.cumsum(np.bincount(ef, minlength=60000))
+        otgt = et[o].astype(np.uint32)
+        tri, deg = G.clustering_coefficients(ooff, otgt)
+        _, otri, odeg = oracle.clustering_coefficients(60000, ooff, otgt)
+        assert np.array_equal(tri, otri) and np.array_equal(deg, odeg), extra
+    # ... and with the caller vouching for the symmetry (what the rule does after as_directed_graph(undirected = true)) the counts are the same
+    o = np.lexsort((sym_t, sym_f))
+    ooff = np.zeros(60001, dtype=np.uint64)
+    ooff[1:] = np.cumsum(np.bincount(sym_f, minlength=60000))
+    otgt = sym_t[o].astype(np.uint32)
+    a, _ = G.clustering_coefficients(ooff, otgt, symmetric=True)
+    b, _ = G.clustering_coefficients(ooff, otgt)
+    _, otri, _ = oracle.clustering_coefficients(60000, ooff, otgt)
+    assert np.array_equal(a, otri) and np.array_equal(b, otri)
 
 
 def test_sssp_costs_bitexact(oracle, gpu_lib):

@@ -93,7 +93,7 @@ class OracleGraphBackend:
     def connected_components(self, off, tgt, poison=None):
         return self.O.tarjan_groups(len(off) - 1, off, tgt)
 
-    def clustering_coefficients(self, off, tgt, poison=None):
+    def clustering_coefficients(self, off, tgt, poison=None, symmetric=False):
         _, tri, deg = self.O.clustering_coefficients(len(off) - 1, off, tgt)
         return tri, deg
 
