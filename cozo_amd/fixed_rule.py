@@ -484,11 +484,19 @@ class PageRank(FixedRule):
         theta = np.float32(payload.unit_interval_option("theta", 0.85))
         epsilon = np.float32(payload.unit_interval_option("epsilon", 0.0001))
         iterations = payload.pos_integer_option("iterations", 10)
+        # an option of the GPU rule alone (absent = false): `in_place: true` runs graph::page_rank under the reading that refreshes a
+        # node's contribution inside the sweep -- the reference's one-thread execution if the crate does that (cz_pagerank_inplace;
+        # DESIGN section 3).  Which reading is the crate's is settled by oracle/ref_fixtures on a box with cargo.
+        in_place = payload.bool_option("in_place", False)
         graph, indices, _ = edges.as_directed_graph(undirected)
         if not indices:
             return
-        scores, _n_run, _err = _graph.pagerank(graph.in_offsets, graph.in_sources, graph.out_degrees(), damping=theta,
-                                               tolerance=float(epsilon), max_iter=iterations, poison=poison.flag)
+        if in_place:
+            scores = _graph.pagerank_inplace(graph.in_offsets, graph.in_sources, graph.out_degrees(), damping=theta,
+                                             tolerance=float(epsilon), max_iter=iterations, poison=poison.flag)[0]
+        else:
+            scores, _n_run, _err = _graph.pagerank(graph.in_offsets, graph.in_sources, graph.out_degrees(), damping=theta,
+                                                   tolerance=float(epsilon), max_iter=iterations, poison=poison.flag)
         for idx, score in enumerate(scores):
             out.put((indices[idx], float(score)))
 

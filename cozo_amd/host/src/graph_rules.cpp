@@ -41,6 +41,9 @@ void PageRank::run(const FixedRulePayload &payload, RegularTempStore &out, const
     const float theta = (float)payload.unit_interval_option("theta", 0.85);
     const float epsilon = (float)payload.unit_interval_option("epsilon", 0.0001);  // narrowed to f32 (:38), widened at :49
     const size_t iterations = payload.pos_integer_option("iterations", 10);
+    // an option of the GPU rule alone: graph::page_rank under the reading that refreshes a contribution inside the sweep (the
+    // reference's one-thread execution if the crate does that; cz_pagerank_inplace)
+    const bool in_place = payload.bool_option("in_place", false);
     GraphWithIndices g = edges.as_directed_graph(undirected);
     if (g.indices.empty()) return;  // :43-45
     const DirectedCsrGraph &gr = g.graph;
@@ -48,8 +51,13 @@ void PageRank::run(const FixedRulePayload &payload, RegularTempStore &out, const
     std::vector<float> scores(gr.n);
     uint32_t iters_run = 0;
     double final_err = 0.0;
-    check_gpu(cz_pagerank(gr.in_offsets.data(), gr.in_sources.data(), out_degree.data(), gr.n, gr.edge_count(), theta,
-                          (double)epsilon, (uint32_t)iterations, scores.data(), &iters_run, &final_err, poison.flag_ptr()));
+    if (in_place)
+        check_gpu(cz_pagerank_inplace(gr.in_offsets.data(), gr.in_sources.data(), out_degree.data(), gr.n, gr.edge_count(), theta,
+                                      (double)epsilon, (uint32_t)iterations, 0, scores.data(), &iters_run, &final_err, nullptr,
+                                      poison.flag_ptr()));
+    else
+        check_gpu(cz_pagerank(gr.in_offsets.data(), gr.in_sources.data(), out_degree.data(), gr.n, gr.edge_count(), theta,
+                              (double)epsilon, (uint32_t)iterations, scores.data(), &iters_run, &final_err, poison.flag_ptr()));
     for (uint32_t i = 0; i < gr.n; i++) out.put(Tuple{g.indices[i], DataValue((double)scores[i])});
 }
 

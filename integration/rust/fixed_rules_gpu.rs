@@ -184,6 +184,10 @@ impl FixedRule for PageRankGpu {
         //   gpus: n      row-shard the sweep over n GPUs of this process (cz_pagerank_multi: one host thread + one RCCL
         //                communicator per GPU, in-place all-gather of the contribution slices each iteration)
         let gpus = payload.pos_integer_option("gpus", Some(1))? as c_int;
+        //   in_place: true   graph::page_rank under the reading that refreshes a node's contribution INSIDE the sweep (the crate's
+        //                one-thread execution if it does that: cz_pagerank_inplace); absent = the Jacobi reading.  Which one the
+        //                crate is gets settled by oracle/ref_fixtures on a box with cargo.
+        let in_place = payload.bool_option("in_place", Some(false))?;
         let flags = 0u32;
         let g = edges.as_gpu_graph(undirected, true)?;
         if g.indices.is_empty() {
@@ -191,7 +195,13 @@ impl FixedRule for PageRankGpu {
         }
         let mut scores = vec![0f32; g.n as usize];
         let (mut it, mut err) = (0u32, 0f64);
-        if gpus > 1 {
+        if in_place {
+            check(unsafe {
+                cz_pagerank_inplace(g.offsets.as_ptr(), g.targets.as_ptr(), g.out_degree.as_ptr(), g.n, g.targets.len() as u64, theta,
+                                    epsilon as f64, iterations as u32, 0, scores.as_mut_ptr(), &mut it, &mut err, std::ptr::null_mut(),
+                                    poison_ptr(&poison))
+            }, &poison)?;
+        } else if gpus > 1 {
             check(unsafe {
                 cz_pagerank_multi(g.offsets.as_ptr(), g.targets.as_ptr(), g.out_degree.as_ptr(), g.n, g.targets.len() as u64,
                                   theta, epsilon as f64, iterations as u32, gpus, flags, scores.as_mut_ptr(), &mut it, &mut err,

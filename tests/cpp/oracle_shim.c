@@ -38,6 +38,24 @@ int cz_pagerank(const uint32_t *in_offsets, const uint32_t *in_sources, const ui
     return CZ_OK;
 }
 
+int cz_pagerank_inplace(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N, uint64_t E,
+                        float damping, double tolerance, uint32_t max_iter, uint32_t flags, float *scores, uint32_t *iters_run,
+                        double *final_err, uint32_t *n_levels, const volatile uint8_t *poison) {
+    (void)E;
+    if (poisoned(poison)) { g_err = "cancelled"; return CZ_E_CANCELLED; }
+    if (n_levels) *n_levels = 1;
+    if (N == 0) return CZ_OK;
+    uint64_t *off = widen(in_offsets, N);
+    uint32_t it = 0;
+    double err = 0;
+    orc_pagerank_mode(N, off, in_sources, out_degree, damping, tolerance, max_iter, ORC_PR_INPLACE, (flags & CZ_PR_ERR_F64_DIFF) ? 1 : 0, scores,
+                      &it, &err);
+    free(off);
+    if (iters_run) *iters_run = it;
+    if (final_err) *final_err = err;
+    return CZ_OK;
+}
+
 int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E, const uint32_t *starts,
            uint32_t n_starts, const uint32_t *goals, uint32_t n_goals, int share_visited, uint32_t *parent, uint32_t *depth,
            uint32_t *order, uint32_t *n_reached, const volatile uint8_t *poison) {

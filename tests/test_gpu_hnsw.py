@@ -251,9 +251,12 @@ def test_edge_cases(gpu_lib, oracle):
     # dimension mismatch is an error (hnsw.rs:876-878)
     with pytest.raises(ValueError):
         g.hnsw_knn_batch(np.ones((1, 9), np.float32), HnswSearch(k=1, ef=1))
-    # ef beyond the LDS-resident list is refused loudly, not silently clamped
+    # ef = 5 000 runs since round 4 (the list is bounded by LDS alone: ~11 000 entries next to a small query) ...
+    ids5, _, cnt5 = g.hnsw_knn_batch(x, HnswSearch(k=1, ef=5000))
+    assert cnt5[0] == 1 and ids5[0, 0] == 0
+    # ... and an ef beyond what 160 KiB of LDS hold is refused loudly, not silently clamped
     with pytest.raises(_lib.CozoGpuError):
-        g.hnsw_knn_batch(x, HnswSearch(k=1, ef=5000))
+        g.hnsw_knn_batch(x, HnswSearch(k=1, ef=20000))
     # duplicates + a zero vector under cosine (NaN distances sort last, never beat a finite distance)
     y = util.vectors(200, 16, 5, "normal")
     y[10] = y[3]

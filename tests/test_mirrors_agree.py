@@ -89,6 +89,8 @@ def _cases():
         ("PageRank", [e], {}),
         ("PageRank", [ints], {"undirected": True, "theta": 0.7, "epsilon": 1e-6, "iterations": 20}),
         ("PageRank", [mixed], {}),
+        ("PageRank", [ints], {"in_place": True}),                      # the other reading of graph::page_rank (cz_pagerank_inplace)
+        ("PageRank", [e], {"in_place": True, "undirected": True, "iterations": 4, "epsilon": 0.0}),
         ("PageRank", [[]], {}),
         ("ConnectedComponents", [ints], {}),
         ("ConnectedComponents", [e, [("lonely",), ("n3",)]], {}),

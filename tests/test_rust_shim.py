@@ -233,7 +233,7 @@ def test_shim_only_names_things_the_reference_or_the_patch_defines():
 
 # ---- every rule the integration guide lists has its `impl FixedRule`, with the reference's arity and option names -------------
 RULES = {  # GPU struct -> (reference file under fixed_rule/algos, reference struct, options the GPU rule may ADD)
-    "PageRankGpu": ("pagerank.rs", "PageRank", {"gpus"}),
+    "PageRankGpu": ("pagerank.rs", "PageRank", {"gpus", "in_place"}),
     "ConnectedComponentsGpu": ("strongly_connected_components.rs", "StronglyConnectedComponent", set()),
     "ShortestPathBFSGpu": ("shortest_path_bfs.rs", "ShortestPathBFS", set()),
     "BfsGpu": ("bfs.rs", "Bfs", set()),

@@ -62,11 +62,17 @@ class OracleGraphBackend:
 
     def install(self, monkeypatch):
         import cozo_amd.graph as G
-        for name in ("pagerank", "bfs", "connected_components", "sssp", "clustering_coefficients", "betweenness", "label_propagation", "closeness"):
+        for name in ("pagerank", "pagerank_inplace", "bfs", "connected_components", "sssp", "clustering_coefficients", "betweenness",
+                     "label_propagation", "closeness"):
             monkeypatch.setattr(G, name, getattr(self, name))
 
     def pagerank(self, in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10, poison=None):
         return self.O.pagerank(len(out_deg), in_off, in_src, out_deg, damping, tolerance, max_iter)
+
+    def pagerank_inplace(self, in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10, err_f64_diff=False, poison=None):
+        s, it, err = self.O.pagerank_mode(len(out_deg), in_off, in_src, out_deg, damping, tolerance, max_iter, mode=self.O.PR_INPLACE,
+                                          err_f64_diff=err_f64_diff)
+        return s, it, err, 1
 
     def bfs(self, out_off, out_tgt, starts, goals=None, share_visited=False, want_depth=False, want_order=False,
             poison=None):
