@@ -425,7 +425,16 @@ def bench_distance_batch(args, torch, x, q, stream, device):
     torch.cuda.synchronize()
     s = e0.elapsed_time(e1) / 1e3 / reps
     algo = P * 4 * x.shape[1]
-    return dict(kernel="cz_distance_batch = distance_pairs_kernel (one hand-written kernel; the whole call is timed)",
+    ceiling = None
+    try:  # this box's HBM under the same access pattern over the same table (cz_hbm_probe: fetch-only kernels)
+        import ctypes as C
+        from cozo_amd import _lib
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        _lib.check(_lib.lib().cz_hbm_probe(C.c_void_p(x.data_ptr()), int(x.shape[0]), int(x.shape[1]) * 4, 0, 0, C.byref(a), C.byref(b)))
+        ceiling = dict(stream_read_gbs=a.value, random_row_fetch_gbs=b.value, frac_of_random_row_fetch=algo / s / 1e9 / b.value if b.value else None)
+    except Exception as e:  # noqa: BLE001
+        ceiling = dict(error=f"{type(e).__name__}: {e}")
+    return dict(kernel="cz_distance_batch = distance_pairs_kernel (one hand-written kernel; the whole call is timed)", measured_ceiling=ceiling,
                 pairs=P, base_rows=int(x.shape[0]), metric="Cosine", ms=s * 1e3, distances_per_s=P / s,
                 roofline=dict(bound="hbm", achieved=algo / s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                               frac=algo / s / 1e9 / HBM_PEAK_GBS, traffic=pmc_traffic("distance_batch", 1, algo) if x.shape[0] == 10_000_000 else None,
@@ -947,7 +956,7 @@ def bench_graph_rules(args, torch, device):
     out["clustering_coefficients"] = entry(dt, int(utgt.size), 4 * int(utgt.size) + 4 * (n + 1) + 12 * n, pmc_key="clustering_coefficients",
                                            triangle_incidences=int(tri.sum()), max_degree=int(deg.max()))
     ones = np.ones(utgt.size, dtype=np.float32)
-    (lab, lp_it, lp_col), dt = timed(lambda: G.label_propagation(uoff, utgt, ones, 10))
+    (lab, lp_it, lp_col), dt = timed(lambda: G.label_propagation(uoff, utgt, ones, 10, symmetric=True))  # (the rule under `undirected: true`)
     out["label_propagation"] = entry(dt, int(utgt.size) * lp_it, lp_it * (8 * int(utgt.size) + 4 * (n + 1) + 8 * n),
                                      pmc_key="label_propagation", iterations=lp_it,
                                      colour_classes=lp_col, labels_left=int(np.unique(lab).size),

@@ -20,7 +20,7 @@ CZ_PR_BLOCKED = 4
 CZ_PR_EXCHANGE_ALLREDUCE = 32
 CZ_PR_OVERLAP_EXCHANGE = 64
 CZ_PR_ERR_F64_DIFF = 128
-CZ_TRI_SYMMETRIC = 512
+CZ_ADJ_SYMMETRIC = 512
 CZ_UNIQUE_ID_BYTES = 128
 CZ_L2, CZ_COSINE, CZ_IP = 0, 1, 2
 CZ_OK, CZ_E_INVALID, CZ_E_NO_DEVICE, CZ_E_HIP, CZ_E_CANCELLED, CZ_E_OOM, CZ_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
@@ -180,7 +180,7 @@ SYMBOLS = {
     "cz_sssp_on": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cz_graph_last_timing": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cz_label_propagation": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, u32p, u32p,
-                                       C.c_void_p]),
+                                       C.c_void_p, C.c_uint32]),
     "cz_closeness": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "cz_betweenness": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
 }

@@ -1273,7 +1273,7 @@ triangles_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
 // tri(c) += m_ac m_bc.  So node v only enumerates pairs of DISTINCT neighbours above itself -- a quarter of the pairs -- tests
 // membership once with the multiplicity (equal range instead of existence), and credits all three corners with atomics
 // (triangles are rare next to pairs: 4 125 incidences against 10^9 pairs on the 10M / 200M uniform graph).
-// Precondition: the adjacency is symmetric with symmetric multiplicities; the caller vouches for it (CZ_TRI_SYMMETRIC) or
+// Precondition: the adjacency is symmetric with symmetric multiplicities; the caller vouches for it (CZ_ADJ_SYMMETRIC) or
 // tri_symmetry_kernel verifies it exactly, and the call falls back to the general kernel otherwise (CZ_TRI_GENERAL=1 forces it).
 __device__ __forceinline__ uint32_t csr_count(const uint32_t *__restrict__ tgt, uint32_t lo, uint32_t hi, uint32_t x) {
     uint32_t l = lo, h = hi;
@@ -1442,14 +1442,14 @@ extern "C" int cz_clustering_coefficients(const uint32_t *offsets, const uint32_
     t_timing.lap(T_UPLOAD);
     bool general = getenv("CZ_TRI_GENERAL") && atoi(getenv("CZ_TRI_GENERAL")) != 0;
     if (!general && E > 0) {  // the oriented count needs a symmetric adjacency without self loops: both are checked EXACTLY, the former
-                              // unless the caller vouches for it (CZ_TRI_SYMMETRIC: the rule, which builds the adjacency that way)
+                              // unless the caller vouches for it (CZ_ADJ_SYMMETRIC: the rule, which builds the adjacency that way)
         cz::DevBuf<uint32_t> d_bad;
         cz::DevBuf<unsigned long long> d_updown;
         CZ_HIP(d_bad.alloc(1));
         CZ_HIP(d_updown.alloc(2));
         CZ_HIP(hipMemsetAsync(d_bad.p, 0, 4, nullptr));
         CZ_HIP(hipMemsetAsync(d_updown.p, 0, 16, nullptr));
-        if (!(flags & CZ_TRI_SYMMETRIC))
+        if (!(flags & CZ_ADJ_SYMMETRIC))
             hipLaunchKernelGGL(tri_symmetry_kernel, dim3(grid_for((uint64_t)N * 16)), dim3(256), 0, nullptr, d_off.p, d_tgt.p, N, d_bad.p,
                                d_updown.p);
         hipLaunchKernelGGL(tri_self_loop_kernel, dim3(grid_for(N)), dim3(256), 0, nullptr, d_off.p, d_tgt.p, N, d_bad.p);
@@ -2061,7 +2061,7 @@ lp_pending_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__
         uint32_t c = 0;
         if (live) {
             const unsigned long long kv = lp_priority(v);
-            for (int side = 0; side < 2; side++) {
+            for (int side = 0; side < (in_off ? 2 : 1); side++) {  // (no transposed adjacency: the graph is symmetric, one side is all)
                 const uint32_t *o = side ? in_off : off, *t = side ? in_src : tgt;
                 const uint32_t e1 = o[v + 1];
                 for (uint32_t e = o[v] + glane; e < e1; e += kSsspLanes) {
@@ -2101,10 +2101,12 @@ lp_colour_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
         if (live) {
             beg[0] = off[v];
             len[0] = off[v + 1] - beg[0];
-            beg[1] = in_off[v];
-            len[1] = in_off[v + 1] - beg[1];
+            if (in_off) {
+                beg[1] = in_off[v];
+                len[1] = in_off[v + 1] - beg[1];
+            }
         }
-        for (int side = 0; side < 2; side++) {
+        for (int side = 0; side < (in_off ? 2 : 1); side++) {
             const uint32_t *t = side ? in_src : tgt;
             uint32_t maxlen = len[side];
 #pragma unroll
@@ -2357,7 +2359,7 @@ lp_update_hub_kernel(const uint32_t *__restrict__ off, const uint32_t *__restric
 
 extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N,
                                     uint64_t E, uint32_t max_iter, uint32_t *labels, uint32_t *iters_run, uint32_t *n_colours,
-                                    const volatile uint8_t *poison) {
+                                    const volatile uint8_t *poison, uint32_t flags) {
     if (iters_run) *iters_run = 0;
     if (n_colours) *n_colours = 0;
     int rc = cz::ensure_device();
@@ -2375,8 +2377,6 @@ extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t 
     CZ_HIP(d_off.alloc((size_t)N + 1));
     CZ_HIP(d_tgt.alloc(E));
     CZ_HIP(d_w.alloc(E));
-    CZ_HIP(d_ioff.alloc((size_t)N + 1));
-    CZ_HIP(d_isrc.alloc(E));
     CZ_HIP(d_colour.alloc(N));
     CZ_HIP(d_labels.alloc(N));
     CZ_HIP(d_order.alloc(N));
@@ -2390,27 +2390,51 @@ extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t 
     }
     hipStream_t s = nullptr;
     t_timing.lap(T_UPLOAD);
-    // ---- the transposed adjacency (sources only, in any order inside a list): the colouring looks at edges in either direction
-    CZ_HIP(hipMemsetAsync(d_cnt.p, 0, ((size_t)N + 1) * 4, s));
+    // ---- the colouring looks at edges in EITHER direction.  On a symmetric adjacency (symmetric multiplicities: what
+    // as_directed_weighted_graph(undirected = true) builds) the in-lists ARE the out-lists, and one side is enough: a node's
+    // pending count is its higher out-entries, and every higher neighbour takes off one per entry of its own list, which is as
+    // many.  The caller may vouch for that (CZ_ADJ_SYMMETRIC); otherwise it is verified exactly (tri_symmetry_kernel: ~E log d
+    // reads) and only an adjacency that is NOT symmetric pays for the transposed one (in-degree histogram + scatter by random
+    // atomics: 16 of the rule's 55 ms on the 10M / 200M graph, round 3).  The labels are the same either way.
     CZ_HIP(hipMemsetAsync(d_flags.p, 0, 16, s));
-    if (E) hipLaunchKernelGGL(lp_indegree_kernel, dim3(grid_for(E)), dim3(kT), 0, s, d_tgt.p, E, N, d_cnt.p, d_flags.p + 2);
-    rc = exclusive_scan(d_cnt.p, d_ioff.p, N + 1, d_flags.p + 3, d_scratch.p, s);
-    if (rc) return rc;
-    CZ_HIP(hipMemsetAsync(d_cnt.p, 0, ((size_t)N + 1) * 4, s));
-    if (E)
-        hipLaunchKernelGGL(lp_transpose_kernel, dim3(grid_for((uint64_t)N * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, N, d_ioff.p,
-                           d_cnt.p, d_isrc.p);
-    {
+    bool symmetric = (flags & CZ_ADJ_SYMMETRIC) != 0;
+    if (!symmetric && E) {
+        cz::DevBuf<unsigned long long> d_updown;
+        CZ_HIP(d_updown.alloc(2));
+        CZ_HIP(hipMemsetAsync(d_updown.p, 0, 16, s));
+        hipLaunchKernelGGL(tri_symmetry_kernel, dim3(grid_for((uint64_t)N * 16)), dim3(256), 0, s, d_off.p, d_tgt.p, N, d_flags.p + 2, d_updown.p);
+        uint32_t bad = 0;
+        unsigned long long updown[2] = {0, 0};
+        CZ_HIP(hipMemcpy(&bad, d_flags.p + 2, 4, hipMemcpyDeviceToHost));
+        CZ_HIP(hipMemcpy(updown, d_updown.p, 16, hipMemcpyDeviceToHost));
+        symmetric = bad == 0 && updown[0] == updown[1];
+        CZ_HIP(hipMemsetAsync(d_flags.p, 0, 16, s));
+    }
+    const uint32_t *c_ioff = nullptr, *c_isrc = nullptr;  // (null: one side)
+    if (!symmetric) {
+        // the transposed adjacency (sources only, in any order inside a list)
+        CZ_HIP(d_ioff.alloc((size_t)N + 1));
+        CZ_HIP(d_isrc.alloc(E));
+        CZ_HIP(hipMemsetAsync(d_cnt.p, 0, ((size_t)N + 1) * 4, s));
+        if (E) hipLaunchKernelGGL(lp_indegree_kernel, dim3(grid_for(E)), dim3(kT), 0, s, d_tgt.p, E, N, d_cnt.p, d_flags.p + 2);
+        rc = exclusive_scan(d_cnt.p, d_ioff.p, N + 1, d_flags.p + 3, d_scratch.p, s);
+        if (rc) return rc;
+        CZ_HIP(hipMemsetAsync(d_cnt.p, 0, ((size_t)N + 1) * 4, s));
+        if (E)
+            hipLaunchKernelGGL(lp_transpose_kernel, dim3(grid_for((uint64_t)N * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, N, d_ioff.p,
+                               d_cnt.p, d_isrc.p);
         uint32_t bad = 0;
         CZ_HIP(hipMemcpy(&bad, d_flags.p + 2, 4, hipMemcpyDeviceToHost));
         if (bad) return cz::set_error(CZ_E_INVALID, "a target is out of range");
+        c_ioff = d_ioff.p;
+        c_isrc = d_isrc.p;
     }
     // ---- colouring
     // (the label and order arrays are not in use yet: they hold this round's and the next round's list of uncoloured nodes)
     uint32_t n_col = 0, coloured = 0;
     uint32_t *list = d_labels.p, *list_next = d_order.p, *pending = d_cnt.p;  // (d_cnt: the transpose is done with its cursors)
     CZ_HIP(hipMemsetAsync(d_flags.p, 0, 4, s));
-    hipLaunchKernelGGL(lp_pending_kernel, dim3(grid_for((uint64_t)N * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, d_ioff.p, d_isrc.p, N,
+    hipLaunchKernelGGL(lp_pending_kernel, dim3(grid_for((uint64_t)N * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, c_ioff, c_isrc, N,
                        pending, d_colour.p, QueueT<uint32_t>{list, d_flags.p});
     uint32_t n_list = 0;
     CZ_HIP(hipMemcpy(&n_list, d_flags.p, 4, hipMemcpyDeviceToHost));
@@ -2419,7 +2443,7 @@ extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t 
         coloured += n_list;
         n_col++;
         CZ_HIP(hipMemsetAsync(d_flags.p, 0, 4, s));
-        hipLaunchKernelGGL(lp_colour_kernel, dim3(grid_for((uint64_t)n_list * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, d_ioff.p, d_isrc.p,
+        hipLaunchKernelGGL(lp_colour_kernel, dim3(grid_for((uint64_t)n_list * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, c_ioff, c_isrc,
                            list, n_list, n_col, pending, d_colour.p, QueueT<uint32_t>{list_next, d_flags.p});
         CZ_HIP(hipMemcpy(&n_list, d_flags.p, 4, hipMemcpyDeviceToHost));
         std::swap(list, list_next);

@@ -834,7 +834,8 @@ class LabelPropagation(FixedRule):
         graph, indices, _ = edges.as_directed_weighted_graph(undirected, True)
         if graph.n == 0:
             return
-        labels, _, _ = _graph.label_propagation(graph.out_offsets, graph.out_targets, graph.out_weights, max_iter, poison=poison.flag)
+        labels, _, _ = _graph.label_propagation(graph.out_offsets, graph.out_targets, graph.out_weights, max_iter, poison=poison.flag,
+                                                symmetric=bool(undirected))  # mirrored rows: symmetric by construction
         poison.check()
         for i in range(graph.n):
             out.put((int(labels[i]), indices[i]))

@@ -229,14 +229,14 @@ def connected_components(off, tgt=None, poison=None):
 
 def clustering_coefficients(off, tgt, poison=None, symmetric=False):
     """cz_clustering_coefficients on the symmetrised out-CSR -> (n_triangles u64 [N], degree u32 [N]).
-    symmetric=True: the caller built the adjacency with as_directed_graph(undirected=True) and vouches for it (CZ_TRI_SYMMETRIC);
+    symmetric=True: the caller built the adjacency with as_directed_graph(undirected=True) and vouches for it (CZ_ADJ_SYMMETRIC);
     otherwise the library verifies the symmetry exactly before it takes the kernel that relies on it."""
     off, tgt = _csr32(off, tgt)
     N = off.size - 1
     tri = np.zeros(N, dtype=np.uint64)
     deg = np.zeros(N, dtype=np.uint32)
     check(_lib.lib().cz_clustering_coefficients(ptr(off), ptr(tgt), N, tgt.size, ptr(tri), ptr(deg), ptr(poison),
-                                                _lib.CZ_TRI_SYMMETRIC if symmetric else 0))
+                                                _lib.CZ_ADJ_SYMMETRIC if symmetric else 0))
     return tri, deg
 
 
@@ -286,15 +286,16 @@ def betweenness(out_off, out_tgt, weights, poison=None):
     return cent
 
 
-def label_propagation(out_off, out_tgt, weights, max_iter=10, poison=None):
-    """cz_label_propagation on the weighted out-CSR -> (labels u32 [N], iterations run, colour classes)"""
+def label_propagation(out_off, out_tgt, weights, max_iter=10, poison=None, symmetric=False):
+    """cz_label_propagation on the weighted out-CSR -> (labels u32 [N], iterations run, colour classes).
+    symmetric=True: the caller vouches that the adjacency is symmetric (undirected = true); otherwise the library finds out"""
     out_off, out_tgt = _csr32(out_off, out_tgt)
     w = np.ascontiguousarray(weights, dtype=np.float32)
     N = out_off.size - 1
     labels = np.empty(N, dtype=np.uint32)
     it, nc = C.c_uint32(0), C.c_uint32(0)
     check(_lib.lib().cz_label_propagation(ptr(out_off), ptr(out_tgt), ptr(w), N, out_tgt.size, int(max_iter), ptr(labels),
-                                          C.byref(it), C.byref(nc), ptr(poison)))
+                                          C.byref(it), C.byref(nc), ptr(poison), _lib.CZ_ADJ_SYMMETRIC if symmetric else 0))
     return labels, it.value, nc.value
 
 

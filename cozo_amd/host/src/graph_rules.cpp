@@ -294,7 +294,7 @@ void ClusteringCoefficients::run(const FixedRulePayload &payload, RegularTempSto
     std::vector<uint64_t> tri(gr.n);
     std::vector<uint32_t> deg(gr.n);
     check_gpu(cz_clustering_coefficients(gr.out_offsets.data(), gr.out_targets.data(), gr.n, gr.edge_count(), tri.data(),
-                                         deg.data(), poison.flag_ptr(), CZ_TRI_SYMMETRIC));  // built two lines up with undirected = true
+                                         deg.data(), poison.flag_ptr(), CZ_ADJ_SYMMETRIC));  // built two lines up with undirected = true
     for (uint32_t i = 0; i < gr.n; i++) {
         const double d = (double)deg[i];
         const double cc = deg[i] < 2 ? 0.0 : 2.0 * (double)tri[i] / (d * (d - 1.0));  // :80-82, :102
@@ -352,7 +352,8 @@ void LabelPropagation::run(const FixedRulePayload &payload, RegularTempStore &ou
     if (gr.n == 0) return;
     std::vector<uint32_t> labels(gr.n);
     check_gpu(cz_label_propagation(gr.out_offsets.data(), gr.out_targets.data(), gr.out_weights.data(), gr.n, gr.edge_count(),
-                                   (uint32_t)std::min<size_t>(max_iter, 0xFFFFFFFFu), labels.data(), nullptr, nullptr, poison.flag_ptr()));
+                                   (uint32_t)std::min<size_t>(max_iter, 0xFFFFFFFFu), labels.data(), nullptr, nullptr, poison.flag_ptr(),
+                                   undirected ? CZ_ADJ_SYMMETRIC : 0u));  // mirrored rows: symmetric by construction
     poison.check();
     for (uint32_t v = 0; v < gr.n; v++) out.put(Tuple{DataValue((int64_t)labels[v]), g.indices[v]});
 }

@@ -13,7 +13,7 @@ pub const CZ_BF_GEMM: u32 = 8;
 pub const CZ_PR_EXCHANGE_ALLREDUCE: u32 = 32;
 pub const CZ_PR_OVERLAP_EXCHANGE: u32 = 64;
 pub const CZ_PR_ERR_F64_DIFF: u32 = 128;
-pub const CZ_TRI_SYMMETRIC: u32 = 512;
+pub const CZ_ADJ_SYMMETRIC: u32 = 512;
 pub const CZ_UNIQUE_ID_BYTES: u32 = 128;
 
 pub const CZ_OK: c_int = 0;
@@ -238,7 +238,7 @@ extern "C" {
     pub fn cz_connected_components_on(g: *const cz_graph, group: *mut u32, n_groups: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_sssp_on(g: *const cz_graph, starts: *const u32, n_starts: u32, dist: *mut c_float, parent: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_label_propagation(out_offsets: *const u32, out_targets: *const u32, weights: *const c_float, n: u32, e: u64,
-                                max_iter: u32, labels: *mut u32, iters_run: *mut u32, n_colours: *mut u32, poison: *const u8) -> c_int;
+                                max_iter: u32, labels: *mut u32, iters_run: *mut u32, n_colours: *mut u32, poison: *const u8, flags: u32) -> c_int;
     pub fn cz_graph_last_timing(upload_ms: *mut c_double, device_ms: *mut c_double, download_ms: *mut c_double) -> c_int;
     pub fn cz_closeness(out_offsets: *const u32, out_targets: *const u32, weights: *const c_float, n: u32, e: u64,
                         centrality: *mut c_double, poison: *const u8) -> c_int;

@@ -360,7 +360,7 @@ impl FixedRule for LabelPropagationGpu {
         check(unsafe {
             cz_label_propagation(g.offsets.as_ptr(), g.targets.as_ptr(), g.weights.as_ptr(), g.n, g.targets.len() as u64,
                                  max_iter.min(u32::MAX as usize) as u32, labels.as_mut_ptr(), std::ptr::null_mut(),
-                                 std::ptr::null_mut(), poison_ptr(&poison))
+                                 std::ptr::null_mut(), poison_ptr(&poison), if undirected { CZ_ADJ_SYMMETRIC } else { 0 })
         }, &poison)?;
         for (idx, label) in labels.into_iter().enumerate() {
             out.put(vec![DataValue::from(label as i64), g.indices[idx].clone()]); // (label, node), :41-44
@@ -744,7 +744,7 @@ impl FixedRule for ClusteringCoefficientsGpu {
         let mut degree = vec![0u32; g.n as usize];
         check(unsafe {
             cz_clustering_coefficients(g.offsets.as_ptr(), g.targets.as_ptr(), g.n, g.targets.len() as u64, n_triangles.as_mut_ptr(),
-                                       degree.as_mut_ptr(), poison_ptr(&poison), CZ_TRI_SYMMETRIC)
+                                       degree.as_mut_ptr(), poison_ptr(&poison), CZ_ADJ_SYMMETRIC)
         }, &poison)?;
         for idx in 0..g.n as usize {
             let (t, d) = (n_triangles[idx], degree[idx]);

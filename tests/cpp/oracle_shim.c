@@ -135,8 +135,10 @@ int cz_betweenness(const uint32_t *out_offsets, const uint32_t *out_targets, con
 }
 
 int cz_label_propagation(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
-                         uint32_t max_iter, uint32_t *labels, uint32_t *iters_run, uint32_t *n_colours, const volatile uint8_t *poison) {
+                         uint32_t max_iter, uint32_t *labels, uint32_t *iters_run, uint32_t *n_colours, const volatile uint8_t *poison,
+                         uint32_t flags) {
     (void)E;
+    (void)flags;
     if (poisoned(poison)) { g_err = "cancelled"; return CZ_E_CANCELLED; }
     uint64_t *off = widen(out_offsets, N);
     uint32_t *colour = (uint32_t *)malloc(sizeof(uint32_t) * (N ? N : 1));

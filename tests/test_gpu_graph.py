@@ -668,6 +668,9 @@ def test_label_propagation_matches_the_fixed_order_execution(oracle, gpu_lib, ca
     # a second run returns the same labels (nothing about the schedule leaks into the result)
     again, _, _ = G.label_propagation(off, tgt, ww, max_iter=10)
     assert np.array_equal(again, labels)
+    if case == "communities":  # symmetric by construction: the caller's word (CZ_ADJ_SYMMETRIC: no check, no transposed adjacency)
+        vouched, it_v, k_v = G.label_propagation(off, tgt, ww, max_iter=10, symmetric=True)
+        assert np.array_equal(vouched, labels) and it_v == iters and k_v == n_col
     one, it1, _ = G.label_propagation(off, tgt, ww, max_iter=1)
     assert it1 == 1 and np.array_equal(one, oracle.label_propagation(n, off, tgt, ww, 1)[0])
 

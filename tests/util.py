@@ -111,7 +111,7 @@ class OracleGraphBackend:
             dist[si], parent[si] = self.O.dijkstra(n, out_off, out_tgt, weights, int(s))
         return dist, parent
 
-    def label_propagation(self, out_off, out_tgt, weights, max_iter=10, poison=None):
+    def label_propagation(self, out_off, out_tgt, weights, max_iter=10, poison=None, symmetric=False):
         n = len(out_off) - 1
         colour, k = self.O.lp_colouring(n, out_off, out_tgt)
         labels, it = self.O.label_propagation(n, out_off, out_tgt, weights, max_iter)
