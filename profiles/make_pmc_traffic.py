@@ -36,6 +36,9 @@ SPEC = {
 }
 
 
+RANDOM_ACCESS = {"bfs", "sssp", "connected_components", "clustering_coefficients", "label_propagation"}
+
+
 def load(round_dir, tag, counter):
     per_kernel = collections.defaultdict(list)
     for f in glob.glob(os.path.join(round_dir, f"pmc_{tag}_{counter}", "**", "*counter_collection.csv"), recursive=True):
@@ -95,6 +98,9 @@ def main():
         algo = sp["algo"] or algos.get(key)
         out[key] = dict(bytes_per_launch=int(total), parts_KiB={k: round(v, 1) for k, v in parts.items()}, algorithmic_bytes=algo,
                         source_hash=bench.kernel_source_hash(key))
+        if key in RANDOM_ACCESS:  # the x2 is calibrated on wide coalesced streams only
+            out[key]["calibration"] = ("UPPER BOUND: FETCH_SIZE x 2 is calibrated on 128-byte coalesced requests; these kernels issue 4- / 8-byte "
+                                       "random accesses, for which the guide gives no factor -- good to about 2x, not a measurement")
         print(f"{key}: {total / 1e9:.3f} GB per launch" + (f" = {total / algo:.3f} x the algorithmic bytes" if algo else ""))
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

@@ -47,9 +47,9 @@ else:
         if rule == "cc":
             G.connected_components(uoff, utgt)
         elif rule == "tri":
-            G.clustering_coefficients(uoff, utgt)
+            G.clustering_coefficients(uoff, utgt, symmetric=True)  # what the rule (and bench.py) passes
         else:
-            G.label_propagation(uoff, utgt, ones, 10)
+            G.label_propagation(uoff, utgt, ones, 10, symmetric=True)
         print(rule, "device ms", G.last_timing()[1], flush=True)
 print("edges", otgt.size, "runs", runs)
 if rule == "sssp" and os.environ.get("SWEEP_DELTA"):
