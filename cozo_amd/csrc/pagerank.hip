@@ -40,7 +40,7 @@
 #include <mutex>
 #include <vector>
 
-#include <rocprim/rocprim.hpp>
+#include "sort_scan.cuh"
 
 #include "common.h"
 #include "exact_sum.cuh"
@@ -1041,7 +1041,6 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
 
     PoolBuf<RowBlock> d_kblocks;
     PoolBuf<uint32_t> d_kchunk, keys_in, keys_out, idx_in, idx_out, d_keyptr, d_bad;
-    PoolBuf<char> d_tmp;
     CZ_HIP(d_kblocks.alloc(key_blocks.size()));
     CZ_HIP(d_kchunk.alloc(key_blocks.size()));
     CZ_HIP(hipMemcpy(d_kblocks.p, key_blocks.data(), key_blocks.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
@@ -1057,16 +1056,20 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
                        p->d_off, p->d_src, wlog, S, n_keys, keys_in.p, idx_in.p);
     unsigned bits = 1;
     while ((1ull << bits) <= n_keys) bits++;
-    size_t tmp_bytes = 0;
-    CZ_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in.p, keys_out.p, idx_in.p, idx_out.p, (size_t)E, 0u, bits,
-                                     (hipStream_t) nullptr));
-    CZ_HIP(d_tmp.alloc(tmp_bytes));
-    CZ_HIP(rocprim::radix_sort_pairs((void *)d_tmp.p, tmp_bytes, keys_in.p, keys_out.p, idx_in.p, idx_out.p, (size_t)E, 0u,
-                                     bits, (hipStream_t) nullptr));
+    {   // stable sort of the (key, edge index) pairs by key: csrc/sort_scan.cuh (own kernels since round 4)
+        PoolBuf<uint32_t> d_sort;
+        CZ_HIP(d_sort.alloc(czsort::sort_scratch_words(E)));
+        bool in_a = true;
+        if (int src_rc = czsort::radix_sort_pairs_u32(keys_in.p, idx_in.p, keys_out.p, idx_out.p, E, bits, d_sort.p, nullptr, &in_a)) return src_rc;
+        if (in_a) {  // an even number of passes: the result sits in the input arrays
+            std::swap(keys_in.p, keys_out.p);
+            std::swap(idx_in.p, idx_out.p);
+        }
+        CZ_HIP(hipStreamSynchronize(nullptr));  // d_sort dies with this scope
+    }
     st.lap("keys + radix sort");
     keys_in.reset();
     idx_in.reset();
-    d_tmp.reset();
     hipLaunchKernelGGL(pb_keyptr_kernel, dim3((n_keys + 256) / 256), dim3(256), 0, nullptr, keys_out.p, (uint32_t)E, n_keys,
                        d_keyptr.p);
     std::vector<uint32_t> key_ptr((size_t)n_keys + 1);
@@ -1243,33 +1246,21 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
             CZ_HIP(plan_alloc((void **)&p->d_rowid, (size_t)rows * 4));
             hipLaunchKernelGGL(pr_row_class_kernel, dim3(2048), dim3(256), 0, nullptr, p->d_off, rows, heavy, drop_empty ? 1 : 0,
                                f_light.p, f_heavy.p, f_empty.p, (uint32_t *)nullptr);
-            size_t tb = 0, need = 0;
-            CZ_HIP(rocprim::exclusive_scan(nullptr, need, f_light.p, p_light.p, 0u, (size_t)rows, rocprim::plus<uint32_t>(), (hipStream_t) nullptr));
-            tb = need;
-            CZ_HIP(rocprim::exclusive_scan(nullptr, need, new_len.p, new_off.p, 0u, (size_t)rows + 1, rocprim::plus<uint32_t>(), (hipStream_t) nullptr));
-            tb = std::max(tb, need);
-            if (n_heavy) {
-                CZ_HIP(rocprim::radix_sort_pairs(nullptr, need, hkey_in.p, hkey_out.p, hrow_in.p, p->d_rowid + n_light, (size_t)n_heavy, 0u, 32u,
-                                                 (hipStream_t) nullptr));
-                tb = std::max(tb, need);
-            }
-            CZ_HIP(tmp.alloc(tb));
-            for (auto pr : {std::make_pair(&f_light, &p_light), std::make_pair(&f_heavy, &p_heavy), std::make_pair(&f_empty, &p_empty)}) {
-                need = tb;
-                CZ_HIP(rocprim::exclusive_scan((void *)tmp.p, need, pr.first->p, pr.second->p, 0u, (size_t)rows, rocprim::plus<uint32_t>(),
-                                               (hipStream_t) nullptr));
-            }
+            // scans and the sort of the heavy rows by (inverted length): csrc/sort_scan.cuh (own kernels since round 4)
+            PoolBuf<uint32_t> d_ss, hrow_out;
+            CZ_HIP(d_ss.alloc(std::max(czsort::scan_scratch_words((uint64_t)rows + 1), czsort::sort_scratch_words(n_heavy))));
+            CZ_HIP(hrow_out.alloc(n_heavy));
+            for (auto pr : {std::make_pair(&f_light, &p_light), std::make_pair(&f_heavy, &p_heavy), std::make_pair(&f_empty, &p_empty)})
+                if (int src_rc = czsort::exclusive_scan_u32(pr.first->p, pr.second->p, rows, d_ss.p, nullptr)) return src_rc;
             hipLaunchKernelGGL(pr_row_place_kernel, dim3(2048), dim3(256), 0, nullptr, p->d_off, rows, f_heavy.p, f_empty.p, p_light.p,
                                p_heavy.p, p_empty.p, n_light, n_heavy, p->d_rowid, hkey_in.p, hrow_in.p);
             if (n_heavy) {
-                need = tb;
-                CZ_HIP(rocprim::radix_sort_pairs((void *)tmp.p, need, hkey_in.p, hkey_out.p, hrow_in.p, p->d_rowid + n_light, (size_t)n_heavy, 0u,
-                                                 32u, (hipStream_t) nullptr));
+                bool in_a = true;
+                if (int src_rc = czsort::radix_sort_pairs_u32(hkey_in.p, hrow_in.p, hkey_out.p, hrow_out.p, n_heavy, 32u, d_ss.p, nullptr, &in_a)) return src_rc;
+                CZ_HIP(hipMemcpyAsync(p->d_rowid + n_light, in_a ? hrow_in.p : hrow_out.p, (size_t)n_heavy * 4, hipMemcpyDeviceToDevice, nullptr));
             }
             hipLaunchKernelGGL(pr_row_len_kernel, dim3(2048), dim3(256), 0, nullptr, p->d_off, p->d_rowid, rows, new_len.p);
-            need = tb;
-            CZ_HIP(rocprim::exclusive_scan((void *)tmp.p, need, new_len.p, new_off.p, 0u, (size_t)rows + 1, rocprim::plus<uint32_t>(),
-                                           (hipStream_t) nullptr));
+            if (int src_rc = czsort::exclusive_scan_u32(new_len.p, new_off.p, rows + 1, d_ss.p, nullptr)) return src_rc;
             hipLaunchKernelGGL(pr_permute_src_kernel, dim3((rows + 255) / 256), dim3(256), 0, nullptr, p->d_off, new_off.p, p->d_rowid,
                                rows, p->d_src, new_src.p);
             perm_off.resize((size_t)rows + 1);

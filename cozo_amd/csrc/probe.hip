@@ -9,6 +9,7 @@
 // difference is the box (the same binary measured 0.64-0.76 of the nominal peak on different GPUs).
 #include "common.h"
 #include "exact_sum.cuh"
+#include "sort_scan.cuh"
 
 namespace {
 
@@ -157,5 +158,33 @@ extern "C" int cz_debug_seq_sum(const float *terms, const uint64_t *row_off, con
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "debug_seq_sum launch: %s", hipGetErrorString(e));
     CZ_HIP(hipMemcpy(out, d_o.p, (size_t)n_rows * 4, hipMemcpyDeviceToHost));
+    return CZ_OK;
+}
+
+// ---- test hook: the plan build's own stable radix sort and scan (csrc/sort_scan.cuh) on arbitrary pairs ------------------------
+extern "C" int cz_debug_sort_pairs(const uint32_t *keys, const uint32_t *vals, uint64_t n, uint32_t bits, uint32_t *out_keys, uint32_t *out_vals,
+                                   uint32_t *out_scan /* [n] exclusive scan of vals, or NULL */) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if (n == 0) return CZ_OK;
+    if (!keys || !vals || !out_keys || !out_vals) return cz::set_error(CZ_E_INVALID, "null buffer");
+    if (bits == 0 || bits > 32) return cz::set_error(CZ_E_INVALID, "bits must be in 1..32");
+    cz::DevBuf<uint32_t> ka, va, kb, vb, scratch;
+    CZ_HIP(ka.alloc(n));
+    CZ_HIP(va.alloc(n));
+    CZ_HIP(kb.alloc(n));
+    CZ_HIP(vb.alloc(n));
+    CZ_HIP(scratch.alloc(std::max(czsort::sort_scratch_words(n), czsort::scan_scratch_words(n))));
+    CZ_HIP(hipMemcpy(ka.p, keys, n * 4, hipMemcpyHostToDevice));
+    CZ_HIP(hipMemcpy(va.p, vals, n * 4, hipMemcpyHostToDevice));
+    if (out_scan) {
+        if (n >= 0xFFFFFFFFull) return cz::set_error(CZ_E_UNSUPPORTED, "scan of at most 2^32 - 2 entries");
+        if ((rc = czsort::exclusive_scan_u32(va.p, vb.p, (uint32_t)n, scratch.p, nullptr))) return rc;
+        CZ_HIP(hipMemcpy(out_scan, vb.p, n * 4, hipMemcpyDeviceToHost));
+    }
+    bool in_a = true;
+    if ((rc = czsort::radix_sort_pairs_u32(ka.p, va.p, kb.p, vb.p, n, bits, scratch.p, nullptr, &in_a))) return rc;
+    CZ_HIP(hipMemcpy(out_keys, in_a ? ka.p : kb.p, n * 4, hipMemcpyDeviceToHost));
+    CZ_HIP(hipMemcpy(out_vals, in_a ? va.p : vb.p, n * 4, hipMemcpyDeviceToHost));
     return CZ_OK;
 }

@@ -240,12 +240,16 @@ def clustering_coefficients(off, tgt, poison=None, symmetric=False):
     return tri, deg
 
 
-def sssp(out_off, out_tgt, weights, starts, poison=None):
-    """cz_sssp; `out_off` may be a DeviceGraph uploaded with weights (then out_tgt / weights are ignored): cz_sssp_on"""
+def sssp(out_off, out_tgt, weights, starts, poison=None, out=None):
+    """cz_sssp; `out_off` may be a DeviceGraph uploaded with weights (then out_tgt / weights are ignored): cz_sssp_on.
+    out: a dict holding the ("dist", "parent") arrays of an earlier call with the same shapes, to be written into again (like bfs)"""
     if isinstance(out_off, DeviceGraph):
         starts = _u32(starts)
-        dist = np.empty((starts.size, out_off.n), dtype=np.float32)
-        parent = np.empty((starts.size, out_off.n), dtype=np.uint32)
+        shape = (starts.size, out_off.n)
+        dist = out.get("dist") if out is not None and getattr(out.get("dist"), "shape", None) == shape else np.empty(shape, dtype=np.float32)
+        parent = out.get("parent") if out is not None and getattr(out.get("parent"), "shape", None) == shape else np.empty(shape, dtype=np.uint32)
+        if out is not None:
+            out["dist"], out["parent"] = dist, parent
         check(_lib.lib().cz_sssp_on(out_off._h, ptr(starts), starts.size, ptr(dist), ptr(parent), ptr(poison)))
         return dist, parent
     out_off, out_tgt = _csr32(out_off, out_tgt)

@@ -78,6 +78,11 @@ int cz_hbm_probe(const void *table, uint64_t rows, uint32_t row_bytes, uint64_t 
  * non-negative finite terms never reach (negative terms, inf / nan, denormal sums ...) are tested on the device. */
 int cz_debug_seq_sum(const float *terms, const uint64_t *row_off, const float *init, uint32_t n_rows, int lanes, int per_lane,
                      float *out);
+/* TEST HOOK: the PageRank plan build's own device primitives (csrc/sort_scan.cuh; no library sort / scan on the product path):
+ * a STABLE sort of n (key, value) pairs by the low `bits` bits of the key (keys < 2^bits), and the exclusive scan of `vals`
+ * (out_scan, optional).  Host pointers. */
+int cz_debug_sort_pairs(const uint32_t *keys, const uint32_t *vals, uint64_t n, uint32_t bits, uint32_t *out_keys, uint32_t *out_vals,
+                        uint32_t *out_scan);
 
 /* =====================================================================================
  * Vectors / HNSW           replaces: runtime/hnsw.rs

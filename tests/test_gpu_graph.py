@@ -840,3 +840,24 @@ def test_exact_sum_fallback_paths_on_the_device(gpu_lib, lanes, per_lane):
     want = np.array([_seq_sum_f32(r, s0) for r, s0 in zip(rows, init)], dtype=np.float32)
     bad = [i for i in range(len(rows)) if not _same_f32(got[i], want[i])]
     assert not bad, [(i, rows[i].size, float(init[i]), got[i], want[i]) for i in bad[:5]]
+
+
+@pytest.mark.parametrize("n,bits", [(1, 1), (255, 8), (4096, 9), (4097, 16), (100_003, 20), (3_000_000, 11), (700_001, 32)])
+def test_plan_build_sort_and_scan_primitives(gpu_lib, n, bits):
+    """csrc/sort_scan.cuh (round 4: the PageRank plan build's own kernels instead of rocprim's): the radix sort must be STABLE --
+    inside a (chunk, slice) key the edges have to stay in (row, source) order -- and the scan exact, ragged tiles included."""
+    from cozo_amd import _lib
+    rng = np.random.default_rng(n + bits)
+    keys = (rng.integers(0, 1 << min(bits, 31), n, dtype=np.uint64) * (2 if bits == 32 else 1) % (1 << bits)).astype(np.uint32)
+    if n > 1000:
+        keys[: n // 3] = keys[0]  # a long run of one key: the whole tile in one digit
+    vals = np.arange(n, dtype=np.uint32)  # the original position: stability shows in the values
+    ok, ov, scan = np.empty(n, np.uint32), np.empty(n, np.uint32), np.empty(n, np.uint32)
+    small = (rng.integers(0, 7, n)).astype(np.uint32)
+    _lib.check(_lib.lib().cz_debug_sort_pairs(_lib.ptr(keys), _lib.ptr(small), n, bits, _lib.ptr(ok), _lib.ptr(ov), _lib.ptr(scan)))
+    want_scan = np.concatenate([[0], np.cumsum(small.astype(np.uint64))[:-1]]).astype(np.uint32)
+    assert np.array_equal(scan, want_scan)
+    _lib.check(_lib.lib().cz_debug_sort_pairs(_lib.ptr(keys), _lib.ptr(vals), n, bits, _lib.ptr(ok), _lib.ptr(ov), None))
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(ok, keys[order])
+    assert np.array_equal(ov, vals[order]), "the sort must keep equal keys in their original order"
