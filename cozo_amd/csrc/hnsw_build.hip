@@ -927,8 +927,8 @@ int check_build_args(uint32_t dim, int metric, uint32_t m, uint32_t ef_construct
     if (metric < CZ_L2 || metric > CZ_IP) return cz::set_error(CZ_E_INVALID, "bad metric %d", metric);
     if (m < 2) return cz::set_error(CZ_E_INVALID, "m must be >= 2");  // level_multiplier = 1/ln(m)
     if (2 * m > 192) return cz::set_error(CZ_E_UNSUPPORTED, "m = %u: m_max0 = 2m must be <= 192 for the GPU build", m);
-    if (ef_construction == 0 || ef_construction > 1024)
-        return cz::set_error(CZ_E_UNSUPPORTED, "ef_construction must be in 1..1024");
+    if (ef_construction == 0) return cz::set_error(CZ_E_INVALID, "ef_construction must be > 0");
+    // (no other limit than the LDS the lists take, checked where they are sized: ~4 400 entries next to a 768-d vector; round 3: 1 024)
     Shape sh = shape_of(dim);
     if (sh.lpv == 64 && sh.iters > 8) return cz::set_error(CZ_E_UNSUPPORTED, "GPU index construction supports dim <= 2048");
     return CZ_OK;

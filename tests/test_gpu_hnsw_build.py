@@ -15,6 +15,7 @@ SEQ_CASES = [
     (500, 100, "Cosine", 1, 8, 40, False, "lowrank"),
     (400, 768, "Cosine", 1, 4, 24, True, "lowrank"),
     (600, 130, "IP", 2, 5, 25, False, "normal"),
+    (1500, 20, "L2", 0, 6, 1200, False, "uniform"),  # ef_construction beyond round 3's 1 024: the ranked merge in the build kernels
 ]
 
 
