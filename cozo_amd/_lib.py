@@ -140,6 +140,7 @@ SYMBOLS = {
     "cz_pagerank_inplace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_double, C.c_uint32,
                                       C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_uint32),
                                       C.c_void_p]),
+    "cz_comm_multi_shutdown": (None, []),
     "cz_pagerank_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_double,
                                     C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, u32p, f64p, C.c_void_p]),
     "cz_bfs_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstring>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -379,6 +380,56 @@ extern "C" int cz_pagerank_sharded(cz_comm *comm, cz_pagerank_plan *plan, uint32
     return rc;
 }
 
+// The communicators of the single-process forms (cz_pagerank_multi, cz_{bfs,sssp,connected_components}_multi): ncclCommInitAll costs
+// ~0.5 s even for ONE device (measured, round 4: every *_multi call on a 200k-node graph took 538 ms), so a set is created on the first
+// call for a device count and kept for the life of the process (cz_shutdown destroys them).  The lock is held for the whole call: one
+// collective job per device set at a time.  A call that failed drops its set -- the next one starts from fresh communicators.
+namespace {
+struct MultiComms {
+    std::mutex mu;
+    std::map<int, std::vector<ncclComm_t>> by_world;
+};
+MultiComms &multi_comms() {
+    static MultiComms m;
+    return m;
+}
+int multi_comms_get(Rccl *R, int world, std::vector<ncclComm_t> **out) {  // caller holds multi_comms().mu
+    auto &m = multi_comms().by_world;
+    auto it = m.find(world);
+    if (it == m.end()) {
+        std::vector<int> devs(world);
+        for (int i = 0; i < world; i++) devs[i] = i;
+        std::vector<ncclComm_t> comms(world, nullptr);
+        CZ_NCCL(R, R->CommInitAll(comms.data(), world, devs.data()));
+        it = m.emplace(world, std::move(comms)).first;
+    }
+    *out = &it->second;
+    return CZ_OK;
+}
+void multi_comms_drop(Rccl *R, int world) {  // caller holds the lock
+    auto &m = multi_comms().by_world;
+    auto it = m.find(world);
+    if (it == m.end()) return;
+    if (!getenv("CZ_COMM_NO_DESTROY"))
+        for (int r = 0; r < world; r++) {
+            (void)hipSetDevice(r);
+            if (it->second[r]) (void)R->CommDestroy(it->second[r]);
+        }
+    m.erase(it);
+    (void)cz::ensure_device();
+}
+}  // namespace
+
+extern "C" void cz_comm_multi_shutdown(void) {
+    std::lock_guard<std::mutex> lk(multi_comms().mu);
+    if (multi_comms().by_world.empty()) return;  // (RCCL is not even loaded then)
+    Rccl *R = nullptr;
+    if (need_rccl(&R)) return;
+    std::vector<int> worlds;
+    for (auto &kv : multi_comms().by_world) worlds.push_back(kv.first);
+    for (int w : worlds) multi_comms_drop(R, w);
+}
+
 // One process, n_gpus devices: rows split evenly, one host thread per GPU, one RCCL communicator per GPU (ncclCommInitAll).
 extern "C" int cz_pagerank_multi(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N,
                                  uint64_t E, float damping, double tolerance, uint32_t max_iter, int n_gpus, uint32_t flags,
@@ -399,8 +450,10 @@ extern "C" int cz_pagerank_multi(const uint32_t *in_offsets, const uint32_t *in_
     const uint32_t per = (uint32_t)(((uint64_t)N + world - 1) / world);
     std::vector<int> devs(world);
     for (int i = 0; i < world; i++) devs[i] = i;
-    std::vector<ncclComm_t> comms(world, nullptr);
-    CZ_NCCL(R, R->CommInitAll(comms.data(), world, devs.data()));
+    std::lock_guard<std::mutex> comms_lock(multi_comms().mu);
+    std::vector<ncclComm_t> *comms_p = nullptr;
+    if ((rc = multi_comms_get(R, world, &comms_p))) return rc;
+    std::vector<ncclComm_t> &comms = *comms_p;
     std::vector<int> rcs(world, CZ_OK);
     std::vector<std::string> msgs(world);
     std::vector<uint32_t> its(world, 0);
@@ -475,14 +528,12 @@ extern "C" int cz_pagerank_multi(const uint32_t *in_offsets, const uint32_t *in_
     for (int r = 1; r < world; r++) th.emplace_back(worker, r);
     worker(0);
     for (auto &t : th) t.join();
-    if (!getenv("CZ_COMM_NO_DESTROY"))
-        for (int r = 0; r < world; r++) {
-            (void)hipSetDevice(devs[r]);
-            (void)R->CommDestroy(comms[r]);
-        }
     (void)cz::ensure_device();
     for (int r = 0; r < world; r++)
-        if (rcs[r]) return cz::set_error(rcs[r], "GPU %d: %s", r, msgs[r].c_str());
+        if (rcs[r]) {
+            multi_comms_drop(R, world);  // (a failed collective job: do not trust its communicators again)
+            return cz::set_error(rcs[r], "GPU %d: %s", r, msgs[r].c_str());
+        }
     if (iters_run) *iters_run = its[0];
     if (final_err) *final_err = errs[0];
     return CZ_OK;
@@ -506,8 +557,10 @@ int run_on_devices(int n_gpus, F fn /* int(int rank, cz_comm *comm) */) {
     if ((rc = need_rccl(&R))) return rc;
     std::vector<int> devs(n_gpus);
     for (int i = 0; i < n_gpus; i++) devs[i] = i;
-    std::vector<ncclComm_t> comms(n_gpus, nullptr);
-    CZ_NCCL(R, R->CommInitAll(comms.data(), n_gpus, devs.data()));
+    std::lock_guard<std::mutex> comms_lock(multi_comms().mu);
+    std::vector<ncclComm_t> *comms_p = nullptr;
+    if ((rc = multi_comms_get(R, n_gpus, &comms_p))) return rc;
+    std::vector<ncclComm_t> &comms = *comms_p;
     std::vector<int> rcs(n_gpus, CZ_OK);
     std::vector<std::string> msgs(n_gpus);
     auto worker = [&](int r) {
@@ -530,14 +583,12 @@ int run_on_devices(int n_gpus, F fn /* int(int rank, cz_comm *comm) */) {
     for (int r = 1; r < n_gpus; r++) th.emplace_back(worker, r);
     worker(0);
     for (auto &t : th) t.join();
-    if (!getenv("CZ_COMM_NO_DESTROY"))
-        for (int r = 0; r < n_gpus; r++) {
-            (void)hipSetDevice(devs[r]);
-            (void)R->CommDestroy(comms[r]);
-        }
     (void)cz::ensure_device();
     for (int r = 0; r < n_gpus; r++)
-        if (rcs[r]) return cz::set_error(rcs[r], "GPU %d: %s", r, msgs[r].c_str());
+        if (rcs[r]) {
+            multi_comms_drop(R, n_gpus);  // (a failed collective job: do not trust its communicators again)
+            return cz::set_error(rcs[r], "GPU %d: %s", r, msgs[r].c_str());
+        }
     return CZ_OK;
 }
 

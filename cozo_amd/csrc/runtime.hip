@@ -66,7 +66,11 @@ int cz_init(int device) {
     return cz::init_device(device);
 }
 
-void cz_shutdown(void) { cz::g_device.store(-1); }
+void cz_comm_multi_shutdown(void);  // comm.hip: the communicators the single-process *_multi forms keep between calls
+void cz_shutdown(void) {
+    cz_comm_multi_shutdown();
+    cz::g_device.store(-1);
+}
 
 int cz_device_count(void) {
     int n = 0;

@@ -354,6 +354,9 @@ int cz_pagerank_sharded_overlapped(cz_comm *comm, cz_pagerank_plan *plan_first, 
 int cz_pagerank_multi(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N,
                       uint64_t E, float damping, double tolerance, uint32_t max_iter, int n_gpus, uint32_t flags,
                       float *scores, uint32_t *iters_run, double *final_err, const volatile uint8_t *poison);
+/* The single-process forms (cz_pagerank_multi, cz_*_multi) keep their RCCL communicators between calls (creating a set costs ~0.5 s
+ * even for one device); cz_shutdown releases them, or this on its own. */
+void cz_comm_multi_shutdown(void);
 /* hnsw_knn over an index partitioned into one independent sub-index per rank (BASELINE.json configs[3]), collectively:
  * rank 0's `queries_dev` [B][dim] are broadcast, every rank searches ITS shard with the same k / ef, the per-shard lists
  * are all-gathered (B * k * 16 bytes per rank) and merged by (distance, id) on every rank.

@@ -193,6 +193,7 @@ extern "C" {
     pub fn cz_pagerank_sharded_overlapped(comm: *mut cz_comm, plan_first: *mut cz_pagerank_plan, plan_second: *mut cz_pagerank_plan,
                                           rows_per_rank: u32, half_rows: u32, tolerance: c_double, max_iter: u32, iters_run: *mut u32,
                                           final_err: *mut c_double, poison: *const u8, stream: *mut c_void) -> c_int;
+    pub fn cz_comm_multi_shutdown();
     pub fn cz_pagerank_multi(in_offsets: *const u32, in_sources: *const u32, out_degree: *const u32, n: u32, e: u64,
                              damping: c_float, tolerance: c_double, max_iter: u32, n_gpus: c_int, flags: u32,
                              scores: *mut c_float, iters_run: *mut u32, final_err: *mut c_double, poison: *const u8) -> c_int;
