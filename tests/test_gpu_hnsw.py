@@ -99,7 +99,8 @@ def case(request, oracle, gpu_lib):
 
 # (ef > 512: the ranked merge; ef > 1 024 and k > 1 024: beyond round 3's cap -- the list outgrows the index on the small cases,
 #  i.e. every node ends up in it, and on the 3 000-node case ef = 2 500 evicts)
-@pytest.mark.parametrize("ef,k", [(1, 1), (10, 10), (64, 10), (200, 50), (700, 10), (1024, 1000), (1100, 10), (2500, 1500), (4096, 10)])
+@pytest.mark.parametrize("ef,k", [(1, 1), (10, 10), (64, 10), (200, 50), (512, 512), (513, 10), (700, 10), (1024, 1000), (1025, 1025), (1100, 10),
+                                  (2049, 7), (2500, 1500), (4096, 10)])
 def test_knn_bitexact_with_gpu_order_oracle(case, oracle, ef, k):
     from cozo_amd.hnsw import HnswSearch
     ids, dist, cnt, nd = case["gix"].hnsw_knn_batch(case["q"], HnswSearch(k=k, ef=ef), with_n_dist=True)
