@@ -7,7 +7,7 @@ NAME=$1; shift
 SRC=${SRC:-$R/cozo_amd/csrc}
 mkdir -p $R/scratch/lib/obj_$NAME
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-value $*"
-for f in runtime hnsw_api hnsw_build graph pagerank comm knn_gemm; do
+for f in $(cd $SRC && ls *.hip | sed "s/\.hip$//"); do
   /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.hip -o $R/scratch/lib/obj_$NAME/$f.o &
 done
 wait
