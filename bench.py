@@ -965,6 +965,22 @@ def bench_graph_rules(args, torch, device):
                                      what="one fixed execution of the reference's randomised loop (include/cozo_gpu.h); device_ms "
                                           "includes the colouring and the class lists")
     del ones, lab, tri, deg
+    # What these rules are bounded by is not HBM bytes but independent random accesses to one word of a per-node array (the HBM
+    # fractions above price bytes no schedule gets down to).  cz_random_access_probe measures what THIS box sustains on that
+    # pattern over an array of the same shape; `random_frac` = the rule's edge visits per device-second over it (a visit = at least
+    # one such access: BFS / CC / LabelPropagation read a 4-byte word per edge, SSSP issues an 8-byte atomicMin per relaxation, and
+    # re-expands 1.7 x the edges on this graph).
+    try:
+        l4, a4 = G.random_access_probe(n, 4)
+        l8, a8 = G.random_access_probe(n, 8)
+        out["random_access"] = dict(what=f"1e9 accesses/s to random words of a {n}-word array on this box (cz_random_access_probe)",
+                                    loads_4B=l4, atomic_min_4B=a4, loads_8B=l8, atomic_min_8B=a8)
+        for name, ceil in (("bfs", l4), ("connected_components", l4), ("sssp", a8), ("label_propagation", l4)):
+            eps = out[name].get("edges_per_s_device")
+            if eps and ceil > 0:
+                out[name]["random_frac"] = eps / (ceil * 1e9)
+    except Exception as e:  # noqa: BLE001
+        out["random_access"] = dict(error=f"{type(e).__name__}: {e}")
     # BetweennessCentrality: SSSP from EVERY node + path counts over the tight edges, all on the device (a 20k-node graph:
     # 4e8 (source, node) pairs; the reference enumerates paths, so there is no CPU figure at this size)
     nb, eb = 20_000, 200_000

@@ -82,6 +82,7 @@ SYMBOLS = {
     "cz_debug_sort_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cz_debug_seq_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
     "cz_hbm_probe": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "cz_random_access_probe": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cz_hnsw_index_create": (C.c_int, [C.POINTER(HnswDesc), C.c_void_p, C.POINTER(C.c_void_p)]),
     "cz_hnsw_index_destroy": (None, [C.c_void_p]),
     "cz_hnsw_index_bytes": (C.c_uint64, [C.c_void_p]),

@@ -796,10 +796,10 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
 // profiling builds only: total shader-clock cycles thread 0 of every workgroup spent per phase since the last reset
 extern "C" int cz_debug_phase_cycles(unsigned long long *out, int reset) {
     CZ_HIP(hipDeviceSynchronize());
-    CZ_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(czh::cz_phase_cycles), 64));
+    CZ_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(czh::cz_phase_cycles), 96));
     if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        CZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(czh::cz_phase_cycles), z, 64));
+        unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        CZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(czh::cz_phase_cycles), z, 96));
     }
     return CZ_OK;
 }

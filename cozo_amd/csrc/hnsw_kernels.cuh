@@ -28,12 +28,12 @@ using namespace czd;
 // Phase timing (profiling builds only: -DCZ_PHASE_TIMING, see scratch/phase_prof.sh): thread 0 of every workgroup
 // stamps the shader clock at the phase boundaries of the level-0 loop and the totals are added up per launch.
 #ifdef CZ_PHASE_TIMING
-__device__ unsigned long long cz_phase_cycles[8];
-#define CZ_PH_DECL unsigned long long ph_t0 = 0, ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+__device__ unsigned long long cz_phase_cycles[12];
+#define CZ_PH_DECL unsigned long long ph_t0 = 0, ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define CZ_PH_START() do { if (tid == 0) ph_t0 = clock64(); } while (0)
 #define CZ_PH_MARK(i) do { if (tid == 0) { unsigned long long t_ = clock64(); if (ph_t0) ph_acc[i] += t_ - ph_t0; ph_t0 = t_; } } while (0)
 #define CZ_PH_COUNT(i, v) do { if (tid == 0) ph_acc[i] += (v); } while (0)
-#define CZ_PH_FLUSH() do { if (tid == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&cz_phase_cycles[i_], ph_acc[i_]); } while (0)
+#define CZ_PH_FLUSH() do { if (tid == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd(&cz_phase_cycles[i_], ph_acc[i_]); } while (0)
 #else
 #define CZ_PH_DECL
 #define CZ_PH_START() do {} while (0)
@@ -685,8 +685,8 @@ struct Searcher {
     // limit).  Now: (a) the eligible entries are compacted; (b) thread e ranks entry e inside the batch (<= n reads) and finds
     // its lower bound in W by bisection (log2 cnt reads): final position = lower bound + rank; the lower bounds, stored by rank,
     // are ascending; (c) a W entry at j moves up by the number of lower bounds <= j -- a bisection over <= 256 sorted words --
-    // and since every move goes UP, W is shifted in place chunk by chunk from the top, one entry per thread and chunk, two
-    // barriers per chunk, and only the chunks at or above the first insertion point are touched; (d) the new entries drop into
+    // and since every move goes UP, W is shifted in place block by block from the top, four entries per thread and one barrier
+    // per block, and only the blocks at or above the first insertion point are touched; (d) the new entries drop into
     // the holes.  No per-thread copy of W, so ef is bounded by LDS alone (4 096 at 64 KiB, the API's limit is the 160 KiB).
     // Same result as the one-at-a-time push / pop of the reference (hnsw.rs:572-583) like the register form above.
     __device__ void merge_wide(int n, int ef) {
@@ -731,6 +731,7 @@ struct Searcher {
             s.nid[e] = myid;
         }
         __syncthreads();
+        CZ_PH_MARK(8);  // (profiling builds: the merge's own phases are 8 = compaction, 9 = rank, 10 = shift; 4 = the rest)
         // (b) thread e < nelig: rank inside the batch, lower bound in W
         int npos = -1;
         if (tid < nelig) {
@@ -749,31 +750,65 @@ struct Searcher {
             npos = lo + r1;
         }
         __syncthreads();
-        // (c) shift W in place, top chunk first
-        const int first = (int)tcur[0];
-        for (int base = ((cnt - 1) / kThreads) * kThreads; base >= 0 && base + kThreads > first; base -= kThreads) {  // uniform
-            const int j = base + tid;
-            uint64_t wk = 0;
-            uint32_t wi = 0;
-            int sft = 0;
-            if (j < cnt && j >= first) {
-                wk = s.wkey[j];
-                wi = s.wid[j];
-                int lo = 0, hi = nelig;  // number of lower bounds <= j
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if ((int)tcur[mid] <= j) lo = mid + 1;
-                    else hi = mid;
+        CZ_PH_MARK(9);
+        // (c) shift W in place from the top, kShiftR chunks (kShiftR entries per thread) per barrier.  A W entry at j moves up by
+        // the number of lower bounds <= j: all of them above the last one (no search), a count over registers when the step
+        // brought at most kLb entries (nearly always), a bisection otherwise.  One barrier per block: a block's entries are read
+        // before the barrier and written after it, into their own block and the start of the one above -- which the previous
+        // round read before ITS barrier -- while the next round's reads (the block below) touch nothing this round writes.
+        // (A list of 8 192 is shifted nearly whole on most steps: with one chunk and two barriers per round the merge was 46 % of
+        // a step, now 25 % is the shift and 9 % the rank, profiles/r04_large_ef_phases.txt; moving 8 192 x 12 bytes in and out of
+        // LDS is 1 500 cycles at 128 B / clock, the shift takes 3 200: what is left is the move itself.)
+        const int first = (int)tcur[0], last = (int)tcur[nelig - 1];
+        constexpr int kLb = 8, kShiftR = 4, kBlock = kShiftR * kThreads;
+        int lb[kLb];
+#pragma unroll
+        for (int i = 0; i < kLb; i++) lb[i] = i < nelig ? (int)tcur[i] : 0x7fffffff;
+        int base = ((cnt - 1) / kBlock) * kBlock;
+        bool more = base >= 0 && base + kBlock > first;  // uniform
+        uint64_t wk[kShiftR];
+        uint32_t wi[kShiftR];
+        int sft[kShiftR];
+        auto fetch = [&]() {
+#pragma unroll
+            for (int r = 0; r < kShiftR; r++) {
+                const int j = base + r * kThreads + tid;
+                sft[r] = 0;
+                if (j < cnt && j >= first) {
+                    wk[r] = s.wkey[j];
+                    wi[r] = s.wid[j];
+                    if (j >= last) sft[r] = nelig;
+                    else if (nelig <= kLb) {
+#pragma unroll
+                        for (int i = 0; i < kLb; i++) sft[r] += lb[i] <= j ? 1 : 0;
+                    } else {
+                        int lo = 0, hi = nelig;
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if ((int)tcur[mid] <= j) lo = mid + 1;
+                            else hi = mid;
+                        }
+                        sft[r] = lo;
+                    }
                 }
-                sft = lo;
             }
+        };
+        if (more) fetch();
+        while (more) {  // uniform
             __syncthreads();
-            if (sft > 0 && j + sft < ef) {
-                s.wkey[j + sft] = wk;
-                s.wid[j + sft] = wi;
+#pragma unroll
+            for (int r = 0; r < kShiftR; r++) {
+                const int j = base + r * kThreads + tid;
+                if (sft[r] > 0 && j + sft[r] < ef) {
+                    s.wkey[j + sft[r]] = wk[r];
+                    s.wid[j + sft[r]] = wi[r];
+                }
             }
-            __syncthreads();
+            base -= kBlock;
+            more = base >= 0 && base + kBlock > first;
+            if (more) fetch();
         }
+        CZ_PH_MARK(10);
         // (d) the new entries into the holes
         if (npos >= 0 && npos < ef) {
             s.wkey[npos] = mykey;
@@ -1091,7 +1126,7 @@ hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t k, uint
     S.clear_all();  // the table / bitmap go back to the pool empty
 #ifdef CZ_PHASE_TIMING
     if (threadIdx.x == 0) {
-        for (int i_ = 0; i_ < 8; i_++) atomicAdd(&cz_phase_cycles[i_], S.ph_acc[i_]);
+        for (int i_ = 0; i_ < 12; i_++) atomicAdd(&cz_phase_cycles[i_], S.ph_acc[i_]);
     }
 #endif
     const int cnt = s.ctl[C_CNT];

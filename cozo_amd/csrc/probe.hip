@@ -5,7 +5,9 @@
 //   rows     a wave fetches whole `row_bytes`-byte rows at pseudo-random row numbers of a table, 4 rows in flight, non-temporal
 //            (what hnsw_knn_kernel / distance_pairs_kernel do with 3 KiB vectors) -- over the CALLER's table, i.e. with its
 //            size, its allocation and its translation footprint.
-// The roofline fractions in bench.py stay priced against the nominal 8 TB/s; these two numbers say how much of a box-to-box
+//   words    every lane has 8 independent accesses in flight to pseudo-random words of a per-node array, as plain loads and as
+//            atomicMin without a returned value (what BFS / SSSP / LabelPropagation do to their per-node words).
+// The roofline fractions in bench.py stay priced against the nominal 8 TB/s; these numbers say how much of a box-to-box
 // difference is the box (the same binary measured 0.64-0.76 of the nominal peak on different GPUs).
 #include "common.h"
 #include "exact_sum.cuh"
@@ -59,7 +61,79 @@ __global__ void __launch_bounds__(256) probe_rows_kernel(const char *__restrict_
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;
 }
 
+// random single words of a per-node array (what the traversal rules do to depth / claim / label / (cost, parent) words): every lane
+// U independent accesses in flight at pseudo-random indices; plain loads, or atomicMin without a returned value
+template <typename W, int U, bool ATOMIC>
+__global__ void __launch_bounds__(256) probe_words_kernel(W *__restrict__ words, uint64_t n_words, uint64_t n_access, uint64_t seed,
+                                                          unsigned long long *__restrict__ sink) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, n_threads = (uint64_t)gridDim.x * 256;
+    unsigned long long acc = 0;
+    for (uint64_t a0 = t * U; a0 < n_access; a0 += n_threads * U) {
+        uint64_t idx[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) idx[u] = mix64(seed + a0 + u) % n_words;
+        if constexpr (ATOMIC) {
+#pragma unroll
+            for (int u = 0; u < U; u++) atomicMin(words + idx[u], (W)(mix64(idx[u] + a0) | 1u));
+        } else {
+            W v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) v[u] = words[idx[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++) acc += (unsigned long long)v[u];
+        }
+    }
+    if (acc == 0x123456789abcdefull) sink[0] = acc;
+}
+
 }  // namespace
+
+// What this box sustains on the traversal rules' access pattern: G accesses / s of independent random loads and of random
+// atomicMin (no return) over a per-node array of n_words words of 4 or 8 bytes (allocated here, filled with 0xFF).
+extern "C" int cz_random_access_probe(uint64_t n_words, uint32_t word_bytes, uint64_t n_access, uint32_t reps, double *loads_g_per_s,
+                                      double *atomic_min_g_per_s) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if (loads_g_per_s) *loads_g_per_s = 0.0;
+    if (atomic_min_g_per_s) *atomic_min_g_per_s = 0.0;
+    if (word_bytes != 4 && word_bytes != 8) return cz::set_error(CZ_E_INVALID, "word_bytes must be 4 or 8");
+    if (n_words == 0) return cz::set_error(CZ_E_INVALID, "empty array");
+    if (n_access == 0) n_access = 256u << 20;
+    if (reps == 0) reps = 3;
+    cz::DevBuf<char> arr;
+    cz::DevBuf<unsigned long long> sink;
+    CZ_HIP(arr.alloc(n_words * word_bytes));
+    CZ_HIP(sink.alloc(1));
+    CZ_HIP(hipMemset(arr.p, 0xFF, n_words * word_bytes));
+    hipEvent_t e0, e1;
+    CZ_HIP(hipEventCreate(&e0));
+    CZ_HIP(hipEventCreate(&e1));
+    const dim3 grid(256 * 32), block(256);
+    for (int pass = 0; pass < 2; pass++) {  // 0: loads, 1: atomicMin
+        float ms = 0.f;
+        for (uint32_t i = 0; i <= reps; i++) {  // (the first launch warms up)
+            if (i == 1) CZ_HIP(hipEventRecord(e0, nullptr));
+            const uint64_t seed = 4242ull + (uint64_t)i * n_access;
+            if (word_bytes == 4) {
+                if (pass == 0) hipLaunchKernelGGL((probe_words_kernel<uint32_t, 8, false>), grid, block, 0, nullptr, (uint32_t *)arr.p, n_words, n_access, seed, sink.p);
+                else hipLaunchKernelGGL((probe_words_kernel<uint32_t, 8, true>), grid, block, 0, nullptr, (uint32_t *)arr.p, n_words, n_access, seed, sink.p);
+            } else {
+                if (pass == 0) hipLaunchKernelGGL((probe_words_kernel<unsigned long long, 8, false>), grid, block, 0, nullptr, (unsigned long long *)arr.p, n_words, n_access, seed, sink.p);
+                else hipLaunchKernelGGL((probe_words_kernel<unsigned long long, 8, true>), grid, block, 0, nullptr, (unsigned long long *)arr.p, n_words, n_access, seed, sink.p);
+            }
+        }
+        CZ_HIP(hipEventRecord(e1, nullptr));
+        CZ_HIP(hipEventSynchronize(e1));
+        CZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+        double *dst = pass == 0 ? loads_g_per_s : atomic_min_g_per_s;
+        if (dst && ms > 0.f) *dst = (double)n_access * reps / (ms * 1e-3) / 1e9;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "probe launch: %s", hipGetErrorString(e));
+    return CZ_OK;
+}
 
 extern "C" int cz_hbm_probe(const void *table, uint64_t rows, uint32_t row_bytes, uint64_t n_fetch, uint32_t reps, double *stream_gbs,
                             double *row_fetch_gbs) {

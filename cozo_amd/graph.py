@@ -263,6 +263,13 @@ def sssp(out_off, out_tgt, weights, starts, poison=None, out=None):
     return dist, parent
 
 
+def random_access_probe(n_words: int, word_bytes: int, n_access: int = 0, reps: int = 0):
+    """cz_random_access_probe: (random loads, random atomicMin) in 1e9 accesses / s over a per-node array of this shape"""
+    a, b = C.c_double(0.0), C.c_double(0.0)
+    check(_lib.lib().cz_random_access_probe(int(n_words), int(word_bytes), int(n_access), int(reps), C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 def last_timing():
     """cz_graph_last_timing: (upload_ms, device_ms, download_ms) of this thread's last whole-graph rule call"""
     a, b, c = C.c_double(), C.c_double(), C.c_double()

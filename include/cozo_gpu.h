@@ -72,6 +72,11 @@ const char *cz_version(void);
  * `reps` timed launches each (0 = 5).  GB/s = 1e9 bytes per second of bytes requested. */
 int cz_hbm_probe(const void *table, uint64_t rows, uint32_t row_bytes, uint64_t n_fetch, uint32_t reps, double *stream_gbs,
                  double *row_fetch_gbs);
+/* The same for the traversal rules' access pattern: independent accesses to pseudo-random words of a per-node array of `n_words`
+ * words of `word_bytes` (4 | 8) bytes (the library's own allocation), `n_access` per launch (0 = 256M), `reps` timed launches (0 = 3):
+ * plain loads, and atomicMin without a returned value, in 1e9 accesses per second. */
+int cz_random_access_probe(uint64_t n_words, uint32_t word_bytes, uint64_t n_access, uint32_t reps, double *loads_g_per_s,
+                           double *atomic_min_g_per_s);
 /* TEST HOOK: the wave-parallel form of a sequential f32 sum (csrc/exact_sum.cuh, what PageRank's long rows use) on arbitrary rows:
  * out[r] = init[r] + terms[row_off[r]] + terms[row_off[r] + 1] + ... added one after the other in f32, by a group of `lanes`
  * (16 | 64) lanes taking `per_lane` (4 | 8 | 16) terms each per pass.  Host pointers.  Exists so that the paths PageRank's

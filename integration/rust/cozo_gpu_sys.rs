@@ -108,6 +108,8 @@ extern "C" {
     pub fn cz_version() -> *const c_char;
     pub fn cz_hbm_probe(table: *const c_void, rows: u64, row_bytes: u32, n_fetch: u64, reps: u32, stream_gbs: *mut c_double,
                         row_fetch_gbs: *mut c_double) -> c_int;
+    pub fn cz_random_access_probe(n_words: u64, word_bytes: u32, n_access: u64, reps: u32, loads_g_per_s: *mut c_double,
+                                  atomic_min_g_per_s: *mut c_double) -> c_int;
     pub fn cz_debug_sort_pairs(keys: *const u32, vals: *const u32, n: u64, bits: u32, out_keys: *mut u32, out_vals: *mut u32,
                                out_scan: *mut u32) -> c_int;
     pub fn cz_debug_seq_sum(terms: *const c_float, row_off: *const u64, init: *const c_float, n_rows: u32, lanes: c_int, per_lane: c_int,

@@ -26,7 +26,7 @@ def main():
     for ef in efs:
         run = lambda: ix.hnsw_knn_batch_device(q, HnswSearch(k=k, ef=ef), ids, dd, cnt, nd, stream)
         for _ in range(2): run()
-        buf = (C.c_ulonglong * 8)()
+        buf = (C.c_ulonglong * 12)()
         L.cz_debug_phase_cycles(buf, 1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 3
@@ -35,12 +35,14 @@ def main():
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         L.cz_debug_phase_cycles(buf, 1)
-        v = [buf[i] / reps / B for i in range(8)]  # per query
-        names = ["select+mark", "row+visited", "eval rounds", "finish", "merge"]
-        tot = sum(v[:5])
+        v = [buf[i] / reps / B for i in range(12)]  # per query
+        names = ["select+mark", "row+visited", "eval rounds", "finish", "merge (rest)", None, None, None, "merge: compact", "merge: rank", "merge: shift"]
+        tot = sum(v[:5]) + sum(v[8:11])
         steps, rows = v[5], v[6]
         print(f"ef={ef}: kernel {ms:.3f} ms/batch; per query: {steps:.1f} steps, {rows:.0f} rows evaluated ({rows/steps:.1f}/step); "
               f"timed cycles/query {tot:.0f}; {tot / steps:.0f} cycles per step")
         for i, nme in enumerate(names):
+            if nme is None:
+                continue
             print(f"  {nme:12s} {v[i]:12.0f} cycles/query  {100*v[i]/tot:5.1f} %   {v[i]/steps:8.0f} cycles/step")
 main()

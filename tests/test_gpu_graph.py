@@ -861,3 +861,14 @@ def test_plan_build_sort_and_scan_primitives(gpu_lib, n, bits):
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(ok, keys[order])
     assert np.array_equal(ov, vals[order]), "the sort must keep equal keys in their original order"
+
+
+@pytest.mark.gpu
+def test_random_access_probe_reports_rates():
+    """cz_random_access_probe (bench.py's ceiling for the traversal rules): both rates positive, bad word sizes refused"""
+    from cozo_amd import graph as G
+    for wb in (4, 8):
+        loads, atomics = G.random_access_probe(1 << 20, wb, n_access=1 << 22, reps=1)
+        assert loads > 0 and atomics > 0
+    with pytest.raises(Exception):
+        G.random_access_probe(1 << 20, 2)
