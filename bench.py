@@ -846,7 +846,11 @@ def bench_single_process_multi(args, torch, world, device):
         dt, _ = wall(lambda: CM.bfs_multi(h_off, h_src, n_gpus, starts), 1)
         res["bfs_multi"] = dict(wall_ms=dt * 1e3)
         dt, _ = wall(lambda: CM.sssp_multi(h_off, h_src, w, n_gpus, starts), 1)
-        res["sssp_multi"] = dict(wall_ms=dt * 1e3)
+        st = CM.sssp_sharded_last_stats()  # (rank 0's loop runs on this thread)
+        res["sssp_multi"] = dict(wall_ms=dt * 1e3, rounds=st["rounds"], pairs_exchanged=st["pairs"], buckets=st["buckets"],
+                                 exchanged_bytes=16 * st["pairs"], dense_exchange_bytes=8 * int(h_off.size - 1) * st["rounds"],
+                                 what="near-far schedule, sparse exchange: (target, word) pairs all-gathered per round; dense = the "
+                                      "N-word all-reduce per round the first form of the loop did")
         dt, (_, k) = wall(lambda: CM.connected_components_multi(h_off, h_src, n_gpus), 1)
         res["connected_components_multi"] = dict(wall_ms=dt * 1e3, groups=int(k), note="the directed CSR taken as is (the rule symmetrises first)")
     except Exception as e:  # noqa: BLE001
@@ -967,15 +971,16 @@ def bench_graph_rules(args, torch, device):
     del ones, lab, tri, deg
     # What these rules are bounded by is not HBM bytes but independent random accesses to one word of a per-node array (the HBM
     # fractions above price bytes no schedule gets down to).  cz_random_access_probe measures what THIS box sustains on that
-    # pattern over an array of the same shape; `random_frac` = the rule's edge visits per device-second over it (a visit = at least
-    # one such access: BFS / CC / LabelPropagation read a 4-byte word per edge, SSSP issues an 8-byte atomicMin per relaxation, and
-    # re-expands 1.7 x the edges on this graph).
+    # pattern over an array of the same shape; `random_frac` = the rule's edge visits per device-second over the LOAD rate (a visit
+    # = at least one such load: BFS / LabelPropagation read a 4-byte word per edge; SSSP reads the target's 8-byte (cost, parent)
+    # word per relaxation -- and relaxes 1.7 x the edges on this graph -- then CASes it when it improves: the atomic rate is the
+    # ceiling of that part).  ConnectedComponents is left out: its reads go to a shrinking set of roots, not to random words.
     try:
         l4, a4 = G.random_access_probe(n, 4)
         l8, a8 = G.random_access_probe(n, 8)
         out["random_access"] = dict(what=f"1e9 accesses/s to random words of a {n}-word array on this box (cz_random_access_probe)",
                                     loads_4B=l4, atomic_min_4B=a4, loads_8B=l8, atomic_min_8B=a8)
-        for name, ceil in (("bfs", l4), ("connected_components", l4), ("sssp", a8), ("label_propagation", l4)):
+        for name, ceil in (("bfs", l4), ("sssp", l8), ("label_propagation", l4)):
             eps = out[name].get("edges_per_s_device")
             if eps and ceil > 0:
                 out[name]["random_frac"] = eps / (ceil * 1e9)

@@ -128,6 +128,13 @@ def sssp_sharded(comm: Comm, off_local, tgt, weights, n: int, row_begin: int, ro
     return dist, parent
 
 
+def sssp_sharded_last_stats():
+    """cz_sssp_sharded_last_stats: dict(rounds, pairs, compactions, buckets) of this thread's last cz_sssp_sharded call"""
+    out = np.zeros(4, dtype=np.uint64)
+    check(_lib.lib().cz_sssp_sharded_last_stats(ptr(out)))
+    return dict(rounds=int(out[0]), pairs=int(out[1]), compactions=int(out[2]), buckets=int(out[3]))
+
+
 def pagerank_multi(in_off, in_src, out_deg, n_gpus: int, damping=0.85, tolerance=1e-4, max_iter=10,
                    allreduce_exchange=False, overlap_exchange=False, poison=None):
     """cz_pagerank on n_gpus devices of THIS process (one host thread + one RCCL communicator per GPU)."""

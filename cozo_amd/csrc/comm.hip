@@ -122,6 +122,21 @@ int comm_all_reduce(cz_comm *c, void *buf, size_t count, int dtype, int op, hipS
     CZ_NCCL(R, R->AllReduce(buf, buf, count, types[dtype], op == COMM_MIN ? ncclMin : ncclSum, c->nccl, stream));
     return CZ_OK;
 }
+int comm_all_gather(cz_comm *c, const void *send, void *recv, size_t count, int dtype, hipStream_t stream) {
+    if (!c || !send || !recv) return set_error(CZ_E_INVALID, "null argument");
+    if (count == 0) return CZ_OK;
+    static const size_t width[] = {4, 8, 4, 8};
+    if (c->world == 1) {
+        if (send != recv) CZ_HIP(hipMemcpyAsync(recv, send, count * width[dtype], hipMemcpyDeviceToDevice, stream));
+        return CZ_OK;
+    }
+    Rccl *R = nullptr;
+    int rc = need_rccl(&R);
+    if (rc) return rc;
+    static const ncclDataType_t types[] = {ncclUint32, ncclUint64, ncclFloat32, ncclFloat64};
+    CZ_NCCL(R, R->AllGather(send, recv, count, types[dtype], c->nccl, stream));
+    return CZ_OK;
+}
 }  // namespace cz
 
 extern "C" int cz_comm_unique_id(uint8_t *id) {

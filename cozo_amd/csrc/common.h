@@ -33,6 +33,8 @@ static inline bool poisoned(const volatile uint8_t *p) { return p && *p; }
 enum { COMM_U32 = 0, COMM_U64 = 1, COMM_F32 = 2, COMM_F64 = 3 };
 enum { COMM_SUM = 0, COMM_MIN = 1 };
 int comm_all_reduce(cz_comm *c, void *buf_dev, size_t count, int dtype, int op, hipStream_t stream);
+// every rank's `count` elements at `send` -> recv[rank * count ...] on every rank; in place when send == recv + rank * count
+int comm_all_gather(cz_comm *c, const void *send_dev, void *recv_dev, size_t count, int dtype, hipStream_t stream);
 int comm_world(const cz_comm *c);
 int comm_rank(const cz_comm *c);
 

@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <list>
 #include <memory>
 #include <mutex>
@@ -2677,42 +2678,157 @@ struct HipShardedBfs {
     int reduce_parents() { return cz::comm_all_reduce(comm, parent.p, N, cz::COMM_U32, cz::COMM_MIN, s); }
 };
 
-// ---- SSSP ----
+// ---- SSSP: near-far piles, sparse exchange (sharded_traversal.hpp says what each step means) ----
+constexpr unsigned long long kIdleProp = ~0ull;  // a proposal slot nobody touched this round
+constexpr unsigned long long kPadNode = 0xFFFFFFFFull;
+
+// relax: a 16-lane group per near entry this rank owns; per target the best strictly improving word lands in prop[] (atomicMin),
+// and whoever finds the slot idle lists the target
 __global__ void __launch_bounds__(kT)
-sssp_sh_propose_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t rb,
-                       uint32_t re, const uint32_t *__restrict__ frontier, uint32_t fsize, const unsigned long long *__restrict__ dp,
-                       unsigned long long *__restrict__ prop) {
+sssp_sp_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t rb,
+                     uint32_t re, const uint32_t *__restrict__ near, uint32_t n_near, const unsigned long long *__restrict__ dp,
+                     unsigned long long *__restrict__ prop, QueueT<uint32_t> touched) {
+    const int lane = threadIdx.x & 63;
     const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes, ngroups = gridDim.x * blockDim.x / kSsspLanes;
-    for (uint32_t i = group; i < fsize; i += ngroups) {
-        const uint32_t u = frontier[i];
-        if (u < rb || u >= re) continue;
-        const float du = __uint_as_float((uint32_t)(dp[u] >> 32));
-        const uint32_t e1 = off[u - rb + 1];
-        for (uint32_t e = off[u - rb] + glane; e < e1; e += kSsspLanes) {
-            const uint32_t v = tgt[e];
-            const uint32_t nb = __float_as_uint(du + w[e]);  // `cost + path_weight` in f32 (shortest_path_dijkstra.rs:303)
-            if (nb < (uint32_t)(dp[v] >> 32))                // strict `<` against the round's starting cost (:304)
-                atomicMin(&prop[v], ((unsigned long long)nb << 32) | u);
+    const uint32_t rounds = (n_near + ngroups - 1) / ngroups;  // every group of the GRID runs the same trip count (ballots, barriers)
+    __shared__ StagedPileT<uint32_t> st;
+    if (threadIdx.x == 0) st.count = 0;
+    __syncthreads();
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i = group + r * ngroups;
+        uint32_t u = i < n_near ? near[i] : CZ_NONE;
+        const bool live = u != CZ_NONE && u >= rb && u < re;
+        const uint32_t e0 = live ? off[u - rb] : 0, e1 = live ? off[u - rb + 1] : 0;
+        const float du = live ? __uint_as_float((uint32_t)(dp[u] >> 32)) : 0.f;
+        uint32_t maxlen = e1 - e0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, o, 64));
+        for (uint32_t b = 0; b < maxlen; b += kSsspLanes) {
+            const uint32_t e = e0 + b + glane;
+            bool first = false;
+            uint32_t v = 0;
+            if (e < e1) {
+                v = tgt[e];
+                const uint32_t nb = __float_as_uint(du + w[e]);  // `cost + path_weight` in f32 (shortest_path_dijkstra.rs:303)
+                if (nb < (uint32_t)(dp[v] >> 32))                // strict `<` against the round's starting cost (:304)
+                    first = atomicMin(&prop[v], ((unsigned long long)nb << 32) | u) == kIdleProp;
+            }
+            staged_push(touched, st, first, v, lane);
+        }
+        if ((r & 7) == 7 || r + 1 == rounds) staged_flush(touched, st);
+    }
+}
+
+// this rank's slot of the exchange buffer: its pairs (word, target), the proposal slots idle again, padding behind them
+__global__ void __launch_bounds__(kT)
+sssp_sp_collect_kernel(const uint32_t *__restrict__ touched, uint32_t n, uint32_t longest, unsigned long long *__restrict__ prop,
+                       unsigned long long *__restrict__ slot) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < longest; i += gridDim.x * blockDim.x) {
+        unsigned long long word = kIdleProp, node = kPadNode;
+        if (i < n) {
+            node = touched[i];
+            word = prop[node];
+            prop[node] = kIdleProp;
+        }
+        slot[2 * (size_t)i] = word;
+        slot[2 * (size_t)i + 1] = node;
+    }
+}
+
+// counts[r] = (pairs of rank r) | (its cancellation flag << 40): every rank writes its own word, the sum gathers them
+__global__ void sssp_sp_count_kernel(unsigned long long *__restrict__ counts, uint32_t world, uint32_t rank, const uint32_t *__restrict__ n_touched,
+                                     uint32_t poisoned) {
+    const uint32_t i = threadIdx.x;
+    if (i < world) counts[i] = i == rank ? ((unsigned long long)*n_touched | ((unsigned long long)poisoned << 40)) : 0ull;
+}
+
+__global__ void __launch_bounds__(kT)
+sssp_sp_apply_min_kernel(const unsigned long long *__restrict__ pairs, uint64_t total, unsigned long long *__restrict__ dp,
+                         uint8_t *__restrict__ lowered) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long word = pairs[2 * i], node = pairs[2 * i + 1];
+        lowered[i] = node != kPadNode && word < atomicMin(&dp[node], word);
+    }
+}
+
+// the winners: a pair that lowered its target's word and still IS that word (words of different ranks differ in the parent)
+__global__ void __launch_bounds__(kT)
+sssp_sp_apply_place_kernel(const unsigned long long *__restrict__ pairs, const uint8_t *__restrict__ lowered, uint64_t total,
+                           const unsigned long long *__restrict__ dp, uint32_t thr_bits, QueueT<uint32_t> near, SsspQueue far) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (total + stride - 1) / stride;
+    __shared__ StagedPileT<uint32_t> st_near;
+    __shared__ StagedPile st_far;
+    if (threadIdx.x == 0) st_near.count = st_far.count = 0;
+    __syncthreads();
+    for (uint64_t r = 0; r < rounds; r++) {
+        const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + r * stride;
+        bool to_near = false, to_far = false;
+        uint32_t v = 0, cost = 0;
+        if (i < total && lowered[i]) {
+            const unsigned long long word = pairs[2 * i];
+            v = (uint32_t)pairs[2 * i + 1];
+            if (dp[v] == word) {
+                cost = (uint32_t)(word >> 32);
+                to_near = cost < thr_bits;
+                to_far = !to_near;
+            }
+        }
+        staged_push(near, st_near, to_near, v, lane);
+        staged_push(far, st_far, to_far, ((unsigned long long)cost << 32) | v, lane);
+        if ((r & 1) == 1 || r + 1 == rounds) {  // at most one entry per thread and iteration: two iterations fit the buffer
+            staged_flush(near, st_near);
+            staged_flush(far, st_far);
         }
     }
 }
 
+// the cheapest LIVE far entry (its node still has the cost it was filed under)
 __global__ void __launch_bounds__(kT)
-sssp_sh_advance_kernel(const unsigned long long *__restrict__ dp, const unsigned long long *__restrict__ prop, uint32_t N,
-                       uint32_t *__restrict__ frontier, uint32_t *__restrict__ count) {
+sssp_sp_far_min_kernel(const unsigned long long *__restrict__ far, uint32_t n_far, const unsigned long long *__restrict__ dp,
+                       uint32_t *__restrict__ min_bits) {
+    uint32_t m = 0xFFFFFFFFu;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_far; i += gridDim.x * blockDim.x) {
+        const unsigned long long ent = far[i];
+        const uint32_t cost = (uint32_t)(ent >> 32);
+        if ((uint32_t)(dp[(uint32_t)ent] >> 32) == cost) m = min(m, cost);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m != 0xFFFFFFFFu) atomicMin(min_bits, m);
+}
+
+// live far entries below the threshold -> the near list, the other live ones -> the next far pile; stale ones are dropped
+__global__ void __launch_bounds__(kT)
+sssp_sp_split_kernel(const unsigned long long *__restrict__ far, uint32_t n_far, const unsigned long long *__restrict__ dp,
+                     uint32_t thr_bits, QueueT<uint32_t> near, SsspQueue far_next) {
     const int lane = threadIdx.x & 63;
-    const uint32_t total = gridDim.x * blockDim.x;
-    const uint32_t rounds = (N + total - 1) / total;
-    const QueueT<uint32_t> q{frontier, count};
-    __shared__ StagedPileT<uint32_t> st;  // (one counter for every wave of the grid serialises: see staged_push)
-    if (threadIdx.x == 0) st.count = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounds = (n_far + stride - 1) / stride;
+    __shared__ StagedPileT<uint32_t> st_near;
+    __shared__ StagedPile st_far;
+    if (threadIdx.x == 0) st_near.count = st_far.count = 0;
     __syncthreads();
     for (uint32_t r = 0; r < rounds; r++) {
-        const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x + r * total;
-        const bool changed = v < N && prop[v] != dp[v];
-        staged_push(q, st, changed, v, lane);
-        if ((r & 3) == 3 || r + 1 == rounds) staged_flush(q, st);  // at most one entry per thread and iteration
+        const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x + r * stride;
+        bool to_near = false, to_far = false;
+        unsigned long long ent = 0;
+        if (i < n_far) {
+            ent = far[i];
+            const uint32_t cost = (uint32_t)(ent >> 32);
+            if ((uint32_t)(dp[(uint32_t)ent] >> 32) == cost) {
+                to_near = cost < thr_bits;
+                to_far = !to_near;
+            }
+        }
+        staged_push(near, st_near, to_near, (uint32_t)ent, lane);
+        staged_push(far_next, st_far, to_far, ent, lane);
+        if ((r & 1) == 1 || r + 1 == rounds) {
+            staged_flush(near, st_near);
+            staged_flush(far_next, st_far);
+        }
     }
 }
 
@@ -2720,68 +2836,179 @@ struct HipShardedSssp {
     cz_comm *comm;
     hipStream_t s;
     uint32_t N, rb, re;
-    cz::DevBuf<uint32_t> off, tgt, frontier, canon, misc, parent;
+    cz::DevBuf<uint32_t> off, tgt, near, touched, canon, misc, parent;
     cz::DevBuf<float> w, dist;
-    cz::DevBuf<unsigned long long> a, b;
-    unsigned long long *dp = nullptr, *prop = nullptr;
+    cz::DevBuf<unsigned long long> dpb, prop, far_a, far_b, pairs, counts;
+    cz::DevBuf<uint8_t> lowered;
+    unsigned long long *dp = nullptr, *far = nullptr, *far_next = nullptr;
+    std::vector<unsigned long long> h_counts;
+    size_t far_cap = 0, compact_at = 0;
+    uint32_t n_far = 0, my_pairs = 0, thr_bits = 0;
+    uint64_t rounds = 0, pairs_exchanged = 0, compactions = 0, buckets = 0;  // (over all the starts of a call)
+    float delta = 0.f;
+    bool one_pile = false;
 
     int alloc(const uint32_t *h_off, const uint32_t *h_tgt, const float *h_w, uint64_t e_local) {
-        const uint32_t rows = re - rb;
+        const uint32_t rows = re - rb, world = (uint32_t)cz::comm_world(comm);
+        far_cap = 3 * (size_t)N + 1024;  // (a compaction leaves at most N live entries, a round adds at most N)
+        compact_at = far_cap;
+        if (const char *fc = getenv("CZ_SSSP_FAR_COMPACT")) compact_at = (size_t)atoll(fc);  // tests: drop the stale entries this often
         CZ_HIP(off.alloc((size_t)rows + 1));
         CZ_HIP(tgt.alloc(e_local));
         CZ_HIP(w.alloc(e_local));
-        CZ_HIP(frontier.alloc(N));
+        CZ_HIP(near.alloc(N));
+        CZ_HIP(touched.alloc(N));
         CZ_HIP(canon.alloc(N));
-        CZ_HIP(misc.alloc(4));
+        CZ_HIP(misc.alloc(8));
         CZ_HIP(parent.alloc(N));
         CZ_HIP(dist.alloc(N));
-        CZ_HIP(a.alloc(N));
-        CZ_HIP(b.alloc(N));
+        CZ_HIP(dpb.alloc(N));
+        CZ_HIP(prop.alloc(N));
+        CZ_HIP(far_a.alloc(far_cap));
+        CZ_HIP(far_b.alloc(far_cap));
+        CZ_HIP(counts.alloc(world));
+        h_counts.resize(world);
         CZ_HIP(hipMemcpy(off.p, h_off, ((size_t)rows + 1) * 4, hipMemcpyHostToDevice));
         if (e_local) {
             CZ_HIP(hipMemcpy(tgt.p, h_tgt, e_local * 4, hipMemcpyHostToDevice));
             CZ_HIP(hipMemcpy(w.p, h_w, e_local * 4, hipMemcpyHostToDevice));
         }
-        dp = a.p;
-        prop = b.p;
+        dp = dpb.p;
+        hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(N)), dim3(kT), 0, s, prop.p, (uint64_t)N, kIdleProp);
         return CZ_OK;
     }
-    int any_poisoned(bool mine, bool *any) {
-        const uint32_t v = mine ? 1u : 0u;
-        CZ_HIP(hipMemcpyAsync(misc.p + 2, &v, 4, hipMemcpyHostToDevice, s));
-        int rc = cz::comm_all_reduce(comm, misc.p + 2, 1, cz::COMM_U32, cz::COMM_SUM, s);
+    // the bucket width: the mean edge weight of the WHOLE graph (the one-GPU rule's choice; CZ_SSSP_DELTA overrides; <= 0 or "inf"
+    // = one pile).  A collective: every rank calls it, with its own sums.
+    int agree_on_delta(const float *h_w, uint64_t e_local) {
+        double h[2] = {0.0, (double)e_local};
+        for (uint64_t e = 0; e < e_local; e++) h[0] += (double)h_w[e];
+        cz::DevBuf<double> d;
+        CZ_HIP(d.alloc(2));
+        CZ_HIP(hipMemcpyAsync(d.p, h, 16, hipMemcpyHostToDevice, s));
+        int rc = cz::comm_all_reduce(comm, d.p, 2, cz::COMM_F64, cz::COMM_SUM, s);
         if (rc) return rc;
-        uint32_t h = 0;
-        CZ_HIP(hipMemcpyAsync(&h, misc.p + 2, 4, hipMemcpyDeviceToHost, s));
+        CZ_HIP(hipMemcpyAsync(h, d.p, 16, hipMemcpyDeviceToHost, s));
         CZ_HIP(hipStreamSynchronize(s));
-        *any = h != 0;
+        delta = h[1] > 0.0 ? (float)(h[0] / h[1]) : 0.f;
+        if (const char *de = getenv("CZ_SSSP_DELTA")) delta = (float)atof(de);
+        one_pile = !(delta > 0.f) || !std::isfinite(delta);
         return CZ_OK;
     }
-    int sssp_seed(uint32_t start, uint32_t *fsize) {
+    // threshold above a cheapest cost: that cost + the bucket width, and always above the cost itself
+    uint32_t threshold_over(uint32_t min_bits) const {
+        if (one_pile) return 0x7F800000u;
+        const float m = __builtin_bit_cast(float, min_bits);
+        float t = m + delta;
+        if (!(t > m)) t = std::nextafter(m, std::numeric_limits<float>::infinity());
+        return __builtin_bit_cast(uint32_t, t);
+    }
+    int read_misc(uint32_t *h, uint32_t n) {
+        CZ_HIP(hipMemcpyAsync(h, misc.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        CZ_HIP(hipStreamSynchronize(s));
+        return CZ_OK;
+    }
+    // misc: [0] near count, [1] far count, [2] touched count, [3] min far cost bits
+    int sssp_seed(uint32_t start, uint32_t *n_near) {
         hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(N)), dim3(kT), 0, s, dp, (uint64_t)N, kInfPacked);
-        *fsize = 0;
+        far = far_a.p;
+        far_next = far_b.p;
+        n_far = 0;
+        thr_bits = threshold_over(0u);
+        *n_near = 0;
         if (start < N) {
             const unsigned long long zero = 0x00000000FFFFFFFFull;  // cost 0.0, no parent
             CZ_HIP(hipMemcpyAsync(dp + start, &zero, 8, hipMemcpyHostToDevice, s));
-            CZ_HIP(hipMemcpyAsync(frontier.p, &start, 4, hipMemcpyHostToDevice, s));
+            CZ_HIP(hipMemcpyAsync(near.p, &start, 4, hipMemcpyHostToDevice, s));
             CZ_HIP(hipStreamSynchronize(s));
-            *fsize = 1;
+            *n_near = 1;
         }
         return CZ_OK;
     }
-    int sssp_propose(uint32_t fsize) {
-        CZ_HIP(hipMemcpyAsync(prop, dp, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(sssp_sh_propose_kernel, dim3(grid_for((uint64_t)fsize * kSsspLanes)), dim3(kT), 0, s, off.p, tgt.p, w.p, rb, re,
-                           frontier.p, fsize, dp, prop);
+    int sssp_relax(uint32_t n_near) {
+        CZ_HIP(hipMemsetAsync(misc.p + 2, 0, 4, s));
+        hipLaunchKernelGGL(sssp_sp_relax_kernel, dim3(grid_for((uint64_t)n_near * kSsspLanes)), dim3(kT), 0, s, off.p, tgt.p, w.p, rb, re,
+                           near.p, n_near, dp, prop.p, QueueT<uint32_t>{touched.p, misc.p + 2});
         return CZ_OK;
     }
-    int reduce_proposals() { return cz::comm_all_reduce(comm, prop, N, cz::COMM_U64, cz::COMM_MIN, s); }
-    int sssp_advance(uint32_t *fsize) {
-        CZ_HIP(hipMemsetAsync(misc.p, 0, 4, s));
-        hipLaunchKernelGGL(sssp_sh_advance_kernel, dim3(grid_for(N)), dim3(kT), 0, s, dp, prop, N, frontier.p, misc.p);
-        CZ_HIP(hipMemcpyAsync(fsize, misc.p, 4, hipMemcpyDeviceToHost, s));
+    int exchange_counts(bool poisoned, uint32_t *longest, bool *any_poisoned) {
+        const uint32_t world = (uint32_t)cz::comm_world(comm), rank = (uint32_t)cz::comm_rank(comm);
+        if (world > 1024) return cz::set_error(CZ_E_UNSUPPORTED, "at most 1024 ranks");
+        hipLaunchKernelGGL(sssp_sp_count_kernel, dim3(1), dim3(1024), 0, s, counts.p, world, rank, misc.p + 2, poisoned ? 1u : 0u);
+        int rc = cz::comm_all_reduce(comm, counts.p, world, cz::COMM_U64, cz::COMM_SUM, s);
+        if (rc) return rc;
+        CZ_HIP(hipMemcpyAsync(h_counts.data(), counts.p, (size_t)world * 8, hipMemcpyDeviceToHost, s));
         CZ_HIP(hipStreamSynchronize(s));
-        std::swap(dp, prop);
+        *longest = 0;
+        *any_poisoned = false;
+        for (uint32_t r = 0; r < world; r++) {
+            *longest = std::max(*longest, (uint32_t)h_counts[r]);
+            *any_poisoned = *any_poisoned || (h_counts[r] >> 40) != 0;
+            pairs_exchanged += (uint32_t)h_counts[r];
+        }
+        my_pairs = (uint32_t)h_counts[rank];
+        rounds++;
+        return CZ_OK;
+    }
+    int exchange_pairs(uint32_t longest) {
+        const uint32_t world = (uint32_t)cz::comm_world(comm), rank = (uint32_t)cz::comm_rank(comm);
+        const size_t need = 2 * (size_t)world * longest;
+        if (pairs.n < need) CZ_HIP(pairs.alloc(need + need / 4));  // (grows with the busiest round so far)
+        if (lowered.n < (size_t)world * longest) CZ_HIP(lowered.alloc((size_t)world * longest + (size_t)world * longest / 4));
+        unsigned long long *slot = pairs.p + 2 * (size_t)rank * longest;
+        hipLaunchKernelGGL(sssp_sp_collect_kernel, dim3(grid_for(longest)), dim3(kT), 0, s, touched.p, my_pairs, longest, prop.p, slot);
+        return cz::comm_all_gather(comm, slot, pairs.p, 2 * (size_t)longest, cz::COMM_U64, s);
+    }
+    int compact_far() {  // drop the stale entries: at most one live entry per node is left
+        CZ_HIP(hipMemsetAsync(misc.p, 0, 8, s));
+        hipLaunchKernelGGL(sssp_sp_split_kernel, dim3(grid_for(n_far)), dim3(kT), 0, s, far, n_far, dp, 0u, QueueT<uint32_t>{near.p, misc.p},
+                           SsspQueue{far_next, (uint32_t *)(misc.p + 1)});
+        uint32_t h[2];
+        int rc = read_misc(h, 2);
+        if (rc) return rc;
+        std::swap(far, far_next);
+        n_far = h[1];
+        compactions++;
+        return CZ_OK;
+    }
+    int sssp_apply(uint32_t longest, uint32_t *n_near, uint32_t *n_far_out) {
+        const uint64_t total = (uint64_t)cz::comm_world(comm) * longest;
+        if (n_far + std::min<uint64_t>(N, total) > far_cap || n_far > compact_at) {
+            int rc = compact_far();
+            if (rc) return rc;
+        }
+        const uint32_t init[2] = {0, n_far};  // near starts empty, the far pile is appended to
+        uint32_t h[2];
+        CZ_HIP(hipMemcpyAsync(misc.p, init, 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(sssp_sp_apply_min_kernel, dim3(grid_for(total)), dim3(kT), 0, s, pairs.p, total, dp, lowered.p);
+        hipLaunchKernelGGL(sssp_sp_apply_place_kernel, dim3(grid_for(total)), dim3(kT), 0, s, pairs.p, lowered.p, total, dp, thr_bits,
+                           QueueT<uint32_t>{near.p, misc.p}, SsspQueue{far, (uint32_t *)(misc.p + 1)});
+        int rc = read_misc(h, 2);
+        if (rc) return rc;
+        *n_near = h[0];
+        *n_far_out = n_far = h[1];
+        return CZ_OK;
+    }
+    int sssp_next_bucket(uint32_t *n_near, uint32_t *n_far_out) {
+        const uint32_t none = 0xFFFFFFFFu;
+        CZ_HIP(hipMemcpyAsync(misc.p + 3, &none, 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(sssp_sp_far_min_kernel, dim3(grid_for(n_far)), dim3(kT), 0, s, far, n_far, dp, misc.p + 3);
+        uint32_t h[4];
+        int rc = read_misc(h, 4);
+        if (rc) return rc;
+        *n_near = 0;
+        if (h[3] == none) {  // every entry was stale
+            *n_far_out = n_far = 0;
+            return CZ_OK;
+        }
+        thr_bits = threshold_over(h[3]);
+        buckets++;
+        CZ_HIP(hipMemsetAsync(misc.p, 0, 8, s));
+        hipLaunchKernelGGL(sssp_sp_split_kernel, dim3(grid_for(n_far)), dim3(kT), 0, s, far, n_far, dp, thr_bits,
+                           QueueT<uint32_t>{near.p, misc.p}, SsspQueue{far_next, (uint32_t *)(misc.p + 1)});
+        if ((rc = read_misc(h, 2))) return rc;
+        std::swap(far, far_next);
+        *n_near = h[0];
+        *n_far_out = n_far = h[1];
         return CZ_OK;
     }
     int sssp_canonical_parents() {
@@ -2792,6 +3019,8 @@ struct HipShardedSssp {
     }
     int reduce_canonical() { return cz::comm_all_reduce(comm, canon.p, N, cz::COMM_U32, cz::COMM_MIN, s); }
 };
+
+thread_local uint64_t t_sssp_sharded_stats[4] = {0, 0, 0, 0};
 
 int check_shard(const uint32_t *off, const uint32_t *tgt, uint32_t N, uint32_t rb, uint32_t re, uint64_t e_local) {
     if (rb > re || re > N) return cz::set_error(CZ_E_INVALID, "bad row range [%u,%u) of %u", rb, re, N);
@@ -2889,6 +3118,7 @@ extern "C" int cz_sssp_sharded(cz_comm *comm, const uint32_t *out_offsets_local,
     b.re = row_end;
     if (!rc) rc = b.alloc(out_offsets_local, out_targets, weights, E_local);
     if ((rc = collective_status(comm, rc))) return rc;
+    if ((rc = b.agree_on_delta(weights, E_local))) return rc;
     for (uint32_t si = 0; si < n_starts; si++) {
         rc = czs::run_sharded_sssp(b, starts[si], N, poison);
         if (rc == czs::TRAVERSAL_CANCELLED) return cz::set_error(CZ_E_CANCELLED, "cancelled");
@@ -2898,7 +3128,17 @@ extern "C" int cz_sssp_sharded(cz_comm *comm, const uint32_t *out_offsets_local,
         if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sharded sssp launch: %s", hipGetErrorString(e));
         CZ_HIP(hipMemcpy(dist + (size_t)si * N, b.dist.p, (size_t)N * 4, hipMemcpyDeviceToHost));
         CZ_HIP(hipMemcpy(parent + (size_t)si * N, b.parent.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+        t_sssp_sharded_stats[0] = b.rounds;
+        t_sssp_sharded_stats[1] = b.pairs_exchanged;
+        t_sssp_sharded_stats[2] = b.compactions;
+        t_sssp_sharded_stats[3] = b.buckets;
     }
+    return CZ_OK;
+}
+
+extern "C" int cz_sssp_sharded_last_stats(uint64_t *out4) {
+    if (!out4) return cz::set_error(CZ_E_INVALID, "null out");
+    for (int i = 0; i < 4; i++) out4[i] = t_sssp_sharded_stats[i];
     return CZ_OK;
 }
 

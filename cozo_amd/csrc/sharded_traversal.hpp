@@ -22,9 +22,20 @@
 // and once at the end an all-reduce(min) of the parent words (each written by exactly one rank, CZ_NONE elsewhere).
 //
 // SSSP: dist[v] = min over predecessors of fl32(dist[u] + w) is the unique fixpoint of monotone relaxation, so costs are
-// bit-identical to Dijkstra's under any schedule.  Per round every rank relaxes the out-edges of ITS frontier nodes into
-// a proposal array (a copy of the packed (cost << 32 | parent) words; atomicMin with proposals that STRICTLY improve on the
-// round's starting cost), the proposals are all-reduced(min, u64), and the nodes whose word changed are the next frontier.
+// bit-identical to Dijkstra's under any schedule.  Round 4: the schedule is the one-GPU rule's near-far piles, and the exchange is
+// SPARSE -- what crosses the links per round is the list of (target, proposed word) pairs, not the N-word state (the first form
+// all-reduced N packed words per round: 80 MB at 10M nodes whatever the frontier held).  Every rank keeps the whole state
+// (packed (cost << 32 | parent) words, the near list, the far pile, the threshold) and all of them apply the SAME pairs, so the
+// replicas stay equal without ever being compared:
+//   relax     every rank relaxes the out-edges of the near nodes IT OWNS against the round's starting state and keeps, per
+//             target, its best strictly improving proposal: one (word, target) pair per touched target
+//   counts    all-gather of one word per rank (its pair count, and its cancellation flag): everyone learns the longest list
+//   pairs     all-gather of the lists, padded to the longest
+//   apply     every rank lowers the words of the targets with every pair (min); the pair that ends up as a target's word is its
+//             one winner, and the winner decides where the target goes: the next near list if its new cost is below the
+//             threshold, else the far pile (with that cost: an entry whose node got cheaper later is stale and is dropped)
+//   bucket    when the near list runs dry: threshold = the cheapest live far entry + the bucket width (the mean edge weight);
+//             live far entries below it become the near list.  No exchange: every rank holds the same pile.
 // A proposal never has the cost a node already has, so no parent pointer is ever replaced at equal cost: the predecessor
 // graph stays a tree.  Afterwards the parents are made canonical exactly like the single-GPU rule does it (the smallest
 // tight predecessor of strictly smaller cost): per-rank candidates + an all-reduce(min).
@@ -93,26 +104,39 @@ int run_sharded_bfs(B &b, uint32_t start, uint32_t N, bool has_goals, bool keep_
 }
 
 // Backend interface, SSSP:
-//   int sssp_seed(uint32_t start, uint32_t *fsize)   every word = (inf, NONE); the start's = (0.0, NONE); frontier = [start]
-//   int sssp_propose(uint32_t fsize)                 proposals = copy of the words; relax the owned frontier nodes into it
-//   int reduce_proposals()                           all-reduce(min, u64) over N words
-//   int sssp_advance(uint32_t *fsize)                frontier = nodes whose proposal differs from their word; words = proposals
+//   int sssp_seed(uint32_t start, uint32_t *n_near)  every word = (inf, NONE); the start's = (0.0, NONE); near = [start]; far empty;
+//                                                    threshold = the bucket width
+//   int sssp_relax(uint32_t n_near)                  the owned near nodes' out-edges -> this rank's pair list
+//   int exchange_counts(bool poisoned, uint32_t *longest, bool *any_poisoned)
+//   int exchange_pairs(uint32_t longest)             all-gather of the lists, each padded to `longest` pairs
+//   int sssp_apply(uint32_t longest, uint32_t *n_near, uint32_t *n_far)   as above; near = this round's winners below the threshold
+//   int sssp_next_bucket(uint32_t *n_near, uint32_t *n_far)               as above; both 0 when no live far entry is left
 //   int sssp_canonical_parents()                     per-rank smallest tight predecessor of strictly smaller cost ...
 //   int reduce_canonical()                           ... all-reduce(min) over N words; a backend's unpack prefers it
 template <class B>
-int run_sharded_sssp(B &b, uint32_t start, uint32_t N, const volatile uint8_t *poison) {
+int run_sharded_sssp(B &b, uint32_t start, uint32_t N, const volatile uint8_t *poison, uint32_t *rounds_out = nullptr) {
     int rc;
-    uint32_t fsize = 0;
-    if ((rc = b.sssp_seed(start, &fsize))) return rc;
-    if (start >= N) fsize = 0;
-    while (fsize > 0) {
-        bool cancel = false;
-        if ((rc = b.any_poisoned(poison && *poison, &cancel))) return rc;
+    uint32_t n_near = 0, n_far = 0, rounds = 0;
+    if ((rc = b.sssp_seed(start, &n_near))) return rc;
+    if (start >= N) n_near = 0;
+    for (;;) {
+        if (n_near == 0) {
+            if (n_far == 0) break;
+            if ((rc = b.sssp_next_bucket(&n_near, &n_far))) return rc;  // local: every rank holds the same pile
+            continue;
+        }
+        if ((rc = b.sssp_relax(n_near))) return rc;
+        uint32_t longest = 0;
+        bool cancel = false;  // collective: every rank leaves in the same round when ANY rank's Poison is set
+        if ((rc = b.exchange_counts(poison && *poison, &longest, &cancel))) return rc;
         if (cancel) return TRAVERSAL_CANCELLED;
-        if ((rc = b.sssp_propose(fsize))) return rc;
-        if ((rc = b.reduce_proposals())) return rc;
-        if ((rc = b.sssp_advance(&fsize))) return rc;
+        rounds++;
+        n_near = 0;
+        if (longest == 0) continue;  // nothing improved anywhere
+        if ((rc = b.exchange_pairs(longest))) return rc;
+        if ((rc = b.sssp_apply(longest, &n_near, &n_far))) return rc;
     }
+    if (rounds_out) *rounds_out = rounds;
     if ((rc = b.sssp_canonical_parents())) return rc;
     return b.reduce_canonical();
 }

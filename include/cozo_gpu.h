@@ -398,8 +398,11 @@ void cz_hnsw_multi_destroy(cz_hnsw_multi *m);
  * start, as for cz_bfs / cz_sssp) are the same on every rank.
  * cz_bfs_sharded keeps the reference's FIFO semantics across the ranks (parents = first discoverers, discovery order):
  * per level an all-reduce(min) of the N claim words, an all-reduce(sum) of the frontier's counts and one of the next
- * frontier; results are bit-identical to cz_bfs on the whole graph.  cz_sssp_sharded: per round an all-reduce(min) of
- * the N packed (cost, parent) proposals; costs and parents identical to cz_sssp's (positive weights).
+ * frontier; results are bit-identical to cz_bfs on the whole graph.  cz_sssp_sharded: the one-GPU rule's near-far schedule with a
+ * SPARSE exchange -- per round an all-gather of one count per rank and one of the ranks' (target, proposed (cost, parent) word)
+ * lists, which every rank applies to its copy of the state (csrc/sharded_traversal.hpp); costs and parents identical to cz_sssp's.
+ * cz_sssp_sharded_last_stats: what this thread's last call exchanged -- out[0] rounds, out[1] pairs over all ranks and rounds,
+ * out[2] compactions of the far pile, out[3] times the threshold moved (summed over the starts).
  * A set poison flag on ANY rank cancels every rank at the same level / round. */
 int cz_bfs_sharded(cz_comm *comm, const uint32_t *out_offsets_local, const uint32_t *out_targets, uint32_t N,
                    uint32_t row_begin, uint32_t row_end, uint64_t E_local, const uint32_t *starts, uint32_t n_starts,
@@ -408,6 +411,7 @@ int cz_bfs_sharded(cz_comm *comm, const uint32_t *out_offsets_local, const uint3
 int cz_sssp_sharded(cz_comm *comm, const uint32_t *out_offsets_local, const uint32_t *out_targets, const float *weights,
                     uint32_t N, uint32_t row_begin, uint32_t row_end, uint64_t E_local, const uint32_t *starts,
                     uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison);
+int cz_sssp_sharded_last_stats(uint64_t *out4);
 
 /* ConnectedComponents (strongly_connected_components.rs:42-77, strong = false) over a vertex partition of the SYMMETRISED
  * graph, collectively: this rank passes the adjacency of [row_begin, row_end) (offsets relative to the shard).  Per round every

@@ -222,6 +222,7 @@ extern "C" {
     pub fn cz_sssp_sharded(comm: *mut cz_comm, out_offsets_local: *const u32, out_targets: *const u32, weights: *const c_float,
                            n: u32, row_begin: u32, row_end: u32, e_local: u64, starts: *const u32, n_starts: u32,
                            dist: *mut c_float, parent: *mut u32, poison: *const u8) -> c_int;
+    pub fn cz_sssp_sharded_last_stats(out4: *mut u64) -> c_int;
 
     pub fn cz_bfs(out_offsets: *const u32, out_targets: *const u32, n: u32, e: u64, starts: *const u32, n_starts: u32,
                   goals: *const u32, n_goals: u32, share_visited: c_int, parent: *mut u32, depth: *mut u32, order: *mut u32,

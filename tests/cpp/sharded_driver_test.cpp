@@ -214,7 +214,7 @@ struct HostTraversal {
     cz_test_all_reduce_u32 ar32;
     cz_test_all_reduce_u64 ar64;
     const volatile uint8_t *poison_after;  // set by the test between levels
-    std::vector<uint32_t> depth, parent, claim, order, cnt, pos, buf, frontier, canon;
+    std::vector<uint32_t> depth, parent, claim, order, cnt, pos, buf, canon;
     std::vector<uint64_t> dp, prop;
     int exchanges = 0;
 
@@ -327,40 +327,127 @@ struct HostTraversal {
         std::memcpy(&f, &b, 4);
         return f;
     }
-    int sssp_seed(uint32_t start, uint32_t *fsize) {
+    // near-far piles + the sparse exchange (the all-gathers are all-reduce(sum)s of buffers zero outside the rank's own slot)
+    int rank = 0, world = 1;
+    float delta = 0.f;
+    uint32_t thr_bits = 0, rounds = 0;
+    uint64_t pairs_exchanged = 0, words_exchanged = 0;
+    std::vector<uint32_t> near, touched;
+    std::vector<uint64_t> far, pairs, counts;
+    uint32_t threshold_over(uint32_t min_bits) const {
+        if (!(delta > 0.f) || !std::isfinite(delta)) return 0x7F800000u;
+        const float m = val(min_bits);
+        float t = m + delta;
+        if (!(t > m)) t = std::nextafter(m, INFINITY);
+        return bits(t);
+    }
+    int sssp_seed(uint32_t start, uint32_t *n_near) {
         dp.assign(N, ((uint64_t)0x7F800000u << 32) | kNone);
-        prop = dp;
-        frontier.assign(N, 0);
+        prop.assign(N, ~0ull);
         canon.assign(N, kNone);
-        *fsize = 0;
+        near.clear();
+        far.clear();
+        touched.clear();
+        thr_bits = threshold_over(0u);
         if (start < N) {
             dp[start] = 0x00000000FFFFFFFFull;
-            frontier[0] = start;
-            *fsize = 1;
+            near.push_back(start);
         }
+        *n_near = (uint32_t)near.size();
         return 0;
     }
-    int sssp_propose(uint32_t fsize) {
-        prop = dp;
-        for (uint32_t i = 0; i < fsize; i++) {
-            const uint32_t u = frontier[i];
+    int sssp_relax(uint32_t n_near) {
+        for (uint32_t i = 0; i < n_near; i++) {
+            const uint32_t u = near[i];
             if (!owned(u)) continue;
             const float du = val((uint32_t)(dp[u] >> 32));
             for (uint64_t e = off[u - rb]; e < off[u - rb + 1]; e++) {
                 const uint32_t v = tgt[e];
                 const uint32_t nb = bits(du + w[e]);
-                if (nb < (uint32_t)(dp[v] >> 32)) prop[v] = std::min(prop[v], ((uint64_t)nb << 32) | u);
+                if (nb < (uint32_t)(dp[v] >> 32)) {
+                    if (prop[v] == ~0ull) touched.push_back(v);
+                    prop[v] = std::min(prop[v], ((uint64_t)nb << 32) | u);
+                }
             }
         }
         return 0;
     }
-    int reduce_proposals() { return ar64(ctx, prop.data(), N, 1); }
-    int sssp_advance(uint32_t *fsize) {
-        uint32_t c = 0;
-        for (uint32_t v = 0; v < N; v++)
-            if (prop[v] != dp[v]) frontier[c++] = v;
-        dp.swap(prop);
-        *fsize = c;
+    int exchange_counts(bool poisoned, uint32_t *longest, bool *any) {
+        counts.assign(world, 0);
+        counts[rank] = (uint64_t)touched.size() | ((uint64_t)(poisoned ? 1 : 0) << 40);
+        const int rc = ar64(ctx, counts.data(), world, 0);
+        exchanges++;
+        *longest = 0;
+        *any = false;
+        for (int r = 0; r < world; r++) {
+            *longest = std::max(*longest, (uint32_t)counts[r]);
+            *any = *any || (counts[r] >> 40) != 0;
+            pairs_exchanged += (uint32_t)counts[r];
+        }
+        rounds++;
+        return rc;
+    }
+    int exchange_pairs(uint32_t longest) {
+        pairs.assign(2 * (size_t)world * longest, 0);
+        uint64_t *slot = pairs.data() + 2 * (size_t)rank * longest;
+        for (uint32_t i = 0; i < longest; i++) {
+            uint64_t word = ~0ull, node = kNone;
+            if (i < touched.size()) {
+                node = touched[i];
+                word = prop[node];
+                prop[node] = ~0ull;
+            }
+            slot[2 * (size_t)i] = word;
+            slot[2 * (size_t)i + 1] = node;
+        }
+        touched.clear();
+        exchanges++;
+        words_exchanged += pairs.size();
+        return ar64(ctx, pairs.data(), pairs.size(), 0);
+    }
+    int sssp_apply(uint32_t longest, uint32_t *n_near, uint32_t *n_far) {
+        const size_t total = (size_t)world * longest;
+        std::vector<uint8_t> lowered(total, 0);
+        for (size_t i = 0; i < total; i++) {
+            const uint64_t word = pairs[2 * i], node = pairs[2 * i + 1];
+            if (node == kNone) continue;
+            if (word < dp[node]) {
+                dp[node] = word;
+                lowered[i] = 1;
+            }
+        }
+        near.clear();
+        for (size_t i = 0; i < total; i++) {
+            if (!lowered[i]) continue;
+            const uint64_t word = pairs[2 * i];
+            const uint32_t v = (uint32_t)pairs[2 * i + 1];
+            if (dp[v] != word) continue;  // a later pair went lower: that one is the winner
+            const uint32_t cost = (uint32_t)(word >> 32);
+            if (cost < thr_bits) near.push_back(v);
+            else far.push_back(((uint64_t)cost << 32) | v);
+        }
+        *n_near = (uint32_t)near.size();
+        *n_far = (uint32_t)far.size();
+        return 0;
+    }
+    int sssp_next_bucket(uint32_t *n_near, uint32_t *n_far) {
+        uint32_t m = 0xFFFFFFFFu;
+        for (uint64_t ent : far)
+            if ((uint32_t)(dp[(uint32_t)ent] >> 32) == (uint32_t)(ent >> 32)) m = std::min(m, (uint32_t)(ent >> 32));
+        near.clear();
+        std::vector<uint64_t> keep;
+        if (m != 0xFFFFFFFFu) {
+            thr_bits = threshold_over(m);
+            for (uint64_t ent : far) {
+                const uint32_t cost = (uint32_t)(ent >> 32);
+                if ((uint32_t)(dp[(uint32_t)ent] >> 32) != cost) continue;  // stale
+                if (cost < thr_bits) near.push_back((uint32_t)ent);
+                else keep.push_back(ent);
+            }
+        }
+        far.swap(keep);
+        *n_near = (uint32_t)near.size();
+        *n_far = (uint32_t)far.size();
         return 0;
     }
     int sssp_canonical_parents() {
@@ -405,9 +492,11 @@ extern "C" int cz_test_sharded_bfs_host(uint32_t N, uint32_t rb, uint32_t re, co
     return rc;
 }
 
-extern "C" int cz_test_sharded_sssp_host(uint32_t N, uint32_t rb, uint32_t re, const uint64_t *off_local, const uint32_t *tgt,
-                                         const float *w, uint32_t start, const volatile uint8_t *poison, void *ctx,
-                                         cz_test_all_reduce_u32 ar32, cz_test_all_reduce_u64 ar64, float *dist, uint32_t *parent) {
+// counters [4] = rounds, exchanges, pairs exchanged (all ranks' lists), u64 words that crossed the exchange (padding included)
+extern "C" int cz_test_sharded_sssp_host(uint32_t N, uint32_t rb, uint32_t re, int rank, int world, float delta, const uint64_t *off_local,
+                                         const uint32_t *tgt, const float *w, uint32_t start, const volatile uint8_t *poison, void *ctx,
+                                         cz_test_all_reduce_u32 ar32, cz_test_all_reduce_u64 ar64, float *dist, uint32_t *parent,
+                                         uint64_t *counters) {
     HostTraversal b;
     b.N = N;
     b.rb = rb;
@@ -420,7 +509,17 @@ extern "C" int cz_test_sharded_sssp_host(uint32_t N, uint32_t rb, uint32_t re, c
     b.ctx = ctx;
     b.ar32 = ar32;
     b.ar64 = ar64;
+    b.rank = rank;
+    b.world = world;
+    b.delta = delta;
     const int rc = czs::run_sharded_sssp(b, start, N, poison);
+    if (counters) {
+        counters[0] = b.rounds;
+        counters[1] = (uint64_t)b.exchanges;
+        counters[2] = b.pairs_exchanged;
+        counters[3] = b.words_exchanged;
+    }
+    if (rc) return rc;
     for (uint32_t v = 0; v < N; v++) {
         dist[v] = HostTraversal::val((uint32_t)(b.dp[v] >> 32));
         parent[v] = b.canon[v] != kNone ? b.canon[v] : (uint32_t)b.dp[v];

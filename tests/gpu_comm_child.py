@@ -100,7 +100,7 @@ def main():
     plain.close()
     print("OK hnsw_multi", flush=True)
     # ONE traversal over a "vertex-partitioned" graph of one rank == the single-GPU rule on the same graph
-    from cozo_amd.comm import bfs_sharded, sssp_sharded
+    from cozo_amd.comm import bfs_sharded, sssp_sharded, sssp_sharded_last_stats
     frm, to = util.random_relation(20000, 90000, 8)
     rng = np.random.default_rng(8)
     gw = util.graph_from_relation(O, frm, to, weights=(rng.integers(1, 40, len(frm)) / 4).astype(np.float64))
@@ -118,6 +118,36 @@ def main():
     assert np.array_equal(d0, d1) and np.array_equal(p0, p1), "cz_sssp_sharded differs from cz_sssp"
     want, _ = O.dijkstra(gw["n"], gw["ooff"], gw["otgt"], gw["ow"], 7)
     assert np.array_equal(d1[1], want)
+    # the near-far schedule of the sharded loop never changes a result: every bucket width (one pile, narrow, one the f32 sum
+    # absorbs, wider than any path), and a far pile whose stale entries are dropped again and again
+    for env in ({"CZ_SSSP_DELTA": "0"}, {"CZ_SSSP_DELTA": "2.0", "CZ_SSSP_FAR_COMPACT": "64"}, {"CZ_SSSP_DELTA": "1e-9"}, {"CZ_SSSP_DELTA": "1e9"}):
+        os.environ.update(env)
+        try:
+            dx, px = sssp_sharded(comm, gw["ooff"], gw["otgt"], gw["ow"], gw["n"], 0, gw["n"], starts)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert np.array_equal(d0, dx) and np.array_equal(p0, px), f"cz_sssp_sharded under {env} differs from cz_sssp"
+        st = sssp_sharded_last_stats()
+        assert st["rounds"] > 0 and st["pairs"] >= 3 * (np.isfinite(d0[0]).sum() - 1) // 2, st
+        if "CZ_SSSP_FAR_COMPACT" in env:
+            assert st["compactions"] > 0 and st["buckets"] > 3, f"the far pile was never compacted: {st}"
+        if env["CZ_SSSP_DELTA"] in ("0", "1e9"):
+            assert st["buckets"] == 0, st  # one pile / everything below the first threshold
+    # a rank that owns only part of the rows relaxes only those: the SSSP of the graph without the other rows' edges
+    half = gw["n"] // 2
+    o64 = gw["ooff"].astype(np.int64)
+    for rb_, re_ in ((0, half), (half, gw["n"])):
+        sub_off = np.zeros(gw["n"] + 1, dtype=np.int64)
+        deg = np.diff(o64)
+        deg[:rb_] = 0
+        deg[re_:] = 0
+        sub_off[1:] = np.cumsum(deg)
+        sub_tgt = gw["otgt"][o64[rb_]:o64[re_]]
+        sub_w = gw["ow"][o64[rb_]:o64[re_]]
+        dw, pw = G.sssp(sub_off.astype(np.uint32), sub_tgt, sub_w, starts)
+        ds, ps = sssp_sharded(comm, (o64[rb_:re_ + 1] - o64[rb_]).astype(np.uint32), sub_tgt, sub_w, gw["n"], rb_, re_, starts)
+        assert np.array_equal(dw, ds) and np.array_equal(pw, ps), f"cz_sssp_sharded over rows [{rb_}, {re_}) differs"
     print("OK bfs_sharded / sssp_sharded", flush=True)
     from cozo_amd.comm import connected_components_sharded
     fr2, to2 = util.random_relation(30000, 28000, 9)  # sparse: hundreds of components

@@ -18,6 +18,7 @@ from tests import util
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "cpp", "sharded_driver_test.cpp")
 HDR = os.path.join(ROOT, "cozo_amd", "csrc", "sharded_pagerank.hpp")
+HDR2 = os.path.join(ROOT, "cozo_amd", "csrc", "sharded_traversal.hpp")
 SO = os.path.join(ROOT, "tests", "cpp", "bin", "libsharded_driver_test.so")
 
 AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_uint64)
@@ -27,7 +28,7 @@ AR64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_uint64)
 
 def build():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR), os.path.getmtime(HDR2)):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", SRC, "-o", SO])
     return SO
 
@@ -204,11 +205,16 @@ def _traversal_worker(rank, world, port, what, g, start, goals, poison_at, q):
         w = np.ascontiguousarray(g["ow"][int(ooff[rb]):int(ooff[re])], dtype=np.float32)
         dist_out = np.empty(n, np.float32)
         parent = np.empty(n, np.uint32)
-        L.cz_test_sharded_sssp_host.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
-                                                C.c_void_p, C.c_void_p, ARU32, ARU64, C.c_void_p, C.c_void_p]
-        rc = L.cz_test_sharded_sssp_host(n, rb, re, off_local.ctypes.data, tgt.ctypes.data, w.ctypes.data, start, poison.ctypes.data,
-                                         None, ar32, ar64, dist_out.ctypes.data, parent.ctypes.data)
-        q.put((rank, rc, dist_out, parent))
+        counters = np.zeros(4, np.uint64)
+        # the bucket width: the mean edge weight of the whole graph unless the test forces one (0 = one pile)
+        delta = float(np.mean(g["ow"])) if g.get("delta") is None and len(g["ow"]) else float(g.get("delta") or 0.0)
+        L.cz_test_sharded_sssp_host.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, ARU32, ARU64, C.c_void_p, C.c_void_p,
+                                                C.c_void_p]
+        rc = L.cz_test_sharded_sssp_host(n, rb, re, rank, world, delta, off_local.ctypes.data, tgt.ctypes.data, w.ctypes.data, start,
+                                         poison.ctypes.data, None, ar32, ar64, dist_out.ctypes.data, parent.ctypes.data,
+                                         counters.ctypes.data)
+        q.put((rank, rc, dist_out, parent, counters.copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -259,7 +265,7 @@ def test_vertex_partitioned_sssp_world2_costs_are_dijkstras(oracle, n, e, seed):
     want_dist, _ = oracle.dijkstra(g["n"], g["ooff"], g["otgt"], g["ow"], 0)
     out = _run_traversal("sssp", g, 0)
     ooff = g["ooff"].astype(np.int64)
-    for _, rc, d, parent in out:
+    for _, rc, d, parent, _counters in out:
         assert rc == 0 and np.array_equal(d, want_dist), "f32 costs must be bit-identical to Dijkstra's"
         # every parent is a tight predecessor of strictly smaller cost -- the smallest such node -- on both ranks alike
         for v in range(g["n"]):
@@ -271,6 +277,53 @@ def test_vertex_partitioned_sssp_world2_costs_are_dijkstras(oracle, n, e, seed):
             if tight is not None:
                 assert parent[v] == min(tight)
     assert np.array_equal(out[0][3], out[1][3])
+
+
+@pytest.mark.parametrize("delta,world", [(None, 2), (0.0, 2), (0.25, 2), (1e-9, 2), (1e9, 2), (None, 3)])
+def test_vertex_partitioned_sssp_schedule_never_changes_the_result(oracle, delta, world):
+    """the near-far schedule of the sharded loop under every bucket width (the mean weight, one pile, a narrow one, one the f32
+    sum absorbs -- the threshold must still move --, one wider than every path) and over 2 and 3 ranks: costs == Dijkstra's,
+    parents equal on every rank; and the exchange is SPARSE: what crossed it is a small multiple of the pairs, far below the
+    rounds x N words the first form of the loop all-reduced"""
+    frm, to = util.random_relation(1200, 6000, 11)
+    rng = np.random.default_rng(11)
+    g = util.graph_from_relation(oracle, frm, to, weights=(rng.integers(1, 40, len(frm)) / 4).astype(np.float64))
+    g["delta"] = delta
+    want_dist, _ = oracle.dijkstra(g["n"], g["ooff"], g["otgt"], g["ow"], 0)
+    out = _run_traversal("sssp", g, 0, world=world)
+    for _, rc, d, parent, counters in out:
+        assert rc == 0 and np.array_equal(d, want_dist)
+        assert np.array_equal(parent, out[0][3])
+        rounds, exchanges, pairs, words = (int(x) for x in counters)
+        assert np.array_equal(counters, out[0][4]), "every rank saw the same rounds and the same pairs"
+        assert exchanges <= 2 * rounds + 1  # per round: the counts, and the pairs when there were any; + the parents at the end
+        assert pairs >= np.isfinite(want_dist).sum() - 1  # every reached node but the start was proposed at least once
+        assert words <= 2 * world * pairs + 2 * world * rounds  # padding to the longest list at most doubles... per rank and round
+        assert words < rounds * g["n"], "the exchange must not scale with rounds x N"
+    if delta is None and world == 2:  # the mean weight: more rounds than one pile, fewer relaxations (pairs)
+        g1 = dict(g, delta=0.0)
+        out1 = _run_traversal("sssp", g1, 0, world=2)
+        assert int(out1[0][4][2]) > int(out[0][4][2]), "one pile proposes more pairs than the near-far schedule"
+
+
+def test_vertex_partitioned_sssp_zero_weights_and_unreachable_nodes(oracle):
+    """all-zero weights (mean 0 = one pile; every cost 0.0) and a graph whose second half is unreachable"""
+    frm, to = util.random_relation(300, 900, 5)
+    keep = frm < 150  # nothing leaves... the nodes >= 150 have no out-edges; some are still reached
+    g = util.graph_from_relation(oracle, frm[keep], to[keep], weights=np.zeros(int(keep.sum())))
+    want_dist, _ = oracle.dijkstra(g["n"], g["ooff"], g["otgt"], g["ow"], 0)
+    out = _run_traversal("sssp", g, 0)
+    for _, rc, d, parent, _c in out:
+        assert rc == 0 and np.array_equal(d, want_dist)
+    assert np.array_equal(out[0][3], out[1][3])
+
+
+def test_vertex_partitioned_sssp_cancellation_is_collective(oracle):
+    frm, to = util.random_relation(600, 2500, 9)
+    rng = np.random.default_rng(9)
+    g = util.graph_from_relation(oracle, frm, to, weights=(rng.integers(1, 40, len(frm)) / 4).astype(np.float64))
+    out = _run_traversal("sssp", g, 0, poison_at=(1, 3))
+    assert [o[1] for o in out] == [1, 1]  # czs::TRAVERSAL_CANCELLED on both ranks, in the same round
 
 
 def test_vertex_partitioned_bfs_cancellation_is_collective(oracle):
