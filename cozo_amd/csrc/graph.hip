@@ -301,8 +301,13 @@ bfs_discover_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict
         if (first) fresh[w_base + w_used + __popcll(m & ((1ull << lane) - 1ull))] = v;
         w_used += cnt;
     };
-    auto claim_first = [&](uint32_t v, uint32_t i) {  // nobody had claimed v yet?
-        return !((vis[v >> 5] >> (v & 31)) & 1u) && atomicMin(&claim[v], i) == CZ_NONE;
+    // nobody had claimed v yet?  The claim word is READ first: a claim at or below position i (a stale copy can only be too
+    // high) needs no atomic -- random atomicMin runs at 27 G/s on this part, random loads at 63 (cz_random_access_probe), and at
+    // the widest level nine of ten claims on a node come after its first.
+    auto claim_first = [&](uint32_t v, uint32_t i) {
+        if ((vis[v >> 5] >> (v & 31)) & 1u) return false;
+        if (claim[v] <= i) return false;
+        return atomicMin(&claim[v], i) == CZ_NONE;
     };
     // A level is a chain of dependent reads per frontier node (frontier -> offsets -> targets -> visited bit -> claim): one
     // node at a time per lane group leaves the wave waiting on each link of the chain.  kBfsNodes nodes go down the chain
@@ -372,7 +377,7 @@ bfs_discover_long_kernel(const uint32_t *__restrict__ off, const uint32_t *__res
                 uint32_t v = 0;
                 if (e < s1) {
                     v = tgt[e];
-                    first = !((vis[v >> 5] >> (v & 31)) & 1u) && atomicMin(&claim[v], i) == CZ_NONE;
+                    first = !((vis[v >> 5] >> (v & 31)) & 1u) && claim[v] > i && atomicMin(&claim[v], i) == CZ_NONE;
                 }
                 const unsigned long long m = __ballot(first);
                 if (m) {
