@@ -97,6 +97,14 @@ void assign_ids_threaded(const czi_rows *rel, czi_graph &g, bool allow_negative_
     const uint64_t E = rel->n_rows;
     const uint32_t P = T;
     WorkerError err;
+    const bool trace = getenv("CZI_TRACE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[czi] assign_ids %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     // per-endpoint scratch, deliberately NOT zero-filled: the threads that write it take the page faults, in parallel
     std::unique_ptr<uint64_t[]> hashes(new uint64_t[2 * E + 1]);
     std::unique_ptr<const uint8_t *[]> eptr(new const uint8_t *[2 * E + 1]);  // the endpoint's memcmp bytes: inside the caller's key
@@ -149,6 +157,7 @@ void assign_ids_threaded(const czi_rows *rel, czi_graph &g, bool allow_negative_
         g_err = err.msg;
         throw Error{err.code};
     }
+    lap("(A) parse + hash");
     // (B)
     g.parts.resize(P);
     g.gid.resize(P);
@@ -192,6 +201,7 @@ void assign_ids_threaded(const czi_rows *rel, czi_graph &g, bool allow_negative_
         g_err = err.msg;
         throw Error{err.code};
     }
+    lap("(B) partitions resolve");
     // (C) rank of every first position
     std::vector<uint32_t> word_rank(first_bits.size());
     uint64_t total = 0;
@@ -220,6 +230,7 @@ void assign_ids_threaded(const czi_rows *rel, czi_graph &g, bool allow_negative_
         for (uint32_t l = 0; l < tab.size(); l++)
             memcpy(g.nodes.bytes.data() + off[g.gid[p][l]], tab.bytes.data() + tab.off[l], tab.off[l + 1] - tab.off[l]);
     });
+    lap("(C) ranks + node keys");
     // (D)
     parallel_for(T, [&](uint32_t t) {
         for (uint64_t i = E * t / T; i < E * (t + 1) / T; i++) {
@@ -227,6 +238,7 @@ void assign_ids_threaded(const czi_rows *rel, czi_graph &g, bool allow_negative_
             g.dst[i] = g.gid[part_of(hashes[2 * i + 1], P)][loc[2 * i + 1]];
         }
     });
+    lap("(D) local -> global");
 }
 
 
