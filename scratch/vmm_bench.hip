@@ -5,6 +5,9 @@
 //   malloc            plain hipMalloc (what hnsw_api.hip did through round 3)
 //   vmm:C:A           hipMemAddressReserve with alignment A MiB, physical chunks of C MiB from hipMemCreate, hipMemMap + hipMemSetAccess
 //   vmm1:A            ONE physical allocation for the whole table, VA aligned to A MiB
+//   vmma:C            chunks of C MiB mapped at a VA aligned to C MiB BY US (the reservation is C MiB larger and the mapping starts at the
+//                     next multiple): if what decides a landing is whether virtual and physical addresses agree modulo a large power of
+//                     two (so that the page tables can use large fragments), this form agrees by construction
 // optionally after fragmenting VRAM (`frag:G:K` = allocate G GiB in K-MiB hipMallocs, free every other one, then take the
 // largest contiguous remainder away with one more hipMalloc).  Usage:
 //   vmm_bench <rows> <reps> mode [mode ...]       (mode "frag:G:K" applies to the modes after it; "window:R" restricts pairs to R rows)
@@ -31,7 +34,8 @@ __global__ void fill_kernel(float *p, uint64_t n, uint32_t seed) {
 
 struct Table {
     float *p = nullptr;
-    size_t bytes = 0, va_bytes = 0;
+    void *va_base = nullptr;      // what hipMemAddressReserve returned (vmma: the mapped range starts above it)
+    size_t bytes = 0, va_bytes = 0, va_reserved = 0;
     std::vector<hipMemGenericAllocationHandle_t> handles;
     bool vmm = false;
     void free_() {
@@ -40,8 +44,10 @@ struct Table {
         else {
             CK(hipMemUnmap(p, va_bytes));
             for (auto h : handles) CK(hipMemRelease(h));
-            CK(hipMemAddressFree(p, va_bytes));
+            CK(hipMemAddressFree(va_base ? va_base : (void *)p, va_reserved ? va_reserved : va_bytes));
             handles.clear();
+            va_base = nullptr;
+            va_reserved = 0;
         }
         p = nullptr;
     }
@@ -63,7 +69,9 @@ static void alloc_table(Table &t, size_t bytes, const std::string &mode) {
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = dev;
     size_t chunk = 0, align = 0;
-    if (mode.rfind("vmm1:", 0) == 0) { align = (size_t)atoll(mode.c_str() + 5) << 20; chunk = 0; }
+    bool self_align = false;
+    if (mode.rfind("vmma:", 0) == 0) { chunk = align = (size_t)atoll(mode.c_str() + 5) << 20; self_align = true; }
+    else if (mode.rfind("vmm1:", 0) == 0) { align = (size_t)atoll(mode.c_str() + 5) << 20; chunk = 0; }
     else if (mode.rfind("vmm:", 0) == 0) {
         const char *s = mode.c_str() + 4;
         chunk = (size_t)atoll(s) << 20;
@@ -76,7 +84,14 @@ static void alloc_table(Table &t, size_t bytes, const std::string &mode) {
     t.va_bytes = n_chunks * chunk;
     t.vmm = true;
     void *va = nullptr;
-    CK(hipMemAddressReserve(&va, t.va_bytes, align, nullptr, 0));
+    if (self_align) {  // the alignment argument is ignored by this runtime: reserve `align` more and start at the next multiple
+        t.va_reserved = t.va_bytes + align;
+        CK(hipMemAddressReserve(&va, t.va_reserved, 0, nullptr, 0));
+        t.va_base = va;
+        va = (void *)(((uintptr_t)va + align - 1) / align * align);
+    } else {
+        CK(hipMemAddressReserve(&va, t.va_bytes, align, nullptr, 0));
+    }
     t.p = (float *)va;
     for (size_t i = 0; i < n_chunks; i++) {
         hipMemGenericAllocationHandle_t h;
