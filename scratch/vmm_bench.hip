@@ -174,6 +174,40 @@ int main(int argc, char **argv) {
             continue;
         }
         if (mode == "unfrag") { for (void *p : frag_keep) CK(hipFree(p)); frag_keep.clear(); continue; }
+        if (mode.rfind("hold:", 0) == 0) {
+            // K tables alive AT ONCE (hipMalloc), each measured in turn, three rounds: is a landing good or bad for as long as it lives
+            // (then index creation can draw K and keep the best), or does the same table move between measurements (then it is noise)?
+            const int K = atoi(mode.c_str() + 5);
+            std::vector<Table> tabs(K);
+            for (int k = 0; k < K; k++) {
+                alloc_table(tabs[k], n * dim * 4, "malloc");
+                fill_kernel<<<4096, 256>>>(tabs[k].p, n * dim, 1u);
+            }
+            CK(hipDeviceSynchronize());
+            uint64_t s = 42;
+            for (uint64_t i = 0; i < P; i++) { h_pairs[2 * i] = (uint32_t)(sm64(s) % nq); h_pairs[2 * i + 1] = (uint32_t)(sm64(s) % window); }
+            CK(hipMemcpy(d_pairs, h_pairs.data(), P * 8, hipMemcpyHostToDevice));
+            for (int round = 0; round < 3; round++)
+                for (int k = 0; k < K; k++) {
+                    for (int i = 0; i < 2; i++) cz_distance_batch(CZ_COSINE, tabs[k].p, (uint32_t)n, dim, d_q, nq, d_pairs, P, d_out, CZ_DEVICE_PTRS, nullptr);
+                    CK(hipDeviceSynchronize());
+                    float sum = 0.f;
+                    for (int i = 0; i < reps; i++) {
+                        CK(hipEventRecord(e0, nullptr));
+                        cz_distance_batch(CZ_COSINE, tabs[k].p, (uint32_t)n, dim, d_q, nq, d_pairs, P, d_out, CZ_DEVICE_PTRS, nullptr);
+                        CK(hipEventRecord(e1, nullptr));
+                        CK(hipEventSynchronize(e1));
+                        float ms = 0;
+                        CK(hipEventElapsedTime(&ms, e0, e1));
+                        sum += ms;
+                    }
+                    printf("hold round %d table %d  va %p  avg %.3f ms  frac %.3f\n", round, k, (void *)tabs[k].p, sum / reps,
+                           (double)P * 3072 / (sum / reps) / 1e9 / 8.0);
+                    fflush(stdout);
+                }
+            for (auto &t : tabs) t.free_();
+            continue;
+        }
         Table t;
         auto t0 = std::chrono::steady_clock::now();
         alloc_table(t, n * dim * 4, mode);
