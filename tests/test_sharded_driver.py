@@ -279,7 +279,7 @@ def test_vertex_partitioned_sssp_world2_costs_are_dijkstras(oracle, n, e, seed):
     assert np.array_equal(out[0][3], out[1][3])
 
 
-@pytest.mark.parametrize("delta,world", [(None, 2), (0.0, 2), (0.25, 2), (1e-9, 2), (1e9, 2), (None, 3)])
+@pytest.mark.parametrize("delta,world", [(None, 2), (0.0, 2), (0.25, 2), (1e-9, 2), (1e9, 2), (None, 3), (0.25, 4)])
 def test_vertex_partitioned_sssp_schedule_never_changes_the_result(oracle, delta, world):
     """the near-far schedule of the sharded loop under every bucket width (the mean weight, one pile, a narrow one, one the f32
     sum absorbs -- the threshold must still move --, one wider than every path) and over 2 and 3 ranks: costs == Dijkstra's,
