@@ -51,3 +51,35 @@ def test_pmc_traffic_is_tied_to_kernels_and_workload():
 def test_thread_ladder_is_sane():
     ladder, usable = _bench().thread_ladder()
     assert usable >= 1 and ladder == sorted(set(ladder)) and ladder[-1] == usable and all(1 <= t <= usable for t in ladder)
+
+
+def test_committed_line_fits_the_drivers_tail_and_keeps_the_contract():
+    """the line of the last full run on record (profiles/r04_bench_final.json) re-printed by today's bench_line: under the limit,
+    `roofline` and `cpu_baseline` whole, and a `built_handle` object (the build's own handle, timed beside the re-created index)
+    survives the cut with its numbers"""
+    b = _bench()
+    with open(os.path.join(ROOT, "profiles", "r04_bench_final_detail.json")) as f:
+        full = json.load(f)
+    full["built_handle"] = dict(ms_per_step=5.44, frac=0.634, avg_launch_ms=5.43, same_results_after_reload=True, reload_s=1.2,
+                                what="x" * 400)
+    txt, _ = b.bench_line(full)
+    line = json.loads(txt)
+    assert len(txt) <= b.LINE_LIMIT
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+    assert line["built_handle"]["frac"] == 0.634 and line["built_handle"]["same_results_after_reload"] is True
+    assert "what" not in line["built_handle"]  # prose stays in the detail file
+    assert "model" not in line["config"] and "workload" in line["config"]
+
+
+def test_reload_flags_default_to_the_boundary_path(monkeypatch):
+    b = _bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = b.parse()
+    assert a.no_reload is False and a.index_cache is None
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--no-reload", "--index-cache", "/tmp/x"])
+    a = b.parse()
+    assert a.no_reload is True and a.index_cache == "/tmp/x"
