@@ -4,6 +4,7 @@
 // base table allocated in different ways:
 //   malloc            plain hipMalloc (what hnsw_api.hip did through round 3)
 //   vmm:C:A           hipMemAddressReserve with alignment A MiB, physical chunks of C MiB from hipMemCreate, hipMemMap + hipMemSetAccess
+//   contig            hipExtMallocWithFlags(hipDeviceMallocContiguous)
 //   vmm1:A            ONE physical allocation for the whole table, VA aligned to A MiB
 //   vmma:C            chunks of C MiB mapped at a VA aligned to C MiB BY US (the reservation is C MiB larger and the mapping starts at the
 //                     next multiple): if what decides a landing is whether virtual and physical addresses agree modulo a large power of
@@ -60,6 +61,16 @@ static void alloc_table(Table &t, size_t bytes, const std::string &mode) {
     if (mode == "malloc") {
         t.vmm = false;
         CK(hipMalloc((void **)&t.p, bytes));
+        return;
+    }
+    if (mode == "contig") {  // hipExtMallocWithFlags(hipDeviceMallocContiguous): physically contiguous VRAM, if the driver finds it
+        t.vmm = false;
+        hipError_t e = hipExtMallocWithFlags((void **)&t.p, bytes, hipDeviceMallocContiguous);
+        if (e != hipSuccess) {
+            printf("contig: %s -- falling back to hipMalloc\n", hipGetErrorString(e));
+            (void)hipGetLastError();
+            CK(hipMalloc((void **)&t.p, bytes));
+        }
         return;
     }
     int dev = 0;
