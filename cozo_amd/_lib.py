@@ -17,6 +17,7 @@ CZ_HNSW_EXTEND_CANDIDATES = 256
 CZ_BF_GEMM = 8
 CZ_PR_GATHER = 2
 CZ_PR_BLOCKED = 4
+CZ_PR_ACCUMULATE = 1024
 CZ_PR_EXCHANGE_ALLREDUCE = 32
 CZ_PR_OVERLAP_EXCHANGE = 64
 CZ_PR_ERR_F64_DIFF = 128
@@ -125,6 +126,8 @@ SYMBOLS = {
     "cz_pagerank_plan_scores": (C.c_void_p, [C.c_void_p]),
     "cz_pagerank_plan_edges": (C.c_uint64, [C.c_void_p]),
     "cz_pagerank_plan_is_blocked": (C.c_int, [C.c_void_p]),
+    "cz_pagerank_plan_formulation": (C.c_int, [C.c_void_p]),
+    "cz_pagerank_plan_shape": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cz_pagerank_plan_read_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "cz_pagerank_plan_nodes": (C.c_uint32, [C.c_void_p]),
     "cz_comm_unique_id": (C.c_int, [C.c_void_p]),

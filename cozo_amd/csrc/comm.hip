@@ -491,12 +491,12 @@ extern "C" int cz_pagerank_multi(const uint32_t *in_offsets, const uint32_t *in_
         const uint32_t half = per / 2;
         const uint32_t mid = overlap ? std::min<uint32_t>(re, rb + half) : re;
         wrc = cz_pagerank_plan_create(off.data(), in_sources + in_offsets[rb], out_degree, N, rb, mid, damping, &plan,
-                                      flags & (CZ_PR_GATHER | CZ_PR_BLOCKED));
+                                      flags & (CZ_PR_GATHER | CZ_PR_BLOCKED | CZ_PR_ACCUMULATE));
         if (!wrc && overlap) {
             std::vector<uint32_t> off2((size_t)(re - mid) + 1);
             for (uint32_t i = 0; i <= re - mid; i++) off2[i] = in_offsets[mid + i] - in_offsets[mid];
             wrc = cz_pagerank_plan_create(off2.data(), in_sources + in_offsets[mid], out_degree, N, mid, re, damping, &plan_b,
-                                          flags & (CZ_PR_GATHER | CZ_PR_BLOCKED));
+                                          flags & (CZ_PR_GATHER | CZ_PR_BLOCKED | CZ_PR_ACCUMULATE));
         }
         // a rank that failed before the loop would leave the others blocked in the first collective: every rank enters
         // the loop, a failed one with its poison flag raised

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/cozo_gpu.h"
@@ -36,6 +37,45 @@ int comm_all_reduce(cz_comm *c, void *buf_dev, size_t count, int dtype, int op, 
 // every rank's `count` elements at `send` -> recv[rank * count ...] on every rank; in place when send == recv + rank * count
 int comm_all_gather(cz_comm *c, const void *send_dev, void *recv_dev, size_t count, int dtype, hipStream_t stream);
 int comm_world(const cz_comm *c);
+// A table the search kernels read at random (an index' vectors): physically contiguous VRAM when the driver can find it
+// (hipExtMallocWithFlags(hipDeviceMallocContiguous): lands the same every time -- profiles/r04_built_vs_created.txt,
+// profiles/r05_contiguous_table.txt), plain hipMalloc otherwise or under CZ_TABLE_CONTIGUOUS=0.  Freed with hipFree either
+// way.  *contiguous (optional) says which one it was; CZ_TABLE_TRACE=1 says it on stderr.
+inline hipError_t alloc_table(void **p, size_t bytes, bool *contiguous = nullptr) {
+    const char *e = getenv("CZ_TABLE_CONTIGUOUS");
+    const bool trace = getenv("CZ_TABLE_TRACE") != nullptr;
+    if (contiguous) *contiguous = false;
+    if ((!e || atoi(e) != 0) && bytes >= (64u << 20)) {
+        if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) == hipSuccess) {
+            if (contiguous) *contiguous = true;
+            if (trace) fprintf(stderr, "[table] %.2f GB contiguous\n", bytes / 1e9);
+            return hipSuccess;
+        }
+        (void)hipGetLastError();
+        if (trace) fprintf(stderr, "[table] %.2f GB: no contiguous range, plain hipMalloc\n", bytes / 1e9);
+    }
+    return hipMalloc(p, bytes);
+}
+// A table that had to be allocated while the one it replaces was still held (an insert: the old rows are copied over) may
+// have missed its contiguous range only because of that.  Once the old table is gone: try again, move the rows, free the
+// first copy.  Leaves *table alone when the second attempt fails too.
+inline void rehome_table(float **table, size_t bytes, hipStream_t stream) {
+    const char *e = getenv("CZ_TABLE_CONTIGUOUS");
+    if ((e && atoi(e) == 0) || bytes < (64u << 20)) return;
+    void *q = nullptr;
+    if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocContiguous) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    if (hipMemcpyAsync(q, *table, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(q);
+        return;
+    }
+    (void)hipFree(*table);
+    *table = (float *)q;
+    if (getenv("CZ_TABLE_TRACE")) fprintf(stderr, "[table] %.2f GB moved into a contiguous range\n", bytes / 1e9);
+}
 int comm_rank(const cz_comm *c);
 
 // RAII device buffer (freed on scope exit unless released)

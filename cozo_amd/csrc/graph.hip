@@ -880,8 +880,11 @@ struct cz_graph {
     unsigned long long bad = ~0ull;    // smallest index of a negative / NaN weight (BadEdgeWeightError when a rule needs them)
     float bad_value = 0.f;
     // the state arrays of the last cz_sssp_on call on this graph (0.64 GB per source batch at 10M nodes), kept for the next one: a
-    // resident graph is what repeated calls run on, and they should not allocate at all (an entry is never shared between threads)
+    // resident graph is what repeated calls run on, and they should not allocate at all.  A handle may be used from several
+    // threads at once (cz_graph_upload hands it to whoever holds the pointer): the kept state belongs to the call that holds
+    // sssp_mu; a call that finds it taken runs on arrays of its own, and only a state that went through a whole call is kept.
     mutable std::shared_ptr<void> sssp_state;
+    mutable std::mutex sssp_mu;
 };
 
 namespace {
@@ -1534,7 +1537,10 @@ struct SsspBatch {
         S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_starts, pairs_budget / std::max<uint32_t>(N, 1)));
         const uint64_t SN = (uint64_t)S * N;
         if (SN >= 0xFFFFFFFFull) return cz::set_error(CZ_E_UNSUPPORTED, "too many (source, node) pairs per launch");
-        if (d_dp.n == SN && d_starts.n == S) return CZ_OK;  // a kept state of the same shape (a resident graph's repeated call)
+        // a kept state of the same shape (a resident graph's repeated call): every array, not just the first ones
+        if (d_dp.n == SN && d_starts.n == S && d_qtag.n == SN && d_ftag.n == SN && d_q[0].n == SN && d_q[1].n == SN && d_q[2].n == SN &&
+            d_q[3].n == SN)
+            return CZ_OK;
         CZ_HIP(d_qtag.alloc(SN));
         CZ_HIP(d_ftag.alloc(SN));
         CZ_HIP(d_dp.alloc(SN));
@@ -1662,35 +1668,44 @@ int sssp_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, float
     int rc = CZ_OK;
     // a resident graph (cz_sssp_on) keeps its state arrays between calls; a one-shot call owns them for its own duration
     std::shared_ptr<SsspCallState> own;
-    if (keep_state && G.sssp_state) own = std::static_pointer_cast<SsspCallState>(G.sssp_state);
+    std::unique_lock<std::mutex> held;
+    if (keep_state) held = std::unique_lock<std::mutex>(G.sssp_mu, std::try_to_lock);
+    const bool kept = keep_state && held.owns_lock();  // (another thread is inside cz_sssp_on on this handle: own arrays)
+    if (kept && G.sssp_state) own = std::static_pointer_cast<SsspCallState>(G.sssp_state);
     else own = std::make_shared<SsspCallState>();
-    if (keep_state) G.sssp_state = own;
+    if (kept) G.sssp_state.reset();  // published again below, once the call has gone through
     SsspBatch &sb = own->sb;
     cz::PoolBuf<uint32_t> &d_parent = own->d_parent;
     cz::PoolBuf<float> &d_dist = own->d_dist;
-    trace_mark("sssp_run: entry");
-    if ((rc = sb.attach(G, n_starts, 80ull << 20))) return rc;  // about 4 GB in all
-    const uint64_t SN = (uint64_t)sb.S * N;
-    if (d_parent.n != SN) CZ_HIP(d_parent.alloc(SN));
-    if (d_dist.n != SN) CZ_HIP(d_dist.alloc(SN));
-    hipStream_t s = sb.s;
-    trace_mark("sssp_run: attach + allocs");
-    t_timing.lap(T_UPLOAD);
-    for (uint32_t s0 = 0; s0 < n_starts; s0 += sb.S) {
-        const uint32_t ns = std::min<uint32_t>(sb.S, n_starts - s0);
-        const uint64_t nsN = (uint64_t)ns * N;
-        if ((rc = sb.run(starts + s0, ns, poison))) return rc;
-        hipLaunchKernelGGL(sssp_unpack_flagged_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, sb.d_dp.p, nsN, d_dist.p, d_parent.p);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sssp launch: %s", hipGetErrorString(e));
-        trace_mark("sssp_run: unpack");
-        t_timing.lap(T_DEVICE);
-        CZ_HIP(hipMemcpy(dist + (size_t)s0 * N, d_dist.p, nsN * 4, hipMemcpyDeviceToHost));
-        CZ_HIP(hipMemcpy(parent + (size_t)s0 * N, d_parent.p, nsN * 4, hipMemcpyDeviceToHost));
-        trace_mark("sssp_run: download");
-        t_timing.lap(T_DOWNLOAD);
-    }
-    return CZ_OK;
+    auto body = [&]() -> int {
+        trace_mark("sssp_run: entry");
+        if ((rc = sb.attach(G, n_starts, 80ull << 20))) return rc;  // about 4 GB in all
+        const uint64_t SN = (uint64_t)sb.S * N;
+        if (d_parent.n != SN) CZ_HIP(d_parent.alloc(SN));
+        if (d_dist.n != SN) CZ_HIP(d_dist.alloc(SN));
+        hipStream_t s = sb.s;
+        trace_mark("sssp_run: attach + allocs");
+        t_timing.lap(T_UPLOAD);
+        for (uint32_t s0 = 0; s0 < n_starts; s0 += sb.S) {
+            const uint32_t ns = std::min<uint32_t>(sb.S, n_starts - s0);
+            const uint64_t nsN = (uint64_t)ns * N;
+            if ((rc = sb.run(starts + s0, ns, poison))) return rc;
+            hipLaunchKernelGGL(sssp_unpack_flagged_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, sb.d_dp.p, nsN, d_dist.p, d_parent.p);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sssp launch: %s", hipGetErrorString(e));
+            trace_mark("sssp_run: unpack");
+            t_timing.lap(T_DEVICE);
+            CZ_HIP(hipMemcpy(dist + (size_t)s0 * N, d_dist.p, nsN * 4, hipMemcpyDeviceToHost));
+            CZ_HIP(hipMemcpy(parent + (size_t)s0 * N, d_parent.p, nsN * 4, hipMemcpyDeviceToHost));
+            trace_mark("sssp_run: download");
+            t_timing.lap(T_DOWNLOAD);
+        }
+        return CZ_OK;
+    };
+    rc = body();
+    // a failed allocation leaves a half-built state behind: it is dropped, not handed to the next call
+    if (kept && (rc == CZ_OK || rc == CZ_E_CANCELLED)) G.sssp_state = own;
+    return rc;
 }
 
 }  // namespace

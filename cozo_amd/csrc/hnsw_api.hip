@@ -652,7 +652,7 @@ extern "C" int cz_hnsw_index_create(const cz_hnsw_desc *desc, const float *vecto
         }
     }
     // vectors
-    CZ_HIP(hipMalloc((void **)&ix->vec, std::max<size_t>(16, (size_t)ix->n * ix->ld * 4)));
+    CZ_HIP(cz::alloc_table((void **)&ix->vec, std::max<size_t>(16, (size_t)ix->n * ix->ld * 4)));
     rc = upload_padded(vectors, ix->n, ix->dim, ix->ld, ix->vec);
     if (rc) return rc;
     if (ix->n_levels > 0) {

@@ -541,7 +541,9 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
     // vectors: old rows kept, new rows appended
     {
         float *nv = nullptr;
-        CZ_HIP(hipMalloc((void **)&nv, std::max<size_t>(16, (size_t)n * ld * 4)));
+        bool contiguous = false;
+        const size_t table_bytes = std::max<size_t>(16, (size_t)n * ld * 4);
+        CZ_HIP(cz::alloc_table((void **)&nv, table_bytes, &contiguous));
         std::unique_ptr<float, void (*)(float *)> guard(nv, [](float *p) { (void)hipFree(p); });
         if (n_old) CZ_HIP(hipMemcpyAsync(nv, ix->vec, (size_t)n_old * ld * 4, hipMemcpyDeviceToDevice, stream));
         float *dst = nv + (size_t)n_old * ld;
@@ -558,8 +560,10 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
             CZ_HIP(hipMemcpy2D(dst, (size_t)ld * 4, vectors, (size_t)dim * 4, (size_t)dim * 4, n_new, hipMemcpyHostToDevice));
         }
         CZ_HIP(hipStreamSynchronize(stream));
+        const bool had_old = ix->vec != nullptr;
         if (ix->vec) (void)hipFree(ix->vec);
         ix->vec = guard.release();
+        if (had_old && !contiguous) cz::rehome_table(&ix->vec, table_bytes, stream);  // the old table was in the way
     }
     // levels: caller-supplied (non-negative = -layer) or drawn here: floor(-ln(U) / ln(m)), hnsw.rs:46-52.
     // Until the build has gone through, the handle must stay what it was: a failure further down (a bad level, an

@@ -279,13 +279,14 @@ pr_hub_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__ 
 }
 
 // ---- "blocked" formulation ----------------------------------------------------------------------------------
-// phase A: val[i] = contrib[slice_base + asrc[i]] for the positions of one work item, slice staged in LDS.
+// phase A: val[i] = contrib[slice * W + asrc[i]] for the positions of one work item, slice staged in LDS (W * 4 bytes of
+// dynamic LDS: a power of two <= 32768 in the blocked formulation, any multiple of 4 up to kMaxAccSlice in the accumulate one).
 // A workgroup step covers 4096 positions: lane t loads 4 local ids (8 bytes) and stores 4 values (16 bytes), so
 // that every wave store is one contiguous KiB; the first id vectors are requested before the slice is staged.
 __global__ void __launch_bounds__(kAThreads)
 pb_expand_kernel(const AItem *__restrict__ items, const uint16_t *__restrict__ asrc,
-                 const float *__restrict__ contrib, uint32_t N, uint32_t wlog, float *__restrict__ val) {
-    __shared__ float sl[1 << kMaxSliceLog2];
+                 const float *__restrict__ contrib, uint32_t N, uint32_t W, float *__restrict__ val) {
+    extern __shared__ __attribute__((aligned(16))) float sl[];
     constexpr int PF = 4;
     constexpr uint32_t STEP = kAThreads * 4;
     const AItem it = items[blockIdx.x];
@@ -296,8 +297,8 @@ pb_expand_kernel(const AItem *__restrict__ items, const uint16_t *__restrict__ a
         const uint32_t i = a0 + j * STEP;
         k[j] = i < it.end ? *(const uint2 *)(asrc + i) : make_uint2(0, 0);
     }
-    const uint32_t base = it.slice << wlog;
-    const uint32_t n = min(1u << wlog, N - base);
+    const uint32_t base = it.slice * W;
+    const uint32_t n = min(W, N - base);
     const float *c = contrib + base;
     if ((reinterpret_cast<uintptr_t>(c) & 15) == 0) {
         const uint32_t n4 = n & ~3u;
@@ -616,16 +617,206 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
 #endif
 }
 
+// ---- "accumulate" formulation: phase B without a tile -------------------------------------------------------------
+// The slices of phase A ascend in source id, and inside a slice the value stream is in CSR order -- (row, source)
+// ascending.  So the reference's sum of a row (s = s + contrib[src], sources ascending) is "the row's values of slice 0 in
+// stream order, then those of slice 1, ...": the values can be ADDED AS THEY ARRIVE into one f32 accumulator per row and
+// nothing has to be put back into CSR order first.  A wave owns a GROUP of consecutive rows (<= rw of them, one LDS word
+// each) and walks the group's piece of every slice's stream -- a CELL, (start, count) in `cell` -- in slice order:
+//   * per stream position a value (4 bytes) and the row's index inside the group (u16): 6 bytes per edge instead of the
+//     tile formulation's 6 + the rows' offsets (4 per row), and no second pass over LDS for the row sums;
+//   * a cell is sorted by row, so the values of one row are neighbours in it: lanes whose row differs from the lane
+//     below add straight into LDS (the usual case: every lane of a wave instruction, all rows distinct); a stretch of
+//     equal rows is added one lane after the other through a DPP wave_shr:1 chain, lowest lane first -- the reference's
+//     order -- and its last lane stores the row;
+//   * LDS operations of one wave execute in order, so a row that continues in the next piece or the next cell reads
+//     what the previous one stored: no barrier anywhere; the waves of a workgroup share nothing but the LDS allocation;
+//   * U pieces (<= 64 values each) are in flight per wave, requested in stream order across cell boundaries; the cells'
+//     descriptors are held 64 at a time across the lanes and the next 64 are requested a batch ahead.
+// The epilogue (new score, |delta|, next contribution) runs over the group's rows, coalesced.
+#ifndef CZ_PR_ACC_U
+#define CZ_PR_ACC_U 8
+#endif
+#ifndef CZ_PR_ACC_NT
+#define CZ_PR_ACC_NT 1  // the value / row streams of phase B are read once: non-temporal loads
+#endif
+constexpr int kAccU = CZ_PR_ACC_U;         // pieces in flight per wave of phase B
+constexpr int kMaxAccSlice = 40448;        // floats of LDS a phase-A workgroup may stage (158 KiB; one workgroup per CU)
+constexpr uint32_t kAccLdsBytes = 161792;  // phase B: accumulators of one CU (158 KiB), split over its workgroups and waves
+
+template <typename T>
+__device__ __forceinline__ T acc_stream_load(const T *p) {
+#if CZ_PR_ACC_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ uint32_t wave_shr1_u32(uint32_t v) {  // lane i <- lane i - 1, lane 0 <- 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
+}
+
+// adds one piece (values v of rows r on lanes < n, rows ascending) into acc[], every row in lane order
+__device__ __forceinline__ void acc_piece(float *acc, float v, uint32_t r, uint32_t n, uint32_t lane) {
+    const bool on = lane < n;
+    const uint32_t below = wave_shr1_u32(r);
+    const bool head = on && (lane == 0 || r != below);
+    const unsigned long long follow = __ballot(on && !head);
+    if (follow == 0ull) {  // every lane a row of its own
+        if (on) acc[r] = acc[r] + v;
+        return;
+    }
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long upto = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    const uint32_t rank = on ? lane - (63u - (uint32_t)__builtin_clzll(upto | 1ull)) : 0u;  // position inside the stretch of equal rows
+    float x = v;
+    if (head) x = acc[r] + v;
+    for (uint32_t k = 1; __ballot(rank >= k) != 0ull; k++) {
+        const float y = __uint_as_float(wave_shr1_u32(__float_as_uint(x)));
+        if (rank == k) x = y + v;
+    }
+    const bool tail = on && (lane + 1 == n || ((heads >> (lane + 1 < 64 ? lane + 1 : 63)) & 1ull));
+    if (tail) acc[r] = x;
+}
+
+template <int NW, int U>
+__global__ void __launch_bounds__(NW * 64)
+pa_reduce_kernel(const uint32_t *__restrict__ grow /* [G + 1]: first plan row of every group */, uint32_t G,
+                 const uint2 *__restrict__ cell /* [G][S + 1]: (stream position, count) */, uint32_t S,
+                 const uint16_t *__restrict__ arow, const float *__restrict__ val, const uint32_t *__restrict__ out_deg,
+                 uint32_t row_begin, float *__restrict__ contrib_out, float *__restrict__ scores, float base, float damping,
+                 double *__restrict__ partial, const uint32_t *__restrict__ row_id, uint32_t rw) {
+    extern __shared__ __attribute__((aligned(16))) float acc_all[];
+    __shared__ double red[NW];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * NW + wave;
+    float *acc = acc_all + (size_t)wave * rw;
+    double err = 0.0;
+    if (g < G) {
+        const uint32_t r0 = grow[g], nr = grow[g + 1] - r0;
+        const uint2 *cg = cell + (size_t)g * (S + 1);
+        // descriptors of the cells: 256 at a time across the lanes of four registers (lane l of dq[q] holds slice
+        // sb + 64 q + l), all of them for a graph of <= 256 slices -- a request in the middle of the stream would have to
+        // be waited for with every piece request that was made after the previous one still in flight
+        uint2 dq[4];
+        auto load_batch = [&](uint32_t sb) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t sl = sb + q * 64 + lane;
+                dq[q] = sl < S ? cg[sl] : make_uint2(0, 0);
+            }
+        };
+        load_batch(0);
+        for (uint32_t i = lane; i < nr; i += 64) acc[i] = 0.0f;
+        uint32_t sb = 0, u = 0, o = 0;
+        uint2 d = dq[0];
+        uint32_t cst = __builtin_amdgcn_readlane(d.x, 0), ccnt = __builtin_amdgcn_readlane(d.y, 0);
+        // the next piece of the group's stream: (position, length <= 64), length 0 when the stream is through
+        auto next_piece = [&](uint32_t &pa, uint32_t &pn) {
+            while (o >= ccnt) {
+                u++;
+                if (sb + u >= S) {
+                    pa = 0;
+                    pn = 0;
+                    return;
+                }
+                if ((u & 63u) == 0) {
+                    if (u == 256) {
+                        sb += 256;
+                        u = 0;
+                        load_batch(sb);
+                        d = dq[0];
+                    } else {
+                        d = u == 64 ? dq[1] : u == 128 ? dq[2] : dq[3];
+                    }
+                }
+                cst = __builtin_amdgcn_readlane(d.x, u & 63u);
+                ccnt = __builtin_amdgcn_readlane(d.y, u & 63u);
+                o = 0;
+            }
+            pa = cst + o;
+            pn = min(64u, ccnt - o);
+            o += 64;
+        };
+        uint32_t pn[U];
+        float v[U];
+        uint32_t r[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            uint32_t pa;
+            next_piece(pa, pn[j]);
+            // (every lane loads: lanes beyond the piece repeat its first element -- no branch around a load, so that the
+            //  compiler can count the loads in flight instead of waiting for all of them)
+            const uint32_t at = pa + (lane < pn[j] ? lane : 0u);
+            v[j] = acc_stream_load(val + at);
+            r[j] = acc_stream_load(arow + at);
+        }
+        while (pn[0] != 0) {
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                if (pn[j] != 0) acc_piece(acc, v[j], r[j], pn[j], lane);
+                uint32_t pa;
+                next_piece(pa, pn[j]);
+                const uint32_t at = pa + (lane < pn[j] ? lane : 0u);
+                v[j] = acc_stream_load(val + at);
+                r[j] = acc_stream_load(arow + at);
+            }
+        }
+        // epilogue: the group's rows, four per lane in flight
+        for (uint32_t i0 = lane; i0 < nr; i0 += 256) {
+            uint32_t cr[4], od[4];
+            float old[4], s4[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t i = i0 + j * 64;
+                if (i < nr) {
+                    cr[j] = caller_row(row_id, r0 + i);
+                    old[j] = scores[cr[j]];
+                    od[j] = out_deg[row_begin + cr[j]];
+                    s4[j] = acc[i];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (i0 + j * 64 < nr) err += finish_row(s4[j], cr[j], old[j], od[j], row_begin, contrib_out, scores, base, damping);
+        }
+    }
+    const double total = block_sum_f64<NW * 64>(err, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+
+// plan construction: the row's index inside its group for every in-edge of the groups' rows (CSR order) ...
+__global__ void __launch_bounds__(256)
+pa_rowlocal_kernel(const uint32_t *__restrict__ grow, const uint32_t *__restrict__ off, uint16_t *__restrict__ rl) {
+    const uint32_t r0 = grow[blockIdx.x], r1 = grow[blockIdx.x + 1];
+    for (uint32_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        const uint32_t a = off[r], z = off[r + 1];
+        for (uint32_t e = a; e < z; e++) rl[e] = (uint16_t)(r - r0);
+    }
+}
+// ... and in stream order; the local source ids of a slice width that is not a power of two
+__global__ void __launch_bounds__(256)
+pa_streams_kernel(const uint32_t *__restrict__ sidx, const uint32_t *__restrict__ src, const uint16_t *__restrict__ rl,
+                  uint32_t n, uint32_t W, uint32_t e_groups, uint16_t *__restrict__ asrc, uint16_t *__restrict__ arow) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t e = sidx[i];
+        const uint32_t sv = src[e];
+        asrc[i] = (uint16_t)(sv - (sv / W) * W);
+        arow[i] = e < e_groups ? rl[e] : (uint16_t)0;
+    }
+}
+
 // ---- plan construction kernels (run once) -------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 pb_keys_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__ blk_chunk,
-               const uint32_t *__restrict__ off, const uint32_t *__restrict__ src, uint32_t wlog, uint32_t S,
+               const uint32_t *__restrict__ off, const uint32_t *__restrict__ src, uint32_t W, uint32_t S,
                uint32_t skip_key, uint32_t *__restrict__ keys, uint32_t *__restrict__ idx) {
     const RowBlock rb = blocks[blockIdx.x];
     const uint32_t ch = blk_chunk[blockIdx.x];
     const uint32_t e0 = rb.e0, e1 = rb.e1;
     for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) {
-        keys[e] = ch == CZ_NONE ? skip_key : ch * S + (src[e] >> wlog);
+        keys[e] = ch == CZ_NONE ? skip_key : ch * S + src[e] / W;
         idx[e] = e;
     }
 }
@@ -646,10 +837,12 @@ pb_keyptr_kernel(const uint32_t *__restrict__ skeys, uint32_t E, uint32_t n_keys
 }
 
 __global__ void __launch_bounds__(256)
-pb_asrc_kernel(const uint32_t *__restrict__ sidx, const uint32_t *__restrict__ src, uint32_t n, uint32_t wmask,
+pb_asrc_kernel(const uint32_t *__restrict__ sidx, const uint32_t *__restrict__ src, uint32_t n, uint32_t W,
                uint16_t *__restrict__ asrc) {
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-        asrc[i] = (uint16_t)(src[sidx[i]] & wmask);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t sv = src[sidx[i]];
+        asrc[i] = (uint16_t)(sv - (sv / W) * W);
+    }
 }
 
 // stability of the sort (edge indices ascending inside every key bucket) is what the layout relies on: verify it
@@ -928,7 +1121,13 @@ struct cz_pagerank_plan {
     uint32_t n_gblocks = 0, n_hblocks = 0;
     RowBlock *d_gblocks = nullptr, *d_hblocks = nullptr;
     // blocked formulation
-    uint32_t wlog = 0, S = 0, n_chunks = 0, n_bblocks = 0;
+    uint32_t slice_w = 0, S = 0, n_chunks = 0, n_bblocks = 0;
+    // accumulate formulation (pa_reduce_kernel): plan rows [0, grow[n_groups]) in groups, one wave each
+    bool accum = false;
+    uint32_t n_groups = 0, e_groups = 0, acc_nw = 16, acc_rw = 0, n_awgs = 0;
+    uint32_t *d_grow = nullptr;
+    uint2 *d_cell = nullptr;
+    uint16_t *d_arow = nullptr;
     RowBlock *d_bblocks = nullptr;
     AItem *d_items = nullptr;
     std::vector<uint32_t> item_ptr, blk_ptr;  // per chunk
@@ -954,7 +1153,7 @@ struct cz_pagerank_plan {
     double *d_partial = nullptr;
     ~cz_pagerank_plan() {
         void *ps[] = {d_gblocks, d_hblocks, d_bblocks, d_items, d_asrc, d_perm, d_vpos, d_seg, d_val, d_off, d_src, d_outdeg, d_scores,
-                      d_partial, d_rowid};
+                      d_partial, d_rowid, d_grow, d_cell, d_arow};
         (void)hipDeviceSynchronize();  // (what hipFree did implicitly: nothing of this plan is in flight any more)
         for (void *p : ps) plan_free(p);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -965,11 +1164,11 @@ struct cz_pagerank_plan {
 
 namespace {
 
-// cut [0, rows) into row blocks: consecutive rows whose in-edges fit one tile; a row longer than a tile is alone
-int cut_row_blocks(const uint32_t *in_offsets, uint32_t rows, uint32_t tile, std::vector<RowBlock> &blocks) {
+// cut [r_begin, rows) into row blocks: consecutive rows whose in-edges fit one tile; a row longer than a tile is alone
+int cut_row_blocks(const uint32_t *in_offsets, uint32_t r_begin, uint32_t rows, uint32_t tile, std::vector<RowBlock> &blocks) {
     blocks.clear();
-    blocks.reserve((size_t)(in_offsets[rows] / tile) + rows / kMaxRowsPerBlock + 16);
-    uint32_t r = 0;
+    blocks.reserve((size_t)((in_offsets[rows] - in_offsets[r_begin]) / tile) + (rows - r_begin) / kMaxRowsPerBlock + 16);
+    uint32_t r = r_begin;
     while (r < rows) {
         uint32_t r1 = r + 1;
         if (in_offsets[r1] - in_offsets[r] <= tile) {
@@ -982,16 +1181,90 @@ int cut_row_blocks(const uint32_t *in_offsets, uint32_t rows, uint32_t tile, std
     return CZ_OK;
 }
 
-// builds the static layout of the blocked formulation on the device; p->d_off / d_src / d_outdeg are resident
-int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uint32_t n_chunks) {
+// The accumulate formulation's shape for a shard: NW waves per phase-B workgroup, `per_cu` workgroups per CU, groups of at
+// most rw rows; phase A: S slices of W sources (W a multiple of 4, W * 4 bytes of LDS)
+struct AccShape {
+    uint32_t W = 0, S = 0, NW = 16, per_cu = 1, rw = 0, a_per_cu = 1;
+};
+int device_cus() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    return cus;
+}
+AccShape acc_shape(uint32_t N) {
+    AccShape a;
+    const uint32_t cus = (uint32_t)device_cus();
+    a.NW = env_int("CZ_PR_ACC_WAVES", 16) == 8 ? 8u : 16u;
+    a.per_cu = (uint32_t)std::min(2, std::max(1, env_int("CZ_PR_ACC_PER_CU", 1)));
+    a.rw = ((kAccLdsBytes / a.per_cu / 4 / a.NW) & ~3u);
+    a.a_per_cu = (uint32_t)std::min(2, std::max(1, env_int("CZ_PR_ACC_A_PER_CU", 1)));
+    const uint32_t wmax = ((uint32_t)kMaxAccSlice / a.a_per_cu) & ~3u;
+    // slices: a multiple of the workgroup slots of phase A (one round of workgroups on a balanced graph)
+    const uint32_t slots = cus * a.a_per_cu;
+    uint32_t k = 1;
+    const int s_env = env_int("CZ_PR_ACC_SLICES", 0);
+    if (s_env > 0) {
+        a.W = std::min<uint32_t>(wmax, std::max<uint32_t>(4, (uint32_t)((((uint64_t)N + s_env - 1) / s_env + 3) & ~3ull)));
+    } else {
+        while ((((uint64_t)N + (uint64_t)slots * k - 1) / ((uint64_t)slots * k)) > wmax) k++;
+        a.W = (uint32_t)(((((uint64_t)N + (uint64_t)slots * k - 1) / ((uint64_t)slots * k)) + 3) & ~3ull);
+        a.W = std::max<uint32_t>(a.W, 1024);
+    }
+    a.S = (uint32_t)(((uint64_t)N + a.W - 1) / a.W);
+    return a;
+}
+
+// groups of the accumulate formulation: plan rows [0, n_rows) cut at equal shares of their edges, no group above rw rows
+void cut_groups(const uint32_t *h_off, uint32_t n_rows, const AccShape &a, std::vector<uint32_t> &grow) {
+    grow.assign(1, 0);
+    if (n_rows == 0) return;
+    const uint32_t cus = (uint32_t)device_cus();
+    const uint64_t E = h_off[n_rows];
+    const uint64_t per_round = (uint64_t)cus * a.per_cu * a.NW;
+    // whole rounds of workgroups; 3 % of head room in rows for groups cut by edges
+    uint64_t G = per_round;
+    while ((n_rows + G - 1) / G > (uint64_t)a.rw * 97 / 100) G += per_round;
+    if (const int g_env = env_int("CZ_PR_ACC_GROUPS", 0)) G = std::max<uint64_t>((uint64_t)g_env, (n_rows + a.rw - 1) / a.rw);
+    G = std::min<uint64_t>(G, n_rows);
+    uint32_t r = 0;
+    for (uint64_t k = 1; k <= G && r < n_rows; k++) {
+        uint32_t r1 = k == G ? n_rows : (uint32_t)(std::lower_bound(h_off + r, h_off + n_rows, (uint32_t)(E * k / G)) - h_off);
+        r1 = std::min(std::max(r1, r + 1), n_rows);
+        while (r1 - r > a.rw) {  // (a stretch of rows with few edges)
+            r += a.rw;
+            grow.push_back(r);
+        }
+        r = r1;
+        grow.push_back(r);
+    }
+    if (grow.back() != n_rows) {
+        while (n_rows - grow.back() > a.rw) grow.push_back(grow.back() + a.rw);
+        grow.push_back(n_rows);
+    }
+}
+
+// builds the static layout of the streamed formulations on the device; p->d_off / d_src / d_outdeg are resident.
+//   blocked:    every row in a tile block (n_group_rows = 0), slices of W = 2^k sources
+//   accumulate: plan rows [0, n_group_rows) in groups (pa_reduce_kernel), the rows behind them -- the heavy ones of a skewed
+//               graph, longest first -- in tile blocks (pb_reduce_kernel), both fed by one value stream
+int build_streamed(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t W, uint32_t n_chunks, uint32_t n_group_rows,
+                   const AccShape *shape) {
     const uint32_t rows = p->rows - p->n_empty;  // the rows without in-edges sit behind the others: pr_empty_rows_kernel
     const uint64_t E = p->E;
     StageTimer st;
+    n_group_rows = std::min(n_group_rows, rows);
+    std::vector<uint32_t> grow;
+    if (n_group_rows) cut_groups(h_off, n_group_rows, *shape, grow);
+    const uint32_t G = grow.empty() ? 0 : (uint32_t)grow.size() - 1;
+    const uint32_t e_groups = n_group_rows ? h_off[n_group_rows] : 0;
     std::vector<RowBlock> all;
-    cut_row_blocks(h_off, rows, kBTileNnz, all);
+    cut_row_blocks(h_off, n_group_rows, rows, kBTileNnz, all);
     st.lap("cut row blocks (host)");
     std::vector<RowBlock> bb, gb;  // blocked / long-row
-    uint64_t e_blocked = 0;
+    uint64_t e_blocked = e_groups;
     for (const RowBlock &rb : all) {
         const uint32_t nnz = rb.e1 - rb.e0;
         if (nnz > (uint32_t)kBTileNnz) gb.push_back(rb);
@@ -1000,7 +1273,8 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
             e_blocked += nnz;
         }
     }
-    const uint32_t S = (uint32_t)(((uint64_t)p->N + (1u << wlog) - 1) >> wlog);
+    const uint32_t S = (uint32_t)(((uint64_t)p->N + W - 1) / W);
+    if (G) n_chunks = 1;
     n_chunks = std::max(1u, std::min<uint32_t>(n_chunks, (uint32_t)std::max<size_t>(1, bb.size())));
     if ((uint64_t)n_chunks * S + 1 >= (1ull << 31)) return cz::set_error(CZ_E_UNSUPPORTED, "too many slices");
     // chunks: consecutive blocked row blocks holding about e_blocked / n_chunks edges each
@@ -1019,7 +1293,7 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
         blk_ptr.push_back((uint32_t)bb.size());
         n_chunks = (uint32_t)blk_ptr.size() - 1;
     }
-    p->wlog = wlog;
+    p->slice_w = W;
     p->S = S;
     p->n_chunks = n_chunks;
     p->n_bblocks = (uint32_t)bb.size();
@@ -1027,17 +1301,34 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
     p->n_hblocks = (uint32_t)gb.size();
     p->blk_ptr = blk_ptr;
     p->E_blocked = e_blocked;
-    const uint32_t n_keys = n_chunks * S;  // key n_keys = "not in the blocked layout" (long rows)
-    // key pass works on the block list [blocked..., long...]
-    std::vector<RowBlock> key_blocks(bb);
+    p->n_groups = G;
+    p->e_groups = e_groups;
+    if (G) {
+        p->acc_nw = shape->NW;
+        p->acc_rw = 0;
+        for (uint32_t g = 0; g < G; g++) p->acc_rw = std::max(p->acc_rw, grow[g + 1] - grow[g]);
+        p->acc_rw = (p->acc_rw + 3) & ~3u;
+        p->n_awgs = (G + shape->NW - 1) / shape->NW;
+    }
+    const uint32_t n_keys = n_chunks * S;  // key n_keys = "not in the streamed layout" (long rows)
+    // key pass works on the block list [groups..., blocked..., long...]; the groups are `key blocks` of chunk 0
+    std::vector<RowBlock> key_blocks;
+    key_blocks.reserve((size_t)G + bb.size() + gb.size());
+    for (uint32_t g = 0; g < G; g++) key_blocks.push_back({grow[g], grow[g + 1], h_off[grow[g]], h_off[grow[g + 1]]});
+    key_blocks.insert(key_blocks.end(), bb.begin(), bb.end());
     key_blocks.insert(key_blocks.end(), gb.begin(), gb.end());
-    std::vector<uint32_t> key_chunk(chunk_of);
+    std::vector<uint32_t> key_chunk(G, 0u);
+    key_chunk.insert(key_chunk.end(), chunk_of.begin(), chunk_of.end());
     key_chunk.resize(key_blocks.size(), CZ_NONE);
 
     CZ_HIP(plan_alloc((void **)&p->d_bblocks, std::max<size_t>(1, bb.size()) * sizeof(RowBlock)));
     if (!bb.empty()) CZ_HIP(hipMemcpy(p->d_bblocks, bb.data(), bb.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
     CZ_HIP(plan_alloc((void **)&p->d_hblocks, std::max<size_t>(1, gb.size()) * sizeof(RowBlock)));
     if (!gb.empty()) CZ_HIP(hipMemcpy(p->d_hblocks, gb.data(), gb.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
+    if (G) {
+        CZ_HIP(plan_alloc((void **)&p->d_grow, ((size_t)G + 1) * 4));
+        CZ_HIP(hipMemcpy(p->d_grow, grow.data(), ((size_t)G + 1) * 4, hipMemcpyHostToDevice));
+    }
 
     PoolBuf<RowBlock> d_kblocks;
     PoolBuf<uint32_t> d_kchunk, keys_in, keys_out, idx_in, idx_out, d_keyptr, d_bad;
@@ -1053,7 +1344,7 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
     CZ_HIP(d_bad.alloc(1));
     CZ_HIP(hipMemset(d_bad.p, 0, 4));
     hipLaunchKernelGGL(pb_keys_kernel, dim3((uint32_t)key_blocks.size()), dim3(256), 0, nullptr, d_kblocks.p, d_kchunk.p,
-                       p->d_off, p->d_src, wlog, S, n_keys, keys_in.p, idx_in.p);
+                       p->d_off, p->d_src, W, S, n_keys, keys_in.p, idx_in.p);
     unsigned bits = 1;
     while ((1ull << bits) <= n_keys) bits++;
     {   // stable sort of the (key, edge index) pairs by key: csrc/sort_scan.cuh (own kernels since round 4)
@@ -1075,7 +1366,7 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
     std::vector<uint32_t> key_ptr((size_t)n_keys + 1);
     CZ_HIP(hipMemcpy(key_ptr.data(), d_keyptr.p, key_ptr.size() * 4, hipMemcpyDeviceToHost));
     if (key_ptr[n_keys] != e_blocked)
-        return cz::set_error(CZ_E_HIP, "blocked PageRank layout: %u edges sorted into slices, expected %llu", key_ptr[n_keys],
+        return cz::set_error(CZ_E_HIP, "streamed PageRank layout: %u edges sorted into slices, expected %llu", key_ptr[n_keys],
                              (unsigned long long)e_blocked);
     const uint32_t EB = (uint32_t)e_blocked;
     hipLaunchKernelGGL(pb_check_sorted_kernel, dim3(2048), dim3(256), 0, nullptr, keys_out.p, idx_out.p, EB, d_bad.p);
@@ -1100,21 +1391,37 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
         }
         CZ_HIP(plan_alloc((void **)&p->d_val, need * 4));
     }
-    CZ_HIP(plan_alloc((void **)&p->d_perm, std::max<uint64_t>(1, E) * 2));
+    // the tile blocks' permutation is addressed by CSR position: theirs start behind the groups' edges
+    const uint64_t e_tiles = E - e_groups;
+    CZ_HIP(plan_alloc((void **)&p->d_perm, std::max<uint64_t>(1, e_tiles) * 2));
     CZ_HIP(plan_alloc((void **)&p->d_seg, std::max<size_t>(1, bb.size()) * ((size_t)S + 1) * sizeof(uint2)));
-    if (EB) hipLaunchKernelGGL(pb_asrc_kernel, dim3(4096), dim3(256), 0, nullptr, idx_out.p, p->d_src, EB, (1u << wlog) - 1, p->d_asrc);
+    if (G) {
+        CZ_HIP(plan_alloc((void **)&p->d_cell, (size_t)G * ((size_t)S + 1) * sizeof(uint2)));
+        CZ_HIP(plan_alloc((void **)&p->d_arow, padded * 2));
+        PoolBuf<uint16_t> rl;
+        CZ_HIP(rl.alloc(std::max<uint32_t>(1, e_groups)));
+        hipLaunchKernelGGL(pa_rowlocal_kernel, dim3(G), dim3(256), 0, nullptr, p->d_grow, p->d_off, rl.p);
+        if (EB) hipLaunchKernelGGL(pa_streams_kernel, dim3(4096), dim3(256), 0, nullptr, idx_out.p, p->d_src, rl.p, EB, W, e_groups,
+                                   p->d_asrc, p->d_arow);
+        const uint64_t pairs = (uint64_t)G * S;
+        hipLaunchKernelGGL(pb_seg_kernel, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, nullptr, d_kblocks.p, d_kchunk.p, G,
+                           p->d_off, d_keyptr.p, idx_out.p, S, p->d_cell);
+        CZ_HIP(hipStreamSynchronize(nullptr));  // rl dies with this scope
+    } else if (EB) {
+        hipLaunchKernelGGL(pb_asrc_kernel, dim3(4096), dim3(256), 0, nullptr, idx_out.p, p->d_src, EB, W, p->d_asrc);
+    }
     if (!bb.empty()) {
         const uint64_t pairs = (uint64_t)bb.size() * S;
-        hipLaunchKernelGGL(pb_seg_kernel, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, nullptr, d_kblocks.p, d_kchunk.p,
+        hipLaunchKernelGGL(pb_seg_kernel, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, nullptr, d_kblocks.p + G, d_kchunk.p + G,
                            (uint32_t)bb.size(), p->d_off, d_keyptr.p, idx_out.p, S, p->d_seg);
         hipLaunchKernelGGL(pb_segscan_kernel, dim3((uint32_t)bb.size()), dim3(64), 0, nullptr, p->d_bblocks, p->d_off, S, p->d_seg,
                            d_bad.p);
         hipLaunchKernelGGL(pb_perm_kernel, dim3((uint32_t)bb.size()), dim3(256), 0, nullptr, p->d_bblocks, p->d_off, p->d_seg, S,
-                           idx_out.p, p->d_perm);
+                           idx_out.p, p->d_perm - e_groups);
         // short runs (average tile / #slices below 20 values): phase B fills its tile element by element
         const int flat_env = env_int("CZ_PR_FLAT", -1);
         const bool flat = flat_env >= 0 ? flat_env != 0 : (uint64_t)kBTileNnz < 20ull * S;
-        if (flat && n_chunks == 1) {
+        if (flat && n_chunks == 1 && G == 0) {
             CZ_HIP(plan_alloc((void **)&p->d_vpos, std::max<uint64_t>(1, E) * 4));
             hipLaunchKernelGGL(pb_vpos_kernel, dim3((uint32_t)bb.size()), dim3(256), 0, nullptr, p->d_bblocks, p->d_seg, S, p->d_vpos);
         }
@@ -1122,15 +1429,24 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
     st.lap("asrc / seg / perm kernels");
     uint32_t bad = 0;
     CZ_HIP(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
-    if (bad) return cz::set_error(CZ_E_HIP, "blocked PageRank layout failed its self-check (%u violations)", bad);
-    // phase-A work items: each key bucket cut into parts of <= kPartEdges positions (cuts on multiples of 8)
+    if (bad) return cz::set_error(CZ_E_HIP, "streamed PageRank layout failed its self-check (%u violations)", bad);
+    // phase-A work items: each key bucket cut into parts (cuts on multiples of 8).  Blocked: parts of <= kPartEdges positions.
+    // Accumulate: a balanced graph's slices are one item each -- S is a multiple of the workgroup slots, so a sweep stages
+    // every contribution once; slices that hold more than their share (a skewed graph's first ones) are cut to a quarter of it.
+    uint32_t part_edges = kPartEdges;
+    if (G) {
+        uint32_t longest = 0;
+        for (uint32_t s = 0; s < S; s++) longest = std::max(longest, key_ptr[s + 1] - key_ptr[s]);
+        const uint64_t share = (e_blocked + S - 1) / S;
+        part_edges = longest <= share + share / 32 + 64 ? std::max<uint32_t>(longest, 8) : (uint32_t)std::max<uint64_t>(kPartEdges / 4, share / 4);
+    }
     std::vector<AItem> items;
     p->item_ptr.assign(1, 0);
     for (uint32_t c = 0; c < n_chunks; c++) {
         for (uint32_t s = 0; s < S; s++) {
             const uint32_t lo = key_ptr[c * S + s], hi = key_ptr[c * S + s + 1];
             if (hi == lo) continue;
-            const uint32_t parts = (hi - lo + kPartEdges - 1) / kPartEdges;
+            const uint32_t parts = (hi - lo + part_edges - 1) / part_edges;
             const uint32_t step = (((hi - lo + parts - 1) / parts) + 7) & ~7u;
             for (uint32_t a = lo; a < hi;) {
                 uint32_t b = std::min<uint64_t>(hi, ((uint64_t)a + step) & ~7ull);
@@ -1149,7 +1465,26 @@ int build_blocked(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t wlog, uin
         plan_free(p->d_src);
         p->d_src = nullptr;
     }
-    p->blocked = true;
+    if (G) {  // the rows' offsets are only needed by the tile blocks
+        if (bb.empty() && gb.empty()) {
+            plan_free(p->d_off);
+            p->d_off = nullptr;
+        }
+        // more than 64 KiB of dynamic LDS has to be asked for, once per kernel
+        static std::once_flag once;
+        std::call_once(once, [] {
+            (void)hipFuncSetAttribute((const void *)pa_reduce_kernel<16, kAccU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAccLdsBytes);
+            (void)hipFuncSetAttribute((const void *)pa_reduce_kernel<8, kAccU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAccLdsBytes);
+        });
+    }
+    {
+        static std::once_flag once_a;
+        std::call_once(once_a, [] {
+            (void)hipFuncSetAttribute((const void *)pb_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxAccSlice * 4);
+        });
+    }
+    p->blocked = G == 0;
+    p->accum = G != 0;
     // Adjacent row blocks on one XCD share the boundary lines of their runs (1.82 -> 1.58 GB per sweep on the uniform graph).
     // A plan that moved its heavy rows has blocks of very different cost in different parts of the list -- light rows
     // first, then the heavy ones longest first -- and a contiguous range per XCD then leaves some XCDs with nothing but
@@ -1217,6 +1552,7 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     // write every result through row_id, so the caller sees its own numbering.
     std::vector<uint32_t> perm_off;  // offsets in plan row order (when rows were moved)
     StageTimer st_plan;
+    uint32_t n_front_rows = rows;  // plan rows in their natural order at the front: all of them unless some were moved
     {
         const uint32_t heavy = (uint32_t)std::max(0, env_int("CZ_PR_HEAVY", (int)kHeavyRowDefault));
         PoolBuf<uint32_t> counts;
@@ -1270,6 +1606,7 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
             if (perm_off[rows] != E) return cz::set_error(CZ_E_HIP, "internal: the reordered rows hold %u edges, expected %llu", perm_off[rows], (unsigned long long)E);
             p->n_empty = n_empty;
             p->n_eblocks = (n_empty + kERowsPerBlock - 1) / kERowsPerBlock;
+            n_front_rows = n_light;
             plan_free(p->d_off);
             plan_free(p->d_src);
             p->d_off = new_off.release();
@@ -1279,13 +1616,15 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
     }
 
     st_plan.lap("row order");
-    // formulation: explicit flag > CZ_PR_MODE (gather | blocked) > heuristic
-    int mode = 0;  // 0 auto, 1 gather, 2 blocked
+    // formulation: explicit flag > CZ_PR_MODE (gather | blocked | accumulate) > heuristic
+    int mode = 0;  // 0 auto, 1 gather, 2 blocked, 3 accumulate
     if (flags & CZ_PR_GATHER) mode = 1;
     else if (flags & CZ_PR_BLOCKED) mode = 2;
-    else if (const char *m = getenv("CZ_PR_MODE")) mode = !strcmp(m, "gather") ? 1 : !strcmp(m, "blocked") ? 2 : 0;
+    else if (flags & CZ_PR_ACCUMULATE) mode = 3;
+    else if (const char *m = getenv("CZ_PR_MODE")) mode = !strcmp(m, "gather") ? 1 : !strcmp(m, "blocked") ? 2 : !strcmp(m, "accumulate") ? 3 : 0;
     uint32_t wlog = (uint32_t)std::min(kMaxSliceLog2, std::max(4, env_int("CZ_PR_SLICE_LOG2", kMaxSliceLog2)));
     const uint32_t n_chunks = (uint32_t)std::max(1, env_int("CZ_PR_CHUNKS", 1));
+    const AccShape shape = acc_shape(N);
     if (mode == 0) {
         // The blocked layout wins whenever there is enough work to stream, short runs included: measured on one
         // rank's shard of a row-sharded graph (10M rows, 100M in-edges, sources over N = 10M * world nodes), runs of
@@ -1295,13 +1634,25 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
         const uint64_t S = ((uint64_t)N + (1u << wlog) - 1) >> wlog;
         const uint64_t seg_bytes = (E / kBTileNnz + 1) * (S + 1) * 8;
         mode = (E >= (4u << 20) && seg_bytes <= (2ull << 30)) ? 2 : 1;
+        // The accumulate formulation walks a (group, slice) cell per wave instruction: it needs cells of some length.
+        // One round of workgroups holds cus * per_cu * NW groups; a cell then averages E_front / (S * groups) values.
+        if (mode == 2 && n_front_rows > 0 && n_chunks == 1 && env_int("CZ_PR_ACC_AUTO", 0) != 0) {
+            const uint64_t per_round = (uint64_t)device_cus() * shape.per_cu * shape.NW;
+            uint64_t G = per_round;
+            while ((n_front_rows + G - 1) / G > (uint64_t)shape.rw * 97 / 100) G += per_round;
+            const uint64_t e_front = in_offsets[n_front_rows];
+            if (e_front / (G * shape.S) >= (uint64_t)std::max(1, env_int("CZ_PR_ACC_MIN_CELL", 24))) mode = 3;
+        }
     }
-    if (mode == 2 && rows > 0 && E > 0) {
-        rc = build_blocked(p.get(), in_offsets, wlog, n_chunks);
+    if (mode == 3 && rows > 0 && E > 0) {
+        rc = build_streamed(p.get(), in_offsets, shape.W, 1, n_front_rows, &shape);
+        if (rc) return rc;
+    } else if (mode == 2 && rows > 0 && E > 0) {
+        rc = build_streamed(p.get(), in_offsets, 1u << wlog, n_chunks, 0, nullptr);
         if (rc) return rc;
     } else {
         std::vector<RowBlock> all, blocks, hubs;
-        if (rows > p->n_empty) cut_row_blocks(in_offsets, rows - p->n_empty, kGTileNnz, all);
+        if (rows > p->n_empty) cut_row_blocks(in_offsets, 0, rows - p->n_empty, kGTileNnz, all);
         for (const RowBlock &rb : all) (rb.e1 - rb.e0 > (uint32_t)kGTileNnz ? hubs : blocks).push_back(rb);
         p->n_gblocks = (uint32_t)blocks.size();
         p->n_hblocks = (uint32_t)hubs.size();
@@ -1310,7 +1661,7 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
         CZ_HIP(plan_alloc((void **)&p->d_hblocks, std::max<size_t>(1, hubs.size()) * sizeof(RowBlock)));
         if (!hubs.empty()) CZ_HIP(hipMemcpy(p->d_hblocks, hubs.data(), hubs.size() * sizeof(RowBlock), hipMemcpyHostToDevice));
     }
-    CZ_HIP(plan_alloc((void **)&p->d_partial, std::max<size_t>(1, (size_t)p->n_bblocks + p->n_gblocks + p->n_hblocks + p->n_eblocks) * 8));
+    CZ_HIP(plan_alloc((void **)&p->d_partial, std::max<size_t>(1, (size_t)p->n_awgs + p->n_bblocks + p->n_gblocks + p->n_hblocks + p->n_eblocks) * 8));
     CZ_HIP(hipDeviceSynchronize());
     p->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
     *out = p.release();
@@ -1343,9 +1694,10 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
     int rc = cz::ensure_device();
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    const uint32_t n_partial = p->n_bblocks + p->n_gblocks + p->n_hblocks + p->n_eblocks;  // partial errors: [blocked | gather | hub | empty]
+    // partial errors: [accumulate workgroups | blocked | gather | hub | empty]
+    const uint32_t n_partial = p->n_awgs + p->n_bblocks + p->n_gblocks + p->n_hblocks + p->n_eblocks;
     if (n_partial == 0) return CZ_OK;
-    const uint32_t n_main = p->n_bblocks + p->n_gblocks;
+    const uint32_t n_main = p->n_awgs + p->n_bblocks + p->n_gblocks;
     const bool side_work = p->n_hblocks > 0 || p->n_eblocks > 0;
     const bool fork = side_work && n_main > 0;
     hipStream_t hs = stream;
@@ -1368,24 +1720,38 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
                            p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores, p->base, p->damping,
                            p->d_partial + n_main + p->n_hblocks);
     if (fork) CZ_HIP(hipEventRecord(p->ev_join, p->side));
-    if (p->blocked) {
+    if (p->blocked || p->accum) {
+        const uint32_t a_lds = (p->slice_w * 4 + 15) & ~15u;
+        double *const bpartial = p->d_partial + p->n_awgs;
+        const uint16_t *const tperm = p->d_perm - p->e_groups;  // (the tile blocks' permutation is addressed by CSR position)
         for (uint32_t c = 0; c < p->n_chunks; c++) {
             const uint32_t i0 = p->item_ptr[c], i1 = p->item_ptr[c + 1];
             const uint32_t b0 = p->blk_ptr[c], b1 = p->blk_ptr[c + 1];
             float *val = p->d_val - p->val_shift[c];  // stream position i of this chunk lives at val[i]
             if (i1 > i0)
-                hipLaunchKernelGGL(pb_expand_kernel, dim3(i1 - i0), dim3(kAThreads), 0, stream, p->d_items + i0, p->d_asrc,
-                                   contrib_in_dev, p->N, p->wlog, val);
+                hipLaunchKernelGGL(pb_expand_kernel, dim3(i1 - i0), dim3(kAThreads), a_lds, stream, p->d_items + i0, p->d_asrc,
+                                   contrib_in_dev, p->N, p->slice_w, val);
+            if (p->n_awgs) {
+                const uint32_t lds = p->acc_nw * p->acc_rw * 4;
+                if (p->acc_nw == 8)
+                    hipLaunchKernelGGL((pa_reduce_kernel<8, kAccU>), dim3(p->n_awgs), dim3(8 * 64), lds, stream, p->d_grow, p->n_groups,
+                                       p->d_cell, p->S, p->d_arow, val, p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores,
+                                       p->base, p->damping, p->d_partial, p->d_rowid, p->acc_rw);
+                else
+                    hipLaunchKernelGGL((pa_reduce_kernel<16, kAccU>), dim3(p->n_awgs), dim3(16 * 64), lds, stream, p->d_grow, p->n_groups,
+                                       p->d_cell, p->S, p->d_arow, val, p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores,
+                                       p->base, p->damping, p->d_partial, p->d_rowid, p->acc_rw);
+            }
             if (b1 > b0) {
                 if (p->d_vpos)
                     hipLaunchKernelGGL(pb_reduce_kernel<true>, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
-                                       p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
-                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap, p->d_rowid,
+                                       p->d_off, p->d_seg, p->S, tperm, p->d_vpos, val, p->d_outdeg, p->row_begin,
+                                       contrib_out_dev, p->d_scores, p->base, p->damping, bpartial, p->xcd_remap, p->d_rowid,
                                        p->wave_row);
                 else
                     hipLaunchKernelGGL(pb_reduce_kernel<false>, dim3(b1 - b0), dim3(kBThreads), 0, stream, p->d_bblocks, b0,
-                                       p->d_off, p->d_seg, p->S, p->d_perm, p->d_vpos, val, p->d_outdeg, p->row_begin,
-                                       contrib_out_dev, p->d_scores, p->base, p->damping, p->d_partial, p->xcd_remap, p->d_rowid,
+                                       p->d_off, p->d_seg, p->S, tperm, p->d_vpos, val, p->d_outdeg, p->row_begin,
+                                       contrib_out_dev, p->d_scores, p->base, p->damping, bpartial, p->xcd_remap, p->d_rowid,
                                        p->wave_row);
             }
         }
@@ -1405,6 +1771,13 @@ extern "C" float *cz_pagerank_plan_scores(cz_pagerank_plan *p) { return p ? p->d
 extern "C" uint64_t cz_pagerank_plan_edges(const cz_pagerank_plan *p) { return p ? p->E : 0; }
 extern "C" uint32_t cz_pagerank_plan_nodes(const cz_pagerank_plan *p) { return p ? p->N : 0; }
 extern "C" int cz_pagerank_plan_is_blocked(const cz_pagerank_plan *p) { return p && p->blocked ? 1 : 0; }
+extern "C" int cz_pagerank_plan_formulation(const cz_pagerank_plan *p) { return !p ? 0 : p->accum ? 3 : p->blocked ? 2 : 1; }
+extern "C" int cz_pagerank_plan_shape(const cz_pagerank_plan *p, uint32_t *out8) {
+    if (!p || !out8) return cz::set_error(CZ_E_INVALID, "null argument");
+    const uint32_t v[8] = {p->S, p->slice_w, p->n_groups, p->acc_nw, p->acc_rw, p->n_awgs, p->n_bblocks, p->n_hblocks};
+    memcpy(out8, v, sizeof(v));
+    return CZ_OK;
+}
 
 extern "C" int cz_pagerank_plan_read_scores(cz_pagerank_plan *p, float *out, uint32_t flags, void *stream_) {
     if (!p || !out) return cz::set_error(CZ_E_INVALID, "null argument");

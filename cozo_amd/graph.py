@@ -25,6 +25,9 @@ def _csr32(off, tgt):
     return _u32(off), _u32(tgt)
 
 
+_PR_MODES = {None: 0, "gather": _lib.CZ_PR_GATHER, "blocked": _lib.CZ_PR_BLOCKED, "accumulate": _lib.CZ_PR_ACCUMULATE}
+
+
 def pagerank(in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10, poison=None, cache_key=None,
              mode: Optional[str] = None, timing: Optional[dict] = None):
     """graph::page_rank as called by PageRank::run (pagerank.rs:47-50): (scores f32[N], iterations, error).
@@ -38,7 +41,7 @@ def pagerank(in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10,
     err = C.c_double(0.0)
     tm = _lib.PagerankTiming()
     hi, lo = cache_key if cache_key is not None else (0, 0)
-    flags = {None: 0, "gather": _lib.CZ_PR_GATHER, "blocked": _lib.CZ_PR_BLOCKED}[mode]
+    flags = _PR_MODES[mode]
     check(_lib.lib().cz_pagerank_cached(int(hi), int(lo), ptr(in_off), ptr(in_src), ptr(out_deg), N, in_src.size,
                                         np.float32(damping), float(tolerance), int(max_iter), flags, ptr(scores),
                                         C.byref(it), C.byref(err), ptr(poison), C.byref(tm)))
@@ -69,8 +72,8 @@ class PageRankPlan:
     def __init__(self, in_off_local, in_src, out_deg, N, row_begin, row_end, damping=0.85, device_ptrs=False,
                  mode: Optional[str] = None):
         """host arrays, or (device_ptrs=True) uint32 device tensors already resident in HBM.
-        mode: None (chosen from the shard's shape) | "gather" | "blocked" -- the two device formulations of the
-        sweep (csrc/pagerank.hip); both give the reference's scores bit for bit."""
+        mode: None (chosen from the shard's shape) | "gather" | "blocked" | "accumulate" -- the device formulations of
+        the sweep (csrc/pagerank.hip); each gives the reference's scores bit for bit."""
         if not device_ptrs:
             in_off_local, in_src = _csr32(in_off_local, in_src)
             out_deg = _u32(out_deg)
@@ -78,8 +81,7 @@ class PageRankPlan:
         check(_lib.lib().cz_pagerank_plan_create(ptr(in_off_local), ptr(in_src), ptr(out_deg), N, row_begin, row_end,
                                                  np.float32(damping), C.byref(h),
                                                  (_lib.CZ_DEVICE_PTRS if device_ptrs else 0)
-                                                 | {None: 0, "gather": _lib.CZ_PR_GATHER,
-                                                    "blocked": _lib.CZ_PR_BLOCKED}[mode]))
+                                                 | _PR_MODES[mode]))
         self._h = h
         self.N, self.row_begin, self.row_end = N, row_begin, row_end
 
@@ -97,6 +99,18 @@ class PageRankPlan:
     @property
     def blocked(self) -> bool:
         return bool(_lib.lib().cz_pagerank_plan_is_blocked(self._h))
+
+    @property
+    def formulation(self) -> str:
+        return {1: "gather", 2: "blocked", 3: "accumulate"}[int(_lib.lib().cz_pagerank_plan_formulation(self._h))]
+
+    @property
+    def shape(self) -> dict:
+        """slices / groups / workgroups of the plan (measurement scripts)"""
+        a = np.zeros(8, dtype=np.uint32)
+        check(_lib.lib().cz_pagerank_plan_shape(self._h, ptr(a)))
+        return dict(zip(("slices", "slice_width", "groups", "waves", "rows_per_group", "acc_workgroups", "tile_blocks", "hub_rows"),
+                        (int(x) for x in a)))
 
     @property
     def timing(self):

@@ -36,10 +36,11 @@ extern "C" {
 #define CZ_DEVICE_PTRS 1u
 /* cz_hnsw_build / cz_hnsw_insert: HnswIndexManifest::extend_candidates (runtime/hnsw.rs:499-511) */
 #define CZ_HNSW_EXTEND_CANDIDATES 256u
-/* cz_pagerank_plan_create: force one of the two device formulations of the sweep (default: chosen from the
- * shard's shape; the environment variable CZ_PR_MODE = gather | blocked overrides the default too) */
+/* cz_pagerank_plan_create: force one of the three device formulations of the sweep (default: chosen from the
+ * shard's shape; the environment variable CZ_PR_MODE = gather | blocked | accumulate overrides the default too) */
 #define CZ_PR_GATHER 2u
 #define CZ_PR_BLOCKED 4u
+#define CZ_PR_ACCUMULATE 1024u
 /* cz_knn_bruteforce: compute the B x N dot products as one dense f32 GEMM on the matrix cores (Cosine / IP only;
  * every dot product is then a k-ordered fmaf chain instead of the search kernel's lane-parallel tree) */
 #define CZ_BF_GEMM 8u
@@ -267,7 +268,7 @@ int cz_pagerank_inplace(const uint32_t *in_offsets, const uint32_t *in_sources, 
  * not cache.  On a hit with the same N, E, damping and flags the arrays are not read again (the key is the caller's
  * promise that they are unchanged), which takes a repeated `?[] <~ PageRank(*rel[])` from upload + plan + iterations
  * to iterations alone.  Up to CZ_PR_CACHE_PLANS (default 4) plans are kept, least recently used dropped first.
- * flags: CZ_PR_GATHER | CZ_PR_BLOCKED.  timing (optional): where the call's time went. */
+ * flags: CZ_PR_GATHER | CZ_PR_BLOCKED | CZ_PR_ACCUMULATE.  timing (optional): where the call's time went. */
 typedef struct {
     double h2d_ms;        /* CSR upload (0 on a cache hit) */
     double plan_build_ms; /* static layout of the sweep (0 on a cache hit) */
@@ -300,8 +301,14 @@ int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_in_dev, floa
 /* device pointer to this shard's scores [row_end-row_begin] */
 float *cz_pagerank_plan_scores(cz_pagerank_plan *p);
 uint64_t cz_pagerank_plan_edges(const cz_pagerank_plan *p);
-/* 1 when the plan runs the source-blocked two-phase sweep, 0 for the CSR-stream gather sweep */
+/* 1 when the plan runs the source-blocked two-phase sweep with LDS tiles, 0 otherwise */
 int cz_pagerank_plan_is_blocked(const cz_pagerank_plan *p);
+/* which formulation the plan runs: 1 = CSR-stream gather, 2 = source-blocked two-phase sweep with tiles, 3 = two-phase
+ * sweep with in-order accumulation (rows of the front part in groups, one wave each; csrc/pagerank.hip) */
+int cz_pagerank_plan_formulation(const cz_pagerank_plan *p);
+/* the plan's shape, for measurement scripts: {slices, slice width, groups, waves per workgroup, rows per group (LDS words),
+ * accumulate workgroups, tile blocks, hub rows} */
+int cz_pagerank_plan_shape(const cz_pagerank_plan *p, uint32_t *out8);
 /* what creating the plan cost: CSR upload and static layout, milliseconds */
 int cz_pagerank_plan_timing(const cz_pagerank_plan *p, double *h2d_ms, double *build_ms);
 /* copy this shard's scores [row_end-row_begin] to `out` (host, or device with CZ_DEVICE_PTRS) */
@@ -355,7 +362,7 @@ int cz_pagerank_sharded_overlapped(cz_comm *comm, cz_pagerank_plan *plan_first, 
                                    uint32_t rows_per_rank, uint32_t half_rows, double tolerance, uint32_t max_iter,
                                    uint32_t *iters_run, double *final_err, const volatile uint8_t *poison, void *stream);
 /* cz_pagerank on n_gpus devices of this process (devices 0 .. n_gpus-1): host CSR in, scores [N] out.
- * flags: CZ_PR_GATHER | CZ_PR_BLOCKED | CZ_PR_EXCHANGE_ALLREDUCE | CZ_PR_OVERLAP_EXCHANGE. */
+ * flags: CZ_PR_GATHER | CZ_PR_BLOCKED | CZ_PR_ACCUMULATE | CZ_PR_EXCHANGE_ALLREDUCE | CZ_PR_OVERLAP_EXCHANGE. */
 int cz_pagerank_multi(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N,
                       uint64_t E, float damping, double tolerance, uint32_t max_iter, int n_gpus, uint32_t flags,
                       float *scores, uint32_t *iters_run, double *final_err, const volatile uint8_t *poison);

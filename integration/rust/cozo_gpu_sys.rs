@@ -9,6 +9,7 @@ pub const CZ_DEVICE_PTRS: u32 = 1;
 pub const CZ_HNSW_EXTEND_CANDIDATES: u32 = 256;
 pub const CZ_PR_GATHER: u32 = 2;
 pub const CZ_PR_BLOCKED: u32 = 4;
+pub const CZ_PR_ACCUMULATE: u32 = 1024;
 pub const CZ_BF_GEMM: u32 = 8;
 pub const CZ_PR_EXCHANGE_ALLREDUCE: u32 = 32;
 pub const CZ_PR_OVERLAP_EXCHANGE: u32 = 64;
@@ -159,6 +160,8 @@ extern "C" {
     pub fn cz_pagerank_plan_scores(p: *mut cz_pagerank_plan) -> *mut c_float;
     pub fn cz_pagerank_plan_edges(p: *const cz_pagerank_plan) -> u64;
     pub fn cz_pagerank_plan_is_blocked(p: *const cz_pagerank_plan) -> c_int;
+    pub fn cz_pagerank_plan_formulation(p: *const cz_pagerank_plan) -> c_int;
+    pub fn cz_pagerank_plan_shape(p: *const cz_pagerank_plan, out8: *mut u32) -> c_int;
     pub fn cz_pagerank_plan_read_scores(p: *mut cz_pagerank_plan, out: *mut c_float, flags: u32, stream: *mut c_void) -> c_int;
 
     pub fn cz_hnsw_insert(ix: *mut cz_hnsw_index, vectors: *const c_float, n_new: u32, m: u32, ef_construction: u32,

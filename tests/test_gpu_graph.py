@@ -153,6 +153,8 @@ def _run_plan(G, g, mode, damping=0.85, tol=1e-4, iters=10, shards=1):
     got = np.empty(n, dtype=np.float32)
     for p, rb, re in zip(plans, cuts[:-1], cuts[1:]):
         got[rb:re] = p.read_scores()
+    if mode == "accumulate":
+        assert [p.formulation for p in plans] == ["accumulate"] * len(plans)
     return got, it, err.item(), [p.blocked for p in plans]
 
 
@@ -487,7 +489,38 @@ def _rows_of_lengths(oracle, lengths, n, seed):
     return util.graph_from_relation(oracle, rows[:, 0].astype(np.int64), rows[:, 1].astype(np.int64))
 
 
-@pytest.mark.parametrize("mode", ["blocked", "gather"])
+@pytest.mark.parametrize("slices,groups,waves,heavy", [(0, 0, 16, None), (7, 40, 16, None), (64, 300, 8, None), (300, 9, 16, 0),
+                                                        (33, 1000, 8, 0), (1, 1, 16, 0), (500, 64, 16, 16)])
+def test_pagerank_accumulate_sweep_bitexact(graphs, hub_graph, oracle, monkeypatch, slices, groups, waves, heavy):
+    """the in-order accumulation sweep (pa_reduce_kernel: a wave adds the values of its rows as they arrive, slice after
+    slice) on small graphs, forced: few / many slices, one group up to several hundred (more than one workgroup, waves
+    without a group), groups of a handful of rows, empty cells, cells longer than a wave instruction, stretches of equal
+    rows inside a piece and across pieces (heavy = 0: the 60k-term hub row stays in its group), heavy rows beside the
+    groups in tile blocks and in the hub kernel (default threshold, and 16)"""
+    from cozo_amd import graph as G
+    if slices:
+        monkeypatch.setenv("CZ_PR_ACC_SLICES", str(slices))
+    if groups:
+        monkeypatch.setenv("CZ_PR_ACC_GROUPS", str(groups))
+    monkeypatch.setenv("CZ_PR_ACC_WAVES", str(waves))
+    if heavy is not None:
+        monkeypatch.setenv("CZ_PR_HEAVY", str(heavy))
+    for g in graphs + [hub_graph]:
+        for tol, iters in [(1e-4, 10), (0.0, 6)]:
+            os_, oit, oerr = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, tol, iters)
+            got, it, err, _ = _run_plan(G, g, "accumulate", 0.85, tol, iters)
+            assert it == oit
+            bad = np.flatnonzero(got != os_)
+            assert bad.size == 0, (g["n"], bad[:10])
+            assert err == pytest.approx(oerr, rel=1e-9)
+    # shard by shard (rows of a rank, sources of the whole graph) against the gather sweep
+    g = hub_graph
+    a, ita, _, _ = _run_plan(G, g, "gather", shards=3)
+    b, itb, _, _ = _run_plan(G, g, "accumulate", shards=3)
+    assert ita == itb and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("mode", ["blocked", "gather", "accumulate"])
 def test_pagerank_long_rows_summed_by_waves_keep_the_sequential_bits(oracle, gpu_lib, mode):
     """Rows of >= 128 terms are summed by a whole wave (csrc/exact_sum.cuh), rows longer than a tile by pr_hub_kernel,
     and both must give the bits of the reference's one-after-the-other f32 sum: lengths on both sides of every
@@ -522,7 +555,7 @@ def test_pagerank_skewed_degrees_bitexact(oracle, gpu_lib):
     rows = np.unique(np.stack([src[keep], dst[keep]], 1), axis=0)
     g = util.graph_from_relation(oracle, rows[:, 0], rows[:, 1])
     want, oit, _ = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 5)
-    for mode in ("blocked", "gather"):
+    for mode in ("blocked", "gather", "accumulate"):
         got, it, _ = G.pagerank(g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 5, mode=mode)
         assert it == oit and np.array_equal(got, want), mode
 
