@@ -38,6 +38,7 @@
 #include <list>
 #include <memory>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "sort_scan.cuh"
@@ -621,29 +622,44 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
 // The slices of phase A ascend in source id, and inside a slice the value stream is in CSR order -- (row, source)
 // ascending.  So the reference's sum of a row (s = s + contrib[src], sources ascending) is "the row's values of slice 0 in
 // stream order, then those of slice 1, ...": the values can be ADDED AS THEY ARRIVE into one f32 accumulator per row and
-// nothing has to be put back into CSR order first.  A wave owns a GROUP of consecutive rows (<= rw of them, one LDS word
-// each) and walks the group's piece of every slice's stream -- a CELL, (start, count) in `cell` -- in slice order:
-//   * per stream position a value (4 bytes) and the row's index inside the group (u16): 6 bytes per edge instead of the
-//     tile formulation's 6 + the rows' offsets (4 per row), and no second pass over LDS for the row sums;
-//   * a cell is sorted by row, so the values of one row are neighbours in it: lanes whose row differs from the lane
-//     below add straight into LDS (the usual case: every lane of a wave instruction, all rows distinct); a stretch of
-//     equal rows is added one lane after the other through a DPP wave_shr:1 chain, lowest lane first -- the reference's
-//     order -- and its last lane stores the row;
+// nothing has to be put back into CSR order first.  A wave owns a GROUP of consecutive rows (<= 8192 of them, one LDS word
+// each) and walks the group's part of every slice's stream (a CELL) in slice order.
+//
+// What bounds such a walk is not bytes but REQUESTS: the chip retires ~22 G wave-level load instructions per second
+// whatever they carry (scratch/cellread_bench.hip: 256-byte requests 5.6 TB/s, 128-byte requests 2.9 TB/s, same rate), and
+// a uniform 10M / 100M graph has about a million (group, slice) cells of some hundred values.  The tile formulation's
+// phase B and the first two forms of this kernel (a value per lane: two 64-lane requests per 48 values on average) all
+// sat on that ceiling at 205-235 us (profiles/r05_pagerank_accumulate.txt).  Hence:
+//   * a PIECE is up to 256 stream positions, FOUR consecutive ones per lane: one 16-byte load per lane for the values (1 KiB
+//     per request), one 8-byte load for the four u16 that carry the rows' indices inside the group; cells start on
+//     multiples of four positions (the stream is padded: < 1 % on the bench graphs) so that both loads are aligned;
+//   * few, long-lived waves: 8 per CU (one workgroup, all of the CU's LDS as accumulators), eight pieces in flight each;
+//   * a cell is sorted by row, so the values of one row are neighbours in it -- a STRETCH.  A lane adds its four values
+//     in order, so a stretch inside one lane needs nothing; a stretch that begins in a lower lane is finished by a DPP
+//     wave_shr:1 chain, one step per lane it crosses, lowest lane first (the reference's order).  Where a value stands is
+//     static and worked out when the plan is built: the u16 carries the row (13 bits), "last of its stretch inside the
+//     piece" (it stores the row's word) and two bits of the number of lanes the stretch of the lane's FIRST value has
+//     crossed (six bits over the first three u16 of the lane); the piece's descriptor carries the largest such number, so
+//     the kernel runs exactly that many chain steps and detects nothing at run time;
 //   * LDS operations of one wave execute in order, so a row that continues in the next piece or the next cell reads
 //     what the previous one stored: no barrier anywhere; the waves of a workgroup share nothing but the LDS allocation;
-//   * U pieces (<= 64 values each) are in flight per wave, requested in stream order across cell boundaries; the cells'
-//     descriptors are held 64 at a time across the lanes and the next 64 are requested a batch ahead.
+//   * the pieces of a group are ONE list (cells cut at 256, empty cells gone, padded to batches of eight plus one empty
+//     batch), read eight descriptors at a time with scalar loads two batches ahead: a counted loop, no cursor.
 // The epilogue (new score, |delta|, next contribution) runs over the group's rows, coalesced.
-#ifndef CZ_PR_ACC_U
-#define CZ_PR_ACC_U 8
-#endif
 #ifndef CZ_PR_ACC_NT
 #define CZ_PR_ACC_NT 1  // the value / row streams of phase B are read once: non-temporal loads
 #endif
-constexpr int kAccU = CZ_PR_ACC_U;         // pieces in flight per wave of phase B
+constexpr int kAccBatch = 8;               // pieces per descriptor batch = pieces in flight per wave of phase B
+constexpr int kAccV = 4;                   // stream positions per lane of a piece
+constexpr uint32_t kAccPiece = 64 * kAccV;
 constexpr int kMaxAccSlice = 40448;        // floats of LDS a phase-A workgroup may stage (158 KiB; one workgroup per CU)
 constexpr uint32_t kAccLdsBytes = 161792;  // phase B: accumulators of one CU (158 KiB), split over its workgroups and waves
+constexpr uint32_t kAccMaxRows = 8192;     // rows of a group: 13 bits of the u16
+constexpr uint32_t kAccTail = 0x2000u;     // u16 bit 13: last value of its stretch inside the piece
+constexpr uint32_t kAccHopShift = 14;      // u16 bits 14-15 of a lane's first three values: lanes crossed by the first value's stretch
 
+typedef float acc_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t acc_u2 __attribute__((ext_vector_type(2)));
 template <typename T>
 __device__ __forceinline__ T acc_stream_load(const T *p) {
 #if CZ_PR_ACC_NT
@@ -652,141 +668,209 @@ __device__ __forceinline__ T acc_stream_load(const T *p) {
     return *p;
 #endif
 }
-__device__ __forceinline__ uint32_t wave_shr1_u32(uint32_t v) {  // lane i <- lane i - 1, lane 0 <- 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
+__device__ __forceinline__ float wave_shr1_f32(float v) {  // lane i <- lane i - 1, lane 0 <- 0
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x138, 0xF, 0xF, false));
 }
 
-// adds one piece (values v of rows r on lanes < n, rows ascending) into acc[], every row in lane order
-__device__ __forceinline__ void acc_piece(float *acc, float v, uint32_t r, uint32_t n, uint32_t lane) {
-    const bool on = lane < n;
-    const uint32_t below = wave_shr1_u32(r);
-    const bool head = on && (lane == 0 || r != below);
-    const unsigned long long follow = __ballot(on && !head);
-    if (follow == 0ull) {  // every lane a row of its own
-        if (on) acc[r] = acc[r] + v;
-        return;
+// adds one piece into acc[]: the lane's four values v and annotated rows (rr: four u16); dy = count | most lanes crossed << 16
+__device__ __forceinline__ void acc_piece(float *acc, acc_f4 v, acc_u2 rr, uint32_t dy, uint32_t lane) {
+    const uint32_t n = dy & 0xffffu, mr = dy >> 16;
+    const uint32_t a[4] = {rr.x & 0xffffu, rr.x >> 16, rr.y & 0xffffu, rr.y >> 16};
+    uint32_t row[4];
+    bool on[4], cont[4];  // cont: the same row as the value before it IN THIS LANE
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        row[j] = a[j] & (kAccMaxRows - 1u);
+        on[j] = lane * 4 + j < n;
+        cont[j] = j > 0 && row[j] == row[j - 1];
     }
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long upto = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-    const uint32_t rank = on ? lane - (63u - (uint32_t)__builtin_clzll(upto | 1ull)) : 0u;  // position inside the stretch of equal rows
-    float x = v;
-    if (head) x = acc[r] + v;
-    for (uint32_t k = 1; __ballot(rank >= k) != 0ull; k++) {
-        const float y = __uint_as_float(wave_shr1_u32(__float_as_uint(x)));
-        if (rank == k) x = y + v;
+    const uint32_t hops = ((a[0] >> kAccHopShift) & 3u) | (((a[1] >> kAccHopShift) & 3u) << 2) | (((a[2] >> kAccHopShift) & 3u) << 4);
+    // the stretches that begin in this lane start from the rows' words
+    float w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool head = j == 0 ? hops == 0 : !cont[j];
+        w[j] = (on[j] && head) ? acc[row[j]] : 0.0f;
     }
-    const bool tail = on && (lane + 1 == n || ((heads >> (lane + 1 < 64 ? lane + 1 : 63)) & 1ull));
-    if (tail) acc[r] = x;
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    float x[4];
+    x[0] = w[0] + vv[0];
+#pragma unroll
+    for (int j = 1; j < 4; j++) x[j] = (cont[j] ? x[j - 1] : w[j]) + vv[j];
+    if (mr != 0) {  // (uniform) some stretch of this piece crosses lanes: lanes at distance k from its first lane join at step k
+        const bool c1 = cont[1], c2 = c1 && cont[2], c3 = c2 && cont[3];  // values of the lane's first stretch
+        for (uint32_t k = 1; k <= mr; k++) {
+            const float y = wave_shr1_f32(x[3]);
+            if (hops == k) {
+                x[0] = y + vv[0];
+                if (c1) x[1] = x[0] + vv[1];
+                if (c2) x[2] = x[1] + vv[2];
+                if (c3) x[3] = x[2] + vv[3];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (on[j] && (a[j] & kAccTail)) acc[row[j]] = x[j];
 }
 
-template <int NW, int U>
+template <int NW>
 __global__ void __launch_bounds__(NW * 64)
 pa_reduce_kernel(const uint32_t *__restrict__ grow /* [G + 1]: first plan row of every group */, uint32_t G,
-                 const uint2 *__restrict__ cell /* [G][S + 1]: (stream position, count) */, uint32_t S,
+                 const uint32_t *__restrict__ pbase /* [G + 1]: the groups' piece lists inside `piece`, multiples of 8 */,
+                 const uint2 *__restrict__ piece /* (stream position, count | most lanes crossed << 16) */,
                  const uint16_t *__restrict__ arow, const float *__restrict__ val, const uint32_t *__restrict__ out_deg,
                  uint32_t row_begin, float *__restrict__ contrib_out, float *__restrict__ scores, float base, float damping,
                  double *__restrict__ partial, const uint32_t *__restrict__ row_id, uint32_t rw) {
     extern __shared__ __attribute__((aligned(16))) float acc_all[];
     __shared__ double red[NW];
+    constexpr int U = kAccBatch;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * NW + wave;
     float *acc = acc_all + (size_t)wave * rw;
     double err = 0.0;
+#ifdef CZ_PR_PHASE_TIMING
+    unsigned long long t_prev_ = clock64();
+#define PA_STAMP(k)                                                 \
+    do {                                                            \
+        if (lane == 0) {                                            \
+            const unsigned long long now_ = clock64();              \
+            atomicAdd(&g_pr_phase[k], now_ - t_prev_);              \
+            t_prev_ = now_;                                         \
+        }                                                           \
+    } while (0)
+#else
+#define PA_STAMP(k)
+#endif
     if (g < G) {
         const uint32_t r0 = grow[g], nr = grow[g + 1] - r0;
-        const uint2 *cg = cell + (size_t)g * (S + 1);
-        // descriptors of the cells: 256 at a time across the lanes of four registers (lane l of dq[q] holds slice
-        // sb + 64 q + l), all of them for a graph of <= 256 slices -- a request in the middle of the stream would have to
-        // be waited for with every piece request that was made after the previous one still in flight
-        uint2 dq[4];
-        auto load_batch = [&](uint32_t sb) {
+        const uint32_t p0 = pbase[g];
+        const uint32_t nb = (pbase[g + 1] - p0) / U - 1;  // batches that hold pieces (the list ends with an empty batch)
+        const uint2 *pd = piece + p0;
+        // (positions are multiples of 4: the value vector of a lane is 16-byte aligned, its four u16 8-byte aligned)
+        const acc_f4 *val4 = reinterpret_cast<const acc_f4 *>(val);
+        const acc_u2 *arow4 = reinterpret_cast<const acc_u2 *>(arow);
+        // (lanes beyond a piece's end repeat its last lane's address: what follows the piece belongs to another wave, most
+        //  often on another XCD, and reading it here as well made the kernel fetch 24 % more than its streams hold)
+        auto lane_of = [&](uint32_t dy) { return min(lane, (((dy & 0xffffu) + 3u) >> 2) - ((dy & 0xffffu) != 0u ? 1u : 0u)); };
+        // Two batches of eight pieces are in flight (the kernel is bound by the memory round trip, ~4 us under load, times
+        // the pieces a wave has to walk, over the pieces it keeps in flight): batch A and batch B take turns, the
+        // descriptors of the batch to be requested next (dn) have arrived, those of the one after it (dm) are on their way.
+        uint32_t ya[U], yb[U];  // count | lanes crossed of the pieces whose loads are in flight
+        uint2 dn[U], dm[U];
+        acc_f4 va[U], vb[U];
+        acc_u2 ra[U], rb[U];
+        const uint32_t last = nb;  // (the empty batch at the end of the list: requests beyond the list read it)
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t sl = sb + q * 64 + lane;
-                dq[q] = sl < S ? cg[sl] : make_uint2(0, 0);
-            }
-        };
-        load_batch(0);
-        for (uint32_t i = lane; i < nr; i += 64) acc[i] = 0.0f;
-        uint32_t sb = 0, u = 0, o = 0;
-        uint2 d = dq[0];
-        uint32_t cst = __builtin_amdgcn_readlane(d.x, 0), ccnt = __builtin_amdgcn_readlane(d.y, 0);
-        // the next piece of the group's stream: (position, length <= 64), length 0 when the stream is through
-        auto next_piece = [&](uint32_t &pa, uint32_t &pn) {
-            while (o >= ccnt) {
-                u++;
-                if (sb + u >= S) {
-                    pa = 0;
-                    pn = 0;
-                    return;
-                }
-                if ((u & 63u) == 0) {
-                    if (u == 256) {
-                        sb += 256;
-                        u = 0;
-                        load_batch(sb);
-                        d = dq[0];
-                    } else {
-                        d = u == 64 ? dq[1] : u == 128 ? dq[2] : dq[3];
-                    }
-                }
-                cst = __builtin_amdgcn_readlane(d.x, u & 63u);
-                ccnt = __builtin_amdgcn_readlane(d.y, u & 63u);
-                o = 0;
-            }
-            pa = cst + o;
-            pn = min(64u, ccnt - o);
-            o += 64;
-        };
-        uint32_t pn[U];
-        float v[U];
-        uint32_t r[U];
+        for (int j = 0; j < U; j++) dn[j] = pd[j];
 #pragma unroll
         for (int j = 0; j < U; j++) {
-            uint32_t pa;
-            next_piece(pa, pn[j]);
-            // (every lane loads: lanes beyond the piece repeat its first element -- no branch around a load, so that the
-            //  compiler can count the loads in flight instead of waiting for all of them)
-            const uint32_t at = pa + (lane < pn[j] ? lane : 0u);
-            v[j] = acc_stream_load(val + at);
-            r[j] = acc_stream_load(arow + at);
+            const uint32_t at = (dn[j].x >> 2) + lane_of(dn[j].y);
+            va[j] = acc_stream_load(val4 + at);
+            ra[j] = acc_stream_load(arow4 + at);
+            ya[j] = dn[j].y;
         }
-        while (pn[0] != 0) {
+        {
+            const uint2 *p1 = pd + (size_t)min(1u, last) * U;
 #pragma unroll
-            for (int j = 0; j < U; j++) {
-                if (pn[j] != 0) acc_piece(acc, v[j], r[j], pn[j], lane);
-                uint32_t pa;
-                next_piece(pa, pn[j]);
-                const uint32_t at = pa + (lane < pn[j] ? lane : 0u);
-                v[j] = acc_stream_load(val + at);
-                r[j] = acc_stream_load(arow + at);
+            for (int j = 0; j < U; j++) dn[j] = p1[j];
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const uint32_t at = (dn[j].x >> 2) + lane_of(dn[j].y);
+            vb[j] = acc_stream_load(val4 + at);
+            rb[j] = acc_stream_load(arow4 + at);
+            yb[j] = dn[j].y;
+        }
+        {
+            const uint2 *p2 = pd + (size_t)min(2u, last) * U;
+#pragma unroll
+            for (int j = 0; j < U; j++) dn[j] = p2[j];
+        }
+        for (uint32_t i = lane; i < nr; i += 64) acc[i] = 0.0f;
+        PA_STAMP(0);  // descriptors, first requests, accumulators cleared
+        for (uint32_t b = 0; b < nb; b += 2) {
+            {
+                const uint2 *pm = pd + (size_t)min(b + 3, last) * U;
+#pragma unroll
+                for (int j = 0; j < U; j++) dm[j] = pm[j];
             }
-        }
-        // epilogue: the group's rows, four per lane in flight
-        for (uint32_t i0 = lane; i0 < nr; i0 += 256) {
-            uint32_t cr[4], od[4];
-            float old[4], s4[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t i = i0 + j * 64;
-                if (i < nr) {
-                    cr[j] = caller_row(row_id, r0 + i);
+            for (int j = 0; j < U; j++) {  // batch b; its registers then take batch b + 2
+                acc_piece(acc, va[j], ra[j], ya[j], lane);
+                const uint32_t at = (dn[j].x >> 2) + lane_of(dn[j].y);
+                va[j] = acc_stream_load(val4 + at);
+                ra[j] = acc_stream_load(arow4 + at);
+                ya[j] = dn[j].y;
+            }
+#pragma unroll
+            for (int j = 0; j < U; j++) dn[j] = dm[j];
+            {
+                const uint2 *pm = pd + (size_t)min(b + 4, last) * U;
+#pragma unroll
+                for (int j = 0; j < U; j++) dm[j] = pm[j];
+            }
+#pragma unroll
+            for (int j = 0; j < U; j++) {  // batch b + 1 (empty when the list holds an odd number of batches); then batch b + 3
+                acc_piece(acc, vb[j], rb[j], yb[j], lane);
+                const uint32_t at = (dn[j].x >> 2) + lane_of(dn[j].y);
+                vb[j] = acc_stream_load(val4 + at);
+                rb[j] = acc_stream_load(arow4 + at);
+                yb[j] = dn[j].y;
+            }
+#pragma unroll
+            for (int j = 0; j < U; j++) dn[j] = dm[j];
+        }
+        PA_STAMP(1);  // the stream
+        // epilogue: the group's rows, sixteen per lane at a time, the next sixteen requested before these are worked on (a
+        // wave has some thousand rows and the CU few waves: four rows per lane at a time, waited for in place, left this
+        // part latency-bound -- 60 of the kernel's 207 us).  The caller's row numbers: the test for "rows were moved" stays
+        // outside the loop (inside it, it put a branch and a wait for everything in flight in front of every row's loads).
+        constexpr int ER = 16;
+        auto rows_out = [&](auto moved) {
+            uint32_t cr0[ER], od0[ER], cr1[ER], od1[ER];
+            float old0[ER], s0[ER], old1[ER], s1[ER];
+            auto request = [&](uint32_t ib, uint32_t (&cr)[ER], uint32_t (&od)[ER], float (&old)[ER], float (&sv)[ER]) {
+#pragma unroll
+                for (int j = 0; j < ER; j++) {
+                    const uint32_t i = min(ib + lane + j * 64, nr - 1);  // (rows beyond the end: the last row again, results dropped)
+                    cr[j] = decltype(moved)::value ? row_id[r0 + i] : r0 + i;
+                    sv[j] = acc[i];
+                }
+#pragma unroll
+                for (int j = 0; j < ER; j++) {
                     old[j] = scores[cr[j]];
                     od[j] = out_deg[row_begin + cr[j]];
-                    s4[j] = acc[i];
                 }
-            }
+            };
+            auto finish = [&](uint32_t ib, uint32_t (&cr)[ER], uint32_t (&od)[ER], float (&old)[ER], float (&sv)[ER]) {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (i0 + j * 64 < nr) err += finish_row(s4[j], cr[j], old[j], od[j], row_begin, contrib_out, scores, base, damping);
-        }
+                for (int j = 0; j < ER; j++)
+                    if (ib + lane + j * 64 < nr) err += finish_row(sv[j], cr[j], old[j], od[j], row_begin, contrib_out, scores, base, damping);
+            };
+            if (nr == 0) return;
+            request(0, cr0, od0, old0, s0);
+            for (uint32_t ib = 0; ib < nr; ib += 128 * ER) {  // (ib is the same on every lane: the branches are uniform)
+                if (ib + 64 * ER < nr) request(ib + 64 * ER, cr1, od1, old1, s1);
+                finish(ib, cr0, od0, old0, s0);
+                if (ib + 128 * ER < nr) request(ib + 128 * ER, cr0, od0, old0, s0);
+                if (ib + 64 * ER < nr) finish(ib + 64 * ER, cr1, od1, old1, s1);
+            }
+        };
+        if (row_id) rows_out(std::true_type{});
+        else rows_out(std::false_type{});
+        PA_STAMP(2);  // the rows
+#ifdef CZ_PR_PHASE_TIMING
+        if (lane == 0) atomicAdd(&g_pr_phase[4], 1ull);
+#endif
     }
     const double total = block_sum_f64<NW * 64>(err, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = total;
 }
 
-// plan construction: the row's index inside its group for every in-edge of the groups' rows (CSR order) ...
+// ---- plan construction of the accumulate formulation ---------------------------------------------------------------------
+// the row's index inside its group for every in-edge of the groups' rows (CSR order)
 __global__ void __launch_bounds__(256)
 pa_rowlocal_kernel(const uint32_t *__restrict__ grow, const uint32_t *__restrict__ off, uint16_t *__restrict__ rl) {
     const uint32_t r0 = grow[blockIdx.x], r1 = grow[blockIdx.x + 1];
@@ -795,16 +879,189 @@ pa_rowlocal_kernel(const uint32_t *__restrict__ grow, const uint32_t *__restrict
         for (uint32_t e = a; e < z; e++) rl[e] = (uint16_t)(r - r0);
     }
 }
-// ... and in stream order; the local source ids of a slice width that is not a power of two
+// per slice: the stream positions its groups' cells take, every cell rounded up to a multiple of four, and their edges
 __global__ void __launch_bounds__(256)
-pa_streams_kernel(const uint32_t *__restrict__ sidx, const uint32_t *__restrict__ src, const uint16_t *__restrict__ rl,
-                  uint32_t n, uint32_t W, uint32_t e_groups, uint16_t *__restrict__ asrc, uint16_t *__restrict__ arow) {
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint32_t e = sidx[i];
-        const uint32_t sv = src[e];
-        asrc[i] = (uint16_t)(sv - (sv / W) * W);
-        arow[i] = e < e_groups ? rl[e] : (uint16_t)0;
+pa_slice_sums_kernel(const uint2 *__restrict__ cell, uint32_t G, uint32_t S, uint32_t *__restrict__ padded_len, uint32_t *__restrict__ edges) {
+    __shared__ uint32_t red[2][4];
+    const uint32_t s = blockIdx.x;
+    uint32_t pl = 0, ed = 0;
+    for (uint32_t g = threadIdx.x; g < G; g += 256) {
+        const uint32_t c = cell[(size_t)g * (S + 1) + s].y;
+        pl += (c + 3u) & ~3u;
+        ed += c;
     }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        pl += __shfl_xor(pl, o, 64);
+        ed += __shfl_xor(ed, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = pl;
+        red[1][threadIdx.x >> 6] = ed;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        padded_len[s] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        edges[s] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+// per slice: the cells' padded positions (an exclusive scan over the groups, from the slice's own start)
+__global__ void __launch_bounds__(256)
+pa_cell_pos_kernel(const uint2 *__restrict__ cell, uint32_t G, uint32_t S, const uint32_t *__restrict__ slice_start,
+                   uint32_t *__restrict__ cellp /* [G][S + 1] */) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t run = slice_start[s];
+    for (uint32_t g0 = 0; g0 < G; g0 += 256) {
+        const uint32_t g = g0 + threadIdx.x;
+        const uint32_t c = g < G ? (cell[(size_t)g * (S + 1) + s].y + 3u) & ~3u : 0u;
+        uint32_t x = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= (uint32_t)o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; w++) before += wsum[w];
+        const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (g < G) cellp[(size_t)g * (S + 1) + s] = run + before + x - c;
+        run += total;
+        __syncthreads();
+    }
+}
+// the streams at their padded positions: a wave per cell (local source ids and rows' indices; the padding reads source 0
+// of the slice and is never added anywhere), a workgroup per slice for the tile blocks' part behind the cells
+__global__ void __launch_bounds__(256)
+pa_cell_streams_kernel(const uint2 *__restrict__ cell, const uint32_t *__restrict__ cellp, uint32_t G, uint32_t S,
+                       const uint32_t *__restrict__ sidx, const uint32_t *__restrict__ src, const uint16_t *__restrict__ rl,
+                       uint32_t W, uint16_t *__restrict__ asrc, uint16_t *__restrict__ arow) {
+    const uint64_t ci = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ci >= (uint64_t)G * S) return;
+    const uint32_t g = (uint32_t)(ci / S), s = (uint32_t)(ci % S), lane = threadIdx.x & 63;
+    const uint2 d = cell[(size_t)g * (S + 1) + s];
+    const uint32_t pp = cellp[(size_t)g * (S + 1) + s];
+    const uint32_t c4 = (d.y + 3u) & ~3u;
+    for (uint32_t k = lane; k < c4; k += 64) {
+        uint16_t ls = 0, lr = 0;
+        if (k < d.y) {
+            const uint32_t e = sidx[d.x + k];
+            ls = (uint16_t)(src[e] - s * W);
+            lr = rl[e];
+        }
+        asrc[pp + k] = ls;
+        arow[pp + k] = lr;
+    }
+}
+__global__ void __launch_bounds__(256)
+pa_tile_streams_kernel(const uint32_t *__restrict__ key_ptr, const uint32_t *__restrict__ slice_edges, const uint32_t *__restrict__ tile_start,
+                       const uint32_t *__restrict__ sidx, const uint32_t *__restrict__ src, uint32_t W, uint16_t *__restrict__ asrc) {
+    const uint32_t s = blockIdx.x;
+    const uint32_t i0 = key_ptr[s] + slice_edges[s], i1 = key_ptr[s + 1], to = tile_start[s];
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256) asrc[to + (i - i0)] = (uint16_t)(src[sidx[i]] - s * W);
+}
+// the tile blocks' segment table was built in sorted-order positions: move every run to where its slice's tile part went
+__global__ void __launch_bounds__(256)
+pa_seg_shift_kernel(uint2 *__restrict__ seg, uint32_t n_blocks, uint32_t S, const uint32_t *__restrict__ key_ptr,
+                    const uint32_t *__restrict__ slice_edges, const uint32_t *__restrict__ tile_start) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (uint64_t)n_blocks * S) return;
+    const uint32_t b = (uint32_t)(t / S), s = (uint32_t)(t % S);
+    uint2 *e = seg + (size_t)b * (S + 1) + s;
+    e->x = e->x - (key_ptr[s] + slice_edges[s]) + tile_start[s];
+}
+// how many of the first `e_front` in-edges fall into every slice (the choice of the formulation: a skewed source distribution
+// leaves most (group, slice) cells nearly empty, and a piece costs the same whatever it holds)
+__global__ void __launch_bounds__(256)
+pa_slice_hist_kernel(const uint32_t *__restrict__ src, uint32_t e_front, uint32_t W, uint32_t S, uint32_t *__restrict__ hist) {
+    extern __shared__ uint32_t h[];
+    for (uint32_t i = threadIdx.x; i < S; i += 256) h[i] = 0;
+    __syncthreads();
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < e_front; e += gridDim.x * 256) atomicAdd(&h[src[e] / W], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < S; i += 256)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+// pieces per group = sum over its cells of ceil(count / 256), padded to batches of eight + one empty batch
+__global__ void __launch_bounds__(64)
+pa_piece_count_kernel(const uint2 *__restrict__ cell, uint32_t S, uint32_t *__restrict__ padded) {
+    const uint2 *cg = cell + (size_t)blockIdx.x * (S + 1);
+    uint32_t n = 0;
+    for (uint32_t s = threadIdx.x; s < S; s += 64) n += (cg[s].y + kAccPiece - 1u) / kAccPiece;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, 64);
+    if (threadIdx.x == 0) padded[blockIdx.x] = ((n + kAccBatch - 1) / kAccBatch + 1) * kAccBatch;
+    if (blockIdx.x == 0 && threadIdx.x == 0) padded[gridDim.x] = 0;
+}
+// one wave per group: the cells' pieces in slice order, then empty pieces up to the padded length
+__global__ void __launch_bounds__(64)
+pa_piece_list_kernel(const uint2 *__restrict__ cell, const uint32_t *__restrict__ cellp, uint32_t S, const uint32_t *__restrict__ pbase,
+                     uint2 *__restrict__ piece) {
+    const uint2 *cg = cell + (size_t)blockIdx.x * (S + 1);
+    const uint32_t *cp = cellp + (size_t)blockIdx.x * (S + 1);
+    const uint32_t p0 = pbase[blockIdx.x], p1 = pbase[blockIdx.x + 1];
+    const int lane = threadIdx.x;
+    uint32_t run = 0;
+    for (uint32_t s0 = 0; s0 < S; s0 += 64) {
+        const uint32_t sl = s0 + lane;
+        const uint32_t cnt = sl < S ? cg[sl].y : 0u, pos = sl < S ? cp[sl] : 0u;
+        const uint32_t c = (cnt + kAccPiece - 1u) / kAccPiece;
+        uint32_t x = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        const uint32_t at = p0 + run + x - c;
+        for (uint32_t k = 0; k < c; k++) piece[at + k] = make_uint2(pos + kAccPiece * k, min(kAccPiece, cnt - kAccPiece * k));
+        run += __shfl(x, 63, 64);
+    }
+    for (uint32_t i = p0 + run + lane; i < p1; i += 64) piece[i] = make_uint2(0, 0);
+}
+// one wave per piece: where every value stands in its stretch of equal rows inside the piece goes into the u16 beside the
+// row index (last of its stretch; lanes crossed by the stretch of the lane's first value), the largest number of lanes
+// crossed into the descriptor
+__global__ void __launch_bounds__(256)
+pa_piece_flags_kernel(uint2 *__restrict__ piece, uint32_t n_pieces, uint16_t *__restrict__ arow) {
+    const uint32_t pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pi >= n_pieces) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint2 d = piece[pi];
+    const uint32_t n = d.y;
+    if (n == 0) return;
+    uint32_t row[4];
+    bool on[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        on[j] = lane * 4 + j < n;
+        row[j] = on[j] ? arow[d.x + lane * 4 + j] : 0xFFFFFFFFu - j;  // (values beyond the end: rows of their own)
+    }
+    const uint32_t below = __shfl_up(row[3], 1, 64), above = __shfl_down(row[0], 1, 64);
+    const bool from_below = lane > 0 && on[0] && row[0] == below;  // the lane's first value continues the lane below
+    // a lane the stretch passes THROUGH: it comes from below and all four values are its row
+    const bool through = from_below && row[1] == row[0] && row[2] == row[0] && row[3] == row[0];
+    const unsigned long long stops = __ballot(!through);
+    const unsigned long long lower = stops & ((1ull << lane) - 1ull);  // lanes below this one that the stretch does not pass through
+    const uint32_t hops = from_below ? lane - (63u - (uint32_t)__builtin_clzll(lower | 1ull)) : 0u;
+    uint32_t mr = hops;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mr = max(mr, (uint32_t)__shfl_xor((int)mr, o, 64));
+    const uint32_t n4 = (n + 3u) & ~3u;  // (a cell's padding positions belong to its last piece: they carry hop bits only)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t idx = lane * 4 + j;
+        if (idx >= n4) continue;
+        const uint32_t hb = j < 3 ? ((hops >> (2 * j)) & 3u) : 0u;
+        if (!on[j]) {
+            arow[d.x + idx] = (uint16_t)(hb << kAccHopShift);
+            continue;
+        }
+        const uint32_t next = j < 3 ? row[j + 1] : (lane < 63 ? above : 0xFFFFFFF0u);
+        const bool tail = idx + 1 == n || next != row[j];
+        arow[d.x + idx] = (uint16_t)(row[j] | (tail ? kAccTail : 0u) | (hb << kAccHopShift));
+    }
+    if (lane == 0) piece[pi].y = n | (mr << 16);
 }
 
 // ---- plan construction kernels (run once) -------------------------------------------------------------------
@@ -1125,8 +1382,9 @@ struct cz_pagerank_plan {
     // accumulate formulation (pa_reduce_kernel): plan rows [0, grow[n_groups]) in groups, one wave each
     bool accum = false;
     uint32_t n_groups = 0, e_groups = 0, acc_nw = 16, acc_rw = 0, n_awgs = 0;
-    uint32_t *d_grow = nullptr;
-    uint2 *d_cell = nullptr;
+    uint32_t *d_grow = nullptr, *d_pbase = nullptr;
+    uint2 *d_piece = nullptr;
+    uint64_t n_pieces = 0, stream_len = 0;
     uint16_t *d_arow = nullptr;
     RowBlock *d_bblocks = nullptr;
     AItem *d_items = nullptr;
@@ -1153,7 +1411,7 @@ struct cz_pagerank_plan {
     double *d_partial = nullptr;
     ~cz_pagerank_plan() {
         void *ps[] = {d_gblocks, d_hblocks, d_bblocks, d_items, d_asrc, d_perm, d_vpos, d_seg, d_val, d_off, d_src, d_outdeg, d_scores,
-                      d_partial, d_rowid, d_grow, d_cell, d_arow};
+                      d_partial, d_rowid, d_grow, d_pbase, d_piece, d_arow};
         (void)hipDeviceSynchronize();  // (what hipFree did implicitly: nothing of this plan is in flight any more)
         for (void *p : ps) plan_free(p);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -1197,9 +1455,9 @@ int device_cus() {
 AccShape acc_shape(uint32_t N) {
     AccShape a;
     const uint32_t cus = (uint32_t)device_cus();
-    a.NW = env_int("CZ_PR_ACC_WAVES", 16) == 8 ? 8u : 16u;
+    a.NW = env_int("CZ_PR_ACC_WAVES", 8) == 16 ? 16u : 8u;
     a.per_cu = (uint32_t)std::min(2, std::max(1, env_int("CZ_PR_ACC_PER_CU", 1)));
-    a.rw = ((kAccLdsBytes / a.per_cu / 4 / a.NW) & ~3u);
+    a.rw = std::min<uint32_t>(kAccMaxRows, (kAccLdsBytes / a.per_cu / 4 / a.NW) & ~3u);
     a.a_per_cu = (uint32_t)std::min(2, std::max(1, env_int("CZ_PR_ACC_A_PER_CU", 1)));
     const uint32_t wmax = ((uint32_t)kMaxAccSlice / a.a_per_cu) & ~3u;
     // slices: a multiple of the workgroup slots of phase A (one round of workgroups on a balanced graph)
@@ -1370,8 +1628,51 @@ int build_streamed(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t W, uint3
                              (unsigned long long)e_blocked);
     const uint32_t EB = (uint32_t)e_blocked;
     hipLaunchKernelGGL(pb_check_sorted_kernel, dim3(2048), dim3(256), 0, nullptr, keys_out.p, idx_out.p, EB, d_bad.p);
-    // phase-A streams (padded to a multiple of 8 entries plus one vector so that aligned 16-byte loads stay inside)
-    const size_t padded = (((size_t)EB + 7) & ~(size_t)7) + 8;
+    // Stream positions.  Blocked: a slice's edges sit where the sort put them.  Accumulate: every (group, slice) cell is
+    // rounded up to a multiple of four positions (aligned 16-byte value loads in phase B), the tile blocks' part of a slice
+    // follows its cells, a slice starts on a multiple of eight: pos_ptr[s] = where slice s starts, tile_start[s] = where its
+    // tile part starts.
+    std::vector<uint32_t> pos_ptr(key_ptr), tile_start, slice_edges;
+    PoolBuf<uint2> cell;       // [G][S + 1]: (sorted-order position, count) of every (group, slice) cell
+    PoolBuf<uint32_t> cellp;   // [G][S + 1]: its stream position
+    PoolBuf<uint32_t> d_slice_edges, d_tile_start, d_slice_start;
+    uint64_t stream_len = EB;
+    if (G) {
+        if (p->acc_rw > kAccMaxRows) return cz::set_error(CZ_E_HIP, "internal: a group of %u rows", p->acc_rw);
+        PoolBuf<uint32_t> d_plen;
+        CZ_HIP(cell.alloc((size_t)G * ((size_t)S + 1)));
+        CZ_HIP(cellp.alloc((size_t)G * ((size_t)S + 1)));
+        CZ_HIP(d_plen.alloc(S));
+        CZ_HIP(d_slice_edges.alloc(S));
+        CZ_HIP(d_tile_start.alloc(S));
+        CZ_HIP(d_slice_start.alloc(S));
+        const uint64_t pairs = (uint64_t)G * S;
+        hipLaunchKernelGGL(pb_seg_kernel, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, nullptr, d_kblocks.p, d_kchunk.p, G,
+                           p->d_off, d_keyptr.p, idx_out.p, S, cell.p);
+        hipLaunchKernelGGL(pa_slice_sums_kernel, dim3(S), dim3(256), 0, nullptr, cell.p, G, S, d_plen.p, d_slice_edges.p);
+        std::vector<uint32_t> plen(S);
+        slice_edges.resize(S);
+        tile_start.resize(S);
+        CZ_HIP(hipMemcpy(plen.data(), d_plen.p, (size_t)S * 4, hipMemcpyDeviceToHost));
+        CZ_HIP(hipMemcpy(slice_edges.data(), d_slice_edges.p, (size_t)S * 4, hipMemcpyDeviceToHost));
+        uint64_t at = 0;
+        for (uint32_t sl = 0; sl < S; sl++) {
+            pos_ptr[sl] = (uint32_t)at;
+            tile_start[sl] = (uint32_t)(at + plen[sl]);
+            at += (uint64_t)plen[sl] + ((key_ptr[sl + 1] - key_ptr[sl]) - slice_edges[sl]);
+            at = (at + 7) & ~7ull;
+            if (at >= 0xFFFFFF00ull) return cz::set_error(CZ_E_UNSUPPORTED, "the padded value stream exceeds 2^32 positions");
+        }
+        pos_ptr[S] = (uint32_t)at;
+        stream_len = at;
+        p->stream_len = at;
+        CZ_HIP(hipMemcpy(d_slice_start.p, pos_ptr.data(), (size_t)S * 4, hipMemcpyHostToDevice));
+        CZ_HIP(hipMemcpy(d_tile_start.p, tile_start.data(), (size_t)S * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(pa_cell_pos_kernel, dim3(S), dim3(256), 0, nullptr, cell.p, G, S, d_slice_start.p, cellp.p);
+    }
+    // phase-A streams (padded to a multiple of 8 entries plus one vector so that aligned 16-byte loads stay inside; + a
+    // piece's length: phase B of the accumulate formulation reads whole wave instructions at a piece's start)
+    const size_t padded = (((size_t)stream_len + 7) & ~(size_t)7) + 8 + kAccPiece;
     CZ_HIP(plan_alloc((void **)&p->d_asrc, padded * 2));
     CZ_HIP(hipMemset(p->d_asrc, 0, padded * 2));
     // value stream: with more than one chunk the chunks can share ONE buffer (each chunk's expand output is
@@ -1390,23 +1691,40 @@ int build_streamed(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t W, uint3
             need = ((need + 7) & ~(size_t)7) + 8;
         }
         CZ_HIP(plan_alloc((void **)&p->d_val, need * 4));
+        if (G) CZ_HIP(hipMemsetAsync(p->d_val, 0, need * 4, nullptr));  // (the padding positions behind the last slice are read, never written)
     }
     // the tile blocks' permutation is addressed by CSR position: theirs start behind the groups' edges
     const uint64_t e_tiles = E - e_groups;
     CZ_HIP(plan_alloc((void **)&p->d_perm, std::max<uint64_t>(1, e_tiles) * 2));
     CZ_HIP(plan_alloc((void **)&p->d_seg, std::max<size_t>(1, bb.size()) * ((size_t)S + 1) * sizeof(uint2)));
     if (G) {
-        CZ_HIP(plan_alloc((void **)&p->d_cell, (size_t)G * ((size_t)S + 1) * sizeof(uint2)));
-        CZ_HIP(plan_alloc((void **)&p->d_arow, padded * 2));
         PoolBuf<uint16_t> rl;
+        PoolBuf<uint32_t> pcount, d_ss;
+        CZ_HIP(plan_alloc((void **)&p->d_arow, padded * 2));
+        CZ_HIP(hipMemsetAsync(p->d_arow, 0, padded * 2, nullptr));
         CZ_HIP(rl.alloc(std::max<uint32_t>(1, e_groups)));
         hipLaunchKernelGGL(pa_rowlocal_kernel, dim3(G), dim3(256), 0, nullptr, p->d_grow, p->d_off, rl.p);
-        if (EB) hipLaunchKernelGGL(pa_streams_kernel, dim3(4096), dim3(256), 0, nullptr, idx_out.p, p->d_src, rl.p, EB, W, e_groups,
-                                   p->d_asrc, p->d_arow);
         const uint64_t pairs = (uint64_t)G * S;
-        hipLaunchKernelGGL(pb_seg_kernel, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, nullptr, d_kblocks.p, d_kchunk.p, G,
-                           p->d_off, d_keyptr.p, idx_out.p, S, p->d_cell);
-        CZ_HIP(hipStreamSynchronize(nullptr));  // rl dies with this scope
+        hipLaunchKernelGGL(pa_cell_streams_kernel, dim3((uint32_t)((pairs + 3) / 4)), dim3(256), 0, nullptr, cell.p, cellp.p, G, S,
+                           idx_out.p, p->d_src, rl.p, W, p->d_asrc, p->d_arow);
+        if (!bb.empty())
+            hipLaunchKernelGGL(pa_tile_streams_kernel, dim3(S), dim3(256), 0, nullptr, d_keyptr.p, d_slice_edges.p, d_tile_start.p, idx_out.p,
+                               p->d_src, W, p->d_asrc);
+        // the groups' piece lists
+        CZ_HIP(pcount.alloc((size_t)G + 1));
+        CZ_HIP(d_ss.alloc(czsort::scan_scratch_words((uint64_t)G + 1)));
+        CZ_HIP(plan_alloc((void **)&p->d_pbase, ((size_t)G + 1) * 4));
+        hipLaunchKernelGGL(pa_piece_count_kernel, dim3(G), dim3(64), 0, nullptr, cell.p, S, pcount.p);
+        if (int src_rc = czsort::exclusive_scan_u32(pcount.p, p->d_pbase, G + 1, d_ss.p, nullptr)) return src_rc;
+        uint32_t total = 0;
+        CZ_HIP(hipMemcpy(&total, p->d_pbase + G, 4, hipMemcpyDeviceToHost));
+        if ((uint64_t)total > (uint64_t)EB + (uint64_t)G * (S + 2 * kAccBatch))
+            return cz::set_error(CZ_E_HIP, "internal: %u pieces for %u stream positions", total, EB);
+        p->n_pieces = total;
+        CZ_HIP(plan_alloc((void **)&p->d_piece, std::max<size_t>(1, total) * sizeof(uint2)));
+        hipLaunchKernelGGL(pa_piece_list_kernel, dim3(G), dim3(64), 0, nullptr, cell.p, cellp.p, S, p->d_pbase, p->d_piece);
+        if (total) hipLaunchKernelGGL(pa_piece_flags_kernel, dim3((total + 3) / 4), dim3(256), 0, nullptr, p->d_piece, total, p->d_arow);
+        CZ_HIP(hipStreamSynchronize(nullptr));  // the temporaries die with this scope
     } else if (EB) {
         hipLaunchKernelGGL(pb_asrc_kernel, dim3(4096), dim3(256), 0, nullptr, idx_out.p, p->d_src, EB, W, p->d_asrc);
     }
@@ -1425,6 +1743,9 @@ int build_streamed(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t W, uint3
             CZ_HIP(plan_alloc((void **)&p->d_vpos, std::max<uint64_t>(1, E) * 4));
             hipLaunchKernelGGL(pb_vpos_kernel, dim3((uint32_t)bb.size()), dim3(256), 0, nullptr, p->d_bblocks, p->d_seg, S, p->d_vpos);
         }
+        if (G)  // (after the permutation, which reads the sorted order through the table)
+            hipLaunchKernelGGL(pa_seg_shift_kernel, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, nullptr, p->d_seg, (uint32_t)bb.size(), S,
+                               d_keyptr.p, d_slice_edges.p, d_tile_start.p);
     }
     st.lap("asrc / seg / perm kernels");
     uint32_t bad = 0;
@@ -1436,21 +1757,22 @@ int build_streamed(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t W, uint3
     uint32_t part_edges = kPartEdges;
     if (G) {
         uint32_t longest = 0;
-        for (uint32_t s = 0; s < S; s++) longest = std::max(longest, key_ptr[s + 1] - key_ptr[s]);
-        const uint64_t share = (e_blocked + S - 1) / S;
+        for (uint32_t s = 0; s < S; s++) longest = std::max(longest, pos_ptr[s + 1] - pos_ptr[s]);
+        const uint64_t share = (stream_len + S - 1) / S;
         part_edges = longest <= share + share / 32 + 64 ? std::max<uint32_t>(longest, 8) : (uint32_t)std::max<uint64_t>(kPartEdges / 4, share / 4);
     }
     std::vector<AItem> items;
     p->item_ptr.assign(1, 0);
     for (uint32_t c = 0; c < n_chunks; c++) {
         for (uint32_t s = 0; s < S; s++) {
-            const uint32_t lo = key_ptr[c * S + s], hi = key_ptr[c * S + s + 1];
+            const uint32_t lo = pos_ptr[c * S + s], hi = pos_ptr[c * S + s + 1];
             if (hi == lo) continue;
             const uint32_t parts = (hi - lo + part_edges - 1) / part_edges;
             const uint32_t step = (((hi - lo + parts - 1) / parts) + 7) & ~7u;
             for (uint32_t a = lo; a < hi;) {
                 uint32_t b = std::min<uint64_t>(hi, ((uint64_t)a + step) & ~7ull);
                 if (b <= a) b = std::min<uint64_t>(hi, (uint64_t)a + step);
+                if (hi - b < 64) b = hi;  // (no item of a handful of positions: it would stage a whole slice for them)
                 items.push_back({a, b, s, 0});
                 a = b;
             }
@@ -1473,8 +1795,8 @@ int build_streamed(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t W, uint3
         // more than 64 KiB of dynamic LDS has to be asked for, once per kernel
         static std::once_flag once;
         std::call_once(once, [] {
-            (void)hipFuncSetAttribute((const void *)pa_reduce_kernel<16, kAccU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAccLdsBytes);
-            (void)hipFuncSetAttribute((const void *)pa_reduce_kernel<8, kAccU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAccLdsBytes);
+            (void)hipFuncSetAttribute((const void *)pa_reduce_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAccLdsBytes);
+            (void)hipFuncSetAttribute((const void *)pa_reduce_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAccLdsBytes);
         });
     }
     {
@@ -1636,12 +1958,28 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
         mode = (E >= (4u << 20) && seg_bytes <= (2ull << 30)) ? 2 : 1;
         // The accumulate formulation walks a (group, slice) cell per wave instruction: it needs cells of some length.
         // One round of workgroups holds cus * per_cu * NW groups; a cell then averages E_front / (S * groups) values.
-        if (mode == 2 && n_front_rows > 0 && n_chunks == 1 && env_int("CZ_PR_ACC_AUTO", 0) != 0) {
+        // The accumulate formulation streams fewer bytes and no tile, but walks a (group, slice) cell in pieces of 256 positions
+        // that cost the same full or empty: it wins when the pieces are well filled (uniform 10M / 100M: 190 of 256, 0.27 ms
+        // against 0.33) and loses when the sources are skewed and most cells hold a handful of values (R-MAT: 0.59 against
+        // 0.51).  The fill is estimated from the slices' edge counts: a cell of slice s holds about count_s / groups values.
+        if (mode == 2 && n_front_rows > 0 && n_chunks == 1 && env_int("CZ_PR_ACC_AUTO", 1) != 0 && shape.S <= 8192) {
             const uint64_t per_round = (uint64_t)device_cus() * shape.per_cu * shape.NW;
             uint64_t G = per_round;
             while ((n_front_rows + G - 1) / G > (uint64_t)shape.rw * 97 / 100) G += per_round;
-            const uint64_t e_front = in_offsets[n_front_rows];
-            if (e_front / (G * shape.S) >= (uint64_t)std::max(1, env_int("CZ_PR_ACC_MIN_CELL", 24))) mode = 3;
+            const uint32_t e_front = in_offsets[n_front_rows];
+            PoolBuf<uint32_t> d_hist;
+            CZ_HIP(d_hist.alloc(shape.S));
+            CZ_HIP(hipMemsetAsync(d_hist.p, 0, (size_t)shape.S * 4, nullptr));
+            hipLaunchKernelGGL(pa_slice_hist_kernel, dim3(1024), dim3(256), shape.S * 4, nullptr, p->d_src, e_front, shape.W, shape.S, d_hist.p);
+            std::vector<uint32_t> hist(shape.S);
+            CZ_HIP(hipMemcpy(hist.data(), d_hist.p, (size_t)shape.S * 4, hipMemcpyDeviceToHost));
+            double pieces = 0;
+            for (uint32_t c : hist)
+                if (c) pieces += (double)G * std::ceil((double)c / (double)G / (double)kAccPiece);
+            const double fill = pieces > 0 ? (double)e_front / (pieces * kAccPiece) : 0.0;
+            const char *mf = getenv("CZ_PR_ACC_MIN_FILL");
+            if (fill >= (mf ? atof(mf) : 0.55)) mode = 3;
+            st_plan.lap("formulation choice (slice histogram)");
         }
     }
     if (mode == 3 && rows > 0 && E > 0) {
@@ -1734,12 +2072,12 @@ extern "C" int cz_pagerank_plan_step(cz_pagerank_plan *p, const float *contrib_i
             if (p->n_awgs) {
                 const uint32_t lds = p->acc_nw * p->acc_rw * 4;
                 if (p->acc_nw == 8)
-                    hipLaunchKernelGGL((pa_reduce_kernel<8, kAccU>), dim3(p->n_awgs), dim3(8 * 64), lds, stream, p->d_grow, p->n_groups,
-                                       p->d_cell, p->S, p->d_arow, val, p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores,
+                    hipLaunchKernelGGL((pa_reduce_kernel<8>), dim3(p->n_awgs), dim3(8 * 64), lds, stream, p->d_grow, p->n_groups,
+                                       p->d_pbase, p->d_piece, p->d_arow, val, p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores,
                                        p->base, p->damping, p->d_partial, p->d_rowid, p->acc_rw);
                 else
-                    hipLaunchKernelGGL((pa_reduce_kernel<16, kAccU>), dim3(p->n_awgs), dim3(16 * 64), lds, stream, p->d_grow, p->n_groups,
-                                       p->d_cell, p->S, p->d_arow, val, p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores,
+                    hipLaunchKernelGGL((pa_reduce_kernel<16>), dim3(p->n_awgs), dim3(16 * 64), lds, stream, p->d_grow, p->n_groups,
+                                       p->d_pbase, p->d_piece, p->d_arow, val, p->d_outdeg, p->row_begin, contrib_out_dev, p->d_scores,
                                        p->base, p->damping, p->d_partial, p->d_rowid, p->acc_rw);
             }
             if (b1 > b0) {
@@ -1772,10 +2110,11 @@ extern "C" uint64_t cz_pagerank_plan_edges(const cz_pagerank_plan *p) { return p
 extern "C" uint32_t cz_pagerank_plan_nodes(const cz_pagerank_plan *p) { return p ? p->N : 0; }
 extern "C" int cz_pagerank_plan_is_blocked(const cz_pagerank_plan *p) { return p && p->blocked ? 1 : 0; }
 extern "C" int cz_pagerank_plan_formulation(const cz_pagerank_plan *p) { return !p ? 0 : p->accum ? 3 : p->blocked ? 2 : 1; }
-extern "C" int cz_pagerank_plan_shape(const cz_pagerank_plan *p, uint32_t *out8) {
-    if (!p || !out8) return cz::set_error(CZ_E_INVALID, "null argument");
-    const uint32_t v[8] = {p->S, p->slice_w, p->n_groups, p->acc_nw, p->acc_rw, p->n_awgs, p->n_bblocks, p->n_hblocks};
-    memcpy(out8, v, sizeof(v));
+extern "C" int cz_pagerank_plan_shape(const cz_pagerank_plan *p, uint32_t *out12) {
+    if (!p || !out12) return cz::set_error(CZ_E_INVALID, "null argument");
+    const uint32_t v[12] = {p->S, p->slice_w, p->n_groups, p->acc_nw, p->acc_rw, p->n_awgs, p->n_bblocks, p->n_hblocks,
+                            (uint32_t)p->n_pieces, p->e_groups, (uint32_t)p->stream_len, 0};
+    memcpy(out12, v, sizeof(v));
     return CZ_OK;
 }
 

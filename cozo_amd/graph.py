@@ -107,10 +107,10 @@ class PageRankPlan:
     @property
     def shape(self) -> dict:
         """slices / groups / workgroups of the plan (measurement scripts)"""
-        a = np.zeros(8, dtype=np.uint32)
+        a = np.zeros(12, dtype=np.uint32)
         check(_lib.lib().cz_pagerank_plan_shape(self._h, ptr(a)))
-        return dict(zip(("slices", "slice_width", "groups", "waves", "rows_per_group", "acc_workgroups", "tile_blocks", "hub_rows"),
-                        (int(x) for x in a)))
+        return dict(zip(("slices", "slice_width", "groups", "waves", "rows_per_group", "acc_workgroups", "tile_blocks", "hub_rows",
+                         "pieces", "group_edges", "stream_positions"), (int(x) for x in a)))
 
     @property
     def timing(self):

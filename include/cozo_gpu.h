@@ -307,8 +307,8 @@ int cz_pagerank_plan_is_blocked(const cz_pagerank_plan *p);
  * sweep with in-order accumulation (rows of the front part in groups, one wave each; csrc/pagerank.hip) */
 int cz_pagerank_plan_formulation(const cz_pagerank_plan *p);
 /* the plan's shape, for measurement scripts: {slices, slice width, groups, waves per workgroup, rows per group (LDS words),
- * accumulate workgroups, tile blocks, hub rows} */
-int cz_pagerank_plan_shape(const cz_pagerank_plan *p, uint32_t *out8);
+ * accumulate workgroups, tile blocks, hub rows, pieces, in-edges of the groups' rows, value-stream positions, 0} */
+int cz_pagerank_plan_shape(const cz_pagerank_plan *p, uint32_t *out12);
 /* what creating the plan cost: CSR upload and static layout, milliseconds */
 int cz_pagerank_plan_timing(const cz_pagerank_plan *p, double *h2d_ms, double *build_ms);
 /* copy this shard's scores [row_end-row_begin] to `out` (host, or device with CZ_DEVICE_PTRS) */

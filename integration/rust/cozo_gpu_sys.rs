@@ -161,7 +161,7 @@ extern "C" {
     pub fn cz_pagerank_plan_edges(p: *const cz_pagerank_plan) -> u64;
     pub fn cz_pagerank_plan_is_blocked(p: *const cz_pagerank_plan) -> c_int;
     pub fn cz_pagerank_plan_formulation(p: *const cz_pagerank_plan) -> c_int;
-    pub fn cz_pagerank_plan_shape(p: *const cz_pagerank_plan, out8: *mut u32) -> c_int;
+    pub fn cz_pagerank_plan_shape(p: *const cz_pagerank_plan, out12: *mut u32) -> c_int;
     pub fn cz_pagerank_plan_read_scores(p: *mut cz_pagerank_plan, out: *mut c_float, flags: u32, stream: *mut c_void) -> c_int;
 
     pub fn cz_hnsw_insert(ix: *mut cz_hnsw_index, vectors: *const c_float, n_new: u32, m: u32, ef_construction: u32,

@@ -14,7 +14,8 @@ CFGS = {
     "blocked": ("blocked", {}),
     "acc": ("accumulate", {}),
     "acc_b2": ("accumulate", {"CZ_PR_ACC_PER_CU": "2"}),
-    "acc_w8b2": ("accumulate", {"CZ_PR_ACC_PER_CU": "2", "CZ_PR_ACC_WAVES": "8"}),
+    "acc_w16": ("accumulate", {"CZ_PR_ACC_WAVES": "16"}),
+    "acc_w16b2": ("accumulate", {"CZ_PR_ACC_PER_CU": "2", "CZ_PR_ACC_WAVES": "16"}),
     "acc_a2": ("accumulate", {"CZ_PR_ACC_A_PER_CU": "2"}),
     "acc_a2b2": ("accumulate", {"CZ_PR_ACC_A_PER_CU": "2", "CZ_PR_ACC_PER_CU": "2"}),
     "acc_s512": ("accumulate", {"CZ_PR_ACC_SLICES": "512"}),
@@ -28,7 +29,7 @@ def main():
     kinds = sys.argv[1] if len(sys.argv) > 1 else "both"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
     e = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000_000
-    names = os.environ.get("PR_CFGS", "blocked,acc,acc_b2,acc_w8b2,acc_a2,acc_s512,auto").split(",")
+    names = os.environ.get("PR_CFGS", "blocked,acc,acc_b2,acc_w16,acc_a2,auto").split(",")
     stream = torch.cuda.current_stream().cuda_stream
     args = types.SimpleNamespace()
     for kind in (["uniform", "rmat"] if kinds == "both" else [kinds]):
@@ -62,6 +63,21 @@ def main():
                     plan.step(c0, c1, err, stream); c0, c1 = c1, c0
                 e1.record(); torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) / 10)
+            if hasattr(L, "cz_pagerank_phase_cycles") or os.environ.get("PR_PHASES"):
+                import ctypes as C
+                try:
+                    fn = L.cz_pagerank_phase_cycles
+                    fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
+                    buf = (C.c_ulonglong * 8)()
+                    fn(None, 1)
+                    for _ in range(5):
+                        plan.step(c0, c1, err, stream); c0, c1 = c1, c0
+                    torch.cuda.synchronize()
+                    fn(buf, 1)
+                    w = max(1, buf[4])
+                    print(f"           phases (cycles per wave, {w // 5} waves): " + " ".join(f"{buf[k] / w:.0f}" for k in range(4)), flush=True)
+                except AttributeError:
+                    pass
             sc = torch.empty(n, dtype=torch.float32, device=dev); plan.read_scores(sc); torch.cuda.synchronize()
             same = None
             if ref is None:
