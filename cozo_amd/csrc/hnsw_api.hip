@@ -759,29 +759,54 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
     const size_t smem = czh::smem_bytes(efcap, wpad, ix->ld, false);
     if (smem > 160 * 1024)
         return set_error(CZ_E_UNSUPPORTED, "dim %u / ef %u need %zu bytes of LDS (> 160 KiB)", ix->dim, ef, smem);
-    HnswIndex::Workspace ws;
-    int rc = ix->acquire(hbits ? ((size_t)B << hbits) * 4 : 0, (size_t)B * words * 4, stream, &ws);
-    if (rc) return rc;
     IndexDev d = ix->dev();
     Shape sh = shape_of(ix->dim);
     czh::PredSet preds;
     memset(&preds, 0, sizeof preds);
     if (preds_in) preds = *preds_in;
-#define CZ_LAUNCH_KNN(LPV, ITERS, U)                                                                                    \
+    // The grid is persistent (hnsw_kernels.cuh): as many workgroups as the chip holds at once -- occupancy of THIS
+    // instantiation with this much LDS x the CUs -- or B if that is fewer; the visited workspace has one slot per workgroup.
+    // Rows in flight per lane group (U) for the 513..768-d shape: 2 when the batch fills the chip, 4 / 8 when it leaves
+    // it half / three quarters empty (a step is then bound by its rounds' latency; CZ_HNSW_U = 1 | 2 | 4 | 8 overrides).
+    int cus = 256;
+    {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    HnswIndex::Workspace ws;
+    int rc = CZ_OK;
+    uint32_t grid = 0;
+#define CZ_LAUNCH_KNN(LPV, ITERS, U) CZ_LAUNCH_KNN_(hnsw_knn_kernel, LPV, ITERS, U)
+#define CZ_LAUNCH_KNN_(KERNEL, LPV, ITERS, U)                                                                           \
     do {                                                                                                                \
-        auto kern = czh::hnsw_knn_kernel<LPV, ITERS, U>;                                                                \
+        auto kern = czh::KERNEL<LPV, ITERS, U>;                                                                         \
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                         (int)smem);                                                    \
-        hipLaunchKernelGGL(kern, dim3(B), dim3(czh::kThreads), smem, stream, d, d_queries, k, ef, efcap, wpad,          \
+        int per_cu = 0;                                                                                                 \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, czh::kThreads, smem) != hipSuccess || per_cu < 1) { \
+            (void)hipGetLastError();                                                                                    \
+            per_cu = 1;                                                                                                 \
+        }                                                                                                               \
+        const char *slots_env = getenv("CZ_HNSW_SLOTS");                                                                \
+        const uint64_t slots = slots_env && atoi(slots_env) > 0 ? (uint64_t)atoi(slots_env) : (uint64_t)per_cu * (uint64_t)cus; \
+        grid = (uint32_t)std::min<uint64_t>(B, slots);                                                                  \
+        rc = ix->acquire(hbits ? ((size_t)grid << hbits) * 4 : 0, (size_t)grid * words * 4, stream, &ws);               \
+        if (rc) return rc;                                                                                              \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(czh::kThreads), smem, stream, d, d_queries, B, k, ef, efcap, wpad,    \
                            has_radius, radius, (uint32_t *)ws.tab, hbits, (uint32_t *)ws.bitmap, words, preds, d_ids,   \
                            d_dist, d_count, (unsigned long long *)d_ndist);                                             \
     } while (0)
-    // experiment knob: rows per round of a lane group for the 513..768-d shape (CZ_HNSW_U = 1 | 2)
     const char *knn_u_env = getenv("CZ_HNSW_U");
-    const int knn_u = knn_u_env ? atoi(knn_u_env) : 0;
-    if (sh.lpv == 64 && sh.iters == 3 && knn_u == 1) CZ_LAUNCH_KNN(64, 3, 1);
-    else CZ_DISPATCH_SHAPE_SEARCH(sh, CZ_LAUNCH_KNN);
+    int knn_u = knn_u_env ? atoi(knn_u_env) : 0;
+    if (sh.lpv == 64 && sh.iters == 3) {
+        if (knn_u == 0) knn_u = (uint64_t)B * 4 <= (uint64_t)cus * 4 ? 8 : ((uint64_t)B * 2 <= (uint64_t)cus * 4 ? 4 : 2);
+        if (knn_u == 1) CZ_LAUNCH_KNN(64, 3, 1);
+        else if (knn_u == 4) CZ_LAUNCH_KNN_(hnsw_knn_wide_kernel, 64, 3, 4);
+        else if (knn_u == 8) CZ_LAUNCH_KNN_(hnsw_knn_wide_kernel, 64, 3, 8);
+        else CZ_LAUNCH_KNN(64, 3, 2);
+    } else CZ_DISPATCH_SHAPE_SEARCH(sh, CZ_LAUNCH_KNN);
 #undef CZ_LAUNCH_KNN
+#undef CZ_LAUNCH_KNN_
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         HnswIndex::destroy(ws);  // its contents are unknown

@@ -1100,20 +1100,27 @@ __device__ __forceinline__ bool pred_pass(const PredSet &ps, uint32_t node) {
 #ifndef CZ_SEARCH_NT
 #define CZ_SEARCH_NT 1
 #endif
+// The grid is PERSISTENT: min(B, the workgroups the chip holds at once) workgroups, workgroup i takes queries i, i + grid,
+// ... and owns ONE visited workspace (slot i) for all of them -- a batch of 4 096 queries then works on the 1 024 tables
+// that stay in L2 / the Infinity Cache instead of 4 096 (512 MB) that do not (profiles/r04_batch_size.txt: 0.66 of the peak
+// at B = 2 048 / 4 096 against 0.76 at 1 024).  U (rows in flight per lane group and round) is chosen from B by the
+// launcher: a batch that leaves most of the chip empty is bound by the latency of a step, and a step by the rounds its
+// rows take -- wider rounds (U = 4 / 8: 16 / 32 rows per round, the registers are free at that occupancy) shorten it.
 template <int LPV, int ITERS, int U>
-__global__ void __launch_bounds__(kThreads)
-hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t efcap,
-                uint32_t wpad, int has_radius, double radius, uint32_t *__restrict__ vtab, uint32_t hbits,
-                uint32_t *__restrict__ vbitmap, uint32_t words, PredSet preds, uint32_t *__restrict__ out_ids,
-                double *__restrict__ out_dist, uint32_t *__restrict__ out_count, unsigned long long *__restrict__ out_n_dist) {
+__device__ __forceinline__ void
+hnsw_knn_body(const IndexDev &ix, const float *__restrict__ queries, uint32_t B, uint32_t k, uint32_t ef, uint32_t efcap,
+              uint32_t wpad, int has_radius, double radius, uint32_t *__restrict__ vtab, uint32_t hbits,
+              uint32_t *__restrict__ vbitmap, uint32_t words, const PredSet &preds, uint32_t *__restrict__ out_ids,
+              double *__restrict__ out_dist, uint32_t *__restrict__ out_count, unsigned long long *__restrict__ out_n_dist) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const uint32_t b = blockIdx.x;
     Smem s = carve(smem_raw, efcap, wpad, ix.ld, false);
     VisitedDev vis;
-    vis.tab = hbits ? vtab + ((size_t)b << hbits) : nullptr;
+    vis.tab = hbits ? vtab + ((size_t)blockIdx.x << hbits) : nullptr;
     vis.hbits = hbits;
-    vis.bitmap = vbitmap + (size_t)b * words;
+    vis.bitmap = vbitmap + (size_t)blockIdx.x * words;
     vis.words = words;
+    for (uint32_t b = blockIdx.x; b < B; b += gridDim.x) {
+    if (b != blockIdx.x) __syncthreads();  // (the output stage of the query before this one has read the list)
     Searcher<LPV, ITERS, U, CZ_SEARCH_NT != 0> S(ix, s, vis);
     S.load_query(queries + (size_t)b * ix.dim);
     S.seed(ix.entry);
@@ -1200,6 +1207,29 @@ hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t k, uint
             out_n_dist[b] = ((unsigned long long)(unsigned int)s.ctl[C_NDIST_HI] << 32) |
                             (unsigned long long)(unsigned int)s.ctl[C_NDIST_LO];
     }
+    }  // the workgroup's next query
+}
+
+// the batch fills the chip: four workgroups per CU, i.e. at most 128 VGPRs (said explicitly: the loop over the
+// workgroup's queries took the compiler's own choice to 141 and the occupancy to three)
+template <int LPV, int ITERS, int U>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+hnsw_knn_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t B, uint32_t k, uint32_t ef, uint32_t efcap,
+                uint32_t wpad, int has_radius, double radius, uint32_t *__restrict__ vtab, uint32_t hbits,
+                uint32_t *__restrict__ vbitmap, uint32_t words, PredSet preds, uint32_t *__restrict__ out_ids,
+                double *__restrict__ out_dist, uint32_t *__restrict__ out_count, unsigned long long *__restrict__ out_n_dist) {
+    hnsw_knn_body<LPV, ITERS, U>(ix, queries, B, k, ef, efcap, wpad, has_radius, radius, vtab, hbits, vbitmap, words, preds, out_ids,
+                                 out_dist, out_count, out_n_dist);
+}
+// a batch that leaves most of the chip empty: more rows in flight per lane group, as many registers as that takes
+template <int LPV, int ITERS, int U>
+__global__ void __launch_bounds__(kThreads)
+hnsw_knn_wide_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t B, uint32_t k, uint32_t ef, uint32_t efcap,
+                     uint32_t wpad, int has_radius, double radius, uint32_t *__restrict__ vtab, uint32_t hbits,
+                     uint32_t *__restrict__ vbitmap, uint32_t words, PredSet preds, uint32_t *__restrict__ out_ids,
+                     double *__restrict__ out_dist, uint32_t *__restrict__ out_count, unsigned long long *__restrict__ out_n_dist) {
+    hnsw_knn_body<LPV, ITERS, U>(ix, queries, B, k, ef, efcap, wpad, has_radius, radius, vtab, hbits, vbitmap, words, preds, out_ids,
+                                 out_dist, out_count, out_n_dist);
 }
 
 }  // namespace czh
