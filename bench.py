@@ -49,6 +49,7 @@ PMC_SOURCES = {  # the kernel-bearing sources each PMC entry of profiles/pmc_tra
     "hnsw_knn": ["hnsw_kernels.cuh", "distance.cuh", "hnsw_api.hip"],
     "distance_batch": ["distance.cuh", "hnsw_api.hip"],
     "pagerank_blocked": ["pagerank.hip", "exact_sum.cuh"],
+    "pagerank_accumulate": ["pagerank.hip", "exact_sum.cuh"],
     "pagerank_gather": ["pagerank.hip", "exact_sum.cuh"],
     "pagerank_blocked_rmat": ["pagerank.hip", "exact_sum.cuh"],
     "hnsw_knn_1m": ["hnsw_kernels.cuh", "distance.cuh", "hnsw_api.hip"],
@@ -738,20 +739,42 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
         kern_s = e0.elapsed_time(e1) / 1e3 / reps
         algo_bytes = 4 * e_kept + 4 * (rows + 1) + 20 * rows  # SURVEY 8d compulsory-traffic model, this rank's shard
         gather_bytes = 8 * e_kept + 4 * (rows + 1) + 16 * rows  # SURVEY 8d's gather-counted variant (every gather = 4 B), for comparison
-        blocked = plan.blocked
-        kernel = "pb_expand_kernel + pb_reduce_kernel (one sweep)" if blocked else "pr_step_kernel"
+        form = plan.formulation  # "accumulate" | "blocked" | "gather": chosen by the plan from the shard's shape
+        shape = plan.shape
+        kernel = {"accumulate": "pb_expand_kernel + pa_reduce_kernel (one sweep)" + (" + pb_reduce_kernel (rows of >= 128 in-edges)" if shape["tile_blocks"] else ""),
+                  "blocked": "pb_expand_kernel + pb_reduce_kernel (one sweep)", "gather": "pr_step_kernel"}[form]
+        # What THIS formulation has to move per sweep, whatever the kernels do (the two-phase sweeps carry every edge through HBM
+        # twice as an f32 besides two 16-bit indices: LDS holds either an edge's sources or its destinations), and what that
+        # costs at the copy ceiling the guide gives for this chip (6.3 TB/s): the fraction of the compulsory model that is the
+        # formulation's own bound.  North_star's 0.70 of the model is out of reach for a sweep that keeps the reference's f32
+        # summation order; this says by how much.
+        fb = None
+        if form == "accumulate":
+            P, npieces = shape["stream_positions"], shape["pieces"]
+            fbytes = (2 * P + 4 * n_total + 4 * P) + (4 * P + 2 * P + 8 * npieces + 16 * rows)
+            if shape["tile_blocks"]:
+                fbytes += 2 * (e_kept - shape["group_edges"]) + 8 * rows  # the tile blocks' permutation and row offsets
+            fb = dict(bytes_per_sweep=fbytes, ms_at_copy_ceiling=fbytes / 6.3e12 * 1e3, frac_of_model=algo_bytes / (fbytes / 6.3e12) / 1e9 / HBM_PEAK_GBS,
+                      what="phase A: 2 B local source id + 4 B value out per stream position, the contribution vector staged once; phase B: "
+                           "4 B value + 2 B annotated row per position, 8 B per piece, 16 B per row (old score, out-degree, new score, new "
+                           "contribution); copy ceiling 6.3 TB/s")
+        elif form == "blocked":
+            fbytes = (2 * e_kept + 4 * e_kept + 4 * 4 * n_total) + (4 * e_kept + 2 * e_kept + 12 * rows + 16 * rows)
+            fb = dict(bytes_per_sweep=fbytes, ms_at_copy_ceiling=fbytes / 6.3e12 * 1e3, frac_of_model=algo_bytes / (fbytes / 6.3e12) / 1e9 / HBM_PEAK_GBS,
+                      what="phase A: 2 + 4 B per edge, every slice staged by ~4 work items; phase B: 4 + 2 B per edge, 12 B of offsets / "
+                           "segment table per row, 16 B per row; copy ceiling 6.3 TB/s (its phase B is bound by the REQUEST rate instead: "
+                           "4.7 M wave-level loads per sweep at ~22 G/s, profiles/r05_pagerank_accumulate.txt)")
         h2d_ms, build_ms = plan.timing
         res = dict(value=e_total * iters / wall, unit="edges/s", iterations=iters, ms_per_iteration=wall / iters * 1e3,
                    nodes=n_total, edges=e_total, graph=kind, longest_in_row=max_in,
                    default_run=dict(iterations=it_default, final_err=err_default),
-                   formulation=("blocked" if blocked else "gather") + ", every row's sum in the reference's sequential f32 order",
+                   formulation=form + ", every row's sum in the reference's sequential f32 order", plan_shape=shape,
                    plan_build_ms=build_ms,
                    roofline=dict(bound="hbm", kernel=kernel, achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
                                  unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
-                                 traffic=pmc_traffic(("pagerank_blocked" if blocked else "pagerank_gather") + ("" if kind == "uniform" else "_" + kind),
-                                                     world, algo_bytes),
+                                 traffic=pmc_traffic("pagerank_" + form + ("" if kind == "uniform" else "_" + kind), world, algo_bytes),
                                  algorithmic_bytes_per_launch=algo_bytes, avg_launch_ms=kern_s * 1e3,
-                                 frac_gather_counted=gather_bytes / kern_s / 1e9 / HBM_PEAK_GBS),
+                                 frac_gather_counted=gather_bytes / kern_s / 1e9 / HBM_PEAK_GBS, formulation_bound=fb),
                    exchange="none" if not args.multi else
                    (f"cz_pagerank_sharded (C++ loop behind the C ABI, RCCL): in-place all-gather of {per * 4} B per rank per iteration + "
                     f"all-reduce of 2 f64" if comm is not None else

@@ -500,6 +500,16 @@ __global__ void bfs_goals_left_kernel(const uint32_t *__restrict__ goals, uint32
 }
 
 __global__ void set_u32_kernel(uint32_t *p, uint32_t idx, uint32_t v) { p[idx] = v; }
+// every target a node id?  (the O(E) part of the adjacency checks that stays when the caller vouches for symmetry: ADVICE r4 --
+// a vouched adjacency with a target out of range was read out of bounds)
+__global__ void targets_in_range_kernel(const uint32_t *__restrict__ tgt, uint64_t E, uint32_t N, uint32_t *__restrict__ bad) {
+    bool any = false;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (uint64_t)gridDim.x * blockDim.x) any |= tgt[e] >= N;
+    if (any) atomicAdd(bad, 1u);
+}
+__global__ void scatter_u32_kernel(uint32_t *__restrict__ p, const uint32_t *__restrict__ idx, uint32_t n, uint32_t v) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[idx[i]] = v;
+}
 __global__ void or_u32_kernel(uint32_t *p, uint32_t idx, uint32_t v) { p[idx] |= v; }
 
 // ---------------------------------------------------------------------------------------------
@@ -831,14 +841,32 @@ sssp_unpack_kernel(const unsigned long long *__restrict__ dp, const uint32_t *__
 }
 
 // the single-GPU words: (cost << 32 | improper << 31 | parent), 0xFFFFFFFF = no parent
+// settled_bits: a run that stopped when its goals were settled (cz_sssp_goals) has final costs below that threshold only; the
+// rest are reported unreached (costs are non-negative floats: their bit patterns order like the values).  +inf = a full run.
 __global__ void __launch_bounds__(kT)
-sssp_unpack_flagged_kernel(const unsigned long long *__restrict__ dp, uint64_t n, float *__restrict__ dist, uint32_t *__restrict__ parent) {
+sssp_unpack_flagged_kernel(const unsigned long long *__restrict__ dp, uint64_t n, float *__restrict__ dist, uint32_t *__restrict__ parent,
+                           uint32_t settled_bits) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const unsigned long long c = dp[i];
-        dist[i] = __uint_as_float((uint32_t)(c >> 32));
+        const uint32_t cb = (uint32_t)(c >> 32);
+        const bool final_cost = cb < settled_bits;
+        dist[i] = final_cost ? __uint_as_float(cb) : __uint_as_float(0x7F800000u);
         const uint32_t p = (uint32_t)c;
-        parent[i] = p == CZ_NONE ? CZ_NONE : (p & 0x7FFFFFFFu);
+        parent[i] = (p == CZ_NONE || !final_cost) ? CZ_NONE : (p & 0x7FFFFFFFu);
     }
+}
+// how many (source, goal) pairs are not settled yet: a goal is settled once its cost is below the threshold every remaining
+// pile entry is at or above (the near pile is empty when this runs)
+__global__ void __launch_bounds__(kT)
+sssp_goals_left_kernel(const unsigned long long *__restrict__ dp, uint32_t N, uint32_t ns, const uint32_t *__restrict__ goals,
+                       uint32_t n_goals, uint32_t thr_bits, uint32_t *__restrict__ left) {
+    const uint64_t total = (uint64_t)ns * n_goals;
+    uint32_t mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t si = (uint32_t)(i / n_goals), g = goals[i % n_goals];
+        if (g < N && (uint32_t)(dp[(size_t)si * N + g] >> 32) >= thr_bits) mine++;
+    }
+    if (mine) atomicAdd(left, mine);
 }
 
 // BadEdgeWeightError (fixed_rule/mod.rs:258-286) on the device copy: the smallest index of a weight that is negative or NaN,
@@ -998,8 +1026,12 @@ extern "C" int cz_graph_last_timing(double *upload_ms, double *device_ms, double
 namespace {
 
 // the rule on a resident graph (cz_bfs uploads one for the call, cz_bfs_on is handed one)
+// merged (cz_bfs_shared; share_visited only): ONE backtrace `parent` [N] and ONE discovery sequence `order` [N] for all starts --
+// order[n_reached[i] .. n_reached[i + 1]) is what start i discovered, n_reached has n_starts + 1 entries -- instead of a row of N
+// per start.  A start that an earlier one reached costs nothing (the host keeps the visited bits), a traversal resets only the
+// claims of the nodes it reached: O(N + E) in all, like the reference's loop, whatever the number of starts.
 int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals, int share_visited,
-            uint32_t *parent, uint32_t *depth, uint32_t *order, uint32_t *n_reached, const volatile uint8_t *poison) {
+            uint32_t *parent, uint32_t *depth, uint32_t *order, uint32_t *n_reached, const volatile uint8_t *poison, bool merged = false) {
     const uint32_t N = G.N;
     const uint64_t E = G.E;
     int rc = CZ_OK;
@@ -1038,10 +1070,24 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
     CZ_HIP(hipMemsetAsync(d_depth.p, 0xFF, (size_t)N * 4, s));
     CZ_HIP(hipMemsetAsync(d_claim.p, 0xFF, (size_t)N * 4, s));
     CZ_HIP(hipMemsetAsync(d_vis.p, 0, vis_words * 4, s));
+    std::vector<uint32_t> hvis;  // merged: the visited bits, kept on the host too
+    uint64_t merged_total = 0;
+    if (merged) {
+        hvis.assign(vis_words, 0u);
+        CZ_HIP(hipMemsetAsync(d_parent.p, 0xFF, (size_t)N * 4, s));
+        n_reached[0] = 0;
+    }
     for (uint32_t si = 0; si < n_starts; si++) {
         if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
         const uint32_t start = starts[si];
         uint32_t reached = 0;
+        if (merged) {
+            if (start >= N || (hvis[start >> 5] >> (start & 31)) & 1u) {  // algos/bfs.rs:52-54 already visited => skip
+                n_reached[si + 1] = (uint32_t)merged_total;
+                continue;
+            }
+            hvis[start >> 5] |= 1u << (start & 31);
+        }
         if (!share_visited && si > 0) {
             CZ_HIP(hipMemsetAsync(d_depth.p, 0xFF, (size_t)N * 4, s));
             CZ_HIP(hipMemsetAsync(d_vis.p, 0, vis_words * 4, s));
@@ -1050,10 +1096,10 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
         // level's new nodes by (claim == frontier position, depth == level + 1), and a node an EARLIER start reached at the same
         // position and depth would pass that test again -- written into the next frontier twice, the last new node pushed past
         // the stretch and never expanded.  Every claimed node is visited, so forgetting the claims loses nothing.
-        if (si > 0) CZ_HIP(hipMemsetAsync(d_claim.p, 0xFF, (size_t)N * 4, s));
-        CZ_HIP(hipMemsetAsync(d_parent.p, 0xFF, (size_t)N * 4, s));
+        if (si > 0 && !merged) CZ_HIP(hipMemsetAsync(d_claim.p, 0xFF, (size_t)N * 4, s));
+        if (!merged) CZ_HIP(hipMemsetAsync(d_parent.p, 0xFF, (size_t)N * 4, s));
         bool run = start < N;
-        if (run && share_visited) {
+        if (run && share_visited && !merged) {
             uint32_t dstart;
             CZ_HIP(hipMemcpy(&dstart, d_depth.p + start, 4, hipMemcpyDeviceToHost));
             run = dstart == CZ_NONE;  // algos/bfs.rs:52-54 already visited => skip
@@ -1112,6 +1158,19 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
             if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "bfs launch: %s", hipGetErrorString(e));
         }
         t_timing.lap(T_DEVICE);
+        if (merged) {
+            if (reached) {
+                // the claims of this traversal's nodes are forgotten (see above), its discovery sequence joins the others'
+                hipLaunchKernelGGL(scatter_u32_kernel, dim3(grid_for(reached)), dim3(kT), 0, s, d_claim.p, d_order.p + 1, reached, CZ_NONE);
+                uint32_t *dst = order + merged_total;
+                CZ_HIP(hipMemcpy(dst, d_order.p + 1, (size_t)reached * 4, hipMemcpyDeviceToHost));
+                for (uint32_t i = 0; i < reached; i++) hvis[dst[i] >> 5] |= 1u << (dst[i] & 31);
+                merged_total += reached;
+            }
+            n_reached[si + 1] = (uint32_t)merged_total;
+            t_timing.lap(T_DOWNLOAD);
+            continue;
+        }
         CZ_HIP(hipMemcpy(parent + (size_t)si * N, d_parent.p, (size_t)N * 4, hipMemcpyDeviceToHost));
         if (depth) {
             CZ_HIP(hipMemcpy(depth + (size_t)si * N, d_depth.p, (size_t)N * 4, hipMemcpyDeviceToHost));
@@ -1122,10 +1181,25 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
         if (n_reached) n_reached[si] = reached;
         t_timing.lap(T_DOWNLOAD);
     }
+    if (merged) CZ_HIP(hipMemcpy(parent, d_parent.p, (size_t)N * 4, hipMemcpyDeviceToHost));
     return CZ_OK;
 }
 
 }  // namespace
+
+extern "C" int cz_bfs_shared(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E, const uint32_t *starts,
+                             uint32_t n_starts, uint32_t *parent, uint32_t *order, uint32_t *first, const volatile uint8_t *poison) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    t_timing.start();
+    if (first)
+        for (uint32_t i = 0; i <= n_starts; i++) first[i] = 0;
+    if (n_starts == 0 || N == 0) return CZ_OK;
+    if (!starts || !parent || !order || !first) return cz::set_error(CZ_E_INVALID, "null starts/parent/order/first");
+    cz_graph G;
+    if ((rc = graph_fill(G, out_offsets, out_targets, nullptr, N, E))) return rc;
+    return bfs_run(G, starts, n_starts, nullptr, 0, 1, parent, nullptr, order, first, poison, true);
+}
 
 extern "C" int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E,
                       const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals,
@@ -1458,9 +1532,18 @@ extern "C" int cz_clustering_coefficients(const uint32_t *offsets, const uint32_
         CZ_HIP(d_updown.alloc(2));
         CZ_HIP(hipMemsetAsync(d_bad.p, 0, 4, nullptr));
         CZ_HIP(hipMemsetAsync(d_updown.p, 0, 16, nullptr));
-        if (!(flags & CZ_ADJ_SYMMETRIC))
+        if (!(flags & CZ_ADJ_SYMMETRIC)) {
             hipLaunchKernelGGL(tri_symmetry_kernel, dim3(grid_for((uint64_t)N * 16)), dim3(256), 0, nullptr, d_off.p, d_tgt.p, N, d_bad.p,
                                d_updown.p);
+        } else {  // vouched for: the range of the targets is still checked (a wrong one is an error, not a reason for the general kernel)
+            cz::DevBuf<uint32_t> d_oor;
+            CZ_HIP(d_oor.alloc(1));
+            CZ_HIP(hipMemsetAsync(d_oor.p, 0, 4, nullptr));
+            hipLaunchKernelGGL(targets_in_range_kernel, dim3(grid_for(E)), dim3(256), 0, nullptr, d_tgt.p, E, N, d_oor.p);
+            uint32_t oor = 0;
+            CZ_HIP(hipMemcpy(&oor, d_oor.p, 4, hipMemcpyDeviceToHost));
+            if (oor) return cz::set_error(CZ_E_INVALID, "a target is out of range");
+        }
         hipLaunchKernelGGL(tri_self_loop_kernel, dim3(grid_for(N)), dim3(256), 0, nullptr, d_off.p, d_tgt.p, N, d_bad.p);
         uint32_t bad = 0;
         unsigned long long updown[2] = {0, 0};
@@ -1551,8 +1634,13 @@ struct SsspBatch {
 
     // d_misc: [0] seed / split near count, [1] far count, [2] far-next count, [3] min far cost bits, [4], [5] the near counters of
     // even / odd rounds (a round appends under its own and zeroes the other for the round after it: no memset per round)
+    // goals (device ids, optional): stop as soon as every goal of every source is settled -- dijkstra()'s early exit when its goal
+    // set is exhausted (shortest_path_dijkstra.rs:300-306); settled_bits then holds the threshold below which costs are final
+    const uint32_t *d_goals = nullptr;
+    uint32_t n_goals = 0, settled_bits = 0x7F800000u;
     int run(const uint32_t *starts, uint32_t ns, const volatile uint8_t *poison) {
         const uint64_t nsN = (uint64_t)ns * N;
+        settled_bits = 0x7F800000u;
         trace_mark("run: entry");
         hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, d_dp.p, nsN, kInfPacked);
         trace_mark("run: fill dp");
@@ -1592,6 +1680,18 @@ struct SsspBatch {
                 round++;
             }
             if (n_far == 0) break;
+            if (d_goals && n_goals && !one_pile) {  // every cost below thr is final now: are the goals among them?
+                uint32_t thr_now;
+                memcpy(&thr_now, &thr, 4);
+                CZ_HIP(hipMemsetAsync(d_misc.p + 6, 0, 4, s));
+                hipLaunchKernelGGL(sssp_goals_left_kernel, dim3(grid_for((uint64_t)ns * n_goals)), dim3(kT), 0, s, d_dp.p, N, ns, d_goals, n_goals,
+                                   thr_now, d_misc.p + 6);
+                if ((rc = read_counters(h))) return rc;
+                if (h[6] == 0) {
+                    settled_bits = thr_now;
+                    break;
+                }
+            }
             // move the threshold to the bucket of the nearest waiting node, then split the far pile
             CZ_HIP(hipMemsetAsync(d_misc.p + 3, 0xFF, 4, s));
             hipLaunchKernelGGL(sssp_far_min_kernel, dim3(grid_for(n_far)), dim3(kT), 0, s, far_cur, n_far, N, d_dp.p, d_misc.p + 3);
@@ -1625,7 +1725,7 @@ struct SsspBatch {
 };
 
 int sssp_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison,
-             bool keep_state);
+             bool keep_state, const uint32_t *goals = nullptr, uint32_t n_goals = 0);
 
 }  // namespace
 
@@ -1641,6 +1741,33 @@ extern "C" int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets,
     cz_graph G;
     if ((rc = graph_fill(G, out_offsets, out_targets, weights, N, E))) return rc;
     return sssp_run(G, starts, n_starts, dist, parent, poison, false);
+}
+
+extern "C" int cz_sssp_goals(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
+                             const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals, float *dist,
+                             uint32_t *parent, const volatile uint8_t *poison) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    t_timing.start();
+    if (n_starts == 0 || N == 0) return CZ_OK;
+    if (!starts || !dist || !parent) return cz::set_error(CZ_E_INVALID, "null starts/dist/parent");
+    if (n_goals && !goals) return cz::set_error(CZ_E_INVALID, "null goals");
+    if (E > 0 && !weights) return cz::set_error(CZ_E_INVALID, "null weights");
+    cz_graph G;
+    if ((rc = graph_fill(G, out_offsets, out_targets, weights, N, E))) return rc;
+    return sssp_run(G, starts, n_starts, dist, parent, poison, false, goals, n_goals);
+}
+
+extern "C" int cz_sssp_goals_on(const cz_graph *g, const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals,
+                                float *dist, uint32_t *parent, const volatile uint8_t *poison) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    t_timing.start();
+    if (!g) return cz::set_error(CZ_E_INVALID, "null graph");
+    if (n_starts == 0 || g->N == 0) return CZ_OK;
+    if (!starts || !dist || !parent) return cz::set_error(CZ_E_INVALID, "null starts/dist/parent");
+    if (n_goals && !goals) return cz::set_error(CZ_E_INVALID, "null goals");
+    return sssp_run(*g, starts, n_starts, dist, parent, poison, true, goals, n_goals);
 }
 
 extern "C" int cz_sssp_on(const cz_graph *g, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent,
@@ -1663,7 +1790,7 @@ struct SsspCallState {
 };
 
 int sssp_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison,
-             bool keep_state) {
+             bool keep_state, const uint32_t *goals, uint32_t n_goals) {
     const uint32_t N = G.N;
     int rc = CZ_OK;
     // a resident graph (cz_sssp_on) keeps its state arrays between calls; a one-shot call owns them for its own duration
@@ -1684,13 +1811,30 @@ int sssp_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, float
         if (d_parent.n != SN) CZ_HIP(d_parent.alloc(SN));
         if (d_dist.n != SN) CZ_HIP(d_dist.alloc(SN));
         hipStream_t s = sb.s;
+        cz::PoolBuf<uint32_t> d_goals;
+        sb.d_goals = nullptr;
+        sb.n_goals = 0;
+        if (goals && n_goals) {
+            CZ_HIP(d_goals.alloc(n_goals));
+            CZ_HIP(hipMemcpyAsync(d_goals.p, goals, (size_t)n_goals * 4, hipMemcpyHostToDevice, s));
+            sb.d_goals = d_goals.p;
+            sb.n_goals = n_goals;
+        }
+        struct GoalsOff {  // (the state may be kept for the next call: it must not remember this call's goal array)
+            SsspBatch &b;
+            ~GoalsOff() {
+                b.d_goals = nullptr;
+                b.n_goals = 0;
+            }
+        } goals_off{sb};
         trace_mark("sssp_run: attach + allocs");
         t_timing.lap(T_UPLOAD);
         for (uint32_t s0 = 0; s0 < n_starts; s0 += sb.S) {
             const uint32_t ns = std::min<uint32_t>(sb.S, n_starts - s0);
             const uint64_t nsN = (uint64_t)ns * N;
             if ((rc = sb.run(starts + s0, ns, poison))) return rc;
-            hipLaunchKernelGGL(sssp_unpack_flagged_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, sb.d_dp.p, nsN, d_dist.p, d_parent.p);
+            hipLaunchKernelGGL(sssp_unpack_flagged_kernel, dim3(grid_for(nsN)), dim3(kT), 0, s, sb.d_dp.p, nsN, d_dist.p, d_parent.p,
+                               sb.settled_bits);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "sssp launch: %s", hipGetErrorString(e));
             trace_mark("sssp_run: unpack");
@@ -2429,6 +2573,13 @@ extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t 
         CZ_HIP(hipMemcpy(&bad, d_flags.p + 2, 4, hipMemcpyDeviceToHost));
         CZ_HIP(hipMemcpy(updown, d_updown.p, 16, hipMemcpyDeviceToHost));
         symmetric = bad == 0 && updown[0] == updown[1];
+        CZ_HIP(hipMemsetAsync(d_flags.p, 0, 16, s));
+    }
+    if ((flags & CZ_ADJ_SYMMETRIC) != 0 && E) {  // vouched for: the range of the targets is still checked
+        hipLaunchKernelGGL(targets_in_range_kernel, dim3(grid_for(E)), dim3(kT), 0, s, d_tgt.p, E, N, d_flags.p + 2);
+        uint32_t oor = 0;
+        CZ_HIP(hipMemcpy(&oor, d_flags.p + 2, 4, hipMemcpyDeviceToHost));
+        if (oor) return cz::set_error(CZ_E_INVALID, "a target is out of range");
         CZ_HIP(hipMemsetAsync(d_flags.p, 0, 16, s));
     }
     const uint32_t *c_ioff = nullptr, *c_isrc = nullptr;  // (null: one side)

@@ -44,6 +44,29 @@ inline int grid_for(uint64_t n, int per_block = kT) {
     return (int)std::max<uint64_t>(1, std::min<uint64_t>((n + per_block - 1) / per_block, 256 * 32));
 }
 
+// what the level schedule relies on: every in-list ascends (strictly or with repeats: parallel edges are kept) and every source is a
+// node.  bad[0] counts lists out of order, bad[1] sources out of range (an unsorted list gave wrong levels -- a sweep
+// then read a contribution of the same or a later level, a race; an id out of range was read out of bounds)
+__global__ void __launch_bounds__(kT) validate_in_lists_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ src, uint32_t N,
+                                                               uint64_t E, uint32_t *__restrict__ bad) {
+    for (uint64_t e = (uint64_t)blockIdx.x * kT + threadIdx.x; e < E; e += (uint64_t)gridDim.x * kT) {
+        const uint32_t v = src[e];
+        if (v >= N) atomicAdd(&bad[1], 1u);
+    }
+    for (uint64_t u = (uint64_t)blockIdx.x * kT + threadIdx.x; u < N; u += (uint64_t)gridDim.x * kT) {
+        const uint32_t a = off[u], z = off[u + 1];
+        if (z < a || z > E) {
+            atomicAdd(&bad[0], 1u);
+            continue;
+        }
+        for (uint32_t e = a + 1; e < z; e++)
+            if (src[e] < src[e - 1]) {
+                atomicAdd(&bad[0], 1u);
+                break;
+            }
+    }
+}
+
 // level(u) = 1 + max level(v) over in-neighbours v < u: relaxed until nothing moves (levels only grow; reading a value another
 // workgroup has just raised only gets there sooner).  A 16-lane group per node; the in-list ascends, so the lanes stop at u.
 __global__ void __launch_bounds__(kT) level_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ src, uint32_t N,
@@ -198,11 +221,26 @@ extern "C" int cz_pagerank_inplace(const uint32_t *in_offsets, const uint32_t *i
     CZ_HIP(hipMemcpy(d_off.p, in_offsets, ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
     if (E) CZ_HIP(hipMemcpy(d_src.p, in_sources, E * 4, hipMemcpyHostToDevice));
     CZ_HIP(hipMemcpy(d_od.p, out_degree, (size_t)N * 4, hipMemcpyHostToDevice));
-    // ---- levels
+    {   // the lists as_directed_graph builds are sorted (CsrLayout::Sorted); anything else is refused, not mis-scheduled
+        cz::DevBuf<uint32_t> d_bad;
+        CZ_HIP(d_bad.alloc(2));
+        CZ_HIP(hipMemset(d_bad.p, 0, 8));
+        hipLaunchKernelGGL(validate_in_lists_kernel, dim3(grid_for(std::max<uint64_t>(E, N))), dim3(kT), 0, nullptr, d_off.p, d_src.p, N, E, d_bad.p);
+        uint32_t bad[2] = {0, 0};
+        CZ_HIP(hipMemcpy(bad, d_bad.p, 8, hipMemcpyDeviceToHost));
+        if (bad[1]) return cz::set_error(CZ_E_INVALID, "%u in_sources are not node ids (>= N = %u)", bad[1], N);
+        if (bad[0]) return cz::set_error(CZ_E_INVALID, "%u in-lists are not in ascending order (the level schedule needs CsrLayout::Sorted rows)", bad[0]);
+    }
+    // ---- levels.  A chain-like graph has about N of them: every level is a launch per sweep and a round trip of the relaxation,
+    // so beyond kMaxLevels the call is refused (CZ_PR_INPLACE_MAX_LEVELS overrides) rather than left to issue millions of launches
+    const char *ml_env = getenv("CZ_PR_INPLACE_MAX_LEVELS");
+    const uint32_t max_levels = ml_env && atoi(ml_env) > 0 ? (uint32_t)atoi(ml_env) : 4096u;
     CZ_HIP(hipMemset(d_level.p, 0, (size_t)N * 4));
     for (uint32_t round = 0;; round++) {
         if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
-        if (round > N) return cz::set_error(CZ_E_HIP, "level relaxation did not converge");
+        if (round > max_levels)
+            return cz::set_error(CZ_E_UNSUPPORTED, "the graph has more than %u dependence levels (a chain-like graph): the level-scheduled sweep "
+                                                   "would be one launch per level; use cz_pagerank or the CPU path", max_levels);
         CZ_HIP(hipMemsetAsync(d_changed.p, 0, 4, nullptr));
         hipLaunchKernelGGL(level_relax_kernel, dim3(grid_for((uint64_t)N * 16)), dim3(kT), 0, nullptr, d_off.p, d_src.p, N, d_level.p,
                            d_changed.p);
@@ -215,6 +253,9 @@ extern "C" int cz_pagerank_inplace(const uint32_t *in_offsets, const uint32_t *i
     // ---- level-major layout (host: a counting sort by level, ids ascending inside a level) and the blocks of every level
     uint32_t L = 0;
     for (uint32_t u = 0; u < N; u++) L = std::max(L, level[u] + 1);
+    if (L > max_levels)
+        return cz::set_error(CZ_E_UNSUPPORTED, "the graph has %u dependence levels (more than %u: a chain-like graph): the level-scheduled "
+                                               "sweep would be one launch per level; use cz_pagerank or the CPU path", L, max_levels);
     std::vector<uint32_t> first(L + 1, 0);
     for (uint32_t u = 0; u < N; u++) first[level[u] + 1]++;
     for (uint32_t l = 0; l < L; l++) first[l + 1] += first[l];

@@ -533,7 +533,7 @@ class ShortestPathBFS(FixedRule):
 
 
 class Bfs(FixedRule):
-    """algos/bfs.rs:25-113 -> cz_bfs(share_visited = 1).  `condition` is a predicate over the node tuple (the
+    """algos/bfs.rs:25-113 -> cz_bfs_shared.  `condition` is a predicate over the node tuple (the
     reference compiles an Expr to bytecode and evaluates it on the tuple bound from `nodes`)."""
 
     def arity(self, options, rule_head) -> int:
@@ -554,13 +554,13 @@ class Bfs(FixedRule):
             return
         graph, indices, inv = edges.as_ordered_graph(start_vals)
         starts = np.array([inv[_canon(s)] for s in start_vals], dtype=np.uint32)
-        parent, _, order, reached = _graph.bfs(graph.out_offsets, graph.out_targets, starts, share_visited=True,
-                                               want_order=True, poison=poison.flag)
+        # one backtrace and one discovery sequence for all starts: the default is EVERY node as a start (bfs.rs:33)
+        parent, order, first = _graph.bfs_shared(graph.out_offsets, graph.out_targets, starts, poison=poison.flag)
         found: List[Tuple[int, int, int]] = []
         done = False
         for si in range(len(start_vals)):
-            for j in range(int(reached[si])):
-                to = int(order[si, j])
+            for j in range(int(first[si]), int(first[si + 1])):
+                to = int(order[j])
                 to_val = indices[to]
                 if skip_query_nodes:
                     cand_tuple = (to_val,)
@@ -568,7 +568,7 @@ class Bfs(FixedRule):
                     cand_tuple = next(nodes.prefix_iter(to_val), None)
                     if cand_tuple is None:
                         # sic: the reference reports the *candidate* (the discoverer) as missing (bfs.rs:74-77)
-                        raise NodeNotFoundError(indices[int(parent[si, to])])
+                        raise NodeNotFoundError(indices[int(parent[to])])
                 if condition(cand_tuple):
                     found.append((si, int(starts[si]), to))
                     if len(found) >= limit:
@@ -578,12 +578,8 @@ class Bfs(FixedRule):
             if done:
                 break
         # the backtrace is shared across starts (bfs.rs:44); every node has exactly one discoverer
-        merged = np.full(graph.n, _lib.CZ_NONE, dtype=np.uint32)
-        for si in range(len(start_vals)):
-            m = parent[si] != _lib.CZ_NONE
-            merged[m] = parent[si][m]
         for si, s, e in found:
-            out.put((indices[s], indices[e], [indices[i] for i in _path(merged, s, e)]))
+            out.put((indices[s], indices[e], [indices[i] for i in _path(parent, s, e)]))
 
 
 class ConnectedComponents(FixedRule):
@@ -665,7 +661,9 @@ class ShortestPathDijkstra(FixedRule):
         if keep_ties and graph.out_weights.size and not (graph.out_weights > 0).all():
             raise FixedRuleError("keep_ties on the GPU path needs positive edge weights")
         starts = np.array(starting_nodes, dtype=np.uint32)
-        dist, parent = _graph.sssp(graph.out_offsets, graph.out_targets, graph.out_weights, starts, poison=poison.flag)
+        # with a termination relation the search stops once every target is settled, like dijkstra()'s goal set (:300-306)
+        goals = None if termination_nodes is None else np.array(termination_nodes, dtype=np.uint32)
+        dist, parent = _graph.sssp(graph.out_offsets, graph.out_targets, graph.out_weights, starts, poison=poison.flag, goals=goals)
         if keep_ties:
             off = np.asarray(graph.out_offsets, dtype=np.int64)
             src_of = np.repeat(np.arange(graph.n, dtype=np.int64), np.diff(off))

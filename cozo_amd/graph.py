@@ -192,6 +192,20 @@ class DeviceGraph:
             pass
 
 
+def bfs_shared(out_off, out_tgt, starts, poison=None):
+    """cz_bfs_shared: Bfs::run's traversal (`visited` / `backtrace` shared by the starts) with O(N) outputs:
+    (parent [N], order [N], first [n_starts + 1]) -- start i discovered order[first[i]:first[i + 1]]."""
+    out_off, out_tgt = _csr32(out_off, out_tgt)
+    N = out_off.size - 1
+    starts = _u32(starts)
+    parent = np.empty(N, dtype=np.uint32)
+    order = np.empty(N, dtype=np.uint32)
+    first = np.zeros(starts.size + 1, dtype=np.uint32)
+    check(_lib.lib().cz_bfs_shared(ptr(out_off), ptr(out_tgt), N, out_tgt.size, ptr(starts), starts.size, ptr(parent), ptr(order),
+                                   ptr(first), ptr(poison)))
+    return parent, order, first
+
+
 def bfs(out_off, out_tgt, starts, goals=None, share_visited=False, want_depth=False, want_order=False, poison=None, out=None):
     """cz_bfs; `out_off` may be a DeviceGraph (then `out_tgt` is ignored): cz_bfs_on.
     out: a dict of result arrays of an earlier call with the same shapes ({"parent", "depth", "order"}) to write into again --
@@ -254,9 +268,12 @@ def clustering_coefficients(off, tgt, poison=None, symmetric=False):
     return tri, deg
 
 
-def sssp(out_off, out_tgt, weights, starts, poison=None, out=None):
+def sssp(out_off, out_tgt, weights, starts, poison=None, out=None, goals=None):
     """cz_sssp; `out_off` may be a DeviceGraph uploaded with weights (then out_tgt / weights are ignored): cz_sssp_on.
-    out: a dict holding the ("dist", "parent") arrays of an earlier call with the same shapes, to be written into again (like bfs)"""
+    out: a dict holding the ("dist", "parent") arrays of an earlier call with the same shapes, to be written into again (like bfs)
+    goals: stop once every goal of every start is settled (cz_sssp_goals: dijkstra's early exit); nodes not settled by then read
+    unreached"""
+    g = _u32(goals) if goals is not None else None
     if isinstance(out_off, DeviceGraph):
         starts = _u32(starts)
         shape = (starts.size, out_off.n)
@@ -264,7 +281,10 @@ def sssp(out_off, out_tgt, weights, starts, poison=None, out=None):
         parent = out.get("parent") if out is not None and getattr(out.get("parent"), "shape", None) == shape else np.empty(shape, dtype=np.uint32)
         if out is not None:
             out["dist"], out["parent"] = dist, parent
-        check(_lib.lib().cz_sssp_on(out_off._h, ptr(starts), starts.size, ptr(dist), ptr(parent), ptr(poison)))
+        if g is not None:
+            check(_lib.lib().cz_sssp_goals_on(out_off._h, ptr(starts), starts.size, ptr(g), g.size, ptr(dist), ptr(parent), ptr(poison)))
+        else:
+            check(_lib.lib().cz_sssp_on(out_off._h, ptr(starts), starts.size, ptr(dist), ptr(parent), ptr(poison)))
         return dist, parent
     out_off, out_tgt = _csr32(out_off, out_tgt)
     w = np.ascontiguousarray(weights, dtype=np.float32)
@@ -272,8 +292,12 @@ def sssp(out_off, out_tgt, weights, starts, poison=None, out=None):
     starts = _u32(starts)
     dist = np.empty((starts.size, N), dtype=np.float32)
     parent = np.empty((starts.size, N), dtype=np.uint32)
-    check(_lib.lib().cz_sssp(ptr(out_off), ptr(out_tgt), ptr(w), N, out_tgt.size, ptr(starts), starts.size, ptr(dist),
-                             ptr(parent), ptr(poison)))
+    if g is not None:
+        check(_lib.lib().cz_sssp_goals(ptr(out_off), ptr(out_tgt), ptr(w), N, out_tgt.size, ptr(starts), starts.size, ptr(g), g.size,
+                                       ptr(dist), ptr(parent), ptr(poison)))
+    else:
+        check(_lib.lib().cz_sssp(ptr(out_off), ptr(out_tgt), ptr(w), N, out_tgt.size, ptr(starts), starts.size, ptr(dist),
+                                 ptr(parent), ptr(poison)))
     return dist, parent
 
 

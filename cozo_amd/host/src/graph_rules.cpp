@@ -118,17 +118,19 @@ void Bfs::run(const FixedRulePayload &payload, RegularTempStore &out, const Pois
     std::vector<uint32_t> starts;
     for (const DataValue &s : start_vals) starts.push_back(g.inv_indices.at(s));
     const size_t ns = starts.size();
-    std::vector<uint32_t> parent(ns * gr.n), order(ns * gr.n), reached(ns);
-    check_gpu(cz_bfs(gr.out_offsets.data(), gr.out_targets.data(), gr.n, gr.edge_count(), starts.data(), (uint32_t)ns, nullptr, 0,
-                     /*share_visited=*/1, parent.data(), nullptr, order.data(), reached.data(), poison.flag_ptr()));
+    // one backtrace and one discovery sequence for all starts (cz_bfs_shared): the default is EVERY node as a start (:33), for which
+    // a row of N per start would be O(N^2)
+    std::vector<uint32_t> parent(gr.n), order(gr.n), first(ns + 1);
+    check_gpu(cz_bfs_shared(gr.out_offsets.data(), gr.out_targets.data(), gr.n, gr.edge_count(), starts.data(), (uint32_t)ns, parent.data(),
+                            order.data(), first.data(), poison.flag_ptr()));
     struct Found {
         uint32_t start, end;
     };
     std::vector<Found> found;
     bool done = false;
     for (size_t si = 0; si < ns && !done; si++) {
-        for (uint32_t j = 0; j < reached[si]; j++) {
-            const uint32_t to = order[si * gr.n + j];
+        for (uint32_t j = first[si]; j < first[si + 1]; j++) {
+            const uint32_t to = order[j];
             const DataValue &to_val = g.indices[to];
             Tuple cand_tuple;
             if (skip_query_nodes) {
@@ -136,7 +138,7 @@ void Bfs::run(const FixedRulePayload &payload, RegularTempStore &out, const Pois
             } else {
                 auto range = nodes.prefix_iter(to_val);
                 if (range.first == range.second)  // sic: the reference reports the *discoverer* as missing (:74-77)
-                    throw NodeNotFoundError(g.indices[parent[si * gr.n + to]]);
+                    throw NodeNotFoundError(g.indices[parent[to]]);
                 cand_tuple = *range.first;
             }
             if (condition.eval(cand_tuple)) {
@@ -150,12 +152,8 @@ void Bfs::run(const FixedRulePayload &payload, RegularTempStore &out, const Pois
         }
     }
     // the backtrace is shared across starts (:44); every node has exactly one discoverer
-    std::vector<uint32_t> merged(gr.n, CZ_NONE);
-    for (size_t si = 0; si < ns; si++)
-        for (uint32_t v = 0; v < gr.n; v++)
-            if (parent[si * gr.n + v] != CZ_NONE) merged[v] = parent[si * gr.n + v];
     for (const Found &f : found)
-        out.put(Tuple{g.indices[f.start], g.indices[f.end], path_value(walk_back(merged.data(), f.start, f.end), g.indices)});
+        out.put(Tuple{g.indices[f.start], g.indices[f.end], path_value(walk_back(parent.data(), f.start, f.end), g.indices)});
 }
 
 // ---- ConnectedComponents / SCC --------------------------------------------------------------------------------
@@ -231,8 +229,10 @@ void ShortestPathDijkstra::run(const FixedRulePayload &payload, RegularTempStore
     const size_t ns = starting_nodes.size();
     std::vector<float> dist(ns * gr.n);
     std::vector<uint32_t> parent(ns * gr.n);
-    check_gpu(cz_sssp(gr.out_offsets.data(), gr.out_targets.data(), gr.out_weights.data(), gr.n, gr.edge_count(),
-                      starting_nodes.data(), (uint32_t)ns, dist.data(), parent.data(), poison.flag_ptr()));
+    // with a termination relation the search stops once every target is settled, like dijkstra()'s goal set (:300-306)
+    check_gpu(cz_sssp_goals(gr.out_offsets.data(), gr.out_targets.data(), gr.out_weights.data(), gr.n, gr.edge_count(),
+                            starting_nodes.data(), (uint32_t)ns, termination ? termination_nodes.data() : nullptr,
+                            termination ? (uint32_t)termination_nodes.size() : 0u, dist.data(), parent.data(), poison.flag_ptr()));
     for (size_t si = 0; si < ns && ties; si++) {
         // dijkstra_keep_ties (:341-450): back_pointers[v] = every edge (u, v) with dist[u] + w == dist[v] in f32 -- read off the
         // device's bit-exact distances -- and EVERY path through them is a row; the start as its own target collects nothing

@@ -457,6 +457,15 @@ int cz_connected_components_multi(const uint32_t *offsets, const uint32_t *targe
 int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E, const uint32_t *starts,
            uint32_t n_starts, const uint32_t *goals, uint32_t n_goals, int share_visited, uint32_t *parent,
            uint32_t *depth, uint32_t *order, uint32_t *n_reached, const volatile uint8_t *poison);
+/* Bfs::run's traversal (algos/bfs.rs:43-98: `visited` and `backtrace` shared by all starting nodes) with outputs of O(N) whatever
+ * the number of starts -- the rule's default is EVERY node of the `nodes` relation (bfs.rs:33), for which cz_bfs's row of N per
+ * start is O(N^2) memory and time:
+ *   parent [N]: the one backtrace (every node has one discoverer; CZ_NONE: a start or unreached);
+ *   order [N]: the discovery sequences of the starts one after the other; first [n_starts + 1]: start i discovered
+ *   order[first[i] .. first[i + 1]) (nothing when an earlier start had reached it: bfs.rs:52-54).
+ * A skipped start costs no device work, a traversal resets only what it touched: O(N + E) in all. */
+int cz_bfs_shared(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E, const uint32_t *starts,
+                  uint32_t n_starts, uint32_t *parent, uint32_t *order, uint32_t *first, const volatile uint8_t *poison);
 
 /* StronglyConnectedComponent{strong:false}::run = ConnectedComponents
  * (algos/strongly_connected_components.rs:42-77): adjacency of the symmetrised graph
@@ -486,6 +495,14 @@ int cz_clustering_coefficients(const uint32_t *offsets, const uint32_t *targets,
  *   start / unreachable.  (The reference's choice among equal-cost predecessors is its heap's pop order.) */
 int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
             const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent, const volatile uint8_t *poison);
+/* dijkstra's early exit (shortest_path_dijkstra.rs:300-306: the search stops once its goal set is exhausted): the same traversal,
+ * stopped as soon as every goal of every start is SETTLED (its cost lies below everything still waiting in the piles; checked once
+ * per bucket).  dist / parent of the goals and of every node on their shortest paths are cz_sssp's; a node the search had not
+ * settled by then is reported unreached (inf / CZ_NONE) -- its tentative cost is never exposed.  An unreachable goal makes the
+ * call a full cz_sssp, like the reference.  n_goals == 0: cz_sssp. */
+int cz_sssp_goals(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
+                  const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals, float *dist,
+                  uint32_t *parent, const volatile uint8_t *poison);
 
 /* A relation's CSR resident on the device.  FixedRule::run (fixed_rule/mod.rs:538-567) is handed the relation anew on every
  * call; on a 10M-node / 100M-edge graph the upload is 8-15 ms of a 20-32 ms call.  cz_graph_upload keeps the arrays of one
@@ -507,6 +524,8 @@ int cz_bfs_on(const cz_graph *g, const uint32_t *starts, uint32_t n_starts, cons
 int cz_connected_components_on(const cz_graph *g, uint32_t *group, uint32_t *n_groups, const volatile uint8_t *poison);
 int cz_sssp_on(const cz_graph *g, const uint32_t *starts, uint32_t n_starts, float *dist, uint32_t *parent,
                const volatile uint8_t *poison);
+int cz_sssp_goals_on(const cz_graph *g, const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals, float *dist,
+                     uint32_t *parent, const volatile uint8_t *poison);
 
 /* Where the last cz_bfs / cz_connected_components / cz_sssp / cz_clustering_coefficients / cz_closeness /
  * cz_betweenness / cz_label_propagation call of THIS

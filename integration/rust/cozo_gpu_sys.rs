@@ -230,6 +230,8 @@ extern "C" {
     pub fn cz_bfs(out_offsets: *const u32, out_targets: *const u32, n: u32, e: u64, starts: *const u32, n_starts: u32,
                   goals: *const u32, n_goals: u32, share_visited: c_int, parent: *mut u32, depth: *mut u32, order: *mut u32,
                   n_reached: *mut u32, poison: *const u8) -> c_int;
+    pub fn cz_bfs_shared(out_offsets: *const u32, out_targets: *const u32, n: u32, e: u64, starts: *const u32, n_starts: u32,
+                         parent: *mut u32, order: *mut u32, first: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_connected_components(offsets: *const u32, targets: *const u32, n: u32, e: u64, group: *mut u32,
                                    n_groups: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_clustering_coefficients(offsets: *const u32, targets: *const u32, n: u32, e: u64, n_triangles: *mut u64,
@@ -245,6 +247,10 @@ extern "C" {
     pub fn cz_bfs_on(g: *const cz_graph, starts: *const u32, n_starts: u32, goals: *const u32, n_goals: u32, share_visited: c_int,
                      parent: *mut u32, depth: *mut u32, order: *mut u32, n_reached: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_connected_components_on(g: *const cz_graph, group: *mut u32, n_groups: *mut u32, poison: *const u8) -> c_int;
+    pub fn cz_sssp_goals(out_offsets: *const u32, out_targets: *const u32, weights: *const c_float, n: u32, e: u64, starts: *const u32,
+                         n_starts: u32, goals: *const u32, n_goals: u32, dist: *mut c_float, parent: *mut u32, poison: *const u8) -> c_int;
+    pub fn cz_sssp_goals_on(g: *const cz_graph, starts: *const u32, n_starts: u32, goals: *const u32, n_goals: u32, dist: *mut c_float,
+                            parent: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_sssp_on(g: *const cz_graph, starts: *const u32, n_starts: u32, dist: *mut c_float, parent: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_label_propagation(out_offsets: *const u32, out_targets: *const u32, weights: *const c_float, n: u32, e: u64,
                                 max_iter: u32, labels: *mut u32, iters_run: *mut u32, n_colours: *mut u32, poison: *const u8, flags: u32) -> c_int;

@@ -376,7 +376,7 @@ impl FixedRule for LabelPropagationGpu {
 /// a graph the library keeps between calls under the stored relation's identity: the route
 /// reconstruction and row emission of :70-153 stay as they are in the rule.
 pub(crate) fn sssp_on_held_graph(edges: &FixedRuleInputRelation<'_, '_>, undirected: bool, g: &GpuWeightedGraph, starts: &[u32],
-                                 poison: &Poison) -> Result<(Vec<f32>, Vec<u32>)> {
+                                 goals: Option<&[u32]>, poison: &Poison) -> Result<(Vec<f32>, Vec<u32>)> {
     let (hi, lo) = edges.stored_identity()?.map_or((0, 0), |(rel_id, version)| (rel_id, (version << 2) | 2 | undirected as u64));
     let mut held: *mut cz_graph = std::ptr::null_mut();
     let mut hit: c_int = 0;
@@ -385,7 +385,14 @@ pub(crate) fn sssp_on_held_graph(edges: &FixedRuleInputRelation<'_, '_>, undirec
     }, poison)?;
     let mut dist = vec![0f32; starts.len() * g.n as usize];
     let mut parent = vec![0u32; starts.len() * g.n as usize];
-    let rc = unsafe { cz_sssp_on(held, starts.as_ptr(), starts.len() as u32, dist.as_mut_ptr(), parent.as_mut_ptr(), poison_ptr(poison)) };
+    // a goal set (the rule's termination relation): the search stops once every goal is settled, as dijkstra() does (:300-306)
+    let rc = match goals {
+        Some(gs) => unsafe {
+            cz_sssp_goals_on(held, starts.as_ptr(), starts.len() as u32, gs.as_ptr(), gs.len() as u32, dist.as_mut_ptr(), parent.as_mut_ptr(),
+                             poison_ptr(poison))
+        },
+        None => unsafe { cz_sssp_on(held, starts.as_ptr(), starts.len() as u32, dist.as_mut_ptr(), parent.as_mut_ptr(), poison_ptr(poison)) },
+    };
     unsafe { cz_graph_release(hi, lo, held) }; // back into the cache, whatever the rule's outcome
     check(rc, poison)?;
     Ok((dist, parent))
@@ -511,23 +518,29 @@ impl FixedRule for ShortestPathBFSGpu {
         let starts: Vec<u32> = starting_nodes.iter().map(|s| g.inv_indices[s]).collect();
         let goals: Vec<u32> = ending_nodes.iter().map(|e| g.inv_indices[e]).collect();
         let n = g.n as usize;
-        let mut parent = vec![CZ_NONE; starts.len() * n];
-        check(unsafe {
-            cz_bfs(g.offsets.as_ptr(), g.targets.as_ptr(), g.n, g.targets.len() as u64, starts.as_ptr(), starts.len() as u32,
-                   goals.as_ptr(), goals.len() as u32, 0, parent.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut(),
-                   std::ptr::null_mut(), poison_ptr(&poison))
-        }, &poison)?;
-        for (si, starting_node) in starting_nodes.iter().enumerate() {
-            let par = &parent[si * n..(si + 1) * n];
-            for (ending_node, goal) in ending_nodes.iter().zip(goals.iter()) {
-                // `backtrace.contains_key(ending_node)` (:86): a goal equal to the start was never discovered -> Null
-                if par[*goal as usize] != CZ_NONE {
-                    out.put(vec![starting_node.clone(), ending_node.clone(), walk_back(par, starts[si], *goal, &g.indices)?]);
-                } else {
-                    out.put(vec![starting_node.clone(), ending_node.clone(), DataValue::Null]);
+        // the backtraces are a row of N per start: the starts go to the library in batches of at most 64 M words (256 MB) and
+        // their rows are written out before the next batch -- the rule's memory does not grow with starts x N
+        let per_call = std::cmp::max(1, std::cmp::min(starts.len(), (64usize << 20) / std::cmp::max(n, 1)));
+        let mut parent = vec![CZ_NONE; per_call * n];
+        for (chunk_idx, chunk) in starts.chunks(per_call).enumerate() {
+            check(unsafe {
+                cz_bfs(g.offsets.as_ptr(), g.targets.as_ptr(), g.n, g.targets.len() as u64, chunk.as_ptr(), chunk.len() as u32,
+                       goals.as_ptr(), goals.len() as u32, 0, parent.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut(),
+                       std::ptr::null_mut(), poison_ptr(&poison))
+            }, &poison)?;
+            for (ci, start) in chunk.iter().enumerate() {
+                let starting_node = &starting_nodes[chunk_idx * per_call + ci];
+                let par = &parent[ci * n..(ci + 1) * n];
+                for (ending_node, goal) in ending_nodes.iter().zip(goals.iter()) {
+                    // `backtrace.contains_key(ending_node)` (:86): a goal equal to the start was never discovered -> Null
+                    if par[*goal as usize] != CZ_NONE {
+                        out.put(vec![starting_node.clone(), ending_node.clone(), walk_back(par, *start, *goal, &g.indices)?]);
+                    } else {
+                        out.put(vec![starting_node.clone(), ending_node.clone(), DataValue::Null]);
+                    }
                 }
+                poison.check()?;
             }
-            poison.check()?;
         }
         Ok(())
     }
@@ -537,8 +550,8 @@ impl FixedRule for ShortestPathBFSGpu {
 }
 
 /// fixed_rule/algos/bfs.rs:25-113 on the device.  The traversal -- `visited` and `backtrace` shared by all starting nodes
-/// (:43-45), a starting node already visited skipped (:52-54) -- is one cz_bfs call with share_visited = 1 that returns the
-/// discovery sequence per start (`order`); `condition` and `limit` are then evaluated on the host over that sequence, in
+/// (:43-45), a starting node already visited skipped (:52-54) -- is one cz_bfs_shared call that returns the discovery
+/// sequences of the starts one after the other (`order`, `first`); `condition` and `limit` are then evaluated on the host over that sequence, in
 /// order, which is where the reference evaluates them (:66-90): the rows are the ones the reference finds, only the traversal
 /// past the limit-th hit is wasted work.
 pub(crate) struct BfsGpu;
@@ -566,24 +579,26 @@ impl FixedRule for BfsGpu {
         let g = edges.as_gpu_ordered_graph(&start_vals)?;
         let starts: Vec<u32> = start_vals.iter().map(|s| g.inv_indices[s]).collect();
         let (n, ns) = (g.n as usize, starts.len());
-        let mut parent = vec![CZ_NONE; ns * n];
-        let mut order = vec![CZ_NONE; ns * n];
-        let mut reached = vec![0u32; ns];
+        // ONE backtrace and ONE discovery sequence for all starts (cz_bfs_shared): the default is every node of `nodes` as a start
+        // (:33), and every node is discovered at most once over all of them -- O(N) memory, not a row of N per start
+        let mut parent = vec![CZ_NONE; n];
+        let mut order = vec![CZ_NONE; n];
+        let mut first = vec![0u32; ns + 1];
         check(unsafe {
-            cz_bfs(g.offsets.as_ptr(), g.targets.as_ptr(), g.n, g.targets.len() as u64, starts.as_ptr(), ns as u32, std::ptr::null(), 0,
-                   1, parent.as_mut_ptr(), std::ptr::null_mut(), order.as_mut_ptr(), reached.as_mut_ptr(), poison_ptr(&poison))
+            cz_bfs_shared(g.offsets.as_ptr(), g.targets.as_ptr(), g.n, g.targets.len() as u64, starts.as_ptr(), ns as u32,
+                          parent.as_mut_ptr(), order.as_mut_ptr(), first.as_mut_ptr(), poison_ptr(&poison))
         }, &poison)?;
         let mut found: Vec<(u32, u32)> = vec![];
         let mut stack = vec![];
         'outer: for si in 0..ns {
-            for j in 0..reached[si] as usize {
-                let to = order[si * n + j];
+            for j in first[si] as usize..first[si + 1] as usize {
+                let to = order[j];
                 let to_node = &g.indices[to as usize];
                 let cand_tuple = if skip_query_nodes {
                     vec![to_node.clone()]
                 } else {
                     // sic: the reference names the DISCOVERER as the missing key (:74-77)
-                    let candidate = g.indices[parent[si * n + to as usize] as usize].clone();
+                    let candidate = g.indices[parent[to as usize] as usize].clone();
                     nodes.prefix_iter(to_node)?.next().ok_or_else(|| NodeNotFoundError { missing: candidate, span: nodes.span() })??
                 };
                 if eval_bytecode_pred(&condition_bytecode, &cand_tuple, &mut stack, condition_span)? {
@@ -596,16 +611,8 @@ impl FixedRule for BfsGpu {
             }
         }
         // one backtrace for all starts (:44): every node has exactly one discoverer
-        let mut merged = vec![CZ_NONE; n];
-        for si in 0..ns {
-            for v in 0..n {
-                if parent[si * n + v] != CZ_NONE {
-                    merged[v] = parent[si * n + v];
-                }
-            }
-        }
         for (starting, ending) in found {
-            out.put(vec![g.indices[starting as usize].clone(), g.indices[ending as usize].clone(), walk_back(&merged, starting, ending, &g.indices)?]);
+            out.put(vec![g.indices[starting as usize].clone(), g.indices[ending as usize].clone(), walk_back(&parent, starting, ending, &g.indices)?]);
         }
         Ok(())
     }
@@ -660,7 +667,8 @@ impl FixedRule for ShortestPathDijkstraGpu {
         }
         let starts: Vec<u32> = starting_nodes.into_iter().collect();
         let n = g.n as usize;
-        let (dist, parent) = sssp_on_held_graph(&edges, undirected, &g, &starts, &poison)?;
+        let goal_ids: Option<Vec<u32>> = term_ids.as_ref().map(|tn| tn.iter().copied().collect());
+        let (dist, parent) = sssp_on_held_graph(&edges, undirected, &g, &starts, goal_ids.as_deref(), &poison)?;
         for (si, start) in starts.iter().enumerate() {
             let d = &dist[si * n..(si + 1) * n];
             let par = &parent[si * n..(si + 1) * n];

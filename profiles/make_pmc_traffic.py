@@ -25,7 +25,9 @@ import bench  # noqa: E402
 SPEC = {
     "hnsw_knn": dict(tag="hnsw", regex=r"hnsw_knn_kernel", mode="last", n=3, algo=None),
     "distance_batch": dict(tag="hnsw", regex=r"distance_pairs_kernel", mode="last", n=3, algo=(1 << 22) * 4 * 768),
-    "pagerank_blocked": dict(tag="pr", regex=r"pb_expand_kernel|pb_reduce_kernel", mode="last", n=3, algo=None),
+    # (the plan chooses the formulation: an entry is written only when its phase-B kernel ran in the tagged pass)
+    "pagerank_blocked": dict(tag="pr", regex=r"pb_expand_kernel|pb_reduce_kernel", mode="last", n=3, algo=None, require=r"pb_reduce_kernel", forbid=r"pa_reduce_kernel"),
+    "pagerank_accumulate": dict(tag="pr", regex=r"pb_expand_kernel|pa_reduce_kernel|pb_reduce_kernel", mode="last", n=3, algo=None, require=r"pa_reduce_kernel"),
     "pagerank_blocked_rmat": dict(tag="prrmat", regex=r"pb_expand_kernel|pb_reduce_kernel|pr_hub_kernel|pr_empty_rows_kernel", mode="last", n=3, algo=None),
     "hnsw_knn_1m": dict(tag="hnsw1m", regex=r"hnsw_knn_kernel", mode="last", n=3, algo=None),
     "bfs": dict(tag="bfs", regex=r"bfs_|scan_tiles_kernel|scan_add_kernel", mode="per_run", runs=2, algo=None),
@@ -56,7 +58,7 @@ def main():
     try:  # algorithmic bytes of the workloads, from the bench line of the same round
         d = json.load(open(os.path.join(round_dir, "bench_detail.json")))
         algos["hnsw_knn"] = d["roofline"]["algorithmic_bytes_per_launch"]
-        algos["pagerank_blocked"] = d["pagerank"]["roofline"]["algorithmic_bytes_per_launch"]
+        algos["pagerank_blocked"] = algos["pagerank_accumulate"] = d["pagerank"]["roofline"]["algorithmic_bytes_per_launch"]
         algos["pagerank_blocked_rmat"] = d["pagerank_rmat"]["roofline"]["algorithmic_bytes_per_launch"]
         algos["hnsw_knn_1m"] = d["hnsw_1m"]["roofline"]["algorithmic_bytes_per_launch"]
         algos["bfs"] = d["graph_rules"]["bfs"]["algorithmic_bytes"]
@@ -85,7 +87,8 @@ def main():
             pk = load(round_dir, sp["tag"], counter)
             rx = re.compile(sp["regex"])
             hit = {k: v for k, v in pk.items() if rx.search(k)}
-            if not hit:
+            if not hit or (sp.get("require") and not any(re.search(sp["require"], k) for k in pk)) or \
+                    (sp.get("forbid") and any(re.search(sp["forbid"], k) for k in pk)):
                 ok = False
                 break
             for k, vals in sorted(hit.items()):

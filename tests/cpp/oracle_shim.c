@@ -85,6 +85,25 @@ int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N,
     return CZ_OK;
 }
 
+/* the reference's loop (algos/bfs.rs:43-98): one `visited` / `backtrace`, a start already reached is skipped */
+int cz_bfs_shared(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E, const uint32_t *starts,
+                  uint32_t n_starts, uint32_t *parent, uint32_t *order, uint32_t *first, const volatile uint8_t *poison) {
+    (void)E;
+    if (poisoned(poison)) { g_err = "cancelled"; return CZ_E_CANCELLED; }
+    uint64_t *off = widen(out_offsets, N);
+    uint8_t *visited = (uint8_t *)calloc(N ? N : 1, 1);
+    for (uint32_t v = 0; v < N; v++) parent[v] = CZ_NONE;
+    uint32_t at = 0;
+    first[0] = 0;
+    for (uint32_t s = 0; s < n_starts; s++) {
+        if (starts[s] < N && !visited[starts[s]]) at += orc_bfs_order(N, off, out_targets, starts[s], visited, parent, order + at);
+        first[s + 1] = at;
+    }
+    free(visited);
+    free(off);
+    return CZ_OK;
+}
+
 int cz_connected_components(const uint32_t *offsets, const uint32_t *targets, uint32_t N, uint64_t E, uint32_t *group,
                             uint32_t *n_groups, const volatile uint8_t *poison) {
     (void)E;
@@ -118,6 +137,14 @@ int cz_sssp(const uint32_t *out_offsets, const uint32_t *out_targets, const floa
         orc_dijkstra(N, off, out_targets, weights, starts[s], NULL, 0, dist + (size_t)s * N, parent + (size_t)s * N);
     free(off);
     return CZ_OK;
+}
+
+/* (the full run: a goal set only lets the device stop early; the rows the rule emits -- the goals' -- are the same) */
+int cz_sssp_goals(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,
+                  const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals, float *dist, uint32_t *parent,
+                  const volatile uint8_t *poison) {
+    (void)goals; (void)n_goals;
+    return cz_sssp(out_offsets, out_targets, weights, N, E, starts, n_starts, dist, parent, poison);
 }
 
 int cz_betweenness(const uint32_t *out_offsets, const uint32_t *out_targets, const float *weights, uint32_t N, uint64_t E,

@@ -231,6 +231,42 @@ def test_bfs_order_and_shared_visited(graphs, oracle):
     assert np.array_equal(order[0, :reached[0]], oorder) and np.array_equal(parent[0], opar)
 
 
+def test_bfs_shared_outputs_are_the_per_start_rows_merged(graphs, oracle, gpu_lib):
+    """cz_bfs_shared (what the Bfs rule calls: O(N) outputs whatever the number of starts) against the reference's
+    loop -- one `visited` / `backtrace` for all starts, starts already reached skipped -- with EVERY node as a start, the
+    rule's default (bfs.rs:33), in an order that makes later starts land in earlier territory; and against cz_bfs's
+    per-start rows.  Includes the stale-claim shape of the test below."""
+    from cozo_amd import graph as G
+    fan = 40
+    edges = [(0, 2), (1, 2)] + [(1, c) for c in range(3, 3 + fan)] + [(3 + fan - 1, 3 + fan)]
+    frm = np.array([e[0] for e in edges], dtype=np.uint32)
+    to = np.array([e[1] for e in edges], dtype=np.uint32)
+    fan_g = dict(n=3 + fan + 1)
+    fan_g["ooff"], fan_g["otgt"] = oracle.build_csr(fan_g["n"], frm, to)
+    for g in [graphs[0], graphs[1], fan_g]:
+        n = g["n"]
+        rng = np.random.default_rng(n)
+        starts = rng.permutation(n).astype(np.uint32)
+        if n > 500:
+            starts = np.concatenate([starts[:300], starts[:5], np.array([n + 7], dtype=np.uint32)])  # repeats and an id out of range
+        parent, order, first = G.bfs_shared(g["ooff"], g["otgt"], starts)
+        visited = np.zeros(n, np.uint8)
+        opar = np.full(n, 0xFFFFFFFF, np.uint32)
+        for si, s in enumerate(starts):
+            if s >= n or visited[s]:
+                assert first[si + 1] == first[si]
+                continue
+            oorder, opar, visited = oracle.bfs_order(n, g["ooff"], g["otgt"], int(s), visited, opar)
+            assert first[si + 1] - first[si] == len(oorder)
+            assert np.array_equal(order[first[si]:first[si + 1]], oorder)
+        assert np.array_equal(parent, opar)
+        ok = starts < n
+        p2, _, o2, r2 = G.bfs(g["ooff"], g["otgt"], starts[ok][:40], share_visited=True, want_order=True)
+        firsts = first[:-1][ok][:40]
+        for si in range(len(r2)):
+            assert np.array_equal(o2[si, :r2[si]], order[firsts[si]:firsts[si] + r2[si]])
+
+
 def test_bfs_shared_visited_stale_claims(oracle, gpu_lib):
     """with share_visited the claim words of an earlier start must not pass for this level's discoveries.
     s1 -> v gives v (claim 0, depth 1); s2 -> v as well, and s2 has > 24 fresh neighbours (the stretch is ordered by
@@ -416,6 +452,57 @@ def test_sssp_costs_bitexact(oracle, gpu_lib):
                     assert hops <= g["n"]
     with pytest.raises(Exception):
         G.sssp(np.array([0, 1, 1], np.uint32), np.array([1], np.uint32), np.array([-1.0], np.float32), [0])
+
+
+def test_sssp_goals_stop_early_with_the_full_runs_values(oracle, gpu_lib):
+    """cz_sssp_goals / cz_sssp_goals_on (dijkstra()'s goal set, shortest_path_dijkstra.rs:300-306): the costs and parents of the
+    goals -- and of every node reported reached -- are the full run's, nodes the search had not settled read unreached, near goals
+    leave most of a large graph unsettled, an unreachable goal makes the run a full one; also on a kept graph (the kept state must
+    not remember a call's goals)."""
+    from cozo_amd import graph as G
+    frm, to = util.random_relation(20000, 120000, 11)
+    w = (np.random.default_rng(11).random(len(frm)).astype(np.float32) + 0.01)
+    g = util.graph_from_relation(oracle, frm, to, weights=w)
+    n = g["n"]
+    starts = np.array([0, 17], dtype=np.uint32)
+    full_d, full_p = G.sssp(g["ooff"], g["otgt"], g["ow"], starts)
+    order = np.argsort(full_d[0])
+    near = order[1:6].astype(np.uint32)                       # the five nodes nearest to start 0
+    reach = np.flatnonzero(np.isfinite(full_d).all(axis=0))
+    for goals in (near, np.array([reach[len(reach) // 2]], dtype=np.uint32), np.array([], dtype=np.uint32)):
+        for held in (False, True):
+            if held:
+                with G.DeviceGraph(g["ooff"], g["otgt"], g["ow"]) as dg:
+                    d, p = G.sssp(dg, None, None, starts, goals=goals)
+                    d2, p2 = G.sssp(dg, None, None, starts)   # the next call on the kept state is a full run again
+                    assert np.array_equal(d2, full_d) and np.array_equal(p2, full_p)
+            else:
+                d, p = G.sssp(g["ooff"], g["otgt"], g["ow"], starts, goals=goals)
+            seen = np.isfinite(d)
+            assert np.array_equal(d[seen], full_d[seen]) and np.array_equal(p[seen], full_p[seen])
+            assert (p[~seen] == 0xFFFFFFFF).all()
+            if goals.size:
+                assert seen[:, goals].all() or not np.isfinite(full_d[:, goals]).all()
+                for si, s in enumerate(starts):               # the goals' paths are there
+                    for t in goals:
+                        if not np.isfinite(full_d[si, t]):
+                            continue
+                        cur = int(t)
+                        while cur != s:
+                            assert seen[si, cur]
+                            cur = int(p[si, cur])
+            else:
+                assert np.array_equal(d, full_d)
+    d, _ = G.sssp(g["ooff"], g["otgt"], g["ow"], starts[:1], goals=near)
+    assert np.isfinite(d).sum() < 0.5 * np.isfinite(full_d[0]).sum()   # near goals: most of the graph was never settled
+    lonely = np.array([n - 1], dtype=np.uint32)
+    frm2 = np.concatenate([frm, [10 ** 9]])                   # a node nothing leads to
+    to2 = np.concatenate([to, [10 ** 9 + 1]])
+    g2 = util.graph_from_relation(oracle, frm2, to2, weights=np.concatenate([w, [1.0]]).astype(np.float32))
+    fd, fp = G.sssp(g2["ooff"], g2["otgt"], g2["ow"], starts[:1])
+    unreachable = np.flatnonzero(~np.isfinite(fd[0]))[:1].astype(np.uint32)
+    d, p = G.sssp(g2["ooff"], g2["otgt"], g2["ow"], starts[:1], goals=unreachable)
+    assert np.array_equal(d, fd) and np.array_equal(p, fp)
 
 
 def test_entry_points_are_reentrant_across_host_threads(oracle, gpu_lib):
@@ -905,3 +992,48 @@ def test_random_access_probe_reports_rates():
         assert loads > 0 and atomics > 0
     with pytest.raises(Exception):
         G.random_access_probe(1 << 20, 2)
+
+
+def test_vouched_adjacency_and_inplace_inputs_are_still_checked(oracle, gpu_lib, monkeypatch):
+    """a caller that vouches for a symmetric adjacency (CZ_ADJ_SYMMETRIC) with a target out of range gets an
+    error, not an out-of-bounds read; cz_pagerank_inplace refuses in-lists that do not ascend, sources that are not nodes,
+    and graphs with more dependence levels than launches are worth."""
+    from cozo_amd import _lib, graph as G
+    n = 64
+    rng = np.random.default_rng(3)
+    frm = rng.integers(0, n, 400)
+    to = rng.integers(0, n, 400)
+    keep = frm != to
+    a = np.concatenate([frm[keep], to[keep]]).astype(np.uint32)
+    b = np.concatenate([to[keep], frm[keep]]).astype(np.uint32)
+    off, tgt = oracle.build_csr(n, a, b)
+    bad_tgt = tgt.copy()
+    bad_tgt[7] = n + 5
+    with pytest.raises(_lib.CozoGpuError, match="out of range"):
+        G.clustering_coefficients(off, bad_tgt, symmetric=True)
+    with pytest.raises(_lib.CozoGpuError, match="out of range"):
+        G.label_propagation(off, bad_tgt, np.ones(bad_tgt.size, np.float32), symmetric=True)
+    G.clustering_coefficients(off, tgt, symmetric=True)  # (the good adjacency still goes through)
+    # cz_pagerank_inplace
+    frm2, to2 = util.random_relation(200, 900, 5)
+    g = util.graph_from_relation(oracle, frm2, to2)
+    G.pagerank_inplace(g["ioff"], g["isrc"], g["outdeg"], max_iter=2)
+    src = g["isrc"].copy()
+    ioff = g["ioff"].astype(np.int64)
+    row = int(np.argmax(np.diff(ioff) >= 2))
+    src[ioff[row]], src[ioff[row] + 1] = src[ioff[row] + 1], src[ioff[row]]
+    with pytest.raises(_lib.CozoGpuError, match="ascending"):
+        G.pagerank_inplace(g["ioff"], src, g["outdeg"], max_iter=2)
+    src = g["isrc"].copy()
+    src[3] = g["n"] + 1
+    with pytest.raises(_lib.CozoGpuError, match="not node ids"):
+        G.pagerank_inplace(g["ioff"], src, g["outdeg"], max_iter=2)
+    chain = np.arange(60, dtype=np.int64)
+    gc = util.graph_from_relation(oracle, chain[:-1], chain[1:])
+    monkeypatch.setenv("CZ_PR_INPLACE_MAX_LEVELS", "8")
+    with pytest.raises(_lib.CozoGpuError, match="dependence levels"):
+        G.pagerank_inplace(gc["ioff"], gc["isrc"], gc["outdeg"], max_iter=2)
+    monkeypatch.delenv("CZ_PR_INPLACE_MAX_LEVELS")
+    s, it, _, levels = G.pagerank_inplace(gc["ioff"], gc["isrc"], gc["outdeg"], max_iter=3)
+    os_, oit, _ = oracle.pagerank_mode(gc["n"], gc["ioff"], gc["isrc"], gc["outdeg"], max_iter=3, mode=oracle.PR_INPLACE)
+    assert np.array_equal(s, os_) and levels >= 59

@@ -62,8 +62,8 @@ class OracleGraphBackend:
 
     def install(self, monkeypatch):
         import cozo_amd.graph as G
-        for name in ("pagerank", "pagerank_inplace", "bfs", "connected_components", "sssp", "clustering_coefficients", "betweenness",
-                     "label_propagation", "closeness"):
+        for name in ("pagerank", "pagerank_inplace", "bfs", "bfs_shared", "connected_components", "sssp", "clustering_coefficients",
+                     "betweenness", "label_propagation", "closeness"):
             monkeypatch.setattr(G, name, getattr(self, name))
 
     def pagerank(self, in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10, poison=None):
@@ -96,6 +96,23 @@ class OracleGraphBackend:
                 order[si, :len(o)] = o
         return parent, None, order, reached
 
+    def bfs_shared(self, out_off, out_tgt, starts, poison=None):
+        """the reference's loop (bfs.rs:43-98): one `visited` / `backtrace`, a start already reached is skipped"""
+        O = self.O
+        n = len(out_off) - 1
+        parent = np.full(n, O.NONE, dtype=np.uint32)
+        visited = np.zeros(n, dtype=np.uint8)
+        order = np.full(n, O.NONE, dtype=np.uint32)
+        first = np.zeros(len(starts) + 1, dtype=np.uint32)
+        at = 0
+        for si, s in enumerate(starts):
+            if s < n and not visited[s]:
+                o, parent, visited = O.bfs_order(n, out_off, out_tgt, int(s), visited, parent)
+                order[at:at + len(o)] = o
+                at += len(o)
+            first[si + 1] = at
+        return parent, order, first
+
     def connected_components(self, off, tgt, poison=None):
         return self.O.tarjan_groups(len(off) - 1, off, tgt)
 
@@ -103,7 +120,7 @@ class OracleGraphBackend:
         _, tri, deg = self.O.clustering_coefficients(len(off) - 1, off, tgt)
         return tri, deg
 
-    def sssp(self, out_off, out_tgt, weights, starts, poison=None):
+    def sssp(self, out_off, out_tgt, weights, starts, poison=None, goals=None):
         n = len(out_off) - 1
         dist = np.empty((len(starts), n), dtype=np.float32)
         parent = np.empty((len(starts), n), dtype=np.uint32)
