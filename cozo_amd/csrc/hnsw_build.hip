@@ -687,7 +687,7 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
     // extend_candidates: per resident workgroup the candidate scratch (every member of the found set -- or of a row --
     // brings at most a row of neighbours) and the copy of the found list; per shrink of a round its staged selection
     const int extend = (flags & CZ_HNSW_EXTEND_CANDIDATES) ? 1 : 0;
-    const uint32_t kStageRows = 65536;
+    uint32_t stage_rows = 0;  // rows the staging arrays hold: grown to the largest round of shrinks (extend_candidates only)
     cz::DevBuf<uint64_t> b_ext_key;
     cz::DevBuf<uint32_t> b_ext_id, b_stage_ids, b_stage_n;
     cz::DevBuf<double> b_stage_dst;
@@ -705,15 +705,23 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
         CZ_HIP(b_ext_id.alloc((size_t)slots * (cap + efcap)));
         ext.key = b_ext_key.p;
         ext.id = b_ext_id.p;
-        CZ_HIP(b_stage_ids.alloc((size_t)kStageRows * stage.width));
-        CZ_HIP(b_stage_dst.alloc((size_t)kStageRows * stage.width));
-        CZ_HIP(b_stage_n.alloc(kStageRows));
-        CZ_HIP(b_stage_self.alloc(kStageRows));
+    }
+    // the staging arrays of a round of `rows` shrinks (width ids + width distances + two counters per row: ~1 KB per row)
+    auto stage_for = [&](uint32_t rows) -> int {
+        if (rows <= stage_rows) return CZ_OK;
+        const uint32_t want = std::max<uint32_t>(rows, std::max<uint32_t>(4096, stage_rows + stage_rows / 2));
+        CZ_HIP(hipStreamSynchronize(stream));  // (nothing of the old arrays is in flight any more)
+        CZ_HIP(b_stage_ids.alloc((size_t)want * stage.width));
+        CZ_HIP(b_stage_dst.alloc((size_t)want * stage.width));
+        CZ_HIP(b_stage_n.alloc(want));
+        CZ_HIP(b_stage_self.alloc(want));
         stage.ids = b_stage_ids.p;
         stage.dst = b_stage_dst.p;
         stage.n = b_stage_n.p;
         stage.self = b_stage_self.p;
-    }
+        stage_rows = want;
+        return CZ_OK;
+    };
     // CZ_BUILD_TRACE=1: wait after every stage and name it (a faulting kernel is the one after the last name printed)
     const bool trace = getenv("CZ_BUILD_TRACE") && atoi(getenv("CZ_BUILD_TRACE")) != 0;
     auto stage_done = [&](const char *what, uint32_t count) {
@@ -722,32 +730,34 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
         fprintf(stderr, "[build] %s (%u) done\n", what, count);
     };
     // one round of shrinks: rows [0, count) of the request arrays (count on the host, or read on the device when `count_dev`).
-    // With extend_candidates a shrink reads OTHER rows, so its selection is staged and applied afterwards -- per part of kStageRows
-    // (65 536) requests: inside a part every shrink sees the rows as the part found them; a round of MORE requests than that (only
-    // the final lazy round of a large batched build) is applied part by part, and a later part reads rows an earlier part of the
-    // same round has already rewritten.  That makes those tables depend on the request order of that round; the
-    // sequential build (max_batch = 1: one request per round) is untouched, and it is the only form whose tables are pinned to the oracle.
-    auto launch_shrinks = [&](const uint32_t *sh_t, const int32_t *sh_lv, uint32_t count, const uint32_t *count_dev) {
-        for (uint32_t off = 0; off < count; off += extend ? kStageRows : count) {
-            const uint32_t part = extend ? std::min(kStageRows, count - off) : count;
-            const uint32_t g3 = std::min<uint32_t>(part, (uint32_t)slots);
+    // With extend_candidates a shrink reads OTHER rows, so the selections of the WHOLE round are staged and applied afterwards:
+    // every shrink of a round sees the rows as the round found them, whatever the round's size (until round 5 the staging held
+    // 65 536 requests and a larger round -- the final lazy round of a large batched build -- was applied part by part, a later
+    // part reading rows an earlier one had rewritten: ADVICE r3).
+    auto launch_shrinks = [&](const uint32_t *sh_t, const int32_t *sh_lv, uint32_t count, const uint32_t *count_dev) -> int {
+        if (count == 0) return CZ_OK;
+        if (extend) {
+            int src = stage_for(count);
+            if (src) return src;
+        }
+        const uint32_t g3 = std::min<uint32_t>(count, (uint32_t)slots);
 #define CZ_LAUNCH_SHRINK(LPV, ITERS, U)                                                                                  \
     do {                                                                                                                 \
         auto kern = extend ? build_shrink_kernel<LPV, ITERS, U, true> : build_shrink_kernel<LPV, ITERS, U, false>;      \
         if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                                         (int)smem);                                                     \
-        hipLaunchKernelGGL(kern, dim3(g3), dim3(kThreads), smem, stream, dev, T, sh_t + off, sh_lv + off, part, count_dev, \
+        hipLaunchKernelGGL(kern, dim3(g3), dim3(kThreads), smem, stream, dev, T, sh_t, sh_lv, count, count_dev,          \
                            efcap, wcap, keep_pruned_connections, b_ndist.p, b_vtab.p, hbits, b_visited.p, words, ext,     \
                            stage);                                                                                       \
     } while (0)
-            CZ_DISPATCH_BUILD_SHAPE(sh, CZ_LAUNCH_SHRINK);
+        CZ_DISPATCH_BUILD_SHAPE(sh, CZ_LAUNCH_SHRINK);
 #undef CZ_LAUNCH_SHRINK
-            stage_done("shrink", part);
-            if (extend)
-                hipLaunchKernelGGL(build_apply_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>((part + 3) / 4, 4096))),
-                                   dim3(256), 0, stream, T, sh_t + off, sh_lv + off, part, count_dev, stage);
-            stage_done("apply", part);
-        }
+        stage_done("shrink", count);
+        if (extend)
+            hipLaunchKernelGGL(build_apply_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>((count + 3) / 4, 4096))),
+                               dim3(256), 0, stream, T, sh_t, sh_lv, count, count_dev, stage);
+        stage_done("apply", count);
+        return CZ_OK;
     };
 
     int top = -1;
@@ -815,7 +825,7 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
                 const Req one{cur->t.p + k, cur->q.p + k, cur->lv.p + k, cur->d.p + k};
                 hipLaunchKernelGGL(build_link_kernel, dim3(1), dim3(64), 0, stream, T, one, 1u, 0, nxt->ref(), b_misc.p + 1,
                                    b_shrink_t.p, b_shrink_lv.p, b_misc.p + 2, 1, 0);
-                launch_shrinks(b_shrink_t.p, b_shrink_lv.p, 1u, b_misc.p + 2);
+                if (int src = launch_shrinks(b_shrink_t.p, b_shrink_lv.p, 1u, b_misc.p + 2)) return src;
             }
             nreq = 0;
         }
@@ -828,7 +838,8 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
             CZ_HIP(hipMemcpyAsync(h, b_misc.p, 32, hipMemcpyDeviceToHost, stream));
             CZ_HIP(hipStreamSynchronize(stream));
             const uint32_t nretry = h[1], nshrink = h[2];
-            if (nshrink > 0) launch_shrinks(b_shrink_t.p, b_shrink_lv.p, nshrink, nullptr);
+            if (nshrink > 0)
+                if (int src = launch_shrinks(b_shrink_t.p, b_shrink_lv.p, nshrink, nullptr)) return src;
             std::swap(cur, nxt);
             if (nretry >= nreq && nshrink == 0)
                 return cz::set_error(CZ_E_HIP, "internal: reverse-link requests made no progress");
@@ -859,7 +870,7 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
         CZ_HIP(hipMemcpyAsync(&nfinal, b_misc.p + 2, 4, hipMemcpyDeviceToHost, stream));
         CZ_HIP(hipStreamSynchronize(stream));
         if (nfinal > 0) {
-            launch_shrinks(f_t.p, f_lv.p, nfinal, nullptr);
+            if (int src = launch_shrinks(f_t.p, f_lv.p, nfinal, nullptr)) return src;
             CZ_HIP(hipStreamSynchronize(stream));  // f_t / f_lv die with this scope
         }
         hipError_t fe = hipGetLastError();
