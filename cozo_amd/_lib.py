@@ -85,6 +85,7 @@ SYMBOLS = {
     "cz_hbm_probe": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cz_random_access_probe": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cz_hnsw_index_create": (C.c_int, [C.POINTER(HnswDesc), C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cz_hnsw_index_create_f64": (C.c_int, [C.POINTER(HnswDesc), C.c_void_p, C.POINTER(C.c_void_p)]),
     "cz_hnsw_index_destroy": (None, [C.c_void_p]),
     "cz_hnsw_index_bytes": (C.c_uint64, [C.c_void_p]),
     "cz_hnsw_build": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p,
@@ -102,12 +103,20 @@ SYMBOLS = {
     "cz_hnsw_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                        C.c_void_p]),
+    "cz_hnsw_search_batch_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                       C.c_void_p]),
     "cz_column_upload": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int32, C.POINTER(C.c_void_p)]),
     "cz_column_destroy": (None, [C.c_void_p]),
     "cz_hnsw_search_filtered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double,
                                           C.POINTER(Predicate), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_uint32, C.c_void_p]),
+    "cz_hnsw_search_filtered_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double,
+                                          C.POINTER(Predicate), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_uint32, C.c_void_p]),
     "cz_distance_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                    C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "cz_distance_batch_f64": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                     C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "cz_knn_bruteforce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
                                     C.c_void_p]),

@@ -758,6 +758,7 @@ static int cz_hnsw_search_sharded_status(cz_comm *comm, cz_hnsw_index *shard, co
         entry_status = cz::set_error(CZ_E_INVALID, "null argument");
     hipStream_t stream = (hipStream_t)stream_;
     auto *ix = reinterpret_cast<cz::HnswIndex *>(shard);
+    if (!entry_status && ix && ix->f64()) entry_status = cz::set_error(CZ_E_UNSUPPORTED, "the sharded search takes F32 indices");
     const uint32_t world = (uint32_t)comm->world;
     const size_t nk = (size_t)B * k;
     cz::DevBuf<float> q;

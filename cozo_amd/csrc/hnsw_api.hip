@@ -522,6 +522,7 @@ void HnswIndex::destroy(Workspace &w) {
 
 HnswIndex::~HnswIndex() {
     if (vec) (void)hipFree(vec);
+    if (vec64) (void)hipFree(vec64);
     if (nbr0) (void)hipFree(nbr0);
     if (up_base) (void)hipFree(up_base);
     if (up_nbrs) (void)hipFree(up_nbrs);
@@ -589,6 +590,7 @@ void visited_shape(uint32_t n, uint32_t ef, uint32_t width, uint32_t *hbits, uin
 IndexDev HnswIndex::dev() const {
     IndexDev d;
     d.vec = vec;
+    d.vec64 = vec64;
     d.n = n;
     d.dim = dim;
     d.ld = ld;
@@ -612,7 +614,16 @@ static int upload_padded(const float *src_host, uint64_t n, uint32_t dim, uint32
     return CZ_OK;
 }
 
+static int index_create(const cz_hnsw_desc *desc, const void *vectors, bool f64, cz_hnsw_index **out);
 extern "C" int cz_hnsw_index_create(const cz_hnsw_desc *desc, const float *vectors, cz_hnsw_index **out) {
+    return index_create(desc, vectors, false, out);
+}
+// VecElementType::F64 (parse/sys.rs:556-560; VectorCache::dist's F64 arms, hnsw.rs:73-78, 86-95, 102-106): the same tables over
+// f64 vectors.  Searched (cz_hnsw_search_batch_f64); building / inserting / removing stays on the reference's CPU path.
+extern "C" int cz_hnsw_index_create_f64(const cz_hnsw_desc *desc, const double *vectors, cz_hnsw_index **out) {
+    return index_create(desc, vectors, true, out);
+}
+static int index_create(const cz_hnsw_desc *desc, const void *vectors, bool f64, cz_hnsw_index **out) {
     if (!desc || !out) return cz::set_error(CZ_E_INVALID, "null argument");
     *out = nullptr;
     int rc = cz::ensure_device();
@@ -625,7 +636,7 @@ extern "C" int cz_hnsw_index_create(const cz_hnsw_desc *desc, const float *vecto
     std::unique_ptr<cz::HnswIndex> guard(ix);
     ix->n = desc->n;
     ix->dim = desc->dim;
-    ix->ld = (desc->dim + 3) & ~3u;
+    ix->ld = f64 ? (desc->dim + 1) & ~1u : (desc->dim + 3) & ~3u;
     ix->metric = desc->metric;
     ix->n_levels = desc->n == 0 ? 0 : desc->n_levels;
     ix->entry = desc->entry;
@@ -652,9 +663,18 @@ extern "C" int cz_hnsw_index_create(const cz_hnsw_desc *desc, const float *vecto
         }
     }
     // vectors
-    CZ_HIP(cz::alloc_table((void **)&ix->vec, std::max<size_t>(16, (size_t)ix->n * ix->ld * 4)));
-    rc = upload_padded(vectors, ix->n, ix->dim, ix->ld, ix->vec);
-    if (rc) return rc;
+    if (f64) {
+        const size_t bytes = std::max<size_t>(16, (size_t)ix->n * ix->ld * 8);
+        CZ_HIP(cz::alloc_table((void **)&ix->vec64, bytes));
+        if (ix->n) {
+            if (ix->ld != ix->dim) CZ_HIP(hipMemset(ix->vec64, 0, bytes));
+            CZ_HIP(hipMemcpy2D(ix->vec64, (size_t)ix->ld * 8, vectors, (size_t)ix->dim * 8, (size_t)ix->dim * 8, ix->n, hipMemcpyHostToDevice));
+        }
+    } else {
+        CZ_HIP(cz::alloc_table((void **)&ix->vec, std::max<size_t>(16, (size_t)ix->n * ix->ld * 4)));
+        rc = upload_padded((const float *)vectors, ix->n, ix->dim, ix->ld, ix->vec);
+        if (rc) return rc;
+    }
     if (ix->n_levels > 0) {
         CZ_HIP(hipMalloc((void **)&ix->nbr0, (size_t)ix->n * ix->w0 * 4));
         CZ_HIP(hipMemcpy(ix->nbr0, desc->level_nbrs[0], (size_t)ix->n * ix->w0 * 4, hipMemcpyHostToDevice));
@@ -723,12 +743,13 @@ extern "C" void cz_hnsw_index_destroy(cz_hnsw_index *h) {
 extern "C" uint64_t cz_hnsw_index_bytes(const cz_hnsw_index *h) {
     if (!h) return 0;
     auto *ix = reinterpret_cast<const cz::HnswIndex *>(h);
-    return (uint64_t)ix->n * ix->ld * 4 + (uint64_t)ix->n * ix->w0 * 4 + (uint64_t)ix->n * 4 + ix->up_rows * ix->wu * 4;
+    return (uint64_t)ix->n * ix->ld * (ix->f64() ? 8 : 4) + (uint64_t)ix->n * ix->w0 * 4 + (uint64_t)ix->n * 4 + ix->up_rows * ix->wu * 4;
 }
 
 extern "C" int cz_hnsw_index_probe(const cz_hnsw_index *h, uint64_t n_fetch, uint32_t reps, double *stream_gbs, double *row_fetch_gbs) {
     auto *ix = reinterpret_cast<const cz::HnswIndex *>(h);
-    if (!ix || !ix->vec || ix->n == 0) return cz::set_error(CZ_E_INVALID, "null or empty index");
+    if (!ix || (!ix->vec && !ix->vec64) || ix->n == 0) return cz::set_error(CZ_E_INVALID, "null or empty index");
+    if (ix->f64()) return cz_hbm_probe(ix->vec64, ix->n, ix->ld * 8u, n_fetch, reps, stream_gbs, row_fetch_gbs);
     return cz_hbm_probe(ix->vec, ix->n, ix->ld * 4u, n_fetch, reps, stream_gbs, row_fetch_gbs);
 }
 
@@ -756,7 +777,7 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
     const uint32_t wpad = (uint32_t)((std::max(ix->w0, ix->wu) + 63) & ~63);
     // the list lives in LDS: 12 bytes + 1 flag byte per entry.  ef = 4 096 takes 62 KiB (two workgroups per CU), the largest list
     // one workgroup can hold next to a 768-d query is ~11 000 entries; the reference has no limit (hnsw.rs:930-938)
-    const size_t smem = czh::smem_bytes(efcap, wpad, ix->ld, false);
+    const size_t smem = czh::smem_bytes(efcap, wpad, ix->f64() ? ix->ld * 2 : ix->ld, false);
     if (smem > 160 * 1024)
         return set_error(CZ_E_UNSUPPORTED, "dim %u / ef %u need %zu bytes of LDS (> 160 KiB)", ix->dim, ef, smem);
     IndexDev d = ix->dev();
@@ -798,7 +819,32 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
     } while (0)
     const char *knn_u_env = getenv("CZ_HNSW_U");
     int knn_u = knn_u_env ? atoi(knn_u_env) : 0;
-    if (sh.lpv == 64 && sh.iters == 3) {
+    if (ix->f64()) {  // f64 vectors: the lane group of distance_f64.cuh, two rows in flight
+        const int lpv64 = czd64::lpv_for(ix->dim);
+#define CZ_LAUNCH_KNN64(LPV) CZ_LAUNCH_KNN_F64_(LPV, 2)
+#define CZ_LAUNCH_KNN_F64_(LPV, U)                                                                                      \
+    do {                                                                                                                \
+        auto kern = czh::hnsw_knn_f64_kernel<LPV, U>;                                                                   \
+        if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                        (int)smem);                                                    \
+        int per_cu = 0;                                                                                                 \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, czh::kThreads, smem) != hipSuccess || per_cu < 1) { \
+            (void)hipGetLastError();                                                                                    \
+            per_cu = 1;                                                                                                 \
+        }                                                                                                               \
+        grid = (uint32_t)std::min<uint64_t>(B, (uint64_t)per_cu * (uint64_t)cus);                                       \
+        rc = ix->acquire(hbits ? ((size_t)grid << hbits) * 4 : 0, (size_t)grid * words * 4, stream, &ws);               \
+        if (rc) return rc;                                                                                              \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(czh::kThreads), smem, stream, d, d_queries, B, k, ef, efcap, wpad,    \
+                           has_radius, radius, (uint32_t *)ws.tab, hbits, (uint32_t *)ws.bitmap, words, preds, d_ids,   \
+                           d_dist, d_count, (unsigned long long *)d_ndist);                                             \
+    } while (0)
+        if (lpv64 == 16) CZ_LAUNCH_KNN64(16);
+        else if (lpv64 == 32) CZ_LAUNCH_KNN64(32);
+        else CZ_LAUNCH_KNN64(64);
+#undef CZ_LAUNCH_KNN64
+#undef CZ_LAUNCH_KNN_F64_
+    } else if (sh.lpv == 64 && sh.iters == 3) {
         if (knn_u == 0) knn_u = (uint64_t)B * 4 <= (uint64_t)cus * 4 ? 8 : ((uint64_t)B * 2 <= (uint64_t)cus * 4 ? 4 : 2);
         if (knn_u == 1) CZ_LAUNCH_KNN(64, 3, 1);
         else if (knn_u == 4) CZ_LAUNCH_KNN_(hnsw_knn_wide_kernel, 64, 3, 4);
@@ -830,33 +876,35 @@ extern "C" int cz_debug_phase_cycles(unsigned long long *out, int reset) {
 }
 #endif
 
-extern "C" int cz_hnsw_search_batch(cz_hnsw_index *h, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
-                                    int has_radius, double radius, uint32_t *out_ids, double *out_dist,
-                                    uint32_t *out_count, uint64_t *out_n_dist, const volatile uint8_t *poison,
-                                    uint32_t flags, void *stream_) {
-    if (!h) return cz::set_error(CZ_E_INVALID, "null index");
-    int rc = cz::ensure_device();
-    if (rc) return rc;
+// queries: f32 rows, or f64 rows when `f64` (the index must hold the same element type: the reference converts the query to the
+// index' dtype before it searches, hnsw.rs:879-884 -- that conversion is the caller's, a cast per element)
+static int search_batch_any(cz_hnsw_index *h, const void *queries, bool f64, uint32_t B, uint32_t k, uint32_t ef, int has_radius,
+                            double radius, const czh::PredSet *ps, uint32_t *out_ids, double *out_dist, uint32_t *out_count,
+                            uint64_t *out_n_dist, const volatile uint8_t *poison, uint32_t flags, void *stream_) {
     auto *ix = reinterpret_cast<cz::HnswIndex *>(h);
+    if (ix->f64() != f64)
+        return cz::set_error(CZ_E_INVALID, f64 ? "the index holds F32 vectors: cz_hnsw_search_batch / _filtered"
+                                               : "the index holds F64 vectors: cz_hnsw_search_batch_f64 / _filtered_f64");
     if (B == 0) return CZ_OK;
     if (!queries || !out_ids || !out_dist || !out_count) return cz::set_error(CZ_E_INVALID, "null buffer");
     if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
     hipStream_t stream = (hipStream_t)stream_;
     if (flags & CZ_DEVICE_PTRS)
-        return cz::hnsw_search_device(ix, queries, B, k, ef, has_radius, radius, out_ids, out_dist, out_count, out_n_dist,
-                                      stream);
-    cz::DevBuf<float> dq;
+        return cz::hnsw_search_device(ix, (const float *)queries, B, k, ef, has_radius, radius, out_ids, out_dist, out_count, out_n_dist,
+                                      stream, ps);
+    const size_t esz = f64 ? 8 : 4;
+    cz::DevBuf<char> dq;
     cz::DevBuf<uint32_t> dids, dcnt;
     cz::DevBuf<double> ddist;
     cz::DevBuf<uint64_t> dnd;
-    CZ_HIP(dq.alloc((size_t)B * ix->dim));
+    CZ_HIP(dq.alloc((size_t)B * ix->dim * esz));
     CZ_HIP(dids.alloc((size_t)B * k));
     CZ_HIP(ddist.alloc((size_t)B * k));
     CZ_HIP(dcnt.alloc(B));
     if (out_n_dist) CZ_HIP(dnd.alloc(B));
-    CZ_HIP(hipMemcpyAsync(dq.p, queries, (size_t)B * ix->dim * 4, hipMemcpyHostToDevice, stream));
-    rc = cz::hnsw_search_device(ix, dq.p, B, k, ef, has_radius, radius, dids.p, ddist.p, dcnt.p, out_n_dist ? dnd.p : nullptr,
-                                stream);
+    CZ_HIP(hipMemcpyAsync(dq.p, queries, (size_t)B * ix->dim * esz, hipMemcpyHostToDevice, stream));
+    int rc = cz::hnsw_search_device(ix, (const float *)dq.p, B, k, ef, has_radius, radius, dids.p, ddist.p, dcnt.p,
+                                    out_n_dist ? dnd.p : nullptr, stream, ps);
     if (rc) return rc;
     CZ_HIP(hipMemcpyAsync(out_ids, dids.p, (size_t)B * k * 4, hipMemcpyDeviceToHost, stream));
     CZ_HIP(hipMemcpyAsync(out_dist, ddist.p, (size_t)B * k * 8, hipMemcpyDeviceToHost, stream));
@@ -865,6 +913,27 @@ extern "C" int cz_hnsw_search_batch(cz_hnsw_index *h, const float *queries, uint
     CZ_HIP(hipStreamSynchronize(stream));
     if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
     return CZ_OK;
+}
+
+extern "C" int cz_hnsw_search_batch(cz_hnsw_index *h, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
+                                    int has_radius, double radius, uint32_t *out_ids, double *out_dist,
+                                    uint32_t *out_count, uint64_t *out_n_dist, const volatile uint8_t *poison,
+                                    uint32_t flags, void *stream_) {
+    if (!h) return cz::set_error(CZ_E_INVALID, "null index");
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    return search_batch_any(h, queries, false, B, k, ef, has_radius, radius, nullptr, out_ids, out_dist, out_count, out_n_dist, poison,
+                            flags, stream_);
+}
+extern "C" int cz_hnsw_search_batch_f64(cz_hnsw_index *h, const double *queries, uint32_t B, uint32_t k, uint32_t ef,
+                                        int has_radius, double radius, uint32_t *out_ids, double *out_dist,
+                                        uint32_t *out_count, uint64_t *out_n_dist, const volatile uint8_t *poison,
+                                        uint32_t flags, void *stream_) {
+    if (!h) return cz::set_error(CZ_E_INVALID, "null index");
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    return search_batch_any(h, queries, true, B, k, ef, has_radius, radius, nullptr, out_ids, out_dist, out_count, out_n_dist, poison,
+                            flags, stream_);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -901,10 +970,9 @@ extern "C" void cz_column_destroy(cz_column *c) {
     delete c;
 }
 
-extern "C" int cz_hnsw_search_filtered(cz_hnsw_index *h, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
-                                       int has_radius, double radius, const cz_predicate *preds, uint32_t n_preds,
-                                       uint32_t *out_ids, double *out_dist, uint32_t *out_count, uint64_t *out_n_dist,
-                                       const volatile uint8_t *poison, uint32_t flags, void *stream_) {
+static int search_filtered_any(cz_hnsw_index *h, const void *queries, bool f64, uint32_t B, uint32_t k, uint32_t ef, int has_radius,
+                               double radius, const cz_predicate *preds, uint32_t n_preds, uint32_t *out_ids, double *out_dist,
+                               uint32_t *out_count, uint64_t *out_n_dist, const volatile uint8_t *poison, uint32_t flags, void *stream_) {
     if (!h) return cz::set_error(CZ_E_INVALID, "null index");
     int rc = cz::ensure_device();
     if (rc) return rc;
@@ -930,33 +998,22 @@ extern "C" int cz_hnsw_search_filtered(cz_hnsw_index *h, const float *queries, u
         ps.t[i].fv = p.f64_value;
         ps.t[i].iv = p.i64_value;
     }
-    if (B == 0) return CZ_OK;
-    if (!queries || !out_ids || !out_dist || !out_count) return cz::set_error(CZ_E_INVALID, "null buffer");
-    if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
-    hipStream_t stream = (hipStream_t)stream_;
-    if (flags & CZ_DEVICE_PTRS)
-        return cz::hnsw_search_device(ix, queries, B, k, ef, has_radius, radius, out_ids, out_dist, out_count, out_n_dist, stream,
-                                      &ps);
-    cz::DevBuf<float> dq;
-    cz::DevBuf<uint32_t> dids, dcnt;
-    cz::DevBuf<double> ddist;
-    cz::DevBuf<uint64_t> dnd;
-    CZ_HIP(dq.alloc((size_t)B * ix->dim));
-    CZ_HIP(dids.alloc((size_t)B * k));
-    CZ_HIP(ddist.alloc((size_t)B * k));
-    CZ_HIP(dcnt.alloc(B));
-    if (out_n_dist) CZ_HIP(dnd.alloc(B));
-    CZ_HIP(hipMemcpyAsync(dq.p, queries, (size_t)B * ix->dim * 4, hipMemcpyHostToDevice, stream));
-    rc = cz::hnsw_search_device(ix, dq.p, B, k, ef, has_radius, radius, dids.p, ddist.p, dcnt.p, out_n_dist ? dnd.p : nullptr, stream,
-                                &ps);
-    if (rc) return rc;
-    CZ_HIP(hipMemcpyAsync(out_ids, dids.p, (size_t)B * k * 4, hipMemcpyDeviceToHost, stream));
-    CZ_HIP(hipMemcpyAsync(out_dist, ddist.p, (size_t)B * k * 8, hipMemcpyDeviceToHost, stream));
-    CZ_HIP(hipMemcpyAsync(out_count, dcnt.p, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
-    if (out_n_dist) CZ_HIP(hipMemcpyAsync(out_n_dist, dnd.p, (size_t)B * 8, hipMemcpyDeviceToHost, stream));
-    CZ_HIP(hipStreamSynchronize(stream));
-    if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
-    return CZ_OK;
+    return search_batch_any(h, queries, f64, B, k, ef, has_radius, radius, &ps, out_ids, out_dist, out_count, out_n_dist, poison, flags,
+                            stream_);
+}
+extern "C" int cz_hnsw_search_filtered(cz_hnsw_index *h, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
+                                       int has_radius, double radius, const cz_predicate *preds, uint32_t n_preds,
+                                       uint32_t *out_ids, double *out_dist, uint32_t *out_count, uint64_t *out_n_dist,
+                                       const volatile uint8_t *poison, uint32_t flags, void *stream_) {
+    return search_filtered_any(h, queries, false, B, k, ef, has_radius, radius, preds, n_preds, out_ids, out_dist, out_count, out_n_dist,
+                               poison, flags, stream_);
+}
+extern "C" int cz_hnsw_search_filtered_f64(cz_hnsw_index *h, const double *queries, uint32_t B, uint32_t k, uint32_t ef,
+                                           int has_radius, double radius, const cz_predicate *preds, uint32_t n_preds,
+                                           uint32_t *out_ids, double *out_dist, uint32_t *out_count, uint64_t *out_n_dist,
+                                           const volatile uint8_t *poison, uint32_t flags, void *stream_) {
+    return search_filtered_any(h, queries, true, B, k, ef, has_radius, radius, preds, n_preds, out_ids, out_dist, out_count, out_n_dist,
+                               poison, flags, stream_);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1138,6 +1195,90 @@ extern "C" int cz_distance_batch(int metric, const float *base, uint32_t n, uint
     return CZ_OK;
 }
 
+// VectorCache::dist over f64 vectors (hnsw.rs:73-78, 86-95, 102-106): a lane group per pair, distance_f64.cuh's tree; a lane group
+// computes the query's own norm as well (cosine).  Rows are read straight from the caller's [*][dim] layout when dim is even
+// (16-byte chunks stay aligned), repacked to an even row length otherwise.
+template <int LPV>
+__global__ void __launch_bounds__(256)
+distance_pairs_f64_kernel(int metric, const double *__restrict__ base, const double *__restrict__ queries, uint32_t ld,
+                          const uint32_t *__restrict__ pairs, uint64_t P, uint32_t n, uint32_t nq, double *__restrict__ out) {
+    const int chunks = (int)(ld / 2);
+    const int glane = (threadIdx.x & 63) % LPV;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPV;
+    const uint64_t ngroups = ((uint64_t)gridDim.x * blockDim.x) / LPV;
+    for (uint64_t p = group; p < P; p += ngroups) {
+        const uint32_t qi = pairs[2 * p], bi = pairs[2 * p + 1];
+        if (qi >= nq || bi >= n) {  // (uniform over the lane group)
+            if (glane == 0) out[p] = __longlong_as_double(0x7FF8000000000000ll);
+            continue;
+        }
+        const double2 *q = (const double2 *)(queries + (size_t)qi * ld);
+        const double2 *rows[1] = {(const double2 *)(base + (size_t)bi * ld)};
+        const double qn = metric == CZ_COSINE ? czd64::self_dot<LPV>(q, glane, chunks) : 0.0;
+        double d[1];
+        czd64::group_distances<LPV, 1>(metric, q, glane, chunks, qn, rows, d);
+        if (glane == 0) out[p] = d[0];
+    }
+}
+__global__ void __launch_bounds__(256)
+pad_rows_f64_kernel(const double *__restrict__ src, double *__restrict__ dst, uint64_t n, uint32_t dim, uint32_t ld) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * ld; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / ld;
+        const uint32_t c = (uint32_t)(i % ld);
+        dst[i] = c < dim ? src[r * dim + c] : 0.0;
+    }
+}
+
+extern "C" int cz_distance_batch_f64(int metric, const double *base, uint32_t n, uint32_t dim, const double *queries, uint32_t nq,
+                                     const uint32_t *pairs, uint64_t P, double *out, uint32_t flags, void *stream_) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if (metric < CZ_L2 || metric > CZ_IP) return cz::set_error(CZ_E_INVALID, "bad metric %d", metric);
+    if (dim == 0) return cz::set_error(CZ_E_INVALID, "dim must be > 0");
+    if (P == 0) return CZ_OK;
+    if (!base || !queries || !pairs || !out) return cz::set_error(CZ_E_INVALID, "null buffer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const uint32_t ld = (dim + 1) & ~1u;
+    const bool dev = (flags & CZ_DEVICE_PTRS) != 0;
+    cz::DevBuf<double> pb, pq, dout;
+    cz::DevBuf<uint32_t> dp;
+    const double *d_base = base, *d_q = queries;
+    const uint32_t *d_pairs = pairs;
+    double *d_out = out;
+    if (!dev) {
+        CZ_HIP(pb.alloc((size_t)n * dim));
+        CZ_HIP(pq.alloc((size_t)nq * dim));
+        CZ_HIP(dp.alloc((size_t)P * 2));
+        CZ_HIP(dout.alloc(P));
+        CZ_HIP(hipMemcpyAsync(pb.p, base, (size_t)n * dim * 8, hipMemcpyHostToDevice, stream));
+        CZ_HIP(hipMemcpyAsync(pq.p, queries, (size_t)nq * dim * 8, hipMemcpyHostToDevice, stream));
+        CZ_HIP(hipMemcpyAsync(dp.p, pairs, (size_t)P * 8, hipMemcpyHostToDevice, stream));
+        d_base = pb.p;
+        d_q = pq.p;
+        d_pairs = dp.p;
+        d_out = dout.p;
+    }
+    cz::DevBuf<double> rb, rq;
+    if (ld != dim) {  // odd dimension: rows repacked to an even length (16-byte aligned chunks)
+        CZ_HIP(rb.alloc((size_t)n * ld));
+        CZ_HIP(rq.alloc((size_t)nq * ld));
+        hipLaunchKernelGGL(pad_rows_f64_kernel, dim3(1024), dim3(256), 0, stream, d_base, rb.p, (uint64_t)n, dim, ld);
+        hipLaunchKernelGGL(pad_rows_f64_kernel, dim3(256), dim3(256), 0, stream, d_q, rq.p, (uint64_t)nq, dim, ld);
+        d_base = rb.p;
+        d_q = rq.p;
+    }
+    const int lpv = czd64::lpv_for(dim);
+    const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(256 * 8, (P * (uint64_t)lpv + 255) / 256));
+    if (lpv == 16) hipLaunchKernelGGL(distance_pairs_f64_kernel<16>, dim3(blocks), dim3(256), 0, stream, metric, d_base, d_q, ld, d_pairs, P, n, nq, d_out);
+    else if (lpv == 32) hipLaunchKernelGGL(distance_pairs_f64_kernel<32>, dim3(blocks), dim3(256), 0, stream, metric, d_base, d_q, ld, d_pairs, P, n, nq, d_out);
+    else hipLaunchKernelGGL(distance_pairs_f64_kernel<64>, dim3(blocks), dim3(256), 0, stream, metric, d_base, d_q, ld, d_pairs, P, n, nq, d_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "distance_pairs_f64_kernel launch: %s", hipGetErrorString(e));
+    if (!dev) CZ_HIP(hipMemcpyAsync(out, dout.p, (size_t)P * 8, hipMemcpyDeviceToHost, stream));
+    if (!dev || ld != dim) CZ_HIP(hipStreamSynchronize(stream));  // temporaries die with this scope
+    return CZ_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // exhaustive k-NN
 // ------------------------------------------------------------------------------------------------
@@ -1157,6 +1298,7 @@ extern "C" int cz_knn_bruteforce(cz_hnsw_index *h, const float *queries, uint32_
     int rc = cz::ensure_device();
     if (rc) return rc;
     auto *ix = reinterpret_cast<cz::HnswIndex *>(h);
+    if (ix->f64()) return cz::set_error(CZ_E_UNSUPPORTED, "the index holds F64 vectors: the exhaustive scan is an f32 path");
     if (B == 0) return CZ_OK;
     if (k == 0 || k > 1024) return cz::set_error(CZ_E_UNSUPPORTED, "k must be in 1..1024");
     if (!queries || !out_ids || !out_dist) return cz::set_error(CZ_E_INVALID, "null buffer");

@@ -1014,6 +1014,7 @@ extern "C" int cz_hnsw_insert(cz_hnsw_index *h, const float *vectors, uint32_t n
     int rc = cz::ensure_device();
     if (rc) return rc;
     auto *ix = reinterpret_cast<cz::HnswIndex *>(h);
+    if (ix->f64()) return cz::set_error(CZ_E_UNSUPPORTED, "the index holds F64 vectors: it is searched on the device, maintained on the CPU path");
     if ((rc = check_build_args(ix->dim, ix->metric, m, ef_construction))) return rc;
     if (n_new == 0) return CZ_OK;
     if (!vectors) return cz::set_error(CZ_E_INVALID, "vectors is null");
@@ -1050,6 +1051,7 @@ extern "C" int cz_hnsw_remove(cz_hnsw_index *h, const uint32_t *nodes, uint32_t 
     int rc = cz::ensure_device();
     if (rc) return rc;
     auto *ix = reinterpret_cast<cz::HnswIndex *>(h);
+    if (ix->f64()) return cz::set_error(CZ_E_UNSUPPORTED, "the index holds F64 vectors: it is searched on the device, maintained on the CPU path");
     if (n_nodes == 0 || ix->n == 0) return CZ_OK;
     if (!nodes) return cz::set_error(CZ_E_INVALID, "null nodes");
     if (ix->top.size() != ix->n || ix->layout_top.size() != ix->n) return cz::set_error(CZ_E_HIP, "internal: level table out of step");
@@ -1179,6 +1181,7 @@ extern "C" int cz_hnsw_index_export_vectors(const cz_hnsw_index *h, float *out) 
     int rc = cz::ensure_device();
     if (rc) return rc;
     auto *ix = reinterpret_cast<const cz::HnswIndex *>(h);
+    if (ix->f64()) return cz::set_error(CZ_E_UNSUPPORTED, "the index holds F64 vectors");
     if (ix->n == 0) return CZ_OK;
     CZ_HIP(hipMemcpy2D(out, (size_t)ix->dim * 4, ix->vec, (size_t)ix->ld * 4, (size_t)ix->dim * 4, ix->n, hipMemcpyDeviceToHost));
     return CZ_OK;

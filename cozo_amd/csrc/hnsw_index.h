@@ -29,6 +29,7 @@ struct HnswIndex {
     int w0 = 1, wu = 1;
     uint64_t up_rows = 0;
     float *vec = nullptr;
+    double *vec64 = nullptr;  // an F64 index (cz_hnsw_index_create_f64): vec is null, ld = dim rounded up to 2; search only
     uint32_t *nbr0 = nullptr;
     uint32_t *up_base = nullptr;
     uint32_t *up_nbrs = nullptr;
@@ -65,6 +66,7 @@ struct HnswIndex {
     std::mutex mu;
     std::vector<Workspace> pool;
 
+    bool f64() const { return vec64 != nullptr; }
     ~HnswIndex();
     int acquire(size_t tab_bytes, size_t bitmap_bytes, hipStream_t stream, Workspace *out);
     int release(Workspace w, hipStream_t stream);
@@ -72,6 +74,7 @@ struct HnswIndex {
     czh::IndexDev dev() const;
 };
 
+// d_queries: [B][dim] floats -- doubles for an F64 index
 int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32_t k, uint32_t ef, int has_radius,
                        double radius, uint32_t *d_ids, double *d_dist, uint32_t *d_count, uint64_t *d_ndist,
                        hipStream_t stream, const czh::PredSet *preds = nullptr);

@@ -20,6 +20,7 @@
 //     (binary search over W for new entries, linear count over the <= 64 new entries for W entries).
 #pragma once
 #include "distance.cuh"
+#include "distance_f64.cuh"
 
 namespace czh {
 
@@ -60,6 +61,7 @@ constexpr int kMergeR = 2, kMergeEC = 2;
 
 struct IndexDev {
     const float *vec;        // [n][ld]
+    const double *vec64;     // [n][ld] of an F64 index (VecElementType::F64; then vec is null and ld = dim rounded up to 2)
     uint32_t n, dim, ld;     // ld = dim rounded up to 4
     int metric;
     const uint32_t *nbr0;    // [n][w0]
@@ -149,8 +151,11 @@ struct VisitedDev {
     uint32_t words;
 };
 
-template <int LPV, int ITERS, int U, bool NT = false>
+// F64: the index holds f64 vectors (search only; ITERS must be 0: the query is read from LDS, where it sits as doubles, and the
+// distances come from distance_f64.cuh).  The list, the visited set and the merges do not know the element type.
+template <int LPV, int ITERS, int U, bool NT = false, bool F64 = false>
 struct Searcher {
+    static_assert(!F64 || ITERS == 0, "the f64 evaluation reads the query from LDS");
     const IndexDev &ix;
     Smem s;
     VisitedDev vis;
@@ -159,6 +164,7 @@ struct Searcher {
     int chunks;
     float4 q[ITERS > 0 ? ITERS : 1];
     float qnorm;
+    double qnorm64 = 0.0;
     CZ_PH_DECL
 
     static constexpr int VPW = 64 / LPV;          // lane groups per wave
@@ -172,11 +178,21 @@ struct Searcher {
         wave = tid >> 6;
         glane = lane % LPV;
         group = wave * VPW + lane / LPV;
-        chunks = (int)(ix.ld / 4);
+        chunks = F64 ? (int)(ix.ld / 2) : (int)(ix.ld / 4);
     }
 
     // stage the query row (zero padded) into LDS and registers
     __device__ void load_query(const float *qrow) {
+        if constexpr (F64) {
+            const double *qrow64 = reinterpret_cast<const double *>(qrow);
+            double *ql = (double *)s.q;
+            for (uint32_t i = tid; i < ix.ld; i += kThreads) ql[i] = i < ix.dim ? qrow64[i] : 0.0;
+            if (tid < C_WORDS) s.ctl[tid] = tid == C_VMODE ? (vis.tab ? 0 : 1) : 0;
+            __syncthreads();
+            qnorm = 0.f;
+            qnorm64 = ix.metric == CZ_COSINE ? czd64::self_dot<LPV>((const double2 *)s.q, glane, chunks) : 0.0;
+            return;
+        }
         float *ql = (float *)s.q;
         for (uint32_t i = tid; i < ix.ld; i += kThreads) ql[i] = i < ix.dim ? qrow[i] : 0.f;
         if (tid < C_WORDS) s.ctl[tid] = tid == C_VMODE ? (vis.tab ? 0 : 1) : 0;
@@ -254,7 +270,30 @@ struct Searcher {
         }
     }
     __device__ void eval_list(const float4 (&qq)[ITERS > 0 ? ITERS : 1], float qqn, int n) {
-        if constexpr (ITERS > 0) {
+        if constexpr (F64) {
+            for (int base = group; base < n; base += TG * U) {
+                const double2 *rows[U];
+                uint32_t ids[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int j = base + u * TG;
+                    ids[u] = j < n ? tcur[j] : CZ_NONE;
+                    rows[u] = j < n ? (const double2 *)(ix.vec64 + (size_t)ids[u] * ix.ld) : nullptr;
+                }
+                double d[U];
+                czd64::group_distances<LPV, U>(ix.metric, (const double2 *)s.q, glane, chunks, qnorm64, rows, d);
+                if (glane == 0) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int j = base + u * TG;
+                        if (j < n) {
+                            s.nkey[j] = dist_key(d[u]);
+                            s.nid[j] = ids[u];
+                        }
+                    }
+                }
+            }
+        } else if constexpr (ITERS > 0) {
             if (ix.metric == CZ_COSINE) eval_rounds<CZ_COSINE>(qq, n);
             else if (ix.metric == CZ_L2) eval_rounds<CZ_L2>(qq, n);
             else eval_rounds<CZ_IP>(qq, n);
@@ -1006,6 +1045,20 @@ struct Searcher {
             s.ctl[C_CNT] = 0;
             s.ctl[C_NDIST_LO] += 1;
         }
+        if constexpr (F64) {
+            if (group == 0) {
+                const double2 *rows[1] = {(const double2 *)(ix.vec64 + (size_t)entry * ix.ld)};
+                double d[1];
+                czd64::group_distances<LPV, 1>(ix.metric, (const double2 *)s.q, glane, chunks, qnorm64, rows, d);
+                if (glane == 0) {
+                    s.wkey[0] = dist_key(d[0]);
+                    s.wid[0] = entry;
+                    s.ctl[C_CNT] = 1;
+                }
+            }
+            __syncthreads();
+            return;
+        }
         if (group == 0) {
             const float4 *row = (const float4 *)(ix.vec + (size_t)entry * ix.ld);
             float a0 = 0.f, a1 = 0.f;
@@ -1106,14 +1159,14 @@ __device__ __forceinline__ bool pred_pass(const PredSet &ps, uint32_t node) {
 // at B = 2 048 / 4 096 against 0.76 at 1 024).  U (rows in flight per lane group and round) is chosen from B by the
 // launcher: a batch that leaves most of the chip empty is bound by the latency of a step, and a step by the rounds its
 // rows take -- wider rounds (U = 4 / 8: 16 / 32 rows per round, the registers are free at that occupancy) shorten it.
-template <int LPV, int ITERS, int U>
+template <int LPV, int ITERS, int U, bool F64 = false>
 __device__ __forceinline__ void
 hnsw_knn_body(const IndexDev &ix, const float *__restrict__ queries, uint32_t B, uint32_t k, uint32_t ef, uint32_t efcap,
               uint32_t wpad, int has_radius, double radius, uint32_t *__restrict__ vtab, uint32_t hbits,
               uint32_t *__restrict__ vbitmap, uint32_t words, const PredSet &preds, uint32_t *__restrict__ out_ids,
               double *__restrict__ out_dist, uint32_t *__restrict__ out_count, unsigned long long *__restrict__ out_n_dist) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    Smem s = carve(smem_raw, efcap, wpad, ix.ld, false);
+    Smem s = carve(smem_raw, efcap, wpad, F64 ? ix.ld * 2 : ix.ld, false);  // (the query row: ld floats, or ld doubles)
     VisitedDev vis;
     vis.tab = hbits ? vtab + ((size_t)blockIdx.x << hbits) : nullptr;
     vis.hbits = hbits;
@@ -1121,8 +1174,9 @@ hnsw_knn_body(const IndexDev &ix, const float *__restrict__ queries, uint32_t B,
     vis.words = words;
     for (uint32_t b = blockIdx.x; b < B; b += gridDim.x) {
     if (b != blockIdx.x) __syncthreads();  // (the output stage of the query before this one has read the list)
-    Searcher<LPV, ITERS, U, CZ_SEARCH_NT != 0> S(ix, s, vis);
-    S.load_query(queries + (size_t)b * ix.dim);
+    Searcher<LPV, ITERS, U, CZ_SEARCH_NT != 0, F64> S(ix, s, vis);
+    S.load_query(F64 ? reinterpret_cast<const float *>(reinterpret_cast<const double *>(queries) + (size_t)b * ix.dim)
+                     : queries + (size_t)b * ix.dim);
     S.seed(ix.entry);
     // :919-938 greedy descent with ef = 1 through the upper levels, then the level-0 search with ef (one call site,
     // so that the traversal is inlined once)
@@ -1230,6 +1284,16 @@ hnsw_knn_wide_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t B,
                      double *__restrict__ out_dist, uint32_t *__restrict__ out_count, unsigned long long *__restrict__ out_n_dist) {
     hnsw_knn_body<LPV, ITERS, U>(ix, queries, B, k, ef, efcap, wpad, has_radius, radius, vtab, hbits, vbitmap, words, preds, out_ids,
                                  out_dist, out_count, out_n_dist);
+}
+// an F64 index (the query rows are doubles behind the float pointer): LPV lanes per vector, the query in LDS
+template <int LPV, int U>
+__global__ void __launch_bounds__(kThreads)
+hnsw_knn_f64_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t B, uint32_t k, uint32_t ef, uint32_t efcap,
+                    uint32_t wpad, int has_radius, double radius, uint32_t *__restrict__ vtab, uint32_t hbits,
+                    uint32_t *__restrict__ vbitmap, uint32_t words, PredSet preds, uint32_t *__restrict__ out_ids,
+                    double *__restrict__ out_dist, uint32_t *__restrict__ out_count, unsigned long long *__restrict__ out_n_dist) {
+    hnsw_knn_body<LPV, 0, U, true>(ix, queries, B, k, ef, efcap, wpad, has_radius, radius, vtab, hbits, vbitmap, words, preds, out_ids,
+                                   out_dist, out_count, out_n_dist);
 }
 
 }  // namespace czh

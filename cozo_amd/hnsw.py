@@ -69,10 +69,13 @@ class GpuHnswIndex:
 
     def __init__(self, manifest: HnswIndexManifest, vectors: np.ndarray, level_nodes: Sequence[np.ndarray],
                  level_nbrs: Sequence[np.ndarray], entry: int):
-        if manifest.dtype != "F32":
-            raise _lib.CozoGpuError(_lib.CZ_E_UNSUPPORTED, "only F32 vector indices are GPU-resident")
+        if manifest.dtype not in ("F32", "F64"):  # VecElementType, parse/sys.rs
+            raise _lib.CozoGpuError(_lib.CZ_E_UNSUPPORTED, f"vector element type {manifest.dtype!r}")
         self.manifest = manifest
-        vectors = np.ascontiguousarray(vectors, dtype=np.float32)
+        # an F64 index keeps f64 vectors and every distance is computed in f64 (VectorCache::dist's F64 arms, hnsw.rs:73-78,
+        # 86-95, 102-106): searched on the device, built / maintained on the reference's CPU path
+        self._np = np.float64 if manifest.dtype == "F64" else np.float32
+        vectors = np.ascontiguousarray(vectors, dtype=self._np)
         if vectors.ndim != 2 or vectors.shape[1] != manifest.vec_dim:
             raise ValueError("vectors must be [n][vec_dim]")
         self.n = vectors.shape[0]
@@ -86,7 +89,8 @@ class GpuHnswIndex:
         desc = _lib.HnswDesc(self.n, manifest.vec_dim, DISTANCES[manifest.distance], nl, int(entry) & 0xFFFFFFFF,
                              size.ctypes.data_as(_lib.u32p), width.ctypes.data_as(_lib.i32p), node_ptrs, nbr_ptrs)
         h = C.c_void_p()
-        check(_lib.lib().cz_hnsw_index_create(C.byref(desc), ptr(vectors), C.byref(h)))
+        create = _lib.lib().cz_hnsw_index_create_f64 if manifest.dtype == "F64" else _lib.lib().cz_hnsw_index_create
+        check(create(C.byref(desc), ptr(vectors), C.byref(h)))
         self._h = h
 
     @classmethod
@@ -272,8 +276,10 @@ class GpuHnswIndex:
     def hnsw_knn_batch(self, queries: np.ndarray, config: HnswSearch, poison: Optional[np.ndarray] = None,
                        with_n_dist: bool = False):
         """Returns (ids [B][kk], dist [B][kk] f64, count [B]) with kk = ef if a filter follows else k
-        (hnsw.rs:943-947), rows ascending by distance; optionally the per-query distance-evaluation count."""
-        q = np.ascontiguousarray(queries, dtype=np.float32)
+        (hnsw.rs:943-947), rows ascending by distance; optionally the per-query distance-evaluation count.
+        The query is converted to the index' element type first (hnsw.rs:879-884)."""
+        f64 = getattr(self, "_np", np.float32) is np.float64
+        q = np.ascontiguousarray(queries, dtype=np.float64 if f64 else np.float32)
         if q.ndim == 1:
             q = q[None, :]
         if q.shape[1] != self.manifest.vec_dim:
@@ -284,9 +290,9 @@ class GpuHnswIndex:
         dist = np.empty((B, kk), dtype=np.float64)
         cnt = np.empty(B, dtype=np.uint32)
         nd = np.zeros(B, dtype=np.uint64) if with_n_dist else None
-        check(_lib.lib().cz_hnsw_search_batch(self._h, ptr(q), B, kk, config.ef, int(config.radius is not None),
-                                              float(config.radius or 0.0), ptr(ids), ptr(dist), ptr(cnt), ptr(nd),
-                                              ptr(poison), 0, None))
+        search = _lib.lib().cz_hnsw_search_batch_f64 if f64 else _lib.lib().cz_hnsw_search_batch
+        check(search(self._h, ptr(q), B, kk, config.ef, int(config.radius is not None), float(config.radius or 0.0), ptr(ids), ptr(dist),
+                     ptr(cnt), ptr(nd), ptr(poison), 0, None))
         return (ids, dist, cnt, nd) if with_n_dist else (ids, dist, cnt)
 
     # ---- filtered search with the comparisons on the device (cz_hnsw_search_filtered) ----
@@ -309,7 +315,8 @@ class GpuHnswIndex:
         """hnsw_knn with a filter that is a conjunction of `column OP constant` (predicates = [(DeviceColumn, op, constant)],
         op in < <= == >= > !=, constant int or float): all ef candidates are filtered on the device, k rows come back
         (hnsw.rs:943-947, 997-1006)."""
-        q = np.ascontiguousarray(queries, dtype=np.float32)
+        f64 = getattr(self, "_np", np.float32) is np.float64
+        q = np.ascontiguousarray(queries, dtype=np.float64 if f64 else np.float32)
         if q.ndim == 1:
             q = q[None, :]
         if q.shape[1] != self.manifest.vec_dim:
@@ -324,7 +331,7 @@ class GpuHnswIndex:
         dist = np.empty((B, config.k), dtype=np.float64)
         cnt = np.empty(B, dtype=np.uint32)
         nd = np.zeros(B, dtype=np.uint64) if with_n_dist else None
-        check(_lib.lib().cz_hnsw_search_filtered(self._h, ptr(q), B, config.k, config.ef, int(config.radius is not None),
+        check((_lib.lib().cz_hnsw_search_filtered_f64 if f64 else _lib.lib().cz_hnsw_search_filtered)(self._h, ptr(q), B, config.k, config.ef, int(config.radius is not None),
                                                  float(config.radius or 0.0), arr, len(predicates), ptr(ids), ptr(dist),
                                                  ptr(cnt), ptr(nd), None, 0, None))
         return (ids, dist, cnt, nd) if with_n_dist else (ids, dist, cnt)
@@ -388,6 +395,19 @@ def distance_batch(distance: str, base: np.ndarray, queries: np.ndarray, pairs: 
     out = np.empty(pairs.shape[0], dtype=np.float64)
     check(_lib.lib().cz_distance_batch(DISTANCES[distance], ptr(base), base.shape[0], base.shape[1], ptr(queries),
                                        queries.shape[0], ptr(pairs), pairs.shape[0], ptr(out), 0, None))
+    return out
+
+
+def distance_batch_f64(distance: str, base: np.ndarray, queries: np.ndarray, pairs: np.ndarray) -> np.ndarray:
+    """VectorCache::dist's F64 arms (hnsw.rs:73-78, 86-95, 102-106) over (query row, base row) pairs of f64 vectors"""
+    base = np.ascontiguousarray(base, dtype=np.float64)
+    queries = np.ascontiguousarray(queries, dtype=np.float64)
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32)
+    if base.shape[1] != queries.shape[1]:
+        raise ValueError("requires two vectors of the same length")
+    out = np.empty(pairs.shape[0], dtype=np.float64)
+    check(_lib.lib().cz_distance_batch_f64(DISTANCES[distance], ptr(base), base.shape[0], base.shape[1], ptr(queries),
+                                           queries.shape[0], ptr(pairs), pairs.shape[0], ptr(out), 0, None))
     return out
 
 

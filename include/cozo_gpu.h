@@ -116,6 +116,12 @@ typedef struct cz_hnsw_index cz_hnsw_index;
 
 /* Upload an index (host pointers).  vectors: f32 [n][dim] row-major (Vector::F32, data/value.rs:207-213). */
 int cz_hnsw_index_create(const cz_hnsw_desc *desc, const float *vectors, cz_hnsw_index **out);
+/* The same for an index of f64 vectors (VecElementType::F64, parse/sys.rs; Vector::F64, data/value.rs:207-213): vectors f64
+ * [n][dim].  Such a handle is SEARCHED on the device (cz_hnsw_search_batch_f64 / _filtered_f64: VectorCache::dist's F64 arms,
+ * runtime/hnsw.rs:73-78, 86-95, 102-106 -- every dot product and the final arithmetic in f64); cz_hnsw_insert / _remove /
+ * cz_knn_bruteforce / cz_hnsw_index_export_vectors refuse it (CZ_E_UNSUPPORTED: F64 indices are built and maintained by the
+ * reference's CPU path and uploaded from their stored rows). */
+int cz_hnsw_index_create_f64(const cz_hnsw_desc *desc, const double *vectors, cz_hnsw_index **out);
 void cz_hnsw_index_destroy(cz_hnsw_index *ix);
 /* device bytes held by the index (vectors + link tables) */
 uint64_t cz_hnsw_index_bytes(const cz_hnsw_index *ix);
@@ -194,6 +200,12 @@ int cz_hnsw_index_export_degrees(const cz_hnsw_index *ix, int32_t level, double 
 int cz_hnsw_search_batch(cz_hnsw_index *ix, const float *queries, uint32_t B, uint32_t k, uint32_t ef,
                          int has_radius, double radius, uint32_t *out_ids, double *out_dist, uint32_t *out_count,
                          uint64_t *out_n_dist, const volatile uint8_t *poison, uint32_t flags, void *stream);
+/* queries [B][dim] f64 on an index created with cz_hnsw_index_create_f64.  The reference converts a query to the index' element type
+ * before it searches (hnsw.rs:879-884: `x as f64` / `x as f32` per element): that cast is the caller's; either entry point
+ * refuses an index of the other element type (CZ_E_INVALID). */
+int cz_hnsw_search_batch_f64(cz_hnsw_index *ix, const double *queries, uint32_t B, uint32_t k, uint32_t ef, int has_radius,
+                             double radius, uint32_t *out_ids, double *out_dist, uint32_t *out_count, uint64_t *out_n_dist,
+                             const volatile uint8_t *poison, uint32_t flags, void *stream);
 
 /* Filtered search with the filter on the device.  The reference keeps all ef candidates when a
  * filter is present, walks them in ascending distance -- radius cut, fetch the row, bind columns, filter bytecode -- and
@@ -222,12 +234,19 @@ int cz_hnsw_search_filtered(cz_hnsw_index *ix, const float *queries, uint32_t B,
                             double radius, const cz_predicate *preds, uint32_t n_preds, uint32_t *out_ids, double *out_dist,
                             uint32_t *out_count, uint64_t *out_n_dist, const volatile uint8_t *poison, uint32_t flags,
                             void *stream);
+int cz_hnsw_search_filtered_f64(cz_hnsw_index *ix, const double *queries, uint32_t B, uint32_t k, uint32_t ef, int has_radius,
+                                double radius, const cz_predicate *preds, uint32_t n_preds, uint32_t *out_ids, double *out_dist,
+                                uint32_t *out_count, uint64_t *out_n_dist, const volatile uint8_t *poison, uint32_t flags,
+                                void *stream);
 
 /* VectorCache::dist (runtime/hnsw.rs:66-109) == op_l2_dist / op_cos_dist / op_ip_dist
  * (data/functions.rs:2185-2255) over P (query, node) pairs:
  *   base [n][dim], queries [nq][dim], pairs [P][2] = (query row, base row), out [P] f64  [all dev-able] */
 int cz_distance_batch(int metric, const float *base, uint32_t n, uint32_t dim, const float *queries, uint32_t nq,
                       const uint32_t *pairs, uint64_t P, double *out, uint32_t flags, void *stream);
+/* the F64 arms of VectorCache::dist (hnsw.rs:73-78, 86-95, 102-106): base / queries f64, every dot product in f64 */
+int cz_distance_batch_f64(int metric, const double *base, uint32_t n, uint32_t dim, const double *queries, uint32_t nq,
+                          const uint32_t *pairs, uint64_t P, double *out, uint32_t flags, void *stream);
 
 /* exact k-NN by exhaustive scan over an uploaded index' vectors (recall ground truth; the "query batch
  * turns distance into a dense GEMM" case).  Same outputs as cz_hnsw_search_batch.  flags: CZ_DEVICE_PTRS,

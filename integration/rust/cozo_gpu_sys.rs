@@ -117,6 +117,7 @@ extern "C" {
                             out: *mut c_float) -> c_int;
 
     pub fn cz_hnsw_index_create(desc: *const cz_hnsw_desc, vectors: *const c_float, out: *mut *mut cz_hnsw_index) -> c_int;
+    pub fn cz_hnsw_index_create_f64(desc: *const cz_hnsw_desc, vectors: *const c_double, out: *mut *mut cz_hnsw_index) -> c_int;
     pub fn cz_hnsw_index_destroy(ix: *mut cz_hnsw_index);
     pub fn cz_hnsw_index_bytes(ix: *const cz_hnsw_index) -> u64;
     pub fn cz_hnsw_index_probe(ix: *const cz_hnsw_index, n_fetch: u64, reps: u32, stream_gbs: *mut c_double, row_fetch_gbs: *mut c_double) -> c_int;
@@ -133,6 +134,11 @@ extern "C" {
     pub fn cz_hnsw_search_batch(ix: *mut cz_hnsw_index, queries: *const c_float, b: u32, k: u32, ef: u32, has_radius: c_int,
                                 radius: c_double, out_ids: *mut u32, out_dist: *mut c_double, out_count: *mut u32,
                                 out_n_dist: *mut u64, poison: *const u8, flags: u32, stream: *mut c_void) -> c_int;
+    pub fn cz_hnsw_search_batch_f64(ix: *mut cz_hnsw_index, queries: *const c_double, b: u32, k: u32, ef: u32, has_radius: c_int,
+                                    radius: c_double, out_ids: *mut u32, out_dist: *mut c_double, out_count: *mut u32,
+                                    out_n_dist: *mut u64, poison: *const u8, flags: u32, stream: *mut c_void) -> c_int;
+    pub fn cz_distance_batch_f64(metric: c_int, base: *const c_double, n: u32, dim: u32, queries: *const c_double, nq: u32,
+                                 pairs: *const u32, p: u64, out: *mut c_double, flags: u32, stream: *mut c_void) -> c_int;
     pub fn cz_distance_batch(metric: c_int, base: *const c_float, n: u32, dim: u32, queries: *const c_float, nq: u32,
                              pairs: *const u32, p: u64, out: *mut c_double, flags: u32, stream: *mut c_void) -> c_int;
     pub fn cz_knn_bruteforce(ix: *mut cz_hnsw_index, queries: *const c_float, b: u32, k: u32, out_ids: *mut u32,
@@ -175,6 +181,10 @@ extern "C" {
                                    radius: c_double, preds: *const cz_predicate, n_preds: u32, out_ids: *mut u32,
                                    out_dist: *mut c_double, out_count: *mut u32, out_n_dist: *mut u64, poison: *const u8,
                                    flags: u32, stream: *mut c_void) -> c_int;
+    pub fn cz_hnsw_search_filtered_f64(ix: *mut cz_hnsw_index, queries: *const c_double, b: u32, k: u32, ef: u32, has_radius: c_int,
+                                       radius: c_double, preds: *const cz_predicate, n_preds: u32, out_ids: *mut u32,
+                                       out_dist: *mut c_double, out_count: *mut u32, out_n_dist: *mut u64, poison: *const u8,
+                                       flags: u32, stream: *mut c_void) -> c_int;
     pub fn cz_pagerank_plan_nodes(p: *const cz_pagerank_plan) -> u32;
 
     // multi-GPU, one node (RCCL over xGMI)

@@ -84,7 +84,17 @@ typedef struct {
     const uint32_t *const *level_nodes; /* [n_levels] -> ids ascending (level 0 may be NULL = identity) */
     const uint32_t *const *level_nbrs;  /* [n_levels] -> [size][width] */
     uint32_t entry;
+    const double *vectors64; /* an F64 index (VecElementType::F64): [n][dim] f64, `vectors` unused; queries are then f64 rows behind
+                                the float pointers of orc_hnsw_knn / orc_hnsw_knn_batch */
 } orc_flat_index;
+
+/* VectorCache::dist, the F64 arms (runtime/hnsw.rs:73-78, 86-95, 102-106): every dot product in f64 -- ndarray's unrolled_dot
+ * (ORC_DOT_NDARRAY) or the HIP kernels' tree over 16-byte chunks of two doubles (ORC_DOT_GPU, cozo_amd/csrc/distance_f64.cuh) */
+double orc_dot_ndarray_f64(const double *a, const double *b, size_t n);
+double orc_dot_gpu_f64(const double *a, const double *b, int dim);
+double orc_distance_f64(int metric, int dot_mode, const double *a, const double *b, int dim);
+void orc_distance_pairs_f64(int metric, int dot_mode, const double *base, const double *queries, int dim, const uint32_t *pairs,
+                            uint64_t P, double *out);
 
 /* returns number of results (<= k), ascending distance; n_dist accumulates distance evaluations */
 int orc_hnsw_knn(const orc_flat_index *ix, const float *q, int k, int ef, int has_radius, double radius,

@@ -48,6 +48,7 @@ class _FlatIndex(C.Structure):
         ("level_nodes", C.POINTER(_u32p)),
         ("level_nbrs", C.POINTER(_u32p)),
         ("entry", C.c_uint32),
+        ("vectors64", C.POINTER(C.c_double)),
     ]
 
 
@@ -157,6 +158,21 @@ def distance(metric: int, a, b, dot_mode: int = DOT_NDARRAY) -> float:
     return float(lib().orc_distance(metric, dot_mode, _p(a, _f32p), _p(b, _f32p), a.size))
 
 
+def distance_pairs_f64(metric: int, base, queries, pairs, dot_mode: int = DOT_NDARRAY) -> np.ndarray:
+    """VectorCache::dist's F64 arms over (query row, base row) pairs"""
+    base = np.ascontiguousarray(base, dtype=np.float64)
+    queries = np.ascontiguousarray(queries, dtype=np.float64)
+    pairs = _u32(pairs)
+    out = np.empty(pairs.shape[0], dtype=np.float64)
+    f64p = C.POINTER(C.c_double)
+    fn = lib().orc_distance_pairs_f64
+    fn.restype = None
+    fn.argtypes = [C.c_int, C.c_int, f64p, f64p, C.c_int, _u32p, C.c_uint64, f64p]
+    fn(metric, dot_mode, base.ctypes.data_as(f64p), queries.ctypes.data_as(f64p), base.shape[1], _p(pairs, _u32p), pairs.shape[0],
+       out.ctypes.data_as(f64p))
+    return out
+
+
 def distance_pairs(metric: int, base, queries, pairs, dot_mode: int = DOT_NDARRAY) -> np.ndarray:
     base, queries, pairs = _f32(base), _f32(queries), _u32(pairs)
     out = np.empty(pairs.shape[0], dtype=np.float64)
@@ -178,8 +194,10 @@ def random_levels(n: int, m: int, seed: int) -> np.ndarray:
 class FlatIndex:
     """The flat HNSW layout handed to both the oracle search and libcozo_gpu (include/cozo_gpu.h)."""
 
-    def __init__(self, vectors, metric, level_nodes, level_nbrs, entry):
-        self.vectors = _f32(vectors)
+    def __init__(self, vectors, metric, level_nodes, level_nbrs, entry, f64=False):
+        """f64: an index of f64 vectors (VecElementType::F64): distances by VectorCache::dist's F64 arms, queries are f64 rows"""
+        self.f64 = bool(f64)
+        self.vectors = np.ascontiguousarray(vectors, dtype=np.float64) if self.f64 else _f32(vectors)
         self.n, self.dim = self.vectors.shape
         self.metric = metric
         self.level_nodes = [_u32(x) for x in level_nodes]
@@ -192,20 +210,23 @@ class FlatIndex:
     def _cstruct(self, dot_mode):
         nodes = (_u32p * max(self.n_levels, 1))(*[_p(x, _u32p) for x in self.level_nodes])
         nbrs = (_u32p * max(self.n_levels, 1))(*[_p(x, _u32p) for x in self.level_nbrs])
-        s = _FlatIndex(self.n, self.dim, self.metric, dot_mode, _p(self.vectors, _f32p), self.n_levels,
-                       _p(self.level_size, _u32p), _p(self.level_width, _i32p), nodes, nbrs, self.entry)
+        f64p = C.POINTER(C.c_double)
+        s = _FlatIndex(self.n, self.dim, self.metric, dot_mode, None if self.f64 else _p(self.vectors, _f32p), self.n_levels,
+                       _p(self.level_size, _u32p), _p(self.level_width, _i32p), nodes, nbrs, self.entry,
+                       self.vectors.ctypes.data_as(f64p) if self.f64 else f64p())
         s._keep = (nodes, nbrs)
         return s
 
     def knn_batch(self, queries, k, ef, radius=None, dot_mode=DOT_NDARRAY, threads=1):
-        queries = _f32(queries)
+        # (the query is converted to the index' element type before the search, runtime/hnsw.rs:879-884)
+        queries = np.ascontiguousarray(queries, dtype=np.float64) if self.f64 else _f32(queries)
         B = queries.shape[0]
         ids = np.empty((B, k), dtype=np.uint32)
         dist = np.empty((B, k), dtype=np.float64)
         cnt = np.empty(B, dtype=np.uint32)
         nd = C.c_uint64(0)
         s = self._cstruct(dot_mode)
-        lib().orc_hnsw_knn_batch(C.byref(s), _p(queries, _f32p), B, k, ef, int(radius is not None),
+        lib().orc_hnsw_knn_batch(C.byref(s), queries.ctypes.data_as(_f32p), B, k, ef, int(radius is not None),
                                  float(radius or 0.0), _p(ids, _u32p), _p(dist, _f64p), _p(cnt, _u32p), C.byref(nd),
                                  threads)
         return ids, dist, cnt, nd.value

@@ -361,3 +361,85 @@ def test_filtered_search_predicates_on_the_device(case, oracle):
             assert (ids[b, len(keep):] == 0xFFFFFFFF).all()
     ci.close()
     cf.close()
+
+
+# ---- F64 vectors (VecElementType::F64): VectorCache::dist's F64 arms and hnsw_knn over them --------------
+@pytest.mark.parametrize("dim", [1, 2, 7, 8, 9, 31, 33, 64, 128, 130, 768, 1536])
+@pytest.mark.parametrize("name,metric", METRICS)
+def test_distance_batch_f64_matches_oracle(gpu_lib, oracle, dim, name, metric):
+    """bit-equal to the oracle's restatement of the kernel's summation tree (two doubles per chunk), and within 1e-12 of the
+    reference's arithmetic (ndarray's unrolled_dot in f64) wherever the value is not the difference of much larger terms"""
+    from cozo_amd.hnsw import distance_batch_f64
+    rng = np.random.default_rng(dim * 11 + metric)
+    base = rng.standard_normal((200, dim))
+    q = rng.standard_normal((13, dim))
+    base[5] = 0.0  # a zero vector: cosine -> NaN (hnsw.rs:86-95 divides by sqrt(0))
+    pairs = np.stack([rng.integers(0, 13, 1500), rng.integers(0, 200, 1500)], 1).astype(np.uint32)
+    got = distance_batch_f64(name, base, q, pairs)
+    exact = oracle.distance_pairs_f64(metric, base, q, pairs, oracle.DOT_GPU)
+    ref = oracle.distance_pairs_f64(metric, base, q, pairs, oracle.DOT_NDARRAY)
+    assert np.array_equal(got, exact, equal_nan=True), "kernel summation tree differs from its CPU restatement"
+    a, b = q[pairs[:, 0]], base[pairs[:, 1]]
+    mag = {0: np.sum((a - b) ** 2, axis=1), 1: np.ones(len(ref)), 2: 1.0 + np.sum(np.abs(a * b), axis=1)}[metric]
+    finite = np.isfinite(ref)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.max(np.abs(got - ref)[finite] / np.maximum(mag[finite], 1e-300)) <= 1e-12
+
+
+@pytest.mark.parametrize("dim,dist,metric", [(7, "L2", 0), (128, "Cosine", 1), (768, "Cosine", 1), (33, "IP", 2)])
+def test_hnsw_knn_f64_index_matches_oracle(gpu_lib, oracle, dim, dist, metric):
+    """an index of f64 vectors searched on the device: ids, f64 distances, counts and evaluation counts equal the oracle's
+    hnsw_knn over the same tables with the F64 arms of VectorCache::dist (kernel summation order); f32 queries are converted
+    to the index' element type (hnsw.rs:879-884); radius and device-side predicates work as on an f32 index; the f32 entry
+    points refuse the handle, and so do build / insert / remove / the exhaustive scan."""
+    from cozo_amd import _lib
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest, HnswSearch
+    n, m = 3000, 8
+    rng = np.random.default_rng(dim)
+    x = rng.standard_normal((n, dim))            # f64 vectors that are NOT representable in f32
+    b = oracle.HnswBuilder(dim, metric, m, 40)
+    b.insert(x.astype(np.float32), oracle.random_levels(n, m, 3))   # any graph will do: the tables of an f32 build
+    f32flat = b.export()
+    flat = oracle.FlatIndex(x, metric, f32flat.level_nodes, f32flat.level_nbrs, f32flat.entry, f64=True)
+    man = HnswIndexManifest(vec_dim=dim, distance=dist, m_neighbours=m, dtype="F64")
+    g = GpuHnswIndex(man, x, [None] + flat.level_nodes[1:], flat.level_nbrs, flat.entry)
+    q = rng.standard_normal((40, dim))
+    for k, ef in [(10, 32), (1, 1), (5, 200)]:
+        ids, dd, cnt, nd = g.hnsw_knn_batch(q, HnswSearch(k=k, ef=ef), with_n_dist=True)
+        oids, odd, ocnt, ond = flat.knn_batch(q, k, ef, dot_mode=oracle.DOT_GPU)
+        assert np.array_equal(ids, oids) and np.array_equal(dd, odd) and np.array_equal(cnt, ocnt)
+        assert int(nd.sum()) == ond
+        rids, rdd, _, _ = flat.knn_batch(q, k, ef, dot_mode=oracle.DOT_NDARRAY)
+        same = (ids == rids).all(axis=1)
+        assert same.mean() >= 0.9
+        assert np.max(np.abs(dd[same] - rdd[same]) / np.maximum(np.abs(rdd[same]), 1e-9)) <= 1e-9
+    # an f32 query is widened, not the index narrowed
+    q32 = q.astype(np.float32)
+    ids32, dd32, _ = g.hnsw_knn_batch(q32, HnswSearch(k=5, ef=32))
+    oids32, odd32, _, _ = flat.knn_batch(q32.astype(np.float64), 5, 32, dot_mode=oracle.DOT_GPU)
+    assert np.array_equal(ids32, oids32) and np.array_equal(dd32, odd32)
+    # radius
+    r = float(np.median(dd[:, -1]))
+    ids_r, dd_r, cnt_r = g.hnsw_knn_batch(q, HnswSearch(k=5, ef=200, radius=r))
+    oids_r, odd_r, ocnt_r, _ = flat.knn_batch(q, 5, 200, radius=r, dot_mode=oracle.DOT_GPU)
+    assert np.array_equal(cnt_r, ocnt_r) and np.array_equal(ids_r, oids_r)
+    # predicates on the device
+    col = g.upload_column(np.arange(n, dtype=np.int64))
+    fids, fdd, fcnt = g.hnsw_knn_batch_filtered(q, HnswSearch(k=5, ef=64), [(col, "<", n // 2)])
+    aids, add_, acnt, _ = flat.knn_batch(q, 64, 64, dot_mode=oracle.DOT_GPU)
+    for i in range(len(q)):
+        keep = [j for j in range(acnt[i]) if aids[i, j] < n // 2][:5]
+        assert fcnt[i] == len(keep) and np.array_equal(fids[i, :len(keep)], aids[i, keep])
+    # the other element type's entry points refuse the handle
+    L = _lib.lib()
+    out_i = np.empty((1, 1), np.uint32); out_d = np.empty((1, 1), np.float64); out_c = np.empty(1, np.uint32)
+    rc = L.cz_hnsw_search_batch(g._h, _lib.ptr(q32[:1].copy()), 1, 1, 1, 0, 0.0, _lib.ptr(out_i), _lib.ptr(out_d), _lib.ptr(out_c), None, None, 0, None)
+    assert rc == _lib.CZ_E_INVALID
+    with pytest.raises(_lib.CozoGpuError):
+        g.insert(x[:1].astype(np.float32))
+    with pytest.raises(_lib.CozoGpuError):
+        g.bruteforce_knn(q32, 3)
+    g32 = GpuHnswIndex(HnswIndexManifest(vec_dim=dim, distance=dist, m_neighbours=m), x.astype(np.float32), [None] + flat.level_nodes[1:],
+                       flat.level_nbrs, flat.entry)
+    rc = L.cz_hnsw_search_batch_f64(g32._h, _lib.ptr(q[:1].copy()), 1, 1, 1, 0, 0.0, _lib.ptr(out_i), _lib.ptr(out_d), _lib.ptr(out_c), None, None, 0, None)
+    assert rc == _lib.CZ_E_INVALID
