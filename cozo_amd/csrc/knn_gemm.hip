@@ -12,6 +12,8 @@
 // Used by cz_knn_bruteforce when the caller passes CZ_BF_GEMM (bench.py's recall ground truth); the default remains
 // the streaming kernel whose summation tree equals the search kernel's.
 #include <algorithm>
+#include <cstdlib>
+#include <vector>
 
 #include "common.h"
 #include "hnsw_index.h"
@@ -45,14 +47,41 @@ row_norms_seq_kernel(const float *__restrict__ x, uint32_t n, uint32_t ld, float
 
 // C[m][n] = sum_k A[m][k] * B[n][k]; A [M][ld], B [N][ld] row-major, ld a multiple of 4 (zero padded);
 // 256 threads = 4 waves, wave (wm, wn) owns a 64 x 64 quadrant = 2 x 2 MFMA tiles of 32 x 32
+// FILTER = false: C[m][n] is written (the first stretch of columns, from which bf_select_kernel takes the lists that set the
+// thresholds).  FILTER = true: nothing is written but the few products that can still enter a query's list -- the GEMM's epilogue
+// compares every score (dot, or dot / |x| for Cosine: both distances fall as it rises) with the query's threshold `need` (the score
+// of its k-th nearest so far, less a margin two orders above the rounding of the f32 score: see bf_need_kernel) and appends the
+// survivors (column, dot) to the query's candidate list.  After a sample of n0 columns a later stretch of c columns leaves about
+// k * c / n0 survivors per query, so the B x N products never reach memory: the selection that cost as much as the GEMM (a 1 GiB
+// slab of products written, then read back) is gone.  NaN passes the filter.
+struct CandOut {
+    const float *need;    // [M] score threshold per query
+    const float *xnorm;   // [n] squared norms of the base rows (Cosine), or null
+    uint32_t col_base;    // id of column 0 of Bm
+    uint32_t *cnt;        // [M] candidates appended per query (may run past cap: the caller checks)
+    uint32_t *col;        // [M][cap]
+    float *dot;           // [M][cap]
+    uint32_t cap;
+};
+template <bool FILTER>
 __global__ void __launch_bounds__(256)
 dot_gemm_mfma_kernel(const float *__restrict__ A, uint32_t M, const float *__restrict__ Bm, uint32_t N, uint32_t ld,
-                     float *__restrict__ C, uint64_t ldc) {
+                     float *__restrict__ C, uint64_t ldc, CandOut co) {
     __shared__ float As[BM * LDP];
     __shared__ float Bs[BN * LDP];
+    __shared__ float need_s[BM];
+    if (FILTER && threadIdx.x < BM) {
+        const uint32_t qrow = (blockIdx.x % ((M + BM - 1) / BM)) * BM + threadIdx.x;
+        need_s[threadIdx.x] = qrow < M ? co.need[qrow] : 0.f;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const uint32_t m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // FILTER: a 1-D grid with the QUERY tiles fastest -- the workgroups that share a tile of base rows are neighbours in
+    // dispatch order and run at the same time, so the tile comes out of HBM once (the other XCDs find it in the Infinity
+    // Cache); with the column tiles fastest every base row was fetched once per query tile, B / 128 times
+    const uint32_t ny = (M + BM - 1) / BM;
+    const uint32_t by = FILTER ? blockIdx.x % ny : blockIdx.y, bx = FILTER ? blockIdx.x / ny : blockIdx.x;
+    const uint32_t m0 = by * BM, n0 = bx * BN;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -104,6 +133,28 @@ dot_gemm_mfma_kernel(const float *__restrict__ A, uint32_t M, const float *__res
         __syncthreads();
     }
     // accumulator layout: register r of lane l is C[row = 8 (r / 4) + 4 (l / 32) + r % 4][col = l % 32] of the tile
+    if constexpr (FILTER) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t col = n0 + wn * 64 + j * 32 + (lane & 31);
+            const bool col_ok = col < N;
+            const float rs = (col_ok && co.xnorm) ? rsqrtf(co.xnorm[co.col_base + col]) : 1.0f;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const uint32_t rl = wm * 64 + i * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                    const float v = acc[i][j][r];
+                    if (col_ok && m0 + rl < M && !(v * rs < need_s[rl])) {  // (a handful per query and stretch: the atomics are rare)
+                        const uint32_t at = atomicAdd(&co.cnt[m0 + rl], 1u);
+                        if (at < co.cap) {
+                            co.col[(size_t)(m0 + rl) * co.cap + at] = co.col_base + col;
+                            co.dot[(size_t)(m0 + rl) * co.cap + at] = v;
+                        }
+                    }
+                }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -115,6 +166,62 @@ dot_gemm_mfma_kernel(const float *__restrict__ A, uint32_t M, const float *__res
                 if (row < M && col < N) C[(size_t)row * ldc + col] = acc[i][j][r];
             }
         }
+    }
+}
+
+// the score a column has to reach to enter query q's list, from the list so far (ids / dist [B][k] ascending, CZ_NONE padded):
+// its k-th distance d gives s = 1 - d (IP) or (1 - d) * |q| (Cosine: dot / |x|), lowered by 1e-4 relative -- two orders above the
+// rounding of the f32 score -- and rounded DOWN to f32; a list that is not full yet (or ends in NaN) lets everything through
+__global__ void __launch_bounds__(256)
+bf_need_kernel(int metric, const uint32_t *__restrict__ ids, const double *__restrict__ dist, uint32_t B, uint32_t k,
+               const float *__restrict__ qnorm, float *__restrict__ need) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= B) return;
+    float nd = -__builtin_inff();
+    const double d = dist[(size_t)q * k + k - 1];
+    if (ids[(size_t)q * k + k - 1] != CZ_NONE && d == d) {
+        const double sk = metric == CZ_COSINE ? (1.0 - d) * sqrt((double)qnorm[q]) : (1.0 - d);
+        const double lim = sk - 1e-4 * fabs(sk) - 1e-30;
+        nd = __double2float_rd(lim);
+    }
+    need[q] = nd;
+}
+
+// one query's candidates -> its k nearest among them, as one more partial list (slot `part` of total_parts)
+__global__ void __launch_bounds__(256)
+bf_cand_kernel(int metric, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ col, const float *__restrict__ dot, uint32_t cap,
+               const float *__restrict__ xnorm, const float *__restrict__ qnorm, uint32_t k, uint32_t part, uint32_t total_parts,
+               uint64_t *__restrict__ part_key, uint32_t *__restrict__ part_id) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint64_t *ckey = (uint64_t *)smem_raw;      // [256]
+    uint32_t *cid = (uint32_t *)(ckey + 256);    // [256]
+    uint64_t *tkey = (uint64_t *)(cid + 256);    // [k]
+    uint32_t *tid_ = (uint32_t *)(tkey + k);
+    const int tid = threadIdx.x;
+    const uint32_t qi = blockIdx.x;
+    for (uint32_t i = tid; i < k; i += 256) {
+        tkey[i] = ~0ull;
+        tid_[i] = CZ_NONE;
+    }
+    const uint32_t n = min(cnt[qi], cap);
+    const float qn = metric == CZ_COSINE ? qnorm[qi] : 0.f;
+    int tcnt = 0;
+    __syncthreads();
+    for (uint32_t p0 = 0; p0 < n; p0 += 256) {
+        const uint32_t p = p0 + tid;
+        if (p < n) {
+            const uint32_t c = col[(size_t)qi * cap + p];
+            const float bn = metric == CZ_COSINE ? xnorm[c] : 0.f;
+            ckey[tid] = dist_key(finish_distance(metric, dot[(size_t)qi * cap + p], bn, qn));
+            cid[tid] = c;
+        }
+        tcnt = topk_merge_batch((int)min(256u, n - p0), ckey, cid, tkey, tid_, tcnt, (int)k);
+    }
+    const size_t o = ((size_t)qi * total_parts + part) * k;
+    for (uint32_t i = tid; i < k; i += 256) {
+        part_key[o + i] = tkey[i];
+        part_id[o + i] = tid_[i];
+    }
 }
 
 // per (column chunk, query): distances from the dot products, the k nearest of the chunk into the partial lists.
@@ -204,17 +311,53 @@ int knn_gemm_device(HnswIndex *ix, const float *d_q, uint32_t B, uint32_t k, uin
     if (ix->metric == CZ_L2)
         return set_error(CZ_E_UNSUPPORTED, "the GEMM form of the exhaustive scan serves Cosine and IP; L2 = dot(a - b, a - b) is not a GEMM");
     const uint32_t n = ix->n, ld = ix->ld;
-    // column slab: B x slab f32 dot products at a time (<= 1 GiB), chunks of 8192 columns for the selection
+    // Stage 0: the first `slab` columns as B x slab f32 dot products (<= 1 GiB), chunks of 8192 columns for the selection.
+    // Stages 1, 2, ...: stretches of up to 8 x the columns seen so far through the GEMM whose epilogue keeps only what can
+    // still enter a list (CandOut): about 8 k survivors per query and stage; 16 k + 1024 slots each, and a stage whose buffer
+    // overflows (data sorted towards the queries) is done again the stage-0 way.  CZ_BF_FUSE=0: every stretch the stage-0 way.
     const uint32_t cols_per_chunk = 8192;
     uint32_t slab = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(cols_per_chunk, ((1ull << 30) / 4 / B) / cols_per_chunk * cols_per_chunk));
+    if (const char *sl = getenv("CZ_BF_SLAB"))  // (tests: a small first stretch, so that small corpora go through the fused stages)
+        if (atoi(sl) > 0) slab = (uint32_t)std::min<uint64_t>(n, (uint64_t)atoi(sl));
     slab = (slab + BN - 1) / BN * BN;
-    const uint32_t total_chunks = (n + cols_per_chunk - 1) / cols_per_chunk;
-    DevBuf<float> dots, xnorm, qnorm, qpad;
+    const char *fuse_env = getenv("CZ_BF_FUSE");
+    const bool fuse = !(fuse_env && atoi(fuse_env) == 0);
+    // the plan: (begin, count, fused?) stretches
+    struct Stretch {
+        uint32_t c0, nc;
+        bool fused;
+    };
+    std::vector<Stretch> plan;
+    for (uint32_t c0 = 0; c0 < n;) {
+        if (c0 == 0 || !fuse) {
+            const uint32_t nc = std::min(slab, n - c0);
+            plan.push_back({c0, nc, false});
+            c0 += nc;
+        } else {
+            const uint32_t nc = (uint32_t)std::min<uint64_t>((uint64_t)n - c0, 8ull * c0);
+            plan.push_back({c0, nc, true});
+            c0 += nc;
+        }
+    }
+    // partial lists: one per 8192-column chunk of an unfused stretch, one per fused stretch (+ room to redo every fused
+    // stretch unfused)
+    auto parts_of = [&](uint32_t count) {  // lists an unfused pass over `count` columns writes: per slab, one per 8192-column chunk
+        uint32_t parts = 0;
+        for (uint32_t done = 0; done < count; done += slab) parts += (std::min(slab, count - done) + cols_per_chunk - 1) / cols_per_chunk;
+        return parts;
+    };
+    uint32_t total_parts = 0;
+    for (const Stretch &st : plan) total_parts += parts_of(st.nc) + (st.fused ? 1 : 0);
+    const uint32_t cap = 16 * k + 1024;
+    DevBuf<float> dots, xnorm, qnorm, qpad, need, cdot;
     DevBuf<uint64_t> pkey;
-    DevBuf<uint32_t> pid;
+    DevBuf<uint32_t> pid, ccnt, ccol, tids;
+    DevBuf<double> tdist;
     CZ_HIP(dots.alloc((size_t)B * slab));
-    CZ_HIP(pkey.alloc((size_t)B * total_chunks * k));
-    CZ_HIP(pid.alloc((size_t)B * total_chunks * k));
+    CZ_HIP(pkey.alloc((size_t)B * total_parts * k));
+    CZ_HIP(pid.alloc((size_t)B * total_parts * k));
+    CZ_HIP(hipMemsetAsync(pkey.p, 0xFF, (size_t)B * total_parts * k * 8, stream));  // empty lists: key ~0, id CZ_NONE
+    CZ_HIP(hipMemsetAsync(pid.p, 0xFF, (size_t)B * total_parts * k * 4, stream));
     const float *q = d_q;
     if (ld != ix->dim) {  // pad the queries like the base rows (zero tail)
         CZ_HIP(qpad.alloc((size_t)B * ld));
@@ -228,16 +371,56 @@ int knn_gemm_device(HnswIndex *ix, const float *d_q, uint32_t B, uint32_t k, uin
         hipLaunchKernelGGL(row_norms_seq_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ix->vec, n, ld, xnorm.p);
         hipLaunchKernelGGL(row_norms_seq_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, q, B, ld, qnorm.p);
     }
-    const size_t smem = (size_t)kSelCand * 12 + (size_t)k * 12 + 16;
-    for (uint32_t c0 = 0; c0 < n; c0 += slab) {
-        const uint32_t nc = std::min(slab, n - c0);
-        hipLaunchKernelGGL(dot_gemm_mfma_kernel, dim3((nc + BN - 1) / BN, (B + BM - 1) / BM), dim3(256), 0, stream, q, B,
-                           ix->vec + (size_t)c0 * ld, nc, ld, dots.p, (uint64_t)slab);
-        hipLaunchKernelGGL(bf_select_kernel, dim3((nc + cols_per_chunk - 1) / cols_per_chunk, B), dim3(256), smem, stream,
-                           ix->metric, dots.p, (uint64_t)slab, nc, c0, xnorm.p, qnorm.p, k, cols_per_chunk, c0 / cols_per_chunk,
-                           total_chunks, pkey.p, pid.p);
+    if (plan.size() > 1 && fuse) {
+        CZ_HIP(need.alloc(B));
+        CZ_HIP(ccnt.alloc(B));
+        CZ_HIP(ccol.alloc((size_t)B * cap));
+        CZ_HIP(cdot.alloc((size_t)B * cap));
+        CZ_HIP(tids.alloc((size_t)B * k));
+        CZ_HIP(tdist.alloc((size_t)B * k));
     }
-    merge(pkey.p, pid.p, B, total_chunks, k, d_ids, d_dist, stream);
+    const size_t smem = (size_t)kSelCand * 12 + (size_t)k * 12 + 16;
+    const size_t smem_cand = (size_t)256 * 12 + (size_t)k * 12 + 16;
+    uint32_t part = 0;
+    const CandOut none{nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0};
+    auto unfused = [&](uint32_t c_begin, uint32_t count) {  // GEMM -> products -> bf_select_kernel, a slab at a time
+        for (uint32_t c0 = c_begin; c0 < c_begin + count; c0 += slab) {
+            const uint32_t nc = std::min(slab, c_begin + count - c0);
+            const uint32_t chunks = (nc + cols_per_chunk - 1) / cols_per_chunk;
+            hipLaunchKernelGGL(dot_gemm_mfma_kernel<false>, dim3((nc + BN - 1) / BN, (B + BM - 1) / BM), dim3(256), 0, stream, q, B,
+                               ix->vec + (size_t)c0 * ld, nc, ld, dots.p, (uint64_t)slab, none);
+            hipLaunchKernelGGL(bf_select_kernel, dim3(chunks, B), dim3(256), smem, stream, ix->metric, dots.p, (uint64_t)slab, nc, c0,
+                               xnorm.p, qnorm.p, k, cols_per_chunk, part, total_parts, pkey.p, pid.p);
+            part += chunks;
+        }
+    };
+    for (const Stretch &st : plan) {
+        if (!st.fused) {
+            unfused(st.c0, st.nc);
+            continue;
+        }
+        // thresholds from everything seen so far
+        merge(pkey.p, pid.p, B, total_parts, k, tids.p, tdist.p, stream);
+        hipLaunchKernelGGL(bf_need_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, ix->metric, tids.p, tdist.p, B, k, qnorm.p, need.p);
+        CZ_HIP(hipMemsetAsync(ccnt.p, 0, (size_t)B * 4, stream));
+        const CandOut co{need.p, ix->metric == CZ_COSINE ? xnorm.p : nullptr, st.c0, ccnt.p, ccol.p, cdot.p, cap};
+        // (the grid's x extent is the column tiles: a stretch of up to ~9M columns = 70 k of them)
+        hipLaunchKernelGGL(dot_gemm_mfma_kernel<true>, dim3(((st.nc + BN - 1) / BN) * ((B + BM - 1) / BM)), dim3(256), 0, stream, q, B,
+                           ix->vec + (size_t)st.c0 * ld, st.nc, ld, (float *)nullptr, (uint64_t)0, co);
+        std::vector<uint32_t> h_cnt(B);
+        CZ_HIP(hipMemcpyAsync(h_cnt.data(), ccnt.p, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+        CZ_HIP(hipStreamSynchronize(stream));
+        uint32_t worst = 0;
+        for (uint32_t c : h_cnt) worst = std::max(worst, c);
+        if (worst > cap) {  // the buffer of some query ran over: this stretch again, the plain way (correct whatever the data)
+            unfused(st.c0, st.nc);
+            continue;
+        }
+        hipLaunchKernelGGL(bf_cand_kernel, dim3(B), dim3(256), smem_cand, stream, ix->metric, ccnt.p, ccol.p, cdot.p, cap, xnorm.p, qnorm.p, k,
+                           part, total_parts, pkey.p, pid.p);
+        part += 1;
+    }
+    merge(pkey.p, pid.p, B, total_parts, k, d_ids, d_dist, stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(CZ_E_HIP, "GEMM exhaustive scan launch: %s", hipGetErrorString(e));
     CZ_HIP(hipStreamSynchronize(stream));  // temporaries die with this scope

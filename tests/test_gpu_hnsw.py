@@ -176,6 +176,32 @@ def test_bruteforce_gemm_form_matches_sequential_chain_oracle(gpu_lib, oracle, n
         l2.bruteforce_knn(q, k, gemm=True)
 
 
+@pytest.mark.parametrize("name,metric", [("Cosine", 1), ("IP", 2)])
+@pytest.mark.parametrize("slab,k", [(256, 10), (1024, 3), (128, 100)])
+def test_bruteforce_gemm_fused_selection_stages(gpu_lib, oracle, monkeypatch, name, metric, slab, k):
+    """the exhaustive scan with the selection in the GEMM's epilogue (knn_gemm.hip): a first stretch of `slab` columns sets the
+    thresholds, later stretches keep only the products that can still enter a list.  A small first stretch (CZ_BF_SLAB) makes a
+    small corpus go through several fused stages; sorted-towards-the-query data overflows a stage's candidate buffer and takes
+    the fallback.  Bit-exact against the oracle (ORC_DOT_SEQ) either way, and equal to the unfused form (CZ_BF_FUSE = 0)."""
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest
+    n, dim, B = 9000, 48, 70
+    base = util.vectors(n, dim, 51, "normal")
+    q = util.vectors(B, dim, 52, "normal")
+    base[17] = 0.0  # a zero vector: Cosine NaN, passes every filter and sorts last
+    man = HnswIndexManifest(vec_dim=dim, distance=name, m_neighbours=8)
+    monkeypatch.setenv("CZ_BF_SLAB", str(slab))
+    for data in (base, base[np.argsort(-(base @ q[0]))[::-1]].copy()):  # random order; then ascending score for query 0: every column beats the list
+        ix = GpuHnswIndex(man, data, [None], [np.full((n, 16), 0xFFFFFFFF, dtype=np.uint32)], 0)
+        ids, dist = ix.bruteforce_knn(q, k, gemm=True)
+        oids, odist = oracle.bruteforce_knn(metric, data, q, k, dot_mode=oracle.DOT_SEQ)
+        assert np.array_equal(ids, oids) and np.array_equal(dist, odist, equal_nan=True)
+        monkeypatch.setenv("CZ_BF_FUSE", "0")
+        uids, udist = ix.bruteforce_knn(q, k, gemm=True)
+        monkeypatch.delenv("CZ_BF_FUSE")
+        assert np.array_equal(ids, uids) and np.array_equal(dist, udist, equal_nan=True)
+        ix.close()
+
+
 def test_search_is_reentrant_on_a_shared_index(case):
     """index handles are immutable after creation and shared by concurrent readers (one SessionTx per thread in the
     reference): four host threads search the same handle at once, every result equals the single-threaded one."""

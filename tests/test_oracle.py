@@ -453,3 +453,27 @@ def test_search_equals_the_literal_row_store(oracle, rows):
     for i in range(q.shape[0]):
         passed = [(int(v), float(d)) for v, d in zip(ids[i][:cnt[i]], dist[i][:cnt[i]]) if keep(int(v))][:4]
         assert passed == st.knn(q[i], 4, 25, accept=keep)
+
+
+def test_distance_f64_arms(oracle):
+    """VectorCache::dist's F64 arms (runtime/hnsw.rs:73-78, 86-95, 102-106): the known answers of runtime/tests.rs:693-694 in f64,
+    and both summation orders (ndarray's unrolled_dot, the HIP kernels' tree) against numpy float64 on random vectors"""
+    a, b = np.array([[1.0, 2.0]]), np.array([[2.0, 3.0]])
+    pairs = np.array([[0, 0]], dtype=np.uint32)
+    assert oracle.distance_pairs_f64(oracle.L2, b, a, pairs)[0] == 2.0
+    assert abs(oracle.distance_pairs_f64(oracle.COSINE, a, a, pairs)[0]) <= 1e-15
+    v = np.array([[0.6, 0.8]])
+    assert abs(oracle.distance_pairs_f64(oracle.IP, v, v, pairs)[0]) <= 1e-15
+    assert np.isnan(oracle.distance_pairs_f64(oracle.COSINE, np.zeros((1, 2)), a, pairs)[0])  # zero vector -> NaN
+    rng = np.random.default_rng(5)
+    for dim in (1, 2, 7, 8, 9, 128, 769, 1536):
+        base, q = rng.standard_normal((40, dim)), rng.standard_normal((6, dim))
+        pr = np.stack([rng.integers(0, 6, 200), rng.integers(0, 40, 200)], 1).astype(np.uint32)
+        x, y = q[pr[:, 0]], base[pr[:, 1]]
+        want = {oracle.L2: np.sum((x - y) ** 2, 1), oracle.COSINE: 1 - np.sum(x * y, 1) / np.sqrt(np.sum(x * x, 1) * np.sum(y * y, 1)),
+                oracle.IP: 1 - np.sum(x * y, 1)}
+        for metric in (oracle.L2, oracle.COSINE, oracle.IP):
+            for mode in (oracle.DOT_NDARRAY, oracle.DOT_GPU):
+                got = oracle.distance_pairs_f64(metric, base, q, pr, mode)
+                scale = 1.0 + np.sum(np.abs(x * y), 1) + (np.sum((x - y) ** 2, 1) if metric == oracle.L2 else 0.0)
+                assert np.max(np.abs(got - want[metric]) / scale) <= 1e-13, (dim, metric, mode)
