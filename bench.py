@@ -121,6 +121,7 @@ def parse():
     p.add_argument("--skip-cpu", action="store_true")
     p.add_argument("--skip-secondary", action="store_true", help="only the primary HNSW workload and the uniform PageRank graph")
     p.add_argument("--cpu-queries", type=int, default=256)
+    p.add_argument("--skip-clustered-10m", action="store_true", help="leave out the 10M x 768 index on BASELINE.md's 16-cluster corpus (a second 10M build)")
     p.add_argument("--no-reload", action="store_true", help="time the handle cz_hnsw_build returned instead of re-creating the index through cz_hnsw_index_create")
     p.add_argument("--index-cache", default=None, help="measurement scripts: directory holding built link tables between processes of one GPU call")
     return p.parse_args()
@@ -252,8 +253,19 @@ class HnswRun:
         self.ix.bruteforce_knn_device(q, self.k, gt, gtd, self.stream, gemm=True)  # B x N x d dot products as one f32 MFMA GEMM
         torch.cuda.synchronize()
         gt_s = time.time() - t0
+        if self.n >= 1_000_000:  # a second, warm call: what the exhaustive scan costs as a SEARCH (recall 1.0), beside the graph search
+            t0 = time.time()
+            self.ix.bruteforce_knn_device(q, self.k, gt, gtd, self.stream, gemm=True)
+            torch.cuda.synchronize()
+            gt_s = time.time() - t0
+        flops = 2.0 * q.shape[0] * self.n * self.dim
+        self.exact_scan = dict(ms_per_batch=gt_s * 1e3, queries_per_s=q.shape[0] / gt_s, recall_at_k=1.0,
+                               roofline=dict(bound="mfma", kernel="dot_gemm_mfma_kernel (selection in its epilogue)", achieved=flops / gt_s / 1e12,
+                                             peak=157.3, unit="TFLOP/s", frac=flops / gt_s / 1e12 / 157.3),
+                               what="cz_knn_bruteforce(CZ_BF_GEMM): B x N x d dot products on the f32 matrix cores, the k nearest kept by the "
+                                    "GEMM's epilogue; whole call incl. norms, thresholds and merges; this run's recall ground truth")
         log(f"exact ground truth over {self.n} vectors (GEMM form on the matrix cores): {gt_s * 1e3:.0f} ms, "
-            f"{2.0 * q.shape[0] * self.n * self.dim / gt_s / 1e12:.1f} TFLOP/s incl. selection")
+            f"{flops / gt_s / 1e12:.1f} TFLOP/s incl. selection")
         return gt.to(torch.int64) & 0xFFFFFFFF
 
     def search(self, ef, q=None):
@@ -339,7 +351,8 @@ def hnsw_secondary(args, torch, device, n, kind, steps, warmup):
         return dict(workload=f"HNSW k={args.k} cosine, {n} x {args.dim} f32 ({kind}), query batch={args.batch}, m={args.m}, "
                              f"ef_construction={args.ef_construction}", value=args.batch * steps / t["wall"], unit="queries/s",
                     ms_per_step=t["ms_per_step"], ef=ef, recall_at_k=rec, reached_recall_target=rec >= args.recall_target,
-                    n_dist_per_query=t["n_dist"] / args.batch, index_build_s=run.build_s, sweep=sweep, roofline=t["roofline"])
+                    n_dist_per_query=t["n_dist"] / args.batch, index_build_s=run.build_s, sweep=sweep, roofline=t["roofline"],
+                    exact_scan=getattr(run, "exact_scan", None))
     finally:
         run.close()
 
@@ -394,9 +407,39 @@ def bench_hnsw(args, torch, dist, rank, world, device):
         del ids_b, dd_b
     t = run.timed(ef, args.steps, args.warmup, dist, args.multi)
     t["roofline"]["traffic"] = pmc_traffic("hnsw_knn", world, t["roofline"]["algorithmic_bytes_per_launch"]) if args.dist == "lowrank" else None
-    res = dict(qps=world * B * args.steps / t["wall"], ms_per_step=t["ms_per_step"], ef=ef, recall=rec, clocks=getattr(run, "clocks", None),
+    ladder = None
+    if rank == 0 and not args.multi and not args.skip_secondary:
+        try:  # HnswSearchRA::iter hands over whatever the parent relation holds (query/ra.rs:1085-1121): latency / throughput against the batch
+            from cozo_amd.hnsw import HnswSearch
+            ladder = []
+            qall = gen_vectors(torch, 4096, dim, args.dist, 977, device)
+            for bb in (1, 8, 64, 256, 512, 1024, 1280, 2048, 4096):
+                qb = qall[:bb].contiguous()
+                ids_l = torch.empty((bb, k), dtype=torch.int32, device=device)
+                dd_l = torch.empty((bb, k), dtype=torch.float64, device=device)
+                cnt_l = torch.empty(bb, dtype=torch.int32, device=device)
+                nd_l = torch.zeros(bb, dtype=torch.int64, device=device)
+                go = lambda: run.ix.hnsw_knn_batch_device(qb, HnswSearch(k=k, ef=ef), ids_l, dd_l, cnt_l, nd_l, stream)  # noqa: E731
+                for _ in range(2):
+                    go()
+                torch.cuda.synchronize()
+                reps = 10 if bb <= 1024 else 4
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    go()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+                ladder.append(dict(batch=bb, ms=ms, queries_per_s=bb / ms * 1e3,
+                                   frac=float(nd_l.sum().item()) * 4 * dim / ms / 1e6 / HBM_PEAK_GBS))
+            del qall
+        except Exception as e:  # noqa: BLE001
+            ladder = dict(error=f"{type(e).__name__}: {e}")
+    res = dict(qps=world * B * args.steps / t["wall"], ms_per_step=t["ms_per_step"], ef=ef, recall=rec, clocks=getattr(run, "clocks", None), batch_ladder=ladder,
                n_dist_per_query=t["n_dist"] / B, build_s=run.build_s, build_n_dist=run.build_nd, roofline=t["roofline"],
-               index_bytes=run.ix.device_bytes, sweep=sweep, distance_batch=db, built_handle=built_handle)
+               index_bytes=run.ix.device_bytes, sweep=sweep, distance_batch=db, built_handle=built_handle,
+               exact_scan=getattr(run, "exact_scan", None))
     # CPU baseline + parity: the oracle (a port of the reference algorithm) on the same index and the same queries
     if rank == 0 and not args.multi and not args.skip_cpu:
         try:
@@ -1194,7 +1237,7 @@ def bench_line(out):
     if isinstance(cfg, dict):
         cfg.pop("ef_sweep", None)
     txt = json.dumps(line)
-    for victim in ("host_ingest", "hnsw_sharded", "graph_rules", "hnsw_1m_clustered", "hnsw_1m"):  # never reached at today's sizes
+    for victim in ("host_ingest", "hnsw_sharded", "batch_ladder", "graph_rules", "hnsw_1m_clustered", "hnsw_1m", "hnsw_10m_clustered"):  # never reached at today's sizes
         if len(txt) <= LINE_LIMIT:
             break
         if victim in line:
@@ -1326,6 +1369,24 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     extra[name] = dict(error=f"{type(e).__name__}: {e}")
                 torch.cuda.empty_cache()
+        # BASELINE.md's own 16-cluster corpus at the metric's size: the ef that reaches recall 0.95 on it, the graph
+        # search's rate there, and the exhaustive scan beside it (which is the faster way to answer on this corpus).  Another 10M
+        # index build (~145 s): only when the run has time left (CZ_BENCH_BUDGET_S, default 420 s for the whole bench).
+        budget = float(os.environ.get("CZ_BENCH_BUDGET_S", "420"))
+        if not args.skip_hnsw and args.n >= 10_000_000 and args.dist != "clustered" and not args.skip_clustered_10m:
+            if time.time() - t_start + 175 <= budget:
+                try:
+                    extra["hnsw_10m_clustered"] = hnsw_secondary(args, torch, device, args.n, "clustered", 5, 2)
+                    ex = extra["hnsw_10m_clustered"].get("exact_scan") or {}
+                    if ex.get("queries_per_s") and ex["queries_per_s"] > extra["hnsw_10m_clustered"]["value"]:
+                        extra["hnsw_10m_clustered"]["faster_way"] = ("on this corpus the exhaustive scan on the matrix cores (recall 1.0) answers faster "
+                                                               "than the graph search at the ef that reaches the recall target")
+                except Exception as e:  # noqa: BLE001
+                    extra["hnsw_10m_clustered"] = dict(error=f"{type(e).__name__}: {e}")
+                torch.cuda.empty_cache()
+            else:
+                extra["hnsw_10m_clustered"] = dict(skipped=f"{time.time() - t_start:.0f} s into the run: no room for another 10M build under "
+                                                           f"CZ_BENCH_BUDGET_S = {budget:.0f}")
     if args.multi and not args.skip_secondary:
         if rank == 0:
             try:
@@ -1353,7 +1414,7 @@ def main():
                            "index_bytes": hn["index_bytes"], "ef_sweep": hn["sweep"]},
                 "roofline": hn["roofline"],
             }
-            for key in ("cpu_baseline", "parity", "distance_batch", "built_handle"):
+            for key in ("cpu_baseline", "parity", "distance_batch", "built_handle", "exact_scan", "batch_ladder"):
                 if hn.get(key):
                     out[key] = hn[key]
             try:  # what the box says about itself: partitions, which GPU of the node, clocks / power during the timed loop
