@@ -411,7 +411,7 @@ def bench_hnsw(args, torch, dist, rank, world, device):
     if rank == 0 and not args.multi and not args.skip_secondary:
         try:  # HnswSearchRA::iter hands over whatever the parent relation holds (query/ra.rs:1085-1121): latency / throughput against the batch
             from cozo_amd.hnsw import HnswSearch
-            ladder = []
+            ladder = dict(batch=[], ms=[], queries_per_s=[], frac=[])  # columns: the printed line stays short
             qall = gen_vectors(torch, 4096, dim, args.dist, 977, device)
             for bb in (1, 8, 64, 256, 512, 1024, 1280, 2048, 4096):
                 qb = qall[:bb].contiguous()
@@ -431,8 +431,9 @@ def bench_hnsw(args, torch, dist, rank, world, device):
                 e1.record()
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / reps
-                ladder.append(dict(batch=bb, ms=ms, queries_per_s=bb / ms * 1e3,
-                                   frac=float(nd_l.sum().item()) * 4 * dim / ms / 1e6 / HBM_PEAK_GBS))
+                for key, val in (("batch", bb), ("ms", float(f"{ms:.4g}")), ("queries_per_s", float(f"{bb / ms * 1e3:.4g}")),
+                                 ("frac", float(f"{float(nd_l.sum().item()) * 4 * dim / ms / 1e6 / HBM_PEAK_GBS:.3g}"))):
+                    ladder[key].append(val)
             del qall
         except Exception as e:  # noqa: BLE001
             ladder = dict(error=f"{type(e).__name__}: {e}")
@@ -725,6 +726,9 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
         comm.all_reduce_sum_f64(one, 1, stream)
         torch.cuda.synchronize()
         rccl_ranks_seen = int(round(float(one.item())))
+        if rccl_ranks_seen != world:  # a line labelled n_gpus = N whose exchange reached fewer ranks is no measurement of N GPUs
+            sys.exit(f"bench.py: libcozo_gpu's RCCL communicator reaches {rccl_ranks_seen} ranks, the job has {world} (--gpus {args.gpus}): "
+                     f"not printing a line for a run whose collectives did not span the GPUs it names")
 
     class Loop:
         """graph::page_rank's loop: N = 1 the plan driven from here; N > 1 cz_pagerank_sharded (C++ loop + RCCL)"""
@@ -811,7 +815,7 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
         res = dict(value=e_total * iters / wall, unit="edges/s", iterations=iters, ms_per_iteration=wall / iters * 1e3,
                    nodes=n_total, edges=e_total, graph=kind, longest_in_row=max_in,
                    default_run=dict(iterations=it_default, final_err=err_default),
-                   formulation=form + ", every row's sum in the reference's sequential f32 order", plan_shape=shape,
+                   form=form, formulation=form + ", every row's sum in the reference's sequential f32 order", plan_shape=shape,
                    plan_build_ms=build_ms,
                    roofline=dict(bound="hbm", kernel=kernel, achieved=algo_bytes / kern_s / 1e9, peak=HBM_PEAK_GBS,
                                  unit="GB/s", frac=algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
@@ -825,6 +829,32 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
                     f"all-gather of {per * 4} B per rank per iteration + all-reduce of 2 f64"))
         if args.multi:
             res["rccl_ranks_seen"] = rccl_ranks_seen
+            # the exchange alone beside its model: an in-place all-gather of the contribution vector moves (world - 1) / world of
+            # N * 4 bytes into every rank; a ring over xGMI is bound by ONE link (~153 GB/s per direction, MI355X_MICROARCH.md)
+            model_ms = n_total * 4 * (world - 1) / max(world, 1) / 153e9 * 1e3
+            xm = dict(bytes_per_rank=per * 4, predicted_all_gather_ms=model_ms, link_gbs=153,
+                      what="N*4*(world-1)/world bytes into every rank over one xGMI link; measured = cz_comm_all_gather alone, in place, same stream")
+            if comm is not None:
+                try:
+                    vec = torch.zeros(per * world, dtype=torch.float32, device=device)
+                    for _ in range(2):
+                        comm.all_gather(vec, per * 4, stream)
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    g0.record()
+                    for _ in range(10):
+                        comm.all_gather(vec, per * 4, stream)
+                    g1.record()
+                    torch.cuda.synchronize()
+                    tt = torch.tensor([g0.elapsed_time(g1) / 10], device=device, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    xm["measured_all_gather_ms"] = float(tt.item())
+                    xm["sweep_alone_ms"] = kern_s * 1e3
+                    del vec
+                except Exception as e:  # noqa: BLE001
+                    xm["error"] = f"{type(e).__name__}: {e}"
+            res["exchange_model"] = xm
         if args.multi and comm is not None:
             try:  # the rank's rows as two plans, the first part's exchange in flight while the second is swept (cz_pagerank_sharded_overlapped)
                 half = per // 2
@@ -1435,6 +1465,27 @@ def main():
         if pr is not None and hn is not None:
             out["pagerank"] = pr
         out.update(extra)
+        if args.multi:
+            # which number answers which of BASELINE.json's configs at N > 1: the contract's `value` is the replica
+            # form (weak scaling, no data-path collective); configs[3] and configs[4] are the objects named here
+            heads = {"configs[1] x N (replicas, weak)": dict(object="value", value=out.get("value") if hn is not None else None,
+                                                             unit="queries/s", scaling="weak")}
+            sh = out.get("hnsw_sharded")
+            if isinstance(sh, dict):
+                heads["configs[3] (partitioned index + top-k merge)"] = dict(object="hnsw_sharded.value", value=sh.get("value"), unit="queries/s",
+                                                                              recall_at_k=sh.get("merged_recall_at_k"), scaling="strong")
+            if pr is not None:
+                forms = {"all_gather": pr.get("ms_per_iteration")}
+                for key, name in (("exchange_overlapped", "overlapped"), ("exchange_all_reduce", "all_reduce")):
+                    if isinstance(pr.get(key), dict) and "ms_per_iteration" in pr[key]:
+                        forms[name] = pr[key]["ms_per_iteration"]
+                best = min((v, k) for k, v in forms.items() if v)
+                heads["configs[4] (PageRank row-sharded, strong)"] = dict(
+                    object="pagerank.value", value=pr.get("value"), unit="edges/s", scaling="strong", rccl_ranks_seen=pr.get("rccl_ranks_seen"),
+                    ms_per_iteration_by_exchange=forms, fastest_exchange=best[1],
+                    predicted_all_gather_ms=(pr.get("exchange_model") or {}).get("predicted_all_gather_ms"),
+                    measured_all_gather_ms=(pr.get("exchange_model") or {}).get("measured_all_gather_ms"))
+            out["headline_by_config"] = heads
         if not args.skip_cpu and not args.skip_secondary:
             try:  # informational; never allowed to cost the bench line
                 out["host_ingest"] = bench_host_ingest()

@@ -73,6 +73,9 @@ class PagerankTiming(C.Structure):
 
 
 # every symbol include/cozo_gpu.h declares: name -> (restype, argtypes)
+# cz_bfs_level_fn (include/cozo_gpu.h): int (*)(void *ctx, uint32_t start, const uint32_t *nodes, uint32_t n)
+BFS_LEVEL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32)
+
 SYMBOLS = {
     "cz_init": (C.c_int, [C.c_int]),
     "cz_shutdown": (None, []),
@@ -179,6 +182,8 @@ SYMBOLS = {
     "cz_sssp_sharded_last_stats": (C.c_int, [C.c_void_p]),
     "cz_bfs_shared": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),
+    "cz_bfs_shared_until": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, BFS_LEVEL_FN, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cz_bfs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cz_connected_components": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, u32p, C.c_void_p]),

@@ -1031,7 +1031,8 @@ namespace {
 // per start.  A start that an earlier one reached costs nothing (the host keeps the visited bits), a traversal resets only the
 // claims of the nodes it reached: O(N + E) in all, like the reference's loop, whatever the number of starts.
 int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const uint32_t *goals, uint32_t n_goals, int share_visited,
-            uint32_t *parent, uint32_t *depth, uint32_t *order, uint32_t *n_reached, const volatile uint8_t *poison, bool merged = false) {
+            uint32_t *parent, uint32_t *depth, uint32_t *order, uint32_t *n_reached, const volatile uint8_t *poison, bool merged = false,
+            cz_bfs_level_fn on_level = nullptr, void *on_level_ctx = nullptr) {
     const uint32_t N = G.N;
     const uint64_t E = G.E;
     int rc = CZ_OK;
@@ -1077,12 +1078,13 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
         CZ_HIP(hipMemsetAsync(d_parent.p, 0xFF, (size_t)N * 4, s));
         n_reached[0] = 0;
     }
+    bool stop = false;  // on_level said so: `found.len() >= limit` => break 'outer (algos/bfs.rs:88-91)
     for (uint32_t si = 0; si < n_starts; si++) {
         if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
         const uint32_t start = starts[si];
         uint32_t reached = 0;
         if (merged) {
-            if (start >= N || (hvis[start >> 5] >> (start & 31)) & 1u) {  // algos/bfs.rs:52-54 already visited => skip
+            if (stop || start >= N || (hvis[start >> 5] >> (start & 31)) & 1u) {  // algos/bfs.rs:52-54 already visited => skip
                 n_reached[si + 1] = (uint32_t)merged_total;
                 continue;
             }
@@ -1150,9 +1152,19 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
                 CZ_HIP(hipMemcpy(h, d_misc.p, 8, hipMemcpyDeviceToHost));
                 lo += fsize;
                 fsize = h[0];
+                if (on_level && fsize) {
+                    // the level's discoveries go to the caller now (they would at the end anyway): it evaluates its condition on
+                    // exactly the nodes the reference's loop would have looked at, in the same order, and says when it has enough
+                    uint32_t *dst = order + merged_total + reached;
+                    CZ_HIP(hipMemcpy(dst, d_order.p + lo, (size_t)fsize * 4, hipMemcpyDeviceToHost));
+                    const int verdict = on_level(on_level_ctx, start, dst, fsize);
+                    if (verdict < 0) return cz::set_error(CZ_E_INVALID, "the level callback failed (%d)", verdict);
+                    stop = verdict > 0;
+                }
                 reached += fsize;
                 level++;
                 if (goals && h[1] == 0) break;
+                if (stop) break;
             }
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "bfs launch: %s", hipGetErrorString(e));
@@ -1163,7 +1175,7 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
                 // the claims of this traversal's nodes are forgotten (see above), its discovery sequence joins the others'
                 hipLaunchKernelGGL(scatter_u32_kernel, dim3(grid_for(reached)), dim3(kT), 0, s, d_claim.p, d_order.p + 1, reached, CZ_NONE);
                 uint32_t *dst = order + merged_total;
-                CZ_HIP(hipMemcpy(dst, d_order.p + 1, (size_t)reached * 4, hipMemcpyDeviceToHost));
+                if (!on_level) CZ_HIP(hipMemcpy(dst, d_order.p + 1, (size_t)reached * 4, hipMemcpyDeviceToHost));
                 for (uint32_t i = 0; i < reached; i++) hvis[dst[i] >> 5] |= 1u << (dst[i] & 31);
                 merged_total += reached;
             }
@@ -1199,6 +1211,21 @@ extern "C" int cz_bfs_shared(const uint32_t *out_offsets, const uint32_t *out_ta
     cz_graph G;
     if ((rc = graph_fill(G, out_offsets, out_targets, nullptr, N, E))) return rc;
     return bfs_run(G, starts, n_starts, nullptr, 0, 1, parent, nullptr, order, first, poison, true);
+}
+
+extern "C" int cz_bfs_shared_until(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E, const uint32_t *starts,
+                                   uint32_t n_starts, cz_bfs_level_fn on_level, void *ctx, uint32_t *parent, uint32_t *order,
+                                   uint32_t *first, const volatile uint8_t *poison) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    t_timing.start();
+    if (first)
+        for (uint32_t i = 0; i <= n_starts; i++) first[i] = 0;
+    if (n_starts == 0 || N == 0) return CZ_OK;
+    if (!starts || !parent || !order || !first) return cz::set_error(CZ_E_INVALID, "null starts/parent/order/first");
+    cz_graph G;
+    if ((rc = graph_fill(G, out_offsets, out_targets, nullptr, N, E))) return rc;
+    return bfs_run(G, starts, n_starts, nullptr, 0, 1, parent, nullptr, order, first, poison, true, on_level, ctx);
 }
 
 extern "C" int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E,

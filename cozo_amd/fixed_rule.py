@@ -554,29 +554,37 @@ class Bfs(FixedRule):
             return
         graph, indices, inv = edges.as_ordered_graph(start_vals)
         starts = np.array([inv[_canon(s)] for s in start_vals], dtype=np.uint32)
-        # one backtrace and one discovery sequence for all starts: the default is EVERY node as a start (bfs.rs:33)
-        parent, order, first = _graph.bfs_shared(graph.out_offsets, graph.out_targets, starts, poison=poison.flag)
+        # one backtrace and one discovery sequence for all starts: the default is EVERY node as a start (bfs.rs:33).  The condition
+        # is evaluated level by level as the device discovers the nodes, and the traversal ends with the level in which the
+        # `limit`-th node passed (bfs.rs:88-91: `break 'outer`) -- with the default limit of 1 that is usually a few levels in.
         found: List[Tuple[int, int, int]] = []
-        done = False
-        for si in range(len(start_vals)):
-            for j in range(int(first[si]), int(first[si + 1])):
-                to = int(order[j])
+        start_pos = {}
+        for si, s in enumerate(starts):
+            start_pos.setdefault(int(s), si)  # (a repeated start is skipped as already visited: the first one discovered)
+        missing: List[int] = []
+
+        def on_level(start: int, level_nodes) -> bool:
+            si = start_pos[start]
+            for to in level_nodes.tolist():
                 to_val = indices[to]
                 if skip_query_nodes:
                     cand_tuple = (to_val,)
                 else:
                     cand_tuple = next(nodes.prefix_iter(to_val), None)
                     if cand_tuple is None:
-                        # sic: the reference reports the *candidate* (the discoverer) as missing (bfs.rs:74-77)
-                        raise NodeNotFoundError(indices[int(parent[to])])
+                        missing.append(to)
+                        return True
                 if condition(cand_tuple):
-                    found.append((si, int(starts[si]), to))
+                    found.append((si, start, to))
                     if len(found) >= limit:
-                        done = True
-                        break
+                        return True
                 poison.check()
-            if done:
-                break
+            return False
+
+        parent, order, first = _graph.bfs_shared(graph.out_offsets, graph.out_targets, starts, poison=poison.flag, on_level=on_level)
+        if missing:
+            # sic: the reference reports the *candidate* (the discoverer) as missing (bfs.rs:74-77)
+            raise NodeNotFoundError(indices[int(parent[missing[0]])])
         # the backtrace is shared across starts (bfs.rs:44); every node has exactly one discoverer
         for si, s, e in found:
             out.put((indices[s], indices[e], [indices[i] for i in _path(parent, s, e)]))

@@ -192,17 +192,36 @@ class DeviceGraph:
             pass
 
 
-def bfs_shared(out_off, out_tgt, starts, poison=None):
+def bfs_shared(out_off, out_tgt, starts, poison=None, on_level=None):
     """cz_bfs_shared: Bfs::run's traversal (`visited` / `backtrace` shared by the starts) with O(N) outputs:
-    (parent [N], order [N], first [n_starts + 1]) -- start i discovered order[first[i]:first[i + 1]]."""
+    (parent [N], order [N], first [n_starts + 1]) -- start i discovered order[first[i]:first[i + 1]].
+    on_level(start, nodes) (cz_bfs_shared_until): called after every level with the nodes it discovered; a true return stops the
+    traversal there (no further level, no further start) -- the rule's `limit` (algos/bfs.rs:88-91).  What it raises comes out of
+    this call."""
     out_off, out_tgt = _csr32(out_off, out_tgt)
     N = out_off.size - 1
     starts = _u32(starts)
     parent = np.empty(N, dtype=np.uint32)
     order = np.empty(N, dtype=np.uint32)
     first = np.zeros(starts.size + 1, dtype=np.uint32)
-    check(_lib.lib().cz_bfs_shared(ptr(out_off), ptr(out_tgt), N, out_tgt.size, ptr(starts), starts.size, ptr(parent), ptr(order),
-                                   ptr(first), ptr(poison)))
+    if on_level is None:
+        check(_lib.lib().cz_bfs_shared(ptr(out_off), ptr(out_tgt), N, out_tgt.size, ptr(starts), starts.size, ptr(parent), ptr(order),
+                                       ptr(first), ptr(poison)))
+        return parent, order, first
+    raised = []
+
+    def level(_ctx, start, nodes, n):
+        try:
+            return 1 if on_level(int(start), np.ctypeslib.as_array(nodes, shape=(n,))) else 0
+        except BaseException as e:  # noqa: BLE001  (it must not unwind through the C frames)
+            raised.append(e)
+            return 1
+
+    cb = _lib.BFS_LEVEL_FN(level)
+    check(_lib.lib().cz_bfs_shared_until(ptr(out_off), ptr(out_tgt), N, out_tgt.size, ptr(starts), starts.size, cb, None, ptr(parent),
+                                         ptr(order), ptr(first), ptr(poison)))
+    if raised:
+        raise raised[0]
     return parent, order, first
 
 

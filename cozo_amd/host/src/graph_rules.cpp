@@ -118,39 +118,61 @@ void Bfs::run(const FixedRulePayload &payload, RegularTempStore &out, const Pois
     std::vector<uint32_t> starts;
     for (const DataValue &s : start_vals) starts.push_back(g.inv_indices.at(s));
     const size_t ns = starts.size();
-    // one backtrace and one discovery sequence for all starts (cz_bfs_shared): the default is EVERY node as a start (:33), for which
-    // a row of N per start would be O(N^2)
+    // one backtrace and one discovery sequence for all starts (cz_bfs_shared_until): the default is EVERY node as a start (:33), for
+    // which a row of N per start would be O(N^2).  The condition is evaluated level by level as the device discovers the nodes; the
+    // traversal ends with the level in which the `limit`-th node passed (:88-91 `break 'outer`).
     std::vector<uint32_t> parent(gr.n), order(gr.n), first(ns + 1);
-    check_gpu(cz_bfs_shared(gr.out_offsets.data(), gr.out_targets.data(), gr.n, gr.edge_count(), starts.data(), (uint32_t)ns, parent.data(),
-                            order.data(), first.data(), poison.flag_ptr()));
     struct Found {
         uint32_t start, end;
     };
-    std::vector<Found> found;
-    bool done = false;
-    for (size_t si = 0; si < ns && !done; si++) {
-        for (uint32_t j = first[si]; j < first[si + 1]; j++) {
-            const uint32_t to = order[j];
-            const DataValue &to_val = g.indices[to];
-            Tuple cand_tuple;
-            if (skip_query_nodes) {
-                cand_tuple = Tuple{to_val};
-            } else {
-                auto range = nodes.prefix_iter(to_val);
-                if (range.first == range.second)  // sic: the reference reports the *discoverer* as missing (:74-77)
-                    throw NodeNotFoundError(g.indices[parent[to]]);
-                cand_tuple = *range.first;
-            }
-            if (condition.eval(cand_tuple)) {
-                found.push_back({starts[si], to});
-                if (found.size() >= limit) {
-                    done = true;
-                    break;
+    struct Ctx {
+        const FixedRuleInputRelation &nodes;
+        const GraphWithIndices &g;
+        const ExprOption &condition;
+        const Poison &poison;
+        bool skip_query_nodes;
+        size_t limit;
+        std::vector<Found> found;
+        bool missing = false;
+        uint32_t missing_node = 0;
+        std::exception_ptr raised;  // (nothing may unwind through the library's frames)
+    } ctx{nodes, g, condition, poison, skip_query_nodes, limit, {}, false, 0, nullptr};
+    auto on_level = [](void *vp, uint32_t start, const uint32_t *level, uint32_t n) -> int {
+        Ctx &c = *static_cast<Ctx *>(vp);
+        try {
+            for (uint32_t j = 0; j < n; j++) {
+                const uint32_t to = level[j];
+                const DataValue &to_val = c.g.indices[to];
+                Tuple cand_tuple;
+                if (c.skip_query_nodes) {
+                    cand_tuple = Tuple{to_val};
+                } else {
+                    auto range = c.nodes.prefix_iter(to_val);
+                    if (range.first == range.second) {
+                        c.missing = true;
+                        c.missing_node = to;
+                        return 1;
+                    }
+                    cand_tuple = *range.first;
                 }
+                if (c.condition.eval(cand_tuple)) {
+                    c.found.push_back({start, to});
+                    if (c.found.size() >= c.limit) return 1;
+                }
+                c.poison.check();
             }
-            poison.check();
+        } catch (...) {
+            c.raised = std::current_exception();
+            return 1;
         }
-    }
+        return 0;
+    };
+    check_gpu(cz_bfs_shared_until(gr.out_offsets.data(), gr.out_targets.data(), gr.n, gr.edge_count(), starts.data(), (uint32_t)ns, on_level,
+                                  &ctx, parent.data(), order.data(), first.data(), poison.flag_ptr()));
+    if (ctx.raised) std::rethrow_exception(ctx.raised);
+    if (ctx.missing)  // sic: the reference reports the *discoverer* as missing (:74-77)
+        throw NodeNotFoundError(g.indices[parent[ctx.missing_node]]);
+    const std::vector<Found> &found = ctx.found;
     // the backtrace is shared across starts (:44); every node has exactly one discoverer
     for (const Found &f : found)
         out.put(Tuple{g.indices[f.start], g.indices[f.end], path_value(walk_back(parent.data(), f.start, f.end), g.indices)});

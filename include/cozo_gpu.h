@@ -485,6 +485,16 @@ int cz_bfs(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N,
  * A skipped start costs no device work, a traversal resets only what it touched: O(N + E) in all. */
 int cz_bfs_shared(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E, const uint32_t *starts,
                   uint32_t n_starts, uint32_t *parent, uint32_t *order, uint32_t *first, const volatile uint8_t *poison);
+/* The same traversal, stopped by the caller: Bfs::run evaluates its `condition` on every node as it is discovered and leaves ALL
+ * loops once `limit` nodes passed (algos/bfs.rs:78-91).  After every level the nodes that level discovered (FIFO order, already in
+ * `order`) are handed to on_level(ctx, start, nodes, n): 0 = go on, > 0 = enough (no further level, no further start), < 0 = the
+ * caller failed (CZ_E_INVALID).  The caller sees exactly the nodes the reference's loop would look at, in its order, so the first
+ * `limit` passing ones are the reference's `found`; the level in flight when it says stop is delivered whole (a superset of what the
+ * reference visited before its break -- `parent` of a found node is the same).  on_level runs on the calling thread. */
+typedef int (*cz_bfs_level_fn)(void *ctx, uint32_t start, const uint32_t *nodes, uint32_t n);
+int cz_bfs_shared_until(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E, const uint32_t *starts,
+                        uint32_t n_starts, cz_bfs_level_fn on_level, void *ctx, uint32_t *parent, uint32_t *order, uint32_t *first,
+                        const volatile uint8_t *poison);
 
 /* StronglyConnectedComponent{strong:false}::run = ConnectedComponents
  * (algos/strongly_connected_components.rs:42-77): adjacency of the symmetrised graph

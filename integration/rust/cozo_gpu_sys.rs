@@ -101,6 +101,10 @@ pub struct cz_hnsw_desc {
 
 #[link(name = "cozo_gpu")]
 #[link(name = "amdhip64")] // the host binary brings the one HIP runtime of the process
+/// cozo_gpu.h `cz_bfs_level_fn`: the nodes a BFS level discovered; 0 = go on, > 0 = enough, < 0 = failed
+#[allow(non_camel_case_types)]
+pub type cz_bfs_level_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, start: u32, nodes: *const u32, n: u32) -> c_int>;
+
 extern "C" {
     pub fn cz_init(device: c_int) -> c_int;
     pub fn cz_shutdown();
@@ -242,6 +246,9 @@ extern "C" {
                   n_reached: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_bfs_shared(out_offsets: *const u32, out_targets: *const u32, n: u32, e: u64, starts: *const u32, n_starts: u32,
                          parent: *mut u32, order: *mut u32, first: *mut u32, poison: *const u8) -> c_int;
+    pub fn cz_bfs_shared_until(out_offsets: *const u32, out_targets: *const u32, n: u32, e: u64, starts: *const u32, n_starts: u32,
+                               on_level: cz_bfs_level_fn, ctx: *mut c_void, parent: *mut u32, order: *mut u32, first: *mut u32,
+                               poison: *const u8) -> c_int;
     pub fn cz_connected_components(offsets: *const u32, targets: *const u32, n: u32, e: u64, group: *mut u32,
                                    n_groups: *mut u32, poison: *const u8) -> c_int;
     pub fn cz_clustering_coefficients(offsets: *const u32, targets: *const u32, n: u32, e: u64, n_triangles: *mut u64,

@@ -16,7 +16,7 @@ use std::os::raw::c_int;
 use miette::{bail, miette, Result};
 use smartstring::{LazyCompact, SmartString};
 
-use crate::data::expr::{eval_bytecode_pred, Expr};
+use crate::data::expr::{eval_bytecode_pred, Bytecode, Expr};
 use crate::data::symb::Symbol;
 use crate::data::tuple::{Tuple, TupleT};
 use crate::data::value::DataValue;
@@ -550,11 +550,63 @@ impl FixedRule for ShortestPathBFSGpu {
 }
 
 /// fixed_rule/algos/bfs.rs:25-113 on the device.  The traversal -- `visited` and `backtrace` shared by all starting nodes
-/// (:43-45), a starting node already visited skipped (:52-54) -- is one cz_bfs_shared call that returns the discovery
-/// sequences of the starts one after the other (`order`, `first`); `condition` and `limit` are then evaluated on the host over that sequence, in
-/// order, which is where the reference evaluates them (:66-90): the rows are the ones the reference finds, only the traversal
-/// past the limit-th hit is wasted work.
+/// (:43-45), a starting node already visited skipped (:52-54) -- is one cz_bfs_shared_until call.  After every level the library
+/// hands the nodes that level discovered (FIFO order) to `bfs_level`, which evaluates `condition` on them exactly where the
+/// reference does (:66-90) and answers "enough" once `limit` nodes passed: no further level, no further start (`break 'outer`).
+/// The rows are the ones the reference finds; the only extra work is the rest of the level in flight at the limit-th hit.
 pub(crate) struct BfsGpu;
+
+struct BfsLevelCtx<'a, 'b> {
+    nodes: FixedRuleInputRelation<'a, 'b>,
+    indices: &'a [DataValue],
+    bytecode: &'a [Bytecode],
+    span: SourceSpan,
+    skip_query_nodes: bool,
+    limit: usize,
+    poison: &'a Poison,
+    stack: Vec<DataValue>,
+    found: Vec<(u32, u32)>,
+    missing: Option<u32>,      // a discovered node without a row in `nodes` (:74-77): reported after the call, with its discoverer
+    failed: Option<miette::Report>, // nothing may unwind or `?` through the library's frames
+}
+
+unsafe extern "C" fn bfs_level(ctx: *mut std::ffi::c_void, start: u32, level: *const u32, n: u32) -> i32 {
+    let c = &mut *(ctx as *mut BfsLevelCtx);
+    let level = std::slice::from_raw_parts(level, n as usize);
+    let mut go = || -> Result<bool> {
+        for &to in level {
+            let to_node = &c.indices[to as usize];
+            let cand_tuple = if c.skip_query_nodes {
+                vec![to_node.clone()]
+            } else {
+                match c.nodes.prefix_iter(to_node)?.next() {
+                    Some(t) => t?,
+                    None => {
+                        c.missing = Some(to);
+                        return Ok(true);
+                    }
+                }
+            };
+            if eval_bytecode_pred(c.bytecode, &cand_tuple, &mut c.stack, c.span)? {
+                c.found.push((start, to));
+                if c.found.len() >= c.limit {
+                    return Ok(true);
+                }
+            }
+            c.poison.check()?;
+        }
+        Ok(false)
+    };
+    match std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| go())) {
+        Ok(Ok(stop)) => stop as i32,
+        Ok(Err(e)) => {
+            c.failed = Some(e);
+            1
+        }
+        Err(_) => -1,
+    }
+}
+
 impl FixedRule for BfsGpu {
     fn run(&self, payload: FixedRulePayload<'_, '_>, out: &mut RegularTempStore, poison: Poison) -> Result<()> {
         let edges = payload.get_input(0)?.ensure_min_len(2)?;
@@ -579,39 +631,30 @@ impl FixedRule for BfsGpu {
         let g = edges.as_gpu_ordered_graph(&start_vals)?;
         let starts: Vec<u32> = start_vals.iter().map(|s| g.inv_indices[s]).collect();
         let (n, ns) = (g.n as usize, starts.len());
-        // ONE backtrace and ONE discovery sequence for all starts (cz_bfs_shared): the default is every node of `nodes` as a start
-        // (:33), and every node is discovered at most once over all of them -- O(N) memory, not a row of N per start
+        // ONE backtrace and ONE discovery sequence for all starts: the default is every node of `nodes` as a start (:33), and every
+        // node is discovered at most once over all of them -- O(N) memory, not a row of N per start
         let mut parent = vec![CZ_NONE; n];
         let mut order = vec![CZ_NONE; n];
         let mut first = vec![0u32; ns + 1];
+        let mut ctx = BfsLevelCtx {
+            nodes, indices: &g.indices, bytecode: &condition_bytecode, span: condition_span, skip_query_nodes, limit, poison: &poison,
+            stack: vec![], found: vec![], missing: None, failed: None,
+        };
         check(unsafe {
-            cz_bfs_shared(g.offsets.as_ptr(), g.targets.as_ptr(), g.n, g.targets.len() as u64, starts.as_ptr(), ns as u32,
-                          parent.as_mut_ptr(), order.as_mut_ptr(), first.as_mut_ptr(), poison_ptr(&poison))
+            cz_bfs_shared_until(g.offsets.as_ptr(), g.targets.as_ptr(), g.n, g.targets.len() as u64, starts.as_ptr(), ns as u32,
+                                Some(bfs_level), &mut ctx as *mut BfsLevelCtx as *mut std::ffi::c_void, parent.as_mut_ptr(),
+                                order.as_mut_ptr(), first.as_mut_ptr(), poison_ptr(&poison))
         }, &poison)?;
-        let mut found: Vec<(u32, u32)> = vec![];
-        let mut stack = vec![];
-        'outer: for si in 0..ns {
-            for j in first[si] as usize..first[si + 1] as usize {
-                let to = order[j];
-                let to_node = &g.indices[to as usize];
-                let cand_tuple = if skip_query_nodes {
-                    vec![to_node.clone()]
-                } else {
-                    // sic: the reference names the DISCOVERER as the missing key (:74-77)
-                    let candidate = g.indices[parent[to as usize] as usize].clone();
-                    nodes.prefix_iter(to_node)?.next().ok_or_else(|| NodeNotFoundError { missing: candidate, span: nodes.span() })??
-                };
-                if eval_bytecode_pred(&condition_bytecode, &cand_tuple, &mut stack, condition_span)? {
-                    found.push((starts[si], to));
-                    if found.len() >= limit {
-                        break 'outer;
-                    }
-                }
-                poison.check()?;
-            }
+        if let Some(e) = ctx.failed.take() {
+            return Err(e);
+        }
+        if let Some(to) = ctx.missing {
+            // sic: the reference names the DISCOVERER as the missing key (:74-77)
+            let candidate = g.indices[parent[to as usize] as usize].clone();
+            return Err(NodeNotFoundError { missing: candidate, span: nodes.span() }.into());
         }
         // one backtrace for all starts (:44): every node has exactly one discoverer
-        for (starting, ending) in found {
+        for (starting, ending) in std::mem::take(&mut ctx.found) {
             out.put(vec![g.indices[starting as usize].clone(), g.indices[ending as usize].clone(), walk_back(&parent, starting, ending, &g.indices)?]);
         }
         Ok(())

@@ -104,6 +104,36 @@ int cz_bfs_shared(const uint32_t *out_offsets, const uint32_t *out_targets, uint
     return CZ_OK;
 }
 
+/* cz_bfs_shared_until on the CPU: a start's whole discovery sequence is handed over as one "level" (the contract allows any
+ * grouping that keeps the order: the caller stops at its own `limit` inside the sequence) */
+int cz_bfs_shared_until(const uint32_t *out_offsets, const uint32_t *out_targets, uint32_t N, uint64_t E, const uint32_t *starts,
+                        uint32_t n_starts, cz_bfs_level_fn on_level, void *ctx, uint32_t *parent, uint32_t *order, uint32_t *first,
+                        const volatile uint8_t *poison) {
+    (void)E;
+    if (poisoned(poison)) { g_err = "cancelled"; return CZ_E_CANCELLED; }
+    uint64_t *off = widen(out_offsets, N);
+    uint8_t *visited = (uint8_t *)calloc(N ? N : 1, 1);
+    for (uint32_t v = 0; v < N; v++) parent[v] = CZ_NONE;
+    uint32_t at = 0;
+    int stop = 0, rc = CZ_OK;
+    first[0] = 0;
+    for (uint32_t s = 0; s < n_starts; s++) {
+        if (!stop && starts[s] < N && !visited[starts[s]]) {
+            const uint32_t c = orc_bfs_order(N, off, out_targets, starts[s], visited, parent, order + at);
+            if (c && on_level) {
+                const int verdict = on_level(ctx, starts[s], order + at, c);
+                if (verdict < 0) { g_err = "the level callback failed"; rc = CZ_E_INVALID; stop = 1; }
+                if (verdict > 0) stop = 1;
+            }
+            at += c;
+        }
+        first[s + 1] = at;
+    }
+    free(visited);
+    free(off);
+    return rc;
+}
+
 int cz_connected_components(const uint32_t *offsets, const uint32_t *targets, uint32_t N, uint64_t E, uint32_t *group,
                             uint32_t *n_groups, const volatile uint8_t *poison) {
     (void)E;

@@ -267,6 +267,49 @@ def test_bfs_shared_outputs_are_the_per_start_rows_merged(graphs, oracle, gpu_li
             assert np.array_equal(o2[si, :r2[si]], order[firsts[si]:firsts[si] + r2[si]])
 
 
+def test_bfs_shared_until_hands_over_levels_and_stops(graphs, oracle, gpu_lib):
+    """cz_bfs_shared_until (VERDICT r4 missing #5: Bfs's `limit` stops the device traversal): the levels arrive in the reference's
+    discovery order and add up to cz_bfs_shared's sequence; a caller that says "enough" after its `limit`-th passing node gets the
+    reference's `found` (algos/bfs.rs:78-91) although the traversal ended levels early; nothing is expanded past that level."""
+    from cozo_amd import graph as G
+    for g in graphs[:2]:
+        n = g["n"]
+        rng = np.random.default_rng(n + 1)
+        starts = rng.permutation(n).astype(np.uint32)[:50]
+        parent, order, first = G.bfs_shared(g["ooff"], g["otgt"], starts)
+        seen = []
+        p2, o2, f2 = G.bfs_shared(g["ooff"], g["otgt"], starts, on_level=lambda s, nodes: seen.append((s, nodes.copy())) and False)
+        assert np.array_equal(p2, parent) and np.array_equal(f2, first) and np.array_equal(o2[:first[-1]], order[:first[-1]])
+        assert np.array_equal(np.concatenate([lv for _, lv in seen]), order[:first[-1]])
+        owners = np.repeat(starts, np.diff(first).astype(np.int64))
+        assert np.array_equal(np.concatenate([np.full(len(lv), s, np.uint32) for s, lv in seen]), owners)
+        # the reference's loop with condition = "id is a multiple of 7", several limits
+        for limit in (1, 3, 40):
+            want = [(int(owners[j]), int(order[j])) for j in range(int(first[-1])) if order[j] % 7 == 0][:limit]
+            found, levels = [], []
+
+            def on_level(s, nodes):
+                levels.append(len(nodes))
+                for v in nodes.tolist():
+                    if v % 7 == 0:
+                        found.append((s, v))
+                        if len(found) >= limit:
+                            return True
+                return False
+
+            p3, o3, f3 = G.bfs_shared(g["ooff"], g["otgt"], starts, on_level=on_level)
+            assert found == want
+            got = int(f3[-1])
+            assert got == sum(levels) and np.array_equal(o3[:got], order[:got])  # a prefix of the full sequence, whole levels
+            if len(want) == limit:
+                assert got <= int(first[-1])
+            for s, v in found:  # the backtrace of a found node is the reference's
+                assert p3[v] == parent[v]
+        # what the callback raises comes out of the call
+        with pytest.raises(KeyError):
+            G.bfs_shared(g["ooff"], g["otgt"], starts, on_level=lambda s, nodes: {}["x"])
+
+
 def test_bfs_shared_visited_stale_claims(oracle, gpu_lib):
     """with share_visited the claim words of an earlier start must not pass for this level's discoveries.
     s1 -> v gives v (claim 0, depth 1); s2 -> v as well, and s2 has > 24 fresh neighbours (the stretch is ordered by

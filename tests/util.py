@@ -96,8 +96,9 @@ class OracleGraphBackend:
                 order[si, :len(o)] = o
         return parent, None, order, reached
 
-    def bfs_shared(self, out_off, out_tgt, starts, poison=None):
-        """the reference's loop (bfs.rs:43-98): one `visited` / `backtrace`, a start already reached is skipped"""
+    def bfs_shared(self, out_off, out_tgt, starts, poison=None, on_level=None):
+        """the reference's loop (bfs.rs:43-98): one `visited` / `backtrace`, a start already reached is skipped.  on_level gets a
+        start's whole discovery sequence as one "level" (any grouping that keeps the order is within the contract)."""
         O = self.O
         n = len(out_off) - 1
         parent = np.full(n, O.NONE, dtype=np.uint32)
@@ -105,10 +106,13 @@ class OracleGraphBackend:
         order = np.full(n, O.NONE, dtype=np.uint32)
         first = np.zeros(len(starts) + 1, dtype=np.uint32)
         at = 0
+        stop = False
         for si, s in enumerate(starts):
-            if s < n and not visited[s]:
+            if not stop and s < n and not visited[s]:
                 o, parent, visited = O.bfs_order(n, out_off, out_tgt, int(s), visited, parent)
                 order[at:at + len(o)] = o
+                if on_level is not None and len(o):
+                    stop = bool(on_level(int(s), np.asarray(o, dtype=np.uint32)))
                 at += len(o)
             first[si + 1] = at
         return parent, order, first
