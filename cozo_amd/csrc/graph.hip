@@ -2381,13 +2381,31 @@ struct LpTab {
     uint32_t bits;
 };
 
+// Which nodes an iteration has to look at.  A node's new label is a function of its neighbours' labels, so a node none of whose
+// neighbours changed since it was last evaluated keeps its label: evaluating it again is the reference's work, not its result.
+//   sparse == 0 (the first iterations: nearly everything changes): every node is evaluated and notes in chg[v] whether its label
+//     changed; once an iteration changed few nodes, lp_mark_kernel turns those notes into dirty[] bytes for their dependants.
+//   sparse == 1: a node is evaluated only if dirty[v]; it clears its byte first and, when its label changes, sets the byte of
+//     every node that has it in its list (moff / mtgt: the out-lists themselves on a symmetric adjacency, else the transposed
+//     lists) -- classes later in this iteration and everything in the next see it.
+// The nodes of a class share no edge, so nobody writes dirty[v] while v's own group is at work.
+struct LpActive {
+    uint8_t *dirty, *chg;
+    const uint32_t *moff, *mtgt;
+    int sparse;
+};
+
 // one node, by one wave (all lanes in the same control flow; table accesses are wave-uniform: every lane reads and writes
 // the same words with the same values)
 __device__ __forceinline__ void lp_update_node(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w,
                                                uint32_t v, uint32_t *__restrict__ labels, const LpTab &tab, int lane,
-                                               uint32_t *__restrict__ flags) {
+                                               uint32_t *__restrict__ flags, const LpActive &act) {
     const uint32_t a = off[v], b = off[v + 1];
     if (a == b) return;  // :74-76
+    if (act.sparse) {
+        if (!act.dirty[v]) return;
+        if (lane == 0) act.dirty[v] = 0;
+    }
     const uint32_t tmask = (1u << tab.bits) - 1u;
     uint32_t used = 0;
     for (uint32_t base = a; base < b; base += 64) {
@@ -2444,13 +2462,17 @@ __device__ __forceinline__ void lp_update_node(const uint32_t *__restrict__ off,
     for (int o = 32; o >= 1; o >>= 1) new_label = min(new_label, (uint32_t)__shfl_xor((int)new_label, o, 64));
     for (uint32_t i = lane; i < used; i += 64) tab.keys[tab.slots[i]] = CZ_NONE;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const bool changed = new_label != CZ_NONE && new_label != labels[v];  // (every lane reads the same word)
     if (lane == 0) {
         if (new_label == CZ_NONE) flags[1] = 1;  // the best score is NaN: `choose` on an empty list, the reference panics
-        else if (new_label != labels[v]) {
+        else if (changed) {
             labels[v] = new_label;
             flags[0] = 1;
         }
+        if (!act.sparse) act.chg[v] = changed;
     }
+    if (act.sparse && changed)
+        for (uint32_t e = act.moff[v] + lane; e < act.moff[v + 1]; e += 64) act.dirty[act.mtgt[e]] = 1;
 }
 
 // the nodes of one colour class with at most kLpTiny neighbours: a 16-lane group per node, the list in registers.  A label's
@@ -2458,72 +2480,140 @@ __device__ __forceinline__ void lp_update_node(const uint32_t *__restrict__ off,
 // every lane walks the whole list in that order and adds up the entries that carry its own label -- the same additions in
 // the same order as the table form, without the table (which serialises a wave per distinct label: 10 M nodes of ~10
 // neighbours spent 50 of the rule's 80 ms there).
+// One node of the tiny kernel as its 16-lane group holds it.  The loads of a node form a chain of four dependent accesses
+// (order -> offsets -> targets -> labels), every link at a random place: a group can work on U nodes at once so that the
+// chains overlap.  It does not pay (see tiny_u at the launch): the rule sits at the request rate of the memory system.
+struct LpTinyNode {
+    uint32_t v, a, b, l0, l1;
+    float w0, w1;
+    bool live;
+};
+template <int U>
 __global__ void __launch_bounds__(kT)
 lp_update_tiny_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w,
-                      const uint32_t *__restrict__ order, uint32_t count, uint32_t *__restrict__ labels, uint32_t *__restrict__ flags) {
+                      const uint32_t *__restrict__ order, uint32_t count, uint32_t *__restrict__ labels, uint32_t *__restrict__ flags,
+                      LpActive act) {
     constexpr int GL = 16;
     const int glane = threadIdx.x & (GL - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / GL, ngroups = gridDim.x * blockDim.x / GL;
-    const uint32_t rounds = (count + ngroups - 1) / ngroups;  // every group of the grid runs the same trip count (shuffles)
+    const uint32_t rounds = (count + ngroups * U - 1) / (ngroups * U);  // every group of the grid runs the same trip count (shuffles)
     for (uint32_t r = 0; r < rounds; r++) {
-        const uint32_t i = group + r * ngroups;
-        const bool live = i < count;
-        const uint32_t v = live ? order[i] : 0;
-        const uint32_t a = live ? off[v] : 0, b = live ? off[v + 1] : 0;
-        const bool v0 = a + glane < b, v1 = a + GL + glane < b;
-        const uint32_t l0 = v0 ? labels[tgt[a + glane]] : CZ_NONE, l1 = v1 ? labels[tgt[a + GL + glane]] : CZ_NONE;
-        const float w0 = v0 ? w[a + glane] : 0.f, w1 = v1 ? w[a + GL + glane] : 0.f;
-        float s0 = 0.0f, s1 = 0.0f;
-        const uint32_t n0 = min(b - a, (uint32_t)GL);
+        LpTinyNode nd[U];
 #pragma unroll
-        for (int j = 0; j < GL; j++) {
-            const uint32_t lj = (uint32_t)__shfl((int)l0, j, GL);
-            const float wj = __shfl(w0, j, GL);
-            if ((uint32_t)j < n0) {
-                if (lj == l0) s0 += wj;
-                if (lj == l1) s1 += wj;
-            }
+        for (int u = 0; u < U; u++) {  // (the loads of the U nodes: nothing here waits for another node's data)
+            const uint32_t i = group + (r * U + u) * ngroups;
+            LpTinyNode &q = nd[u];
+            q.v = i < count ? order[i] : 0;
+            q.live = i < count && (!act.sparse || act.dirty[q.v]);  // (the same for the 16 lanes of a group)
+            q.a = q.live ? off[q.v] : 0;
+            q.b = q.live ? off[q.v + 1] : 0;
         }
-        if (__any(b - a > (uint32_t)GL)) {
-            const uint32_t n1 = b - a > (uint32_t)GL ? b - a - GL : 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            LpTinyNode &q = nd[u];
+            const bool v0 = q.a + glane < q.b, v1 = q.a + GL + glane < q.b;
+            const uint32_t t0 = v0 ? tgt[q.a + glane] : 0, t1 = v1 ? tgt[q.a + GL + glane] : 0;
+            q.w0 = v0 ? w[q.a + glane] : 0.f;
+            q.w1 = v1 ? w[q.a + GL + glane] : 0.f;
+            q.l0 = t0;
+            q.l1 = t1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            LpTinyNode &q = nd[u];
+            const bool v0 = q.a + glane < q.b, v1 = q.a + GL + glane < q.b;
+            q.l0 = v0 ? labels[q.l0] : CZ_NONE;
+            q.l1 = v1 ? labels[q.l1] : CZ_NONE;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const LpTinyNode &q = nd[u];
+            const uint32_t v = q.v, a = q.a, b = q.b, l0 = q.l0, l1 = q.l1;
+            const float w0 = q.w0, w1 = q.w1;
+            const bool live = q.live, v0 = a + glane < b, v1 = a + GL + glane < b;
+            float s0 = 0.0f, s1 = 0.0f;
+            const uint32_t n0 = min(b - a, (uint32_t)GL);
 #pragma unroll
             for (int j = 0; j < GL; j++) {
-                const uint32_t lj = (uint32_t)__shfl((int)l1, j, GL);
-                const float wj = __shfl(w1, j, GL);
-                if ((uint32_t)j < n1) {
+                const uint32_t lj = (uint32_t)__shfl((int)l0, j, GL);
+                const float wj = __shfl(w0, j, GL);
+                if ((uint32_t)j < n0) {
                     if (lj == l0) s0 += wj;
                     if (lj == l1) s1 += wj;
                 }
             }
-        }
-        // :77-85: the largest score under total_cmp; among the labels whose score == it, the smallest
-        auto key_of = [](float f) {
-            const uint32_t bts = __float_as_uint(f);
-            return (bts & 0x80000000u) ? ~bts : (bts | 0x80000000u);
-        };
-        uint32_t best_key = max(v0 ? key_of(s0) : 0u, v1 ? key_of(s1) : 0u);
+            if (__any(b - a > (uint32_t)GL)) {
+                const uint32_t n1 = b - a > (uint32_t)GL ? b - a - GL : 0;
 #pragma unroll
-        for (int o = GL / 2; o >= 1; o >>= 1) best_key = max(best_key, (uint32_t)__shfl_xor((int)best_key, o, GL));
-        const float max_score = __uint_as_float((best_key & 0x80000000u) ? (best_key & 0x7FFFFFFFu) : ~best_key);
-        uint32_t new_label = CZ_NONE;
-        if (v0 && s0 == max_score) new_label = l0;
-        if (v1 && s1 == max_score) new_label = min(new_label, l1);
-#pragma unroll
-        for (int o = GL / 2; o >= 1; o >>= 1) new_label = min(new_label, (uint32_t)__shfl_xor((int)new_label, o, GL));
-        if (live && glane == 0 && a != b) {  // (no neighbours: the node keeps its label, :74-76)
-            if (new_label == CZ_NONE) flags[1] = 1;  // the best score is NaN: `choose` on an empty list, the reference panics
-            else if (new_label != labels[v]) {
-                labels[v] = new_label;
-                flags[0] = 1;
+                for (int j = 0; j < GL; j++) {
+                    const uint32_t lj = (uint32_t)__shfl((int)l1, j, GL);
+                    const float wj = __shfl(w1, j, GL);
+                    if ((uint32_t)j < n1) {
+                        if (lj == l0) s0 += wj;
+                        if (lj == l1) s1 += wj;
+                    }
+                }
             }
+            // :77-85: the largest score under total_cmp; among the labels whose score == it, the smallest
+            auto key_of = [](float f) {
+                const uint32_t bts = __float_as_uint(f);
+                return (bts & 0x80000000u) ? ~bts : (bts | 0x80000000u);
+            };
+            uint32_t best_key = max(v0 ? key_of(s0) : 0u, v1 ? key_of(s1) : 0u);
+#pragma unroll
+            for (int o = GL / 2; o >= 1; o >>= 1) best_key = max(best_key, (uint32_t)__shfl_xor((int)best_key, o, GL));
+            const float max_score = __uint_as_float((best_key & 0x80000000u) ? (best_key & 0x7FFFFFFFu) : ~best_key);
+            uint32_t new_label = CZ_NONE;
+            if (v0 && s0 == max_score) new_label = l0;
+            if (v1 && s1 == max_score) new_label = min(new_label, l1);
+#pragma unroll
+            for (int o = GL / 2; o >= 1; o >>= 1) new_label = min(new_label, (uint32_t)__shfl_xor((int)new_label, o, GL));
+            const bool changed = live && a != b && new_label != CZ_NONE && new_label != labels[v];
+            if (live && glane == 0) {
+                if (act.sparse) act.dirty[v] = 0;
+                if (a != b) {  // (no neighbours: the node keeps its label, :74-76)
+                    if (new_label == CZ_NONE) flags[1] = 1;  // the best score is NaN: `choose` on an empty list, the reference panics
+                    else if (changed) {
+                        labels[v] = new_label;
+                        flags[0] = 1;
+                    }
+                    if (!act.sparse) act.chg[v] = changed;
+                }
+            }
+            if (act.sparse && changed)
+                for (uint32_t e = act.moff[v] + glane; e < act.moff[v + 1]; e += GL) act.dirty[act.mtgt[e]] = 1;
         }
+    }
+}
+
+// how many nodes the iteration changed (its chg[] notes)
+__global__ void __launch_bounds__(kT)
+lp_count_changed_kernel(const uint8_t *__restrict__ chg, uint32_t N, uint32_t *__restrict__ out) {
+    uint32_t mine = 0;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < N; v += gridDim.x * blockDim.x) mine += chg[v];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mine += (uint32_t)__shfl_xor((int)mine, o, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
+}
+
+// the dependants of every node the iteration changed become dirty (a 16-lane group per node)
+__global__ void __launch_bounds__(kT)
+lp_mark_kernel(const uint8_t *__restrict__ chg, uint32_t N, const uint32_t *__restrict__ moff, const uint32_t *__restrict__ mtgt,
+               uint8_t *__restrict__ dirty) {
+    constexpr uint32_t GL = 16;
+    const uint32_t glane = threadIdx.x & (GL - 1);
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / GL, ngroups = gridDim.x * blockDim.x / GL;
+    for (uint32_t v = group; v < N; v += ngroups) {
+        if (!chg[v]) continue;
+        for (uint32_t e = moff[v] + glane; e < moff[v + 1]; e += GL) dirty[mtgt[e]] = 1;
     }
 }
 
 // the nodes order[0 .. count) of one colour class, degree <= kLpSmall: tables in LDS
 __global__ void __launch_bounds__(kT)
 lp_update_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w,
-                 const uint32_t *__restrict__ order, uint32_t count, uint32_t *__restrict__ labels, uint32_t *__restrict__ flags) {
+                 const uint32_t *__restrict__ order, uint32_t count, uint32_t *__restrict__ labels, uint32_t *__restrict__ flags,
+                 LpActive act) {
     __shared__ uint32_t keys[kT / 64][kLpTable];
     __shared__ float vals[kT / 64][kLpTable];
     __shared__ uint32_t slots[kT / 64][kLpTable];
@@ -2532,19 +2622,19 @@ lp_update_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     LpTab tab{keys[wv], vals[wv], slots[wv], 9};
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t i = wave; i < count; i += n_waves) lp_update_node(off, tgt, w, order[i], labels, tab, lane, flags);
+    for (uint32_t i = wave; i < count; i += n_waves) lp_update_node(off, tgt, w, order[i], labels, tab, lane, flags, act);
 }
 
 // the class's nodes of larger degree: a table per wave in global memory, sized for the largest degree of the graph
 __global__ void __launch_bounds__(kT)
 lp_update_hub_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w,
                      const uint32_t *__restrict__ order, uint32_t count, uint32_t *__restrict__ labels, uint32_t *__restrict__ flags,
-                     uint32_t *__restrict__ tkeys, float *__restrict__ tvals, uint32_t *__restrict__ tslots, uint32_t bits) {
+                     uint32_t *__restrict__ tkeys, float *__restrict__ tvals, uint32_t *__restrict__ tslots, uint32_t bits, LpActive act) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const size_t at = (size_t)wave << bits;
     LpTab tab{tkeys + at, tvals + at, tslots + at, bits};
-    for (uint32_t i = wave; i < count; i += n_waves) lp_update_node(off, tgt, w, order[i], labels, tab, lane, flags);
+    for (uint32_t i = wave; i < count; i += n_waves) lp_update_node(off, tgt, w, order[i], labels, tab, lane, flags, act);
 }
 
 }  // namespace
@@ -2713,28 +2803,50 @@ extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t 
         CZ_HIP(hipMemsetAsync(d_tkeys.p, 0xFF, words * 4, s));
     }
     hipLaunchKernelGGL(iota_kernel, dim3(grid_for(N)), dim3(kT), 0, s, d_labels.p, N);  // :61
+    // the active set (LpActive): an iteration that changed at most this share of the nodes switches the rest of the run to
+    // evaluating only the dependants of changed nodes.  CZ_LP_SPARSE_FRAC: 0 = never, 1 = from the second iteration on.
+    double sparse_frac = 0.125;
+    if (const char *sf = getenv("CZ_LP_SPARSE_FRAC")) sparse_frac = atof(sf);
+    cz::DevBuf<uint8_t> d_dirty, d_chg;
+    CZ_HIP(d_dirty.alloc(N));
+    CZ_HIP(d_chg.alloc(N));
+    CZ_HIP(hipMemsetAsync(d_chg.p, 0, N, s));
+    // nodes a 16-lane group of the tiny kernel has in flight (CZ_LP_TINY_U = 1 | 2 | 4).  Measured on the 10M / 200M graph
+    // (scratch/r5_lp.sh): 35.3 / 36.1 / 37.0 ms -- the kernel is at the random-REQUEST rate, not waiting on a chain, so 1.
+    uint32_t tiny_u = 1;
+    if (const char *tu = getenv("CZ_LP_TINY_U")) tiny_u = atoi(tu) == 2 ? 2 : atoi(tu) == 4 ? 4 : 1;
+    LpActive act{d_dirty.p, d_chg.p, symmetric ? d_off.p : c_ioff, symmetric ? d_tgt.p : c_isrc, 0};
     uint32_t iters = 0;
     for (uint32_t it = 0; it < max_iter; it++) {
         if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
-        CZ_HIP(hipMemsetAsync(d_flags.p, 0, 8, s));
+        CZ_HIP(hipMemsetAsync(d_flags.p, 0, 12, s));
         iters++;
         for (uint32_t c = 0; c < n_col; c++) {
             const uint32_t nt = tiny_end[c] - class_off[c], ns = small_end[c] - tiny_end[c], nh = class_off[c + 1] - small_end[c];
-            if (nt)
-                hipLaunchKernelGGL(lp_update_tiny_kernel, dim3(grid_for((uint64_t)nt * 16)), dim3(kT), 0, s, d_off.p, d_tgt.p, d_w.p,
-                                   d_order.p + class_off[c], nt, d_labels.p, d_flags.p);
+            if (nt) {
+                const dim3 gt(grid_for(((uint64_t)nt + tiny_u - 1) / tiny_u * 16));
+                auto tiny = tiny_u == 1 ? lp_update_tiny_kernel<1> : tiny_u == 2 ? lp_update_tiny_kernel<2> : lp_update_tiny_kernel<4>;
+                hipLaunchKernelGGL(tiny, gt, dim3(kT), 0, s, d_off.p, d_tgt.p, d_w.p, d_order.p + class_off[c], nt, d_labels.p, d_flags.p, act);
+            }
             if (ns)
                 hipLaunchKernelGGL(lp_update_kernel, dim3(grid_for((uint64_t)ns * 64)), dim3(kT), 0, s, d_off.p, d_tgt.p, d_w.p,
-                                   d_order.p + tiny_end[c], ns, d_labels.p, d_flags.p);
+                                   d_order.p + tiny_end[c], ns, d_labels.p, d_flags.p, act);
             if (nh)
                 hipLaunchKernelGGL(lp_update_hub_kernel, dim3(std::min<uint32_t>(hub_blocks, (nh + kT / 64 - 1) / (kT / 64))), dim3(kT), 0, s,
                                    d_off.p, d_tgt.p, d_w.p, d_order.p + small_end[c], nh, d_labels.p, d_flags.p, d_tkeys.p, d_tvals.p,
-                                   d_tslots.p, hub_bits);
+                                   d_tslots.p, hub_bits, act);
         }
-        uint32_t h[2];
-        CZ_HIP(hipMemcpy(h, d_flags.p, 8, hipMemcpyDeviceToHost));
+        const bool count_changes = !act.sparse && sparse_frac > 0 && it + 1 < max_iter;
+        if (count_changes) hipLaunchKernelGGL(lp_count_changed_kernel, dim3(grid_for(N)), dim3(kT), 0, s, d_chg.p, N, d_flags.p + 2);
+        uint32_t h[3];
+        CZ_HIP(hipMemcpy(h, d_flags.p, 12, hipMemcpyDeviceToHost));
         if (h[1]) return cz::set_error(CZ_E_INVALID, "LabelPropagation: a node's best label score is NaN (the reference panics there)");
         if (!h[0]) break;  // :92-94
+        if (count_changes && (double)h[2] <= sparse_frac * (double)N) {
+            CZ_HIP(hipMemsetAsync(d_dirty.p, 0, N, s));
+            hipLaunchKernelGGL(lp_mark_kernel, dim3(grid_for((uint64_t)N * 16)), dim3(kT), 0, s, d_chg.p, N, act.moff, act.mtgt, d_dirty.p);
+            act.sparse = 1;
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "label propagation launch: %s", hipGetErrorString(e));

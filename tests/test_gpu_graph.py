@@ -836,6 +836,19 @@ def test_label_propagation_matches_the_fixed_order_execution(oracle, gpu_lib, ca
         assert np.array_equal(vouched, labels) and it_v == iters and k_v == n_col
     one, it1, _ = G.label_propagation(off, tgt, ww, max_iter=1)
     assert it1 == 1 and np.array_equal(one, oracle.label_propagation(n, off, tgt, ww, 1)[0])
+    # the active set (only the dependants of changed nodes are evaluated once an iteration changed few): never, as soon as it
+    # may (from the second iteration on, whatever changed), and at two thresholds in between -- the labels and the iteration
+    # count do not depend on it, for every cap on the iterations (the switch lands in a different iteration each time)
+    import os
+    try:
+        for frac in ("0", "1", "0.5", "0.02"):
+            os.environ["CZ_LP_SPARSE_FRAC"] = frac
+            for cap in (2, 3, 4, 10):
+                got, it_f, _ = G.label_propagation(off, tgt, ww, max_iter=cap)
+                w_l, w_it = (want, want_it) if cap == 10 else oracle.label_propagation(n, off, tgt, ww, cap)
+                assert it_f == w_it and np.array_equal(got, w_l), (frac, cap)
+    finally:
+        os.environ.pop("CZ_LP_SPARSE_FRAC", None)
 
 
 def test_label_propagation_edges(gpu_lib):
