@@ -46,13 +46,13 @@ EF_LADDER = [16, 24, 32, 48, 64, 80, 96, 112, 128, 144, 160, 176, 192, 224, 256,
 
 
 PMC_SOURCES = {  # the kernel-bearing sources each PMC entry of profiles/pmc_traffic.json was measured on
-    "hnsw_knn": ["hnsw_kernels.cuh", "distance.cuh", "hnsw_api.hip"],
+    "hnsw_knn": ["hnsw_kernels.cuh", "distance.cuh", "distance_f64.cuh", "hnsw_api.hip"],
     "distance_batch": ["distance.cuh", "hnsw_api.hip"],
     "pagerank_blocked": ["pagerank.hip", "exact_sum.cuh"],
     "pagerank_accumulate": ["pagerank.hip", "exact_sum.cuh"],
     "pagerank_gather": ["pagerank.hip", "exact_sum.cuh"],
     "pagerank_blocked_rmat": ["pagerank.hip", "exact_sum.cuh"],
-    "hnsw_knn_1m": ["hnsw_kernels.cuh", "distance.cuh", "hnsw_api.hip"],
+    "hnsw_knn_1m": ["hnsw_kernels.cuh", "distance.cuh", "distance_f64.cuh", "hnsw_api.hip"],
     "bfs": ["graph.hip"],
     "sssp": ["graph.hip"],
     "connected_components": ["graph.hip"],
@@ -325,7 +325,8 @@ class HnswRun:
         try:  # what THIS box's HBM delivers over THIS table (cz_hbm_probe: two fetch-only kernels): the measured ceilings next to the nominal peak
             stream_gbs, rows_gbs = self.ix.hbm_probe()
             roof["measured_ceiling"] = dict(stream_read_gbs=stream_gbs, random_row_fetch_gbs=rows_gbs,
-                                            frac_of_random_row_fetch=roof["achieved"] / rows_gbs if rows_gbs else None)
+                                            frac_of_random_row_fetch=roof["achieved"] / rows_gbs if rows_gbs else None,
+                                            table_landing="contiguous" if self.ix.table_contiguous else "paged")
         except Exception as e:  # noqa: BLE001
             roof["measured_ceiling"] = dict(error=f"{type(e).__name__}: {e}")
         return dict(wall=wall, ms_per_step=wall / steps * 1e3, n_dist=n_dist, roofline=roof)
@@ -1449,7 +1450,8 @@ def main():
                     out[key] = hn[key]
             try:  # what the box says about itself: partitions, which GPU of the node, clocks / power during the timed loop
                 import boxstate
-                out["box"] = dict(boxstate.static_state(torch, local), during_timed_loop=hn.get("clocks"))
+                out["box"] = dict(boxstate.static_state(torch, local), during_timed_loop=hn.get("clocks"),
+                                  table_landing=(hn["roofline"].get("measured_ceiling") or {}).get("table_landing"))
             except Exception as e:  # noqa: BLE001
                 out["box"] = dict(error=f"{type(e).__name__}: {e}")
             if hn.get("sharded"):

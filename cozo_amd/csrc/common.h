@@ -58,23 +58,24 @@ inline hipError_t alloc_table(void **p, size_t bytes, bool *contiguous = nullptr
 }
 // A table that had to be allocated while the one it replaces was still held (an insert: the old rows are copied over) may
 // have missed its contiguous range only because of that.  Once the old table is gone: try again, move the rows, free the
-// first copy.  Leaves *table alone when the second attempt fails too.
-inline void rehome_table(float **table, size_t bytes, hipStream_t stream) {
+// first copy.  Leaves *table alone when the second attempt fails too.  -> the table is in a contiguous range now
+inline bool rehome_table(float **table, size_t bytes, hipStream_t stream) {
     const char *e = getenv("CZ_TABLE_CONTIGUOUS");
-    if ((e && atoi(e) == 0) || bytes < (64u << 20)) return;
+    if ((e && atoi(e) == 0) || bytes < (64u << 20)) return false;
     void *q = nullptr;
     if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocContiguous) != hipSuccess) {
         (void)hipGetLastError();
-        return;
+        return false;
     }
     if (hipMemcpyAsync(q, *table, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(q);
-        return;
+        return false;
     }
     (void)hipFree(*table);
     *table = (float *)q;
     if (getenv("CZ_TABLE_TRACE")) fprintf(stderr, "[table] %.2f GB moved into a contiguous range\n", bytes / 1e9);
+    return true;
 }
 int comm_rank(const cz_comm *c);
 

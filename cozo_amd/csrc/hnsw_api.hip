@@ -665,13 +665,13 @@ static int index_create(const cz_hnsw_desc *desc, const void *vectors, bool f64,
     // vectors
     if (f64) {
         const size_t bytes = std::max<size_t>(16, (size_t)ix->n * ix->ld * 8);
-        CZ_HIP(cz::alloc_table((void **)&ix->vec64, bytes));
+        CZ_HIP(cz::alloc_table((void **)&ix->vec64, bytes, &ix->table_contiguous));
         if (ix->n) {
             if (ix->ld != ix->dim) CZ_HIP(hipMemset(ix->vec64, 0, bytes));
             CZ_HIP(hipMemcpy2D(ix->vec64, (size_t)ix->ld * 8, vectors, (size_t)ix->dim * 8, (size_t)ix->dim * 8, ix->n, hipMemcpyHostToDevice));
         }
     } else {
-        CZ_HIP(cz::alloc_table((void **)&ix->vec, std::max<size_t>(16, (size_t)ix->n * ix->ld * 4)));
+        CZ_HIP(cz::alloc_table((void **)&ix->vec, std::max<size_t>(16, (size_t)ix->n * ix->ld * 4), &ix->table_contiguous));
         rc = upload_padded((const float *)vectors, ix->n, ix->dim, ix->ld, ix->vec);
         if (rc) return rc;
     }
@@ -744,6 +744,10 @@ extern "C" uint64_t cz_hnsw_index_bytes(const cz_hnsw_index *h) {
     if (!h) return 0;
     auto *ix = reinterpret_cast<const cz::HnswIndex *>(h);
     return (uint64_t)ix->n * ix->ld * (ix->f64() ? 8 : 4) + (uint64_t)ix->n * ix->w0 * 4 + (uint64_t)ix->n * 4 + ix->up_rows * ix->wu * 4;
+}
+
+extern "C" int cz_hnsw_index_table_contiguous(const cz_hnsw_index *h) {
+    return h && reinterpret_cast<const cz::HnswIndex *>(h)->table_contiguous ? 1 : 0;
 }
 
 extern "C" int cz_hnsw_index_probe(const cz_hnsw_index *h, uint64_t n_fetch, uint32_t reps, double *stream_gbs, double *row_fetch_gbs) {

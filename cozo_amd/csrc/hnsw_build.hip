@@ -563,7 +563,8 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
         const bool had_old = ix->vec != nullptr;
         if (ix->vec) (void)hipFree(ix->vec);
         ix->vec = guard.release();
-        if (had_old && !contiguous) cz::rehome_table(&ix->vec, table_bytes, stream);  // the old table was in the way
+        if (had_old && !contiguous) contiguous = cz::rehome_table(&ix->vec, table_bytes, stream);  // the old table was in the way
+        ix->table_contiguous = contiguous;
     }
     // levels: caller-supplied (non-negative = -layer) or drawn here: floor(-ln(U) / ln(m)), hnsw.rs:46-52.
     // Until the build has gone through, the handle must stay what it was: a failure further down (a bad level, an

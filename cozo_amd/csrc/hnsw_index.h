@@ -29,6 +29,7 @@ struct HnswIndex {
     int w0 = 1, wu = 1;
     uint64_t up_rows = 0;
     float *vec = nullptr;
+    bool table_contiguous = false;  // the vector table sits in one physically contiguous range (cz::alloc_table)
     double *vec64 = nullptr;  // an F64 index (cz_hnsw_index_create_f64): vec is null, ld = dim rounded up to 2; search only
     uint32_t *nbr0 = nullptr;
     uint32_t *up_base = nullptr;

@@ -266,6 +266,11 @@ class GpuHnswIndex:
     def device_bytes(self) -> int:
         return int(_lib.lib().cz_hnsw_index_bytes(self._h))
 
+    @property
+    def table_contiguous(self) -> bool:
+        """cz_hnsw_index_table_contiguous: the vector table got one physically contiguous range (a placement diagnostic)"""
+        return bool(_lib.lib().cz_hnsw_index_table_contiguous(self._h))
+
     def hbm_probe(self, n_fetch: int = 0, reps: int = 0):
         """cz_hnsw_index_probe: (contiguous read GB/s, random whole-row fetch GB/s) over this index' vector table"""
         a, b = C.c_double(0.0), C.c_double(0.0)

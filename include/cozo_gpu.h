@@ -125,6 +125,11 @@ int cz_hnsw_index_create_f64(const cz_hnsw_desc *desc, const double *vectors, cz
 void cz_hnsw_index_destroy(cz_hnsw_index *ix);
 /* device bytes held by the index (vectors + link tables) */
 uint64_t cz_hnsw_index_bytes(const cz_hnsw_index *ix);
+/* 1 when the vector table (the VectorCache's rows, runtime/hnsw.rs:110-151, resident) sits in ONE physically contiguous range of
+ * device memory, 0 when the allocator had none left and it is paged like any hipMalloc.  Placement moves the random whole-row
+ * fetch rate of a 30 GB table by 2-8 %; tables >= 64 MB ask for a contiguous range first
+ * (CZ_TABLE_CONTIGUOUS=0: never).  A diagnostic: results do not depend on it. */
+int cz_hnsw_index_table_contiguous(const cz_hnsw_index *ix);
 /* cz_hbm_probe over THIS index' vector table (its rows, its allocation): the ceiling the search kernels run under on this box */
 int cz_hnsw_index_probe(const cz_hnsw_index *ix, uint64_t n_fetch, uint32_t reps, double *stream_gbs, double *row_fetch_gbs);
 
