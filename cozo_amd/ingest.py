@@ -52,8 +52,11 @@ SYMBOLS = {
     "czi_graph_lookup": (C.c_uint32, [C.c_void_p, C.c_char_p, C.c_uint64]),
     "czi_hnsw_ingest": (C.c_int, [C.POINTER(Rows), C.POINTER(Rows), C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32,
                                   C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "czi_hnsw_ingest_f64": (C.c_int, [C.POINTER(Rows), C.POINTER(Rows), C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32,
+                                  C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "czi_hnsw_free": (None, [C.c_void_p]),
     "czi_hnsw_desc": (C.c_int, [C.c_void_p, C.POINTER(HnswDesc), C.POINTER(f32p)]),
+    "czi_hnsw_desc_f64": (C.c_int, [C.c_void_p, C.POINTER(HnswDesc), C.POINTER(C.POINTER(C.c_double))]),
     "czi_hnsw_nodes": (C.c_int, [C.c_void_p, C.POINTER(u64p), C.POINTER(u32p), C.POINTER(i32p)]),
     "czi_hnsw_row_counts": (C.c_int, [C.c_void_p, u64p, u64p, u64p, u64p]),
     "czi_hnsw_encode_rows_degrees": (C.c_int, [C.POINTER(HnswDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -157,17 +160,20 @@ class StoredHnswIndex:
     """The flat form of one `tbl:idx` relation + the indexed vectors of its base relation, read off the stored bytes."""
 
     def __init__(self, idx: codec.StoredRows, base: codec.StoredRows, vec_fields: Sequence[int], dim: int, metric: int,
-                 m_neighbours: int):
+                 m_neighbours: int, dtype: str = "F32"):
+        """dtype: the manifest's VecElementType (runtime/hnsw.rs:33-44); an F64 index keeps its vectors as f64 (czi_hnsw_ingest_f64)"""
         a, b = _RowsArg(idx), _RowsArg(base)
         vf = np.ascontiguousarray(vec_fields, dtype=np.uint32)
         h = C.c_void_p()
-        check(lib().czi_hnsw_ingest(C.byref(a.c), C.byref(b.c), vf.ctypes.data, vf.size, dim, metric, m_neighbours,
-                                    2 * m_neighbours, C.byref(h)))
+        f64 = dtype == "F64"
+        ingest = lib().czi_hnsw_ingest_f64 if f64 else lib().czi_hnsw_ingest
+        check(ingest(C.byref(a.c), C.byref(b.c), vf.ctypes.data, vf.size, dim, metric, m_neighbours, 2 * m_neighbours, C.byref(h)))
         self._h = h
-        d, v = HnswDesc(), f32p()
-        check(lib().czi_hnsw_desc(h, C.byref(d), C.byref(v)))
+        self.dtype = "F64" if f64 else "F32"
+        d, v = HnswDesc(), (C.POINTER(C.c_double)() if f64 else f32p())
+        check((lib().czi_hnsw_desc_f64 if f64 else lib().czi_hnsw_desc)(h, C.byref(d), C.byref(v)))
         self.n, self.dim, self.metric, self.n_levels, self.entry = d.n, d.dim, d.metric, d.n_levels, d.entry
-        self.vectors = np.ctypeslib.as_array(v, shape=(d.n, d.dim)).copy() if d.n else np.zeros((0, dim), np.float32)
+        self.vectors = np.ctypeslib.as_array(v, shape=(d.n, d.dim)).copy() if d.n else np.zeros((0, dim), np.float64 if f64 else np.float32)
         self.level_size = [int(d.level_size[l]) for l in range(d.n_levels)]
         self.level_width = [int(d.level_width[l]) for l in range(d.n_levels)]
         self.level_nodes = [np.ctypeslib.as_array(d.level_nodes[l], shape=(self.level_size[l],)).copy()

@@ -9,6 +9,8 @@ struct czi_hnsw {
     int32_t metric = 0, n_levels = 0;
     uint32_t entry = 0;
     std::vector<float> vectors;
+    std::vector<double> vectors64;  // an index over F64 vectors (czi_hnsw_ingest_f64): `vectors` stays empty
+    bool f64 = false;
     std::vector<uint32_t> level_size;
     std::vector<int32_t> level_width;
     std::vector<std::vector<uint32_t>> level_nodes, level_nbrs;
@@ -68,9 +70,13 @@ bool parse_idx_row(const czi_rows *idx, uint64_t i, uint32_t K, IdxRow &r) {
     return true;
 }
 
-// the vector a node names, copied as f32[dim] into dst; col = the field's column of the base row
-void copy_vector(const czi_rows *base, uint64_t brow, uint32_t fld, int32_t sub_idx, uint32_t dim, float *dst,
+// the vector a node names, copied as T[dim] (the index' element type, VecElementType: f32 / f64) into dst; col = the field's
+// column of the base row.  A vector of the other element type is not converted: hnsw_put indexes a row's vector only when its
+// type is the manifest's (runtime/hnsw.rs:694-706), so such a node cannot exist in a sound index.
+template <typename T>
+void copy_vector(const czi_rows *base, uint64_t brow, uint32_t fld, int32_t sub_idx, uint32_t dim, T *dst,
                  std::vector<uint8_t> &scratch) {
+    constexpr bool kF64 = sizeof(T) == 8;
     ColumnCursor cur(row_at(base, brow), base->n_key_cols);
     const uint8_t *a = nullptr, *b = nullptr;
     int where = 0;
@@ -89,12 +95,18 @@ void copy_vector(const czi_rows *base, uint64_t brow, uint32_t fld, int32_t sub_
             }
         }
         if (a >= b || *a != VEC_TAG) raise(CZI_E_MISSING_ROW, "base row %llu column %u: not a vector", (unsigned long long)brow, fld);
-        if (a[1] != VEC_F32) raise(CZI_E_UNSUPPORTED, "F64 vectors are not supported on the GPU path");
+        if (a[1] != (kF64 ? VEC_F64 : VEC_F32))
+            raise(CZI_E_UNSUPPORTED, "base row %llu column %u: the vector's element type is not the index' (%s)", (unsigned long long)brow, fld, kF64 ? "F64" : "F32");
         if (be64(a + 2) != dim) raise(CZI_E_CORRUPT, "base row %llu: vector of length %llu, index dimension %u", (unsigned long long)brow, (unsigned long long)be64(a + 2), dim);
         a += 10;
         for (uint32_t d = 0; d < dim; d++) {
-            const uint32_t u = be32(a + 4 * d);
-            memcpy(dst + d, &u, 4);
+            if (kF64) {
+                const uint64_t u = be64(a + 8 * d);
+                memcpy(dst + d, &u, 8);
+            } else {
+                const uint32_t u = be32(a + 4 * d);
+                memcpy(dst + d, &u, 4);
+            }
         }
         return;
     }
@@ -112,8 +124,9 @@ void copy_vector(const czi_rows *base, uint64_t brow, uint32_t fld, int32_t sub_
     const uint8_t *s;
     uint32_t nb;
     mp_vec(m, el, s, nb, scratch);
-    if (el != 0) raise(CZI_E_UNSUPPORTED, "F64 vectors are not supported on the GPU path");
-    if (nb != dim * 4) raise(CZI_E_CORRUPT, "base row %llu: vector of length %u, index dimension %u", (unsigned long long)brow, nb / 4, dim);
+    if (el != (kF64 ? 1 : 0))
+        raise(CZI_E_UNSUPPORTED, "base row %llu column %u: the vector's element type is not the index' (%s)", (unsigned long long)brow, fld, kF64 ? "F64" : "F32");
+    if (nb != dim * sizeof(T)) raise(CZI_E_CORRUPT, "base row %llu: vector of length %u, index dimension %u", (unsigned long long)brow, nb / (uint32_t)sizeof(T), dim);
     memcpy(dst, s, nb);
 }
 
@@ -202,7 +215,8 @@ void ingest_hnsw(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_
     h.base_row.resize(h.n);
     h.field.resize(h.n);
     h.sub.resize(h.n);
-    h.vectors.resize((size_t)h.n * dim);
+    if (h.f64) h.vectors64.resize((size_t)h.n * dim);
+    else h.vectors.resize((size_t)h.n * dim);
     parallel_for(T, [&](uint32_t t) {
         std::vector<uint8_t> scratch;
         uint32_t v = (uint32_t)((uint64_t)h.n * t / T);
@@ -222,7 +236,8 @@ void ingest_hnsw(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_
                 h.base_row[v] = br;
                 h.field[v] = (uint32_t)fld;
                 h.sub[v] = (int32_t)sb;
-                copy_vector(base, br, (uint32_t)fld, (int32_t)sb, dim, h.vectors.data() + (size_t)v * dim, scratch);
+                if (h.f64) copy_vector(base, br, (uint32_t)fld, (int32_t)sb, dim, h.vectors64.data() + (size_t)v * dim, scratch);
+                else copy_vector(base, br, (uint32_t)fld, (int32_t)sb, dim, h.vectors.data() + (size_t)v * dim, scratch);
             }
         });
     });
@@ -323,16 +338,27 @@ void ingest_hnsw(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_
 
 }  // namespace
 
-extern "C" int czi_hnsw_ingest(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_fields, uint32_t n_fields,
-                               uint32_t dim, int32_t metric, uint32_t m_max, uint32_t m_max0, czi_hnsw **out) {
+static int ingest_any(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_fields, uint32_t n_fields, uint32_t dim,
+                      int32_t metric, uint32_t m_max, uint32_t m_max0, bool f64, czi_hnsw **out) {
     if (!out) return fail(CZI_E_INVALID, "null out");
     *out = nullptr;
     std::unique_ptr<czi_hnsw> h(new (std::nothrow) czi_hnsw);
     if (!h) return fail(CZI_E_OOM, "out of host memory");
+    h->f64 = f64;
     const int rc = guarded([&] { ingest_hnsw(idx, base, vec_fields, n_fields, dim, metric, m_max, m_max0, *h); });
     if (rc) return rc;
     *out = h.release();
     return CZI_OK;
+}
+
+extern "C" int czi_hnsw_ingest(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_fields, uint32_t n_fields,
+                               uint32_t dim, int32_t metric, uint32_t m_max, uint32_t m_max0, czi_hnsw **out) {
+    return ingest_any(idx, base, vec_fields, n_fields, dim, metric, m_max, m_max0, false, out);
+}
+
+extern "C" int czi_hnsw_ingest_f64(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_fields, uint32_t n_fields,
+                                   uint32_t dim, int32_t metric, uint32_t m_max, uint32_t m_max0, czi_hnsw **out) {
+    return ingest_any(idx, base, vec_fields, n_fields, dim, metric, m_max, m_max0, true, out);
 }
 
 extern "C" void czi_hnsw_free(czi_hnsw *h) { delete h; }
@@ -348,7 +374,24 @@ extern "C" int czi_hnsw_desc(const czi_hnsw *h, cz_hnsw_desc *desc, const float 
     desc->level_width = h->level_width.data();
     desc->level_nodes = h->level_nodes_p.data();
     desc->level_nbrs = h->level_nbrs_p.data();
+    if (h->f64) return fail(CZI_E_INVALID, "an F64 index: czi_hnsw_desc_f64");
     *vectors = h->vectors.data();
+    return CZI_OK;
+}
+
+extern "C" int czi_hnsw_desc_f64(const czi_hnsw *h, cz_hnsw_desc *desc, const double **vectors) {
+    if (!h || !desc || !vectors) return fail(CZI_E_INVALID, "null argument");
+    if (!h->f64) return fail(CZI_E_INVALID, "an F32 index: czi_hnsw_desc");
+    desc->n = h->n;
+    desc->dim = h->dim;
+    desc->metric = h->metric;
+    desc->n_levels = h->n_levels;
+    desc->entry = h->entry;
+    desc->level_size = h->level_size.data();
+    desc->level_width = h->level_width.data();
+    desc->level_nodes = h->level_nodes_p.data();
+    desc->level_nbrs = h->level_nbrs_p.data();
+    *vectors = h->vectors64.data();
     return CZI_OK;
 }
 

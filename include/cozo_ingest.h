@@ -110,6 +110,12 @@ int czi_hnsw_ingest(const czi_rows *idx, const czi_rows *base, const uint32_t *v
 void czi_hnsw_free(czi_hnsw *h);
 /* the descriptor + vectors cz_hnsw_index_create takes (pointers into the handle) */
 int czi_hnsw_desc(const czi_hnsw *h, cz_hnsw_desc *desc, const float **vectors);
+/* The same for an index whose manifest says VecElementType::F64 (runtime/hnsw.rs:33-44): the rows' vectors are taken as f64
+ * and handed to cz_hnsw_index_create_f64 unconverted.  A node whose stored vector has the other element type is an error in
+ * either form (hnsw_put indexes a vector only when its type is the manifest's, :694-706). */
+int czi_hnsw_ingest_f64(const czi_rows *idx, const czi_rows *base, const uint32_t *vec_fields, uint32_t n_fields, uint32_t dim,
+                        int32_t metric, uint32_t m_max, uint32_t m_max0, czi_hnsw **out);
+int czi_hnsw_desc_f64(const czi_hnsw *h, cz_hnsw_desc *desc, const double **vectors);
 /* node id -> CompoundKey: the base row's position in `base`, the field (column position) and the sub index (-1: the
  * column is the vector itself); [n] each */
 int czi_hnsw_nodes(const czi_hnsw *h, const uint64_t **base_row, const uint32_t **field, const int32_t **sub);

@@ -335,6 +335,9 @@ extern "C" {
                            metric: i32, m_max: u32, m_max0: u32, out: *mut *mut czi_hnsw) -> c_int;
     pub fn czi_hnsw_free(h: *mut czi_hnsw);
     pub fn czi_hnsw_desc(h: *const czi_hnsw, desc: *mut cz_hnsw_desc, vectors: *mut *const c_float) -> c_int;
+    pub fn czi_hnsw_ingest_f64(idx: *const czi_rows, base: *const czi_rows, vec_fields: *const u32, n_fields: u32, dim: u32,
+                               metric: i32, m_max: u32, m_max0: u32, out: *mut *mut czi_hnsw) -> c_int;
+    pub fn czi_hnsw_desc_f64(h: *const czi_hnsw, desc: *mut cz_hnsw_desc, vectors: *mut *const c_double) -> c_int;
     pub fn czi_hnsw_nodes(h: *const czi_hnsw, base_row: *mut *const u64, field: *mut *const u32, sub: *mut *const i32) -> c_int;
     pub fn czi_hnsw_row_counts(h: *const czi_hnsw, n_rows: *mut u64, n_self: *mut u64, n_live_links: *mut u64,
                                n_ignored: *mut u64) -> c_int;

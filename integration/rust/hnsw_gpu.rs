@@ -17,6 +17,7 @@ use itertools::Itertools;
 use miette::{bail, ensure, miette, Result};
 
 use crate::data::program::HnswSearch;
+use crate::data::relation::VecElementType;
 use crate::data::tuple::{Tuple, TupleT};
 use crate::data::value::{DataValue, Vector};
 use crate::runtime::relation::RelationHandle;
@@ -25,8 +26,17 @@ use crate::runtime::transact::SessionTx;
 use super::cozo_gpu_sys::*;
 use crate::fixed_rule::algos::gpu::StoredBytes; // the (key bytes, value bytes) buffers of a scan
 
+/// A batch of query vectors in the index' element type: `hnsw_knn` converts the query to the manifest's dtype before anything else
+/// (runtime/hnsw.rs:879-884), and an F64 index computes every distance in f64 (VectorCache::dist's F64 arms, :73-78, 86-95, 102-106).
+pub(crate) enum QueryBatch {
+    F32(Vec<f32>),
+    F64(Vec<f64>),
+}
+
 pub(crate) struct GpuHnswIndex {
     pub handle: *mut cz_hnsw_index,
+    /// the manifest's element type: which of the library's two search entry points the handle takes
+    pub f64: bool,
     /// node id -> (position of the base row in the scan, field, sub index) = CompoundKey (runtime/hnsw.rs:55)
     pub node_row: Vec<u64>,
     pub node_field: Vec<u32>,
@@ -75,21 +85,36 @@ impl<'a> SessionTx<'a> {
         let (idx_rows, base_rows) = (idx.view(2 * k + 5), base.view(k));
         let fields = mf.vec_fields.iter().map(|f| *f as u32).collect_vec();
         let mut h = std::ptr::null_mut();
+        let f64 = mf.dtype == VecElementType::F64;
         check_ingest(unsafe {
-            czi_hnsw_ingest(&idx_rows, &base_rows, fields.as_ptr(), fields.len() as u32, mf.vec_dim as u32, mf.distance as i32,
-                            mf.m_max as u32, mf.m_max0 as u32, &mut h)
+            if f64 {
+                czi_hnsw_ingest_f64(&idx_rows, &base_rows, fields.as_ptr(), fields.len() as u32, mf.vec_dim as u32, mf.distance as i32,
+                                    mf.m_max as u32, mf.m_max0 as u32, &mut h)
+            } else {
+                czi_hnsw_ingest(&idx_rows, &base_rows, fields.as_ptr(), fields.len() as u32, mf.vec_dim as u32, mf.distance as i32,
+                                mf.m_max as u32, mf.m_max0 as u32, &mut h)
+            }
         })?;
         let mut desc = std::mem::MaybeUninit::<cz_hnsw_desc>::uninit();
-        let mut vectors = std::ptr::null();
-        unsafe { czi_hnsw_desc(h, desc.as_mut_ptr(), &mut vectors) };
+        let (mut vectors, mut vectors64) = (std::ptr::null(), std::ptr::null());
+        unsafe {
+            if f64 { czi_hnsw_desc_f64(h, desc.as_mut_ptr(), &mut vectors64) } else { czi_hnsw_desc(h, desc.as_mut_ptr(), &mut vectors) }
+        };
         let desc = unsafe { desc.assume_init() };
         let (mut row, mut field, mut sub) = (std::ptr::null(), std::ptr::null(), std::ptr::null());
         unsafe { czi_hnsw_nodes(h, &mut row, &mut field, &mut sub) };
         let n = desc.n as usize;
         let mut handle = std::ptr::null_mut();
-        let rc = if desc.n_levels > 0 { unsafe { cz_hnsw_index_create(&desc, vectors, &mut handle) } } else { CZ_OK };
+        let rc = if desc.n_levels == 0 {
+            CZ_OK
+        } else if f64 {
+            unsafe { cz_hnsw_index_create_f64(&desc, vectors64, &mut handle) }
+        } else {
+            unsafe { cz_hnsw_index_create(&desc, vectors, &mut handle) }
+        };
         let out = GpuHnswIndex {
             handle,
+            f64,
             node_row: unsafe { std::slice::from_raw_parts(row, n) }.to_vec(),
             node_field: unsafe { std::slice::from_raw_parts(field, n) }.to_vec(),
             node_sub: unsafe { std::slice::from_raw_parts(sub, n) }.to_vec(),
@@ -103,7 +128,7 @@ impl<'a> SessionTx<'a> {
     /// SessionTx::hnsw_knn (runtime/hnsw.rs:869-1012) for a whole batch of queries: the traversal on the device, the row
     /// assembly of :939-1006 unchanged (base row, bind columns in all_bindings() order, radius, filter bytecode, truncate).
     pub(crate) fn hnsw_knn_batch(
-        &self, gpu: &GpuHnswIndex, queries: &[f32], b: usize, config: &HnswSearch,
+        &self, gpu: &GpuHnswIndex, queries: &QueryBatch, b: usize, config: &HnswSearch,
         filter_bytecode: &Option<(Vec<crate::data::expr::Bytecode>, crate::parse::SourceSpan)>, stack: &mut Vec<DataValue>,
     ) -> Result<Vec<Vec<Tuple>>> {
         if gpu.handle.is_null() {
@@ -113,9 +138,21 @@ impl<'a> SessionTx<'a> {
         let kk = if config.filter.is_some() { config.ef } else { config.k.min(config.ef) };
         let (mut ids, mut dist, mut cnt) = (vec![0u32; b * kk], vec![0f64; b * kk], vec![0u32; b]);
         check(unsafe {
-            cz_hnsw_search_batch(gpu.handle, queries.as_ptr(), b as u32, kk as u32, config.ef as u32, config.radius.is_some() as c_int,
-                                 config.radius.unwrap_or(0.0), ids.as_mut_ptr(), dist.as_mut_ptr(), cnt.as_mut_ptr(),
-                                 std::ptr::null_mut(), std::ptr::null() /* hnsw_knn takes no Poison in the reference either */, 0, std::ptr::null_mut())
+            match queries {
+                QueryBatch::F32(q) => {
+                    ensure!(!gpu.f64, "an F64 index takes f64 queries");
+                    cz_hnsw_search_batch(gpu.handle, q.as_ptr(), b as u32, kk as u32, config.ef as u32, config.radius.is_some() as c_int,
+                                         config.radius.unwrap_or(0.0), ids.as_mut_ptr(), dist.as_mut_ptr(), cnt.as_mut_ptr(),
+                                         std::ptr::null_mut(), std::ptr::null() /* hnsw_knn takes no Poison in the reference either */, 0,
+                                         std::ptr::null_mut())
+                }
+                QueryBatch::F64(q) => {
+                    ensure!(gpu.f64, "an F32 index takes f32 queries");
+                    cz_hnsw_search_batch_f64(gpu.handle, q.as_ptr(), b as u32, kk as u32, config.ef as u32, config.radius.is_some() as c_int,
+                                             config.radius.unwrap_or(0.0), ids.as_mut_ptr(), dist.as_mut_ptr(), cnt.as_mut_ptr(),
+                                             std::ptr::null_mut(), std::ptr::null(), 0, std::ptr::null_mut())
+                }
+            }
         })?;
         let keys = &config.base_handle.metadata.keys;
         let mut out = Vec::with_capacity(b);
@@ -170,12 +207,16 @@ impl<'a> SessionTx<'a> {
 //     let bind_idx = /* unchanged, ra.rs:1091-1098 */;
 //     let config = self.hnsw_search.clone();
 //     let parents: Vec<Tuple> = self.parent.iter(tx, delta_rule, stores)?.try_collect()?;
-//     let mut q = Vec::<f32>::with_capacity(parents.len() * config.manifest.vec_dim);
+//     // the query in the index' element type (hnsw.rs:879-884): an F32 index takes f32 (an f64 query is narrowed), an F64 index f64
+//     let mut q = if config.manifest.dtype == VecElementType::F64 { QueryBatch::F64(vec![]) } else { QueryBatch::F32(vec![]) };
 //     for t in &parents {
-//         match &t[bind_idx] {
-//             DataValue::Vec(Vector::F32(v)) => { ensure!(v.len() == config.manifest.vec_dim, "query vector dimension mismatch"); q.extend(v.iter()) }
-//             DataValue::Vec(Vector::F64(v)) => q.extend(v.iter().map(|x| *x as f32)),          // hnsw.rs:879-884
-//             d => bail!("Expected vector, got {:?}", d),                                         // ra.rs:1106-1109
+//         let DataValue::Vec(v) = &t[bind_idx] else { bail!("Expected vector, got {:?}", t[bind_idx]) };   // ra.rs:1106-1109
+//         ensure!(v.len() == config.manifest.vec_dim, "query vector dimension mismatch");
+//         match (&mut q, v) {
+//             (QueryBatch::F32(q), Vector::F32(v)) => q.extend(v.iter()),
+//             (QueryBatch::F32(q), Vector::F64(v)) => q.extend(v.iter().map(|x| *x as f32)),
+//             (QueryBatch::F64(q), Vector::F64(v)) => q.extend(v.iter()),
+//             (QueryBatch::F64(q), Vector::F32(v)) => q.extend(v.iter().map(|x| *x as f64)),
 //         }
 //     }
 //     let gpu = tx.gpu_hnsw_index_cached(&config)?;
@@ -192,8 +233,13 @@ impl<'a> SessionTx<'a> {
     /// 3. `::hnsw create` on the device: every indexed vector of every row, as hnsw_put collects them (hnsw.rs:694-706: each
     /// vec_field, a Vec or every Vec inside a List).  When some row carries several vectors the library is told every node's base
     /// row (cz_hnsw_set_row_of): hnsw_get_neighbours never returns a link between two vectors of one row (:609-610).
+    ///
+    /// F32 indices only: the device builds, inserts and removes on f32 tables.  The caller (`create_hnsw_index`,
+    /// runtime/relation.rs:1010-1201) keeps the reference's own `hnsw_put` loop for a manifest with dtype F64 -- such an index is then
+    /// SEARCHED on the device like any other (gpu_hnsw_index above takes its stored rows as f64).
     pub(crate) fn hnsw_build_gpu(&mut self, config: &HnswSearch) -> Result<()> {
         let mf = &config.manifest;
+        ensure!(mf.dtype == VecElementType::F32, "hnsw_build_gpu: an F64 index is built by the reference's hnsw_put loop");
         let k = config.base_handle.metadata.keys.len();
         let (mut vectors, mut node_keys, mut node_key_off, mut row_of) = (Vec::<f32>::new(), Vec::<u8>::new(), vec![0u64], Vec::<u32>::new());
         for (row, tuple) in config.base_handle.scan_all(self).enumerate() {
