@@ -469,3 +469,17 @@ def test_hnsw_knn_f64_index_matches_oracle(gpu_lib, oracle, dim, dist, metric):
                        flat.level_nbrs, flat.entry)
     rc = L.cz_hnsw_search_batch_f64(g32._h, _lib.ptr(q[:1].copy()), 1, 1, 1, 0, 0.0, _lib.ptr(out_i), _lib.ptr(out_d), _lib.ptr(out_c), None, None, 0, None)
     assert rc == _lib.CZ_E_INVALID
+    if dim == 7:
+        # the shim's way to the same handle: the index as its stored `tbl:idx` rows + the base relation's f64 vectors, through
+        # libcozo_ingest (czi_hnsw_ingest_f64) and cz_hnsw_index_create_f64 -- same rows back as from the arrays above
+        from cozo_amd import codec
+        from cozo_amd.ingest import StoredHnswIndex, index_relation_tuples
+        rows = [(i, x[i]) for i in range(n)]
+        tuples = index_relation_tuples([(i, 1, -1) for i in range(n)], x, flat.level_nodes, flat.level_nbrs, flat.entry,
+                                       lambda pairs: oracle.distance_pairs_f64(metric, x, x, pairs, oracle.DOT_NDARRAY), relation_id=8)
+        stored = StoredHnswIndex(codec.StoredRows.from_tuples(8, tuples, 7), codec.StoredRows.from_tuples(7, rows, 1), [1], dim, metric, m,
+                                 dtype="F64")
+        gs = stored.to_gpu(man)
+        ids_s, dd_s, cnt_s = gs.hnsw_knn_batch(q, HnswSearch(k=10, ef=32))
+        ids_a, dd_a, cnt_a = g.hnsw_knn_batch(q, HnswSearch(k=10, ef=32))
+        assert np.array_equal(ids_s, ids_a) and np.array_equal(dd_s, dd_a) and np.array_equal(cnt_s, cnt_a)
