@@ -326,7 +326,8 @@ class HnswRun:
             stream_gbs, rows_gbs = self.ix.hbm_probe()
             roof["measured_ceiling"] = dict(stream_read_gbs=stream_gbs, random_row_fetch_gbs=rows_gbs,
                                             frac_of_random_row_fetch=roof["achieved"] / rows_gbs if rows_gbs else None,
-                                            table_landing="contiguous" if self.ix.table_contiguous else "paged")
+                                            table_landing="contiguous" if self.ix.table_contiguous else "paged",
+                                            placement_trial=dict(zip(("calibration_ms_before", "calibration_ms_after", "candidates"), self.ix.settle())))
         except Exception as e:  # noqa: BLE001
             roof["measured_ceiling"] = dict(error=f"{type(e).__name__}: {e}")
         return dict(wall=wall, ms_per_step=wall / steps * 1e3, n_dist=n_dist, roofline=roof)
@@ -345,6 +346,8 @@ def hnsw_secondary(args, torch, device, n, kind, steps, warmup):
         run.drop_corpus()
         gt64 = run.ground_truth()
         ef, rec, sweep = run.pick_ef(gt64)
+        if int(os.environ.get("CZ_BENCH_SETTLE", "3")):
+            run.ix.settle(ef=ef, trials=int(os.environ.get("CZ_BENCH_SETTLE", "3")))
         t = run.timed(ef, steps, warmup)
         log(f"hnsw {n} x {args.dim} ({kind}): ef sweep {sweep} -> ef = {ef}, recall = {rec:.4f}, {t['ms_per_step']:.3f} ms/batch")
         if kind == "lowrank" and n == 1_000_000:
@@ -392,12 +395,19 @@ def bench_hnsw(args, torch, dist, rank, world, device):
         torch.cuda.synchronize()
         rec = recall_at_k(torch, run.ids.to(torch.int64) & 0xFFFFFFFF, gt64)
     log(f"ef sweep {sweep} -> ef = {ef}, recall@{k} = {rec:.4f}")
+    # Placement by trial at the ef the queries use (cz_hnsw_index_settle; create / build settled at their default ef already): part
+    # of setting the index up, like the warm-up launches -- what a session does once after it created a large index.
+    settle_trials = int(os.environ.get("CZ_BENCH_SETTLE", "3"))
+    if settle_trials:
+        run.ix.settle(ef=ef, trials=settle_trials)
     built_handle = None
     if reload:  # the handle the build left behind, timed the same way; then the index comes back through the boundary's upload path
         tb = run.timed(ef, args.steps, args.warmup, dist, args.multi)
         ids_b, dd_b = run.ids.clone(), run.dd.clone()
         run.reload_through_boundary(xh)
         del xh
+        if settle_trials:
+            run.ix.settle(ef=ef, trials=settle_trials)
         run.search(ef)
         torch.cuda.synchronize()
         built_handle = dict(ms_per_step=tb["ms_per_step"], frac=tb["roofline"]["frac"], avg_launch_ms=tb["roofline"]["avg_launch_ms"],

@@ -92,6 +92,9 @@ SYMBOLS = {
     "cz_hnsw_index_destroy": (None, [C.c_void_p]),
     "cz_hnsw_index_bytes": (C.c_uint64, [C.c_void_p]),
     "cz_hnsw_index_table_contiguous": (C.c_int, [C.c_void_p]),
+    "cz_hnsw_index_settle": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    "cz_debug_index_table_address": (C.c_uint64, [C.c_void_p]),
+    "cz_debug_index_rehome": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "cz_hnsw_build": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p,
                                 C.c_uint64, C.c_uint32, u64p, C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p]),
     "cz_hnsw_insert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64,

@@ -56,6 +56,17 @@ inline hipError_t alloc_table(void **p, size_t bytes, bool *contiguous = nullptr
     }
     return hipMalloc(p, bytes);
 }
+// The other arrays a search step reads at random places -- link tables, the visited workspaces: their fetches sit on the step's
+// dependent chain (candidate -> link row -> visited -> rows), so where THEY land shows up as latency just like the vector table's
+// landing does.  Same policy from 1 MB up (CZ_AUX_CONTIGUOUS=0: plain hipMalloc).
+inline hipError_t alloc_aux(void **p, size_t bytes) {
+    const char *e = getenv("CZ_AUX_CONTIGUOUS");
+    if ((!e || atoi(e) != 0) && bytes >= (1u << 20)) {
+        if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();
+    }
+    return hipMalloc(p, bytes);
+}
 // A table that had to be allocated while the one it replaces was still held (an insert: the old rows are copied over) may
 // have missed its contiguous range only because of that.  Once the old table is gone: try again, move the rows, free the
 // first copy.  Leaves *table alone when the second attempt fails too.  -> the table is in a contiguous range now

@@ -551,8 +551,8 @@ int HnswIndex::acquire(size_t tab_bytes, size_t bitmap_bytes, hipStream_t stream
     Workspace w;
     w.tab_bytes = std::max<size_t>(tab_bytes, 16);
     w.bitmap_bytes = std::max<size_t>(bitmap_bytes, 16);
-    hipError_t e = hipMalloc(&w.tab, w.tab_bytes);
-    if (e == hipSuccess) e = hipMalloc(&w.bitmap, w.bitmap_bytes);
+    hipError_t e = cz::alloc_aux(&w.tab, w.tab_bytes);
+    if (e == hipSuccess) e = cz::alloc_aux(&w.bitmap, w.bitmap_bytes);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&w.ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMemsetAsync(w.tab, 0xFF, w.tab_bytes, stream);
     if (e == hipSuccess) e = hipMemsetAsync(w.bitmap, 0, w.bitmap_bytes, stream);
@@ -676,7 +676,7 @@ static int index_create(const cz_hnsw_desc *desc, const void *vectors, bool f64,
         if (rc) return rc;
     }
     if (ix->n_levels > 0) {
-        CZ_HIP(hipMalloc((void **)&ix->nbr0, (size_t)ix->n * ix->w0 * 4));
+        CZ_HIP(cz::alloc_aux((void **)&ix->nbr0, (size_t)ix->n * ix->w0 * 4));
         CZ_HIP(hipMemcpy(ix->nbr0, desc->level_nbrs[0], (size_t)ix->n * ix->w0 * 4, hipMemcpyHostToDevice));
         // upper levels: node -> first row; rows of one node are consecutive (level 1, 2, ... top)
         std::vector<uint32_t> top(ix->n, 0);
@@ -725,11 +725,12 @@ static int index_create(const cz_hnsw_desc *desc, const void *vectors, bool f64,
         ix->up_rows = rows;
         ix->top.assign(top.begin(), top.end());
         ix->layout_top = ix->top;
-        CZ_HIP(hipMalloc((void **)&ix->up_base, (size_t)ix->n * 4));
+        CZ_HIP(cz::alloc_aux((void **)&ix->up_base, (size_t)ix->n * 4));
         CZ_HIP(hipMemcpy(ix->up_base, base.data(), (size_t)ix->n * 4, hipMemcpyHostToDevice));
-        CZ_HIP(hipMalloc((void **)&ix->up_nbrs, up.size() * 4));
+        CZ_HIP(cz::alloc_aux((void **)&ix->up_nbrs, up.size() * 4));
         CZ_HIP(hipMemcpy(ix->up_nbrs, up.data(), up.size() * 4, hipMemcpyHostToDevice));
     }
+    if ((rc = cz::settle_if_large(ix, nullptr))) return rc;
     *out = reinterpret_cast<cz_hnsw_index *>(guard.release());
     return CZ_OK;
 }
@@ -744,6 +745,184 @@ extern "C" uint64_t cz_hnsw_index_bytes(const cz_hnsw_index *h) {
     if (!h) return 0;
     auto *ix = reinterpret_cast<const cz::HnswIndex *>(h);
     return (uint64_t)ix->n * ix->ld * (ix->f64() ? 8 : 4) + (uint64_t)ix->n * ix->w0 * 4 + (uint64_t)ix->n * 4 + ix->up_rows * ix->wu * 4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Placement by trial.  WHERE the vector table and the visited workspaces land in device memory moves the search kernel by up
+// to 16 % on one box with one binary (profiles/r05_landing.txt: 0.63 / 0.69 / 0.74 of the peak -- discrete levels, the same
+// virtual address, physically contiguous or not; the link tables do not matter).  Nothing in the API says where an allocation
+// lands or how good the place is, and a fetch-only probe does not see it (it is latency on the step's dependent chain), so the
+// library asks the only witness there is: it times the search itself on a calibration batch (rows of the table as queries),
+// gives one array a second place while the first is still held -- so it lands elsewhere --, times again, and keeps the faster
+// of the two.  A few candidates per array; the loser is freed.  Results never depend on it.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+__global__ void settle_queries_kernel(const T *__restrict__ table, uint32_t ld, uint32_t dim, uint32_t n, uint32_t B, T *__restrict__ out) {
+    const uint64_t total = (uint64_t)B * dim;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = (uint32_t)(i / dim), c = (uint32_t)(i % dim);
+        const uint64_t row = (uint64_t)b * n / B;
+        out[i] = table[row * ld + c];
+    }
+}
+
+}  // namespace
+
+int cz::settle_placement(HnswIndex *ix, uint32_t ef, uint32_t trials, hipStream_t stream) {
+    if (!ix || ix->n_levels <= 0 || ix->n < 4096 || trials == 0) return CZ_OK;
+    const uint32_t B = 1024, k = 10;
+    if (ef == 0) ef = 128;  // (a caller that knows the ef of its queries settles again with it: the landing that suits one list size
+                            // is not always the one that suits a list twice as long -- profiles/r05_landing.txt)
+    const size_t esz = ix->f64() ? 8 : 4;
+    const size_t table_bytes = (size_t)ix->n * ix->ld * esz;
+    cz::DevBuf<uint8_t> dq;
+    cz::DevBuf<uint32_t> dids, dcnt;
+    cz::DevBuf<double> ddist;
+    cz::DevBuf<uint64_t> dnd;
+    CZ_HIP(dq.alloc((size_t)B * ix->dim * esz));
+    CZ_HIP(dids.alloc((size_t)B * k));
+    CZ_HIP(ddist.alloc((size_t)B * k));
+    CZ_HIP(dcnt.alloc(B));
+    CZ_HIP(dnd.alloc(B));
+    if (ix->f64())
+        hipLaunchKernelGGL(settle_queries_kernel<double>, dim3(1024), dim3(256), 0, stream, ix->vec64, ix->ld, ix->dim, ix->n, B, (double *)dq.p);
+    else
+        hipLaunchKernelGGL(settle_queries_kernel<float>, dim3(1024), dim3(256), 0, stream, ix->vec, ix->ld, ix->dim, ix->n, B, (float *)dq.p);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    CZ_HIP(hipEventCreate(&e0));
+    CZ_HIP(hipEventCreate(&e1));
+    struct EvGuard {
+        hipEvent_t a, b;
+        ~EvGuard() {
+            (void)hipEventDestroy(a);
+            (void)hipEventDestroy(b);
+        }
+    } evg{e0, e1};
+    auto measure = [&](double *ms) -> int {  // one untimed launch, then the fastest of three
+        double best = 1e30;
+        for (int i = 0; i < 4; i++) {
+            CZ_HIP(hipEventRecord(e0, stream));
+            int rc = hnsw_search_device(ix, (const float *)dq.p, B, k, ef, 0, 0.0, dids.p, ddist.p, dcnt.p, dnd.p, stream);
+            if (rc) return rc;
+            CZ_HIP(hipEventRecord(e1, stream));
+            CZ_HIP(hipEventSynchronize(e1));
+            float t = 0.f;
+            CZ_HIP(hipEventElapsedTime(&t, e0, e1));
+            if (i > 0) best = std::min(best, (double)t);
+        }
+        *ms = best;
+        return CZ_OK;
+    };
+    const bool trace = getenv("CZ_TABLE_TRACE") != nullptr;
+    double cur = 0.0;
+    int rc = measure(&cur);
+    if (rc) return rc;
+    ix->settle_ms_before = cur;
+    // "good enough, leave it alone": the calibration launch at this fraction of the nominal 8 TB/s by its algorithmic bytes
+    // (evaluations x row bytes).  A landing at or above it is not touched -- drawing candidates is not free of side effects: the
+    // incumbent's own speed was seen to move when a 30 GB neighbour was mapped and unmapped (profiles/r05_landing.txt).
+    double target_frac = 0.72;
+    if (const char *tf = getenv("CZ_TABLE_SETTLE_TARGET")) target_frac = atof(tf);
+    std::vector<uint64_t> h_nd(B);
+    CZ_HIP(hipMemcpy(h_nd.data(), dnd.p, (size_t)B * 8, hipMemcpyDeviceToHost));
+    double evals = 0.0;
+    for (uint64_t v : h_nd) evals += (double)v;
+    const double target_ms = target_frac > 0 ? evals * (double)ix->dim * (double)esz / (target_frac * 8e12) * 1e3 : 0.0;
+    const double keep_if = 0.985;  // a candidate has to be this much faster to displace the incumbent (the timing's own noise is ~0.3 %)
+    uint32_t tried = 0;
+    auto try_table = [&]() -> int {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < table_bytes + (size_t(2) << 30)) return CZ_OK;  // no room for a second copy
+        void *old_p = ix->f64() ? (void *)ix->vec64 : (void *)ix->vec, *new_p = nullptr;
+        const bool old_c = ix->table_contiguous;
+        bool new_c = false;
+        if (cz::alloc_table(&new_p, table_bytes, &new_c) != hipSuccess) {
+            (void)hipGetLastError();
+            return CZ_OK;
+        }
+        if (hipMemcpyAsync(new_p, old_p, table_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(new_p);
+            return CZ_OK;
+        }
+        if (ix->f64()) ix->vec64 = (double *)new_p; else ix->vec = (float *)new_p;
+        ix->table_contiguous = new_c;
+        double ms = 0.0;
+        int r = measure(&ms);
+        tried++;
+        const bool keep = r == CZ_OK && ms < cur * keep_if;
+        if (trace) fprintf(stderr, "[settle] vector table candidate: %.3f ms (incumbent %.3f) %s\n", ms, cur, keep ? "kept" : "dropped");
+        if (keep) {
+            (void)hipFree(old_p);
+        } else {
+            if (ix->f64()) ix->vec64 = (double *)old_p; else ix->vec = (float *)old_p;
+            ix->table_contiguous = old_c;
+            (void)hipFree(new_p);
+        }
+        return r;
+    };
+    auto try_workspace = [&]() -> int {  // the pool holds the workspace the calibration launches use
+        std::vector<HnswIndex::Workspace> held;
+        {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            held.swap(ix->pool);
+        }
+        double ms = 0.0;
+        int r = measure(&ms);  // the pool is empty: a new workspace is allocated while the old one is still held
+        tried++;
+        const bool keep = r == CZ_OK && ms < cur * keep_if;
+        if (trace) fprintf(stderr, "[settle] visited workspace candidate: %.3f ms (incumbent %.3f) %s\n", ms, cur, keep ? "kept" : "dropped");
+        (void)hipStreamSynchronize(stream);
+        std::lock_guard<std::mutex> lk(ix->mu);
+        if (keep) {
+            for (auto &w : held) HnswIndex::destroy(w);
+        } else {
+            for (auto &w : ix->pool) HnswIndex::destroy(w);
+            ix->pool.swap(held);
+        }
+        return r;
+    };
+    // Rounds of (a table candidate, a workspace candidate), the incumbent timed again after every one -- the loser's memory is
+    // gone by then, and that alone can move it -- until the target is met or 3 x trials rounds are spent.
+    for (uint32_t round = 0; round < 3 * trials && !(target_ms > 0 && cur <= target_ms); round++) {
+        if ((rc = try_table())) return rc;
+        if ((rc = measure(&cur))) return rc;
+        if (target_ms > 0 && cur <= target_ms) break;
+        if ((rc = try_workspace())) return rc;
+        if ((rc = measure(&cur))) return rc;
+    }
+    ix->settle_ms_after = cur;
+    ix->settle_trials = tried;
+    if (trace)
+        fprintf(stderr, "[settle] %.3f -> %.3f ms over %u candidates (target %.3f ms = %.2f of 8 TB/s)\n", ix->settle_ms_before, cur, tried, target_ms,
+                target_frac);
+    return CZ_OK;
+}
+
+// the policy create / build / insert follow: indices whose table is at least 1 GiB (CZ_TABLE_SETTLE=0: never; =n: n candidates per array)
+int cz::settle_if_large(HnswIndex *ix, hipStream_t stream) {
+    const size_t bytes = (size_t)ix->n * ix->ld * (ix->f64() ? 8 : 4);
+    uint32_t trials = 3;
+    if (const char *e = getenv("CZ_TABLE_SETTLE")) trials = (uint32_t)std::max(0, atoi(e));
+    if (trials == 0 || bytes < (size_t(1) << 30)) return CZ_OK;
+    return cz::settle_placement(ix, 0, trials, stream);
+}
+
+extern "C" int cz_hnsw_index_settle(cz_hnsw_index *h, uint32_t ef, uint32_t trials, double *ms_before, double *ms_after, uint32_t *n_tried) {
+    if (!h) return cz::set_error(CZ_E_INVALID, "null index");
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    auto *ix = reinterpret_cast<cz::HnswIndex *>(h);
+    if (trials) {
+        rc = cz::settle_placement(ix, ef, trials, nullptr);
+        if (rc) return rc;
+    }
+    if (ms_before) *ms_before = ix->settle_ms_before;
+    if (ms_after) *ms_after = ix->settle_ms_after;
+    if (n_tried) *n_tried = ix->settle_trials;
+    return CZ_OK;
 }
 
 extern "C" int cz_hnsw_index_table_contiguous(const cz_hnsw_index *h) {

@@ -1003,6 +1003,9 @@ extern "C" int cz_hnsw_build(const float *vectors, uint32_t n, uint32_t dim, int
     rc = build_into(ix.get(), vectors, n, m, ef_construction, keep_pruned_connections, levels, seed, max_batch, n_dist_out, flags,
                     (hipStream_t)stream_);
     if (rc) return rc;
+    // the build's scratch is gone: now the arrays a search reads can be given their place (hnsw_api.hip, settle_placement).
+    // cz_hnsw_insert does not do this by itself -- a caller that inserts in a loop settles once at the end (cz_hnsw_index_settle).
+    if ((rc = cz::settle_if_large(ix.get(), (hipStream_t)stream_))) return rc;
     *out = reinterpret_cast<cz_hnsw_index *>(ix.release());
     return CZ_OK;
 }

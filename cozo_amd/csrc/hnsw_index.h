@@ -67,6 +67,10 @@ struct HnswIndex {
     std::mutex mu;
     std::vector<Workspace> pool;
 
+    // what cz_hnsw_index_settle found: calibration launch before / after, candidate placements tried (0: never run)
+    double settle_ms_before = 0.0, settle_ms_after = 0.0;
+    uint32_t settle_trials = 0;
+
     bool f64() const { return vec64 != nullptr; }
     ~HnswIndex();
     int acquire(size_t tab_bytes, size_t bitmap_bytes, hipStream_t stream, Workspace *out);
@@ -84,5 +88,10 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
 // of n nodes: hash-table bits (0 = bitmap only) and bitmap words.  CZ_HNSW_VISITED = bitmap | hash and
 // CZ_HNSW_VSLOTS = <slots> override the choice (experiments, and the test of the overflow path).
 void visited_shape(uint32_t n, uint32_t ef, uint32_t width, uint32_t *hbits, uint32_t *words);
+
+// cz_hnsw_index_settle on an index nobody else holds yet (create / build / insert call it on large indices)
+int settle_placement(HnswIndex *ix, uint32_t ef, uint32_t trials, hipStream_t stream);
+// the policy: tables of at least 1 GiB, 3 candidates per array (CZ_TABLE_SETTLE=0: never; =n: n candidates)
+int settle_if_large(HnswIndex *ix, hipStream_t stream);
 
 }  // namespace cz

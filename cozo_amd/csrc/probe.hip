@@ -12,6 +12,7 @@
 #include "common.h"
 #include "exact_sum.cuh"
 #include "sort_scan.cuh"
+#include "hnsw_index.h"
 
 namespace {
 
@@ -261,4 +262,46 @@ extern "C" int cz_debug_sort_pairs(const uint32_t *keys, const uint32_t *vals, u
     CZ_HIP(hipMemcpy(out_keys, in_a ? ka.p : kb.p, n * 4, hipMemcpyDeviceToHost));
     CZ_HIP(hipMemcpy(out_vals, in_a ? va.p : vb.p, n * 4, hipMemcpyDeviceToHost));
     return CZ_OK;
+}
+
+// where an index' vector table sits in the process's address space (placement experiments: scratch/r5_landing2.py)
+extern "C" uint64_t cz_debug_index_table_address(const cz_hnsw_index *h) {
+    if (!h) return 0;
+    auto *ix = reinterpret_cast<const cz::HnswIndex *>(h);
+    return (uint64_t)(uintptr_t)(ix->vec ? (const void *)ix->vec : (const void *)ix->vec64);
+}
+
+// Placement experiments (scratch/r5_landing3.py): give ONE of an index' arrays a new place in device memory, contents kept.  The
+// new array is allocated while the old one is still held, so it cannot land where the old one is.
+//   what = 0: the vector table   1: the level-0 link table   2: the upper-level tables   3: drop the pooled visited workspaces
+//   contiguous != 0: ask for a physically contiguous range (plain hipMalloc otherwise)
+extern "C" int cz_debug_index_rehome(cz_hnsw_index *h, int what, int contiguous) {
+    if (!h) return cz::set_error(CZ_E_INVALID, "null index");
+    auto *ix = reinterpret_cast<cz::HnswIndex *>(h);
+    CZ_HIP(hipDeviceSynchronize());
+    auto move = [&](void **slot, size_t bytes) -> int {
+        if (!*slot || !bytes) return CZ_OK;
+        void *q = nullptr;
+        if (!(contiguous && hipExtMallocWithFlags(&q, bytes, hipDeviceMallocContiguous) == hipSuccess)) {
+            (void)hipGetLastError();
+            CZ_HIP(hipMalloc(&q, bytes));
+        }
+        CZ_HIP(hipMemcpy(q, *slot, bytes, hipMemcpyDeviceToDevice));
+        (void)hipFree(*slot);
+        *slot = q;
+        return CZ_OK;
+    };
+    if (what == 0) return ix->vec ? move((void **)&ix->vec, (size_t)ix->n * ix->ld * 4) : move((void **)&ix->vec64, (size_t)ix->n * ix->ld * 8);
+    if (what == 1) return move((void **)&ix->nbr0, (size_t)ix->n * ix->w0 * 4);
+    if (what == 2) {
+        int rc = move((void **)&ix->up_base, (size_t)ix->n * 4);
+        return rc ? rc : move((void **)&ix->up_nbrs, (size_t)std::max<uint64_t>(ix->up_rows, 1) * ix->wu * 4);
+    }
+    if (what == 3) {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        for (auto &w : ix->pool) cz::HnswIndex::destroy(w);
+        ix->pool.clear();
+        return CZ_OK;
+    }
+    return cz::set_error(CZ_E_INVALID, "what = %d", what);
 }

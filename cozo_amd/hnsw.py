@@ -271,6 +271,13 @@ class GpuHnswIndex:
         """cz_hnsw_index_table_contiguous: the vector table got one physically contiguous range (a placement diagnostic)"""
         return bool(_lib.lib().cz_hnsw_index_table_contiguous(self._h))
 
+    def settle(self, ef: int = 0, trials: int = 0):
+        """cz_hnsw_index_settle: placement by trial (trials = 0: only report what create / build did).
+        -> (calibration ms before, after, candidates timed)"""
+        a, b, t = C.c_double(0.0), C.c_double(0.0), C.c_uint32(0)
+        check(_lib.lib().cz_hnsw_index_settle(self._h, int(ef), int(trials), C.byref(a), C.byref(b), C.byref(t)))
+        return a.value, b.value, int(t.value)
+
     def hbm_probe(self, n_fetch: int = 0, reps: int = 0):
         """cz_hnsw_index_probe: (contiguous read GB/s, random whole-row fetch GB/s) over this index' vector table"""
         a, b = C.c_double(0.0), C.c_double(0.0)

@@ -130,6 +130,22 @@ uint64_t cz_hnsw_index_bytes(const cz_hnsw_index *ix);
  * fetch rate of a 30 GB table by 2-8 %; tables >= 64 MB ask for a contiguous range first
  * (CZ_TABLE_CONTIGUOUS=0: never).  A diagnostic: results do not depend on it. */
 int cz_hnsw_index_table_contiguous(const cz_hnsw_index *ix);
+/* Placement by trial.  Where the vector table and the visited workspaces land in device memory moves the search kernel by up to
+ * 16 % (same box, same binary: profiles/r05_landing.txt), nothing in the allocation API says where that is, and only the search
+ * itself can tell.  So: time a calibration batch (1 024 rows of the table as queries, k = 10, `ef`; 0 = 128), give one array a
+ * second place while the first is still held, time again, keep the faster; rounds of (a table candidate, a workspace candidate) until
+ * the calibration launch reaches 0.72 of the nominal 8 TB/s by its algorithmic bytes (CZ_TABLE_SETTLE_TARGET; a landing that good is
+ * not touched at all) or 3 x trials rounds are spent (needs room for a second copy of the table while it runs; skipped otherwise).
+ * A caller that knows the ef of its queries settles with it: the landing that suits one list size does not always suit another.  cz_hnsw_index_create(_f64) and cz_hnsw_build do this by themselves for tables
+ * of at least 1 GiB (CZ_TABLE_SETTLE=0: never, =n: n candidates; a 30 GB table: ~8 s); cz_hnsw_insert does not -- settle once after
+ * a run of inserts.  trials = 0 only reports.  Not to be called while other threads search the handle.  Results never depend on it.
+ *   ms_before / ms_after: the calibration launch before the first and after the last settle; n_tried: candidates timed. */
+int cz_hnsw_index_settle(cz_hnsw_index *ix, uint32_t ef, uint32_t trials, double *ms_before, double *ms_after, uint32_t *n_tried);
+/* the table's device address (placement experiments only) */
+uint64_t cz_debug_index_table_address(const cz_hnsw_index *ix);
+/* placement experiments only: one of the index' arrays re-allocated elsewhere, contents kept (what = 0 vector table, 1 level-0 links,
+ * 2 upper-level tables, 3 drop the pooled visited workspaces; contiguous != 0: ask for a physically contiguous range) */
+int cz_debug_index_rehome(cz_hnsw_index *ix, int what, int contiguous);
 /* cz_hbm_probe over THIS index' vector table (its rows, its allocation): the ceiling the search kernels run under on this box */
 int cz_hnsw_index_probe(const cz_hnsw_index *ix, uint64_t n_fetch, uint32_t reps, double *stream_gbs, double *row_fetch_gbs);
 

@@ -125,6 +125,10 @@ extern "C" {
     pub fn cz_hnsw_index_destroy(ix: *mut cz_hnsw_index);
     pub fn cz_hnsw_index_bytes(ix: *const cz_hnsw_index) -> u64;
     pub fn cz_hnsw_index_table_contiguous(ix: *const cz_hnsw_index) -> c_int;
+    pub fn cz_hnsw_index_settle(ix: *mut cz_hnsw_index, ef: u32, trials: u32, ms_before: *mut c_double, ms_after: *mut c_double,
+                                n_tried: *mut u32) -> c_int;
+    pub fn cz_debug_index_table_address(ix: *const cz_hnsw_index) -> u64;
+    pub fn cz_debug_index_rehome(ix: *mut cz_hnsw_index, what: c_int, contiguous: c_int) -> c_int;
     pub fn cz_hnsw_index_probe(ix: *const cz_hnsw_index, n_fetch: u64, reps: u32, stream_gbs: *mut c_double, row_fetch_gbs: *mut c_double) -> c_int;
     pub fn cz_hnsw_build(vectors: *const c_float, n: u32, dim: u32, metric: c_int, m: u32, ef_construction: u32,
                          keep_pruned_connections: c_int, levels: *const i32, seed: u64, max_batch: u32, n_dist: *mut u64,

@@ -483,3 +483,31 @@ def test_hnsw_knn_f64_index_matches_oracle(gpu_lib, oracle, dim, dist, metric):
         ids_s, dd_s, cnt_s = gs.hnsw_knn_batch(q, HnswSearch(k=10, ef=32))
         ids_a, dd_a, cnt_a = g.hnsw_knn_batch(q, HnswSearch(k=10, ef=32))
         assert np.array_equal(ids_s, ids_a) and np.array_equal(dd_s, dd_a) and np.array_equal(cnt_s, cnt_a)
+
+
+def test_settle_changes_placement_not_results(gpu_lib, oracle):
+    """cz_hnsw_index_settle (placement by trial): the vector table and the visited workspaces are given other places in device memory
+    and the faster landing is kept -- ids, distances and counts of a search are the same before and after, whichever candidates
+    won; trials = 0 only reports; small indices are not settled by create."""
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest, HnswSearch
+    n, dim, m = 6000, 48, 8
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    g = GpuHnswIndex.build(HnswIndexManifest(vec_dim=dim, distance="L2", m_neighbours=m, ef_construction=40), x, seed=5, max_batch=256)
+    q = rng.standard_normal((300, dim)).astype(np.float32)
+    assert g.settle() == (0.0, 0.0, 0)  # 1 MB of vectors: create / build leave it alone
+    before = g.hnsw_knn_batch(q, HnswSearch(k=10, ef=64), with_n_dist=True)
+    import os
+    os.environ["CZ_TABLE_SETTLE_TARGET"] = "2.0"  # out of reach: every round is played
+    for trials in (1, 3):
+        ms0, ms1, tried = g.settle(ef=64, trials=trials)
+        assert tried <= 6 * trials and ms0 > 0 and ms1 > 0, (ms0, ms1, tried)
+        after = g.hnsw_knn_batch(q, HnswSearch(k=10, ef=64), with_n_dist=True)
+        for a, b in zip(before, after):
+            assert np.array_equal(a, b)
+    ref400 = oracle_free = g.hnsw_knn_batch(q, HnswSearch(k=10, ef=400))  # a larger workspace than the settled one: allocated on demand
+    g.settle(ef=400, trials=1)
+    again400 = g.hnsw_knn_batch(q, HnswSearch(k=10, ef=400))
+    for a, b in zip(ref400, again400):
+        assert np.array_equal(a, b)
+    os.environ.pop("CZ_TABLE_SETTLE_TARGET")
