@@ -359,9 +359,10 @@ class GpuHnswIndex:
                               stream: int = 0):
         B = queries.shape[0]
         kk = config.ef if config.has_filter else config.k
-        check(_lib.lib().cz_hnsw_search_batch(self._h, ptr(queries), B, kk, config.ef, int(config.radius is not None),
-                                              float(config.radius or 0.0), ptr(out_ids), ptr(out_dist), ptr(out_count),
-                                              ptr(out_n_dist), None, CZ_DEVICE_PTRS, C.c_void_p(stream)))
+        # (device buffers: f32 rows for an F32 index, f64 rows for an F64 one -- the caller's job, nothing is converted here)
+        fn = _lib.lib().cz_hnsw_search_batch_f64 if getattr(self, "_np", np.float32) is np.float64 else _lib.lib().cz_hnsw_search_batch
+        check(fn(self._h, ptr(queries), B, kk, config.ef, int(config.radius is not None), float(config.radius or 0.0), ptr(out_ids),
+                 ptr(out_dist), ptr(out_count), ptr(out_n_dist), None, CZ_DEVICE_PTRS, C.c_void_p(stream)))
 
     def bruteforce_knn(self, queries: np.ndarray, k: int, gemm: bool = False):
         """exact k-NN by exhaustive scan; gemm=True computes the B x N dot products as one dense f32 GEMM on the
