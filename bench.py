@@ -46,13 +46,13 @@ EF_LADDER = [16, 24, 32, 48, 64, 80, 96, 112, 128, 144, 160, 176, 192, 224, 256,
 
 
 PMC_SOURCES = {  # the kernel-bearing sources each PMC entry of profiles/pmc_traffic.json was measured on
-    "hnsw_knn": ["hnsw_kernels.cuh", "distance.cuh", "distance_f64.cuh", "hnsw_api.hip"],
-    "distance_batch": ["distance.cuh", "hnsw_api.hip"],
-    "pagerank_blocked": ["pagerank.hip", "exact_sum.cuh"],
-    "pagerank_accumulate": ["pagerank.hip", "exact_sum.cuh"],
-    "pagerank_gather": ["pagerank.hip", "exact_sum.cuh"],
-    "pagerank_blocked_rmat": ["pagerank.hip", "exact_sum.cuh"],
-    "hnsw_knn_1m": ["hnsw_kernels.cuh", "distance.cuh", "distance_f64.cuh", "hnsw_api.hip"],
+    "hnsw_knn": ["hnsw_kernels.h", "distance.h", "distance_f64.h", "hnsw_api.hip"],
+    "distance_batch": ["distance.h", "hnsw_api.hip"],
+    "pagerank_blocked": ["pagerank.hip", "exact_sum.h"],
+    "pagerank_accumulate": ["pagerank.hip", "exact_sum.h"],
+    "pagerank_gather": ["pagerank.hip", "exact_sum.h"],
+    "pagerank_blocked_rmat": ["pagerank.hip", "exact_sum.h"],
+    "hnsw_knn_1m": ["hnsw_kernels.h", "distance.h", "distance_f64.h", "hnsw_api.hip"],
     "bfs": ["graph.hip"],
     "sssp": ["graph.hip"],
     "connected_components": ["graph.hip"],

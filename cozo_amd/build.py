@@ -3,7 +3,7 @@
     python -m cozo_amd.build [--force]
 
 hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the arithmetic contract: the kernels
-spell every fma explicitly (distance.cuh) and PageRank's `base + d*sum` must round twice like the reference.
+spell every fma explicitly (distance.h) and PageRank's `base + d*sum` must round twice like the reference.
 """
 from __future__ import annotations
 
@@ -30,7 +30,7 @@ def _deps_mtime():
     m = 0.0
     for root in (CSRC, os.path.join(HERE, "..", "include")):
         for f in os.listdir(root):
-            if f.endswith((".h", ".cuh", ".hip")) and f != "cozo_ingest.h":
+            if f.endswith((".h", ".hip")) and f != "cozo_ingest.h":
                 m = max(m, os.path.getmtime(os.path.join(root, f)))
     return m
 

@@ -16,7 +16,7 @@
 #include <vector>
 
 #include "common.h"
-#include "distance.cuh"
+#include "distance.h"
 #include "hnsw_index.h"
 #include "sharded_pagerank.hpp"
 

@@ -1,4 +1,4 @@
-// distance.cuh -- wave64 distance arithmetic for gfx950 (device code only).
+// distance.h -- wave64 distance arithmetic for gfx950 (device code only).
 //
 // Arithmetic contract (VectorCache::dist, cozo-core/src/runtime/hnsw.rs:66-109, F32 arms):
 //   L2     = dot(a-b, a-b)           f32, widened to f64 at the end      (squared, no sqrt)

@@ -1,4 +1,4 @@
-// distance_f64.cuh -- VectorCache::dist, the F64 arms (cozo-core/src/runtime/hnsw.rs:73-78, 86-95, 102-106): every dot product
+// distance_f64.h -- VectorCache::dist, the F64 arms (cozo-core/src/runtime/hnsw.rs:73-78, 86-95, 102-106): every dot product
 // and the final 1 - x, /, sqrt in f64.  The f32 kernels' tree, element type changed: a vector is cut into 16-byte chunks (TWO
 // doubles), LPV lanes (16 / 32 / 64: the smallest power of two >= the chunk count) own chunks lane, lane + LPV, ...; a lane runs
 // one explicit fma chain over its elements in address order; the lanes are combined by an xor butterfly with offsets

@@ -1,4 +1,4 @@
-// exact_sum.cuh -- the reference's SEQUENTIAL f32 row sum, evaluated by a whole wave, bit for bit.
+// exact_sum.h -- the reference's SEQUENTIAL f32 row sum, evaluated by a whole wave, bit for bit.
 //
 // graph 0.3.1 `page_rank` adds a node's in-neighbour contributions one after the other in f32
 // (oracle/cozo_oracle.c orc_pagerank).  fl(s + a) is not associative, so until round 3 one

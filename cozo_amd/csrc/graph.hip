@@ -864,7 +864,9 @@ sssp_goals_left_kernel(const unsigned long long *__restrict__ dp, uint32_t N, ui
     uint32_t mine = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t si = (uint32_t)(i / n_goals), g = goals[i % n_goals];
-        if (g < N && (uint32_t)(dp[(size_t)si * N + g] >> 32) >= thr_bits) mine++;
+        // a goal that is no node is never settled: the reference's goal set is then never exhausted and the search runs to the end
+        // (shortest_path_dijkstra.rs:296-300) -- skipping it here stopped the search after the first bucket
+        if (g >= N || (uint32_t)(dp[(size_t)si * N + g] >> 32) >= thr_bits) mine++;
     }
     if (mine) atomicAdd(left, mine);
 }

@@ -12,7 +12,7 @@
 //                :434-466 -- the reference soft-deletes them, which is invisible to every reader on this path).
 // extend_candidates (:499-511): the heuristic's candidates are the found set plus the neighbours of its members -- gathered
 // into a per-workgroup scratch array in global memory, sorted there and fed through the LDS list chunk by chunk
-// (hnsw_kernels.cuh select_extended).  In a shrink the target reaches ITSELF through its neighbours' back links and is
+// (hnsw_kernels.h select_extended).  In a shrink the target reaches ITSELF through its neighbours' back links and is
 // selected like anything else; the reference writes that "link" onto the target's self row and puts the self row back
 // (:413-433, :352-357), so all that remains is a degree one above the number of link rows: `ph` below.  A shrink now reads
 // OTHER rows, so the selections of one round are staged and applied afterwards (every shrink of a round sees the rows as
@@ -35,7 +35,7 @@
 
 #include "common.h"
 #include "hnsw_index.h"
-#include "hnsw_kernels.cuh"
+#include "hnsw_kernels.h"
 
 using namespace czd;
 using czh::IndexDev;
@@ -649,7 +649,7 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
     CZ_HIP(hipMemsetAsync(b_deg0.p, 0, (size_t)n * 4, stream));
     CZ_HIP(hipMemsetAsync(b_degU.p, 0, std::max<size_t>(1, rows) * 4, stream));
     CZ_HIP(hipMemsetAsync(b_ndist.p, 0, 8, stream));
-    // one visited set (hash table + overflow bitmap, hnsw_kernels.cuh VisitedDev) per resident workgroup
+    // one visited set (hash table + overflow bitmap, hnsw_kernels.h VisitedDev) per resident workgroup
     const int slots = 1024;
     uint32_t hbits = 0, words = 0;
     cz::visited_shape(n, ef_construction, (uint32_t)std::max(cap0, capU), &hbits, &words);
@@ -710,8 +710,30 @@ int build_into(cz::HnswIndex *ix, const float *vectors, uint32_t n_new, uint32_t
     // the staging arrays of a round of `rows` shrinks (width ids + width distances + two counters per row: ~1 KB per row)
     auto stage_for = [&](uint32_t rows) -> int {
         if (rows <= stage_rows) return CZ_OK;
-        const uint32_t want = std::max<uint32_t>(rows, std::max<uint32_t>(4096, stage_rows + stage_rows / 2));
+        uint32_t want = std::max<uint32_t>(rows, std::max<uint32_t>(4096, stage_rows + stage_rows / 2));
         CZ_HIP(hipStreamSynchronize(stream));  // (nothing of the old arrays is in flight any more)
+        // A round is staged WHOLE (its shrinks must all see the rows as the round found them: applying it part by part is the
+        // ADVICE r3 bug), so the final lazy round of a multi-million-row batched build asks for 12 * width + 5 bytes per row at once.
+        // When that does not fit, say so -- with what would fit -- instead of a bare allocation failure.
+        // CZ_BUILD_STAGE_CAP_BYTES caps it for the tests.
+        {
+            const size_t per_row = (size_t)stage.width * 12 + 5;
+            size_t free_b = 0, total_b = 0, held = (size_t)stage_rows * per_row;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = ~size_t(0) >> 1, (void)hipGetLastError();
+            size_t room = free_b + held;  // the old arrays are released by the allocations below
+            room = room > (size_t(256) << 20) ? room - (size_t(256) << 20) : 0;
+            if (const char *c = getenv("CZ_BUILD_STAGE_CAP_BYTES")) room = std::min<size_t>(room, (size_t)strtoull(c, nullptr, 10));
+            if ((size_t)want * per_row > room) want = rows;  // no head room for growth: exactly this round
+            if ((size_t)want * per_row > room)
+                return cz::set_error(CZ_E_OOM, "extend_candidates: a round of %u shrinks needs %zu MiB of staging (%zu B per row), %zu MiB are free; "
+                                               "a round is applied whole, so build or insert in smaller batches (max_batch) -- at most %zu rows per "
+                                               "round fit", rows, ((size_t)rows * per_row) >> 20, per_row, room >> 20, room / per_row);
+            b_stage_ids.reset();
+            b_stage_dst.reset();
+            b_stage_n.reset();
+            b_stage_self.reset();
+            stage_rows = 0;
+        }
         CZ_HIP(b_stage_ids.alloc((size_t)want * stage.width));
         CZ_HIP(b_stage_dst.alloc((size_t)want * stage.width));
         CZ_HIP(b_stage_n.alloc(want));

@@ -53,7 +53,7 @@ struct HnswIndex {
         return key_rank.empty() ? a < b : (key_rank[a] != key_rank[b] ? key_rank[a] < key_rank[b] : a < b);
     }
 
-    // per-call scratch (the visited sets of a batch: hash tables + overflow bitmaps, hnsw_kernels.cuh VisitedDev):
+    // per-call scratch (the visited sets of a batch: hash tables + overflow bitmaps, hnsw_kernels.h VisitedDev):
     // cached, handed out under a mutex, stream-ordered by an event.  Invariant while pooled: every word of `tab` is
     // CZ_NONE and every word of `bitmap` 0 -- set once when the buffers are allocated, restored by the kernels that use
     // them (so a search never pays a per-launch memset).  A workspace whose kernel failed to launch is destroyed, not pooled.

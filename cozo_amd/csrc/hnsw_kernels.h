@@ -1,4 +1,4 @@
-// hnsw_kernels.cuh -- HNSW layer search for gfx950: one workgroup per query.
+// hnsw_kernels.h -- HNSW layer search for gfx950: one workgroup per query.
 //
 // Restates hnsw_search_level / hnsw_knn (cozo-core/src/runtime/hnsw.rs:539-587, 869-1012) in a form
 // that maps to a CDNA4 workgroup:
@@ -16,11 +16,11 @@
 //     1024 tables of a batch stay in L2 / Infinity Cache -- the per-query BITMAP it replaces is 1.25 MB per query
 //     at n = 10M: every test-and-set was an HBM miss and the rows had to be re-zeroed per launch), with the
 //     bitmap kept as the overflow form; distances use the wave-wide routines of
-//     distance.cuh, U rows in flight per lane group; the merge computes final positions by rank
+//     distance.h, U rows in flight per lane group; the merge computes final positions by rank
 //     (binary search over W for new entries, linear count over the <= 64 new entries for W entries).
 #pragma once
-#include "distance.cuh"
-#include "distance_f64.cuh"
+#include "distance.h"
+#include "distance_f64.h"
 
 namespace czh {
 
@@ -152,7 +152,7 @@ struct VisitedDev {
 };
 
 // F64: the index holds f64 vectors (search only; ITERS must be 0: the query is read from LDS, where it sits as doubles, and the
-// distances come from distance_f64.cuh).  The list, the visited set and the merges do not know the element type.
+// distances come from distance_f64.h).  The list, the visited set and the merges do not know the element type.
 template <int LPV, int ITERS, int U, bool NT = false, bool F64 = false>
 struct Searcher {
     static_assert(!F64 || ITERS == 0, "the f64 evaluation reads the query from LDS");

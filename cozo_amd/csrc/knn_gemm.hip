@@ -4,7 +4,7 @@
 //   dots[q][n] = sum_k Q[q][k] * X[n][k]           v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate: bit for bit a
 //                                                  k-ordered fmaf chain per output element (one rounding per product)
 //   distance    = 1 - dot / sqrt(|q|^2 |x|^2)  (Cosine)   |   1 - dot  (IP)       f64 tail as hnsw.rs:79-101
-//   per query the k nearest of every column chunk (LDS rank-merge, topk.cuh), then the chunk lists are merged.
+//   per query the k nearest of every column chunk (LDS rank-merge, topk.h), then the chunk lists are merged.
 //
 // L2 is NOT served here: the reference computes dot(a - b, a - b), which is not a GEMM; |a|^2 + |b|^2 - 2ab is a
 // different (cancelling) arithmetic.  The squared norms are the same k-ordered fmaf chains (row_norms_seq_kernel), so
@@ -17,7 +17,7 @@
 
 #include "common.h"
 #include "hnsw_index.h"
-#include "topk.cuh"
+#include "topk.h"
 
 using namespace czd;
 

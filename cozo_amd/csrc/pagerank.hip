@@ -7,7 +7,7 @@
 //
 // Two device formulations of the same sweep, both bit-identical to the oracle's restatement of it (each row's
 // in-neighbour contributions are added one by one in ascending source order: short rows by ONE lane each, rows of
-// >= kWaveRow terms by a whole wave through exact_sum.cuh -- the same value as the sequential f32 loop, bit for bit):
+// >= kWaveRow terms by a whole wave through exact_sum.h -- the same value as the sequential f32 loop, bit for bit):
 //
 //  * "blocked" (source-blocked two-phase sweep; the fast path).  A 4-byte gather from a 40 MB contribution
 //    vector moves a whole 128-byte line through the L2->L1 path: measured <= 215 G gathers/s even when the
@@ -41,10 +41,10 @@
 #include <type_traits>
 #include <vector>
 
-#include "sort_scan.cuh"
+#include "sort_scan.h"
 
 #include "common.h"
-#include "exact_sum.cuh"
+#include "exact_sum.h"
 
 namespace {
 
@@ -56,7 +56,7 @@ constexpr int kAThreads = 1024;     // blocked path, phase A
 constexpr int kMaxSliceLog2 = 15;   // 32768 sources = 128 KiB of LDS
 constexpr uint32_t kPartEdges = 98304;  // phase-A work item: at most this many edges of one slice
 constexpr int kMaxRowsPerBlock = 2048;  // = 2 rows per lane of phase B
-constexpr uint32_t kMinWaveRow = 128;   // rows of at least `wave_row` (>= this) terms are summed by a wave (exact_sum.cuh)
+constexpr uint32_t kMinWaveRow = 128;   // rows of at least `wave_row` (>= this) terms are summed by a wave (exact_sum.h)
 constexpr uint32_t kWaveRowDefault = 2048;
 constexpr uint32_t kHeavyRowDefault = 128;  // rows of at least this many terms are moved behind the others, longest first
 constexpr int kHThreads = 1024;         // hub rows: one workgroup per row
@@ -166,7 +166,7 @@ __device__ __forceinline__ uint32_t order_wave_rows(WaveRowList &l) {
     return nl;
 }
 
-// the listed rows, one wave each: exact_sum.cuh gives the value of the sequential f32 loop
+// the listed rows, one wave each: exact_sum.h gives the value of the sequential f32 loop
 template <int THREADS>
 __device__ __forceinline__ double wave_rows(const WaveRowList &l, uint32_t nl, const RowBlock rb,
                                             const uint32_t *__restrict__ off, uint32_t e0, const float *tile,
@@ -235,7 +235,7 @@ pr_step_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__
 
 // ---- hub rows: a row longer than a tile, one workgroup per row -------------------------------------------------------
 // The row is gathered tile by tile (two LDS tiles: waves 1..15 gather the next one while wave 0 adds the current one
-// to the running sum with exact_sum.cuh, ~1 cycle per term instead of the ~14 of a one-lane chain).
+// to the running sum with exact_sum.h, ~1 cycle per term instead of the ~14 of a one-lane chain).
 __global__ void __launch_bounds__(kHThreads)
 pr_hub_kernel(const RowBlock *__restrict__ blocks, const uint32_t *__restrict__ src, const uint32_t *__restrict__ out_deg,
               uint32_t row_begin, const float *__restrict__ contrib_in, float *__restrict__ contrib_out,
@@ -547,7 +547,7 @@ pb_reduce_kernel(const RowBlock *__restrict__ blocks, uint32_t blk0, const uint3
     PR_STAMP(1);  // queued pieces (FLAT: the whole fill)
     double err = 0.0;
     // Rows are summed in order (the reference's sequential f32 sum): one lane per row, and the rows of >= wave_row terms
-    // afterwards by a wave each (exact_sum.cuh: the same bits, without the serial chain a skewed graph's sweep waited for).
+    // afterwards by a wave each (exact_sum.h: the same bits, without the serial chain a skewed graph's sweep waited for).
 #if CZ_PR_ROWS_BATCHED
     {
         // Rows of < 32 terms (all of a uniform graph's): the lane's two rows advance together, eight values each per step,
@@ -1062,6 +1062,20 @@ pa_piece_flags_kernel(uint2 *__restrict__ piece, uint32_t n_pieces, uint16_t *__
         arow[d.x + idx] = (uint16_t)(row[j] | (tail ? kAccTail : 0u) | (hb << kAccHopShift));
     }
     if (lane == 0) piece[pi].y = n | (mr << 16);
+}
+
+// the accumulate formulation adds a row's values slice by slice, which is the CSR order only when every in-list ASCENDS
+// (as_directed_graph's CsrLayout::Sorted does); counts the plan rows whose list does not
+__global__ void __launch_bounds__(256)
+pr_unsorted_rows_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ src, uint32_t rows, uint32_t *__restrict__ bad) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+        const uint32_t a = off[r], z = off[r + 1];
+        for (uint32_t e = a + 1; e < z; e++)
+            if (src[e] < src[e - 1]) {
+                atomicAdd(bad, 1u);
+                break;
+            }
+    }
 }
 
 // ---- plan construction kernels (run once) -------------------------------------------------------------------
@@ -1605,7 +1619,7 @@ int build_streamed(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t W, uint3
                        p->d_off, p->d_src, W, S, n_keys, keys_in.p, idx_in.p);
     unsigned bits = 1;
     while ((1ull << bits) <= n_keys) bits++;
-    {   // stable sort of the (key, edge index) pairs by key: csrc/sort_scan.cuh (own kernels since round 4)
+    {   // stable sort of the (key, edge index) pairs by key: csrc/sort_scan.h (own kernels since round 4)
         PoolBuf<uint32_t> d_sort;
         CZ_HIP(d_sort.alloc(czsort::sort_scratch_words(E)));
         bool in_a = true;
@@ -1792,19 +1806,12 @@ int build_streamed(cz_pagerank_plan *p, const uint32_t *h_off, uint32_t W, uint3
             plan_free(p->d_off);
             p->d_off = nullptr;
         }
-        // more than 64 KiB of dynamic LDS has to be asked for, once per kernel
-        static std::once_flag once;
-        std::call_once(once, [] {
-            (void)hipFuncSetAttribute((const void *)pa_reduce_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAccLdsBytes);
-            (void)hipFuncSetAttribute((const void *)pa_reduce_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAccLdsBytes);
-        });
+        // more than 64 KiB of dynamic LDS has to be asked for -- per DEVICE (the attribute belongs to the kernel's code object on the
+        // current device: cz_pagerank_multi builds one plan per device, each on its own thread), so at every plan build, and checked
+        CZ_HIP(hipFuncSetAttribute((const void *)pa_reduce_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAccLdsBytes));
+        CZ_HIP(hipFuncSetAttribute((const void *)pa_reduce_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAccLdsBytes));
     }
-    {
-        static std::once_flag once_a;
-        std::call_once(once_a, [] {
-            (void)hipFuncSetAttribute((const void *)pb_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxAccSlice * 4);
-        });
-    }
+    CZ_HIP(hipFuncSetAttribute((const void *)pb_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxAccSlice * 4));
     p->blocked = G == 0;
     p->accum = G != 0;
     // Adjacent row blocks on one XCD share the boundary lines of their runs (1.82 -> 1.58 GB per sweep on the uniform graph).
@@ -1904,7 +1911,7 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
             CZ_HIP(plan_alloc((void **)&p->d_rowid, (size_t)rows * 4));
             hipLaunchKernelGGL(pr_row_class_kernel, dim3(2048), dim3(256), 0, nullptr, p->d_off, rows, heavy, drop_empty ? 1 : 0,
                                f_light.p, f_heavy.p, f_empty.p, (uint32_t *)nullptr);
-            // scans and the sort of the heavy rows by (inverted length): csrc/sort_scan.cuh (own kernels since round 4)
+            // scans and the sort of the heavy rows by (inverted length): csrc/sort_scan.h (own kernels since round 4)
             PoolBuf<uint32_t> d_ss, hrow_out;
             CZ_HIP(d_ss.alloc(std::max(czsort::scan_scratch_words((uint64_t)rows + 1), czsort::sort_scratch_words(n_heavy))));
             CZ_HIP(hrow_out.alloc(n_heavy));
@@ -1981,6 +1988,22 @@ extern "C" int cz_pagerank_plan_create(const uint32_t *in_offsets, const uint32_
             if (fill >= (mf ? atof(mf) : 0.55)) mode = 3;
             st_plan.lap("formulation choice (slice histogram)");
         }
+    }
+    if (mode == 3 && rows > 0 && E > 0 && n_front_rows > 0) {
+        //  unsorted in-lists: gather and blocked add in CSR order whatever it is, accumulate in slice order -- the same
+        // only for ascending lists.  An explicit request is refused, the heuristic's choice falls back to the blocked formulation.
+        PoolBuf<uint32_t> d_bad;
+        CZ_HIP(d_bad.alloc(1));
+        CZ_HIP(hipMemsetAsync(d_bad.p, 0, 4, nullptr));
+        hipLaunchKernelGGL(pr_unsorted_rows_kernel, dim3(2048), dim3(256), 0, nullptr, p->d_off, p->d_src, n_front_rows, d_bad.p);
+        uint32_t bad = 0;
+        CZ_HIP(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
+        if (bad) {
+            if ((flags & CZ_PR_ACCUMULATE) || getenv("CZ_PR_MODE"))
+                return cz::set_error(CZ_E_INVALID, "CZ_PR_ACCUMULATE needs ascending in-lists (CsrLayout::Sorted): %u rows are not", bad);
+            mode = 2;
+        }
+        st_plan.lap("in-list order check");
     }
     if (mode == 3 && rows > 0 && E > 0) {
         rc = build_streamed(p.get(), in_offsets, shape.W, 1, n_front_rows, &shape);

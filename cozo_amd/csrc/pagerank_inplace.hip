@@ -16,7 +16,7 @@
 // choice rides in the top bit of the stored source id.  Two contribution arrays take turns as old / new (every node is written
 // once per sweep).  Rows are laid out level by level at set-up so that a level's rows are contiguous and their ids stream coalesced;
 // the row sum is the reference's sequential f32 sum (one lane per row through an LDS tile; rows of >= 1 024 terms by a wave through
-// exact_sum.cuh, tile after tile), the epilogue the same two roundings as pagerank.hip.
+// exact_sum.h, tile after tile), the epilogue the same two roundings as pagerank.hip.
 //
 // Set-up (levels by relaxation to the fixed point on the device, the level-major layout by a counting sort on the host) is paid per
 // call: this is the parity path of a reading that may turn out not to be the reference's, not the tuned one.  Roofline: gather-bound
@@ -26,7 +26,7 @@
 #include <vector>
 
 #include "common.h"
-#include "exact_sum.cuh"
+#include "exact_sum.h"
 
 namespace {
 
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(kT) gs_rows_kernel(const Block *__restrict__ b
 }
 
 // the long rows of one level, one workgroup each: all threads gather a tile, wave 0 adds it to the running sum with the wave form
-// of the sequential f32 sum (exact_sum.cuh), tile after tile
+// of the sequential f32 sum (exact_sum.h), tile after tile
 __global__ void __launch_bounds__(kT) gs_long_kernel(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ off2,
                                                      const uint32_t *__restrict__ src2, const uint32_t *__restrict__ order,
                                                      const uint32_t *__restrict__ out_deg, const float *__restrict__ cold,

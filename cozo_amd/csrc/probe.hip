@@ -10,8 +10,8 @@
 // The roofline fractions in bench.py stay priced against the nominal 8 TB/s; these numbers say how much of a box-to-box
 // difference is the box (the same binary measured 0.64-0.76 of the nominal peak on different GPUs).
 #include "common.h"
-#include "exact_sum.cuh"
-#include "sort_scan.cuh"
+#include "exact_sum.h"
+#include "sort_scan.h"
 #include "hnsw_index.h"
 
 namespace {
@@ -184,7 +184,7 @@ extern "C" int cz_hbm_probe(const void *table, uint64_t rows, uint32_t row_bytes
     return CZ_OK;
 }
 
-// ---- test hook: exact_sum.cuh's wave procedure on arbitrary rows (tests/test_gpu_graph.py) -------------------------------------
+// ---- test hook: exact_sum.h's wave procedure on arbitrary rows (tests/test_gpu_graph.py) -------------------------------------
 // PageRank only ever feeds it non-negative finite terms; the paths it maps "past the binade" (negative terms, inf / nan, denormal
 // running sums, a term above the sum's exponent, a negative or non-finite start) are reached through this entry alone.
 namespace {
@@ -212,7 +212,7 @@ extern "C" int cz_debug_seq_sum(const float *terms, const uint64_t *row_off, con
     const uint64_t total = row_off[n_rows];
     cz::DevBuf<float> d_t, d_i, d_o;
     cz::DevBuf<unsigned long long> d_off;
-    CZ_HIP(d_t.alloc(total + 4));  // (a row's last 16-byte vector may reach past its end: exact_sum.cuh masks the lanes, the bytes must exist)
+    CZ_HIP(d_t.alloc(total + 4));  // (a row's last 16-byte vector may reach past its end: exact_sum.h masks the lanes, the bytes must exist)
     CZ_HIP(d_i.alloc(n_rows));
     CZ_HIP(d_o.alloc(n_rows));
     CZ_HIP(d_off.alloc((size_t)n_rows + 1));
@@ -236,7 +236,7 @@ extern "C" int cz_debug_seq_sum(const float *terms, const uint64_t *row_off, con
     return CZ_OK;
 }
 
-// ---- test hook: the plan build's own stable radix sort and scan (csrc/sort_scan.cuh) on arbitrary pairs ------------------------
+// ---- test hook: the plan build's own stable radix sort and scan (csrc/sort_scan.h) on arbitrary pairs ------------------------
 extern "C" int cz_debug_sort_pairs(const uint32_t *keys, const uint32_t *vals, uint64_t n, uint32_t bits, uint32_t *out_keys, uint32_t *out_vals,
                                    uint32_t *out_scan /* [n] exclusive scan of vals, or NULL */) {
     int rc = cz::ensure_device();

@@ -1,4 +1,4 @@
-// sort_scan.cuh -- the two device primitives the PageRank plan build needs, hand-written for gfx950 (round 4: they replace the
+// sort_scan.h -- the two device primitives the PageRank plan build needs, hand-written for gfx950 (round 4: they replace the
 // rocprim::exclusive_scan / rocprim::radix_sort_pairs calls the plan build carried since round 1; the sweep never used a library).
 //
 //   exclusive_scan_u32   tiles of 1 024, recursive on the tile sums (the same scheme as graph.hip's)

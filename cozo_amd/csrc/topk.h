@@ -1,7 +1,7 @@
-// topk.cuh -- running top-k list of a 256-thread workgroup: rank-merge of a batch of up to 256 (key, id) entries into a
+// topk.h -- running top-k list of a 256-thread workgroup: rank-merge of a batch of up to 256 (key, id) entries into a
 // sorted list in LDS (capacity k <= 1024).  Shared by the exhaustive-scan kernels (streaming and GEMM forms).
 #pragma once
-#include "hnsw_kernels.cuh"
+#include "hnsw_kernels.h"
 
 // bkey/bid[0..nb): the batch (ids distinct from each other and from the list => (key, id) is a strict order);
 // tkey/tid_[0..tcnt): the list, ascending by (key, id).  Returns the new list length (uniform).  Starts and ends with

@@ -368,7 +368,7 @@ def label_propagation(out_off, out_tgt, weights, max_iter=10, poison=None, symme
 
 
 def debug_seq_sum(rows, init, lanes=64, per_lane=16):
-    """TEST HOOK (cz_debug_seq_sum): init[r] + rows[r][0] + rows[r][1] + ... one after the other in f32, by csrc/exact_sum.cuh's
+    """TEST HOOK (cz_debug_seq_sum): init[r] + rows[r][0] + rows[r][1] + ... one after the other in f32, by csrc/exact_sum.h's
     wave procedure; rows = a list of float32 arrays."""
     rows = [np.ascontiguousarray(r, dtype=np.float32) for r in rows]
     off = np.zeros(len(rows) + 1, dtype=np.uint64)

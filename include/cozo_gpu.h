@@ -40,12 +40,12 @@ extern "C" {
  * shard's shape; the environment variable CZ_PR_MODE = gather | blocked | accumulate overrides the default too) */
 #define CZ_PR_GATHER 2u
 #define CZ_PR_BLOCKED 4u
-#define CZ_PR_ACCUMULATE 1024u
+#define CZ_PR_ACCUMULATE 1024u /* needs ascending in-lists (CsrLayout::Sorted); refused with CZ_E_INVALID otherwise (the default choice falls back to CZ_PR_BLOCKED) */
 /* cz_knn_bruteforce: compute the B x N dot products as one dense f32 GEMM on the matrix cores (Cosine / IP only;
  * every dot product is then a k-ordered fmaf chain instead of the search kernel's lane-parallel tree) */
 #define CZ_BF_GEMM 8u
 /* (16u was CZ_PR_RELAXED until round 3 -- reordered sums for long rows, out of north_star's 1e-5 on R-MAT.  Removed:
- * long rows are now summed in parallel AND in the reference's sequential f32 order, csrc/exact_sum.cuh.) */
+ * long rows are now summed in parallel AND in the reference's sequential f32 order, csrc/exact_sum.h.) */
 
 typedef enum {
     CZ_OK = 0,
@@ -78,13 +78,13 @@ int cz_hbm_probe(const void *table, uint64_t rows, uint32_t row_bytes, uint64_t 
  * plain loads, and atomicMin without a returned value, in 1e9 accesses per second. */
 int cz_random_access_probe(uint64_t n_words, uint32_t word_bytes, uint64_t n_access, uint32_t reps, double *loads_g_per_s,
                            double *atomic_min_g_per_s);
-/* TEST HOOK: the wave-parallel form of a sequential f32 sum (csrc/exact_sum.cuh, what PageRank's long rows use) on arbitrary rows:
+/* TEST HOOK: the wave-parallel form of a sequential f32 sum (csrc/exact_sum.h, what PageRank's long rows use) on arbitrary rows:
  * out[r] = init[r] + terms[row_off[r]] + terms[row_off[r] + 1] + ... added one after the other in f32, by a group of `lanes`
  * (16 | 64) lanes taking `per_lane` (4 | 8 | 16) terms each per pass.  Host pointers.  Exists so that the paths PageRank's
  * non-negative finite terms never reach (negative terms, inf / nan, denormal sums ...) are tested on the device. */
 int cz_debug_seq_sum(const float *terms, const uint64_t *row_off, const float *init, uint32_t n_rows, int lanes, int per_lane,
                      float *out);
-/* TEST HOOK: the PageRank plan build's own device primitives (csrc/sort_scan.cuh; no library sort / scan on the product path):
+/* TEST HOOK: the PageRank plan build's own device primitives (csrc/sort_scan.h; no library sort / scan on the product path):
  * a STABLE sort of n (key, value) pairs by the low `bits` bits of the key (keys < 2^bits), and the exclusive scan of `vals`
  * (out_scan, optional).  Host pointers. */
 int cz_debug_sort_pairs(const uint32_t *keys, const uint32_t *vals, uint64_t n, uint32_t bits, uint32_t *out_keys, uint32_t *out_vals,

@@ -46,7 +46,7 @@ float orc_dot_ndarray(const float *a, const float *b, size_t n) {
     return sum;
 }
 
-/* Summation tree of the HIP kernels (cozo_amd/csrc/distance.cuh): a vector of `dim` f32 is cut into
+/* Summation tree of the HIP kernels (cozo_amd/csrc/distance.h): a vector of `dim` f32 is cut into
  * 16-byte chunks; LPV lanes (16/32/64, smallest power of two >= #chunks) own chunks lane, lane+LPV, ...;
  * each lane runs one fma chain over its elements in address order; lanes are combined by an xor
  * butterfly with offsets LPV/2 ... 1.  Zero padding participates (fma(0,0,acc)). */
@@ -163,7 +163,7 @@ double orc_dot_ndarray_f64(const double *a, const double *b, size_t n) {
     for (; i < n; i++) sum = sum + a[i] * b[i];
     return sum;
 }
-/* the HIP kernels' tree (cozo_amd/csrc/distance_f64.cuh): 16-byte chunks of TWO doubles; LPV lanes (16 / 32 / 64: the smallest
+/* the HIP kernels' tree (cozo_amd/csrc/distance_f64.h): 16-byte chunks of TWO doubles; LPV lanes (16 / 32 / 64: the smallest
  * power of two >= the chunk count) own chunks lane, lane + LPV, ...; one fma chain per lane in address order; xor butterfly. */
 static int gpu_lpv_f64(int dim) {
     int chunks = (dim + 1) / 2;

@@ -89,7 +89,7 @@ typedef struct {
 } orc_flat_index;
 
 /* VectorCache::dist, the F64 arms (runtime/hnsw.rs:73-78, 86-95, 102-106): every dot product in f64 -- ndarray's unrolled_dot
- * (ORC_DOT_NDARRAY) or the HIP kernels' tree over 16-byte chunks of two doubles (ORC_DOT_GPU, cozo_amd/csrc/distance_f64.cuh) */
+ * (ORC_DOT_NDARRAY) or the HIP kernels' tree over 16-byte chunks of two doubles (ORC_DOT_GPU, cozo_amd/csrc/distance_f64.h) */
 double orc_dot_ndarray_f64(const double *a, const double *b, size_t n);
 double orc_dot_gpu_f64(const double *a, const double *b, int dim);
 double orc_distance_f64(int metric, int dot_mode, const double *a, const double *b, int dim);

@@ -1,4 +1,4 @@
-// exact_sum_test.cpp -- host check of cozo_amd/csrc/exact_sum.cuh: the wave procedure (run here lane by lane, same
+// exact_sum_test.cpp -- host check of cozo_amd/csrc/exact_sum.h: the wave procedure (run here lane by lane, same
 // primitives, same control flow) against the plain sequential f32 loop it must equal bit for bit.
 //   g++ -O1 -ffp-contract=off tests/cpp/exact_sum_test.cpp -o tests/cpp/bin/exact_sum_test && tests/cpp/bin/exact_sum_test
 #include <algorithm>
@@ -9,7 +9,7 @@
 #include <random>
 #include <vector>
 
-#include "../../cozo_amd/csrc/exact_sum.cuh"
+#include "../../cozo_amd/csrc/exact_sum.h"
 
 using namespace cz_exact;
 

@@ -546,6 +546,10 @@ def test_sssp_goals_stop_early_with_the_full_runs_values(oracle, gpu_lib):
     unreachable = np.flatnonzero(~np.isfinite(fd[0]))[:1].astype(np.uint32)
     d, p = G.sssp(g2["ooff"], g2["otgt"], g2["ow"], starts[:1], goals=unreachable)
     assert np.array_equal(d, fd) and np.array_equal(p, fp)
+    # a goal that is no node at all is never settled either (it used to count as settled and stop the search early)
+    n2 = len(fd[0])
+    d, p = G.sssp(g2["ooff"], g2["otgt"], g2["ow"], starts[:1], goals=np.array([n2 + 5], dtype=np.uint32))
+    assert np.array_equal(d, fd) and np.array_equal(p, fp)
 
 
 def test_entry_points_are_reentrant_across_host_threads(oracle, gpu_lib):
@@ -652,7 +656,7 @@ def test_pagerank_accumulate_sweep_bitexact(graphs, hub_graph, oracle, monkeypat
 
 @pytest.mark.parametrize("mode", ["blocked", "gather", "accumulate"])
 def test_pagerank_long_rows_summed_by_waves_keep_the_sequential_bits(oracle, gpu_lib, mode):
-    """Rows of >= 128 terms are summed by a whole wave (csrc/exact_sum.cuh), rows longer than a tile by pr_hub_kernel,
+    """Rows of >= 128 terms are summed by a whole wave (csrc/exact_sum.h), rows longer than a tile by pr_hub_kernel,
     and both must give the bits of the reference's one-after-the-other f32 sum: lengths on both sides of every
     threshold (lane / wave row at 128, pass sizes 512 / 1024, the tiles 4096 / 8192 / 16384), hubs of several tiles."""
     from cozo_amd import graph as G
@@ -979,7 +983,7 @@ def _same_f32(a, b):
 
 @pytest.mark.parametrize("lanes,per_lane", [(64, 16), (64, 8), (64, 4), (16, 16), (16, 4)])
 def test_exact_sum_fallback_paths_on_the_device(gpu_lib, lanes, per_lane):
-    """exact_sum.cuh maps everything outside its integer view -- negative terms, inf / nan, denormal running
+    """exact_sum.h maps everything outside its integer view -- negative terms, inf / nan, denormal running
     sums, a term above the sum's exponent, a negative / non-finite start -- onto true f32 additions, and PageRank's terms
     (non-negative, finite) never go there; until now only the CPU emulation (tests/cpp/exact_sum_test.cpp) did.  Through the
     test hook cz_debug_seq_sum every row here is summed by the device's wave procedure and must equal the plain f32 loop
@@ -1020,7 +1024,7 @@ def test_exact_sum_fallback_paths_on_the_device(gpu_lib, lanes, per_lane):
 
 @pytest.mark.parametrize("n,bits", [(1, 1), (255, 8), (4096, 9), (4097, 16), (100_003, 20), (3_000_000, 11), (700_001, 32)])
 def test_plan_build_sort_and_scan_primitives(gpu_lib, n, bits):
-    """csrc/sort_scan.cuh (round 4: the PageRank plan build's own kernels instead of rocprim's): the radix sort must be STABLE --
+    """csrc/sort_scan.h (round 4: the PageRank plan build's own kernels instead of rocprim's): the radix sort must be STABLE --
     inside a (chunk, slice) key the edges have to stay in (row, source) order -- and the scan exact, ragged tiles included."""
     from cozo_amd import _lib
     rng = np.random.default_rng(n + bits)

@@ -303,7 +303,7 @@ def test_edge_cases(gpu_lib, oracle):
                          ids=["hash", "bitmap", "overflow-at-once", "overflow-midway"])
 def test_visited_set_forms_are_the_same_set(case, oracle, monkeypatch, env):
     """The per-query visited set is a hash table of node ids that spills into the query's bitmap row when it fills up
-    (hnsw_kernels.cuh VisitedDev).  Every form is an exact set: ids, distances and the evaluation count stay those of the
+    (hnsw_kernels.h VisitedDev).  Every form is an exact set: ids, distances and the evaluation count stay those of the
     oracle -- forced hash tables on these small indices, bitmap only, and tables so small that the move to the bitmap
     happens on the first expansion / in the middle of the level-0 search.  Run twice: the workspace must come back clean."""
     from cozo_amd.hnsw import HnswSearch

@@ -415,6 +415,23 @@ def test_batched_build_with_extend_candidates(gpu_lib, oracle, monkeypatch):
     assert rec >= rec_plain - 0.05, (rec, rec_plain)
 
 
+def test_extend_candidates_staging_that_does_not_fit_is_a_clear_oom(gpu_lib, oracle, monkeypatch):
+    """a round of shrinks is staged whole; when the staging does not fit the device the build says so (CZ_E_OOM, with the
+    number of rows that would fit) instead of a bare allocation failure.  The cap is forced through CZ_BUILD_STAGE_CAP_BYTES."""
+    from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest
+    n, dim, m = 6000, 32, 8
+    x = util.vectors(n, dim, 29, "lowrank")
+    levels = oracle.random_levels(n, m, 7)
+    man = HnswIndexManifest(vec_dim=dim, distance="L2", m_neighbours=m, ef_construction=32, extend_candidates=True)
+    monkeypatch.setenv("CZ_BUILD_STAGE_CAP_BYTES", "4096")  # a handful of rows
+    with pytest.raises(Exception) as ei:
+        GpuHnswIndex.build(man, x, levels=levels, max_batch=512)
+    assert "staging" in str(ei.value) and "rows per" in str(ei.value)
+    monkeypatch.delenv("CZ_BUILD_STAGE_CAP_BYTES")
+    g = GpuHnswIndex.build(man, x, levels=levels, max_batch=512)  # the library is fine afterwards
+    assert g.export()[1][0].shape[0] == n
+
+
 def test_write_back_with_extend_candidates_carries_the_degrees(oracle, gpu_lib):
     """The self rows written back hold the reference's degree (cz_hnsw_index_export_degrees -> czi_hnsw_encode_rows_degrees): with
     extend_candidates one above the node's link rows wherever a shrink selected the node itself."""
