@@ -160,6 +160,15 @@ SYMBOLS = {
     "cz_pagerank_inplace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_double, C.c_uint32,
                                       C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_uint32),
                                       C.c_void_p]),
+    "cz_pagerank_inplace_plan_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_uint32,
+                                                  C.POINTER(C.c_void_p)]),
+    "cz_pagerank_inplace_plan_destroy": (None, [C.c_void_p]),
+    "cz_pagerank_inplace_plan_run": (C.c_int, [C.c_void_p, C.c_double, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.c_void_p,
+                                               C.c_void_p]),
+    "cz_pagerank_inplace_plan_init": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cz_pagerank_inplace_plan_sweeps": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "cz_pagerank_inplace_plan_read_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "cz_pagerank_inplace_plan_info": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "cz_comm_multi_shutdown": (None, []),
     "cz_pagerank_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_double,
                                     C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, u32p, f64p, C.c_void_p]),

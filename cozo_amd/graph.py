@@ -66,6 +66,69 @@ def pagerank_inplace(in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_
     return scores, it.value, err.value, lv.value
 
 
+class InplacePageRankPlan:
+    """Resident PageRank under the in-place reading of graph::page_rank (cz_pagerank_inplace_plan_*, csrc/pagerank_inplace.hip):
+    the level-scheduled ascending Gauss-Seidel sweep with its static layout kept in HBM."""
+
+    def __init__(self, in_off, in_src, out_deg, damping=0.85, device_ptrs=False, err_f64_diff=False):
+        """host arrays, or (device_ptrs=True) uint32 device tensors (offsets [N+1], sources [E], out-degrees [N])"""
+        if not device_ptrs:
+            in_off, in_src = _csr32(in_off, in_src)
+            out_deg = _u32(out_deg)
+            N, E = out_deg.size, in_src.size
+        else:
+            N, E = int(out_deg.numel()), int(in_src.numel())
+        h = C.c_void_p()
+        check(_lib.lib().cz_pagerank_inplace_plan_create(ptr(in_off), ptr(in_src), ptr(out_deg), N, E, np.float32(damping),
+                                                         (_lib.CZ_DEVICE_PTRS if device_ptrs else 0)
+                                                         | (_lib.CZ_PR_ERR_F64_DIFF if err_f64_diff else 0), C.byref(h)))
+        self._h, self.N, self.E = h, N, E
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().cz_pagerank_inplace_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, tolerance=1e-4, max_iter=10, poison=None, stream: int = 0):
+        """graph::page_rank's loop from the initial state -> (iterations, error)"""
+        it, err = C.c_uint32(0), C.c_double(0.0)
+        check(_lib.lib().cz_pagerank_inplace_plan_run(self._h, float(tolerance), int(max_iter), C.byref(it), C.byref(err), ptr(poison),
+                                                      C.c_void_p(stream)))
+        return it.value, err.value
+
+    def init(self, stream: int = 0):
+        check(_lib.lib().cz_pagerank_inplace_plan_init(self._h, C.c_void_p(stream)))
+
+    def sweeps(self, n, stream: int = 0):
+        """n more sweeps on `stream`, nothing read back"""
+        check(_lib.lib().cz_pagerank_inplace_plan_sweeps(self._h, int(n), C.c_void_p(stream)))
+
+    def read_scores(self, out=None, stream: int = 0):
+        """scores [N] in the caller's numbering: into a device tensor, or returned as a numpy array"""
+        if out is not None:
+            check(_lib.lib().cz_pagerank_inplace_plan_read_scores(self._h, ptr(out), _lib.CZ_DEVICE_PTRS, C.c_void_p(stream)))
+            return out
+        host = np.empty(self.N, dtype=np.float32)
+        check(_lib.lib().cz_pagerank_inplace_plan_read_scores(self._h, ptr(host), 0, C.c_void_p(stream)))
+        return host
+
+    @property
+    def info(self) -> dict:
+        a = np.zeros(16, dtype=np.uint64)
+        b, h = C.c_double(0), C.c_double(0)
+        check(_lib.lib().cz_pagerank_inplace_plan_info(self._h, ptr(a), C.byref(b), C.byref(h)))
+        d = dict(zip(("levels", "row_blocks", "expand_items", "long_rows", "urgent_gap", "slice_width", "launches_per_sweep", "graph_replay",
+                      "x_edges", "y_edges", "urgent_edges", "long_row_edges", "x_positions", "y_positions"), (int(x) for x in a)))
+        d["host_build_ms"], d["upload_ms"] = b.value, h.value
+        return d
+
+
 class PageRankPlan:
     """Resident / row-sharded PageRank (cz_pagerank_plan_*): rows [row_begin,row_end) of the in-CSR."""
 

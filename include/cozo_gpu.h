@@ -297,11 +297,35 @@ int cz_pagerank(const uint32_t *in_offsets, const uint32_t *in_sources, const ui
  * orc_pagerank_mode(ORC_PR_INPLACE)); with several threads the reference would depend on their schedule.  Level-scheduled on the
  * device (csrc/pagerank_inplace.hip).  Same arguments as cz_pagerank; flags: CZ_PR_ERR_F64_DIFF = the error term is
  * |f64(new) - f64(old)| instead of the f32 difference widened (scores do not depend on it); n_levels (optional): launches per sweep.
- * Which reading is the reference's is decided by tests/test_ref_fixtures.py on a box with cargo; cz_pagerank stays the default. */
+ * Which reading is the reference's is decided by tests/test_ref_fixtures.py on a box with cargo; until then the two readings
+ * have equal standing (bench.py reports both, event-timed). */
 #define CZ_PR_ERR_F64_DIFF 128u
 int cz_pagerank_inplace(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N, uint64_t E,
                         float damping, double tolerance, uint32_t max_iter, uint32_t flags, float *scores, uint32_t *iters_run,
                         double *final_err, uint32_t *n_levels, const volatile uint8_t *poison);
+
+/* The resident form of the in-place reading (round 6): the static layout of the level-scheduled sweep (csrc/inplace_plan.hpp:
+ * level-major numbering, LDS-staged value streams, one hipGraph per sweep parity) is built once and kept in HBM.
+ *   create      in_offsets [N+1], in_sources [E] ascending per row, out_degree [N]: host memory, or device memory with
+ *               CZ_DEVICE_PTRS (the layout is built on the host either way); flags also takes CZ_PR_ERR_F64_DIFF.
+ *               CZ_E_INVALID for lists that do not ascend / sources that are not nodes, CZ_E_UNSUPPORTED for a chain-like graph
+ *               (more than CZ_PR_INPLACE_MAX_LEVELS = 4096 dependence levels).
+ *   run         graph::page_rank's loop from the initial state: sweeps until err < tolerance or max_iter (pagerank.rs:47-50)
+ *   init/sweeps the same loop in the caller's hands: init, then n sweeps on `stream` with nothing read back (what bench.py
+ *               brackets with HIP events)
+ *   read_scores scores [N] in the caller's numbering (host memory, or device memory with CZ_DEVICE_PTRS)
+ *   info        shape [16] u64: levels, row blocks, phase-A items, long rows, urgent gap, slice width, launches per sweep, graph
+ *               replay (1/0), X edges, Y edges, urgent edges, long-row edges, X positions, Y positions; host build / upload ms */
+typedef struct cz_pagerank_inplace_plan cz_pagerank_inplace_plan;
+int cz_pagerank_inplace_plan_create(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N,
+                                    uint64_t E, float damping, uint32_t flags, cz_pagerank_inplace_plan **out);
+void cz_pagerank_inplace_plan_destroy(cz_pagerank_inplace_plan *p);
+int cz_pagerank_inplace_plan_run(cz_pagerank_inplace_plan *p, double tolerance, uint32_t max_iter, uint32_t *iters_run,
+                                 double *final_err, const volatile uint8_t *poison, void *stream);
+int cz_pagerank_inplace_plan_init(cz_pagerank_inplace_plan *p, void *stream);
+int cz_pagerank_inplace_plan_sweeps(cz_pagerank_inplace_plan *p, uint32_t n, void *stream);
+int cz_pagerank_inplace_plan_read_scores(cz_pagerank_inplace_plan *p, float *scores, uint32_t flags, void *stream);
+int cz_pagerank_inplace_plan_info(const cz_pagerank_inplace_plan *p, uint64_t *shape, double *build_ms, double *h2d_ms);
 
 /* The same with the static device layout (CSR upload + blocked plan) kept between calls: `key_hi:key_lo` is the
  * caller's identity of (relation, snapshot) -- e.g. the stored relation's id and the transaction's snapshot; 0:0 = do

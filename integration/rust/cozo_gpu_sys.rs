@@ -37,6 +37,10 @@ pub struct cz_hnsw_index {
 pub struct cz_pagerank_plan {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct cz_pagerank_inplace_plan {
+    _private: [u8; 0],
+}
 
 #[repr(C)]
 pub struct cz_column {
@@ -159,6 +163,18 @@ extern "C" {
     pub fn cz_pagerank_inplace(in_offsets: *const u32, in_sources: *const u32, out_degree: *const u32, n: u32, e: u64, damping: c_float,
                                tolerance: c_double, max_iter: u32, flags: u32, scores: *mut c_float, iters_run: *mut u32,
                                final_err: *mut c_double, n_levels: *mut u32, poison: *const u8) -> c_int;
+    // the resident form of the in-place reading (round 6): layout kept in HBM, one hipGraph per sweep parity
+    pub fn cz_pagerank_inplace_plan_create(in_offsets: *const u32, in_sources: *const u32, out_degree: *const u32, n: u32, e: u64,
+                                           damping: c_float, flags: u32, out: *mut *mut cz_pagerank_inplace_plan) -> c_int;
+    pub fn cz_pagerank_inplace_plan_destroy(p: *mut cz_pagerank_inplace_plan);
+    pub fn cz_pagerank_inplace_plan_run(p: *mut cz_pagerank_inplace_plan, tolerance: c_double, max_iter: u32, iters_run: *mut u32,
+                                        final_err: *mut c_double, poison: *const u8, stream: *mut c_void) -> c_int;
+    pub fn cz_pagerank_inplace_plan_init(p: *mut cz_pagerank_inplace_plan, stream: *mut c_void) -> c_int;
+    pub fn cz_pagerank_inplace_plan_sweeps(p: *mut cz_pagerank_inplace_plan, n: u32, stream: *mut c_void) -> c_int;
+    pub fn cz_pagerank_inplace_plan_read_scores(p: *mut cz_pagerank_inplace_plan, scores: *mut c_float, flags: u32,
+                                                stream: *mut c_void) -> c_int;
+    pub fn cz_pagerank_inplace_plan_info(p: *const cz_pagerank_inplace_plan, shape: *mut u64, build_ms: *mut c_double,
+                                         h2d_ms: *mut c_double) -> c_int;
     pub fn cz_pagerank_cached(key_hi: u64, key_lo: u64, in_offsets: *const u32, in_sources: *const u32,
                               out_degree: *const u32, n: u32, e: u64, damping: c_float, tolerance: c_double, max_iter: u32,
                               flags: u32, scores: *mut c_float, iters_run: *mut u32, final_err: *mut c_double,

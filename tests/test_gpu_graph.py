@@ -76,6 +76,57 @@ def test_pagerank_inplace_self_loops_sinks_and_long_rows(oracle, gpu_lib):
     assert s0.size == 0 and it0 == 0
 
 
+@pytest.mark.parametrize("env", [{}, {"CZ_PR_INPLACE_GAP": "0"}, {"CZ_PR_INPLACE_GAP": "3"}, {"CZ_PR_INPLACE_GRAPH": "0"},
+                                 {"CZ_PR_INPLACE_SLICE": "64", "CZ_PR_INPLACE_PART": "64"},
+                                 {"CZ_PR_INPLACE_TILE": "512", "CZ_PR_INPLACE_SLICE": "128", "CZ_PR_INPLACE_PART": "64"},
+                                 {"CZ_PR_INPLACE_TILE": "32768", "CZ_PR_INPLACE_SLICE": "32768", "CZ_PR_INPLACE_PART": "65536"},
+                                 {"CZ_PR_INPLACE_SLICE": "256", "CZ_PR_INPLACE_PART": "128", "CZ_PR_INPLACE_GAP": "2", "CZ_PR_INPLACE_GRAPH": "0"}])
+def test_pagerank_inplace_resident_plan(graphs, oracle, monkeypatch, env):
+    """cz_pagerank_inplace_plan_* (round 6): the resident form -- layout kept in HBM, the sweep replayed as a hipGraph, one launch per level
+    (phase B of the level + phase A of the level `gap` below).  Whatever the urgent gap, the slice width, graph replay or plain launches: the oracle's scores bit for bit; a
+    plan is reusable (run twice), and init + n sweeps is the run of n iterations."""
+    from cozo_amd import graph as G
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for g in graphs:
+        plan = G.InplacePageRankPlan(g["ioff"], g["isrc"], g["outdeg"], 0.85)
+        info = plan.info
+        assert info["levels"] >= 1 and info["x_edges"] + info["y_edges"] + info["urgent_edges"] + info["long_row_edges"] == len(g["isrc"])
+        for iters in (1, 2, 7):
+            os_, oit, oerr = oracle.pagerank_mode(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, iters, mode=oracle.PR_INPLACE)
+            it, err = plan.run(0.0, iters)
+            assert it == oit and np.array_equal(plan.read_scores(), os_), (env, iters)
+            assert err == pytest.approx(oerr, rel=1e-9)
+        plan.init()
+        plan.sweeps(3)
+        plan.sweeps(4)
+        assert np.array_equal(plan.read_scores(), os_)
+        os_, oit, _ = oracle.pagerank_mode(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, 1e-4, 10, mode=oracle.PR_INPLACE)
+        it, _ = plan.run(1e-4, 10)  # the reference's defaults: the stopping rule
+        assert it == oit and np.array_equal(plan.read_scores(), os_)
+        plan.close()
+
+
+def test_pagerank_inplace_resident_plan_device_arrays(oracle, gpu_lib):
+    """the plan from arrays already in HBM (CZ_DEVICE_PTRS), scores read into a device tensor"""
+    import torch
+    from cozo_amd import graph as G
+    frm, to = util.random_relation(30000, 400000, 77)
+    g = util.graph_from_relation(oracle, frm, to)
+    dev = torch.device("cuda:0")
+    off = torch.from_numpy(g["ioff"].astype(np.int32)).to(dev)
+    src = torch.from_numpy(g["isrc"].astype(np.int32)).to(dev)
+    od = torch.from_numpy(g["outdeg"].astype(np.int32)).to(dev)
+    plan = G.InplacePageRankPlan(off, src, od, 0.85, device_ptrs=True)
+    plan.run(0.0, 4)
+    out = torch.empty(g["n"], dtype=torch.float32, device=dev)
+    plan.read_scores(out)
+    os_, _, _ = oracle.pagerank_mode(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 4, mode=oracle.PR_INPLACE)
+    assert np.array_equal(out.cpu().numpy(), os_) and np.array_equal(plan.read_scores(), os_)
+    assert plan.info["levels"] > 5 and plan.info["graph_replay"] == 1
+    plan.close()
+
+
 def test_pagerank_undirected_and_empty(oracle, gpu_lib):
     from cozo_amd import graph as G
     frm, to = util.random_relation(500, 2000, 5)
