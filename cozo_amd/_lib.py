@@ -121,6 +121,7 @@ SYMBOLS = {
     "cz_hnsw_search_filtered_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_double,
                                           C.POINTER(Predicate), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_uint32, C.c_void_p]),
+    "cz_hnsw_index_distance_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "cz_distance_batch": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                     C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]),
     "cz_distance_batch_f64": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,

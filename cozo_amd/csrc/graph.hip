@@ -1461,7 +1461,8 @@ __device__ __forceinline__ void tri_credit(const uint32_t *__restrict__ tgt, uin
 
 __global__ void __launch_bounds__(256)
 triangles_oriented_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t N,
-                          unsigned long long *__restrict__ n_tri /* zeroed */, uint32_t *__restrict__ degree) {
+                          unsigned long long *__restrict__ n_tri /* zeroed */, uint32_t *__restrict__ degree,
+                          uint32_t *__restrict__ hubs /* [N] */, uint32_t *__restrict__ n_hubs /* zeroed */) {
     const uint32_t glane = threadIdx.x & (kTriLanes - 1);
     const uint32_t group = (blockIdx.x * 256 + threadIdx.x) / kTriLanes, n_groups = (gridDim.x * 256) / kTriLanes;
     for (uint32_t v = group; v < N; v += n_groups) {
@@ -1501,6 +1502,10 @@ triangles_oriented_kernel(const uint32_t *__restrict__ off, const uint32_t *__re
                         if (oc1 == oc) continue;  // repeated (or a neighbour without a list: cannot be, the graph is symmetric)
                         const bool want = first_b && bb < c;
                         uint32_t cnt = 0;
+                        if (oc1 - oc > 2048u) {  // c is a hub: a search per lane instead of its whole list past every lane (a hub
+                                                 // with high ids had its list read once per NEIGHBOUR: degree^2 words)
+                            if (want) cnt = csr_count(tgt, oc, oc1, bb);
+                        } else
                         for (uint32_t k = oc; k < oc1; k += kTriLanes) {
                             uint32_t L = k + glane < oc1 ? tgt[k + glane] : CZ_NONE - 1u;
 #pragma unroll
@@ -1515,19 +1520,54 @@ triangles_oriented_kernel(const uint32_t *__restrict__ off, const uint32_t *__re
             }
             continue;
         }
-        const unsigned long long P = (unsigned long long)m * (m - 1) / 2;
-        for (unsigned long long p = glane; p < P; p += kTriLanes) {
-            uint32_t i = p < (1ull << 22) ? (uint32_t)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f)
-                                          : (uint32_t)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
-            while ((unsigned long long)i * (i - 1) / 2 > p) i--;
-            while ((unsigned long long)(i + 1) * i / 2 <= p) i++;
-            const uint32_t j = (uint32_t)(p - (unsigned long long)i * (i - 1) / 2);
-            const uint32_t pi = s + i, pj = s + j;
-            const uint32_t c = tgt[pi], bb = tgt[pj];  // c >= bb > v
-            // one representative per pair of distinct values: the FIRST position of each value
-            if (c == bb || tgt[pi - 1] == c || (pj > a && tgt[pj - 1] == bb)) continue;
-            const uint32_t m_bc = csr_count(tgt, off[c], off[c + 1], bb);
-            if (m_bc) tri_credit(tgt, a, b, v, pi, pj, m_bc, n_tri);
+        // a hub (more than kTriMerge neighbours above itself): left to triangles_hub_kernel.  Until round 6 one 16-lane group walked
+        // all m (m - 1) / 2 pairs of its list here -- 10^9 pairs for ONE node of a 1M-node R-MAT graph, 114 s for the rule.
+        if (glane == 0) hubs[atomicAdd(n_hubs, 1u)] = v;
+    }
+}
+
+// The hubs.  A triangle {v < bb < c} is found from v through bb's list instead of through the pairs of v's own: for every
+// neighbour bb above v, every c above bb in bb's list, one binary search of c in v's list -- sum over bb of its (short) list
+// instead of the square of v's (long) one.  A hub's neighbours are dealt to gridDim.y workgroups x 16 lane groups; the lanes of a
+// group stride over bb's list.  Same credit, same multiplicities as the merge form.
+__global__ void __launch_bounds__(256)
+triangles_hub_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ hubs,
+                     const uint32_t *__restrict__ n_hubs, unsigned long long *__restrict__ n_tri) {
+    const uint32_t glane = threadIdx.x & (kTriLanes - 1), gi = threadIdx.x / kTriLanes;
+    constexpr uint32_t kGroups = 256 / kTriLanes;
+    const uint32_t nh = *n_hubs;
+    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+        const uint32_t v = hubs[h];
+        const uint32_t a = off[v], b = off[v + 1];
+        uint32_t s = a, hh = b;
+        while (s < hh) {  // first position whose neighbour is above v
+            const uint32_t mid = s + ((hh - s) >> 1);
+            if (tgt[mid] <= v) s = mid + 1;
+            else hh = mid;
+        }
+        for (uint32_t pj = s + blockIdx.y * kGroups + gi; pj < b; pj += gridDim.y * kGroups) {
+            const uint32_t bb = tgt[pj];
+            if (pj > a && tgt[pj - 1] == bb) continue;  // counted at its first position
+            const uint32_t ob = off[bb], ob1 = off[bb + 1];
+            uint32_t lo = ob, hi = ob1;
+            while (lo < hi) {  // bb's neighbours above bb
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (tgt[mid] <= bb) lo = mid + 1;
+                else hi = mid;
+            }
+            for (uint32_t k = lo + glane; k < ob1; k += kTriLanes) {
+                const uint32_t c = tgt[k];
+                if (k > ob && tgt[k - 1] == c) continue;
+                uint32_t m_bc = 1;
+                while (k + m_bc < ob1 && tgt[k + m_bc] == c) m_bc++;
+                uint32_t l = s, r = b;
+                while (l < r) {  // c's first position in v's list
+                    const uint32_t mid = l + ((r - l) >> 1);
+                    if (tgt[mid] < c) l = mid + 1;
+                    else r = mid;
+                }
+                if (l < b && tgt[l] == c) tri_credit(tgt, a, b, v, l, pj, m_bc, n_tri);
+            }
         }
     }
 }
@@ -1583,9 +1623,15 @@ extern "C" int cz_clustering_coefficients(const uint32_t *offsets, const uint32_
     if (general) {
         hipLaunchKernelGGL(triangles_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, nullptr, d_off.p, d_tgt.p, N, d_tri.p, d_deg.p);
     } else {
+        cz::DevBuf<uint32_t> d_hubs, d_nhubs;
+        CZ_HIP(d_hubs.alloc(N));
+        CZ_HIP(d_nhubs.alloc(1));
+        CZ_HIP(hipMemsetAsync(d_nhubs.p, 0, 4, nullptr));
         CZ_HIP(hipMemsetAsync(d_tri.p, 0, (size_t)N * 8, nullptr));
         hipLaunchKernelGGL(triangles_oriented_kernel, dim3(grid_for((uint64_t)N * kTriLanes)), dim3(256), 0, nullptr, d_off.p, d_tgt.p, N,
-                           d_tri.p, d_deg.p);
+                           d_tri.p, d_deg.p, d_hubs.p, d_nhubs.p);
+        hipLaunchKernelGGL(triangles_hub_kernel, dim3(512, 32), dim3(256), 0, nullptr, d_off.p, d_tgt.p, d_hubs.p, d_nhubs.p, d_tri.p);
+        CZ_HIP(hipDeviceSynchronize());  // (the hub list dies with this scope)
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cz::set_error(CZ_E_HIP, "triangles launch: %s", hipGetErrorString(e));

@@ -1422,6 +1422,53 @@ pad_rows_f64_kernel(const double *__restrict__ src, double *__restrict__ dst, ui
     }
 }
 
+// VectorCache::dist over (query, node) pairs against the vectors of an INDEX (runtime/hnsw.rs:66-109 is only ever called on index
+// nodes): the base table is the index's resident, settled one -- the same rows, padding and alignment the search kernel reads, and
+// the landing cz_hnsw_index_settle chose -- instead of a bare array the caller happened to allocate (the
+// batched-distance roofline target is defined on this kernel, and a bare 30 GB table lands anywhere between 0.65 and 0.73).
+// queries [nq][dim] and pairs [P][2] = (query row, node), out [P] f64: host memory, or device memory with CZ_DEVICE_PTRS.
+extern "C" int cz_hnsw_index_distance_batch(cz_hnsw_index *h, const float *queries, uint32_t nq, const uint32_t *pairs, uint64_t P,
+                                            double *out, uint32_t flags, void *stream_) {
+    int rc = cz::ensure_device();
+    if (rc) return rc;
+    if (!h) return cz::set_error(CZ_E_INVALID, "null index");
+    auto *ix = reinterpret_cast<cz::HnswIndex *>(h);
+    if (ix->f64()) return cz::set_error(CZ_E_UNSUPPORTED, "an F64 index: use cz_distance_batch_f64 on the vectors");
+    if (P == 0) return CZ_OK;
+    if (!queries || !pairs || !out) return cz::set_error(CZ_E_INVALID, "null buffer");
+    hipStream_t stream = (hipStream_t)stream_;
+    const uint32_t dim = ix->dim, ld = ix->ld;
+    cz::DevBuf<float> pq;
+    cz::DevBuf<uint32_t> dp;
+    cz::DevBuf<double> dout;
+    const float *d_q = queries;
+    const uint32_t *d_pairs = pairs;
+    double *d_out = out;
+    const bool dev = (flags & CZ_DEVICE_PTRS) != 0;
+    if (dev) {
+        if (ld != dim) {  // repack the queries to the table's row length
+            CZ_HIP(pq.alloc((size_t)nq * ld));
+            hipLaunchKernelGGL(pad_rows_kernel, dim3(256), dim3(256), 0, stream, queries, pq.p, (uint64_t)nq, dim, ld);
+            d_q = pq.p;
+        }
+    } else {
+        CZ_HIP(pq.alloc((size_t)nq * ld));
+        CZ_HIP(dp.alloc((size_t)P * 2));
+        CZ_HIP(dout.alloc(P));
+        rc = upload_padded(queries, nq, dim, ld, pq.p);
+        if (rc) return rc;
+        CZ_HIP(hipMemcpyAsync(dp.p, pairs, (size_t)P * 8, hipMemcpyHostToDevice, stream));
+        d_q = pq.p;
+        d_pairs = dp.p;
+        d_out = dout.p;
+    }
+    rc = distance_pairs_device(ix->metric, ix->vec, d_q, ld, dim, d_pairs, P, ix->n, nq, d_out, stream);
+    if (rc) return rc;
+    if (!dev) CZ_HIP(hipMemcpyAsync(out, dout.p, (size_t)P * 8, hipMemcpyDeviceToHost, stream));
+    if (!dev || pq.p) CZ_HIP(hipStreamSynchronize(stream));  // temporaries die with this scope
+    return CZ_OK;
+}
+
 extern "C" int cz_distance_batch_f64(int metric, const double *base, uint32_t n, uint32_t dim, const double *queries, uint32_t nq,
                                      const uint32_t *pairs, uint64_t P, double *out, uint32_t flags, void *stream_) {
     int rc = cz::ensure_device();

@@ -51,7 +51,7 @@ constexpr uint32_t kLongTile = 8192;   // long rows: values gathered per round
 constexpr uint32_t kWaveRow = 192;     // rows of at least this many terms are added by a wave
 constexpr uint32_t kMaxWaveRows = 32768 / kWaveRow + 2;
 #ifndef CZ_GI_F
-#define CZ_GI_F 6  // stream groups (four values each) in flight per lane of a row block: a 16384-value tile at once
+#define CZ_GI_F 4  // stream groups (four values each) in flight per lane of a row block: a 16384-value tile at once
 #endif
 constexpr uint32_t kOldBit = czgs::kOldBit;
 constexpr uint32_t kYBit = czgs::kYBit;
@@ -254,7 +254,10 @@ __device__ __forceinline__ void reduce_role(const Block b, float *tile, const Le
 // One launch per level: workgroups [0, nb) are the level's row blocks (phase B), the rest the phase-A items of the level
 // `urgent_gap` below it -- the two are independent (csrc/inplace_plan.hpp), so phase A fills the chip beside phase B without a
 // second stream or an event (a dependency between two branches of a hipGraph measured ~8 us; a kernel boundary ~1.5).
-__global__ void __launch_bounds__(kLT) gi_level_kernel(const LevelArgs a) {
+#ifndef CZ_GI_WAVES
+#define CZ_GI_WAVES 8  // waves per SIMD the level kernel is compiled for: 8 = two 1024-thread workgroups per CU (64 VGPRs)
+#endif
+__global__ void __launch_bounds__(kLT) __attribute__((amdgpu_waves_per_eu(CZ_GI_WAVES, CZ_GI_WAVES))) gi_level_kernel(const LevelArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ double red[kLT / 64];
     __shared__ uint32_t wrow[kMaxWaveRows], n_wrow;

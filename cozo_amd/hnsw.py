@@ -379,6 +379,19 @@ class GpuHnswIndex:
                                            CZ_DEVICE_PTRS | (_lib.CZ_BF_GEMM if gemm else 0), C.c_void_p(stream)))
 
 
+    def distance_batch(self, queries: np.ndarray, pairs: np.ndarray) -> np.ndarray:
+        """VectorCache::dist over (query row, node) pairs against this index's resident vectors (cz_hnsw_index_distance_batch)"""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        pr = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        out = np.empty(pr.shape[0], dtype=np.float64)
+        check(_lib.lib().cz_hnsw_index_distance_batch(self._h, ptr(q), q.shape[0], ptr(pr), pr.shape[0], ptr(out), 0, None))
+        return out
+
+    def distance_batch_device(self, queries, pairs, out, stream: int = 0):
+        check(_lib.lib().cz_hnsw_index_distance_batch(self._h, ptr(queries), queries.shape[0], ptr(pairs), pairs.shape[0], ptr(out),
+                                                      CZ_DEVICE_PTRS, C.c_void_p(stream)))
+
+
 class DeviceColumn:
     """a per-node numeric column resident in HBM (cz_column)"""
 

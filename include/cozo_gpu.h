@@ -265,6 +265,11 @@ int cz_hnsw_search_filtered_f64(cz_hnsw_index *ix, const double *queries, uint32
  *   base [n][dim], queries [nq][dim], pairs [P][2] = (query row, base row), out [P] f64  [all dev-able] */
 int cz_distance_batch(int metric, const float *base, uint32_t n, uint32_t dim, const float *queries, uint32_t nq,
                       const uint32_t *pairs, uint64_t P, double *out, uint32_t flags, void *stream);
+/* The same over the vectors of an INDEX (VectorCache::dist is only ever called on index nodes): pairs [P][2] = (query row, node).
+ * The base table is the index's resident, settled one (cz_hnsw_index_settle), not a bare array wherever the caller's allocation
+ * landed -- the form the batched-distance roofline is quoted on.  Results are cz_distance_batch's, bit for bit.  [dev-able] */
+int cz_hnsw_index_distance_batch(cz_hnsw_index *ix, const float *queries, uint32_t nq, const uint32_t *pairs, uint64_t P,
+                                 double *out, uint32_t flags, void *stream);
 /* the F64 arms of VectorCache::dist (hnsw.rs:73-78, 86-95, 102-106): base / queries f64, every dot product in f64 */
 int cz_distance_batch_f64(int metric, const double *base, uint32_t n, uint32_t dim, const double *queries, uint32_t nq,
                           const uint32_t *pairs, uint64_t P, double *out, uint32_t flags, void *stream);

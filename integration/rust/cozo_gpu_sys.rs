@@ -154,6 +154,8 @@ extern "C" {
                                  pairs: *const u32, p: u64, out: *mut c_double, flags: u32, stream: *mut c_void) -> c_int;
     pub fn cz_distance_batch(metric: c_int, base: *const c_float, n: u32, dim: u32, queries: *const c_float, nq: u32,
                              pairs: *const u32, p: u64, out: *mut c_double, flags: u32, stream: *mut c_void) -> c_int;
+    pub fn cz_hnsw_index_distance_batch(ix: *mut cz_hnsw_index, queries: *const c_float, nq: u32, pairs: *const u32, p: u64,
+                                        out: *mut c_double, flags: u32, stream: *mut c_void) -> c_int;
     pub fn cz_knn_bruteforce(ix: *mut cz_hnsw_index, queries: *const c_float, b: u32, k: u32, out_ids: *mut u32,
                              out_dist: *mut c_double, flags: u32, stream: *mut c_void) -> c_int;
 

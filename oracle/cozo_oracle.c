@@ -1050,6 +1050,55 @@ int orc_pagerank_mode(uint32_t n, const uint64_t *in_off, const uint32_t *in_src
     return 0;
 }
 
+/* The in-place reading on T rayon threads, as ONE deterministic schedule: the crate hands out 16 384-node
+ * chunks through an atomic counter; here the T threads run in lockstep -- in round k thread t owns chunk k*T + t, and the threads
+ * advance node by node together (step s: thread 0's node s, thread 1's node s, ...), each writing its contribution at once.  No
+ * real run follows this schedule exactly; it is a representative of "several threads, contributions refreshed inside the sweep",
+ * used to state how far such a run can be from the one-thread sweep and from the Jacobi reading (bench.py pagerank.readings).
+ * threads == 1 is orc_pagerank_mode(ORC_PR_INPLACE). */
+int orc_pagerank_inplace_lockstep(uint32_t n, const uint64_t *in_off, const uint32_t *in_src, const uint32_t *out_deg, float damping,
+                                  double tolerance, uint32_t max_iter, uint32_t threads, uint32_t chunk, float *scores,
+                                  uint32_t *iters_run, double *final_err) {
+    if (iters_run) *iters_run = 0;
+    if (final_err) *final_err = 0;
+    if (n == 0) return 0;
+    if (threads == 0) threads = 1;
+    if (chunk == 0) chunk = 16384;
+    const float init = 1.0f / (float)n;
+    const float base = (1.0f - damping) / (float)n;
+    float *contrib = (float *)malloc(sizeof(float) * n);
+    for (uint32_t v = 0; v < n; v++) {
+        scores[v] = init;
+        contrib[v] = init / (float)out_deg[v];
+    }
+    const uint64_t n_chunks = ((uint64_t)n + chunk - 1) / chunk;
+    uint32_t it = 0;
+    double err = 0;
+    for (;;) {
+        err = 0;
+        for (uint64_t c0 = 0; c0 < n_chunks; c0 += threads)
+            for (uint32_t s = 0; s < chunk; s++)
+                for (uint32_t t = 0; t < threads && c0 + t < n_chunks; t++) {
+                    const uint64_t u64 = (c0 + t) * chunk + s;
+                    if (u64 >= n) continue;
+                    const uint32_t u = (uint32_t)u64;
+                    float sum = 0.0f;
+                    for (uint64_t e = in_off[u]; e < in_off[u + 1]; e++) sum = sum + contrib[in_src[e]];
+                    const float old = scores[u];
+                    const float nw = base + damping * sum;
+                    scores[u] = nw;
+                    contrib[u] = nw / (float)out_deg[u];
+                    err += fabs((double)(nw - old));
+                }
+        it++;
+        if (err < tolerance || it == max_iter) break;
+    }
+    free(contrib);
+    if (iters_run) *iters_run = it;
+    if (final_err) *final_err = err;
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * ShortestPathBFS, fixed_rule/algos/shortest_path_bfs.rs:65-94.  FIFO queue, neighbours in sorted
  * key order, parent = first discoverer, `pending.is_empty()` only breaks the inner loop.
@@ -1312,6 +1361,47 @@ void orc_clustering_coefficients(uint32_t n, const uint64_t *off, const uint32_t
     }
 }
 
+
+/* the same loop on a SAMPLE of the nodes (v = first, first + step, ...), stopped after max_seconds: what bench.py times as the CPU
+ * baseline of ClusteringCoefficients where the whole graph would take minutes (the literal loop is cubic in a hub's degree).
+ * n_tri[v] is written for the processed nodes only; returns their number, *edges = the adjacency entries of their rows. */
+#include <time.h>
+uint64_t orc_clustering_coefficients_sample(uint32_t n, const uint64_t *off, const uint32_t *tgt, uint32_t first, uint32_t step,
+                                            double max_seconds, uint64_t *n_tri, uint64_t *edges) {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    uint64_t done = 0, ne = 0;
+    if (step == 0) step = 1;
+    for (uint64_t v64 = first; v64 < n; v64 += step) {
+        const uint32_t v = (uint32_t)v64;
+        const uint64_t a = off[v], b = off[v + 1];
+        uint64_t t = 0;
+        if (b - a >= 2) {
+            for (uint64_t i = a; i < b; i++) {
+                const uint32_t e_src = tgt[i];
+                for (uint64_t j = a; j < b; j++) {
+                    const uint32_t e_dst = tgt[j];
+                    if (e_src <= e_dst) continue;
+                    for (uint64_t k = off[e_src]; k < off[e_src + 1]; k++) {
+                        if (tgt[k] == e_dst) {
+                            t++;
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+        n_tri[v] = t;
+        done++;
+        ne += b - a;
+        if ((done & 1023u) == 0) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > max_seconds) break;
+        }
+    }
+    if (edges) *edges = ne;
+    return done;
+}
 
 /* ------------------------------------------------------------------------------------------
  * BetweennessCentrality::run, fixed_rule/algos/all_pairs_shortest_path.rs:31-95, over dijkstra_keep_ties

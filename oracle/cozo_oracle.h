@@ -129,6 +129,10 @@ int orc_pagerank(uint32_t n, const uint64_t *in_off, const uint32_t *in_src, con
 int orc_pagerank_mode(uint32_t n, const uint64_t *in_off, const uint32_t *in_src, const uint32_t *out_deg, float damping,
                       double tolerance, uint32_t max_iter, int mode, int err_f64_diff, float *scores, uint32_t *iters_run,
                       double *final_err);
+/* the in-place reading on `threads` rayon threads under ONE deterministic lockstep schedule of the crate's 16 384-node chunks (see the .c) */
+int orc_pagerank_inplace_lockstep(uint32_t n, const uint64_t *in_off, const uint32_t *in_src, const uint32_t *out_deg, float damping,
+                                  double tolerance, uint32_t max_iter, uint32_t threads, uint32_t chunk, float *scores,
+                                  uint32_t *iters_run, double *final_err);
 
 /* ---- ShortestPathBFS (fixed_rule/algos/shortest_path_bfs.rs:35-113) ---- */
 /* parent[n]: ORC_NONE when no backtrace entry.  Goal semantics as the reference (start itself has no entry). */
@@ -146,6 +150,9 @@ uint32_t orc_tarjan_groups(uint32_t n, const uint64_t *off, const uint32_t *tgt,
 /* ---- ClusteringCoefficients (algos/triangles.rs:25-110) on the symmetrised out-CSR (duplicates kept) ---- */
 void orc_clustering_coefficients(uint32_t n, const uint64_t *off, const uint32_t *tgt, double *cc, uint64_t *n_tri,
                                  uint32_t *degree);
+/* the same loop over the nodes first, first + step, ... until max_seconds are spent (bench.py's bounded CPU baseline) */
+uint64_t orc_clustering_coefficients_sample(uint32_t n, const uint64_t *off, const uint32_t *tgt, uint32_t first, uint32_t step,
+                                            double max_seconds, uint64_t *n_tri, uint64_t *edges);
 
 /* ---- ShortestPathDijkstra (algos/shortest_path_dijkstra.rs:274-339) ---- */
 /* goals NULL => all nodes.  dist[n] f32 (inf unreachable), parent[n] (ORC_NONE) */

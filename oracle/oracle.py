@@ -114,6 +114,9 @@ def lib():
         L.orc_assign_ids.argtypes = [_i64p, _i64p, C.c_uint64, _u32p, _u32p, _i64p]
         L.orc_build_csr.restype = None
         L.orc_build_csr.argtypes = [C.c_uint32, C.c_uint64, _u32p, _u32p, _f32p, C.c_int, _u64p, _u32p, _f32p]
+        L.orc_pagerank_inplace_lockstep.restype = C.c_int
+        L.orc_pagerank_inplace_lockstep.argtypes = [C.c_uint32, _u64p, _u32p, _u32p, C.c_float, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                    _f32p, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         L.orc_pagerank_mode.restype = C.c_int
         L.orc_pagerank_mode.argtypes = [C.c_uint32, _u64p, _u32p, _u32p, C.c_float, C.c_double, C.c_uint32, C.c_int, C.c_int,
                                         _f32p, _u32p, C.POINTER(C.c_double)]
@@ -371,6 +374,19 @@ def pagerank_mode(n, in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_
     return scores, it.value, err.value
 
 
+def pagerank_inplace_lockstep(n, in_off, in_src, out_deg, damping=0.85, tolerance=1e-4, max_iter=10, threads=8, chunk=16384):
+    """the in-place reading on `threads` rayon threads under one deterministic lockstep schedule of the crate's chunks
+    (cozo_oracle.c: orc_pagerank_inplace_lockstep); threads=1 is pagerank_mode(mode=PR_INPLACE)"""
+    in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+    in_src, out_deg = _u32(in_src), _u32(out_deg)
+    scores = np.empty(n, dtype=np.float32)
+    it = C.c_uint32(0)
+    err = C.c_double(0)
+    lib().orc_pagerank_inplace_lockstep(n, _p(in_off, _u64p), _p(in_src, _u32p), _p(out_deg, _u32p), np.float32(damping),
+                                        float(tolerance), max_iter, int(threads), int(chunk), _p(scores, _f32p), C.byref(it), C.byref(err))
+    return scores, it.value, err.value
+
+
 def shortest_path_bfs(n, off, tgt, start, goals):
     off = np.ascontiguousarray(off, dtype=np.uint64)
     tgt, goals = _u32(tgt), _u32(goals)
@@ -423,6 +439,21 @@ def clustering_coefficients(n, off, tgt):
     lib().orc_clustering_coefficients(n, _p(off, _u64p), _p(tgt, _u32p), cc.ctypes.data_as(C.POINTER(C.c_double)),
                                       _p(tri, _u64p), _p(deg, _u32p))
     return cc, tri, deg
+
+
+def clustering_coefficients_sample(n, off, tgt, first=0, step=16, max_seconds=15.0):
+    """triangles.rs:70-110 on the nodes first, first + step, ... until max_seconds are spent
+    -> (node ids processed, their n_triangles, adjacency entries of their rows)"""
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    tgt = _u32(tgt)
+    tri = np.zeros(n, dtype=np.uint64)
+    ne = C.c_uint64(0)
+    fn = lib().orc_clustering_coefficients_sample
+    fn.restype = C.c_uint64
+    done = int(fn(C.c_uint32(n), _p(off, _u64p), _p(tgt, _u32p), C.c_uint32(first), C.c_uint32(step), C.c_double(max_seconds), _p(tri, _u64p),
+                  C.byref(ne)))
+    nodes = (first + step * np.arange(done, dtype=np.int64)).astype(np.int64)
+    return nodes, tri[nodes], int(ne.value)
 
 
 def dijkstra(n, off, tgt, w, start, goals=None):

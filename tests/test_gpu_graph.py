@@ -603,6 +603,38 @@ def test_sssp_goals_stop_early_with_the_full_runs_values(oracle, gpu_lib):
     assert np.array_equal(d, fd) and np.array_equal(p, fp)
 
 
+@pytest.mark.parametrize("hubs_low", [True, False])
+def test_clustering_coefficients_with_hubs(oracle, gpu_lib, hubs_low):
+    """Round 6: a node with more than 256 neighbours above itself used to enumerate the pairs of its own list (a 1M-node R-MAT graph:
+    114 s); now a triangle is found from the hub through its neighbours' lists (triangles_hub_kernel), and a hub met as the larger
+    corner is searched instead of scanned.  Hubs at the low ids (R-MAT as generated) and at the high ids; counts against A^2 (*) A
+    on a simple symmetric graph (no parallel edges: the relation holds each pair once, a < b) and against the oracle's literal loop
+    on a sample of the nodes."""
+    import scipy.sparse as sp
+    from cozo_amd import graph as G
+    n = 6000
+    rng = np.random.default_rng(17)
+    a = (rng.random(120000) ** 4 * n).astype(np.int64)  # skewed towards 0
+    b = rng.integers(0, n, 120000)
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    keep = lo != hi
+    pairs = np.unique(np.stack([lo[keep], hi[keep]], 1), axis=0)
+    if not hubs_low:
+        pairs = np.sort(n - 1 - pairs, axis=1)
+    src = np.concatenate([pairs[:, 0], pairs[:, 1]]).astype(np.uint32)
+    dst = np.concatenate([pairs[:, 1], pairs[:, 0]]).astype(np.uint32)
+    off, tgt = oracle.build_csr(n, src, dst)
+    deg_want = np.diff(off.astype(np.int64))
+    assert deg_want.max() > 1500
+    A = sp.csr_matrix((np.ones(tgt.size, dtype=np.int64), tgt.astype(np.int64), off.astype(np.int64)), shape=(n, n))
+    want = np.asarray((A @ A).multiply(A).sum(axis=1)).ravel() // 2
+    for symmetric in (True, False):
+        tri, deg = G.clustering_coefficients(off, tgt, symmetric=symmetric)
+        assert np.array_equal(deg, deg_want) and np.array_equal(tri.astype(np.int64), want)
+    nodes, otri, _ = oracle.clustering_coefficients_sample(n, off, tgt, first=n // 2, step=7, max_seconds=5.0)
+    assert len(nodes) > 100 and np.array_equal(tri[nodes], otri)
+
+
 def test_entry_points_are_reentrant_across_host_threads(oracle, gpu_lib):
     """`FixedRule: Send + Sync`: sibling rules run on rayon workers (query/eval.rs:199-207) and scripts run concurrently,
     so the C ABI is called from several host threads at once.  Four threads x (PageRank, CC, BFS, triangles) on different

@@ -1,8 +1,15 @@
 """GPU parity: distances and HNSW k-NN search through the C ABI vs the CPU oracle (same seeded inputs).
 
-Bars: the traversal (ids, visit counts) must be bit-identical to the oracle when the oracle uses the
-kernels' summation tree (ORC_DOT_GPU); distances must be within 1e-5 relative of the reference's ndarray
-summation order (ORC_DOT_NDARRAY) -- the tolerance BASELINE.json's north_star states for f32 distances."""
+Two different statements are made here; they are not the same strength and are kept apart:
+
+ * BIT-EQUALITY with ORC_DOT_GPU -- an oracle mode written to restate the kernels' OWN summation tree.  It proves the CPU restatement
+   of the kernel and the kernel agree (and pins the traversal: ids, visit counts).  It says nothing about the reference's arithmetic.
+ * The INDEPENDENT statement: distances against ORC_DOT_NDARRAY, the reference's ndarray summation order (runtime/hnsw.rs:66-109).
+   north_star's bar is 1e-5 RELATIVE to the reference's value, and that is what is asserted for every pair whose value is not the
+   difference of much larger terms.  Where the value cancels (`1 - x` near 0 for Cosine / IP, L2 of nearly equal vectors: |ref| below
+   5 % of the magnitude the f32 sums work at) two f32 summation orders of the same dot cannot agree tighter than eps * sum|a_i b_i|
+   in ABSOLUTE terms; there the FALLBACK bound is 1e-5 of that magnitude.  The fallback is weaker than north_star's bar; the tests
+   print how many pairs took it (`fallback_pairs`), and bench.py's `parity` object carries the same count for the timed batch."""
 import numpy as np
 import pytest
 
@@ -37,9 +44,14 @@ def test_distance_batch_matches_oracle(gpu_lib, oracle, dim, name, metric):
     finite = np.isfinite(ref)
     true_rel = np.abs(got - ref)[finite] / np.maximum(np.abs(ref[finite]), 1e-300)
     well = np.abs(ref[finite]) >= 0.05 * mag[finite]
+    print(f"dim {dim} {name}: north_star bound on {int(well.sum())} pairs, fallback_pairs {int((~well).sum())}")
     if well.any():
-        assert true_rel[well].max() <= RTOL, true_rel[well].max()
-    assert np.max(np.abs(got - ref)[finite] / np.maximum(mag[finite], 1e-300)) <= RTOL
+        assert true_rel[well].max() <= RTOL, true_rel[well].max()  # north_star's bar
+    assert np.max(np.abs(got - ref)[finite] / np.maximum(mag[finite], 1e-300)) <= RTOL  # the cancellation fallback (all pairs satisfy it)
+    if dim in (33, 768):  # the same pairs against the vectors of an INDEX (cz_hnsw_index_distance_batch): the same bits
+        _, flat = util.build_index(oracle, base, metric, 8, 32)
+        gix = util.gpu_index(flat, name, 8)
+        assert np.array_equal(gix.distance_batch(q, pairs), got)
 
 
 @pytest.mark.parametrize("dim,nq", [(33, 17), (128, 4000), (768, 60), (1000, 300), (2052, 9)])
