@@ -21,6 +21,7 @@ CZ_PR_ACCUMULATE = 1024
 CZ_PR_EXCHANGE_ALLREDUCE = 32
 CZ_PR_OVERLAP_EXCHANGE = 64
 CZ_PR_ERR_F64_DIFF = 128
+CZ_PR_INPLACE_AS_JACOBI = 2048
 CZ_ADJ_SYMMETRIC = 512
 CZ_UNIQUE_ID_BYTES = 128
 CZ_L2, CZ_COSINE, CZ_IP = 0, 1, 2

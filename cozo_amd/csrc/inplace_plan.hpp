@@ -43,6 +43,8 @@ struct Params {
     uint32_t part = 16384;           // stream positions of one phase-A work item (multiple of 4)
     uint32_t urgent_gap = 1;         // forward edges over at most this many levels are gathered; 0: none (phase A between the levels)
     uint32_t max_levels = 4096;
+    bool jacobi = false;             // every edge reads the PREVIOUS sweep's contribution: one level, all edges class Y -- graph::page_rank's
+                                     // other reading (oracle orc_pagerank) in this layout (an experiment: csrc/pagerank.hip is its product path)
 };
 
 struct Block {   // phase B work item
@@ -108,7 +110,7 @@ inline bool build_plan(const OffT *in_off, const uint32_t *in_src, const uint32_
         uint32_t best = 0;
         for (uint64_t e = in_off[u]; e < (uint64_t)in_off[u + 1]; e++) {
             const uint32_t v = in_src[e];
-            if (v >= u) break;  // ascending: the rest are "old"
+            if (v >= u || prm.jacobi) break;  // ascending: the rest are "old"
             best = std::max(best, level[v] + 1u);
         }
         level[u] = best;
@@ -160,7 +162,7 @@ inline bool build_plan(const OffT *in_off, const uint32_t *in_src, const uint32_
                 const uint32_t u = p.order[i];
                 for (uint64_t e = in_off[u]; e < (uint64_t)in_off[u + 1]; e++) {
                     const uint32_t v = in_src[e];
-                    p.long_src.push_back(inv[v] | (v >= u ? kOldBit : 0u));
+                    p.long_src.push_back(inv[v] | ((v >= u || prm.jacobi) ? kOldBit : 0u));
                 }
                 p.long_off.push_back((uint32_t)p.long_src.size());
                 p.n_long_edges += p.off2[i + 1] - p.off2[i];
@@ -191,18 +193,19 @@ inline bool build_plan(const OffT *in_off, const uint32_t *in_src, const uint32_
             uint32_t t = p.off2[r];  // position in the level-major CSR
             for (uint64_t e = in_off[u]; e < (uint64_t)in_off[u + 1]; e++, t++) {
                 const uint32_t v = in_src[e], lv = level[v], vi = inv[v];
-                if (v < u && lu - lv <= prm.urgent_gap) {
+                const bool old = v >= u || prm.jacobi;
+                if (!old && lu - lv <= prm.urgent_gap) {
                     code[t] = kOldBit | vi;
                     nu++;
                 } else {
                     const uint32_t rel = vi - p.first[lv];
                     const uint32_t sl = slice_first[lv] + rel / prm.slice;
-                    const uint32_t bucket = 2u * sl + (v >= u ? 1u : 0u);
+                    const uint32_t bucket = 2u * sl + (old ? 1u : 0u);
                     code[t] = bucket;
                     // the local id carries the slice's misalignment: phase A stages aligned 16-byte vectors, LDS word 0 = node (node0 & ~3)
                     loc[t] = (uint16_t)(rel % prm.slice + ((p.first[lv] + (rel / prm.slice) * prm.slice) & 3u));
                     if (lcnt[bucket]++ == 0) touched.push_back(bucket);
-                    p.n_edges[v >= u ? 1 : 0]++;
+                    p.n_edges[old ? 1 : 0]++;
                 }
             }
         }

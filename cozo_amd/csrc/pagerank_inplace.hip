@@ -539,6 +539,7 @@ extern "C" int cz_pagerank_inplace_plan_create(const uint32_t *in_offsets, const
     prm.part &= ~3u;
     if ((rc = env_u32("CZ_PR_INPLACE_GAP", 1, 0, 64, &prm.urgent_gap))) return rc;
     if ((rc = env_u32("CZ_PR_INPLACE_MAX_LEVELS", 4096, 1, 1u << 24, &prm.max_levels))) return rc;
+    if (flags & CZ_PR_INPLACE_AS_JACOBI) prm.jacobi = true;
     czgs::Plan h;
     if (!czgs::build_plan(in_offsets, in_sources, out_degree, N, prm, h))
         return cz::set_error(h.error.find("dependence levels") != std::string::npos ? CZ_E_UNSUPPORTED : CZ_E_INVALID, "%s", h.error.c_str());

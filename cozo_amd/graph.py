@@ -70,7 +70,7 @@ class InplacePageRankPlan:
     """Resident PageRank under the in-place reading of graph::page_rank (cz_pagerank_inplace_plan_*, csrc/pagerank_inplace.hip):
     the level-scheduled ascending Gauss-Seidel sweep with its static layout kept in HBM."""
 
-    def __init__(self, in_off, in_src, out_deg, damping=0.85, device_ptrs=False, err_f64_diff=False):
+    def __init__(self, in_off, in_src, out_deg, damping=0.85, device_ptrs=False, err_f64_diff=False, as_jacobi=False):
         """host arrays, or (device_ptrs=True) uint32 device tensors (offsets [N+1], sources [E], out-degrees [N])"""
         if not device_ptrs:
             in_off, in_src = _csr32(in_off, in_src)
@@ -81,7 +81,8 @@ class InplacePageRankPlan:
         h = C.c_void_p()
         check(_lib.lib().cz_pagerank_inplace_plan_create(ptr(in_off), ptr(in_src), ptr(out_deg), N, E, np.float32(damping),
                                                          (_lib.CZ_DEVICE_PTRS if device_ptrs else 0)
-                                                         | (_lib.CZ_PR_ERR_F64_DIFF if err_f64_diff else 0), C.byref(h)))
+                                                         | (_lib.CZ_PR_ERR_F64_DIFF if err_f64_diff else 0)
+                                                         | (_lib.CZ_PR_INPLACE_AS_JACOBI if as_jacobi else 0), C.byref(h)))
         self._h, self.N, self.E = h, N, E
 
     def close(self):

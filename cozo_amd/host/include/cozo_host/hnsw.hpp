@@ -8,6 +8,13 @@
 //   hnsw_knn            runtime/hnsw.rs:869-1012   one parent tuple
 //   HnswSearchRA::iter  query/ra.rs:1085-1121      the parent iterator is drained into ONE batch, searched by one
 //                       cz_hnsw_search_batch launch, rows re-emitted in parent order as `parent ++ result`
+// SCOPE (frozen in round 6).  The NORMATIVE executable host mirror is the Python one (cozo_amd/hnsw.py,
+// cozo_amd/fixed_rule.py): it is the one every parity test and bench.py drive, and it grows with the C ABI.  This C++ mirror is kept
+// as the compiled twin of the part the Rust shim (integration/rust/) needs a second opinion on -- the FixedRule surface, the F32
+// HnswSearchRA batching and row assembly -- and is held to the Python one by tests/test_mirrors_agree.py, row for row.  Declared
+// gaps (tests/test_mirrors_agree.py::CPP_MIRROR_GAPS lists them and asserts each is REFUSED here, not silently different):
+//   * F64 indices (VecElementType::F64): searched by the Python mirror and the Rust source only; GpuHnswIndex here throws.
+//   * cz_pagerank_inplace_plan_* (the resident in-place plan), cz_hnsw_index_distance_batch, cz_hnsw_index_settle: Python only.
 // Radius, bind columns and the filter predicate are applied on the host to the (node, distance) rows the GPU
 // returns, exactly where the reference applies them (:943-1006).  No CPU fallback: without the device library or
 // a gfx950 device every search throws GpuError.

@@ -321,6 +321,10 @@ int cz_pagerank_inplace(const uint32_t *in_offsets, const uint32_t *in_sources, 
  *   read_scores scores [N] in the caller's numbering (host memory, or device memory with CZ_DEVICE_PTRS)
  *   info        shape [16] u64: levels, row blocks, phase-A items, long rows, urgent gap, slice width, launches per sweep, graph
  *               replay (1/0), X edges, Y edges, urgent edges, long-row edges, X positions, Y positions; host build / upload ms */
+/* cz_pagerank_inplace_plan_create: lay the JACOBI reading out the same way (one level, every edge reads the previous sweep's
+ * contribution; scores == cz_pagerank's, bit for bit): the grouped tile formulation as a sweep of two launches.  Measurement /
+ * cross-check only; cz_pagerank and cz_pagerank_plan_* stay the product path of that reading. */
+#define CZ_PR_INPLACE_AS_JACOBI 2048u
 typedef struct cz_pagerank_inplace_plan cz_pagerank_inplace_plan;
 int cz_pagerank_inplace_plan_create(const uint32_t *in_offsets, const uint32_t *in_sources, const uint32_t *out_degree, uint32_t N,
                                     uint64_t E, float damping, uint32_t flags, cz_pagerank_inplace_plan **out);

@@ -29,6 +29,9 @@ SPEC = {
     "pagerank_blocked": dict(tag="pr", regex=r"pb_expand_kernel|pb_reduce_kernel", mode="last", n=3, algo=None, require=r"pb_reduce_kernel", forbid=r"pa_reduce_kernel"),
     "pagerank_accumulate": dict(tag="pr", regex=r"pb_expand_kernel|pa_reduce_kernel|pb_reduce_kernel", mode="last", n=3, algo=None, require=r"pa_reduce_kernel"),
     "pagerank_blocked_rmat": dict(tag="prrmat", regex=r"pb_expand_kernel|pb_reduce_kernel|pr_hub_kernel|pr_empty_rows_kernel", mode="last", n=3, algo=None),
+    # the in-place reading: init (one launch of every phase-A item) + 5 sweeps of L + 2 launches (scratch/r6_inplace.py, IP_FEW=1)
+    "pagerank_inplace": dict(tag="prip", regex=r"gi_level_kernel|gi_long_kernel|gi_sum_partials_kernel", mode="per_run", runs=5, algo=None,
+                             skip_first={"gi_level_kernel": 1}),
     "hnsw_knn_1m": dict(tag="hnsw1m", regex=r"hnsw_knn_kernel", mode="last", n=3, algo=None),
     "bfs": dict(tag="bfs", regex=r"bfs_|scan_tiles_kernel|scan_add_kernel", mode="per_run", runs=2, algo=None),
     "sssp": dict(tag="sssp", regex=r"sssp_|fill_u64_kernel", mode="per_run", runs=2, algo=None),
@@ -59,6 +62,7 @@ def main():
         d = json.load(open(os.path.join(round_dir, "bench_detail.json")))
         algos["hnsw_knn"] = d["roofline"]["algorithmic_bytes_per_launch"]
         algos["pagerank_blocked"] = algos["pagerank_accumulate"] = d["pagerank"]["roofline"]["algorithmic_bytes_per_launch"]
+        algos["pagerank_inplace"] = d["pagerank"]["roofline"]["algorithmic_bytes_per_launch"]
         algos["pagerank_blocked_rmat"] = d["pagerank_rmat"]["roofline"]["algorithmic_bytes_per_launch"]
         algos["hnsw_knn_1m"] = d["hnsw_1m"]["roofline"]["algorithmic_bytes_per_launch"]
         algos["bfs"] = d["graph_rules"]["bfs"]["algorithmic_bytes"]
@@ -92,6 +96,7 @@ def main():
                 ok = False
                 break
             for k, vals in sorted(hit.items()):
+                vals = vals[sp.get("skip_first", {}).get(k, 0):]
                 kib = sum(vals[-sp["n"]:]) / len(vals[-sp["n"]:]) if sp["mode"] == "last" else sum(vals) / sp["runs"]
                 parts[f"{k} {counter}"] = kib
                 total += kib * 1024.0 * scale

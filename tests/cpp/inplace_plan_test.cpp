@@ -47,7 +47,9 @@ extern "C" int ipt_emulate(const uint64_t *in_off, const uint32_t *in_src, const
     prm.rows_per_block = rows_per_block;
     prm.slice = slice;
     prm.part = part;
-    prm.urgent_gap = urgent_gap;
+    prm.urgent_gap = urgent_gap & 0xffffu;
+    prm.jacobi = (urgent_gap >> 16) != 0;  // (bit 16 of the argument: the Jacobi reading in this layout)
+    urgent_gap &= 0xffffu;
     czgs::Plan p;
     if (!czgs::build_plan(in_off, in_src, out_deg, N, prm, p)) return -1;
     if (info) {

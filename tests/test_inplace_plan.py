@@ -114,3 +114,15 @@ def test_empty_and_edgeless(ipt, oracle):
     want, _, _ = oracle.pagerank_mode(5, g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 2, mode=oracle.PR_INPLACE)
     got, _, info = emulate(ipt, g, sweeps=2)
     assert np.array_equal(got, want) and info["levels"] == 1
+
+
+def test_jacobi_reading_in_the_same_layout(ipt, oracle):
+    """prm.jacobi: one level, every edge reads the previous sweep's contribution -- the walk must equal orc_pagerank (the Jacobi
+    reading), the layout being the grouped tile formulation csrc/pagerank_inplace.hip runs"""
+    for kind, (n, e) in (("uniform", (20000, 200000)), ("skewed", (4000, 60000))):
+        frm, to = util.random_relation(n, e, 5) if kind == "uniform" else skewed_relation(n, e, 6)
+        g = util.graph_from_relation(oracle, frm, to)
+        want, _, _ = oracle.pagerank(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 3)
+        got, _, info = emulate(ipt, g, tile=512, rows=16, slice_=64, part=32, gap=1 | (1 << 16), sweeps=3)
+        assert info["levels"] == 1 and info["x"] == 0 and info["urgent"] == 0
+        assert np.array_equal(got, want)

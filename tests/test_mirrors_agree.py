@@ -146,3 +146,35 @@ def test_python_and_cpp_mirrors_return_the_same_rows(tmp_path, on_gpu, name, inp
         assert len(got[1]) == len(want[1])
         for a, b in zip(got[1], want[1]):
             assert a == b, (codec.decode_tuple_from_key(a), codec.decode_tuple_from_key(b))
+
+
+# ---- the C++ mirror's declared gaps (the Python mirror is the normative one) -----------------------------------
+# What the compiled twin does NOT cover, stated where its scope is frozen (cozo_amd/host/include/cozo_host/hnsw.hpp).  Each entry
+# must be REFUSED or ABSENT there -- never silently different -- and present in the Python mirror.
+CPP_MIRROR_GAPS = {
+    "F64 indices": dict(cpp_refuses='only F32 vector indices are GPU-resident', python_has="cz_hnsw_search_batch_f64"),
+    "resident in-place PageRank plan": dict(cpp_absent="cz_pagerank_inplace_plan_create", python_has="cz_pagerank_inplace_plan_create"),
+    "distance batch on an index table": dict(cpp_absent="cz_hnsw_index_distance_batch", python_has="cz_hnsw_index_distance_batch"),
+    "placement by trial": dict(cpp_absent="cz_hnsw_index_settle", python_has="cz_hnsw_index_settle"),
+}
+
+
+def test_cpp_mirror_gaps_are_declared_and_refused():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "cozo_amd", "host")
+    cpp = ""
+    for d, _, files in os.walk(host):
+        for f in files:
+            if f.endswith((".cpp", ".hpp")):
+                cpp += open(os.path.join(d, f)).read()
+    header = open(os.path.join(host, "include", "cozo_host", "hnsw.hpp")).read()
+    py = "".join(open(os.path.join(root, "cozo_amd", f)).read() for f in ("hnsw.py", "graph.py", "_lib.py"))
+    assert "NORMATIVE executable host mirror is the Python one" in header
+    for what, g in CPP_MIRROR_GAPS.items():
+        assert g["python_has"] in py, what
+        if "cpp_refuses" in g:  # both ways into a C++ GpuHnswIndex (create, from_stored) throw for a non-F32 manifest
+            assert cpp.count(g["cpp_refuses"]) >= 2, what
+        else:  # named in the scope comment, called nowhere in the C++ mirror
+            assert g["cpp_absent"].replace("_create", "") in header or g["cpp_absent"] in header, what
+            code = "\n".join(line for line in cpp.split("\n") if not line.lstrip().startswith("//"))
+            assert g["cpp_absent"] not in code, what
