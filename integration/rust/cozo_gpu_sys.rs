@@ -14,6 +14,7 @@ pub const CZ_BF_GEMM: u32 = 8;
 pub const CZ_PR_EXCHANGE_ALLREDUCE: u32 = 32;
 pub const CZ_PR_OVERLAP_EXCHANGE: u32 = 64;
 pub const CZ_PR_ERR_F64_DIFF: u32 = 128;
+pub const CZ_PR_INPLACE_AS_JACOBI: u32 = 2048;
 pub const CZ_ADJ_SYMMETRIC: u32 = 512;
 pub const CZ_UNIQUE_ID_BYTES: u32 = 128;
 

@@ -19,9 +19,13 @@ CFGS = {
     "acc_a2": ("accumulate", {"CZ_PR_ACC_A_PER_CU": "2"}),
     "acc_a2b2": ("accumulate", {"CZ_PR_ACC_A_PER_CU": "2", "CZ_PR_ACC_PER_CU": "2"}),
     "acc_s512": ("accumulate", {"CZ_PR_ACC_SLICES": "512"}),
+    "blocked_c2": ("blocked", {"CZ_PR_CHUNKS": "2"}),
+    "blocked_c3": ("blocked", {"CZ_PR_CHUNKS": "3"}),
+    "blocked_c4": ("blocked", {"CZ_PR_CHUNKS": "4"}),
+    "blocked_c8": ("blocked", {"CZ_PR_CHUNKS": "8"}),
     "auto": (None, {}),
 }
-KEYS = ("CZ_PR_ACC_PER_CU", "CZ_PR_ACC_WAVES", "CZ_PR_ACC_A_PER_CU", "CZ_PR_ACC_SLICES", "CZ_PR_ACC_GROUPS")
+KEYS = ("CZ_PR_CHUNKS", "CZ_PR_ACC_PER_CU", "CZ_PR_ACC_WAVES", "CZ_PR_ACC_A_PER_CU", "CZ_PR_ACC_SLICES", "CZ_PR_ACC_GROUPS")
 
 def main():
     dev = torch.device("cuda:0")

@@ -29,9 +29,13 @@ CFGS = {
     "t16s32_p64": {"CZ_PR_INPLACE_SLICE": "32768", "CZ_PR_INPLACE_PART": "65536"},
     "t16s24_p32": {"CZ_PR_INPLACE_SLICE": "24576", "CZ_PR_INPLACE_PART": "32768"},
     "t32s32_p64": {"CZ_PR_INPLACE_TILE": "32768", "CZ_PR_INPLACE_SLICE": "32768", "CZ_PR_INPLACE_PART": "65536"},
+    "jacobi_t16s16": {"AS_JACOBI": "1"},
+    "jacobi_t16s32": {"AS_JACOBI": "1", "CZ_PR_INPLACE_SLICE": "32768"},
+    "jacobi_t32s32": {"AS_JACOBI": "1", "CZ_PR_INPLACE_TILE": "32768", "CZ_PR_INPLACE_SLICE": "32768"},
+    "jacobi_t16s32_p64": {"AS_JACOBI": "1", "CZ_PR_INPLACE_SLICE": "32768", "CZ_PR_INPLACE_PART": "65536"},
     "t32s40": {"CZ_PR_INPLACE_TILE": "32768", "CZ_PR_INPLACE_SLICE": "40448"},
 }
-KEYS = ("CZ_PR_INPLACE_GAP", "CZ_PR_INPLACE_GRAPH", "CZ_PR_INPLACE_SLICE", "CZ_PR_INPLACE_PART", "CZ_PR_INPLACE_TILE")
+KEYS = ("CZ_PR_INPLACE_GAP", "CZ_PR_INPLACE_GRAPH", "CZ_PR_INPLACE_SLICE", "CZ_PR_INPLACE_PART", "CZ_PR_INPLACE_TILE", "AS_JACOBI")
 
 def main():
     dev = torch.device("cuda:0")
@@ -46,26 +50,28 @@ def main():
     E = int(off[-1].item())
     off32 = off.to(torch.int32)
     print(f"== {kind}: n={n} E={E} longest in-row {max_in}", flush=True)
-    want = None
+    want = want_j = None
     if os.environ.get("IP_PARITY", "1") != "0":
         from oracle import oracle as O
         t0 = time.time()
         want, _, _ = O.pagerank_mode(n, off.cpu().numpy().astype(np.uint64), s.cpu().numpy().astype(np.uint32), od.cpu().numpy().astype(np.uint32),
                                      0.85, 0.0, 3, mode=O.PR_INPLACE)
-        print(f"oracle 3 sweeps: {time.time() - t0:.1f}s", flush=True)
+        want_j, _, _ = O.pagerank(n, off.cpu().numpy().astype(np.uint64), s.cpu().numpy().astype(np.uint32), od.cpu().numpy().astype(np.uint32), 0.85, 0.0, 3, threads=8)
+        print(f"oracle 3 sweeps (both readings): {time.time() - t0:.1f}s", flush=True)
     algo = 4 * E + 4 * (n + 1) + 20 * n
     for name in names:
         for k in KEYS:
             os.environ.pop(k, None)
         os.environ.update(CFGS[name])
         t0 = time.perf_counter()
-        plan = InplacePageRankPlan(off32, s, od, 0.85, device_ptrs=True)
+        jac = os.environ.get("AS_JACOBI") == "1"
+        plan = InplacePageRankPlan(off32, s, od, 0.85, device_ptrs=True, as_jacobi=jac)
         t_plan = time.perf_counter() - t0
         info = plan.info
         same = None
         if want is not None:
             plan.run(0.0, 3)
-            same = bool(np.array_equal(plan.read_scores(), want))
+            same = bool(np.array_equal(plan.read_scores(), want_j if jac else want))
         plan.init(stream)
         plan.sweeps(3, stream)
         torch.cuda.synchronize()
