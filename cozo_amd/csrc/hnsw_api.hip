@@ -970,7 +970,8 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
     const uint32_t wpad = (uint32_t)((std::max(ix->w0, ix->wu) + 63) & ~63);
     // the list lives in LDS: 12 bytes + 1 flag byte per entry.  ef = 4 096 takes 62 KiB (two workgroups per CU), the largest list
     // one workgroup can hold next to a 768-d query is ~11 000 entries; the reference has no limit (hnsw.rs:930-938)
-    const size_t smem = czh::smem_bytes(efcap, wpad, ix->f64() ? ix->ld * 2 : ix->ld, false);
+    size_t smem = czh::smem_bytes(efcap, wpad, ix->f64() ? ix->ld * 2 : ix->ld, false);
+    uint32_t hbits_pool = hbits;  // bits of the GLOBAL visited table a launch takes from the pool (0: none -- bitmap only, or a table in LDS)
     if (smem > 160 * 1024)
         return set_error(CZ_E_UNSUPPORTED, "dim %u / ef %u need %zu bytes of LDS (> 160 KiB)", ix->dim, ef, smem);
     IndexDev d = ix->dev();
@@ -1004,7 +1005,7 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
         const char *slots_env = getenv("CZ_HNSW_SLOTS");                                                                \
         const uint64_t slots = slots_env && atoi(slots_env) > 0 ? (uint64_t)atoi(slots_env) : (uint64_t)per_cu * (uint64_t)cus; \
         grid = (uint32_t)std::min<uint64_t>(B, slots);                                                                  \
-        rc = ix->acquire(hbits ? ((size_t)grid << hbits) * 4 : 0, (size_t)grid * words * 4, stream, &ws);               \
+        rc = ix->acquire(hbits_pool ? ((size_t)grid << hbits_pool) * 4 : 0, (size_t)grid * words * 4, stream, &ws);     \
         if (rc) return rc;                                                                                              \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(czh::kThreads), smem, stream, d, d_queries, B, k, ef, efcap, wpad,    \
                            has_radius, radius, (uint32_t *)ws.tab, hbits, (uint32_t *)ws.bitmap, words, preds, d_ids,   \
@@ -1039,7 +1040,29 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
 #undef CZ_LAUNCH_KNN_F64_
     } else if (sh.lpv == 64 && sh.iters == 3) {
         if (knn_u == 0) knn_u = (uint64_t)B * 4 <= (uint64_t)cus * 4 ? 8 : ((uint64_t)B * 2 <= (uint64_t)cus * 4 ? 4 : 2);
-        if (knn_u == 1) CZ_LAUNCH_KNN(64, 3, 1);
+        // a batch that leaves at least half of the CUs empty, link rows of at most 64 entries: the speculative step (hnsw_kernels.h
+        // search_level_spec; CZ_HNSW_SPEC = 0 | 1 overrides)
+        const char *spec_env = getenv("CZ_HNSW_SPEC");
+        const bool spec = (spec_env ? atoi(spec_env) != 0 : (uint64_t)B * 2 <= (uint64_t)cus) && d.w0 <= 64 && d.wu <= 64 && wpad <= 256;
+        if (spec) {  // the visited hash table in LDS: what the list leaves of 160 KiB (1 KiB aside for the kernel's static words), at most 2^15 slots
+            uint32_t lbits = 15;
+            const size_t base = (smem + 15) & ~(size_t)15;
+            while (lbits >= 11 && base + ((size_t)4 << lbits) + 1024 > 160 * 1024) lbits--;
+            if (lbits >= 11) {
+                const size_t smem_list = smem;
+                const uint32_t hbits_glob = hbits;
+                smem = base + ((size_t)4 << lbits);
+                hbits = lbits;
+                // (no global table: acquire() below gets 0 table bytes through hbits_pool)
+                hbits_pool = 0;
+                CZ_LAUNCH_KNN_(hnsw_knn_spec_kernel, 64, 3, 8);
+                smem = smem_list;
+                hbits = hbits_glob;
+            } else {
+                CZ_LAUNCH_KNN_(hnsw_knn_wide_kernel, 64, 3, 8);
+            }
+        }
+        else if (knn_u == 1) CZ_LAUNCH_KNN(64, 3, 1);
         else if (knn_u == 4) CZ_LAUNCH_KNN_(hnsw_knn_wide_kernel, 64, 3, 4);
         else if (knn_u == 8) CZ_LAUNCH_KNN_(hnsw_knn_wide_kernel, 64, 3, 8);
         else CZ_LAUNCH_KNN(64, 3, 2);

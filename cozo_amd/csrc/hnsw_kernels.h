@@ -160,6 +160,7 @@ struct Searcher {
     Smem s;
     VisitedDev vis;
     uint32_t *tcur;  // ids evaluated in this step (s.todo)
+    uint32_t *spec = nullptr;  // search_level_spec's scratch: [0, 128) two prefetched link rows, [128..129] whose they are
     int tid, lane, wave, glane, group;
     int chunks;
     float4 q[ITERS > 0 ? ITERS : 1];
@@ -1039,6 +1040,103 @@ struct Searcher {
         }
     }
 
+    // The same traversal for a batch that leaves the chip empty (HnswSearchRA::iter hands over whatever the parent relation holds --
+    // often ONE vector, query/ra.rs:1085-1121).  A step is then a chain of dependent round trips -- link row -> visited atomics ->
+    // vector rows -- on a CU that has nothing else to do, and two of the three are taken off the chain without changing anything
+    // that is computed:
+    //   * the visited set's hash table lives in LDS (the launcher gives this kernel what the list leaves free, up to 128 KiB:
+    //     32 768 slots; beyond 70 % load it moves to the global bitmap like the global table does): a test-and-set is an LDS
+    //     atomic, not an L2 round trip;
+    //   * while a step runs, wave 1 fetches the link row of the nearest un-expanded entry behind the one being expanded -- the next
+    //     step's candidate unless this step's merge puts a nearer one in front of it (then the row is fetched as usual).  The load
+    //     is issued before the step's barriers and consumed after its evaluation: it rides under the vector rows' round trip.
+    // (Evaluating ALL neighbours while the visited test is in flight was tried first: a CU fetches ~50 GB/s, and the 60 % more
+    // rows cost what the shorter chain saved -- profiles/r06_small_batch_latency.txt.)
+    // Same W, same visited set, same ids / distances / n_dist as search_level; link rows of at most 64 entries.
+    __device__ void search_level_spec(int level, int ef, bool log) {
+        int cnt = s.ctl[C_CNT];
+        for (int i = tid; i < cnt; i += kThreads) s.wid[i] &= kIdMask;
+        if (wave == 0) {
+            for (int b = 0; b < cnt; b += 64) {
+                const int j = b + lane;
+                uint32_t where;
+                const bool fresh = visit(j < cnt ? (s.wid[j] & kIdMask) : CZ_NONE, j < cnt, where);
+                if (fresh) log_visit(where, log);
+            }
+        }
+        if (tid == 0) {
+            s.ctl[C_LO] = 0;
+            spec[128] = spec[129] = CZ_NONE;
+        }
+        __syncthreads();
+        const int width = level == 0 ? ix.w0 : ix.wu;
+        auto row_of = [&](uint32_t node) {
+            return level == 0 ? ix.nbr0 + (size_t)node * ix.w0 : ix.up_nbrs + ((size_t)ix.up_base[node] + (level - 1)) * ix.wu;
+        };
+        for (uint32_t step = 0;; step++) {
+            cnt = s.ctl[C_CNT];
+            int idx = -1;
+            for (int b = s.ctl[C_LO]; b < cnt; b += 64) {
+                int j = b + lane;
+                bool un = j < cnt && !(s.wid[j] & kExpanded);
+                unsigned long long m = __ballot(un);
+                if (m) {
+                    idx = b + __ffsll((long long)m) - 1;
+                    break;
+                }
+            }
+            if (idx < 0) break;
+            const uint32_t cand = s.wid[idx] & kIdMask;
+            const uint32_t rd = (step & 1u) ^ 1u, wr = step & 1u;  // the buffer the step before filled / the one this step fills
+            const bool hit = spec[128 + rd] == cand;
+            // wave 1: the next step's link row (the nearest un-expanded entry BEHIND idx: everything before idx is expanded)
+            uint32_t pre = CZ_NONE, pre_c = CZ_NONE;
+            if (wave == 1) {
+                for (int b = idx + 1; b < cnt; b += 64) {
+                    const int j = b + lane;
+                    const bool un = j < cnt && !(s.wid[j] & kExpanded);
+                    const unsigned long long m = __ballot(un);
+                    if (m) {
+                        pre_c = s.wid[b + __ffsll((long long)m) - 1] & kIdMask;
+                        break;
+                    }
+                }
+                if (pre_c != CZ_NONE && lane < width) pre = row_of(pre_c)[lane];
+            }
+            __syncthreads();  // everyone has read wid[idx] / C_LO / the prefetch tags before they change
+            if (tid == 0) {
+                s.wid[idx] = cand | kExpanded;
+                s.ctl[C_LO] = idx + 1;
+            }
+            if (wave == 0) {  // the link row -> its not-yet-visited neighbours, in row order (hnsw.rs:566-571)
+                const uint32_t nb = lane < width ? (hit ? spec[rd * 64 + lane] : row_of(cand)[lane]) : CZ_NONE;
+                uint32_t where;
+                const bool fresh = visit(nb, nb != CZ_NONE, where);
+                const unsigned long long m = __ballot(fresh);
+                if (fresh) {
+                    tcur[__popcll(m & ((1ull << lane) - 1ull))] = nb;
+                    log_visit(where, log);
+                }
+                if (lane == 0) {
+                    s.ctl[C_TODO] = __popcll(m);
+                    count_dist(__popcll(m));
+                }
+            }
+            __syncthreads();
+            const int n = s.ctl[C_TODO];
+            if (n > 0) {
+                eval_todo(n);
+                __syncthreads();
+            }
+            if (wave == 1) {  // (the load has had the whole evaluation to arrive)
+                spec[wr * 64 + lane] = pre;
+                if (lane == 0) spec[128 + wr] = pre_c;
+            }
+            if (n > 0) merge(n, ef);
+            else __syncthreads();  // (merge ends on a barrier; the prefetch tags are read after one either way)
+        }
+    }
+
     // distance to the entry point seeds W (hnsw.rs:915-918): one row, evaluated by the first lane group
     __device__ void seed(uint32_t entry) {
         if (tid == 0) {
@@ -1159,7 +1257,7 @@ __device__ __forceinline__ bool pred_pass(const PredSet &ps, uint32_t node) {
 // at B = 2 048 / 4 096 against 0.76 at 1 024).  U (rows in flight per lane group and round) is chosen from B by the
 // launcher: a batch that leaves most of the chip empty is bound by the latency of a step, and a step by the rounds its
 // rows take -- wider rounds (U = 4 / 8: 16 / 32 rows per round, the registers are free at that occupancy) shorten it.
-template <int LPV, int ITERS, int U, bool F64 = false>
+template <int LPV, int ITERS, int U, bool F64 = false, bool SPEC = false>
 __device__ __forceinline__ void
 hnsw_knn_body(const IndexDev &ix, const float *__restrict__ queries, uint32_t B, uint32_t k, uint32_t ef, uint32_t efcap,
               uint32_t wpad, int has_radius, double radius, uint32_t *__restrict__ vtab, uint32_t hbits,
@@ -1170,18 +1268,29 @@ hnsw_knn_body(const IndexDev &ix, const float *__restrict__ queries, uint32_t B,
     VisitedDev vis;
     vis.tab = hbits ? vtab + ((size_t)blockIdx.x << hbits) : nullptr;
     vis.hbits = hbits;
+    if constexpr (SPEC) {  // the hash table of the visited set sits in LDS behind the list (hbits = what the launcher found room for)
+        const size_t at = (smem_bytes(efcap, wpad, F64 ? ix.ld * 2 : ix.ld, false) + 15) & ~(size_t)15;
+        vis.tab = hbits ? (uint32_t *)(smem_raw + at) : nullptr;
+        for (uint32_t i = threadIdx.x; i < (hbits ? (1u << hbits) : 0u); i += kThreads) vis.tab[i] = CZ_NONE;
+        __syncthreads();
+    }
     vis.bitmap = vbitmap + (size_t)blockIdx.x * words;
     vis.words = words;
     for (uint32_t b = blockIdx.x; b < B; b += gridDim.x) {
     if (b != blockIdx.x) __syncthreads();  // (the output stage of the query before this one has read the list)
     Searcher<LPV, ITERS, U, CZ_SEARCH_NT != 0, F64> S(ix, s, vis);
+    if constexpr (SPEC) {
+        __shared__ uint32_t spec_words[132];  // two prefetched link rows (64 ids each) and their tags
+        S.spec = spec_words;
+    }
     S.load_query(F64 ? reinterpret_cast<const float *>(reinterpret_cast<const double *>(queries) + (size_t)b * ix.dim)
                      : queries + (size_t)b * ix.dim);
     S.seed(ix.entry);
     // :919-938 greedy descent with ef = 1 through the upper levels, then the level-0 search with ef (one call site,
     // so that the traversal is inlined once)
     for (int lv = ix.n_levels - 1; lv >= 0; lv--) {
-        S.search_level(lv, lv > 0 ? 1 : (int)ef, lv > 0);
+        if constexpr (SPEC) S.search_level_spec(lv, lv > 0 ? 1 : (int)ef, lv > 0);
+        else S.search_level(lv, lv > 0 ? 1 : (int)ef, lv > 0);
         if (lv > 0) S.clear_visited();
     }
     S.clear_all();  // the table / bitmap go back to the pool empty
@@ -1284,6 +1393,16 @@ hnsw_knn_wide_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t B,
                      double *__restrict__ out_dist, uint32_t *__restrict__ out_count, unsigned long long *__restrict__ out_n_dist) {
     hnsw_knn_body<LPV, ITERS, U>(ix, queries, B, k, ef, efcap, wpad, has_radius, radius, vtab, hbits, vbitmap, words, preds, out_ids,
                                  out_dist, out_count, out_n_dist);
+}
+// a batch of a few queries (at most a workgroup per two CUs): the speculative step (search_level_spec), eight rows in flight
+template <int LPV, int ITERS, int U>
+__global__ void __launch_bounds__(kThreads)
+hnsw_knn_spec_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t B, uint32_t k, uint32_t ef, uint32_t efcap,
+                     uint32_t wpad, int has_radius, double radius, uint32_t *__restrict__ vtab, uint32_t hbits,
+                     uint32_t *__restrict__ vbitmap, uint32_t words, PredSet preds, uint32_t *__restrict__ out_ids,
+                     double *__restrict__ out_dist, uint32_t *__restrict__ out_count, unsigned long long *__restrict__ out_n_dist) {
+    hnsw_knn_body<LPV, ITERS, U, false, true>(ix, queries, B, k, ef, efcap, wpad, has_radius, radius, vtab, hbits, vbitmap, words, preds,
+                                              out_ids, out_dist, out_count, out_n_dist);
 }
 // an F64 index (the query rows are doubles behind the float pointer): LPV lanes per vector, the query in LDS
 template <int LPV, int U>

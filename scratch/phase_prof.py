@@ -12,7 +12,7 @@ from cozo_amd.hnsw import GpuHnswIndex, HnswIndexManifest, HnswSearch
 def main():
     dev = torch.device("cuda:0")
     assert L.cz_init(0) == 0
-    n, dim, k, B = int(os.environ.get("PH_N", 1_000_000)), 768, 10, 1024
+    n, dim, k, B = int(os.environ.get("PH_N", 1_000_000)), 768, 10, int(os.environ.get("PH_B", 1024))
     kind = os.environ.get("PH_DIST", "lowrank")
     efs = [int(v) for v in os.environ.get("PH_EF", "96").split(",")]
     stream = torch.cuda.current_stream().cuda_stream
