@@ -369,7 +369,10 @@ bfs_discover_long_kernel(const uint32_t *__restrict__ off, const uint32_t *__res
     for (uint32_t k = 0; k < nl; k++) {
         const uint32_t i = long_nodes[k], u = frontier[i];
         const uint32_t e0 = off[u], e1 = off[u + 1];
-        for (uint32_t s0 = e0 + blockIdx.x * kBfsLongList; s0 < e1; s0 += gridDim.x * kBfsLongList) {
+        // (the stretches of node k start at workgroup 37 k mod G: with thousands of listed nodes of 5-100 thousand edges -- a level of
+        // an R-MAT graph -- workgroup 0 used to walk the first stretch of EVERY one of them, 40 ms for one level)
+        const uint32_t first_wg = (uint32_t)(((uint64_t)k * 37u) % gridDim.x);
+        for (uint32_t s0 = e0 + ((blockIdx.x + gridDim.x - first_wg) % gridDim.x) * kBfsLongList; s0 < e1; s0 += gridDim.x * kBfsLongList) {
             const uint32_t s1 = min(e1, s0 + kBfsLongList);
             for (uint32_t b = s0; b < s1; b += kT) {  // (uniform trip count over the workgroup's waves)
                 const uint32_t e = b + threadIdx.x;
@@ -694,51 +697,100 @@ sssp_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__
     const uint32_t rounds = (n_cur + ngroups - 1) / ngroups;  // every group of the GRID runs the same trip count (ballots, barriers)
     if (blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;  // the NEXT round's near counter (this round appends to the other one)
     __shared__ StagedPile st_near, st_far;
-    if (threadIdx.x == 0) st_near.count = st_far.count = 0;
+    // hubs: a 16-lane group walks at most kSsspLongList edges of its node; what is left of a longer list is set aside here and walked
+    // by the whole workgroup at the end of the round (a 100 000-edge hub of an R-MAT graph kept ONE group -- and its wave -- busy
+    // for 6 700 iterations: 18 ms of a 39 ms run).  Relaxations commute (CAS on the packed word), so who walks an edge changes nothing.
+    constexpr uint32_t kSsspLongList = 1024;
+    constexpr uint32_t kGroupsPerWg = kT / kSsspLanes;
+    __shared__ uint32_t lq_si[kGroupsPerWg], lq_u[kGroupsPerWg], lq_e0[kGroupsPerWg], lq_e1[kGroupsPerWg], lq_du[kGroupsPerWg], lq_n;
+    if (threadIdx.x == 0) {
+        st_near.count = st_far.count = 0;
+        lq_n = 0;
+    }
     __syncthreads();
+    // one edge: the target's packed word replaced when the offer is better; where the target goes next
+    auto relax = [&](uint32_t si, uint32_t u, float du, uint32_t e, bool on, bool &to_near, bool &to_far, uint32_t &v) {
+        to_near = to_far = false;
+        v = 0;
+        if (!on) return;
+        unsigned long long *dps = dp + (size_t)si * N;
+        v = tgt[e];
+        const float nd = du + w[e];  // `cost + path_weight` in f32 (shortest_path_dijkstra.rs:303)
+        const uint32_t nb = __float_as_uint(nd);
+        const bool proper = nb != __float_as_uint(du);
+        const unsigned long long want = ((unsigned long long)nb << 32) | (proper ? 0u : 0x80000000u) | u;
+        unsigned long long seen = __hip_atomic_load(&dps[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            const bool lower = nb < (uint32_t)(seen >> 32);  // strict `<` (:304); non-negative floats order as their bits
+            if (!lower && !(proper && nb == (uint32_t)(seen >> 32) && want < seen)) break;
+            const unsigned long long got = atomicCAS(&dps[v], seen, want);
+            if (got == seen) {
+                if (lower) {  // (an equal-cost change of parent is nothing the node's own edges need to hear about)
+                    const size_t at = (size_t)si * N + v;
+                    if (nb < thr_bits) to_near = atomicExch(&qtag[at], round_tag) != round_tag;
+                    else to_far = atomicExch(&ftag[at], phase_tag) != phase_tag;
+                }
+                break;
+            }
+            seen = got;
+        }
+    };
     for (uint32_t r = 0; r < rounds; r++) {
         const uint32_t i = group + r * ngroups;
         const bool live = i < n_cur;
         const unsigned long long ent = live ? cur[i] : 0ull;
         const uint32_t si = (uint32_t)(ent >> 32), u = (uint32_t)ent;
         unsigned long long *dps = dp + (size_t)si * N;
-        const uint32_t e0 = live ? off[u] : 0, e1 = live ? off[u + 1] : 0;
+        const uint32_t e0 = live ? off[u] : 0;
+        uint32_t e1 = live ? off[u + 1] : 0;
         float du = 0.f;
         if (live) du = __uint_as_float((uint32_t)(__hip_atomic_load(&dps[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32));
+        if (e1 - e0 > kSsspLongList) {  // (uniform over the group)
+            if (glane == 0) {
+                const uint32_t q = atomicAdd(&lq_n, 1u);
+                lq_si[q] = si;
+                lq_u[q] = u;
+                lq_e0[q] = e0 + kSsspLongList;
+                lq_e1[q] = e1;
+                lq_du[q] = __float_as_uint(du);
+            }
+            e1 = e0 + kSsspLongList;
+        }
         uint32_t maxlen = e1 - e0;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, o, 64));
         for (uint32_t b = 0; b < maxlen; b += kSsspLanes) {
             const uint32_t e = e0 + b + glane;
-            bool to_near = false, to_far = false;
-            uint32_t v = 0;
-            if (e < e1) {
-                v = tgt[e];
-                const float nd = du + w[e];  // `cost + path_weight` in f32 (shortest_path_dijkstra.rs:303)
-                const uint32_t nb = __float_as_uint(nd);
-                const bool proper = nb != __float_as_uint(du);
-                const unsigned long long want = ((unsigned long long)nb << 32) | (proper ? 0u : 0x80000000u) | u;
-                unsigned long long seen = __hip_atomic_load(&dps[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (;;) {
-                    const bool lower = nb < (uint32_t)(seen >> 32);  // strict `<` (:304); non-negative floats order as their bits
-                    if (!lower && !(proper && nb == (uint32_t)(seen >> 32) && want < seen)) break;
-                    const unsigned long long got = atomicCAS(&dps[v], seen, want);
-                    if (got == seen) {
-                        if (lower) {  // (an equal-cost change of parent is nothing the node's own edges need to hear about)
-                            const size_t at = (size_t)si * N + v;
-                            if (nb < thr_bits) to_near = atomicExch(&qtag[at], round_tag) != round_tag;
-                            else to_far = atomicExch(&ftag[at], phase_tag) != phase_tag;
-                        }
-                        break;
-                    }
-                    seen = got;
-                }
-            }
+            bool to_near, to_far;
+            uint32_t v;
+            relax(si, u, du, e, e < e1, to_near, to_far, v);
             const unsigned long long item = ((unsigned long long)si << 32) | v;
             staged_push(near, st_near, to_near, item, lane);
             staged_push(far, st_far, to_far, item, lane);
         }
-        if ((r & 7) == 7 || r + 1 == rounds) {  // 16 entries per iteration and workgroup: a few hundred pushes gather in 8
+        __syncthreads();
+        const uint32_t nq = lq_n;  // (uniform) the long lists' remainders: every lane of the workgroup takes edges
+        for (uint32_t q = 0; q < nq; q++) {
+            const uint32_t qsi = lq_si[q], qu = lq_u[q], q0 = lq_e0[q], q1 = lq_e1[q];
+            const float qdu = __uint_as_float(lq_du[q]);
+            for (uint32_t b = q0; b < q1; b += kT) {
+                const uint32_t e = b + threadIdx.x;
+                bool to_near, to_far;
+                uint32_t v;
+                relax(qsi, qu, qdu, e, e < q1, to_near, to_far, v);
+                const unsigned long long item = ((unsigned long long)qsi << 32) | v;
+                staged_push(near, st_near, to_near, item, lane);
+                staged_push(far, st_far, to_far, item, lane);
+                if (((b - q0) / kT & 7u) == 7u) {  // (uniform) the staging pile is a few hundred entries
+                    staged_flush(near, st_near);
+                    staged_flush(far, st_far);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) lq_n = 0;
+        __syncthreads();  // (the next round's groups add to it)
+        if (nq || (r & 7) == 7 || r + 1 == rounds) {  // 16 entries per iteration and workgroup: a few hundred pushes gather in 8
             staged_flush(near, st_near);
             staged_flush(far, st_far);
         }
