@@ -26,9 +26,13 @@
 // Rows of more than `tile` in-edges ("long") are gathered by a workgroup each, as before.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace czgs {
@@ -43,6 +47,7 @@ struct Params {
     uint32_t part = 16384;           // stream positions of one phase-A work item (multiple of 4)
     uint32_t urgent_gap = 1;         // forward edges over at most this many levels are gathered; 0: none (phase A between the levels)
     uint32_t max_levels = 4096;
+    uint32_t threads = 0;            // host threads of the two edge passes (0: up to 16; the arrays do not depend on it)
     bool jacobi = false;             // every edge reads the PREVIOUS sweep's contribution: one level, all edges class Y -- graph::page_rank's
                                      // other reading (oracle orc_pagerank) in this layout (an experiment: csrc/pagerank.hip is its product path)
 };
@@ -103,6 +108,14 @@ inline bool build_plan(const OffT *in_off, const uint32_t *in_src, const uint32_
         return false;
     }
     if (N == 0) return true;
+    const bool trace = getenv("CZ_PLAN_TRACE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[inplace plan] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     // ---- levels: the in-neighbours below u are final when u is reached
     std::vector<uint32_t> level(N);
     uint32_t L = 0;
@@ -122,6 +135,7 @@ inline bool build_plan(const OffT *in_off, const uint32_t *in_src, const uint32_
         return false;
     }
     p.L = L;
+    lap("levels");
     // ---- level-major numbering
     p.first.assign(L + 1, 0);
     for (uint32_t u = 0; u < N; u++) p.first[level[u] + 1]++;
@@ -144,6 +158,7 @@ inline bool build_plan(const OffT *in_off, const uint32_t *in_src, const uint32_
         p.off2[i + 1] = p.off2[i] + (uint32_t)(in_off[u + 1] - in_off[u]);
         p.od[i] = out_deg[u];
     }
+    lap("level-major numbering");
     // ---- slices: consecutive nodes of ONE level
     std::vector<uint32_t> slice_first(L + 1, 0);
     for (uint32_t l = 0; l < L; l++) slice_first[l + 1] = slice_first[l] + (p.first[l + 1] - p.first[l] + prm.slice - 1) / prm.slice;
@@ -179,46 +194,84 @@ inline bool build_plan(const OffT *in_off, const uint32_t *in_src, const uint32_
     }
     p.blk_first[L] = (uint32_t)p.blocks.size();
     p.long_first[L] = (uint32_t)p.long_rows.size();
-    // ---- pass 1: every edge of a block row gets its class; stream edges are counted per (slice, class)
+    lap("row blocks");
+    // ---- pass 1: every edge of a block row gets its class; stream edges are counted per (slice, class).  Both passes run on
+    // `threads` host threads over CONTIGUOUS ranges of blocks (cells of one bucket are laid out in block order, so a thread's
+    // cursors start where the threads before it end): the arrays are the same for every thread count.
     // code: urgent = kOldBit | level-major source; stream = bucket (2 * slice + class), local id in `loc`
     std::vector<uint32_t> code(p.E);
     std::vector<uint16_t> loc(p.E);
-    std::vector<uint64_t> cnt((size_t)2 * S + 1, 0);
-    std::vector<uint32_t> lcnt((size_t)2 * S, 0), touched;
-    for (Block &b : p.blocks) {
-        uint32_t nu = 0;
-        touched.clear();
-        for (uint32_t r = b.row0; r < b.row1; r++) {
-            const uint32_t u = p.order[r], lu = level[u];
-            uint32_t t = p.off2[r];  // position in the level-major CSR
-            for (uint64_t e = in_off[u]; e < (uint64_t)in_off[u + 1]; e++, t++) {
-                const uint32_t v = in_src[e], lv = level[v], vi = inv[v];
-                const bool old = v >= u || prm.jacobi;
-                if (!old && lu - lv <= prm.urgent_gap) {
-                    code[t] = kOldBit | vi;
-                    nu++;
-                } else {
-                    const uint32_t rel = vi - p.first[lv];
-                    const uint32_t sl = slice_first[lv] + rel / prm.slice;
-                    const uint32_t bucket = 2u * sl + (old ? 1u : 0u);
-                    code[t] = bucket;
-                    // the local id carries the slice's misalignment: phase A stages aligned 16-byte vectors, LDS word 0 = node (node0 & ~3)
-                    loc[t] = (uint16_t)(rel % prm.slice + ((p.first[lv] + (rel / prm.slice) * prm.slice) & 3u));
-                    if (lcnt[bucket]++ == 0) touched.push_back(bucket);
-                    p.n_edges[old ? 1 : 0]++;
+    const size_t nblk = p.blocks.size();
+    uint32_t T = prm.threads ? prm.threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (p.E < (1u << 20) || nblk < 2 * (size_t)T) T = 1;
+    std::vector<size_t> tb(T + 1, 0);  // thread t owns blocks [tb[t], tb[t + 1]): about equal shares of the edges
+    {
+        size_t bi = 0;
+        for (uint32_t t = 1; t <= T; t++) {
+            const uint64_t goal = p.E / T * t;
+            while (bi < nblk && (t == T || p.blocks[bi].e0 < goal)) bi++;
+            tb[t] = bi;
+        }
+        tb[T] = nblk;
+    }
+    std::vector<std::vector<uint64_t>> cntT(T, std::vector<uint64_t>((size_t)2 * S, 0));
+    std::vector<uint64_t> neT((size_t)T * 3, 0);
+    auto pass1 = [&](uint32_t tix) {
+        std::vector<uint32_t> lcnt((size_t)2 * S, 0), touched;
+        std::vector<uint64_t> &cnt = cntT[tix];
+        for (size_t bi = tb[tix]; bi < tb[tix + 1]; bi++) {
+            Block &b = p.blocks[bi];
+            uint32_t nu = 0;
+            touched.clear();
+            for (uint32_t r = b.row0; r < b.row1; r++) {
+                const uint32_t u = p.order[r], lu = level[u];
+                uint32_t t = p.off2[r];  // position in the level-major CSR
+                for (uint64_t e = in_off[u]; e < (uint64_t)in_off[u + 1]; e++, t++) {
+                    const uint32_t v = in_src[e], lv = level[v], vi = inv[v];
+                    const bool old = v >= u || prm.jacobi;
+                    if (!old && lu - lv <= prm.urgent_gap) {
+                        code[t] = kOldBit | vi;
+                        nu++;
+                    } else {
+                        const uint32_t rel = vi - p.first[lv];
+                        const uint32_t sl = slice_first[lv] + rel / prm.slice;
+                        const uint32_t bucket = 2u * sl + (old ? 1u : 0u);
+                        code[t] = bucket;
+                        // the local id carries the slice's misalignment: phase A stages aligned 16-byte vectors, LDS word 0 = node (node0 & ~3)
+                        loc[t] = (uint16_t)(rel % prm.slice + ((p.first[lv] + (rel / prm.slice) * prm.slice) & 3u));
+                        if (lcnt[bucket]++ == 0) touched.push_back(bucket);
+                        neT[(size_t)tix * 3 + (old ? 1 : 0)]++;
+                    }
                 }
             }
+            uint32_t ng = 0;  // a CELL (this block's elements of one bucket) is padded to whole groups of four
+            for (uint32_t c : touched) {
+                const uint32_t k4 = (lcnt[c] + 3u) & ~3u;
+                cnt[c] += k4;
+                ng += k4 / 4;
+                lcnt[c] = 0;
+            }
+            b.g1 = ng;  // (counts for now)
+            b.u1 = nu;
+            neT[(size_t)tix * 3 + 2] += nu;
         }
-        uint32_t ng = 0;  // a CELL (this block's elements of one bucket) is padded to whole groups of four
-        for (uint32_t c : touched) {
-            const uint32_t k4 = (lcnt[c] + 3u) & ~3u;
-            cnt[c] += k4;
-            ng += k4 / 4;
-            lcnt[c] = 0;
+    };
+    auto run_threads = [&](auto &&fn) {
+        if (T == 1) {
+            fn(0u);
+            return;
         }
-        b.g1 = ng;  // (counts for now)
-        b.u1 = nu;
-        p.n_edges[2] += nu;
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < T; t++) th.emplace_back(fn, t);
+        for (auto &x : th) x.join();
+    };
+    lap("pass 1 set-up");
+    run_threads(pass1);
+    lap("pass 1 (classes, counts)");
+    std::vector<uint64_t> cnt((size_t)2 * S + 1, 0);
+    for (uint32_t t = 0; t < T; t++) {
+        for (size_t c = 0; c < (size_t)2 * S; c++) cnt[c] += cntT[t][c];
+        for (int k = 0; k < 3; k++) p.n_edges[k] += neT[(size_t)t * 3 + k];
     }
     {
         uint64_t g = 0, u = 0;
@@ -268,46 +321,60 @@ inline bool build_plan(const OffT *in_off, const uint32_t *in_src, const uint32_
         }
     }
     // ---- pass 2: block by block, its cells in (slice, class) order -- each a run of consecutive stream positions, a group = four
-    // of them --, the urgent elements in row order
-    std::vector<uint64_t> cur(start);
-    std::vector<uint32_t> cell4;
-    for (const Block &b : p.blocks) {
-        const uint32_t t0 = b.e0, t1 = p.off2[b.row1];
-        touched.clear();
-        for (uint32_t t = t0; t < t1; t++) {
-            const uint32_t c = code[t];
-            if (c & kOldBit) continue;
-            if (lcnt[c]++ == 0) touched.push_back(c);
-        }
-        std::sort(touched.begin(), touched.end());
-        uint32_t g = b.g0;
-        cell4.clear();
-        for (uint32_t c : touched) {  // lcnt becomes (the cell's first slot in gperm) + 1 (0 stays "untouched")
-            const uint32_t k4 = (lcnt[c] + 3u) & ~3u;
-            for (uint32_t j = 0; j < k4 / 4; j++) p.gpos[g + j] = (uint32_t)(cur[c] + 4u * j) | ((c & 1u) ? kYBit : 0u);
-            lcnt[c] = 4u * g + 1;
-            g += k4 / 4;
-            cell4.push_back(k4);
-        }
-        uint32_t uj = b.u0;
-        for (uint32_t t = t0; t < t1; t++) {
-            const uint32_t c = code[t];
-            if (c & kOldBit) {
-                p.upos[uj] = (uint16_t)(t - t0);
-                p.usrc[uj] = c & ~kOldBit;
-                uj++;
-                continue;
-            }
-            const uint32_t slot = lcnt[c]++ - 1;  // index into gperm; its group's position + (slot & 3) is the stream position
-            const uint32_t pos = (p.gpos[slot >> 2] & ~kYBit) + (slot & 3u);
-            p.asrc[c & 1u][pos] = loc[t];
-            p.gperm[slot] = (uint16_t)(t - t0);
-        }
-        for (size_t i = 0; i < touched.size(); i++) {
-            lcnt[touched[i]] = 0;
-            cur[touched[i]] += cell4[i];  // the bucket's next cell (a later block's) follows this one
+    // of them --, the urgent elements in row order.  Thread t's cursor of a bucket starts behind the cells of the threads before it.
+    std::vector<std::vector<uint64_t>> curT(T);
+    {
+        std::vector<uint64_t> run(start);
+        for (uint32_t t = 0; t < T; t++) {
+            curT[t] = run;
+            for (size_t c = 0; c < (size_t)2 * S; c++) run[c] += cntT[t][c];
         }
     }
+    lap("positions, items, arrays");
+    auto pass2 = [&](uint32_t tix) {
+        std::vector<uint64_t> &cur = curT[tix];
+        std::vector<uint32_t> lcnt((size_t)2 * S, 0), touched, cell4;
+        for (size_t bi = tb[tix]; bi < tb[tix + 1]; bi++) {
+            const Block &b = p.blocks[bi];
+            const uint32_t t0 = b.e0, t1 = p.off2[b.row1];
+            touched.clear();
+            for (uint32_t t = t0; t < t1; t++) {
+                const uint32_t c = code[t];
+                if (c & kOldBit) continue;
+                if (lcnt[c]++ == 0) touched.push_back(c);
+            }
+            std::sort(touched.begin(), touched.end());
+            uint32_t g = b.g0;
+            cell4.clear();
+            for (uint32_t c : touched) {  // lcnt becomes (the cell's first slot in gperm) + 1 (0 stays "untouched")
+                const uint32_t k4 = (lcnt[c] + 3u) & ~3u;
+                for (uint32_t j = 0; j < k4 / 4; j++) p.gpos[g + j] = (uint32_t)(cur[c] + 4u * j) | ((c & 1u) ? kYBit : 0u);
+                lcnt[c] = 4u * g + 1;
+                g += k4 / 4;
+                cell4.push_back(k4);
+            }
+            uint32_t uj = b.u0;
+            for (uint32_t t = t0; t < t1; t++) {
+                const uint32_t c = code[t];
+                if (c & kOldBit) {
+                    p.upos[uj] = (uint16_t)(t - t0);
+                    p.usrc[uj] = c & ~kOldBit;
+                    uj++;
+                    continue;
+                }
+                const uint32_t slot = lcnt[c]++ - 1;  // index into gperm; its group's position + (slot & 3) is the stream position
+                const uint32_t pos = (p.gpos[slot >> 2] & ~kYBit) + (slot & 3u);
+                p.asrc[c & 1u][pos] = loc[t];
+                p.gperm[slot] = (uint16_t)(t - t0);
+            }
+            for (size_t i = 0; i < touched.size(); i++) {
+                lcnt[touched[i]] = 0;
+                cur[touched[i]] += cell4[i];  // the bucket's next cell (a later block's) follows this one
+            }
+        }
+    };
+    run_threads(pass2);
+    lap("pass 2 (placement)");
     return true;
 }
 

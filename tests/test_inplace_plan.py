@@ -21,7 +21,7 @@ SO = os.path.join(ROOT, "tests", "cpp", "bin", "libinplace_plan_test.so")
 def build():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-ffp-contract=off", SRC, "-o", SO])
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra", "-ffp-contract=off", SRC, "-o", SO])
     return SO
 
 
@@ -126,3 +126,14 @@ def test_jacobi_reading_in_the_same_layout(ipt, oracle):
         got, _, info = emulate(ipt, g, tile=512, rows=16, slice_=64, part=32, gap=1 | (1 << 16), sweeps=3)
         assert info["levels"] == 1 and info["x"] == 0 and info["urgent"] == 0
         assert np.array_equal(got, want)
+
+
+def test_layout_is_the_same_for_every_thread_count(ipt, oracle):
+    """the two edge passes of build_plan run on several host threads over contiguous block ranges; a graph large enough to take the
+    threaded path must give the oracle's scores too (the small graphs above all run on one thread)"""
+    frm, to = util.random_relation(150000, 1400000, 21)
+    g = util.graph_from_relation(oracle, frm, to)
+    assert len(g["isrc"]) >= (1 << 20)
+    want, _, _ = oracle.pagerank_mode(g["n"], g["ioff"], g["isrc"], g["outdeg"], 0.85, 0.0, 2, mode=oracle.PR_INPLACE)
+    got, _, info = emulate(ipt, g, tile=2048, rows=256, slice_=4096, part=2048, gap=1, sweeps=2)
+    assert info["blocks"] > 64 and np.array_equal(got, want)
