@@ -23,7 +23,7 @@ def main(path):
         print("%-72s %7d %12.1f %11.2f %11.2f %11.2f %6.2f %5s %5s %5s %7s" %
               (short, n, tot / 1e3, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total, vg, ag, sg, lds))
     # the two kernels the bench's roofline objects are about, by launch shape
-    for pat in ("%hnsw_knn_kernel%", "%pr_step_kernel%", "%pb_expand_kernel%", "%pb_reduce_kernel%", "%pa_reduce_kernel%", "%distance_pairs_kernel%", "%distance_runs_kernel%", "%dot_gemm_mfma_kernel%", "%bf_select_kernel%"):
+    for pat in ("%hnsw_knn_kernel%", "%hnsw_knn_spec_kernel%", "%hnsw_knn_wide_kernel%", "%gi_level_kernel%", "%pr_step_kernel%", "%pb_expand_kernel%", "%pb_reduce_kernel%", "%pa_reduce_kernel%", "%distance_pairs_kernel%", "%distance_runs_kernel%", "%dot_gemm_mfma_kernel%", "%bf_select_kernel%"):
         for g, lds, n, avg, mn, mx in c.execute(
                 "select grid_x, lds_size, count(*), avg(duration), min(duration), max(duration) from kernels "
                 "where name like ? group by grid_x, lds_size order by count(*) desc", (pat,)):

@@ -5,11 +5,11 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/round6b
 rm -rf $O; mkdir -p $O
 cd $R
-timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 --index-cache /tmp/ixc > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; grep -v Warning $O/bench.err | tail -8
+timeout 2400 python bench.py --gpus 1 --steps 20 --warmup 5 --index-cache /tmp/ixc > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; grep -v Warning $O/bench.err | tail -8
 cp gpurun_out/bench_detail.json $O/bench_detail.json
 echo "line bytes=$(wc -c < $O/bench.json)"
 cd /tmp && export TMPDIR=/tmp
-timeout 1500 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python $R/bench.py --steps 20 --warmup 5 --skip-cpu --index-cache /tmp/ixc > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+timeout 2400 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- python $R/bench.py --steps 20 --warmup 5 --skip-cpu --index-cache /tmp/ixc > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 echo "trace rc=$?"
 db=$(find $O/trace -name "*.db" | head -1)
 python $R/profiles/summarize.py "$db" > $O/bench_kernel_stats.txt; head -24 $O/bench_kernel_stats.txt | cut -c1-170
