@@ -2725,29 +2725,7 @@ lp_update_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
     for (uint32_t i = wave; i < count; i += n_waves) lp_update_node(off, tgt, w, order[i], labels, tab, lane, flags, act);
 }
 
-// the class's nodes of degree kLpSmall < d <= kLpMid: ONE wave per workgroup with an 8 192-slot table in LDS (96 KiB: a workgroup per
-// CU).  Round 6: on a skewed graph tens of thousands of nodes sit in this range, and they used to share the hub kernel's 40 waves and
-// its tables in GLOBAL memory -- a round trip per distinct label per 64 neighbours (R-MAT 10M / 200M: 13.4 s for the rule).
-constexpr uint32_t kLpMid = 6144, kLpMidBits = 13;
-__global__ void __launch_bounds__(64)
-lp_update_mid_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w,
-                     const uint32_t *__restrict__ order, uint32_t count, uint32_t *__restrict__ labels, uint32_t *__restrict__ flags,
-                     LpActive act) {
-    extern __shared__ uint32_t lp_mid_lds[];
-    uint32_t *keys = lp_mid_lds, *slots = lp_mid_lds + (2u << kLpMidBits);
-    float *vals = (float *)(lp_mid_lds + (1u << kLpMidBits));
-    const int lane = threadIdx.x;
-    for (uint32_t i = lane; i < (1u << kLpMidBits); i += 64) keys[i] = CZ_NONE;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    LpTab tab{keys, vals, slots, kLpMidBits};
-    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-        const uint32_t v = order[i];
-        if (off[v + 1] - off[v] > kLpMid) continue;  // (lp_update_hub_kernel's)
-        lp_update_node(off, tgt, w, v, labels, tab, lane, flags, act);
-    }
-}
-
-// the class's nodes of larger degree still: a table per wave in global memory, sized for the largest degree of the graph
+// the class's nodes of larger degree: a table per wave in global memory, sized for the largest degree of the graph
 __global__ void __launch_bounds__(kT)
 lp_update_hub_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w,
                      const uint32_t *__restrict__ order, uint32_t count, uint32_t *__restrict__ labels, uint32_t *__restrict__ flags,
@@ -2756,11 +2734,7 @@ lp_update_hub_kernel(const uint32_t *__restrict__ off, const uint32_t *__restric
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const size_t at = (size_t)wave << bits;
     LpTab tab{tkeys + at, tvals + at, tslots + at, bits};
-    for (uint32_t i = wave; i < count; i += n_waves) {
-        const uint32_t v = order[i];
-        if (off[v + 1] - off[v] <= kLpMid) continue;  // (lp_update_mid_kernel's)
-        lp_update_node(off, tgt, w, v, labels, tab, lane, flags, act);
-    }
+    for (uint32_t i = wave; i < count; i += n_waves) lp_update_node(off, tgt, w, order[i], labels, tab, lane, flags, act);
 }
 
 }  // namespace
@@ -2928,7 +2902,6 @@ extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t 
         CZ_HIP(d_tslots.alloc(words));
         CZ_HIP(hipMemsetAsync(d_tkeys.p, 0xFF, words * 4, s));
     }
-    if (any_hub) CZ_HIP(hipFuncSetAttribute((const void *)lp_update_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(12u << kLpMidBits)));
     hipLaunchKernelGGL(iota_kernel, dim3(grid_for(N)), dim3(kT), 0, s, d_labels.p, N);  // :61
     // the active set (LpActive): an iteration that changed at most this share of the nodes switches the rest of the run to
     // evaluating only the dependants of changed nodes.  CZ_LP_SPARSE_FRAC: 0 = never, 1 = from the second iteration on.
@@ -2959,9 +2932,6 @@ extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t 
                 hipLaunchKernelGGL(lp_update_kernel, dim3(grid_for((uint64_t)ns * 64)), dim3(kT), 0, s, d_off.p, d_tgt.p, d_w.p,
                                    d_order.p + tiny_end[c], ns, d_labels.p, d_flags.p, act);
             if (nh)
-                hipLaunchKernelGGL(lp_update_mid_kernel, dim3(std::min<uint32_t>(nh, 2048u)), dim3(64), (12u << kLpMidBits), s, d_off.p, d_tgt.p,
-                                   d_w.p, d_order.p + small_end[c], nh, d_labels.p, d_flags.p, act);
-            if (nh && max_deg > kLpMid)
                 hipLaunchKernelGGL(lp_update_hub_kernel, dim3(std::min<uint32_t>(hub_blocks, (nh + kT / 64 - 1) / (kT / 64))), dim3(kT), 0, s,
                                    d_off.p, d_tgt.p, d_w.p, d_order.p + small_end[c], nh, d_labels.p, d_flags.p, d_tkeys.p, d_tvals.p,
                                    d_tslots.p, hub_bits, act);

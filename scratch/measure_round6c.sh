@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, final tree, part C: the PMC passes of the entries tied to graph.hip only (it changed after part A: LabelPropagation's
+# round 6, final tree, part C: the PMC passes of the entries tied to graph.hip only (if it changed after part A)
 # mid-degree kernel), then the GPU suite.  Needs gpurun_out/round6a/bench_detail.json's algorithmic bytes: copied from profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/round6c
