@@ -319,6 +319,8 @@ int cz_pagerank_inplace(const uint32_t *in_offsets, const uint32_t *in_sources, 
  *   init/sweeps the same loop in the caller's hands: init, then n sweeps on `stream` with nothing read back (what bench.py
  *               brackets with HIP events)
  *   read_scores scores [N] in the caller's numbering (host memory, or device memory with CZ_DEVICE_PTRS)
+ *   A plan carries the sweep's state (contributions, value streams, parity): ONE thread drives it at a time; different plans are
+ *   independent.  It belongs to the device that was current when it was created.
  *   info        shape [16] u64: levels, row blocks, phase-A items, long rows, urgent gap, slice width, launches per sweep, graph
  *               replay (1/0), X edges, Y edges, urgent edges, long-row edges, X positions, Y positions; host build / upload ms */
 /* cz_pagerank_inplace_plan_create: lay the JACOBI reading out the same way (one level, every edge reads the previous sweep's
