@@ -997,6 +997,15 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
         return res, plan, sp
 
     res, plan, sp = measure()
+    if rank == 0 and not args.multi and kind == "uniform" and not args.skip_secondary:
+        # the OTHER reading of graph::page_rank (contribution refreshed inside the sweep): a resident plan, event-timed like the Jacobi
+        # sweep; also under --skip-cpu (the profiling passes), where only its oracle legs are left out
+        try:
+            hh = (None, None, None) if args.skip_cpu else (off.cpu().numpy(), s.cpu().numpy().astype(np.uint32), outdeg32.cpu().numpy().astype(np.uint32))
+            res["inplace_reading"] = bench_pagerank_inplace(args, torch, device, stream, off32, s, outdeg32, n_total, e_total, *hh)
+            del hh
+        except Exception as e:  # noqa: BLE001
+            res["inplace_reading"] = dict(error=f"{type(e).__name__}: {e}")
     if rank == 0 and not args.multi and not args.skip_cpu:
         h_off = off.cpu().numpy()
         h_src = s.cpu().numpy().astype(np.uint32)
@@ -1024,11 +1033,6 @@ def bench_pagerank(args, torch, dist, rank, world, device, kind="uniform"):
                      "(relation, snapshot) key reuses the device layout.  Not part of `value`")
         except Exception as e:  # noqa: BLE001
             res["end_to_end"] = dict(error=f"{type(e).__name__}: {e}")
-        if kind == "uniform" and not args.skip_secondary:
-            try:  # the OTHER reading of graph::page_rank (contribution refreshed inside the sweep): a resident plan, event-timed like the Jacobi sweep
-                res["inplace_reading"] = bench_pagerank_inplace(args, torch, device, stream, off32, s, outdeg32, n_total, e_total, h_off, h_src, h_od)
-            except Exception as e:  # noqa: BLE001
-                res["inplace_reading"] = dict(error=f"{type(e).__name__}: {e}")
         try:
             from oracle import oracle as O
             ioff = h_off.astype(np.uint64)
