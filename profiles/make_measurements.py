@@ -49,7 +49,7 @@ def rows(d):
     rf = d.get("roofline", {})
     cb = d.get("cpu_baseline", {})
     par = d.get("parity", {})
-    out.append(("**HNSW k-NN " + str(g(d, "config", "workload", default="10M x 768"))[:60] + "** (`hnsw_knn_kernel`), ef " + f(g(d, "config", "ef")) + ", recall@10 " + f(g(d, "config", "recall_at_k"), 4),
+    out.append(("**" + str(g(d, "config", "workload", default="HNSW k-NN 10M x 768")) + "** (`hnsw_knn_kernel`), ef " + f(g(d, "config", "ef")) + ", recall@10 " + f(g(d, "config", "recall_at_k"), 4),
                 f(d.get("value"), 4, " queries/s") + f", {f(d.get('ms_per_step'), 4)} ms", f(rf.get("frac"), 3), traffic(rf),
                 f(cb.get("value"), 3, " q/s") + f" on {cb.get('cores')} core(s)" + (f"; {f(g(cb, 'all_cores', 'value'), 3)} on {g(cb, 'all_cores', 'cores')}" if cb.get("all_cores") else ""),
                 "bit-equal to the oracle: " + f(par.get("bit_equal_to_oracle", par.get("parity_checked"))) + f"; max rel err vs reference order {f(par.get('max_rel_err_vs_reference_arithmetic'))}"))

@@ -143,6 +143,24 @@ def test_pagerank_10m_100m_formulations_agree(torch_gpu):
             assert float(err.item()) == pytest.approx(want_err, rel=1e-9)
         plan.close()
         del c0, c1
+    # ---- the in-place reading on the same full-size graph (round 6: the resident, level-scheduled plan): 3 sweeps == the oracle's
+    # in-place mode score by score; init + sweeps reproduces run; and it is NOT the Jacobi vector
+    from cozo_amd.graph import InplacePageRankPlan
+    from oracle import oracle as O
+    ip = InplacePageRankPlan(off32, s, outdeg, 0.85, device_ptrs=True)
+    info = ip.info
+    assert info["levels"] > 20 and info["graph_replay"] == 1
+    assert info["x_edges"] + info["y_edges"] + info["urgent_edges"] + info["long_row_edges"] == int(s.numel())
+    it, err = ip.run(0.0, 3)
+    want_ip, _, want_ip_err = O.pagerank_mode(n, h_off, h_src, h_od, 0.85, 0.0, 3, mode=O.PR_INPLACE)
+    got_ip = ip.read_scores()
+    assert it == 3 and np.array_equal(got_ip, want_ip), "10M / 100M: in-place scores after 3 sweeps differ from the oracle"
+    assert err == pytest.approx(want_ip_err, rel=1e-9)
+    ip.init(stream)
+    ip.sweeps(3, stream)
+    assert np.array_equal(ip.read_scores(), want_ip)
+    assert not np.array_equal(want_ip, want)
+    ip.close()
     assert torch.equal(results["blocked"][0], results["gather"][0])
     assert results["blocked"][1] == results["gather"][1]
     errs = results["blocked"][1]
