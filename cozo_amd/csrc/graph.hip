@@ -1494,9 +1494,11 @@ tri_self_loop_kernel(const uint32_t *__restrict__ off, const uint32_t *__restric
 // path are what that costs, wherever the lines come from.  Now c's list is loaded ONCE per (node, c), a lane per entry, and
 // rotated past the lanes (DPP row_ror:1 inside the 16-lane row): every lane holds one neighbour b of the node and counts how
 // often it meets it -- 2 loads and 48 register steps per list instead of 45 probe chains per node.  Nodes with more than
-// kTriMerge neighbours above themselves (hubs) keep the pair form, whose cost does not grow with the square of the list.
+// kTriMerge neighbours above themselves go to triangles_hub_kernel (this form reads every c's list once per 16 of the node's
+// neighbours: the square of the list), and a c whose own list is longer than kTriScan is searched instead of rotated past.
+// (64 / 128: the uniform 10M / 200M graph never meets either bound -- 10.9 ms as before; R-MAT 10M / 200M: 1236 -> 50 ms here.)
 constexpr int kTriLanes = 16;
-constexpr uint32_t kTriMerge = 256;
+constexpr uint32_t kTriMerge = 64, kTriScan = 128;
 
 __device__ __forceinline__ void tri_credit(const uint32_t *__restrict__ tgt, uint32_t a, uint32_t b, uint32_t v, uint32_t pi, uint32_t pj,
                                            uint32_t m_bc, unsigned long long *__restrict__ n_tri) {
@@ -1514,7 +1516,8 @@ __device__ __forceinline__ void tri_credit(const uint32_t *__restrict__ tgt, uin
 __global__ void __launch_bounds__(256)
 triangles_oriented_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t N,
                           unsigned long long *__restrict__ n_tri /* zeroed */, uint32_t *__restrict__ degree,
-                          uint32_t *__restrict__ hubs /* [N] */, uint32_t *__restrict__ n_hubs /* zeroed */) {
+                          uint32_t *__restrict__ hubs /* [N] */, uint32_t *__restrict__ n_hubs /* zeroed */, uint32_t merge_max,
+                          uint32_t scan_max) {
     const uint32_t glane = threadIdx.x & (kTriLanes - 1);
     const uint32_t group = (blockIdx.x * 256 + threadIdx.x) / kTriLanes, n_groups = (gridDim.x * 256) / kTriLanes;
     for (uint32_t v = group; v < N; v += n_groups) {
@@ -1529,7 +1532,7 @@ triangles_oriented_kernel(const uint32_t *__restrict__ off, const uint32_t *__re
         }
         const uint32_t m = b - s;
         if (m < 2) continue;
-        if (m <= kTriMerge) {
+        if (m <= merge_max) {
             for (uint32_t ca = 0; ca < m; ca += kTriLanes) {  // this lane's neighbour bb (first occurrences only)
                 const uint32_t pj = s + ca + glane;
                 const bool have = ca + glane < m;
@@ -1554,8 +1557,8 @@ triangles_oriented_kernel(const uint32_t *__restrict__ off, const uint32_t *__re
                         if (oc1 == oc) continue;  // repeated (or a neighbour without a list: cannot be, the graph is symmetric)
                         const bool want = first_b && bb < c;
                         uint32_t cnt = 0;
-                        if (oc1 - oc > 2048u) {  // c is a hub: a search per lane instead of its whole list past every lane (a hub
-                                                 // with high ids had its list read once per NEIGHBOUR: degree^2 words)
+                        if (oc1 - oc > scan_max) {  // c's list is long: a search per lane instead of the whole list past every lane
+                                                    // (a hub with high ids had its list read once per NEIGHBOUR: degree^2 words)
                             if (want) cnt = csr_count(tgt, oc, oc1, bb);
                         } else
                         for (uint32_t k = oc; k < oc1; k += kTriLanes) {
@@ -1572,23 +1575,113 @@ triangles_oriented_kernel(const uint32_t *__restrict__ off, const uint32_t *__re
             }
             continue;
         }
-        // a hub (more than kTriMerge neighbours above itself): left to triangles_hub_kernel.  Until round 6 one 16-lane group walked
-        // all m (m - 1) / 2 pairs of its list here -- 10^9 pairs for ONE node of a 1M-node R-MAT graph, 114 s for the rule.
+        // more than merge_max neighbours above itself: left to triangles_hub_kernel.  Until round 6 one 16-lane group walked all
+        // m (m - 1) / 2 pairs of its list here -- 10^9 pairs for ONE node of a 1M-node R-MAT graph, 114 s for the rule.
         if (glane == 0) hubs[atomicAdd(n_hubs, 1u)] = v;
     }
 }
 
 // The hubs.  A triangle {v < bb < c} is found from v through bb's list instead of through the pairs of v's own: for every
-// neighbour bb above v, every c above bb in bb's list, one binary search of c in v's list -- sum over bb of its (short) list
-// instead of the square of v's (long) one.  A hub's neighbours are dealt to gridDim.y workgroups x 16 lane groups; the lanes of a
-// group stride over bb's list.  Same credit, same multiplicities as the merge form.
-__global__ void __launch_bounds__(256)
+// neighbour bb above v, every c above bb in bb's list, "how often is c in v's list?" -- sum over bb of its (short) list instead of
+// the square of v's (long) one.  A binary search in a 200 000-entry list is 17 dependent loads, and a wave pays them whenever ONE
+// of its 64 lanes has to: the workgroup first writes v's list into a set of its own that answers with the multiplicity (0, 1, 2,
+// "3 or more": only the last falls back to the search) in one access --
+//   * up to kTriHubLds distinct neighbours: an open-addressing table in LDS (sized to the list, at most half full);
+//   * more: two bits per node in a map of N entries in global memory, one map per workgroup (written with atomics, read past
+//     the L1 -- both act at the L2 -- and wiped entry by entry afterwards).
+// One 1024-thread workgroup per hub at a time (two on a CU), hubs handed out through a counter (they are listed roughly largest
+// first); neighbours whose own list above themselves is long (other hubs) are queued in LDS and walked by a wave each
+// afterwards instead of by one 16-lane group.  The credits of the two smaller corners are summed in registers: every triangle of
+// a hub adds to n_tri[v], every triangle found through bb to n_tri[bb] -- only the largest corner (scattered over the nodes) is
+// credited at once.  Same credit, same multiplicities as the merge form.
+constexpr uint32_t kTriHubThreads = 1024, kTriHubQueue = 2048, kTriHubLong = 512, kTriHubSlots = 8192, kTriHubLds = kTriHubSlots / 2;
+
+struct TriHubSet {
+    const uint32_t *keys;  // LDS table (mask != 0) ...
+    const uint8_t *vals;
+    uint32_t mask, shift;
+    const uint32_t *map;  // ... or the 2-bit map in global memory
+    __device__ __forceinline__ uint32_t count(uint32_t c) const {
+        if (mask) {
+            uint32_t slot = (c * 2654435761u) >> shift;
+            for (;;) {
+                const uint32_t k = keys[slot];
+                if (k == c) return vals[slot];
+                if (k == CZ_NONE) return 0;
+                slot = (slot + 1) & mask;
+            }
+        }
+        return (__hip_atomic_load(&map[c >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (2u * (c & 15u))) & 3u;
+    }
+};
+
+// One entry of bb's list: c with the entries before and after it, loaded together with it (the two are in c's cache line nearly
+// always; a dependent load on the hit path costs every lane of the wave its latency).  Taking the neighbours from the lanes
+// next door instead (DPP rotations, one load per span for the entry past its end) was tried and is SLOWER: 633 against 400 ms.
+struct TriEntry {
+    uint32_t c, prev, next;
+};
+__device__ __forceinline__ TriEntry tri_entry(const uint32_t *__restrict__ tgt, uint32_t ob, uint32_t ob1, uint32_t k) {
+    TriEntry e;
+    const bool in = k < ob1;
+    e.c = in ? tgt[k] : CZ_NONE;
+    e.prev = in && k > ob ? tgt[k - 1] : CZ_NONE;
+    e.next = in && k + 1 < ob1 ? tgt[k + 1] : CZ_NONE;
+    return e;
+}
+
+__device__ __forceinline__ void tri_hub_probe(const uint32_t *__restrict__ tgt, const TriHubSet &set, uint32_t s, uint32_t b, uint32_t m_ab,
+                                              uint32_t ob1, uint32_t k, const TriEntry &e, unsigned long long &acc_v,
+                                              unsigned long long &acc_b, unsigned long long *__restrict__ n_tri) {
+    const uint32_t c = e.c;
+    if (c == CZ_NONE || e.prev == c) return;  // past the list / counted at its first position
+    uint32_t m_ac = set.count(c);
+    if (!m_ac) return;
+    uint32_t m_bc = 1;
+    if (e.next == c) {
+        m_bc = 2;
+        while (k + m_bc < ob1 && tgt[k + m_bc] == c) m_bc++;
+    }
+    if (m_ac == 3) {  // "3 or more": the run in v's list is measured
+        uint32_t l = s, r = b;
+        while (l < r) {
+            const uint32_t mid = l + ((r - l) >> 1);
+            if (tgt[mid] < c) l = mid + 1;
+            else r = mid;
+        }
+        while (l + m_ac < b && tgt[l + m_ac] == c) m_ac++;
+    }
+    acc_v += (unsigned long long)m_ab * m_ac;
+    acc_b += (unsigned long long)m_ab * m_bc;
+    atomicAdd(&n_tri[c], (unsigned long long)m_ac * m_bc);
+}
+
+__device__ __forceinline__ unsigned long long tri_wave_sum(unsigned long long x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += (unsigned long long)__shfl_xor((long long)x, d, 64);
+    return x;
+}
+
+__global__ void __launch_bounds__(kTriHubThreads, 2)
 triangles_hub_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ hubs,
-                     const uint32_t *__restrict__ n_hubs, unsigned long long *__restrict__ n_tri) {
+                     const uint32_t *__restrict__ n_hubs, uint32_t *__restrict__ next_hub /* zeroed */,
+                     uint32_t *maps /* gridDim.x x words, zeroed */, uint32_t words, unsigned long long *__restrict__ n_tri) {
+    __shared__ uint32_t keys[kTriHubSlots];
+    __shared__ uint8_t vals[kTriHubSlots];
+    __shared__ uint32_t q_pj[kTriHubQueue], q_lo[kTriHubQueue];
+    __shared__ uint32_t q_n, h_sh;
     const uint32_t glane = threadIdx.x & (kTriLanes - 1), gi = threadIdx.x / kTriLanes;
-    constexpr uint32_t kGroups = 256 / kTriLanes;
+    constexpr uint32_t kGroups = kTriHubThreads / kTriLanes;
+    uint32_t *map = maps + (size_t)blockIdx.x * words;
     const uint32_t nh = *n_hubs;
-    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+    for (;;) {
+        if (threadIdx.x == 0) {
+            h_sh = atomicAdd(next_hub, 1u);
+            q_n = 0;
+        }
+        __syncthreads();
+        const uint32_t h = h_sh;
+        if (h >= nh) break;
         const uint32_t v = hubs[h];
         const uint32_t a = off[v], b = off[v + 1];
         uint32_t s = a, hh = b;
@@ -1597,9 +1690,37 @@ triangles_hub_kernel(const uint32_t *__restrict__ off, const uint32_t *__restric
             if (tgt[mid] <= v) s = mid + 1;
             else hh = mid;
         }
-        for (uint32_t pj = s + blockIdx.y * kGroups + gi; pj < b; pj += gridDim.y * kGroups) {
+        // ---- v's list into the set (first positions of the runs, multiplicity capped at 3) ----
+        const uint32_t m = b - s;
+        TriHubSet set{keys, vals, 0, 0, map};
+        if (m <= kTriHubLds) {
+            uint32_t bits = 6;
+            while ((1u << bits) < 2 * m) bits++;
+            set.mask = (1u << bits) - 1;
+            set.shift = 32 - bits;
+            for (uint32_t i = threadIdx.x; i <= set.mask; i += kTriHubThreads) keys[i] = CZ_NONE;
+            __syncthreads();
+        }
+        for (uint32_t p = s + threadIdx.x; p < b; p += kTriHubThreads) {
+            const uint32_t x = tgt[p];
+            if (p > s && tgt[p - 1] == x) continue;
+            uint32_t run = 1;
+            while (run < 3 && p + run < b && tgt[p + run] == x) run++;
+            if (set.mask) {
+                uint32_t slot = (x * 2654435761u) >> set.shift;
+                while (atomicCAS(&keys[slot], CZ_NONE, x) != CZ_NONE) slot = (slot + 1) & set.mask;  // (x occurs once here: first of its run)
+                vals[slot] = (uint8_t)run;
+            } else {
+                atomicOr(&map[x >> 4], run << (2u * (x & 15u)));
+            }
+        }
+        __syncthreads();  // (waits for the atomics as well: they have acted at the L2 by now)
+        unsigned long long acc_v = 0;
+        for (uint32_t pj = s + gi; pj < b; pj += kGroups) {
             const uint32_t bb = tgt[pj];
             if (pj > a && tgt[pj - 1] == bb) continue;  // counted at its first position
+            uint32_t m_ab = 1;
+            while (pj + m_ab < b && tgt[pj + m_ab] == bb) m_ab++;
             const uint32_t ob = off[bb], ob1 = off[bb + 1];
             uint32_t lo = ob, hi = ob1;
             while (lo < hi) {  // bb's neighbours above bb
@@ -1607,19 +1728,48 @@ triangles_hub_kernel(const uint32_t *__restrict__ off, const uint32_t *__restric
                 if (tgt[mid] <= bb) lo = mid + 1;
                 else hi = mid;
             }
-            for (uint32_t k = lo + glane; k < ob1; k += kTriLanes) {
-                const uint32_t c = tgt[k];
-                if (k > ob && tgt[k - 1] == c) continue;
-                uint32_t m_bc = 1;
-                while (k + m_bc < ob1 && tgt[k + m_bc] == c) m_bc++;
-                uint32_t l = s, r = b;
-                while (l < r) {  // c's first position in v's list
-                    const uint32_t mid = l + ((r - l) >> 1);
-                    if (tgt[mid] < c) l = mid + 1;
-                    else r = mid;
+            if (ob1 - lo > kTriHubLong) {  // (group-uniform) another hub: the whole workgroup walks it below
+                uint32_t slot = 0;
+                if (glane == 0) slot = atomicAdd(&q_n, 1u);
+                slot = (uint32_t)__shfl((int)slot, 0, kTriLanes);
+                if (slot < kTriHubQueue) {
+                    if (glane == 0) {
+                        q_pj[slot] = pj;
+                        q_lo[slot] = lo;
+                    }
+                    continue;
                 }
-                if (l < b && tgt[l] == c) tri_credit(tgt, a, b, v, l, pj, m_bc, n_tri);
             }
+            unsigned long long acc_b = 0;
+            for (uint32_t k = lo + glane; k < ob1; k += 2 * kTriLanes) {  // two entries per lane in flight
+                const TriEntry e0 = tri_entry(tgt, ob, ob1, k), e1 = tri_entry(tgt, ob, ob1, k + kTriLanes);
+                tri_hub_probe(tgt, set, s, b, m_ab, ob1, k, e0, acc_v, acc_b, n_tri);
+                tri_hub_probe(tgt, set, s, b, m_ab, ob1, k + kTriLanes, e1, acc_v, acc_b, n_tri);
+            }
+            if (acc_b) atomicAdd(&n_tri[bb], acc_b);
+        }
+        __syncthreads();
+        const uint32_t nq = min(q_n, kTriHubQueue);
+        for (uint32_t i = threadIdx.x >> 6; i < nq; i += kTriHubThreads / 64) {  // a wave per queued neighbour
+            const uint32_t pj = q_pj[i], bb = tgt[pj];
+            uint32_t m_ab = 1;
+            while (pj + m_ab < b && tgt[pj + m_ab] == bb) m_ab++;
+            const uint32_t ob = off[bb], ob1 = off[bb + 1];
+            unsigned long long acc_b = 0;
+            for (uint32_t k = q_lo[i] + (threadIdx.x & 63u); k < ob1; k += 128) {
+                const TriEntry e0 = tri_entry(tgt, ob, ob1, k), e1 = tri_entry(tgt, ob, ob1, k + 64);
+                tri_hub_probe(tgt, set, s, b, m_ab, ob1, k, e0, acc_v, acc_b, n_tri);
+                tri_hub_probe(tgt, set, s, b, m_ab, ob1, k + 64, e1, acc_v, acc_b, n_tri);
+            }
+            acc_b = tri_wave_sum(acc_b);
+            if ((threadIdx.x & 63u) == 0 && acc_b) atomicAdd(&n_tri[bb], acc_b);
+        }
+        acc_v = tri_wave_sum(acc_v);
+        if ((threadIdx.x & 63u) == 0 && acc_v) atomicAdd(&n_tri[v], acc_v);
+        __syncthreads();  // (nobody still asks the set; h_sh and q_n may be written again)
+        if (!set.mask) {
+            for (uint32_t p = s + threadIdx.x; p < b; p += kTriHubThreads) map[tgt[p] >> 4] = 0;  // the map goes back to all zero
+            __syncthreads();
         }
     }
 }
@@ -1680,9 +1830,20 @@ extern "C" int cz_clustering_coefficients(const uint32_t *offsets, const uint32_
         CZ_HIP(d_nhubs.alloc(1));
         CZ_HIP(hipMemsetAsync(d_nhubs.p, 0, 4, nullptr));
         CZ_HIP(hipMemsetAsync(d_tri.p, 0, (size_t)N * 8, nullptr));
+        // one 2-bit map of N entries per hub workgroup: two workgroups per CU, fewer when N is so large that they would pass 2 GiB together
+        const uint32_t words = (N + 15u) / 16u;
+        const uint32_t hub_wgs = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(512, ((uint64_t)1 << 29) / words));
+        cz::DevBuf<uint32_t> d_maps, d_next;
+        CZ_HIP(d_maps.alloc((size_t)hub_wgs * words));
+        CZ_HIP(d_next.alloc(1));
+        CZ_HIP(hipMemsetAsync(d_maps.p, 0, (size_t)hub_wgs * words * 4, nullptr));
+        CZ_HIP(hipMemsetAsync(d_next.p, 0, 4, nullptr));
+        const uint32_t merge_max = getenv("CZ_TRI_MERGE") ? (uint32_t)atoi(getenv("CZ_TRI_MERGE")) : kTriMerge;
+        const uint32_t scan_max = getenv("CZ_TRI_SCAN") ? (uint32_t)atoi(getenv("CZ_TRI_SCAN")) : kTriScan;
         hipLaunchKernelGGL(triangles_oriented_kernel, dim3(grid_for((uint64_t)N * kTriLanes)), dim3(256), 0, nullptr, d_off.p, d_tgt.p, N,
-                           d_tri.p, d_deg.p, d_hubs.p, d_nhubs.p);
-        hipLaunchKernelGGL(triangles_hub_kernel, dim3(512, 32), dim3(256), 0, nullptr, d_off.p, d_tgt.p, d_hubs.p, d_nhubs.p, d_tri.p);
+                           d_tri.p, d_deg.p, d_hubs.p, d_nhubs.p, merge_max, scan_max);
+        hipLaunchKernelGGL(triangles_hub_kernel, dim3(hub_wgs), dim3(kTriHubThreads), 0, nullptr, d_off.p, d_tgt.p, d_hubs.p, d_nhubs.p,
+                           d_next.p, d_maps.p, words, d_tri.p);
         CZ_HIP(hipDeviceSynchronize());  // (the hub list dies with this scope)
     }
     hipError_t e = hipGetLastError();

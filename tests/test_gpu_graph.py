@@ -635,6 +635,42 @@ def test_clustering_coefficients_with_hubs(oracle, gpu_lib, hubs_low):
     assert len(nodes) > 100 and np.array_equal(tri[nodes], otri)
 
 
+def test_clustering_coefficients_hub_sets_and_multiplicities(oracle, gpu_lib):
+    """triangles_hub_kernel's two sets: a hub with up to 4096 distinct neighbours above itself answers from an LDS table, a larger
+    one from the 2-bit map in global memory; both hold the multiplicity capped at 3 and measure longer runs in the list.  Two hubs
+    of each kind (low ids: everything they touch is above them), pairs repeated up to 5 times (symmetric multiplicities, as
+    `undirected` builds them), hub-hub edges (the queued, wave-per-neighbour walk needs lists above 512), against the general
+    kernel on every node and the oracle's literal loop on a sample of the ordinary nodes."""
+    import os
+    from cozo_amd import graph as G
+    n = 30000
+    rng = np.random.default_rng(23)
+    parts = []
+    for hub, cnt in ((0, 9000), (1, 5000), (2, 3000), (3, 700)):
+        nb = rng.choice(np.arange(4, n), cnt, replace=False)
+        parts.append(np.stack([np.full(cnt, hub), nb], 1))
+    parts.append(np.array([[0, 1], [0, 2], [1, 2], [0, 3], [2, 3]]))
+    a, b = rng.integers(4, n, 150000), rng.integers(4, n, 150000)
+    parts.append(np.stack([np.minimum(a, b), np.maximum(a, b)], 1)[a != b])
+    pairs = np.unique(np.concatenate(parts), axis=0)
+    rep = rng.choice([1, 1, 1, 2, 3, 5], len(pairs))  # multiplicity of each pair
+    pairs = np.repeat(pairs, rep, axis=0)
+    src = np.concatenate([pairs[:, 0], pairs[:, 1]]).astype(np.uint32)
+    dst = np.concatenate([pairs[:, 1], pairs[:, 0]]).astype(np.uint32)
+    off, tgt = oracle.build_csr(n, src, dst)
+    above0 = np.unique(tgt[off[0]:off[1]])
+    assert above0.size > 4096 and np.unique(tgt[off[2]:off[3]]).size < 4096
+    tri, deg = G.clustering_coefficients(off, tgt, symmetric=True)
+    os.environ["CZ_TRI_GENERAL"] = "1"
+    try:
+        tri2, deg2 = G.clustering_coefficients(off, tgt)
+    finally:
+        del os.environ["CZ_TRI_GENERAL"]
+    assert np.array_equal(deg, deg2) and np.array_equal(tri, tri2) and tri[:4].min() > 0
+    nodes, otri, _ = oracle.clustering_coefficients_sample(n, off, tgt, first=5, step=11, max_seconds=5.0)
+    assert len(nodes) > 500 and np.array_equal(tri[nodes], otri)
+
+
 def test_entry_points_are_reentrant_across_host_threads(oracle, gpu_lib):
     """`FixedRule: Send + Sync`: sibling rules run on rayon workers (query/eval.rs:199-207) and scripts run concurrently,
     so the C ABI is called from several host threads at once.  Four threads x (PageRank, CC, BFS, triangles) on different
