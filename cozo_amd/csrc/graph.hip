@@ -31,6 +31,8 @@
 #include <mutex>
 #include <vector>
 
+#include <rocprim/block/block_radix_sort.hpp>  // (LabelPropagation: a workgroup sorts a chunk of a long list by label)
+
 #include "common.h"
 
 namespace {
@@ -2480,6 +2482,7 @@ namespace {
 
 constexpr uint32_t kLpTable = 512;        // per-wave LDS table; nodes of degree <= kLpSmall never fill it beyond 3/4
 constexpr uint32_t kLpSmall = 384;
+constexpr uint32_t kLpColourLong = 1024;  // the colouring: list entries past this one are walked by the whole grid
 constexpr uint32_t kLpTiny = 32;          // up to here a 16-lane group keeps a node's whole list in registers (two entries a lane)
 
 __device__ __forceinline__ unsigned long long lp_priority(uint32_t v) {
@@ -2537,7 +2540,7 @@ lp_pending_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__
 __global__ void __launch_bounds__(kT)
 lp_colour_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ in_off,
                  const uint32_t *__restrict__ in_src, const uint32_t *__restrict__ list, uint32_t n_list, uint32_t next_colour,
-                 uint32_t *__restrict__ pending, uint32_t *__restrict__ colour, QueueT<uint32_t> next) {
+                 uint32_t *__restrict__ pending, uint32_t *__restrict__ colour, QueueT<uint32_t> next, QueueT<uint32_t> long_nodes) {
     const int lane = threadIdx.x & 63;
     const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes, ngroups = gridDim.x * blockDim.x / kSsspLanes;
@@ -2558,6 +2561,11 @@ lp_colour_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
                 beg[1] = in_off[v];
                 len[1] = in_off[v + 1] - beg[1];
             }
+            // a long list: its first kLpColourLong entries here, the rest by every workgroup of lp_colour_long_kernel (an R-MAT hub
+            // of 215 000 entries kept one 16-lane group busy for 5 ms, and the hubs take their colours one round after the other)
+            if (glane == 0 && max(len[0], len[1]) > kLpColourLong) long_nodes.items[atomicAdd(long_nodes.count, 1u)] = v;
+            len[0] = min(len[0], kLpColourLong);
+            len[1] = min(len[1], kLpColourLong);
         }
         for (int side = 0; side < (in_off ? 2 : 1); side++) {
             const uint32_t *t = side ? in_src : tgt;
@@ -2579,6 +2587,43 @@ lp_colour_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
         }
         if ((r & 7) == 7 || r + 1 == rounds) staged_flush(next, st);
     }
+}
+
+// the lists lp_colour_kernel set aside, from entry kLpColourLong on: every workgroup takes stretches of every one of them
+__global__ void __launch_bounds__(kT)
+lp_colour_long_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ in_off,
+                      const uint32_t *__restrict__ in_src, QueueT<uint32_t> long_nodes, uint32_t next_colour, uint32_t *__restrict__ pending,
+                      uint32_t *__restrict__ colour, QueueT<uint32_t> next) {
+    const int lane = threadIdx.x & 63;
+    __shared__ StagedPileT<uint32_t> st;
+    if (threadIdx.x == 0) st.count = 0;
+    __syncthreads();
+    const uint32_t n_long = *long_nodes.count;
+    uint32_t since_flush = 0;
+    for (uint32_t q = 0; q < n_long; q++) {
+        const uint32_t v = long_nodes.items[q];
+        const unsigned long long kv = lp_priority(v);
+        for (int side = 0; side < (in_off ? 2 : 1); side++) {
+            const uint32_t *t = side ? in_src : tgt;
+            const uint32_t beg = side ? in_off[v] : off[v], len = (side ? in_off[v + 1] : off[v + 1]) - beg;
+            const uint32_t first_wg = (q * 37u + (uint32_t)side * 11u) % gridDim.x;  // (the stretches of different lists start at different workgroups)
+            const uint32_t my = (blockIdx.x + gridDim.x - first_wg) % gridDim.x;
+            for (uint32_t b = kLpColourLong + my * kT; b < len; b += gridDim.x * kT) {  // (uniform over the workgroup)
+                bool ready = false;
+                uint32_t u = 0;
+                if (b + threadIdx.x < len) {
+                    u = t[beg + b + threadIdx.x];
+                    if (u != v && lp_priority(u) < kv && atomicSub(&pending[u], 1u) == 1u) {
+                        ready = true;
+                        colour[u] = next_colour;
+                    }
+                }
+                staged_push(next, st, ready, u, lane);
+                if ((++since_flush & 7u) == 0) staged_flush(next, st);
+            }
+        }
+    }
+    staged_flush(next, st);
 }
 
 __global__ void __launch_bounds__(kT)
@@ -2886,16 +2931,138 @@ lp_update_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ 
     for (uint32_t i = wave; i < count; i += n_waves) lp_update_node(off, tgt, w, order[i], labels, tab, lane, flags, act);
 }
 
-// the class's nodes of larger degree: a table per wave in global memory, sized for the largest degree of the graph
-__global__ void __launch_bounds__(kT)
+// The class's nodes of larger degree: a WORKGROUP per node, a table per workgroup in global memory sized for the largest degree
+// of the graph.  (Until round 6 a wave per node took the list 64 entries at a time and served the labels among them one after the
+// other, every one a chain of table accesses at wave-uniform addresses: ~2 us per label, 0.4 s for ONE 215 000-entry list whose
+// neighbours all carry different labels -- and on an R-MAT graph the large nodes sit alone in their colour classes, one after the
+// other: 13.4 s for 5 iterations over 10M / 200M.)
+// A label's score is still the f32 sum of its entries IN ADJACENCY ORDER: the list is taken kLpHubChunk entries at a time, a
+// chunk is sorted by label (rocPRIM's block radix sort: stable, so equal labels stay in list order), and the thread that holds
+// the first entry of a run of equal labels fetches the label's running score from the table (or enters the label with 0.0), adds
+// the run entry by entry, and writes it back.  Runs are disjoint labels: they go side by side; a chunk costs its longest run.
+// Per chunk (thread 0's clock, R-MAT 10M / 200M): load + label gather 3 us, sort 10 us, table + sums 9..14 us; the final pick
+// 3.5 us per node.  The rule on that graph: 13.4 s -> 1.87 s (this kernel 1.06 s of it, in 13 815 launches: the colour
+// classes of an R-MAT graph are 2 763 and the large nodes come one or two per class).
+constexpr uint32_t kLpHubThreads = 1024, kLpHubItems = 4, kLpHubChunk = kLpHubThreads * kLpHubItems;
+
+__global__ void __launch_bounds__(kLpHubThreads)
 lp_update_hub_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w,
                      const uint32_t *__restrict__ order, uint32_t count, uint32_t *__restrict__ labels, uint32_t *__restrict__ flags,
-                     uint32_t *__restrict__ tkeys, float *__restrict__ tvals, uint32_t *__restrict__ tslots, uint32_t bits, LpActive act) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-    const size_t at = (size_t)wave << bits;
-    LpTab tab{tkeys + at, tvals + at, tslots + at, bits};
-    for (uint32_t i = wave; i < count; i += n_waves) lp_update_node(off, tgt, w, order[i], labels, tab, lane, flags, act);
+                     uint32_t *__restrict__ tkeys, float *__restrict__ tvals, uint32_t *__restrict__ tslots, uint32_t bits,
+                     uint32_t label_bits, LpActive act) {
+    using Sort = rocprim::block_radix_sort<uint32_t, kLpHubThreads, kLpHubItems, float>;
+    __shared__ typename Sort::storage_type sort_storage;
+    __shared__ uint32_t sl[kLpHubChunk + 1];
+    __shared__ float sw[kLpHubChunk];
+    __shared__ uint32_t red[kLpHubThreads / 64];
+    __shared__ uint32_t used_sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const size_t at = (size_t)blockIdx.x << bits;
+    uint32_t *keys = tkeys + at, *slots = tslots + at;
+    float *vals = tvals + at;
+    const uint32_t tmask = (1u << bits) - 1u;
+    auto block_reduce = [&](uint32_t x, bool is_max) {  // every thread gets the maximum / minimum over the workgroup
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const uint32_t y = (uint32_t)__shfl_xor((int)x, o, 64);
+            x = is_max ? max(x, y) : min(x, y);
+        }
+        __syncthreads();  // (red[] may still be read from the last call)
+        if (lane == 0) red[wv] = x;
+        __syncthreads();
+        uint32_t r = red[0];
+        for (uint32_t i = 1; i < kLpHubThreads / 64; i++) r = is_max ? max(r, red[i]) : min(r, red[i]);
+        return r;
+    };
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const uint32_t v = order[i];
+        const uint32_t a = off[v], b = off[v + 1];
+        const bool live = a != b && (!act.sparse || act.dirty[v]);  // (:74-76: no neighbours, the node keeps its label)
+        if (tid == 0) used_sh = 0;
+        __syncthreads();
+        if (!live) continue;
+        if (act.sparse && tid == 0) act.dirty[v] = 0;
+        for (uint32_t base = a; base < b; base += kLpHubChunk) {
+            uint32_t k[kLpHubItems];
+            float x[kLpHubItems];
+#pragma unroll
+            for (uint32_t j = 0; j < kLpHubItems; j++) {  // blocked: thread t holds the entries 4 t .. 4 t + 3 of the chunk
+                const uint32_t e = base + tid * kLpHubItems + j;
+                const bool valid = e < b;
+                const uint32_t t = valid ? tgt[e] : 0;
+                x[j] = valid ? w[e] : 0.f;
+                k[j] = valid ? labels[t] : CZ_NONE;  // (past the list: the largest key, and behind every entry that shares it)
+            }
+            Sort().sort(k, x, sort_storage, 0, label_bits);
+            __syncthreads();
+#pragma unroll
+            for (uint32_t j = 0; j < kLpHubItems; j++) {
+                sl[tid * kLpHubItems + j] = k[j];
+                sw[tid * kLpHubItems + j] = x[j];
+            }
+            __syncthreads();
+            const uint32_t n = min(b - base, kLpHubChunk);
+#pragma unroll
+            for (uint32_t j = 0; j < kLpHubItems; j++) {
+                const uint32_t p = tid * kLpHubItems + j;
+                if (p >= n) continue;
+                const uint32_t L = sl[p];
+                if (p > 0 && sl[p - 1] == L) continue;  // not the first of its run
+                uint32_t h = (L * 0x9E3779B1u) >> (32 - bits);
+                float sum = 0.0f;  // `entry(label).or_default()`
+                for (;;) {
+                    const uint32_t was = atomicCAS(&keys[h], CZ_NONE, L);
+                    if (was == CZ_NONE) {
+                        slots[atomicAdd(&used_sh, 1u)] = h;
+                        break;
+                    }
+                    if (was == L) {
+                        sum = vals[h];
+                        break;
+                    }
+                    h = (h + 1) & tmask;
+                }
+                uint32_t lo = p + 1, hi = n;  // the run's end: the first entry past p with another label (the chunk is sorted)
+                while (lo < hi) {
+                    const uint32_t mid = lo + ((hi - lo) >> 1);
+                    if (sl[mid] == L) lo = mid + 1;
+                    else hi = mid;
+                }
+#pragma unroll 8
+                for (uint32_t q = p; q < lo; q++) sum += sw[q];  // `+= edge.value`, in adjacency order (:72)
+                vals[h] = sum;
+            }
+            __syncthreads();  // (the table and sl / sw are the next chunk's)
+        }
+        // :77-85: the largest score under total_cmp; among the labels whose score == it, the smallest
+        const uint32_t used = used_sh;
+        uint32_t best_key = 0;
+        for (uint32_t q = tid; q < used; q += kLpHubThreads) {
+            const uint32_t bts = __float_as_uint(vals[slots[q]]);
+            best_key = max(best_key, (bts & 0x80000000u) ? ~bts : (bts | 0x80000000u));
+        }
+        best_key = block_reduce(best_key, true);
+        const float max_score = __uint_as_float((best_key & 0x80000000u) ? (best_key & 0x7FFFFFFFu) : ~best_key);
+        uint32_t new_label = CZ_NONE;
+        for (uint32_t q = tid; q < used; q += kLpHubThreads) {
+            const uint32_t slot = slots[q];
+            if (vals[slot] == max_score) new_label = min(new_label, keys[slot]);
+        }
+        new_label = block_reduce(new_label, false);
+        for (uint32_t q = tid; q < used; q += kLpHubThreads) keys[slots[q]] = CZ_NONE;
+        const bool changed = new_label != CZ_NONE && new_label != labels[v];  // (every thread reads the same word)
+        __syncthreads();  // (labels[v] read by everybody before it is written; the table is clean for the next node)
+        if (tid == 0) {
+            if (new_label == CZ_NONE) flags[1] = 1;  // the best score is NaN: `choose` on an empty list, the reference panics
+            else if (changed) {
+                labels[v] = new_label;
+                flags[0] = 1;
+            }
+            if (!act.sparse) act.chg[v] = changed;
+        }
+        if (act.sparse && changed)
+            for (uint32_t e = act.moff[v] + tid; e < act.moff[v + 1]; e += kLpHubThreads) act.dirty[act.mtgt[e]] = 1;
+    }
 }
 
 }  // namespace
@@ -2914,7 +3081,12 @@ extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t 
     if (rc) return rc;
     if (E > 0 && !weights) return cz::set_error(CZ_E_INVALID, "null weights");
     uint32_t max_deg = 0;
-    for (uint32_t v = 0; v < N; v++) max_deg = std::max(max_deg, out_offsets[v + 1] - out_offsets[v]);
+    size_t n_long_nodes = 0;  // (lists the colouring hands to lp_colour_long_kernel)
+    for (uint32_t v = 0; v < N; v++) {
+        const uint32_t deg = out_offsets[v + 1] - out_offsets[v];
+        max_deg = std::max(max_deg, deg);
+        n_long_nodes += deg > kLpColourLong;
+    }
     cz::DevBuf<uint32_t> d_off, d_tgt, d_ioff, d_isrc, d_colour, d_labels, d_order, d_flags, d_cnt, d_scratch;
     cz::DevBuf<float> d_w;
     CZ_HIP(d_off.alloc((size_t)N + 1));
@@ -2988,13 +3160,24 @@ extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t 
                        pending, d_colour.p, QueueT<uint32_t>{list, d_flags.p});
     uint32_t n_list = 0;
     CZ_HIP(hipMemcpy(&n_list, d_flags.p, 4, hipMemcpyDeviceToHost));
+    // the nodes a round sets aside for lp_colour_long_kernel: at most the nodes with a long list on either side
+    uint32_t max_list = max_deg;
+    if (!symmetric) {  // (the in-lists live on the device only; their longest is not known here)
+        max_list = 0xFFFFFFFFu;
+        n_long_nodes = N;
+    }
+    cz::DevBuf<uint32_t> d_long;
+    CZ_HIP(d_long.alloc(std::max<size_t>(n_long_nodes, 1)));
     while (n_list > 0) {
         if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
         coloured += n_list;
         n_col++;
-        CZ_HIP(hipMemsetAsync(d_flags.p, 0, 4, s));
+        CZ_HIP(hipMemsetAsync(d_flags.p, 0, 8, s));
         hipLaunchKernelGGL(lp_colour_kernel, dim3(grid_for((uint64_t)n_list * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, c_ioff, c_isrc,
-                           list, n_list, n_col, pending, d_colour.p, QueueT<uint32_t>{list_next, d_flags.p});
+                           list, n_list, n_col, pending, d_colour.p, QueueT<uint32_t>{list_next, d_flags.p}, QueueT<uint32_t>{d_long.p, d_flags.p + 1});
+        if (max_list > kLpColourLong)  // (reads the count on the device: nothing to do in most rounds)
+            hipLaunchKernelGGL(lp_colour_long_kernel, dim3(256), dim3(kT), 0, s, d_off.p, d_tgt.p, c_ioff, c_isrc,
+                               QueueT<uint32_t>{d_long.p, d_flags.p + 1}, n_col, pending, d_colour.p, QueueT<uint32_t>{list_next, d_flags.p});
         CZ_HIP(hipMemcpy(&n_list, d_flags.p, 4, hipMemcpyDeviceToHost));
         std::swap(list, list_next);
     }
@@ -3053,11 +3236,14 @@ extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t 
     uint32_t hub_bits = 10;
     while ((1ull << hub_bits) * 3 / 4 < max_deg) hub_bits++;
     const bool any_hub = max_deg > kLpSmall;
-    const uint32_t hub_blocks = any_hub ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, (256ull << 20) / ((12ull << hub_bits) * (kT / 64)))) : 0;
+    // (a table per workgroup; a workgroup per CU, fewer when the tables would pass 2 GiB together)
+    const uint32_t hub_blocks = any_hub ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(256, (2048ull << 20) / (12ull << hub_bits))) : 0;
+    uint32_t label_bits = 1;
+    while (label_bits < 32 && (1ull << label_bits) < N) label_bits++;
     cz::DevBuf<uint32_t> d_tkeys, d_tslots;
     cz::DevBuf<float> d_tvals;
     if (any_hub) {
-        const size_t words = ((size_t)hub_blocks * (kT / 64)) << hub_bits;
+        const size_t words = (size_t)hub_blocks << hub_bits;
         CZ_HIP(d_tkeys.alloc(words));
         CZ_HIP(d_tvals.alloc(words));
         CZ_HIP(d_tslots.alloc(words));
@@ -3093,9 +3279,9 @@ extern "C" int cz_label_propagation(const uint32_t *out_offsets, const uint32_t 
                 hipLaunchKernelGGL(lp_update_kernel, dim3(grid_for((uint64_t)ns * 64)), dim3(kT), 0, s, d_off.p, d_tgt.p, d_w.p,
                                    d_order.p + tiny_end[c], ns, d_labels.p, d_flags.p, act);
             if (nh)
-                hipLaunchKernelGGL(lp_update_hub_kernel, dim3(std::min<uint32_t>(hub_blocks, (nh + kT / 64 - 1) / (kT / 64))), dim3(kT), 0, s,
-                                   d_off.p, d_tgt.p, d_w.p, d_order.p + small_end[c], nh, d_labels.p, d_flags.p, d_tkeys.p, d_tvals.p,
-                                   d_tslots.p, hub_bits, act);
+                hipLaunchKernelGGL(lp_update_hub_kernel, dim3(std::min<uint32_t>(hub_blocks, nh)), dim3(kLpHubThreads), 0, s, d_off.p, d_tgt.p,
+                                   d_w.p, d_order.p + small_end[c], nh, d_labels.p, d_flags.p, d_tkeys.p, d_tvals.p, d_tslots.p, hub_bits,
+                                   label_bits, act);
         }
         const bool count_changes = !act.sparse && sparse_frac > 0 && it + 1 < max_iter;
         if (count_changes) hipLaunchKernelGGL(lp_count_changed_kernel, dim3(grid_for(N)), dim3(kT), 0, s, d_chg.p, N, d_flags.p + 2);

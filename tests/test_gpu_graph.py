@@ -912,13 +912,13 @@ def _weighted_csr(n, frm, to, w):
     return off, to[order].astype(np.uint32), w[order].astype(np.float32)
 
 
-@pytest.mark.parametrize("case", ["communities", "weighted_ties", "hubs", "negative_and_loops"])
+@pytest.mark.parametrize("case", ["communities", "weighted_ties", "hubs", "big_hubs", "negative_and_loops"])
 def test_label_propagation_matches_the_fixed_order_execution(oracle, gpu_lib, case):
     """cz_label_propagation == label_propagation.rs:56-109 run with the node order and tie-break the rule fixes (the oracle's
     literal loop, itself checked word for word against a Python restatement in tests/test_fixed_rule.py): labels, the number of
     iterations and the colouring, bit for bit."""
     from cozo_amd import graph as G
-    rng = np.random.default_rng({"communities": 1, "weighted_ties": 2, "hubs": 3, "negative_and_loops": 4}[case])
+    rng = np.random.default_rng({"communities": 1, "weighted_ties": 2, "hubs": 3, "negative_and_loops": 4, "big_hubs": 5}[case])
     if case == "communities":  # 40 planted groups of 250, sparse cross edges, unit weights, symmetric
         n = 10_000
         a = rng.integers(0, n, 60_000)
@@ -936,6 +936,14 @@ def test_label_propagation_matches_the_fixed_order_execution(oracle, gpu_lib, ca
         hubs = rng.integers(0, 8, 30_000)
         frm = np.concatenate([hubs, rng.integers(0, n, 60_000)])
         to = np.concatenate([rng.integers(0, n, 30_000), rng.integers(0, n, 60_000)])
+        w = rng.random(frm.size).astype(np.float32) + np.float32(0.1)
+    elif case == "big_hubs":  # lists of ~20 000 entries: several sorted chunks per node, a label's score carried from chunk to chunk
+        n = 40_000              # through the table; the hubs point at each other and at 50 planted groups, so that long runs of one
+        hubs = rng.integers(0, 3, 60_000)  # label (the sequential sum inside a chunk) appear from the second iteration on
+        a = rng.integers(0, n, 120_000)
+        b = (a // 800) * 800 + rng.integers(0, 800, a.size)
+        frm = np.concatenate([hubs, rng.integers(0, n, 60_000), a, b, [0, 1, 2, 1, 2, 0]])
+        to = np.concatenate([rng.integers(0, n, 60_000), hubs, b, a, [1, 2, 0, 0, 1, 2]])
         w = rng.random(frm.size).astype(np.float32) + np.float32(0.1)
     else:  # negative weights are legal for this rule (allow_negative_weights = true), self loops, isolated targets
         n = 3_000
