@@ -31,6 +31,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -65,6 +66,25 @@ struct Item {    // phase A work item
     uint32_t cls, pad0, pad1, pad2;  // 0 = X, 1 = Y
 };
 
+// the large per-edge arrays: storage that is NOT zero-filled when it is sized (a std::vector would touch every page once more,
+// on one thread: 0.4 s of the 10M / 100M build); pass 2 writes every element, padding included
+template <typename T>
+struct PodVec {
+    using value_type = T;
+    std::unique_ptr<T[]> buf;
+    size_t n = 0;
+    void resize_uninit(size_t k) {
+        buf.reset(new T[k ? k : 1]);
+        n = k;
+    }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T *data() { return buf.get(); }
+    const T *data() const { return buf.get(); }
+    T &operator[](size_t i) { return buf[i]; }
+    const T &operator[](size_t i) const { return buf[i]; }
+};
+
 struct Plan {
     Params prm;
     uint32_t N = 0, L = 0;
@@ -81,12 +101,12 @@ struct Plan {
     std::vector<uint32_t> long_first;  // [L + 1]
     std::vector<uint32_t> long_off;    // [n_long + 1] into long_src
     std::vector<uint32_t> long_src;    // level-major source | kOldBit, in the row's own order
-    std::vector<uint16_t> asrc[2];     // [nX + 4], [nY + 4]: LDS word of every stream position's source = id inside the slice + (node0 & 3); padding: 0
+    PodVec<uint16_t> asrc[2];          // [nX + 4], [nY + 4]: LDS word of every stream position's source = id inside the slice + (node0 & 3); padding: 0
     uint64_t n_pos[2] = {0, 0};        // stream lengths incl. padding
-    std::vector<uint32_t> gpos;        // stream groups of the blocks: position of the group's first value (a multiple of 4) | kYBit
-    std::vector<uint16_t> gperm;       //   ... and where its four values go inside the tile (padding: `tile`, the spare words)
-    std::vector<uint16_t> upos;        // urgent elements: tile position
-    std::vector<uint32_t> usrc;        //   ... and the level-major source
+    PodVec<uint32_t> gpos;             // stream groups of the blocks: position of the group's first value (a multiple of 4) | kYBit
+    PodVec<uint16_t> gperm;            //   ... and where its four values go inside the tile (padding: `tile`, the spare words)
+    PodVec<uint16_t> upos;             // urgent elements: tile position
+    PodVec<uint32_t> usrc;             //   ... and the level-major source
     uint64_t n_edges[3] = {0, 0, 0};   // X, Y, U edges of block rows
     uint64_t n_long_edges = 0;
     std::string error;
@@ -163,6 +183,16 @@ inline bool build_plan(const OffT *in_off, const uint32_t *in_src, const uint32_
     std::vector<uint32_t> slice_first(L + 1, 0);
     for (uint32_t l = 0; l < L; l++) slice_first[l + 1] = slice_first[l] + (p.first[l + 1] - p.first[l] + prm.slice - 1) / prm.slice;
     const uint32_t S = slice_first[L];
+    // what pass 1 needs of an edge's SOURCE, in one 16-byte record (one cache miss per edge instead of two, and no division per edge)
+    struct SrcInfo {
+        uint32_t inv, level, bucket0;  // level-major id; level; 2 * slice
+        uint16_t loc, pad;             // id inside the slice + the slice's misalignment (phase A stages aligned 16-byte vectors, LDS word 0 = node (node0 & ~3))
+    };
+    std::unique_ptr<SrcInfo[]> info(new SrcInfo[N]);
+    for (uint32_t u = 0; u < N; u++) {
+        const uint32_t l = level[u], i = inv[u], rel = i - p.first[l], sl = rel / prm.slice;
+        info[u] = SrcInfo{i, l, 2u * (slice_first[l] + sl), (uint16_t)(rel - sl * prm.slice + ((p.first[l] + sl * prm.slice) & 3u)), 0};
+    }
     // ---- row blocks and long rows, level by level
     p.blk_first.assign(L + 1, 0);
     p.long_first.assign(L + 1, 0);
@@ -199,8 +229,8 @@ inline bool build_plan(const OffT *in_off, const uint32_t *in_src, const uint32_
     // `threads` host threads over CONTIGUOUS ranges of blocks (cells of one bucket are laid out in block order, so a thread's
     // cursors start where the threads before it end): the arrays are the same for every thread count.
     // code: urgent = kOldBit | level-major source; stream = bucket (2 * slice + class), local id in `loc`
-    std::vector<uint32_t> code(p.E);
-    std::vector<uint16_t> loc(p.E);
+    std::unique_ptr<uint32_t[]> code(new uint32_t[p.E ? p.E : 1]);  // (not zero-filled: every block-row edge is written by pass 1, nothing else is read)
+    std::unique_ptr<uint16_t[]> loc(new uint16_t[p.E ? p.E : 1]);
     const size_t nblk = p.blocks.size();
     uint32_t T = prm.threads ? prm.threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     if (p.E < (1u << 20) || nblk < 2 * (size_t)T) T = 1;
@@ -219,28 +249,44 @@ inline bool build_plan(const OffT *in_off, const uint32_t *in_src, const uint32_
     auto pass1 = [&](uint32_t tix) {
         std::vector<uint32_t> lcnt((size_t)2 * S, 0), touched;
         std::vector<uint64_t> &cnt = cntT[tix];
+        // The rows come in level-major order, i.e. at random places of the input: row -> offsets -> sources -> source records is a
+        // chain of cache misses per row.  It is walked three stages ahead (offsets of row r + 12, sources of row r + 6, records of
+        // row r + 3) so that the loop itself finds its lines in the cache.
+        auto ahead = [&](uint32_t r) {
+            if (r + 12 < N) __builtin_prefetch(&in_off[p.order[r + 12]]);
+            if (r + 6 < N) {
+                const uint64_t e0 = in_off[p.order[r + 6]];
+                __builtin_prefetch(&in_src[e0]);
+                __builtin_prefetch(&in_src[e0] + 16);
+            }
+            if (r + 3 < N) {
+                const uint32_t u = p.order[r + 3];
+                const uint64_t e1 = std::min<uint64_t>(in_off[u + 1], (uint64_t)in_off[u] + 32);
+                for (uint64_t e = in_off[u]; e < e1; e++) __builtin_prefetch(&info[in_src[e]]);
+            }
+        };
+        uint64_t ne[2] = {0, 0};
         for (size_t bi = tb[tix]; bi < tb[tix + 1]; bi++) {
             Block &b = p.blocks[bi];
             uint32_t nu = 0;
             touched.clear();
             for (uint32_t r = b.row0; r < b.row1; r++) {
+                ahead(r);
                 const uint32_t u = p.order[r], lu = level[u];
                 uint32_t t = p.off2[r];  // position in the level-major CSR
                 for (uint64_t e = in_off[u]; e < (uint64_t)in_off[u + 1]; e++, t++) {
-                    const uint32_t v = in_src[e], lv = level[v], vi = inv[v];
+                    const uint32_t v = in_src[e];
+                    const SrcInfo &si = info[v];
                     const bool old = v >= u || prm.jacobi;
-                    if (!old && lu - lv <= prm.urgent_gap) {
-                        code[t] = kOldBit | vi;
+                    if (!old && lu - si.level <= prm.urgent_gap) {
+                        code[t] = kOldBit | si.inv;
                         nu++;
                     } else {
-                        const uint32_t rel = vi - p.first[lv];
-                        const uint32_t sl = slice_first[lv] + rel / prm.slice;
-                        const uint32_t bucket = 2u * sl + (old ? 1u : 0u);
+                        const uint32_t bucket = si.bucket0 + (old ? 1u : 0u);
                         code[t] = bucket;
-                        // the local id carries the slice's misalignment: phase A stages aligned 16-byte vectors, LDS word 0 = node (node0 & ~3)
-                        loc[t] = (uint16_t)(rel % prm.slice + ((p.first[lv] + (rel / prm.slice) * prm.slice) & 3u));
+                        loc[t] = si.loc;
                         if (lcnt[bucket]++ == 0) touched.push_back(bucket);
-                        neT[(size_t)tix * 3 + (old ? 1 : 0)]++;
+                        ne[old ? 1 : 0]++;
                     }
                 }
             }
@@ -255,6 +301,8 @@ inline bool build_plan(const OffT *in_off, const uint32_t *in_src, const uint32_
             b.u1 = nu;
             neT[(size_t)tix * 3 + 2] += nu;
         }
+        neT[(size_t)tix * 3] += ne[0];
+        neT[(size_t)tix * 3 + 1] += ne[1];
     };
     auto run_threads = [&](auto &&fn) {
         if (T == 1) {
@@ -286,10 +334,10 @@ inline bool build_plan(const OffT *in_off, const uint32_t *in_src, const uint32_
             p.error = "stream too long";
             return false;
         }
-        p.gpos.assign(g, 0);
-        p.gperm.assign(g * 4, (uint16_t)prm.tile);  // padding lands in the tile's spare words
-        p.upos.resize(u);
-        p.usrc.resize(u);
+        p.gpos.resize_uninit(g);
+        p.gperm.resize_uninit(g * 4);  // (pass 2 sends the padding to the tile's spare words)
+        p.upos.resize_uninit(u);
+        p.usrc.resize_uninit(u);
     }
     // ---- stream positions (every cell, hence every (slice, class) segment, starts on a multiple of four); phase-A items
     std::vector<uint64_t> start((size_t)2 * S, 0);
@@ -317,7 +365,8 @@ inline bool build_plan(const OffT *in_off, const uint32_t *in_src, const uint32_
                 return false;
             }
             p.n_pos[c] = pos[c];
-            p.asrc[c].assign(pos[c] + 4, 0);  // padding positions read LDS word 0
+            p.asrc[c].resize_uninit(pos[c] + 4);  // padding positions read LDS word 0 (pass 2 writes those inside the cells)
+            for (int k = 0; k < 4; k++) p.asrc[c][pos[c] + k] = 0;
         }
     }
     // ---- pass 2: block by block, its cells in (slice, class) order -- each a run of consecutive stream positions, a group = four
@@ -349,6 +398,10 @@ inline bool build_plan(const OffT *in_off, const uint32_t *in_src, const uint32_
             for (uint32_t c : touched) {  // lcnt becomes (the cell's first slot in gperm) + 1 (0 stays "untouched")
                 const uint32_t k4 = (lcnt[c] + 3u) & ~3u;
                 for (uint32_t j = 0; j < k4 / 4; j++) p.gpos[g + j] = (uint32_t)(cur[c] + 4u * j) | ((c & 1u) ? kYBit : 0u);
+                for (uint32_t j = lcnt[c]; j < k4; j++) {  // the cell's padding: tile word `tile` (spare), LDS word 0
+                    p.gperm[4 * (size_t)g + j] = (uint16_t)prm.tile;
+                    p.asrc[c & 1u][cur[c] + j] = 0;
+                }
                 lcnt[c] = 4u * g + 1;
                 g += k4 / 4;
                 cell4.push_back(k4);
