@@ -1518,7 +1518,7 @@ __device__ __forceinline__ void tri_credit(const uint32_t *__restrict__ tgt, uin
 __global__ void __launch_bounds__(256)
 triangles_oriented_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t N,
                           unsigned long long *__restrict__ n_tri /* zeroed */, uint32_t *__restrict__ degree,
-                          uint32_t *__restrict__ hubs /* [N] */, uint32_t *__restrict__ n_hubs /* zeroed */, uint32_t merge_max,
+                          uint32_t *__restrict__ hubs /* [N] */, uint32_t *__restrict__ n_hubs /* [2]: count, longest; zeroed */, uint32_t merge_max,
                           uint32_t scan_max) {
     const uint32_t glane = threadIdx.x & (kTriLanes - 1);
     const uint32_t group = (blockIdx.x * 256 + threadIdx.x) / kTriLanes, n_groups = (gridDim.x * 256) / kTriLanes;
@@ -1579,7 +1579,10 @@ triangles_oriented_kernel(const uint32_t *__restrict__ off, const uint32_t *__re
         }
         // more than merge_max neighbours above itself: left to triangles_hub_kernel.  Until round 6 one 16-lane group walked all
         // m (m - 1) / 2 pairs of its list here -- 10^9 pairs for ONE node of a 1M-node R-MAT graph, 114 s for the rule.
-        if (glane == 0) hubs[atomicAdd(n_hubs, 1u)] = v;
+        if (glane == 0) {
+            hubs[atomicAdd(n_hubs, 1u)] = v;
+            atomicMax(n_hubs + 1, m);  // (the longest such list: whether any needs the map in global memory)
+        }
     }
 }
 
@@ -1829,23 +1832,29 @@ extern "C" int cz_clustering_coefficients(const uint32_t *offsets, const uint32_
     } else {
         cz::DevBuf<uint32_t> d_hubs, d_nhubs;
         CZ_HIP(d_hubs.alloc(N));
-        CZ_HIP(d_nhubs.alloc(1));
-        CZ_HIP(hipMemsetAsync(d_nhubs.p, 0, 4, nullptr));
+        CZ_HIP(d_nhubs.alloc(2));
+        CZ_HIP(hipMemsetAsync(d_nhubs.p, 0, 8, nullptr));
         CZ_HIP(hipMemsetAsync(d_tri.p, 0, (size_t)N * 8, nullptr));
-        // one 2-bit map of N entries per hub workgroup: two workgroups per CU, fewer when N is so large that they would pass 2 GiB together
-        const uint32_t words = (N + 15u) / 16u;
-        const uint32_t hub_wgs = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(512, ((uint64_t)1 << 29) / words));
-        cz::DevBuf<uint32_t> d_maps, d_next;
-        CZ_HIP(d_maps.alloc((size_t)hub_wgs * words));
-        CZ_HIP(d_next.alloc(1));
-        CZ_HIP(hipMemsetAsync(d_maps.p, 0, (size_t)hub_wgs * words * 4, nullptr));
-        CZ_HIP(hipMemsetAsync(d_next.p, 0, 4, nullptr));
         const uint32_t merge_max = getenv("CZ_TRI_MERGE") ? (uint32_t)atoi(getenv("CZ_TRI_MERGE")) : kTriMerge;
         const uint32_t scan_max = getenv("CZ_TRI_SCAN") ? (uint32_t)atoi(getenv("CZ_TRI_SCAN")) : kTriScan;
         hipLaunchKernelGGL(triangles_oriented_kernel, dim3(grid_for((uint64_t)N * kTriLanes)), dim3(256), 0, nullptr, d_off.p, d_tgt.p, N,
                            d_tri.p, d_deg.p, d_hubs.p, d_nhubs.p, merge_max, scan_max);
-        hipLaunchKernelGGL(triangles_hub_kernel, dim3(hub_wgs), dim3(kTriHubThreads), 0, nullptr, d_off.p, d_tgt.p, d_hubs.p, d_nhubs.p,
-                           d_next.p, d_maps.p, words, d_tri.p);
+        uint32_t nh[2] = {0, 0};  // how many nodes were left to the hub kernel, and the longest of their lists
+        CZ_HIP(hipMemcpy(nh, d_nhubs.p, 8, hipMemcpyDeviceToHost));
+        if (nh[0]) {
+            // one 2-bit map of N entries per hub workgroup, if any list is too long for the LDS table: two workgroups per CU, fewer when
+            // N is so large that the maps would pass 2 GiB together
+            const uint32_t words = nh[1] > kTriHubLds ? (N + 15u) / 16u : 0u;
+            const uint32_t hub_wgs = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(512, nh[0]), ((uint64_t)1 << 29) / std::max(words, 1u)));
+            cz::DevBuf<uint32_t> d_maps, d_next;
+            CZ_HIP(d_maps.alloc(std::max<size_t>((size_t)hub_wgs * words, 1)));
+            CZ_HIP(d_next.alloc(1));
+            CZ_HIP(hipMemsetAsync(d_maps.p, 0, std::max<size_t>((size_t)hub_wgs * words, 1) * 4, nullptr));
+            CZ_HIP(hipMemsetAsync(d_next.p, 0, 4, nullptr));
+            hipLaunchKernelGGL(triangles_hub_kernel, dim3(hub_wgs), dim3(kTriHubThreads), 0, nullptr, d_off.p, d_tgt.p, d_hubs.p, d_nhubs.p,
+                               d_next.p, d_maps.p, words, d_tri.p);
+            CZ_HIP(hipDeviceSynchronize());  // (the maps die with this scope)
+        }
         CZ_HIP(hipDeviceSynchronize());  // (the hub list dies with this scope)
     }
     hipError_t e = hipGetLastError();
