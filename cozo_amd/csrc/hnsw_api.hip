@@ -1062,6 +1062,16 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
                 CZ_LAUNCH_KNN_(hnsw_knn_wide_kernel, 64, 3, 8);
             }
         }
+        // a list of thousands of entries: the pending buffer in front of it (hnsw_kernels.h search_level_pending; CZ_HNSW_PEND = 0 | 1
+        // overrides; 4.1 KiB of static LDS on top of the list).  From ef = 4 096 on: there the list's LDS decides the occupancy; below,
+        // the kernel's 162 registers cost more than the shifts it saves (1M clustered, 1 024 queries: ef 2 048 27.6 vs 19.7 ms,
+        // 4 096 45.7 vs 48.8, 8 192 146.7 vs 172.6)
+        else if ((getenv("CZ_HNSW_PEND") ? atoi(getenv("CZ_HNSW_PEND")) != 0 : ef >= 4096) && ef > (uint32_t)czh::kThreads && knn_u == 2 &&
+                 smem + 4200 <= 160 * 1024) {
+            // (a batch that fills the chip only: with 8 rows in flight per lane group the kernel runs out of registers -- 256 queries at
+            // ef 4 096: 40.7 vs 26.5 ms)
+            CZ_LAUNCH_KNN_(hnsw_knn_pend_kernel, 64, 3, 2);
+        }
         else if (knn_u == 1) CZ_LAUNCH_KNN(64, 3, 1);
         else if (knn_u == 4) CZ_LAUNCH_KNN_(hnsw_knn_wide_kernel, 64, 3, 4);
         else if (knn_u == 8) CZ_LAUNCH_KNN_(hnsw_knn_wide_kernel, 64, 3, 8);

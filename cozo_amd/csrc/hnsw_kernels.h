@@ -161,6 +161,12 @@ struct Searcher {
     VisitedDev vis;
     uint32_t *tcur;  // ids evaluated in this step (s.todo)
     uint32_t *spec = nullptr;  // search_level_spec's scratch: [0, 128) two prefetched link rows, [128..129] whose they are
+    // search_level_pending's buffer in front of W (kPend entries: keys, ids | kExpanded, the lower bounds of a flush) and its
+    // control words {entries, first possibly un-expanded}
+    uint64_t *pkey = nullptr;
+    uint32_t *pid = nullptr, *plb = nullptr;
+    int *pctl = nullptr;
+    static constexpr int kPend = kThreads;
     int tid, lane, wave, glane, group;
     int chunks;
     float4 q[ITERS > 0 ? ITERS : 1];
@@ -1040,6 +1046,293 @@ struct Searcher {
         }
     }
 
+    // ---- large ef: a sorted PENDING buffer in front of W ------------------------------------------------------------------------
+    // With W at 8 192 entries nearly every step's handful of new entries lands somewhere in the middle and merge_wide moves most of
+    // the list up by a few places: 25 % of a step for the shift, 9 % for the ranks (profiles/r04_large_ef_phases.txt).  Here the
+    // new entries of a step go into a buffer P of at most kPend entries, itself sorted; W is touched only when P is full (one
+    // shift per ~20-40 steps) and when the level ends.  What the reference calls found_nn / candidates is then the best ef of
+    // W u P: with t = how many of P's entries are among them, these are W[0, ef - t) and P[0, t); their largest key is the
+    // `furthest` the eligibility test compares with (hnsw.rs:575), the nearest un-expanded entry among them is the next candidate,
+    // and the loop ends when there is none (an entry outside the best ef is farther than `furthest`: hnsw.rs:562-564 breaks on it).
+    // Entries outside stay where they are until the next flush drops them; nothing reads them.  P is used only once W is full
+    // (while it fills, the step's entries go to W directly: merge()), so W u P never has fewer than ef entries.
+    // Same ids / distances / n_dist as search_level (tests/test_gpu_hnsw.py compares the two forms at ef 2 049 .. 8 192).
+
+    // t: the largest t in [0, p] with (t == 0 or P[t - 1] < W[ef - t]); every thread computes it (uniform)
+    __device__ __forceinline__ int pending_inside(int p, int ef) const {
+        int lo = 0, hi = p;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (key_lt(pkey[mid - 1], pid[mid - 1] & kIdMask, s.wkey[ef - mid], s.wid[ef - mid] & kIdMask)) lo = mid;
+            else hi = mid - 1;
+        }
+        return lo;
+    }
+
+    // the same from a guess (t moves by a few entries from step to step: two or three probes instead of eight bisection rounds)
+    __device__ __forceinline__ int pending_inside_near(int p, int ef, int guess) const {
+        int t = min(max(guess, 0), p);
+        auto f = [&](int x) {  // x >= 1
+            return key_lt(pkey[x - 1], pid[x - 1] & kIdMask, s.wkey[ef - x], s.wid[ef - x] & kIdMask);
+        };
+        while (t < p && f(t + 1)) t++;
+        while (t > 0 && !f(t)) t--;
+        return t;
+    }
+
+    // P[0, t) into W (full: cnt == ef), the rest of P dropped.  Caller guarantees a barrier before; ends with a barrier.
+    // P is sorted, so entry i's final position is its lower bound in W + i and the lower bounds ascend: merge_wide's shift
+    // (steps (c), (d)) with the ranks for free.
+    __device__ __forceinline__ void flush_pending(int ef) {  // (inlined at both call sites: a call would put the whole Searcher -- the query registers -- in memory)
+        const int p = pctl[0];
+        const int t = p > 0 ? pending_inside(p, ef) : 0;
+        const int cnt = ef;
+        uint64_t mykey = 0;
+        uint32_t myid = CZ_NONE;
+        int npos = -1;
+        if (tid < t) {
+            mykey = pkey[tid];
+            myid = pid[tid];
+            int lo = 0, hi = cnt;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (key_lt(s.wkey[mid], s.wid[mid] & kIdMask, mykey, myid & kIdMask)) lo = mid + 1;
+                else hi = mid;
+            }
+            plb[tid] = (uint32_t)lo;
+            npos = lo + tid;
+        }
+        __syncthreads();
+        if (t > 0) {  // uniform
+            const int first = (int)plb[0], last = (int)plb[t - 1];
+            constexpr int kShiftR = 4, kBlock = kShiftR * kThreads;
+            int base = ((cnt - 1) / kBlock) * kBlock;
+            bool more = base >= 0 && base + kBlock > first;
+            uint64_t wk[kShiftR];
+            uint32_t wi[kShiftR];
+            int sft[kShiftR];
+            auto fetch = [&]() {
+#pragma unroll
+                for (int r = 0; r < kShiftR; r++) {
+                    const int j = base + r * kThreads + tid;
+                    sft[r] = 0;
+                    if (j < cnt && j >= first) {
+                        wk[r] = s.wkey[j];
+                        wi[r] = s.wid[j];
+                        if (j >= last) sft[r] = t;
+                        else {  // how many lower bounds are <= j
+                            int lo = 0, hi = t;
+                            while (lo < hi) {
+                                const int mid = (lo + hi) >> 1;
+                                if ((int)plb[mid] <= j) lo = mid + 1;
+                                else hi = mid;
+                            }
+                            sft[r] = lo;
+                        }
+                    }
+                }
+            };
+            if (more) fetch();
+            while (more) {  // one barrier per block, from the top: merge_wide (c)
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < kShiftR; r++) {
+                    const int j = base + r * kThreads + tid;
+                    if (sft[r] > 0 && j + sft[r] < ef) {
+                        s.wkey[j + sft[r]] = wk[r];
+                        s.wid[j + sft[r]] = wi[r];
+                    }
+                }
+                base -= kBlock;
+                more = base >= 0 && base + kBlock > first;
+                if (more) fetch();
+            }
+            if (npos >= 0 && npos < ef) {
+                s.wkey[npos] = mykey;
+                s.wid[npos] = myid;  // (carries kExpanded if the entry was expanded while it waited)
+                if (!(myid & kExpanded)) atomicMin(&s.ctl[C_LO], npos);
+            }
+        }
+        if (tid == 0) {
+            pctl[0] = 0;
+            pctl[1] = 0;
+        }
+        __syncthreads();
+    }
+
+    // the step's nkey / nid[0, n) into P (W is full).  Caller guarantees a barrier before; ends with a barrier.
+    // t: how many of P's entries are inside (the step's value); returns the guess for the next step's
+    __device__ __forceinline__ int pending_merge(int n, int ef, int t) {
+        int p = pctl[0];
+        // `furthest` of the best ef of W u P (hnsw.rs:575 `neighbour_dist < furthest`, raw compare; a NaN furthest admits nothing)
+        uint64_t fkey = ef - t > 0 ? s.wkey[ef - t - 1] : 0;
+        if (t > 0 && pkey[t - 1] > fkey) fkey = pkey[t - 1];
+        uint64_t mykey = 0;
+        uint32_t myid = CZ_NONE;
+        bool elig = false;
+        if (tid < n) {
+            mykey = s.nkey[tid];
+            myid = s.nid[tid];
+            elig = mykey < fkey && fkey != ~0ull;
+        }
+        const unsigned long long em = __ballot(elig);
+        if (lane == 0) s.ctl[C_WAVE0 + wave] = __popcll(em);
+        __syncthreads();  // also orders the nkey / nid reads above before the in-place rewrite below
+        int before = 0, nelig = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) {
+            const int c = s.ctl[C_WAVE0 + w];
+            if (w < wave) before += c;
+            nelig += c;
+        }
+        if (nelig == 0) return t;
+        if (elig) {
+            const int e = before + __popcll(em & ((1ull << lane) - 1ull));
+            s.nkey[e] = mykey;
+            s.nid[e] = myid;
+        }
+        __syncthreads();
+        CZ_PH_MARK(8);
+        if (p + nelig > kPend) {  // uniform: no room -- P goes into W first (the best ef of W u P do not change by that)
+            flush_pending(ef);
+            p = 0;
+            t = 0;
+            CZ_PH_MARK(10);
+        }
+        // entry e of the batch: rank inside the batch + lower bound in P; entry j of P moves up by the batch entries before it
+        int npos = -1;
+        if (tid < nelig) {
+            mykey = s.nkey[tid];
+            myid = s.nid[tid];
+            int r1 = 0;
+            for (int x = 0; x < nelig; x++)
+                if (key_lt(s.nkey[x], s.nid[x], mykey, myid)) r1++;
+            int lo = 0, hi = p;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (key_lt(pkey[mid], pid[mid] & kIdMask, mykey, myid)) lo = mid + 1;
+                else hi = mid;
+            }
+            npos = lo + r1;
+        }
+        uint64_t pk = 0;
+        uint32_t pi = 0;
+        int up = 0;
+        if (tid < p) {
+            pk = pkey[tid];
+            pi = pid[tid];
+            for (int x = 0; x < nelig; x++)
+                if (key_lt(s.nkey[x], s.nid[x], pk, pi & kIdMask)) up++;
+        }
+        if (tid == 0) pctl[1] = p + nelig;  // the first un-expanded entry of the new P: found below (everybody has read the old value)
+        __syncthreads();
+        if (tid < p && up > 0) {
+            pkey[tid + up] = pk;
+            pid[tid + up] = pi;
+        }
+        if (npos >= 0) {
+            pkey[npos] = mykey;
+            pid[npos] = myid;  // un-expanded
+            atomicMin(&pctl[1], npos);
+        }
+        {   // P's old entries keep their order: a wave's first un-expanded lane holds its smallest new index
+            const unsigned long long um = __ballot(tid < p && !(pi & kExpanded));
+            if (um && lane == __ffsll((long long)um) - 1) atomicMin(&pctl[1], tid + up);
+        }
+        if (tid == 0) pctl[0] = p + nelig;
+        __syncthreads();
+        CZ_PH_MARK(9);
+        return t + nelig;
+    }
+
+    // search_level with the pending buffer (see above); any level, any ef: a list of at most 2 kPend entries takes merge() as before
+    __device__ __forceinline__ void search_level_pending(int level, int ef, bool log) {
+        int cnt = s.ctl[C_CNT];
+        for (int i = tid; i < cnt; i += kThreads) s.wid[i] &= kIdMask;
+        if (wave == 0) {
+            for (int b = 0; b < cnt; b += 64) {
+                const int j = b + lane;
+                uint32_t where;
+                const bool fresh = visit(j < cnt ? (s.wid[j] & kIdMask) : CZ_NONE, j < cnt, where);
+                if (fresh) log_visit(where, log);
+            }
+        }
+        if (tid == 0) {
+            s.ctl[C_LO] = 0;
+            pctl[0] = 0;
+            pctl[1] = 0;
+        }
+        __syncthreads();
+        CZ_PH_START();
+        const int width = level == 0 ? ix.w0 : ix.wu;
+        const bool use_p = ef > 2 * kPend;  // (P never holds more entries than W: pending_inside indexes W[ef - t])
+        int t_guess = 0;
+        for (;;) {
+            cnt = s.ctl[C_CNT];
+            const int p = pctl[0];
+            const int t = p > 0 ? pending_inside_near(p, ef, t_guess) : 0;  // (p > 0 only when cnt == ef)
+            t_guess = t;
+            const int wlim = cnt - t;
+            // nearest un-expanded entry of W[0, wlim) and of P[0, t) (uniform across the workgroup)
+            int iw = -1, ip = -1;
+            for (int b = s.ctl[C_LO]; b < wlim; b += 64) {
+                const int j = b + lane;
+                const bool un = j < wlim && !(s.wid[j] & kExpanded);
+                const unsigned long long m = __ballot(un);
+                if (m) {
+                    iw = b + __ffsll((long long)m) - 1;
+                    break;
+                }
+            }
+            for (int b = pctl[1]; b < t; b += 64) {
+                const int j = b + lane;
+                const bool un = j < t && !(pid[j] & kExpanded);
+                const unsigned long long m = __ballot(un);
+                if (m) {
+                    ip = b + __ffsll((long long)m) - 1;
+                    break;
+                }
+            }
+            if (iw < 0 && ip < 0) break;
+            const bool from_p = ip >= 0 && (iw < 0 || key_lt(pkey[ip], pid[ip] & kIdMask, s.wkey[iw], s.wid[iw] & kIdMask));
+            const uint32_t cand = (from_p ? pid[ip] : s.wid[iw]) & kIdMask;
+            CZ_PH_COUNT(5, 1);
+            __syncthreads();  // everyone has read the lists' heads before they change
+            if (tid == 0) {
+                if (from_p) {
+                    pid[ip] = cand | kExpanded;
+                    pctl[1] = ip + 1;
+                    if (iw >= 0) s.ctl[C_LO] = iw;
+                } else {
+                    s.wid[iw] = cand | kExpanded;
+                    s.ctl[C_LO] = iw + 1;
+                    if (ip >= 0) pctl[1] = ip;
+                }
+            }
+            CZ_PH_MARK(0);
+            if (wave == 0) {  // neighbour row + visited filter, hnsw.rs:566-571
+                const int total = expand_row(cand, level, width, tcur, log);
+                if (lane == 0) {
+                    s.ctl[C_TODO] = total;
+                    count_dist(total);
+                }
+            }
+            __syncthreads();
+            CZ_PH_MARK(1);
+            const int n = s.ctl[C_TODO];
+            if (n == 0) continue;
+            CZ_PH_COUNT(6, n);
+            eval_todo(n);
+            __syncthreads();
+            CZ_PH_MARK(3);
+            if (cnt < ef || !use_p) merge(n, ef);  // W still fills (P is empty) / a short list (the upper levels' ef = 1)
+            else t_guess = pending_merge(n, ef, t);
+            CZ_PH_MARK(4);
+        }
+        __syncthreads();
+        flush_pending(ef);
+    }
+
     // The same traversal for a batch that leaves the chip empty (HnswSearchRA::iter hands over whatever the parent relation holds --
     // often ONE vector, query/ra.rs:1085-1121).  A step is then a chain of dependent round trips -- link row -> visited atomics ->
     // vector rows -- on a CU that has nothing else to do, and two of the three are taken off the chain without changing anything
@@ -1257,7 +1550,7 @@ __device__ __forceinline__ bool pred_pass(const PredSet &ps, uint32_t node) {
 // at B = 2 048 / 4 096 against 0.76 at 1 024).  U (rows in flight per lane group and round) is chosen from B by the
 // launcher: a batch that leaves most of the chip empty is bound by the latency of a step, and a step by the rounds its
 // rows take -- wider rounds (U = 4 / 8: 16 / 32 rows per round, the registers are free at that occupancy) shorten it.
-template <int LPV, int ITERS, int U, bool F64 = false, bool SPEC = false>
+template <int LPV, int ITERS, int U, bool F64 = false, bool SPEC = false, bool PEND = false>
 __device__ __forceinline__ void
 hnsw_knn_body(const IndexDev &ix, const float *__restrict__ queries, uint32_t B, uint32_t k, uint32_t ef, uint32_t efcap,
               uint32_t wpad, int has_radius, double radius, uint32_t *__restrict__ vtab, uint32_t hbits,
@@ -1283,6 +1576,15 @@ hnsw_knn_body(const IndexDev &ix, const float *__restrict__ queries, uint32_t B,
         __shared__ uint32_t spec_words[132];  // two prefetched link rows (64 ids each) and their tags
         S.spec = spec_words;
     }
+    if constexpr (PEND) {  // the pending buffer in front of W (search_level_pending): 4 KiB of static LDS
+        __shared__ uint64_t pend_key[kThreads];
+        __shared__ uint32_t pend_id[kThreads], pend_lb[kThreads];
+        __shared__ int pend_ctl[2];
+        S.pkey = pend_key;
+        S.pid = pend_id;
+        S.plb = pend_lb;
+        S.pctl = pend_ctl;
+    }
     S.load_query(F64 ? reinterpret_cast<const float *>(reinterpret_cast<const double *>(queries) + (size_t)b * ix.dim)
                      : queries + (size_t)b * ix.dim);
     S.seed(ix.entry);
@@ -1290,6 +1592,7 @@ hnsw_knn_body(const IndexDev &ix, const float *__restrict__ queries, uint32_t B,
     // so that the traversal is inlined once)
     for (int lv = ix.n_levels - 1; lv >= 0; lv--) {
         if constexpr (SPEC) S.search_level_spec(lv, lv > 0 ? 1 : (int)ef, lv > 0);
+        else if constexpr (PEND) S.search_level_pending(lv, lv > 0 ? 1 : (int)ef, lv > 0);  // (one call site here too)
         else S.search_level(lv, lv > 0 ? 1 : (int)ef, lv > 0);
         if (lv > 0) S.clear_visited();
     }
@@ -1403,6 +1706,16 @@ hnsw_knn_spec_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t B,
                      double *__restrict__ out_dist, uint32_t *__restrict__ out_count, unsigned long long *__restrict__ out_n_dist) {
     hnsw_knn_body<LPV, ITERS, U, false, true>(ix, queries, B, k, ef, efcap, wpad, has_radius, radius, vtab, hbits, vbitmap, words, preds,
                                               out_ids, out_dist, out_count, out_n_dist);
+}
+// a large ef (the list is thousands of entries): the sorted pending buffer in front of W (search_level_pending)
+template <int LPV, int ITERS, int U>
+__global__ void __launch_bounds__(kThreads)
+hnsw_knn_pend_kernel(IndexDev ix, const float *__restrict__ queries, uint32_t B, uint32_t k, uint32_t ef, uint32_t efcap,
+                     uint32_t wpad, int has_radius, double radius, uint32_t *__restrict__ vtab, uint32_t hbits,
+                     uint32_t *__restrict__ vbitmap, uint32_t words, PredSet preds, uint32_t *__restrict__ out_ids,
+                     double *__restrict__ out_dist, uint32_t *__restrict__ out_count, unsigned long long *__restrict__ out_n_dist) {
+    hnsw_knn_body<LPV, ITERS, U, false, false, true>(ix, queries, B, k, ef, efcap, wpad, has_radius, radius, vtab, hbits, vbitmap, words,
+                                                     preds, out_ids, out_dist, out_count, out_n_dist);
 }
 // an F64 index (the query rows are doubles behind the float pointer): LPV lanes per vector, the query in LDS
 template <int LPV, int U>

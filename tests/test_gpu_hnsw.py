@@ -181,6 +181,46 @@ def test_large_ef_lists_evict_and_shift_over_many_chunks(gpu_lib, oracle):
         gix.close()
 
 
+@pytest.mark.parametrize("metric,name", [(1, "Cosine"), (0, "L2")])
+def test_large_ef_pending_buffer_same_results(gpu_lib, oracle, monkeypatch, metric, name):
+    """Round 6: from ef = 2 048 on, a 513..768-d search keeps the step's new entries in a sorted pending buffer
+    in front of the list and shifts the list only when the buffer is full (hnsw_kernels.h search_level_pending).  Nothing the
+    reference computes changes: ids, f64 distances, counts and the evaluation count n_dist equal the oracle's and the plain
+    step's (CZ_HNSW_PEND = 0) at ef 2 049 / 4 096 / 8 192 on an index the list does not swallow, with k = ef (a filter's call), a
+    radius, and -- Cosine -- an all-zero query whose distances are all NaN (hnsw.rs:575: nothing is `< NaN`).  (The pending form
+    exists for two rows in flight per lane group -- a batch that fills the chip; CZ_HNSW_U = 2 selects it for this small batch.)"""
+    from cozo_amd.hnsw import HnswSearch
+    dim, m = 640, 12
+    x = util.vectors(12000, dim, 11, "lowrank")
+    _, flat = util.build_index(oracle, x, metric, m, 40)
+    gix = util.gpu_index(flat, name, m)
+    q = util.vectors(12, dim, 12, "lowrank")
+    if metric == 1:
+        q[5] = 0.0
+    try:
+        for ef, k in ((2049, 10), (4096, 4096), (8192, 100)):
+            oids, odist, ocnt, ond = flat.knn_batch(q, k, ef, dot_mode=oracle.DOT_GPU)
+            per_query = {}
+            for pend, u in (("1", "2"), ("0", "2"), ("0", "8")):
+                monkeypatch.setenv("CZ_HNSW_PEND", pend)
+                monkeypatch.setenv("CZ_HNSW_U", u)
+                ids, dist, cnt, nd = gix.hnsw_knn_batch(q, HnswSearch(k=k, ef=ef), with_n_dist=True)
+                assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids), (ef, pend, u)
+                for b in range(len(cnt)):
+                    assert np.array_equal(dist[b, :cnt[b]], odist[b, :cnt[b]], equal_nan=True), (ef, pend, u, b)
+                assert int(nd.sum()) == ond, (ef, pend, u)
+                per_query[(pend, u)] = nd
+            assert np.array_equal(per_query[("1", "2")], per_query[("0", "2")]) and np.array_equal(per_query[("1", "2")], per_query[("0", "8")])
+        monkeypatch.setenv("CZ_HNSW_PEND", "1")
+        monkeypatch.setenv("CZ_HNSW_U", "2")
+        r = float(np.nanmedian(flat.knn_batch(q, 10, 2500, dot_mode=oracle.DOT_GPU)[1][:, 4]))
+        ids, dist, cnt = gix.hnsw_knn_batch(q, HnswSearch(k=50, ef=2500, radius=r))
+        oids, odist, ocnt, _ = flat.knn_batch(q, 50, 2500, radius=r, dot_mode=oracle.DOT_GPU)
+        assert np.array_equal(cnt, ocnt) and np.array_equal(ids, oids)
+    finally:
+        gix.close()
+
+
 @pytest.mark.parametrize("ef,k", [(64, 10)])
 def test_knn_within_tolerance_of_reference_order(case, oracle, ef, k):
     from cozo_amd.hnsw import HnswSearch
