@@ -692,10 +692,27 @@ __global__ void __launch_bounds__(kT)
 sssp_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t N,
                   const unsigned long long *__restrict__ cur, uint32_t n_cur, unsigned long long *__restrict__ dp,
                   uint32_t *__restrict__ qtag, uint32_t round_tag, uint32_t *__restrict__ ftag, uint32_t phase_tag,
-                  uint32_t thr_bits, SsspQueue near, SsspQueue far, uint32_t *__restrict__ zero_me) {
+                  uint32_t thr_bits, SsspQueue near, SsspQueue far, uint32_t *__restrict__ zero_me,
+                  const uint32_t *__restrict__ n_cur_dev, uint32_t *__restrict__ bail) {
     const int lane = threadIdx.x & 63;
     const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes, ngroups = gridDim.x * blockDim.x / kSsspLanes;
+    // A round launched AHEAD of the host's knowledge of its pile (SsspBatch::run, bursts of small rounds) reads the pile's size
+    // where the round before it counted it; zero_me is then a THIRD counter (nobody's input, nobody's output in this round).
+    // Its grid was sized on a guess: a pile that outgrew it (an R-MAT hub two rounds behind the start: 1 -> 53 000 -> 1.1M
+    // entries) is NOT walked here with a few workgroups -- the round leaves everything as it found it, says so in bail[0..1]
+    // (its tag, the pile's size), the rounds launched behind it return at once, and the host launches it again, sized.
+    if (n_cur_dev) {
+        if (bail[0] != 0) return;  // (whole workgroups return: the decision is the same for every thread of the grid or harmless)
+        n_cur = *n_cur_dev;
+        if (n_cur > ngroups) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                bail[1] = n_cur;
+                bail[0] = round_tag;
+            }
+            return;
+        }
+    }
     const uint32_t rounds = (n_cur + ngroups - 1) / ngroups;  // every group of the GRID runs the same trip count (ballots, barriers)
     if (blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;  // the NEXT round's near counter (this round appends to the other one)
     __shared__ StagedPile st_near, st_far;
@@ -803,7 +820,9 @@ sssp_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__
 __global__ void __launch_bounds__(kT)
 sssp_split_kernel(const unsigned long long *__restrict__ farq, uint32_t n_far, uint32_t N,
                   const unsigned long long *__restrict__ dp, uint32_t *__restrict__ qtag, uint32_t round_tag,
-                  uint32_t *__restrict__ ftag, uint32_t phase_tag, uint32_t thr_bits, SsspQueue near, SsspQueue far_next) {
+                  uint32_t *__restrict__ ftag, uint32_t phase_tag, uint32_t thr_bits, SsspQueue near, SsspQueue far_next,
+                  const uint32_t *__restrict__ thr_dev) {
+    if (thr_dev) thr_bits = *thr_dev;  // (the threshold sssp_threshold_kernel worked out: no host round trip between the two)
     const int lane = threadIdx.x & 63;
     const uint32_t total = gridDim.x * blockDim.x;
     const uint32_t rounds = (n_far + total - 1) / total;
@@ -843,6 +862,23 @@ sssp_far_min_kernel(const unsigned long long *__restrict__ farq, uint32_t n_far,
     for (int o = 32; o >= 1; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o, 64));
     if ((threadIdx.x & 63) == 0 && m != 0xFFFFFFFFu) atomicMin(out_min, m);
 }
+
+// The threshold move of the near-far schedule on the device (one thread): the bucket of the nearest waiting node, exactly the
+// host expression it replaces -- only the schedule depends on it, never a result.  misc: SsspBatch's counter block; the counters
+// the split and the rounds after it count into start from zero.
+__global__ void sssp_threshold_kernel(uint32_t *__restrict__ misc, float thr_old, float delta, int have_min) {
+    // have_min == 0: the far pile was not searched for its nearest node (SsspBatch::run: a pile of millions has one in the next
+    // bucket) -- the threshold moves by one bucket
+    const float fmin = have_min ? __uint_as_float(misc[3]) : thr_old;
+    float thr = fmaxf(thr_old + delta, (floorf(fmin / delta) + 1.0f) * delta);
+    if (!(thr > fmin)) thr = INFINITY;  // (rounding at huge costs, or no waiting node with a cost: fall back to one pile)
+    misc[7] = __float_as_uint(thr);
+    misc[0] = 0;
+    misc[2] = 0;
+    misc[8] = misc[9] = misc[10] = 0;
+}
+// after the split: the far counter the relax kernel appends to continues from the surviving entries
+__global__ void sssp_far_carry_kernel(uint32_t *__restrict__ misc) { misc[1] = misc[2]; }
 
 __global__ void __launch_bounds__(kT)
 sssp_seed_kernel(const uint32_t *__restrict__ starts, uint32_t n, uint32_t N, unsigned long long *__restrict__ dp,
@@ -1890,10 +1926,11 @@ struct SsspBatch {
     ~SsspBatch() {
         if (h_pin) (void)hipHostFree(h_pin);
     }
+    static constexpr uint32_t kMisc = 16;  // words of the counter block
     int read_counters(uint32_t *h) {
-        CZ_HIP(hipMemcpyAsync(h_pin, d_misc.p, 32, hipMemcpyDeviceToHost, s));
+        CZ_HIP(hipMemcpyAsync(h_pin, d_misc.p, kMisc * 4, hipMemcpyDeviceToHost, s));
         CZ_HIP(hipStreamSynchronize(s));
-        memcpy(h, h_pin, 32);
+        memcpy(h, h_pin, kMisc * 4);
         return CZ_OK;
     }
 
@@ -1907,8 +1944,8 @@ struct SsspBatch {
         d_off.p = G.off.p;
         d_tgt.p = G.tgt.p;
         d_w.p = G.w.p;
-        if (d_misc.n != 8) CZ_HIP(d_misc.alloc(8));
-        if (!h_pin) CZ_HIP(hipHostMalloc((void **)&h_pin, 32));
+        if (d_misc.n != kMisc) CZ_HIP(d_misc.alloc(kMisc));
+        if (!h_pin) CZ_HIP(hipHostMalloc((void **)&h_pin, kMisc * 4));
         const double wsum = G.wsum;
         // bucket width of the near-far schedule: the mean edge weight (CZ_SSSP_DELTA overrides; <= 0 or "inf" = one pile,
         // i.e. plain frontier Bellman-Ford).  Only the schedule depends on it, never the result.
@@ -1931,8 +1968,16 @@ struct SsspBatch {
         return CZ_OK;
     }
 
-    // d_misc: [0] seed / split near count, [1] far count, [2] far-next count, [3] min far cost bits, [4], [5] the near counters of
-    // even / odd rounds (a round appends under its own and zeroes the other for the round after it: no memset per round)
+    // d_misc: [0] seed / split near count, [1] far count, [2] far-next count, [3] min far cost bits, [6] goals not yet settled,
+    // [7] the threshold sssp_threshold_kernel worked out, [8..10] the near counters: round r appends under [8 + r % 3], the round
+    // after it reads its pile's size there -- by value, or from the device when it was launched ahead -- and every round zeroes
+    // [8 + (r + 1) % 3] for the round after it (no memset per round); [11], [12] a launched-ahead round that found its pile beyond
+    // its grid: its tag and the pile's size (sssp_relax_kernel).
+    // Host round trips: a round used to be a launch and one 64-byte copy back (~22 us for a pile of ten nodes: 35 of the 59
+    // rounds of the 10M / 100M bench graph are that small, and a threshold move was three such trips).  Now a SMALL pile starts a
+    // burst of kBurst rounds, launched back to back, each on the pile size the one before it left on the device (an empty round
+    // costs a launch), and the threshold move is four launches and ONE trip.  Results cannot change: the same relaxations, and
+    // the packed CAS makes their order irrelevant.  CZ_SSSP_BURST = 0 | 1 .. 16 (default 6; 0: a trip per round, as before).
     // goals (device ids, optional): stop as soon as every goal of every source is settled -- dijkstra()'s early exit when its goal
     // set is exhausted (shortest_path_dijkstra.rs:300-306); settled_bits then holds the threshold below which costs are final
     const uint32_t *d_goals = nullptr;
@@ -1945,17 +1990,29 @@ struct SsspBatch {
         trace_mark("run: fill dp");
         CZ_HIP(hipMemsetAsync(d_qtag.p, 0, nsN * 4, s));
         CZ_HIP(hipMemsetAsync(d_ftag.p, 0, nsN * 4, s));
-        CZ_HIP(hipMemsetAsync(d_misc.p, 0, 32, s));
+        CZ_HIP(hipMemsetAsync(d_misc.p, 0, kMisc * 4, s));
         trace_mark("run: memsets");
         CZ_HIP(hipMemcpyAsync(d_starts.p, starts, (size_t)ns * 4, hipMemcpyHostToDevice, s));
         unsigned long long *near_cur = d_q[0].p, *near_next = d_q[1].p, *far_cur = d_q[2].p, *far_next = d_q[3].p;
         hipLaunchKernelGGL(sssp_seed_kernel, dim3((ns + kT - 1) / kT), dim3(kT), 0, s, d_starts.p, ns, N, d_dp.p, near_cur, d_misc.p);
-        uint32_t h[8];
+        uint32_t h[kMisc];
         int rc = read_counters(h);
         if (rc) return rc;
         uint32_t n_near = h[0], n_far = 0, round = 1, phase = 1;
         float thr = one_pile ? INFINITY : delta;
         static const bool trace = getenv("CZ_SSSP_TRACE") != nullptr;  // per-round pile sizes on stderr (scratch/ experiments)
+        static const uint32_t burst = [] {
+            const char *e = getenv("CZ_SSSP_BURST");
+            return e ? (uint32_t)std::min(16, std::max(0, atoi(e))) : 6u;
+        }();
+        constexpr uint32_t kBurstPile = 2048;  // a pile of at most this many entries starts a burst ...
+        constexpr uint32_t kBurstGrid = 8192;  // ... whose later rounds are launched for piles of up to this many (beyond: grid-stride)
+        static const uint32_t kFarSearchBelow = [] {  // (CZ_SSSP_FAR_SEARCH_BELOW: piles from this size on move the threshold unasked)
+            const char *e = getenv("CZ_SSSP_FAR_SEARCH_BELOW");
+            return e ? (uint32_t)strtoul(e, nullptr, 10) : (1u << 16);
+        }();
+        bool empty_split = false;
+        auto near_counter = [&](uint32_t r) { return d_misc.p + 8 + r % 3; };
         for (;;) {
             while (n_near > 0) {
                 if (trace) {
@@ -1968,15 +2025,29 @@ struct SsspBatch {
                 if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
                 uint32_t thr_bits;
                 memcpy(&thr_bits, &thr, 4);
-                uint32_t *mine = d_misc.p + 4 + (round & 1), *next = d_misc.p + 4 + ((round + 1) & 1);
-                hipLaunchKernelGGL(sssp_relax_kernel, dim3(grid_for((uint64_t)n_near * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p,
-                                   d_w.p, N, near_cur, n_near, d_dp.p, d_qtag.p, round, d_ftag.p, phase, thr_bits,
-                                   SsspQueue{near_next, mine}, SsspQueue{far_cur, d_misc.p + 1}, next);
+                const uint32_t rounds_now = (burst > 1 && n_near <= kBurstPile) ? burst : 1u;
+                const uint32_t round0 = round;
+                unsigned long long *const cur0 = near_cur, *const next0 = near_next;
+                for (uint32_t j = 0; j < rounds_now; j++, round++) {
+                    const uint64_t pile = j == 0 ? n_near : kBurstGrid;
+                    hipLaunchKernelGGL(sssp_relax_kernel, dim3(grid_for(pile * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, d_w.p, N,
+                                       near_cur, n_near, d_dp.p, d_qtag.p, round, d_ftag.p, phase, thr_bits,
+                                       SsspQueue{near_next, near_counter(round)}, SsspQueue{far_cur, d_misc.p + 1}, near_counter(round + 1),
+                                       j == 0 ? (const uint32_t *)nullptr : (const uint32_t *)near_counter(round - 1), d_misc.p + 11);
+                    std::swap(near_cur, near_next);
+                }
                 if ((rc = read_counters(h))) return rc;
-                n_near = h[4 + (round & 1)];
                 n_far = h[1];
-                std::swap(near_cur, near_next);
-                round++;
+                if (h[11]) {  // round h[11] found its pile (h[12] entries) beyond its grid and left it alone, like the rounds behind it
+                    round = h[11];
+                    n_near = h[12];
+                    const bool even = ((round - round0) & 1u) == 0;  // (the piles alternate between the two arrays)
+                    near_cur = even ? cur0 : next0;
+                    near_next = even ? next0 : cur0;
+                    CZ_HIP(hipMemsetAsync(d_misc.p + 11, 0, 8, s));
+                } else {
+                    n_near = h[8 + (round - 1) % 3];
+                }
             }
             if (n_far == 0) break;
             if (d_goals && n_goals && !one_pile) {  // every cost below thr is final now: are the goals among them?
@@ -1991,28 +2062,27 @@ struct SsspBatch {
                     break;
                 }
             }
-            // move the threshold to the bucket of the nearest waiting node, then split the far pile
-            CZ_HIP(hipMemsetAsync(d_misc.p + 3, 0xFF, 4, s));
-            hipLaunchKernelGGL(sssp_far_min_kernel, dim3(grid_for(n_far)), dim3(kT), 0, s, far_cur, n_far, N, d_dp.p, d_misc.p + 3);
-            if ((rc = read_counters(h))) return rc;
-            float fmin;
-            memcpy(&fmin, &h[3], 4);
-            thr = std::max(thr + delta, (std::floor(fmin / delta) + 1.0f) * delta);
-            if (!(thr > fmin)) thr = INFINITY;  // (rounding at huge costs: fall back to one pile)
+            // move the threshold to the bucket of the nearest waiting node, then split the far pile: all on the device, one trip.
+            // Looking for the nearest of MILLIONS of waiting nodes is a random 8-byte read per entry (0.15 ms at 5M) to learn that
+            // the next bucket is not empty: a large pile moves the threshold by one bucket unasked -- and if that bucket did turn
+            // out empty (the split below found nothing; costs far apart), the next move searches.
+            const bool search_min = n_far < kFarSearchBelow || empty_split;
+            if (search_min) {
+                CZ_HIP(hipMemsetAsync(d_misc.p + 3, 0xFF, 4, s));
+                hipLaunchKernelGGL(sssp_far_min_kernel, dim3(grid_for(n_far)), dim3(kT), 0, s, far_cur, n_far, N, d_dp.p, d_misc.p + 3);
+            }
+            hipLaunchKernelGGL(sssp_threshold_kernel, dim3(1), dim3(1), 0, s, d_misc.p, thr, delta, search_min ? 1 : 0);
             phase++;
-            uint32_t thr_bits;
-            memcpy(&thr_bits, &thr, 4);
-            CZ_HIP(hipMemsetAsync(d_misc.p, 0, 4, s));
-            CZ_HIP(hipMemsetAsync(d_misc.p + 2, 0, 4, s));
             hipLaunchKernelGGL(sssp_split_kernel, dim3(grid_for(n_far)), dim3(kT), 0, s, far_cur, n_far, N, d_dp.p, d_qtag.p, round,
-                               d_ftag.p, phase, thr_bits, SsspQueue{near_cur, d_misc.p}, SsspQueue{far_next, d_misc.p + 2});
+                               d_ftag.p, phase, 0u, SsspQueue{near_cur, d_misc.p}, SsspQueue{far_next, d_misc.p + 2},
+                               (const uint32_t *)(d_misc.p + 7));
+            hipLaunchKernelGGL(sssp_far_carry_kernel, dim3(1), dim3(1), 0, s, d_misc.p);
             if ((rc = read_counters(h))) return rc;
             n_near = h[0];
             n_far = h[2];
+            empty_split = n_near == 0;
+            memcpy(&thr, &h[7], 4);
             std::swap(far_cur, far_next);
-            // the far counter the relax kernel appends to continues from the surviving entries
-            CZ_HIP(hipMemcpyAsync(d_misc.p + 1, &n_far, 4, hipMemcpyHostToDevice, s));
-            CZ_HIP(hipStreamSynchronize(s));
             round++;
             if (cz::poisoned(poison)) return cz::set_error(CZ_E_CANCELLED, "cancelled");
         }

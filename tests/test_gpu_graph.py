@@ -548,6 +548,42 @@ def test_sssp_costs_bitexact(oracle, gpu_lib):
         G.sssp(np.array([0, 1, 1], np.uint32), np.array([1], np.uint32), np.array([-1.0], np.float32), [0])
 
 
+def test_sssp_schedule_paths_same_costs(oracle, gpu_lib):
+    """The near-far schedule's host-free stretches (graph.hip SsspBatch::run): rounds launched ahead on the pile size the round
+    before left on the device -- a pile that GROWS past the launch-ahead grid inside a burst (a 3 000-way fan-out behind a chain
+    of single nodes) --, the threshold worked out on the device, and a far pile of 100 000 entries whose next bucket is empty (the
+    threshold moves one bucket unasked, the split finds nothing, the next move searches for the nearest waiting node).  Costs are
+    dijkstra()'s bit for bit on every path."""
+    from cozo_amd import graph as G
+    rng = np.random.default_rng(5)
+    # (a) chain 0 -> 1 -> ... -> 9, node 9 fans out to 3 000 nodes, each of which fans out to 20 more: tiny piles, then 60 000
+    frm = list(range(9)) + [9] * 3000 + list(np.repeat(np.arange(10, 3010), 20))
+    to = list(range(1, 10)) + list(range(10, 3010)) + list(rng.integers(3010, 80000, 60000))
+    w = np.concatenate([np.full(9, 0.001, np.float32), rng.random(3000).astype(np.float32) * 0.01, rng.random(60000).astype(np.float32)])
+    ga = util.graph_from_relation(oracle, np.array(frm, np.int64), np.array(to, np.int64), weights=w)
+    # (b) node 0 -> 100 000 nodes at weight 1000; 900 000 light edges among all nodes (mean weight ~ 100: the far pile's nearest
+    #     entry sits ten buckets beyond the threshold)
+    n = 150000
+    frm = np.concatenate([np.zeros(100000, np.int64), rng.integers(0, n, 900000)])
+    to = np.concatenate([np.arange(1, 100001, dtype=np.int64), rng.integers(0, n, 900000)])
+    w = np.concatenate([np.full(100000, 1000.0, np.float32), rng.random(900000).astype(np.float32)])
+    gb = util.graph_from_relation(oracle, frm, to, weights=w)
+    for g in (ga, gb):
+        starts = np.array([0], dtype=np.uint32)
+        dist, parent = G.sssp(g["ooff"], g["otgt"], g["ow"], starts)
+        od, _ = oracle.dijkstra(g["n"], g["ooff"], g["otgt"], g["ow"], 0)
+        assert np.array_equal(dist[0], od)
+        reached = np.flatnonzero(np.isfinite(od))
+        assert reached.size > 40000
+        off, tgt, ow = g["ooff"].astype(np.int64), g["otgt"], g["ow"]
+        for v in rng.choice(reached, 200):  # every parent edge is tight
+            if v == 0:
+                continue
+            p_ = int(parent[0, v])
+            ws = ow[off[p_]:off[p_ + 1]][tgt[off[p_]:off[p_ + 1]] == v]
+            assert (np.float32(dist[0, p_]) + ws == dist[0, v]).any()
+
+
 def test_sssp_goals_stop_early_with_the_full_runs_values(oracle, gpu_lib):
     """cz_sssp_goals / cz_sssp_goals_on (dijkstra()'s goal set, shortest_path_dijkstra.rs:300-306): the costs and parents of the
     goals -- and of every node reported reached -- are the full run's, nodes the search had not settled read unreached, near goals
