@@ -951,6 +951,36 @@ extern "C" int cz_hnsw_index_probe(const cz_hnsw_index *h, uint64_t n_fetch, uin
 // ------------------------------------------------------------------------------------------------
 namespace cz {
 
+// How many workgroups of the persistent grid a batch LARGER than the chip's slots should use.  Workgroups take queries as they
+// finish, so a batch of B on S slots runs floor(B / S) full rounds and a last one of B mod S queries at the latency of THAT many
+// queries in flight -- measured on the 10M / 1M indices (bench.py batch_ladder): 0.32 / 0.38 / 0.53 / 0.75 / 1.0 of the full
+// round's time at 1/16, 1/4, 1/2, 3/4 and all of the slots.  With S = all slots a batch just above them pays a nearly empty last
+// round (1 152 queries on 1 024 slots: 0.62 of the HBM peak, 1 280: 0.69); the smaller grid that balances the rounds is faster
+// (1 152 on 640: 0.72, 1 280 on 768: 0.74, 2 304 on 768: 0.77 against 0.73; profiles/r06_batch_rounds.txt).  Candidates: 5/8, 3/4
+// and all of the slots; the model picks, ties go to the larger grid.  Scheduling only.
+static uint64_t balanced_slots(uint64_t B, uint64_t slots) {
+    if (B <= slots || slots < 8) return slots;
+    auto latency = [](double f) {  // of a round with the fraction f of the slots in flight, in full rounds
+        static const double x[] = {0.0, 0.0625, 0.25, 0.5, 0.75, 1.0}, y[] = {0.30, 0.33, 0.385, 0.53, 0.75, 1.0};
+        if (f <= 0.0) return 0.0;
+        for (int i = 1; i < 6; i++)
+            if (f <= x[i]) return y[i - 1] + (y[i] - y[i - 1]) * (f - x[i - 1]) / (x[i] - x[i - 1]);
+        return f;
+    };
+    uint64_t best = slots;
+    double best_t = 1e300;
+    for (int eighths : {8, 6, 5}) {  // (7/8 leaves half of the CUs a workgroup short: its rounds take as long as full ones)
+        const uint64_t S = slots * eighths / 8;
+        const double full = latency((double)S / (double)slots);
+        const double t = (double)(B / S) * full + latency((double)(B % S) / (double)slots);
+        if (t < best_t * 0.995) {
+            best_t = t;
+            best = S;
+        }
+    }
+    return best;
+}
+
 int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32_t k, uint32_t ef, int has_radius,
                        double radius, uint32_t *d_ids, double *d_dist, uint32_t *d_count, uint64_t *d_ndist,
                        hipStream_t stream, const czh::PredSet *preds_in) {
@@ -991,6 +1021,9 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
     HnswIndex::Workspace ws;
     int rc = CZ_OK;
     uint32_t grid = 0;
+    // (balanced_slots above: measured for the 513..768-d f32 shape at the ef of the metric configurations, where registers --
+    //  not the list's LDS -- decide the slots; the other launches keep every slot)
+    const bool balance_rounds = !ix->f64() && shape_of(ix->dim).lpv == 64 && shape_of(ix->dim).iters == 3 && ef <= 1024;
 #define CZ_LAUNCH_KNN(LPV, ITERS, U) CZ_LAUNCH_KNN_(hnsw_knn_kernel, LPV, ITERS, U)
 #define CZ_LAUNCH_KNN_(KERNEL, LPV, ITERS, U)                                                                           \
     do {                                                                                                                \
@@ -1003,7 +1036,9 @@ int hnsw_search_device(HnswIndex *ix, const float *d_queries, uint32_t B, uint32
             per_cu = 1;                                                                                                 \
         }                                                                                                               \
         const char *slots_env = getenv("CZ_HNSW_SLOTS");                                                                \
-        const uint64_t slots = slots_env && atoi(slots_env) > 0 ? (uint64_t)atoi(slots_env) : (uint64_t)per_cu * (uint64_t)cus; \
+        const uint64_t slots = slots_env && atoi(slots_env) > 0 ? (uint64_t)atoi(slots_env)                            \
+                               : balance_rounds ? balanced_slots(B, (uint64_t)per_cu * (uint64_t)cus)                   \
+                                                : (uint64_t)per_cu * (uint64_t)cus;                                     \
         grid = (uint32_t)std::min<uint64_t>(B, slots);                                                                  \
         rc = ix->acquire(hbits_pool ? ((size_t)grid << hbits_pool) * 4 : 0, (size_t)grid * words * 4, stream, &ws);     \
         if (rc) return rc;                                                                                              \
