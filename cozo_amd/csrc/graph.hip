@@ -2006,7 +2006,7 @@ struct SsspBatch {
             return e ? (uint32_t)std::min(16, std::max(0, atoi(e))) : 6u;
         }();
         constexpr uint32_t kBurstPile = 2048;  // a pile of at most this many entries starts a burst ...
-        constexpr uint32_t kBurstGrid = 8192;  // ... whose later rounds are launched for piles of up to this many (beyond: grid-stride)
+        constexpr uint32_t kBurstGrid = 8192;  // ... whose later rounds are launched for piles of up to this many (a larger one: left to the host)
         static const uint32_t kFarSearchBelow = [] {  // (CZ_SSSP_FAR_SEARCH_BELOW: piles from this size on move the threshold unasked)
             const char *e = getenv("CZ_SSSP_FAR_SEARCH_BELOW");
             return e ? (uint32_t)strtoul(e, nullptr, 10) : (1u << 16);
