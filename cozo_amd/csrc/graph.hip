@@ -677,6 +677,62 @@ __device__ __forceinline__ void staged_flush(const QueueT<T> &q, StagedPileT<T> 
     __syncthreads();
 }
 
+// hubs: a 16-lane group walks at most kSsspLongList edges of its node.  What is left of a longer list goes, in stretches of
+// kSsspStretch edges, to a queue in global memory that sssp_relax_long_kernel walks with the whole GRID right after the round
+// (SsspLongQ; the queue holds S x cz_graph::long_stretches items -- every (source, node) pair is in a pile once per round).  Round 6:
+// the remainder used to be walked by the node's own WORKGROUP at the end of the round -- enough to take a 100 000-edge hub off one
+// 16-lane group (R-MAT 39 -> 12 ms), but the first rounds of an R-MAT run are nothing but hubs: one workgroup walked 106 000
+// edges alone (1.2 ms), the next rounds waited for the workgroups that had drawn the hubs (2.1 + 2.9 + 2.9 ms of a 12 ms run).
+// Relaxations commute (CAS on the packed word), so who walks an edge changes nothing.  The group's own share: 256 edges (a workgroup
+// iteration lasts as long as its longest list: R-MAT 10M / 100M 10.4 ms with 1 024, 10.1 with 256, 13.3 with 128 -- a stretch item
+// costs a workgroup a pass and two flushes whatever it holds).
+#ifndef CZ_SSSP_LONG_LIST
+#define CZ_SSSP_LONG_LIST 256
+#endif
+constexpr uint32_t kSsspLongList = CZ_SSSP_LONG_LIST, kSsspStretch = 2048;
+struct SsspLongQ {
+    uint32_t *items;   // [5][cap]: source index, node, first edge, end edge, the node's cost bits -- one item per stretch
+    uint32_t cap;
+    uint32_t *count;   // this round's items (nullptr: no queue -- the workgroup walks its own long lists)
+    uint32_t *count_zero;  // the next round's counter
+};
+struct SsspRelaxCtx {
+    const uint32_t *tgt;
+    const float *w;
+    uint32_t N;
+    unsigned long long *dp;
+    uint32_t *qtag, *ftag;
+    uint32_t round_tag, phase_tag, thr_bits;
+};
+// one edge: the target's packed word replaced when the offer is better; where the target goes next (see the rule below)
+__device__ __forceinline__ void sssp_relax_edge(const SsspRelaxCtx &c, uint32_t si, uint32_t u, float du, uint32_t e, bool on, bool &to_near,
+                                                bool &to_far, uint32_t &v) {
+    to_near = to_far = false;
+    v = 0;
+    if (!on) return;
+    unsigned long long *dps = c.dp + (size_t)si * c.N;
+    v = c.tgt[e];
+    const float nd = du + c.w[e];  // `cost + path_weight` in f32 (shortest_path_dijkstra.rs:303)
+    const uint32_t nb = __float_as_uint(nd);
+    const bool proper = nb != __float_as_uint(du);
+    const unsigned long long want = ((unsigned long long)nb << 32) | (proper ? 0u : 0x80000000u) | u;
+    unsigned long long seen = __hip_atomic_load(&dps[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        const bool lower = nb < (uint32_t)(seen >> 32);  // strict `<` (:304); non-negative floats order as their bits
+        if (!lower && !(proper && nb == (uint32_t)(seen >> 32) && want < seen)) break;
+        const unsigned long long got = atomicCAS(&dps[v], seen, want);
+        if (got == seen) {
+            if (lower) {  // (an equal-cost change of parent is nothing the node's own edges need to hear about)
+                const size_t at = (size_t)si * c.N + v;
+                if (nb < c.thr_bits) to_near = atomicExch(&c.qtag[at], c.round_tag) != c.round_tag;
+                else to_far = atomicExch(&c.ftag[at], c.phase_tag) != c.phase_tag;
+            }
+            break;
+        }
+        seen = got;
+    }
+}
+
 // relax the out-edges of every (source, node) entry of `cur`: a 16-lane group per entry reads the adjacency coalesced.
 // An improved target goes to `near` when its new cost is below the threshold, else to `far`; `qtag` / `ftag` (one word
 // per (source, node)) keep a pair from entering the same pile twice in one round / one phase.
@@ -693,7 +749,7 @@ sssp_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__
                   const unsigned long long *__restrict__ cur, uint32_t n_cur, unsigned long long *__restrict__ dp,
                   uint32_t *__restrict__ qtag, uint32_t round_tag, uint32_t *__restrict__ ftag, uint32_t phase_tag,
                   uint32_t thr_bits, SsspQueue near, SsspQueue far, uint32_t *__restrict__ zero_me,
-                  const uint32_t *__restrict__ n_cur_dev, uint32_t *__restrict__ bail) {
+                  const uint32_t *__restrict__ n_cur_dev, uint32_t *__restrict__ bail, SsspLongQ lq) {
     const int lane = threadIdx.x & 63;
     const uint32_t glane = threadIdx.x & (kSsspLanes - 1);
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) / kSsspLanes, ngroups = gridDim.x * blockDim.x / kSsspLanes;
@@ -714,12 +770,12 @@ sssp_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__
         }
     }
     const uint32_t rounds = (n_cur + ngroups - 1) / ngroups;  // every group of the GRID runs the same trip count (ballots, barriers)
-    if (blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;  // the NEXT round's near counter (this round appends to the other one)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *zero_me = 0;  // the NEXT round's near counter (this round appends to the other one)
+        if (lq.count) *lq.count_zero = 0;
+    }
     __shared__ StagedPile st_near, st_far;
-    // hubs: a 16-lane group walks at most kSsspLongList edges of its node; what is left of a longer list is set aside here and walked
-    // by the whole workgroup at the end of the round (a 100 000-edge hub of an R-MAT graph kept ONE group -- and its wave -- busy
-    // for 6 700 iterations: 18 ms of a 39 ms run).  Relaxations commute (CAS on the packed word), so who walks an edge changes nothing.
-    constexpr uint32_t kSsspLongList = 1024;
+    // (the long lists' remainders when there is no queue, or no room in it: set aside here, walked by the whole workgroup)
     constexpr uint32_t kGroupsPerWg = kT / kSsspLanes;
     __shared__ uint32_t lq_si[kGroupsPerWg], lq_u[kGroupsPerWg], lq_e0[kGroupsPerWg], lq_e1[kGroupsPerWg], lq_du[kGroupsPerWg], lq_n;
     if (threadIdx.x == 0) {
@@ -727,32 +783,9 @@ sssp_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__
         lq_n = 0;
     }
     __syncthreads();
-    // one edge: the target's packed word replaced when the offer is better; where the target goes next
+    const SsspRelaxCtx ctx{tgt, w, N, dp, qtag, ftag, round_tag, phase_tag, thr_bits};
     auto relax = [&](uint32_t si, uint32_t u, float du, uint32_t e, bool on, bool &to_near, bool &to_far, uint32_t &v) {
-        to_near = to_far = false;
-        v = 0;
-        if (!on) return;
-        unsigned long long *dps = dp + (size_t)si * N;
-        v = tgt[e];
-        const float nd = du + w[e];  // `cost + path_weight` in f32 (shortest_path_dijkstra.rs:303)
-        const uint32_t nb = __float_as_uint(nd);
-        const bool proper = nb != __float_as_uint(du);
-        const unsigned long long want = ((unsigned long long)nb << 32) | (proper ? 0u : 0x80000000u) | u;
-        unsigned long long seen = __hip_atomic_load(&dps[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (;;) {
-            const bool lower = nb < (uint32_t)(seen >> 32);  // strict `<` (:304); non-negative floats order as their bits
-            if (!lower && !(proper && nb == (uint32_t)(seen >> 32) && want < seen)) break;
-            const unsigned long long got = atomicCAS(&dps[v], seen, want);
-            if (got == seen) {
-                if (lower) {  // (an equal-cost change of parent is nothing the node's own edges need to hear about)
-                    const size_t at = (size_t)si * N + v;
-                    if (nb < thr_bits) to_near = atomicExch(&qtag[at], round_tag) != round_tag;
-                    else to_far = atomicExch(&ftag[at], phase_tag) != phase_tag;
-                }
-                break;
-            }
-            seen = got;
-        }
+        sssp_relax_edge(ctx, si, u, du, e, on, to_near, to_far, v);
     };
     for (uint32_t r = 0; r < rounds; r++) {
         const uint32_t i = group + r * ngroups;
@@ -765,11 +798,27 @@ sssp_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__
         float du = 0.f;
         if (live) du = __uint_as_float((uint32_t)(__hip_atomic_load(&dps[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32));
         if (e1 - e0 > kSsspLongList) {  // (uniform over the group)
-            if (glane == 0) {
+            const uint32_t r0 = e0 + kSsspLongList, nst = (e1 - r0 + kSsspStretch - 1) / kSsspStretch;
+            bool queued = false;
+            if (lq.count) {  // the remainder as stretches for sssp_relax_long_kernel: one reservation, the group's lanes fill it
+                uint32_t base = 0;
+                if (glane == 0) base = atomicAdd(lq.count, nst);
+                base = (uint32_t)__shfl((int)base, lane & ~(kSsspLanes - 1), 64);
+                queued = base + nst <= lq.cap && base + nst >= base;
+                for (uint32_t t = glane; t < nst && base + t < lq.cap; t += kSsspLanes) {  // (no room: empty items, the list stays here)
+                    const uint32_t q = base + t, a = r0 + t * kSsspStretch;
+                    lq.items[q] = si;
+                    lq.items[lq.cap + q] = u;
+                    lq.items[2 * (size_t)lq.cap + q] = queued ? a : 0u;
+                    lq.items[3 * (size_t)lq.cap + q] = queued ? min(e1, a + kSsspStretch) : 0u;
+                    lq.items[4 * (size_t)lq.cap + q] = __float_as_uint(du);
+                }
+            }
+            if (!queued && glane == 0) {
                 const uint32_t q = atomicAdd(&lq_n, 1u);
                 lq_si[q] = si;
                 lq_u[q] = u;
-                lq_e0[q] = e0 + kSsspLongList;
+                lq_e0[q] = r0;
                 lq_e1[q] = e1;
                 lq_du[q] = __float_as_uint(du);
             }
@@ -814,6 +863,52 @@ sssp_relax_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__
             staged_flush(far, st_far);
         }
     }
+}
+
+// the long lists' remainders of the round that has just run (SsspLongQ): stretch i by workgroup i mod the grid, every thread an edge
+__global__ void __launch_bounds__(kT)
+sssp_relax_long_kernel(const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t N, unsigned long long *__restrict__ dp,
+                       uint32_t *__restrict__ qtag, uint32_t round_tag, uint32_t *__restrict__ ftag, uint32_t phase_tag, uint32_t thr_bits,
+                       SsspQueue near, SsspQueue far, SsspLongQ lq, const uint32_t *__restrict__ bail) {
+    if (bail[0] != 0) return;  // (a launched-ahead round left its pile to the host: nothing was queued, and nothing may be touched)
+    const uint32_t n = min(*lq.count, lq.cap);
+    if (n == 0) return;
+    const int lane = threadIdx.x & 63;
+    __shared__ StagedPile st_near, st_far;
+    if (threadIdx.x == 0) st_near.count = st_far.count = 0;
+    __syncthreads();
+    const SsspRelaxCtx ctx{tgt, w, N, dp, qtag, ftag, round_tag, phase_tag, thr_bits};
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {  // (uniform over the workgroup)
+        const uint32_t si = lq.items[i], u = lq.items[lq.cap + i], q0 = lq.items[2 * (size_t)lq.cap + i], q1 = lq.items[3 * (size_t)lq.cap + i];
+        const float du = __uint_as_float(lq.items[4 * (size_t)lq.cap + i]);
+        for (uint32_t b = q0; b < q1; b += kT) {
+            const uint32_t e = b + threadIdx.x;
+            bool to_near, to_far;
+            uint32_t v;
+            sssp_relax_edge(ctx, si, u, du, e, e < q1, to_near, to_far, v);
+            const unsigned long long item = ((unsigned long long)si << 32) | v;
+            staged_push(near, st_near, to_near, item, lane);
+            staged_push(far, st_far, to_far, item, lane);
+            if (((b - q0) / kT & 3u) == 3u) {  // (uniform) the staging pile holds 1 024 entries: four iterations' worth
+                staged_flush(near, st_near);
+                staged_flush(far, st_far);
+            }
+        }
+        staged_flush(near, st_near);
+        staged_flush(far, st_far);
+    }
+}
+
+// how many stretches the long lists of a graph make (cz_graph::long_stretches: the capacity of SsspLongQ per source)
+__global__ void __launch_bounds__(kT) sssp_long_stretches_kernel(const uint32_t *__restrict__ off, uint32_t N, unsigned long long *__restrict__ out) {
+    unsigned long long mine = 0;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < N; v += gridDim.x * blockDim.x) {
+        const uint32_t len = off[v + 1] - off[v];
+        if (len > kSsspLongList) mine += (len - kSsspLongList + kSsspStretch - 1) / kSsspStretch;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
 }
 
 // the threshold moved: far entries whose CURRENT cost is below it become the next near pile, the rest stay far
@@ -876,6 +971,7 @@ __global__ void sssp_threshold_kernel(uint32_t *__restrict__ misc, float thr_old
     misc[0] = 0;
     misc[2] = 0;
     misc[8] = misc[9] = misc[10] = 0;
+    misc[13] = misc[14] = 0;  // (the long-list queue's counters, by round parity)
 }
 // after the split: the far counter the relax kernel appends to continues from the surviving entries
 __global__ void sssp_far_carry_kernel(uint32_t *__restrict__ misc) { misc[1] = misc[2]; }
@@ -997,6 +1093,7 @@ struct cz_graph {
     uint64_t E = 0;
     bool has_w = false;
     double wsum = 0.0;                 // of the valid weights (the near-far bucket width is their mean)
+    unsigned long long long_stretches = 0;  // of the out-lists beyond kSsspLongList entries (sssp_long_stretches_kernel; weighted graphs)
     unsigned long long bad = ~0ull;    // smallest index of a negative / NaN weight (BadEdgeWeightError when a rule needs them)
     float bad_value = 0.f;
     // the state arrays of the last cz_sssp_on call on this graph (0.64 GB per source batch at 10M nodes), kept for the next one: a
@@ -1033,6 +1130,11 @@ int graph_fill(cz_graph &G, const uint32_t *offsets, const uint32_t *targets, co
             CZ_HIP(hipMemsetAsync(d_sum.p, 0, 8, nullptr));
             CZ_HIP(hipMemsetAsync(d_bad.p, 0xFF, 8, nullptr));
             hipLaunchKernelGGL(weights_check_kernel, dim3(grid_for(E)), dim3(kT), 0, nullptr, G.w.p, E, d_sum.p, d_bad.p);
+            cz::DevBuf<unsigned long long> d_long;
+            CZ_HIP(d_long.alloc(1));
+            CZ_HIP(hipMemsetAsync(d_long.p, 0, 8, nullptr));
+            hipLaunchKernelGGL(sssp_long_stretches_kernel, dim3(grid_for(N)), dim3(kT), 0, nullptr, G.off.p, N, d_long.p);
+            CZ_HIP(hipMemcpy(&G.long_stretches, d_long.p, 8, hipMemcpyDeviceToHost));
             CZ_HIP(hipMemcpy(&G.bad, d_bad.p, 8, hipMemcpyDeviceToHost));
             CZ_HIP(hipMemcpy(&G.wsum, d_sum.p, 8, hipMemcpyDeviceToHost));
             if (G.bad != ~0ull) G.bad_value = weights[G.bad];
@@ -1920,7 +2022,8 @@ struct SsspBatch {
     View<uint32_t> d_off, d_tgt;
     View<float> d_w;
     // (from the stream-ordered pool: 0.56 GB per source batch, allocated and freed by every call -- common.h PoolBuf)
-    cz::PoolBuf<uint32_t> d_qtag, d_ftag, d_misc, d_starts;
+    cz::PoolBuf<uint32_t> d_qtag, d_ftag, d_misc, d_starts, d_lq;
+    uint32_t lq_cap = 0;  // stretch items the long-list queue holds (0: no queue -- no long lists, or too many for one: the workgroups walk them)
     cz::PoolBuf<unsigned long long> d_dp, d_q[4];
     uint32_t *h_pin = nullptr;  // the counters come back through pinned memory: a round is a launch and one 32-byte copy
     ~SsspBatch() {
@@ -1956,6 +2059,18 @@ struct SsspBatch {
         S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_starts, pairs_budget / std::max<uint32_t>(N, 1)));
         const uint64_t SN = (uint64_t)S * N;
         if (SN >= 0xFFFFFFFFull) return cz::set_error(CZ_E_UNSUPPORTED, "too many (source, node) pairs per launch");
+        // the long-list queue (SsspLongQ): a (source, node) pair is in a pile once per round, so S x the graph's stretches is all a
+        // round can queue; 20 bytes an item, at most 1 GiB (beyond: no queue)
+        {
+            const uint64_t want = (uint64_t)S * G.long_stretches;
+            const char *lq_env = getenv("CZ_SSSP_LONG_QUEUE");  // (read per call, like CZ_SSSP_DELTA: tests switch the queue off)
+            const bool lq_off = lq_env && atoi(lq_env) == 0;
+            const uint32_t cap = (want == 0 || want > (1ull << 30) / 20 || lq_off) ? 0u : (uint32_t)want;
+            if (cap != lq_cap || d_lq.n != (size_t)cap * 5) {
+                if (cap) CZ_HIP(d_lq.alloc((size_t)cap * 5));
+                lq_cap = cap;
+            }
+        }
         // a kept state of the same shape (a resident graph's repeated call): every array, not just the first ones
         if (d_dp.n == SN && d_starts.n == S && d_qtag.n == SN && d_ftag.n == SN && d_q[0].n == SN && d_q[1].n == SN && d_q[2].n == SN &&
             d_q[3].n == SN)
@@ -1972,7 +2087,7 @@ struct SsspBatch {
     // [7] the threshold sssp_threshold_kernel worked out, [8..10] the near counters: round r appends under [8 + r % 3], the round
     // after it reads its pile's size there -- by value, or from the device when it was launched ahead -- and every round zeroes
     // [8 + (r + 1) % 3] for the round after it (no memset per round); [11], [12] a launched-ahead round that found its pile beyond
-    // its grid: its tag and the pile's size (sssp_relax_kernel).
+    // its grid: its tag and the pile's size (sssp_relax_kernel); [13], [14] the long-list queue's counters (SsspLongQ), by round parity.
     // Host round trips: a round used to be a launch and one 64-byte copy back (~22 us for a pile of ten nodes: 35 of the 59
     // rounds of the 10M / 100M bench graph are that small, and a threshold move was three such trips).  Now a SMALL pile starts a
     // burst of kBurst rounds, launched back to back, each on the pile size the one before it left on the device (an empty round
@@ -2013,6 +2128,9 @@ struct SsspBatch {
         }();
         bool empty_split = false;
         auto near_counter = [&](uint32_t r) { return d_misc.p + 8 + r % 3; };
+        auto long_queue = [&](uint32_t r) {  // (counters [13], [14] by round parity: a round zeroes the next one's)
+            return SsspLongQ{d_lq.p, lq_cap, lq_cap ? d_misc.p + 13 + (r & 1u) : (uint32_t *)nullptr, d_misc.p + 13 + ((r + 1u) & 1u)};
+        };
         for (;;) {
             while (n_near > 0) {
                 if (trace) {
@@ -2033,7 +2151,12 @@ struct SsspBatch {
                     hipLaunchKernelGGL(sssp_relax_kernel, dim3(grid_for(pile * kSsspLanes)), dim3(kT), 0, s, d_off.p, d_tgt.p, d_w.p, N,
                                        near_cur, n_near, d_dp.p, d_qtag.p, round, d_ftag.p, phase, thr_bits,
                                        SsspQueue{near_next, near_counter(round)}, SsspQueue{far_cur, d_misc.p + 1}, near_counter(round + 1),
-                                       j == 0 ? (const uint32_t *)nullptr : (const uint32_t *)near_counter(round - 1), d_misc.p + 11);
+                                       j == 0 ? (const uint32_t *)nullptr : (const uint32_t *)near_counter(round - 1), d_misc.p + 11,
+                                       long_queue(round));
+                    if (lq_cap)  // what the round queued of its long lists, by the whole grid (the count stays on the device)
+                        hipLaunchKernelGGL(sssp_relax_long_kernel, dim3(1024), dim3(kT), 0, s, d_tgt.p, d_w.p, N, d_dp.p, d_qtag.p, round,
+                                           d_ftag.p, phase, thr_bits, SsspQueue{near_next, near_counter(round)},
+                                           SsspQueue{far_cur, d_misc.p + 1}, long_queue(round), (const uint32_t *)(d_misc.p + 11));
                     std::swap(near_cur, near_next);
                 }
                 if ((rc = read_counters(h))) return rc;

@@ -584,6 +584,44 @@ def test_sssp_schedule_paths_same_costs(oracle, gpu_lib):
             assert (np.float32(dist[0, p_]) + ws == dist[0, v]).any()
 
 
+@pytest.mark.parametrize("long_queue", ["1", "0"])
+def test_sssp_long_lists_same_costs(oracle, gpu_lib, monkeypatch, long_queue):
+    """Out-lists beyond 256 edges (graph.hip SsspLongQ): the node's 16-lane group walks 256 edges, the remainder goes in stretches of
+    2 048 edges to a queue the whole grid walks after the round (sssp_relax_long_kernel) -- or, with no queue (CZ_SSSP_LONG_QUEUE=0:
+    the path taken when S x the graph's stretches is beyond the queue's 1 GiB), to the node's own workgroup.  Lists of 257, 2 304,
+    2 305 and 70 000 edges (zero, one, two and 35 stretches, the last one ragged), hubs that reach each other inside one round
+    (zero-weight edges: a hub re-queued with a lower cost), three sources at once (items of several sources in one queue): costs
+    are dijkstra()'s bit for bit and every parent edge is tight."""
+    from cozo_amd import graph as G
+    monkeypatch.setenv("CZ_SSSP_LONG_QUEUE", long_queue)
+    rng = np.random.default_rng(11)
+    n = 120000
+    lens = {0: 70000, 1: 2305, 2: 2304, 3: 257, 4: 256, 5: 9000}
+    frm = [np.full(c, h, np.int64) for h, c in lens.items()]
+    to = [rng.integers(6, n, c) for c in lens.values()]
+    w = [rng.random(c).astype(np.float32) for c in lens.values()]
+    # the hubs reach each other: 0 -> 1 at zero weight (same round), 5 -> 0 cheaply (hub 0 improved after it was walked), and a ring
+    frm += [np.array([0, 5, 1, 2, 3, 4], np.int64), rng.integers(0, n, 400000)]
+    to += [np.array([1, 0, 2, 3, 4, 5], np.int64), rng.integers(0, n, 400000)]
+    w += [np.array([0.0, 1e-4, 0.5, 0.25, 0.0, 0.125], np.float32), rng.random(400000).astype(np.float32)]
+    g = util.graph_from_relation(oracle, np.concatenate(frm), np.concatenate(to), weights=np.concatenate(w))
+    starts = np.array([0, 5, g["n"] - 1], dtype=np.uint32)  # (ids by first appearance: index 0 is the 70 000-edge hub)
+    dist, parent = G.sssp(g["ooff"], g["otgt"], g["ow"], starts)
+    off, tgt, ow = g["ooff"].astype(np.int64), g["otgt"], g["ow"]
+    assert (np.diff(off) > 256).sum() >= 4 and np.diff(off).max() > 60000
+    for si, s in enumerate(starts):
+        od, _ = oracle.dijkstra(g["n"], g["ooff"], g["otgt"], g["ow"], int(s))
+        assert np.array_equal(dist[si], od)
+        reached = np.flatnonzero(np.isfinite(od))
+        assert reached.size > 50000
+        for v in rng.choice(reached, 200):
+            if v == s:
+                continue
+            p_ = int(parent[si, v])
+            ws = ow[off[p_]:off[p_ + 1]][tgt[off[p_]:off[p_ + 1]] == v]
+            assert (np.float32(dist[si, p_]) + ws == dist[si, v]).any()
+
+
 def test_sssp_goals_stop_early_with_the_full_runs_values(oracle, gpu_lib):
     """cz_sssp_goals / cz_sssp_goals_on (dijkstra()'s goal set, shortest_path_dijkstra.rs:300-306): the costs and parents of the
     goals -- and of every node reported reached -- are the full run's, nodes the search had not settled read unreached, near goals
