@@ -405,13 +405,34 @@ bfs_discover_long_kernel(const uint32_t *__restrict__ off, const uint32_t *__res
         for (uint32_t q = w_used + lane; q < kBfsChunk; q += 64) fresh[w_base + q] = CZ_NONE;
 }
 
+// Round 6: a hub that claims 100 000 nodes in one level took 100 000 atomics on ONE counter here and in bfs_place_kernel (a single
+// word takes ~88 M atomics a second: 2.3 + 2.5 ms of a 12 ms BFS on the R-MAT bench graph) -- and the list is written in runs of one
+// claimer's nodes (a wave's chunk: a hub's stretch, or the lists of the wave's 16-lane groups).  So the lanes of a wave that hold
+// nodes of the same claimer as the first unserved lane add once, together; up to kBfsAggRounds such rounds, the rest one by one (a
+// round that serves a single lane ends the search: a wave of 64 different claimers -- the uniform graph -- pays one round).
+constexpr int kBfsAggRounds = 4;
 __global__ void __launch_bounds__(kT)
 bfs_tally_kernel(const uint32_t *__restrict__ fresh, const uint32_t *__restrict__ n_slots, const uint32_t *__restrict__ claim,
                  uint32_t *__restrict__ cnt) {
     const uint32_t n = *n_slots;
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        const uint32_t v = fresh[k];
-        if (v != CZ_NONE) atomicAdd(&cnt[claim[v]], 1u);
+    const int lane = threadIdx.x & 63;
+    for (uint32_t k0 = blockIdx.x * blockDim.x; k0 < n; k0 += gridDim.x * blockDim.x) {  // (uniform over the wave: ballots below)
+        const uint32_t k = k0 + threadIdx.x;
+        const uint32_t v = k < n ? fresh[k] : CZ_NONE;
+        bool rem = v != CZ_NONE;
+        const uint32_t i = rem ? claim[v] : CZ_NONE;
+        for (int r = 0; r < kBfsAggRounds; r++) {
+            const unsigned long long mrem = __ballot(rem);
+            if (!mrem) break;
+            const int lead = __builtin_ctzll(mrem);
+            const uint32_t i0 = (uint32_t)__shfl((int)i, lead, 64);
+            const bool same = rem && i == i0;
+            const uint32_t c = (uint32_t)__popcll(__ballot(same));
+            if (c == 1) break;
+            if (lane == lead) atomicAdd(&cnt[i0], c);
+            if (same) rem = false;
+        }
+        if (rem) atomicAdd(&cnt[i], 1u);
     }
 }
 
@@ -422,11 +443,34 @@ bfs_place_kernel(const uint32_t *__restrict__ fresh, const uint32_t *__restrict_
                  uint32_t *__restrict__ next, uint32_t *__restrict__ parent, uint32_t *__restrict__ depth,
                  uint32_t *__restrict__ vis, uint32_t next_depth) {
     const uint32_t n = *n_fresh;
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        const uint32_t v = fresh[k];
-        if (v == CZ_NONE) continue;  // a slot its wave did not use
-        const uint32_t i = claim[v];
-        next[pos[i] + atomicSub(&cnt[i], 1u) - 1u] = v;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t k0 = blockIdx.x * blockDim.x; k0 < n; k0 += gridDim.x * blockDim.x) {  // (uniform over the wave)
+        const uint32_t k = k0 + threadIdx.x;
+        const uint32_t v = k < n ? fresh[k] : CZ_NONE;  // (CZ_NONE: a slot its wave did not use)
+        const bool live = v != CZ_NONE;
+        bool rem = live;
+        const uint32_t i = live ? claim[v] : CZ_NONE;
+        uint32_t slot = 0;
+        for (int r = 0; r < kBfsAggRounds; r++) {  // lanes of one claimer take their slots with one atomic (bfs_tally_kernel)
+            const unsigned long long mrem = __ballot(rem);
+            if (!mrem) break;
+            const int lead = __builtin_ctzll(mrem);
+            const uint32_t i0 = (uint32_t)__shfl((int)i, lead, 64);
+            const bool same = rem && i == i0;
+            const unsigned long long ms = __ballot(same);
+            const uint32_t c = (uint32_t)__popcll(ms);
+            if (c == 1) break;
+            uint32_t base = 0;
+            if (lane == lead) base = atomicSub(&cnt[i0], c);
+            base = (uint32_t)__shfl((int)base, lead, 64);
+            if (same) {
+                slot = pos[i0] + base - 1u - (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
+                rem = false;
+            }
+        }
+        if (rem) slot = pos[i] + atomicSub(&cnt[i], 1u) - 1u;
+        if (!live) continue;
+        next[slot] = v;
         parent[v] = frontier[i];
         depth[v] = next_depth;
         atomicOr(&vis[v >> 5], 1u << (v & 31));
@@ -465,31 +509,99 @@ bfs_order_small_kernel(const uint32_t *__restrict__ pos, uint32_t fsize, const u
     }
 }
 
-// a wave per long stretch: the claimer's adjacency list is walked again and its new nodes written in list order
+// a wave per long stretch: the claimer's adjacency list is walked again and its new nodes written in list order.  Round 6: a
+// claimer whose list holds kBfsOrderWg edges or more (an R-MAT hub: 100 000 edges walked 64 at a time by ONE wave, each step a
+// chain tgt -> claim -> depth, was 1.8 ms of a level and 3.7 ms of a 12 ms run) is walked by the whole WORKGROUP, four edges per
+// thread and step (1 024 edges in flight), the running offset carried through LDS.  Workgroups take the listed stretches four at
+// a time: each wave its own when the list is short, then all four waves together each long one among the four.
+constexpr uint32_t kBfsOrderWg = 1024;
+constexpr int kBfsOrderK = 4;
 __global__ void __launch_bounds__(kT)
 bfs_order_big_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
                      const uint32_t *__restrict__ pos, const uint32_t *__restrict__ big, const uint32_t *__restrict__ n_big,
                      const uint32_t *__restrict__ claim, const uint32_t *__restrict__ depth, uint32_t next_depth,
                      uint32_t *__restrict__ next) {
+    constexpr uint32_t kWaves = kT / 64;
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wv = threadIdx.x >> 6;
     const uint32_t n = *n_big;
-    for (uint32_t k = wave; k < n; k += nwaves) {
-        const uint32_t i = big[k], u = frontier[i];
-        const uint32_t e0 = off[u], e1 = off[u + 1];
-        uint32_t o = pos[i];
-        for (uint32_t b = e0; b < e1; b += 64) {
-            const uint32_t e = b + lane;
-            bool hit = false;
-            uint32_t v = 0;
-            if (e < e1) {
-                v = tgt[e];
-                hit = (e == e0 || tgt[e - 1] != v) && claim[v] == i && depth[v] == next_depth;
-            }
-            const unsigned long long m = __ballot(hit);
-            if (hit) next[o + __popcll(m & ((1ull << lane) - 1ull))] = v;
-            o += (uint32_t)__popcll(m);
+    __shared__ uint32_t sh_i[kWaves], sh_e0[kWaves], sh_e1[kWaves], sh_o[kWaves], sh_cnt[kBfsOrderK][kWaves];
+    for (uint32_t k0 = blockIdx.x * kWaves; k0 < n; k0 += gridDim.x * kWaves) {  // (uniform over the workgroup)
+        const uint32_t k = k0 + wv;
+        uint32_t i = 0, e0 = 0, e1 = 0, o = 0;
+        if (k < n) {
+            i = big[k];
+            const uint32_t u = frontier[i];
+            e0 = off[u];
+            e1 = off[u + 1];
+            o = pos[i];
         }
+        const bool together = e1 - e0 >= kBfsOrderWg;
+        if (lane == 0) {
+            sh_i[wv] = i;
+            sh_e0[wv] = e0;
+            sh_e1[wv] = together ? e1 : e0;  // (an empty range: nothing for the workgroup to do)
+            sh_o[wv] = o;
+        }
+        if (!together) {
+            for (uint32_t b = e0; b < e1; b += 64) {
+                const uint32_t e = b + lane;
+                bool hit = false;
+                uint32_t v = 0;
+                if (e < e1) {
+                    v = tgt[e];
+                    hit = (e == e0 || tgt[e - 1] != v) && claim[v] == i && depth[v] == next_depth;
+                }
+                const unsigned long long m = __ballot(hit);
+                if (hit) next[o + __popcll(m & ((1ull << lane) - 1ull))] = v;
+                o += (uint32_t)__popcll(m);
+            }
+        }
+        __syncthreads();
+        for (uint32_t w = 0; w < kWaves; w++) {
+            const uint32_t ci = sh_i[w], c0 = sh_e0[w], c1 = sh_e1[w];
+            uint32_t co = sh_o[w];
+            for (uint32_t b = c0; b < c1; b += kT * kBfsOrderK) {  // (uniform over the workgroup)
+                uint32_t v[kBfsOrderK];
+                bool hit[kBfsOrderK];
+                unsigned long long m[kBfsOrderK];
+#pragma unroll
+                for (int j = 0; j < kBfsOrderK; j++) {
+                    const uint32_t e = b + j * kT + threadIdx.x;
+                    v[j] = e < c1 ? tgt[e] : CZ_NONE;
+                    hit[j] = e < c1 && (e == c0 || tgt[e - 1] != v[j]);
+                }
+                uint32_t cl[kBfsOrderK], dp[kBfsOrderK];  // (unconditional loads: the four chains go out together)
+#pragma unroll
+                for (int j = 0; j < kBfsOrderK; j++) cl[j] = claim[hit[j] ? v[j] : 0u];
+#pragma unroll
+                for (int j = 0; j < kBfsOrderK; j++) dp[j] = depth[hit[j] ? v[j] : 0u];
+#pragma unroll
+                for (int j = 0; j < kBfsOrderK; j++) hit[j] = hit[j] && cl[j] == ci && dp[j] == next_depth;
+#pragma unroll
+                for (int j = 0; j < kBfsOrderK; j++) {
+                    m[j] = __ballot(hit[j]);
+                    if (lane == 0) sh_cnt[j][wv] = (uint32_t)__popcll(m[j]);
+                }
+                __syncthreads();
+                uint32_t run = co;  // edges in order: (j, wave, lane)
+#pragma unroll
+                for (int j = 0; j < kBfsOrderK; j++) {
+                    uint32_t before = 0, all = 0;
+#pragma unroll
+                    for (uint32_t q = 0; q < kWaves; q++) {
+                        const uint32_t c = sh_cnt[j][q];
+                        before += q < wv ? c : 0u;
+                        all += c;
+                    }
+                    if (hit[j]) next[run + before + __popcll(m[j] & ((1ull << lane) - 1ull))] = v[j];
+                    run += all;
+                }
+                co = run;
+                __syncthreads();
+            }
+        }
+        __syncthreads();  // (sh_* are rewritten by the next four)
     }
 }
 

@@ -282,6 +282,46 @@ def test_bfs_order_and_shared_visited(graphs, oracle):
     assert np.array_equal(order[0, :reached[0]], oorder) and np.array_equal(parent[0], opar)
 
 
+def test_bfs_hub_levels_in_the_references_order(oracle, gpu_lib):
+    """A level whose claimers are hubs (graph.hip, round 6): the tally / place passes add a wave's nodes of one claimer with one
+    atomic, and a claimer whose list holds >= 1 024 edges has its stretch of the next frontier written by a whole workgroup (four
+    edges per thread and step, offsets through LDS) -- lists of 1 023, 1 024, 1 025, 4 097, 5 000 and 70 000 edges, parallel edges
+    kept (a repeated target at every position of a 1 024-edge step), hubs that share targets (the lower frontier position claims),
+    six hubs next to each other in the frontier (several long stretches among one workgroup's four) and ordinary nodes between
+    them.  The visiting order, parents and depths are the reference's FIFO traversal (algos/bfs.rs:43-97)."""
+    from cozo_amd import graph as G
+    rng = np.random.default_rng(17)
+    n = 200000
+    lens = [1023, 1024, 1025, 4097, 5000, 70000]
+    nh = len(lens)
+    lists = {0: np.arange(1, 1 + nh + 40)}  # the start points at the hubs and at 40 ordinary nodes
+    for h, c in enumerate(lens):
+        t = rng.integers(1 + nh + 40, 120000, c)  # (shared targets among the hubs: ~ c / 120 000 of each list)
+        t[: c // 3] = np.repeat(t[: c // 6 + 1], 2)[: c // 3]  # parallel edges: pairs of equal targets, at even and odd positions
+        lists[1 + h] = np.sort(t)
+    for v in range(1 + nh, 1 + nh + 40):
+        lists[v] = np.sort(rng.integers(0, n, rng.integers(1, 60)))
+    body = rng.integers(0, n, 300000)
+    src = np.sort(rng.integers(1 + nh + 40, n, 300000))
+    deg = np.bincount(src, minlength=n)
+    for v, l in lists.items():
+        deg[v] = len(l)
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum(deg)
+    tgt = np.empty(off[-1], np.uint32)
+    pos = off[:-1].astype(np.int64).copy()
+    for v, l in lists.items():
+        tgt[off[v]:off[v + 1]] = l
+    o = np.lexsort((body, src))
+    tgt[off[1 + nh + 40]:] = body[o]
+    starts = np.array([0], dtype=np.uint32)
+    parent, depth, order, reached = G.bfs(off, tgt, starts, want_depth=True, want_order=True)
+    oorder, opar, _ = oracle.bfs_order(n, off, tgt, 0)
+    assert reached[0] == len(oorder) and reached[0] > 100000
+    assert np.array_equal(order[0, :reached[0]], oorder)
+    assert np.array_equal(parent[0], opar)
+
+
 def test_bfs_shared_outputs_are_the_per_start_rows_merged(graphs, oracle, gpu_lib):
     """cz_bfs_shared (what the Bfs rule calls: O(N) outputs whatever the number of starts) against the reference's
     loop -- one `visited` / `backtrace` for all starts, starts already reached skipped -- with EVERY node as a start, the
