@@ -275,8 +275,12 @@ bfs_emit_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ t
 // the passes that read the list; `*n_slots` is the number of slots handed out.
 constexpr uint32_t kBfsChunk = 256;
 constexpr int kBfsNodes = 4;  // frontier nodes a lane group works on at once
-constexpr uint32_t kBfsLongList = 4096;  // adjacency lists beyond this are cut over workgroups (a 454k-edge hub walked by one
-                                         // 16-lane group was 60 of the 64 ms of a BFS on the skewed test graph)
+#ifndef CZ_BFS_LONG_LIST
+#define CZ_BFS_LONG_LIST 4096
+#endif
+constexpr uint32_t kBfsLongList = CZ_BFS_LONG_LIST;  // adjacency lists beyond this are cut over workgroups (a 454k-edge hub walked
+                                                     // by one 16-lane group was 60 of the 64 ms of a BFS on the skewed test graph)
+constexpr uint32_t kBfsStretch = 4096;               // ... in stretches of this many edges
 __global__ void __launch_bounds__(kT)
 bfs_discover_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
                     uint32_t fsize, const uint32_t *__restrict__ vis, uint32_t *__restrict__ claim,
@@ -360,7 +364,7 @@ bfs_discover_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict
         for (uint32_t k = w_used + lane; k < kBfsChunk; k += 64) fresh[w_base + k] = CZ_NONE;
 }
 
-// the lists set aside by bfs_discover_kernel: every workgroup takes stretches of kBfsLongList edges of every listed node
+// the lists set aside by bfs_discover_kernel: every workgroup takes stretches of kBfsStretch edges of every listed node
 __global__ void __launch_bounds__(kT)
 bfs_discover_long_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ frontier,
                          const uint32_t *__restrict__ long_nodes, const uint32_t *__restrict__ n_long, const uint32_t *__restrict__ vis,
@@ -368,14 +372,26 @@ bfs_discover_long_kernel(const uint32_t *__restrict__ off, const uint32_t *__res
     const int lane = threadIdx.x & 63;
     const uint32_t nl = *n_long;
     uint32_t w_base = 0, w_used = kBfsChunk;
-    for (uint32_t k = 0; k < nl; k++) {
-        const uint32_t i = long_nodes[k], u = frontier[i];
-        const uint32_t e0 = off[u], e1 = off[u + 1];
+    // (every workgroup looks at every listed node: the chain list -> frontier -> offsets is fetched for 64 nodes at a time, a node
+    // per lane -- one node at a time, thousands of listed nodes cost every workgroup ~2 us each whether or not it had a stretch)
+    for (uint32_t kb = 0; kb < nl; kb += 64) {
+        uint32_t l_i = 0, l_e0 = 0, l_e1 = 0;
+        if (kb + lane < nl) {
+            l_i = long_nodes[kb + lane];
+            const uint32_t lu = frontier[l_i];
+            l_e0 = off[lu];
+            l_e1 = off[lu + 1];
+        }
+        const uint32_t here = min(64u, nl - kb);
+        for (uint32_t q = 0; q < here; q++) {
+        const uint32_t k = kb + q;
+        const uint32_t i = (uint32_t)__shfl((int)l_i, (int)q, 64), e0 = (uint32_t)__shfl((int)l_e0, (int)q, 64),
+                       e1 = (uint32_t)__shfl((int)l_e1, (int)q, 64);
         // (the stretches of node k start at workgroup 37 k mod G: with thousands of listed nodes of 5-100 thousand edges -- a level of
         // an R-MAT graph -- workgroup 0 used to walk the first stretch of EVERY one of them, 40 ms for one level)
         const uint32_t first_wg = (uint32_t)(((uint64_t)k * 37u) % gridDim.x);
-        for (uint32_t s0 = e0 + ((blockIdx.x + gridDim.x - first_wg) % gridDim.x) * kBfsLongList; s0 < e1; s0 += gridDim.x * kBfsLongList) {
-            const uint32_t s1 = min(e1, s0 + kBfsLongList);
+        for (uint32_t s0 = e0 + ((blockIdx.x + gridDim.x - first_wg) % gridDim.x) * kBfsStretch; s0 < e1; s0 += gridDim.x * kBfsStretch) {
+            const uint32_t s1 = min(e1, s0 + kBfsStretch);
             for (uint32_t b = s0; b < s1; b += kT) {  // (uniform trip count over the workgroup's waves)
                 const uint32_t e = b + threadIdx.x;
                 bool first = false;
@@ -400,6 +416,7 @@ bfs_discover_long_kernel(const uint32_t *__restrict__ off, const uint32_t *__res
                 }
             }
         }
+        }
     }
     if (w_used < kBfsChunk)
         for (uint32_t q = w_used + lane; q < kBfsChunk; q += 64) fresh[w_base + q] = CZ_NONE;
@@ -411,9 +428,19 @@ bfs_discover_long_kernel(const uint32_t *__restrict__ off, const uint32_t *__res
 // nodes of the same claimer as the first unserved lane add once, together; up to kBfsAggRounds such rounds, the rest one by one (a
 // round that serves a single lane ends the search: a wave of 64 different claimers -- the uniform graph -- pays one round).
 constexpr int kBfsAggRounds = 4;
+// ... and where the counter of frontier position i lives: the hubs of an R-MAT level are NEIGHBOURS in the frontier (the lowest ids of
+// the start's list), 32 of them shared a 128-byte line of counters, and the atomics of a level -- one request per wave whatever it
+// adds -- queued on that line (tally 0.85 ms, place 0.94 ms for 2.9M new nodes; the next level places 1M nodes in 0.12 ms).
+// Position i counts in word (i mod 32) * rows + i / 32, rows = ceil(fsize / 32): neighbours in the frontier are `rows` words apart;
+// bfs_counts_in_order_kernel reads the counts back in frontier order for the prefix sums.
+__device__ __forceinline__ uint32_t bfs_cnt_at(uint32_t i, uint32_t rows) { return (i & 31u) * rows + (i >> 5); }
+__global__ void __launch_bounds__(kT)
+bfs_counts_in_order_kernel(const uint32_t *__restrict__ cnt, uint32_t fsize, uint32_t rows, uint32_t *__restrict__ out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < fsize; i += gridDim.x * blockDim.x) out[i] = cnt[bfs_cnt_at(i, rows)];
+}
 __global__ void __launch_bounds__(kT)
 bfs_tally_kernel(const uint32_t *__restrict__ fresh, const uint32_t *__restrict__ n_slots, const uint32_t *__restrict__ claim,
-                 uint32_t *__restrict__ cnt) {
+                 uint32_t *__restrict__ cnt, uint32_t rows) {
     const uint32_t n = *n_slots;
     const int lane = threadIdx.x & 63;
     for (uint32_t k0 = blockIdx.x * blockDim.x; k0 < n; k0 += gridDim.x * blockDim.x) {  // (uniform over the wave: ballots below)
@@ -429,10 +456,10 @@ bfs_tally_kernel(const uint32_t *__restrict__ fresh, const uint32_t *__restrict_
             const bool same = rem && i == i0;
             const uint32_t c = (uint32_t)__popcll(__ballot(same));
             if (c == 1) break;
-            if (lane == lead) atomicAdd(&cnt[i0], c);
+            if (lane == lead) atomicAdd(&cnt[bfs_cnt_at(i0, rows)], c);
             if (same) rem = false;
         }
-        if (rem) atomicAdd(&cnt[i], 1u);
+        if (rem) atomicAdd(&cnt[bfs_cnt_at(i, rows)], 1u);
     }
 }
 
@@ -441,7 +468,7 @@ __global__ void __launch_bounds__(kT)
 bfs_place_kernel(const uint32_t *__restrict__ fresh, const uint32_t *__restrict__ n_fresh, const uint32_t *__restrict__ claim,
                  const uint32_t *__restrict__ frontier, const uint32_t *__restrict__ pos, uint32_t *__restrict__ cnt,
                  uint32_t *__restrict__ next, uint32_t *__restrict__ parent, uint32_t *__restrict__ depth,
-                 uint32_t *__restrict__ vis, uint32_t next_depth) {
+                 uint32_t *__restrict__ vis, uint32_t next_depth, uint32_t rows) {
     const uint32_t n = *n_fresh;
     const int lane = threadIdx.x & 63;
     for (uint32_t k0 = blockIdx.x * blockDim.x; k0 < n; k0 += gridDim.x * blockDim.x) {  // (uniform over the wave)
@@ -461,14 +488,14 @@ bfs_place_kernel(const uint32_t *__restrict__ fresh, const uint32_t *__restrict_
             const uint32_t c = (uint32_t)__popcll(ms);
             if (c == 1) break;
             uint32_t base = 0;
-            if (lane == lead) base = atomicSub(&cnt[i0], c);
+            if (lane == lead) base = atomicSub(&cnt[bfs_cnt_at(i0, rows)], c);
             base = (uint32_t)__shfl((int)base, lead, 64);
             if (same) {
                 slot = pos[i0] + base - 1u - (uint32_t)__popcll(ms & ((1ull << lane) - 1ull));
                 rem = false;
             }
         }
-        if (rem) slot = pos[i] + atomicSub(&cnt[i], 1u) - 1u;
+        if (rem) slot = pos[i] + atomicSub(&cnt[bfs_cnt_at(i, rows)], 1u) - 1u;
         if (!live) continue;
         next[slot] = v;
         parent[v] = frontier[i];
@@ -1364,7 +1391,7 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
     CZ_HIP(d_parent.alloc(N));
     CZ_HIP(d_claim.alloc(N));
     CZ_HIP(d_order.alloc((size_t)N + 1));
-    CZ_HIP(d_cnt.alloc(N));
+    CZ_HIP(d_cnt.alloc((size_t)N + 32));  // (32 x ceil(fsize / 32) words: bfs_cnt_at)
     CZ_HIP(d_pos.alloc(N));
     CZ_HIP(d_scratch.alloc(scan_scratch_words(N)));
     CZ_HIP(d_misc.alloc(8));
@@ -1425,20 +1452,23 @@ int bfs_run(const cz_graph &G, const uint32_t *starts, uint32_t n_starts, const 
                 if (one_pass) {
                     // d_misc: [0] next frontier size (scan total), [1] goals left, [2] list slots, [3] long stretches, [4] long lists
                     CZ_HIP(hipMemsetAsync(d_misc.p + 2, 0, 12, s));
-                    CZ_HIP(hipMemsetAsync(d_cnt.p, 0, (size_t)fsize * 4, s));
+                    const uint32_t rows = (fsize + 31u) >> 5;  // (the counters' layout: bfs_cnt_at)
+                    CZ_HIP(hipMemsetAsync(d_cnt.p, 0, (size_t)rows * 32 * 4, s));
                     hipLaunchKernelGGL(bfs_discover_kernel, dim3(g), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, fsize, d_vis.p, d_claim.p,
                                        d_fresh.p, d_misc.p + 2, d_long.p, d_misc.p + 4);
                     hipLaunchKernelGGL(bfs_discover_long_kernel, dim3(1024), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, d_long.p, d_misc.p + 4,
                                        d_vis.p, d_claim.p, d_fresh.p, d_misc.p + 2);
-                    const int gf = grid_for(std::min<uint64_t>((uint64_t)N + N / 2, (uint64_t)fsize * 64 + 4096));  // (the slot count stays on the device)
-                    hipLaunchKernelGGL(bfs_tally_kernel, dim3(gf), dim3(kT), 0, s, d_fresh.p, d_misc.p + 2, d_claim.p, d_cnt.p);
-                    rc = exclusive_scan(d_cnt.p, d_pos.p, fsize, d_misc.p, d_scratch.p, s);
+                    // (the slot count stays on the device; at least 1 024 workgroups: a frontier of ten hubs lists a million nodes)
+                    const int gf = std::max(1024, grid_for(std::min<uint64_t>((uint64_t)N + N / 2, (uint64_t)fsize * 64 + 4096)));
+                    hipLaunchKernelGGL(bfs_tally_kernel, dim3(gf), dim3(kT), 0, s, d_fresh.p, d_misc.p + 2, d_claim.p, d_cnt.p, rows);
+                    hipLaunchKernelGGL(bfs_counts_in_order_kernel, dim3(grid_for(fsize)), dim3(kT), 0, s, d_cnt.p, fsize, rows, d_big.p);
+                    rc = exclusive_scan(d_big.p, d_pos.p, fsize, d_misc.p, d_scratch.p, s);  // (d_big is free until bfs_order_small_kernel)
                     if (rc) return rc;
                     hipLaunchKernelGGL(bfs_place_kernel, dim3(gf), dim3(kT), 0, s, d_fresh.p, d_misc.p + 2, d_claim.p, fr, d_pos.p, d_cnt.p,
-                                       d_order.p + lo + fsize, d_parent.p, d_depth.p, d_vis.p, level + 1);
+                                       d_order.p + lo + fsize, d_parent.p, d_depth.p, d_vis.p, level + 1, rows);
                     hipLaunchKernelGGL(bfs_order_small_kernel, dim3(grid_for(fsize)), dim3(kT), 0, s, d_pos.p, fsize, d_misc.p,
                                        d_order.p + lo + fsize, d_big.p, d_misc.p + 3);
-                    hipLaunchKernelGGL(bfs_order_big_kernel, dim3(std::min(g, 1024)), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, d_pos.p, d_big.p,
+                    hipLaunchKernelGGL(bfs_order_big_kernel, dim3(1024), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, d_pos.p, d_big.p,
                                        d_misc.p + 3, d_claim.p, d_depth.p, level + 1, d_order.p + lo + fsize);
                 } else {
                 hipLaunchKernelGGL(bfs_claim_kernel, dim3(g), dim3(kT), 0, s, G.off.p, G.tgt.p, fr, fsize, d_depth.p, d_vis.p, d_claim.p,
