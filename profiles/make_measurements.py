@@ -1,6 +1,6 @@
 """bench_detail.json (the unabridged objects bench.py writes beside its line) -> the measurement table of DESIGN.md section 5.
 
-    python profiles/make_measurements.py profiles/r06_bench_detail.json [--write]
+    python profiles/make_measurements.py profiles/r06_bench_detail.json [--graph-legs profiles/r06_bench_detail_graph_legs.json] [--write]
 
 Prints the markdown table; with --write it replaces the text between the GENERATED markers in DESIGN.md (the table is never edited
 by hand: VERDICT r5 item 2)."""
@@ -101,8 +101,8 @@ def rows(d):
     return out
 
 
-def table(d, src):
-    lines = [f"_Generated by `profiles/make_measurements.py` from `{src}` (box {g(d, 'box', 'pci', default='?')}, bench wall {f(d.get('bench_wall_s'), 4)} s). "
+def table(d, src, note=""):
+    lines = [f"_Generated by `profiles/make_measurements.py` from `{src}` (box {g(d, 'box', 'pci', default='?')}, bench wall {f(d.get('bench_wall_s'), 4)} s){note}. "
              "Roofline = algorithmic bytes ÷ event-timed launch ÷ 8 TB/s (MFMA row: ÷ 157.3 TFLOP/s); PMC traffic = FETCH_SIZE × 2 + WRITE_SIZE per launch "
              "(`profiles/pmc_traffic.json`); CPU = the oracle (a C port of the reference's loop) on the same box._", "",
              "| line | value | roofline frac | PMC traffic | CPU oracle | parity |", "|---|---|---|---|---|---|"]
@@ -114,7 +114,15 @@ def table(d, src):
 def main():
     path = sys.argv[1]
     d = json.load(open(path))
-    t = table(d, os.path.relpath(os.path.abspath(path), ROOT))
+    note = ""
+    if "--graph-legs" in sys.argv:  # the graph-rule legs of a later `bench.py --skip-hnsw` run (graph.hip changed after the full run)
+        gp = sys.argv[sys.argv.index("--graph-legs") + 1]
+        gd = json.load(open(gp))
+        for leg in ("graph_rules", "graph_rules_rmat"):
+            d[leg] = gd[leg]
+        note = (f"; the BFS … LabelPropagation rows from `{os.path.relpath(os.path.abspath(gp), ROOT)}`, a `bench.py --skip-hnsw` run of the "
+                f"final `graph.hip` (box {g(gd, 'box', 'pci', default='?')})")
+    t = table(d, os.path.relpath(os.path.abspath(path), ROOT), note)
     print(t)
     if "--write" in sys.argv:
         p = os.path.join(ROOT, "DESIGN.md")
