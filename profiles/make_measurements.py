@@ -121,7 +121,7 @@ def main():
         for leg in ("graph_rules", "graph_rules_rmat"):
             d[leg] = gd[leg]
         note = (f"; the BFS … LabelPropagation rows from `{os.path.relpath(os.path.abspath(gp), ROOT)}`, a `bench.py --skip-hnsw` run of the "
-                f"final `graph.hip` (box {g(gd, 'box', 'pci', default='?')})")
+                f"final `graph.hip`" + (f" (box {g(gd, 'box', 'pci')})" if g(gd, 'box', 'pci', default=None) else ""))
     t = table(d, os.path.relpath(os.path.abspath(path), ROOT), note)
     print(t)
     if "--write" in sys.argv:
